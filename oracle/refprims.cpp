@@ -1,0 +1,129 @@
+/* TEST INFRASTRUCTURE ONLY.
+ * Thin C-ABI driver around the REFERENCE's own primitive table (reference: source/common/primitives.h:239-433,
+ * filled by setupCPrimitives(), primitives.h:472 / primitives.cpp:236-246).  It is compiled by oracle/build_ref.sh
+ * against the reference objects into oracle/_ref/librefprims{8,10}.so and is used to
+ *   (1) validate the CPU restatement in oracle/hevc_oracle.c, and
+ *   (2) generate the golden vectors committed under tests/golden/ (tests/golden/make_golden.py).
+ * This file contains no reference code: it only *calls* reference function pointers.
+ * The product (x265-amod_amd/) never links, loads or calls anything from here. */
+#include "common.h"
+#include "primitives.h"
+#include "constants.h"
+
+using namespace X265_NS;
+
+static EncoderPrimitives g_p;
+static bool g_init = false;
+
+static void ensure()
+{
+    if (!g_init)
+    {
+        memset(&g_p, 0, sizeof(g_p));
+        setupCPrimitives(g_p);      /* C references; keeps intra_pred_allangs populated */
+        setupAliasPrimitives(g_p);
+        g_init = true;
+    }
+}
+
+extern "C" {
+
+int ref_bit_depth(void) { return X265_DEPTH; }
+int ref_sizeof_pixel(void) { return (int)sizeof(pixel); }
+int ref_sizeof_sse(void) { return (int)sizeof(sse_t); }
+int ref_partition_from_sizes(int w, int h) { return partitionFromSizes(w, h); }
+
+/* ---- distortion: pixel.cpp ---- */
+int ref_sad(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { ensure(); return g_p.pu[part].sad(a, sa, b, sb); }
+void ref_sad_x3(int part, const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
+{ ensure(); g_p.pu[part].sad_x3(fenc, r0, r1, r2, rs, res); }
+void ref_sad_x4(int part, const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
+{ ensure(); g_p.pu[part].sad_x4(fenc, r0, r1, r2, r3, rs, res); }
+int ref_satd(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { ensure(); return g_p.pu[part].satd(a, sa, b, sb); }
+int ref_sa8d(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { ensure(); return g_p.cu[cu].sa8d(a, sa, b, sb); }
+uint64_t ref_sse_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { ensure(); return (uint64_t)g_p.cu[cu].sse_pp(a, sa, b, sb); }
+uint64_t ref_sse_ss(int cu, const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb) { ensure(); return (uint64_t)g_p.cu[cu].sse_ss(a, sa, b, sb); }
+uint64_t ref_ssd_s(int cu, const int16_t* a, intptr_t sa) { ensure(); return (uint64_t)g_p.cu[cu].ssd_s[NONALIGNED](a, sa); }
+int ref_psy_cost_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { ensure(); return g_p.cu[cu].psy_cost_pp(a, sa, b, sb); }
+int ref_chroma_satd(int csp, int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{ ensure(); return g_p.chroma[csp].pu[part].satd ? g_p.chroma[csp].pu[part].satd(a, sa, b, sb) : -1; }
+int ref_chroma_sa8d(int csp, int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{ ensure(); return g_p.chroma[csp].cu[cu].sa8d(a, sa, b, sb); }
+uint64_t ref_var(int cu, const pixel* a, intptr_t sa) { ensure(); return g_p.cu[cu].var(a, sa); }
+
+/* ---- residual / recon helpers: pixel.cpp ---- */
+void ref_sub_ps(int cu, int16_t* dst, intptr_t ds, const pixel* s0, const pixel* s1, intptr_t ss0, intptr_t ss1)
+{ ensure(); g_p.cu[cu].sub_ps(dst, ds, s0, s1, ss0, ss1); }
+void ref_add_ps(int cu, pixel* dst, intptr_t ds, const pixel* b0, const int16_t* b1, intptr_t ss0, intptr_t ss1)
+{ ensure(); g_p.cu[cu].add_ps[NONALIGNED](dst, ds, b0, b1, ss0, ss1); }
+void ref_pixelavg_pp(int part, pixel* dst, intptr_t ds, const pixel* s0, intptr_t ss0, const pixel* s1, intptr_t ss1)
+{ ensure(); g_p.pu[part].pixelavg_pp[NONALIGNED](dst, ds, s0, ss0, s1, ss1, 32); }
+void ref_addAvg(int part, const int16_t* s0, const int16_t* s1, pixel* dst, intptr_t ss0, intptr_t ss1, intptr_t ds)
+{ ensure(); g_p.pu[part].addAvg[NONALIGNED](s0, s1, dst, ss0, ss1, ds); }
+void ref_chroma_addAvg(int csp, int part, const int16_t* s0, const int16_t* s1, pixel* dst, intptr_t ss0, intptr_t ss1, intptr_t ds)
+{ ensure(); g_p.chroma[csp].pu[part].addAvg[NONALIGNED](s0, s1, dst, ss0, ss1, ds); }
+void ref_weight_pp(const pixel* src, pixel* dst, intptr_t stride, int width, int height, int w0, int round, int shift, int offset)
+{ ensure(); g_p.weight_pp(src, dst, stride, width, height, w0, round, shift, offset); }
+void ref_weight_sp(const int16_t* src, pixel* dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift, int offset)
+{ ensure(); g_p.weight_sp(src, dst, ss, ds, width, height, w0, round, shift, offset); }
+void ref_scale2D_64to32(pixel* dst, const pixel* src, intptr_t stride) { ensure(); g_p.scale2D_64to32(dst, src, stride); }
+void ref_scale1D_128to64(pixel* dst, const pixel* src) { ensure(); g_p.scale1D_128to64[NONALIGNED](dst, src); }
+void ref_transpose(int cu, pixel* dst, const pixel* src, intptr_t stride) { ensure(); g_p.cu[cu].transpose(dst, src, stride); }
+void ref_cpy2Dto1D_shl(int cu, int16_t* dst, const int16_t* src, intptr_t ss, int shift) { ensure(); g_p.cu[cu].cpy2Dto1D_shl(dst, src, ss, shift); }
+void ref_cpy2Dto1D_shr(int cu, int16_t* dst, const int16_t* src, intptr_t ss, int shift) { ensure(); g_p.cu[cu].cpy2Dto1D_shr(dst, src, ss, shift); }
+void ref_cpy1Dto2D_shl(int cu, int16_t* dst, const int16_t* src, intptr_t ds, int shift) { ensure(); g_p.cu[cu].cpy1Dto2D_shl[NONALIGNED](dst, src, ds, shift); }
+void ref_cpy1Dto2D_shr(int cu, int16_t* dst, const int16_t* src, intptr_t ds, int shift) { ensure(); g_p.cu[cu].cpy1Dto2D_shr(dst, src, ds, shift); }
+
+/* ---- transforms + quant: dct.cpp ---- */
+void ref_dct(int cu, const int16_t* src, int16_t* dst, intptr_t stride) { ensure(); g_p.cu[cu].dct(src, dst, stride); }
+void ref_idct(int cu, const int16_t* src, int16_t* dst, intptr_t stride) { ensure(); g_p.cu[cu].idct(src, dst, stride); }
+void ref_dst4x4(const int16_t* src, int16_t* dst, intptr_t stride) { ensure(); g_p.dst4x4(src, dst, stride); }
+void ref_idst4x4(const int16_t* src, int16_t* dst, intptr_t stride) { ensure(); g_p.idst4x4(src, dst, stride); }
+uint32_t ref_quant(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef, int qBits, int add, int numCoeff)
+{ ensure(); return g_p.quant(coef, quantCoeff, deltaU, qCoef, qBits, add, numCoeff); }
+uint32_t ref_nquant(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff)
+{ ensure(); return g_p.nquant(coef, quantCoeff, qCoef, qBits, add, numCoeff); }
+void ref_dequant_normal(const int16_t* quantCoef, int16_t* coef, int num, int scale, int shift)
+{ ensure(); g_p.dequant_normal(quantCoef, coef, num, scale, shift); }
+void ref_dequant_scaling(const int16_t* src, const int32_t* dequantCoef, int16_t* dst, int num, int per, int shift)
+{ ensure(); g_p.dequant_scaling(src, dequantCoef, dst, num, per, shift); }
+int ref_count_nonzero(int cu, const int16_t* q) { ensure(); return g_p.cu[cu].count_nonzero(q); }
+uint32_t ref_copy_cnt(int cu, int16_t* coeff, const int16_t* resi, intptr_t stride) { ensure(); return g_p.cu[cu].copy_cnt(coeff, resi, stride); }
+
+/* ---- intra: intrapred.cpp ---- */
+void ref_intra_pred(int cu, int mode, pixel* dst, intptr_t ds, const pixel* srcPix, int bFilter)
+{ ensure(); g_p.cu[cu].intra_pred[mode](dst, ds, srcPix, mode, bFilter); }
+void ref_intra_filter(int cu, const pixel* refs, pixel* filtered) { ensure(); g_p.cu[cu].intra_filter(refs, filtered); }
+void ref_intra_allangs(int cu, pixel* dst, pixel* refPix, pixel* filtPix, int bLuma)
+{ ensure(); g_p.cu[cu].intra_pred_allangs(dst, refPix, filtPix, bLuma); }
+
+/* ---- interpolation: ipfilter.cpp ---- */
+void ref_luma_hpp(int part, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int idx) { ensure(); g_p.pu[part].luma_hpp(src, ss, dst, ds, idx); }
+void ref_luma_hps(int part, const pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int idx, int rowExt) { ensure(); g_p.pu[part].luma_hps(src, ss, dst, ds, idx, rowExt); }
+void ref_luma_vpp(int part, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int idx) { ensure(); g_p.pu[part].luma_vpp(src, ss, dst, ds, idx); }
+void ref_luma_vps(int part, const pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int idx) { ensure(); g_p.pu[part].luma_vps(src, ss, dst, ds, idx); }
+void ref_luma_vsp(int part, const int16_t* src, intptr_t ss, pixel* dst, intptr_t ds, int idx) { ensure(); g_p.pu[part].luma_vsp(src, ss, dst, ds, idx); }
+void ref_luma_vss(int part, const int16_t* src, intptr_t ss, int16_t* dst, intptr_t ds, int idx) { ensure(); g_p.pu[part].luma_vss(src, ss, dst, ds, idx); }
+void ref_luma_hvpp(int part, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int ix, int iy) { ensure(); g_p.pu[part].luma_hvpp(src, ss, dst, ds, ix, iy); }
+void ref_luma_p2s(int part, const pixel* src, intptr_t ss, int16_t* dst, intptr_t ds) { ensure(); g_p.pu[part].convert_p2s[NONALIGNED](src, ss, dst, ds); }
+void ref_chroma_hpp(int csp, int part, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int idx) { ensure(); g_p.chroma[csp].pu[part].filter_hpp(src, ss, dst, ds, idx); }
+void ref_chroma_hps(int csp, int part, const pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int idx, int rowExt) { ensure(); g_p.chroma[csp].pu[part].filter_hps(src, ss, dst, ds, idx, rowExt); }
+void ref_chroma_vpp(int csp, int part, const pixel* src, intptr_t ss, pixel* dst, intptr_t ds, int idx) { ensure(); g_p.chroma[csp].pu[part].filter_vpp(src, ss, dst, ds, idx); }
+void ref_chroma_vps(int csp, int part, const pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int idx) { ensure(); g_p.chroma[csp].pu[part].filter_vps(src, ss, dst, ds, idx); }
+void ref_chroma_vsp(int csp, int part, const int16_t* src, intptr_t ss, pixel* dst, intptr_t ds, int idx) { ensure(); g_p.chroma[csp].pu[part].filter_vsp(src, ss, dst, ds, idx); }
+void ref_chroma_vss(int csp, int part, const int16_t* src, intptr_t ss, int16_t* dst, intptr_t ds, int idx) { ensure(); g_p.chroma[csp].pu[part].filter_vss(src, ss, dst, ds, idx); }
+void ref_chroma_p2s(int csp, int part, const pixel* src, intptr_t ss, int16_t* dst, intptr_t ds) { ensure(); g_p.chroma[csp].pu[part].p2s[NONALIGNED](src, ss, dst, ds); }
+
+/* ---- constant tables the path reads (constants.cpp) ---- */
+const int16_t* ref_tbl_t4(void) { return &g_t4[0][0]; }
+const int16_t* ref_tbl_t8(void) { return &g_t8[0][0]; }
+const int16_t* ref_tbl_t16(void) { return &g_t16[0][0]; }
+const int16_t* ref_tbl_t32(void) { return &g_t32[0][0]; }
+const int16_t* ref_tbl_lumaFilter(void) { return &g_lumaFilter[0][0]; }
+const int16_t* ref_tbl_chromaFilter(void) { return &g_chromaFilter[0][0]; }
+const double* ref_tbl_lambda(void) { return x265_lambda_tab; }
+const double* ref_tbl_lambda2(void) { return x265_lambda2_tab; }
+const uint8_t* ref_tbl_chromaScale(void) { return g_chromaScale; }
+const uint8_t* ref_tbl_intraFilterFlags(void) { return g_intraFilterFlags; }
+
+} /* extern "C" */

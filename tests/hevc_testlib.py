@@ -1,0 +1,496 @@
+"""Shared parity-test machinery (test infrastructure).
+
+One table of *cases* drives every comparison in the suite, in the style of the reference's TestBench
+(/root/reference/source/test/testbench.cpp:102-261, pixelharness.cpp:30-81: random / all-min / all-max buffers,
+exact equality):
+
+  * oracle  vs reference build (oracle/_ref/librefprims*.so)       -> tests/test_oracle_vs_ref.py   (CPU, here only)
+  * oracle  vs golden vectors generated from the reference          -> tests/test_oracle_golden.py   (CPU)
+  * HIP C-ABI vs oracle (and vs golden)                             -> tests/test_hip_parity.py      (GPU)
+
+A case is a function `case(L, rng) -> list[np.ndarray]` that performs calls through a `PrimLib` `L`
+(`L.call("sad", part, a, sa, b, sb)` resolves to `ref_sad` / `orc_sad` / the HIP per-slot shim
+`x265amd_sad`) and returns every output.  The same seeded rng gives the same inputs to every implementation.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+PKG_DIR = os.path.join(ROOT, "x265-amod_amd")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# enum LumaPU order (reference: source/common/primitives.h:41-55)
+PU_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (32, 16), (16, 32),
+            (64, 32), (32, 64), (16, 12), (12, 16), (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32),
+            (64, 48), (48, 64), (64, 16), (16, 64)]
+CSP_I420 = 1
+FENC_STRIDE = 64
+
+_U64_FUNCS = {"sse_pp", "sse_ss", "ssd_s", "var"}
+
+
+def _ptr(a):
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return a
+
+
+class PrimLib:
+    """ctypes view of one implementation of the primitive set."""
+
+    def __init__(self, path, prefix, depth):
+        self.path, self.prefix, self.depth = path, prefix, depth
+        self.lib = C.CDLL(path)
+        self.pixel = np.uint8 if depth == 8 else np.uint16
+        self.pmax = (1 << depth) - 1
+        got = getattr(self.lib, prefix + "bit_depth")()
+        assert got == depth, (path, got, depth)
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    def call(self, name, *args):
+        fn = getattr(self.lib, self.prefix + name)
+        fn.restype = C.c_uint64 if name in _U64_FUNCS else C.c_int
+        conv = []
+        for a in args:
+            if isinstance(a, np.ndarray):
+                conv.append(_ptr(a))
+            elif isinstance(a, (int, np.integer)):
+                conv.append(C.c_int64(int(a)))
+            else:
+                conv.append(a)
+        return fn(*conv)
+
+
+def oracle_path(depth):
+    return os.path.join(ORACLE_DIR, "liboracle%d.so" % depth)
+
+
+def ref_path(depth):
+    return os.path.join(REF_DIR, "librefprims%d.so" % depth)
+
+
+def have_ref():
+    return os.path.exists(ref_path(8)) and os.path.exists(ref_path(10))
+
+
+def load_oracle(depth):
+    p = oracle_path(depth)
+    if not os.path.exists(p):
+        import subprocess
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return PrimLib(p, "orc_", depth)
+
+
+def load_ref(depth):
+    return PrimLib(ref_path(depth), "ref_", depth)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# buffers
+# ----------------------------------------------------------------------------------------------------------
+MODES = ("random", "min", "max")
+
+
+def pix_buf(L, rng, n, mode):
+    if mode == "min":
+        return np.zeros(n, L.pixel)
+    if mode == "max":
+        return np.full(n, L.pmax, L.pixel)
+    return rng.integers(0, L.pmax + 1, n, dtype=np.int64).astype(L.pixel)
+
+
+def s16_buf(rng, n, lo, hi, mode):
+    if mode == "min":
+        return np.full(n, lo, np.int16)
+    if mode == "max":
+        return np.full(n, hi, np.int16)
+    return rng.integers(lo, hi + 1, n, dtype=np.int64).astype(np.int16)
+
+
+def off(a, elems):
+    """pointer `elems` elements into array a"""
+    return C.c_void_p(a.ctypes.data + elems * a.itemsize)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# cases.  Every case takes (L, rng, mode) and returns a list of arrays.
+# ----------------------------------------------------------------------------------------------------------
+def case_sad(L, rng, mode):
+    out = []
+    for part, (w, h) in enumerate(PU_SIZES):
+        sb = 64 + 2 * int(rng.integers(0, 40))
+        a = pix_buf(L, rng, 64 * 64, mode)
+        b = pix_buf(L, rng, sb * 80 + 80, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        o = int(rng.integers(0, 16))
+        out.append(np.array([L.call("sad", part, a, FENC_STRIDE, off(b, o), sb)], np.int64))
+        res = np.zeros(4, np.int32)
+        L.call("sad_x3", part, a, off(b, o), off(b, o + 1), off(b, o + sb), sb, res)
+        out.append(res[:3].copy())
+        res = np.zeros(4, np.int32)
+        L.call("sad_x4", part, a, off(b, o), off(b, o + 2), off(b, o + sb), off(b, o + 3 * sb + 1), sb, res)
+        out.append(res.copy())
+    return out
+
+
+def case_satd(L, rng, mode):
+    out = []
+    for part, (w, h) in enumerate(PU_SIZES):
+        sa, sb = 64, 64 + 2 * int(rng.integers(0, 40))
+        a = pix_buf(L, rng, sa * 64, mode)
+        b = pix_buf(L, rng, sb * 64 + 64, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        out.append(np.array([L.call("satd", part, a, sa, b, sb)], np.int64))
+        if w >= 8 and h >= 8 and w <= 64 and h <= 64 and (w // 2, h // 2) in PU_SIZES:
+            out.append(np.array([L.call("chroma_satd", CSP_I420, part, a, sa, b, sb)], np.int64))
+    return out
+
+
+def case_sa8d(L, rng, mode):
+    out = []
+    for cu in range(5):
+        sa, sb = 64 + 8 * int(rng.integers(0, 4)), 64 + 2 * int(rng.integers(0, 40))
+        a = pix_buf(L, rng, sa * 64, mode)
+        b = pix_buf(L, rng, sb * 64, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        out.append(np.array([L.call("sa8d", cu, a, sa, b, sb)], np.int64))
+        if cu >= 1:
+            out.append(np.array([L.call("chroma_sa8d", CSP_I420, cu, a, sa, b, sb)], np.int64))
+    return out
+
+
+def case_sse(L, rng, mode):
+    out = []
+    lim = L.pmax
+    for cu in range(5):
+        sa, sb = 64 + 8 * int(rng.integers(0, 4)), 64 + 2 * int(rng.integers(0, 40))
+        a = pix_buf(L, rng, sa * 64, mode)
+        b = pix_buf(L, rng, sb * 64, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        out.append(np.array([L.call("sse_pp", cu, a, sa, b, sb)], np.uint64))
+        sa_ = s16_buf(rng, sa * 64, -lim, lim, mode)
+        sb_ = s16_buf(rng, sb * 64, -lim, lim, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        out.append(np.array([L.call("sse_ss", cu, sa_, sa, sb_, sb)], np.uint64))
+        out.append(np.array([L.call("ssd_s", cu, sa_, sa)], np.uint64))
+    return out
+
+
+def case_psy(L, rng, mode):
+    out = []
+    for cu in range(5):
+        sa, sb = 64 + 8 * int(rng.integers(0, 4)), 64 + 2 * int(rng.integers(0, 40))
+        a = pix_buf(L, rng, sa * 64, mode)
+        b = pix_buf(L, rng, sb * 64, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        out.append(np.array([L.call("psy_cost_pp", cu, a, sa, b, sb)], np.int64))
+    return out
+
+
+def case_residual(L, rng, mode):
+    out = []
+    lim = L.pmax
+    for cu in range(5):
+        n = 4 << cu
+        s0, s1, ds = 64 + 8 * int(rng.integers(0, 3)), 64 + 2 * int(rng.integers(0, 9)), 64
+        a = pix_buf(L, rng, s0 * 64, mode)
+        b = pix_buf(L, rng, s1 * 64, "random" if mode == "random" else ("max" if mode == "min" else "min"))
+        r = np.zeros(ds * 64, np.int16)
+        L.call("sub_ps", cu, r, ds, a, b, s0, s1)
+        out.append(r.reshape(64, ds)[:n, :n].copy())
+        resi = s16_buf(rng, s1 * 64, -lim, lim, mode)
+        rec = np.zeros(ds * 64, L.pixel)
+        L.call("add_ps", cu, rec, ds, a, resi, s0, s1)
+        out.append(rec.reshape(64, ds)[:n, :n].copy())
+    return out
+
+
+def case_avg(L, rng, mode):
+    out = []
+    for part, (w, h) in enumerate(PU_SIZES):
+        s0, s1, ds = 64 + 2 * int(rng.integers(0, 9)), 64 + 2 * int(rng.integers(0, 9)), 64
+        a = pix_buf(L, rng, s0 * 64, mode)
+        b = pix_buf(L, rng, s1 * 64, mode)
+        d = np.zeros(ds * 64, L.pixel)
+        L.call("pixelavg_pp", part, d, ds, a, s0, b, s1)
+        out.append(d.reshape(64, ds)[:h, :w].copy())
+        lo, hi = -8192, 8191
+        x = s16_buf(rng, s0 * 64, lo, hi, mode)
+        y = s16_buf(rng, s1 * 64, lo, hi, mode)
+        d = np.zeros(ds * 64, L.pixel)
+        L.call("addAvg", part, x, y, d, s0, s1, ds)
+        out.append(d.reshape(64, ds)[:h, :w].copy())
+        if w >= 4 and h >= 4:
+            d = np.zeros(ds * 64, L.pixel)
+            L.call("chroma_addAvg", CSP_I420, part, x, y, d, s0, s1, ds)
+            out.append(d.reshape(64, ds)[:h // 2, :w // 2].copy())
+    return out
+
+
+def case_weight(L, rng, mode):
+    out = []
+    corr = 14 - L.depth
+    for _ in range(4):
+        w, h, stride = 16 * int(rng.integers(1, 5)), int(rng.integers(1, 17)), 64 + 16 * int(rng.integers(0, 3))
+        w0 = int(rng.integers(1, 128))
+        shift = int(rng.integers(0, 7)) + corr
+        rnd = (1 << (shift - 1)) if shift else 0
+        rnd &= ~((1 << corr) - 1)
+        offset = int(rng.integers(-20, 21))
+        src = pix_buf(L, rng, stride * 16, mode)
+        dst = np.zeros(stride * 16, L.pixel)
+        L.call("weight_pp", src, dst, stride, w, h, w0, rnd, shift, offset)
+        out.append(dst.reshape(16, stride)[:h, :w].copy())
+        s = s16_buf(rng, stride * 16, -8192, 8191, mode)
+        dst = np.zeros(stride * 16, L.pixel)
+        L.call("weight_sp", s, dst, stride, stride, w - 1, h, w0, rnd, shift, offset)
+        out.append(dst.reshape(16, stride)[:h, :w - 1].copy())
+    return out
+
+
+def case_misc(L, rng, mode):
+    out = []
+    stride = 64 + 2 * int(rng.integers(0, 9))
+    src = pix_buf(L, rng, stride * 64, mode)
+    d = np.zeros(32 * 32, L.pixel)
+    L.call("scale2D_64to32", d, src, stride)
+    out.append(d.copy())
+    s1 = pix_buf(L, rng, 256, mode)
+    d = np.zeros(128, L.pixel)
+    L.call("scale1D_128to64", d, s1)
+    out.append(d.copy())
+    for cu in range(5):
+        n = 4 << cu
+        d = np.zeros(n * n, L.pixel)
+        L.call("transpose", cu, d, src, stride)
+        out.append(d.copy())
+    for cu in range(4):
+        n = 4 << cu
+        st = n + 8 * int(rng.integers(0, 3))
+        s = s16_buf(rng, st * n, -4096, 4095, mode)
+        for name, twod in (("cpy2Dto1D_shl", 0), ("cpy2Dto1D_shr", 0), ("cpy1Dto2D_shl", 1), ("cpy1Dto2D_shr", 1)):
+            shift = int(rng.integers(1, 3))
+            d = np.zeros(st * n, np.int16)
+            L.call(name, cu, d, s, st, shift)
+            out.append(d.reshape(n, st)[:, :n].copy() if twod else d[:n * n].copy())
+        q = s16_buf(rng, n * n, -3, 3, mode)
+        out.append(np.array([L.call("count_nonzero", cu, q)], np.int64))
+        c = np.zeros(n * n, np.int16)
+        out.append(np.array([L.call("copy_cnt", cu, c, s, st)], np.int64))
+        out.append(c.copy())
+    for cu in range(5):
+        out.append(np.array([L.call("var", cu, src, stride)], np.uint64))
+    return out
+
+
+def case_dct(L, rng, mode):
+    out = []
+    lim = L.pmax
+    for cu in range(4):
+        n = 4 << cu
+        st = n + 8 * int(rng.integers(0, 3))
+        src = s16_buf(rng, st * n, -lim, lim, mode)
+        d = np.zeros(n * n, np.int16)
+        L.call("dct", cu, src, d, st)
+        out.append(d.copy())
+        # inverse on plausible coefficient data (the forward result) and on full-range data
+        r = np.zeros(st * n, np.int16)
+        L.call("idct", cu, d, r, st)
+        out.append(r.reshape(n, st)[:, :n].copy())
+        c = s16_buf(rng, n * n, -32768, 32767, mode)
+        r = np.zeros(st * n, np.int16)
+        L.call("idct", cu, c, r, st)
+        out.append(r.reshape(n, st)[:, :n].copy())
+        if cu == 0:
+            d2 = np.zeros(16, np.int16)
+            L.call("dst4x4", src, d2, st)
+            out.append(d2.copy())
+            r = np.zeros(st * 4, np.int16)
+            L.call("idst4x4", d2, r, st)
+            out.append(r.reshape(4, st)[:, :4].copy())
+            r = np.zeros(st * 4, np.int16)
+            L.call("idst4x4", c, r, st)
+            out.append(r.reshape(4, st)[:, :4].copy())
+    return out
+
+
+QUANT_SCALES = [26214, 23302, 20560, 18396, 16384, 14564]   # HEVC quantisation scale per qp%6 (reference: scalinglist.cpp)
+INV_QUANT_SCALES = [40, 45, 51, 57, 64, 72]
+
+
+def case_quant(L, rng, mode):
+    out = []
+    for cu in range(4):
+        n = (4 << cu) ** 2
+        log2n = cu + 2
+        for _ in range(3):
+            qp = int(rng.integers(0, 52))
+            per, rem = qp // 6, qp % 6
+            tshift = 15 - L.depth - log2n                   # MAX_TR_DYNAMIC_RANGE - depth - log2TrSize
+            qbits = 14 + per + tshift
+            add = (171 if rng.integers(0, 2) else 85) << (qbits - 9)
+            coef = s16_buf(rng, n, -32768, 32767, mode)
+            qc = np.full(n, QUANT_SCALES[rem], np.int32)
+            if mode == "random":
+                qc = (qc.astype(np.int64) * 16 // rng.integers(8, 40, n)).astype(np.int32)   # scaling-list style tables
+            du = np.zeros(n, np.int32)
+            q = np.zeros(n, np.int16)
+            ns = L.call("quant", coef, qc, du, q, qbits, add, n)
+            out += [np.array([ns], np.int64), du.copy(), q.copy()]
+            q2 = np.zeros(n, np.int16)
+            ns = L.call("nquant", coef, qc, q2, qbits, add, n)
+            out += [np.array([ns], np.int64), q2.copy()]
+            # dequant (quant.cpp:559-569): shift = QUANT_IQUANT_SHIFT(20) - QUANT_SHIFT(14) - transformShift
+            shift = 20 - 14 - tshift
+            d = np.zeros(n, np.int16)
+            L.call("dequant_normal", q, d, n, INV_QUANT_SCALES[rem] << per, shift)
+            out.append(d.copy())
+            dq = (np.full(n, INV_QUANT_SCALES[rem] * 16, np.int64) if mode != "random"
+                  else INV_QUANT_SCALES[rem] * rng.integers(8, 40, n)).astype(np.int32)
+            d = np.zeros(n, np.int16)
+            L.call("dequant_scaling", q, dq, d, n, per, shift)
+            out.append(d.copy())
+    return out
+
+
+def case_intra(L, rng, mode):
+    out = []
+    for cu in range(4):
+        n = 4 << cu
+        nb = pix_buf(L, rng, 4 * n + 1 + 16, mode)
+        if mode == "random" and rng.integers(0, 2):     # smooth neighbours exercise the rounding paths differently
+            nb = np.clip(np.cumsum(rng.integers(-3, 4, nb.size)) + L.pmax // 2, 0, L.pmax).astype(L.pixel)
+        filt = np.zeros_like(nb)
+        L.call("intra_filter", cu, nb, filt)
+        out.append(filt[:4 * n + 1].copy())
+        ds = n + 8 * int(rng.integers(0, 3))
+        for m in range(35):
+            for bf in (0, 1):
+                d = np.zeros(ds * n, L.pixel)
+                L.call("intra_pred", cu, m, d, ds, nb, bf)
+                out.append(d.reshape(n, ds)[:, :n].copy())
+        for bl in (0, 1):
+            d = np.zeros(33 * n * n, L.pixel)
+            L.call("intra_allangs", cu, d, nb, filt, bl)
+            out.append(d.copy())
+    return out
+
+
+def case_ipfilter_luma(L, rng, mode):
+    out = []
+    for part, (w, h) in enumerate(PU_SIZES):
+        ss = 80 + 2 * int(rng.integers(0, 9))
+        src = pix_buf(L, rng, ss * 80, mode)
+        sp = off(src, 4 * ss + 4)
+        s16 = s16_buf(rng, ss * 80, -8192, 8191 if L.depth == 8 else 8191, mode)
+        s16p = off(s16, 4 * ss + 4)
+        ds = 64 + 2 * int(rng.integers(0, 5))
+        idx = int(rng.integers(0, 4))
+        for name in ("luma_hpp", "luma_vpp"):
+            d = np.zeros(ds * 72, L.pixel)
+            L.call(name, part, sp, ss, d, ds, idx)
+            out.append(d.reshape(72, ds)[:h, :w].copy())
+        for ext in (0, 1):
+            d = np.zeros(ds * 72, np.int16)
+            L.call("luma_hps", part, sp, ss, d, ds, idx, ext)
+            out.append(d.reshape(72, ds)[:h + 7 * ext, :w].copy())
+        d = np.zeros(ds * 72, np.int16)
+        L.call("luma_vps", part, sp, ss, d, ds, idx)
+        out.append(d.reshape(72, ds)[:h, :w].copy())
+        d = np.zeros(ds * 72, L.pixel)
+        L.call("luma_vsp", part, s16p, ss, d, ds, idx)
+        out.append(d.reshape(72, ds)[:h, :w].copy())
+        d = np.zeros(ds * 72, np.int16)
+        L.call("luma_vss", part, s16p, ss, d, ds, idx)
+        out.append(d.reshape(72, ds)[:h, :w].copy())
+        d = np.zeros(ds * 72, L.pixel)
+        L.call("luma_hvpp", part, sp, ss, d, ds, int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        out.append(d.reshape(72, ds)[:h, :w].copy())
+        d = np.zeros(ds * 72, np.int16)
+        L.call("luma_p2s", part, sp, ss, d, ds)
+        out.append(d.reshape(72, ds)[:h, :w].copy())
+    return out
+
+
+def case_ipfilter_chroma(L, rng, mode):
+    out = []
+    for part, (w, h) in enumerate(PU_SIZES):
+        if (w, h) == (4, 4):      # no 2x2 chroma filter entries (reference: ipfilter.cpp:418-466)
+            continue
+        cw, ch = w // 2, h // 2
+        ss = 48 + 2 * int(rng.integers(0, 9))
+        src = pix_buf(L, rng, ss * 48, mode)
+        sp = off(src, 4 * ss + 4)
+        s16 = s16_buf(rng, ss * 48, -8192, 8191, mode)
+        s16p = off(s16, 4 * ss + 4)
+        ds = 32 + 2 * int(rng.integers(0, 5))
+        idx = int(rng.integers(0, 8))
+        for name in ("chroma_hpp", "chroma_vpp"):
+            d = np.zeros(ds * 40, L.pixel)
+            L.call(name, CSP_I420, part, sp, ss, d, ds, idx)
+            out.append(d.reshape(40, ds)[:ch, :cw].copy())
+        for ext in (0, 1):
+            d = np.zeros(ds * 40, np.int16)
+            L.call("chroma_hps", CSP_I420, part, sp, ss, d, ds, idx, ext)
+            out.append(d.reshape(40, ds)[:ch + 3 * ext, :cw].copy())
+        d = np.zeros(ds * 40, np.int16)
+        L.call("chroma_vps", CSP_I420, part, sp, ss, d, ds, idx)
+        out.append(d.reshape(40, ds)[:ch, :cw].copy())
+        d = np.zeros(ds * 40, L.pixel)
+        L.call("chroma_vsp", CSP_I420, part, s16p, ss, d, ds, idx)
+        out.append(d.reshape(40, ds)[:ch, :cw].copy())
+        d = np.zeros(ds * 40, np.int16)
+        L.call("chroma_vss", CSP_I420, part, s16p, ss, d, ds, idx)
+        out.append(d.reshape(40, ds)[:ch, :cw].copy())
+        d = np.zeros(ds * 40, np.int16)
+        L.call("chroma_p2s", CSP_I420, part, sp, ss, d, ds)
+        out.append(d.reshape(40, ds)[:ch, :cw].copy())
+    return out
+
+
+CASES = {
+    "sad": case_sad,
+    "satd": case_satd,
+    "sa8d": case_sa8d,
+    "sse": case_sse,
+    "psy": case_psy,
+    "residual": case_residual,
+    "avg": case_avg,
+    "weight": case_weight,
+    "misc": case_misc,
+    "dct": case_dct,
+    "quant": case_quant,
+    "intra": case_intra,
+    "ipfilter_luma": case_ipfilter_luma,
+    "ipfilter_chroma": case_ipfilter_chroma,
+}
+
+
+def case_seed(name, depth, mode, rep):
+    h = hashlib.sha256(("%s/%d/%s/%d" % (name, depth, mode, rep)).encode()).digest()
+    return int.from_bytes(h[:8], "little")
+
+
+def run_case(L, name, mode, rep=0):
+    rng = np.random.default_rng(case_seed(name, L.depth, mode, rep))
+    return CASES[name](L, rng, mode)
+
+
+def digest(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def assert_same(got, want, what):
+    assert len(got) == len(want), "%s: %d vs %d outputs" % (what, len(got), len(want))
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape and g.dtype == w.dtype, "%s[%d]: shape/dtype %s %s vs %s %s" % (what, i, g.shape, g.dtype, w.shape, w.dtype)
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g != w)
+            raise AssertionError("%s: output %d differs at %d positions, first %s: got %s want %s"
+                                 % (what, i, len(bad), bad[0], g[tuple(bad[0])], w[tuple(bad[0])]))
