@@ -1,0 +1,187 @@
+/* x265amd -- MI355X (gfx950) HEVC encode hot path behind the x265 primitive-table boundary.
+ *
+ * C ABI of libx265amd_main.so (8-bit pixels) / libx265amd_main10.so (10-bit pixels).  Like the reference's
+ * multilib scheme (reference: source/x265.h:2619-2635, encoder/api.cpp:1107-1182) the pixel type is a build-time
+ * property of the library; both libraries export the same symbols.
+ *
+ * Three layers, all plain C (no C++ / torch / HIP types in any signature):
+ *
+ *  1. Per-slot entry points with HOST pointers -- one per slot family of the reference's `EncoderPrimitives`
+ *     function table (reference: source/common/primitives.h:239-433), taking the slot index (LumaPU `part` or
+ *     LumaCU `cu` = log2(size)-2) as first argument and then exactly the arguments of the slot's typedef
+ *     (primitives.h:133-236).  `x265amd_setup_primitives()` installs size-bound thunks of these into a table
+ *     with the reference's layout, the way setupAssemblyPrimitives() does (primitives.h:474).  Each call stages
+ *     its operands to the GPU, runs the SAME kernels as layer 2 with a batch of one and copies the result back:
+ *     they exist for slot-for-slot parity (TestBench style, reference source/test/testbench.cpp:102-261), not speed.
+ *
+ *  2. Batched job lists on DEVICE memory (`x265amd_run_jobs`): the host loop queues any number of independent
+ *     primitive calls (all 35 intra predictions of a CU, all merge candidates, every TU of a residual quad-tree
+ *     level ...) and flushes them as one launch per kernel family; one 64-lane wavefront executes one job.
+ *
+ *  3. Fused frame-level kernels on device-resident pictures (`x265amd_me_*`, `x265amd_intra_*`,
+ *     `x265amd_tu_*`): the form the frame host loop uses; see each prototype.
+ *
+ * Error behaviour: the reference primitives cannot fail (void/int results, primitives.h:133-236); the per-slot
+ * entry points keep those signatures and abort() with a message on a HIP runtime error (no silent CPU fallback).
+ * Layer 2/3 functions return 0 on success or a negative X265AMD_E* code.
+ */
+#ifndef X265AMD_H
+#define X265AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef X265AMD_DEPTH
+#define X265AMD_DEPTH 8
+#endif
+#if X265AMD_DEPTH > 8
+typedef uint16_t x265amd_pixel;     /* reference: common/common.h:126-139 */
+#else
+typedef uint8_t x265amd_pixel;
+#endif
+
+#define X265AMD_OK 0
+#define X265AMD_EINVAL (-1)
+#define X265AMD_EHIP (-2)
+#define X265AMD_ENOMEM (-3)
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* Library / device                                                                                        */
+/* ------------------------------------------------------------------------------------------------------- */
+int x265amd_bit_depth(void);                 /* X265_DEPTH of this build */
+const char* x265amd_version(void);
+int x265amd_device_count(void);              /* number of visible GPUs (0: the per-slot/batched calls will fail loudly) */
+const char* x265amd_last_error(void);        /* message for the last negative return on this thread */
+
+/* Fills the accelerated slots of a table laid out like the reference's `EncoderPrimitives`
+ * (primitives.h:239-433; 2281 slots / 18248 bytes in the 8-bit build).  `table_bytes` must equal the size this
+ * library was generated for (x265amd_primitives_table_bytes()); returns the number of slots written, or <0. */
+int x265amd_setup_primitives(void* encoder_primitives_table, size_t table_bytes);
+size_t x265amd_primitives_table_bytes(void);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* Layer 1: per-slot entry points, HOST pointers.  `part`: enum LumaPU (primitives.h:41-55);                 */
+/* `cu`: enum LumaCU = log2(size)-2 (primitives.h:57-65); `csp`: X265_CSP_I420 = 1.                          */
+/* ------------------------------------------------------------------------------------------------------- */
+typedef x265amd_pixel pixel_t_;
+
+/* pixelcmp_t (primitives.h:133) -- pu[part].sad, pu[part].satd, cu[cu].sa8d, cu[cu].psy_cost_pp */
+int x265amd_sad(int part, const pixel_t_* fenc, intptr_t fencstride, const pixel_t_* fref, intptr_t frefstride);
+int x265amd_satd(int part, const pixel_t_* fenc, intptr_t fencstride, const pixel_t_* fref, intptr_t frefstride);
+int x265amd_sa8d(int cu, const pixel_t_* fenc, intptr_t fencstride, const pixel_t_* fref, intptr_t frefstride);
+int x265amd_psy_cost_pp(int cu, const pixel_t_* source, intptr_t sstride, const pixel_t_* recon, intptr_t rstride);
+int x265amd_chroma_satd(int csp, int part, const pixel_t_* fenc, intptr_t fencstride, const pixel_t_* fref, intptr_t frefstride);
+int x265amd_chroma_sa8d(int csp, int cu, const pixel_t_* fenc, intptr_t fencstride, const pixel_t_* fref, intptr_t frefstride);
+/* pixelcmp_x3_t / pixelcmp_x4_t (primitives.h:139-140) -- fenc stride is FENC_STRIDE (64) */
+void x265amd_sad_x3(int part, const pixel_t_* fenc, const pixel_t_* fref0, const pixel_t_* fref1, const pixel_t_* fref2, intptr_t frefstride, int32_t* res);
+void x265amd_sad_x4(int part, const pixel_t_* fenc, const pixel_t_* fref0, const pixel_t_* fref1, const pixel_t_* fref2, const pixel_t_* fref3, intptr_t frefstride, int32_t* res);
+/* pixel_sse_t / pixel_sse_ss_t / pixel_ssd_s_t (primitives.h:135-137); sse_t widened to 64 bits in the C ABI */
+uint64_t x265amd_sse_pp(int cu, const pixel_t_* fenc, intptr_t fencstride, const pixel_t_* fref, intptr_t frefstride);
+uint64_t x265amd_sse_ss(int cu, const int16_t* fenc, intptr_t fencstride, const int16_t* fref, intptr_t frefstride);
+uint64_t x265amd_ssd_s(int cu, const int16_t* a, intptr_t stride);
+uint64_t x265amd_var(int cu, const pixel_t_* pix, intptr_t stride);                       /* var_t, primitives.h:173 */
+
+/* pixel_sub_ps_t / pixel_add_ps_t / pixelavg_pp_t / addAvg_t (primitives.h:189-192) */
+void x265amd_sub_ps(int cu, int16_t* dst, intptr_t dstride, const pixel_t_* src0, const pixel_t_* src1, intptr_t sstride0, intptr_t sstride1);
+void x265amd_add_ps(int cu, pixel_t_* dst, intptr_t dstride, const pixel_t_* src0, const int16_t* src1, intptr_t sstride0, intptr_t sstride1);
+void x265amd_pixelavg_pp(int part, pixel_t_* dst, intptr_t dstride, const pixel_t_* src0, intptr_t sstride0, const pixel_t_* src1, intptr_t sstride1);
+void x265amd_addAvg(int part, const int16_t* src0, const int16_t* src1, pixel_t_* dst, intptr_t src0Stride, intptr_t src1Stride, intptr_t dstStride);
+void x265amd_chroma_addAvg(int csp, int part, const int16_t* src0, const int16_t* src1, pixel_t_* dst, intptr_t src0Stride, intptr_t src1Stride, intptr_t dstStride);
+/* weightp_pp_t / weightp_sp_t (primitives.h:164-165) */
+void x265amd_weight_pp(const pixel_t_* src, pixel_t_* dst, intptr_t stride, int width, int height, int w0, int round, int shift, int offset);
+void x265amd_weight_sp(const int16_t* src, pixel_t_* dst, intptr_t srcStride, intptr_t dstStride, int width, int height, int w0, int round, int shift, int offset);
+/* scale2D_t / scale1D_t / transpose_t (primitives.h:158,166-167) */
+void x265amd_scale2D_64to32(pixel_t_* dst, const pixel_t_* src, intptr_t stride);
+void x265amd_scale1D_128to64(pixel_t_* dst, const pixel_t_* src);
+void x265amd_transpose(int cu, pixel_t_* dst, const pixel_t_* src, intptr_t stride);
+/* cpy2Dto1D_* / cpy1Dto2D_* / copy_cnt_t / count_nonzero_t (primitives.h:147-151,163) */
+void x265amd_cpy2Dto1D_shl(int cu, int16_t* dst, const int16_t* src, intptr_t srcStride, int shift);
+void x265amd_cpy2Dto1D_shr(int cu, int16_t* dst, const int16_t* src, intptr_t srcStride, int shift);
+void x265amd_cpy1Dto2D_shl(int cu, int16_t* dst, const int16_t* src, intptr_t dstStride, int shift);
+void x265amd_cpy1Dto2D_shr(int cu, int16_t* dst, const int16_t* src, intptr_t dstStride, int shift);
+uint32_t x265amd_copy_cnt(int cu, int16_t* coeff, const int16_t* residual, intptr_t resiStride);
+int x265amd_count_nonzero(int cu, const int16_t* quantCoeff);
+
+/* dct_t / idct_t (primitives.h:153-154) -- cu[cu].dct/idct, dst4x4, idst4x4 */
+void x265amd_dct(int cu, const int16_t* src, int16_t* dst, intptr_t srcStride);
+void x265amd_idct(int cu, const int16_t* src, int16_t* dst, intptr_t dstStride);
+void x265amd_dst4x4(const int16_t* src, int16_t* dst, intptr_t srcStride);
+void x265amd_idst4x4(const int16_t* src, int16_t* dst, intptr_t dstStride);
+/* quant_t / nquant_t / dequant_normal_t / dequant_scaling_t (primitives.h:159-162) */
+uint32_t x265amd_quant(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef, int qBits, int add, int numCoeff);
+uint32_t x265amd_nquant(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff);
+void x265amd_dequant_normal(const int16_t* quantCoef, int16_t* coef, int num, int scale, int shift);
+void x265amd_dequant_scaling(const int16_t* src, const int32_t* dequantCoef, int16_t* dst, int num, int mcqp_miper, int shift);
+
+/* intra_pred_t / intra_filter_t / intra_allangs_t (primitives.h:143-145) */
+void x265amd_intra_pred(int cu, int mode, pixel_t_* dst, intptr_t dstStride, const pixel_t_* srcPix, int bFilter);
+void x265amd_intra_filter(int cu, const pixel_t_* references, pixel_t_* filtered);
+void x265amd_intra_allangs(int cu, pixel_t_* dst, pixel_t_* refPix, pixel_t_* filtPix, int bLuma);
+
+/* filter_pp_t / filter_hps_t / filter_ps_t / filter_sp_t / filter_ss_t / filter_hv_pp_t / filter_p2s_t
+ * (primitives.h:176-182) */
+void x265amd_luma_hpp(int part, const pixel_t_* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_luma_hps(int part, const pixel_t_* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride, int coeffIdx, int isRowExt);
+void x265amd_luma_vpp(int part, const pixel_t_* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_luma_vps(int part, const pixel_t_* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_luma_vsp(int part, const int16_t* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_luma_vss(int part, const int16_t* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_luma_hvpp(int part, const pixel_t_* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int idxX, int idxY);
+void x265amd_luma_p2s(int part, const pixel_t_* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride);
+void x265amd_chroma_hpp(int csp, int part, const pixel_t_* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_chroma_hps(int csp, int part, const pixel_t_* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride, int coeffIdx, int isRowExt);
+void x265amd_chroma_vpp(int csp, int part, const pixel_t_* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_chroma_vps(int csp, int part, const pixel_t_* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_chroma_vsp(int csp, int part, const int16_t* src, intptr_t srcStride, pixel_t_* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_chroma_vss(int csp, int part, const int16_t* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride, int coeffIdx);
+void x265amd_chroma_p2s(int csp, int part, const pixel_t_* src, intptr_t srcStride, int16_t* dst, intptr_t dstStride);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* Layer 2: batched job lists (DEVICE memory).                                                             */
+/* ------------------------------------------------------------------------------------------------------- */
+enum x265amd_op
+{
+    /* family 0: distortion.  a=fenc b=fref (device addresses), sa/sb strides in elements, d -> uint64 result
+     * (sad_x3/x4: d -> int32[4]; the 3/4 candidate addresses are b, c, e[0], e[1]) */
+    X265AMD_OP_SAD = 0, X265AMD_OP_SAD_X3, X265AMD_OP_SAD_X4, X265AMD_OP_SATD, X265AMD_OP_SA8D, X265AMD_OP_SSE_PP,
+    X265AMD_OP_SSE_SS, X265AMD_OP_SSD_S, X265AMD_OP_PSY_COST_PP, X265AMD_OP_VAR, X265AMD_OP_CHROMA_SATD, X265AMD_OP_CHROMA_SA8D,
+    /* family 1: pixel/residual block ops */
+    X265AMD_OP_SUB_PS = 32, X265AMD_OP_ADD_PS, X265AMD_OP_PIXELAVG_PP, X265AMD_OP_ADDAVG, X265AMD_OP_WEIGHT_PP, X265AMD_OP_WEIGHT_SP,
+    X265AMD_OP_SCALE2D_64TO32, X265AMD_OP_SCALE1D_128TO64, X265AMD_OP_TRANSPOSE, X265AMD_OP_CPY2DTO1D_SHL, X265AMD_OP_CPY2DTO1D_SHR,
+    X265AMD_OP_CPY1DTO2D_SHL, X265AMD_OP_CPY1DTO2D_SHR, X265AMD_OP_COPY_CNT, X265AMD_OP_COUNT_NONZERO,
+    /* family 2: transforms + quantisation */
+    X265AMD_OP_DCT = 64, X265AMD_OP_IDCT, X265AMD_OP_DST4, X265AMD_OP_IDST4, X265AMD_OP_QUANT, X265AMD_OP_NQUANT,
+    X265AMD_OP_DEQUANT_NORMAL, X265AMD_OP_DEQUANT_SCALING,
+    /* family 3: intra prediction */
+    X265AMD_OP_INTRA_PRED = 96, X265AMD_OP_INTRA_FILTER, X265AMD_OP_INTRA_ALLANGS,
+    /* family 4: interpolation.  p[0]=taps (8 luma / 4 chroma) p[1]=width p[2]=height p[3]=coeffIdx(X) p[4]=isRowExt / coeffIdxY */
+    X265AMD_OP_IP_HPP = 128, X265AMD_OP_IP_HPS, X265AMD_OP_IP_VPP, X265AMD_OP_IP_VPS, X265AMD_OP_IP_VSP, X265AMD_OP_IP_VSS,
+    X265AMD_OP_IP_HVPP, X265AMD_OP_IP_P2S
+};
+
+typedef struct x265amd_job
+{
+    int32_t op;             /* enum x265amd_op */
+    int32_t size;           /* part (LumaPU) or cu (LumaCU) index, op dependent */
+    int32_t p[6];           /* op-specific integer arguments, in the order of the slot's typedef */
+    uint64_t a, b, c, d;    /* device addresses of the operands (a,b,c inputs; d output) */
+    uint64_t e[2];          /* extra operands (sad_x3/x4 candidates, quant deltaU ...) */
+    int32_t sa, sb, sc, sd; /* strides of a,b,c,d in elements */
+} x265amd_job;
+
+/* Runs jobs[0..n) (device array) on `stream` (a hipStream_t, may be NULL).  All jobs of one call must belong to
+ * the same family (op / 32).  Asynchronous: results are valid after the stream is synchronised. */
+int x265amd_run_jobs(void* stream, const x265amd_job* d_jobs, int n, int family);
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* Layer 3: fused frame-level kernels: see x265amd_frame.h                                                  */
+/* ------------------------------------------------------------------------------------------------------- */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265AMD_H */

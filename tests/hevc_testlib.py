@@ -92,6 +92,15 @@ def load_ref(depth):
     return PrimLib(ref_path(depth), "ref_", depth)
 
 
+def hip_path(depth):
+    return os.path.join(PKG_DIR, "lib", "libx265amd_main.so" if depth == 8 else "libx265amd_main10.so")
+
+
+def load_hip(depth):
+    """the product library; never falls back to anything else"""
+    return PrimLib(hip_path(depth), "x265amd_", depth)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # buffers
 # ----------------------------------------------------------------------------------------------------------

@@ -1,0 +1,29 @@
+#!/usr/bin/env bash
+# Builds libx265amd_main.so (8-bit pixels) and libx265amd_main10.so (10-bit pixels) for gfx950, in-tree.
+# hipcc cross-compiles without a GPU.  Usage: build.sh [-j]   (rebuilds only when sources are newer)
+set -euo pipefail
+HERE=$(cd "$(dirname "$0")" && pwd)
+SRC=$HERE/csrc
+OUT=$HERE/lib
+mkdir -p "$OUT"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -I$HERE/../include"
+SRCS=$(ls "$SRC"/*.hip)
+build_one() {
+    local depth=$1 name=$2
+    local lib=$OUT/$name
+    local newest
+    newest=$(ls -t "$SRC"/* "$HERE"/../include/*.h | head -1)
+    if [ -f "$lib" ] && [ "$lib" -nt "$newest" ]; then return 0; fi
+    local objs=""
+    for f in $SRCS; do
+        local o=$OUT/$(basename "$f" .hip).$depth.o
+        $HIPCC $FLAGS -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
+        objs="$objs $o"
+    done
+    wait
+    $HIPCC --offload-arch=gfx950 -shared -o "$lib" $objs
+}
+build_one 8 libx265amd_main.so
+build_one 10 libx265amd_main10.so
+echo "built: $(ls "$OUT"/*.so | tr '\n' ' ')"

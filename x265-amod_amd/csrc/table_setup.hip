@@ -1,0 +1,161 @@
+/* x265amd_setup_primitives(): installs the HIP-backed entries into a table laid out like the reference's
+ * `EncoderPrimitives` -- the counterpart of setupAssemblyPrimitives(EncoderPrimitives&, int)
+ * (reference: source/common/primitives.h:474, called from x265_setup_primitives(), primitives.cpp:248-285).
+ *
+ * The reference's slots carry no size argument (one function per block size), so each installed entry is a
+ * thunk instantiated per size index that forwards to the layer-1 entry point with the exact typedef signature
+ * of the slot (primitives.h:133-236).  Slots that are not on the north-star path are left untouched.
+ */
+#include <utility>
+#include "x265amd_host.h"
+#include "../host/primitive_table.h"
+
+using namespace x265amd;
+typedef x265amd_pixel pixel;
+enum { CSP420 = 1 };
+
+#if X265AMD_DEPTH > 8
+typedef uint64_t sse_t;     /* reference: common/common.h:142-146 */
+#else
+typedef uint32_t sse_t;
+#endif
+
+namespace {
+
+template<int I> struct Thunk
+{
+    /* pu[I] */
+    static int sad(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_sad(I, a, sa, b, sb); }
+    static void sad_x3(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res) { x265amd_sad_x3(I, f, r0, r1, r2, rs, res); }
+    static void sad_x4(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res) { x265amd_sad_x4(I, f, r0, r1, r2, r3, rs, res); }
+    static int satd(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_satd(I, a, sa, b, sb); }
+    static void luma_hpp(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c) { x265amd_luma_hpp(I, s, ss, d, ds, c); }
+    static void luma_hps(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c, int e) { x265amd_luma_hps(I, s, ss, d, ds, c, e); }
+    static void luma_vpp(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c) { x265amd_luma_vpp(I, s, ss, d, ds, c); }
+    static void luma_vps(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c) { x265amd_luma_vps(I, s, ss, d, ds, c); }
+    static void luma_vsp(const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int c) { x265amd_luma_vsp(I, s, ss, d, ds, c); }
+    static void luma_vss(const int16_t* s, intptr_t ss, int16_t* d, intptr_t ds, int c) { x265amd_luma_vss(I, s, ss, d, ds, c); }
+    static void luma_hvpp(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int x, int y) { x265amd_luma_hvpp(I, s, ss, d, ds, x, y); }
+    static void pixelavg_pp(pixel* d, intptr_t ds, const pixel* s0, intptr_t ss0, const pixel* s1, intptr_t ss1, int) { x265amd_pixelavg_pp(I, d, ds, s0, ss0, s1, ss1); }
+    static void addAvg(const int16_t* s0, const int16_t* s1, pixel* d, intptr_t ss0, intptr_t ss1, intptr_t ds) { x265amd_addAvg(I, s0, s1, d, ss0, ss1, ds); }
+    static void p2s(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds) { x265amd_luma_p2s(I, s, ss, d, ds); }
+    /* chroma[420].pu[I] */
+    static int c_satd(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_chroma_satd(CSP420, I, a, sa, b, sb); }
+    static void c_hpp(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c) { x265amd_chroma_hpp(CSP420, I, s, ss, d, ds, c); }
+    static void c_hps(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c, int e) { x265amd_chroma_hps(CSP420, I, s, ss, d, ds, c, e); }
+    static void c_vpp(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c) { x265amd_chroma_vpp(CSP420, I, s, ss, d, ds, c); }
+    static void c_vps(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c) { x265amd_chroma_vps(CSP420, I, s, ss, d, ds, c); }
+    static void c_vsp(const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int c) { x265amd_chroma_vsp(CSP420, I, s, ss, d, ds, c); }
+    static void c_vss(const int16_t* s, intptr_t ss, int16_t* d, intptr_t ds, int c) { x265amd_chroma_vss(CSP420, I, s, ss, d, ds, c); }
+    static void c_addAvg(const int16_t* s0, const int16_t* s1, pixel* d, intptr_t ss0, intptr_t ss1, intptr_t ds) { x265amd_chroma_addAvg(CSP420, I, s0, s1, d, ss0, ss1, ds); }
+    static void c_p2s(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds) { x265amd_chroma_p2s(CSP420, I, s, ss, d, ds); }
+    /* cu[I] */
+    static void dct(const int16_t* s, int16_t* d, intptr_t st) { x265amd_dct(I, s, d, st); }
+    static void idct(const int16_t* s, int16_t* d, intptr_t st) { x265amd_idct(I, s, d, st); }
+    static void sub_ps(int16_t* d, intptr_t ds, const pixel* s0, const pixel* s1, intptr_t ss0, intptr_t ss1) { x265amd_sub_ps(I, d, ds, s0, s1, ss0, ss1); }
+    static void add_ps(pixel* d, intptr_t ds, const pixel* s0, const int16_t* s1, intptr_t ss0, intptr_t ss1) { x265amd_add_ps(I, d, ds, s0, s1, ss0, ss1); }
+    static uint32_t copy_cnt(int16_t* c, const int16_t* r, intptr_t rs) { return x265amd_copy_cnt(I, c, r, rs); }
+    static int count_nonzero(const int16_t* q) { return x265amd_count_nonzero(I, q); }
+    static void cpy2Dto1D_shl(int16_t* d, const int16_t* s, intptr_t ss, int sh) { x265amd_cpy2Dto1D_shl(I, d, s, ss, sh); }
+    static void cpy2Dto1D_shr(int16_t* d, const int16_t* s, intptr_t ss, int sh) { x265amd_cpy2Dto1D_shr(I, d, s, ss, sh); }
+    static void cpy1Dto2D_shl(int16_t* d, const int16_t* s, intptr_t ds, int sh) { x265amd_cpy1Dto2D_shl(I, d, s, ds, sh); }
+    static void cpy1Dto2D_shr(int16_t* d, const int16_t* s, intptr_t ds, int sh) { x265amd_cpy1Dto2D_shr(I, d, s, ds, sh); }
+    static uint64_t var(const pixel* p, intptr_t st) { return x265amd_var(I, p, st); }
+    static sse_t sse_pp(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return (sse_t)x265amd_sse_pp(I, a, sa, b, sb); }
+    static sse_t sse_ss(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb) { return (sse_t)x265amd_sse_ss(I, a, sa, b, sb); }
+    static sse_t ssd_s(const int16_t* a, intptr_t sa) { return (sse_t)x265amd_ssd_s(I, a, sa); }
+    static int psy_cost_pp(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_psy_cost_pp(I, a, sa, b, sb); }
+    static int sa8d(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_sa8d(I, a, sa, b, sb); }
+    static void transpose(pixel* d, const pixel* s, intptr_t st) { x265amd_transpose(I, d, s, st); }
+    static void allangs(pixel* d, pixel* r, pixel* f, int l) { x265amd_intra_allangs(I, d, r, f, l); }
+    static void intra_filter(const pixel* r, pixel* f) { x265amd_intra_filter(I, r, f); }
+    static void intra_pred(pixel* d, intptr_t ds, const pixel* s, int mode, int bf) { x265amd_intra_pred(I, mode, d, ds, s, bf); }
+    /* chroma[420].cu[I] */
+    static int c_sa8d(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_chroma_sa8d(CSP420, I, a, sa, b, sb); }
+};
+
+/* loose members */
+static void t_dst4x4(const int16_t* s, int16_t* d, intptr_t st) { x265amd_dst4x4(s, d, st); }
+static void t_idst4x4(const int16_t* s, int16_t* d, intptr_t st) { x265amd_idst4x4(s, d, st); }
+static void t_scale1D(pixel* d, const pixel* s) { x265amd_scale1D_128to64(d, s); }
+
+struct Installer
+{
+    generic_fn* t;
+    int n = 0;
+    template<class F> void set(int slot, F f) { t[slot] = reinterpret_cast<generic_fn>(f); n++; }
+
+    template<int I> void pu()
+    {
+        typedef Thunk<I> T;
+        set(slotPU(I, PU_sad), &T::sad); set(slotPU(I, PU_sad_x3), &T::sad_x3); set(slotPU(I, PU_sad_x4), &T::sad_x4);
+        set(slotPU(I, PU_satd), &T::satd);
+        set(slotPU(I, PU_luma_hpp), &T::luma_hpp); set(slotPU(I, PU_luma_hps), &T::luma_hps); set(slotPU(I, PU_luma_vpp), &T::luma_vpp);
+        set(slotPU(I, PU_luma_vps), &T::luma_vps); set(slotPU(I, PU_luma_vsp), &T::luma_vsp); set(slotPU(I, PU_luma_vss), &T::luma_vss);
+        set(slotPU(I, PU_luma_hvpp), &T::luma_hvpp);
+        for (int al = 0; al < 2; al++)
+        {
+            set(slotPU(I, PU_pixelavg_pp + al), &T::pixelavg_pp); set(slotPU(I, PU_addAvg + al), &T::addAvg);
+            set(slotPU(I, PU_convert_p2s + al), &T::p2s);
+            set(slotChromaPU(CSP420, I, CPU_addAvg + al), &T::c_addAvg);
+            if (I != 0) set(slotChromaPU(CSP420, I, CPU_p2s + al), &T::c_p2s);
+        }
+        if (I != 0)     /* no 2x2 chroma filters (reference: ipfilter.cpp:418-466) */
+        {
+            set(slotChromaPU(CSP420, I, CPU_filter_hpp), &T::c_hpp); set(slotChromaPU(CSP420, I, CPU_filter_hps), &T::c_hps);
+            set(slotChromaPU(CSP420, I, CPU_filter_vpp), &T::c_vpp); set(slotChromaPU(CSP420, I, CPU_filter_vps), &T::c_vps);
+            set(slotChromaPU(CSP420, I, CPU_filter_vsp), &T::c_vsp); set(slotChromaPU(CSP420, I, CPU_filter_vss), &T::c_vss);
+        }
+        if (x265amd_chroma_satd_defined(I))
+            set(slotChromaPU(CSP420, I, CPU_satd), &T::c_satd);
+    }
+    template<int I> void cu()
+    {
+        typedef Thunk<I> T;
+        if constexpr (I < 4)      /* TU sizes 4..32 */
+        {
+            set(slotCU(I, CU_dct), &T::dct); set(slotCU(I, CU_idct), &T::idct); set(slotCU(I, CU_standard_dct), &T::dct);
+            set(slotCU(I, CU_copy_cnt), &T::copy_cnt); set(slotCU(I, CU_count_nonzero), &T::count_nonzero);
+            set(slotCU(I, CU_cpy2Dto1D_shl), &T::cpy2Dto1D_shl); set(slotCU(I, CU_cpy2Dto1D_shr), &T::cpy2Dto1D_shr);
+            set(slotCU(I, CU_cpy1Dto2D_shl), &T::cpy1Dto2D_shl); set(slotCU(I, CU_cpy1Dto2D_shl + 1), &T::cpy1Dto2D_shl);
+            set(slotCU(I, CU_cpy1Dto2D_shr), &T::cpy1Dto2D_shr);
+            set(slotCU(I, CU_intra_pred_allangs), &T::allangs); set(slotCU(I, CU_intra_filter), &T::intra_filter);
+            for (int m = 0; m < INTRA_MODES; m++) set(slotCU(I, CU_intra_pred + m), &T::intra_pred);
+        }
+        set(slotCU(I, CU_sub_ps), &T::sub_ps); set(slotCU(I, CU_add_ps), &T::add_ps); set(slotCU(I, CU_add_ps + 1), &T::add_ps);
+        set(slotCU(I, CU_var), &T::var); set(slotCU(I, CU_sse_pp), &T::sse_pp); set(slotCU(I, CU_sse_ss), &T::sse_ss);
+        set(slotCU(I, CU_ssd_s), &T::ssd_s); set(slotCU(I, CU_ssd_s + 1), &T::ssd_s);
+        set(slotCU(I, CU_psy_cost_pp), &T::psy_cost_pp); set(slotCU(I, CU_sa8d), &T::sa8d); set(slotCU(I, CU_transpose), &T::transpose);
+        if constexpr (I >= 1) set(slotChromaCU(CSP420, I, CCU_sa8d), &T::c_sa8d);
+    }
+    static bool x265amd_chroma_satd_defined(int part)
+    {
+        static const uint8_t w[25] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 12, 16, 4, 32, 24, 32, 8, 64, 48, 64, 16 };
+        static const uint8_t h[25] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 12, 16, 4, 16, 24, 32, 8, 32, 48, 64, 16, 64 };
+        return (((w[part] >> 1) | (h[part] >> 1)) & 3) == 0;
+    }
+    template<int... I> void allPU(std::integer_sequence<int, I...>) { (pu<I>(), ...); }
+    template<int... I> void allCU(std::integer_sequence<int, I...>) { (cu<I>(), ...); }
+};
+
+} // namespace
+
+extern "C" size_t x265amd_primitives_table_bytes(void) { return (size_t)TOTAL_SLOTS * sizeof(generic_fn); }
+
+extern "C" int x265amd_setup_primitives(void* table, size_t table_bytes)
+{
+    if (!table || table_bytes != x265amd_primitives_table_bytes())
+        return xa_fail(X265AMD_EINVAL, "x265amd_setup_primitives: table size does not match the EncoderPrimitives layout this library mirrors");
+    if (x265amd_device_count() < 1)
+        return xa_fail(X265AMD_EHIP, "x265amd_setup_primitives: no HIP device visible (there is no CPU fallback)");
+    Installer ins{ (generic_fn*)table };
+    ins.allPU(std::make_integer_sequence<int, NUM_PU_SIZES>());
+    ins.allCU(std::make_integer_sequence<int, NUM_CU_SIZES>());
+    ins.set(slotMisc(M_dst4x4), &t_dst4x4); ins.set(slotMisc(M_idst4x4), &t_idst4x4);
+    ins.set(slotMisc(M_quant), &x265amd_quant); ins.set(slotMisc(M_nquant), &x265amd_nquant);
+    ins.set(slotMisc(M_dequant_scaling), &x265amd_dequant_scaling); ins.set(slotMisc(M_dequant_normal), &x265amd_dequant_normal);
+    ins.set(slotMisc(M_scale1D_128to64), &t_scale1D); ins.set(slotMisc(M_scale1D_128to64 + 1), &t_scale1D);
+    ins.set(slotMisc(M_scale2D_64to32), &x265amd_scale2D_64to32);
+    ins.set(slotMisc(M_weight_sp), &x265amd_weight_sp); ins.set(slotMisc(M_weight_pp), &x265amd_weight_pp);
+    return ins.n;
+}

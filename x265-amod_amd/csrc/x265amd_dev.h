@@ -1,0 +1,239 @@
+/* Device-side building blocks shared by every kernel of libx265amd (gfx950 only, wave64).
+ *
+ * Conventions
+ *   - one 64-lane wavefront cooperates on one block-level operation; `lane` is 0..63
+ *   - all arithmetic is the integer arithmetic of the reference's C primitives (bit-exact results);
+ *     the citations name the reference function whose results each routine reproduces
+ *     (paths relative to /root/reference/source)
+ */
+#ifndef X265AMD_DEV_H
+#define X265AMD_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/x265amd.h"
+
+typedef x265amd_pixel pixel;
+
+#define XA_DEPTH X265AMD_DEPTH
+#define XA_PIXEL_MAX ((1 << XA_DEPTH) - 1)
+#define XA_FENC_STRIDE 64
+#define XA_IF_INTERNAL_PREC 14      /* common/constants.h:66-70 */
+#define XA_IF_FILTER_PREC 6
+#define XA_IF_INTERNAL_OFFS (1 << (XA_IF_INTERNAL_PREC - 1))
+#define XA_WAVE 64
+
+#define XA_DEV __device__ __forceinline__
+
+/* ---- constant tables (generated at compile time from their defining rules; validated against the reference's
+ *      arrays in common/constants.cpp:250-344 through the oracle, tests/test_oracle_vs_ref.py::test_tables) ---- */
+struct XaTables
+{
+    int16_t dct[4][32 * 32];    /* dct[log2N-2][k*N+n]: HEVC core transform matrices (g_t4..g_t32) */
+    int16_t dst4[16];           /* DST-VII 4x4 */
+    int16_t lumaFilter[4][8];   /* g_lumaFilter */
+    int16_t chromaFilter[8][4]; /* g_chromaFilter */
+    int8_t angle[17];           /* intra angle table (intrapred.cpp:131) */
+    int16_t invAngle[8];        /* intrapred.cpp:132 */
+    uint8_t puW[25], puH[25];   /* LumaPU geometry (primitives.h:41-55) */
+};
+
+constexpr int xa_dct_coef32(int k, int n)
+{
+    constexpr int mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                              61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+    if (k == 0) return 64;
+    int a = ((2 * n + 1) * k) & 127;
+    int sgn = 1;
+    if (a > 64) a = 128 - a;
+    if (a > 32) { a = 64 - a; sgn = -1; }
+    return sgn * mag[a];
+}
+
+constexpr XaTables xa_make_tables()
+{
+    XaTables t = {};
+    for (int l = 0; l < 4; l++)
+    {
+        int N = 4 << l, step = 32 / N;
+        for (int k = 0; k < N; k++)
+            for (int n = 0; n < N; n++)
+                t.dct[l][k * N + n] = (int16_t)xa_dct_coef32(k * step, n);
+    }
+    constexpr int dst[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+    for (int i = 0; i < 16; i++) t.dst4[i] = (int16_t)dst[i];
+    constexpr int lf[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+    constexpr int cf[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+                               { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) t.lumaFilter[i][j] = (int16_t)lf[i][j];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) t.chromaFilter[i][j] = (int16_t)cf[i][j];
+    constexpr int ang[17] = { -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+    constexpr int inv[8] = { 4096, 1638, 910, 630, 482, 390, 315, 256 };
+    for (int i = 0; i < 17; i++) t.angle[i] = (int8_t)ang[i];
+    for (int i = 0; i < 8; i++) t.invAngle[i] = (int16_t)inv[i];
+    constexpr int pw[25] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 12, 16, 4, 32, 24, 32, 8, 64, 48, 64, 16 };
+    constexpr int ph[25] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 12, 16, 4, 16, 24, 32, 8, 32, 48, 64, 16, 64 };
+    for (int i = 0; i < 25; i++) { t.puW[i] = (uint8_t)pw[i]; t.puH[i] = (uint8_t)ph[i]; }
+    return t;
+}
+
+__device__ const XaTables xa_tbl = xa_make_tables();
+static const XaTables xa_tbl_host = xa_make_tables();
+
+/* constants.cpp:560-567 (g_intraFilterFlags[mode] & size) from its defining rule */
+XA_DEV int xa_intra_filter_flags(int mode)
+{
+    if (mode == 1) return 0;
+    if (mode == 0) return 8 | 16 | 32;
+    int d1 = abs(mode - 26), d2 = abs(mode - 10);
+    int d = d1 < d2 ? d1 : d2;
+    return (d > 7 ? 8 : 0) | (d > 1 ? 16 : 0) | (d > 0 ? 32 : 0);
+}
+
+/* ---- wave helpers ---- */
+XA_DEV int xa_lane() { return threadIdx.x & 63; }
+
+/* orders LDS traffic of one wavefront: lanes of a wave run in lockstep and the DS unit is in-order per wave, so a
+ * compiler-level fence is all that is needed between a wave's own writes and its cross-lane reads */
+XA_DEV void xa_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template<class T> XA_DEV T xa_wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+XA_DEV int xa_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+XA_DEV pixel xa_clip_pixel(int v) { return (pixel)xa_clip3(0, XA_PIXEL_MAX, v); }
+
+/* ---- Hadamard tiles (pixel.cpp:189-340); results are the plain integer sums the reference's SWAR code yields ---- */
+template<bool HASB>
+XA_DEV int xa_had4_abs(const pixel* a, int sa, const pixel* b, int sb)
+{
+    int t[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        int d0 = a[y * sa + 0], d1 = a[y * sa + 1], d2 = a[y * sa + 2], d3 = a[y * sa + 3];
+        if (HASB) { d0 -= b[y * sb + 0]; d1 -= b[y * sb + 1]; d2 -= b[y * sb + 2]; d3 -= b[y * sb + 3]; }
+        int s01 = d0 + d1, e01 = d0 - d1, s23 = d2 + d3, e23 = d2 - d3;
+        t[y][0] = s01 + s23; t[y][1] = s01 - s23; t[y][2] = e01 + e23; t[y][3] = e01 - e23;
+    }
+    int sum = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+    {
+        int s01 = t[0][x] + t[1][x], e01 = t[0][x] - t[1][x], s23 = t[2][x] + t[3][x], e23 = t[2][x] - t[3][x];
+        sum += abs(s01 + s23) + abs(s01 - s23) + abs(e01 + e23) + abs(e01 - e23);
+    }
+    return sum;
+}
+
+template<bool HASB>
+XA_DEV int xa_had8_abs(const pixel* a, int sa, const pixel* b, int sb)
+{
+    int m[8][8];
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+    {
+        int r[8];
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+            r[x] = HASB ? (int)a[y * sa + x] - (int)b[y * sb + x] : (int)a[y * sa + x];
+#pragma unroll
+        for (int span = 1; span < 8; span <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i += span * 2)
+#pragma unroll
+                for (int j = i; j < i + span; j++)
+                {
+                    int u = r[j], v = r[j + span];
+                    r[j] = u + v; r[j + span] = u - v;
+                }
+#pragma unroll
+        for (int x = 0; x < 8; x++) m[y][x] = r[x];
+    }
+    int sum = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+    {
+        int r[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) r[y] = m[y][x];
+#pragma unroll
+        for (int span = 1; span < 8; span <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i += span * 2)
+#pragma unroll
+                for (int j = i; j < i + span; j++)
+                {
+                    int u = r[j], v = r[j + span];
+                    r[j] = u + v; r[j + span] = u - v;
+                }
+#pragma unroll
+        for (int y = 0; y < 8; y++) sum += abs(r[y]);
+    }
+    return sum;
+}
+
+/* SAD of a w x h block, lanes strided over samples (pixel.cpp:40-54) */
+XA_DEV int xa_wave_sad(const pixel* a, int sa, const pixel* b, int sb, int w, int h, int lane)
+{
+    int sum = 0, n = w * h;
+    for (int i = lane; i < n; i += XA_WAVE)
+    {
+        int y = i / w, x = i - y * w;
+        sum += abs((int)a[y * sa + x] - (int)b[y * sb + x]);
+    }
+    return xa_wave_sum(sum);
+}
+
+/* SATD of a w x h block: one lane per 4x4 tile, halved per tile (pixel.cpp:210-297) */
+XA_DEV int xa_wave_satd(const pixel* a, int sa, const pixel* b, int sb, int w, int h, int lane)
+{
+    int tw = w >> 2, nt = tw * (h >> 2), sum = 0;
+    for (int t = lane; t < nt; t += XA_WAVE)
+    {
+        int ty = t / tw, tx = t - ty * tw;
+        sum += xa_had4_abs<true>(a + 4 * ty * sa + 4 * tx, sa, b + 4 * ty * sb + 4 * tx, sb) >> 1;
+    }
+    return xa_wave_sum(sum);
+}
+
+/* SA8D of a size x size block (size 8..64): one lane per 8x8 tile; 16x16 groups are rounded once
+ * (pixel.cpp:342-384: sa8d_8x8, sa8d_16x16, sa8d16<w,h>).  size 4 -> satd_4x4 (pixel.cpp:1171). */
+XA_DEV int xa_wave_sa8d(const pixel* a, int sa, const pixel* b, int sb, int size, int lane)
+{
+    if (size == 4)
+    {
+        int v = lane == 0 ? xa_had4_abs<true>(a, sa, b, sb) >> 1 : 0;
+        return __shfl(v, 0, 64);
+    }
+    if (size == 8)
+    {
+        int v = lane == 0 ? (xa_had8_abs<true>(a, sa, b, sb) + 2) >> 2 : 0;
+        return __shfl(v, 0, 64);
+    }
+    int g = size >> 4;              /* 16x16 groups per row */
+    int raw = 0;
+    if (lane < 4 * g * g)
+    {
+        int grp = lane >> 2, sub = lane & 3;
+        int gy = grp / g, gx = grp - gy * g;
+        int x = gx * 16 + (sub & 1) * 8, y = gy * 16 + (sub >> 1) * 8;
+        raw = xa_had8_abs<true>(a + y * sa + x, sa, b + y * sb + x, sb);
+    }
+    raw += __shfl_xor(raw, 1, 64);
+    raw += __shfl_xor(raw, 2, 64);
+    int v = (lane & 3) == 0 && lane < 4 * g * g ? (raw + 2) >> 2 : 0;
+    return xa_wave_sum(v);
+}
+
+#endif /* X265AMD_DEV_H */

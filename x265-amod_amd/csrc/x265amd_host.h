@@ -1,0 +1,31 @@
+/* Host-side plumbing shared by the C-ABI translation units of libx265amd. */
+#ifndef X265AMD_HOST_H
+#define X265AMD_HOST_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../include/x265amd.h"
+
+/* records the message for x265amd_last_error() and returns `code` */
+int xa_fail(int code, const char* msg);
+
+/* The reference's primitive slots cannot report failure (primitives.h:133-236), so a HIP error inside a
+ * per-slot entry point is fatal: there is deliberately no CPU fallback. */
+#define XA_HIP_FATAL(expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            fprintf(stderr, "x265amd: fatal: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            abort();                                                                                         \
+        }                                                                                                    \
+    } while (0)
+
+#define XA_HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e_));                           \
+    } while (0)
+
+#endif
