@@ -1,0 +1,448 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle for motion estimation.
+ *
+ * Restates, from the algorithm, the results of the reference's
+ *   BitCost::setQP / CalculateLogs / mvcost      source/encoder/bitcost.cpp:30-109, bitcost.h:40-56
+ *   MotionEstimate::motionEstimate               source/encoder/motion.cpp:764-1594   (DIA, HEX and STAR searches)
+ *   MotionEstimate::StarPatternSearch            source/encoder/motion.cpp:387-629
+ *   MotionEstimate::subpelCompare (luma)         source/encoder/motion.cpp:1596-1623
+ * for a full-resolution (non-lowres) reference without chroma SATD (the subme <= 2 configuration of the medium
+ * preset; chroma SATD for subme > 2 is not restated yet).  Pinned against the reference's own MotionEstimate class
+ * through oracle/_ref/librefprims*.so (tests/test_me_oracle_vs_ref.py) and golden vectors (tests/golden/me_*.json).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef ORC_DEPTH
+#define ORC_DEPTH 8
+#endif
+#if ORC_DEPTH > 8
+typedef uint16_t pixel;
+#else
+typedef uint8_t pixel;
+#endif
+#define FENC_STRIDE 64
+
+int orc_sad(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int orc_satd(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+void orc_luma_hpp(int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx);
+void orc_luma_vpp(int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx);
+void orc_luma_hvpp(int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int ix, int iy);
+int orc_partition_from_sizes(int w, int h);
+int orc_pu_width(int part);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * lambda table and MV cost table
+ * ------------------------------------------------------------------------------------------------------- */
+/* constants.cpp:34-150: lambda = 2^(qp/6 - 2) * 2^(depth-8), tabulated to 4 decimals in the reference.  The
+ * tabulated (rounded) doubles are what BitCost multiplies by, so the table is reproduced as round(x*1e4)/1e4;
+ * tests/test_me_oracle_vs_ref.py::test_lambda_table compares all 70 entries with the reference's array. */
+double orc_lambda(int qp)
+{
+    double v = pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (ORC_DEPTH - 8));
+    return floor(v * 10000.0 + 0.5) / 10000.0;
+}
+
+#define BC_MAX_MV (1 << 15)
+static uint16_t* g_costs[82];
+
+/* bitcost.cpp:95-109 + :30-58.  Arithmetic exactly as the reference build performs it: the C `log` is the double
+ * function (the float argument is widened), the product with the float constant 2/ln(2) and the sum with 1.718f
+ * are evaluated in double and rounded to float once; the cost is double(bits) * lambda + 0.5 truncated. */
+const uint16_t* orc_mvcost_table(int qp)
+{
+    if (!g_costs[qp])
+    {
+        uint16_t* t = (uint16_t*)malloc((4 * BC_MAX_MV + 1) * sizeof(uint16_t));
+        t += 2 * BC_MAX_MV;
+        double lambda = orc_lambda(qp);
+        const double log2_2 = (double)(float)(2.0 / log(2.0));
+        for (int i = 0; i <= 2 * BC_MAX_MV; i++)
+        {
+            float bits = i ? (float)(log((double)(float)(i + 1)) * log2_2 + (double)1.718f) : 0.718f;
+            double c = (double)bits * lambda + 0.5;
+            if (c > (double)((1 << 15) - 1)) c = (double)((1 << 15) - 1);
+            t[i] = t[-i] = (uint16_t)c;
+        }
+        g_costs[qp] = t;
+    }
+    return g_costs[qp];
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * motion search
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct { int x, y; } MV;
+typedef int (*cmp_t)(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+
+typedef struct
+{
+    int part, width;
+    pixel fenc[64 * 64];        /* PU copied to a FENC_STRIDE cache: motion.cpp:219-247 */
+    const pixel* fref;          /* reference plane + blockOffset */
+    intptr_t stride;
+    const uint16_t* cost;       /* s_costs[qp] */
+    MV mvp;
+    MV mvmin, mvmax;
+} ME;
+
+static inline int mvcost(const ME* m, int x, int y) { return (uint16_t)(m->cost[x - m->mvp.x] + m->cost[y - m->mvp.y]); }
+static inline int sad_at(const ME* m, int x, int y) { return orc_sad(m->part, m->fenc, FENC_STRIDE, m->fref + x + y * m->stride, m->stride); }
+static inline int in_range(const ME* m, int x, int y) { return x >= m->mvmin.x && x <= m->mvmax.x && y >= m->mvmin.y && y <= m->mvmax.y; }
+static inline int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* motion.cpp:1596-1623 (luma part) */
+static int subpel_compare(const ME* m, MV q, cmp_t cmp)
+{
+    const pixel* fref = m->fref + (q.x >> 2) + (q.y >> 2) * m->stride;
+    int xf = q.x & 3, yf = q.y & 3;
+    if (!(xf | yf))
+        return cmp(m->part, m->fenc, FENC_STRIDE, fref, m->stride);
+    pixel buf[64 * 64];
+    if (!yf) orc_luma_hpp(m->part, fref, m->stride, buf, m->width, xf);
+    else if (!xf) orc_luma_vpp(m->part, fref, m->stride, buf, m->width, yf);
+    else orc_luma_hvpp(m->part, fref, m->stride, buf, m->width, xf, yf);
+    return cmp(m->part, m->fenc, FENC_STRIDE, buf, m->width);
+}
+
+#define COST_MV(mx, my) do { int c_ = sad_at(m, mx, my) + mvcost(m, (mx) * 4, (my) * 4); if (c_ < bcost) { bcost = c_; bmv.x = (mx); bmv.y = (my); } } while (0)
+#define COST_MV_PT_DIST(mx, my, point, dist) do { int c_ = sad_at(m, mx, my) + mvcost(m, (mx) * 4, (my) * 4); \
+        if (c_ < bcost) { bcost = c_; bmv.x = (mx); bmv.y = (my); bPointNr = (point); bDistance = (dist); } } while (0)
+
+/* motion.cpp:387-629.  The x4 form evaluates the same four points in the same order as four single calls. */
+static void star_pattern(const ME* m, MV* pbmv, int* pbcost, int* pPointNr, int* pDistance, int earlyExitIters, int merange)
+{
+    MV bmv = *pbmv, omv = *pbmv;
+    int bcost = *pbcost, bPointNr = *pPointNr, bDistance = *pDistance;
+    int saved = bcost, rounds = 0;
+    const MV mn = m->mvmin, mx = m->mvmax;
+    {
+        int dist = 1;
+        int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        int all = top >= mn.y && left >= mn.x && right <= mx.x && bottom <= mx.y;
+        if (all || top >= mn.y) COST_MV_PT_DIST(omv.x, top, 2, dist);
+        if (all || left >= mn.x) COST_MV_PT_DIST(left, omv.y, 4, dist);
+        if (all || right <= mx.x) COST_MV_PT_DIST(right, omv.y, 5, dist);
+        if (all || bottom <= mx.y) COST_MV_PT_DIST(omv.x, bottom, 7, dist);
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) goto done;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {
+        int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        int top2 = omv.y - (dist >> 1), bottom2 = omv.y + (dist >> 1), left2 = omv.x - (dist >> 1), right2 = omv.x + (dist >> 1);
+        saved = bcost;
+        if (top >= mn.y && left >= mn.x && right <= mx.x && bottom <= mx.y)
+        {
+            COST_MV_PT_DIST(omv.x, top, 2, dist);
+            COST_MV_PT_DIST(left2, top2, 1, dist >> 1);
+            COST_MV_PT_DIST(right2, top2, 3, dist >> 1);
+            COST_MV_PT_DIST(left, omv.y, 4, dist);
+            COST_MV_PT_DIST(right, omv.y, 5, dist);
+            COST_MV_PT_DIST(left2, bottom2, 6, dist >> 1);
+            COST_MV_PT_DIST(right2, bottom2, 8, dist >> 1);
+            COST_MV_PT_DIST(omv.x, bottom, 7, dist);
+        }
+        else
+        {
+            if (top >= mn.y) COST_MV_PT_DIST(omv.x, top, 2, dist);
+            if (top2 >= mn.y)
+            {
+                if (left2 >= mn.x) COST_MV_PT_DIST(left2, top2, 1, (dist >> 1));
+                if (right2 <= mx.x) COST_MV_PT_DIST(right2, top2, 3, (dist >> 1));
+            }
+            if (left >= mn.x) COST_MV_PT_DIST(left, omv.y, 4, dist);
+            if (right <= mx.x) COST_MV_PT_DIST(right, omv.y, 5, dist);
+            if (bottom2 <= mx.y)
+            {
+                if (left2 >= mn.x) COST_MV_PT_DIST(left2, bottom2, 6, (dist >> 1));
+                if (right2 <= mx.x) COST_MV_PT_DIST(right2, bottom2, 8, (dist >> 1));
+            }
+            if (bottom <= mx.y) COST_MV_PT_DIST(omv.x, bottom, 7, dist);
+        }
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) goto done;
+    }
+    for (int dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {
+        int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        saved = bcost;
+        int all = top >= mn.y && left >= mn.x && right <= mx.x && bottom <= mx.y;
+        if (all || top >= mn.y) COST_MV_PT_DIST(omv.x, top, 0, dist);
+        if (all || left >= mn.x) COST_MV_PT_DIST(left, omv.y, 0, dist);
+        if (all || right <= mx.x) COST_MV_PT_DIST(right, omv.y, 0, dist);
+        if (all || bottom <= mx.y) COST_MV_PT_DIST(omv.x, bottom, 0, dist);
+        for (int index = 1; index < 4; index++)
+        {
+            int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
+            int posXL = omv.x - ((dist >> 2) * index), posXR = omv.x + ((dist >> 2) * index);
+            if (all || posYT >= mn.y)
+            {
+                if (all || posXL >= mn.x) COST_MV_PT_DIST(posXL, posYT, 0, dist);
+                if (all || posXR <= mx.x) COST_MV_PT_DIST(posXR, posYT, 0, dist);
+            }
+            if (all || posYB <= mx.y)
+            {
+                if (all || posXL >= mn.x) COST_MV_PT_DIST(posXL, posYB, 0, dist);
+                if (all || posXR <= mx.x) COST_MV_PT_DIST(posXR, posYB, 0, dist);
+            }
+        }
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) goto done;
+    }
+done:
+    *pbmv = bmv; *pbcost = bcost; *pPointNr = bPointNr; *pDistance = bDistance;
+}
+
+static const MV k_hex2[8] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+static const uint8_t k_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static const MV k_square1[9] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+static const MV k_offsets[16] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                  { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+/* motion.cpp:48-58: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
+static const int k_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                      { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+
+enum { ME_DIA = 0, ME_HEX = 1, ME_UMH = 2, ME_STAR = 3, ME_SEA = 4, ME_FULL = 5 };
+
+/* Arguments: fencPlane/refPlane point at sample (0,0) of two planes of identical geometry (`stride`), the PU is
+ * at (puX,puY); mvmin/mvmax in full-pel, qmvp / mvc in quarter-pel -- exactly the arguments of
+ * MotionEstimate::motionEstimate() (motion.cpp:764-773) after setSourcePU() (motion.cpp:193-217).
+ * Returns the cost, writes the quarter-pel MV to outMv[2]; -1 for search methods not restated. */
+int orc_motion_estimate(const pixel* fencPlane, const pixel* refPlane, intptr_t stride, int puX, int puY, int w, int h,
+                        int method, int subme, int qp, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                        int numCandidates, const int32_t* mvc, int merange, int32_t* outMv)
+{
+    if (method != ME_DIA && method != ME_HEX && method != ME_STAR) return -1;
+    ME me, *m = &me;
+    me.part = orc_partition_from_sizes(w, h);
+    me.width = w;
+    for (int y = 0; y < h; y++)
+        memcpy(me.fenc + y * FENC_STRIDE, fencPlane + (puY + y) * stride + puX, w * sizeof(pixel));
+    me.fref = refPlane + puY * stride + puX;
+    me.stride = stride;
+    me.cost = orc_mvcost_table(qp);
+    me.mvp.x = qmvp[0]; me.mvp.y = qmvp[1];
+    me.mvmin.x = mvmin[0]; me.mvmin.y = mvmin[1]; me.mvmax.x = mvmax[0]; me.mvmax.y = mvmax[1];
+    const MV qmin = { mvmin[0] * 4, mvmin[1] * 4 }, qmax = { mvmax[0] * 4, mvmax[1] * 4 };
+
+    /* motion.cpp:797-846 */
+    MV pmv = { clipi(qmvp[0], qmin.x, qmax.x), clipi(qmvp[1], qmin.y, qmax.y) };
+    MV bestpre = pmv;
+    int bprecost = subpel_compare(m, pmv, orc_sad);
+    MV bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
+    int bcost = bprecost;
+    if ((pmv.x | pmv.y) & 3)
+        bcost = sad_at(m, bmv.x, bmv.y) + mvcost(m, bmv.x * 4, bmv.y * 4);
+    if (pmv.x | pmv.y)
+    {
+        int cost = sad_at(m, 0, 0) + mvcost(m, 0, 0);
+        if (cost < bcost)
+        {
+            bcost = cost;
+            bmv.x = 0;
+            bmv.y = 0 < mvmax[1] ? 0 : mvmax[1];    /* X265_MAX(X265_MIN(0, mvmax.y), mvmin.y) */
+            if (bmv.y < mvmin[1]) bmv.y = mvmin[1];
+        }
+    }
+    for (int i = 0; i < numCandidates; i++)
+    {
+        MV c = { clipi(mvc[2 * i], qmin.x, qmax.x), clipi(mvc[2 * i + 1], qmin.y, qmax.y) };
+        if ((c.x | c.y) && (c.x != pmv.x || c.y != pmv.y) && (c.x != bestpre.x || c.y != bestpre.y))
+        {
+            int cost = subpel_compare(m, c, orc_sad) + mvcost(m, c.x, c.y);
+            if (cost < bprecost) { bprecost = cost; bestpre = c; }
+        }
+    }
+    pmv.x = (pmv.x + 2) >> 2; pmv.y = (pmv.y + 2) >> 2;
+    const MV mn = me.mvmin, mx = me.mvmax;
+
+    switch (method)
+    {
+    case ME_DIA:    /* motion.cpp:855-877: the reference packs the direction into the low 4 bits of the cost; same order */
+    {
+        int i = merange;
+        do
+        {
+            int c0 = sad_at(m, bmv.x, bmv.y - 1) + mvcost(m, bmv.x * 4, (bmv.y - 1) * 4);
+            int c1 = sad_at(m, bmv.x, bmv.y + 1) + mvcost(m, bmv.x * 4, (bmv.y + 1) * 4);
+            int c2 = sad_at(m, bmv.x - 1, bmv.y) + mvcost(m, (bmv.x - 1) * 4, bmv.y * 4);
+            int c3 = sad_at(m, bmv.x + 1, bmv.y) + mvcost(m, (bmv.x + 1) * 4, bmv.y * 4);
+            int packed = bcost << 4;
+            if (bmv.y - 1 >= mn.y && bmv.y - 1 <= mx.y && (c0 << 4) + 1 < packed) packed = (c0 << 4) + 1;
+            if (bmv.y + 1 >= mn.y && bmv.y + 1 <= mx.y && (c1 << 4) + 3 < packed) packed = (c1 << 4) + 3;
+            if ((c2 << 4) + 4 < packed) packed = (c2 << 4) + 4;
+            if ((c3 << 4) + 12 < packed) packed = (c3 << 4) + 12;
+            bcost = packed >> 4;
+            if (!(packed & 15)) break;
+            bmv.x -= (int)((uint32_t)packed << 28) >> 30;
+            bmv.y -= (int)((uint32_t)packed << 30) >> 30;
+        }
+        while (--i && in_range(m, bmv.x, bmv.y));
+        break;
+    }
+    case ME_HEX:    /* motion.cpp:879-987 */
+    {
+        int costs[4], packed, dir;
+#define HEXC(k, dx, dy) costs[k] = sad_at(m, bmv.x + (dx), bmv.y + (dy)) + mvcost(m, (bmv.x + (dx)) * 4, (bmv.y + (dy)) * 4)
+        HEXC(0, -2, 0); HEXC(1, -1, 2); HEXC(2, 1, 2);
+        packed = bcost << 3;
+        if (bmv.y >= mn.y && bmv.y <= mx.y && (costs[0] << 3) + 2 < packed) packed = (costs[0] << 3) + 2;
+        if (bmv.y + 2 >= mn.y && bmv.y + 2 <= mx.y)
+        {
+            if ((costs[1] << 3) + 3 < packed) packed = (costs[1] << 3) + 3;
+            if ((costs[2] << 3) + 4 < packed) packed = (costs[2] << 3) + 4;
+        }
+        HEXC(0, 2, 0); HEXC(1, 1, -2); HEXC(2, -1, -2);
+        if (bmv.y >= mn.y && bmv.y <= mx.y && (costs[0] << 3) + 5 < packed) packed = (costs[0] << 3) + 5;
+        if (bmv.y - 2 >= mn.y && bmv.y - 2 <= mx.y)
+        {
+            if ((costs[1] << 3) + 6 < packed) packed = (costs[1] << 3) + 6;
+            if ((costs[2] << 3) + 7 < packed) packed = (costs[2] << 3) + 7;
+        }
+        if (packed & 7)
+        {
+            dir = (packed & 7) - 2;
+            if (bmv.y + k_hex2[dir + 1].y >= mn.y && bmv.y + k_hex2[dir + 1].y <= mx.y)
+            {
+                bmv.x += k_hex2[dir + 1].x; bmv.y += k_hex2[dir + 1].y;
+                for (int i = (merange >> 1) - 1; i > 0 && in_range(m, bmv.x, bmv.y); i--)
+                {
+                    HEXC(0, k_hex2[dir + 0].x, k_hex2[dir + 0].y);
+                    HEXC(1, k_hex2[dir + 1].x, k_hex2[dir + 1].y);
+                    HEXC(2, k_hex2[dir + 2].x, k_hex2[dir + 2].y);
+                    packed &= ~7;
+                    for (int k = 0; k < 3; k++)
+                        if (bmv.y + k_hex2[dir + k].y >= mn.y && bmv.y + k_hex2[dir + k].y <= mx.y && (costs[k] << 3) + k + 1 < packed)
+                            packed = (costs[k] << 3) + k + 1;
+                    if (!(packed & 7)) break;
+                    dir += (packed & 7) - 2;
+                    dir = k_mod6m1[dir + 1];
+                    bmv.x += k_hex2[dir + 1].x; bmv.y += k_hex2[dir + 1].y;
+                }
+            }
+        }
+        bcost = packed >> 3;
+        /* square refine */
+        dir = 0;
+        HEXC(0, 0, -1); HEXC(1, 0, 1); HEXC(2, -1, 0); HEXC(3, 1, 0);
+        int upOk = bmv.y - 1 >= mn.y && bmv.y - 1 <= mx.y, dnOk = bmv.y + 1 >= mn.y && bmv.y + 1 <= mx.y;
+        if (upOk && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+        if (dnOk && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+        if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+        if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+        HEXC(0, -1, -1); HEXC(1, -1, 1); HEXC(2, 1, -1); HEXC(3, 1, 1);
+        if (upOk && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
+        if (dnOk && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
+        if (upOk && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
+        if (dnOk && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+        bmv.x += k_square1[dir].x; bmv.y += k_square1[dir].y;
+#undef HEXC
+        break;
+    }
+    case ME_STAR:   /* motion.cpp:1156-1265 */
+    {
+        int bPointNr = 0, bDistance = 0;
+        star_pattern(m, &bmv, &bcost, &bPointNr, &bDistance, 3, merange);
+        if (bDistance == 1)
+        {
+            /* best distance was 1: check the two missing outer points; stop unless one of them improves */
+            if (!bPointNr) break;
+            int saved = bcost;
+            MV mv1 = { bmv.x + k_offsets[(bPointNr - 1) * 2].x, bmv.y + k_offsets[(bPointNr - 1) * 2].y };
+            MV mv2 = { bmv.x + k_offsets[(bPointNr - 1) * 2 + 1].x, bmv.y + k_offsets[(bPointNr - 1) * 2 + 1].y };
+            if (in_range(m, mv1.x, mv1.y)) COST_MV(mv1.x, mv1.y);
+            if (in_range(m, mv2.x, mv2.y)) COST_MV(mv2.x, mv2.y);
+            if (bcost == saved) break;
+        }
+        const int RasterDistance = 5;
+        if (bDistance > RasterDistance)
+        {
+            for (int ty = mn.y; ty <= mx.y; ty += RasterDistance)
+                for (int tx = mn.x; tx <= mx.x; tx += RasterDistance)
+                {
+                    if (tx + RasterDistance * 3 <= mx.x)
+                    {
+                        int c[4];
+                        for (int k = 0; k < 4; k++) c[k] = sad_at(m, tx + RasterDistance * k, ty);
+                        c[0] += mvcost(m, tx * 4, ty * 4);
+                        if (c[0] < bcost) { bcost = c[0]; bmv.x = tx; bmv.y = ty; }
+                        tx += RasterDistance;
+                        c[1] += mvcost(m, tx * 4, ty * 4);
+                        if (c[1] < bcost) { bcost = c[1]; bmv.x = tx; bmv.y = ty; }
+                        tx += RasterDistance;
+                        c[2] += mvcost(m, tx * 4, ty * 4);
+                        if (c[2] < bcost) { bcost = c[2]; bmv.x = tx; bmv.y = ty; }
+                        tx += RasterDistance;
+                        c[3] += mvcost(m, tx * 8, ty * 8);      /* sic: the reference shifts by 3 here (motion.cpp:1219) */
+                        if (c[3] < bcost) { bcost = c[3]; bmv.x = tx; bmv.y = ty; }
+                    }
+                    else
+                        COST_MV(tx, ty);
+                }
+        }
+        while (bDistance > 0)
+        {
+            bDistance = 0; bPointNr = 0;
+            star_pattern(m, &bmv, &bcost, &bPointNr, &bDistance, 32, merange);
+            if (bDistance == 1)
+            {
+                if (!bPointNr) break;
+                MV mv1 = { bmv.x + k_offsets[(bPointNr - 1) * 2].x, bmv.y + k_offsets[(bPointNr - 1) * 2].y };
+                MV mv2 = { bmv.x + k_offsets[(bPointNr - 1) * 2 + 1].x, bmv.y + k_offsets[(bPointNr - 1) * 2 + 1].y };
+                if (in_range(m, mv1.x, mv1.y)) COST_MV(mv1.x, mv1.y);
+                if (in_range(m, mv2.x, mv2.y)) COST_MV(mv2.x, mv2.y);
+                break;
+            }
+        }
+        break;
+    }
+    }
+
+    /* motion.cpp:1473-1594 (non-lowres, single slice) */
+    if (bprecost < bcost) { bmv = bestpre; bcost = bprecost; }
+    else { bmv.x *= 4; bmv.y *= 4; }
+    const int* wl = k_workload[subme];
+    if (!bcost)
+        bcost = mvcost(m, bmv.x, bmv.y);
+    else
+    {
+        cmp_t hpelcomp = orc_sad;
+        if (wl[4])
+        {
+            bcost = subpel_compare(m, bmv, orc_satd) + mvcost(m, bmv.x, bmv.y);
+            hpelcomp = orc_satd;
+        }
+        for (int iter = 0; iter < wl[0]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[1]; i++)
+            {
+                MV q = { bmv.x + k_square1[i].x * 2, bmv.y + k_square1[i].y * 2 };
+                if (q.y < qmin.y || q.y > qmax.y) continue;
+                int cost = subpel_compare(m, q, hpelcomp) + mvcost(m, q.x, q.y);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bmv.x += k_square1[bdir].x * 2; bmv.y += k_square1[bdir].y * 2; }
+            else break;
+        }
+        if (!wl[4])
+            bcost = subpel_compare(m, bmv, orc_satd) + mvcost(m, bmv.x, bmv.y);
+        for (int iter = 0; iter < wl[2]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[3]; i++)
+            {
+                MV q = { bmv.x + k_square1[i].x, bmv.y + k_square1[i].y };
+                if (q.y < qmin.y || q.y > qmax.y) continue;
+                int cost = subpel_compare(m, q, orc_satd) + mvcost(m, q.x, q.y);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bmv.x += k_square1[bdir].x; bmv.y += k_square1[bdir].y; }
+            else break;
+        }
+    }
+    outMv[0] = bmv.x; outMv[1] = bmv.y;
+    return bcost;
+}

@@ -9,6 +9,9 @@
 #include "common.h"
 #include "primitives.h"
 #include "constants.h"
+#include "lowres.h"
+#include "bitcost.h"
+#include "motion.h"
 
 using namespace X265_NS;
 
@@ -22,6 +25,12 @@ static void ensure()
         memset(&g_p, 0, sizeof(g_p));
         setupCPrimitives(g_p);      /* C references; keeps intra_pred_allangs populated */
         setupAliasPrimitives(g_p);
+        if (!primitives.pu[0].sad)  /* the global table the reference's classes (MotionEstimate ...) call through */
+        {
+            setupCPrimitives(primitives);
+            setupAliasPrimitives(primitives);
+        }
+        MotionEstimate::initScales();
         g_init = true;
     }
 }
@@ -125,5 +134,30 @@ const double* ref_tbl_lambda(void) { return x265_lambda_tab; }
 const double* ref_tbl_lambda2(void) { return x265_lambda2_tab; }
 const uint8_t* ref_tbl_chromaScale(void) { return g_chromaScale; }
 const uint8_t* ref_tbl_intraFilterFlags(void) { return g_intraFilterFlags; }
+
+/* ---- motion estimation: the reference's own classes (encoder/bitcost.cpp, encoder/motion.cpp) ---- */
+struct BitCostProbe : public BitCost { const uint16_t* table() const { return m_cost; } };
+const uint16_t* ref_mvcost_table(int qp) { static BitCostProbe bc; bc.setQP(qp); return bc.table(); }
+
+/* setSourcePU (lookahead form, motion.cpp:193-217: luma only, blockOffset = offset) + motionEstimate (motion.cpp:764) */
+int ref_motion_estimate(const pixel* fencPlane, const pixel* refPlane, intptr_t stride, int puX, int puY, int w, int h,
+                        int method, int subme, int qp, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                        int numCandidates, const int32_t* mvc, int merange, int32_t* outMv)
+{
+    ensure();
+    MotionEstimate me;
+    me.init(X265_CSP_I420);
+    me.setQP(qp);
+    me.setSourcePU((pixel*)fencPlane, stride, (intptr_t)puY * stride + puX, w, h, method, subme);
+    ReferencePlanes ref;
+    ref.fpelPlane[0] = (pixel*)refPlane;
+    ref.lumaStride = stride;
+    MV cand[16];
+    for (int i = 0; i < numCandidates && i < 16; i++) cand[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out;
+    int cost = me.motionEstimate(&ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]), MV(qmvp[0], qmvp[1]), numCandidates, cand, merange, out, 1, NULL);
+    outMv[0] = out.x; outMv[1] = out.y;
+    return cost;
+}
 
 } /* extern "C" */

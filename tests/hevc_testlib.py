@@ -503,3 +503,85 @@ def assert_same(got, want, what):
             bad = np.argwhere(g != w)
             raise AssertionError("%s: output %d differs at %d positions, first %s: got %s want %s"
                                  % (what, i, len(bad), bad[0], g[tuple(bad[0])], w[tuple(bad[0])]))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# motion-estimation cases: the arguments of MotionEstimate::motionEstimate()
+# ----------------------------------------------------------------------------------------------------------
+ME_DIA, ME_HEX, ME_UMH, ME_STAR = 0, 1, 2, 3
+ME_MARGIN = 96      # padded planes, like PicYuv (reference: common/picyuv.cpp: marginX = maxCU + 32)
+
+
+def me_make_planes(depth, seed, width=256, height=192, motion=(5, -3), noise=3):
+    """Deterministic integer-only synthetic pair: a textured reference plane (with margins) and a current plane that
+    is the reference displaced by `motion` full-pel samples plus small noise.  Returns (cur, ref, stride, origin)
+    where origin is the element offset of sample (0,0)."""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    stride = width + 2 * ME_MARGIN
+    rows = height + 2 * ME_MARGIN
+    base = rng.integers(0, pmax + 1, (rows // 8 + 2, stride // 8 + 2)).astype(np.int64)
+    up = np.kron(base, np.ones((8, 8), np.int64))[:rows, :stride]
+    # cheap integer smoothing so that sub-pel interpolation and the search have structure to follow
+    sm = (up + np.roll(up, 1, 0) + np.roll(up, 1, 1) + np.roll(up, (1, 1), (0, 1)) + 2) >> 2
+    sm = (sm * 3 + np.roll(sm, 3, 1) + 2) >> 2
+    ref = np.clip(sm + rng.integers(-noise, noise + 1, sm.shape), 0, pmax)
+    def shifted(mx, my):
+        return np.roll(ref, (-my, -mx), (0, 1))
+    # four quadrants move differently (one of them by a half-sample) so that results differ from job to job
+    cur = shifted(*motion).copy()
+    hy, hx = rows // 2, stride // 2
+    cur[:hy, hx:] = shifted(motion[0] + 2, motion[1] - 1)[:hy, hx:]
+    cur[hy:, :hx] = ((shifted(motion[0], motion[1]) + shifted(motion[0] + 1, motion[1]) + 1) >> 1)[hy:, :hx]
+    cur[hy:, hx:] = shifted(-motion[0], motion[1] + 4)[hy:, hx:]
+    cur = np.clip(cur + rng.integers(-noise, noise + 1, cur.shape), 0, pmax)
+    dt = np.uint8 if depth == 8 else np.uint16
+    return np.ascontiguousarray(cur.astype(dt)).ravel(), np.ascontiguousarray(ref.astype(dt)).ravel(), stride, ME_MARGIN * stride + ME_MARGIN
+
+
+def me_jobs(seed, n, width=256, height=192, motion=(5, -3), methods=(ME_HEX,), submes=(2,), merange=57):
+    """n random search jobs: dict of arrays, one row per job"""
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (32, 16), (16, 32), (16, 8), (8, 16), (64, 32), (32, 64), (8, 4), (4, 8),
+             (16, 12), (12, 16), (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32), (64, 48), (48, 64), (64, 16), (16, 64)]
+    jobs = []
+    for i in range(n):
+        w, h = sizes[int(rng.integers(0, 4 if i % 3 else len(sizes)))]
+        x = int(rng.integers(0, (width - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (height - h) // 4 + 1)) * 4
+        qp = int(rng.integers(12, 46))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            mvp = (0, 0)
+        elif kind == 1:
+            mvp = (motion[0] * 4 + int(rng.integers(-6, 7)), motion[1] * 4 + int(rng.integers(-6, 7)))
+        else:
+            mvp = (int(rng.integers(-80, 81)), int(rng.integers(-80, 81)))
+        # setSearchRange (reference: search.cpp:2724-2768): window = mvp +- merange, clipped so the block stays
+        # inside the padded picture; values in full-pel
+        mr = merange if rng.integers(0, 3) else int(rng.integers(4, 32))
+        lim = 64 + 8     # how far outside the picture a block may reach (inside the 96-sample margin with taps)
+        mnx = max((mvp[0] >> 2) - mr, -x - lim + 8); mxx = min((mvp[0] >> 2) + mr, width - x - w + lim - 8)
+        mny = max((mvp[1] >> 2) - mr, -y - lim + 8); mxy = min((mvp[1] >> 2) + mr, height - y - h + lim - 8)
+        ncand = int(rng.integers(0, 5))
+        mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(ncand)]
+        if ncand and rng.integers(0, 2):
+            mvc[0] = (motion[0] * 4, motion[1] * 4)
+        jobs.append(dict(x=x, y=y, w=w, h=h, qp=qp, mvp=mvp, mvmin=(mnx, mny), mvmax=(mxx, mxy), mvc=mvc, merange=mr,
+                         method=int(methods[i % len(methods)]), subme=int(submes[(i // len(methods)) % len(submes)])))
+    return jobs
+
+
+def me_run_host(L, cur, ref, stride, origin, jobs):
+    """runs jobs one by one through `<prefix>motion_estimate` (reference driver or oracle); returns int array [n,3]"""
+    out = np.zeros((len(jobs), 3), np.int32)
+    fn = getattr(L.lib, L.prefix + "motion_estimate")
+    fn.restype = C.c_int
+    for i, j in enumerate(jobs):
+        mv = np.zeros(2, np.int32)
+        mvc = np.array(j["mvc"], np.int32).reshape(-1) if j["mvc"] else np.zeros(2, np.int32)
+        cost = fn(off(cur, origin), off(ref, origin), C.c_int64(stride), j["x"], j["y"], j["w"], j["h"], j["method"], j["subme"], j["qp"],
+                  _ptr(np.array(j["mvmin"], np.int32)), _ptr(np.array(j["mvmax"], np.int32)), _ptr(np.array(j["mvp"], np.int32)),
+                  len(j["mvc"]), _ptr(mvc), j["merange"], _ptr(mv))
+        out[i] = (mv[0], mv[1], cost)
+    return out
