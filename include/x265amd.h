@@ -178,8 +178,59 @@ typedef struct x265amd_job
 int x265amd_run_jobs(void* stream, const x265amd_job* d_jobs, int n, int family);
 
 /* ------------------------------------------------------------------------------------------------------- */
-/* Layer 3: fused frame-level kernels: see x265amd_frame.h                                                  */
+/* Layer 3: fused frame-level kernels on device-resident, padded pictures.                                  */
 /* ------------------------------------------------------------------------------------------------------- */
+
+/* --- motion estimation: MotionEstimate::motionEstimate() (reference: source/encoder/motion.cpp:764-1594) ---
+ * One job = one call of the reference's motionEstimate() after setSourcePU() (motion.cpp:193-247): a PU of the
+ * source picture searched in one reference picture.  Jobs are grouped; one workgroup serves one group: it stages
+ * the group's reference window and its 64x64 source tile in LDS once and its wavefronts pull the group's jobs from
+ * an LDS counter, one wavefront per job.  A search that leaves the staged window keeps producing exact results
+ * through a direct-from-HBM path.  Planes are padded exactly like the reference's PicYuv (common/picyuv.cpp:
+ * marginX = maxCU + 32, marginY = maxCU + 16) so that, as in the reference, candidates may lie outside the picture. */
+enum { X265AMD_ME_DIA = 0, X265AMD_ME_HEX = 1, X265AMD_ME_UMH = 2, X265AMD_ME_STAR = 3, X265AMD_ME_SEA = 4, X265AMD_ME_FULL = 5 };
+#define X265AMD_ME_MAX_CAND 12      /* reference: MD_ABOVE_LEFT+1 spatial x 2 + 2 (search.cpp:2086-2154) */
+
+typedef struct x265amd_me_job
+{
+    int16_t x, y;                       /* PU position in the picture, luma samples */
+    uint8_t w, h;                       /* PU size (a LumaPU shape, primitives.h:41-55) */
+    uint8_t method, subme;              /* searchMethod (X265AMD_ME_*), subpelRefine 0..7 (motion.cpp:48-58) */
+    uint8_t qp, num_cand;               /* QP selecting the MV cost table (bitcost.cpp:30-58); number of mvc[] */
+    int16_t merange;
+    int16_t mvmin[2], mvmax[2];         /* search bounds, full-pel (search.cpp:2724-2768) */
+    int16_t mvp[2];                     /* predictor, quarter-pel */
+    int16_t mvc[X265AMD_ME_MAX_CAND][2];/* extra candidates, quarter-pel */
+} x265amd_me_job;
+
+typedef struct x265amd_me_group
+{
+    int32_t first_job, num_jobs;        /* jobs[first_job .. first_job+num_jobs) */
+    int32_t ref;                        /* index into the reference plane array */
+    int16_t win_x, win_y;               /* picture coordinates of the staged window's top-left sample */
+    int16_t win_w, win_h;               /* staged window size in samples, win_w % 4 == 0, <= the launch maxima */
+    int16_t fenc_x, fenc_y;             /* top-left of the 64x64 source tile holding every PU of the group */
+} x265amd_me_group;
+
+typedef struct x265amd_me_result { int16_t mv[2]; int32_t cost; } x265amd_me_result;
+
+typedef struct x265amd_me_ctx x265amd_me_ctx;
+/* Builds the MV cost tables (BitCost::s_costs[qp], bitcost.cpp:30-109) for qp 0..69 on the current device. */
+x265amd_me_ctx* x265amd_me_open(void);
+void x265amd_me_close(x265amd_me_ctx* ctx);
+/* host copy of one table: 2*65536+1 uint16 values, element [65536] is MVD 0 (for parity tests of the table itself) */
+const uint16_t* x265amd_me_host_mvcost(x265amd_me_ctx* ctx, int qp);
+/* Host helper: groups `n` jobs (host array, all against reference `ref`) by the 64x64 source tile they lie in and
+ * sizes each group's window as the bounding box of its jobs' search areas, clipped to max_win_w x max_win_h around
+ * the box centre.  `order[n]` receives the job permutation (jobs must be uploaded in that order); returns the number
+ * of groups written to groups[] (capacity n), or <0. */
+int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int max_win_w, int max_win_h, x265amd_me_group* groups, int32_t* order);
+/* Runs all groups.  d_fenc / d_refs[i]: device addresses of sample (0,0) of the padded source / reference luma
+ * planes, all with the same `stride` (elements).  d_refs, d_groups, d_jobs, d_out: device arrays.  max_win_w/h:
+ * the largest window among the groups (LDS is sized for it).  Asynchronous on `stream`. */
+int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_fenc, const uint64_t* d_refs, intptr_t stride,
+                      const x265amd_me_group* d_groups, int num_groups, const x265amd_me_job* d_jobs, x265amd_me_result* d_out,
+                      int max_win_w, int max_win_h);
 
 #ifdef __cplusplus
 }

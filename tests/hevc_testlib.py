@@ -547,8 +547,9 @@ def me_jobs(seed, n, width=256, height=192, motion=(5, -3), methods=(ME_HEX,), s
     jobs = []
     for i in range(n):
         w, h = sizes[int(rng.integers(0, 4 if i % 3 else len(sizes)))]
-        x = int(rng.integers(0, (width - w) // 4 + 1)) * 4
-        y = int(rng.integers(0, (height - h) // 4 + 1)) * 4
+        # a PU never straddles a CTU: pick a 64x64 tile, then an offset (multiple of 4) that keeps the PU inside it
+        x = int(rng.integers(0, width // 64)) * 64 + int(rng.integers(0, (64 - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, height // 64)) * 64 + int(rng.integers(0, (64 - h) // 4 + 1)) * 4
         qp = int(rng.integers(12, 46))
         kind = int(rng.integers(0, 4))
         if kind == 0:
@@ -585,3 +586,84 @@ def me_run_host(L, cur, ref, stride, origin, jobs):
                   len(j["mvc"]), _ptr(mvc), j["merange"], _ptr(mv))
         out[i] = (mv[0], mv[1], cost)
     return out
+
+
+ME_JOB_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("method", "u1"), ("subme", "u1"), ("qp", "u1"),
+                      ("num_cand", "u1"), ("merange", "<i2"), ("mvmin", "<i2", 2), ("mvmax", "<i2", 2), ("mvp", "<i2", 2),
+                      ("mvc", "<i2", (12, 2))])
+ME_GROUP_DT = np.dtype([("first_job", "<i4"), ("num_jobs", "<i4"), ("ref", "<i4"), ("win_x", "<i2"), ("win_y", "<i2"),
+                        ("win_w", "<i2"), ("win_h", "<i2"), ("fenc_x", "<i2"), ("fenc_y", "<i2")])
+ME_RESULT_DT = np.dtype([("mv", "<i2", 2), ("cost", "<i4")])
+assert ME_JOB_DT.itemsize == 72 and ME_GROUP_DT.itemsize == 24 and ME_RESULT_DT.itemsize == 8
+
+
+def me_pack_jobs(jobs):
+    a = np.zeros(len(jobs), ME_JOB_DT)
+    for i, j in enumerate(jobs):
+        a[i]["x"], a[i]["y"], a[i]["w"], a[i]["h"] = j["x"], j["y"], j["w"], j["h"]
+        a[i]["method"], a[i]["subme"], a[i]["qp"], a[i]["num_cand"], a[i]["merange"] = j["method"], j["subme"], j["qp"], len(j["mvc"]), j["merange"]
+        a[i]["mvmin"], a[i]["mvmax"], a[i]["mvp"] = j["mvmin"], j["mvmax"], j["mvp"]
+        for k, c in enumerate(j["mvc"]):
+            a[i]["mvc"][k] = c
+    return a
+
+
+class HipME:
+    """drives x265amd_me_* (include/x265amd.h layer 3) with torch tensors as device memory"""
+
+    def __init__(self, depth):
+        import torch
+        self.torch = torch
+        self.L = load_hip(depth)
+        self.lib = self.L.lib
+        self.lib.x265amd_me_open.restype = C.c_void_p
+        self.ctx = C.c_void_p(self.lib.x265amd_me_open())
+        assert self.ctx.value, self.lib.x265amd_last_error()
+
+    def close(self):
+        self.lib.x265amd_me_close(self.ctx)
+
+    def host_mvcost(self, qp):
+        self.lib.x265amd_me_host_mvcost.restype = C.POINTER(C.c_uint16)
+        return np.ctypeslib.as_array(self.lib.x265amd_me_host_mvcost(self.ctx, qp), (2 * 65536 + 1,))
+
+    def plan(self, packed, ref=0, max_win=(192, 192)):
+        n = len(packed)
+        groups = np.zeros(max(n, 1), ME_GROUP_DT)
+        order = np.zeros(max(n, 1), np.int32)
+        ng = self.lib.x265amd_me_plan(_ptr(packed), n, ref, max_win[0], max_win[1], _ptr(groups), _ptr(order))
+        assert ng >= 0, self.lib.x265amd_last_error()
+        return groups[:ng].copy(), order[:n].copy()
+
+    def upload(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).cuda()
+        return t
+
+    def search(self, d_cur, d_refs, stride, origin_elems, itemsize, groups, packed_ordered, max_win=(192, 192), stream=None):
+        """d_cur / d_refs: uploaded planes (uint8 tensors); returns result tensor (device, bytes)"""
+        torch = self.torch
+        d_groups = self.upload(groups)
+        d_jobs = self.upload(packed_ordered)
+        d_out = torch.zeros(len(packed_ordered) * 8, dtype=torch.uint8, device="cuda")
+        refs = np.array([r.data_ptr() + origin_elems * itemsize for r in d_refs], np.uint64)
+        d_reftab = self.upload(refs)
+        rc = self.lib.x265amd_me_search(self.ctx, C.c_void_p(stream or 0), C.c_void_p(d_cur.data_ptr() + origin_elems * itemsize),
+                                        C.c_void_p(d_reftab.data_ptr()), C.c_int64(stride), C.c_void_p(d_groups.data_ptr()), len(groups),
+                                        C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), max_win[0], max_win[1])
+        assert rc == 0, self.lib.x265amd_last_error()
+        self._keep = (d_groups, d_jobs, d_reftab)
+        return d_out
+
+    def run(self, cur, ref, stride, origin, jobs, max_win=(192, 192)):
+        """host arrays in, int array [n,3] (mvx, mvy, cost) out, in the order of `jobs`"""
+        packed = me_pack_jobs(jobs)
+        groups, order = self.plan(packed, 0, max_win)
+        d_cur, d_ref = self.upload(cur), self.upload(ref)
+        d_out = self.search(d_cur, [d_ref], stride, origin, cur.itemsize, groups, packed[order], max_win)
+        self.torch.cuda.synchronize()
+        res = d_out.cpu().numpy().view(ME_RESULT_DT)
+        out = np.zeros((len(jobs), 3), np.int32)
+        out[order, 0] = res["mv"][:, 0]
+        out[order, 1] = res["mv"][:, 1]
+        out[order, 2] = res["cost"]
+        return out

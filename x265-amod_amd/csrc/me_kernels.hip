@@ -1,0 +1,700 @@
+/* Layer 3: motion estimation on device-resident pictures (include/x265amd.h, `x265amd_me_*`).
+ *
+ * Device restatement of the reference's MotionEstimate::motionEstimate() (source/encoder/motion.cpp:764-1594) with
+ * its DIA, HEX and STAR integer searches (StarPatternSearch, motion.cpp:387-629), the sub-pel refinement driven by
+ * the `workload` table (motion.cpp:48-58), subpelCompare's luma path (motion.cpp:1596-1623) and BitCost's MV cost
+ * tables (source/encoder/bitcost.cpp:30-109).  Integer arithmetic throughout: results (quarter-pel MV and cost) are
+ * bit-exact with the reference for the same arguments.
+ *
+ * Mapping to gfx950: one workgroup per job group; the group's reference window (<= max_win_w x max_win_h samples)
+ * and its 64x64 source tile are staged in LDS with coalesced row reads; each 64-lane wavefront pulls jobs from an
+ * LDS counter and runs the (data dependent, serial) search for its job with all candidates' SAD/SATD sums reduced
+ * across the wavefront.  8-bit SADs use v_sad_u8 on dwords assembled from the LDS window with v_alignbyte.
+ */
+#include <math.h>
+#include <algorithm>
+#include <vector>
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+
+#define ME_WAVES 4
+#define ME_QP_COUNT 70              /* QP_MAX_MAX + 1 (reference: common/constants.h) */
+#define ME_TBL_HALF 65536           /* 2 * BC_MAX_MV: table index range is [-65536, 65536] (bitcost.h:81) */
+#define ME_TBL_LEN (2 * ME_TBL_HALF + 1)
+
+struct x265amd_me_ctx
+{
+    uint16_t* d_tables = nullptr;           /* ME_QP_COUNT tables of ME_TBL_LEN entries */
+    std::vector<uint16_t> h_tables;
+};
+
+struct MeParams
+{
+    const pixel* fenc;
+    const uint64_t* refs;
+    int stride;
+    const x265amd_me_group* groups;
+    const x265amd_me_job* jobs;
+    x265amd_me_result* out;
+    const uint16_t* tables;
+    int maxWinW, maxWinH;
+};
+
+/* ---- per-wavefront search state ---- */
+struct MeState
+{
+    const pixel* win;   /* LDS window: sample (winX + i, winY + j) at win[j * winW + i] */
+    int winX, winY, winW, winH;
+    const pixel* fencT; /* LDS 64x64 source tile, PU at (fx, fy) */
+    int fx, fy;
+    const pixel* refG;  /* HBM: sample (0,0) of the reference plane */
+    int stride;
+    int px, py, w, h;   /* PU position and size */
+    const uint16_t* cost;
+    int mvpx, mvpy;
+    int mnx, mny, mxx, mxy;
+};
+
+extern __shared__ __attribute__((aligned(16))) char me_smem[];
+/* the per-wavefront state lives in LDS (one MeState per wave): the search helpers are real functions (not inlined
+ * into the ~60 call sites of the search) and find it through its LDS byte offset */
+#define ME_S(off) (*reinterpret_cast<const MeState*>(me_smem + (off)))
+
+XA_DEV int me_mvcost(const MeState& s, int qx, int qy) { return (uint16_t)(s.cost[qx - s.mvpx] + s.cost[qy - s.mvpy]); }
+
+template<bool INWIN> XA_DEV int me_ref(const MeState& s, int X, int Y)
+{
+    return INWIN ? (int)s.win[(Y - s.winY) * s.winW + (X - s.winX)] : (int)s.refG[(long)Y * s.stride + X];
+}
+
+XA_DEV bool me_inwin(const MeState& s, int X0, int Y0, int X1, int Y1)     /* [X0,X1) x [Y0,Y1) inside the staged window */
+{
+    return X0 >= s.winX && Y0 >= s.winY && X1 <= s.winX + s.winW && Y1 <= s.winY + s.winH;
+}
+
+/* SAD of the PU against the reference block whose top-left sample is (X, Y): pixel.cpp:40-54 */
+template<bool INWIN> XA_DEV int me_sad_fpel(const MeState& s, int X, int Y)
+{
+    int gpr = s.w >> 2, total = gpr * s.h, inv = ((1 << 20) + gpr - 1) / gpr, sum = 0;
+    for (int gi = xa_lane(); gi < total; gi += XA_WAVE)
+    {
+        int y = (gi * inv) >> 20, x = (gi - y * gpr) << 2;
+        const pixel* f = s.fencT + (s.fy + y) * 64 + s.fx + x;
+#if XA_DEPTH == 8
+        if (INWIN)
+        {
+            uint32_t fv = *reinterpret_cast<const uint32_t*>(f);
+            int o = (Y + y - s.winY) * s.winW + (X + x - s.winX);
+            const uint32_t* wp = reinterpret_cast<const uint32_t*>(s.win) + (o >> 2);
+            uint32_t rv = __builtin_amdgcn_alignbyte(wp[1], wp[0], o & 3);
+            sum = __builtin_amdgcn_sad_u8(fv, rv, sum);
+            continue;
+        }
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            sum += abs((int)f[k] - me_ref<INWIN>(s, X + x + k, Y + y));
+    }
+    return xa_wave_sum(sum);
+}
+
+__device__ __noinline__ int me_sad_at_f(int sOff, int mx, int my)     /* full-pel MV (mx,my) */
+{
+    const MeState& s = ME_S(sOff);
+    int X = s.px + mx, Y = s.py + my;
+    /* the dword reads of the LDS path touch up to 3 samples past the block's right edge */
+    if (me_inwin(s, X, Y, X + s.w + 4, Y + s.h)) return me_sad_fpel<true>(s, X, Y);
+    return me_sad_fpel<false>(s, X, Y);
+}
+
+/* one interpolated luma sample at integer position (X,Y) + fraction (xf,yf)/4:
+ * luma_hpp / luma_vpp / luma_hvpp (ipfilter.cpp:79-120, :169-210, :370-378 = hps(rowExt) + vsp) */
+template<bool INWIN> XA_DEV int me_pred(const MeState& s, int X, int Y, int xf, int yf)
+{
+    if (!(xf | yf)) return me_ref<INWIN>(s, X, Y);
+    const int16_t* cx = xa_tbl.lumaFilter[xf];
+    const int16_t* cy = xa_tbl.lumaFilter[yf];
+    if (!yf || !xf)
+    {
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            sum += (yf ? me_ref<INWIN>(s, X, Y - 3 + t) * cy[t] : me_ref<INWIN>(s, X - 3 + t, Y) * cx[t]);
+        int16_t val = (int16_t)((sum + (1 << (XA_IF_FILTER_PREC - 1))) >> XA_IF_FILTER_PREC);
+        return xa_clip3(0, XA_PIXEL_MAX, val);
+    }
+    const int headRoom = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    const int shiftH = XA_IF_FILTER_PREC - headRoom, offH = (int)((unsigned)-XA_IF_INTERNAL_OFFS << shiftH);
+    const int shiftV = XA_IF_FILTER_PREC + headRoom, offV = (1 << (shiftV - 1)) + (XA_IF_INTERNAL_OFFS << XA_IF_FILTER_PREC);
+    int sum = 0;
+    for (int r = 0; r < 8; r++)
+    {
+        int hs = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            hs += me_ref<INWIN>(s, X - 3 + t, Y - 3 + r) * cx[t];
+        sum += (int)(int16_t)((hs + offH) >> shiftH) * cy[r];
+    }
+    int16_t val = (int16_t)((sum + offV) >> shiftV);
+    return xa_clip3(0, XA_PIXEL_MAX, val);
+}
+
+/* subpelCompare (motion.cpp:1596-1623) with cmp = sad or satd, quarter-pel MV (qx,qy) */
+template<bool INWIN, bool SATD> XA_DEV int me_subpel_cmp(const MeState& s, int qx, int qy)
+{
+    int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2), xf = qx & 3, yf = qy & 3, sum = 0;
+    if (SATD)       /* one lane per 4x4 tile: pixel.cpp:210-297 */
+    {
+        int tw = s.w >> 2, nt = tw * (s.h >> 2), inv = ((1 << 20) + tw - 1) / tw;
+        for (int t = xa_lane(); t < nt; t += XA_WAVE)
+        {
+            int ty = (t * inv) >> 20, tx = t - ty * tw;
+            int d[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    d[y][x] = (int)s.fencT[(s.fy + 4 * ty + y) * 64 + s.fx + 4 * tx + x] - me_pred<INWIN>(s, X0 + 4 * tx + x, Y0 + 4 * ty + y, xf, yf);
+            int tt[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                int s01 = d[y][0] + d[y][1], e01 = d[y][0] - d[y][1], s23 = d[y][2] + d[y][3], e23 = d[y][2] - d[y][3];
+                tt[y][0] = s01 + s23; tt[y][1] = s01 - s23; tt[y][2] = e01 + e23; tt[y][3] = e01 - e23;
+            }
+            int ts = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int s01 = tt[0][x] + tt[1][x], e01 = tt[0][x] - tt[1][x], s23 = tt[2][x] + tt[3][x], e23 = tt[2][x] - tt[3][x];
+                ts += abs(s01 + s23) + abs(s01 - s23) + abs(e01 + e23) + abs(e01 - e23);
+            }
+            sum += ts >> 1;
+        }
+    }
+    else
+    {
+        int n = s.w * s.h, inv = ((1 << 20) + s.w - 1) / s.w;
+        for (int i = xa_lane(); i < n; i += XA_WAVE)
+        {
+            int y = (i * inv) >> 20, x = i - y * s.w;
+            sum += abs((int)s.fencT[(s.fy + y) * 64 + s.fx + x] - me_pred<INWIN>(s, X0 + x, Y0 + y, xf, yf));
+        }
+    }
+    return xa_wave_sum(sum);
+}
+
+#define me_sad_at(s, mx, my) me_sad_at_f(sOff, mx, my)
+template<bool SATD> __device__ __noinline__ int me_subpel_f(int sOff, int qx, int qy)
+{
+    const MeState& s = ME_S(sOff);
+    if (!SATD && !((qx | qy) & 3)) return me_sad_at(s, qx >> 2, qy >> 2);
+    int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
+    if (me_inwin(s, X0 - 3, Y0 - 3, X0 + s.w + 4, Y0 + s.h + 4)) return me_subpel_cmp<true, SATD>(s, qx, qy);
+    return me_subpel_cmp<false, SATD>(s, qx, qy);
+}
+
+#define me_subpel_sad(qx, qy) me_subpel_f<false>(sOff, qx, qy)
+#define me_subpel_satd(qx, qy) me_subpel_f<true>(sOff, qx, qy)
+XA_DEV bool me_in_range(const MeState& s, int x, int y) { return x >= s.mnx && x <= s.mxx && y >= s.mny && y <= s.mxy; }
+
+#define ME_COST(mx, my) (me_sad_at(s, (mx), (my)) + me_mvcost(s, (mx) * 4, (my) * 4))
+#define ME_COST_MV(mx, my) do { int c_ = ME_COST(mx, my); if (c_ < bcost) { bcost = c_; bx = (mx); by = (my); } } while (0)
+#define ME_COST_PT(mx, my, point, dist) do { int c_ = ME_COST(mx, my); if (c_ < bcost) { bcost = c_; bx = (mx); by = (my); bPointNr = (point); bDistance = (dist); } } while (0)
+
+/* StarPatternSearch: motion.cpp:387-629 (the x4 batches evaluate the same points in the same order) */
+__device__ __noinline__ void me_star_pattern(int sOff, int& bx, int& by, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
+{
+    const MeState& s = ME_S(sOff);
+    const int ox = bx, oy = by;
+    int saved = bcost, rounds = 0;
+    {
+        const int dist = 1;
+        int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
+        bool all = top >= s.mny && left >= s.mnx && right <= s.mxx && bottom <= s.mxy;
+        if (all || top >= s.mny) ME_COST_PT(ox, top, 2, dist);
+        if (all || left >= s.mnx) ME_COST_PT(left, oy, 4, dist);
+        if (all || right <= s.mxx) ME_COST_PT(right, oy, 5, dist);
+        if (all || bottom <= s.mxy) ME_COST_PT(ox, bottom, 7, dist);
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {
+        int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
+        int top2 = oy - (dist >> 1), bottom2 = oy + (dist >> 1), left2 = ox - (dist >> 1), right2 = ox + (dist >> 1);
+        saved = bcost;
+        bool all = top >= s.mny && left >= s.mnx && right <= s.mxx && bottom <= s.mxy;
+        if (all)
+        {
+            ME_COST_PT(ox, top, 2, dist);
+            ME_COST_PT(left2, top2, 1, dist >> 1);
+            ME_COST_PT(right2, top2, 3, dist >> 1);
+            ME_COST_PT(left, oy, 4, dist);
+            ME_COST_PT(right, oy, 5, dist);
+            ME_COST_PT(left2, bottom2, 6, dist >> 1);
+            ME_COST_PT(right2, bottom2, 8, dist >> 1);
+            ME_COST_PT(ox, bottom, 7, dist);
+        }
+        else
+        {
+            if (top >= s.mny) ME_COST_PT(ox, top, 2, dist);
+            if (top2 >= s.mny)
+            {
+                if (left2 >= s.mnx) ME_COST_PT(left2, top2, 1, (dist >> 1));
+                if (right2 <= s.mxx) ME_COST_PT(right2, top2, 3, (dist >> 1));
+            }
+            if (left >= s.mnx) ME_COST_PT(left, oy, 4, dist);
+            if (right <= s.mxx) ME_COST_PT(right, oy, 5, dist);
+            if (bottom2 <= s.mxy)
+            {
+                if (left2 >= s.mnx) ME_COST_PT(left2, bottom2, 6, (dist >> 1));
+                if (right2 <= s.mxx) ME_COST_PT(right2, bottom2, 8, (dist >> 1));
+            }
+            if (bottom <= s.mxy) ME_COST_PT(ox, bottom, 7, dist);
+        }
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {
+        int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
+        saved = bcost;
+        bool all = top >= s.mny && left >= s.mnx && right <= s.mxx && bottom <= s.mxy;
+        if (all || top >= s.mny) ME_COST_PT(ox, top, 0, dist);
+        if (all || left >= s.mnx) ME_COST_PT(left, oy, 0, dist);
+        if (all || right <= s.mxx) ME_COST_PT(right, oy, 0, dist);
+        if (all || bottom <= s.mxy) ME_COST_PT(ox, bottom, 0, dist);
+        for (int index = 1; index < 4; index++)
+        {
+            int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
+            int posXL = ox - ((dist >> 2) * index), posXR = ox + ((dist >> 2) * index);
+            if (all || posYT >= s.mny)
+            {
+                if (all || posXL >= s.mnx) ME_COST_PT(posXL, posYT, 0, dist);
+                if (all || posXR <= s.mxx) ME_COST_PT(posXR, posYT, 0, dist);
+            }
+            if (all || posYB <= s.mxy)
+            {
+                if (all || posXL >= s.mnx) ME_COST_PT(posXL, posYB, 0, dist);
+                if (all || posXR <= s.mxx) ME_COST_PT(posXR, posYB, 0, dist);
+            }
+        }
+        if (bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+}
+
+__device__ const int8_t me_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__device__ const uint8_t me_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+__device__ const int8_t me_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+__device__ const int8_t me_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                              { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+/* motion.cpp:48-58: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
+__device__ const uint8_t me_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                               { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+
+/* MotionEstimate::motionEstimate: motion.cpp:764-1594 (full-resolution reference, one slice, luma only) */
+__device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* out)
+{
+    const MeState& s = ME_S(sOff);
+    const int qminx = s.mnx * 4, qminy = s.mny * 4, qmaxx = s.mxx * 4, qmaxy = s.mxy * 4;
+    const int merange = j.merange;
+    /* motion.cpp:797-846: predictor, zero MV, candidates */
+    int pmx = xa_clip3(qminx, qmaxx, s.mvpx), pmy = xa_clip3(qminy, qmaxy, s.mvpy);
+    int bestprex = pmx, bestprey = pmy;
+    int bprecost = me_subpel_sad(pmx, pmy);
+    int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2;
+    int bcost = bprecost;
+    if ((pmx | pmy) & 3)
+        bcost = ME_COST(bx, by);
+    if (pmx | pmy)
+    {
+        int cost = me_sad_at(s, 0, 0) + me_mvcost(s, 0, 0);
+        if (cost < bcost)
+        {
+            bcost = cost;
+            bx = 0;
+            by = max(min(0, s.mxy), s.mny);
+        }
+    }
+    for (int i = 0; i < j.num_cand; i++)
+    {
+        int cx = xa_clip3(qminx, qmaxx, j.mvc[i][0]), cy = xa_clip3(qminy, qmaxy, j.mvc[i][1]);
+        if ((cx | cy) && (cx != pmx || cy != pmy) && (cx != bestprex || cy != bestprey))
+        {
+            int cost = me_subpel_sad(cx, cy) + me_mvcost(s, cx, cy);
+            if (cost < bprecost) { bprecost = cost; bestprex = cx; bestprey = cy; }
+        }
+    }
+
+    switch (j.method)
+    {
+    case X265AMD_ME_DIA:    /* motion.cpp:855-877 */
+    {
+        int i = merange;
+        do
+        {
+            int c0 = ME_COST(bx, by - 1), c1 = ME_COST(bx, by + 1), c2 = ME_COST(bx - 1, by), c3 = ME_COST(bx + 1, by);
+            int packed = bcost << 4;
+            if (by - 1 >= s.mny && by - 1 <= s.mxy && (c0 << 4) + 1 < packed) packed = (c0 << 4) + 1;
+            if (by + 1 >= s.mny && by + 1 <= s.mxy && (c1 << 4) + 3 < packed) packed = (c1 << 4) + 3;
+            if ((c2 << 4) + 4 < packed) packed = (c2 << 4) + 4;
+            if ((c3 << 4) + 12 < packed) packed = (c3 << 4) + 12;
+            bcost = packed >> 4;
+            if (!(packed & 15)) break;
+            bx -= (int)((uint32_t)packed << 28) >> 30;
+            by -= (int)((uint32_t)packed << 30) >> 30;
+        }
+        while (--i && me_in_range(s, bx, by));
+        break;
+    }
+    case X265AMD_ME_HEX:    /* motion.cpp:879-987 */
+    {
+        int c0, c1, c2, c3, packed, dir;
+        c0 = ME_COST(bx - 2, by); c1 = ME_COST(bx - 1, by + 2); c2 = ME_COST(bx + 1, by + 2);
+        packed = bcost << 3;
+        if (by >= s.mny && by <= s.mxy && (c0 << 3) + 2 < packed) packed = (c0 << 3) + 2;
+        if (by + 2 >= s.mny && by + 2 <= s.mxy)
+        {
+            if ((c1 << 3) + 3 < packed) packed = (c1 << 3) + 3;
+            if ((c2 << 3) + 4 < packed) packed = (c2 << 3) + 4;
+        }
+        c0 = ME_COST(bx + 2, by); c1 = ME_COST(bx + 1, by - 2); c2 = ME_COST(bx - 1, by - 2);
+        if (by >= s.mny && by <= s.mxy && (c0 << 3) + 5 < packed) packed = (c0 << 3) + 5;
+        if (by - 2 >= s.mny && by - 2 <= s.mxy)
+        {
+            if ((c1 << 3) + 6 < packed) packed = (c1 << 3) + 6;
+            if ((c2 << 3) + 7 < packed) packed = (c2 << 3) + 7;
+        }
+        if (packed & 7)
+        {
+            dir = (packed & 7) - 2;
+            if (by + me_hex2[dir + 1][1] >= s.mny && by + me_hex2[dir + 1][1] <= s.mxy)
+            {
+                bx += me_hex2[dir + 1][0]; by += me_hex2[dir + 1][1];
+                for (int i = (merange >> 1) - 1; i > 0 && me_in_range(s, bx, by); i--)
+                {
+                    int cc[3];
+                    for (int k = 0; k < 3; k++)
+                        cc[k] = ME_COST(bx + me_hex2[dir + k][0], by + me_hex2[dir + k][1]);
+                    packed &= ~7;
+                    for (int k = 0; k < 3; k++)
+                        if (by + me_hex2[dir + k][1] >= s.mny && by + me_hex2[dir + k][1] <= s.mxy && (cc[k] << 3) + k + 1 < packed)
+                            packed = (cc[k] << 3) + k + 1;
+                    if (!(packed & 7)) break;
+                    dir += (packed & 7) - 2;
+                    dir = me_mod6m1[dir + 1];
+                    bx += me_hex2[dir + 1][0]; by += me_hex2[dir + 1][1];
+                }
+            }
+        }
+        bcost = packed >> 3;
+        /* square refine */
+        dir = 0;
+        c0 = ME_COST(bx, by - 1); c1 = ME_COST(bx, by + 1); c2 = ME_COST(bx - 1, by); c3 = ME_COST(bx + 1, by);
+        bool upOk = by - 1 >= s.mny && by - 1 <= s.mxy, dnOk = by + 1 >= s.mny && by + 1 <= s.mxy;
+        if (upOk && c0 < bcost) { bcost = c0; dir = 1; }
+        if (dnOk && c1 < bcost) { bcost = c1; dir = 2; }
+        if (c2 < bcost) { bcost = c2; dir = 3; }
+        if (c3 < bcost) { bcost = c3; dir = 4; }
+        c0 = ME_COST(bx - 1, by - 1); c1 = ME_COST(bx - 1, by + 1); c2 = ME_COST(bx + 1, by - 1); c3 = ME_COST(bx + 1, by + 1);
+        if (upOk && c0 < bcost) { bcost = c0; dir = 5; }
+        if (dnOk && c1 < bcost) { bcost = c1; dir = 6; }
+        if (upOk && c2 < bcost) { bcost = c2; dir = 7; }
+        if (dnOk && c3 < bcost) { bcost = c3; dir = 8; }
+        bx += me_square1[dir][0]; by += me_square1[dir][1];
+        break;
+    }
+    case X265AMD_ME_STAR:   /* motion.cpp:1156-1265 */
+    {
+        int bPointNr = 0, bDistance = 0;
+        bool stop = false;
+        me_star_pattern(sOff, bx, by, bcost, bPointNr, bDistance, 3, merange);
+        if (bDistance == 1)
+        {
+            if (!bPointNr) stop = true;
+            else
+            {
+                int saved = bcost;
+                int x1 = bx + me_offsets[(bPointNr - 1) * 2][0], y1 = by + me_offsets[(bPointNr - 1) * 2][1];
+                int x2 = bx + me_offsets[(bPointNr - 1) * 2 + 1][0], y2 = by + me_offsets[(bPointNr - 1) * 2 + 1][1];
+                if (me_in_range(s, x1, y1)) ME_COST_MV(x1, y1);
+                if (me_in_range(s, x2, y2)) ME_COST_MV(x2, y2);
+                if (bcost == saved) stop = true;
+            }
+        }
+        if (stop) break;
+        const int RasterDistance = 5;
+        if (bDistance > RasterDistance)
+        {
+            for (int ty = s.mny; ty <= s.mxy; ty += RasterDistance)
+                for (int tx = s.mnx; tx <= s.mxx; tx += RasterDistance)
+                {
+                    if (tx + RasterDistance * 3 <= s.mxx)
+                    {
+                        int c[4];
+                        for (int k = 0; k < 4; k++) c[k] = me_sad_at(s, tx + RasterDistance * k, ty);
+                        c[0] += me_mvcost(s, tx * 4, ty * 4);
+                        if (c[0] < bcost) { bcost = c[0]; bx = tx; by = ty; }
+                        tx += RasterDistance;
+                        c[1] += me_mvcost(s, tx * 4, ty * 4);
+                        if (c[1] < bcost) { bcost = c[1]; bx = tx; by = ty; }
+                        tx += RasterDistance;
+                        c[2] += me_mvcost(s, tx * 4, ty * 4);
+                        if (c[2] < bcost) { bcost = c[2]; bx = tx; by = ty; }
+                        tx += RasterDistance;
+                        c[3] += me_mvcost(s, tx * 8, ty * 8);       /* sic: the reference shifts this one by 3 (motion.cpp:1219) */
+                        if (c[3] < bcost) { bcost = c[3]; bx = tx; by = ty; }
+                    }
+                    else
+                        ME_COST_MV(tx, ty);
+                }
+        }
+        while (bDistance > 0)
+        {
+            bDistance = 0; bPointNr = 0;
+            me_star_pattern(sOff, bx, by, bcost, bPointNr, bDistance, 32, merange);
+            if (bDistance == 1)
+            {
+                if (!bPointNr) break;
+                int x1 = bx + me_offsets[(bPointNr - 1) * 2][0], y1 = by + me_offsets[(bPointNr - 1) * 2][1];
+                int x2 = bx + me_offsets[(bPointNr - 1) * 2 + 1][0], y2 = by + me_offsets[(bPointNr - 1) * 2 + 1][1];
+                if (me_in_range(s, x1, y1)) ME_COST_MV(x1, y1);
+                if (me_in_range(s, x2, y2)) ME_COST_MV(x2, y2);
+                break;
+            }
+        }
+        break;
+    }
+    default:    /* UMH / SEA / FULL are not implemented: flagged, never silently replaced */
+        if (xa_lane() == 0) { out->mv[0] = 0; out->mv[1] = 0; out->cost = -1; }
+        return;
+    }
+
+    /* motion.cpp:1473-1594 */
+    if (bprecost < bcost) { bx = bestprex; by = bestprey; bcost = bprecost; }
+    else { bx *= 4; by *= 4; }
+    const uint8_t* wl = me_workload[j.subme];
+    if (!bcost)
+        bcost = me_mvcost(s, bx, by);
+    else
+    {
+        bool hsatd = wl[4] != 0;
+        if (hsatd)
+            bcost = me_subpel_satd(bx, by) + me_mvcost(s, bx, by);
+        for (int iter = 0; iter < wl[0]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[1]; i++)
+            {
+                int qx = bx + me_square1[i][0] * 2, qy = by + me_square1[i][1] * 2;
+                if (qy < qminy || qy > qmaxy) continue;
+                int cost = (hsatd ? me_subpel_satd(qx, qy) : me_subpel_sad(qx, qy)) + me_mvcost(s, qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bx += me_square1[bdir][0] * 2; by += me_square1[bdir][1] * 2; }
+            else break;
+        }
+        if (!hsatd)
+            bcost = me_subpel_satd(bx, by) + me_mvcost(s, bx, by);
+        for (int iter = 0; iter < wl[2]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[3]; i++)
+            {
+                int qx = bx + me_square1[i][0], qy = by + me_square1[i][1];
+                if (qy < qminy || qy > qmaxy) continue;
+                int cost = me_subpel_satd(qx, qy) + me_mvcost(s, qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bx += me_square1[bdir][0]; by += me_square1[bdir][1]; }
+            else break;
+        }
+    }
+    if (xa_lane() == 0) { out->mv[0] = (int16_t)bx; out->mv[1] = (int16_t)by; out->cost = bcost; }
+}
+
+__global__ __launch_bounds__(64 * ME_WAVES) void k_me_search(MeParams p)
+{
+    char* smem = me_smem;
+    pixel* win = reinterpret_cast<pixel*>(smem);
+    pixel* fencT = win + p.maxWinW * p.maxWinH + 16;     /* +16: the dword reads may run past the last window sample */
+    int* counter = reinterpret_cast<int*>(fencT + 64 * 64);
+    const int sOff = (int)(reinterpret_cast<char*>(counter + 4) - smem) + (int)(threadIdx.x >> 6) * (int)sizeof(MeState);
+    MeState& s = *reinterpret_cast<MeState*>(smem + sOff);
+
+    const x265amd_me_group g = p.groups[blockIdx.x];
+    const pixel* refG = reinterpret_cast<const pixel*>(p.refs[g.ref]);
+    const int tid = threadIdx.x, nthr = 64 * ME_WAVES;
+
+    /* stage the reference window: rows of win_w samples, 4 samples per lane, coalesced along the row */
+    {
+        int gpr = g.win_w >> 2, total = gpr * g.win_h;
+        for (int i = tid; i < total; i += nthr)
+        {
+            int y = i / gpr, x = (i - y * gpr) << 2;
+            const pixel* src = refG + (long)(g.win_y + y) * p.stride + g.win_x + x;
+            pixel v[4];
+            __builtin_memcpy(v, src, sizeof(v));
+            __builtin_memcpy(win + y * g.win_w + x, v, sizeof(v));
+        }
+        for (int i = tid; i < 16 * 64; i += nthr)
+        {
+            int y = i >> 4, x = (i & 15) << 2;
+            pixel v[4];
+            __builtin_memcpy(v, p.fenc + (long)(g.fenc_y + y) * p.stride + g.fenc_x + x, sizeof(v));
+            __builtin_memcpy(fencT + y * 64 + x, v, sizeof(v));
+        }
+        if (tid == 0) *counter = 0;
+    }
+    __syncthreads();
+
+    const int lane = xa_lane();
+    for (;;)
+    {
+        int ji = 0;
+        if (lane == 0) ji = atomicAdd(counter, 1);
+        ji = __shfl(ji, 0, 64);
+        if (ji >= g.num_jobs) break;
+        const x265amd_me_job j = p.jobs[g.first_job + ji];
+        if (lane == 0)
+        {
+            s.win = win; s.winX = g.win_x; s.winY = g.win_y; s.winW = g.win_w; s.winH = g.win_h;
+            s.fencT = fencT; s.refG = refG; s.stride = p.stride;
+            s.px = j.x; s.py = j.y; s.w = j.w; s.h = j.h;
+            s.fx = j.x - g.fenc_x; s.fy = j.y - g.fenc_y;
+            s.cost = p.tables + (size_t)j.qp * ME_TBL_LEN + ME_TBL_HALF;
+            s.mvpx = j.mvp[0]; s.mvpy = j.mvp[1];
+            s.mnx = j.mvmin[0]; s.mny = j.mvmin[1]; s.mxx = j.mvmax[0]; s.mxy = j.mvmax[1];
+        }
+        xa_wave_sync();
+        me_search(sOff, j, p.out + g.first_job + ji);
+        xa_wave_sync();
+    }
+}
+
+/* =========================================================================================================
+ * host side
+ * ======================================================================================================= */
+/* x265_lambda_tab (constants.cpp:34-150): 2^(qp/6-2) * 2^(depth-8), tabulated to four decimals in the reference */
+static double me_lambda(int qp)
+{
+    double v = pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265AMD_DEPTH - 8));
+    return floor(v * 10000.0 + 0.5) / 10000.0;
+}
+
+/* BitCost::CalculateLogs + setQP (bitcost.cpp:30-58, :95-109) with the arithmetic of the reference build: the C `log`
+ * is the double function applied to the float-converted argument, the scale 2/ln2 is a float constant, the sum is
+ * rounded to float once, and the cost is double(bits) * lambda + 0.5 truncated to uint16 (capped at 2^15 - 1). */
+static void me_build_table(int qp, uint16_t* t /* ME_TBL_LEN */)
+{
+    const double lambda = me_lambda(qp);
+    const double log2_2 = (double)(float)(2.0 / log(2.0));
+    uint16_t* c = t + ME_TBL_HALF;
+    for (int i = 0; i <= ME_TBL_HALF; i++)
+    {
+        float bits = i ? (float)(log((double)(float)(i + 1)) * log2_2 + (double)1.718f) : 0.718f;
+        double v = (double)bits * lambda + 0.5;
+        if (v > 32767.0) v = 32767.0;
+        c[i] = c[-i] = (uint16_t)v;
+    }
+}
+
+extern "C" x265amd_me_ctx* x265amd_me_open(void)
+{
+    x265amd_me_ctx* ctx = new x265amd_me_ctx;
+    ctx->h_tables.resize((size_t)ME_QP_COUNT * ME_TBL_LEN);
+    for (int qp = 0; qp < ME_QP_COUNT; qp++)
+        me_build_table(qp, ctx->h_tables.data() + (size_t)qp * ME_TBL_LEN);
+    size_t bytes = ctx->h_tables.size() * sizeof(uint16_t);
+    if (hipMalloc((void**)&ctx->d_tables, bytes) != hipSuccess ||
+        hipMemcpy(ctx->d_tables, ctx->h_tables.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+    {
+        xa_fail(X265AMD_EHIP, "x265amd_me_open: cannot place the MV cost tables on the device");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void x265amd_me_close(x265amd_me_ctx* ctx)
+{
+    if (!ctx) return;
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    delete ctx;
+}
+
+extern "C" const uint16_t* x265amd_me_host_mvcost(x265amd_me_ctx* ctx, int qp)
+{
+    if (!ctx || qp < 0 || qp >= ME_QP_COUNT) return nullptr;
+    return ctx->h_tables.data() + (size_t)qp * ME_TBL_LEN;
+}
+
+extern "C" int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int max_win_w, int max_win_h, x265amd_me_group* groups, int32_t* order)
+{
+    if (!jobs || !groups || !order || n < 0 || max_win_w < 80 || max_win_h < 80 || (max_win_w & 3))
+        return xa_fail(X265AMD_EINVAL, "x265amd_me_plan: bad arguments");
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; i++)
+    {
+        idx[i] = i;
+        if ((jobs[i].x & 63) + jobs[i].w > 64 || (jobs[i].y & 63) + jobs[i].h > 64 || (jobs[i].x & 3) || (jobs[i].w & 3) || (jobs[i].h & 3) ||
+            jobs[i].num_cand > X265AMD_ME_MAX_CAND || jobs[i].subme > 7 || jobs[i].qp >= ME_QP_COUNT)
+            return xa_fail(X265AMD_EINVAL, "x265amd_me_plan: job outside the supported domain (PU must lie inside one 64x64 CTU tile, x%4==0)");
+    }
+    auto key = [&](int i) { return ((int64_t)(jobs[i].y >> 6) << 32) | (uint32_t)(jobs[i].x >> 6); };
+    /* largest PUs first inside a tile so the long searches start early */
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+        int64_t ka = key(a), kb = key(b);
+        if (ka != kb) return ka < kb;
+        return jobs[a].w * jobs[a].h > jobs[b].w * jobs[b].h; });
+    int ng = 0;
+    for (int i = 0; i < n;)
+    {
+        int e = i;
+        int x0 = 1 << 30, y0 = 1 << 30, x1 = -(1 << 30), y1 = -(1 << 30);
+        while (e < n && key(idx[e]) == key(idx[i]))
+        {
+            const x265amd_me_job& j = jobs[idx[e]];
+            /* search area of the job incl. the 8-tap margins and the +-2 the hexagon may step outside */
+            x0 = std::min(x0, j.x + j.mvmin[0] - 6); y0 = std::min(y0, j.y + j.mvmin[1] - 6);
+            x1 = std::max(x1, j.x + j.w + j.mvmax[0] + 10); y1 = std::max(y1, j.y + j.h + j.mvmax[1] + 7);
+            order[e] = idx[e];
+            e++;
+        }
+        x265amd_me_group& g = groups[ng++];
+        g.first_job = i; g.num_jobs = e - i; g.ref = ref;
+        g.fenc_x = (int16_t)((jobs[idx[i]].x >> 6) << 6); g.fenc_y = (int16_t)((jobs[idx[i]].y >> 6) << 6);
+        int w = (x1 - x0 + 3) & ~3, h = y1 - y0;
+        if (w > max_win_w) { x0 += (w - max_win_w) / 2; w = max_win_w; }
+        if (h > max_win_h) { y0 += (h - max_win_h) / 2; h = max_win_h; }
+        g.win_x = (int16_t)x0; g.win_y = (int16_t)y0; g.win_w = (int16_t)w; g.win_h = (int16_t)h;
+        i = e;
+    }
+    return ng;
+}
+
+extern "C" int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_fenc, const uint64_t* d_refs, intptr_t stride,
+                                 const x265amd_me_group* d_groups, int num_groups, const x265amd_me_job* d_jobs, x265amd_me_result* d_out,
+                                 int max_win_w, int max_win_h)
+{
+    if (!ctx || !d_fenc || !d_refs || !d_groups || !d_jobs || !d_out || num_groups < 0 || (max_win_w & 3))
+        return xa_fail(X265AMD_EINVAL, "x265amd_me_search: bad arguments");
+    if (num_groups == 0) return X265AMD_OK;
+    size_t lds = ((size_t)max_win_w * max_win_h + 16 + 64 * 64) * sizeof(pixel) + 16 + ME_WAVES * sizeof(MeState);
+    if (lds > 160 * 1024) return xa_fail(X265AMD_EINVAL, "x265amd_me_search: window does not fit the 160 KiB LDS");
+    static thread_local size_t configured = 0;
+    if (lds > configured)
+    {
+        XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_me_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    MeParams p;
+    p.fenc = d_fenc; p.refs = d_refs; p.stride = (int)stride; p.groups = d_groups; p.jobs = d_jobs; p.out = d_out;
+    p.tables = ctx->d_tables; p.maxWinW = max_win_w; p.maxWinH = max_win_h;
+    hipLaunchKernelGGL(k_me_search, dim3(num_groups), dim3(64 * ME_WAVES), lds, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
