@@ -156,7 +156,7 @@ def main():
         rt = reftab[cur]
         rc = me.lib.x265amd_me_search(me.ctx, C.c_void_p(stream.cuda_stream), C.c_void_p(d_frames[cur].data_ptr() + origin),
                                       C.c_void_p(rt.data_ptr()), C.c_int64(stride), C.c_void_p(d_groups.data_ptr()), len(groups),
-                                      C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), MAX_WIN[0], MAX_WIN[1])
+                                      C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), MAX_WIN[0], MAX_WIN[1], 0)
         assert rc == 0, me.lib.x265amd_last_error()
         if world > 1:
             # exchange step of the frame-parallel design: every rank publishes the picture it just finished so that all

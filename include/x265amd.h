@@ -227,10 +227,15 @@ const uint16_t* x265amd_me_host_mvcost(x265amd_me_ctx* ctx, int qp);
 int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int max_win_w, int max_win_h, x265amd_me_group* groups, int32_t* order);
 /* Runs all groups.  d_fenc / d_refs[i]: device addresses of sample (0,0) of the padded source / reference luma
  * planes, all with the same `stride` (elements).  d_refs, d_groups, d_jobs, d_out: device arrays.  max_win_w/h:
- * the largest window among the groups (LDS is sized for it).  Asynchronous on `stream`. */
+ * the largest window among the groups (LDS is sized for it).  Asynchronous on `stream`.  Two launches: the
+ * window-resident kernel, then a pass that redoes, reading the reference from HBM, the jobs whose search left the
+ * staged window -- results never depend on the window size. */
 int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_fenc, const uint64_t* d_refs, intptr_t stride,
                       const x265amd_me_group* d_groups, int num_groups, const x265amd_me_job* d_jobs, x265amd_me_result* d_out,
-                      int max_win_w, int max_win_h);
+                      int max_win_w, int max_win_h, int flags);
+/* flags: X265AMD_ME_FLAG_STAR must be set when any job uses X265AMD_ME_STAR (selects the kernel variant that carries
+ * the star search; without it such jobs still produce exact results through the slower second pass). */
+#define X265AMD_ME_FLAG_STAR 1
 
 #ifdef __cplusplus
 }

@@ -639,7 +639,7 @@ class HipME:
         t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).cuda()
         return t
 
-    def search(self, d_cur, d_refs, stride, origin_elems, itemsize, groups, packed_ordered, max_win=(192, 192), stream=None):
+    def search(self, d_cur, d_refs, stride, origin_elems, itemsize, groups, packed_ordered, max_win=(192, 192), stream=None, flags=None):
         """d_cur / d_refs: uploaded planes (uint8 tensors); returns result tensor (device, bytes)"""
         torch = self.torch
         d_groups = self.upload(groups)
@@ -647,19 +647,21 @@ class HipME:
         d_out = torch.zeros(len(packed_ordered) * 8, dtype=torch.uint8, device="cuda")
         refs = np.array([r.data_ptr() + origin_elems * itemsize for r in d_refs], np.uint64)
         d_reftab = self.upload(refs)
+        if flags is None:
+            flags = 1 if (packed_ordered["method"] == ME_STAR).any() else 0
         rc = self.lib.x265amd_me_search(self.ctx, C.c_void_p(stream or 0), C.c_void_p(d_cur.data_ptr() + origin_elems * itemsize),
                                         C.c_void_p(d_reftab.data_ptr()), C.c_int64(stride), C.c_void_p(d_groups.data_ptr()), len(groups),
-                                        C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), max_win[0], max_win[1])
+                                        C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), max_win[0], max_win[1], flags)
         assert rc == 0, self.lib.x265amd_last_error()
         self._keep = (d_groups, d_jobs, d_reftab)
         return d_out
 
-    def run(self, cur, ref, stride, origin, jobs, max_win=(192, 192)):
+    def run(self, cur, ref, stride, origin, jobs, max_win=(192, 192), flags=None):
         """host arrays in, int array [n,3] (mvx, mvy, cost) out, in the order of `jobs`"""
         packed = me_pack_jobs(jobs)
         groups, order = self.plan(packed, 0, max_win)
         d_cur, d_ref = self.upload(cur), self.upload(ref)
-        d_out = self.search(d_cur, [d_ref], stride, origin, cur.itemsize, groups, packed[order], max_win)
+        d_out = self.search(d_cur, [d_ref], stride, origin, cur.itemsize, groups, packed[order], max_win, flags=flags)
         self.torch.cuda.synchronize()
         res = d_out.cpu().numpy().view(ME_RESULT_DT)
         out = np.zeros((len(jobs), 3), np.int32)

@@ -7,14 +7,14 @@ SRC=$HERE/csrc
 OUT=$HERE/lib
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -I$HERE/../include"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -I$HERE/../include ${X265AMD_EXTRA_FLAGS:-}"
 SRCS=$(ls "$SRC"/*.hip)
 build_one() {
     local depth=$1 name=$2
     local lib=$OUT/$name
     local newest
     newest=$(ls -t "$SRC"/* "$HERE"/../include/*.h | head -1)
-    if [ -f "$lib" ] && [ "$lib" -nt "$newest" ]; then return 0; fi
+    if [ -z "${X265AMD_FORCE:-}" ] && [ -f "$lib" ] && [ "$lib" -nt "$newest" ]; then return 0; fi
     local objs=""
     for f in $SRCS; do
         local o=$OUT/$(basename "$f" .hip).$depth.o
@@ -24,6 +24,7 @@ build_one() {
     wait
     $HIPCC --offload-arch=gfx950 -shared -o "$lib" $objs
 }
-build_one 8 libx265amd_main.so
-build_one 10 libx265amd_main10.so
+for d in ${X265AMD_DEPTHS:-8 10}; do
+    if [ "$d" = 8 ]; then build_one 8 libx265amd_main.so; else build_one "$d" libx265amd_main$d.so; fi
+done
 echo "built: $(ls "$OUT"/*.so | tr '\n' ' ')"

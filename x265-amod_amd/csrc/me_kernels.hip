@@ -17,7 +17,13 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 
-#define ME_WAVES 4
+#ifndef ME_WAVES
+#define ME_WAVES 8
+#endif
+#ifndef ME_MIN_WAVES_PER_EU
+#define ME_MIN_WAVES_PER_EU 4
+#endif
+#define ME_DEFERRED ((int)0x80000000)   /* result marker: redo this job with the direct-from-HBM kernel */
 #define ME_QP_COUNT 70              /* QP_MAX_MAX + 1 (reference: common/constants.h) */
 #define ME_TBL_HALF 65536           /* 2 * BC_MAX_MV: table index range is [-65536, 65536] (bitcost.h:81) */
 #define ME_TBL_LEN (2 * ME_TBL_HALF + 1)
@@ -53,12 +59,16 @@ struct MeState
     const uint16_t* cost;
     int mvpx, mvpy;
     int mnx, mny, mxx, mxy;
+    int oob;            /* set by the window-resident kernel when a candidate left the staged window: the job is redone
+                           by the direct-from-HBM kernel (k_me_deferred) */
 };
 
 extern __shared__ __attribute__((aligned(16))) char me_smem[];
 /* the per-wavefront state lives in LDS (one MeState per wave): the search helpers are real functions (not inlined
  * into the ~60 call sites of the search) and find it through its LDS byte offset */
 #define ME_S(off) (*reinterpret_cast<const MeState*>(me_smem + (off)))
+#define ME_OOB(off) (reinterpret_cast<MeState*>(me_smem + (off))->oob = 1)
+#define ME_OOB_COST 0x3fffffff      /* never wins a comparison; the job's result is discarded anyway */
 
 XA_DEV int me_mvcost(const MeState& s, int qx, int qy) { return (uint16_t)(s.cost[qx - s.mvpx] + s.cost[qy - s.mvpy]); }
 
@@ -98,13 +108,15 @@ template<bool INWIN> XA_DEV int me_sad_fpel(const MeState& s, int X, int Y)
     return xa_wave_sum(sum);
 }
 
-__device__ __noinline__ int me_sad_at_f(int sOff, int mx, int my)     /* full-pel MV (mx,my) */
+template<bool SLOW> __device__ __noinline__ int me_sad_at_f(int sOff, int mx, int my)     /* full-pel MV (mx,my) */
 {
     const MeState& s = ME_S(sOff);
     int X = s.px + mx, Y = s.py + my;
+    if (SLOW) return me_sad_fpel<false>(s, X, Y);
     /* the dword reads of the LDS path touch up to 3 samples past the block's right edge */
     if (me_inwin(s, X, Y, X + s.w + 4, Y + s.h)) return me_sad_fpel<true>(s, X, Y);
-    return me_sad_fpel<false>(s, X, Y);
+    ME_OOB(sOff);
+    return ME_OOB_COST;
 }
 
 /* one interpolated luma sample at integer position (X,Y) + fraction (xf,yf)/4:
@@ -117,7 +129,7 @@ template<bool INWIN> XA_DEV int me_pred(const MeState& s, int X, int Y, int xf, 
     if (!yf || !xf)
     {
         int sum = 0;
-#pragma unroll
+#pragma unroll 1
         for (int t = 0; t < 8; t++)
             sum += (yf ? me_ref<INWIN>(s, X, Y - 3 + t) * cy[t] : me_ref<INWIN>(s, X - 3 + t, Y) * cx[t]);
         int16_t val = (int16_t)((sum + (1 << (XA_IF_FILTER_PREC - 1))) >> XA_IF_FILTER_PREC);
@@ -127,10 +139,11 @@ template<bool INWIN> XA_DEV int me_pred(const MeState& s, int X, int Y, int xf, 
     const int shiftH = XA_IF_FILTER_PREC - headRoom, offH = (int)((unsigned)-XA_IF_INTERNAL_OFFS << shiftH);
     const int shiftV = XA_IF_FILTER_PREC + headRoom, offV = (1 << (shiftV - 1)) + (XA_IF_INTERNAL_OFFS << XA_IF_FILTER_PREC);
     int sum = 0;
+#pragma unroll 1
     for (int r = 0; r < 8; r++)
     {
         int hs = 0;
-#pragma unroll
+#pragma unroll 1
         for (int t = 0; t < 8; t++)
             hs += me_ref<INWIN>(s, X - 3 + t, Y - 3 + r) * cx[t];
         sum += (int)(int16_t)((hs + offH) >> shiftH) * cy[r];
@@ -140,8 +153,9 @@ template<bool INWIN> XA_DEV int me_pred(const MeState& s, int X, int Y, int xf, 
 }
 
 /* subpelCompare (motion.cpp:1596-1623) with cmp = sad or satd, quarter-pel MV (qx,qy) */
-template<bool INWIN, bool SATD> XA_DEV int me_subpel_cmp(const MeState& s, int qx, int qy)
+template<bool INWIN, bool SATD> __device__ __noinline__ int me_subpel_cmp(int sOff, int qx, int qy)
 {
+    const MeState& s = ME_S(sOff);
     int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2), xf = qx & 3, yf = qy & 3, sum = 0;
     if (SATD)       /* one lane per 4x4 tile: pixel.cpp:210-297 */
     {
@@ -152,9 +166,13 @@ template<bool INWIN, bool SATD> XA_DEV int me_subpel_cmp(const MeState& s, int q
             int d[4][4];
 #pragma unroll
             for (int y = 0; y < 4; y++)
-#pragma unroll
+            {
+                int row[4];
+#pragma unroll 1
                 for (int x = 0; x < 4; x++)
-                    d[y][x] = (int)s.fencT[(s.fy + 4 * ty + y) * 64 + s.fx + 4 * tx + x] - me_pred<INWIN>(s, X0 + 4 * tx + x, Y0 + 4 * ty + y, xf, yf);
+                    row[x] = (int)s.fencT[(s.fy + 4 * ty + y) * 64 + s.fx + 4 * tx + x] - me_pred<INWIN>(s, X0 + 4 * tx + x, Y0 + 4 * ty + y, xf, yf);
+                d[y][0] = row[0]; d[y][1] = row[1]; d[y][2] = row[2]; d[y][3] = row[3];
+            }
             int tt[4][4];
 #pragma unroll
             for (int y = 0; y < 4; y++)
@@ -184,26 +202,279 @@ template<bool INWIN, bool SATD> XA_DEV int me_subpel_cmp(const MeState& s, int q
     return xa_wave_sum(sum);
 }
 
-#define me_sad_at(s, mx, my) me_sad_at_f(sOff, mx, my)
-template<bool SATD> __device__ __noinline__ int me_subpel_f(int sOff, int qx, int qy)
+#if XA_DEPTH == 8
+/* ---- 8-bit fast paths: the staged window is read as dwords (4 samples), v_alignbyte realigns, v_dot4_u32_u8 does
+ *      the 8-tap horizontal filter as (positive taps) - (negative taps) ---- */
+XA_DEV uint32_t me_win_dword(const uint32_t* wd, int o)     /* samples o..o+3 of the window (o = byte offset) */
 {
-    const MeState& s = ME_S(sOff);
-    if (!SATD && !((qx | qy) & 3)) return me_sad_at(s, qx >> 2, qy >> 2);
-    int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
-    if (me_inwin(s, X0 - 3, Y0 - 3, X0 + s.w + 4, Y0 + s.h + 4)) return me_subpel_cmp<true, SATD>(s, qx, qy);
-    return me_subpel_cmp<false, SATD>(s, qx, qy);
+    const uint32_t* p = wd + (o >> 2);
+    return __builtin_amdgcn_alignbyte(p[1], p[0], o & 3);
 }
 
-#define me_subpel_sad(qx, qy) me_subpel_f<false>(sOff, qx, qy)
-#define me_subpel_satd(qx, qy) me_subpel_f<true>(sOff, qx, qy)
+struct MeTaps { uint32_t pos[4][2], neg[4][2]; };
+constexpr MeTaps me_make_taps()
+{
+    MeTaps t = {};
+    constexpr int lf[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+    for (int f = 0; f < 4; f++)
+        for (int k = 0; k < 8; k++)
+        {
+            int c = lf[f][k];
+            if (c > 0) t.pos[f][k >> 2] |= (uint32_t)c << (8 * (k & 3));
+            if (c < 0) t.neg[f][k >> 2] |= (uint32_t)(-c) << (8 * (k & 3));
+        }
+    return t;
+}
+__device__ const MeTaps me_taps = me_make_taps();
+
+/* vertical taps arranged by SOURCE row: c[yf][rr] packs, for output rows r = 0..3 of a 4x4 tile, the tap
+ * g_lumaFilter[yf][rr - r] (0 when rr - r is outside 0..7) that source row rr (= by-3+rr) contributes */
+struct MeVTaps { uint32_t c[4][11]; };
+constexpr MeVTaps me_make_vtaps()
+{
+    MeVTaps t = {};
+    constexpr int lf[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+    for (int f = 0; f < 4; f++)
+        for (int rr = 0; rr < 11; rr++)
+            for (int r = 0; r < 4; r++)
+            {
+                int k = rr - r;
+                int c = (k >= 0 && k < 8) ? lf[f][k] : 0;
+                t.c[f][rr] |= (uint32_t)(uint8_t)(int8_t)c << (8 * r);
+            }
+    return t;
+}
+__device__ const MeVTaps me_vtaps = me_make_vtaps();
+
+/* 8-tap horizontal filter sums of 4 consecutive outputs; d0..d2 hold samples x-3 .. x+8 of the row */
+XA_DEV void me_hfilt4(uint32_t d0, uint32_t d1, uint32_t d2, int xf, int out[4])
+{
+    const uint32_t pl = me_taps.pos[xf][0], ph = me_taps.pos[xf][1], nl = me_taps.neg[xf][0], nh = me_taps.neg[xf][1];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+        uint32_t a = j ? __builtin_amdgcn_alignbyte(d1, d0, j) : d0;
+        uint32_t b = j ? __builtin_amdgcn_alignbyte(d2, d1, j) : d1;
+        uint32_t pos = __builtin_amdgcn_udot4(a, pl, __builtin_amdgcn_udot4(b, ph, 0u, false), false);
+        uint32_t neg = __builtin_amdgcn_udot4(a, nl, __builtin_amdgcn_udot4(b, nh, 0u, false), false);
+        out[j] = (int)pos - (int)neg;
+    }
+}
+
+/* prediction of one 4x4 tile whose top-left integer sample is window position (bx,by), fraction (xf,yf)/4:
+ * luma_hpp / luma_vpp / luma_hvpp (ipfilter.cpp:79-120, :169-210, :370-378).  The vertical pass is streamed: each of
+ * the 11 source rows is filtered horizontally once and immediately accumulated into the (up to 4) output rows it
+ * contributes to, so only the 16 accumulators stay live. */
+XA_DEV void me_pred_tile(const uint32_t* wd, int winW, int bx, int by, int xf, int yf, int pred[4][4])
+{
+    if (!yf)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            if (!xf)
+            {
+                uint32_t d = me_win_dword(wd, (by + r) * winW + bx);
+#pragma unroll
+                for (int x = 0; x < 4; x++) pred[r][x] = (int)__builtin_amdgcn_ubfe(d, 8 * x, 8);
+            }
+            else
+            {
+                int o = (by + r) * winW + bx - 3;
+                int hs[4];
+                me_hfilt4(me_win_dword(wd, o), me_win_dword(wd, o + 4), me_win_dword(wd, o + 8), xf, hs);
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    pred[r][x] = xa_clip3(0, 255, (int)(int16_t)((hs[x] + 32) >> 6));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) pred[r][x] = 0;
+    /* not unrolled on purpose: one source row in flight keeps the routine near 40 VGPRs (occupancy) */
+#pragma unroll 1
+    for (int rr = 0; rr < 11; rr++)     /* source rows by-3 .. by+7 */
+    {
+        int iv[4];
+        if (!xf)
+        {
+            uint32_t d = me_win_dword(wd, (by - 3 + rr) * winW + bx);
+#pragma unroll
+            for (int x = 0; x < 4; x++) iv[x] = (int)__builtin_amdgcn_ubfe(d, 8 * x, 8);
+        }
+        else
+        {
+            /* hps with row extension: shift 0, offset -8192 at 8 bits (ipfilter.cpp:122-167) */
+            int o = (by - 3 + rr) * winW + bx - 3;
+            me_hfilt4(me_win_dword(wd, o), me_win_dword(wd, o + 4), me_win_dword(wd, o + 8), xf, iv);
+#pragma unroll
+            for (int x = 0; x < 4; x++) iv[x] = (int)(int16_t)(iv[x] - XA_IF_INTERNAL_OFFS);
+        }
+        const uint32_t cw = me_vtaps.c[yf][rr];    /* taps of source row rr for output rows 0..3, one signed byte each */
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int c = (int)(int8_t)(cw >> (8 * r));
+#pragma unroll
+            for (int x = 0; x < 4; x++) pred[r][x] += iv[x] * c;
+        }
+    }
+    /* vpp: (sum + 32) >> 6 ; vsp after hps: (sum + 2048 + (8192 << 6)) >> 12 */
+    const int off = xf ? (1 << 11) + (XA_IF_INTERNAL_OFFS << XA_IF_FILTER_PREC) : 32, sh = xf ? 12 : 6;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            pred[r][x] = xa_clip3(0, 255, (int)(int16_t)((pred[r][x] + off) >> sh));
+}
+
+/* subpelCompare (motion.cpp:1596-1623) on the LDS window, one lane per 4x4 tile */
+template<bool SATD> XA_DEV int me_subpel_cmp_fast(const MeState& s, int qx, int qy)
+{
+    const uint32_t* wd = reinterpret_cast<const uint32_t*>(s.win);
+    const uint32_t* fd = reinterpret_cast<const uint32_t*>(s.fencT);
+    int X0 = s.px + (qx >> 2) - s.winX, Y0 = s.py + (qy >> 2) - s.winY, xf = qx & 3, yf = qy & 3, sum = 0;
+    int tw = s.w >> 2, nt = tw * (s.h >> 2), inv = ((1 << 20) + tw - 1) / tw;
+    for (int t = xa_lane(); t < nt; t += XA_WAVE)
+    {
+        int ty = (t * inv) >> 20, tx = t - ty * tw;
+        int pred[4][4];
+        me_pred_tile(wd, s.winW, X0 + 4 * tx, Y0 + 4 * ty, xf, yf, pred);
+        int d[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            uint32_t f = fd[(s.fy + 4 * ty + y) * 16 + (s.fx >> 2) + tx];
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                d[y][x] = (int)__builtin_amdgcn_ubfe(f, 8 * x, 8) - pred[y][x];
+        }
+        if (SATD)
+        {
+            int tt[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                int s01 = d[y][0] + d[y][1], e01 = d[y][0] - d[y][1], s23 = d[y][2] + d[y][3], e23 = d[y][2] - d[y][3];
+                tt[y][0] = s01 + s23; tt[y][1] = s01 - s23; tt[y][2] = e01 + e23; tt[y][3] = e01 - e23;
+            }
+            int ts = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                int s01 = tt[0][x] + tt[1][x], e01 = tt[0][x] - tt[1][x], s23 = tt[2][x] + tt[3][x], e23 = tt[2][x] - tt[3][x];
+                ts += abs(s01 + s23) + abs(s01 - s23) + abs(e01 + e23) + abs(e01 - e23);
+            }
+            sum += ts >> 1;
+        }
+        else
+        {
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) sum += abs(d[y][x]);
+        }
+    }
+    return xa_wave_sum(sum);
+}
+#endif /* XA_DEPTH == 8 */
+
+template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_f(int sOff, int qx, int qy)
+{
+    const MeState& s = ME_S(sOff);
+    if (!SATD && !((qx | qy) & 3)) return me_sad_at_f<SLOW>(sOff, qx >> 2, qy >> 2);
+    if (SLOW) return me_subpel_cmp<false, SATD>(sOff, qx, qy);
+    int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
+    /* +8 on the right: the dword reads of the fast path touch samples up to x+8 of the last tile */
+    if (me_inwin(s, X0 - 3, Y0 - 3, X0 + s.w + 8, Y0 + s.h + 4))
+    {
+#if XA_DEPTH == 8
+        return me_subpel_cmp_fast<SATD>(s, qx, qy);
+#else
+        return me_subpel_cmp<true, SATD>(sOff, qx, qy);
+#endif
+    }
+    ME_OOB(sOff);
+    return ME_OOB_COST;
+}
+
+/* SAD + MV cost of up to four full-pel candidates in one call (the reference's sad_x3 / sad_x4 batches,
+ * motion.cpp:271-360).  Candidates are packed (my << 16) | (mx & 0xffff).  Returns, in lane k, the cost of candidate k.
+ * Small PUs run several candidates side by side in one pass: a PU with <= 16 four-sample groups (8x8) evaluates
+ * four candidates at once in the four 16-lane quarters of the wavefront. */
+#define ME_PK(mx, my) ((int)(((uint32_t)(my) << 16) | ((uint32_t)(mx) & 0xffffu)))
+template<bool SLOW> __device__ __noinline__ int me_cost_multi_f(int sOff, int n, int m0, int m1, int m2, int m3)
+{
+    const MeState& s = ME_S(sOff);
+    const int lane = xa_lane();
+    int res = 0x7fffffff;
+#if XA_DEPTH == 8
+    const int w = s.w, h = s.h, gpr = w >> 2, ng = gpr * h;
+    bool fast = !SLOW && (w & (w - 1)) == 0;
+    for (int k = 0; k < n; k++)
+    {
+        int mk = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3;
+        int X = s.px + (int)(int16_t)(mk & 0xffff), Y = s.py + (mk >> 16);
+        fast = fast && me_inwin(s, X, Y, X + w + 4, Y + h);
+    }
+    if (fast)
+    {
+        const uint32_t* wd = reinterpret_cast<const uint32_t*>(s.win);
+        const uint32_t* fd = reinterpret_cast<const uint32_t*>(s.fencT);
+        const int lg = 31 - __clz(gpr);
+        const int lgseg = ng <= 16 ? 4 : ng <= 32 ? 5 : 6, seg = 1 << lgseg, cpp = 64 >> lgseg;
+        for (int c0 = 0; c0 < n; c0 += cpp)
+        {
+            int cl = c0 + (lane >> lgseg);
+            int mk = cl == 0 ? m0 : cl == 1 ? m1 : cl == 2 ? m2 : m3;
+            if (cl >= n) mk = m0;
+            int mx = (int)(int16_t)(mk & 0xffff), my = mk >> 16;
+            int X = s.px + mx - s.winX, Y = s.py + my - s.winY, sum = 0;
+            for (int gi = lane & (seg - 1); gi < ng; gi += seg)
+            {
+                int y = gi >> lg, x4 = gi & (gpr - 1);
+                uint32_t fv = fd[(s.fy + y) * 16 + (s.fx >> 2) + x4];
+                uint32_t rv = me_win_dword(wd, (Y + y) * s.winW + X + 4 * x4);
+                sum = __builtin_amdgcn_sad_u8(fv, rv, sum);
+            }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
+            if (lgseg >= 5) sum += __shfl_xor(sum, 16, 64);
+            if (lgseg >= 6) sum += __shfl_xor(sum, 32, 64);
+            int cost = sum + me_mvcost(s, mx * 4, my * 4);
+            for (int jj = 0; jj < cpp && c0 + jj < n; jj++)
+            {
+                int v = __shfl(cost, jj << lgseg, 64);
+                if (lane == c0 + jj) res = v;
+            }
+        }
+        return res;
+    }
+#endif
+    for (int k = 0; k < n; k++)
+    {
+        int mk = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3;
+        int mx = (int)(int16_t)(mk & 0xffff), my = mk >> 16;
+        int c = me_sad_at_f<SLOW>(sOff, mx, my) + me_mvcost(s, mx * 4, my * 4);
+        if (lane == k) res = c;
+    }
+    return res;
+}
+#define ME_LANE(v, k) __builtin_amdgcn_readlane((v), (k))
+
+#define me_subpel_sad(qx, qy) me_subpel_f<false, SLOW>(sOff, qx, qy)
+#define me_subpel_satd(qx, qy) me_subpel_f<true, SLOW>(sOff, qx, qy)
 XA_DEV bool me_in_range(const MeState& s, int x, int y) { return x >= s.mnx && x <= s.mxx && y >= s.mny && y <= s.mxy; }
 
-#define ME_COST(mx, my) (me_sad_at(s, (mx), (my)) + me_mvcost(s, (mx) * 4, (my) * 4))
+#define ME_COST(mx, my) ME_LANE(me_cost_multi_f<SLOW>(sOff, 1, ME_PK(mx, my), 0, 0, 0), 0)
+#define me_sad_at(s, mx, my) me_sad_at_f<SLOW>(sOff, mx, my)
 #define ME_COST_MV(mx, my) do { int c_ = ME_COST(mx, my); if (c_ < bcost) { bcost = c_; bx = (mx); by = (my); } } while (0)
 #define ME_COST_PT(mx, my, point, dist) do { int c_ = ME_COST(mx, my); if (c_ < bcost) { bcost = c_; bx = (mx); by = (my); bPointNr = (point); bDistance = (dist); } } while (0)
 
 /* StarPatternSearch: motion.cpp:387-629 (the x4 batches evaluate the same points in the same order) */
-__device__ __noinline__ void me_star_pattern(int sOff, int& bx, int& by, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
+template<bool SLOW> __device__ __noinline__ void me_star_pattern(int sOff, int& bx, int& by, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
 {
     const MeState& s = ME_S(sOff);
     const int ox = bx, oy = by;
@@ -295,7 +566,7 @@ __device__ const uint8_t me_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 
                                                { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
 
 /* MotionEstimate::motionEstimate: motion.cpp:764-1594 (full-resolution reference, one slice, luma only) */
-__device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* out)
+template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* out)
 {
     const MeState& s = ME_S(sOff);
     const int qminx = s.mnx * 4, qminy = s.mny * 4, qmaxx = s.mxx * 4, qmaxy = s.mxy * 4;
@@ -310,7 +581,7 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
         bcost = ME_COST(bx, by);
     if (pmx | pmy)
     {
-        int cost = me_sad_at(s, 0, 0) + me_mvcost(s, 0, 0);
+        int cost = ME_COST(0, 0);
         if (cost < bcost)
         {
             bcost = cost;
@@ -335,7 +606,8 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
         int i = merange;
         do
         {
-            int c0 = ME_COST(bx, by - 1), c1 = ME_COST(bx, by + 1), c2 = ME_COST(bx - 1, by), c3 = ME_COST(bx + 1, by);
+            int cv = me_cost_multi_f<SLOW>(sOff, 4, ME_PK(bx, by - 1), ME_PK(bx, by + 1), ME_PK(bx - 1, by), ME_PK(bx + 1, by));
+            int c0 = ME_LANE(cv, 0), c1 = ME_LANE(cv, 1), c2 = ME_LANE(cv, 2), c3 = ME_LANE(cv, 3);
             int packed = bcost << 4;
             if (by - 1 >= s.mny && by - 1 <= s.mxy && (c0 << 4) + 1 < packed) packed = (c0 << 4) + 1;
             if (by + 1 >= s.mny && by + 1 <= s.mxy && (c1 << 4) + 3 < packed) packed = (c1 << 4) + 3;
@@ -351,8 +623,9 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
     }
     case X265AMD_ME_HEX:    /* motion.cpp:879-987 */
     {
-        int c0, c1, c2, c3, packed, dir;
-        c0 = ME_COST(bx - 2, by); c1 = ME_COST(bx - 1, by + 2); c2 = ME_COST(bx + 1, by + 2);
+        int c0, c1, c2, c3, packed, dir, cv;
+        cv = me_cost_multi_f<SLOW>(sOff, 3, ME_PK(bx - 2, by), ME_PK(bx - 1, by + 2), ME_PK(bx + 1, by + 2), 0);
+        c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2);
         packed = bcost << 3;
         if (by >= s.mny && by <= s.mxy && (c0 << 3) + 2 < packed) packed = (c0 << 3) + 2;
         if (by + 2 >= s.mny && by + 2 <= s.mxy)
@@ -360,7 +633,8 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
             if ((c1 << 3) + 3 < packed) packed = (c1 << 3) + 3;
             if ((c2 << 3) + 4 < packed) packed = (c2 << 3) + 4;
         }
-        c0 = ME_COST(bx + 2, by); c1 = ME_COST(bx + 1, by - 2); c2 = ME_COST(bx - 1, by - 2);
+        cv = me_cost_multi_f<SLOW>(sOff, 3, ME_PK(bx + 2, by), ME_PK(bx + 1, by - 2), ME_PK(bx - 1, by - 2), 0);
+        c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2);
         if (by >= s.mny && by <= s.mxy && (c0 << 3) + 5 < packed) packed = (c0 << 3) + 5;
         if (by - 2 >= s.mny && by - 2 <= s.mxy)
         {
@@ -375,9 +649,9 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
                 bx += me_hex2[dir + 1][0]; by += me_hex2[dir + 1][1];
                 for (int i = (merange >> 1) - 1; i > 0 && me_in_range(s, bx, by); i--)
                 {
-                    int cc[3];
-                    for (int k = 0; k < 3; k++)
-                        cc[k] = ME_COST(bx + me_hex2[dir + k][0], by + me_hex2[dir + k][1]);
+                    cv = me_cost_multi_f<SLOW>(sOff, 3, ME_PK(bx + me_hex2[dir][0], by + me_hex2[dir][1]), ME_PK(bx + me_hex2[dir + 1][0], by + me_hex2[dir + 1][1]),
+                                         ME_PK(bx + me_hex2[dir + 2][0], by + me_hex2[dir + 2][1]), 0);
+                    int cc[3] = { ME_LANE(cv, 0), ME_LANE(cv, 1), ME_LANE(cv, 2) };
                     packed &= ~7;
                     for (int k = 0; k < 3; k++)
                         if (by + me_hex2[dir + k][1] >= s.mny && by + me_hex2[dir + k][1] <= s.mxy && (cc[k] << 3) + k + 1 < packed)
@@ -392,13 +666,15 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
         bcost = packed >> 3;
         /* square refine */
         dir = 0;
-        c0 = ME_COST(bx, by - 1); c1 = ME_COST(bx, by + 1); c2 = ME_COST(bx - 1, by); c3 = ME_COST(bx + 1, by);
+        cv = me_cost_multi_f<SLOW>(sOff, 4, ME_PK(bx, by - 1), ME_PK(bx, by + 1), ME_PK(bx - 1, by), ME_PK(bx + 1, by));
+        c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2); c3 = ME_LANE(cv, 3);
         bool upOk = by - 1 >= s.mny && by - 1 <= s.mxy, dnOk = by + 1 >= s.mny && by + 1 <= s.mxy;
         if (upOk && c0 < bcost) { bcost = c0; dir = 1; }
         if (dnOk && c1 < bcost) { bcost = c1; dir = 2; }
         if (c2 < bcost) { bcost = c2; dir = 3; }
         if (c3 < bcost) { bcost = c3; dir = 4; }
-        c0 = ME_COST(bx - 1, by - 1); c1 = ME_COST(bx - 1, by + 1); c2 = ME_COST(bx + 1, by - 1); c3 = ME_COST(bx + 1, by + 1);
+        cv = me_cost_multi_f<SLOW>(sOff, 4, ME_PK(bx - 1, by - 1), ME_PK(bx - 1, by + 1), ME_PK(bx + 1, by - 1), ME_PK(bx + 1, by + 1));
+        c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2); c3 = ME_LANE(cv, 3);
         if (upOk && c0 < bcost) { bcost = c0; dir = 5; }
         if (dnOk && c1 < bcost) { bcost = c1; dir = 6; }
         if (upOk && c2 < bcost) { bcost = c2; dir = 7; }
@@ -407,10 +683,11 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
         break;
     }
     case X265AMD_ME_STAR:   /* motion.cpp:1156-1265 */
+    if constexpr (STAR)
     {
         int bPointNr = 0, bDistance = 0;
         bool stop = false;
-        me_star_pattern(sOff, bx, by, bcost, bPointNr, bDistance, 3, merange);
+        me_star_pattern<SLOW>(sOff, bx, by, bcost, bPointNr, bDistance, 3, merange);
         if (bDistance == 1)
         {
             if (!bPointNr) stop = true;
@@ -454,7 +731,7 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
         while (bDistance > 0)
         {
             bDistance = 0; bPointNr = 0;
-            me_star_pattern(sOff, bx, by, bcost, bPointNr, bDistance, 32, merange);
+            me_star_pattern<SLOW>(sOff, bx, by, bcost, bPointNr, bDistance, 32, merange);
             if (bDistance == 1)
             {
                 if (!bPointNr) break;
@@ -465,6 +742,11 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
                 break;
             }
         }
+        break;
+    }
+    else
+    {
+        ME_OOB(sOff);       /* this kernel variant was built without the star search: redo in k_me_deferred */
         break;
     }
     default:    /* UMH / SEA / FULL are not implemented: flagged, never silently replaced */
@@ -512,10 +794,26 @@ __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* 
             else break;
         }
     }
+    if (!SLOW && s.oob) { bx = 0; by = 0; bcost = ME_DEFERRED; }
     if (xa_lane() == 0) { out->mv[0] = (int16_t)bx; out->mv[1] = (int16_t)by; out->cost = bcost; }
 }
 
-__global__ __launch_bounds__(64 * ME_WAVES) void k_me_search(MeParams p)
+/* fills the per-wave state for one job (lane 0) */
+XA_DEV void me_set_job(MeState& s, const x265amd_me_job& j, const x265amd_me_group& g, const MeParams& p, const pixel* win, int winW, int winH,
+                       const pixel* fencT, const pixel* refG)
+{
+    s.win = win; s.winX = g.win_x; s.winY = g.win_y; s.winW = winW; s.winH = winH;
+    s.fencT = fencT; s.refG = refG; s.stride = p.stride;
+    s.px = j.x; s.py = j.y; s.w = j.w; s.h = j.h;
+    s.fx = j.x - g.fenc_x; s.fy = j.y - g.fenc_y;
+    s.cost = p.tables + (size_t)j.qp * ME_TBL_LEN + ME_TBL_HALF;
+    s.mvpx = j.mvp[0]; s.mvpy = j.mvp[1];
+    s.mnx = j.mvmin[0]; s.mny = j.mvmin[1]; s.mxx = j.mvmax[0]; s.mxy = j.mvmax[1];
+    s.oob = 0;
+}
+
+/* window-resident kernel: one workgroup per group, window + source tile in LDS, one wavefront per job */
+template<bool STAR> __global__ __launch_bounds__(64 * ME_WAVES, ME_MIN_WAVES_PER_EU) void k_me_search(MeParams p)
 {
     char* smem = me_smem;
     pixel* win = reinterpret_cast<pixel*>(smem);
@@ -558,18 +856,50 @@ __global__ __launch_bounds__(64 * ME_WAVES) void k_me_search(MeParams p)
         ji = __shfl(ji, 0, 64);
         if (ji >= g.num_jobs) break;
         const x265amd_me_job j = p.jobs[g.first_job + ji];
-        if (lane == 0)
-        {
-            s.win = win; s.winX = g.win_x; s.winY = g.win_y; s.winW = g.win_w; s.winH = g.win_h;
-            s.fencT = fencT; s.refG = refG; s.stride = p.stride;
-            s.px = j.x; s.py = j.y; s.w = j.w; s.h = j.h;
-            s.fx = j.x - g.fenc_x; s.fy = j.y - g.fenc_y;
-            s.cost = p.tables + (size_t)j.qp * ME_TBL_LEN + ME_TBL_HALF;
-            s.mvpx = j.mvp[0]; s.mvpy = j.mvp[1];
-            s.mnx = j.mvmin[0]; s.mny = j.mvmin[1]; s.mxx = j.mvmax[0]; s.mxy = j.mvmax[1];
-        }
+        if (lane == 0) me_set_job(s, j, g, p, win, g.win_w, g.win_h, fencT, refG);
         xa_wave_sync();
-        me_search(sOff, j, p.out + g.first_job + ji);
+        me_search<false, STAR>(sOff, j, p.out + g.first_job + ji);
+        xa_wave_sync();
+    }
+}
+
+/* direct-from-HBM kernel: redoes the jobs the window-resident kernel marked ME_DEFERRED (a candidate left the staged
+ * window, or the search method was not compiled into the fast variant).  Same arithmetic, reference samples read
+ * from HBM/L2; only the 64x64 source tile is staged. */
+__global__ __launch_bounds__(64 * ME_WAVES) void k_me_deferred(MeParams p)
+{
+    char* smem = me_smem;
+    pixel* fencT = reinterpret_cast<pixel*>(smem);
+    int* flag = reinterpret_cast<int*>(fencT + 64 * 64);
+    const int sOff = (int)(reinterpret_cast<char*>(flag + 4) - smem) + (int)(threadIdx.x >> 6) * (int)sizeof(MeState);
+    MeState& s = *reinterpret_cast<MeState*>(smem + sOff);
+    const x265amd_me_group g = p.groups[blockIdx.x];
+    const pixel* refG = reinterpret_cast<const pixel*>(p.refs[g.ref]);
+    const int tid = threadIdx.x, nthr = 64 * ME_WAVES, lane = xa_lane(), wv = threadIdx.x >> 6;
+
+    /* anything to redo in this group? */
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    int any = 0;
+    for (int i = tid; i < g.num_jobs; i += nthr) any |= p.out[g.first_job + i].cost == ME_DEFERRED;
+    if (any) atomicOr(flag, 1);
+    __syncthreads();
+    if (!*flag) return;
+    for (int i = tid; i < 16 * 64; i += nthr)
+    {
+        int y = i >> 4, x = (i & 15) << 2;
+        pixel v[4];
+        __builtin_memcpy(v, p.fenc + (long)(g.fenc_y + y) * p.stride + g.fenc_x + x, sizeof(v));
+        __builtin_memcpy(fencT + y * 64 + x, v, sizeof(v));
+    }
+    __syncthreads();
+    for (int ji = wv; ji < g.num_jobs; ji += ME_WAVES)
+    {
+        if (p.out[g.first_job + ji].cost != ME_DEFERRED) continue;
+        const x265amd_me_job j = p.jobs[g.first_job + ji];
+        if (lane == 0) me_set_job(s, j, g, p, nullptr, 0, 0, fencT, refG);
+        xa_wave_sync();
+        me_search<true, true>(sOff, j, p.out + g.first_job + ji);
         xa_wave_sync();
     }
 }
@@ -677,24 +1007,34 @@ extern "C" int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int m
 
 extern "C" int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_fenc, const uint64_t* d_refs, intptr_t stride,
                                  const x265amd_me_group* d_groups, int num_groups, const x265amd_me_job* d_jobs, x265amd_me_result* d_out,
-                                 int max_win_w, int max_win_h)
+                                 int max_win_w, int max_win_h, int flags)
 {
     if (!ctx || !d_fenc || !d_refs || !d_groups || !d_jobs || !d_out || num_groups < 0 || (max_win_w & 3))
         return xa_fail(X265AMD_EINVAL, "x265amd_me_search: bad arguments");
     if (num_groups == 0) return X265AMD_OK;
     size_t lds = ((size_t)max_win_w * max_win_h + 16 + 64 * 64) * sizeof(pixel) + 16 + ME_WAVES * sizeof(MeState);
     if (lds > 160 * 1024) return xa_fail(X265AMD_EINVAL, "x265amd_me_search: window does not fit the 160 KiB LDS");
-    static thread_local size_t configured = 0;
-    if (lds > configured)
+    const bool star = (flags & X265AMD_ME_FLAG_STAR) != 0;
+    static thread_local size_t configured[2] = { 0, 0 };
+    if (lds > configured[star])
     {
-        XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_me_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+        const void* fn = star ? (const void*)k_me_search<true> : (const void*)k_me_search<false>;
+        XA_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[star] = lds;
     }
     MeParams p;
     p.fenc = d_fenc; p.refs = d_refs; p.stride = (int)stride; p.groups = d_groups; p.jobs = d_jobs; p.out = d_out;
     p.tables = ctx->d_tables; p.maxWinW = max_win_w; p.maxWinH = max_win_h;
-    hipLaunchKernelGGL(k_me_search, dim3(num_groups), dim3(64 * ME_WAVES), lds, (hipStream_t)stream, p);
+    if (star)
+        hipLaunchKernelGGL(k_me_search<true>, dim3(num_groups), dim3(64 * ME_WAVES), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_me_search<false>, dim3(num_groups), dim3(64 * ME_WAVES), lds, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    /* second pass: jobs whose search left the staged window (exactness is never traded for the fast path) */
+    size_t lds2 = (size_t)64 * 64 * sizeof(pixel) + 16 + ME_WAVES * sizeof(MeState);
+    hipLaunchKernelGGL(k_me_deferred, dim3(num_groups), dim3(64 * ME_WAVES), lds2, (hipStream_t)stream, p);
+    e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }
