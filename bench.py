@@ -77,9 +77,9 @@ def frame_jobs(T, refdist):
     return jobs
 
 
-def cpu_baseline(T, frames, jobs_by_ref, budget_s=12.0):
-    """the same searches on ONE host core through the reference's own MotionEstimate (oracle/_ref) when present,
-    else through the oracle port; bounded sample, extrapolated to frames/s"""
+def cpu_baseline(T, frames, packed_by_ref, budget_s=15.0):
+    """the same searches on ONE host core, timed inside one C loop: through the reference's own MotionEstimate class
+    (oracle/_ref, kind "reference") when that build is present, else through the oracle port.  Bounded sample."""
     if T.have_ref():
         L, kind = T.load_ref(DEPTH), "reference"
     else:
@@ -87,21 +87,31 @@ def cpu_baseline(T, frames, jobs_by_ref, budget_s=12.0):
     stride = W + 2 * MARGIN_X
     origin = MARGIN_Y * stride + MARGIN_X
     cur = frames[NUM_REFS].ravel()
-    total_jobs = sum(len(j) for j in jobs_by_ref)
-    done, t0 = 0, time.perf_counter()
-    step = 97      # stride through the job list so that every PU size and picture region is sampled
-    for r, jobs in enumerate(jobs_by_ref):
+    total_jobs = sum(len(j) for j in packed_by_ref)
+    done, spent = 0, 0.0
+    for r, pk in enumerate(packed_by_ref):
         ref = frames[NUM_REFS - 1 - r].ravel()
-        sample = jobs[r::step]
-        for k in range(0, len(sample), 64):
-            T.me_run_host(L, cur, ref, stride, origin, sample[k:k + 64])
-            done += len(sample[k:k + 64])
-            if time.perf_counter() - t0 > budget_s / NUM_REFS * (r + 1):
+        for k in range(0, len(pk), 8192):
+            t0 = time.perf_counter()
+            T.me_run_host_batch(L, cur, ref, stride, origin, pk[k:k + 8192])
+            spent += time.perf_counter() - t0
+            done += len(pk[k:k + 8192])
+            if spent > budget_s * (r + 1) / NUM_REFS:
                 break
-    dt = time.perf_counter() - t0
-    fps = (done / dt) / total_jobs
+    fps = (done / spent) / total_jobs
     return {"value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "%d of %d motion searches of one 1080p frame (every 97th job, all 3 refs) in %.1f s, extrapolated" % (done, total_jobs, dt)}
+            "sample": "%d of the %d motion searches of one 1080p frame (all PU sizes, 3 refs) in %.1f s on one core, extrapolated to frames/s"
+                      % (done, total_jobs, spent)}
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run
+    separately: counters cannot be read inside the bench); the summary is committed under profiles/"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_me_v2_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch_uncorrected"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -135,10 +145,11 @@ def main():
 
     # job lists: identical PU set for each reference distance; planned once (windows depend only on the predictors)
     jobs_by_ref = [frame_jobs(T, r + 1) for r in range(NUM_REFS)]
-    packed, groups = [], []
+    packed, groups, packed_unordered = [], [], []
     base = 0
     for r, jobs in enumerate(jobs_by_ref):
         pk = T.me_pack_jobs(jobs)
+        packed_unordered.append(pk)
         g, order = me.plan(pk, r, MAX_WIN)
         g["first_job"] += base
         base += len(pk)
@@ -149,7 +160,9 @@ def main():
     alg_bytes = int((groups["win_w"].astype(np.int64) * groups["win_h"]).sum() + len(groups) * 64 * 64 + len(packed) * (72 + 8))
 
     stream = torch.cuda.current_stream()
-    gather_buf = torch.empty(world * d_frames[0].numel(), dtype=torch.uint8, device="cuda") if world > 1 else None
+    import __graft_entry__ as entry
+    fs = entry.load_package().frame_shard
+    ring, gather = fs.ReferenceRing(depth=NUM_REFS * max(world, 1) + world), [None]
 
     def step(k):
         cur = NUM_REFS + (k % (nring - NUM_REFS))
@@ -161,7 +174,7 @@ def main():
         if world > 1:
             # exchange step of the frame-parallel design: every rank publishes the picture it just finished so that all
             # ranks hold it as a reference (here the source stands in for the reconstruction)
-            dist.all_gather_into_tensor(gather_buf, d_frames[cur])
+            gather[0] = fs.publish_step(d_frames[cur], k, ring, gather[0])
 
     # device tables of reference-plane addresses, one per possible current frame (built outside the timed region)
     reftab = {cur: me.upload(np.array([d_frames[cur - 1 - r].data_ptr() + origin for r in range(NUM_REFS)], np.uint64))
@@ -218,11 +231,11 @@ def main():
                                    "NOT a full encode" % len(packed),
                        "frames_per_step_per_gpu": 1, "searches_per_frame": int(len(packed)), "parallelism": "frame-per-gpu x%d" % world},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "k_me_search", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(T, frames, jobs_by_ref)
+            line["cpu_baseline"] = cpu_baseline(T, frames, packed_unordered)
         else:
             line["cpu_baseline"] = None
         line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(parity_ok)}

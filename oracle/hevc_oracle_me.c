@@ -446,3 +446,18 @@ int orc_motion_estimate(const pixel* fencPlane, const pixel* refPlane, intptr_t 
     outMv[0] = bmv.x; outMv[1] = bmv.y;
     return bcost;
 }
+
+/* batch form over the packed job records of include/x265amd.h (struct x265amd_me_job, 72 bytes) */
+typedef struct { int16_t x, y; uint8_t w, h, method, subme, qp, num_cand; int16_t merange, mvmin[2], mvmax[2], mvp[2], mvc[12][2]; } PackedMeJob;
+int orc_motion_estimate_batch(const pixel* fencPlane, const pixel* refPlane, intptr_t stride, const PackedMeJob* jobs, int n, int32_t* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const PackedMeJob* j = &jobs[i];
+        int32_t mn[2] = { j->mvmin[0], j->mvmin[1] }, mx[2] = { j->mvmax[0], j->mvmax[1] }, mvp[2] = { j->mvp[0], j->mvp[1] }, mvc[24], mv[2];
+        for (int k = 0; k < j->num_cand; k++) { mvc[2 * k] = j->mvc[k][0]; mvc[2 * k + 1] = j->mvc[k][1]; }
+        out[3 * i + 2] = orc_motion_estimate(fencPlane, refPlane, stride, j->x, j->y, j->w, j->h, j->method, j->subme, j->qp, mn, mx, mvp, j->num_cand, mvc, j->merange, mv);
+        out[3 * i] = mv[0]; out[3 * i + 1] = mv[1];
+    }
+    return n;
+}

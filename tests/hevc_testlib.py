@@ -588,6 +588,15 @@ def me_run_host(L, cur, ref, stride, origin, jobs):
     return out
 
 
+def me_run_host_batch(L, cur, ref, stride, origin, packed):
+    """all jobs of a packed array (ME_JOB_DT) in ONE C call; returns int32 [n,3]"""
+    out = np.zeros((len(packed), 3), np.int32)
+    fn = getattr(L.lib, L.prefix + "motion_estimate_batch")
+    fn.restype = C.c_int
+    fn(off(cur, origin), off(ref, origin), C.c_int64(stride), _ptr(np.ascontiguousarray(packed)), len(packed), _ptr(out))
+    return out
+
+
 ME_JOB_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "u1"), ("h", "u1"), ("method", "u1"), ("subme", "u1"), ("qp", "u1"),
                       ("num_cand", "u1"), ("merange", "<i2"), ("mvmin", "<i2", 2), ("mvmax", "<i2", 2), ("mvp", "<i2", 2),
                       ("mvc", "<i2", (12, 2))])

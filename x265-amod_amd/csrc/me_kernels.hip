@@ -566,11 +566,13 @@ __device__ const uint8_t me_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 
                                                { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
 
 /* MotionEstimate::motionEstimate: motion.cpp:764-1594 (full-resolution reference, one slice, luma only) */
-template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd_me_job& j, x265amd_me_result* out)
+/* `jp` points at the job record in HBM: its fields are wave-uniform scalar loads (a by-value copy would live in scratch
+ * because mvc[] is indexed dynamically -- measured as 457 MB of scratch writes per 1080p launch) */
+template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd_me_job* __restrict__ jp, x265amd_me_result* out)
 {
     const MeState& s = ME_S(sOff);
     const int qminx = s.mnx * 4, qminy = s.mny * 4, qmaxx = s.mxx * 4, qmaxy = s.mxy * 4;
-    const int merange = j.merange;
+    const int merange = jp->merange, numCand = jp->num_cand, method = jp->method, subme = jp->subme;
     /* motion.cpp:797-846: predictor, zero MV, candidates */
     int pmx = xa_clip3(qminx, qmaxx, s.mvpx), pmy = xa_clip3(qminy, qmaxy, s.mvpy);
     int bestprex = pmx, bestprey = pmy;
@@ -589,9 +591,9 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
             by = max(min(0, s.mxy), s.mny);
         }
     }
-    for (int i = 0; i < j.num_cand; i++)
+    for (int i = 0; i < numCand; i++)
     {
-        int cx = xa_clip3(qminx, qmaxx, j.mvc[i][0]), cy = xa_clip3(qminy, qmaxy, j.mvc[i][1]);
+        int cx = xa_clip3(qminx, qmaxx, jp->mvc[i][0]), cy = xa_clip3(qminy, qmaxy, jp->mvc[i][1]);
         if ((cx | cy) && (cx != pmx || cy != pmy) && (cx != bestprex || cy != bestprey))
         {
             int cost = me_subpel_sad(cx, cy) + me_mvcost(s, cx, cy);
@@ -599,7 +601,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         }
     }
 
-    switch (j.method)
+    switch (method)
     {
     case X265AMD_ME_DIA:    /* motion.cpp:855-877 */
     {
@@ -757,7 +759,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
     /* motion.cpp:1473-1594 */
     if (bprecost < bcost) { bx = bestprex; by = bestprey; bcost = bprecost; }
     else { bx *= 4; by *= 4; }
-    const uint8_t* wl = me_workload[j.subme];
+    const uint8_t* wl = me_workload[subme];
     if (!bcost)
         bcost = me_mvcost(s, bx, by);
     else
@@ -855,10 +857,10 @@ template<bool STAR> __global__ __launch_bounds__(64 * ME_WAVES, ME_MIN_WAVES_PER
         if (lane == 0) ji = atomicAdd(counter, 1);
         ji = __shfl(ji, 0, 64);
         if (ji >= g.num_jobs) break;
-        const x265amd_me_job j = p.jobs[g.first_job + ji];
-        if (lane == 0) me_set_job(s, j, g, p, win, g.win_w, g.win_h, fencT, refG);
+        const x265amd_me_job* jp = p.jobs + g.first_job + ji;
+        if (lane == 0) me_set_job(s, *jp, g, p, win, g.win_w, g.win_h, fencT, refG);
         xa_wave_sync();
-        me_search<false, STAR>(sOff, j, p.out + g.first_job + ji);
+        me_search<false, STAR>(sOff, jp, p.out + g.first_job + ji);
         xa_wave_sync();
     }
 }
@@ -896,10 +898,10 @@ __global__ __launch_bounds__(64 * ME_WAVES) void k_me_deferred(MeParams p)
     for (int ji = wv; ji < g.num_jobs; ji += ME_WAVES)
     {
         if (p.out[g.first_job + ji].cost != ME_DEFERRED) continue;
-        const x265amd_me_job j = p.jobs[g.first_job + ji];
-        if (lane == 0) me_set_job(s, j, g, p, nullptr, 0, 0, fencT, refG);
+        const x265amd_me_job* jp = p.jobs + g.first_job + ji;
+        if (lane == 0) me_set_job(s, *jp, g, p, nullptr, 0, 0, fencT, refG);
         xa_wave_sync();
-        me_search<true, true>(sOff, j, p.out + g.first_job + ji);
+        me_search<true, true>(sOff, jp, p.out + g.first_job + ji);
         xa_wave_sync();
     }
 }
