@@ -237,6 +237,44 @@ int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_
  * the star search; without it such jobs still produce exact results through the slower second pass). */
 #define X265AMD_ME_FLAG_STAR 1
 
+/* --- residual (transform unit) path: Quant::transformNxN / invtransformNxN (reference: source/common/quant.cpp:397-605,
+ * sign-bit hiding :247-395) and the per-TU measurement of the residual quad-tree (source/encoder/search.cpp:3276-3330).
+ * Flat scaling lists, no RDOQ / transform skip / bypass / noise reduction (the medium preset's configuration).
+ * qp_scaled = QP + 6*(depth-8) after the chroma mapping of Quant::setQPforQuant (quant.cpp:221-244);
+ * slice_type: 0 B, 1 P, 2 I; ttype: 0 luma, 1 Cb, 2 Cr; dir_mode: intra direction that selects the coefficient scan
+ * (CUData::getTUEntropyCodingParameters, cudata.cpp:2059-2100). */
+typedef struct x265amd_tu_job
+{
+    uint64_t fenc, pred;            /* device addresses of the block's top-left sample (pixels) */
+    uint64_t coeff;                 /* out: N*N levels (int16) */
+    uint64_t resi;                  /* out: N x N reconstructed residual (int16), resi_stride */
+    uint64_t recon;                 /* out: N x N reconstruction (pixels), recon_stride */
+    int32_t fenc_stride, pred_stride, resi_stride, recon_stride;
+    uint8_t log2_tr_size, ttype, intra, dir_mode, slice_type, qp_scaled, sign_hide, reserved;
+} x265amd_tu_job;
+
+typedef struct x265amd_tu_result
+{
+    uint32_t num_sig;               /* return value of transformNxN (after sign-bit hiding) */
+    uint32_t zero_energy, nz_energy;/* psyCost(fenc, pred) / psyCost(fenc, recon)  (rdcost.h:114-117) */
+    uint32_t reserved;
+    uint64_t zero_dist, nz_dist;    /* sse_pp(fenc, pred) / sse_pp(fenc, recon); nz_* repeat zero_* when num_sig == 0 */
+} x265amd_tu_result;
+
+/* one wavefront per TU: residual, forward transform, quantisation, sign-bit hiding, and when levels remain
+ * dequantisation, inverse transform (with the reference's DC shortcut) and reconstruction, plus the distortion and psy
+ * energies both ways -- everything estimateResidualQT needs for a TU except the entropy bits.  Asynchronous. */
+int x265amd_tu_chain(void* stream, const x265amd_tu_job* d_jobs, int n, x265amd_tu_result* d_out);
+
+/* host-pointer forms of the two Quant entry points (parity surface, same staging as layer 1) */
+uint32_t x265amd_transform_tu(const x265amd_pixel* fenc, intptr_t fencStride, const int16_t* resi, intptr_t resiStride, int16_t* coeff,
+                              int log2TrSize, int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide);
+void x265amd_invtransform_tu(int16_t* resi, intptr_t resiStride, const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int qpScaled, uint32_t numSig);
+
+/* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
+ * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
+void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

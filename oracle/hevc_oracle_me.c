@@ -44,6 +44,15 @@ double orc_lambda(int qp)
     return floor(v * 10000.0 + 0.5) / 10000.0;
 }
 
+/* x265_lambda2_tab (constants.cpp:53-150): 0.038 * exp(0.234 * qp) cut (not rounded) to four decimals in the 8-bit
+ * table; the 10/12-bit tables are the 8-bit entries times 4^(depth-8).  All 70 entries are compared with the reference's
+ * array by tests/test_tu_oracle_vs_ref.py::test_lambda2_table. */
+double orc_lambda2(int qp)
+{
+    double v = floor(0.038 * exp(0.234 * (double)qp) * 10000.0) / 10000.0;
+    return v * (double)(1 << (2 * (ORC_DEPTH - 8)));
+}
+
 #define BC_MAX_MV (1 << 15)
 static uint16_t* g_costs[82];
 

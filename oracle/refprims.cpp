@@ -12,6 +12,12 @@
 #include "lowres.h"
 #include "bitcost.h"
 #include "motion.h"
+#include "slice.h"
+#include "cudata.h"
+#include "scalinglist.h"
+#include "entropy.h"
+#include "quant.h"
+#include "rdcost.h"
 
 using namespace X265_NS;
 
@@ -175,6 +181,84 @@ int ref_motion_estimate_batch(const pixel* fencPlane, const pixel* refPlane, int
         out[3 * i] = mv[0]; out[3 * i + 1] = mv[1];
     }
     return n;
+}
+
+/* ---- residual path: the reference's own Quant class (common/quant.cpp:397-605) ---- */
+const uint16_t* ref_tbl_scan(int scanType, int log2TrSize) { return g_scanOrder[scanType][log2TrSize - 2]; }
+
+struct QuantProbe : public Quant
+{
+    void configure(int ttype, int qpScaled) { m_qpParam[ttype].setQpParam(qpScaled); m_rdoqLevel = 0; m_nr = NULL; }
+};
+
+struct TuEnv
+{
+    ScalingList sl;
+    Entropy entropy;
+    QuantProbe quant;
+    CUData cu;
+    Slice slice;
+    SPS sps;
+    PPS pps;
+    uint8_t predMode[256], lumaDir[256], chromaDir[256], tqBypass[256];
+    TuEnv()
+    {
+        sl.init();
+        sl.m_bEnabled = false;                      /* --scaling-list off, as Encoder::create leaves it (flat lists) */
+        sl.m_bDataPresent = false;
+        sl.setupQuantMatrices(X265_CSP_I420);
+        quant.init(0.0, sl, entropy);
+        memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
+        sps.quadtreeTULog2MaxSize = 5;
+        slice.m_sps = &sps; slice.m_pps = &pps;
+        cu.m_slice = &slice;
+        cu.m_chromaFormat = X265_CSP_I420; cu.m_hChromaShift = 1; cu.m_vChromaShift = 1;
+        cu.m_predMode = predMode; cu.m_lumaIntraDir = lumaDir; cu.m_chromaIntraDir = chromaDir; cu.m_tqBypass = tqBypass;
+        memset(tqBypass, 0, sizeof(tqBypass));
+    }
+    void set(int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide)
+    {
+        memset(predMode, bIntra ? MODE_INTRA : MODE_INTER, sizeof(predMode));
+        memset(lumaDir, dirMode, sizeof(lumaDir)); memset(chromaDir, dirMode, sizeof(chromaDir));
+        slice.m_sliceType = (SliceType)sliceType;
+        pps.bSignHideEnabled = signHide != 0;
+        quant.configure(ttype, qpScaled);
+    }
+};
+static TuEnv* tuEnv() { ensure(); static TuEnv* e = new TuEnv; return e; }
+
+/* Quant::transformNxN (quant.cpp:397-480): qpScaled = qp + QP_BD_OFFSET after the chroma mapping of setQPforQuant;
+ * sliceType: 0 B, 1 P, 2 I; dirMode: intra direction used to choose the coefficient scan */
+uint32_t ref_transform_tu(const pixel* fenc, intptr_t fencStride, const int16_t* resi, intptr_t resiStride, int16_t* coeff, int log2TrSize,
+                          int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide)
+{
+    TuEnv* e = tuEnv();
+    e->set(ttype, bIntra, dirMode, sliceType, qpScaled, signHide);
+    return e->quant.transformNxN(e->cu, fenc, (uint32_t)fencStride, resi, (uint32_t)resiStride, coeff, log2TrSize, (TextType)ttype, 0, false);
+}
+
+/* Quant::invtransformNxN (quant.cpp:543-605) */
+void ref_invtransform_tu(int16_t* resi, intptr_t resiStride, const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int qpScaled, uint32_t numSig)
+{
+    TuEnv* e = tuEnv();
+    e->set(ttype, bIntra, 0, 1, qpScaled, 0);
+    e->quant.invtransformNxN(e->cu, resi, (uint32_t)resiStride, coeff, log2TrSize, (TextType)ttype, bIntra != 0, false, numSig);
+}
+
+/* RDCost (encoder/rdcost.h:34-174) for a 4:2:0 slice without chroma QP offsets */
+void ref_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out /* lambda2, lambda, psyRd, rd, psyrd, rdsad */)
+{
+    TuEnv* e = tuEnv();
+    e->sps.chromaFormatIdc = X265_CSP_I420;
+    e->slice.m_sliceType = (SliceType)sliceType;
+    RDCost rd;
+    rd.setPsyRdScale(psyRdScale);
+    rd.setSsimRd(0);
+    rd.setQP(e->slice, qp);
+    out[0] = rd.m_lambda2; out[1] = rd.m_lambda; out[2] = rd.m_psyRd;
+    out[3] = rd.calcRdCost((sse_t)dist, bits);
+    out[4] = rd.m_psyRd ? rd.calcPsyRdCost((sse_t)dist, bits, psycost) : 0;
+    out[5] = rd.calcRdSADCost((uint32_t)dist, bits);
 }
 
 } /* extern "C" */

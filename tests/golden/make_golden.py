@@ -38,6 +38,7 @@ def main():
         json.dump({"reference": "DJATOM/x265-aMod 3.6+1-aa7f602f7 [noasm] C primitives", "digests": digests}, f, indent=0, sort_keys=True)
     print("wrote", len(digests), "digests")
     make_me_golden()
+    make_tu_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -67,6 +68,33 @@ def make_me_golden():
         out["mvcost_sha256/%d" % depth] = np.stack(dig)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "me_golden.npz"), **out)
     print("wrote me_golden.npz with", len(out), "arrays")
+
+
+
+def make_tu_golden():
+    """Quant::transformNxN / invtransformNxN results and RDCost values from the reference build -> tests/golden/tu_golden.npz"""
+    import ctypes as C
+    out = {}
+    for depth in (8, 10):
+        ref = T.load_ref(depth)
+        for seed in range(4):
+            cases = T.tu_cases(depth, 100 + seed, 150)
+            res = T.tu_run_host(ref, cases)
+            out["tu/%d/%d/numsig" % (depth, seed)] = np.array([r[0] for r in res], np.int32)
+            out["tu/%d/%d/coeff" % (depth, seed)] = np.concatenate([r[1] for r in res])
+            out["tu/%d/%d/resi" % (depth, seed)] = np.concatenate([r[2].ravel() for r in res])
+        rng = np.random.default_rng(5)
+        rows = []
+        for _ in range(300):
+            qp, st = int(rng.integers(0, 70)), int(rng.integers(0, 3))
+            psy = float(rng.choice([0.0, 1.0, 2.0, 0.7]))
+            dist, bits, pc = int(rng.integers(0, 1 << 24)), int(rng.integers(0, 1 << 16)), int(rng.integers(0, 1 << 16))
+            a = np.zeros(6, np.uint64)
+            ref.lib.ref_rdcost(qp, st, C.c_double(psy), C.c_uint64(dist), C.c_uint32(bits), C.c_uint32(pc), T._ptr(a))
+            rows.append(a)
+        out["rdcost/%d" % depth] = np.stack(rows)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "tu_golden.npz"), **out)
+    print("wrote tu_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

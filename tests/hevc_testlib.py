@@ -97,7 +97,12 @@ def hip_path(depth):
 
 
 def load_hip(depth):
-    """the product library; never falls back to anything else"""
+    """the product library; never falls back to anything else.  torch (which bundles its own HIP runtime) is imported
+    first: the other order leaves torch unable to see the GPU once libx265amd has initialised the system runtime."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return PrimLib(hip_path(depth), "x265amd_", depth)
 
 
@@ -678,3 +683,74 @@ class HipME:
         out[order, 1] = res["mv"][:, 1]
         out[order, 2] = res["cost"]
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# residual (transform unit) cases: Quant::transformNxN / invtransformNxN / the per-TU measurement
+# ----------------------------------------------------------------------------------------------------------
+def tu_cases(depth, seed, n):
+    """n random TUs: dict(fenc, pred (N x N arrays), log2, ttype, intra, dir, slice, qpScaled, signhide)"""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    cases = []
+    for i in range(n):
+        log2 = int(rng.integers(2, 6))
+        N = 1 << log2
+        ttype = int(rng.integers(0, 3))
+        intra = int(rng.integers(0, 2))
+        base = rng.integers(0, pmax + 1, (N // 4 + 1, N // 4 + 1)).astype(np.int64)
+        tex = np.kron(base, np.ones((4, 4), np.int64))[:N, :N]
+        amp = int(rng.choice([1, 3, 8, 24, 80])) << (depth - 8)
+        fenc = np.clip(tex + rng.integers(-amp, amp + 1, (N, N)), 0, pmax)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            pred = np.clip(fenc + rng.integers(-2, 3, (N, N)), 0, pmax)           # tiny residual -> mostly zero levels
+        elif kind == 1:
+            pred = np.clip(tex + rng.integers(-amp, amp + 1, (N, N)), 0, pmax)
+        elif kind == 2:
+            pred = np.full((N, N), int(fenc.mean()))                                # DC-ish prediction
+        else:
+            pred = np.clip(fenc + int(rng.integers(-3, 4)), 0, pmax)                # DC-only residual
+        qp = int(rng.integers(4, 52))
+        cases.append(dict(fenc=np.ascontiguousarray(fenc.astype(dt)), pred=np.ascontiguousarray(pred.astype(dt)), log2=log2, ttype=ttype,
+                          intra=intra, dir=int(rng.integers(0, 35)), slice=int(rng.integers(0, 3)), qp=qp + 6 * (depth - 8),
+                          signhide=int(rng.integers(0, 4) != 0)))
+    return cases
+
+
+def tu_run_host(L, cases):
+    """through <prefix>transform_tu / invtransform_tu; returns list of (numSig, coeff, resi)"""
+    out = []
+    ft = getattr(L.lib, L.prefix + "transform_tu"); ft.restype = C.c_uint32
+    fi = getattr(L.lib, L.prefix + "invtransform_tu")
+    for c in cases:
+        N = 1 << c["log2"]
+        resi = (c["fenc"].astype(np.int32) - c["pred"].astype(np.int32)).astype(np.int16)
+        coeff = np.zeros(N * N, np.int16)
+        ns = ft(_ptr(c["fenc"]), C.c_int64(N), _ptr(resi), C.c_int64(N), _ptr(coeff), c["log2"], c["ttype"], c["intra"], c["dir"], c["slice"], c["qp"], c["signhide"])
+        r2 = np.zeros((N, N), np.int16)
+        if ns:
+            fi(_ptr(r2), C.c_int64(N), _ptr(coeff), c["log2"], c["ttype"], c["intra"], c["qp"], C.c_uint32(ns))
+        out.append((int(ns), coeff.copy(), r2.copy()))
+    return out
+
+
+def tu_run_chain_oracle(L, cases):
+    """orc_tu_chain: returns list of (stats[5], coeff, resi, recon)"""
+    out = []
+    for c in cases:
+        N = 1 << c["log2"]
+        coeff = np.zeros(N * N, np.int16); resi = np.zeros((N, N), np.int16); recon = np.zeros((N, N), c["fenc"].dtype)
+        st = np.zeros(5, np.uint64)
+        L.lib.orc_tu_chain(_ptr(c["fenc"]), C.c_int64(N), _ptr(c["pred"]), C.c_int64(N), c["log2"], c["ttype"], c["intra"], c["dir"], c["slice"],
+                           c["qp"], c["signhide"], _ptr(coeff), _ptr(resi), C.c_int64(N), _ptr(recon), C.c_int64(N), _ptr(st))
+        out.append((st.copy(), coeff, resi, recon))
+    return out
+
+
+TU_JOB_DT = np.dtype([("fenc", "<u8"), ("pred", "<u8"), ("coeff", "<u8"), ("resi", "<u8"), ("recon", "<u8"),
+                      ("fenc_stride", "<i4"), ("pred_stride", "<i4"), ("resi_stride", "<i4"), ("recon_stride", "<i4"),
+                      ("log2", "u1"), ("ttype", "u1"), ("intra", "u1"), ("dir", "u1"), ("slice", "u1"), ("qp", "u1"), ("signhide", "u1"), ("reserved", "u1")])
+TU_RESULT_DT = np.dtype([("num_sig", "<u4"), ("zero_energy", "<u4"), ("nz_energy", "<u4"), ("reserved", "<u4"), ("zero_dist", "<u8"), ("nz_dist", "<u8")])
+assert TU_JOB_DT.itemsize == 64 and TU_RESULT_DT.itemsize == 32

@@ -30,6 +30,10 @@ def load(depth=8):
     path = lib_path(depth)
     if not os.path.exists(path):
         raise X265AmdError("HIP library %s not built: run x265-amod_amd/build.sh (there is no CPU fallback)" % path)
+    try:
+        import torch  # noqa: F401  (load torch's HIP runtime first; see tests/hevc_testlib.py::load_hip)
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.x265amd_version.restype = C.c_char_p
     lib.x265amd_last_error.restype = C.c_char_p

@@ -14,23 +14,6 @@ template<class T> XA_DEV T* P(uint64_t addr) { return reinterpret_cast<T*>(addr)
 /* =========================================================================================================
  * family 0: distortion (pixel.cpp)
  * ======================================================================================================= */
-XA_DEV uint64_t wave_sse_pp(const pixel* a, int sa, const pixel* b, int sb, int size, int lane)     /* pixel.cpp:167-186 */
-{
-    uint64_t sum = 0;
-    int n = size * size, sh = 31 - __clz(size);
-    for (int i = lane; i < n; i += XA_WAVE)
-    {
-        int y = i >> sh, x = i & (size - 1);
-        int t = (int)a[y * sa + x] - (int)b[y * sb + x];
-        sum += (uint64_t)(uint32_t)(t * t);
-    }
-    sum = xa_wave_sum(sum);
-#if XA_DEPTH <= 8
-    sum = (uint32_t)sum;        /* sse_t is uint32_t below 10 bits (common/common.h:142-146) */
-#endif
-    return sum;
-}
-
 XA_DEV uint64_t wave_sse_ss(const int16_t* a, int sa, const int16_t* b, int sb, int size, int lane, bool self)
 {
     uint64_t sum = 0;
@@ -46,39 +29,6 @@ XA_DEV uint64_t wave_sse_ss(const int16_t* a, int sa, const int16_t* b, int sb, 
     sum = (uint32_t)sum;
 #endif
     return sum;
-}
-
-/* pixel.cpp:744-775 */
-XA_DEV int wave_psy_cost(const pixel* src, int ss, const pixel* rec, int rs, int cu, int lane)
-{
-    if (cu == 0)
-    {
-        int v = 0;
-        if (lane == 0)
-        {
-            int sadS = 0, sadR = 0;
-            for (int y = 0; y < 4; y++)
-                for (int x = 0; x < 4; x++) { sadS += src[y * ss + x]; sadR += rec[y * rs + x]; }
-            int se = (xa_had4_abs<false>(src, ss, nullptr, 0) >> 1) - (sadS >> 2);
-            int re = (xa_had4_abs<false>(rec, rs, nullptr, 0) >> 1) - (sadR >> 2);
-            v = abs(se - re);
-        }
-        return __shfl(v, 0, 64);
-    }
-    int tiles = 1 << (cu - 1), nt = tiles * tiles, v = 0;      /* 8x8 tiles per row */
-    if (lane < nt)
-    {
-        int ty = lane / tiles, tx = lane - ty * tiles;
-        const pixel* s = src + 8 * ty * ss + 8 * tx;
-        const pixel* r = rec + 8 * ty * rs + 8 * tx;
-        int sadS = 0, sadR = 0;
-        for (int y = 0; y < 8; y++)
-            for (int x = 0; x < 8; x++) { sadS += s[y * ss + x]; sadR += r[y * rs + x]; }
-        int se = ((xa_had8_abs<false>(s, ss, nullptr, 0) + 2) >> 2) - (sadS >> 2);
-        int re = ((xa_had8_abs<false>(r, rs, nullptr, 0) + 2) >> 2) - (sadR >> 2);
-        v = abs(se - re);
-    }
-    return xa_wave_sum(v);
 }
 
 __global__ __launch_bounds__(256) void k_distortion(const x265amd_job* jobs, int n)
@@ -312,32 +262,6 @@ __global__ __launch_bounds__(256) void k_pixel(const x265amd_job* jobs, int n)
  * family 2: transforms + quantisation (dct.cpp).  The reference's partial butterflies are exact integer
  * factorisations of the matrix product, so out[k][j] = (sum_n T[k][n] in[j][n] + add) >> shift is bit-exact.
  * ======================================================================================================= */
-XA_DEV void wave_fwd_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int shift, int lane)
-{
-    int N = 1 << log2N, add = 1 << (shift - 1);
-    for (int i = lane; i < N * N; i += XA_WAVE)
-    {
-        int k = i >> log2N, jj = i & (N - 1);   /* consecutive lanes: consecutive j (dst row k contiguous) */
-        int sum = 0;
-        for (int nn = 0; nn < N; nn++)
-            sum += T[k * N + nn] * src[jj * N + nn];
-        dst[k * N + jj] = (int16_t)((sum + add) >> shift);
-    }
-}
-
-XA_DEV void wave_inv_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int dstStride, int shift, int lane)
-{
-    int N = 1 << log2N, add = 1 << (shift - 1);
-    for (int i = lane; i < N * N; i += XA_WAVE)
-    {
-        int jj = i >> log2N, nn = i & (N - 1);
-        int sum = 0;
-        for (int k = 0; k < N; k++)
-            sum += T[k * N + nn] * src[k * N + jj];
-        dst[jj * dstStride + nn] = (int16_t)xa_clip3(-32768, 32767, (sum + add) >> shift);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_transform(const x265amd_job* jobs, int n)
 {
     __shared__ int16_t lds[WAVES_PER_BLOCK][2][32 * 32];
