@@ -271,6 +271,27 @@ uint32_t x265amd_transform_tu(const x265amd_pixel* fenc, intptr_t fencStride, co
                               int log2TrSize, int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide);
 void x265amd_invtransform_tu(int16_t* resi, intptr_t resiStride, const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int qpScaled, uint32_t numSig);
 
+/* --- intra: neighbour set + 35-mode luma scan.  Per job: Predict::initAdiPattern with dirMode = ALL_IDX (reference:
+ * source/common/predict.cpp:600-649, fillReferenceSamples :736-877: substitution of unavailable neighbours, [1 2 1] or
+ * strong bilinear smoothing) on the reconstructed plane, then the sa8d of every one of the 35 luma predictions against
+ * the source block -- the mode scan of Search::estIntraPredQT (source/encoder/search.cpp:1566-1613).  The host adds
+ * the mode bits (entropy state) and picks the candidates. */
+typedef struct x265amd_intra_job
+{
+    uint64_t recon;                 /* device address of the block's top-left sample inside the reconstructed plane */
+    uint64_t fenc;                  /* device address of the source block's top-left sample */
+    uint64_t avail;                 /* bit u: neighbour unit u (4 samples) available; order of IntraNeighbors::bNeighborFlags:
+                                       below-left (bottom-most first) ... left, above-left, above ... above-right */
+    int32_t recon_stride, fenc_stride;
+    uint8_t log2_tr_size;           /* 2..5 */
+    uint8_t strong_smoothing;       /* sps.bUseStrongIntraSmoothing */
+    uint8_t reserved[6];
+} x265amd_intra_job;
+
+/* d_sa8d: n * 35 int32 (mode-major per job).  d_neighbours: optional (may be NULL) n * 2 * 129 pixels receiving the
+ * unfiltered and filtered neighbour buffers ([0] above-left, [1..2N] above, [2N+1..4N] left).  Asynchronous. */
+int x265amd_intra_scan(void* stream, const x265amd_intra_job* d_jobs, int n, int32_t* d_sa8d, x265amd_pixel* d_neighbours);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

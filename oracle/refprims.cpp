@@ -18,6 +18,9 @@
 #include "entropy.h"
 #include "quant.h"
 #include "rdcost.h"
+#include "predict.h"
+#include "framedata.h"
+#include "picyuv.h"
 
 using namespace X265_NS;
 
@@ -259,6 +262,68 @@ void ref_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_
     out[3] = rd.calcRdCost((sse_t)dist, bits);
     out[4] = rd.m_psyRd ? rd.calcPsyRdCost((sse_t)dist, bits, psycost) : 0;
     out[5] = rd.calcRdSADCost((uint32_t)dist, bits);
+}
+
+/* ---- intra: the reference's own Predict::initAdiPattern (common/predict.cpp:600-649, fillReferenceSamples :736-877) ---- */
+struct IntraEnv
+{
+    Predict pred;
+    FrameData fd;
+    PicYuv* pic;
+    intptr_t zeroCu[1];
+    intptr_t zeroBu[256];
+    IntraEnv()
+    {
+        pic = new PicYuv;       /* never destroyed: it does not own the sample buffer */
+        zeroCu[0] = 0; memset(zeroBu, 0, sizeof(zeroBu));
+        pic->m_cuOffsetY = zeroCu; pic->m_buOffsetY = zeroBu;
+        fd.m_reconPic = pic;
+    }
+};
+
+/* recon: top-left sample of the block inside a reconstructed plane; flags[totalUnits]: bNeighborFlags in the reference's
+ * order (below-left ... left, above-left, above ... above-right), 4-sample units.  dirMode -1 = ALL_IDX. */
+void ref_init_adi_pattern(const pixel* recon, intptr_t stride, int log2TrSize, const uint8_t* flags, int strongSmoothing, int dirMode,
+                          pixel* outRef, pixel* outFlt)
+{
+    static IntraEnv* ie = NULL;
+    TuEnv* e = tuEnv();
+    if (!ie) ie = new IntraEnv;
+    int units = (1 << log2TrSize) >> 2;
+    Predict::IntraNeighbors nb;
+    nb.aboveUnits = 2 * units; nb.leftUnits = 2 * units; nb.totalUnits = 4 * units + 1;
+    nb.unitWidth = 4; nb.unitHeight = 4; nb.log2TrSize = log2TrSize;
+    nb.numIntraNeighbor = 0;
+    for (int i = 0; i < nb.totalUnits; i++) { nb.bNeighborFlags[i] = flags[i] != 0; nb.numIntraNeighbor += flags[i] != 0; }
+    ie->pic->m_picOrg[0] = (pixel*)recon;
+    ie->pic->m_stride = stride;
+    e->sps.bUseStrongIntraSmoothing = strongSmoothing != 0;
+    e->cu.m_encData = &ie->fd;
+    e->cu.m_cuAddr = 0;
+    CUGeom g; memset(&g, 0, sizeof(g));
+    ie->pred.initAdiPattern(e->cu, g, 0, nb, dirMode);
+    memcpy(outRef, ie->pred.intraNeighbourBuf[0], 258 * sizeof(pixel));
+    memcpy(outFlt, ie->pred.intraNeighbourBuf[1], 258 * sizeof(pixel));
+}
+
+/* the 35-mode luma scan of Search::estIntraPredQT (encoder/search.cpp:1566-1613, individual-angle path): sa8d of every
+ * prediction against fenc, with the reference's own primitives and neighbour buffers */
+void ref_intra_scan(const pixel* fenc, intptr_t fencStride, int log2TrSize, const pixel* refBuf, const pixel* fltBuf, int32_t* sa8d35)
+{
+    ensure();
+    int sizeIdx = log2TrSize - 2, N = 1 << log2TrSize;
+    ALIGN_VAR_32(pixel, predBuf[32 * 32]);
+    g_p.cu[sizeIdx].intra_pred[DC_IDX](predBuf, N, refBuf, 0, N <= 16);
+    sa8d35[DC_IDX] = g_p.cu[sizeIdx].sa8d(fenc, fencStride, predBuf, N);
+    const pixel* planar = (N >= 8 && N <= 32) ? fltBuf : refBuf;
+    g_p.cu[sizeIdx].intra_pred[PLANAR_IDX](predBuf, N, planar, 0, 0);
+    sa8d35[PLANAR_IDX] = g_p.cu[sizeIdx].sa8d(fenc, fencStride, predBuf, N);
+    for (int mode = 2; mode < 35; mode++)
+    {
+        int filter = !!(g_intraFilterFlags[mode] & N);
+        g_p.cu[sizeIdx].intra_pred[mode](predBuf, N, filter ? fltBuf : refBuf, mode, N <= 16);
+        sa8d35[mode] = g_p.cu[sizeIdx].sa8d(fenc, fencStride, predBuf, N);
+    }
 }
 
 } /* extern "C" */

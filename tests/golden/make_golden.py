@@ -39,6 +39,7 @@ def main():
     print("wrote", len(digests), "digests")
     make_me_golden()
     make_tu_golden()
+    make_intra_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -95,6 +96,20 @@ def make_tu_golden():
         out["rdcost/%d" % depth] = np.stack(rows)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "tu_golden.npz"), **out)
     print("wrote tu_golden.npz with", len(out), "arrays")
+
+
+def make_intra_golden():
+    """neighbour sets of the reference's Predict::initAdiPattern and the 35-mode sa8d scan -> tests/golden/intra_golden.npz"""
+    out = {}
+    for depth in (8, 10):
+        ref = T.load_ref(depth)
+        for seed in range(4):
+            res = T.intra_run_host(ref, T.intra_cases(depth, 500 + seed, 200))
+            out["intra/%d/%d/ref" % (depth, seed)] = np.concatenate([r[0] for r in res])
+            out["intra/%d/%d/flt" % (depth, seed)] = np.concatenate([r[1] for r in res if r[1] is not None])
+            out["intra/%d/%d/sa8d" % (depth, seed)] = np.stack([r[2] for r in res])
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_golden.npz"), **out)
+    print("wrote intra_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -754,3 +754,99 @@ TU_JOB_DT = np.dtype([("fenc", "<u8"), ("pred", "<u8"), ("coeff", "<u8"), ("resi
                       ("log2", "u1"), ("ttype", "u1"), ("intra", "u1"), ("dir", "u1"), ("slice", "u1"), ("qp", "u1"), ("signhide", "u1"), ("reserved", "u1")])
 TU_RESULT_DT = np.dtype([("num_sig", "<u4"), ("zero_energy", "<u4"), ("nz_energy", "<u4"), ("reserved", "<u4"), ("zero_dist", "<u8"), ("nz_dist", "<u8")])
 assert TU_JOB_DT.itemsize == 64 and TU_RESULT_DT.itemsize == 32
+
+
+# ----------------------------------------------------------------------------------------------------------
+# intra cases: neighbour set (initAdiPattern) + 35-mode sa8d scan
+# ----------------------------------------------------------------------------------------------------------
+def intra_cases(depth, seed, n):
+    """n random intra blocks inside a small reconstructed plane; dict(plane, stride, off (block top-left), log2, flags, strong, fenc)"""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    cases = []
+    for i in range(n):
+        log2 = int(rng.integers(2, 6))
+        N = 1 << log2
+        stride = 3 * N + 16
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            plane = rng.integers(0, pmax + 1, (3 * N + 8, stride))
+        elif kind == 1:     # smooth plane: triggers the strong (bilinear) smoothing at 32x32
+            yy, xx = np.mgrid[0:3 * N + 8, 0:stride]
+            plane = np.clip((pmax // 3) + (xx * int(rng.integers(0, 3)) + yy * int(rng.integers(0, 3))) // 4 + rng.integers(0, 2, xx.shape), 0, pmax)
+        else:
+            base = rng.integers(0, pmax + 1, ((3 * N + 8) // 8 + 1, stride // 8 + 1))
+            plane = np.kron(base, np.ones((8, 8), np.int64))[:3 * N + 8, :stride]
+        plane = np.ascontiguousarray(plane.astype(dt))
+        units = N // 4
+        total = 4 * units + 1
+        mode = int(rng.integers(0, 5))
+        if mode == 0:
+            flags = np.ones(total, np.uint8)
+        elif mode == 1:
+            flags = np.zeros(total, np.uint8)
+        elif mode == 2:     # typical: left + above available, below-left / above-right not
+            flags = np.ones(total, np.uint8); flags[:units] = 0; flags[3 * units + 1:] = 0
+        elif mode == 3:     # picture top edge
+            flags = np.zeros(total, np.uint8); flags[units:2 * units] = 1
+        else:
+            flags = rng.integers(0, 2, total).astype(np.uint8)
+        fenc = np.ascontiguousarray(np.clip(plane[N + 4:2 * N + 4, N + 4:2 * N + 4].astype(np.int64) + rng.integers(-6, 7, (N, N)), 0, pmax).astype(dt))
+        cases.append(dict(plane=plane.ravel(), stride=stride, off=(N + 4) * stride + N + 4, log2=log2, flags=flags,
+                          strong=int(rng.integers(0, 2)), fenc=fenc))
+    return cases
+
+
+def intra_run_host(L, cases):
+    """returns list of (ref[4N+1], flt[4N+1] or None, sa8d[35])"""
+    out = []
+    fa = getattr(L.lib, L.prefix + "init_adi_pattern")
+    fs = getattr(L.lib, L.prefix + "intra_scan")
+    for c in cases:
+        N = 1 << c["log2"]
+        ref = np.zeros(258, c["plane"].dtype); flt = np.zeros(258, c["plane"].dtype)
+        fa(off(c["plane"], c["off"]), C.c_int64(c["stride"]), c["log2"], _ptr(c["flags"]), c["strong"], -1, _ptr(ref), _ptr(flt))
+        filtered = N >= 8
+        if not filtered:
+            flt[:] = 0
+        sa = np.zeros(35, np.int32)
+        fs(_ptr(c["fenc"]), C.c_int64(N), c["log2"], _ptr(ref), _ptr(flt if filtered else ref), _ptr(sa))
+        out.append((ref[:4 * N + 1].copy(), flt[:4 * N + 1].copy() if filtered else None, sa))
+    return out
+
+
+INTRA_JOB_DT = np.dtype([("recon", "<u8"), ("fenc", "<u8"), ("avail", "<u8"), ("recon_stride", "<i4"), ("fenc_stride", "<i4"),
+                         ("log2", "u1"), ("strong", "u1"), ("reserved", "u1", 6)])
+assert INTRA_JOB_DT.itemsize == 40
+
+
+def intra_run_hip(L, cases):
+    """x265amd_intra_scan on a batch; same return shape as intra_run_host"""
+    import torch
+    isz = cases[0]["plane"].itemsize
+    planes = np.concatenate([c["plane"].view(np.uint8) for c in cases])
+    fencs = np.concatenate([c["fenc"].ravel().view(np.uint8) for c in cases])
+    d_planes, d_fencs = torch.from_numpy(planes).cuda(), torch.from_numpy(fencs).cuda()
+    jobs = np.zeros(len(cases), INTRA_JOB_DT)
+    po = fo = 0
+    for i, c in enumerate(cases):
+        N = 1 << c["log2"]
+        mask = 0
+        for u, f in enumerate(c["flags"]):
+            mask |= int(f) << u
+        jobs[i] = (d_planes.data_ptr() + po + c["off"] * isz, d_fencs.data_ptr() + fo, mask, c["stride"], N, c["log2"], c["strong"], 0)
+        po += c["plane"].nbytes; fo += c["fenc"].nbytes
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).copy()).cuda()
+    d_sa = torch.zeros(len(cases) * 35, dtype=torch.int32, device="cuda")
+    d_nb = torch.zeros(len(cases) * 2 * 129 * isz, dtype=torch.uint8, device="cuda")
+    rc = L.lib.x265amd_intra_scan(None, C.c_void_p(d_jobs.data_ptr()), len(cases), C.c_void_p(d_sa.data_ptr()), C.c_void_p(d_nb.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    sa = d_sa.cpu().numpy().reshape(-1, 35)
+    nb = d_nb.cpu().numpy().view(cases[0]["plane"].dtype).reshape(-1, 2, 129)
+    out = []
+    for i, c in enumerate(cases):
+        N = 1 << c["log2"]
+        out.append((nb[i, 0, :4 * N + 1].copy(), nb[i, 1, :4 * N + 1].copy() if N >= 8 else None, sa[i].copy()))
+    return out

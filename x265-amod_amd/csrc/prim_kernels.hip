@@ -356,29 +356,6 @@ __global__ __launch_bounds__(256) void k_transform(const x265amd_job* jobs, int 
  * family 3: intra prediction (intrapred.cpp).  Neighbour layout (predict.cpp:600-877): s[0] top-left,
  * s[1..2N] above+above-right, s[2N+1..4N] left+below-left.
  * ======================================================================================================= */
-/* one angular prediction sample in "vertical orientation" on (possibly swapped) neighbours: intrapred.cpp:106-196 */
-XA_DEV pixel ang_sample(const pixel* s, int N, int angle, int invAngle, int bFilter, int y, int x)
-{
-    int N2 = 2 * N;
-    if (!angle)
-    {
-        if (bFilter && x == 0)
-            return xa_clip_pixel((int16_t)(s[1] + ((s[N2 + 1 + y] - s[0]) >> 1)));
-        return s[1 + x];
-    }
-    int angSum = (y + 1) * angle;
-    int off = angSum >> 5, frac = angSum & 31;
-    /* ref[i]: i >= -1 -> s[i+1]; i <= -2 (negative angles only) -> projected left neighbour */
-    int i0 = off + x, i1 = off + x + 1;
-    int r0, r1;
-    if (i0 >= -1) r0 = s[i0 + 1];
-    else r0 = s[N2 + ((128 + (-1 - i0) * invAngle) >> 8)];
-    if (!frac) return (pixel)r0;
-    if (i1 >= -1) r1 = s[i1 + 1];
-    else r1 = s[N2 + ((128 + (-1 - i1) * invAngle) >> 8)];
-    return (pixel)(((32 - frac) * r0 + frac * r1 + 16) >> 5);
-}
-
 /* writes one N x N prediction; s = neighbours in LDS.  keepTransposed: all-angles layout (intrapred.cpp:211-241) */
 XA_DEV void wave_intra_pred(const pixel* s, pixel* swapped, int cu, int mode, int bFilter, pixel* dst, int ds, bool keepTransposed, int lane)
 {
@@ -436,21 +413,6 @@ XA_DEV void wave_intra_pred(const pixel* s, pixel* swapped, int cu, int mode, in
         dst[y * ds + x] = flip ? ang_sample(nb, N, angle, invAngle, bFilter, x, y) : ang_sample(nb, N, angle, invAngle, bFilter, y, x);
     }
     xa_wave_sync();
-}
-
-/* intrapred.cpp:30-52 */
-XA_DEV void wave_intra_filter(const pixel* s, pixel* f, int N, int lane)
-{
-    int N2 = 2 * N;
-    for (int i = lane; i <= 2 * N2; i += XA_WAVE)
-    {
-        int v;
-        if (i == 0) v = (2 * s[0] + s[1] + s[N2 + 1] + 2) >> 2;
-        else if (i == N2 || i == 2 * N2) v = s[i];
-        else if (i == N2 + 1) v = (2 * s[N2 + 1] + s[0] + s[N2 + 2] + 2) >> 2;
-        else v = (2 * s[i] + s[i - 1] + s[i + 1] + 2) >> 2;
-        f[i] = (pixel)v;
-    }
 }
 
 __global__ __launch_bounds__(256) void k_intra(const x265amd_job* jobs, int n)

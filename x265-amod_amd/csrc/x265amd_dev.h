@@ -183,6 +183,41 @@ XA_DEV int xa_had8_abs(const pixel* a, int sa, const pixel* b, int sb)
     return sum;
 }
 
+/* sum of |Hadamard8x8(m)| for a difference block already in registers (same transform as xa_had8_abs) */
+XA_DEV int xa_had8_abs_regs(int m[8][8])
+{
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+#pragma unroll
+        for (int span = 1; span < 8; span <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i += span * 2)
+#pragma unroll
+                for (int j = i; j < i + span; j++)
+                {
+                    int u = m[y][j], v = m[y][j + span];
+                    m[y][j] = u + v; m[y][j + span] = u - v;
+                }
+    int sum = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+    {
+#pragma unroll
+        for (int span = 1; span < 8; span <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i += span * 2)
+#pragma unroll
+                for (int j = i; j < i + span; j++)
+                {
+                    int u = m[j][x], v = m[j + span][x];
+                    m[j][x] = u + v; m[j + span][x] = u - v;
+                }
+#pragma unroll
+        for (int y = 0; y < 8; y++) sum += abs(m[y][x]);
+    }
+    return sum;
+}
+
 /* SAD of a w x h block, lanes strided over samples (pixel.cpp:40-54) */
 XA_DEV int xa_wave_sad(const pixel* a, int sa, const pixel* b, int sb, int w, int h, int lane)
 {
@@ -235,6 +270,46 @@ XA_DEV int xa_wave_sa8d(const pixel* a, int sa, const pixel* b, int sb, int size
     int v = (lane & 3) == 0 && lane < 4 * g * g ? (raw + 2) >> 2 : 0;
     return xa_wave_sum(v);
 }
+
+/* ---- intra building blocks shared by the job-list and the fused intra kernels ---- */
+/* one angular prediction sample in "vertical orientation" on (possibly swapped) neighbours: intrapred.cpp:106-196 */
+XA_DEV pixel ang_sample(const pixel* s, int N, int angle, int invAngle, int bFilter, int y, int x)
+{
+    int N2 = 2 * N;
+    if (!angle)
+    {
+        if (bFilter && x == 0)
+            return xa_clip_pixel((int16_t)(s[1] + ((s[N2 + 1 + y] - s[0]) >> 1)));
+        return s[1 + x];
+    }
+    int angSum = (y + 1) * angle;
+    int off = angSum >> 5, frac = angSum & 31;
+    /* ref[i]: i >= -1 -> s[i+1]; i <= -2 (negative angles only) -> projected left neighbour */
+    int i0 = off + x, i1 = off + x + 1;
+    int r0, r1;
+    if (i0 >= -1) r0 = s[i0 + 1];
+    else r0 = s[N2 + ((128 + (-1 - i0) * invAngle) >> 8)];
+    if (!frac) return (pixel)r0;
+    if (i1 >= -1) r1 = s[i1 + 1];
+    else r1 = s[N2 + ((128 + (-1 - i1) * invAngle) >> 8)];
+    return (pixel)(((32 - frac) * r0 + frac * r1 + 16) >> 5);
+}
+
+/* intrapred.cpp:30-52 */
+XA_DEV void wave_intra_filter(const pixel* s, pixel* f, int N, int lane)
+{
+    int N2 = 2 * N;
+    for (int i = lane; i <= 2 * N2; i += XA_WAVE)
+    {
+        int v;
+        if (i == 0) v = (2 * s[0] + s[1] + s[N2 + 1] + 2) >> 2;
+        else if (i == N2 || i == 2 * N2) v = s[i];
+        else if (i == N2 + 1) v = (2 * s[N2 + 1] + s[0] + s[N2 + 2] + 2) >> 2;
+        else v = (2 * s[i] + s[i - 1] + s[i + 1] + 2) >> 2;
+        f[i] = (pixel)v;
+    }
+}
+
 
 /* ---- block metrics shared by the job-list and the fused TU kernels ---- */
 XA_DEV uint64_t wave_sse_pp(const pixel* a, int sa, const pixel* b, int sb, int size, int lane)     /* pixel.cpp:167-186 */
