@@ -43,17 +43,77 @@ def lcg_noise(shape, seed):
 
 
 def make_clip(nframes):
-    """padded luma planes of a moving textured gradient: frame t is the base shifted by (2t, t) samples"""
+    """padded planes (Y, U, V) of a moving textured gradient: frame t is the base shifted by (2t, t) luma samples"""
     bw, bh = W + 2 * nframes + 8, H + nframes + 8
     yy, xx = np.mgrid[0:bh, 0:bw].astype(np.int64)
     base = 128 + ((xx * 3 + yy * 2) % 160 - 80) // 2 + (((xx >> 4) ^ (yy >> 4)) & 7) * 6 + lcg_noise((bh, bw), 0x9E3779B9 ^ (2 << 8))
     base = np.clip(base, 0, 255)
+    cy, cx = np.mgrid[0:bh // 2, 0:bw // 2].astype(np.int64)
+    baseU = np.clip(96 + (cx + cy) % 64 + lcg_noise((bh // 2, bw // 2), 77) // 3, 0, 255)
+    baseV = np.clip(160 - (cx * 2 + cy) % 48 + lcg_noise((bh // 2, bw // 2), 78) // 3, 0, 255)
     frames = []
     for t in range(nframes):
-        pic = base[t:t + H, 2 * t:2 * t + W] + lcg_noise((H, W), 1000 + t) // 4
-        pic = np.clip(pic, 0, 255).astype(np.uint8)
-        frames.append(np.pad(pic, ((MARGIN_Y, MARGIN_Y), (MARGIN_X, MARGIN_X)), mode="edge"))
+        pic = np.clip(base[t:t + H, 2 * t:2 * t + W] + lcg_noise((H, W), 1000 + t) // 4, 0, 255).astype(np.uint8)
+        u = np.clip(baseU[t // 2:t // 2 + H // 2, t:t + W // 2] + lcg_noise((H // 2, W // 2), 2000 + t) // 6, 0, 255).astype(np.uint8)
+        v = np.clip(baseV[t // 2:t // 2 + H // 2, t:t + W // 2] + lcg_noise((H // 2, W // 2), 3000 + t) // 6, 0, 255).astype(np.uint8)
+        frames.append((np.pad(pic, ((MARGIN_Y, MARGIN_Y), (MARGIN_X, MARGIN_X)), mode="edge"),
+                       np.pad(u, ((MARGIN_Y // 2, MARGIN_Y // 2), (MARGIN_X // 2, MARGIN_X // 2)), mode="edge"),
+                       np.pad(v, ((MARGIN_Y // 2, MARGIN_Y // 2), (MARGIN_X // 2, MARGIN_X // 2)), mode="edge")))
     return frames
+
+
+def cu_grid(size):
+    """top-left corners of every size x size CU that lies inside the picture"""
+    ys, xs = np.mgrid[0:H - size + 1:size, 0:W - size + 1:size]
+    return xs.ravel().astype(np.int64), ys.ravel().astype(np.int64)
+
+
+def tu_jobs(T, cur, ref, arena_base):
+    """residual measurements of one frame: for every CU of size 32/16/8 the luma TU and both chroma TUs, prediction = the
+    previous picture displaced by the true motion (inter P-slice, sign hiding on).  Returns (jobs, arena_bytes)."""
+    stride, stride_c = W + 2 * MARGIN_X, W // 2 + MARGIN_X
+    org, org_c = MARGIN_Y * stride + MARGIN_X, (MARGIN_Y // 2) * stride_c + MARGIN_X // 2
+    parts, off = [], 0
+    for size in (32, 16, 8):
+        x, y = cu_grid(size)
+        for plane, (n, st, o, mvx, mvy, qp) in enumerate(((size, stride, org, 2, 1, QP), (size // 2, stride_c, org_c, 1, 0, 31), (size // 2, stride_c, org_c, 1, 0, 31))):
+            sx, sy = (x, y) if plane == 0 else (x // 2, y // 2)
+            j = np.zeros(len(x), T.TU_JOB_DT)
+            j["fenc"] = cur[plane] + o + sy * st + sx
+            j["pred"] = ref[plane] + o + (sy + mvy) * st + sx + mvx
+            per = n * n * 5                                   # recon n*n, coeff 2*n*n, resi 2*n*n
+            base = arena_base + off + np.arange(len(x), dtype=np.int64) * per
+            j["recon"], j["coeff"], j["resi"] = base, base + n * n, base + 3 * n * n
+            j["fenc_stride"], j["pred_stride"], j["resi_stride"], j["recon_stride"] = st, st, n, n
+            j["log2"], j["ttype"], j["intra"], j["dir"], j["slice"], j["qp"], j["signhide"] = int(np.log2(n)), plane, 0, 0, 1, qp, 1
+            off += len(x) * per
+            parts.append(j)
+    return np.concatenate(parts), off
+
+
+def intra_jobs(T, cur, ref):
+    """35-mode scans of one frame: every CU of size 32/16/8; the previous picture stands in for the reconstruction"""
+    stride = W + 2 * MARGIN_X
+    org = MARGIN_Y * stride + MARGIN_X
+    parts = []
+    for size in (32, 16, 8):
+        x, y = cu_grid(size)
+        u = size // 4
+        left, above = x > 0, y > 0
+        above_right = above & (x + 2 * size <= W) & (((x // size) & 1) == 0)
+        mask = np.zeros(len(x), np.uint64)
+        ones = lambda k: np.uint64((1 << k) - 1)
+        mask |= np.where(left, ones(u) << np.uint64(u), np.uint64(0))
+        mask |= np.where(left & above, np.uint64(1) << np.uint64(2 * u), np.uint64(0))
+        mask |= np.where(above, ones(u) << np.uint64(2 * u + 1), np.uint64(0))
+        mask |= np.where(above_right, ones(u) << np.uint64(3 * u + 1), np.uint64(0))
+        j = np.zeros(len(x), T.INTRA_JOB_DT)
+        j["recon"] = ref[0] + org + y * stride + x
+        j["fenc"] = cur[0] + org + y * stride + x
+        j["avail"] = mask
+        j["recon_stride"], j["fenc_stride"], j["log2"], j["strong"] = stride, stride, int(np.log2(size)), 1
+        parts.append(j)
+    return np.concatenate(parts)
 
 
 def frame_jobs(T, refdist):
@@ -77,31 +137,64 @@ def frame_jobs(T, refdist):
     return jobs
 
 
-def cpu_baseline(T, frames, packed_by_ref, budget_s=15.0):
-    """the same searches on ONE host core, timed inside one C loop: through the reference's own MotionEstimate class
-    (oracle/_ref, kind "reference") when that build is present, else through the oracle port.  Bounded sample."""
+def cpu_baseline(T, frames, packed_by_ref, budget_s=20.0):
+    """the SAME frame workload on ONE host core, timed inside C loops: through the reference's own MotionEstimate / Predict /
+    Quant classes and primitives (oracle/_ref, kind "reference") when that build is present, else through the oracle port.
+    Bounded: each of the three parts is cut off at its share of the budget and extrapolated."""
     if T.have_ref():
         L, kind = T.load_ref(DEPTH), "reference"
     else:
         L, kind = T.load_oracle(DEPTH), "port"
     stride = W + 2 * MARGIN_X
     origin = MARGIN_Y * stride + MARGIN_X
-    cur = frames[NUM_REFS].ravel()
-    total_jobs = sum(len(j) for j in packed_by_ref)
-    done, spent = 0, 0.0
+    cur, prev = frames[NUM_REFS], frames[NUM_REFS - 1]
+    hcur = np.concatenate([p.ravel() for p in cur]); hprev = np.concatenate([p.ravel() for p in prev])
+    ysz, csz = cur[0].size, cur[1].size
+    addr = lambda h: (h.ctypes.data, h.ctypes.data + ysz, h.ctypes.data + ysz + csz)
+    secs_per_frame, notes = 0.0, []
+    # motion searches
+    total, done, spent = sum(len(j) for j in packed_by_ref), 0, 0.0
     for r, pk in enumerate(packed_by_ref):
-        ref = frames[NUM_REFS - 1 - r].ravel()
+        ref = frames[NUM_REFS - 1 - r][0].ravel()
         for k in range(0, len(pk), 8192):
             t0 = time.perf_counter()
-            T.me_run_host_batch(L, cur, ref, stride, origin, pk[k:k + 8192])
-            spent += time.perf_counter() - t0
-            done += len(pk[k:k + 8192])
-            if spent > budget_s * (r + 1) / NUM_REFS:
+            T.me_run_host_batch(L, cur[0].ravel(), ref, stride, origin, pk[k:k + 8192])
+            spent += time.perf_counter() - t0; done += len(pk[k:k + 8192])
+            if spent > budget_s / 3 * (r + 1) / NUM_REFS:
                 break
-    fps = (done / spent) / total_jobs
-    return {"value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "%d of the %d motion searches of one 1080p frame (all PU sizes, 3 refs) in %.1f s on one core, extrapolated to frames/s"
-                      % (done, total_jobs, spent)}
+    secs_per_frame += spent * total / done; notes.append("%d/%d searches %.1fs" % (done, total, spent))
+    # intra scans
+    ij = intra_jobs(T, addr(hcur), addr(hprev))
+    out = np.zeros(len(ij) * 35, np.int32)
+    fn = getattr(L.lib, L.prefix + "intra_scan_batch")
+    done, spent = 0, 0.0
+    for k in range(0, len(ij), 2048):
+        t0 = time.perf_counter()
+        fn(T._ptr(np.ascontiguousarray(ij[k:k + 2048])), len(ij[k:k + 2048]), T.off(out, 35 * k))
+        spent += time.perf_counter() - t0; done += len(ij[k:k + 2048])
+        if spent > budget_s / 3:
+            break
+    secs_per_frame += spent * len(ij) / done; notes.append("%d/%d intra scans %.1fs" % (done, len(ij), spent))
+    # TU chains
+    arena = np.zeros(1, np.uint8)
+    tj, nbytes = tu_jobs(T, addr(hcur), addr(hprev), 0)
+    arena = np.zeros(nbytes, np.uint8)
+    for f in ("recon", "coeff", "resi"):
+        tj[f] += arena.ctypes.data
+    tout = np.zeros(len(tj), T.TU_RESULT_DT)
+    fn = getattr(L.lib, L.prefix + "tu_chain_batch")
+    done, spent = 0, 0.0
+    order = np.random.default_rng(0).permutation(len(tj))       # sizes are grouped in the list: sample them evenly
+    tj = np.ascontiguousarray(tj[order])
+    for k in range(0, len(tj), 4096):
+        t0 = time.perf_counter()
+        fn(T._ptr(tj[k:k + 4096]), len(tj[k:k + 4096]), T.off(tout.view(np.uint8), 32 * k))
+        spent += time.perf_counter() - t0; done += len(tj[k:k + 4096])
+        if spent > budget_s / 3:
+            break
+    secs_per_frame += spent * len(tj) / done; notes.append("%d/%d TU chains %.1fs" % (done, len(tj), spent))
+    return {"value": 1.0 / secs_per_frame, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "one 1080p frame of the same workload on one core: " + ", ".join(notes) + "; parts cut at their budget are extrapolated"}
 
 
 def measured_traffic():
@@ -137,13 +230,17 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     me = T.HipME(DEPTH)
+    lib = me.lib
     stride = W + 2 * MARGIN_X
     origin = MARGIN_Y * stride + MARGIN_X
     nring = NUM_REFS + 6
     frames = make_clip(nring)
-    d_frames = [me.upload(f) for f in frames]
+    # one contiguous device buffer per picture: Y | U | V  (the unit that is published to the other ranks)
+    ysz, csz = frames[0][0].size, frames[0][1].size
+    d_pics = [me.upload(np.concatenate([f[0].ravel(), f[1].ravel(), f[2].ravel()])) for f in frames]
+    planes = [(d.data_ptr(), d.data_ptr() + ysz, d.data_ptr() + ysz + csz) for d in d_pics]
 
-    # job lists: identical PU set for each reference distance; planned once (windows depend only on the predictors)
+    # ---- motion estimation: identical PU set for each reference distance; planned once ----
     jobs_by_ref = [frame_jobs(T, r + 1) for r in range(NUM_REFS)]
     packed, groups, packed_unordered = [], [], []
     base = 0
@@ -157,40 +254,63 @@ def main():
     packed = np.concatenate(packed); groups = np.concatenate(groups)
     d_groups, d_jobs = me.upload(groups), me.upload(packed)
     d_out = torch.zeros(len(packed) * 8, dtype=torch.uint8, device="cuda")
-    alg_bytes = int((groups["win_w"].astype(np.int64) * groups["win_h"]).sum() + len(groups) * 64 * 64 + len(packed) * (72 + 8))
+    me_bytes = int((groups["win_w"].astype(np.int64) * groups["win_h"]).sum() + len(groups) * 64 * 64 + len(packed) * (72 + 8))
+
+    # ---- residual + intra job lists, one variant per possible current picture (addresses are absolute) ----
+    curs = list(range(NUM_REFS, nring))
+    tu0, arena_bytes = tu_jobs(T, planes[curs[0]], planes[curs[0] - 1], 0)
+    d_arena = torch.zeros(arena_bytes, dtype=torch.uint8, device="cuda")
+    d_tu, d_in, reftab = {}, {}, {}
+    for cur in curs:
+        tj, _ = tu_jobs(T, planes[cur], planes[cur - 1], d_arena.data_ptr())
+        d_tu[cur] = me.upload(tj)
+        d_in[cur] = me.upload(intra_jobs(T, planes[cur], planes[cur - 1]))
+        reftab[cur] = me.upload(np.array([planes[cur - 1 - r][0] + origin for r in range(NUM_REFS)], np.uint64))
+    n_tu, n_in = len(tu0), len(intra_jobs(T, planes[curs[0]], planes[curs[0] - 1]))
+    d_tu_out = torch.zeros(n_tu * T.TU_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda")
+    d_in_out = torch.zeros(n_in * 35, dtype=torch.int32, device="cuda")
+    tu_n2 = (1 << tu0["log2"].astype(np.int64)) ** 2
+    tu_bytes = int((tu_n2 * (1 + 1 + 1 + 2 + 2)).sum() + n_tu * (64 + 32))
+    ij = intra_jobs(T, planes[curs[0]], planes[curs[0] - 1])
+    in_n = 1 << ij["log2"].astype(np.int64)
+    in_bytes = int((in_n * in_n + 4 * in_n + 1).sum() + n_in * (40 + 140))
 
     stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
     import __graft_entry__ as entry
     fs = entry.load_package().frame_shard
     ring, gather = fs.ReferenceRing(depth=NUM_REFS * max(world, 1) + world), [None]
+    NK = 3
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(NK + 1)] for _ in range(args.steps)]
 
-    def step(k):
-        cur = NUM_REFS + (k % (nring - NUM_REFS))
-        rt = reftab[cur]
-        rc = me.lib.x265amd_me_search(me.ctx, C.c_void_p(stream.cuda_stream), C.c_void_p(d_frames[cur].data_ptr() + origin),
-                                      C.c_void_p(rt.data_ptr()), C.c_int64(stride), C.c_void_p(d_groups.data_ptr()), len(groups),
-                                      C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), MAX_WIN[0], MAX_WIN[1], 0)
-        assert rc == 0, me.lib.x265amd_last_error()
+    def step(k, marks=None):
+        cur = curs[k % len(curs)]
+        if marks: marks[0].record(stream)
+        rc = lib.x265amd_me_search(me.ctx, sp, C.c_void_p(planes[cur][0] + origin), C.c_void_p(reftab[cur].data_ptr()), C.c_int64(stride),
+                                   C.c_void_p(d_groups.data_ptr()), len(groups), C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()),
+                                   MAX_WIN[0], MAX_WIN[1], 0)
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[1].record(stream)
+        rc = lib.x265amd_intra_scan(sp, C.c_void_p(d_in[cur].data_ptr()), n_in, C.c_void_p(d_in_out.data_ptr()), None)
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[2].record(stream)
+        rc = lib.x265amd_tu_chain(sp, C.c_void_p(d_tu[cur].data_ptr()), n_tu, C.c_void_p(d_tu_out.data_ptr()))
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[3].record(stream)
         if world > 1:
             # exchange step of the frame-parallel design: every rank publishes the picture it just finished so that all
             # ranks hold it as a reference (here the source stands in for the reconstruction)
-            gather[0] = fs.publish_step(d_frames[cur], k, ring, gather[0])
+            gather[0] = fs.publish_step(d_pics[cur], k, ring, gather[0])
 
-    # device tables of reference-plane addresses, one per possible current frame (built outside the timed region)
-    reftab = {cur: me.upload(np.array([d_frames[cur - 1 - r].data_ptr() + origin for r in range(NUM_REFS)], np.uint64))
-              for cur in range(NUM_REFS, nring)}
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        step(args.warmup + k)
-        ev[k][1].record(stream)
+        step(args.warmup + k, ev[k])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,45 +320,71 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))     # HIP events on the launch stream
+    kms = [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(NK)]     # HIP events on the launch stream
 
     if rank == 0:
-        # parity spot check inside the bench: a sample of this very workload (last step's frame) against the oracle
-        res = d_out.cpu().numpy().view(T.ME_RESULT_DT)
-        last = NUM_REFS + ((args.warmup + args.steps - 1) % (nring - NUM_REFS))
+        # ---- parity spot checks inside the bench: samples of this very workload (last step's frame) against the oracle ----
         orc = T.load_oracle(DEPTH)
-        parity_ok, checked, off0 = True, 0, 0
+        last = curs[(args.warmup + args.steps - 1) % len(curs)]
+        res = d_out.cpu().numpy().view(T.ME_RESULT_DT)
+        ok, checked, off0 = True, 0, 0
         for r in range(NUM_REFS):
             n_r = len(jobs_by_ref[r])
             pk = packed[off0:off0 + n_r]
-            for i in range(r, n_r, 509):
-                j = dict(x=int(pk[i]["x"]), y=int(pk[i]["y"]), w=int(pk[i]["w"]), h=int(pk[i]["h"]), qp=int(pk[i]["qp"]),
-                         mvp=tuple(int(v) for v in pk[i]["mvp"]), mvmin=tuple(int(v) for v in pk[i]["mvmin"]), mvmax=tuple(int(v) for v in pk[i]["mvmax"]),
-                         mvc=[tuple(int(v) for v in pk[i]["mvc"][k]) for k in range(int(pk[i]["num_cand"]))], merange=int(pk[i]["merange"]),
-                         method=int(pk[i]["method"]), subme=int(pk[i]["subme"]))
-                want = T.me_run_host(orc, frames[last].ravel(), frames[last - 1 - r].ravel(), stride, origin, [j])[0]
-                got = (int(res[off0 + i]["mv"][0]), int(res[off0 + i]["mv"][1]), int(res[off0 + i]["cost"]))
-                parity_ok &= tuple(int(v) for v in want) == got
-                checked += 1
+            sel = np.arange(r, n_r, 509)
+            want = T.me_run_host_batch(orc, frames[last][0].ravel(), frames[last - 1 - r][0].ravel(), stride, origin, pk[sel])
+            got = np.stack([res["mv"][off0 + sel, 0], res["mv"][off0 + sel, 1], res["cost"][off0 + sel]], axis=1)
+            ok &= bool(np.array_equal(want, got)); checked += len(sel)
             off0 += n_r
+        # TU chain and intra scan samples
+        tj = d_tu[last].cpu().numpy().view(T.TU_JOB_DT)
+        tres = d_tu_out.cpu().numpy().view(T.TU_RESULT_DT)
+        host = [np.concatenate([f[0].ravel(), f[1].ravel(), f[2].ravel()]) for f in (frames[last], frames[last - 1])]
+        bases = (d_pics[last].data_ptr(), d_pics[last - 1].data_ptr())
+        tu_ok = True
+        for i in range(0, n_tu, 997):
+            N = 1 << int(tj[i]["log2"])
+            fo, po = int(tj[i]["fenc"]) - bases[0], int(tj[i]["pred"]) - bases[1]
+            coeff = np.zeros(N * N, np.int16); resi = np.zeros((N, N), np.int16); recon = np.zeros((N, N), np.uint8); st = np.zeros(5, np.uint64)
+            orc.lib.orc_tu_chain(T.off(host[0], fo), C.c_int64(int(tj[i]["fenc_stride"])), T.off(host[1], po), C.c_int64(int(tj[i]["pred_stride"])), int(tj[i]["log2"]),
+                                 int(tj[i]["ttype"]), 0, 0, 1, int(tj[i]["qp"]), 1, T._ptr(coeff), T._ptr(resi), C.c_int64(N), T._ptr(recon), C.c_int64(N), T._ptr(st))
+            g = tres[i]
+            tu_ok &= (int(g["num_sig"]), int(g["zero_dist"]), int(g["zero_energy"]), int(g["nz_dist"]), int(g["nz_energy"])) == tuple(int(v) for v in st)
+            checked += 1
+        ijb = d_in[last].cpu().numpy().view(T.INTRA_JOB_DT)
+        ires = d_in_out.cpu().numpy().reshape(-1, 35)
+        in_ok = True
+        for i in range(0, n_in, 499):
+            N = 1 << int(ijb[i]["log2"])
+            flags = np.array([(int(ijb[i]["avail"]) >> u) & 1 for u in range(N + 1)], np.uint8)
+            rb = np.zeros(258, np.uint8); fb = np.zeros(258, np.uint8); sa = np.zeros(35, np.int32)
+            orc.lib.orc_init_adi_pattern(T.off(host[1], int(ijb[i]["recon"]) - bases[1]), C.c_int64(stride), int(ijb[i]["log2"]), T._ptr(flags), 1, -1, T._ptr(rb), T._ptr(fb))
+            orc.lib.orc_intra_scan(T.off(host[0], int(ijb[i]["fenc"]) - bases[0]), C.c_int64(stride), int(ijb[i]["log2"]), T._ptr(rb), T._ptr(fb), T._ptr(sa))
+            in_ok &= bool(np.array_equal(sa, ires[i])); checked += 1
+        names = ("k_me_search", "k_intra_scan", "k_tu_chain")
+        algb = (me_bytes, in_bytes, tu_bytes)
+        dom = int(np.argmax(kms))
         line = {
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
             "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1920x1080 8-bit 4:2:0 synthetic, --preset medium search parameters (hex, merange 57, subme 2, 3 refs): "
-                                   "motion-estimation hot path only (every 2Nx2N PU 64..8 of every CTU x 3 refs = %d searches/frame); "
-                                   "NOT a full encode" % len(packed),
-                       "frames_per_step_per_gpu": 1, "searches_per_frame": int(len(packed)), "parallelism": "frame-per-gpu x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "k_me_search", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "config": {"workload": "1920x1080 8-bit 4:2:0 synthetic, --preset medium parameters: analysis hot-path kernels of one frame = "
+                                   "%d motion searches (every 2Nx2N PU 64..8 of every CTU x 3 refs; hex, merange 57, subme 2) + %d intra 35-mode scans "
+                                   "(CUs 32/16/8) + %d TU residual chains (luma + 2 chroma per CU 32/16/8; dct, quant, sign hiding, dequant, idct, recon, sse, psy); "
+                                   "NOT a full encode (no mode decision / entropy coding yet)" % (len(packed), n_in, n_tu),
+                       "frames_per_step_per_gpu": 1, "parallelism": "frame-per-gpu x%d" % world},
+            "kernels": {names[i]: {"ms": kms[i], "algorithmic_bytes": algb[i], "GB/s": algb[i] / (kms[i] * 1e-3) / 1e9} for i in range(NK)},
+            "roofline": {"bound": "hbm", "achieved": algb[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": algb[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic() if dom == 0 else None,
+                         "kernel": names[dom], "kernel_ms": kms[dom], "algorithmic_bytes_per_launch": algb[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, frames, packed_unordered)
         else:
             line["cpu_baseline"] = None
-        line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(parity_ok)}
+        line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(ok and tu_ok and in_ok),
+                                 "me": bool(ok), "tu_chain": bool(tu_ok), "intra_scan": bool(in_ok)}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -104,3 +104,19 @@ void orc_intra_scan(const pixel* fenc, intptr_t fencStride, int log2TrSize, cons
         sa8d35[mode] = orc_sa8d(cu, fenc, fencStride, pred, N);
     }
 }
+
+typedef struct { uint64_t recon, fenc, avail; int32_t reconStride, fencStride; uint8_t log2, strong, reserved[6]; } PackedIntraJob;
+int orc_intra_scan_batch(const PackedIntraJob* jobs, int n, int32_t* sa8d)
+{
+    pixel rb[258], fb[258];
+    uint8_t flags[33];
+    for (int i = 0; i < n; i++)
+    {
+        const PackedIntraJob* j = &jobs[i];
+        int total = (1 << j->log2) + 1;
+        for (int u = 0; u < total; u++) flags[u] = (uint8_t)((j->avail >> u) & 1);
+        orc_init_adi_pattern((const pixel*)j->recon, j->reconStride, j->log2, flags, j->strong, -1, rb, fb);
+        orc_intra_scan((const pixel*)j->fenc, j->fencStride, j->log2, rb, j->log2 >= 3 ? fb : rb, sa8d + 35 * i);
+    }
+    return n;
+}

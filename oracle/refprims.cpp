@@ -326,4 +326,54 @@ void ref_intra_scan(const pixel* fenc, intptr_t fencStride, int log2TrSize, cons
     }
 }
 
+/* ---- batch forms for bench.py's cpu_baseline leg (records of include/x265amd.h; addresses are HOST addresses here) ---- */
+struct PackedTuJob { uint64_t fenc, pred, coeff, resi, recon; int32_t fencStride, predStride, resiStride, reconStride;
+                     uint8_t log2, ttype, intra, dir, slice, qp, signhide, reserved; };
+struct PackedTuResult { uint32_t numSig, zeroEnergy, nzEnergy, reserved; uint64_t zeroDist, nzDist; };
+
+/* the per-TU measurement of estimateResidualQT (search.cpp:3276-3330) with the reference's own functions */
+int ref_tu_chain_batch(const PackedTuJob* jobs, int n, PackedTuResult* out)
+{
+    TuEnv* e = tuEnv();
+    ALIGN_VAR_32(int16_t, resi[32 * 32]);
+    for (int i = 0; i < n; i++)
+    {
+        const PackedTuJob& j = jobs[i];
+        const pixel* fenc = (const pixel*)j.fenc; const pixel* pred = (const pixel*)j.pred;
+        int sizeIdx = j.log2 - 2, N = 1 << j.log2;
+        g_p.cu[sizeIdx].sub_ps(resi, N, fenc, pred, j.fencStride, j.predStride);
+        e->set(j.ttype, j.intra, j.dir, j.slice, j.qp, j.signhide);
+        uint32_t ns = e->quant.transformNxN(e->cu, fenc, j.fencStride, resi, N, (coeff_t*)j.coeff, j.log2, (TextType)j.ttype, 0, false);
+        PackedTuResult& r = out[i];
+        r.numSig = ns; r.reserved = 0;
+        r.zeroDist = g_p.cu[sizeIdx].sse_pp(fenc, j.fencStride, pred, j.predStride);
+        r.zeroEnergy = g_p.cu[sizeIdx].psy_cost_pp(fenc, j.fencStride, pred, j.predStride);
+        r.nzDist = r.zeroDist; r.nzEnergy = r.zeroEnergy;
+        if (ns)
+        {
+            e->quant.invtransformNxN(e->cu, (int16_t*)j.resi, j.resiStride, (coeff_t*)j.coeff, j.log2, (TextType)j.ttype, j.intra != 0, false, ns);
+            g_p.cu[sizeIdx].add_ps[NONALIGNED]((pixel*)j.recon, j.reconStride, pred, (int16_t*)j.resi, j.predStride, j.resiStride);
+            r.nzDist = g_p.cu[sizeIdx].sse_pp(fenc, j.fencStride, (pixel*)j.recon, j.reconStride);
+            r.nzEnergy = g_p.cu[sizeIdx].psy_cost_pp(fenc, j.fencStride, (pixel*)j.recon, j.reconStride);
+        }
+    }
+    return n;
+}
+
+struct PackedIntraJob { uint64_t recon, fenc, avail; int32_t reconStride, fencStride; uint8_t log2, strong, reserved[6]; };
+int ref_intra_scan_batch(const PackedIntraJob* jobs, int n, int32_t* sa8d)
+{
+    pixel rb[258], fb[258];
+    uint8_t flags[33];
+    for (int i = 0; i < n; i++)
+    {
+        const PackedIntraJob& j = jobs[i];
+        int total = (1 << j.log2) + 1;
+        for (int u = 0; u < total; u++) flags[u] = (j.avail >> u) & 1;
+        ref_init_adi_pattern((const pixel*)j.recon, j.reconStride, j.log2, flags, j.strong, -1, rb, fb);
+        ref_intra_scan((const pixel*)j.fenc, j.fencStride, j.log2, rb, j.log2 >= 3 ? fb : rb, sa8d + 35 * i);
+    }
+    return n;
+}
+
 } /* extern "C" */
