@@ -59,6 +59,8 @@ struct MeState
     const uint16_t* cost;
     int mvpx, mvpy;
     int mnx, mny, mxx, mxy;
+    int acc[16];        /* per-candidate accumulators of the batched sub-pel comparisons */
+    int cand[16];       /* their quarter-pel MVs, packed (qy << 16) | (qx & 0xffff) */
     int oob;            /* set by the window-resident kernel when a candidate left the staged window: the job is redone
                            by the direct-from-HBM kernel (k_me_deferred) */
 };
@@ -229,7 +231,7 @@ __device__ const MeTaps me_taps = me_make_taps();
 
 /* vertical taps arranged by SOURCE row: c[yf][rr] packs, for output rows r = 0..3 of a 4x4 tile, the tap
  * g_lumaFilter[yf][rr - r] (0 when rr - r is outside 0..7) that source row rr (= by-3+rr) contributes */
-struct MeVTaps { uint32_t c[4][11]; };
+struct MeVTaps { uint32_t c[11][4]; };    /* [source row][yf]: the row's four dwords are one uniform (scalar) load */
 constexpr MeVTaps me_make_vtaps()
 {
     MeVTaps t = {};
@@ -240,7 +242,7 @@ constexpr MeVTaps me_make_vtaps()
             {
                 int k = rr - r;
                 int c = (k >= 0 && k < 8) ? lf[f][k] : 0;
-                t.c[f][rr] |= (uint32_t)(uint8_t)(int8_t)c << (8 * r);
+                t.c[rr][f] |= (uint32_t)(uint8_t)(int8_t)c << (8 * r);
             }
     return t;
 }
@@ -249,7 +251,13 @@ __device__ const MeVTaps me_vtaps = me_make_vtaps();
 /* 8-tap horizontal filter sums of 4 consecutive outputs; d0..d2 hold samples x-3 .. x+8 of the row */
 XA_DEV void me_hfilt4(uint32_t d0, uint32_t d1, uint32_t d2, int xf, int out[4])
 {
-    const uint32_t pl = me_taps.pos[xf][0], ph = me_taps.pos[xf][1], nl = me_taps.neg[xf][0], nh = me_taps.neg[xf][1];
+    /* xf may differ from lane to lane (batched candidates): the packed taps are compile-time constants picked with
+     * v_cndmask, not gathered from memory */
+    constexpr MeTaps T = me_make_taps();
+    const uint32_t pl = xf == 1 ? T.pos[1][0] : (xf == 2 ? T.pos[2][0] : T.pos[3][0]);
+    const uint32_t ph = xf == 1 ? T.pos[1][1] : (xf == 2 ? T.pos[2][1] : T.pos[3][1]);
+    const uint32_t nl = xf == 1 ? T.neg[1][0] : (xf == 2 ? T.neg[2][0] : T.neg[3][0]);
+    const uint32_t nh = xf == 1 ? T.neg[1][1] : (xf == 2 ? T.neg[2][1] : T.neg[3][1]);
 #pragma unroll
     for (int j = 0; j < 4; j++)
     {
@@ -313,7 +321,10 @@ XA_DEV void me_pred_tile(const uint32_t* wd, int winW, int bx, int by, int xf, i
 #pragma unroll
             for (int x = 0; x < 4; x++) iv[x] = (int)(int16_t)(iv[x] - XA_IF_INTERNAL_OFFS);
         }
-        const uint32_t cw = me_vtaps.c[yf][rr];    /* taps of source row rr for output rows 0..3, one signed byte each */
+        /* taps of source row rr for output rows 0..3, one signed byte each.  rr is wave-uniform (scalar load of the row);
+         * yf may differ from lane to lane (batched candidates): selected with two v_cndmask instead of a per-lane gather */
+        const uint32_t c1 = me_vtaps.c[rr][1], c2 = me_vtaps.c[rr][2], c3 = me_vtaps.c[rr][3];
+        const uint32_t cw = yf == 1 ? c1 : (yf == 2 ? c2 : c3);
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
@@ -401,6 +412,15 @@ template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_f(int sOff,
     return ME_OOB_COST;
 }
 
+__device__ const int8_t me_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__device__ const uint8_t me_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+__device__ const int8_t me_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+__device__ const int8_t me_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
+                                              { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
+/* motion.cpp:48-58: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
+__device__ const uint8_t me_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
+                                               { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
+
 /* SAD + MV cost of up to four full-pel candidates in one call (the reference's sad_x3 / sad_x4 batches,
  * motion.cpp:271-360).  Candidates are packed (my << 16) | (mx & 0xffff).  Returns, in lane k, the cost of candidate k.
  * Small PUs run several candidates side by side in one pass: a PU with <= 16 four-sample groups (8x8) evaluates
@@ -440,7 +460,7 @@ template<bool SLOW> __device__ __noinline__ int me_cost_multi_f(int sOff, int n,
                 uint32_t rv = me_win_dword(wd, (Y + y) * s.winW + X + 4 * x4);
                 sum = __builtin_amdgcn_sad_u8(fv, rv, sum);
             }
-            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
+            sum = xa_row16_sum(sum);                    /* every lane: sum of its 16-lane row (DPP) */
             if (lgseg >= 5) sum += __shfl_xor(sum, 16, 64);
             if (lgseg >= 6) sum += __shfl_xor(sum, 32, 64);
             int cost = sum + me_mvcost(s, mx * 4, my * 4);
@@ -463,6 +483,103 @@ template<bool SLOW> __device__ __noinline__ int me_cost_multi_f(int sOff, int n,
     return res;
 }
 #define ME_LANE(v, k) __builtin_amdgcn_readlane((v), (k))
+
+/* Sub-pel comparison (subpelCompare, motion.cpp:1596-1623) of up to 16 quarter-pel candidates in one call: the
+ * candidates are read from MeState::cand[0..n), lane k returns the SAD/SATD of candidate k (MV cost not included).  All
+ * (candidate, 4x4 tile) pairs are spread over the lanes -- an 8x8 PU with 4 candidates keeps 16 lanes busy instead of 4, a
+ * 16x16 PU all 64 -- and summed per candidate with LDS atomics.  Evaluation has no side effects, so callers may evaluate
+ * candidates the reference would skip and apply the reference's tests and selection order afterwards. */
+template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_list_f(int sOff, int n)
+{
+    const MeState& s = ME_S(sOff);
+    const int lane = xa_lane();
+#if XA_DEPTH == 8
+    bool fast = !SLOW;
+    for (int k = 0; k < n && fast; k++)
+    {
+        int qx = (int)(int16_t)(s.cand[k] & 0xffff), qy = s.cand[k] >> 16;
+        int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
+        fast = me_inwin(s, X0 - 3, Y0 - 3, X0 + s.w + 8, Y0 + s.h + 4);
+    }
+    if (fast)
+    {
+        int* acc = reinterpret_cast<int*>(me_smem + sOff + offsetof(MeState, acc));
+        if (lane < 16) acc[lane] = 0;
+        xa_wave_sync();
+        const uint32_t* wd = reinterpret_cast<const uint32_t*>(s.win);
+        const uint32_t* fd = reinterpret_cast<const uint32_t*>(s.fencT);
+        const int tw = s.w >> 2, nt = tw * (s.h >> 2), invT = ((1 << 20) + tw - 1) / tw, invN = ((1 << 20) + nt - 1) / nt;
+        for (int item = lane; item < nt * n; item += XA_WAVE)
+        {
+            int c = (item * invN) >> 20, t = item - c * nt;
+            int ty = (t * invT) >> 20, tx = t - ty * tw;
+            int qx = (int)(int16_t)(s.cand[c] & 0xffff), qy = s.cand[c] >> 16;
+            int pred[4][4];
+            me_pred_tile(wd, s.winW, s.px + (qx >> 2) - s.winX + 4 * tx, s.py + (qy >> 2) - s.winY + 4 * ty, qx & 3, qy & 3, pred);
+            int d[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+            {
+                uint32_t f = fd[(s.fy + 4 * ty + y) * 16 + (s.fx >> 2) + tx];
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    d[y][x] = (int)__builtin_amdgcn_ubfe(f, 8 * x, 8) - pred[y][x];
+            }
+            int cost = 0;
+            if (SATD)
+            {
+                int tt[4][4];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                {
+                    int s01 = d[y][0] + d[y][1], e01 = d[y][0] - d[y][1], s23 = d[y][2] + d[y][3], e23 = d[y][2] - d[y][3];
+                    tt[y][0] = s01 + s23; tt[y][1] = s01 - s23; tt[y][2] = e01 + e23; tt[y][3] = e01 - e23;
+                }
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                {
+                    int s01 = tt[0][x] + tt[1][x], e01 = tt[0][x] - tt[1][x], s23 = tt[2][x] + tt[3][x], e23 = tt[2][x] - tt[3][x];
+                    cost += abs(s01 + s23) + abs(s01 - s23) + abs(e01 + e23) + abs(e01 - e23);
+                }
+                cost >>= 1;
+            }
+            else
+            {
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) cost += abs(d[y][x]);
+            }
+            atomicAdd(&acc[c], cost);
+        }
+        xa_wave_sync();
+        int res = lane < n ? acc[lane] : ME_OOB_COST;
+        xa_wave_sync();
+        return res;
+    }
+#endif
+    int res = ME_OOB_COST;
+    for (int k = 0; k < n; k++)
+    {
+        int c = me_subpel_f<SATD, SLOW>(sOff, (int)(int16_t)(s.cand[k] & 0xffff), s.cand[k] >> 16);
+        if (lane == k) res = c;
+    }
+    return res;
+}
+
+/* One refinement round of motion.cpp:1535-1586: costs (comparison + MV cost) of the `dirs` (4 or 8) neighbours
+ * square1[1..dirs] * step of the quarter-pel MV (bqx,bqy); lane i-1 returns the cost of direction i. */
+template<bool SATD, bool SLOW> XA_DEV int me_subpel_dirs_f(int sOff, int bqx, int bqy, int step, int dirs)
+{
+    const MeState& s = ME_S(sOff);
+    const int lane = xa_lane();
+    const int qx = bqx + (lane < dirs ? me_square1[lane + 1][0] * step : 0), qy = bqy + (lane < dirs ? me_square1[lane + 1][1] * step : 0);
+    int* cand = reinterpret_cast<int*>(me_smem + sOff + offsetof(MeState, cand));
+    if (lane < dirs) cand[lane] = ME_PK(qx, qy);
+    xa_wave_sync();
+    int v = me_subpel_list_f<SATD, SLOW>(sOff, dirs);
+    return lane < dirs ? v + me_mvcost(s, qx, qy) : ME_OOB_COST;
+}
 
 #define me_subpel_sad(qx, qy) me_subpel_f<false, SLOW>(sOff, qx, qy)
 #define me_subpel_satd(qx, qy) me_subpel_f<true, SLOW>(sOff, qx, qy)
@@ -556,15 +673,6 @@ template<bool SLOW> __device__ __noinline__ void me_star_pattern(int sOff, int& 
     }
 }
 
-__device__ const int8_t me_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
-__device__ const uint8_t me_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
-__device__ const int8_t me_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
-__device__ const int8_t me_offsets[16][2] = { { -1, 0 }, { 0, -1 }, { -1, -1 }, { 1, -1 }, { -1, 0 }, { 1, 0 }, { -1, 1 }, { -1, -1 },
-                                              { 1, -1 }, { 1, 1 }, { -1, 0 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { 1, 0 }, { 0, 1 } };
-/* motion.cpp:48-58: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
-__device__ const uint8_t me_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 0 }, { 1, 4, 1, 4, 1 }, { 2, 4, 1, 4, 1 },
-                                               { 2, 4, 2, 4, 1 }, { 1, 8, 1, 8, 1 }, { 2, 8, 1, 8, 1 }, { 2, 8, 2, 8, 1 } };
-
 /* MotionEstimate::motionEstimate: motion.cpp:764-1594 (full-resolution reference, one slice, luma only) */
 /* `jp` points at the job record in HBM: its fields are wave-uniform scalar loads (a by-value copy would live in scratch
  * because mvc[] is indexed dynamically -- measured as 457 MB of scratch writes per 1080p launch) */
@@ -576,7 +684,18 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
     /* motion.cpp:797-846: predictor, zero MV, candidates */
     int pmx = xa_clip3(qminx, qmaxx, s.mvpx), pmy = xa_clip3(qminy, qmaxy, s.mvpy);
     int bestprex = pmx, bestprey = pmy;
-    int bprecost = me_subpel_sad(pmx, pmy);
+    /* the clipped predictor and every clipped candidate are compared in ONE batched call (evaluation has no side effects;
+     * the reference's skip tests and update order are applied below on the returned values) */
+    {
+        int* cand = reinterpret_cast<int*>(me_smem + sOff + offsetof(MeState, cand));
+        const int lane = xa_lane();
+        if (lane == 0) cand[0] = ME_PK(pmx, pmy);
+        if (lane >= 1 && lane <= numCand)
+            cand[lane] = ME_PK(xa_clip3(qminx, qmaxx, jp->mvc[lane - 1][0]), xa_clip3(qminy, qmaxy, jp->mvc[lane - 1][1]));
+        xa_wave_sync();
+    }
+    const int preSads = me_subpel_list_f<false, SLOW>(sOff, 1 + numCand);
+    int bprecost = __shfl(preSads, 0, 64);
     int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2;
     int bcost = bprecost;
     if ((pmx | pmy) & 3)
@@ -596,7 +715,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         int cx = xa_clip3(qminx, qmaxx, jp->mvc[i][0]), cy = xa_clip3(qminy, qmaxy, jp->mvc[i][1]);
         if ((cx | cy) && (cx != pmx || cy != pmy) && (cx != bestprex || cy != bestprey))
         {
-            int cost = me_subpel_sad(cx, cy) + me_mvcost(s, cx, cy);
+            int cost = __shfl(preSads, i + 1, 64) + me_mvcost(s, cx, cy);
             if (cost < bprecost) { bprecost = cost; bestprex = cx; bestprey = cy; }
         }
     }
@@ -770,11 +889,12 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         for (int iter = 0; iter < wl[0]; iter++)
         {
             int bdir = 0;
+            int cv = hsatd ? me_subpel_dirs_f<true, SLOW>(sOff, bx, by, 2, wl[1]) : me_subpel_dirs_f<false, SLOW>(sOff, bx, by, 2, wl[1]);
             for (int i = 1; i <= wl[1]; i++)
             {
-                int qx = bx + me_square1[i][0] * 2, qy = by + me_square1[i][1] * 2;
+                int qy = by + me_square1[i][1] * 2;
                 if (qy < qminy || qy > qmaxy) continue;
-                int cost = (hsatd ? me_subpel_satd(qx, qy) : me_subpel_sad(qx, qy)) + me_mvcost(s, qx, qy);
+                int cost = __shfl(cv, i - 1, 64);
                 if (cost < bcost) { bcost = cost; bdir = i; }
             }
             if (bdir) { bx += me_square1[bdir][0] * 2; by += me_square1[bdir][1] * 2; }
@@ -785,11 +905,12 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         for (int iter = 0; iter < wl[2]; iter++)
         {
             int bdir = 0;
+            int cv = me_subpel_dirs_f<true, SLOW>(sOff, bx, by, 1, wl[3]);
             for (int i = 1; i <= wl[3]; i++)
             {
-                int qx = bx + me_square1[i][0], qy = by + me_square1[i][1];
+                int qy = by + me_square1[i][1];
                 if (qy < qminy || qy > qmaxy) continue;
-                int cost = me_subpel_satd(qx, qy) + me_mvcost(s, qx, qy);
+                int cost = __shfl(cv, i - 1, 64);
                 if (cost < bcost) { bcost = cost; bdir = i; }
             }
             if (bdir) { bx += me_square1[bdir][0]; by += me_square1[bdir][1]; }

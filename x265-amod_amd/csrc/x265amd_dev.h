@@ -110,6 +110,25 @@ template<class T> XA_DEV T xa_wave_sum(T v)
     return v;
 }
 
+/* 32-bit sums use DPP row operations (one VALU instruction per step, no LDS round trips):
+ * quad_perm / row_ror leave every lane with the sum of its 16-lane row, row_bcast:15 / :31 carry the row sums to lane 63 */
+XA_DEV int xa_row16_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);      /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);      /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true);     /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);     /* row_ror:8 */
+    return v;
+}
+template<> XA_DEV int xa_wave_sum<int>(int v)
+{
+    v = xa_row16_sum(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    /* row_bcast:15 into rows 1 and 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    /* row_bcast:31 into rows 2 and 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template<> XA_DEV uint32_t xa_wave_sum<uint32_t>(uint32_t v) { return (uint32_t)xa_wave_sum<int>((int)v); }
+
 XA_DEV int xa_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 XA_DEV pixel xa_clip_pixel(int v) { return (pixel)xa_clip3(0, XA_PIXEL_MAX, v); }
 
