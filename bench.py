@@ -197,12 +197,12 @@ def cpu_baseline(T, frames, packed_by_ref, budget_s=20.0):
             "sample": "one 1080p frame of the same workload on one core: " + ", ".join(notes) + "; parts cut at their budget are extrapolated"}
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run
-    separately: counters cannot be read inside the bench); the summary is committed under profiles/"""
+def measured_traffic(kernel="k_me_search"):
+    """HBM bytes per launch of a kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately:
+    counters cannot be read inside the bench); the summary is committed under profiles/"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_me_v2_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch_uncorrected"]
+        with open(os.path.join(ROOT, "profiles", "r01_analysis_v3_traffic.json")) as f:
+            return json.load(f)[kernel]["hbm_bytes_per_launch_uncorrected"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -376,7 +376,7 @@ def main():
                        "frames_per_step_per_gpu": 1, "parallelism": "frame-per-gpu x%d" % world},
             "kernels": {names[i]: {"ms": kms[i], "algorithmic_bytes": algb[i], "GB/s": algb[i] / (kms[i] * 1e-3) / 1e9} for i in range(NK)},
             "roofline": {"bound": "hbm", "achieved": algb[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algb[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic() if dom == 0 else None,
+                         "frac": algb[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(names[dom]),
                          "kernel": names[dom], "kernel_ms": kms[dom], "algorithmic_bytes_per_launch": algb[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
