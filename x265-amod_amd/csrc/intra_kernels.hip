@@ -16,6 +16,9 @@ struct IntraLds
 {
     pixel ref[136], flt[136], refSw[136], fltSw[136];   /* neighbour sets and their left/above mirrored copies (horizontal modes) */
     int acc[35][4];                                     /* raw Hadamard sums per (mode, 16x16 group) */
+    int16_t diff[64][64];                               /* per-lane 8x8 difference tile: diff[y*8+x][lane].  Rows are produced by a
+                                                           rolled loop (runtime y), which in registers would turn into scratch memory
+                                                           (measured: 2.4 GB of scratch traffic per 1080p launch) */
 };
 
 XA_DEV int in_first_of_unit(int u, int L, int N2) { return u < L ? 4 * u : (u == L ? N2 : N2 + 1 + 4 * (u - L - 1)); }
@@ -164,17 +167,17 @@ __global__ __launch_bounds__(64 * IN_WAVES) void k_intra_scan(const x265amd_intr
     {
         int mode = it >> lgt, tile = it & (nt - 1);
         int ty = tile / tpr, tx = tile - ty * tpr;
-        int m[8][8];
 #pragma unroll 1
-        for (int y = 0; y < 8; y++)
+        for (int i = 0; i < 64; i++)
         {
-            int row[8];
-#pragma unroll 1
-            for (int x = 0; x < 8; x++)
-                row[x] = (int)fenc[(8 * ty + y) * j.fenc_stride + 8 * tx + x] - in_pred_sample(s, mode, N, log2N, dc, 8 * ty + y, 8 * tx + x);
-#pragma unroll
-            for (int x = 0; x < 8; x++) m[y][x] = row[x];
+            int y = i >> 3, x = i & 7;
+            s.diff[i][lane] = (int16_t)((int)fenc[(8 * ty + y) * j.fenc_stride + 8 * tx + x] - in_pred_sample(s, mode, N, log2N, dc, 8 * ty + y, 8 * tx + x));
         }
+        int m[8][8];
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+#pragma unroll
+            for (int x = 0; x < 8; x++) m[y][x] = s.diff[y * 8 + x][lane];
         int raw = xa_had8_abs_regs(m);
         if (N == 8) res[mode] = (raw + 2) >> 2;                              /* sa8d_8x8 (pixel.cpp:342-345) */
         else atomicAdd(&s.acc[mode][(ty >> 1) * (N >> 4) + (tx >> 1)], raw);  /* sa8d_16x16 groups (pixel.cpp:347-384) */

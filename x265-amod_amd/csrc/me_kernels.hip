@@ -17,6 +17,10 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 
+/* Every search helper exists twice: its body (inlined) and a real-function wrapper.  The HEX/DIA kernel variant inlines
+ * the bodies into the search (no call overhead and no callee-saved VGPR spills: 2.02 -> 1.74 ms per 1080p frame, at 85 KB
+ * of code); the variants that carry the star search (dozens of call sites) and the deferred kernel call the wrappers. */
+#define ME_HELPER __device__ __forceinline__
 #ifndef ME_WAVES
 #define ME_WAVES 8
 #endif
@@ -72,6 +76,12 @@ extern __shared__ __attribute__((aligned(16))) char me_smem[];
 #define ME_OOB(off) (reinterpret_cast<MeState*>(me_smem + (off))->oob = 1)
 #define ME_OOB_COST 0x3fffffff      /* never wins a comparison; the job's result is discarded anyway */
 
+/* dispatchers: inline the body (INL) or call the real-function wrapper */
+template<bool SLOW, bool INL> XA_DEV int me_sad_at_f(int sOff, int mx, int my);
+template<bool SATD, bool SLOW, bool INL> XA_DEV int me_subpel_f(int sOff, int qx, int qy);
+template<bool SLOW, bool INL> XA_DEV int me_cost_multi_f(int sOff, int n, int m0, int m1, int m2, int m3);
+template<bool SATD, bool SLOW, bool INL> XA_DEV int me_subpel_list_f(int sOff, int n);
+
 XA_DEV int me_mvcost(const MeState& s, int qx, int qy) { return (uint16_t)(s.cost[qx - s.mvpx] + s.cost[qy - s.mvpy]); }
 
 template<bool INWIN> XA_DEV int me_ref(const MeState& s, int X, int Y)
@@ -110,7 +120,7 @@ template<bool INWIN> XA_DEV int me_sad_fpel(const MeState& s, int X, int Y)
     return xa_wave_sum(sum);
 }
 
-template<bool SLOW> __device__ __noinline__ int me_sad_at_f(int sOff, int mx, int my)     /* full-pel MV (mx,my) */
+template<bool SLOW, bool INL> ME_HELPER int me_sad_at_b(int sOff, int mx, int my)     /* full-pel MV (mx,my) */
 {
     const MeState& s = ME_S(sOff);
     int X = s.px + mx, Y = s.py + my;
@@ -393,10 +403,10 @@ template<bool SATD> XA_DEV int me_subpel_cmp_fast(const MeState& s, int qx, int 
 }
 #endif /* XA_DEPTH == 8 */
 
-template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_f(int sOff, int qx, int qy)
+template<bool SATD, bool SLOW, bool INL> ME_HELPER int me_subpel_b(int sOff, int qx, int qy)
 {
     const MeState& s = ME_S(sOff);
-    if (!SATD && !((qx | qy) & 3)) return me_sad_at_f<SLOW>(sOff, qx >> 2, qy >> 2);
+    if (!SATD && !((qx | qy) & 3)) return me_sad_at_f<SLOW, INL>(sOff, qx >> 2, qy >> 2);
     if (SLOW) return me_subpel_cmp<false, SATD>(sOff, qx, qy);
     int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
     /* +8 on the right: the dword reads of the fast path touch samples up to x+8 of the last tile */
@@ -426,7 +436,7 @@ __device__ const uint8_t me_workload[8][5] = { { 1, 4, 0, 4, 0 }, { 1, 4, 1, 4, 
  * Small PUs run several candidates side by side in one pass: a PU with <= 16 four-sample groups (8x8) evaluates
  * four candidates at once in the four 16-lane quarters of the wavefront. */
 #define ME_PK(mx, my) ((int)(((uint32_t)(my) << 16) | ((uint32_t)(mx) & 0xffffu)))
-template<bool SLOW> __device__ __noinline__ int me_cost_multi_f(int sOff, int n, int m0, int m1, int m2, int m3)
+template<bool SLOW, bool INL> ME_HELPER int me_cost_multi_b(int sOff, int n, int m0, int m1, int m2, int m3)
 {
     const MeState& s = ME_S(sOff);
     const int lane = xa_lane();
@@ -477,19 +487,19 @@ template<bool SLOW> __device__ __noinline__ int me_cost_multi_f(int sOff, int n,
     {
         int mk = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3;
         int mx = (int)(int16_t)(mk & 0xffff), my = mk >> 16;
-        int c = me_sad_at_f<SLOW>(sOff, mx, my) + me_mvcost(s, mx * 4, my * 4);
+        int c = me_sad_at_f<SLOW, INL>(sOff, mx, my) + me_mvcost(s, mx * 4, my * 4);
         if (lane == k) res = c;
     }
     return res;
 }
-#define ME_LANE(v, k) __builtin_amdgcn_readlane((v), (k))
+XA_DEV int ME_LANE(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
 /* Sub-pel comparison (subpelCompare, motion.cpp:1596-1623) of up to 16 quarter-pel candidates in one call: the
  * candidates are read from MeState::cand[0..n), lane k returns the SAD/SATD of candidate k (MV cost not included).  All
  * (candidate, 4x4 tile) pairs are spread over the lanes -- an 8x8 PU with 4 candidates keeps 16 lanes busy instead of 4, a
  * 16x16 PU all 64 -- and summed per candidate with LDS atomics.  Evaluation has no side effects, so callers may evaluate
  * candidates the reference would skip and apply the reference's tests and selection order afterwards. */
-template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_list_f(int sOff, int n)
+template<bool SATD, bool SLOW, bool INL> ME_HELPER int me_subpel_list_b(int sOff, int n)
 {
     const MeState& s = ME_S(sOff);
     const int lane = xa_lane();
@@ -561,15 +571,29 @@ template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_list_f(int 
     int res = ME_OOB_COST;
     for (int k = 0; k < n; k++)
     {
-        int c = me_subpel_f<SATD, SLOW>(sOff, (int)(int16_t)(s.cand[k] & 0xffff), s.cand[k] >> 16);
+        int c = me_subpel_f<SATD, SLOW, INL>(sOff, (int)(int16_t)(s.cand[k] & 0xffff), s.cand[k] >> 16);
         if (lane == k) res = c;
     }
     return res;
 }
 
+/* real-function wrappers and the dispatchers */
+template<bool SLOW> __device__ __noinline__ int me_sad_at_w(int sOff, int mx, int my) { return me_sad_at_b<SLOW, false>(sOff, mx, my); }
+template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_w(int sOff, int qx, int qy) { return me_subpel_b<SATD, SLOW, false>(sOff, qx, qy); }
+template<bool SLOW> __device__ __noinline__ int me_cost_multi_w(int sOff, int n, int m0, int m1, int m2, int m3) { return me_cost_multi_b<SLOW, false>(sOff, n, m0, m1, m2, m3); }
+template<bool SATD, bool SLOW> __device__ __noinline__ int me_subpel_list_w(int sOff, int n) { return me_subpel_list_b<SATD, SLOW, false>(sOff, n); }
+template<bool SLOW, bool INL> XA_DEV int me_sad_at_f(int sOff, int mx, int my)
+{ if constexpr (INL) return me_sad_at_b<SLOW, true>(sOff, mx, my); else return me_sad_at_w<SLOW>(sOff, mx, my); }
+template<bool SATD, bool SLOW, bool INL> XA_DEV int me_subpel_f(int sOff, int qx, int qy)
+{ if constexpr (INL) return me_subpel_b<SATD, SLOW, true>(sOff, qx, qy); else return me_subpel_w<SATD, SLOW>(sOff, qx, qy); }
+template<bool SLOW, bool INL> XA_DEV int me_cost_multi_f(int sOff, int n, int m0, int m1, int m2, int m3)
+{ if constexpr (INL) return me_cost_multi_b<SLOW, true>(sOff, n, m0, m1, m2, m3); else return me_cost_multi_w<SLOW>(sOff, n, m0, m1, m2, m3); }
+template<bool SATD, bool SLOW, bool INL> XA_DEV int me_subpel_list_f(int sOff, int n)
+{ if constexpr (INL) return me_subpel_list_b<SATD, SLOW, true>(sOff, n); else return me_subpel_list_w<SATD, SLOW>(sOff, n); }
+
 /* One refinement round of motion.cpp:1535-1586: costs (comparison + MV cost) of the `dirs` (4 or 8) neighbours
  * square1[1..dirs] * step of the quarter-pel MV (bqx,bqy); lane i-1 returns the cost of direction i. */
-template<bool SATD, bool SLOW> XA_DEV int me_subpel_dirs_f(int sOff, int bqx, int bqy, int step, int dirs)
+template<bool SATD, bool SLOW, bool INL> XA_DEV int me_subpel_dirs_f(int sOff, int bqx, int bqy, int step, int dirs)
 {
     const MeState& s = ME_S(sOff);
     const int lane = xa_lane();
@@ -577,22 +601,23 @@ template<bool SATD, bool SLOW> XA_DEV int me_subpel_dirs_f(int sOff, int bqx, in
     int* cand = reinterpret_cast<int*>(me_smem + sOff + offsetof(MeState, cand));
     if (lane < dirs) cand[lane] = ME_PK(qx, qy);
     xa_wave_sync();
-    int v = me_subpel_list_f<SATD, SLOW>(sOff, dirs);
+    int v = me_subpel_list_f<SATD, SLOW, INL>(sOff, dirs);
     return lane < dirs ? v + me_mvcost(s, qx, qy) : ME_OOB_COST;
 }
 
-#define me_subpel_sad(qx, qy) me_subpel_f<false, SLOW>(sOff, qx, qy)
-#define me_subpel_satd(qx, qy) me_subpel_f<true, SLOW>(sOff, qx, qy)
+#define me_subpel_sad(qx, qy) me_subpel_f<false, SLOW, INL>(sOff, qx, qy)
+#define me_subpel_satd(qx, qy) me_subpel_f<true, SLOW, INL>(sOff, qx, qy)
 XA_DEV bool me_in_range(const MeState& s, int x, int y) { return x >= s.mnx && x <= s.mxx && y >= s.mny && y <= s.mxy; }
 
-#define ME_COST(mx, my) ME_LANE(me_cost_multi_f<SLOW>(sOff, 1, ME_PK(mx, my), 0, 0, 0), 0)
-#define me_sad_at(s, mx, my) me_sad_at_f<SLOW>(sOff, mx, my)
+#define ME_COST(mx, my) ME_LANE((me_cost_multi_f<SLOW, INL>(sOff, 1, ME_PK(mx, my), 0, 0, 0)), 0)
+#define me_sad_at(s, mx, my) me_sad_at_f<SLOW, INL>(sOff, mx, my)
 #define ME_COST_MV(mx, my) do { int c_ = ME_COST(mx, my); if (c_ < bcost) { bcost = c_; bx = (mx); by = (my); } } while (0)
 #define ME_COST_PT(mx, my, point, dist) do { int c_ = ME_COST(mx, my); if (c_ < bcost) { bcost = c_; bx = (mx); by = (my); bPointNr = (point); bDistance = (dist); } } while (0)
 
 /* StarPatternSearch: motion.cpp:387-629 (the x4 batches evaluate the same points in the same order) */
 template<bool SLOW> __device__ __noinline__ void me_star_pattern(int sOff, int& bx, int& by, int& bcost, int& bPointNr, int& bDistance, int earlyExitIters, int merange)
 {
+    constexpr bool INL = false;
     const MeState& s = ME_S(sOff);
     const int ox = bx, oy = by;
     int saved = bcost, rounds = 0;
@@ -678,6 +703,7 @@ template<bool SLOW> __device__ __noinline__ void me_star_pattern(int sOff, int& 
  * because mvc[] is indexed dynamically -- measured as 457 MB of scratch writes per 1080p launch) */
 template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd_me_job* __restrict__ jp, x265amd_me_result* out)
 {
+    constexpr bool INL = !SLOW && !STAR;    /* the HEX/DIA window-resident variant inlines the helper bodies */
     const MeState& s = ME_S(sOff);
     const int qminx = s.mnx * 4, qminy = s.mny * 4, qmaxx = s.mxx * 4, qmaxy = s.mxy * 4;
     const int merange = jp->merange, numCand = jp->num_cand, method = jp->method, subme = jp->subme;
@@ -694,7 +720,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
             cand[lane] = ME_PK(xa_clip3(qminx, qmaxx, jp->mvc[lane - 1][0]), xa_clip3(qminy, qmaxy, jp->mvc[lane - 1][1]));
         xa_wave_sync();
     }
-    const int preSads = me_subpel_list_f<false, SLOW>(sOff, 1 + numCand);
+    const int preSads = me_subpel_list_f<false, SLOW, INL>(sOff, 1 + numCand);
     int bprecost = __shfl(preSads, 0, 64);
     int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2;
     int bcost = bprecost;
@@ -727,7 +753,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         int i = merange;
         do
         {
-            int cv = me_cost_multi_f<SLOW>(sOff, 4, ME_PK(bx, by - 1), ME_PK(bx, by + 1), ME_PK(bx - 1, by), ME_PK(bx + 1, by));
+            int cv = me_cost_multi_f<SLOW, INL>(sOff, 4, ME_PK(bx, by - 1), ME_PK(bx, by + 1), ME_PK(bx - 1, by), ME_PK(bx + 1, by));
             int c0 = ME_LANE(cv, 0), c1 = ME_LANE(cv, 1), c2 = ME_LANE(cv, 2), c3 = ME_LANE(cv, 3);
             int packed = bcost << 4;
             if (by - 1 >= s.mny && by - 1 <= s.mxy && (c0 << 4) + 1 < packed) packed = (c0 << 4) + 1;
@@ -745,7 +771,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
     case X265AMD_ME_HEX:    /* motion.cpp:879-987 */
     {
         int c0, c1, c2, c3, packed, dir, cv;
-        cv = me_cost_multi_f<SLOW>(sOff, 3, ME_PK(bx - 2, by), ME_PK(bx - 1, by + 2), ME_PK(bx + 1, by + 2), 0);
+        cv = me_cost_multi_f<SLOW, INL>(sOff, 3, ME_PK(bx - 2, by), ME_PK(bx - 1, by + 2), ME_PK(bx + 1, by + 2), 0);
         c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2);
         packed = bcost << 3;
         if (by >= s.mny && by <= s.mxy && (c0 << 3) + 2 < packed) packed = (c0 << 3) + 2;
@@ -754,7 +780,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
             if ((c1 << 3) + 3 < packed) packed = (c1 << 3) + 3;
             if ((c2 << 3) + 4 < packed) packed = (c2 << 3) + 4;
         }
-        cv = me_cost_multi_f<SLOW>(sOff, 3, ME_PK(bx + 2, by), ME_PK(bx + 1, by - 2), ME_PK(bx - 1, by - 2), 0);
+        cv = me_cost_multi_f<SLOW, INL>(sOff, 3, ME_PK(bx + 2, by), ME_PK(bx + 1, by - 2), ME_PK(bx - 1, by - 2), 0);
         c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2);
         if (by >= s.mny && by <= s.mxy && (c0 << 3) + 5 < packed) packed = (c0 << 3) + 5;
         if (by - 2 >= s.mny && by - 2 <= s.mxy)
@@ -770,7 +796,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
                 bx += me_hex2[dir + 1][0]; by += me_hex2[dir + 1][1];
                 for (int i = (merange >> 1) - 1; i > 0 && me_in_range(s, bx, by); i--)
                 {
-                    cv = me_cost_multi_f<SLOW>(sOff, 3, ME_PK(bx + me_hex2[dir][0], by + me_hex2[dir][1]), ME_PK(bx + me_hex2[dir + 1][0], by + me_hex2[dir + 1][1]),
+                    cv = me_cost_multi_f<SLOW, INL>(sOff, 3, ME_PK(bx + me_hex2[dir][0], by + me_hex2[dir][1]), ME_PK(bx + me_hex2[dir + 1][0], by + me_hex2[dir + 1][1]),
                                          ME_PK(bx + me_hex2[dir + 2][0], by + me_hex2[dir + 2][1]), 0);
                     int cc[3] = { ME_LANE(cv, 0), ME_LANE(cv, 1), ME_LANE(cv, 2) };
                     packed &= ~7;
@@ -787,14 +813,14 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         bcost = packed >> 3;
         /* square refine */
         dir = 0;
-        cv = me_cost_multi_f<SLOW>(sOff, 4, ME_PK(bx, by - 1), ME_PK(bx, by + 1), ME_PK(bx - 1, by), ME_PK(bx + 1, by));
+        cv = me_cost_multi_f<SLOW, INL>(sOff, 4, ME_PK(bx, by - 1), ME_PK(bx, by + 1), ME_PK(bx - 1, by), ME_PK(bx + 1, by));
         c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2); c3 = ME_LANE(cv, 3);
         bool upOk = by - 1 >= s.mny && by - 1 <= s.mxy, dnOk = by + 1 >= s.mny && by + 1 <= s.mxy;
         if (upOk && c0 < bcost) { bcost = c0; dir = 1; }
         if (dnOk && c1 < bcost) { bcost = c1; dir = 2; }
         if (c2 < bcost) { bcost = c2; dir = 3; }
         if (c3 < bcost) { bcost = c3; dir = 4; }
-        cv = me_cost_multi_f<SLOW>(sOff, 4, ME_PK(bx - 1, by - 1), ME_PK(bx - 1, by + 1), ME_PK(bx + 1, by - 1), ME_PK(bx + 1, by + 1));
+        cv = me_cost_multi_f<SLOW, INL>(sOff, 4, ME_PK(bx - 1, by - 1), ME_PK(bx - 1, by + 1), ME_PK(bx + 1, by - 1), ME_PK(bx + 1, by + 1));
         c0 = ME_LANE(cv, 0); c1 = ME_LANE(cv, 1); c2 = ME_LANE(cv, 2); c3 = ME_LANE(cv, 3);
         if (upOk && c0 < bcost) { bcost = c0; dir = 5; }
         if (dnOk && c1 < bcost) { bcost = c1; dir = 6; }
@@ -889,7 +915,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         for (int iter = 0; iter < wl[0]; iter++)
         {
             int bdir = 0;
-            int cv = hsatd ? me_subpel_dirs_f<true, SLOW>(sOff, bx, by, 2, wl[1]) : me_subpel_dirs_f<false, SLOW>(sOff, bx, by, 2, wl[1]);
+            int cv = hsatd ? me_subpel_dirs_f<true, SLOW, INL>(sOff, bx, by, 2, wl[1]) : me_subpel_dirs_f<false, SLOW, INL>(sOff, bx, by, 2, wl[1]);
             for (int i = 1; i <= wl[1]; i++)
             {
                 int qy = by + me_square1[i][1] * 2;
@@ -905,7 +931,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
         for (int iter = 0; iter < wl[2]; iter++)
         {
             int bdir = 0;
-            int cv = me_subpel_dirs_f<true, SLOW>(sOff, bx, by, 1, wl[3]);
+            int cv = me_subpel_dirs_f<true, SLOW, INL>(sOff, bx, by, 1, wl[3]);
             for (int i = 1; i <= wl[3]; i++)
             {
                 int qy = by + me_square1[i][1];
