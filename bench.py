@@ -194,7 +194,7 @@ def cpu_baseline(T, frames, packed_by_ref, budget_s=20.0):
             break
     secs_per_frame += spent * len(tj) / done; notes.append("%d/%d TU chains %.1fs" % (done, len(tj), spent))
     return {"value": 1.0 / secs_per_frame, "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "one 1080p frame of the same workload on one core: " + ", ".join(notes) + "; parts cut at their budget are extrapolated"}
+            "sample": "one %dx%d frame of the same workload on one core: " % (W, H) + ", ".join(notes) + "; parts cut at their budget are extrapolated"}
 
 
 def measured_traffic(kernel="k_me_search"):
@@ -213,7 +213,12 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--res", choices=["1080p", "2160p"], default="1080p",
+                    help="1080p = BASELINE.json configs[1] (the bench line); 2160p = the same pass at 3840x2160 (informational)")
     args = ap.parse_args()
+    global W, H
+    if args.res == "2160p":
+        W, H = 3840, 2160
 
     import torch
     import torch.distributed as dist
@@ -369,14 +374,14 @@ def main():
             "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1920x1080 8-bit 4:2:0 synthetic, --preset medium parameters: analysis hot-path kernels of one frame = "
+            "config": {"workload": ("%dx%d 8-bit 4:2:0 synthetic, --preset medium parameters: analysis hot-path kernels of one frame = " % (W, H)) + (
                                    "%d motion searches (every 2Nx2N PU 64..8 of every CTU x 3 refs; hex, merange 57, subme 2) + %d intra 35-mode scans "
                                    "(CUs 32/16/8) + %d TU residual chains (luma + 2 chroma per CU 32/16/8; dct, quant, sign hiding, dequant, idct, recon, sse, psy); "
-                                   "NOT a full encode (no mode decision / entropy coding yet)" % (len(packed), n_in, n_tu),
+                                   "NOT a full encode (no mode decision / entropy coding yet)") % (len(packed), n_in, n_tu),
                        "frames_per_step_per_gpu": 1, "parallelism": "frame-per-gpu x%d" % world},
             "kernels": {names[i]: {"ms": kms[i], "algorithmic_bytes": algb[i], "GB/s": algb[i] / (kms[i] * 1e-3) / 1e9} for i in range(NK)},
             "roofline": {"bound": "hbm", "achieved": algb[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": algb[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(names[dom]),
+                         "frac": algb[dom] / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(names[dom]) if args.res == "1080p" else None,
                          "kernel": names[dom], "kernel_ms": kms[dom], "algorithmic_bytes_per_launch": algb[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
