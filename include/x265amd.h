@@ -292,6 +292,30 @@ typedef struct x265amd_intra_job
  * unfiltered and filtered neighbour buffers ([0] above-left, [1..2N] above, [2N+1..4N] left).  Asynchronous. */
 int x265amd_intra_scan(void* stream, const x265amd_intra_job* d_jobs, int n, int32_t* d_sa8d, x265amd_pixel* d_neighbours);
 
+/* --- inter prediction: Predict::motionCompensation (reference: source/common/predict.cpp:77-243 with
+ * predInterLuma/Chroma Pixel/Short :245-408, addWeightBi/Uni :411-577, Yuv::addAvg yuv.cpp:189-211 and CUData::clipMv
+ * cudata.cpp:1915-1928), 4:2:0.  One job = one PU: uni- or bi-prediction from one picture per list, optional explicit
+ * weights, luma and/or chroma, written to a caller-owned prediction block. */
+typedef struct x265amd_mc_job
+{
+    uint64_t dst_y, dst_u, dst_v;       /* device addresses of the PU's top-left sample in the prediction buffers */
+    int32_t dst_stride, dst_cstride;
+    int16_t x, y;                       /* PU position in the picture (luma samples) */
+    int16_t cu_x, cu_y;                 /* position of the CU that owns the PU (clipMv is relative to the CU) */
+    uint8_t w, h;                       /* PU size */
+    int8_t ref0, ref1;                  /* picture index into the plane table per list, -1: list unused */
+    int16_t mv0[2], mv1[2];             /* quarter-pel MVs (clipped by the kernel exactly like cu.clipMv) */
+    uint8_t slice_type;                 /* 1 = P slice, 0 = B slice */
+    uint8_t flags;                      /* 1 luma, 2 chroma, 4 pps.bUseWeightPred, 8 pps.bUseWeightedBiPred */
+    struct { int16_t w, o; uint8_t denom, present; } wp[2][3];    /* WeightParam inputWeight/inputOffset/log2WeightDenom/wtPresent */
+    uint8_t reserved[6];
+} x265amd_mc_job;
+
+/* d_planes: num_pics x 3 device addresses of sample (0,0) of the padded Y, U, V planes; all pictures share
+ * `stride` / `cstride`.  pic_w / pic_h: luma picture size (clipMv).  Asynchronous. */
+int x265amd_motion_compensation(void* stream, const uint64_t* d_planes, intptr_t stride, intptr_t cstride, int pic_w, int pic_h,
+                                const x265amd_mc_job* d_jobs, int n);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

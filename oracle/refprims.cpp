@@ -21,6 +21,8 @@
 #include "predict.h"
 #include "framedata.h"
 #include "picyuv.h"
+#include "yuv.h"
+#include "shortyuv.h"
 
 using namespace X265_NS;
 
@@ -324,6 +326,93 @@ void ref_intra_scan(const pixel* fenc, intptr_t fencStride, int log2TrSize, cons
         g_p.cu[sizeIdx].intra_pred[mode](predBuf, N, filter ? fltBuf : refBuf, mode, N <= 16);
         sa8d35[mode] = g_p.cu[sizeIdx].sa8d(fenc, fencStride, predBuf, N);
     }
+}
+
+/* ---- inter prediction: the reference's own Predict::motionCompensation (common/predict.cpp:77-243) ---- */
+struct PackedMcJob
+{
+    uint64_t dstY, dstU, dstV; int32_t dstStride, dstCStride;
+    int16_t x, y, cuX, cuY; uint8_t w, h; int8_t ref0, ref1; int16_t mv0[2], mv1[2];
+    uint8_t sliceType, flags;           /* flags: 1 luma, 2 chroma, 4 bUseWeightPred, 8 bUseWeightedBiPred */
+    struct { int16_t w, o; uint8_t denom, present; } wp[2][3];
+    uint8_t reserved[2];
+};
+
+struct McEnv
+{
+    Predict pred;
+    FrameData fd;
+    x265_param param;
+    PicYuv* pic[2];
+    Yuv predYuv;
+    intptr_t zeroCu[1], zeroBu[256];
+    int8_t refIdx[2][256];
+    MV mv[2][256];
+    McEnv()
+    {
+        pred.allocBuffers(X265_CSP_I420);
+        memset(&param, 0, sizeof(param)); param.maxCUSize = 64;
+        fd.m_param = &param;
+        zeroCu[0] = 0; memset(zeroBu, 0, sizeof(zeroBu));
+        for (int i = 0; i < 2; i++)
+        {
+            pic[i] = new PicYuv;
+            pic[i]->m_cuOffsetY = zeroCu; pic[i]->m_buOffsetY = zeroBu; pic[i]->m_cuOffsetC = zeroCu; pic[i]->m_buOffsetC = zeroBu;
+        }
+        predYuv.create(64, X265_CSP_I420);
+    }
+};
+
+/* planes: nref x 3 addresses of sample (0,0) (Y, U, V) of padded pictures with strides stride / cstride */
+int ref_motion_compensation_batch(const uint64_t* planes, intptr_t stride, intptr_t cstride, int picW, int picH, const PackedMcJob* jobs, int n)
+{
+    static McEnv* m = NULL;
+    TuEnv* e = tuEnv();
+    if (!m) m = new McEnv;
+    for (int i = 0; i < n; i++)
+    {
+        const PackedMcJob& j = jobs[i];
+        e->sps.picWidthInLumaSamples = picW; e->sps.picHeightInLumaSamples = picH;
+        e->slice.m_sliceType = j.sliceType ? P_SLICE : B_SLICE;
+        e->pps.bUseWeightPred = !!(j.flags & 4); e->pps.bUseWeightedBiPred = !!(j.flags & 8);
+        const int8_t refs[2] = { j.ref0, j.ref1 };
+        for (int l = 0; l < 2; l++)
+        {
+            memset(m->refIdx[l], refs[l] >= 0 ? 0 : -1, 256);
+            m->mv[l][0] = l ? MV(j.mv1[0], j.mv1[1]) : MV(j.mv0[0], j.mv0[1]);
+            e->slice.m_numRefIdx[l] = 1;
+            e->slice.m_refReconPicList[l][0] = m->pic[l];
+            if (refs[l] >= 0)
+            {
+                m->pic[l]->m_picOrg[0] = (pixel*)planes[3 * refs[l] + 0] + (intptr_t)j.y * stride + j.x;
+                m->pic[l]->m_picOrg[1] = (pixel*)planes[3 * refs[l] + 1] + (intptr_t)(j.y >> 1) * cstride + (j.x >> 1);
+                m->pic[l]->m_picOrg[2] = (pixel*)planes[3 * refs[l] + 2] + (intptr_t)(j.y >> 1) * cstride + (j.x >> 1);
+                m->pic[l]->m_stride = stride; m->pic[l]->m_strideC = cstride;
+            }
+            for (int c = 0; c < 3; c++)
+            {
+                WeightParam& w = e->slice.m_weightPredTable[l][0][c];
+                w.inputWeight = j.wp[l][c].w; w.inputOffset = j.wp[l][c].o; w.log2WeightDenom = j.wp[l][c].denom; w.wtPresent = j.wp[l][c].present;
+            }
+        }
+        e->cu.m_encData = &m->fd;
+        e->cu.m_refIdx[0] = m->refIdx[0]; e->cu.m_refIdx[1] = m->refIdx[1];
+        e->cu.m_mv[0] = m->mv[0]; e->cu.m_mv[1] = m->mv[1];
+        e->cu.m_cuPelX = j.cuX; e->cu.m_cuPelY = j.cuY;
+        char pubuf[sizeof(PredictionUnit)];
+        PredictionUnit* pu = (PredictionUnit*)pubuf;
+        pu->ctuAddr = 0; pu->cuAbsPartIdx = 0; pu->puAbsPartIdx = 0; pu->width = j.w; pu->height = j.h;
+        m->pred.motionCompensation(e->cu, *pu, m->predYuv, !!(j.flags & 1), !!(j.flags & 2));
+        if (j.flags & 1)
+            for (int y = 0; y < j.h; y++) memcpy((pixel*)j.dstY + (intptr_t)y * j.dstStride, m->predYuv.m_buf[0] + y * m->predYuv.m_size, j.w * sizeof(pixel));
+        if (j.flags & 2)
+            for (int y = 0; y < j.h / 2; y++)
+            {
+                memcpy((pixel*)j.dstU + (intptr_t)y * j.dstCStride, m->predYuv.m_buf[1] + y * m->predYuv.m_csize, (j.w / 2) * sizeof(pixel));
+                memcpy((pixel*)j.dstV + (intptr_t)y * j.dstCStride, m->predYuv.m_buf[2] + y * m->predYuv.m_csize, (j.w / 2) * sizeof(pixel));
+            }
+    }
+    return n;
 }
 
 /* ---- batch forms for bench.py's cpu_baseline leg (records of include/x265amd.h; addresses are HOST addresses here) ---- */

@@ -40,6 +40,7 @@ def main():
     make_me_golden()
     make_tu_golden()
     make_intra_golden()
+    make_mc_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -110,6 +111,20 @@ def make_intra_golden():
             out["intra/%d/%d/sa8d" % (depth, seed)] = np.stack([r[2] for r in res])
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_golden.npz"), **out)
     print("wrote intra_golden.npz with", len(out), "arrays")
+
+
+def make_mc_golden():
+    """outputs of the reference's own Predict::motionCompensation -> sha256 per scene in tests/golden/mc_golden.npz"""
+    import hashlib
+    out = {}
+    for depth in (8, 10):
+        ref = T.load_ref(depth)
+        for seed in range(3):
+            pics, stride, cstride, org = T.mc_make_refs(depth, 900 + seed)
+            res = T.mc_run_host(ref, pics, stride, cstride, org, T.mc_jobs(900 + seed, 400))
+            out["mc/%d/%d" % (depth, seed)] = np.frombuffer(T.mc_digest(res), np.uint8)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "mc_golden.npz"), **out)
+    print("wrote mc_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

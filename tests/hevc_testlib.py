@@ -850,3 +850,128 @@ def intra_run_hip(L, cases):
         N = 1 << c["log2"]
         out.append((nb[i, 0, :4 * N + 1].copy(), nb[i, 1, :4 * N + 1].copy() if N >= 8 else None, sa[i].copy()))
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# inter prediction cases: Predict::motionCompensation
+# ----------------------------------------------------------------------------------------------------------
+MC_WP_DT = np.dtype([("w", "<i2"), ("o", "<i2"), ("denom", "u1"), ("present", "u1")])
+MC_JOB_DT = np.dtype([("dstY", "<u8"), ("dstU", "<u8"), ("dstV", "<u8"), ("dstStride", "<i4"), ("dstCStride", "<i4"),
+                      ("x", "<i2"), ("y", "<i2"), ("cuX", "<i2"), ("cuY", "<i2"), ("w", "u1"), ("h", "u1"), ("ref0", "i1"), ("ref1", "i1"),
+                      ("mv0", "<i2", 2), ("mv1", "<i2", 2), ("sliceType", "u1"), ("flags", "u1"), ("wp", MC_WP_DT, (2, 3)), ("reserved", "u1", 6)])
+assert MC_JOB_DT.itemsize == 96
+MC_W, MC_H, MC_MX, MC_MY = 256, 192, 96, 80
+
+
+def mc_make_refs(depth, seed, nref=3):
+    """nref padded 4:2:0 pictures (Y, U, V planes concatenated per picture); returns (list of arrays, stride, cstride, offsets)"""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    stride, cstride = MC_W + 2 * MC_MX, MC_W // 2 + MC_MX
+    rows, crows = MC_H + 2 * MC_MY, MC_H // 2 + MC_MY
+    pics = []
+    for r in range(nref):
+        planes = []
+        for (rw, st) in ((rows, stride), (crows, cstride), (crows, cstride)):
+            base = rng.integers(0, pmax + 1, (rw // 4 + 1, st // 4 + 1)).astype(np.int64)
+            p = np.kron(base, np.ones((4, 4), np.int64))[:rw, :st]
+            p = np.clip((p + np.roll(p, 1, 0) + np.roll(p, 2, 1) + rng.integers(-3, 4, p.shape) * 3) // 2, 0, pmax)
+            planes.append(p.astype(dt).ravel())
+        pics.append(np.concatenate(planes))
+    ysz, csz = rows * stride, crows * cstride
+    org = (MC_MY * stride + MC_MX, ysz + (MC_MY // 2) * cstride + MC_MX // 2, ysz + csz + (MC_MY // 2) * cstride + MC_MX // 2)
+    return pics, stride, cstride, org
+
+
+def mc_jobs(seed, n):
+    rng = np.random.default_rng(seed ^ 0xC0FFEE)
+    j = np.zeros(n, MC_JOB_DT)
+    for i in range(n):
+        w, h = PU_SIZES[int(rng.integers(1, 25))] if i % 2 else [(8, 8), (16, 16), (32, 32), (64, 64)][int(rng.integers(0, 4))]
+        cu = max(w, h)
+        cux = int(rng.integers(0, MC_W // cu)) * cu; cuy = int(rng.integers(0, MC_H // cu)) * cu
+        x = cux + (cu - w if rng.integers(0, 2) else 0); y = cuy + (cu - h if rng.integers(0, 2) else 0)
+        j[i]["x"], j[i]["y"], j[i]["cuX"], j[i]["cuY"], j[i]["w"], j[i]["h"] = x, y, cux, cuy, w, h
+        p = int(rng.integers(0, 2))
+        j[i]["sliceType"] = p
+        if p:
+            j[i]["ref0"], j[i]["ref1"] = int(rng.integers(0, 3)), -1
+        else:
+            k = int(rng.integers(0, 3))
+            j[i]["ref0"], j[i]["ref1"] = [(int(rng.integers(0, 3)), int(rng.integers(0, 3))), (int(rng.integers(0, 3)), -1), (-1, int(rng.integers(0, 3)))][k]
+        far = rng.integers(0, 8) == 0       # occasionally far outside: exercises clipMv
+        for key in ("mv0", "mv1"):
+            j[i][key] = (int(rng.integers(-2000, 2001)) if far else int(rng.integers(-70, 71)), int(rng.integers(-1500, 1501)) if far else int(rng.integers(-70, 71)))
+        if rng.integers(0, 4) == 0:
+            j[i][("mv0", "mv1")[int(rng.integers(0, 2))]] = (int(rng.integers(-8, 9)) * 4, int(rng.integers(-8, 9)) * 4)     # full-pel
+        flags = 3 if rng.integers(0, 4) else int(rng.integers(1, 3))
+        wmode = int(rng.integers(0, 3))
+        if wmode:
+            flags |= 4 | 8
+            for l in range(2):
+                pres = int(rng.integers(0, 2)) if wmode == 1 else 1
+                for c in range(3):
+                    den = int(rng.integers(0, 8)) if c == 0 else int(rng.integers(0, 8))
+                    j[i]["wp"][l][c] = (int(rng.integers(-20, 128)), int(rng.integers(-30, 31)), den, pres)
+        j[i]["flags"] = flags
+    return j
+
+
+def mc_run_host(L, pics, stride, cstride, org, jobs):
+    """through <prefix>motion_compensation_batch with host addresses; returns list of (Y, U, V) arrays (None when a plane is off)"""
+    n = len(jobs)
+    dt = pics[0].dtype
+    isz = dt.itemsize
+    planes = np.array([p.ctypes.data + org[c] * isz for p in pics for c in range(3)], np.uint64)
+    outY = np.zeros((n, 64, 64), dt); outU = np.zeros((n, 32, 32), dt); outV = np.zeros((n, 32, 32), dt)
+    jb = jobs.copy()
+    jb["dstY"] = outY.ctypes.data + np.arange(n) * 64 * 64 * isz
+    jb["dstU"] = outU.ctypes.data + np.arange(n) * 32 * 32 * isz
+    jb["dstV"] = outV.ctypes.data + np.arange(n) * 32 * 32 * isz
+    jb["dstStride"], jb["dstCStride"] = 64, 32
+    fn = getattr(L.lib, L.prefix + "motion_compensation_batch")
+    fn(_ptr(planes), C.c_int64(stride), C.c_int64(cstride), MC_W, MC_H, _ptr(jb), n)
+    res = []
+    for i in range(n):
+        w, h, f = int(jobs[i]["w"]), int(jobs[i]["h"]), int(jobs[i]["flags"])
+        res.append((outY[i, :h, :w].copy() if f & 1 else None, outU[i, :h // 2, :w // 2].copy() if f & 2 else None, outV[i, :h // 2, :w // 2].copy() if f & 2 else None))
+    return res
+
+
+def mc_digest(res):
+    h = hashlib.sha256()
+    for y, u, v in res:
+        for a in (y, u, v):
+            h.update(b"-" if a is None else np.ascontiguousarray(a).tobytes())
+    return h.digest()
+
+
+def mc_run_hip(L, pics, stride, cstride, org, jobs):
+    """x265amd_motion_compensation on device memory; same return shape as mc_run_host"""
+    import torch
+    n = len(jobs)
+    dt = pics[0].dtype
+    isz = dt.itemsize
+    d_pics = [torch.from_numpy(p.view(np.uint8)).cuda() for p in pics]
+    planes = np.array([d.data_ptr() + org[c] * isz for d in d_pics for c in range(3)], np.uint64)
+    d_planes = torch.from_numpy(planes.view(np.uint8).copy()).cuda()
+    d_y = torch.zeros(n * 64 * 64 * isz, dtype=torch.uint8, device="cuda")
+    d_u = torch.zeros(n * 32 * 32 * isz, dtype=torch.uint8, device="cuda")
+    d_v = torch.zeros(n * 32 * 32 * isz, dtype=torch.uint8, device="cuda")
+    jb = jobs.copy()
+    jb["dstY"] = d_y.data_ptr() + np.arange(n) * 64 * 64 * isz
+    jb["dstU"] = d_u.data_ptr() + np.arange(n) * 32 * 32 * isz
+    jb["dstV"] = d_v.data_ptr() + np.arange(n) * 32 * 32 * isz
+    jb["dstStride"], jb["dstCStride"] = 64, 32
+    d_jobs = torch.from_numpy(jb.view(np.uint8).copy()).cuda()
+    rc = L.lib.x265amd_motion_compensation(None, C.c_void_p(d_planes.data_ptr()), C.c_int64(stride), C.c_int64(cstride), MC_W, MC_H,
+                                           C.c_void_p(d_jobs.data_ptr()), n)
+    assert rc == 0
+    torch.cuda.synchronize()
+    outY = d_y.cpu().numpy().view(dt).reshape(n, 64, 64); outU = d_u.cpu().numpy().view(dt).reshape(n, 32, 32); outV = d_v.cpu().numpy().view(dt).reshape(n, 32, 32)
+    res = []
+    for i in range(n):
+        w, h, f = int(jobs[i]["w"]), int(jobs[i]["h"]), int(jobs[i]["flags"])
+        res.append((outY[i, :h, :w].copy() if f & 1 else None, outU[i, :h // 2, :w // 2].copy() if f & 2 else None, outV[i, :h // 2, :w // 2].copy() if f & 2 else None))
+    return res

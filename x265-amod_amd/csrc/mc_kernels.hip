@@ -1,0 +1,161 @@
+/* Layer 3: inter prediction (include/x265amd.h, `x265amd_motion_compensation`).
+ *
+ * Device restatement of Predict::motionCompensation (reference: source/common/predict.cpp:77-243) and its helpers
+ * predInterLuma/Chroma Pixel/Short (:245-408), addWeightBi/Uni (:411-577), Yuv::addAvg (yuv.cpp:189-211), and
+ * CUData::clipMv (cudata.cpp:1915-1928), 4:2:0.  One 64-lane wavefront per PU, lanes strided over the output samples;
+ * every sample recomputes its (separable) interpolation with the reference's intermediate roundings (the int16
+ * row-extended horizontal pass of the hv cases included), so results are bit-exact.
+ */
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+
+#define MC_WAVES 4
+
+/* one interpolated sample.  SHORT = false: the pixel path (copy / hpp / vpp / hps(rowExt)+vsp: ipfilter.cpp:79-120, :169-210,
+ * :250-292); SHORT = true: the 14-bit intermediate path (p2s / hps / vps / hps(rowExt)+vss: ipfilter.cpp:39-56, :122-167,
+ * :212-248, :294-324).  TAPS 8: luma, fractions in quarter samples; TAPS 4: chroma, eighth samples. */
+template<int TAPS, bool SHORT> XA_DEV int mc_sample(const pixel* src, long stride, int xf, int yf)
+{
+    const int half = TAPS / 2 - 1;
+    const int headRoom = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    const int shiftH = XA_IF_FILTER_PREC - headRoom, offH = (int)((unsigned)-XA_IF_INTERNAL_OFFS << shiftH);
+    const int16_t* cx = TAPS == 8 ? xa_tbl.lumaFilter[xf] : xa_tbl.chromaFilter[xf];
+    const int16_t* cy = TAPS == 8 ? xa_tbl.lumaFilter[yf] : xa_tbl.chromaFilter[yf];
+    if (!(xf | yf))
+        return SHORT ? (int)(int16_t)((int16_t)(src[0] << headRoom) - (int16_t)XA_IF_INTERNAL_OFFS) : (int)src[0];
+    if (!yf || !xf)
+    {
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; t++)
+            sum += yf ? (int)src[(long)(t - half) * stride] * cy[t] : (int)src[t - half] * cx[t];
+        if (SHORT) return (int)(int16_t)((sum + offH) >> shiftH);
+        return xa_clip3(0, XA_PIXEL_MAX, (int)(int16_t)((sum + (1 << (XA_IF_FILTER_PREC - 1))) >> XA_IF_FILTER_PREC));
+    }
+    int sum = 0;
+#pragma unroll 1
+    for (int r = 0; r < TAPS; r++)
+    {
+        const pixel* row = src + (long)(r - half) * stride - half;
+        int hs = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) hs += (int)row[t] * cx[t];
+        sum += (int)(int16_t)((hs + offH) >> shiftH) * cy[r];
+    }
+    if (SHORT) return (int)(int16_t)(sum >> XA_IF_FILTER_PREC);
+    const int shiftV = XA_IF_FILTER_PREC + headRoom, offV = (1 << (shiftV - 1)) + (XA_IF_INTERNAL_OFFS << XA_IF_FILTER_PREC);
+    return xa_clip3(0, XA_PIXEL_MAX, (int)(int16_t)((sum + offV) >> shiftV));
+}
+
+struct McPlane { const pixel* src[2]; long stride; int xf[2], yf[2]; int w, h; pixel* dst; int dstStride; int c; };
+
+template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& j, int mode, int lsel, int lane)
+{
+    /* mode 0: pixel path from list lsel; 1: weighted uni from list lsel; 2: bi average; 3: weighted bi */
+    const int c = p.c;
+    const int shiftNum = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    int inv = ((1 << 20) + p.w - 1) / p.w;
+    for (int i = lane; i < p.w * p.h; i += XA_WAVE)
+    {
+        int y = (i * inv) >> 20, x = i - y * p.w;
+        int v;
+        if (mode == 0)
+            v = mc_sample<TAPS, false>(p.src[lsel] + (long)y * p.stride + x, p.stride, p.xf[lsel], p.yf[lsel]);
+        else if (mode == 1)
+        {
+            /* addWeightUni -> weight_sp_c (predict.cpp:520-577, pixel.cpp:493-517) */
+            int s0 = mc_sample<TAPS, true>(p.src[lsel] + (long)y * p.stride + x, p.stride, p.xf[lsel], p.yf[lsel]);
+            int shift = j.wp[lsel][c].denom + shiftNum, round = shift ? 1 << (shift - 1) : 0;
+            int off = j.wp[lsel][c].o * (1 << (XA_DEPTH - 8));
+            v = xa_clip3(0, XA_PIXEL_MAX, ((j.wp[lsel][c].w * (s0 + XA_IF_INTERNAL_OFFS) + round) >> shift) + off);
+        }
+        else
+        {
+            int s0 = mc_sample<TAPS, true>(p.src[0] + (long)y * p.stride + x, p.stride, p.xf[0], p.yf[0]);
+            int s1 = mc_sample<TAPS, true>(p.src[1] + (long)y * p.stride + x, p.stride, p.xf[1], p.yf[1]);
+            if (mode == 2)      /* addAvg (pixel.cpp:860-879) */
+            {
+                const int shift = shiftNum + 1, offset = (1 << (shift - 1)) + 2 * XA_IF_INTERNAL_OFFS;
+                v = xa_clip3(0, XA_PIXEL_MAX, (s0 + s1 + offset) >> shift);
+            }
+            else                /* addWeightBi / weightBidir (predict.cpp:52-55, :411-518) */
+            {
+                int shift = j.wp[0][c].denom + shiftNum + 1, round = shift ? 1 << (shift - 1) : 0;
+                int offset = (j.wp[0][c].o + j.wp[1][c].o) * (1 << (XA_DEPTH - 8));
+                v = xa_clip3(0, XA_PIXEL_MAX, (j.wp[0][c].w * (s0 + XA_IF_INTERNAL_OFFS) + j.wp[1][c].w * (s1 + XA_IF_INTERNAL_OFFS) + round + (offset * (1 << (shift - 1)))) >> shift);
+            }
+        }
+        p.dst[(long)y * p.dstStride + x] = (pixel)v;
+    }
+}
+
+__global__ __launch_bounds__(64 * MC_WAVES) void k_motion_compensation(const uint64_t* planes, long stride, long cstride, int picW, int picH,
+                                                                       const x265amd_mc_job* jobs, int n)
+{
+    const int lane = xa_lane();
+    const int ji = blockIdx.x * MC_WAVES + (threadIdx.x >> 6);
+    if (ji >= n) return;
+    const x265amd_mc_job j = jobs[ji];
+    const int refs[2] = { j.ref0, j.ref1 };
+    int mv[2][2] = { { j.mv0[0], j.mv0[1] }, { j.mv1[0], j.mv1[1] } };
+    /* CUData::clipMv */
+    {
+        const int maxCU = 64, offset = 8;
+        int xmax = (picW + offset - j.cu_x - 1) << 2, xmin = -((maxCU + offset + j.cu_x - 1) << 2);
+        int ymax = (picH + offset - j.cu_y - 1) << 2, ymin = -((maxCU + offset + j.cu_y - 1) << 2);
+        for (int l = 0; l < 2; l++)
+        {
+            mv[l][0] = min(xmax, max(xmin, mv[l][0]));
+            mv[l][1] = min(ymax, max(ymin, mv[l][1]));
+        }
+    }
+    /* which combination rule applies: predict.cpp:82-243 */
+    int mode, lsel = 0;
+    if (j.slice_type)
+        mode = ((j.flags & 4) && j.wp[0][0].present) ? 1 : 0;
+    else
+    {
+        bool wb = (j.flags & 8) != 0;
+        if (refs[0] >= 0 && refs[1] >= 0)
+            mode = (wb && (j.wp[0][0].present || j.wp[1][0].present)) ? 3 : 2;
+        else
+        {
+            lsel = refs[0] >= 0 ? 0 : 1;
+            mode = (wb && j.wp[lsel][0].present) ? 1 : 0;
+        }
+    }
+    McPlane p;
+    if (j.flags & 1)
+    {
+        for (int l = 0; l < 2; l++)
+        {
+            p.src[l] = refs[l] >= 0 ? reinterpret_cast<const pixel*>(planes[3 * refs[l]]) + (long)(j.y + (mv[l][1] >> 2)) * stride + j.x + (mv[l][0] >> 2) : nullptr;
+            p.xf[l] = mv[l][0] & 3; p.yf[l] = mv[l][1] & 3;
+        }
+        p.stride = stride; p.w = j.w; p.h = j.h; p.dst = reinterpret_cast<pixel*>(j.dst_y); p.dstStride = j.dst_stride; p.c = 0;
+        mc_plane<8>(p, j, mode, lsel, lane);
+    }
+    if (j.flags & 2)
+        for (int c = 1; c < 3; c++)
+        {
+            for (int l = 0; l < 2; l++)
+            {
+                p.src[l] = refs[l] >= 0 ? reinterpret_cast<const pixel*>(planes[3 * refs[l] + c]) + (long)((j.y >> 1) + (mv[l][1] >> 3)) * cstride + (j.x >> 1) + (mv[l][0] >> 3) : nullptr;
+                p.xf[l] = mv[l][0] & 7; p.yf[l] = mv[l][1] & 7;
+            }
+            p.stride = cstride; p.w = j.w >> 1; p.h = j.h >> 1; p.dst = reinterpret_cast<pixel*>(c == 1 ? j.dst_u : j.dst_v); p.dstStride = j.dst_cstride; p.c = c;
+            mc_plane<4>(p, j, mode, lsel, lane);
+        }
+}
+
+extern "C" int x265amd_motion_compensation(void* stream, const uint64_t* d_planes, intptr_t stride, intptr_t cstride, int pic_w, int pic_h,
+                                           const x265amd_mc_job* d_jobs, int n)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!d_planes || !d_jobs) return xa_fail(X265AMD_EINVAL, "x265amd_motion_compensation: bad arguments");
+    hipLaunchKernelGGL(k_motion_compensation, dim3((n + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, (hipStream_t)stream,
+                       d_planes, (long)stride, (long)cstride, pic_w, pic_h, d_jobs, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
