@@ -293,7 +293,7 @@ def main():
         if marks: marks[0].record(stream)
         rc = lib.x265amd_me_search(me.ctx, sp, C.c_void_p(planes[cur][0] + origin), C.c_void_p(reftab[cur].data_ptr()), C.c_int64(stride),
                                    C.c_void_p(d_groups.data_ptr()), len(groups), C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()),
-                                   MAX_WIN[0], MAX_WIN[1], 0)
+                                   MAX_WIN[0], MAX_WIN[1], 0, None, C.c_int64(0))
         assert rc == 0, lib.x265amd_last_error()
         if marks: marks[1].record(stream)
         rc = lib.x265amd_intra_scan(sp, C.c_void_p(d_in[cur].data_ptr()), n_in, C.c_void_p(d_in_out.data_ptr()), None)

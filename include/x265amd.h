@@ -195,7 +195,7 @@ typedef struct x265amd_me_job
 {
     int16_t x, y;                       /* PU position in the picture, luma samples */
     uint8_t w, h;                       /* PU size (a LumaPU shape, primitives.h:41-55) */
-    uint8_t method, subme;              /* searchMethod (X265AMD_ME_*), subpelRefine 0..7 (motion.cpp:48-58) */
+    uint8_t method, subme;              /* searchMethod (X265AMD_ME_*, | X265AMD_ME_CHROMA_SATD), subpelRefine 0..7 (motion.cpp:48-58) */
     uint8_t qp, num_cand;               /* QP selecting the MV cost table (bitcost.cpp:30-58); number of mvc[] */
     int16_t merange;
     int16_t mvmin[2], mvmax[2];         /* search bounds, full-pel (search.cpp:2724-2768) */
@@ -232,10 +232,15 @@ int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int max_win_w, i
  * staged window -- results never depend on the window size. */
 int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_fenc, const uint64_t* d_refs, intptr_t stride,
                       const x265amd_me_group* d_groups, int num_groups, const x265amd_me_job* d_jobs, x265amd_me_result* d_out,
-                      int max_win_w, int max_win_h, int flags);
+                      int max_win_w, int max_win_h, int flags, const uint64_t* d_chroma, intptr_t cstride);
 /* flags: X265AMD_ME_FLAG_STAR must be set when any job uses X265AMD_ME_STAR (selects the kernel variant that carries
  * the star search; without it such jobs still produce exact results through the slower second pass). */
 #define X265AMD_ME_FLAG_STAR 1
+/* Chroma SATD (MotionEstimate::bChromaSATD, motion.cpp:234-237): a job whose `method` has X265AMD_ME_CHROMA_SATD set was
+ * configured with bChroma = true in setSourcePU; with subme > 2 and a 4:2:0 chroma PU that is a multiple of 4x4 every
+ * sub-pel comparison then adds the SATD of both chroma blocks (motion.cpp:1625-1686).  d_chroma (device array, may be NULL
+ * when no job asks for it): [0],[1] = source U,V sample (0,0); [2+2r],[3+2r] = reference r U,V; all with stride `cstride`. */
+#define X265AMD_ME_CHROMA_SATD 0x80
 
 /* --- residual (transform unit) path: Quant::transformNxN / invtransformNxN (reference: source/common/quant.cpp:397-605,
  * sign-bit hiding :247-395) and the per-TU measurement of the residual quad-tree (source/encoder/search.cpp:3276-3330).

@@ -31,6 +31,12 @@ void orc_luma_vpp(int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, 
 void orc_luma_hvpp(int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int ix, int iy);
 int orc_partition_from_sizes(int w, int h);
 int orc_pu_width(int part);
+int orc_pu_height(int part);
+int orc_chroma_satd(int csp, int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+void orc_chroma_hpp(int csp, int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx);
+void orc_chroma_vpp(int csp, int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx);
+void orc_chroma_hps(int csp, int part, const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int idx, int rowExt);
+void orc_chroma_vsp(int csp, int part, const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int idx);
 
 /* ---------------------------------------------------------------------------------------------------------
  * lambda table and MV cost table
@@ -94,6 +100,11 @@ typedef struct
     const uint16_t* cost;       /* s_costs[qp] */
     MV mvp;
     MV mvmin, mvmax;
+    /* chroma SATD (bChromaSATD, motion.cpp:234-237): subpelRefine > 2 and the 4:2:0 chroma PU is a multiple of 4x4 */
+    int chroma;
+    pixel fencC[2][32 * 32];    /* chroma PU copies at stride FENC_STRIDE / 2 */
+    const pixel* refC[2];       /* chroma reference planes + block offset */
+    intptr_t cstride;
 } ME;
 
 static inline int mvcost(const ME* m, int x, int y) { return (uint16_t)(m->cost[x - m->mvp.x] + m->cost[y - m->mvp.y]); }
@@ -105,14 +116,38 @@ static inline int clipi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? 
 static int subpel_compare(const ME* m, MV q, cmp_t cmp)
 {
     const pixel* fref = m->fref + (q.x >> 2) + (q.y >> 2) * m->stride;
-    int xf = q.x & 3, yf = q.y & 3;
-    if (!(xf | yf))
-        return cmp(m->part, m->fenc, FENC_STRIDE, fref, m->stride);
+    int xf = q.x & 3, yf = q.y & 3, cost;
     pixel buf[64 * 64];
-    if (!yf) orc_luma_hpp(m->part, fref, m->stride, buf, m->width, xf);
-    else if (!xf) orc_luma_vpp(m->part, fref, m->stride, buf, m->width, yf);
-    else orc_luma_hvpp(m->part, fref, m->stride, buf, m->width, xf, yf);
-    return cmp(m->part, m->fenc, FENC_STRIDE, buf, m->width);
+    if (!(xf | yf))
+        cost = cmp(m->part, m->fenc, FENC_STRIDE, fref, m->stride);
+    else
+    {
+        if (!yf) orc_luma_hpp(m->part, fref, m->stride, buf, m->width, xf);
+        else if (!xf) orc_luma_vpp(m->part, fref, m->stride, buf, m->width, yf);
+        else orc_luma_hvpp(m->part, fref, m->stride, buf, m->width, xf, yf);
+        cost = cmp(m->part, m->fenc, FENC_STRIDE, buf, m->width);
+    }
+    if (m->chroma)      /* motion.cpp:1625-1686, 4:2:0: the luma quarter-pel MV is the chroma eighth-pel MV */
+    {
+        intptr_t off = (q.x >> 3) + (q.y >> 3) * m->cstride;
+        int cw = m->width >> 1;
+        xf = q.x & 7; yf = q.y & 7;
+        for (int c = 0; c < 2; c++)
+        {
+            const pixel* ref = m->refC[c] + off;
+            if (!(xf | yf)) { cost += orc_chroma_satd(1, m->part, m->fencC[c], 32, ref, m->cstride); continue; }
+            if (!yf) orc_chroma_hpp(1, m->part, ref, m->cstride, buf, cw, xf);
+            else if (!xf) orc_chroma_vpp(1, m->part, ref, m->cstride, buf, cw, yf);
+            else
+            {
+                int16_t immed[32 * (32 + 3)];
+                orc_chroma_hps(1, m->part, ref, m->cstride, immed, cw, xf, 1);
+                orc_chroma_vsp(1, m->part, immed + cw, cw, buf, cw, yf);
+            }
+            cost += orc_chroma_satd(1, m->part, m->fencC[c], 32, buf, cw);
+        }
+    }
+    return cost;
 }
 
 #define COST_MV(mx, my) do { int c_ = sad_at(m, mx, my) + mvcost(m, (mx) * 4, (my) * 4); if (c_ < bcost) { bcost = c_; bmv.x = (mx); bmv.y = (my); } } while (0)
@@ -219,12 +254,42 @@ enum { ME_DIA = 0, ME_HEX = 1, ME_UMH = 2, ME_STAR = 3, ME_SEA = 4, ME_FULL = 5 
  * at (puX,puY); mvmin/mvmax in full-pel, qmvp / mvc in quarter-pel -- exactly the arguments of
  * MotionEstimate::motionEstimate() (motion.cpp:764-773) after setSourcePU() (motion.cpp:193-217).
  * Returns the cost, writes the quarter-pel MV to outMv[2]; -1 for search methods not restated. */
+int orc_motion_estimate_c(const pixel* const* fencPl, const pixel* const* refPl, intptr_t stride, intptr_t cstride, int puX, int puY, int w, int h,
+                          int method, int subme, int qp, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                          int numCandidates, const int32_t* mvc, int merange, int bChroma, int32_t* outMv);
+
 int orc_motion_estimate(const pixel* fencPlane, const pixel* refPlane, intptr_t stride, int puX, int puY, int w, int h,
                         int method, int subme, int qp, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
                         int numCandidates, const int32_t* mvc, int merange, int32_t* outMv)
 {
+    const pixel* f[3] = { fencPlane, 0, 0 };
+    const pixel* r[3] = { refPlane, 0, 0 };
+    return orc_motion_estimate_c(f, r, stride, 0, puX, puY, w, h, method, subme, qp, mvmin, mvmax, qmvp, numCandidates, mvc, merange, 0, outMv);
+}
+
+/* the encoder form: setSourcePU from a CU Yuv (motion.cpp:219-247), chroma SATD when bChroma, subme > 2 and the chroma PU is
+ * a multiple of 4x4.  fencPl / refPl: sample (0,0) of the Y, U, V planes (U, V may be NULL when bChroma is 0) */
+int orc_motion_estimate_c(const pixel* const* fencPl, const pixel* const* refPl, intptr_t stride, intptr_t cstride, int puX, int puY, int w, int h,
+                          int method, int subme, int qp, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                          int numCandidates, const int32_t* mvc, int merange, int bChroma, int32_t* outMv)
+{
     if (method != ME_DIA && method != ME_HEX && method != ME_STAR) return -1;
-    ME me, *m = &me;
+    const pixel* fencPlane = fencPl[0];
+    const pixel* refPlane = refPl[0];
+    static ME me_storage;
+    ME* m = &me_storage;
+#define me (*m)
+    me.chroma = bChroma && subme > 2 && (((w >> 1) | (h >> 1)) & 3) == 0;
+    if (me.chroma)
+    {
+        for (int c = 0; c < 2; c++)
+        {
+            for (int y = 0; y < h / 2; y++)
+                memcpy(me.fencC[c] + y * 32, fencPl[1 + c] + (puY / 2 + y) * cstride + puX / 2, (w / 2) * sizeof(pixel));
+            me.refC[c] = refPl[1 + c] + (puY / 2) * cstride + puX / 2;
+        }
+        me.cstride = cstride;
+    }
     me.part = orc_partition_from_sizes(w, h);
     me.width = w;
     for (int y = 0; y < h; y++)
@@ -454,6 +519,7 @@ int orc_motion_estimate(const pixel* fencPlane, const pixel* refPlane, intptr_t 
     }
     outMv[0] = bmv.x; outMv[1] = bmv.y;
     return bcost;
+#undef me
 }
 
 /* batch form over the packed job records of include/x265amd.h (struct x265amd_me_job, 72 bytes) */

@@ -172,6 +172,40 @@ int ref_motion_estimate(const pixel* fencPlane, const pixel* refPlane, intptr_t 
     return cost;
 }
 
+/* setSourcePU (encoder form, motion.cpp:219-247: PU copied from a CU Yuv, chroma SATD when subpelRefine > 2 and the
+ * chroma PU is a multiple of 4x4) + motionEstimate.  planes: sample (0,0) of Y,U,V of the source and of the reference. */
+int ref_motion_estimate_c(const pixel* const* fencPl, const pixel* const* refPl, intptr_t stride, intptr_t cstride, int puX, int puY, int w, int h,
+                          int method, int subme, int qp, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                          int numCandidates, const int32_t* mvc, int merange, int bChroma, int32_t* outMv)
+{
+    ensure();
+    static MotionEstimate me;
+    static bool meInit = false;
+    static Yuv fencYuv;
+    static PicYuv* pic = NULL;
+    static intptr_t zeroCu[1] = { 0 }, buY[256], buC[256];
+    if (!meInit) { me.init(X265_CSP_I420); fencYuv.create(64, X265_CSP_I420); pic = new PicYuv; meInit = true; }
+    me.setQP(qp);
+    for (int y = 0; y < h; y++) memcpy(fencYuv.m_buf[0] + y * fencYuv.m_size, fencPl[0] + (intptr_t)(puY + y) * stride + puX, w * sizeof(pixel));
+    for (int c = 1; c < 3; c++)
+        for (int y = 0; y < h / 2; y++) memcpy(fencYuv.m_buf[c] + y * fencYuv.m_csize, fencPl[c] + (intptr_t)(puY / 2 + y) * cstride + puX / 2, (w / 2) * sizeof(pixel));
+    me.setSourcePU(fencYuv, 0, 0, 0, w, h, method, subme, bChroma != 0);
+    memset(buY, 0, sizeof(buY)); memset(buC, 0, sizeof(buC));
+    buY[0] = (intptr_t)puY * stride + puX; buC[0] = (intptr_t)(puY / 2) * cstride + puX / 2;
+    pic->m_picOrg[0] = (pixel*)refPl[0]; pic->m_picOrg[1] = (pixel*)refPl[1]; pic->m_picOrg[2] = (pixel*)refPl[2];
+    pic->m_stride = stride; pic->m_strideC = cstride;
+    pic->m_cuOffsetY = zeroCu; pic->m_cuOffsetC = zeroCu; pic->m_buOffsetY = buY; pic->m_buOffsetC = buC;
+    ReferencePlanes ref;
+    ref.fpelPlane[0] = (pixel*)refPl[0]; ref.fpelPlane[1] = (pixel*)refPl[1]; ref.fpelPlane[2] = (pixel*)refPl[2];
+    ref.lumaStride = stride; ref.chromaStride = cstride; ref.reconPic = pic;
+    MV cand[16];
+    for (int i = 0; i < numCandidates && i < 16; i++) cand[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out;
+    int cost = me.motionEstimate(&ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]), MV(qmvp[0], qmvp[1]), numCandidates, cand, merange, out, 1, NULL);
+    outMv[0] = out.x; outMv[1] = out.y;
+    return cost;
+}
+
 /* batch form over the packed job records of include/x265amd.h (struct x265amd_me_job, 72 bytes) -- used by bench.py's
  * cpu_baseline leg so that the timed loop is the reference's C code, not Python call overhead */
 struct PackedMeJob { int16_t x, y; uint8_t w, h, method, subme, qp, num_cand; int16_t merange, mvmin[2], mvmax[2], mvp[2], mvc[12][2]; };

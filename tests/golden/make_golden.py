@@ -46,6 +46,8 @@ def main():
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
               (T.ME_STAR, 2), (T.ME_STAR, 4)]
 ME_SCENES = ((1, (5, -3)), (2, (-17, 9)), (3, (0, 0)), (4, (33, 21)))
+ME_CHROMA_CONFIGS = [(T.ME_STAR, 3), (T.ME_HEX, 3), (T.ME_STAR, 4), (T.ME_HEX, 7), (T.ME_DIA, 5)]
+ME_CHROMA_SCENES = ((11, (6, -4)), (12, (-18, 10)))
 
 
 def make_me_golden():
@@ -61,6 +63,11 @@ def make_me_golden():
                 cur, rp, stride, origin = T.me_make_planes(depth, seed, motion=motion)
                 jobs = T.me_jobs(seed * 100 + method * 10 + subme, 60, motion=motion, methods=(method,), submes=(subme,))
                 out["me/%d/%d/%d/%d" % (depth, method, subme, seed)] = T.me_run_host(ref, cur, rp, stride, origin, jobs)
+        for method, subme in ME_CHROMA_CONFIGS:
+            for seed, motion in ME_CHROMA_SCENES:
+                cur, rp, stride, cstride, origin, corg = T.me_make_yuv(depth, seed, motion=motion)
+                jobs = T.me_jobs(seed * 100 + method * 10 + subme, 50, motion=motion, methods=(method,), submes=(subme,))
+                out["mec/%d/%d/%d/%d" % (depth, method, subme, seed)] = T.me_run_host_c(ref, cur, rp, stride, cstride, origin, corg, jobs)
         ref.lib.ref_mvcost_table.restype = C.POINTER(C.c_uint16)
         dig = []
         for qp in range(70):

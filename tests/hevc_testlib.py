@@ -517,14 +517,15 @@ ME_DIA, ME_HEX, ME_UMH, ME_STAR = 0, 1, 2, 3
 ME_MARGIN = 96      # padded planes, like PicYuv (reference: common/picyuv.cpp: marginX = maxCU + 32)
 
 
-def me_make_planes(depth, seed, width=256, height=192, motion=(5, -3), noise=3):
+def me_make_planes(depth, seed, width=256, height=192, motion=(5, -3), noise=3, margin=None):
     """Deterministic integer-only synthetic pair: a textured reference plane (with margins) and a current plane that
     is the reference displaced by `motion` full-pel samples plus small noise.  Returns (cur, ref, stride, origin)
     where origin is the element offset of sample (0,0)."""
     rng = np.random.default_rng(seed)
     pmax = (1 << depth) - 1
-    stride = width + 2 * ME_MARGIN
-    rows = height + 2 * ME_MARGIN
+    margin = ME_MARGIN if margin is None else margin
+    stride = width + 2 * margin
+    rows = height + 2 * margin
     base = rng.integers(0, pmax + 1, (rows // 8 + 2, stride // 8 + 2)).astype(np.int64)
     up = np.kron(base, np.ones((8, 8), np.int64))[:rows, :stride]
     # cheap integer smoothing so that sub-pel interpolation and the search have structure to follow
@@ -541,7 +542,7 @@ def me_make_planes(depth, seed, width=256, height=192, motion=(5, -3), noise=3):
     cur[hy:, hx:] = shifted(-motion[0], motion[1] + 4)[hy:, hx:]
     cur = np.clip(cur + rng.integers(-noise, noise + 1, cur.shape), 0, pmax)
     dt = np.uint8 if depth == 8 else np.uint16
-    return np.ascontiguousarray(cur.astype(dt)).ravel(), np.ascontiguousarray(ref.astype(dt)).ravel(), stride, ME_MARGIN * stride + ME_MARGIN
+    return np.ascontiguousarray(cur.astype(dt)).ravel(), np.ascontiguousarray(ref.astype(dt)).ravel(), stride, margin * stride + margin
 
 
 def me_jobs(seed, n, width=256, height=192, motion=(5, -3), methods=(ME_HEX,), submes=(2,), merange=57):
@@ -653,7 +654,8 @@ class HipME:
         t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).cuda()
         return t
 
-    def search(self, d_cur, d_refs, stride, origin_elems, itemsize, groups, packed_ordered, max_win=(192, 192), stream=None, flags=None):
+    def search(self, d_cur, d_refs, stride, origin_elems, itemsize, groups, packed_ordered, max_win=(192, 192), stream=None, flags=None,
+               d_chroma=None, cstride=0):
         """d_cur / d_refs: uploaded planes (uint8 tensors); returns result tensor (device, bytes)"""
         torch = self.torch
         d_groups = self.upload(groups)
@@ -662,13 +664,29 @@ class HipME:
         refs = np.array([r.data_ptr() + origin_elems * itemsize for r in d_refs], np.uint64)
         d_reftab = self.upload(refs)
         if flags is None:
-            flags = 1 if (packed_ordered["method"] == ME_STAR).any() else 0
+            flags = 1 if ((packed_ordered["method"] & 0x7f) == ME_STAR).any() else 0
         rc = self.lib.x265amd_me_search(self.ctx, C.c_void_p(stream or 0), C.c_void_p(d_cur.data_ptr() + origin_elems * itemsize),
                                         C.c_void_p(d_reftab.data_ptr()), C.c_int64(stride), C.c_void_p(d_groups.data_ptr()), len(groups),
-                                        C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), max_win[0], max_win[1], flags)
+                                        C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), max_win[0], max_win[1], flags,
+                                        C.c_void_p(d_chroma.data_ptr() if d_chroma is not None else 0), C.c_int64(cstride))
         assert rc == 0, self.lib.x265amd_last_error()
         self._keep = (d_groups, d_jobs, d_reftab)
         return d_out
+
+    def run_c(self, cur, ref, stride, cstride, origin, corg, jobs, max_win=(192, 192)):
+        """encoder form with chroma SATD: cur / ref are [Y, U, V] host planes"""
+        packed = me_pack_jobs(jobs)
+        packed["method"] |= 0x80
+        groups, order = self.plan(packed, 0, max_win)
+        d = [self.upload(p) for p in cur + ref]
+        isz = cur[0].itemsize
+        chroma = self.upload(np.array([d[1].data_ptr() + corg * isz, d[2].data_ptr() + corg * isz, d[4].data_ptr() + corg * isz, d[5].data_ptr() + corg * isz], np.uint64))
+        d_out = self.search(d[0], [d[3]], stride, origin, isz, groups, packed[order], max_win, d_chroma=chroma, cstride=cstride)
+        self.torch.cuda.synchronize()
+        res = d_out.cpu().numpy().view(ME_RESULT_DT)
+        out = np.zeros((len(jobs), 3), np.int32)
+        out[order, 0] = res["mv"][:, 0]; out[order, 1] = res["mv"][:, 1]; out[order, 2] = res["cost"]
+        return out
 
     def run(self, cur, ref, stride, origin, jobs, max_win=(192, 192), flags=None):
         """host arrays in, int array [n,3] (mvx, mvy, cost) out, in the order of `jobs`"""
@@ -975,3 +993,30 @@ def mc_run_hip(L, pics, stride, cstride, org, jobs):
         w, h, f = int(jobs[i]["w"]), int(jobs[i]["h"]), int(jobs[i]["flags"])
         res.append((outY[i, :h, :w].copy() if f & 1 else None, outU[i, :h // 2, :w // 2].copy() if f & 2 else None, outV[i, :h // 2, :w // 2].copy() if f & 2 else None))
     return res
+
+
+# ---- motion estimation with chroma SATD (subme > 2): the encoder form of setSourcePU ----
+def me_make_yuv(depth, seed, motion=(5, -3)):
+    """(cur, ref) each a list [Y, U, V] of flat padded planes; plus (stride, cstride, originY, originC)"""
+    cy, ry, stride, origin = me_make_planes(depth, seed, motion=motion)
+    cmarg = ME_MARGIN // 2
+    cu, ru, cstride, corg = me_make_planes(depth, seed + 1000, width=128, height=96, motion=(motion[0] // 2, motion[1] // 2), noise=2, margin=cmarg)
+    cv, rv, _, _ = me_make_planes(depth, seed + 2000, width=128, height=96, motion=(motion[0] // 2, motion[1] // 2), noise=2, margin=cmarg)
+    return [cy, cu, cv], [ry, ru, rv], stride, cstride, origin, corg
+
+
+def me_run_host_c(L, cur, ref, stride, cstride, origin, corg, jobs, bChroma=1):
+    out = np.zeros((len(jobs), 3), np.int32)
+    fn = getattr(L.lib, L.prefix + "motion_estimate_c")
+    fn.restype = C.c_int
+    isz = cur[0].itemsize
+    fpl = (C.c_void_p * 3)(cur[0].ctypes.data + origin * isz, cur[1].ctypes.data + corg * isz, cur[2].ctypes.data + corg * isz)
+    rpl = (C.c_void_p * 3)(ref[0].ctypes.data + origin * isz, ref[1].ctypes.data + corg * isz, ref[2].ctypes.data + corg * isz)
+    for i, j in enumerate(jobs):
+        mv = np.zeros(2, np.int32)
+        mvc = np.array(j["mvc"], np.int32).reshape(-1) if j["mvc"] else np.zeros(2, np.int32)
+        cost = fn(fpl, rpl, C.c_int64(stride), C.c_int64(cstride), j["x"], j["y"], j["w"], j["h"], j["method"], j["subme"], j["qp"],
+                  _ptr(np.array(j["mvmin"], np.int32)), _ptr(np.array(j["mvmax"], np.int32)), _ptr(np.array(j["mvp"], np.int32)),
+                  len(j["mvc"]), _ptr(mvc), j["merange"], bChroma, _ptr(mv))
+        out[i] = (mv[0], mv[1], cost)
+    return out

@@ -50,3 +50,21 @@ def test_me_small_window_fallback(depth):
         got = me.run(cur, rp, stride, origin, jobs, max_win=win)
         assert np.array_equal(want, got), win
     me.close()
+
+
+CHROMA_CONFIGS = sorted({tuple(int(v) for v in k.split("/")[2:4]) for k in GOLD.files if k.startswith("mec/")})
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method,subme", CHROMA_CONFIGS)
+def test_me_search_chroma_satd(depth, method, subme):
+    """encoder form (setSourcePU from a CU Yuv with bChroma): chroma SATD joins the sub-pel comparisons when subme > 2"""
+    me = T.HipME(depth)
+    for seed, motion in ((11, (6, -4)), (12, (-18, 10))):
+        cur, rp, stride, cstride, origin, corg = T.me_make_yuv(depth, seed, motion=motion)
+        jobs = T.me_jobs(seed * 100 + method * 10 + subme, 50, motion=motion, methods=(method,), submes=(subme,))
+        want = GOLD["mec/%d/%d/%d/%d" % (depth, method, subme, seed)]
+        got = me.run_c(cur, rp, stride, cstride, origin, corg, jobs)
+        bad = np.argwhere((want != got).any(axis=1))
+        assert len(bad) == 0, "job %d: %s want %s got %s" % (bad[0][0], jobs[int(bad[0][0])], want[int(bad[0][0])], got[int(bad[0][0])])
+    me.close()

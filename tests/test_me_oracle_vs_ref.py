@@ -40,3 +40,20 @@ def test_motion_estimate(depth, method, subme):
         bad = np.argwhere((want != got).any(axis=1))
         assert len(bad) == 0, "job %d: %s want %s got %s" % (bad[0][0], jobs[int(bad[0][0])], want[int(bad[0][0])], got[int(bad[0][0])])
         assert len({tuple(r[:2]) for r in want}) > 3      # the searches actually move
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method,subme", [(T.ME_STAR, 3), (T.ME_HEX, 3), (T.ME_STAR, 4), (T.ME_HEX, 7), (T.ME_DIA, 5)])
+def test_motion_estimate_chroma_satd(depth, method, subme):
+    """encoder form of setSourcePU: chroma SATD joins every subpelCompare when subme > 2 (motion.cpp:234-237, :1625-1686)"""
+    ref, orc = T.load_ref(depth), T.load_oracle(depth)
+    for seed, motion in ((11, (6, -4)), (12, (-18, 10))):
+        cur, rp, stride, cstride, origin, corg = T.me_make_yuv(depth, seed, motion=motion)
+        jobs = T.me_jobs(seed * 100 + method * 10 + subme, 50, motion=motion, methods=(method,), submes=(subme,))
+        want = T.me_run_host_c(ref, cur, rp, stride, cstride, origin, corg, jobs)
+        got = T.me_run_host_c(orc, cur, rp, stride, cstride, origin, corg, jobs)
+        bad = np.argwhere((want != got).any(axis=1))
+        assert len(bad) == 0, "job %d: %s want %s got %s" % (bad[0][0], jobs[int(bad[0][0])], want[int(bad[0][0])], got[int(bad[0][0])])
+        # chroma really contributes: the luma-only search gives different costs
+        luma_only = T.me_run_host(ref, cur[0], rp[0], stride, origin, jobs)
+        assert (luma_only[:, 2] != want[:, 2]).sum() > 10

@@ -42,7 +42,8 @@ struct MeParams
 {
     const pixel* fenc;
     const uint64_t* refs;
-    int stride;
+    const uint64_t* chroma;     /* NULL, or [0],[1] source U,V origins and [2+2r],[3+2r] reference r U,V origins */
+    int stride, cstride;
     const x265amd_me_group* groups;
     const x265amd_me_job* jobs;
     x265amd_me_result* out;
@@ -63,6 +64,10 @@ struct MeState
     const uint16_t* cost;
     int mvpx, mvpy;
     int mnx, mny, mxx, mxy;
+    /* chroma SATD (MotionEstimate::bChromaSATD, motion.cpp:234-237): 4:2:0 chroma blocks of the PU in HBM */
+    int chroma, cstride;
+    const pixel* fencC[2];
+    const pixel* refC[2];
     int acc[16];        /* per-candidate accumulators of the batched sub-pel comparisons */
     int cand[16];       /* their quarter-pel MVs, packed (qy << 16) | (qx & 0xffff) */
     int oob;            /* set by the window-resident kernel when a candidate left the staged window: the job is redone
@@ -116,6 +121,49 @@ template<bool INWIN> XA_DEV int me_sad_fpel(const MeState& s, int X, int Y)
 #pragma unroll
         for (int k = 0; k < 4; k++)
             sum += abs((int)f[k] - me_ref<INWIN>(s, X + x + k, Y + y));
+    }
+    return xa_wave_sum(sum);
+}
+
+/* chroma part of subpelCompare (motion.cpp:1625-1686): SATD of both 4:2:0 chroma blocks at the luma quarter-pel MV
+ * (= chroma eighth-pel MV), prediction as predInterChromaPixel does it; one lane per 4x4 chroma tile, samples from HBM/L2 */
+__device__ __noinline__ int me_chroma_satd(int sOff, int qx, int qy)
+{
+    const MeState& s = ME_S(sOff);
+    const int lane = xa_lane();
+    const int cw = s.w >> 1, ch = s.h >> 1, tw = cw >> 2, nt = tw * (ch >> 2);
+    const int xf = qx & 7, yf = qy & 7;
+    const long off = (long)(qy >> 3) * s.cstride + (qx >> 3);
+    int sum = 0;
+    for (int it = lane; it < 2 * nt; it += XA_WAVE)
+    {
+        int c = it >= nt, t = c ? it - nt : it;
+        int ty = t / tw, tx = t - ty * tw;
+        const pixel* ref = s.refC[c] + off + (long)(4 * ty) * s.cstride + 4 * tx;
+        const pixel* f = s.fencC[c] + (long)(4 * ty) * s.cstride + 4 * tx;
+        int d[4][4];
+#pragma unroll 1
+        for (int y = 0; y < 4; y++)
+        {
+            int r0 = (int)f[(long)y * s.cstride + 0] - mc_sample<4, false>(ref + (long)y * s.cstride + 0, s.cstride, xf, yf);
+            int r1 = (int)f[(long)y * s.cstride + 1] - mc_sample<4, false>(ref + (long)y * s.cstride + 1, s.cstride, xf, yf);
+            int r2 = (int)f[(long)y * s.cstride + 2] - mc_sample<4, false>(ref + (long)y * s.cstride + 2, s.cstride, xf, yf);
+            int r3 = (int)f[(long)y * s.cstride + 3] - mc_sample<4, false>(ref + (long)y * s.cstride + 3, s.cstride, xf, yf);
+            int s01 = r0 + r1, e01 = r0 - r1, s23 = r2 + r3, e23 = r2 - r3;
+            int a0 = s01 + s23, a1 = s01 - s23, a2 = e01 + e23, a3 = e01 - e23;
+            if (y == 0) { d[0][0] = a0; d[0][1] = a1; d[0][2] = a2; d[0][3] = a3; }
+            else if (y == 1) { d[1][0] = a0; d[1][1] = a1; d[1][2] = a2; d[1][3] = a3; }
+            else if (y == 2) { d[2][0] = a0; d[2][1] = a1; d[2][2] = a2; d[2][3] = a3; }
+            else { d[3][0] = a0; d[3][1] = a1; d[3][2] = a2; d[3][3] = a3; }
+        }
+        int ts = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+        {
+            int s01 = d[0][x] + d[1][x], e01 = d[0][x] - d[1][x], s23 = d[2][x] + d[3][x], e23 = d[2][x] - d[3][x];
+            ts += abs(s01 + s23) + abs(s01 - s23) + abs(e01 + e23) + abs(e01 - e23);
+        }
+        sum += ts >> 1;
     }
     return xa_wave_sum(sum);
 }
@@ -406,16 +454,17 @@ template<bool SATD> XA_DEV int me_subpel_cmp_fast(const MeState& s, int qx, int 
 template<bool SATD, bool SLOW, bool INL> ME_HELPER int me_subpel_b(int sOff, int qx, int qy)
 {
     const MeState& s = ME_S(sOff);
-    if (!SATD && !((qx | qy) & 3)) return me_sad_at_f<SLOW, INL>(sOff, qx >> 2, qy >> 2);
-    if (SLOW) return me_subpel_cmp<false, SATD>(sOff, qx, qy);
+    const int chromaCost = s.chroma ? me_chroma_satd(sOff, qx, qy) : 0;
+    if (!SATD && !((qx | qy) & 3)) return me_sad_at_f<SLOW, INL>(sOff, qx >> 2, qy >> 2) + chromaCost;
+    if (SLOW) return me_subpel_cmp<false, SATD>(sOff, qx, qy) + chromaCost;
     int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
     /* +8 on the right: the dword reads of the fast path touch samples up to x+8 of the last tile */
     if (me_inwin(s, X0 - 3, Y0 - 3, X0 + s.w + 8, Y0 + s.h + 4))
     {
 #if XA_DEPTH == 8
-        return me_subpel_cmp_fast<SATD>(s, qx, qy);
+        return me_subpel_cmp_fast<SATD>(s, qx, qy) + chromaCost;
 #else
-        return me_subpel_cmp<true, SATD>(sOff, qx, qy);
+        return me_subpel_cmp<true, SATD>(sOff, qx, qy) + chromaCost;
 #endif
     }
     ME_OOB(sOff);
@@ -565,6 +614,12 @@ template<bool SATD, bool SLOW, bool INL> ME_HELPER int me_subpel_list_b(int sOff
         xa_wave_sync();
         int res = lane < n ? acc[lane] : ME_OOB_COST;
         xa_wave_sync();
+        if (s.chroma)
+            for (int k = 0; k < n; k++)
+            {
+                int cc = me_chroma_satd(sOff, (int)(int16_t)(s.cand[k] & 0xffff), s.cand[k] >> 16);
+                if (lane == k) res += cc;
+            }
         return res;
     }
 #endif
@@ -706,7 +761,7 @@ template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd
     constexpr bool INL = !SLOW && !STAR;    /* the HEX/DIA window-resident variant inlines the helper bodies */
     const MeState& s = ME_S(sOff);
     const int qminx = s.mnx * 4, qminy = s.mny * 4, qmaxx = s.mxx * 4, qmaxy = s.mxy * 4;
-    const int merange = jp->merange, numCand = jp->num_cand, method = jp->method, subme = jp->subme;
+    const int merange = jp->merange, numCand = jp->num_cand, method = jp->method & 0x7f, subme = jp->subme;
     /* motion.cpp:797-846: predictor, zero MV, candidates */
     int pmx = xa_clip3(qminx, qmaxx, s.mvpx), pmy = xa_clip3(qminy, qmaxy, s.mvpy);
     int bestprex = pmx, bestprey = pmy;
@@ -959,6 +1014,18 @@ XA_DEV void me_set_job(MeState& s, const x265amd_me_job& j, const x265amd_me_gro
     s.mvpx = j.mvp[0]; s.mvpy = j.mvp[1];
     s.mnx = j.mvmin[0]; s.mny = j.mvmin[1]; s.mxx = j.mvmax[0]; s.mxy = j.mvmax[1];
     s.oob = 0;
+    /* bChromaSATD = requested && subpelRefine > 2 && chroma PU a multiple of 4x4 (NULL chromaSatd otherwise) */
+    s.chroma = p.chroma && (j.method & X265AMD_ME_CHROMA_SATD) && j.subme > 2 && ((((j.w >> 1) | (j.h >> 1)) & 3) == 0);
+    s.cstride = p.cstride;
+    if (s.chroma)
+    {
+        const long coff = (long)(j.y >> 1) * p.cstride + (j.x >> 1);
+        for (int c = 0; c < 2; c++)
+        {
+            s.fencC[c] = reinterpret_cast<const pixel*>(p.chroma[c]) + coff;
+            s.refC[c] = reinterpret_cast<const pixel*>(p.chroma[2 + 2 * g.ref + c]) + coff;
+        }
+    }
 }
 
 /* window-resident kernel: one workgroup per group, window + source tile in LDS, one wavefront per job */
@@ -1119,7 +1186,7 @@ extern "C" int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int m
     {
         idx[i] = i;
         if ((jobs[i].x & 63) + jobs[i].w > 64 || (jobs[i].y & 63) + jobs[i].h > 64 || (jobs[i].x & 3) || (jobs[i].w & 3) || (jobs[i].h & 3) ||
-            jobs[i].num_cand > X265AMD_ME_MAX_CAND || jobs[i].subme > 7 || jobs[i].qp >= ME_QP_COUNT)
+            jobs[i].num_cand > X265AMD_ME_MAX_CAND || jobs[i].subme > 7 || (jobs[i].method & 0x7f) > X265AMD_ME_FULL || jobs[i].qp >= ME_QP_COUNT)
             return xa_fail(X265AMD_EINVAL, "x265amd_me_plan: job outside the supported domain (PU must lie inside one 64x64 CTU tile, x%4==0)");
     }
     auto key = [&](int i) { return ((int64_t)(jobs[i].y >> 6) << 32) | (uint32_t)(jobs[i].x >> 6); };
@@ -1156,7 +1223,7 @@ extern "C" int x265amd_me_plan(const x265amd_me_job* jobs, int n, int ref, int m
 
 extern "C" int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_fenc, const uint64_t* d_refs, intptr_t stride,
                                  const x265amd_me_group* d_groups, int num_groups, const x265amd_me_job* d_jobs, x265amd_me_result* d_out,
-                                 int max_win_w, int max_win_h, int flags)
+                                 int max_win_w, int max_win_h, int flags, const uint64_t* d_chroma, intptr_t cstride)
 {
     if (!ctx || !d_fenc || !d_refs || !d_groups || !d_jobs || !d_out || num_groups < 0 || (max_win_w & 3))
         return xa_fail(X265AMD_EINVAL, "x265amd_me_search: bad arguments");
@@ -1173,6 +1240,7 @@ extern "C" int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265am
     }
     MeParams p;
     p.fenc = d_fenc; p.refs = d_refs; p.stride = (int)stride; p.groups = d_groups; p.jobs = d_jobs; p.out = d_out;
+    p.chroma = d_chroma; p.cstride = (int)cstride;
     p.tables = ctx->d_tables; p.maxWinW = max_win_w; p.maxWinH = max_win_h;
     if (star)
         hipLaunchKernelGGL(k_me_search<true>, dim3(num_groups), dim3(64 * ME_WAVES), lds, (hipStream_t)stream, p);

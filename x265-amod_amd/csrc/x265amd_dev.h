@@ -290,6 +290,44 @@ XA_DEV int xa_wave_sa8d(const pixel* a, int sa, const pixel* b, int sb, int size
     return xa_wave_sum(v);
 }
 
+/* ---- interpolation of one sample, shared by the MC kernel and the chroma-SATD part of the ME kernel ---- */
+/* one interpolated sample.  SHORT = false: the pixel path (copy / hpp / vpp / hps(rowExt)+vsp: ipfilter.cpp:79-120, :169-210,
+ * :250-292); SHORT = true: the 14-bit intermediate path (p2s / hps / vps / hps(rowExt)+vss: ipfilter.cpp:39-56, :122-167,
+ * :212-248, :294-324).  TAPS 8: luma, fractions in quarter samples; TAPS 4: chroma, eighth samples. */
+template<int TAPS, bool SHORT> XA_DEV int mc_sample(const pixel* src, long stride, int xf, int yf)
+{
+    const int half = TAPS / 2 - 1;
+    const int headRoom = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    const int shiftH = XA_IF_FILTER_PREC - headRoom, offH = (int)((unsigned)-XA_IF_INTERNAL_OFFS << shiftH);
+    const int16_t* cx = TAPS == 8 ? xa_tbl.lumaFilter[xf] : xa_tbl.chromaFilter[xf];
+    const int16_t* cy = TAPS == 8 ? xa_tbl.lumaFilter[yf] : xa_tbl.chromaFilter[yf];
+    if (!(xf | yf))
+        return SHORT ? (int)(int16_t)((int16_t)(src[0] << headRoom) - (int16_t)XA_IF_INTERNAL_OFFS) : (int)src[0];
+    if (!yf || !xf)
+    {
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; t++)
+            sum += yf ? (int)src[(long)(t - half) * stride] * cy[t] : (int)src[t - half] * cx[t];
+        if (SHORT) return (int)(int16_t)((sum + offH) >> shiftH);
+        return xa_clip3(0, XA_PIXEL_MAX, (int)(int16_t)((sum + (1 << (XA_IF_FILTER_PREC - 1))) >> XA_IF_FILTER_PREC));
+    }
+    int sum = 0;
+#pragma unroll 1
+    for (int r = 0; r < TAPS; r++)
+    {
+        const pixel* row = src + (long)(r - half) * stride - half;
+        int hs = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; t++) hs += (int)row[t] * cx[t];
+        sum += (int)(int16_t)((hs + offH) >> shiftH) * cy[r];
+    }
+    if (SHORT) return (int)(int16_t)(sum >> XA_IF_FILTER_PREC);
+    const int shiftV = XA_IF_FILTER_PREC + headRoom, offV = (1 << (shiftV - 1)) + (XA_IF_INTERNAL_OFFS << XA_IF_FILTER_PREC);
+    return xa_clip3(0, XA_PIXEL_MAX, (int)(int16_t)((sum + offV) >> shiftV));
+}
+
+
 /* ---- intra building blocks shared by the job-list and the fused intra kernels ---- */
 /* one angular prediction sample in "vertical orientation" on (possibly swapped) neighbours: intrapred.cpp:106-196 */
 XA_DEV pixel ang_sample(const pixel* s, int N, int angle, int invAngle, int bFilter, int y, int x)
