@@ -236,6 +236,7 @@ int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_
 /* flags: X265AMD_ME_FLAG_STAR must be set when any job uses X265AMD_ME_STAR (selects the kernel variant that carries
  * the star search; without it such jobs still produce exact results through the slower second pass). */
 #define X265AMD_ME_FLAG_STAR 1
+#define X265AMD_ME_FLAG_CHROMA 2          /* some job has X265AMD_ME_CHROMA_SATD set: selects the kernel variant that carries it */
 /* Chroma SATD (MotionEstimate::bChromaSATD, motion.cpp:234-237): a job whose `method` has X265AMD_ME_CHROMA_SATD set was
  * configured with bChroma = true in setSourcePU; with subme > 2 and a 4:2:0 chroma PU that is a multiple of 4x4 every
  * sub-pel comparison then adds the SATD of both chroma blocks (motion.cpp:1625-1686).  d_chroma (device array, may be NULL

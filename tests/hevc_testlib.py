@@ -664,7 +664,7 @@ class HipME:
         refs = np.array([r.data_ptr() + origin_elems * itemsize for r in d_refs], np.uint64)
         d_reftab = self.upload(refs)
         if flags is None:
-            flags = 1 if ((packed_ordered["method"] & 0x7f) == ME_STAR).any() else 0
+            flags = (1 if ((packed_ordered["method"] & 0x7f) == ME_STAR).any() else 0) | (2 if (packed_ordered["method"] & 0x80).any() else 0)
         rc = self.lib.x265amd_me_search(self.ctx, C.c_void_p(stream or 0), C.c_void_p(d_cur.data_ptr() + origin_elems * itemsize),
                                         C.c_void_p(d_reftab.data_ptr()), C.c_int64(stride), C.c_void_p(d_groups.data_ptr()), len(groups),
                                         C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_out.data_ptr()), max_win[0], max_win[1], flags,

@@ -454,7 +454,8 @@ template<bool SATD> XA_DEV int me_subpel_cmp_fast(const MeState& s, int qx, int 
 template<bool SATD, bool SLOW, bool INL> ME_HELPER int me_subpel_b(int sOff, int qx, int qy)
 {
     const MeState& s = ME_S(sOff);
-    const int chromaCost = s.chroma ? me_chroma_satd(sOff, qx, qy) : 0;
+    int chromaCost = 0;
+    if constexpr (!INL) { if (s.chroma) chromaCost = me_chroma_satd(sOff, qx, qy); }      /* the inlined variant never sees chroma jobs */
     if (!SATD && !((qx | qy) & 3)) return me_sad_at_f<SLOW, INL>(sOff, qx >> 2, qy >> 2) + chromaCost;
     if (SLOW) return me_subpel_cmp<false, SATD>(sOff, qx, qy) + chromaCost;
     int X0 = s.px + (qx >> 2), Y0 = s.py + (qy >> 2);
@@ -614,12 +615,15 @@ template<bool SATD, bool SLOW, bool INL> ME_HELPER int me_subpel_list_b(int sOff
         xa_wave_sync();
         int res = lane < n ? acc[lane] : ME_OOB_COST;
         xa_wave_sync();
-        if (s.chroma)
-            for (int k = 0; k < n; k++)
-            {
-                int cc = me_chroma_satd(sOff, (int)(int16_t)(s.cand[k] & 0xffff), s.cand[k] >> 16);
-                if (lane == k) res += cc;
-            }
+        if constexpr (!INL)
+        {
+            if (s.chroma)
+                for (int k = 0; k < n; k++)
+                {
+                    int cc = me_chroma_satd(sOff, (int)(int16_t)(s.cand[k] & 0xffff), s.cand[k] >> 16);
+                    if (lane == k) res += cc;
+                }
+        }
         return res;
     }
 #endif
@@ -759,6 +763,15 @@ template<bool SLOW> __device__ __noinline__ void me_star_pattern(int sOff, int& 
 template<bool SLOW, bool STAR> __device__ void me_search(int sOff, const x265amd_me_job* __restrict__ jp, x265amd_me_result* out)
 {
     constexpr bool INL = !SLOW && !STAR;    /* the HEX/DIA window-resident variant inlines the helper bodies */
+    if constexpr (INL)
+    {
+        /* that variant carries neither the star search nor chroma SATD: such jobs are redone by k_me_deferred */
+        if (ME_S(sOff).chroma)
+        {
+            if (xa_lane() == 0) { out->mv[0] = 0; out->mv[1] = 0; out->cost = ME_DEFERRED; }
+            return;
+        }
+    }
     const MeState& s = ME_S(sOff);
     const int qminx = s.mnx * 4, qminy = s.mny * 4, qmaxx = s.mxx * 4, qmaxy = s.mxy * 4;
     const int merange = jp->merange, numCand = jp->num_cand, method = jp->method & 0x7f, subme = jp->subme;
@@ -1230,7 +1243,8 @@ extern "C" int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265am
     if (num_groups == 0) return X265AMD_OK;
     size_t lds = ((size_t)max_win_w * max_win_h + 16 + 64 * 64) * sizeof(pixel) + 16 + ME_WAVES * sizeof(MeState);
     if (lds > 160 * 1024) return xa_fail(X265AMD_EINVAL, "x265amd_me_search: window does not fit the 160 KiB LDS");
-    const bool star = (flags & X265AMD_ME_FLAG_STAR) != 0;
+    const bool star = (flags & (X265AMD_ME_FLAG_STAR | X265AMD_ME_FLAG_CHROMA)) != 0;   /* the variant with star search + chroma SATD */
+    if ((flags & X265AMD_ME_FLAG_CHROMA) && !d_chroma) return xa_fail(X265AMD_EINVAL, "x265amd_me_search: X265AMD_ME_FLAG_CHROMA without chroma planes");
     static thread_local size_t configured[2] = { 0, 0 };
     if (lds > configured[star])
     {
