@@ -14,6 +14,7 @@
 #   oracle/_ref/libx265_refD.so   full encoder library (x265_api_get_209 ...)
 #   oracle/_ref/x265_refD         CLI
 #   oracle/_ref/librefprimsD.so   tiny C-ABI driver (oracle/refprims.cpp) around the reference primitive table
+#   oracle/_ref/x265_dropinD      reference encoder + optional x265amd_setup_primitives() override (oracle/ref_encode_with_table.cpp)
 set -euo pipefail
 REF=${X265_REFERENCE:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -57,6 +58,8 @@ build_depth() {
     g++ -o "$OUT/x265_ref$D" $cliobjs $objs -lpthread -ldl
     # C-ABI driver around the reference primitive table (our file, includes reference headers at compile time)
     g++ $FLAGS -shared -o "$OUT/librefprims$D.so" "$HERE/refprims.cpp" $objs -lpthread -ldl
+    # the reference encoder as a program whose primitive table can be overridden through the drop-in hook (our file + reference objects)
+    g++ $FLAGS -o "$OUT/x265_dropin$D" "$HERE/ref_encode_with_table.cpp" $objs -lpthread -ldl
 }
 for D in 8 10; do build_depth $D; done
 echo "oracle/_ref built: $(ls "$OUT" | tr '\n' ' ')"

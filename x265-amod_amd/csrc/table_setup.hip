@@ -69,7 +69,11 @@ template<int I> struct Thunk
     static void transpose(pixel* d, const pixel* s, intptr_t st) { x265amd_transpose(I, d, s, st); }
     static void allangs(pixel* d, pixel* r, pixel* f, int l) { x265amd_intra_allangs(I, d, r, f, l); }
     static void intra_filter(const pixel* r, pixel* f) { x265amd_intra_filter(I, r, f); }
-    static void intra_pred(pixel* d, intptr_t ds, const pixel* s, int mode, int bf) { x265amd_intra_pred(I, mode, d, ds, s, bf); }
+    /* the reference's planar / DC functions ignore dirMode (intrapred.cpp:70,88) and its callers pass 0 for both
+     * (search.cpp:1358,1369): the SLOT decides the mode there; only the angular slots read the argument (intrapred.cpp:103) */
+    static void intra_planar(pixel* d, intptr_t ds, const pixel* s, int, int bf) { x265amd_intra_pred(I, 0, d, ds, s, bf); }
+    static void intra_dc(pixel* d, intptr_t ds, const pixel* s, int, int bf) { x265amd_intra_pred(I, 1, d, ds, s, bf); }
+    static void intra_ang(pixel* d, intptr_t ds, const pixel* s, int mode, int bf) { x265amd_intra_pred(I, mode, d, ds, s, bf); }
     /* chroma[420].cu[I] */
     static int c_sa8d(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return x265amd_chroma_sa8d(CSP420, I, a, sa, b, sb); }
 };
@@ -120,7 +124,8 @@ struct Installer
             set(slotCU(I, CU_cpy1Dto2D_shl), &T::cpy1Dto2D_shl); set(slotCU(I, CU_cpy1Dto2D_shl + 1), &T::cpy1Dto2D_shl);
             set(slotCU(I, CU_cpy1Dto2D_shr), &T::cpy1Dto2D_shr);
             set(slotCU(I, CU_intra_pred_allangs), &T::allangs); set(slotCU(I, CU_intra_filter), &T::intra_filter);
-            for (int m = 0; m < INTRA_MODES; m++) set(slotCU(I, CU_intra_pred + m), &T::intra_pred);
+            set(slotCU(I, CU_intra_pred + 0), &T::intra_planar); set(slotCU(I, CU_intra_pred + 1), &T::intra_dc);
+            for (int m = 2; m < INTRA_MODES; m++) set(slotCU(I, CU_intra_pred + m), &T::intra_ang);
         }
         set(slotCU(I, CU_sub_ps), &T::sub_ps); set(slotCU(I, CU_add_ps), &T::add_ps); set(slotCU(I, CU_add_ps + 1), &T::add_ps);
         set(slotCU(I, CU_var), &T::var); set(slotCU(I, CU_sse_pp), &T::sse_pp); set(slotCU(I, CU_sse_ss), &T::sse_ss);
