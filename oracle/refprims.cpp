@@ -228,6 +228,7 @@ const uint16_t* ref_tbl_scan(int scanType, int log2TrSize) { return g_scanOrder[
 struct QuantProbe : public Quant
 {
     void configure(int ttype, int qpScaled) { m_qpParam[ttype].setQpParam(qpScaled); m_rdoqLevel = 0; m_nr = NULL; }
+    void configureRdoq(int level, int psyRdoqScale) { m_rdoqLevel = level; m_psyRdoqScale = psyRdoqScale; }
 };
 
 struct TuEnv
@@ -239,7 +240,7 @@ struct TuEnv
     Slice slice;
     SPS sps;
     PPS pps;
-    uint8_t predMode[256], lumaDir[256], chromaDir[256], tqBypass[256];
+    uint8_t predMode[256], lumaDir[256], chromaDir[256], tqBypass[256], tuDepth[256];
     TuEnv()
     {
         sl.init();
@@ -254,6 +255,7 @@ struct TuEnv
         cu.m_chromaFormat = X265_CSP_I420; cu.m_hChromaShift = 1; cu.m_vChromaShift = 1;
         cu.m_predMode = predMode; cu.m_lumaIntraDir = lumaDir; cu.m_chromaIntraDir = chromaDir; cu.m_tqBypass = tqBypass;
         memset(tqBypass, 0, sizeof(tqBypass));
+        cu.m_tuDepth = tuDepth; memset(tuDepth, 0, sizeof(tuDepth));
     }
     void set(int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide)
     {
@@ -274,6 +276,62 @@ uint32_t ref_transform_tu(const pixel* fenc, intptr_t fencStride, const int16_t*
     TuEnv* e = tuEnv();
     e->set(ttype, bIntra, dirMode, sliceType, qpScaled, signHide);
     return e->quant.transformNxN(e->cu, fenc, (uint32_t)fencStride, resi, (uint32_t)resiStride, coeff, log2TrSize, (TextType)ttype, 0, false);
+}
+
+/* ---- entropy-side pieces of the residual path ---- */
+void ref_ctx_tables(uint32_t* bits128, uint8_t* next256)
+{
+    memcpy(bits128, g_entropyBits, 128 * sizeof(uint32_t));
+    memcpy(next256, g_nextState, 256);
+}
+/* Entropy::resetEntropy (entropy.cpp:1321-1355) */
+void ref_entropy_reset(int sliceType, int qp, uint8_t* ctx)
+{
+    TuEnv* e = tuEnv();
+    e->slice.m_sliceType = (SliceType)sliceType;
+    e->slice.m_sliceQp = qp;
+    e->entropy.resetEntropy(e->slice);
+    memcpy(ctx, e->entropy.m_contextState, MAX_OFF_CTX_MOD);
+}
+/* Entropy::estBit (entropy.cpp:2220-2390); est: 184 ints in EstBitsSbac member order, untouched entries stay as passed */
+void ref_est_bit(const uint8_t* ctx, int log2TrSize, int isLuma, int* est)
+{
+    TuEnv* e = tuEnv();
+    memcpy(e->entropy.m_contextState, ctx, MAX_OFF_CTX_MOD);
+    EstBitsSbac eb;
+    memcpy(&eb, est, sizeof(eb));
+    e->entropy.estBit(eb, log2TrSize, isLuma != 0);
+    memcpy(est, &eb, sizeof(eb));
+}
+int ref_est_bits_ints(void) { return (int)(sizeof(EstBitsSbac) / sizeof(int)); }
+/* Quant::transformNxN with RDOQ (quant.cpp:397-480 -> rdoQuant :609-1424); est as for ref_est_bit; psyRdoqScale = Quant::m_psyRdoqScale */
+uint32_t ref_transform_tu_rdoq(const pixel* fenc, intptr_t fencStride, const int16_t* resi, intptr_t resiStride, int16_t* coeff, int log2TrSize,
+                               int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide, int tuDepth, int rdoqLevel,
+                               int psyRdoqScale, const int* est)
+{
+    TuEnv* e = tuEnv();
+    e->set(ttype, bIntra, dirMode, sliceType, qpScaled, signHide);
+    e->quant.configureRdoq(rdoqLevel, psyRdoqScale);
+    memset(e->tuDepth, tuDepth, sizeof(e->tuDepth));
+    memcpy(&e->entropy.m_estBitsSbac, est, sizeof(EstBitsSbac));
+    uint32_t r = e->quant.transformNxN(e->cu, fenc, (uint32_t)fencStride, resi, (uint32_t)resiStride, coeff, log2TrSize, (TextType)ttype, 0, false);
+    e->quant.configureRdoq(0, 0);
+    memset(e->tuDepth, 0, sizeof(e->tuDepth));
+    return r;
+}
+/* Entropy::codeCoeffNxN in bit-counting mode (entropy.cpp:1828-2200): returns the FIX15 bits added, updates ctx */
+uint64_t ref_code_coeff_bits(const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int dirMode, int signHide, uint8_t* ctx)
+{
+    TuEnv* e = tuEnv();
+    e->set(ttype, bIntra, dirMode, 1, 30, signHide);
+    ALIGN_VAR_32(int16_t, c[32 * 32]);
+    memcpy(c, coeff, sizeof(int16_t) << (2 * log2TrSize));
+    memcpy(e->entropy.m_contextState, ctx, MAX_OFF_CTX_MOD);
+    e->entropy.zeroFract();
+    e->entropy.resetBits();
+    e->entropy.codeCoeffNxN(e->cu, c, 0, log2TrSize, (TextType)ttype);
+    memcpy(ctx, e->entropy.m_contextState, MAX_OFF_CTX_MOD);
+    return e->entropy.m_fracBits;
 }
 
 /* Quant::invtransformNxN (quant.cpp:543-605) */

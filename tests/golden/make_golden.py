@@ -41,6 +41,7 @@ def main():
     make_tu_golden()
     make_intra_golden()
     make_mc_golden()
+    make_entropy_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -132,6 +133,34 @@ def make_mc_golden():
             out["mc/%d/%d" % (depth, seed)] = np.frombuffer(T.mc_digest(res), np.uint8)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "mc_golden.npz"), **out)
     print("wrote mc_golden.npz with", len(out), "arrays")
+
+
+def make_entropy_golden():
+    """context initialisation, estBit tables, RDOQ levels and bits-only coefficient coding of the reference build
+    -> tests/golden/entropy_golden.npz"""
+    out = {}
+    for depth in (8, 10):
+        ref = T.load_ref(depth)
+        out["reset/%d" % depth] = np.stack([T.entropy_reset(ref, st, qp) for st in range(3) for qp in range(52)])
+        ests = []
+        for st in range(3):
+            for qp in (0, 17, 30, 43, 51):
+                ctx = T.entropy_reset(ref, st, qp)
+                for log2 in range(2, 6):
+                    for luma in (1, 0):
+                        if luma or log2 < 5:
+                            ests.append(T.est_bit(ref, ctx, log2, luma))
+        out["est/%d" % depth] = np.stack(ests)
+        for seed in range(3):
+            cases = T.rdoq_cases(depth, 700 + seed, 250, ctxlib=ref)
+            res = T.rdoq_run(ref, cases)
+            bits = T.coeff_bits_run(ref, cases, res)
+            out["rdoq/%d/%d/numsig" % (depth, seed)] = np.array([r[0] for r in res], np.int32)
+            out["rdoq/%d/%d/coeff" % (depth, seed)] = np.concatenate([r[1] for r in res])
+            out["rdoq/%d/%d/bits" % (depth, seed)] = np.array([b[0] for b in bits], np.uint64)
+            out["rdoq/%d/%d/ctx" % (depth, seed)] = np.stack([b[1] for b in bits])
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "entropy_golden.npz"), **out)
+    print("wrote entropy_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -1020,3 +1020,73 @@ def me_run_host_c(L, cur, ref, stride, cstride, origin, corg, jobs, bChroma=1):
                   len(j["mvc"]), _ptr(mvc), j["merange"], bChroma, _ptr(mv))
         out[i] = (mv[0], mv[1], cost)
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# entropy side of the residual path: contexts, estBit tables, RDOQ, bits-only coefficient coding
+# ----------------------------------------------------------------------------------------------------------
+CTX_COUNT = 157          # MAX_OFF_CTX_MOD (contexts.h:106)
+EST_INTS = 184           # sizeof(EstBitsSbac) / sizeof(int) (entropy.h:88-97)
+
+
+def entropy_reset(L, sliceType, qp):
+    ctx = np.zeros(160, np.uint8)
+    getattr(L.lib, L.prefix + "entropy_reset")(sliceType, qp, _ptr(ctx))
+    return ctx[:CTX_COUNT].copy()
+
+
+def est_bit(L, ctx, log2, isLuma):
+    est = np.zeros(EST_INTS, np.int32)
+    c = np.zeros(160, np.uint8); c[:CTX_COUNT] = ctx[:CTX_COUNT]
+    getattr(L.lib, L.prefix + "est_bit")(_ptr(c), log2, isLuma, _ptr(est))
+    return est
+
+
+def rdoq_cases(depth, seed, n, ctxlib=None):
+    """tu_cases + RDOQ parameters: tuDepth, rdoq level, psy-rdoq scale (Quant::m_psyRdoqScale = psyRdoq * 256) and a context
+    set: slice-start states of a random QP, part of the cases with states perturbed as after some coding"""
+    rng = np.random.default_rng(seed + 1000)
+    cases = tu_cases(depth, seed, n)
+    from_oracle = ctxlib or load_oracle(depth)
+    for c in cases:
+        if c["ttype"] and c["log2"] == 5:
+            c["log2"] = 4
+            c["fenc"] = np.ascontiguousarray(c["fenc"][:16, :16]); c["pred"] = np.ascontiguousarray(c["pred"][:16, :16])
+        c["tudepth"] = int(rng.integers(0, 3))
+        c["rdoq"] = int(rng.integers(1, 3))
+        c["psyrdoq"] = int(rng.choice([0, 0, 256, 1024, 2560]))
+        ctx = entropy_reset(from_oracle, c["slice"], int(rng.integers(10, 50)))
+        if rng.integers(0, 2):
+            k = rng.integers(0, CTX_COUNT, 40)
+            ctx[k] = rng.integers(0, 124, 40).astype(np.uint8)
+        c["ctx"] = ctx
+    return cases
+
+
+def rdoq_run(L, cases):
+    """<prefix>transform_tu_rdoq with the estBit tables of the case's contexts; returns list of (numSig, coeff)"""
+    out = []
+    f = getattr(L.lib, L.prefix + "transform_tu_rdoq"); f.restype = C.c_uint32
+    for c in cases:
+        N = 1 << c["log2"]
+        est = est_bit(L, c["ctx"], c["log2"], int(c["ttype"] == 0))
+        resi = (c["fenc"].astype(np.int32) - c["pred"].astype(np.int32)).astype(np.int16)
+        coeff = np.zeros(N * N, np.int16)
+        ns = f(_ptr(c["fenc"]), C.c_int64(N), _ptr(resi), C.c_int64(N), _ptr(coeff), c["log2"], c["ttype"], c["intra"], c["dir"], c["slice"], c["qp"],
+               c["signhide"], c["tudepth"], c["rdoq"], c["psyrdoq"], _ptr(est))
+        out.append((int(ns), coeff.copy()))
+    return out
+
+
+def coeff_bits_run(L, cases, levels):
+    """<prefix>code_coeff_bits on given level arrays; returns list of (bits FIX15, updated contexts)"""
+    out = []
+    f = getattr(L.lib, L.prefix + "code_coeff_bits"); f.restype = C.c_uint64
+    for c, (ns, coeff) in zip(cases, levels):
+        ctx = np.zeros(160, np.uint8); ctx[:CTX_COUNT] = c["ctx"]
+        if ns == 0:
+            out.append((0, ctx[:CTX_COUNT].copy()))
+            continue
+        bits = f(_ptr(coeff), c["log2"], c["ttype"], c["intra"], c["dir"], c["signhide"], _ptr(ctx))
+        out.append((int(bits), ctx[:CTX_COUNT].copy()))
+    return out
