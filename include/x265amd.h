@@ -272,6 +272,51 @@ typedef struct x265amd_tu_result
  * energies both ways -- everything estimateResidualQT needs for a TU except the entropy bits.  Asynchronous. */
 int x265amd_tu_chain(void* stream, const x265amd_tu_job* d_jobs, int n, x265amd_tu_result* d_out);
 
+/* --- RDOQ (Quant::rdoQuant, source/common/quant.cpp:609-1424; selected by param.rdoqLevel, the slow presets) and the
+ * entropy-side tables it reads.  Context states are the reference's: one byte per context, (pStateIdx << 1) | valMps,
+ * X265AMD_CTX_COUNT of them in the order of source/common/contexts.h:75-106, stored X265AMD_CTX_STRIDE apart. */
+#define X265AMD_CTX_COUNT 157
+#define X265AMD_CTX_STRIDE 160
+/* EstBitsSbac (source/encoder/entropy.h:88-97), same member order: significantCoeffGroupBits[2][2], significantBits[2][42],
+ * lastBits[2][10], greaterOneBits[24][2], levelAbsBits[6][2], blockCbpBits[7][2], blockRootCbpBits[2]; FIX15 bits */
+typedef struct x265amd_est_bits { int32_t v[184]; } x265amd_est_bits;
+/* second record of a TU job when RDOQ is on (parallel array to x265amd_tu_job) */
+typedef struct x265amd_tu_rdoq
+{
+    uint64_t est_bits;              /* device address of the x265amd_est_bits of the job's (size, plane) and context set */
+    int64_t lambda2;                /* QpParam::lambda2 / lambda, FIX8 (quant.h:50-60): x265amd_rdoq_lambda() */
+    int32_t lambda;
+    int32_t psy_rdoq_scale;         /* Quant::m_psyRdoqScale = (int)(param.psyRdoq * 256) */
+    uint8_t rdoq_level;             /* 0 (plain quantisation for this job), 1, 2 */
+    uint8_t tu_depth;               /* cu.m_tuDepth[absPartIdx]: selects the CBF context */
+    uint8_t reserved[6];
+} x265amd_tu_rdoq;
+/* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */
+int x265amd_tu_chain_rdoq(void* stream, const x265amd_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);
+void x265amd_rdoq_lambda(int qpScaled, int64_t* lambda2, int32_t* lambda);
+
+/* Entropy::resetEntropy (source/encoder/entropy.cpp:1321-1355): context states at slice start (host arithmetic); ctx: X265AMD_CTX_STRIDE bytes */
+void x265amd_entropy_reset(int sliceType, int qp, uint8_t* ctx);
+/* Entropy::estBit (entropy.cpp:2220-2390), batched: job i reads the context set at `ctx` and fills the entries of `est`
+ * that the reference fills for (log2_tr_size, is_luma); other entries are left as they are. */
+typedef struct x265amd_est_job { uint64_t ctx, est; uint8_t log2_tr_size, is_luma, reserved[6]; } x265amd_est_job;
+int x265amd_est_bit(void* stream, const x265amd_est_job* d_jobs, int n);
+/* Entropy::codeCoeffNxN in bit-counting mode (entropy.cpp:1828-2200, with costCoeffNxN / costC1C2Flag / costCoeffRemain,
+ * source/common/dct.cpp:838-993): FIX15 bits of the levels of one TU under the context set at ctx_in; the adapted context
+ * set is written to ctx_out (may equal ctx_in).  d_bits[i] receives what the call adds to Entropy::m_fracBits. */
+typedef struct x265amd_coeff_bits_job
+{
+    uint64_t coeff, ctx_in, ctx_out;
+    uint8_t log2_tr_size, ttype, intra, dir_mode, sign_hide, reserved[3];
+} x265amd_coeff_bits_job;
+int x265amd_coeff_bits(void* stream, const x265amd_coeff_bits_job* d_jobs, int n, uint64_t* d_bits);
+/* host-pointer forms (parity surface) */
+void x265amd_est_bit_host(const uint8_t* ctx, int log2TrSize, int isLuma, int32_t* est);
+uint64_t x265amd_code_coeff_bits(const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int dirMode, int signHide, uint8_t* ctx);
+uint32_t x265amd_transform_tu_rdoq(const x265amd_pixel* fenc, intptr_t fencStride, const int16_t* resi, intptr_t resiStride, int16_t* coeff,
+                                   int log2TrSize, int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide,
+                                   int tuDepth, int rdoqLevel, int psyRdoqScale, const int32_t* est);
+
 /* host-pointer forms of the two Quant entry points (parity surface, same staging as layer 1) */
 uint32_t x265amd_transform_tu(const x265amd_pixel* fenc, intptr_t fencStride, const int16_t* resi, intptr_t resiStride, int16_t* coeff,
                               int log2TrSize, int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide);

@@ -893,3 +893,37 @@ uint32_t orc_transform_tu_rdoq(const pixel* fenc, intptr_t fencStride, const int
     return orc_rdo_quant(dct, fdct, coeff, log2TrSize, ttype, bIntra, dirMode, qpScaled, tuDepth, signHide, rdoqLevel, psyRdoqScale, usePsy,
                          (const OrcEstBits*)est);
 }
+
+/* The per-TU measurement of the residual quad-tree (search.cpp:3276-3330) with RDOQ as the quantiser: as orc_tu_chain
+ * (hevc_oracle_tu.c) but transformNxN runs rdoQuant. */
+void orc_sub_ps(int cu, int16_t* dst, intptr_t ds, const pixel* s0, const pixel* s1, intptr_t ss0, intptr_t ss1);
+void orc_add_ps(int cu, pixel* dst, intptr_t ds, const pixel* b0, const int16_t* b1, intptr_t ss0, intptr_t ss1);
+uint64_t orc_sse_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int orc_psy_cost_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+void orc_invtransform_tu(int16_t* resi, intptr_t resiStride, const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int qpScaled, uint32_t numSig);
+void orc_tu_chain_rdoq(const pixel* fenc, intptr_t fencStride, const pixel* pred, intptr_t predStride, int log2TrSize, int ttype, int bIntra, int dirMode,
+                       int sliceType, int qpScaled, int signHide, int tuDepth, int rdoqLevel, int psyRdoqScale, const int* est,
+                       int16_t* coeff, int16_t* resiOut, intptr_t resiStride, pixel* recon, intptr_t reconStride, uint64_t* out)
+{
+    int sizeIdx = log2TrSize - 2, N = 1 << log2TrSize;
+    int16_t resi[32 * 32];
+    orc_sub_ps(sizeIdx, resi, N, fenc, pred, fencStride, predStride);
+    uint32_t numSig = orc_transform_tu_rdoq(fenc, fencStride, resi, N, coeff, log2TrSize, ttype, bIntra, dirMode, sliceType, qpScaled, signHide,
+                                            tuDepth, rdoqLevel, psyRdoqScale, est);
+    out[0] = numSig;
+    out[1] = orc_sse_pp(sizeIdx, fenc, fencStride, pred, predStride);
+    out[2] = (uint64_t)(int64_t)orc_psy_cost_pp(sizeIdx, fenc, fencStride, pred, predStride);
+    if (numSig)
+    {
+        orc_invtransform_tu(resiOut, resiStride, coeff, log2TrSize, ttype, bIntra, qpScaled, numSig);
+        orc_add_ps(sizeIdx, recon, reconStride, pred, resiOut, predStride, resiStride);
+        out[3] = orc_sse_pp(sizeIdx, fenc, fencStride, recon, reconStride);
+        out[4] = (uint64_t)(int64_t)orc_psy_cost_pp(sizeIdx, fenc, fencStride, recon, reconStride);
+    }
+    else
+    {
+        for (int y = 0; y < N; y++)
+            for (int x = 0; x < N; x++) { resiOut[y * resiStride + x] = 0; recon[y * reconStride + x] = pred[y * predStride + x]; }
+        out[3] = out[1]; out[4] = out[2];
+    }
+}

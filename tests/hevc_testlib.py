@@ -1038,7 +1038,8 @@ def entropy_reset(L, sliceType, qp):
 def est_bit(L, ctx, log2, isLuma):
     est = np.zeros(EST_INTS, np.int32)
     c = np.zeros(160, np.uint8); c[:CTX_COUNT] = ctx[:CTX_COUNT]
-    getattr(L.lib, L.prefix + "est_bit")(_ptr(c), log2, isLuma, _ptr(est))
+    # the product's x265amd_est_bit is the batched device entry; its host-pointer form carries the _host suffix
+    getattr(L.lib, L.prefix + ("est_bit_host" if L.prefix == "x265amd_" else "est_bit"))(_ptr(c), log2, isLuma, _ptr(est))
     return est
 
 
@@ -1089,4 +1090,27 @@ def coeff_bits_run(L, cases, levels):
             continue
         bits = f(_ptr(coeff), c["log2"], c["ttype"], c["intra"], c["dir"], c["signhide"], _ptr(ctx))
         out.append((int(bits), ctx[:CTX_COUNT].copy()))
+    return out
+
+
+TU_RDOQ_DT = np.dtype([("est_bits", "<u8"), ("lambda2", "<i8"), ("lambda_", "<i4"), ("psy_rdoq_scale", "<i4"), ("rdoq_level", "u1"), ("tu_depth", "u1"),
+                       ("reserved", "u1", 6)])
+EST_JOB_DT = np.dtype([("ctx", "<u8"), ("est", "<u8"), ("log2", "u1"), ("is_luma", "u1"), ("reserved", "u1", 6)])
+COEFF_BITS_JOB_DT = np.dtype([("coeff", "<u8"), ("ctx_in", "<u8"), ("ctx_out", "<u8"), ("log2", "u1"), ("ttype", "u1"), ("intra", "u1"), ("dir", "u1"),
+                              ("signhide", "u1"), ("reserved", "u1", 3)])
+assert TU_RDOQ_DT.itemsize == 32 and EST_JOB_DT.itemsize == 24 and COEFF_BITS_JOB_DT.itemsize == 32
+
+
+def rdoq_chain_oracle(L, cases):
+    """orc_tu_chain_rdoq: list of (stats[5], coeff, resi, recon)"""
+    out = []
+    for c in cases:
+        N = 1 << c["log2"]
+        est = est_bit(L, c["ctx"], c["log2"], int(c["ttype"] == 0))
+        coeff = np.zeros(N * N, np.int16); resi = np.zeros((N, N), np.int16); recon = np.zeros((N, N), c["fenc"].dtype)
+        st = np.zeros(5, np.uint64)
+        L.lib.orc_tu_chain_rdoq(_ptr(c["fenc"]), C.c_int64(N), _ptr(c["pred"]), C.c_int64(N), c["log2"], c["ttype"], c["intra"], c["dir"], c["slice"],
+                                c["qp"], c["signhide"], c["tudepth"], c["rdoq"], c["psyrdoq"], _ptr(est),
+                                _ptr(coeff), _ptr(resi), C.c_int64(N), _ptr(recon), C.c_int64(N), _ptr(st))
+        out.append((st.copy(), coeff, resi, recon))
     return out
