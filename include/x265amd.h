@@ -357,15 +357,32 @@ typedef struct x265amd_mc_job
     int8_t ref0, ref1;                  /* picture index into the plane table per list, -1: list unused */
     int16_t mv0[2], mv1[2];             /* quarter-pel MVs (clipped by the kernel exactly like cu.clipMv) */
     uint8_t slice_type;                 /* 1 = P slice, 0 = B slice */
-    uint8_t flags;                      /* 1 luma, 2 chroma, 4 pps.bUseWeightPred, 8 pps.bUseWeightedBiPred */
+    uint8_t flags;                      /* 1 luma, 2 chroma, 4 pps.bUseWeightPred, 8 pps.bUseWeightedBiPred, 16 pixel average (see x265amd_inter_cost) */
     struct { int16_t w, o; uint8_t denom, present; } wp[2][3];    /* WeightParam inputWeight/inputOffset/log2WeightDenom/wtPresent */
-    uint8_t reserved[6];
+    uint8_t metric;                     /* x265amd_inter_cost only: 1 SAD, 2 SATD, 3 SA8D (0: none) */
+    uint8_t chroma_cost;                /* x265amd_inter_cost only: also measure U and V (SATD / SA8D) */
+    uint8_t reserved[4];
 } x265amd_mc_job;
 
 /* d_planes: num_pics x 3 device addresses of sample (0,0) of the padded Y, U, V planes; all pictures share
  * `stride` / `cstride`.  pic_w / pic_h: luma picture size (clipMv).  Asynchronous. */
 int x265amd_motion_compensation(void* stream, const uint64_t* d_planes, intptr_t stride, intptr_t cstride, int pic_w, int pic_h,
                                 const x265amd_mc_job* d_jobs, int n);
+
+/* Distortion of inter prediction candidates: the job's prediction is produced exactly as by x265amd_motion_compensation
+ * (and written to its dst_* blocks), then measured against the source picture at the PU's position with the metric the
+ * reference's decision uses at that point:
+ *   metric 1, SAD : Search::selectMVP (source/encoder/search.cpp:1992-2018: bufSAD of the candidate's luma prediction);
+ *   metric 2, SATD: Search::mergeEstimation (search.cpp:1891-1966) and the bi-prediction tries of predInterSearch
+ *                   (search.cpp:2473-2576): bufSATD, plus bufChromaSATD when chroma_cost is set (PU chroma 4:2:0 a multiple of 4x4);
+ *   metric 3, SA8D: the merge scan of Analysis::checkMerge2Nx2N_rd0_4 (source/encoder/analysis.cpp:2750-2880): cu[].sa8d of a
+ *                   square PU, plus the chroma sa8d when chroma_cost is set (CU >= 16).
+ * flags & 16: the prediction is pixelavg_pp of the two lists' pixel-path luma predictions (the bi-prediction try without
+ * chroma SATD, search.cpp:2499-2511; luma only) instead of motionCompensation's addAvg.
+ * d_fenc_planes: 3 device addresses of sample (0,0) of the source Y, U, V planes.  d_cost[2*i] = luma, d_cost[2*i+1] = U + V. */
+int x265amd_inter_cost(void* stream, const uint64_t* d_planes, intptr_t stride, intptr_t cstride, int pic_w, int pic_h,
+                       const x265amd_mc_job* d_jobs, int n, const uint64_t* d_fenc_planes, intptr_t fenc_stride, intptr_t fenc_cstride,
+                       uint32_t* d_cost);
 
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */

@@ -237,3 +237,78 @@ int orc_motion_compensation_batch(const uint64_t* planes, intptr_t stride, intpt
     }
     return n;
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * distortion of inter prediction candidates: motion compensation of the candidate followed by the metric the
+ * reference's decision uses at that point --
+ *   SAD   (metric 1): Search::selectMVP, search.cpp:1992-2018 (m_me.bufSAD of predInterLumaPixel);
+ *   SATD  (metric 2): Search::mergeEstimation search.cpp:1891-1966 and the bi-prediction tries of predInterSearch
+ *                     search.cpp:2473-2576 (m_me.bufSATD [+ bufChromaSATD]);
+ *   SA8D  (metric 3): the merge scan of Analysis::checkMerge2Nx2N_rd0_4, analysis.cpp:2750-2880 (cu[].sa8d [+ chroma sa8d]).
+ * flags & 16: the prediction is the pixel average of the two pixel-path predictions (pixelavg_pp of two
+ * predInterLumaPixel results, search.cpp:2499-2511) instead of motionCompensation's addAvg.
+ * reserved[0] = metric, reserved[1] = 1 to add the chroma metric.  out[i] = { luma, chroma (U + V) }.
+ * ------------------------------------------------------------------------------------------------------- */
+int orc_sad(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int orc_satd(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int orc_sa8d(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int orc_chroma_satd(int csp, int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+int orc_chroma_sa8d(int csp, int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb);
+void orc_pixelavg_pp(int part, pixel* dst, intptr_t ds, const pixel* s0, intptr_t ss0, const pixel* s1, intptr_t ss1);
+void orc_chroma_pixelavg_pp(int csp, int part, pixel* dst, intptr_t ds, const pixel* s0, intptr_t ss0, const pixel* s1, intptr_t ss1);
+
+int orc_inter_cost_batch(const uint64_t* planes, intptr_t stride, intptr_t cstride, int picW, int picH, const PackedMcJob* jobs, int n,
+                         const uint64_t* fencPlanes, intptr_t fstride, intptr_t fcstride, uint32_t* out)
+{
+    static pixel tmp[2][3][64 * 64];
+    for (int i = 0; i < n; i++)
+    {
+        const PackedMcJob* j = &jobs[i];
+        /* the pixel-average form exists for luma only (with chroma SATD on, the reference runs motionCompensation instead) */
+        const int part = orc_partition_from_sizes(j->w, j->h), luma = j->flags & 1, chroma = ((j->flags >> 1) & 1) && !(j->flags & 16);
+        pixel* dY = (pixel*)j->dstY; pixel* dU = (pixel*)j->dstU; pixel* dV = (pixel*)j->dstV;
+        if (j->flags & 16)
+        {
+            const int refs[2] = { j->ref0, j->ref1 };
+            for (int l = 0; l < 2; l++)
+            {
+                const pixel* pl[3];
+                int mvx = l ? j->mv1[0] : j->mv0[0], mvy = l ? j->mv1[1] : j->mv0[1];
+                pl[0] = (const pixel*)planes[3 * refs[l]] + (intptr_t)j->y * stride + j->x;
+                pl[1] = (const pixel*)planes[3 * refs[l] + 1] + (intptr_t)(j->y >> 1) * cstride + (j->x >> 1);
+                pl[2] = (const pixel*)planes[3 * refs[l] + 2] + (intptr_t)(j->y >> 1) * cstride + (j->x >> 1);
+                clip_mv(&mvx, &mvy, j->cuX, j->cuY, picW, picH);
+                pred_pixel(part, j->w, pl, stride, cstride, mvx, mvy, tmp[l][0], tmp[l][1], tmp[l][2], 64, 32, luma, chroma);
+            }
+            if (luma)
+                for (int y = 0; y < j->h; y++)
+                    for (int x = 0; x < j->w; x++) dY[y * j->dstStride + x] = (pixel)((tmp[0][0][y * 64 + x] + tmp[1][0][y * 64 + x] + 1) >> 1);    /* pixelavg_pp, pixel.cpp:880-893 */
+            if (chroma)
+                for (int y = 0; y < j->h / 2; y++)
+                    for (int x = 0; x < j->w / 2; x++)
+                    {
+                        dU[y * j->dstCStride + x] = (pixel)((tmp[0][1][y * 32 + x] + tmp[1][1][y * 32 + x] + 1) >> 1);
+                        dV[y * j->dstCStride + x] = (pixel)((tmp[0][2][y * 32 + x] + tmp[1][2][y * 32 + x] + 1) >> 1);
+                    }
+        }
+        else
+            orc_motion_compensation_batch(planes, stride, cstride, picW, picH, j, 1);
+        const pixel* fY = (const pixel*)fencPlanes[0] + (intptr_t)j->y * fstride + j->x;
+        const pixel* fU = (const pixel*)fencPlanes[1] + (intptr_t)(j->y >> 1) * fcstride + (j->x >> 1);
+        const pixel* fV = (const pixel*)fencPlanes[2] + (intptr_t)(j->y >> 1) * fcstride + (j->x >> 1);
+        const int metric = j->reserved[0], addChroma = j->reserved[1];
+        int cu = 0;
+        while ((4 << cu) < j->w) cu++;
+        uint32_t l = 0, c = 0;
+        if (luma)
+            l = metric == 1 ? (uint32_t)orc_sad(part, fY, fstride, dY, j->dstStride) : metric == 2 ? (uint32_t)orc_satd(part, fY, fstride, dY, j->dstStride)
+              : metric == 3 ? (uint32_t)orc_sa8d(cu, fY, fstride, dY, j->dstStride) : 0;
+        if (chroma && addChroma)
+        {
+            if (metric == 2) c = (uint32_t)(orc_chroma_satd(CSP420, part, fU, fcstride, dU, j->dstCStride) + orc_chroma_satd(CSP420, part, fV, fcstride, dV, j->dstCStride));
+            else if (metric == 3) c = (uint32_t)(orc_chroma_sa8d(CSP420, cu, fU, fcstride, dU, j->dstCStride) + orc_chroma_sa8d(CSP420, cu, fV, fcstride, dV, j->dstCStride));
+        }
+        out[2 * i] = l; out[2 * i + 1] = c;
+    }
+    return n;
+}

@@ -507,6 +507,66 @@ int ref_motion_compensation_batch(const uint64_t* planes, intptr_t stride, intpt
     return n;
 }
 
+/* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,
+ * flags & 16, two Predict::predInterLumaPixel + pixelavg_pp as search.cpp:2499-2511) and then pu[].sad / pu[].satd /
+ * cu[].sa8d (+ the 4:2:0 chroma satd / sa8d) against the source picture.  reserved[0] metric 1 SAD 2 SATD 3 SA8D,
+ * reserved[1] add chroma.  out[i] = { luma, chroma } */
+int ref_inter_cost_batch(const uint64_t* planes, intptr_t stride, intptr_t cstride, int picW, int picH, const PackedMcJob* jobs, int n,
+                         const uint64_t* fencPlanes, intptr_t fstride, intptr_t fcstride, uint32_t* out)
+{
+    static McEnv* m = NULL;
+    static Yuv* tmpYuv = NULL;
+    TuEnv* e = tuEnv();
+    if (!m) { m = new McEnv; tmpYuv = new Yuv[2]; tmpYuv[0].create(64, X265_CSP_I420); tmpYuv[1].create(64, X265_CSP_I420); }
+    for (int i = 0; i < n; i++)
+    {
+        const PackedMcJob& j = jobs[i];
+        const int part = partitionFromSizes(j.w, j.h);
+        const bool luma = !!(j.flags & 1), chroma = (j.flags & 2) && !(j.flags & 16);
+        if (j.flags & 16)
+        {
+            e->sps.picWidthInLumaSamples = picW; e->sps.picHeightInLumaSamples = picH;
+            e->cu.m_encData = &m->fd;
+            e->cu.m_cuPelX = j.cuX; e->cu.m_cuPelY = j.cuY;
+            char pubuf[sizeof(PredictionUnit)];
+            PredictionUnit* pu = (PredictionUnit*)pubuf;
+            pu->ctuAddr = 0; pu->cuAbsPartIdx = 0; pu->puAbsPartIdx = 0; pu->width = j.w; pu->height = j.h;
+            const int8_t refs[2] = { j.ref0, j.ref1 };
+            for (int l = 0; l < 2; l++)
+            {
+                m->pic[l]->m_picOrg[0] = (pixel*)planes[3 * refs[l] + 0] + (intptr_t)j.y * stride + j.x;
+                m->pic[l]->m_stride = stride; m->pic[l]->m_strideC = cstride;
+                MV mv = l ? MV(j.mv1[0], j.mv1[1]) : MV(j.mv0[0], j.mv0[1]);
+                e->cu.clipMv(mv);
+                m->pred.predInterLumaPixel(*pu, tmpYuv[l], *m->pic[l], mv);
+            }
+            if (luma)
+                g_p.pu[part].pixelavg_pp[NONALIGNED]((pixel*)j.dstY, j.dstStride, tmpYuv[0].m_buf[0], tmpYuv[0].m_size, tmpYuv[1].m_buf[0], tmpYuv[1].m_size, 32);
+        }
+        else
+            ref_motion_compensation_batch(planes, stride, cstride, picW, picH, &j, 1);
+        const pixel* fY = (const pixel*)fencPlanes[0] + (intptr_t)j.y * fstride + j.x;
+        const pixel* fU = (const pixel*)fencPlanes[1] + (intptr_t)(j.y >> 1) * fcstride + (j.x >> 1);
+        const pixel* fV = (const pixel*)fencPlanes[2] + (intptr_t)(j.y >> 1) * fcstride + (j.x >> 1);
+        const int metric = j.reserved[0], addChroma = j.reserved[1];
+        int cu = 0;
+        while ((4 << cu) < j.w) cu++;
+        uint32_t l = 0, c = 0;
+        if (luma)
+            l = metric == 1 ? g_p.pu[part].sad(fY, fstride, (pixel*)j.dstY, j.dstStride) : metric == 2 ? g_p.pu[part].satd(fY, fstride, (pixel*)j.dstY, j.dstStride)
+              : metric == 3 ? g_p.cu[cu].sa8d(fY, fstride, (pixel*)j.dstY, j.dstStride) : 0;
+        if (chroma && addChroma)
+        {
+            if (metric == 2)
+                c = g_p.chroma[X265_CSP_I420].pu[part].satd(fU, fcstride, (pixel*)j.dstU, j.dstCStride) + g_p.chroma[X265_CSP_I420].pu[part].satd(fV, fcstride, (pixel*)j.dstV, j.dstCStride);
+            else if (metric == 3)
+                c = g_p.chroma[X265_CSP_I420].cu[cu].sa8d(fU, fcstride, (pixel*)j.dstU, j.dstCStride) + g_p.chroma[X265_CSP_I420].cu[cu].sa8d(fV, fcstride, (pixel*)j.dstV, j.dstCStride);
+        }
+        out[2 * i] = l; out[2 * i + 1] = c;
+    }
+    return n;
+}
+
 /* ---- batch forms for bench.py's cpu_baseline leg (records of include/x265amd.h; addresses are HOST addresses here) ---- */
 struct PackedTuJob { uint64_t fenc, pred, coeff, resi, recon; int32_t fencStride, predStride, resiStride, reconStride;
                      uint8_t log2, ttype, intra, dir, slice, qp, signhide, reserved; };

@@ -42,6 +42,7 @@ def main():
     make_intra_golden()
     make_mc_golden()
     make_entropy_golden()
+    make_inter_cost_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -161,6 +162,19 @@ def make_entropy_golden():
             out["rdoq/%d/%d/ctx" % (depth, seed)] = np.stack([b[1] for b in bits])
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "entropy_golden.npz"), **out)
     print("wrote entropy_golden.npz with", len(out), "arrays")
+
+
+def make_inter_cost_golden():
+    """costs of inter prediction candidates from the reference's Predict + primitives -> tests/golden/inter_cost_golden.npz"""
+    out = {}
+    for depth in (8, 10):
+        ref = T.load_ref(depth)
+        for seed in range(2):
+            pics, stride, cstride, org = T.mc_make_refs(depth, 1300 + seed, nref=4)
+            cost, _ = T.inter_cost_run_host(ref, pics[:3], pics[3], stride, cstride, org, T.inter_cost_jobs(40 + seed, 500))
+            out["cost/%d/%d" % (depth, seed)] = cost
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "inter_cost_golden.npz"), **out)
+    print("wrote inter_cost_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

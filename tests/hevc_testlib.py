@@ -876,7 +876,7 @@ def intra_run_hip(L, cases):
 MC_WP_DT = np.dtype([("w", "<i2"), ("o", "<i2"), ("denom", "u1"), ("present", "u1")])
 MC_JOB_DT = np.dtype([("dstY", "<u8"), ("dstU", "<u8"), ("dstV", "<u8"), ("dstStride", "<i4"), ("dstCStride", "<i4"),
                       ("x", "<i2"), ("y", "<i2"), ("cuX", "<i2"), ("cuY", "<i2"), ("w", "u1"), ("h", "u1"), ("ref0", "i1"), ("ref1", "i1"),
-                      ("mv0", "<i2", 2), ("mv1", "<i2", 2), ("sliceType", "u1"), ("flags", "u1"), ("wp", MC_WP_DT, (2, 3)), ("reserved", "u1", 6)])
+                      ("mv0", "<i2", 2), ("mv1", "<i2", 2), ("sliceType", "u1"), ("flags", "u1"), ("wp", MC_WP_DT, (2, 3)), ("metric", "u1"), ("chroma_cost", "u1"), ("reserved", "u1", 4)])
 assert MC_JOB_DT.itemsize == 96
 MC_W, MC_H, MC_MX, MC_MY = 256, 192, 96, 80
 
@@ -1114,3 +1114,89 @@ def rdoq_chain_oracle(L, cases):
                                 _ptr(coeff), _ptr(resi), C.c_int64(N), _ptr(recon), C.c_int64(N), _ptr(st))
         out.append((st.copy(), coeff, resi, recon))
     return out
+
+
+# ---- distortion of inter prediction candidates (x265amd_inter_cost): MC jobs + a metric ----
+def inter_cost_jobs(seed, n):
+    """mc_jobs with the decision metrics of the reference: SAD (selectMVP), SATD (+chroma: mergeEstimation / bi-prediction
+    tries), SA8D on square PUs (+chroma: merge scan), and the pixel-average form of the bi-prediction try"""
+    rng = np.random.default_rng(seed ^ 0xBEEF)
+    j = mc_jobs(seed, n)
+    for i in range(n):
+        w, h = int(j[i]["w"]), int(j[i]["h"])
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                       # selectMVP: luma pixel path of one list, SAD
+            j[i]["metric"], j[i]["chroma_cost"] = 1, 0
+            j[i]["flags"] = 1
+            j[i]["sliceType"] = 1
+            if j[i]["ref0"] < 0:
+                j[i]["ref0"], j[i]["ref1"] = 0, -1
+        elif kind == 1:                     # merge estimation / bidir with chroma SATD
+            j[i]["metric"] = 2
+            ok = (w // 2) % 4 == 0 and (h // 2) % 4 == 0
+            j[i]["chroma_cost"] = 1 if ok and rng.integers(0, 2) else 0
+            j[i]["flags"] = (int(j[i]["flags"]) & ~3) | (3 if j[i]["chroma_cost"] else 1)
+        elif kind == 2:                     # merge scan: square PU = CU, SA8D (+ chroma for CU >= 16)
+            s = int(rng.choice([8, 16, 32, 64]))
+            cux = int(rng.integers(0, MC_W // s)) * s; cuy = int(rng.integers(0, MC_H // s)) * s
+            j[i]["x"], j[i]["y"], j[i]["cuX"], j[i]["cuY"], j[i]["w"], j[i]["h"] = cux, cuy, cux, cuy, s, s
+            j[i]["metric"] = 3
+            j[i]["chroma_cost"] = 1 if s >= 16 and rng.integers(0, 2) else 0
+            j[i]["flags"] = (int(j[i]["flags"]) & ~3) | (3 if j[i]["chroma_cost"] else 1)
+        else:                               # bi-prediction try without chroma SATD: pixel average, SATD
+            j[i]["metric"], j[i]["chroma_cost"] = 2, 0
+            j[i]["sliceType"] = 0
+            j[i]["ref0"], j[i]["ref1"] = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            j[i]["flags"] = 1 | 16
+            if rng.integers(0, 3) == 0:
+                j[i]["mv0"] = (0, 0); j[i]["mv1"] = (0, 0)
+    return j
+
+
+def inter_cost_run_host(L, pics, fenc, stride, cstride, org, jobs):
+    """<prefix>inter_cost_batch with host addresses: (n x 2 costs, predictions as mc_run_host)"""
+    n = len(jobs)
+    dt = pics[0].dtype
+    isz = dt.itemsize
+    planes = np.array([p.ctypes.data + org[c] * isz for p in pics for c in range(3)], np.uint64)
+    fplanes = np.array([fenc.ctypes.data + org[c] * isz for c in range(3)], np.uint64)
+    outY = np.zeros((n, 64, 64), dt); outU = np.zeros((n, 32, 32), dt); outV = np.zeros((n, 32, 32), dt)
+    jb = jobs.copy()
+    jb["dstY"] = outY.ctypes.data + np.arange(n) * 64 * 64 * isz
+    jb["dstU"] = outU.ctypes.data + np.arange(n) * 32 * 32 * isz
+    jb["dstV"] = outV.ctypes.data + np.arange(n) * 32 * 32 * isz
+    jb["dstStride"], jb["dstCStride"] = 64, 32
+    cost = np.zeros((n, 2), np.uint32)
+    getattr(L.lib, L.prefix + "inter_cost_batch")(_ptr(planes), C.c_int64(stride), C.c_int64(cstride), MC_W, MC_H, _ptr(jb), n,
+                                                  _ptr(fplanes), C.c_int64(stride), C.c_int64(cstride), _ptr(cost))
+    return cost, [outY[i, :int(jobs[i]["h"]), :int(jobs[i]["w"])].copy() for i in range(n)]
+
+
+def inter_cost_run_hip(L, pics, fenc, stride, cstride, org, jobs):
+    import torch
+    n = len(jobs)
+    dt = pics[0].dtype
+    isz = dt.itemsize
+    d_pics = [torch.from_numpy(p.view(np.uint8)).cuda() for p in pics]
+    d_fenc = torch.from_numpy(fenc.view(np.uint8)).cuda()
+    planes = np.array([d.data_ptr() + org[c] * isz for d in d_pics for c in range(3)], np.uint64)
+    fplanes = np.array([d_fenc.data_ptr() + org[c] * isz for c in range(3)], np.uint64)
+    d_planes = torch.from_numpy(planes.view(np.uint8).copy()).cuda()
+    d_fplanes = torch.from_numpy(fplanes.view(np.uint8).copy()).cuda()
+    d_y = torch.zeros(n * 64 * 64 * isz, dtype=torch.uint8, device="cuda")
+    d_u = torch.zeros(n * 32 * 32 * isz, dtype=torch.uint8, device="cuda")
+    d_v = torch.zeros(n * 32 * 32 * isz, dtype=torch.uint8, device="cuda")
+    jb = jobs.copy()
+    jb["dstY"] = d_y.data_ptr() + np.arange(n) * 64 * 64 * isz
+    jb["dstU"] = d_u.data_ptr() + np.arange(n) * 32 * 32 * isz
+    jb["dstV"] = d_v.data_ptr() + np.arange(n) * 32 * 32 * isz
+    jb["dstStride"], jb["dstCStride"] = 64, 32
+    d_jobs = torch.from_numpy(jb.view(np.uint8).copy()).cuda()
+    d_cost = torch.zeros(n * 2, dtype=torch.int32, device="cuda")
+    rc = L.lib.x265amd_inter_cost(None, C.c_void_p(d_planes.data_ptr()), C.c_int64(stride), C.c_int64(cstride), MC_W, MC_H,
+                                  C.c_void_p(d_jobs.data_ptr()), n, C.c_void_p(d_fplanes.data_ptr()), C.c_int64(stride), C.c_int64(cstride),
+                                  C.c_void_p(d_cost.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    outY = d_y.cpu().numpy().view(dt).reshape(n, 64, 64)
+    return d_cost.cpu().numpy().view(np.uint32).reshape(n, 2), [outY[i, :int(jobs[i]["h"]), :int(jobs[i]["w"])].copy() for i in range(n)]

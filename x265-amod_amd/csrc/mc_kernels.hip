@@ -15,7 +15,8 @@ struct McPlane { const pixel* src[2]; long stride; int xf[2], yf[2]; int w, h; p
 
 template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& j, int mode, int lsel, int lane)
 {
-    /* mode 0: pixel path from list lsel; 1: weighted uni from list lsel; 2: bi average; 3: weighted bi */
+    /* mode 0: pixel path from list lsel; 1: weighted uni from list lsel; 2: bi average; 3: weighted bi;
+     * 4: pixel average of the two pixel-path predictions (pixelavg_pp of two predInterLumaPixel, search.cpp:2499-2511) */
     const int c = p.c;
     const int shiftNum = XA_IF_INTERNAL_PREC - XA_DEPTH;
     int inv = ((1 << 20) + p.w - 1) / p.w;
@@ -25,6 +26,12 @@ template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& 
         int v;
         if (mode == 0)
             v = mc_sample<TAPS, false>(p.src[lsel] + (long)y * p.stride + x, p.stride, p.xf[lsel], p.yf[lsel]);
+        else if (mode == 4)
+        {
+            int a = mc_sample<TAPS, false>(p.src[0] + (long)y * p.stride + x, p.stride, p.xf[0], p.yf[0]);
+            int b = mc_sample<TAPS, false>(p.src[1] + (long)y * p.stride + x, p.stride, p.xf[1], p.yf[1]);
+            v = (a + b + 1) >> 1;       /* pixelavg_pp (pixel.cpp:880-893) */
+        }
         else if (mode == 1)
         {
             /* addWeightUni -> weight_sp_c (predict.cpp:520-577, pixel.cpp:493-517) */
@@ -53,8 +60,11 @@ template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& 
     }
 }
 
+/* COST: after the prediction has been written, its distortion against the source picture (x265amd_inter_cost) */
+template<bool COST>
 __global__ __launch_bounds__(64 * MC_WAVES) void k_motion_compensation(const uint64_t* planes, long stride, long cstride, int picW, int picH,
-                                                                       const x265amd_mc_job* jobs, int n)
+                                                                       const x265amd_mc_job* jobs, int n,
+                                                                       const uint64_t* fencPlanes, long fstride, long fcstride, uint32_t* cost)
 {
     const int lane = xa_lane();
     const int ji = blockIdx.x * MC_WAVES + (threadIdx.x >> 6);
@@ -88,6 +98,8 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_motion_compensation(const uin
             mode = (wb && j.wp[lsel][0].present) ? 1 : 0;
         }
     }
+    if (j.flags & 16) mode = 4;
+    const bool doChroma = (j.flags & 2) && mode != 4;
     McPlane p;
     if (j.flags & 1)
     {
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_motion_compensation(const uin
         p.stride = stride; p.w = j.w; p.h = j.h; p.dst = reinterpret_cast<pixel*>(j.dst_y); p.dstStride = j.dst_stride; p.c = 0;
         mc_plane<8>(p, j, mode, lsel, lane);
     }
-    if (j.flags & 2)
+    if (doChroma)
         for (int c = 1; c < 3; c++)
         {
             for (int l = 0; l < 2; l++)
@@ -110,6 +122,33 @@ __global__ __launch_bounds__(64 * MC_WAVES) void k_motion_compensation(const uin
             p.stride = cstride; p.w = j.w >> 1; p.h = j.h >> 1; p.dst = reinterpret_cast<pixel*>(c == 1 ? j.dst_u : j.dst_v); p.dstStride = j.dst_cstride; p.c = c;
             mc_plane<4>(p, j, mode, lsel, lane);
         }
+    if constexpr (COST)
+    {
+        /* the wave reads back what it has just written */
+        __threadfence_block();
+        xa_wave_sync();
+        const int metric = j.metric;
+        uint32_t lumaCost = 0, chromaCost = 0;
+        int cu = 0;
+        while ((4 << cu) < j.w) cu++;
+        if (j.flags & 1)
+        {
+            const pixel* f = reinterpret_cast<const pixel*>(fencPlanes[0]) + (long)j.y * fstride + j.x;
+            const pixel* d = reinterpret_cast<const pixel*>(j.dst_y);
+            lumaCost = metric == 1 ? (uint32_t)xa_wave_sad(f, (int)fstride, d, j.dst_stride, j.w, j.h, lane)
+                     : metric == 2 ? (uint32_t)xa_wave_satd(f, (int)fstride, d, j.dst_stride, j.w, j.h, lane)
+                     : metric == 3 ? (uint32_t)xa_wave_sa8d(f, (int)fstride, d, j.dst_stride, 4 << cu, lane) : 0;
+        }
+        if (doChroma && j.chroma_cost && metric >= 2)
+            for (int c = 1; c < 3; c++)
+            {
+                const pixel* f = reinterpret_cast<const pixel*>(fencPlanes[c]) + (long)(j.y >> 1) * fcstride + (j.x >> 1);
+                const pixel* d = reinterpret_cast<const pixel*>(c == 1 ? j.dst_u : j.dst_v);
+                chromaCost += metric == 2 ? (uint32_t)xa_wave_satd(f, (int)fcstride, d, j.dst_cstride, j.w >> 1, j.h >> 1, lane)
+                                          : (uint32_t)xa_wave_sa8d(f, (int)fcstride, d, j.dst_cstride, 2 << cu, lane);
+            }
+        if (lane == 0) { cost[2 * ji] = lumaCost; cost[2 * ji + 1] = chromaCost; }
+    }
 }
 
 extern "C" int x265amd_motion_compensation(void* stream, const uint64_t* d_planes, intptr_t stride, intptr_t cstride, int pic_w, int pic_h,
@@ -117,8 +156,21 @@ extern "C" int x265amd_motion_compensation(void* stream, const uint64_t* d_plane
 {
     if (n <= 0) return X265AMD_OK;
     if (!d_planes || !d_jobs) return xa_fail(X265AMD_EINVAL, "x265amd_motion_compensation: bad arguments");
-    hipLaunchKernelGGL(k_motion_compensation, dim3((n + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, (hipStream_t)stream,
-                       d_planes, (long)stride, (long)cstride, pic_w, pic_h, d_jobs, n);
+    hipLaunchKernelGGL(k_motion_compensation<false>, dim3((n + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, (hipStream_t)stream,
+                       d_planes, (long)stride, (long)cstride, pic_w, pic_h, d_jobs, n, (const uint64_t*)nullptr, 0L, 0L, (uint32_t*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_inter_cost(void* stream, const uint64_t* d_planes, intptr_t stride, intptr_t cstride, int pic_w, int pic_h,
+                                  const x265amd_mc_job* d_jobs, int n, const uint64_t* d_fenc_planes, intptr_t fenc_stride, intptr_t fenc_cstride,
+                                  uint32_t* d_cost)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!d_planes || !d_jobs || !d_fenc_planes || !d_cost) return xa_fail(X265AMD_EINVAL, "x265amd_inter_cost: bad arguments");
+    hipLaunchKernelGGL(k_motion_compensation<true>, dim3((n + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, (hipStream_t)stream,
+                       d_planes, (long)stride, (long)cstride, pic_w, pic_h, d_jobs, n, d_fenc_planes, (long)fenc_stride, (long)fenc_cstride, d_cost);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
