@@ -291,6 +291,25 @@ typedef struct x265amd_tu_rdoq
     uint8_t tu_depth;               /* cu.m_tuDepth[absPartIdx]: selects the CBF context */
     uint8_t reserved[6];
 } x265amd_tu_rdoq;
+
+/* Intra TU step of Search::codeIntraLumaQT (source/encoder/search.cpp:305-508) / codeIntraChromaQt (:819-945), fused: the
+ * neighbour set of the job's one mode from the reconstructed plane (Predict::initAdiPattern(dirMode) / initAdiPatternChroma,
+ * source/common/predict.cpp:600-649), the prediction (predIntraLumaAng / predIntraChromaAng 4:2:0, predict.cpp:579-598) and
+ * the per-TU measurement of x265amd_tu_chain.  tu.dir_mode is the prediction mode (a chroma DM mode resolved by the caller) and
+ * selects the coefficient scan; tu.intra is taken as 1; tu.pred (may be 0) receives the prediction; tu.recon may point into
+ * the reconstructed plane itself so that later launches see the block as a neighbour.  avail / strong_smoothing as in
+ * x265amd_intra_job.  d_rdoq: NULL, or the RDOQ records (Quant::m_rdoqLevel != 0). */
+typedef struct x265amd_intra_tu_job
+{
+    x265amd_tu_job tu;
+    uint64_t nb;                    /* device address of the block's top-left sample in the reconstructed plane (neighbour source) */
+    uint64_t avail;
+    int32_t nb_stride;
+    uint8_t strong_smoothing;
+    uint8_t reserved[11];
+} x265amd_intra_tu_job;
+int x265amd_intra_tu_chain(void* stream, const x265amd_intra_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);
+
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */
 int x265amd_tu_chain_rdoq(void* stream, const x265amd_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);
 void x265amd_rdoq_lambda(int qpScaled, int64_t* lambda2, int32_t* lambda);

@@ -120,3 +120,70 @@ int orc_intra_scan_batch(const PackedIntraJob* jobs, int n, int32_t* sa8d)
     }
     return n;
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * One intra prediction as the TU coding loops make it (Search::codeIntraLumaQT search.cpp:305-508 / codeIntraChromaQt
+ * :819-945): neighbour set for this one mode, then
+ *   luma   Predict::initAdiPattern(dirMode) + predIntraLumaAng (predict.cpp:579-588): filtered neighbours when
+ *          g_intraFilterFlags[dirMode] & N, edge filters for N <= 16;
+ *   chroma Predict::initAdiPatternChroma + predIntraChromaAng (predict.cpp:590-598, :624-649), 4:2:0: unfiltered
+ *          neighbours, no edge filters.
+ * flags: availability per 4-sample unit as for orc_init_adi_pattern.
+ * ------------------------------------------------------------------------------------------------------- */
+void orc_intra_pred(int cu, int mode, pixel* dst, intptr_t ds, const pixel* srcPix, int bFilter);
+int orc_intra_filter_flags(int mode);
+void orc_intra_predict(const pixel* recon, intptr_t stride, int log2TrSize, const uint8_t* flags, int strongSmoothing, int isChroma, int mode,
+                       pixel* pred, intptr_t predStride)
+{
+    pixel rb[258], fb[258];
+    const int N = 1 << log2TrSize;
+    if (isChroma)
+    {
+        orc_init_adi_pattern(recon, stride, log2TrSize, flags, 0, 1 /* DC: never filtered */, rb, fb);
+        orc_intra_pred(log2TrSize - 2, mode, pred, predStride, rb, 0);
+        return;
+    }
+    orc_init_adi_pattern(recon, stride, log2TrSize, flags, strongSmoothing, mode, rb, fb);
+    const int filter = (orc_intra_filter_flags(mode) & N) != 0;
+    orc_intra_pred(log2TrSize - 2, mode, pred, predStride, filter ? fb : rb, log2TrSize <= 4);
+}
+
+/* fused job of the intra TU loops: prediction from the reconstructed plane, then the per-TU measurement (orc_tu_chain /
+ * orc_tu_chain_rdoq with bIntra = 1).  Record layout = x265amd_intra_tu_job (include/x265amd.h); addresses are HOST addresses. */
+typedef struct { uint64_t fenc, pred, coeff, resi, recon; int32_t fencStride, predStride, resiStride, reconStride;
+                 uint8_t log2, ttype, intra, dir, slice, qp, signhide, reserved; } PackedTuJobI;
+typedef struct { PackedTuJobI tu; uint64_t nb, avail; int32_t nbStride; uint8_t strong, reserved[11]; } PackedIntraTuJob;
+typedef struct { uint64_t est; int64_t lambda2; int32_t lambda, psyRdoqScale; uint8_t rdoqLevel, tuDepth, reserved[6]; } PackedTuRdoq;
+typedef struct { uint32_t numSig, zeroEnergy, nzEnergy, reserved; uint64_t zeroDist, nzDist; } PackedTuResultI;
+void orc_tu_chain(const pixel* fenc, intptr_t fencStride, const pixel* pred, intptr_t predStride, int log2TrSize, int ttype, int bIntra, int dirMode,
+                  int sliceType, int qpScaled, int signHide, int16_t* coeff, int16_t* resiOut, intptr_t resiStride, pixel* recon, intptr_t reconStride,
+                  uint64_t* out);
+void orc_tu_chain_rdoq(const pixel* fenc, intptr_t fencStride, const pixel* pred, intptr_t predStride, int log2TrSize, int ttype, int bIntra, int dirMode,
+                       int sliceType, int qpScaled, int signHide, int tuDepth, int rdoqLevel, int psyRdoqScale, const int* est,
+                       int16_t* coeff, int16_t* resiOut, intptr_t resiStride, pixel* recon, intptr_t reconStride, uint64_t* out);
+int orc_intra_tu_chain_batch(const PackedIntraTuJob* jobs, const PackedTuRdoq* rq, int n, PackedTuResultI* out)
+{
+    uint8_t flags[33];
+    pixel predTmp[32 * 32];
+    for (int i = 0; i < n; i++)
+    {
+        const PackedIntraTuJob* j = &jobs[i];
+        const PackedTuJobI* t = &j->tu;
+        int total = (1 << t->log2) + 1;
+        for (int u = 0; u < total; u++) flags[u] = (uint8_t)((j->avail >> u) & 1);
+        pixel* pred = t->pred ? (pixel*)t->pred : predTmp;
+        intptr_t ps = t->pred ? t->predStride : 32;
+        orc_intra_predict((const pixel*)j->nb, j->nbStride, t->log2, flags, j->strong, t->ttype != 0, t->dir, pred, ps);
+        uint64_t st[5];
+        if (rq && rq[i].rdoqLevel)
+            orc_tu_chain_rdoq((const pixel*)t->fenc, t->fencStride, pred, ps, t->log2, t->ttype, 1, t->dir, t->slice, t->qp, t->signhide,
+                              rq[i].tuDepth, rq[i].rdoqLevel, rq[i].psyRdoqScale, (const int*)rq[i].est,
+                              (int16_t*)t->coeff, (int16_t*)t->resi, t->resiStride, (pixel*)t->recon, t->reconStride, st);
+        else
+            orc_tu_chain((const pixel*)t->fenc, t->fencStride, pred, ps, t->log2, t->ttype, 1, t->dir, t->slice, t->qp, t->signhide,
+                         (int16_t*)t->coeff, (int16_t*)t->resi, t->resiStride, (pixel*)t->recon, t->reconStride, st);
+        out[i].numSig = (uint32_t)st[0]; out[i].zeroDist = st[1]; out[i].zeroEnergy = (uint32_t)st[2]; out[i].nzDist = st[3]; out[i].nzEnergy = (uint32_t)st[4];
+        out[i].reserved = 0;
+    }
+    return n;
+}

@@ -370,8 +370,9 @@ struct IntraEnv
     {
         pic = new PicYuv;       /* never destroyed: it does not own the sample buffer */
         zeroCu[0] = 0; memset(zeroBu, 0, sizeof(zeroBu));
-        pic->m_cuOffsetY = zeroCu; pic->m_buOffsetY = zeroBu;
+        pic->m_cuOffsetY = zeroCu; pic->m_buOffsetY = zeroBu; pic->m_cuOffsetC = zeroCu; pic->m_buOffsetC = zeroBu;
         fd.m_reconPic = pic;
+        pred.allocBuffers(X265_CSP_I420);       /* sets Predict::m_csp (read by the chroma paths) */
     }
 };
 
@@ -398,6 +399,38 @@ void ref_init_adi_pattern(const pixel* recon, intptr_t stride, int log2TrSize, c
     ie->pred.initAdiPattern(e->cu, g, 0, nb, dirMode);
     memcpy(outRef, ie->pred.intraNeighbourBuf[0], 258 * sizeof(pixel));
     memcpy(outFlt, ie->pred.intraNeighbourBuf[1], 258 * sizeof(pixel));
+}
+
+/* one intra prediction as the TU coding loops make it: Predict::initAdiPattern(dirMode) + predIntraLumaAng (predict.cpp:579-588,
+ * :600-622) for luma, initAdiPatternChroma + predIntraChromaAng (predict.cpp:590-598, :624-649) for 4:2:0 chroma */
+void ref_intra_predict(const pixel* recon, intptr_t stride, int log2TrSize, const uint8_t* flags, int strongSmoothing, int isChroma, int mode,
+                       pixel* pred, intptr_t predStride)
+{
+    static IntraEnv* ie = NULL;
+    TuEnv* e = tuEnv();
+    if (!ie) ie = new IntraEnv;
+    int units = (1 << log2TrSize) >> 2;
+    Predict::IntraNeighbors nb;
+    nb.aboveUnits = 2 * units; nb.leftUnits = 2 * units; nb.totalUnits = 4 * units + 1;
+    nb.unitWidth = 4; nb.unitHeight = 4; nb.log2TrSize = log2TrSize;
+    nb.numIntraNeighbor = 0;
+    for (int i = 0; i < nb.totalUnits; i++) { nb.bNeighborFlags[i] = flags[i] != 0; nb.numIntraNeighbor += flags[i] != 0; }
+    ie->pic->m_picOrg[0] = ie->pic->m_picOrg[1] = ie->pic->m_picOrg[2] = (pixel*)recon;
+    ie->pic->m_stride = stride; ie->pic->m_strideC = stride;
+    e->sps.bUseStrongIntraSmoothing = strongSmoothing != 0;
+    e->cu.m_encData = &ie->fd;
+    e->cu.m_cuAddr = 0;
+    CUGeom g; memset(&g, 0, sizeof(g));
+    if (isChroma)
+    {
+        ie->pred.initAdiPatternChroma(e->cu, g, 0, nb, 1);
+        ie->pred.predIntraChromaAng(mode, pred, predStride, log2TrSize);
+    }
+    else
+    {
+        ie->pred.initAdiPattern(e->cu, g, 0, nb, mode);
+        ie->pred.predIntraLumaAng(mode, pred, predStride, log2TrSize);
+    }
 }
 
 /* the 35-mode luma scan of Search::estIntraPredQT (encoder/search.cpp:1566-1613, individual-angle path): sa8d of every
@@ -596,6 +629,59 @@ int ref_tu_chain_batch(const PackedTuJob* jobs, int n, PackedTuResult* out)
             g_p.cu[sizeIdx].add_ps[NONALIGNED]((pixel*)j.recon, j.reconStride, pred, (int16_t*)j.resi, j.predStride, j.resiStride);
             r.nzDist = g_p.cu[sizeIdx].sse_pp(fenc, j.fencStride, (pixel*)j.recon, j.reconStride);
             r.nzEnergy = g_p.cu[sizeIdx].psy_cost_pp(fenc, j.fencStride, (pixel*)j.recon, j.reconStride);
+        }
+    }
+    return n;
+}
+
+/* fused intra TU job with the reference's own classes: prediction (ref_intra_predict), then the per-TU measurement with Quant
+ * (optionally RDOQ) -- record layouts of include/x265amd.h with host addresses */
+struct PackedIntraTuJob { PackedTuJob tu; uint64_t nb, avail; int32_t nbStride; uint8_t strong, reserved[11]; };
+struct PackedTuRdoq { uint64_t est; int64_t lambda2; int32_t lambda, psyRdoqScale; uint8_t rdoqLevel, tuDepth, reserved[6]; };
+int ref_intra_tu_chain_batch(const PackedIntraTuJob* jobs, const PackedTuRdoq* rq, int n, PackedTuResult* out)
+{
+    TuEnv* e = tuEnv();
+    ALIGN_VAR_32(int16_t, resi[32 * 32]);
+    ALIGN_VAR_32(pixel, predTmp[32 * 32]);
+    uint8_t flags[33];
+    for (int i = 0; i < n; i++)
+    {
+        const PackedIntraTuJob& J = jobs[i];
+        const PackedTuJob& j = J.tu;
+        int total = (1 << j.log2) + 1;
+        for (int u = 0; u < total; u++) flags[u] = (uint8_t)((J.avail >> u) & 1);
+        pixel* pred = j.pred ? (pixel*)j.pred : predTmp;
+        intptr_t ps = j.pred ? j.predStride : 32;
+        ref_intra_predict((const pixel*)J.nb, J.nbStride, j.log2, flags, J.strong, j.ttype != 0, j.dir, pred, ps);
+        const pixel* fenc = (const pixel*)j.fenc;
+        int sizeIdx = j.log2 - 2, N = 1 << j.log2;
+        g_p.cu[sizeIdx].sub_ps(resi, N, fenc, pred, j.fencStride, ps);
+        e->set(j.ttype, 1, j.dir, j.slice, j.qp, j.signhide);
+        if (rq && rq[i].rdoqLevel)
+        {
+            e->quant.configureRdoq(rq[i].rdoqLevel, rq[i].psyRdoqScale);
+            memset(e->tuDepth, rq[i].tuDepth, sizeof(e->tuDepth));
+            memcpy(&e->entropy.m_estBitsSbac, (const void*)rq[i].est, sizeof(EstBitsSbac));
+        }
+        uint32_t ns = e->quant.transformNxN(e->cu, fenc, j.fencStride, resi, N, (coeff_t*)j.coeff, j.log2, (TextType)j.ttype, 0, false);
+        e->quant.configureRdoq(0, 0);
+        memset(e->tuDepth, 0, sizeof(e->tuDepth));
+        PackedTuResult& r = out[i];
+        r.numSig = ns; r.reserved = 0;
+        r.zeroDist = g_p.cu[sizeIdx].sse_pp(fenc, j.fencStride, pred, ps);
+        r.zeroEnergy = g_p.cu[sizeIdx].psy_cost_pp(fenc, j.fencStride, pred, ps);
+        r.nzDist = r.zeroDist; r.nzEnergy = r.zeroEnergy;
+        if (ns)
+        {
+            e->quant.invtransformNxN(e->cu, (int16_t*)j.resi, j.resiStride, (coeff_t*)j.coeff, j.log2, (TextType)j.ttype, true, false, ns);
+            g_p.cu[sizeIdx].add_ps[NONALIGNED]((pixel*)j.recon, j.reconStride, pred, (int16_t*)j.resi, ps, j.resiStride);
+            r.nzDist = g_p.cu[sizeIdx].sse_pp(fenc, j.fencStride, (pixel*)j.recon, j.reconStride);
+            r.nzEnergy = g_p.cu[sizeIdx].psy_cost_pp(fenc, j.fencStride, (pixel*)j.recon, j.reconStride);
+        }
+        else
+        {
+            for (int y = 0; y < N; y++)
+                for (int x = 0; x < N; x++) { ((pixel*)j.recon)[y * j.reconStride + x] = pred[y * ps + x]; ((int16_t*)j.resi)[y * j.resiStride + x] = 0; }
         }
     }
     return n;

@@ -43,6 +43,7 @@ def main():
     make_mc_golden()
     make_entropy_golden()
     make_inter_cost_golden()
+    make_intra_tu_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -175,6 +176,21 @@ def make_inter_cost_golden():
             out["cost/%d/%d" % (depth, seed)] = cost
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "inter_cost_golden.npz"), **out)
     print("wrote inter_cost_golden.npz with", len(out), "arrays")
+
+
+def make_intra_tu_golden():
+    """fused intra TU step with the reference's Predict / Quant classes -> sha256 per case set in tests/golden/intra_tu_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tit", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_intra_tu.py"))
+    tit = importlib.util.module_from_spec(spec); spec.loader.exec_module(tit)
+    out = {}
+    for depth in (8, 10):
+        ref = T.load_ref(depth)
+        for seed in range(2):
+            cases = T.intra_tu_cases(depth, 2100 + seed, 300, rdoq=bool(seed))
+            out["digest/%d/%d" % (depth, seed)] = tit.digest(T.intra_tu_run_host(ref, cases))
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_tu_golden.npz"), **out)
+    print("wrote intra_tu_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

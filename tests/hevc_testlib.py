@@ -1200,3 +1200,118 @@ def inter_cost_run_hip(L, pics, fenc, stride, cstride, org, jobs):
     torch.cuda.synchronize()
     outY = d_y.cpu().numpy().view(dt).reshape(n, 64, 64)
     return d_cost.cpu().numpy().view(np.uint32).reshape(n, 2), [outY[i, :int(jobs[i]["h"]), :int(jobs[i]["w"])].copy() for i in range(n)]
+
+
+# ---- fused intra TU jobs: prediction from the reconstructed plane + per-TU measurement (x265amd_intra_tu_chain) ----
+INTRA_TU_JOB_DT = np.dtype([("tu", TU_JOB_DT), ("nb", "<u8"), ("avail", "<u8"), ("nb_stride", "<i4"), ("strong", "u1"), ("reserved", "u1", 11)])
+assert INTRA_TU_JOB_DT.itemsize == 96
+
+
+def intra_tu_cases(depth, seed, n, rdoq=False):
+    """intra_cases + a prediction mode, plane type and the TU parameters; with rdoq=True also the RDOQ parameters and contexts"""
+    rng = np.random.default_rng(seed + 4242)
+    cases = intra_cases(depth, seed, n)
+    orc = load_oracle(depth)
+    for c in cases:
+        c["ttype"] = int(rng.integers(0, 3))
+        c["mode"] = int(rng.integers(0, 35)) if c["ttype"] == 0 else int(rng.choice([0, 1, 10, 26, 34, int(rng.integers(2, 35))]))
+        c["slice"] = int(rng.integers(0, 3))
+        c["qp"] = int(rng.integers(4, 52)) + 6 * (depth - 8)
+        c["signhide"] = int(rng.integers(0, 4) != 0)
+        c["rdoq"] = int(rng.integers(0, 3)) if rdoq else 0
+        c["tudepth"] = int(rng.integers(0, 3))
+        c["psyrdoq"] = int(rng.choice([0, 256, 1024]))
+        c["ctx"] = entropy_reset(orc, c["slice"], int(rng.integers(10, 50)))
+    return cases
+
+
+def intra_predict_host(L, cases):
+    out = []
+    f = getattr(L.lib, L.prefix + "intra_predict")
+    for c in cases:
+        N = 1 << c["log2"]
+        pred = np.zeros((N, N), c["plane"].dtype)
+        f(off(c["plane"], c["off"]), C.c_int64(c["stride"]), c["log2"], _ptr(c["flags"]), c["strong"], int(c["ttype"] != 0), c["mode"], _ptr(pred), C.c_int64(N))
+        out.append(pred)
+    return out
+
+
+def intra_tu_pack(cases, addr_plane, addr_fenc, addr_out, est_addr=None, L=None):
+    """job / rdoq records; addr_*(i) -> base address of case i's plane, fenc and output area (pred | recon | coeff | resi at stride 32)"""
+    n = len(cases)
+    jobs = np.zeros(n, INTRA_TU_JOB_DT); rq = np.zeros(n, TU_RDOQ_DT)
+    isz = cases[0]["plane"].itemsize
+    for i, c in enumerate(cases):
+        N = 1 << c["log2"]
+        o = addr_out(i)
+        mask = 0
+        for u, f in enumerate(c["flags"]):
+            mask |= int(f) << u
+        jobs[i]["tu"] = (addr_fenc(i), o, o + 2048 * isz, o + 2048 * isz + 2048, o + 1024 * isz, N, 32, 32, 32,
+                         c["log2"], c["ttype"], 1, c["mode"], c["slice"], c["qp"], c["signhide"], 0)
+        jobs[i]["nb"] = addr_plane(i) + c["off"] * isz
+        jobs[i]["avail"], jobs[i]["nb_stride"], jobs[i]["strong"] = mask, c["stride"], c["strong"]
+        if c["rdoq"]:
+            l2, l1 = C.c_int64(0), C.c_int32(0)
+            L.lib.x265amd_rdoq_lambda(c["qp"], C.byref(l2), C.byref(l1)) if L is not None and L.prefix == "x265amd_" else None
+            rq[i] = (est_addr(i), l2.value, l1.value, c["psyrdoq"], c["rdoq"], c["tudepth"], 0)
+    return jobs, rq
+
+
+INTRA_TU_OUT_BYTES = lambda isz: 1024 * isz * 2 + 4096
+
+
+def intra_tu_run_host(L, cases):
+    """<prefix>intra_tu_chain_batch on host memory: list of (stats tuple, pred, recon, coeff, resi)"""
+    n = len(cases)
+    dt = cases[0]["plane"].dtype
+    isz = dt.itemsize
+    per = INTRA_TU_OUT_BYTES(isz)
+    arena = np.zeros(n * per, np.uint8)
+    ests = np.stack([est_bit(L, c["ctx"], c["log2"], int(c["ttype"] == 0)) for c in cases])
+    jobs, rq = intra_tu_pack(cases, lambda i: cases[i]["plane"].ctypes.data, lambda i: cases[i]["fenc"].ctypes.data, lambda i: arena.ctypes.data + i * per,
+                             lambda i: ests.ctypes.data + i * EST_INTS * 4)
+    res = np.zeros(n, TU_RESULT_DT)
+    getattr(L.lib, L.prefix + "intra_tu_chain_batch")(_ptr(jobs), _ptr(rq), n, _ptr(res))
+    return intra_tu_unpack(cases, res, arena, per)
+
+
+def intra_tu_unpack(cases, res, arena, per):
+    dt = cases[0]["plane"].dtype
+    isz = dt.itemsize
+    out = []
+    for i, c in enumerate(cases):
+        N = 1 << c["log2"]
+        b = i * per
+        pred = arena[b:b + 1024 * isz].view(dt).reshape(32, 32)[:N, :N].copy()
+        recon = arena[b + 1024 * isz:b + 2048 * isz].view(dt).reshape(32, 32)[:N, :N].copy()
+        coeff = arena[b + 2048 * isz:b + 2048 * isz + N * N * 2].view(np.int16).copy()
+        resi = arena[b + 2048 * isz + 2048:b + 2048 * isz + 4096].view(np.int16).reshape(32, 32)[:N, :N].copy()
+        st = (int(res[i]["num_sig"]), int(res[i]["zero_dist"]), int(res[i]["zero_energy"]), int(res[i]["nz_dist"]), int(res[i]["nz_energy"]))
+        out.append((st, pred, recon, coeff, resi))
+    return out
+
+
+def intra_tu_run_hip(L, cases):
+    import torch
+    n = len(cases)
+    dt = cases[0]["plane"].dtype
+    isz = dt.itemsize
+    per = INTRA_TU_OUT_BYTES(isz)
+    orc = load_oracle(L.depth)
+    ests = np.stack([est_bit(orc, c["ctx"], c["log2"], int(c["ttype"] == 0)) for c in cases])
+    planes = np.concatenate([c["plane"].view(np.uint8) for c in cases])
+    fencs = np.concatenate([c["fenc"].ravel().view(np.uint8) for c in cases])
+    po = np.cumsum([0] + [c["plane"].nbytes for c in cases]); fo = np.cumsum([0] + [c["fenc"].nbytes for c in cases])
+    d_planes, d_fencs, d_est = torch.from_numpy(planes).cuda(), torch.from_numpy(fencs).cuda(), torch.from_numpy(ests).cuda()
+    d_arena = torch.zeros(n * per, dtype=torch.uint8, device="cuda")
+    jobs, rq = intra_tu_pack(cases, lambda i: d_planes.data_ptr() + int(po[i]), lambda i: d_fencs.data_ptr() + int(fo[i]), lambda i: d_arena.data_ptr() + i * per,
+                             lambda i: d_est.data_ptr() + i * EST_INTS * 4, L)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).copy()).cuda()
+    d_rq = torch.from_numpy(rq.view(np.uint8).copy()).cuda()
+    d_out = torch.zeros(n * TU_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda")
+    rc = L.lib.x265amd_intra_tu_chain(None, C.c_void_p(d_jobs.data_ptr()), C.c_void_p(d_rq.data_ptr()) if any(c["rdoq"] for c in cases) else None, n,
+                                      C.c_void_p(d_out.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    return intra_tu_unpack(cases, d_out.cpu().numpy().view(TU_RESULT_DT), d_arena.cpu().numpy(), per)

@@ -21,8 +21,6 @@ struct IntraLds
                                                            (measured: 2.4 GB of scratch traffic per 1080p launch) */
 };
 
-XA_DEV int in_first_of_unit(int u, int L, int N2) { return u < L ? 4 * u : (u == L ? N2 : N2 + 1 + 4 * (u - L - 1)); }
-XA_DEV int in_last_of_unit(int u, int L, int N2) { return u < L ? 4 * u + 3 : (u == L ? N2 : N2 + 1 + 4 * (u - L - 1) + 3); }
 
 /* one prediction sample of `mode` at (y, x): intrapred.cpp:54-209 */
 XA_DEV int in_pred_sample(const IntraLds& s, int mode, int N, int log2N, int dc, int y, int x)
@@ -66,56 +64,8 @@ __global__ __launch_bounds__(64 * IN_WAVES) void k_intra_scan(const x265amd_intr
     const pixel* recon = reinterpret_cast<const pixel*>(j.recon);
     const pixel* fenc = reinterpret_cast<const pixel*>(j.fenc);
     const long rs = j.recon_stride;
-    const uint64_t avail = j.avail & ((units == 8) ? 0x1ffffffffull : ((1ull << (4 * units + 1)) - 1));
 
-    /* ---- fillReferenceSamples: substitution order index i: 0 = bottom-most below-left ... 2N = above-left ... 4N ---- */
-    for (int i = lane; i <= 4 * N; i += XA_WAVE)
-    {
-        int u = i < N2 ? i >> 2 : (i == N2 ? L : L + 1 + ((i - N2 - 1) >> 2));
-        int src = i;
-        if (!((avail >> u) & 1))
-        {
-            uint64_t before = avail & ((1ull << u) - 1);
-            if (before) src = in_last_of_unit(63 - __clzll((long long)before), L, N2);
-            else if (avail) src = in_first_of_unit(__ffsll((long long)avail) - 1, L, N2);
-            else src = -1;
-        }
-        int v;
-        if (src < 0) v = 1 << (XA_DEPTH - 1);
-        else if (src < N2) v = recon[(long)(N2 - 1 - src) * rs - 1];
-        else if (src == N2) v = recon[-rs - 1];
-        else v = recon[-rs + (src - N2 - 1)];
-        int d = i == N2 ? 0 : (i > N2 ? i - N2 : N2 + (N2 - i));      /* destination index in the neighbour-buffer layout */
-        s.ref[d] = (pixel)v;
-    }
-    xa_wave_sync();
-    /* ---- initAdiPattern(ALL_IDX): smoothing for 8x8 .. 32x32 ---- */
-    if (N >= 8)
-    {
-        bool strong = false;
-        if (j.strong_smoothing && N == 32)
-        {
-            const int threshold = 1 << (XA_DEPTH - 5);
-            int topLeft = s.ref[0], topLast = s.ref[N2], leftLast = s.ref[2 * N2];
-            strong = abs(topLeft + topLast - 2 * s.ref[32]) < threshold && abs(topLeft + leftLast - 2 * s.ref[N2 + 32]) < threshold;
-            if (strong)
-            {
-                int init = (topLeft << 6) + N, deltaL = leftLast - topLeft, deltaR = topLast - topLeft;
-                for (int i = lane; i <= 2 * N2; i += XA_WAVE)
-                {
-                    int v;
-                    if (i == 0) v = topLeft;
-                    else if (i == N2) v = topLast;
-                    else if (i == 2 * N2) v = leftLast;
-                    else if (i < N2) v = (init + deltaR * i) >> 6;
-                    else v = (init + deltaL * (i - N2)) >> 6;
-                    s.flt[i] = (pixel)v;
-                }
-            }
-        }
-        if (!strong) wave_intra_filter(s.ref, s.flt, N, lane);
-    }
-    xa_wave_sync();
+    wave_intra_neighbours(recon, rs, j.avail, log2N, j.strong_smoothing != 0, N >= 8, s.ref, s.flt, lane);
     /* mirrored copies for the horizontal modes (intrapred.cpp:114-124) */
     for (int i = lane; i < N2; i += XA_WAVE)
     {

@@ -356,65 +356,6 @@ __global__ __launch_bounds__(256) void k_transform(const x265amd_job* jobs, int 
  * family 3: intra prediction (intrapred.cpp).  Neighbour layout (predict.cpp:600-877): s[0] top-left,
  * s[1..2N] above+above-right, s[2N+1..4N] left+below-left.
  * ======================================================================================================= */
-/* writes one N x N prediction; s = neighbours in LDS.  keepTransposed: all-angles layout (intrapred.cpp:211-241) */
-XA_DEV void wave_intra_pred(const pixel* s, pixel* swapped, int cu, int mode, int bFilter, pixel* dst, int ds, bool keepTransposed, int lane)
-{
-    int log2N = cu + 2, N = 1 << log2N, N2 = 2 * N;
-    if (mode == 0)      /* planar: intrapred.cpp:90-104 */
-    {
-        const pixel* above = s + 1; const pixel* left = s + N2 + 1;
-        int topRight = above[N], bottomLeft = left[N];
-        for (int i = lane; i < N * N; i += XA_WAVE)
-        {
-            int y = i >> log2N, x = i & (N - 1);
-            dst[y * ds + x] = (pixel)(((N - 1 - x) * left[y] + (N - 1 - y) * above[x] + (x + 1) * topRight + (y + 1) * bottomLeft + N) >> (log2N + 1));
-        }
-        return;
-    }
-    if (mode == 1)      /* DC: intrapred.cpp:54-88 */
-    {
-        const pixel* above = s + 1; const pixel* left = s + N2 + 1;
-        int part = lane < N ? above[lane] + left[lane] : 0;
-        int dc = (xa_wave_sum(part) + N) / (2 * N);
-        for (int i = lane; i < N * N; i += XA_WAVE)
-        {
-            int y = i >> log2N, x = i & (N - 1);
-            int v = dc;
-            if (bFilter)
-            {
-                if (x == 0 && y == 0) v = (above[0] + left[0] + 2 * dc + 2) >> 2;
-                else if (y == 0) v = (above[x] + 3 * dc + 2) >> 2;
-                else if (x == 0) v = (left[y] + 3 * dc + 2) >> 2;
-            }
-            dst[y * ds + x] = (pixel)v;
-        }
-        return;
-    }
-    bool hor = mode < 18;
-    const pixel* nb = s;
-    if (hor)            /* mirror the neighbours: intrapred.cpp:114-124 */
-    {
-        for (int i = lane; i < N2; i += XA_WAVE)
-        {
-            swapped[1 + i] = s[N2 + 1 + i];
-            swapped[N2 + 1 + i] = s[1 + i];
-        }
-        if (lane == 0) swapped[0] = s[0];
-        xa_wave_sync();
-        nb = swapped;
-    }
-    int angOff = hor ? 10 - mode : mode - 26;
-    int angle = xa_tbl.angle[8 + angOff];
-    int invAngle = angle < 0 ? xa_tbl.invAngle[-angOff - 1] : 0;
-    bool flip = hor && !keepTransposed;
-    for (int i = lane; i < N * N; i += XA_WAVE)
-    {
-        int y = i >> log2N, x = i & (N - 1);
-        dst[y * ds + x] = flip ? ang_sample(nb, N, angle, invAngle, bFilter, x, y) : ang_sample(nb, N, angle, invAngle, bFilter, y, x);
-    }
-    xa_wave_sync();
-}
-
 __global__ __launch_bounds__(256) void k_intra(const x265amd_job* jobs, int n)
 {
     __shared__ pixel lds[WAVES_PER_BLOCK][3][136];

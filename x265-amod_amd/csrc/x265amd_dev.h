@@ -368,6 +368,127 @@ XA_DEV void wave_intra_filter(const pixel* s, pixel* f, int N, int lane)
 }
 
 
+/* ---- intra neighbour set: Predict::fillReferenceSamples + the smoothing of initAdiPattern (predict.cpp:600-649, :736-877).
+ * recon: the block's top-left sample in the reconstructed plane; availMask bit u: neighbour unit u (4 samples) available, order
+ * below-left (bottom-most first) ... left, above-left, above ... above-right.  ref / flt: [0] above-left, [1..2N] above +
+ * above-right, [2N+1..4N] left + below-left (LDS, one wave).  flt is produced when wantFilter (8x8..32x32 luma). ---- */
+XA_DEV int in_first_of_unit(int u, int L, int N2) { return u < L ? 4 * u : (u == L ? N2 : N2 + 1 + 4 * (u - L - 1)); }
+XA_DEV int in_last_of_unit(int u, int L, int N2) { return u < L ? 4 * u + 3 : (u == L ? N2 : N2 + 1 + 4 * (u - L - 1) + 3); }
+XA_DEV void wave_intra_neighbours(const pixel* recon, long rs, uint64_t availMask, int log2N, bool strongSmoothing, bool wantFilter,
+                                  pixel* ref, pixel* flt, int lane)
+{
+    const int N = 1 << log2N, N2 = 2 * N, units = N >> 2, L = 2 * units;
+    const uint64_t avail = availMask & ((units == 8) ? 0x1ffffffffull : ((1ull << (4 * units + 1)) - 1));
+    /* ---- fillReferenceSamples: substitution order index i: 0 = bottom-most below-left ... 2N = above-left ... 4N ---- */
+    for (int i = lane; i <= 4 * N; i += XA_WAVE)
+    {
+        int u = i < N2 ? i >> 2 : (i == N2 ? L : L + 1 + ((i - N2 - 1) >> 2));
+        int src = i;
+        if (!((avail >> u) & 1))
+        {
+            uint64_t before = avail & ((1ull << u) - 1);
+            if (before) src = in_last_of_unit(63 - __clzll((long long)before), L, N2);
+            else if (avail) src = in_first_of_unit(__ffsll((long long)avail) - 1, L, N2);
+            else src = -1;
+        }
+        int v;
+        if (src < 0) v = 1 << (XA_DEPTH - 1);
+        else if (src < N2) v = recon[(long)(N2 - 1 - src) * rs - 1];
+        else if (src == N2) v = recon[-rs - 1];
+        else v = recon[-rs + (src - N2 - 1)];
+        int d = i == N2 ? 0 : (i > N2 ? i - N2 : N2 + (N2 - i));      /* destination index in the neighbour-buffer layout */
+        ref[d] = (pixel)v;
+    }
+    xa_wave_sync();
+    /* ---- initAdiPattern(ALL_IDX): smoothing for 8x8 .. 32x32 ---- */
+    if (wantFilter && N >= 8)
+    {
+        bool strong = false;
+        if (strongSmoothing && N == 32)
+        {
+            const int threshold = 1 << (XA_DEPTH - 5);
+            int topLeft = ref[0], topLast = ref[N2], leftLast = ref[2 * N2];
+            strong = abs(topLeft + topLast - 2 * ref[32]) < threshold && abs(topLeft + leftLast - 2 * ref[N2 + 32]) < threshold;
+            if (strong)
+            {
+                int init = (topLeft << 6) + N, deltaL = leftLast - topLeft, deltaR = topLast - topLeft;
+                for (int i = lane; i <= 2 * N2; i += XA_WAVE)
+                {
+                    int v;
+                    if (i == 0) v = topLeft;
+                    else if (i == N2) v = topLast;
+                    else if (i == 2 * N2) v = leftLast;
+                    else if (i < N2) v = (init + deltaR * i) >> 6;
+                    else v = (init + deltaL * (i - N2)) >> 6;
+                    flt[i] = (pixel)v;
+                }
+            }
+        }
+        if (!strong) wave_intra_filter(ref, flt, N, lane);
+    }
+    xa_wave_sync();
+}
+
+/* writes one N x N prediction; s = neighbours in LDS.  keepTransposed: all-angles layout (intrapred.cpp:211-241) */
+XA_DEV void wave_intra_pred(const pixel* s, pixel* swapped, int cu, int mode, int bFilter, pixel* dst, int ds, bool keepTransposed, int lane)
+{
+    int log2N = cu + 2, N = 1 << log2N, N2 = 2 * N;
+    if (mode == 0)      /* planar: intrapred.cpp:90-104 */
+    {
+        const pixel* above = s + 1; const pixel* left = s + N2 + 1;
+        int topRight = above[N], bottomLeft = left[N];
+        for (int i = lane; i < N * N; i += XA_WAVE)
+        {
+            int y = i >> log2N, x = i & (N - 1);
+            dst[y * ds + x] = (pixel)(((N - 1 - x) * left[y] + (N - 1 - y) * above[x] + (x + 1) * topRight + (y + 1) * bottomLeft + N) >> (log2N + 1));
+        }
+        return;
+    }
+    if (mode == 1)      /* DC: intrapred.cpp:54-88 */
+    {
+        const pixel* above = s + 1; const pixel* left = s + N2 + 1;
+        int part = lane < N ? above[lane] + left[lane] : 0;
+        int dc = (xa_wave_sum(part) + N) / (2 * N);
+        for (int i = lane; i < N * N; i += XA_WAVE)
+        {
+            int y = i >> log2N, x = i & (N - 1);
+            int v = dc;
+            if (bFilter)
+            {
+                if (x == 0 && y == 0) v = (above[0] + left[0] + 2 * dc + 2) >> 2;
+                else if (y == 0) v = (above[x] + 3 * dc + 2) >> 2;
+                else if (x == 0) v = (left[y] + 3 * dc + 2) >> 2;
+            }
+            dst[y * ds + x] = (pixel)v;
+        }
+        return;
+    }
+    bool hor = mode < 18;
+    const pixel* nb = s;
+    if (hor)            /* mirror the neighbours: intrapred.cpp:114-124 */
+    {
+        for (int i = lane; i < N2; i += XA_WAVE)
+        {
+            swapped[1 + i] = s[N2 + 1 + i];
+            swapped[N2 + 1 + i] = s[1 + i];
+        }
+        if (lane == 0) swapped[0] = s[0];
+        xa_wave_sync();
+        nb = swapped;
+    }
+    int angOff = hor ? 10 - mode : mode - 26;
+    int angle = xa_tbl.angle[8 + angOff];
+    int invAngle = angle < 0 ? xa_tbl.invAngle[-angOff - 1] : 0;
+    bool flip = hor && !keepTransposed;
+    for (int i = lane; i < N * N; i += XA_WAVE)
+    {
+        int y = i >> log2N, x = i & (N - 1);
+        dst[y * ds + x] = flip ? ang_sample(nb, N, angle, invAngle, bFilter, x, y) : ang_sample(nb, N, angle, invAngle, bFilter, y, x);
+    }
+    xa_wave_sync();
+}
+
+
 /* ---- block metrics shared by the job-list and the fused TU kernels ---- */
 XA_DEV uint64_t wave_sse_pp(const pixel* a, int sa, const pixel* b, int sb, int size, int lane)     /* pixel.cpp:167-186 */
 {
