@@ -116,6 +116,66 @@ def intra_jobs(T, cur, ref):
     return np.concatenate(parts)
 
 
+def inter_cost_jobs(T, cur_idx, arena_base):
+    """merge-candidate scan of one frame (checkMerge2Nx2N_rd0_4): for every 2Nx2N CU 64..8 two candidates predicted from the
+    previous picture (uni-prediction, P slice) at the true motion and one quarter sample off it, measured with SA8D
+    (+ chroma SA8D for CUs >= 16).  Returns (jobs, arena_bytes)."""
+    parts, off = [], 0
+    for size in (64, 32, 16, 8):
+        x, y = cu_grid(size)
+        for cand in range(2):
+            j = np.zeros(len(x), T.MC_JOB_DT)
+            chroma = size >= 16
+            per = size * size + (size * size // 2 if chroma else 0)
+            base = arena_base + off + np.arange(len(x), dtype=np.int64) * per
+            j["dstY"], j["dstU"], j["dstV"] = base, base + size * size, base + size * size + size * size // 4
+            j["dstStride"], j["dstCStride"] = size, size // 2
+            j["x"], j["y"], j["cuX"], j["cuY"], j["w"], j["h"] = x, y, x, y, size, size
+            j["ref0"], j["ref1"] = cur_idx - 1, -1
+            j["mv0"][:, 0], j["mv0"][:, 1] = -8 + cand, -4 - cand
+            j["sliceType"], j["flags"], j["metric"], j["chroma_cost"] = 1, 3 if chroma else 1, 3, 1 if chroma else 0
+            off += len(x) * per
+            parts.append(j)
+    return np.concatenate(parts), off
+
+
+def intra_tu_jobs(T, cur, ref, arena_base):
+    """intra TU coding step of one frame: for every CU of size 32/16/8 one luma TU (mode varies with the position) and both
+    chroma TUs (DC / planar), neighbours from the previous picture standing in for the reconstruction"""
+    stride, stride_c = W + 2 * MARGIN_X, W // 2 + MARGIN_X
+    org, org_c = MARGIN_Y * stride + MARGIN_X, (MARGIN_Y // 2) * stride_c + MARGIN_X // 2
+    parts, off = [], 0
+    for size in (32, 16, 8):
+        x, y = cu_grid(size)
+        left, above = x > 0, y > 0
+        above_right = above & (x + 2 * size <= W) & (((x // size) & 1) == 0)
+        for plane, (n, st, o, qp) in enumerate(((size, stride, org, QP), (size // 2, stride_c, org_c, 31), (size // 2, stride_c, org_c, 31))):
+            u = n // 4
+            ones = lambda k: np.uint64((1 << k) - 1)
+            mask = np.zeros(len(x), np.uint64)
+            mask |= np.where(left, ones(u) << np.uint64(u), np.uint64(0))
+            mask |= np.where(left & above, np.uint64(1) << np.uint64(2 * u), np.uint64(0))
+            mask |= np.where(above, ones(u) << np.uint64(2 * u + 1), np.uint64(0))
+            mask |= np.where(above_right, ones(u) << np.uint64(3 * u + 1), np.uint64(0))
+            sx, sy = (x, y) if plane == 0 else (x // 2, y // 2)
+            j = np.zeros(len(x), T.INTRA_TU_JOB_DT)
+            t = j["tu"]
+            per = n * n * 5
+            base = arena_base + off + np.arange(len(x), dtype=np.int64) * per
+            t["fenc"] = cur[plane] + o + sy * st + sx
+            t["pred"] = 0
+            t["recon"], t["coeff"], t["resi"] = base, base + n * n, base + 3 * n * n
+            t["fenc_stride"], t["pred_stride"], t["resi_stride"], t["recon_stride"] = st, n, n, n
+            t["log2"], t["ttype"], t["intra"], t["slice"], t["qp"], t["signhide"] = int(np.log2(n)), plane, 1, 1, qp, 1
+            t["dir"] = ((x // size) * 7 + (y // size) * 3) % 35 if plane == 0 else 1 - (plane & 1)
+            j["tu"] = t
+            j["nb"] = ref[plane] + o + sy * st + sx
+            j["avail"], j["nb_stride"], j["strong"] = mask, st, 1
+            off += len(x) * per
+            parts.append(j)
+    return np.concatenate(parts), off
+
+
 def frame_jobs(T, refdist):
     """every 2Nx2N PU of every CTU that lies inside the picture, for one reference at temporal distance refdist"""
     jobs = []
@@ -193,8 +253,124 @@ def cpu_baseline(T, frames, packed_by_ref, budget_s=20.0):
         if spent > budget_s / 3:
             break
     secs_per_frame += spent * len(tj) / done; notes.append("%d/%d TU chains %.1fs" % (done, len(tj), spent))
+    # coefficient bits of the TU chains that were run
+    ndone = done
+    ctx0 = np.zeros(160, np.uint8)
+    getattr(L.lib, L.prefix + "entropy_reset")(1, QP, T._ptr(ctx0))
+    ctx_out = np.zeros((ndone, 160), np.uint8)
+    cb = np.zeros(ndone, T.COEFF_BITS_JOB_DT)
+    cb["coeff"], cb["ctx_in"], cb["ctx_out"] = tj["coeff"][:ndone], ctx0.ctypes.data, ctx_out.ctypes.data + np.arange(ndone, dtype=np.int64) * 160
+    cb["log2"], cb["ttype"], cb["signhide"] = tj["log2"][:ndone], tj["ttype"][:ndone], 1
+    bits = np.zeros(ndone, np.uint64)
+    fn = getattr(L.lib, L.prefix + "coeff_bits_batch")
+    t0 = time.perf_counter()
+    fn(T._ptr(cb), ndone, T._ptr(bits))
+    spent = time.perf_counter() - t0
+    secs_per_frame += spent * len(tj) / ndone; notes.append("%d/%d coefficient codings %.1fs" % (ndone, len(tj), spent))
+    # merge-candidate costs
+    stride_c = W // 2 + MARGIN_X
+    origin_c = (MARGIN_Y // 2) * stride_c + MARGIN_X // 2
+    ic, nbytes = inter_cost_jobs(T, 1, 0)
+    icarena = np.zeros(nbytes, np.uint8)
+    for f in ("dstY", "dstU", "dstV"):
+        ic[f] += icarena.ctypes.data
+    ic = np.ascontiguousarray(ic[np.random.default_rng(1).permutation(len(ic))])
+    pl = np.array([hprev.ctypes.data + origin, hprev.ctypes.data + ysz + origin_c, hprev.ctypes.data + ysz + csz + origin_c], np.uint64)
+    fp = np.array([hcur.ctypes.data + origin, hcur.ctypes.data + ysz + origin_c, hcur.ctypes.data + ysz + csz + origin_c], np.uint64)
+    cost = np.zeros((len(ic), 2), np.uint32)
+    fn = getattr(L.lib, L.prefix + "inter_cost_batch")
+    done, spent = 0, 0.0
+    for k in range(0, len(ic), 4096):
+        t0 = time.perf_counter()
+        fn(T._ptr(pl), C.c_int64(stride), C.c_int64(stride_c), W, H, T._ptr(ic[k:k + 4096]), len(ic[k:k + 4096]), T._ptr(fp), C.c_int64(stride), C.c_int64(stride_c),
+           T.off(cost.view(np.uint8).ravel(), 8 * k))
+        spent += time.perf_counter() - t0; done += len(ic[k:k + 4096])
+        if spent > budget_s / 4:
+            break
+    secs_per_frame += spent * len(ic) / done; notes.append("%d/%d merge-candidate costs %.1fs" % (done, len(ic), spent))
+    # intra TU steps
+    it, nbytes = intra_tu_jobs(T, addr(hcur), addr(hprev), 0)
+    itarena = np.zeros(nbytes, np.uint8)
+    for f in ("recon", "coeff", "resi"):
+        it["tu"][f] += itarena.ctypes.data
+    it = np.ascontiguousarray(it[np.random.default_rng(2).permutation(len(it))])
+    res = np.zeros(len(it), T.TU_RESULT_DT)
+    fn = getattr(L.lib, L.prefix + "intra_tu_chain_batch")
+    done, spent = 0, 0.0
+    for k in range(0, len(it), 4096):
+        t0 = time.perf_counter()
+        fn(T._ptr(it[k:k + 4096]), None, len(it[k:k + 4096]), T.off(res.view(np.uint8), 32 * k))
+        spent += time.perf_counter() - t0; done += len(it[k:k + 4096])
+        if spent > budget_s / 4:
+            break
+    secs_per_frame += spent * len(it) / done; notes.append("%d/%d intra TU steps %.1fs" % (done, len(it), spent))
     return {"value": 1.0 / secs_per_frame, "unit": "frames/s", "cores": 1, "kind": kind,
             "sample": "one %dx%d frame of the same workload on one core: " % (W, H) + ", ".join(notes) + "; parts cut at their budget are extrapolated"}
+
+
+def sample_more(T, orc, frames, last, d_ic, d_ic_out, d_ic_arena, d_it, d_it_out, d_it_arena, d_cb, d_bits, d_ctx_out, d_arena, ctx0, d_pics, planes):
+    """oracle checks of samples of the merge-candidate costs, intra TU steps and coefficient bits of the last timed frame: the jobs'
+    device addresses are rebased onto host copies of the pictures and arenas and run through the oracle's batch forms"""
+    stride, stride_c = W + 2 * MARGIN_X, W // 2 + MARGIN_X
+    origin, origin_c = MARGIN_Y * stride + MARGIN_X, (MARGIN_Y // 2) * stride_c + MARGIN_X // 2
+    ysz, csz = frames[0][0].size, frames[0][1].size
+    host = {k: np.concatenate([f.ravel() for f in frames[k]]) for k in (last, last - 1)}
+    dev = {k: d_pics[k].data_ptr() for k in (last, last - 1)}
+    ok, checked = True, 0
+
+    def rebase(a, which):
+        return a - dev[which] + host[which].ctypes.data
+
+    # merge-candidate costs
+    ic = d_ic.cpu().numpy().view(T.MC_JOB_DT)
+    sel = np.arange(0, len(ic), 1009)
+    jb = ic[sel].copy()
+    buf = np.zeros((len(sel), 64 * 64 * 2), np.uint8)
+    jb["dstY"] = buf.ctypes.data + np.arange(len(sel)) * buf.shape[1]
+    jb["dstU"] = jb["dstY"] + 64 * 64; jb["dstV"] = jb["dstY"] + 64 * 64 + 32 * 32
+    jb["ref0"] = 0
+    pl = np.array([host[last - 1].ctypes.data + origin, host[last - 1].ctypes.data + ysz + origin_c, host[last - 1].ctypes.data + ysz + csz + origin_c], np.uint64)
+    fp = np.array([host[last].ctypes.data + origin, host[last].ctypes.data + ysz + origin_c, host[last].ctypes.data + ysz + csz + origin_c], np.uint64)
+    want = np.zeros((len(sel), 2), np.uint32)
+    orc.lib.orc_inter_cost_batch(T._ptr(pl), C.c_int64(stride), C.c_int64(stride_c), W, H, T._ptr(jb), len(sel), T._ptr(fp), C.c_int64(stride), C.c_int64(stride_c), T._ptr(want))
+    got = d_ic_out.cpu().numpy().view(np.uint32).reshape(-1, 2)[sel]
+    ok &= bool(np.array_equal(want, got)); checked += len(sel)
+    # intra TU steps
+    it = d_it.cpu().numpy().view(T.INTRA_TU_JOB_DT)
+    sel = np.arange(0, len(it), 997)
+    jb = it[sel].copy()
+    t = jb["tu"]
+    t["fenc"] = rebase(t["fenc"].astype(np.int64), last).astype(np.uint64)
+    out = np.zeros((len(sel), 32 * 32 * 5), np.uint8)
+    n2 = (1 << t["log2"].astype(np.int64)) ** 2
+    t["recon"] = out.ctypes.data + np.arange(len(sel)) * out.shape[1]
+    t["coeff"] = t["recon"] + n2; t["resi"] = t["recon"] + 3 * n2
+    jb["tu"] = t
+    jb["nb"] = rebase(jb["nb"].astype(np.int64), last - 1).astype(np.uint64)
+    res = np.zeros(len(sel), T.TU_RESULT_DT)
+    orc.lib.orc_intra_tu_chain_batch(T._ptr(jb), None, len(sel), T._ptr(res))
+    gres = d_it_out.cpu().numpy().view(T.TU_RESULT_DT)[sel]
+    arena = d_it_arena.cpu().numpy()
+    for k, i in enumerate(sel):
+        ok &= bool(res[k].tobytes() == gres[k].tobytes())
+        o = int(it[i]["tu"]["recon"]) - d_it_arena.data_ptr()
+        ok &= bool(np.array_equal(arena[o:o + 5 * int(n2[k])], out[k, :5 * int(n2[k])]))
+    checked += len(sel)
+    # coefficient bits (on the levels the TU chain kernel has just written)
+    cb = d_cb.cpu().numpy().view(T.COEFF_BITS_JOB_DT)
+    sel = np.arange(0, len(cb), 991)
+    jb = cb[sel].copy()
+    tarena = d_arena.cpu().numpy()
+    ctx_in = np.ascontiguousarray(ctx0); ctx_out = np.zeros((len(sel), 160), np.uint8)
+    jb["coeff"] = jb["coeff"] - np.uint64(d_arena.data_ptr()) + np.uint64(tarena.ctypes.data)
+    jb["ctx_in"] = ctx_in.ctypes.data
+    jb["ctx_out"] = ctx_out.ctypes.data + np.arange(len(sel)) * 160
+    bits = np.zeros(len(sel), np.uint64)
+    orc.lib.orc_coeff_bits_batch(T._ptr(jb), len(sel), T._ptr(bits))
+    ok &= bool(np.array_equal(bits, d_bits.cpu().numpy().view(np.uint64)[sel]))
+    ok &= bool(np.array_equal(ctx_out[:, :T.CTX_COUNT], d_ctx_out.cpu().numpy().reshape(-1, 160)[sel][:, :T.CTX_COUNT]))
+    checked += len(sel)
+    return ok, checked
 
 
 def measured_traffic(kernel="k_me_search"):
@@ -280,12 +456,43 @@ def main():
     in_n = 1 << ij["log2"].astype(np.int64)
     in_bytes = int((in_n * in_n + 4 * in_n + 1).sum() + n_in * (40 + 140))
 
+    # ---- merge-candidate costs, intra TU steps, coefficient bits ----
+    d_planetab = me.upload(np.array([[p[0] + origin, p[1] + (MARGIN_Y // 2) * (W // 2 + MARGIN_X) + MARGIN_X // 2,
+                                      p[2] + (MARGIN_Y // 2) * (W // 2 + MARGIN_X) + MARGIN_X // 2] for p in planes], np.uint64).ravel())
+    ic0, ic_bytes_arena = inter_cost_jobs(T, curs[0], 0)
+    d_ic_arena = torch.zeros(ic_bytes_arena, dtype=torch.uint8, device="cuda")
+    it0, it_bytes_arena = intra_tu_jobs(T, planes[curs[0]], planes[curs[0] - 1], 0)
+    d_it_arena = torch.zeros(it_bytes_arena, dtype=torch.uint8, device="cuda")
+    d_ic, d_it, d_fenctab = {}, {}, {}
+    for cur in curs:
+        d_ic[cur] = me.upload(inter_cost_jobs(T, cur, d_ic_arena.data_ptr())[0])
+        d_it[cur] = me.upload(intra_tu_jobs(T, planes[cur], planes[cur - 1], d_it_arena.data_ptr())[0])
+        d_fenctab[cur] = d_planetab.data_ptr() + cur * 24
+    n_ic, n_it = len(ic0), len(it0)
+    d_ic_out = torch.zeros(n_ic * 2, dtype=torch.int32, device="cuda")
+    d_it_out = torch.zeros(n_it * T.TU_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda")
+    ic_sz = ic0["w"].astype(np.int64) ** 2
+    ic_bytes = int((ic_sz * np.where(ic0["chroma_cost"] > 0, 1.5, 1.0) * 3).sum() + n_ic * (96 + 8))     # ref read + pred write + source read
+    it_n = 1 << it0["tu"]["log2"].astype(np.int64)
+    it_bytes = int((it_n * it_n * (1 + 1 + 2 + 2) + 4 * it_n + 1).sum() + n_it * (96 + 32))
+    ctx0 = np.zeros(160, np.uint8)
+    lib.x265amd_entropy_reset(1, QP, T._ptr(ctx0))
+    d_ctx0 = me.upload(ctx0)
+    d_ctx_out = torch.zeros(n_tu * 160, dtype=torch.uint8, device="cuda")
+    tjv = tu_jobs(T, planes[curs[0]], planes[curs[0] - 1], d_arena.data_ptr())[0]
+    cb = np.zeros(n_tu, T.COEFF_BITS_JOB_DT)
+    cb["coeff"], cb["ctx_in"], cb["ctx_out"] = tjv["coeff"], d_ctx0.data_ptr(), d_ctx_out.data_ptr() + np.arange(n_tu, dtype=np.int64) * 160
+    cb["log2"], cb["ttype"], cb["intra"], cb["dir"], cb["signhide"] = tjv["log2"], tjv["ttype"], 0, 0, 1
+    d_cb = me.upload(cb)
+    d_bits = torch.zeros(n_tu, dtype=torch.int64, device="cuda")
+    cb_bytes = int((tu_n2 * 2).sum() + n_tu * (32 + 8 + 320))
+
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     import __graft_entry__ as entry
     fs = entry.load_package().frame_shard
     ring, gather = fs.ReferenceRing(depth=NUM_REFS * max(world, 1) + world), [None]
-    NK = 3
+    NK = 6
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(NK + 1)] for _ in range(args.steps)]
 
     def step(k, marks=None):
@@ -302,6 +509,17 @@ def main():
         rc = lib.x265amd_tu_chain(sp, C.c_void_p(d_tu[cur].data_ptr()), n_tu, C.c_void_p(d_tu_out.data_ptr()))
         assert rc == 0, lib.x265amd_last_error()
         if marks: marks[3].record(stream)
+        rc = lib.x265amd_inter_cost(sp, C.c_void_p(d_planetab.data_ptr()), C.c_int64(stride), C.c_int64(W // 2 + MARGIN_X), W, H,
+                                    C.c_void_p(d_ic[cur].data_ptr()), n_ic, C.c_void_p(d_fenctab[cur]), C.c_int64(stride), C.c_int64(W // 2 + MARGIN_X),
+                                    C.c_void_p(d_ic_out.data_ptr()))
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[4].record(stream)
+        rc = lib.x265amd_intra_tu_chain(sp, C.c_void_p(d_it[cur].data_ptr()), None, n_it, C.c_void_p(d_it_out.data_ptr()))
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[5].record(stream)
+        rc = lib.x265amd_coeff_bits(sp, C.c_void_p(d_cb.data_ptr()), n_tu, C.c_void_p(d_bits.data_ptr()))
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[6].record(stream)
         if world > 1:
             # exchange step of the frame-parallel design: every rank publishes the picture it just finished so that all
             # ranks hold it as a reference (here the source stands in for the reconstruction)
@@ -366,8 +584,12 @@ def main():
             orc.lib.orc_init_adi_pattern(T.off(host[1], int(ijb[i]["recon"]) - bases[1]), C.c_int64(stride), int(ijb[i]["log2"]), T._ptr(flags), 1, -1, T._ptr(rb), T._ptr(fb))
             orc.lib.orc_intra_scan(T.off(host[0], int(ijb[i]["fenc"]) - bases[0]), C.c_int64(stride), int(ijb[i]["log2"]), T._ptr(rb), T._ptr(fb), T._ptr(sa))
             in_ok &= bool(np.array_equal(sa, ires[i])); checked += 1
-        names = ("k_me_search", "k_intra_scan", "k_tu_chain")
-        algb = (me_bytes, in_bytes, tu_bytes)
+        # merge-candidate costs, intra TU steps and coefficient bits: samples through the oracle's batch forms on host copies
+        more_ok = sample_more(T, orc, frames, last, d_ic[last], d_ic_out, d_ic_arena, d_it[last], d_it_out, d_it_arena, d_cb, d_bits, d_ctx_out,
+                              d_arena, ctx0, d_pics, planes)
+        checked += more_ok[1]
+        names = ("k_me_search", "k_intra_scan", "k_tu_chain", "k_motion_compensation<cost>", "k_intra_tu_chain", "k_coeff_bits")
+        algb = (me_bytes, in_bytes, tu_bytes, ic_bytes, it_bytes, cb_bytes)
         dom = int(np.argmax(kms))
         line = {
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
@@ -376,8 +598,10 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("%dx%d 8-bit 4:2:0 synthetic, --preset medium parameters: analysis hot-path kernels of one frame = " % (W, H)) + (
                                    "%d motion searches (every 2Nx2N PU 64..8 of every CTU x 3 refs; hex, merange 57, subme 2) + %d intra 35-mode scans "
-                                   "(CUs 32/16/8) + %d TU residual chains (luma + 2 chroma per CU 32/16/8; dct, quant, sign hiding, dequant, idct, recon, sse, psy); "
-                                   "NOT a full encode (no mode decision / entropy coding yet)") % (len(packed), n_in, n_tu),
+                                   "(CUs 32/16/8) + %d TU residual chains (luma + 2 chroma per CU 32/16/8; dct, quant, sign hiding, dequant, idct, recon, sse, psy) + "
+                                   "%d merge-candidate costs (2 per CU 64..8: motion compensation + SA8D incl. chroma) + %d intra TU steps (neighbours, prediction, "
+                                   "residual chain; luma + 2 chroma per CU 32/16/8) + %d bits-only coefficient codings (one per TU chain); "
+                                   "NOT a full encode (no mode decision loop / bitstream yet)") % (len(packed), n_in, n_tu, n_ic, n_it, n_tu),
                        "frames_per_step_per_gpu": 1, "parallelism": "frame-per-gpu x%d" % world},
             "kernels": {names[i]: {"ms": kms[i], "algorithmic_bytes": algb[i], "GB/s": algb[i] / (kms[i] * 1e-3) / 1e9} for i in range(NK)},
             "roofline": {"bound": "hbm", "achieved": algb[dom] / (kms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -388,8 +612,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(T, frames, packed_unordered)
         else:
             line["cpu_baseline"] = None
-        line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(ok and tu_ok and in_ok),
-                                 "me": bool(ok), "tu_chain": bool(tu_ok), "intra_scan": bool(in_ok)}
+        line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(ok and tu_ok and in_ok and more_ok[0]),
+                                 "me": bool(ok), "tu_chain": bool(tu_ok), "intra_scan": bool(in_ok), "inter_cost_intra_tu_coeff_bits": bool(more_ok[0])}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -245,7 +245,7 @@ int x265amd_me_search(x265amd_me_ctx* ctx, void* stream, const x265amd_pixel* d_
 
 /* --- residual (transform unit) path: Quant::transformNxN / invtransformNxN (reference: source/common/quant.cpp:397-605,
  * sign-bit hiding :247-395) and the per-TU measurement of the residual quad-tree (source/encoder/search.cpp:3276-3330).
- * Flat scaling lists, no RDOQ / transform skip / bypass / noise reduction (the medium preset's configuration).
+ * Flat scaling lists, no transform skip / bypass / noise reduction; plain quantisation here, RDOQ through x265amd_tu_chain_rdoq below.
  * qp_scaled = QP + 6*(depth-8) after the chroma mapping of Quant::setQPforQuant (quant.cpp:221-244);
  * slice_type: 0 B, 1 P, 2 I; ttype: 0 luma, 1 Cb, 2 Cr; dir_mode: intra direction that selects the coefficient scan
  * (CUData::getTUEntropyCodingParameters, cudata.cpp:2059-2100). */

@@ -927,3 +927,17 @@ void orc_tu_chain_rdoq(const pixel* fenc, intptr_t fencStride, const pixel* pred
         out[3] = out[1]; out[4] = out[2];
     }
 }
+
+/* batch form for bench.py's cpu_baseline leg (record of include/x265amd.h, x265amd_coeff_bits_job; HOST addresses) */
+typedef struct { uint64_t coeff, ctxIn, ctxOut; uint8_t log2, ttype, intra, dir, signhide, reserved[3]; } PackedCoeffBitsJob;
+int orc_coeff_bits_batch(const PackedCoeffBitsJob* jobs, int n, uint64_t* bits)
+{
+    for (int i = 0; i < n; i++)
+    {
+        uint8_t ctx[160];
+        memcpy(ctx, (const void*)jobs[i].ctxIn, 160);
+        bits[i] = orc_code_coeff_bits((const int16_t*)jobs[i].coeff, jobs[i].log2, jobs[i].ttype, jobs[i].intra, jobs[i].dir, jobs[i].signhide, ctx);
+        memcpy((void*)jobs[i].ctxOut, ctx, 160);
+    }
+    return n;
+}

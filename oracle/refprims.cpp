@@ -334,6 +334,30 @@ uint64_t ref_code_coeff_bits(const int16_t* coeff, int log2TrSize, int ttype, in
     return e->entropy.m_fracBits;
 }
 
+struct PackedCoeffBitsJob { uint64_t coeff, ctxIn, ctxOut; uint8_t log2, ttype, intra, dir, signhide, reserved[3]; };
+int ref_coeff_bits_batch(const PackedCoeffBitsJob* jobs, int n, uint64_t* bits)
+{
+    TuEnv* e = tuEnv();
+    for (int i = 0; i < n; i++)
+    {
+        const PackedCoeffBitsJob& j = jobs[i];
+        const int16_t* c = (const int16_t*)j.coeff;
+        int nz = 0;
+        for (int k = 0; k < (1 << (2 * j.log2)); k++) nz |= c[k];
+        memcpy((void*)j.ctxOut, (const void*)j.ctxIn, 160);
+        bits[i] = 0;
+        if (!nz) continue;              /* the encoder only codes TUs with cbf != 0 */
+        e->set(j.ttype, j.intra, j.dir, 1, 30, j.signhide);
+        memcpy(e->entropy.m_contextState, (const void*)j.ctxIn, MAX_OFF_CTX_MOD);
+        e->entropy.zeroFract();
+        e->entropy.resetBits();
+        e->entropy.codeCoeffNxN(e->cu, c, 0, j.log2, (TextType)j.ttype);
+        memcpy((void*)j.ctxOut, e->entropy.m_contextState, MAX_OFF_CTX_MOD);
+        bits[i] = e->entropy.m_fracBits;
+    }
+    return n;
+}
+
 /* Quant::invtransformNxN (quant.cpp:543-605) */
 void ref_invtransform_tu(int16_t* resi, intptr_t resiStride, const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int qpScaled, uint32_t numSig)
 {
