@@ -403,6 +403,16 @@ int x265amd_inter_cost(void* stream, const uint64_t* d_planes, intptr_t stride, 
                        const x265amd_mc_job* d_jobs, int n, const uint64_t* d_fenc_planes, intptr_t fenc_stride, intptr_t fenc_cstride,
                        uint32_t* d_cost);
 
+/* --- reference-plane production.  d_pic / d_src / d_dst: device address of sample (0,0) of a
+ * padded plane with at least marginX samples left/right and marginY rows above/below.
+ * x265amd_extend_pic_border = extendPicBorder (source/common/pixel.cpp:1044-1058): the margins repeat the nearest picture sample.
+ * x265amd_weight_plane = MotionReference::applyWeight over all rows (source/encoder/reference.cpp:109-185): d_dst receives the
+ * weighted copy (weight_pp_c, pixel.cpp:519-538, with w = inputWeight, offset = inputOffset << (depth - 8), shift =
+ * log2WeightDenom) of the picture area and its margins -- the plane MotionReference::fpelPlane[] points to when wtPresent. */
+int x265amd_extend_pic_border(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY);
+int x265amd_weight_plane(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, intptr_t stride, int width, int height,
+                         int marginX, int marginY, int inputWeight, int inputOffset, int log2WeightDenom);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

@@ -312,3 +312,33 @@ int orc_inter_cost_batch(const uint64_t* planes, intptr_t stride, intptr_t cstri
     }
     return n;
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * reference-plane production: extendPicBorder (pixel.cpp:1044-1058) and MotionReference::applyWeight over all rows
+ * (reference.cpp:109-185; weight_pp_c pixel.cpp:519-538)
+ * ------------------------------------------------------------------------------------------------------- */
+void orc_extend_pic_border(pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < marginX; x++)
+        {
+            pic[y * stride - marginX + x] = pic[y * stride];
+            pic[y * stride + width + x] = pic[y * stride + width - 1];
+        }
+    for (int y = 0; y < marginY; y++)
+    {
+        memcpy(pic - marginX - (y + 1) * stride, pic - marginX, (size_t)(width + 2 * marginX) * sizeof(pixel));
+        memcpy(pic - marginX + (height + y) * stride, pic - marginX + (height - 1) * stride, (size_t)(width + 2 * marginX) * sizeof(pixel));
+    }
+}
+
+void orc_weight_plane(const pixel* src, pixel* dst, intptr_t stride, int width, int height, int marginX, int marginY, int inputWeight, int inputOffset, int log2Denom)
+{
+    const int correction = IF_INTERNAL_PREC - ORC_DEPTH;
+    const int offset = inputOffset * (1 << (ORC_DEPTH - 8));
+    const int round = (log2Denom ? 1 << (log2Denom - 1) : 0) << correction, shift = log2Denom + correction;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            dst[y * stride + x] = clip_pix(((inputWeight * ((int)src[y * stride + x] << correction) + round) >> shift) + offset);
+    orc_extend_pic_border(dst, stride, width, height, marginX, marginY);
+}

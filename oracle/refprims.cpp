@@ -8,6 +8,7 @@
  * The product (x265-amod_amd/) never links, loads or calls anything from here. */
 #include "common.h"
 #include "primitives.h"
+#include "reference.h"
 #include "constants.h"
 #include "lowres.h"
 #include "bitcost.h"
@@ -562,6 +563,40 @@ int ref_motion_compensation_batch(const uint64_t* planes, intptr_t stride, intpt
             }
     }
     return n;
+}
+
+/* ---- reference-plane production: extendPicBorder (common/pixel.cpp:1044-1058) and the reference's own MotionReference
+ * (encoder/reference.cpp:51-185) applied to all rows of a plane ---- */
+void ref_extend_pic_border(pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    ensure();
+    extendPicBorder(pic, stride, width, height, marginX, marginY);
+}
+void ref_weight_plane(const pixel* src, pixel* dst, intptr_t stride, int width, int height, int marginX, int marginY, int inputWeight, int inputOffset, int log2Denom)
+{
+    ensure();
+    x265_param param;
+    memset(&param, 0, sizeof(param));
+    param.maxCUSize = 64; param.maxSlices = 1; param.subpelRefine = 2; param.internalCsp = X265_CSP_I420;
+    PicYuv pic;
+    pic.m_param = &param;
+    pic.m_picOrg[0] = (pixel*)src; pic.m_picBuf[0] = (pixel*)src - marginY * stride - marginX;
+    pic.m_stride = stride; pic.m_picWidth = width; pic.m_picHeight = height;
+    pic.m_lumaMarginX = marginX; pic.m_lumaMarginY = marginY; pic.m_picCsp = X265_CSP_I420;
+    pic.m_hChromaShift = pic.m_vChromaShift = 1;
+    WeightParam wp[3];
+    memset(wp, 0, sizeof(wp));
+    wp[0].inputWeight = inputWeight; wp[0].inputOffset = inputOffset; wp[0].log2WeightDenom = log2Denom; wp[0].wtPresent = 1;
+    {
+        MotionReference mref;
+        mref.init(&pic, wp, param);
+        uint32_t numRows = (height + 63) / 64;
+        mref.applyWeight(numRows - 1, numRows, numRows, 0);
+        for (int y = -marginY; y < height + marginY; y++)
+            memcpy(dst + y * stride - marginX, mref.fpelPlane[0] + y * stride - marginX, (width + 2 * marginX) * sizeof(pixel));
+    }
+    pic.m_picOrg[0] = pic.m_picBuf[0] = NULL;     /* the PicYuv never owned the samples */
+    pic.m_param = NULL;
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

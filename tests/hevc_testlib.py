@@ -1315,3 +1315,47 @@ def intra_tu_run_hip(L, cases):
     assert rc == 0
     torch.cuda.synchronize()
     return intra_tu_unpack(cases, d_out.cpu().numpy().view(TU_RESULT_DT), d_arena.cpu().numpy(), per)
+
+
+# ---- reference-plane production: extendPicBorder / MotionReference::applyWeight ----
+def plane_cases(depth, seed):
+    """(plane array incl. margins with garbage in the margins, stride, w, h, mx, my, weight, offset, denom)"""
+    rng = np.random.default_rng(seed)
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    out = []
+    for (w, h, mx, my) in ((200, 120, 96, 80), (96, 72, 48, 40), (64, 136, 16, 8), (130, 70, 32, 24), (352, 288, 96, 80)):
+        stride = w + 2 * mx
+        buf = rng.integers(0, pmax + 1, (h + 2 * my) * stride).astype(dt)
+        denom = int(rng.integers(0, 8))
+        out.append(dict(buf=buf, stride=stride, w=w, h=h, mx=mx, my=my, org=my * stride + mx,
+                        weight=int(rng.integers(1, 128)) if denom else 1, offset=int(rng.integers(-20, 21)), denom=denom))
+    return out
+
+
+def plane_run_host(L, cases):
+    res = []
+    fe = getattr(L.lib, L.prefix + "extend_pic_border"); fw = getattr(L.lib, L.prefix + "weight_plane")
+    for c in cases:
+        a = c["buf"].copy()
+        fe(off(a, c["org"]), C.c_int64(c["stride"]), c["w"], c["h"], c["mx"], c["my"])
+        b = np.zeros_like(c["buf"])
+        fw(off(c["buf"], c["org"]), off(b, c["org"]), C.c_int64(c["stride"]), c["w"], c["h"], c["mx"], c["my"], c["weight"], c["offset"], c["denom"])
+        res.append((a, b))
+    return res
+
+
+def plane_run_hip(L, cases):
+    import torch
+    res = []
+    for c in cases:
+        isz = c["buf"].itemsize
+        d_a = torch.from_numpy(c["buf"].view(np.uint8).copy()).cuda()
+        d_s = torch.from_numpy(c["buf"].view(np.uint8).copy()).cuda()
+        d_b = torch.zeros_like(d_s)
+        assert L.lib.x265amd_extend_pic_border(None, C.c_void_p(d_a.data_ptr() + c["org"] * isz), C.c_int64(c["stride"]), c["w"], c["h"], c["mx"], c["my"]) == 0
+        assert L.lib.x265amd_weight_plane(None, C.c_void_p(d_s.data_ptr() + c["org"] * isz), C.c_void_p(d_b.data_ptr() + c["org"] * isz), C.c_int64(c["stride"]),
+                                          c["w"], c["h"], c["mx"], c["my"], c["weight"], c["offset"], c["denom"]) == 0
+        torch.cuda.synchronize()
+        res.append((d_a.cpu().numpy().view(c["buf"].dtype), d_b.cpu().numpy().view(c["buf"].dtype)))
+    return res

@@ -1,0 +1,71 @@
+/* Reference-plane production (include/x265amd.h: x265amd_extend_pic_border, x265amd_weight_plane).
+ *
+ *  - extendPicBorder (reference: source/common/pixel.cpp:1044-1058 with extendCURowColBorder, source/common/ipfilter.cpp:500-518):
+ *    the margins of a padded plane repeat the nearest picture sample;
+ *  - MotionReference::applyWeight over all rows (source/encoder/reference.cpp:109-185): the weighted copy of a reconstructed
+ *    plane that motion estimation / compensation read when weighted prediction is on (weight_pp_c, pixel.cpp:519-538), with its
+ *    margins.
+ * HBM-bound: every output sample is one clamped read and one store, 16 samples per thread where alignment allows it is not
+ * worth more here -- a 1080p plane is 2.6 MB, i.e. a few microseconds at HBM speed; launches are row-parallel and coalesced.
+ */
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+
+__global__ __launch_bounds__(256) void k_extend_border(pixel* pic, long stride, int width, int height, int marginX, int marginY)
+{
+    const int y = (int)blockIdx.x - marginY;                /* padded row */
+    const int cy = min(max(y, 0), height - 1);
+    const pixel* srcRow = pic + (long)cy * stride;
+    pixel* dstRow = pic + (long)y * stride;
+    if (y >= 0 && y < height)
+    {
+        const pixel l = srcRow[0], r = srcRow[width - 1];
+        for (int i = threadIdx.x; i < 2 * marginX; i += blockDim.x)
+        {
+            if (i < marginX) dstRow[-marginX + i] = l;
+            else dstRow[width + (i - marginX)] = r;
+        }
+        return;
+    }
+    for (int x = -marginX + (int)threadIdx.x; x < width + marginX; x += blockDim.x)
+        dstRow[x] = srcRow[min(max(x, 0), width - 1)];
+}
+
+__global__ __launch_bounds__(256) void k_weight_plane(const pixel* src, pixel* dst, long stride, int width, int height, int marginX, int marginY,
+                                                      int w0, int round, int shift, int offset)
+{
+    const int y = (int)blockIdx.x - marginY;
+    const int cy = min(max(y, 0), height - 1);
+    const pixel* srcRow = src + (long)cy * stride;
+    pixel* dstRow = dst + (long)y * stride;
+    const int correction = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    for (int x = -marginX + (int)threadIdx.x; x < width + marginX; x += blockDim.x)
+    {
+        const int v = (int)srcRow[min(max(x, 0), width - 1)] << correction;
+        dstRow[x] = xa_clip_pixel(((w0 * v + round) >> shift) + offset);
+    }
+}
+
+extern "C" int x265amd_extend_pic_border(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    if (!d_pic || width <= 0 || height <= 0 || marginX < 0 || marginY < 0) return xa_fail(X265AMD_EINVAL, "x265amd_extend_pic_border: bad arguments");
+    hipLaunchKernelGGL(k_extend_border, dim3(height + 2 * marginY), dim3(256), 0, (hipStream_t)stream, (pixel*)d_pic, (long)stride, width, height, marginX, marginY);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_weight_plane(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, intptr_t stride, int width, int height,
+                                    int marginX, int marginY, int inputWeight, int inputOffset, int log2WeightDenom)
+{
+    if (!d_src || !d_dst || width <= 0 || height <= 0 || marginX < 0 || marginY < 0) return xa_fail(X265AMD_EINVAL, "x265amd_weight_plane: bad arguments");
+    /* MotionReference::init (reference.cpp:98-101) and the call in applyWeight (:154-156) */
+    const int correction = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    const int offset = inputOffset * (1 << (XA_DEPTH - 8));
+    const int round = (log2WeightDenom ? 1 << (log2WeightDenom - 1) : 0) << correction;
+    hipLaunchKernelGGL(k_weight_plane, dim3(height + 2 * marginY), dim3(256), 0, (hipStream_t)stream, (const pixel*)d_src, (pixel*)d_dst, (long)stride,
+                       width, height, marginX, marginY, inputWeight, round, log2WeightDenom + correction, offset);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
