@@ -413,6 +413,26 @@ int x265amd_extend_pic_border(void* stream, x265amd_pixel* d_pic, intptr_t strid
 int x265amd_weight_plane(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, intptr_t stride, int width, int height,
                          int marginX, int marginY, int inputWeight, int inputOffset, int log2WeightDenom);
 
+/* --- in-loop deblocking of a picture: Deblock::deblockCTU over all CTUs (reference:
+ * source/common/deblock.cpp:37-510; sample filters deblock.cpp:268-310 and source/common/loopfilter.cpp:140-180), 4:2:0.
+ * The picture's coding data is one record per 4x4 unit in raster order ((width/4) x (height/4); what the per-CTU CUData arrays
+ * hold in z-order).  ref[l]: identity of the picture referenced through list l (any numbering under which equal values mean the
+ * same picture, as the reference compares Frame pointers), -1 when the list is unused. */
+#define X265AMD_DB_INTRA 1          /* isIntra */
+#define X265AMD_DB_CBF 2            /* getCbf(part, TEXT_LUMA, tuDepth): the unit's TU carries luma coefficients */
+#define X265AMD_DB_BYPASS 4         /* m_tqBypass */
+#define X265AMD_DB_TU_LEFT 8        /* the unit's left border is a TU or CU edge (setEdgefilterTU / bsCuEdge) */
+#define X265AMD_DB_PU_LEFT 16       /* ... a PU edge inside the CU (setEdgefilterPU) */
+#define X265AMD_DB_TU_TOP 32
+#define X265AMD_DB_PU_TOP 64
+typedef struct x265amd_deblock_unit { uint8_t flags; int8_t qp; int8_t ref[2]; int16_t mv[2][2]; } x265amd_deblock_unit;
+/* d_y / d_u / d_v: sample (0,0) of the reconstructed planes (filtered in place).  width / height: multiples of 8.
+ * beta / tc offsets and chroma QP offsets as in the PPS; passes: bit 0 vertical edges, bit 1 horizontal edges (3 = both, in that
+ * order).  Asynchronous. */
+int x265amd_deblock_picture(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
+                            int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
+                            int cbQpOffset, int crQpOffset, int bypassEnabled, int passes);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

@@ -9,6 +9,9 @@
 #include "common.h"
 #include "primitives.h"
 #include "reference.h"
+#include "deblock.h"
+#include "frame.h"
+#include "x265.h"
 #include "constants.h"
 #include "lowres.h"
 #include "bitcost.h"
@@ -597,6 +600,85 @@ void ref_weight_plane(const pixel* src, pixel* dst, intptr_t stride, int width, 
     }
     pic.m_picOrg[0] = pic.m_picBuf[0] = NULL;     /* the PicYuv never owned the samples */
     pic.m_param = NULL;
+}
+
+/* ---- in-loop deblocking with the reference's own Deblock class (common/deblock.cpp) on a hand-assembled FrameData: one CUData
+ * per CTU filled from raster records (one per 4x4 unit) describing the coding quad-tree, then deblockCTU for every CTU in the
+ * two directions ---- */
+struct RefDbUnit { uint8_t log2CU, partSize, tuDepth, intra, cbf, bypass; int8_t qp; int8_t ref[2]; uint8_t pad; int16_t mv[2][2]; };
+void ref_deblock_picture(pixel* const* planes, intptr_t stride, intptr_t cstride, int width, int height, const RefDbUnit* units,
+                         int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset, int bypassEnabled, int sliceType, int pass)
+{
+    ensure();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420;
+    param->maxCUSize = 64; param->minCUSize = 8; param->maxLog2CUSize = 6; param->unitSizeDepth = 4; param->num4x4Partitions = 256;
+    param->bLossless = 0; param->bDynamicRefine = 0; param->rc.bStatWrite = 0;
+    SPS sps; PPS pps;
+    memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
+    sps.numCuInWidth = (width + 63) / 64; sps.numCuInHeight = (height + 63) / 64; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+    sps.numPartitions = 256; sps.numPartInCUSize = 16; sps.chromaFormatIdc = X265_CSP_I420;
+    sps.picWidthInLumaSamples = width; sps.picHeightInLumaSamples = height;
+    sps.log2MinCodingBlockSize = 3; sps.log2DiffMaxMinCodingBlockSize = 3;
+    pps.deblockingFilterBetaOffsetDiv2 = betaOffsetDiv2; pps.deblockingFilterTcOffsetDiv2 = tcOffsetDiv2;
+    pps.chromaQpOffset[0] = cbQpOffset; pps.chromaQpOffset[1] = crQpOffset; pps.bTransquantBypassEnabled = bypassEnabled != 0;
+    FrameData* fd = new FrameData;
+    fd->create(*param, sps, X265_CSP_I420);
+    Slice* slice = fd->m_slice;
+    slice->m_sps = &sps; slice->m_pps = &pps; slice->m_param = param;
+    slice->m_sliceType = sliceType ? P_SLICE : B_SLICE;
+    static Frame fakeRefs[16];                      /* only their addresses are compared (deblock.cpp:202-235) */
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 16; i++) slice->m_refFrameList[l][i] = &fakeRefs[i];    /* refIdx i of either list = picture i */
+    PicYuv* rec = new PicYuv;
+    rec->m_param = param; rec->m_picCsp = X265_CSP_I420; rec->m_hChromaShift = rec->m_vChromaShift = 1;
+    rec->m_picOrg[0] = planes[0]; rec->m_picOrg[1] = planes[1]; rec->m_picOrg[2] = planes[2];
+    rec->m_stride = stride; rec->m_strideC = cstride; rec->m_picWidth = width; rec->m_picHeight = height;
+    rec->createOffsets(sps);
+    fd->m_reconPic = rec;
+    Frame frame;
+    frame.m_encData = fd; frame.m_param = param;
+    const int w4 = width >> 2;
+    for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+    {
+        CUData& ctu = fd->m_picCTU[addr];
+        ctu.initCTU(frame, addr, 30, 0, 0, 0);
+        ctu.m_chromaFormat = X265_CSP_I420; ctu.m_hChromaShift = ctu.m_vChromaShift = 1;
+        const int cx = (addr % sps.numCuInWidth) * 64, cy = (addr / sps.numCuInWidth) * 64;
+        for (uint32_t z = 0; z < 256; z++)
+        {
+            const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
+            if (x >= width || y >= height) { ctu.m_predMode[z] = MODE_NONE; ctu.m_cuDepth[z] = 3; ctu.m_log2CUSize[z] = 3; continue; }
+            const RefDbUnit& u = units[(y >> 2) * w4 + (x >> 2)];
+            ctu.m_log2CUSize[z] = u.log2CU; ctu.m_cuDepth[z] = (uint8_t)(6 - u.log2CU);
+            ctu.m_partSize[z] = u.partSize; ctu.m_tuDepth[z] = u.tuDepth;
+            ctu.m_predMode[z] = u.intra ? MODE_INTRA : MODE_INTER;
+            ctu.m_cbf[0][z] = u.cbf ? 0xFF : 0;
+            ctu.m_tqBypass[z] = u.bypass; ctu.m_qp[z] = u.qp;
+            for (int l = 0; l < 2; l++) { ctu.m_refIdx[l][z] = u.ref[l]; ctu.m_mv[l][z] = MV(u.mv[l][0], u.mv[l][1]); }
+        }
+    }
+    Deblock db;
+    for (int dir = 0; dir < 2; dir++)
+    {
+        if (!((pass >> dir) & 1)) continue;
+        for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+        {
+            CUGeom geoms[CUGeom::MAX_GEOMS];
+            const int cx = (addr % sps.numCuInWidth) * 64, cy = (addr / sps.numCuInWidth) * 64;
+            CUData::calcCTUGeoms(X265_MIN(64, width - cx), X265_MIN(64, height - cy), 64, 8, geoms);
+            db.deblockCTU(&fd->m_picCTU[addr], geoms[0], dir);
+        }
+    }
+    rec->m_picOrg[0] = rec->m_picOrg[1] = rec->m_picOrg[2] = NULL;
+    X265_FREE(rec->m_cuOffsetY); X265_FREE(rec->m_cuOffsetC); X265_FREE(rec->m_buOffsetY); X265_FREE(rec->m_buOffsetC);
+    rec->m_cuOffsetY = rec->m_cuOffsetC = rec->m_buOffsetY = rec->m_buOffsetC = NULL;
+    delete rec;
+    fd->m_reconPic = NULL;
+    fd->destroy();
+    delete fd;
+    x265_param_free(param);
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

@@ -1359,3 +1359,126 @@ def plane_run_hip(L, cases):
         torch.cuda.synchronize()
         res.append((d_a.cpu().numpy().view(c["buf"].dtype), d_b.cpu().numpy().view(c["buf"].dtype)))
     return res
+
+
+# ---- in-loop deblocking of a picture described per 4x4 unit ----
+DB_UNIT_DT = np.dtype([("flags", "u1"), ("qp", "i1"), ("ref", "i1", 2), ("mv", "<i2", (2, 2))])
+REF_DB_UNIT_DT = np.dtype([("log2CU", "u1"), ("partSize", "u1"), ("tuDepth", "u1"), ("intra", "u1"), ("cbf", "u1"), ("bypass", "u1"), ("qp", "i1"),
+                           ("ref", "i1", 2), ("pad", "u1"), ("mv", "<i2", (2, 2))])
+assert DB_UNIT_DT.itemsize == 12 and REF_DB_UNIT_DT.itemsize == 18
+DB_INTRA, DB_CBF, DB_BYPASS, DB_TU_LEFT, DB_PU_LEFT, DB_TU_TOP, DB_PU_TOP = 1, 2, 4, 8, 16, 32, 64
+# PU rectangles (x, y, w, h in quarters of the CU) per PartSize (SIZE_2Nx2N .. SIZE_nRx2N, common.h)
+_PU_RECTS = {0: [(0, 0, 4, 4)], 1: [(0, 0, 4, 2), (0, 2, 4, 2)], 2: [(0, 0, 2, 4), (2, 0, 2, 4)], 3: [(0, 0, 2, 2), (2, 0, 2, 2), (0, 2, 2, 2), (2, 2, 2, 2)],
+             4: [(0, 0, 4, 1), (0, 1, 4, 3)], 5: [(0, 0, 4, 3), (0, 3, 4, 1)], 6: [(0, 0, 1, 4), (1, 0, 3, 4)], 7: [(0, 0, 3, 4), (3, 0, 1, 4)]}
+
+
+def deblock_case(depth, seed, width, height, slice_b=True, bypass=False):
+    """a random coding quad-tree over a width x height picture (multiples of 8): returns dict with padded planes, the raster
+    records for the reference driver (REF_DB_UNIT_DT) and for the oracle / product (DB_UNIT_DT), and the PPS offsets"""
+    rng = np.random.default_rng(seed)
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    w4, h4 = width // 4, height // 4
+    ru = np.zeros((h4, w4), REF_DB_UNIT_DT)
+    du = np.zeros((h4, w4), DB_UNIT_DT)
+
+    def tu_split(x, y, size, d, maxd, cuinfo):
+        if d < maxd and size > 4 and (size > 32 or rng.integers(0, 2)):
+            for k in range(4):
+                tu_split(x + (k & 1) * size // 2, y + (k >> 1) * size // 2, size // 2, d + 1, maxd, cuinfo)
+            return
+        cbf = int(rng.integers(0, 2))
+        ys, xs = slice(y // 4, (y + size) // 4), slice(x // 4, (x + size) // 4)
+        ru["tuDepth"][ys, xs] = d; ru["cbf"][ys, xs] = cbf
+        du["flags"][ys, xs] |= cbf * DB_CBF
+        du["flags"][ys, x // 4] |= DB_TU_LEFT
+        du["flags"][y // 4, xs] |= DB_TU_TOP
+
+    def leaf(x, y, size):
+        log2 = int(np.log2(size))
+        intra = int(rng.integers(0, 4) == 0)
+        if intra:
+            part = 3 if (size == 8 and rng.integers(0, 2)) else 0
+        else:
+            part = int(rng.choice([0, 0, 1, 2] + ([4, 5, 6, 7] if size >= 16 else [])))
+        qp = int(rng.integers(18, 46))
+        byp = int(bypass and rng.integers(0, 6) == 0)
+        ys, xs = slice(y // 4, (y + size) // 4), slice(x // 4, (x + size) // 4)
+        ru["log2CU"][ys, xs] = log2; ru["partSize"][ys, xs] = part; ru["intra"][ys, xs] = intra; ru["qp"][ys, xs] = qp; ru["bypass"][ys, xs] = byp
+        du["qp"][ys, xs] = qp
+        du["flags"][ys, xs] |= intra * DB_INTRA + byp * DB_BYPASS
+        q = size // 4
+        for (px, py, pw, ph) in _PU_RECTS[part]:
+            pys, pxs = slice((y + py * q) // 4, (y + (py + ph) * q) // 4), slice((x + px * q) // 4, (x + (px + pw) * q) // 4)
+            if intra:
+                refs, mvs = (-1, -1), ((0, 0), (0, 0))
+            else:
+                kind = int(rng.integers(0, 3)) if slice_b else 0
+                refs = [(int(rng.integers(0, 3)), -1), (-1, int(rng.integers(0, 3))), (int(rng.integers(0, 3)), int(rng.integers(0, 3)))][kind]
+                base = (int(rng.integers(-6, 7)), int(rng.integers(-6, 7)))
+                mvs = tuple((base[0] + int(rng.integers(-3, 4)), base[1] + int(rng.integers(-3, 4))) if refs[l] >= 0 else (0, 0) for l in range(2))
+            for arr in (ru, du):
+                arr["ref"][pys, pxs] = refs
+                arr["mv"][pys, pxs] = mvs
+            if px:
+                du["flags"][pys, (x + px * q) // 4] |= DB_PU_LEFT
+            if py:
+                du["flags"][(y + py * q) // 4, pxs] |= DB_PU_TOP
+        maxd = int(rng.integers(0, 3))
+        if part == 3 or size == 64:
+            maxd = max(maxd, 1)
+        tu_split(x, y, size, 0, min(maxd, log2 - 2), None)
+
+    def cu(x, y, size):
+        if x >= width or y >= height:
+            return
+        inside = x + size <= width and y + size <= height
+        if size > 8 and (not inside or rng.integers(0, 3) > 0):
+            for k in range(4):
+                cu(x + (k & 1) * size // 2, y + (k >> 1) * size // 2, size // 2)
+            return
+        leaf(x, y, size)
+
+    for cy in range(0, height, 64):
+        for cx in range(0, width, 64):
+            cu(cx, cy, 64)
+    mx, my = 16, 16
+    stride, cstride = width + 2 * mx, width // 2 + mx
+    planes = []
+    for (w, h, st, m) in ((width, height, stride, mx), (width // 2, height // 2, cstride, mx // 2), (width // 2, height // 2, cstride, mx // 2)):
+        base = rng.integers(0, pmax + 1, (h // 8 + 1, w // 8 + 1)).astype(np.int64)
+        p = np.kron(base, np.ones((8, 8), np.int64))[:h, :w]
+        p = np.clip(p // 3 + pmax // 3 + rng.integers(-2, 3, p.shape) * (1 << (depth - 8)), 0, pmax)     # blocky with small steps: all filter branches fire
+        full = np.zeros((h + 2 * m, st), dt)
+        full[m:m + h, m:m + w] = p
+        planes.append(full)
+    return dict(planes=planes, stride=stride, cstride=cstride, org=(my * stride + mx, (my // 2) * cstride + mx // 2), width=width, height=height,
+                ref_units=np.ascontiguousarray(ru.ravel()), units=np.ascontiguousarray(du.ravel()),
+                beta=int(rng.integers(-3, 4)), tc=int(rng.integers(-3, 4)), cb=int(rng.integers(-4, 5)), cr=int(rng.integers(-4, 5)),
+                bypass=int(bypass), slice_p=int(not slice_b))
+
+
+def deblock_run_host(L, c, passes=3):
+    pl = [p.copy() for p in c["planes"]]
+    isz = pl[0].itemsize
+    ptrs = np.array([pl[0].ctypes.data + c["org"][0] * isz, pl[1].ctypes.data + c["org"][1] * isz, pl[2].ctypes.data + c["org"][1] * isz], np.uint64)
+    if L.prefix == "ref_":
+        L.lib.ref_deblock_picture(_ptr(ptrs), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"], _ptr(c["ref_units"]),
+                                  c["beta"], c["tc"], c["cb"], c["cr"], c["bypass"], c["slice_p"], passes)
+    else:
+        L.lib.orc_deblock_picture(_ptr(ptrs), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"], _ptr(c["units"]),
+                                  c["beta"], c["tc"], c["cb"], c["cr"], c["bypass"], passes)
+    return pl
+
+
+def deblock_run_hip(L, c, passes=3):
+    import torch
+    isz = c["planes"][0].itemsize
+    d = [torch.from_numpy(p.view(np.uint8).copy()).cuda() for p in c["planes"]]
+    d_units = torch.from_numpy(c["units"].view(np.uint8).copy()).cuda()
+    rc = L.lib.x265amd_deblock_picture(None, C.c_void_p(d[0].data_ptr() + c["org"][0] * isz), C.c_void_p(d[1].data_ptr() + c["org"][1] * isz),
+                                       C.c_void_p(d[2].data_ptr() + c["org"][1] * isz), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"],
+                                       C.c_void_p(d_units.data_ptr()), c["beta"], c["tc"], c["cb"], c["cr"], c["bypass"], passes)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return [t.cpu().numpy().view(c["planes"][0].dtype).reshape(p.shape) for t, p in zip(d, c["planes"])]
