@@ -433,6 +433,26 @@ int x265amd_deblock_picture(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u
                             int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
                             int cbQpOffset, int crQpOffset, int bypassEnabled, int passes);
 
+/* --- sample adaptive offset over a picture, the two data-parallel halves; 4:2:0, sao-non-deblock off.
+ * Plane tables are HOST arrays of 3 device addresses (sample (0,0) of Y, U, V).
+ * x265amd_sao_stats = SAO::calcSaoStatsCTU for every CTU and plane (reference: source/encoder/sao.cpp:735-917 with
+ * saoCuStatsBO/E0..E3 :1762-1925): d_count / d_offset_org[((ctu * 3 + plane) * 5 + type) * 32 + class], type 0..3 = EO_0..3
+ * (classes 0..4), 4 = BO (32 bands); rec = the deblocked planes, fenc = the source planes.
+ * x265amd_sao_apply = SAO::generateLumaOffsets / generateChromaOffsets / applyPixelOffsets (sao.cpp:274-733) for given per-CTU
+ * parameters (merge modes resolved by the caller): dst receives the offset picture (picture area only); every sample is
+ * classified on the deblocked src planes.  The parameter choice (rdoSaoUnitCu) is the host loop's. */
+typedef struct x265amd_sao_ctu
+{
+    int8_t type[2];                 /* SaoCtuParam::typeIdx of luma / of both chroma planes: -1 off, 0..3 EO_0..3, 4 BO */
+    uint8_t band_pos[3];            /* SaoCtuParam::bandPos per plane */
+    int8_t offset[3][4];            /* SaoCtuParam::offset per plane */
+    uint8_t reserved[3];
+} x265amd_sao_ctu;
+int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
+                      int width, int height, int32_t* d_count, int32_t* d_offset_org);
+int x265amd_sao_apply(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
+                      int width, int height, const x265amd_sao_ctu* d_params);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

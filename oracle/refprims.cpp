@@ -10,6 +10,7 @@
 #include "primitives.h"
 #include "reference.h"
 #include "deblock.h"
+#include "sao.h"
 #include "frame.h"
 #include "x265.h"
 #include "constants.h"
@@ -679,6 +680,121 @@ void ref_deblock_picture(pixel* const* planes, intptr_t stride, intptr_t cstride
     fd->destroy();
     delete fd;
     x265_param_free(param);
+}
+
+/* ---- sample adaptive offset with the reference's own SAO class (encoder/sao.cpp): statistics of every CTU (calcSaoStatsCTU) and
+ * application of given per-CTU parameters (generateLumaOffsets / generateChromaOffsets, driven row by row like
+ * FrameFilter::ParallelFilter::processSaoCTU with copySaoAboveRef, encoder/framefilter.cpp:300-343) ---- */
+struct SaoProbe : public SAO
+{
+    const int32_t* cnt(int plane) const { return &m_count[plane][0][0]; }
+    const int32_t* org(int plane) const { return &m_offsetOrg[plane][0][0]; }
+    void clear() { memset(m_count, 0, sizeof(m_count)); memset(m_offsetOrg, 0, sizeof(m_offsetOrg)); }
+    pixel* tmpU(int plane) { return m_tmpU[plane]; }
+};
+struct SaoFixture
+{
+    x265_param* param; SPS sps; PPS pps; FrameData* fd; PicYuv* rec; PicYuv* fenc; Frame frame; SaoProbe sao;
+    SaoFixture(pixel* const* recPlanes, pixel* const* fencPlanes, intptr_t stride, intptr_t cstride, int width, int height)
+    {
+        param = x265_param_alloc();
+        x265_param_default(param);
+        param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420;
+        param->maxCUSize = 64; param->minCUSize = 8; param->maxLog2CUSize = 6; param->unitSizeDepth = 4; param->num4x4Partitions = 256;
+        param->bSaoNonDeblocked = 0; param->bLimitSAO = 0;
+        memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
+        sps.numCuInWidth = (width + 63) / 64; sps.numCuInHeight = (height + 63) / 64; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+        sps.numPartitions = 256; sps.numPartInCUSize = 16; sps.chromaFormatIdc = X265_CSP_I420;
+        fd = new FrameData;
+        fd->create(*param, sps, X265_CSP_I420);
+        fd->m_slice->m_sps = &sps; fd->m_slice->m_pps = &pps; fd->m_slice->m_param = param; fd->m_slice->m_sliceType = P_SLICE;
+        rec = mk(recPlanes, stride, cstride, width, height);
+        fenc = mk(fencPlanes, stride, cstride, width, height);
+        fd->m_reconPic = rec;
+        frame.m_encData = fd; frame.m_param = param; frame.m_reconPic = rec; frame.m_fencPic = fenc;
+        for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+        {
+            uint32_t row = addr / sps.numCuInWidth;
+            fd->m_picCTU[addr].initCTU(frame, addr, 30, row == 0, row == sps.numCuInHeight - 1, 0);
+        }
+        sao.create(param, 1);
+        sao.m_frame = &frame;
+    }
+    PicYuv* mk(pixel* const* planes, intptr_t stride, intptr_t cstride, int width, int height)
+    {
+        PicYuv* p = new PicYuv;
+        p->m_param = param; p->m_picCsp = X265_CSP_I420; p->m_hChromaShift = p->m_vChromaShift = 1;
+        p->m_picOrg[0] = planes[0]; p->m_picOrg[1] = planes[1]; p->m_picOrg[2] = planes[2];
+        p->m_stride = stride; p->m_strideC = cstride; p->m_picWidth = width; p->m_picHeight = height;
+        p->createOffsets(sps);
+        return p;
+    }
+    void drop(PicYuv* p)
+    {
+        p->m_picOrg[0] = p->m_picOrg[1] = p->m_picOrg[2] = NULL;
+        X265_FREE(p->m_cuOffsetY); X265_FREE(p->m_cuOffsetC); X265_FREE(p->m_buOffsetY); X265_FREE(p->m_buOffsetC);
+        p->m_cuOffsetY = p->m_cuOffsetC = p->m_buOffsetY = p->m_buOffsetC = NULL;
+        delete p;
+    }
+    ~SaoFixture()
+    {
+        sao.destroy(1);
+        drop(rec); drop(fenc);
+        fd->m_reconPic = NULL; frame.m_reconPic = NULL; frame.m_fencPic = NULL; frame.m_encData = NULL;
+        fd->destroy(); delete fd;
+        x265_param_free(param);
+    }
+};
+void ref_sao_stats_picture(pixel* const* rec, pixel* const* fenc, intptr_t stride, intptr_t cstride, int width, int height, int32_t* count, int32_t* offsetOrg)
+{
+    ensure();
+    SaoFixture f(rec, fenc, stride, cstride, width, height);
+    for (uint32_t addr = 0; addr < f.sps.numCUsInFrame; addr++)
+    {
+        f.sao.clear();
+        for (int plane = 0; plane < 3; plane++)
+        {
+            f.sao.calcSaoStatsCTU((int)addr, plane);
+            memcpy(count + ((size_t)addr * 3 + plane) * 5 * 32, f.sao.cnt(plane), 5 * 32 * sizeof(int32_t));
+            memcpy(offsetOrg + ((size_t)addr * 3 + plane) * 5 * 32, f.sao.org(plane), 5 * 32 * sizeof(int32_t));
+        }
+    }
+}
+struct PackedSaoCtu { int8_t type[2]; uint8_t bandPos[3]; int8_t offset[3][4]; uint8_t pad[3]; };
+/* planes are filtered in place; pre: an untouched copy of the same (deblocked) planes, the source of the saved line above each row */
+void ref_sao_apply_picture(pixel* const* planes, pixel* const* pre, intptr_t stride, intptr_t cstride, int width, int height, const PackedSaoCtu* params)
+{
+    ensure();
+    SaoFixture f(planes, pre, stride, cstride, width, height);
+    const int numCtu = (int)f.sps.numCUsInFrame, ctuW = (int)f.sps.numCuInWidth;
+    SaoCtuParam* cp[3];
+    for (int c = 0; c < 3; c++)
+    {
+        cp[c] = new SaoCtuParam[numCtu];
+        for (int a = 0; a < numCtu; a++)
+        {
+            cp[c][a].reset();
+            cp[c][a].typeIdx = params[a].type[c ? 1 : 0];
+            cp[c][a].bandPos = params[a].bandPos[c];
+            for (int i = 0; i < 4; i++) cp[c][a].offset[i] = params[a].offset[c][i];
+        }
+    }
+    for (int row = 0; row < (int)f.sps.numCuInHeight; row++)
+    {
+        for (int c = 0; c < 3; c++)
+        {
+            const intptr_t st = c ? cstride : stride;
+            const int picW = c ? width / 2 : width, y = (row * 64) >> (c ? 1 : 0);
+            const pixel* line = pre[c] + (intptr_t)(row ? y - 1 : y) * st;
+            for (int x = -1; x <= picW; x++) f.sao.tmpU(c)[x] = line[x];
+        }
+        for (int col = 0; col < ctuW; col++)
+        {
+            f.sao.generateLumaOffsets(cp[0], row, col);
+            f.sao.generateChromaOffsets(cp, row, col);
+        }
+    }
+    for (int c = 0; c < 3; c++) delete[] cp[c];
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

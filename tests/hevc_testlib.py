@@ -1482,3 +1482,73 @@ def deblock_run_hip(L, c, passes=3):
     assert rc == 0
     torch.cuda.synchronize()
     return [t.cpu().numpy().view(c["planes"][0].dtype).reshape(p.shape) for t, p in zip(d, c["planes"])]
+
+
+# ---- sample adaptive offset: statistics and application over a picture ----
+SAO_CTU_DT = np.dtype([("type", "i1", 2), ("bandPos", "u1", 3), ("offset", "i1", (3, 4)), ("pad", "u1", 3)])
+assert SAO_CTU_DT.itemsize == 20
+
+
+def sao_case(depth, seed, width, height):
+    rng = np.random.default_rng(seed)
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    mx = 16
+    stride, cstride = width + 2 * mx, width // 2 + mx
+    rec, fenc = [], []
+    for (w, h, st, m) in ((width, height, stride, mx), (width // 2, height // 2, cstride, mx // 2), (width // 2, height // 2, cstride, mx // 2)):
+        base = rng.integers(0, pmax + 1, (h // 4 + 2, w // 4 + 2)).astype(np.int64)
+        p = np.kron(base, np.ones((4, 4), np.int64))[:h + 2 * m, :st] if False else None
+        full = rng.integers(0, pmax + 1, (h + 2 * m, st)).astype(np.int64)
+        smooth = (full + np.roll(full, 1, 0) + np.roll(full, 1, 1) + np.roll(full, -1, 0)) // 4
+        kind = rng.integers(0, 2)
+        r = smooth if kind else (smooth // 8) * 8 + rng.integers(0, 3, smooth.shape)
+        f = np.clip(r + rng.integers(-6, 7, r.shape), 0, pmax)
+        rec.append(np.ascontiguousarray(np.clip(r, 0, pmax).astype(dt))); fenc.append(np.ascontiguousarray(f.astype(dt)))
+    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    params = np.zeros(nctu, SAO_CTU_DT)
+    params["type"] = rng.integers(-1, 5, (nctu, 2))
+    params["bandPos"] = rng.integers(0, 32, (nctu, 3))
+    params["offset"] = rng.integers(-7, 8, (nctu, 3, 4)) * (1 if depth == 8 else 3)
+    return dict(rec=rec, fenc=fenc, stride=stride, cstride=cstride, org=(mx * stride + mx, (mx // 2) * cstride + mx // 2), width=width, height=height,
+                params=params, nctu=nctu)
+
+
+def _plane_ptrs(planes, org):
+    isz = planes[0].itemsize
+    return np.array([planes[0].ctypes.data + org[0] * isz, planes[1].ctypes.data + org[1] * isz, planes[2].ctypes.data + org[1] * isz], np.uint64)
+
+
+def sao_run_host(L, c):
+    """returns (count, offsetOrg, offset planes)"""
+    n = c["nctu"] * 3 * 5 * 32
+    cnt = np.zeros(n, np.int32); org = np.zeros(n, np.int32)
+    rp, fp = _plane_ptrs(c["rec"], c["org"]), _plane_ptrs(c["fenc"], c["org"])
+    getattr(L.lib, L.prefix + "sao_stats_picture")(_ptr(rp), _ptr(fp), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"], _ptr(cnt), _ptr(org))
+    if L.prefix == "ref_":
+        work = [p.copy() for p in c["rec"]]
+        L.lib.ref_sao_apply_picture(_ptr(_plane_ptrs(work, c["org"])), _ptr(rp), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"], _ptr(c["params"]))
+        out = work
+    else:
+        out = [p.copy() for p in c["rec"]]
+        L.lib.orc_sao_apply_picture(_ptr(rp), _ptr(_plane_ptrs(out, c["org"])), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"], _ptr(c["params"]))
+    return cnt, org, out
+
+
+def sao_run_hip(L, c):
+    import torch
+    isz = c["rec"][0].itemsize
+    d_rec = [torch.from_numpy(p.view(np.uint8).copy()).cuda() for p in c["rec"]]
+    d_fenc = [torch.from_numpy(p.view(np.uint8).copy()).cuda() for p in c["fenc"]]
+    d_out = [torch.from_numpy(p.view(np.uint8).copy()).cuda() for p in c["rec"]]
+    tab = lambda ds: np.array([ds[0].data_ptr() + c["org"][0] * isz, ds[1].data_ptr() + c["org"][1] * isz, ds[2].data_ptr() + c["org"][1] * isz], np.uint64)
+    n = c["nctu"] * 3 * 5 * 32
+    d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda"); d_org = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_par = torch.from_numpy(c["params"].view(np.uint8).copy()).cuda()
+    assert L.lib.x265amd_sao_stats(None, _ptr(tab(d_rec)), _ptr(tab(d_fenc)), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"],
+                                   C.c_void_p(d_cnt.data_ptr()), C.c_void_p(d_org.data_ptr())) == 0
+    assert L.lib.x265amd_sao_apply(None, _ptr(tab(d_rec)), _ptr(tab(d_out)), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), c["width"], c["height"],
+                                   C.c_void_p(d_par.data_ptr())) == 0
+    torch.cuda.synchronize()
+    dt = c["rec"][0].dtype
+    return d_cnt.cpu().numpy(), d_org.cpu().numpy(), [t.cpu().numpy().view(dt).reshape(p.shape) for t, p in zip(d_out, c["rec"])]

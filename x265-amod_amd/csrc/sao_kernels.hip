@@ -1,0 +1,149 @@
+/* Sample adaptive offset over a whole picture (include/x265amd.h: x265amd_sao_stats, x265amd_sao_apply).
+ *
+ * Device restatement of SAO::calcSaoStatsCTU with saoCuStatsBO/E0..E3 (reference: source/encoder/sao.cpp:735-917, :1762-1925;
+ * sao-non-deblock off) and of SAO::generateLumaOffsets / generateChromaOffsets / applyPixelOffsets (sao.cpp:274-733), 4:2:0.
+ * The reference walks CTUs in order and keeps the not-yet-offset samples it still needs in m_tmpU / m_tmpL; here the offset picture
+ * is written to separate planes, so every sample is classified on the deblocked input directly and all samples are independent.
+ * Statistics: one workgroup per (CTU, plane); every thread keeps the 4 x 5 edge-class sums and counts of its samples in registers
+ * and the 32 band classes go through LDS atomics; one flush per thread at the end.  HBM-bound: the picture is read once (plus the
+ * source picture for the statistics) and written once.
+ */
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+
+struct SaoPlanes { const pixel* rec[3]; const pixel* fenc[3]; pixel* dst[3]; long stride, cstride; int width, height; };
+
+XA_DEV int sao_sgn(int v) { return (v > 0) - (v < 0); }
+XA_DEV int sao_class(int v, int a, int b)            /* SAO::s_eoTable[sign + sign + 2] (sao.cpp:65-72): {1, 2, 0, 3, 4} */
+{
+    const int e = sao_sgn(v - a) + sao_sgn(v - b) + 2;
+    return e == 2 ? 0 : (e < 2 ? e + 1 : e);
+}
+
+__global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, int32_t* offsetOrg)
+{
+    __shared__ int sCnt[5 * 32], sOrg[5 * 32];
+    const int plane = blockIdx.y, ctu = blockIdx.x;
+    const int ctuW = (P.width + 63) >> 6;
+    const int cx = ctu % ctuW, cy = ctu / ctuW;
+    const int sh = plane ? 1 : 0, po = plane ? 2 : 0;
+    const long st = plane ? P.cstride : P.stride;
+    const int picW = P.width >> sh, picH = P.height >> sh, lpelx = (cx * 64) >> sh, tpely = (cy * 64) >> sh;
+    const int rpelx = min(lpelx + (64 >> sh), picW), bpely = min(tpely + (64 >> sh), picH);
+    const int cw = rpelx - lpelx, ch = bpely - tpely;
+    const pixel* r0 = P.rec[plane] + (long)tpely * st + lpelx;
+    const pixel* f0 = P.fenc[plane] + (long)tpely * st + lpelx;
+    for (int i = threadIdx.x; i < 5 * 32; i += blockDim.x) { sCnt[i] = 0; sOrg[i] = 0; }
+    __syncthreads();
+    const bool atRight = rpelx == picW, atBottom = bpely == picH;
+    const int aboveUnavail = !tpely;
+    const int endXfull = atRight ? cw : cw - 5 + po, endXedge = atRight ? cw - 1 : cw - 5 + po;
+    const int endYfull = atBottom ? ch : ch - 4 + po, endYedge = atBottom ? ch - 1 : ch - 4 + po;
+    const int x0e = !lpelx;
+    int cnt[4][5], org[4][5];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) { cnt[t][c] = 0; org[t][c] = 0; }
+    for (int i = threadIdx.x; i < cw * ch; i += blockDim.x)
+    {
+        const int y = i / cw, x = i - y * cw;
+        const pixel* r = r0 + (long)y * st + x;
+        const int v = r[0], d = (int)f0[(long)y * st + x] - v;
+        if (x < endXfull && y < endYfull)
+        {
+            const int band = v >> (XA_DEPTH - 5);
+            atomicAdd(&sCnt[4 * 32 + band], 1); atomicAdd(&sOrg[4 * 32 + band], d);
+        }
+        const bool inXe = x >= x0e && x < endXedge, inYe = y >= aboveUnavail && y < endYedge;
+        int cls;
+#define ACC(t, c) { cls = (c); _Pragma("unroll") for (int k = 0; k < 5; k++) if (cls == k) { cnt[t][k]++; org[t][k] += d; } }
+        if (inXe && y < ch - 4 + po) ACC(0, sao_class(v, r[-1], r[1]))
+        if (x < endXfull && inYe) ACC(1, sao_class(v, r[-st], r[st]))
+        if (inXe && inYe)
+        {
+            ACC(2, sao_class(v, r[-st - 1], r[st + 1]))
+            ACC(3, sao_class(v, r[-st + 1], r[st - 1]))
+        }
+#undef ACC
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+            if (cnt[t][c]) { atomicAdd(&sCnt[t * 32 + c], cnt[t][c]); atomicAdd(&sOrg[t * 32 + c], org[t][c]); }
+    __syncthreads();
+    const size_t base = ((size_t)ctu * 3 + plane) * 5 * 32;
+    for (int i = threadIdx.x; i < 5 * 32; i += blockDim.x) { count[base + i] = sCnt[i]; offsetOrg[base + i] = sOrg[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_sao_apply(SaoPlanes P, const x265amd_sao_ctu* params)
+{
+    const int plane = blockIdx.z;
+    const int sh = plane ? 1 : 0;
+    const long st = plane ? P.cstride : P.stride;
+    const int picW = P.width >> sh, picH = P.height >> sh;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= picW || y >= picH) return;
+    const int ctuW = (P.width + 63) >> 6;
+    const x265amd_sao_ctu p = params[((y << sh) >> 6) * ctuW + ((x << sh) >> 6)];
+    const int type = p.type[plane ? 1 : 0];
+    const pixel* s = P.rec[plane] + (long)y * st + x;
+    const int v = s[0];
+    int out = v;
+    if (type == 4)
+    {
+        const int k = ((v >> (XA_DEPTH - 5)) - p.band_pos[plane]) & 31;
+        if (k < 4) out = v + p.offset[plane][k];
+    }
+    else if (type >= 0)
+    {
+        const int dx = type == 1 ? 0 : (type == 3 ? 1 : -1), dy = type == 0 ? 0 : -1;
+        const bool edge = (dx && (x == 0 || x == picW - 1)) || (dy && (y == 0 || y == picH - 1));
+        if (!edge)
+        {
+            const int cls = sao_class(v, s[dy * st + dx], s[-dy * st - dx]);
+            if (cls) out = v + p.offset[plane][cls - 1];
+        }
+    }
+    P.dst[plane][(long)y * st + x] = xa_clip_pixel(out);
+}
+
+static int sao_fill(SaoPlanes& P, const uint64_t* rec, const uint64_t* fenc, const uint64_t* dst, intptr_t stride, intptr_t cstride, int width, int height)
+{
+    for (int c = 0; c < 3; c++)
+    {
+        P.rec[c] = (const pixel*)(uintptr_t)rec[c];
+        P.fenc[c] = fenc ? (const pixel*)(uintptr_t)fenc[c] : nullptr;
+        P.dst[c] = dst ? (pixel*)(uintptr_t)dst[c] : nullptr;
+    }
+    P.stride = (long)stride; P.cstride = (long)cstride; P.width = width; P.height = height;
+    return 0;
+}
+
+extern "C" int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
+                                 int width, int height, int32_t* d_count, int32_t* d_offset_org)
+{
+    if (!rec_planes || !fenc_planes || !d_count || !d_offset_org || width <= 0 || height <= 0 || (width & 7) || (height & 7))
+        return xa_fail(X265AMD_EINVAL, "x265amd_sao_stats: bad arguments");
+    SaoPlanes P;
+    sao_fill(P, rec_planes, fenc_planes, nullptr, stride, cstride, width, height);
+    const int nctu = ((width + 63) >> 6) * ((height + 63) >> 6);
+    hipLaunchKernelGGL(k_sao_stats, dim3(nctu, 3), dim3(256), 0, (hipStream_t)stream, P, d_count, d_offset_org);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_sao_apply(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
+                                 int width, int height, const x265amd_sao_ctu* d_params)
+{
+    if (!src_planes || !dst_planes || !d_params || width <= 0 || height <= 0 || (width & 7) || (height & 7))
+        return xa_fail(X265AMD_EINVAL, "x265amd_sao_apply: bad arguments");
+    SaoPlanes P;
+    sao_fill(P, src_planes, nullptr, dst_planes, stride, cstride, width, height);
+    hipLaunchKernelGGL(k_sao_apply, dim3((width + 255) / 256, height, 3), dim3(256), 0, (hipStream_t)stream, P, d_params);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
