@@ -304,6 +304,15 @@ def cpu_baseline(T, frames, packed_by_ref, budget_s=20.0):
         if spent > budget_s / 4:
             break
     secs_per_frame += spent * len(it) / done; notes.append("%d/%d intra TU steps %.1fs" % (done, len(it), spent))
+    # in-loop filters of one picture (the reference's Deblock / SAO classes on a CUData fixture when kind == "reference")
+    hflt = (H // 8) * 8
+    dbc = T.deblock_case(DEPTH, 9, W, hflt, True, False)
+    sac = T.sao_case(DEPTH, 7, W, hflt)
+    t0 = time.perf_counter()
+    T.deblock_run_host(L, dbc)
+    T.sao_run_host(L, sac)
+    spent = time.perf_counter() - t0
+    secs_per_frame += spent; notes.append("in-loop filters %.2fs (includes building the CUData fixture)" % spent)
     return {"value": 1.0 / secs_per_frame, "unit": "frames/s", "cores": 1, "kind": kind,
             "sample": "one %dx%d frame of the same workload on one core: " % (W, H) + ", ".join(notes) + "; parts cut at their budget are extrapolated"}
 
@@ -487,12 +496,37 @@ def main():
     d_bits = torch.zeros(n_tu, dtype=torch.int64, device="cuda")
     cb_bytes = int((tu_n2 * 2).sum() + n_tu * (32 + 8 + 320))
 
+    # ---- in-loop filters on a synthetic reconstructed picture of the same size: random coding quad-tree (deblock), random SAO parameters ----
+    hflt = (H // 8) * 8
+    dbc = T.deblock_case(DEPTH, 9, W, hflt, True, False)
+    sac = T.sao_case(DEPTH, 7, W, hflt)
+    d_db = [me.upload(p.ravel()) for p in dbc["planes"]]
+    d_db_units = me.upload(dbc["units"])
+    d_sa_rec = [me.upload(p.ravel()) for p in sac["rec"]]
+    d_sa_fenc = [me.upload(p.ravel()) for p in sac["fenc"]]
+    d_sa_out = [torch.zeros_like(t) for t in d_sa_rec]
+    satab = lambda ds: np.array([ds[0].data_ptr() + sac["org"][0], ds[1].data_ptr() + sac["org"][1], ds[2].data_ptr() + sac["org"][1]], np.uint64)
+    sa_rec_tab, sa_fenc_tab, sa_out_tab = satab(d_sa_rec), satab(d_sa_fenc), satab(d_sa_out)
+    d_sa_cnt = torch.zeros(sac["nctu"] * 480, dtype=torch.int32, device="cuda"); d_sa_org = torch.zeros_like(d_sa_cnt)
+    d_sa_par = me.upload(sac["params"])
+    pic_bytes = W * hflt * 3 // 2
+    db_bytes = 2 * 2 * pic_bytes + 2 * len(dbc["units"]) * 12         # two passes, each reads and writes the picture; unit records
+    ss_bytes = 2 * pic_bytes + sac["nctu"] * 480 * 8
+    sap_bytes = 2 * pic_bytes + sac["nctu"] * 20
+    ext_bytes = (W + 32) * (hflt + 32) * 3 // 2
+
+    def run_filters(db_planes):
+        rc = lib.x265amd_deblock_picture(sp, C.c_void_p(db_planes[0].data_ptr() + dbc["org"][0]), C.c_void_p(db_planes[1].data_ptr() + dbc["org"][1]),
+                                         C.c_void_p(db_planes[2].data_ptr() + dbc["org"][1]), C.c_int64(dbc["stride"]), C.c_int64(dbc["cstride"]), W, hflt,
+                                         C.c_void_p(d_db_units.data_ptr()), dbc["beta"], dbc["tc"], dbc["cb"], dbc["cr"], 0, 3)
+        assert rc == 0, lib.x265amd_last_error()
+
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     import __graft_entry__ as entry
     fs = entry.load_package().frame_shard
     ring, gather = fs.ReferenceRing(depth=NUM_REFS * max(world, 1) + world), [None]
-    NK = 6
+    NK = 10
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(NK + 1)] for _ in range(args.steps)]
 
     def step(k, marks=None):
@@ -520,6 +554,20 @@ def main():
         rc = lib.x265amd_coeff_bits(sp, C.c_void_p(d_cb.data_ptr()), n_tu, C.c_void_p(d_bits.data_ptr()))
         assert rc == 0, lib.x265amd_last_error()
         if marks: marks[6].record(stream)
+        run_filters(d_db)
+        if marks: marks[7].record(stream)
+        rc = lib.x265amd_sao_stats(sp, T._ptr(sa_rec_tab), T._ptr(sa_fenc_tab), C.c_int64(sac["stride"]), C.c_int64(sac["cstride"]), W, hflt,
+                                   C.c_void_p(d_sa_cnt.data_ptr()), C.c_void_p(d_sa_org.data_ptr()))
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[8].record(stream)
+        rc = lib.x265amd_sao_apply(sp, T._ptr(sa_rec_tab), T._ptr(sa_out_tab), C.c_int64(sac["stride"]), C.c_int64(sac["cstride"]), W, hflt, C.c_void_p(d_sa_par.data_ptr()))
+        assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[9].record(stream)
+        for c in range(3):
+            rc = lib.x265amd_extend_pic_border(sp, C.c_void_p(int(sa_out_tab[c])), C.c_int64(sac["stride"] if c == 0 else sac["cstride"]),
+                                               W >> (c > 0), hflt >> (c > 0), 16 >> (c > 0), 16 >> (c > 0))
+            assert rc == 0, lib.x265amd_last_error()
+        if marks: marks[10].record(stream)
         if world > 1:
             # exchange step of the frame-parallel design: every rank publishes the picture it just finished so that all
             # ranks hold it as a reference (here the source stands in for the reconstruction)
@@ -588,8 +636,26 @@ def main():
         more_ok = sample_more(T, orc, frames, last, d_ic[last], d_ic_out, d_ic_arena, d_it[last], d_it_out, d_it_arena, d_cb, d_bits, d_ctx_out,
                               d_arena, ctx0, d_pics, planes)
         checked += more_ok[1]
-        names = ("k_me_search", "k_intra_scan", "k_tu_chain", "k_motion_compensation<cost>", "k_intra_tu_chain", "k_coeff_bits")
-        algb = (me_bytes, in_bytes, tu_bytes, ic_bytes, it_bytes, cb_bytes)
+        # in-loop filters: whole-picture check against the oracle on fresh copies of the inputs
+        d_fresh = [me.upload(p.ravel()) for p in dbc["planes"]]
+        run_filters(d_fresh)
+        torch.cuda.synchronize()
+        want = T.deblock_run_host(orc, dbc)
+        flt_ok = all(np.array_equal(d_fresh[k].cpu().numpy().view(dbc["planes"][k].dtype).reshape(dbc["planes"][k].shape), want[k]) for k in range(3))
+        wcnt, worg, wout = T.sao_run_host(orc, sac)
+        flt_ok &= bool(np.array_equal(d_sa_cnt.cpu().numpy(), wcnt) and np.array_equal(d_sa_org.cpu().numpy(), worg))
+        for k in range(3):
+            m = 16 >> (k > 0)
+            wk = wout[k].copy()
+            hk, wk_w = (hflt >> (k > 0)), (W >> (k > 0))
+            core = wk[m:m + hk, m:m + wk_w]
+            wk[:] = np.pad(core, ((m, m), (m, wk.shape[1] - wk_w - m)), mode="edge")
+            got = d_sa_out[k].cpu().numpy().view(wk.dtype).reshape(wk.shape)
+            flt_ok &= bool(np.array_equal(got[:, :wk_w + 2 * m], wk[:, :wk_w + 2 * m]))
+        checked += 3          # three whole-picture comparisons (deblocked planes, SAO statistics, offset + extended planes)
+        names = ("k_me_search", "k_intra_scan", "k_tu_chain", "k_motion_compensation<cost>", "k_intra_tu_chain", "k_coeff_bits",
+                 "k_deblock<0>+<1>", "k_sao_stats", "k_sao_apply", "k_extend_border")
+        algb = (me_bytes, in_bytes, tu_bytes, ic_bytes, it_bytes, cb_bytes, db_bytes, ss_bytes, sap_bytes, ext_bytes)
         dom = int(np.argmax(kms))
         line = {
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
@@ -600,7 +666,8 @@ def main():
                                    "%d motion searches (every 2Nx2N PU 64..8 of every CTU x 3 refs; hex, merange 57, subme 2) + %d intra 35-mode scans "
                                    "(CUs 32/16/8) + %d TU residual chains (luma + 2 chroma per CU 32/16/8; dct, quant, sign hiding, dequant, idct, recon, sse, psy) + "
                                    "%d merge-candidate costs (2 per CU 64..8: motion compensation + SA8D incl. chroma) + %d intra TU steps (neighbours, prediction, "
-                                   "residual chain; luma + 2 chroma per CU 32/16/8) + %d bits-only coefficient codings (one per TU chain); "
+                                   "residual chain; luma + 2 chroma per CU 32/16/8) + %d bits-only coefficient codings (one per TU chain) + in-loop filters of one picture "
+                                   "(deblocking of a random coding quad-tree, SAO statistics, SAO application, border extension); "
                                    "NOT a full encode (no mode decision loop / bitstream yet)") % (len(packed), n_in, n_tu, n_ic, n_it, n_tu),
                        "frames_per_step_per_gpu": 1, "parallelism": "frame-per-gpu x%d" % world},
             "kernels": {names[i]: {"ms": kms[i], "algorithmic_bytes": algb[i], "GB/s": algb[i] / (kms[i] * 1e-3) / 1e9} for i in range(NK)},
@@ -612,8 +679,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(T, frames, packed_unordered)
         else:
             line["cpu_baseline"] = None
-        line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(ok and tu_ok and in_ok and more_ok[0]),
-                                 "me": bool(ok), "tu_chain": bool(tu_ok), "intra_scan": bool(in_ok), "inter_cost_intra_tu_coeff_bits": bool(more_ok[0])}
+        line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(ok and tu_ok and in_ok and more_ok[0] and flt_ok),
+                                 "me": bool(ok), "tu_chain": bool(tu_ok), "intra_scan": bool(in_ok), "inter_cost_intra_tu_coeff_bits": bool(more_ok[0]),
+                                 "in_loop_filters_whole_picture": bool(flt_ok)}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -45,15 +45,26 @@ __global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, 
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int c = 0; c < 5; c++) { cnt[t][c] = 0; org[t][c] = 0; }
-    for (int i = threadIdx.x; i < cw * ch; i += blockDim.x)
+    const int total = cw * ch, rounds = (total + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (int it = 0; it < rounds; it++)         /* uniform trip count: the band step uses wave-wide operations */
     {
-        const int y = i / cw, x = i - y * cw;
-        const pixel* r = r0 + (long)y * st + x;
-        const int v = r[0], d = (int)f0[(long)y * st + x] - v;
-        if (x < endXfull && y < endYfull)
+        const int i = it * blockDim.x + threadIdx.x;
+        const bool live = i < total;
+        const int y = live ? i / cw : 0, x = live ? i - y * cw : cw;      /* x = cw lies outside every region */
+        const pixel* r = r0 + (long)y * st + (live ? x : 0);
+        const int v = r[0], d = live ? (int)f0[(long)y * st + x] - v : 0;
+        /* band offset: neighbouring samples mostly share a band, so the wave adds per distinct band, not per lane */
         {
-            const int band = v >> (XA_DEPTH - 5);
-            atomicAdd(&sCnt[4 * 32 + band], 1); atomicAdd(&sOrg[4 * 32 + band], d);
+            const int band = (x < endXfull && y < endYfull) ? v >> (XA_DEPTH - 5) : -1;
+            uint64_t todo = __ballot(band >= 0);
+            while (todo)
+            {
+                const int b = __shfl(band, __ffsll((long long)todo) - 1, 64);
+                const uint64_t m = __ballot(band == b);
+                const int sum = xa_wave_sum(band == b ? d : 0);
+                if ((threadIdx.x & 63) == 0) { atomicAdd(&sCnt[4 * 32 + b], __popcll(m)); atomicAdd(&sOrg[4 * 32 + b], sum); }
+                todo &= ~m;
+            }
         }
         const bool inXe = x >= x0e && x < endXedge, inYe = y >= aboveUnavail && y < endYedge;
         int cls;
