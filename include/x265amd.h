@@ -453,6 +453,58 @@ int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], const uint64_t
 int x265amd_sao_apply(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
                       int width, int height, const x265amd_sao_ctu* d_params);
 
+/* --- final entropy coding of CTUs: the CABAC write pass, host code.  Entropy::encodeCTU / encodeCU /
+ * encodeTransform / codePredInfo / codeCoeffNxN and the arithmetic coder (reference: source/encoder/entropy.cpp:768-1222, :1431-2200,
+ * :2399-2612) with CUData's context derivations (source/common/cudata.cpp:814-1012); 4:2:0, no transform skip.
+ * The decisions of a picture are one record per 4x4 unit in raster order ((pic_width/4) x (pic_height/4)); the fields are those of
+ * CUData (source/common/cudata.h:190-240), per-CU / per-PU / per-TU values repeated over the units they cover. */
+enum { X265AMD_MODE_NONE = 0, X265AMD_MODE_INTER = 1, X265AMD_MODE_INTRA = 2, X265AMD_MODE_SKIP = 3 };
+typedef struct x265amd_cu_unit
+{
+    uint8_t depth;                  /* m_cuDepth */
+    uint8_t pred_mode;              /* X265AMD_MODE_* (m_predMode) */
+    uint8_t part_size;              /* m_partSize: 0 2Nx2N, 1 2NxN, 2 Nx2N, 3 NxN, 4 2NxnU, 5 2NxnD, 6 nLx2N, 7 nRx2N */
+    uint8_t tu_depth;               /* m_tuDepth */
+    uint8_t luma_dir, chroma_dir;   /* m_lumaIntraDir, m_chromaIntraDir (36 = DM_CHROMA_IDX) */
+    uint8_t merge_flag, inter_dir;  /* m_mergeFlag, m_interDir (1 L0, 2 L1, 3 both) */
+    uint8_t cbf[3];                 /* m_cbf[plane]: bit d = coded coefficients in the unit's TU at depth d */
+    uint8_t tq_bypass;
+    int8_t qp;                      /* m_qp (rewritten by the coder where no delta QP is coded, as finishCU does) */
+    int8_t ref_idx[2];              /* m_refIdx */
+    uint8_t mvp_idx[2];             /* m_mvpIdx ([0] carries the merge index of merged / skipped blocks) */
+    uint8_t reserved;
+    int16_t mvd[2][2];              /* m_mvd */
+} x265amd_cu_unit;                  /* 26 bytes */
+typedef struct x265amd_slice_info
+{
+    int32_t pic_width, pic_height;  /* multiples of 8 (minimum CU size); CTU size 64 */
+    int32_t slice_type;             /* 0 B, 1 P, 2 I */
+    int32_t slice_qp;
+    int32_t num_ref_idx[2];
+    int32_t max_num_merge_cand;
+    int32_t use_dqp, max_cu_dqp_depth;      /* pps.bUseDQP, pps.maxCuDQPDepth */
+    int32_t sign_hide, tq_bypass_enabled;   /* pps.bSignHideEnabled, pps.bTransquantBypassEnabled */
+    int32_t wpp;                            /* pps.bEntropyCodingSyncEnabled (only read by the last-coded-QP rule) */
+    int32_t max_cu_depth;                   /* param.maxCUDepth: log2(maxCUSize) - log2(minCUSize) */
+    int32_t max_amp_depth;                  /* sps.maxAMPDepth */
+    int32_t tu_log2_min, tu_log2_max;       /* sps.quadtreeTULog2MinSize / MaxSize */
+    int32_t tu_max_depth_inter, tu_max_depth_intra;
+} x265amd_slice_info;
+typedef struct x265amd_cabac x265amd_cabac;
+/* units: the picture's map (kept by reference; its qp fields are updated).  bits_only != 0: no bitstream, fractional bits are
+ * counted instead (the reference's m_fracBits, FIX15).  Contexts start at Entropy::resetEntropy(slice). */
+x265amd_cabac* x265amd_cabac_open(const x265amd_slice_info* si, x265amd_cu_unit* units, int bits_only);
+void x265amd_cabac_close(x265amd_cabac*);
+void x265amd_cabac_set_contexts(x265amd_cabac*, const uint8_t* ctx);
+void x265amd_cabac_get_contexts(const x265amd_cabac*, uint8_t* ctx);
+/* Entropy::encodeCTU for CTU ctu_addr; coeff*: the CTU's quantised levels in the reference's layout (CUData::m_trCoeff: TU blocks at
+ * z-order offsets, 64*64 luma and 32*32 per chroma plane). */
+int x265amd_cabac_encode_ctu(x265amd_cabac*, int ctu_addr, const int16_t* coeffY, const int16_t* coeffU, const int16_t* coeffV);
+uint64_t x265amd_cabac_frac_bits(const x265amd_cabac*);      /* the reference's m_fracBits (finishCU's resetBits() keeps only the fraction at a CTU end) */
+uint64_t x265amd_cabac_ctu_bits(const x265amd_cabac*);       /* bit-counting mode: FIX15 bits of the CTU coded last */
+/* Entropy::finishSlice: terminating bin, flush, rbsp trailing bits; returns the slice data size in bytes, copied to out when it fits */
+size_t x265amd_cabac_finish_slice(x265amd_cabac*, uint8_t* out, size_t cap);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

@@ -11,6 +11,7 @@
 #include "reference.h"
 #include "deblock.h"
 #include "sao.h"
+#include "bitstream.h"
 #include "frame.h"
 #include "x265.h"
 #include "constants.h"
@@ -795,6 +796,108 @@ void ref_sao_apply_picture(pixel* const* planes, pixel* const* pre, intptr_t str
         }
     }
     for (int c = 0; c < 3; c++) delete[] cp[c];
+}
+
+/* ---- final entropy coding with the reference's own Entropy class (encoder/entropy.cpp: encodeCTU ... finishSlice) on CUData built from
+ * the raster records of include/x265amd.h (x265amd_cu_unit / x265amd_slice_info), coefficients in the reference's per-CTU layout ---- */
+struct RefCuUnit { uint8_t depth, predMode, partSize, tuDepth, lumaDir, chromaDir, mergeFlag, interDir; uint8_t cbf[3]; uint8_t tqBypass; int8_t qp; int8_t refIdx[2];
+                   uint8_t mvpIdx[2]; uint8_t reserved; int16_t mvd[2][2]; };
+struct RefSliceInfo { int32_t picWidth, picHeight, sliceType, sliceQp, numRefIdx[2], maxNumMergeCand, useDqp, maxCuDqpDepth, signHide, tqBypassEnabled, wpp,
+                      maxCuDepth, maxAmpDepth, tuLog2Min, tuLog2Max, tuMaxDepthInter, tuMaxDepthIntra; };
+/* coeff: numCtu x (64*64 + 2*32*32) int16 (Y | U | V per CTU).  bitsOnly: no bitstream; ctxOut receives the final context states,
+ * qpOut (optional) the qp map after coding.  Returns the number of bytes written to out. */
+size_t ref_encode_ctus(const RefSliceInfo* si, const RefCuUnit* units, const int16_t* coeff, int bitsOnly, uint8_t* out, size_t cap, uint8_t* ctxOut, int8_t* qpOut)
+{
+    ensure();
+    const int width = si->picWidth, height = si->picHeight;
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420;
+    param->maxCUSize = 64; param->minCUSize = 8; param->maxLog2CUSize = 6; param->unitSizeDepth = 4; param->num4x4Partitions = 256;
+    param->maxCUDepth = si->maxCuDepth; param->bLossless = 0;
+    SPS sps; PPS pps;
+    memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
+    sps.numCuInWidth = (width + 63) / 64; sps.numCuInHeight = (height + 63) / 64; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+    sps.numPartitions = 256; sps.numPartInCUSize = 16; sps.chromaFormatIdc = X265_CSP_I420;
+    sps.picWidthInLumaSamples = width; sps.picHeightInLumaSamples = height;
+    sps.log2MinCodingBlockSize = 3; sps.log2DiffMaxMinCodingBlockSize = 3;
+    sps.quadtreeTULog2MinSize = si->tuLog2Min; sps.quadtreeTULog2MaxSize = si->tuLog2Max;
+    sps.quadtreeTUMaxDepthInter = si->tuMaxDepthInter; sps.quadtreeTUMaxDepthIntra = si->tuMaxDepthIntra; sps.maxAMPDepth = si->maxAmpDepth;
+    pps.bUseDQP = si->useDqp != 0; pps.maxCuDQPDepth = si->maxCuDqpDepth; pps.bSignHideEnabled = si->signHide != 0;
+    pps.bTransquantBypassEnabled = si->tqBypassEnabled != 0; pps.bTransformSkipEnabled = 0; pps.bEntropyCodingSyncEnabled = si->wpp != 0;
+    FrameData* fd = new FrameData;
+    fd->create(*param, sps, X265_CSP_I420);
+    Slice* slice = fd->m_slice;
+    slice->m_sps = &sps; slice->m_pps = &pps; slice->m_param = param;
+    slice->m_sliceType = si->sliceType == 2 ? I_SLICE : (si->sliceType == 1 ? P_SLICE : B_SLICE);
+    slice->m_sliceQp = si->sliceQp; slice->m_numRefIdx[0] = si->numRefIdx[0]; slice->m_numRefIdx[1] = si->numRefIdx[1];
+    slice->m_maxNumMergeCand = si->maxNumMergeCand;
+    slice->m_endCUAddr = slice->realEndAddress(sps.numCUsInFrame * 256);
+    Frame frame;
+    frame.m_encData = fd; frame.m_param = param;
+    const int w4 = width >> 2;
+    for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+    {
+        CUData& ctu = fd->m_picCTU[addr];
+        ctu.initCTU(frame, addr, si->sliceQp, addr < sps.numCuInWidth, addr / sps.numCuInWidth == sps.numCuInHeight - 1, 0);
+        ctu.m_chromaFormat = X265_CSP_I420; ctu.m_hChromaShift = ctu.m_vChromaShift = 1;
+        const int cx = (addr % sps.numCuInWidth) * 64, cy = (addr / sps.numCuInWidth) * 64;
+        for (uint32_t z = 0; z < 256; z++)
+        {
+            const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
+            if (x >= width || y >= height) { ctu.m_predMode[z] = MODE_NONE; ctu.m_cuDepth[z] = 0; continue; }
+            const RefCuUnit& u = units[(y >> 2) * w4 + (x >> 2)];
+            ctu.m_cuDepth[z] = u.depth; ctu.m_log2CUSize[z] = (uint8_t)(6 - u.depth);
+            ctu.m_predMode[z] = u.predMode == 1 ? MODE_INTER : (u.predMode == 2 ? MODE_INTRA : (u.predMode == 3 ? MODE_SKIP : MODE_NONE));
+            ctu.m_partSize[z] = u.partSize; ctu.m_tuDepth[z] = u.tuDepth; ctu.m_lumaIntraDir[z] = u.lumaDir; ctu.m_chromaIntraDir[z] = u.chromaDir;
+            ctu.m_mergeFlag[z] = u.mergeFlag; ctu.m_interDir[z] = u.interDir; ctu.m_skipFlag[0][z] = ctu.m_skipFlag[1][z] = 0;
+            for (int c = 0; c < 3; c++) ctu.m_cbf[c][z] = u.cbf[c];
+            ctu.m_tqBypass[z] = u.tqBypass; ctu.m_qp[z] = u.qp;
+            for (int l = 0; l < 2; l++) { ctu.m_refIdx[l][z] = u.refIdx[l]; ctu.m_mvpIdx[l][z] = u.mvpIdx[l]; ctu.m_mvd[l][z] = MV(u.mvd[l][0], u.mvd[l][1]); }
+            ctu.m_transformSkip[0][z] = ctu.m_transformSkip[1][z] = ctu.m_transformSkip[2][z] = 0;
+        }
+    }
+    Entropy e;
+    Bitstream bs;
+    if (!bitsOnly) e.setBitstream(&bs);
+    e.resetEntropy(*slice);
+    e.zeroFract();
+    for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+    {
+        CUData& ctu = fd->m_picCTU[addr];
+        const int16_t* c = coeff + (size_t)addr * (64 * 64 + 2 * 32 * 32);
+        coeff_t* save[3] = { ctu.m_trCoeff[0], ctu.m_trCoeff[1], ctu.m_trCoeff[2] };
+        ctu.m_trCoeff[0] = (coeff_t*)c; ctu.m_trCoeff[1] = (coeff_t*)c + 64 * 64; ctu.m_trCoeff[2] = (coeff_t*)c + 64 * 64 + 32 * 32;
+        CUGeom geoms[CUGeom::MAX_GEOMS];
+        const int cx = (addr % sps.numCuInWidth) * 64, cy = (addr / sps.numCuInWidth) * 64;
+        CUData::calcCTUGeoms(X265_MIN(64, width - cx), X265_MIN(64, height - cy), 64, 8, geoms);
+        e.encodeCTU(ctu, geoms[0]);
+        if (getenv("REF_CTX_TRACE"))
+        {
+            FILE* f = fopen(getenv("REF_CTX_TRACE"), addr ? "ab" : "wb");
+            fwrite(e.m_contextState, 1, 160, f); fclose(f);
+        }
+        ctu.m_trCoeff[0] = save[0]; ctu.m_trCoeff[1] = save[1]; ctu.m_trCoeff[2] = save[2];
+    }
+    size_t n = 0;
+    if (!bitsOnly)
+    {
+        e.finishSlice();
+        n = bs.getNumberOfWrittenBytes();
+        if (n <= cap) memcpy(out, bs.getFIFO(), n);
+    }
+    memcpy(ctxOut, e.m_contextState, MAX_OFF_CTX_MOD);
+    if (qpOut)
+        for (int y4 = 0; y4 < (height >> 2); y4++)
+            for (int x4 = 0; x4 < w4; x4++)
+            {
+                const uint32_t addr = (y4 >> 4) * sps.numCuInWidth + (x4 >> 4);
+                qpOut[y4 * w4 + x4] = fd->m_picCTU[addr].m_qp[g_rasterToZscan[(y4 & 15) * 16 + (x4 & 15)]];
+            }
+    frame.m_encData = NULL;
+    fd->destroy(); delete fd;
+    x265_param_free(param);
+    return n;
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

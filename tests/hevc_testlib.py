@@ -1552,3 +1552,224 @@ def sao_run_hip(L, c):
     torch.cuda.synchronize()
     dt = c["rec"][0].dtype
     return d_cnt.cpu().numpy(), d_org.cpu().numpy(), [t.cpu().numpy().view(dt).reshape(p.shape) for t, p in zip(d_out, c["rec"])]
+
+
+# ---- final entropy coding of CTUs (x265amd_cabac_*): random valid coding trees ----
+CU_UNIT_DT = np.dtype([("depth", "u1"), ("pred_mode", "u1"), ("part_size", "u1"), ("tu_depth", "u1"), ("luma_dir", "u1"), ("chroma_dir", "u1"),
+                       ("merge_flag", "u1"), ("inter_dir", "u1"), ("cbf", "u1", 3), ("tq_bypass", "u1"), ("qp", "i1"), ("ref_idx", "i1", 2),
+                       ("mvp_idx", "u1", 2), ("reserved", "u1"), ("mvd", "<i2", (2, 2))])
+SLICE_INFO_DT = np.dtype([(n, "<i4") for n in ("pic_width", "pic_height", "slice_type", "slice_qp")] + [("num_ref_idx", "<i4", 2)] +
+                         [(n, "<i4") for n in ("max_num_merge_cand", "use_dqp", "max_cu_dqp_depth", "sign_hide", "tq_bypass_enabled", "wpp", "max_cu_depth",
+                                               "max_amp_depth", "tu_log2_min", "tu_log2_max", "tu_max_depth_inter", "tu_max_depth_intra")])
+assert CU_UNIT_DT.itemsize == 26 and SLICE_INFO_DT.itemsize == 72
+MODE_NONE, MODE_INTER, MODE_INTRA, MODE_SKIP = 0, 1, 2, 3
+CTU_COEFFS = 64 * 64 + 2 * 32 * 32
+
+
+def _zorder(x4, y4):
+    z = 0
+    for b in range(4):
+        z |= ((x4 >> b) & 1) << (2 * b) | ((y4 >> b) & 1) << (2 * b + 1)
+    return z
+
+
+def cabac_case(seed, width, height, slice_type, dense=False):
+    """random picture of valid CU / PU / TU decisions + levels: dict(si, units (h4 x w4), coeff (numCtu x CTU_COEFFS))"""
+    rng = np.random.default_rng(seed)
+    w4, h4 = width // 4, height // 4
+    ctuW, ctuH = (width + 63) // 64, (height + 63) // 64
+    si = np.zeros(1, SLICE_INFO_DT)[0]
+    si["pic_width"], si["pic_height"], si["slice_type"], si["slice_qp"] = width, height, slice_type, int(rng.integers(20, 40))
+    si["num_ref_idx"] = (int(rng.integers(1, 5)), int(rng.integers(1, 4)) if slice_type == 0 else 0)
+    si["max_num_merge_cand"] = int(rng.integers(1, 6))
+    si["use_dqp"], si["max_cu_dqp_depth"] = int(rng.integers(0, 2)), int(rng.integers(0, 3))
+    si["sign_hide"], si["tq_bypass_enabled"], si["wpp"] = int(rng.integers(0, 2)), int(rng.integers(0, 4) == 0), int(rng.integers(0, 2))
+    si["max_cu_depth"], si["max_amp_depth"] = 3, int(rng.choice([0, 3]))
+    si["tu_log2_min"], si["tu_log2_max"] = 2, 5
+    si["tu_max_depth_inter"], si["tu_max_depth_intra"] = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    units = np.zeros((h4, w4), CU_UNIT_DT)
+    coeff = np.zeros((ctuW * ctuH, CTU_COEFFS), np.int16)
+    qg = 64 >> int(si["max_cu_dqp_depth"])
+    qgqp = {}
+
+    def levels(n):
+        a = np.zeros(n * n, np.int16)
+        k = int(rng.integers(1, max(2, (n * n) // (2 if dense else 6))))
+        idx = rng.choice(n * n, size=min(k, n * n), replace=False)
+        mag = rng.choice([1, 1, 1, 2, 2, 3, 4, 7, 15, 40, 300], size=len(idx))
+        a[idx] = (mag * rng.choice([-1, 1], size=len(idx))).astype(np.int16)
+        if rng.integers(0, 3) == 0:         # low-frequency concentration like real transforms
+            a[n * 2:] = 0 if n > 4 else a[n * 2:]
+            if not a.any():
+                a[0] = 1
+        return a
+
+    def put(plane, x, y, n, a):
+        addr = (y // 64) * ctuW + (x // 64)
+        z = _zorder((x % 64) // 4, (y % 64) // 4)
+        off = (z << 4) if plane == 0 else (64 * 64 + (plane - 1) * 32 * 32 + ((z << 4) >> 2))
+        coeff[addr, off:off + n * n] = a
+
+    def tu(x, y, log2, d, cu):
+        """returns (cbfY, cbfU, cbfV) ORs of the subtree; sets tu_depth and cbf bits"""
+        size = 1 << log2
+        intra, part, lo = cu["intra"], cu["part"], cu["lo"]
+        if intra and part != 0 and log2 == 3:
+            sub = True
+        elif (not intra) and part != 0 and d == 0 and si["tu_max_depth_inter"] == 1:
+            sub = True
+        elif log2 > si["tu_log2_max"]:
+            sub = True
+        elif log2 == si["tu_log2_min"] or log2 == lo:
+            sub = False
+        else:
+            sub = bool(rng.integers(0, 2))
+        ys, xs = slice(y // 4, (y + size) // 4), slice(x // 4, (x + size) // 4)
+        if sub:
+            small_child = log2 - 1 == 2          # children are 4x4 luma: chroma stays at this level
+            res = [tu(x + (k & 1) * size // 2, y + (k >> 1) * size // 2, log2 - 1, d + 1, cu) for k in range(4)]
+            cy = any(r[0] for r in res)
+            if small_child:
+                cu_, cv_ = bool(rng.integers(0, 2)) and not cu["nores"], bool(rng.integers(0, 2)) and not cu["nores"]
+                for c, v in ((1, cu_), (2, cv_)):
+                    if v:
+                        units["cbf"][ys, xs, c] |= (1 << d) | (1 << (d + 1))
+                        put(c, x, y, 4, levels(4))
+            else:
+                cu_, cv_ = any(r[1] for r in res), any(r[2] for r in res)
+                for c, v in ((1, cu_), (2, cv_)):
+                    if v:
+                        units["cbf"][ys, xs, c] |= 1 << d
+            if cy:
+                units["cbf"][ys, xs, 0] |= 1 << d
+            return cy, cu_, cv_
+        units["tu_depth"][ys, xs] = d
+        out = []
+        for c in range(3):
+            if c and log2 == 2:
+                out.append(False)
+                continue
+            v = bool(rng.integers(0, 3) > 0) and not cu["nores"]
+            if v:
+                units["cbf"][ys, xs, c] |= 1 << d
+                n = size if c == 0 else size // 2
+                put(c, x, y, n, levels(n))
+            out.append(v)
+        return tuple(out)
+
+    def leaf(x, y, size, depth):
+        ys, xs = slice(y // 4, (y + size) // 4), slice(x // 4, (x + size) // 4)
+        u = units[ys, xs]
+        u["depth"] = depth
+        key = (x // qg, y // qg)
+        if size >= qg or key not in qgqp:
+            qgqp[key] = int(si["slice_qp"]) + int(rng.integers(-6, 7))
+        u["qp"] = qgqp[key]
+        u["tq_bypass"] = int(si["tq_bypass_enabled"] and rng.integers(0, 5) == 0)
+        kind = 2 if slice_type == 2 else int(rng.choice([0, 1, 1, 2]))      # 0 skip, 1 inter, 2 intra
+        log2 = int(np.log2(size))
+        cu = dict(intra=kind == 2, part=0, nores=False)
+        if kind == 0:
+            u["pred_mode"], u["part_size"], u["merge_flag"] = MODE_SKIP, 0, 1
+            u["mvp_idx"] = (int(rng.integers(0, si["max_num_merge_cand"])), 0)
+            u["inter_dir"] = 1
+            units[ys, xs] = u
+            return
+        if kind == 2:
+            part = 3 if (size == 8 and rng.integers(0, 2)) else 0
+            u["pred_mode"], u["part_size"] = MODE_INTRA, part
+            units[ys, xs] = u
+            if part == 3:
+                for k in range(4):
+                    units["luma_dir"][y // 4 + (k >> 1), x // 4 + (k & 1)] = int(rng.integers(0, 35))
+            else:
+                units["luma_dir"][ys, xs] = int(rng.integers(0, 35))
+            first = int(units["luma_dir"][y // 4, x // 4])
+            c = int(rng.choice([0, 26, 10, 1, 36]))
+            if c != 36 and c == first:
+                c = 34
+            units["chroma_dir"][ys, xs] = c
+            cu["part"] = part
+            maxd, split = int(si["tu_max_depth_intra"]), int(part != 0)
+        else:
+            parts = [0, 0, 1, 2] + ([4, 5, 6, 7] if (depth < si["max_amp_depth"] and size >= 16) else [])
+            part = int(rng.choice(parts))
+            u["pred_mode"], u["part_size"] = MODE_INTER, part
+            units[ys, xs] = u
+            q = size // 4
+            all_merge = True
+            for (px, py, pw, ph) in _PU_RECTS[part]:
+                pys, pxs = slice((y + py * q) // 4, (y + (py + ph) * q) // 4), slice((x + px * q) // 4, (x + (px + pw) * q) // 4)
+                mf = int(rng.integers(0, 3) == 0)
+                all_merge &= bool(mf)
+                units["merge_flag"][pys, pxs] = mf
+                if mf:
+                    units["mvp_idx"][pys, pxs] = (int(rng.integers(0, si["max_num_merge_cand"])), 0)
+                    units["inter_dir"][pys, pxs] = 1
+                    continue
+                if slice_type == 0:
+                    idir = int(rng.integers(1, 3)) if (size == 8 and part != 0) else int(rng.integers(1, 4))
+                else:
+                    idir = 1
+                units["inter_dir"][pys, pxs] = idir
+                refs = [int(rng.integers(0, si["num_ref_idx"][l])) if idir & (1 << l) else -1 for l in range(2)]
+                units["ref_idx"][pys, pxs] = refs
+                units["mvp_idx"][pys, pxs] = (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+                units["mvd"][pys, pxs] = [[int(rng.choice([0, 0, 1, -1, 2, -3, 17, -250, 4000])), int(rng.choice([0, 0, 1, -1, 5, -2, 33, 700]))] for _ in range(2)]
+            cu["part"] = part
+            cu["nores"] = bool(rng.integers(0, 4) == 0) and not (part == 0 and all_merge)     # root cbf 0 (a 2Nx2N merge without residual would be a skip)
+            maxd, split = int(si["tu_max_depth_inter"]), int(si["tu_max_depth_inter"] == 1 and part != 0)
+        lo = log2 - (maxd - 1 + split)
+        cu["lo"] = min(max(lo, int(si["tu_log2_min"])), int(si["tu_log2_max"]))
+        cy, cu_, cv_ = tu(x, y, log2, 0, cu)
+        if kind == 1 and part == 0 and units["merge_flag"][y // 4, x // 4] and not (cy or cu_ or cv_):
+            # merged 2Nx2N without a coded root flag implies residual: give the first TU a level
+            d = int(units["tu_depth"][y // 4, x // 4])
+            n = size >> d
+            for dd in range(d + 1):
+                units["cbf"][y // 4:(y + (size >> dd)) // 4, x // 4:(x + (size >> dd)) // 4, 0] |= 1 << dd
+            put(0, x, y, n, levels(n))
+        elif kind == 1 and not cu["nores"] and not (cy or cu_ or cv_):
+            pass
+
+    def walk(x, y, size, depth):
+        if x >= width or y >= height:
+            return
+        inside = x + size <= width and y + size <= height
+        if size > 8 and (not inside or rng.integers(0, 3) > 0):
+            for k in range(4):
+                walk(x + (k & 1) * size // 2, y + (k >> 1) * size // 2, size // 2, depth + 1)
+            return
+        leaf(x, y, size, depth)
+
+    for cy in range(0, height, 64):
+        for cx in range(0, width, 64):
+            walk(cx, cy, 64, 0)
+    return dict(si=si, units=np.ascontiguousarray(units), coeff=coeff, ctus=ctuW * ctuH)
+
+
+def cabac_run_ref(R, c, bits_only=0):
+    out = np.zeros(1 << 22, np.uint8); ctx = np.zeros(160, np.uint8); qp = np.zeros(c["units"].size, np.int8)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    R.lib.ref_encode_ctus.restype = C.c_size_t
+    n = R.lib.ref_encode_ctus(_ptr(si), _ptr(c["units"]), _ptr(c["coeff"]), bits_only, _ptr(out), C.c_size_t(out.size), _ptr(ctx), _ptr(qp))
+    return out[:n].copy(), ctx[:CTX_COUNT].copy(), qp
+
+
+def cabac_run_product(L, c, bits_only=0):
+    units = c["units"].copy()
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    L.lib.x265amd_cabac_open.restype = C.c_void_p
+    L.lib.x265amd_cabac_finish_slice.restype = C.c_size_t
+    L.lib.x265amd_cabac_frac_bits.restype = C.c_uint64
+    h = C.c_void_p(L.lib.x265amd_cabac_open(_ptr(si), _ptr(units), bits_only))
+    assert h.value
+    for a in range(c["ctus"]):
+        row = c["coeff"][a]
+        rc = L.lib.x265amd_cabac_encode_ctu(h, a, off(row, 0), off(row, 64 * 64), off(row, 64 * 64 + 32 * 32))
+        assert rc == 0
+    out = np.zeros(1 << 22, np.uint8); ctx = np.zeros(160, np.uint8)
+    n = L.lib.x265amd_cabac_finish_slice(h, _ptr(out), C.c_size_t(out.size))
+    L.lib.x265amd_cabac_get_contexts(h, _ptr(ctx))
+    L.lib.x265amd_cabac_close(h)
+    return out[:n].copy(), ctx[:CTX_COUNT].copy(), units["qp"].ravel().copy()

@@ -9,16 +9,22 @@ mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -I$HERE/../include ${X265AMD_EXTRA_FLAGS:-}"
 SRCS=$(ls "$SRC"/*.hip)
+HOSTSRCS=$(ls "$HERE"/host/*.cpp 2>/dev/null || true)
 build_one() {
     local depth=$1 name=$2
     local lib=$OUT/$name
     local newest
-    newest=$(ls -t "$SRC"/* "$HERE"/../include/*.h | head -1)
+    newest=$(ls -t "$SRC"/* "$HERE"/host/* "$HERE"/../include/*.h | head -1)
     if [ -z "${X265AMD_FORCE:-}" ] && [ -f "$lib" ] && [ "$lib" -nt "$newest" ]; then return 0; fi
     local objs=""
     for f in $SRCS; do
         local o=$OUT/$(basename "$f" .hip).$depth.o
         $HIPCC $FLAGS -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
+        objs="$objs $o"
+    done
+    for f in $HOSTSRCS; do
+        local o=$OUT/$(basename "$f" .cpp).$depth.host.o
+        g++ -O2 -std=c++17 -fPIC -Wall -I"$HERE/../include" -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
         objs="$objs $o"
     done
     wait
