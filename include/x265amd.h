@@ -505,6 +505,28 @@ uint64_t x265amd_cabac_ctu_bits(const x265amd_cabac*);       /* bit-counting mod
 /* Entropy::finishSlice: terminating bin, flush, rbsp trailing bits; returns the slice data size in bytes, copied to out when it fits */
 size_t x265amd_cabac_finish_slice(x265amd_cabac*, uint8_t* out, size_t cap);
 
+/* --- motion vector prediction, host code: CUData::getInterMergeCandidates (reference: source/common/cudata.cpp:1458-1712)
+ * and getNeighbourMV + getPMV (:1715-1875) with the temporal candidates (:1968-2045).  The motion field of a picture is one record per
+ * 4x4 unit in raster order; "cur" holds what has been decided so far in coding order (including the current CU's earlier PUs), "col"
+ * is the co-located picture's field (only read when temporal_mvp).  Intra / uncoded units carry ref_idx -1. */
+typedef struct x265amd_mv_unit { uint8_t pred_mode, inter_dir; int8_t ref_idx[2]; int16_t mv[2][2]; } x265amd_mv_unit;      /* 12 bytes */
+typedef struct x265amd_mvpred_info
+{
+    int32_t pic_width, pic_height;
+    int32_t is_inter_b, num_ref_idx[2], max_num_merge_cand;
+    int32_t temporal_mvp;           /* sps.bTemporalMVPEnabled */
+    int32_t col_from_l0, check_ldc; /* slice.m_colFromL0Flag, m_bCheckLDC */
+    int32_t poc, ref_poc[2][16];    /* slice.m_poc, m_refPOCList */
+    int32_t col_poc, col_ref_poc[2][16];    /* the same of the co-located picture's slice */
+} x265amd_mvpred_info;
+typedef struct x265amd_merge_cand { int16_t mv[2][2]; int8_t ref_idx[2]; uint8_t dir; uint8_t reserved; } x265amd_merge_cand;
+/* returns the number of candidates written (max_num_merge_cand); part_size as in x265amd_cu_unit */
+int x265amd_merge_candidates(const x265amd_mvpred_info* info, const x265amd_mv_unit* cur, const x265amd_mv_unit* col, int cu_x, int cu_y, int log2_cu_size,
+                             int part_size, int pu_idx, x265amd_merge_cand* out);
+/* amvp: the two AMVP candidates of (list, ref_idx); mvc: the motion candidates for the search start (returns their number, at most 11) */
+int x265amd_amvp_candidates(const x265amd_mvpred_info* info, const x265amd_mv_unit* cur, const x265amd_mv_unit* col, int cu_x, int cu_y, int log2_cu_size,
+                            int part_size, int pu_idx, int list, int ref_idx, int16_t amvp[2][2], int16_t mvc[12][2]);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

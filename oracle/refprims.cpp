@@ -900,6 +900,119 @@ size_t ref_encode_ctus(const RefSliceInfo* si, const RefCuUnit* units, const int
     return n;
 }
 
+/* ---- motion vector prediction with the reference's own CUData methods (common/cudata.cpp: getInterMergeCandidates, getNeighbourMV,
+ * getPMV) on fixtures built from raster motion fields (records of include/x265amd.h) ---- */
+struct RefMvUnit { uint8_t predMode, interDir; int8_t refIdx[2]; int16_t mv[2][2]; };
+struct RefMvInfo { int32_t picWidth, picHeight, isInterB, numRefIdx[2], maxNumMergeCand, temporalMvp, colFromL0, checkLdc, poc, refPoc[2][16], colPoc, colRefPoc[2][16]; };
+struct RefMergeCand { int16_t mv[2][2]; int8_t refIdx[2]; uint8_t dir, reserved; };
+struct MvFixture
+{
+    x265_param* param; SPS sps; PPS pps; FrameData* fd[2]; Frame frame[2];
+    MvFixture(const RefMvInfo* I, const RefMvUnit* cur, const RefMvUnit* col)
+    {
+        const int width = I->picWidth, height = I->picHeight;
+        param = x265_param_alloc();
+        x265_param_default(param);
+        param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420;
+        param->maxCUSize = 64; param->minCUSize = 8; param->maxLog2CUSize = 6; param->unitSizeDepth = 4; param->num4x4Partitions = 256; param->maxCUDepth = 3;
+        memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
+        sps.numCuInWidth = (width + 63) / 64; sps.numCuInHeight = (height + 63) / 64; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+        sps.numPartitions = 256; sps.numPartInCUSize = 16; sps.chromaFormatIdc = X265_CSP_I420;
+        sps.picWidthInLumaSamples = width; sps.picHeightInLumaSamples = height; sps.bTemporalMVPEnabled = I->temporalMvp != 0;
+        for (int k = 0; k < 2; k++)
+        {
+            fd[k] = new FrameData;
+            fd[k]->create(*param, sps, X265_CSP_I420);
+            Slice* sl = fd[k]->m_slice;
+            sl->m_sps = &sps; sl->m_pps = &pps; sl->m_param = param;
+            sl->m_sliceType = I->isInterB ? B_SLICE : P_SLICE;
+            sl->m_poc = k ? I->colPoc : I->poc;
+            for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) sl->m_refPOCList[l][r] = k ? I->colRefPoc[l][r] : I->refPoc[l][r];
+            frame[k].m_encData = fd[k]; frame[k].m_param = param;
+            const RefMvUnit* map = k ? col : cur;
+            const int w4 = width >> 2;
+            for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+            {
+                CUData& ctu = fd[k]->m_picCTU[addr];
+                ctu.initCTU(frame[k], addr, 30, addr < sps.numCuInWidth, 0, 0);
+                const int cx = (addr % sps.numCuInWidth) * 64, cy = (addr / sps.numCuInWidth) * 64;
+                for (uint32_t z = 0; z < 256; z++)
+                {
+                    const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
+                    if (x >= width || y >= height || !map) { ctu.m_predMode[z] = MODE_NONE; ctu.m_refIdx[0][z] = ctu.m_refIdx[1][z] = -1; continue; }
+                    const RefMvUnit& u = map[(y >> 2) * w4 + (x >> 2)];
+                    ctu.m_predMode[z] = u.predMode == 1 ? MODE_INTER : (u.predMode == 2 ? MODE_INTRA : (u.predMode == 3 ? MODE_SKIP : MODE_NONE));
+                    ctu.m_interDir[z] = u.interDir;
+                    for (int l = 0; l < 2; l++) { ctu.m_refIdx[l][z] = u.refIdx[l]; ctu.m_mv[l][z] = MV(u.mv[l][0], u.mv[l][1]); }
+                }
+            }
+        }
+        Slice* sl = fd[0]->m_slice;
+        sl->m_numRefIdx[0] = I->numRefIdx[0]; sl->m_numRefIdx[1] = I->numRefIdx[1]; sl->m_maxNumMergeCand = I->maxNumMergeCand;
+        sl->m_colFromL0Flag = I->colFromL0; sl->m_colRefIdx = 0; sl->m_bCheckLDC = I->checkLdc != 0;
+        for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) sl->m_refFrameList[l][r] = &frame[1];
+    }
+    ~MvFixture()
+    {
+        for (int k = 0; k < 2; k++) { frame[k].m_encData = NULL; fd[k]->destroy(); delete fd[k]; }
+        x265_param_free(param);
+    }
+};
+/* out: merge candidates (count returned in *numMerge); amvp[list][ref][2][2], mvc[list][ref][12][2], numMvc[list][ref] for every reference of every list */
+void ref_mv_pred(const RefMvInfo* I, const RefMvUnit* cur, const RefMvUnit* col, int cuX, int cuY, int log2CU, int partSize, int puIdx,
+                 RefMergeCand* merge, int* numMerge, int16_t* amvp, int16_t* mvc, int* numMvc)
+{
+    ensure();
+    MvFixture f(I, cur, col);
+    const uint32_t addr = (cuY >> 6) * f.sps.numCuInWidth + (cuX >> 6);
+    CUData& ctu = f.fd[0]->m_picCTU[addr];
+    CUGeom geoms[CUGeom::MAX_GEOMS];
+    CUData::calcCTUGeoms(64, 64, 64, 8, geoms);
+    const uint32_t depth = 6 - log2CU;
+    const uint32_t absPartIdx = g_rasterToZscan[((cuY & 63) >> 2) * 16 + ((cuX & 63) >> 2)];
+    const CUGeom* g = NULL;
+    for (int i = 0; i < CUGeom::MAX_GEOMS; i++)
+        if (geoms[i].depth == depth && geoms[i].absPartIdx == absPartIdx) { g = &geoms[i]; break; }
+    CUDataMemPool pool;
+    pool.create(depth, X265_CSP_I420, 1, *f.param);
+    CUData sub;
+    sub.initialize(pool, depth, *f.param, 0);
+    sub.initSubCU(ctu, *g, 30);
+    const int w4 = I->picWidth >> 2;
+    for (uint32_t i = 0; i < g->numPartitions; i++)
+    {
+        const int x = cuX + g_zscanToPelX[absPartIdx + i] - g_zscanToPelX[absPartIdx], y = cuY + g_zscanToPelY[absPartIdx + i] - g_zscanToPelY[absPartIdx];
+        const RefMvUnit& u = cur[(y >> 2) * w4 + (x >> 2)];
+        sub.m_predMode[i] = u.predMode == 1 ? MODE_INTER : (u.predMode == 2 ? MODE_INTRA : (u.predMode == 3 ? MODE_SKIP : MODE_NONE));
+        sub.m_interDir[i] = u.interDir; sub.m_partSize[i] = (uint8_t)partSize; sub.m_log2CUSize[i] = (uint8_t)log2CU; sub.m_cuDepth[i] = (uint8_t)depth;
+        for (int l = 0; l < 2; l++) { sub.m_refIdx[l][i] = u.refIdx[l]; sub.m_mv[l][i] = MV(u.mv[l][0], u.mv[l][1]); }
+    }
+    uint32_t puAddr; int pw, ph;
+    sub.getPartIndexAndSize(puIdx, puAddr, pw, ph);
+    MVField cand[MRG_MAX_NUM_CANDS][2];
+    uint8_t dirs[MRG_MAX_NUM_CANDS];
+    *numMerge = (int)sub.getInterMergeCandidates(puAddr, puIdx, cand, dirs);
+    for (int i = 0; i < *numMerge; i++)
+    {
+        memset(&merge[i], 0, sizeof(merge[i]));
+        merge[i].dir = dirs[i];
+        for (int l = 0; l < 2; l++) { merge[i].mv[l][0] = cand[i][l].mv.x; merge[i].mv[l][1] = cand[i][l].mv.y; merge[i].refIdx[l] = (int8_t)cand[i][l].refIdx; }
+    }
+    InterNeighbourMV nb[6];
+    sub.getNeighbourMV(puIdx, puAddr, nb);
+    for (int l = 0; l < (I->isInterB ? 2 : 1); l++)
+        for (int r = 0; r < I->numRefIdx[l]; r++)
+        {
+            MV a[2], m[(MD_ABOVE_LEFT + 1) * 2 + 2];
+            int n = sub.getPMV(nb, l, r, a, m);
+            int16_t* ao = amvp + (l * 16 + r) * 4; int16_t* mo = mvc + (l * 16 + r) * 24;
+            ao[0] = a[0].x; ao[1] = a[0].y; ao[2] = a[1].x; ao[3] = a[1].y;
+            for (int k = 0; k < n; k++) { mo[2 * k] = m[k].x; mo[2 * k + 1] = m[k].y; }
+            numMvc[l * 16 + r] = n;
+        }
+    pool.destroy();
+}
+
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,
  * flags & 16, two Predict::predInterLumaPixel + pixelavg_pp as search.cpp:2499-2511) and then pu[].sad / pu[].satd /
  * cu[].sa8d (+ the 4:2:0 chroma satd / sa8d) against the source picture.  reserved[0] metric 1 SAD 2 SATD 3 SA8D,

@@ -1773,3 +1773,92 @@ def cabac_run_product(L, c, bits_only=0):
     L.lib.x265amd_cabac_get_contexts(h, _ptr(ctx))
     L.lib.x265amd_cabac_close(h)
     return out[:n].copy(), ctx[:CTX_COUNT].copy(), units["qp"].ravel().copy()
+
+
+# ---- motion vector prediction (merge / AMVP candidates) ----
+MV_UNIT_DT = np.dtype([("pred_mode", "u1"), ("inter_dir", "u1"), ("ref_idx", "i1", 2), ("mv", "<i2", (2, 2))])
+MVPRED_INFO_DT = np.dtype([("pic_width", "<i4"), ("pic_height", "<i4"), ("is_inter_b", "<i4"), ("num_ref_idx", "<i4", 2), ("max_num_merge_cand", "<i4"),
+                           ("temporal_mvp", "<i4"), ("col_from_l0", "<i4"), ("check_ldc", "<i4"), ("poc", "<i4"), ("ref_poc", "<i4", (2, 16)),
+                           ("col_poc", "<i4"), ("col_ref_poc", "<i4", (2, 16))])
+MERGE_CAND_DT = np.dtype([("mv", "<i2", (2, 2)), ("ref_idx", "i1", 2), ("dir", "u1"), ("reserved", "u1")])
+assert MV_UNIT_DT.itemsize == 12 and MERGE_CAND_DT.itemsize == 12 and MVPRED_INFO_DT.itemsize == 4 * (10 + 32 + 1 + 32)
+
+
+def mv_field(rng, width, height, is_b, nref, block=8):
+    """random motion field, constant over block x block areas (with some 4-sample detail), about a quarter intra"""
+    w4, h4 = width // 4, height // 4
+    f = np.zeros((h4, w4), MV_UNIT_DT)
+    for by in range(0, h4, block // 4):
+        for bx in range(0, w4, block // 4):
+            sl = f[by:by + block // 4, bx:bx + block // 4]
+            k = int(rng.integers(0, 8))
+            if k == 0:
+                sl["pred_mode"], sl["ref_idx"] = MODE_INTRA, (-1, -1)
+                continue
+            sl["pred_mode"] = MODE_SKIP if k == 1 else MODE_INTER
+            idir = int(rng.integers(1, 4)) if is_b else 1
+            sl["inter_dir"] = idir
+            base = (int(rng.integers(-3, 4)), int(rng.integers(-3, 4)))
+            for l in range(2):
+                if idir & (1 << l):
+                    sl["ref_idx"][..., l] = int(rng.integers(0, nref[l]))
+                    sl["mv"][..., l, 0] = base[0] * 4 + int(rng.integers(-1, 2)) * int(rng.integers(0, 2))
+                    sl["mv"][..., l, 1] = base[1] * 4 + int(rng.integers(-1, 2)) * int(rng.integers(0, 2))
+                else:
+                    sl["ref_idx"][..., l] = -1
+    return f
+
+
+def mvpred_case(seed, width, height, is_b):
+    rng = np.random.default_rng(seed)
+    info = np.zeros(1, MVPRED_INFO_DT)[0]
+    nref = (int(rng.integers(1, 5)), int(rng.integers(1, 4)) if is_b else 0)
+    info["pic_width"], info["pic_height"], info["is_inter_b"], info["num_ref_idx"] = width, height, int(is_b), nref
+    info["max_num_merge_cand"], info["temporal_mvp"] = int(rng.integers(1, 6)), int(rng.integers(0, 4) > 0)
+    info["col_from_l0"], info["check_ldc"] = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    poc = int(rng.integers(8, 40))
+    info["poc"] = poc
+    rp = np.zeros((2, 16), np.int32)
+    rp[0, :] = poc - 1 - np.arange(16) * int(rng.integers(1, 3))
+    rp[1, :] = (poc + 1 + np.arange(16)) if rng.integers(0, 2) else rp[0, :]          # forward references, or a low-delay style list
+    info["ref_poc"] = rp
+    info["col_poc"] = int(rp[0, 0])
+    info["col_ref_poc"] = np.stack([rp[0, 0] - 1 - np.arange(16) * 2, rp[0, 0] + 2 + np.arange(16)])
+    cur = mv_field(rng, width, height, is_b, nref)
+    col = mv_field(rng, width, height, True, (4, 3), block=16)
+    # the CUs / PUs to predict: random positions and shapes
+    pus = []
+    for _ in range(60):
+        log2 = int(rng.integers(3, 7))
+        size = 1 << log2
+        if size > min(width, height):
+            continue
+        x, y = int(rng.integers(0, (width - size) // size + 1)) * size, int(rng.integers(0, (height - size) // size + 1)) * size
+        part = int(rng.choice([0, 1, 2] + ([4, 5, 6, 7] if size >= 16 else [])))
+        pus.append((x, y, log2, part, int(rng.integers(0, 1 if part == 0 else 2))))
+    return dict(info=info, cur=np.ascontiguousarray(cur.ravel()), col=np.ascontiguousarray(col.ravel()), pus=pus)
+
+
+def mvpred_run(L, c):
+    """list per PU of (merge array, {(list, ref): (amvp 2x2, mvc k x 2)})"""
+    info = np.array([c["info"]], MVPRED_INFO_DT)
+    nref = c["info"]["num_ref_idx"]
+    out = []
+    for (x, y, log2, part, pu) in c["pus"]:
+        merge = np.zeros(5, MERGE_CAND_DT)
+        if L.prefix == "ref_":
+            nm = C.c_int(0)
+            amvp = np.zeros((2, 16, 2, 2), np.int16); mvc = np.zeros((2, 16, 12, 2), np.int16); nmvc = np.zeros((2, 16), np.int32)
+            L.lib.ref_mv_pred(_ptr(info), _ptr(c["cur"]), _ptr(c["col"]), x, y, log2, part, pu, _ptr(merge), C.byref(nm), _ptr(amvp), _ptr(mvc), _ptr(nmvc))
+            res = {(l, r): (amvp[l, r].copy(), mvc[l, r, :nmvc[l, r]].copy()) for l in range(2 if c["info"]["is_inter_b"] else 1) for r in range(int(nref[l]))}
+            out.append((merge[:nm.value].copy(), res))
+        else:
+            nm = L.lib.x265amd_merge_candidates(_ptr(info), _ptr(c["cur"]), _ptr(c["col"]), x, y, log2, part, pu, _ptr(merge))
+            res = {}
+            for l in range(2 if c["info"]["is_inter_b"] else 1):
+                for r in range(int(nref[l])):
+                    a = np.zeros((2, 2), np.int16); m = np.zeros((12, 2), np.int16)
+                    k = L.lib.x265amd_amvp_candidates(_ptr(info), _ptr(c["cur"]), _ptr(c["col"]), x, y, log2, part, pu, l, r, _ptr(a), _ptr(m))
+                    res[(l, r)] = (a, m[:k].copy())
+            out.append((merge[:nm].copy(), res))
+    return out
