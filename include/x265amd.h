@@ -527,6 +527,34 @@ int x265amd_merge_candidates(const x265amd_mvpred_info* info, const x265amd_mv_u
 int x265amd_amvp_candidates(const x265amd_mvpred_info* info, const x265amd_mv_unit* cur, const x265amd_mv_unit* col, int cu_x, int cu_y, int log2_cu_size,
                             int part_size, int pu_idx, int list, int ref_idx, int16_t amvp[2][2], int16_t mvc[12][2]);
 
+/* --- whole-CU inter search for a batch of CUs: Search::predInterSearch (reference: source/encoder/search.cpp:2181-2647)
+ * with mergeEstimation, selectMVP, setSearchRange, checkBestMVP, getBlkBits.  Decisions are made on the host in the reference's order;
+ * the block operations of each step of all CUs run as one GPU batch (x265amd_inter_cost, x265amd_me_search,
+ * x265amd_motion_compensation).  No weighted prediction, HME, analysis reuse or frame-parallel lag clipping. */
+typedef struct x265amd_inter_search_params
+{
+    int32_t search_method, subpel_refine, search_range;     /* param.searchMethod (X265AMD_ME_*), subpelRefine, searchRange */
+    int32_t qp;                                             /* the CU's QP: lambda (RDCost::setQP) and the MV cost table (MotionEstimate::setQP) */
+    int32_t chroma_mc;                                      /* bChromaMC: chroma in the final prediction, and chroma SATD when subpel_refine > 2 */
+    int32_t ref_pic[2][16];                                 /* picture index (into the plane table) of reference r of list l */
+} x265amd_inter_search_params;
+typedef struct x265amd_inter_cu { int16_t x, y; uint8_t log2_size, part_size; uint8_t reserved[2]; } x265amd_inter_cu;
+typedef struct x265amd_pu_result
+{
+    uint8_t merge_flag, inter_dir;  /* m_mergeFlag, m_interDir */
+    int8_t ref_idx[2];
+    uint8_t mvp_idx[2];             /* m_mvpIdx ([0] = merge index for merged PUs) */
+    uint8_t reserved[2];
+    int16_t mv[2][2], mvd[2][2];
+} x265amd_pu_result;
+/* cur: the picture's motion field (host; patched and restored during the call); col: co-located field or NULL.  h_planes: HOST array of
+ * num_pics x 3 device addresses (sample (0,0) of Y, U, V; the last picture is the source).  out: n x 2 PU results; bits_out[i]: what
+ * predInterSearch adds to sa8dBits.  d_pred: device buffer of n tiles of pred_bytes_per_cu bytes, each 64x64 luma (stride 64) followed by
+ * 32x32 U and V (stride 32), receiving interMode.predYuv.  Synchronous (it reads costs back between its steps). */
+int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* info, const x265amd_inter_search_params* sp,
+                              x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
+                              const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

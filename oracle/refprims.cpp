@@ -12,6 +12,8 @@
 #include "deblock.h"
 #include "sao.h"
 #include "bitstream.h"
+#include "search.h"
+#include <vector>
 #include "frame.h"
 #include "x265.h"
 #include "constants.h"
@@ -1011,6 +1013,139 @@ void ref_mv_pred(const RefMvInfo* I, const RefMvUnit* cur, const RefMvUnit* col,
             numMvc[l * 16 + r] = n;
         }
     pool.destroy();
+}
+
+/* ---- Search::predInterSearch (encoder/search.cpp:2181-2647) itself, on a fixture: CUData / Slice / MotionReference / Frame objects built
+ * from raster motion fields and padded planes; one CU per call ---- */
+struct RefSearchParams { int32_t searchMethod, subpelRefine, searchRange, qp, bChromaMC, numPics, refPic[2][16]; };
+struct RefPuResult { uint8_t mergeFlag, interDir; int8_t refIdx[2]; uint8_t mvpIdx[2]; uint8_t pad[2]; int16_t mv[2][2]; int16_t mvd[2][2]; };
+static PicYuv* mkPic(x265_param* param, const SPS& sps, const uint64_t* planes, intptr_t stride, intptr_t cstride, int width, int height, int mx, int my)
+{
+    PicYuv* p = new PicYuv;
+    p->m_param = param; p->m_picCsp = X265_CSP_I420; p->m_hChromaShift = p->m_vChromaShift = 1;
+    p->m_picOrg[0] = (pixel*)planes[0]; p->m_picOrg[1] = (pixel*)planes[1]; p->m_picOrg[2] = (pixel*)planes[2];
+    p->m_picBuf[0] = p->m_picOrg[0] - my * stride - mx; p->m_picBuf[1] = p->m_picOrg[1] - (my / 2) * cstride - mx / 2; p->m_picBuf[2] = p->m_picOrg[2] - (my / 2) * cstride - mx / 2;
+    p->m_stride = stride; p->m_strideC = cstride; p->m_picWidth = width; p->m_picHeight = height;
+    p->m_lumaMarginX = mx; p->m_lumaMarginY = my; p->m_chromaMarginX = mx / 2; p->m_chromaMarginY = my / 2;
+    p->createOffsets(sps);
+    return p;
+}
+static void dropPic(PicYuv* p)
+{
+    for (int c = 0; c < 3; c++) p->m_picOrg[c] = p->m_picBuf[c] = NULL;
+    X265_FREE(p->m_cuOffsetY); X265_FREE(p->m_cuOffsetC); X265_FREE(p->m_buOffsetY); X265_FREE(p->m_buOffsetC);
+    p->m_cuOffsetY = p->m_cuOffsetC = p->m_buOffsetY = p->m_buOffsetC = NULL;
+    delete p;
+}
+/* planes: numPics x 3 addresses of sample (0,0); picture numPics-1 is the source.  refPic[list][ref] = picture index of that reference.
+ * predY / predU / predV: 64x64 / 32x32 buffers (strides 64 / 32) receiving interMode.predYuv; returns sa8dBits */
+int ref_pred_inter_search(const RefMvInfo* I, const RefSearchParams* S, const RefMvUnit* cur, const RefMvUnit* col, const uint64_t* planes, intptr_t stride,
+                          intptr_t cstride, int marginX, int marginY, int cuX, int cuY, int log2CU, int partSize, RefPuResult* out, pixel* predY, pixel* predU, pixel* predV)
+{
+    ensure();
+    MvFixture f(I, cur, col);
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 0 done\n");
+    x265_param* param = f.param;
+    param->searchMethod = S->searchMethod; param->subpelRefine = S->subpelRefine; param->searchRange = S->searchRange;
+    param->frameNumThreads = 1; param->maxSlices = 1; param->bframes = 0; param->bEnableWeightedPred = param->bEnableWeightedBiPred = 0;
+    param->bDistributeMotionEstimation = 0; param->bEnableHME = 0; param->analysisLoadReuseLevel = 0; param->analysisSave = NULL; param->analysisLoad = NULL;
+    param->analysisMultiPassRefine = 0; param->bAnalysisType = 0; param->bIntraRefresh = 0; param->bSourceReferenceEstimation = 0;
+    param->psyRd = 0; param->bSsimRd = 0; param->psyRdoq = 0; param->noiseReductionIntra = param->noiseReductionInter = 0; param->limitTU = 0;
+    param->interRefine = 0; param->mvRefine = 1; param->rc.bStatRead = 0;
+    Slice* slice = f.fd[0]->m_slice;
+    f.sps.quadtreeTULog2MaxSize = 5; f.sps.quadtreeTULog2MinSize = 2;
+    std::vector<PicYuv*> pics;
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 1 done\n");
+    for (int i = 0; i < S->numPics; i++) pics.push_back(mkPic(param, f.sps, planes + 3 * i, stride, cstride, I->picWidth, I->picHeight, marginX, marginY));
+    static Frame refFrames[2][16];
+    static MV noLowres(0x7FFF, 0);
+    MotionReference (*mref)[MAX_NUM_REF + 1] = new MotionReference[2][MAX_NUM_REF + 1];       /* FrameEncoder::m_mref */
+    slice->m_mref = mref;
+    Frame& frame = f.frame[0];
+    frame.m_fencPic = pics.back();
+    for (int l = 0; l < 2; l++) for (int i = 0; i < X265_BFRAME_MAX + 2; i++) frame.m_lowres.lowresMvs[l][i] = &noLowres;
+    f.fd[0]->m_reconPic = pics.back();
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < I->numRefIdx[l]; r++)
+        {
+            PicYuv* rp = pics[S->refPic[l][r]];
+            slice->m_refReconPicList[l][r] = rp;
+            refFrames[l][r].m_encData = f.fd[1]; refFrames[l][r].m_reconPic = rp; refFrames[l][r].m_fencPic = rp; refFrames[l][r].m_param = param;
+            slice->m_refFrameList[l][r] = &refFrames[l][r];
+            slice->m_mref[l][r].init(rp, NULL, *param);
+        }
+    int bits = 0;
+    {
+        Search* search = new Search;
+        ScalingList* sl = new ScalingList;
+        sl->init(); sl->m_bEnabled = false; sl->m_bDataPresent = false; sl->setupQuantMatrices(X265_CSP_I420);
+        search->initSearch(*param, *sl);
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 2 done\n");
+        search->m_slice = slice; search->m_frame = &frame;
+        const uint32_t addr = (cuY >> 6) * f.sps.numCuInWidth + (cuX >> 6);
+        CUData& ctu = f.fd[0]->m_picCTU[addr];
+        search->setLambdaFromQP(ctu, S->qp);
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 3 done\n");
+        CUGeom geoms[CUGeom::MAX_GEOMS];
+        CUData::calcCTUGeoms(64, 64, 64, 8, geoms);
+        const uint32_t depth = 6 - log2CU;
+        const uint32_t absPartIdx = g_rasterToZscan[((cuY & 63) >> 2) * 16 + ((cuX & 63) >> 2)];
+        const CUGeom* g = NULL;
+        for (int i = 0; i < CUGeom::MAX_GEOMS; i++)
+            if (geoms[i].depth == depth && geoms[i].absPartIdx == absPartIdx) { g = &geoms[i]; break; }
+        CUDataMemPool pool;
+        pool.create(depth, X265_CSP_I420, 1, *param);
+        Mode* mode = new Mode;
+        mode->cu.initialize(pool, depth, *param, 0);
+        mode->predYuv.create(1 << log2CU, X265_CSP_I420);
+        Yuv fenc;
+        fenc.create(1 << log2CU, X265_CSP_I420);
+        fenc.copyFromPicYuv(*frame.m_fencPic, addr, absPartIdx);
+        mode->fencYuv = &fenc;
+        mode->cu.initSubCU(ctu, *g, S->qp);
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 4 done\n");
+        mode->cu.setPartSizeSubParts((PartSize)partSize);
+        mode->cu.setPredModeSubParts(MODE_INTER);
+        mode->initCosts();
+        uint32_t masks[2] = { 0, 0 };
+        search->predInterSearch(*mode, *g, S->bChromaMC != 0, masks);
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 5 done\n");
+        bits = (int)mode->sa8dBits;
+        const int numPart = mode->cu.getNumPartInter(0);
+        for (int p = 0; p < numPart; p++)
+        {
+            uint32_t pa; int pw, ph;
+            mode->cu.getPartIndexAndSize(p, pa, pw, ph);
+            RefPuResult& r = out[p];
+            memset(&r, 0, sizeof(r));
+            r.mergeFlag = mode->cu.m_mergeFlag[pa]; r.interDir = mode->cu.m_interDir[pa];
+            for (int l = 0; l < 2; l++)
+            {
+                r.refIdx[l] = mode->cu.m_refIdx[l][pa]; r.mvpIdx[l] = mode->cu.m_mvpIdx[l][pa];
+                r.mv[l][0] = mode->cu.m_mv[l][pa].x; r.mv[l][1] = mode->cu.m_mv[l][pa].y;
+                r.mvd[l][0] = mode->cu.m_mvd[l][pa].x; r.mvd[l][1] = mode->cu.m_mvd[l][pa].y;
+            }
+        }
+        const int n = 1 << log2CU;
+        for (int y = 0; y < n; y++) memcpy(predY + y * 64, mode->predYuv.m_buf[0] + y * mode->predYuv.m_size, n * sizeof(pixel));
+        if (S->bChromaMC)
+            for (int y = 0; y < n / 2; y++)
+            {
+                memcpy(predU + y * 32, mode->predYuv.m_buf[1] + y * mode->predYuv.m_csize, (n / 2) * sizeof(pixel));
+                memcpy(predV + y * 32, mode->predYuv.m_buf[2] + y * mode->predYuv.m_csize, (n / 2) * sizeof(pixel));
+            }
+        mode->predYuv.destroy(); fenc.destroy();
+        delete mode;
+        pool.destroy();
+        delete search;
+    if (getenv("REF_TRACE")) fprintf(stderr, "stage 6 done\n");
+        delete sl;
+    }
+    f.fd[0]->m_reconPic = NULL; frame.m_fencPic = NULL;
+    slice->m_mref = NULL;
+    delete[] mref;
+    for (size_t i = 0; i < pics.size(); i++) dropPic(pics[i]);
+    return bits;
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

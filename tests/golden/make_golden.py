@@ -44,6 +44,7 @@ def main():
     make_entropy_golden()
     make_inter_cost_golden()
     make_intra_tu_golden()
+    make_inter_search_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -191,6 +192,19 @@ def make_intra_tu_golden():
             out["digest/%d/%d" % (depth, seed)] = tit.digest(T.intra_tu_run_host(ref, cases))
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_tu_golden.npz"), **out)
     print("wrote intra_tu_golden.npz with", len(out), "arrays")
+
+
+def make_inter_search_golden():
+    """results of the reference's Search::predInterSearch on CUData / Slice / MotionReference fixtures -> tests/golden/inter_search_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tis", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_inter_search.py"))
+    tis = importlib.util.module_from_spec(spec); spec.loader.exec_module(tis)
+    out = {}
+    for i, (depth, seed, b) in enumerate(tis.CASES):
+        bits, pus, dig = tis.pack(T.inter_search_run_ref(T.load_ref(depth), T.inter_search_case(depth, seed, b)))
+        out["bits/%d" % i], out["pus/%d" % i], out["pred/%d" % i] = bits, pus, dig
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "inter_search_golden.npz"), **out)
+    print("wrote inter_search_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

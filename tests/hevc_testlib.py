@@ -1862,3 +1862,119 @@ def mvpred_run(L, c):
                     res[(l, r)] = (a, m[:k].copy())
             out.append((merge[:nm].copy(), res))
     return out
+
+
+# ---- predInterSearch: whole-CU inter search (AMVP, ME, merge, bi-prediction, choice, final MC) ----
+SEARCH_PARAMS_DT = np.dtype([("searchMethod", "<i4"), ("subpelRefine", "<i4"), ("searchRange", "<i4"), ("qp", "<i4"), ("bChromaMC", "<i4"), ("numPics", "<i4"),
+                             ("refPic", "<i4", (2, 16))])
+PU_RESULT_DT = np.dtype([("merge_flag", "u1"), ("inter_dir", "u1"), ("ref_idx", "i1", 2), ("mvp_idx", "u1", 2), ("pad", "u1", 2), ("mv", "<i2", (2, 2)), ("mvd", "<i2", (2, 2))])
+assert PU_RESULT_DT.itemsize == 24
+
+
+def inter_scene(depth, seed, npics=4):
+    """npics padded 4:2:0 pictures that are displaced, noisy views of one textured picture (last one = the source): returns
+    (list of flat arrays Y|U|V, stride, cstride, origins) with the geometry of mc_make_refs"""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    stride, cstride = MC_W + 2 * MC_MX, MC_W // 2 + MC_MX
+    big = rng.integers(0, pmax + 1, ((MC_H + 64) // 8 + 2, (MC_W + 64) // 8 + 2)).astype(np.int64)
+    big = np.kron(big, np.ones((8, 8), np.int64))
+    big = (big + np.roll(big, 3, 0) + np.roll(big, 5, 1) + np.roll(big, -2, 1)) // 4
+    cb = (np.roll(big, 7, 0)[::2, ::2] + big[1::2, 1::2]) // 2
+    cr = (np.roll(big, 11, 1)[::2, ::2] + big[::2, 1::2]) // 2
+    pics = []
+    for k in range(npics):
+        dx, dy = (0, 0) if k == npics - 1 else (int(rng.integers(-6, 7)) * 2, int(rng.integers(-5, 6)) * 2)
+        planes = []
+        for (src, w, h, m_x, m_y, sx, sy) in ((big, MC_W, MC_H, MC_MX, MC_MY, dx, dy), (cb, MC_W // 2, MC_H // 2, MC_MX // 2, MC_MY // 2, dx // 2, dy // 2),
+                                             (cr, MC_W // 2, MC_H // 2, MC_MX // 2, MC_MY // 2, dx // 2, dy // 2)):
+            o = 16 if src is big else 8
+            core = src[o + sy:o + sy + h, o + sx:o + sx + w] + rng.integers(-2, 3, (h, w)) * (1 << (depth - 8))
+            core = np.clip(core, 0, pmax).astype(dt)
+            planes.append(np.pad(core, ((m_y, m_y), (m_x, m_x)), mode="edge").ravel())
+        pics.append(np.concatenate(planes))
+    ysz, csz = (MC_H + 2 * MC_MY) * stride, (MC_H // 2 + MC_MY) * cstride
+    org = (MC_MY * stride + MC_MX, ysz + (MC_MY // 2) * cstride + MC_MX // 2, ysz + csz + (MC_MY // 2) * cstride + MC_MX // 2)
+    return pics, stride, cstride, org
+
+
+def inter_search_case(depth, seed, is_b):
+    rng = np.random.default_rng(seed)
+    pics, stride, cstride, org = inter_scene(depth, seed)
+    c = mvpred_case(seed, MC_W, MC_H, is_b)
+    info = c["info"]
+    sp = np.zeros(1, SEARCH_PARAMS_DT)[0]
+    sp["searchMethod"], sp["subpelRefine"] = int(rng.choice([ME_HEX, ME_STAR, ME_DIA])), int(rng.choice([1, 2, 3]))
+    sp["searchRange"], sp["qp"], sp["numPics"] = 57, int(rng.integers(22, 40)), len(pics)
+    sp["bChromaMC"] = int(rng.integers(0, 2))
+    rp = np.zeros((2, 16), np.int32)
+    for l in range(2):
+        for r in range(16):
+            rp[l, r] = (r + l) % (len(pics) - 1)
+    sp["refPic"] = rp
+    cus = []
+    for _ in range(14):
+        log2 = int(rng.integers(3, 7))
+        size = 1 << log2
+        x, y = int(rng.integers(0, MC_W // size)) * size, int(rng.integers(0, MC_H // size)) * size
+        part = int(rng.choice([0, 0, 1, 2] + ([4, 5, 6, 7] if size >= 16 else [])))
+        cus.append((x, y, log2, part))
+    return dict(pics=pics, stride=stride, cstride=cstride, org=org, info=info, sp=sp, cur=c["cur"], col=c["col"], cus=cus)
+
+
+def inter_search_run_ref(R, c):
+    isz = c["pics"][0].itemsize
+    planes = np.array([p.ctypes.data + c["org"][k] * isz for p in c["pics"] for k in range(3)], np.uint64)
+    info = np.array([c["info"]], MVPRED_INFO_DT); sp = np.array([c["sp"]], SEARCH_PARAMS_DT)
+    out = []
+    dt = c["pics"][0].dtype
+    for (x, y, log2, part) in c["cus"]:
+        res = np.zeros(2, PU_RESULT_DT)
+        py, pu, pv = np.zeros((64, 64), dt), np.zeros((32, 32), dt), np.zeros((32, 32), dt)
+        bits = R.lib.ref_pred_inter_search(_ptr(info), _ptr(sp), _ptr(c["cur"]), _ptr(c["col"]), _ptr(planes), C.c_int64(c["stride"]), C.c_int64(c["cstride"]),
+                                           MC_MX, MC_MY, x, y, log2, part, _ptr(res), _ptr(py), _ptr(pu), _ptr(pv))
+        n = 1 << log2
+        out.append((int(bits), res[:(1 if part == 0 else 2)].copy(), py[:n, :n].copy(), pu[:n // 2, :n // 2].copy(), pv[:n // 2, :n // 2].copy()))
+    return out
+
+
+INTER_CU_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("log2", "u1"), ("part", "u1"), ("reserved", "u1", 2)])
+INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16))])
+
+
+def inter_search_run_hip(L, me, c):
+    """x265amd_pred_inter_search on the whole CU list of the case; same return shape as inter_search_run_ref"""
+    import torch
+    isz = c["pics"][0].itemsize
+    dt = c["pics"][0].dtype
+    d_pics = [torch.from_numpy(p.view(np.uint8)).cuda() for p in c["pics"]]
+    planes = np.array([d.data_ptr() + c["org"][k] * isz for d in d_pics for k in range(3)], np.uint64)
+    info = np.array([c["info"]], MVPRED_INFO_DT)
+    sp = np.zeros(1, INTER_SP_DT)
+    for a, b in (("search_method", "searchMethod"), ("subpel_refine", "subpelRefine"), ("search_range", "searchRange"), ("qp", "qp"), ("chroma_mc", "bChromaMC")):
+        sp[0][a] = c["sp"][b]
+    sp[0]["ref_pic"] = c["sp"]["refPic"]
+    n = len(c["cus"])
+    cus = np.zeros(n, INTER_CU_DT)
+    for i, (x, y, log2, part) in enumerate(c["cus"]):
+        cus[i] = (x, y, log2, part, 0)
+    out = np.zeros(2 * n, PU_RESULT_DT); bits = np.zeros(n, np.int32)
+    per = (64 * 64 + 2 * 32 * 32) * isz
+    d_pred = torch.zeros(n * per, dtype=torch.uint8, device="cuda")
+    cur = c["cur"].copy()
+    rc = L.lib.x265amd_pred_inter_search(me.ctx, None, _ptr(info), _ptr(sp), _ptr(cur), _ptr(c["col"]), _ptr(planes), len(c["pics"]), C.c_int64(c["stride"]),
+                                         C.c_int64(c["cstride"]), _ptr(cus), n, _ptr(out), _ptr(bits), C.c_uint64(d_pred.data_ptr()), C.c_size_t(per))
+    assert rc == 0, L.lib.x265amd_last_error()
+    assert np.array_equal(cur, c["cur"])            # the motion field is restored
+    pred = d_pred.cpu().numpy().reshape(n, per)
+    res = []
+    for i, (x, y, log2, part) in enumerate(c["cus"]):
+        s = 1 << log2
+        py = pred[i, :64 * 64 * isz].view(dt).reshape(64, 64)[:s, :s].copy()
+        pu = pred[i, 64 * 64 * isz:(64 * 64 + 32 * 32) * isz].view(dt).reshape(32, 32)[:s // 2, :s // 2].copy()
+        pv = pred[i, (64 * 64 + 32 * 32) * isz:].view(dt).reshape(32, 32)[:s // 2, :s // 2].copy()
+        if not c["sp"]["bChromaMC"]:
+            pu[:] = 0; pv[:] = 0
+        res.append((int(bits[i]), out[2 * i:2 * i + (1 if part == 0 else 2)].copy(), py, pu, pv))
+    return res
