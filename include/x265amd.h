@@ -555,6 +555,69 @@ int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const x265amd_mv
                               x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
                               const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu);
 
+/* --- residual RD of inter CUs: Search::encodeResAndCalcRdInterCU (reference: source/encoder/search.cpp:2822-2975) with
+ * estimateResidualQT (:3178-3857), splitTU (:3126-3176), estimateNullCbfCost (:3114-3124), codeInterSubdivCbfQT (:3859-3887),
+ * saveResidualQTData (:3889-3972) and checkDQP (:3974-4003), for a batch of independent candidate CUs.
+ * The transform chains of every node of every CU's residual quad-tree run as one x265amd_tu_chain launch (plain quantisation does not
+ * depend on the entropy state); the bit counting and the decisions walk the tree on the host in the reference's order with the
+ * bit-counting CABAC coder; a second launch assembles the chosen residual, reconstructs and measures the CU.
+ * Supported: 4:2:0, rdoqLevel 0, no transform skip / lossless / limit-tu / ssim-rd, chroma QP offsets 0. */
+typedef struct x265amd_rd_params
+{
+    double psy_rd;                  /* param.psyRd (RDCost::setPsyRdScale, rdcost.h:43) */
+    int32_t rd_level;               /* param.rdLevel: how checkDQP prices a delta QP (>= 3 codes it, 2 counts one bit) */
+    int32_t reserved;
+} x265amd_rd_params;
+typedef struct x265amd_rd_cu
+{
+    int16_t x, y;                   /* luma position of the CU in the picture */
+    uint8_t log2_size;              /* 3..6 */
+    int8_t qp;                      /* the CU's QP (setLambdaFromQP: RD lambdas and quantiser) */
+    uint8_t reserved[2];
+    uint64_t frac_bits;             /* m_rqt[depth].cur.m_fracBits on entry (only its low 15 bits matter) */
+    uint8_t ctx[X265AMD_CTX_STRIDE];/* m_rqt[depth].cur context states on entry */
+} x265amd_rd_cu;                    /* 176 bytes */
+typedef struct x265amd_rd_result
+{
+    uint64_t rd_cost, distortion;   /* Mode::rdCost, Mode::distortion */
+    uint64_t frac_bits;             /* Mode::contexts.m_fracBits */
+    uint32_t total_bits, mv_bits, coeff_bits, psy_energy, luma_distortion, chroma_distortion, res_energy, reserved;
+    uint8_t ctx[X265AMD_CTX_STRIDE];/* Mode::contexts context states */
+} x265amd_rd_result;                /* 216 bytes */
+/* units: the picture's unit map (what is coded so far; read for the skip-flag / QP neighbourhood, patched and restored during the call).
+ * cu_units: n x 256 records, the candidate CU's units in raster order with row length size/4, carrying the prediction fields
+ * (pred_mode X265AMD_MODE_INTER, part_size, merge_flag, inter_dir, ref_idx, mvp_idx, mvd, qp); on return tu_depth, cbf, pred_mode (SKIP when
+ * a merged 2Nx2N CU ends without residual) and qp are filled in as the reference leaves them in Mode::cu.
+ * h_src: HOST array of 3 device addresses, sample (0,0) of the source Y, U, V (strides stride / cstride).
+ * d_pred / d_recon: device tiles as x265amd_pred_inter_search writes them (64x64 luma stride 64, then 32x32 U and V stride 32);
+ * tile_bytes apart.  coeff_out: HOST, n x (4096 + 2 x 1024) levels in CUData::m_trCoeff layout (TU blocks at z-order offsets), only TUs with
+ * a coded block flag are written (others zero); may be NULL.  Synchronous. */
+int x265amd_inter_residual_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                              const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                              x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
+                              x265amd_rd_result* out, int16_t* coeff_out);
+
+/* The host stages x265amd_inter_residual_rd runs around its two launches, callable on their own (no GPU work inside): the addresses they
+ * handle are opaque, so a test can drive them with any engine that executes x265amd_tu_job records.
+ * Per-CU scratch (x265amd_inter_rd_scratch_bytes() apart): E = 4 * 4096 + 6 * 1024 elements each of levels (int16), residual (int16) and a
+ * reconstruction dump (pixels).  Element offsets: luma layer L (transform log2 size 2..5) at (L - 2) * 4096, chroma layer C (2..4) of plane
+ * p (1, 2) at 16384 + ((C - 2) * 2 + p - 1) * 1024; levels are TU blocks in raster TU order, residual / dump blocks sit at their position in
+ * a stride-64 (luma) / stride-32 (chroma) tile.  The selection map (384 bytes per CU): for each luma 4x4 unit (row length 16), then each
+ * chroma 4x4 unit of U and of V (row length 8), the layer whose residual block was kept, 0xFF for none. */
+typedef struct x265amd_cu_measure { uint64_t sse[3]; uint32_t psy, reserved; } x265amd_cu_measure;     /* sse_pp per plane, luma psyCost */
+size_t x265amd_inter_rd_scratch_bytes(void);
+/* emits the transform-chain jobs of all CUs (returns their number; jobs_out may be NULL to count) */
+int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
+                          intptr_t stride, intptr_t cstride, uint64_t pred, size_t tile_bytes, uint64_t scratch, x265amd_tu_job* jobs_out, int cap);
+/* the decisions: res = the results of the plan's jobs in order, levels = the level part of CU i's scratch at levels + i * levels_stride_bytes,
+ * zero_meas = prediction-vs-source measurement per CU; fills cu_units, sel, the entropy side of out, coeff_out */
+int x265amd_inter_rd_walk(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
+                          x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
+                          const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out);
+/* final_meas = reconstruction-vs-source measurement per CU: distortion, psy energy and rd_cost of out */
+void x265amd_inter_rd_finish(const x265amd_slice_info* si, const x265amd_rd_params* rp, const x265amd_rd_cu* cus, int n,
+                             const x265amd_cu_measure* final_meas, x265amd_rd_result* out);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

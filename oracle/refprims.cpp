@@ -1148,6 +1148,161 @@ int ref_pred_inter_search(const RefMvInfo* I, const RefSearchParams* S, const Re
     return bits;
 }
 
+/* ---- Search::encodeResAndCalcRdInterCU (encoder/search.cpp:2822-2975: estimateResidualQT, the no-residual alternative, the CU's
+ * syntax bits, reconstruction, updateModeCost, checkDQP) itself, on a fixture: picture CUData built from the raster unit map (which already
+ * carries the candidate CU's prediction fields), the source picture, and a given prediction block; one CU per call ---- */
+struct RefRdParams { double psyRd; int32_t rdLevel, reserved; };
+struct RefRdResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, mvBits, coeffBits, psyEnergy, lumaDist, chromaDist, resEnergy, reserved; uint8_t ctx[160]; };
+/* srcPlanes: addresses of sample (0,0) of the source Y, U, V.  predY/U/V: strides 64 / 32.  cuUnitsOut: the CU's units after the call, raster within the
+ * CU (row length size/4).  coeffOut: 4096 + 2 * 1024 levels in CUData::m_trCoeff layout.  reconY/U/V: strides 64 / 32. */
+void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
+                           int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, const pixel* predY, const pixel* predU, const pixel* predV,
+                           RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
+{
+    ensure();
+    const int width = si->picWidth, height = si->picHeight;
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420;
+    param->maxCUSize = 64; param->minCUSize = 8; param->maxLog2CUSize = 6; param->unitSizeDepth = 4; param->num4x4Partitions = 256;
+    param->maxCUDepth = si->maxCuDepth; param->bLossless = 0;
+    param->frameNumThreads = 1; param->maxSlices = 1; param->bEnableWeightedPred = param->bEnableWeightedBiPred = 0;
+    param->bDistributeMotionEstimation = 0; param->bEnableHME = 0; param->analysisLoadReuseLevel = 0; param->analysisSave = NULL; param->analysisLoad = NULL;
+    param->psyRd = rp->psyRd; param->bSsimRd = 0; param->psyRdoq = 0; param->rdoqLevel = 0; param->noiseReductionIntra = param->noiseReductionInter = 0;
+    param->limitTU = 0; param->rdLevel = rp->rdLevel; param->bEnableTransformSkip = 0; param->bEnableTSkipFast = 0;
+    param->bEnableSignHiding = si->signHide; param->maxTUSize = 1 << si->tuLog2Max;
+    param->tuQTMaxInterDepth = si->tuMaxDepthInter; param->tuQTMaxIntraDepth = si->tuMaxDepthIntra;
+    SPS sps; PPS pps;
+    memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
+    sps.numCuInWidth = (width + 63) / 64; sps.numCuInHeight = (height + 63) / 64; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
+    sps.numPartitions = 256; sps.numPartInCUSize = 16; sps.chromaFormatIdc = X265_CSP_I420;
+    sps.picWidthInLumaSamples = width; sps.picHeightInLumaSamples = height;
+    sps.log2MinCodingBlockSize = 3; sps.log2DiffMaxMinCodingBlockSize = 3;
+    sps.quadtreeTULog2MinSize = si->tuLog2Min; sps.quadtreeTULog2MaxSize = si->tuLog2Max;
+    sps.quadtreeTUMaxDepthInter = si->tuMaxDepthInter; sps.quadtreeTUMaxDepthIntra = si->tuMaxDepthIntra; sps.maxAMPDepth = si->maxAmpDepth;
+    pps.bUseDQP = si->useDqp != 0; pps.maxCuDQPDepth = si->maxCuDqpDepth; pps.bSignHideEnabled = si->signHide != 0;
+    pps.bTransquantBypassEnabled = si->tqBypassEnabled != 0; pps.bTransformSkipEnabled = 0; pps.bEntropyCodingSyncEnabled = si->wpp != 0;
+    FrameData* fd = new FrameData;
+    fd->create(*param, sps, X265_CSP_I420);
+    Slice* slice = fd->m_slice;
+    slice->m_sps = &sps; slice->m_pps = &pps; slice->m_param = param;
+    slice->m_sliceType = si->sliceType == 2 ? I_SLICE : (si->sliceType == 1 ? P_SLICE : B_SLICE);
+    slice->m_sliceQp = si->sliceQp; slice->m_numRefIdx[0] = si->numRefIdx[0]; slice->m_numRefIdx[1] = si->numRefIdx[1];
+    slice->m_maxNumMergeCand = si->maxNumMergeCand;
+    slice->m_endCUAddr = slice->realEndAddress(sps.numCUsInFrame * 256);
+    Frame frame;
+    frame.m_encData = fd; frame.m_param = param;
+    PicYuv* src = mkPic(param, sps, srcPlanes, stride, cstride, width, height, 0, 0);
+    frame.m_fencPic = src;
+    const int w4 = width >> 2;
+    for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
+    {
+        CUData& ctu = fd->m_picCTU[addr];
+        ctu.initCTU(frame, addr, si->sliceQp, addr < sps.numCuInWidth, addr / sps.numCuInWidth == sps.numCuInHeight - 1, 0);
+        ctu.m_chromaFormat = X265_CSP_I420; ctu.m_hChromaShift = ctu.m_vChromaShift = 1;
+        const int cx = (addr % sps.numCuInWidth) * 64, cy = (addr / sps.numCuInWidth) * 64;
+        for (uint32_t z = 0; z < 256; z++)
+        {
+            const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
+            if (x >= width || y >= height) { ctu.m_predMode[z] = MODE_NONE; ctu.m_cuDepth[z] = 0; continue; }
+            const RefCuUnit& u = units[(y >> 2) * w4 + (x >> 2)];
+            ctu.m_cuDepth[z] = u.depth; ctu.m_log2CUSize[z] = (uint8_t)(6 - u.depth);
+            ctu.m_predMode[z] = u.predMode == 1 ? MODE_INTER : (u.predMode == 2 ? MODE_INTRA : (u.predMode == 3 ? MODE_SKIP : MODE_NONE));
+            ctu.m_partSize[z] = u.partSize; ctu.m_tuDepth[z] = u.tuDepth; ctu.m_lumaIntraDir[z] = u.lumaDir; ctu.m_chromaIntraDir[z] = u.chromaDir;
+            ctu.m_mergeFlag[z] = u.mergeFlag; ctu.m_interDir[z] = u.interDir; ctu.m_skipFlag[0][z] = ctu.m_skipFlag[1][z] = 0;
+            for (int c = 0; c < 3; c++) ctu.m_cbf[c][z] = u.cbf[c];
+            ctu.m_tqBypass[z] = u.tqBypass; ctu.m_qp[z] = u.qp;
+            for (int l = 0; l < 2; l++) { ctu.m_refIdx[l][z] = u.refIdx[l]; ctu.m_mvpIdx[l][z] = u.mvpIdx[l]; ctu.m_mvd[l][z] = MV(u.mvd[l][0], u.mvd[l][1]); }
+            ctu.m_transformSkip[0][z] = ctu.m_transformSkip[1][z] = ctu.m_transformSkip[2][z] = 0;
+        }
+    }
+    {
+        Search* search = new Search;
+        ScalingList* sl = new ScalingList;
+        sl->init(); sl->m_bEnabled = false; sl->m_bDataPresent = false; sl->setupQuantMatrices(X265_CSP_I420);
+        search->initSearch(*param, *sl);
+        search->m_slice = slice; search->m_frame = &frame;
+        const uint32_t addr = (cuY >> 6) * sps.numCuInWidth + (cuX >> 6);
+        CUData& ctu = fd->m_picCTU[addr];
+        CUGeom geoms[CUGeom::MAX_GEOMS];
+        CUData::calcCTUGeoms(64, 64, 64, 8, geoms);
+        const uint32_t depth = 6 - log2CU;
+        const uint32_t absPartIdx = g_rasterToZscan[((cuY & 63) >> 2) * 16 + ((cuX & 63) >> 2)];
+        const CUGeom* g = NULL;
+        for (int i = 0; i < CUGeom::MAX_GEOMS; i++)
+            if (geoms[i].depth == depth && geoms[i].absPartIdx == absPartIdx) { g = &geoms[i]; break; }
+        CUDataMemPool pool;
+        pool.create(depth, X265_CSP_I420, 1, *param);
+        Mode* mode = new Mode;
+        mode->cu.initialize(pool, depth, *param, 0);
+        const int n = 1 << log2CU;
+        mode->predYuv.create(n, X265_CSP_I420);
+        mode->reconYuv.create(n, X265_CSP_I420);
+        Yuv fenc;
+        fenc.create(n, X265_CSP_I420);
+        fenc.copyFromPicYuv(*src, addr, absPartIdx);
+        mode->fencYuv = &fenc;
+        mode->cu.initSubCU(ctu, *g, qp);
+        /* the candidate's fields, copied from the picture CTU (initSubCU resets them) */
+        for (uint32_t i = 0; i < g->numPartitions; i++)
+        {
+            const uint32_t z = absPartIdx + i;
+            mode->cu.m_predMode[i] = ctu.m_predMode[z]; mode->cu.m_partSize[i] = ctu.m_partSize[z]; mode->cu.m_mergeFlag[i] = ctu.m_mergeFlag[z];
+            mode->cu.m_interDir[i] = ctu.m_interDir[z]; mode->cu.m_qp[i] = ctu.m_qp[z]; mode->cu.m_tqBypass[i] = 0;
+            for (int l = 0; l < 2; l++) { mode->cu.m_refIdx[l][i] = ctu.m_refIdx[l][z]; mode->cu.m_mvpIdx[l][i] = ctu.m_mvpIdx[l][z]; mode->cu.m_mvd[l][i] = ctu.m_mvd[l][z]; }
+        }
+        for (int y = 0; y < n; y++) memcpy(mode->predYuv.m_buf[0] + y * mode->predYuv.m_size, predY + y * 64, n * sizeof(pixel));
+        for (int y = 0; y < n / 2; y++)
+        {
+            memcpy(mode->predYuv.m_buf[1] + y * mode->predYuv.m_csize, predU + y * 32, (n / 2) * sizeof(pixel));
+            memcpy(mode->predYuv.m_buf[2] + y * mode->predYuv.m_csize, predV + y * 32, (n / 2) * sizeof(pixel));
+        }
+        mode->initCosts();
+        search->setLambdaFromQP(mode->cu, qp);
+        Entropy start;
+        start.resetEntropy(*slice);
+        memcpy(start.m_contextState, ctxIn, MAX_OFF_CTX_MOD);
+        start.m_fracBits = fracIn;
+        search->m_rqt[depth].cur.load(start);
+        search->encodeResAndCalcRdInterCU(*mode, *g);
+        memset(out, 0, sizeof(*out));
+        out->rdCost = mode->rdCost; out->distortion = mode->distortion; out->fracBits = mode->contexts.m_fracBits;
+        out->totalBits = mode->totalBits; out->mvBits = mode->mvBits; out->coeffBits = mode->coeffBits; out->psyEnergy = mode->psyEnergy;
+        out->lumaDist = (uint32_t)mode->lumaDistortion; out->chromaDist = (uint32_t)mode->chromaDistortion; out->resEnergy = (uint32_t)mode->resEnergy;
+        memcpy(out->ctx, mode->contexts.m_contextState, MAX_OFF_CTX_MOD);
+        const int u4 = n >> 2;
+        for (uint32_t i = 0; i < g->numPartitions; i++)
+        {
+            const int ux = (g_zscanToPelX[absPartIdx + i] - g_zscanToPelX[absPartIdx]) >> 2, uy = (g_zscanToPelY[absPartIdx + i] - g_zscanToPelY[absPartIdx]) >> 2;
+            RefCuUnit& u = cuUnitsOut[uy * u4 + ux];
+            u = units[((cuY >> 2) + uy) * w4 + (cuX >> 2) + ux];
+            const int pm = mode->cu.m_predMode[i];
+            u.predMode = pm == MODE_SKIP ? 3 : (pm == MODE_INTRA ? 2 : (pm == MODE_INTER ? 1 : 0));
+            u.tuDepth = mode->cu.m_tuDepth[i]; u.qp = mode->cu.m_qp[i];
+            for (int c = 0; c < 3; c++) u.cbf[c] = mode->cu.m_cbf[c][i];
+        }
+        memcpy(coeffOut, mode->cu.m_trCoeff[0], n * n * sizeof(int16_t));
+        memcpy(coeffOut + 4096, mode->cu.m_trCoeff[1], (n * n / 4) * sizeof(int16_t));
+        memcpy(coeffOut + 4096 + 1024, mode->cu.m_trCoeff[2], (n * n / 4) * sizeof(int16_t));
+        for (int y = 0; y < n; y++) memcpy(reconY + y * 64, mode->reconYuv.m_buf[0] + y * mode->reconYuv.m_size, n * sizeof(pixel));
+        for (int y = 0; y < n / 2; y++)
+        {
+            memcpy(reconU + y * 32, mode->reconYuv.m_buf[1] + y * mode->reconYuv.m_csize, (n / 2) * sizeof(pixel));
+            memcpy(reconV + y * 32, mode->reconYuv.m_buf[2] + y * mode->reconYuv.m_csize, (n / 2) * sizeof(pixel));
+        }
+        mode->predYuv.destroy(); mode->reconYuv.destroy(); fenc.destroy();
+        delete mode;
+        pool.destroy();
+        delete search;
+        delete sl;
+    }
+    frame.m_fencPic = NULL;
+    dropPic(src);
+    frame.m_encData = NULL;
+    fd->destroy(); delete fd;
+    x265_param_free(param);
+}
+
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,
  * flags & 16, two Predict::predInterLumaPixel + pixelavg_pp as search.cpp:2499-2511) and then pu[].sad / pu[].satd /
  * cu[].sa8d (+ the 4:2:0 chroma satd / sa8d) against the source picture.  reserved[0] metric 1 SAD 2 SATD 3 SA8D,

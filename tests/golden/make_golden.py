@@ -45,6 +45,7 @@ def main():
     make_inter_cost_golden()
     make_intra_tu_golden()
     make_inter_search_golden()
+    make_inter_rd_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -205,6 +206,21 @@ def make_inter_search_golden():
         out["bits/%d" % i], out["pus/%d" % i], out["pred/%d" % i] = bits, pus, dig
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "inter_search_golden.npz"), **out)
     print("wrote inter_search_golden.npz with", len(out), "arrays")
+
+
+def make_inter_rd_golden():
+    """results of the reference's Search::encodeResAndCalcRdInterCU on CUData / Slice / Search fixtures -> tests/golden/inter_rd_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tird", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_inter_rd.py"))
+    tird = importlib.util.module_from_spec(spec); spec.loader.exec_module(tird)
+    out = {}
+    for k, (depth, seed, st, td, psy) in enumerate(tird.CASES):
+        c = T.rd_case(depth, seed, st, td, psy)
+        for i, d in enumerate(T.rd_pack(T.rd_run_ref(T.load_ref(depth), c), c)):
+            for name, a in d.items():
+                out["%d/%d/%s" % (k, i, name)] = a
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "inter_rd_golden.npz"), **out)
+    print("wrote inter_rd_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

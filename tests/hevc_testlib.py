@@ -1978,3 +1978,303 @@ def inter_search_run_hip(L, me, c):
             pu[:] = 0; pv[:] = 0
         res.append((int(bits[i]), out[2 * i:2 * i + (1 if part == 0 else 2)].copy(), py, pu, pv))
     return res
+
+
+# ---- residual RD of inter CUs (x265amd_inter_residual_rd vs Search::encodeResAndCalcRdInterCU) ----
+RD_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("reserved", "<i4")])
+RD_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("mv_bits", "<u4"), ("coeff_bits", "<u4"),
+                         ("psy_energy", "<u4"), ("luma_distortion", "<u4"), ("chroma_distortion", "<u4"), ("res_energy", "<u4"), ("reserved", "<u4"),
+                         ("ctx", "u1", 160)])
+RD_CU_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("log2_size", "u1"), ("qp", "i1"), ("reserved", "u1", 2), ("frac_bits", "<u8"), ("ctx", "u1", 160)])
+assert RD_RESULT_DT.itemsize == 216 and RD_CU_DT.itemsize == 176
+RD_TILE = 64 * 64 + 2 * 32 * 32
+
+
+def rd_case(depth, seed, slice_type, tu_inter_depth, psy_rd, ncu=10, width=128, height=128, strength=None):
+    """a random coded neighbourhood (cabac_case), a textured source picture, and `ncu` candidate inter CUs each with its own prediction tile
+    (the source block disturbed so that the residual has realistic structure), start contexts and QP"""
+    rng = np.random.default_rng(seed + 77)
+    base = cabac_case(seed, width, height, slice_type)
+    si = base["si"].copy()
+    si["tq_bypass_enabled"] = 0
+    si["tu_max_depth_inter"] = tu_inter_depth
+    units = base["units"].copy()
+    units["tq_bypass"] = 0
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    def plane(w, h, sd):
+        r = np.random.default_rng(sd)
+        b = r.integers(pmax // 8, pmax - pmax // 8, (h // 8 + 2, w // 8 + 2)).astype(np.int64)
+        up = np.kron(b, np.ones((8, 8), np.int64))[:h, :w]
+        sm = (up + np.roll(up, 2, 0) + np.roll(up, 3, 1) + np.roll(up, (5, 4), (0, 1)) + 2) >> 2
+        return np.clip(sm + r.integers(-4, 5, sm.shape), 0, pmax)
+    src = [plane(width, height, seed * 3 + 1), plane(width // 2, height // 2, seed * 3 + 2), plane(width // 2, height // 2, seed * 3 + 3)]
+    cus = np.zeros(ncu, RD_CU_DT)
+    preds = np.zeros((ncu, RD_TILE), dt)
+    cu_units = np.zeros((ncu, 256), CU_UNIT_DT)
+    maps = []
+    ctx_pool = [entropy_reset_np(int(si["slice_type"]), q) for q in (22, 30, 37)]
+    for i in range(ncu):
+        log2 = int(rng.choice([3, 4, 4, 5, 5, 6]))
+        size = 1 << log2
+        x, y = int(rng.integers(0, width // size)) * size, int(rng.integers(0, height // size)) * size
+        qp = int(rng.integers(18, 42))
+        cus[i]["x"], cus[i]["y"], cus[i]["log2_size"], cus[i]["qp"] = x, y, log2, qp
+        ctx = ctx_pool[int(rng.integers(0, 3))].copy()
+        # disturb some context states so that the walk does not start from initial values
+        idx = rng.choice(CTX_COUNT, size=40, replace=False)
+        ctx[idx] = rng.integers(0, 126, size=40).astype(np.uint8)
+        cus[i]["ctx"][:CTX_COUNT] = ctx[:CTX_COUNT]
+        cus[i]["frac_bits"] = int(rng.integers(0, 32768))
+        # the candidate's prediction fields
+        depth_cu = 6 - log2
+        parts = [0, 0, 0, 1, 2] + ([4, 5, 6, 7] if (depth_cu < si["max_amp_depth"] and size >= 16) else [])
+        part = int(rng.choice(parts))
+        m = units.copy()
+        ys, xs = slice(y // 4, (y + size) // 4), slice(x // 4, (x + size) // 4)
+        u = np.zeros((size // 4, size // 4), CU_UNIT_DT)
+        u["depth"], u["pred_mode"], u["part_size"], u["qp"] = depth_cu, MODE_INTER, part, qp
+        q = size // 4
+        for (px, py, pw, ph) in _PU_RECTS[part]:
+            pys, pxs = slice((py * q) // 4, ((py + ph) * q) // 4), slice((px * q) // 4, ((px + pw) * q) // 4)
+            mf = int(rng.integers(0, 3) == 0)
+            u["merge_flag"][pys, pxs] = mf
+            if mf:
+                u["mvp_idx"][pys, pxs] = (int(rng.integers(0, si["max_num_merge_cand"])), 0)
+                u["inter_dir"][pys, pxs] = 1
+                u["ref_idx"][pys, pxs] = (0, -1)
+                continue
+            idir = (int(rng.integers(1, 3)) if (size == 8 and part != 0) else int(rng.integers(1, 4))) if slice_type == 0 else 1
+            u["inter_dir"][pys, pxs] = idir
+            u["ref_idx"][pys, pxs] = [int(rng.integers(0, si["num_ref_idx"][l])) if idir & (1 << l) else -1 for l in range(2)]
+            u["mvp_idx"][pys, pxs] = (int(rng.integers(0, 2)), int(rng.integers(0, 2)))
+            u["mvd"][pys, pxs] = [[int(rng.choice([0, 0, 1, -1, 2, -3, 17])), int(rng.choice([0, 0, 1, -1, 5, -2, 33]))] for _ in range(2)]
+        m[ys, xs] = u
+        maps.append(m)
+        cu_units[i, :u.size] = u.ravel()
+        # prediction: the source block, smoothed and offset, with noise whose strength varies from "skip-like" to "busy"
+        st = int(rng.choice([0, 1, 2, 4, 8, 16])) if strength is None else strength
+        t = preds[i]
+        for p in range(3):
+            s = size if p == 0 else size // 2
+            px, py = (x, y) if p == 0 else (x // 2, y // 2)
+            blk = src[p][py:py + s, px:px + s]
+            sm = (blk * 2 + np.roll(blk, 1, 0) + np.roll(blk, 1, 1) + 2) >> 2 if st else blk
+            dist = sm + rng.integers(-st, st + 1, blk.shape) + (int(rng.integers(-3, 4)) if st else 0)
+            if st and rng.integers(0, 2):       # a localised error so that TU splits pay off
+                hy, hx = int(rng.integers(0, s)), int(rng.integers(0, s))
+                dist[hy:hy + max(2, s // 4), hx:hx + max(2, s // 4)] += int(rng.integers(-40, 41)) << (depth - 8)
+            tile = np.clip(dist, 0, pmax).astype(dt)
+            o = 0 if p == 0 else 4096 + (p - 1) * 1024
+            st_ = 64 if p == 0 else 32
+            view = t[o:o + st_ * st_].reshape(st_, st_)
+            view[:s, :s] = tile
+    rp = np.zeros(1, RD_PARAMS_DT)
+    rp["psy_rd"], rp["rd_level"] = psy_rd, 3
+    return dict(si=si, units=units, maps=maps, src=[np.ascontiguousarray(p.astype(dt)) for p in src], cus=cus, preds=preds, cu_units=cu_units, rp=rp,
+                width=width, height=height, depth=depth)
+
+
+def entropy_reset_np(slice_type, qp):
+    """context initialisation by rule (H.265 9.3.2.2) -- only used to seed plausible start states for tests"""
+    from_lib = getattr(entropy_reset_np, "_lib", None)
+    if from_lib is None:
+        entropy_reset_np._lib = from_lib = load_oracle(8)
+    return entropy_reset(from_lib, slice_type, qp)
+
+
+def rd_run_ref(R, c):
+    """Search::encodeResAndCalcRdInterCU per CU: returns (results, cu_units_out (n x 256), coeff (n x RD_TILE), recon (n x RD_TILE))"""
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    res = np.zeros(n, RD_RESULT_DT); uo = np.zeros((n, 256), CU_UNIT_DT); coeff = np.zeros((n, RD_TILE), np.int16); recon = np.zeros((n, RD_TILE), dt)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    planes = np.array([p.ctypes.data for p in c["src"]], np.uint64)
+    for i in range(n):
+        cu = c["cus"][i]
+        ctx = np.zeros(160, np.uint8); ctx[:] = cu["ctx"]
+        m = np.ascontiguousarray(c["maps"][i])
+        pr = c["preds"][i]
+        R.lib.ref_inter_residual_rd(_ptr(si), _ptr(c["rp"]), _ptr(m), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                    int(cu["x"]), int(cu["y"]), int(cu["log2_size"]), int(cu["qp"]), _ptr(ctx), C.c_uint64(int(cu["frac_bits"])),
+                                    off(pr, 0), off(pr, 4096), off(pr, 4096 + 1024), off(uo[i], 0), off(coeff[i], 0),
+                                    off(recon[i], 0), off(recon[i], 4096), off(recon[i], 4096 + 1024), off(res, i))
+    return res, uo, coeff, recon
+
+
+CU_MEASURE_DT = np.dtype([("sse", "<u8", 3), ("psy", "<u4"), ("reserved", "<u4")])
+RD_SCRATCH_ELEMS = 4 * 4096 + 6 * 1024
+RD_SEL_BYTES = 384
+
+
+def _rd_layer_offset(plane, layer):
+    return 4 * 4096 + ((layer - 2) * 2 + plane - 1) * 1024 if plane else (layer - 2) * 4096
+
+
+def rd_measure_cpu(O, c, scratch, sel, recon_out):
+    """CPU stand-in of the product's k_cu_measure for the staged host test: assemble (sel is None: prediction only), reconstruct, measure
+    with the oracle's sse_pp / psyCost_pp"""
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    isz = dt.itemsize
+    per = RD_SCRATCH_ELEMS * (4 + isz)
+    pmax = (1 << c["depth"]) - 1
+    out = np.zeros(n, CU_MEASURE_DT)
+    O.lib.orc_sse_pp.restype = C.c_uint64
+    for i in range(n):
+        cu = c["cus"][i]
+        log2 = int(cu["log2_size"]); S = 1 << log2
+        resi = scratch[i * per + RD_SCRATCH_ELEMS * 2:i * per + RD_SCRATCH_ELEMS * 4].view(np.int16)
+        for p in range(3):
+            s = S if p == 0 else S // 2
+            ts = 64 if p == 0 else 32
+            o = 0 if p == 0 else 4096 + (p - 1) * 1024
+            tile = c["preds"][i][o:o + ts * ts].reshape(ts, ts).astype(np.int64)
+            if sel is not None:
+                for uy in range(s // 4):
+                    for ux in range(s // 4):
+                        layer = int(sel[i * RD_SEL_BYTES + (uy * 16 + ux if p == 0 else 256 + (p - 1) * 64 + uy * 8 + ux)])
+                        if layer != 0xFF:
+                            r = resi[_rd_layer_offset(p, layer):_rd_layer_offset(p, layer) + ts * ts].reshape(ts, ts)
+                            tile[uy * 4:uy * 4 + 4, ux * 4:ux * 4 + 4] = np.clip(tile[uy * 4:uy * 4 + 4, ux * 4:ux * 4 + 4] + r[uy * 4:uy * 4 + 4, ux * 4:ux * 4 + 4], 0, pmax)
+            rec = np.ascontiguousarray(tile.astype(dt))
+            recon_out[i][o:o + ts * ts] = rec.ravel()
+            src = c["src"][p]
+            x, y = (int(cu["x"]), int(cu["y"])) if p == 0 else (int(cu["x"]) // 2, int(cu["y"]) // 2)
+            fenc = np.ascontiguousarray(src[y:y + s, x:x + s])
+            blk = np.ascontiguousarray(rec[:s, :s])
+            cuidx = int(np.log2(s)) - 2
+            out[i]["sse"][p] = O.lib.orc_sse_pp(cuidx, _ptr(fenc), C.c_int64(s), _ptr(blk), C.c_int64(s))
+            if p == 0:
+                out[i]["psy"] = O.lib.orc_psy_cost_pp(cuidx, _ptr(fenc), C.c_int64(s), _ptr(blk), C.c_int64(s))
+    return out
+
+
+def rd_run_stages_cpu(L, O, c):
+    """the product's host stages (plan / walk / finish) with the oracle executing the transform-chain jobs and the CU measurements:
+    checks the host logic without a GPU"""
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    isz = dt.itemsize
+    lib = L.lib
+    lib.x265amd_inter_rd_scratch_bytes.restype = C.c_size_t
+    per = lib.x265amd_inter_rd_scratch_bytes()
+    assert per == RD_SCRATCH_ELEMS * (4 + isz)
+    scratch = np.zeros(n * per, np.uint8)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    planes = np.array([p.ctypes.data for p in c["src"]], np.uint64)
+    cu_units = c["cu_units"].copy()
+    preds = np.ascontiguousarray(c["preds"])
+    args = (_ptr(si), _ptr(c["cus"]), n, _ptr(cu_units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+            C.c_uint64(preds.ctypes.data), C.c_size_t(RD_TILE * isz), C.c_uint64(scratch.ctypes.data))
+    nj = lib.x265amd_inter_rd_plan(*args, None, 0)
+    assert nj > 0
+    jobs = np.zeros(nj, TU_JOB_DT)
+    assert lib.x265amd_inter_rd_plan(*args, _ptr(jobs), nj) == nj
+    res = np.zeros(nj, TU_RESULT_DT)
+    assert O.lib.orc_tu_chain_batch(_ptr(jobs), nj, _ptr(res)) == nj
+    dump = np.zeros((n, RD_TILE), dt)
+    m0 = rd_measure_cpu(O, c, scratch, None, dump)
+    sel = np.zeros(n * RD_SEL_BYTES, np.uint8)
+    out = np.zeros(n, RD_RESULT_DT)
+    coeff = np.zeros((n, RD_TILE), np.int16)
+    units = np.ascontiguousarray(c["units"].copy())
+    # every candidate has its own neighbourhood map in the test case: one CU per walk call
+    for i in range(n):
+        m = np.ascontiguousarray(c["maps"][i].copy())
+        before = m.copy()
+        # the walk indexes results globally, so hand it the whole arrays with CU i as a batch of its own would shift indices: run all, map per CU
+        rc = lib.x265amd_inter_rd_walk(_ptr(si), _ptr(c["rp"]), _ptr(m), off(c["cus"], i), 1, off(cu_units, i * 256),
+                                       off(res, _rd_first_job(lib, args, c, i)), C.c_void_p(scratch.ctypes.data + i * per), C.c_size_t(per),
+                                       off(m0, i), off(sel, i * RD_SEL_BYTES), off(out, i), off(coeff[i], 0))
+        assert rc == 0
+        assert (m == before).all(), "the picture map must be restored"
+    recon = np.zeros((n, RD_TILE), dt)
+    m1 = rd_measure_cpu(O, c, scratch, sel, recon)
+    lib.x265amd_inter_rd_finish(_ptr(si), _ptr(c["rp"]), _ptr(c["cus"]), n, _ptr(m1), _ptr(out))
+    return out, cu_units, coeff, recon
+
+
+def _rd_first_job(lib, args, c, i):
+    """index of CU i's first job = number of jobs of the CUs before it"""
+    if i == 0:
+        return 0
+    a = list(args)
+    a[2] = i
+    return lib.x265amd_inter_rd_plan(*a, None, 0)
+
+
+def rd_compare(got, want, c, what):
+    """(results, cu_units, coeff, recon) of the product vs the reference driver"""
+    gr, gu, gc, grec = got
+    wr, wu, wc, wrec = want
+    for i in range(len(wr)):
+        cu = c["cus"][i]
+        n4 = (1 << int(cu["log2_size"])) // 4
+        tag = "%s CU %d (log2 %d qp %d)" % (what, i, cu["log2_size"], cu["qp"])
+        for f in ("total_bits", "mv_bits", "coeff_bits", "luma_distortion", "chroma_distortion", "distortion", "psy_energy", "res_energy", "rd_cost", "frac_bits"):
+            assert int(gr[i][f]) == int(wr[i][f]), "%s: %s %d != %d" % (tag, f, gr[i][f], wr[i][f])
+        assert (gr[i]["ctx"][:CTX_COUNT] == wr[i]["ctx"][:CTX_COUNT]).all(), tag + ": contexts"
+        for f in ("tu_depth", "cbf", "pred_mode", "qp"):
+            assert (gu[i][f][:n4 * n4] == wu[i][f][:n4 * n4]).all(), "%s: unit field %s" % (tag, f)
+        S = 1 << int(cu["log2_size"])
+        for p in range(3):
+            s = S if p == 0 else S // 2
+            ts = 64 if p == 0 else 32
+            o = 0 if p == 0 else 4096 + (p - 1) * 1024
+            assert (grec[i][o:o + ts * ts].reshape(ts, ts)[:s, :s] == wrec[i][o:o + ts * ts].reshape(ts, ts)[:s, :s]).all(), "%s: recon plane %d" % (tag, p)
+        if wu[i]["cbf"][:n4 * n4].any():
+            assert (gc[i][:S * S] == wc[i][:S * S]).all(), tag + ": luma levels"
+            assert (gc[i][4096:4096 + S * S // 4] == wc[i][4096:4096 + S * S // 4]).all(), tag + ": U levels"
+            assert (gc[i][5120:5120 + S * S // 4] == wc[i][5120:5120 + S * S // 4]).all(), tag + ": V levels"
+
+
+def rd_run_hip(L, c):
+    """x265amd_inter_residual_rd on the whole candidate list (one call); same return shape as rd_run_ref"""
+    import torch
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    isz = dt.itemsize
+    d_src = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)).cuda() for p in c["src"]]
+    planes = np.array([d.data_ptr() for d in d_src], np.uint64)
+    d_pred = torch.from_numpy(np.ascontiguousarray(c["preds"]).view(np.uint8).reshape(-1)).cuda()
+    d_recon = torch.zeros(n * RD_TILE * isz, dtype=torch.uint8, device="cuda")
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    units = np.ascontiguousarray(c["units"].copy())
+    cu_units = c["cu_units"].copy()
+    out = np.zeros(n, RD_RESULT_DT)
+    coeff = np.zeros((n, RD_TILE), np.int16)
+    rc = L.lib.x265amd_inter_residual_rd(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                         _ptr(c["cus"]), n, _ptr(cu_units), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()),
+                                         C.c_size_t(RD_TILE * isz), _ptr(out), _ptr(coeff))
+    assert rc == 0, L.lib.x265amd_last_error()
+    assert np.array_equal(units, c["units"])           # the picture map is restored
+    recon = d_recon.cpu().numpy().view(dt).reshape(n, RD_TILE).copy()
+    return out, cu_units, coeff, recon
+
+
+def rd_pack(res, c):
+    """golden form of (results, cu_units, coeff, recon): the compared fields only"""
+    r, u, co, rec = res
+    keep = []
+    for i in range(len(r)):
+        cu = c["cus"][i]
+        S = 1 << int(cu["log2_size"]); n4 = S // 4
+        d = dict(res=np.array([int(r[i][f]) for f in ("total_bits", "mv_bits", "coeff_bits", "luma_distortion", "chroma_distortion", "distortion", "psy_energy",
+                                                        "res_energy", "rd_cost", "frac_bits")], np.uint64),
+                 ctx=r[i]["ctx"][:CTX_COUNT].copy(),
+                 # columns: tu_depth, cbf Y/U/V, pred_mode, qp
+                 units=np.concatenate([u[i][f][:n4 * n4].astype(np.int16).reshape(n4 * n4, -1) for f in ("tu_depth", "cbf", "pred_mode", "qp")], 1))
+        planes = []
+        for p in range(3):
+            s = S if p == 0 else S // 2
+            ts = 64 if p == 0 else 32
+            o = 0 if p == 0 else 4096 + (p - 1) * 1024
+            planes.append(rec[i][o:o + ts * ts].reshape(ts, ts)[:s, :s].astype(np.uint16).ravel())
+        d["recon"] = np.concatenate(planes)
+        if u[i]["cbf"][:n4 * n4].any():
+            d["coeff"] = np.concatenate([co[i][:S * S], co[i][4096:4096 + S * S // 4], co[i][5120:5120 + S * S // 4]])
+        else:
+            d["coeff"] = np.zeros(0, np.int16)
+        keep.append(d)
+    return keep

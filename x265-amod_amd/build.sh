@@ -7,7 +7,7 @@ SRC=$HERE/csrc
 OUT=$HERE/lib
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -I$HERE/../include ${X265AMD_EXTRA_FLAGS:-}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -Wno-missing-braces -I$HERE/../include ${X265AMD_EXTRA_FLAGS:-}"
 SRCS=$(ls "$SRC"/*.hip)
 HOSTSRCS=$(ls "$HERE"/host/*.cpp 2>/dev/null || true)
 build_one() {

@@ -1,0 +1,735 @@
+/* Residual RD of inter CUs (include/x265amd.h: x265amd_inter_residual_rd): SURVEY row a8.
+ *
+ * Restatement of Search::encodeResAndCalcRdInterCU (reference: source/encoder/search.cpp:2822-2975) with estimateResidualQT
+ * (:3178-3857), splitTU (:3126-3176), estimateNullCbfCost (:3114-3124), codeInterSubdivCbfQT (:3859-3887), saveResidualQTData
+ * (:3889-3972), updateModeCost (search.h:437-439) and checkDQP (search.cpp:3974-4003) for a batch of independent candidate CUs.
+ *
+ * The reference evaluates one TU at a time: transform + quantise, count the coefficient bits with the RD entropy coder, inverse
+ * transform, measure, compare with the zero-residual alternative, then recurse into the four sub-TUs and compare again.  With plain
+ * quantisation (rdoqLevel 0) none of the block arithmetic depends on the entropy state, so here
+ *   1. every node of every CU's residual quad-tree (all allowed transform sizes, luma + both chroma planes) runs as ONE
+ *      x265amd_tu_chain launch, and one k_cu_measure launch prices the no-residual alternative of every CU;
+ *   2. the host walks each tree in the reference's order with the bit-counting CABAC coder (host/cabac_coder.h), reading the
+ *      per-node measurements and levels, and takes the reference's decisions (coded block flags, transform splits, root flag, skip);
+ *   3. a second k_cu_measure launch assembles the chosen residual blocks, reconstructs every CU and measures the final distortion /
+ *      psy energy.
+ * The walk keeps the reference's quirks: the fractional bit carry of m_fracBits through resetBits(), coded block flags of parent depths
+ * living only in a node's first unit, split energy added to the cost of a rejected split.
+ */
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+#include "../host/cabac_coder.h"
+#include <string.h>
+#include <vector>
+
+/* ---------------- device: CU assembly + measurement ---------------- */
+#define RD_LUMA_ELEMS 4096
+#define RD_CHROMA_ELEMS 1024
+#define RD_SCRATCH_ELEMS (4 * RD_LUMA_ELEMS + 3 * 2 * RD_CHROMA_ELEMS)      /* luma layers 4..32, chroma layers 4..16 x {U, V} */
+#define RD_SEL_BYTES 384                                                     /* 256 luma units (row length 16) + 2 x 64 chroma units (row length 8) */
+
+struct CuMeasureJob
+{
+    uint64_t fenc[3];               /* source block top-left per plane */
+    uint64_t pred, recon;           /* tiles: 64x64 luma (stride 64), 32x32 U, 32x32 V (stride 32) */
+    uint64_t resi;                  /* the CU's residual scratch (int16, RD_SCRATCH_ELEMS) */
+    uint64_t sel;                   /* per unit: transform layer (log2 size) whose residual block covers it, 0xFF = none */
+    int32_t fenc_stride, fenc_cstride, log2_size, assemble;
+};
+typedef x265amd_cu_measure CuMeasure;
+
+XA_DEV size_t rd_layer_offset(int plane, int layer)
+{
+    return plane ? (size_t)4 * RD_LUMA_ELEMS + (size_t)((layer - 2) * 2 + (plane - 1)) * RD_CHROMA_ELEMS : (size_t)(layer - 2) * RD_LUMA_ELEMS;
+}
+
+/* one wavefront per CU: reconYuv = predYuv (+ clipped residual where a block was kept: Yuv::addClip, yuv.cpp:158-183), then
+ * sse_pp per plane and the luma psyCost against the source (search.cpp:2937-2958 / :2869-2889) */
+__global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int n, CuMeasure* out)
+{
+    __shared__ pixel tile[64 * 64];
+    const int lane = xa_lane(), ji = blockIdx.x;
+    if (ji >= n) return;
+    const CuMeasureJob j = jobs[ji];
+    const uint8_t* sel = reinterpret_cast<const uint8_t*>(j.sel);
+    const int16_t* resi = reinterpret_cast<const int16_t*>(j.resi);
+    CuMeasure m;
+    m.psy = 0; m.reserved = 0;
+    for (int plane = 0; plane < 3; plane++)
+    {
+        const int log2S = plane ? j.log2_size - 1 : j.log2_size, s = 1 << log2S, ts = plane ? 32 : 64;
+        const size_t tileOff = plane ? 4096 + (size_t)(plane - 1) * 1024 : 0;
+        const pixel* pred = reinterpret_cast<const pixel*>(j.pred) + tileOff;
+        pixel* recon = reinterpret_cast<pixel*>(j.recon) + tileOff;
+        for (int i = lane; i < s * s; i += XA_WAVE)
+        {
+            const int y = i >> log2S, x = i & (s - 1);
+            int v = pred[y * ts + x];
+            if (j.assemble)
+            {
+                const int layer = plane ? sel[256 + (plane - 1) * 64 + (y >> 2) * 8 + (x >> 2)] : sel[(y >> 2) * 16 + (x >> 2)];
+                if (layer != 0xFF) v = xa_clip_pixel(v + (int)resi[rd_layer_offset(plane, layer) + y * ts + x]);
+            }
+            tile[y * ts + x] = (pixel)v;
+            recon[y * ts + x] = (pixel)v;
+        }
+        __syncthreads();
+        const pixel* f = reinterpret_cast<const pixel*>(j.fenc[plane]);
+        const int fs = plane ? j.fenc_cstride : j.fenc_stride;
+        m.sse[plane] = wave_sse_pp(f, fs, tile, ts, s, lane);
+        if (!plane) m.psy = (uint32_t)wave_psy_cost(f, fs, tile, ts, j.log2_size - 2, lane);
+        __syncthreads();
+    }
+    if (lane == 0) out[ji] = m;
+}
+
+/* ---------------- host: the reference's walk ---------------- */
+namespace {
+
+#if X265AMD_DEPTH < 10
+typedef uint32_t sse_t;             /* common/common.h:142-146 */
+#else
+typedef uint64_t sse_t;
+#endif
+
+struct Snap { uint8_t ctx[X265AMD_CTX_STRIDE]; uint64_t frac; };
+struct Cost { uint64_t rdcost; uint32_t bits; sse_t distortion; uint32_t energy; };       /* search.h:  struct Cost */
+const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
+const uint32_t kCtxCbf[3][5] = { { 1, 0, 0, 0, 0 }, { 2, 3, 4, 5, 6 }, { 2, 3, 4, 5, 6 } };          /* contexts.h:120 */
+
+struct CuPlan
+{
+    int x, y, log2, size, depth, qp, part;
+    int range[2];
+    int lumaRes[6];                 /* first result index of luma layer L (log2 size), -1 when the layer is not evaluated */
+    int chromaRes[5][3];            /* the same of chroma layer C and plane 1 / 2 */
+};
+
+inline uint32_t zorder_in_cu(int x4, int y4)
+{
+    uint32_t z = 0;
+    for (int b = 0; b < 4; b++) z |= (((uint32_t)x4 >> b) & 1) << (2 * b) | (((uint32_t)y4 >> b) & 1) << (2 * b + 1);
+    return z;
+}
+inline size_t host_layer_offset(int plane, int layer)
+{
+    return plane ? (size_t)4 * RD_LUMA_ELEMS + (size_t)((layer - 2) * 2 + (plane - 1)) * RD_CHROMA_ELEMS : (size_t)(layer - 2) * RD_LUMA_ELEMS;
+}
+
+struct Walker
+{
+    x265amd_cabac& c;
+    const CuPlan& P;
+    const x265amd_tu_result* res;   /* all results of the launch */
+    const int16_t* levels;          /* this CU's level scratch (host copy), RD_SCRATCH_ELEMS */
+    uint64_t lambda2, lambda; uint32_t psyRd;
+    Snap rqtRoot[6], rqtTest[6];
+
+    Walker(x265amd_cabac& coder, const CuPlan& plan, const x265amd_tu_result* r, const int16_t* lv) : c(coder), P(plan), res(r), levels(lv) {}
+
+    /* Entropy: getNumberOfWrittenBits / resetBits / load / store / bitsCodeBin (entropy.h:120-140, :219-224; entropy.cpp:2445-2455) */
+    uint32_t bits() const { return (uint32_t)(c.fracBits >> 15); }
+    void resetBits() { c.fracBits &= 32767; }
+    void store(Snap& s) const { memcpy(s.ctx, c.ctx, X265AMD_CTX_STRIDE); s.frac = c.fracBits; }
+    void load(const Snap& s) { memcpy(c.ctx, s.ctx, X265AMD_CTX_STRIDE); c.fracBits = s.frac; }
+    uint32_t bitsCodeBin(uint32_t bin, int ctxIdx) const { return (uint32_t)(((c.fracBits & 32767) + k_bits[c.ctx[ctxIdx] ^ bin]) >> 15); }
+    uint32_t estimateCbfBits(uint32_t cbf, int ttype, int tuDepth) const { return bitsCodeBin(cbf, C_QT_CBF + (int)kCtxCbf[ttype][tuDepth]); }
+
+    /* RDCost (rdcost.h:99-153) */
+    uint64_t calcRdCost(sse_t dist, uint32_t b) const { return dist + (((uint64_t)b * lambda2 + 128) >> 8); }
+    uint64_t calcPsyRdCost(sse_t dist, uint32_t b, uint32_t energy) const { return dist + ((lambda * psyRd * energy) >> 24) + (((uint64_t)b * lambda2) >> 8); }
+    uint64_t cost(sse_t dist, uint32_t b, uint32_t energy) const { return psyRd ? calcPsyRdCost(dist, b, energy) : calcRdCost(dist, b); }
+    uint64_t estimateNullCbfCost(sse_t dist, uint32_t energy, int tuDepth, int ttype) const { return cost(dist, estimateCbfBits(0, ttype, tuDepth), energy); }
+
+    x265amd_cu_unit& U(int x, int y) { return c.U(x >> 2, y >> 2); }
+    bool cbfBit(int x, int y, int plane, int d) { return (U(x, y).cbf[plane] >> d) & 1; }
+    void setTuDepth(int x, int y, int size, int d)
+    {
+        for (int yy = y; yy < y + size; yy += 4) for (int xx = x; xx < x + size; xx += 4) U(xx, yy).tu_depth = (uint8_t)d;
+    }
+    void setCbf(int plane, int x, int y, int size, int v)           /* setCbfSubParts / setCbfPartRange: plain assignment */
+    {
+        for (int yy = y; yy < y + size; yy += 4) for (int xx = x; xx < x + size; xx += 4) U(xx, yy).cbf[plane] = (uint8_t)v;
+    }
+
+    const x265amd_tu_result& nodeResult(int plane, int layer, int x, int y) const
+    {
+        const int sh = plane ? 1 : 0, n = 1 << layer, nt = (P.size >> sh) >> layer;
+        const int tx = ((x - P.x) >> sh) / n, ty = ((y - P.y) >> sh) / n;
+        return res[(plane ? P.chromaRes[layer][plane] : P.lumaRes[layer]) + ty * nt + tx];
+    }
+    const int16_t* nodeLevels(int plane, int layer, int x, int y) const
+    {
+        const int sh = plane ? 1 : 0, n = 1 << layer, nt = (P.size >> sh) >> layer;
+        const int tx = ((x - P.x) >> sh) / n, ty = ((y - P.y) >> sh) / n;
+        return levels + host_layer_offset(plane, layer) + (size_t)(ty * nt + tx) * n * n;
+    }
+
+    void estimateResidualQT(int x, int y, int tuDepth, Cost& outCosts)
+    {
+        const int log2TrSize = P.log2 - tuDepth, depth = P.depth + tuDepth, trSize = 1 << log2TrSize;
+        bool bCheckSplit = log2TrSize > P.range[0];
+        bool bCheckFull = log2TrSize <= P.range[1];
+        const bool bSplitPresentFlag = bCheckSplit && bCheckFull;
+        if (P.part != 0 && !tuDepth && bCheckSplit) bCheckFull = false;
+
+        int log2TrSizeC = log2TrSize - 1;
+        bool codeChroma = true;
+        if (log2TrSizeC < 2)
+        {
+            log2TrSizeC = 2;
+            codeChroma = !((x & 4) || (y & 4));             /* !(absPartIdx & 3): the quartet's first 4x4 carries the chroma block */
+        }
+        const int chromaArea = trSize < 8 ? 8 : trSize;     /* luma extent of the units the chroma block covers */
+
+        Cost fullCost = { kMaxCost, 0, 0, 0 };
+        uint32_t cbfFlag[3] = { 0, 0, 0 }, singleBits[3] = { 0, 0, 0 }, singleEnergy[3] = { 0, 0, 0 };
+        sse_t singleDist[3] = { 0, 0, 0 };
+
+        store(rqtRoot[depth]);
+
+        if (bCheckFull)
+        {
+            setTuDepth(x, y, trSize, tuDepth);
+            {
+                const x265amd_tu_result& r = nodeResult(0, log2TrSize, x, y);
+                cbfFlag[0] = r.num_sig != 0;
+                resetBits();
+                if (bSplitPresentFlag && log2TrSize > P.range[0]) c.bin(0, C_TRANS_SUBDIV + 5 - log2TrSize);
+                if (cbfFlag[0]) c.coeffNxN(nodeLevels(0, log2TrSize, x, y), log2TrSize, 0, U(x, y));
+                singleBits[0] = bits();
+                const sse_t zeroDist = (sse_t)r.zero_dist;
+                const uint32_t zeroEnergy = psyRd ? r.zero_energy : 0;
+                if (cbfFlag[0])
+                {
+                    const sse_t nzDist = (sse_t)r.nz_dist;
+                    const uint32_t nzCbfBits = estimateCbfBits(1, 0, tuDepth);
+                    const uint32_t nzEnergy = psyRd ? r.nz_energy : 0;
+                    const uint64_t singleCost = cost(nzDist, nzCbfBits + singleBits[0], nzEnergy);
+                    const uint64_t nullCost = estimateNullCbfCost(zeroDist, zeroEnergy, tuDepth, 0);
+                    if (nullCost < singleCost)
+                    {
+                        cbfFlag[0] = 0; singleBits[0] = 0;
+                        singleDist[0] = zeroDist; singleEnergy[0] = zeroEnergy;
+                    }
+                    else { singleDist[0] = nzDist; singleEnergy[0] = nzEnergy; }
+                }
+                else { singleDist[0] = zeroDist; singleBits[0] = 0; singleEnergy[0] = zeroEnergy; }
+                setCbf(0, x, y, trSize, cbfFlag[0] << tuDepth);
+            }
+            if (codeChroma)
+                for (int p = 1; p < 3; p++)
+                {
+                    const x265amd_tu_result& r = nodeResult(p, log2TrSizeC, x, y);
+                    cbfFlag[p] = r.num_sig != 0;
+                    const uint32_t latestBitCount = bits();
+                    if (cbfFlag[p]) c.coeffNxN(nodeLevels(p, log2TrSizeC, x, y), log2TrSizeC, p, U(x, y));
+                    singleBits[p] = bits() - latestBitCount;
+                    const sse_t zeroDist = (sse_t)r.zero_dist;          /* scaleChromaDist: weight 256 for 4:2:0 (rdcost.h:80-90) */
+                    const uint32_t zeroEnergy = psyRd ? r.zero_energy : 0;
+                    if (cbfFlag[p])
+                    {
+                        const sse_t nzDist = (sse_t)r.nz_dist;
+                        const uint32_t nzCbfBits = estimateCbfBits(1, p, tuDepth);
+                        const uint32_t nzEnergy = psyRd ? r.nz_energy : 0;
+                        const uint64_t singleCost = cost(nzDist, nzCbfBits + singleBits[p], nzEnergy);
+                        const uint64_t nullCost = estimateNullCbfCost(zeroDist, zeroEnergy, tuDepth, p);
+                        if (nullCost < singleCost)
+                        {
+                            cbfFlag[p] = 0; singleBits[p] = 0;
+                            singleDist[p] = zeroDist; singleEnergy[p] = zeroEnergy;
+                        }
+                        else { singleDist[p] = nzDist; singleEnergy[p] = nzEnergy; }
+                    }
+                    else { singleBits[p] = 0; singleDist[p] = zeroDist; singleEnergy[p] = zeroEnergy; }
+                    setCbf(p, x, y, chromaArea, cbfFlag[p] << tuDepth);
+                }
+
+            /* the flags are priced from the node's start state; the coefficient bits were collected above (:3652-3690) */
+            load(rqtRoot[depth]);
+            resetBits();
+            if (codeChroma)
+            {
+                c.bin(cbfFlag[1], C_QT_CBF + 2 + tuDepth);
+                c.bin(cbfFlag[2], C_QT_CBF + 2 + tuDepth);
+            }
+            c.bin(cbfFlag[0], C_QT_CBF + !tuDepth);
+            const uint32_t cbfBits = bits();
+            const uint32_t coeffBits = singleBits[0] + singleBits[1] + singleBits[2];
+            fullCost.bits = bSplitPresentFlag ? cbfBits + coeffBits : coeffBits;
+            fullCost.distortion += singleDist[0];
+            fullCost.energy += singleEnergy[0];
+            fullCost.distortion += singleDist[1];
+            fullCost.distortion += singleDist[2];
+            fullCost.rdcost = cost(fullCost.distortion, fullCost.bits, fullCost.energy);
+        }
+
+        if (bCheckSplit)
+        {
+            if (bCheckFull)
+            {
+                store(rqtTest[depth]);
+                load(rqtRoot[depth]);
+            }
+            Cost splitCost = { 0, 0, 0, 0 };
+            if (bSplitPresentFlag && (log2TrSize <= P.range[1] && log2TrSize > P.range[0]))
+            {
+                resetBits();
+                c.bin(1, C_TRANS_SUBDIV + 5 - log2TrSize);
+                splitCost.bits = bits();
+            }
+            const bool yCbCrCbf = splitTU(x, y, tuDepth, splitCost);
+            if (yCbCrCbf || !bCheckFull)
+            {
+                if (splitCost.rdcost < fullCost.rdcost)
+                {
+                    outCosts.distortion += splitCost.distortion;
+                    outCosts.rdcost += splitCost.rdcost;
+                    outCosts.bits += splitCost.bits;
+                    outCosts.energy += splitCost.energy;
+                    return;
+                }
+                else
+                    outCosts.energy += splitCost.energy;
+            }
+            load(rqtTest[depth]);
+        }
+
+        setTuDepth(x, y, trSize, tuDepth);
+        setCbf(0, x, y, trSize, cbfFlag[0] << tuDepth);
+        if (codeChroma)
+        {
+            setCbf(1, x, y, trSize, cbfFlag[1] << tuDepth);
+            setCbf(2, x, y, trSize, cbfFlag[2] << tuDepth);
+        }
+        outCosts.distortion += fullCost.distortion;
+        outCosts.rdcost += fullCost.rdcost;
+        outCosts.bits += fullCost.bits;
+        outCosts.energy += fullCost.energy;
+    }
+
+    bool splitTU(int x, int y, int tuDepth, Cost& splitCost)
+    {
+        const int depth = P.depth + tuDepth, log2TrSize = P.log2 - tuDepth, half = 1 << (log2TrSize - 1);
+        uint32_t ycbf = 0, ucbf = 0, vcbf = 0;
+        for (int q = 0; q < 4; q++)
+        {
+            const int qx = x + (q & 1) * half, qy = y + (q >> 1) * half;
+            estimateResidualQT(qx, qy, tuDepth + 1, splitCost);
+            ycbf |= cbfBit(qx, qy, 0, tuDepth + 1);
+            ucbf |= cbfBit(qx, qy, 1, tuDepth + 1);
+            vcbf |= cbfBit(qx, qy, 2, tuDepth + 1);
+        }
+        U(x, y).cbf[0] |= (uint8_t)(ycbf << tuDepth);
+        U(x, y).cbf[1] |= (uint8_t)(ucbf << tuDepth);
+        U(x, y).cbf[2] |= (uint8_t)(vcbf << tuDepth);
+
+        load(rqtRoot[depth]);
+        resetBits();
+        codeInterSubdivCbfQT(x, y, tuDepth);
+        splitCost.bits += bits();
+        splitCost.rdcost = cost(splitCost.distortion, splitCost.bits, splitCost.energy);
+        return ycbf || ucbf || vcbf;
+    }
+
+    void codeInterSubdivCbfQT(int x, int y, int tuDepth)
+    {
+        const bool bSubdiv = tuDepth < U(x, y).tu_depth;
+        const int log2TrSize = P.log2 - tuDepth;
+        if (!(log2TrSize - 1 < 2))
+        {
+            const int psz = 2 << log2TrSize;
+            const int px = P.x + ((x - P.x) & ~(psz - 1)), py = P.y + ((y - P.y) & ~(psz - 1));
+            for (int p = 1; p < 3; p++)
+                if (!tuDepth || cbfBit(px, py, p, tuDepth - 1))
+                {
+                    /* Entropy::codeQtCbfChroma(cu, ...) (entropy.cpp:1758-1780) */
+                    const bool canQuadSplit = log2TrSize - 1 > 2;
+                    const int lowest = tuDepth + ((bSubdiv && !canQuadSplit) ? 1 : 0);
+                    c.bin(cbfBit(x, y, p, lowest), C_QT_CBF + tuDepth + 2);
+                }
+        }
+        if (!bSubdiv) c.bin(cbfBit(x, y, 0, tuDepth), C_QT_CBF + !tuDepth);
+        else
+        {
+            const int half = 1 << (log2TrSize - 1);
+            for (int q = 0; q < 4; q++) codeInterSubdivCbfQT(x + (q & 1) * half, y + (q >> 1) * half, tuDepth + 1);
+        }
+    }
+
+    /* saveResidualQTData: which layer's blocks make up the final residual / levels */
+    void collect(int x, int y, int tuDepth, uint8_t* sel, int16_t* coeffCu)
+    {
+        const int log2TrSize = P.log2 - tuDepth;
+        if (tuDepth < U(x, y).tu_depth)
+        {
+            const int half = 1 << (log2TrSize - 1);
+            for (int q = 0; q < 4; q++) collect(x + (q & 1) * half, y + (q >> 1) * half, tuDepth + 1, sel, coeffCu);
+            return;
+        }
+        const int trSize = 1 << log2TrSize;
+        const int ux = (x - P.x) >> 2, uy = (y - P.y) >> 2;
+        const uint32_t z = zorder_in_cu(ux, uy);
+        if (cbfBit(x, y, 0, tuDepth))
+            for (int yy = 0; yy < trSize >> 2; yy++) for (int xx = 0; xx < trSize >> 2; xx++) sel[(uy + yy) * 16 + ux + xx] = (uint8_t)log2TrSize;
+        if (coeffCu) memcpy(coeffCu + (z << 4), nodeLevels(0, log2TrSize, x, y), sizeof(int16_t) << (2 * log2TrSize));
+        int log2TrSizeC = log2TrSize - 1;
+        bool codeChroma = true;
+        if (log2TrSizeC < 2) { log2TrSizeC = 2; codeChroma = !((x & 4) || (y & 4)); }
+        if (!codeChroma) return;
+        const int cs = 1 << log2TrSizeC;
+        for (int p = 1; p < 3; p++)
+        {
+            if (cbfBit(x, y, p, tuDepth))
+                for (int yy = 0; yy < cs >> 2; yy++) for (int xx = 0; xx < cs >> 2; xx++) sel[256 + (p - 1) * 64 + ((uy >> 1) + yy) * 8 + (ux >> 1) + xx] = (uint8_t)log2TrSizeC;
+            if (coeffCu) memcpy(coeffCu + 4096 + (p - 1) * 1024 + ((z << 4) >> 2), nodeLevels(p, log2TrSizeC, x, y), sizeof(int16_t) << (2 * log2TrSizeC));
+        }
+    }
+};
+
+struct DevBuf
+{
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+} // namespace
+
+/* RDCost::setQP for one CU */
+static void rd_lambdas(const x265amd_slice_info* si, const x265amd_rd_params* rp, int qp, Walker& w)
+{
+    uint64_t rd[6];
+    x265amd_rdcost(qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+    w.lambda2 = rd[0]; w.lambda = rd[1]; w.psyRd = (uint32_t)rd[2];
+}
+
+/* the nodes of one CU's tree; jobs == NULL: only the plan */
+static int make_plan(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int part, CuPlan& P, int firstJob, const uint64_t* src, intptr_t stride, intptr_t cstride,
+                     uint64_t tile, uint64_t scratch, std::vector<x265amd_tu_job>* jobs)
+{
+    static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
+                                             32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };       /* H.265 table 8-10 */
+    P.x = cu.x; P.y = cu.y; P.log2 = cu.log2_size; P.size = 1 << P.log2; P.depth = 6 - P.log2; P.qp = cu.qp;
+    if (P.log2 < 3 || P.log2 > 6 || (P.x & (P.size - 1)) || (P.y & (P.size - 1)) || P.x < 0 || P.y < 0 || P.x + P.size > si->pic_width || P.y + P.size > si->pic_height)
+        return xa_fail(X265AMD_EINVAL, "inter_residual_rd: CU outside the picture or misaligned");
+    P.part = part;
+    /* CUData::getInterTUQtDepthRange (cudata.cpp:983-993) */
+    const int splitFlag = si->tu_max_depth_inter == 1 && P.part != 0;
+    const int lo = P.log2 - (si->tu_max_depth_inter - 1 + splitFlag);
+    P.range[0] = lo < si->tu_log2_min ? si->tu_log2_min : (lo > si->tu_log2_max ? si->tu_log2_max : lo);
+    P.range[1] = si->tu_log2_max;
+    if (P.range[0] < 2 || P.range[1] > 5 || P.range[0] > P.range[1]) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: transform size range");
+    /* Quant::setQPforQuant (quant.cpp:221-244), chroma QP offsets 0 */
+    const int qpQuant = P.qp < 0 ? 0 : (P.qp > 51 ? 51 : P.qp);
+    const int bd = 6 * (X265AMD_DEPTH - 8);
+    int qpC = qpQuant < -bd ? -bd : (qpQuant > 57 ? 57 : qpQuant);
+    if (qpC >= 30) qpC = chromaScale[qpC];
+    const int hi = P.log2 < P.range[1] ? P.log2 : P.range[1];
+    for (int L = 0; L < 6; L++) P.lumaRes[L] = -1;
+    for (int C = 0; C < 5; C++) P.chromaRes[C][0] = P.chromaRes[C][1] = P.chromaRes[C][2] = -1;
+    const uint64_t levelBase = scratch, resiBase = scratch + (uint64_t)RD_SCRATCH_ELEMS * 2, dumpBase = scratch + (uint64_t)RD_SCRATCH_ELEMS * 4;
+    int count = firstJob;
+    x265amd_tu_job j;
+    memset(&j, 0, sizeof(j));
+    j.slice_type = (uint8_t)si->slice_type; j.sign_hide = (uint8_t)(si->sign_hide != 0);
+    for (int L = hi; L >= P.range[0]; L--)
+    {
+        const int N = 1 << L, nt = P.size >> L;
+        P.lumaRes[L] = count;
+        count += nt * nt;
+        if (!jobs) continue;
+        j.log2_tr_size = (uint8_t)L; j.ttype = 0; j.qp_scaled = (uint8_t)(qpQuant + bd);
+        j.fenc_stride = (int32_t)stride; j.pred_stride = 64; j.resi_stride = 64; j.recon_stride = 64;
+        for (int ty = 0; ty < nt; ty++)
+            for (int tx = 0; tx < nt; tx++)
+            {
+                const size_t tileOff = (size_t)ty * N * 64 + (size_t)tx * N;
+                j.fenc = src[0] + ((uint64_t)(P.y + ty * N) * stride + P.x + tx * N) * sizeof(pixel);
+                j.pred = tile + tileOff * sizeof(pixel);
+                j.coeff = levelBase + (host_layer_offset(0, L) + (size_t)(ty * nt + tx) * N * N) * 2;
+                j.resi = resiBase + (host_layer_offset(0, L) + tileOff) * 2;
+                j.recon = dumpBase + (host_layer_offset(0, L) + tileOff) * sizeof(pixel);
+                jobs->push_back(j);
+            }
+    }
+    for (int C = 4; C >= 2; C--)
+    {
+        const bool wanted = (C + 1 <= hi && C + 1 >= P.range[0]) || (C == 2 && P.range[0] == 2);
+        if (!wanted) continue;
+        const int N = 1 << C, nt = (P.size >> 1) >> C;
+        for (int p = 1; p < 3; p++)
+        {
+            P.chromaRes[C][p] = count;
+            count += nt * nt;
+            if (!jobs) continue;
+            j.log2_tr_size = (uint8_t)C; j.ttype = (uint8_t)p; j.qp_scaled = (uint8_t)(qpC + bd);
+            j.fenc_stride = (int32_t)cstride; j.pred_stride = 32; j.resi_stride = 32; j.recon_stride = 32;
+            for (int ty = 0; ty < nt; ty++)
+                for (int tx = 0; tx < nt; tx++)
+                {
+                    const size_t tileOff = (size_t)ty * N * 32 + (size_t)tx * N;
+                    j.fenc = src[p] + ((uint64_t)((P.y >> 1) + ty * N) * cstride + (P.x >> 1) + tx * N) * sizeof(pixel);
+                    j.pred = tile + (4096 + (size_t)(p - 1) * 1024 + tileOff) * sizeof(pixel);
+                    j.coeff = levelBase + (host_layer_offset(p, C) + (size_t)(ty * nt + tx) * N * N) * 2;
+                    j.resi = resiBase + (host_layer_offset(p, C) + tileOff) * 2;
+                    j.recon = dumpBase + (host_layer_offset(p, C) + tileOff) * sizeof(pixel);
+                    jobs->push_back(j);
+                }
+        }
+    }
+    return count;
+}
+
+extern "C" size_t x265amd_inter_rd_scratch_bytes(void) { return (size_t)RD_SCRATCH_ELEMS * (2 + 2 + sizeof(pixel)); }
+
+extern "C" int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
+                                     intptr_t stride, intptr_t cstride, uint64_t pred, size_t tile_bytes, uint64_t scratch, x265amd_tu_job* jobs_out, int cap)
+{
+    if (!si || !cus || !cu_units || !src || n < 0) return xa_fail(X265AMD_EINVAL, "inter_rd_plan: null argument");
+    std::vector<x265amd_tu_job> jobs;
+    const size_t perCu = x265amd_inter_rd_scratch_bytes();
+    int count = 0;
+    for (int i = 0; i < n; i++)
+    {
+        CuPlan P;
+        count = make_plan(si, cus[i], cu_units[(size_t)i * 256].part_size, P, count, src, stride, cstride, pred + (uint64_t)tile_bytes * i, scratch + (uint64_t)perCu * i, &jobs);
+        if (count < 0) return count;
+    }
+    if (jobs_out)
+    {
+        if (cap < count) return xa_fail(X265AMD_EINVAL, "inter_rd_plan: job array too small");
+        memcpy(jobs_out, jobs.data(), sizeof(x265amd_tu_job) * jobs.size());
+    }
+    return count;
+}
+
+extern "C" int x265amd_inter_rd_walk(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
+                                     x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
+                                     const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out)
+{
+    if (!si || !rp || !units || !cus || !cu_units || !res || !levels || !zero_meas || !sel || !out || n < 0) return xa_fail(X265AMD_EINVAL, "inter_rd_walk: null argument");
+    if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
+    const int w4 = si->pic_width >> 2;
+    x265amd_cabac* coder = x265amd_cabac_open(si, units, 1);
+    if (!coder) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: slice description");
+    memset(sel, 0xFF, (size_t)RD_SEL_BYTES * n);
+    std::vector<int16_t> coeffCu(4096 + 2048);
+    std::vector<x265amd_cu_unit> saved(256);
+    int firstJob = 0;
+    for (int i = 0; i < n; i++)
+    {
+        CuPlan P;
+        x265amd_cu_unit* mine = cu_units + (size_t)i * 256;
+        const int next = make_plan(si, cus[i], mine[0].part_size, P, firstJob, nullptr, 0, 0, 0, 0, nullptr);
+        if (next < 0) { x265amd_cabac_close(coder); return next; }
+        firstJob = next;
+        const x265amd_rd_cu& cu = cus[i];
+        const int u4 = P.size >> 2;
+        for (int yy = 0; yy < u4; yy++)
+        {
+            memcpy(&saved[yy * u4], &units[((P.y >> 2) + yy) * w4 + (P.x >> 2)], sizeof(x265amd_cu_unit) * u4);
+            memcpy(&units[((P.y >> 2) + yy) * w4 + (P.x >> 2)], &mine[yy * u4], sizeof(x265amd_cu_unit) * u4);
+        }
+        Walker w(*coder, P, res, (const int16_t*)((const char*)levels + levels_stride_bytes * i));
+        rd_lambdas(si, rp, P.qp, w);
+        for (int yy = 0; yy < u4; yy++)
+            for (int xx = 0; xx < u4; xx++)
+            {
+                x265amd_cu_unit& u = units[((P.y >> 2) + yy) * w4 + (P.x >> 2) + xx];
+                u.cbf[0] = u.cbf[1] = u.cbf[2] = 0; u.tu_depth = 0; u.depth = (uint8_t)P.depth;
+            }
+        Snap cur;
+        memset(&cur, 0, sizeof(cur));
+        memcpy(cur.ctx, cu.ctx, X265AMD_CTX_COUNT);
+        cur.frac = cu.frac_bits;
+
+        w.load(cur);
+        Cost costs = { 0, 0, 0, 0 };
+        w.estimateResidualQT(P.x, P.y, 0, costs);
+
+        /* the RD cost of not signalling any residual (:2869-2895) */
+        const x265amd_cu_measure& m0 = zero_meas[i];
+        sse_t cbf0Dist = (sse_t)m0.sse[0];
+        cbf0Dist += (sse_t)m0.sse[1];
+        cbf0Dist += (sse_t)m0.sse[2];
+        w.load(cur);
+        w.resetBits();
+        coder->bin(0, C_QT_ROOT_CBF);
+        const uint32_t cbf0Bits = w.bits();
+        const uint64_t cbf0Cost = w.cost(cbf0Dist, cbf0Bits, w.psyRd ? m0.psy : 0);
+        if (cbf0Cost < costs.rdcost)
+            for (int yy = 0; yy < u4; yy++)
+                for (int xx = 0; xx < u4; xx++)
+                {
+                    x265amd_cu_unit& u = units[((P.y >> 2) + yy) * w4 + (P.x >> 2) + xx];
+                    u.cbf[0] = u.cbf[1] = u.cbf[2] = 0; u.tu_depth = 0;
+                }
+        x265amd_cu_unit& u0 = units[(P.y >> 2) * w4 + (P.x >> 2)];
+        const bool rootCbf = u0.cbf[0] || u0.cbf[1] || u0.cbf[2];
+        std::fill(coeffCu.begin(), coeffCu.end(), 0);
+        if (rootCbf) w.collect(P.x, P.y, 0, sel + (size_t)RD_SEL_BYTES * i, coeffCu.data());
+
+        /* signal bits of the inter / merge / skip coded CU (:2900-2930) */
+        w.load(cur);
+        w.resetBits();
+        uint32_t coeffBits, bits, mvBits;
+        const x265amd_cu_unit* l = coder->at((P.x >> 2) - 1, P.y >> 2);
+        const x265amd_cu_unit* a = coder->at(P.x >> 2, (P.y >> 2) - 1);
+        const int skipCtx = (x265amd_cabac::coded(l) && l->pred_mode == X265AMD_MODE_SKIP) + (x265amd_cabac::coded(a) && a->pred_mode == X265AMD_MODE_SKIP);
+        if (u0.merge_flag && u0.part_size == 0 && !rootCbf)
+        {
+            for (int yy = 0; yy < u4; yy++)
+                for (int xx = 0; xx < u4; xx++) units[((P.y >> 2) + yy) * w4 + (P.x >> 2) + xx].pred_mode = X265AMD_MODE_SKIP;
+            coder->bin(1, C_SKIP + skipCtx);
+            const uint32_t skipFlagBits = w.bits();
+            coder->mergeIndex(u0);
+            mvBits = w.bits() - skipFlagBits;
+            coeffBits = 0;
+            bits = mvBits + skipFlagBits;
+        }
+        else
+        {
+            coder->bin(0, C_SKIP + skipCtx);
+            const uint32_t skipFlagBits = w.bits();
+            coder->bin(0, C_PRED_MODE);
+            coder->partSize(u0, P.depth, P.size);
+            coder->predInfo(P.x, P.y, P.size, u0);
+            mvBits = w.bits() - skipFlagBits;
+            bool dqp = si->use_dqp != 0;
+            /* Entropy::codeCoeff (entropy.cpp:1207-1222) */
+            if (!(u0.merge_flag && u0.part_size == 0)) coder->bin(rootCbf, C_QT_ROOT_CBF);
+            if (rootCbf)
+            {
+                coder->coeffCtu[0] = coeffCu.data(); coder->coeffCtu[1] = coeffCu.data() + 4096; coder->coeffCtu[2] = coeffCu.data() + 4096 + 1024;
+                coder->ctuX0 = P.x; coder->ctuY0 = P.y;
+                coder->transform(P.x, P.y, P.x, P.y, 0, P.log2, dqp, P.range);
+            }
+            bits = w.bits();
+            coeffBits = bits - mvBits - skipFlagBits;
+        }
+        x265amd_rd_result& r = out[i];
+        memset(&r, 0, sizeof(r));
+        r.total_bits = bits; r.mv_bits = mvBits; r.coeff_bits = coeffBits; r.res_energy = (uint32_t)(sse_t)m0.sse[0];
+        /* checkDQP's entropy side (:3974-4003); the cost follows in x265amd_inter_rd_finish once the distortion is known */
+        if (si->use_dqp && P.depth <= si->max_cu_dqp_depth)
+        {
+            if (rootCbf)
+            {
+                if (rp->rd_level >= 3)
+                {
+                    w.resetBits();
+                    coder->deltaQP(P.x, P.y);
+                    r.total_bits += w.bits();
+                }
+                else if (rp->rd_level == 2) r.total_bits++;
+            }
+            else
+            {
+                const int8_t q = (int8_t)coder->refQP(P.x, P.y);
+                for (int yy = 0; yy < u4; yy++)
+                    for (int xx = 0; xx < u4; xx++) units[((P.y >> 2) + yy) * w4 + (P.x >> 2) + xx].qp = q;
+            }
+        }
+        memcpy(r.ctx, coder->ctx, X265AMD_CTX_COUNT);
+        r.frac_bits = coder->fracBits;
+        if (coeff_out) memcpy(coeff_out + (size_t)i * (4096 + 2048), coeffCu.data(), sizeof(int16_t) * (4096 + 2048));
+        for (int yy = 0; yy < u4; yy++)
+        {
+            memcpy(&mine[yy * u4], &units[((P.y >> 2) + yy) * w4 + (P.x >> 2)], sizeof(x265amd_cu_unit) * u4);
+            memcpy(&units[((P.y >> 2) + yy) * w4 + (P.x >> 2)], &saved[yy * u4], sizeof(x265amd_cu_unit) * u4);
+        }
+    }
+    x265amd_cabac_close(coder);
+    return X265AMD_OK;
+}
+
+/* reconstruction-side results (:2932-2958), updateModeCost with the bits checkDQP may have added */
+extern "C" void x265amd_inter_rd_finish(const x265amd_slice_info* si, const x265amd_rd_params* rp, const x265amd_rd_cu* cus, int n,
+                                        const x265amd_cu_measure* final_meas, x265amd_rd_result* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_cu_measure& m1 = final_meas[i];
+        x265amd_rd_result& r = out[i];
+        uint64_t rd[6];
+        x265amd_rdcost(cus[i].qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+        const sse_t bestLumaDist = (sse_t)m1.sse[0];
+        sse_t bestChromaDist = (sse_t)m1.sse[1];
+        bestChromaDist += (sse_t)m1.sse[2];
+        const sse_t distortion = bestLumaDist + bestChromaDist;
+        r.luma_distortion = (uint32_t)bestLumaDist; r.chroma_distortion = (uint32_t)bestChromaDist; r.distortion = distortion;
+        r.psy_energy = rd[2] ? m1.psy : 0;
+        x265amd_rdcost(cus[i].qp, si->slice_type, rp->psy_rd, distortion, r.total_bits, r.psy_energy, rd);
+        r.rd_cost = rd[2] ? rd[4] : rd[3];
+    }
+}
+
+extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                                         const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                                         x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
+                                         x265amd_rd_result* out, int16_t* coeff_out)
+{
+    if (!si || !rp || !units || !h_src || !cus || !cu_units || !d_pred || !d_recon || !out || n < 0) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: null argument");
+    if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: tile too small");
+    if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
+    if (n == 0) return X265AMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+
+    /* ---- plan + launch 1: all transform chains and the no-residual measurement ---- */
+    const size_t perCuBytes = x265amd_inter_rd_scratch_bytes();
+    DevBuf dScratch, dJobs, dRes, dMJobs, dMeas, dSel;
+    XA_HIP_CHECK(dScratch.alloc(perCuBytes * n));
+    char* scratch = (char*)dScratch.p;
+    const int nJobs = x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, nullptr, 0);
+    if (nJobs < 0) return nJobs;
+    std::vector<x265amd_tu_job> jobs(nJobs);
+    x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, jobs.data(), nJobs);
+    XA_HIP_CHECK(dJobs.alloc(sizeof(x265amd_tu_job) * nJobs));
+    XA_HIP_CHECK(dRes.alloc(sizeof(x265amd_tu_result) * nJobs));
+    XA_HIP_CHECK(dMJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(dMeas.alloc(sizeof(x265amd_cu_measure) * n * 2));
+    XA_HIP_CHECK(dSel.alloc((size_t)RD_SEL_BYTES * n));
+    XA_HIP_CHECK(hipMemcpyAsync(dJobs.p, jobs.data(), sizeof(x265amd_tu_job) * nJobs, hipMemcpyHostToDevice, stream));
+    int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)dJobs.p, nJobs, (x265amd_tu_result*)dRes.p);
+    if (rc != X265AMD_OK) return rc;
+    std::vector<CuMeasureJob> mjobs(n);
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_rd_cu& cu = cus[i];
+        CuMeasureJob& m = mjobs[i];
+        m.fenc[0] = h_src[0] + ((uint64_t)cu.y * stride + cu.x) * sizeof(pixel);
+        m.fenc[1] = h_src[1] + ((uint64_t)(cu.y >> 1) * cstride + (cu.x >> 1)) * sizeof(pixel);
+        m.fenc[2] = h_src[2] + ((uint64_t)(cu.y >> 1) * cstride + (cu.x >> 1)) * sizeof(pixel);
+        m.pred = d_pred + (uint64_t)tile_bytes * i; m.recon = d_recon + (uint64_t)tile_bytes * i;
+        m.resi = (uint64_t)(uintptr_t)(scratch + perCuBytes * i) + (uint64_t)RD_SCRATCH_ELEMS * 2;
+        m.sel = (uint64_t)(uintptr_t)((char*)dSel.p + (size_t)RD_SEL_BYTES * i);
+        m.fenc_stride = (int32_t)stride; m.fenc_cstride = (int32_t)cstride; m.log2_size = cu.log2_size; m.assemble = 0;
+    }
+    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
+    XA_HIP_CHECK(hipGetLastError());
+    std::vector<x265amd_tu_result> res(nJobs);
+    std::vector<x265amd_cu_measure> meas(2 * (size_t)n);
+    std::vector<int16_t> levels((size_t)RD_SCRATCH_ELEMS * n);
+    XA_HIP_CHECK(hipMemcpyAsync(res.data(), dRes.p, sizeof(x265amd_tu_result) * nJobs, hipMemcpyDeviceToHost, stream));
+    XA_HIP_CHECK(hipMemcpyAsync(meas.data(), dMeas.p, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
+    XA_HIP_CHECK(hipMemcpy2DAsync(levels.data(), (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n, hipMemcpyDeviceToHost, stream));
+    XA_HIP_CHECK(hipStreamSynchronize(stream));
+
+    /* ---- the walk ---- */
+    std::vector<uint8_t> sel((size_t)RD_SEL_BYTES * n);
+    rc = x265amd_inter_rd_walk(si, rp, units, cus, n, cu_units, res.data(), levels.data(), (size_t)RD_SCRATCH_ELEMS * 2, meas.data(), sel.data(), out, coeff_out);
+    if (rc != X265AMD_OK) return rc;
+
+    /* ---- launch 2: assemble, reconstruct, measure ---- */
+    for (int i = 0; i < n; i++) mjobs[i].assemble = 1;
+    XA_HIP_CHECK(hipMemcpyAsync(dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice, stream));
+    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p + n);
+    XA_HIP_CHECK(hipGetLastError());
+    XA_HIP_CHECK(hipMemcpyAsync(meas.data() + n, (x265amd_cu_measure*)dMeas.p + n, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
+    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    x265amd_inter_rd_finish(si, rp, cus, n, meas.data() + n, out);
+    return X265AMD_OK;
+}
