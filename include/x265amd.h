@@ -618,6 +618,15 @@ int x265amd_inter_rd_walk(const x265amd_slice_info* si, const x265amd_rd_params*
 void x265amd_inter_rd_finish(const x265amd_slice_info* si, const x265amd_rd_params* rp, const x265amd_rd_cu* cus, int n,
                              const x265amd_cu_measure* final_meas, x265amd_rd_result* out);
 
+/* Search::encodeResAndCalcRdSkipCU (reference: source/encoder/search.cpp:2770-2818) for a batch of merge candidates: reconstruction =
+ * prediction, distortion / psy energy from one k_cu_measure launch, bits of the skip flag and the merge index (cu_units[].mvp_idx[0]).
+ * Arguments as x265amd_inter_residual_rd; cu_units return pred_mode SKIP, cbf 0, tu_depth 0.  x265amd_skip_rd_host is its host stage. */
+int x265amd_skip_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                    const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                    x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, x265amd_rd_result* out);
+int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
+                         x265amd_cu_unit* cu_units, const x265amd_cu_measure* meas, x265amd_rd_result* out);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

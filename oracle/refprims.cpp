@@ -1155,7 +1155,7 @@ struct RefRdParams { double psyRd; int32_t rdLevel, reserved; };
 struct RefRdResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, mvBits, coeffBits, psyEnergy, lumaDist, chromaDist, resEnergy, reserved; uint8_t ctx[160]; };
 /* srcPlanes: addresses of sample (0,0) of the source Y, U, V.  predY/U/V: strides 64 / 32.  cuUnitsOut: the CU's units after the call, raster within the
  * CU (row length size/4).  coeffOut: 4096 + 2 * 1024 levels in CUData::m_trCoeff layout.  reconY/U/V: strides 64 / 32. */
-void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
+static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
                            int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, const pixel* predY, const pixel* predU, const pixel* predV,
                            RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
 {
@@ -1264,7 +1264,8 @@ void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const 
         memcpy(start.m_contextState, ctxIn, MAX_OFF_CTX_MOD);
         start.m_fracBits = fracIn;
         search->m_rqt[depth].cur.load(start);
-        search->encodeResAndCalcRdInterCU(*mode, *g);
+        if (skipCU) search->encodeResAndCalcRdSkipCU(*mode);
+        else search->encodeResAndCalcRdInterCU(*mode, *g);
         memset(out, 0, sizeof(*out));
         out->rdCost = mode->rdCost; out->distortion = mode->distortion; out->fracBits = mode->contexts.m_fracBits;
         out->totalBits = mode->totalBits; out->mvBits = mode->mvBits; out->coeffBits = mode->coeffBits; out->psyEnergy = mode->psyEnergy;
@@ -1301,6 +1302,20 @@ void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const 
     frame.m_encData = NULL;
     fd->destroy(); delete fd;
     x265_param_free(param);
+}
+
+void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
+                           int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, const pixel* predY, const pixel* predU, const pixel* predV,
+                           RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
+{
+    rd_fixture_run(0, si, rp, units, srcPlanes, stride, cstride, cuX, cuY, log2CU, qp, ctxIn, fracIn, predY, predU, predV, cuUnitsOut, coeffOut, reconY, reconU, reconV, out);
+}
+/* Search::encodeResAndCalcRdSkipCU (encoder/search.cpp:2770-2818) on the same fixture */
+void ref_skip_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
+                 int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, const pixel* predY, const pixel* predU, const pixel* predV,
+                 RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
+{
+    rd_fixture_run(1, si, rp, units, srcPlanes, stride, cstride, cuX, cuY, log2CU, qp, ctxIn, fracIn, predY, predU, predV, cuUnitsOut, coeffOut, reconY, reconU, reconV, out);
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

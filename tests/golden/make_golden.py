@@ -221,6 +221,14 @@ def make_inter_rd_golden():
                 out["%d/%d/%s" % (k, i, name)] = a
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "inter_rd_golden.npz"), **out)
     print("wrote inter_rd_golden.npz with", len(out), "arrays")
+    out = {}
+    for k, (depth, seed, st, psy) in enumerate(tird.SKIP_CASES):
+        c = T.skip_case(depth, seed, st, psy)
+        for i, d in enumerate(T.rd_pack(T.skip_run_ref(T.load_ref(depth), c), c)):
+            for name, a in d.items():
+                out["%d/%d/%s" % (k, i, name)] = a
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "skip_rd_golden.npz"), **out)
+    print("wrote skip_rd_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -2278,3 +2278,76 @@ def rd_pack(res, c):
             d["coeff"] = np.zeros(0, np.int16)
         keep.append(d)
     return keep
+
+
+def skip_case(depth, seed, slice_type, psy_rd, ncu=10):
+    """rd_case with every candidate a merged 2Nx2N CU (the only kind encodeResAndCalcRdSkipCU sees)"""
+    c = rd_case(depth, seed, slice_type, 1, psy_rd, ncu=ncu)
+    rng = np.random.default_rng(seed + 5)
+    for i in range(len(c["cus"])):
+        cu = c["cus"][i]
+        n4 = (1 << int(cu["log2_size"])) // 4
+        u = c["cu_units"][i]
+        u["part_size"][:n4 * n4] = 0
+        u["merge_flag"][:n4 * n4] = 1
+        u["mvp_idx"][:n4 * n4] = (int(rng.integers(0, c["si"]["max_num_merge_cand"])), 0)
+        u["inter_dir"][:n4 * n4] = 1
+        u["ref_idx"][:n4 * n4] = (0, -1)
+        u["mvd"][:n4 * n4] = 0
+        x, y = int(cu["x"]), int(cu["y"])
+        c["maps"][i][y // 4:y // 4 + n4, x // 4:x // 4 + n4] = u[:n4 * n4].reshape(n4, n4)
+    return c
+
+
+def skip_run_ref(R, c):
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    res = np.zeros(n, RD_RESULT_DT); uo = np.zeros((n, 256), CU_UNIT_DT); coeff = np.zeros((n, RD_TILE), np.int16); recon = np.zeros((n, RD_TILE), dt)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    planes = np.array([p.ctypes.data for p in c["src"]], np.uint64)
+    for i in range(n):
+        cu = c["cus"][i]
+        ctx = np.zeros(160, np.uint8); ctx[:] = cu["ctx"]
+        m = np.ascontiguousarray(c["maps"][i])
+        pr = c["preds"][i]
+        R.lib.ref_skip_rd(_ptr(si), _ptr(c["rp"]), _ptr(m), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                          int(cu["x"]), int(cu["y"]), int(cu["log2_size"]), int(cu["qp"]), _ptr(ctx), C.c_uint64(int(cu["frac_bits"])),
+                          off(pr, 0), off(pr, 4096), off(pr, 4096 + 1024), off(uo[i], 0), off(coeff[i], 0),
+                          off(recon[i], 0), off(recon[i], 4096), off(recon[i], 4096 + 1024), off(res, i))
+    return res, uo, coeff, recon
+
+
+def skip_run_host_cpu(L, O, c):
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    recon = np.zeros((n, RD_TILE), dt)
+    m = rd_measure_cpu(O, c, np.zeros(n * RD_SCRATCH_ELEMS * (4 + dt.itemsize), np.uint8), None, recon)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    units = np.ascontiguousarray(c["units"].copy())
+    cu_units = c["cu_units"].copy()
+    out = np.zeros(n, RD_RESULT_DT)
+    rc = L.lib.x265amd_skip_rd_host(_ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(c["cus"]), n, _ptr(cu_units), _ptr(m), _ptr(out))
+    assert rc == 0
+    assert np.array_equal(units, c["units"])
+    return out, cu_units, np.zeros((n, RD_TILE), np.int16), recon
+
+
+def skip_run_hip(L, c):
+    import torch
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    isz = dt.itemsize
+    d_src = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)).cuda() for p in c["src"]]
+    planes = np.array([d.data_ptr() for d in d_src], np.uint64)
+    d_pred = torch.from_numpy(np.ascontiguousarray(c["preds"]).view(np.uint8).reshape(-1)).cuda()
+    d_recon = torch.zeros(n * RD_TILE * isz, dtype=torch.uint8, device="cuda")
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    units = np.ascontiguousarray(c["units"].copy())
+    cu_units = c["cu_units"].copy()
+    out = np.zeros(n, RD_RESULT_DT)
+    rc = L.lib.x265amd_skip_rd(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                               _ptr(c["cus"]), n, _ptr(cu_units), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), C.c_size_t(RD_TILE * isz), _ptr(out))
+    assert rc == 0, L.lib.x265amd_last_error()
+    assert np.array_equal(units, c["units"])
+    recon = d_recon.cpu().numpy().view(dt).reshape(n, RD_TILE).copy()
+    return out, cu_units, np.zeros((n, RD_TILE), np.int16), recon

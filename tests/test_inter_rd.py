@@ -67,3 +67,30 @@ def test_hip_matches_host_stages_on_a_larger_batch():
     got = T.rd_run_hip(T.load_hip(8), c)
     want = T.rd_run_stages_cpu(T.load_hip(8), T.load_oracle(8), c)
     T.rd_compare(got, want, c, "batch")
+
+
+# ---- Search::encodeResAndCalcRdSkipCU ----
+SKIP_CASES = [(8, 501, 1, 2.0), (8, 502, 0, 0.0), (10, 503, 0, 2.0)]
+SKIP_GOLD_PATH = os.path.join(T.GOLDEN_DIR, "skip_rd_golden.npz")
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref not built")
+def test_skip_host_stage_matches_reference():
+    for k, (depth, seed, st, psy) in enumerate(SKIP_CASES + [(8, 511, 1, 0.6), (10, 512, 1, 0.0)]):
+        c = T.skip_case(depth, seed, st, psy)
+        T.rd_compare(T.skip_run_host_cpu(T.load_hip(depth), T.load_oracle(depth), c), T.skip_run_ref(T.load_ref(depth), c), c, "skip case %d" % k)
+
+
+def test_skip_host_stage_matches_golden():
+    gold = np.load(SKIP_GOLD_PATH)
+    for k, (depth, seed, st, psy) in enumerate(SKIP_CASES):
+        c = T.skip_case(depth, seed, st, psy)
+        check_golden(T.skip_run_host_cpu(T.load_hip(depth), T.load_oracle(depth), c), c, gold, k)
+
+
+@pytest.mark.gpu
+def test_hip_skip_rd_matches_reference_golden():
+    gold = np.load(SKIP_GOLD_PATH)
+    for k, (depth, seed, st, psy) in enumerate(SKIP_CASES):
+        c = T.skip_case(depth, seed, st, psy)
+        check_golden(T.skip_run_hip(T.load_hip(depth), c), c, gold, k)

@@ -665,6 +665,112 @@ extern "C" void x265amd_inter_rd_finish(const x265amd_slice_info* si, const x265
     }
 }
 
+/* Search::encodeResAndCalcRdSkipCU (search.cpp:2770-2818): the entropy side and the cost, given prediction-vs-source measurements */
+extern "C" int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
+                                    x265amd_cu_unit* cu_units, const x265amd_cu_measure* meas, x265amd_rd_result* out)
+{
+    if (!si || !rp || !units || !cus || !cu_units || !meas || !out || n < 0) return xa_fail(X265AMD_EINVAL, "skip_rd: null argument");
+    if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "skip_rd: lossless coding is not supported");
+    const int w4 = si->pic_width >> 2;
+    x265amd_cabac* coder = x265amd_cabac_open(si, units, 1);
+    if (!coder) return xa_fail(X265AMD_EINVAL, "skip_rd: slice description");
+    std::vector<x265amd_cu_unit> saved(256);
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_rd_cu& cu = cus[i];
+        const int log2 = cu.log2_size, size = 1 << log2, u4 = size >> 2, x = cu.x, y = cu.y;
+        if (log2 < 3 || log2 > 6 || (x & (size - 1)) || (y & (size - 1)) || x < 0 || y < 0 || x + size > si->pic_width || y + size > si->pic_height)
+        {
+            x265amd_cabac_close(coder);
+            return xa_fail(X265AMD_EINVAL, "skip_rd: CU outside the picture or misaligned");
+        }
+        x265amd_cu_unit* mine = cu_units + (size_t)i * 256;
+        for (int yy = 0; yy < u4; yy++)
+        {
+            memcpy(&saved[yy * u4], &units[((y >> 2) + yy) * w4 + (x >> 2)], sizeof(x265amd_cu_unit) * u4);
+            memcpy(&units[((y >> 2) + yy) * w4 + (x >> 2)], &mine[yy * u4], sizeof(x265amd_cu_unit) * u4);
+        }
+        for (int yy = 0; yy < u4; yy++)
+            for (int xx = 0; xx < u4; xx++)
+            {
+                x265amd_cu_unit& u = units[((y >> 2) + yy) * w4 + (x >> 2) + xx];
+                u.pred_mode = X265AMD_MODE_SKIP; u.cbf[0] = u.cbf[1] = u.cbf[2] = 0; u.tu_depth = 0; u.depth = (uint8_t)(6 - log2);
+            }
+        memcpy(coder->ctx, cu.ctx, X265AMD_CTX_COUNT);
+        coder->fracBits = cu.frac_bits & 32767;             /* load(cur); resetBits() */
+        const x265amd_cu_unit* l = coder->at((x >> 2) - 1, y >> 2);
+        const x265amd_cu_unit* a = coder->at(x >> 2, (y >> 2) - 1);
+        const int skipCtx = (x265amd_cabac::coded(l) && l->pred_mode == X265AMD_MODE_SKIP) + (x265amd_cabac::coded(a) && a->pred_mode == X265AMD_MODE_SKIP);
+        coder->bin(1, C_SKIP + skipCtx);
+        const uint32_t skipFlagBits = (uint32_t)(coder->fracBits >> 15);
+        coder->mergeIndex(units[(y >> 2) * w4 + (x >> 2)]);
+        x265amd_rd_result& r = out[i];
+        memset(&r, 0, sizeof(r));
+        r.mv_bits = (uint32_t)(coder->fracBits >> 15) - skipFlagBits;
+        r.coeff_bits = 0;
+        r.total_bits = r.mv_bits + skipFlagBits;
+        const x265amd_cu_measure& m = meas[i];
+        const sse_t luma = (sse_t)m.sse[0];
+        sse_t chroma = (sse_t)m.sse[1];
+        chroma += (sse_t)m.sse[2];
+        const sse_t distortion = luma + chroma;
+        uint64_t rd[6];
+        x265amd_rdcost(cu.qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+        r.luma_distortion = (uint32_t)luma; r.chroma_distortion = (uint32_t)chroma; r.distortion = distortion; r.res_energy = (uint32_t)luma;
+        r.psy_energy = rd[2] ? m.psy : 0;
+        x265amd_rdcost(cu.qp, si->slice_type, rp->psy_rd, distortion, r.total_bits, r.psy_energy, rd);
+        r.rd_cost = rd[2] ? rd[4] : rd[3];
+        memcpy(r.ctx, coder->ctx, X265AMD_CTX_COUNT);
+        r.frac_bits = coder->fracBits;
+        for (int yy = 0; yy < u4; yy++)
+        {
+            memcpy(&mine[yy * u4], &units[((y >> 2) + yy) * w4 + (x >> 2)], sizeof(x265amd_cu_unit) * u4);
+            memcpy(&units[((y >> 2) + yy) * w4 + (x >> 2)], &saved[yy * u4], sizeof(x265amd_cu_unit) * u4);
+        }
+    }
+    x265amd_cabac_close(coder);
+    return X265AMD_OK;
+}
+
+static void fill_measure_jobs(std::vector<CuMeasureJob>& mjobs, const x265amd_rd_cu* cus, int n, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
+                              uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, const char* scratch, size_t perCuBytes, const char* dSel)
+{
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_rd_cu& cu = cus[i];
+        CuMeasureJob& m = mjobs[i];
+        m.fenc[0] = h_src[0] + ((uint64_t)cu.y * stride + cu.x) * sizeof(pixel);
+        m.fenc[1] = h_src[1] + ((uint64_t)(cu.y >> 1) * cstride + (cu.x >> 1)) * sizeof(pixel);
+        m.fenc[2] = h_src[2] + ((uint64_t)(cu.y >> 1) * cstride + (cu.x >> 1)) * sizeof(pixel);
+        m.pred = d_pred + (uint64_t)tile_bytes * i; m.recon = d_recon + (uint64_t)tile_bytes * i;
+        m.resi = scratch ? (uint64_t)(uintptr_t)(scratch + perCuBytes * i) + (uint64_t)RD_SCRATCH_ELEMS * 2 : 0;
+        m.sel = dSel ? (uint64_t)(uintptr_t)(dSel + (size_t)RD_SEL_BYTES * i) : 0;
+        m.fenc_stride = (int32_t)stride; m.fenc_cstride = (int32_t)cstride; m.log2_size = cu.log2_size; m.assemble = 0;
+    }
+}
+
+extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                               const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                               x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, x265amd_rd_result* out)
+{
+    if (!si || !rp || !units || !h_src || !cus || !cu_units || !d_pred || !d_recon || !out || n < 0) return xa_fail(X265AMD_EINVAL, "skip_rd: null argument");
+    if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "skip_rd: tile too small");
+    if (n == 0) return X265AMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DevBuf dMJobs, dMeas;
+    XA_HIP_CHECK(dMJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(dMeas.alloc(sizeof(x265amd_cu_measure) * n));
+    std::vector<CuMeasureJob> mjobs(n);
+    fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, nullptr, 0, nullptr);
+    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
+    XA_HIP_CHECK(hipGetLastError());
+    std::vector<x265amd_cu_measure> meas(n);
+    XA_HIP_CHECK(hipMemcpyAsync(meas.data(), dMeas.p, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
+    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    return x265amd_skip_rd_host(si, rp, units, cus, n, cu_units, meas.data(), out);
+}
+
 extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
                                          const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
                                          x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
@@ -694,18 +800,7 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)dJobs.p, nJobs, (x265amd_tu_result*)dRes.p);
     if (rc != X265AMD_OK) return rc;
     std::vector<CuMeasureJob> mjobs(n);
-    for (int i = 0; i < n; i++)
-    {
-        const x265amd_rd_cu& cu = cus[i];
-        CuMeasureJob& m = mjobs[i];
-        m.fenc[0] = h_src[0] + ((uint64_t)cu.y * stride + cu.x) * sizeof(pixel);
-        m.fenc[1] = h_src[1] + ((uint64_t)(cu.y >> 1) * cstride + (cu.x >> 1)) * sizeof(pixel);
-        m.fenc[2] = h_src[2] + ((uint64_t)(cu.y >> 1) * cstride + (cu.x >> 1)) * sizeof(pixel);
-        m.pred = d_pred + (uint64_t)tile_bytes * i; m.recon = d_recon + (uint64_t)tile_bytes * i;
-        m.resi = (uint64_t)(uintptr_t)(scratch + perCuBytes * i) + (uint64_t)RD_SCRATCH_ELEMS * 2;
-        m.sel = (uint64_t)(uintptr_t)((char*)dSel.p + (size_t)RD_SEL_BYTES * i);
-        m.fenc_stride = (int32_t)stride; m.fenc_cstride = (int32_t)cstride; m.log2_size = cu.log2_size; m.assemble = 0;
-    }
+    fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, scratch, perCuBytes, (const char*)dSel.p);
     XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
     XA_HIP_CHECK(hipGetLastError());
