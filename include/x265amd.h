@@ -555,6 +555,21 @@ int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const x265amd_mv
                               x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
                               const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu);
 
+/* x265amd_pred_inter_search that also reports what the reference keeps in Mode::bestME[0][list] / amvpCand of the CU's first PU (search.h:79-99),
+ * which Analysis::checkBidir2Nx2N reads afterwards.  cost[l] == 0xFFFFFFFF: list l was not searched. */
+typedef struct x265amd_me_detail
+{
+    int16_t mv[2][2], mvp[2][2];
+    int16_t amvp[2][2][2];          /* the two AMVP candidates of each list's best reference */
+    int8_t ref[2]; uint8_t mvp_idx[2];
+    uint32_t bits[2], cost[2], mv_cost[2];
+    uint32_t list_sel_bits[3];      /* Search::m_listSelBits */
+} x265amd_me_detail;                /* 72 bytes */
+int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* info, const x265amd_inter_search_params* sp,
+                                 x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
+                                 const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu,
+                                 x265amd_me_detail* detail);
+
 /* --- residual RD of inter CUs: Search::encodeResAndCalcRdInterCU (reference: source/encoder/search.cpp:2822-2975) with
  * estimateResidualQT (:3178-3857), splitTU (:3126-3176), estimateNullCbfCost (:3114-3124), codeInterSubdivCbfQT (:3859-3887),
  * saveResidualQTData (:3889-3972) and checkDQP (:3974-4003), for a batch of independent candidate CUs.
@@ -604,7 +619,10 @@ int x265amd_inter_residual_rd(void* stream, const x265amd_slice_info* si, const 
  * p (1, 2) at 16384 + ((C - 2) * 2 + p - 1) * 1024; levels are TU blocks in raster TU order, residual / dump blocks sit at their position in
  * a stride-64 (luma) / stride-32 (chroma) tile.  The selection map (384 bytes per CU): for each luma 4x4 unit (row length 16), then each
  * chroma 4x4 unit of U and of V (row length 8), the layer whose residual block was kept, 0xFF for none. */
-typedef struct x265amd_cu_measure { uint64_t sse[3]; uint32_t psy, reserved; } x265amd_cu_measure;     /* sse_pp per plane, luma psyCost */
+typedef struct x265amd_cu_measure { uint64_t sse[3]; uint32_t psy, sa8d; } x265amd_cu_measure;     /* sse_pp per plane, luma psyCost, cu[].sa8d of Y + U + V */
+/* tile-vs-source measurement of n CUs (k_cu_measure without assembly): d_tiles as d_pred above; cus: only x, y, log2_size are read.  Synchronous. */
+int x265amd_measure_tiles(void* stream, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                          uint64_t d_tiles, size_t tile_bytes, x265amd_cu_measure* out);
 size_t x265amd_inter_rd_scratch_bytes(void);
 /* emits the transform-chain jobs of all CUs (returns their number; jobs_out may be NULL to count) */
 int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
@@ -626,6 +644,31 @@ int x265amd_skip_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd
                     x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, x265amd_rd_result* out);
 int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
                          x265amd_cu_unit* cu_units, const x265amd_cu_measure* meas, x265amd_rd_result* out);
+
+/* --- CTU mode decision of inter slices: Analysis::compressCTU -> compressInterCU_rd0_4 (reference:
+ * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N
+ * (:3145-3277), topSkipMinDepth (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426).  Host recursion in the
+ * reference's order over the batch entry points above; one CTU per call.
+ * Built subset: B slices without intra candidates (b_intra 0), 2Nx2N partitions (rect / amp 0), limit_refs 0, limit_modes 0, no delta QP,
+ * rd_level 3-4, rskip 0 / 1, early_skip 0 / 1.  Anything else is rejected with X265AMD_EINVAL. */
+typedef struct x265amd_analysis_params
+{
+    double psy_rd;                  /* param.psyRd */
+    int32_t rd_level, early_skip, rskip, limit_refs, b_intra, rect, amp, limit_modes;
+} x265amd_analysis_params;          /* 40 bytes */
+typedef struct x265amd_cu_stat { uint32_t count[4]; uint32_t pad[2]; uint64_t avg_cost[4]; } x265amd_cu_stat;     /* FrameData::RCStatCU count / avgCost per depth */
+typedef struct x265amd_ctu_result { uint64_t rd_cost, distortion, frac_bits; uint32_t total_bits, reserved; uint8_t ctx[X265AMD_CTX_STRIDE]; } x265amd_ctu_result;
+/* units / cur: the picture's unit map and motion field (what is coded so far); the CTU's part is reset and then filled with the decisions.
+ * ref_depth: CU depths of the co-located pictures refFrameList[0][0] and [1][0], one byte per 4x4 unit, two maps; ref_qp0: their CTU QPs
+ * (2 x number of CTUs).  h_planes: HOST array of num_pics x 3 device addresses; the last picture is the source, the one before it receives
+ * the reconstruction.  cu_stat: per CTU, updated.  ctx_in / frac_in: the row coder's state at the CTU start.  coeff_out: 4096 + 2 x 1024
+ * levels in CUData::m_trCoeff layout (may be NULL).  merge_flag / mvp_idx / mvd of a PU are uniform over its units here (the reference only
+ * writes them at the PU's first unit).  Synchronous. */
+int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* info, const x265amd_inter_search_params* sp,
+                               const x265amd_slice_info* si, const x265amd_analysis_params* ap, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                               const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                               intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
+                               int16_t* coeff_out, x265amd_ctu_result* out);
 
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */

@@ -13,6 +13,7 @@
 #include "sao.h"
 #include "bitstream.h"
 #include "search.h"
+#include "analysis.h"
 #include <vector>
 #include "frame.h"
 #include "x265.h"
@@ -1316,6 +1317,168 @@ void ref_skip_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit*
                  RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
 {
     rd_fixture_run(1, si, rp, units, srcPlanes, stride, cstride, cuX, cuY, log2CU, qp, ctxIn, fracIn, predY, predU, predV, cuUnitsOut, coeffOut, reconY, reconU, reconV, out);
+}
+
+/* ---- Analysis::compressCTU (encoder/analysis.cpp:138-317 -> compressInterCU_rd0_4 :1146-1848 with checkMerge2Nx2N_rd0_4, checkInter_rd0_4,
+ * checkBidir2Nx2N and the Search methods below them) itself, for one CTU of an inter slice, on a fixture: picture CUData from the raster
+ * unit + motion maps (what is coded so far), reference pictures, their motion / depth maps, the source picture ---- */
+struct RefAnalysisParams { double psyRd; int32_t rdLevel, earlySkip, rskip, limitRefs, bIntraInB, rect, amp, limitModes; };
+struct RefCuStat { uint32_t count[4]; uint32_t pad; uint64_t avgCost[4]; };
+struct RefCtuResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, reserved; uint8_t ctx[160]; };
+/* planes: numPics x 3 addresses of sample (0,0); picture numPics-1 is the source, numPics-2 the reconstruction being written.
+ * refDepth: the co-located CU depths of reference [list][0] per 4x4 unit (two maps, list 0 then list 1); refQp0[list]: their CTU QPs (per CTU).
+ * unitsOut / mvOut: the CTU's 16x16 units after analysis (raster). */
+void ref_compress_ctu(const RefMvInfo* I, const RefSearchParams* S, const RefSliceInfo* si, const RefAnalysisParams* A, const RefCuUnit* units,
+                      const RefMvUnit* cur, const RefMvUnit* col, const uint8_t* refDepth, const int8_t* refQp0, const uint64_t* planes, intptr_t stride,
+                      intptr_t cstride, int marginX, int marginY, RefCuStat* cuStat, int ctuAddr, const uint8_t* ctxIn, uint64_t fracIn,
+                      RefCuUnit* unitsOut, RefMvUnit* mvOut, int16_t* coeffOut, RefCtuResult* out)
+{
+    ensure();
+    MvFixture f(I, cur, col);
+    const int width = I->picWidth, height = I->picHeight, w4 = width >> 2;
+    x265_param* param = f.param;
+    param->searchMethod = S->searchMethod; param->subpelRefine = S->subpelRefine; param->searchRange = S->searchRange;
+    param->frameNumThreads = 1; param->maxSlices = 1; param->bframes = 0; param->bEnableWeightedPred = param->bEnableWeightedBiPred = 0;
+    param->bDistributeMotionEstimation = 0; param->bDistributeModeAnalysis = 0; param->bEnableHME = 0; param->analysisLoadReuseLevel = 0; param->analysisSaveReuseLevel = 0;
+    param->analysisSave = NULL; param->analysisLoad = NULL;
+    param->analysisMultiPassRefine = 0; param->bAnalysisType = 0; param->bIntraRefresh = 0; param->bSourceReferenceEstimation = 0;
+    param->psyRd = A->psyRd; param->bSsimRd = 0; param->psyRdoq = 0; param->rdoqLevel = 0; param->noiseReductionIntra = param->noiseReductionInter = 0; param->limitTU = 0;
+    param->interRefine = 0; param->mvRefine = 1; param->rc.bStatRead = 0; param->rdLevel = A->rdLevel; param->bEnableEarlySkip = A->earlySkip;
+    param->recursionSkipMode = A->rskip; param->limitReferences = A->limitRefs; param->bIntraInBFrames = A->bIntraInB; param->bEnableRectInter = A->rect;
+    param->bEnableAMP = A->amp; param->limitModes = A->limitModes; param->bCTUInfo = 0; param->bEnableRdRefine = 0; param->bOptCUDeltaQP = 0; param->csvLogLevel = 0;
+    param->bEnableTransformSkip = 0; param->bLossless = 0; param->bCULossless = 0; param->bEnableSignHiding = si->signHide; param->maxTUSize = 1 << si->tuLog2Max;
+    param->tuQTMaxInterDepth = si->tuMaxDepthInter; param->tuQTMaxIntraDepth = si->tuMaxDepthIntra; param->maxNumMergeCand = I->maxNumMergeCand;
+    param->rc.aqMode = 0; param->rc.cuTree = 0; param->rc.qgSize = 64; param->maxCUDepth = si->maxCuDepth;
+    f.sps.quadtreeTULog2MaxSize = si->tuLog2Max; f.sps.quadtreeTULog2MinSize = si->tuLog2Min;
+    f.sps.quadtreeTUMaxDepthInter = si->tuMaxDepthInter; f.sps.quadtreeTUMaxDepthIntra = si->tuMaxDepthIntra; f.sps.maxAMPDepth = si->maxAmpDepth;
+    f.sps.log2MinCodingBlockSize = 3; f.sps.log2DiffMaxMinCodingBlockSize = 3;
+    f.pps.bUseDQP = si->useDqp != 0; f.pps.maxCuDQPDepth = si->maxCuDqpDepth; f.pps.bSignHideEnabled = si->signHide != 0;
+    f.pps.bTransquantBypassEnabled = 0; f.pps.bTransformSkipEnabled = 0; f.pps.bEntropyCodingSyncEnabled = si->wpp != 0;
+    Slice* slice = f.fd[0]->m_slice;
+    slice->m_sliceQp = si->sliceQp;
+    slice->m_endCUAddr = slice->realEndAddress(f.sps.numCUsInFrame * 256);
+    /* the remaining CUData fields of the current picture, and the reference pictures' depth maps */
+    for (uint32_t addr = 0; addr < f.sps.numCUsInFrame; addr++)
+    {
+        CUData& ctu = f.fd[0]->m_picCTU[addr];
+        CUData& rctu = f.fd[1]->m_picCTU[addr];
+        ctu.m_chromaFormat = X265_CSP_I420; ctu.m_hChromaShift = ctu.m_vChromaShift = 1;
+        const int cx = (addr % f.sps.numCuInWidth) * 64, cy = (addr / f.sps.numCuInWidth) * 64;
+        for (uint32_t z = 0; z < 256; z++)
+        {
+            const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
+            if (x >= width || y >= height) { ctu.m_cuDepth[z] = 0; rctu.m_cuDepth[z] = 0; continue; }
+            const RefCuUnit& u = units[(y >> 2) * w4 + (x >> 2)];
+            ctu.m_cuDepth[z] = u.depth; ctu.m_log2CUSize[z] = (uint8_t)(6 - u.depth);
+            ctu.m_partSize[z] = u.partSize; ctu.m_tuDepth[z] = u.tuDepth; ctu.m_lumaIntraDir[z] = u.lumaDir; ctu.m_chromaIntraDir[z] = u.chromaDir;
+            ctu.m_mergeFlag[z] = u.mergeFlag; ctu.m_skipFlag[0][z] = ctu.m_skipFlag[1][z] = 0;
+            for (int c = 0; c < 3; c++) ctu.m_cbf[c][z] = u.cbf[c];
+            ctu.m_tqBypass[z] = 0; ctu.m_qp[z] = u.qp;
+            for (int l = 0; l < 2; l++) { ctu.m_mvpIdx[l][z] = u.mvpIdx[l]; ctu.m_mvd[l][z] = MV(u.mvd[l][0], u.mvd[l][1]); }
+            ctu.m_transformSkip[0][z] = ctu.m_transformSkip[1][z] = ctu.m_transformSkip[2][z] = 0;
+            rctu.m_cuDepth[z] = refDepth[(y >> 2) * w4 + (x >> 2)];
+        }
+        rctu.m_qp[0] = refQp0[addr];
+        for (int d = 0; d < 4; d++) { f.fd[0]->m_cuStat[addr].count[d] = cuStat[addr].count[d]; f.fd[0]->m_cuStat[addr].avgCost[d] = cuStat[addr].avgCost[d]; }
+    }
+    /* a second depth map for list 1: its own FrameData so that topSkipMinDepth sees different co-located CTUs per list */
+    FrameData* fdL1 = new FrameData;
+    fdL1->create(*param, f.sps, X265_CSP_I420);
+    Frame frameL1;
+    frameL1.m_encData = fdL1; frameL1.m_param = param;
+    fdL1->m_slice->m_sps = &f.sps; fdL1->m_slice->m_pps = &f.pps; fdL1->m_slice->m_param = param;
+    fdL1->m_slice->m_sliceType = f.fd[1]->m_slice->m_sliceType; fdL1->m_slice->m_poc = f.fd[1]->m_slice->m_poc;
+    for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) fdL1->m_slice->m_refPOCList[l][r] = f.fd[1]->m_slice->m_refPOCList[l][r];
+    for (uint32_t addr = 0; addr < f.sps.numCUsInFrame; addr++)
+    {
+        CUData& dst = fdL1->m_picCTU[addr];
+        const CUData& src = f.fd[1]->m_picCTU[addr];
+        dst.initCTU(frameL1, addr, 30, addr < f.sps.numCuInWidth, 0, 0);
+        const int cx = (addr % f.sps.numCuInWidth) * 64, cy = (addr / f.sps.numCuInWidth) * 64;
+        for (uint32_t z = 0; z < 256; z++)
+        {
+            dst.m_predMode[z] = src.m_predMode[z]; dst.m_interDir[z] = src.m_interDir[z];
+            for (int l = 0; l < 2; l++) { dst.m_refIdx[l][z] = src.m_refIdx[l][z]; dst.m_mv[l][z] = src.m_mv[l][z]; }
+            const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
+            dst.m_cuDepth[z] = (x >= width || y >= height) ? 0 : refDepth[(size_t)(height >> 2) * w4 + (y >> 2) * w4 + (x >> 2)];
+        }
+        dst.m_qp[0] = refQp0[f.sps.numCUsInFrame + addr];
+    }
+    std::vector<PicYuv*> pics;
+    for (int i = 0; i < S->numPics; i++) pics.push_back(mkPic(param, f.sps, planes + 3 * i, stride, cstride, width, height, marginX, marginY));
+    static Frame refFrames[2][16];
+    static MV noLowres(0x7FFF, 0);
+    MotionReference (*mref)[MAX_NUM_REF + 1] = new MotionReference[2][MAX_NUM_REF + 1];
+    slice->m_mref = mref;
+    Frame& frame = f.frame[0];
+    frame.m_fencPic = pics.back();
+    for (int l = 0; l < 2; l++) for (int i = 0; i < X265_BFRAME_MAX + 2; i++) frame.m_lowres.lowresMvs[l][i] = &noLowres;
+    f.fd[0]->m_reconPic = pics[S->numPics - 2];
+    frame.m_reconPic = pics[S->numPics - 2];
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < I->numRefIdx[l]; r++)
+        {
+            PicYuv* rp = pics[S->refPic[l][r]];
+            slice->m_refReconPicList[l][r] = rp;
+            refFrames[l][r].m_encData = (l == 1 && r == 0) ? fdL1 : f.fd[1]; refFrames[l][r].m_reconPic = rp; refFrames[l][r].m_fencPic = rp; refFrames[l][r].m_param = param;
+            slice->m_refFrameList[l][r] = &refFrames[l][r];
+            slice->m_mref[l][r].init(rp, NULL, *param);
+        }
+    {
+        Analysis* an = new Analysis;
+        ScalingList* sl = new ScalingList;
+        sl->init(); sl->m_bEnabled = false; sl->m_bDataPresent = false; sl->setupQuantMatrices(X265_CSP_I420);
+        an->initSearch(*param, *sl);
+        an->create(NULL);
+        CUData& ctu = f.fd[0]->m_picCTU[ctuAddr];
+        CUGeom geoms[CUGeom::MAX_GEOMS];
+        const int cx = (ctuAddr % f.sps.numCuInWidth) * 64, cy = (ctuAddr / f.sps.numCuInWidth) * 64;
+        CUData::calcCTUGeoms(X265_MIN(64, width - cx), X265_MIN(64, height - cy), 64, 8, geoms);
+        Entropy start;
+        start.resetEntropy(*slice);
+        memcpy(start.m_contextState, ctxIn, MAX_OFF_CTX_MOD);
+        start.m_fracBits = fracIn;
+        ctu.initCTU(frame, ctuAddr, si->sliceQp, ctuAddr < (int)f.sps.numCuInWidth, ctuAddr / f.sps.numCuInWidth == f.sps.numCuInHeight - 1, 0);
+        ctu.m_chromaFormat = X265_CSP_I420; ctu.m_hChromaShift = ctu.m_vChromaShift = 1;
+        Mode& best = an->compressCTU(ctu, frame, geoms[0], start);
+        memset(out, 0, sizeof(*out));
+        out->rdCost = best.rdCost; out->distortion = best.distortion; out->totalBits = best.totalBits; out->fracBits = best.contexts.m_fracBits;
+        memcpy(out->ctx, best.contexts.m_contextState, MAX_OFF_CTX_MOD);
+        for (uint32_t z = 0; z < 256; z++)
+        {
+            const int ux = g_zscanToPelX[z] >> 2, uy = g_zscanToPelY[z] >> 2;
+            RefCuUnit& u = unitsOut[uy * 16 + ux];
+            RefMvUnit& m = mvOut[uy * 16 + ux];
+            memset(&u, 0, sizeof(u)); memset(&m, 0, sizeof(m));
+            if (cx + ux * 4 >= width || cy + uy * 4 >= height) continue;
+            const int pm = ctu.m_predMode[z];
+            u.depth = ctu.m_cuDepth[z]; u.predMode = pm == MODE_SKIP ? 3 : (pm == MODE_INTRA ? 2 : (pm == MODE_INTER ? 1 : 0));
+            u.partSize = ctu.m_partSize[z]; u.tuDepth = ctu.m_tuDepth[z]; u.lumaDir = ctu.m_lumaIntraDir[z]; u.chromaDir = ctu.m_chromaIntraDir[z];
+            u.mergeFlag = ctu.m_mergeFlag[z]; u.interDir = ctu.m_interDir[z];
+            for (int c = 0; c < 3; c++) u.cbf[c] = ctu.m_cbf[c][z];
+            u.qp = ctu.m_qp[z];
+            m.predMode = u.predMode; m.interDir = u.interDir;
+            for (int l = 0; l < 2; l++)
+            {
+                u.refIdx[l] = ctu.m_refIdx[l][z]; u.mvpIdx[l] = ctu.m_mvpIdx[l][z]; u.mvd[l][0] = ctu.m_mvd[l][z].x; u.mvd[l][1] = ctu.m_mvd[l][z].y;
+                m.refIdx[l] = ctu.m_refIdx[l][z]; m.mv[l][0] = ctu.m_mv[l][z].x; m.mv[l][1] = ctu.m_mv[l][z].y;
+            }
+        }
+        memcpy(coeffOut, ctu.m_trCoeff[0], 4096 * sizeof(int16_t));
+        memcpy(coeffOut + 4096, ctu.m_trCoeff[1], 1024 * sizeof(int16_t));
+        memcpy(coeffOut + 4096 + 1024, ctu.m_trCoeff[2], 1024 * sizeof(int16_t));
+        for (uint32_t addr = 0; addr < f.sps.numCUsInFrame; addr++)
+            for (int d = 0; d < 4; d++) { cuStat[addr].count[d] = f.fd[0]->m_cuStat[addr].count[d]; cuStat[addr].avgCost[d] = f.fd[0]->m_cuStat[addr].avgCost[d]; }
+        an->destroy();
+        delete an;
+        delete sl;
+    }
+    f.fd[0]->m_reconPic = NULL; frame.m_fencPic = NULL; frame.m_reconPic = NULL;
+    slice->m_mref = NULL;
+    delete[] mref;
+    for (size_t i = 0; i < pics.size(); i++) dropPic(pics[i]);
+    frameL1.m_encData = NULL;
+    fdL1->destroy(); delete fdL1;
 }
 
 /* distortion of inter prediction candidates with the reference's own classes and primitives: Predict::motionCompensation (or,

@@ -46,6 +46,7 @@ def main():
     make_intra_tu_golden()
     make_inter_search_golden()
     make_inter_rd_golden()
+    make_ctu_analysis_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -229,6 +230,21 @@ def make_inter_rd_golden():
                 out["%d/%d/%s" % (k, i, name)] = a
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "skip_rd_golden.npz"), **out)
     print("wrote skip_rd_golden.npz with", len(out), "arrays")
+
+
+def make_ctu_analysis_golden():
+    """results of the reference's Analysis::compressCTU on fixtures -> tests/golden/ctu_analysis_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tca", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_ctu_analysis.py"))
+    tca = importlib.util.module_from_spec(spec); spec.loader.exec_module(tca)
+    out = {}
+    for k, cfg in enumerate(tca.CASES):
+        c = tca.make_case(k)
+        for i, d in enumerate(T.ctu_pack(T.ctu_run_ref(T.load_ref(cfg[0]), c))):
+            for name, a in d.items():
+                out["%d/%d/%s" % (k, i, name)] = a
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz"), **out)
+    print("wrote ctu_analysis_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

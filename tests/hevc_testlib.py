@@ -2102,7 +2102,7 @@ def rd_run_ref(R, c):
     return res, uo, coeff, recon
 
 
-CU_MEASURE_DT = np.dtype([("sse", "<u8", 3), ("psy", "<u4"), ("reserved", "<u4")])
+CU_MEASURE_DT = np.dtype([("sse", "<u8", 3), ("psy", "<u4"), ("sa8d", "<u4")])
 RD_SCRATCH_ELEMS = 4 * 4096 + 6 * 1024
 RD_SEL_BYTES = 384
 
@@ -2351,3 +2351,226 @@ def skip_run_hip(L, c):
     assert np.array_equal(units, c["units"])
     recon = d_recon.cpu().numpy().view(dt).reshape(n, RD_TILE).copy()
     return out, cu_units, np.zeros((n, RD_TILE), np.int16), recon
+
+
+# ---- CTU analysis of inter slices (x265amd_compress_ctu_inter vs Analysis::compressCTU) ----
+ANALYSIS_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("early_skip", "<i4"), ("rskip", "<i4"), ("limit_refs", "<i4"), ("b_intra", "<i4"),
+                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4")])
+CU_STAT_DT = np.dtype([("count", "<u4", 4), ("pad", "<u4", 2), ("avg_cost", "<u8", 4)])
+CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("reserved", "<u4"), ("ctx", "u1", 160)])
+assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 40
+
+
+def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0):
+    """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
+    the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
+    rng = np.random.default_rng(seed + 901)
+    pics, stride, cstride, org = inter_scene(depth, seed, npics=4)
+    recon = np.zeros_like(pics[0])
+    width, height = MC_W, MC_H
+    # local detail in the source so that small CUs pay off: blocks moved differently from their surroundings, and blocks of plain noise
+    src = pics[3].copy()
+    pmax = (1 << depth) - 1
+    ysz = (MC_H + 2 * MC_MY) * stride
+    csz = (MC_H // 2 + MC_MY) * cstride
+    views = [(src[:ysz].reshape(-1, stride), pics[0][:ysz].reshape(-1, stride), MC_MX, MC_MY, 1),
+             (src[ysz:ysz + csz].reshape(-1, cstride), pics[0][ysz:ysz + csz].reshape(-1, cstride), MC_MX // 2, MC_MY // 2, 2),
+             (src[ysz + csz:].reshape(-1, cstride), pics[0][ysz + csz:].reshape(-1, cstride), MC_MX // 2, MC_MY // 2, 2)]
+    for _ in range(int(detail * 30)):
+        bs = int(rng.choice([8, 8, 16, 16, 32]))
+        bx, by = int(rng.integers(0, width // bs)) * bs, int(rng.integers(0, height // bs)) * bs
+        kind = int(rng.integers(0, 3))
+        dx, dy = int(rng.integers(-8, 9)) * 2, int(rng.integers(-6, 7)) * 2
+        for (sv, rv, mx_, my_, sub) in views:
+            b, x0, y0 = bs // sub, bx // sub + mx_, by // sub + my_
+            if kind == 0:
+                sv[y0:y0 + b, x0:x0 + b] = rng.integers(pmax // 4, 3 * pmax // 4, (b, b))
+            else:
+                sv[y0:y0 + b, x0:x0 + b] = rv[y0 + dy // sub:y0 + dy // sub + b, x0 + dx // sub:x0 + dx // sub + b]
+    pics = pics[:3] + [recon, src]                  # refs 0..2, reconstruction, source
+    w4, h4, ctuW, ctuH = width // 4, height // 4, width // 64, height // 64
+    mp = mvpred_case(seed, width, height, is_b)
+    info = mp["info"].copy()
+    info["max_num_merge_cand"] = int(rng.integers(2, 6))
+    nref = info["num_ref_idx"]
+    base = cabac_case(seed, width, height, 0 if is_b else 1)
+    si = base["si"].copy()
+    si["slice_type"] = 0 if is_b else 1
+    si["tq_bypass_enabled"], si["use_dqp"], si["max_cu_dqp_depth"] = 0, 0, 0
+    si["tu_max_depth_inter"], si["max_num_merge_cand"], si["num_ref_idx"] = tu_inter_depth, info["max_num_merge_cand"], nref
+    si["slice_qp"] = int(rng.integers(24, 38))
+    si["max_amp_depth"] = 0
+    units = base["units"].copy()
+    units["tq_bypass"] = 0
+    units["qp"] = si["slice_qp"]
+    # a motion field that agrees with the unit map's prediction modes
+    cur = np.zeros((h4, w4), MV_UNIT_DT)
+    cur["ref_idx"] = -1
+    for by in range(0, h4, 2):
+        for bx in range(0, w4, 2):
+            pm = int(units["pred_mode"][by, bx])
+            sl = cur[by:by + 2, bx:bx + 2]
+            sl["pred_mode"] = units["pred_mode"][by:by + 2, bx:bx + 2]
+            if pm in (MODE_INTER, MODE_SKIP):
+                idir = int(rng.integers(1, 4)) if is_b else 1
+                sl["inter_dir"] = idir
+                for l in range(2):
+                    if idir & (1 << l):
+                        sl["ref_idx"][..., l] = int(rng.integers(0, nref[l]))
+                        sl["mv"][..., l, 0] = int(rng.integers(-10, 11)) * 2
+                        sl["mv"][..., l, 1] = int(rng.integers(-8, 9)) * 2
+                units["inter_dir"][by:by + 2, bx:bx + 2] = idir
+                units["ref_idx"][by:by + 2, bx:bx + 2] = sl["ref_idx"]
+    sp = np.zeros(1, SEARCH_PARAMS_DT)[0]
+    sp["searchMethod"], sp["subpelRefine"] = int(rng.choice([ME_HEX, ME_STAR])), int(rng.choice([1, 2, 3]))
+    sp["searchRange"], sp["qp"], sp["numPics"] = 57, int(si["slice_qp"]), len(pics)
+    sp["bChromaMC"] = 1
+    rp = np.zeros((2, 16), np.int32)
+    for l in range(2):
+        for r in range(16):
+            rp[l, r] = (r + l) % 3
+    sp["refPic"] = rp
+    ap = np.zeros(1, ANALYSIS_PARAMS_DT)
+    ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"] = psy_rd, 3, early_skip, rskip, 0, 0
+    # reference pictures' CU depths (two lists) and CTU QPs; running cost statistics of the CTUs coded so far
+    ref_depth = np.zeros((2, h4, w4), np.uint8)
+    for l in range(2):
+        for by in range(0, h4, 4):
+            for bx in range(0, w4, 4):
+                ref_depth[l, by:by + 4, bx:bx + 4] = int(rng.integers(0, 4))
+        for cy in range(ctuH):                       # some CTUs entirely at depth 0 / 1
+            for cx in range(ctuW):
+                if rng.integers(0, 4) == 0:
+                    ref_depth[l, cy * 16:cy * 16 + 16, cx * 16:cx * 16 + 16] = int(rng.integers(0, 2))
+    ref_qp0 = rng.integers(int(si["slice_qp"]) - 4, int(si["slice_qp"]) + 5, (2, ctuW * ctuH)).astype(np.int8)
+    stat = np.zeros(ctuW * ctuH + 1, CU_STAT_DT)
+    ctus = sorted(int(a) for a in rng.choice(np.arange(1, ctuW * ctuH), size=nctu, replace=False))
+    maps = []
+    ctx_pool = [entropy_reset_np(int(si["slice_type"]), q) for q in (26, 32)]
+    starts = []
+    for a in ctus:
+        u = units.copy(); m = cur.copy()
+        for addr in range(a, ctuW * ctuH):
+            cx, cy = (addr % ctuW) * 16, (addr // ctuW) * 16
+            u["pred_mode"][cy:cy + 16, cx:cx + 16] = MODE_NONE
+            m["pred_mode"][cy:cy + 16, cx:cx + 16] = MODE_NONE
+            m["ref_idx"][cy:cy + 16, cx:cx + 16] = -1
+        st = stat.copy()
+        for addr in range(a):
+            st[addr]["count"] = rng.integers(0, 6, 4)
+            st[addr]["avg_cost"] = rng.integers(2000, 60000, 4) * (st[addr]["count"] > 0)
+        ctx = ctx_pool[int(rng.integers(0, 2))].copy()
+        idx = rng.choice(CTX_COUNT, size=30, replace=False)
+        ctx[idx] = rng.integers(0, 126, size=30).astype(np.uint8)
+        maps.append((np.ascontiguousarray(u), np.ascontiguousarray(m), st))
+        starts.append((ctx, int(rng.integers(0, 32768))))
+    return dict(pics=pics, stride=stride, cstride=cstride, org=org, info=info, sp=sp, si=si, ap=ap, col=mp["col"], ref_depth=ref_depth, ref_qp0=ref_qp0,
+                ctus=ctus, maps=maps, starts=starts, width=width, height=height, depth=depth)
+
+
+def ctu_run_ref(R, c):
+    """Analysis::compressCTU for each listed CTU (independently, each on its own 'coded so far' state):
+    list of (result, units 16x16, motion 16x16, coeff, recon planes of the CTU, stats)"""
+    isz = c["pics"][0].itemsize
+    info = np.array([c["info"]], MVPRED_INFO_DT); sp = np.array([c["sp"]], SEARCH_PARAMS_DT); si = np.array([c["si"]], SLICE_INFO_DT)
+    out = []
+    for k, a in enumerate(c["ctus"]):
+        pics = [p.copy() for p in c["pics"]]
+        planes = np.array([p.ctypes.data + c["org"][j] * isz for p in pics for j in range(3)], np.uint64)
+        u, m, st = c["maps"][k]
+        st = st.copy()
+        ctx = np.zeros(160, np.uint8); ctx[:len(c["starts"][k][0])] = c["starts"][k][0]
+        uo = np.zeros((16, 16), CU_UNIT_DT); mo = np.zeros((16, 16), MV_UNIT_DT); coeff = np.zeros(RD_TILE, np.int16); res = np.zeros(1, CTU_RESULT_DT)
+        R.lib.ref_compress_ctu(_ptr(info), _ptr(sp), _ptr(si), _ptr(c["ap"]), _ptr(u), _ptr(m), _ptr(c["col"]), _ptr(c["ref_depth"]), _ptr(c["ref_qp0"]),
+                               _ptr(planes), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), MC_MX, MC_MY, _ptr(st), a, _ptr(ctx),
+                               C.c_uint64(c["starts"][k][1]), _ptr(uo), _ptr(mo), _ptr(coeff), _ptr(res))
+        out.append((res[0].copy(), uo, mo, coeff, ctu_recon(c, pics[-2], a), st))
+    return out
+
+
+def ctu_recon(c, recon_pic, addr):
+    """the three planes of CTU addr cut out of a flat padded picture"""
+    ctuW = c["width"] // 64
+    x, y = (addr % ctuW) * 64, (addr // ctuW) * 64
+    out = []
+    for p in range(3):
+        st = c["stride"] if p == 0 else c["cstride"]
+        s = 64 if p == 0 else 32
+        px, py = (x, y) if p == 0 else (x // 2, y // 2)
+        o = c["org"][p] + py * st + px
+        out.append(np.stack([recon_pic[o + r * st:o + r * st + s] for r in range(s)]))
+    return out
+
+
+def ctu_run_hip(L, me, c):
+    """x265amd_compress_ctu_inter for each listed CTU, each on its own 'coded so far' state; same return shape as ctu_run_ref"""
+    import torch
+    isz = c["pics"][0].itemsize
+    info = np.array([c["info"]], MVPRED_INFO_DT); si = np.array([c["si"]], SLICE_INFO_DT)
+    sp = np.zeros(1, INTER_SP_DT)
+    for a, b in (("search_method", "searchMethod"), ("subpel_refine", "subpelRefine"), ("search_range", "searchRange"), ("qp", "qp"), ("chroma_mc", "bChromaMC")):
+        sp[0][a] = c["sp"][b]
+    sp[0]["ref_pic"] = c["sp"]["refPic"]
+    out = []
+    w4 = c["width"] // 4
+    ctuW = c["width"] // 64
+    for k, a in enumerate(c["ctus"]):
+        d_pics = [torch.from_numpy(p.view(np.uint8)).cuda() for p in c["pics"]]
+        planes = np.array([d.data_ptr() + c["org"][j] * isz for d in d_pics for j in range(3)], np.uint64)
+        u, m, st = c["maps"][k]
+        u = u.copy(); m = m.copy(); st = st.copy()
+        ctx = np.zeros(160, np.uint8); ctx[:len(c["starts"][k][0])] = c["starts"][k][0]
+        coeff = np.zeros(RD_TILE, np.int16); res = np.zeros(1, CTU_RESULT_DT)
+        rc = L.lib.x265amd_compress_ctu_inter(me.ctx, None, _ptr(info), _ptr(sp), _ptr(si), _ptr(c["ap"]), _ptr(u), _ptr(m), _ptr(c["col"]), _ptr(c["ref_depth"]),
+                                              _ptr(c["ref_qp0"]), _ptr(planes), len(c["pics"]), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), _ptr(st), a, _ptr(ctx),
+                                              C.c_uint64(c["starts"][k][1]), _ptr(coeff), _ptr(res))
+        assert rc == 0, L.lib.x265amd_last_error()
+        cx, cy = (a % ctuW) * 16, (a // ctuW) * 16
+        recon_pic = d_pics[-2].cpu().numpy().view(c["pics"][0].dtype)
+        out.append((res[0].copy(), u[cy:cy + 16, cx:cx + 16].copy(), m.reshape(-1, w4)[cy:cy + 16, cx:cx + 16].copy(), coeff, ctu_recon(c, recon_pic, a), st))
+    return out
+
+
+def _ctu_first_fields(u, first):
+    """merge_flag, mvp_idx, mvd at the first unit of each CU, and only where the syntax codes them: the merge index (mvp_idx[0]) of merged
+    CUs, mvp_idx[l] / mvd[l] of the lists a non-merged CU uses (the reference leaves stale values elsewhere)"""
+    f = first.reshape(256) & (u["pred_mode"].reshape(256) != MODE_NONE)
+    mf = u["merge_flag"].reshape(256).astype(np.int16)
+    idir = u["inter_dir"].reshape(256).astype(np.int16)
+    cols = [mf * f]
+    for l in range(2):
+        used = f & (((mf == 0) & ((idir >> l) & 1 == 1)) | ((mf == 1) & (l == 0)))
+        cols.append(u["mvp_idx"].reshape(256, 2)[:, l].astype(np.int16) * used)
+    for l in range(2):
+        used = f & (mf == 0) & ((idir >> l) & 1 == 1)
+        for k in range(2):
+            cols.append(u["mvd"].reshape(256, 2, 2)[:, l, k].astype(np.int16) * used)
+    return np.stack(cols, 1)
+
+
+def ctu_pack(results):
+    """golden form of ctu_run_* results: only what the product is specified to reproduce (see x265amd_compress_ctu_inter)"""
+    out = []
+    for (r, u, m, coeff, rec, st) in results:
+        first = np.zeros((16, 16), bool)            # first unit of each CU
+        for y in range(16):
+            for x in range(16):
+                n = 16 >> int(u["depth"][y, x])
+                first[y, x] = (x % n == 0) and (y % n == 0)
+        d = dict(res=np.array([int(r["rd_cost"]), int(r["distortion"]), int(r["total_bits"]), int(r["frac_bits"])], np.uint64), ctx=r["ctx"][:CTX_COUNT].copy(),
+                 units=np.concatenate([u[f].astype(np.int16).reshape(256, -1) for f in ("depth", "pred_mode", "part_size", "tu_depth", "cbf", "inter_dir", "ref_idx", "qp")], 1),
+                 first=_ctu_first_fields(u, first),
+                 motion=np.concatenate([m[f].astype(np.int16).reshape(256, -1) for f in ("pred_mode", "inter_dir", "ref_idx", "mv")], 1),
+                 recon=np.concatenate([p.astype(np.uint16).ravel() for p in rec]),
+                 stat=np.concatenate([st["count"].astype(np.uint64).ravel(), st["avg_cost"].ravel()]))
+        # levels of coded blocks only: mask by the luma / chroma coded block flags at each unit's own transform depth
+        keep = np.zeros(RD_TILE, bool)
+        for y in range(16):
+            for x in range(16):
+                z = _zorder(x, y)
+                td = int(u["tu_depth"][y, x])
+                if (int(u["cbf"][y, x, 0]) >> td) & 1:
+                    keep[z * 16:z * 16 + 16] = True
+        d["coeff"] = (coeff[:4096] * keep[:4096]).astype(np.int16)
+        out.append(d)
+    return out

@@ -1,0 +1,46 @@
+"""CTU mode decision of inter slices (x265amd_compress_ctu_inter) against golden results of the reference's own
+Analysis::compressCTU run on CUData / Slice / Frame / MotionReference fixtures of the same pictures and maps
+(tests/golden/ctu_analysis_golden.npz, generated here from oracle/_ref by tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import hevc_testlib as T
+
+# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth)
+CASES = [(8, 1, 1, 1, 2.0, 1), (8, 2, 0, 1, 2.0, 2), (8, 3, 1, 0, 0.0, 1), (10, 4, 0, 1, 2.0, 1), (8, 5, 1, 1, 1.0, 3), (8, 6, 0, 0, 2.0, 1)]
+GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
+
+
+def make_case(k):
+    depth, seed, es, rs, psy, td = CASES[k]
+    return T.ctu_case(depth, seed, early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td)
+
+
+def test_golden_outcomes_are_varied():
+    gold = np.load(GOLD_PATH)
+    depths = np.zeros(4, np.int64); modes = np.zeros(4, np.int64); coded = 0
+    for k in range(len(CASES)):
+        for i in range(3):
+            u = gold["%d/%d/units" % (k, i)]
+            depths += np.bincount(u[:, 0], minlength=4); modes += np.bincount(u[:, 1], minlength=4); coded += int((u[:, 4:7] > 0).any(1).sum())
+    assert (depths[1:] > 100).all() and modes[1] > 500 and modes[3] > 500 and coded > 300, (depths, modes, coded)
+
+
+@pytest.mark.gpu
+def test_hip_compress_ctu_inter_matches_reference_golden():
+    gold = np.load(GOLD_PATH)
+    mes = {}
+    for k, (depth, seed, es, rs, psy, td) in enumerate(CASES):
+        if depth not in mes:
+            mes[depth] = T.HipME(depth)
+        c = make_case(k)
+        got = T.ctu_pack(T.ctu_run_hip(T.load_hip(depth), mes[depth], c))
+        for i, d in enumerate(got):
+            for name, a in d.items():
+                want = gold["%d/%d/%s" % (k, i, name)]
+                if not np.array_equal(a, want):
+                    bad = np.argwhere(np.asarray(a) != want)[:6].tolist()
+                    raise AssertionError("case %d CTU %d (addr %d): %s differs from the reference's result at %s: got %s want %s" % (
+                        k, i, c["ctus"][i], name, bad, np.asarray(a)[tuple(np.array(bad).T)].tolist(), want[tuple(np.array(bad).T)].tolist()))

@@ -1,0 +1,599 @@
+/* CTU mode decision of inter slices (include/x265amd.h: x265amd_compress_ctu_inter): SURVEY rows a1 / a2.
+ *
+ * Restatement of Analysis::compressCTU (reference: source/encoder/analysis.cpp:138-317) -> compressInterCU_rd0_4 (:1146-1848) at RD
+ * levels 3-4 with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N (:3145-3277), topSkipMinDepth
+ * (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426), checkBestMode (analysis.h:211-221), Mode::addSubCosts
+ * (search.h:145-159) and CUData::copyPartFrom / copyToPic.
+ *
+ * The recursion, the candidate order and every comparison are the reference's and run on the host; every block operation is one of
+ * the batch entry points of this library: x265amd_merge_candidates (host), x265amd_motion_compensation + x265amd_measure_tiles (merge
+ * candidates, bi-prediction tries, SA8D of finished predictions), x265amd_pred_inter_search_ex (the 2Nx2N search),
+ * x265amd_skip_rd / x265amd_inter_residual_rd (RD of the chosen candidates).  Each mode of each depth owns a prediction and a
+ * reconstruction tile in device memory; the best mode's units, motion and reconstruction are written into the picture maps / the
+ * reconstructed picture at the end of every CU, exactly when the reference's copyToPic does, so later neighbours see what the
+ * reference's would.
+ *
+ * Scope of this entry point: B slices without intra candidates (--no-b-intra), 2Nx2N partitions (no --rect / --amp), --limit-refs 0,
+ * no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.  P slices need the intra candidates (checkIntraInInter /
+ * encodeIntraInInter), which are not built yet: rejected.
+ */
+#include "x265amd_dev.h"
+#include "inter_common.h"
+#include "../host/cabac_coder.h"
+#include <string.h>
+#include <vector>
+
+using namespace xa_inter;
+
+namespace {
+
+#if X265AMD_DEPTH < 10
+typedef uint32_t sse_t;
+#else
+typedef uint64_t sse_t;
+#endif
+
+enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_SPLIT, NUM_PRED };
+const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
+const int kTileElems = 4096 + 2048;
+
+struct Snap { uint8_t ctx[X265AMD_CTX_STRIDE]; uint64_t frac; };
+
+struct Mode
+{
+    x265amd_cu_unit u[256];         /* the CU's units, raster with row length size/4 */
+    x265amd_mv_unit m[256];
+    std::vector<int16_t> coeff;     /* CUData::m_trCoeff layout */
+    Snap contexts;
+    uint64_t rdCost, sa8dCost;
+    uint32_t sa8dBits, psyEnergy, totalBits, mvBits, coeffBits;
+    sse_t resEnergy, lumaDistortion, chromaDistortion, distortion;
+    int predTile, reconTile;        /* tile indices in the device arena */
+    Mode() : coeff(kTileElems, 0) { initCosts(); }
+    void initCosts()
+    {
+        rdCost = 0; sa8dCost = 0; sa8dBits = 0; psyEnergy = 0; resEnergy = 0; lumaDistortion = 0; chromaDistortion = 0; distortion = 0;
+        totalBits = 0; mvBits = 0; coeffBits = 0;
+    }
+    void addSubCosts(const Mode& s)
+    {
+        rdCost += s.rdCost; sa8dCost += s.sa8dCost; sa8dBits += s.sa8dBits; psyEnergy += s.psyEnergy; resEnergy += s.resEnergy;
+        lumaDistortion += s.lumaDistortion; chromaDistortion += s.chromaDistortion; distortion += s.distortion;
+        totalBits += s.totalBits; mvBits += s.mvBits; coeffBits += s.coeffBits;
+    }
+    bool isSkipped() const { return u[0].pred_mode == X265AMD_MODE_SKIP; }
+};
+
+struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; };
+
+struct DevBuf
+{
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+struct Analyzer
+{
+    x265amd_me_ctx* me; hipStream_t st;
+    const x265amd_mvpred_info* I; const x265amd_inter_search_params* S; const x265amd_slice_info* si; const x265amd_analysis_params* A;
+    x265amd_cu_unit* units; x265amd_mv_unit* cur; const x265amd_mv_unit* col;
+    const uint8_t* refDepth; const int8_t* refQp0;
+    const uint64_t* planes; int numPics; intptr_t stride, cstride;
+    x265amd_cu_stat* cuStat; int ctuAddr, ctuX, ctuY, ctuW, w4, h4, qp;
+    ModeDepth md[4];
+    DevBuf dTiles, dPlanes, dJobs;
+    size_t tileBytes;
+    uint64_t lambda2, lambda; uint32_t psyRd;
+    x265amd_rd_params rp;
+    int err;
+
+    uint64_t tileAddr(int t) const { return (uint64_t)(uintptr_t)dTiles.p + (size_t)t * tileBytes; }
+    /* tiles: per depth NUM_PRED prediction + NUM_PRED reconstruction tiles, then 5 merge-candidate tiles + 1 scratch tile per depth */
+    int predTile(int depth, int k) const { return depth * (2 * NUM_PRED + 6) + k; }
+    int reconTile(int depth, int k) const { return depth * (2 * NUM_PRED + 6) + NUM_PRED + k; }
+    int candTile(int depth, int k) const { return depth * (2 * NUM_PRED + 6) + 2 * NUM_PRED + k; }
+
+    uint64_t calcRdCost(sse_t d, uint32_t b) const { return d + (((uint64_t)b * lambda2 + 128) >> 8); }
+    uint64_t calcPsyRdCost(sse_t d, uint32_t b, uint32_t e) const { return d + ((lambda * psyRd * e) >> 24) + (((uint64_t)b * lambda2) >> 8); }
+    uint64_t calcRdSADCost(uint32_t d, uint32_t b) const { return d + (((uint64_t)b * lambda + 128) >> 8); }
+    uint32_t getCost(uint32_t b) const { return (uint32_t)(((uint64_t)b * lambda + 128) >> 8); }
+    void updateModeCost(Mode& m) const { m.rdCost = psyRd ? calcPsyRdCost(m.distortion, m.totalBits, m.psyEnergy) : calcRdCost(m.distortion, m.totalBits); }
+
+    int fail(const char* msg) { if (!err) err = xa_fail(X265AMD_EHIP, msg); return err; }
+
+    /* ---- block operations ---- */
+    x265amd_mc_job mcJob(int x, int y, int size, int tile, int dir, const int8_t ref[2], const int16_t mv[2][2])
+    {
+        x265amd_mc_job j;
+        memset(&j, 0, sizeof(j));
+        const size_t isz = sizeof(pixel);
+        j.dst_y = tileAddr(tile); j.dst_u = j.dst_y + 4096 * isz; j.dst_v = j.dst_u + 1024 * isz;
+        j.dst_stride = 64; j.dst_cstride = 32;
+        j.x = (int16_t)x; j.y = (int16_t)y; j.cu_x = (int16_t)x; j.cu_y = (int16_t)y; j.w = (uint8_t)size; j.h = (uint8_t)size;
+        j.ref0 = (dir & 1) && ref[0] >= 0 ? (int8_t)S->ref_pic[0][ref[0]] : -1;
+        j.ref1 = (dir & 2) && ref[1] >= 0 ? (int8_t)S->ref_pic[1][ref[1]] : -1;
+        j.mv0[0] = mv[0][0]; j.mv0[1] = mv[0][1]; j.mv1[0] = mv[1][0]; j.mv1[1] = mv[1][1];
+        j.slice_type = (uint8_t)!I->is_inter_b; j.flags = 3;
+        return j;
+    }
+    /* motionCompensation(luma + chroma) of the jobs into their tiles, then sa8d / sse / psy of each tile against the source */
+    int predictAndMeasure(std::vector<x265amd_mc_job>& jobs, int x, int y, int log2, const int* tiles, x265amd_cu_measure* meas)
+    {
+        const int n = (int)jobs.size();
+        if (hipMemcpyAsync(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * n, hipMemcpyHostToDevice, st) != hipSuccess) return fail("ctu analysis: job upload");
+        if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, n) != X265AMD_OK)
+            return err = X265AMD_EHIP;
+        for (int k = 0; k < n; k++)
+        {
+            x265amd_rd_cu c;
+            memset(&c, 0, sizeof(c));
+            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2;
+            if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &c, 1, tileAddr(tiles[k]), tileBytes, meas + k) != X265AMD_OK) return err = X265AMD_EHIP;
+        }
+        return 0;
+    }
+    void copyTile(int dst, int src, int dx, int dy, int size)       /* src tile (size x size at its origin) -> dst tile at (dx, dy) */
+    {
+        const size_t isz = sizeof(pixel);
+        const uint64_t d = tileAddr(dst), s = tileAddr(src);
+        (void)hipMemcpy2DAsync((void*)(uintptr_t)(d + ((size_t)dy * 64 + dx) * isz), 64 * isz, (const void*)(uintptr_t)s, 64 * isz, size * isz, size, hipMemcpyDeviceToDevice, st);
+        for (int p = 0; p < 2; p++)
+            (void)hipMemcpy2DAsync((void*)(uintptr_t)(d + (4096 + p * 1024 + (size_t)(dy / 2) * 32 + dx / 2) * isz), 32 * isz,
+                                   (const void*)(uintptr_t)(s + (4096 + p * 1024) * isz), 32 * isz, size / 2 * isz, size / 2, hipMemcpyDeviceToDevice, st);
+    }
+    void tileToPicture(int tile, int x, int y, int size)
+    {
+        const size_t isz = sizeof(pixel);
+        const int w = size < I->pic_width - x ? size : I->pic_width - x, h = size < I->pic_height - y ? size : I->pic_height - y;
+        const uint64_t* rec = planes + 3 * (numPics - 2);
+        const uint64_t s = tileAddr(tile);
+        (void)hipMemcpy2DAsync((void*)(uintptr_t)(rec[0] + ((size_t)y * stride + x) * isz), stride * isz, (const void*)(uintptr_t)s, 64 * isz, w * isz, h, hipMemcpyDeviceToDevice, st);
+        for (int p = 0; p < 2; p++)
+            (void)hipMemcpy2DAsync((void*)(uintptr_t)(rec[1 + p] + ((size_t)(y / 2) * cstride + x / 2) * isz), cstride * isz,
+                                   (const void*)(uintptr_t)(s + (4096 + p * 1024) * isz), 32 * isz, w / 2 * isz, h / 2, hipMemcpyDeviceToDevice, st);
+    }
+
+    /* ---- CU bookkeeping ---- */
+    void initSubCU(Mode& m, int depth)          /* CUData::initSubCU: a clean inter-less CU of this depth and QP */
+    {
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++)
+        {
+            memset(&m.u[i], 0, sizeof(x265amd_cu_unit));
+            memset(&m.m[i], 0, sizeof(x265amd_mv_unit));
+            m.u[i].depth = (uint8_t)depth; m.u[i].qp = (int8_t)qp; m.u[i].ref_idx[0] = m.u[i].ref_idx[1] = -1;
+            m.m[i].ref_idx[0] = m.m[i].ref_idx[1] = -1;
+        }
+    }
+    void setInter(Mode& m, int depth, int mergeFlag, int mergeIdx, int dir, const int8_t ref[2], const int16_t mv[2][2], const int16_t mvd[2][2], const uint8_t mvpIdx[2])
+    {
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++)
+        {
+            x265amd_cu_unit& u = m.u[i];
+            u.pred_mode = X265AMD_MODE_INTER; u.part_size = 0; u.merge_flag = (uint8_t)mergeFlag; u.inter_dir = (uint8_t)dir;
+            for (int l = 0; l < 2; l++)
+            {
+                u.ref_idx[l] = (dir & (1 << l)) ? ref[l] : -1;
+                u.mvp_idx[l] = mergeFlag ? (l ? 0 : (uint8_t)mergeIdx) : mvpIdx[l];
+                u.mvd[l][0] = mergeFlag ? 0 : mvd[l][0]; u.mvd[l][1] = mergeFlag ? 0 : mvd[l][1];
+            }
+            x265amd_mv_unit& v = m.m[i];
+            v.pred_mode = X265AMD_MODE_INTER; v.inter_dir = (uint8_t)dir;
+            for (int l = 0; l < 2; l++)
+            {
+                v.ref_idx[l] = (dir & (1 << l)) ? ref[l] : -1;
+                v.mv[l][0] = (dir & (1 << l)) ? mv[l][0] : 0; v.mv[l][1] = (dir & (1 << l)) ? mv[l][1] : 0;
+            }
+        }
+    }
+    void toPicture(const Mode& m, int x, int y, int depth)      /* CUData::copyToPic */
+    {
+        const int n4 = 16 >> depth;
+        for (int yy = 0; yy < n4; yy++)
+            for (int xx = 0; xx < n4; xx++)
+            {
+                if (x + xx * 4 >= I->pic_width || y + yy * 4 >= I->pic_height) continue;
+                units[((y >> 2) + yy) * w4 + (x >> 2) + xx] = m.u[yy * n4 + xx];
+                x265amd_mv_unit v = m.m[yy * n4 + xx];
+                v.pred_mode = m.u[yy * n4 + xx].pred_mode;
+                cur[((y >> 2) + yy) * w4 + (x >> 2) + xx] = v;
+            }
+    }
+
+    /* RD of one candidate through the batch entry points (n = 1) */
+    int rdInter(Mode& m, int x, int y, int depth, bool skipOnly)
+    {
+        x265amd_rd_cu c;
+        memset(&c, 0, sizeof(c));
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
+        memcpy(c.ctx, md[depth].cur.ctx, X265AMD_CTX_COUNT);
+        c.frac_bits = md[depth].cur.frac;
+        x265amd_rd_result r;
+        /* the batch entry points take 256 records per CU in raster order with row length size/4: Mode::u is laid out like that */
+        int rc;
+        if (skipOnly)
+            rc = x265amd_skip_rd(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, 1, m.u, tileAddr(m.predTile), tileAddr(m.reconTile), tileBytes, &r);
+        else
+            rc = x265amd_inter_residual_rd(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, 1, m.u, tileAddr(m.predTile), tileAddr(m.reconTile), tileBytes,
+                                           &r, m.coeff.data());
+        if (rc != X265AMD_OK) return err = rc;
+        if (skipOnly) std::fill(m.coeff.begin(), m.coeff.end(), 0);
+        m.rdCost = r.rd_cost; m.distortion = (sse_t)r.distortion; m.totalBits = r.total_bits; m.mvBits = r.mv_bits; m.coeffBits = r.coeff_bits;
+        m.psyEnergy = r.psy_energy; m.lumaDistortion = r.luma_distortion; m.chromaDistortion = r.chroma_distortion; m.resEnergy = r.res_energy;
+        memcpy(m.contexts.ctx, r.ctx, X265AMD_CTX_STRIDE);
+        m.contexts.frac = r.frac_bits;
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++) m.m[i].pred_mode = m.u[i].pred_mode;
+        return 0;
+    }
+
+    /* ---- Analysis helpers ---- */
+    uint32_t topSkipMinDepth(int x, int y, int depth)
+    {
+        const int currentQP = qp;
+        int previousQP = currentQP;
+        uint32_t minDepth0 = 4, minDepth1 = 4, sum = 0;
+        int numRefs = 0;
+        const int size = 64 >> depth;
+        for (int l = 0; l < 2; l++)
+        {
+            if (!I->num_ref_idx[l]) continue;
+            numRefs++;
+            const uint8_t* map = refDepth + (size_t)l * w4 * h4;
+            if (l == 0) previousQP = refQp0[ctuAddr];
+            if (!map[(y >> 2) * w4 + (x >> 2)]) return 0;
+            uint32_t& mn = l ? minDepth1 : minDepth0;
+            for (int yy = y; yy < y + size; yy += 8)
+                for (int xx = x; xx < x + size; xx += 8)
+                {
+                    const uint32_t d = (xx < I->pic_width && yy < I->pic_height) ? map[(yy >> 2) * w4 + (xx >> 2)] : 0;
+                    mn = d < mn ? d : mn;
+                    sum += d;
+                }
+        }
+        if (!numRefs) return 0;
+        uint32_t minDepth = minDepth0 < minDepth1 ? minDepth0 : minDepth1;
+        const uint32_t thresh = minDepth * numRefs * ((uint32_t)(size >> 2) * (size >> 2) >> 2);
+        if (minDepth && currentQP >= previousQP && (sum <= thresh + (thresh >> 1))) minDepth -= 1;
+        return minDepth;
+    }
+    bool recursionDepthCheck(int depth, const Mode& best)
+    {
+        const x265amd_cu_stat& cs = cuStat[ctuAddr];
+        const uint64_t cuCost = cs.avg_cost[depth] * cs.count[depth], cuCount = cs.count[depth];
+        uint64_t neighCost = 0, neighCount = 0;
+        const int cx = ctuAddr % ctuW;
+        const bool above = ctuAddr >= ctuW, left = cx > 0;
+        auto add = [&](int addr) { neighCost += cuStat[addr].avg_cost[depth] * cuStat[addr].count[depth]; neighCount += cuStat[addr].count[depth]; };
+        if (above)
+        {
+            add(ctuAddr - ctuW);
+            if (left) add(ctuAddr - ctuW - 1);
+            if (cx < ctuW - 1) add(ctuAddr - ctuW + 1);
+        }
+        if (left) add(ctuAddr - 1);
+        if (neighCount + cuCount)
+        {
+            const uint64_t avgCost = ((3 * cuCost) + (2 * neighCost)) / ((3 * cuCount) + (2 * neighCount));
+            if (best.rdCost < avgCost && avgCost) return true;
+        }
+        return false;
+    }
+    void addSplitFlagCost(Mode& m, int x, int y, int depth)
+    {
+        const x265amd_cu_unit* l = (x >> 2) > 0 ? &units[(y >> 2) * w4 + (x >> 2) - 1] : nullptr;
+        const x265amd_cu_unit* a = (y >> 2) > 0 ? &units[((y >> 2) - 1) * w4 + (x >> 2)] : nullptr;
+        const int c = (l && l->pred_mode != X265AMD_MODE_NONE && l->depth > depth) + (a && a->pred_mode != X265AMD_MODE_NONE && a->depth > depth);
+        const uint32_t flag = m.u[0].depth > depth;
+        m.contexts.frac &= 32767;
+        const uint8_t state = m.contexts.ctx[C_SPLIT + c];
+        m.contexts.frac += k_bits[state ^ flag];
+        m.contexts.ctx[C_SPLIT + c] = ctxNext(state, flag);
+        m.totalBits += (uint32_t)(m.contexts.frac >> 15);
+        updateModeCost(m);
+    }
+    void checkBestMode(Mode& m, int depth)
+    {
+        if (md[depth].best) { if (m.rdCost < md[depth].best->rdCost) md[depth].best = &m; }
+        else md[depth].best = &m;
+    }
+
+    /* checkMerge2Nx2N_rd0_4 */
+    int checkMerge(int x, int y, int depth)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        Mode* tempPred = &d.pred[PRED_MERGE];
+        Mode* bestPred = &d.pred[PRED_SKIP];
+        tempPred->initCosts(); bestPred->initCosts();
+        x265amd_merge_cand cand[5];
+        const int numCand = x265amd_merge_candidates(I, cur, col, x, y, log2, 0, 0, cand);
+        if (numCand <= 0) return 0;
+        std::vector<x265amd_mc_job> jobs;
+        int tiles[5];
+        for (int i = 0; i < numCand; i++)
+        {
+            tiles[i] = candTile(depth, i);
+            jobs.push_back(mcJob(x, y, size, tiles[i], cand[i].dir, cand[i].ref_idx, cand[i].mv));
+        }
+        x265amd_cu_measure meas[5];
+        if (predictAndMeasure(jobs, x, y, log2, tiles, meas)) return err;
+        uint64_t bestCost = kMaxCost; uint32_t bestBits = 0;
+        int bestSadCand = -1;
+        for (int i = 0; i < numCand; i++)
+        {
+            const uint32_t bits = (uint32_t)(i + (i < numCand - 1));          /* getTUBits */
+            const uint64_t c = calcRdSADCost(meas[i].sa8d, bits);
+            if (c < bestCost) { bestCost = c; bestBits = bits; bestSadCand = i; }
+        }
+        if (bestSadCand < 0) return 0;
+        const x265amd_merge_cand& b = cand[bestSadCand];
+        const int16_t zero[2][2] = { { 0, 0 }, { 0, 0 } };
+        const uint8_t noIdx[2] = { 0, 0 };
+        for (Mode* m : { bestPred, tempPred })
+        {
+            setInter(*m, depth, 1, bestSadCand, b.dir, b.ref_idx, b.mv, zero, noIdx);
+            m->sa8dCost = bestCost; m->sa8dBits = bestBits;
+            m->predTile = tiles[bestSadCand];
+        }
+        bestPred->reconTile = reconTile(depth, PRED_SKIP);
+        tempPred->reconTile = reconTile(depth, PRED_MERGE);
+        if (rdInter(*bestPred, x, y, depth, true)) return err;
+        if (rdInter(*tempPred, x, y, depth, false)) return err;
+        d.best = tempPred->rdCost < bestPred->rdCost ? tempPred : bestPred;
+        /* the winner keeps the candidate's prediction: move it out of the candidate tiles, which the next merge scan reuses */
+        const int keep = predTile(depth, d.best == tempPred ? PRED_MERGE : PRED_SKIP);
+        copyTile(keep, tiles[bestSadCand], 0, 0, size);
+        d.best->predTile = keep;
+        return 0;
+    }
+
+    /* checkInter_rd0_4(2Nx2N) + checkBidir2Nx2N */
+    int checkInter(int x, int y, int depth)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        Mode& inter = d.pred[PRED_2Nx2N];
+        Mode& bidir = d.pred[PRED_BIDIR];
+        inter.initCosts();
+        inter.predTile = predTile(depth, PRED_2Nx2N); inter.reconTile = reconTile(depth, PRED_2Nx2N);
+        x265amd_inter_cu c;
+        memset(&c, 0, sizeof(c));
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.part_size = 0;
+        x265amd_pu_result pu[2];
+        int32_t bits = 0;
+        x265amd_me_detail det;
+        x265amd_inter_search_params sp = *S;
+        sp.qp = qp; sp.chroma_mc = 1;
+        int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(inter.predTile), tileBytes, &det);
+        if (rc != X265AMD_OK) return err = rc;
+        setInter(inter, depth, pu[0].merge_flag, pu[0].mvp_idx[0], pu[0].inter_dir, pu[0].ref_idx, pu[0].mv, pu[0].mvd, pu[0].mvp_idx);
+        x265amd_rd_cu rc1;
+        memset(&rc1, 0, sizeof(rc1));
+        rc1.x = (int16_t)x; rc1.y = (int16_t)y; rc1.log2_size = (uint8_t)log2;
+        x265amd_cu_measure ms;
+        if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &rc1, 1, tileAddr(inter.predTile), tileBytes, &ms) != X265AMD_OK) return err = X265AMD_EHIP;
+        inter.sa8dBits = (uint32_t)bits;
+        inter.distortion = ms.sa8d;
+        inter.sa8dCost = calcRdSADCost(ms.sa8d, inter.sa8dBits);
+
+        bidir.initCosts();
+        bidir.sa8dCost = kMaxCost; bidir.rdCost = kMaxCost;
+        if (!I->is_inter_b || det.cost[0] == 0xFFFFFFFFu || det.cost[1] == 0xFFFFFFFFu) return 0;
+        bidir.predTile = predTile(depth, PRED_BIDIR); bidir.reconTile = reconTile(depth, PRED_BIDIR);
+        const int8_t refs[2] = { det.ref[0], det.ref[1] };
+        int16_t mv[2][2] = { { det.mv[0][0], det.mv[0][1] }, { det.mv[1][0], det.mv[1][1] } };
+        Mv mvp[2] = { Mv{ det.mvp[0][0], det.mvp[0][1] }, Mv{ det.mvp[1][0], det.mvp[1][1] } };
+        int mvpIdx[2] = { det.mvp_idx[0], det.mvp_idx[1] };
+        const Mv best[2] = { Mv{ mv[0][0], mv[0][1] }, Mv{ mv[1][0], mv[1][1] } };
+        bool bTryZero = best[0].x || best[0].y || best[1].x || best[1].y;
+        if (bTryZero)
+        {
+            Mv mn, mx;
+            search_range(Mv{ 0, 0 }, I->pic_width > I->pic_height ? I->pic_width : I->pic_height, x, y, I->pic_width, I->pic_height, mn, mx);
+            mx.y += 2;
+            mn.x <<= 2; mn.y <<= 2; mx.x <<= 2; mx.y <<= 2;
+            for (int l = 0; l < 2; l++) bTryZero &= mvp[l].x >= mn.x && mvp[l].x <= mx.x && mvp[l].y >= mn.y && mvp[l].y <= mx.y;
+        }
+        std::vector<x265amd_mc_job> jobs;
+        int tiles[2] = { bidir.predTile, candTile(depth, 5) };
+        const int16_t zeroMv[2][2] = { { 0, 0 }, { 0, 0 } };
+        jobs.push_back(mcJob(x, y, size, tiles[0], 3, refs, mv));
+        if (bTryZero) jobs.push_back(mcJob(x, y, size, tiles[1], 3, refs, zeroMv));
+        x265amd_cu_measure meas[2];
+        if (predictAndMeasure(jobs, x, y, log2, tiles, meas)) return err;
+        const uint32_t* ls = det.list_sel_bits;
+        bidir.sa8dBits = det.bits[0] + det.bits[1] + ls[2] - (ls[0] + ls[1]);
+        bidir.sa8dCost = (uint64_t)meas[0].sa8d + getCost(bidir.sa8dBits);
+        bool zeroWins = false;
+        if (bTryZero)
+        {
+            const Mv zero{ 0, 0 };
+            uint32_t bits0 = det.bits[0] - is_bitcost(best[0], mvp[0]) + is_bitcost(zero, mvp[0]);
+            uint32_t bits1 = det.bits[1] - is_bitcost(best[1], mvp[1]) + is_bitcost(zero, mvp[1]);
+            for (int l = 0; l < 2; l++)             /* checkBestMVP (search.cpp:2702-2713): only the bits and the predictor matter here */
+            {
+                const Mv am[2] = { Mv{ det.amvp[l][0][0], det.amvp[l][0][1] }, Mv{ det.amvp[l][1][0], det.amvp[l][1][1] } };
+                uint32_t& b = l ? bits1 : bits0;
+                const int diffBits = (int)is_bitcost(zero, am[!mvpIdx[l]]) - (int)is_bitcost(zero, am[mvpIdx[l]]);
+                if (diffBits < 0) { mvpIdx[l] = !mvpIdx[l]; b = b + diffBits; }
+                mvp[l] = am[mvpIdx[l]];
+            }
+            const uint32_t zbits = bits0 + bits1 + ls[2] - (ls[0] + ls[1]);
+            const uint32_t zcost = meas[1].sa8d + getCost(zbits);
+            if (zcost < bidir.sa8dCost)
+            {
+                bidir.sa8dBits = zbits; bidir.sa8dCost = zcost;
+                mv[0][0] = mv[0][1] = mv[1][0] = mv[1][1] = 0;
+                copyTile(bidir.predTile, tiles[1], 0, 0, size);
+                zeroWins = true;
+            }
+        }
+        if (!zeroWins) { mvp[0] = Mv{ det.mvp[0][0], det.mvp[0][1] }; mvp[1] = Mv{ det.mvp[1][0], det.mvp[1][1] }; mvpIdx[0] = det.mvp_idx[0]; mvpIdx[1] = det.mvp_idx[1]; }
+        int16_t mvd[2][2]; uint8_t idx[2];
+        for (int l = 0; l < 2; l++) { mvd[l][0] = (int16_t)(mv[l][0] - mvp[l].x); mvd[l][1] = (int16_t)(mv[l][1] - mvp[l].y); idx[l] = (uint8_t)mvpIdx[l]; }
+        setInter(bidir, depth, 0, 0, 3, refs, mv, mvd, idx);
+        return 0;
+    }
+
+    /* compressInterCU_rd0_4 */
+    int compress(int x, int y, int depth)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        d.best = nullptr;
+        const bool mightSplit = depth < si->max_cu_depth;
+        const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
+        const uint32_t minDepth = topSkipMinDepth(x, y, depth);
+        bool skipModes = false, skipRecursion = false;
+        for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
+
+        /* Step 1: merge / skip candidates */
+        if (mightNotSplit && (uint32_t)depth >= minDepth)
+        {
+            if (checkMerge(x, y, depth)) return err;
+            skipModes = A->early_skip && d.best && d.best->isSkipped();
+        }
+        if (d.best && A->rskip)
+        {
+            skipRecursion = d.best->isSkipped();
+            if (mightSplit && !skipRecursion && (uint32_t)depth >= minDepth && A->rskip == 1 && depth)
+                skipRecursion = recursionDepthCheck(depth, *d.best);
+        }
+        /* Step 2: the four sub-blocks in series */
+        if (mightSplit && !skipRecursion)
+        {
+            Mode& split = d.pred[PRED_SPLIT];
+            split.initCosts();
+            split.predTile = predTile(depth, PRED_SPLIT); split.reconTile = reconTile(depth, PRED_SPLIT);
+            const int n4 = 16 >> depth, half = size >> 1, h4n = n4 >> 1;
+            const Snap* nextContext = &d.cur;
+            for (int q = 0; q < 4; q++)
+            {
+                const int cx = x + (q & 1) * half, cy = y + (q >> 1) * half;
+                if (cx < I->pic_width && cy < I->pic_height)
+                {
+                    md[depth + 1].cur = *nextContext;
+                    if (compress(cx, cy, depth + 1)) return err;
+                    const Mode& nb = *md[depth + 1].best;
+                    for (int yy = 0; yy < h4n; yy++)
+                        for (int xx = 0; xx < h4n; xx++)
+                        {
+                            split.u[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.u[yy * h4n + xx];
+                            split.m[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.m[yy * h4n + xx];
+                        }
+                    split.addSubCosts(nb);
+                    copyTile(split.reconTile, nb.reconTile, (q & 1) * half, (q >> 1) * half, half);
+                    const int nc = half * half;
+                    memcpy(&split.coeff[(size_t)q * nc], nb.coeff.data(), sizeof(int16_t) * nc);
+                    memcpy(&split.coeff[4096 + (size_t)q * nc / 4], nb.coeff.data() + 4096, sizeof(int16_t) * nc / 4);
+                    memcpy(&split.coeff[5120 + (size_t)q * nc / 4], nb.coeff.data() + 5120, sizeof(int16_t) * nc / 4);
+                    nextContext = &nb.contexts;
+                }
+                else
+                    for (int yy = 0; yy < h4n; yy++)            /* setEmptyPart */
+                        for (int xx = 0; xx < h4n; xx++) split.u[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx].depth = (uint8_t)(depth + 1);
+            }
+            split.contexts = *nextContext;
+            if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
+            else updateModeCost(split);
+        }
+        /* Step 3: ME and RD at the current depth */
+        if (mightNotSplit && (uint32_t)depth >= minDepth)
+        {
+            if (!skipModes)
+            {
+                if (checkInter(x, y, depth)) return err;
+                Mode* bestInter = &d.pred[PRED_2Nx2N];
+                Mode& bidir = d.pred[PRED_BIDIR];
+                if (rdInter(*bestInter, x, y, depth, false)) return err;
+                checkBestMode(*bestInter, depth);
+                if (I->is_inter_b && bidir.sa8dCost != kMaxCost && bidir.sa8dCost * 16 <= bestInter->sa8dCost * 17)
+                {
+                    if (rdInter(bidir, x, y, depth, false)) return err;
+                    checkBestMode(bidir, depth);
+                }
+            }
+            if (mightSplit) addSplitFlagCost(*d.best, x, y, depth);
+        }
+        if (mightSplit && !skipRecursion)
+        {
+            Mode& split = d.pred[PRED_SPLIT];
+            if (!d.best) d.best = &split;
+            else checkBestMode(split, depth);
+        }
+        if (mightNotSplit && d.best->isSkipped())
+        {
+            x265amd_cu_stat& cs = cuStat[ctuAddr];
+            const uint64_t temp = cs.avg_cost[depth] * cs.count[depth];
+            cs.count[depth] += 1;
+            cs.avg_cost[depth] = (temp + d.best->rdCost) / cs.count[depth];
+        }
+        toPicture(*d.best, x, y, depth);
+        tileToPicture(d.best->reconTile, x, y, size);
+        return 0;
+    }
+};
+
+} // namespace
+
+extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                                          const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                                          const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                                          intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
+                                          int16_t* coeff_out, x265amd_ctu_result* out)
+{
+    if (!me || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 3)
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
+    if (!I->is_inter_b || A->b_intra) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: intra candidates in inter slices are not built (B slices with b_intra = 0 only)");
+    if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, 2Nx2N only, limit-refs 0, no delta QP, rskip 0/1)");
+    if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
+    Analyzer* an = new Analyzer;
+    Analyzer& a = *an;
+    a.me = me; a.st = (hipStream_t)stream; a.I = I; a.S = S; a.si = si; a.A = A; a.units = units; a.cur = cur; a.col = col;
+    a.refDepth = ref_depth; a.refQp0 = ref_qp0; a.planes = h_planes; a.numPics = num_pics; a.stride = stride; a.cstride = cstride;
+    a.cuStat = cu_stat; a.ctuAddr = ctu_addr; a.ctuW = (I->pic_width + 63) >> 6; a.w4 = I->pic_width >> 2; a.h4 = I->pic_height >> 2;
+    a.ctuX = (ctu_addr % a.ctuW) * 64; a.ctuY = (ctu_addr / a.ctuW) * 64; a.qp = si->slice_qp; a.err = 0;
+    int rc = X265AMD_OK;
+    if (a.ctuX >= I->pic_width || a.ctuY >= I->pic_height || ctu_addr < 0) rc = xa_fail(X265AMD_EINVAL, "compress_ctu_inter: CTU address");
+    a.tileBytes = (size_t)kTileElems * sizeof(pixel);
+    if (rc == X265AMD_OK && (a.dTiles.alloc(a.tileBytes * 4 * (2 * NUM_PRED + 6)) != hipSuccess || a.dPlanes.alloc((size_t)num_pics * 24) != hipSuccess ||
+                             a.dJobs.alloc(sizeof(x265amd_mc_job) * 8) != hipSuccess))
+        rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: out of device memory");
+    if (rc == X265AMD_OK && hipMemcpyAsync(a.dPlanes.p, h_planes, (size_t)num_pics * 24, hipMemcpyHostToDevice, a.st) != hipSuccess)
+        rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: plane table upload");
+    if (rc == X265AMD_OK)
+    {
+        uint64_t rd[6];
+        x265amd_rdcost(a.qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
+        a.lambda2 = rd[0]; a.lambda = rd[1]; a.psyRd = (uint32_t)rd[2];
+        a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.reserved = 0;
+        /* CUData::initCTU: nothing of this CTU is decided yet */
+        for (int yy = a.ctuY >> 2; yy < (a.ctuY >> 2) + 16 && yy < a.h4; yy++)
+            for (int xx = a.ctuX >> 2; xx < (a.ctuX >> 2) + 16 && xx < a.w4; xx++)
+            {
+                memset(&units[yy * a.w4 + xx], 0, sizeof(x265amd_cu_unit));
+                units[yy * a.w4 + xx].qp = (int8_t)a.qp;
+                memset(&cur[yy * a.w4 + xx], 0, sizeof(x265amd_mv_unit));
+                cur[yy * a.w4 + xx].ref_idx[0] = cur[yy * a.w4 + xx].ref_idx[1] = -1;
+            }
+        memset(&a.md[0].cur, 0, sizeof(Snap));
+        memcpy(a.md[0].cur.ctx, ctx_in, X265AMD_CTX_COUNT);
+        a.md[0].cur.frac = frac_in;
+        rc = a.compress(a.ctuX, a.ctuY, 0);
+        if (rc == X265AMD_OK && hipStreamSynchronize(a.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
+    }
+    if (rc == X265AMD_OK)
+    {
+        const Mode& b = *a.md[0].best;
+        memset(out, 0, sizeof(*out));
+        out->rd_cost = b.rdCost; out->distortion = b.distortion; out->total_bits = b.totalBits; out->frac_bits = b.contexts.frac;
+        memcpy(out->ctx, b.contexts.ctx, X265AMD_CTX_COUNT);
+        if (coeff_out) memcpy(coeff_out, b.coeff.data(), sizeof(int16_t) * kTileElems);
+    }
+    delete an;
+    return rc;
+}

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int
     const uint8_t* sel = reinterpret_cast<const uint8_t*>(j.sel);
     const int16_t* resi = reinterpret_cast<const int16_t*>(j.resi);
     CuMeasure m;
-    m.psy = 0; m.reserved = 0;
+    m.psy = 0; m.sa8d = 0;
     for (int plane = 0; plane < 3; plane++)
     {
         const int log2S = plane ? j.log2_size - 1 : j.log2_size, s = 1 << log2S, ts = plane ? 32 : 64;
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int
         const int fs = plane ? j.fenc_cstride : j.fenc_stride;
         m.sse[plane] = wave_sse_pp(f, fs, tile, ts, s, lane);
         if (!plane) m.psy = (uint32_t)wave_psy_cost(f, fs, tile, ts, j.log2_size - 2, lane);
+        m.sa8d += (uint32_t)xa_wave_sa8d(f, fs, tile, ts, s, lane);
         __syncthreads();
     }
     if (lane == 0) out[ji] = m;
@@ -747,6 +748,26 @@ static void fill_measure_jobs(std::vector<CuMeasureJob>& mjobs, const x265amd_rd
         m.sel = dSel ? (uint64_t)(uintptr_t)(dSel + (size_t)RD_SEL_BYTES * i) : 0;
         m.fenc_stride = (int32_t)stride; m.fenc_cstride = (int32_t)cstride; m.log2_size = cu.log2_size; m.assemble = 0;
     }
+}
+
+extern "C" int x265amd_measure_tiles(void* stream_, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                                     uint64_t d_tiles, size_t tile_bytes, x265amd_cu_measure* out)
+{
+    if (!h_src || !cus || !d_tiles || !out || n < 0) return xa_fail(X265AMD_EINVAL, "measure_tiles: null argument");
+    if (n == 0) return X265AMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    DevBuf dMJobs, dMeas, dDump;
+    XA_HIP_CHECK(dMJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(dMeas.alloc(sizeof(x265amd_cu_measure) * n));
+    XA_HIP_CHECK(dDump.alloc((size_t)(4096 + 2048) * sizeof(pixel)));
+    std::vector<CuMeasureJob> mjobs(n);
+    fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_tiles, d_tiles, tile_bytes, nullptr, 0, nullptr);       /* "recon" = the tile itself */
+    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
+    XA_HIP_CHECK(hipGetLastError());
+    XA_HIP_CHECK(hipMemcpyAsync(out, dMeas.p, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
+    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    return X265AMD_OK;
 }
 
 extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,

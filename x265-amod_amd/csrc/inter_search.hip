@@ -12,41 +12,15 @@
  * Second PUs of two-part CUs run through the same steps afterwards, with the first PU's choice patched into the motion field.
  * Not supported (rejected or absent): weighted prediction, HME, analysis reuse, distributed ME, frame-parallel lag clipping.
  */
-#include "x265amd_host.h"
+#include "inter_common.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
 
+using namespace xa_inter;
+
 namespace {
-
-struct Mv { int x, y; };
-inline bool operator==(Mv a, Mv b) { return a.x == b.x && a.y == b.y; }
-
-double is_lambda(int qp)           /* x265_lambda_tab (constants.cpp:34-52) by rule */
-{
-    double v = pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265AMD_DEPTH - 8));
-    return floor(v * 10000.0 + 0.5) / 10000.0;
-}
-/* BitCost::s_bitsizes (bitcost.cpp:95-109), evaluated as the reference build does */
-float is_bitsize(int d)
-{
-    const int i = abs(d);
-    const double log2_2 = (double)(float)(2.0 / log(2.0));
-    return i ? (float)(log((double)(float)(i + 1)) * log2_2 + (double)1.718f) : 0.718f;
-}
-uint32_t is_bitcost(Mv mv, Mv mvp) { return (uint32_t)(is_bitsize(mv.x - mvp.x) + is_bitsize(mv.y - mvp.y) + 0.5f); }
-
-struct Geo { int x, y, w, h; };
-Geo pu_geo(int cuX, int cuY, int size, int part, int idx)
-{
-    static const uint8_t rects[8][4][4] = {
-        { { 0, 0, 4, 4 } }, { { 0, 0, 4, 2 }, { 0, 2, 4, 2 } }, { { 0, 0, 2, 4 }, { 2, 0, 2, 4 } }, { { 0, 0, 2, 2 }, { 2, 0, 2, 2 }, { 0, 2, 2, 2 }, { 2, 2, 2, 2 } },
-        { { 0, 0, 4, 1 }, { 0, 1, 4, 3 } }, { { 0, 0, 4, 3 }, { 0, 3, 4, 1 } }, { { 0, 0, 1, 4 }, { 1, 0, 3, 4 } }, { { 0, 0, 3, 4 }, { 3, 0, 1, 4 } } };
-    const uint8_t* r = rects[part][idx];
-    const int q = size / 4;
-    return Geo{ cuX + r[0] * q, cuY + r[1] * q, r[2] * q, r[3] * q };
-}
 
 struct MeBest { Mv mv, mvp; int mvpIdx, ref, bits; uint32_t mvCost, cost; };
 
@@ -76,6 +50,14 @@ struct Dev
 extern "C" int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                                          x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
                                          const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu)
+{
+    return x265amd_pred_inter_search_ex(me, stream, I, S, cur, col, h_planes, num_pics, stride, cstride, cus, n, out, bits_out, d_pred, pred_bytes_per_cu, nullptr);
+}
+
+extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                                            x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
+                                            const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu,
+                                            x265amd_me_detail* detail)
 {
     if (!me || !I || !S || !cur || !h_planes || !cus || !out || !bits_out || n < 0 || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "x265amd_pred_inter_search: bad arguments");
@@ -111,26 +93,8 @@ extern "C" int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const
     memset(out, 0, sizeof(x265amd_pu_result) * 2 * (size_t)n);
     std::vector<x265amd_mc_job> finalMc;
 
-    /* cu.clipMv (cudata.cpp:1915-1928) */
-    auto clipMv = [&](Mv& mv, int cuX, int cuY) {
-        const int maxCU = 64, offset = 8;
-        const int xmax = (I->pic_width + offset - cuX - 1) << 2, xmin = -((maxCU + offset + cuX - 1) << 2);
-        const int ymax = (I->pic_height + offset - cuY - 1) << 2, ymin = -((maxCU + offset + cuY - 1) << 2);
-        mv.x = mv.x < xmin ? xmin : (mv.x > xmax ? xmax : mv.x);
-        mv.y = mv.y < ymin ? ymin : (mv.y > ymax ? ymax : mv.y);
-    };
-    /* Search::setSearchRange without frame-parallel / slice / intra-refresh restrictions (search.cpp:2724-2768) */
-    auto searchRange = [&](Mv mvp, int merange, int cuX, int cuY, Mv& mn, Mv& mx) {
-        mn = Mv{ mvp.x - (merange << 2), mvp.y - (merange << 2) }; mx = Mv{ mvp.x + (merange << 2), mvp.y + (merange << 2) };
-        clipMv(mn, cuX, cuY); clipMv(mx, cuX, cuY);
-        const int maxLen = (1 << 15) - 1;
-        mn.x = mn.x < -maxLen ? -maxLen : mn.x; mn.y = mn.y < -maxLen ? -maxLen : mn.y;
-        mx.x = mx.x > maxLen ? maxLen : mx.x; mx.y = mx.y > maxLen ? maxLen : mx.y;
-        mn.x >>= 2; mn.y >>= 2; mx.x >>= 2; mx.y >>= 2;
-        const int lag = I->pic_height;
-        mn.y = mn.y < lag ? mn.y : lag; mx.y = mx.y < lag ? mx.y : lag;
-        mx.y = mx.y > mn.y ? mx.y : mn.y;
-    };
+    auto clipMv = [&](Mv& mv, int cuX, int cuY) { clip_mv(mv, cuX, cuY, I->pic_width, I->pic_height); };
+    auto searchRange = [&](Mv mvp, int merange, int cuX, int cuY, Mv& mn, Mv& mx) { search_range(mvp, merange, cuX, cuY, I->pic_width, I->pic_height, mn, mx); };
     auto mcJob = [&](const Geo& g, int cuX, int cuY, int sliceP, int pic0, Mv mv0, int pic1, Mv mv1, int flags, int metric, int chromaCost) {
         x265amd_mc_job j;
         memset(&j, 0, sizeof(j));
@@ -353,6 +317,21 @@ extern "C" int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const
                     }
                     if (cc < w.best[list].cost) w.best[list] = MeBest{ outmv, a[mvpIdx], mvpIdx, ref, (int)bits, mvCost, cc };
                 }
+            if (detail && pidx == 0)
+            {
+                x265amd_me_detail& d = detail[w.cu];
+                memset(&d, 0, sizeof(d));
+                for (int l = 0; l < 2; l++)
+                {
+                    const MeBest& b = w.best[l];
+                    d.cost[l] = b.cost; d.ref[l] = (int8_t)b.ref;
+                    if (b.ref < 0) continue;
+                    d.mv[l][0] = (int16_t)b.mv.x; d.mv[l][1] = (int16_t)b.mv.y; d.mvp[l][0] = (int16_t)b.mvp.x; d.mvp[l][1] = (int16_t)b.mvp.y;
+                    d.mvp_idx[l] = (uint8_t)b.mvpIdx; d.bits[l] = (uint32_t)b.bits; d.mv_cost[l] = b.mvCost;
+                    for (int k = 0; k < 2; k++) { d.amvp[l][k][0] = w.amvp[l][b.ref][k][0]; d.amvp[l][k][1] = w.amvp[l][b.ref][k][1]; }
+                }
+                for (int k = 0; k < 3; k++) d.list_sel_bits[k] = w.listSelBits[k];
+            }
             w.bidirJob[0] = w.bidirJob[1] = -1;
             if (isB && !(c.log2_size == 3 && c.part_size != 0) && c.part_size != 0 && w.best[0].cost != 0xFFFFFFFFu && w.best[1].cost != 0xFFFFFFFFu)
             {
