@@ -556,7 +556,8 @@ int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const x265amd_mv
                               const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu);
 
 /* x265amd_pred_inter_search that also reports what the reference keeps in Mode::bestME[0][list] / amvpCand of the CU's first PU (search.h:79-99),
- * which Analysis::checkBidir2Nx2N reads afterwards.  cost[l] == 0xFFFFFFFF: list l was not searched. */
+ * which Analysis::checkBidir2Nx2N reads afterwards.  cost[l] == 0xFFFFFFFF: list l was not searched.
+ * ref_masks (may be NULL): n x 2 words, predInterSearch's refMasks per PU: bit r allows reference r of list 0, bit 16 + r of list 1; 0 = all. */
 typedef struct x265amd_me_detail
 {
     int16_t mv[2][2], mvp[2][2];
@@ -568,7 +569,7 @@ typedef struct x265amd_me_detail
 int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* info, const x265amd_inter_search_params* sp,
                                  x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
                                  const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu,
-                                 x265amd_me_detail* detail);
+                                 x265amd_me_detail* detail, const uint32_t* ref_masks);
 
 /* --- residual RD of inter CUs: Search::encodeResAndCalcRdInterCU (reference: source/encoder/search.cpp:2822-2975) with
  * estimateResidualQT (:3178-3857), splitTU (:3126-3176), estimateNullCbfCost (:3114-3124), codeInterSubdivCbfQT (:3859-3887),
@@ -649,7 +650,7 @@ int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_rd_params* 
  * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N
  * (:3145-3277), topSkipMinDepth (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426).  Host recursion in the
  * reference's order over the batch entry points above; one CTU per call.
- * Built subset: B slices without intra candidates (b_intra 0), 2Nx2N partitions (rect / amp 0), limit_refs 0, limit_modes 0, no delta QP,
+ * Built subset: B slices without intra candidates (b_intra 0), 2Nx2N partitions (rect / amp 0), limit_refs 0-3, limit_modes 0, no delta QP,
  * rd_level 3-4, rskip 0 / 1, early_skip 0 / 1.  Anything else is rejected with X265AMD_EINVAL. */
 typedef struct x265amd_analysis_params
 {

@@ -2361,7 +2361,7 @@ CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits
 assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 40
 
 
-def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0):
+def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0):
     """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
     the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
     rng = np.random.default_rng(seed + 901)
@@ -2431,7 +2431,7 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
             rp[l, r] = (r + l) % 3
     sp["refPic"] = rp
     ap = np.zeros(1, ANALYSIS_PARAMS_DT)
-    ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"] = psy_rd, 3, early_skip, rskip, 0, 0
+    ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"] = psy_rd, 3, early_skip, rskip, limit_refs, 0
     # reference pictures' CU depths (two lists) and CTU QPs; running cost statistics of the CTUs coded so far
     ref_depth = np.zeros((2, h4, w4), np.uint8)
     for l in range(2):

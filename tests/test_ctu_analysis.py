@@ -8,14 +8,15 @@ import pytest
 
 import hevc_testlib as T
 
-# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth)
-CASES = [(8, 1, 1, 1, 2.0, 1), (8, 2, 0, 1, 2.0, 2), (8, 3, 1, 0, 0.0, 1), (10, 4, 0, 1, 2.0, 1), (8, 5, 1, 1, 1.0, 3), (8, 6, 0, 0, 2.0, 1)]
+# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth, limit-refs)
+CASES = [(8, 1, 1, 1, 2.0, 1, 0), (8, 2, 0, 1, 2.0, 2, 0), (8, 3, 1, 0, 0.0, 1, 0), (10, 4, 0, 1, 2.0, 1, 0), (8, 5, 1, 1, 1.0, 3, 0), (8, 6, 0, 0, 2.0, 1, 0),
+         (8, 7, 1, 1, 2.0, 1, 3), (8, 8, 0, 0, 2.0, 1, 3), (10, 9, 0, 1, 0.0, 2, 1), (8, 10, 0, 1, 2.0, 1, 2)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 
 def make_case(k):
-    depth, seed, es, rs, psy, td = CASES[k]
-    return T.ctu_case(depth, seed, early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td)
+    depth, seed, es, rs, psy, td, lr = CASES[k]
+    return T.ctu_case(depth, seed, early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr)
 
 
 def test_golden_outcomes_are_varied():
@@ -32,7 +33,7 @@ def test_golden_outcomes_are_varied():
 def test_hip_compress_ctu_inter_matches_reference_golden():
     gold = np.load(GOLD_PATH)
     mes = {}
-    for k, (depth, seed, es, rs, psy, td) in enumerate(CASES):
+    for k, (depth, seed, es, rs, psy, td, lr) in enumerate(CASES):
         if depth not in mes:
             mes[depth] = T.HipME(depth)
         c = make_case(k)

@@ -13,7 +13,7 @@
  * reconstructed picture at the end of every CU, exactly when the reference's copyToPic does, so later neighbours see what the
  * reference's would.
  *
- * Scope of this entry point: B slices without intra candidates (--no-b-intra), 2Nx2N partitions (no --rect / --amp), --limit-refs 0,
+ * Scope of this entry point: B slices without intra candidates (--no-b-intra), 2Nx2N partitions (no --rect / --amp), --limit-refs 0-3,
  * no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.  P slices need the intra candidates (checkIntraInInter /
  * encodeIntraInInter), which are not built yet: rejected.
  */
@@ -351,7 +351,7 @@ struct Analyzer
     }
 
     /* checkInter_rd0_4(2Nx2N) + checkBidir2Nx2N */
-    int checkInter(int x, int y, int depth)
+    int checkInter(int x, int y, int depth, uint32_t refMask)
     {
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
@@ -367,7 +367,8 @@ struct Analyzer
         x265amd_me_detail det;
         x265amd_inter_search_params sp = *S;
         sp.qp = qp; sp.chroma_mc = 1;
-        int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(inter.predTile), tileBytes, &det);
+        const uint32_t masks[2] = { refMask, 0 };
+        int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(inter.predTile), tileBytes, &det, masks);
         if (rc != X265AMD_OK) return err = rc;
         setInter(inter, depth, pu[0].merge_flag, pu[0].mvp_idx[0], pu[0].inter_dir, pu[0].ref_idx, pu[0].mv, pu[0].mvd, pu[0].mvp_idx);
         x265amd_rd_cu rc1;
@@ -439,7 +440,12 @@ struct Analyzer
     }
 
     /* compressInterCU_rd0_4 */
-    int compress(int x, int y, int depth)
+    static uint32_t bestRefIdx(const x265amd_cu_unit& u)        /* CUData::getBestRefIdx (cudata.h:279-280) */
+    {
+        return ((u.inter_dir & 1) && u.ref_idx[0] >= 0 ? 1u << u.ref_idx[0] : 0) | ((u.inter_dir & 2) && u.ref_idx[1] >= 0 ? 1u << (u.ref_idx[1] + 16) : 0);
+    }
+
+    int compress(int x, int y, int depth, uint32_t& splitRefsOut)
     {
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
@@ -448,6 +454,7 @@ struct Analyzer
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
         const uint32_t minDepth = topSkipMinDepth(x, y, depth);
         bool skipModes = false, skipRecursion = false;
+        uint32_t splitRefs[4] = { 0, 0, 0, 0 };
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
 
         /* Step 1: merge / skip candidates */
@@ -476,7 +483,7 @@ struct Analyzer
                 if (cx < I->pic_width && cy < I->pic_height)
                 {
                     md[depth + 1].cur = *nextContext;
-                    if (compress(cx, cy, depth + 1)) return err;
+                    if (compress(cx, cy, depth + 1, splitRefs[q])) return err;
                     const Mode& nb = *md[depth + 1].best;
                     for (int yy = 0; yy < h4n; yy++)
                         for (int xx = 0; xx < h4n; xx++)
@@ -500,13 +507,15 @@ struct Analyzer
             if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
             else updateModeCost(split);
         }
+        uint32_t allSplitRefs = splitRefs[0] | splitRefs[1] | splitRefs[2] | splitRefs[3];
         /* Step 3: ME and RD at the current depth */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
             if (!skipModes)
             {
-                if (checkInter(x, y, depth)) return err;
+                if (checkInter(x, y, depth, allSplitRefs)) return err;
                 Mode* bestInter = &d.pred[PRED_2Nx2N];
+                if (A->limit_refs & 2) allSplitRefs = bestRefIdx(bestInter->u[0]);       /* X265_REF_LIMIT_CU */
                 Mode& bidir = d.pred[PRED_BIDIR];
                 if (rdInter(*bestInter, x, y, depth, false)) return err;
                 checkBestMode(*bestInter, depth);
@@ -524,6 +533,9 @@ struct Analyzer
             if (!d.best) d.best = &split;
             else checkBestMode(split, depth);
         }
+        /* which motion references the parent CU should search (X265_REF_LIMIT_DEPTH) */
+        splitRefsOut = 0;
+        if (A->limit_refs & 1) splitRefsOut = d.best == &d.pred[PRED_SPLIT] ? allSplitRefs : bestRefIdx(d.best->u[0]);
         if (mightNotSplit && d.best->isSkipped())
         {
             x265amd_cu_stat& cs = cuStat[ctuAddr];
@@ -548,8 +560,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if (!me || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 3)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (!I->is_inter_b || A->b_intra) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: intra candidates in inter slices are not built (B slices with b_intra = 0 only)");
-    if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
-        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, 2Nx2N only, limit-refs 0, no delta QP, rskip 0/1)");
+    if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs < 0 || A->limit_refs > 3 || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, 2Nx2N only, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
     Analyzer* an = new Analyzer;
     Analyzer& a = *an;
@@ -583,7 +595,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         memset(&a.md[0].cur, 0, sizeof(Snap));
         memcpy(a.md[0].cur.ctx, ctx_in, X265AMD_CTX_COUNT);
         a.md[0].cur.frac = frac_in;
-        rc = a.compress(a.ctuX, a.ctuY, 0);
+        uint32_t topRefs = 0;
+        rc = a.compress(a.ctuX, a.ctuY, 0, topRefs);
         if (rc == X265AMD_OK && hipStreamSynchronize(a.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)

@@ -51,13 +51,13 @@ extern "C" int x265amd_pred_inter_search(x265amd_me_ctx* me, void* stream, const
                                          x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
                                          const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu)
 {
-    return x265amd_pred_inter_search_ex(me, stream, I, S, cur, col, h_planes, num_pics, stride, cstride, cus, n, out, bits_out, d_pred, pred_bytes_per_cu, nullptr);
+    return x265amd_pred_inter_search_ex(me, stream, I, S, cur, col, h_planes, num_pics, stride, cstride, cus, n, out, bits_out, d_pred, pred_bytes_per_cu, nullptr, nullptr);
 }
 
 extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                                             x265amd_mv_unit* cur, const x265amd_mv_unit* col, const uint64_t* h_planes, int num_pics, intptr_t stride, intptr_t cstride,
                                             const x265amd_inter_cu* cus, int n, x265amd_pu_result* out, int32_t* bits_out, uint64_t d_pred, size_t pred_bytes_per_cu,
-                                            x265amd_me_detail* detail)
+                                            x265amd_me_detail* detail, const uint32_t* ref_masks)
 {
     if (!me || !I || !S || !cur || !h_planes || !cus || !out || !bits_out || n < 0 || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "x265amd_pred_inter_search: bad arguments");
@@ -67,6 +67,11 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     const size_t isz = sizeof(x265amd_pixel);
     const uint64_t lambda = (uint64_t)floor(256.0 * is_lambda(S->qp));
     auto getCost = [&](uint32_t bits) { return (uint32_t)((bits * lambda + 128) >> 8); };
+    /* refMasks of predInterSearch (search.cpp:2389-2400, :2469): bit r of the low half allows reference r of list 0, the high half list 1; 0 = all */
+    auto allowed = [&](int cu, int pidx, int list, int ref) {
+        const uint32_t m = ref_masks && ref_masks[2 * cu + pidx] ? ref_masks[2 * cu + pidx] : 0xFFFFFFFFu;
+        return ((m >> (16 * list)) >> ref) & 1u;
+    };
     const uint16_t* mvcostTab = x265amd_me_host_mvcost(me, S->qp) + 65536;
     auto mvcost = [&](Mv mv, Mv mvp) { return (uint32_t)mvcostTab[mv.x - mvp.x] + (uint32_t)mvcostTab[mv.y - mvp.y]; };
 
@@ -197,6 +202,8 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             for (int list = 0; list < (isB ? 2 : 1); list++)
                 for (int ref = 0; ref < I->num_ref_idx[list]; ref++)
                 {
+                    w.mvpJob0[list][ref] = -1; w.meJob[list][ref] = -1;
+                    if (!allowed(w.cu, pidx, list, ref)) continue;
                     w.numMvc[list][ref] = x265amd_amvp_candidates(I, cur, col, c.x, c.y, c.log2_size, c.part_size, pidx, list, ref, w.amvp[list][ref], w.mvc[list][ref]);
                     w.mvpJob0[list][ref] = -1;
                     const int16_t (*a)[2] = w.amvp[list][ref];
@@ -238,6 +245,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             for (int list = 0; list < (isB ? 2 : 1); list++)
                 for (int ref = 0; ref < I->num_ref_idx[list]; ref++)
                 {
+                    if (!allowed(w.cu, pidx, list, ref)) continue;
                     int idx = 0;
                     if (w.mvpJob0[list][ref] >= 0) idx = cost[2 * w.mvpJob0[list][ref]] <= cost[2 * (w.mvpJob0[list][ref] + 1)] ? 0 : 1;
                     w.mvpIdx[list][ref] = idx;
@@ -298,6 +306,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             for (int list = 0; list < (isB ? 2 : 1); list++)
                 for (int ref = 0; ref < I->num_ref_idx[list]; ref++)
                 {
+                    if (w.meJob[list][ref] < 0) continue;
                     const x265amd_me_result& r = mres[w.meJob[list][ref]];
                     int mvpIdx = w.mvpIdx[list][ref];
                     const Mv outmv{ r.mv[0], r.mv[1] };
