@@ -582,7 +582,7 @@ typedef struct x265amd_rd_params
 {
     double psy_rd;                  /* param.psyRd (RDCost::setPsyRdScale, rdcost.h:43) */
     int32_t rd_level;               /* param.rdLevel: how checkDQP prices a delta QP (>= 3 codes it, 2 counts one bit) */
-    int32_t reserved;
+    int32_t strong_intra_smoothing; /* sps.bUseStrongIntraSmoothing (intra candidates only) */
 } x265amd_rd_params;
 typedef struct x265amd_rd_cu
 {
@@ -645,6 +645,19 @@ int x265amd_skip_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd
                     x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, x265amd_rd_result* out);
 int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
                          x265amd_cu_unit* cu_units, const x265amd_cu_measure* meas, x265amd_rd_result* out);
+
+/* --- intra candidate of an inter-slice CU (RD side): Search::checkIntraInInter + encodeIntraInInter (reference:
+ * source/encoder/search.cpp:1291-1452, :1454-1507) with codeIntraLumaQT (:305-508), estIntraPredChromaQT (:1754-1889), codeIntraChromaQt
+ * (:819-945) for ONE 2Nx2N CU of 8..32 samples: the 35-mode SA8D scan + mode bits choose the luma mode, then every transform unit is one
+ * x265amd_intra_tu_chain launch whose reconstruction is written into the reconstructed picture before the next one starts (intra blocks
+ * predict from their neighbours' reconstruction, so the TUs of a CU are serial), the five chroma modes are tried in the reference's order.
+ * h_rec: HOST array of 3 device addresses of the reconstructed picture (read for neighbours, written with this CU's reconstruction).
+ * cu_units: (size/4)^2 records (raster, row length size/4) returning pred_mode INTRA, luma_dir, chroma_dir, tu_depth, cbf, qp.
+ * d_pred: tile receiving intraMode.predYuv (luma only), d_recon: tile receiving intraMode.reconYuv.  info (may be NULL): luma mode, sa8dCost,
+ * sa8dBits, SA8D distortion as checkIntraInInter leaves them.  Synchronous. */
+int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                           const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
+                           x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info);
 
 /* --- CTU mode decision of inter slices: Analysis::compressCTU -> compressInterCU_rd0_4 (reference:
  * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N

@@ -1156,6 +1156,7 @@ struct RefRdParams { double psyRd; int32_t rdLevel, reserved; };
 struct RefRdResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, mvBits, coeffBits, psyEnergy, lumaDist, chromaDist, resEnergy, reserved; uint8_t ctx[160]; };
 /* srcPlanes: addresses of sample (0,0) of the source Y, U, V.  predY/U/V: strides 64 / 32.  cuUnitsOut: the CU's units after the call, raster within the
  * CU (row length size/4).  coeffOut: 4096 + 2 * 1024 levels in CUData::m_trCoeff layout.  reconY/U/V: strides 64 / 32. */
+static const uint64_t* g_rdReconPlanes = NULL; static int g_rdStrongSmoothing = 0; static uint64_t* g_rdIntraInfo = NULL; static pixel* g_rdPredOut = NULL;
 static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
                            int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, const pixel* predY, const pixel* predU, const pixel* predV,
                            RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
@@ -1195,6 +1196,14 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
     frame.m_encData = fd; frame.m_param = param;
     PicYuv* src = mkPic(param, sps, srcPlanes, stride, cstride, width, height, 0, 0);
     frame.m_fencPic = src;
+    PicYuv* rec = NULL;
+    if (skipCU == 2)
+    {
+        rec = mkPic(param, sps, g_rdReconPlanes, stride, cstride, width, height, 0, 0);
+        frame.m_reconPic = rec; fd->m_reconPic = rec;
+        sps.bUseStrongIntraSmoothing = g_rdStrongSmoothing != 0;
+        param->bEnableStrongIntraSmoothing = g_rdStrongSmoothing; param->bEnableFastIntra = 0; param->bEnableConstrainedIntra = 0; param->rdPenalty = 0;
+    }
     const int w4 = width >> 2;
     for (uint32_t addr = 0; addr < sps.numCUsInFrame; addr++)
     {
@@ -1245,7 +1254,7 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
         mode->fencYuv = &fenc;
         mode->cu.initSubCU(ctu, *g, qp);
         /* the candidate's fields, copied from the picture CTU (initSubCU resets them) */
-        for (uint32_t i = 0; i < g->numPartitions; i++)
+        for (uint32_t i = 0; skipCU != 2 && i < g->numPartitions; i++)
         {
             const uint32_t z = absPartIdx + i;
             mode->cu.m_predMode[i] = ctu.m_predMode[z]; mode->cu.m_partSize[i] = ctu.m_partSize[z]; mode->cu.m_mergeFlag[i] = ctu.m_mergeFlag[z];
@@ -1265,7 +1274,14 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
         memcpy(start.m_contextState, ctxIn, MAX_OFF_CTX_MOD);
         start.m_fracBits = fracIn;
         search->m_rqt[depth].cur.load(start);
-        if (skipCU) search->encodeResAndCalcRdSkipCU(*mode);
+        if (skipCU == 2)
+        {
+            search->checkIntraInInter(*mode, *g);
+            g_rdIntraInfo[0] = mode->cu.m_lumaIntraDir[0]; g_rdIntraInfo[1] = mode->sa8dCost; g_rdIntraInfo[2] = mode->sa8dBits; g_rdIntraInfo[3] = mode->distortion;
+            search->encodeIntraInInter(*mode, *g);
+            for (int y = 0; y < (1 << log2CU); y++) memcpy(g_rdPredOut + y * 64, mode->predYuv.m_buf[0] + y * mode->predYuv.m_size, (1 << log2CU) * sizeof(pixel));
+        }
+        else if (skipCU) search->encodeResAndCalcRdSkipCU(*mode);
         else search->encodeResAndCalcRdInterCU(*mode, *g);
         memset(out, 0, sizeof(*out));
         out->rdCost = mode->rdCost; out->distortion = mode->distortion; out->fracBits = mode->contexts.m_fracBits;
@@ -1281,6 +1297,7 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
             const int pm = mode->cu.m_predMode[i];
             u.predMode = pm == MODE_SKIP ? 3 : (pm == MODE_INTRA ? 2 : (pm == MODE_INTER ? 1 : 0));
             u.tuDepth = mode->cu.m_tuDepth[i]; u.qp = mode->cu.m_qp[i];
+            if (skipCU == 2) { u.partSize = mode->cu.m_partSize[i]; u.lumaDir = mode->cu.m_lumaIntraDir[i]; u.chromaDir = mode->cu.m_chromaIntraDir[i]; u.depth = (uint8_t)depth; u.mergeFlag = 0; u.interDir = 0; }
             for (int c = 0; c < 3; c++) u.cbf[c] = mode->cu.m_cbf[c][i];
         }
         memcpy(coeffOut, mode->cu.m_trCoeff[0], n * n * sizeof(int16_t));
@@ -1300,9 +1317,22 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
     }
     frame.m_fencPic = NULL;
     dropPic(src);
+    if (rec) { frame.m_reconPic = NULL; fd->m_reconPic = NULL; dropPic(rec); }
     frame.m_encData = NULL;
     fd->destroy(); delete fd;
     x265_param_free(param);
+}
+
+/* Search::checkIntraInInter + encodeIntraInInter (encoder/search.cpp:1291-1452, :1454-1507) on the same fixture, with a reconstructed picture
+ * (read for the neighbours, written with the CU's reconstruction as the reference does).  info: luma mode, sa8dCost, sa8dBits, sa8d distortion
+ * as checkIntraInInter leaves them; predY: intraMode.predYuv luma (stride 64) */
+void ref_intra_in_inter(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, const uint64_t* reconPlanes, intptr_t stride,
+                        intptr_t cstride, int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, int strongSmoothing,
+                        RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* predY, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out, uint64_t* info)
+{
+    static pixel dummy[64 * 64];
+    g_rdReconPlanes = reconPlanes; g_rdStrongSmoothing = strongSmoothing; g_rdIntraInfo = info; g_rdPredOut = predY;
+    rd_fixture_run(2, si, rp, units, srcPlanes, stride, cstride, cuX, cuY, log2CU, qp, ctxIn, fracIn, dummy, dummy, dummy, cuUnitsOut, coeffOut, reconY, reconU, reconV, out);
 }
 
 void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,

@@ -47,6 +47,7 @@ def main():
     make_inter_search_golden()
     make_inter_rd_golden()
     make_ctu_analysis_golden()
+    make_intra_rd_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -245,6 +246,21 @@ def make_ctu_analysis_golden():
                 out["%d/%d/%s" % (k, i, name)] = a
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz"), **out)
     print("wrote ctu_analysis_golden.npz with", len(out), "arrays")
+
+
+def make_intra_rd_golden():
+    """results of the reference's Search::checkIntraInInter + encodeIntraInInter on fixtures -> tests/golden/intra_rd_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tir", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_intra_rd.py"))
+    tir = importlib.util.module_from_spec(spec); spec.loader.exec_module(tir)
+    out = {}
+    for k, (depth, seed, st, psy, strong) in enumerate(tir.CASES):
+        c = T.intra_rd_case(depth, seed, st, psy, strong=strong)
+        for i, d in enumerate(T.intra_rd_pack(T.intra_rd_run_ref(T.load_ref(depth), c), c)):
+            for name, a in d.items():
+                out["%d/%d/%s" % (k, i, name)] = a
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_rd_golden.npz"), **out)
+    print("wrote intra_rd_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

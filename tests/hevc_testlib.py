@@ -1981,7 +1981,7 @@ def inter_search_run_hip(L, me, c):
 
 
 # ---- residual RD of inter CUs (x265amd_inter_residual_rd vs Search::encodeResAndCalcRdInterCU) ----
-RD_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("reserved", "<i4")])
+RD_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("strong", "<i4")])
 RD_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("mv_bits", "<u4"), ("coeff_bits", "<u4"),
                          ("psy_energy", "<u4"), ("luma_distortion", "<u4"), ("chroma_distortion", "<u4"), ("res_energy", "<u4"), ("reserved", "<u4"),
                          ("ctx", "u1", 160)])
@@ -2574,3 +2574,85 @@ def ctu_pack(results):
         d["coeff"] = (coeff[:4096] * keep[:4096]).astype(np.int16)
         out.append(d)
     return out
+
+
+# ---- intra candidates of inter slices (x265amd_intra_in_inter vs Search::checkIntraInInter + encodeIntraInInter) ----
+def intra_rd_case(depth, seed, slice_type, psy_rd, ncu=10, strong=1):
+    """rd_case plus a reconstructed picture (the source with coding-like noise) that supplies the intra neighbours; CU sizes 8..32"""
+    c = rd_case(depth, seed, slice_type, 1, psy_rd, ncu=ncu)
+    rng = np.random.default_rng(seed + 313)
+    dt = c["preds"].dtype
+    pmax = (1 << depth) - 1
+    c["rec"] = [np.ascontiguousarray(np.clip(p.astype(np.int64) + rng.integers(-3, 4, p.shape), 0, pmax).astype(dt)) for p in c["src"]]
+    for i in range(ncu):
+        cu = c["cus"][i]
+        log2 = int(rng.choice([3, 3, 4, 4, 5]))
+        size = 1 << log2
+        edge = int(rng.integers(0, 4))
+        x = 0 if edge == 0 else int(rng.integers(0, c["width"] // size)) * size
+        y = 0 if edge == 1 else int(rng.integers(0, c["height"] // size)) * size
+        cu["x"], cu["y"], cu["log2_size"] = x, y, log2
+    c["rp"]["strong"] = strong
+    return c
+
+
+def intra_rd_run_ref(R, c):
+    """returns (results, cu_units_out, coeff, recon tiles, pred luma tiles, info (n x 4))"""
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    res = np.zeros(n, RD_RESULT_DT); uo = np.zeros((n, 256), CU_UNIT_DT); coeff = np.zeros((n, RD_TILE), np.int16); recon = np.zeros((n, RD_TILE), dt)
+    pred = np.zeros((n, 4096), dt); info = np.zeros((n, 4), np.uint64)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    planes = np.array([p.ctypes.data for p in c["src"]], np.uint64)
+    for i in range(n):
+        cu = c["cus"][i]
+        rec = [p.copy() for p in c["rec"]]
+        rplanes = np.array([p.ctypes.data for p in rec], np.uint64)
+        ctx = np.zeros(160, np.uint8); ctx[:] = cu["ctx"]
+        m = np.ascontiguousarray(c["units"])
+        R.lib.ref_intra_in_inter(_ptr(si), _ptr(c["rp"]), _ptr(m), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                 int(cu["x"]), int(cu["y"]), int(cu["log2_size"]), int(cu["qp"]), _ptr(ctx), C.c_uint64(int(cu["frac_bits"])), int(c["rp"]["strong"][0]),
+                                 off(uo[i], 0), off(coeff[i], 0), off(pred[i], 0), off(recon[i], 0), off(recon[i], 4096), off(recon[i], 4096 + 1024), off(res, i), off(info[i], 0))
+    return res, uo, coeff, recon, pred, info
+
+
+def intra_rd_run_hip(L, c):
+    """x265amd_intra_in_inter per candidate, each on a fresh copy of the reconstructed picture; same return shape as intra_rd_run_ref"""
+    import torch
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    isz = dt.itemsize
+    d_src = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)).cuda() for p in c["src"]]
+    planes = np.array([d.data_ptr() for d in d_src], np.uint64)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    res = np.zeros(n, RD_RESULT_DT); uo = np.zeros((n, 256), CU_UNIT_DT); coeff = np.zeros((n, RD_TILE), np.int16); recon = np.zeros((n, RD_TILE), dt)
+    pred = np.zeros((n, 4096), dt); info = np.zeros((n, 4), np.uint64)
+    for i in range(n):
+        d_rec = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)).cuda() for p in c["rec"]]
+        rplanes = np.array([d.data_ptr() for d in d_rec], np.uint64)
+        d_pred = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
+        d_recon = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
+        units = np.ascontiguousarray(c["units"].copy())
+        rc = L.lib.x265amd_intra_in_inter(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                          off(c["cus"], i), off(uo[i], 0), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), off(res, i), off(coeff[i], 0),
+                                          off(info[i], 0))
+        assert rc == 0, L.lib.x265amd_last_error()
+        assert np.array_equal(units, c["units"])
+        recon[i] = d_recon.cpu().numpy().view(dt)
+        pred[i] = d_pred.cpu().numpy().view(dt)[:4096]
+    return res, uo, coeff, recon, pred, info
+
+
+def intra_rd_pack(r, c):
+    """golden form: rd_pack's fields plus the intra directions, the luma prediction and the scan's choice"""
+    res, uo, coeff, recon, pred, info = r
+    base = rd_pack((res, uo, coeff, recon), c)
+    for i, d in enumerate(base):
+        cu = c["cus"][i]
+        S = 1 << int(cu["log2_size"]); n4 = S // 4
+        d["dirs"] = np.stack([uo[i]["luma_dir"][:n4 * n4], uo[i]["chroma_dir"][:n4 * n4], uo[i]["part_size"][:n4 * n4]], 1).astype(np.int16)
+        d["pred"] = pred[i].reshape(64, 64)[:S, :S].astype(np.uint16).ravel()
+        d["info"] = info[i].copy()
+        # an intra CU's levels are always exported
+        d["coeff"] = np.concatenate([coeff[i][:S * S], coeff[i][4096:4096 + S * S // 4], coeff[i][5120:5120 + S * S // 4]])
+    return base

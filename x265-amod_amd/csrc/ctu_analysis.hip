@@ -582,7 +582,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         uint64_t rd[6];
         x265amd_rdcost(a.qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
         a.lambda2 = rd[0]; a.lambda = rd[1]; a.psyRd = (uint32_t)rd[2];
-        a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.reserved = 0;
+        a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = 0;
         /* CUData::initCTU: nothing of this CTU is decided yet */
         for (int yy = a.ctuY >> 2; yy < (a.ctuY >> 2) + 16 && yy < a.h4; yy++)
             for (int xx = a.ctuX >> 2; xx < (a.ctuX >> 2) + 16 && xx < a.w4; xx++)

@@ -1,0 +1,585 @@
+/* Intra candidates of inter slices (include/x265amd.h: x265amd_intra_in_inter): SURVEY row a7's RD side.
+ *
+ * Restatement of Search::checkIntraInInter (reference: source/encoder/search.cpp:1291-1452) and encodeIntraInInter (:1454-1507) with
+ * codeIntraLumaQT (:305-508), extractIntraResultQT (:763-786), estIntraPredChromaQT (:1754-1889), codeIntraChromaQt (:819-945),
+ * codeSubdivCbfQTChroma / codeCoeffQTChroma (:233-303), getIntraRemModeBits (:1698-1709) and Predict::initIntraNeighbors
+ * (source/common/predict.cpp:664-715 with the availability look-ups :878-976, cudata.cpp:745-811).
+ *
+ * Intra blocks predict from the reconstruction of their neighbours, so the transform units of one CU are inherently serial: each TU is
+ * one x265amd_intra_tu_chain launch (neighbours from the reconstructed picture, prediction, residual chain, reconstruction) whose
+ * reconstruction goes back into the picture before the next TU starts, exactly as the reference's loops do.  The mode scan is one
+ * x265amd_intra_scan launch; both chroma planes of a TU share a launch.  Bits and decisions are the host's (host/cabac_coder.h).
+ */
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+#include "../host/cabac_coder.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+#if X265AMD_DEPTH < 10
+typedef uint32_t sse_t;
+#else
+typedef uint64_t sse_t;
+#endif
+
+struct Snap { uint8_t ctx[X265AMD_CTX_STRIDE]; uint64_t frac; };
+struct Cost { uint64_t rdcost; uint32_t bits; sse_t distortion; uint32_t energy; };
+const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
+
+struct DevBuf
+{
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+
+inline unsigned zUnit(int ux, int uy)           /* z-order of unit (ux, uy) inside its CTU */
+{
+    unsigned r = 0;
+    for (int b = 0; b < 4; b++) r |= (((unsigned)ux >> b) & 1u) << (2 * b) | (((unsigned)uy >> b) & 1u) << (2 * b + 1);
+    return r;
+}
+
+struct IntraRd
+{
+    hipStream_t st;
+    const x265amd_slice_info* si; const x265amd_rd_params* rp;
+    x265amd_cu_unit* units; int w4;
+    const uint64_t* src; const uint64_t* rec; intptr_t stride, cstride;
+    int cuX, cuY, log2, size, depth, qp, qpLumaScaled, qpChromaScaled;
+    int range[2];
+    x265amd_cabac* c;
+    Snap cur, rqtRoot[6], rqtTest[6];
+    uint64_t lambda2, lambda; uint32_t psyRd;
+    uint64_t predTile, reconTile;
+    DevBuf dJobs, dRes, dCoeff, dResi, dLayer, dScan, dScanJob;
+    std::vector<int16_t> coeffL[4];             /* luma levels per transform layer (CUData offsets) */
+    std::vector<int16_t> coeffC[2], coeffCBest[2];
+    int err;
+
+    /* ---- entropy / cost helpers (as in inter_rd.hip) ---- */
+    uint32_t bits() const { return (uint32_t)(c->fracBits >> 15); }
+    void resetBits() { c->fracBits &= 32767; }
+    void store(Snap& s) const { memcpy(s.ctx, c->ctx, X265AMD_CTX_STRIDE); s.frac = c->fracBits; }
+    void load(const Snap& s) { memcpy(c->ctx, s.ctx, X265AMD_CTX_STRIDE); c->fracBits = s.frac; }
+    uint64_t calcRdCost(sse_t d, uint32_t b) const { return d + (((uint64_t)b * lambda2 + 128) >> 8); }
+    uint64_t calcPsyRdCost(sse_t d, uint32_t b, uint32_t e) const { return d + ((lambda * psyRd * e) >> 24) + (((uint64_t)b * lambda2) >> 8); }
+    uint64_t cost(sse_t d, uint32_t b, uint32_t e) const { return psyRd ? calcPsyRdCost(d, b, e) : calcRdCost(d, b); }
+    uint64_t calcRdSADCost(uint32_t d, uint32_t b) const { return d + (((uint64_t)b * lambda + 128) >> 8); }
+
+    x265amd_cu_unit& U(int x, int y) { return c->U(x >> 2, y >> 2); }
+    bool cbfBit(int x, int y, int plane, int d) { return (U(x, y).cbf[plane] >> d) & 1; }
+    void setTuDepth(int x, int y, int sz, int d) { for (int yy = y; yy < y + sz; yy += 4) for (int xx = x; xx < x + sz; xx += 4) U(xx, yy).tu_depth = (uint8_t)d; }
+    void setCbf(int plane, int x, int y, int sz, int v) { for (int yy = y; yy < y + sz; yy += 4) for (int xx = x; xx < x + sz; xx += 4) U(xx, yy).cbf[plane] = (uint8_t)v; }
+    uint32_t zInCu(int x, int y) const { return zUnit((x - cuX) >> 2, (y - cuY) >> 2); }
+
+    /* Predict::initIntraNeighbors without constrained intra prediction: which 4-sample neighbour units exist and are already coded.
+     * (x, y): luma position of the block, sz: its luma extent (a 4:2:0 chroma block covers the same units). */
+    uint64_t available(int x, int y, int sz) const
+    {
+        const int n = sz >> 2, picW = si->pic_width, picH = si->pic_height;
+        uint64_t m = 0;
+        const int xRT = x + sz - 4, yLB = y + sz - 4;
+        for (int i = 0; i < n; i++)             /* below-left, bottom-most first */
+        {
+            const int k = n - i, ny = yLB + 4 * k;
+            bool a = false;
+            if (ny < picH && ((yLB & 63) >> 2) < 16 - k)
+                a = (x & 63) ? zUnit((x & 63) >> 2, (yLB & 63) >> 2) > zUnit(((x & 63) >> 2) - 1, (ny & 63) >> 2) : x > 0;
+            if (a) m |= 1ull << i;
+        }
+        for (int r = 0; r < n; r++) if (x > 0) m |= 1ull << (2 * n - 1 - r);         /* left */
+        if (x > 0 && y > 0) m |= 1ull << (2 * n);                                    /* above-left */
+        for (int j = 0; j < n; j++) if (y > 0) m |= 1ull << (2 * n + 1 + j);         /* above */
+        for (int k = 1; k <= n; k++)            /* above-right */
+        {
+            const int nx = xRT + 4 * k;
+            bool a = false;
+            if (nx < picW)
+            {
+                if (((xRT & 63) >> 2) < 16 - k)
+                    a = (y & 63) ? zUnit((xRT & 63) >> 2, (y & 63) >> 2) > zUnit((nx & 63) >> 2, ((y & 63) >> 2) - 1) : y > 0;
+                else
+                    a = !(y & 63) && y > 0;
+            }
+            if (a) m |= 1ull << (3 * n + k);
+        }
+        return m;
+    }
+
+    /* The kernels take one flag per 4 samples of the block's own plane; a 4:2:0 chroma block's flags come per 2 chroma samples (= one luma
+     * unit).  Chroma blocks cover 8-aligned luma areas and everything around them is coded in 8x8 luma granules, so the two luma units
+     * behind one 4-sample chroma unit always agree: fold them. */
+    static uint64_t foldChroma(uint64_t fine, int n)
+    {
+        const int m = n >> 1;
+        uint64_t out = 0;
+        auto both = [&](int a, int b) { return ((fine >> a) & 1) & ((fine >> b) & 1); };
+        for (int i = 0; i < 2 * m; i++) out |= (uint64_t)both(2 * i, 2 * i + 1) << i;                       /* below-left and left runs */
+        out |= ((fine >> (2 * n)) & 1) << (2 * m);                                                          /* above-left */
+        for (int j = 0; j < 2 * m; j++) out |= (uint64_t)both(2 * n + 1 + 2 * j, 2 * n + 2 + 2 * j) << (2 * m + 1 + j);   /* above and above-right runs */
+        return out;
+    }
+
+    int fail(const char* msg) { if (!err) err = xa_fail(X265AMD_EHIP, msg); return err; }
+
+    /* one launch of up to two intra TU jobs; results and levels come back to the host */
+    int runJobs(x265amd_intra_tu_job* jobs, int n, x265amd_tu_result* res, int16_t* const* levelsOut, int numCoeff)
+    {
+        if (hipMemcpyAsync(dJobs.p, jobs, sizeof(x265amd_intra_tu_job) * n, hipMemcpyHostToDevice, st) != hipSuccess) return fail("intra rd: job upload");
+        if (x265amd_intra_tu_chain(st, (const x265amd_intra_tu_job*)dJobs.p, nullptr, n, (x265amd_tu_result*)dRes.p) != X265AMD_OK) return err = X265AMD_EHIP;
+        if (hipMemcpyAsync(res, dRes.p, sizeof(x265amd_tu_result) * n, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("intra rd: result download");
+        for (int k = 0; k < n; k++)
+            if (hipMemcpyAsync(levelsOut[k], (const int16_t*)dCoeff.p + 1024 * k, sizeof(int16_t) * numCoeff, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("intra rd: level download");
+        if (hipStreamSynchronize(st) != hipSuccess) return fail("intra rd: synchronize");
+        return 0;
+    }
+    void fillJob(x265amd_intra_tu_job& j, int plane, int x, int y, int log2N, int mode, uint64_t pred, int predStride, uint64_t recon, int reconStride, int slot)
+    {
+        memset(&j, 0, sizeof(j));
+        const size_t isz = sizeof(pixel);
+        const int sh = plane ? 1 : 0;
+        const intptr_t ps = plane ? cstride : stride;
+        j.tu.fenc = src[plane] + ((uint64_t)(y >> sh) * ps + (x >> sh)) * isz;
+        j.tu.pred = pred; j.tu.pred_stride = predStride;
+        j.tu.coeff = (uint64_t)(uintptr_t)((int16_t*)dCoeff.p + 1024 * slot);
+        j.tu.resi = (uint64_t)(uintptr_t)((int16_t*)dResi.p + 1024 * slot); j.tu.resi_stride = 1 << log2N;
+        j.tu.recon = recon; j.tu.recon_stride = reconStride;
+        j.tu.fenc_stride = (int32_t)ps;
+        j.tu.log2_tr_size = (uint8_t)log2N; j.tu.ttype = (uint8_t)plane; j.tu.intra = 1; j.tu.dir_mode = (uint8_t)mode;
+        j.tu.slice_type = (uint8_t)si->slice_type; j.tu.qp_scaled = (uint8_t)(plane ? qpChromaScaled : qpLumaScaled); j.tu.sign_hide = (uint8_t)(si->sign_hide != 0);
+        j.nb = rec[plane] + ((uint64_t)(y >> sh) * ps + (x >> sh)) * isz;
+        j.nb_stride = (int32_t)ps;
+        j.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
+    }
+    void copy2D(uint64_t dst, size_t dstStride, uint64_t s, size_t srcStride, int w, int h)
+    {
+        const size_t isz = sizeof(pixel);
+        (void)hipMemcpy2DAsync((void*)(uintptr_t)dst, dstStride * isz, (const void*)(uintptr_t)s, srcStride * isz, w * isz, h, hipMemcpyDeviceToDevice, st);
+    }
+
+    /* ---- luma ---- */
+    int codeIntraLumaQT(int x, int y, int tuDepth, bool bAllowSplit, Cost& outCost)
+    {
+        const int log2TrSize = log2 - tuDepth, fullDepth = depth + tuDepth, trSize = 1 << log2TrSize, layer = log2TrSize - 2;
+        const bool mightNotSplit = log2TrSize <= range[1];
+        const bool mightSplit = (log2TrSize > range[0]) && (bAllowSplit || !mightNotSplit);
+        const size_t isz = sizeof(pixel);
+        Cost fullCost = { 0, 0, 0, 0 };
+        uint32_t bCBF = 0;
+        const uint64_t layerRecon = (uint64_t)(uintptr_t)dLayer.p + ((size_t)layer * 4096 + (size_t)(y - cuY) * 64 + (x - cuX)) * isz;
+        if (mightNotSplit)
+        {
+            if (mightSplit) store(rqtRoot[fullDepth]);
+            x265amd_cu_unit& u = U(x, y);
+            x265amd_intra_tu_job job;
+            fillJob(job, 0, x, y, log2TrSize, u.luma_dir, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, layerRecon, 64, 0);
+            job.avail = available(x, y, trSize);
+            x265amd_tu_result r;
+            int16_t* lv = coeffL[layer].data() + ((size_t)zInCu(x, y) << 4);
+            if (runJobs(&job, 1, &r, &lv, trSize * trSize)) return err;
+            setTuDepth(x, y, trSize, tuDepth);
+            bCBF = (uint32_t)(r.num_sig != 0) << tuDepth;
+            setCbf(0, x, y, trSize, bCBF);
+            fullCost.distortion = (sse_t)r.nz_dist;
+
+            resetBits();
+            const bool firstOfCu = x == cuX && y == cuY;
+            if (firstOfCu)
+            {
+                if (si->slice_type != 2)
+                {
+                    const x265amd_cu_unit* l = c->at((cuX >> 2) - 1, cuY >> 2);
+                    const x265amd_cu_unit* a = c->at(cuX >> 2, (cuY >> 2) - 1);
+                    const int skipCtx = (x265amd_cabac::coded(l) && l->pred_mode == X265AMD_MODE_SKIP) + (x265amd_cabac::coded(a) && a->pred_mode == X265AMD_MODE_SKIP);
+                    c->bin(0, C_SKIP + skipCtx);
+                    c->bin(1, C_PRED_MODE);
+                }
+                c->partSize(u, depth, size);
+            }
+            if (U(cuX, cuY).part_size == 0)
+            {
+                if (firstOfCu) c->intraDirLuma(&cuX, &cuY, 1);
+            }
+            else
+            {
+                const int half = size >> 1;
+                if (!tuDepth)
+                    for (int q = 0; q < 4; q++) { const int px = cuX + (q & 1) * half, py = cuY + (q >> 1) * half; c->intraDirLuma(&px, &py, 1); }
+                else if (!((x - cuX) & (half - 1)) && !((y - cuY) & (half - 1)))
+                    c->intraDirLuma(&x, &y, 1);
+            }
+            if (log2TrSize != range[0]) c->bin(0, C_TRANS_SUBDIV + 5 - log2TrSize);
+            c->bin(r.num_sig != 0, C_QT_CBF + !tuDepth);
+            if (cbfBit(x, y, 0, tuDepth)) c->coeffNxN(lv, log2TrSize, 0, u);
+            fullCost.bits = bits();
+            fullCost.energy = psyRd ? r.nz_energy : 0;
+            fullCost.rdcost = cost(fullCost.distortion, fullCost.bits, fullCost.energy);
+        }
+        else
+            fullCost.rdcost = kMaxCost;
+
+        if (mightSplit)
+        {
+            if (mightNotSplit)
+            {
+                store(rqtTest[fullDepth]);
+                load(rqtRoot[fullDepth]);
+            }
+            Cost splitCost = { 0, 0, 0, 0 };
+            uint32_t cbf = 0;
+            const int half = trSize >> 1;
+            for (int q = 0; q < 4; q++)
+            {
+                const int qx = x + (q & 1) * half, qy = y + (q >> 1) * half;
+                if (codeIntraLumaQT(qx, qy, tuDepth + 1, bAllowSplit, splitCost)) return err;
+                cbf |= cbfBit(qx, qy, 0, tuDepth + 1);
+            }
+            U(x, y).cbf[0] |= (uint8_t)(cbf << tuDepth);
+            if (mightNotSplit && log2TrSize != range[0])
+            {
+                resetBits();
+                c->bin(1, C_TRANS_SUBDIV + 5 - log2TrSize);
+                splitCost.bits += bits();
+                splitCost.rdcost = cost(splitCost.distortion, splitCost.bits, splitCost.energy);
+            }
+            if (splitCost.rdcost < fullCost.rdcost)
+            {
+                outCost.rdcost += splitCost.rdcost; outCost.distortion += splitCost.distortion; outCost.bits += splitCost.bits; outCost.energy += splitCost.energy;
+                return 0;
+            }
+            load(rqtTest[fullDepth]);
+            setTuDepth(x, y, trSize, tuDepth);
+            setCbf(0, x, y, trSize, bCBF);
+        }
+        /* the reconstruction becomes the neighbourhood of the next blocks */
+        copy2D(rec[0] + ((uint64_t)y * stride + x) * isz, stride, layerRecon, 64, trSize, trSize);
+        outCost.rdcost += fullCost.rdcost; outCost.distortion += fullCost.distortion; outCost.bits += fullCost.bits; outCost.energy += fullCost.energy;
+        return 0;
+    }
+    void extractLuma(int x, int y, int tuDepth, int16_t* coeffCu)
+    {
+        const int log2TrSize = log2 - tuDepth;
+        if (tuDepth == U(x, y).tu_depth)
+        {
+            const size_t off = (size_t)zInCu(x, y) << 4;
+            memcpy(coeffCu + off, coeffL[log2TrSize - 2].data() + off, sizeof(int16_t) << (2 * log2TrSize));
+            return;
+        }
+        const int half = 1 << (log2TrSize - 1);
+        for (int q = 0; q < 4; q++) extractLuma(x + (q & 1) * half, y + (q >> 1) * half, tuDepth + 1, coeffCu);
+    }
+
+    /* ---- chroma ---- */
+    int codeIntraChromaQt(int x, int y, int tuDepth, Cost& outCost)
+    {
+        const int log2TrSize = log2 - tuDepth;
+        if (tuDepth < U(x, y).tu_depth)
+        {
+            const int half = 1 << (log2TrSize - 1);
+            uint32_t splitCbfU = 0, splitCbfV = 0;
+            for (int q = 0; q < 4; q++)
+            {
+                const int qx = x + (q & 1) * half, qy = y + (q >> 1) * half;
+                if (codeIntraChromaQt(qx, qy, tuDepth + 1, outCost)) return err;
+                splitCbfU |= cbfBit(qx, qy, 1, tuDepth + 1);
+                splitCbfV |= cbfBit(qx, qy, 2, tuDepth + 1);
+            }
+            U(x, y).cbf[1] |= (uint8_t)(splitCbfU << tuDepth);
+            U(x, y).cbf[2] |= (uint8_t)(splitCbfV << tuDepth);
+            return 0;
+        }
+        int log2TrSizeC = log2TrSize - 1;
+        if (log2TrSizeC < 2)
+        {
+            if ((x & 4) || (y & 4)) return 0;
+            log2TrSizeC = 2;
+        }
+        const int areaLuma = 2 << log2TrSizeC, nC = 1 << log2TrSizeC;
+        const size_t isz = sizeof(pixel);
+        const x265amd_cu_unit& u = U(x, y);
+        int mode = u.chroma_dir == 36 ? U(cuX, cuY).luma_dir : u.chroma_dir;
+        x265amd_intra_tu_job jobs[2];
+        x265amd_tu_result r[2];
+        int16_t* lv[2];
+        const uint64_t avail = foldChroma(available(x, y, areaLuma), areaLuma >> 2);
+        for (int p = 1; p < 3; p++)
+        {
+            const uint64_t picC = rec[p] + ((uint64_t)(y >> 1) * cstride + (x >> 1)) * isz;
+            fillJob(jobs[p - 1], p, x, y, log2TrSizeC, mode, 0, nC, picC, (int)cstride, p - 1);
+            jobs[p - 1].avail = avail;
+            lv[p - 1] = coeffC[p - 1].data() + (((size_t)zInCu(x, y) << 4) >> 2);
+        }
+        if (runJobs(jobs, 2, r, lv, nC * nC)) return err;
+        for (int p = 1; p < 3; p++)
+        {
+            setCbf(p, x, y, areaLuma, r[p - 1].num_sig ? 1 << tuDepth : 0);
+            outCost.distortion += (sse_t)r[p - 1].nz_dist;          /* scaleChromaDist: weight 256 */
+            if (psyRd) outCost.energy += r[p - 1].nz_energy;
+        }
+        return 0;
+    }
+    void codeSubdivCbfQTChroma(int x, int y, int tuDepth)
+    {
+        const bool subdiv = tuDepth < U(x, y).tu_depth;
+        const int log2TrSize = log2 - tuDepth;
+        if (!(log2TrSize - 1 < 2))
+        {
+            const int psz = 2 << log2TrSize;
+            const int px = cuX + ((x - cuX) & ~(psz - 1)), py = cuY + ((y - cuY) & ~(psz - 1));
+            for (int p = 1; p < 3; p++)
+                if (!tuDepth || cbfBit(px, py, p, tuDepth - 1))
+                {
+                    const bool canQuadSplit = log2TrSize - 1 > 2;
+                    const int lowest = tuDepth + ((subdiv && !canQuadSplit) ? 1 : 0);
+                    c->bin(cbfBit(x, y, p, lowest), C_QT_CBF + tuDepth + 2);
+                }
+        }
+        if (subdiv)
+        {
+            const int half = 1 << (log2TrSize - 1);
+            for (int q = 0; q < 4; q++) codeSubdivCbfQTChroma(x + (q & 1) * half, y + (q >> 1) * half, tuDepth + 1);
+        }
+    }
+    void codeCoeffQTChroma(int x, int y, int tuDepth, int p)
+    {
+        if (!cbfBit(x, y, p, tuDepth)) return;
+        const int log2TrSize = log2 - tuDepth;
+        if (tuDepth < U(x, y).tu_depth)
+        {
+            const int half = 1 << (log2TrSize - 1);
+            for (int q = 0; q < 4; q++) codeCoeffQTChroma(x + (q & 1) * half, y + (q >> 1) * half, tuDepth + 1, p);
+            return;
+        }
+        int log2TrSizeC = log2TrSize - 1;
+        if (log2TrSizeC < 2)
+        {
+            if ((x & 4) || (y & 4)) return;
+            log2TrSizeC = 2;
+        }
+        c->coeffNxN(coeffC[p - 1].data() + (((size_t)zInCu(x, y) << 4) >> 2), log2TrSizeC, p, U(x, y));
+    }
+    int estIntraPredChromaQT(sse_t& totalDistortion)
+    {
+        const int n4 = size >> 2;
+        uint32_t modeList[5] = { 0, 26, 10, 1, 36 };            /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
+        const uint32_t lumaDir = U(cuX, cuY).luma_dir;
+        for (int i = 0; i < 4; i++) if (lumaDir == modeList[i]) { modeList[i] = 34; break; }
+        uint32_t bestMode = 0; sse_t bestDist = 0; uint64_t bestCost = kMaxCost;
+        std::vector<uint8_t> bestCbf(2 * (size_t)n4 * n4, 0);
+        const size_t isz = sizeof(pixel);
+        for (int k = 0; k < 5; k++)
+        {
+            load(cur);
+            for (int yy = 0; yy < size; yy += 4) for (int xx = 0; xx < size; xx += 4) U(cuX + xx, cuY + yy).chroma_dir = (uint8_t)modeList[k];
+            Cost outCost = { 0, 0, 0, 0 };
+            if (codeIntraChromaQt(cuX, cuY, 0, outCost)) return err;
+            resetBits();
+            c->intraDirChroma(U(cuX, cuY));
+            codeSubdivCbfQTChroma(cuX, cuY, 0);
+            codeCoeffQTChroma(cuX, cuY, 0, 1);
+            codeCoeffQTChroma(cuX, cuY, 0, 2);
+            const uint32_t b = bits();
+            const uint64_t cst = cost(outCost.distortion, b, outCost.energy);
+            if (cst < bestCost)
+            {
+                bestCost = cst; bestDist = outCost.distortion; bestMode = modeList[k];
+                /* extractIntraResultChromaQT: levels and reconstruction of this mode */
+                coeffCBest[0] = coeffC[0]; coeffCBest[1] = coeffC[1];
+                for (int p = 1; p < 3; p++)
+                    copy2D(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, size >> 1, size >> 1);
+                for (int yy = 0; yy < n4; yy++)
+                    for (int xx = 0; xx < n4; xx++)
+                    {
+                        bestCbf[(size_t)(yy * n4 + xx) * 2] = U(cuX + 4 * xx, cuY + 4 * yy).cbf[1];
+                        bestCbf[(size_t)(yy * n4 + xx) * 2 + 1] = U(cuX + 4 * xx, cuY + 4 * yy).cbf[2];
+                    }
+            }
+        }
+        for (int yy = 0; yy < n4; yy++)
+            for (int xx = 0; xx < n4; xx++)
+            {
+                x265amd_cu_unit& u = U(cuX + 4 * xx, cuY + 4 * yy);
+                u.cbf[1] = bestCbf[(size_t)(yy * n4 + xx) * 2]; u.cbf[2] = bestCbf[(size_t)(yy * n4 + xx) * 2 + 1];
+                u.chroma_dir = (uint8_t)bestMode;
+            }
+        totalDistortion = bestDist;
+        load(cur);
+        return 0;
+    }
+};
+
+} // namespace
+
+extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                                      const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
+                                      x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info)
+{
+    if (!si || !rp || !units || !h_src || !h_rec || !cu || !cu_units || !d_pred || !d_recon || !out) return xa_fail(X265AMD_EINVAL, "intra_in_inter: null argument");
+    if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "intra_in_inter: lossless coding is not supported");
+    IntraRd* ip = new IntraRd;
+    IntraRd& R = *ip;
+    R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
+    R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
+    R.predTile = d_pred; R.reconTile = d_recon;
+    int rc = X265AMD_OK;
+    if (R.log2 < 3 || R.log2 > 5 || (R.cuX & (R.size - 1)) || (R.cuY & (R.size - 1)) || R.cuX < 0 || R.cuY < 0 || R.cuX + R.size > si->pic_width || R.cuY + R.size > si->pic_height)
+        rc = xa_fail(X265AMD_EINVAL, "intra_in_inter: CU outside the picture, misaligned, or not 8..32");
+    static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
+                                             32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+    const int bd = 6 * (X265AMD_DEPTH - 8);
+    const int qpQuant = R.qp < 0 ? 0 : (R.qp > 51 ? 51 : R.qp);
+    int qpC = qpQuant > 57 ? 57 : qpQuant;
+    if (qpC >= 30) qpC = chromaScale[qpC];
+    R.qpLumaScaled = qpQuant + bd; R.qpChromaScaled = qpC + bd;
+    /* CUData::getIntraTUQtDepthRange (cudata.cpp:972-981), 2Nx2N */
+    {
+        const int lo = R.log2 - (si->tu_max_depth_intra - 1);
+        R.range[0] = lo < si->tu_log2_min ? si->tu_log2_min : (lo > si->tu_log2_max ? si->tu_log2_max : lo);
+        R.range[1] = si->tu_log2_max;
+    }
+    if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * 2) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * 2) != hipSuccess ||
+                             R.dCoeff.alloc(2 * 1024 * 2) != hipSuccess || R.dResi.alloc(2 * 1024 * 2) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
+                             R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess))
+        rc = xa_fail(X265AMD_EHIP, "intra_in_inter: out of device memory");
+    x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
+    if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra_in_inter: slice description");
+    if (rc != X265AMD_OK) { delete ip; return rc; }
+    R.c = coder;
+    for (int l = 0; l < 4; l++) R.coeffL[l].assign(4096, 0);
+    for (int p = 0; p < 2; p++) { R.coeffC[p].assign(1024, 0); R.coeffCBest[p].assign(1024, 0); }
+    uint64_t rd[6];
+    x265amd_rdcost(R.qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+    R.lambda2 = rd[0]; R.lambda = rd[1]; R.psyRd = (uint32_t)rd[2];
+    memset(&R.cur, 0, sizeof(R.cur));
+    memcpy(R.cur.ctx, cu->ctx, X265AMD_CTX_COUNT);
+    R.cur.frac = cu->frac_bits;
+    const int w4 = R.w4, u4 = R.size >> 2;
+    std::vector<x265amd_cu_unit> saved((size_t)u4 * u4);
+    for (int yy = 0; yy < u4; yy++) memcpy(&saved[(size_t)yy * u4], &units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], sizeof(x265amd_cu_unit) * u4);
+    const size_t isz = sizeof(pixel);
+
+    /* ---- checkIntraInInter: the 35-mode scan and the mode bits ---- */
+    uint32_t bmode = 1, bbits = 0, bsad = 0; uint64_t bcost = 0;
+    {
+        x265amd_intra_job sj;
+        memset(&sj, 0, sizeof(sj));
+        sj.recon = h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz; sj.fenc = h_src[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz;
+        sj.avail = R.available(R.cuX, R.cuY, R.size);
+        sj.recon_stride = (int32_t)stride; sj.fenc_stride = (int32_t)stride; sj.log2_tr_size = (uint8_t)R.log2; sj.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
+        int32_t sa8d[35];
+        if (hipMemcpyAsync(R.dScanJob.p, &sj, sizeof(sj), hipMemcpyHostToDevice, R.st) != hipSuccess ||
+            x265amd_intra_scan(R.st, (const x265amd_intra_job*)R.dScanJob.p, 1, (int32_t*)R.dScan.p, nullptr) != X265AMD_OK ||
+            hipMemcpyAsync(sa8d, R.dScan.p, sizeof(sa8d), hipMemcpyDeviceToHost, R.st) != hipSuccess || hipStreamSynchronize(R.st) != hipSuccess)
+            rc = xa_fail(X265AMD_EHIP, "intra_in_inter: mode scan");
+        if (rc == X265AMD_OK)
+        {
+            /* loadIntraDirModeLuma + getIntraRemModeBits + bitsIntraModeMPM / NonMPM (entropy.h:196-197, :219-224) */
+            uint32_t preds[3];
+            coder->lumaPreds(R.cuX, R.cuY, preds);
+            const uint64_t frac = R.cur.frac & 32767;
+            const uint8_t adi = R.cur.ctx[C_ADI];
+            const uint32_t rbits = (uint32_t)((frac + k_bits[adi ^ 0]) >> 15) + 5;
+            const uint32_t mpmBase = (uint32_t)((frac + k_bits[adi ^ 1]) >> 15);
+            auto modeBits = [&](uint32_t mode) {
+                for (int i = 0; i < 3; i++) if (preds[i] == mode) return mpmBase + (mode == preds[0] ? 1u : 2u);
+                return rbits;
+            };
+            static const uint8_t order[35] = { 1, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34 };
+            for (int k = 0; k < 35; k++)
+            {
+                const uint32_t mode = order[k], sad = (uint32_t)sa8d[mode], b = modeBits(mode);
+                const uint64_t cst = R.calcRdSADCost(sad, b);
+                if (!k || cst < bcost) { bcost = cst; bmode = mode; bsad = sad; bbits = b; }
+            }
+            if (info) { info[0] = bmode; info[1] = bcost; info[2] = bbits; info[3] = bsad; }
+        }
+    }
+
+    /* ---- encodeIntraInInter ---- */
+    if (rc == X265AMD_OK)
+    {
+        for (int yy = 0; yy < u4; yy++)
+            for (int xx = 0; xx < u4; xx++)
+            {
+                x265amd_cu_unit& u = units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2) + xx];
+                memset(&u, 0, sizeof(u));
+                u.depth = (uint8_t)R.depth; u.pred_mode = X265AMD_MODE_INTRA; u.part_size = 0; u.luma_dir = (uint8_t)bmode; u.chroma_dir = 36; u.qp = (int8_t)R.qp;
+                u.ref_idx[0] = u.ref_idx[1] = -1;
+            }
+        R.load(R.cur);
+        Cost icosts = { 0, 0, 0, 0 };
+        sse_t chromaDist = 0;
+        rc = R.codeIntraLumaQT(R.cuX, R.cuY, 0, false, icosts);
+        std::vector<int16_t> coeffCu(4096 + 2048, 0);
+        if (rc == X265AMD_OK)
+        {
+            R.extractLuma(R.cuX, R.cuY, 0, coeffCu.data());
+            R.copy2D(d_recon, 64, h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz, stride, R.size, R.size);
+            rc = R.estIntraPredChromaQT(chromaDist);
+        }
+        if (rc == X265AMD_OK)
+        {
+            memcpy(coeffCu.data() + 4096, R.coeffCBest[0].data(), sizeof(int16_t) * 1024);
+            memcpy(coeffCu.data() + 5120, R.coeffCBest[1].data(), sizeof(int16_t) * 1024);
+            x265amd_cu_unit& u0 = units[(R.cuY >> 2) * w4 + (R.cuX >> 2)];
+            R.resetBits();
+            const x265amd_cu_unit* l = coder->at((R.cuX >> 2) - 1, R.cuY >> 2);
+            const x265amd_cu_unit* a = coder->at(R.cuX >> 2, (R.cuY >> 2) - 1);
+            const int skipCtx = (x265amd_cabac::coded(l) && l->pred_mode == X265AMD_MODE_SKIP) + (x265amd_cabac::coded(a) && a->pred_mode == X265AMD_MODE_SKIP);
+            coder->bin(0, C_SKIP + skipCtx);
+            const uint32_t skipFlagBits = R.bits();
+            coder->bin(1, C_PRED_MODE);
+            coder->partSize(u0, R.depth, R.size);
+            coder->predInfo(R.cuX, R.cuY, R.size, u0);
+            const uint32_t mvBits = R.bits() - skipFlagBits;
+            bool dqp = si->use_dqp != 0;
+            coder->coeffCtu[0] = coeffCu.data(); coder->coeffCtu[1] = coeffCu.data() + 4096; coder->coeffCtu[2] = coeffCu.data() + 5120;
+            coder->ctuX0 = R.cuX; coder->ctuY0 = R.cuY;
+            coder->transform(R.cuX, R.cuY, R.cuX, R.cuY, 0, R.log2, dqp, R.range);
+            memset(out, 0, sizeof(*out));
+            out->total_bits = R.bits(); out->mv_bits = mvBits; out->coeff_bits = out->total_bits - mvBits - skipFlagBits;
+            out->luma_distortion = (uint32_t)icosts.distortion; out->chroma_distortion = (uint32_t)chromaDist;
+            const sse_t distortion = icosts.distortion + chromaDist;
+            out->distortion = distortion;
+            /* psy energy of the reconstruction, residual energy of the prediction (luma) */
+            x265amd_rd_cu mc = *cu;
+            x265amd_cu_measure mr, mp;
+            if (x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_recon, 0, &mr) != X265AMD_OK || x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_pred, 0, &mp) != X265AMD_OK)
+                rc = X265AMD_EHIP;
+            out->psy_energy = R.psyRd ? mr.psy : 0;
+            out->res_energy = (uint32_t)(sse_t)mp.sse[0];
+            out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
+            /* checkDQP (search.cpp:3974-4003) */
+            if (si->use_dqp && R.depth <= si->max_cu_dqp_depth)
+            {
+                const bool rootCbf = u0.cbf[0] || u0.cbf[1] || u0.cbf[2];
+                if (rootCbf)
+                {
+                    if (rp->rd_level >= 3) { R.resetBits(); coder->deltaQP(R.cuX, R.cuY); out->total_bits += R.bits(); }
+                    else if (rp->rd_level == 2) out->total_bits++;
+                    out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
+                }
+                else
+                {
+                    const int8_t q = (int8_t)coder->refQP(R.cuX, R.cuY);
+                    for (int yy = 0; yy < u4; yy++) for (int xx = 0; xx < u4; xx++) units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2) + xx].qp = q;
+                }
+            }
+            memcpy(out->ctx, coder->ctx, X265AMD_CTX_COUNT);
+            out->frac_bits = coder->fracBits;
+            if (coeff_out) memcpy(coeff_out, coeffCu.data(), sizeof(int16_t) * (4096 + 2048));
+        }
+    }
+    for (int yy = 0; yy < u4; yy++)
+    {
+        memcpy(&cu_units[(size_t)yy * u4], &units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], sizeof(x265amd_cu_unit) * u4);
+        memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
+    }
+    if (rc == X265AMD_OK && hipStreamSynchronize(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra_in_inter: synchronize");
+    x265amd_cabac_close(coder);
+    delete ip;
+    return rc;
+}

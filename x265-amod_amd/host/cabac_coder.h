@@ -338,47 +338,57 @@ struct x265amd_cabac
         }
     }
 
+    /* codeIntraDirLumaAng (:1592-1642) for the partitions whose first samples are (px[j], py[j]) */
+    void intraDirLuma(const int* px, const int* py, int partNum)
+    {
+        uint32_t dir[4], preds[4][3]; int predIdx[4];
+        for (int j = 0; j < partNum; j++)
+        {
+            dir[j] = U(px[j] >> 2, py[j] >> 2).luma_dir;
+            lumaPreds(px[j], py[j], preds[j]);
+            predIdx[j] = -1;
+            for (int i = 0; i < 3; i++) if (dir[j] == preds[j][i]) predIdx[j] = i;
+            bin(predIdx[j] != -1, C_ADI);
+        }
+        for (int j = 0; j < partNum; j++)
+        {
+            if (predIdx[j] != -1) { const int nz = !!predIdx[j]; binsEP((uint32_t)(predIdx[j] + nz), 1 + nz); }
+            else
+            {
+                uint32_t* p = preds[j];
+                if (p[0] > p[1]) { uint32_t t = p[0]; p[0] = p[1]; p[1] = t; }
+                if (p[0] > p[2]) { uint32_t t = p[0]; p[0] = p[2]; p[2] = t; }
+                if (p[1] > p[2]) { uint32_t t = p[1]; p[1] = p[2]; p[2] = t; }
+                uint32_t d = dir[j];
+                d -= d > p[2]; d -= d > p[1]; d -= d > p[0];
+                binsEP(d, 5);
+            }
+        }
+    }
+    /* codeIntraDirChroma with getAllowedChromaDir (:1644-1664, cudata.cpp:889-907) */
+    void intraDirChroma(const x265amd_cu_unit& u)
+    {
+        uint32_t c = u.chroma_dir;
+        if (c == 36) bin(0, C_CHROMA_PRED);
+        else
+        {
+            uint32_t list[4] = { 0, 26, 10, 1 };
+            for (int i = 0; i < 4; i++) if (u.luma_dir == list[i]) { list[i] = 34; break; }
+            for (uint32_t i = 0; i < 4; i++) if (c == list[i]) { c = i; break; }
+            bin(1, C_CHROMA_PRED);
+            binsEP(c, 2);
+        }
+    }
+
     void predInfo(int x, int y, int size, const x265amd_cu_unit& u)     /* codePredInfo / codePUWise (:1138-1197) */
     {
         if (u.pred_mode == X265AMD_MODE_INTRA)
         {
-            /* codeIntraDirLumaAng (:1592-1642) */
             const int partNum = u.part_size != PART_2Nx2N ? 4 : 1;
-            uint32_t dir[4], preds[4][3]; int predIdx[4];
-            for (int j = 0; j < partNum; j++)
-            {
-                const int px = x + (j & 1) * size / 2, py = y + (j >> 1) * size / 2;
-                dir[j] = U(px >> 2, py >> 2).luma_dir;
-                lumaPreds(px, py, preds[j]);
-                predIdx[j] = -1;
-                for (int i = 0; i < 3; i++) if (dir[j] == preds[j][i]) predIdx[j] = i;
-                bin(predIdx[j] != -1, C_ADI);
-            }
-            for (int j = 0; j < partNum; j++)
-            {
-                if (predIdx[j] != -1) { const int nz = !!predIdx[j]; binsEP((uint32_t)(predIdx[j] + nz), 1 + nz); }
-                else
-                {
-                    uint32_t* p = preds[j];
-                    if (p[0] > p[1]) { uint32_t t = p[0]; p[0] = p[1]; p[1] = t; }
-                    if (p[0] > p[2]) { uint32_t t = p[0]; p[0] = p[2]; p[2] = t; }
-                    if (p[1] > p[2]) { uint32_t t = p[1]; p[1] = p[2]; p[2] = t; }
-                    uint32_t d = dir[j];
-                    d -= d > p[2]; d -= d > p[1]; d -= d > p[0];
-                    binsEP(d, 5);
-                }
-            }
-            /* codeIntraDirChroma with getAllowedChromaDir (:1644-1664, cudata.cpp:889-907) */
-            uint32_t c = u.chroma_dir;
-            if (c == 36) bin(0, C_CHROMA_PRED);
-            else
-            {
-                uint32_t list[4] = { 0, 26, 10, 1 };
-                for (int i = 0; i < 4; i++) if (u.luma_dir == list[i]) { list[i] = 34; break; }
-                for (uint32_t i = 0; i < 4; i++) if (c == list[i]) { c = i; break; }
-                bin(1, C_CHROMA_PRED);
-                binsEP(c, 2);
-            }
+            int px[4], py[4];
+            for (int j = 0; j < partNum; j++) { px[j] = x + (j & 1) * size / 2; py[j] = y + (j >> 1) * size / 2; }
+            intraDirLuma(px, py, partNum);
+            intraDirChroma(u);
             return;
         }
         /* inter: every PU */
