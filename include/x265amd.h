@@ -663,13 +663,14 @@ int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x26
  * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N
  * (:3145-3277), topSkipMinDepth (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426).  Host recursion in the
  * reference's order over the batch entry points above; one CTU per call.
- * Built subset: B slices without intra candidates (b_intra 0), 2Nx2N partitions (rect / amp 0), limit_refs 0-3, limit_modes 0, no delta QP,
+ * Built subset: P and B slices (b_intra 0 / 1), 2Nx2N partitions (rect / amp 0), limit_refs 0-3, limit_modes 0, no delta QP,
  * rd_level 3-4, rskip 0 / 1, early_skip 0 / 1.  Anything else is rejected with X265AMD_EINVAL. */
 typedef struct x265amd_analysis_params
 {
     double psy_rd;                  /* param.psyRd */
     int32_t rd_level, early_skip, rskip, limit_refs, b_intra, rect, amp, limit_modes;
-} x265amd_analysis_params;          /* 40 bytes */
+    int32_t strong_intra_smoothing, reserved;   /* sps.bUseStrongIntraSmoothing */
+} x265amd_analysis_params;          /* 48 bytes */
 typedef struct x265amd_cu_stat { uint32_t count[4]; uint32_t pad[2]; uint64_t avg_cost[4]; } x265amd_cu_stat;     /* FrameData::RCStatCU count / avgCost per depth */
 typedef struct x265amd_ctu_result { uint64_t rd_cost, distortion, frac_bits; uint32_t total_bits, reserved; uint8_t ctx[X265AMD_CTX_STRIDE]; } x265amd_ctu_result;
 /* units / cur: the picture's unit map and motion field (what is coded so far); the CTU's part is reset and then filled with the decisions.

@@ -1352,7 +1352,7 @@ void ref_skip_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit*
 /* ---- Analysis::compressCTU (encoder/analysis.cpp:138-317 -> compressInterCU_rd0_4 :1146-1848 with checkMerge2Nx2N_rd0_4, checkInter_rd0_4,
  * checkBidir2Nx2N and the Search methods below them) itself, for one CTU of an inter slice, on a fixture: picture CUData from the raster
  * unit + motion maps (what is coded so far), reference pictures, their motion / depth maps, the source picture ---- */
-struct RefAnalysisParams { double psyRd; int32_t rdLevel, earlySkip, rskip, limitRefs, bIntraInB, rect, amp, limitModes; };
+struct RefAnalysisParams { double psyRd; int32_t rdLevel, earlySkip, rskip, limitRefs, bIntraInB, rect, amp, limitModes, strongIntraSmoothing, reserved; };
 struct RefCuStat { uint32_t count[4]; uint32_t pad; uint64_t avgCost[4]; };
 struct RefCtuResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, reserved; uint8_t ctx[160]; };
 /* planes: numPics x 3 addresses of sample (0,0); picture numPics-1 is the source, numPics-2 the reconstruction being written.
@@ -1382,6 +1382,8 @@ void ref_compress_ctu(const RefMvInfo* I, const RefSearchParams* S, const RefSli
     f.sps.quadtreeTULog2MaxSize = si->tuLog2Max; f.sps.quadtreeTULog2MinSize = si->tuLog2Min;
     f.sps.quadtreeTUMaxDepthInter = si->tuMaxDepthInter; f.sps.quadtreeTUMaxDepthIntra = si->tuMaxDepthIntra; f.sps.maxAMPDepth = si->maxAmpDepth;
     f.sps.log2MinCodingBlockSize = 3; f.sps.log2DiffMaxMinCodingBlockSize = 3;
+    f.sps.bUseStrongIntraSmoothing = A->strongIntraSmoothing != 0; param->bEnableStrongIntraSmoothing = A->strongIntraSmoothing; param->bEnableFastIntra = 0;
+    param->bEnableConstrainedIntra = 0; param->rdPenalty = 0;
     f.pps.bUseDQP = si->useDqp != 0; f.pps.maxCuDQPDepth = si->maxCuDqpDepth; f.pps.bSignHideEnabled = si->signHide != 0;
     f.pps.bTransquantBypassEnabled = 0; f.pps.bTransformSkipEnabled = 0; f.pps.bEntropyCodingSyncEnabled = si->wpp != 0;
     Slice* slice = f.fd[0]->m_slice;

@@ -2355,13 +2355,13 @@ def skip_run_hip(L, c):
 
 # ---- CTU analysis of inter slices (x265amd_compress_ctu_inter vs Analysis::compressCTU) ----
 ANALYSIS_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("early_skip", "<i4"), ("rskip", "<i4"), ("limit_refs", "<i4"), ("b_intra", "<i4"),
-                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4")])
+                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4"), ("strong", "<i4"), ("reserved", "<i4")])
 CU_STAT_DT = np.dtype([("count", "<u4", 4), ("pad", "<u4", 2), ("avg_cost", "<u8", 4)])
 CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("reserved", "<u4"), ("ctx", "u1", 160)])
-assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 40
+assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 48
 
 
-def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0):
+def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1):
     """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
     the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
     rng = np.random.default_rng(seed + 901)
@@ -2431,7 +2431,7 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
             rp[l, r] = (r + l) % 3
     sp["refPic"] = rp
     ap = np.zeros(1, ANALYSIS_PARAMS_DT)
-    ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"] = psy_rd, 3, early_skip, rskip, limit_refs, 0
+    ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = psy_rd, 3, early_skip, rskip, limit_refs, b_intra, strong
     # reference pictures' CU depths (two lists) and CTU QPs; running cost statistics of the CTUs coded so far
     ref_depth = np.zeros((2, h4, w4), np.uint8)
     for l in range(2):
@@ -2558,9 +2558,12 @@ def ctu_pack(results):
                 n = 16 >> int(u["depth"][y, x])
                 first[y, x] = (x % n == 0) and (y % n == 0)
         d = dict(res=np.array([int(r["rd_cost"]), int(r["distortion"]), int(r["total_bits"]), int(r["frac_bits"])], np.uint64), ctx=r["ctx"][:CTX_COUNT].copy(),
-                 units=np.concatenate([u[f].astype(np.int16).reshape(256, -1) for f in ("depth", "pred_mode", "part_size", "tu_depth", "cbf", "inter_dir", "ref_idx", "qp")], 1),
+                 units=np.concatenate([u[f].astype(np.int16).reshape(256, -1) * (1 if f not in ("inter_dir", "ref_idx") else (u["pred_mode"].reshape(256, 1) != MODE_INTRA))
+                                       for f in ("depth", "pred_mode", "part_size", "tu_depth", "cbf", "inter_dir", "ref_idx", "qp")], 1),
                  first=_ctu_first_fields(u, first),
-                 motion=np.concatenate([m[f].astype(np.int16).reshape(256, -1) for f in ("pred_mode", "inter_dir", "ref_idx", "mv")], 1),
+                 motion=np.concatenate([m[f].astype(np.int16).reshape(256, -1) * (1 if f == "pred_mode" else (m["pred_mode"].reshape(256, 1) != MODE_INTRA))
+                                        for f in ("pred_mode", "inter_dir", "ref_idx", "mv")], 1),
+                 intra=np.stack([u[f].astype(np.int16).reshape(256) * (u["pred_mode"].reshape(256) == MODE_INTRA) for f in ("luma_dir", "chroma_dir")], 1),
                  recon=np.concatenate([p.astype(np.uint16).ravel() for p in rec]),
                  stat=np.concatenate([st["count"].astype(np.uint64).ravel(), st["avg_cost"].ravel()]))
         # levels of coded blocks only: mask by the luma / chroma coded block flags at each unit's own transform depth

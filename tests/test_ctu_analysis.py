@@ -8,15 +8,17 @@ import pytest
 
 import hevc_testlib as T
 
-# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth, limit-refs)
+# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth, limit-refs[, B slice, b-intra])
 CASES = [(8, 1, 1, 1, 2.0, 1, 0), (8, 2, 0, 1, 2.0, 2, 0), (8, 3, 1, 0, 0.0, 1, 0), (10, 4, 0, 1, 2.0, 1, 0), (8, 5, 1, 1, 1.0, 3, 0), (8, 6, 0, 0, 2.0, 1, 0),
-         (8, 7, 1, 1, 2.0, 1, 3), (8, 8, 0, 0, 2.0, 1, 3), (10, 9, 0, 1, 0.0, 2, 1), (8, 10, 0, 1, 2.0, 1, 2)]
+         (8, 7, 1, 1, 2.0, 1, 3), (8, 8, 0, 0, 2.0, 1, 3), (10, 9, 0, 1, 0.0, 2, 1), (8, 10, 0, 1, 2.0, 1, 2),
+         (8, 11, 1, 1, 2.0, 1, 3, 0, 0), (8, 12, 0, 1, 2.0, 1, 0, 0, 0), (10, 13, 0, 0, 0.0, 2, 3, 0, 0), (8, 14, 0, 1, 2.0, 1, 3, 1, 1), (8, 15, 1, 0, 1.0, 1, 0, 1, 1)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 
 def make_case(k):
-    depth, seed, es, rs, psy, td, lr = CASES[k]
-    return T.ctu_case(depth, seed, early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr)
+    depth, seed, es, rs, psy, td, lr = CASES[k][:7]
+    is_b, b_intra = (CASES[k][7], CASES[k][8]) if len(CASES[k]) > 7 else (1, 0)
+    return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr, b_intra=b_intra)
 
 
 def test_golden_outcomes_are_varied():
@@ -33,7 +35,8 @@ def test_golden_outcomes_are_varied():
 def test_hip_compress_ctu_inter_matches_reference_golden():
     gold = np.load(GOLD_PATH)
     mes = {}
-    for k, (depth, seed, es, rs, psy, td, lr) in enumerate(CASES):
+    for k, cfg in enumerate(CASES):
+        depth = cfg[0]
         if depth not in mes:
             mes[depth] = T.HipME(depth)
         c = make_case(k)

@@ -8,14 +8,13 @@
  * The recursion, the candidate order and every comparison are the reference's and run on the host; every block operation is one of
  * the batch entry points of this library: x265amd_merge_candidates (host), x265amd_motion_compensation + x265amd_measure_tiles (merge
  * candidates, bi-prediction tries, SA8D of finished predictions), x265amd_pred_inter_search_ex (the 2Nx2N search),
- * x265amd_skip_rd / x265amd_inter_residual_rd (RD of the chosen candidates).  Each mode of each depth owns a prediction and a
+ * x265amd_skip_rd / x265amd_inter_residual_rd / x265amd_intra_in_inter (RD of the chosen candidates).  Each mode of each depth owns a prediction and a
  * reconstruction tile in device memory; the best mode's units, motion and reconstruction are written into the picture maps / the
  * reconstructed picture at the end of every CU, exactly when the reference's copyToPic does, so later neighbours see what the
  * reference's would.
  *
- * Scope of this entry point: B slices without intra candidates (--no-b-intra), 2Nx2N partitions (no --rect / --amp), --limit-refs 0-3,
- * no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.  P slices need the intra candidates (checkIntraInInter /
- * encodeIntraInInter), which are not built yet: rejected.
+ * Scope of this entry point: P and B slices (intra candidates through x265amd_intra_in_inter; --b-intra on / off), 2Nx2N partitions
+ * (no --rect / --amp), --limit-refs 0-3, no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.
  */
 #include "x265amd_dev.h"
 #include "inter_common.h"
@@ -33,7 +32,7 @@ typedef uint32_t sse_t;
 typedef uint64_t sse_t;
 #endif
 
-enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_SPLIT, NUM_PRED };
+enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_INTRA, PRED_SPLIT, NUM_PRED };
 const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
 const int kTileElems = 4096 + 2048;
 
@@ -226,6 +225,35 @@ struct Analyzer
         m.contexts.frac = r.frac_bits;
         const int n4 = 16 >> depth;
         for (int i = 0; i < n4 * n4; i++) m.m[i].pred_mode = m.u[i].pred_mode;
+        return 0;
+    }
+
+    /* checkIntraInInter + encodeIntraInInter */
+    int rdIntra(Mode& m, int x, int y, int depth)
+    {
+        x265amd_rd_cu c;
+        memset(&c, 0, sizeof(c));
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
+        memcpy(c.ctx, md[depth].cur.ctx, X265AMD_CTX_COUNT);
+        c.frac_bits = md[depth].cur.frac;
+        x265amd_rd_result r;
+        m.initCosts();
+        m.predTile = predTile(depth, PRED_INTRA); m.reconTile = reconTile(depth, PRED_INTRA);
+        uint64_t info[4];
+        const int rc = x265amd_intra_in_inter(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, m.u, tileAddr(m.predTile),
+                                              tileAddr(m.reconTile), &r, m.coeff.data(), info);
+        if (rc != X265AMD_OK) return err = rc;
+        m.sa8dCost = info[1]; m.sa8dBits = (uint32_t)info[2];
+        m.rdCost = r.rd_cost; m.distortion = (sse_t)r.distortion; m.totalBits = r.total_bits; m.mvBits = r.mv_bits; m.coeffBits = r.coeff_bits;
+        m.psyEnergy = r.psy_energy; m.lumaDistortion = r.luma_distortion; m.chromaDistortion = r.chroma_distortion; m.resEnergy = r.res_energy;
+        memcpy(m.contexts.ctx, r.ctx, X265AMD_CTX_STRIDE);
+        m.contexts.frac = r.frac_bits;
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++)
+        {
+            memset(&m.m[i], 0, sizeof(x265amd_mv_unit));
+            m.m[i].pred_mode = X265AMD_MODE_INTRA; m.m[i].ref_idx[0] = m.m[i].ref_idx[1] = -1;
+        }
         return 0;
     }
 
@@ -453,7 +481,7 @@ struct Analyzer
         const bool mightSplit = depth < si->max_cu_depth;
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
         const uint32_t minDepth = topSkipMinDepth(x, y, depth);
-        bool skipModes = false, skipRecursion = false;
+        bool skipModes = false, skipRecursion = false, splitIntra = true;
         uint32_t splitRefs[4] = { 0, 0, 0, 0 };
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
 
@@ -477,6 +505,7 @@ struct Analyzer
             split.predTile = predTile(depth, PRED_SPLIT); split.reconTile = reconTile(depth, PRED_SPLIT);
             const int n4 = 16 >> depth, half = size >> 1, h4n = n4 >> 1;
             const Snap* nextContext = &d.cur;
+            splitIntra = false;
             for (int q = 0; q < 4; q++)
             {
                 const int cx = x + (q & 1) * half, cy = y + (q >> 1) * half;
@@ -485,6 +514,7 @@ struct Analyzer
                     md[depth + 1].cur = *nextContext;
                     if (compress(cx, cy, depth + 1, splitRefs[q])) return err;
                     const Mode& nb = *md[depth + 1].best;
+                    splitIntra |= nb.u[0].pred_mode == X265AMD_MODE_INTRA;
                     for (int yy = 0; yy < h4n; yy++)
                         for (int xx = 0; xx < h4n; xx++)
                         {
@@ -524,6 +554,13 @@ struct Analyzer
                     if (rdInter(bidir, x, y, depth, false)) return err;
                     checkBestMode(bidir, depth);
                 }
+                const bool bTryIntra = (!I->is_inter_b || A->b_intra) && log2 != 6;
+                const x265amd_cu_unit& b0 = d.best->u[0];
+                if (bTryIntra && (b0.cbf[0] || b0.cbf[1] || b0.cbf[2]) && (!A->limit_refs || splitIntra))
+                {
+                    if (rdIntra(d.pred[PRED_INTRA], x, y, depth)) return err;
+                    checkBestMode(d.pred[PRED_INTRA], depth);
+                }
             }
             if (mightSplit) addSplitFlagCost(*d.best, x, y, depth);
         }
@@ -535,7 +572,8 @@ struct Analyzer
         }
         /* which motion references the parent CU should search (X265_REF_LIMIT_DEPTH) */
         splitRefsOut = 0;
-        if (A->limit_refs & 1) splitRefsOut = d.best == &d.pred[PRED_SPLIT] ? allSplitRefs : bestRefIdx(d.best->u[0]);
+        if (A->limit_refs & 1)
+            splitRefsOut = d.best == &d.pred[PRED_SPLIT] ? allSplitRefs : bestRefIdx(d.best->u[0].pred_mode == X265AMD_MODE_INTRA ? d.pred[PRED_2Nx2N].u[0] : d.best->u[0]);
         if (mightNotSplit && d.best->isSkipped())
         {
             x265amd_cu_stat& cs = cuStat[ctuAddr];
@@ -559,7 +597,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
 {
     if (!me || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 3)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
-    if (!I->is_inter_b || A->b_intra) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: intra candidates in inter slices are not built (B slices with b_intra = 0 only)");
+    if ((si->slice_type == 0) != (I->is_inter_b != 0) || si->slice_type == 2) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
     if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs < 0 || A->limit_refs > 3 || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, 2Nx2N only, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
@@ -582,7 +620,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         uint64_t rd[6];
         x265amd_rdcost(a.qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
         a.lambda2 = rd[0]; a.lambda = rd[1]; a.psyRd = (uint32_t)rd[2];
-        a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = 0;
+        a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = A->strong_intra_smoothing;
         /* CUData::initCTU: nothing of this CTU is decided yet */
         for (int yy = a.ctuY >> 2; yy < (a.ctuY >> 2) + 16 && yy < a.h4; yy++)
             for (int xx = a.ctuX >> 2; xx < (a.ctuX >> 2) + 16 && xx < a.w4; xx++)
