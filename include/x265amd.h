@@ -659,6 +659,14 @@ int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x26
                            const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
                            x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info);
 
+/* Search::checkIntra (reference: source/encoder/search.cpp:1236-1287) with estIntraPredQT (:1509-1696): the intra CU of I slices and of the
+ * rd 5-6 paths.  part_size 0 (2Nx2N) or 3 (NxN, 8x8 CUs): per partition the 35-mode scan, the candidate list (updateCandList, at most
+ * 2 + rd_level + depth / 2 modes within 25 % of the best or MPM[0]), simple RDO of each candidate, then the winner again with transform
+ * splits allowed; chroma and the CU's bits as x265amd_intra_in_inter.  Arguments as x265amd_intra_in_inter. */
+int x265amd_check_intra(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                        const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, int part_size,
+                        x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out);
+
 /* --- CTU mode decision of inter slices: Analysis::compressCTU -> compressInterCU_rd0_4 (reference:
  * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N
  * (:3145-3277), topSkipMinDepth (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426).  Host recursion in the

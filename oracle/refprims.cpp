@@ -1156,7 +1156,7 @@ struct RefRdParams { double psyRd; int32_t rdLevel, reserved; };
 struct RefRdResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, mvBits, coeffBits, psyEnergy, lumaDist, chromaDist, resEnergy, reserved; uint8_t ctx[160]; };
 /* srcPlanes: addresses of sample (0,0) of the source Y, U, V.  predY/U/V: strides 64 / 32.  cuUnitsOut: the CU's units after the call, raster within the
  * CU (row length size/4).  coeffOut: 4096 + 2 * 1024 levels in CUData::m_trCoeff layout.  reconY/U/V: strides 64 / 32. */
-static const uint64_t* g_rdReconPlanes = NULL; static int g_rdStrongSmoothing = 0; static uint64_t* g_rdIntraInfo = NULL; static pixel* g_rdPredOut = NULL;
+static const uint64_t* g_rdReconPlanes = NULL; static int g_rdStrongSmoothing = 0; static uint64_t* g_rdIntraInfo = NULL; static pixel* g_rdPredOut = NULL; static int g_rdPartSize = 0;
 static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,
                            int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, const pixel* predY, const pixel* predU, const pixel* predV,
                            RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
@@ -1197,7 +1197,7 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
     PicYuv* src = mkPic(param, sps, srcPlanes, stride, cstride, width, height, 0, 0);
     frame.m_fencPic = src;
     PicYuv* rec = NULL;
-    if (skipCU == 2)
+    if (skipCU >= 2)
     {
         rec = mkPic(param, sps, g_rdReconPlanes, stride, cstride, width, height, 0, 0);
         frame.m_reconPic = rec; fd->m_reconPic = rec;
@@ -1254,7 +1254,7 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
         mode->fencYuv = &fenc;
         mode->cu.initSubCU(ctu, *g, qp);
         /* the candidate's fields, copied from the picture CTU (initSubCU resets them) */
-        for (uint32_t i = 0; skipCU != 2 && i < g->numPartitions; i++)
+        for (uint32_t i = 0; skipCU < 2 && i < g->numPartitions; i++)
         {
             const uint32_t z = absPartIdx + i;
             mode->cu.m_predMode[i] = ctu.m_predMode[z]; mode->cu.m_partSize[i] = ctu.m_partSize[z]; mode->cu.m_mergeFlag[i] = ctu.m_mergeFlag[z];
@@ -1281,6 +1281,11 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
             search->encodeIntraInInter(*mode, *g);
             for (int y = 0; y < (1 << log2CU); y++) memcpy(g_rdPredOut + y * 64, mode->predYuv.m_buf[0] + y * mode->predYuv.m_size, (1 << log2CU) * sizeof(pixel));
         }
+        else if (skipCU == 3)
+        {
+            search->checkIntra(*mode, *g, (PartSize)g_rdPartSize);
+            for (int y = 0; y < (1 << log2CU); y++) memcpy(g_rdPredOut + y * 64, mode->predYuv.m_buf[0] + y * mode->predYuv.m_size, (1 << log2CU) * sizeof(pixel));
+        }
         else if (skipCU) search->encodeResAndCalcRdSkipCU(*mode);
         else search->encodeResAndCalcRdInterCU(*mode, *g);
         memset(out, 0, sizeof(*out));
@@ -1297,7 +1302,7 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
             const int pm = mode->cu.m_predMode[i];
             u.predMode = pm == MODE_SKIP ? 3 : (pm == MODE_INTRA ? 2 : (pm == MODE_INTER ? 1 : 0));
             u.tuDepth = mode->cu.m_tuDepth[i]; u.qp = mode->cu.m_qp[i];
-            if (skipCU == 2) { u.partSize = mode->cu.m_partSize[i]; u.lumaDir = mode->cu.m_lumaIntraDir[i]; u.chromaDir = mode->cu.m_chromaIntraDir[i]; u.depth = (uint8_t)depth; u.mergeFlag = 0; u.interDir = 0; }
+            if (skipCU >= 2) { u.partSize = mode->cu.m_partSize[i]; u.lumaDir = mode->cu.m_lumaIntraDir[i]; u.chromaDir = mode->cu.m_chromaIntraDir[i]; u.depth = (uint8_t)depth; u.mergeFlag = 0; u.interDir = 0; }
             for (int c = 0; c < 3; c++) u.cbf[c] = mode->cu.m_cbf[c][i];
         }
         memcpy(coeffOut, mode->cu.m_trCoeff[0], n * n * sizeof(int16_t));
@@ -1333,6 +1338,17 @@ void ref_intra_in_inter(const RefSliceInfo* si, const RefRdParams* rp, const Ref
     static pixel dummy[64 * 64];
     g_rdReconPlanes = reconPlanes; g_rdStrongSmoothing = strongSmoothing; g_rdIntraInfo = info; g_rdPredOut = predY;
     rd_fixture_run(2, si, rp, units, srcPlanes, stride, cstride, cuX, cuY, log2CU, qp, ctxIn, fracIn, dummy, dummy, dummy, cuUnitsOut, coeffOut, reconY, reconU, reconV, out);
+}
+
+/* Search::checkIntra (encoder/search.cpp:1236-1287: estIntraPredQT, estIntraPredChromaQT, the CU's bits) on the same fixture; partSize 0 / 3 */
+void ref_check_intra(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, const uint64_t* reconPlanes, intptr_t stride,
+                     intptr_t cstride, int cuX, int cuY, int log2CU, int qp, const uint8_t* ctxIn, uint64_t fracIn, int strongSmoothing, int partSize,
+                     RefCuUnit* cuUnitsOut, int16_t* coeffOut, pixel* predY, pixel* reconY, pixel* reconU, pixel* reconV, RefRdResult* out)
+{
+    static pixel dummy[64 * 64];
+    static uint64_t info[4];
+    g_rdReconPlanes = reconPlanes; g_rdStrongSmoothing = strongSmoothing; g_rdIntraInfo = info; g_rdPredOut = predY; g_rdPartSize = partSize;
+    rd_fixture_run(3, si, rp, units, srcPlanes, stride, cstride, cuX, cuY, log2CU, qp, ctxIn, fracIn, dummy, dummy, dummy, cuUnitsOut, coeffOut, reconY, reconU, reconV, out);
 }
 
 void ref_inter_residual_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit* units, const uint64_t* srcPlanes, intptr_t stride, intptr_t cstride,

@@ -261,6 +261,14 @@ def make_intra_rd_golden():
                 out["%d/%d/%s" % (k, i, name)] = a
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_rd_golden.npz"), **out)
     print("wrote intra_rd_golden.npz with", len(out), "arrays")
+    out = {}
+    for k, (depth, seed, st, psy, strong) in enumerate(tir.CHECK_CASES):
+        c = T.check_intra_case(depth, seed, st, psy, strong=strong)
+        for i, d in enumerate(T.intra_rd_pack(T.check_intra_run_ref(T.load_ref(depth), c), c)):
+            for name, a in d.items():
+                out["%d/%d/%s" % (k, i, name)] = a
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "check_intra_golden.npz"), **out)
+    print("wrote check_intra_golden.npz with", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -2659,3 +2659,56 @@ def intra_rd_pack(r, c):
         # an intra CU's levels are always exported
         d["coeff"] = np.concatenate([coeff[i][:S * S], coeff[i][4096:4096 + S * S // 4], coeff[i][5120:5120 + S * S // 4]])
     return base
+
+
+# ---- Search::checkIntra (I slices / rd 5-6): x265amd_check_intra ----
+def check_intra_case(depth, seed, slice_type, psy_rd, ncu=10, strong=1):
+    c = intra_rd_case(depth, seed, slice_type, psy_rd, ncu=ncu, strong=strong)
+    rng = np.random.default_rng(seed + 717)
+    c["parts"] = [3 if (int(c["cus"][i]["log2_size"]) == 3 and rng.integers(0, 2)) else 0 for i in range(ncu)]
+    return c
+
+
+def check_intra_run_ref(R, c):
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    res = np.zeros(n, RD_RESULT_DT); uo = np.zeros((n, 256), CU_UNIT_DT); coeff = np.zeros((n, RD_TILE), np.int16); recon = np.zeros((n, RD_TILE), dt)
+    pred = np.zeros((n, 4096), dt); info = np.zeros((n, 4), np.uint64)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    planes = np.array([p.ctypes.data for p in c["src"]], np.uint64)
+    for i in range(n):
+        cu = c["cus"][i]
+        rec = [p.copy() for p in c["rec"]]
+        rplanes = np.array([p.ctypes.data for p in rec], np.uint64)
+        ctx = np.zeros(160, np.uint8); ctx[:] = cu["ctx"]
+        m = np.ascontiguousarray(c["units"])
+        R.lib.ref_check_intra(_ptr(si), _ptr(c["rp"]), _ptr(m), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                              int(cu["x"]), int(cu["y"]), int(cu["log2_size"]), int(cu["qp"]), _ptr(ctx), C.c_uint64(int(cu["frac_bits"])), int(c["rp"]["strong"][0]),
+                              int(c["parts"][i]), off(uo[i], 0), off(coeff[i], 0), off(pred[i], 0), off(recon[i], 0), off(recon[i], 4096), off(recon[i], 4096 + 1024), off(res, i))
+    return res, uo, coeff, recon, pred, info
+
+
+def check_intra_run_hip(L, c):
+    import torch
+    n = len(c["cus"])
+    dt = c["preds"].dtype
+    isz = dt.itemsize
+    d_src = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)).cuda() for p in c["src"]]
+    planes = np.array([d.data_ptr() for d in d_src], np.uint64)
+    si = np.array([c["si"]], SLICE_INFO_DT)
+    res = np.zeros(n, RD_RESULT_DT); uo = np.zeros((n, 256), CU_UNIT_DT); coeff = np.zeros((n, RD_TILE), np.int16); recon = np.zeros((n, RD_TILE), dt)
+    pred = np.zeros((n, 4096), dt); info = np.zeros((n, 4), np.uint64)
+    for i in range(n):
+        d_rec = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)).cuda() for p in c["rec"]]
+        rplanes = np.array([d.data_ptr() for d in d_rec], np.uint64)
+        d_pred = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
+        d_recon = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
+        units = np.ascontiguousarray(c["units"].copy())
+        rc = L.lib.x265amd_check_intra(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                       off(c["cus"], i), int(c["parts"][i]), off(uo[i], 0), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), off(res, i),
+                                       off(coeff[i], 0))
+        assert rc == 0, L.lib.x265amd_last_error()
+        assert np.array_equal(units, c["units"])
+        recon[i] = d_recon.cpu().numpy().view(dt)
+        pred[i] = d_pred.cpu().numpy().view(dt)[:4096]
+    return res, uo, coeff, recon, pred, info

@@ -39,3 +39,35 @@ def test_hip_intra_in_inter_matches_reference_golden():
                     raise AssertionError("case %d CU %d (x %d y %d log2 %d qp %d): %s differs from the reference's result at %s: got %s want %s" % (
                         k, i, c["cus"][i]["x"], c["cus"][i]["y"], c["cus"][i]["log2_size"], c["cus"][i]["qp"], name, bad,
                         a[tuple(np.array(bad).T)].tolist() if bad != "shape" else a.shape, want[tuple(np.array(bad).T)].tolist() if bad != "shape" else want.shape))
+
+
+# ---- Search::checkIntra: (depth, seed, slice type (2 I, 1 P, 0 B), psy-rd, strong intra smoothing) ----
+CHECK_CASES = [(8, 701, 2, 2.0, 1), (8, 702, 2, 0.0, 1), (10, 703, 2, 2.0, 0), (8, 704, 1, 2.0, 1), (10, 705, 2, 1.0, 1), (8, 706, 2, 2.0, 1)]
+CHECK_GOLD_PATH = os.path.join(T.GOLDEN_DIR, "check_intra_golden.npz")
+
+
+def test_check_intra_golden_covers_nxn_and_splits():
+    gold = np.load(CHECK_GOLD_PATH)
+    nxn = split = 0
+    for k in range(len(CHECK_CASES)):
+        for i in range(10):
+            nxn += int(gold["%d/%d/dirs" % (k, i)][0, 2] == 3)
+            split += int(gold["%d/%d/units" % (k, i)][:, 0].max() > int(gold["%d/%d/dirs" % (k, i)][0, 2] == 3))
+    assert nxn >= 5 and split >= 3, (nxn, split)
+
+
+@pytest.mark.gpu
+def test_hip_check_intra_matches_reference_golden():
+    gold = np.load(CHECK_GOLD_PATH)
+    for k, (depth, seed, st, psy, strong) in enumerate(CHECK_CASES):
+        c = T.check_intra_case(depth, seed, st, psy, strong=strong)
+        got = T.intra_rd_pack(T.check_intra_run_hip(T.load_hip(depth), c), c)
+        for i, d in enumerate(got):
+            for name in ("dirs", "pred", "units", "coeff", "recon", "res", "ctx"):
+                want = gold["%d/%d/%s" % (k, i, name)]
+                a = np.asarray(d[name])
+                if not np.array_equal(a, want):
+                    bad = np.argwhere(a != want)[:6].tolist() if a.shape == want.shape else "shape"
+                    raise AssertionError("case %d CU %d (x %d y %d log2 %d qp %d part %d): %s differs from the reference's result at %s: got %s want %s" % (
+                        k, i, c["cus"][i]["x"], c["cus"][i]["y"], c["cus"][i]["log2_size"], c["cus"][i]["qp"], c["parts"][i], name, bad,
+                        a[tuple(np.array(bad).T)].tolist() if bad != "shape" else a.shape, want[tuple(np.array(bad).T)].tolist() if bad != "shape" else want.shape))

@@ -272,6 +272,93 @@ struct IntraRd
         for (int q = 0; q < 4; q++) extractLuma(x + (q & 1) * half, y + (q >> 1) * half, tuDepth + 1, coeffCu);
     }
 
+    /* the 35-mode scan of one block and the mode bits (loadIntraDirModeLuma + getIntraRemModeBits + bitsIntraModeMPM / NonMPM,
+     * entropy.h:196-197, :219-224): cost / bits / sa8d per mode */
+    int lumaScan(int x, int y, int log2N, uint64_t* modeCosts, uint32_t* modeBitsOut, uint32_t* sadOut)
+    {
+        const size_t isz = sizeof(pixel);
+        x265amd_intra_job sj;
+        memset(&sj, 0, sizeof(sj));
+        sj.recon = rec[0] + ((uint64_t)y * stride + x) * isz; sj.fenc = src[0] + ((uint64_t)y * stride + x) * isz;
+        sj.avail = available(x, y, 1 << log2N);
+        sj.recon_stride = (int32_t)stride; sj.fenc_stride = (int32_t)stride; sj.log2_tr_size = (uint8_t)log2N; sj.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
+        int32_t sa8d[35];
+        if (hipMemcpyAsync(dScanJob.p, &sj, sizeof(sj), hipMemcpyHostToDevice, st) != hipSuccess ||
+            x265amd_intra_scan(st, (const x265amd_intra_job*)dScanJob.p, 1, (int32_t*)dScan.p, nullptr) != X265AMD_OK ||
+            hipMemcpyAsync(sa8d, dScan.p, sizeof(sa8d), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail("intra rd: mode scan");
+        uint32_t preds[3];
+        c->lumaPreds(x, y, preds);
+        const uint64_t frac = cur.frac & 32767;
+        const uint8_t adi = cur.ctx[C_ADI];
+        const uint32_t rbits = (uint32_t)((frac + k_bits[adi ^ 0]) >> 15) + 5;
+        const uint32_t mpmBase = (uint32_t)((frac + k_bits[adi ^ 1]) >> 15);
+        for (uint32_t mode = 0; mode < 35; mode++)
+        {
+            uint32_t b = rbits;
+            for (int i = 0; i < 3; i++) if (preds[i] == mode) { b = mpmBase + (mode == preds[0] ? 1u : 2u); break; }
+            modeBitsOut[mode] = b; sadOut[mode] = (uint32_t)sa8d[mode];
+            modeCosts[mode] = calcRdSADCost((uint32_t)sa8d[mode], b);
+        }
+        mpm0 = preds[0];
+        return 0;
+    }
+    uint32_t mpm0;
+
+    /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
+     * best mode again with TU splits allowed */
+    int estIntraPredQT(int partSize, int rdLevel, sse_t& totalDistortion)
+    {
+        const int initTuDepth = partSize != 0, numPU = 1 << (2 * initTuDepth), log2TrSize = log2 - initTuDepth, tuSize = 1 << log2TrSize;
+        totalDistortion = 0;
+        for (int puIdx = 0; puIdx < numPU; puIdx++)
+        {
+            const int px = cuX + (initTuDepth ? (puIdx & 1) * tuSize : 0), py = cuY + (initTuDepth ? (puIdx >> 1) * tuSize : 0);
+            uint32_t bmode = 0;
+            uint64_t candCostList[35]; uint32_t rdModeList[35];
+            const int maxCandCount = 2 + rdLevel + ((depth + initTuDepth) >> 1);
+            uint64_t modeCosts[35]; uint32_t mb[35], ms[35];
+            if (lumaScan(px, py, log2TrSize, modeCosts, mb, ms)) return err;
+            uint64_t bcost = modeCosts[1];
+            if (modeCosts[0] < bcost) bcost = modeCosts[0];
+            for (int mode = 2; mode < 35; mode++) if (modeCosts[mode] < bcost) bcost = modeCosts[mode];
+            for (int i = 0; i < maxCandCount; i++) candCostList[i] = kMaxCost;
+            const uint64_t paddedBcost = bcost + (bcost >> 2);
+            for (uint32_t mode = 0; mode < 35; mode++)
+                if (modeCosts[mode] < paddedBcost || mode == mpm0)
+                {
+                    /* updateCandList (search.cpp:3953-3972) */
+                    uint32_t maxIndex = 0; uint64_t maxValue = 0;
+                    for (int i = 0; i < maxCandCount; i++) if (maxValue < candCostList[i]) { maxValue = candCostList[i]; maxIndex = (uint32_t)i; }
+                    if (modeCosts[mode] < maxValue) { candCostList[maxIndex] = modeCosts[mode]; rdModeList[maxIndex] = mode; }
+                }
+            bcost = kMaxCost;
+            for (int i = 0; i < maxCandCount; i++)
+            {
+                if (candCostList[i] == kMaxCost) break;
+                load(cur);
+                for (int yy = 0; yy < tuSize; yy += 4) for (int xx = 0; xx < tuSize; xx += 4) U(px + xx, py + yy).luma_dir = (uint8_t)rdModeList[i];
+                Cost icosts = { 0, 0, 0, 0 };
+                if (codeIntraLumaQT(px, py, initTuDepth, false, icosts)) return err;
+                if (icosts.rdcost < bcost) { bcost = icosts.rdcost; bmode = rdModeList[i]; }
+            }
+            for (int yy = 0; yy < tuSize; yy += 4) for (int xx = 0; xx < tuSize; xx += 4) U(px + xx, py + yy).luma_dir = (uint8_t)bmode;
+            load(cur);
+            Cost icosts = { 0, 0, 0, 0 };
+            if (codeIntraLumaQT(px, py, initTuDepth, true, icosts)) return err;
+            totalDistortion += icosts.distortion;
+        }
+        if (numPU > 1)
+        {
+            uint32_t comb = 0;
+            const int half = size >> 1;
+            for (int q = 0; q < 4; q++) comb |= cbfBit(cuX + (q & 1) * half, cuY + (q >> 1) * half, 0, 1);
+            U(cuX, cuY).cbf[0] |= (uint8_t)comb;
+        }
+        load(cur);
+        return 0;
+    }
+
     /* ---- chroma ---- */
     int codeIntraChromaQt(int x, int y, int tuDepth, Cost& outCost)
     {
@@ -413,12 +500,14 @@ struct IntraRd
 
 } // namespace
 
-extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
-                                      const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
-                                      x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info)
+/* shared body: kind 0 = checkIntraInInter + encodeIntraInInter, kind 1 = checkIntra(part_size) */
+static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                         const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
+                         x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info)
 {
-    if (!si || !rp || !units || !h_src || !h_rec || !cu || !cu_units || !d_pred || !d_recon || !out) return xa_fail(X265AMD_EINVAL, "intra_in_inter: null argument");
-    if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "intra_in_inter: lossless coding is not supported");
+    if (!si || !rp || !units || !h_src || !h_rec || !cu || !cu_units || !d_pred || !d_recon || !out) return xa_fail(X265AMD_EINVAL, "intra rd: null argument");
+    if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "intra rd: lossless coding is not supported");
+    if (partSize != 0 && (partSize != 3 || cu->log2_size != 3 || si->tu_log2_min > 2)) return xa_fail(X265AMD_EINVAL, "intra rd: NxN only for 8x8 CUs with 4x4 transforms");
     IntraRd* ip = new IntraRd;
     IntraRd& R = *ip;
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
@@ -426,7 +515,7 @@ extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si
     R.predTile = d_pred; R.reconTile = d_recon;
     int rc = X265AMD_OK;
     if (R.log2 < 3 || R.log2 > 5 || (R.cuX & (R.size - 1)) || (R.cuY & (R.size - 1)) || R.cuX < 0 || R.cuY < 0 || R.cuX + R.size > si->pic_width || R.cuY + R.size > si->pic_height)
-        rc = xa_fail(X265AMD_EINVAL, "intra_in_inter: CU outside the picture, misaligned, or not 8..32");
+        rc = xa_fail(X265AMD_EINVAL, "intra rd: CU outside the picture, misaligned, or not 8..32");
     static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
                                              32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
     const int bd = 6 * (X265AMD_DEPTH - 8);
@@ -434,18 +523,18 @@ extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si
     int qpC = qpQuant > 57 ? 57 : qpQuant;
     if (qpC >= 30) qpC = chromaScale[qpC];
     R.qpLumaScaled = qpQuant + bd; R.qpChromaScaled = qpC + bd;
-    /* CUData::getIntraTUQtDepthRange (cudata.cpp:972-981), 2Nx2N */
+    /* CUData::getIntraTUQtDepthRange (cudata.cpp:972-981) */
     {
-        const int lo = R.log2 - (si->tu_max_depth_intra - 1);
+        const int lo = R.log2 - (si->tu_max_depth_intra - 1 + (partSize != 0));
         R.range[0] = lo < si->tu_log2_min ? si->tu_log2_min : (lo > si->tu_log2_max ? si->tu_log2_max : lo);
         R.range[1] = si->tu_log2_max;
     }
     if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * 2) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * 2) != hipSuccess ||
                              R.dCoeff.alloc(2 * 1024 * 2) != hipSuccess || R.dResi.alloc(2 * 1024 * 2) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
                              R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess))
-        rc = xa_fail(X265AMD_EHIP, "intra_in_inter: out of device memory");
+        rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
-    if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra_in_inter: slice description");
+    if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra rd: slice description");
     if (rc != X265AMD_OK) { delete ip; return rc; }
     R.c = coder;
     for (int l = 0; l < 4; l++) R.coeffL[l].assign(4096, 0);
@@ -460,126 +549,121 @@ extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si
     std::vector<x265amd_cu_unit> saved((size_t)u4 * u4);
     for (int yy = 0; yy < u4; yy++) memcpy(&saved[(size_t)yy * u4], &units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], sizeof(x265amd_cu_unit) * u4);
     const size_t isz = sizeof(pixel);
-
-    /* ---- checkIntraInInter: the 35-mode scan and the mode bits ---- */
-    uint32_t bmode = 1, bbits = 0, bsad = 0; uint64_t bcost = 0;
+    /* the CU as initSubCU + setPartSizeSubParts + setPredModeSubParts leave it */
+    for (int yy = 0; yy < u4; yy++)
+        for (int xx = 0; xx < u4; xx++)
+        {
+            x265amd_cu_unit& u = units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2) + xx];
+            memset(&u, 0, sizeof(u));
+            u.depth = (uint8_t)R.depth; u.pred_mode = X265AMD_MODE_INTRA; u.part_size = (uint8_t)partSize; u.luma_dir = 1; u.chroma_dir = 36; u.qp = (int8_t)R.qp;
+            u.ref_idx[0] = u.ref_idx[1] = -1;
+        }
+    Cost icosts = { 0, 0, 0, 0 };
+    sse_t lumaDist = 0, chromaDist = 0;
+    if (kind == 0)
     {
-        x265amd_intra_job sj;
-        memset(&sj, 0, sizeof(sj));
-        sj.recon = h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz; sj.fenc = h_src[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz;
-        sj.avail = R.available(R.cuX, R.cuY, R.size);
-        sj.recon_stride = (int32_t)stride; sj.fenc_stride = (int32_t)stride; sj.log2_tr_size = (uint8_t)R.log2; sj.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
-        int32_t sa8d[35];
-        if (hipMemcpyAsync(R.dScanJob.p, &sj, sizeof(sj), hipMemcpyHostToDevice, R.st) != hipSuccess ||
-            x265amd_intra_scan(R.st, (const x265amd_intra_job*)R.dScanJob.p, 1, (int32_t*)R.dScan.p, nullptr) != X265AMD_OK ||
-            hipMemcpyAsync(sa8d, R.dScan.p, sizeof(sa8d), hipMemcpyDeviceToHost, R.st) != hipSuccess || hipStreamSynchronize(R.st) != hipSuccess)
-            rc = xa_fail(X265AMD_EHIP, "intra_in_inter: mode scan");
+        /* ---- checkIntraInInter: DC first, then planar, then the angular modes, strict improvement ---- */
+        uint64_t modeCosts[35]; uint32_t mb[35], ms[35];
+        rc = R.lumaScan(R.cuX, R.cuY, R.log2, modeCosts, mb, ms);
         if (rc == X265AMD_OK)
         {
-            /* loadIntraDirModeLuma + getIntraRemModeBits + bitsIntraModeMPM / NonMPM (entropy.h:196-197, :219-224) */
-            uint32_t preds[3];
-            coder->lumaPreds(R.cuX, R.cuY, preds);
-            const uint64_t frac = R.cur.frac & 32767;
-            const uint8_t adi = R.cur.ctx[C_ADI];
-            const uint32_t rbits = (uint32_t)((frac + k_bits[adi ^ 0]) >> 15) + 5;
-            const uint32_t mpmBase = (uint32_t)((frac + k_bits[adi ^ 1]) >> 15);
-            auto modeBits = [&](uint32_t mode) {
-                for (int i = 0; i < 3; i++) if (preds[i] == mode) return mpmBase + (mode == preds[0] ? 1u : 2u);
-                return rbits;
-            };
             static const uint8_t order[35] = { 1, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34 };
-            for (int k = 0; k < 35; k++)
-            {
-                const uint32_t mode = order[k], sad = (uint32_t)sa8d[mode], b = modeBits(mode);
-                const uint64_t cst = R.calcRdSADCost(sad, b);
-                if (!k || cst < bcost) { bcost = cst; bmode = mode; bsad = sad; bbits = b; }
-            }
-            if (info) { info[0] = bmode; info[1] = bcost; info[2] = bbits; info[3] = bsad; }
+            uint32_t bmode = 1;
+            for (int k = 1; k < 35; k++) if (modeCosts[order[k]] < modeCosts[bmode]) bmode = order[k];
+            if (info) { info[0] = bmode; info[1] = modeCosts[bmode]; info[2] = mb[bmode]; info[3] = ms[bmode]; }
+            for (int yy = 0; yy < R.size; yy += 4) for (int xx = 0; xx < R.size; xx += 4) R.U(R.cuX + xx, R.cuY + yy).luma_dir = (uint8_t)bmode;
+            /* ---- encodeIntraInInter ---- */
+            R.load(R.cur);
+            rc = R.codeIntraLumaQT(R.cuX, R.cuY, 0, false, icosts);
+            lumaDist = icosts.distortion;
         }
     }
-
-    /* ---- encodeIntraInInter ---- */
+    else
+        rc = R.estIntraPredQT(partSize, rp->rd_level, lumaDist);
+    std::vector<int16_t> coeffCu(4096 + 2048, 0);
     if (rc == X265AMD_OK)
     {
-        for (int yy = 0; yy < u4; yy++)
-            for (int xx = 0; xx < u4; xx++)
-            {
-                x265amd_cu_unit& u = units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2) + xx];
-                memset(&u, 0, sizeof(u));
-                u.depth = (uint8_t)R.depth; u.pred_mode = X265AMD_MODE_INTRA; u.part_size = 0; u.luma_dir = (uint8_t)bmode; u.chroma_dir = 36; u.qp = (int8_t)R.qp;
-                u.ref_idx[0] = u.ref_idx[1] = -1;
-            }
-        R.load(R.cur);
-        Cost icosts = { 0, 0, 0, 0 };
-        sse_t chromaDist = 0;
-        rc = R.codeIntraLumaQT(R.cuX, R.cuY, 0, false, icosts);
-        std::vector<int16_t> coeffCu(4096 + 2048, 0);
-        if (rc == X265AMD_OK)
+        R.extractLuma(R.cuX, R.cuY, 0, coeffCu.data());
+        R.copy2D(d_recon, 64, h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz, stride, R.size, R.size);
+        rc = R.estIntraPredChromaQT(chromaDist);
+    }
+    if (rc == X265AMD_OK)
+    {
+        memcpy(coeffCu.data() + 4096, R.coeffCBest[0].data(), sizeof(int16_t) * 1024);
+        memcpy(coeffCu.data() + 5120, R.coeffCBest[1].data(), sizeof(int16_t) * 1024);
+        x265amd_cu_unit& u0 = units[(R.cuY >> 2) * w4 + (R.cuX >> 2)];
+        R.resetBits();
+        uint32_t skipFlagBits = 0;
+        if (si->slice_type != 2)
         {
-            R.extractLuma(R.cuX, R.cuY, 0, coeffCu.data());
-            R.copy2D(d_recon, 64, h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz, stride, R.size, R.size);
-            rc = R.estIntraPredChromaQT(chromaDist);
-        }
-        if (rc == X265AMD_OK)
-        {
-            memcpy(coeffCu.data() + 4096, R.coeffCBest[0].data(), sizeof(int16_t) * 1024);
-            memcpy(coeffCu.data() + 5120, R.coeffCBest[1].data(), sizeof(int16_t) * 1024);
-            x265amd_cu_unit& u0 = units[(R.cuY >> 2) * w4 + (R.cuX >> 2)];
-            R.resetBits();
             const x265amd_cu_unit* l = coder->at((R.cuX >> 2) - 1, R.cuY >> 2);
             const x265amd_cu_unit* a = coder->at(R.cuX >> 2, (R.cuY >> 2) - 1);
             const int skipCtx = (x265amd_cabac::coded(l) && l->pred_mode == X265AMD_MODE_SKIP) + (x265amd_cabac::coded(a) && a->pred_mode == X265AMD_MODE_SKIP);
             coder->bin(0, C_SKIP + skipCtx);
-            const uint32_t skipFlagBits = R.bits();
+            skipFlagBits = R.bits();
             coder->bin(1, C_PRED_MODE);
-            coder->partSize(u0, R.depth, R.size);
-            coder->predInfo(R.cuX, R.cuY, R.size, u0);
-            const uint32_t mvBits = R.bits() - skipFlagBits;
-            bool dqp = si->use_dqp != 0;
-            coder->coeffCtu[0] = coeffCu.data(); coder->coeffCtu[1] = coeffCu.data() + 4096; coder->coeffCtu[2] = coeffCu.data() + 5120;
-            coder->ctuX0 = R.cuX; coder->ctuY0 = R.cuY;
-            coder->transform(R.cuX, R.cuY, R.cuX, R.cuY, 0, R.log2, dqp, R.range);
-            memset(out, 0, sizeof(*out));
-            out->total_bits = R.bits(); out->mv_bits = mvBits; out->coeff_bits = out->total_bits - mvBits - skipFlagBits;
-            out->luma_distortion = (uint32_t)icosts.distortion; out->chroma_distortion = (uint32_t)chromaDist;
-            const sse_t distortion = icosts.distortion + chromaDist;
-            out->distortion = distortion;
-            /* psy energy of the reconstruction, residual energy of the prediction (luma) */
-            x265amd_rd_cu mc = *cu;
-            x265amd_cu_measure mr, mp;
-            if (x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_recon, 0, &mr) != X265AMD_OK || x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_pred, 0, &mp) != X265AMD_OK)
-                rc = X265AMD_EHIP;
-            out->psy_energy = R.psyRd ? mr.psy : 0;
-            out->res_energy = (uint32_t)(sse_t)mp.sse[0];
-            out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
-            /* checkDQP (search.cpp:3974-4003) */
-            if (si->use_dqp && R.depth <= si->max_cu_dqp_depth)
-            {
-                const bool rootCbf = u0.cbf[0] || u0.cbf[1] || u0.cbf[2];
-                if (rootCbf)
-                {
-                    if (rp->rd_level >= 3) { R.resetBits(); coder->deltaQP(R.cuX, R.cuY); out->total_bits += R.bits(); }
-                    else if (rp->rd_level == 2) out->total_bits++;
-                    out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
-                }
-                else
-                {
-                    const int8_t q = (int8_t)coder->refQP(R.cuX, R.cuY);
-                    for (int yy = 0; yy < u4; yy++) for (int xx = 0; xx < u4; xx++) units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2) + xx].qp = q;
-                }
-            }
-            memcpy(out->ctx, coder->ctx, X265AMD_CTX_COUNT);
-            out->frac_bits = coder->fracBits;
-            if (coeff_out) memcpy(coeff_out, coeffCu.data(), sizeof(int16_t) * (4096 + 2048));
         }
+        coder->partSize(u0, R.depth, R.size);
+        coder->predInfo(R.cuX, R.cuY, R.size, u0);
+        const uint32_t mvBits = R.bits() - skipFlagBits;
+        bool dqp = si->use_dqp != 0;
+        coder->coeffCtu[0] = coeffCu.data(); coder->coeffCtu[1] = coeffCu.data() + 4096; coder->coeffCtu[2] = coeffCu.data() + 5120;
+        coder->ctuX0 = R.cuX; coder->ctuY0 = R.cuY;
+        coder->transform(R.cuX, R.cuY, R.cuX, R.cuY, 0, R.log2, dqp, R.range);
+        memset(out, 0, sizeof(*out));
+        out->total_bits = R.bits(); out->mv_bits = mvBits; out->coeff_bits = out->total_bits - mvBits - skipFlagBits;
+        out->luma_distortion = (uint32_t)lumaDist; out->chroma_distortion = (uint32_t)chromaDist;
+        const sse_t distortion = lumaDist + chromaDist;
+        out->distortion = distortion;
+        /* psy energy of the reconstruction, residual energy of the prediction (luma) */
+        x265amd_rd_cu mc = *cu;
+        x265amd_cu_measure mr, mp;
+        if (x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_recon, 0, &mr) != X265AMD_OK || x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_pred, 0, &mp) != X265AMD_OK)
+            rc = X265AMD_EHIP;
+        out->psy_energy = R.psyRd ? mr.psy : 0;
+        out->res_energy = (uint32_t)(sse_t)mp.sse[0];
+        out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
+        memcpy(out->ctx, coder->ctx, X265AMD_CTX_COUNT);            /* Mode::contexts is stored before checkDQP codes into it */
+        out->frac_bits = coder->fracBits;
+        /* checkDQP (search.cpp:3974-4003) */
+        if (si->use_dqp && R.depth <= si->max_cu_dqp_depth)
+        {
+            const bool rootCbf = u0.cbf[0] || u0.cbf[1] || u0.cbf[2];
+            if (rootCbf)
+            {
+                if (rp->rd_level >= 3) { R.resetBits(); coder->deltaQP(R.cuX, R.cuY); out->total_bits += R.bits(); memcpy(out->ctx, coder->ctx, X265AMD_CTX_COUNT); out->frac_bits = coder->fracBits; }
+                else if (rp->rd_level == 2) out->total_bits++;
+                out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
+            }
+            else
+            {
+                const int8_t q = (int8_t)coder->refQP(R.cuX, R.cuY);
+                for (int yy = 0; yy < u4; yy++) for (int xx = 0; xx < u4; xx++) units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2) + xx].qp = q;
+            }
+        }
+        if (coeff_out) memcpy(coeff_out, coeffCu.data(), sizeof(int16_t) * (4096 + 2048));
     }
     for (int yy = 0; yy < u4; yy++)
     {
         memcpy(&cu_units[(size_t)yy * u4], &units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], sizeof(x265amd_cu_unit) * u4);
         memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
     }
-    if (rc == X265AMD_OK && hipStreamSynchronize(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra_in_inter: synchronize");
+    if (rc == X265AMD_OK && hipStreamSynchronize(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: synchronize");
     x265amd_cabac_close(coder);
     delete ip;
     return rc;
+}
+
+extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                                      const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
+                                      x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info)
+{
+    return intra_cu_impl(0, 0, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, cu_units, d_pred, d_recon, out, coeff_out, info);
+}
+
+extern "C" int x265amd_check_intra(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                                   const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, int part_size,
+                                   x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out)
+{
+    return intra_cu_impl(1, part_size, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, cu_units, d_pred, d_recon, out, coeff_out, nullptr);
 }
