@@ -1404,6 +1404,8 @@ void ref_compress_ctu(const RefMvInfo* I, const RefSearchParams* S, const RefSli
     f.pps.bTransquantBypassEnabled = 0; f.pps.bTransformSkipEnabled = 0; f.pps.bEntropyCodingSyncEnabled = si->wpp != 0;
     Slice* slice = f.fd[0]->m_slice;
     slice->m_sliceQp = si->sliceQp;
+    if (si->sliceType == 2) slice->m_sliceType = I_SLICE;
+    param->bEnableSplitRdSkip = 0; param->intraRefine = 0;
     slice->m_endCUAddr = slice->realEndAddress(f.sps.numCUsInFrame * 256);
     /* the remaining CUData fields of the current picture, and the reference pictures' depth maps */
     for (uint32_t addr = 0; addr < f.sps.numCUsInFrame; addr++)

@@ -2361,7 +2361,7 @@ CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits
 assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 48
 
 
-def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1):
+def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1, intra_slice=False):
     """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
     the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
     rng = np.random.default_rng(seed + 901)
@@ -2387,15 +2387,16 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
                 sv[y0:y0 + b, x0:x0 + b] = rng.integers(pmax // 4, 3 * pmax // 4, (b, b))
             else:
                 sv[y0:y0 + b, x0:x0 + b] = rv[y0 + dy // sub:y0 + dy // sub + b, x0 + dx // sub:x0 + dx // sub + b]
+    recon[:] = np.clip(src.astype(np.int64) + rng.integers(-3, 4, src.shape), 0, pmax).astype(src.dtype)      # what earlier CTUs left (intra neighbours)
     pics = pics[:3] + [recon, src]                  # refs 0..2, reconstruction, source
     w4, h4, ctuW, ctuH = width // 4, height // 4, width // 64, height // 64
     mp = mvpred_case(seed, width, height, is_b)
     info = mp["info"].copy()
     info["max_num_merge_cand"] = int(rng.integers(2, 6))
     nref = info["num_ref_idx"]
-    base = cabac_case(seed, width, height, 0 if is_b else 1)
+    base = cabac_case(seed, width, height, 2 if intra_slice else (0 if is_b else 1))
     si = base["si"].copy()
-    si["slice_type"] = 0 if is_b else 1
+    si["slice_type"] = 2 if intra_slice else (0 if is_b else 1)
     si["tq_bypass_enabled"], si["use_dqp"], si["max_cu_dqp_depth"] = 0, 0, 0
     si["tu_max_depth_inter"], si["max_num_merge_cand"], si["num_ref_idx"] = tu_inter_depth, info["max_num_merge_cand"], nref
     si["slice_qp"] = int(rng.integers(24, 38))

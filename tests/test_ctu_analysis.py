@@ -8,17 +8,19 @@ import pytest
 
 import hevc_testlib as T
 
-# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth, limit-refs[, B slice, b-intra])
+# (depth, seed, early skip, rskip, psy-rd, tuQTMaxInterDepth, limit-refs[, B slice, b-intra[, I slice]])
 CASES = [(8, 1, 1, 1, 2.0, 1, 0), (8, 2, 0, 1, 2.0, 2, 0), (8, 3, 1, 0, 0.0, 1, 0), (10, 4, 0, 1, 2.0, 1, 0), (8, 5, 1, 1, 1.0, 3, 0), (8, 6, 0, 0, 2.0, 1, 0),
          (8, 7, 1, 1, 2.0, 1, 3), (8, 8, 0, 0, 2.0, 1, 3), (10, 9, 0, 1, 0.0, 2, 1), (8, 10, 0, 1, 2.0, 1, 2),
-         (8, 11, 1, 1, 2.0, 1, 3, 0, 0), (8, 12, 0, 1, 2.0, 1, 0, 0, 0), (10, 13, 0, 0, 0.0, 2, 3, 0, 0), (8, 14, 0, 1, 2.0, 1, 3, 1, 1), (8, 15, 1, 0, 1.0, 1, 0, 1, 1)]
+         (8, 11, 1, 1, 2.0, 1, 3, 0, 0), (8, 12, 0, 1, 2.0, 1, 0, 0, 0), (10, 13, 0, 0, 0.0, 2, 3, 0, 0), (8, 14, 0, 1, 2.0, 1, 3, 1, 1), (8, 15, 1, 0, 1.0, 1, 0, 1, 1),
+         (8, 16, 0, 0, 2.0, 1, 0, 0, 0, 1), (10, 17, 0, 0, 0.0, 1, 0, 0, 0, 1), (8, 18, 0, 0, 1.0, 1, 0, 0, 0, 1)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 
 def make_case(k):
     depth, seed, es, rs, psy, td, lr = CASES[k][:7]
     is_b, b_intra = (CASES[k][7], CASES[k][8]) if len(CASES[k]) > 7 else (1, 0)
-    return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr, b_intra=b_intra)
+    return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr, b_intra=b_intra,
+                      intra_slice=len(CASES[k]) > 9 and bool(CASES[k][9]))
 
 
 def test_golden_outcomes_are_varied():

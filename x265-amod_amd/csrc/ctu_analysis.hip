@@ -13,7 +13,9 @@
  * reconstructed picture at the end of every CU, exactly when the reference's copyToPic does, so later neighbours see what the
  * reference's would.
  *
- * Scope of this entry point: P and B slices (intra candidates through x265amd_intra_in_inter; --b-intra on / off), 2Nx2N partitions
+ * I slices take compressIntraCU (:514-668): checkIntra 2Nx2N (+ NxN at 8x8) through x265amd_check_intra, then the four sub-CUs.
+ *
+ * Scope of this entry point: I, P and B slices (intra candidates through x265amd_intra_in_inter; --b-intra on / off), 2Nx2N partitions
  * (no --rect / --amp), --limit-refs 0-3, no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.
  */
 #include "x265amd_dev.h"
@@ -32,7 +34,7 @@ typedef uint32_t sse_t;
 typedef uint64_t sse_t;
 #endif
 
-enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_INTRA, PRED_SPLIT, NUM_PRED };
+enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_INTRA, PRED_INTRA_NxN, PRED_SPLIT, NUM_PRED };
 const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
 const int kTileElems = 4096 + 2048;
 
@@ -229,7 +231,7 @@ struct Analyzer
     }
 
     /* checkIntraInInter + encodeIntraInInter */
-    int rdIntra(Mode& m, int x, int y, int depth)
+    int rdIntra(Mode& m, int x, int y, int depth, int slot = PRED_INTRA, bool full = false, int partSize = 0)
     {
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
@@ -238,10 +240,12 @@ struct Analyzer
         c.frac_bits = md[depth].cur.frac;
         x265amd_rd_result r;
         m.initCosts();
-        m.predTile = predTile(depth, PRED_INTRA); m.reconTile = reconTile(depth, PRED_INTRA);
-        uint64_t info[4];
-        const int rc = x265amd_intra_in_inter(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, m.u, tileAddr(m.predTile),
-                                              tileAddr(m.reconTile), &r, m.coeff.data(), info);
+        m.predTile = predTile(depth, slot); m.reconTile = reconTile(depth, slot);
+        uint64_t info[4] = { 0, 0, 0, 0 };
+        const int rc = full ? x265amd_check_intra(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, partSize, m.u,
+                                                  tileAddr(m.predTile), tileAddr(m.reconTile), &r, m.coeff.data())
+                            : x265amd_intra_in_inter(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, m.u, tileAddr(m.predTile),
+                                                     tileAddr(m.reconTile), &r, m.coeff.data(), info);
         if (rc != X265AMD_OK) return err = rc;
         m.sa8dCost = info[1]; m.sa8dBits = (uint32_t)info[2];
         m.rdCost = r.rd_cost; m.distortion = (sse_t)r.distortion; m.totalBits = r.total_bits; m.mvBits = r.mv_bits; m.coeffBits = r.coeff_bits;
@@ -473,6 +477,69 @@ struct Analyzer
         return ((u.inter_dir & 1) && u.ref_idx[0] >= 0 ? 1u << u.ref_idx[0] : 0) | ((u.inter_dir & 2) && u.ref_idx[1] >= 0 ? 1u << (u.ref_idx[1] + 16) : 0);
     }
 
+    /* compressIntraCU (analysis.cpp:514-668) without analysis reuse / split-rd-skip */
+    int compressIntra(int x, int y, int depth)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        d.best = nullptr;
+        const bool mightSplit = depth < si->max_cu_depth;
+        const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
+        for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
+        if (log2 != 6 && mightNotSplit)
+        {
+            if (rdIntra(d.pred[PRED_INTRA], x, y, depth, PRED_INTRA, true, 0)) return err;
+            checkBestMode(d.pred[PRED_INTRA], depth);
+            if (log2 == 3 && si->tu_log2_min < 3)
+            {
+                if (rdIntra(d.pred[PRED_INTRA_NxN], x, y, depth, PRED_INTRA_NxN, true, 3)) return err;
+                checkBestMode(d.pred[PRED_INTRA_NxN], depth);
+            }
+            if (mightSplit) addSplitFlagCost(*d.best, x, y, depth);
+        }
+        if (mightSplit)
+        {
+            Mode& split = d.pred[PRED_SPLIT];
+            split.initCosts();
+            split.predTile = predTile(depth, PRED_SPLIT); split.reconTile = reconTile(depth, PRED_SPLIT);
+            const int n4 = 16 >> depth, half = size >> 1, h4n = n4 >> 1;
+            const Snap* nextContext = &d.cur;
+            for (int q = 0; q < 4; q++)
+            {
+                const int cx = x + (q & 1) * half, cy = y + (q >> 1) * half;
+                if (cx < I->pic_width && cy < I->pic_height)
+                {
+                    md[depth + 1].cur = *nextContext;
+                    if (compressIntra(cx, cy, depth + 1)) return err;
+                    const Mode& nb = *md[depth + 1].best;
+                    for (int yy = 0; yy < h4n; yy++)
+                        for (int xx = 0; xx < h4n; xx++)
+                        {
+                            split.u[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.u[yy * h4n + xx];
+                            split.m[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.m[yy * h4n + xx];
+                        }
+                    split.addSubCosts(nb);
+                    copyTile(split.reconTile, nb.reconTile, (q & 1) * half, (q >> 1) * half, half);
+                    const int nc = half * half;
+                    memcpy(&split.coeff[(size_t)q * nc], nb.coeff.data(), sizeof(int16_t) * nc);
+                    memcpy(&split.coeff[4096 + (size_t)q * nc / 4], nb.coeff.data() + 4096, sizeof(int16_t) * nc / 4);
+                    memcpy(&split.coeff[5120 + (size_t)q * nc / 4], nb.coeff.data() + 5120, sizeof(int16_t) * nc / 4);
+                    nextContext = &nb.contexts;
+                }
+                else
+                    for (int yy = 0; yy < h4n; yy++)
+                        for (int xx = 0; xx < h4n; xx++) split.u[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx].depth = (uint8_t)(depth + 1);
+            }
+            split.contexts = *nextContext;
+            if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
+            else updateModeCost(split);
+            checkBestMode(split, depth);
+        }
+        toPicture(*d.best, x, y, depth);
+        if (d.best != &d.pred[PRED_SPLIT]) tileToPicture(d.best->reconTile, x, y, size);
+        return 0;
+    }
+
     int compress(int x, int y, int depth, uint32_t& splitRefsOut)
     {
         ModeDepth& d = md[depth];
@@ -595,9 +662,9 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
                                           intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
                                           int16_t* coeff_out, x265amd_ctu_result* out)
 {
-    if (!me || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 3)
+    if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 3)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
-    if ((si->slice_type == 0) != (I->is_inter_b != 0) || si->slice_type == 2) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
+    if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
     if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs < 0 || A->limit_refs > 3 || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, 2Nx2N only, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
@@ -634,7 +701,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         memcpy(a.md[0].cur.ctx, ctx_in, X265AMD_CTX_COUNT);
         a.md[0].cur.frac = frac_in;
         uint32_t topRefs = 0;
-        rc = a.compress(a.ctuX, a.ctuY, 0, topRefs);
+        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : a.compress(a.ctuX, a.ctuY, 0, topRefs);
         if (rc == X265AMD_OK && hipStreamSynchronize(a.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)
