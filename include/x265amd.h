@@ -677,7 +677,8 @@ typedef struct x265amd_analysis_params
 {
     double psy_rd;                  /* param.psyRd */
     int32_t rd_level, early_skip, rskip, limit_refs, b_intra, rect, amp, limit_modes;
-    int32_t strong_intra_smoothing, reserved;   /* sps.bUseStrongIntraSmoothing */
+    int32_t strong_intra_smoothing;             /* sps.bUseStrongIntraSmoothing */
+    int32_t use_sao;                            /* slice.m_bUseSao: x265amd_analyse_frame only (the row coder counts bits only when SAO is on) */
 } x265amd_analysis_params;          /* 48 bytes */
 typedef struct x265amd_cu_stat { uint32_t count[4]; uint32_t pad[2]; uint64_t avg_cost[4]; } x265amd_cu_stat;     /* FrameData::RCStatCU count / avgCost per depth */
 typedef struct x265amd_ctu_result { uint64_t rd_cost, distortion, frac_bits; uint32_t total_bits, reserved; uint8_t ctx[X265AMD_CTX_STRIDE]; } x265amd_ctu_result;
@@ -692,6 +693,18 @@ int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_m
                                const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                                intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
                                int16_t* coeff_out, x265amd_ctu_result* out);
+
+/* The CTU loop of one frame (FrameEncoder::processRowEncoder, reference: source/encoder/frameencoder.cpp:1399-1700, without rate control,
+ * VBV, slices and in-loop filters): clears units / cur / cu_stat, then for every CTU takes the start state from the row coder (si->wpp: one
+ * coder per row, rows > 0 start from the state saved after the second CTU of the row above; otherwise one coder through all rows), runs
+ * x265amd_compress_ctu_inter and lets the row coder code the CTU in bit-counting mode.  coeff_out: numCtu x (4096 + 2 x 1024) levels.
+ * results (may be NULL): per CTU.  slice_data / slice_bytes (may be NULL; wpp = 0 only): the slice data as FrameEncoder::encodeSlice writes
+ * it (:1298-1370), i.e. everything after the slice header.  Other arguments as x265amd_compress_ctu_inter. */
+int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* info, const x265amd_inter_search_params* sp,
+                          const x265amd_slice_info* si, const x265amd_analysis_params* ap, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                          const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                          intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
+                          uint8_t* slice_data, size_t cap, size_t* slice_bytes);
 
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */

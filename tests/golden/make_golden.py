@@ -48,6 +48,7 @@ def main():
     make_inter_rd_golden()
     make_ctu_analysis_golden()
     make_intra_rd_golden()
+    make_frame_pipeline_golden()
 
 
 ME_CONFIGS = [(T.ME_HEX, 2), (T.ME_HEX, 0), (T.ME_HEX, 1), (T.ME_HEX, 5), (T.ME_HEX, 7), (T.ME_DIA, 0), (T.ME_DIA, 2),
@@ -269,6 +270,66 @@ def make_intra_rd_golden():
                 out["%d/%d/%s" % (k, i, name)] = a
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "check_intra_golden.npz"), **out)
     print("wrote check_intra_golden.npz with", len(out), "arrays")
+
+
+def make_frame_pipeline_golden():
+    """the reference ENCODER's own output for the clip of T.frame_clip(): reconstructed frames and slice payloads -> frame_pipeline_golden.npz"""
+    import subprocess, tempfile, csv
+    frames, stride, cstride, org = T.frame_clip(8, 4)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "clip.y4m"), "wb") as f:
+            f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420\n" % (T.MC_W, T.MC_H))
+            for p in frames:
+                f.write(b"FRAME\n")
+                for pl in T.frame_planes(p, stride, cstride, org):
+                    f.write(np.ascontiguousarray(pl).tobytes())
+        exe = os.path.join(T.REF_DIR, "x265_ref8")
+        r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv", "--csv", "log.csv", "--csv-log-level", "1"] + T.FRAME_CLI_ARGS,
+                           cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
+        hevc = open(os.path.join(d, "out.hevc"), "rb").read()
+        qps = []
+        for row in csv.reader(open(os.path.join(d, "log.csv"))):
+            if len(row) > 3 and row[1].strip().endswith("SLICE"):
+                qps.append(int(float(row[3])))
+    out = {"nframes": np.array(4), "slice_qp": np.array(qps, np.int32)}
+    fsz = T.MC_W * T.MC_H * 3 // 2
+    for k in range(4):
+        fr = rec[k * fsz:(k + 1) * fsz]
+        out["recon/%d/0" % k] = fr[:T.MC_W * T.MC_H].reshape(T.MC_H, T.MC_W)
+        out["recon/%d/1" % k] = fr[T.MC_W * T.MC_H:T.MC_W * T.MC_H * 5 // 4].reshape(T.MC_H // 2, T.MC_W // 2)
+        out["recon/%d/2" % k] = fr[T.MC_W * T.MC_H * 5 // 4:].reshape(T.MC_H // 2, T.MC_W // 2)
+    # NAL units (Annex B): VCL units (types 0..31) in order; payload with emulation prevention bytes removed, 2-byte NAL header dropped
+    pos, nals = 0, []
+    starts = []
+    i = 0
+    while i + 3 <= len(hevc):
+        if hevc[i:i + 3] == b"\x00\x00\x01":
+            starts.append(i + 3); i += 3
+        else:
+            i += 1
+    for a, b in zip(starts, starts[1:] + [len(hevc) + 4]):
+        end = b - 3 if b <= len(hevc) else len(hevc)
+        nal = hevc[a:end]
+        while nal.endswith(b"\x00") and b <= len(hevc):
+            nal = nal[:-1]
+        nals.append(nal)
+    k = 0
+    for nal in nals:
+        if ((nal[0] >> 1) & 0x3f) < 32:
+            rbsp = bytearray(); z = 0
+            for byte in nal[2:]:
+                if z >= 2 and byte == 3:
+                    z = 0
+                    continue
+                rbsp.append(byte)
+                z = z + 1 if byte == 0 else 0
+            out["slice/%d" % k] = np.frombuffer(bytes(rbsp), np.uint8)
+            k += 1
+    assert k == 4, k
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
+    print("wrote frame_pipeline_golden.npz:", qps, [len(out["slice/%d" % i]) for i in range(4)])
 
 
 if __name__ == "__main__":

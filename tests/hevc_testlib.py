@@ -2355,7 +2355,7 @@ def skip_run_hip(L, c):
 
 # ---- CTU analysis of inter slices (x265amd_compress_ctu_inter vs Analysis::compressCTU) ----
 ANALYSIS_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("early_skip", "<i4"), ("rskip", "<i4"), ("limit_refs", "<i4"), ("b_intra", "<i4"),
-                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4"), ("strong", "<i4"), ("reserved", "<i4")])
+                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4"), ("strong", "<i4"), ("use_sao", "<i4")])
 CU_STAT_DT = np.dtype([("count", "<u4", 4), ("pad", "<u4", 2), ("avg_cost", "<u8", 4)])
 CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("reserved", "<u4"), ("ctx", "u1", 160)])
 assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 48
@@ -2713,3 +2713,96 @@ def check_intra_run_hip(L, c):
         recon[i] = d_recon.cpu().numpy().view(dt)
         pred[i] = d_pred.cpu().numpy().view(dt)[:4096]
     return res, uo, coeff, recon, pred, info
+
+
+# ---- frame pipeline (x265amd_analyse_frame) against the reference encoder itself ----
+FRAME_CLIP_SEED = 4242
+FRAME_CLI_ARGS = ["--preset", "medium", "--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--bframes", "0", "--b-adapt", "0",
+                  "--no-scenecut", "--keyint", "250", "--rd", "3", "--no-sao", "--no-deblock", "--no-wpp", "--frame-threads", "1", "--pools", "none",
+                  "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", "3", "--max-merge", "3", "--no-info", "--no-open-gop", "--rc-lookahead", "0",
+                  "--lookahead-slices", "0"]
+
+
+def frame_clip(depth=8, nframes=4):
+    """source frames (padded flat Y|U|V arrays in inter_scene geometry), in coding order"""
+    pics, stride, cstride, org = inter_scene(depth, FRAME_CLIP_SEED, npics=4)
+    order = [pics[3], pics[0], pics[1], pics[2]][:nframes]
+    return order, stride, cstride, org
+
+
+def frame_planes(pic, stride, cstride, org):
+    out = []
+    for k in range(3):
+        st = stride if k == 0 else cstride
+        w, h = (MC_W, MC_H) if k == 0 else (MC_W // 2, MC_H // 2)
+        out.append(np.stack([pic[org[k] + r * st:org[k] + r * st + w] for r in range(h)]))
+    return out
+
+
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8):
+    """I + P frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, no filters,
+    one substream): returns per frame (recon planes, slice data bytes)"""
+    import torch
+    frames, stride, cstride, org = frame_clip(depth, nframes)
+    isz = frames[0].itemsize
+    W, H = MC_W, MC_H
+    w4, h4, nctu = W // 4, H // 4, (W // 64) * (H // 64)
+    lib = L.lib
+    d_src = [torch.from_numpy(f.view(np.uint8)).cuda() for f in frames]
+    d_rec = [torch.zeros_like(d) for d in d_src]
+    def addr(d):
+        return [d.data_ptr() + org[k] * isz for k in range(3)]
+    prev_fields, prev_units, prev_refpoc, out = [], [], [], []
+    for k in range(nframes):
+        is_i = k == 0
+        refs = [] if is_i else list(range(k - 1, max(-1, k - 4), -1))          # L0: closest first, at most 3
+        planes = []
+        for r in refs:
+            planes += addr(d_rec[r])
+        planes += addr(d_rec[k]) + addr(d_src[k])
+        planes = np.array(planes, np.uint64)
+        info = np.zeros(1, MVPRED_INFO_DT)
+        info["pic_width"], info["pic_height"], info["is_inter_b"], info["max_num_merge_cand"] = W, H, 0, 3
+        info["num_ref_idx"] = (len(refs), 0)
+        info["temporal_mvp"], info["col_from_l0"], info["check_ldc"], info["poc"] = 1, 1, 1, k
+        rp = np.zeros((2, 16), np.int32)
+        rp[0, :len(refs)] = refs
+        info["ref_poc"] = rp
+        if not is_i:
+            info["col_poc"] = k - 1
+            info["col_ref_poc"] = prev_refpoc[k - 1]
+        sp = np.zeros(1, INTER_SP_DT)
+        sp["search_method"], sp["subpel_refine"], sp["search_range"], sp["qp"], sp["chroma_mc"] = ME_HEX, 2, 57, slice_qps[k], 1
+        rpic = np.zeros((2, 16), np.int32)
+        rpic[0, :len(refs)] = np.arange(len(refs))
+        sp["ref_pic"] = rpic
+        si = np.zeros(1, SLICE_INFO_DT)
+        si["pic_width"], si["pic_height"], si["slice_type"], si["slice_qp"] = W, H, 2 if is_i else 1, slice_qps[k]
+        si["num_ref_idx"] = (len(refs), 0)
+        si["max_num_merge_cand"], si["sign_hide"], si["max_cu_depth"], si["tu_log2_min"], si["tu_log2_max"] = 3, 1, 3, 2, 5
+        si["tu_max_depth_inter"], si["tu_max_depth_intra"] = 1, 1
+        ap = np.zeros(1, ANALYSIS_PARAMS_DT)
+        ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
+        units = np.zeros((h4, w4), CU_UNIT_DT); cur = np.zeros((h4, w4), MV_UNIT_DT)
+        col = prev_fields[k - 1] if not is_i else np.zeros((h4, w4), MV_UNIT_DT)
+        ref_depth = np.zeros((2, h4, w4), np.uint8)
+        ref_qp0 = np.zeros((2, nctu), np.int8)
+        if not is_i:
+            ref_depth[0] = prev_units[k - 1]["depth"]
+            ref_qp0[0, :] = slice_qps[k - 1]
+        stat = np.zeros(nctu + 1, CU_STAT_DT)
+        coeff = np.zeros((nctu, RD_TILE), np.int16)
+        data = np.zeros(1 << 20, np.uint8); nbytes = C.c_size_t(0)
+        rc = lib.x265amd_analyse_frame(me.ctx, None, _ptr(info), _ptr(sp), _ptr(si), _ptr(ap), _ptr(units), _ptr(cur), _ptr(col), _ptr(ref_depth), _ptr(ref_qp0),
+                                       _ptr(planes), len(planes) // 3, C.c_int64(stride), C.c_int64(cstride), _ptr(stat), _ptr(coeff), None,
+                                       _ptr(data), C.c_size_t(data.size), C.byref(nbytes))
+        assert rc == 0, lib.x265amd_last_error()
+        # the reconstruction becomes a reference: extend its borders (PicYuv margins 96 / 80)
+        for p in range(3):
+            w, h, mx, my, st = (W, H, MC_MX, MC_MY, stride) if p == 0 else (W // 2, H // 2, MC_MX // 2, MC_MY // 2, cstride)
+            assert lib.x265amd_extend_pic_border(None, C.c_void_p(d_rec[k].data_ptr() + org[p] * isz), C.c_int64(st), w, h, mx, my) == 0
+        torch.cuda.synchronize()
+        prev_fields.append(np.ascontiguousarray(cur)); prev_units.append(units); prev_refpoc.append(rp)
+        rec = d_rec[k].cpu().numpy().view(frames[0].dtype)
+        out.append((frame_planes(rec, stride, cstride, org), data[:nbytes.value].copy()))
+    return out

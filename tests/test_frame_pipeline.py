@@ -1,0 +1,36 @@
+"""Frame pipeline end to end against the reference ENCODER (not a fixture): the reference's own command line program encodes a 4-frame
+synthetic clip (I P P P; CQP, no AQ / cutree / weighted prediction / in-loop filters / WPP, preset medium otherwise: rd 3, hex subme 2,
+3 references, limit-refs 3, early skip, rskip, psy-rd 2.0, sign hiding, strong intra smoothing, temporal MVP); its reconstructed frames
+(--recon) and the slice data of its bitstream are the golden data (tests/golden/frame_pipeline_golden.npz, generated here by
+tests/golden/make_golden.py).  x265amd_analyse_frame must reproduce every reconstructed sample and every slice-data byte."""
+import os
+
+import numpy as np
+import pytest
+
+import hevc_testlib as T
+
+GOLD_PATH = os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz")
+
+
+def test_golden_is_a_real_encode():
+    g = np.load(GOLD_PATH)
+    assert list(g["slice_qp"]) == [27, 30, 30, 30] and int(g["nframes"]) == 4
+    assert all(len(g["slice/%d" % k]) > 20 for k in range(4))
+
+
+@pytest.mark.gpu
+def test_hip_frame_pipeline_matches_reference_encoder():
+    g = np.load(GOLD_PATH)
+    me = T.HipME(8)
+    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g["slice_qp"]])
+    for k, (planes, data) in enumerate(got):
+        for p in range(3):
+            want = g["recon/%d/%d" % (k, p)]
+            if not np.array_equal(planes[p], want):
+                bad = np.argwhere(planes[p] != want)
+                raise AssertionError("frame %d plane %d: %d reconstructed samples differ from the reference encoder's, first at (y, x) = %s" % (
+                    k, p, len(bad), bad[0].tolist()))
+        ref_slice = g["slice/%d" % k]
+        assert len(data) <= len(ref_slice) and np.array_equal(ref_slice[len(ref_slice) - len(data):], data), \
+            "frame %d: slice data differs from the reference encoder's bitstream (%d vs %d payload bytes)" % (k, len(data), len(ref_slice))

@@ -662,7 +662,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
                                           intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
                                           int16_t* coeff_out, x265amd_ctu_result* out)
 {
-    if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 3)
+    if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
     if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs < 0 || A->limit_refs > 3 || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
@@ -713,5 +713,72 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         if (coeff_out) memcpy(coeff_out, b.coeff.data(), sizeof(int16_t) * kTileElems);
     }
     delete an;
+    return rc;
+}
+
+/* The CTU loop of one frame: FrameEncoder::processRowEncoder (reference: source/encoder/frameencoder.cpp:1399-1700) without rate control,
+ * VBV, slices or filters: every CTU in raster order (which respects the wavefront dependencies), its start state taken from the row coder
+ * (one per row under WPP: row r > 0 starts from the state saved after the second CTU of row r - 1, frameencoder.cpp:1568-1573 / :1596-1598;
+ * otherwise one coder runs through all rows), compressCTU, then the row coder codes the CTU in bit-counting mode to advance its state.
+ * Without WPP the slice data can be written afterwards (FrameEncoder::encodeSlice, :1298-1370).
+ * The reference's row coder only counts bits when SAO is on; without SAO it writes the final bitstream itself (frameencoder.cpp:683-699)
+ * and its m_fracBits stays 0, so every CTU then starts from a zero bit fraction (ap->use_sao). */
+extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                                     const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                                     const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                                     intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
+                                     uint8_t* slice_data, size_t cap, size_t* slice_bytes)
+{
+    if (!I || !si || !units || !cur || !cu_stat || !coeff_out) return xa_fail(X265AMD_EINVAL, "analyse_frame: null argument");
+    const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2, h4 = si->pic_height >> 2;
+    for (int i = 0; i < w4 * h4; i++)
+    {
+        memset(&units[i], 0, sizeof(x265amd_cu_unit));
+        units[i].qp = (int8_t)si->slice_qp;
+        memset(&cur[i], 0, sizeof(x265amd_mv_unit));
+        cur[i].ref_idx[0] = cur[i].ref_idx[1] = -1;
+    }
+    memset(cu_stat, 0, sizeof(x265amd_cu_stat) * (numCtu + 1));          /* FrameData::reinit */
+    const bool wpp = si->wpp != 0;
+    std::vector<x265amd_cabac*> rows(wpp ? ctuH : 1, nullptr);
+    for (size_t r = 0; r < rows.size(); r++)
+    {
+        rows[r] = x265amd_cabac_open(si, units, 1);
+        if (!rows[r]) { for (x265amd_cabac* c : rows) if (c) x265amd_cabac_close(c); return xa_fail(X265AMD_EINVAL, "analyse_frame: slice description"); }
+    }
+    std::vector<uint8_t> buffered((size_t)ctuH * X265AMD_CTX_STRIDE, 0);
+    int rc = X265AMD_OK;
+    for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
+    {
+        const int row = addr / ctuW, colIdx = addr % ctuW;
+        x265amd_cabac* rowCoder = rows[wpp ? row : 0];
+        if (wpp && !colIdx && row)
+        {
+            /* copyState(m_initSliceContext) + loadContexts(bufferedEntropy of the row above) */
+            memcpy(rowCoder->ctx, &buffered[(size_t)(row - 1) * X265AMD_CTX_STRIDE], X265AMD_CTX_STRIDE);
+            rowCoder->fracBits = 0;
+        }
+        x265amd_ctu_result res;
+        int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
+        rc = x265amd_compress_ctu_inter(me, stream, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
+                                        rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res);
+        if (rc != X265AMD_OK) break;
+        if (results) results[addr] = res;
+        rc = x265amd_cabac_encode_ctu(rowCoder, addr, coeff, coeff + 4096, coeff + 5120);
+        if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], rowCoder->ctx, X265AMD_CTX_STRIDE);
+    }
+    for (x265amd_cabac* c : rows) x265amd_cabac_close(c);
+    if (rc == X265AMD_OK && slice_data && slice_bytes)
+    {
+        if (wpp) return xa_fail(X265AMD_EINVAL, "analyse_frame: slice data is written for single-substream slices only (wpp = 0)");
+        x265amd_cabac* w = x265amd_cabac_open(si, units, 0);
+        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
+        {
+            const int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
+            rc = x265amd_cabac_encode_ctu(w, addr, coeff, coeff + 4096, coeff + 5120);
+        }
+        if (rc == X265AMD_OK) *slice_bytes = x265amd_cabac_finish_slice(w, slice_data, cap);
+        x265amd_cabac_close(w);
+    }
     return rc;
 }
