@@ -425,6 +425,10 @@ int x265amd_weight_plane(void* stream, const x265amd_pixel* d_src, x265amd_pixel
 #define X265AMD_DB_PU_LEFT 16       /* ... a PU edge inside the CU (setEdgefilterPU) */
 #define X265AMD_DB_TU_TOP 32
 #define X265AMD_DB_PU_TOP 64
+typedef struct x265amd_slice_info x265amd_slice_info;
+typedef struct x265amd_mvpred_info x265amd_mvpred_info;
+typedef struct x265amd_cu_unit x265amd_cu_unit;
+typedef struct x265amd_mv_unit x265amd_mv_unit;
 typedef struct x265amd_deblock_unit { uint8_t flags; int8_t qp; int8_t ref[2]; int16_t mv[2][2]; } x265amd_deblock_unit;
 /* d_y / d_u / d_v: sample (0,0) of the reconstructed planes (filtered in place).  width / height: multiples of 8.
  * beta / tc offsets and chroma QP offsets as in the PPS; passes: bit 0 vertical edges, bit 1 horizontal edges (3 = both, in that
@@ -432,6 +436,11 @@ typedef struct x265amd_deblock_unit { uint8_t flags; int8_t qp; int8_t ref[2]; i
 int x265amd_deblock_picture(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
                             int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
                             int cbQpOffset, int crQpOffset, int bypassEnabled, int passes);
+
+/* the deblocking records of a picture from the maps the analysis fills in (host): edge marks from the CU / PU / TU structure as
+ * Deblock::deblockCU sets them (deblock.cpp:70-185), picture identities from info->ref_poc.  out: (width/4) x (height/4) records. */
+int x265amd_deblock_units(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
+                          x265amd_deblock_unit* out);
 
 /* --- sample adaptive offset over a picture, the two data-parallel halves; 4:2:0, sao-non-deblock off.
  * Plane tables are HOST arrays of 3 device addresses (sample (0,0) of Y, U, V).

@@ -276,6 +276,15 @@ def make_frame_pipeline_golden():
     """the reference ENCODER's own output for the clip of T.frame_clip(): reconstructed frames and slice payloads -> frame_pipeline_golden.npz"""
     import subprocess, tempfile, csv
     frames, stride, cstride, org = T.frame_clip(8, 4)
+    out = {"nframes": np.array(4)}
+    for tag, cli in (("", T.FRAME_CLI_ARGS), ("deblock/", [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"])):
+        _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
+    print("wrote frame_pipeline_golden.npz:", [len(out["slice/%d" % i]) for i in range(4)], [len(out["deblock/slice/%d" % i]) for i in range(4)])
+
+
+def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out):
+    import subprocess, tempfile, csv
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "clip.y4m"), "wb") as f:
             f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420\n" % (T.MC_W, T.MC_H))
@@ -284,7 +293,7 @@ def make_frame_pipeline_golden():
                 for pl in T.frame_planes(p, stride, cstride, org):
                     f.write(np.ascontiguousarray(pl).tobytes())
         exe = os.path.join(T.REF_DIR, "x265_ref8")
-        r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv", "--csv", "log.csv", "--csv-log-level", "1"] + T.FRAME_CLI_ARGS,
+        r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv", "--csv", "log.csv", "--csv-log-level", "1"] + cli,
                            cwd=d, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
@@ -293,13 +302,13 @@ def make_frame_pipeline_golden():
         for row in csv.reader(open(os.path.join(d, "log.csv"))):
             if len(row) > 3 and row[1].strip().endswith("SLICE"):
                 qps.append(int(float(row[3])))
-    out = {"nframes": np.array(4), "slice_qp": np.array(qps, np.int32)}
+    out[tag + "slice_qp"] = np.array(qps, np.int32)
     fsz = T.MC_W * T.MC_H * 3 // 2
     for k in range(4):
         fr = rec[k * fsz:(k + 1) * fsz]
-        out["recon/%d/0" % k] = fr[:T.MC_W * T.MC_H].reshape(T.MC_H, T.MC_W)
-        out["recon/%d/1" % k] = fr[T.MC_W * T.MC_H:T.MC_W * T.MC_H * 5 // 4].reshape(T.MC_H // 2, T.MC_W // 2)
-        out["recon/%d/2" % k] = fr[T.MC_W * T.MC_H * 5 // 4:].reshape(T.MC_H // 2, T.MC_W // 2)
+        out[tag + "recon/%d/0" % k] = fr[:T.MC_W * T.MC_H].reshape(T.MC_H, T.MC_W)
+        out[tag + "recon/%d/1" % k] = fr[T.MC_W * T.MC_H:T.MC_W * T.MC_H * 5 // 4].reshape(T.MC_H // 2, T.MC_W // 2)
+        out[tag + "recon/%d/2" % k] = fr[T.MC_W * T.MC_H * 5 // 4:].reshape(T.MC_H // 2, T.MC_W // 2)
     # NAL units (Annex B): VCL units (types 0..31) in order; payload with emulation prevention bytes removed, 2-byte NAL header dropped
     pos, nals = 0, []
     starts = []
@@ -325,11 +334,9 @@ def make_frame_pipeline_golden():
                     continue
                 rbsp.append(byte)
                 z = z + 1 if byte == 0 else 0
-            out["slice/%d" % k] = np.frombuffer(bytes(rbsp), np.uint8)
+            out[tag + "slice/%d" % k] = np.frombuffer(bytes(rbsp), np.uint8)
             k += 1
     assert k == 4, k
-    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
-    print("wrote frame_pipeline_golden.npz:", qps, [len(out["slice/%d" % i]) for i in range(4)])
 
 
 if __name__ == "__main__":

@@ -2739,7 +2739,7 @@ def frame_planes(pic, stride, cstride, org):
     return out
 
 
-def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8):
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False):
     """I + P frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, no filters,
     one substream): returns per frame (recon planes, slice data bytes)"""
     import torch
@@ -2797,6 +2797,15 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8):
                                        _ptr(planes), len(planes) // 3, C.c_int64(stride), C.c_int64(cstride), _ptr(stat), _ptr(coeff), None,
                                        _ptr(data), C.c_size_t(data.size), C.byref(nbytes))
         assert rc == 0, lib.x265amd_last_error()
+        if deblock:
+            # FrameFilter: in-loop deblocking of the finished picture (default offsets), before it becomes a reference
+            dbu = np.zeros(w4 * h4, DB_UNIT_DT)
+            assert lib.x265amd_deblock_units(_ptr(si), _ptr(info), _ptr(units), _ptr(cur), _ptr(dbu)) == 0
+            d_dbu = torch.from_numpy(dbu.view(np.uint8)).cuda()
+            pl = addr(d_rec[k])
+            assert lib.x265amd_deblock_picture(None, C.c_void_p(pl[0]), C.c_void_p(pl[1]), C.c_void_p(pl[2]), C.c_int64(stride), C.c_int64(cstride), W, H,
+                                               C.c_void_p(d_dbu.data_ptr()), 0, 0, 0, 0, 0, 3) == 0
+            torch.cuda.synchronize()
         # the reconstruction becomes a reference: extend its borders (PicYuv margins 96 / 80)
         for p in range(3):
             w, h, mx, my, st = (W, H, MC_MX, MC_MY, stride) if p == 0 else (W // 2, H // 2, MC_MX // 2, MC_MY // 2, cstride)

@@ -20,17 +20,19 @@ def test_golden_is_a_real_encode():
 
 
 @pytest.mark.gpu
-def test_hip_frame_pipeline_matches_reference_encoder():
+@pytest.mark.parametrize("tag", ["", "deblock/"])
+def test_hip_frame_pipeline_matches_reference_encoder(tag):
+    """tag "deblock/": the same encode with the in-loop deblocking filter on (x265amd_deblock_units + x265amd_deblock_picture per frame)"""
     g = np.load(GOLD_PATH)
     me = T.HipME(8)
-    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g["slice_qp"]])
+    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], deblock=bool(tag))
     for k, (planes, data) in enumerate(got):
         for p in range(3):
-            want = g["recon/%d/%d" % (k, p)]
+            want = g[tag + "recon/%d/%d" % (k, p)]
             if not np.array_equal(planes[p], want):
                 bad = np.argwhere(planes[p] != want)
                 raise AssertionError("frame %d plane %d: %d reconstructed samples differ from the reference encoder's, first at (y, x) = %s" % (
                     k, p, len(bad), bad[0].tolist()))
-        ref_slice = g["slice/%d" % k]
+        ref_slice = g[tag + "slice/%d" % k]
         assert len(data) <= len(ref_slice) and np.array_equal(ref_slice[len(ref_slice) - len(data):], data), \
             "frame %d: slice data differs from the reference encoder's bitstream (%d vs %d payload bytes)" % (k, len(data), len(ref_slice))
