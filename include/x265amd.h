@@ -707,13 +707,36 @@ int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_m
  * VBV, slices and in-loop filters): clears units / cur / cu_stat, then for every CTU takes the start state from the row coder (si->wpp: one
  * coder per row, rows > 0 start from the state saved after the second CTU of the row above; otherwise one coder through all rows), runs
  * x265amd_compress_ctu_inter and lets the row coder code the CTU in bit-counting mode.  coeff_out: numCtu x (4096 + 2 x 1024) levels.
- * results (may be NULL): per CTU.  slice_data / slice_bytes (may be NULL; wpp = 0 only): the slice data as FrameEncoder::encodeSlice writes
- * it (:1298-1370), i.e. everything after the slice header.  Other arguments as x265amd_compress_ctu_inter. */
+ * results (may be NULL): per CTU.  slice_data / substream_sizes / num_substreams (may be NULL): the CABAC sub-streams as
+ * FrameEncoder::encodeSlice writes them (:1298-1370), back to back: one per CTU row under WPP, otherwise one; x265amd_write_slice_nal packs
+ * them behind the slice header.  Other arguments as x265amd_compress_ctu_inter. */
 int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* info, const x265amd_inter_search_params* sp,
                           const x265amd_slice_info* si, const x265amd_analysis_params* ap, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                           const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                           intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
-                          uint8_t* slice_data, size_t cap, size_t* slice_bytes);
+                          uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams);
+
+/* --- slice NAL units (host): Entropy::codeSliceHeader + codeSliceHeaderWPPEntryPoints + the byte-stream packing of
+ * NALList::serialize / serializeSubstreams (reference: source/encoder/entropy.cpp:593-766, source/encoder/nal.cpp:60-232).  One slice per picture;
+ * no weighted prediction tables, long-term references or dependent slices.  slice_type as in the bitstream: 0 B, 1 P, 2 I. */
+typedef struct x265amd_slice_header
+{
+    int32_t nal_unit_type;          /* 0 TRAIL_N, 1 TRAIL_R, 19 IDR_W_RADL, 20 IDR_N_LP, 21 CRA ... */
+    int32_t temporal_id_plus1;      /* 0 is taken as 1 */
+    int32_t first_in_access_unit;   /* 4-byte start code (first NAL of the access unit) instead of 3 */
+    int32_t slice_type, poc, last_idr_poc, log2_max_poc_lsb;
+    int32_t rps_idx, num_rps_in_sps;/* rps_idx < 0: the reference picture set is coded in the header */
+    int32_t num_negative, num_positive, delta_poc[16], used[16];
+    int32_t temporal_mvp_enabled, use_sao, sao_luma, sao_chroma, selective_sao;
+    int32_t num_ref_idx[2], num_ref_idx_default[2], col_from_l0, col_ref_idx, max_num_merge_cand;
+    int32_t slice_qp, pps_init_qp;  /* 26 + init_qp_minus26 of the PPS */
+    int32_t chroma_qp_offsets_present, cb_qp_offset, cr_qp_offset;
+    int32_t deblocking_disabled;    /* pps.bPicDisableDeblockingFilter */
+    int32_t slfase_flag;            /* slice.m_sLFaseFlag */
+    int32_t wpp;                    /* entry points are written; one sub-stream per CTU row */
+} x265amd_slice_header;
+/* substreams: the raw (unescaped) CABAC sub-streams back to back, sizes[i] bytes each.  Returns the NAL size in bytes (written when it fits). */
+size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const uint8_t* substreams, const uint32_t* sizes, int num_substreams, uint8_t* out, size_t cap);
 
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */

@@ -277,10 +277,11 @@ def make_frame_pipeline_golden():
     import subprocess, tempfile, csv
     frames, stride, cstride, org = T.frame_clip(8, 4)
     out = {"nframes": np.array(4)}
-    for tag, cli in (("", T.FRAME_CLI_ARGS), ("deblock/", [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"])):
+    for tag, cli in (("", T.FRAME_CLI_ARGS), ("deblock/", [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]),
+                     ("wpp/", [("2" if a == "none" else a) for a in T.FRAME_CLI_ARGS if a not in ("--no-deblock", "--no-wpp")] + ["--wpp"])):   # WPP needs a thread pool
         _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
-    print("wrote frame_pipeline_golden.npz:", [len(out["slice/%d" % i]) for i in range(4)], [len(out["deblock/slice/%d" % i]) for i in range(4)])
+    print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 
 
 def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out):
@@ -324,9 +325,11 @@ def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out):
         while nal.endswith(b"\x00") and b <= len(hevc):
             nal = nal[:-1]
         nals.append(nal)
+    out[tag + "stream"] = np.frombuffer(hevc, np.uint8)
     k = 0
     for nal in nals:
         if ((nal[0] >> 1) & 0x3f) < 32:
+            out[tag + "nal/%d" % k] = np.frombuffer(nal, np.uint8)          # as in the byte stream (escaped), without the start code
             rbsp = bytearray(); z = 0
             for byte in nal[2:]:
                 if z >= 2 and byte == 3:

@@ -2739,9 +2739,32 @@ def frame_planes(pic, stride, cstride, org):
     return out
 
 
-def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False):
+SLICE_HEADER_DT = np.dtype([(n, "<i4") for n in ("nal_unit_type", "temporal_id_plus1", "first_in_access_unit", "slice_type", "poc", "last_idr_poc", "log2_max_poc_lsb",
+                                                    "rps_idx", "num_rps_in_sps", "num_negative", "num_positive")] + [("delta_poc", "<i4", 16), ("used", "<i4", 16)] +
+                           [(n, "<i4") for n in ("temporal_mvp_enabled", "use_sao", "sao_luma", "sao_chroma", "selective_sao")] +
+                           [("num_ref_idx", "<i4", 2), ("num_ref_idx_default", "<i4", 2)] +
+                           [(n, "<i4") for n in ("col_from_l0", "col_ref_idx", "max_num_merge_cand", "slice_qp", "pps_init_qp", "chroma_qp_offsets_present", "cb_qp_offset",
+                                                 "cr_qp_offset", "deblocking_disabled", "slfase_flag", "wpp")])
+
+
+def frame_slice_header(k, slice_qp, deblock, wpp):
+    """the slice header fields of frame k of the I P P P clip as the reference's DPB / encoder set them (dpb.cpp:prepareEncode, encoder.cpp)"""
+    h = np.zeros(1, SLICE_HEADER_DT)
+    h["nal_unit_type"] = 20 if k == 0 else 1            # IDR_N_LP, then TRAIL_R
+    h["first_in_access_unit"] = int(k > 0)              # the IDR slice follows the parameter sets in its access unit
+    h["slice_type"], h["poc"], h["log2_max_poc_lsb"], h["rps_idx"] = (2 if k == 0 else 1), k, 8, -1
+    h["num_negative"] = min(k, 3)
+    h["delta_poc"][0, :3] = [-1, -2, -3]; h["used"][0, :3] = 1
+    h["temporal_mvp_enabled"] = 1
+    h["num_ref_idx"] = (min(k, 3), 0); h["num_ref_idx_default"] = (1, 1); h["col_from_l0"] = 1; h["max_num_merge_cand"] = 3
+    h["slice_qp"], h["pps_init_qp"], h["deblocking_disabled"], h["wpp"] = slice_qp, 26, int(not deblock), int(wpp)
+    h["slfase_flag"] = (0x5f4e4a53 >> (k % 31)) & 1     # SLFASE_CONSTANT (dpb.cpp:294)
+    return h
+
+
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False):
     """I + P frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, no filters,
-    one substream): returns per frame (recon planes, slice data bytes)"""
+    optionally wavefront sub-streams): returns per frame (recon planes, the slice NAL unit with its start code)"""
     import torch
     frames, stride, cstride, org = frame_clip(depth, nframes)
     isz = frames[0].itemsize
@@ -2780,7 +2803,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False):
         si["pic_width"], si["pic_height"], si["slice_type"], si["slice_qp"] = W, H, 2 if is_i else 1, slice_qps[k]
         si["num_ref_idx"] = (len(refs), 0)
         si["max_num_merge_cand"], si["sign_hide"], si["max_cu_depth"], si["tu_log2_min"], si["tu_log2_max"] = 3, 1, 3, 2, 5
-        si["tu_max_depth_inter"], si["tu_max_depth_intra"] = 1, 1
+        si["tu_max_depth_inter"], si["tu_max_depth_intra"], si["wpp"] = 1, 1, int(wpp)
         ap = np.zeros(1, ANALYSIS_PARAMS_DT)
         ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
         units = np.zeros((h4, w4), CU_UNIT_DT); cur = np.zeros((h4, w4), MV_UNIT_DT)
@@ -2792,10 +2815,10 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False):
             ref_qp0[0, :] = slice_qps[k - 1]
         stat = np.zeros(nctu + 1, CU_STAT_DT)
         coeff = np.zeros((nctu, RD_TILE), np.int16)
-        data = np.zeros(1 << 20, np.uint8); nbytes = C.c_size_t(0)
+        data = np.zeros(1 << 20, np.uint8); sizes = np.zeros(64, np.uint32); nsub = C.c_int(0)
         rc = lib.x265amd_analyse_frame(me.ctx, None, _ptr(info), _ptr(sp), _ptr(si), _ptr(ap), _ptr(units), _ptr(cur), _ptr(col), _ptr(ref_depth), _ptr(ref_qp0),
                                        _ptr(planes), len(planes) // 3, C.c_int64(stride), C.c_int64(cstride), _ptr(stat), _ptr(coeff), None,
-                                       _ptr(data), C.c_size_t(data.size), C.byref(nbytes))
+                                       _ptr(data), C.c_size_t(data.size), _ptr(sizes), C.byref(nsub))
         assert rc == 0, lib.x265amd_last_error()
         if deblock:
             # FrameFilter: in-loop deblocking of the finished picture (default offsets), before it becomes a reference
@@ -2813,5 +2836,10 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False):
         torch.cuda.synchronize()
         prev_fields.append(np.ascontiguousarray(cur)); prev_units.append(units); prev_refpoc.append(rp)
         rec = d_rec[k].cpu().numpy().view(frames[0].dtype)
-        out.append((frame_planes(rec, stride, cstride, org), data[:nbytes.value].copy()))
+        nal = np.zeros(1 << 20, np.uint8)
+        lib.x265amd_write_slice_nal.restype = C.c_size_t
+        hdr = frame_slice_header(k, slice_qps[k], deblock, wpp)
+        n = lib.x265amd_write_slice_nal(_ptr(hdr), _ptr(data), _ptr(sizes), nsub.value, _ptr(nal), C.c_size_t(nal.size))
+        assert 0 < n <= nal.size
+        out.append((frame_planes(rec, stride, cstride, org), nal[:n].copy()))
     return out

@@ -20,12 +20,14 @@ def test_golden_is_a_real_encode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["", "deblock/"])
+@pytest.mark.parametrize("tag", ["", "deblock/", "wpp/"])
 def test_hip_frame_pipeline_matches_reference_encoder(tag):
-    """tag "deblock/": the same encode with the in-loop deblocking filter on (x265amd_deblock_units + x265amd_deblock_picture per frame)"""
+    """tag "deblock/": the same encode with the in-loop deblocking filter on (x265amd_deblock_units + x265amd_deblock_picture per frame);
+    "wpp/": deblocking and wavefront parallel processing on (per-row entropy states, one sub-stream per CTU row, entry points in the slice header).
+    The slice NAL units (x265amd_write_slice_nal) behind the reference's parameter sets must give the reference's byte stream."""
     g = np.load(GOLD_PATH)
     me = T.HipME(8)
-    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], deblock=bool(tag))
+    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], deblock=bool(tag), wpp=tag == "wpp/")
     for k, (planes, data) in enumerate(got):
         for p in range(3):
             want = g[tag + "recon/%d/%d" % (k, p)]
@@ -33,6 +35,12 @@ def test_hip_frame_pipeline_matches_reference_encoder(tag):
                 bad = np.argwhere(planes[p] != want)
                 raise AssertionError("frame %d plane %d: %d reconstructed samples differ from the reference encoder's, first at (y, x) = %s" % (
                     k, p, len(bad), bad[0].tolist()))
-        ref_slice = g[tag + "slice/%d" % k]
-        assert len(data) <= len(ref_slice) and np.array_equal(ref_slice[len(ref_slice) - len(data):], data), \
-            "frame %d: slice data differs from the reference encoder's bitstream (%d vs %d payload bytes)" % (k, len(data), len(ref_slice))
+        want_nal = g[tag + "nal/%d" % k]
+        sc = 4 if k else 3
+        assert np.array_equal(data[sc:], want_nal), "frame %d: slice NAL unit differs from the reference encoder's (%d vs %d bytes)" % (k, len(data) - sc, len(want_nal))
+    # the whole byte stream: the reference's VPS / SPS / PPS (configuration constants, taken from its stream) + our slice NAL units
+    stream = g[tag + "stream"]
+    first = len(stream) - sum(len(g[tag + "nal/%d" % k]) + (4 if k else 3) for k in range(4))
+    ours = np.concatenate([stream[:first]] + [d for (_, d) in got])
+    import hashlib
+    assert hashlib.md5(ours.tobytes()).hexdigest() == hashlib.md5(stream.tobytes()).hexdigest()

@@ -727,7 +727,7 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
                                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
-                                     uint8_t* slice_data, size_t cap, size_t* slice_bytes)
+                                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams)
 {
     if (!I || !si || !units || !cur || !cu_stat || !coeff_out) return xa_fail(X265AMD_EINVAL, "analyse_frame: null argument");
     const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2, h4 = si->pic_height >> 2;
@@ -768,17 +768,36 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
         if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], rowCoder->ctx, X265AMD_CTX_STRIDE);
     }
     for (x265amd_cabac* c : rows) x265amd_cabac_close(c);
-    if (rc == X265AMD_OK && slice_data && slice_bytes)
+    if (rc == X265AMD_OK && slice_data && substream_sizes && num_substreams)
     {
-        if (wpp) return xa_fail(X265AMD_EINVAL, "analyse_frame: slice data is written for single-substream slices only (wpp = 0)");
-        x265amd_cabac* w = x265amd_cabac_open(si, units, 0);
+        /* FrameEncoder::encodeSlice: one sub-stream per CTU row under WPP (each row starts from the state saved after the second CTU of the row
+         * above and ends with finishSlice), otherwise one for the picture */
+        size_t total = 0;
+        int count = 0;
+        x265amd_cabac* w = nullptr;
         for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
         {
+            const int row = addr / ctuW, colIdx = addr % ctuW;
+            if (!w)
+            {
+                w = x265amd_cabac_open(si, units, 0);
+                if (wpp && row) memcpy(w->ctx, &buffered[(size_t)(row - 1) * X265AMD_CTX_STRIDE], X265AMD_CTX_STRIDE);
+            }
             const int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
             rc = x265amd_cabac_encode_ctu(w, addr, coeff, coeff + 4096, coeff + 5120);
+            if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], w->ctx, X265AMD_CTX_STRIDE);
+            if ((wpp && colIdx == ctuW - 1) || addr == numCtu - 1)
+            {
+                const size_t n = x265amd_cabac_finish_slice(w, slice_data + total, cap > total ? cap - total : 0);
+                if (total + n > cap) rc = xa_fail(X265AMD_EINVAL, "analyse_frame: slice data buffer too small");
+                substream_sizes[count++] = (uint32_t)n;
+                total += n;
+                x265amd_cabac_close(w);
+                w = nullptr;
+            }
         }
-        if (rc == X265AMD_OK) *slice_bytes = x265amd_cabac_finish_slice(w, slice_data, cap);
-        x265amd_cabac_close(w);
+        if (w) x265amd_cabac_close(w);
+        *num_substreams = count;
     }
     return rc;
 }
