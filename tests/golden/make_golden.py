@@ -280,11 +280,17 @@ def make_frame_pipeline_golden():
     for tag, cli in (("", T.FRAME_CLI_ARGS), ("deblock/", [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]),
                      ("wpp/", [("2" if a == "none" else a) for a in T.FRAME_CLI_ARGS if a not in ("--no-deblock", "--no-wpp")] + ["--wpp"])):   # WPP needs a thread pool
         _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out)
+    # a clip with B frames: fixed mini-GOP (I P b b P b b in coding order), deblocking on
+    framesb, stride, cstride, org = T.frame_clip_b(8)
+    clib = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
+    clib[clib.index("--bframes") + 1] = "2"
+    clib[clib.index("--rc-lookahead") + 1] = "5"
+    _frame_pipeline_one(framesb, stride, cstride, org, "bframes/", clib + ["--no-b-pyramid"], out, nframes=7)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
     print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 
 
-def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out):
+def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out, nframes=4):
     import subprocess, tempfile, csv
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "clip.y4m"), "wb") as f:
@@ -299,14 +305,20 @@ def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out):
         assert r.returncode == 0, r.stderr[-2000:]
         rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
         hevc = open(os.path.join(d, "out.hevc"), "rb").read()
-        qps = []
+        qps, sched = [], []
         for row in csv.reader(open(os.path.join(d, "log.csv"))):
-            if len(row) > 3 and row[1].strip().endswith("SLICE"):
+            if len(row) > 8 and row[1].strip().endswith("SLICE"):
                 qps.append(int(float(row[3])))
+                l0 = [int(v) for v in row[7].split()] if row[7].strip() != "-" else []
+                l1 = [int(v) for v in row[8].split()] if row[8].strip() != "-" else []
+                t = row[1].strip()
+                # type: 2 I, 1 P, 0 B; referenced: upper-case type names
+                sched.append([{"I": 2, "P": 1, "B": 0, "b": 0}[t[0]], int(row[2]), int(t[0] != "b")] + (l0 + [-1] * 4)[:4] + (l1 + [-1] * 4)[:4])
     out[tag + "slice_qp"] = np.array(qps, np.int32)
+    out[tag + "schedule"] = np.array(sched, np.int32)          # per coded frame: type, poc, referenced, L0 pocs (4), L1 pocs (4)
     fsz = T.MC_W * T.MC_H * 3 // 2
-    for k in range(4):
-        fr = rec[k * fsz:(k + 1) * fsz]
+    for k in range(nframes):
+        fr = rec[k * fsz:(k + 1) * fsz]                    # output (POC) order
         out[tag + "recon/%d/0" % k] = fr[:T.MC_W * T.MC_H].reshape(T.MC_H, T.MC_W)
         out[tag + "recon/%d/1" % k] = fr[T.MC_W * T.MC_H:T.MC_W * T.MC_H * 5 // 4].reshape(T.MC_H // 2, T.MC_W // 2)
         out[tag + "recon/%d/2" % k] = fr[T.MC_W * T.MC_H * 5 // 4:].reshape(T.MC_H // 2, T.MC_W // 2)
@@ -339,7 +351,7 @@ def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out):
                 z = z + 1 if byte == 0 else 0
             out[tag + "slice/%d" % k] = np.frombuffer(bytes(rbsp), np.uint8)
             k += 1
-    assert k == 4, k
+    assert k == nframes, k
 
 
 if __name__ == "__main__":

@@ -2747,72 +2747,99 @@ SLICE_HEADER_DT = np.dtype([(n, "<i4") for n in ("nal_unit_type", "temporal_id_p
                                                  "cr_qp_offset", "deblocking_disabled", "slfase_flag", "wpp")])
 
 
-def frame_slice_header(k, slice_qp, deblock, wpp):
-    """the slice header fields of frame k of the I P P P clip as the reference's DPB / encoder set them (dpb.cpp:prepareEncode, encoder.cpp)"""
+def frame_clip_b(depth=8):
+    """7 source frames in display order for the B-frame clip"""
+    pics, stride, cstride, org = inter_scene(depth, 777, npics=7)
+    return pics, stride, cstride, org
+
+
+def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb):
+    """the slice header fields of the k-th coded frame as the reference's DPB / encoder set them (dpb.cpp: prepareEncode / computeRPS,
+    encoder.cpp); dpb: POCs of the reference pictures kept so far"""
+    stype, poc, referenced = int(sched[0]), int(sched[1]), int(sched[2])
+    l0 = [int(v) for v in sched[3:7] if v >= 0]; l1 = [int(v) for v in sched[7:11] if v >= 0]
     h = np.zeros(1, SLICE_HEADER_DT)
-    h["nal_unit_type"] = 20 if k == 0 else 1            # IDR_N_LP, then TRAIL_R
+    h["nal_unit_type"] = 20 if stype == 2 else (1 if referenced else 0)     # IDR_N_LP / TRAIL_R / TRAIL_N
     h["first_in_access_unit"] = int(k > 0)              # the IDR slice follows the parameter sets in its access unit
-    h["slice_type"], h["poc"], h["log2_max_poc_lsb"], h["rps_idx"] = (2 if k == 0 else 1), k, 8, -1
-    h["num_negative"] = min(k, 3)
-    h["delta_poc"][0, :3] = [-1, -2, -3]; h["used"][0, :3] = 1
+    h["slice_type"], h["poc"], h["log2_max_poc_lsb"], h["rps_idx"] = stype, poc, 8, -1
+    neg = sorted([p for p in dpb if p < poc], reverse=True); pos = sorted([p for p in dpb if p > poc])
+    h["num_negative"], h["num_positive"] = len(neg), len(pos)
+    for j, p in enumerate(neg + pos):
+        h["delta_poc"][0, j] = p - poc; h["used"][0, j] = 1
     h["temporal_mvp_enabled"] = 1
-    h["num_ref_idx"] = (min(k, 3), 0); h["num_ref_idx_default"] = (1, 1); h["col_from_l0"] = 1; h["max_num_merge_cand"] = 3
+    h["num_ref_idx"] = (len(l0), len(l1)); h["num_ref_idx_default"] = (1, 1); h["col_from_l0"] = int(stype != 0); h["max_num_merge_cand"] = 3
     h["slice_qp"], h["pps_init_qp"], h["deblocking_disabled"], h["wpp"] = slice_qp, 26, int(not deblock), int(wpp)
-    h["slfase_flag"] = (0x5f4e4a53 >> (k % 31)) & 1     # SLFASE_CONSTANT (dpb.cpp:294)
+    h["slfase_flag"] = (0x5f4e4a53 >> (poc % 31)) & 1   # SLFASE_CONSTANT (dpb.cpp:294)
     return h
 
 
-def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False):
-    """I + P frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, no filters,
-    optionally wavefront sub-streams): returns per frame (recon planes, the slice NAL unit with its start code)"""
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None):
+    """frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, optional deblocking and
+    wavefront sub-streams).  schedule: per coded frame (type 2 I / 1 P / 0 B, poc, referenced, 4 L0 pocs, 4 L1 pocs), default I P P P.
+    Returns per coded frame (poc, recon planes, the slice NAL unit with its start code)"""
     import torch
-    frames, stride, cstride, org = frame_clip(depth, nframes)
+    if frames is None:
+        frames, stride, cstride, org = frame_clip(depth, nframes)
+    else:
+        frames, stride, cstride, org = frames
+    if schedule is None:
+        schedule = [[2 if k == 0 else 1, k, 1] + (list(range(k - 1, max(-1, k - 4), -1)) + [-1] * 4)[:4] + [-1] * 4 for k in range(nframes)]
     isz = frames[0].itemsize
     W, H = MC_W, MC_H
     w4, h4, nctu = W // 4, H // 4, (W // 64) * (H // 64)
     lib = L.lib
-    d_src = [torch.from_numpy(f.view(np.uint8)).cuda() for f in frames]
-    d_rec = [torch.zeros_like(d) for d in d_src]
+    lib.x265amd_write_slice_nal.restype = C.c_size_t
+    d_src = {p: torch.from_numpy(frames[p].view(np.uint8)).cuda() for p in range(len(frames))}
+    d_rec = {}
     def addr(d):
         return [d.data_ptr() + org[k] * isz for k in range(3)]
-    prev_fields, prev_units, prev_refpoc, out = [], [], [], []
-    for k in range(nframes):
-        is_i = k == 0
-        refs = [] if is_i else list(range(k - 1, max(-1, k - 4), -1))          # L0: closest first, at most 3
-        planes = []
-        for r in refs:
-            planes += addr(d_rec[r])
-        planes += addr(d_rec[k]) + addr(d_src[k])
+    fields, unit_maps, refpocs, qp_of, dpb, out = {}, {}, {}, {}, [], []
+    for k, sc in enumerate(schedule):
+        stype, poc, referenced = int(sc[0]), int(sc[1]), int(sc[2])
+        lists = [[int(v) for v in sc[3:7] if v >= 0], [int(v) for v in sc[7:11] if v >= 0]]
+        d_rec[poc] = torch.zeros_like(d_src[poc])
+        planes, index = [], {}
+        for l in range(2):
+            for r in lists[l]:
+                if r not in index:
+                    index[r] = len(planes) // 3
+                    planes += addr(d_rec[r])
+        planes += addr(d_rec[poc]) + addr(d_src[poc])
         planes = np.array(planes, np.uint64)
         info = np.zeros(1, MVPRED_INFO_DT)
-        info["pic_width"], info["pic_height"], info["is_inter_b"], info["max_num_merge_cand"] = W, H, 0, 3
-        info["num_ref_idx"] = (len(refs), 0)
-        info["temporal_mvp"], info["col_from_l0"], info["check_ldc"], info["poc"] = 1, 1, 1, k
+        info["pic_width"], info["pic_height"], info["is_inter_b"], info["max_num_merge_cand"] = W, H, int(stype == 0), 3
+        info["num_ref_idx"] = (len(lists[0]), len(lists[1]))
+        info["temporal_mvp"], info["col_from_l0"], info["check_ldc"], info["poc"] = 1, int(stype != 0), int(stype != 0), poc
         rp = np.zeros((2, 16), np.int32)
-        rp[0, :len(refs)] = refs
+        for l in range(2):
+            rp[l, :len(lists[l])] = lists[l]
         info["ref_poc"] = rp
-        if not is_i:
-            info["col_poc"] = k - 1
-            info["col_ref_poc"] = prev_refpoc[k - 1]
+        col_poc = None
+        if stype != 2:
+            col_poc = lists[0][0] if stype == 1 else lists[1][0]
+            info["col_poc"] = col_poc
+            info["col_ref_poc"] = refpocs[col_poc]
         sp = np.zeros(1, INTER_SP_DT)
         sp["search_method"], sp["subpel_refine"], sp["search_range"], sp["qp"], sp["chroma_mc"] = ME_HEX, 2, 57, slice_qps[k], 1
         rpic = np.zeros((2, 16), np.int32)
-        rpic[0, :len(refs)] = np.arange(len(refs))
+        for l in range(2):
+            rpic[l, :len(lists[l])] = [index[r] for r in lists[l]]
         sp["ref_pic"] = rpic
         si = np.zeros(1, SLICE_INFO_DT)
-        si["pic_width"], si["pic_height"], si["slice_type"], si["slice_qp"] = W, H, 2 if is_i else 1, slice_qps[k]
-        si["num_ref_idx"] = (len(refs), 0)
+        si["pic_width"], si["pic_height"], si["slice_type"], si["slice_qp"] = W, H, stype, slice_qps[k]
+        si["num_ref_idx"] = (len(lists[0]), len(lists[1]))
         si["max_num_merge_cand"], si["sign_hide"], si["max_cu_depth"], si["tu_log2_min"], si["tu_log2_max"] = 3, 1, 3, 2, 5
         si["tu_max_depth_inter"], si["tu_max_depth_intra"], si["wpp"] = 1, 1, int(wpp)
         ap = np.zeros(1, ANALYSIS_PARAMS_DT)
         ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
         units = np.zeros((h4, w4), CU_UNIT_DT); cur = np.zeros((h4, w4), MV_UNIT_DT)
-        col = prev_fields[k - 1] if not is_i else np.zeros((h4, w4), MV_UNIT_DT)
+        col = fields[col_poc] if col_poc is not None else np.zeros((h4, w4), MV_UNIT_DT)
         ref_depth = np.zeros((2, h4, w4), np.uint8)
         ref_qp0 = np.zeros((2, nctu), np.int8)
-        if not is_i:
-            ref_depth[0] = prev_units[k - 1]["depth"]
-            ref_qp0[0, :] = slice_qps[k - 1]
+        for l in range(2):
+            if lists[l]:
+                ref_depth[l] = unit_maps[lists[l][0]]["depth"]
+                ref_qp0[l, :] = qp_of[lists[l][0]]
         stat = np.zeros(nctu + 1, CU_STAT_DT)
         coeff = np.zeros((nctu, RD_TILE), np.int16)
         data = np.zeros(1 << 20, np.uint8); sizes = np.zeros(64, np.uint32); nsub = C.c_int(0)
@@ -2825,21 +2852,22 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
             dbu = np.zeros(w4 * h4, DB_UNIT_DT)
             assert lib.x265amd_deblock_units(_ptr(si), _ptr(info), _ptr(units), _ptr(cur), _ptr(dbu)) == 0
             d_dbu = torch.from_numpy(dbu.view(np.uint8)).cuda()
-            pl = addr(d_rec[k])
+            pl = addr(d_rec[poc])
             assert lib.x265amd_deblock_picture(None, C.c_void_p(pl[0]), C.c_void_p(pl[1]), C.c_void_p(pl[2]), C.c_int64(stride), C.c_int64(cstride), W, H,
                                                C.c_void_p(d_dbu.data_ptr()), 0, 0, 0, 0, 0, 3) == 0
             torch.cuda.synchronize()
         # the reconstruction becomes a reference: extend its borders (PicYuv margins 96 / 80)
         for p in range(3):
             w, h, mx, my, st = (W, H, MC_MX, MC_MY, stride) if p == 0 else (W // 2, H // 2, MC_MX // 2, MC_MY // 2, cstride)
-            assert lib.x265amd_extend_pic_border(None, C.c_void_p(d_rec[k].data_ptr() + org[p] * isz), C.c_int64(st), w, h, mx, my) == 0
+            assert lib.x265amd_extend_pic_border(None, C.c_void_p(d_rec[poc].data_ptr() + org[p] * isz), C.c_int64(st), w, h, mx, my) == 0
         torch.cuda.synchronize()
-        prev_fields.append(np.ascontiguousarray(cur)); prev_units.append(units); prev_refpoc.append(rp)
-        rec = d_rec[k].cpu().numpy().view(frames[0].dtype)
+        fields[poc] = np.ascontiguousarray(cur); unit_maps[poc] = units; refpocs[poc] = rp; qp_of[poc] = slice_qps[k]
+        rec = d_rec[poc].cpu().numpy().view(frames[0].dtype)
         nal = np.zeros(1 << 20, np.uint8)
-        lib.x265amd_write_slice_nal.restype = C.c_size_t
-        hdr = frame_slice_header(k, slice_qps[k], deblock, wpp)
+        hdr = frame_slice_header(k, sc, slice_qps[k], deblock, wpp, dpb)
         n = lib.x265amd_write_slice_nal(_ptr(hdr), _ptr(data), _ptr(sizes), nsub.value, _ptr(nal), C.c_size_t(nal.size))
         assert 0 < n <= nal.size
-        out.append((frame_planes(rec, stride, cstride, org), nal[:n].copy()))
+        if referenced:
+            dpb.append(poc)
+        out.append((poc, frame_planes(rec, stride, cstride, org), nal[:n].copy()))
     return out

@@ -15,32 +15,36 @@ GOLD_PATH = os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz")
 
 def test_golden_is_a_real_encode():
     g = np.load(GOLD_PATH)
-    assert list(g["slice_qp"]) == [27, 30, 30, 30] and int(g["nframes"]) == 4
+    assert list(g["slice_qp"]) == [27, 30, 30, 30] and list(g["bframes/slice_qp"]) == [27, 30, 32, 32, 30, 32, 32]
     assert all(len(g["slice/%d" % k]) > 20 for k in range(4))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["", "deblock/", "wpp/"])
+@pytest.mark.parametrize("tag", ["", "deblock/", "wpp/", "bframes/"])
 def test_hip_frame_pipeline_matches_reference_encoder(tag):
     """tag "deblock/": the same encode with the in-loop deblocking filter on (x265amd_deblock_units + x265amd_deblock_picture per frame);
-    "wpp/": deblocking and wavefront parallel processing on (per-row entropy states, one sub-stream per CTU row, entry points in the slice header).
+    "wpp/": deblocking and wavefront parallel processing on (per-row entropy states, one sub-stream per CTU row, entry points in the slice header);
+    "bframes/": a 7-frame clip coded I P b b P b b (two lists, bi-prediction, collocated picture from list 1, non-referenced pictures), deblocking.
     The slice NAL units (x265amd_write_slice_nal) behind the reference's parameter sets must give the reference's byte stream."""
+    import hashlib
     g = np.load(GOLD_PATH)
     me = T.HipME(8)
-    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], deblock=bool(tag), wpp=tag == "wpp/")
-    for k, (planes, data) in enumerate(got):
+    sched = g[tag + "schedule"]
+    n = len(sched)
+    got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], nframes=n, deblock=bool(tag), wpp=tag == "wpp/", schedule=sched,
+                                   frames=T.frame_clip_b(8) if tag == "bframes/" else None)
+    for k, (poc, planes, data) in enumerate(got):
         for p in range(3):
-            want = g[tag + "recon/%d/%d" % (k, p)]
+            want = g[tag + "recon/%d/%d" % (poc, p)]
             if not np.array_equal(planes[p], want):
                 bad = np.argwhere(planes[p] != want)
-                raise AssertionError("frame %d plane %d: %d reconstructed samples differ from the reference encoder's, first at (y, x) = %s" % (
-                    k, p, len(bad), bad[0].tolist()))
+                raise AssertionError("coded frame %d (poc %d) plane %d: %d reconstructed samples differ from the reference encoder's, first at (y, x) = %s" % (
+                    k, poc, p, len(bad), bad[0].tolist()))
         want_nal = g[tag + "nal/%d" % k]
         sc = 4 if k else 3
-        assert np.array_equal(data[sc:], want_nal), "frame %d: slice NAL unit differs from the reference encoder's (%d vs %d bytes)" % (k, len(data) - sc, len(want_nal))
+        assert np.array_equal(data[sc:], want_nal), "coded frame %d: slice NAL unit differs from the reference encoder's (%d vs %d bytes)" % (k, len(data) - sc, len(want_nal))
     # the whole byte stream: the reference's VPS / SPS / PPS (configuration constants, taken from its stream) + our slice NAL units
     stream = g[tag + "stream"]
-    first = len(stream) - sum(len(g[tag + "nal/%d" % k]) + (4 if k else 3) for k in range(4))
-    ours = np.concatenate([stream[:first]] + [d for (_, d) in got])
-    import hashlib
+    first = len(stream) - sum(len(g[tag + "nal/%d" % k]) + (4 if k else 3) for k in range(n))
+    ours = np.concatenate([stream[:first]] + [d for (_, _, d) in got])
     assert hashlib.md5(ours.tobytes()).hexdigest() == hashlib.md5(stream.tobytes()).hexdigest()
