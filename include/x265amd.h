@@ -738,6 +738,19 @@ typedef struct x265amd_slice_header
 /* substreams: the raw (unescaped) CABAC sub-streams back to back, sizes[i] bytes each.  Returns the NAL size in bytes (written when it fits). */
 size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const uint8_t* substreams, const uint32_t* sizes, int num_substreams, uint8_t* out, size_t cap);
 
+/* FrameEncoder::encodeSlice (reference: source/encoder/frameencoder.cpp:1298-1370): the final CABAC pass over a decided picture -> sub-streams
+ * (one per CTU row when si->wpp, else one).  sao / sao_flags (may be NULL): the SAO parameters of every CTU (reserved[0] = merge mode: 0 none,
+ * 1 left, 2 up) and slice_sao_luma_flag / slice_sao_chroma_flag; their syntax precedes each CTU. */
+int x265amd_encode_slice_data(const x265amd_slice_info* si, x265amd_cu_unit* units, const int16_t* coeffs, const x265amd_sao_ctu* sao,
+                              const int32_t* sao_flags, uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams);
+/* SAO parameter decision of a picture (host): SAO::startSlice + rdoSaoUnitCu for every CTU + rdoSaoUnitRowEnd (reference:
+ * source/encoder/sao.cpp:227-272, :1207-1761) on the statistics of x265amd_sao_stats (host copies, same layout).  referenced: IS_REFERENCED(frame);
+ * frame_threads: param.frameNumThreads (the automatic switch-off of startSlice only runs when 1); qp_min / qp_max: param.rc.qpMin / qpMax.
+ * depth_sao_rate: 8 doubles kept across the pictures of an encode (SAO::m_depthSaoRate), zero at the start.  params: per CTU (reserved[0] =
+ * merge mode); sao_flags[2]: slice_sao_luma_flag, slice_sao_chroma_flag.  limit-sao and sao-non-deblock are not supported. */
+int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                    const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

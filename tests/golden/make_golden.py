@@ -286,6 +286,8 @@ def make_frame_pipeline_golden():
     clib[clib.index("--bframes") + 1] = "2"
     clib[clib.index("--rc-lookahead") + 1] = "5"
     _frame_pipeline_one(framesb, stride, cstride, org, "bframes/", clib + ["--no-b-pyramid"], out, nframes=7)
+    _frame_pipeline_one(framesb, stride, cstride, org, "sao_bframes/", [a for a in clib if a != "--no-sao"] + ["--no-b-pyramid", "--sao"], out, nframes=7)
+    _frame_pipeline_one(frames, stride, cstride, org, "sao/", [a for a in T.FRAME_CLI_ARGS if a not in ("--no-deblock", "--no-sao")] + ["--sao"], out)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
     print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 

@@ -2739,6 +2739,7 @@ def frame_planes(pic, stride, cstride, org):
     return out
 
 
+SAO_CTU_PROD_DT = np.dtype([("type", "i1", 2), ("band_pos", "u1", 3), ("offset", "i1", (3, 4)), ("merge", "u1"), ("reserved", "u1", 2)])
 SLICE_HEADER_DT = np.dtype([(n, "<i4") for n in ("nal_unit_type", "temporal_id_plus1", "first_in_access_unit", "slice_type", "poc", "last_idr_poc", "log2_max_poc_lsb",
                                                     "rps_idx", "num_rps_in_sps", "num_negative", "num_positive")] + [("delta_poc", "<i4", 16), ("used", "<i4", 16)] +
                            [(n, "<i4") for n in ("temporal_mvp_enabled", "use_sao", "sao_luma", "sao_chroma", "selective_sao")] +
@@ -2753,7 +2754,7 @@ def frame_clip_b(depth=8):
     return pics, stride, cstride, org
 
 
-def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb):
+def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb, sao_flags=None):
     """the slice header fields of the k-th coded frame as the reference's DPB / encoder set them (dpb.cpp: prepareEncode / computeRPS,
     encoder.cpp); dpb: POCs of the reference pictures kept so far"""
     stype, poc, referenced = int(sched[0]), int(sched[1]), int(sched[2])
@@ -2770,10 +2771,12 @@ def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb):
     h["num_ref_idx"] = (len(l0), len(l1)); h["num_ref_idx_default"] = (1, 1); h["col_from_l0"] = int(stype != 0); h["max_num_merge_cand"] = 3
     h["slice_qp"], h["pps_init_qp"], h["deblocking_disabled"], h["wpp"] = slice_qp, 26, int(not deblock), int(wpp)
     h["slfase_flag"] = (0x5f4e4a53 >> (poc % 31)) & 1   # SLFASE_CONSTANT (dpb.cpp:294)
+    if sao_flags is not None:
+        h["use_sao"], h["sao_luma"], h["sao_chroma"] = 1, int(sao_flags[0]), int(sao_flags[1])
     return h
 
 
-def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None):
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None, sao=False):
     """frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, optional deblocking and
     wavefront sub-streams).  schedule: per coded frame (type 2 I / 1 P / 0 B, poc, referenced, 4 L0 pocs, 4 L1 pocs), default I P P P.
     Returns per coded frame (poc, recon planes, the slice NAL unit with its start code)"""
@@ -2794,6 +2797,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
     def addr(d):
         return [d.data_ptr() + org[k] * isz for k in range(3)]
     fields, unit_maps, refpocs, qp_of, dpb, out = {}, {}, {}, {}, [], []
+    depth_sao_rate = np.zeros(8, np.float64)
     for k, sc in enumerate(schedule):
         stype, poc, referenced = int(sc[0]), int(sc[1]), int(sc[2])
         lists = [[int(v) for v in sc[3:7] if v >= 0], [int(v) for v in sc[7:11] if v >= 0]]
@@ -2832,6 +2836,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
         si["tu_max_depth_inter"], si["tu_max_depth_intra"], si["wpp"] = 1, 1, int(wpp)
         ap = np.zeros(1, ANALYSIS_PARAMS_DT)
         ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
+        ap["use_sao"] = int(sao)
         units = np.zeros((h4, w4), CU_UNIT_DT); cur = np.zeros((h4, w4), MV_UNIT_DT)
         col = fields[col_poc] if col_poc is not None else np.zeros((h4, w4), MV_UNIT_DT)
         ref_depth = np.zeros((2, h4, w4), np.uint8)
@@ -2845,7 +2850,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
         data = np.zeros(1 << 20, np.uint8); sizes = np.zeros(64, np.uint32); nsub = C.c_int(0)
         rc = lib.x265amd_analyse_frame(me.ctx, None, _ptr(info), _ptr(sp), _ptr(si), _ptr(ap), _ptr(units), _ptr(cur), _ptr(col), _ptr(ref_depth), _ptr(ref_qp0),
                                        _ptr(planes), len(planes) // 3, C.c_int64(stride), C.c_int64(cstride), _ptr(stat), _ptr(coeff), None,
-                                       _ptr(data), C.c_size_t(data.size), _ptr(sizes), C.byref(nsub))
+                                       None if sao else _ptr(data), C.c_size_t(data.size), _ptr(sizes), C.byref(nsub))
         assert rc == 0, lib.x265amd_last_error()
         if deblock:
             # FrameFilter: in-loop deblocking of the finished picture (default offsets), before it becomes a reference
@@ -2856,6 +2861,27 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
             assert lib.x265amd_deblock_picture(None, C.c_void_p(pl[0]), C.c_void_p(pl[1]), C.c_void_p(pl[2]), C.c_int64(stride), C.c_int64(cstride), W, H,
                                                C.c_void_p(d_dbu.data_ptr()), 0, 0, 0, 0, 0, 3) == 0
             torch.cuda.synchronize()
+        sao_flags = None
+        if sao:
+            # SAO: statistics of all CTUs on the deblocked picture (GPU), parameter decision (host), offsets applied out of place (GPU),
+            # then the slice data with the SAO syntax in front of every CTU
+            n_stat = nctu * 3 * 5 * 32
+            d_count = torch.zeros(n_stat, dtype=torch.int32, device="cuda"); d_org = torch.zeros(n_stat, dtype=torch.int32, device="cuda")
+            recp = np.array(addr(d_rec[poc]), np.uint64); srcp = np.array(addr(d_src[poc]), np.uint64)
+            assert lib.x265amd_sao_stats(None, _ptr(recp), _ptr(srcp), C.c_int64(stride), C.c_int64(cstride), W, H, C.c_void_p(d_count.data_ptr()),
+                                         C.c_void_p(d_org.data_ptr())) == 0
+            torch.cuda.synchronize()
+            cnt = d_count.cpu().numpy(); orgs = d_org.cpu().numpy()
+            sparams = np.zeros(nctu, SAO_CTU_PROD_DT); sao_flags = np.zeros(2, np.int32)
+            assert lib.x265amd_sao_rdo(_ptr(si), referenced, 1, 0, 69, _ptr(units), _ptr(cnt), _ptr(orgs), _ptr(depth_sao_rate), _ptr(sparams), _ptr(sao_flags)) == 0
+            d_params = torch.from_numpy(sparams.view(np.uint8)).cuda()
+            d_out = d_rec[poc].clone()
+            dstp = np.array(addr(d_out), np.uint64)
+            assert lib.x265amd_sao_apply(None, _ptr(recp), _ptr(dstp), C.c_int64(stride), C.c_int64(cstride), W, H, C.c_void_p(d_params.data_ptr())) == 0
+            torch.cuda.synchronize()
+            d_rec[poc] = d_out
+            assert lib.x265amd_encode_slice_data(_ptr(si), _ptr(units), _ptr(coeff), _ptr(sparams), _ptr(sao_flags), _ptr(data), C.c_size_t(data.size), _ptr(sizes),
+                                                 C.byref(nsub)) == 0
         # the reconstruction becomes a reference: extend its borders (PicYuv margins 96 / 80)
         for p in range(3):
             w, h, mx, my, st = (W, H, MC_MX, MC_MY, stride) if p == 0 else (W // 2, H // 2, MC_MX // 2, MC_MY // 2, cstride)
@@ -2864,7 +2890,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
         fields[poc] = np.ascontiguousarray(cur); unit_maps[poc] = units; refpocs[poc] = rp; qp_of[poc] = slice_qps[k]
         rec = d_rec[poc].cpu().numpy().view(frames[0].dtype)
         nal = np.zeros(1 << 20, np.uint8)
-        hdr = frame_slice_header(k, sc, slice_qps[k], deblock, wpp, dpb)
+        hdr = frame_slice_header(k, sc, slice_qps[k], deblock, wpp, dpb, sao_flags)
         n = lib.x265amd_write_slice_nal(_ptr(hdr), _ptr(data), _ptr(sizes), nsub.value, _ptr(nal), C.c_size_t(nal.size))
         assert 0 < n <= nal.size
         if referenced:

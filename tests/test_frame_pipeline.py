@@ -20,11 +20,12 @@ def test_golden_is_a_real_encode():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["", "deblock/", "wpp/", "bframes/"])
+@pytest.mark.parametrize("tag", ["", "deblock/", "wpp/", "bframes/", "sao/", "sao_bframes/"])
 def test_hip_frame_pipeline_matches_reference_encoder(tag):
     """tag "deblock/": the same encode with the in-loop deblocking filter on (x265amd_deblock_units + x265amd_deblock_picture per frame);
     "wpp/": deblocking and wavefront parallel processing on (per-row entropy states, one sub-stream per CTU row, entry points in the slice header);
     "bframes/": a 7-frame clip coded I P b b P b b (two lists, bi-prediction, collocated picture from list 1, non-referenced pictures), deblocking.
+    "sao/", "sao_bframes/": the same clips with sample adaptive offset on (x265amd_sao_stats, x265amd_sao_rdo, x265amd_sao_apply, SAO syntax).
     The slice NAL units (x265amd_write_slice_nal) behind the reference's parameter sets must give the reference's byte stream."""
     import hashlib
     g = np.load(GOLD_PATH)
@@ -32,7 +33,7 @@ def test_hip_frame_pipeline_matches_reference_encoder(tag):
     sched = g[tag + "schedule"]
     n = len(sched)
     got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], nframes=n, deblock=bool(tag), wpp=tag == "wpp/", schedule=sched,
-                                   frames=T.frame_clip_b(8) if tag == "bframes/" else None)
+                                   frames=T.frame_clip_b(8) if "bframes" in tag else None, sao="sao" in tag)
     for k, (poc, planes, data) in enumerate(got):
         for p in range(3):
             want = g[tag + "recon/%d/%d" % (poc, p)]

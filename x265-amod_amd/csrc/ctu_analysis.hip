@@ -770,34 +770,49 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
     for (x265amd_cabac* c : rows) x265amd_cabac_close(c);
     if (rc == X265AMD_OK && slice_data && substream_sizes && num_substreams)
     {
-        /* FrameEncoder::encodeSlice: one sub-stream per CTU row under WPP (each row starts from the state saved after the second CTU of the row
-         * above and ends with finishSlice), otherwise one for the picture */
-        size_t total = 0;
-        int count = 0;
-        x265amd_cabac* w = nullptr;
-        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
-        {
-            const int row = addr / ctuW, colIdx = addr % ctuW;
-            if (!w)
-            {
-                w = x265amd_cabac_open(si, units, 0);
-                if (wpp && row) memcpy(w->ctx, &buffered[(size_t)(row - 1) * X265AMD_CTX_STRIDE], X265AMD_CTX_STRIDE);
-            }
-            const int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
-            rc = x265amd_cabac_encode_ctu(w, addr, coeff, coeff + 4096, coeff + 5120);
-            if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], w->ctx, X265AMD_CTX_STRIDE);
-            if ((wpp && colIdx == ctuW - 1) || addr == numCtu - 1)
-            {
-                const size_t n = x265amd_cabac_finish_slice(w, slice_data + total, cap > total ? cap - total : 0);
-                if (total + n > cap) rc = xa_fail(X265AMD_EINVAL, "analyse_frame: slice data buffer too small");
-                substream_sizes[count++] = (uint32_t)n;
-                total += n;
-                x265amd_cabac_close(w);
-                w = nullptr;
-            }
-        }
-        if (w) x265amd_cabac_close(w);
-        *num_substreams = count;
+        if (A->use_sao) return xa_fail(X265AMD_EINVAL, "analyse_frame: with SAO the slice data follows the SAO decision: call x265amd_encode_slice_data afterwards");
+        rc = x265amd_encode_slice_data(si, units, coeff_out, nullptr, nullptr, slice_data, cap, substream_sizes, num_substreams);
     }
+    return rc;
+}
+
+/* FrameEncoder::encodeSlice (frameencoder.cpp:1298-1370): the final CABAC pass over the decided picture.  One sub-stream per CTU row under WPP
+ * (each row starts from the state saved after the second CTU of the row above and ends with finishSlice), otherwise one for the picture; the
+ * SAO syntax of a CTU precedes its coding tree when the slice uses SAO. */
+extern "C" int x265amd_encode_slice_data(const x265amd_slice_info* si, x265amd_cu_unit* units, const int16_t* coeffs, const x265amd_sao_ctu* sao,
+                                         const int32_t* sao_flags, uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams)
+{
+    if (!si || !units || !coeffs || !slice_data || !substream_sizes || !num_substreams) return xa_fail(X265AMD_EINVAL, "encode_slice_data: null argument");
+    const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH;
+    const bool wpp = si->wpp != 0;
+    std::vector<uint8_t> buffered((size_t)ctuH * X265AMD_CTX_STRIDE, 0);
+    size_t total = 0;
+    int count = 0, rc = X265AMD_OK;
+    x265amd_cabac* w = nullptr;
+    for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
+    {
+        const int row = addr / ctuW, colIdx = addr % ctuW;
+        if (!w)
+        {
+            w = x265amd_cabac_open(si, units, 0);
+            if (!w) return xa_fail(X265AMD_EINVAL, "encode_slice_data: slice description");
+            if (wpp && row) memcpy(w->ctx, &buffered[(size_t)(row - 1) * X265AMD_CTX_STRIDE], X265AMD_CTX_STRIDE);
+        }
+        if (sao && sao_flags) w->saoCtu(colIdx, row == 0, sao[addr], sao_flags[0] != 0, sao_flags[1] != 0);
+        const int16_t* coeff = coeffs + (size_t)addr * kTileElems;
+        rc = x265amd_cabac_encode_ctu(w, addr, coeff, coeff + 4096, coeff + 5120);
+        if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], w->ctx, X265AMD_CTX_STRIDE);
+        if ((wpp && colIdx == ctuW - 1) || addr == numCtu - 1)
+        {
+            const size_t n = x265amd_cabac_finish_slice(w, slice_data + total, cap > total ? cap - total : 0);
+            if (total + n > cap) rc = xa_fail(X265AMD_EINVAL, "encode_slice_data: buffer too small");
+            substream_sizes[count++] = (uint32_t)n;
+            total += n;
+            x265amd_cabac_close(w);
+            w = nullptr;
+        }
+    }
+    if (w) x265amd_cabac_close(w);
+    *num_substreams = count;
     return rc;
 }

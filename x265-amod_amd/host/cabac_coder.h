@@ -380,6 +380,55 @@ struct x265amd_cabac
         }
     }
 
+    /* ---- SAO syntax of a CTU (FrameEncoder::encodeSlice, frameencoder.cpp:1320-1346; Entropy::codeSaoOffset / codeSaoMaxUvlc,
+     * entropy.cpp:1224-1262, :2201-2217).  flags: slice_sao_luma_flag, slice_sao_chroma_flag ---- */
+    void saoMaxUvlc(uint32_t code, uint32_t maxSymbol)
+    {
+        binEP(code != 0);
+        if (code)
+        {
+            const uint32_t isLast = maxSymbol > code;
+            uint32_t mask = (1u << (code - 1)) - 1;
+            const uint32_t len = code - 1 + isLast;
+            mask <<= isLast;
+            binsEP(mask, (int)len);
+        }
+    }
+    void saoOffset(int typeIdx, int bandPos, const int8_t* offset, int plane)
+    {
+        const uint32_t thresh = (1u << ((X265AMD_DEPTH - 5) < 5 ? (X265AMD_DEPTH - 5) : 5)) - 1;
+        if (plane != 2)
+        {
+            bin(typeIdx >= 0, C_SAO_TYPE);
+            if (typeIdx >= 0) binEP(typeIdx < 4 ? 1 : 0);
+        }
+        if (typeIdx < 0) return;
+        if (typeIdx == 4)
+        {
+            for (int i = 0; i < 4; i++) saoMaxUvlc((uint32_t)abs(offset[i]), thresh);
+            for (int i = 0; i < 4; i++) if (offset[i]) binEP(offset[i] < 0);
+            binsEP((uint32_t)bandPos, 5);
+        }
+        else
+        {
+            saoMaxUvlc((uint32_t)offset[0], thresh); saoMaxUvlc((uint32_t)offset[1], thresh);
+            saoMaxUvlc((uint32_t)-offset[2], thresh); saoMaxUvlc((uint32_t)-offset[3], thresh);
+            if (plane != 2) binsEP((uint32_t)typeIdx, 2);
+        }
+    }
+    void saoCtu(int col, bool firstRowInSlice, const x265amd_sao_ctu& p, bool lumaFlag, bool chromaFlag)
+    {
+        if (!lumaFlag && !chromaFlag) return;
+        const int mergeLeft = col && p.reserved[0] == 1, mergeUp = !firstRowInSlice && p.reserved[0] == 2;
+        if (col) bin((uint32_t)mergeLeft, C_SAO_MERGE);
+        if (!firstRowInSlice && !mergeLeft) bin((uint32_t)mergeUp, C_SAO_MERGE);
+        if (!mergeLeft && !mergeUp)
+        {
+            if (lumaFlag) saoOffset(p.type[0], p.band_pos[0], p.offset[0], 0);
+            if (chromaFlag) { saoOffset(p.type[1], p.band_pos[1], p.offset[1], 1); saoOffset(p.type[1], p.band_pos[2], p.offset[2], 2); }
+        }
+    }
+
     void predInfo(int x, int y, int size, const x265amd_cu_unit& u)     /* codePredInfo / codePUWise (:1138-1197) */
     {
         if (u.pred_mode == X265AMD_MODE_INTRA)
