@@ -386,7 +386,7 @@ def measured_traffic(kernel="k_me_search"):
     """HBM bytes per launch of a kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately:
     counters cannot be read inside the bench); the summary is committed under profiles/"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_analysis10_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_analysis11_traffic.json")) as f:
             return json.load(f)[kernel]["hbm_bytes_per_launch_uncorrected"]
     except (OSError, KeyError, ValueError):
         return None
