@@ -751,6 +751,9 @@ int x265amd_encode_slice_data(const x265amd_slice_info* si, x265amd_cu_unit* uni
 int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
                     const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags);
 
+/* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
+void x265amd_release_scratch(void);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

@@ -391,8 +391,8 @@ struct Walker
 struct DevBuf
 {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    ~DevBuf() { xa_scratch_free(p); }
+    hipError_t alloc(size_t bytes) { return xa_scratch_alloc(&p, bytes ? bytes : 16); }
 };
 
 } // namespace

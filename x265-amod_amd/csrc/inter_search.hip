@@ -41,8 +41,8 @@ struct PuWork
 struct Dev
 {
     void* p = nullptr;
-    ~Dev() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
+    ~Dev() { xa_scratch_free(p); }
+    int alloc(size_t bytes) { return xa_scratch_alloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : -1; }
 };
 
 } // namespace

@@ -31,8 +31,8 @@ const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
 struct DevBuf
 {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    ~DevBuf() { xa_scratch_free(p); }
+    hipError_t alloc(size_t bytes) { return xa_scratch_alloc(&p, bytes ? bytes : 16); }
 };
 
 inline unsigned zUnit(int ux, int uy)           /* z-order of unit (ux, uy) inside its CTU */

@@ -164,3 +164,48 @@ extern "C" int x265amd_setup_primitives(void* table, size_t table_bytes)
     ins.set(slotMisc(M_weight_sp), &x265amd_weight_sp); ins.set(slotMisc(M_weight_pp), &x265amd_weight_pp);
     return ins.n;
 }
+
+
+/* ---- device scratch pool (x265amd_host.h) ---- */
+#include <map>
+#include <mutex>
+#include <vector>
+namespace {
+struct ScratchPool
+{
+    std::mutex m;
+    std::map<size_t, std::vector<void*>> free_;     /* size class -> idle blocks */
+    std::map<void*, size_t> size_;                  /* block -> size class */
+    static size_t cls(size_t b) { size_t c = 256; while (c < b) c <<= 1; return c; }
+};
+ScratchPool& scratch_pool() { static ScratchPool* p = new ScratchPool; return *p; }
+}
+hipError_t xa_scratch_alloc(void** p, size_t bytes)
+{
+    ScratchPool& P = scratch_pool();
+    const size_t c = ScratchPool::cls(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        std::vector<void*>& v = P.free_[c];
+        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    const hipError_t e = hipMalloc(p, c);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(P.m); P.size_[*p] = c; }
+    return e;
+}
+void xa_scratch_free(void* p)
+{
+    if (!p) return;
+    ScratchPool& P = scratch_pool();
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.size_.find(p);
+    if (it == P.size_.end()) { (void)hipFree(p); return; }
+    P.free_[it->second].push_back(p);
+}
+extern "C" void x265amd_release_scratch(void)
+{
+    ScratchPool& P = scratch_pool();
+    std::lock_guard<std::mutex> g(P.m);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipFree(q); P.size_.erase(q); } kv.second.clear(); }
+}

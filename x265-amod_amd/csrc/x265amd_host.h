@@ -11,6 +11,12 @@
 /* records the message for x265amd_last_error() and returns `code` */
 int xa_fail(int code, const char* msg);
 
+/* Device scratch for the host orchestrators: blocks are kept in size classes and handed out again instead of going back to hipFree
+ * (hipMalloc / hipFree cost more than the kernels of a CU-sized step).  A block may be reused as soon as it is released: every user
+ * enqueues its work on one stream, so reuse is stream-ordered.  x265amd_release_scratch() returns everything to the runtime. */
+hipError_t xa_scratch_alloc(void** p, size_t bytes);
+void xa_scratch_free(void* p);
+
 /* The reference's primitive slots cannot report failure (primitives.h:133-236), so a HIP error inside a
  * per-slot entry point is fatal: there is deliberately no CPU fallback. */
 #define XA_HIP_FATAL(expr)                                                                                   \
