@@ -54,7 +54,11 @@ struct IntraRd
     Snap cur, rqtRoot[6], rqtTest[6];
     uint64_t lambda2, lambda; uint32_t psyRd;
     uint64_t predTile, reconTile;
-    DevBuf dJobs, dRes, dCoeff, dResi, dLayer, dScan, dScanJob;
+    DevBuf dJobs, dRes, dCoeff, dResi, dLayer, dScan, dScanJob, dCand;
+    enum { MAX_JOBS = 16 };
+    /* a luma TU whose chain already ran in a batch (the candidates of one partition share their neighbours, so they run as one launch):
+     * codeIntraLumaQT takes the result instead of launching; the winner's prediction / reconstruction are copied when it is measured again */
+    struct Pre { bool on; int x, y, log2; x265amd_tu_result r; const int16_t* lv; uint64_t recon, pred; bool copyBlocks; } pre;
     std::vector<int16_t> coeffL[4];             /* luma levels per transform layer (CUData offsets) */
     std::vector<int16_t> coeffC[2], coeffCBest[2];
     int err;
@@ -179,7 +183,17 @@ struct IntraRd
             job.avail = available(x, y, trSize);
             x265amd_tu_result r;
             int16_t* lv = coeffL[layer].data() + ((size_t)zInCu(x, y) << 4);
-            if (runJobs(&job, 1, &r, &lv, trSize * trSize)) return err;
+            if (pre.on && pre.x == x && pre.y == y && pre.log2 == log2TrSize)
+            {
+                r = pre.r;
+                memcpy(lv, pre.lv, sizeof(int16_t) * trSize * trSize);
+                if (pre.copyBlocks)
+                {
+                    copy2D(layerRecon, 64, pre.recon, trSize, trSize, trSize);
+                    copy2D(predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, pre.pred, trSize, trSize, trSize);
+                }
+            }
+            else if (runJobs(&job, 1, &r, &lv, trSize * trSize)) return err;
             setTuDepth(x, y, trSize, tuDepth);
             bCBF = (uint32_t)(r.num_sig != 0) << tuDepth;
             setCbf(0, x, y, trSize, bCBF);
@@ -332,20 +346,56 @@ struct IntraRd
                     for (int i = 0; i < maxCandCount; i++) if (maxValue < candCostList[i]) { maxValue = candCostList[i]; maxIndex = (uint32_t)i; }
                     if (modeCosts[mode] < maxValue) { candCostList[maxIndex] = modeCosts[mode]; rdModeList[maxIndex] = mode; }
                 }
-            bcost = kMaxCost;
-            for (int i = 0; i < maxCandCount; i++)
+            /* the candidates only differ in the mode: their transform chains run as ONE launch, the bits and costs follow on the host in the
+             * reference's order; the winner's chain is not run again when it is measured with splits allowed */
+            int numCand = 0;
+            while (numCand < maxCandCount && candCostList[numCand] != kMaxCost) numCand++;
+            const bool batch = log2TrSize <= range[1] && numCand <= MAX_JOBS;
+            std::vector<x265amd_tu_result> cres((size_t)numCand);
+            std::vector<int16_t> clev((size_t)numCand * 1024);
+            const size_t isz = sizeof(pixel);
+            if (batch && numCand)
             {
-                if (candCostList[i] == kMaxCost) break;
+                std::vector<x265amd_intra_tu_job> jobs((size_t)numCand);
+                std::vector<int16_t*> lvp((size_t)numCand);
+                const uint64_t avail = available(px, py, tuSize);
+                for (int i = 0; i < numCand; i++)
+                {
+                    const uint64_t slot = (uint64_t)(uintptr_t)dCand.p + (size_t)i * 2048 * isz;
+                    fillJob(jobs[i], 0, px, py, log2TrSize, (int)rdModeList[i], slot + 1024 * isz, tuSize, slot, tuSize, i);
+                    jobs[i].avail = avail;
+                    lvp[i] = clev.data() + (size_t)i * 1024;
+                }
+                if (runJobs(jobs.data(), numCand, cres.data(), lvp.data(), tuSize * tuSize)) return err;
+            }
+            bcost = kMaxCost;
+            int bestIdx = -1;
+            for (int i = 0; i < numCand; i++)
+            {
                 load(cur);
                 for (int yy = 0; yy < tuSize; yy += 4) for (int xx = 0; xx < tuSize; xx += 4) U(px + xx, py + yy).luma_dir = (uint8_t)rdModeList[i];
                 Cost icosts = { 0, 0, 0, 0 };
-                if (codeIntraLumaQT(px, py, initTuDepth, false, icosts)) return err;
-                if (icosts.rdcost < bcost) { bcost = icosts.rdcost; bmode = rdModeList[i]; }
+                if (batch)
+                {
+                    const uint64_t slot = (uint64_t)(uintptr_t)dCand.p + (size_t)i * 2048 * isz;
+                    pre = Pre{ true, px, py, log2TrSize, cres[i], clev.data() + (size_t)i * 1024, slot, slot + 1024 * isz, false };
+                }
+                const int rcq = codeIntraLumaQT(px, py, initTuDepth, false, icosts);
+                pre.on = false;
+                if (rcq) return err;
+                if (icosts.rdcost < bcost) { bcost = icosts.rdcost; bmode = rdModeList[i]; bestIdx = i; }
             }
             for (int yy = 0; yy < tuSize; yy += 4) for (int xx = 0; xx < tuSize; xx += 4) U(px + xx, py + yy).luma_dir = (uint8_t)bmode;
             load(cur);
             Cost icosts = { 0, 0, 0, 0 };
-            if (codeIntraLumaQT(px, py, initTuDepth, true, icosts)) return err;
+            if (batch && bestIdx >= 0)
+            {
+                const uint64_t slot = (uint64_t)(uintptr_t)dCand.p + (size_t)bestIdx * 2048 * isz;
+                pre = Pre{ true, px, py, log2TrSize, cres[bestIdx], clev.data() + (size_t)bestIdx * 1024, slot, slot + 1024 * isz, true };
+            }
+            const int rcq = codeIntraLumaQT(px, py, initTuDepth, true, icosts);
+            pre.on = false;
+            if (rcq) return err;
             totalDistortion += icosts.distortion;
         }
         if (numPU > 1)
@@ -457,12 +507,51 @@ struct IntraRd
         uint32_t bestMode = 0; sse_t bestDist = 0; uint64_t bestCost = kMaxCost;
         std::vector<uint8_t> bestCbf(2 * (size_t)n4 * n4, 0);
         const size_t isz = sizeof(pixel);
+        /* one chroma block per plane for the whole CU (no luma transform split, or an 8x8 CU): the five modes x two planes are independent
+         * and run as ONE launch; bits, costs and the choice follow on the host in the reference's order */
+        const int td = U(cuX, cuY).tu_depth;
+        const bool single = td == 0 || (log2 == 3 && td == 1);
+        std::vector<x265amd_tu_result> cres(10);
+        std::vector<int16_t> clev((size_t)10 * 1024);
+        const int log2C = log2 == 3 ? 2 : log2 - 1 - 0, nC = 1 << (single ? (log2 == 3 ? 2 : log2 - 1) : 2);
+        int bestK = -1;
+        if (single)
+        {
+            x265amd_intra_tu_job jobs[10];
+            int16_t* lvp[10];
+            const uint64_t avail = foldChroma(available(cuX, cuY, size), size >> 2);
+            for (int k = 0; k < 5; k++)
+                for (int p = 1; p < 3; p++)
+                {
+                    const int j = k * 2 + p - 1;
+                    const int mode = modeList[k] == 36 ? (int)lumaDir : (int)modeList[k];
+                    const uint64_t slot = (uint64_t)(uintptr_t)dCand.p + (size_t)j * 2048 * isz;
+                    fillJob(jobs[j], p, cuX, cuY, log2 == 3 ? 2 : log2 - 1, mode, 0, nC, slot, nC, j);
+                    jobs[j].avail = avail;
+                    lvp[j] = clev.data() + (size_t)j * 1024;
+                }
+            if (runJobs(jobs, 10, cres.data(), lvp, nC * nC)) return err;
+            (void)log2C;
+        }
         for (int k = 0; k < 5; k++)
         {
             load(cur);
             for (int yy = 0; yy < size; yy += 4) for (int xx = 0; xx < size; xx += 4) U(cuX + xx, cuY + yy).chroma_dir = (uint8_t)modeList[k];
             Cost outCost = { 0, 0, 0, 0 };
-            if (codeIntraChromaQt(cuX, cuY, 0, outCost)) return err;
+            if (single)
+            {
+                /* codeIntraChromaQt for the one block per plane (and the parent's flag when the block sits one level down, :827-840) */
+                for (int p = 1; p < 3; p++)
+                {
+                    const x265amd_tu_result& r = cres[(size_t)k * 2 + p - 1];
+                    memcpy(coeffC[p - 1].data(), clev.data() + (size_t)(k * 2 + p - 1) * 1024, sizeof(int16_t) * nC * nC);
+                    setCbf(p, cuX, cuY, size, r.num_sig ? 1 << td : 0);
+                    if (td) U(cuX, cuY).cbf[p] |= (uint8_t)((U(cuX, cuY).cbf[p] >> td) & 1);
+                    outCost.distortion += (sse_t)r.nz_dist;
+                    if (psyRd) outCost.energy += r.nz_energy;
+                }
+            }
+            else if (codeIntraChromaQt(cuX, cuY, 0, outCost)) return err;
             resetBits();
             c->intraDirChroma(U(cuX, cuY));
             codeSubdivCbfQTChroma(cuX, cuY, 0);
@@ -475,8 +564,10 @@ struct IntraRd
                 bestCost = cst; bestDist = outCost.distortion; bestMode = modeList[k];
                 /* extractIntraResultChromaQT: levels and reconstruction of this mode */
                 coeffCBest[0] = coeffC[0]; coeffCBest[1] = coeffC[1];
-                for (int p = 1; p < 3; p++)
-                    copy2D(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, size >> 1, size >> 1);
+                bestK = k;
+                if (!single)
+                    for (int p = 1; p < 3; p++)
+                        copy2D(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, size >> 1, size >> 1);
                 for (int yy = 0; yy < n4; yy++)
                     for (int xx = 0; xx < n4; xx++)
                     {
@@ -491,6 +582,15 @@ struct IntraRd
                 x265amd_cu_unit& u = U(cuX + 4 * xx, cuY + 4 * yy);
                 u.cbf[1] = bestCbf[(size_t)(yy * n4 + xx) * 2]; u.cbf[2] = bestCbf[(size_t)(yy * n4 + xx) * 2 + 1];
                 u.chroma_dir = (uint8_t)bestMode;
+            }
+        if (single)
+            for (int p = 1; p < 3; p++)
+            {
+                /* the winner's reconstruction is the CU's; the picture keeps the last tried mode's, as after the reference's loop */
+                const uint64_t bestSlot = (uint64_t)(uintptr_t)dCand.p + (size_t)(bestK * 2 + p - 1) * 2048 * isz;
+                const uint64_t lastSlot = (uint64_t)(uintptr_t)dCand.p + (size_t)(4 * 2 + p - 1) * 2048 * isz;
+                copy2D(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, bestSlot, nC, nC, nC);
+                copy2D(rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, lastSlot, nC, nC, nC);
             }
         totalDistortion = bestDist;
         load(cur);
@@ -513,6 +613,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
     R.predTile = d_pred; R.reconTile = d_recon;
+    R.pre.on = false;
     int rc = X265AMD_OK;
     if (R.log2 < 3 || R.log2 > 5 || (R.cuX & (R.size - 1)) || (R.cuY & (R.size - 1)) || R.cuX < 0 || R.cuY < 0 || R.cuX + R.size > si->pic_width || R.cuY + R.size > si->pic_height)
         rc = xa_fail(X265AMD_EINVAL, "intra rd: CU outside the picture, misaligned, or not 8..32");
@@ -529,8 +630,9 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         R.range[0] = lo < si->tu_log2_min ? si->tu_log2_min : (lo > si->tu_log2_max ? si->tu_log2_max : lo);
         R.range[1] = si->tu_log2_max;
     }
-    if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * 2) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * 2) != hipSuccess ||
-                             R.dCoeff.alloc(2 * 1024 * 2) != hipSuccess || R.dResi.alloc(2 * 1024 * 2) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
+    if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * IntraRd::MAX_JOBS) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * IntraRd::MAX_JOBS) != hipSuccess ||
+                             R.dCoeff.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess || R.dResi.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess ||
+                             R.dCand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
                              R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess))
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
