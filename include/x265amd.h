@@ -680,7 +680,7 @@ int x265amd_check_intra(void* stream, const x265amd_slice_info* si, const x265am
  * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N
  * (:3145-3277), topSkipMinDepth (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426).  Host recursion in the
  * reference's order over the batch entry points above; one CTU per call.
- * Built subset: P and B slices (b_intra 0 / 1), 2Nx2N partitions (rect / amp 0), limit_refs 0-3, limit_modes 0, no delta QP,
+ * Built subset: I, P and B slices (b_intra 0 / 1), 2Nx2N / rect / amp partitions, limit_refs 0-3, limit_modes 0 / 1, no delta QP,
  * rd_level 3-4, rskip 0 / 1, early_skip 0 / 1.  Anything else is rejected with X265AMD_EINVAL. */
 typedef struct x265amd_analysis_params
 {

@@ -240,7 +240,7 @@ def make_ctu_analysis_golden():
     spec = importlib.util.spec_from_file_location("tca", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_ctu_analysis.py"))
     tca = importlib.util.module_from_spec(spec); spec.loader.exec_module(tca)
     out = {}
-    for k, cfg in enumerate(tca.CASES):
+    for k, cfg in enumerate(tca.CASES + tca.PART_CASES):
         c = tca.make_case(k)
         for i, d in enumerate(T.ctu_pack(T.ctu_run_ref(T.load_ref(cfg[0]), c))):
             for name, a in d.items():
@@ -288,6 +288,9 @@ def make_frame_pipeline_golden():
     _frame_pipeline_one(framesb, stride, cstride, org, "bframes/", clib + ["--no-b-pyramid"], out, nframes=7)
     _frame_pipeline_one(framesb, stride, cstride, org, "sao_bframes/", [a for a in clib if a != "--no-sao"] + ["--no-b-pyramid", "--sao"], out, nframes=7)
     _frame_pipeline_one(frames, stride, cstride, org, "sao/", [a for a in T.FRAME_CLI_ARGS if a not in ("--no-deblock", "--no-sao")] + ["--sao"], out)
+    # rectangular + asymmetric partitions (with and without --limit-modes) on both clips, deblocking on
+    _frame_pipeline_one(framesb, stride, cstride, org, "rectamp_bframes/", clib + ["--no-b-pyramid", "--rect", "--amp"], out, nframes=7)
+    _frame_pipeline_one(frames, stride, cstride, org, "rectamp_lm/", [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"] + ["--rect", "--amp", "--limit-modes"], out)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
     print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 

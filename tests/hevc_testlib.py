@@ -2361,7 +2361,8 @@ CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits
 assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 48
 
 
-def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1, intra_slice=False):
+def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1, intra_slice=False,
+             rect=0, amp=0, limit_modes=0):
     """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
     the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
     rng = np.random.default_rng(seed + 901)
@@ -2387,6 +2388,22 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
                 sv[y0:y0 + b, x0:x0 + b] = rng.integers(pmax // 4, 3 * pmax // 4, (b, b))
             else:
                 sv[y0:y0 + b, x0:x0 + b] = rv[y0 + dy // sub:y0 + dy // sub + b, x0 + dx // sub:x0 + dx // sub + b]
+    if rect or amp:
+        # CUs whose two halves / quarter + three quarters move differently, so that two-part prediction pays off
+        rng2 = np.random.default_rng(seed + 977)
+        for _ in range(60):
+            bs = int(rng2.choice([16, 16, 32, 32, 64] if amp else [8, 16, 16, 32, 64]))
+            bx, by = int(rng2.integers(0, width // bs)) * bs, int(rng2.integers(0, height // bs)) * bs
+            shape = int(rng2.choice(([1, 2] if rect else []) + ([4, 5, 6, 7] if amp else [])))
+            cut = {1: bs // 2, 2: bs // 2, 4: bs // 4, 5: 3 * bs // 4, 6: bs // 4, 7: 3 * bs // 4}[shape]
+            horiz = shape in (1, 4, 5)
+            for k in range(2):
+                dx, dy = int(rng2.integers(-6, 7)) * 2, int(rng2.integers(-5, 6)) * 2
+                px, py = (bx, by + (cut if k else 0)) if horiz else (bx + (cut if k else 0), by)
+                pw, ph = (bs, (bs - cut) if k else cut) if horiz else ((bs - cut) if k else cut, bs)
+                for (sv, rv, mx_, my_, sub) in views:
+                    x0, y0, w_, h_ = px // sub + mx_, py // sub + my_, pw // sub, ph // sub
+                    sv[y0:y0 + h_, x0:x0 + w_] = rv[y0 + dy // sub:y0 + dy // sub + h_, x0 + dx // sub:x0 + dx // sub + w_]
     recon[:] = np.clip(src.astype(np.int64) + rng.integers(-3, 4, src.shape), 0, pmax).astype(src.dtype)      # what earlier CTUs left (intra neighbours)
     pics = pics[:3] + [recon, src]                  # refs 0..2, reconstruction, source
     w4, h4, ctuW, ctuH = width // 4, height // 4, width // 64, height // 64
@@ -2400,7 +2417,7 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
     si["tq_bypass_enabled"], si["use_dqp"], si["max_cu_dqp_depth"] = 0, 0, 0
     si["tu_max_depth_inter"], si["max_num_merge_cand"], si["num_ref_idx"] = tu_inter_depth, info["max_num_merge_cand"], nref
     si["slice_qp"] = int(rng.integers(24, 38))
-    si["max_amp_depth"] = 0
+    si["max_amp_depth"] = 3 if amp else 0          # sps.maxAMPDepth = bEnableAMP ? maxCUDepth : 0
     units = base["units"].copy()
     units["tq_bypass"] = 0
     units["qp"] = si["slice_qp"]
@@ -2433,6 +2450,7 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
     sp["refPic"] = rp
     ap = np.zeros(1, ANALYSIS_PARAMS_DT)
     ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = psy_rd, 3, early_skip, rskip, limit_refs, b_intra, strong
+    ap["rect"], ap["amp"], ap["limit_modes"] = rect, amp, limit_modes
     # reference pictures' CU depths (two lists) and CTU QPs; running cost statistics of the CTUs coded so far
     ref_depth = np.zeros((2, h4, w4), np.uint8)
     for l in range(2):
@@ -2557,7 +2575,10 @@ def ctu_pack(results):
         for y in range(16):
             for x in range(16):
                 n = 16 >> int(u["depth"][y, x])
-                first[y, x] = (x % n == 0) and (y % n == 0)
+                ps = int(u["part_size"][y, x]) if int(u["pred_mode"][y, x]) != MODE_INTRA else 0
+                xs = {2: (0, n // 2), 6: (0, n // 4), 7: (0, 3 * n // 4)}.get(ps, (0,))        # first unit of each PU
+                ys = {1: (0, n // 2), 4: (0, n // 4), 5: (0, 3 * n // 4)}.get(ps, (0,))
+                first[y, x] = (x % n in xs) and (y % n in ys)
         d = dict(res=np.array([int(r["rd_cost"]), int(r["distortion"]), int(r["total_bits"]), int(r["frac_bits"])], np.uint64), ctx=r["ctx"][:CTX_COUNT].copy(),
                  units=np.concatenate([u[f].astype(np.int16).reshape(256, -1) * (1 if f not in ("inter_dir", "ref_idx") else (u["pred_mode"].reshape(256, 1) != MODE_INTRA))
                                        for f in ("depth", "pred_mode", "part_size", "tu_depth", "cbf", "inter_dir", "ref_idx", "qp")], 1),
@@ -2776,7 +2797,7 @@ def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb, sao_flags=None):
     return h
 
 
-def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None, sao=False):
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None, sao=False, rect=0, amp=0, limit_modes=0):
     """frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, optional deblocking and
     wavefront sub-streams).  schedule: per coded frame (type 2 I / 1 P / 0 B, poc, referenced, 4 L0 pocs, 4 L1 pocs), default I P P P.
     Returns per coded frame (poc, recon planes, the slice NAL unit with its start code)"""
@@ -2837,6 +2858,8 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
         ap = np.zeros(1, ANALYSIS_PARAMS_DT)
         ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
         ap["use_sao"] = int(sao)
+        ap["rect"], ap["amp"], ap["limit_modes"] = rect, amp, limit_modes
+        si["max_amp_depth"] = 3 if amp else 0
         units = np.zeros((h4, w4), CU_UNIT_DT); cur = np.zeros((h4, w4), MV_UNIT_DT)
         col = fields[col_poc] if col_poc is not None else np.zeros((h4, w4), MV_UNIT_DT)
         ref_depth = np.zeros((2, h4, w4), np.uint8)

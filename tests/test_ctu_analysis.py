@@ -13,10 +13,16 @@ CASES = [(8, 1, 1, 1, 2.0, 1, 0), (8, 2, 0, 1, 2.0, 2, 0), (8, 3, 1, 0, 0.0, 1, 
          (8, 7, 1, 1, 2.0, 1, 3), (8, 8, 0, 0, 2.0, 1, 3), (10, 9, 0, 1, 0.0, 2, 1), (8, 10, 0, 1, 2.0, 1, 2),
          (8, 11, 1, 1, 2.0, 1, 3, 0, 0), (8, 12, 0, 1, 2.0, 1, 0, 0, 0), (10, 13, 0, 0, 0.0, 2, 3, 0, 0), (8, 14, 0, 1, 2.0, 1, 3, 1, 1), (8, 15, 1, 0, 1.0, 1, 0, 1, 1),
          (8, 16, 0, 0, 2.0, 1, 0, 0, 0, 1), (10, 17, 0, 0, 0.0, 1, 0, 0, 0, 1), (8, 18, 0, 0, 1.0, 1, 0, 0, 0, 1)]
+# rectangular / asymmetric partitions: (depth, seed, early skip, rskip, psy-rd, limit-refs, B slice, b-intra, rect, amp, limit-modes)
+PART_CASES = [(8, 21, 0, 1, 2.0, 3, 1, 0, 1, 0, 0), (8, 22, 0, 0, 2.0, 0, 0, 0, 1, 1, 0), (10, 23, 1, 1, 0.0, 3, 1, 1, 1, 1, 1), (8, 24, 0, 1, 1.0, 1, 0, 0, 1, 1, 1),
+              (8, 25, 0, 0, 2.0, 2, 1, 0, 1, 1, 0), (8, 26, 0, 1, 2.0, 3, 0, 0, 1, 0, 1)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 
 def make_case(k):
+    if k >= len(CASES):
+        depth, seed, es, rs, psy, lr, is_b, b_intra, rect, amp, lm = PART_CASES[k - len(CASES)]
+        return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, limit_refs=lr, b_intra=b_intra, rect=rect, amp=amp, limit_modes=lm)
     depth, seed, es, rs, psy, td, lr = CASES[k][:7]
     is_b, b_intra = (CASES[k][7], CASES[k][8]) if len(CASES[k]) > 7 else (1, 0)
     return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr, b_intra=b_intra,
@@ -26,18 +32,21 @@ def make_case(k):
 def test_golden_outcomes_are_varied():
     gold = np.load(GOLD_PATH)
     depths = np.zeros(4, np.int64); modes = np.zeros(4, np.int64); coded = 0
-    for k in range(len(CASES)):
+    parts = np.zeros(8, np.int64)
+    for k in range(len(CASES) + len(PART_CASES)):
         for i in range(3):
             u = gold["%d/%d/units" % (k, i)]
+            parts += np.bincount(u[:, 2][u[:, 1] == T.MODE_INTER], minlength=8)
             depths += np.bincount(u[:, 0], minlength=4); modes += np.bincount(u[:, 1], minlength=4); coded += int((u[:, 4:7] > 0).any(1).sum())
     assert (depths[1:] > 100).all() and modes[1] > 500 and modes[3] > 500 and coded > 300, (depths, modes, coded)
+    assert (parts[[1, 2]] > 50).all() and (parts[4:] > 0).all(), parts          # every rectangular / asymmetric partition was chosen somewhere
 
 
 @pytest.mark.gpu
 def test_hip_compress_ctu_inter_matches_reference_golden():
     gold = np.load(GOLD_PATH)
     mes = {}
-    for k, cfg in enumerate(CASES):
+    for k, cfg in enumerate(CASES + PART_CASES):
         depth = cfg[0]
         if depth not in mes:
             mes[depth] = T.HipME(depth)

@@ -15,8 +15,8 @@
  *
  * I slices take compressIntraCU (:514-668): checkIntra 2Nx2N (+ NxN at 8x8) through x265amd_check_intra, then the four sub-CUs.
  *
- * Scope of this entry point: I, P and B slices (intra candidates through x265amd_intra_in_inter; --b-intra on / off), 2Nx2N partitions
- * (no --rect / --amp), --limit-refs 0-3, no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.
+ * Scope of this entry point: I, P and B slices (intra candidates through x265amd_intra_in_inter; --b-intra on / off), 2Nx2N, rectangular
+ * (--rect) and asymmetric (--amp) partitions with --limit-modes, --limit-refs 0-3, no delta QP (aq-mode 0, no cutree), rd 3-4, rskip 0/1, early skip on/off.
  */
 #include "x265amd_dev.h"
 #include "inter_common.h"
@@ -34,7 +34,8 @@ typedef uint32_t sse_t;
 typedef uint64_t sse_t;
 #endif
 
-enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_INTRA, PRED_INTRA_NxN, PRED_SPLIT, NUM_PRED };
+enum { PRED_MERGE, PRED_SKIP, PRED_2Nx2N, PRED_BIDIR, PRED_INTRA, PRED_INTRA_NxN, PRED_2NxN, PRED_Nx2N, PRED_2NxnU, PRED_2NxnD, PRED_nLx2N, PRED_nRx2N, PRED_SPLIT, NUM_PRED };
+struct SplitData { uint32_t splitRefs, mvCost[2]; uint64_t sa8dCost; };
 const uint64_t kMaxCost = 0x7FFFFFFFFFFFFFFFULL;
 const int kTileElems = 4096 + 2048;
 
@@ -65,7 +66,7 @@ struct Mode
     bool isSkipped() const { return u[0].pred_mode == X265AMD_MODE_SKIP; }
 };
 
-struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; };
+struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; uint32_t mvCost2Nx2N[2]; };
 
 struct DevBuf
 {
@@ -403,6 +404,7 @@ struct Analyzer
         int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(inter.predTile), tileBytes, &det, masks);
         if (rc != X265AMD_OK) return err = rc;
         setInter(inter, depth, pu[0].merge_flag, pu[0].mvp_idx[0], pu[0].inter_dir, pu[0].ref_idx, pu[0].mv, pu[0].mvd, pu[0].mvp_idx);
+        d.mvCost2Nx2N[0] = det.mv_cost[0]; d.mvCost2Nx2N[1] = det.mv_cost[1];       /* bestME[0][list].mvCost (zero where the list was not searched) */
         x265amd_rd_cu rc1;
         memset(&rc1, 0, sizeof(rc1));
         rc1.x = (int16_t)x; rc1.y = (int16_t)y; rc1.log2_size = (uint8_t)log2;
@@ -477,6 +479,63 @@ struct Analyzer
         return ((u.inter_dir & 1) && u.ref_idx[0] >= 0 ? 1u << u.ref_idx[0] : 0) | ((u.inter_dir & 2) && u.ref_idx[1] >= 0 ? 1u << (u.ref_idx[1] + 16) : 0);
     }
 
+    /* checkInter_rd0_4 for a two-part CU (rect / AMP): predInterSearch of both PUs, then the SA8D of the whole CU's prediction */
+    int checkInterPart(int x, int y, int depth, int part, int slot, const uint32_t refMasks[2])
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2, n4 = size >> 2;
+        Mode& m = d.pred[slot];
+        m.initCosts();
+        m.predTile = predTile(depth, slot); m.reconTile = reconTile(depth, slot);
+        x265amd_inter_cu c;
+        memset(&c, 0, sizeof(c));
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.part_size = (uint8_t)part;
+        x265amd_pu_result pu[2];
+        int32_t bits = 0;
+        x265amd_inter_search_params sp = *S;
+        sp.qp = qp; sp.chroma_mc = 1;
+        int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(m.predTile), tileBytes, nullptr, refMasks);
+        if (rc != X265AMD_OK) return err = rc;
+        for (int i = 0; i < n4 * n4; i++) { m.u[i].pred_mode = X265AMD_MODE_INTER; m.u[i].part_size = (uint8_t)part; }
+        for (int k = 0; k < 2; k++)
+        {
+            const Geo g = pu_geo(0, 0, size, part, k);
+            const x265amd_pu_result& r = pu[k];
+            for (int yy = g.y >> 2; yy < (g.y + g.h) >> 2; yy++)
+                for (int xx = g.x >> 2; xx < (g.x + g.w) >> 2; xx++)
+                {
+                    x265amd_cu_unit& u = m.u[yy * n4 + xx];
+                    x265amd_mv_unit& v = m.m[yy * n4 + xx];
+                    u.merge_flag = r.merge_flag; u.inter_dir = r.inter_dir;
+                    v.pred_mode = X265AMD_MODE_INTER; v.inter_dir = r.inter_dir;
+                    for (int l = 0; l < 2; l++)
+                    {
+                        const bool used = (r.inter_dir >> l) & 1;
+                        u.ref_idx[l] = used ? r.ref_idx[l] : -1; u.mvp_idx[l] = r.mvp_idx[l];
+                        u.mvd[l][0] = r.merge_flag ? 0 : r.mvd[l][0]; u.mvd[l][1] = r.merge_flag ? 0 : r.mvd[l][1];
+                        v.ref_idx[l] = used ? r.ref_idx[l] : -1; v.mv[l][0] = used ? r.mv[l][0] : 0; v.mv[l][1] = used ? r.mv[l][1] : 0;
+                    }
+                }
+        }
+        x265amd_rd_cu rc1;
+        memset(&rc1, 0, sizeof(rc1));
+        rc1.x = (int16_t)x; rc1.y = (int16_t)y; rc1.log2_size = (uint8_t)log2;
+        x265amd_cu_measure ms;
+        if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &rc1, 1, tileAddr(m.predTile), tileBytes, &ms) != X265AMD_OK) return err = X265AMD_EHIP;
+        m.sa8dBits = (uint32_t)bits;
+        m.distortion = ms.sa8d;
+        m.sa8dCost = calcRdSADCost(ms.sa8d, m.sa8dBits);
+        return 0;
+    }
+    uint32_t bestRefIdxCu(const Mode& m, int depth) const       /* OR of getBestRefIdx over the CU's PUs */
+    {
+        const int size = 64 >> depth, n4 = size >> 2, part = m.u[0].part_size;
+        static const uint8_t nb[8] = { 1, 2, 2, 4, 2, 2, 2, 2 };
+        uint32_t r = 0;
+        for (int k = 0; k < nb[part]; k++) { const Geo g = pu_geo(0, 0, size, part, k); r |= bestRefIdx(m.u[(g.y >> 2) * n4 + (g.x >> 2)]); }
+        return r;
+    }
+
     /* compressIntraCU (analysis.cpp:514-668) without analysis reuse / split-rd-skip */
     int compressIntra(int x, int y, int depth)
     {
@@ -540,7 +599,7 @@ struct Analyzer
         return 0;
     }
 
-    int compress(int x, int y, int depth, uint32_t& splitRefsOut)
+    int compress(int x, int y, int depth, SplitData& splitOut)
     {
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
@@ -549,8 +608,11 @@ struct Analyzer
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
         const uint32_t minDepth = topSkipMinDepth(x, y, depth);
         bool skipModes = false, skipRecursion = false, splitIntra = true;
-        uint32_t splitRefs[4] = { 0, 0, 0, 0 };
+        SplitData splitData[4];
+        memset(splitData, 0, sizeof(splitData));
+        d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
+        d.pred[PRED_2Nx2N].sa8dCost = 0;                 /* what a parent reads under --limit-modes when 2Nx2N is not searched here */
 
         /* Step 1: merge / skip candidates */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
@@ -579,7 +641,7 @@ struct Analyzer
                 if (cx < I->pic_width && cy < I->pic_height)
                 {
                     md[depth + 1].cur = *nextContext;
-                    if (compress(cx, cy, depth + 1, splitRefs[q])) return err;
+                    if (compress(cx, cy, depth + 1, splitData[q])) return err;
                     const Mode& nb = *md[depth + 1].best;
                     splitIntra |= nb.u[0].pred_mode == X265AMD_MODE_INTRA;
                     for (int yy = 0; yy < h4n; yy++)
@@ -604,7 +666,7 @@ struct Analyzer
             if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
             else updateModeCost(split);
         }
-        uint32_t allSplitRefs = splitRefs[0] | splitRefs[1] | splitRefs[2] | splitRefs[3];
+        uint32_t allSplitRefs = splitData[0].splitRefs | splitData[1].splitRefs | splitData[2].splitRefs | splitData[3].splitRefs;
         /* Step 3: ME and RD at the current depth */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
@@ -612,8 +674,59 @@ struct Analyzer
             {
                 if (checkInter(x, y, depth, allSplitRefs)) return err;
                 Mode* bestInter = &d.pred[PRED_2Nx2N];
-                if (A->limit_refs & 2) allSplitRefs = bestRefIdx(bestInter->u[0]);       /* X265_REF_LIMIT_CU */
+                if (A->limit_refs & 2)                                                     /* X265_REF_LIMIT_CU */
+                {
+                    allSplitRefs = bestRefIdx(bestInter->u[0]);
+                    for (int q = 0; q < 4; q++) splitData[q].splitRefs = allSplitRefs;
+                }
                 Mode& bidir = d.pred[PRED_BIDIR];
+                /* rectangular and asymmetric partitions (analysis.cpp:1447-1594); with limit-modes only where the sub-CUs' motion suggests it */
+                {
+                    const Mode& p2N = d.pred[PRED_2Nx2N];
+                    const bool isP = !I->is_inter_b;
+                    auto thr = [&](int a, int b) { return isP ? splitData[a].mvCost[0] + splitData[b].mvCost[0]
+                                                              : (splitData[a].mvCost[0] + splitData[b].mvCost[0] + splitData[a].mvCost[1] + splitData[b].mvCost[1] + 1) >> 1; };
+                    const uint64_t splitCost = splitData[0].sa8dCost + splitData[1].sa8dCost + splitData[2].sa8dCost + splitData[3].sa8dCost;
+                    auto tryPart = [&](int part, int slot, uint32_t m0, uint32_t m1) -> int {
+                        const uint32_t masks[2] = { m0, m1 };
+                        if (checkInterPart(x, y, depth, part, slot, masks)) return err;
+                        if (d.pred[slot].sa8dCost < bestInter->sa8dCost) bestInter = &d.pred[slot];
+                        return 0;
+                    };
+                    const uint32_t top = splitData[0].splitRefs | splitData[1].splitRefs, bot = splitData[2].splitRefs | splitData[3].splitRefs;
+                    const uint32_t lft = splitData[0].splitRefs | splitData[2].splitRefs, rgt = splitData[1].splitRefs | splitData[3].splitRefs;
+                    if (A->rect)
+                    {
+                        const uint32_t t2NxN = thr(0, 1), tNx2N = thr(0, 2);
+                        const bool first2NxN = t2NxN < tNx2N;
+                        if (first2NxN && splitCost < p2N.sa8dCost + t2NxN) { if (tryPart(1, PRED_2NxN, top, bot)) return err; }
+                        if (splitCost < p2N.sa8dCost + tNx2N) { if (tryPart(2, PRED_Nx2N, lft, rgt)) return err; }
+                        if (!first2NxN && splitCost < p2N.sa8dCost + t2NxN) { if (tryPart(1, PRED_2NxN, top, bot)) return err; }
+                    }
+                    if (A->amp && si->max_amp_depth > depth)
+                    {
+                        const uint32_t tU = thr(0, 1), tD = thr(2, 3), tL = thr(0, 2), tR = thr(1, 3);
+                        bool bHor = false, bVer = false;
+                        const int bp = bestInter->u[0].part_size;
+                        if (bp == 1) bHor = true;
+                        else if (bp == 2) bVer = true;
+                        else if (bp == 0 && d.best && (d.best->u[0].cbf[0] || d.best->u[0].cbf[1] || d.best->u[0].cbf[2])) { bHor = true; bVer = true; }
+                        if (bHor)
+                        {
+                            const bool firstD = tD < tU;
+                            if (firstD && splitCost < p2N.sa8dCost + tD) { if (tryPart(5, PRED_2NxnD, allSplitRefs, bot)) return err; }
+                            if (splitCost < p2N.sa8dCost + tU) { if (tryPart(4, PRED_2NxnU, top, allSplitRefs)) return err; }
+                            if (!firstD && splitCost < p2N.sa8dCost + tD) { if (tryPart(5, PRED_2NxnD, allSplitRefs, bot)) return err; }
+                        }
+                        if (bVer)
+                        {
+                            const bool firstR = tR < tL;
+                            if (firstR && splitCost < p2N.sa8dCost + tR) { if (tryPart(7, PRED_nRx2N, allSplitRefs, rgt)) return err; }
+                            if (splitCost < p2N.sa8dCost + tL) { if (tryPart(6, PRED_nLx2N, lft, allSplitRefs)) return err; }
+                            if (!firstR && splitCost < p2N.sa8dCost + tR) { if (tryPart(7, PRED_nRx2N, allSplitRefs, rgt)) return err; }
+                        }
+                    }
+                }
                 if (rdInter(*bestInter, x, y, depth, false)) return err;
                 checkBestMode(*bestInter, depth);
                 if (I->is_inter_b && bidir.sa8dCost != kMaxCost && bidir.sa8dCost * 16 <= bestInter->sa8dCost * 17)
@@ -638,9 +751,15 @@ struct Analyzer
             else checkBestMode(split, depth);
         }
         /* which motion references the parent CU should search (X265_REF_LIMIT_DEPTH) */
-        splitRefsOut = 0;
+        memset(&splitOut, 0, sizeof(splitOut));
         if (A->limit_refs & 1)
-            splitRefsOut = d.best == &d.pred[PRED_SPLIT] ? allSplitRefs : bestRefIdx(d.best->u[0].pred_mode == X265AMD_MODE_INTRA ? d.pred[PRED_2Nx2N].u[0] : d.best->u[0]);
+            splitOut.splitRefs = d.best == &d.pred[PRED_SPLIT] ? allSplitRefs
+                                                                : bestRefIdxCu(d.best->u[0].pred_mode == X265AMD_MODE_INTRA ? d.pred[PRED_2Nx2N] : *d.best, depth);
+        if (A->limit_modes)
+        {
+            splitOut.mvCost[0] = d.mvCost2Nx2N[0]; splitOut.mvCost[1] = d.mvCost2Nx2N[1];
+            splitOut.sa8dCost = d.pred[PRED_2Nx2N].sa8dCost;
+        }
         if (mightNotSplit && d.best->isSkipped())
         {
             x265amd_cu_stat& cs = cuStat[ctuAddr];
@@ -665,8 +784,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
-    if (A->rd_level < 3 || A->rd_level > 4 || A->rect || A->amp || A->limit_refs < 0 || A->limit_refs > 3 || A->limit_modes || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
-        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, 2Nx2N only, no delta QP, rskip 0/1)");
+    if (A->rd_level < 3 || A->rd_level > 4 || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
     Analyzer* an = new Analyzer;
     Analyzer& a = *an;
@@ -700,8 +819,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         memset(&a.md[0].cur, 0, sizeof(Snap));
         memcpy(a.md[0].cur.ctx, ctx_in, X265AMD_CTX_COUNT);
         a.md[0].cur.frac = frac_in;
-        uint32_t topRefs = 0;
-        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : a.compress(a.ctuX, a.ctuY, 0, topRefs);
+        SplitData topSplit;
+        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : a.compress(a.ctuX, a.ctuY, 0, topSplit);
         if (rc == X265AMD_OK && hipStreamSynchronize(a.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)
