@@ -738,6 +738,36 @@ typedef struct x265amd_slice_header
 /* substreams: the raw (unescaped) CABAC sub-streams back to back, sizes[i] bytes each.  Returns the NAL size in bytes (written when it fits). */
 size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const uint8_t* substreams, const uint32_t* sizes, int num_substreams, uint8_t* out, size_t cap);
 
+/* Stream headers: Encoder::getStreamHeaders' VPS, SPS and PPS NAL units (reference: source/encoder/encoder.cpp:3234-3259, Entropy::codeVPS / codeSPS /
+ * codeProfileTier / codeVUI / codePPS, source/encoder/entropy.cpp:233-502).  The fields are the reference's VPS / SPS / PPS / ProfileTierLevel / VUI
+ * members (source/common/slice.h) as the encoder configured them; no scaling lists, SPS reference picture sets or HRD parameters. */
+typedef struct x265amd_stream_params
+{
+    /* ProfileTierLevel */
+    int32_t tier_flag, profile_idc; uint32_t profile_compatibility_flags;   /* bit j = profileCompatibilityFlag[j] */
+    int32_t progressive_source, interlaced_source, non_packed_constraint, frame_only_constraint;
+    int32_t bit_depth_constraint, chroma_format_constraint, intra_constraint, one_picture_only_constraint, lower_bit_rate_constraint;   /* range extension profiles */
+    int32_t level_idc;
+    int32_t max_temporal_sub_layers, max_dec_pic_buffering[8], num_reorder_pics[8], max_latency_increase[8];
+    /* SPS */
+    int32_t chroma_format_idc, pic_width, pic_height, conformance_window, conf_win_offsets[4];      /* left, right, top, bottom in luma samples */
+    int32_t bit_depth, log2_max_poc_lsb, log2_min_cu_size, log2_diff_max_min_cu_size, tu_log2_min, tu_log2_max, tu_max_depth_inter, tu_max_depth_intra;
+    int32_t amp, sao, temporal_mvp, strong_intra_smoothing;
+    /* VUI */
+    int32_t aspect_ratio_idc, sar_width, sar_height;                /* aspect_ratio_idc 0: not present */
+    int32_t overscan_info_present, overscan_appropriate, video_signal_type_present, video_format, video_full_range;
+    int32_t colour_description_present, colour_primaries, transfer_characteristics, matrix_coefficients;
+    int32_t chroma_loc_info_present, chroma_sample_loc_top, chroma_sample_loc_bottom, field_seq, frame_field_info_present;
+    int32_t default_display_window, def_disp_win_offsets[4];
+    int32_t emit_timing_info; uint32_t num_units_in_tick, time_scale;
+    /* PPS */
+    int32_t sign_hide, num_ref_idx_default[2], init_qp_minus26, constrained_intra_pred, transform_skip, use_dqp, max_cu_dqp_depth;
+    int32_t cb_qp_offset, cr_qp_offset, slice_chroma_qp_offsets_present, weighted_pred, weighted_bipred, transquant_bypass, wpp;
+    int32_t loop_filter_across_slices, deblocking_filter_control_present, pic_disable_deblocking, beta_offset_div2, tc_offset_div2;
+} x265amd_stream_params;
+/* Returns the size of the three NAL units in bytes (written to out when it fits), 0 on bad arguments. */
+size_t x265amd_write_stream_headers(const x265amd_stream_params* p, uint8_t* out, size_t cap);
+
 /* FrameEncoder::encodeSlice (reference: source/encoder/frameencoder.cpp:1298-1370): the final CABAC pass over a decided picture -> sub-streams
  * (one per CTU row when si->wpp, else one).  sao / sao_flags (may be NULL): the SAO parameters of every CTU (reserved[0] = merge mode: 0 none,
  * 1 left, 2 up) and slice_sao_luma_flag / slice_sao_chroma_flag; their syntax precedes each CTU. */

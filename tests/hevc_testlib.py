@@ -2744,6 +2744,58 @@ FRAME_CLI_ARGS = ["--preset", "medium", "--qp", "30", "--aq-mode", "0", "--no-cu
                   "--lookahead-slices", "0"]
 
 
+STREAM_PARAMS_DT = np.dtype([("tier_flag", "<i4"), ("profile_idc", "<i4"), ("profile_compatibility_flags", "<u4"),
+                             ("progressive_source", "<i4"), ("interlaced_source", "<i4"), ("non_packed_constraint", "<i4"), ("frame_only_constraint", "<i4"),
+                             ("bit_depth_constraint", "<i4"), ("chroma_format_constraint", "<i4"), ("intra_constraint", "<i4"), ("one_picture_only_constraint", "<i4"),
+                             ("lower_bit_rate_constraint", "<i4"), ("level_idc", "<i4"),
+                             ("max_temporal_sub_layers", "<i4"), ("max_dec_pic_buffering", "<i4", 8), ("num_reorder_pics", "<i4", 8), ("max_latency_increase", "<i4", 8),
+                             ("chroma_format_idc", "<i4"), ("pic_width", "<i4"), ("pic_height", "<i4"), ("conformance_window", "<i4"), ("conf_win_offsets", "<i4", 4),
+                             ("bit_depth", "<i4"), ("log2_max_poc_lsb", "<i4"), ("log2_min_cu_size", "<i4"), ("log2_diff_max_min_cu_size", "<i4"),
+                             ("tu_log2_min", "<i4"), ("tu_log2_max", "<i4"), ("tu_max_depth_inter", "<i4"), ("tu_max_depth_intra", "<i4"),
+                             ("amp", "<i4"), ("sao", "<i4"), ("temporal_mvp", "<i4"), ("strong_intra_smoothing", "<i4"),
+                             ("aspect_ratio_idc", "<i4"), ("sar_width", "<i4"), ("sar_height", "<i4"),
+                             ("overscan_info_present", "<i4"), ("overscan_appropriate", "<i4"), ("video_signal_type_present", "<i4"), ("video_format", "<i4"),
+                             ("video_full_range", "<i4"), ("colour_description_present", "<i4"), ("colour_primaries", "<i4"), ("transfer_characteristics", "<i4"),
+                             ("matrix_coefficients", "<i4"), ("chroma_loc_info_present", "<i4"), ("chroma_sample_loc_top", "<i4"), ("chroma_sample_loc_bottom", "<i4"),
+                             ("field_seq", "<i4"), ("frame_field_info_present", "<i4"), ("default_display_window", "<i4"), ("def_disp_win_offsets", "<i4", 4),
+                             ("emit_timing_info", "<i4"), ("num_units_in_tick", "<u4"), ("time_scale", "<u4"),
+                             ("sign_hide", "<i4"), ("num_ref_idx_default", "<i4", 2), ("init_qp_minus26", "<i4"), ("constrained_intra_pred", "<i4"), ("transform_skip", "<i4"),
+                             ("use_dqp", "<i4"), ("max_cu_dqp_depth", "<i4"), ("cb_qp_offset", "<i4"), ("cr_qp_offset", "<i4"), ("slice_chroma_qp_offsets_present", "<i4"),
+                             ("weighted_pred", "<i4"), ("weighted_bipred", "<i4"), ("transquant_bypass", "<i4"), ("wpp", "<i4"), ("loop_filter_across_slices", "<i4"),
+                             ("deblocking_filter_control_present", "<i4"), ("pic_disable_deblocking", "<i4"), ("beta_offset_div2", "<i4"), ("tc_offset_div2", "<i4")])
+
+
+def frame_stream_params(bframes=0, deblock=False, wpp=False, sao=False, amp=False, qp=30):
+    """what the reference encoder configures for FRAME_CLI_ARGS (+ the variations of the end-to-end goldens) on the MC_W x MC_H clip at 30 fps:
+    Main profile, level 2, 8-bit 4:2:0, CTU 64 / min CU 8, TU 4..32 with depth 1, --ref 3"""
+    p = np.zeros(1, STREAM_PARAMS_DT)[0]
+    p["profile_idc"], p["profile_compatibility_flags"], p["progressive_source"], p["frame_only_constraint"], p["level_idc"] = 1, 0x6, 1, 1, 60
+    p["max_temporal_sub_layers"] = 1
+    p["num_reorder_pics"][0] = 1 if bframes else 0                          # no b-pyramid
+    p["max_dec_pic_buffering"][0] = min(16, max(p["num_reorder_pics"][0] + 2, 3) + 1)     # maxNumReferences 3 (Encoder::initSPS / initVPS)
+    p["max_latency_increase"][0] = bframes                                   # Encoder::initSPS: maxLatencyIncrease = param.bframes
+    p["chroma_format_idc"], p["pic_width"], p["pic_height"], p["bit_depth"], p["log2_max_poc_lsb"] = 1, MC_W, MC_H, 8, 8
+    p["log2_min_cu_size"], p["log2_diff_max_min_cu_size"], p["tu_log2_min"], p["tu_log2_max"], p["tu_max_depth_inter"], p["tu_max_depth_intra"] = 3, 3, 2, 5, 1, 1
+    p["amp"], p["sao"], p["temporal_mvp"], p["strong_intra_smoothing"] = int(amp), int(sao), 1, 1
+    p["aspect_ratio_idc"] = 1
+    p["emit_timing_info"], p["num_units_in_tick"], p["time_scale"] = 1, 1, 30
+    p["sign_hide"], p["num_ref_idx_default"] = 1, (1, 1)
+    p["init_qp_minus26"] = 0
+    p["wpp"], p["loop_filter_across_slices"] = int(wpp), 1
+    p["deblocking_filter_control_present"], p["pic_disable_deblocking"] = int(not deblock), int(not deblock)
+    return p
+
+
+def frame_stream_headers(L, **config):
+    lib = L.lib
+    lib.x265amd_write_stream_headers.restype = C.c_size_t
+    p = np.array([frame_stream_params(**config)])
+    out = np.zeros(512, np.uint8)
+    n = lib.x265amd_write_stream_headers(_ptr(p), _ptr(out), C.c_size_t(out.size))
+    assert 0 < n <= out.size
+    return out[:n].copy()
+
+
 def frame_clip(depth=8, nframes=4):
     """source frames (padded flat Y|U|V arrays in inter_scene geometry), in coding order"""
     pics, stride, cstride, org = inter_scene(depth, FRAME_CLIP_SEED, npics=4)
@@ -2782,7 +2834,7 @@ def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb, sao_flags=None):
     l0 = [int(v) for v in sched[3:7] if v >= 0]; l1 = [int(v) for v in sched[7:11] if v >= 0]
     h = np.zeros(1, SLICE_HEADER_DT)
     h["nal_unit_type"] = 20 if stype == 2 else (1 if referenced else 0)     # IDR_N_LP / TRAIL_R / TRAIL_N
-    h["first_in_access_unit"] = int(k > 0)              # the IDR slice follows the parameter sets in its access unit
+    h["first_in_access_unit"] = 1                       # each picture's slice NAL opens its own NAL list (the stream headers are emitted separately)
     h["slice_type"], h["poc"], h["log2_max_poc_lsb"], h["rps_idx"] = stype, poc, 8, -1
     neg = sorted([p for p in dpb if p < poc], reverse=True); pos = sorted([p for p in dpb if p > poc])
     h["num_negative"], h["num_positive"] = len(neg), len(pos)

@@ -19,8 +19,26 @@ def test_golden_is_a_real_encode():
     assert all(len(g["slice/%d" % k]) > 20 for k in range(4))
 
 
+TAGS = ["", "deblock/", "wpp/", "bframes/", "sao/", "sao_bframes/", "rectamp_bframes/", "rectamp_lm/"]
+
+
+def header_config(tag):
+    return dict(bframes=2 if "bframes" in tag else 0, deblock=bool(tag), wpp=tag == "wpp/", sao="sao" in tag, amp="rectamp" in tag)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_stream_headers_match_reference_encoder(tag):
+    """VPS / SPS / PPS NAL units (x265amd_write_stream_headers, host code) against the head of the reference encoder's stream"""
+    g = np.load(GOLD_PATH)
+    stream = g[tag + "stream"]
+    n = len(g[tag + "schedule"])
+    first = len(stream) - sum(len(g[tag + "nal/%d" % k]) + 4 for k in range(n))      # every slice NAL opens an access unit: 4-byte start codes
+    got = T.frame_stream_headers(T.load_hip(8), **header_config(tag))
+    assert got.tobytes().hex() == stream[:first].tobytes().hex()
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["", "deblock/", "wpp/", "bframes/", "sao/", "sao_bframes/", "rectamp_bframes/", "rectamp_lm/"])
+@pytest.mark.parametrize("tag", TAGS)
 def test_hip_frame_pipeline_matches_reference_encoder(tag):
     """tag "deblock/": the same encode with the in-loop deblocking filter on (x265amd_deblock_units + x265amd_deblock_picture per frame);
     "wpp/": deblocking and wavefront parallel processing on (per-row entropy states, one sub-stream per CTU row, entry points in the slice header);
@@ -44,10 +62,10 @@ def test_hip_frame_pipeline_matches_reference_encoder(tag):
                 raise AssertionError("coded frame %d (poc %d) plane %d: %d reconstructed samples differ from the reference encoder's, first at (y, x) = %s" % (
                     k, poc, p, len(bad), bad[0].tolist()))
         want_nal = g[tag + "nal/%d" % k]
-        sc = 4 if k else 3
+        sc = 4
         assert np.array_equal(data[sc:], want_nal), "coded frame %d: slice NAL unit differs from the reference encoder's (%d vs %d bytes)" % (k, len(data) - sc, len(want_nal))
-    # the whole byte stream: the reference's VPS / SPS / PPS (configuration constants, taken from its stream) + our slice NAL units
+    # the whole byte stream: our VPS / SPS / PPS (x265amd_write_stream_headers) + our slice NAL units
     stream = g[tag + "stream"]
-    first = len(stream) - sum(len(g[tag + "nal/%d" % k]) + (4 if k else 3) for k in range(n))
-    ours = np.concatenate([stream[:first]] + [d for (_, _, d) in got])
+    ours = np.concatenate([T.frame_stream_headers(T.load_hip(8), **header_config(tag))] + [d for (_, _, d) in got])
+    assert len(ours) == len(stream)
     assert hashlib.md5(ours.tobytes()).hexdigest() == hashlib.md5(stream.tobytes()).hexdigest()

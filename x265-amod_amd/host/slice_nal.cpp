@@ -1,4 +1,4 @@
-/* Slice NAL units (include/x265amd.h: x265amd_write_slice_nal): host C++, part of SURVEY section 8f rank 4 (formats).
+/* Slice NAL units (include/x265amd.h: x265amd_write_slice_nal, x265amd_write_stream_headers): host C++, part of SURVEY section 8f rank 4 (formats).
  *
  * Restatement of Entropy::codeSliceHeader / codeSliceHeaderWPPEntryPoints / codeShortTermRefPicSet (reference:
  * source/encoder/entropy.cpp:593-766), Bitstream::writeByteAlignment (source/common/bitstream.cpp), and the byte-stream packing of
@@ -21,6 +21,153 @@ struct Bits
     void align() { put(1, 1); while (n) put(0, 1); }
 };
 
+/* NALList::serialize (nal.cpp:60-160): start code, NAL header, payload with emulation prevention (the look-back starts past the header) */
+void serialize(std::vector<uint8_t>& nal, int nalUnitType, int temporalIdPlus1, bool longStartCode, const std::vector<uint8_t>& payload)
+{
+    if (longStartCode) nal.push_back(0);
+    nal.push_back(0); nal.push_back(0); nal.push_back(1);
+    nal.push_back((uint8_t)(nalUnitType << 1));
+    nal.push_back((uint8_t)temporalIdPlus1);
+    for (size_t i = 0; i < payload.size(); i++)
+    {
+        const size_t bytes = nal.size();
+        if (i > 2 && !nal[bytes - 2] && !nal[bytes - 3] && nal[bytes - 1] <= 3)
+        {
+            const uint8_t last = nal[bytes - 1];
+            nal[bytes - 1] = 3;
+            nal.push_back(last);
+        }
+        nal.push_back(payload[i]);
+    }
+}
+
+/* Entropy::codeProfileTier (entropy.cpp:380-429) */
+void profileTier(Bits& b, const x265amd_stream_params* p)
+{
+    b.put(0, 2);
+    b.flag(p->tier_flag != 0);
+    b.put((uint32_t)p->profile_idc, 5);
+    for (int j = 0; j < 32; j++) b.flag((p->profile_compatibility_flags >> j) & 1);
+    b.flag(p->progressive_source != 0); b.flag(p->interlaced_source != 0); b.flag(p->non_packed_constraint != 0); b.flag(p->frame_only_constraint != 0);
+    if (p->profile_idc == 4 || p->profile_idc == 5)            /* MAINREXT, HIGHTHROUGHPUTREXT */
+    {
+        const int depth = p->bit_depth_constraint, csp = p->chroma_format_constraint;     /* csp: 0 400, 1 420, 2 422, 3 444 */
+        b.flag(depth <= 12); b.flag(depth <= 10); b.flag(depth <= 8 && csp != 2);
+        b.flag(csp == 2 || csp == 1 || csp == 0); b.flag(csp == 1 || csp == 0); b.flag(csp == 0);
+        b.flag(p->intra_constraint != 0); b.flag(p->one_picture_only_constraint != 0); b.flag(p->lower_bit_rate_constraint != 0);
+        b.put(0, 16); b.put(0, 16); b.put(0, 3);
+    }
+    else { b.put(0, 16); b.put(0, 16); b.put(0, 12); }
+    b.put((uint32_t)p->level_idc, 8);
+    if (p->max_temporal_sub_layers > 1)
+    {
+        for (int i = 0; i < p->max_temporal_sub_layers - 1; i++) { b.flag(false); b.flag(false); }
+        for (int i = p->max_temporal_sub_layers - 1; i < 8; i++) b.put(0, 2);
+    }
+}
+
+}
+
+/* Encoder::getStreamHeaders (encoder.cpp:3234-3259): VPS, SPS and PPS NAL units, each behind a 4-byte start code.
+ * Entropy::codeVPS / codeSPS / codeVUI / codePPS (entropy.cpp:233-378, :431-502); no scaling lists, no SPS reference picture sets, no HRD. */
+extern "C" size_t x265amd_write_stream_headers(const x265amd_stream_params* p, uint8_t* out, size_t cap)
+{
+    if (!p || p->max_temporal_sub_layers < 1 || p->max_temporal_sub_layers > 7) return 0;
+    const int layers = p->max_temporal_sub_layers;
+    std::vector<uint8_t> nal;
+    {
+        Bits b;                                                  /* codeVPS */
+        b.put(0, 4); b.put(3, 2); b.put(0, 6);
+        b.put((uint32_t)(layers - 1), 3); b.flag(layers == 1); b.put(0xffff, 16);
+        profileTier(b, p);
+        b.flag(true);
+        for (int i = 0; i < layers; i++) { b.ue((uint32_t)(p->max_dec_pic_buffering[i] - 1)); b.ue((uint32_t)p->num_reorder_pics[i]); b.ue((uint32_t)(p->max_latency_increase[i] + 1)); }
+        b.put(0, 6); b.ue(0); b.flag(false); b.flag(false);
+        b.align();
+        serialize(nal, 32, 1, true, b.out);
+    }
+    {
+        Bits b;                                                  /* codeSPS */
+        b.put(0, 4); b.put((uint32_t)(layers - 1), 3); b.flag(layers == 1);
+        profileTier(b, p);
+        b.ue(0);
+        b.ue((uint32_t)p->chroma_format_idc);
+        if (p->chroma_format_idc == 3) b.flag(false);
+        b.ue((uint32_t)p->pic_width); b.ue((uint32_t)p->pic_height);
+        b.flag(p->conformance_window != 0);
+        if (p->conformance_window)
+        {
+            const int hs = p->chroma_format_idc == 1 || p->chroma_format_idc == 2, vs = p->chroma_format_idc == 1;
+            b.ue((uint32_t)(p->conf_win_offsets[0] >> hs)); b.ue((uint32_t)(p->conf_win_offsets[1] >> hs));
+            b.ue((uint32_t)(p->conf_win_offsets[2] >> vs)); b.ue((uint32_t)(p->conf_win_offsets[3] >> vs));
+        }
+        b.ue((uint32_t)(p->bit_depth - 8)); b.ue((uint32_t)(p->bit_depth - 8));
+        b.ue((uint32_t)(p->log2_max_poc_lsb - 4));
+        b.flag(true);
+        for (int i = 0; i < layers; i++) { b.ue((uint32_t)(p->max_dec_pic_buffering[i] - 1)); b.ue((uint32_t)p->num_reorder_pics[i]); b.ue((uint32_t)(p->max_latency_increase[i] + 1)); }
+        b.ue((uint32_t)(p->log2_min_cu_size - 3)); b.ue((uint32_t)p->log2_diff_max_min_cu_size);
+        b.ue((uint32_t)(p->tu_log2_min - 2)); b.ue((uint32_t)(p->tu_log2_max - p->tu_log2_min));
+        b.ue((uint32_t)(p->tu_max_depth_inter - 1)); b.ue((uint32_t)(p->tu_max_depth_intra - 1));
+        b.flag(false);                                           /* scaling_list_enabled_flag */
+        b.flag(p->amp != 0); b.flag(p->sao != 0);
+        b.flag(false);                                           /* pcm_enabled_flag */
+        b.ue(0);                                                 /* num_short_term_ref_pic_sets */
+        b.flag(false);                                           /* long_term_ref_pics_present_flag */
+        b.flag(p->temporal_mvp != 0); b.flag(p->strong_intra_smoothing != 0);
+        b.flag(true);                                            /* vui_parameters_present_flag; codeVUI */
+        b.flag(p->aspect_ratio_idc != 0);
+        if (p->aspect_ratio_idc)
+        {
+            b.put((uint32_t)p->aspect_ratio_idc, 8);
+            if (p->aspect_ratio_idc == 255) { b.put((uint32_t)p->sar_width, 16); b.put((uint32_t)p->sar_height, 16); }
+        }
+        b.flag(p->overscan_info_present != 0);
+        if (p->overscan_info_present) b.flag(p->overscan_appropriate != 0);
+        b.flag(p->video_signal_type_present != 0);
+        if (p->video_signal_type_present)
+        {
+            b.put((uint32_t)p->video_format, 3); b.flag(p->video_full_range != 0); b.flag(p->colour_description_present != 0);
+            if (p->colour_description_present) { b.put((uint32_t)p->colour_primaries, 8); b.put((uint32_t)p->transfer_characteristics, 8); b.put((uint32_t)p->matrix_coefficients, 8); }
+        }
+        b.flag(p->chroma_loc_info_present != 0);
+        if (p->chroma_loc_info_present) { b.ue((uint32_t)p->chroma_sample_loc_top); b.ue((uint32_t)p->chroma_sample_loc_bottom); }
+        b.flag(false);                                           /* neutral_chroma_indication_flag */
+        b.flag(p->field_seq != 0); b.flag(p->frame_field_info_present != 0);
+        b.flag(p->default_display_window != 0);
+        if (p->default_display_window) for (int i = 0; i < 4; i++) b.ue((uint32_t)p->def_disp_win_offsets[i]);
+        b.flag(p->emit_timing_info != 0);
+        if (p->emit_timing_info) { b.put(p->num_units_in_tick, 32); b.put(p->time_scale, 32); b.flag(false); }
+        b.flag(false);                                           /* vui_hrd_parameters_present_flag */
+        b.flag(false);                                           /* bitstream_restriction_flag */
+        b.flag(false);                                           /* sps_extension_flag */
+        b.align();
+        serialize(nal, 33, 1, true, b.out);
+    }
+    {
+        Bits b;                                                  /* codePPS */
+        b.ue(0); b.ue(0); b.flag(false); b.flag(false); b.put(0, 3);
+        b.flag(p->sign_hide != 0); b.flag(false);
+        b.ue((uint32_t)(p->num_ref_idx_default[0] - 1)); b.ue((uint32_t)(p->num_ref_idx_default[1] - 1));
+        b.se(p->init_qp_minus26);
+        b.flag(p->constrained_intra_pred != 0); b.flag(p->transform_skip != 0);
+        b.flag(p->use_dqp != 0);
+        if (p->use_dqp) b.ue((uint32_t)p->max_cu_dqp_depth);
+        b.se(p->cb_qp_offset); b.se(p->cr_qp_offset); b.flag(p->slice_chroma_qp_offsets_present != 0);
+        b.flag(p->weighted_pred != 0); b.flag(p->weighted_bipred != 0); b.flag(p->transquant_bypass != 0);
+        b.flag(false);                                           /* tiles_enabled_flag */
+        b.flag(p->wpp != 0); b.flag(p->loop_filter_across_slices != 0);
+        b.flag(p->deblocking_filter_control_present != 0);
+        if (p->deblocking_filter_control_present)
+        {
+            b.flag(false); b.flag(p->pic_disable_deblocking != 0);
+            if (!p->pic_disable_deblocking) { b.se(p->beta_offset_div2); b.se(p->tc_offset_div2); }
+        }
+        b.flag(false); b.flag(false); b.ue(0); b.flag(false); b.flag(false);
+        b.align();
+        serialize(nal, 34, 1, true, b.out);
+    }
+    if (out && cap >= nal.size()) memcpy(out, nal.data(), nal.size());
+    return nal.size();
 }
 
 extern "C" size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const uint8_t* substreams, const uint32_t* sizes, int numSubstreams, uint8_t* out, size_t cap)
@@ -108,25 +255,8 @@ extern "C" size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const u
         for (uint32_t i = 0; i < n; i++) b.put(escaped[i] - 1, (int)offsetLen);
     }
     b.align();
-    /* NALList::serialize */
     std::vector<uint8_t> nal;
-    if (h->first_in_access_unit) nal.push_back(0);
-    nal.push_back(0); nal.push_back(0); nal.push_back(1);
-    const size_t hdr0 = nal.size();
-    nal.push_back((uint8_t)(h->nal_unit_type << 1));
-    nal.push_back((uint8_t)(h->temporal_id_plus1 ? h->temporal_id_plus1 : 1));
-    for (size_t i = 0; i < b.out.size(); i++)
-    {
-        const size_t bytes = nal.size();
-        if (i > 2 && !nal[bytes - 2] && !nal[bytes - 3] && nal[bytes - 1] <= 3)
-        {
-            const uint8_t last = nal[bytes - 1];
-            nal[bytes - 1] = 3;
-            nal.push_back(last);
-        }
-        nal.push_back(b.out[i]);
-    }
-    (void)hdr0;
+    serialize(nal, h->nal_unit_type, h->temporal_id_plus1 ? h->temporal_id_plus1 : 1, h->first_in_access_unit != 0, b.out);
     nal.insert(nal.end(), data.begin(), data.end());
     if (!nal.back()) nal.push_back(3);
     if (out && cap >= nal.size()) memcpy(out, nal.data(), nal.size());
