@@ -291,6 +291,11 @@ def make_frame_pipeline_golden():
     # rectangular + asymmetric partitions (with and without --limit-modes) on both clips, deblocking on
     _frame_pipeline_one(framesb, stride, cstride, org, "rectamp_bframes/", clib + ["--no-b-pyramid", "--rect", "--amp"], out, nframes=7)
     _frame_pipeline_one(frames, stride, cstride, org, "rectamp_lm/", [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"] + ["--rect", "--amp", "--limit-modes"], out)
+    # rd 5 (RD on every candidate: compressInterCU_rd5_6) with and without rect / amp
+    _frame_pipeline_one(framesb, stride, cstride, org, "rd5_bframes/", [("5" if (a == "3" and clib[i - 1] == "--rd") else a) for i, a in enumerate(clib)] + ["--no-b-pyramid"], out, nframes=7)
+    cli5 = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
+    cli5[cli5.index("--rd") + 1] = "6"
+    _frame_pipeline_one(frames, stride, cstride, org, "rd6_rectamp/", cli5 + ["--rect", "--amp", "--limit-modes"], out)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
     print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 

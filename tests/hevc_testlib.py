@@ -2362,7 +2362,7 @@ assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_
 
 
 def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1, intra_slice=False,
-             rect=0, amp=0, limit_modes=0):
+             rect=0, amp=0, limit_modes=0, rd_level=3):
     """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
     the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
     rng = np.random.default_rng(seed + 901)
@@ -2451,6 +2451,7 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
     ap = np.zeros(1, ANALYSIS_PARAMS_DT)
     ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = psy_rd, 3, early_skip, rskip, limit_refs, b_intra, strong
     ap["rect"], ap["amp"], ap["limit_modes"] = rect, amp, limit_modes
+    ap["rd_level"] = rd_level
     # reference pictures' CU depths (two lists) and CTU QPs; running cost statistics of the CTUs coded so far
     ref_depth = np.zeros((2, h4, w4), np.uint8)
     for l in range(2):
@@ -2849,7 +2850,8 @@ def frame_slice_header(k, sched, slice_qp, deblock, wpp, dpb, sao_flags=None):
     return h
 
 
-def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None, sao=False, rect=0, amp=0, limit_modes=0):
+def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, wpp=False, schedule=None, frames=None, sao=False, rect=0, amp=0, limit_modes=0,
+                           rd_level=3):
     """frames through x265amd_analyse_frame the way the reference's frame encoder strings them together (CQP, no AQ, optional deblocking and
     wavefront sub-streams).  schedule: per coded frame (type 2 I / 1 P / 0 B, poc, referenced, 4 L0 pocs, 4 L1 pocs), default I P P P.
     Returns per coded frame (poc, recon planes, the slice NAL unit with its start code)"""
@@ -2910,7 +2912,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
         ap = np.zeros(1, ANALYSIS_PARAMS_DT)
         ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
         ap["use_sao"] = int(sao)
-        ap["rect"], ap["amp"], ap["limit_modes"] = rect, amp, limit_modes
+        ap["rect"], ap["amp"], ap["limit_modes"], ap["rd_level"] = rect, amp, limit_modes, rd_level
         si["max_amp_depth"] = 3 if amp else 0
         units = np.zeros((h4, w4), CU_UNIT_DT); cur = np.zeros((h4, w4), MV_UNIT_DT)
         col = fields[col_poc] if col_poc is not None else np.zeros((h4, w4), MV_UNIT_DT)

@@ -13,16 +13,19 @@ CASES = [(8, 1, 1, 1, 2.0, 1, 0), (8, 2, 0, 1, 2.0, 2, 0), (8, 3, 1, 0, 0.0, 1, 
          (8, 7, 1, 1, 2.0, 1, 3), (8, 8, 0, 0, 2.0, 1, 3), (10, 9, 0, 1, 0.0, 2, 1), (8, 10, 0, 1, 2.0, 1, 2),
          (8, 11, 1, 1, 2.0, 1, 3, 0, 0), (8, 12, 0, 1, 2.0, 1, 0, 0, 0), (10, 13, 0, 0, 0.0, 2, 3, 0, 0), (8, 14, 0, 1, 2.0, 1, 3, 1, 1), (8, 15, 1, 0, 1.0, 1, 0, 1, 1),
          (8, 16, 0, 0, 2.0, 1, 0, 0, 0, 1), (10, 17, 0, 0, 0.0, 1, 0, 0, 0, 1), (8, 18, 0, 0, 1.0, 1, 0, 0, 0, 1)]
-# rectangular / asymmetric partitions: (depth, seed, early skip, rskip, psy-rd, limit-refs, B slice, b-intra, rect, amp, limit-modes)
+# rectangular / asymmetric partitions and rd 5-6: (depth, seed, early skip, rskip, psy-rd, limit-refs, B slice, b-intra, rect, amp, limit-modes[, rd level])
 PART_CASES = [(8, 21, 0, 1, 2.0, 3, 1, 0, 1, 0, 0), (8, 22, 0, 0, 2.0, 0, 0, 0, 1, 1, 0), (10, 23, 1, 1, 0.0, 3, 1, 1, 1, 1, 1), (8, 24, 0, 1, 1.0, 1, 0, 0, 1, 1, 1),
-              (8, 25, 0, 0, 2.0, 2, 1, 0, 1, 1, 0), (8, 26, 0, 1, 2.0, 3, 0, 0, 1, 0, 1)]
+              (8, 25, 0, 0, 2.0, 2, 1, 0, 1, 1, 0), (8, 26, 0, 1, 2.0, 3, 0, 0, 1, 0, 1),
+              (8, 31, 0, 1, 2.0, 3, 1, 1, 0, 0, 0, 5), (8, 32, 1, 0, 2.0, 0, 0, 0, 1, 1, 0, 6), (10, 33, 0, 1, 0.0, 1, 1, 0, 1, 1, 1, 5), (8, 34, 1, 1, 1.0, 3, 0, 0, 1, 0, 1, 6),
+              (8, 35, 0, 0, 2.0, 2, 1, 1, 1, 1, 0, 5)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 
 def make_case(k):
     if k >= len(CASES):
-        depth, seed, es, rs, psy, lr, is_b, b_intra, rect, amp, lm = PART_CASES[k - len(CASES)]
-        return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, limit_refs=lr, b_intra=b_intra, rect=rect, amp=amp, limit_modes=lm)
+        depth, seed, es, rs, psy, lr, is_b, b_intra, rect, amp, lm = PART_CASES[k - len(CASES)][:11]
+        rd = PART_CASES[k - len(CASES)][11] if len(PART_CASES[k - len(CASES)]) > 11 else 3
+        return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, limit_refs=lr, b_intra=b_intra, rect=rect, amp=amp, limit_modes=lm, rd_level=rd)
     depth, seed, es, rs, psy, td, lr = CASES[k][:7]
     is_b, b_intra = (CASES[k][7], CASES[k][8]) if len(CASES[k]) > 7 else (1, 0)
     return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr, b_intra=b_intra,

@@ -66,7 +66,7 @@ struct Mode
     bool isSkipped() const { return u[0].pred_mode == X265AMD_MODE_SKIP; }
 };
 
-struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; uint32_t mvCost2Nx2N[2]; };
+struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; uint32_t mvCost2Nx2N[2]; x265amd_me_detail det; };
 
 struct DevBuf
 {
@@ -383,13 +383,12 @@ struct Analyzer
         return 0;
     }
 
-    /* checkInter_rd0_4(2Nx2N) + checkBidir2Nx2N */
-    int checkInter(int x, int y, int depth, uint32_t refMask)
+    /* checkInter_rd0_4(2Nx2N) + checkBidir2Nx2N; searchOnly: predInterSearch alone (checkInter_rd5_6 runs the RD itself, the bi-prediction try comes later) */
+    int checkInter(int x, int y, int depth, uint32_t refMask, bool searchOnly = false)
     {
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
         Mode& inter = d.pred[PRED_2Nx2N];
-        Mode& bidir = d.pred[PRED_BIDIR];
         inter.initCosts();
         inter.predTile = predTile(depth, PRED_2Nx2N); inter.reconTile = reconTile(depth, PRED_2Nx2N);
         x265amd_inter_cu c;
@@ -397,7 +396,7 @@ struct Analyzer
         c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.part_size = 0;
         x265amd_pu_result pu[2];
         int32_t bits = 0;
-        x265amd_me_detail det;
+        x265amd_me_detail& det = d.det;
         x265amd_inter_search_params sp = *S;
         sp.qp = qp; sp.chroma_mc = 1;
         const uint32_t masks[2] = { refMask, 0 };
@@ -405,6 +404,8 @@ struct Analyzer
         if (rc != X265AMD_OK) return err = rc;
         setInter(inter, depth, pu[0].merge_flag, pu[0].mvp_idx[0], pu[0].inter_dir, pu[0].ref_idx, pu[0].mv, pu[0].mvd, pu[0].mvp_idx);
         d.mvCost2Nx2N[0] = det.mv_cost[0]; d.mvCost2Nx2N[1] = det.mv_cost[1];       /* bestME[0][list].mvCost (zero where the list was not searched) */
+        inter.sa8dBits = (uint32_t)bits;
+        if (searchOnly) return 0;
         x265amd_rd_cu rc1;
         memset(&rc1, 0, sizeof(rc1));
         rc1.x = (int16_t)x; rc1.y = (int16_t)y; rc1.log2_size = (uint8_t)log2;
@@ -413,7 +414,15 @@ struct Analyzer
         inter.sa8dBits = (uint32_t)bits;
         inter.distortion = ms.sa8d;
         inter.sa8dCost = calcRdSADCost(ms.sa8d, inter.sa8dBits);
-
+        return checkBidir(x, y, depth);
+    }
+    /* checkBidir2Nx2N (analysis.cpp:3145-3277) on what the 2Nx2N search left in Mode::bestME */
+    int checkBidir(int x, int y, int depth)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        Mode& bidir = d.pred[PRED_BIDIR];
+        const x265amd_me_detail& det = d.det;
         bidir.initCosts();
         bidir.sa8dCost = kMaxCost; bidir.rdCost = kMaxCost;
         if (!I->is_inter_b || det.cost[0] == 0xFFFFFFFFu || det.cost[1] == 0xFFFFFFFFu) return 0;
@@ -480,7 +489,7 @@ struct Analyzer
     }
 
     /* checkInter_rd0_4 for a two-part CU (rect / AMP): predInterSearch of both PUs, then the SA8D of the whole CU's prediction */
-    int checkInterPart(int x, int y, int depth, int part, int slot, const uint32_t refMasks[2])
+    int checkInterPart(int x, int y, int depth, int part, int slot, const uint32_t refMasks[2], bool searchOnly = false)
     {
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2, n4 = size >> 2;
@@ -517,12 +526,13 @@ struct Analyzer
                     }
                 }
         }
+        m.sa8dBits = (uint32_t)bits;
+        if (searchOnly) return 0;
         x265amd_rd_cu rc1;
         memset(&rc1, 0, sizeof(rc1));
         rc1.x = (int16_t)x; rc1.y = (int16_t)y; rc1.log2_size = (uint8_t)log2;
         x265amd_cu_measure ms;
         if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &rc1, 1, tileAddr(m.predTile), tileBytes, &ms) != X265AMD_OK) return err = X265AMD_EHIP;
-        m.sa8dBits = (uint32_t)bits;
         m.distortion = ms.sa8d;
         m.sa8dCost = calcRdSADCost(ms.sa8d, m.sa8dBits);
         return 0;
@@ -534,6 +544,221 @@ struct Analyzer
         uint32_t r = 0;
         for (int k = 0; k < nb[part]; k++) { const Geo g = pu_geo(0, 0, size, part, k); r |= bestRefIdx(m.u[(g.y >> 2) * n4 + (g.x >> 2)]); }
         return r;
+    }
+
+    /* checkMerge2Nx2N_rd5_6 (analysis.cpp:2883-3019): every merge candidate by RD, with residual until one codes without, and as a skip */
+    int checkMerge56(int x, int y, int depth)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        Mode* tempPred = &d.pred[PRED_MERGE];
+        Mode* bestPred = &d.pred[PRED_SKIP];
+        tempPred->initCosts(); bestPred->initCosts();
+        tempPred->predTile = predTile(depth, PRED_MERGE); tempPred->reconTile = reconTile(depth, PRED_MERGE);
+        bestPred->predTile = predTile(depth, PRED_SKIP); bestPred->reconTile = reconTile(depth, PRED_SKIP);
+        x265amd_merge_cand cand[5];
+        const int numCand = x265amd_merge_candidates(I, cur, col, x, y, log2, 0, 0, cand);
+        bool foundCbf0Merge = false, triedPZero = false, triedBZero = false;
+        bestPred->rdCost = kMaxCost;
+        const int16_t zero[2][2] = { { 0, 0 }, { 0, 0 } };
+        const uint8_t noIdx[2] = { 0, 0 };
+        for (int i = 0; i < numCand; i++)
+        {
+            const x265amd_merge_cand& c = cand[i];
+            const bool z0 = !c.mv[0][0] && !c.mv[0][1] && !c.ref_idx[0], z1 = !c.mv[1][0] && !c.mv[1][1] && !c.ref_idx[1];
+            if (c.dir == 1 && z0) { if (triedPZero) continue; triedPZero = true; }
+            else if (c.dir == 3 && z0 && z1) { if (triedBZero) continue; triedBZero = true; }
+            setInter(*tempPred, depth, 1, i, c.dir, c.ref_idx, c.mv, zero, noIdx);
+            {
+                std::vector<x265amd_mc_job> jobs;
+                jobs.push_back(mcJob(x, y, size, tempPred->predTile, c.dir, c.ref_idx, c.mv));
+                x265amd_cu_measure meas;
+                const int tiles[1] = { tempPred->predTile };
+                if (predictAndMeasure(jobs, x, y, log2, tiles, &meas)) return err;
+            }
+            bool hasCbf = true, swapped = false;
+            if (!foundCbf0Merge)
+            {
+                if (rdInter(*tempPred, x, y, depth, false)) return err;
+                hasCbf = tempPred->u[0].cbf[0] || tempPred->u[0].cbf[1] || tempPred->u[0].cbf[2];
+                foundCbf0Merge = !hasCbf;
+                if (tempPred->rdCost < bestPred->rdCost) { std::swap(tempPred, bestPred); swapped = true; }
+            }
+            if (hasCbf)
+            {
+                if (swapped)
+                {
+                    setInter(*tempPred, depth, 1, i, c.dir, c.ref_idx, c.mv, zero, noIdx);
+                    copyTile(tempPred->predTile, bestPred->predTile, 0, 0, size);
+                }
+                if (rdInter(*tempPred, x, y, depth, true)) return err;
+                if (tempPred->rdCost < bestPred->rdCost) std::swap(tempPred, bestPred);
+            }
+        }
+        if (bestPred->rdCost < kMaxCost) d.best = bestPred;
+        return 0;
+    }
+
+    /* compressInterCU_rd5_6 (analysis.cpp:1850-2417) without analysis reuse / CTU info / lossless / edge-based rskip */
+    int compress56(int x, int y, int depth, SplitData& splitOut)
+    {
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2;
+        d.best = nullptr;
+        const bool mightSplit = depth < si->max_cu_depth;
+        const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
+        bool skipModes = false, skipRecursion = false, splitIntra = true;
+        SplitData splitData[4];
+        memset(splitData, 0, sizeof(splitData));
+        d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
+        for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
+        d.pred[PRED_2Nx2N].rdCost = 0;
+        uint32_t allSplitRefs = 0;
+        auto rootCbf = [](const Mode& m) { return m.u[0].cbf[0] || m.u[0].cbf[1] || m.u[0].cbf[2]; };
+        auto interRd = [&](int part, int slot, uint32_t m0, uint32_t m1) -> int {          /* checkInter_rd5_6 + checkBestMode */
+            const uint32_t masks[2] = { m0, m1 };
+            if (part == 0 ? checkInter(x, y, depth, m0, true) : checkInterPart(x, y, depth, part, slot, masks, true)) return err;
+            if (rdInter(d.pred[slot], x, y, depth, false)) return err;
+            checkBestMode(d.pred[slot], depth);
+            return 0;
+        };
+        /* Step 1: merge / skip candidates and 2Nx2N */
+        if (mightNotSplit)
+        {
+            if (checkMerge56(x, y, depth)) return err;
+            skipModes = A->early_skip && d.best && !rootCbf(*d.best);
+            if (interRd(0, PRED_2Nx2N, allSplitRefs, 0)) return err;
+            if (A->rskip == 1 && depth && md[depth - 1].best) skipRecursion = d.best && !rootCbf(*d.best);
+        }
+        /* Step 2: the four sub-blocks in series */
+        if (mightSplit && !skipRecursion)
+        {
+            Mode& split = d.pred[PRED_SPLIT];
+            split.initCosts();
+            split.predTile = predTile(depth, PRED_SPLIT); split.reconTile = reconTile(depth, PRED_SPLIT);
+            const int n4 = 16 >> depth, half = size >> 1, h4n = n4 >> 1;
+            const Snap* nextContext = &d.cur;
+            splitIntra = false;
+            for (int q = 0; q < 4; q++)
+            {
+                const int cx = x + (q & 1) * half, cy = y + (q >> 1) * half;
+                if (cx < I->pic_width && cy < I->pic_height)
+                {
+                    md[depth + 1].cur = *nextContext;
+                    if (compress56(cx, cy, depth + 1, splitData[q])) return err;
+                    const Mode& nb = *md[depth + 1].best;
+                    splitIntra |= nb.u[0].pred_mode == X265AMD_MODE_INTRA;
+                    for (int yy = 0; yy < h4n; yy++)
+                        for (int xx = 0; xx < h4n; xx++)
+                        {
+                            split.u[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.u[yy * h4n + xx];
+                            split.m[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.m[yy * h4n + xx];
+                        }
+                    split.addSubCosts(nb);
+                    copyTile(split.reconTile, nb.reconTile, (q & 1) * half, (q >> 1) * half, half);
+                    const int nc = half * half;
+                    memcpy(&split.coeff[(size_t)q * nc], nb.coeff.data(), sizeof(int16_t) * nc);
+                    memcpy(&split.coeff[4096 + (size_t)q * nc / 4], nb.coeff.data() + 4096, sizeof(int16_t) * nc / 4);
+                    memcpy(&split.coeff[5120 + (size_t)q * nc / 4], nb.coeff.data() + 5120, sizeof(int16_t) * nc / 4);
+                    nextContext = &nb.contexts;
+                }
+                else
+                    for (int yy = 0; yy < h4n; yy++)            /* setEmptyPart */
+                        for (int xx = 0; xx < h4n; xx++) split.u[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx].depth = (uint8_t)(depth + 1);
+            }
+            split.contexts = *nextContext;
+            if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
+            else updateModeCost(split);
+        }
+        allSplitRefs = splitData[0].splitRefs | splitData[1].splitRefs | splitData[2].splitRefs | splitData[3].splitRefs;
+        /* Step 3: bi-prediction, rectangular / asymmetric partitions and intra at the current depth */
+        if (mightNotSplit)
+        {
+            if (!skipModes)
+            {
+                if (A->limit_refs & 2)
+                {
+                    allSplitRefs = bestRefIdx(d.pred[PRED_2Nx2N].u[0]);
+                    for (int q = 0; q < 4; q++) splitData[q].splitRefs = allSplitRefs;
+                }
+                if (I->is_inter_b)
+                {
+                    if (checkBidir(x, y, depth)) return err;
+                    Mode& bidir = d.pred[PRED_BIDIR];
+                    if (bidir.sa8dCost < kMaxCost)
+                    {
+                        if (rdInter(bidir, x, y, depth, false)) return err;
+                        checkBestMode(bidir, depth);
+                    }
+                }
+                const bool isP = !I->is_inter_b;
+                auto thr = [&](int a, int b) { return isP ? splitData[a].mvCost[0] + splitData[b].mvCost[0]
+                                                          : (splitData[a].mvCost[0] + splitData[b].mvCost[0] + splitData[a].mvCost[1] + splitData[b].mvCost[1] + 1) >> 1; };
+                const uint64_t splitCost = splitData[0].sa8dCost + splitData[1].sa8dCost + splitData[2].sa8dCost + splitData[3].sa8dCost;
+                const uint32_t top = splitData[0].splitRefs | splitData[1].splitRefs, bot = splitData[2].splitRefs | splitData[3].splitRefs;
+                const uint32_t lft = splitData[0].splitRefs | splitData[2].splitRefs, rgt = splitData[1].splitRefs | splitData[3].splitRefs;
+                if (A->rect)
+                {
+                    const uint32_t t2NxN = thr(0, 1), tNx2N = thr(0, 2);
+                    const bool first2NxN = t2NxN < tNx2N;
+                    if (first2NxN && splitCost < d.best->rdCost + t2NxN) { if (interRd(1, PRED_2NxN, top, bot)) return err; }
+                    if (splitCost < d.best->rdCost + tNx2N) { if (interRd(2, PRED_Nx2N, lft, rgt)) return err; }
+                    if (!first2NxN && splitCost < d.best->rdCost + t2NxN) { if (interRd(1, PRED_2NxN, top, bot)) return err; }
+                }
+                if ((A->rect || A->amp) && A->amp && si->max_amp_depth > depth)
+                {
+                    const uint32_t tU = thr(0, 1), tD = thr(2, 3), tL = thr(0, 2), tR = thr(1, 3);
+                    bool bHor = false, bVer = false;
+                    const int bp = d.best->u[0].part_size;
+                    if (bp == 1) bHor = true;
+                    else if (bp == 2) bVer = true;
+                    else if (bp == 0 && !d.best->u[0].merge_flag) { bHor = true; bVer = true; }
+                    if (bHor)
+                    {
+                        const bool firstD = tD < tU;
+                        if (firstD && splitCost < d.best->rdCost + tD) { if (interRd(5, PRED_2NxnD, allSplitRefs, bot)) return err; }
+                        if (splitCost < d.best->rdCost + tU) { if (interRd(4, PRED_2NxnU, top, allSplitRefs)) return err; }
+                        if (!firstD && splitCost < d.best->rdCost + tD) { if (interRd(5, PRED_2NxnD, allSplitRefs, bot)) return err; }
+                    }
+                    if (bVer)
+                    {
+                        const bool firstR = tR < tL;
+                        if (firstR && splitCost < d.best->rdCost + tR) { if (interRd(7, PRED_nRx2N, allSplitRefs, rgt)) return err; }
+                        if (splitCost < d.best->rdCost + tL) { if (interRd(6, PRED_nLx2N, lft, allSplitRefs)) return err; }
+                        if (!firstR && splitCost < d.best->rdCost + tR) { if (interRd(7, PRED_nRx2N, allSplitRefs, rgt)) return err; }
+                    }
+                }
+                if ((!I->is_inter_b || A->b_intra) && log2 != 6 && (!A->limit_refs || splitIntra))
+                {
+                    if (rdIntra(d.pred[PRED_INTRA], x, y, depth, PRED_INTRA, true, 0)) return err;
+                    checkBestMode(d.pred[PRED_INTRA], depth);
+                    if (log2 == 3 && si->tu_log2_min < 3)
+                    {
+                        if (rdIntra(d.pred[PRED_INTRA_NxN], x, y, depth, PRED_INTRA_NxN, true, 3)) return err;
+                        checkBestMode(d.pred[PRED_INTRA_NxN], depth);
+                    }
+                }
+            }
+            if (mightSplit) addSplitFlagCost(*d.best, x, y, depth);
+        }
+        if (mightSplit && !skipRecursion)
+        {
+            Mode& split = d.pred[PRED_SPLIT];
+            if (!d.best) d.best = &split;
+            else checkBestMode(split, depth);
+        }
+        memset(&splitOut, 0, sizeof(splitOut));
+        if (A->limit_refs & 1)
+            splitOut.splitRefs = d.best == &d.pred[PRED_SPLIT] ? allSplitRefs
+                                                                : bestRefIdxCu(d.best->u[0].pred_mode == X265AMD_MODE_INTRA ? d.pred[PRED_2Nx2N] : *d.best, depth);
+        if (A->limit_modes)
+        {
+            splitOut.mvCost[0] = d.mvCost2Nx2N[0]; splitOut.mvCost[1] = d.mvCost2Nx2N[1];
+            splitOut.sa8dCost = d.pred[PRED_2Nx2N].rdCost;
+        }
+        toPicture(*d.best, x, y, depth);
+        tileToPicture(d.best->reconTile, x, y, size);
+        return 0;
     }
 
     /* compressIntraCU (analysis.cpp:514-668) without analysis reuse / split-rd-skip */
@@ -784,8 +1009,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
-    if (A->rd_level < 3 || A->rd_level > 4 || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
-        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-4, no delta QP, rskip 0/1)");
+    if (A->rd_level < 3 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-6, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
     Analyzer* an = new Analyzer;
     Analyzer& a = *an;
@@ -820,7 +1045,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         memcpy(a.md[0].cur.ctx, ctx_in, X265AMD_CTX_COUNT);
         a.md[0].cur.frac = frac_in;
         SplitData topSplit;
-        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : a.compress(a.ctuX, a.ctuY, 0, topSplit);
+        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit));
         if (rc == X265AMD_OK && hipStreamSynchronize(a.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)
