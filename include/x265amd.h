@@ -629,7 +629,12 @@ int x265amd_inter_residual_rd(void* stream, const x265amd_slice_info* si, const 
  * p (1, 2) at 16384 + ((C - 2) * 2 + p - 1) * 1024; levels are TU blocks in raster TU order, residual / dump blocks sit at their position in
  * a stride-64 (luma) / stride-32 (chroma) tile.  The selection map (384 bytes per CU): for each luma 4x4 unit (row length 16), then each
  * chroma 4x4 unit of U and of V (row length 8), the layer whose residual block was kept, 0xFF for none. */
-typedef struct x265amd_cu_measure { uint64_t sse[3]; uint32_t psy, sa8d; } x265amd_cu_measure;     /* sse_pp per plane, luma psyCost, cu[].sa8d of Y + U + V */
+typedef struct x265amd_cu_measure
+{
+    uint64_t sse[3]; uint32_t psy, sa8d;    /* sse_pp per plane, luma psyCost, cu[].sa8d of Y + U + V */
+    uint32_t sa8d_luma;                     /* cu[].sa8d of Y alone (rd levels below 3 rank by luma) */
+    uint32_t src_mean, src_homo, reserved;  /* mean and mean absolute deviation of the SOURCE luma block (Analysis::complexityCheckCU) */
+} x265amd_cu_measure;                       /* 48 bytes */
 /* tile-vs-source measurement of n CUs (k_cu_measure without assembly): d_tiles as d_pred above; cus: only x, y, log2_size are read.  Synchronous. */
 int x265amd_measure_tiles(void* stream, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
                           uint64_t d_tiles, size_t tile_bytes, x265amd_cu_measure* out);
@@ -680,7 +685,7 @@ int x265amd_check_intra(void* stream, const x265amd_slice_info* si, const x265am
  * source/encoder/analysis.cpp:138-317, :1146-1848) with checkMerge2Nx2N_rd0_4 (:2750-2880), checkInter_rd0_4 (:3023-3085), checkBidir2Nx2N
  * (:3145-3277), topSkipMinDepth (:3428-3476), recursionDepthCheck (:3479-3534), addSplitFlagCost (:3405-3426).  Host recursion in the
  * reference's order over the batch entry points above; one CTU per call.
- * Built subset: I, P and B slices (b_intra 0 / 1), 2Nx2N / rect / amp partitions, limit_refs 0-3, limit_modes 0 / 1, no delta QP,
+ * Built subset: rd levels 2-6; I, P and B slices (b_intra 0 / 1), 2Nx2N / rect / amp partitions, limit_refs 0-3, limit_modes 0 / 1, no delta QP,
  * rd_level 3-4, rskip 0 / 1, early_skip 0 / 1.  Anything else is rejected with X265AMD_EINVAL. */
 typedef struct x265amd_analysis_params
 {

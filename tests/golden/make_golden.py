@@ -296,6 +296,13 @@ def make_frame_pipeline_golden():
     cli5 = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
     cli5[cli5.index("--rd") + 1] = "6"
     _frame_pipeline_one(frames, stride, cstride, org, "rd6_rectamp/", cli5 + ["--rect", "--amp", "--limit-modes"], out)
+    # rd 2 (SA8D mode choice, only the winner coded)
+    cli2 = list(clib)
+    cli2[cli2.index("--rd") + 1] = "2"
+    _frame_pipeline_one(framesb, stride, cstride, org, "rd2_bframes/", cli2 + ["--no-b-pyramid"], out, nframes=7)
+    cli2 = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
+    cli2[cli2.index("--rd") + 1] = "2"
+    _frame_pipeline_one(frames, stride, cstride, org, "rd2_rectamp/", cli2 + ["--rect", "--amp", "--limit-modes"], out)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
     print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 

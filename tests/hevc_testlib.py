@@ -2102,7 +2102,7 @@ def rd_run_ref(R, c):
     return res, uo, coeff, recon
 
 
-CU_MEASURE_DT = np.dtype([("sse", "<u8", 3), ("psy", "<u4"), ("sa8d", "<u4")])
+CU_MEASURE_DT = np.dtype([("sse", "<u8", 3), ("psy", "<u4"), ("sa8d", "<u4"), ("sa8d_luma", "<u4"), ("src_mean", "<u4"), ("src_homo", "<u4"), ("reserved", "<u4")])
 RD_SCRATCH_ELEMS = 4 * 4096 + 6 * 1024
 RD_SEL_BYTES = 384
 
@@ -2910,7 +2910,7 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
         si["max_num_merge_cand"], si["sign_hide"], si["max_cu_depth"], si["tu_log2_min"], si["tu_log2_max"] = 3, 1, 3, 2, 5
         si["tu_max_depth_inter"], si["tu_max_depth_intra"], si["wpp"] = 1, 1, int(wpp)
         ap = np.zeros(1, ANALYSIS_PARAMS_DT)
-        ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 3, 1, 1, 3, 1, 1
+        ap["psy_rd"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = 2.0, 1, 1, 3, 1, 1
         ap["use_sao"] = int(sao)
         ap["rect"], ap["amp"], ap["limit_modes"], ap["rd_level"] = rect, amp, limit_modes, rd_level
         si["max_amp_depth"] = 3 if amp else 0

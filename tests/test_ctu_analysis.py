@@ -17,7 +17,8 @@ CASES = [(8, 1, 1, 1, 2.0, 1, 0), (8, 2, 0, 1, 2.0, 2, 0), (8, 3, 1, 0, 0.0, 1, 
 PART_CASES = [(8, 21, 0, 1, 2.0, 3, 1, 0, 1, 0, 0), (8, 22, 0, 0, 2.0, 0, 0, 0, 1, 1, 0), (10, 23, 1, 1, 0.0, 3, 1, 1, 1, 1, 1), (8, 24, 0, 1, 1.0, 1, 0, 0, 1, 1, 1),
               (8, 25, 0, 0, 2.0, 2, 1, 0, 1, 1, 0), (8, 26, 0, 1, 2.0, 3, 0, 0, 1, 0, 1),
               (8, 31, 0, 1, 2.0, 3, 1, 1, 0, 0, 0, 5), (8, 32, 1, 0, 2.0, 0, 0, 0, 1, 1, 0, 6), (10, 33, 0, 1, 0.0, 1, 1, 0, 1, 1, 1, 5), (8, 34, 1, 1, 1.0, 3, 0, 0, 1, 0, 1, 6),
-              (8, 35, 0, 0, 2.0, 2, 1, 1, 1, 1, 0, 5)]
+              (8, 35, 0, 0, 2.0, 2, 1, 1, 1, 1, 0, 5),
+              (8, 41, 1, 1, 0.0, 3, 1, 1, 0, 0, 0, 2), (8, 42, 0, 1, 2.0, 0, 0, 0, 1, 1, 1, 2), (10, 43, 0, 0, 0.0, 1, 1, 0, 1, 0, 0, 2), (8, 44, 1, 0, 1.0, 2, 0, 0, 0, 0, 0, 2)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 

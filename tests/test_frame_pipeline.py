@@ -19,7 +19,7 @@ def test_golden_is_a_real_encode():
     assert all(len(g["slice/%d" % k]) > 20 for k in range(4))
 
 
-TAGS = ["", "deblock/", "wpp/", "bframes/", "sao/", "sao_bframes/", "rectamp_bframes/", "rectamp_lm/", "rd5_bframes/", "rd6_rectamp/"]
+TAGS = ["", "deblock/", "wpp/", "bframes/", "sao/", "sao_bframes/", "rectamp_bframes/", "rectamp_lm/", "rd5_bframes/", "rd6_rectamp/", "rd2_bframes/", "rd2_rectamp/"]
 
 
 def header_config(tag):
@@ -44,7 +44,7 @@ def test_hip_frame_pipeline_matches_reference_encoder(tag):
     "wpp/": deblocking and wavefront parallel processing on (per-row entropy states, one sub-stream per CTU row, entry points in the slice header);
     "bframes/": a 7-frame clip coded I P b b P b b (two lists, bi-prediction, collocated picture from list 1, non-referenced pictures), deblocking.
     "sao/", "sao_bframes/": the same clips with sample adaptive offset on (x265amd_sao_stats, x265amd_sao_rdo, x265amd_sao_apply, SAO syntax).
-    "rectamp_*": --rect --amp (and --limit-modes) on both clips.  "rd5_*", "rd6_*": --rd 5 / 6 (compressInterCU_rd5_6).
+    "rectamp_*": --rect --amp (and --limit-modes) on both clips.  "rd5_*", "rd6_*": --rd 5 / 6 (compressInterCU_rd5_6); "rd2_*": --rd 2.
     The slice NAL units (x265amd_write_slice_nal) behind the reference's parameter sets must give the reference's byte stream."""
     import hashlib
     g = np.load(GOLD_PATH)
@@ -53,8 +53,8 @@ def test_hip_frame_pipeline_matches_reference_encoder(tag):
     n = len(sched)
     got = T.frame_pipeline_run_hip(T.load_hip(8), me, [int(q) for q in g[tag + "slice_qp"]], nframes=n, deblock=bool(tag), wpp=tag == "wpp/", schedule=sched,
                                    frames=T.frame_clip_b(8) if "bframes" in tag else None, sao="sao" in tag,
-                                   rect=int("rectamp" in tag), amp=int("rectamp" in tag), limit_modes=int("_lm" in tag or "rd6" in tag),
-                                   rd_level=5 if "rd5" in tag else 6 if "rd6" in tag else 3)
+                                   rect=int("rectamp" in tag), amp=int("rectamp" in tag), limit_modes=int("_lm" in tag or "rd6" in tag or "rd2_rect" in tag),
+                                   rd_level=5 if "rd5" in tag else 6 if "rd6" in tag else 2 if "rd2" in tag else 3)
     for k, (poc, planes, data) in enumerate(got):
         for p in range(3):
             want = g[tag + "recon/%d/%d" % (poc, p)]

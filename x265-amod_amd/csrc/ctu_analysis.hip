@@ -66,7 +66,7 @@ struct Mode
     bool isSkipped() const { return u[0].pred_mode == X265AMD_MODE_SKIP; }
 };
 
-struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; uint32_t mvCost2Nx2N[2]; x265amd_me_detail det; };
+struct ModeDepth { Mode pred[NUM_PRED]; Mode* best; Snap cur; uint32_t mvCost2Nx2N[2]; x265amd_me_detail det; uint32_t srcMean, srcHomo; };
 
 struct DevBuf
 {
@@ -102,6 +102,9 @@ struct Analyzer
     uint32_t getCost(uint32_t b) const { return (uint32_t)(((uint64_t)b * lambda + 128) >> 8); }
     void updateModeCost(Mode& m) const { m.rdCost = psyRd ? calcPsyRdCost(m.distortion, m.totalBits, m.psyEnergy) : calcRdCost(m.distortion, m.totalBits); }
 
+    /* m_bChromaSa8d (analysis.cpp:707): SA8D ranking includes chroma from rd level 3 */
+    uint32_t sa8dOf(const x265amd_cu_measure& ms) const { return A->rd_level >= 3 ? ms.sa8d : ms.sa8d_luma; }
+
     int fail(const char* msg) { if (!err) err = xa_fail(X265AMD_EHIP, msg); return err; }
 
     /* ---- block operations ---- */
@@ -118,6 +121,27 @@ struct Analyzer
         j.mv0[0] = mv[0][0]; j.mv0[1] = mv[0][1]; j.mv1[0] = mv[1][0]; j.mv1[1] = mv[1][1];
         j.slice_type = (uint8_t)!I->is_inter_b; j.flags = 3;
         return j;
+    }
+    /* motionCompensation(luma + chroma) of every PU of an inter mode into its prediction tile (rd 2: the chosen mode's chroma was not predicted yet) */
+    int mcMode(Mode& m, int x, int y, int depth)
+    {
+        const int size = 64 >> depth, n4 = size >> 2, part = m.u[0].part_size;
+        static const uint8_t nb[8] = { 1, 2, 2, 4, 2, 2, 2, 2 };
+        std::vector<x265amd_mc_job> jobs;
+        for (int k = 0; k < nb[part]; k++)
+        {
+            const Geo g = pu_geo(0, 0, size, part, k);
+            const x265amd_mv_unit& v = m.m[(g.y >> 2) * n4 + (g.x >> 2)];
+            x265amd_mc_job j = mcJob(x, y, size, m.predTile, v.inter_dir, v.ref_idx, v.mv);
+            j.x = (int16_t)(x + g.x); j.y = (int16_t)(y + g.y); j.w = (uint8_t)g.w; j.h = (uint8_t)g.h;
+            j.dst_y += (size_t)(g.y * 64 + g.x) * sizeof(pixel);
+            j.dst_u += (size_t)((g.y >> 1) * 32 + (g.x >> 1)) * sizeof(pixel); j.dst_v += (size_t)((g.y >> 1) * 32 + (g.x >> 1)) * sizeof(pixel);
+            jobs.push_back(j);
+        }
+        if (hipMemcpyAsync(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess) return fail("ctu analysis: job upload");
+        if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, (int)jobs.size()) != X265AMD_OK)
+            return err = X265AMD_EHIP;
+        return 0;
     }
     /* motionCompensation(luma + chroma) of the jobs into their tiles, then sa8d / sse / psy of each tile against the source */
     int predictAndMeasure(std::vector<x265amd_mc_job>& jobs, int x, int y, int log2, const int* tiles, x265amd_cu_measure* meas)
@@ -319,6 +343,7 @@ struct Analyzer
         const x265amd_cu_unit* l = (x >> 2) > 0 ? &units[(y >> 2) * w4 + (x >> 2) - 1] : nullptr;
         const x265amd_cu_unit* a = (y >> 2) > 0 ? &units[((y >> 2) - 1) * w4 + (x >> 2)] : nullptr;
         const int c = (l && l->pred_mode != X265AMD_MODE_NONE && l->depth > depth) + (a && a->pred_mode != X265AMD_MODE_NONE && a->depth > depth);
+        if (A->rd_level == 2) { m.totalBits++; updateModeCost(m); return; }
         const uint32_t flag = m.u[0].depth > depth;
         m.contexts.frac &= 32767;
         const uint8_t state = m.contexts.ctx[C_SPLIT + c];
@@ -358,10 +383,11 @@ struct Analyzer
         for (int i = 0; i < numCand; i++)
         {
             const uint32_t bits = (uint32_t)(i + (i < numCand - 1));          /* getTUBits */
-            const uint64_t c = calcRdSADCost(meas[i].sa8d, bits);
+            const uint64_t c = calcRdSADCost(sa8dOf(meas[i]), bits);
             if (c < bestCost) { bestCost = c; bestBits = bits; bestSadCand = i; }
         }
         if (bestSadCand < 0) return 0;
+        d.srcMean = meas[0].src_mean; d.srcHomo = meas[0].src_homo;
         const x265amd_merge_cand& b = cand[bestSadCand];
         const int16_t zero[2][2] = { { 0, 0 }, { 0, 0 } };
         const uint8_t noIdx[2] = { 0, 0 };
@@ -398,7 +424,7 @@ struct Analyzer
         int32_t bits = 0;
         x265amd_me_detail& det = d.det;
         x265amd_inter_search_params sp = *S;
-        sp.qp = qp; sp.chroma_mc = 1;
+        sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         const uint32_t masks[2] = { refMask, 0 };
         int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(inter.predTile), tileBytes, &det, masks);
         if (rc != X265AMD_OK) return err = rc;
@@ -412,8 +438,8 @@ struct Analyzer
         x265amd_cu_measure ms;
         if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &rc1, 1, tileAddr(inter.predTile), tileBytes, &ms) != X265AMD_OK) return err = X265AMD_EHIP;
         inter.sa8dBits = (uint32_t)bits;
-        inter.distortion = ms.sa8d;
-        inter.sa8dCost = calcRdSADCost(ms.sa8d, inter.sa8dBits);
+        inter.distortion = sa8dOf(ms);
+        inter.sa8dCost = calcRdSADCost(sa8dOf(ms), inter.sa8dBits);
         return checkBidir(x, y, depth);
     }
     /* checkBidir2Nx2N (analysis.cpp:3145-3277) on what the 2Nx2N search left in Mode::bestME */
@@ -450,7 +476,7 @@ struct Analyzer
         if (predictAndMeasure(jobs, x, y, log2, tiles, meas)) return err;
         const uint32_t* ls = det.list_sel_bits;
         bidir.sa8dBits = det.bits[0] + det.bits[1] + ls[2] - (ls[0] + ls[1]);
-        bidir.sa8dCost = (uint64_t)meas[0].sa8d + getCost(bidir.sa8dBits);
+        bidir.sa8dCost = (uint64_t)sa8dOf(meas[0]) + getCost(bidir.sa8dBits);
         bool zeroWins = false;
         if (bTryZero)
         {
@@ -466,7 +492,7 @@ struct Analyzer
                 mvp[l] = am[mvpIdx[l]];
             }
             const uint32_t zbits = bits0 + bits1 + ls[2] - (ls[0] + ls[1]);
-            const uint32_t zcost = meas[1].sa8d + getCost(zbits);
+            const uint32_t zcost = sa8dOf(meas[1]) + getCost(zbits);
             if (zcost < bidir.sa8dCost)
             {
                 bidir.sa8dBits = zbits; bidir.sa8dCost = zcost;
@@ -502,7 +528,7 @@ struct Analyzer
         x265amd_pu_result pu[2];
         int32_t bits = 0;
         x265amd_inter_search_params sp = *S;
-        sp.qp = qp; sp.chroma_mc = 1;
+        sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(m.predTile), tileBytes, nullptr, refMasks);
         if (rc != X265AMD_OK) return err = rc;
         for (int i = 0; i < n4 * n4; i++) { m.u[i].pred_mode = X265AMD_MODE_INTER; m.u[i].part_size = (uint8_t)part; }
@@ -533,8 +559,8 @@ struct Analyzer
         rc1.x = (int16_t)x; rc1.y = (int16_t)y; rc1.log2_size = (uint8_t)log2;
         x265amd_cu_measure ms;
         if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &rc1, 1, tileAddr(m.predTile), tileBytes, &ms) != X265AMD_OK) return err = X265AMD_EHIP;
-        m.distortion = ms.sa8d;
-        m.sa8dCost = calcRdSADCost(ms.sa8d, m.sa8dBits);
+        m.distortion = sa8dOf(ms);
+        m.sa8dCost = calcRdSADCost(sa8dOf(ms), m.sa8dBits);
         return 0;
     }
     uint32_t bestRefIdxCu(const Mode& m, int depth) const       /* OR of getBestRefIdx over the CU's PUs */
@@ -848,8 +874,13 @@ struct Analyzer
         if (d.best && A->rskip)
         {
             skipRecursion = d.best->isSkipped();
-            if (mightSplit && !skipRecursion && (uint32_t)depth >= minDepth && A->rskip == 1 && depth)
-                skipRecursion = recursionDepthCheck(depth, *d.best);
+            if (mightSplit && !skipRecursion && (uint32_t)depth >= minDepth && A->rskip == 1)
+            {
+                if (depth) skipRecursion = recursionDepthCheck(depth, *d.best);
+                /* complexityCheckCU on HD pictures at rd 2 (analysis.cpp:1326, :3538-3559) */
+                if (I->pic_width * I->pic_height >= 1280 * 720 && !skipRecursion && A->rd_level == 2 && size != 64)
+                    skipRecursion = (double)d.srcHomo < (.1 * d.srcMean);
+            }
         }
         /* Step 2: the four sub-blocks in series */
         if (mightSplit && !skipRecursion)
@@ -952,19 +983,44 @@ struct Analyzer
                         }
                     }
                 }
-                if (rdInter(*bestInter, x, y, depth, false)) return err;
-                checkBestMode(*bestInter, depth);
-                if (I->is_inter_b && bidir.sa8dCost != kMaxCost && bidir.sa8dCost * 16 <= bestInter->sa8dCost * 17)
-                {
-                    if (rdInter(bidir, x, y, depth, false)) return err;
-                    checkBestMode(bidir, depth);
-                }
                 const bool bTryIntra = (!I->is_inter_b || A->b_intra) && log2 != 6;
-                const x265amd_cu_unit& b0 = d.best->u[0];
-                if (bTryIntra && (b0.cbf[0] || b0.cbf[1] || b0.cbf[2]) && (!A->limit_refs || splitIntra))
+                if (A->rd_level >= 3)
                 {
-                    if (rdIntra(d.pred[PRED_INTRA], x, y, depth)) return err;
-                    checkBestMode(d.pred[PRED_INTRA], depth);
+                    if (rdInter(*bestInter, x, y, depth, false)) return err;
+                    checkBestMode(*bestInter, depth);
+                    if (I->is_inter_b && bidir.sa8dCost != kMaxCost && bidir.sa8dCost * 16 <= bestInter->sa8dCost * 17)
+                    {
+                        if (rdInter(bidir, x, y, depth, false)) return err;
+                        checkBestMode(bidir, depth);
+                    }
+                    const x265amd_cu_unit& b0 = d.best->u[0];
+                    if (bTryIntra && (b0.cbf[0] || b0.cbf[1] || b0.cbf[2]) && (!A->limit_refs || splitIntra))
+                    {
+                        if (rdIntra(d.pred[PRED_INTRA], x, y, depth)) return err;
+                        checkBestMode(d.pred[PRED_INTRA], depth);
+                    }
+                }
+                else
+                {
+                    /* rd 2 (analysis.cpp:1655-1703): SA8D choice between merge / skip, inter, bidir and intra; only the winner is coded */
+                    if (!d.best || bestInter->sa8dCost < d.best->sa8dCost) d.best = bestInter;
+                    if (I->is_inter_b && bidir.sa8dCost < d.best->sa8dCost) d.best = &bidir;
+                    bool intraCoded = false;
+                    if ((bTryIntra || d.best->sa8dCost == kMaxCost) && (!A->limit_refs || splitIntra))
+                    {
+                        /* checkIntraInInter ranks by SA8D; encodeIntraInInter's result is kept only if intra wins (it has no side effects) */
+                        if (rdIntra(d.pred[PRED_INTRA], x, y, depth)) return err;
+                        if (d.pred[PRED_INTRA].sa8dCost < d.best->sa8dCost) { d.best = &d.pred[PRED_INTRA]; intraCoded = true; }
+                    }
+                    const x265amd_cu_unit& b0 = d.best->u[0];
+                    const bool codedMerge = (d.best == &d.pred[PRED_MERGE] || d.best == &d.pred[PRED_SKIP]) && b0.part_size == 0;
+                    if (!codedMerge && !intraCoded)
+                    {
+                        const uint64_t sa8dCost = d.best->sa8dCost; const uint32_t sa8dBits = d.best->sa8dBits;
+                        if (mcMode(*d.best, x, y, depth)) return err;
+                        if (rdInter(*d.best, x, y, depth, false)) return err;
+                        d.best->sa8dCost = sa8dCost; d.best->sa8dBits = sa8dBits;
+                    }
                 }
             }
             if (mightSplit) addSplitFlagCost(*d.best, x, y, depth);
@@ -1009,8 +1065,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
-    if (A->rd_level < 3 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
-        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 3-6, no delta QP, rskip 0/1)");
+    if (A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 2-6, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
     Analyzer* an = new Analyzer;
     Analyzer& a = *an;

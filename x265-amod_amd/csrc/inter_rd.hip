@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int
     const uint8_t* sel = reinterpret_cast<const uint8_t*>(j.sel);
     const int16_t* resi = reinterpret_cast<const int16_t*>(j.resi);
     CuMeasure m;
-    m.psy = 0; m.sa8d = 0;
+    m.psy = 0; m.sa8d = 0; m.sa8d_luma = 0; m.src_mean = 0; m.src_homo = 0; m.reserved = 0;
     for (int plane = 0; plane < 3; plane++)
     {
         const int log2S = plane ? j.log2_size - 1 : j.log2_size, s = 1 << log2S, ts = plane ? 32 : 64;
@@ -79,6 +79,16 @@ __global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int
         m.sse[plane] = wave_sse_pp(f, fs, tile, ts, s, lane);
         if (!plane) m.psy = (uint32_t)wave_psy_cost(f, fs, tile, ts, j.log2_size - 2, lane);
         m.sa8d += (uint32_t)xa_wave_sa8d(f, fs, tile, ts, s, lane);
+        if (!plane)
+        {
+            m.sa8d_luma = m.sa8d;
+            uint32_t sum = 0;                                   /* complexityCheckCU (analysis.cpp:3538-3559): mean, then mean |sample - mean| */
+            for (int i = lane; i < s * s; i += XA_WAVE) sum += f[(i >> log2S) * fs + (i & (s - 1))];
+            const uint32_t mean = (uint32_t)xa_wave_sum((int)sum) / (uint32_t)(s * s);
+            uint32_t dev = 0;
+            for (int i = lane; i < s * s; i += XA_WAVE) { const int v = (int)f[(i >> log2S) * fs + (i & (s - 1))] - (int)mean; dev += (uint32_t)(v < 0 ? -v : v); }
+            m.src_mean = mean; m.src_homo = (uint32_t)xa_wave_sum((int)dev) / (uint32_t)(s * s); m.reserved = 0;
+        }
         __syncthreads();
     }
     if (lane == 0) out[ji] = m;
