@@ -877,8 +877,8 @@ struct Analyzer
             if (mightSplit && !skipRecursion && (uint32_t)depth >= minDepth && A->rskip == 1)
             {
                 if (depth) skipRecursion = recursionDepthCheck(depth, *d.best);
-                /* complexityCheckCU on HD pictures at rd 2 (analysis.cpp:1326, :3538-3559) */
-                if (I->pic_width * I->pic_height >= 1280 * 720 && !skipRecursion && A->rd_level == 2 && size != 64)
+                /* complexityCheckCU on HD pictures (m_bHD: sourceHeight >= 1080, analysis.cpp:116) at rd 2 (analysis.cpp:1326, :3538-3559) */
+                if (I->pic_height >= 1080 && !skipRecursion && A->rd_level == 2 && size != 64)
                     skipRecursion = (double)d.srcHomo < (.1 * d.srcMean);
             }
         }
