@@ -1,0 +1,69 @@
+/* x265amd_encoder.h -- the OUTER drop-in boundary: the encoder object behind the reference's public API (reference: source/x265.h,
+ * `x265_encoder_open` :2412, `x265_encoder_headers` :2427, `x265_encoder_encode` :2437, `x265_encoder_close` :2471, struct x265_api
+ * :2561-2614; implementation source/encoder/api.cpp:96-600, encoder.cpp `Encoder::encode`, dpb.cpp `DPB::prepareEncode`,
+ * slicetype.cpp `Lookahead::slicetypeDecide`, ratecontrol.cpp CQP branch).
+ *
+ * One process per GPU; every picture of the encode lives in device memory from the moment it is handed in.  The host loop below the
+ * API is C++ (csrc/encoder_api.hip): mini-GOP formation, decoded picture buffer and reference picture sets, reference lists, slice QPs,
+ * per-frame calls into the frame pipeline (x265amd_analyse_frame, deblocking, SAO, border extension, slice NAL) and the stream headers.
+ *
+ * Built subset (everything else is rejected by x265amd_encoder_open with NULL + x265amd_last_error): 4:2:0, bit depth of the library,
+ * constant QP (rc.rateControlMode = X265_RC_CQP), fixed mini-GOPs (bFrameAdaptive 0, no scenecut, no B-pyramid, closed GOPs), no AQ /
+ * cutree / weighted prediction, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
+ * is the reference encoder's (tests/test_encoder_api.py compares whole streams with the reference command line program's). */
+#ifndef X265AMD_ENCODER_H
+#define X265AMD_ENCODER_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* the fields of x265_param (x265.h:1034-2275) the built subset reads, under the reference's names */
+typedef struct x265amd_param
+{
+    int32_t sourceWidth, sourceHeight;      /* luma samples; multiples of 8 */
+    uint32_t fpsNum, fpsDenom;
+    int32_t bframes;                        /* consecutive B frames of a mini-GOP (0..16); bFrameAdaptive is 0 */
+    int32_t keyframeMax;                    /* IDR interval (closed GOP) */
+    int32_t maxNumReferences;               /* --ref */
+    int32_t qp;                             /* rc.qp (CQP) */
+    double ipFactor, pbFactor;              /* rc.ipFactor / rc.pbFactor: QP offsets of I and B slices */
+    int32_t rdLevel;                        /* 2..6 */
+    int32_t bEnableRectInter, bEnableAMP, limitModes, limitReferences;
+    int32_t bEnableEarlySkip, recursionSkipMode, bIntraInBFrames;
+    double psyRd;
+    int32_t searchMethod, subpelRefine, searchRange;       /* X265AMD_ME_* (dia / hex / star), subme, merange */
+    int32_t maxNumMergeCand;
+    int32_t bEnableSignHiding, bEnableStrongIntraSmoothing, bEnableTemporalMvp;
+    int32_t tuQTMaxInterDepth, tuQTMaxIntraDepth;
+    int32_t bEnableLoopFilter, bEnableSAO, bEnableWavefront;
+    int32_t aspectRatioIdc;                 /* vui.aspectRatioIdc (1 = square samples; 0 = not signalled) */
+    int32_t reserved[7];
+} x265amd_param;
+
+/* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */
+void x265amd_param_default(x265amd_param* p);
+
+typedef struct x265amd_nal { uint32_t type; uint32_t sizeBytes; uint8_t* payload; } x265amd_nal;      /* x265_nal (x265.h:94-99) */
+typedef struct x265amd_picture                                                                        /* the used part of x265_picture (x265.h:397-490) */
+{
+    void* planes[3];            /* host pointers: Y, U, V (8-bit samples for the 8-bit library, 16-bit little endian otherwise) */
+    int32_t stride[3];          /* bytes */
+    int32_t poc, sliceType;     /* filled on output: display order count, X265_TYPE_* (1 IDR, 3 P, 5 B) */
+    int32_t qp;                 /* filled on output: the slice QP */
+} x265amd_picture;
+
+typedef struct x265amd_encoder x265amd_encoder;
+x265amd_encoder* x265amd_encoder_open(const x265amd_param* p);
+/* VPS, SPS, PPS; the array and payloads stay valid until the next call on this encoder.  Returns the total payload size or -1. */
+int x265amd_encoder_headers(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t* pi_nal);
+/* pic_in == NULL flushes.  Returns 1 when a coded picture was emitted (its NAL units in *pp_nal, its reconstruction copied to
+ * pic_out's planes when pic_out is given), 0 when none is ready yet (or the flush is complete), -1 on error. */
+int x265amd_encoder_encode(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t* pi_nal, const x265amd_picture* pic_in, x265amd_picture* pic_out);
+void x265amd_encoder_close(x265amd_encoder* enc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

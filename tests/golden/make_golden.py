@@ -303,6 +303,13 @@ def make_frame_pipeline_golden():
     cli2 = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
     cli2[cli2.index("--rd") + 1] = "2"
     _frame_pipeline_one(frames, stride, cstride, org, "rd2_rectamp/", cli2 + ["--rect", "--amp", "--limit-modes"], out)
+    # mini-GOP / keyframe logic of the encoder object (tests/test_encoder_api.py): 3 B frames with a short last mini-GOP; IDR every 4 frames
+    cli3 = list(clib)
+    cli3[cli3.index("--bframes") + 1] = "3"
+    _frame_pipeline_one(framesb, stride, cstride, org, "bframes3/", cli3 + ["--no-b-pyramid"], out, nframes=7)
+    clik = list(clib)
+    clik[clik.index("--keyint") + 1] = "4"
+    _frame_pipeline_one(framesb, stride, cstride, org, "keyint/", clik + ["--no-b-pyramid", "--min-keyint", "4"], out, nframes=7)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz"), **out)
     print("wrote frame_pipeline_golden.npz:", [[len(out[t + "slice/%d" % i]) for i in range(4)] for t in ("", "deblock/", "wpp/")])
 

@@ -2974,3 +2974,82 @@ def frame_pipeline_run_hip(L, me, slice_qps, nframes=4, depth=8, deblock=False, 
             dpb.append(poc)
         out.append((poc, frame_planes(rec, stride, cstride, org), nal[:n].copy()))
     return out
+
+
+# ---- the encoder object (include/x265amd_encoder.h): x265_encoder_open / headers / encode / close over the frame pipeline ----
+class EncParam(C.Structure):
+    _fields_ = [("sourceWidth", C.c_int32), ("sourceHeight", C.c_int32), ("fpsNum", C.c_uint32), ("fpsDenom", C.c_uint32), ("bframes", C.c_int32),
+                ("keyframeMax", C.c_int32), ("maxNumReferences", C.c_int32), ("qp", C.c_int32), ("ipFactor", C.c_double), ("pbFactor", C.c_double),
+                ("rdLevel", C.c_int32), ("bEnableRectInter", C.c_int32), ("bEnableAMP", C.c_int32), ("limitModes", C.c_int32), ("limitReferences", C.c_int32),
+                ("bEnableEarlySkip", C.c_int32), ("recursionSkipMode", C.c_int32), ("bIntraInBFrames", C.c_int32), ("psyRd", C.c_double),
+                ("searchMethod", C.c_int32), ("subpelRefine", C.c_int32), ("searchRange", C.c_int32), ("maxNumMergeCand", C.c_int32),
+                ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
+                ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
+                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class EncNal(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("sizeBytes", C.c_uint32), ("payload", C.POINTER(C.c_uint8))]
+
+
+class EncPicture(C.Structure):
+    _fields_ = [("planes", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("poc", C.c_int32), ("sliceType", C.c_int32), ("qp", C.c_int32)]
+
+
+def encoder_run(L, planes_per_frame, width, height, **overrides):
+    """x265amd_encoder_open -> headers -> encode every frame -> flush -> close.  planes_per_frame: per frame (Y, U, V) arrays in display order.
+    Returns (whole byte stream, [(poc, slice type, qp, recon planes)] in coding order)"""
+    lib = L.lib
+    lib.x265amd_encoder_open.restype = C.c_void_p
+    lib.x265amd_encoder_open.argtypes = [C.POINTER(EncParam)]
+    lib.x265amd_encoder_headers.argtypes = [C.c_void_p, C.POINTER(C.POINTER(EncNal)), C.POINTER(C.c_uint32)]
+    lib.x265amd_encoder_encode.argtypes = [C.c_void_p, C.POINTER(C.POINTER(EncNal)), C.POINTER(C.c_uint32), C.POINTER(EncPicture), C.POINTER(EncPicture)]
+    lib.x265amd_encoder_close.argtypes = [C.c_void_p]
+    lib.x265amd_param_default.argtypes = [C.POINTER(EncParam)]
+    lib.x265amd_last_error.restype = C.c_char_p
+    prm = EncParam()
+    lib.x265amd_param_default(C.byref(prm))
+    prm.sourceWidth, prm.sourceHeight = width, height
+    for k, v in overrides.items():
+        assert hasattr(prm, k), k
+        setattr(prm, k, v)
+    enc = lib.x265amd_encoder_open(C.byref(prm))
+    assert enc, lib.x265amd_last_error()
+    stream = bytearray()
+    nal = C.POINTER(EncNal)(); nnal = C.c_uint32(0)
+    assert lib.x265amd_encoder_headers(enc, C.byref(nal), C.byref(nnal)) > 0
+    for i in range(nnal.value):
+        stream += bytes(nal[i].payload[:nal[i].sizeBytes])
+    dt = planes_per_frame[0][0].dtype
+    coded = []
+
+    def take(ret, out, bufs):
+        assert ret >= 0, lib.x265amd_last_error()
+        if ret:
+            for i in range(nnal.value):
+                stream.extend(bytes(nal[i].payload[:nal[i].sizeBytes]))
+            coded.append((out.poc, out.sliceType, out.qp, [b.copy() for b in bufs]))
+        return ret
+
+    def out_picture():
+        bufs = [np.zeros((height, width), dt), np.zeros((height // 2, width // 2), dt), np.zeros((height // 2, width // 2), dt)]
+        out = EncPicture()
+        for k in range(3):
+            out.planes[k] = bufs[k].ctypes.data; out.stride[k] = bufs[k].strides[0]
+        return out, bufs
+
+    try:
+        for planes in planes_per_frame:
+            pic = EncPicture()
+            keep = [np.ascontiguousarray(pl) for pl in planes]
+            for k in range(3):
+                pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
+            out, bufs = out_picture()
+            take(lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), C.byref(pic), C.byref(out)), out, bufs)
+        while True:
+            out, bufs = out_picture()
+            if not take(lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), None, C.byref(out)), out, bufs):
+                break
+    finally:
+        lib.x265amd_encoder_close(enc)
+    return np.frombuffer(bytes(stream), np.uint8), coded

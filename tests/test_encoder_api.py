@@ -1,0 +1,64 @@
+"""The encoder object (include/x265amd_encoder.h: x265amd_encoder_open / headers / encode / close -- the x265_api entry points of the
+reference, source/x265.h:2412-2471) end to end against the reference ENCODER: source frames in, byte stream out.  Unlike
+tests/test_frame_pipeline.py nothing is taken from the golden data but the expected bytes: frame types, coding order, slice QPs, reference
+picture sets and lists, parameter sets and slice headers are all derived by the C++ host loop (csrc/encoder_api.hip)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import hevc_testlib as T
+
+GOLD_PATH = os.path.join(T.GOLDEN_DIR, "frame_pipeline_golden.npz")
+
+# tag of the reference command line in tests/golden/make_golden.py -> x265amd_param fields that differ from x265amd_param_default
+BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=0, bEnableWavefront=0)
+CONFIGS = {
+    "": dict(BASE, bEnableLoopFilter=0),
+    "deblock/": dict(BASE),
+    "wpp/": dict(BASE, bEnableWavefront=1),
+    "sao/": dict(BASE, bEnableSAO=1),
+    "bframes/": dict(BASE, bframes=2),
+    "sao_bframes/": dict(BASE, bframes=2, bEnableSAO=1),
+    "rectamp_bframes/": dict(BASE, bframes=2, bEnableRectInter=1, bEnableAMP=1),
+    "rectamp_lm/": dict(BASE, bEnableRectInter=1, bEnableAMP=1, limitModes=1),
+    "rd5_bframes/": dict(BASE, bframes=2, rdLevel=5),
+    "rd6_rectamp/": dict(BASE, rdLevel=6, bEnableRectInter=1, bEnableAMP=1, limitModes=1),
+    "rd2_bframes/": dict(BASE, bframes=2, rdLevel=2),
+    "rd2_rectamp/": dict(BASE, rdLevel=2, bEnableRectInter=1, bEnableAMP=1, limitModes=1),
+    "bframes3/": dict(BASE, bframes=3),
+    "keyint/": dict(BASE, bframes=2, keyframeMax=4),
+}
+
+
+def display_frames(tag):
+    """the clip of the golden encode as (Y, U, V) planes per frame in display order"""
+    if "bframes" in tag or tag == "keyint/":
+        frames, stride, cstride, org = T.frame_clip_b(8)
+    else:
+        frames, stride, cstride, org = T.frame_clip(8, 4)
+    return [T.frame_planes(f, stride, cstride, org) for f in frames]
+
+
+def test_param_struct_matches_header():
+    import ctypes
+    assert ctypes.sizeof(T.EncParam) == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(CONFIGS))
+def test_encoder_object_reproduces_reference_stream(tag):
+    g = np.load(GOLD_PATH)
+    frames = display_frames(tag)
+    stream, coded = T.encoder_run(T.load_hip(8), frames, T.MC_W, T.MC_H, **CONFIGS[tag])
+    want = g[tag + "stream"]
+    sched = g[tag + "schedule"]
+    # the log's POC column restarts at every IDR; the encoder object reports display order counts
+    order = [int(s[1]) for s in sched] if tag != "keyint/" else [0, 3, 1, 2, 4, 6, 5]
+    assert [c[0] for c in coded] == order, "coding order"
+    assert [c[2] for c in coded] == [int(q) for q in g[tag + "slice_qp"]], "slice QPs"
+    for (poc, _, _, planes) in coded:
+        for p in range(3):
+            assert np.array_equal(planes[p], g[tag + "recon/%d/%d" % (poc, p)]), "reconstruction of poc %d plane %d" % (poc, p)
+    assert len(stream) == len(want) and hashlib.md5(stream.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()

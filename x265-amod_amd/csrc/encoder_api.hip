@@ -1,0 +1,492 @@
+/* The encoder object behind include/x265amd_encoder.h: the frame-level host loop of the reference (SURVEY section 8b outer boundary and 8f rank 1),
+ * restated for a device-resident encode.  What it follows in the reference:
+ *   - mini-GOP formation with bFrameAdaptive 0:   Lookahead::slicetypeDecide        source/encoder/slicetype.cpp:1929-2040
+ *   - constant QP per slice type:                  RateControl::init / rateControlStart  source/encoder/ratecontrol.cpp:321-346, :1592-1597
+ *   - decoded picture buffer, RPS, NAL type:       DPB::prepareEncode / computeRPS / applyReferencePictureSet / decodingRefreshMarking /
+ *                                                  getNalUnitType                  source/encoder/dpb.cpp:134-330, :336-470, :487-510
+ *   - reference lists:                             Slice::setRefPicList            source/common/slice.cpp:32-140
+ *   - DPB sizes, level:                            Encoder::initVPS/initSPS, determineLevel   source/encoder/encoder.cpp:3340-3470, level.cpp:44-230, :290-300
+ *   - per frame: FrameEncoder::compressFrame (analysis rows, deblocking, SAO, border extension, slice NAL)   source/encoder/frameencoder.cpp:470-1130
+ * Pictures (source and reconstruction) are padded planes in device memory with the reference's PicYuv margins (maxCUSize + 32 / + 16). */
+#include <hip/hip_runtime.h>
+#include "x265amd.h"
+#include "x265amd_encoder.h"
+#include "x265amd_host.h"
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <deque>
+#include <memory>
+#include <vector>
+
+namespace {
+
+typedef x265amd_pixel pixel;
+enum { TYPE_IDR = 1, TYPE_P = 3, TYPE_B = 5 };          /* X265_TYPE_IDR / _P / _B (x265.h:255-261) */
+enum { RD_TILE_ELEMS = 4096 + 2 * 1024 };
+
+struct Pic
+{
+    int poc = 0, type = 0, sliceQp = 0;
+    bool hasReferences = false;
+    pixel* dSrc = nullptr; pixel* dRec = nullptr;       /* flat Y | U | V padded buffers */
+    std::vector<x265amd_cu_unit> units;
+    std::vector<x265amd_mv_unit> motion;
+    int32_t refPoc[2][16];
+    Pic() { memset(refPoc, 0, sizeof(refPoc)); }
+    ~Pic() { if (dSrc) (void)hipFree(dSrc); if (dRec) (void)hipFree(dRec); }
+};
+typedef std::shared_ptr<Pic> PicP;
+
+}
+
+struct x265amd_encoder
+{
+    x265amd_param p;
+    x265amd_me_ctx* me = nullptr;
+    int W = 0, H = 0, w4 = 0, h4 = 0, ctuW = 0, ctuH = 0, nctu = 0;
+    int marginX = 96, marginY = 80;
+    intptr_t stride = 0, cstride = 0;
+    size_t org[3] = { 0, 0, 0 }, picElems = 0;
+    int qpConstant[3] = { 0, 0, 0 };                    /* indexed by slice type 0 B, 1 P, 2 I */
+    int maxDecPicBuffering = 0, numReorderPics = 0;
+    int frameCount = 0, lastKeyframe = 0, lastIDR = 0;
+    bool first = true;
+    std::deque<PicP> input;                             /* display order, not yet typed */
+    std::deque<PicP> ready;                             /* coding order */
+    std::vector<PicP> picList;                          /* front = most recently coded (PicList::pushFront) */
+    double depthSaoRate[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    std::vector<uint8_t> headerBytes, outBytes;
+    std::vector<x265amd_nal> nals;
+    std::vector<pixel> staging;
+    int32_t* dSaoCount = nullptr; int32_t* dSaoOrg = nullptr; x265amd_sao_ctu* dSaoParams = nullptr; x265amd_deblock_unit* dDbUnits = nullptr;
+    pixel* dSaoTmp = nullptr;
+
+    ~x265amd_encoder()
+    {
+        if (me) x265amd_me_close(me);
+        if (dSaoCount) (void)hipFree(dSaoCount);
+        if (dSaoOrg) (void)hipFree(dSaoOrg);
+        if (dSaoParams) (void)hipFree(dSaoParams);
+        if (dDbUnits) (void)hipFree(dDbUnits);
+        if (dSaoTmp) (void)hipFree(dSaoTmp);
+    }
+    uint64_t planeAddr(const pixel* base, int k) const { return (uint64_t)(uintptr_t)(base + org[k]); }
+
+    void fillStreamParams(x265amd_stream_params& s) const;
+    int uploadPicture(const x265amd_picture* in, Pic& pic);
+    void decideMiniGop(bool flush);
+    int encodeOne(Pic& pic, x265amd_picture* picOut);
+};
+
+/* ---- configuration ---- */
+extern "C" void x265amd_param_default(x265amd_param* p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->fpsNum = 25; p->fpsDenom = 1;
+    p->bframes = 0; p->keyframeMax = 250; p->maxNumReferences = 3; p->qp = 30; p->ipFactor = 1.4; p->pbFactor = 1.3;
+    p->rdLevel = 3; p->limitReferences = 3; p->bEnableEarlySkip = 1; p->recursionSkipMode = 1; p->bIntraInBFrames = 1; p->psyRd = 2.0;
+    p->searchMethod = X265AMD_ME_HEX; p->subpelRefine = 2; p->searchRange = 57; p->maxNumMergeCand = 3;
+    p->bEnableSignHiding = 1; p->bEnableStrongIntraSmoothing = 1; p->bEnableTemporalMvp = 1; p->tuQTMaxInterDepth = 1; p->tuQTMaxIntraDepth = 1;
+    p->bEnableLoopFilter = 1; p->bEnableSAO = 1; p->bEnableWavefront = 1; p->aspectRatioIdc = 0;
+}
+
+void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
+{
+    memset(&s, 0, sizeof(s));
+    /* determineLevel (level.cpp:76-230): Main / Main 10, main tier, the lowest level that holds the picture size, rate and DPB */
+    static const struct { uint32_t maxLumaSamples, maxLumaSamplesPerSecond; int idc; } levels[] = {
+        { 36864, 552960, 30 }, { 122880, 3686400, 60 }, { 245760, 7372800, 63 }, { 552960, 16588800, 90 }, { 983040, 33177600, 93 },
+        { 2228224, 66846720, 120 }, { 2228224, 133693440, 123 }, { 8912896, 267386880, 150 }, { 8912896, 534773760, 153 },
+        { 8912896, 1069547520, 156 }, { 35651584, 1069547520, 180 }, { 35651584, 2139095040u, 183 }, { 35651584, 4278190080u, 186 } };
+    s.profile_idc = X265AMD_DEPTH <= 8 ? 1 : 2;
+    s.profile_compatibility_flags = X265AMD_DEPTH <= 8 ? (1u << 1) | (1u << 2) : (1u << 2);
+    s.progressive_source = 1; s.frame_only_constraint = 1;
+    s.bit_depth_constraint = X265AMD_DEPTH; s.chroma_format_constraint = 1; s.lower_bit_rate_constraint = 1;
+    s.intra_constraint = p.keyframeMax <= 1;
+    const uint32_t lumaSamples = (uint32_t)(W * H);
+    const uint32_t samplesPerSec = (uint32_t)(lumaSamples * ((double)p.fpsNum / p.fpsDenom));
+    s.level_idc = 255;
+    for (const auto& l : levels)
+    {
+        if (lumaSamples > l.maxLumaSamples || samplesPerSec > l.maxLumaSamplesPerSecond) continue;
+        if (W > sqrt(l.maxLumaSamples * 8.0f) || H > sqrt(l.maxLumaSamples * 8.0f)) continue;
+        uint32_t maxDpbSize = 6;
+        if (lumaSamples <= (l.maxLumaSamples >> 2)) maxDpbSize = 16;
+        else if (lumaSamples <= (l.maxLumaSamples >> 1)) maxDpbSize = 12;
+        else if (lumaSamples <= ((3 * l.maxLumaSamples) >> 2)) maxDpbSize = 8;
+        if ((uint32_t)maxDecPicBuffering > maxDpbSize) continue;
+        s.level_idc = l.idc;
+        break;
+    }
+    s.max_temporal_sub_layers = 1;
+    s.max_dec_pic_buffering[0] = maxDecPicBuffering; s.num_reorder_pics[0] = numReorderPics; s.max_latency_increase[0] = p.bframes;
+    s.chroma_format_idc = 1; s.pic_width = W; s.pic_height = H; s.bit_depth = X265AMD_DEPTH; s.log2_max_poc_lsb = 8;
+    s.log2_min_cu_size = 3; s.log2_diff_max_min_cu_size = 3; s.tu_log2_min = 2; s.tu_log2_max = 5;
+    s.tu_max_depth_inter = p.tuQTMaxInterDepth; s.tu_max_depth_intra = p.tuQTMaxIntraDepth;
+    s.amp = p.bEnableAMP != 0; s.sao = p.bEnableSAO != 0; s.temporal_mvp = p.bEnableTemporalMvp != 0; s.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0;
+    s.aspect_ratio_idc = p.aspectRatioIdc;
+    s.emit_timing_info = 1; s.num_units_in_tick = p.fpsDenom; s.time_scale = p.fpsNum;
+    s.sign_hide = p.bEnableSignHiding != 0; s.num_ref_idx_default[0] = s.num_ref_idx_default[1] = 1; s.init_qp_minus26 = 0;
+    s.wpp = p.bEnableWavefront != 0; s.loop_filter_across_slices = 1;
+    s.deblocking_filter_control_present = !p.bEnableLoopFilter; s.pic_disable_deblocking = !p.bEnableLoopFilter;
+}
+
+extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
+{
+    if (!p) { xa_fail(X265AMD_EINVAL, "encoder_open: null param"); return nullptr; }
+    if (p->sourceWidth < 16 || p->sourceHeight < 16 || (p->sourceWidth & 7) || (p->sourceHeight & 7) || p->sourceWidth > 8192 || p->sourceHeight > 4320)
+    { xa_fail(X265AMD_EINVAL, "encoder_open: picture size must be a multiple of 8 (16..8192 x 16..4320)"); return nullptr; }
+    if (!p->fpsNum || !p->fpsDenom || p->bframes < 0 || p->bframes > 16 || p->keyframeMax < 1 || p->maxNumReferences < 1 || p->maxNumReferences > 8 ||
+        p->qp < 0 || p->qp > 51 || p->rdLevel < 2 || p->rdLevel > 6 || p->maxNumMergeCand < 1 || p->maxNumMergeCand > 5 ||
+        p->tuQTMaxInterDepth < 1 || p->tuQTMaxInterDepth > 4 || p->tuQTMaxIntraDepth < 1 || p->tuQTMaxIntraDepth > 4 ||
+        (p->searchMethod != X265AMD_ME_DIA && p->searchMethod != X265AMD_ME_HEX && p->searchMethod != X265AMD_ME_STAR) || p->subpelRefine < 0 || p->subpelRefine > 7 ||
+        p->recursionSkipMode < 0 || p->recursionSkipMode > 1 || p->limitReferences < 0 || p->limitReferences > 3 || (p->bEnableAMP && !p->bEnableRectInter))
+    { xa_fail(X265AMD_EINVAL, "encoder_open: parameter outside the built subset (see x265amd_encoder.h)"); return nullptr; }
+    std::unique_ptr<x265amd_encoder> e(new x265amd_encoder);
+    e->p = *p;
+    e->W = p->sourceWidth; e->H = p->sourceHeight; e->w4 = e->W / 4; e->h4 = e->H / 4;
+    e->ctuW = (e->W + 63) / 64; e->ctuH = (e->H + 63) / 64; e->nctu = e->ctuW * e->ctuH;
+    e->stride = e->W + 2 * e->marginX; e->cstride = e->W / 2 + e->marginX;
+    const size_t ysz = (size_t)(e->H + 2 * e->marginY) * e->stride, csz = (size_t)(e->H / 2 + e->marginY) * e->cstride;
+    e->org[0] = (size_t)e->marginY * e->stride + e->marginX;
+    e->org[1] = ysz + (size_t)(e->marginY / 2) * e->cstride + e->marginX / 2;
+    e->org[2] = ysz + csz + (size_t)(e->marginY / 2) * e->cstride + e->marginX / 2;
+    e->picElems = ysz + 2 * csz;
+    /* RateControl (ratecontrol.cpp:321-346): constant QPs of the three slice types */
+    const double ipOffset = 6.0 * log2(p->ipFactor), pbOffset = 6.0 * log2(p->pbFactor);
+    auto clipQp = [](int q) { return q < 0 ? 0 : q > 69 ? 69 : q; };
+    e->qpConstant[1] = p->qp;
+    e->qpConstant[2] = clipQp((int)(p->qp - ipOffset + 0.5));
+    e->qpConstant[0] = clipQp((int)(p->qp + pbOffset + 0.5));
+    if (e->qpConstant[0] > 51 || e->qpConstant[2] > 51) { xa_fail(X265AMD_EINVAL, "encoder_open: slice QP above 51"); return nullptr; }
+    /* level.cpp:290-296 */
+    e->numReorderPics = p->bframes ? 1 : 0;
+    e->maxDecPicBuffering = std::min(16, std::max(e->numReorderPics + 2, p->maxNumReferences) + 1);
+    e->lastKeyframe = -p->keyframeMax;
+    e->me = x265amd_me_open();
+    if (!e->me) return nullptr;
+    const size_t nstat = (size_t)e->nctu * 3 * 5 * 32;
+    if (hipMalloc((void**)&e->dSaoCount, nstat * 4) != hipSuccess || hipMalloc((void**)&e->dSaoOrg, nstat * 4) != hipSuccess ||
+        hipMalloc((void**)&e->dSaoParams, sizeof(x265amd_sao_ctu) * e->nctu) != hipSuccess ||
+        hipMalloc((void**)&e->dDbUnits, sizeof(x265amd_deblock_unit) * e->w4 * e->h4) != hipSuccess ||
+        hipMalloc((void**)&e->dSaoTmp, e->picElems * sizeof(pixel)) != hipSuccess)
+    { xa_fail(X265AMD_EHIP, "encoder_open: device allocation"); return nullptr; }
+    x265amd_stream_params sp;
+    e->fillStreamParams(sp);
+    e->headerBytes.resize(512);
+    const size_t n = x265amd_write_stream_headers(&sp, e->headerBytes.data(), e->headerBytes.size());
+    if (!n || n > e->headerBytes.size()) { xa_fail(X265AMD_EINVAL, "encoder_open: stream headers"); return nullptr; }
+    e->headerBytes.resize(n);
+    return e.release();
+}
+
+extern "C" void x265amd_encoder_close(x265amd_encoder* e) { delete e; }
+
+/* splits a byte stream of NAL units behind 4-byte start codes into x265_nal records (payload includes the start code, as the reference's do) */
+static void splitNals(std::vector<uint8_t>& bytes, std::vector<x265amd_nal>& nals)
+{
+    nals.clear();
+    size_t start = 0;
+    for (size_t i = 4; i + 4 <= bytes.size() + 1; i++)
+    {
+        const bool sc = i + 4 <= bytes.size() && !bytes[i] && !bytes[i + 1] && !bytes[i + 2] && bytes[i + 3] == 1;
+        if (sc || i + 4 > bytes.size())
+        {
+            const size_t end = sc ? i : bytes.size();
+            x265amd_nal n;
+            n.type = (bytes[start + 4] >> 1) & 63; n.sizeBytes = (uint32_t)(end - start); n.payload = bytes.data() + start;
+            nals.push_back(n);
+            start = end;
+            if (!sc) break;
+        }
+    }
+}
+
+extern "C" int x265amd_encoder_headers(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal)
+{
+    if (!e || !ppNal || !piNal) return xa_fail(X265AMD_EINVAL, "encoder_headers: null argument");
+    e->outBytes = e->headerBytes;
+    splitNals(e->outBytes, e->nals);
+    *ppNal = e->nals.data(); *piNal = (uint32_t)e->nals.size();
+    return (int)e->outBytes.size();
+}
+
+/* ---- pictures ---- */
+int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic)
+{
+    /* the picture area of each plane with its margins filled by edge replication (PicYuv::copyFromPicture pads, extendPicBorder) */
+    staging.assign(picElems, 0);
+    for (int k = 0; k < 3; k++)
+    {
+        const int w = k ? W / 2 : W, h = k ? H / 2 : H, mx = k ? marginX / 2 : marginX, my = k ? marginY / 2 : marginY;
+        const intptr_t st = k ? cstride : stride;
+        if (!in->planes[k] || in->stride[k] < (int)(w * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
+        pixel* base = staging.data() + org[k];
+        for (int y = 0; y < h; y++)
+        {
+            const pixel* src = (const pixel*)((const uint8_t*)in->planes[k] + (size_t)y * in->stride[k]);
+            pixel* row = base + (intptr_t)y * st;
+            memcpy(row, src, sizeof(pixel) * w);
+            for (int x = 1; x <= mx; x++) { row[-x] = row[0]; row[w - 1 + x] = row[w - 1]; }
+        }
+        for (int y = 1; y <= my; y++)
+        {
+            memcpy(base + (intptr_t)(-y) * st - mx, base - mx, sizeof(pixel) * (w + 2 * mx));
+            memcpy(base + (intptr_t)(h - 1 + y) * st - mx, base + (intptr_t)(h - 1) * st - mx, sizeof(pixel) * (w + 2 * mx));
+        }
+    }
+    if (hipMalloc((void**)&pic.dSrc, picElems * sizeof(pixel)) != hipSuccess || hipMalloc((void**)&pic.dRec, picElems * sizeof(pixel)) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+    if (hipMemcpy(pic.dSrc, staging.data(), picElems * sizeof(pixel), hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: upload");
+    if (hipMemset(pic.dRec, 0, picElems * sizeof(pixel)) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+    return 0;
+}
+
+/* Lookahead::slicetypeDecide with bFrameAdaptive 0 and no scenecut (slicetype.cpp:1929-2040): the next mini-GOP, moved to `ready` in coding order */
+void x265amd_encoder::decideMiniGop(bool flush)
+{
+    while (!input.empty())
+    {
+        if (!flush && (int)input.size() < p.bframes + 1 && !(first && !input.empty())) return;
+        int b = 0;
+        for (;; b++)
+        {
+            Pic& frm = *input[b];
+            if (frm.poc - lastKeyframe >= p.keyframeMax) frm.type = TYPE_IDR;
+            if (frm.type == TYPE_IDR)
+            {
+                /* closed GOP: the frame before a keyframe becomes P and ends the mini-GOP; the keyframe opens the next one */
+                if (b > 0) { input[b - 1]->type = TYPE_P; b--; break; }
+                lastKeyframe = frm.poc;
+                break;
+            }
+            if (b == p.bframes || b + 1 >= (int)input.size()) { frm.type = TYPE_P; break; }
+            frm.type = TYPE_B;
+        }
+        /* coding order: the non-B frame first, then the B frames in display order */
+        ready.push_back(input[b]);
+        for (int i = 0; i < b; i++) ready.push_back(input[i]);
+        input.erase(input.begin(), input.begin() + b + 1);
+        first = false;
+        if (!flush) return;
+    }
+}
+
+int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
+{
+    const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
+    /* ---- DPB::prepareEncode ---- */
+    const int nalType = pic.type == TYPE_IDR ? 20 : (pic.type == TYPE_B ? 0 : 1);      /* IDR_N_LP, TRAIL_N, TRAIL_R */
+    if (pic.type == TYPE_IDR) lastIDR = pic.poc;
+    pic.hasReferences = pic.type != TYPE_B;
+    /* recycleUnreferenced: pictures nobody references leave the list */
+    picList.erase(std::remove_if(picList.begin(), picList.end(), [](const PicP& q) { return !q->hasReferences; }), picList.end());
+    if (pic.type == TYPE_IDR) { for (auto& q : picList) q->hasReferences = false; }                 /* decodingRefreshMarking */
+    std::vector<Pic*> rps;                                                                              /* computeRPS */
+    for (auto& q : picList)
+    {
+        if ((int)rps.size() >= maxDecPicBuffering - 1) break;
+        if (q->poc != pic.poc && q->hasReferences && (lastIDR >= pic.poc || lastIDR <= q->poc)) rps.push_back(q.get());
+    }
+    for (auto& q : picList)                                                                             /* applyReferencePictureSet */
+        if (q->hasReferences && std::find(rps.begin(), rps.end(), q.get()) == rps.end()) q->hasReferences = false;
+    std::vector<Pic*> neg, pos;
+    for (Pic* q : rps) (q->poc < pic.poc ? neg : pos).push_back(q);
+    std::sort(neg.begin(), neg.end(), [](Pic* a, Pic* b) { return a->poc > b->poc; });                 /* RPS::sortDeltaPOC */
+    std::sort(pos.begin(), pos.end(), [](Pic* a, Pic* b) { return a->poc < b->poc; });
+    std::vector<Pic*> lists[2];
+    if (stype != 2)
+    {
+        const int n0 = std::min(std::max(1, (int)neg.size()), p.maxNumReferences), n1 = stype == 0 ? std::min(1, (int)pos.size()) : 0;
+        std::vector<Pic*> l0(neg), l1(pos);
+        l0.insert(l0.end(), pos.begin(), pos.end()); l1.insert(l1.end(), neg.begin(), neg.end());
+        if ((int)l0.size() < n0 || (int)l1.size() < n1 || (stype == 0 && !n1)) return xa_fail(X265AMD_EINVAL, "encoder_encode: reference lists");
+        lists[0].assign(l0.begin(), l0.begin() + n0); lists[1].assign(l1.begin(), l1.begin() + n1);
+    }
+    /* ---- rateControlStart, CQP ---- */
+    pic.sliceQp = qpConstant[stype];
+
+    /* ---- the frame ---- */
+    std::vector<uint64_t> planes;
+    std::vector<Pic*> index;
+    int32_t refPic[2][16];
+    memset(refPic, 0, sizeof(refPic)); memset(pic.refPoc, 0, sizeof(pic.refPoc));
+    for (int l = 0; l < 2; l++)
+        for (size_t r = 0; r < lists[l].size(); r++)
+        {
+            Pic* q = lists[l][r];
+            size_t k = std::find(index.begin(), index.end(), q) - index.begin();
+            if (k == index.size()) { index.push_back(q); for (int c = 0; c < 3; c++) planes.push_back(planeAddr(q->dRec, c)); }
+            refPic[l][r] = (int32_t)k; pic.refPoc[l][r] = q->poc;
+        }
+    for (int c = 0; c < 3; c++) planes.push_back(planeAddr(pic.dRec, c));
+    for (int c = 0; c < 3; c++) planes.push_back(planeAddr(pic.dSrc, c));
+
+    x265amd_mvpred_info info;
+    memset(&info, 0, sizeof(info));
+    info.pic_width = W; info.pic_height = H; info.is_inter_b = stype == 0; info.max_num_merge_cand = p.maxNumMergeCand;
+    info.num_ref_idx[0] = (int32_t)lists[0].size(); info.num_ref_idx[1] = (int32_t)lists[1].size();
+    info.temporal_mvp = p.bEnableTemporalMvp != 0; info.col_from_l0 = stype != 0; info.check_ldc = stype != 0; info.poc = pic.poc;
+    memcpy(info.ref_poc, pic.refPoc, sizeof(info.ref_poc));
+    const Pic* colPic = stype == 2 ? nullptr : (stype == 1 ? lists[0][0] : lists[1][0]);
+    if (colPic) { info.col_poc = colPic->poc; memcpy(info.col_ref_poc, colPic->refPoc, sizeof(info.col_ref_poc)); }
+
+    x265amd_inter_search_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.search_method = p.searchMethod; sp.subpel_refine = p.subpelRefine; sp.search_range = p.searchRange; sp.qp = pic.sliceQp; sp.chroma_mc = 1;
+    memcpy(sp.ref_pic, refPic, sizeof(sp.ref_pic));
+
+    x265amd_slice_info si;
+    memset(&si, 0, sizeof(si));
+    si.pic_width = W; si.pic_height = H; si.slice_type = stype; si.slice_qp = pic.sliceQp;
+    si.num_ref_idx[0] = info.num_ref_idx[0]; si.num_ref_idx[1] = info.num_ref_idx[1];
+    si.max_num_merge_cand = p.maxNumMergeCand; si.sign_hide = p.bEnableSignHiding != 0; si.wpp = p.bEnableWavefront != 0;
+    si.max_cu_depth = 3; si.max_amp_depth = p.bEnableAMP ? 3 : 0; si.tu_log2_min = 2; si.tu_log2_max = 5;
+    si.tu_max_depth_inter = p.tuQTMaxInterDepth; si.tu_max_depth_intra = p.tuQTMaxIntraDepth;
+
+    x265amd_analysis_params ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.psy_rd = p.psyRd; ap.rd_level = p.rdLevel; ap.early_skip = p.bEnableEarlySkip != 0; ap.rskip = p.recursionSkipMode; ap.limit_refs = p.limitReferences;
+    ap.b_intra = p.bIntraInBFrames != 0; ap.rect = p.bEnableRectInter != 0; ap.amp = p.bEnableAMP != 0; ap.limit_modes = p.limitModes != 0;
+    ap.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0; ap.use_sao = p.bEnableSAO != 0;
+
+    const size_t nUnits = (size_t)w4 * h4;
+    pic.units.assign(nUnits, x265amd_cu_unit()); pic.motion.assign(nUnits, x265amd_mv_unit());
+    memset(pic.units.data(), 0, sizeof(x265amd_cu_unit) * nUnits); memset(pic.motion.data(), 0, sizeof(x265amd_mv_unit) * nUnits);
+    std::vector<x265amd_mv_unit> noCol;
+    if (!colPic) { noCol.resize(nUnits); memset(noCol.data(), 0, sizeof(x265amd_mv_unit) * nUnits); }
+    std::vector<uint8_t> refDepth(2 * nUnits, 0);
+    std::vector<int8_t> refQp0(2 * (size_t)nctu, 0);
+    for (int l = 0; l < 2; l++)
+        if (!lists[l].empty())
+        {
+            const Pic* q = lists[l][0];
+            for (size_t i = 0; i < nUnits; i++) refDepth[l * nUnits + i] = q->units[i].depth;
+            for (int i = 0; i < nctu; i++) refQp0[(size_t)l * nctu + i] = (int8_t)q->sliceQp;
+        }
+    std::vector<x265amd_cu_stat> stat((size_t)nctu + 1);
+    memset(stat.data(), 0, sizeof(x265amd_cu_stat) * stat.size());
+    std::vector<int16_t> coeff((size_t)nctu * RD_TILE_ELEMS, 0);
+    std::vector<uint8_t> data((size_t)W * H * 3 + (1u << 16));
+    std::vector<uint32_t> sizes((size_t)ctuH + 1, 0);
+    int nsub = 0;
+    const bool sao = p.bEnableSAO != 0;
+    int rc = x265amd_analyse_frame(me, nullptr, &info, &sp, &si, &ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
+                                   refDepth.data(), refQp0.data(), planes.data(), (int)(planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
+                                   sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub);
+    if (rc != X265AMD_OK) return rc;
+    pixel* recY = pic.dRec + org[0]; pixel* recU = pic.dRec + org[1]; pixel* recV = pic.dRec + org[2];
+    if (p.bEnableLoopFilter)
+    {
+        std::vector<x265amd_deblock_unit> dbu(nUnits);
+        rc = x265amd_deblock_units(&si, &info, pic.units.data(), pic.motion.data(), dbu.data());
+        if (rc != X265AMD_OK) return rc;
+        if (hipMemcpy(dDbUnits, dbu.data(), sizeof(x265amd_deblock_unit) * nUnits, hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: deblock upload");
+        rc = x265amd_deblock_picture(nullptr, recY, recU, recV, stride, cstride, W, H, dDbUnits, 0, 0, 0, 0, 0, 3);
+        if (rc != X265AMD_OK) return rc;
+        if (hipDeviceSynchronize() != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: deblock");
+    }
+    int32_t saoFlags[2] = { 0, 0 };
+    if (sao)
+    {
+        const size_t nstat = (size_t)nctu * 3 * 5 * 32;
+        const uint64_t recP[3] = { planeAddr(pic.dRec, 0), planeAddr(pic.dRec, 1), planeAddr(pic.dRec, 2) };
+        const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
+        if (hipMemset(dSaoCount, 0, nstat * 4) != hipSuccess || hipMemset(dSaoOrg, 0, nstat * 4) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao memset");
+        rc = x265amd_sao_stats(nullptr, recP, srcP, stride, cstride, W, H, dSaoCount, dSaoOrg);
+        if (rc != X265AMD_OK) return rc;
+        std::vector<int32_t> cnt(nstat), orgs(nstat);
+        if (hipMemcpy(cnt.data(), dSaoCount, nstat * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(orgs.data(), dSaoOrg, nstat * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder: sao download");
+        std::vector<x265amd_sao_ctu> sparams((size_t)nctu);
+        memset(sparams.data(), 0, sizeof(x265amd_sao_ctu) * nctu);
+        rc = x265amd_sao_rdo(&si, pic.hasReferences ? 1 : 0, 1, 0, 69, pic.units.data(), cnt.data(), orgs.data(), depthSaoRate, sparams.data(), saoFlags);
+        if (rc != X265AMD_OK) return rc;
+        if (hipMemcpy(dSaoParams, sparams.data(), sizeof(x265amd_sao_ctu) * nctu, hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao upload");
+        if (hipMemcpy(dSaoTmp, pic.dRec, picElems * sizeof(pixel), hipMemcpyDeviceToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao copy");
+        const uint64_t dstP[3] = { planeAddr(dSaoTmp, 0), planeAddr(dSaoTmp, 1), planeAddr(dSaoTmp, 2) };
+        rc = x265amd_sao_apply(nullptr, recP, dstP, stride, cstride, W, H, dSaoParams);
+        if (rc != X265AMD_OK) return rc;
+        if (hipDeviceSynchronize() != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao");
+        std::swap(pic.dRec, dSaoTmp);
+        recY = pic.dRec + org[0]; recU = pic.dRec + org[1]; recV = pic.dRec + org[2];
+        rc = x265amd_encode_slice_data(&si, pic.units.data(), coeff.data(), sparams.data(), saoFlags, data.data(), data.size(), sizes.data(), &nsub);
+        if (rc != X265AMD_OK) return rc;
+    }
+    /* the reconstruction becomes a reference: extend its borders */
+    rc = x265amd_extend_pic_border(nullptr, recY, stride, W, H, marginX, marginY);
+    if (rc == X265AMD_OK) rc = x265amd_extend_pic_border(nullptr, recU, cstride, W / 2, H / 2, marginX / 2, marginY / 2);
+    if (rc == X265AMD_OK) rc = x265amd_extend_pic_border(nullptr, recV, cstride, W / 2, H / 2, marginX / 2, marginY / 2);
+    if (rc != X265AMD_OK) return rc;
+    if (hipDeviceSynchronize() != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: border extension");
+
+    /* ---- slice header (Entropy::codeSliceHeader inputs as DPB / Encoder set them) ---- */
+    x265amd_slice_header h;
+    memset(&h, 0, sizeof(h));
+    h.nal_unit_type = nalType; h.temporal_id_plus1 = 1; h.first_in_access_unit = 1;
+    h.slice_type = stype; h.poc = pic.poc; h.last_idr_poc = lastIDR; h.log2_max_poc_lsb = 8; h.rps_idx = -1; h.num_rps_in_sps = 0;
+    h.num_negative = (int32_t)neg.size(); h.num_positive = (int32_t)pos.size();
+    {
+        int j = 0;
+        for (Pic* q : neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+        for (Pic* q : pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+    }
+    h.temporal_mvp_enabled = p.bEnableTemporalMvp != 0;
+    h.use_sao = sao; h.sao_luma = saoFlags[0]; h.sao_chroma = saoFlags[1];
+    h.num_ref_idx[0] = info.num_ref_idx[0]; h.num_ref_idx[1] = info.num_ref_idx[1]; h.num_ref_idx_default[0] = h.num_ref_idx_default[1] = 1;
+    h.col_from_l0 = stype != 0; h.col_ref_idx = 0; h.max_num_merge_cand = p.maxNumMergeCand;
+    h.slice_qp = pic.sliceQp; h.pps_init_qp = 26; h.deblocking_disabled = !p.bEnableLoopFilter;
+    h.slfase_flag = (0x5f4e4a53u >> (pic.poc % 31)) & 1;                                              /* SLFASE_CONSTANT (dpb.cpp:294) */
+    h.wpp = p.bEnableWavefront != 0;
+    size_t dataBytes = 0;
+    for (int s = 0; s < nsub; s++) dataBytes += sizes[s];
+    outBytes.assign(dataBytes * 3 / 2 + 4096, 0);
+    const size_t n = x265amd_write_slice_nal(&h, data.data(), sizes.data(), nsub, outBytes.data(), outBytes.size());
+    if (!n || n > outBytes.size()) return xa_fail(X265AMD_EINVAL, "encoder: slice NAL");
+    outBytes.resize(n);
+    splitNals(outBytes, nals);
+
+    if (picOut)
+    {
+        staging.resize(picElems);
+        if (hipMemcpy(staging.data(), pic.dRec, picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: recon download");
+        for (int k = 0; k < 3; k++)
+        {
+            if (!picOut->planes[k]) continue;
+            const int w = k ? W / 2 : W, hh = k ? H / 2 : H;
+            const intptr_t st = k ? cstride : stride;
+            for (int y = 0; y < hh; y++) memcpy((uint8_t*)picOut->planes[k] + (size_t)y * picOut->stride[k], staging.data() + org[k] + (intptr_t)y * st, sizeof(pixel) * w);
+        }
+        picOut->poc = pic.poc; picOut->sliceType = pic.type; picOut->qp = pic.sliceQp;
+    }
+    /* the source is no longer needed; the reconstruction stays while the picture is referenced */
+    (void)hipFree(pic.dSrc); pic.dSrc = nullptr;
+    return 0;
+}
+
+extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal, const x265amd_picture* picIn, x265amd_picture* picOut)
+{
+    if (!e) return xa_fail(X265AMD_EINVAL, "encoder_encode: null encoder");
+    if (ppNal) *ppNal = nullptr;
+    if (piNal) *piNal = 0;
+    if (picIn)
+    {
+        PicP pic(new Pic);
+        pic->poc = e->frameCount++;
+        const int rc = e->uploadPicture(picIn, *pic);
+        if (rc) return -1;
+        e->input.push_back(pic);
+    }
+    if (e->ready.empty()) e->decideMiniGop(picIn == nullptr);
+    if (e->ready.empty()) return 0;
+    PicP pic = e->ready.front();
+    e->ready.pop_front();
+    const int rc = e->encodeOne(*pic, picOut);
+    if (rc) return -1;
+    e->picList.insert(e->picList.begin(), pic);                 /* PicList::pushFront */
+    if (ppNal) *ppNal = e->nals.data();
+    if (piNal) *piNal = (uint32_t)e->nals.size();
+    return 1;
+}
