@@ -378,5 +378,39 @@ def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out, nframes=4):
     assert k == nframes, k
 
 
+def make_encoder_api_golden():
+    """whole streams + per-frame reconstruction digests of the reference encoder for clips the frame-pipeline goldens do not cover:
+    picture sizes that are not multiples of the CTU size (partial CTUs at the right / bottom edge) and a 14-frame clip (the DPB evicts
+    pictures) -> tests/golden/encoder_api_golden.npz"""
+    import subprocess, tempfile, hashlib
+    out = {}
+    for tag, (w, h), nframes, extra in (("crop_p/", (200, 152), 4, ["--bframes", "0"]),
+                                        ("crop_b/", (248, 184), 7, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "2"]),
+                                        ("long/", (128, 128), 14, ["--bframes", "2", "--no-b-pyramid", "--ref", "4"])):
+        planes = T.encoder_api_clip(tag, w, h, nframes)
+        cli = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
+        # later options override earlier ones on the reference's command line
+        cli = cli + ["--rc-lookahead", "5"] + extra
+        if "--sao" in extra:
+            cli = [a for a in cli if a not in ("--no-sao", "--no-wpp")]
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "clip.y4m"), "wb") as f:
+                f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420\n" % (w, h))
+                for fr in planes:
+                    f.write(b"FRAME\n")
+                    for pl in fr:
+                        f.write(np.ascontiguousarray(pl).tobytes())
+            exe = os.path.join(T.REF_DIR, "x265_ref8")
+            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv"] + cli, cwd=d, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
+            fsz = w * h * 3 // 2
+            assert len(rec) == fsz * nframes
+            out[tag + "stream"] = np.frombuffer(open(os.path.join(d, "out.hevc"), "rb").read(), np.uint8)
+            out[tag + "recon_md5"] = np.array([hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)])
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "encoder_api_golden.npz"), **out)
+    print("wrote encoder_api_golden.npz:", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     main()

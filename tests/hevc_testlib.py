@@ -3053,3 +3053,25 @@ def encoder_run(L, planes_per_frame, width, height, **overrides):
     finally:
         lib.x265amd_encoder_close(enc)
     return np.frombuffer(bytes(stream), np.uint8), coded
+
+
+def encoder_api_clip(tag, w, h, nframes, depth=8):
+    """display-order (Y, U, V) planes of a w x h clip: a textured picture drifting a few samples per frame plus noise (integer only)"""
+    rng = np.random.default_rng(w * 1000003 + h * 1009 + nframes)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    big = rng.integers(0, pmax + 1, ((h + 96) // 8 + 2, (w + 96) // 8 + 2)).astype(np.int64)
+    big = np.kron(big, np.ones((8, 8), np.int64))
+    big = (big + np.roll(big, 3, 0) + np.roll(big, 5, 1) + np.roll(big, -2, 1)) // 4
+    cb = (np.roll(big, 7, 0)[::2, ::2] + big[1::2, 1::2]) // 2
+    cr = (np.roll(big, 11, 1)[::2, ::2] + big[::2, 1::2]) // 2
+    frames = []
+    for t in range(nframes):
+        dx, dy = 2 * ((3 * t) % 11), 2 * ((2 * t) % 7)
+        planes = []
+        for (src, pw, ph, sx, sy) in ((big, w, h, dx, dy), (cb, w // 2, h // 2, dx // 2, dy // 2), (cr, w // 2, h // 2, dx // 2, dy // 2)):
+            o = 16 if src is big else 8
+            core = src[o + sy:o + sy + ph, o + sx:o + sx + pw] + rng.integers(-2, 3, (ph, pw)) * (1 << (depth - 8))
+            planes.append(np.clip(core, 0, pmax).astype(dt))
+        frames.append(planes)
+    return frames

@@ -62,3 +62,26 @@ def test_encoder_object_reproduces_reference_stream(tag):
         for p in range(3):
             assert np.array_equal(planes[p], g[tag + "recon/%d/%d" % (poc, p)]), "reconstruction of poc %d plane %d" % (poc, p)
     assert len(stream) == len(want) and hashlib.md5(stream.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+
+
+EDGE_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_api_golden.npz")
+EDGE_CONFIGS = {
+    "crop_p/": ((200, 152), 4, dict(BASE)),
+    "crop_b/": ((248, 184), 7, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1)),
+    "long/": ((128, 128), 14, dict(BASE, bframes=2, maxNumReferences=4)),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(EDGE_CONFIGS))
+def test_encoder_object_partial_ctus_and_long_clip(tag):
+    """picture sizes that are not multiples of 64 (partial CTUs: forced splits at the right / bottom edge, filters and SAO on cut CTUs) and
+    a 14-frame clip with 4 references (reference pictures leave the decoded picture buffer)"""
+    g = np.load(EDGE_GOLD)
+    (w, h), n, cfg = EDGE_CONFIGS[tag]
+    stream, coded = T.encoder_run(T.load_hip(8), T.encoder_api_clip(tag, w, h, n), w, h, **cfg)
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    want = g[tag + "stream"]
+    assert len(stream) == len(want) and hashlib.md5(stream.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
