@@ -386,8 +386,11 @@ def make_encoder_api_golden():
     out = {}
     for tag, (w, h), nframes, extra in (("crop_p/", (200, 152), 4, ["--bframes", "0"]),
                                         ("crop_b/", (248, 184), 7, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "2"]),
-                                        ("long/", (128, 128), 14, ["--bframes", "2", "--no-b-pyramid", "--ref", "4"])):
-        planes = T.encoder_api_clip(tag, w, h, nframes)
+                                        ("long/", (128, 128), 14, ["--bframes", "2", "--no-b-pyramid", "--ref", "4"]),
+                                        ("hbd_b/", (192, 136), 7, ["--bframes", "2", "--no-b-pyramid", "--sao", "--rect", "--amp"]),
+                                        ("hbd_rd5/", (128, 128), 4, ["--bframes", "0", "--rd", "5"])):
+        depth = 10 if tag.startswith("hbd") else 8
+        planes = T.encoder_api_clip(tag, w, h, nframes, depth)
         cli = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
         # later options override earlier ones on the reference's command line
         cli = cli + ["--rc-lookahead", "5"] + extra
@@ -395,16 +398,16 @@ def make_encoder_api_golden():
             cli = [a for a in cli if a not in ("--no-sao", "--no-wpp")]
         with tempfile.TemporaryDirectory() as d:
             with open(os.path.join(d, "clip.y4m"), "wb") as f:
-                f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420\n" % (w, h))
+                f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
                 for fr in planes:
                     f.write(b"FRAME\n")
                     for pl in fr:
                         f.write(np.ascontiguousarray(pl).tobytes())
-            exe = os.path.join(T.REF_DIR, "x265_ref8")
+            exe = os.path.join(T.REF_DIR, "x265_ref%d" % depth)
             r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv"] + cli, cwd=d, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
-            fsz = w * h * 3 // 2
+            fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
             assert len(rec) == fsz * nframes
             out[tag + "stream"] = np.frombuffer(open(os.path.join(d, "out.hevc"), "rb").read(), np.uint8)
             out[tag + "recon_md5"] = np.array([hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)])

@@ -69,6 +69,8 @@ EDGE_CONFIGS = {
     "crop_p/": ((200, 152), 4, dict(BASE)),
     "crop_b/": ((248, 184), 7, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1)),
     "long/": ((128, 128), 14, dict(BASE, bframes=2, maxNumReferences=4)),
+    "hbd_b/": ((192, 136), 7, dict(BASE, bframes=2, bEnableSAO=1, bEnableRectInter=1, bEnableAMP=1)),       # 10-bit library (libx265amd_main10.so)
+    "hbd_rd5/": ((128, 128), 4, dict(BASE, rdLevel=5)),
 }
 
 
@@ -79,7 +81,8 @@ def test_encoder_object_partial_ctus_and_long_clip(tag):
     a 14-frame clip with 4 references (reference pictures leave the decoded picture buffer)"""
     g = np.load(EDGE_GOLD)
     (w, h), n, cfg = EDGE_CONFIGS[tag]
-    stream, coded = T.encoder_run(T.load_hip(8), T.encoder_api_clip(tag, w, h, n), w, h, **cfg)
+    depth = 10 if tag.startswith("hbd") else 8
+    stream, coded = T.encoder_run(T.load_hip(depth), T.encoder_api_clip(tag, w, h, n, depth), w, h, **cfg)
     for (poc, _, _, planes) in coded:
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
         assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
