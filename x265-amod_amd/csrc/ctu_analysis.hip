@@ -84,7 +84,8 @@ struct Analyzer
     const uint64_t* planes; int numPics; intptr_t stride, cstride;
     x265amd_cu_stat* cuStat; int ctuAddr, ctuX, ctuY, ctuW, w4, h4, qp;
     ModeDepth md[4];
-    DevBuf dTiles, dPlanes, dJobs;
+    DevBuf dTiles, dPlanes;
+    XaMapped dJobs;                         /* motion compensation jobs: host memory the kernel reads in place */
     size_t tileBytes;
     uint64_t lambda2, lambda; uint32_t psyRd;
     x265amd_rd_params rp;
@@ -138,7 +139,7 @@ struct Analyzer
             j.dst_u += (size_t)((g.y >> 1) * 32 + (g.x >> 1)) * sizeof(pixel); j.dst_v += (size_t)((g.y >> 1) * 32 + (g.x >> 1)) * sizeof(pixel);
             jobs.push_back(j);
         }
-        if (hipMemcpyAsync(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * jobs.size(), hipMemcpyHostToDevice, st) != hipSuccess) return fail("ctu analysis: job upload");
+        memcpy(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * jobs.size());
         if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, (int)jobs.size()) != X265AMD_OK)
             return err = X265AMD_EHIP;
         return 0;
@@ -147,7 +148,7 @@ struct Analyzer
     int predictAndMeasure(std::vector<x265amd_mc_job>& jobs, int x, int y, int log2, const int* tiles, x265amd_cu_measure* meas)
     {
         const int n = (int)jobs.size();
-        if (hipMemcpyAsync(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * n, hipMemcpyHostToDevice, st) != hipSuccess) return fail("ctu analysis: job upload");
+        memcpy(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * n);
         if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, n) != X265AMD_OK)
             return err = X265AMD_EHIP;
         for (int k = 0; k < n; k++)

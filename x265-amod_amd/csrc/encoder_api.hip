@@ -13,6 +13,9 @@
 #include "x265amd_encoder.h"
 #include "x265amd_host.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
 #include <string.h>
 #include <algorithm>
 #include <deque>
@@ -483,7 +486,12 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     if (e->ready.empty()) return 0;
     PicP pic = e->ready.front();
     e->ready.pop_front();
+    const bool timing = getenv("X265AMD_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = e->encodeOne(*pic, picOut);
+    if (timing)
+        fprintf(stderr, "x265amd: poc %d type %d qp %d: %.2f ms\n", pic->poc, pic->type, pic->sliceQp,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (rc) return -1;
     e->picList.insert(e->picList.begin(), pic);                 /* PicList::pushFront */
     if (ppNal) *ppNal = e->nals.data();

@@ -743,7 +743,7 @@ extern "C" int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_
     return X265AMD_OK;
 }
 
-static void fill_measure_jobs(std::vector<CuMeasureJob>& mjobs, const x265amd_rd_cu* cus, int n, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
+static void fill_measure_jobs(CuMeasureJob* mjobs, const x265amd_rd_cu* cus, int n, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
                               uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, const char* scratch, size_t perCuBytes, const char* dSel)
 {
     for (int i = 0; i < n; i++)
@@ -766,17 +766,14 @@ extern "C" int x265amd_measure_tiles(void* stream_, const uint64_t* h_src, intpt
     if (!h_src || !cus || !d_tiles || !out || n < 0) return xa_fail(X265AMD_EINVAL, "measure_tiles: null argument");
     if (n == 0) return X265AMD_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    DevBuf dMJobs, dMeas, dDump;
-    XA_HIP_CHECK(dMJobs.alloc(sizeof(CuMeasureJob) * n));
-    XA_HIP_CHECK(dMeas.alloc(sizeof(x265amd_cu_measure) * n));
-    XA_HIP_CHECK(dDump.alloc((size_t)(4096 + 2048) * sizeof(pixel)));
-    std::vector<CuMeasureJob> mjobs(n);
-    fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_tiles, d_tiles, tile_bytes, nullptr, 0, nullptr);       /* "recon" = the tile itself */
-    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
+    XaMapped mJobs, mMeas;              /* job and result records live in host memory the kernel reads / writes in place */
+    XA_HIP_CHECK(mJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
+    fill_measure_jobs((CuMeasureJob*)mJobs.p, cus, n, h_src, stride, cstride, d_tiles, d_tiles, tile_bytes, nullptr, 0, nullptr);       /* "recon" = the tile itself */
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
     XA_HIP_CHECK(hipGetLastError());
-    XA_HIP_CHECK(hipMemcpyAsync(out, dMeas.p, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
     XA_HIP_CHECK(hipStreamSynchronize(stream));
+    memcpy(out, mMeas.p, sizeof(x265amd_cu_measure) * n);
     return X265AMD_OK;
 }
 
@@ -788,17 +785,14 @@ extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, cons
     if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "skip_rd: tile too small");
     if (n == 0) return X265AMD_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    DevBuf dMJobs, dMeas;
-    XA_HIP_CHECK(dMJobs.alloc(sizeof(CuMeasureJob) * n));
-    XA_HIP_CHECK(dMeas.alloc(sizeof(x265amd_cu_measure) * n));
-    std::vector<CuMeasureJob> mjobs(n);
-    fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, nullptr, 0, nullptr);
-    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
+    XaMapped mJobs, mMeas;
+    XA_HIP_CHECK(mJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
+    fill_measure_jobs((CuMeasureJob*)mJobs.p, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
     XA_HIP_CHECK(hipGetLastError());
-    std::vector<x265amd_cu_measure> meas(n);
-    XA_HIP_CHECK(hipMemcpyAsync(meas.data(), dMeas.p, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
     XA_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<x265amd_cu_measure> meas((const x265amd_cu_measure*)mMeas.p, (const x265amd_cu_measure*)mMeas.p + n);
     return x265amd_skip_rd_host(si, rp, units, cus, n, cu_units, meas.data(), out);
 }
 
@@ -815,47 +809,42 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
 
     /* ---- plan + launch 1: all transform chains and the no-residual measurement ---- */
     const size_t perCuBytes = x265amd_inter_rd_scratch_bytes();
-    DevBuf dScratch, dJobs, dRes, dMJobs, dMeas, dSel;
+    DevBuf dScratch, dSel;
+    XaMapped mJobs, mRes, mMJobs, mMeas, mLevels;       /* records the kernels touch once: host memory, read / written in place */
     XA_HIP_CHECK(dScratch.alloc(perCuBytes * n));
     char* scratch = (char*)dScratch.p;
     const int nJobs = x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, nullptr, 0);
     if (nJobs < 0) return nJobs;
-    std::vector<x265amd_tu_job> jobs(nJobs);
-    x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, jobs.data(), nJobs);
-    XA_HIP_CHECK(dJobs.alloc(sizeof(x265amd_tu_job) * nJobs));
-    XA_HIP_CHECK(dRes.alloc(sizeof(x265amd_tu_result) * nJobs));
-    XA_HIP_CHECK(dMJobs.alloc(sizeof(CuMeasureJob) * n));
-    XA_HIP_CHECK(dMeas.alloc(sizeof(x265amd_cu_measure) * n * 2));
+    XA_HIP_CHECK(mJobs.alloc(sizeof(x265amd_tu_job) * nJobs));
+    XA_HIP_CHECK(mRes.alloc(sizeof(x265amd_tu_result) * nJobs));
+    XA_HIP_CHECK(mMJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n * 2));
+    XA_HIP_CHECK(mLevels.alloc((size_t)RD_SCRATCH_ELEMS * 2 * n));
     XA_HIP_CHECK(dSel.alloc((size_t)RD_SEL_BYTES * n));
-    XA_HIP_CHECK(hipMemcpyAsync(dJobs.p, jobs.data(), sizeof(x265amd_tu_job) * nJobs, hipMemcpyHostToDevice, stream));
-    int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)dJobs.p, nJobs, (x265amd_tu_result*)dRes.p);
+    x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs);
+    int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)mJobs.p, nJobs, (x265amd_tu_result*)mRes.p);
     if (rc != X265AMD_OK) return rc;
-    std::vector<CuMeasureJob> mjobs(n);
+    CuMeasureJob* mjobs = (CuMeasureJob*)mMJobs.p;
+    x265amd_cu_measure* meas = (x265amd_cu_measure*)mMeas.p;
     fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, scratch, perCuBytes, (const char*)dSel.p);
-    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p);
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mjobs, n, meas);
     XA_HIP_CHECK(hipGetLastError());
-    std::vector<x265amd_tu_result> res(nJobs);
-    std::vector<x265amd_cu_measure> meas(2 * (size_t)n);
-    std::vector<int16_t> levels((size_t)RD_SCRATCH_ELEMS * n);
-    XA_HIP_CHECK(hipMemcpyAsync(res.data(), dRes.p, sizeof(x265amd_tu_result) * nJobs, hipMemcpyDeviceToHost, stream));
-    XA_HIP_CHECK(hipMemcpyAsync(meas.data(), dMeas.p, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
-    XA_HIP_CHECK(hipMemcpy2DAsync(levels.data(), (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n, hipMemcpyDeviceToHost, stream));
+    /* the levels (the head of each CU's scratch) come to pinned host memory in one strided copy */
+    XA_HIP_CHECK(hipMemcpy2DAsync(mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n, hipMemcpyDeviceToHost, stream));
     XA_HIP_CHECK(hipStreamSynchronize(stream));
 
     /* ---- the walk ---- */
     std::vector<uint8_t> sel((size_t)RD_SEL_BYTES * n);
-    rc = x265amd_inter_rd_walk(si, rp, units, cus, n, cu_units, res.data(), levels.data(), (size_t)RD_SCRATCH_ELEMS * 2, meas.data(), sel.data(), out, coeff_out);
+    rc = x265amd_inter_rd_walk(si, rp, units, cus, n, cu_units, (const x265amd_tu_result*)mRes.p, (const int16_t*)mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, meas, sel.data(), out,
+                               coeff_out);
     if (rc != X265AMD_OK) return rc;
 
     /* ---- launch 2: assemble, reconstruct, measure ---- */
     for (int i = 0; i < n; i++) mjobs[i].assemble = 1;
     XA_HIP_CHECK(hipMemcpyAsync(dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice, stream));
-    XA_HIP_CHECK(hipMemcpyAsync(dMJobs.p, mjobs.data(), sizeof(CuMeasureJob) * n, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)dMJobs.p, n, (x265amd_cu_measure*)dMeas.p + n);
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mjobs, n, meas + n);
     XA_HIP_CHECK(hipGetLastError());
-    XA_HIP_CHECK(hipMemcpyAsync(meas.data() + n, (x265amd_cu_measure*)dMeas.p + n, sizeof(x265amd_cu_measure) * n, hipMemcpyDeviceToHost, stream));
     XA_HIP_CHECK(hipStreamSynchronize(stream));
-    x265amd_inter_rd_finish(si, rp, cus, n, meas.data() + n, out);
+    x265amd_inter_rd_finish(si, rp, cus, n, meas + n, out);
     return X265AMD_OK;
 }

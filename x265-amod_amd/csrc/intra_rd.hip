@@ -54,7 +54,8 @@ struct IntraRd
     Snap cur, rqtRoot[6], rqtTest[6];
     uint64_t lambda2, lambda; uint32_t psyRd;
     uint64_t predTile, reconTile;
-    DevBuf dJobs, dRes, dCoeff, dResi, dLayer, dScan, dScanJob, dCand;
+    DevBuf dResi, dLayer, dCand;
+    XaMapped dJobs, dRes, dCoeff, dScan, dScanJob;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     enum { MAX_JOBS = 16 };
     /* a luma TU whose chain already ran in a batch (the candidates of one partition share their neighbours, so they run as one launch):
      * codeIntraLumaQT takes the result instead of launching; the winner's prediction / reconstruction are copied when it is measured again */
@@ -132,12 +133,11 @@ struct IntraRd
     /* one launch of up to two intra TU jobs; results and levels come back to the host */
     int runJobs(x265amd_intra_tu_job* jobs, int n, x265amd_tu_result* res, int16_t* const* levelsOut, int numCoeff)
     {
-        if (hipMemcpyAsync(dJobs.p, jobs, sizeof(x265amd_intra_tu_job) * n, hipMemcpyHostToDevice, st) != hipSuccess) return fail("intra rd: job upload");
+        memcpy(dJobs.p, jobs, sizeof(x265amd_intra_tu_job) * n);
         if (x265amd_intra_tu_chain(st, (const x265amd_intra_tu_job*)dJobs.p, nullptr, n, (x265amd_tu_result*)dRes.p) != X265AMD_OK) return err = X265AMD_EHIP;
-        if (hipMemcpyAsync(res, dRes.p, sizeof(x265amd_tu_result) * n, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("intra rd: result download");
-        for (int k = 0; k < n; k++)
-            if (hipMemcpyAsync(levelsOut[k], (const int16_t*)dCoeff.p + 1024 * k, sizeof(int16_t) * numCoeff, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("intra rd: level download");
         if (hipStreamSynchronize(st) != hipSuccess) return fail("intra rd: synchronize");
+        memcpy(res, dRes.p, sizeof(x265amd_tu_result) * n);
+        for (int k = 0; k < n; k++) memcpy(levelsOut[k], (const int16_t*)dCoeff.p + 1024 * k, sizeof(int16_t) * numCoeff);
         return 0;
     }
     void fillJob(x265amd_intra_tu_job& j, int plane, int x, int y, int log2N, int mode, uint64_t pred, int predStride, uint64_t recon, int reconStride, int slot)
@@ -297,10 +297,10 @@ struct IntraRd
         sj.avail = available(x, y, 1 << log2N);
         sj.recon_stride = (int32_t)stride; sj.fenc_stride = (int32_t)stride; sj.log2_tr_size = (uint8_t)log2N; sj.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
         int32_t sa8d[35];
-        if (hipMemcpyAsync(dScanJob.p, &sj, sizeof(sj), hipMemcpyHostToDevice, st) != hipSuccess ||
-            x265amd_intra_scan(st, (const x265amd_intra_job*)dScanJob.p, 1, (int32_t*)dScan.p, nullptr) != X265AMD_OK ||
-            hipMemcpyAsync(sa8d, dScan.p, sizeof(sa8d), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        memcpy(dScanJob.p, &sj, sizeof(sj));
+        if (x265amd_intra_scan(st, (const x265amd_intra_job*)dScanJob.p, 1, (int32_t*)dScan.p, nullptr) != X265AMD_OK || hipStreamSynchronize(st) != hipSuccess)
             return fail("intra rd: mode scan");
+        memcpy(sa8d, dScan.p, sizeof(sa8d));
         uint32_t preds[3];
         c->lumaPreds(x, y, preds);
         const uint64_t frac = cur.frac & 32767;

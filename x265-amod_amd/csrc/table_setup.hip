@@ -202,10 +202,40 @@ void xa_scratch_free(void* p)
     if (it == P.size_.end()) { (void)hipFree(p); return; }
     P.free_[it->second].push_back(p);
 }
+namespace { ScratchPool& mapped_pool() { static ScratchPool* p = new ScratchPool; return *p; } }
+hipError_t xa_mapped_alloc(void** p, size_t bytes)
+{
+    ScratchPool& P = mapped_pool();
+    const size_t c = ScratchPool::cls(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        std::vector<void*>& v = P.free_[c];
+        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    const hipError_t e = hipHostMalloc(p, c, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(P.m); P.size_[*p] = c; }
+    return e;
+}
+void xa_mapped_free(void* p)
+{
+    if (!p) return;
+    ScratchPool& P = mapped_pool();
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.size_.find(p);
+    if (it == P.size_.end()) { (void)hipHostFree(p); return; }
+    P.free_[it->second].push_back(p);
+}
 extern "C" void x265amd_release_scratch(void)
 {
-    ScratchPool& P = scratch_pool();
-    std::lock_guard<std::mutex> g(P.m);
     (void)hipDeviceSynchronize();
-    for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipFree(q); P.size_.erase(q); } kv.second.clear(); }
+    {
+        ScratchPool& P = scratch_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipFree(q); P.size_.erase(q); } kv.second.clear(); }
+    }
+    {
+        ScratchPool& P = mapped_pool();
+        std::lock_guard<std::mutex> g(P.m);
+        for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipHostFree(q); P.size_.erase(q); } kv.second.clear(); }
+    }
 }

@@ -17,6 +17,21 @@ int xa_fail(int code, const char* msg);
 hipError_t xa_scratch_alloc(void** p, size_t bytes);
 void xa_scratch_free(void* p);
 
+/* Host-visible staging for the orchestrators' small job and result records: pinned host memory that the kernels read and write in place
+ * (hipHostMalloc, mapped + coherent), pooled like the device scratch.  It replaces a hipMemcpyAsync per record array: the host fills the
+ * jobs, launches, synchronises the stream and reads the results where the kernel left them.  Only for data a kernel touches once
+ * (fine-grained host memory is not cached on the device). */
+hipError_t xa_mapped_alloc(void** p, size_t bytes);
+void xa_mapped_free(void* p);
+#ifdef __cplusplus
+struct XaMapped
+{
+    void* p = nullptr;
+    ~XaMapped() { xa_mapped_free(p); }
+    hipError_t alloc(size_t bytes) { return xa_mapped_alloc(&p, bytes ? bytes : 16); }
+};
+#endif
+
 /* The reference's primitive slots cannot report failure (primitives.h:133-236), so a HIP error inside a
  * per-slot entry point is fatal: there is deliberately no CPU fallback. */
 #define XA_HIP_FATAL(expr)                                                                                   \
