@@ -638,6 +638,9 @@ typedef struct x265amd_cu_measure
 /* tile-vs-source measurement of n CUs (k_cu_measure without assembly): d_tiles as d_pred above; cus: only x, y, log2_size are read.  Synchronous. */
 int x265amd_measure_tiles(void* stream, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
                           uint64_t d_tiles, size_t tile_bytes, x265amd_cu_measure* out);
+/* the same for tiles at arbitrary device addresses (tile_addrs[i] for cus[i]), one launch */
+int x265amd_measure_tile_list(void* stream, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                              const uint64_t* tile_addrs, x265amd_cu_measure* out);
 size_t x265amd_inter_rd_scratch_bytes(void);
 /* emits the transform-chain jobs of all CUs (returns their number; jobs_out may be NULL to count) */
 int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,

@@ -151,23 +151,26 @@ struct Analyzer
         memcpy(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * n);
         if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, n) != X265AMD_OK)
             return err = X265AMD_EHIP;
-        for (int k = 0; k < n; k++)
-        {
-            x265amd_rd_cu c;
-            memset(&c, 0, sizeof(c));
-            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2;
-            if (x265amd_measure_tiles(st, planes + 3 * (numPics - 1), stride, cstride, &c, 1, tileAddr(tiles[k]), tileBytes, meas + k) != X265AMD_OK) return err = X265AMD_EHIP;
-        }
+        x265amd_rd_cu c[8];
+        uint64_t addr[8];
+        memset(c, 0, sizeof(c));
+        for (int k = 0; k < n; k++) { c[k].x = (int16_t)x; c[k].y = (int16_t)y; c[k].log2_size = (uint8_t)log2; addr[k] = tileAddr(tiles[k]); }
+        if (x265amd_measure_tile_list(st, planes + 3 * (numPics - 1), stride, cstride, c, n, addr, meas) != X265AMD_OK) return err = X265AMD_EHIP;      /* one launch */
         return 0;
     }
     void copyTile(int dst, int src, int dx, int dy, int size)       /* src tile (size x size at its origin) -> dst tile at (dx, dy) */
     {
         const size_t isz = sizeof(pixel);
         const uint64_t d = tileAddr(dst), s = tileAddr(src);
-        (void)hipMemcpy2DAsync((void*)(uintptr_t)(d + ((size_t)dy * 64 + dx) * isz), 64 * isz, (const void*)(uintptr_t)s, 64 * isz, size * isz, size, hipMemcpyDeviceToDevice, st);
+        XaRects r;
+        r.n = 3;
+        r.dst[0] = d + ((size_t)dy * 64 + dx) * isz; r.src[0] = s; r.dst_stride[0] = r.src_stride[0] = 64; r.w[0] = r.h[0] = size;
         for (int p = 0; p < 2; p++)
-            (void)hipMemcpy2DAsync((void*)(uintptr_t)(d + (4096 + p * 1024 + (size_t)(dy / 2) * 32 + dx / 2) * isz), 32 * isz,
-                                   (const void*)(uintptr_t)(s + (4096 + p * 1024) * isz), 32 * isz, size / 2 * isz, size / 2, hipMemcpyDeviceToDevice, st);
+        {
+            r.dst[1 + p] = d + (4096 + p * 1024 + (size_t)(dy / 2) * 32 + dx / 2) * isz; r.src[1 + p] = s + (4096 + p * 1024) * isz;
+            r.dst_stride[1 + p] = r.src_stride[1 + p] = 32; r.w[1 + p] = r.h[1 + p] = size / 2;
+        }
+        xa_copy_rects(st, r);
     }
     void tileToPicture(int tile, int x, int y, int size)
     {
@@ -175,10 +178,15 @@ struct Analyzer
         const int w = size < I->pic_width - x ? size : I->pic_width - x, h = size < I->pic_height - y ? size : I->pic_height - y;
         const uint64_t* rec = planes + 3 * (numPics - 2);
         const uint64_t s = tileAddr(tile);
-        (void)hipMemcpy2DAsync((void*)(uintptr_t)(rec[0] + ((size_t)y * stride + x) * isz), stride * isz, (const void*)(uintptr_t)s, 64 * isz, w * isz, h, hipMemcpyDeviceToDevice, st);
+        XaRects r;
+        r.n = 3;
+        r.dst[0] = rec[0] + ((size_t)y * stride + x) * isz; r.src[0] = s; r.dst_stride[0] = (int32_t)stride; r.src_stride[0] = 64; r.w[0] = w; r.h[0] = h;
         for (int p = 0; p < 2; p++)
-            (void)hipMemcpy2DAsync((void*)(uintptr_t)(rec[1 + p] + ((size_t)(y / 2) * cstride + x / 2) * isz), cstride * isz,
-                                   (const void*)(uintptr_t)(s + (4096 + p * 1024) * isz), 32 * isz, w / 2 * isz, h / 2, hipMemcpyDeviceToDevice, st);
+        {
+            r.dst[1 + p] = rec[1 + p] + ((size_t)(y / 2) * cstride + x / 2) * isz; r.src[1 + p] = s + (4096 + p * 1024) * isz;
+            r.dst_stride[1 + p] = (int32_t)cstride; r.src_stride[1 + p] = 32; r.w[1 + p] = w / 2; r.h[1 + p] = h / 2;
+        }
+        xa_copy_rects(st, r);
     }
 
     /* ---- CU bookkeeping ---- */

@@ -777,6 +777,24 @@ extern "C" int x265amd_measure_tiles(void* stream_, const uint64_t* h_src, intpt
     return X265AMD_OK;
 }
 
+extern "C" int x265amd_measure_tile_list(void* stream_, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                                         const uint64_t* tile_addrs, x265amd_cu_measure* out)
+{
+    if (!h_src || !cus || !tile_addrs || !out || n < 0) return xa_fail(X265AMD_EINVAL, "measure_tile_list: null argument");
+    if (n == 0) return X265AMD_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    XaMapped mJobs, mMeas;
+    XA_HIP_CHECK(mJobs.alloc(sizeof(CuMeasureJob) * n));
+    XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
+    CuMeasureJob* jobs = (CuMeasureJob*)mJobs.p;
+    for (int i = 0; i < n; i++) fill_measure_jobs(jobs + i, cus + i, 1, h_src, stride, cstride, tile_addrs[i], tile_addrs[i], 0, nullptr, 0, nullptr);
+    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)jobs, n, (x265amd_cu_measure*)mMeas.p);
+    XA_HIP_CHECK(hipGetLastError());
+    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    memcpy(out, mMeas.p, sizeof(x265amd_cu_measure) * n);
+    return X265AMD_OK;
+}
+
 extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
                                const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
                                x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, x265amd_rd_result* out)

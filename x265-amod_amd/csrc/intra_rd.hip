@@ -160,8 +160,17 @@ struct IntraRd
     }
     void copy2D(uint64_t dst, size_t dstStride, uint64_t s, size_t srcStride, int w, int h)
     {
-        const size_t isz = sizeof(pixel);
-        (void)hipMemcpy2DAsync((void*)(uintptr_t)dst, dstStride * isz, (const void*)(uintptr_t)s, srcStride * isz, w * isz, h, hipMemcpyDeviceToDevice, st);
+        XaRects r;
+        r.n = 1; r.dst[0] = dst; r.src[0] = s; r.dst_stride[0] = (int32_t)dstStride; r.src_stride[0] = (int32_t)srcStride; r.w[0] = w; r.h[0] = h;
+        xa_copy_rects(st, r);
+    }
+    void copy2Dx2(uint64_t dst0, size_t dstStride0, uint64_t s0, size_t srcStride0, uint64_t dst1, size_t dstStride1, uint64_t s1, size_t srcStride1, int w, int h)
+    {
+        XaRects r;
+        r.n = 2;
+        r.dst[0] = dst0; r.src[0] = s0; r.dst_stride[0] = (int32_t)dstStride0; r.src_stride[0] = (int32_t)srcStride0; r.w[0] = w; r.h[0] = h;
+        r.dst[1] = dst1; r.src[1] = s1; r.dst_stride[1] = (int32_t)dstStride1; r.src_stride[1] = (int32_t)srcStride1; r.w[1] = w; r.h[1] = h;
+        xa_copy_rects(st, r);
     }
 
     /* ---- luma ---- */
@@ -189,8 +198,7 @@ struct IntraRd
                 memcpy(lv, pre.lv, sizeof(int16_t) * trSize * trSize);
                 if (pre.copyBlocks)
                 {
-                    copy2D(layerRecon, 64, pre.recon, trSize, trSize, trSize);
-                    copy2D(predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, pre.pred, trSize, trSize, trSize);
+                    copy2Dx2(layerRecon, 64, pre.recon, trSize, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, pre.pred, trSize, trSize, trSize);
                 }
             }
             else if (runJobs(&job, 1, &r, &lv, trSize * trSize)) return err;
@@ -589,8 +597,7 @@ struct IntraRd
                 /* the winner's reconstruction is the CU's; the picture keeps the last tried mode's, as after the reference's loop */
                 const uint64_t bestSlot = (uint64_t)(uintptr_t)dCand.p + (size_t)(bestK * 2 + p - 1) * 2048 * isz;
                 const uint64_t lastSlot = (uint64_t)(uintptr_t)dCand.p + (size_t)(4 * 2 + p - 1) * 2048 * isz;
-                copy2D(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, bestSlot, nC, nC, nC);
-                copy2D(rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, lastSlot, nC, nC, nC);
+                copy2Dx2(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, bestSlot, nC, rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, lastSlot, nC, nC, nC);
             }
         totalDistortion = bestDist;
         load(cur);

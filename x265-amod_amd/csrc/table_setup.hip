@@ -239,3 +239,24 @@ extern "C" void x265amd_release_scratch(void)
         for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipHostFree(q); P.size_.erase(q); } kv.second.clear(); }
     }
 }
+
+
+/* ---- xa_copy_rects (x265amd_host.h) ---- */
+__global__ __launch_bounds__(256) void k_copy_rects(XaRects r)
+{
+    const int k = blockIdx.x;
+    if (k >= r.n) return;
+    const x265amd_pixel* src = reinterpret_cast<const x265amd_pixel*>(r.src[k]);
+    x265amd_pixel* dst = reinterpret_cast<x265amd_pixel*>(r.dst[k]);
+    const int w = r.w[k], total = w * r.h[k];
+    for (int i = threadIdx.x; i < total; i += 256)
+    {
+        const int y = i / w, x = i - y * w;
+        dst[(size_t)y * r.dst_stride[k] + x] = src[(size_t)y * r.src_stride[k] + x];
+    }
+}
+void xa_copy_rects(hipStream_t st, const XaRects& r)
+{
+    if (r.n <= 0) return;
+    hipLaunchKernelGGL(k_copy_rects, dim3(r.n), dim3(256), 0, st, r);
+}

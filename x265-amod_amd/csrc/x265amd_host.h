@@ -32,6 +32,11 @@ struct XaMapped
 };
 #endif
 
+/* up to three 2-D sample copies (device to device) as ONE launch: the three planes of a tile, or a prediction / reconstruction pair.
+ * Strides and sizes in samples. */
+struct XaRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };
+void xa_copy_rects(hipStream_t st, const XaRects& r);
+
 /* The reference's primitive slots cannot report failure (primitives.h:133-236), so a HIP error inside a
  * per-slot entry point is fatal: there is deliberately no CPU fallback. */
 #define XA_HIP_FATAL(expr)                                                                                   \
