@@ -26,6 +26,18 @@
 
 using namespace xa_inter;
 
+#include <chrono>
+/* X265AMD_TIMING=1: wall time per analysis stage, printed per frame by x265amd_analyse_frame */
+static double g_stageMs[8];
+static const char* const g_stageName[8] = { "merge", "search", "rdInter", "rdIntra", "bidir", "copies", "intraSlice", "other" };
+static bool g_timing = getenv("X265AMD_TIMING") != nullptr;
+struct StageTimer
+{
+    int k; std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(int k_) : k(k_) { if (g_timing) t0 = std::chrono::steady_clock::now(); }
+    ~StageTimer() { if (g_timing) g_stageMs[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 namespace {
 
 #if X265AMD_DEPTH < 10
@@ -240,6 +252,7 @@ struct Analyzer
     /* RD of one candidate through the batch entry points (n = 1) */
     int rdInter(Mode& m, int x, int y, int depth, bool skipOnly)
     {
+        StageTimer timer_(2);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
         c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
@@ -267,6 +280,7 @@ struct Analyzer
     /* checkIntraInInter + encodeIntraInInter */
     int rdIntra(Mode& m, int x, int y, int depth, int slot = PRED_INTRA, bool full = false, int partSize = 0)
     {
+        StageTimer timer_(3);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
         c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
@@ -370,6 +384,7 @@ struct Analyzer
     /* checkMerge2Nx2N_rd0_4 */
     int checkMerge(int x, int y, int depth)
     {
+        StageTimer timer_(0);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
         Mode* tempPred = &d.pred[PRED_MERGE];
@@ -421,6 +436,7 @@ struct Analyzer
     /* checkInter_rd0_4(2Nx2N) + checkBidir2Nx2N; searchOnly: predInterSearch alone (checkInter_rd5_6 runs the RD itself, the bi-prediction try comes later) */
     int checkInter(int x, int y, int depth, uint32_t refMask, bool searchOnly = false)
     {
+        StageTimer timer_(1);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
         Mode& inter = d.pred[PRED_2Nx2N];
@@ -454,6 +470,7 @@ struct Analyzer
     /* checkBidir2Nx2N (analysis.cpp:3145-3277) on what the 2Nx2N search left in Mode::bestME */
     int checkBidir(int x, int y, int depth)
     {
+        StageTimer timer_(4);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
         Mode& bidir = d.pred[PRED_BIDIR];
@@ -526,6 +543,7 @@ struct Analyzer
     /* checkInter_rd0_4 for a two-part CU (rect / AMP): predInterSearch of both PUs, then the SA8D of the whole CU's prediction */
     int checkInterPart(int x, int y, int depth, int part, int slot, const uint32_t refMasks[2], bool searchOnly = false)
     {
+        StageTimer timer_(1);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2, n4 = size >> 2;
         Mode& m = d.pred[slot];
@@ -584,6 +602,7 @@ struct Analyzer
     /* checkMerge2Nx2N_rd5_6 (analysis.cpp:2883-3019): every merge candidate by RD, with residual until one codes without, and as a skip */
     int checkMerge56(int x, int y, int depth)
     {
+        StageTimer timer_(0);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
         Mode* tempPred = &d.pred[PRED_MERGE];
@@ -1177,6 +1196,12 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
         if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], rowCoder->ctx, X265AMD_CTX_STRIDE);
     }
     for (x265amd_cabac* c : rows) x265amd_cabac_close(c);
+    if (g_timing)
+    {
+        fprintf(stderr, "x265amd: analysis stages (ms):");
+        for (int k = 0; k < 5; k++) { fprintf(stderr, " %s %.1f", g_stageName[k], g_stageMs[k]); g_stageMs[k] = 0; }
+        fprintf(stderr, "\n");
+    }
     if (rc == X265AMD_OK && slice_data && substream_sizes && num_substreams)
     {
         if (A->use_sao) return xa_fail(X265AMD_EINVAL, "analyse_frame: with SAO the slice data follows the SAO decision: call x265amd_encode_slice_data afterwards");
