@@ -26,7 +26,11 @@
 
 using namespace xa_inter;
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 /* X265AMD_TIMING=1: wall time per analysis stage, printed per frame by x265amd_analyse_frame */
 static double g_stageMs[8];
 static const char* const g_stageName[8] = { "merge", "search", "rdInter", "rdIntra", "bidir", "copies", "intraSlice", "other" };
@@ -1176,8 +1180,8 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
     }
     std::vector<uint8_t> buffered((size_t)ctuH * X265AMD_CTX_STRIDE, 0);
     int rc = X265AMD_OK;
-    for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
-    {
+    /* one CTU: analysis with the row coder's state, then the row coder codes it (bits only) to carry the contexts on */
+    auto doCtu = [&](int addr, void* st) -> int {
         const int row = addr / ctuW, colIdx = addr % ctuW;
         x265amd_cabac* rowCoder = rows[wpp ? row : 0];
         if (wpp && !colIdx && row)
@@ -1188,12 +1192,74 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
         }
         x265amd_ctu_result res;
         int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
-        rc = x265amd_compress_ctu_inter(me, stream, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
-                                        rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res);
-        if (rc != X265AMD_OK) break;
+        int r = x265amd_compress_ctu_inter(me, st, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
+                                           rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res);
+        if (r != X265AMD_OK) return r;
         if (results) results[addr] = res;
-        rc = x265amd_cabac_encode_ctu(rowCoder, addr, coeff, coeff + 4096, coeff + 5120);
+        r = x265amd_cabac_encode_ctu(rowCoder, addr, coeff, coeff + 4096, coeff + 5120);
         if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], rowCoder->ctx, X265AMD_CTX_STRIDE);
+        return r;
+    };
+    int rowThreads = 1;
+    if (wpp && ctuH > 1 && ctuW > 1)
+    {
+        const char* e = getenv("X265AMD_ROW_THREADS");
+        rowThreads = e ? atoi(e) : 16;
+        if (rowThreads > ctuH) rowThreads = ctuH;
+    }
+    if (rowThreads <= 1)
+    {
+        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++) rc = doCtu(addr, stream);
+    }
+    else
+    {
+        /* Wavefront parallel processing as the reference's row threads run it (frameencoder.cpp:1399-1968): CTU (r, c) starts when (r - 1, c + 1)
+         * is finished -- its neighbours' decisions, reconstruction, cost statistics and the contexts saved after (r - 1, 1) are then final, so
+         * every CTU sees exactly what the serial order shows it.  One host thread and one HIP stream per row in flight; the block operations of
+         * different rows overlap on the device. */
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
+        std::vector<int> done((size_t)ctuH, 0);
+        std::mutex m;
+        std::condition_variable cv;
+        std::atomic<int> nextRow(0), firstErr(X265AMD_OK);
+        auto worker = [&]() {
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { firstErr = xa_fail(X265AMD_EHIP, "analyse_frame: stream"); cv.notify_all(); return; }
+            for (;;)
+            {
+                const int row = nextRow.fetch_add(1);
+                if (row >= ctuH) break;
+                for (int c = 0; c < ctuW; c++)
+                {
+                    if (row)
+                    {
+                        const int need = c + 2 < ctuW ? c + 2 : ctuW;
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return done[row - 1] >= need || firstErr.load() != X265AMD_OK; });
+                    }
+                    int r = firstErr.load();
+                    if (r == X265AMD_OK) r = doCtu(row * ctuW + c, st);
+                    if (r == X265AMD_OK && hipStreamSynchronize(st) != hipSuccess) r = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (r != X265AMD_OK) { int ok = X265AMD_OK; firstErr.compare_exchange_strong(ok, r); }
+                        done[row] = c + 1;
+                    }
+                    cv.notify_all();
+                    if (r != X265AMD_OK) break;
+                }
+                if (firstErr.load() != X265AMD_OK) { std::lock_guard<std::mutex> lk(m); done[row] = ctuW; cv.notify_all(); }
+            }
+            (void)hipStreamDestroy(st);
+        };
+        if (rc == X265AMD_OK)
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < rowThreads; t++) pool.emplace_back(worker);
+            for (auto& t : pool) t.join();
+            rc = firstErr.load();
+            if (rc != X265AMD_OK) xa_fail(rc, "analyse_frame: a CTU row failed");
+        }
     }
     for (x265amd_cabac* c : rows) x265amd_cabac_close(c);
     if (g_timing)
