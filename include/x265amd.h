@@ -789,6 +789,18 @@ int x265amd_encode_slice_data(const x265amd_slice_info* si, x265amd_cu_unit* uni
 int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
                     const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags);
 
+/* --- lookahead lowres pipeline, first stage.
+ * x265amd_lowres_init = Lowres::init (reference: source/common/lowres.cpp:337-403): frame_init_lowres_core (source/common/pixel.cpp:605-628) from the
+ * padded full-resolution luma plane (d_src = its sample (0,0); the filter reads one sample beyond the right and bottom edge, i.e. the margin)
+ * into the four lowres planes (d_planes[k] = sample (0,0) of fpel, H, V, C), then extendPicBorder of each.  width / height: of the lowres picture.
+ * x265amd_lowres_intra_costs = LookaheadTLD::lowresIntraEstimate (source/encoder/slicetype.cpp:715-824), per 8x8 block of the lowres picture:
+ * d_cost[cuXY] = Lowres::intraCost (best SATD + 5 * lambda + 4), d_mode[cuXY] = Lowres::intraMode; lambda = (int)x265_lambda_tab[X265_LOOKAHEAD_QP], X265_LOOKAHEAD_QP = 12 + 6 * (bit depth - 8) (common/common.h:213): 1 for 8-bit, 16 for 10-bit.
+ * The frame sums (costEst, costEstAq, rowSatds, lowresCosts) are the caller's reduction over these.  Asynchronous. */
+int x265amd_lowres_init(void* stream, const x265amd_pixel* d_src, intptr_t src_stride, int width, int height, x265amd_pixel* const d_planes[4],
+                        intptr_t stride, int marginX, int marginY);
+int x265amd_lowres_intra_costs(void* stream, const x265amd_pixel* d_plane, intptr_t stride, int width_in_cu, int height_in_cu, int lambda,
+                               int32_t* d_cost, uint8_t* d_mode);
+
 /* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
 void x265amd_release_scratch(void);
 

@@ -14,6 +14,7 @@
 #include "bitstream.h"
 #include "search.h"
 #include "analysis.h"
+#include "slicetype.h"
 #include <vector>
 #include "frame.h"
 #include "x265.h"
@@ -1692,6 +1693,35 @@ int ref_intra_scan_batch(const PackedIntraJob* jobs, int n, int32_t* sa8d)
         ref_intra_scan((const pixel*)j.fenc, j.fencStride, j.log2, rb, j.log2 >= 3 ? fb : rb, sa8d + 35 * i);
     }
     return n;
+}
+
+/* ---- lookahead lowres pipeline: the reference's own Lowres::init steps and LookaheadTLD::lowresIntraEstimate ---- */
+/* src / planes[k]: sample (0,0) of padded planes */
+void ref_lowres_init(const pixel* src, intptr_t srcStride, int width, int height, pixel* p0, pixel* ph, pixel* pv, pixel* pc, intptr_t stride, int marginX, int marginY)
+{
+    ensure();
+    g_p.frameInitLowres(src, p0, ph, pv, pc, srcStride, stride, width, height);      /* lowres.cpp:368-376 */
+    extendPicBorder(p0, stride, width, height, marginX, marginY);
+    extendPicBorder(ph, stride, width, height, marginX, marginY);
+    extendPicBorder(pv, stride, width, height, marginX, marginY);
+    extendPicBorder(pc, stride, width, height, marginX, marginY);
+}
+
+/* out: intraCost[ncu], intraMode[ncu], rowSatds[heightInCU], lowresCosts[ncu]; sums[0] = costEst[0][0], sums[1] = costEstAq[0][0].  No AQ (invQscaleFactor NULL). */
+void ref_lowres_intra(pixel* plane0, intptr_t stride, int widthInCU, int heightInCU, int32_t* intraCost, uint8_t* intraMode, int32_t* rowSatds, uint16_t* lowresCosts,
+                      int64_t* sums)
+{
+    ensure();
+    static LookaheadTLD* tld = new LookaheadTLD;
+    tld->init(widthInCU, heightInCU, widthInCU * heightInCU);
+    Lowres* fenc = (Lowres*)calloc(1, sizeof(Lowres));
+    fenc->lowresPlane[0] = plane0; fenc->lumaStride = stride;
+    fenc->intraCost = intraCost; fenc->intraMode = intraMode;
+    fenc->rowSatds[0][0] = rowSatds; fenc->lowresCosts[0][0] = lowresCosts;
+    fenc->invQscaleFactor = NULL;
+    tld->lowresIntraEstimate(*fenc, 16);
+    sums[0] = fenc->costEst[0][0]; sums[1] = fenc->costEstAq[0][0];
+    free(fenc);
 }
 
 } /* extern "C" */

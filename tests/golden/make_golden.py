@@ -378,6 +378,21 @@ def _frame_pipeline_one(frames, stride, cstride, org, tag, cli, out, nframes=4):
     assert k == nframes, k
 
 
+def make_lowres_golden():
+    """Lowres::init planes (digests) and LookaheadTLD::lowresIntraEstimate outputs of the reference -> tests/golden/lowres_golden.npz"""
+    import importlib.util, hashlib
+    spec = importlib.util.spec_from_file_location("tl", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_lowres.py"))
+    tl = importlib.util.module_from_spec(spec); spec.loader.exec_module(tl)
+    out = {}
+    for k, (depth, seed, crop) in enumerate(tl.CASES):
+        c = T.lowres_case(depth, seed, crop)
+        planes, cost, mode, rows, lc, sums = T.lowres_run_ref(T.load_ref(depth), c)
+        out["%d/plane_md5" % k] = np.array([hashlib.md5(np.ascontiguousarray(p).tobytes()).hexdigest() for p in planes])
+        out["%d/cost" % k], out["%d/mode" % k], out["%d/row_satds" % k], out["%d/lowres_costs" % k], out["%d/sums" % k] = cost, mode, rows, lc, sums
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "lowres_golden.npz"), **out)
+    print("wrote lowres_golden.npz with", len(out), "arrays")
+
+
 def make_encoder_api_golden():
     """whole streams + per-frame reconstruction digests of the reference encoder for clips the frame-pipeline goldens do not cover:
     picture sizes that are not multiples of the CTU size (partial CTUs at the right / bottom edge) and a 14-frame clip (the DPB evicts

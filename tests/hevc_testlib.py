@@ -3075,3 +3075,69 @@ def encoder_api_clip(tag, w, h, nframes, depth=8):
             planes.append(np.clip(core, 0, pmax).astype(dt))
         frames.append(planes)
     return frames
+
+
+# ---- lookahead lowres pipeline (x265amd_lowres_init / x265amd_lowres_intra_costs vs Lowres::init / LookaheadTLD::lowresIntraEstimate) ----
+LOWRES_LAMBDA = {8: 1, 10: 16}      # (int)x265_lambda_tab[X265_LOOKAHEAD_QP], X265_LOOKAHEAD_QP = 12 + 6 * (X265_DEPTH - 8) (common/constants.cpp, common/common.h:213)
+
+
+def lowres_case(depth, seed, crop=(0, 0)):
+    """padded full-resolution luma plane of inter_scene and the lowres geometry (half size, same margins)"""
+    pics, stride, cstride, org = inter_scene(depth, seed, npics=1)
+    W, H = MC_W - crop[0], MC_H - crop[1]
+    luma = pics[0][:(MC_H + 2 * MC_MY) * stride].reshape(-1, stride).copy()
+    if crop != (0, 0):      # a smaller picture inside the same buffer: re-extend its borders
+        core = luma[MC_MY:MC_MY + H, MC_MX:MC_MX + W]
+        luma = np.pad(core, ((MC_MY, MC_MY + crop[1]), (MC_MX, MC_MX + crop[0])), mode="edge")
+    lw, lh = W // 2, H // 2
+    lstride = lw + 2 * MC_MX
+    return dict(depth=depth, luma=np.ascontiguousarray(luma), stride=stride, W=W, H=H, lw=lw, lh=lh, lstride=lstride, rows=lh + 2 * MC_MY,
+                wcu=(lw + 7) >> 3, hcu=(lh + 7) >> 3)
+
+
+def lowres_run_ref(R, c):
+    dt = c["luma"].dtype
+    planes = [np.zeros((c["rows"], c["lstride"]), dt) for _ in range(4)]
+    o = MC_MY * c["lstride"] + MC_MX
+    isz = dt.itemsize
+    src0 = c["luma"].ctypes.data + (MC_MY * c["stride"] + MC_MX) * isz
+    R.lib.ref_lowres_init.restype = None
+    R.lib.ref_lowres_init(C.c_void_p(src0), C.c_int64(c["stride"]), c["lw"], c["lh"], *[C.c_void_p(p.ctypes.data + o * isz) for p in planes], C.c_int64(c["lstride"]),
+                          MC_MX, MC_MY)
+    ncu = c["wcu"] * c["hcu"]
+    cost = np.zeros(ncu, np.int32); mode = np.zeros(ncu, np.uint8); rows = np.zeros(c["hcu"], np.int32); lc = np.zeros(ncu, np.uint16); sums = np.zeros(2, np.int64)
+    R.lib.ref_lowres_intra.restype = None
+    R.lib.ref_lowres_intra(C.c_void_p(planes[0].ctypes.data + o * isz), C.c_int64(c["lstride"]), c["wcu"], c["hcu"], _ptr(cost), _ptr(mode), _ptr(rows), _ptr(lc), _ptr(sums))
+    return planes, cost, mode, rows, lc, sums
+
+
+def lowres_frame_sums(c, cost):
+    """the caller's reduction of lowresIntraEstimate without AQ (slicetype.cpp:797-823): lowresCosts, rowSatds, costEst"""
+    wcu, hcu = c["wcu"], c["hcu"]
+    cc = cost.reshape(hcu, wcu).astype(np.int64)
+    inner = np.zeros((hcu, wcu), bool)
+    inner[1:hcu - 1, 1:wcu - 1] = True
+    if wcu <= 2 or hcu <= 2:
+        inner[:] = True
+    return np.minimum(cost, 0x3FFF).astype(np.uint16), cc.sum(1).astype(np.int32), int(cc[inner].sum())
+
+
+def lowres_run_hip(L, c):
+    import torch
+    dt = c["luma"].dtype
+    isz = dt.itemsize
+    d_src = torch.from_numpy(c["luma"].view(np.uint8)).cuda()
+    d_planes = [torch.zeros(c["rows"] * c["lstride"] * isz, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    o = (MC_MY * c["lstride"] + MC_MX) * isz
+    ptrs = (C.c_void_p * 4)(*[p.data_ptr() + o for p in d_planes])
+    rc = L.lib.x265amd_lowres_init(None, C.c_void_p(d_src.data_ptr() + (MC_MY * c["stride"] + MC_MX) * isz), C.c_int64(c["stride"]), c["lw"], c["lh"], ptrs,
+                                   C.c_int64(c["lstride"]), MC_MX, MC_MY)
+    assert rc == 0
+    ncu = c["wcu"] * c["hcu"]
+    d_cost = torch.zeros(ncu, dtype=torch.int32, device="cuda"); d_mode = torch.zeros(ncu, dtype=torch.uint8, device="cuda")
+    rc = L.lib.x265amd_lowres_intra_costs(None, C.c_void_p(d_planes[0].data_ptr() + o), C.c_int64(c["lstride"]), c["wcu"], c["hcu"], LOWRES_LAMBDA[c["depth"]],
+                                          C.c_void_p(d_cost.data_ptr()), C.c_void_p(d_mode.data_ptr()))
+    assert rc == 0
+    torch.cuda.synchronize()
+    planes = [p.cpu().numpy().view(dt).reshape(c["rows"], c["lstride"]) for p in d_planes]
+    return planes, d_cost.cpu().numpy(), d_mode.cpu().numpy()
