@@ -386,7 +386,7 @@ def measured_traffic(kernel="k_me_search"):
     """HBM bytes per launch of a kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately:
     counters cannot be read inside the bench); the summary is committed under profiles/"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_analysis11_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_analysis12_traffic.json")) as f:
             return json.load(f)[kernel]["hbm_bytes_per_launch_uncorrected"]
     except (OSError, KeyError, ValueError):
         return None
@@ -709,7 +709,7 @@ def main():
         line["parity_sample"] = {"checked": checked, "bit_exact_vs_oracle": bool(ok and tu_ok and in_ok and more_ok[0] and flt_ok),
                                  "me": bool(ok), "tu_chain": bool(tu_ok), "intra_scan": bool(in_ok), "inter_cost_intra_tu_coeff_bits": bool(more_ok[0]),
                                  "in_loop_filters_whole_picture": bool(flt_ok)}
-        if world == 1:
+        if world == 1 and not args.no_cpu_baseline:         # profiling passes (--no-cpu-baseline) keep to the timed kernels
             line["encoder_pipeline"] = encoder_pipeline_sample(T)
         print(json.dumps(line))
     if world > 1:
