@@ -88,3 +88,44 @@ def test_encoder_object_partial_ctus_and_long_clip(tag):
         assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
     want = g[tag + "stream"]
     assert len(stream) == len(want) and hashlib.md5(stream.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+
+
+def _write_y4m(path, frames, w, h, depth):
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
+        for fr in frames:
+            f.write(b"FRAME\n")
+            for pl in fr:
+                f.write(np.ascontiguousarray(pl).tobytes())
+
+
+CLI = os.path.join(os.path.dirname(T.GOLDEN_DIR), "..", "x265-amod_amd", "bin", "x265amd")
+
+
+def test_cli_is_built():
+    assert os.path.exists(CLI), "x265-amod_amd/build.sh builds bin/x265amd"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["sao_bframes/", "hbd_b/"])
+def test_command_line_program_reproduces_reference_stream(tag, tmp_path):
+    """x265-amod_amd/bin/x265amd (y4m in, .hevc + reconstruction out; it loads the 8- or 10-bit library by the input's depth) against the reference
+    command line program's output for the same clip and options"""
+    import subprocess
+    if tag == "hbd_b/":
+        (w, h), n, _ = EDGE_CONFIGS[tag]
+        frames, depth = T.encoder_api_clip(tag, w, h, n, 10), 10
+        want = np.load(EDGE_GOLD)[tag + "stream"]
+        opts = ["--bframes", "2", "--sao", "--rect", "--amp", "--no-wpp"]
+    else:
+        w, h, depth = T.MC_W, T.MC_H, 8
+        frames = display_frames(tag)
+        want = np.load(GOLD_PATH)[tag + "stream"]
+        opts = ["--bframes", "2", "--sao", "--no-wpp"]
+    _write_y4m(tmp_path / "clip.y4m", frames, w, h, depth)
+    r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc"), "--recon", str(tmp_path / "rec.yuv"), "--qp", "30"] + opts,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(tmp_path / "out.hevc", np.uint8)
+    assert len(got) == len(want) and hashlib.md5(got.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+    assert os.path.getsize(tmp_path / "rec.yuv") == len(frames) * w * h * 3 // 2 * (2 if depth == 10 else 1)

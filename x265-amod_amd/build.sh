@@ -33,4 +33,9 @@ build_one() {
 for d in ${X265AMD_DEPTHS:-8 10}; do
     if [ "$d" = 8 ]; then build_one 8 libx265amd_main.so; else build_one "$d" libx265amd_main$d.so; fi
 done
-echo "built: $(ls "$OUT"/*.so | tr '\n' ' ')"
+# command line front end (host C++; loads the library for the input's bit depth with dlopen)
+mkdir -p "$HERE/bin"
+if [ ! -f "$HERE/bin/x265amd" ] || [ "$HERE/cli/x265amd_cli.cpp" -nt "$HERE/bin/x265amd" ] || [ "$HERE/../include/x265amd_encoder.h" -nt "$HERE/bin/x265amd" ]; then
+    g++ -O2 -std=c++17 -Wall -o "$HERE/bin/x265amd" "$HERE/cli/x265amd_cli.cpp" -ldl
+fi
+echo "built: $(ls "$OUT"/*.so | tr '\n' ' ') $HERE/bin/x265amd"
