@@ -801,6 +801,19 @@ int x265amd_lowres_init(void* stream, const x265amd_pixel* d_src, intptr_t src_s
 int x265amd_lowres_intra_costs(void* stream, const x265amd_pixel* d_plane, intptr_t stride, int width_in_cu, int height_in_cu, int lambda,
                                int32_t* d_cost, uint8_t* d_mode);
 
+/* x265amd_lowres_frame_cost = the block loop of CostEstimateGroup::estimateFrameCost (reference: source/encoder/slicetype.cpp:4050-4059) with
+ * estimateCUCost (:4077-4249) for every 8x8 block of the lowres picture against reference p0 (d_ref0: fpel, H, V, C planes) and, for a B candidate,
+ * p1 (d_ref1, else NULL): neighbour MV predictors by SATD, MotionEstimate::motionEstimate in its lowres form (hexagon, merange 16, subme 1 on the four
+ * half-pel planes; source/encoder/motion.cpp), the bi-prediction and co-located averages, the intra alternative for P.  do_search: the MVs of that list are
+ * still unknown (Lowres::lowresMvs[..][0].x == 0x7FFF); otherwise d_mvs / d_mv_costs are read.  Outputs per block: d_mvs (quarter-pel x, y),
+ * d_mv_costs, d_lowres_costs (Lowres::lowresCosts: min(cost, 0x3FFF) | lists used << 14), d_bcost (the unclipped cost); the frame sums (costEst,
+ * intraMbs, rowSatds) are the caller's reduction.  d_progress: height_in_cu ints of scratch.  No AQ, weighted prediction, HME or cooperative slices.
+ * Asynchronous after a short synchronous set-up. */
+int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref0[4],
+                              const x265amd_pixel* const d_ref1[4], intptr_t stride, int width_in_cu, int height_in_cu, int do_search0, int do_search1,
+                              const int32_t* d_intra_cost, int16_t* d_mvs0, int32_t* d_mv_costs0, int16_t* d_mvs1, int32_t* d_mv_costs1,
+                              uint16_t* d_lowres_costs, int32_t* d_bcost, int32_t* d_progress);
+
 /* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
 void x265amd_release_scratch(void);
 

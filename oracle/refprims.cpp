@@ -1724,4 +1724,63 @@ void ref_lowres_intra(pixel* plane0, intptr_t stride, int widthInCU, int heightI
     free(fenc);
 }
 
+/* ---- lookahead frame cost: the reference's own CostEstimateGroup::estimateFrameCost (slicetype.cpp:3976-4075) on Lowres objects made by
+ * Lowres::create / init from three padded luma planes (frames[0..2] in display order).  No AQ, weighted prediction, HME or cooperative slices. ---- */
+namespace {
+struct CostGroup : public CostEstimateGroup
+{
+    CostGroup(Lookahead& l, Lowres** f) : CostEstimateGroup(l, f) {}
+    int64_t run(LookaheadTLD& tld, int p0, int p1, int b) { return estimateFrameCost(tld, p0, p1, b, false); }
+};
+}
+/* luma[k]: sample (0,0) of frame k's padded luma plane.  out arrays sized by the 8x8 grid of the half-resolution picture (ncu = wcu * hcu):
+ * lowresCosts u16[ncu], mvs i16[2][ncu][2], mvCosts i32[2][ncu], intraCost i32[ncu], rowSatds i32[hcu]; sums: score, costEst before scaling is not kept by the
+ * reference, so sums[0] = returned score, sums[1] = costEstAq, sums[2] = intraMbs[b - p0] */
+int ref_lowres_frame_cost(const pixel* const* luma, intptr_t stride, int width, int height, int marginX, int marginY, int p0, int b, int p1, int bframes,
+                          uint16_t* lowresCosts, int16_t* mvs, int32_t* mvCosts, int32_t* intraCost, int32_t* rowSatds, int64_t* sums)
+{
+    ensure();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420; param->bframes = bframes;
+    param->bEnableWeightedPred = 0; param->bEnableWeightedBiPred = 0; param->rc.aqMode = 0; param->rc.cuTree = 0; param->lookaheadSlices = 0; param->bEnableHME = 0;
+    param->maxSlices = 1; param->bFrameBias = 0; param->rc.qgSize = 32; param->bEnableTemporalFilter = 0;
+    Lookahead* la = new Lookahead(param, NULL);
+    Lowres* frames[3];
+    PicYuv* pics[3];
+    for (int k = 0; k < 3; k++)
+    {
+        pics[k] = new PicYuv;
+        pics[k]->m_param = param; pics[k]->m_picWidth = width; pics[k]->m_picHeight = height; pics[k]->m_lumaMarginX = marginX; pics[k]->m_lumaMarginY = marginY;
+        pics[k]->m_stride = stride; pics[k]->m_picOrg[0] = const_cast<pixel*>(luma[k]);
+        frames[k] = new Lowres();
+        if (!frames[k]->create(param, pics[k], param->rc.qgSize)) return -1;
+        frames[k]->init(pics[k], k);
+    }
+    const int wcu = la->m_8x8Width, hcu = la->m_8x8Height, ncu = wcu * hcu;
+    LookaheadTLD* tld = new LookaheadTLD;
+    tld->init(wcu, hcu, ncu);
+    for (int k = 0; k < 3; k++) tld->lowresIntraEstimate(*frames[k], param->rc.qgSize);       /* PreLookaheadGroup::processTasks (slicetype.cpp:1745-1762) */
+    CostGroup g(*la, frames);
+    const int64_t score = g.run(*tld, p0, p1, b);
+    Lowres* f = frames[b];
+    memcpy(lowresCosts, f->lowresCosts[b - p0][p1 - b], sizeof(uint16_t) * ncu);
+    for (int l = 0; l < 2; l++)
+    {
+        const int dist = l ? p1 - b : b - p0;
+        for (int i = 0; i < ncu; i++)
+        {
+            const bool have = l ? p1 > b : b > p0;
+            mvs[(l * ncu + i) * 2] = have ? f->lowresMvs[l][dist][i].x : 0; mvs[(l * ncu + i) * 2 + 1] = have ? f->lowresMvs[l][dist][i].y : 0;
+            mvCosts[l * ncu + i] = have ? f->lowresMvCosts[l][dist][i] : 0;
+        }
+    }
+    memcpy(intraCost, f->intraCost, sizeof(int32_t) * ncu);
+    memcpy(rowSatds, f->rowSatds[b - p0][p1 - b], sizeof(int32_t) * hcu);
+    sums[0] = score; sums[1] = f->costEstAq[b - p0][p1 - b]; sums[2] = f->intraMbs[b - p0];
+    for (int k = 0; k < 3; k++) { frames[k]->destroy(param); delete frames[k]; pics[k]->m_picOrg[0] = NULL; }
+    delete tld;
+    return ncu;
+}
+
 } /* extern "C" */

@@ -393,6 +393,21 @@ def make_lowres_golden():
     print("wrote lowres_golden.npz with", len(out), "arrays")
 
 
+def make_lowres_cost_golden():
+    """CostEstimateGroup::estimateFrameCost of the reference on Lowres fixtures -> tests/golden/lowres_cost_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tl", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_lowres.py"))
+    tl = importlib.util.module_from_spec(spec); spec.loader.exec_module(tl)
+    out = {}
+    for k, (depth, seed, crop, p0, b, p1) in enumerate(tl.COST_CASES):
+        c = T.lowres_cost_case(depth, seed, crop)
+        r = T.lowres_cost_run_ref(T.load_ref(depth), c, p0, b, p1)
+        for name, a in r.items():
+            out["%d/%s" % (k, name)] = a
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "lowres_cost_golden.npz"), **out)
+    print("wrote lowres_cost_golden.npz with", len(out), "arrays")
+
+
 def make_encoder_api_golden():
     """whole streams + per-frame reconstruction digests of the reference encoder for clips the frame-pipeline goldens do not cover:
     picture sizes that are not multiples of the CTU size (partial CTUs at the right / bottom edge) and a 14-frame clip (the DPB evicts

@@ -3141,3 +3141,93 @@ def lowres_run_hip(L, c):
     torch.cuda.synchronize()
     planes = [p.cpu().numpy().view(dt).reshape(c["rows"], c["lstride"]) for p in d_planes]
     return planes, d_cost.cpu().numpy(), d_mode.cpu().numpy()
+
+
+# ---- lookahead frame cost (x265amd_lowres_frame_cost vs CostEstimateGroup::estimateFrameCost) ----
+def lowres_cost_case(depth, seed, crop=(0, 0)):
+    """three frames (display order) of a scene with global drift plus blocks that move on their own, as padded luma planes"""
+    pics, stride, cstride, org = inter_scene(depth, seed, npics=3)
+    rng = np.random.default_rng(seed + 4711)
+    W, H = MC_W - crop[0], MC_H - crop[1]
+    rows = MC_H + 2 * MC_MY
+    lumas = []
+    base = pics[0][:rows * stride].reshape(rows, stride)
+    for k in range(3):
+        l = pics[k][:rows * stride].reshape(rows, stride).copy()
+        for _ in range(25):
+            bs = int(rng.choice([16, 16, 32, 48]))
+            bx, by = int(rng.integers(0, (W - bs) // 2)) * 2, int(rng.integers(0, (H - bs) // 2)) * 2
+            dx, dy = int(rng.integers(-12, 13)), int(rng.integers(-10, 11))
+            l[MC_MY + by:MC_MY + by + bs, MC_MX + bx:MC_MX + bx + bs] = base[MC_MY + by + dy:MC_MY + by + dy + bs, MC_MX + bx + dx:MC_MX + bx + dx + bs]
+        core = l[MC_MY:MC_MY + H, MC_MX:MC_MX + W]
+        lumas.append(np.ascontiguousarray(np.pad(core, ((MC_MY, MC_MY + crop[1]), (MC_MX, MC_MX + crop[0])), mode="edge")))
+    return dict(depth=depth, lumas=lumas, stride=stride, W=W, H=H, wcu=(W // 2 + 7) >> 3, hcu=(H // 2 + 7) >> 3)
+
+
+def lowres_cost_run_ref(R, c, p0, b, p1):
+    isz = c["lumas"][0].itemsize
+    ptrs = (C.c_void_p * 3)(*[l.ctypes.data + (MC_MY * c["stride"] + MC_MX) * isz for l in c["lumas"]])
+    ncu = c["wcu"] * c["hcu"]
+    lc = np.zeros(ncu, np.uint16); mvs = np.zeros((2, ncu, 2), np.int16); mvc = np.zeros((2, ncu), np.int32); ic = np.zeros(ncu, np.int32)
+    rows = np.zeros(c["hcu"], np.int32); sums = np.zeros(3, np.int64)
+    R.lib.ref_lowres_frame_cost.restype = C.c_int
+    n = R.lib.ref_lowres_frame_cost(ptrs, C.c_int64(c["stride"]), c["W"], c["H"], MC_MX, MC_MY, p0, b, p1, 2, _ptr(lc), _ptr(mvs), _ptr(mvc), _ptr(ic), _ptr(rows), _ptr(sums))
+    assert n == ncu, (n, ncu)
+    return dict(lowres_costs=lc, mvs=mvs, mv_costs=mvc, intra_cost=ic, row_satds=rows, sums=sums)
+
+
+def lowres_cost_sums(c, lowres_costs, bcost, bidir):
+    """the caller's reduction (estimateCUCost tail + estimateFrameCost, slicetype.cpp:4220-4248, :4062-4067): score, intra block count, row sums"""
+    wcu, hcu = c["wcu"], c["hcu"]
+    bc = bcost.reshape(hcu, wcu).astype(np.int64)
+    inner = np.zeros((hcu, wcu), bool)
+    inner[1:hcu - 1, 1:wcu - 1] = True
+    if wcu <= 2 or hcu <= 2:
+        inner[:] = True
+    est = int(bc[inner].sum())
+    intra_mbs = 0 if bidir else int((((lowres_costs.reshape(hcu, wcu) >> 14) == 0) & inner).sum())
+    score = est * 100 // 130 if bidir else est
+    return score, est, intra_mbs, bc.sum(1).astype(np.int32)
+
+
+def lowres_cost_run_hip(L, me, c, p0, b, p1):
+    """Lowres::init of the three frames, intra costs, then the frame cost of b against p0 (and p1 when p1 > b) -- a P cost first when the L0 MVs
+    of that distance are needed, exactly as the reference's estimateFrameCost finds them"""
+    import torch
+    depth = c["depth"]
+    dt = c["lumas"][0].dtype
+    isz = dt.itemsize
+    lw, lh = c["wcu"] * 8, c["hcu"] * 8                 # Lowres::create rounds the lowres size up to whole blocks
+    lstride = (c["W"] // 2) + 2 * MC_MX
+    lstride += (32 - (lstride & 31)) & 31
+    rows = lh + 2 * MC_MY
+    o = (MC_MY * lstride + MC_MX) * isz
+    planes, intra = [], []
+    ncu = c["wcu"] * c["hcu"]
+    for k in range(3):
+        d_src = torch.from_numpy(c["lumas"][k].view(np.uint8)).cuda()
+        d_pl = [torch.zeros(rows * lstride * isz, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        ptrs = (C.c_void_p * 4)(*[p.data_ptr() + o for p in d_pl])
+        assert L.lib.x265amd_lowres_init(None, C.c_void_p(d_src.data_ptr() + (MC_MY * c["stride"] + MC_MX) * isz), C.c_int64(c["stride"]), lw, lh, ptrs, C.c_int64(lstride),
+                                         MC_MX, MC_MY) == 0
+        d_cost = torch.zeros(ncu, dtype=torch.int32, device="cuda"); d_mode = torch.zeros(ncu, dtype=torch.uint8, device="cuda")
+        assert L.lib.x265amd_lowres_intra_costs(None, C.c_void_p(d_pl[0].data_ptr() + o), C.c_int64(lstride), c["wcu"], c["hcu"], LOWRES_LAMBDA[depth],
+                                                C.c_void_p(d_cost.data_ptr()), C.c_void_p(d_mode.data_ptr())) == 0
+        planes.append(d_pl); intra.append(d_cost)
+    torch.cuda.synchronize()
+    bidir = p1 > b
+    d_mvs = [torch.zeros(ncu * 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+    d_mvc = [torch.zeros(ncu, dtype=torch.int32, device="cuda") for _ in range(2)]
+    d_lc = torch.zeros(ncu, dtype=torch.int16, device="cuda"); d_bc = torch.zeros(ncu, dtype=torch.int32, device="cuda"); d_prog = torch.zeros(c["hcu"], dtype=torch.int32, device="cuda")
+    ref0 = (C.c_void_p * 4)(*[p.data_ptr() + o for p in planes[p0]])
+    ref1 = (C.c_void_p * 4)(*[p.data_ptr() + o for p in planes[p1]]) if bidir else None
+    rc = L.lib.x265amd_lowres_frame_cost(None, me.ctx, C.c_void_p(planes[b][0].data_ptr() + o), ref0, ref1, C.c_int64(lstride), c["wcu"], c["hcu"], 1, int(bidir),
+                                         C.c_void_p(intra[b].data_ptr()), C.c_void_p(d_mvs[0].data_ptr()), C.c_void_p(d_mvc[0].data_ptr()),
+                                         C.c_void_p(d_mvs[1].data_ptr()) if bidir else None, C.c_void_p(d_mvc[1].data_ptr()) if bidir else None,
+                                         C.c_void_p(d_lc.data_ptr()), C.c_void_p(d_bc.data_ptr()), C.c_void_p(d_prog.data_ptr()))
+    assert rc == 0, L.lib.x265amd_last_error()
+    torch.cuda.synchronize()
+    lc = d_lc.cpu().numpy().view(np.uint16); bc = d_bc.cpu().numpy()
+    mvs = np.stack([d_mvs[l].cpu().numpy().reshape(ncu, 2) for l in range(2)]); mvc = np.stack([d_mvc[l].cpu().numpy() for l in range(2)])
+    score, est, intra_mbs, rows_ = lowres_cost_sums(c, lc, bc, bidir)
+    return dict(lowres_costs=lc, mvs=mvs, mv_costs=mvc, intra_cost=intra[b].cpu().numpy(), row_satds=rows_, sums=np.array([score, est, intra_mbs], np.int64))

@@ -34,3 +34,31 @@ def test_hip_lowres_matches_reference_golden(k):
         assert hashlib.md5(np.ascontiguousarray(p).tobytes()).hexdigest() == str(g["%d/plane_md5" % k][i]), "lowres plane %d" % i
     assert np.array_equal(cost, g["%d/cost" % k]), np.argwhere(cost != g["%d/cost" % k])[:5].tolist()
     assert np.array_equal(mode, g["%d/mode" % k]), np.argwhere(mode != g["%d/mode" % k])[:5].tolist()
+
+
+COST_GOLD = os.path.join(T.GOLDEN_DIR, "lowres_cost_golden.npz")
+# (bit depth, seed, crop, p0, b, p1): P candidates (p1 == b) and B candidates between two references
+COST_CASES = [(8, 21, (0, 0), 0, 1, 1), (8, 21, (0, 0), 0, 2, 2), (8, 22, (0, 0), 0, 1, 2), (8, 23, (24, 8), 0, 1, 2), (10, 24, (0, 0), 0, 1, 1), (10, 25, (8, 40), 0, 1, 2)]
+
+
+def test_cost_golden_is_varied():
+    g = np.load(COST_GOLD)
+    used = np.zeros(4, np.int64); nmv = 0
+    for k in range(len(COST_CASES)):
+        used += np.bincount(g["%d/lowres_costs" % k] >> 14, minlength=4)
+        nmv += len(np.unique(g["%d/mvs" % k][0], axis=0))
+    assert (used > 20).all() and nmv > 100, (used, nmv)        # intra, L0, L1 and bi-prediction all win somewhere; many different vectors
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(COST_CASES)))
+def test_hip_lowres_frame_cost_matches_reference_golden(k):
+    g = np.load(COST_GOLD)
+    depth, seed, crop, p0, b, p1 = COST_CASES[k]
+    c = T.lowres_cost_case(depth, seed, crop)
+    got = T.lowres_cost_run_hip(T.load_hip(depth), T.HipME(depth), c, p0, b, p1)
+    for name in ("intra_cost", "mvs", "mv_costs", "lowres_costs", "row_satds"):
+        want = g["%d/%s" % (k, name)]
+        assert np.array_equal(got[name], want), (name, np.argwhere(got[name] != want)[:6].tolist())
+    want = g["%d/sums" % k]
+    assert int(got["sums"][0]) == int(want[0]) and int(got["sums"][2]) == int(want[2]), (got["sums"], want)

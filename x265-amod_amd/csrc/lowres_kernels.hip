@@ -11,6 +11,8 @@
  * reference's order (the refinement depends on the coarse scan's winner).  Blocks are independent: one launch covers the picture. */
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
+#include <string.h>
+#include <vector>
 
 __global__ __launch_bounds__(256) void k_lowres_init(const pixel* src, long srcStride, pixel* d0, pixel* dh, pixel* dv, pixel* dc, long dstStride, int width, int height)
 {
@@ -101,6 +103,304 @@ extern "C" int x265amd_lowres_intra_costs(void* stream, const x265amd_pixel* d_p
     const int penalty = 5 * lambda + 4;         /* intraPenalty + lowresPenalty (slicetype.cpp:722-724) */
     hipLaunchKernelGGL(k_lowres_intra, dim3(width_in_cu * height_in_cu), dim3(64), 0, (hipStream_t)stream, (const pixel*)d_plane, (long)stride, width_in_cu, height_in_cu,
                        penalty, d_cost, d_mode);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+
+/* ---------------- lookahead frame cost: CostEstimateGroup::estimateCUCost for every 8x8 block (slicetype.cpp:4077-4249) ----------------
+ * with MotionEstimate::motionEstimate in its lowres form (motion.cpp:764-860 start, :879-987 hexagon, :1469-1525 sub-pel on the four half-pel
+ * planes) and ReferencePlanes::lowresMC / lowresQPelCost (lowres.h:71-124).
+ *
+ * The blocks of a frame are chained: a block's MV predictor candidates are the MVs found for its right, lower, lower-left and lower-right
+ * neighbours (reverse raster order).  One wavefront owns one block ROW and walks it right to left; it starts block x when the row below has
+ * finished block max(x - 1, 0) (progress counters in global memory, release / acquire).  Rows are launched bottom row first, so the wavefronts a
+ * row waits for are always dispatched before it.  Lane = sample of the 8x8 block; SAD / SATD through LDS. */
+struct LowresCostParams
+{
+    const pixel* fenc; const pixel* ref[2][4];     /* sample (0,0) of the planes: fenc fpel; per list fpel, H, V, C */
+    long stride;
+    int widthInCU, heightInCU, bidir, doSearch[2], merange;
+    const int32_t* intraCost;
+    int16_t* mvs[2]; int32_t* mvCosts[2];       /* Lowres::lowresMvs / lowresMvCosts of (list, distance): read when !doSearch, written otherwise */
+    uint16_t* lowresCosts; int32_t* bcost;
+    const uint16_t* cost;                       /* MV cost table centre */
+    int* progress;                              /* per row: the leftmost finished block (widthInCU = none yet) */
+};
+
+struct LrBlock
+{
+    pixel* fencT; pixel* buf;                   /* LDS: source block, candidate block */
+    const LowresCostParams* p;
+    int list, lane;
+    long off;                                   /* blockOffset */
+    int mvpx, mvpy;
+};
+
+XA_DEV int lr_mvcost(const LrBlock& b, int qx, int qy) { return (uint16_t)(b.p->cost[qx - b.mvpx] + b.p->cost[qy - b.mvpy]); }
+
+/* lowresMC: the candidate block of quarter-pel MV (qx, qy) into b.buf (stride 8) */
+XA_DEV void lr_fetch(const LrBlock& b, int qx, int qy)
+{
+    const pixel* const* plane = b.p->ref[b.list];
+    const int lx = b.lane & 7, ly = b.lane >> 3;
+    const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+    const pixel* a = plane[hpelA] + b.off + (qx >> 2) + (long)(qy >> 2) * b.p->stride;
+    int v = a[(long)ly * b.p->stride + lx];
+    if ((qx | qy) & 1)
+    {
+        const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
+        const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
+        const pixel* c = plane[hpelB] + b.off + (qx2 >> 2) + (long)(qy2 >> 2) * b.p->stride;
+        v = (v + c[(long)ly * b.p->stride + lx] + 1) >> 1;          /* pixelavg_pp */
+    }
+    xa_wave_sync();
+    b.buf[b.lane] = (pixel)v;
+    xa_wave_sync();
+}
+XA_DEV int lr_sad_q(const LrBlock& b, int qx, int qy) { lr_fetch(b, qx, qy); return xa_wave_sad(b.fencT, 8, b.buf, 8, 8, 8, b.lane); }
+XA_DEV int lr_satd_q(const LrBlock& b, int qx, int qy) { lr_fetch(b, qx, qy); return xa_wave_satd(b.fencT, 8, b.buf, 8, 8, 8, b.lane); }
+/* full-pel SAD on the fpel plane + MV cost: COST_MV */
+XA_DEV int lr_cost_f(const LrBlock& b, int mx, int my) { return lr_sad_q(b, mx * 4, my * 4) + lr_mvcost(b, mx * 4, my * 4); }
+
+__device__ const int8_t lr_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
+__device__ const uint8_t lr_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+__device__ const int8_t lr_square1[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 }, { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+
+/* MotionEstimate::motionEstimate(ref, mvmin, mvmax, qmvp, 0, NULL, merange, outQMv) for a lowres reference, HEX search, subpelRefine 1 */
+XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, int qmvpx, int qmvpy, int merange, int& outx, int& outy)
+{
+    b.mvpx = qmvpx; b.mvpy = qmvpy;                                     /* setMVP */
+    const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
+    int pmx = min(max(qmvpx, qmnx), qmxx), pmy = min(max(qmvpy, qmny), qmxy);       /* clipped */
+    const int bestprex = pmx, bestprey = pmy;
+    const int bprecost = lr_sad_q(b, pmx, pmy);
+    int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2;                       /* roundToFPel */
+    int bcost = bprecost;
+    if ((pmx | pmy) & 3) bcost = lr_sad_q(b, bx * 4, by * 4) + lr_mvcost(b, bx * 4, by * 4);
+    if (pmx | pmy)
+    {
+        const int c = lr_sad_q(b, 0, 0) + lr_mvcost(b, 0, 0);
+        if (c < bcost) { bcost = c; bx = 0; by = max(min(0, mxy), mny); }
+    }
+    auto inRange = [&](int x, int y) { return x >= mnx && x <= mxx && y >= mny && y <= mxy; };
+    /* hexagon search (motion.cpp:879-987) */
+    {
+        int c0 = lr_cost_f(b, bx - 2, by), c1 = lr_cost_f(b, bx - 1, by + 2), c2 = lr_cost_f(b, bx + 1, by + 2);
+        int packed = bcost << 3;
+        if (by >= mny && by <= mxy && (c0 << 3) + 2 < packed) packed = (c0 << 3) + 2;
+        if (by + 2 >= mny && by + 2 <= mxy)
+        {
+            if ((c1 << 3) + 3 < packed) packed = (c1 << 3) + 3;
+            if ((c2 << 3) + 4 < packed) packed = (c2 << 3) + 4;
+        }
+        c0 = lr_cost_f(b, bx + 2, by); c1 = lr_cost_f(b, bx + 1, by - 2); c2 = lr_cost_f(b, bx - 1, by - 2);
+        if (by >= mny && by <= mxy && (c0 << 3) + 5 < packed) packed = (c0 << 3) + 5;
+        if (by - 2 >= mny && by - 2 <= mxy)
+        {
+            if ((c1 << 3) + 6 < packed) packed = (c1 << 3) + 6;
+            if ((c2 << 3) + 7 < packed) packed = (c2 << 3) + 7;
+        }
+        if (packed & 7)
+        {
+            int dir = (packed & 7) - 2;
+            if (by + lr_hex2[dir + 1][1] >= mny && by + lr_hex2[dir + 1][1] <= mxy)
+            {
+                bx += lr_hex2[dir + 1][0]; by += lr_hex2[dir + 1][1];
+                for (int i = (merange >> 1) - 1; i > 0 && inRange(bx, by); i--)
+                {
+                    int cc[3];
+                    for (int k = 0; k < 3; k++) cc[k] = lr_cost_f(b, bx + lr_hex2[dir + k][0], by + lr_hex2[dir + k][1]);
+                    packed &= ~7;
+                    for (int k = 0; k < 3; k++)
+                        if (by + lr_hex2[dir + k][1] >= mny && by + lr_hex2[dir + k][1] <= mxy && (cc[k] << 3) + k + 1 < packed) packed = (cc[k] << 3) + k + 1;
+                    if (!(packed & 7)) break;
+                    dir += (packed & 7) - 2;
+                    dir = lr_mod6m1[dir + 1];
+                    bx += lr_hex2[dir + 1][0]; by += lr_hex2[dir + 1][1];
+                }
+            }
+        }
+        bcost = packed >> 3;
+        /* square refine */
+        int dir = 0;
+        const bool upOk = by - 1 >= mny && by - 1 <= mxy, dnOk = by + 1 >= mny && by + 1 <= mxy;
+        int c[4] = { lr_cost_f(b, bx, by - 1), lr_cost_f(b, bx, by + 1), lr_cost_f(b, bx - 1, by), lr_cost_f(b, bx + 1, by) };
+        if (upOk && c[0] < bcost) { bcost = c[0]; dir = 1; }
+        if (dnOk && c[1] < bcost) { bcost = c[1]; dir = 2; }
+        if (c[2] < bcost) { bcost = c[2]; dir = 3; }
+        if (c[3] < bcost) { bcost = c[3]; dir = 4; }
+        int d[4] = { lr_cost_f(b, bx - 1, by - 1), lr_cost_f(b, bx - 1, by + 1), lr_cost_f(b, bx + 1, by - 1), lr_cost_f(b, bx + 1, by + 1) };
+        if (upOk && d[0] < bcost) { bcost = d[0]; dir = 5; }
+        if (dnOk && d[1] < bcost) { bcost = d[1]; dir = 6; }
+        if (upOk && d[2] < bcost) { bcost = d[2]; dir = 7; }
+        if (dnOk && d[3] < bcost) { bcost = d[3]; dir = 8; }
+        bx += lr_square1[dir][0]; by += lr_square1[dir][1];
+    }
+    int qx, qy;
+    if (bprecost < bcost) { qx = bestprex; qy = bestprey; bcost = bprecost; }
+    else { qx = bx * 4; qy = by * 4; }
+    if (!bcost) bcost = lr_mvcost(b, qx, qy);
+    else
+    {
+        /* lowres sub-pel refinement (motion.cpp:1496-1525), workload[1]: 4 half-pel SADs, 4 quarter-pel SATDs */
+        int bdir = 0;
+        for (int i = 1; i <= 4; i++)
+        {
+            const int tx = qx + lr_square1[i][0] * 2, ty = qy + lr_square1[i][1] * 2;
+            if (ty < qmny || ty > qmxy) continue;
+            const int c = lr_sad_q(b, tx, ty) + lr_mvcost(b, tx, ty);
+            if (c < bcost) { bcost = c; bdir = i; }
+        }
+        qx += lr_square1[bdir][0] * 2; qy += lr_square1[bdir][1] * 2;
+        bcost = lr_satd_q(b, qx, qy) + lr_mvcost(b, qx, qy);
+        bdir = 0;
+        for (int i = 1; i <= 4; i++)
+        {
+            const int tx = qx + lr_square1[i][0], ty = qy + lr_square1[i][1];
+            if (ty < qmny || ty > qmxy) continue;
+            const int c = lr_satd_q(b, tx, ty) + lr_mvcost(b, tx, ty);
+            if (c < bcost) { bcost = c; bdir = i; }
+        }
+        qx += lr_square1[bdir][0]; qy += lr_square1[bdir][1];
+    }
+    outx = qx; outy = qy;
+    return bcost;
+}
+
+__global__ __launch_bounds__(64) void k_lowres_cost(LowresCostParams p)
+{
+    __shared__ pixel fencT[64];
+    __shared__ pixel buf[64];
+    __shared__ pixel buf2[64];
+    const int lane = xa_lane();
+    const int cuY = p.heightInCU - 1 - (int)blockIdx.x;            /* bottom row first */
+    const bool lastRow = cuY == p.heightInCU - 1;
+    const int W = p.widthInCU;
+    LrBlock b;
+    b.fencT = fencT; b.buf = buf; b.p = &p; b.lane = lane;
+    for (int cuX = W - 1; cuX >= 0; cuX--)
+    {
+        if (!lastRow)
+        {
+            const int need = cuX > 0 ? cuX - 1 : 0;
+            if (lane == 0) while (__atomic_load_n(&p.progress[cuY + 1], __ATOMIC_ACQUIRE) > need) __builtin_amdgcn_s_sleep(2);
+            xa_wave_sync();
+            __threadfence();
+        }
+        const int cuXY = cuX + cuY * W;
+        b.off = 8L * cuX + 8L * cuY * p.stride;
+        xa_wave_sync();
+        fencT[lane] = p.fenc[b.off + (long)(lane >> 3) * p.stride + (lane & 7)];
+        xa_wave_sync();
+        const int mnx = -cuX * 8 - 8, mny = -cuY * 8 - 8, mxx = (W - cuX - 1) * 8 + 8, mxy = (p.heightInCU - cuY - 1) * 8 + 8;
+        int bcost = 1 << 28, listused = 0;          /* MotionEstimate::COST_MAX */
+        int mvx[2] = { 0, 0 }, mvy[2] = { 0, 0 };
+        for (int i = 0; i < 1 + p.bidir; i++)
+        {
+            b.list = i;
+            int fencCost;
+            if (!p.doSearch[i])
+            {
+                fencCost = p.mvCosts[i][cuXY];
+                mvx[i] = p.mvs[i][2 * cuXY]; mvy[i] = p.mvs[i][2 * cuXY + 1];
+                if (fencCost < bcost) { bcost = fencCost; listused = i + 1; }
+                continue;
+            }
+            /* reverse-order MV prediction: the cheapest neighbour MV by SATD is the predictor */
+            int numc = 0, mcx[4], mcy[4];
+            const int16_t* mv = p.mvs[i];
+            /* written by other wavefronts during this launch: read past the caches */
+            auto add = [&](int idx) {
+                const int v = __atomic_load_n(reinterpret_cast<const int*>(mv) + idx, __ATOMIC_RELAXED);
+                mcx[numc] = (int16_t)(v & 0xFFFF); mcy[numc] = (int16_t)(v >> 16); numc++;
+            };
+            if (cuX < W - 1) add(cuXY + 1);
+            if (!lastRow)
+            {
+                add(cuXY + W);
+                if (cuX > 0) add(cuXY + W - 1);
+                if (cuX < W - 1) add(cuXY + W + 1);
+            }
+            int mvpx = 0, mvpy = 0, skipCost = 0x7FFFFFFF;
+            if (numc)
+            {
+                int mvpcost = 1 << 28;
+                for (int k = 0; k < numc; k++)
+                {
+                    const int c = lr_satd_q(b, mcx[k], mcy[k]);
+                    if (c < mvpcost) { mvpcost = c; mvpx = mcx[k]; mvpy = mcy[k]; }
+                    if (!(mvpx | mvpy) && p.bidir) skipCost = c;
+                }
+            }
+            int ox, oy;
+            fencCost = lr_motion_estimate(b, mnx, mny, mxx, mxy, mvpx, mvpy, p.merange, ox, oy);
+            if (skipCost < 64 && skipCost < fencCost && p.bidir) { fencCost = skipCost; ox = 0; oy = 0; }
+            mvx[i] = ox; mvy[i] = oy;
+            if (lane == 0) { p.mvs[i][2 * cuXY] = (int16_t)ox; p.mvs[i][2 * cuXY + 1] = (int16_t)oy; p.mvCosts[i][cuXY] = fencCost; }
+            if (fencCost < bcost) { bcost = fencCost; listused = i + 1; }
+        }
+        if (p.bidir)
+        {
+            /* avg(l0-mv, l1-mv), then the co-located average */
+            b.list = 0; lr_fetch(b, mvx[0], mvy[0]);
+            const int a0 = buf[lane];
+            b.list = 1; lr_fetch(b, mvx[1], mvy[1]);
+            xa_wave_sync();
+            buf2[lane] = (pixel)((a0 + buf[lane] + 1) >> 1);
+            xa_wave_sync();
+            int bicost = xa_wave_satd(fencT, 8, buf2, 8, 8, 8, lane);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            const long o = b.off + (long)(lane >> 3) * p.stride + (lane & 7);
+            xa_wave_sync();
+            buf2[lane] = (pixel)((p.ref[0][0][o] + p.ref[1][0][o] + 1) >> 1);
+            xa_wave_sync();
+            bicost = xa_wave_satd(fencT, 8, buf2, 8, 8, 8, lane);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            bcost += 4;
+        }
+        else
+        {
+            bcost += 4;
+            if (p.intraCost[cuXY] < bcost) { bcost = p.intraCost[cuXY]; listused = 0; }
+        }
+        if (lane == 0)
+        {
+            p.bcost[cuXY] = bcost;
+            p.lowresCosts[cuXY] = (uint16_t)(min(bcost, 0x3FFF) | (listused << 14));
+            __threadfence();
+            __atomic_store_n(&p.progress[cuY], cuX, __ATOMIC_RELEASE);
+        }
+    }
+}
+
+extern "C" int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref0[4],
+                                         const x265amd_pixel* const d_ref1[4], intptr_t stride, int width_in_cu, int height_in_cu, int do_search0, int do_search1,
+                                         const int32_t* d_intra_cost, int16_t* d_mvs0, int32_t* d_mv_costs0, int16_t* d_mvs1, int32_t* d_mv_costs1,
+                                         uint16_t* d_lowres_costs, int32_t* d_bcost, int32_t* d_progress)
+{
+    if (!me || !d_fenc || !d_ref0 || !d_intra_cost || !d_mvs0 || !d_mv_costs0 || !d_lowres_costs || !d_bcost || !d_progress || width_in_cu <= 0 || height_in_cu <= 0 ||
+        (d_ref1 && (!d_mvs1 || !d_mv_costs1)))
+        return xa_fail(X265AMD_EINVAL, "x265amd_lowres_frame_cost: bad arguments");
+    LowresCostParams p;
+    memset(&p, 0, sizeof(p));
+    p.fenc = (const pixel*)d_fenc;
+    for (int k = 0; k < 4; k++) { p.ref[0][k] = (const pixel*)d_ref0[k]; p.ref[1][k] = d_ref1 ? (const pixel*)d_ref1[k] : nullptr; }
+    p.stride = (long)stride; p.widthInCU = width_in_cu; p.heightInCU = height_in_cu; p.bidir = d_ref1 != nullptr;
+    p.doSearch[0] = do_search0 != 0; p.doSearch[1] = d_ref1 && do_search1;
+    p.merange = 16;                                     /* CostEstimateGroup::s_merange */
+    p.intraCost = d_intra_cost;
+    p.mvs[0] = d_mvs0; p.mvCosts[0] = d_mv_costs0; p.mvs[1] = d_mvs1; p.mvCosts[1] = d_mv_costs1;
+    p.lowresCosts = d_lowres_costs; p.bcost = d_bcost;
+    p.cost = xa_me_device_mvcost(me, 12 + 6 * (XA_DEPTH - 8));          /* X265_LOOKAHEAD_QP */
+    p.progress = d_progress;
+    hipStream_t st = (hipStream_t)stream;
+    /* progress[row] = width_in_cu: nothing finished yet (0x01010101-style memset cannot express it: a tiny fill) */
+    std::vector<int32_t> init((size_t)height_in_cu, width_in_cu);
+    XA_HIP_CHECK(hipMemcpyAsync(d_progress, init.data(), sizeof(int32_t) * height_in_cu, hipMemcpyHostToDevice, st));
+    XA_HIP_CHECK(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_lowres_cost, dim3(height_in_cu), dim3(64), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;

@@ -1184,6 +1184,13 @@ extern "C" void x265amd_me_close(x265amd_me_ctx* ctx)
     delete ctx;
 }
 
+/* device address of the centre (MVD 0) of the MV cost table of `qp` (for the lookahead's motion search, csrc/lowres_kernels.hip) */
+const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp)
+{
+    if (!ctx || qp < 0 || qp >= ME_QP_COUNT) return nullptr;
+    return ctx->d_tables + (size_t)qp * ME_TBL_LEN + ME_TBL_HALF;
+}
+
 extern "C" const uint16_t* x265amd_me_host_mvcost(x265amd_me_ctx* ctx, int qp)
 {
     if (!ctx || qp < 0 || qp >= ME_QP_COUNT) return nullptr;

@@ -37,6 +37,9 @@ struct XaMapped
 struct XaRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };
 void xa_copy_rects(hipStream_t st, const XaRects& r);
 
+/* device address of the centre (MVD 0) of x265amd_me_ctx's MV cost table for `qp` (BitCost::s_costs[qp]) */
+const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp);
+
 /* The reference's primitive slots cannot report failure (primitives.h:133-236), so a HIP error inside a
  * per-slot entry point is fatal: there is deliberately no CPU fallback. */
 #define XA_HIP_FATAL(expr)                                                                                   \
