@@ -814,6 +814,14 @@ int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pi
                               const int32_t* d_intra_cost, int16_t* d_mvs0, int32_t* d_mv_costs0, int16_t* d_mvs1, int32_t* d_mv_costs1,
                               uint16_t* d_lowres_costs, int32_t* d_bcost, int32_t* d_progress);
 
+/* x265amd_aq_energy = LookaheadTLD::acEnergyCu for every quantisation group of a source picture (reference: source/encoder/slicetype.cpp:48-92, :264-283):
+ * d_energy[group] (raster order, ceil(width / qg) groups per row; qg_size 16 or 8) = AC energy of the luma block + the two 4:2:0 chroma blocks;
+ * d_wp[0..2] = Lowres::wp_sum[plane], d_wp[3..5] = wp_ssd[plane] (sums over all groups).  planes: HOST array of the device addresses of sample (0,0)
+ * of Y, U, V (padded planes: groups at the right / bottom edge read into the margin, as the reference does).  The double-precision part of
+ * calcAdaptiveQuantFrame (energies -> QP offsets) is not built yet.  Asynchronous. */
+int x265amd_aq_energy(void* stream, const uint64_t planes[3], intptr_t stride, intptr_t cstride, int width, int height, int qg_size,
+                      uint32_t* d_energy, uint64_t* d_wp);
+
 /* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
 void x265amd_release_scratch(void);
 

@@ -1783,4 +1783,27 @@ int ref_lowres_frame_cost(const pixel* const* luma, intptr_t stride, int width, 
     return ncu;
 }
 
+/* ---- adaptive quantisation, block energies: the reference's own LookaheadTLD::acEnergyCu over a picture (slicetype.cpp:264-283) ---- */
+int ref_aq_energy(const pixel* y, const pixel* u, const pixel* v, intptr_t stride, intptr_t cstride, int width, int height, int qgSize, uint32_t* energy, uint64_t* wp)
+{
+    ensure();
+    struct Tld : public LookaheadTLD { uint32_t energy(Frame* f, uint32_t x, uint32_t y, uint32_t qg) { return acEnergyCu(f, x, y, X265_CSP_I420, qg); } };
+    static Tld* tld = new Tld;
+    Frame* frame = new Frame;
+    PicYuv* pic = new PicYuv;
+    pic->m_picWidth = width; pic->m_picHeight = height; pic->m_stride = stride; pic->m_strideC = cstride; pic->m_picCsp = X265_CSP_I420;
+    pic->m_picOrg[0] = const_cast<pixel*>(y); pic->m_picOrg[1] = const_cast<pixel*>(u); pic->m_picOrg[2] = const_cast<pixel*>(v);
+    frame->m_fencPic = pic;
+    for (int p = 0; p < 3; p++) { frame->m_lowres.wp_ssd[p] = 0; frame->m_lowres.wp_sum[p] = 0; }
+    int n = 0;
+    for (int by = 0; by < height; by += qgSize)
+        for (int bx = 0; bx < width; bx += qgSize)
+            energy[n++] = tld->energy(frame, bx, by, qgSize);
+    for (int p = 0; p < 3; p++) { wp[p] = frame->m_lowres.wp_sum[p]; wp[3 + p] = frame->m_lowres.wp_ssd[p]; }
+    frame->m_fencPic = NULL;
+    pic->m_picOrg[0] = pic->m_picOrg[1] = pic->m_picOrg[2] = NULL;
+    delete pic;
+    return n;
+}
+
 } /* extern "C" */

@@ -408,6 +408,18 @@ def make_lowres_cost_golden():
     print("wrote lowres_cost_golden.npz with", len(out), "arrays")
 
 
+def make_aq_energy_golden():
+    """LookaheadTLD::acEnergyCu of the reference over whole pictures -> tests/golden/aq_energy_golden.npz"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tl", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_lowres.py"))
+    tl = importlib.util.module_from_spec(spec); spec.loader.exec_module(tl)
+    out = {}
+    for k, (depth, seed, W, H, qg) in enumerate(tl.AQ_CASES):
+        out["%d/energy" % k], out["%d/wp" % k] = T.aq_run_ref(T.load_ref(depth), T.aq_case(depth, seed), W, H, qg)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "aq_energy_golden.npz"), **out)
+    print("wrote aq_energy_golden.npz with", len(out), "arrays")
+
+
 def make_encoder_api_golden():
     """whole streams + per-frame reconstruction digests of the reference encoder for clips the frame-pipeline goldens do not cover:
     picture sizes that are not multiples of the CTU size (partial CTUs at the right / bottom edge) and a 14-frame clip (the DPB evicts

@@ -3231,3 +3231,32 @@ def lowres_cost_run_hip(L, me, c, p0, b, p1):
     mvs = np.stack([d_mvs[l].cpu().numpy().reshape(ncu, 2) for l in range(2)]); mvc = np.stack([d_mvc[l].cpu().numpy() for l in range(2)])
     score, est, intra_mbs, rows_ = lowres_cost_sums(c, lc, bc, bidir)
     return dict(lowres_costs=lc, mvs=mvs, mv_costs=mvc, intra_cost=intra[b].cpu().numpy(), row_satds=rows_, sums=np.array([score, est, intra_mbs], np.int64))
+
+
+# ---- adaptive quantisation block energies (x265amd_aq_energy vs LookaheadTLD::acEnergyCu) ----
+def aq_case(depth, seed):
+    pics, stride, cstride, org = inter_scene(depth, seed, npics=1)
+    return dict(depth=depth, pic=pics[0], stride=stride, cstride=cstride, org=org)
+
+
+def aq_run_ref(R, c, W, H, qg):
+    isz = c["pic"].itemsize
+    n = ((W + qg - 1) // qg) * ((H + qg - 1) // qg)
+    energy = np.zeros(n, np.uint32); wp = np.zeros(6, np.uint64)
+    base = c["pic"].ctypes.data
+    R.lib.ref_aq_energy.restype = C.c_int
+    got = R.lib.ref_aq_energy(*[C.c_void_p(base + c["org"][k] * isz) for k in range(3)], C.c_int64(c["stride"]), C.c_int64(c["cstride"]), W, H, qg, _ptr(energy), _ptr(wp))
+    assert got == n
+    return energy, wp
+
+
+def aq_run_hip(L, c, W, H, qg):
+    import torch
+    isz = c["pic"].itemsize
+    d = torch.from_numpy(c["pic"].view(np.uint8)).cuda()
+    planes = np.array([d.data_ptr() + c["org"][k] * isz for k in range(3)], np.uint64)
+    n = ((W + qg - 1) // qg) * ((H + qg - 1) // qg)
+    d_e = torch.zeros(n, dtype=torch.int32, device="cuda"); d_wp = torch.zeros(6, dtype=torch.int64, device="cuda")
+    assert L.lib.x265amd_aq_energy(None, _ptr(planes), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), W, H, qg, C.c_void_p(d_e.data_ptr()), C.c_void_p(d_wp.data_ptr())) == 0
+    torch.cuda.synchronize()
+    return d_e.cpu().numpy().view(np.uint32), d_wp.cpu().numpy().view(np.uint64)

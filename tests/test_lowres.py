@@ -62,3 +62,23 @@ def test_hip_lowres_frame_cost_matches_reference_golden(k):
         assert np.array_equal(got[name], want), (name, np.argwhere(got[name] != want)[:6].tolist())
     want = g["%d/sums" % k]
     assert int(got["sums"][0]) == int(want[0]) and int(got["sums"][2]) == int(want[2]), (got["sums"], want)
+
+
+AQ_GOLD = os.path.join(T.GOLDEN_DIR, "aq_energy_golden.npz")
+AQ_CASES = [(8, 41, T.MC_W, T.MC_H, 16), (8, 42, T.MC_W - 8, T.MC_H - 24, 16), (8, 43, T.MC_W, T.MC_H, 8), (10, 44, T.MC_W - 40, T.MC_H, 16), (10, 45, T.MC_W, T.MC_H - 8, 8)]
+
+
+def test_aq_golden_shapes():
+    g = np.load(AQ_GOLD)
+    for k, (depth, seed, W, H, qg) in enumerate(AQ_CASES):
+        assert len(g["%d/energy" % k]) == ((W + qg - 1) // qg) * ((H + qg - 1) // qg) and g["%d/energy" % k].max() > 1000 and g["%d/wp" % k].min() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(AQ_CASES)))
+def test_hip_aq_energy_matches_reference_golden(k):
+    g = np.load(AQ_GOLD)
+    depth, seed, W, H, qg = AQ_CASES[k]
+    energy, wp = T.aq_run_hip(T.load_hip(depth), T.aq_case(depth, seed), W, H, qg)
+    assert np.array_equal(energy, g["%d/energy" % k]), np.argwhere(energy != g["%d/energy" % k])[:5].tolist()
+    assert np.array_equal(wp, g["%d/wp" % k]), (wp, g["%d/wp" % k])

@@ -405,3 +405,49 @@ extern "C" int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }
+
+
+/* ---------------- adaptive quantisation, the data-parallel half: LookaheadTLD::acEnergyCu for every quantisation group ----------------
+ * (slicetype.cpp:48-92, :264-283; cu[].var = pixel_var, pixel.cpp:720-737): AC energy of the luma block and the two 4:2:0 chroma blocks,
+ * plus the frame's running sums Lowres::wp_sum / wp_ssd that weighted prediction analysis reads.  One wavefront per group; HBM-bound (every
+ * source sample is read once: algorithmic bytes = 1.5 x width x height x sizeof(pixel)).  The double-precision mapping of the energies to QP
+ * offsets (calcAdaptiveQuantFrame) is host code and not part of this entry point. */
+__global__ __launch_bounds__(64) void k_aq_energy(const pixel* y, const pixel* u, const pixel* v, long stride, long cstride, int blocksW, int numBlocks, int qg,
+                                                  uint32_t* energy, unsigned long long* wp)
+{
+    const int lane = xa_lane(), blk = blockIdx.x;
+    if (blk >= numBlocks) return;
+    const int bx = (blk % blocksW) * qg, by = (blk / blocksW) * qg;
+    uint32_t total = 0;
+    for (int plane = 0; plane < 3; plane++)
+    {
+        const int n = plane ? qg >> 1 : qg, log2n = plane ? (qg == 16 ? 3 : 2) : (qg == 16 ? 4 : 3);
+        const pixel* src = plane == 0 ? y + (long)by * stride + bx : (plane == 1 ? u : v) + (long)(by >> 1) * cstride + (bx >> 1);
+        const long st = plane ? cstride : stride;
+        uint32_t sum = 0, sqr = 0;
+        for (int i = lane; i < n * n; i += XA_WAVE)
+        {
+            const uint32_t p = src[(long)(i >> log2n) * st + (i & (n - 1))];
+            sum += p; sqr += p * p;
+        }
+        sum = xa_wave_sum(sum); sqr = xa_wave_sum(sqr);
+        total += sqr - (uint32_t)(((unsigned long long)sum * sum) >> (2 * log2n));
+        if (lane == 0) { atomicAdd(&wp[plane], (unsigned long long)sum); atomicAdd(&wp[3 + plane], (unsigned long long)sqr); }
+    }
+    if (lane == 0) energy[blk] = total;
+}
+
+extern "C" int x265amd_aq_energy(void* stream, const uint64_t planes[3], intptr_t stride, intptr_t cstride, int width, int height, int qg_size,
+                                 uint32_t* d_energy, uint64_t* d_wp)
+{
+    if (!planes || !planes[0] || !planes[1] || !planes[2] || !d_energy || !d_wp || width <= 0 || height <= 0 || (qg_size != 16 && qg_size != 8))
+        return xa_fail(X265AMD_EINVAL, "x265amd_aq_energy: bad arguments");
+    const int bw = (width + qg_size - 1) / qg_size, bh = (height + qg_size - 1) / qg_size;
+    hipStream_t st = (hipStream_t)stream;
+    XA_HIP_CHECK(hipMemsetAsync(d_wp, 0, 6 * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(k_aq_energy, dim3(bw * bh), dim3(64), 0, st, (const pixel*)(uintptr_t)planes[0], (const pixel*)(uintptr_t)planes[1], (const pixel*)(uintptr_t)planes[2],
+                       (long)stride, (long)cstride, bw, bw * bh, qg_size, d_energy, (unsigned long long*)d_wp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
