@@ -430,7 +430,8 @@ def make_encoder_api_golden():
                                         ("crop_b/", (248, 184), 7, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "2"]),
                                         ("long/", (128, 128), 14, ["--bframes", "2", "--no-b-pyramid", "--ref", "4"]),
                                         ("hbd_b/", (192, 136), 7, ["--bframes", "2", "--no-b-pyramid", "--sao", "--rect", "--amp"]),
-                                        ("hbd_rd5/", (128, 128), 4, ["--bframes", "0", "--rd", "5"])):
+                                        ("hbd_rd5/", (128, 128), 4, ["--bframes", "0", "--rd", "5"]),
+                                        ("wvga/", (832, 480), 5, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"])):
         depth = 10 if tag.startswith("hbd") else 8
         planes = T.encoder_api_clip(tag, w, h, nframes, depth)
         cli = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]

@@ -71,6 +71,7 @@ EDGE_CONFIGS = {
     "long/": ((128, 128), 14, dict(BASE, bframes=2, maxNumReferences=4)),
     "hbd_b/": ((192, 136), 7, dict(BASE, bframes=2, bEnableSAO=1, bEnableRectInter=1, bEnableAMP=1)),       # 10-bit library (libx265amd_main10.so)
     "hbd_rd5/": ((128, 128), 4, dict(BASE, rdLevel=5)),
+    "wvga/": ((832, 480), 5, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1)),     # 13 x 8 CTUs (last row cut), 8 row threads in flight
 }
 
 
