@@ -19,6 +19,7 @@
 #include <string.h>
 #include <algorithm>
 #include <deque>
+#include <future>
 #include <memory>
 #include <vector>
 
@@ -28,18 +29,25 @@ typedef x265amd_pixel pixel;
 enum { TYPE_IDR = 1, TYPE_P = 3, TYPE_B = 5 };          /* X265_TYPE_IDR / _P / _B (x265.h:255-261) */
 enum { RD_TILE_ELEMS = 4096 + 2 * 1024 };
 
+struct Pic;
+typedef std::shared_ptr<Pic> PicP;
 struct Pic
 {
     int poc = 0, type = 0, sliceQp = 0;
     bool hasReferences = false;
-    pixel* dSrc = nullptr; pixel* dRec = nullptr;       /* flat Y | U | V padded buffers */
+    pixel* dSrc = nullptr; pixel* dRec = nullptr;       /* flat Y | U | V padded buffers (pooled device memory) */
     std::vector<x265amd_cu_unit> units;
     std::vector<x265amd_mv_unit> motion;
     int32_t refPoc[2][16];
+    /* what DPB::prepareEncode decided for this picture (coding order, main thread) */
+    int nalType = 0, lastIDR = 0;
+    std::vector<PicP> neg, pos, lists[2];
+    /* the frame task: result code when the picture is completely coded (reconstruction final, NAL written) */
+    std::shared_future<int> done;
+    std::vector<uint8_t> nalBytes;
     Pic() { memset(refPoc, 0, sizeof(refPoc)); }
-    ~Pic() { if (dSrc) (void)hipFree(dSrc); if (dRec) (void)hipFree(dRec); }
+    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); }
 };
-typedef std::shared_ptr<Pic> PicP;
 
 }
 
@@ -56,7 +64,10 @@ struct x265amd_encoder
     int frameCount = 0, lastKeyframe = 0, lastIDR = 0;
     bool first = true;
     std::deque<PicP> input;                             /* display order, not yet typed */
-    std::deque<PicP> ready;                             /* coding order */
+    std::deque<PicP> ready;                             /* coding order, typed, not yet started */
+    std::deque<PicP> inflight;                          /* coding order, frame tasks running */
+    std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
+    int frameThreads = 1;
     std::vector<PicP> picList;                          /* front = most recently coded (PicList::pushFront) */
     double depthSaoRate[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     std::vector<uint8_t> headerBytes, outBytes;
@@ -67,19 +78,21 @@ struct x265amd_encoder
 
     ~x265amd_encoder()
     {
+        for (auto& q : inflight) if (q->done.valid()) q->done.wait();
         if (me) x265amd_me_close(me);
         if (dSaoCount) (void)hipFree(dSaoCount);
         if (dSaoOrg) (void)hipFree(dSaoOrg);
         if (dSaoParams) (void)hipFree(dSaoParams);
         if (dDbUnits) (void)hipFree(dDbUnits);
-        if (dSaoTmp) (void)hipFree(dSaoTmp);
+        xa_scratch_free(dSaoTmp);
     }
     uint64_t planeAddr(const pixel* base, int k) const { return (uint64_t)(uintptr_t)(base + org[k]); }
 
     void fillStreamParams(x265amd_stream_params& s) const;
     int uploadPicture(const x265amd_picture* in, Pic& pic);
     void decideMiniGop(bool flush);
-    int encodeOne(Pic& pic, x265amd_picture* picOut);
+    int prepare(const PicP& pic);
+    int runFrame(const PicP& pic, std::shared_future<int> prev);
 };
 
 /* ---- configuration ---- */
@@ -168,13 +181,20 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     e->numReorderPics = p->bframes ? 1 : 0;
     e->maxDecPicBuffering = std::min(16, std::max(e->numReorderPics + 2, p->maxNumReferences) + 1);
     e->lastKeyframe = -p->keyframeMax;
+    {
+        /* pictures whose references are complete are analysed concurrently (B frames of a mini-GOP, the next P): the reference's frame threads, but
+         * a picture only starts when its references are final, so the output does not depend on the thread count */
+        const char* ft = getenv("X265AMD_FRAME_THREADS");
+        e->frameThreads = ft ? atoi(ft) : 3;
+        if (e->frameThreads < 1) e->frameThreads = 1;
+    }
     e->me = x265amd_me_open();
     if (!e->me) return nullptr;
     const size_t nstat = (size_t)e->nctu * 3 * 5 * 32;
     if (hipMalloc((void**)&e->dSaoCount, nstat * 4) != hipSuccess || hipMalloc((void**)&e->dSaoOrg, nstat * 4) != hipSuccess ||
         hipMalloc((void**)&e->dSaoParams, sizeof(x265amd_sao_ctu) * e->nctu) != hipSuccess ||
         hipMalloc((void**)&e->dDbUnits, sizeof(x265amd_deblock_unit) * e->w4 * e->h4) != hipSuccess ||
-        hipMalloc((void**)&e->dSaoTmp, e->picElems * sizeof(pixel)) != hipSuccess)
+        xa_scratch_alloc((void**)&e->dSaoTmp, e->picElems * sizeof(pixel)) != hipSuccess)
     { xa_fail(X265AMD_EHIP, "encoder_open: device allocation"); return nullptr; }
     x265amd_stream_params sp;
     e->fillStreamParams(sp);
@@ -240,10 +260,11 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic)
             memcpy(base + (intptr_t)(h - 1 + y) * st - mx, base + (intptr_t)(h - 1) * st - mx, sizeof(pixel) * (w + 2 * mx));
         }
     }
-    if (hipMalloc((void**)&pic.dSrc, picElems * sizeof(pixel)) != hipSuccess || hipMalloc((void**)&pic.dRec, picElems * sizeof(pixel)) != hipSuccess)
+    if (xa_scratch_alloc((void**)&pic.dSrc, picElems * sizeof(pixel)) != hipSuccess || xa_scratch_alloc((void**)&pic.dRec, picElems * sizeof(pixel)) != hipSuccess)
         return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
     if (hipMemcpy(pic.dSrc, staging.data(), picElems * sizeof(pixel), hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: upload");
-    if (hipMemset(pic.dRec, 0, picElems * sizeof(pixel)) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+    /* the frame tasks run on their own non-blocking streams: make sure the picture is in place before one can start */
+    if (hipMemset(pic.dRec, 0, picElems * sizeof(pixel)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
     return 0;
 }
 
@@ -277,41 +298,57 @@ void x265amd_encoder::decideMiniGop(bool flush)
     }
 }
 
-int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
+/* DPB::prepareEncode for the next picture in coding order (main thread): NAL type, reference picture set, reference lists, slice QP */
+int x265amd_encoder::prepare(const PicP& picp)
 {
+    Pic& pic = *picp;
     const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
-    /* ---- DPB::prepareEncode ---- */
-    const int nalType = pic.type == TYPE_IDR ? 20 : (pic.type == TYPE_B ? 0 : 1);      /* IDR_N_LP, TRAIL_N, TRAIL_R */
+    pic.nalType = pic.type == TYPE_IDR ? 20 : (pic.type == TYPE_B ? 0 : 1);      /* IDR_N_LP, TRAIL_N, TRAIL_R */
     if (pic.type == TYPE_IDR) lastIDR = pic.poc;
+    pic.lastIDR = lastIDR;
     pic.hasReferences = pic.type != TYPE_B;
     /* recycleUnreferenced: pictures nobody references leave the list */
     picList.erase(std::remove_if(picList.begin(), picList.end(), [](const PicP& q) { return !q->hasReferences; }), picList.end());
     if (pic.type == TYPE_IDR) { for (auto& q : picList) q->hasReferences = false; }                 /* decodingRefreshMarking */
-    std::vector<Pic*> rps;                                                                              /* computeRPS */
+    std::vector<PicP> rps;                                                                              /* computeRPS */
     for (auto& q : picList)
     {
         if ((int)rps.size() >= maxDecPicBuffering - 1) break;
-        if (q->poc != pic.poc && q->hasReferences && (lastIDR >= pic.poc || lastIDR <= q->poc)) rps.push_back(q.get());
+        if (q->poc != pic.poc && q->hasReferences && (lastIDR >= pic.poc || lastIDR <= q->poc)) rps.push_back(q);
     }
     for (auto& q : picList)                                                                             /* applyReferencePictureSet */
-        if (q->hasReferences && std::find(rps.begin(), rps.end(), q.get()) == rps.end()) q->hasReferences = false;
-    std::vector<Pic*> neg, pos;
-    for (Pic* q : rps) (q->poc < pic.poc ? neg : pos).push_back(q);
-    std::sort(neg.begin(), neg.end(), [](Pic* a, Pic* b) { return a->poc > b->poc; });                 /* RPS::sortDeltaPOC */
-    std::sort(pos.begin(), pos.end(), [](Pic* a, Pic* b) { return a->poc < b->poc; });
-    std::vector<Pic*> lists[2];
+        if (q->hasReferences && std::find(rps.begin(), rps.end(), q) == rps.end()) q->hasReferences = false;
+    pic.neg.clear(); pic.pos.clear(); pic.lists[0].clear(); pic.lists[1].clear();
+    for (const PicP& q : rps) (q->poc < pic.poc ? pic.neg : pic.pos).push_back(q);
+    std::sort(pic.neg.begin(), pic.neg.end(), [](const PicP& a, const PicP& b) { return a->poc > b->poc; });           /* RPS::sortDeltaPOC */
+    std::sort(pic.pos.begin(), pic.pos.end(), [](const PicP& a, const PicP& b) { return a->poc < b->poc; });
     if (stype != 2)
     {
-        const int n0 = std::min(std::max(1, (int)neg.size()), p.maxNumReferences), n1 = stype == 0 ? std::min(1, (int)pos.size()) : 0;
-        std::vector<Pic*> l0(neg), l1(pos);
-        l0.insert(l0.end(), pos.begin(), pos.end()); l1.insert(l1.end(), neg.begin(), neg.end());
+        const int n0 = std::min(std::max(1, (int)pic.neg.size()), p.maxNumReferences), n1 = stype == 0 ? std::min(1, (int)pic.pos.size()) : 0;
+        std::vector<PicP> l0(pic.neg), l1(pic.pos);
+        l0.insert(l0.end(), pic.pos.begin(), pic.pos.end()); l1.insert(l1.end(), pic.neg.begin(), pic.neg.end());
         if ((int)l0.size() < n0 || (int)l1.size() < n1 || (stype == 0 && !n1)) return xa_fail(X265AMD_EINVAL, "encoder_encode: reference lists");
-        lists[0].assign(l0.begin(), l0.begin() + n0); lists[1].assign(l1.begin(), l1.begin() + n1);
+        pic.lists[0].assign(l0.begin(), l0.begin() + n0); pic.lists[1].assign(l1.begin(), l1.begin() + n1);
     }
-    /* ---- rateControlStart, CQP ---- */
-    pic.sliceQp = qpConstant[stype];
+    pic.sliceQp = qpConstant[stype];                    /* rateControlStart, CQP */
+    picList.insert(picList.begin(), picp);              /* PicList::pushFront */
+    return 0;
+}
 
-    /* ---- the frame ---- */
+/* FrameEncoder::compressFrame for one picture (its own thread and HIP stream).  The analysis starts when every reference picture is final; the
+ * in-loop filters, SAO (its decision carries state from picture to picture, SAO::m_depthSaoRate) and the shared filter scratch run in coding
+ * order, i.e. after the previous picture's task. */
+int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
+{
+    Pic& pic = *picp;
+    const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
+    for (int l = 0; l < 2; l++)
+        for (const PicP& q : pic.lists[l]) if (q->done.valid() && q->done.get() != 0) return X265AMD_EHIP;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: stream");
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    const std::vector<PicP>* lists = pic.lists;
+
     std::vector<uint64_t> planes;
     std::vector<Pic*> index;
     int32_t refPic[2][16];
@@ -319,7 +356,7 @@ int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
     for (int l = 0; l < 2; l++)
         for (size_t r = 0; r < lists[l].size(); r++)
         {
-            Pic* q = lists[l][r];
+            Pic* q = lists[l][r].get();
             size_t k = std::find(index.begin(), index.end(), q) - index.begin();
             if (k == index.size()) { index.push_back(q); for (int c = 0; c < 3; c++) planes.push_back(planeAddr(q->dRec, c)); }
             refPic[l][r] = (int32_t)k; pic.refPoc[l][r] = q->poc;
@@ -333,7 +370,7 @@ int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
     info.num_ref_idx[0] = (int32_t)lists[0].size(); info.num_ref_idx[1] = (int32_t)lists[1].size();
     info.temporal_mvp = p.bEnableTemporalMvp != 0; info.col_from_l0 = stype != 0; info.check_ldc = stype != 0; info.poc = pic.poc;
     memcpy(info.ref_poc, pic.refPoc, sizeof(info.ref_poc));
-    const Pic* colPic = stype == 2 ? nullptr : (stype == 1 ? lists[0][0] : lists[1][0]);
+    const Pic* colPic = stype == 2 ? nullptr : (stype == 1 ? lists[0][0].get() : lists[1][0].get());
     if (colPic) { info.col_poc = colPic->poc; memcpy(info.col_ref_poc, colPic->refPoc, sizeof(info.col_ref_poc)); }
 
     x265amd_inter_search_params sp;
@@ -365,7 +402,7 @@ int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
     for (int l = 0; l < 2; l++)
         if (!lists[l].empty())
         {
-            const Pic* q = lists[l][0];
+            const Pic* q = lists[l][0].get();
             for (size_t i = 0; i < nUnits; i++) refDepth[l * nUnits + i] = q->units[i].depth;
             for (int i = 0; i < nctu; i++) refQp0[(size_t)l * nctu + i] = (int8_t)q->sliceQp;
         }
@@ -376,20 +413,25 @@ int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
     std::vector<uint32_t> sizes((size_t)ctuH + 1, 0);
     int nsub = 0;
     const bool sao = p.bEnableSAO != 0;
-    int rc = x265amd_analyse_frame(me, nullptr, &info, &sp, &si, &ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
+    int rc = x265amd_analyse_frame(me, st, &info, &sp, &si, &ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                    refDepth.data(), refQp0.data(), planes.data(), (int)(planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
                                    sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub);
     if (rc != X265AMD_OK) return rc;
+    if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: analysis");
+
+    /* ---- from here on in coding order ---- */
+    if (prev.valid() && prev.get() != 0) return X265AMD_EHIP;
     pixel* recY = pic.dRec + org[0]; pixel* recU = pic.dRec + org[1]; pixel* recV = pic.dRec + org[2];
     if (p.bEnableLoopFilter)
     {
         std::vector<x265amd_deblock_unit> dbu(nUnits);
         rc = x265amd_deblock_units(&si, &info, pic.units.data(), pic.motion.data(), dbu.data());
         if (rc != X265AMD_OK) return rc;
-        if (hipMemcpy(dDbUnits, dbu.data(), sizeof(x265amd_deblock_unit) * nUnits, hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: deblock upload");
-        rc = x265amd_deblock_picture(nullptr, recY, recU, recV, stride, cstride, W, H, dDbUnits, 0, 0, 0, 0, 0, 3);
+        if (hipMemcpyAsync(dDbUnits, dbu.data(), sizeof(x265amd_deblock_unit) * nUnits, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder: deblock upload");
+        rc = x265amd_deblock_picture(st, recY, recU, recV, stride, cstride, W, H, dDbUnits, 0, 0, 0, 0, 0, 3);
         if (rc != X265AMD_OK) return rc;
-        if (hipDeviceSynchronize() != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: deblock");
+        if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: deblock");
     }
     int32_t saoFlags[2] = { 0, 0 };
     if (sao)
@@ -397,44 +439,47 @@ int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
         const size_t nstat = (size_t)nctu * 3 * 5 * 32;
         const uint64_t recP[3] = { planeAddr(pic.dRec, 0), planeAddr(pic.dRec, 1), planeAddr(pic.dRec, 2) };
         const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
-        if (hipMemset(dSaoCount, 0, nstat * 4) != hipSuccess || hipMemset(dSaoOrg, 0, nstat * 4) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao memset");
-        rc = x265amd_sao_stats(nullptr, recP, srcP, stride, cstride, W, H, dSaoCount, dSaoOrg);
+        if (hipMemsetAsync(dSaoCount, 0, nstat * 4, st) != hipSuccess || hipMemsetAsync(dSaoOrg, 0, nstat * 4, st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao memset");
+        rc = x265amd_sao_stats(st, recP, srcP, stride, cstride, W, H, dSaoCount, dSaoOrg);
         if (rc != X265AMD_OK) return rc;
         std::vector<int32_t> cnt(nstat), orgs(nstat);
-        if (hipMemcpy(cnt.data(), dSaoCount, nstat * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(orgs.data(), dSaoOrg, nstat * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipMemcpyAsync(cnt.data(), dSaoCount, nstat * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipMemcpyAsync(orgs.data(), dSaoOrg, nstat * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return xa_fail(X265AMD_EHIP, "encoder: sao download");
         std::vector<x265amd_sao_ctu> sparams((size_t)nctu);
         memset(sparams.data(), 0, sizeof(x265amd_sao_ctu) * nctu);
-        rc = x265amd_sao_rdo(&si, pic.hasReferences ? 1 : 0, 1, 0, 69, pic.units.data(), cnt.data(), orgs.data(), depthSaoRate, sparams.data(), saoFlags);
+        rc = x265amd_sao_rdo(&si, pic.type != TYPE_B ? 1 : 0, 1, 0, 69,       /* IS_REFERENCED: fixed by the type (hasReferences changes as later pictures are prepared) */
+                             pic.units.data(), cnt.data(), orgs.data(), depthSaoRate, sparams.data(), saoFlags);
         if (rc != X265AMD_OK) return rc;
-        if (hipMemcpy(dSaoParams, sparams.data(), sizeof(x265amd_sao_ctu) * nctu, hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao upload");
-        if (hipMemcpy(dSaoTmp, pic.dRec, picElems * sizeof(pixel), hipMemcpyDeviceToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao copy");
+        if (hipMemcpyAsync(dSaoParams, sparams.data(), sizeof(x265amd_sao_ctu) * nctu, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dSaoTmp, pic.dRec, picElems * sizeof(pixel), hipMemcpyDeviceToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder: sao upload");
         const uint64_t dstP[3] = { planeAddr(dSaoTmp, 0), planeAddr(dSaoTmp, 1), planeAddr(dSaoTmp, 2) };
-        rc = x265amd_sao_apply(nullptr, recP, dstP, stride, cstride, W, H, dSaoParams);
+        rc = x265amd_sao_apply(st, recP, dstP, stride, cstride, W, H, dSaoParams);
         if (rc != X265AMD_OK) return rc;
-        if (hipDeviceSynchronize() != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao");
+        if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: sao");
         std::swap(pic.dRec, dSaoTmp);
         recY = pic.dRec + org[0]; recU = pic.dRec + org[1]; recV = pic.dRec + org[2];
         rc = x265amd_encode_slice_data(&si, pic.units.data(), coeff.data(), sparams.data(), saoFlags, data.data(), data.size(), sizes.data(), &nsub);
         if (rc != X265AMD_OK) return rc;
     }
     /* the reconstruction becomes a reference: extend its borders */
-    rc = x265amd_extend_pic_border(nullptr, recY, stride, W, H, marginX, marginY);
-    if (rc == X265AMD_OK) rc = x265amd_extend_pic_border(nullptr, recU, cstride, W / 2, H / 2, marginX / 2, marginY / 2);
-    if (rc == X265AMD_OK) rc = x265amd_extend_pic_border(nullptr, recV, cstride, W / 2, H / 2, marginX / 2, marginY / 2);
+    rc = x265amd_extend_pic_border(st, recY, stride, W, H, marginX, marginY);
+    if (rc == X265AMD_OK) rc = x265amd_extend_pic_border(st, recU, cstride, W / 2, H / 2, marginX / 2, marginY / 2);
+    if (rc == X265AMD_OK) rc = x265amd_extend_pic_border(st, recV, cstride, W / 2, H / 2, marginX / 2, marginY / 2);
     if (rc != X265AMD_OK) return rc;
-    if (hipDeviceSynchronize() != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: border extension");
+    if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: border extension");
 
     /* ---- slice header (Entropy::codeSliceHeader inputs as DPB / Encoder set them) ---- */
     x265amd_slice_header h;
     memset(&h, 0, sizeof(h));
-    h.nal_unit_type = nalType; h.temporal_id_plus1 = 1; h.first_in_access_unit = 1;
-    h.slice_type = stype; h.poc = pic.poc; h.last_idr_poc = lastIDR; h.log2_max_poc_lsb = 8; h.rps_idx = -1; h.num_rps_in_sps = 0;
-    h.num_negative = (int32_t)neg.size(); h.num_positive = (int32_t)pos.size();
+    h.nal_unit_type = pic.nalType; h.temporal_id_plus1 = 1; h.first_in_access_unit = 1;
+    h.slice_type = stype; h.poc = pic.poc; h.last_idr_poc = pic.lastIDR; h.log2_max_poc_lsb = 8; h.rps_idx = -1; h.num_rps_in_sps = 0;
+    h.num_negative = (int32_t)pic.neg.size(); h.num_positive = (int32_t)pic.pos.size();
     {
         int j = 0;
-        for (Pic* q : neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
-        for (Pic* q : pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+        for (const PicP& q : pic.neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+        for (const PicP& q : pic.pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
     }
     h.temporal_mvp_enabled = p.bEnableTemporalMvp != 0;
     h.use_sao = sao; h.sao_luma = saoFlags[0]; h.sao_chroma = saoFlags[1];
@@ -445,27 +490,13 @@ int x265amd_encoder::encodeOne(Pic& pic, x265amd_picture* picOut)
     h.wpp = p.bEnableWavefront != 0;
     size_t dataBytes = 0;
     for (int s = 0; s < nsub; s++) dataBytes += sizes[s];
-    outBytes.assign(dataBytes * 3 / 2 + 4096, 0);
-    const size_t n = x265amd_write_slice_nal(&h, data.data(), sizes.data(), nsub, outBytes.data(), outBytes.size());
-    if (!n || n > outBytes.size()) return xa_fail(X265AMD_EINVAL, "encoder: slice NAL");
-    outBytes.resize(n);
-    splitNals(outBytes, nals);
-
-    if (picOut)
-    {
-        staging.resize(picElems);
-        if (hipMemcpy(staging.data(), pic.dRec, picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: recon download");
-        for (int k = 0; k < 3; k++)
-        {
-            if (!picOut->planes[k]) continue;
-            const int w = k ? W / 2 : W, hh = k ? H / 2 : H;
-            const intptr_t st = k ? cstride : stride;
-            for (int y = 0; y < hh; y++) memcpy((uint8_t*)picOut->planes[k] + (size_t)y * picOut->stride[k], staging.data() + org[k] + (intptr_t)y * st, sizeof(pixel) * w);
-        }
-        picOut->poc = pic.poc; picOut->sliceType = pic.type; picOut->qp = pic.sliceQp;
-    }
-    /* the source is no longer needed; the reconstruction stays while the picture is referenced */
-    (void)hipFree(pic.dSrc); pic.dSrc = nullptr;
+    pic.nalBytes.assign(dataBytes * 3 / 2 + 4096, 0);
+    const size_t n = x265amd_write_slice_nal(&h, data.data(), sizes.data(), nsub, pic.nalBytes.data(), pic.nalBytes.size());
+    if (!n || n > pic.nalBytes.size()) return xa_fail(X265AMD_EINVAL, "encoder: slice NAL");
+    pic.nalBytes.resize(n);
+    /* the source is no longer needed; the reconstruction stays while the picture is referenced.  The reference lists are only needed by pictures
+     * that are still to come through their own lists */
+    xa_scratch_free(pic.dSrc); pic.dSrc = nullptr;
     return 0;
 }
 
@@ -482,18 +513,52 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         if (rc) return -1;
         e->input.push_back(pic);
     }
-    if (e->ready.empty()) e->decideMiniGop(picIn == nullptr);
-    if (e->ready.empty()) return 0;
-    PicP pic = e->ready.front();
-    e->ready.pop_front();
-    const bool timing = getenv("X265AMD_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    const int rc = e->encodeOne(*pic, picOut);
-    if (timing)
-        fprintf(stderr, "x265amd: poc %d type %d qp %d: %.2f ms\n", pic->poc, pic->type, pic->sliceQp,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (rc) return -1;
-    e->picList.insert(e->picList.begin(), pic);                 /* PicList::pushFront */
+    e->decideMiniGop(picIn == nullptr);
+    /* start every typed picture: preparation in coding order here, the frame itself as a task */
+    while (!e->ready.empty())
+    {
+        PicP pic = e->ready.front();
+        e->ready.pop_front();
+        if (e->prepare(pic)) return -1;
+        std::shared_future<int> prev = e->lastTask;
+        const bool timing = getenv("X265AMD_TIMING") != nullptr;
+        pic->done = std::async(std::launch::async, [e, pic, prev, timing]() {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = e->runFrame(pic, prev);
+            if (timing)
+                fprintf(stderr, "x265amd: poc %d type %d qp %d: %.2f ms\n", pic->poc, pic->type, pic->sliceQp,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            return rc;
+        }).share();
+        e->lastTask = pic->done;
+        e->inflight.push_back(pic);
+        if (e->frameThreads <= 1) pic->done.wait();
+    }
+    if (e->inflight.empty()) return 0;
+    PicP front = e->inflight.front();
+    const bool mustWait = !picIn || (int)e->inflight.size() > e->frameThreads + 1;
+    if (!mustWait && front->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return 0;
+    const int rc = front->done.get();
+    e->inflight.pop_front();
+    if (rc) { xa_fail(rc, "encoder_encode: a frame task failed"); return -1; }
+    e->outBytes.swap(front->nalBytes);
+    splitNals(e->outBytes, e->nals);
+    if (picOut)
+    {
+        e->staging.resize(e->picElems);
+        if (hipMemcpy(e->staging.data(), front->dRec, e->picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder: recon download"); return -1; }
+        for (int k = 0; k < 3; k++)
+        {
+            if (!picOut->planes[k]) continue;
+            const int w = k ? e->W / 2 : e->W, hh = k ? e->H / 2 : e->H;
+            const intptr_t st = k ? e->cstride : e->stride;
+            for (int y = 0; y < hh; y++)
+                memcpy((uint8_t*)picOut->planes[k] + (size_t)y * picOut->stride[k], e->staging.data() + e->org[k] + (intptr_t)y * st, sizeof(pixel) * w);
+        }
+        picOut->poc = front->poc; picOut->sliceType = front->type; picOut->qp = front->sliceQp;
+    }
+    /* a finished picture that nobody references any more releases its lists (and with them the pictures only it kept alive) */
+    front->lists[0].clear(); front->lists[1].clear(); front->neg.clear(); front->pos.clear();
     if (ppNal) *ppNal = e->nals.data();
     if (piNal) *piNal = (uint32_t)e->nals.size();
     return 1;
