@@ -431,7 +431,16 @@ def make_encoder_api_golden():
                                         ("long/", (128, 128), 14, ["--bframes", "2", "--no-b-pyramid", "--ref", "4"]),
                                         ("hbd_b/", (192, 136), 7, ["--bframes", "2", "--no-b-pyramid", "--sao", "--rect", "--amp"]),
                                         ("hbd_rd5/", (128, 128), 4, ["--bframes", "0", "--rd", "5"]),
-                                        ("wvga/", (832, 480), 5, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"])):
+                                        ("wvga/", (832, 480), 5, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"]),
+                                        # the option space of the built subset (tests/test_encoder_api.py OPTION_CONFIGS)
+                                        ("opt_a/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--me", "star", "--subme", "3", "--ref", "2", "--max-merge", "5"]),
+                                        ("opt_b/", (192, 128), 5, ["--bframes", "0", "--me", "dia", "--subme", "1", "--ref", "1", "--max-merge", "2", "--no-early-skip", "--rskip", "0"]),
+                                        ("opt_c/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--tu-inter-depth", "3", "--tu-intra-depth", "3", "--limit-refs", "0", "--no-signhide"]),
+                                        ("opt_d/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--no-strong-intra-smoothing", "--no-temporal-mvp", "--no-b-intra", "--limit-refs", "1"]),
+                                        ("opt_e/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--subme", "5", "--rd", "4", "--sao"]),
+                                        ("opt_f/", (192, 128), 4, ["--bframes", "0", "--qp", "22", "--subme", "4"]),
+                                        ("opt_g/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--qp", "38", "--subme", "7", "--me", "star", "--rd", "5", "--rect", "--amp"]),
+                                        ("opt_h/", (192, 128), 4, ["--bframes", "0", "--subme", "0", "--rd", "2", "--tu-inter-depth", "2"])):
         depth = 10 if tag.startswith("hbd") else 8
         planes = T.encoder_api_clip(tag, w, h, nframes, depth)
         cli = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]

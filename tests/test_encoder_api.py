@@ -72,6 +72,15 @@ EDGE_CONFIGS = {
     "hbd_b/": ((192, 136), 7, dict(BASE, bframes=2, bEnableSAO=1, bEnableRectInter=1, bEnableAMP=1)),       # 10-bit library (libx265amd_main10.so)
     "hbd_rd5/": ((128, 128), 4, dict(BASE, rdLevel=5)),
     "wvga/": ((832, 480), 5, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1)),     # 13 x 8 CTUs (last row cut), 8 row threads in flight
+    # the option space of the built subset: search methods and sub-pel levels, reference counts, merge candidates, early-outs, TU depths, tools on / off, QPs
+    "opt_a/": ((192, 128), 5, dict(BASE, bframes=2, searchMethod=3, subpelRefine=3, maxNumReferences=2, maxNumMergeCand=5)),
+    "opt_b/": ((192, 128), 5, dict(BASE, searchMethod=0, subpelRefine=1, maxNumReferences=1, maxNumMergeCand=2, bEnableEarlySkip=0, recursionSkipMode=0)),
+    "opt_c/": ((192, 128), 5, dict(BASE, bframes=2, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3, limitReferences=0, bEnableSignHiding=0)),
+    "opt_d/": ((192, 128), 5, dict(BASE, bframes=2, bEnableStrongIntraSmoothing=0, bEnableTemporalMvp=0, bIntraInBFrames=0, limitReferences=1)),
+    "opt_e/": ((192, 128), 5, dict(BASE, bframes=2, subpelRefine=5, rdLevel=4, bEnableSAO=1)),
+    "opt_f/": ((192, 128), 4, dict(BASE, qp=22, subpelRefine=4)),
+    "opt_g/": ((192, 128), 5, dict(BASE, bframes=2, qp=38, subpelRefine=7, searchMethod=3, rdLevel=5, bEnableRectInter=1, bEnableAMP=1)),
+    "opt_h/": ((192, 128), 4, dict(BASE, subpelRefine=0, rdLevel=2, tuQTMaxInterDepth=2)),
 }
 
 
