@@ -586,13 +586,16 @@ int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, const x265amd
  * The transform chains of every node of every CU's residual quad-tree run as one x265amd_tu_chain launch (plain quantisation does not
  * depend on the entropy state); the bit counting and the decisions walk the tree on the host in the reference's order with the
  * bit-counting CABAC coder; a second launch assembles the chosen residual, reconstructs and measures the CU.
- * Supported: 4:2:0, rdoqLevel 0, no transform skip / lossless / limit-tu / ssim-rd, chroma QP offsets 0. */
+ * Supported: 4:2:0, rdoqLevel 0-2 (psy-rdoq), no transform skip / lossless / limit-tu / ssim-rd, chroma QP offsets 0. */
 typedef struct x265amd_rd_params
 {
     double psy_rd;                  /* param.psyRd (RDCost::setPsyRdScale, rdcost.h:43) */
     int32_t rd_level;               /* param.rdLevel: how checkDQP prices a delta QP (>= 3 codes it, 2 counts one bit) */
     int32_t strong_intra_smoothing; /* sps.bUseStrongIntraSmoothing (intra candidates only) */
-} x265amd_rd_params;
+    int32_t rdoq_level;             /* param.rdoqLevel 0 / 1 / 2: with RDOQ every transform unit is quantised under the entropy state the walk has reached
+                                     * (Entropy::estBit before each Quant::transformNxN, search.cpp:355, :852, :3272, :3397), one launch per unit */
+    int32_t psy_rdoq_scale;         /* Quant::m_psyRdoqScale = (int)(param.psyRdoq * 256) */
+} x265amd_rd_params;                /* 24 bytes */
 typedef struct x265amd_rd_cu
 {
     int16_t x, y;                   /* luma position of the CU in the picture */
@@ -696,7 +699,8 @@ typedef struct x265amd_analysis_params
     int32_t rd_level, early_skip, rskip, limit_refs, b_intra, rect, amp, limit_modes;
     int32_t strong_intra_smoothing;             /* sps.bUseStrongIntraSmoothing */
     int32_t use_sao;                            /* slice.m_bUseSao: x265amd_analyse_frame only (the row coder counts bits only when SAO is on) */
-} x265amd_analysis_params;          /* 48 bytes */
+    int32_t rdoq_level, psy_rdoq_scale;         /* param.rdoqLevel, (int)(param.psyRdoq * 256) */
+} x265amd_analysis_params;          /* 56 bytes */
 typedef struct x265amd_cu_stat { uint32_t count[4]; uint32_t pad[2]; uint64_t avg_cost[4]; } x265amd_cu_stat;     /* FrameData::RCStatCU count / avgCost per depth */
 typedef struct x265amd_ctu_result { uint64_t rd_cost, distortion, frac_bits; uint32_t total_bits, reserved; uint8_t ctx[X265AMD_CTX_STRIDE]; } x265amd_ctu_result;
 /* units / cur: the picture's unit map and motion field (what is coded so far); the CTU's part is reset and then filled with the decisions.

@@ -440,7 +440,12 @@ def make_encoder_api_golden():
                                         ("opt_e/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--subme", "5", "--rd", "4", "--sao"]),
                                         ("opt_f/", (192, 128), 4, ["--bframes", "0", "--qp", "22", "--subme", "4"]),
                                         ("opt_g/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--qp", "38", "--subme", "7", "--me", "star", "--rd", "5", "--rect", "--amp"]),
-                                        ("opt_h/", (192, 128), 4, ["--bframes", "0", "--subme", "0", "--rd", "2", "--tu-inter-depth", "2"])):
+                                        ("opt_h/", (192, 128), 4, ["--bframes", "0", "--subme", "0", "--rd", "2", "--tu-inter-depth", "2"]),
+                                        # rate-distortion optimised quantisation (the slow presets): level 1, level 2 with psy-rdoq, with TU splits
+                                        ("rdoq_a/", (192, 128), 4, ["--bframes", "0", "--rdoq-level", "1"]),
+                                        ("rdoq_b/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "1.0", "--rd", "4"]),
+                                        ("rdoq_c/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "2.5", "--tu-inter-depth", "3",
+                                                                    "--tu-intra-depth", "3", "--rd", "5", "--no-signhide"])):
         depth = 10 if tag.startswith("hbd") else 8
         planes = T.encoder_api_clip(tag, w, h, nframes, depth)
         cli = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]

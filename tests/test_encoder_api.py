@@ -81,6 +81,10 @@ EDGE_CONFIGS = {
     "opt_f/": ((192, 128), 4, dict(BASE, qp=22, subpelRefine=4)),
     "opt_g/": ((192, 128), 5, dict(BASE, bframes=2, qp=38, subpelRefine=7, searchMethod=3, rdLevel=5, bEnableRectInter=1, bEnableAMP=1)),
     "opt_h/": ((192, 128), 4, dict(BASE, subpelRefine=0, rdLevel=2, tuQTMaxInterDepth=2)),
+    # RDOQ: every transform unit is quantised under the entropy state the RD walk has reached (one launch per unit)
+    "rdoq_a/": ((192, 128), 4, dict(BASE, rdoqLevel=1)),
+    "rdoq_b/": ((192, 128), 5, dict(BASE, bframes=2, rdoqLevel=2, psyRdoqFix8=256, rdLevel=4)),
+    "rdoq_c/": ((192, 128), 5, dict(BASE, bframes=2, rdoqLevel=2, psyRdoqFix8=640, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3, rdLevel=5, bEnableSignHiding=0)),
 }
 
 

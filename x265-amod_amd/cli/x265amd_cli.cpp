@@ -4,7 +4,7 @@
  *
  *     x265amd --input clip.y4m -o out.hevc [--recon rec.yuv] [--qp N] [--bframes N] [--keyint N] [--ref N] [--rd 2..6] [--rect] [--amp]
  *             [--limit-modes] [--limit-refs N] [--[no-]early-skip] [--rskip 0|1] [--psy-rd F] [--[no-]b-intra] [--me dia|hex|star] [--subme N]
- *             [--merange N] [--max-merge N] [--[no-]deblock] [--[no-]sao] [--[no-]wpp] [--frames N]
+ *             [--merange N] [--max-merge N] [--rdoq-level N] [--psy-rdoq F] [--[no-]deblock] [--[no-]sao] [--[no-]wpp] [--frames N]
  *
  * Like the reference (source/encoder/api.cpp:1107-1182, x265_api_get) the pixel depth selects the library: libx265amd_main.so for 8-bit input,
  * libx265amd_main10.so for 10-bit, loaded with dlopen from the directory of this program's ../lib.  Host C++ only; all device work is the library's. */
@@ -152,6 +152,8 @@ int main(int argc, char** argv)
         else if (k == "--no-sao") p.bEnableSAO = 0;
         else if (k == "--wpp") p.bEnableWavefront = 1;
         else if (k == "--no-wpp") p.bEnableWavefront = 0;
+        else if (k == "--rdoq-level") p.rdoqLevel = atoi(v);
+        else if (k == "--psy-rdoq") p.psyRdoqFix8 = (int)(atof(v) * 256.0);
         else if (k == "--ipratio") p.ipFactor = atof(v);
         else if (k == "--pbratio") p.pbFactor = atof(v);
         else { fprintf(stderr, "x265amd: unknown option %s\n", k.c_str()); return 2; }

@@ -1097,7 +1097,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
-    if (A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+    if (A->rdoq_level < 0 || A->rdoq_level > 2 || A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 2-6, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
     Analyzer* an = new Analyzer;
@@ -1120,6 +1120,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         x265amd_rdcost(a.qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
         a.lambda2 = rd[0]; a.lambda = rd[1]; a.psyRd = (uint32_t)rd[2];
         a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = A->strong_intra_smoothing;
+        a.rp.rdoq_level = A->rdoq_level; a.rp.psy_rdoq_scale = A->rdoq_level ? A->psy_rdoq_scale : 0;
         /* CUData::initCTU: nothing of this CTU is decided yet */
         for (int yy = a.ctuY >> 2; yy < (a.ctuY >> 2) + 16 && yy < a.h4; yy++)
             for (int xx = a.ctuX >> 2; xx < (a.ctuX >> 2) + 16 && xx < a.w4; xx++)

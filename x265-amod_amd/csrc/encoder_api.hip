@@ -158,7 +158,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         p->qp < 0 || p->qp > 51 || p->rdLevel < 2 || p->rdLevel > 6 || p->maxNumMergeCand < 1 || p->maxNumMergeCand > 5 ||
         p->tuQTMaxInterDepth < 1 || p->tuQTMaxInterDepth > 4 || p->tuQTMaxIntraDepth < 1 || p->tuQTMaxIntraDepth > 4 ||
         (p->searchMethod != X265AMD_ME_DIA && p->searchMethod != X265AMD_ME_HEX && p->searchMethod != X265AMD_ME_STAR) || p->subpelRefine < 0 || p->subpelRefine > 7 ||
-        p->recursionSkipMode < 0 || p->recursionSkipMode > 1 || p->limitReferences < 0 || p->limitReferences > 3 || (p->bEnableAMP && !p->bEnableRectInter))
+        p->rdoqLevel < 0 || p->rdoqLevel > 2 || p->psyRdoqFix8 < 0 || p->recursionSkipMode < 0 || p->recursionSkipMode > 1 || p->limitReferences < 0 || p->limitReferences > 3 || (p->bEnableAMP && !p->bEnableRectInter))
     { xa_fail(X265AMD_EINVAL, "encoder_open: parameter outside the built subset (see x265amd_encoder.h)"); return nullptr; }
     std::unique_ptr<x265amd_encoder> e(new x265amd_encoder);
     e->p = *p;
@@ -391,6 +391,7 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
     ap.psy_rd = p.psyRd; ap.rd_level = p.rdLevel; ap.early_skip = p.bEnableEarlySkip != 0; ap.rskip = p.recursionSkipMode; ap.limit_refs = p.limitReferences;
     ap.b_intra = p.bIntraInBFrames != 0; ap.rect = p.bEnableRectInter != 0; ap.amp = p.bEnableAMP != 0; ap.limit_modes = p.limitModes != 0;
     ap.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0; ap.use_sao = p.bEnableSAO != 0;
+    ap.rdoq_level = p.rdoqLevel; ap.psy_rdoq_scale = p.rdoqLevel ? p.psyRdoqFix8 : 0;      /* encoder.cpp:3667: no psy-rdoq without RDOQ */
 
     const size_t nUnits = (size_t)w4 * h4;
     pic.units.assign(nUnits, x265amd_cu_unit()); pic.motion.assign(nUnits, x265amd_mv_unit());

@@ -21,6 +21,7 @@
 #include "../host/cabac_coder.h"
 #include <string.h>
 #include <vector>
+#include <functional>
 
 /* ---------------- device: CU assembly + measurement ---------------- */
 #define RD_LUMA_ELEMS 4096
@@ -136,7 +137,18 @@ struct Walker
     uint64_t lambda2, lambda; uint32_t psyRd;
     Snap rqtRoot[6], rqtTest[6];
 
+    /* RDOQ: the transform units are not quantised ahead of the walk; `demand(first job, count, luma?, size, tuDepth)` runs them when the walk reaches them,
+     * under the entropy state it has then (it fills res / levels for those jobs) */
+    std::function<int(int, int, bool, int, int)> demand;
+    int err = 0;
+
     Walker(x265amd_cabac& coder, const CuPlan& plan, const x265amd_tu_result* r, const int16_t* lv) : c(coder), P(plan), res(r), levels(lv) {}
+    int nodeJob(int plane, int layer, int x, int y) const
+    {
+        const int sh = plane ? 1 : 0, n = 1 << layer, nt = (P.size >> sh) >> layer;
+        const int tx = ((x - P.x) >> sh) / n, ty = ((y - P.y) >> sh) / n;
+        return (plane ? P.chromaRes[layer][plane] : P.lumaRes[layer]) + ty * nt + tx;
+    }
 
     /* Entropy: getNumberOfWrittenBits / resetBits / load / store / bitsCodeBin (entropy.h:120-140, :219-224; entropy.cpp:2445-2455) */
     uint32_t bits() const { return (uint32_t)(c.fracBits >> 15); }
@@ -202,6 +214,7 @@ struct Walker
         if (bCheckFull)
         {
             setTuDepth(x, y, trSize, tuDepth);
+            if (demand && !err) err = demand(nodeJob(0, log2TrSize, x, y), 1, true, log2TrSize, tuDepth);
             {
                 const x265amd_tu_result& r = nodeResult(0, log2TrSize, x, y);
                 cbfFlag[0] = r.num_sig != 0;
@@ -231,6 +244,12 @@ struct Walker
             if (codeChroma)
                 for (int p = 1; p < 3; p++)
                 {
+                    /* one table for both chroma planes, taken before U is coded (search.cpp:3397) */
+                    if (p == 1 && demand && !err)
+                    {
+                        err = demand(nodeJob(1, log2TrSizeC, x, y), 1, false, log2TrSizeC, tuDepth);
+                        if (!err) err = demand(nodeJob(2, log2TrSizeC, x, y), 1, false, -log2TrSizeC, tuDepth);      /* negative size: keep the table */
+                    }
                     const x265amd_tu_result& r = nodeResult(p, log2TrSizeC, x, y);
                     cbfFlag[p] = r.num_sig != 0;
                     const uint32_t latestBitCount = bits();
@@ -515,9 +534,23 @@ extern "C" int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd
     return count;
 }
 
+/* runs jobs [first, first + count) of CU i now (RDOQ): ctx = the walk's entropy state */
+typedef std::function<int(int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth)> RdoqDemand;
+static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
+                              x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
+                              const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out, const RdoqDemand* demand);
+
 extern "C" int x265amd_inter_rd_walk(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
                                      x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
                                      const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out)
+{
+    if (rp && rp->rdoq_level) return xa_fail(X265AMD_EINVAL, "inter_rd_walk: with RDOQ the transform units are quantised during the walk: use x265amd_inter_residual_rd");
+    return inter_rd_walk_impl(si, rp, units, cus, n, cu_units, res, levels, levels_stride_bytes, zero_meas, sel, out, coeff_out, nullptr);
+}
+
+static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
+                              x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
+                              const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out, const RdoqDemand* demand)
 {
     if (!si || !rp || !units || !cus || !cu_units || !res || !levels || !zero_meas || !sel || !out || n < 0) return xa_fail(X265AMD_EINVAL, "inter_rd_walk: null argument");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
@@ -557,7 +590,10 @@ extern "C" int x265amd_inter_rd_walk(const x265amd_slice_info* si, const x265amd
 
         w.load(cur);
         Cost costs = { 0, 0, 0, 0 };
+        if (demand)
+            w.demand = [&, i](int first, int count, bool luma, int log2TrSize, int tuDepth) { return (*demand)(i, coder->ctx, first, count, luma, log2TrSize, tuDepth); };
         w.estimateResidualQT(P.x, P.y, 0, costs);
+        if (w.err) { x265amd_cabac_close(coder); return w.err; }
 
         /* the RD cost of not signalling any residual (:2869-2895) */
         const x265amd_cu_measure& m0 = zero_meas[i];
@@ -840,21 +876,65 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     XA_HIP_CHECK(mLevels.alloc((size_t)RD_SCRATCH_ELEMS * 2 * n));
     XA_HIP_CHECK(dSel.alloc((size_t)RD_SEL_BYTES * n));
     x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs);
-    int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)mJobs.p, nJobs, (x265amd_tu_result*)mRes.p);
-    if (rc != X265AMD_OK) return rc;
+    const bool rdoq = rp->rdoq_level != 0;
+    int rc = X265AMD_OK;
+    if (!rdoq)
+    {
+        rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)mJobs.p, nJobs, (x265amd_tu_result*)mRes.p);
+        if (rc != X265AMD_OK) return rc;
+    }
     CuMeasureJob* mjobs = (CuMeasureJob*)mMJobs.p;
     x265amd_cu_measure* meas = (x265amd_cu_measure*)mMeas.p;
     fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, scratch, perCuBytes, (const char*)dSel.p);
     hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mjobs, n, meas);
     XA_HIP_CHECK(hipGetLastError());
     /* the levels (the head of each CU's scratch) come to pinned host memory in one strided copy */
-    XA_HIP_CHECK(hipMemcpy2DAsync(mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n, hipMemcpyDeviceToHost, stream));
+    if (!rdoq) XA_HIP_CHECK(hipMemcpy2DAsync(mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n, hipMemcpyDeviceToHost, stream));
     XA_HIP_CHECK(hipStreamSynchronize(stream));
 
     /* ---- the walk ---- */
     std::vector<uint8_t> sel((size_t)RD_SEL_BYTES * n);
-    rc = x265amd_inter_rd_walk(si, rp, units, cus, n, cu_units, (const x265amd_tu_result*)mRes.p, (const int16_t*)mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, meas, sel.data(), out,
-                               coeff_out);
+    XaMapped mCtx, mEstJob, mRdoq;
+    DevBuf dEst;
+    RdoqDemand demandFn;
+    if (rdoq)
+    {
+        /* Quant::rdoQuant reads Entropy::m_estBitsSbac, refreshed by Entropy::estBit from the live contexts before each transform: k_est_bit on the
+         * walk's contexts, then the unit's chain, in stream order; results and levels are read back before the walk prices the unit */
+        XA_HIP_CHECK(mCtx.alloc(X265AMD_CTX_STRIDE)); XA_HIP_CHECK(mEstJob.alloc(sizeof(x265amd_est_job))); XA_HIP_CHECK(mRdoq.alloc(sizeof(x265amd_tu_rdoq)));
+        XA_HIP_CHECK(dEst.alloc(sizeof(x265amd_est_bits)));
+        XA_HIP_CHECK(hipMemsetAsync(dEst.p, 0, sizeof(x265amd_est_bits), stream));
+        demandFn = [&](int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth) -> int {
+            const x265amd_tu_job* jobs = (const x265amd_tu_job*)mJobs.p;
+            for (int k = first; k < first + count; k++)
+            {
+                if (log2TrSize > 0)
+                {
+                    memcpy(mCtx.p, ctx, X265AMD_CTX_COUNT);
+                    x265amd_est_job* ej = (x265amd_est_job*)mEstJob.p;
+                    memset(ej, 0, sizeof(*ej));
+                    ej->ctx = (uint64_t)(uintptr_t)mCtx.p; ej->est = (uint64_t)(uintptr_t)dEst.p; ej->log2_tr_size = (uint8_t)log2TrSize; ej->is_luma = luma ? 1 : 0;
+                    const int r = x265amd_est_bit(stream_, ej, 1);
+                    if (r != X265AMD_OK) return r;
+                }
+                x265amd_tu_rdoq* rq = (x265amd_tu_rdoq*)mRdoq.p;
+                memset(rq, 0, sizeof(*rq));
+                rq->est_bits = (uint64_t)(uintptr_t)dEst.p;
+                x265amd_rdoq_lambda(jobs[k].qp_scaled, &rq->lambda2, &rq->lambda);
+                rq->psy_rdoq_scale = rp->psy_rdoq_scale; rq->rdoq_level = (uint8_t)rp->rdoq_level; rq->tu_depth = (uint8_t)tuDepth;
+                const int r = x265amd_tu_chain_rdoq(stream_, jobs + k, rq, 1, (x265amd_tu_result*)mRes.p + k);
+                if (r != X265AMD_OK) return r;
+                const size_t nCoeff = (size_t)1 << (2 * jobs[k].log2_tr_size);
+                const size_t off = (size_t)(jobs[k].coeff - (uint64_t)(uintptr_t)scratch);          /* inside CU i's scratch: i * perCuBytes + level offset */
+                char* dst = (char*)mLevels.p + (size_t)RD_SCRATCH_ELEMS * 2 * i + (off - perCuBytes * i);
+                if (hipMemcpyAsync(dst, (const void*)(uintptr_t)jobs[k].coeff, nCoeff * 2, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+                    return xa_fail(X265AMD_EHIP, "inter_residual_rd: RDOQ unit");
+            }
+            return X265AMD_OK;
+        };
+    }
+    rc = inter_rd_walk_impl(si, rp, units, cus, n, cu_units, (const x265amd_tu_result*)mRes.p, (const int16_t*)mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, meas, sel.data(), out,
+                            coeff_out, rdoq ? &demandFn : nullptr);
     if (rc != X265AMD_OK) return rc;
 
     /* ---- launch 2: assemble, reconstruct, measure ---- */

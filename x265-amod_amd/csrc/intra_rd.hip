@@ -56,6 +56,8 @@ struct IntraRd
     uint64_t predTile, reconTile;
     DevBuf dResi, dLayer, dCand;
     XaMapped dJobs, dRes, dCoeff, dScan, dScanJob;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
+    DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
     /* a luma TU whose chain already ran in a batch (the candidates of one partition share their neighbours, so they run as one launch):
      * codeIntraLumaQT takes the result instead of launching; the winner's prediction / reconstruction are copied when it is measured again */
@@ -131,10 +133,32 @@ struct IntraRd
     int fail(const char* msg) { if (!err) err = xa_fail(X265AMD_EHIP, msg); return err; }
 
     /* one launch of up to two intra TU jobs; results and levels come back to the host */
-    int runJobs(x265amd_intra_tu_job* jobs, int n, x265amd_tu_result* res, int16_t* const* levelsOut, int numCoeff)
+    /* estCtx (RDOQ only): the contexts Entropy::estBit(log2 size, luma?) reads before these units' Quant::transformNxN; NULL keeps the table */
+    int runJobs(x265amd_intra_tu_job* jobs, int n, x265amd_tu_result* res, int16_t* const* levelsOut, int numCoeff, const uint8_t* estCtx, int tuDepth)
     {
         memcpy(dJobs.p, jobs, sizeof(x265amd_intra_tu_job) * n);
-        if (x265amd_intra_tu_chain(st, (const x265amd_intra_tu_job*)dJobs.p, nullptr, n, (x265amd_tu_result*)dRes.p) != X265AMD_OK) return err = X265AMD_EHIP;
+        const x265amd_tu_rdoq* rdoq = nullptr;
+        if (rp->rdoq_level)
+        {
+            if (estCtx)
+            {
+                memcpy(mCtx.p, estCtx, X265AMD_CTX_COUNT);
+                x265amd_est_job* ej = (x265amd_est_job*)mEstJob.p;
+                memset(ej, 0, sizeof(*ej));
+                ej->ctx = (uint64_t)(uintptr_t)mCtx.p; ej->est = (uint64_t)(uintptr_t)dEst.p; ej->log2_tr_size = jobs[0].tu.log2_tr_size; ej->is_luma = jobs[0].tu.ttype == 0;
+                if (x265amd_est_bit(st, ej, 1) != X265AMD_OK) return err = X265AMD_EHIP;
+            }
+            x265amd_tu_rdoq* rq = (x265amd_tu_rdoq*)mRdoq.p;
+            for (int k = 0; k < n; k++)
+            {
+                memset(&rq[k], 0, sizeof(rq[k]));
+                rq[k].est_bits = (uint64_t)(uintptr_t)dEst.p;
+                x265amd_rdoq_lambda(jobs[k].tu.qp_scaled, &rq[k].lambda2, &rq[k].lambda);
+                rq[k].psy_rdoq_scale = rp->psy_rdoq_scale; rq[k].rdoq_level = (uint8_t)rp->rdoq_level; rq[k].tu_depth = (uint8_t)tuDepth;
+            }
+            rdoq = rq;
+        }
+        if (x265amd_intra_tu_chain(st, (const x265amd_intra_tu_job*)dJobs.p, rdoq, n, (x265amd_tu_result*)dRes.p) != X265AMD_OK) return err = X265AMD_EHIP;
         if (hipStreamSynchronize(st) != hipSuccess) return fail("intra rd: synchronize");
         memcpy(res, dRes.p, sizeof(x265amd_tu_result) * n);
         for (int k = 0; k < n; k++) memcpy(levelsOut[k], (const int16_t*)dCoeff.p + 1024 * k, sizeof(int16_t) * numCoeff);
@@ -201,7 +225,7 @@ struct IntraRd
                     copy2Dx2(layerRecon, 64, pre.recon, trSize, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, pre.pred, trSize, trSize, trSize);
                 }
             }
-            else if (runJobs(&job, 1, &r, &lv, trSize * trSize)) return err;
+            else if (runJobs(&job, 1, &r, &lv, trSize * trSize, c->ctx, tuDepth)) return err;
             setTuDepth(x, y, trSize, tuDepth);
             bCBF = (uint32_t)(r.num_sig != 0) << tuDepth;
             setCbf(0, x, y, trSize, bCBF);
@@ -374,7 +398,7 @@ struct IntraRd
                     jobs[i].avail = avail;
                     lvp[i] = clev.data() + (size_t)i * 1024;
                 }
-                if (runJobs(jobs.data(), numCand, cres.data(), lvp.data(), tuSize * tuSize)) return err;
+                if (runJobs(jobs.data(), numCand, cres.data(), lvp.data(), tuSize * tuSize, cur.ctx, initTuDepth)) return err;      /* every candidate starts from m_rqt[depth].cur */
             }
             bcost = kMaxCost;
             int bestIdx = -1;
@@ -457,7 +481,7 @@ struct IntraRd
             jobs[p - 1].avail = avail;
             lv[p - 1] = coeffC[p - 1].data() + (((size_t)zInCu(x, y) << 4) >> 2);
         }
-        if (runJobs(jobs, 2, r, lv, nC * nC)) return err;
+        if (runJobs(jobs, 2, r, lv, nC * nC, c->ctx, U(x, y).tu_depth)) return err;        /* rdoQuant reads cu.m_tuDepth[absPartIdx] for the CBF context */
         for (int p = 1; p < 3; p++)
         {
             setCbf(p, x, y, areaLuma, r[p - 1].num_sig ? 1 << tuDepth : 0);
@@ -538,7 +562,7 @@ struct IntraRd
                     jobs[j].avail = avail;
                     lvp[j] = clev.data() + (size_t)j * 1024;
                 }
-            if (runJobs(jobs, 10, cres.data(), lvp, nC * nC)) return err;
+            if (runJobs(jobs, 10, cres.data(), lvp, nC * nC, cur.ctx, td)) return err;
             (void)log2C;
         }
         for (int k = 0; k < 5; k++)
@@ -640,7 +664,10 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * IntraRd::MAX_JOBS) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * IntraRd::MAX_JOBS) != hipSuccess ||
                              R.dCoeff.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess || R.dResi.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess ||
                              R.dCand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
-                             R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess))
+                             R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
+                             R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
+                             R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess ||
+                             hipMemsetAsync(R.dEst.p, 0, sizeof(x265amd_est_bits), R.st) != hipSuccess))
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
     if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra rd: slice description");
