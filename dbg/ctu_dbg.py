@@ -4,7 +4,7 @@ import numpy as np, hevc_testlib as T, test_ctu_analysis as tca
 gold = np.load(tca.GOLD_PATH)
 mes = {}
 for k in [int(a) for a in sys.argv[1:]]:
-    cfg = (tca.CASES + tca.PART_CASES)[k]
+    cfg = (tca.CASES + tca.PART_CASES + tca.RDOQ_CASES)[k]
     depth = cfg[0]
     if depth not in mes: mes[depth] = T.HipME(depth)
     c = tca.make_case(k)

@@ -595,7 +595,9 @@ typedef struct x265amd_rd_params
     int32_t rdoq_level;             /* param.rdoqLevel 0 / 1 / 2: with RDOQ every transform unit is quantised under the entropy state the walk has reached
                                      * (Entropy::estBit before each Quant::transformNxN, search.cpp:355, :852, :3272, :3397), one launch per unit */
     int32_t psy_rdoq_scale;         /* Quant::m_psyRdoqScale = (int)(param.psyRdoq * 256) */
-} x265amd_rd_params;                /* 24 bytes */
+    int32_t fast_intra;             /* param.bEnableFastIntra: checkIntraInInter samples every fifth angle and refines (search.cpp:1401-1434) */
+    int32_t reserved;
+} x265amd_rd_params;                /* 32 bytes */
 typedef struct x265amd_rd_cu
 {
     int16_t x, y;                   /* luma position of the CU in the picture */
@@ -700,7 +702,8 @@ typedef struct x265amd_analysis_params
     int32_t strong_intra_smoothing;             /* sps.bUseStrongIntraSmoothing */
     int32_t use_sao;                            /* slice.m_bUseSao: x265amd_analyse_frame only (the row coder counts bits only when SAO is on) */
     int32_t rdoq_level, psy_rdoq_scale;         /* param.rdoqLevel, (int)(param.psyRdoq * 256) */
-} x265amd_analysis_params;          /* 56 bytes */
+    int32_t fast_intra, reserved;               /* param.bEnableFastIntra */
+} x265amd_analysis_params;          /* 64 bytes */
 typedef struct x265amd_cu_stat { uint32_t count[4]; uint32_t pad[2]; uint64_t avg_cost[4]; } x265amd_cu_stat;     /* FrameData::RCStatCU count / avgCost per depth */
 typedef struct x265amd_ctu_result { uint64_t rd_cost, distortion, frac_bits; uint32_t total_bits, reserved; uint8_t ctx[X265AMD_CTX_STRIDE]; } x265amd_ctu_result;
 /* units / cur: the picture's unit map and motion field (what is coded so far); the CTU's part is reset and then filled with the decisions.

@@ -41,7 +41,8 @@ typedef struct x265amd_param
     int32_t aspectRatioIdc;                 /* vui.aspectRatioIdc (1 = square samples; 0 = not signalled) */
     int32_t rdoqLevel;                      /* 0..2 */
     int32_t psyRdoqFix8;                    /* (int)(psyRdoq * 256), i.e. Quant::m_psyRdoqScale; needs rdoqLevel > 0 */
-    int32_t reserved[5];
+    int32_t bEnableFastIntra;
+    int32_t reserved[4];
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

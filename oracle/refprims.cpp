@@ -1153,7 +1153,7 @@ int ref_pred_inter_search(const RefMvInfo* I, const RefSearchParams* S, const Re
 /* ---- Search::encodeResAndCalcRdInterCU (encoder/search.cpp:2822-2975: estimateResidualQT, the no-residual alternative, the CU's
  * syntax bits, reconstruction, updateModeCost, checkDQP) itself, on a fixture: picture CUData built from the raster unit map (which already
  * carries the candidate CU's prediction fields), the source picture, and a given prediction block; one CU per call ---- */
-struct RefRdParams { double psyRd; int32_t rdLevel, reserved, rdoqLevel, psyRdoqScale; };
+struct RefRdParams { double psyRd; int32_t rdLevel, reserved, rdoqLevel, psyRdoqScale, fastIntra, reserved2; };
 struct RefRdResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, mvBits, coeffBits, psyEnergy, lumaDist, chromaDist, resEnergy, reserved; uint8_t ctx[160]; };
 /* srcPlanes: addresses of sample (0,0) of the source Y, U, V.  predY/U/V: strides 64 / 32.  cuUnitsOut: the CU's units after the call, raster within the
  * CU (row length size/4).  coeffOut: 4096 + 2 * 1024 levels in CUData::m_trCoeff layout.  reconY/U/V: strides 64 / 32. */
@@ -1171,7 +1171,7 @@ static void rd_fixture_run(int skipCU, const RefSliceInfo* si, const RefRdParams
     param->maxCUDepth = si->maxCuDepth; param->bLossless = 0;
     param->frameNumThreads = 1; param->maxSlices = 1; param->bEnableWeightedPred = param->bEnableWeightedBiPred = 0;
     param->bDistributeMotionEstimation = 0; param->bEnableHME = 0; param->analysisLoadReuseLevel = 0; param->analysisSave = NULL; param->analysisLoad = NULL;
-    param->psyRd = rp->psyRd; param->bSsimRd = 0; param->rdoqLevel = rp->rdoqLevel; param->psyRdoq = rp->rdoqLevel ? rp->psyRdoqScale / 256.0 : 0; param->noiseReductionIntra = param->noiseReductionInter = 0;
+    param->psyRd = rp->psyRd; param->bSsimRd = 0; param->rdoqLevel = rp->rdoqLevel; param->psyRdoq = rp->rdoqLevel ? rp->psyRdoqScale / 256.0 : 0; param->bEnableFastIntra = rp->fastIntra; param->noiseReductionIntra = param->noiseReductionInter = 0;
     param->limitTU = 0; param->rdLevel = rp->rdLevel; param->bEnableTransformSkip = 0; param->bEnableTSkipFast = 0;
     param->bEnableSignHiding = si->signHide; param->maxTUSize = 1 << si->tuLog2Max;
     param->tuQTMaxInterDepth = si->tuMaxDepthInter; param->tuQTMaxIntraDepth = si->tuMaxDepthIntra;
@@ -1369,7 +1369,7 @@ void ref_skip_rd(const RefSliceInfo* si, const RefRdParams* rp, const RefCuUnit*
 /* ---- Analysis::compressCTU (encoder/analysis.cpp:138-317 -> compressInterCU_rd0_4 :1146-1848 with checkMerge2Nx2N_rd0_4, checkInter_rd0_4,
  * checkBidir2Nx2N and the Search methods below them) itself, for one CTU of an inter slice, on a fixture: picture CUData from the raster
  * unit + motion maps (what is coded so far), reference pictures, their motion / depth maps, the source picture ---- */
-struct RefAnalysisParams { double psyRd; int32_t rdLevel, earlySkip, rskip, limitRefs, bIntraInB, rect, amp, limitModes, strongIntraSmoothing, reserved, rdoqLevel, psyRdoqScale; };
+struct RefAnalysisParams { double psyRd; int32_t rdLevel, earlySkip, rskip, limitRefs, bIntraInB, rect, amp, limitModes, strongIntraSmoothing, reserved, rdoqLevel, psyRdoqScale, fastIntra, reserved2; };
 struct RefCuStat { uint32_t count[4]; uint32_t pad; uint64_t avgCost[4]; };
 struct RefCtuResult { uint64_t rdCost, distortion, fracBits; uint32_t totalBits, reserved; uint8_t ctx[160]; };
 /* planes: numPics x 3 addresses of sample (0,0); picture numPics-1 is the source, numPics-2 the reconstruction being written.
@@ -1389,7 +1389,7 @@ void ref_compress_ctu(const RefMvInfo* I, const RefSearchParams* S, const RefSli
     param->bDistributeMotionEstimation = 0; param->bDistributeModeAnalysis = 0; param->bEnableHME = 0; param->analysisLoadReuseLevel = 0; param->analysisSaveReuseLevel = 0;
     param->analysisSave = NULL; param->analysisLoad = NULL;
     param->analysisMultiPassRefine = 0; param->bAnalysisType = 0; param->bIntraRefresh = 0; param->bSourceReferenceEstimation = 0;
-    param->psyRd = A->psyRd; param->bSsimRd = 0; param->rdoqLevel = A->rdoqLevel; param->psyRdoq = A->rdoqLevel ? A->psyRdoqScale / 256.0 : 0; param->noiseReductionIntra = param->noiseReductionInter = 0; param->limitTU = 0;
+    param->psyRd = A->psyRd; param->bSsimRd = 0; param->rdoqLevel = A->rdoqLevel; param->psyRdoq = A->rdoqLevel ? A->psyRdoqScale / 256.0 : 0; param->bEnableFastIntra = A->fastIntra; param->noiseReductionIntra = param->noiseReductionInter = 0; param->limitTU = 0;
     param->interRefine = 0; param->mvRefine = 1; param->rc.bStatRead = 0; param->rdLevel = A->rdLevel; param->bEnableEarlySkip = A->earlySkip;
     param->recursionSkipMode = A->rskip; param->limitReferences = A->limitRefs; param->bIntraInBFrames = A->bIntraInB; param->bEnableRectInter = A->rect;
     param->bEnableAMP = A->amp; param->limitModes = A->limitModes; param->bCTUInfo = 0; param->bEnableRdRefine = 0; param->bOptCUDeltaQP = 0; param->csvLogLevel = 0;

@@ -240,7 +240,7 @@ def make_ctu_analysis_golden():
     spec = importlib.util.spec_from_file_location("tca", os.path.join(os.path.dirname(T.GOLDEN_DIR), "test_ctu_analysis.py"))
     tca = importlib.util.module_from_spec(spec); spec.loader.exec_module(tca)
     out = {}
-    for k, cfg in enumerate(tca.CASES + tca.PART_CASES):
+    for k, cfg in enumerate(tca.CASES + tca.PART_CASES + tca.RDOQ_CASES):
         c = tca.make_case(k)
         for i, d in enumerate(T.ctu_pack(T.ctu_run_ref(T.load_ref(cfg[0]), c))):
             for name, a in d.items():
@@ -442,6 +442,10 @@ def make_encoder_api_golden():
                                         ("opt_g/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--qp", "38", "--subme", "7", "--me", "star", "--rd", "5", "--rect", "--amp"]),
                                         ("opt_h/", (192, 128), 4, ["--bframes", "0", "--subme", "0", "--rd", "2", "--tu-inter-depth", "2"]),
                                         # rate-distortion optimised quantisation (the slow presets): level 1, level 2 with psy-rdoq, with TU splits
+                                        ("preset_veryfast/", (192, 128), 10, ["--preset", "veryfast"]),
+                                        ("preset_fast/", (192, 128), 10, ["--preset", "fast"]),
+                                        ("preset_slow/", (192, 128), 10, ["--preset", "slow"]),
+                                        ("preset_veryslow/", (192, 128), 10, ["--preset", "veryslow"]),
                                         ("rdoq_a/", (192, 128), 4, ["--bframes", "0", "--rdoq-level", "1"]),
                                         ("rdoq_b/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "1.0", "--rd", "4"]),
                                         ("rdoq_c/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "2.5", "--tu-inter-depth", "3",
@@ -451,6 +455,11 @@ def make_encoder_api_golden():
         cli = [a for a in T.FRAME_CLI_ARGS if a != "--no-deblock"]
         # later options override earlier ones on the reference's command line
         cli = cli + ["--rc-lookahead", "5"] + extra
+        if "--preset" in extra:
+            # a whole preset's analysis settings: only what the built subset cannot do yet is switched off (AQ, cutree, weighted prediction, adaptive GOPs, rate control)
+            cli = ["--preset", extra[extra.index("--preset") + 1], "--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut",
+                   "--keyint", "250", "--no-wpp", "--frame-threads", "1", "--pools", "none", "--no-info", "--no-open-gop", "--rc-lookahead", "10", "--lookahead-slices", "0",
+                   "--no-b-pyramid"]
         if "--sao" in extra:
             cli = [a for a in cli if a not in ("--no-sao", "--no-wpp")]
         with tempfile.TemporaryDirectory() as d:

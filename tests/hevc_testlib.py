@@ -1981,7 +1981,7 @@ def inter_search_run_hip(L, me, c):
 
 
 # ---- residual RD of inter CUs (x265amd_inter_residual_rd vs Search::encodeResAndCalcRdInterCU) ----
-RD_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("strong", "<i4"), ("rdoq_level", "<i4"), ("psy_rdoq_scale", "<i4")])
+RD_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("strong", "<i4"), ("rdoq_level", "<i4"), ("psy_rdoq_scale", "<i4"), ("fast_intra", "<i4"), ("reserved", "<i4")])
 RD_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("mv_bits", "<u4"), ("coeff_bits", "<u4"),
                          ("psy_energy", "<u4"), ("luma_distortion", "<u4"), ("chroma_distortion", "<u4"), ("res_energy", "<u4"), ("reserved", "<u4"),
                          ("ctx", "u1", 160)])
@@ -2355,14 +2355,14 @@ def skip_run_hip(L, c):
 
 # ---- CTU analysis of inter slices (x265amd_compress_ctu_inter vs Analysis::compressCTU) ----
 ANALYSIS_PARAMS_DT = np.dtype([("psy_rd", "<f8"), ("rd_level", "<i4"), ("early_skip", "<i4"), ("rskip", "<i4"), ("limit_refs", "<i4"), ("b_intra", "<i4"),
-                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4"), ("strong", "<i4"), ("use_sao", "<i4"), ("rdoq_level", "<i4"), ("psy_rdoq_scale", "<i4")])
+                               ("rect", "<i4"), ("amp", "<i4"), ("limit_modes", "<i4"), ("strong", "<i4"), ("use_sao", "<i4"), ("rdoq_level", "<i4"), ("psy_rdoq_scale", "<i4"), ("fast_intra", "<i4"), ("reserved", "<i4")])
 CU_STAT_DT = np.dtype([("count", "<u4", 4), ("pad", "<u4", 2), ("avg_cost", "<u8", 4)])
 CTU_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("distortion", "<u8"), ("frac_bits", "<u8"), ("total_bits", "<u4"), ("reserved", "<u4"), ("ctx", "u1", 160)])
-assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 56
+assert CU_STAT_DT.itemsize == 56 and CTU_RESULT_DT.itemsize == 192 and ANALYSIS_PARAMS_DT.itemsize == 64
 
 
 def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter_depth=1, nctu=3, detail=1.0, limit_refs=0, b_intra=0, strong=1, intra_slice=False,
-             rect=0, amp=0, limit_modes=0, rd_level=3):
+             rect=0, amp=0, limit_modes=0, rd_level=3, rdoq_level=0, psy_rdoq_scale=0, fast_intra=0):
     """a picture in the middle of being coded: reference pictures + source (inter_scene, plus one picture that receives the reconstruction),
     the unit map and motion field of the CTUs coded so far, the reference pictures' depth maps, running cost statistics, and the CTUs to analyse"""
     rng = np.random.default_rng(seed + 901)
@@ -2452,6 +2452,7 @@ def ctu_case(depth, seed, is_b=True, early_skip=1, rskip=1, psy_rd=2.0, tu_inter
     ap["psy_rd"], ap["rd_level"], ap["early_skip"], ap["rskip"], ap["limit_refs"], ap["b_intra"], ap["strong"] = psy_rd, 3, early_skip, rskip, limit_refs, b_intra, strong
     ap["rect"], ap["amp"], ap["limit_modes"] = rect, amp, limit_modes
     ap["rd_level"] = rd_level
+    ap["rdoq_level"], ap["psy_rdoq_scale"], ap["fast_intra"] = rdoq_level, psy_rdoq_scale, fast_intra
     # reference pictures' CU depths (two lists) and CTU QPs; running cost statistics of the CTUs coded so far
     ref_depth = np.zeros((2, h4, w4), np.uint8)
     for l in range(2):
@@ -2985,7 +2986,7 @@ class EncParam(C.Structure):
                 ("searchMethod", C.c_int32), ("subpelRefine", C.c_int32), ("searchRange", C.c_int32), ("maxNumMergeCand", C.c_int32),
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
-                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class EncNal(C.Structure):

@@ -19,10 +19,17 @@ PART_CASES = [(8, 21, 0, 1, 2.0, 3, 1, 0, 1, 0, 0), (8, 22, 0, 0, 2.0, 0, 0, 0, 
               (8, 31, 0, 1, 2.0, 3, 1, 1, 0, 0, 0, 5), (8, 32, 1, 0, 2.0, 0, 0, 0, 1, 1, 0, 6), (10, 33, 0, 1, 0.0, 1, 1, 0, 1, 1, 1, 5), (8, 34, 1, 1, 1.0, 3, 0, 0, 1, 0, 1, 6),
               (8, 35, 0, 0, 2.0, 2, 1, 1, 1, 1, 0, 5),
               (8, 41, 1, 1, 0.0, 3, 1, 1, 0, 0, 0, 2), (8, 42, 0, 1, 2.0, 0, 0, 0, 1, 1, 1, 2), (10, 43, 0, 0, 0.0, 1, 1, 0, 1, 0, 0, 2), (8, 44, 1, 0, 1.0, 2, 0, 0, 0, 0, 0, 2)]
+# RDOQ / fast-intra: (depth, seed, early skip, rskip, psy-rd, tu-inter-depth, limit-refs, B slice, b-intra, rect, amp, limit-modes, rd level, rdoq level, psy-rdoq * 256, fast intra)
+RDOQ_CASES = [(8, 51, 0, 1, 2.0, 3, 0, 1, 1, 1, 1, 0, 6, 2, 256, 0), (8, 52, 0, 0, 2.0, 3, 3, 0, 0, 1, 1, 1, 5, 2, 256, 0), (10, 53, 1, 1, 2.0, 2, 1, 1, 0, 0, 0, 0, 3, 1, 0, 0),
+              (8, 54, 0, 1, 0.0, 1, 3, 1, 1, 1, 0, 1, 4, 2, 640, 0), (8, 55, 1, 1, 2.0, 1, 3, 1, 0, 0, 0, 0, 2, 0, 0, 1), (8, 56, 0, 1, 2.0, 3, 0, 0, 0, 1, 1, 0, 6, 2, 256, 0)]
 GOLD_PATH = os.path.join(T.GOLDEN_DIR, "ctu_analysis_golden.npz")
 
 
 def make_case(k):
+    if k >= len(CASES) + len(PART_CASES):
+        depth, seed, es, rs, psy, td, lr, is_b, b_intra, rect, amp, lm, rd, rq, prq, fi = RDOQ_CASES[k - len(CASES) - len(PART_CASES)]
+        return T.ctu_case(depth, seed, is_b=bool(is_b), early_skip=es, rskip=rs, psy_rd=psy, tu_inter_depth=td, limit_refs=lr, b_intra=b_intra, rect=rect, amp=amp, limit_modes=lm,
+                          rd_level=rd, rdoq_level=rq, psy_rdoq_scale=prq, fast_intra=fi)
     if k >= len(CASES):
         depth, seed, es, rs, psy, lr, is_b, b_intra, rect, amp, lm = PART_CASES[k - len(CASES)][:11]
         rd = PART_CASES[k - len(CASES)][11] if len(PART_CASES[k - len(CASES)]) > 11 else 3
@@ -37,7 +44,7 @@ def test_golden_outcomes_are_varied():
     gold = np.load(GOLD_PATH)
     depths = np.zeros(4, np.int64); modes = np.zeros(4, np.int64); coded = 0
     parts = np.zeros(8, np.int64)
-    for k in range(len(CASES) + len(PART_CASES)):
+    for k in range(len(CASES) + len(PART_CASES) + len(RDOQ_CASES)):
         for i in range(3):
             u = gold["%d/%d/units" % (k, i)]
             parts += np.bincount(u[:, 2][u[:, 1] == T.MODE_INTER], minlength=8)
@@ -50,7 +57,7 @@ def test_golden_outcomes_are_varied():
 def test_hip_compress_ctu_inter_matches_reference_golden():
     gold = np.load(GOLD_PATH)
     mes = {}
-    for k, cfg in enumerate(CASES + PART_CASES):
+    for k, cfg in enumerate(CASES + PART_CASES + RDOQ_CASES):
         depth = cfg[0]
         if depth not in mes:
             mes[depth] = T.HipME(depth)

@@ -81,6 +81,14 @@ EDGE_CONFIGS = {
     "opt_f/": ((192, 128), 4, dict(BASE, qp=22, subpelRefine=4)),
     "opt_g/": ((192, 128), 5, dict(BASE, bframes=2, qp=38, subpelRefine=7, searchMethod=3, rdLevel=5, bEnableRectInter=1, bEnableAMP=1)),
     "opt_h/": ((192, 128), 4, dict(BASE, subpelRefine=0, rdLevel=2, tuQTMaxInterDepth=2)),
+    # whole presets (source/common/param.cpp:425-600): their analysis settings with AQ / cutree / weighted prediction / adaptive GOPs / rate control off
+    "preset_veryfast/": ((192, 128), 10, dict(BASE, bframes=4, bEnableSAO=1, maxNumMergeCand=2, bIntraInBFrames=0, subpelRefine=1, rdLevel=2, maxNumReferences=2, bEnableFastIntra=1)),
+    "preset_fast/": ((192, 128), 10, dict(BASE, bframes=4, bEnableSAO=1, maxNumMergeCand=2, bEnableEarlySkip=0, bIntraInBFrames=0, rdLevel=2, maxNumReferences=3, bEnableFastIntra=1)),
+    "preset_slow/": ((192, 128), 10, dict(BASE, bframes=4, bEnableSAO=1, bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256,
+                                          subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)),
+    "preset_veryslow/": ((192, 128), 10, dict(BASE, bframes=8, bEnableSAO=1, bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3,
+                                              rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=4, maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0,
+                                              limitModes=0)),
     # RDOQ: every transform unit is quantised under the entropy state the RD walk has reached (one launch per unit)
     "rdoq_a/": ((192, 128), 4, dict(BASE, rdoqLevel=1)),
     "rdoq_b/": ((192, 128), 5, dict(BASE, bframes=2, rdoqLevel=2, psyRdoqFix8=256, rdLevel=4)),

@@ -102,7 +102,7 @@ int main(int argc, char** argv)
         else if (a == "--recon" || a == "-r") recon = val();
         else if (a == "--frames" || a == "-f") frames = atoi(val());
         else if (a == "--rect" || a == "--amp" || a == "--limit-modes" || a == "--early-skip" || a == "--no-early-skip" || a == "--b-intra" || a == "--no-b-intra" ||
-                 a == "--deblock" || a == "--no-deblock" || a == "--sao" || a == "--no-sao" || a == "--wpp" || a == "--no-wpp" || a == "--no-rect" || a == "--no-amp")
+                 a == "--deblock" || a == "--no-deblock" || a == "--sao" || a == "--no-sao" || a == "--wpp" || a == "--no-wpp" || a == "--no-rect" || a == "--no-amp" || a == "--fast-intra" || a == "--no-fast-intra")
             opts.push_back({ a, "" });
         else if (a.rfind("--", 0) == 0) opts.push_back({ a, val() });
         else { fprintf(stderr, "x265amd: unknown argument %s\n", a.c_str()); return 2; }
@@ -152,6 +152,8 @@ int main(int argc, char** argv)
         else if (k == "--no-sao") p.bEnableSAO = 0;
         else if (k == "--wpp") p.bEnableWavefront = 1;
         else if (k == "--no-wpp") p.bEnableWavefront = 0;
+        else if (k == "--fast-intra") p.bEnableFastIntra = 1;
+        else if (k == "--no-fast-intra") p.bEnableFastIntra = 0;
         else if (k == "--rdoq-level") p.rdoqLevel = atoi(v);
         else if (k == "--psy-rdoq") p.psyRdoqFix8 = (int)(atof(v) * 256.0);
         else if (k == "--ipratio") p.ipFactor = atof(v);

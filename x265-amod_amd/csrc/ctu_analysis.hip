@@ -1100,6 +1100,42 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if (A->rdoq_level < 0 || A->rdoq_level > 2 || A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 2-6, no delta QP, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
+    /* debugging aid: X265AMD_DUMP_CTU=<dir> X265AMD_DUMP_POC=<poc> X265AMD_DUMP_MARGIN=<mx>,<my> writes every input of this call (before) and its outputs
+     * (after) to <dir>/ctu_<addr>.bin so that the reference's compressCTU can be run on exactly the same state (dbg/ctu_replay.py) */
+    FILE* dump = nullptr;
+    int dumpMx = 0, dumpMy = 0;
+    if (const char* dir = getenv("X265AMD_DUMP_CTU"))
+    {
+        const char* poc = getenv("X265AMD_DUMP_POC"); const char* mg = getenv("X265AMD_DUMP_MARGIN");
+        if (poc && mg && atoi(poc) == I->poc && sscanf(mg, "%d,%d", &dumpMx, &dumpMy) == 2)
+        {
+            char path[512];
+            snprintf(path, sizeof(path), "%s/ctu_%d.bin", dir, ctu_addr);
+            dump = fopen(path, "wb");
+        }
+    }
+    if (dump)
+    {
+        const int w4d = si->pic_width >> 2, h4d = si->pic_height >> 2, nctu = ((si->pic_width + 63) >> 6) * ((si->pic_height + 63) >> 6);
+        const int32_t hdr[12] = { si->pic_width, si->pic_height, num_pics, (int32_t)stride, (int32_t)cstride, dumpMx, dumpMy, ctu_addr, (int32_t)sizeof(pixel), nctu, 0, 0 };
+        fwrite(hdr, sizeof(hdr), 1, dump);
+        fwrite(I, sizeof(*I), 1, dump); fwrite(S, sizeof(*S), 1, dump); fwrite(si, sizeof(*si), 1, dump); fwrite(A, sizeof(*A), 1, dump);
+        fwrite(units, sizeof(x265amd_cu_unit), (size_t)w4d * h4d, dump); fwrite(cur, sizeof(x265amd_mv_unit), (size_t)w4d * h4d, dump);
+        if (col) fwrite(col, sizeof(x265amd_mv_unit), (size_t)w4d * h4d, dump); else { std::vector<x265amd_mv_unit> z((size_t)w4d * h4d); memset(z.data(), 0, z.size() * sizeof(x265amd_mv_unit)); fwrite(z.data(), sizeof(x265amd_mv_unit), z.size(), dump); }
+        fwrite(ref_depth, 1, (size_t)2 * w4d * h4d, dump); fwrite(ref_qp0, 1, (size_t)2 * nctu, dump);
+        fwrite(cu_stat, sizeof(x265amd_cu_stat), (size_t)nctu + 1, dump);
+        fwrite(ctx_in, 1, X265AMD_CTX_STRIDE, dump); fwrite(&frac_in, 8, 1, dump);
+        (void)hipDeviceSynchronize();
+        for (int k = 0; k < num_pics * 3; k++)
+        {
+            const bool luma = k % 3 == 0;
+            const int mx = luma ? dumpMx : dumpMx / 2, my = luma ? dumpMy : dumpMy / 2, ph = luma ? si->pic_height : si->pic_height / 2;
+            const intptr_t st = luma ? stride : cstride;
+            std::vector<pixel> buf((size_t)(ph + 2 * my) * st);
+            (void)hipMemcpy(buf.data(), (const pixel*)(uintptr_t)h_planes[k] - (intptr_t)my * st - mx, buf.size() * sizeof(pixel), hipMemcpyDeviceToHost);
+            fwrite(buf.data(), sizeof(pixel), buf.size(), dump);
+        }
+    }
     Analyzer* an = new Analyzer;
     Analyzer& a = *an;
     a.me = me; a.st = (hipStream_t)stream; a.I = I; a.S = S; a.si = si; a.A = A; a.units = units; a.cur = cur; a.col = col;
@@ -1120,7 +1156,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         x265amd_rdcost(a.qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
         a.lambda2 = rd[0]; a.lambda = rd[1]; a.psyRd = (uint32_t)rd[2];
         a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = A->strong_intra_smoothing;
-        a.rp.rdoq_level = A->rdoq_level; a.rp.psy_rdoq_scale = A->rdoq_level ? A->psy_rdoq_scale : 0;
+        a.rp.rdoq_level = A->rdoq_level; a.rp.psy_rdoq_scale = A->rdoq_level ? A->psy_rdoq_scale : 0; a.rp.fast_intra = A->fast_intra != 0;
         /* CUData::initCTU: nothing of this CTU is decided yet */
         for (int yy = a.ctuY >> 2; yy < (a.ctuY >> 2) + 16 && yy < a.h4; yy++)
             for (int xx = a.ctuX >> 2; xx < (a.ctuX >> 2) + 16 && xx < a.w4; xx++)
@@ -1144,6 +1180,14 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         out->rd_cost = b.rdCost; out->distortion = b.distortion; out->total_bits = b.totalBits; out->frac_bits = b.contexts.frac;
         memcpy(out->ctx, b.contexts.ctx, X265AMD_CTX_COUNT);
         if (coeff_out) memcpy(coeff_out, b.coeff.data(), sizeof(int16_t) * kTileElems);
+    }
+    if (dump)
+    {
+        const int w4d = si->pic_width >> 2, h4d = si->pic_height >> 2;
+        fwrite(out, sizeof(*out), 1, dump);
+        fwrite(units, sizeof(x265amd_cu_unit), (size_t)w4d * h4d, dump); fwrite(cur, sizeof(x265amd_mv_unit), (size_t)w4d * h4d, dump);
+        if (rc == X265AMD_OK) fwrite(a.md[0].best->coeff.data(), sizeof(int16_t), kTileElems, dump);
+        fclose(dump);
     }
     delete an;
     return rc;

@@ -139,7 +139,7 @@ struct Walker
 
     /* RDOQ: the transform units are not quantised ahead of the walk; `demand(first job, count, luma?, size, tuDepth)` runs them when the walk reaches them,
      * under the entropy state it has then (it fills res / levels for those jobs) */
-    std::function<int(int, int, bool, int, int)> demand;
+    std::function<int(int, int, bool, int, int, const uint8_t*)> demand;
     int err = 0;
 
     Walker(x265amd_cabac& coder, const CuPlan& plan, const x265amd_tu_result* r, const int16_t* lv) : c(coder), P(plan), res(r), levels(lv) {}
@@ -206,6 +206,7 @@ struct Walker
         const int chromaArea = trSize < 8 ? 8 : trSize;     /* luma extent of the units the chroma block covers */
 
         Cost fullCost = { kMaxCost, 0, 0, 0 };
+        uint8_t fullChromaCtx[X265AMD_CTX_STRIDE];
         uint32_t cbfFlag[3] = { 0, 0, 0 }, singleBits[3] = { 0, 0, 0 }, singleEnergy[3] = { 0, 0, 0 };
         sse_t singleDist[3] = { 0, 0, 0 };
 
@@ -214,7 +215,7 @@ struct Walker
         if (bCheckFull)
         {
             setTuDepth(x, y, trSize, tuDepth);
-            if (demand && !err) err = demand(nodeJob(0, log2TrSize, x, y), 1, true, log2TrSize, tuDepth);
+            if (demand && !err) err = demand(nodeJob(0, log2TrSize, x, y), 1, true, log2TrSize, tuDepth, c.ctx);
             {
                 const x265amd_tu_result& r = nodeResult(0, log2TrSize, x, y);
                 cbfFlag[0] = r.num_sig != 0;
@@ -247,8 +248,9 @@ struct Walker
                     /* one table for both chroma planes, taken before U is coded (search.cpp:3397) */
                     if (p == 1 && demand && !err)
                     {
-                        err = demand(nodeJob(1, log2TrSizeC, x, y), 1, false, log2TrSizeC, tuDepth);
-                        if (!err) err = demand(nodeJob(2, log2TrSizeC, x, y), 1, false, -log2TrSizeC, tuDepth);      /* negative size: keep the table */
+                        memcpy(fullChromaCtx, c.ctx, X265AMD_CTX_COUNT);
+                        err = demand(nodeJob(1, log2TrSizeC, x, y), 1, false, log2TrSizeC, tuDepth, c.ctx);
+                        if (!err) err = demand(nodeJob(2, log2TrSizeC, x, y), 1, false, -log2TrSizeC, tuDepth, c.ctx);      /* negative size: keep the table */
                     }
                     const x265amd_tu_result& r = nodeResult(p, log2TrSizeC, x, y);
                     cbfFlag[p] = r.num_sig != 0;
@@ -323,6 +325,13 @@ struct Walker
                     outCosts.energy += splitCost.energy;
             }
             load(rqtTest[depth]);
+            /* RDOQ: an 8x8 node and its 4x4 children own the SAME 4x4 chroma blocks (one slot in the scratch, where the reference has one buffer per
+             * layer); the children's pass re-quantised them under its own entropy state.  The full node won: bring its version back */
+            if (demand && !err && bCheckFull && codeChroma && log2TrSize == 3)
+            {
+                err = demand(nodeJob(1, log2TrSizeC, x, y), 1, false, log2TrSizeC, tuDepth, fullChromaCtx);
+                if (!err) err = demand(nodeJob(2, log2TrSizeC, x, y), 1, false, -log2TrSizeC, tuDepth, fullChromaCtx);
+            }
         }
 
         setTuDepth(x, y, trSize, tuDepth);
@@ -591,7 +600,7 @@ static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_par
         w.load(cur);
         Cost costs = { 0, 0, 0, 0 };
         if (demand)
-            w.demand = [&, i](int first, int count, bool luma, int log2TrSize, int tuDepth) { return (*demand)(i, coder->ctx, first, count, luma, log2TrSize, tuDepth); };
+            w.demand = [&, i](int first, int count, bool luma, int log2TrSize, int tuDepth, const uint8_t* ctx) { return (*demand)(i, ctx, first, count, luma, log2TrSize, tuDepth); };
         w.estimateResidualQT(P.x, P.y, 0, costs);
         if (w.err) { x265amd_cabac_close(coder); return w.err; }
 

@@ -705,7 +705,24 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         {
             static const uint8_t order[35] = { 1, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34 };
             uint32_t bmode = 1;
-            for (int k = 1; k < 35; k++) if (modeCosts[order[k]] < modeCosts[bmode]) bmode = order[k];
+            if (rp->fast_intra)
+            {
+                /* the best angle sampled at distance 5, refined at distance 2 and 1 (search.cpp:1401-1434); DC / planar first as always */
+                if (modeCosts[0] < modeCosts[bmode]) bmode = 0;
+                uint32_t amode = 5;
+                uint64_t acost = kMaxCost;
+                for (uint32_t mode = 5; mode < 35; mode += 5) if (modeCosts[mode] < acost) { acost = modeCosts[mode]; amode = mode; }
+                for (uint32_t dist = 2; dist >= 1; dist--)
+                {
+                    const uint32_t lowmode = amode - dist, highmode = amode + dist;
+                    if (modeCosts[lowmode] < acost) { acost = modeCosts[lowmode]; amode = lowmode; }
+                    if (modeCosts[highmode] < acost) { acost = modeCosts[highmode]; amode = highmode; }
+                }
+                if (amode == 33 && modeCosts[34] < acost) { acost = modeCosts[34]; amode = 34; }
+                if (acost < modeCosts[bmode]) bmode = amode;
+            }
+            else
+                for (int k = 1; k < 35; k++) if (modeCosts[order[k]] < modeCosts[bmode]) bmode = order[k];
             if (info) { info[0] = bmode; info[1] = modeCosts[bmode]; info[2] = mb[bmode]; info[3] = ms[bmode]; }
             for (int yy = 0; yy < R.size; yy += 4) for (int xx = 0; xx < R.size; xx += 4) R.U(R.cuX + xx, R.cuY + yy).luma_dir = (uint8_t)bmode;
             /* ---- encodeIntraInInter ---- */
