@@ -825,9 +825,17 @@ int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pi
  * d_energy[group] (raster order, ceil(width / qg) groups per row; qg_size 16 or 8) = AC energy of the luma block + the two 4:2:0 chroma blocks;
  * d_wp[0..2] = Lowres::wp_sum[plane], d_wp[3..5] = wp_ssd[plane] (sums over all groups).  planes: HOST array of the device addresses of sample (0,0)
  * of Y, U, V (padded planes: groups at the right / bottom edge read into the margin, as the reference does).  The double-precision part of
- * calcAdaptiveQuantFrame (energies -> QP offsets) is not built yet.  Asynchronous. */
+ * calcAdaptiveQuantFrame (energies -> QP offsets) is x265amd_aq_offsets below.  Asynchronous. */
 int x265amd_aq_energy(void* stream, const uint64_t planes[3], intptr_t stride, intptr_t cstride, int width, int height, int qg_size,
                       uint32_t* d_energy, uint64_t* d_wp);
+
+/* x265amd_aq_offsets = the rest of LookaheadTLD::calcAdaptiveQuantFrame (reference: source/encoder/slicetype.cpp:513-640), host code: the energies of
+ * x265amd_aq_energy -> Lowres::qpAqOffset, qpCuTreeOffset (doubles) and invQscaleFactor (x265_exp2fix8) per quantisation group, for aq_mode 1 (variance),
+ * 2 (auto-variance), 3 (auto-variance biased); aq_strength / aq_bias_strength = param.rc.aqStrength / aqBiasStrength.  No HDR10 offsets, external quant
+ * offsets, hevc-aq or edge modes.  num_blocks: the groups of x265amd_aq_energy; avg_block_count: the count the reference averages over (lowres widthInCU x
+ * heightInCU, x 4 for qg 8; equal to num_blocks when the picture size is a multiple of 16).  Returns X265AMD_OK or X265AMD_EINVAL. */
+int x265amd_aq_offsets(const uint32_t* energy, int num_blocks, int avg_block_count, int aq_mode, double aq_strength, double aq_bias_strength, int qg_size,
+                       double* qp_aq_offset, double* qp_cutree_offset, int32_t* inv_qscale_factor);
 
 /* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
 void x265amd_release_scratch(void);

@@ -1806,4 +1806,37 @@ int ref_aq_energy(const pixel* y, const pixel* u, const pixel* v, intptr_t strid
     return n;
 }
 
+/* ---- adaptive quantisation, whole function: the reference's own LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:452-713) on a Frame fixture ---- */
+int ref_aq_frame(const pixel* y, const pixel* u, const pixel* v, intptr_t stride, intptr_t cstride, int width, int height, int marginX, int marginY, int aqMode,
+                 double aqStrength, double aqBiasStrength, int qgSize, double* qpAqOffset, double* qpCuTreeOffset, int32_t* invQscaleFactor)
+{
+    ensure();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420; param->bframes = 0;
+    param->rc.aqMode = aqMode; param->rc.aqStrength = aqStrength; param->rc.aqBiasStrength = aqBiasStrength; param->rc.qgSize = qgSize; param->rc.hevcAq = 0;
+    param->bEnableWeightedPred = 0; param->bEnableWeightedBiPred = 0; param->bHDR10Opt = 0; param->bDynamicRefine = 0; param->bEnableFades = 0; param->rc.bStatRead = 0;
+    param->bAQMotion = 0; param->bEnableHME = 0; param->recursionSkipMode = 1;
+    PicYuv* pic = new PicYuv;
+    pic->m_param = param; pic->m_picWidth = width; pic->m_picHeight = height; pic->m_stride = stride; pic->m_strideC = cstride; pic->m_picCsp = X265_CSP_I420;
+    pic->m_lumaMarginX = marginX; pic->m_lumaMarginY = marginY;
+    pic->m_picOrg[0] = const_cast<pixel*>(y); pic->m_picOrg[1] = const_cast<pixel*>(u); pic->m_picOrg[2] = const_cast<pixel*>(v);
+    Frame* frame = new Frame;
+    frame->m_fencPic = pic; frame->m_param = param; frame->m_quantOffsets = NULL;
+    if (!frame->m_lowres.create(param, pic, qgSize)) return -1;
+    LookaheadTLD* tld = new LookaheadTLD;
+    const int wcu = ((width / 2) + 7) >> 3, hcu = ((height / 2) + 7) >> 3;
+    tld->init(wcu, hcu, wcu * hcu);
+    tld->calcAdaptiveQuantFrame(frame, param);
+    const int n = qgSize == 8 ? frame->m_lowres.maxBlocksInRowFullRes * frame->m_lowres.maxBlocksInColFullRes : wcu * hcu;
+    memcpy(qpAqOffset, frame->m_lowres.qpAqOffset, sizeof(double) * n);
+    memcpy(qpCuTreeOffset, frame->m_lowres.qpCuTreeOffset, sizeof(double) * n);
+    memcpy(invQscaleFactor, frame->m_lowres.invQscaleFactor, sizeof(int32_t) * n);
+    frame->m_lowres.destroy(param);
+    frame->m_fencPic = NULL;
+    pic->m_picOrg[0] = pic->m_picOrg[1] = pic->m_picOrg[2] = NULL;
+    delete pic; delete tld;
+    return n;
+}
+
 } /* extern "C" */

@@ -416,6 +416,9 @@ def make_aq_energy_golden():
     out = {}
     for k, (depth, seed, W, H, qg) in enumerate(tl.AQ_CASES):
         out["%d/energy" % k], out["%d/wp" % k] = T.aq_run_ref(T.load_ref(depth), T.aq_case(depth, seed), W, H, qg)
+    for k, (ci, mode, strength, bias) in enumerate(tl.AQ_OFFSET_CASES):
+        depth, seed, W, H, qg = tl.AQ_CASES[ci]
+        out["o%d/qp_aq_offset" % k], out["o%d/qp_cutree_offset" % k], out["o%d/inv_qscale_factor" % k] = T.aq_offsets_ref(T.load_ref(depth), T.aq_case(depth, seed), W, H, mode, strength, bias, qg)
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "aq_energy_golden.npz"), **out)
     print("wrote aq_energy_golden.npz with", len(out), "arrays")
 

@@ -3261,3 +3261,24 @@ def aq_run_hip(L, c, W, H, qg):
     assert L.lib.x265amd_aq_energy(None, _ptr(planes), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), W, H, qg, C.c_void_p(d_e.data_ptr()), C.c_void_p(d_wp.data_ptr())) == 0
     torch.cuda.synchronize()
     return d_e.cpu().numpy().view(np.uint32), d_wp.cpu().numpy().view(np.uint64)
+
+
+def aq_offsets_ref(R, c, W, H, mode, strength, bias, qg):
+    isz = c["pic"].itemsize
+    wcu, hcu = ((W // 2) + 7) >> 3, ((H // 2) + 7) >> 3
+    n = wcu * hcu * (4 if qg == 8 else 1)
+    a = np.zeros(n, np.float64); t = np.zeros(n, np.float64); f = np.zeros(n, np.int32)
+    base = c["pic"].ctypes.data
+    R.lib.ref_aq_frame.restype = C.c_int
+    got = R.lib.ref_aq_frame(*[C.c_void_p(base + c["org"][k] * isz) for k in range(3)], C.c_int64(c["stride"]), C.c_int64(c["cstride"]), W, H, MC_MX, MC_MY, mode,
+                             C.c_double(strength), C.c_double(bias), qg, _ptr(a), _ptr(t), _ptr(f))
+    assert got == n, (got, n)
+    return a, t, f
+
+
+def aq_offsets_prod(L, energy, avg_count, mode, strength, bias, qg):
+    n = len(energy)
+    a = np.zeros(n, np.float64); t = np.zeros(n, np.float64); f = np.zeros(n, np.int32)
+    rc = L.lib.x265amd_aq_offsets(_ptr(np.ascontiguousarray(energy)), n, avg_count, mode, C.c_double(strength), C.c_double(bias), qg, _ptr(a), _ptr(t), _ptr(f))
+    assert rc == 0
+    return a, t, f

@@ -82,3 +82,23 @@ def test_hip_aq_energy_matches_reference_golden(k):
     energy, wp = T.aq_run_hip(T.load_hip(depth), T.aq_case(depth, seed), W, H, qg)
     assert np.array_equal(energy, g["%d/energy" % k]), np.argwhere(energy != g["%d/energy" % k])[:5].tolist()
     assert np.array_equal(wp, g["%d/wp" % k]), (wp, g["%d/wp" % k])
+
+
+# adaptive quantisation, host half: (AQ_CASES index, aq-mode, strength, bias strength)
+AQ_OFFSET_CASES = [(0, 1, 1.0, 1.0), (0, 2, 1.0, 1.0), (0, 3, 0.8, 1.5), (2, 2, 1.2, 1.0), (3, 1, 0.6, 1.0), (3, 3, 1.0, 1.0), (4, 2, 1.0, 1.0), (1, 2, 1.0, 1.0)]
+
+
+@pytest.mark.parametrize("k", range(len(AQ_OFFSET_CASES)))
+def test_aq_offsets_match_reference_golden_bit_for_bit(k):
+    """x265amd_aq_offsets (host code of the library, no GPU work) on the golden block energies against the reference's calcAdaptiveQuantFrame: the doubles
+    must be identical, not close"""
+    g = np.load(AQ_GOLD)
+    ci, mode, strength, bias = AQ_OFFSET_CASES[k]
+    depth, seed, W, H, qg = AQ_CASES[ci]
+    energy = g["%d/energy" % ci]
+    avg = (((W // 2) + 7) >> 3) * (((H // 2) + 7) >> 3) * (4 if qg == 8 else 1)
+    a, t, f = T.aq_offsets_prod(T.load_hip(depth), energy, avg, mode, strength, bias, qg)
+    n = len(energy)
+    assert np.array_equal(a.view(np.uint64), g["o%d/qp_aq_offset" % k][:n].view(np.uint64)), float(np.abs(a - g["o%d/qp_aq_offset" % k][:n]).max())
+    assert np.array_equal(t.view(np.uint64), g["o%d/qp_cutree_offset" % k][:n].view(np.uint64))
+    assert np.array_equal(f, g["o%d/inv_qscale_factor" % k][:n])
