@@ -263,8 +263,9 @@ def make_intra_rd_golden():
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "intra_rd_golden.npz"), **out)
     print("wrote intra_rd_golden.npz with", len(out), "arrays")
     out = {}
-    for k, (depth, seed, st, psy, strong) in enumerate(tir.CHECK_CASES):
-        c = T.check_intra_case(depth, seed, st, psy, strong=strong)
+    for k, cfg in enumerate(tir.CHECK_CASES):
+        depth, seed, st, psy, strong = cfg[:5]
+        c = T.check_intra_case(depth, seed, st, psy, strong=strong, tu_intra=cfg[5] if len(cfg) > 5 else 0)
         for i, d in enumerate(T.intra_rd_pack(T.check_intra_run_ref(T.load_ref(depth), c), c)):
             for name, a in d.items():
                 out["%d/%d/%s" % (k, i, name)] = a
@@ -449,6 +450,8 @@ def make_encoder_api_golden():
                                         ("preset_fast/", (192, 128), 10, ["--preset", "fast"]),
                                         ("preset_slow/", (192, 128), 10, ["--preset", "slow"]),
                                         ("preset_veryslow/", (192, 128), 10, ["--preset", "veryslow"]),
+                                        ("placebo_notskip/", (192, 128), 10, ["--preset", "placebo", "--no-tskip"]),
+                                        ("hbd_slow/", (192, 128), 6, ["--preset", "slow"]),
                                         ("rdoq_a/", (192, 128), 4, ["--bframes", "0", "--rdoq-level", "1"]),
                                         ("rdoq_b/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "1.0", "--rd", "4"]),
                                         ("rdoq_c/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "2.5", "--tu-inter-depth", "3",
@@ -462,7 +465,7 @@ def make_encoder_api_golden():
             # a whole preset's analysis settings: only what the built subset cannot do yet is switched off (AQ, cutree, weighted prediction, adaptive GOPs, rate control)
             cli = ["--preset", extra[extra.index("--preset") + 1], "--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut",
                    "--keyint", "250", "--no-wpp", "--frame-threads", "1", "--pools", "none", "--no-info", "--no-open-gop", "--rc-lookahead", "10", "--lookahead-slices", "0",
-                   "--no-b-pyramid"]
+                   "--no-b-pyramid"] + [a for a in extra if a not in ("--preset", extra[extra.index("--preset") + 1])]
         if "--sao" in extra:
             cli = [a for a in cli if a not in ("--no-sao", "--no-wpp")]
         with tempfile.TemporaryDirectory() as d:

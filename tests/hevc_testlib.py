@@ -2686,8 +2686,10 @@ def intra_rd_pack(r, c):
 
 
 # ---- Search::checkIntra (I slices / rd 5-6): x265amd_check_intra ----
-def check_intra_case(depth, seed, slice_type, psy_rd, ncu=10, strong=1):
+def check_intra_case(depth, seed, slice_type, psy_rd, ncu=10, strong=1, tu_intra=0):
     c = intra_rd_case(depth, seed, slice_type, psy_rd, ncu=ncu, strong=strong)
+    if tu_intra:
+        c["si"]["tu_max_depth_intra"] = tu_intra
     rng = np.random.default_rng(seed + 717)
     c["parts"] = [3 if (int(c["cus"][i]["log2_size"]) == 3 and rng.integers(0, 2)) else 0 for i in range(ncu)]
     return c

@@ -89,6 +89,12 @@ EDGE_CONFIGS = {
     "preset_veryslow/": ((192, 128), 10, dict(BASE, bframes=8, bEnableSAO=1, bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3,
                                               rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=4, maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0,
                                               limitModes=0)),
+    # placebo without transform skip: TU depth 4, merange 92, subme 5, no rskip on top of the veryslow tools
+    "placebo_notskip/": ((192, 128), 10, dict(BASE, bframes=8, bEnableSAO=1, bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=4, tuQTMaxIntraDepth=4,
+                                              rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=5, maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0,
+                                              limitModes=0, searchRange=92, recursionSkipMode=0)),
+    "hbd_slow/": ((192, 128), 6, dict(BASE, bframes=4, bEnableSAO=1, bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256,
+                                      subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)),        # 10-bit library
     # RDOQ: every transform unit is quantised under the entropy state the RD walk has reached (one launch per unit)
     "rdoq_a/": ((192, 128), 4, dict(BASE, rdoqLevel=1)),
     "rdoq_b/": ((192, 128), 5, dict(BASE, bframes=2, rdoqLevel=2, psyRdoqFix8=256, rdLevel=4)),

@@ -42,7 +42,8 @@ def test_hip_intra_in_inter_matches_reference_golden():
 
 
 # ---- Search::checkIntra: (depth, seed, slice type (2 I, 1 P, 0 B), psy-rd, strong intra smoothing) ----
-CHECK_CASES = [(8, 701, 2, 2.0, 1), (8, 702, 2, 0.0, 1), (10, 703, 2, 2.0, 0), (8, 704, 1, 2.0, 1), (10, 705, 2, 1.0, 1), (8, 706, 2, 2.0, 1)]
+CHECK_CASES = [(8, 701, 2, 2.0, 1), (8, 702, 2, 0.0, 1), (10, 703, 2, 2.0, 0), (8, 704, 1, 2.0, 1), (10, 705, 2, 1.0, 1), (8, 706, 2, 2.0, 1),
+               (8, 707, 2, 2.0, 1, 4), (8, 708, 1, 0.0, 1, 4), (10, 709, 2, 2.0, 1, 4)]           # 6th field: tu-intra-depth 4 (three levels of transform splits)
 CHECK_GOLD_PATH = os.path.join(T.GOLDEN_DIR, "check_intra_golden.npz")
 
 
@@ -59,8 +60,9 @@ def test_check_intra_golden_covers_nxn_and_splits():
 @pytest.mark.gpu
 def test_hip_check_intra_matches_reference_golden():
     gold = np.load(CHECK_GOLD_PATH)
-    for k, (depth, seed, st, psy, strong) in enumerate(CHECK_CASES):
-        c = T.check_intra_case(depth, seed, st, psy, strong=strong)
+    for k, cfg in enumerate(CHECK_CASES):
+        depth, seed, st, psy, strong = cfg[:5]
+        c = T.check_intra_case(depth, seed, st, psy, strong=strong, tu_intra=cfg[5] if len(cfg) > 5 else 0)
         got = T.intra_rd_pack(T.check_intra_run_hip(T.load_hip(depth), c), c)
         for i, d in enumerate(got):
             for name in ("dirs", "pred", "units", "coeff", "recon", "res", "ctx"):

@@ -455,8 +455,8 @@ static int make_plan(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int 
     P.part = part;
     /* CUData::getInterTUQtDepthRange (cudata.cpp:983-993) */
     const int splitFlag = si->tu_max_depth_inter == 1 && P.part != 0;
-    const int lo = P.log2 - (si->tu_max_depth_inter - 1 + splitFlag);
-    P.range[0] = lo < si->tu_log2_min ? si->tu_log2_min : (lo > si->tu_log2_max ? si->tu_log2_max : lo);
+    const uint32_t lo = (uint32_t)P.log2 - (uint32_t)(si->tu_max_depth_inter - 1 + splitFlag);      /* unsigned as in the reference */
+    P.range[0] = lo < (uint32_t)si->tu_log2_min ? si->tu_log2_min : (lo > (uint32_t)si->tu_log2_max ? si->tu_log2_max : (int)lo);
     P.range[1] = si->tu_log2_max;
     if (P.range[0] < 2 || P.range[1] > 5 || P.range[0] > P.range[1]) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: transform size range");
     /* Quant::setQPforQuant (quant.cpp:221-244), chroma QP offsets 0 */

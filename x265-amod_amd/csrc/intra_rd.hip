@@ -657,8 +657,9 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     R.qpLumaScaled = qpQuant + bd; R.qpChromaScaled = qpC + bd;
     /* CUData::getIntraTUQtDepthRange (cudata.cpp:972-981) */
     {
-        const int lo = R.log2 - (si->tu_max_depth_intra - 1 + (partSize != 0));
-        R.range[0] = lo < si->tu_log2_min ? si->tu_log2_min : (lo > si->tu_log2_max ? si->tu_log2_max : lo);
+        /* unsigned in the reference: an 8x8 NxN CU with tu-intra-depth 4 wraps below zero and clips to the MAXIMUM size (no transform splits) */
+        const uint32_t lo = (uint32_t)R.log2 - (uint32_t)(si->tu_max_depth_intra - 1 + (partSize != 0));
+        R.range[0] = lo < (uint32_t)si->tu_log2_min ? si->tu_log2_min : (lo > (uint32_t)si->tu_log2_max ? si->tu_log2_max : (int)lo);
         R.range[1] = si->tu_log2_max;
     }
     if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * IntraRd::MAX_JOBS) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * IntraRd::MAX_JOBS) != hipSuccess ||

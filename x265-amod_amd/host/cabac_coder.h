@@ -258,8 +258,8 @@ struct x265amd_cabac
         const bool intra = u.pred_mode == X265AMD_MODE_INTRA;
         const int maxDepth = intra ? si.tu_max_depth_intra : si.tu_max_depth_inter;
         const int splitFlag = intra ? u.part_size != PART_2Nx2N : (maxDepth == 1 && u.part_size != PART_2Nx2N);
-        int lo = log2CU - (maxDepth - 1 + splitFlag);
-        range[0] = lo < range[0] ? range[0] : (lo > range[1] ? range[1] : lo);
+        const uint32_t lo = (uint32_t)log2CU - (uint32_t)(maxDepth - 1 + splitFlag);      /* unsigned as in the reference: a wrap below zero clips to the maximum */
+        range[0] = lo < (uint32_t)range[0] ? range[0] : (lo > (uint32_t)range[1] ? range[1] : (int)lo);
         /* codeCoeff (:1207-1222) */
         bool any = true;
         if (!intra)
