@@ -452,6 +452,14 @@ def make_encoder_api_golden():
                                         ("preset_veryslow/", (192, 128), 10, ["--preset", "veryslow"]),
                                         ("placebo_notskip/", (192, 128), 10, ["--preset", "placebo", "--no-tskip"]),
                                         ("hbd_slow/", (192, 128), 6, ["--preset", "slow"]),
+                                        ("hbd_veryslow/", (192, 128), 6, ["--preset", "veryslow", "--bframes", "3"]),
+                                        ("opt_j/", (192, 128), 4, ["--bframes", "0", "--qp", "10"]),
+                                        ("opt_k/", (192, 128), 6, ["--bframes", "3", "--no-b-pyramid", "--qp", "45"]),
+                                        ("opt_l/", (192, 128), 10, ["--bframes", "2", "--no-b-pyramid", "--ref", "6", "--max-merge", "1"]),
+                                        ("opt_m/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--no-deblock", "--sao"]),      # (with --wpp on top the reference program itself hangs)
+                                        ("opt_n/", (192, 128), 10, ["--bframes", "1", "--no-b-pyramid", "--keyint", "3", "--min-keyint", "3"]),
+                                        ("opt_o/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rd", "4", "--rect", "--limit-modes", "--limit-refs", "2", "--subme", "6", "--me", "dia"]),
+                                        ("opt_p/", (328, 248), 5, ["--preset", "slow", "--wpp", "--pools", "4", "--bframes", "2"]),
                                         ("rdoq_a/", (192, 128), 4, ["--bframes", "0", "--rdoq-level", "1"]),
                                         ("rdoq_b/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "1.0", "--rd", "4"]),
                                         ("rdoq_c/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "2.5", "--tu-inter-depth", "3",

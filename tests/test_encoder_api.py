@@ -95,6 +95,16 @@ EDGE_CONFIGS = {
                                               limitModes=0, searchRange=92, recursionSkipMode=0)),
     "hbd_slow/": ((192, 128), 6, dict(BASE, bframes=4, bEnableSAO=1, bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256,
                                       subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)),        # 10-bit library
+    "hbd_veryslow/": ((192, 128), 6, dict(BASE, bframes=3, bEnableSAO=1, bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3,
+                                          rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=4, maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0, limitModes=0)),
+    "opt_j/": ((192, 128), 4, dict(BASE, qp=10)),
+    "opt_k/": ((192, 128), 6, dict(BASE, bframes=3, qp=45)),
+    "opt_l/": ((192, 128), 10, dict(BASE, bframes=2, maxNumReferences=6, maxNumMergeCand=1)),
+    "opt_m/": ((192, 128), 5, dict(BASE, bframes=2, bEnableLoopFilter=0, bEnableSAO=1)),
+    "opt_n/": ((192, 128), 10, dict(BASE, bframes=1, keyframeMax=3)),
+    "opt_o/": ((192, 128), 5, dict(BASE, bframes=2, rdLevel=4, bEnableRectInter=1, limitModes=1, limitReferences=2, subpelRefine=6, searchMethod=0)),
+    "opt_p/": ((328, 248), 5, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1, bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256,
+                                   subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)),
     # RDOQ: every transform unit is quantised under the entropy state the RD walk has reached (one launch per unit)
     "rdoq_a/": ((192, 128), 4, dict(BASE, rdoqLevel=1)),
     "rdoq_b/": ((192, 128), 5, dict(BASE, bframes=2, rdoqLevel=2, psyRdoqFix8=256, rdLevel=4)),
