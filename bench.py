@@ -386,7 +386,7 @@ def measured_traffic(kernel="k_me_search"):
     """HBM bytes per launch of a kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, run separately:
     counters cannot be read inside the bench); the summary is committed under profiles/"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_analysis12_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_analysis13_traffic.json")) as f:
             return json.load(f)[kernel]["hbm_bytes_per_launch_uncorrected"]
     except (OSError, KeyError, ValueError):
         return None
@@ -426,6 +426,15 @@ def encoder_pipeline_sample(T):
         out["wpp_832x480"] = {"clip": "832x480 8-bit, 5 frames I P b b P, same settings + WPP (13 x 8 CTUs, up to 8 CTU rows in flight)",
                               "frames_per_s": len(coded2) / dt2, "seconds": dt2,
                               "byte_stream_md5_equals_reference_encoder": bool(len(stream2) == len(want2) and hashlib.md5(stream2.tobytes()).hexdigest() == hashlib.md5(want2.tobytes()).hexdigest())}
+        # and at the headline configuration's picture size (BASELINE.json configs[1] geometry): 4 frames I P b b, WPP
+        planes3 = T.encoder_api_clip("fhd/", 1920, 1080, 4)
+        t0 = time.perf_counter()
+        stream3, coded3 = T.encoder_run(L, planes3, 1920, 1080, **cfg2)
+        dt3 = time.perf_counter() - t0
+        want3 = g2["fhd/stream"]
+        out["wpp_1920x1080"] = {"clip": "1920x1080 8-bit, 4 frames I P b b, same settings + WPP (30 x 17 CTUs); the I frame alone takes about 6 s",
+                                "frames_per_s": len(coded3) / dt3, "seconds": dt3,
+                                "byte_stream_md5_equals_reference_encoder": bool(len(stream3) == len(want3) and hashlib.md5(stream3.tobytes()).hexdigest() == hashlib.md5(want3.tobytes()).hexdigest())}
         return out
     except Exception as e:     # the kernel workload above stays valid without it
         return {"error": repr(e)}

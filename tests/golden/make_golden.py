@@ -460,6 +460,7 @@ def make_encoder_api_golden():
                                         ("opt_n/", (192, 128), 10, ["--bframes", "1", "--no-b-pyramid", "--keyint", "3", "--min-keyint", "3"]),
                                         ("opt_o/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rd", "4", "--rect", "--limit-modes", "--limit-refs", "2", "--subme", "6", "--me", "dia"]),
                                         ("opt_p/", (328, 248), 5, ["--preset", "slow", "--wpp", "--pools", "4", "--bframes", "2"]),
+                                        ("fhd/", (1920, 1080), 4, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "8"]),       # BASELINE.json configs[1] geometry
                                         ("rdoq_a/", (192, 128), 4, ["--bframes", "0", "--rdoq-level", "1"]),
                                         ("rdoq_b/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "1.0", "--rd", "4"]),
                                         ("rdoq_c/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "2.5", "--tu-inter-depth", "3",
