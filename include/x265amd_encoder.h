@@ -42,7 +42,11 @@ typedef struct x265amd_param
     int32_t rdoqLevel;                      /* 0..2 */
     int32_t psyRdoqFix8;                    /* (int)(psyRdoq * 256), i.e. Quant::m_psyRdoqScale; needs rdoqLevel > 0 */
     int32_t bEnableFastIntra;
-    int32_t reserved[4];
+    int32_t firstFrame;                     /* display-order number of the first picture handed in (0 for a whole encode).  A closed GOP depends on nothing
+                                             * before its IDR picture, so a stream can be cut at IDR pictures and the pieces encoded by different encoder objects
+                                             * (different GPUs): each piece starts with firstFrame = its first picture and the slice NAL units concatenate to the
+                                             * single-encoder stream (headers from one of them) */
+    int32_t reserved[3];
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -2988,7 +2988,7 @@ class EncParam(C.Structure):
                 ("searchMethod", C.c_int32), ("subpelRefine", C.c_int32), ("searchRange", C.c_int32), ("maxNumMergeCand", C.c_int32),
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
-                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class EncNal(C.Structure):
@@ -2999,7 +2999,7 @@ class EncPicture(C.Structure):
     _fields_ = [("planes", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("poc", C.c_int32), ("sliceType", C.c_int32), ("qp", C.c_int32)]
 
 
-def encoder_run(L, planes_per_frame, width, height, **overrides):
+def encoder_run(L, planes_per_frame, width, height, want_headers=True, **overrides):
     """x265amd_encoder_open -> headers -> encode every frame -> flush -> close.  planes_per_frame: per frame (Y, U, V) arrays in display order.
     Returns (whole byte stream, [(poc, slice type, qp, recon planes)] in coding order)"""
     lib = L.lib
@@ -3021,7 +3021,7 @@ def encoder_run(L, planes_per_frame, width, height, **overrides):
     stream = bytearray()
     nal = C.POINTER(EncNal)(); nnal = C.c_uint32(0)
     assert lib.x265amd_encoder_headers(enc, C.byref(nal), C.byref(nnal)) > 0
-    for i in range(nnal.value):
+    for i in range(nnal.value if want_headers else 0):
         stream += bytes(nal[i].payload[:nal[i].sizeBytes])
     dt = planes_per_frame[0][0].dtype
     coded = []

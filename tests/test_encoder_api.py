@@ -168,3 +168,17 @@ def test_command_line_program_reproduces_reference_stream(tag, tmp_path):
     got = np.fromfile(tmp_path / "out.hevc", np.uint8)
     assert len(got) == len(want) and hashlib.md5(got.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
     assert os.path.getsize(tmp_path / "rec.yuv") == len(frames) * w * h * 3 // 2 * (2 if depth == 10 else 1)
+
+
+@pytest.mark.gpu
+def test_closed_gops_encode_independently():
+    """the unit of multi-GPU sharding: the pictures between two IDR frames depend on nothing outside, so two encoder objects (as two ranks would hold them) coding
+    GOP 0 (frames 0-3) and GOP 1 (frames 4-6, firstFrame = 4) give, concatenated, the single-encoder stream of the reference for --keyint 4"""
+    g = np.load(GOLD_PATH)
+    frames = display_frames("keyint/")
+    a, _ = T.encoder_run(T.load_hip(8), frames[:4], T.MC_W, T.MC_H, **CONFIGS["keyint/"])
+    b, coded = T.encoder_run(T.load_hip(8), frames[4:], T.MC_W, T.MC_H, want_headers=False, **dict(CONFIGS["keyint/"], firstFrame=4))
+    assert [c[0] for c in coded] == [4, 6, 5]
+    got = np.concatenate([a, b])
+    want = g["keyint/stream"]
+    assert len(got) == len(want) and hashlib.md5(got.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()

@@ -180,7 +180,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     /* level.cpp:290-296 */
     e->numReorderPics = p->bframes ? 1 : 0;
     e->maxDecPicBuffering = std::min(16, std::max(e->numReorderPics + 2, p->maxNumReferences) + 1);
-    e->lastKeyframe = -p->keyframeMax;
+    if (p->firstFrame < 0) { xa_fail(X265AMD_EINVAL, "encoder_open: firstFrame"); return nullptr; }
+    e->frameCount = p->firstFrame; e->lastKeyframe = p->firstFrame - p->keyframeMax; e->lastIDR = p->firstFrame;
     {
         /* pictures whose references are complete are analysed concurrently (B frames of a mini-GOP, the next P): the reference's frame threads, but
          * a picture only starts when its references are final, so the output does not depend on the thread count */
