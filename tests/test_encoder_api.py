@@ -182,3 +182,21 @@ def test_closed_gops_encode_independently():
     got = np.concatenate([a, b])
     want = g["keyint/stream"]
     assert len(got) == len(want) and hashlib.md5(got.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+def test_gop_sharded_encode_one_rank():
+    """x265-amod_amd/gop_shard.py with real encoder objects (one rank here; the two-rank schedule and gather run on CPU in tests/test_distributed_cpu.py)"""
+    import __graft_entry__ as ge
+    gs = ge.load_package().gop_shard
+    g = np.load(GOLD_PATH)
+    frames = display_frames("keyint/")
+    L = T.load_hip(8)
+    cfg = CONFIGS["keyint/"]
+
+    def encode_gop(first, end):
+        return T.encoder_run(L, frames[first:end], T.MC_W, T.MC_H, want_headers=False, **dict(cfg, firstFrame=first))[0].tobytes()
+
+    stream = gs.encode_sharded(len(frames), 4, encode_gop, lambda: T.frame_stream_headers(L, bframes=2, deblock=True).tobytes())
+    want = g["keyint/stream"]
+    assert len(stream) == len(want) and hashlib.md5(stream).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
