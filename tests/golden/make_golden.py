@@ -460,6 +460,11 @@ def make_encoder_api_golden():
                                         ("opt_n/", (192, 128), 10, ["--bframes", "1", "--no-b-pyramid", "--keyint", "3", "--min-keyint", "3"]),
                                         ("opt_o/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rd", "4", "--rect", "--limit-modes", "--limit-refs", "2", "--subme", "6", "--me", "dia"]),
                                         ("opt_p/", (328, 248), 5, ["--preset", "slow", "--wpp", "--pools", "4", "--bframes", "2"]),
+                                        ("hbd_wpp/", (328, 248), 5, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4", "--rect", "--amp"]),
+                                        ("opt_q/", (192, 128), 4, ["--bframes", "0", "--qp", "48"]),
+                                        ("opt_r/", (192, 128), 8, ["--bframes", "4", "--no-b-pyramid", "--ref", "1", "--no-early-skip", "--rd", "5", "--rect"]),
+                                        ("opt_s/", (640, 368), 5, ["--bframes", "2", "--no-b-pyramid", "--me", "star", "--merange", "24", "--subme", "7", "--max-merge", "4", "--rect", "--amp",
+                                                                   "--sao", "--wpp", "--pools", "4"]),
                                         ("fhd/", (1920, 1080), 4, ["--bframes", "2", "--no-b-pyramid", "--sao", "--wpp", "--pools", "8"]),       # BASELINE.json configs[1] geometry
                                         ("rdoq_a/", (192, 128), 4, ["--bframes", "0", "--rdoq-level", "1"]),
                                         ("rdoq_b/", (192, 128), 5, ["--bframes", "2", "--no-b-pyramid", "--rdoq-level", "2", "--psy-rdoq", "1.0", "--rd", "4"]),

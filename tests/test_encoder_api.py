@@ -105,6 +105,10 @@ EDGE_CONFIGS = {
     "opt_o/": ((192, 128), 5, dict(BASE, bframes=2, rdLevel=4, bEnableRectInter=1, limitModes=1, limitReferences=2, subpelRefine=6, searchMethod=0)),
     "opt_p/": ((328, 248), 5, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1, bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256,
                                    subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)),
+    "hbd_wpp/": ((328, 248), 5, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1, bEnableRectInter=1, bEnableAMP=1)),        # 10-bit, partial CTUs, WPP
+    "opt_q/": ((192, 128), 4, dict(BASE, qp=48)),
+    "opt_r/": ((192, 128), 8, dict(BASE, bframes=4, maxNumReferences=1, bEnableEarlySkip=0, rdLevel=5, bEnableRectInter=1)),
+    "opt_s/": ((640, 368), 5, dict(BASE, bframes=2, searchMethod=3, searchRange=24, subpelRefine=7, maxNumMergeCand=4, bEnableRectInter=1, bEnableAMP=1, bEnableSAO=1, bEnableWavefront=1)),
     "fhd/": ((1920, 1080), 4, dict(BASE, bframes=2, bEnableSAO=1, bEnableWavefront=1)),        # 1920x1080 (30 x 17 CTUs, the last row cut): the size of BASELINE.json's headline configuration
     # RDOQ: every transform unit is quantised under the entropy state the RD walk has reached (one launch per unit)
     "rdoq_a/": ((192, 128), 4, dict(BASE, rdoqLevel=1)),
