@@ -6,9 +6,10 @@ W, H, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 planes = T.encoder_api_clip("big/", W, H, N)
 cfg = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bframes=2, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1)
 T.encoder_run(L, planes[:2], W, H, **cfg)
-for ft in sys.argv[4:]:
-    os.environ["X265AMD_FRAME_THREADS"] = ft
+for spec in sys.argv[4:]:
+    ft, rt = spec.split(":")
+    os.environ["X265AMD_FRAME_THREADS"] = ft; os.environ["X265AMD_ROW_THREADS"] = rt
     t0 = time.perf_counter()
     stream, coded = T.encoder_run(L, planes, W, H, **cfg)
     dt = time.perf_counter() - t0
-    print("frame threads", ft, "seconds %.3f" % dt, "fps %.2f" % (len(coded) / dt), "bytes", len(stream), hashlib.md5(stream.tobytes()).hexdigest())
+    print("frame threads", ft, "row threads", rt, "seconds %.3f" % dt, "fps %.2f" % (len(coded) / dt), hashlib.md5(stream.tobytes()).hexdigest()[:8])
