@@ -840,6 +840,16 @@ int x265amd_aq_offsets(const uint32_t* energy, int num_blocks, int avg_block_cou
 /* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
 void x265amd_release_scratch(void);
 
+/* Device job queues (csrc/xa_queue.h): the CTU rows of x265amd_analyse_frame run their block operations as commands to resident workgroups instead of
+ * kernel launches (environment: X265AMD_QUEUES = number of queues, default 64, 0 = launches on HIP streams as before).  The self test pushes `rounds`
+ * rounds of copies, fills and rectangle copies through `numQueues` queues from as many host threads and compares every byte that comes back. */
+int x265amd_queue_selftest(int rounds, int numQueues);
+/* A queue handle for the `stream` argument of the orchestrating entry points (x265amd_pred_inter_search, x265amd_inter_residual_rd, x265amd_skip_rd,
+ * x265amd_intra_in_inter, x265amd_check_intra, x265amd_compress_ctu_inter): they return with the queue drained.  NULL when none is free.  While a
+ * queue is held a workgroup is resident on the device: release it before anything that synchronises the whole device. */
+void* x265amd_queue_acquire(void);
+void x265amd_queue_release(void* queue);
+
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */
 void x265amd_rdcost(int qp, int sliceType, double psyRdScale, uint64_t dist, uint32_t bits, uint32_t psycost, uint64_t* out);

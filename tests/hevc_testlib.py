@@ -68,6 +68,29 @@ class PrimLib:
         return fn(*conv)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# stream argument of the orchestrating entry points: NULL stream, or (X265AMD_TEST_QUEUE=1) a device job queue
+# (csrc/xa_queue.h) held for the duration of the call -- the same calls then run as commands to a resident workgroup
+# ----------------------------------------------------------------------------------------------------------
+class call_stream:
+    def __init__(self, L):
+        self.lib = L.lib if hasattr(L, "lib") else L
+        self.h = None
+
+    def __enter__(self):
+        if os.environ.get("X265AMD_TEST_QUEUE"):
+            self.lib.x265amd_queue_acquire.restype = C.c_void_p
+            self.h = self.lib.x265amd_queue_acquire()
+            assert self.h, "no device job queue (X265AMD_QUEUES=0?)"
+            return C.c_void_p(self.h)
+        return None
+
+    def __exit__(self, *exc):
+        if self.h:
+            self.lib.x265amd_queue_release(C.c_void_p(self.h))
+        return False
+
+
 def oracle_path(depth):
     return os.path.join(ORACLE_DIR, "liboracle%d.so" % depth)
 
@@ -1963,8 +1986,9 @@ def inter_search_run_hip(L, me, c):
     per = (64 * 64 + 2 * 32 * 32) * isz
     d_pred = torch.zeros(n * per, dtype=torch.uint8, device="cuda")
     cur = c["cur"].copy()
-    rc = L.lib.x265amd_pred_inter_search(me.ctx, None, _ptr(info), _ptr(sp), _ptr(cur), _ptr(c["col"]), _ptr(planes), len(c["pics"]), C.c_int64(c["stride"]),
-                                         C.c_int64(c["cstride"]), _ptr(cus), n, _ptr(out), _ptr(bits), C.c_uint64(d_pred.data_ptr()), C.c_size_t(per))
+    with call_stream(L) as st_:
+        rc = L.lib.x265amd_pred_inter_search(me.ctx, st_, _ptr(info), _ptr(sp), _ptr(cur), _ptr(c["col"]), _ptr(planes), len(c["pics"]), C.c_int64(c["stride"]),
+                                             C.c_int64(c["cstride"]), _ptr(cus), n, _ptr(out), _ptr(bits), C.c_uint64(d_pred.data_ptr()), C.c_size_t(per))
     assert rc == 0, L.lib.x265amd_last_error()
     assert np.array_equal(cur, c["cur"])            # the motion field is restored
     pred = d_pred.cpu().numpy().reshape(n, per)
@@ -2244,9 +2268,10 @@ def rd_run_hip(L, c):
     cu_units = c["cu_units"].copy()
     out = np.zeros(n, RD_RESULT_DT)
     coeff = np.zeros((n, RD_TILE), np.int16)
-    rc = L.lib.x265amd_inter_residual_rd(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
-                                         _ptr(c["cus"]), n, _ptr(cu_units), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()),
-                                         C.c_size_t(RD_TILE * isz), _ptr(out), _ptr(coeff))
+    with call_stream(L) as st_:
+        rc = L.lib.x265amd_inter_residual_rd(st_, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                             _ptr(c["cus"]), n, _ptr(cu_units), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()),
+                                             C.c_size_t(RD_TILE * isz), _ptr(out), _ptr(coeff))
     assert rc == 0, L.lib.x265amd_last_error()
     assert np.array_equal(units, c["units"])           # the picture map is restored
     recon = d_recon.cpu().numpy().view(dt).reshape(n, RD_TILE).copy()
@@ -2345,8 +2370,9 @@ def skip_run_hip(L, c):
     units = np.ascontiguousarray(c["units"].copy())
     cu_units = c["cu_units"].copy()
     out = np.zeros(n, RD_RESULT_DT)
-    rc = L.lib.x265amd_skip_rd(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
-                               _ptr(c["cus"]), n, _ptr(cu_units), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), C.c_size_t(RD_TILE * isz), _ptr(out))
+    with call_stream(L) as st_:
+        rc = L.lib.x265amd_skip_rd(st_, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                   _ptr(c["cus"]), n, _ptr(cu_units), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), C.c_size_t(RD_TILE * isz), _ptr(out))
     assert rc == 0, L.lib.x265amd_last_error()
     assert np.array_equal(units, c["units"])
     recon = d_recon.cpu().numpy().view(dt).reshape(n, RD_TILE).copy()
@@ -2542,9 +2568,10 @@ def ctu_run_hip(L, me, c):
         u = u.copy(); m = m.copy(); st = st.copy()
         ctx = np.zeros(160, np.uint8); ctx[:len(c["starts"][k][0])] = c["starts"][k][0]
         coeff = np.zeros(RD_TILE, np.int16); res = np.zeros(1, CTU_RESULT_DT)
-        rc = L.lib.x265amd_compress_ctu_inter(me.ctx, None, _ptr(info), _ptr(sp), _ptr(si), _ptr(c["ap"]), _ptr(u), _ptr(m), _ptr(c["col"]), _ptr(c["ref_depth"]),
-                                              _ptr(c["ref_qp0"]), _ptr(planes), len(c["pics"]), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), _ptr(st), a, _ptr(ctx),
-                                              C.c_uint64(c["starts"][k][1]), _ptr(coeff), _ptr(res))
+        with call_stream(L) as st_:
+            rc = L.lib.x265amd_compress_ctu_inter(me.ctx, st_, _ptr(info), _ptr(sp), _ptr(si), _ptr(c["ap"]), _ptr(u), _ptr(m), _ptr(c["col"]), _ptr(c["ref_depth"]),
+                                                  _ptr(c["ref_qp0"]), _ptr(planes), len(c["pics"]), C.c_int64(c["stride"]), C.c_int64(c["cstride"]), _ptr(st), a, _ptr(ctx),
+                                                  C.c_uint64(c["starts"][k][1]), _ptr(coeff), _ptr(res))
         assert rc == 0, L.lib.x265amd_last_error()
         cx, cy = (a % ctuW) * 16, (a // ctuW) * 16
         recon_pic = d_pics[-2].cpu().numpy().view(c["pics"][0].dtype)
@@ -2660,9 +2687,10 @@ def intra_rd_run_hip(L, c):
         d_pred = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
         d_recon = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
         units = np.ascontiguousarray(c["units"].copy())
-        rc = L.lib.x265amd_intra_in_inter(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
-                                          off(c["cus"], i), off(uo[i], 0), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), off(res, i), off(coeff[i], 0),
-                                          off(info[i], 0))
+        with call_stream(L) as st_:
+            rc = L.lib.x265amd_intra_in_inter(st_, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                              off(c["cus"], i), off(uo[i], 0), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), off(res, i), off(coeff[i], 0),
+                                              off(info[i], 0))
         assert rc == 0, L.lib.x265amd_last_error()
         assert np.array_equal(units, c["units"])
         recon[i] = d_recon.cpu().numpy().view(dt)
@@ -2730,9 +2758,10 @@ def check_intra_run_hip(L, c):
         d_pred = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
         d_recon = torch.zeros(RD_TILE * isz, dtype=torch.uint8, device="cuda")
         units = np.ascontiguousarray(c["units"].copy())
-        rc = L.lib.x265amd_check_intra(None, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
-                                       off(c["cus"], i), int(c["parts"][i]), off(uo[i], 0), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), off(res, i),
-                                       off(coeff[i], 0))
+        with call_stream(L) as st_:
+            rc = L.lib.x265amd_check_intra(st_, _ptr(si), _ptr(c["rp"]), _ptr(units), _ptr(planes), _ptr(rplanes), C.c_ssize_t(c["width"]), C.c_ssize_t(c["width"] // 2),
+                                           off(c["cus"], i), int(c["parts"][i]), off(uo[i], 0), C.c_uint64(d_pred.data_ptr()), C.c_uint64(d_recon.data_ptr()), off(res, i),
+                                           off(coeff[i], 0))
         assert rc == 0, L.lib.x265amd_last_error()
         assert np.array_equal(units, c["units"])
         recon[i] = d_recon.cpu().numpy().view(dt)

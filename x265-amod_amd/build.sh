@@ -16,18 +16,27 @@ build_one() {
     local newest
     newest=$(ls -t "$SRC"/* "$HERE"/host/* "$HERE"/../include/*.h | head -1)
     if [ -z "${X265AMD_FORCE:-}" ] && [ -f "$lib" ] && [ "$lib" -nt "$newest" ]; then return 0; fi
-    local objs=""
+    local objs="" pids=""
     for f in $SRCS; do
         local o=$OUT/$(basename "$f" .hip).$depth.o
+        if [ -z "${X265AMD_FORCE:-}" ] && [ -f "$o" ] && [ "$o" -nt "$f" ] && [ -z "$(find "$SRC" "$HERE/../include" "$HERE/host" -name '*.h' -newer "$o" | head -1)" ]; then
+            objs="$objs $o"; continue       # object newer than its source and every header
+        fi
+        rm -f "$o"
         $HIPCC $FLAGS -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
+        pids="$pids $!"
         objs="$objs $o"
     done
     for f in $HOSTSRCS; do
         local o=$OUT/$(basename "$f" .cpp).$depth.host.o
+        rm -f "$o"
         g++ -O2 -std=c++17 -fPIC -Wall -I"$HERE/../include" -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
+        pids="$pids $!"
         objs="$objs $o"
     done
-    wait
+    local failed=0
+    for p in $pids; do wait "$p" || failed=1; done      # a failed compile must not link yesterday's object
+    if [ "$failed" != 0 ]; then echo "build.sh: compilation failed" >&2; rm -f "$lib"; exit 1; fi
     $HIPCC --offload-arch=gfx950 -shared -o "$lib" $objs
 }
 for d in ${X265AMD_DEPTHS:-8 10}; do

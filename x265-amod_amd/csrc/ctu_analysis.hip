@@ -20,6 +20,7 @@
  */
 #include "x265amd_dev.h"
 #include "inter_common.h"
+#include "xa_queue.h"
 #include "../host/cabac_coder.h"
 #include <string.h>
 #include <vector>
@@ -1148,7 +1149,9 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
     if (rc == X265AMD_OK && (a.dTiles.alloc(a.tileBytes * 4 * (2 * NUM_PRED + 6)) != hipSuccess || a.dPlanes.alloc((size_t)num_pics * 24) != hipSuccess ||
                              a.dJobs.alloc(sizeof(x265amd_mc_job) * 8) != hipSuccess))
         rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: out of device memory");
-    if (rc == X265AMD_OK && hipMemcpyAsync(a.dPlanes.p, h_planes, (size_t)num_pics * 24, hipMemcpyHostToDevice, a.st) != hipSuccess)
+    /* a device job queue is a resident workgroup: it has to be told to look at what other rows, pictures and copies wrote (and, below, to publish) */
+    if (rc == X265AMD_OK && xa_stream_fence(a.st, XA_CMD_ACQUIRE) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: queue");
+    if (rc == X265AMD_OK && xa_copy_async(a.st, a.dPlanes.p, h_planes, (size_t)num_pics * 24, hipMemcpyHostToDevice) != hipSuccess)
         rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: plane table upload");
     if (rc == X265AMD_OK)
     {
@@ -1171,7 +1174,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         a.md[0].cur.frac = frac_in;
         SplitData topSplit;
         rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit));
-        if (rc == X265AMD_OK && hipStreamSynchronize(a.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
+        if (rc == X265AMD_OK && (xa_stream_fence(a.st, XA_CMD_RELEASE) != hipSuccess || xa_stream_sync(a.st) != hipSuccess)) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)
     {
@@ -1249,12 +1252,17 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
     if (wpp && ctuH > 1 && ctuW > 1)
     {
         const char* e = getenv("X265AMD_ROW_THREADS");
-        rowThreads = e ? atoi(e) : 16;
+        rowThreads = e ? atoi(e) : 64;        /* the wavefront never holds more than min(rows, columns / 2) CTUs at once */
         if (rowThreads > ctuH) rowThreads = ctuH;
+        if (rowThreads > (ctuW + 1) / 2) rowThreads = (ctuW + 1) / 2;
     }
+    const bool dumping = getenv("X265AMD_DUMP_CTU") != nullptr;        /* the dump synchronises the device: not behind a resident kernel */
     if (rowThreads <= 1)
     {
-        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++) rc = doCtu(addr, stream);
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
+        void* q = dumping ? nullptr : xa_queue_acquire();
+        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++) rc = doCtu(addr, q ? q : stream);
+        if (q) xa_queue_release(q);
     }
     else
     {
@@ -1268,8 +1276,14 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
         std::condition_variable cv;
         std::atomic<int> nextRow(0), firstErr(X265AMD_OK);
         auto worker = [&]() {
-            hipStream_t st = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { firstErr = xa_fail(X265AMD_EHIP, "analyse_frame: stream"); cv.notify_all(); return; }
+            /* a device job queue per row in flight (x265amd_host.h); a HIP stream when the queues are off or all taken */
+            void* st = dumping ? nullptr : xa_queue_acquire();
+            hipStream_t own = nullptr;
+            if (!st)
+            {
+                if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { firstErr = xa_fail(X265AMD_EHIP, "analyse_frame: stream"); cv.notify_all(); return; }
+                st = own;
+            }
             for (;;)
             {
                 const int row = nextRow.fetch_add(1);
@@ -1284,7 +1298,7 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
                     }
                     int r = firstErr.load();
                     if (r == X265AMD_OK) r = doCtu(row * ctuW + c, st);
-                    if (r == X265AMD_OK && hipStreamSynchronize(st) != hipSuccess) r = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");
+                    if (r == X265AMD_OK && xa_stream_sync(st) != hipSuccess) r = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");
                     {
                         std::lock_guard<std::mutex> lk(m);
                         if (r != X265AMD_OK) { int ok = X265AMD_OK; firstErr.compare_exchange_strong(ok, r); }
@@ -1295,7 +1309,8 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
                 }
                 if (firstErr.load() != X265AMD_OK) { std::lock_guard<std::mutex> lk(m); done[row] = ctuW; cv.notify_all(); }
             }
-            (void)hipStreamDestroy(st);
+            if (own) (void)hipStreamDestroy(own);
+            else xa_queue_release(st);
         };
         if (rc == X265AMD_OK)
         {

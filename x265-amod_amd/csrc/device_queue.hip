@@ -1,0 +1,777 @@
+/* Device job queues (x265amd_host.h: xa_q_*, xa_stream_*): the resident server kernel and its host side.  See xa_queue.h for the why and the
+ * protocol.  The host loop being replaced is the reference's worker thread calling primitives one block at a time
+ * (reference: source/encoder/analysis.cpp:1146-1848 -> source/common/primitives.h:239-433); the queue keeps that call order per CTU row and removes
+ * the launch + synchronise pair from every call.
+ */
+#include "x265amd_dev.h"
+#include "x265amd_host.h"
+#include "xa_queue.h"
+#include "tu_dev.h"
+#include "intra_dev.h"
+#include "mc_dev.h"
+#include "me_dev.h"
+#include "measure_dev.h"
+#include "entropy_dev.h"
+#include <immintrin.h>
+#include <signal.h>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+/* =========================================================================================================
+ * device side
+ * ======================================================================================================= */
+extern __shared__ __attribute__((aligned(16))) char xa_smem[];
+__device__ uint64_t* xa_dbg_area[256];                                /* per workgroup: XaRingHost::dbg (debugging aid) */
+#define XA_DBG(c, slot, v) do { if (((c).reserved & 2) && (threadIdx.x & 63) == 0) __hip_atomic_store(&xa_dbg_area[blockIdx.x][((threadIdx.x >> 6) * 8 + (slot)) & 63], (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)      /* aliases tu_smem / me_smem: one dynamic LDS block, laid out per command */
+
+XA_DEV uint64_t xa_sys_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+XA_DEV void xa_sys_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+/* byte copies by the whole workgroup: 16 bytes per lane where both sides allow it */
+XA_DEV void block_copy(char* dst, const char* src, size_t bytes, int tid, int nthr)
+{
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0)
+    {
+        const size_t n16 = bytes >> 4;
+        for (size_t i = tid; i < n16; i += nthr) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (size_t i = (n16 << 4) + tid; i < bytes; i += nthr) dst[i] = src[i];
+    }
+    else
+        for (size_t i = tid; i < bytes; i += nthr) dst[i] = src[i];
+}
+
+XA_DEV void block_copy_rects(const XaArgsRects& r, int tid, int nthr)
+{
+    for (int k = 0; k < r.n; k++)
+    {
+        const pixel* src = reinterpret_cast<const pixel*>(r.src[k]);
+        pixel* dst = reinterpret_cast<pixel*>(r.dst[k]);
+        const int w = r.w[k], total = w * r.h[k];
+        for (int i = tid; i < total; i += nthr)
+        {
+            const int y = i / w, x = i - y * w;
+            dst[(size_t)y * r.dst_stride[k] + x] = src[(size_t)y * r.src_stride[k] + x];
+        }
+    }
+}
+
+/* every command body is a function of its own: the register allocation of one does not weigh on the others */
+__device__ __noinline__ void xa_op_copy(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsCopy& a = *reinterpret_cast<const XaArgsCopy*>(c.args);
+        block_copy(reinterpret_cast<char*>(a.dst), reinterpret_cast<const char*>(a.src), a.bytes, tid, NT);
+    }
+}
+
+__device__ __noinline__ void xa_op_copy2d(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsCopy2D& a = *reinterpret_cast<const XaArgsCopy2D*>(c.args);
+        for (uint64_t y = wv; y < a.height; y += XA_SERVER_WAVES)
+            block_copy(reinterpret_cast<char*>(a.dst + y * a.dpitch), reinterpret_cast<const char*>(a.src + y * a.spitch), a.width, lane, 64);
+    }
+}
+
+__device__ __noinline__ void xa_op_fill(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsFill& a = *reinterpret_cast<const XaArgsFill*>(c.args);
+        char* d = reinterpret_cast<char*>(a.dst);
+        for (size_t i = tid; i < a.bytes; i += NT) d[i] = (char)a.value;
+    }
+}
+
+__device__ __noinline__ void xa_op_copy_rects(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+        block_copy_rects(*reinterpret_cast<const XaArgsRects*>(c.args), tid, NT);
+}
+
+__device__ __noinline__ void xa_op_mc(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsMc a = *reinterpret_cast<const XaArgsMc*>(c.args);
+        const bool cost = c.op == XA_OP_MC_COST;
+        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
+        {
+            XA_DBG(c, 0, 0x6000000000000000ull | (uint64_t)ji); XA_DBG(c, 1, a.jobs + ji); XA_DBG(c, 2, a.jobs[ji].dst_y); XA_DBG(c, 3, a.jobs[ji].dst_v); XA_DBG(c, 4, a.planes);
+            if (cost) wave_mc_job<true>(a, ji, lane);
+            else wave_mc_job<false>(a, ji, lane);
+            XA_DBG(c, 7, 0x6666000000000000ull | (uint64_t)ji);
+        }
+    }
+}
+
+__device__ __noinline__ void xa_op_cu_measure(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        constexpr int W = (XA_SERVER_LDS / (64 * 64 * (int)sizeof(pixel))) < XA_SERVER_WAVES ? (XA_SERVER_LDS / (64 * 64 * (int)sizeof(pixel))) : XA_SERVER_WAVES;
+        if (wv < W)
+            for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : W)
+            {
+                const CuMeasureJob* jp = reinterpret_cast<const CuMeasureJob*>(a.a) + ji;
+                XA_DBG(c, 0, 0x8000000000000000ull | (uint64_t)ji); XA_DBG(c, 1, jp); XA_DBG(c, 2, jp->pred); XA_DBG(c, 3, jp->recon); XA_DBG(c, 4, jp->fenc[0]); XA_DBG(c, 5, jp->fenc[2]);
+                XA_DBG(c, 6, ((uint64_t)(uint32_t)jp->log2_size << 32) | (uint32_t)jp->assemble);
+                if ((c.reserved & 4) && (!jp->pred || !jp->recon || !jp->fenc[0] || !jp->fenc[1] || !jp->fenc[2] || !a.b)) continue;
+                wave_cu_measure_job(reinterpret_cast<const CuMeasureJob*>(a.a), ji, reinterpret_cast<CuMeasure*>(a.b), reinterpret_cast<pixel*>(xa_smem) + wv * 64 * 64, lane);
+                XA_DBG(c, 7, 0x7777000000000000ull | (uint64_t)ji);
+            }
+    }
+}
+
+__device__ __noinline__ void xa_op_tu_chain(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        static_assert(XA_SERVER_WAVES * sizeof(TuLds) <= XA_SERVER_LDS, "LDS budget");
+        TuLds& s = reinterpret_cast<TuLds*>(xa_smem)[wv];
+        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
+            wave_tu_chain_job<false>(reinterpret_cast<const x265amd_tu_job*>(a.a), nullptr, ji, reinterpret_cast<x265amd_tu_result*>(a.c), s, nullptr, lane);
+    }
+}
+
+__device__ __noinline__ void xa_op_tu_chain_rdoq(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        constexpr int W = XA_SERVER_LDS / (int)(sizeof(TuLds) + sizeof(RdoqLds));
+        static_assert(W >= 1, "LDS budget");
+        if (wv < W)
+        {
+            TuLds& s = reinterpret_cast<TuLds*>(xa_smem)[wv];
+            char* rdoqLds = xa_smem + W * sizeof(TuLds) + wv * sizeof(RdoqLds);
+            for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : W)
+                wave_tu_chain_job<true>(reinterpret_cast<const x265amd_tu_job*>(a.a), reinterpret_cast<const x265amd_tu_rdoq*>(a.b), ji, reinterpret_cast<x265amd_tu_result*>(a.c), s, rdoqLds, lane);
+        }
+    }
+}
+
+__device__ __noinline__ void xa_op_intra_tu_chain(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        static_assert(XA_SERVER_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)) <= XA_SERVER_LDS, "LDS budget");
+        TuLds& s = reinterpret_cast<TuLds*>(xa_smem)[wv];
+        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(xa_smem + XA_SERVER_WAVES * sizeof(TuLds))[wv];
+        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
+            wave_intra_tu_chain_job<false>(reinterpret_cast<const x265amd_intra_tu_job*>(a.a), nullptr, ji, reinterpret_cast<x265amd_tu_result*>(a.c), s, ip, nullptr, lane);
+    }
+}
+
+__device__ __noinline__ void xa_op_intra_tu_chain_rdoq(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        constexpr int W = XA_SERVER_LDS / (int)(sizeof(TuLds) + sizeof(IntraTuLds) + sizeof(RdoqLds));
+        static_assert(W >= 1, "LDS budget");
+        if (wv < W)
+        {
+            TuLds& s = reinterpret_cast<TuLds*>(xa_smem)[wv];
+            IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(xa_smem + W * sizeof(TuLds))[wv];
+            char* rdoqLds = xa_smem + W * (sizeof(TuLds) + sizeof(IntraTuLds)) + wv * sizeof(RdoqLds);
+            for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : W)
+                wave_intra_tu_chain_job<true>(reinterpret_cast<const x265amd_intra_tu_job*>(a.a), reinterpret_cast<const x265amd_tu_rdoq*>(a.b), ji,
+                                              reinterpret_cast<x265amd_tu_result*>(a.c), s, ip, rdoqLds, lane);
+        }
+    }
+}
+
+__device__ __noinline__ void xa_op_intra_scan(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        static_assert(XA_SERVER_WAVES * sizeof(IntraLds) <= XA_SERVER_LDS, "LDS budget");
+        IntraLds& s = reinterpret_cast<IntraLds*>(xa_smem)[wv];
+        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
+            wave_intra_scan_job(reinterpret_cast<const x265amd_intra_job*>(a.a), ji, reinterpret_cast<int32_t*>(a.b), reinterpret_cast<pixel*>(a.c), s, lane);
+    }
+}
+
+__device__ __noinline__ void xa_op_est_bit(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const int lane = tid & 63, wv = tid >> 6;
+    (void)NT; (void)lane; (void)wv;
+    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
+    (void)serial;
+    {
+        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES) wave_est_bit_job(reinterpret_cast<const x265amd_est_job*>(a.a), ji, lane);
+    }
+}
+
+/* the groups of a launch one after the other: each stages its window, its jobs go to the wavefronts */
+template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int tid)
+{
+    constexpr int NT = 64 * XA_SERVER_WAVES;
+    const MeParams p = *reinterpret_cast<const MeParams*>(c.args);
+    const int groups = (int)c.count;
+    for (int vb = 0; vb < groups; vb++)
+    {
+        if (WHICH == 0) block_me_search<false>(p, vb, tid, NT);
+        else if (WHICH == 1) block_me_search<true>(p, vb, tid, NT);
+        else block_me_deferred(p, vb, tid, NT);
+        __syncthreads();
+    }
+}
+
+XA_DEV void xa_dispatch(const XaCmd& c, int tid)
+{
+    switch (c.op)
+    {
+    case XA_OP_COPY:
+        xa_op_copy(c, tid);
+        break;
+    case XA_OP_COPY2D:
+        xa_op_copy2d(c, tid);
+        break;
+    case XA_OP_FILL:
+        xa_op_fill(c, tid);
+        break;
+    case XA_OP_COPY_RECTS:
+        xa_op_copy_rects(c, tid);
+        break;
+    case XA_OP_MC:
+    case XA_OP_MC_COST:
+        xa_op_mc(c, tid);
+        break;
+    case XA_OP_CU_MEASURE:
+        xa_op_cu_measure(c, tid);
+        break;
+    case XA_OP_TU_CHAIN:
+        xa_op_tu_chain(c, tid);
+        break;
+    case XA_OP_TU_CHAIN_RDOQ:
+        xa_op_tu_chain_rdoq(c, tid);
+        break;
+    case XA_OP_INTRA_TU_CHAIN:
+        xa_op_intra_tu_chain(c, tid);
+        break;
+    case XA_OP_INTRA_TU_CHAIN_RDOQ:
+        xa_op_intra_tu_chain_rdoq(c, tid);
+        break;
+    case XA_OP_INTRA_SCAN:
+        xa_op_intra_scan(c, tid);
+        break;
+    case XA_OP_EST_BIT:
+        xa_op_est_bit(c, tid);
+        break;
+    case XA_OP_ME_SEARCH: xa_op_me<0>(c, tid); break;
+    case XA_OP_ME_SEARCH_STAR: xa_op_me<1>(c, tid); break;
+    case XA_OP_ME_DEFERRED: xa_op_me<2>(c, tid); break;
+    default:
+        break;
+    }
+}
+
+/* One workgroup per queue.  Wavefront 0 polls the ring head (a relaxed system-scope load of its own device memory), copies the next command into LDS
+ * and the workgroup runs it.  A workgroup leaves when its queue's quit word is set or when it has seen no command for `idleTicks` of the 100 MHz
+ * wall clock (nothing resident outlives a host that went away). */
+__global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* rings, XaRingHost* hosts, long long idleTicks, uint64_t generation)
+{
+    __shared__ XaCmd s_cmd;
+    __shared__ int s_go;
+    XaRingDev* rd = rings + blockIdx.x;
+    XaRingHost* rh = hosts + blockIdx.x;
+    const int tid = threadIdx.x;
+    uint64_t seen = 0, rereads = 0;
+    if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
+    __syncthreads();
+    for (;;)
+    {
+        if (tid < 64)
+        {
+            int go = 1;
+            if (tid == 0)
+            {
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                for (;;)
+                {
+                    if (xa_sys_load(&rd->head) > seen) break;
+                    if (xa_sys_load(&rd->quit)) { go = 0; break; }
+                    if ((++spins & 1023) == 0 && wall_clock64() - t0 > idleTicks) { go = 0; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            go = __shfl(go, 0, 64);
+            if (go)
+            {
+                /* the slot, until its check word closes over the other fifteen and this command's number */
+                const uint64_t* slot = reinterpret_cast<const uint64_t*>(&rd->cmd[seen % XA_RING]);
+                for (unsigned tries = 0;; tries++)
+                {
+                    const uint64_t w = tid < 16 ? xa_sys_load(slot + tid) : 0;
+                    uint64_t x = tid < 15 ? w : 0;
+                    x ^= __shfl_xor(x, 1, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 8, 64);
+                    const uint64_t want = __shfl(x, 0, 64) ^ (XA_CHECK_MUL * (seen + 1)) ^ generation;
+                    const uint64_t got = __shfl(w, 15, 64);
+                    if (got == want)
+                    {
+                        if (tid < 16) reinterpret_cast<uint64_t*>(&s_cmd)[tid] = w;
+                        if (tries && tid == 0) { rereads += tries; xa_sys_store(&rh->dbg[63], rereads); }     /* how often a slot was not complete yet */
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (tid == 0)
+            {
+                s_go = go;
+                /* Every command starts behind an acquire: the job records and small tables it reads live in pinned host memory that the host rewrites
+                 * in place between commands, and this CU's vector L1 keeps lines across commands (measured: without it the second use of a record
+                 * array reads the first use's bytes).  The same invalidation is what XA_CMD_ACQUIRE asks for, so that flag costs nothing extra. */
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                /* ... and so does the scalar data cache, which no fence touches: wave-uniform record loads (jobs[ji]) are scalar loads */
+                __builtin_amdgcn_s_dcache_inv();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (!s_go) break;
+        const uint32_t flags = s_cmd.flags;
+        if (s_cmd.op == XA_OP_EXIT) break;
+        xa_dispatch(s_cmd, tid);
+        /* every wavefront's stores have left before the workgroup reports (results live in host memory, read as soon as the count moves) */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        seen++;
+        if (tid == 0)
+        {
+            if (flags & (XA_CMD_RELEASE | XA_CMD_SIGNAL))
+            {
+                /* what the host (results in pinned memory) and other workgroups (pictures) will read leaves this XCD's L2 now: the L2 keeps the lines a
+                 * workgroup has stored to host memory, and nothing but a release writes them back while the kernel is resident */
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (flags & XA_CMD_SIGNAL) xa_sys_store(&rh->tail, seen);
+        }
+    }
+    if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
+}
+
+/* =========================================================================================================
+ * host side
+ * ======================================================================================================= */
+namespace {
+
+const size_t kStagingBytes = 1 << 20;
+
+struct Deferred { void* dst; const void* src; size_t bytes; };      /* staging -> pageable destination once the queue has drained */
+
+}
+
+struct XaQueue
+{
+    int idx = 0;
+    XaRingDev* rd = nullptr;            /* device memory through the BAR */
+    XaRingHost* rh = nullptr;           /* pinned host memory */
+    uint64_t submitted = 0;             /* commands written so far */
+    uint64_t lastSignal = 0;            /* `submitted` after the last command that carried XA_CMD_SIGNAL */
+    uint64_t generation = 0;            /* of the server kernel this queue talks to: part of every command's check word, so that a slot left over from an
+                                           earlier kernel (the rings are not cleared, and command numbers restart) never passes for a new command */
+    char* staging = nullptr; size_t stagingUsed = 0, stagingUsedOut = 0;
+    std::vector<Deferred> deferred;
+    bool busy = false;
+};
+
+namespace {
+
+void dump_debug_areas(int);
+
+struct Server
+{
+    std::mutex m;
+    int numQueues = 0;
+    XaRingDev* rings = nullptr;
+    XaRingHost* hosts = nullptr;
+    char* staging = nullptr;
+    std::vector<XaQueue> q;
+    hipStream_t stream = nullptr;
+    bool running = false;
+    int refs = 0;
+    uint64_t generation = 0;
+    bool disabled = false, ringsInHost = false;
+
+    int init()
+    {
+        if (numQueues) return 0;
+        const char* e = getenv("X265AMD_QUEUES");
+        int n = e ? atoi(e) : 64;
+        if (n <= 0) { disabled = true; return -1; }
+        if (n > 224) n = 224;
+        ringsInHost = getenv("X265AMD_RING_HOST") != nullptr;
+        if (ringsInHost ? hipHostMalloc((void**)&rings, sizeof(XaRingDev) * n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess
+                        : hipExtMallocWithFlags((void**)&rings, sizeof(XaRingDev) * n, hipDeviceMallocUncached) != hipSuccess)
+            return -1;
+        if (!ringsInHost && (hipMemset(rings, 0, sizeof(XaRingDev) * n) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) return -1;
+        if (ringsInHost) memset((void*)rings, 0, sizeof(XaRingDev) * n);
+        if (hipHostMalloc((void**)&hosts, sizeof(XaRingHost) * n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
+        if (hipHostMalloc((void**)&staging, kStagingBytes * n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void*)k_job_server, hipFuncAttributeMaxDynamicSharedMemorySize, XA_SERVER_LDS) != hipSuccess) return -1;
+        memset((void*)hosts, 0, sizeof(XaRingHost) * n);
+        q.resize(n);
+        for (int i = 0; i < n; i++) { q[i].idx = i; q[i].rd = rings + i; q[i].rh = hosts + i; q[i].staging = staging + kStagingBytes * i; }
+        numQueues = n;
+        if (getenv("X265AMD_QUEUE_DEBUG") && (atoi(getenv("X265AMD_QUEUE_DEBUG")) & 2)) signal(SIGABRT, dump_debug_areas);
+        return 0;
+    }
+    /* called with the lock held */
+    int start()
+    {
+        if (running) return 0;
+        /* every workgroup starts counting at 0; the head and quit words are reset through the BAR (posted writes, ordered before the launch's doorbell) */
+        generation += 0x0123456789ABCDEFull;
+        for (int i = 0; i < numQueues; i++)
+        {
+            XaQueue& x = q[i];
+            x.submitted = 0; x.lastSignal = 0; x.generation = generation;
+            x.rh->tail = 0; x.rh->state = 0; x.rh->dbg[63] = 0;
+            *reinterpret_cast<volatile uint64_t*>(&rings[i].head) = 0;
+            *reinterpret_cast<volatile uint64_t*>(&rings[i].quit) = 0;
+        }
+        _mm_sfence();
+        hipLaunchKernelGGL(k_job_server, dim3(numQueues), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 20, generation);
+        if (hipGetLastError() != hipSuccess) return -1;
+        running = true;
+        return 0;
+    }
+    void stop()
+    {
+        if (!running) return;
+        for (int i = 0; i < numQueues; i++) rings[i].quit = 1;
+        _mm_sfence();
+        (void)hipStreamSynchronize(stream);
+        running = false;
+    }
+};
+
+Server& server() { static Server* s = new Server; return *s; }
+
+/* X265AMD_QUEUE_DEBUG & 2: the runtime aborts the process on a GPU memory fault; say what the wavefronts had announced */
+void dump_debug_areas(int)
+{
+    Server& S = server();
+    for (int i = 0; i < S.numQueues; i++)
+    {
+        if (!S.q[i].busy) continue;
+        fprintf(stderr, "x265amd queue %d debug area (wave x slot):\n", i);
+        for (int w = 0; w < 8; w++)
+        {
+            fprintf(stderr, "  wave %d:", w);
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %llx", (unsigned long long)S.hosts[i].dbg[w * 8 + k]);
+            fprintf(stderr, "\n");
+        }
+    }
+    fflush(stderr);
+    signal(SIGABRT, SIG_DFL);
+    abort();
+}
+
+inline XaQueue* as_queue(void* st) { return reinterpret_cast<XaQueue*>((uintptr_t)st & ~(uintptr_t)1); }
+
+int q_wait(XaQueue* q, uint64_t target)
+{
+    const volatile uint64_t* tail = &q->rh->tail;
+    if (*tail >= target) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++)
+    {
+        if (*tail >= target) break;
+        _mm_pause();
+        if ((spins & 0xFFFFF) == 0xFFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+        {
+            fprintf(stderr, "x265amd queue %d: no answer: submitted %llu, waiting for %llu, finished %llu, resident %llu, slot re-reads %llu\n", q->idx,
+                    (unsigned long long)q->submitted, (unsigned long long)target, (unsigned long long)*tail, (unsigned long long)q->rh->state, (unsigned long long)q->rh->dbg[63]);
+            return -1;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+
+int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* args, size_t argBytes)
+{
+    if (argBytes > sizeof(uint64_t) * XA_CMD_ARG_WORDS) return -1;
+    if (q->submitted - q->lastSignal >= XA_RING - 2) flags |= XA_CMD_SIGNAL;
+    if (q->submitted >= XA_RING && q_wait(q, q->submitted - XA_RING + 1)) return -1;        /* the slot must have been consumed */
+    XaCmd c;
+    memset(&c, 0, sizeof(c));
+    static const uint32_t debugBits = getenv("X265AMD_QUEUE_DEBUG") ? (uint32_t)atoi(getenv("X265AMD_QUEUE_DEBUG")) : 0;
+    c.op = op; c.flags = flags; c.count = count; c.reserved = debugBits;
+    if (argBytes) memcpy(c.args, args, argBytes);
+    {
+        const uint64_t* w = reinterpret_cast<const uint64_t*>(&c);
+        uint64_t x = 0;
+        for (int i = 0; i < 15; i++) x ^= w[i];
+        c.check = x ^ (XA_CHECK_MUL * (q->submitted + 1)) ^ q->generation;
+    }
+    XaCmd* slot = &q->rd->cmd[q->submitted % XA_RING];
+    /* 128 bytes through the write-combining BAR mapping, then the doorbell behind a store fence */
+    const __m128i* s = reinterpret_cast<const __m128i*>(&c);
+    __m128i* d = reinterpret_cast<__m128i*>(slot);
+    for (int i = 0; i < 8; i++) _mm_store_si128(d + i, _mm_load_si128(s + i));
+    _mm_sfence();
+    q->submitted++;
+    *reinterpret_cast<volatile uint64_t*>(&q->rd->head) = q->submitted;
+    _mm_sfence();
+    if (flags & XA_CMD_SIGNAL) q->lastSignal = q->submitted;
+    return 0;
+}
+
+} // namespace
+
+bool xa_queues_enabled()
+{
+    Server& S = server();
+    std::lock_guard<std::mutex> g(S.m);
+    return !S.disabled && S.init() == 0;
+}
+
+void* xa_queue_acquire()
+{
+    Server& S = server();
+    std::lock_guard<std::mutex> g(S.m);
+    if (S.disabled || S.init() != 0) return nullptr;
+    XaQueue* f = nullptr;
+    for (XaQueue& x : S.q) if (!x.busy) { f = &x; break; }
+    if (!f) return nullptr;
+    if (S.start() != 0) return nullptr;
+    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear();
+    S.refs++;
+    xa_scratch_local_begin();           /* the calling thread is the one that uses the queue */
+    return reinterpret_cast<void*>((uintptr_t)f | 1);
+}
+
+void xa_queue_release(void* st)
+{
+    if (!xa_is_queue(st)) return;
+    XaQueue* q = as_queue(st);
+    (void)xa_stream_fence(st, XA_CMD_RELEASE);
+    (void)xa_stream_sync(st);
+    xa_scratch_local_end();
+    Server& S = server();
+    std::lock_guard<std::mutex> g(S.m);
+    q->busy = false;
+    if (getenv("X265AMD_QUEUE_DEBUG") && q->rh->dbg[63]) fprintf(stderr, "x265amd queue %d: %llu command slot re-reads so far\n", q->idx, (unsigned long long)q->rh->dbg[63]);
+    if (--S.refs == 0) S.stop();
+}
+
+hipError_t xa_q_enqueue(void* st, int op, const void* args, size_t argBytes, int count, int flags)
+{
+    static const bool trace = getenv("X265AMD_QUEUE_TRACE") != nullptr;     /* debugging: name every command and wait for it */
+    XaQueue* q = as_queue(st);
+    if (trace)
+    {
+        fprintf(stderr, "x265amd queue %d: op %d count %d flags %d args", q->idx, op, count, flags);
+        for (size_t i = 0; i < argBytes / 8; i++) fprintf(stderr, " %llx", (unsigned long long)reinterpret_cast<const uint64_t*>(args)[i]);
+        fprintf(stderr, "\n");
+        fflush(stderr);
+        if (q_push(q, (uint32_t)op, (uint32_t)flags | XA_CMD_SIGNAL, (uint32_t)count, args, argBytes) || q_wait(q, q->submitted)) return hipErrorUnknown;
+        if (op == XA_OP_CU_MEASURE || op == XA_OP_MC)
+            for (int w = 0; w < 8; w++)
+            {
+                fprintf(stderr, "  wave %d:", w);
+                for (int k = 0; k < 8; k++) fprintf(stderr, " %llx", (unsigned long long)q->rh->dbg[w * 8 + k]);
+                fprintf(stderr, "\n");
+            }
+        if (op == XA_OP_CU_MEASURE)
+            for (int k = 0; k < count; k++)
+            {
+                const uint64_t* r = reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint64_t*>(args)[0]) + 9 * k;
+                fprintf(stderr, "  host job %d:", k);
+                for (int w = 0; w < 9; w++) fprintf(stderr, " %llx", (unsigned long long)r[w]);
+                fprintf(stderr, "\n");
+            }
+        return hipSuccess;
+    }
+    return q_push(q, (uint32_t)op, (uint32_t)flags, (uint32_t)count, args, argBytes) == 0 ? hipSuccess : hipErrorUnknown;
+}
+
+hipError_t xa_stream_sync(void* st)
+{
+    if (!xa_is_queue(st)) return hipStreamSynchronize((hipStream_t)st);
+    XaQueue* q = as_queue(st);
+    if (q->lastSignal != q->submitted && q_push(q, XA_OP_NOP, XA_CMD_SIGNAL, 0, nullptr, 0)) return hipErrorUnknown;
+    if (q_wait(q, q->submitted)) { xa_fail(X265AMD_EHIP, "device queue: no answer from the job server"); return hipErrorUnknown; }
+    for (const Deferred& d : q->deferred) memcpy(d.dst, d.src, d.bytes);
+    q->deferred.clear();
+    q->stagingUsed = 0; q->stagingUsedOut = 0;
+    return hipSuccess;
+}
+
+hipError_t xa_stream_fence(void* st, int flags)
+{
+    if (!xa_is_queue(st)) return hipSuccess;        /* kernel boundaries of a stream are release / acquire points already */
+    return xa_q_enqueue(st, XA_OP_NOP, nullptr, 0, 0, flags);
+}
+
+/* the staging area in halves by direction (see XaMapped in x265amd_host.h: lines the workgroup has stored to are not to be read by it later) */
+static char* q_stage(XaQueue* q, size_t bytes, bool deviceWrites)
+{
+    const size_t need = (bytes + 127) & ~(size_t)127;
+    size_t& used = deviceWrites ? q->stagingUsedOut : q->stagingUsed;
+    if (used + need > kStagingBytes / 2) return nullptr;
+    char* p = q->staging + (deviceWrites ? kStagingBytes / 2 : 0) + used;
+    used += need;
+    return p;
+}
+
+hipError_t xa_copy_async(void* st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    if (!xa_is_queue(st)) return hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)st);
+    if (!bytes) return hipSuccess;
+    XaQueue* q = as_queue(st);
+    XaArgsCopy a = { (uint64_t)(uintptr_t)dst, (uint64_t)(uintptr_t)src, bytes };
+    if (kind == hipMemcpyHostToDevice)
+    {
+        /* pageable source: through this queue's pinned staging area (the call returns with the source free to change, as hipMemcpyAsync does) */
+        char* s = q_stage(q, bytes, false);
+        if (!s)
+        {
+            if (xa_stream_sync(st) != hipSuccess) return hipErrorUnknown;
+            s = q_stage(q, bytes, false);
+            if (!s) return hipMemcpy(dst, src, bytes, kind);
+        }
+        memcpy(s, src, bytes);
+        a.src = (uint64_t)(uintptr_t)s;
+    }
+    else if (kind == hipMemcpyDeviceToHost)
+    {
+        char* s = q_stage(q, bytes, true);
+        if (!s)
+        {
+            if (xa_stream_sync(st) != hipSuccess) return hipErrorUnknown;
+            s = q_stage(q, bytes, true);
+            if (!s) return hipMemcpy(dst, src, bytes, kind);
+        }
+        a.dst = (uint64_t)(uintptr_t)s;
+        q->deferred.push_back(Deferred{ dst, s, bytes });
+    }
+    return xa_q_enqueue(st, XA_OP_COPY, &a, sizeof(a), 1, 0);
+}
+
+hipError_t xa_copy2d_to_mapped_async(void* st, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height)
+{
+    if (!xa_is_queue(st)) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)st);
+    XaArgsCopy2D a = { (uint64_t)(uintptr_t)dst, (uint64_t)(uintptr_t)src, dpitch, spitch, width, height };
+    return xa_q_enqueue(st, XA_OP_COPY2D, &a, sizeof(a), 1, 0);
+}
+
+hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes)
+{
+    if (!xa_is_queue(st)) return hipMemsetAsync(dst, value, bytes, (hipStream_t)st);
+    XaArgsFill a = { (uint64_t)(uintptr_t)dst, bytes, (uint32_t)value };
+    return xa_q_enqueue(st, XA_OP_FILL, &a, sizeof(a), 1, 0);
+}
+
+extern "C" void* x265amd_queue_acquire(void) { return xa_queue_acquire(); }
+extern "C" void x265amd_queue_release(void* queue) { xa_queue_release(queue); }
+
+/* ---- self test (tests/test_device_queue.py): copies, fills and rectangle copies through a queue against the same through a stream ---- */
+extern "C" int x265amd_queue_selftest(int rounds, int numQueues)
+{
+    if (rounds <= 0 || numQueues <= 0) return xa_fail(X265AMD_EINVAL, "queue_selftest: arguments");
+    std::vector<void*> qs;
+    for (int i = 0; i < numQueues; i++)
+    {
+        void* q = xa_queue_acquire();
+        if (!q) { for (void* p : qs) xa_queue_release(p); return xa_fail(X265AMD_EHIP, "queue_selftest: no queue"); }
+        qs.push_back(q);
+    }
+    std::atomic<int> bad(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < numQueues; t++)
+        pool.emplace_back([&, t] {
+            void* st = qs[t];
+            const size_t n = 4096 + 64 * t;
+            void *dA = nullptr, *dB = nullptr, *mapped = nullptr;
+            if (xa_scratch_alloc(&dA, n) != hipSuccess || xa_scratch_alloc(&dB, n) != hipSuccess || xa_mapped_alloc(&mapped, n, true) != hipSuccess) { bad++; return; }
+            std::vector<uint8_t> src(n), back(n);
+            for (int r = 0; r < rounds; r++)
+            {
+                for (size_t i = 0; i < n; i++) src[i] = (uint8_t)(i * 7 + r * 13 + t);
+                /* the first command of a round sees whatever other agents wrote; the last one publishes */
+                if (xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) { bad++; break; }
+                if (xa_copy_async(st, dA, src.data(), n, hipMemcpyHostToDevice) != hipSuccess) { bad++; break; }
+                XaRects rc;
+                memset(&rc, 0, sizeof(rc));
+                rc.n = 1; rc.dst[0] = (uint64_t)(uintptr_t)dB; rc.src[0] = (uint64_t)(uintptr_t)dA; rc.dst_stride[0] = rc.src_stride[0] = 64; rc.w[0] = 64;
+                rc.h[0] = (int32_t)(n / 64 / sizeof(x265amd_pixel));
+                xa_copy_rects(st, rc);
+                if (xa_fill_async(st, dA, r & 255, 128) != hipSuccess) { bad++; break; }
+                /* same data three ways back: pageable (deferred), mapped in place */
+                if (xa_copy_async(st, back.data(), dB, n, hipMemcpyDeviceToHost) != hipSuccess) { bad++; break; }
+                if (xa_copy2d_to_mapped_async(st, mapped, 64, dB, 64, 64, n / 64) != hipSuccess) { bad++; break; }
+                if (xa_stream_fence(st, XA_CMD_RELEASE) != hipSuccess || xa_stream_sync(st) != hipSuccess) { bad++; break; }
+                const size_t copied = (size_t)rc.h[0] * 64 * sizeof(x265amd_pixel);
+                if (memcmp(back.data(), src.data(), copied) != 0 || memcmp(mapped, src.data(), copied) != 0) { bad++; break; }
+            }
+            xa_scratch_free(dA); xa_scratch_free(dB); xa_mapped_free(mapped);
+        });
+    for (auto& th : pool) th.join();
+    for (void* p : qs) xa_queue_release(p);
+    return bad.load() ? xa_fail(X265AMD_EHIP, "queue_selftest: mismatch") : X265AMD_OK;
+}

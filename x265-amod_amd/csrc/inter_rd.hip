@@ -23,76 +23,14 @@
 #include <vector>
 #include <functional>
 
-/* ---------------- device: CU assembly + measurement ---------------- */
-#define RD_LUMA_ELEMS 4096
-#define RD_CHROMA_ELEMS 1024
-#define RD_SCRATCH_ELEMS (4 * RD_LUMA_ELEMS + 3 * 2 * RD_CHROMA_ELEMS)      /* luma layers 4..32, chroma layers 4..16 x {U, V} */
-#define RD_SEL_BYTES 384                                                     /* 256 luma units (row length 16) + 2 x 64 chroma units (row length 8) */
+#include "measure_dev.h"
+#include "xa_queue.h"
 
-struct CuMeasureJob
-{
-    uint64_t fenc[3];               /* source block top-left per plane */
-    uint64_t pred, recon;           /* tiles: 64x64 luma (stride 64), 32x32 U, 32x32 V (stride 32) */
-    uint64_t resi;                  /* the CU's residual scratch (int16, RD_SCRATCH_ELEMS) */
-    uint64_t sel;                   /* per unit: transform layer (log2 size) whose residual block covers it, 0xFF = none */
-    int32_t fenc_stride, fenc_cstride, log2_size, assemble;
-};
-typedef x265amd_cu_measure CuMeasure;
-
-XA_DEV size_t rd_layer_offset(int plane, int layer)
-{
-    return plane ? (size_t)4 * RD_LUMA_ELEMS + (size_t)((layer - 2) * 2 + (plane - 1)) * RD_CHROMA_ELEMS : (size_t)(layer - 2) * RD_LUMA_ELEMS;
-}
-
-/* one wavefront per CU: reconYuv = predYuv (+ clipped residual where a block was kept: Yuv::addClip, yuv.cpp:158-183), then
- * sse_pp per plane and the luma psyCost against the source (search.cpp:2937-2958 / :2869-2889) */
 __global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int n, CuMeasure* out)
 {
     __shared__ pixel tile[64 * 64];
-    const int lane = xa_lane(), ji = blockIdx.x;
-    if (ji >= n) return;
-    const CuMeasureJob j = jobs[ji];
-    const uint8_t* sel = reinterpret_cast<const uint8_t*>(j.sel);
-    const int16_t* resi = reinterpret_cast<const int16_t*>(j.resi);
-    CuMeasure m;
-    m.psy = 0; m.sa8d = 0; m.sa8d_luma = 0; m.src_mean = 0; m.src_homo = 0; m.reserved = 0;
-    for (int plane = 0; plane < 3; plane++)
-    {
-        const int log2S = plane ? j.log2_size - 1 : j.log2_size, s = 1 << log2S, ts = plane ? 32 : 64;
-        const size_t tileOff = plane ? 4096 + (size_t)(plane - 1) * 1024 : 0;
-        const pixel* pred = reinterpret_cast<const pixel*>(j.pred) + tileOff;
-        pixel* recon = reinterpret_cast<pixel*>(j.recon) + tileOff;
-        for (int i = lane; i < s * s; i += XA_WAVE)
-        {
-            const int y = i >> log2S, x = i & (s - 1);
-            int v = pred[y * ts + x];
-            if (j.assemble)
-            {
-                const int layer = plane ? sel[256 + (plane - 1) * 64 + (y >> 2) * 8 + (x >> 2)] : sel[(y >> 2) * 16 + (x >> 2)];
-                if (layer != 0xFF) v = xa_clip_pixel(v + (int)resi[rd_layer_offset(plane, layer) + y * ts + x]);
-            }
-            tile[y * ts + x] = (pixel)v;
-            recon[y * ts + x] = (pixel)v;
-        }
-        __syncthreads();
-        const pixel* f = reinterpret_cast<const pixel*>(j.fenc[plane]);
-        const int fs = plane ? j.fenc_cstride : j.fenc_stride;
-        m.sse[plane] = wave_sse_pp(f, fs, tile, ts, s, lane);
-        if (!plane) m.psy = (uint32_t)wave_psy_cost(f, fs, tile, ts, j.log2_size - 2, lane);
-        m.sa8d += (uint32_t)xa_wave_sa8d(f, fs, tile, ts, s, lane);
-        if (!plane)
-        {
-            m.sa8d_luma = m.sa8d;
-            uint32_t sum = 0;                                   /* complexityCheckCU (analysis.cpp:3538-3559): mean, then mean |sample - mean| */
-            for (int i = lane; i < s * s; i += XA_WAVE) sum += f[(i >> log2S) * fs + (i & (s - 1))];
-            const uint32_t mean = (uint32_t)xa_wave_sum((int)sum) / (uint32_t)(s * s);
-            uint32_t dev = 0;
-            for (int i = lane; i < s * s; i += XA_WAVE) { const int v = (int)f[(i >> log2S) * fs + (i & (s - 1))] - (int)mean; dev += (uint32_t)(v < 0 ? -v : v); }
-            m.src_mean = mean; m.src_homo = (uint32_t)xa_wave_sum((int)dev) / (uint32_t)(s * s); m.reserved = 0;
-        }
-        __syncthreads();
-    }
-    if (lane == 0) out[ji] = m;
+    if ((int)blockIdx.x >= n) return;
+    wave_cu_measure_job(jobs, blockIdx.x, out, tile, xa_lane());
 }
 
 /* ---------------- host: the reference's walk ---------------- */
@@ -810,14 +748,14 @@ extern "C" int x265amd_measure_tiles(void* stream_, const uint64_t* h_src, intpt
 {
     if (!h_src || !cus || !d_tiles || !out || n < 0) return xa_fail(X265AMD_EINVAL, "measure_tiles: null argument");
     if (n == 0) return X265AMD_OK;
-    hipStream_t stream = (hipStream_t)stream_;
-    XaMapped mJobs, mMeas;              /* job and result records live in host memory the kernel reads / writes in place */
+    XaMapped mJobs; XaMappedOut mMeas;  /* job and result records live in host memory the kernel reads / writes in place */
     XA_HIP_CHECK(mJobs.alloc(sizeof(CuMeasureJob) * n));
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
     fill_measure_jobs((CuMeasureJob*)mJobs.p, cus, n, h_src, stride, cstride, d_tiles, d_tiles, tile_bytes, nullptr, 0, nullptr);       /* "recon" = the tile itself */
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
-    XA_HIP_CHECK(hipGetLastError());
-    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mJobs.p), (uint64_t)(uintptr_t)((x265amd_cu_measure*)mMeas.p), 0, 0, n }; hipError_t le;
+      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
+      XA_HIP_CHECK(le); }
+    XA_HIP_CHECK(xa_stream_sync(stream_));
     memcpy(out, mMeas.p, sizeof(x265amd_cu_measure) * n);
     return X265AMD_OK;
 }
@@ -827,15 +765,15 @@ extern "C" int x265amd_measure_tile_list(void* stream_, const uint64_t* h_src, i
 {
     if (!h_src || !cus || !tile_addrs || !out || n < 0) return xa_fail(X265AMD_EINVAL, "measure_tile_list: null argument");
     if (n == 0) return X265AMD_OK;
-    hipStream_t stream = (hipStream_t)stream_;
-    XaMapped mJobs, mMeas;
+    XaMapped mJobs; XaMappedOut mMeas;
     XA_HIP_CHECK(mJobs.alloc(sizeof(CuMeasureJob) * n));
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
     CuMeasureJob* jobs = (CuMeasureJob*)mJobs.p;
     for (int i = 0; i < n; i++) fill_measure_jobs(jobs + i, cus + i, 1, h_src, stride, cstride, tile_addrs[i], tile_addrs[i], 0, nullptr, 0, nullptr);
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)jobs, n, (x265amd_cu_measure*)mMeas.p);
-    XA_HIP_CHECK(hipGetLastError());
-    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(jobs), (uint64_t)(uintptr_t)((x265amd_cu_measure*)mMeas.p), 0, 0, n }; hipError_t le;
+      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)jobs, n, (x265amd_cu_measure*)mMeas.p);
+      XA_HIP_CHECK(le); }
+    XA_HIP_CHECK(xa_stream_sync(stream_));
     memcpy(out, mMeas.p, sizeof(x265amd_cu_measure) * n);
     return X265AMD_OK;
 }
@@ -847,14 +785,14 @@ extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, cons
     if (!si || !rp || !units || !h_src || !cus || !cu_units || !d_pred || !d_recon || !out || n < 0) return xa_fail(X265AMD_EINVAL, "skip_rd: null argument");
     if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "skip_rd: tile too small");
     if (n == 0) return X265AMD_OK;
-    hipStream_t stream = (hipStream_t)stream_;
-    XaMapped mJobs, mMeas;
+    XaMapped mJobs; XaMappedOut mMeas;
     XA_HIP_CHECK(mJobs.alloc(sizeof(CuMeasureJob) * n));
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
     fill_measure_jobs((CuMeasureJob*)mJobs.p, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, nullptr, 0, nullptr);
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
-    XA_HIP_CHECK(hipGetLastError());
-    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mJobs.p), (uint64_t)(uintptr_t)((x265amd_cu_measure*)mMeas.p), 0, 0, n }; hipError_t le;
+      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
+      XA_HIP_CHECK(le); }
+    XA_HIP_CHECK(xa_stream_sync(stream_));
     std::vector<x265amd_cu_measure> meas((const x265amd_cu_measure*)mMeas.p, (const x265amd_cu_measure*)mMeas.p + n);
     return x265amd_skip_rd_host(si, rp, units, cus, n, cu_units, meas.data(), out);
 }
@@ -868,12 +806,11 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: tile too small");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
     if (n == 0) return X265AMD_OK;
-    hipStream_t stream = (hipStream_t)stream_;
 
     /* ---- plan + launch 1: all transform chains and the no-residual measurement ---- */
     const size_t perCuBytes = x265amd_inter_rd_scratch_bytes();
     DevBuf dScratch, dSel;
-    XaMapped mJobs, mRes, mMJobs, mMeas, mLevels;       /* records the kernels touch once: host memory, read / written in place */
+    XaMapped mJobs, mMJobs; XaMappedOut mRes, mMeas, mLevels;       /* records the kernels touch once: host memory, read / written in place */
     XA_HIP_CHECK(dScratch.alloc(perCuBytes * n));
     char* scratch = (char*)dScratch.p;
     const int nJobs = x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, nullptr, 0);
@@ -895,11 +832,12 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     CuMeasureJob* mjobs = (CuMeasureJob*)mMJobs.p;
     x265amd_cu_measure* meas = (x265amd_cu_measure*)mMeas.p;
     fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, scratch, perCuBytes, (const char*)dSel.p);
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mjobs, n, meas);
-    XA_HIP_CHECK(hipGetLastError());
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas), 0, 0, n }; hipError_t le;
+      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas);
+      XA_HIP_CHECK(le); }
     /* the levels (the head of each CU's scratch) come to pinned host memory in one strided copy */
-    if (!rdoq) XA_HIP_CHECK(hipMemcpy2DAsync(mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n, hipMemcpyDeviceToHost, stream));
-    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    if (!rdoq) XA_HIP_CHECK(xa_copy2d_to_mapped_async(stream_, mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n));
+    XA_HIP_CHECK(xa_stream_sync(stream_));
 
     /* ---- the walk ---- */
     std::vector<uint8_t> sel((size_t)RD_SEL_BYTES * n);
@@ -912,7 +850,7 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
          * walk's contexts, then the unit's chain, in stream order; results and levels are read back before the walk prices the unit */
         XA_HIP_CHECK(mCtx.alloc(X265AMD_CTX_STRIDE)); XA_HIP_CHECK(mEstJob.alloc(sizeof(x265amd_est_job))); XA_HIP_CHECK(mRdoq.alloc(sizeof(x265amd_tu_rdoq)));
         XA_HIP_CHECK(dEst.alloc(sizeof(x265amd_est_bits)));
-        XA_HIP_CHECK(hipMemsetAsync(dEst.p, 0, sizeof(x265amd_est_bits), stream));
+        XA_HIP_CHECK(xa_fill_async(stream_, dEst.p, 0, sizeof(x265amd_est_bits)));
         demandFn = [&](int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth) -> int {
             const x265amd_tu_job* jobs = (const x265amd_tu_job*)mJobs.p;
             for (int k = first; k < first + count; k++)
@@ -936,7 +874,7 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
                 const size_t nCoeff = (size_t)1 << (2 * jobs[k].log2_tr_size);
                 const size_t off = (size_t)(jobs[k].coeff - (uint64_t)(uintptr_t)scratch);          /* inside CU i's scratch: i * perCuBytes + level offset */
                 char* dst = (char*)mLevels.p + (size_t)RD_SCRATCH_ELEMS * 2 * i + (off - perCuBytes * i);
-                if (hipMemcpyAsync(dst, (const void*)(uintptr_t)jobs[k].coeff, nCoeff * 2, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+                if (xa_copy_async(stream_, dst, (const void*)(uintptr_t)jobs[k].coeff, nCoeff * 2, hipMemcpyDeviceToHost) != hipSuccess || xa_stream_sync(stream_) != hipSuccess)
                     return xa_fail(X265AMD_EHIP, "inter_residual_rd: RDOQ unit");
             }
             return X265AMD_OK;
@@ -948,10 +886,11 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
 
     /* ---- launch 2: assemble, reconstruct, measure ---- */
     for (int i = 0; i < n; i++) mjobs[i].assemble = 1;
-    XA_HIP_CHECK(hipMemcpyAsync(dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_cu_measure, dim3(n), dim3(64), 0, stream, (const CuMeasureJob*)mjobs, n, meas + n);
-    XA_HIP_CHECK(hipGetLastError());
-    XA_HIP_CHECK(hipStreamSynchronize(stream));
+    XA_HIP_CHECK(xa_copy_async(stream_, dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice));
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + n), 0, 0, n }; hipError_t le;
+      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas + n);
+      XA_HIP_CHECK(le); }
+    XA_HIP_CHECK(xa_stream_sync(stream_));
     x265amd_inter_rd_finish(si, rp, cus, n, meas + n, out);
     return X265AMD_OK;
 }

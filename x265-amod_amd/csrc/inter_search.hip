@@ -81,9 +81,9 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     chromaTab[0] = h_planes[3 * srcPic + 1]; chromaTab[1] = h_planes[3 * srcPic + 2];
     Dev dPlanes, dLuma, dChroma;
     if (dPlanes.alloc(num_pics * 24) || dLuma.alloc(num_pics * 8) || dChroma.alloc(chromaTab.size() * 8)) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
-    XA_HIP_CHECK(hipMemcpyAsync(dPlanes.p, h_planes, num_pics * 24, hipMemcpyHostToDevice, st));
-    XA_HIP_CHECK(hipMemcpyAsync(dLuma.p, lumaTab.data(), num_pics * 8, hipMemcpyHostToDevice, st));
-    XA_HIP_CHECK(hipMemcpyAsync(dChroma.p, chromaTab.data(), chromaTab.size() * 8, hipMemcpyHostToDevice, st));
+    XA_HIP_CHECK(xa_copy_async(st, dPlanes.p, h_planes, num_pics * 24, hipMemcpyHostToDevice));
+    XA_HIP_CHECK(xa_copy_async(st, dLuma.p, lumaTab.data(), num_pics * 8, hipMemcpyHostToDevice));
+    XA_HIP_CHECK(xa_copy_async(st, dChroma.p, chromaTab.data(), chromaTab.size() * 8, hipMemcpyHostToDevice));
     const uint64_t* dFencTab = (const uint64_t*)dPlanes.p + 3 * srcPic;
 
     struct CuState { int numPart, lastMode, totalBits; };
@@ -124,11 +124,11 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             jobs[i].dst_y = b; jobs[i].dst_u = b + (size_t)jobs[i].w * jobs[i].h * isz; jobs[i].dst_v = jobs[i].dst_u + (size_t)jobs[i].w * jobs[i].h / 4 * isz;
             jobs[i].dst_stride = jobs[i].w; jobs[i].dst_cstride = jobs[i].w / 2;
         }
-        if (hipMemcpyAsync(dJobs.p, jobs.data(), jobs.size() * sizeof(x265amd_mc_job), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        if (xa_copy_async(st, dJobs.p, jobs.data(), jobs.size() * sizeof(x265amd_mc_job), hipMemcpyHostToDevice) != hipSuccess) return -1;
         if (x265amd_inter_cost(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, (int)jobs.size(),
                                dFencTab, stride, cstride, (uint32_t*)dCost.p) != X265AMD_OK) return -1;
-        if (hipMemcpyAsync(cost.data(), dCost.p, cost.size() * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (xa_copy_async(st, cost.data(), dCost.p, cost.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (xa_stream_sync(st) != hipSuccess) return -1;
         return 0;
     };
 
@@ -284,14 +284,14 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             Dev dJ, dG, dO;
             if (dJ.alloc(ordered.size() * sizeof(x265amd_me_job)) || dG.alloc(groups.size() * sizeof(x265amd_me_group)) || dO.alloc(ordered.size() * sizeof(x265amd_me_result)))
                 return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
-            XA_HIP_CHECK(hipMemcpyAsync(dJ.p, ordered.data(), ordered.size() * sizeof(x265amd_me_job), hipMemcpyHostToDevice, st));
-            XA_HIP_CHECK(hipMemcpyAsync(dG.p, groups.data(), groups.size() * sizeof(x265amd_me_group), hipMemcpyHostToDevice, st));
+            XA_HIP_CHECK(xa_copy_async(st, dJ.p, ordered.data(), ordered.size() * sizeof(x265amd_me_job), hipMemcpyHostToDevice));
+            XA_HIP_CHECK(xa_copy_async(st, dG.p, groups.data(), groups.size() * sizeof(x265amd_me_group), hipMemcpyHostToDevice));
             int rc = x265amd_me_search(me, st, (const x265amd_pixel*)(uintptr_t)h_planes[3 * srcPic], (const uint64_t*)dLuma.p, stride, (const x265amd_me_group*)dG.p, (int)groups.size(),
                                        (const x265amd_me_job*)dJ.p, (x265amd_me_result*)dO.p, maxW, maxH, flags, (const uint64_t*)dChroma.p, cstride);
             if (rc != X265AMD_OK) return rc;
             std::vector<x265amd_me_result> tmp(ordered.size());
-            XA_HIP_CHECK(hipMemcpyAsync(tmp.data(), dO.p, tmp.size() * sizeof(x265amd_me_result), hipMemcpyDeviceToHost, st));
-            XA_HIP_CHECK(hipStreamSynchronize(st));
+            XA_HIP_CHECK(xa_copy_async(st, tmp.data(), dO.p, tmp.size() * sizeof(x265amd_me_result), hipMemcpyDeviceToHost));
+            XA_HIP_CHECK(xa_stream_sync(st));
             for (size_t k = 0; k < tmp.size(); k++) mres[origin[k]] = tmp[k];
         }
 
@@ -459,10 +459,10 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     {
         Dev dJ;
         if (dJ.alloc(finalMc.size() * sizeof(x265amd_mc_job))) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
-        XA_HIP_CHECK(hipMemcpyAsync(dJ.p, finalMc.data(), finalMc.size() * sizeof(x265amd_mc_job), hipMemcpyHostToDevice, st));
+        XA_HIP_CHECK(xa_copy_async(st, dJ.p, finalMc.data(), finalMc.size() * sizeof(x265amd_mc_job), hipMemcpyHostToDevice));
         int rc = x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJ.p, (int)finalMc.size());
         if (rc != X265AMD_OK) return rc;
-        XA_HIP_CHECK(hipStreamSynchronize(st));
+        XA_HIP_CHECK(xa_stream_sync(st));
     }
     return X265AMD_OK;
 }

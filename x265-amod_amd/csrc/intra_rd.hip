@@ -55,7 +55,7 @@ struct IntraRd
     uint64_t lambda2, lambda; uint32_t psyRd;
     uint64_t predTile, reconTile;
     DevBuf dResi, dLayer, dCand;
-    XaMapped dJobs, dRes, dCoeff, dScan, dScanJob;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    XaMapped dJobs, dScanJob; XaMappedOut dRes, dCoeff, dScan;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -159,7 +159,7 @@ struct IntraRd
             rdoq = rq;
         }
         if (x265amd_intra_tu_chain(st, (const x265amd_intra_tu_job*)dJobs.p, rdoq, n, (x265amd_tu_result*)dRes.p) != X265AMD_OK) return err = X265AMD_EHIP;
-        if (hipStreamSynchronize(st) != hipSuccess) return fail("intra rd: synchronize");
+        if (xa_stream_sync(st) != hipSuccess) return fail("intra rd: synchronize");
         memcpy(res, dRes.p, sizeof(x265amd_tu_result) * n);
         for (int k = 0; k < n; k++) memcpy(levelsOut[k], (const int16_t*)dCoeff.p + 1024 * k, sizeof(int16_t) * numCoeff);
         return 0;
@@ -330,7 +330,7 @@ struct IntraRd
         sj.recon_stride = (int32_t)stride; sj.fenc_stride = (int32_t)stride; sj.log2_tr_size = (uint8_t)log2N; sj.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
         int32_t sa8d[35];
         memcpy(dScanJob.p, &sj, sizeof(sj));
-        if (x265amd_intra_scan(st, (const x265amd_intra_job*)dScanJob.p, 1, (int32_t*)dScan.p, nullptr) != X265AMD_OK || hipStreamSynchronize(st) != hipSuccess)
+        if (x265amd_intra_scan(st, (const x265amd_intra_job*)dScanJob.p, 1, (int32_t*)dScan.p, nullptr) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
             return fail("intra rd: mode scan");
         memcpy(sa8d, dScan.p, sizeof(sa8d));
         uint32_t preds[3];
@@ -668,7 +668,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
                              R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
                              R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
                              R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess ||
-                             hipMemsetAsync(R.dEst.p, 0, sizeof(x265amd_est_bits), R.st) != hipSuccess))
+                             xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess))
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
     if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra rd: slice description");
@@ -802,7 +802,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         memcpy(&cu_units[(size_t)yy * u4], &units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], sizeof(x265amd_cu_unit) * u4);
         memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
     }
-    if (rc == X265AMD_OK && hipStreamSynchronize(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: synchronize");
+    if (rc == X265AMD_OK && xa_stream_sync(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: synchronize");
     x265amd_cabac_close(coder);
     delete ip;
     return rc;

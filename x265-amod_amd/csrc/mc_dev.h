@@ -1,0 +1,152 @@
+/* Device code of motion compensation (see mc_kernels.hip): shared with the device job server (device_queue.hip). */
+#ifndef X265AMD_MC_DEV_H
+#define X265AMD_MC_DEV_H
+#include "x265amd_dev.h"
+
+#define MC_WAVES 4
+
+struct McPlane { const pixel* src[2]; long stride; int xf[2], yf[2]; int w, h; pixel* dst; int dstStride; int c; };
+
+template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& j, int mode, int lsel, int lane)
+{
+    /* mode 0: pixel path from list lsel; 1: weighted uni from list lsel; 2: bi average; 3: weighted bi;
+     * 4: pixel average of the two pixel-path predictions (pixelavg_pp of two predInterLumaPixel, search.cpp:2499-2511) */
+    const int c = p.c;
+    const int shiftNum = XA_IF_INTERNAL_PREC - XA_DEPTH;
+    int inv = ((1 << 20) + p.w - 1) / p.w;
+    for (int i = lane; i < p.w * p.h; i += XA_WAVE)
+    {
+        int y = (i * inv) >> 20, x = i - y * p.w;
+        int v;
+        if (mode == 0)
+            v = mc_sample<TAPS, false>(p.src[lsel] + (long)y * p.stride + x, p.stride, p.xf[lsel], p.yf[lsel]);
+        else if (mode == 4)
+        {
+            int a = mc_sample<TAPS, false>(p.src[0] + (long)y * p.stride + x, p.stride, p.xf[0], p.yf[0]);
+            int b = mc_sample<TAPS, false>(p.src[1] + (long)y * p.stride + x, p.stride, p.xf[1], p.yf[1]);
+            v = (a + b + 1) >> 1;       /* pixelavg_pp (pixel.cpp:880-893) */
+        }
+        else if (mode == 1)
+        {
+            /* addWeightUni -> weight_sp_c (predict.cpp:520-577, pixel.cpp:493-517) */
+            int s0 = mc_sample<TAPS, true>(p.src[lsel] + (long)y * p.stride + x, p.stride, p.xf[lsel], p.yf[lsel]);
+            int shift = j.wp[lsel][c].denom + shiftNum, round = shift ? 1 << (shift - 1) : 0;
+            int off = j.wp[lsel][c].o * (1 << (XA_DEPTH - 8));
+            v = xa_clip3(0, XA_PIXEL_MAX, ((j.wp[lsel][c].w * (s0 + XA_IF_INTERNAL_OFFS) + round) >> shift) + off);
+        }
+        else
+        {
+            int s0 = mc_sample<TAPS, true>(p.src[0] + (long)y * p.stride + x, p.stride, p.xf[0], p.yf[0]);
+            int s1 = mc_sample<TAPS, true>(p.src[1] + (long)y * p.stride + x, p.stride, p.xf[1], p.yf[1]);
+            if (mode == 2)      /* addAvg (pixel.cpp:860-879) */
+            {
+                const int shift = shiftNum + 1, offset = (1 << (shift - 1)) + 2 * XA_IF_INTERNAL_OFFS;
+                v = xa_clip3(0, XA_PIXEL_MAX, (s0 + s1 + offset) >> shift);
+            }
+            else                /* addWeightBi / weightBidir (predict.cpp:52-55, :411-518) */
+            {
+                int shift = j.wp[0][c].denom + shiftNum + 1, round = shift ? 1 << (shift - 1) : 0;
+                int offset = (j.wp[0][c].o + j.wp[1][c].o) * (1 << (XA_DEPTH - 8));
+                v = xa_clip3(0, XA_PIXEL_MAX, (j.wp[0][c].w * (s0 + XA_IF_INTERNAL_OFFS) + j.wp[1][c].w * (s1 + XA_IF_INTERNAL_OFFS) + round + (offset * (1 << (shift - 1)))) >> shift);
+            }
+        }
+        p.dst[(long)y * p.dstStride + x] = (pixel)v;
+    }
+}
+
+/* COST: after the prediction has been written, its distortion against the source picture (x265amd_inter_cost) */
+struct XaArgsMc
+{
+    const uint64_t* planes; long stride, cstride; int picW, picH; const x265amd_mc_job* jobs; int n;
+    const uint64_t* fencPlanes; long fstride, fcstride; uint32_t* cost;
+};
+
+/* one job of a list on one wavefront */
+template<bool COST>
+XA_DEV void wave_mc_job(const XaArgsMc& a, int ji, int lane)
+{
+    const uint64_t* planes = a.planes; const long stride = a.stride, cstride = a.cstride; const int picW = a.picW, picH = a.picH;
+    const uint64_t* fencPlanes = a.fencPlanes; const long fstride = a.fstride, fcstride = a.fcstride; uint32_t* cost = a.cost;
+    const x265amd_mc_job j = a.jobs[ji];
+    const int refs[2] = { j.ref0, j.ref1 };
+    int mv[2][2] = { { j.mv0[0], j.mv0[1] }, { j.mv1[0], j.mv1[1] } };
+    /* CUData::clipMv */
+    {
+        const int maxCU = 64, offset = 8;
+        int xmax = (picW + offset - j.cu_x - 1) << 2, xmin = -((maxCU + offset + j.cu_x - 1) << 2);
+        int ymax = (picH + offset - j.cu_y - 1) << 2, ymin = -((maxCU + offset + j.cu_y - 1) << 2);
+        for (int l = 0; l < 2; l++)
+        {
+            mv[l][0] = min(xmax, max(xmin, mv[l][0]));
+            mv[l][1] = min(ymax, max(ymin, mv[l][1]));
+        }
+    }
+    /* which combination rule applies: predict.cpp:82-243 */
+    int mode, lsel = 0;
+    if (j.slice_type)
+        mode = ((j.flags & 4) && j.wp[0][0].present) ? 1 : 0;
+    else
+    {
+        bool wb = (j.flags & 8) != 0;
+        if (refs[0] >= 0 && refs[1] >= 0)
+            mode = (wb && (j.wp[0][0].present || j.wp[1][0].present)) ? 3 : 2;
+        else
+        {
+            lsel = refs[0] >= 0 ? 0 : 1;
+            mode = (wb && j.wp[lsel][0].present) ? 1 : 0;
+        }
+    }
+    if (j.flags & 16) mode = 4;
+    const bool doChroma = (j.flags & 2) && mode != 4;
+    McPlane p;
+    if (j.flags & 1)
+    {
+        for (int l = 0; l < 2; l++)
+        {
+            p.src[l] = refs[l] >= 0 ? reinterpret_cast<const pixel*>(planes[3 * refs[l]]) + (long)(j.y + (mv[l][1] >> 2)) * stride + j.x + (mv[l][0] >> 2) : nullptr;
+            p.xf[l] = mv[l][0] & 3; p.yf[l] = mv[l][1] & 3;
+        }
+        p.stride = stride; p.w = j.w; p.h = j.h; p.dst = reinterpret_cast<pixel*>(j.dst_y); p.dstStride = j.dst_stride; p.c = 0;
+        mc_plane<8>(p, j, mode, lsel, lane);
+    }
+    if (doChroma)
+        for (int c = 1; c < 3; c++)
+        {
+            for (int l = 0; l < 2; l++)
+            {
+                p.src[l] = refs[l] >= 0 ? reinterpret_cast<const pixel*>(planes[3 * refs[l] + c]) + (long)((j.y >> 1) + (mv[l][1] >> 3)) * cstride + (j.x >> 1) + (mv[l][0] >> 3) : nullptr;
+                p.xf[l] = mv[l][0] & 7; p.yf[l] = mv[l][1] & 7;
+            }
+            p.stride = cstride; p.w = j.w >> 1; p.h = j.h >> 1; p.dst = reinterpret_cast<pixel*>(c == 1 ? j.dst_u : j.dst_v); p.dstStride = j.dst_cstride; p.c = c;
+            mc_plane<4>(p, j, mode, lsel, lane);
+        }
+    if constexpr (COST)
+    {
+        /* the wave reads back what it has just written */
+        __threadfence_block();
+        xa_wave_sync();
+        const int metric = j.metric;
+        uint32_t lumaCost = 0, chromaCost = 0;
+        int cu = 0;
+        while ((4 << cu) < j.w) cu++;
+        if (j.flags & 1)
+        {
+            const pixel* f = reinterpret_cast<const pixel*>(fencPlanes[0]) + (long)j.y * fstride + j.x;
+            const pixel* d = reinterpret_cast<const pixel*>(j.dst_y);
+            lumaCost = metric == 1 ? (uint32_t)xa_wave_sad(f, (int)fstride, d, j.dst_stride, j.w, j.h, lane)
+                     : metric == 2 ? (uint32_t)xa_wave_satd(f, (int)fstride, d, j.dst_stride, j.w, j.h, lane)
+                     : metric == 3 ? (uint32_t)xa_wave_sa8d(f, (int)fstride, d, j.dst_stride, 4 << cu, lane) : 0;
+        }
+        if (doChroma && j.chroma_cost && metric >= 2)
+            for (int c = 1; c < 3; c++)
+            {
+                const pixel* f = reinterpret_cast<const pixel*>(fencPlanes[c]) + (long)(j.y >> 1) * fcstride + (j.x >> 1);
+                const pixel* d = reinterpret_cast<const pixel*>(c == 1 ? j.dst_u : j.dst_v);
+                chromaCost += metric == 2 ? (uint32_t)xa_wave_satd(f, (int)fcstride, d, j.dst_cstride, j.w >> 1, j.h >> 1, lane)
+                                          : (uint32_t)xa_wave_sa8d(f, (int)fcstride, d, j.dst_cstride, 2 << cu, lane);
+            }
+        if (lane == 0) { cost[2 * ji] = lumaCost; cost[2 * ji + 1] = chromaCost; }
+    }
+}
+
+#endif

@@ -8,6 +8,7 @@
  */
 #include <utility>
 #include "x265amd_host.h"
+#include "xa_queue.h"
 #include "../host/primitive_table.h"
 
 using namespace x265amd;
@@ -180,10 +181,28 @@ struct ScratchPool
 };
 ScratchPool& scratch_pool() { static ScratchPool* p = new ScratchPool; return *p; }
 }
+namespace { thread_local std::map<size_t, std::vector<void*>>* t_local = nullptr; }
+void xa_scratch_local_begin() { if (!t_local) t_local = new std::map<size_t, std::vector<void*>>; }
+void xa_scratch_local_end()
+{
+    if (!t_local) return;
+    ScratchPool& P = scratch_pool();
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        for (auto& kv : *t_local) { std::vector<void*>& v = P.free_[kv.first]; v.insert(v.end(), kv.second.begin(), kv.second.end()); }
+    }
+    delete t_local;
+    t_local = nullptr;
+}
 hipError_t xa_scratch_alloc(void** p, size_t bytes)
 {
     ScratchPool& P = scratch_pool();
     const size_t c = ScratchPool::cls(bytes ? bytes : 1);
+    if (t_local)
+    {
+        std::vector<void*>& v = (*t_local)[c];
+        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
+    }
     {
         std::lock_guard<std::mutex> g(P.m);
         std::vector<void*>& v = P.free_[c];
@@ -197,15 +216,23 @@ void xa_scratch_free(void* p)
 {
     if (!p) return;
     ScratchPool& P = scratch_pool();
-    std::lock_guard<std::mutex> g(P.m);
-    auto it = P.size_.find(p);
-    if (it == P.size_.end()) { (void)hipFree(p); return; }
-    P.free_[it->second].push_back(p);
+    size_t c = 0;
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        auto it = P.size_.find(p);
+        if (it != P.size_.end())
+        {
+            c = it->second;
+            if (!t_local) { P.free_[c].push_back(p); return; }
+        }
+    }
+    if (!c) { (void)hipFree(p); return; }
+    (*t_local)[c].push_back(p);
 }
-namespace { ScratchPool& mapped_pool() { static ScratchPool* p = new ScratchPool; return *p; } }
-hipError_t xa_mapped_alloc(void** p, size_t bytes)
+namespace { ScratchPool& mapped_pool(bool deviceWrites) { static ScratchPool* p[2] = { new ScratchPool, new ScratchPool }; return *p[deviceWrites ? 1 : 0]; } }
+hipError_t xa_mapped_alloc(void** p, size_t bytes, bool deviceWrites)
 {
-    ScratchPool& P = mapped_pool();
+    ScratchPool& P = mapped_pool(deviceWrites);
     const size_t c = ScratchPool::cls(bytes ? bytes : 1);
     {
         std::lock_guard<std::mutex> g(P.m);
@@ -219,11 +246,16 @@ hipError_t xa_mapped_alloc(void** p, size_t bytes)
 void xa_mapped_free(void* p)
 {
     if (!p) return;
-    ScratchPool& P = mapped_pool();
-    std::lock_guard<std::mutex> g(P.m);
-    auto it = P.size_.find(p);
-    if (it == P.size_.end()) { (void)hipHostFree(p); return; }
-    P.free_[it->second].push_back(p);
+    for (int d = 0; d < 2; d++)
+    {
+        ScratchPool& P = mapped_pool(d != 0);
+        std::lock_guard<std::mutex> g(P.m);
+        auto it = P.size_.find(p);
+        if (it == P.size_.end()) continue;
+        P.free_[it->second].push_back(p);
+        return;
+    }
+    (void)hipHostFree(p);
 }
 extern "C" void x265amd_release_scratch(void)
 {
@@ -233,8 +265,9 @@ extern "C" void x265amd_release_scratch(void)
         std::lock_guard<std::mutex> g(P.m);
         for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipFree(q); P.size_.erase(q); } kv.second.clear(); }
     }
+    for (int d = 0; d < 2; d++)
     {
-        ScratchPool& P = mapped_pool();
+        ScratchPool& P = mapped_pool(d != 0);
         std::lock_guard<std::mutex> g(P.m);
         for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipHostFree(q); P.size_.erase(q); } kv.second.clear(); }
     }
@@ -255,8 +288,10 @@ __global__ __launch_bounds__(256) void k_copy_rects(XaRects r)
         dst[(size_t)y * r.dst_stride[k] + x] = src[(size_t)y * r.src_stride[k] + x];
     }
 }
-void xa_copy_rects(hipStream_t st, const XaRects& r)
+void xa_copy_rects(void* st, const XaRects& r)
 {
     if (r.n <= 0) return;
-    hipLaunchKernelGGL(k_copy_rects, dim3(r.n), dim3(256), 0, st, r);
+    static_assert(sizeof(XaRects) == sizeof(XaArgsRects), "XaRects is the argument record of XA_OP_COPY_RECTS");
+    hipError_t e_;
+    XA_LAUNCH(e_, st, XA_OP_COPY_RECTS, 1, r, k_copy_rects, dim3(r.n), dim3(256), 0, r);
 }

@@ -8,775 +8,10 @@
  */
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
+#include "tu_dev.h"
+#include "xa_queue.h"
 #include <math.h>
 #include <string.h>
-
-#define TU_WAVES 4
-
-/* coefficient scans g_scanOrder (constants.cpp:364-461) generated by rule: 4x4 groups in `type` order (diagonal for
- * 16x16 / 32x32), samples inside a group in `type` order; 0 diagonal, 1 horizontal, 2 vertical */
-struct TuScans { uint16_t s4[3][16], s8[3][64], s16[256], s32[1024]; };
-constexpr void tu_scan_square(int type, int n, int* xs, int* ys)
-{
-    int i = 0;
-    if (type == 1) { for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) { xs[i] = x; ys[i++] = y; } }
-    else if (type == 2) { for (int x = 0; x < n; x++) for (int y = 0; y < n; y++) { xs[i] = x; ys[i++] = y; } }
-    else
-        for (int d = 0; d < 2 * n - 1; d++)
-            for (int y = d < n ? d : n - 1; y >= 0 && d - y < n; y--) { xs[i] = d - y; ys[i++] = y; }
-}
-constexpr void tu_fill_scan(uint16_t* dst, int type, int log2N)
-{
-    int N = 1 << log2N, ncg = N >> 2;
-    int t = log2N >= 4 ? 0 : type;
-    int cx[64] = {}, cy[64] = {}, ix[16] = {}, iy[16] = {};
-    tu_scan_square(t, ncg, cx, cy);
-    tu_scan_square(t, 4, ix, iy);
-    int k = 0;
-    for (int c = 0; c < ncg * ncg; c++)
-        for (int i = 0; i < 16; i++)
-            dst[k++] = (uint16_t)((cy[c] * 4 + iy[i]) * N + cx[c] * 4 + ix[i]);
-}
-constexpr TuScans tu_make_scans()
-{
-    TuScans s = {};
-    for (int t = 0; t < 3; t++) { tu_fill_scan(s.s4[t], t, 2); tu_fill_scan(s.s8[t], t, 3); }
-    tu_fill_scan(s.s16, 0, 4);
-    tu_fill_scan(s.s32, 0, 5);
-    return s;
-}
-__device__ const TuScans tu_scans = tu_make_scans();
-
-XA_DEV const uint16_t* tu_scan(int type, int log2N)
-{
-    return log2N == 2 ? tu_scans.s4[type] : log2N == 3 ? tu_scans.s8[type] : log2N == 4 ? tu_scans.s16 : tu_scans.s32;
-}
-
-/* CUData::getTUEntropyCodingParameters, scan type only (cudata.cpp:2059-2092), 4:2:0 */
-XA_DEV int tu_scan_type(int bIntra, int isLuma, int log2N, int dirMode)
-{
-    if (!bIntra) return 0;
-    if (log2N <= 2 || (isLuma && log2N == 3))
-        return dirMode >= 22 && dirMode <= 30 ? 1 : (dirMode >= 6 && dirMode <= 14 ? 2 : 0);
-    return 0;
-}
-
-__device__ const int tu_quantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };     /* scalinglist.cpp:129-130 */
-__device__ const int tu_invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };
-
-struct TuLds
-{
-    int16_t a[32 * 32];     /* residual in / dequantised coefficients / reconstructed residual */
-    int16_t b[32 * 32];     /* pass scratch */
-    int16_t dct[32 * 32];   /* transform coefficients before quantisation (sign source for sign-bit hiding) */
-    int16_t q[32 * 32];     /* levels */
-    int32_t deltaU[32 * 32];
-    pixel rec[32 * 32];
-};
-
-/* forward half: s.a holds the N x N residual (row-major, stride N).  Leaves the levels in s.q, returns numSig. */
-XA_DEV uint32_t wave_tu_forward(TuLds& s, int log2N, int ttype, int bIntra, int dirMode, int sliceType, int qpScaled, int signHide, int lane)
-{
-    const int N = 1 << log2N, numCoeff = N * N, isLuma = ttype == 0;
-    const bool dst = log2N == 2 && isLuma && bIntra;
-    const int16_t* T = dst ? xa_tbl.dst4 : xa_tbl.dct[log2N - 2];
-    wave_fwd_pass(T, log2N, s.a, s.b, log2N - 1 + XA_DEPTH - 8, lane);
-    xa_wave_sync();
-    wave_fwd_pass(T, log2N, s.b, s.dct, log2N + 6, lane);
-    xa_wave_sync();
-    /* quant_c (dct.cpp:664-686) with the flat list quantCoeff = s_quantScales[rem] */
-    const int rem = qpScaled % 6, per = qpScaled / 6;
-    const int transformShift = 15 - XA_DEPTH - log2N;
-    const int qbits = 14 + per + transformShift, qbits8 = qbits - 8;
-    const int add = (sliceType == 2 ? 171 : 85) << (qbits - 9);
-    const int qc = tu_quantScales[rem];
-    int cnt = 0;
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-    {
-        int level = s.dct[i];
-        int sign = level < 0 ? -1 : 1;
-        int tmplevel = abs(level) * qc;
-        level = (tmplevel + add) >> qbits;
-        s.deltaU[i] = (tmplevel - (level << qbits)) >> qbits8;
-        cnt += level != 0;
-        s.q[i] = (int16_t)xa_clip3(-32768, 32767, level * sign);
-    }
-    uint32_t numSig = (uint32_t)xa_wave_sum(cnt);
-    xa_wave_sync();
-    if (numSig < 2 || !signHide) return numSig;
-
-    /* signBitHidingHDQ (quant.cpp:247-395): one lane per 4x4 coefficient group */
-    const uint16_t* scan = tu_scan(tu_scan_type(bIntra, isLuma, log2N, dirMode), log2N);
-    int last = -1;
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-        if (s.q[scan[i]]) last = i;         /* i grows with the loop: the lane keeps its largest hit */
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    const int cgLast = last >> 4, cg = lane;
-    int delta = 0;
-    if (cg <= cgLast)
-    {
-        const int start = cg << 4;
-        int firstNZ = -1, lastNZ = -1;
-        uint32_t absSum = 0;
-        for (int nn = 0; nn < 16; nn++)
-        {
-            int v = s.q[scan[start + nn]];
-            if (v) { if (firstNZ < 0) firstNZ = nn; lastNZ = nn; }
-        }
-        if (firstNZ >= 0 && lastNZ - firstNZ >= 4)      /* SBH_THRESHOLD */
-        {
-            for (int nn = firstNZ; nn <= lastNZ; nn++) absSum += (uint32_t)(int)s.q[scan[start + nn]];
-            uint32_t signbit = s.q[scan[start + firstNZ]] > 0 ? 0 : 1;
-            if (signbit != (absSum & 1))
-            {
-                int minCostInc = 0x7fffffff, minPos = -1, finalChange = 0, curCost = 0x7fffffff, curChange = 0;
-                for (int nn = (cg == cgLast ? lastNZ : 15); nn >= 0; --nn)
-                {
-                    int blkPos = scan[start + nn];
-                    int c = s.q[blkPos], dU = s.deltaU[blkPos];
-                    if (c)
-                    {
-                        if (dU > 0) { curCost = -dU; curChange = 1; }
-                        else if (nn == firstNZ && abs(c) == 1) curCost = 0x7fffffff;
-                        else { curCost = dU; curChange = -1; }
-                    }
-                    else if (nn < firstNZ)
-                    {
-                        uint32_t thisSignBit = s.dct[blkPos] >= 0 ? 0 : 1;
-                        if (thisSignBit != signbit) curCost = 0x7fffffff;
-                        else { curCost = -dU; curChange = 1; }
-                    }
-                    else { curCost = -dU; curChange = 1; }
-                    if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = blkPos; }
-                }
-                int c = s.q[minPos];
-                if (c == 32767 || c == -32768) finalChange = -1;
-                if (!c) delta = 1;
-                else if (finalChange == -1 && abs(c) == 1) delta = -1;
-                int16_t sigMask = (int16_t)(s.dct[minPos] >> 15);
-                s.q[minPos] = (int16_t)(c + (((int16_t)finalChange ^ sigMask) - sigMask));
-            }
-        }
-    }
-    numSig = (uint32_t)((int)numSig + xa_wave_sum(delta));
-    xa_wave_sync();
-    return numSig;
-}
-
-/* =========================================================================================================
- * RDOQ: Quant::rdoQuant (quant.cpp:609-1424), flat scaling lists.  One wavefront per TU.  The decision of a level
- * depends on the CABAC state left by the levels coded before it (c1, c2, Rice parameter, context set), so the
- * non-zero levels of a 4x4 group are decided one after the other in reverse scan order; everything that does not
- * depend on that state -- uncoded distortion, significance contexts and costs of the zero levels, group statistics,
- * the choice of the last position inside a group, sign restoration, and the sign-hiding pass (one lane per group) --
- * runs across lanes.  All sums are exact 64-bit integers, so the order of additions is free.
- * ======================================================================================================= */
-struct RdoqLds
-{
-    int64_t costSig[32 * 32];       /* by scan position: lambda * bits of the significance flag */
-    int64_t delta[32 * 32];         /* by scan position: what un-coding the position adds to the total (costUncoded - costCoeff) */
-    int32_t rateDown[32 * 32];      /* by block position (sign hiding) */
-    int32_t sigDelta[32 * 32];
-    int64_t costCg[64];
-    int64_t tmp[16];
-    int32_t est[184];               /* EstBitsSbac of the job (entropy.h:88-97) */
-};
-#define EST_SIGCG(ctx, bin) r.est[(ctx) * 2 + (bin)]
-#define EST_SIG(bin, ctx) r.est[4 + (bin) * 42 + (ctx)]
-#define EST_LAST(i, c) r.est[88 + (i) * 10 + (c)]
-#define EST_G1(ctx, bin) r.est[108 + (ctx) * 2 + (bin)]
-#define EST_ABS(ctx, bin) r.est[156 + (ctx) * 2 + (bin)]
-#define EST_CBF(ctx, bin) r.est[168 + (ctx) * 2 + (bin)]
-#define EST_ROOTCBF(bin) r.est[182 + (bin)]
-#define RDOQ_IEP 32768
-
-/* significance context increment of raster sample rr of a 4x4 group (quant.cpp:739-780) */
-XA_DEV uint32_t rdoq_sig_ctx_inc(int log2N, uint32_t pattern, uint32_t rr)
-{
-    if (log2N == 2) return (uint32_t)((0x8877886654325410ULL >> (4 * rr)) & 15);
-    const uint64_t t = pattern == 0 ? 0x0000000100110112ULL : pattern == 1 ? 0x0000000011112222ULL : pattern == 2 ? 0x0012001200120012ULL : 0x2222222222222222ULL;
-    return (uint32_t)((t >> (4 * rr)) & 15);
-}
-/* getICRateCost (quant.cpp:131-165) */
-XA_DEV uint32_t rdoq_level_rate(uint32_t absLevel, int32_t diff, int g1_0, int g1_1, int ab0, uint32_t rice, uint32_t c1c2Rate)
-{
-    if (diff < 0) return absLevel == 2 ? (uint32_t)(g1_1 + ab0) : (uint32_t)g1_0;
-    uint32_t symbol = (uint32_t)diff, rate;
-    if ((symbol >> rice) < 3) rate = ((symbol >> rice) + 1 + rice) << 15;
-    else
-    {
-        uint32_t length = 0;
-        symbol = (symbol >> rice) - 3;
-        if (symbol) length = 31 - (uint32_t)__clz((int)(symbol + 1));
-        rate = (3 + length + rice + 1 + length) << 15;
-    }
-    return rate + c1c2Rate;
-}
-/* getICRate (quant.cpp:54-104) */
-XA_DEV int rdoq_rate_sbh(uint32_t absLevel, int32_t diff, int g1_0, int g1_1, int ab0, uint32_t rice, uint32_t maxVlc, uint32_t c1c2Rate)
-{
-    if (!absLevel) return 0;
-    if (diff < 0) return absLevel == 2 ? g1_1 + ab0 : g1_0;
-    int rate = 0;
-    uint32_t symbol = (uint32_t)diff;
-    if (symbol > maxVlc)
-    {
-        int size = 31 - __clz((int)(symbol - maxVlc));
-        rate += (size * 2 + 1) << 15;
-        symbol = maxVlc + 1;
-    }
-    rate += min((int)((symbol >> rice) + 1 + rice), 8) << 15;
-    return rate + (int)c1c2Rate;
-}
-XA_DEV int rdoq_rate_less_vlc(uint32_t absLevel, int32_t diff, uint32_t rice)      /* getICRateLessVlc (quant.cpp:122-139) */
-{
-    if (!absLevel) return 0;
-    return min((int)(((uint32_t)diff >> rice) + 1 + rice), 8) << 15;
-}
-XA_DEV uint32_t rdoq_sig_cg_ctx(uint64_t cgFlags, uint32_t cgX, uint32_t cgY, uint32_t cgBlk, uint32_t cgStride, bool pattern)
-{
-    const uint32_t sigPos = cgBlk + 1 < 64 ? (uint32_t)(cgFlags >> (cgBlk + 1)) : 0;
-    const uint32_t right = (cgX != cgStride - 1) & sigPos, lower = (cgY != cgStride - 1) & (sigPos >> (cgStride - 1));
-    return pattern ? (cgStride == 1 ? 0 : right + lower * 2) : (right | lower);
-}
-/* prefix group index and suffix length of a last-position coordinate (g_lastCoeffTable, constants.cpp:473-479, by rule) */
-XA_DEV uint32_t rdoq_last_bits(const RdoqLds& r, int i, uint32_t pos)
-{
-    if (pos < 4) return (uint32_t)EST_LAST(i, pos);
-    const uint32_t l = 31 - (uint32_t)__clz((int)pos);
-    return (uint32_t)EST_LAST(i, 2 * l + ((pos >> (l - 1)) & 1)) + RDOQ_IEP * (l - 1);
-}
-
-struct RdoqParams { const int* est; int64_t lambda2; int32_t lambda, psyRdoqScale; int rdoqLevel, tuDepth; };
-
-/* s.dct: transform coefficients of the residual; (int16_t*)s.deltaU: those of the source block when usePsy.
- * Leaves the signed levels in s.q, returns numSig.  s.a/s.b are used as scratch (rateUp). */
-XA_DEV uint32_t wave_rdo_quant(TuLds& s, RdoqLds& r, const RdoqParams& P, int log2N, int ttype, int bIntra, int dirMode, int qpScaled, int signHide,
-                               bool usePsy, int lane)
-{
-    const int N = 1 << log2N, numCoeff = N * N, isLuma = ttype == 0;
-    const int rem = qpScaled % 6, per = qpScaled / 6;
-    const int transformShift = 15 - XA_DEPTH - log2N;
-    const int qbits = 14 + per + transformShift, add = 1 << (qbits - 1);
-    const int qc = tu_quantScales[rem];
-    const int16_t* dct = s.dct;
-    const int16_t* fdct = reinterpret_cast<const int16_t*>(s.deltaU);
-    int32_t* rateUp = reinterpret_cast<int32_t*>(s.a);
-
-    /* nquant_c (dct.cpp:688-713): absolute levels */
-    int cnt = 0;
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-    {
-        int level = dct[i];
-        int sign = level < 0 ? -1 : 1;
-        level = (abs(level) * qc + add) >> qbits;
-        cnt += level != 0;
-        s.q[i] = (int16_t)abs(xa_clip3(-32768, 32767, level * sign));
-    }
-    for (int i = lane; i < 184; i += XA_WAVE) r.est[i] = P.est[i];
-    uint32_t numSig = (uint32_t)xa_wave_sum(cnt);
-    xa_wave_sync();
-    if (!numSig) return 0;
-
-    const int64_t lambda2 = P.lambda2;
-    const int64_t psyScale = (int64_t)P.psyRdoqScale * P.lambda;
-    const int uqScale = tu_invQuantScales[rem] << per;
-    const int uqShift = 20 - 14 - transformShift;
-    const int uqRound = uqShift > per ? 1 << (uqShift - per - 1) : 0;
-    const int scaleBits = 15 - 2 * transformShift;
-    const int psyShift = max(0, 2 * transformShift + 1);
-#define SIGCOST(bits) ((lambda2 * (int64_t)(bits)) >> 8)
-#define PSYVAL(rec) ((psyScale * (int64_t)(rec)) >> psyShift)
-
-    const int scanType = tu_scan_type(bIntra, isLuma, log2N, dirMode);
-    const uint16_t* scan = tu_scan(scanType, log2N);
-    /* raster offsets of the 16 samples of a 4x4 group in scan order (g_scan4x4), 4 bits each */
-    const uint64_t inCgPacked = scanType == 1 ? 0xFEDCBA9876543210ULL : scanType == 2 ? 0xFB73EA62D951C840ULL : 0xFBE7AD369C258140ULL;
-    const int firstSig = log2N == 2 ? 0 : log2N == 3 ? ((scanType != 0 && isLuma) ? 15 : 9) : (isLuma ? 21 : 12);
-    const uint32_t log2CG = (uint32_t)log2N - 2, cgNum = 1u << (2 * log2CG), cgStride = (uint32_t)N >> 2;
-
-    int last = -1;
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-        if (s.q[scan[i]]) last = i;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    const int lastScanPos = last, cgLast = lastScanPos >> 4;
-
-    int64_t totalUncoded = 0, totalRd = 0;
-    uint64_t cgFlags = 0;
-
-    /* groups behind the last level: uncoded distortion only (psy form counts each sample twice, dct.cpp:1029-1066) */
-    {
-        int64_t acc = 0;
-        for (int i = (cgLast + 1) * 16 + lane; i < numCoeff; i += XA_WAVE)
-        {
-            const int b = scan[i];
-            const int64_t c = dct[b];
-            int64_t cu = (c * c) << scaleBits;
-            acc += cu;
-            if (usePsy) { cu -= (psyScale * ((int64_t)fdct[b] - c)) >> psyShift; acc += cu; }
-        }
-        acc = xa_wave_sum(acc);
-        totalUncoded += acc; totalRd += acc;
-    }
-
-    const int k = lane & 15;
-    const bool act = lane < 16;
-    uint32_t c1 = 1;
-    for (int cg = cgLast; cg >= 0; cg--)
-    {
-        uint32_t ctxSet = (cg && isLuma) ? 2 : 0;
-        const uint32_t cgBlk = ((uint32_t)(scan[cg * 16] >> log2N) >> 2) * cgStride + (((uint32_t)scan[cg * 16] & (uint32_t)(N - 1)) >> 2);
-        const uint32_t cgY = cgBlk >> log2CG, cgX = cgBlk & ((1u << log2CG) - 1);
-        const uint64_t cgMask = (uint64_t)1 << cgBlk;
-        const uint32_t pattern = rdoq_sig_cg_ctx(cgFlags, cgX, cgY, cgBlk, cgStride, true);
-        const int sigOff = firstSig + ((cg && isLuma) ? 3 : 0);
-        if (c1 == 0) ctxSet++;
-        c1 = 1;
-
-        const int scanPos = cg * 16 + k;
-        const int b = scan[scanPos];
-        const uint32_t maxAbs = (uint32_t)s.q[b];
-        const int signCoef = dct[b];
-        const int predicted = (usePsy ? (int)fdct[b] : 0) - signCoef;
-        const bool beyond = scanPos > lastScanPos;
-        const uint32_t nzMask = (uint32_t)__ballot(act && !beyond && maxAbs != 0) & 0xFFFF;
-
-        if (cg && !nzMask)
-        {
-            /* an empty group in front of the last level (quant.cpp:786-848): only the totals are used afterwards */
-            int64_t cu = ((int64_t)signCoef * signCoef) << scaleBits, acc = cu;
-            if (usePsy) { cu -= (psyScale * (int64_t)predicted) >> psyShift; acc += cu; }
-            acc = xa_wave_sum(act ? acc : (int64_t)0);
-            totalUncoded += acc; totalRd += acc;
-            const uint32_t ctx = rdoq_sig_cg_ctx(cgFlags, cgX, cgY, cgBlk, cgStride, false);
-            const int64_t cs = SIGCOST(EST_SIGCG(ctx, 0));
-            if (lane == 0) r.costCg[cg] = cs;
-            totalRd += cs;
-            continue;
-        }
-
-        const bool psyHere = usePsy && scanPos;
-        int64_t costUncoded = ((int64_t)signCoef * signCoef) << scaleBits;
-        if (psyHere) costUncoded -= PSYVAL(predicted);
-        const uint32_t ctxSig = b == 0 ? 0 : rdoq_sig_ctx_inc(log2N, pattern, (uint32_t)((inCgPacked >> (4 * k)) & 15)) + (uint32_t)sigOff;
-        const int sig0 = EST_SIG(0, ctxSig), sig1 = EST_SIG(1, ctxSig);
-
-        int64_t costCoeff = 0, costSigV = 0;
-        uint32_t level = 0;
-        const bool isNz = act && !beyond && maxAbs != 0;
-        const bool isZero = act && !beyond && maxAbs == 0;
-        if (isZero)
-        {
-            costSigV = SIGCOST(sig0);
-            costCoeff = costUncoded + costSigV;
-            r.sigDelta[b] = sig1 - sig0;
-        }
-        uint32_t myC1 = c1;
-        uint32_t c2 = 0, rice = 0, levelThreshold = 3, c1Idx = 0, c2Idx = 0;
-        uint32_t m = nzMask;
-        while (m)
-        {
-            const int p = 31 - __clz((int)m);
-            m &= ~(1u << p);
-            const uint32_t hasC1 = c1Idx < 8, noC2 = c2Idx == 0;
-            const uint32_t baseLevel = hasC1 ? 2 + noC2 : 1;
-            if (lane == p)
-            {
-                const int g1_0 = EST_G1(4 * ctxSet + c1, 0), g1_1 = EST_G1(4 * ctxSet + c1, 1);
-                const int ab0 = EST_ABS(ctxSet + c2, 0), ab1 = EST_ABS(ctxSet + c2, 1);
-                const uint32_t c1c2Rate = (hasC1 ? (uint32_t)g1_1 : 0) + ((hasC1 && noC2) ? (uint32_t)ab1 : 0);
-                uint32_t sigBits = 0;
-                costCoeff = INT64_MAX;
-                if (scanPos == lastScanPos) r.sigDelta[b] = 0;
-                else
-                {
-                    if (maxAbs < 3)
-                    {
-                        costSigV = SIGCOST(sig0);
-                        costCoeff = costUncoded + costSigV;
-                    }
-                    r.sigDelta[b] = sig1 - sig0;
-                    sigBits = (uint32_t)sig1;
-                }
-                const uint32_t uq = maxAbs * (uint32_t)uqScale + (uint32_t)uqRound;
-                const int absCoef = abs(signCoef);
-                const int sgnPred = signCoef < 0 ? -predicted : predicted;
-                for (uint32_t t = 0; t < 2 && t < maxAbs; t++)      /* candidate levels maxAbs and, above 1, maxAbs - 1 */
-                {
-                    const uint32_t lv = maxAbs - t;
-                    uint32_t bits;
-                    if (maxAbs == 1) bits = (hasC1 ? (uint32_t)g1_0 : ((1 + rice) << 15)) + RDOQ_IEP;
-                    else bits = rdoq_level_rate(lv, (int32_t)lv - (int32_t)baseLevel, g1_0, g1_1, ab0, rice, c1c2Rate) + RDOQ_IEP;
-                    const int uqAbs = (int)((uq - t * (uint32_t)uqScale) >> uqShift);
-                    const int d = absCoef - uqAbs;
-                    int64_t cost = (((int64_t)d * d) << scaleBits) + SIGCOST(sigBits + bits);
-                    if (psyHere) cost -= PSYVAL(abs(uqAbs + sgnPred));
-                    if (cost < costCoeff) { level = lv; costCoeff = cost; costSigV = SIGCOST(sigBits); }
-                }
-                if (signHide && level)
-                {
-                    const int32_t diff0 = (int32_t)level - 1 - (int32_t)baseLevel, diff2 = (int32_t)level + 1 - (int32_t)baseLevel;
-                    const int32_t maxVlc = rice == 0 ? 7 : rice == 1 ? 14 : rice == 2 ? 26 : rice == 3 ? 46 : 78;     /* g_goRiceRange */
-                    int r0, r1, r2;
-                    if (diff0 < -2) { r0 = 0; r2 = g1_1 + ab0; r1 = g1_0; }
-                    else if (diff0 >= 0 && diff2 <= maxVlc)
-                    {
-                        r1 = rdoq_rate_less_vlc(level, diff0 + 1, rice);
-                        r2 = rdoq_rate_less_vlc(level + 1, diff0 + 2, rice);
-                        r0 = rdoq_rate_less_vlc(level - 1, diff0, rice);
-                    }
-                    else
-                    {
-                        r1 = rdoq_rate_sbh(level, diff0 + 1, g1_0, g1_1, ab0, rice, (uint32_t)maxVlc, c1c2Rate);
-                        r2 = rdoq_rate_sbh(level + 1, diff0 + 2, g1_0, g1_1, ab0, rice, (uint32_t)maxVlc, c1c2Rate);
-                        r0 = rdoq_rate_sbh(level - 1, diff0, g1_0, g1_1, ab0, rice, (uint32_t)maxVlc, c1c2Rate);
-                    }
-                    rateUp[b] = r2 - r1;
-                    r.rateDown[b] = r0 - r1;
-                }
-                else { rateUp[b] = g1_0; r.rateDown[b] = 0; }
-            }
-            const uint32_t lv = (uint32_t)__shfl((int)level, p, 64);
-            if (lv >= baseLevel && rice < 4 && lv > levelThreshold) { rice++; levelThreshold <<= 1; }
-            const uint32_t nz = lv != 0;
-            c1Idx += nz;
-            if (lv > 1) { c1 = 0; c2 += c2 < 2; c2Idx++; }
-            else if ((c1 == 1 || c1 == 2) && nz) c1++;
-            if (k < p) myC1 = c1;
-        }
-        if (isZero) rateUp[b] = EST_G1(4 * ctxSet + myC1, 0);
-        if (isNz) s.q[b] = (int16_t)level;
-
-        /* group sums */
-        const bool coded = isNz && level != 0;
-        int64_t rdAdd = !act ? 0 : beyond ? costUncoded : costCoeff;
-        if (act)
-        {
-            r.costSig[scanPos] = costSigV;
-            r.delta[scanPos] = coded ? costUncoded - costCoeff : -costSigV;
-        }
-        const int64_t sumUncoded = xa_wave_sum(act ? costUncoded : (int64_t)0);
-        rdAdd = xa_wave_sum(rdAdd);
-        int64_t sigCost = xa_wave_sum(act ? costSigV : (int64_t)0);
-        const int64_t codedLevelAndDist = xa_wave_sum(coded ? costCoeff - costSigV : (int64_t)0);
-        const int64_t uncodedDist = xa_wave_sum(coded ? costUncoded : (int64_t)0);
-        const int nnzBeforePos0 = xa_wave_sum(coded ? k : 0);
-        const int64_t sigCost0 = __shfl(costSigV, 0, 64);
-        const bool anyCoded = __ballot(coded) != 0;
-        totalUncoded += sumUncoded;
-        totalRd += rdAdd;
-        if (anyCoded) cgFlags |= cgMask;
-
-        int64_t costCg = 0;
-        if (!cg || cg == cgLast) { }
-        else if (cgFlags & cgMask)
-        {
-            if (!nnzBeforePos0) { totalRd -= sigCost0; sigCost -= sigCost0; }
-            const uint32_t ctx = rdoq_sig_cg_ctx(cgFlags, cgX, cgY, cgBlk, cgStride, false);
-            int64_t costZeroCG = totalRd + SIGCOST(EST_SIGCG(ctx, 0));
-            costZeroCG += uncodedDist;
-            costZeroCG -= codedLevelAndDist;
-            costZeroCG -= sigCost;
-            costCg = SIGCOST(EST_SIGCG(ctx, 1));
-            totalRd += costCg;
-            if (costZeroCG < totalRd && P.rdoqLevel > 1)
-            {
-                cgFlags &= ~cgMask;
-                totalRd = costZeroCG;
-                costCg = SIGCOST(EST_SIGCG(ctx, 0));
-                if (act) s.q[b] = 0;
-            }
-        }
-        else
-        {
-            const uint32_t ctx = rdoq_sig_cg_ctx(cgFlags, cgX, cgY, cgBlk, cgStride, false);
-            costCg = SIGCOST(EST_SIGCG(ctx, 0));
-            totalRd += costCg;
-            totalRd -= sigCost;
-        }
-        if (lane == 0) r.costCg[cg] = costCg;
-        xa_wave_sync();
-    }
-
-    /* CBF = 0 against the coded block (quant.cpp:1158-1171) */
-    int64_t bestCost;
-    if (!bIntra && isLuma && !P.tuDepth)
-    {
-        bestCost = totalUncoded + SIGCOST(EST_ROOTCBF(0));
-        totalRd += SIGCOST(EST_ROOTCBF(1));
-    }
-    else
-    {
-        const uint32_t ctx = ttype == 0 ? (P.tuDepth == 0 ? 1 : 0) : 2 + (uint32_t)P.tuDepth;     /* ctxCbf (contexts.h:120) */
-        bestCost = totalUncoded + SIGCOST(EST_CBF(ctx, 0));
-        totalRd += SIGCOST(EST_CBF(ctx, 1));
-    }
-
-    /* last significant position (quant.cpp:1173-1254) */
-    int bestLastIdx = 0;
-    for (int cg = cgLast; cg >= 0; cg--)
-    {
-        const uint32_t cgBlk = ((uint32_t)(scan[cg * 16] >> log2N) >> 2) * cgStride + (((uint32_t)scan[cg * 16] & (uint32_t)(N - 1)) >> 2);
-        if (!cg || cg == cgLast) { }
-        else if (cgFlags & ((uint64_t)1 << cgBlk)) totalRd -= r.costCg[cg];
-        else { totalRd -= r.costCg[cg]; continue; }
-
-        const int scanPos = cg * 16 + k;
-        const int b = scan[scanPos];
-        const bool valid = act && scanPos <= lastScanPos;
-        const int lv = valid ? (int)s.q[b] : 0;
-        const int64_t d = valid ? r.delta[scanPos] : 0;
-        if (act) r.tmp[k] = d;
-        xa_wave_sync();
-        int64_t above = 0;          /* what the positions scanned before this one (larger k) have added */
-        for (int kk = 15; kk > k; kk--) above += r.tmp[kk];
-        int64_t asLast = INT64_MAX;
-        if (lv)
-        {
-            uint32_t px = (uint32_t)b & (uint32_t)(N - 1), py = (uint32_t)b >> log2N;
-            if (scanType == 2) { uint32_t t = px; px = py; py = t; }
-            const uint32_t bitsLast = rdoq_last_bits(r, 0, px) + rdoq_last_bits(r, 1, py);
-            asLast = totalRd + above - r.costSig[scanPos] + SIGCOST(bitsLast);
-        }
-        const uint32_t nzM = (uint32_t)__ballot(lv != 0) & 0xFFFF;
-        const uint32_t stopM = (uint32_t)__ballot(lv > 1 || (P.rdoqLevel == 1 && lv != 0)) & 0xFFFF;
-        const int pstop = stopM ? 31 - __clz((int)stopM) : -1;
-        uint32_t m = pstop >= 0 ? nzM & ~((1u << pstop) - 1) : nzM;
-        while (m)
-        {
-            const int p = 31 - __clz((int)m);
-            m &= ~(1u << p);
-            const int64_t c = __shfl(asLast, p, 64);
-            if (c < bestCost) { bestCost = c; bestLastIdx = cg * 16 + p + 1; }
-        }
-        xa_wave_sync();
-        if (pstop >= 0) break;
-        int64_t all = 0;
-        for (int kk = 0; kk < 16; kk++) all += r.tmp[kk];
-        totalRd += all;
-        xa_wave_sync();
-    }
-
-    /* signs back; everything from the chosen last position on is dropped (quant.cpp:1256-1283) */
-    cnt = 0;
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-    {
-        const int b = scan[i];
-        if (i < bestLastIdx)
-        {
-            const int lv = s.q[b];
-            cnt += lv != 0;
-            s.q[b] = (int16_t)(dct[b] < 0 ? -lv : lv);
-        }
-        else s.q[b] = 0;
-    }
-    numSig = (uint32_t)xa_wave_sum(cnt);
-    xa_wave_sync();
-
-    /* rate-distortion based sign hiding (quant.cpp:1285-1421): one lane per 4x4 group */
-    if (signHide && numSig >= 2)
-    {
-        const int realLast = (bestLastIdx - 1) >> 4, sub = lane;
-        int delta = 0;
-        if (sub <= realLast)
-        {
-            const int subPos = sub << 4;
-            const uint32_t cgBlk = ((uint32_t)(scan[subPos] >> log2N) >> 2) * cgStride + (((uint32_t)scan[subPos] & (uint32_t)(N - 1)) >> 2);
-            if (cgFlags & ((uint64_t)1 << cgBlk))
-            {
-                const int lastCG = sub == realLast;
-                int lastNZ = -1, firstNZ = 16;
-                for (int n = 0; n < 16; n++)
-                    if (s.q[scan[subPos + n]]) { if (firstNZ == 16) firstNZ = n; lastNZ = n; }
-                if (lastNZ - firstNZ >= 4)
-                {
-                    uint32_t absSum = 0;
-                    for (int n = firstNZ; n <= lastNZ; n++) absSum += (uint32_t)(int)s.q[scan[subPos + n]];
-                    const int32_t signbit = s.q[scan[subPos + firstNZ]];
-                    if (((uint32_t)signbit >> 31) != (absSum & 1))
-                    {
-                        int64_t minCostInc = INT64_MAX, curCost = INT64_MAX;
-                        int minPos = 0, minAbs = 0, finalChange = 0, curChange = 0;
-                        uint32_t lastAdjust = (uint32_t)(lastCG & (abs((int)s.q[scan[lastNZ + subPos]]) == 1)) * 4 * RDOQ_IEP;
-                        for (int n = lastCG ? lastNZ : 15; n >= 0; --n)
-                        {
-                            const int b = scan[n + subPos];
-                            const int signCoef = dct[b];
-                            const int lvS = s.q[b];
-                            const int absLevel = abs(lvS);
-                            const uint32_t step = (uint32_t)uqScale;
-                            const uint32_t uq = (uint32_t)absLevel * step + (uint32_t)uqRound;
-                            int d = abs(signCoef) - (int)(uq >> uqShift);
-                            const int64_t origDist = (int64_t)d * d;
-#define DELTA_RD(dd, bits) (((((int64_t)(dd) * (dd)) - origDist) << scaleBits) + ((lambda2 * (int64_t)(bits)) >> 8))
-                            const uint32_t isOne = absLevel == 1;
-                            if (lvS)
-                            {
-                                d = abs(signCoef) - (int)((uq + step) >> uqShift);
-                                const int64_t costUp = DELTA_RD(d, rateUp[b]);
-                                d = abs(signCoef) - (int)((uq - step) >> uqShift);
-                                const int downBits = r.rateDown[b] - (isOne ? (RDOQ_IEP + r.sigDelta[b]) : 0);
-                                int64_t costDown = DELTA_RD(d, downBits);
-                                costDown -= lastAdjust;
-                                curCost = ((n == firstNZ) & isOne) ? INT64_MAX : costDown;
-                                curChange = 2 * (costUp < costDown) - 1;
-                                curCost = (costUp < costDown) ? costUp : curCost;
-                            }
-                            else if ((n < firstNZ) & ((signbit ^ signCoef) < 0)) curCost = INT64_MAX;
-                            else
-                            {
-                                d = abs(signCoef) - (int)((step + (uint32_t)uqRound) >> uqShift);
-                                curCost = DELTA_RD(d, rateUp[b] + RDOQ_IEP + r.sigDelta[b]);
-                                curChange = 1;
-                            }
-                            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = b; minAbs = absLevel; }
-                            lastAdjust = 0;
-                        }
-                        if (minAbs >= 32767) finalChange = -1;
-                        delta = (minAbs == 0) - ((finalChange == -1) & (minAbs == 1));
-                        if (finalChange)    /* (a zero change would only rewrite s.q[0], which belongs to another lane's group) */
-                            s.q[minPos] = (int16_t)(s.q[minPos] + (dct[minPos] < 0 ? -finalChange : finalChange));
-                    }
-                }
-            }
-        }
-        numSig = (uint32_t)((int)numSig + xa_wave_sum(delta));
-        xa_wave_sync();
-    }
-    return numSig;
-#undef SIGCOST
-#undef PSYVAL
-}
-
-/* inverse half: levels in s.q -> N x N residual in s.a (row-major, stride N) */
-XA_DEV void wave_tu_inverse(TuLds& s, int log2N, int ttype, int bIntra, int qpScaled, uint32_t numSig, int lane)
-{
-    const int N = 1 << log2N, numCoeff = N * N;
-    const int rem = qpScaled % 6, per = qpScaled / 6;
-    const int transformShift = 15 - XA_DEPTH - log2N;
-    const int shift = 20 - 14 - transformShift, addq = 1 << (shift - 1), scale = tu_invQuantScales[rem] << per;
-    const bool dst = log2N == 2 && ttype == 0 && bIntra;
-    /* dequant_normal_c (dct.cpp:612-634) */
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-        s.b[i] = (int16_t)xa_clip3(-32768, 32767, (s.q[i] * scale + addq) >> shift);
-    xa_wave_sync();
-    if (numSig == 1 && s.q[0] != 0 && !dst)     /* DC only (quant.cpp:588-598) */
-    {
-        const int shift_1st = 7 - 6, add_1st = 1 << (shift_1st - 1);
-        const int shift_2nd = 12 - (XA_DEPTH - 8) - 3, add_2nd = 1 << (shift_2nd - 1);
-        int dc = (((s.b[0] * (64 >> 6) + add_1st) >> shift_1st) * (64 >> 3) + add_2nd) >> shift_2nd;
-        xa_wave_sync();
-        for (int i = lane; i < numCoeff; i += XA_WAVE) s.a[i] = (int16_t)dc;
-        xa_wave_sync();
-        return;
-    }
-    const int16_t* T = dst ? xa_tbl.dst4 : xa_tbl.dct[log2N - 2];
-    wave_inv_pass(T, log2N, s.b, s.dct, N, 7, lane);        /* s.dct is free again: reuse as pass scratch */
-    xa_wave_sync();
-    wave_inv_pass(T, log2N, s.dct, s.a, N, 12 - (XA_DEPTH - 8), lane);
-    xa_wave_sync();
-}
-
-/* RDOQ form of the forward half: transform of the residual (s.a) into s.dct, transform of the source block into the
- * deltaU area when psy-rdoq applies (quant.cpp:428-441), then rdoQuant */
-XA_DEV uint32_t wave_tu_forward_rdoq(TuLds& s, RdoqLds& r, const RdoqParams& P, const pixel* fenc, int fencStride, int log2N, int ttype, int bIntra,
-                                     int dirMode, int qpScaled, int signHide, int lane)
-{
-    const int N = 1 << log2N, numCoeff = N * N, isLuma = ttype == 0;
-    const bool dst = log2N == 2 && isLuma && bIntra;
-    const int16_t* T = dst ? xa_tbl.dst4 : xa_tbl.dct[log2N - 2];
-    wave_fwd_pass(T, log2N, s.a, s.b, log2N - 1 + XA_DEPTH - 8, lane);
-    xa_wave_sync();
-    wave_fwd_pass(T, log2N, s.b, s.dct, log2N + 6, lane);
-    xa_wave_sync();
-    const bool usePsy = P.psyRdoqScale != 0 && isLuma;
-    if (usePsy)
-    {
-        for (int i = lane; i < numCoeff; i += XA_WAVE) s.a[i] = (int16_t)fenc[(i >> log2N) * fencStride + (i & (N - 1))];
-        xa_wave_sync();
-        const int16_t* Td = xa_tbl.dct[log2N - 2];       /* always the DCT (copy_ps + dct, quant.cpp:436-440) */
-        wave_fwd_pass(Td, log2N, s.a, s.b, log2N - 1 + XA_DEPTH - 8, lane);
-        xa_wave_sync();
-        wave_fwd_pass(Td, log2N, s.b, reinterpret_cast<int16_t*>(s.deltaU), log2N + 6, lane);
-        xa_wave_sync();
-    }
-    return wave_rdo_quant(s, r, P, log2N, ttype, bIntra, dirMode, qpScaled, signHide, usePsy, lane);
-}
-
-#define TU_RDOQ_WAVES 2
-
-/* the per-TU measurement given the prediction block (global or LDS): residual, forward half (plain or RDOQ), levels out,
- * and when levels remain the inverse half, reconstruction and both distortions / psy energies */
-template<bool RDOQ>
-XA_DEV void wave_tu_measure(TuLds& s, char* rdoqLds, const x265amd_tu_job& j, const x265amd_tu_rdoq* rq, const pixel* pred, int predStride,
-                            x265amd_tu_result* out, int lane)
-{
-    const int log2N = j.log2_tr_size, N = 1 << log2N, numCoeff = N * N, cu = log2N - 2;
-    const pixel* fenc = reinterpret_cast<const pixel*>(j.fenc);
-    /* residual: pixel_sub_ps_c (pixel.cpp:832-844) */
-    for (int i = lane; i < numCoeff; i += XA_WAVE)
-    {
-        int y = i >> log2N, x = i & (N - 1);
-        s.a[i] = (int16_t)((int)fenc[y * j.fenc_stride + x] - (int)pred[y * predStride + x]);
-    }
-    xa_wave_sync();
-    uint32_t numSig;
-    if constexpr (RDOQ)
-    {
-        RdoqLds& r = *reinterpret_cast<RdoqLds*>(rdoqLds);
-        const x265amd_tu_rdoq q = *rq;
-        if (q.rdoq_level)
-        {
-            RdoqParams P = { reinterpret_cast<const int*>(q.est_bits), q.lambda2, q.lambda, q.psy_rdoq_scale, q.rdoq_level, q.tu_depth };
-            numSig = wave_tu_forward_rdoq(s, r, P, fenc, j.fenc_stride, log2N, j.ttype, j.intra, j.dir_mode, j.qp_scaled, j.sign_hide, lane);
-        }
-        else numSig = wave_tu_forward(s, log2N, j.ttype, j.intra, j.dir_mode, j.slice_type, j.qp_scaled, j.sign_hide, lane);
-    }
-    else numSig = wave_tu_forward(s, log2N, j.ttype, j.intra, j.dir_mode, j.slice_type, j.qp_scaled, j.sign_hide, lane);
-    int16_t* coeff = reinterpret_cast<int16_t*>(j.coeff);
-    for (int i = lane; i < numCoeff; i += XA_WAVE) coeff[i] = s.q[i];
-    uint64_t zeroDist = wave_sse_pp(fenc, j.fenc_stride, pred, predStride, N, lane);
-    uint32_t zeroEnergy = (uint32_t)wave_psy_cost(fenc, j.fenc_stride, pred, predStride, cu, lane);
-    uint64_t nzDist = zeroDist;
-    uint32_t nzEnergy = zeroEnergy;
-    int16_t* resi = reinterpret_cast<int16_t*>(j.resi);
-    pixel* recon = reinterpret_cast<pixel*>(j.recon);
-    if (numSig)
-    {
-        wave_tu_inverse(s, log2N, j.ttype, j.intra, j.qp_scaled, numSig, lane);
-        /* pixel_add_ps_c (pixel.cpp:846-858) */
-        for (int i = lane; i < numCoeff; i += XA_WAVE)
-        {
-            int y = i >> log2N, x = i & (N - 1);
-            pixel rr = xa_clip_pixel((int)pred[y * predStride + x] + (int)s.a[i]);
-            s.rec[i] = rr;
-            recon[y * j.recon_stride + x] = rr;
-            resi[y * j.resi_stride + x] = s.a[i];
-        }
-        xa_wave_sync();
-        nzDist = wave_sse_pp(fenc, j.fenc_stride, s.rec, N, N, lane);
-        nzEnergy = (uint32_t)wave_psy_cost(fenc, j.fenc_stride, s.rec, N, cu, lane);
-    }
-    else
-    {
-        for (int i = lane; i < numCoeff; i += XA_WAVE)
-        {
-            int y = i >> log2N, x = i & (N - 1);
-            recon[y * j.recon_stride + x] = pred[y * predStride + x];
-            resi[y * j.resi_stride + x] = 0;
-        }
-    }
-    if (lane == 0)
-    {
-        x265amd_tu_result res;
-        res.num_sig = numSig; res.zero_energy = zeroEnergy; res.nz_energy = nzEnergy; res.reserved = 0;
-        res.zero_dist = zeroDist; res.nz_dist = nzDist;
-        *out = res;
-    }
-}
-
 
 template<bool RDOQ>
 __global__ __launch_bounds__(64 * (RDOQ ? TU_RDOQ_WAVES : TU_WAVES)) void k_tu_chain(const x265amd_tu_job* jobs, const x265amd_tu_rdoq* rq, int n, x265amd_tu_result* out)
@@ -787,17 +22,8 @@ __global__ __launch_bounds__(64 * (RDOQ ? TU_RDOQ_WAVES : TU_WAVES)) void k_tu_c
     const int ji = blockIdx.x * WAVES + wv;
     if (ji >= n) return;
     TuLds& s = reinterpret_cast<TuLds*>(tu_smem)[wv];
-    const x265amd_tu_job j = jobs[ji];
-    wave_tu_measure<RDOQ>(s, RDOQ ? tu_smem + WAVES * sizeof(TuLds) + wv * sizeof(RdoqLds) : nullptr, j, RDOQ ? rq + ji : nullptr,
-                          reinterpret_cast<const pixel*>(j.pred), j.pred_stride, out + ji, lane);
+    wave_tu_chain_job<RDOQ>(jobs, rq, ji, out, s, RDOQ ? tu_smem + WAVES * sizeof(TuLds) + wv * sizeof(RdoqLds) : nullptr, lane);
 }
-
-/* Intra TU step (Search::codeIntraLumaQT search.cpp:305-508 / codeIntraChromaQt :819-945, one TU): the neighbour set of the
- * job's one mode from the reconstructed plane (initAdiPattern(dirMode) / initAdiPatternChroma), the prediction
- * (predIntraLumaAng: filtered neighbours by g_intraFilterFlags, edge filters up to 16x16; predIntraChromaAng, 4:2:0:
- * unfiltered, no edge filters; predict.cpp:579-598), then the measurement above.  The prediction lives in LDS and is
- * stored to tu.pred only when that address is non-zero. */
-struct IntraTuLds { pixel ref[136], flt[136], sw[136]; pixel pred[32 * 32]; };
 
 template<bool RDOQ>
 __global__ __launch_bounds__(64 * (RDOQ ? TU_RDOQ_WAVES : TU_WAVES)) void k_intra_tu_chain(const x265amd_intra_tu_job* jobs, const x265amd_tu_rdoq* rq, int n,
@@ -811,20 +37,7 @@ __global__ __launch_bounds__(64 * (RDOQ ? TU_RDOQ_WAVES : TU_WAVES)) void k_intr
     TuLds& s = reinterpret_cast<TuLds*>(tu_smem)[wv];
     char* extra = tu_smem + WAVES * sizeof(TuLds);
     IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(extra)[wv];
-    char* rdoqLds = RDOQ ? extra + WAVES * sizeof(IntraTuLds) + wv * sizeof(RdoqLds) : nullptr;
-    const x265amd_intra_tu_job J = jobs[ji];
-    const int log2N = J.tu.log2_tr_size, N = 1 << log2N, mode = J.tu.dir_mode;
-    const bool isChroma = J.tu.ttype != 0;
-    const bool filter = !isChroma && (xa_intra_filter_flags(mode) & N) != 0;
-    wave_intra_neighbours(reinterpret_cast<const pixel*>(J.nb), J.nb_stride, J.avail, log2N, J.strong_smoothing != 0, filter, ip.ref, ip.flt, lane);
-    wave_intra_pred(filter ? ip.flt : ip.ref, ip.sw, log2N - 2, mode, (!isChroma && log2N <= 4) ? 1 : 0, ip.pred, N, false, lane);
-    xa_wave_sync();
-    if (J.tu.pred)
-    {
-        pixel* dst = reinterpret_cast<pixel*>(J.tu.pred);
-        for (int i = lane; i < N * N; i += XA_WAVE) dst[(i >> log2N) * J.tu.pred_stride + (i & (N - 1))] = ip.pred[i];
-    }
-    wave_tu_measure<RDOQ>(s, rdoqLds, J.tu, RDOQ ? rq + ji : nullptr, ip.pred, N, out + ji, lane);
+    wave_intra_tu_chain_job<RDOQ>(jobs, rq, ji, out, s, ip, RDOQ ? extra + WAVES * sizeof(IntraTuLds) + wv * sizeof(RdoqLds) : nullptr, lane);
 }
 
 /* the two Quant entry points on their own (parity surface): op 0 forward (a = residual in, coeff out, numSig -> out),
@@ -890,11 +103,12 @@ extern "C" int x265amd_tu_chain(void* stream, const x265amd_tu_job* d_jobs, int 
 {
     if (n <= 0) return X265AMD_OK;
     if (!d_jobs || !d_out) return xa_fail(X265AMD_EINVAL, "x265amd_tu_chain: bad arguments");
-    int rc = tu_configure();
+    int rc = xa_is_queue(stream) ? X265AMD_OK : tu_configure();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tu_chain<false>, dim3((n + TU_WAVES - 1) / TU_WAVES), dim3(64 * TU_WAVES), TU_WAVES * sizeof(TuLds), (hipStream_t)stream, d_jobs,
-                       (const x265amd_tu_rdoq*)nullptr, n, d_out);
-    hipError_t e = hipGetLastError();
+    const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_jobs, 0, (uint64_t)(uintptr_t)d_out, 0, n };
+    hipError_t e;
+    XA_LAUNCH(e, stream, XA_OP_TU_CHAIN, n, qa, k_tu_chain<false>, dim3((n + TU_WAVES - 1) / TU_WAVES), dim3(64 * TU_WAVES), TU_WAVES * sizeof(TuLds), d_jobs,
+                             (const x265amd_tu_rdoq*)nullptr, n, d_out);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }
@@ -903,11 +117,12 @@ extern "C" int x265amd_tu_chain_rdoq(void* stream, const x265amd_tu_job* d_jobs,
 {
     if (n <= 0) return X265AMD_OK;
     if (!d_jobs || !d_rdoq || !d_out) return xa_fail(X265AMD_EINVAL, "x265amd_tu_chain_rdoq: bad arguments");
-    int rc = tu_configure();
+    int rc = xa_is_queue(stream) ? X265AMD_OK : tu_configure();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tu_chain<true>, dim3((n + TU_RDOQ_WAVES - 1) / TU_RDOQ_WAVES), dim3(64 * TU_RDOQ_WAVES),
-                       TU_RDOQ_WAVES * (sizeof(TuLds) + sizeof(RdoqLds)), (hipStream_t)stream, d_jobs, d_rdoq, n, d_out);
-    hipError_t e = hipGetLastError();
+    const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_jobs, (uint64_t)(uintptr_t)d_rdoq, (uint64_t)(uintptr_t)d_out, 0, n };
+    hipError_t e;
+    XA_LAUNCH(e, stream, XA_OP_TU_CHAIN_RDOQ, n, qa, k_tu_chain<true>, dim3((n + TU_RDOQ_WAVES - 1) / TU_RDOQ_WAVES), dim3(64 * TU_RDOQ_WAVES),
+                             TU_RDOQ_WAVES * (sizeof(TuLds) + sizeof(RdoqLds)), d_jobs, d_rdoq, n, d_out);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }
@@ -916,15 +131,16 @@ extern "C" int x265amd_intra_tu_chain(void* stream, const x265amd_intra_tu_job* 
 {
     if (n <= 0) return X265AMD_OK;
     if (!d_jobs || !d_out) return xa_fail(X265AMD_EINVAL, "x265amd_intra_tu_chain: bad arguments");
-    int rc = tu_configure();
+    int rc = xa_is_queue(stream) ? X265AMD_OK : tu_configure();
     if (rc) return rc;
+    const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_jobs, (uint64_t)(uintptr_t)d_rdoq, (uint64_t)(uintptr_t)d_out, 0, n };
+    hipError_t e;
     if (d_rdoq)
-        hipLaunchKernelGGL(k_intra_tu_chain<true>, dim3((n + TU_RDOQ_WAVES - 1) / TU_RDOQ_WAVES), dim3(64 * TU_RDOQ_WAVES),
-                           TU_RDOQ_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds) + sizeof(RdoqLds)), (hipStream_t)stream, d_jobs, d_rdoq, n, d_out);
+        XA_LAUNCH(e, stream, XA_OP_INTRA_TU_CHAIN_RDOQ, n, qa, k_intra_tu_chain<true>, dim3((n + TU_RDOQ_WAVES - 1) / TU_RDOQ_WAVES), dim3(64 * TU_RDOQ_WAVES),
+                      TU_RDOQ_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds) + sizeof(RdoqLds)), d_jobs, d_rdoq, n, d_out);
     else
-        hipLaunchKernelGGL(k_intra_tu_chain<false>, dim3((n + TU_WAVES - 1) / TU_WAVES), dim3(64 * TU_WAVES), TU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)),
-                           (hipStream_t)stream, d_jobs, (const x265amd_tu_rdoq*)nullptr, n, d_out);
-    hipError_t e = hipGetLastError();
+        XA_LAUNCH(e, stream, XA_OP_INTRA_TU_CHAIN, n, qa, k_intra_tu_chain<false>, dim3((n + TU_WAVES - 1) / TU_WAVES), dim3(64 * TU_WAVES),
+                      TU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)), d_jobs, (const x265amd_tu_rdoq*)nullptr, n, d_out);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }

@@ -16,26 +16,66 @@ int xa_fail(int code, const char* msg);
  * enqueues its work on one stream, so reuse is stream-ordered.  x265amd_release_scratch() returns everything to the runtime. */
 hipError_t xa_scratch_alloc(void** p, size_t bytes);
 void xa_scratch_free(void* p);
+/* While a thread holds a device job queue its freed blocks wait in a list of its own and serve its own next allocations: the queue's workgroup may
+ * still own dirty L2 lines of a block (a resident workgroup writes back when told to, XA_CMD_RELEASE, not at a kernel boundary), and a block handed to
+ * another queue on another XCD in that state is overwritten by the late write-back.  xa_scratch_local_end() returns the list to the shared pool; the
+ * queue has been released (fenced + drained) by then. */
+void xa_scratch_local_begin();
+void xa_scratch_local_end();
 
 /* Host-visible staging for the orchestrators' small job and result records: pinned host memory that the kernels read and write in place
  * (hipHostMalloc, mapped + coherent), pooled like the device scratch.  It replaces a hipMemcpyAsync per record array: the host fills the
  * jobs, launches, synchronises the stream and reads the results where the kernel left them.  Only for data a kernel touches once
- * (fine-grained host memory is not cached on the device). */
-hipError_t xa_mapped_alloc(void** p, size_t bytes);
+ * (fine-grained host memory is not cached on the device).
+ * Two pools, by direction: a block is either written by the host and read by the device (XaMapped: job records) or written by the device and
+ * read by the host (XaMappedOut: results, levels).  A resident workgroup (device job queue) keeps the lines it has STORED to host memory in its L2,
+ * and no acquire drops them: a block that served as a result array and came back from the pool as a job array was read as the old results
+ * (measured, dbg/README.md).  Kernel boundaries hid that; keeping the directions apart removes it. */
+hipError_t xa_mapped_alloc(void** p, size_t bytes, bool deviceWrites = false);
 void xa_mapped_free(void* p);
 #ifdef __cplusplus
 struct XaMapped
 {
     void* p = nullptr;
+    bool deviceWrites;
+    explicit XaMapped(bool deviceWrites_ = false) : deviceWrites(deviceWrites_) {}
     ~XaMapped() { xa_mapped_free(p); }
-    hipError_t alloc(size_t bytes) { return xa_mapped_alloc(&p, bytes ? bytes : 16); }
+    hipError_t alloc(size_t bytes) { return xa_mapped_alloc(&p, bytes ? bytes : 16, deviceWrites); }
 };
+struct XaMappedOut : XaMapped { XaMappedOut() : XaMapped(true) {} };
 #endif
+
+/* ---- streams and device job queues ----
+ * The `stream` argument of the batch entry points is either a hipStream_t or a device job queue (xa_queue.h): a queue handle has its low bit set.
+ * A queue is a resident workgroup bound to the calling host thread; enqueueing a command is a store into device memory, waiting for it is a spin on
+ * pinned host memory -- no runtime call either way.  The helpers below take either kind, so the orchestrators are written once:
+ *   xa_stream_sync          hipStreamSynchronize / wait until the queue has run everything enqueued (then finish the deferred host copies)
+ *   xa_copy_async           hipMemcpyAsync / a copy command; pageable host memory goes through the queue's pinned staging area
+ *   xa_copy2d_to_mapped_async  device rows -> pinned host memory (hipMemcpy2DAsync / a copy command)
+ *   xa_fill_async           hipMemsetAsync / a fill command
+ *   xa_stream_fence         queue only: XA_CMD_ACQUIRE before reading what other workgroups, kernels or copies wrote, XA_CMD_RELEASE after writing what
+ *                           they will read (the boundaries of a kernel do both; a resident workgroup has to be told)
+ *   XA_LAUNCH               a kernel launch on a stream, or the same body as a command on a queue */
+inline bool xa_is_queue(const void* st) { return ((uintptr_t)st & 1) != 0; }
+bool xa_queues_enabled();
+void* xa_queue_acquire();               /* NULL when queues are off (X265AMD_QUEUES=0) or all are taken: use a stream then */
+void xa_queue_release(void* st);
+hipError_t xa_stream_sync(void* st);
+hipError_t xa_stream_fence(void* st, int flags);
+hipError_t xa_copy_async(void* st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+hipError_t xa_copy2d_to_mapped_async(void* st, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
+hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes);
+hipError_t xa_q_enqueue(void* st, int op, const void* args, size_t argBytes, int count, int flags);
+#define XA_LAUNCH(ERR, st, OP, COUNT, ARGS, KERNEL, GRID, BLOCK, LDS, ...)                                                   \
+    do {                                                                                                                     \
+        if (xa_is_queue(st)) (ERR) = xa_q_enqueue((st), (OP), &(ARGS), sizeof(ARGS), (COUNT), 0);                           \
+        else { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, (hipStream_t)(st), __VA_ARGS__); (ERR) = hipGetLastError(); }   \
+    } while (0)
 
 /* up to three 2-D sample copies (device to device) as ONE launch: the three planes of a tile, or a prediction / reconstruction pair.
  * Strides and sizes in samples. */
 struct XaRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };
-void xa_copy_rects(hipStream_t st, const XaRects& r);
+void xa_copy_rects(void* st, const XaRects& r);
 
 /* device address of the centre (MVD 0) of x265amd_me_ctx's MV cost table for `qp` (BitCost::s_costs[qp]) */
 const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp);

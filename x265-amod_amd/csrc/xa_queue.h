@@ -1,0 +1,61 @@
+/* Device job queues: the records shared by the host side (device_queue.hip: xa_q_*) and the resident server kernel (k_job_server).
+ *
+ * Why: the reference's mode decision is a serial chain of small block operations per CTU (analysis.cpp:1146-1848); run as kernel launches, every link
+ * costs a launch and a stream synchronisation (about 11 us uncontended on MI355X, 30-45 us when the CTU rows of several pictures launch from their own
+ * threads and serialise inside the HIP runtime).  A queue replaces launch + synchronise with a 128-byte command the host thread stores straight into
+ * device memory (the BAR mapping of a fine-grained allocation) and a resident workgroup that polls for it in its own memory; completion comes back as
+ * a store into pinned host memory the host thread polls.  Both sides poll local memory and write remote memory, so a round trip is two posted PCIe
+ * writes: 3.4 us measured (dbg/mbox), with no runtime call in between and no lock shared by the rows.
+ *
+ * One queue = one workgroup of XA_SERVER_WAVES wavefronts bound to one host thread (a CTU row in flight); commands run in order, like a stream.  The
+ * kernels' wave-level bodies (tu_dev.h, intra_dev.h, mc_dev.h, me_dev.h, measure_dev.h) are shared between the ordinary kernels and the server.
+ */
+#ifndef X265AMD_XA_QUEUE_H
+#define X265AMD_XA_QUEUE_H
+#include <stdint.h>
+
+enum XaOp
+{
+    XA_OP_NOP = 0, XA_OP_EXIT, XA_OP_COPY, XA_OP_COPY2D, XA_OP_FILL, XA_OP_COPY_RECTS, XA_OP_MC, XA_OP_MC_COST, XA_OP_CU_MEASURE, XA_OP_TU_CHAIN, XA_OP_TU_CHAIN_RDOQ,
+    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_COUNT
+};
+enum
+{
+    XA_CMD_ACQUIRE = 1,     /* before the command: make other workgroups' / kernels' / copy engines' writes visible (agent-scope acquire) */
+    XA_CMD_RELEASE = 2,     /* after the command: make this workgroup's device-memory writes visible to them (agent-scope release) */
+    XA_CMD_SIGNAL = 4       /* after the command: publish the count of finished commands to the host */
+};
+
+#define XA_RING 64              /* commands per queue ring */
+#define XA_CMD_ARG_WORDS 13
+#define XA_SERVER_WAVES 8
+#define XA_SERVER_LDS (144 * 1024)
+
+/* `check` closes the command: XA_CHECK_MUL * (number of this command, from 1) xor all fifteen words before it.  The host's stores reach device memory
+ * through the BAR; a workgroup that has seen the ring head move is not promised that the slot's sixteen words have all landed where its loads look
+ * (observed: a command read back partly as the slot's previous content), so it reads the slot until the check holds. */
+struct alignas(128) XaCmd { uint32_t op, flags, count, reserved; uint64_t args[XA_CMD_ARG_WORDS]; uint64_t check; };
+#define XA_CHECK_MUL 0x9E3779B97F4A7C15ull
+
+/* device memory (fine-grained), written by the host through the BAR, polled by the workgroup */
+struct alignas(128) XaRingDev
+{
+    XaCmd cmd[XA_RING];
+    uint64_t head; uint64_t pad0[15];           /* commands submitted so far */
+    uint64_t quit; uint64_t pad1[15];
+};
+/* pinned host memory, written by the workgroup, polled by the host thread */
+struct alignas(128) XaRingHost
+{
+    uint64_t tail; uint64_t pad0[15];           /* commands finished, as of the last signalling command */
+    uint64_t state; uint64_t pad1[15];          /* 1 while the workgroup is resident */
+    uint64_t dbg[64];                           /* X265AMD_QUEUE_DEBUG & 2: what each wavefront was about to touch (dumped on abort) */
+};
+
+struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, second array, results, extra, count) shapes of the job-list kernels */
+struct XaArgsCopy { uint64_t dst, src, bytes; };
+struct XaArgsCopy2D { uint64_t dst, src, dpitch, spitch, width, height; };
+struct XaArgsFill { uint64_t dst, bytes; uint32_t value; };
+struct XaArgsRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };     /* = XaRects (x265amd_host.h) */
+
+#endif
