@@ -12,3 +12,5 @@ stream, coded = T.encoder_run(L, planes, W, H, **cfg)
 dt = time.perf_counter() - t0
 print("queues", os.environ.get("X265AMD_QUEUES", "default"), "%dx%d" % (W, H), "frames", len(coded), "seconds %.3f" % dt, "fps %.2f" % (len(coded) / dt), "bytes", len(stream),
       hashlib.md5(stream.tobytes()).hexdigest())
+if os.environ.get("X265AMD_QUEUE_PROF"):
+    L.lib.x265amd_queue_profile_report()

@@ -849,6 +849,8 @@ int x265amd_queue_selftest(int rounds, int numQueues);
  * queue is held a workgroup is resident on the device: release it before anything that synchronises the whole device. */
 void* x265amd_queue_acquire(void);
 void x265amd_queue_release(void* queue);
+/* prints (stderr) what the job server's workgroups have spent per command kind so far; the counters are kept when X265AMD_QUEUE_PROF is set */
+void x265amd_queue_profile_report(void);
 
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */

@@ -6,6 +6,10 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 #include "xa_queue.h"
+/* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside" */
+__shared__ unsigned long long xa_stage_acc[16];
+__shared__ long long xa_stage_prev;
+#define XA_STAGE(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_stage_acc[k] += (unsigned long long)(t_ - xa_stage_prev); xa_stage_prev = t_; } } while (0)
 #include "tu_dev.h"
 #include "intra_dev.h"
 #include "mc_dev.h"
@@ -113,21 +117,19 @@ __device__ __noinline__ void xa_op_copy_rects(const XaCmd& c, int tid)
 
 __device__ __noinline__ void xa_op_mc(const XaCmd& c, int tid)
 {
-    constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
-    (void)NT; (void)lane; (void)wv;
-    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
-    (void)serial;
+    const XaArgsMc a = *reinterpret_cast<const XaArgsMc*>(c.args);
+    if (c.op == XA_OP_MC_COST)
     {
-        const XaArgsMc a = *reinterpret_cast<const XaArgsMc*>(c.args);
-        const bool cost = c.op == XA_OP_MC_COST;
-        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
-        {
-            XA_DBG(c, 0, 0x6000000000000000ull | (uint64_t)ji); XA_DBG(c, 1, a.jobs + ji); XA_DBG(c, 2, a.jobs[ji].dst_y); XA_DBG(c, 3, a.jobs[ji].dst_v); XA_DBG(c, 4, a.planes);
-            if (cost) wave_mc_job<true>(a, ji, lane);
-            else wave_mc_job<false>(a, ji, lane);
-            XA_DBG(c, 7, 0x6666000000000000ull | (uint64_t)ji);
-        }
+        for (int ji = wv; ji < a.n; ji += XA_SERVER_WAVES) wave_mc_job<true>(a, ji, lane);
+        return;
+    }
+    /* prediction only: every sample stands alone, so the wavefronts are dealt out over the jobs (one job: all eight on it) */
+    const int wpj = a.n >= XA_SERVER_WAVES ? 1 : XA_SERVER_WAVES / a.n, perRound = XA_SERVER_WAVES / wpj;
+    for (int base = 0; base < a.n; base += perRound)
+    {
+        const int ji = base + wv / wpj, sub = wv % wpj;
+        if (wv < perRound * wpj && ji < a.n) wave_mc_job<false>(a, ji, sub * 64 + lane, wpj * 64);
     }
 }
 
@@ -135,38 +137,48 @@ __device__ __noinline__ void xa_op_cu_measure(const XaCmd& c, int tid)
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
-    (void)NT; (void)lane; (void)wv;
-    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
-    (void)serial;
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    const CuMeasureJob* jobs = reinterpret_cast<const CuMeasureJob*>(a.a);
+    CuMeasure* out = reinterpret_cast<CuMeasure*>(a.b);
+    static_assert(sizeof(CuMeasureLds) <= XA_SERVER_LDS, "LDS budget");
+    if (a.n <= 2 * XA_SERVER_WAVES)
     {
-        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
-        constexpr int W = (XA_SERVER_LDS / (64 * 64 * (int)sizeof(pixel))) < XA_SERVER_WAVES ? (XA_SERVER_LDS / (64 * 64 * (int)sizeof(pixel))) : XA_SERVER_WAVES;
-        if (wv < W)
-            for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : W)
-            {
-                const CuMeasureJob* jp = reinterpret_cast<const CuMeasureJob*>(a.a) + ji;
-                XA_DBG(c, 0, 0x8000000000000000ull | (uint64_t)ji); XA_DBG(c, 1, jp); XA_DBG(c, 2, jp->pred); XA_DBG(c, 3, jp->recon); XA_DBG(c, 4, jp->fenc[0]); XA_DBG(c, 5, jp->fenc[2]);
-                XA_DBG(c, 6, ((uint64_t)(uint32_t)jp->log2_size << 32) | (uint32_t)jp->assemble);
-                if ((c.reserved & 4) && (!jp->pred || !jp->recon || !jp->fenc[0] || !jp->fenc[1] || !jp->fenc[2] || !a.b)) continue;
-                wave_cu_measure_job(reinterpret_cast<const CuMeasureJob*>(a.a), ji, reinterpret_cast<CuMeasure*>(a.b), reinterpret_cast<pixel*>(xa_smem) + wv * 64 * 64, lane);
-                XA_DBG(c, 7, 0x7777000000000000ull | (uint64_t)ji);
-            }
+        /* a few candidates of one CU: the whole workgroup on each in turn */
+        CuMeasureLds& s = *reinterpret_cast<CuMeasureLds*>(xa_smem);
+        for (int ji = 0; ji < a.n; ji++)
+        {
+            const CuMeasureJob j = xa_ld_record(jobs + ji);
+            block_cu_measure_job(j, out + ji, s, tid, NT);
+        }
+        return;
     }
+    constexpr int W = (XA_SERVER_LDS / (64 * 64 * (int)sizeof(pixel))) < XA_SERVER_WAVES ? (XA_SERVER_LDS / (64 * 64 * (int)sizeof(pixel))) : XA_SERVER_WAVES;
+    if (wv < W)
+        for (int ji = wv; ji < a.n; ji += W) wave_cu_measure_job(jobs, ji, out, reinterpret_cast<pixel*>(xa_smem) + wv * 64 * 64, lane);
 }
 
 __device__ __noinline__ void xa_op_tu_chain(const XaCmd& c, int tid)
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
-    (void)NT; (void)lane; (void)wv;
-    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
-    (void)serial;
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    static_assert((XA_SERVER_WAVES + 1) * sizeof(TuLds) + 64 <= XA_SERVER_LDS, "LDS budget");
+    const x265amd_tu_job* jobs = reinterpret_cast<const x265amd_tu_job*>(a.a);
+    x265amd_tu_result* out = reinterpret_cast<x265amd_tu_result*>(a.c);
+    /* The units of an inter CU: a few large ones (16x16, 32x32) and some small ones.  A large unit on one wavefront is tens of microseconds the row
+     * waits for; the whole workgroup takes those one after the other, then the small ones go one per wavefront. */
+    TuLds& big = reinterpret_cast<TuLds*>(xa_smem)[XA_SERVER_WAVES];
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(xa_smem + (XA_SERVER_WAVES + 1) * sizeof(TuLds));
+    const bool few = a.n <= 4 * XA_SERVER_WAVES;
+    if (few)
+        for (int ji = 0; ji < a.n; ji++)
+            if (__hip_atomic_load(&jobs[ji].log2_tr_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 4) block_tu_chain_job(jobs, ji, out, big, red, tid, NT);
+    TuLds& s = reinterpret_cast<TuLds*>(xa_smem)[wv];
+    int k = 0;
+    for (int ji = 0; ji < a.n; ji++)
     {
-        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
-        static_assert(XA_SERVER_WAVES * sizeof(TuLds) <= XA_SERVER_LDS, "LDS budget");
-        TuLds& s = reinterpret_cast<TuLds*>(xa_smem)[wv];
-        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
-            wave_tu_chain_job<false>(reinterpret_cast<const x265amd_tu_job*>(a.a), nullptr, ji, reinterpret_cast<x265amd_tu_result*>(a.c), s, nullptr, lane);
+        if (few && __hip_atomic_load(&jobs[ji].log2_tr_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= 4) continue;
+        if ((k++ % XA_SERVER_WAVES) == wv) wave_tu_chain_job<false>(jobs, nullptr, ji, out, s, nullptr, lane);
     }
 }
 
@@ -235,16 +247,24 @@ __device__ __noinline__ void xa_op_intra_scan(const XaCmd& c, int tid)
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
-    (void)NT; (void)lane; (void)wv;
-    const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
-    (void)serial;
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    static_assert(XA_SERVER_WAVES * sizeof(IntraLds) <= XA_SERVER_LDS && sizeof(IntraScanLds) <= XA_SERVER_LDS, "LDS budget");
+    const x265amd_intra_job* jobs = reinterpret_cast<const x265amd_intra_job*>(a.a);
+    int32_t* out = reinterpret_cast<int32_t*>(a.b);
+    pixel* nbOut = reinterpret_cast<pixel*>(a.c);
+    if (a.n <= 2 * XA_SERVER_WAVES)
     {
-        const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
-        static_assert(XA_SERVER_WAVES * sizeof(IntraLds) <= XA_SERVER_LDS, "LDS budget");
-        IntraLds& s = reinterpret_cast<IntraLds*>(xa_smem)[wv];
-        for (int ji = serial ? (wv ? a.n : 0) : wv; ji < a.n; ji += serial ? 1 : XA_SERVER_WAVES)
-            wave_intra_scan_job(reinterpret_cast<const x265amd_intra_job*>(a.a), ji, reinterpret_cast<int32_t*>(a.b), reinterpret_cast<pixel*>(a.c), s, lane);
+        /* the usual case is ONE block (the next CU of the row): the whole workgroup on it */
+        IntraScanLds& s = *reinterpret_cast<IntraScanLds*>(xa_smem);
+        for (int ji = 0; ji < a.n; ji++)
+        {
+            const x265amd_intra_job j = xa_ld_record(jobs + ji);
+            block_intra_scan_job(j, out + (size_t)ji * 35, nbOut ? nbOut + (size_t)ji * 2 * 129 : nullptr, s, tid, NT);
+        }
+        return;
     }
+    IntraLds& s = reinterpret_cast<IntraLds*>(xa_smem)[wv];
+    for (int ji = wv; ji < a.n; ji += XA_SERVER_WAVES) wave_intra_scan_job(jobs, ji, out, nbOut, s, lane);
 }
 
 __device__ __noinline__ void xa_op_est_bit(const XaCmd& c, int tid)
@@ -331,10 +351,14 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
 {
     __shared__ XaCmd s_cmd;
     __shared__ int s_go;
+    __shared__ unsigned long long s_prof[64];
     XaRingDev* rd = rings + blockIdx.x;
     XaRingHost* rh = hosts + blockIdx.x;
     const int tid = threadIdx.x;
     uint64_t seen = 0, rereads = 0;
+    if (tid < 64) s_prof[tid] = 0;
+    if (tid < 16) xa_stage_acc[tid] = 0;
+    if (tid == 0) xa_stage_prev = wall_clock64();
     if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
     __syncthreads();
     for (;;)
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                 unsigned spins = 0;
                 for (;;)
                 {
-                    if (xa_sys_load(&rd->head) > seen) break;
+                    if (xa_sys_load(&rd->head) > seen) { s_prof[62] += (unsigned long long)(wall_clock64() - t0); break; }
                     if (xa_sys_load(&rd->quit)) { go = 0; break; }
                     if ((++spins & 1023) == 0 && wall_clock64() - t0 > idleTicks) { go = 0; break; }
                     __builtin_amdgcn_s_sleep(2);
@@ -369,6 +393,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                     if (got == want)
                     {
                         if (tid < 16) reinterpret_cast<uint64_t*>(&s_cmd)[tid] = w;
+                        xa_wave_sync();
                         if (tries && tid == 0) { rereads += tries; xa_sys_store(&rh->dbg[63], rereads); }     /* how often a slot was not complete yet */
                         break;
                     }
@@ -378,36 +403,67 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
             if (tid == 0)
             {
                 s_go = go;
-                /* Every command starts behind an acquire: the job records and small tables it reads live in pinned host memory that the host rewrites
-                 * in place between commands, and this CU's vector L1 keeps lines across commands (measured: without it the second use of a record
-                 * array reads the first use's bytes).  The same invalidation is what XA_CMD_ACQUIRE asks for, so that flag costs nothing extra. */
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-                /* ... and so does the scalar data cache, which no fence touches: wave-uniform record loads (jobs[ji]) are scalar loads */
-                __builtin_amdgcn_s_dcache_inv();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                /* Caches and the resident workgroup.  Job records are read with system-scope loads (xa_ld_record) and what a command produces is
+                 * read back by this same CU, so most commands need no cache maintenance.  The exceptions: a command that asks for it (XA_CMD_ACQUIRE:
+                 * other rows', pictures' and copy engines' writes), copies (their source may be the pinned staging area the host refills in place) and
+                 * the RDOQ / estBit commands, which read host-written tables with plain loads.  Without the invalidation the second use of such a
+                 * buffer reads the first use's bytes (measured).  The scalar data cache is never touched by a fence: see below. */
+                const uint32_t op = go ? reinterpret_cast<const uint32_t*>(&s_cmd)[0] : 0, fl = go ? reinterpret_cast<const uint32_t*>(&s_cmd)[1] : 0;
+                if ((fl & XA_CMD_ACQUIRE) || op == XA_OP_COPY || op == XA_OP_EST_BIT || op == XA_OP_TU_CHAIN_RDOQ || op == XA_OP_INTRA_TU_CHAIN_RDOQ)
+                {
+                    const long long tf = wall_clock64();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    __builtin_amdgcn_s_dcache_inv();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    s_prof[63] += (unsigned long long)(wall_clock64() - tf);
+                }
             }
         }
         __syncthreads();
         if (!s_go) break;
         const uint32_t flags = s_cmd.flags;
         if (s_cmd.op == XA_OP_EXIT) break;
+        const long long td = wall_clock64();
         xa_dispatch(s_cmd, tid);
         /* every wavefront's stores have left before the workgroup reports (results live in host memory, read as soon as the count moves) */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        /* what a copy or fill has just written may be read with SCALAR loads by the commands behind it (plane tables, group lists: wave-uniform
+         * addresses); the scalar data cache is coherent with nothing, so it goes now */
+        if (tid == 0 && (s_cmd.op == XA_OP_COPY || s_cmd.op == XA_OP_COPY2D || s_cmd.op == XA_OP_FILL || s_cmd.op == XA_OP_COPY_RECTS))
+        {
+            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         seen++;
         if (tid == 0)
         {
+            const long long te = wall_clock64();
+            s_prof[2 * (s_cmd.op & 31)] += 1; s_prof[2 * (s_cmd.op & 31) + 1] += (unsigned long long)(te - td);
+            if (s_cmd.reserved & 16)        /* X265AMD_QUEUE_DEBUG & 16: single-job commands of the three hot kinds by block size */
+            {
+                const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(s_cmd.args);
+                int b = -1;
+                if (s_cmd.op == XA_OP_INTRA_SCAN && a.n == 1) b = 20 + (reinterpret_cast<const x265amd_intra_job*>(a.a)->log2_tr_size - 2);
+                else if (s_cmd.op == XA_OP_INTRA_TU_CHAIN) b = 24 + (reinterpret_cast<const x265amd_intra_tu_job*>(a.a)->tu.log2_tr_size - 2);
+                else if (s_cmd.op == XA_OP_CU_MEASURE && a.n == 1) b = 28 + (reinterpret_cast<const CuMeasureJob*>(a.a)->log2_size - 3);
+                if (b >= 20 && b < 31) { s_prof[2 * b] += 1; s_prof[2 * b + 1] += (unsigned long long)(te - td); }
+            }
             if (flags & (XA_CMD_RELEASE | XA_CMD_SIGNAL))
             {
                 /* what the host (results in pinned memory) and other workgroups (pictures) will read leaves this XCD's L2 now: the L2 keeps the lines a
                  * workgroup has stored to host memory, and nothing but a release writes them back while the kernel is resident */
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                s_prof[63] += (unsigned long long)(wall_clock64() - te);
             }
             if (flags & XA_CMD_SIGNAL) xa_sys_store(&rh->tail, seen);
         }
     }
+    __syncthreads();
+    if (tid < 16) s_prof[36 + tid] = xa_stage_acc[tid];        /* [36..51]: the stages of the transform chains */
+    __syncthreads();
+    if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
 }
 
@@ -434,11 +490,14 @@ struct XaQueue
     char* staging = nullptr; size_t stagingUsed = 0, stagingUsedOut = 0;
     std::vector<Deferred> deferred;
     bool busy = false;
+    std::chrono::steady_clock::time_point acquired;
 };
 
 namespace {
 
 void dump_debug_areas(int);
+std::atomic<uint64_t> g_waitNs(0), g_heldNs(0), g_waits(0);
+const bool g_prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
 
 struct Server
 {
@@ -505,7 +564,34 @@ struct Server
         _mm_sfence();
         (void)hipStreamSynchronize(stream);
         running = false;
+        static const bool prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
+        if (prof) profile_report(false);
     }
+    void profile_report(bool final)
+    {
+        static const char* const names[XA_OP_COUNT] = { "nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain",
+                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit" };
+        uint64_t tot[64] = { 0 };
+        for (int i = 0; i < numQueues; i++) for (int k = 0; k < 64; k++) tot[k] += hosts[i].prof[k];
+        uint64_t cmds = 0, ticks = 0;
+        for (int op = 0; op < XA_OP_COUNT; op++) { cmds += tot[2 * op]; ticks += tot[2 * op + 1]; }
+        if (!final && cmds < lastReported + 2000000) return;
+        lastReported = cmds;
+        fprintf(stderr, "x265amd host threads: queues held %.1f ms in all, of which %.1f ms waiting for the device in %llu waits (%.2f us each)\n", g_heldNs.load() / 1e6, g_waitNs.load() / 1e6,
+                (unsigned long long)g_waits.load(), g_waits.load() ? g_waitNs.load() / 1e3 / g_waits.load() : 0.0);
+        fprintf(stderr, "x265amd job server: %llu commands, %.1f ms in command bodies, %.1f ms in fences, %.1f ms polling (all queues; 100 MHz clock)\n", (unsigned long long)cmds,
+                ticks / 1e5, tot[63] / 1e5, tot[62] / 1e5);
+        for (int op = 0; op < XA_OP_COUNT; op++)
+            if (tot[2 * op]) fprintf(stderr, "  %-20s %9llu x %7.2f us = %8.1f ms\n", names[op], (unsigned long long)tot[2 * op], tot[2 * op + 1] / 100.0 / tot[2 * op], tot[2 * op + 1] / 1e5);
+        fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
+                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, elsewhere %.1f\n", tot[36] / 1e5, tot[37] / 1e5, tot[38] / 1e5, tot[39] / 1e5, tot[40] / 1e5,
+                tot[41] / 1e5, tot[42] / 1e5, tot[43] / 1e5, tot[44] / 1e5, tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[51] / 1e5);
+        static const char* const sized[11] = { "intra_scan 4", "intra_scan 8", "intra_scan 16", "intra_scan 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
+                                               "cu_measure 8", "cu_measure 16", "cu_measure 32" };
+        for (int b = 20; b < 31; b++)
+            if (tot[2 * b]) fprintf(stderr, "  (n = 1) %-12s %9llu x %7.2f us = %8.1f ms\n", sized[b - 20], (unsigned long long)tot[2 * b], tot[2 * b + 1] / 100.0 / tot[2 * b], tot[2 * b + 1] / 1e5);
+    }
+    uint64_t lastReported = 0;
 };
 
 Server& server() { static Server* s = new Server; return *s; }
@@ -537,6 +623,7 @@ int q_wait(XaQueue* q, uint64_t target)
     const volatile uint64_t* tail = &q->rh->tail;
     if (*tail >= target) return 0;
     const auto t0 = std::chrono::steady_clock::now();
+    struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { if (g_prof) { g_waitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_waits++; } } } acc{ t0 };
     for (unsigned spins = 0;; spins++)
     {
         if (*tail >= target) break;
@@ -602,6 +689,7 @@ void* xa_queue_acquire()
     f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear();
     S.refs++;
     xa_scratch_local_begin();           /* the calling thread is the one that uses the queue */
+    f->acquired = std::chrono::steady_clock::now();
     return reinterpret_cast<void*>((uintptr_t)f | 1);
 }
 
@@ -615,6 +703,7 @@ void xa_queue_release(void* st)
     Server& S = server();
     std::lock_guard<std::mutex> g(S.m);
     q->busy = false;
+    if (g_prof) g_heldNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - q->acquired).count();
     if (getenv("X265AMD_QUEUE_DEBUG") && q->rh->dbg[63]) fprintf(stderr, "x265amd queue %d: %llu command slot re-reads so far\n", q->idx, (unsigned long long)q->rh->dbg[63]);
     if (--S.refs == 0) S.stop();
 }
@@ -729,6 +818,7 @@ hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes)
 
 extern "C" void* x265amd_queue_acquire(void) { return xa_queue_acquire(); }
 extern "C" void x265amd_queue_release(void* queue) { xa_queue_release(queue); }
+extern "C" void x265amd_queue_profile_report(void) { Server& S = server(); std::lock_guard<std::mutex> g(S.m); if (S.numQueues) S.profile_report(true); }
 
 /* ---- self test (tests/test_device_queue.py): copies, fills and rectangle copies through a queue against the same through a stream ---- */
 extern "C" int x265amd_queue_selftest(int rounds, int numQueues)

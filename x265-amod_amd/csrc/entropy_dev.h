@@ -41,7 +41,7 @@ XA_DEV uint8_t en_next(uint8_t state, uint32_t bin)
 /* one table of a job list on one wavefront */
 XA_DEV void wave_est_bit_job(const x265amd_est_job* jobs, int ji, int lane)
 {
-    const x265amd_est_job j = jobs[ji];
+    const x265amd_est_job j = xa_ld_record(jobs + ji);
     const uint8_t* ctx = reinterpret_cast<const uint8_t*>(j.ctx);
     int32_t* e = reinterpret_cast<int32_t*>(j.est);
     const int log2N = j.log2_tr_size, isLuma = j.is_luma;

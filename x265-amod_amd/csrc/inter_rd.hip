@@ -33,6 +33,21 @@ __global__ __launch_bounds__(64) void k_cu_measure(const CuMeasureJob* jobs, int
     wave_cu_measure_job(jobs, blockIdx.x, out, tile, xa_lane());
 }
 
+/* one CU per workgroup (block_cu_measure_job): the form for a handful of CUs, where the time of one counts */
+#define MEASURE_WG_WAVES 8
+__global__ __launch_bounds__(64 * MEASURE_WG_WAVES) void k_cu_measure_wg(const CuMeasureJob* jobs, int n, CuMeasure* out)
+{
+    __shared__ CuMeasureLds lds;
+    if ((int)blockIdx.x >= n) return;
+    const CuMeasureJob j = xa_ld_record(jobs + blockIdx.x);
+    block_cu_measure_job(j, out + blockIdx.x, lds, threadIdx.x, 64 * MEASURE_WG_WAVES);
+}
+static bool measure_use_wg(int n)
+{
+    static const int wgMax = getenv("X265AMD_MEASURE_WG_MAX") ? atoi(getenv("X265AMD_MEASURE_WG_MAX")) : 64;
+    return n <= wgMax;
+}
+
 /* ---------------- host: the reference's walk ---------------- */
 namespace {
 
@@ -753,7 +768,8 @@ extern "C" int x265amd_measure_tiles(void* stream_, const uint64_t* h_src, intpt
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
     fill_measure_jobs((CuMeasureJob*)mJobs.p, cus, n, h_src, stride, cstride, d_tiles, d_tiles, tile_bytes, nullptr, 0, nullptr);       /* "recon" = the tile itself */
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mJobs.p), (uint64_t)(uintptr_t)((x265amd_cu_measure*)mMeas.p), 0, 0, n }; hipError_t le;
-      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
+      if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
       XA_HIP_CHECK(le); }
     XA_HIP_CHECK(xa_stream_sync(stream_));
     memcpy(out, mMeas.p, sizeof(x265amd_cu_measure) * n);
@@ -771,7 +787,8 @@ extern "C" int x265amd_measure_tile_list(void* stream_, const uint64_t* h_src, i
     CuMeasureJob* jobs = (CuMeasureJob*)mJobs.p;
     for (int i = 0; i < n; i++) fill_measure_jobs(jobs + i, cus + i, 1, h_src, stride, cstride, tile_addrs[i], tile_addrs[i], 0, nullptr, 0, nullptr);
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(jobs), (uint64_t)(uintptr_t)((x265amd_cu_measure*)mMeas.p), 0, 0, n }; hipError_t le;
-      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)jobs, n, (x265amd_cu_measure*)mMeas.p);
+      if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)jobs, n, (x265amd_cu_measure*)mMeas.p);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)jobs, n, (x265amd_cu_measure*)mMeas.p);
       XA_HIP_CHECK(le); }
     XA_HIP_CHECK(xa_stream_sync(stream_));
     memcpy(out, mMeas.p, sizeof(x265amd_cu_measure) * n);
@@ -790,7 +807,8 @@ extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, cons
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n));
     fill_measure_jobs((CuMeasureJob*)mJobs.p, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, nullptr, 0, nullptr);
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mJobs.p), (uint64_t)(uintptr_t)((x265amd_cu_measure*)mMeas.p), 0, 0, n }; hipError_t le;
-      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
+      if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mJobs.p, n, (x265amd_cu_measure*)mMeas.p);
       XA_HIP_CHECK(le); }
     XA_HIP_CHECK(xa_stream_sync(stream_));
     std::vector<x265amd_cu_measure> meas((const x265amd_cu_measure*)mMeas.p, (const x265amd_cu_measure*)mMeas.p + n);
@@ -833,7 +851,8 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     x265amd_cu_measure* meas = (x265amd_cu_measure*)mMeas.p;
     fill_measure_jobs(mjobs, cus, n, h_src, stride, cstride, d_pred, d_recon, tile_bytes, scratch, perCuBytes, (const char*)dSel.p);
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas), 0, 0, n }; hipError_t le;
-      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas);
+      if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, n, meas);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas);
       XA_HIP_CHECK(le); }
     /* the levels (the head of each CU's scratch) come to pinned host memory in one strided copy */
     if (!rdoq) XA_HIP_CHECK(xa_copy2d_to_mapped_async(stream_, mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n));
@@ -888,7 +907,8 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     for (int i = 0; i < n; i++) mjobs[i].assemble = 1;
     XA_HIP_CHECK(xa_copy_async(stream_, dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice));
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + n), 0, 0, n }; hipError_t le;
-      XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas + n);
+      if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, n, meas + n);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas + n);
       XA_HIP_CHECK(le); }
     XA_HIP_CHECK(xa_stream_sync(stream_));
     x265amd_inter_rd_finish(si, rp, cus, n, meas + n, out);

@@ -7,14 +7,15 @@
 
 struct McPlane { const pixel* src[2]; long stride; int xf[2], yf[2]; int w, h; pixel* dst; int dstStride; int c; };
 
-template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& j, int mode, int lsel, int lane)
+/* the samples idx, idx + step, ... of the block: a wavefront takes (lane, 64), several wavefronts sharing a block (sub * 64 + lane, waves * 64) */
+template<int TAPS> XA_DEV void mc_plane(const McPlane& p, const x265amd_mc_job& j, int mode, int lsel, int idx, int step)
 {
     /* mode 0: pixel path from list lsel; 1: weighted uni from list lsel; 2: bi average; 3: weighted bi;
      * 4: pixel average of the two pixel-path predictions (pixelavg_pp of two predInterLumaPixel, search.cpp:2499-2511) */
     const int c = p.c;
     const int shiftNum = XA_IF_INTERNAL_PREC - XA_DEPTH;
     int inv = ((1 << 20) + p.w - 1) / p.w;
-    for (int i = lane; i < p.w * p.h; i += XA_WAVE)
+    for (int i = idx; i < p.w * p.h; i += step)
     {
         int y = (i * inv) >> 20, x = i - y * p.w;
         int v;
@@ -61,13 +62,14 @@ struct XaArgsMc
     const uint64_t* fencPlanes; long fstride, fcstride; uint32_t* cost;
 };
 
-/* one job of a list on one wavefront */
+/* one job of a list on one wavefront (idx = lane, step = 64), or -- prediction only -- on the `step / 64` wavefronts that share it */
 template<bool COST>
-XA_DEV void wave_mc_job(const XaArgsMc& a, int ji, int lane)
+XA_DEV void wave_mc_job(const XaArgsMc& a, int ji, int idx, int step = XA_WAVE)
 {
+    const int lane = idx & 63;
     const uint64_t* planes = a.planes; const long stride = a.stride, cstride = a.cstride; const int picW = a.picW, picH = a.picH;
     const uint64_t* fencPlanes = a.fencPlanes; const long fstride = a.fstride, fcstride = a.fcstride; uint32_t* cost = a.cost;
-    const x265amd_mc_job j = a.jobs[ji];
+    const x265amd_mc_job j = xa_ld_record(a.jobs + ji);
     const int refs[2] = { j.ref0, j.ref1 };
     int mv[2][2] = { { j.mv0[0], j.mv0[1] }, { j.mv1[0], j.mv1[1] } };
     /* CUData::clipMv */
@@ -107,7 +109,7 @@ XA_DEV void wave_mc_job(const XaArgsMc& a, int ji, int lane)
             p.xf[l] = mv[l][0] & 3; p.yf[l] = mv[l][1] & 3;
         }
         p.stride = stride; p.w = j.w; p.h = j.h; p.dst = reinterpret_cast<pixel*>(j.dst_y); p.dstStride = j.dst_stride; p.c = 0;
-        mc_plane<8>(p, j, mode, lsel, lane);
+        mc_plane<8>(p, j, mode, lsel, idx, step);
     }
     if (doChroma)
         for (int c = 1; c < 3; c++)
@@ -118,7 +120,7 @@ XA_DEV void wave_mc_job(const XaArgsMc& a, int ji, int lane)
                 p.xf[l] = mv[l][0] & 7; p.yf[l] = mv[l][1] & 7;
             }
             p.stride = cstride; p.w = j.w >> 1; p.h = j.h >> 1; p.dst = reinterpret_cast<pixel*>(c == 1 ? j.dst_u : j.dst_v); p.dstStride = j.dst_cstride; p.c = c;
-            mc_plane<4>(p, j, mode, lsel, lane);
+            mc_plane<4>(p, j, mode, lsel, idx, step);
         }
     if constexpr (COST)
     {

@@ -129,6 +129,46 @@ template<> XA_DEV int xa_wave_sum<int>(int v)
 }
 template<> XA_DEV uint32_t xa_wave_sum<uint32_t>(uint32_t v) { return (uint32_t)xa_wave_sum<int>((int)v); }
 
+
+
+/* A job record as the host last wrote it: system-scope loads (sc0 sc1), which no cache level serves.  The records of the device job queues are
+ * rewritten in place by the host between commands while the reading workgroup stays resident with its caches; in an ordinary kernel the loads are
+ * merely uncached.  T: a multiple of 8 bytes, 8-byte aligned. */
+template<class T> XA_DEV T xa_ld_record(const T* p)
+{
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) >= 8, "job records are sequences of 64-bit words");
+    union { T v; uint64_t w[sizeof(T) / 8]; } u;
+    const uint64_t* s = reinterpret_cast<const uint64_t*>(p);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 8; i++) u.w[i] = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return u.v;
+}
+
+/* ---- Hadamard transforms ACROSS the lanes of a wavefront (one sample per lane): the workgroup-per-block forms of the kernels, where the time of one
+ * block counts.  A butterfly stage exchanges with the lane whose index differs in bit M: DPP where one instruction does it, the LDS crossbar
+ * otherwise.  The stages over bits 1, 2, 4 transform rows of 8, the stages over 8, 16, 32 the columns: all six give the 8x8 Hadamard of the wave's
+ * 64 samples (one coefficient per lane, some order), four the 4x4 Hadamard of each group of 16 lanes.  Sums of absolute coefficients do not depend on
+ * the order. ---- */
+template<int M> XA_DEV int xa_lane_xor(int v)
+{
+    if (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);     /* quad_perm [1,0,3,2] */
+    if (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);     /* quad_perm [2,3,0,1] */
+    if (M == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);    /* row_ror:8 */
+    return __shfl_xor(v, M, 64);
+}
+template<int M> XA_DEV int xa_butterfly(int v, int lane) { const int o = xa_lane_xor<M>(v); return (lane & M) ? o - v : v + o; }
+XA_DEV int xa_lane_had8x8(int v, int lane)
+{
+    v = xa_butterfly<1>(v, lane); v = xa_butterfly<2>(v, lane); v = xa_butterfly<4>(v, lane);
+    v = xa_butterfly<8>(v, lane); v = xa_butterfly<16>(v, lane); v = xa_butterfly<32>(v, lane);
+    return v;
+}
+XA_DEV int xa_lane_had4x4(int v, int lane)
+{
+    v = xa_butterfly<1>(v, lane); v = xa_butterfly<2>(v, lane); v = xa_butterfly<4>(v, lane); v = xa_butterfly<8>(v, lane);
+    return v;
+}
+
 XA_DEV int xa_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 XA_DEV pixel xa_clip_pixel(int v) { return (pixel)xa_clip3(0, XA_PIXEL_MAX, v); }
 
@@ -490,62 +530,120 @@ XA_DEV void wave_intra_pred(const pixel* s, pixel* swapped, int cu, int mode, in
 
 
 /* ---- block metrics shared by the job-list and the fused TU kernels ---- */
-XA_DEV uint64_t wave_sse_pp(const pixel* a, int sa, const pixel* b, int sb, int size, int lane)     /* pixel.cpp:167-186 */
+
+/* ---- thread groups: the transform-chain helpers run on one wavefront (XaWave: a batch of many blocks, one per wavefront) or on a whole workgroup
+ * (XaBlock: the device job queues, where a command carries a few large blocks and the time of one counts).  A group strides over samples with
+ * idx / step(), orders its LDS traffic with sync() and reduces with sum() / maxv(). ---- */
+struct XaWave
+{
+    int idx;
+    XA_DEV int step() const { return XA_WAVE; }
+    XA_DEV int wave() const { return 0; }
+    XA_DEV int waves() const { return 1; }
+    XA_DEV void sync() const { xa_wave_sync(); }
+    XA_DEV int sum(int v) const { return xa_wave_sum(v); }
+    XA_DEV uint32_t sum(uint32_t v) const { return xa_wave_sum(v); }
+    XA_DEV uint64_t sum(uint64_t v) const { return xa_wave_sum(v); }
+    XA_DEV int maxv(int v) const
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+        return v;
+    }
+};
+struct XaBlock
+{
+    int idx, nthr;
+    unsigned long long* red;        /* LDS: nthr / 64 words */
+    XA_DEV int step() const { return nthr; }
+    XA_DEV int wave() const { return idx >> 6; }
+    XA_DEV int waves() const { return nthr >> 6; }
+    XA_DEV void sync() const { __syncthreads(); }
+    XA_DEV uint64_t sum(uint64_t v) const
+    {
+        v = xa_wave_sum(v);
+        if ((idx & 63) == 0) red[idx >> 6] = v;
+        __syncthreads();
+        uint64_t t = 0;
+        for (int w = 0; w < (nthr >> 6); w++) t += red[w];
+        __syncthreads();
+        return t;
+    }
+    XA_DEV int sum(int v) const { return (int)(int64_t)sum((uint64_t)(int64_t)v); }
+    XA_DEV uint32_t sum(uint32_t v) const { return (uint32_t)sum((uint64_t)v); }
+    XA_DEV int maxv(int v) const
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+        if ((idx & 63) == 0) red[idx >> 6] = (unsigned long long)(long long)v;
+        __syncthreads();
+        int t = (int)(long long)red[0];
+        for (int w = 1; w < (nthr >> 6); w++) t = max(t, (int)(long long)red[w]);
+        __syncthreads();
+        return t;
+    }
+};
+
+template<class G> XA_DEV uint64_t grp_sse_pp(const pixel* a, int sa, const pixel* b, int sb, int size, const G& g)     /* pixel.cpp:167-186 */
 {
     uint64_t sum = 0;
     int n = size * size, sh = 31 - __clz(size);
-    for (int i = lane; i < n; i += XA_WAVE)
+    for (int i = g.idx; i < n; i += g.step())
     {
         int y = i >> sh, x = i & (size - 1);
         int t = (int)a[y * sa + x] - (int)b[y * sb + x];
         sum += (uint64_t)(uint32_t)(t * t);
     }
-    sum = xa_wave_sum(sum);
+    sum = g.sum(sum);
 #if XA_DEPTH <= 8
     sum = (uint32_t)sum;        /* sse_t is uint32_t below 10 bits (common/common.h:142-146) */
 #endif
     return sum;
 }
+XA_DEV uint64_t wave_sse_pp(const pixel* a, int sa, const pixel* b, int sb, int size, int lane) { return grp_sse_pp(a, sa, b, sb, size, XaWave{ lane }); }
 
 /* pixel.cpp:744-775 */
-XA_DEV int wave_psy_cost(const pixel* src, int ss, const pixel* rec, int rs, int cu, int lane)
+/* psyCost_pp (pixel.cpp:744-775): per 8x8 tile |(sa8d(src) - sad(src) / 4) - (sa8d(rec) - sad(rec) / 4)| with the "sa8d" and "sad" of a block against
+ * zeros, i.e. the sum of its absolute Hadamard coefficients and the sum of its samples (4x4 blocks: satd).  One wavefront per tile, one lane per sample:
+ * the Hadamard runs across the lanes, and its coefficient 0 (lane 0) IS the sum of the samples. */
+template<class G> XA_DEV int grp_psy_cost(const pixel* src, int ss, const pixel* rec, int rs, int cu, const G& g)
 {
+    const int lane = g.idx & 63;
+    int acc = 0;
     if (cu == 0)
     {
-        int v = 0;
-        if (lane == 0)
+        if (g.wave() == 0)
         {
-            int sadS = 0, sadR = 0;
-            for (int y = 0; y < 4; y++)
-                for (int x = 0; x < 4; x++) { sadS += src[y * ss + x]; sadR += rec[y * rs + x]; }
-            int se = (xa_had4_abs<false>(src, ss, nullptr, 0) >> 1) - (sadS >> 2);
-            int re = (xa_had4_abs<false>(rec, rs, nullptr, 0) >> 1) - (sadR >> 2);
-            v = abs(se - re);
+            const int l = lane & 15, y = l >> 2, x = l & 3;
+            const int hs = xa_lane_had4x4((int)src[y * ss + x], lane), hr = xa_lane_had4x4((int)rec[y * rs + x], lane);
+            const int sumS = xa_row16_sum(abs(hs)), sumR = xa_row16_sum(abs(hr));
+            const int sadS = __builtin_amdgcn_readfirstlane(hs), sadR = __builtin_amdgcn_readfirstlane(hr);
+            const int se = (__builtin_amdgcn_readfirstlane(sumS) >> 1) - (sadS >> 2), re = (__builtin_amdgcn_readfirstlane(sumR) >> 1) - (sadR >> 2);
+            acc = abs(se - re);
         }
-        return __shfl(v, 0, 64);
     }
-    int tiles = 1 << (cu - 1), nt = tiles * tiles, v = 0;      /* 8x8 tiles per row */
-    if (lane < nt)
+    else
     {
-        int ty = lane / tiles, tx = lane - ty * tiles;
-        const pixel* s = src + 8 * ty * ss + 8 * tx;
-        const pixel* r = rec + 8 * ty * rs + 8 * tx;
-        int sadS = 0, sadR = 0;
-        for (int y = 0; y < 8; y++)
-            for (int x = 0; x < 8; x++) { sadS += s[y * ss + x]; sadR += r[y * rs + x]; }
-        int se = ((xa_had8_abs<false>(s, ss, nullptr, 0) + 2) >> 2) - (sadS >> 2);
-        int re = ((xa_had8_abs<false>(r, rs, nullptr, 0) + 2) >> 2) - (sadR >> 2);
-        v = abs(se - re);
+        const int tiles = 1 << (cu - 1), nt = tiles * tiles, ly = lane >> 3, lx = lane & 7;
+        for (int t = g.wave(); t < nt; t += g.waves())
+        {
+            const int ty = t / tiles, tx = t - ty * tiles;
+            const int hs = xa_lane_had8x8((int)src[(8 * ty + ly) * ss + 8 * tx + lx], lane), hr = xa_lane_had8x8((int)rec[(8 * ty + ly) * rs + 8 * tx + lx], lane);
+            const int sumS = xa_wave_sum(abs(hs)), sumR = xa_wave_sum(abs(hr));
+            const int sadS = __builtin_amdgcn_readfirstlane(hs), sadR = __builtin_amdgcn_readfirstlane(hr);
+            acc += abs((((sumS + 2) >> 2) - (sadS >> 2)) - (((sumR + 2) >> 2) - (sadR >> 2)));
+        }
     }
-    return xa_wave_sum(v);
+    return g.sum(lane == 0 ? acc : 0);
 }
+XA_DEV int wave_psy_cost(const pixel* src, int ss, const pixel* rec, int rs, int cu, int lane) { return grp_psy_cost(src, ss, rec, rs, cu, XaWave{ lane }); }
 
 
 /* ---- transform passes (dct.cpp:83-440 partial butterflies == exact integer matrix products) ---- */
-XA_DEV void wave_fwd_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int shift, int lane)
+template<class G> XA_DEV void grp_fwd_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int shift, const G& g)
 {
     int N = 1 << log2N, add = 1 << (shift - 1);
-    for (int i = lane; i < N * N; i += XA_WAVE)
+    for (int i = g.idx; i < N * N; i += g.step())
     {
         int k = i >> log2N, jj = i & (N - 1);   /* consecutive lanes: consecutive j (dst row k contiguous) */
         int sum = 0;
@@ -554,11 +652,12 @@ XA_DEV void wave_fwd_pass(const int16_t* T, int log2N, const int16_t* src, int16
         dst[k * N + jj] = (int16_t)((sum + add) >> shift);
     }
 }
+XA_DEV void wave_fwd_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int shift, int lane) { grp_fwd_pass(T, log2N, src, dst, shift, XaWave{ lane }); }
 
-XA_DEV void wave_inv_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int dstStride, int shift, int lane)
+template<class G> XA_DEV void grp_inv_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int dstStride, int shift, const G& g)
 {
     int N = 1 << log2N, add = 1 << (shift - 1);
-    for (int i = lane; i < N * N; i += XA_WAVE)
+    for (int i = g.idx; i < N * N; i += g.step())
     {
         int jj = i >> log2N, nn = i & (N - 1);
         int sum = 0;
@@ -567,6 +666,7 @@ XA_DEV void wave_inv_pass(const int16_t* T, int log2N, const int16_t* src, int16
         dst[jj * dstStride + nn] = (int16_t)xa_clip3(-32768, 32767, (sum + add) >> shift);
     }
 }
+XA_DEV void wave_inv_pass(const int16_t* T, int log2N, const int16_t* src, int16_t* dst, int dstStride, int shift, int lane) { grp_inv_pass(T, log2N, src, dst, dstStride, shift, XaWave{ lane }); }
 
 
 #endif /* X265AMD_DEV_H */
