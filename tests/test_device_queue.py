@@ -33,3 +33,21 @@ def test_stream_path_still_reproduces_reference_stream():
 
 def test_selftest_symbol_is_exported():
     assert hasattr(C.CDLL(T.hip_path(8)), "x265amd_queue_selftest")
+
+
+@pytest.mark.gpu
+def test_repeated_encodes_are_identical():
+    """the same clip eight times in one process (warm buffer pools, the job server restarted between pictures): every stream must be the reference
+    encoder's.  A transport fault shows here as an occasional different stream -- a command slot accepted half written did exactly that once."""
+    import hashlib
+    import numpy as np
+    import test_encoder_api as E
+    g = np.load(E.EDGE_GOLD)
+    tag = "wvga/"
+    (w, h), n, cfg = E.EDGE_CONFIGS[tag]
+    want = hashlib.md5(g[tag + "stream"].tobytes()).hexdigest()
+    clip = T.encoder_api_clip(tag, w, h, n, 8)
+    L = T.load_hip(8)
+    for r in range(8):
+        stream, _ = T.encoder_run(L, clip, w, h, **cfg)
+        assert hashlib.md5(stream.tobytes()).hexdigest() == want, "run %d" % r

@@ -1293,8 +1293,10 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
                     if (row)
                     {
                         const int need = c + 2 < ctuW ? c + 2 : ctuW;
+                        const auto w0 = std::chrono::steady_clock::now();
                         std::unique_lock<std::mutex> lk(m);
                         cv.wait(lk, [&] { return done[row - 1] >= need || firstErr.load() != X265AMD_OK; });
+                        xa_prof_dependency_wait((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
                     }
                     int r = firstErr.load();
                     if (r == X265AMD_OK) r = doCtu(row * ctuW + c, st);

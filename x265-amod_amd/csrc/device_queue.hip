@@ -35,9 +35,22 @@ __device__ uint64_t* xa_dbg_area[256];                                /* per wor
 XA_DEV uint64_t xa_sys_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 XA_DEV void xa_sys_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-/* byte copies by the whole workgroup: 16 bytes per lane where both sides allow it */
-XA_DEV void block_copy(char* dst, const char* src, size_t bytes, int tid, int nthr)
+/* byte copies by the whole workgroup: 16 bytes per lane where both sides allow it.  HOSTDST: the destination is pinned host memory (results the host
+ * reads as soon as the command has signalled): system-scope stores, 8 bytes per lane */
+template<bool HOSTDST> XA_DEV void block_copy(char* dst, const char* src, size_t bytes, int tid, int nthr)
 {
+    if (HOSTDST)
+    {
+        if ((((uintptr_t)dst | (uintptr_t)src) & 7) == 0)
+        {
+            const size_t n8 = bytes >> 3;
+            for (size_t i = tid; i < n8; i += nthr) xa_sys_store(reinterpret_cast<uint64_t*>(dst) + i, reinterpret_cast<const uint64_t*>(src)[i]);
+            for (size_t i = (n8 << 3) + tid; i < bytes; i += nthr) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        else
+            for (size_t i = tid; i < bytes; i += nthr) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0)
     {
         const size_t n16 = bytes >> 4;
@@ -73,7 +86,7 @@ __device__ __noinline__ void xa_op_copy(const XaCmd& c, int tid)
     (void)serial;
     {
         const XaArgsCopy& a = *reinterpret_cast<const XaArgsCopy*>(c.args);
-        block_copy(reinterpret_cast<char*>(a.dst), reinterpret_cast<const char*>(a.src), a.bytes, tid, NT);
+        block_copy<false>(reinterpret_cast<char*>(a.dst), reinterpret_cast<const char*>(a.src), a.bytes, tid, NT);
     }
 }
 
@@ -87,7 +100,7 @@ __device__ __noinline__ void xa_op_copy2d(const XaCmd& c, int tid)
     {
         const XaArgsCopy2D& a = *reinterpret_cast<const XaArgsCopy2D*>(c.args);
         for (uint64_t y = wv; y < a.height; y += XA_SERVER_WAVES)
-            block_copy(reinterpret_cast<char*>(a.dst + y * a.dpitch), reinterpret_cast<const char*>(a.src + y * a.spitch), a.width, lane, 64);
+            block_copy<false>(reinterpret_cast<char*>(a.dst + y * a.dpitch), reinterpret_cast<const char*>(a.src + y * a.spitch), a.width, lane, 64);
     }
 }
 
@@ -344,7 +357,7 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
     }
 }
 
-/* One workgroup per queue.  Wavefront 0 polls the ring head (a relaxed system-scope load of its own device memory), copies the next command into LDS
+/* One workgroup per queue.  Wavefront 0 polls the slot of the next command (relaxed system-scope loads of its own device memory), copies it into LDS
  * and the workgroup runs it.  A workgroup leaves when its queue's quit word is set or when it has seen no command for `idleTicks` of the 100 MHz
  * wall clock (nothing resident outlives a host that went away). */
 __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* rings, XaRingHost* hosts, long long idleTicks, uint64_t generation)
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     XaRingDev* rd = rings + blockIdx.x;
     XaRingHost* rh = hosts + blockIdx.x;
     const int tid = threadIdx.x;
-    uint64_t seen = 0, rereads = 0;
+    uint64_t seen = 0;
     if (tid < 64) s_prof[tid] = 0;
     if (tid < 16) xa_stage_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
@@ -365,41 +378,37 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     {
         if (tid < 64)
         {
-            int go = 1;
-            if (tid == 0)
+            /* Wavefront 0 polls the next command's SLOT (relaxed system-scope loads of the workgroup's own uncached memory): the slot's check word closes
+             * over its other fifteen words, this command's number and the server generation, so a slot that passes is the command, complete -- no
+             * separate head word to read first (one memory latency less per command), and a slot caught half written just fails and is read again. */
+            int go = 0;
+            const uint64_t* slot = reinterpret_cast<const uint64_t*>(&rd->cmd[seen % XA_RING]);
+            const long long t0 = wall_clock64();
+            for (unsigned spins = 1;; spins++)
             {
-                const long long t0 = wall_clock64();
-                unsigned spins = 0;
-                for (;;)
+                const uint64_t w = tid < 16 ? xa_sys_load(slot + tid) : 0;
+                /* position-weighted sum of the fifteen words (each times its own odd constant): a slot caught between two commands -- some words of the
+                 * old one, some of the new -- does not pass.  A plain xor did: tile-to-tile copies change `dst` and `src` by the same bits, the two
+                 * changes cancelled, and a half-arrived slot ran with the old addresses (one corrupted stream in five at 832x480). */
+                uint64_t x = tid < 15 ? w * (XA_CHECK_MUL * (uint64_t)(2 * tid + 1)) : 0;
+                x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+                const uint64_t want = __shfl(x, 0, 64) ^ (XA_CHECK_MUL * (seen + 1)) ^ generation;
+                if (__shfl(w, 15, 64) == want)
                 {
-                    if (xa_sys_load(&rd->head) > seen) { s_prof[62] += (unsigned long long)(wall_clock64() - t0); break; }
-                    if (xa_sys_load(&rd->quit)) { go = 0; break; }
-                    if ((++spins & 1023) == 0 && wall_clock64() - t0 > idleTicks) { go = 0; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    if (tid < 16) reinterpret_cast<uint64_t*>(&s_cmd)[tid] = w;
+                    xa_wave_sync();
+                    go = 1;
+                    break;
                 }
-            }
-            go = __shfl(go, 0, 64);
-            if (go)
-            {
-                /* the slot, until its check word closes over the other fifteen and this command's number */
-                const uint64_t* slot = reinterpret_cast<const uint64_t*>(&rd->cmd[seen % XA_RING]);
-                for (unsigned tries = 0;; tries++)
+                if ((spins & 63) == 0)
                 {
-                    const uint64_t w = tid < 16 ? xa_sys_load(slot + tid) : 0;
-                    uint64_t x = tid < 15 ? w : 0;
-                    x ^= __shfl_xor(x, 1, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 8, 64);
-                    const uint64_t want = __shfl(x, 0, 64) ^ (XA_CHECK_MUL * (seen + 1)) ^ generation;
-                    const uint64_t got = __shfl(w, 15, 64);
-                    if (got == want)
-                    {
-                        if (tid < 16) reinterpret_cast<uint64_t*>(&s_cmd)[tid] = w;
-                        xa_wave_sync();
-                        if (tries && tid == 0) { rereads += tries; xa_sys_store(&rh->dbg[63], rereads); }     /* how often a slot was not complete yet */
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
+                    int stop = 0;
+                    if (tid == 0) stop = xa_sys_load(&rd->quit) != 0 || wall_clock64() - t0 > idleTicks;
+                    if (__shfl(stop, 0, 64)) break;
                 }
+                __builtin_amdgcn_s_sleep(1);
             }
+            if (tid == 0) s_prof[62] += (unsigned long long)(wall_clock64() - t0);
             if (tid == 0)
             {
                 s_go = go;
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                  * the RDOQ / estBit commands, which read host-written tables with plain loads.  Without the invalidation the second use of such a
                  * buffer reads the first use's bytes (measured).  The scalar data cache is never touched by a fence: see below. */
                 const uint32_t op = go ? reinterpret_cast<const uint32_t*>(&s_cmd)[0] : 0, fl = go ? reinterpret_cast<const uint32_t*>(&s_cmd)[1] : 0;
-                if ((fl & XA_CMD_ACQUIRE) || op == XA_OP_COPY || op == XA_OP_EST_BIT || op == XA_OP_TU_CHAIN_RDOQ || op == XA_OP_INTRA_TU_CHAIN_RDOQ)
+                if ((fl & XA_CMD_ACQUIRE) || (reinterpret_cast<const uint32_t*>(&s_cmd)[3] & 32) || op == XA_OP_COPY || op == XA_OP_EST_BIT || op == XA_OP_TU_CHAIN_RDOQ || op == XA_OP_INTRA_TU_CHAIN_RDOQ)
                 {
                     const long long tf = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -452,7 +461,8 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
             if (flags & (XA_CMD_RELEASE | XA_CMD_SIGNAL))
             {
                 /* what the host (results in pinned memory) and other workgroups (pictures) will read leaves this XCD's L2 now: the L2 keeps the lines a
-                 * workgroup has stored to host memory, and nothing but a release writes them back while the kernel is resident */
+                 * workgroup has stored to host memory, and nothing but a release writes them back while the kernel is resident.  (Storing the
+                 * results with system scope instead was measured: slower, every store then waits for the host's acknowledgement.) */
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 s_prof[63] += (unsigned long long)(wall_clock64() - te);
@@ -496,7 +506,7 @@ struct XaQueue
 namespace {
 
 void dump_debug_areas(int);
-std::atomic<uint64_t> g_waitNs(0), g_heldNs(0), g_waits(0);
+std::atomic<uint64_t> g_waitNs(0), g_heldNs(0), g_waits(0), g_depNs(0);
 const bool g_prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
 
 struct Server
@@ -548,7 +558,6 @@ struct Server
             XaQueue& x = q[i];
             x.submitted = 0; x.lastSignal = 0; x.generation = generation;
             x.rh->tail = 0; x.rh->state = 0; x.rh->dbg[63] = 0;
-            *reinterpret_cast<volatile uint64_t*>(&rings[i].head) = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].quit) = 0;
         }
         _mm_sfence();
@@ -577,8 +586,8 @@ struct Server
         for (int op = 0; op < XA_OP_COUNT; op++) { cmds += tot[2 * op]; ticks += tot[2 * op + 1]; }
         if (!final && cmds < lastReported + 2000000) return;
         lastReported = cmds;
-        fprintf(stderr, "x265amd host threads: queues held %.1f ms in all, of which %.1f ms waiting for the device in %llu waits (%.2f us each)\n", g_heldNs.load() / 1e6, g_waitNs.load() / 1e6,
-                (unsigned long long)g_waits.load(), g_waits.load() ? g_waitNs.load() / 1e3 / g_waits.load() : 0.0);
+        fprintf(stderr, "x265amd host threads: queues held %.1f ms in all, of which %.1f ms waiting for the row above, %.1f ms waiting for the device in %llu waits (%.2f us each)\n",
+                g_heldNs.load() / 1e6, g_depNs.load() / 1e6, g_waitNs.load() / 1e6, (unsigned long long)g_waits.load(), g_waits.load() ? g_waitNs.load() / 1e3 / g_waits.load() : 0.0);
         fprintf(stderr, "x265amd job server: %llu commands, %.1f ms in command bodies, %.1f ms in fences, %.1f ms polling (all queues; 100 MHz clock)\n", (unsigned long long)cmds,
                 ticks / 1e5, tot[63] / 1e5, tot[62] / 1e5);
         for (int op = 0; op < XA_OP_COUNT; op++)
@@ -652,23 +661,26 @@ int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* 
     {
         const uint64_t* w = reinterpret_cast<const uint64_t*>(&c);
         uint64_t x = 0;
-        for (int i = 0; i < 15; i++) x ^= w[i];
+        for (int i = 0; i < 15; i++) x += w[i] * (XA_CHECK_MUL * (uint64_t)(2 * i + 1));
         c.check = x ^ (XA_CHECK_MUL * (q->submitted + 1)) ^ q->generation;
     }
+    /* everything the command refers to (job records pushed through the BAR, staging and other host memory) is globally visible before the slot:
+     * the slot is what the workgroup polls, and write-combining buffers drain in no particular order */
+    _mm_sfence();
     XaCmd* slot = &q->rd->cmd[q->submitted % XA_RING];
     /* 128 bytes through the write-combining BAR mapping, then the doorbell behind a store fence */
     const __m128i* s = reinterpret_cast<const __m128i*>(&c);
     __m128i* d = reinterpret_cast<__m128i*>(slot);
     for (int i = 0; i < 8; i++) _mm_store_si128(d + i, _mm_load_si128(s + i));
-    _mm_sfence();
+    _mm_sfence();                       /* the slot is the doorbell: out of the write-combining buffer now */
     q->submitted++;
-    *reinterpret_cast<volatile uint64_t*>(&q->rd->head) = q->submitted;
-    _mm_sfence();
     if (flags & XA_CMD_SIGNAL) q->lastSignal = q->submitted;
     return 0;
 }
 
 } // namespace
+
+void xa_prof_dependency_wait(uint64_t ns) { if (g_prof) g_depNs += ns; }
 
 bool xa_queues_enabled()
 {
@@ -773,7 +785,7 @@ hipError_t xa_copy_async(void* st, void* dst, const void* src, size_t bytes, hip
     if (!xa_is_queue(st)) return hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)st);
     if (!bytes) return hipSuccess;
     XaQueue* q = as_queue(st);
-    XaArgsCopy a = { (uint64_t)(uintptr_t)dst, (uint64_t)(uintptr_t)src, bytes };
+    XaArgsCopy a = { (uint64_t)(uintptr_t)dst, (uint64_t)(uintptr_t)src, bytes, kind == hipMemcpyDeviceToHost ? 1u : 0u };
     if (kind == hipMemcpyHostToDevice)
     {
         /* pageable source: through this queue's pinned staging area (the call returns with the source free to change, as hipMemcpyAsync does) */
@@ -819,6 +831,40 @@ hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes)
 extern "C" void* x265amd_queue_acquire(void) { return xa_queue_acquire(); }
 extern "C" void x265amd_queue_release(void* queue) { xa_queue_release(queue); }
 extern "C" void x265amd_queue_profile_report(void) { Server& S = server(); std::lock_guard<std::mutex> g(S.m); if (S.numQueues) S.profile_report(true); }
+
+
+/* ---- coherence probe (dbg): does a resident workgroup see what a copy engine / another kernel wrote into a buffer it has read before?
+ * mode 0: hipMemcpy host -> device; mode 1: a kernel on another stream.  Returns the number of stale rounds out of `rounds`. ---- */
+__global__ void k_probe_fill(uint32_t* p, int n, uint32_t v) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v + (uint32_t)i; }
+extern "C" int x265amd_queue_coherence_probe(int rounds, int mode, int bytes)
+{
+    void* st = xa_queue_acquire();
+    if (!st) return -1;
+    void* dX = nullptr; void* mapped = nullptr;
+    const int n = bytes / 4;
+    if (hipMalloc(&dX, bytes) != hipSuccess || xa_mapped_alloc(&mapped, bytes, true) != hipSuccess) return -2;
+    hipStream_t other; (void)hipStreamCreateWithFlags(&other, hipStreamNonBlocking);
+    std::vector<uint32_t> h(n);
+    int stale = 0;
+    for (int r = 0; r < rounds; r++)
+    {
+        const uint32_t v = 0x1000000u * (uint32_t)(r + 1);
+        if (mode == 0) { for (int i = 0; i < n; i++) h[i] = v + (uint32_t)i; (void)hipMemcpy(dX, h.data(), bytes, hipMemcpyHostToDevice); }
+        else { hipLaunchKernelGGL(k_probe_fill, dim3(64), dim3(256), 0, other, (uint32_t*)dX, n, v); (void)hipStreamSynchronize(other); }
+        (void)xa_stream_fence(st, XA_CMD_ACQUIRE);
+        XaArgsCopy a = { (uint64_t)(uintptr_t)mapped, (uint64_t)(uintptr_t)dX, (uint64_t)bytes, 1 };
+        (void)xa_q_enqueue(st, XA_OP_COPY, &a, sizeof(a), 1, 0);
+        (void)xa_stream_sync(st);
+        const uint32_t* got = (const uint32_t*)mapped;
+        bool bad = false;
+        for (int i = 0; i < n; i++) if (got[i] != v + (uint32_t)i) { bad = true; break; }
+        stale += bad;
+    }
+    (void)hipStreamDestroy(other);
+    xa_queue_release(st);
+    xa_mapped_free(mapped); (void)hipFree(dX);
+    return stale;
+}
 
 /* ---- self test (tests/test_device_queue.py): copies, fills and rectangle copies through a queue against the same through a stream ---- */
 extern "C" int x265amd_queue_selftest(int rounds, int numQueues)

@@ -144,6 +144,22 @@ template<class T> XA_DEV T xa_ld_record(const T* p)
     return u.v;
 }
 
+
+/* Results the host reads (pinned host memory): system-scope stores, written through every cache level.  A resident workgroup has no kernel boundary
+ * to flush for it, and its L2 otherwise keeps the lines it has stored to host memory. */
+template<class T> XA_DEV void xa_st_result(T* p, const T& v)
+{
+    if constexpr (sizeof(T) % 8 == 0 && alignof(T) >= 8)
+    {
+        union { T v; uint64_t w[sizeof(T) / 8]; } u;
+        u.v = v;
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 8; i++) __hip_atomic_store(reinterpret_cast<uint64_t*>(p) + i, u.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    else
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* ---- Hadamard transforms ACROSS the lanes of a wavefront (one sample per lane): the workgroup-per-block forms of the kernels, where the time of one
  * block counts.  A butterfly stage exchanges with the lane whose index differs in bit M: DPP where one instruction does it, the LDS crossbar
  * otherwise.  The stages over bits 1, 2, 4 transform rows of 8, the stages over 8, 16, 32 the columns: all six give the 8x8 Hadamard of the wave's

@@ -31,9 +31,10 @@ enum
 #define XA_SERVER_WAVES 8
 #define XA_SERVER_LDS (144 * 1024)
 
-/* `check` closes the command: XA_CHECK_MUL * (number of this command, from 1) xor all fifteen words before it.  The host's stores reach device memory
- * through the BAR; a workgroup that has seen the ring head move is not promised that the slot's sixteen words have all landed where its loads look
- * (observed: a command read back partly as the slot's previous content), so it reads the slot until the check holds. */
+/* `check` closes the command: the sum of its other fifteen words, each times its own odd constant (XA_CHECK_MUL * (2 i + 1)), xor XA_CHECK_MUL * (number
+ * of this command, from 1) xor the server generation.  The workgroup polls the slot itself: the host's stores reach device memory through write-combining
+ * buffers in no particular order, so a slot may be seen half old, half new -- it is read again until the check holds.  The weights matter: with a plain
+ * xor, two address words that changed by the same bits cancelled and a half-arrived copy command ran with the previous addresses. */
 struct alignas(128) XaCmd { uint32_t op, flags, count, reserved; uint64_t args[XA_CMD_ARG_WORDS]; uint64_t check; };
 #define XA_CHECK_MUL 0x9E3779B97F4A7C15ull
 
@@ -41,7 +42,7 @@ struct alignas(128) XaCmd { uint32_t op, flags, count, reserved; uint64_t args[X
 struct alignas(128) XaRingDev
 {
     XaCmd cmd[XA_RING];
-    uint64_t head; uint64_t pad0[15];           /* commands submitted so far */
+    uint64_t head; uint64_t pad0[15];           /* unused (the slots themselves are polled) */
     uint64_t quit; uint64_t pad1[15];
 };
 /* pinned host memory, written by the workgroup, polled by the host thread */
@@ -55,7 +56,7 @@ struct alignas(128) XaRingHost
 };
 
 struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, second array, results, extra, count) shapes of the job-list kernels */
-struct XaArgsCopy { uint64_t dst, src, bytes; };
+struct XaArgsCopy { uint64_t dst, src, bytes; uint32_t hostDst; };
 struct XaArgsCopy2D { uint64_t dst, src, dpitch, spitch, width, height; };
 struct XaArgsFill { uint64_t dst, bytes; uint32_t value; };
 struct XaArgsRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };     /* = XaRects (x265amd_host.h) */
