@@ -841,7 +841,7 @@ int x265amd_aq_offsets(const uint32_t* energy, int num_blocks, int avg_block_cou
 void x265amd_release_scratch(void);
 
 /* Device job queues (csrc/xa_queue.h): the CTU rows of x265amd_analyse_frame run their block operations as commands to resident workgroups instead of
- * kernel launches (environment: X265AMD_QUEUES = number of queues, default 64, 0 = launches on HIP streams as before).  The self test pushes `rounds`
+ * kernel launches (environment: X265AMD_QUEUES = number of queues, default 128, 0 = launches on HIP streams as before).  The self test pushes `rounds`
  * rounds of copies, fills and rectangle copies through `numQueues` queues from as many host threads and compares every byte that comes back. */
 int x265amd_queue_selftest(int rounds, int numQueues);
 /* A queue handle for the `stream` argument of the orchestrating entry points (x265amd_pred_inter_search, x265amd_inter_residual_rd, x265amd_skip_rd,

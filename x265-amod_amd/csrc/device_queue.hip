@@ -20,6 +20,7 @@ __shared__ long long xa_stage_prev;
 #include <signal.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <string.h>
 #include <thread>
@@ -77,7 +78,7 @@ XA_DEV void block_copy_rects(const XaArgsRects& r, int tid, int nthr)
 }
 
 /* every command body is a function of its own: the register allocation of one does not weigh on the others */
-__device__ __noinline__ void xa_op_copy(const XaCmd& c, int tid)
+XA_DEV void xa_op_copy(const XaCmd& c, int tid)        /* small: inlined into the server loop (no call frame) */
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
@@ -90,7 +91,7 @@ __device__ __noinline__ void xa_op_copy(const XaCmd& c, int tid)
     }
 }
 
-__device__ __noinline__ void xa_op_copy2d(const XaCmd& c, int tid)
+XA_DEV void xa_op_copy2d(const XaCmd& c, int tid)        /* small: inlined into the server loop (no call frame) */
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
@@ -104,7 +105,7 @@ __device__ __noinline__ void xa_op_copy2d(const XaCmd& c, int tid)
     }
 }
 
-__device__ __noinline__ void xa_op_fill(const XaCmd& c, int tid)
+XA_DEV void xa_op_fill(const XaCmd& c, int tid)        /* small: inlined into the server loop (no call frame) */
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
@@ -118,7 +119,7 @@ __device__ __noinline__ void xa_op_fill(const XaCmd& c, int tid)
     }
 }
 
-__device__ __noinline__ void xa_op_copy_rects(const XaCmd& c, int tid)
+XA_DEV void xa_op_copy_rects(const XaCmd& c, int tid)        /* small: inlined into the server loop (no call frame) */
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const int lane = tid & 63, wv = tid >> 6;
@@ -434,8 +435,10 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         if (s_cmd.op == XA_OP_EXIT) break;
         const long long td = wall_clock64();
         xa_dispatch(s_cmd, tid);
-        /* every wavefront's stores have left before the workgroup reports (results live in host memory, read as soon as the count moves) */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        /* before the workgroup reports or publishes, every wavefront's stores have left (results live in host memory, read as soon as the count
+         * moves).  Between two commands of the queue the barrier is enough: the CU's vector memory path keeps the order of one workgroup's accesses,
+         * which is all the compiler itself relies on for a workgroup-scope release in this execution mode. */
+        if (flags & (XA_CMD_RELEASE | XA_CMD_SIGNAL)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         /* what a copy or fill has just written may be read with SCALAR loads by the commands behind it (plane tables, group lists: wave-uniform
          * addresses); the scalar data cache is coherent with nothing, so it goes now */
@@ -512,6 +515,7 @@ const bool g_prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
 struct Server
 {
     std::mutex m;
+    std::condition_variable freed;
     int numQueues = 0;
     XaRingDev* rings = nullptr;
     XaRingHost* hosts = nullptr;
@@ -527,7 +531,7 @@ struct Server
     {
         if (numQueues) return 0;
         const char* e = getenv("X265AMD_QUEUES");
-        int n = e ? atoi(e) : 64;
+        int n = e ? atoi(e) : 128;
         if (n <= 0) { disabled = true; return -1; }
         if (n > 224) n = 224;
         ringsInHost = getenv("X265AMD_RING_HOST") != nullptr;
@@ -538,7 +542,14 @@ struct Server
         if (ringsInHost) memset((void*)rings, 0, sizeof(XaRingDev) * n);
         if (hipHostMalloc((void**)&hosts, sizeof(XaRingHost) * n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
         if (hipHostMalloc((void**)&staging, kStagingBytes * n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
+        /* The resident kernel must not share a hardware queue with anything: a kernel launched behind it on the same hardware queue waits until it
+         * leaves (the in-loop filters of a finished picture would wait for every other picture's analysis).  Streams of another priority are given
+         * hardware queues of their own, and nothing else in this library asks for a priority. */
+        {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest) != hipSuccess)
+                if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
+        }
         if (hipFuncSetAttribute((const void*)k_job_server, hipFuncAttributeMaxDynamicSharedMemorySize, XA_SERVER_LDS) != hipSuccess) return -1;
         memset((void*)hosts, 0, sizeof(XaRingHost) * n);
         q.resize(n);
@@ -561,7 +572,7 @@ struct Server
             *reinterpret_cast<volatile uint64_t*>(&rings[i].quit) = 0;
         }
         _mm_sfence();
-        hipLaunchKernelGGL(k_job_server, dim3(numQueues), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 20, generation);
+        hipLaunchKernelGGL(k_job_server, dim3(numQueues), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 60, generation);
         if (hipGetLastError() != hipSuccess) return -1;
         running = true;
         return 0;
@@ -692,11 +703,18 @@ bool xa_queues_enabled()
 void* xa_queue_acquire()
 {
     Server& S = server();
-    std::lock_guard<std::mutex> g(S.m);
+    std::unique_lock<std::mutex> g(S.m);
     if (S.disabled || S.init() != 0) return nullptr;
+    /* All queues taken: wait for one.  Falling back to a HIP stream here would put ordinary kernels beside the resident one, and a row that runs on
+     * launches while the rows around it run on queues can starve behind the resident kernel.  The rows of a picture take their queues in row order,
+     * so the row everybody else waits for always holds one: the wait ends. */
     XaQueue* f = nullptr;
-    for (XaQueue& x : S.q) if (!x.busy) { f = &x; break; }
-    if (!f) return nullptr;
+    for (;;)
+    {
+        for (XaQueue& x : S.q) if (!x.busy) { f = &x; break; }
+        if (f) break;
+        if (S.freed.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) return nullptr;
+    }
     if (S.start() != 0) return nullptr;
     f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear();
     S.refs++;
@@ -715,6 +733,7 @@ void xa_queue_release(void* st)
     Server& S = server();
     std::lock_guard<std::mutex> g(S.m);
     q->busy = false;
+    S.freed.notify_one();
     if (g_prof) g_heldNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - q->acquired).count();
     if (getenv("X265AMD_QUEUE_DEBUG") && q->rh->dbg[63]) fprintf(stderr, "x265amd queue %d: %llu command slot re-reads so far\n", q->idx, (unsigned long long)q->rh->dbg[63]);
     if (--S.refs == 0) S.stop();
