@@ -410,6 +410,9 @@ int x265amd_inter_cost(void* stream, const uint64_t* d_planes, intptr_t stride, 
  * weighted copy (weight_pp_c, pixel.cpp:519-538, with w = inputWeight, offset = inputOffset << (depth - 8), shift =
  * log2WeightDenom) of the picture area and its margins -- the plane MotionReference::fpelPlane[] points to when wtPresent. */
 int x265amd_extend_pic_border(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY);
+/* the same for picture lines y_begin .. y_end - 1 only (their left / right margins; the top margin with line 0, the bottom margin with the last line):
+ * the row-by-row form of FrameFilter::processPostRow (source/encoder/framefilter.cpp:592-664), used when pictures are coded in parallel */
+int x265amd_extend_border_rows(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY, int y_begin, int y_end);
 int x265amd_weight_plane(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, intptr_t stride, int width, int height,
                          int marginX, int marginY, int inputWeight, int inputOffset, int log2WeightDenom);
 
@@ -437,10 +440,19 @@ int x265amd_deblock_picture(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u
                             int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
                             int cbQpOffset, int crQpOffset, int bypassEnabled, int passes);
 
+/* the edges of unit rows y4_begin .. y4_end - 1 only (even numbers; 16 per CTU row): one CTU row of FrameFilter::processRow (framefilter.cpp:559-590).
+ * Bands filtered in row order give the picture-wide result. */
+int x265amd_deblock_rows(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
+                         int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
+                         int cbQpOffset, int crQpOffset, int bypassEnabled, int passes, int y4_begin, int y4_end);
+
 /* the deblocking records of a picture from the maps the analysis fills in (host): edge marks from the CU / PU / TU structure as
  * Deblock::deblockCU sets them (deblock.cpp:70-185), picture identities from info->ref_poc.  out: (width/4) x (height/4) records. */
 int x265amd_deblock_units(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
                           x265amd_deblock_unit* out);
+/* the records of unit rows y4_begin .. y4_end - 1 (same array); picture identities are numbered the same way in every call for a picture */
+int x265amd_deblock_units_rows(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
+                               x265amd_deblock_unit* out, int y4_begin, int y4_end);
 
 /* --- sample adaptive offset over a picture, the two data-parallel halves; 4:2:0, sao-non-deblock off.
  * Plane tables are HOST arrays of 3 device addresses (sample (0,0) of Y, U, V).
@@ -461,6 +473,13 @@ int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], const uint64_t
                       int width, int height, int32_t* d_count, int32_t* d_offset_org);
 int x265amd_sao_apply(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
                       int width, int height, const x265amd_sao_ctu* d_params);
+/* the same for CTU rows ctu_row_begin .. ctu_row_end - 1 (arrays indexed by the CTU address in the picture): the row-by-row order of the reference's
+ * frame filter (source/encoder/framefilter.cpp:559-664), used when pictures are coded in parallel.  A row's statistics need the row deblocked; its offset
+ * samples need the row below deblocked as well. */
+int x265amd_sao_stats_rows(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
+                           int width, int height, int32_t* d_count, int32_t* d_offset_org, int ctu_row_begin, int ctu_row_end);
+int x265amd_sao_apply_rows(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
+                           int width, int height, const x265amd_sao_ctu* d_params, int ctu_row_begin, int ctu_row_end);
 
 /* --- final entropy coding of CTUs: the CABAC write pass, host code.  Entropy::encodeCTU / encodeCU /
  * encodeTransform / codePredInfo / codeCoeffNxN and the arithmetic coder (reference: source/encoder/entropy.cpp:768-1222, :1431-2200,
@@ -539,13 +558,16 @@ int x265amd_amvp_candidates(const x265amd_mvpred_info* info, const x265amd_mv_un
 /* --- whole-CU inter search for a batch of CUs: Search::predInterSearch (reference: source/encoder/search.cpp:2181-2647)
  * with mergeEstimation, selectMVP, setSearchRange, checkBestMVP, getBlkBits.  Decisions are made on the host in the reference's order;
  * the block operations of each step of all CUs run as one GPU batch (x265amd_inter_cost, x265amd_me_search,
- * x265amd_motion_compensation).  No weighted prediction, HME, analysis reuse or frame-parallel lag clipping. */
+ * x265amd_motion_compensation).  No weighted prediction, HME or analysis reuse. */
 typedef struct x265amd_inter_search_params
 {
     int32_t search_method, subpel_refine, search_range;     /* param.searchMethod (X265AMD_ME_*), subpelRefine, searchRange */
     int32_t qp;                                             /* the CU's QP: lambda (RDCost::setQP) and the MV cost table (MotionEstimate::setQP) */
     int32_t chroma_mc;                                      /* bChromaMC: chroma in the final prediction, and chroma SATD when subpel_refine > 2 */
     int32_t ref_pic[2][16];                                 /* picture index (into the plane table) of reference r of list l */
+    int32_t frame_parallel;                                 /* Search::m_bFrameParallel (param.frameNumThreads > 1, search.cpp:77): vertical search limit
+                                                             * m_refLagPixels = searchRange (search.cpp:92, :2763), merge candidates (search.cpp:1934,
+                                                             * analysis.cpp:2803, :2933) and AMVP candidates (search.cpp:2009) reaching below it are left out */
 } x265amd_inter_search_params;
 typedef struct x265amd_inter_cu { int16_t x, y; uint8_t log2_size, part_size; uint8_t reserved[2]; } x265amd_inter_cu;
 typedef struct x265amd_pu_result
@@ -795,6 +817,10 @@ int x265amd_encode_slice_data(const x265amd_slice_info* si, x265amd_cu_unit* uni
  * merge mode); sao_flags[2]: slice_sao_luma_flag, slice_sao_chroma_flag.  limit-sao and sao-non-deblock are not supported. */
 int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
                     const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags);
+/* CTU rows ctu_row_begin .. ctu_row_end - 1 of the same decision (rows in order; frame_threads > 1 unless the call covers the picture) */
+int x265amd_sao_rdo_rows(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                         const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags,
+                         int ctu_row_begin, int ctu_row_end);
 
 /* --- lookahead lowres pipeline, first stage.
  * x265amd_lowres_init = Lowres::init (reference: source/common/lowres.cpp:337-403): frame_init_lowres_core (source/common/pixel.cpp:605-628) from the

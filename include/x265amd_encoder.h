@@ -46,7 +46,14 @@ typedef struct x265amd_param
                                              * before its IDR picture, so a stream can be cut at IDR pictures and the pieces encoded by different encoder objects
                                              * (different GPUs): each piece starts with firstFrame = its first picture and the slice NAL units concatenate to the
                                              * single-encoder stream (headers from one of them) */
-    int32_t reserved[3];
+    int32_t frameNumThreads;                /* 0 / 1: a picture is coded when its reference pictures are complete (the reference's --frame-threads 1).  > 1: the
+                                             * reference's frame-parallel rules, which are what its default gives on any machine with four cores or more
+                                             * (threadpool.cpp:661-677): a CTU row starts when the reference pictures have finished the rows down to refLagRows below it
+                                             * (frameencoder.cpp:170-175, :893-908), motion vectors stop at searchRange below the block (search.cpp:92, :2763) and
+                                             * candidates beyond are left out (search.cpp:1934, :2009; analysis.cpp:2803, :2933), SAO is never switched off from
+                                             * picture to picture (sao.cpp:264).  The stream is the same for every value > 1; the number of pictures in flight is the
+                                             * library's own choice (X265AMD_FRAME_THREADS) */
+    int32_t reserved[2];
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

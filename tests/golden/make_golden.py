@@ -501,5 +501,46 @@ def make_encoder_api_golden():
     print("wrote encoder_api_golden.npz:", {k: len(v) for k, v in out.items()})
 
 
+def make_encoder_ft_golden():
+    """streams + reconstruction digests of the reference encoder run with several frame threads (its default on any machine with four cores or more): the
+    frame-parallel rules of search.cpp:77-92 / sao.cpp:264 -> tests/golden/encoder_ft_golden.npz.  For the clips whose motion reaches beyond the lag the
+    stream must differ from the --frame-threads 1 stream (otherwise the case would not test the rules)."""
+    import subprocess, tempfile, hashlib
+    out = {}
+    for tag, ((w, h), nframes, depth, kind, _, extra) in T.FT_CASES.items():
+        planes = T.encoder_ft_frames(tag)
+        streams = {}
+        for ft in ("3", "1", "2"):
+            cli = [a for a in T.FT_CLI]
+            cli[cli.index("--frame-threads") + 1] = ft
+            cli = cli + extra
+            with tempfile.TemporaryDirectory() as d:
+                with open(os.path.join(d, "clip.y4m"), "wb") as f:
+                    f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
+                    for fr in planes:
+                        f.write(b"FRAME\n")
+                        for pl in fr:
+                            f.write(np.ascontiguousarray(pl).tobytes())
+                exe = os.path.join(T.REF_DIR, "x265_ref%d" % depth)
+                r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv"] + cli, cwd=d, capture_output=True, text=True, timeout=600)
+                assert r.returncode == 0, r.stderr[-2000:]
+                streams[ft] = open(os.path.join(d, "out.hevc"), "rb").read()
+                if ft == "3":
+                    rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
+                    fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
+                    assert len(rec) == fsz * nframes
+                    out[tag + "recon_md5"] = np.array([hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)])
+        assert streams["3"] == streams["2"], tag + ": the frame-parallel stream depends on the thread count"
+        print(tag, len(streams["3"]), "bytes; differs from --frame-threads 1:", streams["3"] != streams["1"])
+        if kind.startswith("down"):
+            assert streams["3"] != streams["1"], tag + ": the clip does not reach beyond the lag"
+        out[tag + "stream"] = np.frombuffer(streams["3"], np.uint8)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "encoder_ft_golden.npz"), **out)
+    print("wrote encoder_ft_golden.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ft":
+        make_encoder_ft_golden()
+    else:
+        main()

@@ -1963,7 +1963,7 @@ def inter_search_run_ref(R, c):
 
 
 INTER_CU_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("log2", "u1"), ("part", "u1"), ("reserved", "u1", 2)])
-INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16))])
+INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16)), ("frame_parallel", "<i4")])
 
 
 def inter_search_run_hip(L, me, c):
@@ -3017,7 +3017,7 @@ class EncParam(C.Structure):
                 ("searchMethod", C.c_int32), ("subpelRefine", C.c_int32), ("searchRange", C.c_int32), ("maxNumMergeCand", C.c_int32),
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
-                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class EncNal(C.Structure):
@@ -3107,6 +3107,59 @@ def encoder_api_clip(tag, w, h, nframes, depth=8):
             planes.append(np.clip(core, 0, pmax).astype(dt))
         frames.append(planes)
     return frames
+
+
+def encoder_ft_clip(w, h, nframes, depth=8, dy0=30, dy_inc=20, dx_step=6):
+    """display-order (Y, U, V) planes of a clip whose content moves UP faster and faster (by dy0, dy0 + dy_inc, ... luma samples from frame to frame), i.e. motion
+    vectors point further and further DOWN into the reference picture: the predictors follow the motion, the search (--merange 57 around the predictor) finds
+    it, and beyond 57 samples the reference's frame-parallel rules (search.cpp:92, :1934, :2009, :2763) cut vectors off"""
+    rng = np.random.default_rng(w * 7919 + h * 104729 + nframes)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    pos = [0]
+    for t in range(1, nframes):
+        pos.append(pos[-1] + dy0 + dy_inc * (t - 1))
+    th, tw = h + 64 + pos[-1], w + 64 + dx_step * nframes
+    big = rng.integers(0, pmax + 1, (th // 8 + 2, tw // 8 + 2)).astype(np.int64)
+    big = np.kron(big, np.ones((8, 8), np.int64))
+    big = (big + np.roll(big, 3, 0) + np.roll(big, 5, 1) + np.roll(big, -2, 1)) // 4
+    cb = (np.roll(big, 7, 0)[::2, ::2] + big[1::2, 1::2]) // 2
+    cr = (np.roll(big, 11, 1)[::2, ::2] + big[::2, 1::2]) // 2
+    frames = []
+    for t in range(nframes):
+        dx, dy = 2 * ((dx_step * t) // 2), 2 * (pos[t] // 2)
+        planes = []
+        for (src, pw, ph, sx, sy) in ((big, w, h, dx, dy), (cb, w // 2, h // 2, dx // 2, dy // 2), (cr, w // 2, h // 2, dx // 2, dy // 2)):
+            o = 16 if src is big else 8
+            core = src[o + sy:o + sy + ph, o + sx:o + sx + pw] + rng.integers(-2, 3, (ph, pw)) * (1 << (depth - 8))
+            planes.append(np.clip(core, 0, pmax).astype(dt))
+        frames.append(planes)
+    return frames
+
+
+# cases of tests/test_encoder_api.py::test_frame_parallel_rules: tag -> ((w, h), frames, depth, clip kind, x265amd_param overrides, reference command line on top of FT_CLI)
+FT_CLI = ["--preset", "medium", "--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut", "--keyint", "250", "--rd", "3",
+          "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", "3", "--max-merge", "3", "--no-info", "--no-open-gop", "--rc-lookahead", "5", "--lookahead-slices", "0", "--no-b-pyramid",
+          "--frame-threads", "3"]
+FT_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3)
+FT_CASES = {
+    "ft_p/": ((256, 448), 5, 8, "drift", dict(FT_BASE, bframes=0), ["--bframes", "0", "--sao", "--wpp", "--pools", "4"]),
+    "ft_b/": ((256, 448), 8, 8, "drift", dict(FT_BASE, bframes=3), ["--bframes", "3", "--sao", "--wpp", "--pools", "4"]),
+    "ft_v/": ((256, 448), 6, 8, "down", dict(FT_BASE, bframes=0), ["--bframes", "0", "--sao", "--wpp", "--pools", "4"]),        # vectors beyond the lag: clipped / left out
+    "ft_vb/": ((256, 448), 8, 8, "downb", dict(FT_BASE, bframes=1), ["--bframes", "1", "--sao", "--wpp", "--pools", "4"]),
+    "ft_vp/": ((192, 320), 4, 8, "down", dict(FT_BASE, bframes=0, bEnableSAO=0, bEnableWavefront=0), ["--bframes", "0", "--no-sao", "--no-wpp", "--pools", "none"]),
+    "ft_nofilter/": ((192, 320), 5, 8, "drift", dict(FT_BASE, bframes=2, bEnableSAO=0, bEnableLoopFilter=0), ["--bframes", "2", "--no-sao", "--no-deblock", "--wpp", "--pools", "4"]),
+    "ft_hbd/": ((192, 320), 5, 10, "down", dict(FT_BASE, bframes=0, rdLevel=4, bEnableRectInter=1), ["--bframes", "0", "--sao", "--wpp", "--pools", "4", "--rd", "4", "--rect"]),
+}
+
+
+def encoder_ft_frames(tag):
+    (w, h), n, depth, kind, _, _ = FT_CASES[tag]
+    if kind == "down":
+        return encoder_ft_clip(w, h, n, depth)
+    if kind == "downb":
+        return encoder_ft_clip(w, h, n, depth, dy0=27, dy_inc=2)
+    return encoder_api_clip(tag, w, h, n, depth)
 
 
 # ---- lookahead lowres pipeline (x265amd_lowres_init / x265amd_lowres_intra_costs vs Lowres::init / LookaheadTLD::lowresIntraEstimate) ----

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 168 and T.EncParam.frameNumThreads.offset == 156 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -126,6 +126,26 @@ def test_encoder_object_partial_ctus_and_long_clip(tag):
     (w, h), n, cfg = EDGE_CONFIGS[tag]
     depth = 10 if tag.startswith("hbd") else 8
     stream, coded = T.encoder_run(T.load_hip(depth), T.encoder_api_clip(tag, w, h, n, depth), w, h, **cfg)
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    want = g[tag + "stream"]
+    assert len(stream) == len(want) and hashlib.md5(stream.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+
+
+FT_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_ft_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.FT_CASES))
+def test_frame_parallel_rules(tag):
+    """x265amd_param.frameNumThreads > 1: the stream of the reference encoder run with several frame threads (its default; golden data made with
+    --frame-threads 3, checked equal to --frame-threads 2).  Pictures are then coded side by side, a CTU row starting when its reference pictures have
+    finished the rows it may read, with the in-loop filters following the analysis row by row; vectors reaching below the lag are cut off (the "down" clips
+    accelerate until they do: there the stream differs from the --frame-threads 1 stream)"""
+    g = np.load(FT_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.FT_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.encoder_ft_frames(tag), w, h, **cfg)
     for (poc, _, _, planes) in coded:
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
         assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc

@@ -411,6 +411,8 @@ struct Analyzer
         int bestSadCand = -1;
         for (int i = 0; i < numCand; i++)
         {
+            /* pictures coded in parallel: candidates reaching below the rows the references have finished are left out (analysis.cpp:2789-2806) */
+            if (S->frame_parallel && (below_lag(cand[i].mv[0][1], S->search_range) || below_lag(cand[i].mv[1][1], S->search_range))) continue;
             const uint32_t bits = (uint32_t)(i + (i < numCand - 1));          /* getTUBits */
             const uint64_t c = calcRdSADCost(sa8dOf(meas[i]), bits);
             if (c < bestCost) { bestCost = c; bestBits = bits; bestSadCand = i; }
@@ -493,7 +495,8 @@ struct Analyzer
         if (bTryZero)
         {
             Mv mn, mx;
-            search_range(Mv{ 0, 0 }, I->pic_width > I->pic_height ? I->pic_width : I->pic_height, x, y, I->pic_width, I->pic_height, mn, mx);
+            search_range(Mv{ 0, 0 }, I->pic_width > I->pic_height ? I->pic_width : I->pic_height, x, y, I->pic_width, I->pic_height,
+                         S->frame_parallel ? S->search_range : I->pic_height, mn, mx);
             mx.y += 2;
             mn.x <<= 2; mn.y <<= 2; mx.x <<= 2; mx.y <<= 2;
             for (int l = 0; l < 2; l++) bTryZero &= mvp[l].x >= mn.x && mvp[l].x <= mx.x && mvp[l].y >= mn.y && mvp[l].y <= mx.y;
@@ -624,6 +627,7 @@ struct Analyzer
         for (int i = 0; i < numCand; i++)
         {
             const x265amd_merge_cand& c = cand[i];
+            if (S->frame_parallel && (below_lag(c.mv[0][1], S->search_range) || below_lag(c.mv[1][1], S->search_range))) continue;       /* analysis.cpp:2919-2936 */
             const bool z0 = !c.mv[0][0] && !c.mv[0][1] && !c.ref_idx[0], z1 = !c.mv[1][0] && !c.mv[1][1] && !c.ref_idx[1];
             if (c.dir == 1 && z0) { if (triedPZero) continue; triedPZero = true; }
             else if (c.dir == 3 && z0 && z1) { if (triedBZero) continue; triedBZero = true; }
@@ -1209,6 +1213,18 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
                                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
                                      uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams)
 {
+    return xa_analyse_frame(me, stream, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, coeff_out, results, slice_data, cap,
+                            substream_sizes, num_substreams, nullptr);
+}
+
+/* hooks (pictures coded in parallel, FrameEncoder::compressFrame's row loop, frameencoder.cpp:880-960): before_row blocks until the reference pictures have
+ * finished the rows this CTU row may read; after_row hands the analysed row to the in-loop filters */
+int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                     const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                     const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                     intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
+                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks)
+{
     if (!I || !si || !units || !cur || !cu_stat || !coeff_out) return xa_fail(X265AMD_EINVAL, "analyse_frame: null argument");
     const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2, h4 = si->pic_height >> 2;
     for (int i = 0; i < w4 * h4; i++)
@@ -1261,7 +1277,13 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
     {
         if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
         void* q = dumping ? nullptr : xa_queue_acquire();
-        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++) rc = doCtu(addr, q ? q : stream);
+        for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
+        {
+            if (hooks && addr % ctuW == 0 && hooks->before_row(hooks->ctx, addr / ctuW)) { rc = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"); break; }
+            rc = doCtu(addr, q ? q : stream);
+            if (rc == X265AMD_OK && xa_stream_sync(q ? q : stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
+            if (hooks && rc == X265AMD_OK && addr % ctuW == ctuW - 1) hooks->after_row(hooks->ctx, addr / ctuW);
+        }
         if (q) xa_queue_release(q);
     }
     else
@@ -1275,19 +1297,41 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
         std::mutex m;
         std::condition_variable cv;
         std::atomic<int> nextRow(0), firstErr(X265AMD_OK);
+        int queuedRows = 0;         /* with hooks: rows that hold (or have held) a queue; guarded by m */
         auto worker = [&]() {
-            /* a device job queue per row in flight (x265amd_host.h); a HIP stream when the queues are off or all taken */
-            void* st = dumping ? nullptr : xa_queue_acquire();
+            /* a device job queue per row in flight (x265amd_host.h); a HIP stream when the queues are off or all taken.  Pictures coded in parallel (hooks):
+             * a row takes its queue only when the reference pictures let it start, after the row above has taken one, and gives it back at the end of the
+             * row -- so every held queue belongs to a row that can run, whatever the number of pictures in flight, and waiting for a queue always ends. */
+            void* st = nullptr;
             hipStream_t own = nullptr;
-            if (!st)
-            {
-                if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { firstErr = xa_fail(X265AMD_EHIP, "analyse_frame: stream"); cv.notify_all(); return; }
+            auto take = [&]() -> bool {
+                st = dumping ? nullptr : xa_queue_acquire();
+                if (st) return true;
+                if (!own && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { firstErr = xa_fail(X265AMD_EHIP, "analyse_frame: stream"); cv.notify_all(); return false; }
                 st = own;
-            }
+                return true;
+            };
+            if (!hooks && !take()) return;
             for (;;)
             {
                 const int row = nextRow.fetch_add(1);
                 if (row >= ctuH) break;
+                if (hooks)
+                {
+                    if (firstErr.load() == X265AMD_OK && hooks->before_row(hooks->ctx, row))
+                    {
+                        int ok = X265AMD_OK;
+                        firstErr.compare_exchange_strong(ok, xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"));
+                    }
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv.wait(lk, [&] { return queuedRows >= row; });
+                    }
+                    const bool ok = take();
+                    { std::lock_guard<std::mutex> lk(m); queuedRows = row + 1; }
+                    cv.notify_all();
+                    if (!ok) { std::lock_guard<std::mutex> lk(m); done[row] = ctuW; cv.notify_all(); continue; }
+                }
                 for (int c = 0; c < ctuW; c++)
                 {
                     if (row)
@@ -1308,11 +1352,13 @@ extern "C" int x265amd_analyse_frame(x265amd_me_ctx* me, void* stream, const x26
                     }
                     cv.notify_all();
                     if (r != X265AMD_OK) break;
+                    if (hooks && c == ctuW - 1) hooks->after_row(hooks->ctx, row);
                 }
                 if (firstErr.load() != X265AMD_OK) { std::lock_guard<std::mutex> lk(m); done[row] = ctuW; cv.notify_all(); }
+                if (hooks && st && st != (void*)own) { xa_queue_release(st); st = nullptr; }
             }
             if (own) (void)hipStreamDestroy(own);
-            else xa_queue_release(st);
+            else if (st) xa_queue_release(st);
         };
         if (rc == X265AMD_OK)
         {

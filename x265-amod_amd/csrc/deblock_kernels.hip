@@ -26,6 +26,7 @@ struct DbParams
     int width, height;
     const x265amd_deblock_unit* units;
     int betaOffset, tcOffset, cqpOffset[2], bypassEnabled;
+    int y4Begin, y4End;         /* the unit rows whose edges this launch filters (a band of CTU rows; the whole picture: 0 .. height / 4) */
 };
 
 __device__ const uint8_t db_cqp[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };     /* g_chromaScale[30..43], 4:2:0 (constants.cpp:346-350) */
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(256) void k_deblock(DbParams P)
     const int nx = DIR == 0 ? (w4 >> 1) : w4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int iy = t / nx, ix = t - iy * nx;
-    const int x4 = DIR == 0 ? 2 * ix : ix, y4 = DIR == 0 ? iy : 2 * iy;
-    if (y4 >= h4 || (DIR == 0 ? x4 == 0 : y4 == 0)) return;
+    const int x4 = DIR == 0 ? 2 * ix : ix, y4 = P.y4Begin + (DIR == 0 ? iy : 2 * iy);
+    if (y4 >= h4 || y4 >= P.y4End || (DIR == 0 ? x4 == 0 : y4 == 0)) return;
     const x265amd_deblock_unit q = P.units[y4 * w4 + x4];
     const x265amd_deblock_unit p = P.units[DIR == 0 ? y4 * w4 + x4 - 1 : (y4 - 1) * w4 + x4];
     const int bs = db_strength(q, p, q.flags & (DIR ? X265AMD_DB_TU_TOP : X265AMD_DB_TU_LEFT), q.flags & (DIR ? X265AMD_DB_PU_TOP : X265AMD_DB_PU_LEFT));
@@ -167,14 +168,25 @@ extern "C" int x265amd_deblock_picture(void* stream, x265amd_pixel* d_y, x265amd
                                        int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
                                        int cbQpOffset, int crQpOffset, int bypassEnabled, int passes)
 {
-    if (!d_y || !d_u || !d_v || !d_units || width <= 0 || height <= 0 || (width & 7) || (height & 7))
+    return x265amd_deblock_rows(stream, d_y, d_u, d_v, stride, cstride, width, height, d_units, betaOffsetDiv2, tcOffsetDiv2, cbQpOffset, crQpOffset, bypassEnabled, passes,
+                                0, height >> 2);
+}
+
+/* The edges of the unit rows y4_begin .. y4_end - 1 (multiples of 2; a CTU row is 16 unit rows): what FrameFilter::processRow does for one CTU row
+ * (reference: source/encoder/framefilter.cpp:559-590), as the two passes over that band.  Filtering band after band in row order gives the picture-wide
+ * result: the horizontal edges of a band read what the vertical edges of this band and of the band above have left, and touch nothing below. */
+extern "C" int x265amd_deblock_rows(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
+                                    int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
+                                    int cbQpOffset, int crQpOffset, int bypassEnabled, int passes, int y4_begin, int y4_end)
+{
+    if (!d_y || !d_u || !d_v || !d_units || width <= 0 || height <= 0 || (width & 7) || (height & 7) || y4_begin < 0 || y4_end > (height >> 2) || y4_begin >= y4_end || (y4_begin & 1) || (y4_end & 1))
         return xa_fail(X265AMD_EINVAL, "x265amd_deblock_picture: bad arguments (picture dimensions must be multiples of 8)");
     DbParams P;
     P.planes[0] = (pixel*)d_y; P.planes[1] = (pixel*)d_u; P.planes[2] = (pixel*)d_v;
     P.stride = (long)stride; P.cstride = (long)cstride; P.width = width; P.height = height; P.units = d_units;
     P.betaOffset = betaOffsetDiv2 * 2; P.tcOffset = tcOffsetDiv2 * 2; P.cqpOffset[0] = cbQpOffset; P.cqpOffset[1] = crQpOffset;
-    P.bypassEnabled = bypassEnabled;
-    const int w4 = width >> 2, h4 = height >> 2;
+    P.bypassEnabled = bypassEnabled; P.y4Begin = y4_begin; P.y4End = y4_end;
+    const int w4 = width >> 2, h4 = y4_end - y4_begin;
     if (passes & 1)
     {
         const int n = (w4 >> 1) * h4;

@@ -18,7 +18,10 @@
 #include <chrono>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
+#include <thread>
 #include <future>
 #include <memory>
 #include <vector>
@@ -45,8 +48,16 @@ struct Pic
     /* the frame task: result code when the picture is completely coded (reconstruction final, NAL written) */
     std::shared_future<int> done;
     std::vector<uint8_t> nalBytes;
+    /* pictures coded in parallel (param.frameNumThreads > 1): the filtered picture is built row by row in dFin (dRec when SAO is off) and `reconRows` CTU rows
+     * of it are final -- Frame::m_reconRowFlag (frameencoder.cpp:900-905, framefilter.cpp:654-664) */
+    pixel* dFin = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    int reconRows = 0, analysedRows = 0;
+    bool failed = false;
+    const pixel* finalPlanes() const { return dFin ? dFin : dRec; }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); }
-    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); }
+    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); }
 };
 
 }
@@ -68,6 +79,8 @@ struct x265amd_encoder
     std::deque<PicP> inflight;                          /* coding order, frame tasks running */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
+    bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
+    int refLagRows = 0;                                 /* FrameEncoder::m_refLagRows (frameencoder.cpp:170-175) */
     std::vector<PicP> picList;                          /* front = most recently coded (PicList::pushFront) */
     double depthSaoRate[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     std::vector<uint8_t> headerBytes, outBytes;
@@ -93,6 +106,8 @@ struct x265amd_encoder
     void decideMiniGop(bool flush);
     int prepare(const PicP& pic);
     int runFrame(const PicP& pic, std::shared_future<int> prev);
+    int runFrameParallel(const PicP& pic);
+    int filterRows(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
 };
 
 /* ---- configuration ---- */
@@ -189,6 +204,26 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         e->frameThreads = ft ? atoi(ft) : 3;
         if (e->frameThreads < 1) e->frameThreads = 1;
     }
+    if (p->frameNumThreads < 0 || p->frameNumThreads > 16) { xa_fail(X265AMD_EINVAL, "encoder_open: frameNumThreads"); return nullptr; }
+    e->frameParallel = p->frameNumThreads > 1;
+    if (e->frameParallel)
+    {
+        /* FrameEncoder::init (frameencoder.cpp:170-175): rows of a reference picture that must be final before a row of this picture starts */
+        static const int hpelIters[8] = { 1, 1, 1, 2, 3, 1, 2, 3 };         /* MotionEstimate::hpelIterationCount: hpel_iters + qpel_iters / 2 (motion.cpp:48-58, :155) */
+        int range = p->searchRange;
+        range += p->searchMethod < 2;
+        range += 8 / 2;
+        range += 2 + (hpelIters[p->subpelRefine] + 1) / 2;
+        e->refLagRows = 1 + ((range + 63) / 64);
+        if (!getenv("X265AMD_FRAME_THREADS"))
+        {
+            /* every CTU row in flight holds a device job queue; pictures in flight never wait for one */
+            const char* q = getenv("X265AMD_QUEUES");
+            const int queues = q ? atoi(q) : 128;
+            const int rowsInFlight = p->bEnableWavefront ? std::max(1, std::min(e->ctuH, (e->ctuW + 1) / 2)) : 1;
+            e->frameThreads = std::max(2, std::min(16, (queues > 0 ? queues : 16) / rowsInFlight));
+        }
+    }
     e->me = x265amd_me_open();
     if (!e->me) return nullptr;
     const size_t nstat = (size_t)e->nctu * 3 * 5 * 32;
@@ -266,6 +301,11 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic)
     if (hipMemcpy(pic.dSrc, staging.data(), picElems * sizeof(pixel), hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: upload");
     /* the frame tasks run on their own non-blocking streams: make sure the picture is in place before one can start */
     if (hipMemset(pic.dRec, 0, picElems * sizeof(pixel)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+    if (frameParallel && p.bEnableSAO)
+    {
+        if (xa_scratch_alloc((void**)&pic.dFin, picElems * sizeof(pixel)) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+        if (hipMemset(pic.dFin, 0, picElems * sizeof(pixel)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+    }
     return 0;
 }
 
@@ -333,6 +373,112 @@ int x265amd_encoder::prepare(const PicP& picp)
     }
     pic.sliceQp = qpConstant[stype];                    /* rateControlStart, CQP */
     picList.insert(picList.begin(), picp);              /* PicList::pushFront */
+    if (frameParallel)
+    {
+        /* what pictures coded beside this one read of it exists before any task starts: the maps (rows become valid as they are coded) and the POC lists */
+        const size_t nUnits = (size_t)w4 * h4;
+        pic.units.assign(nUnits, x265amd_cu_unit()); pic.motion.assign(nUnits, x265amd_mv_unit());
+        memset(pic.units.data(), 0, sizeof(x265amd_cu_unit) * nUnits); memset(pic.motion.data(), 0, sizeof(x265amd_mv_unit) * nUnits);
+        memset(pic.refPoc, 0, sizeof(pic.refPoc));
+        for (int l = 0; l < 2; l++)
+            for (size_t r = 0; r < pic.lists[l].size(); r++) pic.refPoc[l][r] = pic.lists[l][r]->poc;
+    }
+    return 0;
+}
+
+/* what the analysis and the slice header of one picture need, derived from the picture's lists (DPB::prepareEncode has run) */
+struct FrameCtx
+{
+    int stype = 0;
+    std::vector<uint64_t> planes;           /* reference pictures (distinct), then the reconstruction, then the source: 3 addresses each */
+    x265amd_mvpred_info info;
+    x265amd_inter_search_params sp;
+    x265amd_slice_info si;
+    x265amd_analysis_params ap;
+    const Pic* colPic = nullptr;
+};
+
+static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
+{
+    const x265amd_param& p = e.p;
+    const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
+    c.stype = stype;
+    const std::vector<PicP>* lists = pic.lists;
+    std::vector<Pic*> index;
+    int32_t refPic[2][16];
+    memset(refPic, 0, sizeof(refPic));
+    if (!e.frameParallel) memset(pic.refPoc, 0, sizeof(pic.refPoc));        /* coded in parallel: set by prepare(), other pictures' tasks may be reading it */
+    for (int l = 0; l < 2; l++)
+        for (size_t r = 0; r < lists[l].size(); r++)
+        {
+            Pic* q = lists[l][r].get();
+            size_t k = std::find(index.begin(), index.end(), q) - index.begin();
+            if (k == index.size()) { index.push_back(q); for (int cc = 0; cc < 3; cc++) c.planes.push_back(e.planeAddr(q->finalPlanes(), cc)); }
+            refPic[l][r] = (int32_t)k;
+            if (!e.frameParallel) pic.refPoc[l][r] = q->poc;
+        }
+    for (int cc = 0; cc < 3; cc++) c.planes.push_back(e.planeAddr(pic.dRec, cc));
+    for (int cc = 0; cc < 3; cc++) c.planes.push_back(e.planeAddr(pic.dSrc, cc));
+
+    x265amd_mvpred_info& info = c.info;
+    memset(&info, 0, sizeof(info));
+    info.pic_width = e.W; info.pic_height = e.H; info.is_inter_b = stype == 0; info.max_num_merge_cand = p.maxNumMergeCand;
+    info.num_ref_idx[0] = (int32_t)lists[0].size(); info.num_ref_idx[1] = (int32_t)lists[1].size();
+    info.temporal_mvp = p.bEnableTemporalMvp != 0; info.col_from_l0 = stype != 0; info.check_ldc = stype != 0; info.poc = pic.poc;
+    memcpy(info.ref_poc, pic.refPoc, sizeof(info.ref_poc));
+    c.colPic = stype == 2 ? nullptr : (stype == 1 ? lists[0][0].get() : lists[1][0].get());
+    if (c.colPic) { info.col_poc = c.colPic->poc; memcpy(info.col_ref_poc, c.colPic->refPoc, sizeof(info.col_ref_poc)); }
+
+    x265amd_inter_search_params& sp = c.sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.search_method = p.searchMethod; sp.subpel_refine = p.subpelRefine; sp.search_range = p.searchRange; sp.qp = pic.sliceQp; sp.chroma_mc = 1;
+    sp.frame_parallel = e.frameParallel;
+    memcpy(sp.ref_pic, refPic, sizeof(sp.ref_pic));
+
+    x265amd_slice_info& si = c.si;
+    memset(&si, 0, sizeof(si));
+    si.pic_width = e.W; si.pic_height = e.H; si.slice_type = stype; si.slice_qp = pic.sliceQp;
+    si.num_ref_idx[0] = info.num_ref_idx[0]; si.num_ref_idx[1] = info.num_ref_idx[1];
+    si.max_num_merge_cand = p.maxNumMergeCand; si.sign_hide = p.bEnableSignHiding != 0; si.wpp = p.bEnableWavefront != 0;
+    si.max_cu_depth = 3; si.max_amp_depth = p.bEnableAMP ? 3 : 0; si.tu_log2_min = 2; si.tu_log2_max = 5;
+    si.tu_max_depth_inter = p.tuQTMaxInterDepth; si.tu_max_depth_intra = p.tuQTMaxIntraDepth;
+
+    x265amd_analysis_params& ap = c.ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.psy_rd = p.psyRd; ap.rd_level = p.rdLevel; ap.early_skip = p.bEnableEarlySkip != 0; ap.rskip = p.recursionSkipMode; ap.limit_refs = p.limitReferences;
+    ap.b_intra = p.bIntraInBFrames != 0; ap.rect = p.bEnableRectInter != 0; ap.amp = p.bEnableAMP != 0; ap.limit_modes = p.limitModes != 0;
+    ap.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0; ap.use_sao = p.bEnableSAO != 0;
+    ap.fast_intra = p.bEnableFastIntra != 0;
+    ap.rdoq_level = p.rdoqLevel; ap.psy_rdoq_scale = p.rdoqLevel ? p.psyRdoqFix8 : 0;      /* encoder.cpp:3667: no psy-rdoq without RDOQ */
+}
+
+/* slice header (Entropy::codeSliceHeader inputs as DPB / Encoder set them) + the sub-streams -> the picture's NAL unit */
+static int sliceNal(const x265amd_encoder& e, Pic& pic, const FrameCtx& c, const int32_t* saoFlags, const std::vector<uint8_t>& data, const std::vector<uint32_t>& sizes, int nsub)
+{
+    const x265amd_param& p = e.p;
+    x265amd_slice_header h;
+    memset(&h, 0, sizeof(h));
+    h.nal_unit_type = pic.nalType; h.temporal_id_plus1 = 1; h.first_in_access_unit = 1;
+    h.slice_type = c.stype; h.poc = pic.poc; h.last_idr_poc = pic.lastIDR; h.log2_max_poc_lsb = 8; h.rps_idx = -1; h.num_rps_in_sps = 0;
+    h.num_negative = (int32_t)pic.neg.size(); h.num_positive = (int32_t)pic.pos.size();
+    {
+        int j = 0;
+        for (const PicP& q : pic.neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+        for (const PicP& q : pic.pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+    }
+    h.temporal_mvp_enabled = p.bEnableTemporalMvp != 0;
+    h.use_sao = p.bEnableSAO != 0; h.sao_luma = saoFlags[0]; h.sao_chroma = saoFlags[1];
+    h.num_ref_idx[0] = c.info.num_ref_idx[0]; h.num_ref_idx[1] = c.info.num_ref_idx[1]; h.num_ref_idx_default[0] = h.num_ref_idx_default[1] = 1;
+    h.col_from_l0 = c.stype != 0; h.col_ref_idx = 0; h.max_num_merge_cand = p.maxNumMergeCand;
+    h.slice_qp = pic.sliceQp; h.pps_init_qp = 26; h.deblocking_disabled = !p.bEnableLoopFilter;
+    h.slfase_flag = (0x5f4e4a53u >> (pic.poc % 31)) & 1;                                              /* SLFASE_CONSTANT (dpb.cpp:294) */
+    h.wpp = p.bEnableWavefront != 0;
+    size_t dataBytes = 0;
+    for (int s = 0; s < nsub; s++) dataBytes += sizes[s];
+    pic.nalBytes.assign(dataBytes * 3 / 2 + 4096, 0);
+    const size_t n = x265amd_write_slice_nal(&h, data.data(), sizes.data(), nsub, pic.nalBytes.data(), pic.nalBytes.size());
+    if (!n || n > pic.nalBytes.size()) return xa_fail(X265AMD_EINVAL, "encoder: slice NAL");
+    pic.nalBytes.resize(n);
     return 0;
 }
 
@@ -342,58 +488,22 @@ int x265amd_encoder::prepare(const PicP& picp)
 int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
 {
     Pic& pic = *picp;
-    const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
     for (int l = 0; l < 2; l++)
         for (const PicP& q : pic.lists[l]) if (q->done.valid() && q->done.get() != 0) return X265AMD_EHIP;
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: stream");
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
     const std::vector<PicP>* lists = pic.lists;
-
-    std::vector<uint64_t> planes;
-    std::vector<Pic*> index;
-    int32_t refPic[2][16];
-    memset(refPic, 0, sizeof(refPic)); memset(pic.refPoc, 0, sizeof(pic.refPoc));
-    for (int l = 0; l < 2; l++)
-        for (size_t r = 0; r < lists[l].size(); r++)
-        {
-            Pic* q = lists[l][r].get();
-            size_t k = std::find(index.begin(), index.end(), q) - index.begin();
-            if (k == index.size()) { index.push_back(q); for (int c = 0; c < 3; c++) planes.push_back(planeAddr(q->dRec, c)); }
-            refPic[l][r] = (int32_t)k; pic.refPoc[l][r] = q->poc;
-        }
-    for (int c = 0; c < 3; c++) planes.push_back(planeAddr(pic.dRec, c));
-    for (int c = 0; c < 3; c++) planes.push_back(planeAddr(pic.dSrc, c));
-
-    x265amd_mvpred_info info;
-    memset(&info, 0, sizeof(info));
-    info.pic_width = W; info.pic_height = H; info.is_inter_b = stype == 0; info.max_num_merge_cand = p.maxNumMergeCand;
-    info.num_ref_idx[0] = (int32_t)lists[0].size(); info.num_ref_idx[1] = (int32_t)lists[1].size();
-    info.temporal_mvp = p.bEnableTemporalMvp != 0; info.col_from_l0 = stype != 0; info.check_ldc = stype != 0; info.poc = pic.poc;
-    memcpy(info.ref_poc, pic.refPoc, sizeof(info.ref_poc));
-    const Pic* colPic = stype == 2 ? nullptr : (stype == 1 ? lists[0][0].get() : lists[1][0].get());
-    if (colPic) { info.col_poc = colPic->poc; memcpy(info.col_ref_poc, colPic->refPoc, sizeof(info.col_ref_poc)); }
-
-    x265amd_inter_search_params sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.search_method = p.searchMethod; sp.subpel_refine = p.subpelRefine; sp.search_range = p.searchRange; sp.qp = pic.sliceQp; sp.chroma_mc = 1;
-    memcpy(sp.ref_pic, refPic, sizeof(sp.ref_pic));
-
-    x265amd_slice_info si;
-    memset(&si, 0, sizeof(si));
-    si.pic_width = W; si.pic_height = H; si.slice_type = stype; si.slice_qp = pic.sliceQp;
-    si.num_ref_idx[0] = info.num_ref_idx[0]; si.num_ref_idx[1] = info.num_ref_idx[1];
-    si.max_num_merge_cand = p.maxNumMergeCand; si.sign_hide = p.bEnableSignHiding != 0; si.wpp = p.bEnableWavefront != 0;
-    si.max_cu_depth = 3; si.max_amp_depth = p.bEnableAMP ? 3 : 0; si.tu_log2_min = 2; si.tu_log2_max = 5;
-    si.tu_max_depth_inter = p.tuQTMaxInterDepth; si.tu_max_depth_intra = p.tuQTMaxIntraDepth;
-
-    x265amd_analysis_params ap;
-    memset(&ap, 0, sizeof(ap));
-    ap.psy_rd = p.psyRd; ap.rd_level = p.rdLevel; ap.early_skip = p.bEnableEarlySkip != 0; ap.rskip = p.recursionSkipMode; ap.limit_refs = p.limitReferences;
-    ap.b_intra = p.bIntraInBFrames != 0; ap.rect = p.bEnableRectInter != 0; ap.amp = p.bEnableAMP != 0; ap.limit_modes = p.limitModes != 0;
-    ap.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0; ap.use_sao = p.bEnableSAO != 0;
-    ap.fast_intra = p.bEnableFastIntra != 0;
-    ap.rdoq_level = p.rdoqLevel; ap.psy_rdoq_scale = p.rdoqLevel ? p.psyRdoqFix8 : 0;      /* encoder.cpp:3667: no psy-rdoq without RDOQ */
+    FrameCtx fc;
+    frameContext(*this, pic, fc);
+    const int stype = fc.stype;
+    std::vector<uint64_t>& planes = fc.planes;
+    x265amd_mvpred_info& info = fc.info;
+    x265amd_inter_search_params& sp = fc.sp;
+    x265amd_slice_info& si = fc.si;
+    x265amd_analysis_params& ap = fc.ap;
+    const Pic* colPic = fc.colPic;
+    (void)stype;
 
     const size_t nUnits = (size_t)w4 * h4;
     pic.units.assign(nUnits, x265amd_cu_unit()); pic.motion.assign(nUnits, x265amd_mv_unit());
@@ -473,34 +583,191 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
     if (rc != X265AMD_OK) return rc;
     if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: border extension");
 
-    /* ---- slice header (Entropy::codeSliceHeader inputs as DPB / Encoder set them) ---- */
-    x265amd_slice_header h;
-    memset(&h, 0, sizeof(h));
-    h.nal_unit_type = pic.nalType; h.temporal_id_plus1 = 1; h.first_in_access_unit = 1;
-    h.slice_type = stype; h.poc = pic.poc; h.last_idr_poc = pic.lastIDR; h.log2_max_poc_lsb = 8; h.rps_idx = -1; h.num_rps_in_sps = 0;
-    h.num_negative = (int32_t)pic.neg.size(); h.num_positive = (int32_t)pic.pos.size();
-    {
-        int j = 0;
-        for (const PicP& q : pic.neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
-        for (const PicP& q : pic.pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
-    }
-    h.temporal_mvp_enabled = p.bEnableTemporalMvp != 0;
-    h.use_sao = sao; h.sao_luma = saoFlags[0]; h.sao_chroma = saoFlags[1];
-    h.num_ref_idx[0] = info.num_ref_idx[0]; h.num_ref_idx[1] = info.num_ref_idx[1]; h.num_ref_idx_default[0] = h.num_ref_idx_default[1] = 1;
-    h.col_from_l0 = stype != 0; h.col_ref_idx = 0; h.max_num_merge_cand = p.maxNumMergeCand;
-    h.slice_qp = pic.sliceQp; h.pps_init_qp = 26; h.deblocking_disabled = !p.bEnableLoopFilter;
-    h.slfase_flag = (0x5f4e4a53u >> (pic.poc % 31)) & 1;                                              /* SLFASE_CONSTANT (dpb.cpp:294) */
-    h.wpp = p.bEnableWavefront != 0;
-    size_t dataBytes = 0;
-    for (int s = 0; s < nsub; s++) dataBytes += sizes[s];
-    pic.nalBytes.assign(dataBytes * 3 / 2 + 4096, 0);
-    const size_t n = x265amd_write_slice_nal(&h, data.data(), sizes.data(), nsub, pic.nalBytes.data(), pic.nalBytes.size());
-    if (!n || n > pic.nalBytes.size()) return xa_fail(X265AMD_EINVAL, "encoder: slice NAL");
-    pic.nalBytes.resize(n);
+    rc = sliceNal(*this, pic, fc, saoFlags, data, sizes, nsub);
+    if (rc) return rc;
     /* the source is no longer needed; the reconstruction stays while the picture is referenced.  The reference lists are only needed by pictures
      * that are still to come through their own lists */
     xa_scratch_free(pic.dSrc); pic.dSrc = nullptr;
     return 0;
+}
+
+/* ---- pictures coded in parallel (param.frameNumThreads > 1) ----
+ * FrameEncoder::compressFrame as the reference runs it with several frame encoders (frameencoder.cpp:880-960, :1930-1960; framefilter.cpp:559-664): a CTU row
+ * of this picture starts when every reference picture has finished the rows down to refLagRows below it, and the in-loop filters follow the analysis row by
+ * row so that the rows of this picture become available to the pictures that reference it while its lower rows are still being analysed. */
+struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; };
+
+static int gateBeforeRow(void* ctx, int row)
+{
+    RowGate& g = *(RowGate*)ctx;
+    const x265amd_encoder& e = *g.e;
+    const int need = std::min(e.ctuH, row + 1 + e.refLagRows);
+    for (Pic* q : g.refs)
+    {
+        std::unique_lock<std::mutex> lk(q->mu);
+        q->cv.wait(lk, [&] { return q->reconRows >= need || q->failed; });
+        if (q->failed) return 1;
+    }
+    /* the co-located CTUs' depths (topSkipMinDepth reads refFrameList[l][0] at this CTU's address): that row of the reference picture is coded now */
+    for (int l = 0; l < 2; l++)
+        if (!g.pic->lists[l].empty())
+        {
+            const Pic* q = g.pic->lists[l][0].get();
+            const int y0 = row * 16, y1 = std::min(e.h4, y0 + 16);
+            for (int i = y0 * e.w4; i < y1 * e.w4; i++) (*g.refDepth)[l * g.nUnits + i] = q->units[i].depth;
+        }
+    return 0;
+}
+static void gateAfterRow(void* ctx, int row)
+{
+    RowGate& g = *(RowGate*)ctx;
+    { std::lock_guard<std::mutex> lk(g.pic->mu); g.pic->analysedRows = row + 1; }
+    g.pic->cv.notify_all();
+}
+
+/* The filter thread of a picture: FrameFilter::processRow / processPostRow for each CTU row as the analysis delivers it.  Row r is deblocked when row r + 1
+ * is analysed (its vertical edges, then its horizontal edges, which reach three samples up into row r - 1); its SAO statistics follow (they leave out the samples
+ * the rows below still change) and its parameters are decided; row r - 1 can then be offset (its last lines and the line below them are final), its borders
+ * extended and the row published.  The last row publishes itself. */
+int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags)
+{
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: stream");
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    const bool sao = p.bEnableSAO != 0, dbl = p.bEnableLoopFilter != 0;
+    const size_t nUnits = (size_t)w4 * h4, nstat = (size_t)nctu * 3 * 5 * 32, rowStat = (size_t)ctuW * 3 * 5 * 32;
+    struct Scratch { void* p = nullptr; ~Scratch() { xa_scratch_free(p); } } dDb, dCnt, dOrg, dPar;
+    std::vector<x265amd_deblock_unit> dbu;
+    std::vector<int32_t> cnt, orgs;
+    if (dbl) { if (xa_scratch_alloc(&dDb.p, sizeof(x265amd_deblock_unit) * nUnits) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: device allocation"); dbu.resize(nUnits); }
+    if (sao)
+    {
+        if (xa_scratch_alloc(&dCnt.p, nstat * 4) != hipSuccess || xa_scratch_alloc(&dOrg.p, nstat * 4) != hipSuccess || xa_scratch_alloc(&dPar.p, sizeof(x265amd_sao_ctu) * nctu) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder: device allocation");
+        cnt.resize(nstat); orgs.resize(nstat);
+        saoFlags[0] = saoFlags[1] = 1;          /* SAO::startSlice: never switched off when pictures are coded in parallel (sao.cpp:264) */
+    }
+    pixel* recY = pic.dRec + org[0]; pixel* recU = pic.dRec + org[1]; pixel* recV = pic.dRec + org[2];
+    const uint64_t recP[3] = { planeAddr(pic.dRec, 0), planeAddr(pic.dRec, 1), planeAddr(pic.dRec, 2) };
+    const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
+    pixel* fin = sao ? pic.dFin : pic.dRec;
+    const uint64_t finP[3] = { planeAddr(fin, 0), planeAddr(fin, 1), planeAddr(fin, 2) };
+    double unusedRate[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int rc = X265AMD_OK;
+    /* offsets, borders, publication of CTU row k */
+    auto finish = [&](int k) -> int {
+        const int y0 = k * 64, y1 = std::min(H, y0 + 64);
+        if (sao)
+        {
+            int r = x265amd_sao_apply_rows(st, recP, finP, stride, cstride, W, H, (const x265amd_sao_ctu*)dPar.p, k, k + 1);
+            if (r != X265AMD_OK) return r;
+        }
+        int r = x265amd_extend_border_rows(st, fin + org[0], stride, W, H, marginX, marginY, y0, y1);
+        if (r == X265AMD_OK) r = x265amd_extend_border_rows(st, fin + org[1], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2);
+        if (r == X265AMD_OK) r = x265amd_extend_border_rows(st, fin + org[2], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2);
+        if (r != X265AMD_OK) return r;
+        if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: row filters");
+        { std::lock_guard<std::mutex> lk(pic.mu); pic.reconRows = k + 1; }
+        pic.cv.notify_all();
+        return X265AMD_OK;
+    };
+    for (int r = 0; r < ctuH && rc == X265AMD_OK; r++)
+    {
+        {
+            std::unique_lock<std::mutex> lk(pic.mu);
+            /* intra prediction of row r + 1 reads the unfiltered last line of row r: FrameEncoder::m_filterRowDelay (frameencoder.cpp:124-126, :1936-1950) */
+            const int needRows = (dbl || sao) ? std::min(ctuH, r + 2) : r + 1;
+            pic.cv.wait(lk, [&] { return pic.analysedRows >= needRows || pic.failed; });
+            if (pic.failed) return X265AMD_EHIP;
+        }
+        const int y4b = r * 16, y4e = std::min(h4, y4b + 16);
+        if (dbl)
+        {
+            rc = x265amd_deblock_units_rows(&si, &info, pic.units.data(), pic.motion.data(), dbu.data(), y4b, y4e);
+            if (rc != X265AMD_OK) break;
+            if (hipMemcpyAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4, dbu.data() + (size_t)y4b * w4, sizeof(x265amd_deblock_unit) * (size_t)(y4e - y4b) * w4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+            { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
+            rc = x265amd_deblock_rows(st, recY, recU, recV, stride, cstride, W, H, (const x265amd_deblock_unit*)dDb.p, 0, 0, 0, 0, 0, 3, y4b, y4e);
+            if (rc != X265AMD_OK) break;
+        }
+        if (sao)
+        {
+            if (hipMemsetAsync((int32_t*)dCnt.p + r * rowStat, 0, rowStat * 4, st) != hipSuccess || hipMemsetAsync((int32_t*)dOrg.p + r * rowStat, 0, rowStat * 4, st) != hipSuccess)
+            { rc = xa_fail(X265AMD_EHIP, "encoder: sao memset"); break; }
+            rc = x265amd_sao_stats_rows(st, recP, srcP, stride, cstride, W, H, (int32_t*)dCnt.p, (int32_t*)dOrg.p, r, r + 1);
+            if (rc != X265AMD_OK) break;
+            if (hipMemcpyAsync(cnt.data() + r * rowStat, (int32_t*)dCnt.p + r * rowStat, rowStat * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(orgs.data() + r * rowStat, (int32_t*)dOrg.p + r * rowStat, rowStat * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            { rc = xa_fail(X265AMD_EHIP, "encoder: sao download"); break; }
+            int32_t flags[2] = { 1, 1 };
+            rc = x265amd_sao_rdo_rows(&si, pic.type != TYPE_B ? 1 : 0, 2, 0, 69, pic.units.data(), cnt.data(), orgs.data(), unusedRate, sparams.data(), flags, r, r + 1);
+            if (rc != X265AMD_OK) break;
+            if (hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + (size_t)r * ctuW, sparams.data() + (size_t)r * ctuW, sizeof(x265amd_sao_ctu) * ctuW, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+            { rc = xa_fail(X265AMD_EHIP, "encoder: sao upload"); break; }
+        }
+        if (!dbl && !sao) { rc = finish(r); continue; }         /* nothing below changes this row */
+        if (r > 0) rc = finish(r - 1);
+        if (rc == X265AMD_OK && r == ctuH - 1) rc = finish(r);
+    }
+    return rc;
+}
+
+int x265amd_encoder::runFrameParallel(const PicP& picp)
+{
+    Pic& pic = *picp;
+    /* whatever happens, the pictures waiting for rows of this one are released */
+    struct Release { Pic& pic; int* rc; ~Release() { if (*rc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } } };
+    int rc = X265AMD_EHIP;
+    Release release{ pic, &rc };
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: stream");
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    const std::vector<PicP>* lists = pic.lists;
+    FrameCtx fc;
+    frameContext(*this, pic, fc);
+    const Pic* colPic = fc.colPic;
+    const size_t nUnits = (size_t)w4 * h4;
+    std::vector<x265amd_mv_unit> noCol;
+    if (!colPic) { noCol.resize(nUnits); memset(noCol.data(), 0, sizeof(x265amd_mv_unit) * nUnits); }
+    std::vector<uint8_t> refDepth(2 * nUnits, 0);
+    std::vector<int8_t> refQp0(2 * (size_t)nctu, 0);
+    RowGate gate{ this, &pic, {}, &refDepth, nUnits };
+    for (int l = 0; l < 2; l++)
+    {
+        for (const PicP& q : lists[l]) if (std::find(gate.refs.begin(), gate.refs.end(), q.get()) == gate.refs.end()) gate.refs.push_back(q.get());
+        if (!lists[l].empty()) for (int i = 0; i < nctu; i++) refQp0[(size_t)l * nctu + i] = (int8_t)lists[l][0]->sliceQp;
+    }
+    std::vector<x265amd_cu_stat> stat((size_t)nctu + 1);
+    memset(stat.data(), 0, sizeof(x265amd_cu_stat) * stat.size());
+    std::vector<int16_t> coeff((size_t)nctu * RD_TILE_ELEMS, 0);
+    std::vector<uint8_t> data((size_t)W * H * 3 + (1u << 16));
+    std::vector<uint32_t> sizes((size_t)ctuH + 1, 0);
+    int nsub = 0;
+    const bool sao = p.bEnableSAO != 0;
+    std::vector<x265amd_sao_ctu> sparams((size_t)nctu);
+    memset(sparams.data(), 0, sizeof(x265amd_sao_ctu) * nctu);
+    int32_t saoFlags[2] = { 0, 0 };
+    int filterRc = X265AMD_OK;
+    std::thread filters([&] { filterRc = filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } });
+    const XaRowHooks hooks{ &gate, gateBeforeRow, gateAfterRow };
+    int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
+                               refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
+                               sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);
+    if (arc != X265AMD_OK) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); }
+    filters.join();
+    if (arc != X265AMD_OK) return rc = arc;
+    if (filterRc != X265AMD_OK) return rc = filterRc;
+    if (sao)
+    {
+        arc = x265amd_encode_slice_data(&fc.si, pic.units.data(), coeff.data(), sparams.data(), saoFlags, data.data(), data.size(), sizes.data(), &nsub);
+        if (arc != X265AMD_OK) return rc = arc;
+    }
+    arc = sliceNal(*this, pic, fc, saoFlags, data, sizes, nsub);
+    if (arc) return rc = arc;
+    xa_scratch_free(pic.dSrc); pic.dSrc = nullptr;
+    return rc = 0;
 }
 
 extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal, const x265amd_picture* picIn, x265amd_picture* picOut)
@@ -527,7 +794,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         const bool timing = getenv("X265AMD_TIMING") != nullptr;
         pic->done = std::async(std::launch::async, [e, pic, prev, timing]() {
             const auto t0 = std::chrono::steady_clock::now();
-            const int rc = e->runFrame(pic, prev);
+            const int rc = e->frameParallel ? e->runFrameParallel(pic) : e->runFrame(pic, prev);
             if (timing)
                 fprintf(stderr, "x265amd: poc %d type %d qp %d: %.2f ms\n", pic->poc, pic->type, pic->sliceQp,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -549,7 +816,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     if (picOut)
     {
         e->staging.resize(e->picElems);
-        if (hipMemcpy(e->staging.data(), front->dRec, e->picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder: recon download"); return -1; }
+        if (hipMemcpy(e->staging.data(), front->finalPlanes(), e->picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder: recon download"); return -1; }
         for (int k = 0; k < 3; k++)
         {
             if (!picOut->planes[k]) continue;

@@ -46,8 +46,9 @@ inline void clip_mv(Mv& mv, int cuX, int cuY, int picW, int picH)
     mv.x = mv.x < xmin ? xmin : (mv.x > xmax ? xmax : mv.x);
     mv.y = mv.y < ymin ? ymin : (mv.y > ymax ? ymax : mv.y);
 }
-/* Search::setSearchRange without frame-parallel / slice / intra-refresh restrictions (search.cpp:2724-2768) */
-inline void search_range(Mv mvp, int merange, int cuX, int cuY, int picW, int picH, Mv& mn, Mv& mx)
+/* Search::setSearchRange without slice / intra-refresh restrictions (search.cpp:2724-2768); lag = Search::m_refLagPixels: the picture height, or
+ * param.searchRange when pictures are coded in parallel (search.cpp:92) */
+inline void search_range(Mv mvp, int merange, int cuX, int cuY, int picW, int picH, int lag, Mv& mn, Mv& mx)
 {
     mn = Mv{ mvp.x - (merange << 2), mvp.y - (merange << 2) }; mx = Mv{ mvp.x + (merange << 2), mvp.y + (merange << 2) };
     clip_mv(mn, cuX, cuY, picW, picH); clip_mv(mx, cuX, cuY, picW, picH);
@@ -55,10 +56,12 @@ inline void search_range(Mv mvp, int merange, int cuX, int cuY, int picW, int pi
     mn.x = mn.x < -maxLen ? -maxLen : mn.x; mn.y = mn.y < -maxLen ? -maxLen : mn.y;
     mx.x = mx.x > maxLen ? maxLen : mx.x; mx.y = mx.y > maxLen ? maxLen : mx.y;
     mn.x >>= 2; mn.y >>= 2; mx.x >>= 2; mx.y >>= 2;
-    const int lag = picH;
     mn.y = mn.y < lag ? mn.y : lag; mx.y = mx.y < lag ? mx.y : lag;
     mx.y = mx.y > mn.y ? mx.y : mn.y;
 }
+
+/* merge and AMVP candidates a picture coded in parallel with its references must not use (search.cpp:1934-1936, :2009-2010; analysis.cpp:2803, :2933) */
+inline bool below_lag(int mvY, int searchRange) { return mvY >= (searchRange + 1) * 4; }
 
 } // namespace xa_inter
 #endif

@@ -99,7 +99,8 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     std::vector<x265amd_mc_job> finalMc;
 
     auto clipMv = [&](Mv& mv, int cuX, int cuY) { clip_mv(mv, cuX, cuY, I->pic_width, I->pic_height); };
-    auto searchRange = [&](Mv mvp, int merange, int cuX, int cuY, Mv& mn, Mv& mx) { search_range(mvp, merange, cuX, cuY, I->pic_width, I->pic_height, mn, mx); };
+    const int lagPixels = S->frame_parallel ? S->search_range : I->pic_height;          /* Search::m_refLagPixels (search.cpp:92) */
+    auto searchRange = [&](Mv mvp, int merange, int cuX, int cuY, Mv& mn, Mv& mx) { search_range(mvp, merange, cuX, cuY, I->pic_width, I->pic_height, lagPixels, mn, mx); };
     auto mcJob = [&](const Geo& g, int cuX, int cuY, int sliceP, int pic0, Mv mv0, int pic1, Mv mv1, int flags, int metric, int chromaCost) {
         x265amd_mc_job j;
         memset(&j, 0, sizeof(j));
@@ -238,6 +239,8 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             const bool chromaSatd = S->subpel_refine > 2 && S->chroma_mc && chromaOk;
             for (int k = 0; k < w.nMerge; k++)
             {
+                /* pictures coded in parallel: no candidate that reaches below the rows the reference pictures have finished (search.cpp:1918-1937) */
+                if (S->frame_parallel && (below_lag(w.mcand[k].mv[0][1], S->search_range) || below_lag(w.mcand[k].mv[1][1], S->search_range))) continue;
                 const uint32_t bits = (uint32_t)(k + (k < w.nMerge - 1));                  /* getTUBits */
                 const uint32_t cc = cost[2 * (w.mergeJob0 + k)] + cost[2 * (w.mergeJob0 + k) + 1] + getCost(bits);
                 if (cc < w.mrgCost) { w.mrgCost = cc; w.mrgBits = (int)bits; w.mrgIdx = k; }
@@ -247,7 +250,14 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 {
                     if (!allowed(w.cu, pidx, list, ref)) continue;
                     int idx = 0;
-                    if (w.mvpJob0[list][ref] >= 0) idx = cost[2 * w.mvpJob0[list][ref]] <= cost[2 * (w.mvpJob0[list][ref] + 1)] ? 0 : 1;
+                    if (w.mvpJob0[list][ref] >= 0)
+                    {
+                        /* selectMVP (search.cpp:1992-2024); coded in parallel, a candidate below the lag keeps COST_MAX (:2005-2010) */
+                        uint32_t c2[2] = { cost[2 * w.mvpJob0[list][ref]], cost[2 * (w.mvpJob0[list][ref] + 1)] };
+                        if (S->frame_parallel)
+                            for (int k = 0; k < 2; k++) if (below_lag(w.amvp[list][ref][k][1], S->search_range)) c2[k] = 1u << 28;
+                        idx = c2[0] <= c2[1] ? 0 : 1;
+                    }
                     w.mvpIdx[list][ref] = idx;
                     const Mv mvp{ w.amvp[list][ref][idx][0], w.amvp[list][ref][idx][1] };
                     Mv mn, mx;

@@ -11,9 +11,9 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 
-__global__ __launch_bounds__(256) void k_extend_border(pixel* pic, long stride, int width, int height, int marginX, int marginY)
+__global__ __launch_bounds__(256) void k_extend_border(pixel* pic, long stride, int width, int height, int marginX, int marginY, int firstRow)
 {
-    const int y = (int)blockIdx.x - marginY;                /* padded row */
+    const int y = firstRow + (int)blockIdx.x;               /* padded row (-marginY .. height + marginY - 1) */
     const int cy = min(max(y, 0), height - 1);
     const pixel* srcRow = pic + (long)cy * stride;
     pixel* dstRow = pic + (long)y * stride;
@@ -48,8 +48,17 @@ __global__ __launch_bounds__(256) void k_weight_plane(const pixel* src, pixel* d
 
 extern "C" int x265amd_extend_pic_border(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY)
 {
-    if (!d_pic || width <= 0 || height <= 0 || marginX < 0 || marginY < 0) return xa_fail(X265AMD_EINVAL, "x265amd_extend_pic_border: bad arguments");
-    hipLaunchKernelGGL(k_extend_border, dim3(height + 2 * marginY), dim3(256), 0, (hipStream_t)stream, (pixel*)d_pic, (long)stride, width, height, marginX, marginY);
+    return x265amd_extend_border_rows(stream, d_pic, stride, width, height, marginX, marginY, 0, height);
+}
+
+/* the margins beside picture lines y_begin .. y_end - 1, plus the top margin when the band holds line 0 and the bottom margin when it holds the last
+ * line: PicYuv borders as FrameFilter::processPostRow extends them row by row (reference: source/encoder/framefilter.cpp:592-664) */
+extern "C" int x265amd_extend_border_rows(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY, int y_begin, int y_end)
+{
+    if (!d_pic || width <= 0 || height <= 0 || marginX < 0 || marginY < 0 || y_begin < 0 || y_begin >= y_end || y_end > height)
+        return xa_fail(X265AMD_EINVAL, "x265amd_extend_pic_border: bad arguments");
+    const int first = y_begin == 0 ? -marginY : y_begin, last = y_end == height ? height + marginY : y_end;
+    hipLaunchKernelGGL(k_extend_border, dim3(last - first), dim3(256), 0, (hipStream_t)stream, (pixel*)d_pic, (long)stride, width, height, marginX, marginY, first);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;

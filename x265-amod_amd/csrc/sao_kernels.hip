@@ -11,7 +11,7 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 
-struct SaoPlanes { const pixel* rec[3]; const pixel* fenc[3]; pixel* dst[3]; long stride, cstride; int width, height; };
+struct SaoPlanes { const pixel* rec[3]; const pixel* fenc[3]; pixel* dst[3]; long stride, cstride; int width, height; int ctuRow0, ctuRows; };      /* the CTU rows of this launch */
 
 XA_DEV int sao_sgn(int v) { return (v > 0) - (v < 0); }
 XA_DEV int sao_class(int v, int a, int b)            /* SAO::s_eoTable[sign + sign + 2] (sao.cpp:65-72): {1, 2, 0, 3, 4} */
@@ -23,8 +23,8 @@ XA_DEV int sao_class(int v, int a, int b)            /* SAO::s_eoTable[sign + si
 __global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, int32_t* offsetOrg)
 {
     __shared__ int sCnt[5 * 32], sOrg[5 * 32];
-    const int plane = blockIdx.y, ctu = blockIdx.x;
     const int ctuW = (P.width + 63) >> 6;
+    const int plane = blockIdx.y, ctu = P.ctuRow0 * ctuW + blockIdx.x;
     const int cx = ctu % ctuW, cy = ctu / ctuW;
     const int sh = plane ? 1 : 0, po = plane ? 2 : 0;
     const long st = plane ? P.cstride : P.stride;
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void k_sao_apply(SaoPlanes P, const x265amd_sa
     const int sh = plane ? 1 : 0;
     const long st = plane ? P.cstride : P.stride;
     const int picW = P.width >> sh, picH = P.height >> sh;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= picW || y >= picH) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = ((P.ctuRow0 * 64) >> sh) + blockIdx.y;
+    if (x >= picW || y >= picH || y >= (((P.ctuRow0 + P.ctuRows) * 64) >> sh)) return;
     const int ctuW = (P.width + 63) >> 6;
     const x265amd_sao_ctu p = params[((y << sh) >> 6) * ctuW + ((x << sh) >> 6)];
     const int type = p.type[plane ? 1 : 0];
@@ -128,18 +128,28 @@ static int sao_fill(SaoPlanes& P, const uint64_t* rec, const uint64_t* fenc, con
         P.fenc[c] = fenc ? (const pixel*)(uintptr_t)fenc[c] : nullptr;
         P.dst[c] = dst ? (pixel*)(uintptr_t)dst[c] : nullptr;
     }
-    P.stride = (long)stride; P.cstride = (long)cstride; P.width = width; P.height = height;
+    P.stride = (long)stride; P.cstride = (long)cstride; P.width = width; P.height = height; P.ctuRow0 = 0; P.ctuRows = (height + 63) >> 6;
     return 0;
 }
 
 extern "C" int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
                                  int width, int height, int32_t* d_count, int32_t* d_offset_org)
 {
-    if (!rec_planes || !fenc_planes || !d_count || !d_offset_org || width <= 0 || height <= 0 || (width & 7) || (height & 7))
+    return x265amd_sao_stats_rows(stream, rec_planes, fenc_planes, stride, cstride, width, height, d_count, d_offset_org, 0, (height + 63) >> 6);
+}
+
+/* the statistics of CTU rows ctu_row_begin .. ctu_row_end - 1 (same arrays, indexed by the CTU's address in the picture).  A CTU's statistics leave out
+ * the samples the deblocking of the CTUs to its right and below still changes (sao.cpp:760-776), so a row can be measured as soon as it is deblocked itself. */
+extern "C" int x265amd_sao_stats_rows(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
+                                      int width, int height, int32_t* d_count, int32_t* d_offset_org, int ctu_row_begin, int ctu_row_end)
+{
+    if (!rec_planes || !fenc_planes || !d_count || !d_offset_org || width <= 0 || height <= 0 || (width & 7) || (height & 7) || ctu_row_begin < 0 || ctu_row_begin >= ctu_row_end ||
+        ctu_row_end > ((height + 63) >> 6))
         return xa_fail(X265AMD_EINVAL, "x265amd_sao_stats: bad arguments");
     SaoPlanes P;
     sao_fill(P, rec_planes, fenc_planes, nullptr, stride, cstride, width, height);
-    const int nctu = ((width + 63) >> 6) * ((height + 63) >> 6);
+    P.ctuRow0 = ctu_row_begin; P.ctuRows = ctu_row_end - ctu_row_begin;
+    const int nctu = ((width + 63) >> 6) * P.ctuRows;
     hipLaunchKernelGGL(k_sao_stats, dim3(nctu, 3), dim3(256), 0, (hipStream_t)stream, P, d_count, d_offset_org);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
@@ -149,11 +159,21 @@ extern "C" int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], con
 extern "C" int x265amd_sao_apply(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
                                  int width, int height, const x265amd_sao_ctu* d_params)
 {
-    if (!src_planes || !dst_planes || !d_params || width <= 0 || height <= 0 || (width & 7) || (height & 7))
+    return x265amd_sao_apply_rows(stream, src_planes, dst_planes, stride, cstride, width, height, d_params, 0, (height + 63) >> 6);
+}
+
+/* the offset samples of CTU rows ctu_row_begin .. ctu_row_end - 1; the rows' samples are classified on src, whose row below must be deblocked already */
+extern "C" int x265amd_sao_apply_rows(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
+                                      int width, int height, const x265amd_sao_ctu* d_params, int ctu_row_begin, int ctu_row_end)
+{
+    if (!src_planes || !dst_planes || !d_params || width <= 0 || height <= 0 || (width & 7) || (height & 7) || ctu_row_begin < 0 || ctu_row_begin >= ctu_row_end ||
+        ctu_row_end > ((height + 63) >> 6))
         return xa_fail(X265AMD_EINVAL, "x265amd_sao_apply: bad arguments");
     SaoPlanes P;
     sao_fill(P, src_planes, nullptr, dst_planes, stride, cstride, width, height);
-    hipLaunchKernelGGL(k_sao_apply, dim3((width + 255) / 256, height, 3), dim3(256), 0, (hipStream_t)stream, P, d_params);
+    P.ctuRow0 = ctu_row_begin; P.ctuRows = ctu_row_end - ctu_row_begin;
+    const int lines = (height < ctu_row_end * 64 ? height : ctu_row_end * 64) - ctu_row_begin * 64;
+    hipLaunchKernelGGL(k_sao_apply, dim3((width + 255) / 256, lines, 3), dim3(256), 0, (hipStream_t)stream, P, d_params);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;

@@ -78,6 +78,16 @@ void xa_prof_dependency_wait(uint64_t ns);        /* X265AMD_QUEUE_PROF: time a 
 struct XaRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };
 void xa_copy_rects(void* st, const XaRects& r);
 
+/* x265amd_analyse_frame with row hooks for pictures coded in parallel (csrc/ctu_analysis.hip; used by the encoder object): before_row(ctx, row) returns when
+ * the reference pictures have finished the rows CTU row `row` may read (non-zero: give up), after_row(ctx, row) is called once the row is analysed and its
+ * reconstruction is in device memory.  Rows finish in order. */
+struct XaRowHooks { void* ctx; int (*before_row)(void* ctx, int row); void (*after_row)(void* ctx, int row); };
+int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                     const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                     const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                     intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
+                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks);
+
 /* device address of the centre (MVD 0) of x265amd_me_ctx's MV cost table for `qp` (BitCost::s_costs[qp]) */
 const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp);
 

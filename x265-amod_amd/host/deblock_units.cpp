@@ -10,8 +10,15 @@
 extern "C" int x265amd_deblock_units(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
                                      x265amd_deblock_unit* out)
 {
-    if (!si || !info || !units || !motion || !out) return X265AMD_EINVAL;
-    const int w4 = si->pic_width >> 2, h4 = si->pic_height >> 2;
+    if (!si) return X265AMD_EINVAL;
+    return x265amd_deblock_units_rows(si, info, units, motion, out, 0, si->pic_height >> 2);
+}
+
+extern "C" int x265amd_deblock_units_rows(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
+                                          x265amd_deblock_unit* out, int y4_begin, int y4_end)
+{
+    if (!si || !info || !units || !motion || !out || y4_begin < 0 || y4_end > (si->pic_height >> 2)) return X265AMD_EINVAL;
+    const int w4 = si->pic_width >> 2;
     /* picture identities: equal POC = same picture, whatever the list */
     int pocs[32], npoc = 0;
     auto ident = [&](int list, int refIdx) -> int {
@@ -21,7 +28,10 @@ extern "C" int x265amd_deblock_units(const x265amd_slice_info* si, const x265amd
         pocs[npoc] = poc;
         return npoc++;
     };
-    for (int y4 = 0; y4 < h4; y4++)
+    /* the same numbers whichever rows a call covers: every reference picture of the slice, list 0 first */
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < info->num_ref_idx[l] && r < 16; r++) (void)ident(l, r);
+    for (int y4 = y4_begin; y4 < y4_end; y4++)
         for (int x4 = 0; x4 < w4; x4++)
         {
             const x265amd_cu_unit& u = units[y4 * w4 + x4];

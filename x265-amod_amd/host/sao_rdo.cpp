@@ -211,8 +211,22 @@ struct Rdo
 extern "C" int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
                                const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags)
 {
+    if (!si) return X265AMD_EINVAL;
+    return x265amd_sao_rdo_rows(si, referenced, frame_threads, qp_min, qp_max, units, count, offset_org, depth_sao_rate, params, sao_flags, 0, (si->pic_height + 63) >> 6);
+}
+
+/* CTU rows ctu_row_begin .. ctu_row_end - 1 of the same decision: every CTU row owns its SAO object and entropy state in the reference (framefilter.cpp:239), and
+ * a CTU only looks at the parameters of its left and upper neighbours, so rows can be decided one by one in order.  The share of unfiltered CTUs
+ * (depth_sao_rate, rdoSaoUnitRowEnd) is only kept when the call covers the whole picture; the reference reads it with one frame thread only (sao.cpp:264). */
+extern "C" int x265amd_sao_rdo_rows(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                                    const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags,
+                                    int ctu_row_begin, int ctu_row_end)
+{
     if (!si || !units || !count || !offset_org || !depth_sao_rate || !params || !sao_flags) return X265AMD_EINVAL;
     const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2;
+    if (ctu_row_begin < 0 || ctu_row_begin >= ctu_row_end || ctu_row_end > ctuH) return X265AMD_EINVAL;
+    const bool whole = ctu_row_begin == 0 && ctu_row_end == ctuH;
+    if (!whole && frame_threads == 1) return X265AMD_EINVAL;
     /* SAO::startSlice */
     const int refDepth = si->slice_type == 2 ? 0 : (si->slice_type == 1 ? 1 : 2 + !referenced);
     sao_flags[0] = 1; sao_flags[1] = 1;
@@ -229,7 +243,7 @@ extern "C" int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int
     if (!R->c) { delete R; return X265AMD_EINVAL; }
     Snap init;
     R->store(init);
-    for (int addr = 0; addr < numCtu; addr++)
+    for (int addr = ctu_row_begin * ctuW; addr < ctu_row_end * ctuW; addr++)
     {
         const int idxX = addr % ctuW, row = addr / ctuW;
         if (!idxX) R->cur = init;                   /* every CTU row owns its SAO object and entropy state */
@@ -294,8 +308,11 @@ extern "C" int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int
         R->store(R->cur);
     }
     /* rdoSaoUnitRowEnd */
-    depth_sao_rate[refDepth] = sao_flags[0] ? numNoSao[0] / (double)numCtu : 1.0;
-    depth_sao_rate[4 + refDepth] = sao_flags[1] ? numNoSao[1] / (double)numCtu : 1.0;
+    if (whole)
+    {
+        depth_sao_rate[refDepth] = sao_flags[0] ? numNoSao[0] / (double)numCtu : 1.0;
+        depth_sao_rate[4 + refDepth] = sao_flags[1] ? numNoSao[1] / (double)numCtu : 1.0;
+    }
     x265amd_cabac_close(R->c);
     delete R;
     return X265AMD_OK;
