@@ -42,7 +42,8 @@ HBM_PEAK_GBS = 8000.0                # /opt/skills/guides/MI355X_MICROARCH.md: H
 BFRAMES, REFS, QP = 4, 3, 30
 
 # x265amd_param fields that differ from x265amd_param_default, and the same settings on the reference's command line
-ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1)
+# frameNumThreads > 1: the reference's frame-parallel rules, i.e. what its default (--frame-threads 0 = by core count) gives on any machine with four cores or more
+ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5)
 REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "0",
            "--no-b-pyramid", "--no-scenecut", "--rd", "3", "--sao", "--wpp", "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", str(REFS), "--max-merge", "3",
            "--no-info", "--no-open-gop", "--rc-lookahead", "5", "--lookahead-slices", "0"]
@@ -135,9 +136,9 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True):
 
 def reference_encode(frames):
     """the same clip through the reference encoder (oracle/_ref/x265_ref8: the reference compiled by oracle/build_ref.sh, C primitives, no assembly) on
-    this box's host cores, twice: with --frame-threads 1 (a picture starts when its references are complete, which is how the encoder object schedules,
-    so THAT stream is the parity target) and with its defaults (frame threads by core count; the reference then clips vertical motion to the rows its
-    frame threads have finished, frameencoder.cpp:893-908, and a clip with enough motion codes a few bytes differently).  Returns a dict or None."""
+    this box's host cores, twice: with its defaults (frame threads by core count -- 5 for 1080p on 32 cores or more, threadpool.cpp:661-677: THAT stream is
+    the parity target, the encoder object runs with the same frame-parallel rules) and with --frame-threads 1 (informational: one picture at a time; vertical
+    motion is then not limited to the lag, so a clip with enough motion codes differently).  Returns a dict or None."""
     exe = os.path.join(ROOT, "oracle", "_ref", "x265_ref8")
     if not os.path.exists(exe):
         return None
@@ -150,7 +151,7 @@ def reference_encode(frames):
                 for pl in fr:
                     f.write(np.ascontiguousarray(pl).tobytes())
         out = {"cores": os.cpu_count()}
-        for tag, extra in (("f1", ["--frame-threads", "1"]), ("default", [])):
+        for tag, extra in (("default", []), ("f1", ["--frame-threads", "1"])):
             t0 = time.perf_counter()
             r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc"] + REF_CLI + extra, cwd=d, capture_output=True, text=True, timeout=900)
             wall = time.perf_counter() - t0
@@ -193,7 +194,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    os.environ.setdefault("X265AMD_FRAME_THREADS", str(BFRAMES + 2))      # the B frames of a mini-GOP and the next P in flight together
 
     def sync():
         torch.cuda.synchronize()
@@ -221,15 +221,14 @@ def main():
     if rank == 0:
         ref = None if (world > 1 or args.no_cpu_baseline) else reference_encode(frames)
         if ref is not None:
-            same = ref["f1"]["stream"] == stream
-            best = min(ref["f1"]["seconds"], ref["default"]["seconds"])
-            cpu = {"value": K / best, "unit": "frames/s", "cores": ref["cores"], "kind": "reference",
+            same = ref["default"]["stream"] == stream
+            cpu = {"value": K / ref["default"]["seconds"], "unit": "frames/s", "cores": ref["cores"], "kind": "reference",
                    "sample": "the same %d-frame 1920x1080 clip and options through oracle/_ref/x265_ref8 (the reference itself compiled from /root/reference, C primitives: no "
-                             "assembler in the image) on this box's %d hardware threads, its thread pool at its default; value = the faster of its two runs, by its own "
+                             "assembler in the image) on this box's %d hardware threads, thread pool and frame threads at their defaults; by its own "
                              "'encoded N frames in T' figure" % (K, ref["cores"]),
-                   "frame_threads_1": {"frames_per_s": K / ref["f1"]["seconds"], "says": ref["f1"]["says"], "stream_equals_ours": bool(same)},
-                   "frame_threads_default": {"frames_per_s": K / ref["default"]["seconds"], "says": ref["default"]["says"],
-                                             "stream_equals_frame_threads_1": bool(ref["default"]["stream"] == ref["f1"]["stream"])}}
+                   "frame_threads_default": {"frames_per_s": K / ref["default"]["seconds"], "says": ref["default"]["says"], "stream_equals_ours": bool(same)},
+                   "frame_threads_1": {"frames_per_s": K / ref["f1"]["seconds"], "says": ref["f1"]["says"],
+                                       "stream_equals_default": bool(ref["default"]["stream"] == ref["f1"]["stream"])}}
         else:
             same, cpu = None, None
         # algorithmic bytes of a frame = payload x (source read + reconstruction write + distinct reference pictures read)
@@ -244,10 +243,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1920x1080 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + fixed mini-GOPs of %d B frames), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
-                                   "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, CABAC, Annex-B stream; CQP %d with "
+                                   "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
                                    "the lookahead's decisions fixed (no b-adapt / scenecut / AQ / cutree / weighted prediction: not built yet, switched off on both sides)" % (K, BFRAMES, REFS, QP),
                        "frames_per_step_per_gpu": 1, "parallelism": "closed GOP per GPU x%d" % world if world > 1 else "one encoder object",
-                       "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI) + " --frame-threads 1"},
+                       "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},
             "bit_exact_vs_reference_encoder": same,
             "stream": {"bytes_per_gop": [s[0] for s in sizes], "md5_per_gop": [s[1] for s in sizes]},
             "cpu_baseline": cpu,

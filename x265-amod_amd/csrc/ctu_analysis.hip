@@ -30,6 +30,8 @@ using namespace xa_inter;
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
+#include "xa_fiber.h"
 #include <mutex>
 #include <thread>
 /* X265AMD_TIMING=1: wall time per analysis stage, printed per frame by x265amd_analyse_frame */
@@ -1279,7 +1281,13 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         void* q = dumping ? nullptr : xa_queue_acquire();
         for (int addr = 0; addr < numCtu && rc == X265AMD_OK; addr++)
         {
-            if (hooks && addr % ctuW == 0 && hooks->before_row(hooks->ctx, addr / ctuW)) { rc = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"); break; }
+            if (hooks && addr % ctuW == 0)
+            {
+                struct W { const XaRowHooks* h; int row; } w{ hooks, addr / ctuW };
+                xa_wait_until([](void* c) -> int { W* x = (W*)c; return x->h->row_ready(x->h->ctx, x->row) != 0; }, &w);
+                if (hooks->row_ready(hooks->ctx, addr / ctuW) < 0) { rc = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"); break; }
+                hooks->before_row(hooks->ctx, addr / ctuW);
+            }
             rc = doCtu(addr, q ? q : stream);
             if (rc == X265AMD_OK && xa_stream_sync(q ? q : stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
             if (hooks && rc == X265AMD_OK && addr % ctuW == ctuW - 1) hooks->after_row(hooks->ctx, addr / ctuW);
@@ -1288,90 +1296,104 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
     }
     else
     {
-        /* Wavefront parallel processing as the reference's row threads run it (frameencoder.cpp:1399-1968): CTU (r, c) starts when (r - 1, c + 1)
+        /* Wavefront parallel processing as the reference's row jobs run it (frameencoder.cpp:1399-1968): CTU (r, c) starts when (r - 1, c + 1)
          * is finished -- its neighbours' decisions, reconstruction, cost statistics and the contexts saved after (r - 1, 1) are then final, so
-         * every CTU sees exactly what the serial order shows it.  One host thread and one HIP stream per row in flight; the block operations of
-         * different rows overlap on the device. */
+         * every CTU sees exactly what the serial order shows it.  Every CTU row is a task on the worker threads (xa_fiber.h) with a device job queue
+         * while it runs; the block operations of different rows overlap on the device, and a row that waits (for the device, for the row above, for
+         * a reference picture) leaves its worker thread to the rows that can go on.  A row takes its queue only when the reference pictures let it
+         * start and after the row above has taken one, and gives it back at the end of the row: every held queue belongs to a row that can run,
+         * whatever the number of pictures in flight, so waiting for a queue always ends. */
         if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
-        std::vector<int> done((size_t)ctuH, 0);
-        std::mutex m;
-        std::condition_variable cv;
-        std::atomic<int> nextRow(0), firstErr(X265AMD_OK);
-        int queuedRows = 0;         /* with hooks: rows that hold (or have held) a queue; guarded by m */
-        auto worker = [&]() {
-            /* a device job queue per row in flight (x265amd_host.h); a HIP stream when the queues are off or all taken.  Pictures coded in parallel (hooks):
-             * a row takes its queue only when the reference pictures let it start, after the row above has taken one, and gives it back at the end of the
-             * row -- so every held queue belongs to a row that can run, whatever the number of pictures in flight, and waiting for a queue always ends. */
-            void* st = nullptr;
-            hipStream_t own = nullptr;
-            auto take = [&]() -> bool {
-                st = dumping ? nullptr : xa_queue_acquire();
-                if (st) return true;
-                if (!own && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { firstErr = xa_fail(X265AMD_EHIP, "analyse_frame: stream"); cv.notify_all(); return false; }
-                st = own;
-                return true;
-            };
-            if (!hooks && !take()) return;
-            for (;;)
+        struct Frame
+        {
+            std::vector<volatile uint64_t*> done;   /* CTUs finished per row: counters the parked rows below wait on (xa_fiber.h) */
+            volatile uint64_t* queuedRows;          /* rows that hold (or have held) a queue */
+            std::atomic<int> firstErr{ X265AMD_OK };
+            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc;
+            std::function<int(int, void*)> doCtu;
+            explicit Frame(int rowsN) : done(rowsN) { for (auto& d : done) d = xa_counter_alloc(); queuedRows = xa_counter_alloc(); }
+            ~Frame() { for (auto& d : done) xa_counter_free(d); xa_counter_free(queuedRows); }
+        } F(ctuH);
+        F.hooks = hooks; F.ctuW = ctuW; F.ctuH = ctuH; F.dumping = dumping; F.poc = I->poc; F.doCtu = doCtu;
+        struct Row { Frame* f; int row; };
+        std::vector<Row> rowsArg((size_t)ctuH);
+        std::vector<XaTask> tasks((size_t)ctuH);
+        static std::atomic<uint64_t> frameSeq{ 0 };
+        const uint64_t seq = frameSeq.fetch_add(1);         /* analyses start in coding order: older pictures' rows go first */
+        auto rowReady = [](void* c) -> int {
+            Row* r = (Row*)c; Frame& f = *r->f;
+            if (f.firstErr.load() != X265AMD_OK) return 1;
+            return f.hooks ? f.hooks->row_ready(f.hooks->ctx, r->row) != 0 : 1;
+        };
+        auto rowMain = [](void* c) {
+            Row* r = (Row*)c; Frame& f = *r->f;
+            const int row = r->row, ctuW = f.ctuW;
+            const auto tStart = std::chrono::steady_clock::now();
+            if (f.hooks && f.firstErr.load() == X265AMD_OK)
             {
-                const int row = nextRow.fetch_add(1);
-                if (row >= ctuH) break;
-                if (hooks)
-                {
-                    if (firstErr.load() == X265AMD_OK && hooks->before_row(hooks->ctx, row))
-                    {
-                        int ok = X265AMD_OK;
-                        firstErr.compare_exchange_strong(ok, xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"));
-                    }
-                    {
-                        std::unique_lock<std::mutex> lk(m);
-                        cv.wait(lk, [&] { return queuedRows >= row; });
-                    }
-                    const bool ok = take();
-                    { std::lock_guard<std::mutex> lk(m); queuedRows = row + 1; }
-                    cv.notify_all();
-                    if (!ok) { std::lock_guard<std::mutex> lk(m); done[row] = ctuW; cv.notify_all(); continue; }
-                }
-                for (int c = 0; c < ctuW; c++)
-                {
-                    if (row)
-                    {
-                        const int need = c + 2 < ctuW ? c + 2 : ctuW;
-                        const auto w0 = std::chrono::steady_clock::now();
-                        std::unique_lock<std::mutex> lk(m);
-                        cv.wait(lk, [&] { return done[row - 1] >= need || firstErr.load() != X265AMD_OK; });
-                        xa_prof_dependency_wait((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
-                    }
-                    int r = firstErr.load();
-                    if (r == X265AMD_OK) r = doCtu(row * ctuW + c, st);
-                    if (r == X265AMD_OK && xa_stream_sync(st) != hipSuccess) r = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");
-                    {
-                        std::lock_guard<std::mutex> lk(m);
-                        if (r != X265AMD_OK) { int ok = X265AMD_OK; firstErr.compare_exchange_strong(ok, r); }
-                        done[row] = c + 1;
-                    }
-                    cv.notify_all();
-                    if (r != X265AMD_OK) break;
-                    if (hooks && c == ctuW - 1) hooks->after_row(hooks->ctx, row);
-                }
-                if (firstErr.load() != X265AMD_OK) { std::lock_guard<std::mutex> lk(m); done[row] = ctuW; cv.notify_all(); }
-                if (hooks && st && st != (void*)own) { xa_queue_release(st); st = nullptr; }
+                if (f.hooks->row_ready(f.hooks->ctx, row) < 0) { int ok = X265AMD_OK; f.firstErr.compare_exchange_strong(ok, xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed")); }
+                else f.hooks->before_row(f.hooks->ctx, row);
             }
+            void* st = f.dumping ? nullptr : xa_queue_acquire();
+            hipStream_t own = nullptr;
+            if (!st)
+            {
+                if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { int ok = X265AMD_OK; f.firstErr.compare_exchange_strong(ok, xa_fail(X265AMD_EHIP, "analyse_frame: stream")); }
+                st = own;
+            }
+            std::atomic_thread_fence(std::memory_order_release);
+            *f.queuedRows = (uint64_t)(row + 1);
+            const auto tQueue = std::chrono::steady_clock::now();
+            for (int c2 = 0; c2 < ctuW; c2++)
+            {
+                if (row)
+                {
+                    const int need = c2 + 2 < ctuW ? c2 + 2 : ctuW;
+                    const auto w0 = std::chrono::steady_clock::now();
+                    xa_wait_counter(f.done[row - 1], (uint64_t)need);          /* a failing row sets its counter to the end, so this always ends */
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    xa_prof_dependency_wait((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
+                }
+                int r2 = f.firstErr.load();
+                if (r2 == X265AMD_OK && !st) r2 = X265AMD_EHIP;
+                if (r2 == X265AMD_OK) r2 = f.doCtu(row * ctuW + c2, st);
+                if (r2 == X265AMD_OK && xa_stream_sync(st) != hipSuccess) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");
+                if (r2 != X265AMD_OK) { int ok = X265AMD_OK; f.firstErr.compare_exchange_strong(ok, r2); }
+                std::atomic_thread_fence(std::memory_order_release);
+                *f.done[row] = (uint64_t)(c2 + 1);
+                if (r2 != X265AMD_OK) break;
+                if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
+            }
+            if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;
             if (own) (void)hipStreamDestroy(own);
             else if (st) xa_queue_release(st);
+            if (g_timing && f.hooks)
+            {
+                static const auto t00 = std::chrono::steady_clock::now();
+                auto ms = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(t - t00).count(); };
+                fprintf(stderr, "x265amd: row: poc %d row %d start %.1f queue %.1f end %.1f ran %.1f\n", f.poc, row, ms(tStart), ms(tQueue), ms(std::chrono::steady_clock::now()), xa_task_run_ns() / 1e6);
+            }
         };
+        for (int r = 0; r < ctuH; r++)
+        {
+            rowsArg[r] = Row{ &F, r };
+            tasks[r].fn = rowMain; tasks[r].arg = &rowsArg[r]; tasks[r].ready = rowReady; tasks[r].readyCtx = &rowsArg[r];
+            tasks[r].startCounter = F.queuedRows; tasks[r].startValue = (uint64_t)r;          /* after the row above has taken its queue */
+            tasks[r].priority = (seq << 12) | (uint64_t)r;
+        }
         if (rc == X265AMD_OK)
         {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < rowThreads; t++) pool.emplace_back(worker);
-            for (auto& t : pool) t.join();
-            rc = firstErr.load();
+            xa_tasks_run(tasks.data(), ctuH);
+            rc = F.firstErr.load();
             if (rc != X265AMD_OK) xa_fail(rc, "analyse_frame: a CTU row failed");
         }
     }
     for (x265amd_cabac* c : rows) x265amd_cabac_close(c);
     if (g_timing)
     {
+        uint64_t ss[3];
+        xa_sched_stats(ss);
+        fprintf(stderr, "x265amd: workers so far: %.1f ms running tasks, %.1f ms looking for one, %llu switches\n", ss[0] / 1e6, ss[1] / 1e6, (unsigned long long)ss[2]);
         fprintf(stderr, "x265amd: analysis stages (ms):");
         for (int k = 0; k < 5; k++) { fprintf(stderr, " %s %.1f", g_stageName[k], g_stageMs[k]); g_stageMs[k] = 0; }
         fprintf(stderr, "\n");

@@ -6,6 +6,7 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 #include "xa_queue.h"
+#include "xa_fiber.h"
 /* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside" */
 __shared__ unsigned long long xa_stage_acc[16];
 __shared__ long long xa_stage_prev;
@@ -526,6 +527,7 @@ struct Server
     int refs = 0;
     uint64_t generation = 0;
     bool disabled = false, ringsInHost = false;
+    volatile uint64_t freeCount = 0;            /* queues not taken (what parked row tasks watch; changed under the lock) */
 
     int init()
     {
@@ -555,6 +557,7 @@ struct Server
         q.resize(n);
         for (int i = 0; i < n; i++) { q[i].idx = i; q[i].rd = rings + i; q[i].rh = hosts + i; q[i].staging = staging + kStagingBytes * i; }
         numQueues = n;
+        freeCount = n;
         if (getenv("X265AMD_QUEUE_DEBUG") && (atoi(getenv("X265AMD_QUEUE_DEBUG")) & 2)) signal(SIGABRT, dump_debug_areas);
         return 0;
     }
@@ -644,6 +647,14 @@ int q_wait(XaQueue* q, uint64_t target)
     if (*tail >= target) return 0;
     const auto t0 = std::chrono::steady_clock::now();
     struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { if (g_prof) { g_waitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_waits++; } } } acc{ t0 };
+    if (xa_in_task())
+    {
+        /* a row task: park; the worker thread runs another row meanwhile (xa_fiber.h).  A server that went away shows as a wait without end, as below:
+         * the tasks of the picture then never finish, which the 30 s limit of the ordinary path turns into an error for direct callers only. */
+        xa_wait_counter(tail, target);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return 0;
+    }
     for (unsigned spins = 0;; spins++)
     {
         if (*tail >= target) break;
@@ -713,10 +724,19 @@ void* xa_queue_acquire()
     {
         for (XaQueue& x : S.q) if (!x.busy) { f = &x; break; }
         if (f) break;
+        if (xa_in_task())
+        {
+            /* a row task never sleeps on a condition variable: it parks until a queue is given back */
+            g.unlock();
+            xa_wait_counter(&S.freeCount, 1);
+            g.lock();
+            continue;
+        }
         if (S.freed.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) return nullptr;
     }
     if (S.start() != 0) return nullptr;
     f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear();
+    S.freeCount = S.freeCount - 1;
     S.refs++;
     xa_scratch_local_begin();           /* the calling thread is the one that uses the queue */
     f->acquired = std::chrono::steady_clock::now();
@@ -733,6 +753,7 @@ void xa_queue_release(void* st)
     Server& S = server();
     std::lock_guard<std::mutex> g(S.m);
     q->busy = false;
+    S.freeCount = S.freeCount + 1;
     S.freed.notify_one();
     if (g_prof) g_heldNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - q->acquired).count();
     if (getenv("X265AMD_QUEUE_DEBUG") && q->rh->dbg[63]) fprintf(stderr, "x265amd queue %d: %llu command slot re-reads so far\n", q->idx, (unsigned long long)q->rh->dbg[63]);

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -53,8 +54,9 @@ struct Pic
     pixel* dFin = nullptr;
     std::mutex mu;
     std::condition_variable cv;
-    int reconRows = 0, analysedRows = 0;
-    bool failed = false;
+    std::atomic<int> reconRows{ 0 };        /* polled by the row tasks of the pictures that reference this one */
+    int analysedRows = 0;
+    std::atomic<bool> failed{ false };
     const pixel* finalPlanes() const { return dFin ? dFin : dRec; }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); }
     ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); }
@@ -597,17 +599,22 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
  * row so that the rows of this picture become available to the pictures that reference it while its lower rows are still being analysed. */
 struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; };
 
-static int gateBeforeRow(void* ctx, int row)
+static int gateRowReady(void* ctx, int row)
 {
     RowGate& g = *(RowGate*)ctx;
     const x265amd_encoder& e = *g.e;
     const int need = std::min(e.ctuH, row + 1 + e.refLagRows);
     for (Pic* q : g.refs)
     {
-        std::unique_lock<std::mutex> lk(q->mu);
-        q->cv.wait(lk, [&] { return q->reconRows >= need || q->failed; });
-        if (q->failed) return 1;
+        if (q->failed.load(std::memory_order_acquire)) return -1;
+        if (q->reconRows.load(std::memory_order_acquire) < need) return 0;
     }
+    return 1;
+}
+static void gateBeforeRow(void* ctx, int row)
+{
+    RowGate& g = *(RowGate*)ctx;
+    const x265amd_encoder& e = *g.e;
     /* the co-located CTUs' depths (topSkipMinDepth reads refFrameList[l][0] at this CTU's address): that row of the reference picture is coded now */
     for (int l = 0; l < 2; l++)
         if (!g.pic->lists[l].empty())
@@ -616,7 +623,6 @@ static int gateBeforeRow(void* ctx, int row)
             const int y0 = row * 16, y1 = std::min(e.h4, y0 + 16);
             for (int i = y0 * e.w4; i < y1 * e.w4; i++) (*g.refDepth)[l * g.nUnits + i] = q->units[i].depth;
         }
-    return 0;
 }
 static void gateAfterRow(void* ctx, int row)
 {
@@ -667,8 +673,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
         if (r == X265AMD_OK) r = x265amd_extend_border_rows(st, fin + org[2], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2);
         if (r != X265AMD_OK) return r;
         if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: row filters");
-        { std::lock_guard<std::mutex> lk(pic.mu); pic.reconRows = k + 1; }
-        pic.cv.notify_all();
+        pic.reconRows.store(k + 1, std::memory_order_release);
         return X265AMD_OK;
     };
     for (int r = 0; r < ctuH && rc == X265AMD_OK; r++)
@@ -751,7 +756,7 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     int32_t saoFlags[2] = { 0, 0 };
     int filterRc = X265AMD_OK;
     std::thread filters([&] { filterRc = filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } });
-    const XaRowHooks hooks{ &gate, gateBeforeRow, gateAfterRow };
+    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
                                sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);

@@ -8,6 +8,7 @@
  */
 #include <utility>
 #include "x265amd_host.h"
+#include "xa_fiber.h"
 #include "xa_queue.h"
 #include "../host/primitive_table.h"
 
@@ -184,6 +185,8 @@ ScratchPool& scratch_pool() { static ScratchPool* p = new ScratchPool; return *p
 }
 namespace { thread_local std::map<size_t, std::vector<void*>>* t_local = nullptr; }
 void xa_scratch_local_begin() { if (!t_local) t_local = new std::map<size_t, std::vector<void*>>; }
+/* row tasks (xa_fiber.h): the list belongs to the task, not to the worker thread that happens to run it */
+void* xa_scratch_local_swap(void* list) { void* old = t_local; t_local = static_cast<std::map<size_t, std::vector<void*>>*>(list); return old; }
 void xa_scratch_local_end()
 {
     if (!t_local) return;

@@ -78,10 +78,11 @@ void xa_prof_dependency_wait(uint64_t ns);        /* X265AMD_QUEUE_PROF: time a 
 struct XaRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };
 void xa_copy_rects(void* st, const XaRects& r);
 
-/* x265amd_analyse_frame with row hooks for pictures coded in parallel (csrc/ctu_analysis.hip; used by the encoder object): before_row(ctx, row) returns when
- * the reference pictures have finished the rows CTU row `row` may read (non-zero: give up), after_row(ctx, row) is called once the row is analysed and its
- * reconstruction is in device memory.  Rows finish in order. */
-struct XaRowHooks { void* ctx; int (*before_row)(void* ctx, int row); void (*after_row)(void* ctx, int row); };
+/* x265amd_analyse_frame with row hooks for pictures coded in parallel (csrc/ctu_analysis.hip; used by the encoder object): row_ready(ctx, row) says whether
+ * the reference pictures have finished the rows CTU row `row` may read (1 yes, 0 not yet, -1 a reference picture failed; polled, no blocking, no side
+ * effects), before_row(ctx, row) runs once before the row's first CTU, after_row(ctx, row) once the row is analysed and its reconstruction is in device
+ * memory.  Rows finish in order. */
+struct XaRowHooks { void* ctx; int (*row_ready)(void* ctx, int row); void (*before_row)(void* ctx, int row); void (*after_row)(void* ctx, int row); };
 int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
