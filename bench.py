@@ -50,24 +50,26 @@ REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree
 
 
 def bench_clip(first, count):
-    """frames first .. first + count - 1 (display order) of the synthetic clip: a textured picture drifting a few samples per frame plus noise.
-    Integer arithmetic only, and frame t depends on t alone, so every rank (and the reference run) sees the same pictures."""
-    rng = np.random.default_rng(20261002)
-    big = rng.integers(0, 256, ((H + 224) // 8 + 2, (W + 224) // 8 + 2)).astype(np.int64)
-    big = np.kron(big, np.ones((8, 8), np.int64))
-    big = (big + np.roll(big, 3, 0) + np.roll(big, 5, 1) + np.roll(big, -2, 1)) // 4
-    cb = (np.roll(big, 7, 0)[::2, ::2] + big[1::2, 1::2]) // 2
-    cr = (np.roll(big, 11, 1)[::2, ::2] + big[::2, 1::2]) // 2
+    """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes: luma = a smooth 2-D integer gradient shifted by
+    (2t, t) samples plus a noise field in [-12, 12] that moves with it (so motion estimation has real work and every block carries a residual), chroma = low-frequency
+    integer ramps shifted by (t, t / 2); the noise field is re-seeded every 24th frame.  Integer arithmetic only, and frame t depends on t alone, so every rank
+    (and the reference run) sees the same pictures."""
+    def tri(a, period):
+        a = a % period
+        return np.minimum(a, period - a)
     frames = []
     for t in range(first, first + count):
-        noise = np.random.default_rng(977 * t + 13)
-        dx, dy = 2 * ((3 * t) % 31), 2 * ((2 * t) % 23)
-        planes = []
-        for (src, pw, ph, sx, sy) in ((big, W, H, dx, dy), (cb, W // 2, H // 2, dx // 2, dy // 2), (cr, W // 2, H // 2, dx // 2, dy // 2)):
-            o = 16 if src is big else 8
-            core = src[o + sy:o + sy + ph, o + sx:o + sx + pw] + noise.integers(-2, 3, (ph, pw))
-            planes.append(np.clip(core, 0, 255).astype(np.uint8))
-        frames.append(planes)
+        epoch = t // 24
+        noise = np.random.default_rng(0x9E3779B9 ^ (2 << 8) ^ (epoch << 20)).integers(-12, 13, (H + 64, W + 128))     # cfg_id 2; indexed by the moving coordinates
+        tt = t % 24
+        v = np.arange(H, dtype=np.int64)[:, None] + tt + 24 * epoch
+        u = np.arange(W, dtype=np.int64)[None, :] + 2 * tt + 48 * epoch
+        luma = 60 + (tri(u, 512) * 96) // 256 + (tri(v, 384) * 64) // 192 + noise[tt:tt + H, 2 * tt:2 * tt + W]
+        vc = np.arange(H // 2, dtype=np.int64)[:, None] + t // 2
+        uc = np.arange(W // 2, dtype=np.int64)[None, :] + t
+        cb = 96 + (tri(uc, 640) * 64) // 320 + (tri(vc, 448) * 16) // 224
+        cr = 160 - (tri(uc + 200, 720) * 48) // 360 + (tri(vc + 100, 512) * 16) // 256
+        frames.append([np.clip(luma, 0, 255).astype(np.uint8), np.clip(cb, 0, 255).astype(np.uint8), np.clip(cr, 0, 255).astype(np.uint8)])
     return frames
 
 

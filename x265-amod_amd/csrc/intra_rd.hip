@@ -220,10 +220,10 @@ struct IntraRd
             {
                 r = pre.r;
                 memcpy(lv, pre.lv, sizeof(int16_t) * trSize * trSize);
-                if (pre.copyBlocks)
-                {
+                /* a candidate's blocks stay where the batch left them; the winner's go to the layer, the prediction tile and the picture -- in one command below
+                 * when no split is tried; before the split trial otherwise (its units then predict into the same tile, as in the reference) */
+                if (pre.copyBlocks && mightSplit)
                     copy2Dx2(layerRecon, 64, pre.recon, trSize, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, pre.pred, trSize, trSize, trSize);
-                }
             }
             else if (runJobs(&job, 1, &r, &lv, trSize * trSize, c->ctx, tuDepth)) return err;
             setTuDepth(x, y, trSize, tuDepth);
@@ -300,8 +300,21 @@ struct IntraRd
             setTuDepth(x, y, trSize, tuDepth);
             setCbf(0, x, y, trSize, bCBF);
         }
-        /* the reconstruction becomes the neighbourhood of the next blocks */
-        copy2D(rec[0] + ((uint64_t)y * stride + x) * isz, stride, layerRecon, 64, trSize, trSize);
+        /* the reconstruction becomes the neighbourhood of the next blocks.  A candidate taken from the batch (pre.on without copyBlocks) is never looked at
+         * in the picture: the same block is measured again as the winner before anything reads it, so its copy is left out. */
+        const bool fromBatch = mightNotSplit && pre.on && pre.x == x && pre.y == y && pre.log2 == log2TrSize;
+        if (fromBatch && pre.copyBlocks && !mightSplit)
+        {
+            XaRects r3;
+            r3.n = 3;
+            r3.dst[0] = layerRecon; r3.src[0] = pre.recon; r3.dst_stride[0] = 64; r3.src_stride[0] = trSize;
+            r3.dst[1] = predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz; r3.src[1] = pre.pred; r3.dst_stride[1] = 64; r3.src_stride[1] = trSize;
+            r3.dst[2] = rec[0] + ((uint64_t)y * stride + x) * isz; r3.src[2] = pre.recon; r3.dst_stride[2] = (int32_t)stride; r3.src_stride[2] = trSize;
+            for (int k = 0; k < 3; k++) { r3.w[k] = trSize; r3.h[k] = trSize; }
+            xa_copy_rects(st, r3);
+        }
+        else if (!fromBatch || pre.copyBlocks)
+            copy2D(rec[0] + ((uint64_t)y * stride + x) * isz, stride, layerRecon, 64, trSize, trSize);
         outCost.rdcost += fullCost.rdcost; outCost.distortion += fullCost.distortion; outCost.bits += fullCost.bits; outCost.energy += fullCost.energy;
         return 0;
     }
@@ -668,7 +681,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
                              R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
                              R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
                              R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess ||
-                             xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess))
+                             (rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)))         /* the table is only read by RDOQ */
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
     if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra rd: slice description");
@@ -770,10 +783,13 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         const sse_t distortion = lumaDist + chromaDist;
         out->distortion = distortion;
         /* psy energy of the reconstruction, residual energy of the prediction (luma) */
-        x265amd_rd_cu mc = *cu;
-        x265amd_cu_measure mr, mp;
-        if (x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_recon, 0, &mr) != X265AMD_OK || x265amd_measure_tiles(stream, h_src, stride, cstride, &mc, 1, d_pred, 0, &mp) != X265AMD_OK)
-            rc = X265AMD_EHIP;
+        x265amd_rd_cu mc2[2] = { *cu, *cu };
+        x265amd_cu_measure m2[2];
+        /* reconstruction and prediction tile in one launch */
+        const uint64_t both[2] = { d_recon, d_pred };
+        if (x265amd_measure_tile_list(stream, h_src, stride, cstride, mc2, 2, both, m2) != X265AMD_OK) rc = X265AMD_EHIP;
+        const x265amd_cu_measure& mr = m2[0];
+        const x265amd_cu_measure& mp = m2[1];
         out->psy_energy = R.psyRd ? mr.psy : 0;
         out->res_energy = (uint32_t)(sse_t)mp.sse[0];
         out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
