@@ -3,6 +3,7 @@
  * (up to 16 return addresses).  At exit: /proc/self/maps and the samples go to SPROF_OUT; dbg/tools/sprof_report.py turns them into a flat + caller profile. */
 #define _GNU_SOURCE
 #include <execinfo.h>
+#include <link.h>
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,17 +23,28 @@ static void on_prof(int sig, siginfo_t* si, void* uc)
     int n = backtrace(tmp, DEPTH + 2);
     for (int k = 0; k < DEPTH; k++) g_buf[i][k] = k + 2 < n ? tmp[k + 2] : 0;      /* skip the handler and the signal trampoline */
 }
+static int phdr_cb(struct dl_phdr_info* info, size_t size, void* data)
+{
+    (void)size;
+    unsigned long hi = 0;
+    for (int i = 0; i < info->dlpi_phnum; i++)
+        if (info->dlpi_phdr[i].p_type == PT_LOAD)
+        {
+            unsigned long e = info->dlpi_addr + info->dlpi_phdr[i].p_vaddr + info->dlpi_phdr[i].p_memsz;
+            if (e > hi) hi = e;
+        }
+    fprintf((FILE*)data, "M %lx %lx %s\n", (unsigned long)info->dlpi_addr, hi, info->dlpi_name && info->dlpi_name[0] ? info->dlpi_name : "/proc/self/exe");
+    return 0;
+}
 static void dump(void)
 {
     struct itimerval z; memset(&z, 0, sizeof(z)); setitimer(ITIMER_PROF, &z, 0);
     const char* out = getenv("SPROF_OUT");
     if (!out) out = "sprof.out";
+    if (g_n == 0) return;               /* a wrapper process (timeout, env): leave the file to the program itself */
     FILE* f = fopen(out, "w");
     if (!f) return;
-    FILE* m = fopen("/proc/self/maps", "r");
-    char line[1024];
-    while (m && fgets(line, sizeof(line), m)) if (strstr(line, " r-xp ")) fprintf(f, "M %s", line);
-    if (m) fclose(m);
+    dl_iterate_phdr(phdr_cb, f);        /* "M <load bias> <end of the highest segment> <path>": pc - bias is the address addr2line wants */
     long n = g_n < MAXS ? g_n : MAXS;
     for (long i = 0; i < n; i++)
     {

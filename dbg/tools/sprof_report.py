@@ -5,15 +5,13 @@ maps = []; samples = []
 for line in open(path):
     if line.startswith("M "):
         f = line[2:].split()
-        lo, hi = [int(x, 16) for x in f[0].split("-")]
-        off = int(f[2], 16)
-        maps.append((lo, hi, off, f[5] if len(f) > 5 else ""))
+        maps.append((int(f[0], 16), int(f[1], 16), 0, f[2] if len(f) > 2 else ""))
     elif line.startswith("S"):
         samples.append([int(x, 16) for x in line.split()[1:]])
 maps.sort()
 def locate(a):
     for lo, hi, off, name in maps:
-        if lo <= a < hi: return name, a - lo + off
+        if lo <= a < hi and (lo or name == "/proc/self/exe"): return name, a - lo
     return "?", a
 byfile = collections.defaultdict(set)
 for s in samples:

@@ -109,6 +109,8 @@ struct Analyzer
     uint64_t lambda2, lambda; uint32_t psyRd;
     x265amd_rd_params rp;
     int err;
+    void* intraWs = nullptr;                /* the intra RD's working set, kept for the CUs of this CTU (intra_rd.hip) */
+    ~Analyzer() { xa_intra_ws_free(intraWs); }
 
     uint64_t tileAddr(int t) const { return (uint64_t)(uintptr_t)dTiles.p + (size_t)t * tileBytes; }
     /* tiles: per depth NUM_PRED prediction + NUM_PRED reconstruction tiles, then 5 merge-candidate tiles + 1 scratch tile per depth */
@@ -297,10 +299,10 @@ struct Analyzer
         m.initCosts();
         m.predTile = predTile(depth, slot); m.reconTile = reconTile(depth, slot);
         uint64_t info[4] = { 0, 0, 0, 0 };
-        const int rc = full ? x265amd_check_intra(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, partSize, m.u,
-                                                  tileAddr(m.predTile), tileAddr(m.reconTile), &r, m.coeff.data())
-                            : x265amd_intra_in_inter(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, m.u, tileAddr(m.predTile),
-                                                     tileAddr(m.reconTile), &r, m.coeff.data(), info);
+        const int rc = full ? xa_check_intra_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, partSize, m.u,
+                                                tileAddr(m.predTile), tileAddr(m.reconTile), &r, m.coeff.data(), &intraWs)
+                            : xa_intra_in_inter_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c, m.u, tileAddr(m.predTile),
+                                                   tileAddr(m.reconTile), &r, m.coeff.data(), info, &intraWs);
         if (rc != X265AMD_OK) return err = rc;
         m.sa8dCost = info[1]; m.sa8dBits = (uint32_t)info[2];
         m.rdCost = r.rd_cost; m.distortion = (sse_t)r.distortion; m.totalBits = r.total_bits; m.mvBits = r.mv_bits; m.coeffBits = r.coeff_bits;
@@ -1262,7 +1264,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                                            rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res);
         if (r != X265AMD_OK) return r;
         if (results) results[addr] = res;
+        xa_phase(XA_PH_ANALYZER);
         r = x265amd_cabac_encode_ctu(rowCoder, addr, coeff, coeff + 4096, coeff + 5120);
+        xa_phase(XA_PH_CABAC_CTU);
         if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], rowCoder->ctx, X265AMD_CTX_STRIDE);
         return r;
     };
@@ -1393,6 +1397,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
     {
         uint64_t ss[3];
         xa_sched_stats(ss);
+        xa_phase_report();
         fprintf(stderr, "x265amd: workers so far: %.1f ms running tasks, %.1f ms looking for one, %llu switches\n", ss[0] / 1e6, ss[1] / 1e6, (unsigned long long)ss[2]);
         fprintf(stderr, "x265amd: analysis stages (ms):");
         for (int k = 0; k < 5; k++) { fprintf(stderr, " %s %.1f", g_stageName[k], g_stageMs[k]); g_stageMs[k] = 0; }

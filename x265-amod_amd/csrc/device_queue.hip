@@ -670,8 +670,12 @@ int q_wait(XaQueue* q, uint64_t target)
     return 0;
 }
 
+std::atomic<uint64_t> g_pushNs{ 0 }, g_pushN{ 0 };
 int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* args, size_t argBytes)
 {
+    static const bool timing = getenv("X265AMD_TIMING") != nullptr;
+    struct PushTimer { bool on; std::chrono::steady_clock::time_point t0; ~PushTimer() { if (on) { g_pushNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_pushN++; } } }
+        pt{ timing, timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point() };
     if (argBytes > sizeof(uint64_t) * XA_CMD_ARG_WORDS) return -1;
     if (q->submitted - q->lastSignal >= XA_RING - 2) flags |= XA_CMD_SIGNAL;
     if (q->submitted >= XA_RING && q_wait(q, q->submitted - XA_RING + 1)) return -1;        /* the slot must have been consumed */
@@ -703,6 +707,31 @@ int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* 
 } // namespace
 
 void xa_prof_dependency_wait(uint64_t ns) { if (g_prof) g_depNs += ns; }
+
+/* ---- X265AMD_TIMING: host phases of the row tasks ---- */
+namespace {
+std::atomic<uint64_t> g_phaseNs[XA_PH_COUNT], g_phaseN[XA_PH_COUNT];
+const bool g_phases = getenv("X265AMD_TIMING") != nullptr;
+}
+void xa_phase(int k)
+{
+    if (!g_phases) return;
+    uint64_t* mark = xa_task_mark();
+    if (!mark) return;
+    const uint64_t now = xa_task_run_ns();
+    if (*mark && now >= *mark) { g_phaseNs[k] += now - *mark; g_phaseN[k]++; }
+    *mark = now;
+}
+void xa_phase_report(void)
+{
+    if (!g_phases) return;
+    static const char* const names[XA_PH_COUNT] = { "other", "intra setup", "intra scan", "intra candidates", "intra bits", "intra chroma", "intra final", "push", "row coder", "analyzer",
+                                                    "inter search", "inter rd", "merge" };
+    fprintf(stderr, "x265amd: command pushes: %llu, %.1f ms in all (%.2f us each)\n", (unsigned long long)g_pushN.load(), g_pushNs.load() / 1e6, g_pushN.load() ? g_pushNs.load() / 1e3 / g_pushN.load() : 0.0);
+    fprintf(stderr, "x265amd: host phases of the row tasks (ms, stamps):");
+    for (int k = 0; k < XA_PH_COUNT; k++) fprintf(stderr, " %s %.1f (%llu)", names[k], g_phaseNs[k].load() / 1e6, (unsigned long long)g_phaseN[k].load());
+    fprintf(stderr, "\n");
+}
 
 bool xa_queues_enabled()
 {

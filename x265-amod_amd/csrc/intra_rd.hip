@@ -34,6 +34,7 @@ struct DevBuf
     ~DevBuf() { xa_scratch_free(p); }
     hipError_t alloc(size_t bytes) { return xa_scratch_alloc(&p, bytes ? bytes : 16); }
 };
+struct MappedBuf : XaMapped { void free() { xa_mapped_free(p); p = nullptr; } };
 
 inline unsigned zUnit(int ux, int uy)           /* z-order of unit (ux, uy) inside its CTU */
 {
@@ -55,7 +56,7 @@ struct IntraRd
     uint64_t lambda2, lambda; uint32_t psyRd;
     uint64_t predTile, reconTile;
     DevBuf dResi, dLayer, dCand;
-    XaMapped dJobs, dScanJob; XaMappedOut dRes, dCoeff, dScan;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    MappedBuf dJobs; XaMapped dScanJob; XaMappedOut dRes, dCoeff, dScan;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -206,6 +207,9 @@ struct IntraRd
         const size_t isz = sizeof(pixel);
         Cost fullCost = { 0, 0, 0, 0 };
         uint32_t bCBF = 0;
+        x265amd_tu_result rFull;
+        memset(&rFull, 0, sizeof(rFull));
+        if (!tuDepth) haveWhole = false;
         const uint64_t layerRecon = (uint64_t)(uintptr_t)dLayer.p + ((size_t)layer * 4096 + (size_t)(y - cuY) * 64 + (x - cuX)) * isz;
         if (mightNotSplit)
         {
@@ -226,6 +230,7 @@ struct IntraRd
                     copy2Dx2(layerRecon, 64, pre.recon, trSize, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, pre.pred, trSize, trSize, trSize);
             }
             else if (runJobs(&job, 1, &r, &lv, trSize * trSize, c->ctx, tuDepth)) return err;
+            rFull = r;
             setTuDepth(x, y, trSize, tuDepth);
             bCBF = (uint32_t)(r.num_sig != 0) << tuDepth;
             setCbf(0, x, y, trSize, bCBF);
@@ -316,6 +321,8 @@ struct IntraRd
         else if (!fromBatch || pre.copyBlocks)
             copy2D(rec[0] + ((uint64_t)y * stride + x) * isz, stride, layerRecon, 64, trSize, trSize);
         outCost.rdcost += fullCost.rdcost; outCost.distortion += fullCost.distortion; outCost.bits += fullCost.bits; outCost.energy += fullCost.energy;
+        /* (after a split trial the prediction tile holds the trial's predictions, which is what the reference measures then: no shortcut) */
+        if (!tuDepth && trSize == size && U(cuX, cuY).part_size == 0 && !mightSplit) { haveWhole = true; wholeRes = rFull; }
         return 0;
     }
     void extractLuma(int x, int y, int tuDepth, int16_t* coeffCu)
@@ -342,10 +349,12 @@ struct IntraRd
         sj.avail = available(x, y, 1 << log2N);
         sj.recon_stride = (int32_t)stride; sj.fenc_stride = (int32_t)stride; sj.log2_tr_size = (uint8_t)log2N; sj.strong_smoothing = (uint8_t)(rp->strong_intra_smoothing != 0);
         int32_t sa8d[35];
+        xa_phase(XA_PH_INTRA_CAND);
         memcpy(dScanJob.p, &sj, sizeof(sj));
         if (x265amd_intra_scan(st, (const x265amd_intra_job*)dScanJob.p, 1, (int32_t*)dScan.p, nullptr) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
             return fail("intra rd: mode scan");
         memcpy(sa8d, dScan.p, sizeof(sa8d));
+        xa_phase(XA_PH_INTRA_SCAN);
         uint32_t preds[3];
         c->lumaPreds(x, y, preds);
         const uint64_t frac = cur.frac & 32767;
@@ -363,6 +372,10 @@ struct IntraRd
         return 0;
     }
     uint32_t mpm0;
+    /* the transform unit that covers the whole CU, when the CU ends up with that one unit: its measurements are the CU's (psy energy of the reconstruction,
+     * residual energy of the prediction), so no separate measurement launch is needed */
+    bool haveWhole = false;
+    x265amd_tu_result wholeRes;
 
     /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
      * best mode again with TU splits allowed */
@@ -645,15 +658,20 @@ struct IntraRd
 } // namespace
 
 /* shared body: kind 0 = checkIntraInInter + encodeIntraInInter, kind 1 = checkIntra(part_size) */
+/* ws (optional): where the caller keeps this routine's working set between calls -- the CUs of one CTU on one stream / queue use the same buffers
+ * one after the other (xa_intra_ws_free releases it) */
 static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
                          const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
-                         x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info)
+                         x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info, void** ws = nullptr)
 {
     if (!si || !rp || !units || !h_src || !h_rec || !cu || !cu_units || !d_pred || !d_recon || !out) return xa_fail(X265AMD_EINVAL, "intra rd: null argument");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "intra rd: lossless coding is not supported");
     if (partSize != 0 && (partSize != 3 || cu->log2_size != 3 || si->tu_log2_min > 2)) return xa_fail(X265AMD_EINVAL, "intra rd: NxN only for 8x8 CUs with 4x4 transforms");
-    IntraRd* ip = new IntraRd;
+    xa_phase(XA_PH_ANALYZER);
+    IntraRd* ip = ws && *ws ? static_cast<IntraRd*>(*ws) : new IntraRd;
+    if (ws) *ws = ip;
     IntraRd& R = *ip;
+    R.haveWhole = false;
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
     R.predTile = d_pred; R.reconTile = d_recon;
@@ -675,17 +693,22 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         R.range[0] = lo < (uint32_t)si->tu_log2_min ? si->tu_log2_min : (lo > (uint32_t)si->tu_log2_max ? si->tu_log2_max : (int)lo);
         R.range[1] = si->tu_log2_max;
     }
-    if (rc == X265AMD_OK && (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * IntraRd::MAX_JOBS) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * IntraRd::MAX_JOBS) != hipSuccess ||
-                             R.dCoeff.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess || R.dResi.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess ||
-                             R.dCand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
-                             R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
-                             R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
-                             R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess ||
-                             (rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)))         /* the table is only read by RDOQ */
+    if (rc == X265AMD_OK && !R.dJobs.p &&
+        (R.dJobs.alloc(sizeof(x265amd_intra_tu_job) * IntraRd::MAX_JOBS) != hipSuccess || R.dRes.alloc(sizeof(x265amd_tu_result) * IntraRd::MAX_JOBS) != hipSuccess ||
+         R.dCoeff.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess || R.dResi.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess ||
+         R.dCand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
+         R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
+         R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
+         R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess))
+    {
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
+        R.dJobs.free();         /* a partly made working set is made again next time */
+    }
+    if (rc == X265AMD_OK && rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)         /* the table is only read by RDOQ */
+        rc = xa_fail(X265AMD_EHIP, "intra rd: fill");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
     if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra rd: slice description");
-    if (rc != X265AMD_OK) { delete ip; return rc; }
+    if (rc != X265AMD_OK) { if (coder) x265amd_cabac_close(coder); if (!ws) delete ip; return rc; }
     R.c = coder;
     for (int l = 0; l < 4; l++) R.coeffL[l].assign(4096, 0);
     for (int p = 0; p < 2; p++) { R.coeffC[p].assign(1024, 0); R.coeffCBest[p].assign(1024, 0); }
@@ -710,6 +733,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         }
     Cost icosts = { 0, 0, 0, 0 };
     sse_t lumaDist = 0, chromaDist = 0;
+    xa_phase(XA_PH_INTRA_SETUP);
     if (kind == 0)
     {
         /* ---- checkIntraInInter: DC first, then planar, then the angular modes, strict improvement ---- */
@@ -747,6 +771,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     }
     else
         rc = R.estIntraPredQT(partSize, rp->rd_level, lumaDist);
+    xa_phase(XA_PH_INTRA_CAND);
     std::vector<int16_t> coeffCu(4096 + 2048, 0);
     if (rc == X265AMD_OK)
     {
@@ -754,6 +779,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         R.copy2D(d_recon, 64, h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz, stride, R.size, R.size);
         rc = R.estIntraPredChromaQT(chromaDist);
     }
+    xa_phase(XA_PH_INTRA_CHROMA);
     if (rc == X265AMD_OK)
     {
         memcpy(coeffCu.data() + 4096, R.coeffCBest[0].data(), sizeof(int16_t) * 1024);
@@ -785,13 +811,21 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         /* psy energy of the reconstruction, residual energy of the prediction (luma) */
         x265amd_rd_cu mc2[2] = { *cu, *cu };
         x265amd_cu_measure m2[2];
-        /* reconstruction and prediction tile in one launch */
-        const uint64_t both[2] = { d_recon, d_pred };
-        if (x265amd_measure_tile_list(stream, h_src, stride, cstride, mc2, 2, both, m2) != X265AMD_OK) rc = X265AMD_EHIP;
-        const x265amd_cu_measure& mr = m2[0];
-        const x265amd_cu_measure& mp = m2[1];
-        out->psy_energy = R.psyRd ? mr.psy : 0;
-        out->res_energy = (uint32_t)(sse_t)mp.sse[0];
+        if (R.haveWhole && partSize == 0)
+        {
+            /* one transform unit = the CU: psyCost(fenc, recon) and sse(fenc, pred) of the luma block came with the unit's result (rdcost.h:114-117,
+             * search.cpp:1279-1283 / :1486-1503 measure exactly these two) */
+            out->psy_energy = R.psyRd ? R.wholeRes.nz_energy : 0;
+            out->res_energy = (uint32_t)(sse_t)R.wholeRes.zero_dist;
+        }
+        else
+        {
+            /* reconstruction and prediction tile in one launch */
+            const uint64_t both[2] = { d_recon, d_pred };
+            if (x265amd_measure_tile_list(stream, h_src, stride, cstride, mc2, 2, both, m2) != X265AMD_OK) rc = X265AMD_EHIP;
+            out->psy_energy = R.psyRd ? m2[0].psy : 0;
+            out->res_energy = (uint32_t)(sse_t)m2[1].sse[0];
+        }
         out->rd_cost = R.cost(distortion, out->total_bits, out->psy_energy);
         memcpy(out->ctx, coder->ctx, X265AMD_CTX_COUNT);            /* Mode::contexts is stored before checkDQP codes into it */
         out->frac_bits = coder->fracBits;
@@ -820,8 +854,23 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     }
     if (rc == X265AMD_OK && xa_stream_sync(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: synchronize");
     x265amd_cabac_close(coder);
-    delete ip;
+    if (!ws) delete ip;
+    xa_phase(XA_PH_INTRA_FINAL);
     return rc;
+}
+
+void xa_intra_ws_free(void* ws) { delete static_cast<IntraRd*>(ws); }
+int xa_check_intra_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                      intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, int part_size, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon,
+                      x265amd_rd_result* out, int16_t* coeff_out, void** ws)
+{
+    return intra_cu_impl(1, part_size, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, cu_units, d_pred, d_recon, out, coeff_out, nullptr, ws);
+}
+int xa_intra_in_inter_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                         intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out,
+                         int16_t* coeff_out, uint64_t* info, void** ws)
+{
+    return intra_cu_impl(0, 0, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, cu_units, d_pred, d_recon, out, coeff_out, info, ws);
 }
 
 extern "C" int x265amd_intra_in_inter(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,

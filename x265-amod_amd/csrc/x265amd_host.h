@@ -89,6 +89,22 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
                      uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks);
 
+/* x265amd_check_intra / x265amd_intra_in_inter with a working set the caller keeps between the CUs of one CTU (csrc/intra_rd.hip): *ws starts as NULL */
+int xa_check_intra_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                      intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, int part_size, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon,
+                      x265amd_rd_result* out, int16_t* coeff_out, void** ws);
+int xa_intra_in_inter_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                         intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out,
+                         int16_t* coeff_out, uint64_t* info, void** ws);
+void xa_intra_ws_free(void* ws);
+
+/* X265AMD_TIMING: host time of a row task by phase (running time only: the clock stops while the task is parked).  XA_PHASE(k) charges the time since the
+ * previous stamp of this task to phase k; the totals are printed per frame. */
+enum { XA_PH_OTHER = 0, XA_PH_INTRA_SETUP, XA_PH_INTRA_SCAN, XA_PH_INTRA_CAND, XA_PH_INTRA_BITS, XA_PH_INTRA_CHROMA, XA_PH_INTRA_FINAL, XA_PH_PUSH, XA_PH_CABAC_CTU, XA_PH_ANALYZER,
+       XA_PH_INTER_SEARCH, XA_PH_INTER_RD, XA_PH_MERGE, XA_PH_COUNT };
+void xa_phase(int k);
+void xa_phase_report(void);
+
 /* device address of the centre (MVD 0) of x265amd_me_ctx's MV cost table for `qp` (BitCost::s_costs[qp]) */
 const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp);
 
