@@ -310,6 +310,24 @@ typedef struct x265amd_intra_tu_job
 } x265amd_intra_tu_job;
 int x265amd_intra_tu_chain(void* stream, const x265amd_intra_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);
 
+/* One prediction unit of Search::estIntraPredQT up to the point where bits have to be counted (search.cpp:1509-1650), as ONE launch: the neighbour set and the
+ * 35-mode SA8D scan of the block, the mode bits (mode == an MPM: mpm_base + 1 for the first, + 2 for the others; otherwise rbits) and costs
+ * (sa8d + ((bits * lambda + 128) >> 8)), the candidate list (the modes within 25 % of the best cost and the first MPM, at most max_cand of them, updateCandList
+ * :3953-3972), and the transform chain of every candidate.  tmpl is the chain job of candidate 0 (its dir_mode is ignored); candidate i uses the same job with
+ * dir_mode = modes[i], pred / recon moved by i * slot_pixels samples and coeff / resi by i * slot_coeffs values; d_res[i] is its result.  The serial link
+ * between scan and candidates is the algorithm's, but the host round trip between them is not: this halves the waits of a prediction unit. */
+typedef struct x265amd_intra_pu_job
+{
+    x265amd_intra_tu_job tmpl;
+    uint64_t lambda;                /* RDCost::m_lambda of calcRdSADCost */
+    uint32_t rbits, mpm_base;
+    uint32_t slot_pixels, slot_coeffs;
+    uint8_t preds[3], max_cand;     /* the three most probable modes (loadIntraDirModeLuma); max_cand <= 16 */
+    uint8_t reserved[4];
+} x265amd_intra_pu_job;             /* 128 bytes */
+typedef struct x265amd_intra_pu_out { int32_t sa8d[35]; uint32_t num_cand; uint8_t modes[16]; } x265amd_intra_pu_out;      /* 160 bytes */
+int x265amd_intra_pu(void* stream, const x265amd_intra_pu_job* d_job, x265amd_intra_pu_out* d_out, x265amd_tu_result* d_res);
+
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */
 int x265amd_tu_chain_rdoq(void* stream, const x265amd_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);
 void x265amd_rdoq_lambda(int qpScaled, int64_t* lambda2, int32_t* lambda);

@@ -17,6 +17,7 @@ __shared__ long long xa_stage_prev;
 #include "me_dev.h"
 #include "measure_dev.h"
 #include "entropy_dev.h"
+#include "intra_pu_dev.h"
 #include <immintrin.h>
 #include <signal.h>
 #include <atomic>
@@ -295,6 +296,14 @@ __device__ __noinline__ void xa_op_est_bit(const XaCmd& c, int tid)
     }
 }
 
+__device__ __noinline__ void xa_op_intra_pu(const XaCmd& c, int tid)
+{
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    static_assert(sizeof(IntraScanLds) <= XA_SERVER_LDS && XA_SERVER_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)) <= XA_SERVER_LDS, "LDS budget");
+    block_intra_pu(reinterpret_cast<const x265amd_intra_pu_job*>(a.a), reinterpret_cast<x265amd_intra_pu_out*>(a.b), reinterpret_cast<x265amd_tu_result*>(a.c), xa_smem, tid,
+                   64 * XA_SERVER_WAVES);
+}
+
 /* the groups of a launch one after the other: each stages its window, its jobs go to the wavefronts */
 template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int tid)
 {
@@ -350,6 +359,9 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
         break;
     case XA_OP_EST_BIT:
         xa_op_est_bit(c, tid);
+        break;
+    case XA_OP_INTRA_PU:
+        xa_op_intra_pu(c, tid);
         break;
     case XA_OP_ME_SEARCH: xa_op_me<0>(c, tid); break;
     case XA_OP_ME_SEARCH_STAR: xa_op_me<1>(c, tid); break;
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         }
     }
     __syncthreads();
-    if (tid < 16) s_prof[36 + tid] = xa_stage_acc[tid];        /* [36..51]: the stages of the transform chains */
+    if (tid < 16) s_prof[38 + tid] = xa_stage_acc[tid];        /* [38..53]: the stages of the transform chains */
     __syncthreads();
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
@@ -593,7 +605,7 @@ struct Server
     void profile_report(bool final)
     {
         static const char* const names[XA_OP_COUNT] = { "nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain",
-                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit" };
+                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu" };
         uint64_t tot[64] = { 0 };
         for (int i = 0; i < numQueues; i++) for (int k = 0; k < 64; k++) tot[k] += hosts[i].prof[k];
         uint64_t cmds = 0, ticks = 0;
@@ -607,8 +619,8 @@ struct Server
         for (int op = 0; op < XA_OP_COUNT; op++)
             if (tot[2 * op]) fprintf(stderr, "  %-20s %9llu x %7.2f us = %8.1f ms\n", names[op], (unsigned long long)tot[2 * op], tot[2 * op + 1] / 100.0 / tot[2 * op], tot[2 * op + 1] / 1e5);
         fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
-                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, elsewhere %.1f\n", tot[36] / 1e5, tot[37] / 1e5, tot[38] / 1e5, tot[39] / 1e5, tot[40] / 1e5,
-                tot[41] / 1e5, tot[42] / 1e5, tot[43] / 1e5, tot[44] / 1e5, tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[51] / 1e5);
+                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", tot[38] / 1e5, tot[39] / 1e5, tot[40] / 1e5, tot[41] / 1e5, tot[42] / 1e5,
+                tot[43] / 1e5, tot[44] / 1e5, tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5);
         static const char* const sized[11] = { "intra_scan 4", "intra_scan 8", "intra_scan 16", "intra_scan 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };
         for (int b = 20; b < 31; b++)
@@ -933,6 +945,32 @@ extern "C" int x265amd_queue_coherence_probe(int rounds, int mode, int bytes)
     xa_queue_release(st);
     xa_mapped_free(mapped); (void)hipFree(dX);
     return stale;
+}
+
+/* ---- round-trip probe (dbg): nanoseconds per host -> queue -> host round trip.  mode 0: one empty signalling command; mode 1: a 64-byte fill, then the wait
+ * (xa_stream_sync: what every block operation of the analysis pays); mode 2: three fills, then the wait ---- */
+extern "C" double x265amd_queue_rtt_ns(int iters, int mode)
+{
+    void* st = xa_queue_acquire();
+    if (!st || iters <= 0) return -1.0;
+    void* d = nullptr;
+    if (xa_scratch_alloc(&d, 4096) != hipSuccess) return -1.0;
+    for (int warm = 0; warm < 2; warm++)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; i++)
+        {
+            if (mode == 0) { (void)xa_stream_fence(st, XA_CMD_SIGNAL); (void)xa_stream_sync(st); }
+            else
+            {
+                for (int k = 0; k < (mode == 1 ? 1 : 3); k++) (void)xa_fill_async(st, (char*)d + 64 * k, i & 255, 64);
+                (void)xa_stream_sync(st);
+            }
+        }
+        const double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / iters;
+        if (warm) { xa_scratch_free(d); xa_queue_release(st); return ns; }
+    }
+    return -1.0;
 }
 
 /* ---- self test (tests/test_device_queue.py): copies, fills and rectangle copies through a queue against the same through a stream ---- */

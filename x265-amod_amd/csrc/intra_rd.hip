@@ -56,7 +56,7 @@ struct IntraRd
     uint64_t lambda2, lambda; uint32_t psyRd;
     uint64_t predTile, reconTile;
     DevBuf dResi, dLayer, dCand;
-    MappedBuf dJobs; XaMapped dScanJob; XaMappedOut dRes, dCoeff, dScan;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    MappedBuf dJobs; XaMapped dScanJob, dPuJob; XaMappedOut dRes, dCoeff, dScan, dPuOut;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -389,9 +389,52 @@ struct IntraRd
             uint32_t bmode = 0;
             uint64_t candCostList[35]; uint32_t rdModeList[35];
             const int maxCandCount = 2 + rdLevel + ((depth + initTuDepth) >> 1);
+            const size_t isz = sizeof(pixel);
+            /* Without RDOQ nothing the host knows enters between the scan and the candidates' transform chains: scan, candidate list and chains are ONE
+             * launch (x265amd_intra_pu), the host's share starts with the bits.  (With RDOQ the bit estimates made from the current contexts go to the
+             * device first: scan and chains stay two steps.) */
+            const bool fused = !rp->rdoq_level && log2TrSize <= range[1] && maxCandCount <= MAX_JOBS;
+            int numCand = 0;
+            std::vector<x265amd_tu_result> cres;
+            std::vector<int16_t> clev;
+            uint64_t bcost;
+            if (fused)
+            {
+                xa_phase(XA_PH_INTRA_CAND);
+                uint32_t preds[3];
+                c->lumaPreds(px, py, preds);
+                const uint64_t frac = cur.frac & 32767;
+                const uint8_t adi = cur.ctx[C_ADI];
+                x265amd_intra_pu_job pj;
+                memset(&pj, 0, sizeof(pj));
+                const uint64_t slot0 = (uint64_t)(uintptr_t)dCand.p;
+                fillJob(pj.tmpl, 0, px, py, log2TrSize, 0, slot0 + 1024 * isz, tuSize, slot0, tuSize, 0);
+                pj.tmpl.avail = available(px, py, tuSize);
+                pj.lambda = lambda;
+                pj.rbits = (uint32_t)((frac + k_bits[adi ^ 0]) >> 15) + 5;           /* as lumaScan below: bitsIntraModeNonMPM / bitsIntraModeMPM */
+                pj.mpm_base = (uint32_t)((frac + k_bits[adi ^ 1]) >> 15);
+                pj.slot_pixels = 2048; pj.slot_coeffs = 1024;
+                for (int i = 0; i < 3; i++) pj.preds[i] = (uint8_t)preds[i];
+                pj.max_cand = (uint8_t)maxCandCount;
+                memcpy(dPuJob.p, &pj, sizeof(pj));
+                if (x265amd_intra_pu(st, (const x265amd_intra_pu_job*)dPuJob.p, (x265amd_intra_pu_out*)dPuOut.p, (x265amd_tu_result*)dRes.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
+                    return fail("intra rd: prediction unit step");
+                x265amd_intra_pu_out po;
+                memcpy(&po, dPuOut.p, sizeof(po));
+                xa_phase(XA_PH_INTRA_SCAN);
+                numCand = (int)po.num_cand;
+                if (numCand < 0 || numCand > maxCandCount) return fail("intra rd: candidate count");
+                for (int i = 0; i < numCand; i++) rdModeList[i] = po.modes[i];
+                cres.resize((size_t)numCand); clev.resize((size_t)numCand * 1024);
+                memcpy(cres.data(), dRes.p, sizeof(x265amd_tu_result) * numCand);
+                for (int i = 0; i < numCand; i++) memcpy(clev.data() + (size_t)i * 1024, (const int16_t*)dCoeff.p + 1024 * i, sizeof(int16_t) * tuSize * tuSize);
+                mpm0 = preds[0];
+            }
+            else
+            {
             uint64_t modeCosts[35]; uint32_t mb[35], ms[35];
             if (lumaScan(px, py, log2TrSize, modeCosts, mb, ms)) return err;
-            uint64_t bcost = modeCosts[1];
+            bcost = modeCosts[1];
             if (modeCosts[0] < bcost) bcost = modeCosts[0];
             for (int mode = 2; mode < 35; mode++) if (modeCosts[mode] < bcost) bcost = modeCosts[mode];
             for (int i = 0; i < maxCandCount; i++) candCostList[i] = kMaxCost;
@@ -406,13 +449,11 @@ struct IntraRd
                 }
             /* the candidates only differ in the mode: their transform chains run as ONE launch, the bits and costs follow on the host in the
              * reference's order; the winner's chain is not run again when it is measured with splits allowed */
-            int numCand = 0;
             while (numCand < maxCandCount && candCostList[numCand] != kMaxCost) numCand++;
-            const bool batch = log2TrSize <= range[1] && numCand <= MAX_JOBS;
-            std::vector<x265amd_tu_result> cres((size_t)numCand);
-            std::vector<int16_t> clev((size_t)numCand * 1024);
-            const size_t isz = sizeof(pixel);
-            if (batch && numCand)
+            }
+            const bool batch = fused || (log2TrSize <= range[1] && numCand <= MAX_JOBS);
+            if (!fused) { cres.resize((size_t)numCand); clev.resize((size_t)numCand * 1024); }
+            if (batch && numCand && !fused)
             {
                 std::vector<x265amd_intra_tu_job> jobs((size_t)numCand);
                 std::vector<int16_t*> lvp((size_t)numCand);
@@ -698,6 +739,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
          R.dCoeff.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess || R.dResi.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2) != hipSuccess ||
          R.dCand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
          R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
+         R.dPuJob.alloc(sizeof(x265amd_intra_pu_job)) != hipSuccess || R.dPuOut.alloc(sizeof(x265amd_intra_pu_out)) != hipSuccess ||
          R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
          R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess))
     {
@@ -852,7 +894,9 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         memcpy(&cu_units[(size_t)yy * u4], &units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], sizeof(x265amd_cu_unit) * u4);
         memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
     }
-    if (rc == X265AMD_OK && xa_stream_sync(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: synchronize");
+    /* What is still pending are block copies into tiles and the picture; the commands of a stream / queue run in order, so whoever reads them next waits for
+     * them anyway.  A caller that keeps the working set (same stream, next CU) goes on at once; the plain entry points return with everything done. */
+    if (rc == X265AMD_OK && !ws && xa_stream_sync(R.st) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: synchronize");
     x265amd_cabac_close(coder);
     if (!ws) delete ip;
     xa_phase(XA_PH_INTRA_FINAL);

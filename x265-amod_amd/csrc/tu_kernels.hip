@@ -9,6 +9,7 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 #include "tu_dev.h"
+#include "intra_pu_dev.h"
 #include "xa_queue.h"
 #include <math.h>
 #include <string.h>
@@ -78,6 +79,14 @@ __global__ __launch_bounds__(64) void k_tu_solo(TuSoloJob j)
     }
 }
 
+#define INTRA_PU_WAVES 8
+constexpr size_t kIntraPuLds = sizeof(IntraScanLds) > INTRA_PU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)) ? sizeof(IntraScanLds) : INTRA_PU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds));
+__global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_pu(const x265amd_intra_pu_job* job, x265amd_intra_pu_out* out, x265amd_tu_result* res)
+{
+    extern __shared__ __attribute__((aligned(16))) char tu_smem[];
+    block_intra_pu(job, out, res, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
+}
+
 /* =========================================================================================================
  * host side
  * ======================================================================================================= */
@@ -94,6 +103,7 @@ static int tu_configure()
                                          (int)(TU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)))));
         XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_intra_tu_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(TU_RDOQ_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds) + sizeof(RdoqLds)))));
+        XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_intra_pu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIntraPuLds));
         done = true;
     }
     return X265AMD_OK;
@@ -141,6 +151,18 @@ extern "C" int x265amd_intra_tu_chain(void* stream, const x265amd_intra_tu_job* 
     else
         XA_LAUNCH(e, stream, XA_OP_INTRA_TU_CHAIN, n, qa, k_intra_tu_chain<false>, dim3((n + TU_WAVES - 1) / TU_WAVES), dim3(64 * TU_WAVES),
                       TU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)), d_jobs, (const x265amd_tu_rdoq*)nullptr, n, d_out);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_intra_pu(void* stream, const x265amd_intra_pu_job* d_job, x265amd_intra_pu_out* d_out, x265amd_tu_result* d_res)
+{
+    if (!d_job || !d_out || !d_res) return xa_fail(X265AMD_EINVAL, "x265amd_intra_pu: bad arguments");
+    int rc = xa_is_queue(stream) ? X265AMD_OK : tu_configure();
+    if (rc) return rc;
+    const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_job, (uint64_t)(uintptr_t)d_out, (uint64_t)(uintptr_t)d_res, 0, 1 };
+    hipError_t e;
+    XA_LAUNCH(e, stream, XA_OP_INTRA_PU, 1, qa, k_intra_pu, dim3(1), dim3(64 * INTRA_PU_WAVES), kIntraPuLds, d_job, d_out, d_res);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }
