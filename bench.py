@@ -136,6 +136,18 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True):
     return bytes(stream), dt
 
 
+def usable_cores():
+    """the host cores this process may really use: the cgroup's CPU quota when there is one (the GPU boxes of this project: 16 of 256 hardware threads)"""
+    n = os.cpu_count() or 1
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def reference_encode(frames):
     """the same clip through the reference encoder (oracle/_ref/x265_ref8: the reference compiled by oracle/build_ref.sh, C primitives, no assembly) on
     this box's host cores, twice: with its defaults (frame threads by core count -- 5 for 1080p on 32 cores or more, threadpool.cpp:661-677: THAT stream is
@@ -152,7 +164,7 @@ def reference_encode(frames):
                 f.write(b"FRAME\n")
                 for pl in fr:
                     f.write(np.ascontiguousarray(pl).tobytes())
-        out = {"cores": os.cpu_count()}
+        out = {"cores": usable_cores()}
         for tag, extra in (("default", []), ("f1", ["--frame-threads", "1"])):
             t0 = time.perf_counter()
             r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc"] + REF_CLI + extra, cwd=d, capture_output=True, text=True, timeout=900)
@@ -226,8 +238,8 @@ def main():
             same = ref["default"]["stream"] == stream
             cpu = {"value": K / ref["default"]["seconds"], "unit": "frames/s", "cores": ref["cores"], "kind": "reference",
                    "sample": "the same %d-frame 1920x1080 clip and options through oracle/_ref/x265_ref8 (the reference itself compiled from /root/reference, C primitives: no "
-                             "assembler in the image) on this box's %d hardware threads, thread pool and frame threads at their defaults; by its own "
-                             "'encoded N frames in T' figure" % (K, ref["cores"]),
+                             "assembler in the image) on this box's host cores (%d usable: the cgroup's CPU quota; the machine has %d hardware threads), thread pool and "
+                             "frame threads at their defaults; by its own 'encoded N frames in T' figure" % (K, ref["cores"], os.cpu_count() or 0),
                    "frame_threads_default": {"frames_per_s": K / ref["default"]["seconds"], "says": ref["default"]["says"], "stream_equals_ours": bool(same)},
                    "frame_threads_1": {"frames_per_s": K / ref["f1"]["seconds"], "says": ref["f1"]["says"],
                                        "stream_equals_default": bool(ref["default"]["stream"] == ref["f1"]["stream"])}}
