@@ -89,6 +89,8 @@ int default_workers()
         }
         fclose(f);
     }
+    /* several encoder processes on one host (one per GPU: torch.distributed.run sets LOCAL_WORLD_SIZE) share the cores */
+    if (const char* l = getenv("LOCAL_WORLD_SIZE")) { const int procs = atoi(l); if (procs > 1) n /= procs; }
     n -= 2;
     return n < 2 ? 2 : (n > 64 ? 64 : n);
 }
