@@ -7,6 +7,9 @@
 #include "x265amd_host.h"
 #include "xa_queue.h"
 #include "xa_fiber.h"
+#ifndef XA_PREFETCH_SLOT
+#define XA_PREFETCH_SLOT 0          /* fetching the next slot while a command runs: measured, no gain (the load competes with the command's own first loads) */
+#endif
 /* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside" */
 __shared__ unsigned long long xa_stage_acc[16];
 __shared__ long long xa_stage_prev;
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     XaRingDev* rd = rings + blockIdx.x;
     XaRingHost* rh = hosts + blockIdx.x;
     const int tid = threadIdx.x;
-    uint64_t seen = 0;
+    uint64_t seen = 0, signalled = 0, pre = 0;
+    bool havePre = false;
     if (tid < 64) s_prof[tid] = 0;
     if (tid < 16) xa_stage_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
@@ -400,7 +404,12 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
             const long long t0 = wall_clock64();
             for (unsigned spins = 1;; spins++)
             {
-                const uint64_t w = tid < 16 ? xa_sys_load(slot + tid) : 0;
+                /* lanes 0..15: the slot; lane 16: the doorbell (the command number the host is waiting for).  The first look uses what was fetched while the
+                 * previous command ran: a command queued behind another costs no memory latency of its own. */
+                uint64_t w;
+                if (spins == 1 && havePre) w = pre;
+                else w = tid < 16 ? xa_sys_load(slot + tid) : (tid == 16 ? xa_sys_load(&rd->head) : 0);
+                havePre = false;
                 /* position-weighted sum of the fifteen words (each times its own odd constant): a slot caught between two commands -- some words of the
                  * old one, some of the new -- does not pass.  A plain xor did: tile-to-tile copies change `dst` and `src` by the same bits, the two
                  * changes cancelled, and a half-arrived slot ran with the old addresses (one corrupted stream in five at 832x480). */
@@ -414,6 +423,9 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                     go = 1;
                     break;
                 }
+                /* nothing to run: if the host waits for what has been run (doorbell) and has not been told yet, tell it.  (A doorbell seen ahead of a
+                 * command still on its way only makes this report early; the next one follows when the queue is empty again.) */
+                if (__shfl(w, 16, 64) >= seen && signalled < seen) { go = 2; break; }
                 if ((spins & 63) == 0)
                 {
                     int stop = 0;
@@ -431,8 +443,8 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                  * other rows', pictures' and copy engines' writes), copies (their source may be the pinned staging area the host refills in place) and
                  * the RDOQ / estBit commands, which read host-written tables with plain loads.  Without the invalidation the second use of such a
                  * buffer reads the first use's bytes (measured).  The scalar data cache is never touched by a fence: see below. */
-                const uint32_t op = go ? reinterpret_cast<const uint32_t*>(&s_cmd)[0] : 0, fl = go ? reinterpret_cast<const uint32_t*>(&s_cmd)[1] : 0;
-                if ((fl & XA_CMD_ACQUIRE) || (reinterpret_cast<const uint32_t*>(&s_cmd)[3] & 32) || op == XA_OP_COPY || op == XA_OP_EST_BIT || op == XA_OP_TU_CHAIN_RDOQ || op == XA_OP_INTRA_TU_CHAIN_RDOQ)
+                const uint32_t op = go == 1 ? reinterpret_cast<const uint32_t*>(&s_cmd)[0] : 0, fl = go == 1 ? reinterpret_cast<const uint32_t*>(&s_cmd)[1] : 0;
+                if (go == 1 && ((fl & XA_CMD_ACQUIRE) || (reinterpret_cast<const uint32_t*>(&s_cmd)[3] & 32) || op == XA_OP_COPY || op == XA_OP_EST_BIT || op == XA_OP_TU_CHAIN_RDOQ || op == XA_OP_INTRA_TU_CHAIN_RDOQ))
                 {
                     const long long tf = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -444,9 +456,32 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         }
         __syncthreads();
         if (!s_go) break;
+        if (s_go == 2)
+        {
+            /* the queue is empty and the host waits: every wavefront's stores leave, then the count goes out (as after a signalling command, below) */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+            {
+                const long long te = wall_clock64();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                xa_sys_store(&rh->tail, seen);
+                s_prof[63] += (unsigned long long)(wall_clock64() - te);
+            }
+            signalled = seen;
+            continue;
+        }
         const uint32_t flags = s_cmd.flags;
         if (s_cmd.op == XA_OP_EXIT) break;
         const long long td = wall_clock64();
+        /* the slot behind this command and the doorbell, fetched while the command runs */
+        if (XA_PREFETCH_SLOT && tid < 64)
+        {
+            const uint64_t* nextSlot = reinterpret_cast<const uint64_t*>(&rd->cmd[(seen + 1) % XA_RING]);
+            pre = tid < 16 ? xa_sys_load(nextSlot + tid) : (tid == 16 ? xa_sys_load(&rd->head) : 0);
+            havePre = true;
+        }
         xa_dispatch(s_cmd, tid);
         /* before the workgroup reports or publishes, every wavefront's stores have left (results live in host memory, read as soon as the count
          * moves).  Between two commands of the queue the barrier is enough: the CU's vector memory path keeps the order of one workgroup's accesses,
@@ -470,6 +505,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                 const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(s_cmd.args);
                 int b = -1;
                 if (s_cmd.op == XA_OP_INTRA_SCAN && a.n == 1) b = 20 + (reinterpret_cast<const x265amd_intra_job*>(a.a)->log2_tr_size - 2);
+                else if (s_cmd.op == XA_OP_INTRA_PU) b = 20 + (reinterpret_cast<const x265amd_intra_pu_job*>(a.a)->tmpl.tu.log2_tr_size - 2);
                 else if (s_cmd.op == XA_OP_INTRA_TU_CHAIN) b = 24 + (reinterpret_cast<const x265amd_intra_tu_job*>(a.a)->tu.log2_tr_size - 2);
                 else if (s_cmd.op == XA_OP_CU_MEASURE && a.n == 1) b = 28 + (reinterpret_cast<const CuMeasureJob*>(a.a)->log2_size - 3);
                 if (b >= 20 && b < 31) { s_prof[2 * b] += 1; s_prof[2 * b + 1] += (unsigned long long)(te - td); }
@@ -485,6 +521,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
             }
             if (flags & XA_CMD_SIGNAL) xa_sys_store(&rh->tail, seen);
         }
+        if (flags & XA_CMD_SIGNAL) signalled = seen;
     }
     __syncthreads();
     if (tid < 16) s_prof[38 + tid] = xa_stage_acc[tid];        /* [38..53]: the stages of the transform chains */
@@ -585,6 +622,7 @@ struct Server
             x.submitted = 0; x.lastSignal = 0; x.generation = generation;
             x.rh->tail = 0; x.rh->state = 0; x.rh->dbg[63] = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].quit) = 0;
+            *reinterpret_cast<volatile uint64_t*>(&rings[i].head) = 0;
         }
         _mm_sfence();
         hipLaunchKernelGGL(k_job_server, dim3(numQueues), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 60, generation);
@@ -621,7 +659,7 @@ struct Server
         fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
                 "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", tot[38] / 1e5, tot[39] / 1e5, tot[40] / 1e5, tot[41] / 1e5, tot[42] / 1e5,
                 tot[43] / 1e5, tot[44] / 1e5, tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5);
-        static const char* const sized[11] = { "intra_scan 4", "intra_scan 8", "intra_scan 16", "intra_scan 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
+        static const char* const sized[11] = { "scan / pu 4", "scan / pu 8", "scan / pu 16", "scan / pu 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };
         for (int b = 20; b < 31; b++)
             if (tot[2 * b]) fprintf(stderr, "  (n = 1) %-12s %9llu x %7.2f us = %8.1f ms\n", sized[b - 20], (unsigned long long)tot[2 * b], tot[2 * b + 1] / 100.0 / tot[2 * b], tot[2 * b + 1] / 1e5);
@@ -836,7 +874,14 @@ hipError_t xa_stream_sync(void* st)
 {
     if (!xa_is_queue(st)) return hipStreamSynchronize((hipStream_t)st);
     XaQueue* q = as_queue(st);
-    if (q->lastSignal != q->submitted && q_push(q, XA_OP_NOP, XA_CMD_SIGNAL, 0, nullptr, 0)) return hipErrorUnknown;
+    if (q->lastSignal != q->submitted)
+    {
+        /* the doorbell: the number of the command the host waits for, stored into the queue's device memory (one posted 8-byte write).  The workgroup reads it
+         * together with the next slot and reports as soon as it has run that far and finds nothing to run -- no empty signalling command to fetch (1.45 us). */
+        *reinterpret_cast<volatile uint64_t*>(&q->rd->head) = q->submitted;
+        _mm_sfence();
+        q->lastSignal = q->submitted;
+    }
     if (q_wait(q, q->submitted)) { xa_fail(X265AMD_EHIP, "device queue: no answer from the job server"); return hipErrorUnknown; }
     for (const Deferred& d : q->deferred) memcpy(d.dst, d.src, d.bytes);
     q->deferred.clear();

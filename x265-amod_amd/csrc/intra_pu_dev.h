@@ -25,69 +25,65 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
     __syncthreads();
     XA_STAGE(14);
     if (tid < 35) po->sa8d[tid] = s_sa8d[tid];
-    /* estIntraPredQT (search.cpp:1615-1650): costs (a lane per mode), the padded best, then updateCandList over the eligible modes in mode order.  The
-     * list lives in LDS: indexed local arrays would go to scratch memory, microseconds per access. */
-    __shared__ unsigned long long s_cost[35], s_list[16];
+    /* estIntraPredQT (search.cpp:1615-1650): costs (a lane per mode), the padded best, then updateCandList over the eligible modes in mode order.  Costs fit
+     * 32 bits with room to spare (sa8d of a 32x32 block of 12-bit samples < 2^28, bits x lambda >> 8 < 2^14), so the comparisons are the reference's. */
     if (tid < 64)
     {
-        const unsigned long long kMax = ~0ull;
-        unsigned long long myCost = kMax;
+        const uint32_t kMax = 0xFFFFFFFFu;
+        uint32_t myCost = kMax;
         if (tid < 35)
         {
             uint32_t b = P.rbits;
             if (tid == P.preds[0]) b = P.mpm_base + 1u;
             else if (tid == P.preds[1] || tid == P.preds[2]) b = P.mpm_base + 2u;
-            myCost = (unsigned long long)(uint32_t)s_sa8d[tid] + (((unsigned long long)b * P.lambda + 128) >> 8);
-            s_cost[tid] = myCost;
+            myCost = (uint32_t)s_sa8d[tid] + (uint32_t)(((unsigned long long)b * P.lambda + 128) >> 8);
         }
-        /* minimum over the wavefront: both halves travel together */
-        unsigned long long bcost = myCost;
-        for (int off = 32; off; off >>= 1)
-        {
-            const uint32_t lo = __shfl_xor((uint32_t)bcost, off, 64), hi = __shfl_xor((uint32_t)(bcost >> 32), off, 64);
-            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-            bcost = o < bcost ? o : bcost;
-        }
-        const unsigned long long padded = bcost + (bcost >> 2);
+        uint32_t bcost = myCost;
+        for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(bcost, off, 64); bcost = o < bcost ? o : bcost; }
+        const uint32_t padded = bcost + (bcost >> 2);
         unsigned long long todo = __ballot(tid < 35 && (myCost < padded || tid == P.preds[0]));
         const int maxCand = P.max_cand > 16 ? 16 : P.max_cand;
-        if (tid < 16) { s_list[tid] = kMax; s_modes[tid] = 0; }
-        xa_wave_sync();
         const int numEligible = __popcll(todo);
+        /* the first maxCand eligible modes take the places in order (each replaces the first empty place) */
+        const int myRank = __popcll(todo & ((1ull << tid) - 1));
+        const bool mineEligible = tid < 35 && ((todo >> tid) & 1);
+        if (tid < 16) s_modes[tid] = 0;
+        xa_wave_sync();
+        if (mineEligible && myRank < maxCand) s_modes[myRank] = (uint8_t)tid;
+        xa_wave_sync();
         if (numEligible <= maxCand)
         {
-            /* no more eligible modes than places: each takes the next free place, in mode order */
-            if (tid < 35 && ((todo >> tid) & 1)) s_modes[__popcll(todo & ((1ull << tid) - 1))] = (uint8_t)tid;
             if (tid == 0) { s_num = numEligible; po->num_cand = (uint32_t)numEligible; }
         }
         else
         {
-            /* updateCandList with the list across lanes 0..15 (one place per lane; places beyond maxCand hold 0 and are never the largest): per eligible
-             * mode one 16-lane maximum with row shifts (DPP: no LDS traffic), the first lane holding it is the place to replace.  A single lane doing the
-             * same compares one after the other costs five microseconds. */
-            unsigned long long mine = tid < maxCand ? kMax : 0;
-            uint32_t myMode = 0;
-            const uint32_t costLo = (uint32_t)myCost, costHi = (uint32_t)(myCost >> 32);
+            /* updateCandList for the rest, the list across lanes 0..15 (one place per lane; places beyond maxCand hold 0 and are never the largest): per
+             * eligible mode one 16-lane maximum with row shifts (DPP: no LDS traffic), the first lane holding it is the place to replace.  (A single lane
+             * doing the same compares one after the other costs five microseconds.) */
+            uint32_t myMode = tid < 16 ? s_modes[tid] : 0;
+            const uint32_t got = (uint32_t)__shfl((int)myCost, (int)myMode, 64);         /* the cost of the mode in this lane's place */
+            uint32_t mine = tid < maxCand ? got : 0;
+            /* drop the modes already placed */
+            for (int k = 0; k < maxCand; k++) todo &= todo - 1;
 #define XA_ROW_SHR(v, n) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (n), 0xF, 0xF, true))
             while (todo)
             {
                 const int m = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                const unsigned long long c = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)costHi, m) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)costLo, m);
-                unsigned long long cur = mine;
-#define XA_MAX_STEP(n) { const unsigned long long o = ((unsigned long long)XA_ROW_SHR((uint32_t)(cur >> 32), n) << 32) | XA_ROW_SHR((uint32_t)cur, n); cur = o > cur ? o : cur; }
-                XA_MAX_STEP(1) XA_MAX_STEP(2) XA_MAX_STEP(4) XA_MAX_STEP(8)
-#undef XA_MAX_STEP
-                const unsigned long long maxValue = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), 15) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur, 15);
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)myCost, m);
+                uint32_t cur = mine, o;
+                o = XA_ROW_SHR(cur, 1); cur = o > cur ? o : cur;
+                o = XA_ROW_SHR(cur, 2); cur = o > cur ? o : cur;
+                o = XA_ROW_SHR(cur, 4); cur = o > cur ? o : cur;
+                o = XA_ROW_SHR(cur, 8); cur = o > cur ? o : cur;
+                const uint32_t maxValue = (uint32_t)__builtin_amdgcn_readlane((int)cur, 15);
                 const unsigned long long holders = __ballot(tid < 16 && mine == maxValue);
                 const int maxIndex = holders ? __ffsll((long long)holders) - 1 : 0;
                 if (c < maxValue && tid == maxIndex) { mine = c; myMode = (uint32_t)m; }
             }
 #undef XA_ROW_SHR
-            const unsigned long long filled = __ballot(tid < maxCand && mine != kMax);
-            const int n = __ffsll((long long)~filled) - 1;          /* the leading places that are taken */
             if (tid < 16) s_modes[tid] = (uint8_t)myMode;
-            if (tid == 0) { s_num = n; po->num_cand = (uint32_t)n; }
+            if (tid == 0) { s_num = maxCand; po->num_cand = (uint32_t)maxCand; }
         }
         xa_wave_sync();
         if (tid < 16) po->modes[tid] = tid < s_num ? s_modes[tid] : 0;

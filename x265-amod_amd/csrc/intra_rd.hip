@@ -215,12 +215,16 @@ struct IntraRd
         {
             if (mightSplit) store(rqtRoot[fullDepth]);
             x265amd_cu_unit& u = U(x, y);
-            x265amd_intra_tu_job job;
-            fillJob(job, 0, x, y, log2TrSize, u.luma_dir, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, layerRecon, 64, 0);
-            job.avail = available(x, y, trSize);
             x265amd_tu_result r;
             int16_t* lv = coeffL[layer].data() + ((size_t)zInCu(x, y) << 4);
-            if (pre.on && pre.x == x && pre.y == y && pre.log2 == log2TrSize)
+            const bool hit = pre.on && pre.x == x && pre.y == y && pre.log2 == log2TrSize;
+            x265amd_intra_tu_job job;
+            if (!hit)
+            {
+                fillJob(job, 0, x, y, log2TrSize, u.luma_dir, predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz, 64, layerRecon, 64, 0);
+                job.avail = available(x, y, trSize);
+            }
+            if (hit)
             {
                 r = pre.r;
                 memcpy(lv, pre.lv, sizeof(int16_t) * trSize * trSize);

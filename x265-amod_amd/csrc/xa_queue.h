@@ -42,7 +42,7 @@ struct alignas(128) XaCmd { uint32_t op, flags, count, reserved; uint64_t args[X
 struct alignas(128) XaRingDev
 {
     XaCmd cmd[XA_RING];
-    uint64_t head; uint64_t pad0[15];           /* unused (the slots themselves are polled) */
+    uint64_t head; uint64_t pad0[15];           /* the doorbell: the number of the command the host waits for (0: none); read with the next slot */
     uint64_t quit; uint64_t pad1[15];
 };
 /* pinned host memory, written by the workgroup, polled by the host thread */
