@@ -193,11 +193,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=4, help="frames of the untimed warm-up encode")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference encoder's run (profiling passes)")
     ap.add_argument("--no-kernel-workload", action="store_true", help="skip bench_kernels.py (profiling passes of the encoder alone)")
+    ap.add_argument("--res", choices=["1080p", "2160p"], default="1080p", help="1080p = BASELINE.json configs[1] (the bench line); 2160p: the same encode at 3840x2160 (informational)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import hevc_testlib as T
+    global W, H
+    if args.res == "2160p":
+        W, H = 3840, 2160
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -237,7 +241,7 @@ def main():
         if ref is not None:
             same = ref["default"]["stream"] == stream
             cpu = {"value": K / ref["default"]["seconds"], "unit": "frames/s", "cores": ref["cores"], "kind": "reference",
-                   "sample": "the same %d-frame 1920x1080 clip and options through oracle/_ref/x265_ref8 (the reference itself compiled from /root/reference, C primitives: no "
+                   "sample": "the same %d-frame clip and options through oracle/_ref/x265_ref8 (the reference itself compiled from /root/reference, C primitives: no "
                              "assembler in the image) on this box's host cores (%d usable: the cgroup's CPU quota; the machine has %d hardware threads), thread pool and "
                              "frame threads at their defaults; by its own 'encoded N frames in T' figure" % (K, ref["cores"], os.cpu_count() or 0),
                    "frame_threads_default": {"frames_per_s": K / ref["default"]["seconds"], "says": ref["default"]["says"], "stream_equals_ours": bool(same)},
@@ -255,10 +259,10 @@ def main():
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1920x1080 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + fixed mini-GOPs of %d B frames), encoded END TO END by the encoder object "
+            "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + fixed mini-GOPs of %d B frames), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
                                    "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
-                                   "the lookahead's decisions fixed (no b-adapt / scenecut / AQ / cutree / weighted prediction: not built yet, switched off on both sides)" % (K, BFRAMES, REFS, QP),
+                                   "the lookahead's decisions fixed (no b-adapt / scenecut / AQ / cutree / weighted prediction: not built yet, switched off on both sides)" % (W, H, K, BFRAMES, REFS, QP),
                        "frames_per_step_per_gpu": 1, "parallelism": "closed GOP per GPU x%d" % world if world > 1 else "one encoder object",
                        "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},
             "bit_exact_vs_reference_encoder": same,
@@ -271,7 +275,7 @@ def main():
     # ---- the hot-path kernels on their own (bench_kernels.py): a frame's worth of batched block operations ----
     if not args.no_kernel_workload:
         import bench_kernels
-        kargs = bench_kernels.parse_args(["--gpus", str(args.gpus), "--steps", str(max(5, min(20, K))), "--warmup", "3"] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+        kargs = bench_kernels.parse_args(["--gpus", str(args.gpus), "--steps", str(max(5, min(20, K))), "--warmup", "3", "--res", args.res] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         kw = bench_kernels.run(kargs)
         if rank == 0 and kw is not None:
             line["roofline"] = dict(kw["roofline"], of="the dominant kernel of kernel_workload (a frame's batched block operations); the encode itself is one resident kernel")

@@ -158,6 +158,7 @@ int main(int argc, char** argv)
         else if (k == "--psy-rdoq") p.psyRdoqFix8 = (int)(atof(v) * 256.0);
         else if (k == "--ipratio") p.ipFactor = atof(v);
         else if (k == "--pbratio") p.pbFactor = atof(v);
+        else if (k == "--frame-threads" || k == "-F") p.frameNumThreads = atoi(v);        /* > 1: the reference's frame-parallel rules (its default); 1: one picture at a time */
         else { fprintf(stderr, "x265amd: unknown option %s\n", k.c_str()); return 2; }
     }
     x265amd_encoder* enc = api.open(&p);
