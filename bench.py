@@ -49,18 +49,19 @@ REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree
            "--no-info", "--no-open-gop", "--rc-lookahead", "5", "--lookahead-slices", "0"]
 
 
-def bench_clip(first, count):
+def bench_clip(first, count, gop=0):
     """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes: luma = a smooth 2-D integer gradient shifted by
     (2t, t) samples plus a noise field in [-12, 12] that moves with it (so motion estimation has real work and every block carries a residual), chroma = low-frequency
     integer ramps shifted by (t, t / 2); the noise field is re-seeded every 24th frame.  Integer arithmetic only, and frame t depends on t alone, so every rank
-    (and the reference run) sees the same pictures."""
+    (and the reference run) sees the same pictures.  gop: the closed GOP a rank codes in a multi-GPU run -- its own noise field (a scene of its own behind its IDR
+    picture), the same motion, so that every rank has the same amount of work."""
     def tri(a, period):
         a = a % period
         return np.minimum(a, period - a)
     frames = []
     for t in range(first, first + count):
         epoch = t // 24
-        noise = np.random.default_rng(0x9E3779B9 ^ (2 << 8) ^ (epoch << 20)).integers(-12, 13, (H + 64, W + 128))     # cfg_id 2; indexed by the moving coordinates
+        noise = np.random.default_rng(0x9E3779B9 ^ (2 << 8) ^ (epoch << 20) ^ (gop << 12)).integers(-12, 13, (H + 64, W + 128))     # cfg_id 2; indexed by the moving coordinates
         tt = t % 24
         v = np.arange(H, dtype=np.int64)[:, None] + tt + 24 * epoch
         u = np.arange(W, dtype=np.int64)[None, :] + 2 * tt + 48 * epoch
@@ -222,7 +223,7 @@ def main():
     L = T.load_hip(8)
     K, Wm = args.steps, args.warmup
     # rank r codes GOP r: frames r K .. r K + K - 1 of the clip, IDR first (closed GOPs need nothing from each other)
-    frames = bench_clip(rank * K, K)
+    frames = bench_clip(0, K, gop=rank)
     if Wm > 0:
         encode(T, L, bench_clip(0, Wm), 0, 0, sync, timed=False)
     stream, dt = encode(T, L, frames, rank * K, K if world > 1 else 0, sync)
