@@ -3366,3 +3366,77 @@ def aq_offsets_prod(L, energy, avg_count, mode, strength, bias, qg):
     rc = L.lib.x265amd_aq_offsets(_ptr(np.ascontiguousarray(energy)), n, avg_count, mode, C.c_double(strength), C.c_double(bias), qg, _ptr(a), _ptr(t), _ptr(f))
     assert rc == 0
     return a, t, f
+
+
+# ---- x265amd_intra_pu: scan + candidate list + candidate chains of one prediction unit as one launch ----
+INTRA_PU_JOB_DT = np.dtype([("tmpl", INTRA_TU_JOB_DT), ("lambda", "<u8"), ("rbits", "<u4"), ("mpm_base", "<u4"), ("slot_pixels", "<u4"), ("slot_coeffs", "<u4"),
+                            ("preds", "u1", 3), ("max_cand", "u1"), ("reserved", "u1", 4)])
+INTRA_PU_OUT_DT = np.dtype([("sa8d", "<i4", 35), ("num_cand", "<u4"), ("modes", "u1", 16)])
+assert INTRA_PU_JOB_DT.itemsize == 128 and INTRA_PU_OUT_DT.itemsize == 160
+
+
+def intra_pu_candidates(sa8d, preds, rbits, mpm_base, lam, max_cand):
+    """Search::estIntraPredQT's candidate list (search.cpp:1615-1650 with updateCandList :3953-3972) on given SA8D costs: the modes in list order"""
+    kmax = (1 << 64) - 1
+    cost = []
+    for m in range(35):
+        b = rbits
+        for i in range(3):
+            if preds[i] == m:
+                b = mpm_base + (1 if m == preds[0] else 2)
+                break
+        cost.append(int(sa8d[m]) + ((b * lam + 128) >> 8))
+    bcost = min(cost)
+    padded = bcost + (bcost >> 2)
+    lst, modes = [kmax] * max_cand, [0] * max_cand
+    for m in range(35):
+        if cost[m] < padded or m == preds[0]:
+            mi, mv = 0, 0
+            for i in range(max_cand):
+                if mv < lst[i]:
+                    mv, mi = lst[i], i
+            if cost[m] < mv:
+                lst[mi], modes[mi] = cost[m], m
+    n = 0
+    while n < max_cand and lst[n] != kmax:
+        n += 1
+    return modes[:n]
+
+
+def intra_pu_run_hip(L, c, preds, rbits, mpm_base, lam, max_cand):
+    """x265amd_intra_pu on one luma block of intra_tu_cases (ttype 0): returns (sa8d[35], modes, [(stats, pred, recon, coeff, resi)] per candidate)"""
+    import torch
+    dt = c["plane"].dtype
+    isz = dt.itemsize
+    N = 1 << c["log2"]
+    d_plane = torch.from_numpy(c["plane"].view(np.uint8).copy()).cuda()
+    d_fenc = torch.from_numpy(np.ascontiguousarray(c["fenc"]).ravel().view(np.uint8).copy()).cuda()
+    slot_pixels, slot_coeffs = 2048, 1024
+    d_cand = torch.zeros(16 * slot_pixels * isz, dtype=torch.uint8, device="cuda")          # per candidate: recon at 0, pred at 1024 samples (stride N), as the intra RD lays them out
+    d_coeff = torch.zeros(16 * slot_coeffs * 2, dtype=torch.uint8, device="cuda")
+    d_resi = torch.zeros(16 * slot_coeffs * 2, dtype=torch.uint8, device="cuda")
+    job = np.zeros(1, INTRA_PU_JOB_DT)
+    mask = 0
+    for u, f in enumerate(c["flags"]):
+        mask |= int(f) << u
+    job[0]["tmpl"]["tu"] = (d_fenc.data_ptr(), d_cand.data_ptr() + 1024 * isz, d_coeff.data_ptr(), d_resi.data_ptr(), d_cand.data_ptr(), N, N, N, N,
+                            c["log2"], 0, 1, 0, c["slice"], c["qp"], c["signhide"], 0)
+    job[0]["tmpl"]["nb"] = d_plane.data_ptr() + c["off"] * isz
+    job[0]["tmpl"]["avail"], job[0]["tmpl"]["nb_stride"], job[0]["tmpl"]["strong"] = mask, c["stride"], c["strong"]
+    job[0]["lambda"], job[0]["rbits"], job[0]["mpm_base"], job[0]["slot_pixels"], job[0]["slot_coeffs"] = lam, rbits, mpm_base, slot_pixels, slot_coeffs
+    job[0]["preds"], job[0]["max_cand"] = preds, max_cand
+    d_job = torch.from_numpy(job.view(np.uint8).copy()).cuda()
+    d_out = torch.zeros(INTRA_PU_OUT_DT.itemsize, dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros(16 * TU_RESULT_DT.itemsize, dtype=torch.uint8, device="cuda")
+    assert L.lib.x265amd_intra_pu(None, C.c_void_p(d_job.data_ptr()), C.c_void_p(d_out.data_ptr()), C.c_void_p(d_res.data_ptr())) == 0
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().view(INTRA_PU_OUT_DT)[0]
+    res = d_res.cpu().numpy().view(TU_RESULT_DT)
+    cand, coeff, resi = d_cand.cpu().numpy().view(dt), d_coeff.cpu().numpy().view(np.int16), d_resi.cpu().numpy().view(np.int16)
+    per = []
+    for i in range(int(out["num_cand"])):
+        recon = cand[i * slot_pixels:i * slot_pixels + N * N].reshape(N, N).copy()
+        pred = cand[i * slot_pixels + 1024:i * slot_pixels + 1024 + N * N].reshape(N, N).copy()
+        st = (int(res[i]["num_sig"]), int(res[i]["zero_dist"]), int(res[i]["zero_energy"]), int(res[i]["nz_dist"]), int(res[i]["nz_energy"]))
+        per.append((st, pred, recon, coeff[i * slot_coeffs:i * slot_coeffs + N * N].copy(), resi[i * slot_coeffs:i * slot_coeffs + N * N].reshape(N, N).copy()))
+    return out["sa8d"].copy(), [int(m) for m in out["modes"][:int(out["num_cand"])]], per
