@@ -328,6 +328,29 @@ typedef struct x265amd_intra_pu_job
 typedef struct x265amd_intra_pu_out { int32_t sa8d[35]; uint32_t num_cand; uint8_t modes[16]; } x265amd_intra_pu_out;      /* 160 bytes */
 int x265amd_intra_pu(void* stream, const x265amd_intra_pu_job* d_job, x265amd_intra_pu_out* d_out, x265amd_tu_result* d_res);
 
+/* The luma part of Search::estIntraPredQT for an 8x8 CU coded NxN (four 4x4 prediction units, search.cpp:1509-1696), decisions included, as ONE launch.  Per unit,
+ * in z-order: the most probable modes from the neighbours' modes (getIntraDirLumaPredictor, cudata.cpp:910-953: the units to the left and above inside the CU are the
+ * winners of this call, outside it left_mode / above_mode), the step of x265amd_intra_pu (scan, candidate list, candidate chains), then for every candidate the bits the
+ * reference counts for it -- prev_intra_luma_pred_flag and the mode index (entropy.cpp:1592-1642), the coded block flag, the coefficients (lane_coeff_bits: a 4x4 unit is
+ * short enough for one lane) on top of frac_start[unit] with the contexts `ctx` -- and its cost (rdcost.h:99-117: psy_scale = lambda * psyRd, 0 without psy-rd); the first
+ * cheapest candidate wins (search.cpp:1680-1690), its reconstruction goes to the picture (tmpl[unit].nb) and to layer_dst, its prediction to pred_dst (tiles of stride
+ * 64), and the next unit predicts from it.  A 4x4 unit has no transform split to try, so the host only repeats the winner's bookkeeping.  Four host round trips less
+ * per CU, and the candidates' bits leave the host. */
+typedef struct x265amd_intra_nxn_job
+{
+    x265amd_intra_tu_job tmpl[4];   /* the chain job of candidate 0 of each unit; coeff / resi in DEVICE memory */
+    uint64_t pred_dst[4], layer_dst[4];
+    uint64_t lambda, lambda2, psy_scale;
+    uint64_t frac_start[4];         /* Entropy::m_fracBits before the unit's direction bins (unit 0: after the CU's skip flag / prediction mode / partition size) */
+    uint32_t scan_frac;             /* m_fracBits & 32767 of m_rqt[depth].cur: the mode bits of the scan (search.cpp:1566-1577) */
+    uint32_t slot_pixels, slot_coeffs;
+    uint8_t left_mode[2], above_mode[2];    /* left of unit 0 / unit 2, above of unit 0 / unit 1, as the predictor derivation sees them (DC = 1 when absent or not intra) */
+    uint8_t ctx[X265AMD_CTX_STRIDE];
+    uint8_t max_cand, reserved[3];
+} x265amd_intra_nxn_job;
+typedef struct x265amd_intra_nxn_out { uint8_t mode[4], num_cand[4]; x265amd_tu_result res[4]; int16_t levels[4][16]; } x265amd_intra_nxn_out;     /* 264 bytes */
+int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_job, x265amd_intra_nxn_out* d_out);
+
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */
 int x265amd_tu_chain_rdoq(void* stream, const x265amd_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);
 void x265amd_rdoq_lambda(int qpScaled, int64_t* lambda2, int32_t* lambda);

@@ -307,6 +307,12 @@ __device__ __noinline__ void xa_op_intra_pu(const XaCmd& c, int tid)
                    64 * XA_SERVER_WAVES);
 }
 
+__device__ __noinline__ void xa_op_intra_nxn(const XaCmd& c, int tid)
+{
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(a.a), reinterpret_cast<x265amd_intra_nxn_out*>(a.b), xa_smem, tid, 64 * XA_SERVER_WAVES);
+}
+
 /* the groups of a launch one after the other: each stages its window, its jobs go to the wavefronts */
 template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int tid)
 {
@@ -365,6 +371,9 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
         break;
     case XA_OP_INTRA_PU:
         xa_op_intra_pu(c, tid);
+        break;
+    case XA_OP_INTRA_NXN:
+        xa_op_intra_nxn(c, tid);
         break;
     case XA_OP_ME_SEARCH: xa_op_me<0>(c, tid); break;
     case XA_OP_ME_SEARCH_STAR: xa_op_me<1>(c, tid); break;
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         if (flags & XA_CMD_SIGNAL) signalled = seen;
     }
     __syncthreads();
-    if (tid < 16) s_prof[38 + tid] = xa_stage_acc[tid];        /* [38..53]: the stages of the transform chains */
+    if (tid < 16) s_prof[40 + tid] = xa_stage_acc[tid];        /* [40..55]: the stages of the transform chains */
     __syncthreads();
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
@@ -643,7 +652,7 @@ struct Server
     void profile_report(bool final)
     {
         static const char* const names[XA_OP_COUNT] = { "nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain",
-                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu" };
+                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn" };
         uint64_t tot[64] = { 0 };
         for (int i = 0; i < numQueues; i++) for (int k = 0; k < 64; k++) tot[k] += hosts[i].prof[k];
         uint64_t cmds = 0, ticks = 0;
@@ -657,8 +666,8 @@ struct Server
         for (int op = 0; op < XA_OP_COUNT; op++)
             if (tot[2 * op]) fprintf(stderr, "  %-20s %9llu x %7.2f us = %8.1f ms\n", names[op], (unsigned long long)tot[2 * op], tot[2 * op + 1] / 100.0 / tot[2 * op], tot[2 * op + 1] / 1e5);
         fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
-                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", tot[38] / 1e5, tot[39] / 1e5, tot[40] / 1e5, tot[41] / 1e5, tot[42] / 1e5,
-                tot[43] / 1e5, tot[44] / 1e5, tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5);
+                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", tot[40] / 1e5, tot[41] / 1e5, tot[42] / 1e5, tot[43] / 1e5, tot[44] / 1e5,
+                tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5, tot[54] / 1e5, tot[55] / 1e5);
         static const char* const sized[11] = { "scan / pu 4", "scan / pu 8", "scan / pu 16", "scan / pu 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };
         for (int b = 20; b < 31; b++)

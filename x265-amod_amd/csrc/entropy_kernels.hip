@@ -51,43 +51,6 @@ __global__ __launch_bounds__(64 * EST_WAVES) void k_est_bit(const x265amd_est_jo
 #define CB_LANES 64
 struct CbLds { uint8_t ctx[CB_LANES][X265AMD_CTX_STRIDE]; };
 
-XA_DEV uint32_t cb_bin(uint8_t* st, uint32_t bin) { const uint8_t s = *st; *st = en_next(s, bin); return en_bits[s ^ bin]; }
-
-/* the 16 sample offsets of a 4x4 group in scan order `type` (g_scan4x4, constants.cpp:364-400, by rule), packed 4 bits each */
-XA_DEV uint32_t cb_in_cg(int type, int k)
-{
-    const uint64_t t = type == 1 ? 0xFEDCBA9876543210ULL : type == 2 ? 0xFB73EA62D951C840ULL : 0xFBE7AD369C258140ULL;
-    return (uint32_t)((t >> (4 * k)) & 15);
-}
-XA_DEV uint32_t cb_sig_ctx_inc(int log2N, uint32_t pattern, uint32_t rr)
-{
-    if (log2N == 2) return (uint32_t)((0x8877886654325410ULL >> (4 * rr)) & 15);
-    const uint64_t t = pattern == 0 ? 0x0000000100110112ULL : pattern == 1 ? 0x0000000011112222ULL : pattern == 2 ? 0x0012001200120012ULL : 0x2222222222222222ULL;
-    return (uint32_t)((t >> (4 * rr)) & 15);
-}
-/* raster index of group scan position g (g_scanOrderCG, constants.cpp:402-461, by rule): groups in `type` order for the 2x2 grid
- * of an 8x8 TU, up-right diagonal for the 4x4 / 8x8 grids of 16x16 / 32x32 TUs */
-struct CbDiag { uint8_t d4[16], d8[64]; };
-constexpr CbDiag cb_make_diag()
-{
-    CbDiag t = {};
-    for (int n = 4; n <= 8; n += 4)
-    {
-        int i = 0;
-        for (int d = 0; d < 2 * n - 1; d++)
-            for (int y = d < n ? d : n - 1; y >= 0 && d - y < n; y--, i++)
-                (n == 4 ? t.d4 : t.d8)[i] = (uint8_t)(y * n + (d - y));
-    }
-    return t;
-}
-__device__ const CbDiag cb_diag = cb_make_diag();
-XA_DEV uint32_t cb_cg_blk(int type, int log2N, int g)
-{
-    if (log2N == 2) return 0;
-    if (log2N == 3) return ((type == 1 ? 0x3210u : 0x3120u) >> (4 * g)) & 15;
-    return log2N == 4 ? cb_diag.d4[g] : cb_diag.d8[g];
-}
-
 __global__ __launch_bounds__(CB_LANES) void k_coeff_bits(const x265amd_coeff_bits_job* jobs, int n, uint64_t* out)
 {
     __shared__ CbLds lds;
@@ -101,179 +64,7 @@ __global__ __launch_bounds__(CB_LANES) void k_coeff_bits(const x265amd_coeff_bit
         uint32_t* dst = reinterpret_cast<uint32_t*>(ctx);
         for (int i = 0; i < X265AMD_CTX_STRIDE / 4; i++) dst[i] = src[i];
     }
-    const int16_t* coeff = reinterpret_cast<const int16_t*>(j.coeff);
-    const int log2N = j.log2_tr_size, N = 1 << log2N, isLuma = j.ttype == 0;
-    const int scanType = !j.intra ? 0 : ((log2N <= 2 || (isLuma && log2N == 3)) ? (j.dir_mode >= 22 && j.dir_mode <= 30 ? 1 : (j.dir_mode >= 6 && j.dir_mode <= 14 ? 2 : 0)) : 0);
-    const int cgType = log2N >= 4 ? 0 : scanType;
-    const int ncgAll = 1 << (2 * (log2N - 2));
-    const uint32_t log2CG = (uint32_t)log2N - 2, cgStride = (uint32_t)N >> 2;
-    uint64_t bits = 0;
-
-    /* scanPosLast_c (dct.cpp:757-790) folded in: find the last group / position holding a level, and the group flags */
-    int lastSet = -1, lastK = -1;
-    uint64_t cgFlags = 0;
-    for (int g = ncgAll - 1; g >= 0 && lastSet < 0; g--)
-    {
-        const uint32_t blk = cb_cg_blk(cgType, log2N, g);
-        const int base = (int)((blk >> log2CG) * 4) * N + (int)((blk & ((1u << log2CG) - 1)) * 4);
-        for (int k = 15; k >= 0; k--)
-        {
-            const uint32_t rr = cb_in_cg(cgType == 0 && log2N >= 4 ? 0 : scanType, k);
-            if (coeff[base + (int)(rr >> 2) * N + (int)(rr & 3)]) { lastSet = g; lastK = k; break; }
-        }
-    }
-    if (lastSet < 0)
-    {
-        out[ji] = 0;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(j.ctx_out);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ctx);
-        for (int i = 0; i < X265AMD_CTX_STRIDE / 4; i++) dst[i] = src[i];
-        return;
-    }
-    const int inType = log2N >= 4 ? 0 : scanType;
-
-    /* last position: context-coded prefixes, bypass suffixes (entropy.cpp:1874-1908) */
-    {
-        const uint32_t blk = cb_cg_blk(cgType, log2N, lastSet);
-        const uint32_t rr = cb_in_cg(inType, lastK);
-        uint32_t px = (blk & ((1u << log2CG) - 1)) * 4 + (rr & 3), py = (blk >> log2CG) * 4 + (rr >> 2);
-        if (scanType == 2) { const uint32_t t = px; px = py; py = t; }
-        int ctxIdx = isLuma ? 3 * (log2N - 2) + (log2N == 5) : N_LAST_XY_LUMA;
-        const int ctxShift = isLuma ? (log2N > 2) : log2N - 2;
-        const uint32_t maxGroupIdx = ((uint32_t)log2N << 1) - 1;
-        for (int i = 0; i < 2; i++, ctxIdx += N_LAST_XY)
-        {
-            const uint32_t pos = i ? py : px;
-            uint32_t prefix = pos, suffixLen = 0;
-            if (pos >= 4) { const uint32_t l = 31 - (uint32_t)__clz((int)pos); suffixLen = l - 1; prefix = 2 * l + ((pos >> (l - 1)) & 1); }
-            uint8_t* c = ctx + CTX_LAST_X + ctxIdx;
-            for (uint32_t k = 0; k < prefix; k++) bits += cb_bin(c + (k >> ctxShift), 1);
-            if (prefix < maxGroupIdx) bits += cb_bin(c + (prefix >> ctxShift), 0);
-            bits += (uint64_t)suffixLen << 15;
-        }
-    }
-    /* groups in front of the last one that hold levels (entropy.cpp:1862-1868) */
-    for (int g = 0; g < lastSet; g++)
-    {
-        const uint32_t blk = cb_cg_blk(cgType, log2N, g);
-        const int base = (int)((blk >> log2CG) * 4) * N + (int)((blk & ((1u << log2CG) - 1)) * 4);
-        bool any = false;
-        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) any |= coeff[base + y * N + x] != 0;
-        if (any) cgFlags |= (uint64_t)1 << blk;
-    }
-
-    uint8_t* cgCtx = ctx + CTX_SIG_CG + (isLuma ? 0 : N_SIG_CG);
-    uint8_t* sigCtx = ctx + CTX_SIG + (isLuma ? 0 : N_SIG_LUMA);
-    const int firstSig = log2N == 2 ? 0 : log2N == 3 ? ((scanType != 0 && isLuma) ? 15 : 9) : (isLuma ? 21 : 12);
-    uint32_t c1 = 1;
-    int sigOff = lastK - 1;
-    uint16_t absCoeff[16];
-    uint32_t numNonZero = 1;
-    {
-        const uint32_t blk = cb_cg_blk(cgType, log2N, lastSet);
-        const uint32_t rr = cb_in_cg(inType, lastK);
-        absCoeff[0] = (uint16_t)abs((int)coeff[(int)((blk >> log2CG) * 4 + (rr >> 2)) * N + (int)((blk & ((1u << log2CG) - 1)) * 4 + (rr & 3))]);
-    }
-    for (int sub = lastSet; sub >= 0; sub--)
-    {
-        const int subBase = sub << 4;
-        const uint32_t cgBlk = cb_cg_blk(cgType, log2N, sub), cgY = cgBlk >> log2CG, cgX = cgBlk & ((1u << log2CG) - 1);
-        const uint64_t cgMask = (uint64_t)1 << cgBlk;
-        const int base = (int)(cgY * 4) * N + (int)(cgX * 4);
-        uint32_t firstNZ = 16, lastNZ = 0;      /* positions (scan offsets) of the first / last level of this group */
-        if (sub == lastSet || !sub) cgFlags |= cgMask;
-        else
-        {
-            const uint32_t sigPos = cgBlk + 1 < 64 ? (uint32_t)(cgFlags >> (cgBlk + 1)) : 0;
-            const uint32_t right = (cgX != cgStride - 1) & sigPos, lower = (cgY != cgStride - 1) & (sigPos >> (cgStride - 1));
-            bits += cb_bin(cgCtx + (right | lower), (cgFlags & cgMask) != 0);
-        }
-        if (sub == lastSet) { firstNZ = lastNZ = (uint32_t)lastK; }
-        if (sigOff >= 0 && (cgFlags & cgMask))
-        {
-            /* costCoeffNxN_c (dct.cpp:838-890) */
-            uint32_t pattern = 0;
-            if (cgStride != 1)
-            {
-                const uint32_t sigPos = cgBlk + 1 < 64 ? (uint32_t)(cgFlags >> (cgBlk + 1)) : 0;
-                const uint32_t right = (cgX != cgStride - 1) & sigPos, lower = (cgY != cgStride - 1) & (sigPos >> (cgStride - 1));
-                pattern = right + lower * 2;
-            }
-            const int offset = firstSig + ((isLuma && sub) ? 3 : 0);
-            uint32_t nnz = sigOff < 15 ? 1 : 0;
-            uint32_t sum = 0;
-            for (int k = sigOff; k >= 0; k--)
-            {
-                const uint32_t rr = cb_in_cg(inType, k);
-                const int v = coeff[base + (int)(rr >> 2) * N + (int)(rr & 3)];
-                const uint32_t sig = v != 0;
-                if (k != 0 || subBase == 0 || nnz)
-                {
-                    const uint32_t ctxSig = (subBase + k) ? cb_sig_ctx_inc(log2N, pattern, rr) + (uint32_t)offset : 0;
-                    sum += cb_bin(sigCtx + ctxSig, sig);
-                }
-                if (sig)
-                {
-                    absCoeff[nnz] = (uint16_t)abs(v);
-                    if (firstNZ == 16 || (uint32_t)k < firstNZ) firstNZ = (uint32_t)k;
-                    if (nnz == 0) lastNZ = (uint32_t)k;
-                }
-                nnz += sig;
-            }
-            bits += sum & 0xFFFFFF;
-            numNonZero = nnz;
-        }
-        else if (sub != lastSet) numNonZero = 0;
-        if (numNonZero > 0)
-        {
-            const bool signHidden = lastNZ - firstNZ >= 4;
-            const uint32_t ctxSet = (((sub > 0) + (uint32_t)isLuma) & 2) + !(c1 & 3);
-            uint8_t* oneCtx = ctx + CTX_ONE + (isLuma ? 0 : N_ONE_LUMA) + 4 * ctxSet;
-            const uint32_t numC1 = numNonZero < 8 ? numNonZero : 8;
-            /* costC1C2Flag_c (dct.cpp:942-993) */
-            uint32_t sum = 0, firstC2Idx = 8, firstC2Flag = 2, c1Next = 0xFFFFFFFE;
-            c1 = 1;
-            for (uint32_t idx = 0; idx < numC1; idx++)
-            {
-                const uint32_t s1 = absCoeff[idx] > 1, s2 = absCoeff[idx] > 2;
-                sum += cb_bin(oneCtx + c1, s1);
-                if (s1) c1Next = 0;
-                if (s1 + firstC2Flag == 3) firstC2Flag = s2;
-                if (s1 + firstC2Idx == 9) firstC2Idx = idx;
-                c1 = c1Next & 3;
-                c1Next >>= 2;
-            }
-            if (!c1) sum += cb_bin(ctx + CTX_ABS + (isLuma ? 0 : N_ABS_LUMA) + ctxSet, firstC2Flag);
-            bits += sum & 0x00FFFFFF;
-            bits += (uint64_t)(numNonZero - ((j.sign_hide && signHidden) ? 1 : 0)) << 15;
-            if (numNonZero > firstC2Idx)
-            {
-                /* costCoeffRemain_c (dct.cpp:892-938) */
-                uint32_t rice = 0, rsum = 0;
-                int baseLevel = 3;
-                for (uint32_t idx = firstC2Idx; idx < numNonZero; idx++)
-                {
-                    if (idx >= 8) baseLevel = 1;
-                    int code = (int)absCoeff[idx] - baseLevel;
-                    if (code >= 0)
-                    {
-                        code = (int)((uint32_t)code >> rice) - 3;
-                        if (code >= 0)
-                        {
-                            const uint32_t length = 31 - (uint32_t)__clz(code + 1);
-                            code = (int)(length + length);
-                        }
-                        rsum += (uint32_t)(3 + 1 + (int)rice + code);
-                        if (absCoeff[idx] > (3u << rice)) rice = (rice + 1) - (rice >> 2);
-                    }
-                    baseLevel = 2;
-                }
-                bits += (uint64_t)rsum << 15;
-            }
-        }
-        numNonZero = 0;
-        sigOff = 15;
-    }
+    const uint64_t bits = lane_coeff_bits(ctx, reinterpret_cast<const int16_t*>(j.coeff), j.log2_tr_size, j.ttype, j.intra, j.dir_mode, j.sign_hide);
     out[ji] = bits;
     uint32_t* dst = reinterpret_cast<uint32_t*>(j.ctx_out);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(ctx);

@@ -4,27 +4,13 @@
 #define X265AMD_INTRA_PU_DEV_H
 #include "tu_dev.h"
 #include "intra_dev.h"
+#include "entropy_dev.h"
 
-/* x265amd_intra_pu: scan, candidate list, candidate chains by one workgroup (see include/x265amd.h).  smem: the larger of IntraScanLds and one
- * TuLds + IntraTuLds per wavefront. */
-XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out* po, x265amd_tu_result* res, char* smem, int tid, int nthr)
+struct IntraPuShared { int32_t sa8d[35]; uint8_t modes[16]; int num; };
+
+/* the candidate list of a prediction unit from its 35 SA8D costs (S.sa8d): called by the first wavefront, all 64 lanes; leaves S.modes / S.num */
+XA_DEV void wave0_candidate_list(IntraPuShared& S, uint32_t preds0, uint32_t preds1, uint32_t preds2, uint32_t rbits, uint32_t mpmBase, unsigned long long lambda, int maxCandIn, int tid)
 {
-    __shared__ int32_t s_sa8d[35];
-    __shared__ uint8_t s_modes[16];
-    __shared__ int s_num;
-    XA_STAGE(15);
-    const x265amd_intra_pu_job P = xa_ld_record(pj);
-    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
-    XA_STAGE(13);
-    {
-        x265amd_intra_job sj;
-        sj.recon = P.tmpl.nb; sj.fenc = P.tmpl.tu.fenc; sj.avail = P.tmpl.avail; sj.recon_stride = P.tmpl.nb_stride; sj.fenc_stride = P.tmpl.tu.fenc_stride;
-        sj.log2_tr_size = P.tmpl.tu.log2_tr_size; sj.strong_smoothing = P.tmpl.strong_smoothing;
-        block_intra_scan_job(sj, s_sa8d, nullptr, *reinterpret_cast<IntraScanLds*>(smem), tid, nthr);
-    }
-    __syncthreads();
-    XA_STAGE(14);
-    if (tid < 35) po->sa8d[tid] = s_sa8d[tid];
     /* estIntraPredQT (search.cpp:1615-1650): costs (a lane per mode), the padded best, then updateCandList over the eligible modes in mode order.  Costs fit
      * 32 bits with room to spare (sa8d of a 32x32 block of 12-bit samples < 2^28, bits x lambda >> 8 < 2^14), so the comparisons are the reference's. */
     if (tid < 64)
@@ -33,34 +19,34 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
         uint32_t myCost = kMax;
         if (tid < 35)
         {
-            uint32_t b = P.rbits;
-            if (tid == P.preds[0]) b = P.mpm_base + 1u;
-            else if (tid == P.preds[1] || tid == P.preds[2]) b = P.mpm_base + 2u;
-            myCost = (uint32_t)s_sa8d[tid] + (uint32_t)(((unsigned long long)b * P.lambda + 128) >> 8);
+            uint32_t b = rbits;
+            if (tid == preds0) b = mpmBase + 1u;
+            else if (tid == preds1 || tid == preds2) b = mpmBase + 2u;
+            myCost = (uint32_t)S.sa8d[tid] + (uint32_t)(((unsigned long long)b * lambda + 128) >> 8);
         }
         uint32_t bcost = myCost;
         for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(bcost, off, 64); bcost = o < bcost ? o : bcost; }
         const uint32_t padded = bcost + (bcost >> 2);
-        unsigned long long todo = __ballot(tid < 35 && (myCost < padded || tid == P.preds[0]));
-        const int maxCand = P.max_cand > 16 ? 16 : P.max_cand;
+        unsigned long long todo = __ballot(tid < 35 && (myCost < padded || tid == preds0));
+        const int maxCand = maxCandIn > 16 ? 16 : maxCandIn;
         const int numEligible = __popcll(todo);
         /* the first maxCand eligible modes take the places in order (each replaces the first empty place) */
         const int myRank = __popcll(todo & ((1ull << tid) - 1));
         const bool mineEligible = tid < 35 && ((todo >> tid) & 1);
-        if (tid < 16) s_modes[tid] = 0;
+        if (tid < 16) S.modes[tid] = 0;
         xa_wave_sync();
-        if (mineEligible && myRank < maxCand) s_modes[myRank] = (uint8_t)tid;
+        if (mineEligible && myRank < maxCand) S.modes[myRank] = (uint8_t)tid;
         xa_wave_sync();
         if (numEligible <= maxCand)
         {
-            if (tid == 0) { s_num = numEligible; po->num_cand = (uint32_t)numEligible; }
+            if (tid == 0) { S.num = numEligible; }
         }
         else
         {
             /* updateCandList for the rest, the list across lanes 0..15 (one place per lane; places beyond maxCand hold 0 and are never the largest): per
              * eligible mode one 16-lane maximum with row shifts (DPP: no LDS traffic), the first lane holding it is the place to replace.  (A single lane
              * doing the same compares one after the other costs five microseconds.) */
-            uint32_t myMode = tid < 16 ? s_modes[tid] : 0;
+            uint32_t myMode = tid < 16 ? S.modes[tid] : 0;
             const uint32_t got = (uint32_t)__shfl((int)myCost, (int)myMode, 64);         /* the cost of the mode in this lane's place */
             uint32_t mine = tid < maxCand ? got : 0;
             /* drop the modes already placed */
@@ -82,24 +68,151 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
                 if (c < maxValue && tid == maxIndex) { mine = c; myMode = (uint32_t)m; }
             }
 #undef XA_ROW_SHR
-            if (tid < 16) s_modes[tid] = (uint8_t)myMode;
-            if (tid == 0) { s_num = maxCand; po->num_cand = (uint32_t)maxCand; }
+            if (tid < 16) S.modes[tid] = (uint8_t)myMode;
+            if (tid == 0) { S.num = maxCand; }
         }
         xa_wave_sync();
-        if (tid < 16) po->modes[tid] = tid < s_num ? s_modes[tid] : 0;
+    }
+}
+
+/* x265amd_intra_pu: scan, candidate list, candidate chains by one workgroup (see include/x265amd.h).  smem: the larger of IntraScanLds and one
+ * TuLds + IntraTuLds per wavefront. */
+XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out* po, x265amd_tu_result* res, char* smem, int tid, int nthr)
+{
+    __shared__ IntraPuShared S;
+    XA_STAGE(15);
+    const x265amd_intra_pu_job P = xa_ld_record(pj);
+    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    XA_STAGE(13);
+    {
+        x265amd_intra_job sj;
+        sj.recon = P.tmpl.nb; sj.fenc = P.tmpl.tu.fenc; sj.avail = P.tmpl.avail; sj.recon_stride = P.tmpl.nb_stride; sj.fenc_stride = P.tmpl.tu.fenc_stride;
+        sj.log2_tr_size = P.tmpl.tu.log2_tr_size; sj.strong_smoothing = P.tmpl.strong_smoothing;
+        block_intra_scan_job(sj, S.sa8d, nullptr, *reinterpret_cast<IntraScanLds*>(smem), tid, nthr);
+    }
+    __syncthreads();
+    XA_STAGE(14);
+    if (tid < 35) po->sa8d[tid] = S.sa8d[tid];
+    if (tid < 64)
+    {
+        wave0_candidate_list(S, P.preds[0], P.preds[1], P.preds[2], P.rbits, P.mpm_base, P.lambda, P.max_cand, tid);
+        if (tid == 0) po->num_cand = (uint32_t)S.num;
+        if (tid < 16) po->modes[tid] = tid < S.num ? S.modes[tid] : 0;
     }
     __syncthreads();
     XA_STAGE(13);
     TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
     IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
-    const int n = s_num;
+    const int n = S.num;
     for (int i = wv; i < n; i += nwv)
     {
         x265amd_intra_tu_job J = P.tmpl;
-        J.tu.dir_mode = s_modes[i];
+        J.tu.dir_mode = S.modes[i];
         J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
         J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
         wave_intra_tu_chain_body<false>(J, nullptr, res + i, s, ip, nullptr, lane);
+    }
+}
+
+/* x265amd_intra_nxn (include/x265amd.h): the four 4x4 prediction units of an 8x8 NxN CU, decisions included, by one workgroup. */
+XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_out* po, char* smem, int tid, int nthr)
+{
+    __shared__ IntraPuShared S;
+    __shared__ x265amd_tu_result s_res[16];
+    __shared__ unsigned long long s_cost[16];
+    __shared__ uint8_t s_ctxw[16][X265AMD_CTX_STRIDE];
+    __shared__ int s_win;
+    __shared__ uint8_t s_winMode[4];
+    __shared__ x265amd_intra_nxn_job sP;           /* the job record: 688 bytes, indexed by the unit -- in LDS, not in registers */
+    static_assert(sizeof(x265amd_intra_nxn_job) % 8 == 0, "job records are sequences of 64-bit words");
+    __syncthreads();
+    for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_job) / 8); i += nthr)
+        reinterpret_cast<uint64_t*>(&sP)[i] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(pj) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    const x265amd_intra_nxn_job& P = sP;
+    const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    const uint32_t adi = P.ctx[13];                                                         /* C_ADI: prev_intra_luma_pred_flag */
+    const uint32_t rbits = (uint32_t)(((unsigned long long)P.scan_frac + en_bits[adi ^ 0]) >> 15) + 5;
+    const uint32_t mpmBase = (uint32_t)(((unsigned long long)P.scan_frac + en_bits[adi ^ 1]) >> 15);
+    const int maxCand = P.max_cand > 16 ? 16 : P.max_cand;
+    for (int k = 0; k < 4; k++)
+    {
+        const x265amd_intra_tu_job& T = P.tmpl[k];
+        /* getIntraDirLumaPredictor: the left / above units' modes */
+        __syncthreads();
+        const uint32_t left = (k & 1) ? s_winMode[k - 1] : P.left_mode[k >> 1], above = (k & 2) ? s_winMode[k - 2] : P.above_mode[k & 1];
+        uint32_t p0, p1, p2;
+        if (left == above)
+        {
+            if (left >= 2) { p0 = left; p1 = ((left - 2 + 31) & 31) + 2; p2 = ((left - 2 + 1) & 31) + 2; }
+            else { p0 = 0; p1 = 1; p2 = 26; }
+        }
+        else { p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
+        {
+            x265amd_intra_job sj;
+            sj.recon = T.nb; sj.fenc = T.tu.fenc; sj.avail = T.avail; sj.recon_stride = T.nb_stride; sj.fenc_stride = T.tu.fenc_stride;
+            sj.log2_tr_size = T.tu.log2_tr_size; sj.strong_smoothing = T.strong_smoothing;
+            block_intra_scan_job(sj, S.sa8d, nullptr, *reinterpret_cast<IntraScanLds*>(smem), tid, nthr);
+        }
+        __syncthreads();
+        if (tid < 64) wave0_candidate_list(S, p0, p1, p2, rbits, mpmBase, P.lambda, maxCand, tid);
+        __syncthreads();
+        const int n = S.num;
+        TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
+        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
+        for (int i = wv; i < n; i += nwv)
+        {
+            x265amd_intra_tu_job J = T;
+            const uint32_t mode = S.modes[i];
+            J.tu.dir_mode = (uint8_t)mode;
+            J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
+            J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
+            wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane);
+            /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400): the lane's own copy of the contexts */
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[i][b] = P.ctx[b];
+            xa_wave_sync();
+            if (lane == 0)
+            {
+                uint8_t* cw = s_ctxw[i];
+                const int pidx = mode == p0 ? 0 : (mode == p1 ? 1 : (mode == p2 ? 2 : -1));
+                unsigned long long frac = P.frac_start[k];
+                frac += en_bits[cw[13] ^ (pidx != -1 ? 1u : 0u)];
+                frac += (unsigned long long)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
+                const x265amd_tu_result r = s_res[i];
+                frac += en_bits[cw[CTX_QT_CBF] ^ (r.num_sig != 0 ? 1u : 0u)];
+                if (r.num_sig) frac += lane_coeff_bits(cw, s.q, 2, 0, 1, (int)mode, T.tu.sign_hide);         /* the levels are still in this wavefront's LDS */
+                const unsigned long long bits = (uint32_t)(frac >> 15);
+                const unsigned long long dist = r.nz_dist;
+                s_cost[i] = P.psy_scale ? dist + ((P.psy_scale * (unsigned long long)r.nz_energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
+            }
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            int w = 0;
+            unsigned long long best = ~0ull;
+            for (int i = 0; i < n; i++) if (s_cost[i] < best) { best = s_cost[i]; w = i; }
+            s_win = w; s_winMode[k] = S.modes[w];
+            po->mode[k] = S.modes[w]; po->num_cand[k] = (uint8_t)n; po->res[k] = s_res[w];
+        }
+        __syncthreads();
+        {
+            /* the winner's blocks: reconstruction into the picture and the layer tile, prediction into the prediction tile; its levels to the host */
+            const int w = s_win;
+            const pixel* rec = reinterpret_cast<const pixel*>(T.tu.recon) + (size_t)w * P.slot_pixels;
+            const pixel* prd = reinterpret_cast<const pixel*>(T.tu.pred) + (size_t)w * P.slot_pixels;
+            const int16_t* lv = reinterpret_cast<const int16_t*>(T.tu.coeff) + (size_t)w * P.slot_coeffs;
+            if (tid < 16)
+            {
+                const int y = tid >> 2, x = tid & 3;
+                const pixel v = rec[y * T.tu.recon_stride + x];
+                reinterpret_cast<pixel*>(T.nb)[(long)y * T.nb_stride + x] = v;
+                reinterpret_cast<pixel*>(P.layer_dst[k])[y * 64 + x] = v;
+                reinterpret_cast<pixel*>(P.pred_dst[k])[y * 64 + x] = prd[y * T.tu.pred_stride + x];
+                po->levels[k][tid] = lv[tid];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
+        }
     }
 }
 

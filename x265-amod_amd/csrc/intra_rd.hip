@@ -56,7 +56,8 @@ struct IntraRd
     uint64_t lambda2, lambda; uint32_t psyRd;
     uint64_t predTile, reconTile;
     DevBuf dResi, dLayer, dCand;
-    MappedBuf dJobs; XaMapped dScanJob, dPuJob; XaMappedOut dRes, dCoeff, dScan, dPuOut;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    MappedBuf dJobs; XaMapped dScanJob, dPuJob, dNxnJob; XaMappedOut dRes, dCoeff, dScan, dPuOut, dNxnOut;
+    DevBuf dCoeffDev;                                   /* candidate levels / residuals of the device-decided NxN path (device memory: only the winner's levels travel) */      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -387,6 +388,61 @@ struct IntraRd
     {
         const int initTuDepth = partSize != 0, numPU = 1 << (2 * initTuDepth), log2TrSize = log2 - initTuDepth, tuSize = 1 << log2TrSize;
         totalDistortion = 0;
+        /* An 8x8 CU coded NxN: the four 4x4 units with their decisions are ONE launch (x265amd_intra_nxn) -- a 4x4 unit has no transform split to try and its
+         * coefficients are few enough for the device to count their bits, so nothing of the host's enters between the units.  The host repeats the winners'
+         * bookkeeping (units, bits, contexts) afterwards.  Not with RDOQ (the quantiser then reads bit estimates of the current contexts per unit). */
+        x265amd_intra_nxn_out nxn;
+        const bool deviceNxN = partSize != 0 && log2 == 3 && log2TrSize == 2 && range[0] == 2 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS;
+        if (deviceNxN)
+        {
+            xa_phase(XA_PH_INTRA_CAND);
+            const size_t isz = sizeof(pixel);
+            x265amd_intra_nxn_job nj;
+            memset(&nj, 0, sizeof(nj));
+            const uint64_t slot0 = (uint64_t)(uintptr_t)dCand.p;
+            for (int k = 0; k < 4; k++)
+            {
+                const int px = cuX + (k & 1) * 4, py = cuY + (k >> 1) * 4;
+                fillJob(nj.tmpl[k], 0, px, py, 2, 0, slot0 + 1024 * isz, 4, slot0, 4, 0);
+                nj.tmpl[k].tu.coeff = (uint64_t)(uintptr_t)dCoeffDev.p;
+                nj.tmpl[k].tu.resi = (uint64_t)(uintptr_t)dCoeffDev.p + (size_t)MAX_JOBS * 1024 * 2; nj.tmpl[k].tu.resi_stride = 4;
+                nj.tmpl[k].avail = available(px, py, 4);
+                nj.pred_dst[k] = predTile + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
+                nj.layer_dst[k] = (uint64_t)(uintptr_t)dLayer.p + ((size_t)0 * 4096 + (size_t)(py - cuY) * 64 + (px - cuX)) * isz;     /* layer of the 4x4 units */
+                nj.frac_start[k] = cur.frac & 32767;
+            }
+            {
+                /* what codeIntraLumaQT codes in front of the first unit's direction: skip flag and prediction mode (P / B slices), the partition size */
+                load(cur); resetBits();
+                if (si->slice_type != 2)
+                {
+                    const x265amd_cu_unit* l = c->at((cuX >> 2) - 1, cuY >> 2);
+                    const x265amd_cu_unit* a = c->at(cuX >> 2, (cuY >> 2) - 1);
+                    const int skipCtx = (x265amd_cabac::coded(l) && l->pred_mode == X265AMD_MODE_SKIP) + (x265amd_cabac::coded(a) && a->pred_mode == X265AMD_MODE_SKIP);
+                    c->bin(0, C_SKIP + skipCtx);
+                    c->bin(1, C_PRED_MODE);
+                }
+                c->partSize(U(cuX, cuY), depth, size);
+                nj.frac_start[0] = c->fracBits;
+                load(cur);
+            }
+            auto seen = [&](int x, int y, bool aboveOne) -> uint8_t {       /* getIntraDirLumaPredictor's view of a neighbour outside the CU (cudata.cpp:910-953) */
+                const x265amd_cu_unit* u = aboveOne ? ((y & 63) ? c->at(x >> 2, (y >> 2) - 1) : nullptr) : c->at((x >> 2) - 1, y >> 2);
+                return (uint8_t)((x265amd_cabac::coded(u) && u->pred_mode == X265AMD_MODE_INTRA) ? u->luma_dir : 1);
+            };
+            nj.left_mode[0] = seen(cuX, cuY, false); nj.left_mode[1] = seen(cuX, cuY + 4, false);
+            nj.above_mode[0] = seen(cuX, cuY, true); nj.above_mode[1] = seen(cuX + 4, cuY, true);
+            nj.lambda = lambda; nj.lambda2 = lambda2; nj.psy_scale = psyRd ? lambda * psyRd : 0;
+            nj.scan_frac = (uint32_t)(cur.frac & 32767);
+            nj.slot_pixels = 2048; nj.slot_coeffs = 1024;
+            memcpy(nj.ctx, cur.ctx, X265AMD_CTX_STRIDE);
+            nj.max_cand = (uint8_t)(2 + rdLevel + ((depth + initTuDepth) >> 1));
+            memcpy(dNxnJob.p, &nj, sizeof(nj));
+            if (x265amd_intra_nxn(st, (const x265amd_intra_nxn_job*)dNxnJob.p, (x265amd_intra_nxn_out*)dNxnOut.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
+                return fail("intra rd: NxN step");
+            memcpy(&nxn, dNxnOut.p, sizeof(nxn));
+            xa_phase(XA_PH_INTRA_SCAN);
+        }
         for (int puIdx = 0; puIdx < numPU; puIdx++)
         {
             const int px = cuX + (initTuDepth ? (puIdx & 1) * tuSize : 0), py = cuY + (initTuDepth ? (puIdx >> 1) * tuSize : 0);
@@ -394,6 +450,21 @@ struct IntraRd
             uint64_t candCostList[35]; uint32_t rdModeList[35];
             const int maxCandCount = 2 + rdLevel + ((depth + initTuDepth) >> 1);
             const size_t isz = sizeof(pixel);
+            if (deviceNxN)
+            {
+                /* the unit was decided on the device: its mode, result and levels; its blocks are in place.  codeIntraLumaQT repeats the bookkeeping. */
+                const uint32_t bm = nxn.mode[puIdx];
+                if (bm > 34) return fail("intra rd: NxN mode");
+                U(px, py).luma_dir = (uint8_t)bm;
+                load(cur);
+                Cost ic = { 0, 0, 0, 0 };
+                pre = Pre{ true, px, py, log2TrSize, nxn.res[puIdx], nxn.levels[puIdx], 0, 0, false };
+                const int rq = codeIntraLumaQT(px, py, initTuDepth, true, ic);
+                pre.on = false;
+                if (rq) return err;
+                totalDistortion += ic.distortion;
+                continue;
+            }
             /* Without RDOQ nothing the host knows enters between the scan and the candidates' transform chains: scan, candidate list and chains are ONE
              * launch (x265amd_intra_pu), the host's share starts with the bits.  (With RDOQ the bit estimates made from the current contexts go to the
              * device first: scan and chains stay two steps.) */
@@ -744,6 +815,8 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
          R.dCand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dLayer.alloc((size_t)4 * 4096 * sizeof(pixel)) != hipSuccess ||
          R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
          R.dPuJob.alloc(sizeof(x265amd_intra_pu_job)) != hipSuccess || R.dPuOut.alloc(sizeof(x265amd_intra_pu_out)) != hipSuccess ||
+         R.dNxnJob.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess ||
+         R.dCoeffDev.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
          R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
          R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess))
     {

@@ -87,6 +87,12 @@ __global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_pu(const x265amd_
     block_intra_pu(job, out, res, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
 }
 
+__global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_nxn(const x265amd_intra_nxn_job* job, x265amd_intra_nxn_out* out)
+{
+    extern __shared__ __attribute__((aligned(16))) char tu_smem[];
+    block_intra_nxn(job, out, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
+}
+
 /* =========================================================================================================
  * host side
  * ======================================================================================================= */
@@ -104,6 +110,7 @@ static int tu_configure()
         XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_intra_tu_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)(TU_RDOQ_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds) + sizeof(RdoqLds)))));
         XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_intra_pu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIntraPuLds));
+        XA_HIP_CHECK(hipFuncSetAttribute((const void*)k_intra_nxn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIntraPuLds));
         done = true;
     }
     return X265AMD_OK;
@@ -163,6 +170,18 @@ extern "C" int x265amd_intra_pu(void* stream, const x265amd_intra_pu_job* d_job,
     const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_job, (uint64_t)(uintptr_t)d_out, (uint64_t)(uintptr_t)d_res, 0, 1 };
     hipError_t e;
     XA_LAUNCH(e, stream, XA_OP_INTRA_PU, 1, qa, k_intra_pu, dim3(1), dim3(64 * INTRA_PU_WAVES), kIntraPuLds, d_job, d_out, d_res);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_job, x265amd_intra_nxn_out* d_out)
+{
+    if (!d_job || !d_out) return xa_fail(X265AMD_EINVAL, "x265amd_intra_nxn: bad arguments");
+    int rc = xa_is_queue(stream) ? X265AMD_OK : tu_configure();
+    if (rc) return rc;
+    const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_job, (uint64_t)(uintptr_t)d_out, 0, 0, 1 };
+    hipError_t e;
+    XA_LAUNCH(e, stream, XA_OP_INTRA_NXN, 1, qa, k_intra_nxn, dim3(1), dim3(64 * INTRA_PU_WAVES), kIntraPuLds, d_job, d_out);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }
