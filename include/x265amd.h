@@ -335,7 +335,8 @@ int x265amd_intra_pu(void* stream, const x265amd_intra_pu_job* d_job, x265amd_in
  * short enough for one lane) on top of frac_start[unit] with the contexts `ctx` -- and its cost (rdcost.h:99-117: psy_scale = lambda * psyRd, 0 without psy-rd); the first
  * cheapest candidate wins (search.cpp:1680-1690), its reconstruction goes to the picture (tmpl[unit].nb) and to layer_dst, its prediction to pred_dst (tiles of stride
  * 64), and the next unit predicts from it.  A 4x4 unit has no transform split to try, so the host only repeats the winner's bookkeeping.  Four host round trips less
- * per CU, and the candidates' bits leave the host. */
+ * per CU, and the candidates' bits leave the host.  With all four units in place the CU's two luma measurements follow in the same launch (cu_luma: the CU's first
+ * sample in the reconstructed plane is tmpl[0].nb, in the prediction tile pred_dst[0]). */
 typedef struct x265amd_intra_nxn_job
 {
     x265amd_intra_tu_job tmpl[4];   /* the chain job of candidate 0 of each unit; coeff / resi in DEVICE memory */
@@ -348,7 +349,12 @@ typedef struct x265amd_intra_nxn_job
     uint8_t ctx[X265AMD_CTX_STRIDE];
     uint8_t max_cand, reserved[3];
 } x265amd_intra_nxn_job;
-typedef struct x265amd_intra_nxn_out { uint8_t mode[4], num_cand[4]; x265amd_tu_result res[4]; int16_t levels[4][16]; } x265amd_intra_nxn_out;     /* 264 bytes */
+typedef struct x265amd_intra_nxn_out
+{
+    uint8_t mode[4], num_cand[4]; x265amd_tu_result res[4]; int16_t levels[4][16];
+    uint32_t psy_energy;            /* psyCost of the CU's 8x8 luma reconstruction against the source (rdcost.h:114-117; what checkIntra measures at the end, search.cpp:1279-1283) */
+    uint32_t res_energy;            /* sse of the CU's 8x8 luma prediction against the source */
+} x265amd_intra_nxn_out;            /* 272 bytes */
 int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_job, x265amd_intra_nxn_out* d_out);
 
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */

@@ -214,6 +214,16 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
         }
     }
+    /* the CU's luma measurements on the finished 8x8 block: psy energy of the reconstruction, residual energy of the prediction */
+    __syncthreads();
+    if (wv == 0)
+    {
+        const x265amd_intra_tu_job& T0 = P.tmpl[0];
+        const pixel* f = reinterpret_cast<const pixel*>(T0.tu.fenc);
+        const int psy = wave_psy_cost(f, T0.tu.fenc_stride, reinterpret_cast<const pixel*>(T0.nb), T0.nb_stride, 1, lane);
+        const uint64_t sse = wave_sse_pp(f, T0.tu.fenc_stride, reinterpret_cast<const pixel*>(P.pred_dst[0]), 64, 8, lane);
+        if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
+    }
 }
 
 #endif

@@ -381,6 +381,8 @@ struct IntraRd
      * residual energy of the prediction), so no separate measurement launch is needed */
     bool haveWhole = false;
     x265amd_tu_result wholeRes;
+    bool haveNxn = false;                       /* the device-decided NxN path measured the CU's luma block itself */
+    uint32_t nxnPsy = 0, nxnRes = 0;
 
     /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
      * best mode again with TU splits allowed */
@@ -441,6 +443,7 @@ struct IntraRd
             if (x265amd_intra_nxn(st, (const x265amd_intra_nxn_job*)dNxnJob.p, (x265amd_intra_nxn_out*)dNxnOut.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
                 return fail("intra rd: NxN step");
             memcpy(&nxn, dNxnOut.p, sizeof(nxn));
+            haveNxn = true; nxnPsy = nxn.psy_energy; nxnRes = nxn.res_energy;
             xa_phase(XA_PH_INTRA_SCAN);
         }
         for (int puIdx = 0; puIdx < numPU; puIdx++)
@@ -787,7 +790,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     IntraRd* ip = ws && *ws ? static_cast<IntraRd*>(*ws) : new IntraRd;
     if (ws) *ws = ip;
     IntraRd& R = *ip;
-    R.haveWhole = false;
+    R.haveWhole = false; R.haveNxn = false;
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
     R.predTile = d_pred; R.reconTile = d_recon;
@@ -930,7 +933,12 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         /* psy energy of the reconstruction, residual energy of the prediction (luma) */
         x265amd_rd_cu mc2[2] = { *cu, *cu };
         x265amd_cu_measure m2[2];
-        if (R.haveWhole && partSize == 0)
+        if (R.haveNxn && partSize != 0)
+        {
+            out->psy_energy = R.psyRd ? R.nxnPsy : 0;
+            out->res_energy = R.nxnRes;
+        }
+        else if (R.haveWhole && partSize == 0)
         {
             /* one transform unit = the CU: psyCost(fenc, recon) and sse(fenc, pred) of the luma block came with the unit's result (rdcost.h:114-117,
              * search.cpp:1279-1283 / :1486-1503 measure exactly these two) */
