@@ -347,14 +347,24 @@ typedef struct x265amd_intra_nxn_job
     uint32_t slot_pixels, slot_coeffs;
     uint8_t left_mode[2], above_mode[2];    /* left of unit 0 / unit 2, above of unit 0 / unit 1, as the predictor derivation sees them (DC = 1 when absent or not intra) */
     uint8_t ctx[X265AMD_CTX_STRIDE];
-    uint8_t max_cand, reserved[3];
+    uint8_t max_cand, do_chroma, reserved[2];
+    /* do_chroma: Search::estIntraPredChromaQT for the CU's one 4x4 block per chroma plane in the same launch (search.cpp:1754-1889): the five allowed modes (planar,
+     * vertical, horizontal, DC with the one equal to the first unit's luma mode replaced by 34, then the luma mode itself), each a wavefront running the U and the V
+     * chain and counting the mode's bits -- intra_chroma_pred_mode, the two coded block flags, U's and V's coefficients, on the contexts `ctx` from scan_frac --; the first
+     * cheapest wins.  ctmpl: the chain jobs of mode 0 of U and V (recon = slot 0 of the plane; mode m of plane p uses slot 2 m + p; no prediction output); the winner's
+     * reconstruction goes to crecon_dst (stride 32), and the picture (ctmpl[p].nb) keeps the LAST tried mode's, as after the reference's loop. */
+    x265amd_intra_tu_job ctmpl[2];
+    uint64_t crecon_dst[2];
 } x265amd_intra_nxn_job;
 typedef struct x265amd_intra_nxn_out
 {
     uint8_t mode[4], num_cand[4]; x265amd_tu_result res[4]; int16_t levels[4][16];
     uint32_t psy_energy;            /* psyCost of the CU's 8x8 luma reconstruction against the source (rdcost.h:114-117; what checkIntra measures at the end, search.cpp:1279-1283) */
     uint32_t res_energy;            /* sse of the CU's 8x8 luma prediction against the source */
-} x265amd_intra_nxn_out;            /* 272 bytes */
+    uint32_t chroma_best, chroma_reserved;      /* do_chroma: index of the winning mode in the list of five; its two results and levels */
+    x265amd_tu_result cres[2];
+    int16_t clevels[2][16];
+} x265amd_intra_nxn_out;            /* 408 bytes */
 int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_job, x265amd_intra_nxn_out* d_out);
 
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */

@@ -224,6 +224,76 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         const uint64_t sse = wave_sse_pp(f, T0.tu.fenc_stride, reinterpret_cast<const pixel*>(P.pred_dst[0]), 64, 8, lane);
         if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
     }
+    if (!P.do_chroma) return;
+    /* ---- estIntraPredChromaQT for the one 4x4 block per plane: a wavefront per mode ---- */
+    __shared__ x265amd_tu_result s_cres[5][2];
+    __shared__ int16_t s_clev[5][2][16];
+    __shared__ uint8_t s_cmode[5];
+    const uint32_t lumaDir = s_winMode[0];
+    if (tid < 5)
+    {
+        /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
+        uint32_t list[5] = { 0, 26, 10, 1, 36 };
+        for (int i = 0; i < 4; i++) if (lumaDir == list[i]) { list[i] = 34; break; }
+        s_cmode[tid] = (uint8_t)list[tid];
+    }
+    __syncthreads();
+    if (wv < 5)
+    {
+        TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
+        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
+        const uint32_t listed = s_cmode[wv], mode = listed == 36 ? lumaDir : listed;
+        for (int pl = 0; pl < 2; pl++)
+        {
+            x265amd_intra_tu_job J = P.ctmpl[pl];
+            J.tu.dir_mode = (uint8_t)mode;
+            J.tu.recon += (uint64_t)(2 * wv + pl) * P.slot_pixels * sizeof(pixel);
+            J.tu.coeff += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t);
+            wave_intra_tu_chain_body<false>(J, nullptr, &s_cres[wv][pl], s, ip, nullptr, lane);
+            if (lane < 16) s_clev[wv][pl][lane] = s.q[lane];
+            xa_wave_sync();
+        }
+        for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[wv][b] = P.ctx[b];
+        xa_wave_sync();
+        if (lane == 0)
+        {
+            uint8_t* cw = s_ctxw[wv];
+            unsigned long long frac = P.scan_frac;
+            frac += cb_bin(cw + 14, listed == 36 ? 0u : 1u);                                /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
+            if (listed != 36) frac += 2ull << 15;
+            /* the two coded block flags share a context (codeSubdivCbfQTChroma at depth 0, both planes: C_QT_CBF + 2), then U's and V's coefficients */
+            for (int pl = 0; pl < 2; pl++) frac += cb_bin(cw + CTX_QT_CBF + 2, s_cres[wv][pl].num_sig != 0 ? 1u : 0u);
+            unsigned long long dist = 0, energy = 0;
+            for (int pl = 0; pl < 2; pl++)
+            {
+                if (s_cres[wv][pl].num_sig) frac += lane_coeff_bits(cw, s_clev[wv][pl], 2, 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide);
+                dist += s_cres[wv][pl].nz_dist; energy += s_cres[wv][pl].nz_energy;
+            }
+            const unsigned long long bits = (uint32_t)(frac >> 15);
+            s_cost[wv] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        int w = 0;
+        unsigned long long best = ~0ull;
+        for (int i = 0; i < 5; i++) if (s_cost[i] < best) { best = s_cost[i]; w = i; }
+        s_win = w;
+        po->chroma_best = (uint32_t)w; po->chroma_reserved = 0;
+        po->cres[0] = s_cres[w][0]; po->cres[1] = s_cres[w][1];
+    }
+    __syncthreads();
+    if (tid < 32)
+    {
+        const int pl = tid >> 4, i = tid & 15, y = i >> 2, x = i & 3, w = s_win;
+        const x265amd_intra_tu_job& C = P.ctmpl[pl];
+        const pixel* best = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * w + pl) * P.slot_pixels;
+        const pixel* last = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * 4 + pl) * P.slot_pixels;
+        reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = best[y * C.tu.recon_stride + x];
+        reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = last[y * C.tu.recon_stride + x];
+        po->clevels[pl][i] = s_clev[w][pl][i];
+    }
 }
 
 #endif

@@ -383,6 +383,7 @@ struct IntraRd
     x265amd_tu_result wholeRes;
     bool haveNxn = false;                       /* the device-decided NxN path measured the CU's luma block itself */
     uint32_t nxnPsy = 0, nxnRes = 0;
+    x265amd_intra_nxn_out nxnChroma;            /* ... and chose the chroma mode */
 
     /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
      * best mode again with TU splits allowed */
@@ -439,11 +440,26 @@ struct IntraRd
             nj.slot_pixels = 2048; nj.slot_coeffs = 1024;
             memcpy(nj.ctx, cur.ctx, X265AMD_CTX_STRIDE);
             nj.max_cand = (uint8_t)(2 + rdLevel + ((depth + initTuDepth) >> 1));
+            {
+                /* the chroma decision rides along (estIntraPredChromaQT's one 4x4 block per plane: its inputs do not depend on the luma result, its mode list does
+                 * and the device knows the first unit's winner) */
+                const uint64_t avail = foldChroma(available(cuX, cuY, size), size >> 2);
+                for (int pl = 1; pl < 3; pl++)
+                {
+                    fillJob(nj.ctmpl[pl - 1], pl, cuX, cuY, 2, 0, 0, 4, slot0, 4, 0);
+                    nj.ctmpl[pl - 1].avail = avail;
+                    nj.ctmpl[pl - 1].tu.coeff = (uint64_t)(uintptr_t)dCoeffDev.p;
+                    nj.ctmpl[pl - 1].tu.resi = (uint64_t)(uintptr_t)dCoeffDev.p + (size_t)MAX_JOBS * 1024 * 2; nj.ctmpl[pl - 1].tu.resi_stride = 4;
+                    nj.crecon_dst[pl - 1] = reconTile + (4096 + (size_t)(pl - 1) * 1024) * isz;
+                }
+                nj.do_chroma = 1;
+            }
             memcpy(dNxnJob.p, &nj, sizeof(nj));
             if (x265amd_intra_nxn(st, (const x265amd_intra_nxn_job*)dNxnJob.p, (x265amd_intra_nxn_out*)dNxnOut.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
                 return fail("intra rd: NxN step");
             memcpy(&nxn, dNxnOut.p, sizeof(nxn));
             haveNxn = true; nxnPsy = nxn.psy_energy; nxnRes = nxn.res_energy;
+            nxnChroma = nxn;
             xa_phase(XA_PH_INTRA_SCAN);
         }
         for (int puIdx = 0; puIdx < numPU; puIdx++)
@@ -684,6 +700,27 @@ struct IntraRd
         uint32_t bestMode = 0; sse_t bestDist = 0; uint64_t bestCost = kMaxCost;
         std::vector<uint8_t> bestCbf(2 * (size_t)n4 * n4, 0);
         const size_t isz = sizeof(pixel);
+        if (haveNxn && U(cuX, cuY).part_size != 0)
+        {
+            /* decided on the device with the luma units (x265amd_intra_nxn, do_chroma): what the loop below leaves behind for the winner -- its blocks are in place */
+            const int td1 = U(cuX, cuY).tu_depth;
+            const int k = (int)nxnChroma.chroma_best;
+            if (k < 0 || k > 4) return fail("intra rd: chroma mode index");
+            for (int yy = 0; yy < size; yy += 4) for (int xx = 0; xx < size; xx += 4) U(cuX + xx, cuY + yy).chroma_dir = (uint8_t)modeList[k];
+            sse_t dist = 0;
+            for (int p = 1; p < 3; p++)
+            {
+                const x265amd_tu_result& r = nxnChroma.cres[p - 1];
+                memcpy(coeffC[p - 1].data(), nxnChroma.clevels[p - 1], sizeof(int16_t) * 16);
+                setCbf(p, cuX, cuY, size, r.num_sig ? 1 << td1 : 0);
+                if (td1) U(cuX, cuY).cbf[p] |= (uint8_t)((U(cuX, cuY).cbf[p] >> td1) & 1);
+                dist += (sse_t)r.nz_dist;
+            }
+            coeffCBest[0] = coeffC[0]; coeffCBest[1] = coeffC[1];
+            totalDistortion = dist;
+            load(cur);
+            return 0;
+        }
         /* one chroma block per plane for the whole CU (no luma transform split, or an 8x8 CU): the five modes x two planes are independent
          * and run as ONE launch; bits, costs and the choice follow on the host in the reference's order */
         const int td = U(cuX, cuY).tu_depth;
