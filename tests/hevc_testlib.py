@@ -3440,3 +3440,42 @@ def intra_pu_run_hip(L, c, preds, rbits, mpm_base, lam, max_cand):
         st = (int(res[i]["num_sig"]), int(res[i]["zero_dist"]), int(res[i]["zero_energy"]), int(res[i]["nz_dist"]), int(res[i]["nz_energy"]))
         per.append((st, pred, recon, coeff[i * slot_coeffs:i * slot_coeffs + N * N].copy(), resi[i * slot_coeffs:i * slot_coeffs + N * N].reshape(N, N).copy()))
     return out["sa8d"].copy(), [int(m) for m in out["modes"][:int(out["num_cand"])]], per
+
+
+# ---- x265amd_intra_nxn: an 8x8 NxN CU (four 4x4 luma units with their decisions, the luma measurements, the chroma decision) as one launch ----
+INTRA_NXN_JOB_DT = np.dtype([("tmpl", INTRA_TU_JOB_DT, 4), ("pred_dst", "<u8", 4), ("layer_dst", "<u8", 4), ("lambda", "<u8"), ("lambda2", "<u8"), ("psy_scale", "<u8"),
+                             ("frac_start", "<u8", 4), ("scan_frac", "<u4"), ("slot_pixels", "<u4"), ("slot_coeffs", "<u4"), ("left_mode", "u1", 2), ("above_mode", "u1", 2),
+                             ("ctx", "u1", 160), ("max_cand", "u1"), ("do_chroma", "u1"), ("reserved", "u1", 2), ("pad", "u1", 4), ("ctmpl", INTRA_TU_JOB_DT, 2), ("crecon_dst", "<u8", 2)])
+INTRA_NXN_OUT_DT = np.dtype([("mode", "u1", 4), ("num_cand", "u1", 4), ("res", TU_RESULT_DT, 4), ("levels", "<i2", (4, 16)), ("psy_energy", "<u4"), ("res_energy", "<u4"),
+                             ("chroma_best", "<u4"), ("chroma_reserved", "<u4"), ("cres", TU_RESULT_DT, 2), ("clevels", "<i2", (2, 16))])
+assert INTRA_NXN_JOB_DT.itemsize == 896 and INTRA_NXN_OUT_DT.itemsize == 408
+
+
+def entropy_bit_tables():
+    """(bits[128], lpsNext[64]) of the CABAC estimator, read from the product's own header (the tables are the standard's: H.265 9.3.4.3, entropy.cpp:2627-2700)"""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "x265-amod_amd", "csrc", "entropy_dev.h")).read()
+    def table(name):
+        body = src[src.index(name):]
+        body = body[body.index("{") + 1:body.index("};")]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [int(x, 0) for x in re.findall(r"0x[0-9a-fA-F]+|\d+", body)]
+    return table("en_bits[128]"), table("en_lpsNext[64]")
+
+
+def cabac_next_state(state, bin_, lps_next):
+    p, mps = state >> 1, state & 1
+    if p == 63:
+        return state
+    if bin_ == mps:
+        return ((p + 1 if p < 62 else 62) << 1) | mps
+    if p == 0:
+        return 1 - mps
+    return (lps_next[p] << 1) | mps
+
+
+def luma_mpm(left, above):
+    """getIntraDirLumaPredictor (cudata.cpp:910-953) on the two neighbour modes"""
+    if left == above:
+        return [left, ((left - 2 + 31) & 31) + 2, ((left - 2 + 1) & 31) + 2] if left >= 2 else [0, 1, 26]
+    return [left, above, 0 if (left and above) else (26 if left + above < 2 else 1)]
