@@ -347,7 +347,9 @@ typedef struct x265amd_intra_nxn_job
     uint32_t slot_pixels, slot_coeffs;
     uint8_t left_mode[2], above_mode[2];    /* left of unit 0 / unit 2, above of unit 0 / unit 1, as the predictor derivation sees them (DC = 1 when absent or not intra) */
     uint8_t ctx[X265AMD_CTX_STRIDE];
-    uint8_t max_cand, do_chroma, reserved[2];
+    uint8_t max_cand, do_chroma;
+    uint8_t num_units, unit_log2;   /* 4 units of 4x4 (NxN; 0 / 0 mean that), or 1 unit of 8x8: the same CU coded 2Nx2N with its one transform unit -- then the coded block flag
+                                     * is the one of transform depth 0, the 64 levels fill `levels` as one array and the luma measurements are the unit's own result */
     /* do_chroma: Search::estIntraPredChromaQT for the CU's one 4x4 block per chroma plane in the same launch (search.cpp:1754-1889): the five allowed modes (planar,
      * vertical, horizontal, DC with the one equal to the first unit's luma mode replaced by 34, then the luma mode itself), each a wavefront running the U and the V
      * chain and counting the mode's bits -- intra_chroma_pred_mode, the two coded block flags, U's and V's coefficients, on the contexts `ctx` from scan_frac --; the first

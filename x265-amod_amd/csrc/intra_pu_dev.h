@@ -135,7 +135,9 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     const uint32_t rbits = (uint32_t)(((unsigned long long)P.scan_frac + en_bits[adi ^ 0]) >> 15) + 5;
     const uint32_t mpmBase = (uint32_t)(((unsigned long long)P.scan_frac + en_bits[adi ^ 1]) >> 15);
     const int maxCand = P.max_cand > 16 ? 16 : P.max_cand;
-    for (int k = 0; k < 4; k++)
+    const int numUnits = P.num_units ? P.num_units : 4, unitLog2 = P.unit_log2 ? P.unit_log2 : 2, N = 1 << unitLog2;
+    const int cbfCtx = CTX_QT_CBF + (numUnits == 1 ? 1 : 0);                               /* C_QT_CBF + !tuDepth */
+    for (int k = 0; k < numUnits; k++)
     {
         const x265amd_intra_tu_job& T = P.tmpl[k];
         /* getIntraDirLumaPredictor: the left / above units' modes */
@@ -179,8 +181,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
                 frac += en_bits[cw[13] ^ (pidx != -1 ? 1u : 0u)];
                 frac += (unsigned long long)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
                 const x265amd_tu_result r = s_res[i];
-                frac += en_bits[cw[CTX_QT_CBF] ^ (r.num_sig != 0 ? 1u : 0u)];
-                if (r.num_sig) frac += lane_coeff_bits(cw, s.q, 2, 0, 1, (int)mode, T.tu.sign_hide);         /* the levels are still in this wavefront's LDS */
+                frac += en_bits[cw[cbfCtx] ^ (r.num_sig != 0 ? 1u : 0u)];
+                if (r.num_sig) frac += lane_coeff_bits(cw, s.q, unitLog2, 0, 1, (int)mode, T.tu.sign_hide);         /* the levels are still in this wavefront's LDS */
                 const unsigned long long bits = (uint32_t)(frac >> 15);
                 const unsigned long long dist = r.nz_dist;
                 s_cost[i] = P.psy_scale ? dist + ((P.psy_scale * (unsigned long long)r.nz_energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
@@ -202,21 +204,21 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             const pixel* rec = reinterpret_cast<const pixel*>(T.tu.recon) + (size_t)w * P.slot_pixels;
             const pixel* prd = reinterpret_cast<const pixel*>(T.tu.pred) + (size_t)w * P.slot_pixels;
             const int16_t* lv = reinterpret_cast<const int16_t*>(T.tu.coeff) + (size_t)w * P.slot_coeffs;
-            if (tid < 16)
+            if (tid < N * N)
             {
-                const int y = tid >> 2, x = tid & 3;
+                const int y = tid >> unitLog2, x = tid & (N - 1);
                 const pixel v = rec[y * T.tu.recon_stride + x];
                 reinterpret_cast<pixel*>(T.nb)[(long)y * T.nb_stride + x] = v;
                 reinterpret_cast<pixel*>(P.layer_dst[k])[y * 64 + x] = v;
                 reinterpret_cast<pixel*>(P.pred_dst[k])[y * 64 + x] = prd[y * T.tu.pred_stride + x];
-                po->levels[k][tid] = lv[tid];
+                (&po->levels[0][0])[k * 16 + tid] = lv[tid];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
         }
     }
     /* the CU's luma measurements on the finished 8x8 block: psy energy of the reconstruction, residual energy of the prediction */
     __syncthreads();
-    if (wv == 0)
+    if (wv == 0 && numUnits == 4)
     {
         const x265amd_intra_tu_job& T0 = P.tmpl[0];
         const pixel* f = reinterpret_cast<const pixel*>(T0.tu.fenc);

@@ -384,6 +384,7 @@ struct IntraRd
     bool haveNxn = false;                       /* the device-decided NxN path measured the CU's luma block itself */
     uint32_t nxnPsy = 0, nxnRes = 0;
     x265amd_intra_nxn_out nxnChroma;            /* ... and chose the chroma mode */
+    bool haveDevChroma = false;
 
     /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
      * best mode again with TU splits allowed */
@@ -395,7 +396,12 @@ struct IntraRd
          * coefficients are few enough for the device to count their bits, so nothing of the host's enters between the units.  The host repeats the winners'
          * bookkeeping (units, bits, contexts) afterwards.  Not with RDOQ (the quantiser then reads bit estimates of the current contexts per unit). */
         x265amd_intra_nxn_out nxn;
-        const bool deviceNxN = partSize != 0 && log2 == 3 && log2TrSize == 2 && range[0] == 2 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS;
+        /* (The device routine also takes the same CU coded 2Nx2N -- one 8x8 unit, num_units = 1 -- and gives the same stream, but a lane needs 45 us for the bits of
+         * 64 coefficients, several times the host: measured, the I picture 12 % slower.  X265AMD_DEVICE_2Nx2N=1 switches it on.) */
+        static const bool dev2Nx2N = getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) != 0;
+        const bool deviceNxN = log2 == 3 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
+                               (partSize != 0 ? (log2TrSize == 2 && range[0] == 2) : (dev2Nx2N && range[0] == 3 && range[1] >= 3));
+        const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
         if (deviceNxN)
         {
             xa_phase(XA_PH_INTRA_CAND);
@@ -403,17 +409,18 @@ struct IntraRd
             x265amd_intra_nxn_job nj;
             memset(&nj, 0, sizeof(nj));
             const uint64_t slot0 = (uint64_t)(uintptr_t)dCand.p;
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < devUnits; k++)
             {
                 const int px = cuX + (k & 1) * 4, py = cuY + (k >> 1) * 4;
-                fillJob(nj.tmpl[k], 0, px, py, 2, 0, slot0 + 1024 * isz, 4, slot0, 4, 0);
+                fillJob(nj.tmpl[k], 0, px, py, devLog2, 0, slot0 + 1024 * isz, devN, slot0, devN, 0);
                 nj.tmpl[k].tu.coeff = (uint64_t)(uintptr_t)dCoeffDev.p;
-                nj.tmpl[k].tu.resi = (uint64_t)(uintptr_t)dCoeffDev.p + (size_t)MAX_JOBS * 1024 * 2; nj.tmpl[k].tu.resi_stride = 4;
-                nj.tmpl[k].avail = available(px, py, 4);
+                nj.tmpl[k].tu.resi = (uint64_t)(uintptr_t)dCoeffDev.p + (size_t)MAX_JOBS * 1024 * 2; nj.tmpl[k].tu.resi_stride = devN;
+                nj.tmpl[k].avail = available(px, py, devN);
                 nj.pred_dst[k] = predTile + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
-                nj.layer_dst[k] = (uint64_t)(uintptr_t)dLayer.p + ((size_t)0 * 4096 + (size_t)(py - cuY) * 64 + (px - cuX)) * isz;     /* layer of the 4x4 units */
+                nj.layer_dst[k] = (uint64_t)(uintptr_t)dLayer.p + ((size_t)(devLog2 - 2) * 4096 + (size_t)(py - cuY) * 64 + (px - cuX)) * isz;     /* the units' layer */
                 nj.frac_start[k] = cur.frac & 32767;
             }
+            nj.num_units = (uint8_t)devUnits; nj.unit_log2 = (uint8_t)devLog2;
             {
                 /* what codeIntraLumaQT codes in front of the first unit's direction: skip flag and prediction mode (P / B slices), the partition size */
                 load(cur); resetBits();
@@ -458,7 +465,8 @@ struct IntraRd
             if (x265amd_intra_nxn(st, (const x265amd_intra_nxn_job*)dNxnJob.p, (x265amd_intra_nxn_out*)dNxnOut.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
                 return fail("intra rd: NxN step");
             memcpy(&nxn, dNxnOut.p, sizeof(nxn));
-            haveNxn = true; nxnPsy = nxn.psy_energy; nxnRes = nxn.res_energy;
+            haveNxn = partSize != 0; nxnPsy = nxn.psy_energy; nxnRes = nxn.res_energy;      /* (one 8x8 unit: the unit's own result, haveWhole) */
+            haveDevChroma = true;
             nxnChroma = nxn;
             xa_phase(XA_PH_INTRA_SCAN);
         }
@@ -474,10 +482,10 @@ struct IntraRd
                 /* the unit was decided on the device: its mode, result and levels; its blocks are in place.  codeIntraLumaQT repeats the bookkeeping. */
                 const uint32_t bm = nxn.mode[puIdx];
                 if (bm > 34) return fail("intra rd: NxN mode");
-                U(px, py).luma_dir = (uint8_t)bm;
+                for (int yy = 0; yy < tuSize; yy += 4) for (int xx = 0; xx < tuSize; xx += 4) U(px + xx, py + yy).luma_dir = (uint8_t)bm;
                 load(cur);
                 Cost ic = { 0, 0, 0, 0 };
-                pre = Pre{ true, px, py, log2TrSize, nxn.res[puIdx], nxn.levels[puIdx], 0, 0, false };
+                pre = Pre{ true, px, py, log2TrSize, nxn.res[puIdx], &nxn.levels[0][0] + 16 * puIdx, 0, 0, false };
                 const int rq = codeIntraLumaQT(px, py, initTuDepth, true, ic);
                 pre.on = false;
                 if (rq) return err;
@@ -700,7 +708,7 @@ struct IntraRd
         uint32_t bestMode = 0; sse_t bestDist = 0; uint64_t bestCost = kMaxCost;
         std::vector<uint8_t> bestCbf(2 * (size_t)n4 * n4, 0);
         const size_t isz = sizeof(pixel);
-        if (haveNxn && U(cuX, cuY).part_size != 0)
+        if (haveDevChroma)
         {
             /* decided on the device with the luma units (x265amd_intra_nxn, do_chroma): what the loop below leaves behind for the winner -- its blocks are in place */
             const int td1 = U(cuX, cuY).tu_depth;
@@ -827,7 +835,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     IntraRd* ip = ws && *ws ? static_cast<IntraRd*>(*ws) : new IntraRd;
     if (ws) *ws = ip;
     IntraRd& R = *ip;
-    R.haveWhole = false; R.haveNxn = false;
+    R.haveWhole = false; R.haveNxn = false; R.haveDevChroma = false;
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
     R.predTile = d_pred; R.reconTile = d_recon;
