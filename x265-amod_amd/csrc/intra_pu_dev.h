@@ -6,7 +6,7 @@
 #include "intra_dev.h"
 #include "entropy_dev.h"
 
-struct IntraPuShared { int32_t sa8d[35]; uint8_t modes[16]; int num; };
+struct IntraPuShared { int32_t sa8d[35]; uint8_t modes[16]; int num; pixel nbRef[136], nbFlt[136]; };      /* nb*: the scan's neighbour arrays, kept for the chains */
 
 /* the candidate list of a prediction unit from its 35 SA8D costs (S.sa8d): called by the first wavefront, all 64 lanes; leaves S.modes / S.num */
 XA_DEV void wave0_candidate_list(IntraPuShared& S, uint32_t preds0, uint32_t preds1, uint32_t preds2, uint32_t rbits, uint32_t mpmBase, unsigned long long lambda, int maxCandIn, int tid)
@@ -92,6 +92,11 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
     }
     __syncthreads();
     XA_STAGE(14);
+    {
+        const IntraScanLds& sc = *reinterpret_cast<const IntraScanLds*>(smem);
+        const int n4 = 4 << P.tmpl.tu.log2_tr_size;
+        for (int i = tid; i <= n4; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
+    }
     if (tid < 35) po->sa8d[tid] = S.sa8d[tid];
     if (tid < 64)
     {
@@ -110,7 +115,7 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
         J.tu.dir_mode = S.modes[i];
         J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
         J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
-        wave_intra_tu_chain_body<false>(J, nullptr, res + i, s, ip, nullptr, lane);
+        wave_intra_tu_chain_body<false>(J, nullptr, res + i, s, ip, nullptr, lane, S.nbRef, S.nbFlt);
     }
 }
 
@@ -157,6 +162,10 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             block_intra_scan_job(sj, S.sa8d, nullptr, *reinterpret_cast<IntraScanLds*>(smem), tid, nthr);
         }
         __syncthreads();
+        {
+            const IntraScanLds& sc = *reinterpret_cast<const IntraScanLds*>(smem);
+            for (int i = tid; i <= 4 * N; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
+        }
         if (tid < 64) wave0_candidate_list(S, p0, p1, p2, rbits, mpmBase, P.lambda, maxCand, tid);
         __syncthreads();
         const int n = S.num;
@@ -169,7 +178,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             J.tu.dir_mode = (uint8_t)mode;
             J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
-            wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane);
+            wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
             /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400): the lane's own copy of the contexts */
             for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[i][b] = P.ctx[b];
             xa_wave_sync();
