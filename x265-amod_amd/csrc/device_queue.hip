@@ -11,7 +11,7 @@
 #define XA_PREFETCH_SLOT 0          /* fetching the next slot while a command runs: measured, no gain (the load competes with the command's own first loads) */
 #endif
 /* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside" */
-__shared__ unsigned long long xa_stage_acc[16];
+__shared__ unsigned long long xa_stage_acc[22];      /* [0..15] transform chains and the prediction-unit step, [16..21] the NxN step */
 __shared__ long long xa_stage_prev;
 #define XA_STAGE(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_stage_acc[k] += (unsigned long long)(t_ - xa_stage_prev); xa_stage_prev = t_; } } while (0)
 #include "tu_dev.h"
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     uint64_t seen = 0, signalled = 0, pre = 0;
     bool havePre = false;
     if (tid < 64) s_prof[tid] = 0;
-    if (tid < 16) xa_stage_acc[tid] = 0;
+    if (tid < 22) xa_stage_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
     if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
     __syncthreads();
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         if (flags & XA_CMD_SIGNAL) signalled = seen;
     }
     __syncthreads();
-    if (tid < 16) s_prof[40 + tid] = xa_stage_acc[tid];        /* [40..55]: the stages of the transform chains */
+    if (tid < 22) s_prof[40 + tid] = xa_stage_acc[tid];        /* [40..61]: the stages of the transform chains and the fused intra steps */
     __syncthreads();
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
@@ -668,6 +668,8 @@ struct Server
         fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
                 "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", tot[40] / 1e5, tot[41] / 1e5, tot[42] / 1e5, tot[43] / 1e5, tot[44] / 1e5,
                 tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5, tot[54] / 1e5, tot[55] / 1e5);
+        fprintf(stderr, "  stages of the NxN step (ms): record + predictors %.1f, scan %.1f, candidate list %.1f, chains %.1f, bits %.1f, choice + blocks + measurements + chroma %.1f\n",
+                tot[56] / 1e5, tot[57] / 1e5, tot[58] / 1e5, tot[59] / 1e5, tot[60] / 1e5, tot[61] / 1e5);
         static const char* const sized[11] = { "scan / pu 4", "scan / pu 8", "scan / pu 16", "scan / pu 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };
         for (int b = 20; b < 31; b++)

@@ -34,6 +34,18 @@ XA_DEV uint8_t en_next(uint8_t state, uint32_t bin)
     return (uint8_t)((en_lpsNext[p] << 1) | mps);
 }
 
+/* the two tables of the estimator where the caller keeps them: global memory (en_bits / en_lpsNext), or a copy in LDS -- a lane that codes bins one after the other
+ * waits for every look-up, and an LDS look-up is a third of a cached global one */
+struct EnTabs { const uint32_t* bits; const uint8_t* lps; };
+XA_DEV uint8_t en_next_t(const EnTabs& t, uint8_t state, uint32_t bin)
+{
+    const uint32_t p = state >> 1, mps = state & 1;
+    if (p == 63) return state;
+    if (bin == mps) return (uint8_t)(((p < 62 ? p + 1 : 62) << 1) | mps);
+    if (p == 0) return (uint8_t)(1 - mps);
+    return (uint8_t)((t.lps[p] << 1) | mps);
+}
+XA_DEV uint32_t cb_bin_t(const EnTabs& t, uint8_t* st, uint32_t bin) { const uint8_t s = *st; *st = en_next_t(t, s, bin); return t.bits[s ^ bin]; }
 XA_DEV uint32_t cb_bin(uint8_t* st, uint32_t bin) { const uint8_t s = *st; *st = en_next(s, bin); return en_bits[s ^ bin]; }
 
 /* the 16 sample offsets of a 4x4 group in scan order `type` (g_scan4x4, constants.cpp:364-400, by rule), packed 4 bits each */
@@ -74,7 +86,7 @@ XA_DEV uint32_t cb_cg_blk(int type, int log2N, int g)
 
 /* bits-only Entropy::codeCoeffNxN of ONE transform unit by the calling lane (reference: source/encoder/entropy.cpp:1828-2199 with the counting primitives of
  * source/common/dct.cpp:757-993): FIX15 bits; ctx: the lane's own copy of the context states (updated).  Serial by nature -- every coded bin moves its context. */
-XA_DEV uint64_t lane_coeff_bits(uint8_t* ctx, const int16_t* coeff, int log2N, int ttype, int intra, int dir_mode, int sign_hide)
+XA_DEV uint64_t lane_coeff_bits(uint8_t* ctx, const int16_t* coeff, int log2N, int ttype, int intra, int dir_mode, int sign_hide, const EnTabs& tabs)
 {
     const int N = 1 << log2N, isLuma = ttype == 0;
     const int scanType = !intra ? 0 : ((log2N <= 2 || (isLuma && log2N == 3)) ? (dir_mode >= 22 && dir_mode <= 30 ? 1 : (dir_mode >= 6 && dir_mode <= 14 ? 2 : 0)) : 0);
@@ -114,8 +126,8 @@ XA_DEV uint64_t lane_coeff_bits(uint8_t* ctx, const int16_t* coeff, int log2N, i
             uint32_t prefix = pos, suffixLen = 0;
             if (pos >= 4) { const uint32_t l = 31 - (uint32_t)__clz((int)pos); suffixLen = l - 1; prefix = 2 * l + ((pos >> (l - 1)) & 1); }
             uint8_t* c = ctx + CTX_LAST_X + ctxIdx;
-            for (uint32_t k = 0; k < prefix; k++) bits += cb_bin(c + (k >> ctxShift), 1);
-            if (prefix < maxGroupIdx) bits += cb_bin(c + (prefix >> ctxShift), 0);
+            for (uint32_t k = 0; k < prefix; k++) bits += cb_bin_t(tabs, c + (k >> ctxShift), 1);
+            if (prefix < maxGroupIdx) bits += cb_bin_t(tabs, c + (prefix >> ctxShift), 0);
             bits += (uint64_t)suffixLen << 15;
         }
     }
@@ -153,7 +165,7 @@ XA_DEV uint64_t lane_coeff_bits(uint8_t* ctx, const int16_t* coeff, int log2N, i
         {
             const uint32_t sigPos = cgBlk + 1 < 64 ? (uint32_t)(cgFlags >> (cgBlk + 1)) : 0;
             const uint32_t right = (cgX != cgStride - 1) & sigPos, lower = (cgY != cgStride - 1) & (sigPos >> (cgStride - 1));
-            bits += cb_bin(cgCtx + (right | lower), (cgFlags & cgMask) != 0);
+            bits += cb_bin_t(tabs, cgCtx + (right | lower), (cgFlags & cgMask) != 0);
         }
         if (sub == lastSet) { firstNZ = lastNZ = (uint32_t)lastK; }
         if (sigOff >= 0 && (cgFlags & cgMask))
@@ -177,7 +189,7 @@ XA_DEV uint64_t lane_coeff_bits(uint8_t* ctx, const int16_t* coeff, int log2N, i
                 if (k != 0 || subBase == 0 || nnz)
                 {
                     const uint32_t ctxSig = (subBase + k) ? cb_sig_ctx_inc(log2N, pattern, rr) + (uint32_t)offset : 0;
-                    sum += cb_bin(sigCtx + ctxSig, sig);
+                    sum += cb_bin_t(tabs, sigCtx + ctxSig, sig);
                 }
                 if (sig)
                 {
@@ -203,14 +215,14 @@ XA_DEV uint64_t lane_coeff_bits(uint8_t* ctx, const int16_t* coeff, int log2N, i
             for (uint32_t idx = 0; idx < numC1; idx++)
             {
                 const uint32_t s1 = absCoeff[idx] > 1, s2 = absCoeff[idx] > 2;
-                sum += cb_bin(oneCtx + c1, s1);
+                sum += cb_bin_t(tabs, oneCtx + c1, s1);
                 if (s1) c1Next = 0;
                 if (s1 + firstC2Flag == 3) firstC2Flag = s2;
                 if (s1 + firstC2Idx == 9) firstC2Idx = idx;
                 c1 = c1Next & 3;
                 c1Next >>= 2;
             }
-            if (!c1) sum += cb_bin(ctx + CTX_ABS + (isLuma ? 0 : N_ABS_LUMA) + ctxSet, firstC2Flag);
+            if (!c1) sum += cb_bin_t(tabs, ctx + CTX_ABS + (isLuma ? 0 : N_ABS_LUMA) + ctxSet, firstC2Flag);
             bits += sum & 0x00FFFFFF;
             bits += (uint64_t)(numNonZero - ((sign_hide && signHidden) ? 1 : 0)) << 15;
             if (numNonZero > firstC2Idx)

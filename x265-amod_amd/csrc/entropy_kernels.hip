@@ -64,7 +64,7 @@ __global__ __launch_bounds__(CB_LANES) void k_coeff_bits(const x265amd_coeff_bit
         uint32_t* dst = reinterpret_cast<uint32_t*>(ctx);
         for (int i = 0; i < X265AMD_CTX_STRIDE / 4; i++) dst[i] = src[i];
     }
-    const uint64_t bits = lane_coeff_bits(ctx, reinterpret_cast<const int16_t*>(j.coeff), j.log2_tr_size, j.ttype, j.intra, j.dir_mode, j.sign_hide);
+    const uint64_t bits = lane_coeff_bits(ctx, reinterpret_cast<const int16_t*>(j.coeff), j.log2_tr_size, j.ttype, j.intra, j.dir_mode, j.sign_hide, EnTabs{ en_bits, en_lpsNext });
     out[ji] = bits;
     uint32_t* dst = reinterpret_cast<uint32_t*>(j.ctx_out);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(ctx);

@@ -128,12 +128,19 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ uint8_t s_ctxw[16][X265AMD_CTX_STRIDE];
     __shared__ int s_win;
     __shared__ uint8_t s_winMode[4];
-    __shared__ x265amd_intra_nxn_job sP;           /* the job record: 688 bytes, indexed by the unit -- in LDS, not in registers */
+    XA_STAGE(15);
+    __shared__ x265amd_intra_nxn_job sP;           /* the job record: 896 bytes, indexed by the unit -- in LDS, not in registers */
     static_assert(sizeof(x265amd_intra_nxn_job) % 8 == 0, "job records are sequences of 64-bit words");
     __syncthreads();
     for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_job) / 8); i += nthr)
         reinterpret_cast<uint64_t*>(&sP)[i] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(pj) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
+    /* the estimator's tables beside it: the lanes that count bits look them up bin after bin */
+    __shared__ uint32_t s_enBits[128];
+    __shared__ uint8_t s_enLps[64];
+    if (tid < 128) s_enBits[tid] = en_bits[tid];
+    if (tid < 64) s_enLps[tid] = en_lpsNext[tid];
+    const EnTabs tabs{ s_enBits, s_enLps };
     const x265amd_intra_nxn_job& P = sP;
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
     const uint32_t adi = P.ctx[13];                                                         /* C_ADI: prev_intra_luma_pred_flag */
@@ -155,6 +162,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             else { p0 = 0; p1 = 1; p2 = 26; }
         }
         else { p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
+        XA_STAGE(16);
         {
             x265amd_intra_job sj;
             sj.recon = T.nb; sj.fenc = T.tu.fenc; sj.avail = T.avail; sj.recon_stride = T.nb_stride; sj.fenc_stride = T.tu.fenc_stride;
@@ -162,12 +170,14 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             block_intra_scan_job(sj, S.sa8d, nullptr, *reinterpret_cast<IntraScanLds*>(smem), tid, nthr);
         }
         __syncthreads();
+        XA_STAGE(17);
         {
             const IntraScanLds& sc = *reinterpret_cast<const IntraScanLds*>(smem);
             for (int i = tid; i <= 4 * N; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
         }
         if (tid < 64) wave0_candidate_list(S, p0, p1, p2, rbits, mpmBase, P.lambda, maxCand, tid);
         __syncthreads();
+        XA_STAGE(18);
         const int n = S.num;
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
         IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
@@ -179,6 +189,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
             wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
+            XA_STAGE(19);
             /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400): the lane's own copy of the contexts */
             for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[i][b] = P.ctx[b];
             xa_wave_sync();
@@ -187,16 +198,18 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
                 uint8_t* cw = s_ctxw[i];
                 const int pidx = mode == p0 ? 0 : (mode == p1 ? 1 : (mode == p2 ? 2 : -1));
                 unsigned long long frac = P.frac_start[k];
-                frac += en_bits[cw[13] ^ (pidx != -1 ? 1u : 0u)];
+                frac += s_enBits[cw[13] ^ (pidx != -1 ? 1u : 0u)];
                 frac += (unsigned long long)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
                 const x265amd_tu_result r = s_res[i];
-                frac += en_bits[cw[cbfCtx] ^ (r.num_sig != 0 ? 1u : 0u)];
-                if (r.num_sig) frac += lane_coeff_bits(cw, s.q, unitLog2, 0, 1, (int)mode, T.tu.sign_hide);         /* the levels are still in this wavefront's LDS */
+                frac += s_enBits[cw[cbfCtx] ^ (r.num_sig != 0 ? 1u : 0u)];
+                /* the levels are still in this wavefront's LDS; the size as a constant: the 4x4 case folds to one coefficient group without the group bookkeeping */
+                if (r.num_sig) frac += unitLog2 == 2 ? lane_coeff_bits(cw, s.q, 2, 0, 1, (int)mode, T.tu.sign_hide, tabs) : lane_coeff_bits(cw, s.q, 3, 0, 1, (int)mode, T.tu.sign_hide, tabs);
                 const unsigned long long bits = (uint32_t)(frac >> 15);
                 const unsigned long long dist = r.nz_dist;
                 s_cost[i] = P.psy_scale ? dist + ((P.psy_scale * (unsigned long long)r.nz_energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
             }
         }
+        XA_STAGE(20);
         __syncthreads();
         if (tid == 0)
         {
@@ -224,6 +237,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
         }
+        XA_STAGE(21);
     }
     /* the CU's luma measurements on the finished 8x8 block: psy energy of the reconstruction, residual energy of the prediction */
     __syncthreads();
@@ -270,14 +284,14 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         {
             uint8_t* cw = s_ctxw[wv];
             unsigned long long frac = P.scan_frac;
-            frac += cb_bin(cw + 14, listed == 36 ? 0u : 1u);                                /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
+            frac += cb_bin_t(tabs, cw + 14, listed == 36 ? 0u : 1u);                                /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
             if (listed != 36) frac += 2ull << 15;
             /* the two coded block flags share a context (codeSubdivCbfQTChroma at depth 0, both planes: C_QT_CBF + 2), then U's and V's coefficients */
-            for (int pl = 0; pl < 2; pl++) frac += cb_bin(cw + CTX_QT_CBF + 2, s_cres[wv][pl].num_sig != 0 ? 1u : 0u);
+            for (int pl = 0; pl < 2; pl++) frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, s_cres[wv][pl].num_sig != 0 ? 1u : 0u);
             unsigned long long dist = 0, energy = 0;
             for (int pl = 0; pl < 2; pl++)
             {
-                if (s_cres[wv][pl].num_sig) frac += lane_coeff_bits(cw, s_clev[wv][pl], 2, 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide);
+                if (s_cres[wv][pl].num_sig) frac += lane_coeff_bits(cw, s_clev[wv][pl], 2, 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide, tabs);
                 dist += s_cres[wv][pl].nz_dist; energy += s_cres[wv][pl].nz_energy;
             }
             const unsigned long long bits = (uint32_t)(frac >> 15);
