@@ -357,6 +357,7 @@ typedef struct x265amd_intra_nxn_job
      * reconstruction goes to crecon_dst (stride 32), and the picture (ctmpl[p].nb) keeps the LAST tried mode's, as after the reference's loop. */
     x265amd_intra_tu_job ctmpl[2];
     uint64_t crecon_dst[2];
+    uint64_t recon_dst[4];          /* optional (0: none): a third place for the winners' luma reconstruction, stride 64 (the mode's reconstruction tile) */
 } x265amd_intra_nxn_job;
 typedef struct x265amd_intra_nxn_out
 {

@@ -201,11 +201,11 @@ struct Analyzer
         const uint64_t s = tileAddr(tile);
         XaRects r;
         r.n = 3;
-        r.dst[0] = rec[0] + ((size_t)y * stride + x) * isz; r.src[0] = s; r.dst_stride[0] = (int32_t)stride; r.src_stride[0] = 64; r.w[0] = w; r.h[0] = h;
+        r.dst[0] = rec[0] + ((size_t)y * stride + x) * isz; r.src[0] = s; r.dst_stride[0] = (int16_t)stride; r.src_stride[0] = 64; r.w[0] = w; r.h[0] = h;
         for (int p = 0; p < 2; p++)
         {
             r.dst[1 + p] = rec[1 + p] + ((size_t)(y / 2) * cstride + x / 2) * isz; r.src[1 + p] = s + (4096 + p * 1024) * isz;
-            r.dst_stride[1 + p] = (int32_t)cstride; r.src_stride[1 + p] = 32; r.w[1 + p] = w / 2; r.h[1 + p] = h / 2;
+            r.dst_stride[1 + p] = (int16_t)cstride; r.src_stride[1 + p] = 32; r.w[1 + p] = w / 2; r.h[1 + p] = h / 2;
         }
         xa_copy_rects(st, r);
     }

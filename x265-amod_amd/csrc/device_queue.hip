@@ -1058,7 +1058,7 @@ extern "C" int x265amd_queue_selftest(int rounds, int numQueues)
                 XaRects rc;
                 memset(&rc, 0, sizeof(rc));
                 rc.n = 1; rc.dst[0] = (uint64_t)(uintptr_t)dB; rc.src[0] = (uint64_t)(uintptr_t)dA; rc.dst_stride[0] = rc.src_stride[0] = 64; rc.w[0] = 64;
-                rc.h[0] = (int32_t)(n / 64 / sizeof(x265amd_pixel));
+                rc.h[0] = (int16_t)(n / 64 / sizeof(x265amd_pixel));
                 xa_copy_rects(st, rc);
                 if (xa_fill_async(st, dA, r & 255, 128) != hipSuccess) { bad++; break; }
                 /* same data three ways back: pageable (deferred), mapped in place */

@@ -232,6 +232,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
                 const pixel v = rec[y * T.tu.recon_stride + x];
                 reinterpret_cast<pixel*>(T.nb)[(long)y * T.nb_stride + x] = v;
                 reinterpret_cast<pixel*>(P.layer_dst[k])[y * 64 + x] = v;
+                if (P.recon_dst[k]) reinterpret_cast<pixel*>(P.recon_dst[k])[y * 64 + x] = v;
                 reinterpret_cast<pixel*>(P.pred_dst[k])[y * 64 + x] = prd[y * T.tu.pred_stride + x];
                 (&po->levels[0][0])[k * 16 + tid] = lv[tid];
             }

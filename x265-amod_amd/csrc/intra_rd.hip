@@ -187,15 +187,15 @@ struct IntraRd
     void copy2D(uint64_t dst, size_t dstStride, uint64_t s, size_t srcStride, int w, int h)
     {
         XaRects r;
-        r.n = 1; r.dst[0] = dst; r.src[0] = s; r.dst_stride[0] = (int32_t)dstStride; r.src_stride[0] = (int32_t)srcStride; r.w[0] = w; r.h[0] = h;
+        r.n = 1; r.dst[0] = dst; r.src[0] = s; r.dst_stride[0] = (int16_t)dstStride; r.src_stride[0] = (int16_t)srcStride; r.w[0] = w; r.h[0] = h;
         xa_copy_rects(st, r);
     }
     void copy2Dx2(uint64_t dst0, size_t dstStride0, uint64_t s0, size_t srcStride0, uint64_t dst1, size_t dstStride1, uint64_t s1, size_t srcStride1, int w, int h)
     {
         XaRects r;
         r.n = 2;
-        r.dst[0] = dst0; r.src[0] = s0; r.dst_stride[0] = (int32_t)dstStride0; r.src_stride[0] = (int32_t)srcStride0; r.w[0] = w; r.h[0] = h;
-        r.dst[1] = dst1; r.src[1] = s1; r.dst_stride[1] = (int32_t)dstStride1; r.src_stride[1] = (int32_t)srcStride1; r.w[1] = w; r.h[1] = h;
+        r.dst[0] = dst0; r.src[0] = s0; r.dst_stride[0] = (int16_t)dstStride0; r.src_stride[0] = (int16_t)srcStride0; r.w[0] = w; r.h[0] = h;
+        r.dst[1] = dst1; r.src[1] = s1; r.dst_stride[1] = (int16_t)dstStride1; r.src_stride[1] = (int16_t)srcStride1; r.w[1] = w; r.h[1] = h;
         xa_copy_rects(st, r);
     }
 
@@ -316,12 +316,14 @@ struct IntraRd
         if (fromBatch && pre.copyBlocks && !mightSplit)
         {
             XaRects r3;
-            r3.n = 3;
-            r3.dst[0] = layerRecon; r3.src[0] = pre.recon; r3.dst_stride[0] = 64; r3.src_stride[0] = trSize;
-            r3.dst[1] = predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz; r3.src[1] = pre.pred; r3.dst_stride[1] = 64; r3.src_stride[1] = trSize;
-            r3.dst[2] = rec[0] + ((uint64_t)y * stride + x) * isz; r3.src[2] = pre.recon; r3.dst_stride[2] = (int32_t)stride; r3.src_stride[2] = trSize;
-            for (int k = 0; k < 3; k++) { r3.w[k] = trSize; r3.h[k] = trSize; }
+            r3.n = 4;
+            r3.dst[0] = layerRecon; r3.src[0] = pre.recon; r3.dst_stride[0] = 64; r3.src_stride[0] = (int16_t)trSize;
+            r3.dst[1] = predTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz; r3.src[1] = pre.pred; r3.dst_stride[1] = 64; r3.src_stride[1] = (int16_t)trSize;
+            r3.dst[2] = rec[0] + ((uint64_t)y * stride + x) * isz; r3.src[2] = pre.recon; r3.dst_stride[2] = (int16_t)stride; r3.src_stride[2] = (int16_t)trSize;
+            r3.dst[3] = reconTile + ((size_t)(y - cuY) * 64 + (x - cuX)) * isz; r3.src[3] = pre.recon; r3.dst_stride[3] = 64; r3.src_stride[3] = (int16_t)trSize;     /* the mode's reconstruction tile */
+            for (int k = 0; k < 4; k++) { r3.w[k] = (int16_t)trSize; r3.h[k] = (int16_t)trSize; }
             xa_copy_rects(st, r3);
+            if (!tuDepth && trSize == size) lumaTileDone = true;
         }
         else if (!fromBatch || pre.copyBlocks)
             copy2D(rec[0] + ((uint64_t)y * stride + x) * isz, stride, layerRecon, 64, trSize, trSize);
@@ -385,6 +387,7 @@ struct IntraRd
     uint32_t nxnPsy = 0, nxnRes = 0;
     x265amd_intra_nxn_out nxnChroma;            /* ... and chose the chroma mode */
     bool haveDevChroma = false;
+    bool lumaTileDone = false;                  /* the mode's reconstruction tile already holds the CU's luma (written with the winner's other copies) */
 
     /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
      * best mode again with TU splits allowed */
@@ -418,6 +421,7 @@ struct IntraRd
                 nj.tmpl[k].avail = available(px, py, devN);
                 nj.pred_dst[k] = predTile + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
                 nj.layer_dst[k] = (uint64_t)(uintptr_t)dLayer.p + ((size_t)(devLog2 - 2) * 4096 + (size_t)(py - cuY) * 64 + (px - cuX)) * isz;     /* the units' layer */
+                nj.recon_dst[k] = reconTile + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
                 nj.frac_start[k] = cur.frac & 32767;
             }
             nj.num_units = (uint8_t)devUnits; nj.unit_log2 = (uint8_t)devLog2;
@@ -466,7 +470,7 @@ struct IntraRd
                 return fail("intra rd: NxN step");
             memcpy(&nxn, dNxnOut.p, sizeof(nxn));
             haveNxn = partSize != 0; nxnPsy = nxn.psy_energy; nxnRes = nxn.res_energy;      /* (one 8x8 unit: the unit's own result, haveWhole) */
-            haveDevChroma = true;
+            haveDevChroma = true; lumaTileDone = true;
             nxnChroma = nxn;
             xa_phase(XA_PH_INTRA_SCAN);
         }
@@ -806,13 +810,21 @@ struct IntraRd
                 u.chroma_dir = (uint8_t)bestMode;
             }
         if (single)
+        {
+            /* the winner's reconstruction is the CU's; the picture keeps the last tried mode's, as after the reference's loop: both planes in one command */
+            XaRects r4;
+            r4.n = 4;
             for (int p = 1; p < 3; p++)
             {
-                /* the winner's reconstruction is the CU's; the picture keeps the last tried mode's, as after the reference's loop */
                 const uint64_t bestSlot = (uint64_t)(uintptr_t)dCand.p + (size_t)(bestK * 2 + p - 1) * 2048 * isz;
                 const uint64_t lastSlot = (uint64_t)(uintptr_t)dCand.p + (size_t)(4 * 2 + p - 1) * 2048 * isz;
-                copy2Dx2(reconTile + (4096 + (size_t)(p - 1) * 1024) * isz, 32, bestSlot, nC, rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz, cstride, lastSlot, nC, nC, nC);
+                const int a = 2 * (p - 1);
+                r4.dst[a] = reconTile + (4096 + (size_t)(p - 1) * 1024) * isz; r4.src[a] = bestSlot; r4.dst_stride[a] = 32; r4.src_stride[a] = (int16_t)nC;
+                r4.dst[a + 1] = rec[p] + ((uint64_t)(cuY >> 1) * cstride + (cuX >> 1)) * isz; r4.src[a + 1] = lastSlot; r4.dst_stride[a + 1] = (int16_t)cstride; r4.src_stride[a + 1] = (int16_t)nC;
+                r4.w[a] = r4.w[a + 1] = r4.h[a] = r4.h[a + 1] = (int16_t)nC;
             }
+            xa_copy_rects(st, r4);
+        }
         totalDistortion = bestDist;
         load(cur);
         return 0;
@@ -835,7 +847,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     IntraRd* ip = ws && *ws ? static_cast<IntraRd*>(*ws) : new IntraRd;
     if (ws) *ws = ip;
     IntraRd& R = *ip;
-    R.haveWhole = false; R.haveNxn = false; R.haveDevChroma = false;
+    R.haveWhole = false; R.haveNxn = false; R.haveDevChroma = false; R.lumaTileDone = false;
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
     R.predTile = d_pred; R.reconTile = d_recon;
@@ -943,7 +955,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (rc == X265AMD_OK)
     {
         R.extractLuma(R.cuX, R.cuY, 0, coeffCu.data());
-        R.copy2D(d_recon, 64, h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz, stride, R.size, R.size);
+        if (!R.lumaTileDone) R.copy2D(d_recon, 64, h_rec[0] + ((uint64_t)R.cuY * stride + R.cuX) * isz, stride, R.size, R.size);
         rc = R.estIntraPredChromaQT(chromaDist);
     }
     xa_phase(XA_PH_INTRA_CHROMA);

@@ -73,9 +73,9 @@ void xa_prof_dependency_wait(uint64_t ns);        /* X265AMD_QUEUE_PROF: time a 
         else { hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, (hipStream_t)(st), __VA_ARGS__); (ERR) = hipGetLastError(); }   \
     } while (0)
 
-/* up to three 2-D sample copies (device to device) as ONE launch: the three planes of a tile, or a prediction / reconstruction pair.
+/* up to four 2-D sample copies (device to device) as ONE launch: the three planes of a tile, a prediction / reconstruction pair, a winner's blocks.
  * Strides and sizes in samples. */
-struct XaRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };
+struct XaRects { uint64_t dst[4], src[4]; int16_t dst_stride[4], src_stride[4], w[4], h[4]; int32_t n; };         /* up to four; strides < 32768 samples */
 void xa_copy_rects(void* st, const XaRects& r);
 
 /* x265amd_analyse_frame with row hooks for pictures coded in parallel (csrc/ctu_analysis.hip; used by the encoder object): row_ready(ctx, row) says whether

@@ -59,6 +59,6 @@ struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, secon
 struct XaArgsCopy { uint64_t dst, src, bytes; uint32_t hostDst; };
 struct XaArgsCopy2D { uint64_t dst, src, dpitch, spitch, width, height; };
 struct XaArgsFill { uint64_t dst, bytes; uint32_t value; };
-struct XaArgsRects { uint64_t dst[3], src[3]; int32_t dst_stride[3], src_stride[3], w[3], h[3]; int32_t n; };     /* = XaRects (x265amd_host.h) */
+struct XaArgsRects { uint64_t dst[4], src[4]; int16_t dst_stride[4], src_stride[4], w[4], h[4]; int32_t n; };     /* = XaRects (x265amd_host.h): 100 bytes */
 
 #endif
