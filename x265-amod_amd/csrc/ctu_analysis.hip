@@ -270,6 +270,8 @@ struct Analyzer
         x265amd_rd_result r;
         /* the batch entry points take 256 records per CU in raster order with row length size/4: Mode::u is laid out like that */
         int rc;
+        xa_phase(XA_PH_ANALYZER);
+        struct PhEnd { ~PhEnd() { xa_phase(XA_PH_INTER_RD); } } phEnd;
         if (skipOnly)
             rc = x265amd_skip_rd(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, 1, m.u, tileAddr(m.predTile), tileAddr(m.reconTile), tileBytes, &r);
         else
@@ -283,6 +285,36 @@ struct Analyzer
         m.contexts.frac = r.frac_bits;
         const int n4 = 16 >> depth;
         for (int i = 0; i < n4 * n4; i++) m.m[i].pred_mode = m.u[i].pred_mode;
+        return 0;
+    }
+
+    /* encodeResAndCalcRdSkipCU on `skip` and encodeResAndCalcRdInterCU on `merge` (the same candidate, the same prediction tile) with the shared measurement done once */
+    int rdMergePair(Mode& skip, Mode& merge, int x, int y, int depth)
+    {
+        StageTimer timer_(2);
+        x265amd_rd_cu c;
+        memset(&c, 0, sizeof(c));
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
+        memcpy(c.ctx, md[depth].cur.ctx, X265AMD_CTX_COUNT);
+        c.frac_bits = md[depth].cur.frac;
+        x265amd_rd_result rs, rm;
+        int same = 0;
+        const int rc = xa_merge_rd(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, skip.u, merge.u, tileAddr(skip.predTile), tileAddr(skip.reconTile),
+                                   tileAddr(merge.reconTile), &rs, &rm, merge.coeff.data(), &same);
+        if (rc != X265AMD_OK) return err = rc;
+        std::fill(skip.coeff.begin(), skip.coeff.end(), 0);
+        const int n4 = 16 >> depth;
+        Mode* ms[2] = { &skip, &merge };
+        const x265amd_rd_result* rr[2] = { &rs, &rm };
+        for (int k = 0; k < 2; k++)
+        {
+            Mode& m = *ms[k]; const x265amd_rd_result& r = *rr[k];
+            m.rdCost = r.rd_cost; m.distortion = (sse_t)r.distortion; m.totalBits = r.total_bits; m.mvBits = r.mv_bits; m.coeffBits = r.coeff_bits;
+            m.psyEnergy = r.psy_energy; m.lumaDistortion = r.luma_distortion; m.chromaDistortion = r.chroma_distortion; m.resEnergy = r.res_energy;
+            memcpy(m.contexts.ctx, r.ctx, X265AMD_CTX_STRIDE);
+            m.contexts.frac = r.frac_bits;
+            for (int i = 0; i < n4 * n4; i++) m.m[i].pred_mode = m.u[i].pred_mode;
+        }
         return 0;
     }
 
@@ -400,7 +432,9 @@ struct Analyzer
         Mode* bestPred = &d.pred[PRED_SKIP];
         tempPred->initCosts(); bestPred->initCosts();
         x265amd_merge_cand cand[5];
+        xa_phase(XA_PH_ANALYZER);
         const int numCand = x265amd_merge_candidates(I, cur, col, x, y, log2, 0, 0, cand);
+        xa_phase(XA_PH_MERGE_CAND);
         if (numCand <= 0) return 0;
         std::vector<x265amd_mc_job> jobs;
         int tiles[5];
@@ -411,6 +445,7 @@ struct Analyzer
         }
         x265amd_cu_measure meas[5];
         if (predictAndMeasure(jobs, x, y, log2, tiles, meas)) return err;
+        xa_phase(XA_PH_MERGE);
         uint64_t bestCost = kMaxCost; uint32_t bestBits = 0;
         int bestSadCand = -1;
         for (int i = 0; i < numCand; i++)
@@ -434,8 +469,12 @@ struct Analyzer
         }
         bestPred->reconTile = reconTile(depth, PRED_SKIP);
         tempPred->reconTile = reconTile(depth, PRED_MERGE);
-        if (rdInter(*bestPred, x, y, depth, true)) return err;
-        if (rdInter(*tempPred, x, y, depth, false)) return err;
+        if (rp.rdoq_level)
+        {
+            if (rdInter(*bestPred, x, y, depth, true)) return err;
+            if (rdInter(*tempPred, x, y, depth, false)) return err;
+        }
+        else { xa_phase(XA_PH_ANALYZER); if (rdMergePair(*bestPred, *tempPred, x, y, depth)) return err; xa_phase(XA_PH_MERGE_RD); }
         d.best = tempPred->rdCost < bestPred->rdCost ? tempPred : bestPred;
         /* the winner keeps the candidate's prediction: move it out of the candidate tiles, which the next merge scan reuses */
         const int keep = predTile(depth, d.best == tempPred ? PRED_MERGE : PRED_SKIP);
@@ -462,6 +501,8 @@ struct Analyzer
         x265amd_inter_search_params sp = *S;
         sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         const uint32_t masks[2] = { refMask, 0 };
+        xa_phase(XA_PH_ANALYZER);
+        struct PhEnd { ~PhEnd() { xa_phase(XA_PH_INTER_SEARCH); } } phEnd;
         int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(inter.predTile), tileBytes, &det, masks);
         if (rc != X265AMD_OK) return err = rc;
         setInter(inter, depth, pu[0].merge_flag, pu[0].mvp_idx[0], pu[0].inter_dir, pu[0].ref_idx, pu[0].mv, pu[0].mvd, pu[0].mvp_idx);
@@ -1344,6 +1385,11 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             {
                 if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { int ok = X265AMD_OK; f.firstErr.compare_exchange_strong(ok, xa_fail(X265AMD_EHIP, "analyse_frame: stream")); }
                 st = own;
+            }
+            {
+                static const char* const lg = getenv("X265AMD_QUEUE_LOG");
+                int lp = -1, lr = -1;
+                if (lg && sscanf(lg, "%d,%d", &lp, &lr) == 2 && lp == f.poc && lr == row && st && !own) xa_queue_log(st, lp, lr);
             }
             std::atomic_thread_fence(std::memory_order_release);
             *f.queuedRows = (uint64_t)(row + 1);

@@ -563,6 +563,15 @@ struct XaQueue
     std::vector<Deferred> deferred;
     bool busy = false;
     std::chrono::steady_clock::time_point acquired;
+    /* X265AMD_QUEUE_LOG: the events of one row (xa_queue_log): wall time, the task's running time, kind ('E' command written, 'W' wait begins, 'R' wait over), op */
+    struct Ev { uint64_t wallNs, runNs; char kind; int op; };
+    std::vector<Ev> log; bool logging = false; int logPoc = 0, logRow = 0;
+    void ev(char kind, int op)
+    {
+        if (!logging) return;
+        static const auto t00 = std::chrono::steady_clock::now();
+        log.push_back(Ev{ (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t00).count(), xa_task_run_ns(), kind, op });
+    }
 };
 
 namespace {
@@ -706,6 +715,8 @@ int q_wait(XaQueue* q, uint64_t target)
 {
     const volatile uint64_t* tail = &q->rh->tail;
     if (*tail >= target) return 0;
+    q->ev('W', 0);
+    struct EvEnd { XaQueue* q; ~EvEnd() { q->ev('R', 0); } } evEnd{ q };
     const auto t0 = std::chrono::steady_clock::now();
     struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { if (g_prof) { g_waitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_waits++; } } } acc{ t0 };
     if (xa_in_task())
@@ -762,6 +773,7 @@ int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* 
     _mm_sfence();                       /* the slot is the doorbell: out of the write-combining buffer now */
     q->submitted++;
     if (flags & XA_CMD_SIGNAL) q->lastSignal = q->submitted;
+    q->ev('E', (int)op);
     return 0;
 }
 
@@ -787,7 +799,7 @@ void xa_phase_report(void)
 {
     if (!g_phases) return;
     static const char* const names[XA_PH_COUNT] = { "other", "intra setup", "intra scan", "intra candidates", "intra bits", "intra chroma", "intra final", "push", "row coder", "analyzer",
-                                                    "inter search", "inter rd", "merge" };
+                                                    "inter search", "inter rd", "merge predict + measure", "merge candidates", "merge rd", "rd plan + launch", "rd skip host", "rd walk" };
     fprintf(stderr, "x265amd: command pushes: %llu, %.1f ms in all (%.2f us each)\n", (unsigned long long)g_pushN.load(), g_pushNs.load() / 1e6, g_pushN.load() ? g_pushNs.load() / 1e3 / g_pushN.load() : 0.0);
     fprintf(stderr, "x265amd: host phases of the row tasks (ms, stamps):");
     for (int k = 0; k < XA_PH_COUNT; k++) fprintf(stderr, " %s %.1f (%llu)", names[k], g_phaseNs[k].load() / 1e6, (unsigned long long)g_phaseN[k].load());
@@ -833,12 +845,25 @@ void* xa_queue_acquire()
     return reinterpret_cast<void*>((uintptr_t)f | 1);
 }
 
+void xa_queue_log(void* st, int poc, int row)
+{
+    if (!xa_is_queue(st)) return;
+    XaQueue* q = as_queue(st);
+    q->logging = true; q->logPoc = poc; q->logRow = row; q->log.clear(); q->log.reserve(1 << 16);
+}
+
 void xa_queue_release(void* st)
 {
     if (!xa_is_queue(st)) return;
     XaQueue* q = as_queue(st);
     (void)xa_stream_fence(st, XA_CMD_RELEASE);
     (void)xa_stream_sync(st);
+    if (q->logging)
+    {
+        q->logging = false;
+        for (const XaQueue::Ev& e : q->log) fprintf(stderr, "x265amd qlog poc %d row %d: %.2f %.2f %c %d\n", q->logPoc, q->logRow, e.wallNs / 1e3, e.runNs / 1e3, e.kind, e.op);
+        q->log.clear();
+    }
     xa_scratch_local_end();
     Server& S = server();
     std::lock_guard<std::mutex> g(S.m);
@@ -856,11 +881,16 @@ hipError_t xa_q_enqueue(void* st, int op, const void* args, size_t argBytes, int
     XaQueue* q = as_queue(st);
     if (trace)
     {
-        fprintf(stderr, "x265amd queue %d: op %d count %d flags %d args", q->idx, op, count, flags);
+        static const auto t00 = std::chrono::steady_clock::now();
+        const double tEnq = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count();
+        fprintf(stderr, "x265amd queue %d: t %.1f op %d count %d flags %d args", q->idx, tEnq, op, count, flags);
         for (size_t i = 0; i < argBytes / 8; i++) fprintf(stderr, " %llx", (unsigned long long)reinterpret_cast<const uint64_t*>(args)[i]);
         fprintf(stderr, "\n");
         fflush(stderr);
         if (q_push(q, (uint32_t)op, (uint32_t)flags | XA_CMD_SIGNAL, (uint32_t)count, args, argBytes) || q_wait(q, q->submitted)) return hipErrorUnknown;
+        fprintf(stderr, "  took %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t00).count() - tEnq);
+        static const bool verbose = getenv("X265AMD_QUEUE_TRACE")[0] == '2';
+        if (!verbose) return hipSuccess;
         if (op == XA_OP_CU_MEASURE || op == XA_OP_MC)
             for (int w = 0; w < 8; w++)
             {

@@ -676,8 +676,14 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
         pic.reconRows.store(k + 1, std::memory_order_release);
         return X265AMD_OK;
     };
+    static const bool timing = getenv("X265AMD_TIMING") != nullptr;
+    double tPh[6] = { 0, 0, 0, 0, 0, 0 };
+    auto tLast = std::chrono::steady_clock::now();
+    auto stamp = [&](int k) { if (!timing) return; const auto n = std::chrono::steady_clock::now(); tPh[k] += std::chrono::duration<double, std::milli>(n - tLast).count(); tLast = n; };
+    struct Report { const bool& on; double* t; int poc; ~Report() { if (on) fprintf(stderr, "x265amd: filter rows of poc %d (ms): waiting %.1f, deblock units + upload %.1f, deblock %.1f, sao statistics %.1f, sao decision + upload %.1f, offsets + borders %.1f\n", poc, t[0], t[1], t[2], t[3], t[4], t[5]); } } report{ timing, tPh, pic.poc };
     for (int r = 0; r < ctuH && rc == X265AMD_OK; r++)
     {
+        stamp(5);
         {
             std::unique_lock<std::mutex> lk(pic.mu);
             /* intra prediction of row r + 1 reads the unfiltered last line of row r: FrameEncoder::m_filterRowDelay (frameencoder.cpp:124-126, :1936-1950) */
@@ -685,6 +691,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
             pic.cv.wait(lk, [&] { return pic.analysedRows >= needRows || pic.failed; });
             if (pic.failed) return X265AMD_EHIP;
         }
+        stamp(0);
         const int y4b = r * 16, y4e = std::min(h4, y4b + 16);
         if (dbl)
         {
@@ -693,6 +700,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
             if (hipMemcpyAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4, dbu.data() + (size_t)y4b * w4, sizeof(x265amd_deblock_unit) * (size_t)(y4e - y4b) * w4, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
             { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
+            stamp(1);
             rc = x265amd_deblock_rows(st, recY, recU, recV, stride, cstride, W, H, (const x265amd_deblock_unit*)dDb.p, 0, 0, 0, 0, 0, 3, y4b, y4e);
             if (rc != X265AMD_OK) break;
         }
@@ -705,12 +713,14 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
             if (hipMemcpyAsync(cnt.data() + r * rowStat, (int32_t*)dCnt.p + r * rowStat, rowStat * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipMemcpyAsync(orgs.data() + r * rowStat, (int32_t*)dOrg.p + r * rowStat, rowStat * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             { rc = xa_fail(X265AMD_EHIP, "encoder: sao download"); break; }
+            stamp(3);
             int32_t flags[2] = { 1, 1 };
             rc = x265amd_sao_rdo_rows(&si, pic.type != TYPE_B ? 1 : 0, 2, 0, 69, pic.units.data(), cnt.data(), orgs.data(), unusedRate, sparams.data(), flags, r, r + 1);
             if (rc != X265AMD_OK) break;
             if (hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + (size_t)r * ctuW, sparams.data() + (size_t)r * ctuW, sizeof(x265amd_sao_ctu) * ctuW, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
             { rc = xa_fail(X265AMD_EHIP, "encoder: sao upload"); break; }
+            stamp(4);
         }
         if (!dbl && !sao) { rc = finish(r); continue; }         /* nothing below changes this row */
         if (r > 0) rc = finish(r - 1);

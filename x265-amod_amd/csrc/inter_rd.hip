@@ -914,3 +914,76 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     x265amd_inter_rd_finish(si, rp, cus, n, meas + n, out);
     return X265AMD_OK;
 }
+
+/* checkMerge2Nx2N_rd0_4's two RD measurements of the chosen candidate as ONE device round trip where the reference's result allows it (analysis.cpp:2852-2880):
+ * encodeResAndCalcRdSkipCU and the first half of encodeResAndCalcRdInterCU share the prediction-against-source measurement, so the transform chains and that
+ * one measurement go out together (the measurement leaves the prediction in the skip mode's reconstruction tile).  When no transform unit keeps a level the
+ * residual mode is the skip mode -- same bits, distortion, energy and cost, and `tempPred->rdCost < bestPred->rdCost` is false -- so the tree walk, the
+ * assembly and the second measurement are left out; *merge_is_skip says so (the merge mode's units then equal the skip mode's, its reconstruction tile is not
+ * written).  Otherwise the walk and the assembly run as in x265amd_inter_residual_rd.  Without RDOQ only (returns X265AMD_EINVAL with it). */
+int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
+                const x265amd_rd_cu* cu, x265amd_cu_unit* skip_units, x265amd_cu_unit* merge_units, uint64_t d_pred, uint64_t d_recon_skip, uint64_t d_recon_merge,
+                x265amd_rd_result* out_skip, x265amd_rd_result* out_merge, int16_t* coeff_out, int* merge_is_skip)
+{
+    if (!si || !rp || !units || !h_src || !cu || !skip_units || !merge_units || !d_pred || !d_recon_skip || !d_recon_merge || !out_skip || !out_merge || !merge_is_skip)
+        return xa_fail(X265AMD_EINVAL, "merge_rd: null argument");
+    if (rp->rdoq_level || si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "merge_rd: RDOQ / lossless go through the separate entry points");
+    const size_t tile_bytes = (size_t)(4096 + 2048) * sizeof(pixel);
+    const size_t perCuBytes = x265amd_inter_rd_scratch_bytes();
+    DevBuf dScratch, dSel;
+    XaMapped mJobs, mMJobs; XaMappedOut mRes, mMeas, mLevels;
+    XA_HIP_CHECK(dScratch.alloc(perCuBytes));
+    char* scratch = (char*)dScratch.p;
+    const int nJobs = x265amd_inter_rd_plan(si, cu, 1, merge_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, nullptr, 0);
+    if (nJobs < 0) return nJobs;
+    XA_HIP_CHECK(mJobs.alloc(sizeof(x265amd_tu_job) * nJobs));
+    XA_HIP_CHECK(mRes.alloc(sizeof(x265amd_tu_result) * nJobs));
+    XA_HIP_CHECK(mMJobs.alloc(sizeof(CuMeasureJob)));
+    XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * 2));
+    XA_HIP_CHECK(mLevels.alloc((size_t)RD_SCRATCH_ELEMS * 2));
+    XA_HIP_CHECK(dSel.alloc((size_t)RD_SEL_BYTES));
+    x265amd_inter_rd_plan(si, cu, 1, merge_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs);
+    int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)mJobs.p, nJobs, (x265amd_tu_result*)mRes.p);
+    if (rc != X265AMD_OK) return rc;
+    CuMeasureJob* mjobs = (CuMeasureJob*)mMJobs.p;
+    x265amd_cu_measure* meas = (x265amd_cu_measure*)mMeas.p;
+    fill_measure_jobs(mjobs, cu, 1, h_src, stride, cstride, d_pred, d_recon_skip, tile_bytes, scratch, perCuBytes, (const char*)dSel.p);
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas), 0, 0, 1 }; hipError_t le;
+      if (measure_use_wg(1)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure_wg, dim3(1), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, 1, meas);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure, dim3(1), dim3(64), 0, (const CuMeasureJob*)mjobs, 1, meas);
+      XA_HIP_CHECK(le); }
+    XA_HIP_CHECK(xa_copy2d_to_mapped_async(stream_, mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, 1));
+    xa_phase(XA_PH_RD_PLAN);
+    XA_HIP_CHECK(xa_stream_sync(stream_));
+    xa_phase(XA_PH_OTHER);
+
+    const x265amd_cu_measure m0 = meas[0];
+    rc = x265amd_skip_rd_host(si, rp, units, cu, 1, skip_units, &m0, out_skip);
+    if (rc != X265AMD_OK) return rc;
+    xa_phase(XA_PH_RD_SKIPHOST);
+    bool anyLevel = si->use_dqp != 0;            /* checkDQP touches the units of a residual-free CU: the walk does that */
+    const x265amd_tu_result* res = (const x265amd_tu_result*)mRes.p;
+    for (int k = 0; k < nJobs; k++) anyLevel |= res[k].num_sig != 0;
+    if (!anyLevel)
+    {
+        *merge_is_skip = 1;
+        *out_merge = *out_skip;
+        memcpy(merge_units, skip_units, sizeof(x265amd_cu_unit) * 256);
+        if (coeff_out) memset(coeff_out, 0, sizeof(int16_t) * (4096 + 2048));
+        return X265AMD_OK;
+    }
+    *merge_is_skip = 0;
+    std::vector<uint8_t> sel((size_t)RD_SEL_BYTES);
+    rc = inter_rd_walk_impl(si, rp, units, cu, 1, merge_units, res, (const int16_t*)mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, &m0, sel.data(), out_merge, coeff_out, nullptr);
+    if (rc != X265AMD_OK) return rc;
+    xa_phase(XA_PH_RD_WALK);
+    mjobs[0].assemble = 1; mjobs[0].recon = d_recon_merge;
+    XA_HIP_CHECK(xa_copy_async(stream_, dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice));
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + 1), 0, 0, 1 }; hipError_t le;
+      if (measure_use_wg(1)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure_wg, dim3(1), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, 1, meas + 1);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure, dim3(1), dim3(64), 0, (const CuMeasureJob*)mjobs, 1, meas + 1);
+      XA_HIP_CHECK(le); }
+    XA_HIP_CHECK(xa_stream_sync(stream_));
+    x265amd_inter_rd_finish(si, rp, cu, 1, meas + 1, out_merge);
+    return X265AMD_OK;
+}

@@ -60,6 +60,7 @@ inline bool xa_is_queue(const void* st) { return ((uintptr_t)st & 1) != 0; }
 bool xa_queues_enabled();
 void* xa_queue_acquire();               /* NULL when queues are off (X265AMD_QUEUES=0) or all are taken: use a stream then */
 void xa_queue_release(void* st);
+void xa_queue_log(void* st, int poc, int row);      /* X265AMD_QUEUE_LOG=poc,row: the command / wait timeline of that row goes to stderr when the queue is given back */
 hipError_t xa_stream_sync(void* st);
 hipError_t xa_stream_fence(void* st, int flags);
 hipError_t xa_copy_async(void* st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
@@ -98,10 +99,15 @@ int xa_intra_in_inter_ws(void* stream, const x265amd_slice_info* si, const x265a
                          int16_t* coeff_out, uint64_t* info, void** ws);
 void xa_intra_ws_free(void* ws);
 
+/* the skip and the residual measurement of a merge candidate together (csrc/inter_rd.hip) */
+int xa_merge_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
+                const x265amd_rd_cu* cu, x265amd_cu_unit* skip_units, x265amd_cu_unit* merge_units, uint64_t d_pred, uint64_t d_recon_skip, uint64_t d_recon_merge,
+                x265amd_rd_result* out_skip, x265amd_rd_result* out_merge, int16_t* coeff_out, int* merge_is_skip);
+
 /* X265AMD_TIMING: host time of a row task by phase (running time only: the clock stops while the task is parked).  XA_PHASE(k) charges the time since the
  * previous stamp of this task to phase k; the totals are printed per frame. */
 enum { XA_PH_OTHER = 0, XA_PH_INTRA_SETUP, XA_PH_INTRA_SCAN, XA_PH_INTRA_CAND, XA_PH_INTRA_BITS, XA_PH_INTRA_CHROMA, XA_PH_INTRA_FINAL, XA_PH_PUSH, XA_PH_CABAC_CTU, XA_PH_ANALYZER,
-       XA_PH_INTER_SEARCH, XA_PH_INTER_RD, XA_PH_MERGE, XA_PH_COUNT };
+       XA_PH_INTER_SEARCH, XA_PH_INTER_RD, XA_PH_MERGE, XA_PH_MERGE_CAND, XA_PH_MERGE_RD, XA_PH_RD_PLAN, XA_PH_RD_SKIPHOST, XA_PH_RD_WALK, XA_PH_COUNT };
 void xa_phase(int k);
 void xa_phase_report(void);
 
