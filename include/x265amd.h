@@ -389,6 +389,10 @@ typedef struct x265amd_coeff_bits_job
     uint8_t log2_tr_size, ttype, intra, dir_mode, sign_hide, reserved[3];
 } x265amd_coeff_bits_job;
 int x265amd_coeff_bits(void* stream, const x265amd_coeff_bits_job* d_jobs, int n, uint64_t* d_bits);
+/* the same with a wavefront per unit: the contexts of a unit are independent state machines (a state moves only with the bins coded in that context), so
+ * the lanes lay out from the levels which bins every context codes, then one lane per context walks its own bins -- instead of one lane coding all of them in
+ * turn.  Same bits, same adapted contexts.  The form the fused intra steps use on the device (csrc/entropy_dev.h) */
+int x265amd_coeff_bits_wave(void* stream, const x265amd_coeff_bits_job* d_jobs, int n, uint64_t* d_bits);
 /* host-pointer forms (parity surface) */
 void x265amd_est_bit_host(const uint8_t* ctx, int log2TrSize, int isLuma, int32_t* est);
 uint64_t x265amd_code_coeff_bits(const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int dirMode, int signHide, uint8_t* ctx);

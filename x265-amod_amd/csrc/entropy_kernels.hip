@@ -71,9 +71,42 @@ __global__ __launch_bounds__(CB_LANES) void k_coeff_bits(const x265amd_coeff_bit
     for (int i = 0; i < X265AMD_CTX_STRIDE / 4; i++) dst[i] = src[i];
 }
 
+/* the wavefront form (wave_coeff_bits / wave_coeff_bits_4x4, entropy_dev.h): a wavefront per job */
+#define CB4_WAVES 4
+__global__ __launch_bounds__(64 * CB4_WAVES) void k_coeff_bits_wave(const x265amd_coeff_bits_job* jobs, int n, uint64_t* out)
+{
+    __shared__ uint8_t s_ctx[CB4_WAVES][X265AMD_CTX_STRIDE];
+    __shared__ int16_t s_lev[CB4_WAVES][16];
+    __shared__ uint32_t s_step[256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_step[i] = en_step.v[i];
+    __syncthreads();
+    const int ji = blockIdx.x * CB4_WAVES + wv;
+    if (ji >= n) return;
+    const x265amd_coeff_bits_job j = jobs[ji];
+    for (int b = lane; b < X265AMD_CTX_STRIDE; b += 64) s_ctx[wv][b] = reinterpret_cast<const uint8_t*>(j.ctx_in)[b];
+    if (lane < 16) s_lev[wv][lane] = reinterpret_cast<const int16_t*>(j.coeff)[lane];
+    xa_wave_sync();
+    const uint64_t bits = j.log2_tr_size == 2 ? wave_coeff_bits_4x4(s_ctx[wv], s_ctx[wv], s_lev[wv], j.ttype, j.intra, j.dir_mode, j.sign_hide, s_step, lane)
+                                              : wave_coeff_bits(s_ctx[wv], s_ctx[wv], reinterpret_cast<const int16_t*>(j.coeff), j.log2_tr_size, j.ttype, j.intra, j.dir_mode, j.sign_hide, s_step, lane);
+    xa_wave_sync();
+    if (lane == 0) out[ji] = bits;
+    for (int b = lane; b < X265AMD_CTX_STRIDE; b += 64) reinterpret_cast<uint8_t*>(j.ctx_out)[b] = s_ctx[wv][b];
+}
+
 /* =========================================================================================================
  * host side
  * ======================================================================================================= */
+extern "C" int x265amd_coeff_bits_wave(void* stream, const x265amd_coeff_bits_job* d_jobs, int n, uint64_t* d_bits)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!d_jobs || !d_bits) return xa_fail(X265AMD_EINVAL, "x265amd_coeff_bits_wave: bad arguments");
+    hipLaunchKernelGGL(k_coeff_bits_wave, dim3((n + CB4_WAVES - 1) / CB4_WAVES), dim3(64 * CB4_WAVES), 0, (hipStream_t)stream, d_jobs, n, d_bits);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
 extern "C" int x265amd_est_bit(void* stream, const x265amd_est_job* d_jobs, int n)
 {
     if (n <= 0) return X265AMD_OK;

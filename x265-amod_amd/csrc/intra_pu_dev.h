@@ -138,8 +138,10 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     /* the estimator's tables beside it: the lanes that count bits look them up bin after bin */
     __shared__ uint32_t s_enBits[128];
     __shared__ uint8_t s_enLps[64];
+    __shared__ uint32_t s_step[256];               /* bits and next state per (state, bin): the one look-up of the per-context walks (wave_coeff_bits_4x4) */
     if (tid < 128) s_enBits[tid] = en_bits[tid];
     if (tid < 64) s_enLps[tid] = en_lpsNext[tid];
+    for (int i = tid; i < 256; i += nthr) s_step[i] = en_step.v[i];
     const EnTabs tabs{ s_enBits, s_enLps };
     const x265amd_intra_nxn_job& P = sP;
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
@@ -190,20 +192,29 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
             wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
             XA_STAGE(19);
-            /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400): the lane's own copy of the contexts */
-            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[i][b] = P.ctx[b];
+            /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400).  The levels are still in this wavefront's LDS.  A 4x4 unit: its contexts as
+             * independent state machines across the lanes, straight from the job's context set (a candidate is only priced, nothing is written back); an 8x8
+             * unit: one lane on its own copy of the contexts */
             xa_wave_sync();
+            const uint32_t numSig = s_res[i].num_sig;
+            unsigned long long coeffFrac = 0;
+            if (unitLog2 == 2) { if (numSig) coeffFrac = wave_coeff_bits_4x4(P.ctx, nullptr, s.q, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane); }
+            else
+            {
+                for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[i][b] = P.ctx[b];
+                xa_wave_sync();
+                if (lane == 0 && numSig) coeffFrac = lane_coeff_bits(s_ctxw[i], s.q, 3, 0, 1, (int)mode, T.tu.sign_hide, tabs);
+            }
             if (lane == 0)
             {
-                uint8_t* cw = s_ctxw[i];
+                const uint8_t* cw = P.ctx;
                 const int pidx = mode == p0 ? 0 : (mode == p1 ? 1 : (mode == p2 ? 2 : -1));
                 unsigned long long frac = P.frac_start[k];
                 frac += s_enBits[cw[13] ^ (pidx != -1 ? 1u : 0u)];
                 frac += (unsigned long long)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
                 const x265amd_tu_result r = s_res[i];
                 frac += s_enBits[cw[cbfCtx] ^ (r.num_sig != 0 ? 1u : 0u)];
-                /* the levels are still in this wavefront's LDS; the size as a constant: the 4x4 case folds to one coefficient group without the group bookkeeping */
-                if (r.num_sig) frac += unitLog2 == 2 ? lane_coeff_bits(cw, s.q, 2, 0, 1, (int)mode, T.tu.sign_hide, tabs) : lane_coeff_bits(cw, s.q, 3, 0, 1, (int)mode, T.tu.sign_hide, tabs);
+                frac += coeffFrac;
                 const unsigned long long bits = (uint32_t)(frac >> 15);
                 const unsigned long long dist = r.nz_dist;
                 s_cost[i] = P.psy_scale ? dist + ((P.psy_scale * (unsigned long long)r.nz_energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
@@ -281,6 +292,13 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[wv][b] = P.ctx[b];
         xa_wave_sync();
+        /* U's coefficients, then V's on the contexts U has moved (the flags in front of them live in other contexts: their order against the coefficients is free) */
+        unsigned long long coeffFrac = 0;
+        for (int pl = 0; pl < 2; pl++)
+        {
+            if (s_cres[wv][pl].num_sig) coeffFrac += wave_coeff_bits_4x4(s_ctxw[wv], s_ctxw[wv], s_clev[wv][pl], 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide, s_step, lane);
+            xa_wave_sync();
+        }
         if (lane == 0)
         {
             uint8_t* cw = s_ctxw[wv];
@@ -289,12 +307,9 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             if (listed != 36) frac += 2ull << 15;
             /* the two coded block flags share a context (codeSubdivCbfQTChroma at depth 0, both planes: C_QT_CBF + 2), then U's and V's coefficients */
             for (int pl = 0; pl < 2; pl++) frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, s_cres[wv][pl].num_sig != 0 ? 1u : 0u);
+            frac += coeffFrac;
             unsigned long long dist = 0, energy = 0;
-            for (int pl = 0; pl < 2; pl++)
-            {
-                if (s_cres[wv][pl].num_sig) frac += lane_coeff_bits(cw, s_clev[wv][pl], 2, 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide, tabs);
-                dist += s_cres[wv][pl].nz_dist; energy += s_cres[wv][pl].nz_energy;
-            }
+            for (int pl = 0; pl < 2; pl++) { dist += s_cres[wv][pl].nz_dist; energy += s_cres[wv][pl].nz_energy; }
             const unsigned long long bits = (uint32_t)(frac >> 15);
             s_cost[wv] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
         }
