@@ -193,18 +193,12 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
             XA_STAGE(19);
             /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400).  The levels are still in this wavefront's LDS.  A 4x4 unit: its contexts as
-             * independent state machines across the lanes, straight from the job's context set (a candidate is only priced, nothing is written back); an 8x8
-             * unit: one lane on its own copy of the contexts */
+             * independent state machines across the lanes, straight from the job's context set (a candidate is only priced, nothing is written back) */
             xa_wave_sync();
             const uint32_t numSig = s_res[i].num_sig;
             unsigned long long coeffFrac = 0;
-            if (unitLog2 == 2) { if (numSig) coeffFrac = wave_coeff_bits_4x4(P.ctx, nullptr, s.q, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane); }
-            else
-            {
-                for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[i][b] = P.ctx[b];
-                xa_wave_sync();
-                if (lane == 0 && numSig) coeffFrac = lane_coeff_bits(s_ctxw[i], s.q, 3, 0, 1, (int)mode, T.tu.sign_hide, tabs);
-            }
+            if (numSig) coeffFrac = unitLog2 == 2 ? wave_coeff_bits_4x4(P.ctx, nullptr, s.q, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane)
+                                                  : wave_coeff_bits(P.ctx, nullptr, s.q, 3, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane);
             if (lane == 0)
             {
                 const uint8_t* cw = P.ctx;

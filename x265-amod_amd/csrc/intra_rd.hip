@@ -399,9 +399,10 @@ struct IntraRd
          * coefficients are few enough for the device to count their bits, so nothing of the host's enters between the units.  The host repeats the winners'
          * bookkeeping (units, bits, contexts) afterwards.  Not with RDOQ (the quantiser then reads bit estimates of the current contexts per unit). */
         x265amd_intra_nxn_out nxn;
-        /* (The device routine also takes the same CU coded 2Nx2N -- one 8x8 unit, num_units = 1 -- and gives the same stream, but a lane needs 45 us for the bits of
-         * 64 coefficients, several times the host: measured, the I picture 12 % slower.  X265AMD_DEVICE_2Nx2N=1 switches it on.) */
-        static const bool dev2Nx2N = getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) != 0;
+        /* The device routine also takes the same CU coded 2Nx2N -- one 8x8 unit, num_units = 1, chroma decision included: one round trip instead of two and no
+         * candidate bits on the host.  (It paid only once the bits of a unit were counted by a wavefront, a lane per context: a single lane needs 45 us for the 64
+         * coefficients.)  X265AMD_DEVICE_2Nx2N=0 takes the prediction-unit step with host bits instead. */
+        static const bool dev2Nx2N = !(getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) == 0);
         const bool deviceNxN = log2 == 3 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
                                (partSize != 0 ? (log2TrSize == 2 && range[0] == 2) : (dev2Nx2N && range[0] == 3 && range[1] >= 3));
         const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
