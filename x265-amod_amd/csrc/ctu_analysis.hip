@@ -880,6 +880,8 @@ struct Analyzer
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
         if (log2 != 6 && mightNotSplit)
         {
+            if (log2 == 3 && si->tu_log2_min < 3 && xa_queue_helper(st))         /* the NxN try below may start beside this one */
+                xa_intra_ws_hint_nxn(&intraWs, tileAddr(predTile(depth, PRED_INTRA_NxN)), tileAddr(reconTile(depth, PRED_INTRA_NxN)));
             if (rdIntra(d.pred[PRED_INTRA], x, y, depth, PRED_INTRA, true, 0)) return err;
             checkBestMode(d.pred[PRED_INTRA], depth);
             if (log2 == 3 && si->tu_log2_min < 3)
@@ -1354,12 +1356,12 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             std::vector<volatile uint64_t*> done;   /* CTUs finished per row: counters the parked rows below wait on (xa_fiber.h) */
             volatile uint64_t* queuedRows;          /* rows that hold (or have held) a queue */
             std::atomic<int> firstErr{ X265AMD_OK };
-            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc;
+            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc; bool intraOnly;
             std::function<int(int, void*)> doCtu;
             explicit Frame(int rowsN) : done(rowsN) { for (auto& d : done) d = xa_counter_alloc(); queuedRows = xa_counter_alloc(); }
             ~Frame() { for (auto& d : done) xa_counter_free(d); xa_counter_free(queuedRows); }
         } F(ctuH);
-        F.hooks = hooks; F.ctuW = ctuW; F.ctuH = ctuH; F.dumping = dumping; F.poc = I->poc; F.doCtu = doCtu;
+        F.hooks = hooks; F.ctuW = ctuW; F.ctuH = ctuH; F.dumping = dumping; F.poc = I->poc; F.doCtu = doCtu; F.intraOnly = si->slice_type == 2;
         struct Row { Frame* f; int row; };
         std::vector<Row> rowsArg((size_t)ctuH);
         std::vector<XaTask> tasks((size_t)ctuH);
@@ -1391,6 +1393,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 int lp = -1, lr = -1;
                 if (lg && sscanf(lg, "%d,%d", &lp, &lr) == 2 && lp == f.poc && lr == row && st && !own) xa_queue_log(st, lp, lr);
             }
+            /* I pictures: a second queue for the row when one is to spare -- the two partitionings of an 8x8 CU are evaluated side by side (intra_rd.hip) */
+            void* helper = (f.intraOnly && st && !own) ? xa_queue_try_acquire() : nullptr;
+            if (helper) xa_queue_set_helper(st, helper);
             std::atomic_thread_fence(std::memory_order_release);
             *f.queuedRows = (uint64_t)(row + 1);
             const auto tQueue = std::chrono::steady_clock::now();
@@ -1415,6 +1420,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
             }
             if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;
+            if (helper) { xa_queue_set_helper(st, nullptr); xa_queue_release_helper(helper); }
             if (own) (void)hipStreamDestroy(own);
             else if (st) xa_queue_release(st);
             if (g_timing && f.hooks)

@@ -13,7 +13,11 @@
 /* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside" */
 __shared__ unsigned long long xa_stage_acc[22];      /* [0..15] transform chains and the prediction-unit step, [16..21] the NxN step */
 __shared__ long long xa_stage_prev;
+#ifdef XA_NO_STAGES
+#define XA_STAGE(k)
+#else
 #define XA_STAGE(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_stage_acc[k] += (unsigned long long)(t_ - xa_stage_prev); xa_stage_prev = t_; } } while (0)
+#endif
 #include "tu_dev.h"
 #include "intra_dev.h"
 #include "mc_dev.h"
@@ -566,6 +570,7 @@ struct XaQueue
     /* X265AMD_QUEUE_LOG: the events of one row (xa_queue_log): wall time, the task's running time, kind ('E' command written, 'W' wait begins, 'R' wait over), op */
     struct Ev { uint64_t wallNs, runNs; char kind; int op; };
     std::vector<Ev> log; bool logging = false; int logPoc = 0, logRow = 0;
+    void* helper = nullptr;             /* a second queue the holder of this one may use beside it (xa_queue_set_helper) */
     void ev(char kind, int op)
     {
         if (!logging) return;
@@ -837,13 +842,48 @@ void* xa_queue_acquire()
         if (S.freed.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) return nullptr;
     }
     if (S.start() != 0) return nullptr;
-    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear();
+    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr;
     S.freeCount = S.freeCount - 1;
     S.refs++;
     xa_scratch_local_begin();           /* the calling thread is the one that uses the queue */
     f->acquired = std::chrono::steady_clock::now();
     return reinterpret_cast<void*>((uintptr_t)f | 1);
 }
+
+/* a second queue for the holder of a first one, if one is free right now: never waits (the rows of a picture take their FIRST queues in row order so that
+ * waiting for one always ends; a second queue is a bonus) */
+void* xa_queue_try_acquire()
+{
+    Server& S = server();
+    std::unique_lock<std::mutex> g(S.m);
+    if (S.disabled || S.init() != 0) return nullptr;
+    static const int spare = getenv("X265AMD_HELPER_SPARE") ? atoi(getenv("X265AMD_HELPER_SPARE")) : 24;       /* queues left to the rows that need a first one */
+    int freeN = 0;
+    XaQueue* f = nullptr;
+    for (XaQueue& x : S.q) if (!x.busy) { freeN++; if (!f) f = &x; }
+    if (!f || freeN <= spare) return nullptr;
+    if (S.start() != 0) return nullptr;
+    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr;
+    S.freeCount = S.freeCount - 1;
+    S.refs++;
+    f->acquired = std::chrono::steady_clock::now();
+    return reinterpret_cast<void*>((uintptr_t)f | 1);
+}
+void xa_queue_release_helper(void* st)
+{
+    if (!xa_is_queue(st)) return;
+    XaQueue* q = as_queue(st);
+    (void)xa_stream_fence(st, XA_CMD_RELEASE);
+    (void)xa_stream_sync(st);
+    Server& S = server();
+    std::lock_guard<std::mutex> g(S.m);
+    q->busy = false;
+    S.freeCount = S.freeCount + 1;
+    S.freed.notify_one();
+    if (--S.refs == 0) S.stop();
+}
+void xa_queue_set_helper(void* st, void* helper) { if (xa_is_queue(st)) as_queue(st)->helper = helper; }
+void* xa_queue_helper(void* st) { return xa_is_queue(st) ? as_queue(st)->helper : nullptr; }
 
 void xa_queue_log(void* st, int poc, int row)
 {

@@ -6,7 +6,9 @@
 #include "intra_dev.h"
 #include "entropy_dev.h"
 
-struct IntraPuShared { int32_t sa8d[35]; uint8_t modes[16]; int num; pixel nbRef[136], nbFlt[136]; };      /* nb*: the scan's neighbour arrays, kept for the chains */
+/* nb*: the scan's neighbour arrays, kept for the chains; fenc: its copy of the source block (row length N) -- the candidates' chains read the source five times
+ * each (residual, two distortions, two psy energies), from here instead of from global memory (a microsecond per dependent read) */
+struct IntraPuShared { int32_t sa8d[35]; uint8_t modes[16]; int num; pixel nbRef[136], nbFlt[136]; pixel fenc[32 * 32]; };
 
 /* the candidate list of a prediction unit from its 35 SA8D costs (S.sa8d): called by the first wavefront, all 64 lanes; leaves S.modes / S.num */
 XA_DEV void wave0_candidate_list(IntraPuShared& S, uint32_t preds0, uint32_t preds1, uint32_t preds2, uint32_t rbits, uint32_t mpmBase, unsigned long long lambda, int maxCandIn, int tid)
@@ -96,6 +98,7 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
         const IntraScanLds& sc = *reinterpret_cast<const IntraScanLds*>(smem);
         const int n4 = 4 << P.tmpl.tu.log2_tr_size;
         for (int i = tid; i <= n4; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
+        for (int i = tid; i < (1 << (2 * P.tmpl.tu.log2_tr_size)); i += nthr) S.fenc[i] = sc.fenc[i];
     }
     if (tid < 35) po->sa8d[tid] = S.sa8d[tid];
     if (tid < 64)
@@ -113,6 +116,7 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
     {
         x265amd_intra_tu_job J = P.tmpl;
         J.tu.dir_mode = S.modes[i];
+        J.tu.fenc = (uint64_t)(uintptr_t)(const void*)S.fenc; J.tu.fenc_stride = 1 << P.tmpl.tu.log2_tr_size;
         J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
         J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
         wave_intra_tu_chain_body<false>(J, nullptr, res + i, s, ip, nullptr, lane, S.nbRef, S.nbFlt);
@@ -176,6 +180,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         {
             const IntraScanLds& sc = *reinterpret_cast<const IntraScanLds*>(smem);
             for (int i = tid; i <= 4 * N; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
+            for (int i = tid; i < N * N; i += nthr) S.fenc[i] = sc.fenc[i];
         }
         if (tid < 64) wave0_candidate_list(S, p0, p1, p2, rbits, mpmBase, P.lambda, maxCand, tid);
         __syncthreads();
@@ -188,6 +193,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             x265amd_intra_tu_job J = T;
             const uint32_t mode = S.modes[i];
             J.tu.dir_mode = (uint8_t)mode;
+            J.tu.fenc = (uint64_t)(uintptr_t)(const void*)S.fenc; J.tu.fenc_stride = N;
             J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
             wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
@@ -235,7 +241,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             {
                 const int y = tid >> unitLog2, x = tid & (N - 1);
                 const pixel v = rec[y * T.tu.recon_stride + x];
-                reinterpret_cast<pixel*>(T.nb)[(long)y * T.nb_stride + x] = v;
+                if (!P.no_picture) reinterpret_cast<pixel*>(T.nb)[(long)y * T.nb_stride + x] = v;
                 reinterpret_cast<pixel*>(P.layer_dst[k])[y * 64 + x] = v;
                 if (P.recon_dst[k]) reinterpret_cast<pixel*>(P.recon_dst[k])[y * 64 + x] = v;
                 reinterpret_cast<pixel*>(P.pred_dst[k])[y * 64 + x] = prd[y * T.tu.pred_stride + x];
@@ -260,7 +266,13 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ x265amd_tu_result s_cres[5][2];
     __shared__ int16_t s_clev[5][2][16];
     __shared__ uint8_t s_cmode[5];
+    __shared__ pixel s_cfenc[2][16];                /* the two source blocks, read by the five modes' chains */
     const uint32_t lumaDir = s_winMode[0];
+    if (tid >= 64 && tid < 96)
+    {
+        const int pl = (tid - 64) >> 4, i = tid & 15;
+        s_cfenc[pl][i] = reinterpret_cast<const pixel*>(P.ctmpl[pl].tu.fenc)[(i >> 2) * P.ctmpl[pl].tu.fenc_stride + (i & 3)];
+    }
     if (tid < 5)
     {
         /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
@@ -278,6 +290,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         {
             x265amd_intra_tu_job J = P.ctmpl[pl];
             J.tu.dir_mode = (uint8_t)mode;
+            J.tu.fenc = (uint64_t)(uintptr_t)(const void*)s_cfenc[pl]; J.tu.fenc_stride = 4;
             J.tu.recon += (uint64_t)(2 * wv + pl) * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t);
             wave_intra_tu_chain_body<false>(J, nullptr, &s_cres[wv][pl], s, ip, nullptr, lane);
@@ -326,7 +339,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         const pixel* best = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * w + pl) * P.slot_pixels;
         const pixel* last = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * 4 + pl) * P.slot_pixels;
         reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = best[y * C.tu.recon_stride + x];
-        reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = last[y * C.tu.recon_stride + x];
+        if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = last[y * C.tu.recon_stride + x];
         po->clevels[pl][i] = s_clev[w][pl][i];
     }
 }

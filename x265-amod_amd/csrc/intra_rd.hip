@@ -12,6 +12,7 @@
  */
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
+#include "xa_queue.h"
 #include "../host/cabac_coder.h"
 #include <string.h>
 #include <vector>
@@ -57,7 +58,16 @@ struct IntraRd
     uint64_t predTile, reconTile;
     DevBuf dResi, dLayer, dCand;
     MappedBuf dJobs; XaMapped dScanJob, dPuJob, dNxnJob; XaMappedOut dRes, dCoeff, dScan, dPuOut, dNxnOut;
-    DevBuf dCoeffDev;                                   /* candidate levels / residuals of the device-decided NxN path (device memory: only the winner's levels travel) */      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    DevBuf dCoeffDev;                                   /* candidate levels / residuals of the device-decided NxN path (device memory: only the winner's levels travel) */
+    /* The NxN evaluation of an 8x8 CU beside its 2Nx2N evaluation, on a second device job queue: both start from the same contexts and read the same
+     * neighbours, neither needs the other's result -- only the reference's ORDER has 2Nx2N first, and the order matters for what the picture holds afterwards
+     * (the last tried mode's samples), which the NxN command writes while the 2Nx2N command is told to leave the picture alone.  helper: the second queue;
+     * hintPred / hintRecon: the NxN mode's tiles, announced by the caller before the 2Nx2N call; ahead: a running NxN command and the CU it belongs to.  Its
+     * scratch is a set of its own (two workgroups write at the same time). */
+    void* helper = nullptr;
+    uint64_t hintPred = 0, hintRecon = 0;
+    struct Ahead { bool on = false; int x = 0, y = 0; } ahead;
+    DevBuf dCand2, dCoeffDev2; XaMapped dNxnJob2; XaMappedOut dNxnOut2;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -389,40 +399,25 @@ struct IntraRd
     bool haveDevChroma = false;
     bool lumaTileDone = false;                  /* the mode's reconstruction tile already holds the CU's luma (written with the winner's other copies) */
 
-    /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
-     * best mode again with TU splits allowed */
-    int estIntraPredQT(int partSize, int rdLevel, sse_t& totalDistortion)
+    /* the job record of x265amd_intra_nxn for this CU coded NxN (partSize 3: four 4x4 units) or 2Nx2N (one 8x8 unit); tiles: the mode's prediction / reconstruction
+     * tiles; cand / coeffDev: the command's scratch */
+    void buildDevJob(x265amd_intra_nxn_job& nj, int partSize, int rdLevel, uint64_t predTileM, uint64_t reconTileM, uint64_t cand, uint64_t coeffDev)
     {
-        const int initTuDepth = partSize != 0, numPU = 1 << (2 * initTuDepth), log2TrSize = log2 - initTuDepth, tuSize = 1 << log2TrSize;
-        totalDistortion = 0;
-        /* An 8x8 CU coded NxN: the four 4x4 units with their decisions are ONE launch (x265amd_intra_nxn) -- a 4x4 unit has no transform split to try and its
-         * coefficients are few enough for the device to count their bits, so nothing of the host's enters between the units.  The host repeats the winners'
-         * bookkeeping (units, bits, contexts) afterwards.  Not with RDOQ (the quantiser then reads bit estimates of the current contexts per unit). */
-        x265amd_intra_nxn_out nxn;
-        /* The device routine also takes the same CU coded 2Nx2N -- one 8x8 unit, num_units = 1, chroma decision included: one round trip instead of two and no
-         * candidate bits on the host.  (It paid only once the bits of a unit were counted by a wavefront, a lane per context: a single lane needs 45 us for the 64
-         * coefficients.)  X265AMD_DEVICE_2Nx2N=0 takes the prediction-unit step with host bits instead. */
-        static const bool dev2Nx2N = !(getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) == 0);
-        const bool deviceNxN = log2 == 3 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
-                               (partSize != 0 ? (log2TrSize == 2 && range[0] == 2) : (dev2Nx2N && range[0] == 3 && range[1] >= 3));
+        const int initTuDepth = partSize != 0;
         const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
-        if (deviceNxN)
-        {
-            xa_phase(XA_PH_INTRA_CAND);
-            const size_t isz = sizeof(pixel);
-            x265amd_intra_nxn_job nj;
+        const size_t isz = sizeof(pixel);
             memset(&nj, 0, sizeof(nj));
-            const uint64_t slot0 = (uint64_t)(uintptr_t)dCand.p;
+            const uint64_t slot0 = cand;
             for (int k = 0; k < devUnits; k++)
             {
                 const int px = cuX + (k & 1) * 4, py = cuY + (k >> 1) * 4;
                 fillJob(nj.tmpl[k], 0, px, py, devLog2, 0, slot0 + 1024 * isz, devN, slot0, devN, 0);
-                nj.tmpl[k].tu.coeff = (uint64_t)(uintptr_t)dCoeffDev.p;
-                nj.tmpl[k].tu.resi = (uint64_t)(uintptr_t)dCoeffDev.p + (size_t)MAX_JOBS * 1024 * 2; nj.tmpl[k].tu.resi_stride = devN;
+                nj.tmpl[k].tu.coeff = coeffDev;
+                nj.tmpl[k].tu.resi = coeffDev + (size_t)MAX_JOBS * 1024 * 2; nj.tmpl[k].tu.resi_stride = devN;
                 nj.tmpl[k].avail = available(px, py, devN);
-                nj.pred_dst[k] = predTile + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
+                nj.pred_dst[k] = predTileM + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
                 nj.layer_dst[k] = (uint64_t)(uintptr_t)dLayer.p + ((size_t)(devLog2 - 2) * 4096 + (size_t)(py - cuY) * 64 + (px - cuX)) * isz;     /* the units' layer */
-                nj.recon_dst[k] = reconTile + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
+                nj.recon_dst[k] = reconTileM + ((size_t)(py - cuY) * 64 + (px - cuX)) * isz;
                 nj.frac_start[k] = cur.frac & 32767;
             }
             nj.num_units = (uint8_t)devUnits; nj.unit_log2 = (uint8_t)devLog2;
@@ -460,16 +455,72 @@ struct IntraRd
                 {
                     fillJob(nj.ctmpl[pl - 1], pl, cuX, cuY, 2, 0, 0, 4, slot0, 4, 0);
                     nj.ctmpl[pl - 1].avail = avail;
-                    nj.ctmpl[pl - 1].tu.coeff = (uint64_t)(uintptr_t)dCoeffDev.p;
-                    nj.ctmpl[pl - 1].tu.resi = (uint64_t)(uintptr_t)dCoeffDev.p + (size_t)MAX_JOBS * 1024 * 2; nj.ctmpl[pl - 1].tu.resi_stride = 4;
-                    nj.crecon_dst[pl - 1] = reconTile + (4096 + (size_t)(pl - 1) * 1024) * isz;
+                    nj.ctmpl[pl - 1].tu.coeff = coeffDev;
+                    nj.ctmpl[pl - 1].tu.resi = coeffDev + (size_t)MAX_JOBS * 1024 * 2; nj.ctmpl[pl - 1].tu.resi_stride = 4;
+                    nj.crecon_dst[pl - 1] = reconTileM + (4096 + (size_t)(pl - 1) * 1024) * isz;
                 }
                 nj.do_chroma = 1;
             }
-            memcpy(dNxnJob.p, &nj, sizeof(nj));
-            if (x265amd_intra_nxn(st, (const x265amd_intra_nxn_job*)dNxnJob.p, (x265amd_intra_nxn_out*)dNxnOut.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
-                return fail("intra rd: NxN step");
-            memcpy(&nxn, dNxnOut.p, sizeof(nxn));
+    }
+
+    /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
+     * best mode again with TU splits allowed */
+    int estIntraPredQT(int partSize, int rdLevel, sse_t& totalDistortion)
+    {
+        const int initTuDepth = partSize != 0, numPU = 1 << (2 * initTuDepth), log2TrSize = log2 - initTuDepth, tuSize = 1 << log2TrSize;
+        totalDistortion = 0;
+        /* An 8x8 CU coded NxN: the four 4x4 units with their decisions are ONE launch (x265amd_intra_nxn) -- a 4x4 unit has no transform split to try and its
+         * coefficients are few enough for the device to count their bits, so nothing of the host's enters between the units.  The host repeats the winners'
+         * bookkeeping (units, bits, contexts) afterwards.  Not with RDOQ (the quantiser then reads bit estimates of the current contexts per unit). */
+        x265amd_intra_nxn_out nxn;
+        /* The device routine also takes the same CU coded 2Nx2N -- one 8x8 unit, num_units = 1, chroma decision included: one round trip instead of two and no
+         * candidate bits on the host.  (It paid only once the bits of a unit were counted by a wavefront, a lane per context: a single lane needs 45 us for the 64
+         * coefficients.)  X265AMD_DEVICE_2Nx2N=0 takes the prediction-unit step with host bits instead. */
+        static const bool dev2Nx2N = !(getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) == 0);
+        const bool deviceNxN = log2 == 3 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
+                               (partSize != 0 ? (log2TrSize == 2 && range[0] == 2) : (dev2Nx2N && range[0] == 3 && range[1] >= 3));
+        const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
+        if (deviceNxN)
+        {
+            xa_phase(XA_PH_INTRA_CAND);
+            const bool mine = ahead.on && partSize != 0 && ahead.x == cuX && ahead.y == cuY;
+            if (mine)
+            {
+                /* this CU's NxN command has been running on the second queue since the 2Nx2N call: its results, and what it wrote for the first queue to see */
+                ahead.on = false;
+                if (xa_stream_sync(helper) != hipSuccess) return fail("intra rd: NxN step");
+                memcpy(&nxn, dNxnOut2.p, sizeof(nxn));
+                if (xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) return fail("intra rd: fence");
+            }
+            else
+            {
+                ahead.on = false;
+                x265amd_intra_nxn_job nj;
+                /* the NxN command first, on the second queue, when the caller has announced that mode's tiles (an 8x8 CU of an I picture): everything this queue has
+                 * written is out (synchronised: a signalling command releases), the other workgroup looks (acquire) */
+                const uint32_t loN = (uint32_t)log2 - (uint32_t)(si->tu_max_depth_intra - 1 + 1);           /* the NxN call's transform range, as intra_cu_impl will find it */
+                const int rangeN0 = loN < (uint32_t)si->tu_log2_min ? si->tu_log2_min : (loN > (uint32_t)si->tu_log2_max ? si->tu_log2_max : (int)loN);
+                const bool goAhead = partSize == 0 && helper && hintPred && hintRecon && rangeN0 == 2 && 2 + rdLevel + ((depth + 1) >> 1) <= MAX_JOBS && dCand2.p;
+                if (goAhead)
+                {
+                    const uint8_t keep = U(cuX, cuY).part_size;
+                    U(cuX, cuY).part_size = 3;
+                    buildDevJob(nj, 3, rdLevel, hintPred, hintRecon, (uint64_t)(uintptr_t)dCand2.p, (uint64_t)(uintptr_t)dCoeffDev2.p);
+                    U(cuX, cuY).part_size = keep;
+                    memcpy(dNxnJob2.p, &nj, sizeof(nj));
+                    if (xa_stream_sync(st) != hipSuccess || xa_stream_fence(helper, XA_CMD_ACQUIRE) != hipSuccess ||
+                        x265amd_intra_nxn(helper, (const x265amd_intra_nxn_job*)dNxnJob2.p, (x265amd_intra_nxn_out*)dNxnOut2.p) != X265AMD_OK)
+                        return fail("intra rd: NxN step ahead");
+                    ahead.on = true; ahead.x = cuX; ahead.y = cuY;
+                }
+                hintPred = hintRecon = 0;
+                buildDevJob(nj, partSize, rdLevel, predTile, reconTile, (uint64_t)(uintptr_t)dCand.p, (uint64_t)(uintptr_t)dCoeffDev.p);
+                nj.no_picture = goAhead ? 1 : 0;
+                memcpy(dNxnJob.p, &nj, sizeof(nj));
+                if (x265amd_intra_nxn(st, (const x265amd_intra_nxn_job*)dNxnJob.p, (x265amd_intra_nxn_out*)dNxnOut.p) != X265AMD_OK || xa_stream_sync(st) != hipSuccess)
+                    return fail("intra rd: NxN step");
+                memcpy(&nxn, dNxnOut.p, sizeof(nxn));
+            }
             haveNxn = partSize != 0; nxnPsy = nxn.psy_energy; nxnRes = nxn.res_energy;      /* (one 8x8 unit: the unit's own result, haveWhole) */
             haveDevChroma = true; lumaTileDone = true;
             nxnChroma = nxn;
@@ -848,6 +899,14 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     IntraRd* ip = ws && *ws ? static_cast<IntraRd*>(*ws) : new IntraRd;
     if (ws) *ws = ip;
     IntraRd& R = *ip;
+    R.helper = xa_queue_helper(stream);
+    if (R.ahead.on && !(kind == 1 && partSize == 3 && R.ahead.x == cu->x && R.ahead.y == cu->y))
+    {
+        /* a command started ahead that nobody came for: let it finish before anything else touches what it writes */
+        R.ahead.on = false;
+        if (xa_stream_sync(R.helper) != hipSuccess || xa_stream_fence(stream, XA_CMD_ACQUIRE) != hipSuccess) return xa_fail(X265AMD_EHIP, "intra rd: second queue");
+    }
+    if (kind != 1 || partSize != 0 || cu->log2_size != 3) R.hintPred = R.hintRecon = 0;
     R.haveWhole = false; R.haveNxn = false; R.haveDevChroma = false; R.lumaTileDone = false;
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.cuX = cu->x; R.cuY = cu->y; R.log2 = cu->log2_size; R.size = 1 << R.log2; R.depth = 6 - R.log2; R.qp = cu->qp; R.err = 0;
@@ -884,6 +943,10 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
         R.dJobs.free();         /* a partly made working set is made again next time */
     }
+    if (rc == X265AMD_OK && R.helper && !R.dCand2.p &&
+        (R.dCand2.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dCoeffDev2.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
+         R.dNxnJob2.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut2.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess))
+        rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     if (rc == X265AMD_OK && rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)         /* the table is only read by RDOQ */
         rc = xa_fail(X265AMD_EHIP, "intra rd: fill");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
@@ -1046,7 +1109,19 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     return rc;
 }
 
-void xa_intra_ws_free(void* ws) { delete static_cast<IntraRd*>(ws); }
+void xa_intra_ws_free(void* ws)
+{
+    IntraRd* ip = static_cast<IntraRd*>(ws);
+    if (ip && ip->ahead.on && ip->helper) (void)xa_stream_sync(ip->helper);          /* its buffers are about to go back to the pool */
+    delete ip;
+}
+void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn)
+{
+    if (!ws) return;
+    if (!*ws) *ws = new IntraRd;
+    IntraRd* ip = static_cast<IntraRd*>(*ws);
+    ip->hintPred = d_pred_nxn; ip->hintRecon = d_recon_nxn;
+}
 int xa_check_intra_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
                       intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, int part_size, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon,
                       x265amd_rd_result* out, int16_t* coeff_out, void** ws)

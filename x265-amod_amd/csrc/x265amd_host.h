@@ -60,6 +60,10 @@ inline bool xa_is_queue(const void* st) { return ((uintptr_t)st & 1) != 0; }
 bool xa_queues_enabled();
 void* xa_queue_acquire();               /* NULL when queues are off (X265AMD_QUEUES=0) or all are taken: use a stream then */
 void xa_queue_release(void* st);
+void* xa_queue_try_acquire();           /* a second queue for the holder of a first one, or NULL at once: never waits */
+void xa_queue_release_helper(void* st);
+void xa_queue_set_helper(void* st, void* helper);       /* the second queue rides on the first: whoever gets `st` finds it with xa_queue_helper */
+void* xa_queue_helper(void* st);
 void xa_queue_log(void* st, int poc, int row);      /* X265AMD_QUEUE_LOG=poc,row: the command / wait timeline of that row goes to stderr when the queue is given back */
 hipError_t xa_stream_sync(void* st);
 hipError_t xa_stream_fence(void* st, int flags);
@@ -98,6 +102,9 @@ int xa_intra_in_inter_ws(void* stream, const x265amd_slice_info* si, const x265a
                          intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out,
                          int16_t* coeff_out, uint64_t* info, void** ws);
 void xa_intra_ws_free(void* ws);
+/* before xa_check_intra_ws(.., part_size 0, ..) of an 8x8 CU that will be tried as NxN next: the NxN mode's tiles.  With a second queue on the stream
+ * (xa_queue_helper) the NxN evaluation then starts beside the 2Nx2N one; the NxN call that follows collects it. */
+void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn);
 
 /* the skip and the residual measurement of a merge candidate together (csrc/inter_rd.hip) */
 int xa_merge_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
