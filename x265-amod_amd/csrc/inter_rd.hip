@@ -398,7 +398,7 @@ static void rd_lambdas(const x265amd_slice_info* si, const x265amd_rd_params* rp
 
 /* the nodes of one CU's tree; jobs == NULL: only the plan */
 static int make_plan(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int part, CuPlan& P, int firstJob, const uint64_t* src, intptr_t stride, intptr_t cstride,
-                     uint64_t tile, uint64_t scratch, std::vector<x265amd_tu_job>* jobs)
+                     uint64_t tile, uint64_t scratch, std::vector<x265amd_tu_job>* jobs, uint64_t levels = 0)
 {
     static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
                                              32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };       /* H.265 table 8-10 */
@@ -420,7 +420,9 @@ static int make_plan(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int 
     const int hi = P.log2 < P.range[1] ? P.log2 : P.range[1];
     for (int L = 0; L < 6; L++) P.lumaRes[L] = -1;
     for (int C = 0; C < 5; C++) P.chromaRes[C][0] = P.chromaRes[C][1] = P.chromaRes[C][2] = -1;
-    const uint64_t levelBase = scratch, resiBase = scratch + (uint64_t)RD_SCRATCH_ELEMS * 2, dumpBase = scratch + (uint64_t)RD_SCRATCH_ELEMS * 4;
+    /* levels: where the chains leave the quantised levels when not at the head of the scratch -- pinned host memory, so that they reach the host with the
+     * chains' own stores instead of a copy command behind them (the whole level area of a CU is 45 KB, a small CU uses a fraction) */
+    const uint64_t levelBase = levels ? levels : scratch, resiBase = scratch + (uint64_t)RD_SCRATCH_ELEMS * 2, dumpBase = scratch + (uint64_t)RD_SCRATCH_ELEMS * 4;
     int count = firstJob;
     x265amd_tu_job j;
     memset(&j, 0, sizeof(j));
@@ -475,8 +477,16 @@ static int make_plan(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int 
 
 extern "C" size_t x265amd_inter_rd_scratch_bytes(void) { return (size_t)RD_SCRATCH_ELEMS * (2 + 2 + sizeof(pixel)); }
 
+static int inter_rd_plan_levels(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
+                                intptr_t stride, intptr_t cstride, uint64_t pred, size_t tile_bytes, uint64_t scratch, x265amd_tu_job* jobs_out, int cap, uint64_t levels);
 extern "C" int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
                                      intptr_t stride, intptr_t cstride, uint64_t pred, size_t tile_bytes, uint64_t scratch, x265amd_tu_job* jobs_out, int cap)
+{
+    return inter_rd_plan_levels(si, cus, n, cu_units, src, stride, cstride, pred, tile_bytes, scratch, jobs_out, cap, 0);
+}
+/* levels != 0: CU i's levels go to levels + i * RD_SCRATCH_ELEMS * 2 (same layout as the head of its scratch) */
+static int inter_rd_plan_levels(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
+                                intptr_t stride, intptr_t cstride, uint64_t pred, size_t tile_bytes, uint64_t scratch, x265amd_tu_job* jobs_out, int cap, uint64_t levels)
 {
     if (!si || !cus || !cu_units || !src || n < 0) return xa_fail(X265AMD_EINVAL, "inter_rd_plan: null argument");
     std::vector<x265amd_tu_job> jobs;
@@ -485,7 +495,8 @@ extern "C" int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd
     for (int i = 0; i < n; i++)
     {
         CuPlan P;
-        count = make_plan(si, cus[i], cu_units[(size_t)i * 256].part_size, P, count, src, stride, cstride, pred + (uint64_t)tile_bytes * i, scratch + (uint64_t)perCu * i, &jobs);
+        count = make_plan(si, cus[i], cu_units[(size_t)i * 256].part_size, P, count, src, stride, cstride, pred + (uint64_t)tile_bytes * i, scratch + (uint64_t)perCu * i, &jobs,
+                          levels ? levels + (uint64_t)RD_SCRATCH_ELEMS * 2 * i : 0);
         if (count < 0) return count;
     }
     if (jobs_out)
@@ -827,8 +838,8 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
 
     /* ---- plan + launch 1: all transform chains and the no-residual measurement ---- */
     const size_t perCuBytes = x265amd_inter_rd_scratch_bytes();
-    DevBuf dScratch, dSel;
-    XaMapped mJobs, mMJobs; XaMappedOut mRes, mMeas, mLevels;       /* records the kernels touch once: host memory, read / written in place */
+    DevBuf dScratch;
+    XaMapped mJobs, mMJobs, dSel; XaMappedOut mRes, mMeas, mLevels;       /* records the kernels touch once: host memory, read / written in place (dSel: host writes, the assembly reads) */
     XA_HIP_CHECK(dScratch.alloc(perCuBytes * n));
     char* scratch = (char*)dScratch.p;
     const int nJobs = x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, nullptr, 0);
@@ -839,8 +850,9 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * n * 2));
     XA_HIP_CHECK(mLevels.alloc((size_t)RD_SCRATCH_ELEMS * 2 * n));
     XA_HIP_CHECK(dSel.alloc((size_t)RD_SEL_BYTES * n));
-    x265amd_inter_rd_plan(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs);
     const bool rdoq = rp->rdoq_level != 0;
+    inter_rd_plan_levels(si, cus, n, cu_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs,
+                         rdoq ? 0 : (uint64_t)(uintptr_t)mLevels.p);        /* without RDOQ the chains write the levels where the host reads them */
     int rc = X265AMD_OK;
     if (!rdoq)
     {
@@ -854,8 +866,6 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
       if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, n, meas);
       else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas);
       XA_HIP_CHECK(le); }
-    /* the levels (the head of each CU's scratch) come to pinned host memory in one strided copy */
-    if (!rdoq) XA_HIP_CHECK(xa_copy2d_to_mapped_async(stream_, mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, n));
     XA_HIP_CHECK(xa_stream_sync(stream_));
 
     /* ---- the walk ---- */
@@ -905,7 +915,7 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
 
     /* ---- launch 2: assemble, reconstruct, measure ---- */
     for (int i = 0; i < n; i++) mjobs[i].assemble = 1;
-    XA_HIP_CHECK(xa_copy_async(stream_, dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice));
+    memcpy(dSel.p, sel.data(), sel.size());
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + n), 0, 0, n }; hipError_t le;
       if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, n, meas + n);
       else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure, dim3(n), dim3(64), 0, (const CuMeasureJob*)mjobs, n, meas + n);
@@ -930,8 +940,8 @@ int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_pa
     if (rp->rdoq_level || si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "merge_rd: RDOQ / lossless go through the separate entry points");
     const size_t tile_bytes = (size_t)(4096 + 2048) * sizeof(pixel);
     const size_t perCuBytes = x265amd_inter_rd_scratch_bytes();
-    DevBuf dScratch, dSel;
-    XaMapped mJobs, mMJobs; XaMappedOut mRes, mMeas, mLevels;
+    DevBuf dScratch;
+    XaMapped mJobs, mMJobs, dSel; XaMappedOut mRes, mMeas, mLevels;
     XA_HIP_CHECK(dScratch.alloc(perCuBytes));
     char* scratch = (char*)dScratch.p;
     const int nJobs = x265amd_inter_rd_plan(si, cu, 1, merge_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, nullptr, 0);
@@ -942,7 +952,7 @@ int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_pa
     XA_HIP_CHECK(mMeas.alloc(sizeof(x265amd_cu_measure) * 2));
     XA_HIP_CHECK(mLevels.alloc((size_t)RD_SCRATCH_ELEMS * 2));
     XA_HIP_CHECK(dSel.alloc((size_t)RD_SEL_BYTES));
-    x265amd_inter_rd_plan(si, cu, 1, merge_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs);
+    inter_rd_plan_levels(si, cu, 1, merge_units, h_src, stride, cstride, d_pred, tile_bytes, (uint64_t)(uintptr_t)scratch, (x265amd_tu_job*)mJobs.p, nJobs, (uint64_t)(uintptr_t)mLevels.p);
     int rc = x265amd_tu_chain(stream_, (const x265amd_tu_job*)mJobs.p, nJobs, (x265amd_tu_result*)mRes.p);
     if (rc != X265AMD_OK) return rc;
     CuMeasureJob* mjobs = (CuMeasureJob*)mMJobs.p;
@@ -952,7 +962,6 @@ int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_pa
       if (measure_use_wg(1)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure_wg, dim3(1), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, 1, meas);
       else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure, dim3(1), dim3(64), 0, (const CuMeasureJob*)mjobs, 1, meas);
       XA_HIP_CHECK(le); }
-    XA_HIP_CHECK(xa_copy2d_to_mapped_async(stream_, mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, scratch, perCuBytes, (size_t)RD_SCRATCH_ELEMS * 2, 1));
     xa_phase(XA_PH_RD_PLAN);
     XA_HIP_CHECK(xa_stream_sync(stream_));
     xa_phase(XA_PH_OTHER);
@@ -978,7 +987,7 @@ int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_pa
     if (rc != X265AMD_OK) return rc;
     xa_phase(XA_PH_RD_WALK);
     mjobs[0].assemble = 1; mjobs[0].recon = d_recon_merge;
-    XA_HIP_CHECK(xa_copy_async(stream_, dSel.p, sel.data(), sel.size(), hipMemcpyHostToDevice));
+    memcpy(dSel.p, sel.data(), sel.size());
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + 1), 0, 0, 1 }; hipError_t le;
       if (measure_use_wg(1)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure_wg, dim3(1), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, 1, meas + 1);
       else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure, dim3(1), dim3(64), 0, (const CuMeasureJob*)mjobs, 1, meas + 1);
