@@ -571,6 +571,7 @@ struct XaQueue
     struct Ev { uint64_t wallNs, runNs; char kind; int op; };
     std::vector<Ev> log; bool logging = false; int logPoc = 0, logRow = 0;
     void* helper = nullptr;             /* a second queue the holder of this one may use beside it (xa_queue_set_helper) */
+    uint32_t nextFlags = 0;             /* flags the next command gets on top of its own (xa_q_next_flags) */
     void ev(char kind, int op)
     {
         if (!logging) return;
@@ -915,10 +916,15 @@ void xa_queue_release(void* st)
     if (--S.refs == 0) S.stop();
 }
 
+/* the next command of the queue also carries `flags` (XA_CMD_ACQUIRE before a command that reads tables the host has just pushed into reused memory: the
+ * scalar data cache may still hold the block's previous contents) -- cheaper than a command of its own; streams: nothing to do */
+void xa_q_next_flags(void* st, int flags) { if (xa_is_queue(st)) as_queue(st)->nextFlags |= (uint32_t)flags; }
+
 hipError_t xa_q_enqueue(void* st, int op, const void* args, size_t argBytes, int count, int flags)
 {
     static const bool trace = getenv("X265AMD_QUEUE_TRACE") != nullptr;     /* debugging: name every command and wait for it */
     XaQueue* q = as_queue(st);
+    flags |= (int)q->nextFlags; q->nextFlags = 0;
     if (trace)
     {
         static const auto t00 = std::chrono::steady_clock::now();

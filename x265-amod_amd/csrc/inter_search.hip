@@ -13,6 +13,7 @@
  * Not supported (rejected or absent): weighted prediction, HME, analysis reuse, distributed ME, frame-parallel lag clipping.
  */
 #include "inter_common.h"
+#include "xa_queue.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -79,11 +80,16 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     std::vector<uint64_t> lumaTab(num_pics), chromaTab(2 + 2 * num_pics);
     for (int i = 0; i < num_pics; i++) { lumaTab[i] = h_planes[3 * i]; chromaTab[2 + 2 * i] = h_planes[3 * i + 1]; chromaTab[3 + 2 * i] = h_planes[3 * i + 2]; }
     chromaTab[0] = h_planes[3 * srcPic + 1]; chromaTab[1] = h_planes[3 * srcPic + 2];
-    Dev dPlanes, dLuma, dChroma;
-    if (dPlanes.alloc(num_pics * 24) || dLuma.alloc(num_pics * 8) || dChroma.alloc(chromaTab.size() * 8)) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
-    XA_HIP_CHECK(xa_copy_async(st, dPlanes.p, h_planes, num_pics * 24, hipMemcpyHostToDevice));
-    XA_HIP_CHECK(xa_copy_async(st, dLuma.p, lumaTab.data(), num_pics * 8, hipMemcpyHostToDevice));
-    XA_HIP_CHECK(xa_copy_async(st, dChroma.p, chromaTab.data(), chromaTab.size() * 8, hipMemcpyHostToDevice));
+    /* Tables and job records are pushed into device memory by the host (XaMapped), results come back in pinned host memory (XaMappedOut): no copy commands.
+     * The kernels read the tables and the search's group / job records with plain (partly scalar) loads, and the pool hands out reused blocks: the first
+     * command behind a push carries an acquire, which also empties the scalar data cache. */
+    XaMapped dPlanes, dLuma, dChroma;
+    if (dPlanes.alloc(num_pics * 24) != hipSuccess || dLuma.alloc(num_pics * 8) != hipSuccess || dChroma.alloc(chromaTab.size() * 8) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
+    memcpy(dPlanes.p, h_planes, (size_t)num_pics * 24);
+    memcpy(dLuma.p, lumaTab.data(), (size_t)num_pics * 8);
+    memcpy(dChroma.p, chromaTab.data(), chromaTab.size() * 8);
+    xa_q_next_flags(st, XA_CMD_ACQUIRE);
     const uint64_t* dFencTab = (const uint64_t*)dPlanes.p + 3 * srcPic;
 
     struct CuState { int numPart, lastMode, totalBits; };
@@ -117,19 +123,19 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
         size_t arena = 0;
         std::vector<size_t> offs(jobs.size());
         for (size_t i = 0; i < jobs.size(); i++) { offs[i] = arena; arena += ((size_t)jobs[i].w * jobs[i].h * 3 / 2 * isz + 63) & ~(size_t)63; }
-        Dev dArena, dJobs, dCost;
-        if (dArena.alloc(arena) || dJobs.alloc(jobs.size() * sizeof(x265amd_mc_job)) || dCost.alloc(cost.size() * 4)) return -1;
+        Dev dArena; XaMapped dJobs; XaMappedOut dCost;
+        if (dArena.alloc(arena) || dJobs.alloc(jobs.size() * sizeof(x265amd_mc_job)) != hipSuccess || dCost.alloc(cost.size() * 4) != hipSuccess) return -1;
         for (size_t i = 0; i < jobs.size(); i++)
         {
             const uint64_t b = (uint64_t)(uintptr_t)dArena.p + offs[i];
             jobs[i].dst_y = b; jobs[i].dst_u = b + (size_t)jobs[i].w * jobs[i].h * isz; jobs[i].dst_v = jobs[i].dst_u + (size_t)jobs[i].w * jobs[i].h / 4 * isz;
             jobs[i].dst_stride = jobs[i].w; jobs[i].dst_cstride = jobs[i].w / 2;
         }
-        if (xa_copy_async(st, dJobs.p, jobs.data(), jobs.size() * sizeof(x265amd_mc_job), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        memcpy(dJobs.p, jobs.data(), jobs.size() * sizeof(x265amd_mc_job));
         if (x265amd_inter_cost(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, (int)jobs.size(),
                                dFencTab, stride, cstride, (uint32_t*)dCost.p) != X265AMD_OK) return -1;
-        if (xa_copy_async(st, cost.data(), dCost.p, cost.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (xa_stream_sync(st) != hipSuccess) return -1;
+        memcpy(cost.data(), dCost.p, cost.size() * 4);
         return 0;
     };
 
@@ -291,11 +297,13 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 for (size_t k = 0; k < sub.size(); k++) { ordered.push_back(sub[order[k]]); origin.push_back(idx[order[k]]); }
             }
             for (const x265amd_me_job& j : mj) { if ((j.method & 0x7f) == X265AMD_ME_STAR) flags |= X265AMD_ME_FLAG_STAR; if (j.method & X265AMD_ME_CHROMA_SATD) flags |= X265AMD_ME_FLAG_CHROMA; }
-            Dev dJ, dG, dO;
-            if (dJ.alloc(ordered.size() * sizeof(x265amd_me_job)) || dG.alloc(groups.size() * sizeof(x265amd_me_group)) || dO.alloc(ordered.size() * sizeof(x265amd_me_result)))
+            XaMapped dJ, dG; Dev dO;           /* the results stay in device memory: the deferred pass reads what the first pass left there */
+            if (dJ.alloc(ordered.size() * sizeof(x265amd_me_job)) != hipSuccess || dG.alloc(groups.size() * sizeof(x265amd_me_group)) != hipSuccess ||
+                dO.alloc(ordered.size() * sizeof(x265amd_me_result)))
                 return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
-            XA_HIP_CHECK(xa_copy_async(st, dJ.p, ordered.data(), ordered.size() * sizeof(x265amd_me_job), hipMemcpyHostToDevice));
-            XA_HIP_CHECK(xa_copy_async(st, dG.p, groups.data(), groups.size() * sizeof(x265amd_me_group), hipMemcpyHostToDevice));
+            memcpy(dJ.p, ordered.data(), ordered.size() * sizeof(x265amd_me_job));
+            memcpy(dG.p, groups.data(), groups.size() * sizeof(x265amd_me_group));
+            xa_q_next_flags(st, XA_CMD_ACQUIRE);
             int rc = x265amd_me_search(me, st, (const x265amd_pixel*)(uintptr_t)h_planes[3 * srcPic], (const uint64_t*)dLuma.p, stride, (const x265amd_me_group*)dG.p, (int)groups.size(),
                                        (const x265amd_me_job*)dJ.p, (x265amd_me_result*)dO.p, maxW, maxH, flags, (const uint64_t*)dChroma.p, cstride);
             if (rc != X265AMD_OK) return rc;
@@ -467,9 +475,9 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     }
     /* ---- final predictions ---- */
     {
-        Dev dJ;
-        if (dJ.alloc(finalMc.size() * sizeof(x265amd_mc_job))) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
-        XA_HIP_CHECK(xa_copy_async(st, dJ.p, finalMc.data(), finalMc.size() * sizeof(x265amd_mc_job), hipMemcpyHostToDevice));
+        XaMapped dJ;
+        if (dJ.alloc(finalMc.size() * sizeof(x265amd_mc_job)) != hipSuccess) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
+        memcpy(dJ.p, finalMc.data(), finalMc.size() * sizeof(x265amd_mc_job));
         int rc = x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJ.p, (int)finalMc.size());
         if (rc != X265AMD_OK) return rc;
         XA_HIP_CHECK(xa_stream_sync(st));
