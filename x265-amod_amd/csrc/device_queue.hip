@@ -323,6 +323,18 @@ template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int ti
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const MeParams p = *reinterpret_cast<const MeParams*>(c.args);
     const int groups = (int)c.count;
+    if (WHICH != 2 && me_multi_fits(p, groups, XA_SERVER_WAVES, XA_SERVER_LDS))
+    {
+        /* one job per group (the searches of one prediction unit, a reference picture each): side by side, a wavefront each */
+        bool single = true;
+        for (int vb = 0; vb < groups; vb++) single &= p.groups[vb].num_jobs == 1;
+        if (single)
+        {
+            if (WHICH == 0) block_me_search_multi<false>(p, groups, tid, NT); else block_me_search_multi<true>(p, groups, tid, NT);
+            __syncthreads();
+            return;
+        }
+    }
     for (int vb = 0; vb < groups; vb++)
     {
         if (WHICH == 0) block_me_search<false>(p, vb, tid, NT);

@@ -1073,6 +1073,59 @@ template<bool STAR> XA_DEV void block_me_search(const MeParams& p, int vb, int t
     }
 }
 
+/* The groups of one command side by side (device job server: the searches of ONE prediction unit in its reference pictures arrive as groups of one job each, and
+ * a workgroup that takes them one after the other keeps seven of its eight wavefronts idle): every group gets a window and a source tile of its own in LDS, all
+ * are staged together, then wavefront k runs the job of group k.  The caller has checked that the groups hold one job each, that there are no more of them than
+ * wavefronts and that the LDS holds them (me_multi_fits). */
+XA_DEV size_t me_multi_region_bytes(const MeParams& p) { return (((size_t)p.maxWinW * p.maxWinH + 16 + 64 * 64) * sizeof(pixel) + 15) & ~(size_t)15; }
+XA_DEV bool me_multi_fits(const MeParams& p, int groups, int waves, size_t ldsBytes)
+{
+    return groups > 1 && groups <= waves && (size_t)groups * me_multi_region_bytes(p) + 16 + (size_t)waves * sizeof(MeState) <= ldsBytes;
+}
+template<bool STAR> XA_DEV void block_me_search_multi(const MeParams& p, int groups, int tid, int nthr)
+{
+    char* smem = me_smem;
+    const size_t region = me_multi_region_bytes(p);
+    const int wv = tid >> 6, lane = tid & 63;
+    const int sOff = (int)((size_t)groups * region + 16) + wv * (int)sizeof(MeState);
+    MeState& s = *reinterpret_cast<MeState*>(smem + sOff);
+    for (int gi = 0; gi < groups; gi++)
+    {
+        const x265amd_me_group g = p.groups[gi];
+        const pixel* refG = reinterpret_cast<const pixel*>(p.refs[g.ref]);
+        pixel* win = reinterpret_cast<pixel*>(smem + (size_t)gi * region);
+        pixel* fencT = win + p.maxWinW * p.maxWinH + 16;
+        const int gpr = g.win_w >> 2, total = gpr * g.win_h;
+        for (int i = tid; i < total; i += nthr)
+        {
+            const int y = i / gpr, x = (i - y * gpr) << 2;
+            pixel v[4];
+            __builtin_memcpy(v, refG + (long)(g.win_y + y) * p.stride + g.win_x + x, sizeof(v));
+            __builtin_memcpy(win + y * g.win_w + x, v, sizeof(v));
+        }
+        for (int i = tid; i < 16 * 64; i += nthr)
+        {
+            const int y = i >> 4, x = (i & 15) << 2;
+            pixel v[4];
+            __builtin_memcpy(v, p.fenc + (long)(g.fenc_y + y) * p.stride + g.fenc_x + x, sizeof(v));
+            __builtin_memcpy(fencT + y * 64 + x, v, sizeof(v));
+        }
+    }
+    __syncthreads();
+    if (wv < groups)
+    {
+        const x265amd_me_group g = p.groups[wv];
+        const pixel* refG = reinterpret_cast<const pixel*>(p.refs[g.ref]);
+        pixel* win = reinterpret_cast<pixel*>(smem + (size_t)wv * region);
+        pixel* fencT = win + p.maxWinW * p.maxWinH + 16;
+        const x265amd_me_job* jp = p.jobs + g.first_job;
+        if (lane == 0) me_set_job(s, *jp, g, p, win, g.win_w, g.win_h, fencT, refG);
+        xa_wave_sync();
+        me_search<false, STAR>(sOff, jp, p.out + g.first_job);
+        xa_wave_sync();
+    }
+}
+
 /* direct-from-HBM kernel: redoes the jobs the window-resident kernel marked ME_DEFERRED (a candidate left the staged
  * window, or the search method was not compiled into the fast variant).  Same arithmetic, reference samples read
  * from HBM/L2; only the 64x64 source tile is staged. */
