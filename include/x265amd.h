@@ -361,6 +361,8 @@ typedef struct x265amd_intra_nxn_job
     x265amd_intra_tu_job ctmpl[2];
     uint64_t crecon_dst[2];
     uint64_t recon_dst[4];          /* optional (0: none): a third place for the winners' luma reconstruction, stride 64 (the mode's reconstruction tile) */
+    uint64_t levels_dst, clevels_dst;   /* one unit larger than 8x8 (unit_log2 4: a 16x16 CU coded 2Nx2N, chroma blocks 8x8): where the winner's luma levels (N x N) and
+                                         * the chroma winner's levels (U then V, N/2 x N/2 each) go instead of the result record's arrays; 0: the record */
 } x265amd_intra_nxn_job;
 typedef struct x265amd_intra_nxn_out
 {

@@ -3445,10 +3445,10 @@ def intra_pu_run_hip(L, c, preds, rbits, mpm_base, lam, max_cand):
 # ---- x265amd_intra_nxn: an 8x8 NxN CU (four 4x4 luma units with their decisions, the luma measurements, the chroma decision) as one launch ----
 INTRA_NXN_JOB_DT = np.dtype([("tmpl", INTRA_TU_JOB_DT, 4), ("pred_dst", "<u8", 4), ("layer_dst", "<u8", 4), ("lambda", "<u8"), ("lambda2", "<u8"), ("psy_scale", "<u8"),
                              ("frac_start", "<u8", 4), ("scan_frac", "<u4"), ("slot_pixels", "<u4"), ("slot_coeffs", "<u4"), ("left_mode", "u1", 2), ("above_mode", "u1", 2),
-                             ("ctx", "u1", 160), ("max_cand", "u1"), ("do_chroma", "u1"), ("reserved", "u1", 2), ("pad", "u1", 4), ("ctmpl", INTRA_TU_JOB_DT, 2), ("crecon_dst", "<u8", 2), ("recon_dst", "<u8", 4)])
+                             ("ctx", "u1", 160), ("max_cand", "u1"), ("do_chroma", "u1"), ("reserved", "u1", 2), ("pad", "u1", 4), ("ctmpl", INTRA_TU_JOB_DT, 2), ("crecon_dst", "<u8", 2), ("recon_dst", "<u8", 4), ("levels_dst", "<u8"), ("clevels_dst", "<u8")])
 INTRA_NXN_OUT_DT = np.dtype([("mode", "u1", 4), ("num_cand", "u1", 4), ("res", TU_RESULT_DT, 4), ("levels", "<i2", (4, 16)), ("psy_energy", "<u4"), ("res_energy", "<u4"),
                              ("chroma_best", "<u4"), ("chroma_reserved", "<u4"), ("cres", TU_RESULT_DT, 2), ("clevels", "<i2", (2, 16))])
-assert INTRA_NXN_JOB_DT.itemsize == 928 and INTRA_NXN_OUT_DT.itemsize == 408
+assert INTRA_NXN_JOB_DT.itemsize == 944 and INTRA_NXN_OUT_DT.itemsize == 408
 
 
 def entropy_bit_tables():

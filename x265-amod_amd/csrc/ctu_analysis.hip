@@ -878,7 +878,24 @@ struct Analyzer
         const bool mightSplit = depth < si->max_cu_depth;
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
-        if (log2 != 6 && mightNotSplit)
+        /* a 16x16 CU: its 2Nx2N evaluation may start now on a queue of its own and be collected after the four sub-CUs (intra_rd.hip); the comparisons keep
+         * the reference's order */
+        bool deferred = false;
+        if (log2 == 4 && mightNotSplit && mightSplit)
+        {
+            Mode& m = d.pred[PRED_INTRA];
+            x265amd_rd_cu c;
+            memset(&c, 0, sizeof(c));
+            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.qp = (int8_t)qp;
+            memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
+            c.frac_bits = d.cur.frac;
+            const int b = xa_check_intra_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
+                                                  tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+            if (b < 0) return err = b;
+            deferred = b == 1;
+            (void)m;
+        }
+        if (log2 != 6 && mightNotSplit && !deferred)
         {
             if (log2 == 3 && si->tu_log2_min < 3 && xa_queue_helper(st))         /* the NxN try below may start beside this one */
                 xa_intra_ws_hint_nxn(&intraWs, tileAddr(predTile(depth, PRED_INTRA_NxN)), tileAddr(reconTile(depth, PRED_INTRA_NxN)));
@@ -927,6 +944,13 @@ struct Analyzer
             split.contexts = *nextContext;
             if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
             else updateModeCost(split);
+            if (deferred)
+            {
+                /* now the 2Nx2N result, then the comparisons in the reference's order */
+                if (rdIntra(d.pred[PRED_INTRA], x, y, depth, PRED_INTRA, true, 0)) return err;
+                checkBestMode(d.pred[PRED_INTRA], depth);
+                addSplitFlagCost(*d.best, x, y, depth);
+            }
             checkBestMode(split, depth);
         }
         toPicture(*d.best, x, y, depth);
@@ -1395,7 +1419,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             }
             /* I pictures: a second queue for the row when one is to spare -- the two partitionings of an 8x8 CU are evaluated side by side (intra_rd.hip) */
             void* helper = (f.intraOnly && st && !own) ? xa_queue_try_acquire() : nullptr;
+            void* helper2 = helper ? xa_queue_try_acquire() : nullptr;         /* and a third: the 16x16 CUs' 2Nx2N evaluations beside their sub-CUs */
             if (helper) xa_queue_set_helper(st, helper);
+            if (helper2) xa_queue_set_helper(helper, helper2);
             std::atomic_thread_fence(std::memory_order_release);
             *f.queuedRows = (uint64_t)(row + 1);
             const auto tQueue = std::chrono::steady_clock::now();
@@ -1420,6 +1446,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
             }
             if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;
+            if (helper2) { xa_queue_set_helper(helper, nullptr); xa_queue_release_helper(helper2); }
             if (helper) { xa_queue_set_helper(st, nullptr); xa_queue_release_helper(helper); }
             if (own) (void)hipStreamDestroy(own);
             else if (st) xa_queue_release(st);

@@ -204,7 +204,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             const uint32_t numSig = s_res[i].num_sig;
             unsigned long long coeffFrac = 0;
             if (numSig) coeffFrac = unitLog2 == 2 ? wave_coeff_bits_4x4(P.ctx, nullptr, s.q, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane)
-                                                  : wave_coeff_bits(P.ctx, nullptr, s.q, 3, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane);
+                                                  : wave_coeff_bits(P.ctx, nullptr, s.q, unitLog2, 0, 1, (int)mode, T.tu.sign_hide, s_step, lane);
             if (lane == 0)
             {
                 const uint8_t* cw = P.ctx;
@@ -237,15 +237,16 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             const pixel* rec = reinterpret_cast<const pixel*>(T.tu.recon) + (size_t)w * P.slot_pixels;
             const pixel* prd = reinterpret_cast<const pixel*>(T.tu.pred) + (size_t)w * P.slot_pixels;
             const int16_t* lv = reinterpret_cast<const int16_t*>(T.tu.coeff) + (size_t)w * P.slot_coeffs;
-            if (tid < N * N)
+            int16_t* lvOut = P.levels_dst ? reinterpret_cast<int16_t*>(P.levels_dst) : &po->levels[0][0];
+            for (int t = tid; t < N * N; t += nthr)
             {
-                const int y = tid >> unitLog2, x = tid & (N - 1);
+                const int y = t >> unitLog2, x = t & (N - 1);
                 const pixel v = rec[y * T.tu.recon_stride + x];
                 if (!P.no_picture) reinterpret_cast<pixel*>(T.nb)[(long)y * T.nb_stride + x] = v;
                 reinterpret_cast<pixel*>(P.layer_dst[k])[y * 64 + x] = v;
                 if (P.recon_dst[k]) reinterpret_cast<pixel*>(P.recon_dst[k])[y * 64 + x] = v;
                 reinterpret_cast<pixel*>(P.pred_dst[k])[y * 64 + x] = prd[y * T.tu.pred_stride + x];
-                (&po->levels[0][0])[k * 16 + tid] = lv[tid];
+                lvOut[k * 16 + t] = lv[t];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
         }
@@ -262,13 +263,13 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
     }
     if (!P.do_chroma) return;
-    /* ---- estIntraPredChromaQT for the one 4x4 block per plane: a wavefront per mode ---- */
+    /* ---- estIntraPredChromaQT for the one block per plane (4x4 for an 8x8 CU, N/2 for a larger single unit): a wavefront per mode ---- */
     __shared__ x265amd_tu_result s_cres[5][2];
-    __shared__ int16_t s_clev[5][2][16];
     __shared__ uint8_t s_cmode[5];
-    __shared__ pixel s_cfenc[2][16];                /* the two source blocks, read by the five modes' chains */
+    __shared__ pixel s_cfenc[2][16];                /* the two source blocks of the 4x4 case, read by the five modes' chains */
+    const int cLog2 = numUnits == 1 ? unitLog2 - 1 : 2, CN = 1 << cLog2;
     const uint32_t lumaDir = s_winMode[0];
-    if (tid >= 64 && tid < 96)
+    if (cLog2 == 2 && tid >= 64 && tid < 96)
     {
         const int pl = (tid - 64) >> 4, i = tid & 15;
         s_cfenc[pl][i] = reinterpret_cast<const pixel*>(P.ctmpl[pl].tu.fenc)[(i >> 2) * P.ctmpl[pl].tu.fenc_stride + (i & 3)];
@@ -286,24 +287,21 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
         IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
         const uint32_t listed = s_cmode[wv], mode = listed == 36 ? lumaDir : listed;
+        for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[wv][b] = P.ctx[b];
+        xa_wave_sync();
+        /* U's chain and coefficients, then V's on the contexts U has moved (the flags in front of them live in other contexts: their order against the coefficients
+         * is free); the levels are counted where the chain left them, in this wavefront's LDS */
+        unsigned long long coeffFrac = 0;
         for (int pl = 0; pl < 2; pl++)
         {
             x265amd_intra_tu_job J = P.ctmpl[pl];
             J.tu.dir_mode = (uint8_t)mode;
-            J.tu.fenc = (uint64_t)(uintptr_t)(const void*)s_cfenc[pl]; J.tu.fenc_stride = 4;
+            if (cLog2 == 2) { J.tu.fenc = (uint64_t)(uintptr_t)(const void*)s_cfenc[pl]; J.tu.fenc_stride = 4; }
             J.tu.recon += (uint64_t)(2 * wv + pl) * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t);
             wave_intra_tu_chain_body<false>(J, nullptr, &s_cres[wv][pl], s, ip, nullptr, lane);
-            if (lane < 16) s_clev[wv][pl][lane] = s.q[lane];
             xa_wave_sync();
-        }
-        for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[wv][b] = P.ctx[b];
-        xa_wave_sync();
-        /* U's coefficients, then V's on the contexts U has moved (the flags in front of them live in other contexts: their order against the coefficients is free) */
-        unsigned long long coeffFrac = 0;
-        for (int pl = 0; pl < 2; pl++)
-        {
-            if (s_cres[wv][pl].num_sig) coeffFrac += wave_coeff_bits_4x4(s_ctxw[wv], s_ctxw[wv], s_clev[wv][pl], 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide, s_step, lane);
+            if (s_cres[wv][pl].num_sig) coeffFrac += wave_coeff_bits(s_ctxw[wv], s_ctxw[wv], s.q, cLog2, 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide, s_step, lane);
             xa_wave_sync();
         }
         if (lane == 0)
@@ -332,15 +330,20 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         po->cres[0] = s_cres[w][0]; po->cres[1] = s_cres[w][1];
     }
     __syncthreads();
-    if (tid < 32)
     {
-        const int pl = tid >> 4, i = tid & 15, y = i >> 2, x = i & 3, w = s_win;
-        const x265amd_intra_tu_job& C = P.ctmpl[pl];
-        const pixel* best = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * w + pl) * P.slot_pixels;
-        const pixel* last = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * 4 + pl) * P.slot_pixels;
-        reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = best[y * C.tu.recon_stride + x];
-        if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = last[y * C.tu.recon_stride + x];
-        po->clevels[pl][i] = s_clev[w][pl][i];
+        const int w = s_win, cn2 = CN * CN;
+        int16_t* clOut = P.clevels_dst ? reinterpret_cast<int16_t*>(P.clevels_dst) : &po->clevels[0][0];
+        for (int t = tid; t < 2 * cn2; t += nthr)
+        {
+            const int pl = t >= cn2, i = t - pl * cn2, y = i >> cLog2, x = i & (CN - 1);
+            const x265amd_intra_tu_job& C = P.ctmpl[pl];
+            const pixel* best = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * w + pl) * P.slot_pixels;
+            const pixel* last = reinterpret_cast<const pixel*>(C.tu.recon) + (size_t)(2 * 4 + pl) * P.slot_pixels;
+            const int16_t* lv = reinterpret_cast<const int16_t*>(C.tu.coeff) + (size_t)(2 * w + pl) * P.slot_coeffs;
+            reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = best[y * C.tu.recon_stride + x];
+            if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = last[y * C.tu.recon_stride + x];
+            clOut[pl * cn2 + i] = lv[i];
+        }
     }
 }
 

@@ -67,7 +67,14 @@ struct IntraRd
     void* helper = nullptr;
     uint64_t hintPred = 0, hintRecon = 0;
     struct Ahead { bool on = false; int x = 0, y = 0; } ahead;
-    DevBuf dCand2, dCoeffDev2; XaMapped dNxnJob2; XaMappedOut dNxnOut2;      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    DevBuf dCand2, dCoeffDev2; XaMapped dNxnJob2; XaMappedOut dNxnOut2;
+    XaMappedOut dDevLevels, dDevCLevels;                /* the device-decided 16x16 unit: its 256 luma levels, the chroma winner's 2 x 64 */
+    /* A 16x16 CU's 2Nx2N evaluation started BEFORE the recursion into its four 8x8 CUs, on a third queue, and collected after it (xa_check_intra_begin_ws):
+     * it reads only what lies outside the CU and writes only its own tiles (no_picture), so it runs beside the sub-CUs, which own the picture meanwhile. */
+    void* helper2 = nullptr;
+    struct Ahead16 { bool on = false; int x = 0, y = 0; } a16;
+    DevBuf dCand3, dCoeffDev3; XaMapped dNxnJob3; XaMappedOut dNxnOut3, dDevLevels3, dDevCLevels3;
+    const int16_t* curLevels = nullptr; const int16_t* curCLevels = nullptr;       /* where the last device-decided large unit left its levels */      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -401,10 +408,12 @@ struct IntraRd
 
     /* the job record of x265amd_intra_nxn for this CU coded NxN (partSize 3: four 4x4 units) or 2Nx2N (one 8x8 unit); tiles: the mode's prediction / reconstruction
      * tiles; cand / coeffDev: the command's scratch */
-    void buildDevJob(x265amd_intra_nxn_job& nj, int partSize, int rdLevel, uint64_t predTileM, uint64_t reconTileM, uint64_t cand, uint64_t coeffDev)
+    void buildDevJob(x265amd_intra_nxn_job& nj, int partSize, int rdLevel, uint64_t predTileM, uint64_t reconTileM, uint64_t cand, uint64_t coeffDev,
+                     void* levelsBuf = nullptr, void* clevelsBuf = nullptr)
     {
         const int initTuDepth = partSize != 0;
-        const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
+        const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : log2, devN = 1 << devLog2;
+        const int cLog2 = log2 - 1, cN = 1 << cLog2;        /* the chroma block per plane: 4x4 for an 8x8 CU, 8x8 for a 16x16 CU */
         const size_t isz = sizeof(pixel);
             memset(&nj, 0, sizeof(nj));
             const uint64_t slot0 = cand;
@@ -453,13 +462,17 @@ struct IntraRd
                 const uint64_t avail = foldChroma(available(cuX, cuY, size), size >> 2);
                 for (int pl = 1; pl < 3; pl++)
                 {
-                    fillJob(nj.ctmpl[pl - 1], pl, cuX, cuY, 2, 0, 0, 4, slot0, 4, 0);
+                    fillJob(nj.ctmpl[pl - 1], pl, cuX, cuY, cLog2, 0, 0, cN, slot0, cN, 0);
                     nj.ctmpl[pl - 1].avail = avail;
                     nj.ctmpl[pl - 1].tu.coeff = coeffDev;
-                    nj.ctmpl[pl - 1].tu.resi = coeffDev + (size_t)MAX_JOBS * 1024 * 2; nj.ctmpl[pl - 1].tu.resi_stride = 4;
+                    nj.ctmpl[pl - 1].tu.resi = coeffDev + (size_t)MAX_JOBS * 1024 * 2; nj.ctmpl[pl - 1].tu.resi_stride = cN;
                     nj.crecon_dst[pl - 1] = reconTileM + (4096 + (size_t)(pl - 1) * 1024) * isz;
                 }
                 nj.do_chroma = 1;
+            }
+            if (devLog2 > 3)
+            {
+                nj.levels_dst = (uint64_t)(uintptr_t)(levelsBuf ? levelsBuf : dDevLevels.p); nj.clevels_dst = (uint64_t)(uintptr_t)(clevelsBuf ? clevelsBuf : dDevCLevels.p);
             }
     }
 
@@ -477,14 +490,28 @@ struct IntraRd
          * candidate bits on the host.  (It paid only once the bits of a unit were counted by a wavefront, a lane per context: a single lane needs 45 us for the 64
          * coefficients.)  X265AMD_DEVICE_2Nx2N=0 takes the prediction-unit step with host bits instead. */
         static const bool dev2Nx2N = !(getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) == 0);
-        const bool deviceNxN = log2 == 3 && !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
-                               (partSize != 0 ? (log2TrSize == 2 && range[0] == 2) : (dev2Nx2N && range[0] == 3 && range[1] >= 3));
+        /* ... and the 16x16 CU coded 2Nx2N with its one 16x16 unit (chroma blocks 8x8): X265AMD_DEVICE_16=0 leaves it to the prediction-unit step */
+        static const bool dev16 = !(getenv("X265AMD_DEVICE_16") && atoi(getenv("X265AMD_DEVICE_16")) == 0);
+        const bool deviceNxN = !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
+                               (partSize != 0 ? (log2 == 3 && log2TrSize == 2 && range[0] == 2)
+                                              : (dev2Nx2N && (log2 == 3 || (log2 == 4 && dev16)) && range[0] == log2 && range[1] >= log2));
         const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
         if (deviceNxN)
         {
             xa_phase(XA_PH_INTRA_CAND);
             const bool mine = ahead.on && partSize != 0 && ahead.x == cuX && ahead.y == cuY;
-            if (mine)
+            const bool mine16 = a16.on && partSize == 0 && log2 == 4 && a16.x == cuX && a16.y == cuY;
+            curLevels = (const int16_t*)dDevLevels.p; curCLevels = (const int16_t*)dDevCLevels.p;
+            if (mine16)
+            {
+                /* started before the recursion into the sub-CUs, on the third queue */
+                a16.on = false;
+                if (xa_stream_sync(helper2) != hipSuccess) return fail("intra rd: 16x16 step");
+                memcpy(&nxn, dNxnOut3.p, sizeof(nxn));
+                curLevels = (const int16_t*)dDevLevels3.p; curCLevels = (const int16_t*)dDevCLevels3.p;
+                if (xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) return fail("intra rd: fence");
+            }
+            else if (mine)
             {
                 /* this CU's NxN command has been running on the second queue since the 2Nx2N call: its results, and what it wrote for the first queue to see */
                 ahead.on = false;
@@ -541,7 +568,7 @@ struct IntraRd
                 for (int yy = 0; yy < tuSize; yy += 4) for (int xx = 0; xx < tuSize; xx += 4) U(px + xx, py + yy).luma_dir = (uint8_t)bm;
                 load(cur);
                 Cost ic = { 0, 0, 0, 0 };
-                pre = Pre{ true, px, py, log2TrSize, nxn.res[puIdx], &nxn.levels[0][0] + 16 * puIdx, 0, 0, false };
+                pre = Pre{ true, px, py, log2TrSize, nxn.res[puIdx], log2TrSize > 3 ? curLevels : &nxn.levels[0][0] + 16 * puIdx, 0, 0, false };
                 const int rq = codeIntraLumaQT(px, py, initTuDepth, true, ic);
                 pre.on = false;
                 if (rq) return err;
@@ -775,7 +802,9 @@ struct IntraRd
             for (int p = 1; p < 3; p++)
             {
                 const x265amd_tu_result& r = nxnChroma.cres[p - 1];
-                memcpy(coeffC[p - 1].data(), nxnChroma.clevels[p - 1], sizeof(int16_t) * 16);
+                const int cN = size >> 1;
+                const int16_t* lvC = cN > 4 ? curCLevels + (size_t)(p - 1) * cN * cN : nxnChroma.clevels[p - 1];
+                memcpy(coeffC[p - 1].data(), lvC, sizeof(int16_t) * cN * cN);
                 setCbf(p, cuX, cuY, size, r.num_sig ? 1 << td1 : 0);
                 if (td1) U(cuX, cuY).cbf[p] |= (uint8_t)((U(cuX, cuY).cbf[p] >> td1) & 1);
                 dist += (sse_t)r.nz_dist;
@@ -892,7 +921,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
                          const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
                          x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info, void** ws = nullptr)
 {
-    if (!si || !rp || !units || !h_src || !h_rec || !cu || !cu_units || !d_pred || !d_recon || !out) return xa_fail(X265AMD_EINVAL, "intra rd: null argument");
+    if (!si || !rp || !units || !h_src || !h_rec || !cu || (kind != 2 && (!cu_units || !out)) || !d_pred || !d_recon) return xa_fail(X265AMD_EINVAL, "intra rd: null argument");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "intra rd: lossless coding is not supported");
     if (partSize != 0 && (partSize != 3 || cu->log2_size != 3 || si->tu_log2_min > 2)) return xa_fail(X265AMD_EINVAL, "intra rd: NxN only for 8x8 CUs with 4x4 transforms");
     xa_phase(XA_PH_ANALYZER);
@@ -900,6 +929,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (ws) *ws = ip;
     IntraRd& R = *ip;
     R.helper = xa_queue_helper(stream);
+    R.helper2 = R.helper ? xa_queue_helper(R.helper) : nullptr;           /* the third queue rides on the second */
     if (R.ahead.on && !(kind == 1 && partSize == 3 && R.ahead.x == cu->x && R.ahead.y == cu->y))
     {
         /* a command started ahead that nobody came for: let it finish before anything else touches what it writes */
@@ -936,6 +966,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
          R.dScan.alloc(35 * 4) != hipSuccess || R.dScanJob.alloc(sizeof(x265amd_intra_job)) != hipSuccess ||
          R.dPuJob.alloc(sizeof(x265amd_intra_pu_job)) != hipSuccess || R.dPuOut.alloc(sizeof(x265amd_intra_pu_out)) != hipSuccess ||
          R.dNxnJob.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess ||
+         R.dDevLevels.alloc(1024 * 2) != hipSuccess || R.dDevCLevels.alloc(2 * 256 * 2) != hipSuccess ||
          R.dCoeffDev.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
          R.mCtx.alloc(X265AMD_CTX_STRIDE) != hipSuccess || R.mEstJob.alloc(sizeof(x265amd_est_job)) != hipSuccess ||
          R.mRdoq.alloc(sizeof(x265amd_tu_rdoq) * IntraRd::MAX_JOBS) != hipSuccess || R.dEst.alloc(sizeof(x265amd_est_bits)) != hipSuccess))
@@ -946,6 +977,11 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (rc == X265AMD_OK && R.helper && !R.dCand2.p &&
         (R.dCand2.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dCoeffDev2.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
          R.dNxnJob2.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut2.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess))
+        rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
+    if (rc == X265AMD_OK && R.helper2 && !R.dCand3.p &&
+        (R.dCand3.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dCoeffDev3.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
+         R.dNxnJob3.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut3.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess ||
+         R.dDevLevels3.alloc(1024 * 2) != hipSuccess || R.dDevCLevels3.alloc(2 * 256 * 2) != hipSuccess))
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     if (rc == X265AMD_OK && rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)         /* the table is only read by RDOQ */
         rc = xa_fail(X265AMD_EHIP, "intra rd: fill");
@@ -974,6 +1010,27 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
             u.depth = (uint8_t)R.depth; u.pred_mode = X265AMD_MODE_INTRA; u.part_size = (uint8_t)partSize; u.luma_dir = 1; u.chroma_dir = 36; u.qp = (int8_t)R.qp;
             u.ref_idx[0] = u.ref_idx[1] = -1;
         }
+    if (kind == 2)
+    {
+        /* only start the CU's 2Nx2N command (a 16x16 CU of an I picture, the third queue): the caller recurses into the sub-CUs and comes back with the ordinary call */
+        static const bool dev16 = !(getenv("X265AMD_DEVICE_16") && atoi(getenv("X265AMD_DEVICE_16")) == 0);
+        static const bool ahead16 = !(getenv("X265AMD_AHEAD_16") && atoi(getenv("X265AMD_AHEAD_16")) == 0);
+        int started = 0;
+        if (dev16 && ahead16 && R.helper2 && R.dCand3.p && !R.a16.on && R.log2 == 4 && !rp->rdoq_level && R.range[0] == 4 && R.range[1] >= 4 && 2 + rp->rd_level + (R.depth >> 1) <= IntraRd::MAX_JOBS)
+        {
+            x265amd_intra_nxn_job nj;
+            R.buildDevJob(nj, 0, rp->rd_level, d_pred, d_recon, (uint64_t)(uintptr_t)R.dCand3.p, (uint64_t)(uintptr_t)R.dCoeffDev3.p, R.dDevLevels3.p, R.dDevCLevels3.p);
+            nj.no_picture = 1;
+            memcpy(R.dNxnJob3.p, &nj, sizeof(nj));
+            if (xa_stream_sync(R.st) != hipSuccess || xa_stream_fence(R.helper2, XA_CMD_ACQUIRE) != hipSuccess ||
+                x265amd_intra_nxn(R.helper2, (const x265amd_intra_nxn_job*)R.dNxnJob3.p, (x265amd_intra_nxn_out*)R.dNxnOut3.p) != X265AMD_OK)
+                rc = xa_fail(X265AMD_EHIP, "intra rd: 16x16 step ahead");
+            else { R.a16.on = true; R.a16.x = R.cuX; R.a16.y = R.cuY; started = 1; }
+        }
+        for (int yy = 0; yy < u4; yy++) memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
+        x265amd_cabac_close(coder);
+        return rc != X265AMD_OK ? rc : (started ? 1 : 0);
+    }
     Cost icosts = { 0, 0, 0, 0 };
     sse_t lumaDist = 0, chromaDist = 0;
     xa_phase(XA_PH_INTRA_SETUP);
@@ -1113,7 +1170,14 @@ void xa_intra_ws_free(void* ws)
 {
     IntraRd* ip = static_cast<IntraRd*>(ws);
     if (ip && ip->ahead.on && ip->helper) (void)xa_stream_sync(ip->helper);          /* its buffers are about to go back to the pool */
+    if (ip && ip->a16.on && ip->helper2) (void)xa_stream_sync(ip->helper2);
     delete ip;
+}
+int xa_check_intra_begin_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                            intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, uint64_t d_pred, uint64_t d_recon, void** ws)
+{
+    if (!ws || !xa_queue_helper(stream) || !xa_queue_helper(xa_queue_helper(stream))) return 0;
+    return intra_cu_impl(2, 0, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, nullptr, d_pred, d_recon, nullptr, nullptr, nullptr, ws);
 }
 void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn)
 {

@@ -106,6 +106,11 @@ void xa_intra_ws_free(void* ws);
 /* before xa_check_intra_ws(.., part_size 0, ..) of an 8x8 CU that will be tried as NxN next: the NxN mode's tiles.  With a second queue on the stream
  * (xa_queue_helper) the NxN evaluation then starts beside the 2Nx2N one; the NxN call that follows collects it. */
 void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn);
+/* starts the 2Nx2N evaluation of a 16x16 CU on the stream's third queue (the helper's helper) and returns 1, or returns 0 when that is not possible (then nothing
+ * has happened); < 0: error.  The caller evaluates the CU's sub-CUs, then calls xa_check_intra_ws(.., part_size 0, ..) for the same CU with the same tiles, which
+ * collects the result.  The contexts in `cu` are those the later call passes. */
+int xa_check_intra_begin_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                            intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, uint64_t d_pred, uint64_t d_recon, void** ws);
 
 /* the skip and the residual measurement of a merge candidate together (csrc/inter_rd.hip) */
 int xa_merge_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, intptr_t stride, intptr_t cstride,
