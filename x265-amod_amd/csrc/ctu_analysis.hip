@@ -881,7 +881,7 @@ struct Analyzer
         /* a 16x16 CU: its 2Nx2N evaluation may start now on a queue of its own and be collected after the four sub-CUs (intra_rd.hip); the comparisons keep
          * the reference's order */
         bool deferred = false;
-        if (log2 == 4 && mightNotSplit && mightSplit)
+        if ((log2 == 4 || log2 == 5) && mightNotSplit && mightSplit)
         {
             Mode& m = d.pred[PRED_INTRA];
             x265amd_rd_cu c;
@@ -1419,9 +1419,11 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             }
             /* I pictures: a second queue for the row when one is to spare -- the two partitionings of an 8x8 CU are evaluated side by side (intra_rd.hip) */
             void* helper = (f.intraOnly && st && !own) ? xa_queue_try_acquire() : nullptr;
-            void* helper2 = helper ? xa_queue_try_acquire() : nullptr;         /* and a third: the 16x16 CUs' 2Nx2N evaluations beside their sub-CUs */
+            void* helper2 = helper ? xa_queue_try_acquire() : nullptr;         /* and a third and a fourth: the 16x16 / 32x32 CUs' 2Nx2N evaluations beside their sub-CUs */
+            void* helper3 = helper2 ? xa_queue_try_acquire() : nullptr;
             if (helper) xa_queue_set_helper(st, helper);
             if (helper2) xa_queue_set_helper(helper, helper2);
+            if (helper3) xa_queue_set_helper(helper2, helper3);
             std::atomic_thread_fence(std::memory_order_release);
             *f.queuedRows = (uint64_t)(row + 1);
             const auto tQueue = std::chrono::steady_clock::now();
@@ -1446,6 +1448,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
             }
             if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;
+            if (helper3) { xa_queue_set_helper(helper2, nullptr); xa_queue_release_helper(helper3); }
             if (helper2) { xa_queue_set_helper(helper, nullptr); xa_queue_release_helper(helper2); }
             if (helper) { xa_queue_set_helper(st, nullptr); xa_queue_release_helper(helper); }
             if (own) (void)hipStreamDestroy(own);

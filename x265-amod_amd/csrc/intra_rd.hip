@@ -71,9 +71,7 @@ struct IntraRd
     XaMappedOut dDevLevels, dDevCLevels;                /* the device-decided 16x16 unit: its 256 luma levels, the chroma winner's 2 x 64 */
     /* A 16x16 CU's 2Nx2N evaluation started BEFORE the recursion into its four 8x8 CUs, on a third queue, and collected after it (xa_check_intra_begin_ws):
      * it reads only what lies outside the CU and writes only its own tiles (no_picture), so it runs beside the sub-CUs, which own the picture meanwhile. */
-    void* helper2 = nullptr;
-    struct Ahead16 { bool on = false; int x = 0, y = 0; } a16;
-    DevBuf dCand3, dCoeffDev3; XaMapped dNxnJob3; XaMappedOut dNxnOut3, dDevLevels3, dDevCLevels3;
+    struct Big { void* q = nullptr; bool on = false; int x = 0, y = 0; DevBuf cand, coeffDev; XaMapped job; XaMappedOut out, levels, clevels; } big[2];    /* [0] 16x16 (third queue), [1] 32x32 (fourth) */
     const int16_t* curLevels = nullptr; const int16_t* curCLevels = nullptr;       /* where the last device-decided large unit left its levels */      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
@@ -492,23 +490,25 @@ struct IntraRd
         static const bool dev2Nx2N = !(getenv("X265AMD_DEVICE_2Nx2N") && atoi(getenv("X265AMD_DEVICE_2Nx2N")) == 0);
         /* ... and the 16x16 CU coded 2Nx2N with its one 16x16 unit (chroma blocks 8x8): X265AMD_DEVICE_16=0 leaves it to the prediction-unit step */
         static const bool dev16 = !(getenv("X265AMD_DEVICE_16") && atoi(getenv("X265AMD_DEVICE_16")) == 0);
+        static const bool dev32 = !(getenv("X265AMD_DEVICE_32") && atoi(getenv("X265AMD_DEVICE_32")) == 0);
         const bool deviceNxN = !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
                                (partSize != 0 ? (log2 == 3 && log2TrSize == 2 && range[0] == 2)
-                                              : (dev2Nx2N && (log2 == 3 || (log2 == 4 && dev16)) && range[0] == log2 && range[1] >= log2));
+                                              : (dev2Nx2N && (log2 == 3 || (log2 == 4 && dev16) || (log2 == 5 && dev32)) && range[0] == log2 && range[1] >= log2));
         const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
         if (deviceNxN)
         {
             xa_phase(XA_PH_INTRA_CAND);
             const bool mine = ahead.on && partSize != 0 && ahead.x == cuX && ahead.y == cuY;
-            const bool mine16 = a16.on && partSize == 0 && log2 == 4 && a16.x == cuX && a16.y == cuY;
+            Big& bg = big[log2 == 5 ? 1 : 0];
+            const bool mine16 = bg.on && partSize == 0 && (log2 == 4 || log2 == 5) && bg.x == cuX && bg.y == cuY;
             curLevels = (const int16_t*)dDevLevels.p; curCLevels = (const int16_t*)dDevCLevels.p;
             if (mine16)
             {
                 /* started before the recursion into the sub-CUs, on the third queue */
-                a16.on = false;
-                if (xa_stream_sync(helper2) != hipSuccess) return fail("intra rd: 16x16 step");
-                memcpy(&nxn, dNxnOut3.p, sizeof(nxn));
-                curLevels = (const int16_t*)dDevLevels3.p; curCLevels = (const int16_t*)dDevCLevels3.p;
+                bg.on = false;
+                if (xa_stream_sync(bg.q) != hipSuccess) return fail("intra rd: large unit step");
+                memcpy(&nxn, bg.out.p, sizeof(nxn));
+                curLevels = (const int16_t*)bg.levels.p; curCLevels = (const int16_t*)bg.clevels.p;
                 if (xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) return fail("intra rd: fence");
             }
             else if (mine)
@@ -929,7 +929,8 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (ws) *ws = ip;
     IntraRd& R = *ip;
     R.helper = xa_queue_helper(stream);
-    R.helper2 = R.helper ? xa_queue_helper(R.helper) : nullptr;           /* the third queue rides on the second */
+    R.big[0].q = R.helper ? xa_queue_helper(R.helper) : nullptr;          /* the third queue rides on the second, the fourth on the third */
+    R.big[1].q = R.big[0].q ? xa_queue_helper(R.big[0].q) : nullptr;
     if (R.ahead.on && !(kind == 1 && partSize == 3 && R.ahead.x == cu->x && R.ahead.y == cu->y))
     {
         /* a command started ahead that nobody came for: let it finish before anything else touches what it writes */
@@ -978,11 +979,15 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         (R.dCand2.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dCoeffDev2.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
          R.dNxnJob2.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut2.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess))
         rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
-    if (rc == X265AMD_OK && R.helper2 && !R.dCand3.p &&
-        (R.dCand3.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || R.dCoeffDev3.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
-         R.dNxnJob3.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.dNxnOut3.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess ||
-         R.dDevLevels3.alloc(1024 * 2) != hipSuccess || R.dDevCLevels3.alloc(2 * 256 * 2) != hipSuccess))
-        rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
+    for (int b = 0; b < 2 && rc == X265AMD_OK; b++)
+    {
+        IntraRd::Big& g = R.big[b];
+        if (g.q && !g.cand.p &&
+            (g.cand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || g.coeffDev.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
+             g.job.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || g.out.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess ||
+             g.levels.alloc(1024 * 2) != hipSuccess || g.clevels.alloc(2 * 256 * 2) != hipSuccess))
+            rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
+    }
     if (rc == X265AMD_OK && rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)         /* the table is only read by RDOQ */
         rc = xa_fail(X265AMD_EHIP, "intra rd: fill");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
@@ -1015,17 +1020,20 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         /* only start the CU's 2Nx2N command (a 16x16 CU of an I picture, the third queue): the caller recurses into the sub-CUs and comes back with the ordinary call */
         static const bool dev16 = !(getenv("X265AMD_DEVICE_16") && atoi(getenv("X265AMD_DEVICE_16")) == 0);
         static const bool ahead16 = !(getenv("X265AMD_AHEAD_16") && atoi(getenv("X265AMD_AHEAD_16")) == 0);
+        static const bool dev32 = !(getenv("X265AMD_DEVICE_32") && atoi(getenv("X265AMD_DEVICE_32")) == 0);
         int started = 0;
-        if (dev16 && ahead16 && R.helper2 && R.dCand3.p && !R.a16.on && R.log2 == 4 && !rp->rdoq_level && R.range[0] == 4 && R.range[1] >= 4 && 2 + rp->rd_level + (R.depth >> 1) <= IntraRd::MAX_JOBS)
+        IntraRd::Big& g = R.big[R.log2 == 5 ? 1 : 0];
+        if (ahead16 && ((R.log2 == 4 && dev16) || (R.log2 == 5 && dev32)) && g.q && g.cand.p && !g.on && !rp->rdoq_level && R.range[0] == R.log2 && R.range[1] >= R.log2 &&
+            2 + rp->rd_level + (R.depth >> 1) <= IntraRd::MAX_JOBS)
         {
             x265amd_intra_nxn_job nj;
-            R.buildDevJob(nj, 0, rp->rd_level, d_pred, d_recon, (uint64_t)(uintptr_t)R.dCand3.p, (uint64_t)(uintptr_t)R.dCoeffDev3.p, R.dDevLevels3.p, R.dDevCLevels3.p);
+            R.buildDevJob(nj, 0, rp->rd_level, d_pred, d_recon, (uint64_t)(uintptr_t)g.cand.p, (uint64_t)(uintptr_t)g.coeffDev.p, g.levels.p, g.clevels.p);
             nj.no_picture = 1;
-            memcpy(R.dNxnJob3.p, &nj, sizeof(nj));
-            if (xa_stream_sync(R.st) != hipSuccess || xa_stream_fence(R.helper2, XA_CMD_ACQUIRE) != hipSuccess ||
-                x265amd_intra_nxn(R.helper2, (const x265amd_intra_nxn_job*)R.dNxnJob3.p, (x265amd_intra_nxn_out*)R.dNxnOut3.p) != X265AMD_OK)
-                rc = xa_fail(X265AMD_EHIP, "intra rd: 16x16 step ahead");
-            else { R.a16.on = true; R.a16.x = R.cuX; R.a16.y = R.cuY; started = 1; }
+            memcpy(g.job.p, &nj, sizeof(nj));
+            if (xa_stream_sync(R.st) != hipSuccess || xa_stream_fence(g.q, XA_CMD_ACQUIRE) != hipSuccess ||
+                x265amd_intra_nxn(g.q, (const x265amd_intra_nxn_job*)g.job.p, (x265amd_intra_nxn_out*)g.out.p) != X265AMD_OK)
+                rc = xa_fail(X265AMD_EHIP, "intra rd: large unit step ahead");
+            else { g.on = true; g.x = R.cuX; g.y = R.cuY; started = 1; }
         }
         for (int yy = 0; yy < u4; yy++) memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
         x265amd_cabac_close(coder);
@@ -1170,7 +1178,7 @@ void xa_intra_ws_free(void* ws)
 {
     IntraRd* ip = static_cast<IntraRd*>(ws);
     if (ip && ip->ahead.on && ip->helper) (void)xa_stream_sync(ip->helper);          /* its buffers are about to go back to the pool */
-    if (ip && ip->a16.on && ip->helper2) (void)xa_stream_sync(ip->helper2);
+    for (int b = 0; ip && b < 2; b++) if (ip->big[b].on && ip->big[b].q) (void)xa_stream_sync(ip->big[b].q);
     delete ip;
 }
 int xa_check_intra_begin_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
