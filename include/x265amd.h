@@ -352,7 +352,10 @@ typedef struct x265amd_intra_nxn_job
                                      * is the one of transform depth 0, the 64 levels fill `levels` as one array and the luma measurements are the unit's own result */
     uint8_t no_picture;             /* 1: the winners' samples go to the tiles only, not to the reconstructed planes (tmpl[].nb / ctmpl[].nb are then only read): the caller
                                      * runs the CU's other partitioning beside this one and THAT one is the last tried, whose samples the picture keeps.  One unit only */
-    uint8_t reserved[3];
+    uint8_t pick_sa8d;              /* 1 (one unit): no candidate list -- the unit's mode is Search::checkIntraInInter's choice (search.cpp:1291-1452): the cheapest of the 35 by
+                                     * SA8D + mode bits, DC first, then planar, then the angular modes, strict improvement; its chain, its bits and the chroma decision
+                                     * follow as for a list of one (encodeIntraInInter); the result record's chroma_reserved carries the mode's SA8D */
+    uint8_t reserved[2];
     /* do_chroma: Search::estIntraPredChromaQT for the CU's one 4x4 block per chroma plane in the same launch (search.cpp:1754-1889): the five allowed modes (planar,
      * vertical, horizontal, DC with the one equal to the first unit's luma mode replaced by 34, then the luma mode itself), each a wavefront running the U and the V
      * chain and counting the mode's bits -- intra_chroma_pred_mode, the two coded block flags, U's and V's coefficients, on the contexts `ctx` from scan_frac --; the first

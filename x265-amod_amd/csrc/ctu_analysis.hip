@@ -990,6 +990,19 @@ struct Analyzer
                     skipRecursion = (double)d.srcHomo < (.1 * d.srcMean);
             }
         }
+        /* the intra try of step 3 depends on nothing that happens until then: when the CU is not skipped and a queue is to spare it starts now, beside the sub-CUs
+         * and the motion searches (intra_rd.hip; a try the analysis does not get to is dropped) */
+        if (mightNotSplit && (uint32_t)depth >= minDepth && !skipModes && (!I->is_inter_b || A->b_intra) && log2 != 6 && xa_is_queue(st))
+        {
+            x265amd_rd_cu c;
+            memset(&c, 0, sizeof(c));
+            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.qp = (int8_t)qp;
+            memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
+            c.frac_bits = d.cur.frac;
+            const int b = xa_intra_in_inter_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
+                                                     tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+            if (b < 0) return err = b;
+        }
         /* Step 2: the four sub-blocks in series */
         if (mightSplit && !skipRecursion)
         {
@@ -1380,12 +1393,13 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             std::vector<volatile uint64_t*> done;   /* CTUs finished per row: counters the parked rows below wait on (xa_fiber.h) */
             volatile uint64_t* queuedRows;          /* rows that hold (or have held) a queue */
             std::atomic<int> firstErr{ X265AMD_OK };
-            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc; bool intraOnly;
+            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc; bool intraOnly, intraTry;
             std::function<int(int, void*)> doCtu;
             explicit Frame(int rowsN) : done(rowsN) { for (auto& d : done) d = xa_counter_alloc(); queuedRows = xa_counter_alloc(); }
             ~Frame() { for (auto& d : done) xa_counter_free(d); xa_counter_free(queuedRows); }
         } F(ctuH);
         F.hooks = hooks; F.ctuW = ctuW; F.ctuH = ctuH; F.dumping = dumping; F.poc = I->poc; F.doCtu = doCtu; F.intraOnly = si->slice_type == 2;
+        F.intraTry = si->slice_type == 1 || (si->slice_type == 0 && A->b_intra);       /* pictures whose CUs try intra beside their inter modes */
         struct Row { Frame* f; int row; };
         std::vector<Row> rowsArg((size_t)ctuH);
         std::vector<XaTask> tasks((size_t)ctuH);

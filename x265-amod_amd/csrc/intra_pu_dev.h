@@ -132,6 +132,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ uint8_t s_ctxw[16][X265AMD_CTX_STRIDE];
     __shared__ int s_win;
     __shared__ uint8_t s_winMode[4];
+    __shared__ uint32_t s_pickSa8d;
     XA_STAGE(15);
     __shared__ x265amd_intra_nxn_job sP;           /* the job record: 896 bytes, indexed by the unit -- in LDS, not in registers */
     static_assert(sizeof(x265amd_intra_nxn_job) % 8 == 0, "job records are sequences of 64-bit words");
@@ -182,7 +183,28 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             for (int i = tid; i <= 4 * N; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
             for (int i = tid; i < N * N; i += nthr) S.fenc[i] = sc.fenc[i];
         }
-        if (tid < 64) wave0_candidate_list(S, p0, p1, p2, rbits, mpmBase, P.lambda, maxCand, tid);
+        if (tid < 64)
+        {
+            if (P.pick_sa8d)
+            {
+                /* checkIntraInInter: cost = sa8d + mode bits as in the list; the first minimum in the order DC, planar, 2..34 */
+                unsigned long long key = ~0ull;
+                if (tid < 35)
+                {
+                    uint32_t b = rbits;
+                    if ((uint32_t)tid == p0) b = mpmBase + 1u;
+                    else if ((uint32_t)tid == p1 || (uint32_t)tid == p2) b = mpmBase + 2u;
+                    const uint32_t c = (uint32_t)S.sa8d[tid] + (uint32_t)(((unsigned long long)b * P.lambda + 128) >> 8);
+                    const uint32_t rank = tid == 1 ? 0u : (tid == 0 ? 1u : (uint32_t)tid);
+                    key = ((unsigned long long)c << 8) | rank;
+                }
+                for (int off = 32; off; off >>= 1) { const unsigned long long o = __shfl_xor(key, off, 64); key = o < key ? o : key; }
+                const uint32_t rank = (uint32_t)(key & 255u), mode = rank == 0 ? 1u : (rank == 1 ? 0u : rank);
+                if (tid == 0) { S.modes[0] = (uint8_t)mode; S.num = 1; s_pickSa8d = (uint32_t)S.sa8d[mode]; }
+                xa_wave_sync();
+            }
+            else wave0_candidate_list(S, p0, p1, p2, rbits, mpmBase, P.lambda, maxCand, tid);
+        }
         __syncthreads();
         XA_STAGE(18);
         const int n = S.num;
@@ -326,7 +348,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         unsigned long long best = ~0ull;
         for (int i = 0; i < 5; i++) if (s_cost[i] < best) { best = s_cost[i]; w = i; }
         s_win = w;
-        po->chroma_best = (uint32_t)w; po->chroma_reserved = 0;
+        po->chroma_best = (uint32_t)w; po->chroma_reserved = P.pick_sa8d ? s_pickSa8d : 0;
         po->cres[0] = s_cres[w][0]; po->cres[1] = s_cres[w][1];
     }
     __syncthreads();

@@ -71,8 +71,12 @@ struct IntraRd
     XaMappedOut dDevLevels, dDevCLevels;                /* the device-decided 16x16 unit: its 256 luma levels, the chroma winner's 2 x 64 */
     /* A 16x16 CU's 2Nx2N evaluation started BEFORE the recursion into its four 8x8 CUs, on a third queue, and collected after it (xa_check_intra_begin_ws):
      * it reads only what lies outside the CU and writes only its own tiles (no_picture), so it runs beside the sub-CUs, which own the picture meanwhile. */
-    struct Big { void* q = nullptr; bool on = false; int x = 0, y = 0; DevBuf cand, coeffDev; XaMapped job; XaMappedOut out, levels, clevels; } big[2];    /* [0] 16x16 (third queue), [1] 32x32 (fourth) */
-    const int16_t* curLevels = nullptr; const int16_t* curCLevels = nullptr;       /* where the last device-decided large unit left its levels */      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
+    struct Big { void* q = nullptr; bool on = false, owned = false; int x = 0, y = 0; DevBuf cand, coeffDev; XaMapped job; XaMappedOut out, levels, clevels; } big[2];    /* [0] 16x16 (third queue), [1] 32x32 (fourth) */
+    const int16_t* curLevels = nullptr; const int16_t* curCLevels = nullptr;       /* where the last device-decided large unit left its levels */
+    /* The intra try of a CU of a P / B picture (checkIntraInInter + encodeIntraInInter) as ONE command with the mode picked on the device (pick_sa8d), started at
+     * the CU's entry on the queue of its depth (second, third, fourth: 32x32, 16x16, 8x8) and collected when the analysis gets to it -- after the recursion into
+     * the sub-CUs and the CU's own inter modes.  A command nobody collects is waited for before the slot is used again. */
+    Big inter[3];      /* job / result / level records: host memory the kernels read and write in place (x265amd_host.h) */
     XaMapped mCtx, mEstJob, mRdoq;                      /* RDOQ: the contexts the bit-estimate table is made from, its job record, the per-job RDOQ records */
     DevBuf dEst;                                        /* Entropy::m_estBitsSbac */
     enum { MAX_JOBS = 16 };
@@ -472,6 +476,19 @@ struct IntraRd
             {
                 nj.levels_dst = (uint64_t)(uintptr_t)(levelsBuf ? levelsBuf : dDevLevels.p); nj.clevels_dst = (uint64_t)(uintptr_t)(clevelsBuf ? clevelsBuf : dDevCLevels.p);
             }
+    }
+
+    /* checkIntraInInter + encodeIntraInInter of this CU as one command (decided on the device) possible? */
+    bool devIntraInInter() const
+    {
+        static const bool on = !(getenv("X265AMD_DEVICE_IININTER") && atoi(getenv("X265AMD_DEVICE_IININTER")) == 0);
+        return on && !rp->rdoq_level && !rp->fast_intra && log2 >= 3 && log2 <= 5 && range[0] == log2 && range[1] >= log2 && !si->tq_bypass_enabled;
+    }
+    void buildInInterJob(x265amd_intra_nxn_job& nj, uint64_t predTileM, uint64_t reconTileM, uint64_t cand, uint64_t coeffDev, void* levelsBuf, void* clevelsBuf)
+    {
+        buildDevJob(nj, 0, 0, predTileM, reconTileM, cand, coeffDev, levelsBuf, clevelsBuf);
+        nj.pick_sa8d = 1; nj.max_cand = 1;
+        nj.no_picture = 1;              /* the picture gets the CU's best mode when the CU is decided (copyToPic); nothing reads this try's samples there before */
     }
 
     /* Search::estIntraPredQT (search.cpp:1509-1696): per partition the scan, the candidate list, simple RDO of the candidates, then the
@@ -921,7 +938,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
                          const uint64_t* h_src, const uint64_t* h_rec, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
                          x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out, int16_t* coeff_out, uint64_t* info, void** ws = nullptr)
 {
-    if (!si || !rp || !units || !h_src || !h_rec || !cu || (kind != 2 && (!cu_units || !out)) || !d_pred || !d_recon) return xa_fail(X265AMD_EINVAL, "intra rd: null argument");
+    if (!si || !rp || !units || !h_src || !h_rec || !cu || (kind < 2 && (!cu_units || !out)) || !d_pred || !d_recon) return xa_fail(X265AMD_EINVAL, "intra rd: null argument");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "intra rd: lossless coding is not supported");
     if (partSize != 0 && (partSize != 3 || cu->log2_size != 3 || si->tu_log2_min > 2)) return xa_fail(X265AMD_EINVAL, "intra rd: NxN only for 8x8 CUs with 4x4 transforms");
     xa_phase(XA_PH_ANALYZER);
@@ -1015,6 +1032,41 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
             u.depth = (uint8_t)R.depth; u.pred_mode = X265AMD_MODE_INTRA; u.part_size = (uint8_t)partSize; u.luma_dir = 1; u.chroma_dir = 36; u.qp = (int8_t)R.qp;
             u.ref_idx[0] = u.ref_idx[1] = -1;
         }
+    if (kind == 3)
+    {
+        int started = 0;
+        /* off unless asked for (X265AMD_AHEAD_INTER=1): measured on the bench clip, what the try hides (40 us of device time per CU that gets to it) is eaten by what
+         * starting it costs every unskipped CU (a synchronisation of the row's queue, the job, a queue and its buffers per CTU): last rows 1-4 % SLOWER */
+        static const bool aheadInter = getenv("X265AMD_AHEAD_INTER") && atoi(getenv("X265AMD_AHEAD_INTER")) != 0;
+        IntraRd::Big& g = R.inter[R.log2 >= 3 && R.log2 <= 5 ? 5 - R.log2 : 0];
+        if (aheadInter && R.log2 >= 3 && R.log2 <= 5 && R.devIntraInInter() && xa_is_queue(R.st))
+        {
+            /* the queue of this depth: taken when the first CU of the CTU wants it (never waiting for one), given back with the CTU's working set */
+            if (!g.q) { g.q = xa_queue_try_acquire(); g.owned = g.q != nullptr; }
+            if (g.q && !g.cand.p &&
+                (g.cand.alloc((size_t)IntraRd::MAX_JOBS * 2048 * sizeof(pixel)) != hipSuccess || g.coeffDev.alloc((size_t)IntraRd::MAX_JOBS * 1024 * 2 * 2) != hipSuccess ||
+                 g.job.alloc(sizeof(x265amd_intra_nxn_job)) != hipSuccess || g.out.alloc(sizeof(x265amd_intra_nxn_out)) != hipSuccess ||
+                 g.levels.alloc(1024 * 2) != hipSuccess || g.clevels.alloc(2 * 256 * 2) != hipSuccess))
+                rc = xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
+        }
+        if (rc == X265AMD_OK && aheadInter && R.log2 >= 3 && R.log2 <= 5 && g.q && g.cand.p && R.devIntraInInter())
+        {
+            if (g.on) { g.on = false; if (xa_stream_sync(g.q) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: second queue"); }      /* an earlier try nobody collected */
+            if (rc == X265AMD_OK)
+            {
+                x265amd_intra_nxn_job nj;
+                R.buildInInterJob(nj, d_pred, d_recon, (uint64_t)(uintptr_t)g.cand.p, (uint64_t)(uintptr_t)g.coeffDev.p, g.levels.p, g.clevels.p);
+                memcpy(g.job.p, &nj, sizeof(nj));
+                if (xa_stream_sync(R.st) != hipSuccess || xa_stream_fence(g.q, XA_CMD_ACQUIRE) != hipSuccess ||
+                    x265amd_intra_nxn(g.q, (const x265amd_intra_nxn_job*)g.job.p, (x265amd_intra_nxn_out*)g.out.p) != X265AMD_OK)
+                    rc = xa_fail(X265AMD_EHIP, "intra rd: intra try ahead");
+                else { g.on = true; g.x = R.cuX; g.y = R.cuY; started = 1; }
+            }
+        }
+        for (int yy = 0; yy < u4; yy++) memcpy(&units[((R.cuY >> 2) + yy) * w4 + (R.cuX >> 2)], &saved[(size_t)yy * u4], sizeof(x265amd_cu_unit) * u4);
+        x265amd_cabac_close(coder);
+        return rc != X265AMD_OK ? rc : (started ? 1 : 0);
+    }
     if (kind == 2)
     {
         /* only start the CU's 2Nx2N command (a 16x16 CU of an I picture, the third queue): the caller recurses into the sub-CUs and comes back with the ordinary call */
@@ -1042,7 +1094,56 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     Cost icosts = { 0, 0, 0, 0 };
     sse_t lumaDist = 0, chromaDist = 0;
     xa_phase(XA_PH_INTRA_SETUP);
-    if (kind == 0)
+    if (kind == 0 && R.devIntraInInter())
+    {
+        /* ---- checkIntraInInter + encodeIntraInInter as one command, the mode picked on the device; started ahead at the CU's entry when a queue was to spare ---- */
+        IntraRd::Big& g = R.inter[5 - R.log2];
+        x265amd_intra_nxn_out nxn;
+        const bool mineAhead = g.on && g.x == R.cuX && g.y == R.cuY;
+        R.curLevels = (const int16_t*)R.dDevLevels.p; R.curCLevels = (const int16_t*)R.dDevCLevels.p;
+        if (mineAhead)
+        {
+            g.on = false;
+            if (xa_stream_sync(g.q) != hipSuccess || xa_stream_fence(R.st, XA_CMD_ACQUIRE) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: intra try");
+            memcpy(&nxn, g.out.p, sizeof(nxn));
+            R.curLevels = (const int16_t*)g.levels.p; R.curCLevels = (const int16_t*)g.clevels.p;
+        }
+        else
+        {
+            x265amd_intra_nxn_job nj;
+            R.buildInInterJob(nj, d_pred, d_recon, (uint64_t)(uintptr_t)R.dCand.p, (uint64_t)(uintptr_t)R.dCoeffDev.p, nullptr, nullptr);
+            memcpy(R.dNxnJob.p, &nj, sizeof(nj));
+            if (x265amd_intra_nxn(R.st, (const x265amd_intra_nxn_job*)R.dNxnJob.p, (x265amd_intra_nxn_out*)R.dNxnOut.p) != X265AMD_OK || xa_stream_sync(R.st) != hipSuccess)
+                rc = xa_fail(X265AMD_EHIP, "intra rd: intra try");
+            memcpy(&nxn, R.dNxnOut.p, sizeof(nxn));
+        }
+        if (rc == X265AMD_OK)
+        {
+            const uint32_t bmode = nxn.mode[0];
+            if (bmode > 34) rc = xa_fail(X265AMD_EHIP, "intra rd: intra try mode");
+            else
+            {
+                /* the mode's bits and cost as the scan prices them (loadIntraDirModeLuma + bitsIntraModeMPM / NonMPM) */
+                uint32_t preds[3];
+                R.c->lumaPreds(R.cuX, R.cuY, preds);
+                const uint64_t frac = R.cur.frac & 32767;
+                const uint8_t adi = R.cur.ctx[C_ADI];
+                uint32_t b = (uint32_t)((frac + k_bits[adi ^ 0]) >> 15) + 5;
+                const uint32_t mpmBase = (uint32_t)((frac + k_bits[adi ^ 1]) >> 15);
+                for (int i = 0; i < 3; i++) if (preds[i] == bmode) { b = mpmBase + (bmode == preds[0] ? 1u : 2u); break; }
+                const uint32_t sad = nxn.chroma_reserved;
+                if (info) { info[0] = bmode; info[1] = R.calcRdSADCost(sad, b); info[2] = b; info[3] = sad; }
+                for (int yy = 0; yy < R.size; yy += 4) for (int xx = 0; xx < R.size; xx += 4) R.U(R.cuX + xx, R.cuY + yy).luma_dir = (uint8_t)bmode;
+                R.load(R.cur);
+                R.pre = IntraRd::Pre{ true, R.cuX, R.cuY, R.log2, nxn.res[0], R.log2 > 3 ? R.curLevels : &nxn.levels[0][0], 0, 0, false };
+                rc = R.codeIntraLumaQT(R.cuX, R.cuY, 0, false, icosts) ? R.err : X265AMD_OK;
+                R.pre.on = false;
+                lumaDist = icosts.distortion;
+                R.haveDevChroma = true; R.lumaTileDone = true; R.nxnChroma = nxn;
+            }
+        }
+    }
+    else if (kind == 0)
     {
         /* ---- checkIntraInInter: DC first, then planar, then the angular modes, strict improvement ---- */
         uint64_t modeCosts[35]; uint32_t mb[35], ms[35];
@@ -1179,6 +1280,11 @@ void xa_intra_ws_free(void* ws)
     IntraRd* ip = static_cast<IntraRd*>(ws);
     if (ip && ip->ahead.on && ip->helper) (void)xa_stream_sync(ip->helper);          /* its buffers are about to go back to the pool */
     for (int b = 0; ip && b < 2; b++) if (ip->big[b].on && ip->big[b].q) (void)xa_stream_sync(ip->big[b].q);
+    for (int b = 0; ip && b < 3; b++)
+    {
+        if (ip->inter[b].on && ip->inter[b].q) (void)xa_stream_sync(ip->inter[b].q);
+        if (ip->inter[b].owned) { xa_queue_release_helper(ip->inter[b].q); ip->inter[b].q = nullptr; ip->inter[b].owned = false; }
+    }
     delete ip;
 }
 int xa_check_intra_begin_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
@@ -1186,6 +1292,12 @@ int xa_check_intra_begin_ws(void* stream, const x265amd_slice_info* si, const x2
 {
     if (!ws || !xa_queue_helper(stream) || !xa_queue_helper(xa_queue_helper(stream))) return 0;
     return intra_cu_impl(2, 0, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, nullptr, d_pred, d_recon, nullptr, nullptr, nullptr, ws);
+}
+int xa_intra_in_inter_begin_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                               intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, uint64_t d_pred, uint64_t d_recon, void** ws)
+{
+    if (!ws || !xa_is_queue(stream)) return 0;
+    return intra_cu_impl(3, 0, stream, si, rp, units, h_src, h_rec, stride, cstride, cu, nullptr, d_pred, d_recon, nullptr, nullptr, nullptr, ws);
 }
 void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn)
 {

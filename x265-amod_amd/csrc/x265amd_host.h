@@ -103,6 +103,10 @@ int xa_intra_in_inter_ws(void* stream, const x265amd_slice_info* si, const x265a
                          intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, x265amd_rd_result* out,
                          int16_t* coeff_out, uint64_t* info, void** ws);
 void xa_intra_ws_free(void* ws);
+/* P / B pictures: starts the intra try of a CU (what xa_intra_in_inter_ws will compute, with the same contexts in `cu` and the same tiles) on the queue of the CU's
+ * depth and returns 1, or 0 when that is not possible; the later xa_intra_in_inter_ws call for the same CU collects it, a try nobody collects is dropped. */
+int xa_intra_in_inter_begin_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                               intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu, uint64_t d_pred, uint64_t d_recon, void** ws);
 /* before xa_check_intra_ws(.., part_size 0, ..) of an 8x8 CU that will be tried as NxN next: the NxN mode's tiles.  With a second queue on the stream
  * (xa_queue_helper) the NxN evaluation then starts beside the 2Nx2N one; the NxN call that follows collects it. */
 void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn);
