@@ -275,7 +275,7 @@ struct Analyzer
         if (skipOnly)
             rc = x265amd_skip_rd(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, 1, m.u, tileAddr(m.predTile), tileAddr(m.reconTile), tileBytes, &r);
         else
-            rc = x265amd_inter_residual_rd(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, 1, m.u, tileAddr(m.predTile), tileAddr(m.reconTile), tileBytes,
+            rc = xa_inter_residual_rd_lazy(st, si, &rp, units, planes + 3 * (numPics - 1), stride, cstride, &c, m.u, tileAddr(m.predTile), tileAddr(m.reconTile), tileBytes,
                                            &r, m.coeff.data());
         if (rc != X265AMD_OK) return err = rc;
         if (skipOnly) std::fill(m.coeff.begin(), m.coeff.end(), 0);

@@ -826,10 +826,31 @@ extern "C" int x265amd_skip_rd(void* stream_, const x265amd_slice_info* si, cons
     return x265amd_skip_rd_host(si, rp, units, cus, n, cu_units, meas.data(), out);
 }
 
+static bool compose_final_measure(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int part, const x265amd_tu_result* res, const uint8_t* sel, x265amd_cu_measure& m);
+static int assemble_async(void* stream_, const CuMeasureJob& job, const uint8_t* sel);
+static int inter_residual_rd_impl(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                                  const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                                  x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
+                                  x265amd_rd_result* out, int16_t* coeff_out, bool lazyAssemble);
 extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
                                          const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
                                          x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
                                          x265amd_rd_result* out, int16_t* coeff_out)
+{
+    return inter_residual_rd_impl(stream_, si, rp, units, h_src, stride, cstride, cus, n, cu_units, d_pred, d_recon, tile_bytes, out, coeff_out, false);
+}
+/* the same for one CU on a device job queue, returning with the reconstruction tile still being assembled (the queue's later commands are ordered behind it) when
+ * the results do not need the assembled samples (compose_final_measure) */
+int xa_inter_residual_rd_lazy(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                              const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cu,
+                              x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes, x265amd_rd_result* out, int16_t* coeff_out)
+{
+    return inter_residual_rd_impl(stream_, si, rp, units, h_src, stride, cstride, cu, 1, cu_units, d_pred, d_recon, tile_bytes, out, coeff_out, true);
+}
+static int inter_residual_rd_impl(void* stream_, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units,
+                                  const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
+                                  x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
+                                  x265amd_rd_result* out, int16_t* coeff_out, bool lazyAssemble)
 {
     if (!si || !rp || !units || !h_src || !cus || !cu_units || !d_pred || !d_recon || !out || n < 0) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: null argument");
     if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: tile too small");
@@ -915,6 +936,18 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
 
     /* ---- launch 2: assemble, reconstruct, measure ---- */
     for (int i = 0; i < n; i++) mjobs[i].assemble = 1;
+    if (lazyAssemble && n == 1 && !rdoq && xa_is_queue(stream_))
+    {
+        static const bool composeOn = !(getenv("X265AMD_COMPOSE_MEASURE") && atoi(getenv("X265AMD_COMPOSE_MEASURE")) == 0);
+        x265amd_cu_measure mc;
+        if (composeOn && compose_final_measure(si, cus[0], cu_units[0].part_size, (const x265amd_tu_result*)mRes.p, sel.data(), mc))
+        {
+            rc = assemble_async(stream_, mjobs[0], sel.data());
+            if (rc != X265AMD_OK) return rc;
+            x265amd_inter_rd_finish(si, rp, cus, 1, &mc, out);
+            return X265AMD_OK;
+        }
+    }
     memcpy(dSel.p, sel.data(), sel.size());
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + n), 0, 0, n }; hipError_t le;
       if (measure_use_wg(n)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, n, qa, k_cu_measure_wg, dim3(n), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, n, meas + n);
@@ -922,6 +955,60 @@ extern "C" int x265amd_inter_residual_rd(void* stream_, const x265amd_slice_info
       XA_HIP_CHECK(le); }
     XA_HIP_CHECK(xa_stream_sync(stream_));
     x265amd_inter_rd_finish(si, rp, cus, n, meas + n, out);
+    return X265AMD_OK;
+}
+
+/* What the second measurement would report, put together from the transform units' own results: with ONE transform size per plane (no split to choose from:
+ * tu-inter-depth 1, 2Nx2N) the CU's reconstruction is, unit by unit, either the unit's reconstruction (kept) or its prediction (dropped), the squared error adds
+ * up over the units and so does the psy energy (psyCost_pp sums over 8x8 blocks, pixel.cpp:744-775; luma units are 8x8 or larger here).  false: not that case. */
+static bool compose_final_measure(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int part, const x265amd_tu_result* res, const uint8_t* sel, x265amd_cu_measure& m)
+{
+    CuPlan P;
+    if (make_plan(si, cu, part, P, 0, nullptr, 0, 0, 0, 0, nullptr) < 0) return false;
+    int lumaLayers = 0, L0 = -1;
+    for (int L = 2; L <= 5; L++) if (P.lumaRes[L] >= 0) { lumaLayers++; L0 = L; }
+    if (lumaLayers != 1 || L0 < 3) return false;
+    int chromaLayers = 0, C0 = -1;
+    for (int C = 2; C <= 4; C++) if (P.chromaRes[C][1] >= 0) { chromaLayers++; C0 = C; }
+    if (chromaLayers != 1) return false;
+    memset(&m, 0, sizeof(m));
+    const int nt = P.size >> L0, n4 = 1 << (L0 - 2);
+    for (int ty = 0; ty < nt; ty++)
+        for (int tx = 0; tx < nt; tx++)
+        {
+            const x265amd_tu_result& r = res[P.lumaRes[L0] + ty * nt + tx];
+            const bool kept = sel[(ty * n4) * 16 + tx * n4] == (uint8_t)L0;
+            m.sse[0] += kept ? r.nz_dist : r.zero_dist;
+            m.psy += kept ? r.nz_energy : r.zero_energy;
+        }
+    const int ntc = (P.size >> 1) >> C0, c4 = 1 << (C0 - 2);
+    for (int p = 1; p < 3; p++)
+        for (int ty = 0; ty < ntc; ty++)
+            for (int tx = 0; tx < ntc; tx++)
+            {
+                const x265amd_tu_result& r = res[P.chromaRes[C0][p] + ty * ntc + tx];
+                const bool kept = sel[256 + (p - 1) * 64 + (ty * c4) * 8 + tx * c4] == (uint8_t)C0;
+                m.sse[p] += kept ? r.nz_dist : r.zero_dist;
+            }
+    return true;
+}
+
+/* the assembly of the kept residual blocks into the reconstruction tile without anybody waiting for it (its measurements are not needed: composed above): job record
+ * and selection go through device scratch that the queue's later commands may reuse in order */
+static int assemble_async(void* stream_, const CuMeasureJob& job, const uint8_t* sel)
+{
+    DevBuf dJob, dSel2, dOut;
+    XA_HIP_CHECK(dJob.alloc(sizeof(CuMeasureJob)));
+    XA_HIP_CHECK(dSel2.alloc(RD_SEL_BYTES));
+    XA_HIP_CHECK(dOut.alloc(sizeof(x265amd_cu_measure)));
+    CuMeasureJob j = job;
+    j.assemble = 1; j.sel = (uint64_t)(uintptr_t)dSel2.p;
+    XA_HIP_CHECK(xa_copy_async(stream_, dSel2.p, sel, RD_SEL_BYTES, hipMemcpyHostToDevice));
+    XA_HIP_CHECK(xa_copy_async(stream_, dJob.p, &j, sizeof(j), hipMemcpyHostToDevice));
+    { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)dJob.p, (uint64_t)(uintptr_t)dOut.p, 0, 0, 1 }; hipError_t le;
+      if (measure_use_wg(1)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure_wg, dim3(1), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)dJob.p, 1, (x265amd_cu_measure*)dOut.p);
+      else XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure, dim3(1), dim3(64), 0, (const CuMeasureJob*)dJob.p, 1, (x265amd_cu_measure*)dOut.p);
+      XA_HIP_CHECK(le); }
     return X265AMD_OK;
 }
 
@@ -987,6 +1074,19 @@ int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_pa
     if (rc != X265AMD_OK) return rc;
     xa_phase(XA_PH_RD_WALK);
     mjobs[0].assemble = 1; mjobs[0].recon = d_recon_merge;
+    {
+        /* one transform size per plane: the final measurement follows from the units' results, the assembly runs without being waited for */
+        static const bool composeOn = !(getenv("X265AMD_COMPOSE_MEASURE") && atoi(getenv("X265AMD_COMPOSE_MEASURE")) == 0);
+        x265amd_cu_measure mc;
+        if (composeOn && xa_is_queue(stream_) && compose_final_measure(si, *cu, merge_units[0].part_size, res, sel.data(), mc))
+        {
+            /* the scratch with the residual blocks must outlive this call: it goes back to the queue's own list and is reused behind the assembly, in order */
+            rc = assemble_async(stream_, mjobs[0], sel.data());
+            if (rc != X265AMD_OK) return rc;
+            x265amd_inter_rd_finish(si, rp, cu, 1, &mc, out_merge);
+            return X265AMD_OK;
+        }
+    }
     memcpy(dSel.p, sel.data(), sel.size());
     { const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)(mjobs), (uint64_t)(uintptr_t)(meas + 1), 0, 0, 1 }; hipError_t le;
       if (measure_use_wg(1)) XA_LAUNCH(le, stream_, XA_OP_CU_MEASURE, 1, qa, k_cu_measure_wg, dim3(1), dim3(64 * MEASURE_WG_WAVES), 0, (const CuMeasureJob*)mjobs, 1, meas + 1);

@@ -121,6 +121,10 @@ int xa_merge_rd(void* stream, const x265amd_slice_info* si, const x265amd_rd_par
                 const x265amd_rd_cu* cu, x265amd_cu_unit* skip_units, x265amd_cu_unit* merge_units, uint64_t d_pred, uint64_t d_recon_skip, uint64_t d_recon_merge,
                 x265amd_rd_result* out_skip, x265amd_rd_result* out_merge, int16_t* coeff_out, int* merge_is_skip);
 
+int xa_inter_residual_rd_lazy(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, intptr_t stride,
+                              intptr_t cstride, const x265amd_rd_cu* cu, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
+                              x265amd_rd_result* out, int16_t* coeff_out);
+
 /* X265AMD_TIMING: host time of a row task by phase (running time only: the clock stops while the task is parked).  XA_PHASE(k) charges the time since the
  * previous stamp of this task to phase k; the totals are printed per frame. */
 enum { XA_PH_OTHER = 0, XA_PH_INTRA_SETUP, XA_PH_INTRA_SCAN, XA_PH_INTRA_CAND, XA_PH_INTRA_BITS, XA_PH_INTRA_CHROMA, XA_PH_INTRA_FINAL, XA_PH_PUSH, XA_PH_CABAC_CTU, XA_PH_ANALYZER,
