@@ -598,6 +598,8 @@ void dump_debug_areas(int);
 std::atomic<uint64_t> g_waitNs(0), g_heldNs(0), g_waits(0), g_depNs(0);
 const bool g_prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
 
+std::atomic<int> g_queuesHint{ 128 };       /* the number of queues when X265AMD_QUEUES does not say (xa_queues_hint, before the first use) */
+
 struct Server
 {
     std::mutex m;
@@ -618,7 +620,7 @@ struct Server
     {
         if (numQueues) return 0;
         const char* e = getenv("X265AMD_QUEUES");
-        int n = e ? atoi(e) : 128;
+        int n = e ? atoi(e) : g_queuesHint.load();
         if (n <= 0) { disabled = true; return -1; }
         if (n > 224) n = 224;
         ringsInHost = getenv("X265AMD_RING_HOST") != nullptr;
@@ -822,6 +824,17 @@ void xa_phase_report(void)
     fprintf(stderr, "x265amd: host phases of the row tasks (ms, stamps):");
     for (int k = 0; k < XA_PH_COUNT; k++) fprintf(stderr, " %s %.1f (%llu)", names[k], g_phaseNs[k].load() / 1e6, (unsigned long long)g_phaseN[k].load());
     fprintf(stderr, "\n");
+}
+
+/* A caller that knows it will want more queues than the default (pictures above 1080 lines: more CTU rows in flight, and the rows of I pictures take up to
+ * four) says so before the job server starts; afterwards the call changes nothing.  Returns the number a server started now would have. */
+int xa_queues_hint(int n)
+{
+    if (n > 224) n = 224;
+    int cur = g_queuesHint.load();
+    while (n > cur && !g_queuesHint.compare_exchange_weak(cur, n)) {}
+    const char* e = getenv("X265AMD_QUEUES");
+    return e ? atoi(e) : g_queuesHint.load();
 }
 
 bool xa_queues_enabled()

@@ -58,6 +58,7 @@ struct XaMappedOut : XaMapped { XaMappedOut() : XaMapped(true) {} };
  *   XA_LAUNCH               a kernel launch on a stream, or the same body as a command on a queue */
 inline bool xa_is_queue(const void* st) { return ((uintptr_t)st & 1) != 0; }
 bool xa_queues_enabled();
+int xa_queues_hint(int n);              /* before the job server's first use: at least n queues (unless X265AMD_QUEUES says otherwise); returns the number in force */
 void* xa_queue_acquire();               /* NULL when queues are off (X265AMD_QUEUES=0) or all are taken: use a stream then */
 void xa_queue_release(void* st);
 void* xa_queue_try_acquire();           /* a second queue for the holder of a first one, or NULL at once: never waits */
