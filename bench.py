@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the reference encoder's run (profiling passes)")
     ap.add_argument("--no-kernel-workload", action="store_true", help="skip bench_kernels.py (profiling passes of the encoder alone)")
     ap.add_argument("--res", choices=["1080p", "2160p"], default="1080p", help="1080p = BASELINE.json configs[1] (the bench line); 2160p: the same encode at 3840x2160 (informational)")
+    ap.add_argument("--no-2160p", action="store_true", help="skip the 3840x2160 encode that the 1080p single-GPU run reports beside the bench line (`also_2160p`)")
     args = ap.parse_args()
 
     import torch
@@ -273,6 +274,24 @@ def main():
                             "note": "SURVEY 8d's end-to-end figure: frame payload x (source read + reconstruction write + reference pictures read); the encoder is bound "
                                     "by the latency of the reference's serial decision chain, not by bandwidth"},
         }
+    # ---- the same encode at 3840x2160 (BASELINE.json's metric names both sizes; the bench line is the 1080p one): reported beside it, never instead of it ----
+    if rank == 0 and world == 1 and args.res == "1080p" and not args.no_2160p and not args.no_cpu_baseline:
+        try:
+            W, H = 3840, 2160
+            frames4 = bench_clip(0, K)
+            encode(T, L, bench_clip(0, 2), 0, 0, sync, timed=False)
+            stream4, dt4 = encode(T, L, frames4, 0, 0, sync)
+            ref4 = reference_encode(frames4)
+            line["also_2160p"] = {"value": K / dt4, "unit": "frames/s", "frames": K, "stream_md5": hashlib.md5(stream4).hexdigest(),
+                                  "bit_exact_vs_reference_encoder": None if ref4 is None else bool(ref4["default"]["stream"] == stream4),
+                                  "cpu_baseline": None if ref4 is None else {"value": K / ref4["default"]["seconds"], "cores": ref4["cores"], "kind": "reference",
+                                                                             "says": ref4["default"]["says"], "frame_threads_1": K / ref4["f1"]["seconds"]},
+                                  "note": "the same clip generator, options and comparison at 3840x2160 8-bit (34 CTU rows)"}
+            del frames4, stream4
+        except Exception as exc:       # the bench line stands on its own
+            line["also_2160p"] = {"error": repr(exc)}
+        finally:
+            W, H = 1920, 1080
     # ---- the hot-path kernels on their own (bench_kernels.py): a frame's worth of batched block operations ----
     if not args.no_kernel_workload:
         import bench_kernels

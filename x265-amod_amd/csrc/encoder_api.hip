@@ -208,9 +208,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     }
     if (p->frameNumThreads < 0 || p->frameNumThreads > 16) { xa_fail(X265AMD_EINVAL, "encoder_open: frameNumThreads"); return nullptr; }
     e->frameParallel = p->frameNumThreads > 1;
-    /* pictures above 1080 lines: more rows in flight, and the rows of an I picture take up to four queues (intra_rd.hip): measured at 2160p, 224 queues 12.8 frames/s
-     * against 9.9 with 128 (at 1080p the larger number is no gain) */
-    const int queues = xa_queues_hint(e->ctuH > 17 ? 224 : 128);
+    const int queues = xa_queues_hint(0);           /* the number of device job queues in force (224 unless X265AMD_QUEUES says otherwise) */
     if (e->frameParallel)
     {
         /* FrameEncoder::init (frameencoder.cpp:170-175): rows of a reference picture that must be final before a row of this picture starts */
