@@ -635,7 +635,9 @@ typedef struct x265amd_inter_search_params
 {
     int32_t search_method, subpel_refine, search_range;     /* param.searchMethod (X265AMD_ME_*), subpelRefine, searchRange */
     int32_t qp;                                             /* the CU's QP: lambda (RDCost::setQP) and the MV cost table (MotionEstimate::setQP) */
-    int32_t chroma_mc;                                      /* bChromaMC: chroma in the final prediction, and chroma SATD when subpel_refine > 2 */
+    int32_t chroma_mc;                                      /* bit 0: bChromaMC -- chroma in the final prediction, and chroma SATD when subpel_refine > 2; bit 1 (device job
+                                                             * queues only): the call returns with the final predictions enqueued, not finished -- the decisions are
+                                                             * final, and the caller's next command on the queue (the measurement of the prediction tile) is ordered behind */
     int32_t ref_pic[2][16];                                 /* picture index (into the plane table) of reference r of list l */
     int32_t frame_parallel;                                 /* Search::m_bFrameParallel (param.frameNumThreads > 1, search.cpp:77): vertical search limit
                                                              * m_refLagPixels = searchRange (search.cpp:92, :2763), merge candidates (search.cpp:1934,

@@ -584,6 +584,7 @@ struct XaQueue
     std::vector<Ev> log; bool logging = false; int logPoc = 0, logRow = 0;
     void* helper = nullptr;             /* a second queue the holder of this one may use beside it (xa_queue_set_helper) */
     uint32_t nextFlags = 0;             /* flags the next command gets on top of its own (xa_q_next_flags) */
+    std::vector<void*> laterMapped;     /* pushed-record blocks that commands still in the queue read: back to the pool at the next synchronisation (xa_q_free_mapped_later) */
     void ev(char kind, int op)
     {
         if (!logging) return;
@@ -945,6 +946,14 @@ void xa_queue_release(void* st)
 
 /* the next command of the queue also carries `flags` (XA_CMD_ACQUIRE before a command that reads tables the host has just pushed into reused memory: the
  * scalar data cache may still hold the block's previous contents) -- cheaper than a command of its own; streams: nothing to do */
+/* a block of pushed records (xa_mapped_alloc) that a command not yet waited for reads: it goes back to the pool when the queue is next synchronised.  Streams:
+ * returns false, the caller synchronises and frees as usual. */
+bool xa_q_free_mapped_later(void* st, void* p)
+{
+    if (!xa_is_queue(st) || !p) return false;
+    as_queue(st)->laterMapped.push_back(p);
+    return true;
+}
 void xa_q_next_flags(void* st, int flags) { if (xa_is_queue(st)) as_queue(st)->nextFlags |= (uint32_t)flags; }
 
 hipError_t xa_q_enqueue(void* st, int op, const void* args, size_t argBytes, int count, int flags)
@@ -999,6 +1008,8 @@ hipError_t xa_stream_sync(void* st)
     if (q_wait(q, q->submitted)) { xa_fail(X265AMD_EHIP, "device queue: no answer from the job server"); return hipErrorUnknown; }
     for (const Deferred& d : q->deferred) memcpy(d.dst, d.src, d.bytes);
     q->deferred.clear();
+    for (void* p : q->laterMapped) xa_mapped_free(p);
+    q->laterMapped.clear();
     q->stagingUsed = 0; q->stagingUsedOut = 0;
     return hipSuccess;
 }

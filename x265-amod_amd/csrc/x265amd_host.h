@@ -72,7 +72,8 @@ hipError_t xa_copy_async(void* st, void* dst, const void* src, size_t bytes, hip
 hipError_t xa_copy2d_to_mapped_async(void* st, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
 hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes);
 hipError_t xa_q_enqueue(void* st, int op, const void* args, size_t argBytes, int count, int flags);
-void xa_q_next_flags(void* st, int flags);         /* queue only: the next command also carries these flags */
+void xa_q_next_flags(void* st, int flags);
+bool xa_q_free_mapped_later(void* st, void* p);   /* queue only (false otherwise): the pushed-record block goes back to the pool at the queue's next synchronisation */         /* queue only: the next command also carries these flags */
 void xa_prof_dependency_wait(uint64_t ns);        /* X265AMD_QUEUE_PROF: time a row spent waiting for the row above (queue held, nobody working) */
 #define XA_LAUNCH(ERR, st, OP, COUNT, ARGS, KERNEL, GRID, BLOCK, LDS, ...)                                                   \
     do {                                                                                                                     \
