@@ -539,8 +539,44 @@ def make_encoder_ft_golden():
     print("wrote encoder_ft_golden.npz")
 
 
+def make_encoder_full_golden(only=None):
+    """BASELINE.json's configurations 3-5 at their stated size (and an rd 2 clip of 1080 rows for complexityCheckCU): the reference encoder's stream digest + size and
+    the digest of every reconstructed picture -> tests/golden/encoder_full_golden.json.  The clips are SURVEY.md section 8d's generator (hevc_testlib.survey_clip)."""
+    import subprocess, tempfile, hashlib, time
+    path = os.path.join(T.GOLDEN_DIR, "encoder_full_golden.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for tag, ((w, h), nframes, depth, cfg_id, _, extra) in T.FULL_CASES.items():
+        if only and tag not in only:
+            continue
+        planes = T.full_case_frames(tag)
+        cli = extra + T.FULL_CLI
+        with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+            with open(os.path.join(d, "clip.y4m"), "wb") as f:
+                f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
+                for fr in planes:
+                    f.write(b"FRAME\n")
+                    for pl in fr:
+                        f.write(np.ascontiguousarray(pl).tobytes())
+            exe = os.path.join(T.REF_DIR, "x265_ref%d" % depth)
+            t0 = time.time()
+            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv"] + cli, cwd=d, capture_output=True, text=True, timeout=7200)
+            assert r.returncode == 0, r.stderr[-2000:]
+            fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
+            rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
+            assert len(rec) == fsz * nframes
+            stream = open(os.path.join(d, "out.hevc"), "rb").read()
+            out[tag] = {"stream_md5": hashlib.md5(stream).hexdigest(), "stream_bytes": len(stream),
+                        "recon_md5": [hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)],
+                        "reference_command_line": " ".join(cli), "reference_seconds": round(time.time() - t0, 1)}
+            print(tag, out[tag], r.stderr.strip().splitlines()[-1])
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ft":
         make_encoder_ft_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":
+        make_encoder_full_golden(sys.argv[2:] or None)
     else:
         main()

@@ -3162,6 +3162,57 @@ def encoder_ft_frames(tag):
     return encoder_api_clip(tag, w, h, n, depth)
 
 
+# ---- BASELINE.json's configurations at their stated size (SURVEY.md section 8d's synthetic clip) ----
+def survey_clip(w, h, depth, cfg_id, first, count, gop=0):
+    """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes: luma = a smooth 2-D integer gradient shifted by
+    (2t, t) samples plus a noise field in [-12, 12] (times 4 for 10-bit samples) that moves with it (motion estimation has real work, every block carries a
+    residual), chroma = low-frequency integer ramps shifted by (t, t / 2); the noise field is re-seeded every 24th frame (a scene change).  Integer arithmetic
+    only, and frame t depends on t alone, so every machine and every rank sees the same pictures.  gop: the closed GOP a rank codes in a multi-GPU run (its own
+    noise field behind its IDR picture).  For (1920, 1080, 8, cfg_id 2) these are the frames of bench.py since round 2."""
+    def tri(a, period):
+        a = a % period
+        return np.minimum(a, period - a)
+    sc = 1 << (depth - 8)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    frames = []
+    for t in range(first, first + count):
+        epoch = t // 24
+        noise = np.random.default_rng(0x9E3779B9 ^ (cfg_id << 8) ^ (epoch << 20) ^ (gop << 12)).integers(-12, 13, (h + 64, w + 128))     # indexed by the moving coordinates
+        tt = t % 24
+        v = np.arange(h, dtype=np.int64)[:, None] + tt + 24 * epoch
+        u = np.arange(w, dtype=np.int64)[None, :] + 2 * tt + 48 * epoch
+        luma = 60 + (tri(u, 512) * 96) // 256 + (tri(v, 384) * 64) // 192 + noise[tt:tt + h, 2 * tt:2 * tt + w]
+        vc = np.arange(h // 2, dtype=np.int64)[:, None] + t // 2
+        uc = np.arange(w // 2, dtype=np.int64)[None, :] + t
+        cb = 96 + (tri(uc, 640) * 64) // 320 + (tri(vc, 448) * 16) // 224
+        cr = 160 - (tri(uc + 200, 720) * 48) // 360 + (tri(vc + 100, 512) * 16) // 256
+        frames.append([np.clip(luma * sc, 0, pmax).astype(dt), np.clip(cb * sc, 0, pmax).astype(dt), np.clip(cr * sc, 0, pmax).astype(dt)])
+    return frames
+
+
+# the reference command line shared by the full-size cases: a whole preset in CQP with only what the encoder object does not build switched off, frame-parallel rules
+FULL_CLI = ["--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut", "--keyint", "250", "--no-info", "--no-open-gop",
+            "--rc-lookahead", "5", "--lookahead-slices", "0", "--no-b-pyramid", "--wpp", "--frame-threads", "3", "--pools", "8"]
+FULL_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3, bframes=4)
+SLOW_TOOLS = dict(bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)
+VERYSLOW_TOOLS = dict(bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3, rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=4,
+                      maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0, limitModes=0)
+# tag -> ((w, h), frames, depth, cfg_id of the clip, x265amd_param fields, the reference's command line in front of FULL_CLI)
+FULL_CASES = {
+    "cfg3_2160p_slow/": ((3840, 2160), 3, 8, 3, dict(FULL_BASE, **SLOW_TOOLS), ["--preset", "slow"]),                    # BASELINE.json configs[2]
+    "cfg4_2160p_main10/": ((3840, 2160), 3, 10, 4, dict(FULL_BASE), ["--preset", "medium"]),                              # configs[3]
+    "cfg5_4320p_veryslow_rd6/": ((7680, 4320), 2, 10, 5, dict(FULL_BASE, **VERYSLOW_TOOLS), ["--preset", "veryslow", "--rd", "6", "--bframes", "4"]),      # configs[4]
+    # rd 2 on a picture of 1080 rows: Analysis::complexityCheckCU is active (analysis.cpp:3536-3559, only for pictures of at least 1080 rows at rd 0-2)
+    "fhd_rd2/": ((1920, 1080), 3, 8, 2, dict(FULL_BASE, rdLevel=2, bframes=1), ["--preset", "medium", "--rd", "2", "--bframes", "1"]),
+}
+
+
+def full_case_frames(tag):
+    (w, h), n, depth, cfg_id, _, _ = FULL_CASES[tag]
+    return survey_clip(w, h, depth, cfg_id, 0, n)
+
+
 # ---- lookahead lowres pipeline (x265amd_lowres_init / x265amd_lowres_intra_costs vs Lowres::init / LookaheadTLD::lowresIntraEstimate) ----
 LOWRES_LAMBDA = {8: 1, 10: 16}      # (int)x265_lambda_tab[X265_LOOKAHEAD_QP], X265_LOOKAHEAD_QP = 12 + 6 * (X265_DEPTH - 8) (common/constants.cpp, common/common.h:213)
 

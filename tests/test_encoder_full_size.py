@@ -1,0 +1,50 @@
+"""BASELINE.json's configurations 3, 4 and 5 at their STATED size through the encoder object (include/x265amd_encoder.h), against the reference encoder's stream
+and reconstruction digests (tests/golden/encoder_full_golden.json, made by tests/golden/make_golden.py full with oracle/_ref/x265_ref{8,10}):
+
+  cfg3  3840x2160  8-bit  --preset slow tools (rd 4, RDOQ 2, star / subme 3, 4 references, rect + limit-modes), 3 frames (I P B)
+  cfg4  3840x2160 10-bit  --preset medium (Main 10),                                                             3 frames
+  cfg5  7680x4320 10-bit  --preset veryslow tools + rd 6 (AMP, TU depth 3, 5 merge candidates),                 2 frames (I P)
+  fhd_rd2  1920x1080 rd 2: Analysis::complexityCheckCU (analysis.cpp:3536-3559) is active only for rd 0-2 on pictures of at least 1080 rows
+
+Picture-size dependent code is what these pin: 34 / 68 CTU rows in flight and the queues they take, the cut last CTU row (2160 = 33 x 64 + 48, 4320 = 67 x 64 + 32),
+64-bit squared errors of Main 10 (common.h:142-146), the star search's raster over the full window, level / DPB derivation of the headers at these sizes.
+The clip is SURVEY.md section 8d's generator (hevc_testlib.survey_clip); WPP, frame-parallel rules (the reference's --frame-threads 3), CQP 30."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hevc_testlib as T
+
+GOLD = os.path.join(T.GOLDEN_DIR, "encoder_full_golden.json")
+
+
+def test_full_size_golden_present():
+    g = json.load(open(GOLD))
+    for tag, ((w, h), n, depth, cfg_id, cfg, cli) in T.FULL_CASES.items():
+        assert tag in g and len(g[tag]["recon_md5"]) == n and g[tag]["stream_bytes"] > 0, tag
+
+
+def test_survey_clip_is_the_bench_clip():
+    """the generator is integer only and depends on (t, cfg_id) alone; 10-bit samples are the 8-bit ones times four"""
+    a = T.survey_clip(256, 128, 8, 2, 23, 2)
+    b = T.survey_clip(256, 128, 10, 2, 23, 2)
+    for fa, fb in zip(a, b):
+        for pa, pb in zip(fa, fb):
+            assert pa.dtype == np.uint8 and pb.dtype == np.uint16 and np.array_equal(pa.astype(np.uint16) * 4, pb)
+    assert not np.array_equal(a[0][0], a[1][0])         # frame 24 is a new scene
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.FULL_CASES))
+def test_encoder_object_full_size(tag):
+    g = json.load(open(GOLD))[tag]
+    (w, h), n, depth, cfg_id, cfg, _ = T.FULL_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(tag), w, h, **cfg)
+    assert len(coded) == n
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == g["recon_md5"][poc], "reconstruction of poc %d" % poc
+    assert len(stream) == g["stream_bytes"] and hashlib.md5(stream.tobytes()).hexdigest() == g["stream_md5"]
