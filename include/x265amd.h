@@ -635,13 +635,14 @@ typedef struct x265amd_inter_search_params
 {
     int32_t search_method, subpel_refine, search_range;     /* param.searchMethod (X265AMD_ME_*), subpelRefine, searchRange */
     int32_t qp;                                             /* the CU's QP: lambda (RDCost::setQP) and the MV cost table (MotionEstimate::setQP) */
-    int32_t chroma_mc;                                      /* bit 0: bChromaMC -- chroma in the final prediction, and chroma SATD when subpel_refine > 2; bit 1 (device job
-                                                             * queues only): the call returns with the final predictions enqueued, not finished -- the decisions are
-                                                             * final, and the caller's next command on the queue (the measurement of the prediction tile) is ordered behind */
+    int32_t chroma_mc;                                      /* bChromaMC (non-zero = yes): chroma in the final prediction, and chroma SATD when subpel_refine > 2 */
     int32_t ref_pic[2][16];                                 /* picture index (into the plane table) of reference r of list l */
     int32_t frame_parallel;                                 /* Search::m_bFrameParallel (param.frameNumThreads > 1, search.cpp:77): vertical search limit
                                                              * m_refLagPixels = searchRange (search.cpp:92, :2763), merge candidates (search.cpp:1934,
                                                              * analysis.cpp:2803, :2933) and AMVP candidates (search.cpp:2009) reaching below it are left out */
+    int32_t lazy_sync;                                      /* device job queues only, non-zero: the call returns with the final predictions enqueued, not finished -- the
+                                                             * decisions are final, and the caller's next command on the queue (the measurement of the prediction tile) is
+                                                             * ordered behind them.  0 (every public caller): the call returns with everything done */
 } x265amd_inter_search_params;
 typedef struct x265amd_inter_cu { int16_t x, y; uint8_t log2_size, part_size; uint8_t reserved[2]; } x265amd_inter_cu;
 typedef struct x265amd_pu_result
@@ -951,6 +952,13 @@ void* x265amd_queue_acquire(void);
 void x265amd_queue_release(void* queue);
 /* prints (stderr) what the job server's workgroups have spent per command kind so far; the counters are kept when X265AMD_QUEUE_PROF is set */
 void x265amd_queue_profile_report(void);
+/* Counters of the resident kernel k_job_server since the last reset -- what bench.py's roofline object is made of.  Valid while no queue is held (the
+ * workgroups write them when they leave).  out[0] commands run, [1] ticks of the 100 MHz clock in command bodies, [2] in fences, [3] polling for commands,
+ * [4] algorithmic bytes of all commands (what each command has to read and write, from the sizes in its job records: DESIGN.md section 5), [5] resident
+ * ticks summed over the workgroups, [6] launches of k_job_server, [7] their summed duration by HIP events on its stream in microseconds, [8] workgroups per
+ * launch, [9] reserved; then per command kind k (XaOp, csrc/xa_queue.h): [10 + 3 k] count, [11 + 3 k] body ticks, [12 + 3 k] algorithmic bytes.
+ * n = words available in out (at least 10; 106 for everything); reset != 0 clears the counters afterwards. */
+int x265amd_queue_stats(uint64_t* out, int n, int reset);
 
 /* RDCost (reference: source/encoder/rdcost.h:34-174), 4:2:0 without chroma QP offsets: host-side integer formulas.
  * out[0..5] = lambda2 (FIX8), lambda (FIX8), psyRd, calcRdCost, calcPsyRdCost (0 when psyRd == 0), calcRdSADCost */

@@ -1963,7 +1963,7 @@ def inter_search_run_ref(R, c):
 
 
 INTER_CU_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("log2", "u1"), ("part", "u1"), ("reserved", "u1", 2)])
-INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16)), ("frame_parallel", "<i4")])
+INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16)), ("frame_parallel", "<i4"), ("lazy_sync", "<i4")])
 
 
 def inter_search_run_hip(L, me, c):

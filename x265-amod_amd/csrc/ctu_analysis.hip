@@ -501,7 +501,7 @@ struct Analyzer
         x265amd_inter_search_params sp = *S;
         sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         static const bool lazyMc = !(getenv("X265AMD_LAZY_MC") && atoi(getenv("X265AMD_LAZY_MC")) == 0);
-        if (!searchOnly && lazyMc) sp.chroma_mc |= 2;       /* the measurement below waits for the final prediction */
+        sp.lazy_sync = !searchOnly && lazyMc;       /* the measurement below waits for the final prediction */
         const uint32_t masks[2] = { refMask, 0 };
         xa_phase(XA_PH_ANALYZER);
         struct PhEnd { ~PhEnd() { xa_phase(XA_PH_INTER_SEARCH); } } phEnd;
@@ -612,7 +612,7 @@ struct Analyzer
         x265amd_inter_search_params sp = *S;
         sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         static const bool lazyMc = !(getenv("X265AMD_LAZY_MC") && atoi(getenv("X265AMD_LAZY_MC")) == 0);
-        if (!searchOnly && lazyMc) sp.chroma_mc |= 2;
+        sp.lazy_sync = !searchOnly && lazyMc;
         int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(m.predTile), tileBytes, nullptr, refMasks);
         if (rc != X265AMD_OK) return err = rc;
         for (int i = 0; i < n4 * n4; i++) { m.u[i].pred_mode = X265AMD_MODE_INTER; m.u[i].part_size = (uint8_t)part; }

@@ -3,6 +3,7 @@
  * (reference: source/encoder/analysis.cpp:1146-1848 -> source/common/primitives.h:239-433); the queue keeps that call order per CTU row and removes
  * the launch + synchronise pair from every call.
  */
+#define XA_SERVER_BYTES
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 #include "xa_queue.h"
@@ -97,6 +98,7 @@ XA_DEV void xa_op_copy(const XaCmd& c, int tid)        /* small: inlined into th
     {
         const XaArgsCopy& a = *reinterpret_cast<const XaArgsCopy*>(c.args);
         block_copy<false>(reinterpret_cast<char*>(a.dst), reinterpret_cast<const char*>(a.src), a.bytes, tid, NT);
+        if (tid == 0) XA_BYTES(2 * a.bytes);
     }
 }
 
@@ -111,6 +113,7 @@ XA_DEV void xa_op_copy2d(const XaCmd& c, int tid)        /* small: inlined into 
         const XaArgsCopy2D& a = *reinterpret_cast<const XaArgsCopy2D*>(c.args);
         for (uint64_t y = wv; y < a.height; y += XA_SERVER_WAVES)
             block_copy<false>(reinterpret_cast<char*>(a.dst + y * a.dpitch), reinterpret_cast<const char*>(a.src + y * a.spitch), a.width, lane, 64);
+        if (tid == 0) XA_BYTES(2 * a.width * a.height);
     }
 }
 
@@ -125,6 +128,7 @@ XA_DEV void xa_op_fill(const XaCmd& c, int tid)        /* small: inlined into th
         const XaArgsFill& a = *reinterpret_cast<const XaArgsFill*>(c.args);
         char* d = reinterpret_cast<char*>(a.dst);
         for (size_t i = tid; i < a.bytes; i += NT) d[i] = (char)a.value;
+        if (tid == 0) XA_BYTES(a.bytes);
     }
 }
 
@@ -136,6 +140,13 @@ XA_DEV void xa_op_copy_rects(const XaCmd& c, int tid)        /* small: inlined i
     const bool serial = (c.reserved & 1) != 0;      /* debugging: one wavefront runs every job */
     (void)serial;
         block_copy_rects(*reinterpret_cast<const XaArgsRects*>(c.args), tid, NT);
+        if (tid == 0)
+        {
+            const XaArgsRects& r = *reinterpret_cast<const XaArgsRects*>(c.args);
+            unsigned long long b = 0;
+            for (int k = 0; k < r.n; k++) b += 2ull * (unsigned)r.w[k] * (unsigned)r.h[k] * sizeof(pixel);
+            XA_BYTES(b);
+        }
 }
 
 __device__ __noinline__ void xa_op_mc(const XaCmd& c, int tid)
@@ -400,8 +411,10 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
 }
 
 /* One workgroup per queue.  Wavefront 0 polls the slot of the next command (relaxed system-scope loads of its own device memory), copies it into LDS
- * and the workgroup runs it.  A workgroup leaves when its queue's quit word is set or when it has seen no command for `idleTicks` of the 100 MHz
- * wall clock (nothing resident outlives a host that went away). */
+ * and the workgroup runs it.  A workgroup leaves when its queue's quit word is set, or when it has seen no command for `idleTicks` of the 100 MHz
+ * wall clock AND the host's heartbeat (hosts[0].alive: bumped with every queue taken and every 256th command of any queue) has stood still for that
+ * long -- nothing resident outlives a host that went away, and no queue of a server in use loses its workgroup because its own row was idle (a queue
+ * handed out later would have been written to with nobody reading). */
 __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* rings, XaRingHost* hosts, long long idleTicks, uint64_t generation)
 {
     __shared__ XaCmd s_cmd;
@@ -410,9 +423,13 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     XaRingDev* rd = rings + blockIdx.x;
     XaRingHost* rh = hosts + blockIdx.x;
     const int tid = threadIdx.x;
-    uint64_t seen = 0, signalled = 0, pre = 0;
+    uint64_t seen = 0, signalled = 0, pre = 0, lastAlive = 0;
     bool havePre = false;
+    __shared__ unsigned long long s_bytes[32];
+    const long long tResident0 = wall_clock64();
     if (tid < 64) s_prof[tid] = 0;
+    if (tid < 32) s_bytes[tid] = 0;
+    if (tid == 0) xa_bytes_acc = 0;
     if (tid < 22) xa_stage_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
     if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
@@ -427,6 +444,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
             int go = 0;
             const uint64_t* slot = reinterpret_cast<const uint64_t*>(&rd->cmd[seen % XA_RING]);
             const long long t0 = wall_clock64();
+            long long tIdle = t0;
             for (unsigned spins = 1;; spins++)
             {
                 /* lanes 0..15: the slot; lane 16: the doorbell (the command number the host is waiting for).  The first look uses what was fetched while the
@@ -454,7 +472,15 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                 if ((spins & 63) == 0)
                 {
                     int stop = 0;
-                    if (tid == 0) stop = xa_sys_load(&rd->quit) != 0 || wall_clock64() - t0 > idleTicks;
+                    if (tid == 0)
+                    {
+                        stop = xa_sys_load(&rd->quit) != 0;
+                        if (!stop && wall_clock64() - tIdle > idleTicks)
+                        {
+                            const uint64_t a = xa_sys_load(&hosts[0].alive);
+                            if (a == lastAlive) stop = 1; else { lastAlive = a; tIdle = wall_clock64(); }
+                        }
+                    }
                     if (__shfl(stop, 0, 64)) break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -525,6 +551,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         {
             const long long te = wall_clock64();
             s_prof[2 * (s_cmd.op & 31)] += 1; s_prof[2 * (s_cmd.op & 31) + 1] += (unsigned long long)(te - td);
+            s_bytes[s_cmd.op & 31] += xa_bytes_acc; xa_bytes_acc = 0;          /* behind the barrier: every lane's contribution is in */
             if (s_cmd.reserved & 16)        /* X265AMD_QUEUE_DEBUG & 16: single-job commands of the three hot kinds by block size */
             {
                 const XaArgsJobs4& a = *reinterpret_cast<const XaArgsJobs4*>(s_cmd.args);
@@ -552,12 +579,16 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid < 22) s_prof[40 + tid] = xa_stage_acc[tid];        /* [40..61]: the stages of the transform chains and the fused intra steps */
     __syncthreads();
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
+    if (tid < 32) xa_sys_store(&rh->bytes[tid], rh->bytes[tid] + s_bytes[tid]);
+    if (tid == 32) xa_sys_store(&rh->resident, rh->resident + (unsigned long long)(wall_clock64() - tResident0));
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
 }
 
 /* =========================================================================================================
  * host side
  * ======================================================================================================= */
+void xa_bind_device();
+void xa_thread_device();
 namespace {
 
 const size_t kStagingBytes = 1 << 20;
@@ -613,6 +644,8 @@ struct Server
     char* staging = nullptr;
     std::vector<XaQueue> q;
     hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;        /* around every launch of the resident kernel, on its stream: its duration by HIP events (bench.py's roofline) */
+    double kernelMs = 0.0; uint64_t launches = 0;
     bool running = false;
     int refs = 0;
     uint64_t generation = 0;
@@ -622,6 +655,8 @@ struct Server
     int init()
     {
         if (numQueues) return 0;
+        xa_bind_device();
+        xa_thread_device();
         const char* e = getenv("X265AMD_QUEUES");
         int n = e ? atoi(e) : g_queuesHint.load();
         if (n <= 0) { disabled = true; return -1; }
@@ -643,6 +678,7 @@ struct Server
                 if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
         }
         if (hipFuncSetAttribute((const void*)k_job_server, hipFuncAttributeMaxDynamicSharedMemorySize, XA_SERVER_LDS) != hipSuccess) return -1;
+        if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return -1;
         memset((void*)hosts, 0, sizeof(XaRingHost) * n);
         q.resize(n);
         for (int i = 0; i < n; i++) { q[i].idx = i; q[i].rd = rings + i; q[i].rh = hosts + i; q[i].staging = staging + kStagingBytes * i; }
@@ -655,6 +691,7 @@ struct Server
     int start()
     {
         if (running) return 0;
+        xa_thread_device();
         /* every workgroup starts counting at 0; the head and quit words are reset through the BAR (posted writes, ordered before the launch's doorbell) */
         generation += 0x0123456789ABCDEFull;
         for (int i = 0; i < numQueues; i++)
@@ -666,8 +703,10 @@ struct Server
             *reinterpret_cast<volatile uint64_t*>(&rings[i].head) = 0;
         }
         _mm_sfence();
+        (void)hipEventRecord(ev0, stream);
         hipLaunchKernelGGL(k_job_server, dim3(numQueues), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 60, generation);
         if (hipGetLastError() != hipSuccess) return -1;
+        (void)hipEventRecord(ev1, stream);
         running = true;
         return 0;
     }
@@ -678,6 +717,7 @@ struct Server
         _mm_sfence();
         (void)hipStreamSynchronize(stream);
         running = false;
+        { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { kernelMs += ms; launches++; } }
         static const bool prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
         if (prof) profile_report(false);
     }
@@ -744,9 +784,14 @@ int q_wait(XaQueue* q, uint64_t target)
     struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { if (g_prof) { g_waitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_waits++; } } } acc{ t0 };
     if (xa_in_task())
     {
-        /* a row task: park; the worker thread runs another row meanwhile (xa_fiber.h).  A server that went away shows as a wait without end, as below:
-         * the tasks of the picture then never finish, which the 30 s limit of the ordinary path turns into an error for direct callers only. */
-        xa_wait_counter(tail, target);
+        /* a row task: park; the worker thread runs another row meanwhile (xa_fiber.h).  A server that went away shows as a wait without end: the time limit
+         * (longer than any command: 120 s) turns it into an error, as the 30 s of the ordinary path below does for direct callers */
+        if (xa_wait_counter_deadline(tail, target, 120ull * 1000000000ull))
+        {
+            fprintf(stderr, "x265amd queue %d: no answer: submitted %llu, waiting for %llu, finished %llu, resident %llu\n", q->idx,
+                    (unsigned long long)q->submitted, (unsigned long long)target, (unsigned long long)*tail, (unsigned long long)q->rh->state);
+            return -1;
+        }
         std::atomic_thread_fence(std::memory_order_acquire);
         return 0;
     }
@@ -765,6 +810,7 @@ int q_wait(XaQueue* q, uint64_t target)
     return 0;
 }
 
+void xa_server_alive();
 std::atomic<uint64_t> g_pushNs{ 0 }, g_pushN{ 0 };
 int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* args, size_t argBytes)
 {
@@ -795,6 +841,7 @@ int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* 
     for (int i = 0; i < 8; i++) _mm_store_si128(d + i, _mm_load_si128(s + i));
     _mm_sfence();                       /* the slot is the doorbell: out of the write-combining buffer now */
     q->submitted++;
+    if ((q->submitted & 255) == 0) xa_server_alive();
     if (flags & XA_CMD_SIGNAL) q->lastSignal = q->submitted;
     q->ev('E', (int)op);
     return 0;
@@ -802,7 +849,21 @@ int q_push(XaQueue* q, uint32_t op, uint32_t flags, uint32_t count, const void* 
 
 } // namespace
 
+namespace { void xa_server_alive() { Server& S = server(); if (S.hosts) __atomic_fetch_add(&S.hosts[0].alive, 1, __ATOMIC_RELAXED); } }
 void xa_prof_dependency_wait(uint64_t ns) { if (g_prof) g_depNs += ns; }
+
+/* ---- the process's device.  HIP's current device is per thread and defaults to 0; a process of a multi-GPU job selects its GPU on its main thread only
+ * (torch.cuda.set_device(LOCAL_RANK)).  The first encoder object / job server records that thread's device, and every thread this library creates
+ * (row-task workers, picture tasks, filter threads) selects it before its first HIP call. ---- */
+namespace { std::atomic<int> g_device{ -1 }; }
+void xa_bind_device()
+{
+    int expect = -1, dev = 0;
+    if (g_device.load() >= 0 || hipGetDevice(&dev) != hipSuccess) return;
+    g_device.compare_exchange_strong(expect, dev);
+    xa_fiber_set_thread_init(xa_thread_device);
+}
+void xa_thread_device() { const int d = g_device.load(); if (d >= 0) (void)hipSetDevice(d); }
 
 /* ---- X265AMD_TIMING: host phases of the row tasks ---- */
 namespace {
@@ -871,6 +932,7 @@ void* xa_queue_acquire()
         if (S.freed.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) return nullptr;
     }
     if (S.start() != 0) return nullptr;
+    __atomic_fetch_add(&S.hosts[0].alive, 1, __ATOMIC_RELAXED);
     f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr;
     S.freeCount = S.freeCount - 1;
     S.refs++;
@@ -1005,7 +1067,14 @@ hipError_t xa_stream_sync(void* st)
         _mm_sfence();
         q->lastSignal = q->submitted;
     }
-    if (q_wait(q, q->submitted)) { xa_fail(X265AMD_EHIP, "device queue: no answer from the job server"); return hipErrorUnknown; }
+    if (q_wait(q, q->submitted))
+    {
+        /* the server is gone: nothing reads the pushed records any more */
+        for (void* p : q->laterMapped) xa_mapped_free(p);
+        q->laterMapped.clear(); q->deferred.clear();
+        xa_fail(X265AMD_EHIP, "device queue: no answer from the job server");
+        return hipErrorUnknown;
+    }
     for (const Deferred& d : q->deferred) memcpy(d.dst, d.src, d.bytes);
     q->deferred.clear();
     for (void* p : q->laterMapped) xa_mapped_free(p);
@@ -1081,6 +1150,39 @@ hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes)
 
 extern "C" void* x265amd_queue_acquire(void) { return xa_queue_acquire(); }
 extern "C" void x265amd_queue_release(void* queue) { xa_queue_release(queue); }
+/* Counters of the resident kernel since the last reset (valid while no queue is held: the workgroups write them when they leave).  out[0] commands,
+ * [1] ticks (100 MHz) in command bodies, [2] in fences, [3] polling, [4] algorithmic bytes of all commands, [5] resident ticks summed over the workgroups,
+ * [6] launches of k_job_server, [7] their duration by HIP events in microseconds (summed), [8] workgroups per launch, [9] reserved;
+ * then per command kind k < 32: [10 + 3 k] count, [11 + 3 k] body ticks, [12 + 3 k] algorithmic bytes.  n: words available in out (>= 106 for everything). */
+extern "C" int x265amd_queue_stats(uint64_t* out, int n, int reset)
+{
+    Server& S = server();
+    std::lock_guard<std::mutex> g(S.m);
+    if (!out || n < 10) return xa_fail(X265AMD_EINVAL, "queue_stats: arguments");
+    for (int i = 0; i < n; i++) out[i] = 0;
+    if (!S.numQueues) return X265AMD_OK;
+    if (S.running && S.refs == 0) S.stop();
+    for (int i = 0; i < S.numQueues; i++)
+    {
+        const XaRingHost& h = S.hosts[i];
+        for (int k = 0; k < 32; k++)
+        {
+            const uint64_t cnt = k < 31 ? h.prof[2 * k] : 0, tk = k < 31 ? h.prof[2 * k + 1] : 0;
+            if (k < XA_OP_COUNT) { out[0] += cnt; out[1] += tk; }
+            out[4] += h.bytes[k];
+            if (10 + 3 * k + 2 < n && k < XA_OP_COUNT) { out[10 + 3 * k] += cnt; out[11 + 3 * k] += tk; out[12 + 3 * k] += h.bytes[k]; }
+        }
+        out[2] += h.prof[63]; out[3] += h.prof[62]; out[5] += h.resident;
+    }
+    out[6] = S.launches; out[7] = (uint64_t)(S.kernelMs * 1000.0); out[8] = (uint64_t)S.numQueues;
+    if (reset)
+    {
+        for (int i = 0; i < S.numQueues; i++) { memset((void*)S.hosts[i].prof, 0, sizeof(S.hosts[i].prof)); memset((void*)S.hosts[i].bytes, 0, sizeof(S.hosts[i].bytes)); S.hosts[i].resident = 0; }
+        S.kernelMs = 0.0; S.launches = 0;
+    }
+    return X265AMD_OK;
+}
+
 extern "C" void x265amd_queue_profile_report(void) { Server& S = server(); std::lock_guard<std::mutex> g(S.m); if (S.numQueues) S.profile_report(true); }
 
 

@@ -171,12 +171,31 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     if (!p) { xa_fail(X265AMD_EINVAL, "encoder_open: null param"); return nullptr; }
     if (p->sourceWidth < 16 || p->sourceHeight < 16 || (p->sourceWidth & 7) || (p->sourceHeight & 7) || p->sourceWidth > 8192 || p->sourceHeight > 4320)
     { xa_fail(X265AMD_EINVAL, "encoder_open: picture size must be a multiple of 8 (16..8192 x 16..4320)"); return nullptr; }
-    if (!p->fpsNum || !p->fpsDenom || p->bframes < 0 || p->bframes > 16 || p->keyframeMax < 1 || p->maxNumReferences < 1 || p->maxNumReferences > 8 ||
-        p->qp < 0 || p->qp > 51 || p->rdLevel < 2 || p->rdLevel > 6 || p->maxNumMergeCand < 1 || p->maxNumMergeCand > 5 ||
-        p->tuQTMaxInterDepth < 1 || p->tuQTMaxInterDepth > 4 || p->tuQTMaxIntraDepth < 1 || p->tuQTMaxIntraDepth > 4 ||
-        (p->searchMethod != X265AMD_ME_DIA && p->searchMethod != X265AMD_ME_HEX && p->searchMethod != X265AMD_ME_STAR) || p->subpelRefine < 0 || p->subpelRefine > 7 ||
-        p->rdoqLevel < 0 || p->rdoqLevel > 2 || p->psyRdoqFix8 < 0 || p->recursionSkipMode < 0 || p->recursionSkipMode > 1 || p->limitReferences < 0 || p->limitReferences > 3 || (p->bEnableAMP && !p->bEnableRectInter))
-    { xa_fail(X265AMD_EINVAL, "encoder_open: parameter outside the built subset (see x265amd_encoder.h)"); return nullptr; }
+    {
+        /* every field outside the built subset is named (the reference logs "x265 [error]: <what>" per field, encoder/api.cpp:96-239 -> x265_check_params) */
+        static thread_local char why[160];
+        const char* bad = nullptr;
+#define XA_REQUIRE(cond, text) do { if (!bad && !(cond)) bad = text; } while (0)
+        XA_REQUIRE(p->fpsNum && p->fpsDenom, "fpsNum / fpsDenom must be non-zero");
+        XA_REQUIRE(p->bframes >= 0 && p->bframes <= 16, "bframes outside 0..16");
+        XA_REQUIRE(p->keyframeMax >= 1, "keyframeMax below 1");
+        XA_REQUIRE(p->maxNumReferences >= 1 && p->maxNumReferences <= 8, "maxNumReferences outside 1..8");
+        XA_REQUIRE(p->qp >= 0 && p->qp <= 51, "qp outside 0..51 (constant QP is the only rate control built)");
+        XA_REQUIRE(p->rdLevel >= 2 && p->rdLevel <= 6, "rdLevel outside 2..6 (rd 0-1 are not built)");
+        XA_REQUIRE(p->maxNumMergeCand >= 1 && p->maxNumMergeCand <= 5, "maxNumMergeCand outside 1..5");
+        XA_REQUIRE(p->tuQTMaxInterDepth >= 1 && p->tuQTMaxInterDepth <= 4, "tuQTMaxInterDepth outside 1..4");
+        XA_REQUIRE(p->tuQTMaxIntraDepth >= 1 && p->tuQTMaxIntraDepth <= 4, "tuQTMaxIntraDepth outside 1..4");
+        XA_REQUIRE(p->searchMethod == X265AMD_ME_DIA || p->searchMethod == X265AMD_ME_HEX || p->searchMethod == X265AMD_ME_STAR, "searchMethod: only dia, hex and star are built (no umh / sea / full)");
+        XA_REQUIRE(p->subpelRefine >= 0 && p->subpelRefine <= 7, "subpelRefine outside 0..7");
+        XA_REQUIRE(p->rdoqLevel >= 0 && p->rdoqLevel <= 2, "rdoqLevel outside 0..2");
+        XA_REQUIRE(p->psyRdoqFix8 >= 0, "psyRdoqFix8 negative");
+        XA_REQUIRE(p->recursionSkipMode >= 0 && p->recursionSkipMode <= 1, "recursionSkipMode: only 0 and 1 are built (no edge-based rskip)");
+        XA_REQUIRE(p->limitReferences >= 0 && p->limitReferences <= 3, "limitReferences outside 0..3");
+        XA_REQUIRE(!p->bEnableAMP || p->bEnableRectInter, "bEnableAMP needs bEnableRectInter");
+#undef XA_REQUIRE
+        if (bad) { snprintf(why, sizeof(why), "encoder_open: %s", bad); xa_fail(X265AMD_EINVAL, why); return nullptr; }
+    }
+    xa_bind_device();           /* the threads of this library work on the opening thread's GPU */
     std::unique_ptr<x265amd_encoder> e(new x265amd_encoder);
     e->p = *p;
     e->W = p->sourceWidth; e->H = p->sourceHeight; e->w4 = e->W / 4; e->h4 = e->H / 4;
@@ -764,7 +783,7 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     memset(sparams.data(), 0, sizeof(x265amd_sao_ctu) * nctu);
     int32_t saoFlags[2] = { 0, 0 };
     int filterRc = X265AMD_OK;
-    std::thread filters([&] { filterRc = filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } });
+    std::thread filters([&] { xa_thread_device(); filterRc = filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } });
     const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
@@ -807,6 +826,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         std::shared_future<int> prev = e->lastTask;
         const bool timing = getenv("X265AMD_TIMING") != nullptr;
         pic->done = std::async(std::launch::async, [e, pic, prev, timing]() {
+            xa_thread_device();
             const auto t0 = std::chrono::steady_clock::now();
             const int rc = e->frameParallel ? e->runFrameParallel(pic) : e->runFrame(pic, prev);
             if (timing)

@@ -158,7 +158,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             const x265amd_inter_cu& c = cus[w.cu];
             const int size = 1 << c.log2_size;
             const bool chromaOk = !((w.g.w >> 1) & 3) && !((w.g.h >> 1) & 3);
-            const bool chromaSatd = S->subpel_refine > 2 && (S->chroma_mc & 1) && chromaOk;       /* MotionEstimate::setSourcePU (motion.cpp:234-237) */
+            const bool chromaSatd = S->subpel_refine > 2 && (S->chroma_mc != 0) && chromaOk;       /* MotionEstimate::setSourcePU (motion.cpp:234-237) */
             /* the second PU sees the first one's choice where the reference reads it from the CU under analysis */
             std::vector<x265amd_mv_unit> saved;
             Geo g0 = pu_geo(c.x, c.y, size, c.part_size, 0);
@@ -242,7 +242,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
         {
             const x265amd_inter_cu& c = cus[w.cu];
             const bool chromaOk = !((w.g.w >> 1) & 3) && !((w.g.h >> 1) & 3);
-            const bool chromaSatd = S->subpel_refine > 2 && (S->chroma_mc & 1) && chromaOk;
+            const bool chromaSatd = S->subpel_refine > 2 && (S->chroma_mc != 0) && chromaOk;
             for (int k = 0; k < w.nMerge; k++)
             {
                 /* pictures coded in parallel: no candidate that reaches below the rows the reference pictures have finished (search.cpp:1918-1937) */
@@ -319,7 +319,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
         {
             const x265amd_inter_cu& c = cus[w.cu];
             const bool chromaOk = !((w.g.w >> 1) & 3) && !((w.g.h >> 1) & 3);
-            const bool chromaSatd = S->subpel_refine > 2 && (S->chroma_mc & 1) && chromaOk;
+            const bool chromaSatd = S->subpel_refine > 2 && (S->chroma_mc != 0) && chromaOk;
             for (int list = 0; list < 2; list++) { w.best[list].cost = 0xFFFFFFFFu; w.best[list].ref = -1; }
             for (int list = 0; list < (isB ? 2 : 1); list++)
                 for (int ref = 0; ref < I->num_ref_idx[list]; ref++)
@@ -463,7 +463,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             if (!(r.inter_dir & 1)) pic0 = -1;
             if (!(r.inter_dir & 2)) pic1 = -1;
             /* final prediction: motionCompensation(cu, pu, *predYuv, true, bChromaMC) into the CU's prediction tile */
-            x265amd_mc_job f = mcJob(w.g, c.x, c.y, !isB, pic0, mv0, pic1, mv1, (S->chroma_mc & 1) ? 3 : 1, 0, 0);
+            x265amd_mc_job f = mcJob(w.g, c.x, c.y, !isB, pic0, mv0, pic1, mv1, (S->chroma_mc != 0) ? 3 : 1, 0, 0);
             const uint64_t base = d_pred + (size_t)w.cu * pred_bytes_per_cu;
             f.dst_y = base + ((size_t)(w.g.y - c.y) * 64 + (w.g.x - c.x)) * isz;
             f.dst_u = base + (64 * 64 + (size_t)((w.g.y - c.y) / 2) * 32 + (w.g.x - c.x) / 2) * isz;
@@ -480,9 +480,9 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
         memcpy(dJ.p, finalMc.data(), finalMc.size() * sizeof(x265amd_mc_job));
         int rc = x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJ.p, (int)finalMc.size());
         if (rc != X265AMD_OK) return rc;
-        /* chroma_mc bit 1: the caller's next command on this queue waits for the predictions (the decisions are final already).  What the pending command reads --
+        /* lazy_sync: the caller's next command on this queue waits for the predictions (the decisions are final already).  What the pending command reads --
          * its jobs, the plane table -- stays out of the pool until the queue is next synchronised. */
-        if ((S->chroma_mc & 2) && xa_q_free_mapped_later(st, dJ.p) && xa_q_free_mapped_later(st, dPlanes.p)) { dJ.p = nullptr; dPlanes.p = nullptr; }
+        if (S->lazy_sync && xa_q_free_mapped_later(st, dJ.p) && xa_q_free_mapped_later(st, dPlanes.p)) { dJ.p = nullptr; dPlanes.p = nullptr; }
         else XA_HIP_CHECK(xa_stream_sync(st));
     }
     return X265AMD_OK;

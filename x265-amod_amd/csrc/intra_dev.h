@@ -52,6 +52,7 @@ XA_DEV void wave_intra_scan_job(const x265amd_intra_job* jobs, int ji, int32_t* 
 {
     const x265amd_intra_job j = xa_ld_record(jobs + ji);
     const int log2N = j.log2_tr_size, N = 1 << log2N, N2 = 2 * N, units = N >> 2, L = 2 * units;
+    if (lane == 0) XA_BYTES((4 * N + 1 + N * N) * sizeof(pixel) + 35 * 4);
     const pixel* recon = reinterpret_cast<const pixel*>(j.recon);
     const pixel* fenc = reinterpret_cast<const pixel*>(j.fenc);
     const long rs = j.recon_stride;
@@ -152,6 +153,7 @@ XA_DEV void block_intra_scan_job(const x265amd_intra_job& j, int32_t* res, pixel
     static_assert(offsetof(IntraScanLds, acc) == offsetof(IntraLds, acc), "in_pred_sample reads the neighbour arrays at the head of either layout");
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
     const int log2N = j.log2_tr_size, N = 1 << log2N, N2 = 2 * N;
+    if (tid == 0) XA_BYTES((4 * N + 1 + N * N) * sizeof(pixel) + 35 * 4);
     const pixel* recon = reinterpret_cast<const pixel*>(j.recon);
     const pixel* fenc = reinterpret_cast<const pixel*>(j.fenc);
     __syncthreads();            /* the previous block's readers are done with the LDS */

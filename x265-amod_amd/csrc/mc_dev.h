@@ -71,6 +71,9 @@ XA_DEV void wave_mc_job(const XaArgsMc& a, int ji, int idx, int step = XA_WAVE)
     const uint64_t* fencPlanes = a.fencPlanes; const long fstride = a.fstride, fcstride = a.fcstride; uint32_t* cost = a.cost;
     const x265amd_mc_job j = xa_ld_record(a.jobs + ji);
     const int refs[2] = { j.ref0, j.ref1 };
+    if (idx == 0)       /* per direction: the luma block with its 8-tap border and both chroma blocks with their 4-tap border; the prediction written (+ the source read when costs are taken) */
+        XA_BYTES((unsigned long long)((j.ref0 >= 0) + (j.ref1 >= 0)) * ((unsigned)(j.w + 7) * (j.h + 7) + 2u * (unsigned)(j.w / 2 + 3) * (j.h / 2 + 3)) * sizeof(pixel) +
+                 3ull * j.w * j.h / 2 * sizeof(pixel) * (COST ? 2 : 1));
     int mv[2][2] = { { j.mv0[0], j.mv0[1] }, { j.mv1[0], j.mv1[1] } };
     /* CUData::clipMv */
     {

@@ -1035,6 +1035,7 @@ template<bool STAR> XA_DEV void block_me_search(const MeParams& p, int vb, int t
 
     const x265amd_me_group g = p.groups[vb];
     const pixel* refG = reinterpret_cast<const pixel*>(p.refs[g.ref]);
+    if (tid == 0) XA_BYTES(((unsigned long long)g.win_w * g.win_h + 64 * 64) * sizeof(pixel) + (unsigned long long)g.num_jobs * (sizeof(x265amd_me_job) + 8));     /* window + source tile + job / result records */
 
     /* stage the reference window: rows of win_w samples, 4 samples per lane, coalesced along the row */
     {
@@ -1093,6 +1094,7 @@ template<bool STAR> XA_DEV void block_me_search_multi(const MeParams& p, int gro
     {
         const x265amd_me_group g = p.groups[gi];
         const pixel* refG = reinterpret_cast<const pixel*>(p.refs[g.ref]);
+        if (tid == 0) XA_BYTES(((unsigned long long)g.win_w * g.win_h + 64 * 64) * sizeof(pixel) + (unsigned long long)g.num_jobs * (sizeof(x265amd_me_job) + 8));
         pixel* win = reinterpret_cast<pixel*>(smem + (size_t)gi * region);
         pixel* fencT = win + p.maxWinW * p.maxWinH + 16;
         const int gpr = g.win_w >> 2, total = gpr * g.win_h;

@@ -29,6 +29,7 @@ XA_DEV size_t rd_layer_offset(int plane, int layer)
 XA_DEV void wave_cu_measure_job(const CuMeasureJob* jobs, int ji, CuMeasure* out, pixel* tile /* this wave's 64 x 64 LDS tile */, int lane)
 {
     const CuMeasureJob j = xa_ld_record(jobs + ji);
+    if (lane == 0) XA_BYTES((9ull << (2 * j.log2_size)) / 2 * sizeof(pixel));         /* source, prediction tile read; reconstruction tile written: 3 x 1.5 N^2 samples */
     const uint8_t* sel = reinterpret_cast<const uint8_t*>(j.sel);
     const int16_t* resi = reinterpret_cast<const int16_t*>(j.resi);
     CuMeasure m;
@@ -89,6 +90,7 @@ struct CuMeasureLds
 XA_DEV void block_cu_measure_job(const CuMeasureJob& j, CuMeasure* out, CuMeasureLds& s, int tid, int nthr)
 {
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
+    if (tid == 0) XA_BYTES((9ull << (2 * j.log2_size)) / 2 * sizeof(pixel));
     const uint8_t* sel = reinterpret_cast<const uint8_t*>(j.sel);
     const int16_t* resi = reinterpret_cast<const int16_t*>(j.resi);
     const int log2S = j.log2_size, S = 1 << log2S, C = S >> 1;

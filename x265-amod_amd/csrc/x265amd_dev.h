@@ -13,6 +13,16 @@
 #include <stdint.h>
 #include "../../include/x265amd.h"
 
+/* algorithmic bytes of the running command: added by ONE lane per unit of work from the sizes in its job record.  Counted by the job server (device_queue.hip
+ * defines XA_SERVER_BYTES before this header: its roofline counters); nothing in the ordinary kernels */
+#ifdef XA_SERVER_BYTES
+__shared__ unsigned long long xa_bytes_acc;
+#define XA_BYTES(v) atomicAdd(&xa_bytes_acc, (unsigned long long)(v))
+#else
+#define XA_BYTES(v)
+#endif
+
+
 typedef x265amd_pixel pixel;
 
 #define XA_DEPTH X265AMD_DEPTH

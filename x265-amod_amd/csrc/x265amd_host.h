@@ -127,6 +127,11 @@ int xa_inter_residual_rd_lazy(void* stream, const x265amd_slice_info* si, const 
                               intptr_t cstride, const x265amd_rd_cu* cu, x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
                               x265amd_rd_result* out, int16_t* coeff_out);
 
+/* The process's GPU (csrc/device_queue.hip): xa_bind_device records the calling thread's current device (first call wins); xa_thread_device selects it on
+ * the calling thread -- every thread the library creates calls it before its first HIP call (HIP's current device is per thread, default 0). */
+void xa_bind_device();
+void xa_thread_device();
+
 /* X265AMD_TIMING: host time of a row task by phase (running time only: the clock stops while the task is parked).  XA_PHASE(k) charges the time since the
  * previous stamp of this task to phase k; the totals are printed per frame. */
 enum { XA_PH_OTHER = 0, XA_PH_INTRA_SETUP, XA_PH_INTRA_SCAN, XA_PH_INTRA_CAND, XA_PH_INTRA_BITS, XA_PH_INTRA_CHROMA, XA_PH_INTRA_FINAL, XA_PH_PUSH, XA_PH_CABAC_CTU, XA_PH_ANALYZER,

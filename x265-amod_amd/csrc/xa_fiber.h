@@ -36,6 +36,10 @@ struct XaTask
 void xa_tasks_run(const XaTask* tasks, int n);
 /* inside a task: parks it until *counter >= value.  On an ordinary thread: polls (pause; after a while short sleeps). */
 void xa_wait_counter(const volatile uint64_t* counter, uint64_t value);
+/* the same with a time limit: 0 when the counter got there, -1 when `timeoutNs` passed first (a device queue whose server went away) */
+int xa_wait_counter_deadline(const volatile uint64_t* counter, uint64_t value, uint64_t timeoutNs);
+/* run by every worker thread before its first task (set before the first xa_tasks_run: the workers start there).  HIP's current device is per thread. */
+void xa_fiber_set_thread_init(void (*fn)(void));
 /* general condition: an ordinary thread polls it; a task is parked and the condition is evaluated by whichever worker holds the task at that moment */
 void xa_wait_until(XaPred pred, void* ctx);
 int xa_in_task(void);

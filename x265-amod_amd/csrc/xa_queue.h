@@ -49,10 +49,16 @@ struct alignas(128) XaRingDev
 struct alignas(128) XaRingHost
 {
     uint64_t tail; uint64_t pad0[15];           /* commands finished, as of the last signalling command */
-    uint64_t state; uint64_t pad1[15];          /* 1 while the workgroup is resident */
+    uint64_t state;                             /* 1 while the workgroup is resident */
+    uint64_t alive;                             /* hosts[0] only: bumped by the host while queues are in use; an idle workgroup leaves only when this has stood still */
+    uint64_t pad1[14];
     uint64_t dbg[64];                           /* X265AMD_QUEUE_DEBUG & 2: what each wavefront was about to touch (dumped on abort) */
     uint64_t prof[64];                          /* X265AMD_QUEUE_PROF: per command kind [2 * op] count, [2 * op + 1] ticks of the 100 MHz clock (written when the
                                                    workgroup leaves); [62] ticks spent polling, [63] ticks in fences */
+    uint64_t bytes[32];                         /* algorithmic bytes per command kind (what each command has to read and write, from its job records: see
+                                                   DESIGN.md section 5); always counted, written when the workgroup leaves */
+    uint64_t resident;                          /* ticks of the 100 MHz clock between the workgroup's start and its exit, summed over server generations */
+    uint64_t pad2[15];
 };
 
 struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, second array, results, extra, count) shapes of the job-list kernels */

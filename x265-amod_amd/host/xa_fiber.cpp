@@ -42,6 +42,7 @@ struct Fiber
     Group* group = nullptr;
     std::atomic<const volatile uint64_t*> waitCounter{ nullptr };      /* parked: resume when *waitCounter >= waitValue (read by every worker) */
     std::atomic<uint64_t> waitValue{ 0 };
+    std::atomic<uint64_t> deadlineNs{ 0 };                              /* parked with a time limit: resume (to report the timeout) once the clock has passed this */
     XaPred pred = nullptr; void* predCtx = nullptr;                     /* parked on a general condition: evaluated by the worker that has taken the task */
     void* sp = nullptr;                 /* saved stack pointer while parked */
     char* stack = nullptr;
@@ -64,6 +65,7 @@ struct Sched
     std::atomic<int> highWater{ 0 };
     std::mutex m; std::condition_variable cv;          /* workers sleep here while there is no task at all */
     std::mutex stackM; std::vector<char*> stacks;
+    std::mutex placeM;                  /* one submitter places its tasks at a time */
     std::vector<std::thread> threads;
     int numWorkers = 0;
     bool started = false;
@@ -147,18 +149,21 @@ void prepare_stack(Fiber* f)
     f->sp = s;
 }
 
+void (*g_threadInit)(void) = nullptr;
+
 void worker_loop()
 {
     Sched& S = sched();
     Worker w;
     t_worker = &w;
+    if (g_threadInit) g_threadInit();       /* e.g. hipSetDevice: HIP's current device is per thread */
     unsigned idle = 0;
     Fiber* failed[32]; int nFailed = 0;
     uint64_t tIdle0 = 0;
     for (;;)
     {
         Fiber* best = nullptr;
-        uint64_t bestPrio = ~0ull;
+        uint64_t bestPrio = ~0ull, nowCached = 0;
         const int hw = S.highWater.load(std::memory_order_acquire);
         for (int i = 0; i < hw; i++)
         {
@@ -171,7 +176,13 @@ void worker_loop()
             if (skip) continue;
             /* the counter part of the condition, without taking the task (see xa_fiber.h: the words stay mapped, a stale look wakes early at worst) */
             const volatile uint64_t* c = st == ST_NEW ? f.task.startCounter : f.waitCounter.load(std::memory_order_acquire);
-            if (c && *c < (st == ST_NEW ? f.task.startValue : f.waitValue.load(std::memory_order_acquire))) continue;
+            if (c && *c < (st == ST_NEW ? f.task.startValue : f.waitValue.load(std::memory_order_acquire)))
+            {
+                const uint64_t dl = st == ST_PARKED ? f.deadlineNs.load(std::memory_order_acquire) : 0;
+                if (!dl) continue;
+                if (!nowCached) nowCached = now_ns();
+                if (nowCached < dl) continue;           /* past its time limit: it runs to report that */
+            }
             best = &f; bestPrio = f.task.priority;
         }
         if (!best)
@@ -274,6 +285,11 @@ void xa_tasks_run(const XaTask* tasks, int n)
     Sched& S = sched();
     Group grp;
     grp.left = n;
+    if (n > kMaxTasks) { fprintf(stderr, "x265amd: fatal: %d tasks in one submission (limit %d)\n", n, (int)kMaxTasks); abort(); }
+    /* all n slots or none: rows of a later picture wait for rows of an earlier one, so a picture placed in part (the table full of later pictures' rows that
+     * cannot start) would never get its remaining rows in -- wait until the whole picture fits, then place it without another submitter in between */
+    std::unique_lock<std::mutex> place(S.placeM);
+    while (kMaxTasks - S.live.load(std::memory_order_acquire) < n) { struct timespec ts = { 0, 1000000 }; nanosleep(&ts, nullptr); }
     for (int k = 0; k < n; k++)
     {
         /* a free slot (several pictures submit concurrently) */
@@ -286,7 +302,7 @@ void xa_tasks_run(const XaTask* tasks, int n)
                 int expect = ST_EMPTY;
                 if (f.state.load(std::memory_order_acquire) != ST_EMPTY || !f.state.compare_exchange_strong(expect, ST_RUNNING, std::memory_order_acq_rel)) continue;
                 f.task = tasks[k]; f.group = &grp; f.pred = nullptr; f.predCtx = nullptr; f.sp = nullptr; f.stack = nullptr; f.scratchList = nullptr; f.worker = nullptr;
-                f.waitCounter.store(nullptr); f.waitValue.store(0); f.runNs = 0; f.userMark = 0;
+                f.waitCounter.store(nullptr); f.waitValue.store(0); f.deadlineNs.store(0); f.runNs = 0; f.userMark = 0;
                 int hw = S.highWater.load(std::memory_order_acquire);
                 while (hw < i + 1 && !S.highWater.compare_exchange_weak(hw, i + 1, std::memory_order_acq_rel)) {}
                 S.live.fetch_add(1, std::memory_order_acq_rel);
@@ -297,6 +313,7 @@ void xa_tasks_run(const XaTask* tasks, int n)
             struct timespec ts = { 0, 1000000 }; nanosleep(&ts, nullptr);         /* all slots taken: wait for a task to finish */
         }
     }
+    place.unlock();
     { std::lock_guard<std::mutex> lk(S.m); }
     S.cv.notify_all();
     std::unique_lock<std::mutex> lk(grp.m);
@@ -326,6 +343,38 @@ void xa_wait_counter(const volatile uint64_t* counter, uint64_t value)
         else { struct timespec ts = { 0, 20000 }; nanosleep(&ts, nullptr); }
     }
 }
+
+int xa_wait_counter_deadline(const volatile uint64_t* counter, uint64_t value, uint64_t timeoutNs)
+{
+    if (*counter >= value) return 0;
+    const uint64_t deadline = now_ns() + timeoutNs;
+    Worker* w = current_worker();
+    if (w && w->cur)
+    {
+        Fiber* f = w->cur;
+        f->pred = nullptr;
+        int rc = 0;
+        do
+        {
+            f->deadlineNs.store(deadline, std::memory_order_release);
+            f->waitValue.store(value, std::memory_order_release); f->waitCounter.store(counter, std::memory_order_release);
+            Worker* on = f->worker;
+            xa_ctx_switch(&f->sp, on->sp);
+            if (*counter < value && now_ns() >= deadline) { rc = -1; break; }
+        } while (*counter < value);
+        f->waitCounter.store(nullptr, std::memory_order_release);
+        f->deadlineNs.store(0, std::memory_order_release);
+        return rc;
+    }
+    for (unsigned spins = 0; *counter < value; spins++)
+    {
+        if (spins < 20000) _mm_pause();
+        else { struct timespec ts = { 0, 20000 }; nanosleep(&ts, nullptr); if (now_ns() >= deadline) return *counter >= value ? 0 : -1; }
+    }
+    return 0;
+}
+
+void xa_fiber_set_thread_init(void (*fn)(void)) { g_threadInit = fn; }
 
 void xa_wait_until(XaPred pred, void* ctx)
 {
