@@ -17,8 +17,9 @@ outside -- so rank r encodes GOP r of the clip (keyint K, x265amd_param.firstFra
 digests are gathered for the report.  Per-GPU work is fixed: weak scaling.
 
 The kernels of the hot path are timed on their own in bench_kernels.py (a frame's worth of motion searches, intra scans, transform chains, merge
-costs, coefficient codings and filters as batches): its figures ride along as `kernel_workload`, and the roofline object prices that workload's
-dominant kernel (the encoder itself runs one resident kernel per encode, whose "launch" is the whole analysis).
+costs, coefficient codings and filters as batches): its figures ride along as `kernel_workload`.  The `roofline` object prices the kernel the timed
+region actually runs: k_job_server, resident for the whole encode -- the algorithmic bytes of every command it ran (counted on the device) over its launch
+duration (HIP events on its stream), and the share of its resident time spent inside command bodies (`busy_frac`).
 
 Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
 """
@@ -50,28 +51,11 @@ REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree
 
 
 def bench_clip(first, count, gop=0):
-    """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes: luma = a smooth 2-D integer gradient shifted by
-    (2t, t) samples plus a noise field in [-12, 12] that moves with it (so motion estimation has real work and every block carries a residual), chroma = low-frequency
-    integer ramps shifted by (t, t / 2); the noise field is re-seeded every 24th frame.  Integer arithmetic only, and frame t depends on t alone, so every rank
-    (and the reference run) sees the same pictures.  gop: the closed GOP a rank codes in a multi-GPU run -- its own noise field (a scene of its own behind its IDR
-    picture), the same motion, so that every rank has the same amount of work."""
-    def tri(a, period):
-        a = a % period
-        return np.minimum(a, period - a)
-    frames = []
-    for t in range(first, first + count):
-        epoch = t // 24
-        noise = np.random.default_rng(0x9E3779B9 ^ (2 << 8) ^ (epoch << 20) ^ (gop << 12)).integers(-12, 13, (H + 64, W + 128))     # cfg_id 2; indexed by the moving coordinates
-        tt = t % 24
-        v = np.arange(H, dtype=np.int64)[:, None] + tt + 24 * epoch
-        u = np.arange(W, dtype=np.int64)[None, :] + 2 * tt + 48 * epoch
-        luma = 60 + (tri(u, 512) * 96) // 256 + (tri(v, 384) * 64) // 192 + noise[tt:tt + H, 2 * tt:2 * tt + W]
-        vc = np.arange(H // 2, dtype=np.int64)[:, None] + t // 2
-        uc = np.arange(W // 2, dtype=np.int64)[None, :] + t
-        cb = 96 + (tri(uc, 640) * 64) // 320 + (tri(vc, 448) * 16) // 224
-        cr = 160 - (tri(uc + 200, 720) * 48) // 360 + (tri(vc + 100, 512) * 16) // 256
-        frames.append([np.clip(luma, 0, 255).astype(np.uint8), np.clip(cb, 0, 255).astype(np.uint8), np.clip(cr, 0, 255).astype(np.uint8)])
-    return frames
+    """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes (tests/hevc_testlib.py: survey_clip, cfg_id 2 --
+    the generator the full-size parity cases use as well): integer arithmetic only, frame t depends on t alone, the noise field is re-seeded every 24th frame.
+    gop: the closed GOP a rank codes in a multi-GPU run (its own noise field behind its IDR picture, the same motion: every rank has the same amount of work)."""
+    import hevc_testlib as T
+    return T.survey_clip(W, H, 8, 2, first, count, gop)
 
 
 def encode(T, L, frames, first_frame, keyint, sync, timed=True):
@@ -137,6 +121,37 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True):
     return bytes(stream), dt
 
 
+def queue_stats(L, reset):
+    """x265amd_queue_stats (include/x265amd.h): the counters of the resident kernel k_job_server since the last reset"""
+    out = (C.c_uint64 * 106)()
+    L.lib.x265amd_queue_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int]
+    rc = L.lib.x265amd_queue_stats(out, 106, 1 if reset else 0)
+    return list(out) if rc == 0 else None
+
+
+XA_OPS = ["nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain", "intra_tu_chain_rdoq", "intra_scan",
+          "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn"]
+
+
+def job_server_roofline(st, frames_payload_bytes, wall_s):
+    """the roofline object of the timed region's dominant (and only resident) kernel.  One launch of k_job_server lasts the whole encode: `achieved` = the
+    algorithmic bytes of every command it ran (what each command has to read and write, from the sizes in its job records, counted on the device) / the launch
+    duration by HIP events on its stream.  busy_frac = ticks inside command bodies / resident ticks summed over the workgroups: the rest is polling for the
+    host's next command."""
+    if not st or not st[6]:
+        return None
+    kernel_s = st[7] / 1e6
+    per_op = {XA_OPS[k]: {"commands": st[10 + 3 * k], "body_ms": st[11 + 3 * k] / 1e5, "algorithmic_MB": st[12 + 3 * k] / 1e6} for k in range(len(XA_OPS)) if st[10 + 3 * k]}
+    achieved = st[4] / kernel_s / 1e9
+    return {"bound": "hbm", "kernel": "k_job_server", "launches": st[6], "workgroups": st[8], "launch_ms": 1000.0 * kernel_s / st[6], "bytes": st[4],
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "busy_frac": st[1] / st[5] if st[5] else None, "commands": st[0], "body_ms_all_workgroups": st[1] / 1e5, "polling_ms_all_workgroups": st[3] / 1e5,
+            "frame_payload_bytes_8d": frames_payload_bytes, "frac_8d": frames_payload_bytes / wall_s / 1e9 / HBM_PEAK_GBS,
+            "per_command_kind": per_op,
+            "note": "k_job_server is resident for the whole encode (one launch = the timed region); bytes = sum over its commands of their algorithmic bytes; traffic: "
+                    "the PMC counter passes do not survive a resident kernel (profiles/collect.sh), the per-kernel counter figures of the batched kernels are under kernel_workload"}
+
+
 def usable_cores():
     """the host cores this process may really use: the cgroup's CPU quota when there is one (the GPU boxes of this project: 16 of 256 hardware threads)"""
     n = os.cpu_count() or 1
@@ -196,6 +211,7 @@ def main():
     ap.add_argument("--no-kernel-workload", action="store_true", help="skip bench_kernels.py (profiling passes of the encoder alone)")
     ap.add_argument("--res", choices=["1080p", "2160p"], default="1080p", help="1080p = BASELINE.json configs[1] (the bench line); 2160p: the same encode at 3840x2160 (informational)")
     ap.add_argument("--no-2160p", action="store_true", help="skip the 3840x2160 encode that the 1080p single-GPU run reports beside the bench line (`also_2160p`)")
+    ap.add_argument("--no-scene-clip", action="store_true", help="skip the 60-frame clip with both re-seeds inside that the 1080p single-GPU run reports beside the bench line (`scene_change_clip`)")
     args = ap.parse_args()
 
     import torch
@@ -227,7 +243,9 @@ def main():
     frames = bench_clip(0, K, gop=rank)
     if Wm > 0:
         encode(T, L, bench_clip(0, Wm), 0, 0, sync, timed=False)
+    queue_stats(L, True)                 # the counters of the resident kernel from here on: the timed encode alone
     stream, dt = encode(T, L, frames, rank * K, K if world > 1 else 0, sync)
+    qstats = queue_stats(L, True)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -270,10 +288,26 @@ def main():
             "bit_exact_vs_reference_encoder": same,
             "stream": {"bytes_per_gop": [s[0] for s in sizes], "md5_per_gop": [s[1] for s in sizes]},
             "cpu_baseline": cpu,
+            "roofline": job_server_roofline(qstats, alg, dt),
             "encoder_hbm": {"algorithmic_bytes": alg, "achieved_GB/s": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS,
                             "note": "SURVEY 8d's end-to-end figure: frame payload x (source read + reconstruction write + reference pictures read); the encoder is bound "
                                     "by the latency of the reference's serial decision chain, not by bandwidth"},
         }
+    # ---- SURVEY.md section 8d's whole clip: 60 frames with both re-seeds of the noise field inside (pictures with new content everywhere) ----
+    if rank == 0 and world == 1 and args.res == "1080p" and not args.no_scene_clip and not args.no_cpu_baseline:
+        try:
+            frames60 = bench_clip(0, 60)
+            stream60, dt60 = encode(T, L, frames60, 0, 0, sync)
+            ref60 = reference_encode(frames60)
+            line["scene_change_clip"] = {"value": 60 / dt60, "unit": "frames/s", "frames": 60, "stream_md5": hashlib.md5(stream60).hexdigest(),
+                                         "bit_exact_vs_reference_encoder": None if ref60 is None else bool(ref60["default"]["stream"] == stream60),
+                                         "cpu_baseline": None if ref60 is None else {"value": 60 / ref60["default"]["seconds"], "cores": ref60["cores"], "kind": "reference",
+                                                                                     "says": ref60["default"]["says"], "frame_threads_1": 60 / ref60["f1"]["seconds"]},
+                                         "note": "the same clip generator and options over 60 frames: the noise field is re-seeded at frames 24 and 48 (no scene-cut detection on either side: "
+                                                 "those pictures are coded as P / B pictures whose CUs end up intra coded)"}
+            del frames60, stream60
+        except Exception as exc:       # the bench line stands on its own
+            line["scene_change_clip"] = {"error": repr(exc)}
     # ---- the same encode at 3840x2160 (BASELINE.json's metric names both sizes; the bench line is the 1080p one): reported beside it, never instead of it ----
     if rank == 0 and world == 1 and args.res == "1080p" and not args.no_2160p and not args.no_cpu_baseline:
         try:
@@ -298,11 +332,9 @@ def main():
         kargs = bench_kernels.parse_args(["--gpus", str(args.gpus), "--steps", str(max(5, min(20, K))), "--warmup", "3", "--res", args.res] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         kw = bench_kernels.run(kargs)
         if rank == 0 and kw is not None:
-            line["roofline"] = dict(kw["roofline"], of="the dominant kernel of kernel_workload (a frame's batched block operations); the encode itself is one resident kernel")
-            line["kernel_workload"] = {"frames_per_s": kw["value"], "ms_per_frame": kw["ms_per_step"], "workload": kw["config"]["workload"], "kernels": kw["kernels"],
+            line["kernel_workload"] = {"roofline": dict(kw["roofline"], of="the dominant kernel of this workload (a frame's batched block operations)"),
+                                       "frames_per_s": kw["value"], "ms_per_frame": kw["ms_per_step"], "workload": kw["config"]["workload"], "kernels": kw["kernels"],
                                        "parity_sample": kw["parity_sample"], "cpu_baseline": kw.get("cpu_baseline")}
-    elif rank == 0:
-        line["roofline"] = None
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

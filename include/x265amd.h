@@ -485,6 +485,11 @@ int x265amd_extend_pic_border(void* stream, x265amd_pixel* d_pic, intptr_t strid
 /* the same for picture lines y_begin .. y_end - 1 only (their left / right margins; the top margin with line 0, the bottom margin with the last line):
  * the row-by-row form of FrameFilter::processPostRow (source/encoder/framefilter.cpp:592-664), used when pictures are coded in parallel */
 int x265amd_extend_border_rows(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY, int y_begin, int y_end);
+/* the margins of lines y_begin .. y_end - 1 whose samples are final in the columns x_begin .. x_end - 1 only (a CTU row published column by column while its
+ * analysis advances): the left margin when left != 0, the right margin when right != 0, with the last picture line the bottom margin below those columns and
+ * with line 0 the top margin above them (their corners under the same conditions). */
+int x265amd_extend_border_band(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY, int y_begin, int y_end,
+                               int x_begin, int x_end, int left, int right);
 int x265amd_weight_plane(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, intptr_t stride, int width, int height,
                          int marginX, int marginY, int inputWeight, int inputOffset, int log2WeightDenom);
 
@@ -517,6 +522,12 @@ int x265amd_deblock_picture(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u
 int x265amd_deblock_rows(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
                          int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
                          int cbQpOffset, int crQpOffset, int bypassEnabled, int passes, int y4_begin, int y4_end);
+/* ... restricted to the CTU columns ctu_col_begin .. ctu_col_end - 1: the vertical edges right of the first column's left boundary up to and including the right
+ * boundary of the last column (the CTU right of it must be analysed), then the horizontal edges inside the columns.  Chunks in column order give the band's
+ * result: the last CTU rows of a picture are filtered while their analysis advances, so that pictures referencing it follow a few CTUs behind. */
+int x265amd_deblock_rows_cols(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
+                              int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
+                              int cbQpOffset, int crQpOffset, int bypassEnabled, int passes, int y4_begin, int y4_end, int ctu_col_begin, int ctu_col_end);
 
 /* the deblocking records of a picture from the maps the analysis fills in (host): edge marks from the CU / PU / TU structure as
  * Deblock::deblockCU sets them (deblock.cpp:70-185), picture identities from info->ref_poc.  out: (width/4) x (height/4) records. */
@@ -525,6 +536,9 @@ int x265amd_deblock_units(const x265amd_slice_info* si, const x265amd_mvpred_inf
 /* the records of unit rows y4_begin .. y4_end - 1 (same array); picture identities are numbered the same way in every call for a picture */
 int x265amd_deblock_units_rows(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
                                x265amd_deblock_unit* out, int y4_begin, int y4_end);
+/* ... of the unit columns x4_begin .. x4_end - 1 of those rows */
+int x265amd_deblock_units_rect(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
+                               x265amd_deblock_unit* out, int y4_begin, int y4_end, int x4_begin, int x4_end);
 
 /* --- sample adaptive offset over a picture, the two data-parallel halves; 4:2:0, sao-non-deblock off.
  * Plane tables are HOST arrays of 3 device addresses (sample (0,0) of Y, U, V).
@@ -552,6 +566,12 @@ int x265amd_sao_stats_rows(void* stream, const uint64_t rec_planes[3], const uin
                            int width, int height, int32_t* d_count, int32_t* d_offset_org, int ctu_row_begin, int ctu_row_end);
 int x265amd_sao_apply_rows(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
                            int width, int height, const x265amd_sao_ctu* d_params, int ctu_row_begin, int ctu_row_end);
+/* the column forms: statistics of the CTU columns ctu_col_begin .. ctu_col_end - 1 of those rows; offset samples of the luma sample columns x_begin .. x_end - 1
+ * (even; the deblocked input must be final one sample beyond either end) */
+int x265amd_sao_stats_rows_cols(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
+                                int width, int height, int32_t* d_count, int32_t* d_offset_org, int ctu_row_begin, int ctu_row_end, int ctu_col_begin, int ctu_col_end);
+int x265amd_sao_apply_rows_cols(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
+                                int width, int height, const x265amd_sao_ctu* d_params, int ctu_row_begin, int ctu_row_end, int x_begin, int x_end);
 
 /* --- final entropy coding of CTUs: the CABAC write pass, host code.  Entropy::encodeCTU / encodeCU /
  * encodeTransform / codePredInfo / codeCoeffNxN and the arithmetic coder (reference: source/encoder/entropy.cpp:768-1222, :1431-2200,
@@ -896,6 +916,11 @@ int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int frame_thre
 int x265amd_sao_rdo_rows(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
                          const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags,
                          int ctu_row_begin, int ctu_row_end);
+/* the CTUs ctu_col_begin .. ctu_col_end - 1 of ONE row (frame_threads > 1): `carry` (X265AMD_CTX_STRIDE + 8 bytes, the caller's) takes the row's entropy state
+ * from one call to the next; a call that starts at column 0 starts the row.  Columns in order. */
+int x265amd_sao_rdo_cols(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                         const int32_t* count, const int32_t* offset_org, x265amd_sao_ctu* params, int32_t* sao_flags,
+                         int ctu_row, int ctu_col_begin, int ctu_col_end, uint8_t* carry);
 
 /* --- lookahead lowres pipeline, first stage.
  * x265amd_lowres_init = Lowres::init (reference: source/common/lowres.cpp:337-403): frame_init_lowres_core (source/common/pixel.cpp:605-628) from the

@@ -45,6 +45,51 @@ struct StageTimer
     ~StageTimer() { if (g_timing) g_stageMs[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+/* ---- reference-picture guards (x265amd_host.h): the row task's hooks live in its task slot ---- */
+static int xa_ref_guard_wait(int pic, int yMin, int yMax, int xMax)
+{
+    void** slot = xa_task_slot();
+    const XaRowHooks* h = slot ? (const XaRowHooks*)*slot : nullptr;
+    if (!h || !h->ref_wait) return 0;
+    return h->ref_wait(h->ctx, pic, yMin, yMax, xMax);
+}
+int xa_ref_guard_mc(const x265amd_mc_job* jobs, int n)
+{
+    void** slot = xa_task_slot();
+    if (!slot || !*slot) return 0;
+    int yMin[32], yMax[32], xMax[32];
+    for (int k = 0; k < 32; k++) { yMin[k] = 1 << 30; yMax[k] = -(1 << 30); xMax[k] = -(1 << 30); }
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_mc_job& j = jobs[i];
+        const int refs[2] = { j.ref0, j.ref1 };
+        const int16_t* mv[2] = { j.mv0, j.mv1 };
+        for (int l = 0; l < 2; l++)
+        {
+            if (refs[l] < 0 || refs[l] >= 32) continue;
+            /* the block moved by the vector's full-sample part (floor) with the taps of the 8-tap luma filter around it (chroma reaches no further in luma terms) */
+            const int y0 = j.y + (mv[l][1] >> 2) - 4, y1 = j.y + j.h - 1 + (mv[l][1] >> 2) + 5, x1 = j.x + j.w - 1 + (mv[l][0] >> 2) + 5;
+            if (y0 < yMin[refs[l]]) yMin[refs[l]] = y0;
+            if (y1 > yMax[refs[l]]) yMax[refs[l]] = y1;
+            if (x1 > xMax[refs[l]]) xMax[refs[l]] = x1;
+        }
+    }
+    for (int k = 0; k < 32; k++) if (yMax[k] > -(1 << 30)) if (xa_ref_guard_wait(k, yMin[k], yMax[k], xMax[k])) return -1;
+    return 0;
+}
+int xa_ref_guard_me(const x265amd_me_job* jobs, const int* pics, int n)
+{
+    void** slot = xa_task_slot();
+    if (!slot || !*slot) return 0;
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_me_job& j = jobs[i];
+        /* the search area with the interpolation margins and what the pattern / sub-sample refinement may step outside (x265amd_me_plan's bounds) */
+        if (xa_ref_guard_wait(pics[i], j.y + j.mvmin[1] - 8, j.y + j.h + j.mvmax[1] + 8, j.x + j.w + j.mvmax[0] + 10)) return -1;
+    }
+    return 0;
+}
+
 namespace {
 
 #if X265AMD_DEPTH < 10
@@ -160,6 +205,7 @@ struct Analyzer
             j.dst_u += (size_t)((g.y >> 1) * 32 + (g.x >> 1)) * sizeof(pixel); j.dst_v += (size_t)((g.y >> 1) * 32 + (g.x >> 1)) * sizeof(pixel);
             jobs.push_back(j);
         }
+        if (xa_ref_guard_mc(jobs.data(), (int)jobs.size())) return fail("a reference picture failed");
         memcpy(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * jobs.size());
         if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, (int)jobs.size()) != X265AMD_OK)
             return err = X265AMD_EHIP;
@@ -169,6 +215,7 @@ struct Analyzer
     int predictAndMeasure(std::vector<x265amd_mc_job>& jobs, int x, int y, int log2, const int* tiles, x265amd_cu_measure* meas)
     {
         const int n = (int)jobs.size();
+        if (xa_ref_guard_mc(jobs.data(), n)) return fail("a reference picture failed");
         memcpy(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * n);
         if (x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, n) != X265AMD_OK)
             return err = X265AMD_EHIP;
@@ -1376,8 +1423,11 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (hooks->row_ready(hooks->ctx, addr / ctuW) < 0) { rc = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"); break; }
                 hooks->before_row(hooks->ctx, addr / ctuW);
             }
+            if (hooks && hooks->ctu_wait && hooks->ctu_wait(hooks->ctx, addr / ctuW, addr % ctuW)) { rc = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed"); break; }
+            if (hooks && hooks->before_ctu) hooks->before_ctu(hooks->ctx, addr / ctuW, addr % ctuW);
             rc = doCtu(addr, q ? q : stream);
             if (rc == X265AMD_OK && xa_stream_sync(q ? q : stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "analyse_frame: synchronize");
+            if (hooks && rc == X265AMD_OK && hooks->after_ctu) hooks->after_ctu(hooks->ctx, addr / ctuW, addr % ctuW);
             if (hooks && rc == X265AMD_OK && addr % ctuW == ctuW - 1) hooks->after_row(hooks->ctx, addr / ctuW);
         }
         if (q) xa_queue_release(q);
@@ -1418,6 +1468,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             Row* r = (Row*)c; Frame& f = *r->f;
             const int row = r->row, ctuW = f.ctuW;
             const auto tStart = std::chrono::steady_clock::now();
+            if (void** slot = xa_task_slot()) *slot = (void*)f.hooks;          /* the guards of this row's reference reads (xa_ref_guard_*) */
             if (f.hooks && f.firstErr.load() == X265AMD_OK)
             {
                 if (f.hooks->row_ready(f.hooks->ctx, row) < 0) { int ok = X265AMD_OK; f.firstErr.compare_exchange_strong(ok, xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed")); }
@@ -1457,12 +1508,16 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 }
                 int r2 = f.firstErr.load();
                 if (r2 == X265AMD_OK && !st) r2 = X265AMD_EHIP;
+                /* the reference pictures are published column by column: this CTU follows them (parked on their counters meanwhile) */
+                if (r2 == X265AMD_OK && f.hooks && f.hooks->ctu_wait && f.hooks->ctu_wait(f.hooks->ctx, row, c2)) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed");
+                if (r2 == X265AMD_OK && f.hooks && f.hooks->before_ctu) f.hooks->before_ctu(f.hooks->ctx, row, c2);
                 if (r2 == X265AMD_OK) r2 = f.doCtu(row * ctuW + c2, st);
                 if (r2 == X265AMD_OK && xa_stream_sync(st) != hipSuccess) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");
                 if (r2 != X265AMD_OK) { int ok = X265AMD_OK; f.firstErr.compare_exchange_strong(ok, r2); }
                 std::atomic_thread_fence(std::memory_order_release);
                 *f.done[row] = (uint64_t)(c2 + 1);
                 if (r2 != X265AMD_OK) break;
+                if (f.hooks && f.hooks->after_ctu) f.hooks->after_ctu(f.hooks->ctx, row, c2);
                 if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
             }
             if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;

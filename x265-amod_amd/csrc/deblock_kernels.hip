@@ -27,6 +27,8 @@ struct DbParams
     const x265amd_deblock_unit* units;
     int betaOffset, tcOffset, cqpOffset[2], bypassEnabled;
     int y4Begin, y4End;         /* the unit rows whose edges this launch filters (a band of CTU rows; the whole picture: 0 .. height / 4) */
+    int xvBegin, xvEnd;         /* vertical edges: the unit columns x4 (edge between x4 - 1 and x4) with xvBegin <= x4 < xvEnd */
+    int xhBegin, xhEnd;         /* horizontal edges: the unit columns xhBegin <= x4 < xhEnd */
 };
 
 __device__ const uint8_t db_cqp[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };     /* g_chromaScale[30..43], 4:2:0 (constants.cpp:346-350) */
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void k_deblock(DbParams P)
     const int iy = t / nx, ix = t - iy * nx;
     const int x4 = DIR == 0 ? 2 * ix : ix, y4 = P.y4Begin + (DIR == 0 ? iy : 2 * iy);
     if (y4 >= h4 || y4 >= P.y4End || (DIR == 0 ? x4 == 0 : y4 == 0)) return;
+    if (DIR == 0 ? (x4 < P.xvBegin || x4 >= P.xvEnd) : (x4 < P.xhBegin || x4 >= P.xhEnd)) return;
     const x265amd_deblock_unit q = P.units[y4 * w4 + x4];
     const x265amd_deblock_unit p = P.units[DIR == 0 ? y4 * w4 + x4 - 1 : (y4 - 1) * w4 + x4];
     const int bs = db_strength(q, p, q.flags & (DIR ? X265AMD_DB_TU_TOP : X265AMD_DB_TU_LEFT), q.flags & (DIR ? X265AMD_DB_PU_TOP : X265AMD_DB_PU_LEFT));
@@ -179,6 +182,20 @@ extern "C" int x265amd_deblock_rows(void* stream, x265amd_pixel* d_y, x265amd_pi
                                     int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
                                     int cbQpOffset, int crQpOffset, int bypassEnabled, int passes, int y4_begin, int y4_end)
 {
+    return x265amd_deblock_rows_cols(stream, d_y, d_u, d_v, stride, cstride, width, height, d_units, betaOffsetDiv2, tcOffsetDiv2, cbQpOffset, crQpOffset, bypassEnabled, passes,
+                                     y4_begin, y4_end, 0, (width + 63) >> 6);
+}
+
+/* The same band restricted to the CTU columns ctu_col_begin .. ctu_col_end - 1, for a CTU row that is filtered while its analysis still advances (the last rows
+ * of a picture coded in parallel with the pictures that reference it, csrc/encoder_api.hip): the vertical edges right of the first column's left boundary up to
+ * and INCLUDING the right boundary of the last column (the CTU to the right must be analysed), then the horizontal edges inside the columns.  Vertical edges
+ * lie eight samples apart and touch three on either side, horizontal edges only read their own columns: chunk after chunk in column order gives the band's
+ * result (the boundary edge of a chunk is filtered before the horizontal edges on either side of it read its samples). */
+extern "C" int x265amd_deblock_rows_cols(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride,
+                                         int width, int height, const x265amd_deblock_unit* d_units, int betaOffsetDiv2, int tcOffsetDiv2,
+                                         int cbQpOffset, int crQpOffset, int bypassEnabled, int passes, int y4_begin, int y4_end, int ctu_col_begin, int ctu_col_end)
+{
+    if (ctu_col_begin < 0 || ctu_col_begin >= ctu_col_end || ctu_col_end > ((width + 63) >> 6)) return xa_fail(X265AMD_EINVAL, "x265amd_deblock_rows_cols: column range");
     if (!d_y || !d_u || !d_v || !d_units || width <= 0 || height <= 0 || (width & 7) || (height & 7) || y4_begin < 0 || y4_end > (height >> 2) || y4_begin >= y4_end || (y4_begin & 1) || (y4_end & 1))
         return xa_fail(X265AMD_EINVAL, "x265amd_deblock_picture: bad arguments (picture dimensions must be multiples of 8)");
     DbParams P;
@@ -186,6 +203,7 @@ extern "C" int x265amd_deblock_rows(void* stream, x265amd_pixel* d_y, x265amd_pi
     P.stride = (long)stride; P.cstride = (long)cstride; P.width = width; P.height = height; P.units = d_units;
     P.betaOffset = betaOffsetDiv2 * 2; P.tcOffset = tcOffsetDiv2 * 2; P.cqpOffset[0] = cbQpOffset; P.cqpOffset[1] = crQpOffset;
     P.bypassEnabled = bypassEnabled; P.y4Begin = y4_begin; P.y4End = y4_end;
+    P.xvBegin = 16 * ctu_col_begin + 1; P.xvEnd = 16 * ctu_col_end + 1; P.xhBegin = 16 * ctu_col_begin; P.xhEnd = 16 * ctu_col_end;
     const int w4 = width >> 2, h4 = y4_end - y4_begin;
     if (passes & 1)
     {

@@ -12,6 +12,7 @@
 #include "x265amd.h"
 #include "x265amd_encoder.h"
 #include "x265amd_host.h"
+#include "xa_fiber.h"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,17 +50,30 @@ struct Pic
     /* the frame task: result code when the picture is completely coded (reconstruction final, NAL written) */
     std::shared_future<int> done;
     std::vector<uint8_t> nalBytes;
-    /* pictures coded in parallel (param.frameNumThreads > 1): the filtered picture is built row by row in dFin (dRec when SAO is off) and `reconRows` CTU rows
-     * of it are final -- Frame::m_reconRowFlag (frameencoder.cpp:900-905, framefilter.cpp:654-664) */
+    /* pictures coded in parallel (param.frameNumThreads > 1): the filtered picture is built in dFin (dRec when SAO is off) while the picture is analysed and
+     * published to the pictures that reference it as it becomes final (finalX below) -- Frame::m_reconRowFlag (frameencoder.cpp:900-905, framefilter.cpp:654-664),
+     * by columns instead of whole rows */
     pixel* dFin = nullptr;
     std::mutex mu;
     std::condition_variable cv;
-    std::atomic<int> reconRows{ 0 };        /* polled by the row tasks of the pictures that reference this one */
     int analysedRows = 0;
+    /* Publication by columns: finalX[r] luma sample columns of CTU row r are final in the filtered picture (the picture width: the whole row, right margin
+     * included); what the pictures referencing this one wait for, CTU by CTU (gateCtuReady / gateRefReady).  analysedCols[r] (under `mu`): CTUs of row r analysed. */
+    std::vector<volatile uint64_t*> finalX;     /* counters (xa_fiber.h): the row tasks of other pictures park on them */
+    std::vector<int> analysedCols;
     std::atomic<bool> failed{ false };
     const pixel* finalPlanes() const { return dFin ? dFin : dRec; }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); }
-    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); }
+    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
+    void publish(int row, int x) { std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x; }
+    int published(int row) const { const int v = (int)*finalX[row]; std::atomic_thread_fence(std::memory_order_acquire); return v; }
+    void fail()         /* whoever waits for this picture is released */
+    {
+        failed.store(true, std::memory_order_release);
+        for (volatile uint64_t* c : finalX) *c = 1u << 30;
+        { std::lock_guard<std::mutex> lk(mu); }
+        cv.notify_all();
+    }
 };
 
 }
@@ -110,6 +124,7 @@ struct x265amd_encoder
     int runFrame(const PicP& pic, std::shared_future<int> prev);
     int runFrameParallel(const PicP& pic);
     int filterRows(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
+    int filterRowsCols(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
 };
 
 /* ---- configuration ---- */
@@ -402,6 +417,9 @@ int x265amd_encoder::prepare(const PicP& picp)
         memset(pic.refPoc, 0, sizeof(pic.refPoc));
         for (int l = 0; l < 2; l++)
             for (size_t r = 0; r < pic.lists[l].size(); r++) pic.refPoc[l][r] = pic.lists[l][r]->poc;
+        pic.finalX.resize(ctuH);
+        for (int r = 0; r < ctuH; r++) pic.finalX[r] = xa_counter_alloc();
+        pic.analysedCols.assign(ctuH, 0);
     }
     return 0;
 }
@@ -617,30 +635,82 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
  * row so that the rows of this picture become available to the pictures that reference it while its lower rows are still being analysed. */
 struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; };
 
-static int gateRowReady(void* ctx, int row)
+/* What a CTU may read of a reference picture, and when.  The reference waits for whole rows: row + refLagRows rows of every reference picture before a row
+ * starts (frameencoder.cpp:893-908).  What the row's commands can actually read is less -- vectors end searchRange samples below the block (search.cpp:92,
+ * :2763; merge / AMVP candidates beyond are left out), plus sub-sample steps and interpolation taps: the rows row - 2 .. row + 2 at most -- and pictures here
+ * are published by COLUMNS (Pic::finalX, filterRowsCols): a CTU starts when those rows of every reference picture are final two CTUs to its right, which covers
+ * ordinary vectors, the co-located CTUs' motion and the co-located depths; every command that reads reference samples first asks gateRefReady with its exact
+ * reach (xa_ref_guard_*), so a long vector waits for exactly what it needs.  A picture therefore follows its reference pictures a few CTUs behind instead of
+ * rows behind, and the slow last CTU row of a picture (cut CTUs when the height is no multiple of 64) no longer holds up every picture behind it.  Results do
+ * not depend on any of this: a sample is only ever read when it is final.  (Deadlock freedom with few device queues: a row takes its queue when it starts, and
+ * it starts only when finalX of the rows it will follow is above zero, i.e. when those rows hold their queues and run.) */
+/* the per-CTU gate: the rows row - 2 .. row + 1 of every reference picture final up to 56 samples beyond the CTU to the right (vectors up to that length, the
+ * co-located CTUs' motion and depths), row + 2 begun (a vector reaching into its first lines is rare: gateRefWait then waits for it, and the row holds its queue) */
+static inline int gateNeed(const x265amd_encoder& e, int col) { return std::min(e.W, 64 * col + 120); }
+static int gateCtuReady(void* ctx, int row, int col)        /* polled (the start condition of a row task): 1 yes, 0 not yet, -1 a reference picture failed */
 {
     RowGate& g = *(RowGate*)ctx;
     const x265amd_encoder& e = *g.e;
-    const int need = std::min(e.ctuH, row + 1 + e.refLagRows);
+    const int need = gateNeed(e, col), r0 = std::max(0, row - 2), r1 = std::min(e.ctuH - 1, row + 1);
     for (Pic* q : g.refs)
     {
         if (q->failed.load(std::memory_order_acquire)) return -1;
-        if (q->reconRows.load(std::memory_order_acquire) < need) return 0;
+        if (row + 2 < e.ctuH && q->published(row + 2) < 1) return 0;
+        for (int r = r1; r >= r0; r--) if (q->published(r) < need) return 0;
     }
     return 1;
 }
-static void gateBeforeRow(void* ctx, int row)
+static int gateRowReady(void* ctx, int row) { return gateCtuReady(ctx, row, 0); }
+static int gateCtuWait(void* ctx, int row, int col)         /* blocking: the task parks on the counters */
 {
     RowGate& g = *(RowGate*)ctx;
     const x265amd_encoder& e = *g.e;
-    /* the co-located CTUs' depths (topSkipMinDepth reads refFrameList[l][0] at this CTU's address): that row of the reference picture is coded now */
+    const int need = gateNeed(e, col), r0 = std::max(0, row - 2), r1 = std::min(e.ctuH - 1, row + 1);
+    for (Pic* q : g.refs)
+        for (int r = r1; r >= r0; r--)
+        {
+            if (q->published(r) < need) xa_wait_counter(q->finalX[r], (uint64_t)need);
+            if (q->failed.load(std::memory_order_acquire)) return -1;
+        }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+static int gateRefWait(void* ctx, int picIdx, int yMin, int yMax, int xMax)
+{
+    RowGate& g = *(RowGate*)ctx;
+    const x265amd_encoder& e = *g.e;
+    if (picIdx < 0 || picIdx >= (int)g.refs.size()) return 0;          /* the picture itself / the source: not a reference */
+    Pic* q = g.refs[picIdx];
+    const int need = xMax >= e.W - 1 ? e.W : std::max(0, xMax + 1);
+    const int r0 = std::min(std::max(yMin, 0), e.H - 1) >> 6, r1 = std::min(std::max(yMax, 0), e.H - 1) >> 6;
+    for (int r = r1; r >= r0; r--)
+    {
+        if (q->published(r) < need) xa_wait_counter(q->finalX[r], (uint64_t)need);
+        if (q->failed.load(std::memory_order_acquire)) return -1;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+static void gateBeforeRow(void*, int) {}
+static void gateBeforeCtu(void* ctx, int row, int col)
+{
+    RowGate& g = *(RowGate*)ctx;
+    const x265amd_encoder& e = *g.e;
+    /* the co-located CTU's depths (topSkipMinDepth reads refFrameList[l][0] at this CTU's address): that CTU of the reference picture is coded now */
     for (int l = 0; l < 2; l++)
         if (!g.pic->lists[l].empty())
         {
             const Pic* q = g.pic->lists[l][0].get();
-            const int y0 = row * 16, y1 = std::min(e.h4, y0 + 16);
-            for (int i = y0 * e.w4; i < y1 * e.w4; i++) (*g.refDepth)[l * g.nUnits + i] = q->units[i].depth;
+            const int y0 = row * 16, y1 = std::min(e.h4, y0 + 16), x0 = col * 16, x1 = std::min(e.w4, x0 + 16);
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) (*g.refDepth)[l * g.nUnits + (size_t)y * e.w4 + x] = q->units[(size_t)y * e.w4 + x].depth;
         }
+}
+static void gateAfterCtu(void* ctx, int row, int col)
+{
+    RowGate& g = *(RowGate*)ctx;
+    { std::lock_guard<std::mutex> lk(g.pic->mu); g.pic->analysedCols[row] = col + 1; }
+    g.pic->cv.notify_all();
 }
 static void gateAfterRow(void* ctx, int row)
 {
@@ -691,7 +761,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
         if (r == X265AMD_OK) r = x265amd_extend_border_rows(st, fin + org[2], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2);
         if (r != X265AMD_OK) return r;
         if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: row filters");
-        pic.reconRows.store(k + 1, std::memory_order_release);
+        pic.publish(k, W);
         return X265AMD_OK;
     };
     static const bool timing = getenv("X265AMD_TIMING") != nullptr;
@@ -747,11 +817,180 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
     return rc;
 }
 
+/* The filter thread of a picture, by columns.  A UNIT is a CTU row r and a range of its CTU columns [c0, c1): the deblocking of the unit's edges (vertical edges
+ * right of c0's left boundary up to and including c1's left boundary, then the horizontal edges of the columns, the top one reaching three samples into row
+ * r - 1), the SAO statistics and decisions of its CTUs; behind it row r - 1 (and the last row itself) is offset, its borders extended and its columns published
+ * up to eight samples short of the unit's right end (the offsets of those need the next unit's horizontal edges).  A unit is ready when
+ *   - row r is analysed through CTU c1 (the vertical edge at its right boundary reads both sides' coding data),
+ *   - row r + 1 is analysed through CTU c1 (its intra prediction has then read everything it needs of row r's last line UNFILTERED:
+ *     FrameEncoder::m_filterRowDelay, frameencoder.cpp:124-126, :1936-1950),
+ *   - the units of row r - 1 cover the columns (their vertical edges precede this unit's top horizontal edge, their decisions are the merge-up candidates).
+ * The same samples as FrameFilter's row order produce (framefilter.cpp:559-664): vertical edges lie eight samples apart and touch three on either side, so
+ * their order is free; a horizontal edge reads its own columns behind the vertical edges on both sides; a CTU's statistics leave out what the CTUs to its right
+ * and below still change (sao.cpp:760-776); an offset sample is written when it and its neighbours are final.  Units are taken as large as the analysis
+ * allows (a row the filter falls behind on is caught up in one unit), at least `minChunk` CTUs. */
+int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags)
+{
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: stream");
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    const bool sao = p.bEnableSAO != 0, dbl = p.bEnableLoopFilter != 0;
+    const size_t nUnits = (size_t)w4 * h4, ctuStat = (size_t)3 * 5 * 32, nstat = (size_t)nctu * ctuStat;
+    /* device: deblocking records, SAO parameters.  Pinned host memory the device reads / writes in place (no staging copies, no synchronisation to free a
+     * staging buffer): the records as the host derives them (copied to the device in stream order), the statistics as the kernel stores them, the parameters as
+     * decided (copied in stream order). */
+    struct Scratch { void* p = nullptr; ~Scratch() { xa_scratch_free(p); } } dDb, dPar;
+    XaMapped hDb, hPar; XaMappedOut hCnt, hOrg;
+    if (dbl && (xa_scratch_alloc(&dDb.p, sizeof(x265amd_deblock_unit) * nUnits) != hipSuccess || hDb.alloc(sizeof(x265amd_deblock_unit) * nUnits) != hipSuccess))
+        return xa_fail(X265AMD_EHIP, "encoder: device allocation");
+    if (sao)
+    {
+        if (xa_scratch_alloc(&dPar.p, sizeof(x265amd_sao_ctu) * nctu) != hipSuccess || hPar.alloc(sizeof(x265amd_sao_ctu) * nctu) != hipSuccess ||
+            hCnt.alloc(nstat * 4) != hipSuccess || hOrg.alloc(nstat * 4) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder: device allocation");
+        saoFlags[0] = saoFlags[1] = 1;          /* SAO::startSlice: never switched off when pictures are coded in parallel (sao.cpp:264) */
+    }
+    x265amd_deblock_unit* dbu = (x265amd_deblock_unit*)hDb.p;
+    int32_t* cnt = (int32_t*)hCnt.p; int32_t* orgs = (int32_t*)hOrg.p;
+    pixel* recY = pic.dRec + org[0]; pixel* recU = pic.dRec + org[1]; pixel* recV = pic.dRec + org[2];
+    const uint64_t recP[3] = { planeAddr(pic.dRec, 0), planeAddr(pic.dRec, 1), planeAddr(pic.dRec, 2) };
+    const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
+    pixel* fin = sao ? pic.dFin : pic.dRec;
+    const uint64_t finP[3] = { planeAddr(fin, 0), planeAddr(fin, 1), planeAddr(fin, 2) };
+    static const bool timing = getenv("X265AMD_TIMING") != nullptr;
+    double tWait = 0, tWork = 0; int numUnits = 0, numSweeps = 0;
+    auto tLast = std::chrono::steady_clock::now();
+    auto lap = [&](double& acc) { if (!timing) return; const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(n - tLast).count(); tLast = n; };
+    struct Report { const bool& on; double& w; double& k; int& n; int& sw; int poc; ~Report() { if (on) fprintf(stderr, "x265amd: filter units of poc %d: %d units in %d sweeps, %.1f ms waiting for the analysis, %.1f ms filtering\n", poc, n, sw, w, k); } } report{ timing, tWait, tWork, numUnits, numSweeps, pic.poc };
+    /* a picture nobody references is waited for by nobody: whole rows */
+    static const int minChunkEnv = getenv("X265AMD_FILTER_CHUNK") ? atoi(getenv("X265AMD_FILTER_CHUNK")) : 0;
+    const int minChunk = pic.type == TYPE_B ? ctuW : (minChunkEnv > 0 ? minChunkEnv : 2);
+    /* the last rows are where a chain of pictures waits for each other (they finish last, and cut CTUs make the last row the slowest): every CTU of them at once */
+    auto minChunkOf = [&](int r) { return (pic.type != TYPE_B && r >= ctuH - 3) ? 1 : minChunk; };
+    std::vector<int> doneC((size_t)ctuH, 0), pubX((size_t)ctuH, 0), a((size_t)ctuH, 0);
+    std::vector<uint8_t> carry((size_t)ctuH * (X265AMD_CTX_STRIDE + 8), 0);
+    struct Unit { int r, c0, c1; };
+    std::vector<Unit> todo;
+    int rc = X265AMD_OK;
+    /* offsets and borders of the sample columns [pubX[k], newX) of CTU row k (enqueued; published behind the sweep's synchronisation) */
+    auto finishCols = [&](int k, int newX) -> int {
+        const int x0 = pubX[k];
+        if (newX <= x0) return X265AMD_OK;
+        const int y0 = k * 64, y1 = std::min(H, y0 + 64);
+        if (sao)
+        {
+            int r = x265amd_sao_apply_rows_cols(st, recP, finP, stride, cstride, W, H, (const x265amd_sao_ctu*)dPar.p, k, k + 1, x0, newX);
+            if (r != X265AMD_OK) return r;
+        }
+        int r = x265amd_extend_border_band(st, fin + org[0], stride, W, H, marginX, marginY, y0, y1, x0, newX, x0 == 0, newX == W);
+        if (r == X265AMD_OK) r = x265amd_extend_border_band(st, fin + org[1], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2, x0 / 2, newX / 2, x0 == 0, newX == W);
+        if (r == X265AMD_OK) r = x265amd_extend_border_band(st, fin + org[2], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2, x0 / 2, newX / 2, x0 == 0, newX == W);
+        return r;
+    };
+    auto limitOf = [&](const std::vector<int>& an, int r) -> int {
+        int lim = an[r] == ctuW ? ctuW : an[r] - 1;
+        if (r + 1 < ctuH) lim = std::min(lim, an[r + 1] == ctuW ? ctuW : an[r + 1] - 1);
+        if (r > 0) lim = std::min(lim, doneC[r - 1]);
+        return lim;
+    };
+    for (;;)
+    {
+        {
+            std::unique_lock<std::mutex> lk(pic.mu);
+            /* something to do? (a snapshot of the analysis: the rows only advance) */
+            auto ready = [&]() -> bool {
+                if (pic.failed) return true;
+                bool allDone = true;
+                for (int r = 0; r < ctuH; r++)
+                {
+                    if (doneC[r] == ctuW) continue;
+                    allDone = false;
+                    const int lim = limitOf(pic.analysedCols, r);
+                    if (lim > doneC[r] && (lim == ctuW || lim - doneC[r] >= minChunkOf(r))) return true;
+                }
+                return allDone;
+            };
+            pic.cv.wait(lk, ready);
+            if (pic.failed) return X265AMD_EHIP;
+            a = pic.analysedCols;
+        }
+        lap(tWait);
+        /* ---- one sweep: every unit that is ready, top row first (a unit of row r may follow a unit of row r - 1 of the same sweep: the stream orders them).
+         * First the edges and the statistics of all of them, one synchronisation, then the decisions on the host, then offsets + borders, a second
+         * synchronisation, then the publication: two waits per sweep however many rows are in flight. ---- */
+        todo.clear();
+        bool all = true;
+        for (int r = 0; r < ctuH && rc == X265AMD_OK; r++)
+        {
+            if (doneC[r] == ctuW) continue;
+            all = false;
+            const int c0 = doneC[r], c1 = limitOf(a, r);
+            if (c1 <= c0 || (c1 < ctuW && c1 - c0 < minChunkOf(r))) continue;
+            const int y4b = r * 16, y4e = std::min(h4, y4b + 16), x4b = c0 * 16, x4e = std::min(w4, c1 * 16 + 1);       /* + the unit column right of the boundary edge */
+            if (dbl)
+            {
+                rc = x265amd_deblock_units_rect(&si, &info, pic.units.data(), pic.motion.data(), dbu, y4b, y4e, x4b, x4e);
+                if (rc != X265AMD_OK) break;
+                if (hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
+                                     sizeof(x265amd_deblock_unit) * (size_t)(x4e - x4b), (size_t)(y4e - y4b), hipMemcpyHostToDevice, st) != hipSuccess)
+                { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
+                rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, (const x265amd_deblock_unit*)dDb.p, 0, 0, 0, 0, 0, 3, y4b, y4e, c0, c1);
+                if (rc != X265AMD_OK) break;
+            }
+            if (sao)
+            {
+                /* every workgroup stores all 160 sums and counts of its (CTU, plane): nothing to clear; the host reads them where the kernel leaves them */
+                rc = x265amd_sao_stats_rows_cols(st, recP, srcP, stride, cstride, W, H, cnt, orgs, r, r + 1, c0, c1);
+                if (rc != X265AMD_OK) break;
+            }
+            todo.push_back(Unit{ r, c0, c1 });
+            doneC[r] = c1;
+        }
+        if (rc != X265AMD_OK) break;
+        if (todo.empty()) { if (all) break; continue; }
+        numUnits += (int)todo.size(); numSweeps++;
+        if (sao)
+        {
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: sao statistics"); break; }
+            for (const Unit& u : todo)
+            {
+                int32_t flags[2] = { 1, 1 };
+                rc = x265amd_sao_rdo_cols(&si, pic.type != TYPE_B ? 1 : 0, 2, 0, 69, pic.units.data(), cnt, orgs, sparams.data(), flags, u.r, u.c0, u.c1,
+                                          carry.data() + (size_t)u.r * (X265AMD_CTX_STRIDE + 8));
+                if (rc != X265AMD_OK) break;
+                const size_t off = (size_t)u.r * ctuW + u.c0, n = (size_t)(u.c1 - u.c0);
+                memcpy((x265amd_sao_ctu*)hPar.p + off, sparams.data() + off, sizeof(x265amd_sao_ctu) * n);
+                if (hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + off, (const x265amd_sao_ctu*)hPar.p + off, sizeof(x265amd_sao_ctu) * n, hipMemcpyHostToDevice, st) != hipSuccess)
+                { rc = xa_fail(X265AMD_EHIP, "encoder: sao upload"); break; }
+            }
+            if (rc != X265AMD_OK) break;
+        }
+        /* final now: row r - 1 (and the last row itself) up to eight samples short of the unit's right end */
+        for (const Unit& u : todo)
+        {
+            const int newX = u.c1 == ctuW ? W : 64 * u.c1 - 8;
+            if (u.r > 0) rc = finishCols(u.r - 1, newX);
+            if (rc == X265AMD_OK && u.r == ctuH - 1) rc = finishCols(u.r, newX);
+            if (rc != X265AMD_OK) break;
+        }
+        if (rc != X265AMD_OK) break;
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: row filters"); break; }
+        for (const Unit& u : todo)
+        {
+            const int newX = u.c1 == ctuW ? W : 64 * u.c1 - 8;
+            if (u.r > 0 && newX > pubX[u.r - 1]) { pubX[u.r - 1] = newX; pic.publish(u.r - 1, newX); }
+            if (u.r == ctuH - 1 && newX > pubX[u.r]) { pubX[u.r] = newX; pic.publish(u.r, newX); }
+        }
+        lap(tWork);
+    }
+    return rc;
+}
+
 int x265amd_encoder::runFrameParallel(const PicP& picp)
 {
     Pic& pic = *picp;
     /* whatever happens, the pictures waiting for rows of this one are released */
-    struct Release { Pic& pic; int* rc; ~Release() { if (*rc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } } };
+    struct Release { Pic& pic; int* rc; ~Release() { if (*rc) pic.fail(); } };
     int rc = X265AMD_EHIP;
     Release release{ pic, &rc };
     hipStream_t st = nullptr;
@@ -783,12 +1022,15 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     memset(sparams.data(), 0, sizeof(x265amd_sao_ctu) * nctu);
     int32_t saoFlags[2] = { 0, 0 };
     int filterRc = X265AMD_OK;
-    std::thread filters([&] { xa_thread_device(); filterRc = filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); } });
-    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow };
+    /* by columns when there is something to filter and the rows run as a wavefront; the row-by-row form otherwise */
+    static const bool colsOff = getenv("X265AMD_FILTER_COLS") && atoi(getenv("X265AMD_FILTER_COLS")) == 0;
+    const bool byCols = !colsOff && p.bEnableWavefront && (p.bEnableLoopFilter || p.bEnableSAO) && ctuH > 1 && ctuW > 1;
+    std::thread filters([&, byCols] { xa_thread_device(); filterRc = byCols ? filterRowsCols(pic, fc.si, fc.info, sparams, saoFlags) : filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) pic.fail(); });
+    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
                                sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);
-    if (arc != X265AMD_OK) { { std::lock_guard<std::mutex> lk(pic.mu); pic.failed = true; } pic.cv.notify_all(); }
+    if (arc != X265AMD_OK) pic.fail();
     filters.join();
     if (arc != X265AMD_OK) return rc = arc;
     if (filterRc != X265AMD_OK) return rc = filterRc;

@@ -131,6 +131,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             jobs[i].dst_y = b; jobs[i].dst_u = b + (size_t)jobs[i].w * jobs[i].h * isz; jobs[i].dst_v = jobs[i].dst_u + (size_t)jobs[i].w * jobs[i].h / 4 * isz;
             jobs[i].dst_stride = jobs[i].w; jobs[i].dst_cstride = jobs[i].w / 2;
         }
+        if (xa_ref_guard_mc(jobs.data(), (int)jobs.size())) return -1;
         memcpy(dJobs.p, jobs.data(), jobs.size() * sizeof(x265amd_mc_job));
         if (x265amd_inter_cost(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJobs.p, (int)jobs.size(),
                                dFencTab, stride, cstride, (uint32_t*)dCost.p) != X265AMD_OK) return -1;
@@ -281,6 +282,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 }
         }
         std::vector<x265amd_me_result> mres(mj.size());
+        if (xa_ref_guard_me(mj.data(), mjPic.data(), (int)mj.size())) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: a reference picture failed");
         {
             /* plan per reference picture, upload in planned order */
             std::vector<x265amd_me_job> ordered; std::vector<x265amd_me_group> groups; std::vector<int> origin;
@@ -477,6 +479,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     {
         XaMapped dJ;
         if (dJ.alloc(finalMc.size() * sizeof(x265amd_mc_job)) != hipSuccess) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: out of device memory");
+        if (xa_ref_guard_mc(finalMc.data(), (int)finalMc.size())) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: a reference picture failed");
         memcpy(dJ.p, finalMc.data(), finalMc.size() * sizeof(x265amd_mc_job));
         int rc = x265amd_motion_compensation(st, (const uint64_t*)dPlanes.p, stride, cstride, I->pic_width, I->pic_height, (const x265amd_mc_job*)dJ.p, (int)finalMc.size());
         if (rc != X265AMD_OK) return rc;

@@ -31,6 +31,30 @@ __global__ __launch_bounds__(256) void k_extend_border(pixel* pic, long stride, 
         dstRow[x] = srcRow[min(max(x, 0), width - 1)];
 }
 
+/* margins of a band of picture lines whose samples become final column by column: left margin (doLeft) and right margin (doRight) beside lines y0 .. y1 - 1, and
+ * when the band holds the last line the bottom margin below the sample columns xa .. xb - 1 (with the corner left of column 0 / right of the last column) */
+__global__ __launch_bounds__(256) void k_extend_band(pixel* pic, long stride, int width, int height, int marginX, int marginY, int y0, int y1, int xa, int xb, int doLeft, int doRight)
+{
+    int y = y0 + (int)blockIdx.x;                           /* y0 .. y1 - 1: picture lines; then the bottom margin lines when y1 == height, then the top margin lines when y0 == 0 */
+    const int bottomLines = y1 == height ? marginY : 0;
+    if (y >= y1 + bottomLines) y = -1 - (y - y1 - bottomLines);         /* the top margin: lines -1 .. -marginY */
+    if (y >= 0 && y < y1)
+    {
+        pixel* row = pic + (long)y * stride;
+        const pixel l = row[0], r = row[width - 1];
+        for (int i = threadIdx.x; i < marginX; i += blockDim.x)
+        {
+            if (doLeft) row[-marginX + i] = l;
+            if (doRight) row[width + i] = r;
+        }
+        return;
+    }
+    const pixel* src = pic + (long)(y < 0 ? 0 : height - 1) * stride;
+    pixel* dst = pic + (long)y * stride;
+    const int from = (doLeft && xa == 0) ? -marginX : xa, to = (doRight && xb == width) ? width + marginX : xb;
+    for (int x = from + (int)threadIdx.x; x < to; x += blockDim.x) dst[x] = src[min(max(x, 0), width - 1)];
+}
+
 __global__ __launch_bounds__(256) void k_weight_plane(const pixel* src, pixel* dst, long stride, int width, int height, int marginX, int marginY,
                                                       int w0, int round, int shift, int offset)
 {
@@ -59,6 +83,22 @@ extern "C" int x265amd_extend_border_rows(void* stream, x265amd_pixel* d_pic, in
         return xa_fail(X265AMD_EINVAL, "x265amd_extend_pic_border: bad arguments");
     const int first = y_begin == 0 ? -marginY : y_begin, last = y_end == height ? height + marginY : y_end;
     hipLaunchKernelGGL(k_extend_border, dim3(last - first), dim3(256), 0, (hipStream_t)stream, (pixel*)d_pic, (long)stride, width, height, marginX, marginY, first);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+/* the margins of the picture lines y_begin .. y_end - 1 whose samples have become final in the columns x_begin .. x_end - 1 only: the left margin when left != 0,
+ * the right margin when right != 0 (the caller says when the first / last sample of the lines is final), and, when the band holds the last picture line, the bottom
+ * margin below those columns and with line 0 the top margin above them (with their corners under the same two conditions). */
+extern "C" int x265amd_extend_border_band(void* stream, x265amd_pixel* d_pic, intptr_t stride, int width, int height, int marginX, int marginY, int y_begin, int y_end,
+                                          int x_begin, int x_end, int left, int right)
+{
+    if (!d_pic || width <= 0 || height <= 0 || marginX < 0 || marginY < 0 || y_begin < 0 || y_begin >= y_end || y_end > height || x_begin < 0 || x_begin >= x_end || x_end > width)
+        return xa_fail(X265AMD_EINVAL, "x265amd_extend_border_band: bad arguments");
+    const int lines = (y_end - y_begin) + (y_end == height ? marginY : 0) + (y_begin == 0 ? marginY : 0);
+    hipLaunchKernelGGL(k_extend_band, dim3(lines), dim3(256), 0, (hipStream_t)stream, (pixel*)d_pic, (long)stride, width, height, marginX, marginY, y_begin, y_end, x_begin, x_end,
+                       left, right);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;

@@ -11,7 +11,7 @@
 #include "x265amd_dev.h"
 #include "x265amd_host.h"
 
-struct SaoPlanes { const pixel* rec[3]; const pixel* fenc[3]; pixel* dst[3]; long stride, cstride; int width, height; int ctuRow0, ctuRows; };      /* the CTU rows of this launch */
+struct SaoPlanes { const pixel* rec[3]; const pixel* fenc[3]; pixel* dst[3]; long stride, cstride; int width, height; int ctuRow0, ctuRows; int ctuCol0, ctuCols; int x0, x1; };      /* the CTU rows (and columns: statistics; luma sample columns x0 .. x1 - 1: offsets) of this launch */
 
 XA_DEV int sao_sgn(int v) { return (v > 0) - (v < 0); }
 XA_DEV int sao_class(int v, int a, int b)            /* SAO::s_eoTable[sign + sign + 2] (sao.cpp:65-72): {1, 2, 0, 3, 4} */
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, 
 {
     __shared__ int sCnt[5 * 32], sOrg[5 * 32];
     const int ctuW = (P.width + 63) >> 6;
-    const int plane = blockIdx.y, ctu = P.ctuRow0 * ctuW + blockIdx.x;
+    const int plane = blockIdx.y, ctu = (P.ctuRow0 + (int)blockIdx.x / P.ctuCols) * ctuW + P.ctuCol0 + (int)blockIdx.x % P.ctuCols;
     const int cx = ctu % ctuW, cy = ctu / ctuW;
     const int sh = plane ? 1 : 0, po = plane ? 2 : 0;
     const long st = plane ? P.cstride : P.stride;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_sao_apply(SaoPlanes P, const x265amd_sa
     const long st = plane ? P.cstride : P.stride;
     const int picW = P.width >> sh, picH = P.height >> sh;
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = ((P.ctuRow0 * 64) >> sh) + blockIdx.y;
-    if (x >= picW || y >= picH || y >= (((P.ctuRow0 + P.ctuRows) * 64) >> sh)) return;
+    if (x >= picW || y >= picH || y >= (((P.ctuRow0 + P.ctuRows) * 64) >> sh) || x < (P.x0 >> sh) || x >= (P.x1 >> sh)) return;
     const int ctuW = (P.width + 63) >> 6;
     const x265amd_sao_ctu p = params[((y << sh) >> 6) * ctuW + ((x << sh) >> 6)];
     const int type = p.type[plane ? 1 : 0];
@@ -129,6 +129,7 @@ static int sao_fill(SaoPlanes& P, const uint64_t* rec, const uint64_t* fenc, con
         P.dst[c] = dst ? (pixel*)(uintptr_t)dst[c] : nullptr;
     }
     P.stride = (long)stride; P.cstride = (long)cstride; P.width = width; P.height = height; P.ctuRow0 = 0; P.ctuRows = (height + 63) >> 6;
+    P.ctuCol0 = 0; P.ctuCols = (width + 63) >> 6; P.x0 = 0; P.x1 = width;
     return 0;
 }
 
@@ -143,13 +144,22 @@ extern "C" int x265amd_sao_stats(void* stream, const uint64_t rec_planes[3], con
 extern "C" int x265amd_sao_stats_rows(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
                                       int width, int height, int32_t* d_count, int32_t* d_offset_org, int ctu_row_begin, int ctu_row_end)
 {
+    return x265amd_sao_stats_rows_cols(stream, rec_planes, fenc_planes, stride, cstride, width, height, d_count, d_offset_org, ctu_row_begin, ctu_row_end, 0, (width + 63) >> 6);
+}
+
+/* ... of the CTU columns ctu_col_begin .. ctu_col_end - 1 of those rows (a CTU's statistics read nothing right of its own columns but what the deblocking of the
+ * CTU to its right leaves alone) */
+extern "C" int x265amd_sao_stats_rows_cols(void* stream, const uint64_t rec_planes[3], const uint64_t fenc_planes[3], intptr_t stride, intptr_t cstride,
+                                           int width, int height, int32_t* d_count, int32_t* d_offset_org, int ctu_row_begin, int ctu_row_end, int ctu_col_begin, int ctu_col_end)
+{
+    if (ctu_col_begin < 0 || ctu_col_begin >= ctu_col_end || ctu_col_end > ((width + 63) >> 6)) return xa_fail(X265AMD_EINVAL, "x265amd_sao_stats: column range");
     if (!rec_planes || !fenc_planes || !d_count || !d_offset_org || width <= 0 || height <= 0 || (width & 7) || (height & 7) || ctu_row_begin < 0 || ctu_row_begin >= ctu_row_end ||
         ctu_row_end > ((height + 63) >> 6))
         return xa_fail(X265AMD_EINVAL, "x265amd_sao_stats: bad arguments");
     SaoPlanes P;
     sao_fill(P, rec_planes, fenc_planes, nullptr, stride, cstride, width, height);
-    P.ctuRow0 = ctu_row_begin; P.ctuRows = ctu_row_end - ctu_row_begin;
-    const int nctu = ((width + 63) >> 6) * P.ctuRows;
+    P.ctuRow0 = ctu_row_begin; P.ctuRows = ctu_row_end - ctu_row_begin; P.ctuCol0 = ctu_col_begin; P.ctuCols = ctu_col_end - ctu_col_begin;
+    const int nctu = P.ctuCols * P.ctuRows;
     hipLaunchKernelGGL(k_sao_stats, dim3(nctu, 3), dim3(256), 0, (hipStream_t)stream, P, d_count, d_offset_org);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
@@ -166,12 +176,21 @@ extern "C" int x265amd_sao_apply(void* stream, const uint64_t src_planes[3], con
 extern "C" int x265amd_sao_apply_rows(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
                                       int width, int height, const x265amd_sao_ctu* d_params, int ctu_row_begin, int ctu_row_end)
 {
+    return x265amd_sao_apply_rows_cols(stream, src_planes, dst_planes, stride, cstride, width, height, d_params, ctu_row_begin, ctu_row_end, 0, width);
+}
+
+/* ... restricted to the luma sample columns x_begin .. x_end - 1 (even; chroma: half): a sample is classified on itself and its two neighbours along the class
+ * direction, so the deblocked input must be final one sample beyond either end */
+extern "C" int x265amd_sao_apply_rows_cols(void* stream, const uint64_t src_planes[3], const uint64_t dst_planes[3], intptr_t stride, intptr_t cstride,
+                                           int width, int height, const x265amd_sao_ctu* d_params, int ctu_row_begin, int ctu_row_end, int x_begin, int x_end)
+{
+    if (x_begin < 0 || x_begin >= x_end || x_end > width || (x_begin & 1) || (x_end & 1)) return xa_fail(X265AMD_EINVAL, "x265amd_sao_apply: column range");
     if (!src_planes || !dst_planes || !d_params || width <= 0 || height <= 0 || (width & 7) || (height & 7) || ctu_row_begin < 0 || ctu_row_begin >= ctu_row_end ||
         ctu_row_end > ((height + 63) >> 6))
         return xa_fail(X265AMD_EINVAL, "x265amd_sao_apply: bad arguments");
     SaoPlanes P;
     sao_fill(P, src_planes, nullptr, dst_planes, stride, cstride, width, height);
-    P.ctuRow0 = ctu_row_begin; P.ctuRows = ctu_row_end - ctu_row_begin;
+    P.ctuRow0 = ctu_row_begin; P.ctuRows = ctu_row_end - ctu_row_begin; P.x0 = x_begin; P.x1 = x_end;
     const int lines = (height < ctu_row_end * 64 ? height : ctu_row_end * 64) - ctu_row_begin * 64;
     hipLaunchKernelGGL(k_sao_apply, dim3((width + 255) / 256, lines, 3), dim3(256), 0, (hipStream_t)stream, P, d_params);
     hipError_t e = hipGetLastError();

@@ -90,7 +90,21 @@ void xa_copy_rects(void* st, const XaRects& r);
  * the reference pictures have finished the rows CTU row `row` may read (1 yes, 0 not yet, -1 a reference picture failed; polled, no blocking, no side
  * effects), before_row(ctx, row) runs once before the row's first CTU, after_row(ctx, row) once the row is analysed and its reconstruction is in device
  * memory.  Rows finish in order. */
-struct XaRowHooks { void* ctx; int (*row_ready)(void* ctx, int row); void (*before_row)(void* ctx, int row); void (*after_row)(void* ctx, int row); };
+struct XaRowHooks
+{
+    void* ctx; int (*row_ready)(void* ctx, int row); void (*before_row)(void* ctx, int row); void (*after_row)(void* ctx, int row);
+    /* optional (NULL: not used), per CTU: ctu_wait(ctx, row, col) BLOCKS until the reference pictures let CTU (row, col) start (they are published column by
+     * column) and returns 0, or -1 when one of them failed -- it waits on counters (xa_wait_counter: a row task parks, cheaply, however many rows wait);
+     * before_ctu / after_ctu around the CTU's analysis (after_ctu: its reconstruction is in device memory, its units and motion are in the maps);
+     * ref_wait(ctx, pic, y_min, y_max, x_max): blocks until the samples of reference picture `pic` (index into the plane table) of the lines y_min .. y_max, right
+     * to column x_max (picture coordinates; beyond the picture edge = its margin) may be read; 0, or -1 when the picture failed.  Called before every command
+     * that reads reference samples (xa_ref_guard_*): the per-CTU gate covers ordinary vectors, this covers the long ones. */
+    int (*ctu_wait)(void* ctx, int row, int col); void (*before_ctu)(void* ctx, int row, int col); void (*after_ctu)(void* ctx, int row, int col);
+    int (*ref_wait)(void* ctx, int pic, int y_min, int y_max, int x_max);
+};
+/* the guards (csrc/ctu_analysis.hip): wait until the row task's hooks (if it has any) let the jobs' reference samples be read; 0, or -1 when a picture failed */
+int xa_ref_guard_mc(const x265amd_mc_job* jobs, int n);
+int xa_ref_guard_me(const x265amd_me_job* jobs, const int* pics, int n);
 int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,

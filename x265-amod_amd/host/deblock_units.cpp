@@ -17,7 +17,14 @@ extern "C" int x265amd_deblock_units(const x265amd_slice_info* si, const x265amd
 extern "C" int x265amd_deblock_units_rows(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
                                           x265amd_deblock_unit* out, int y4_begin, int y4_end)
 {
-    if (!si || !info || !units || !motion || !out || y4_begin < 0 || y4_end > (si->pic_height >> 2)) return X265AMD_EINVAL;
+    if (!si) return X265AMD_EINVAL;
+    return x265amd_deblock_units_rect(si, info, units, motion, out, y4_begin, y4_end, 0, si->pic_width >> 2);
+}
+
+extern "C" int x265amd_deblock_units_rect(const x265amd_slice_info* si, const x265amd_mvpred_info* info, const x265amd_cu_unit* units, const x265amd_mv_unit* motion,
+                                          x265amd_deblock_unit* out, int y4_begin, int y4_end, int x4_begin, int x4_end)
+{
+    if (!si || !info || !units || !motion || !out || y4_begin < 0 || y4_end > (si->pic_height >> 2) || x4_begin < 0 || x4_end > (si->pic_width >> 2)) return X265AMD_EINVAL;
     const int w4 = si->pic_width >> 2;
     /* picture identities: equal POC = same picture, whatever the list */
     int pocs[32], npoc = 0;
@@ -32,7 +39,7 @@ extern "C" int x265amd_deblock_units_rows(const x265amd_slice_info* si, const x2
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < info->num_ref_idx[l] && r < 16; r++) (void)ident(l, r);
     for (int y4 = y4_begin; y4 < y4_end; y4++)
-        for (int x4 = 0; x4 < w4; x4++)
+        for (int x4 = x4_begin; x4 < x4_end; x4++)
         {
             const x265amd_cu_unit& u = units[y4 * w4 + x4];
             const x265amd_mv_unit& m = motion[y4 * w4 + x4];

@@ -218,9 +218,31 @@ extern "C" int x265amd_sao_rdo(const x265amd_slice_info* si, int referenced, int
 /* CTU rows ctu_row_begin .. ctu_row_end - 1 of the same decision: every CTU row owns its SAO object and entropy state in the reference (framefilter.cpp:239), and
  * a CTU only looks at the parameters of its left and upper neighbours, so rows can be decided one by one in order.  The share of unfiltered CTUs
  * (depth_sao_rate, rdoSaoUnitRowEnd) is only kept when the call covers the whole picture; the reference reads it with one frame thread only (sao.cpp:264). */
+static int sao_rdo_range(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                         const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags,
+                         int ctu_row_begin, int ctu_row_end, int colBegin, int colEnd, uint8_t* carry);
+
 extern "C" int x265amd_sao_rdo_rows(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
                                     const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags,
                                     int ctu_row_begin, int ctu_row_end)
+{
+    if (!si) return X265AMD_EINVAL;
+    return sao_rdo_range(si, referenced, frame_threads, qp_min, qp_max, units, count, offset_org, depth_sao_rate, params, sao_flags, ctu_row_begin, ctu_row_end, 0,
+                         (si->pic_width + 63) >> 6, nullptr);
+}
+
+extern "C" int x265amd_sao_rdo_cols(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                                    const int32_t* count, const int32_t* offset_org, x265amd_sao_ctu* params, int32_t* sao_flags,
+                                    int ctu_row, int ctu_col_begin, int ctu_col_end, uint8_t* carry)
+{
+    if (!si || !carry || frame_threads <= 1 || ctu_col_begin < 0 || ctu_col_begin >= ctu_col_end || ctu_col_end > ((si->pic_width + 63) >> 6)) return X265AMD_EINVAL;
+    double unused[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    return sao_rdo_range(si, referenced, frame_threads, qp_min, qp_max, units, count, offset_org, unused, params, sao_flags, ctu_row, ctu_row + 1, ctu_col_begin, ctu_col_end, carry);
+}
+
+static int sao_rdo_range(const x265amd_slice_info* si, int referenced, int frame_threads, int qp_min, int qp_max, x265amd_cu_unit* units,
+                         const int32_t* count, const int32_t* offset_org, double* depth_sao_rate, x265amd_sao_ctu* params, int32_t* sao_flags,
+                         int ctu_row_begin, int ctu_row_end, int colBegin, int colEnd, uint8_t* carry)
 {
     if (!si || !units || !count || !offset_org || !depth_sao_rate || !params || !sao_flags) return X265AMD_EINVAL;
     const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2;
@@ -243,9 +265,12 @@ extern "C" int x265amd_sao_rdo_rows(const x265amd_slice_info* si, int referenced
     if (!R->c) { delete R; return X265AMD_EINVAL; }
     Snap init;
     R->store(init);
+    static_assert(sizeof(Snap) <= X265AMD_CTX_STRIDE + 8, "the caller's carry buffer holds a Snap");
+    if (carry && colBegin) memcpy(&R->cur, carry, sizeof(Snap));          /* the row's state as the previous call left it */
     for (int addr = ctu_row_begin * ctuW; addr < ctu_row_end * ctuW; addr++)
     {
         const int idxX = addr % ctuW, row = addr / ctuW;
+        if (idxX < colBegin || idxX >= colEnd) continue;
         if (!idxX) R->cur = init;                   /* every CTU row owns its SAO object and entropy state */
         x265amd_sao_ctu& p = params[addr];
         memset(&p, 0, sizeof(p));
@@ -307,6 +332,7 @@ extern "C" int x265amd_sao_rdo_rows(const x265amd_slice_info* si, int referenced
         R->load(R->temp);
         R->store(R->cur);
     }
+    if (carry) memcpy(carry, &R->cur, sizeof(Snap));
     /* rdoSaoUnitRowEnd */
     if (whole)
     {

@@ -50,6 +50,7 @@ struct Fiber
     uint64_t runNs = 0;                 /* X265AMD_TIMING: time spent running (not parked) */
     uint64_t stintStart = 0;            /* when it was last resumed */
     uint64_t userMark = 0;              /* for the caller's phase accounting */
+    void* userSlot = nullptr;           /* a pointer of the caller's (the row's reference-picture guard) */
     struct Worker* worker = nullptr;    /* the worker running it now */
 };
 
@@ -274,6 +275,7 @@ void xa_counter_free(volatile uint64_t* c)
 
 int xa_worker_count(void) { start_workers(); return sched().numWorkers; }
 uint64_t xa_task_run_ns(void) { Worker* w = current_worker(); return w && w->cur ? w->cur->runNs + (g_stats ? now_ns() - w->cur->stintStart : 0) : 0; }
+void** xa_task_slot(void) { Worker* w = current_worker(); return w && w->cur ? &w->cur->userSlot : nullptr; }
 uint64_t* xa_task_mark(void) { Worker* w = current_worker(); return w && w->cur ? &w->cur->userMark : nullptr; }
 void xa_sched_stats(uint64_t out[3]) { out[0] = g_busyNs.load(); out[1] = g_idleNs.load(); out[2] = g_switches.load(); }
 int xa_in_task(void) { Worker* w = current_worker(); return w && w->cur; }
@@ -302,7 +304,7 @@ void xa_tasks_run(const XaTask* tasks, int n)
                 int expect = ST_EMPTY;
                 if (f.state.load(std::memory_order_acquire) != ST_EMPTY || !f.state.compare_exchange_strong(expect, ST_RUNNING, std::memory_order_acq_rel)) continue;
                 f.task = tasks[k]; f.group = &grp; f.pred = nullptr; f.predCtx = nullptr; f.sp = nullptr; f.stack = nullptr; f.scratchList = nullptr; f.worker = nullptr;
-                f.waitCounter.store(nullptr); f.waitValue.store(0); f.deadlineNs.store(0); f.runNs = 0; f.userMark = 0;
+                f.waitCounter.store(nullptr); f.waitValue.store(0); f.deadlineNs.store(0); f.runNs = 0; f.userMark = 0; f.userSlot = nullptr;
                 int hw = S.highWater.load(std::memory_order_acquire);
                 while (hw < i + 1 && !S.highWater.compare_exchange_weak(hw, i + 1, std::memory_order_acq_rel)) {}
                 S.live.fetch_add(1, std::memory_order_acq_rel);
