@@ -965,6 +965,8 @@ int x265amd_aq_offsets(const uint32_t* energy, int num_blocks, int avg_block_cou
 
 /* returns the device scratch the host orchestrators keep between calls (a size-class pool) to the HIP runtime */
 void x265amd_release_scratch(void);
+/* X265AMD_HOSTPROF=1: prints (stderr) the host CPU time by named scope collected so far (development aid) */
+void x265amd_hostprof_report(void);
 
 /* Device job queues (csrc/xa_queue.h): the CTU rows of x265amd_analyse_frame run their block operations as commands to resident workgroups instead of
  * kernel launches (environment: X265AMD_QUEUES = number of queues, default 128, 0 = launches on HIP streams as before).  The self test pushes `rounds`

@@ -214,6 +214,7 @@ struct Analyzer
     /* motionCompensation(luma + chroma) of the jobs into their tiles, then sa8d / sse / psy of each tile against the source */
     int predictAndMeasure(std::vector<x265amd_mc_job>& jobs, int x, int y, int log2, const int* tiles, x265amd_cu_measure* meas)
     {
+        XA_HOSTPROF("an.predictAndMeasure");
         const int n = (int)jobs.size();
         if (xa_ref_guard_mc(jobs.data(), n)) return fail("a reference picture failed");
         memcpy(dJobs.p, jobs.data(), sizeof(x265amd_mc_job) * n);
@@ -308,6 +309,7 @@ struct Analyzer
     /* RD of one candidate through the batch entry points (n = 1) */
     int rdInter(Mode& m, int x, int y, int depth, bool skipOnly)
     {
+        XA_HOSTPROF("an.rdInter (all)");
         StageTimer timer_(2);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
@@ -338,6 +340,7 @@ struct Analyzer
     /* encodeResAndCalcRdSkipCU on `skip` and encodeResAndCalcRdInterCU on `merge` (the same candidate, the same prediction tile) with the shared measurement done once */
     int rdMergePair(Mode& skip, Mode& merge, int x, int y, int depth)
     {
+        XA_HOSTPROF("an.rdMergePair (all)");
         StageTimer timer_(2);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
@@ -368,6 +371,7 @@ struct Analyzer
     /* checkIntraInInter + encodeIntraInInter */
     int rdIntra(Mode& m, int x, int y, int depth, int slot = PRED_INTRA, bool full = false, int partSize = 0)
     {
+        XA_HOSTPROF("an.rdIntra (all)");
         StageTimer timer_(3);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
@@ -472,6 +476,7 @@ struct Analyzer
     /* checkMerge2Nx2N_rd0_4 */
     int checkMerge(int x, int y, int depth)
     {
+        XA_HOSTPROF("an.checkMerge (all)");
         StageTimer timer_(0);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
@@ -533,6 +538,7 @@ struct Analyzer
     /* checkInter_rd0_4(2Nx2N) + checkBidir2Nx2N; searchOnly: predInterSearch alone (checkInter_rd5_6 runs the RD itself, the bi-prediction try comes later) */
     int checkInter(int x, int y, int depth, uint32_t refMask, bool searchOnly = false)
     {
+        XA_HOSTPROF("an.checkInter (all)");
         StageTimer timer_(1);
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
@@ -1021,7 +1027,7 @@ struct Analyzer
         SplitData splitData[4];
         memset(splitData, 0, sizeof(splitData));
         d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
-        for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
+        { XA_HOSTPROF("an.initSubCU x13"); for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth); }
         d.pred[PRED_2Nx2N].sa8dCost = 0;                 /* what a parent reads under --limit-modes when 2Nx2N is not searched here */
 
         /* Step 1: merge / skip candidates */
@@ -1276,7 +1282,8 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
             fwrite(buf.data(), sizeof(pixel), buf.size(), dump);
         }
     }
-    Analyzer* an = new Analyzer;
+    Analyzer* an;
+    { XA_HOSTPROF("ctu.new Analyzer"); an = new Analyzer; }
     Analyzer& a = *an;
     a.me = me; a.st = (hipStream_t)stream; a.I = I; a.S = S; a.si = si; a.A = A; a.units = units; a.cur = cur; a.col = col;
     a.refDepth = ref_depth; a.refQp0 = ref_qp0; a.planes = h_planes; a.numPics = num_pics; a.stride = stride; a.cstride = cstride;
@@ -1331,7 +1338,7 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         if (rc == X265AMD_OK) fwrite(a.md[0].best->coeff.data(), sizeof(int16_t), kTileElems, dump);
         fclose(dump);
     }
-    delete an;
+    { XA_HOSTPROF("ctu.delete Analyzer"); delete an; }
     return rc;
 }
 
@@ -1396,7 +1403,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         if (r != X265AMD_OK) return r;
         if (results) results[addr] = res;
         xa_phase(XA_PH_ANALYZER);
-        r = x265amd_cabac_encode_ctu(rowCoder, addr, coeff, coeff + 4096, coeff + 5120);
+        { XA_HOSTPROF("row.cabac_encode_ctu"); r = x265amd_cabac_encode_ctu(rowCoder, addr, coeff, coeff + 4096, coeff + 5120); }
         xa_phase(XA_PH_CABAC_CTU);
         if (wpp && colIdx == 1) memcpy(&buffered[(size_t)row * X265AMD_CTX_STRIDE], rowCoder->ctx, X265AMD_CTX_STRIDE);
         return r;
@@ -1509,7 +1516,13 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 int r2 = f.firstErr.load();
                 if (r2 == X265AMD_OK && !st) r2 = X265AMD_EHIP;
                 /* the reference pictures are published column by column: this CTU follows them (parked on their counters meanwhile) */
+                static const bool ctuLog = getenv("X265AMD_CTU_LOG") != nullptr;
+                static const auto tLog0 = std::chrono::steady_clock::now();
+                const double tA = ctuLog ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count() : 0;
                 if (r2 == X265AMD_OK && f.hooks && f.hooks->ctu_wait && f.hooks->ctu_wait(f.hooks->ctx, row, c2)) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed");
+                const double tB = ctuLog ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count() : 0;
+                struct CtuLog { bool on; int poc, row, col; double a, b; ~CtuLog() { if (on) fprintf(stderr, "x265amd ctu: poc %d row %d col %d: row-above wait from %.2f, gate passed %.2f, done %.2f\n", poc, row, col, a, b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count()); } }
+                    ctuLogger{ ctuLog && row >= f.ctuH - 3, f.poc, row, c2, tA, tB };
                 if (r2 == X265AMD_OK && f.hooks && f.hooks->before_ctu) f.hooks->before_ctu(f.hooks->ctx, row, c2);
                 if (r2 == X265AMD_OK) r2 = f.doCtu(row * ctuW + c2, st);
                 if (r2 == X265AMD_OK && xa_stream_sync(st) != hipSuccess) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");

@@ -400,6 +400,7 @@ static void rd_lambdas(const x265amd_slice_info* si, const x265amd_rd_params* rp
 static int make_plan(const x265amd_slice_info* si, const x265amd_rd_cu& cu, int part, CuPlan& P, int firstJob, const uint64_t* src, intptr_t stride, intptr_t cstride,
                      uint64_t tile, uint64_t scratch, std::vector<x265amd_tu_job>* jobs, uint64_t levels = 0)
 {
+    XA_HOSTPROF("rd.make_plan");
     static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
                                              32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };       /* H.265 table 8-10 */
     P.x = cu.x; P.y = cu.y; P.log2 = cu.log2_size; P.size = 1 << P.log2; P.depth = 6 - P.log2; P.qp = cu.qp;
@@ -488,6 +489,7 @@ extern "C" int x265amd_inter_rd_plan(const x265amd_slice_info* si, const x265amd
 static int inter_rd_plan_levels(const x265amd_slice_info* si, const x265amd_rd_cu* cus, int n, const x265amd_cu_unit* cu_units, const uint64_t* src,
                                 intptr_t stride, intptr_t cstride, uint64_t pred, size_t tile_bytes, uint64_t scratch, x265amd_tu_job* jobs_out, int cap, uint64_t levels)
 {
+    XA_HOSTPROF("rd.plan_levels");
     if (!si || !cus || !cu_units || !src || n < 0) return xa_fail(X265AMD_EINVAL, "inter_rd_plan: null argument");
     std::vector<x265amd_tu_job> jobs;
     const size_t perCu = x265amd_inter_rd_scratch_bytes();
@@ -525,6 +527,7 @@ static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_par
                               x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
                               const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out, const RdoqDemand* demand)
 {
+    XA_HOSTPROF("rd.walk_impl");
     if (!si || !rp || !units || !cus || !cu_units || !res || !levels || !zero_meas || !sel || !out || n < 0) return xa_fail(X265AMD_EINVAL, "inter_rd_walk: null argument");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
     const int w4 = si->pic_width >> 2;
@@ -689,6 +692,7 @@ extern "C" void x265amd_inter_rd_finish(const x265amd_slice_info* si, const x265
 extern "C" int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
                                     x265amd_cu_unit* cu_units, const x265amd_cu_measure* meas, x265amd_rd_result* out)
 {
+    XA_HOSTPROF("rd.skip_rd_host");
     if (!si || !rp || !units || !cus || !cu_units || !meas || !out || n < 0) return xa_fail(X265AMD_EINVAL, "skip_rd: null argument");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "skip_rd: lossless coding is not supported");
     const int w4 = si->pic_width >> 2;
@@ -790,6 +794,7 @@ extern "C" int x265amd_measure_tiles(void* stream_, const uint64_t* h_src, intpt
 extern "C" int x265amd_measure_tile_list(void* stream_, const uint64_t* h_src, intptr_t stride, intptr_t cstride, const x265amd_rd_cu* cus, int n,
                                          const uint64_t* tile_addrs, x265amd_cu_measure* out)
 {
+    XA_HOSTPROF("rd.measure_tile_list");
     if (!h_src || !cus || !tile_addrs || !out || n < 0) return xa_fail(X265AMD_EINVAL, "measure_tile_list: null argument");
     if (n == 0) return X265AMD_OK;
     XaMapped mJobs; XaMappedOut mMeas;
@@ -852,6 +857,7 @@ static int inter_residual_rd_impl(void* stream_, const x265amd_slice_info* si, c
                                   x265amd_cu_unit* cu_units, uint64_t d_pred, uint64_t d_recon, size_t tile_bytes,
                                   x265amd_rd_result* out, int16_t* coeff_out, bool lazyAssemble)
 {
+    XA_HOSTPROF("rd.inter_residual_rd_impl (all)");
     if (!si || !rp || !units || !h_src || !cus || !cu_units || !d_pred || !d_recon || !out || n < 0) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: null argument");
     if (tile_bytes < (size_t)(4096 + 2048) * sizeof(pixel)) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: tile too small");
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
@@ -1022,6 +1028,7 @@ int xa_merge_rd(void* stream_, const x265amd_slice_info* si, const x265amd_rd_pa
                 const x265amd_rd_cu* cu, x265amd_cu_unit* skip_units, x265amd_cu_unit* merge_units, uint64_t d_pred, uint64_t d_recon_skip, uint64_t d_recon_merge,
                 x265amd_rd_result* out_skip, x265amd_rd_result* out_merge, int16_t* coeff_out, int* merge_is_skip)
 {
+    XA_HOSTPROF("rd.xa_merge_rd (all)");
     if (!si || !rp || !units || !h_src || !cu || !skip_units || !merge_units || !d_pred || !d_recon_skip || !d_recon_merge || !out_skip || !out_merge || !merge_is_skip)
         return xa_fail(X265AMD_EINVAL, "merge_rd: null argument");
     if (rp->rdoq_level || si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "merge_rd: RDOQ / lossless go through the separate entry points");

@@ -63,6 +63,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     if (!me || !I || !S || !cur || !h_planes || !cus || !out || !bits_out || n < 0 || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "x265amd_pred_inter_search: bad arguments");
     if (n == 0) return X265AMD_OK;
+    XA_HOSTPROF("is.pred_inter_search (all)");
     hipStream_t st = (hipStream_t)stream;
     const int srcPic = num_pics - 1, isB = I->is_inter_b, w4 = I->pic_width >> 2;
     const size_t isz = sizeof(x265amd_pixel);
@@ -120,6 +121,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
     auto runCost = [&](std::vector<x265amd_mc_job>& jobs, std::vector<uint32_t>& cost) -> int {
         cost.assign(2 * jobs.size(), 0);
         if (jobs.empty()) return 0;
+        XA_HOSTPROF("is.runCost (incl. wait)");
         size_t arena = 0;
         std::vector<size_t> offs(jobs.size());
         for (size_t i = 0; i < jobs.size(); i++) { offs[i] = arena; arena += ((size_t)jobs[i].w * jobs[i].h * 3 / 2 * isz + 63) & ~(size_t)63; }
@@ -154,6 +156,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
         if (W.empty()) break;
         /* ---- step 1: candidates and their cost jobs ---- */
         std::vector<x265amd_mc_job> cj;
+        { XA_HOSTPROF("is.step1 candidates");
         for (PuWork& w : W)
         {
             const x265amd_inter_cu& c = cus[w.cu];
@@ -212,6 +215,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 {
                     w.mvpJob0[list][ref] = -1; w.meJob[list][ref] = -1;
                     if (!allowed(w.cu, pidx, list, ref)) continue;
+                    XA_HOSTPROF("is.amvp_candidates");
                     w.numMvc[list][ref] = x265amd_amvp_candidates(I, cur, col, c.x, c.y, c.log2_size, c.part_size, pidx, list, ref, w.amvp[list][ref], w.mvc[list][ref]);
                     w.mvpJob0[list][ref] = -1;
                     const int16_t (*a)[2] = w.amvp[list][ref];
@@ -232,6 +236,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 for (int y = g0.y; y < g0.y + g0.h; y += 4)
                     for (int x = g0.x; x < g0.x + g0.w; x += 4) cur[(y >> 2) * w4 + (x >> 2)] = saved[k++];
             }
+        }
         }
         std::vector<uint32_t> cost;
         if (runCost(cj, cost)) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: candidate cost launch failed");
@@ -282,6 +287,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 }
         }
         std::vector<x265amd_me_result> mres(mj.size());
+        XA_HOSTPROF("is.me plan+launch+wait+rest");
         if (xa_ref_guard_me(mj.data(), mjPic.data(), (int)mj.size())) return xa_fail(X265AMD_EHIP, "x265amd_pred_inter_search: a reference picture failed");
         {
             /* plan per reference picture, upload in planned order */

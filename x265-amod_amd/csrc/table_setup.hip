@@ -168,120 +168,155 @@ extern "C" int x265amd_setup_primitives(void* table, size_t table_bytes)
 }
 
 
-/* ---- device scratch pool (x265amd_host.h) ---- */
+/* ---- device scratch and mapped-record pools (x265amd_host.h) ----
+ * Three pools of blocks in power-of-two size classes: device scratch, records the host writes and the device reads (device memory through the BAR), records the
+ * device writes and the host reads (pinned host memory).  The CTU rows call these dozens of times per CU from as many threads as the host grants cores, so the hot
+ * path takes no lock: a row task (it holds a device job queue: xa_scratch_local_begin) allocates from and frees into lists of its own, and a block's size class is
+ * found in a lock-free table.  The shared pools behind a mutex serve the first allocations, the threads without lists (picture / filter threads) and take the
+ * lists back when the queue is released. */
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
 namespace {
+enum { POOL_SCRATCH = 0, POOL_MAPPED_IN = 1, POOL_MAPPED_OUT = 2, POOL_COUNT = 3, CLS_MIN_LOG2 = 8, CLS_COUNT = 28 };
+inline int cls_index(size_t b) { int i = 0; size_t c = (size_t)1 << CLS_MIN_LOG2; while (c < b) { c <<= 1; i++; } return i; }
+inline size_t cls_bytes(int i) { return (size_t)1 << (CLS_MIN_LOG2 + i); }
 struct ScratchPool
 {
     std::mutex m;
-    std::map<size_t, std::vector<void*>> free_;     /* size class -> idle blocks */
-    std::map<void*, size_t> size_;                  /* block -> size class */
+    std::vector<void*> free_[CLS_COUNT];            /* size class -> idle blocks */
+    std::vector<void*> all_;                        /* every block of the pool (x265amd_release_scratch) */
     bool device_ = false;                           /* mapped pools: blocks are device memory (hipFree) rather than pinned host memory */
-    static size_t cls(size_t b) { size_t c = 256; while (c < b) c <<= 1; return c; }
 };
-ScratchPool& scratch_pool() { static ScratchPool* p = new ScratchPool; return *p; }
+ScratchPool& pool_of(int k) { static ScratchPool* p[POOL_COUNT] = { new ScratchPool, new ScratchPool, new ScratchPool }; return *p[k]; }
+
+/* block -> (pool, size class): open addressing, insert under the owning pool's mutex (a block enters once, when the runtime hands it out), lock-free look-up.
+ * Entries go away only in x265amd_release_scratch, which runs while nothing else uses the pools. */
+enum { TAB_BITS = 18, TAB_SIZE = 1 << TAB_BITS };
+struct TabEntry { std::atomic<uintptr_t> key; std::atomic<uint32_t> val; };
+TabEntry* g_tab = new TabEntry[TAB_SIZE]();
+std::mutex g_tabM;
+inline uint32_t tab_hash(uintptr_t k) { return (uint32_t)((k >> 8) * 0x9E3779B97F4A7C15ull >> (64 - TAB_BITS)); }
+void tab_insert(void* p, int pool, int cls)
+{
+    std::lock_guard<std::mutex> g(g_tabM);
+    const uintptr_t k = (uintptr_t)p;
+    for (uint32_t i = tab_hash(k), n = 0; n < TAB_SIZE; i = (i + 1) & (TAB_SIZE - 1), n++)
+    {
+        const uintptr_t cur = g_tab[i].key.load(std::memory_order_relaxed);
+        if (cur == 0 || cur == k) { g_tab[i].val.store((uint32_t)(pool << 8 | cls), std::memory_order_relaxed); g_tab[i].key.store(k, std::memory_order_release); return; }
+    }
+    fprintf(stderr, "x265amd: fatal: block table full\n"); abort();
 }
-namespace { thread_local std::map<size_t, std::vector<void*>>* t_local = nullptr; }
-void xa_scratch_local_begin() { if (!t_local) t_local = new std::map<size_t, std::vector<void*>>; }
-/* row tasks (xa_fiber.h): the list belongs to the task, not to the worker thread that happens to run it */
-void* xa_scratch_local_swap(void* list) { void* old = t_local; t_local = static_cast<std::map<size_t, std::vector<void*>>*>(list); return old; }
+bool tab_find(const void* p, int& pool, int& cls)
+{
+    const uintptr_t k = (uintptr_t)p;
+    for (uint32_t i = tab_hash(k), n = 0; n < TAB_SIZE; i = (i + 1) & (TAB_SIZE - 1), n++)
+    {
+        const uintptr_t cur = g_tab[i].key.load(std::memory_order_acquire);
+        if (cur == k) { const uint32_t v = g_tab[i].val.load(std::memory_order_relaxed); pool = (int)(v >> 8); cls = (int)(v & 255); return true; }
+        if (cur == 0) return false;
+    }
+    return false;
+}
+
+struct LocalLists { std::vector<void*> v[POOL_COUNT][CLS_COUNT]; };
+thread_local LocalLists* t_local = nullptr;
+
+hipError_t pool_alloc(int k, void** p, size_t bytes)
+{
+    const int c = cls_index(bytes ? bytes : 1);
+    if (c >= CLS_COUNT) return hipErrorOutOfMemory;
+    if (t_local)
+    {
+        std::vector<void*>& v = t_local->v[k][c];
+        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    ScratchPool& P = pool_of(k);
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        std::vector<void*>& v = P.free_[c];
+        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
+    }
+    hipError_t e;
+    bool device = true;
+    if (k == POOL_SCRATCH) e = hipMalloc(p, cls_bytes(c));
+    else
+    {
+        /* Job records (host writes, device reads) live in DEVICE memory the host writes through the BAR: the stores are posted and travel in order ahead of
+         * the command that uses them (or are long there when a kernel launches), and the device reads them at local latency instead of pulling them over
+         * PCIe (about 1.7 us per command saved in queue mode).  Uncached allocation: nothing of it lingers in the L2 between uses.  Results (device
+         * writes, host reads) stay in pinned host memory: a host read over the BAR costs a microsecond per access.  X265AMD_PUSH_RECORDS=0: host memory for both. */
+        static const bool push = !(getenv("X265AMD_PUSH_RECORDS") && atoi(getenv("X265AMD_PUSH_RECORDS")) == 0);
+        device = k == POOL_MAPPED_IN && push;
+        e = device ? hipExtMallocWithFlags(p, cls_bytes(c), hipDeviceMallocUncached) : hipHostMalloc(p, cls_bytes(c), hipHostMallocMapped | hipHostMallocCoherent);
+    }
+    if (e == hipSuccess)
+    {
+        { std::lock_guard<std::mutex> g(P.m); P.all_.push_back(*p); P.device_ = device; }
+        tab_insert(*p, k, c);
+    }
+    return e;
+}
+/* returns false when the block is not one of ours */
+bool pool_free(void* p)
+{
+    int k, c;
+    if (!tab_find(p, k, c)) return false;
+    if (t_local) { t_local->v[k][c].push_back(p); return true; }
+    ScratchPool& P = pool_of(k);
+    std::lock_guard<std::mutex> g(P.m);
+    P.free_[c].push_back(p);
+    return true;
+}
+}
+void xa_scratch_local_begin() { if (!t_local) t_local = new LocalLists; }
+/* row tasks (xa_fiber.h): the lists belong to the task, not to the worker thread that happens to run it */
+void* xa_scratch_local_swap(void* list) { void* old = t_local; t_local = static_cast<LocalLists*>(list); return old; }
 void xa_scratch_local_end()
 {
     if (!t_local) return;
-    ScratchPool& P = scratch_pool();
+    for (int k = 0; k < POOL_COUNT; k++)
     {
+        ScratchPool& P = pool_of(k);
         std::lock_guard<std::mutex> g(P.m);
-        for (auto& kv : *t_local) { std::vector<void*>& v = P.free_[kv.first]; v.insert(v.end(), kv.second.begin(), kv.second.end()); }
+        for (int c = 0; c < CLS_COUNT; c++) { std::vector<void*>& v = P.free_[c]; v.insert(v.end(), t_local->v[k][c].begin(), t_local->v[k][c].end()); }
     }
     delete t_local;
     t_local = nullptr;
 }
-hipError_t xa_scratch_alloc(void** p, size_t bytes)
-{
-    ScratchPool& P = scratch_pool();
-    const size_t c = ScratchPool::cls(bytes ? bytes : 1);
-    if (t_local)
-    {
-        std::vector<void*>& v = (*t_local)[c];
-        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
-    }
-    {
-        std::lock_guard<std::mutex> g(P.m);
-        std::vector<void*>& v = P.free_[c];
-        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
-    }
-    const hipError_t e = hipMalloc(p, c);
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(P.m); P.size_[*p] = c; }
-    return e;
-}
+hipError_t xa_scratch_alloc(void** p, size_t bytes) { return pool_alloc(POOL_SCRATCH, p, bytes); }
 void xa_scratch_free(void* p)
 {
     if (!p) return;
-    ScratchPool& P = scratch_pool();
-    size_t c = 0;
-    {
-        std::lock_guard<std::mutex> g(P.m);
-        auto it = P.size_.find(p);
-        if (it != P.size_.end())
-        {
-            c = it->second;
-            if (!t_local) { P.free_[c].push_back(p); return; }
-        }
-    }
-    if (!c) { (void)hipFree(p); return; }
-    (*t_local)[c].push_back(p);
+    if (!pool_free(p)) (void)hipFree(p);
 }
-namespace { ScratchPool& mapped_pool(bool deviceWrites) { static ScratchPool* p[2] = { new ScratchPool, new ScratchPool }; return *p[deviceWrites ? 1 : 0]; } }
-hipError_t xa_mapped_alloc(void** p, size_t bytes, bool deviceWrites)
-{
-    ScratchPool& P = mapped_pool(deviceWrites);
-    const size_t c = ScratchPool::cls(bytes ? bytes : 1);
-    {
-        std::lock_guard<std::mutex> g(P.m);
-        std::vector<void*>& v = P.free_[c];
-        if (!v.empty()) { *p = v.back(); v.pop_back(); return hipSuccess; }
-    }
-    /* Job records (host writes, device reads) live in DEVICE memory the host writes through the BAR: the stores are posted and travel in order ahead of
-     * the command that uses them (or are long there when a kernel launches), and the device reads them at local latency instead of pulling them over
-     * PCIe (about 1.7 us per command saved in queue mode).  Uncached allocation: nothing of it lingers in the L2 between uses.  Results (device
-     * writes, host reads) stay in pinned host memory: a host read over the BAR costs a microsecond per access.  X265AMD_PUSH_RECORDS=0: host memory for both. */
-    static const bool push = !(getenv("X265AMD_PUSH_RECORDS") && atoi(getenv("X265AMD_PUSH_RECORDS")) == 0);
-    const hipError_t e = (!deviceWrites && push) ? hipExtMallocWithFlags(p, c, hipDeviceMallocUncached) : hipHostMalloc(p, c, hipHostMallocMapped | hipHostMallocCoherent);
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(P.m); P.size_[*p] = c; P.device_ = !deviceWrites && push; }
-    return e;
-}
+hipError_t xa_mapped_alloc(void** p, size_t bytes, bool deviceWrites) { return pool_alloc(deviceWrites ? POOL_MAPPED_OUT : POOL_MAPPED_IN, p, bytes); }
 void xa_mapped_free(void* p)
 {
     if (!p) return;
-    for (int d = 0; d < 2; d++)
-    {
-        ScratchPool& P = mapped_pool(d != 0);
-        std::lock_guard<std::mutex> g(P.m);
-        auto it = P.size_.find(p);
-        if (it == P.size_.end()) continue;
-        P.free_[it->second].push_back(p);
-        return;
-    }
-    (void)hipHostFree(p);
+    if (!pool_free(p)) (void)hipHostFree(p);
 }
 extern "C" void x265amd_release_scratch(void)
 {
     (void)hipDeviceSynchronize();
+    for (int k = 0; k < POOL_COUNT; k++)
     {
-        ScratchPool& P = scratch_pool();
+        ScratchPool& P = pool_of(k);
         std::lock_guard<std::mutex> g(P.m);
-        for (auto& kv : P.free_) { for (void* q : kv.second) { (void)hipFree(q); P.size_.erase(q); } kv.second.clear(); }
-    }
-    for (int d = 0; d < 2; d++)
-    {
-        ScratchPool& P = mapped_pool(d != 0);
-        std::lock_guard<std::mutex> g(P.m);
-        for (auto& kv : P.free_) { for (void* q : kv.second) { if (P.device_) (void)hipFree(q); else (void)hipHostFree(q); P.size_.erase(q); } kv.second.clear(); }
+        /* only idle blocks go back to the runtime; their table entries stay (a block of the same address that comes back later is entered again with its new class) */
+        for (int c = 0; c < CLS_COUNT; c++)
+        {
+            for (void* q : P.free_[c])
+            {
+                if (k == POOL_SCRATCH || P.device_) (void)hipFree(q); else (void)hipHostFree(q);
+                for (size_t i = 0; i < P.all_.size(); i++) if (P.all_[i] == q) { P.all_[i] = P.all_.back(); P.all_.pop_back(); break; }
+            }
+            P.free_[c].clear();
+        }
     }
 }
-
 
 /* ---- xa_copy_rects (x265amd_host.h) ---- */
 __global__ __launch_bounds__(256) void k_copy_rects(XaRects r)
@@ -304,3 +339,31 @@ void xa_copy_rects(void* st, const XaRects& r)
     hipError_t e_;
     XA_LAUNCH(e_, st, XA_OP_COPY_RECTS, 1, r, k_copy_rects, dim3(r.n), dim3(256), 0, r);
 }
+
+/* ---- X265AMD_HOSTPROF (x265amd_host.h) ---- */
+#include "xa_fiber.h"
+#include <atomic>
+#include <time.h>
+bool g_xaHostProf = getenv("X265AMD_HOSTPROF") != nullptr;
+namespace {
+struct HpEntry { const char* name; std::atomic<uint64_t> calls, ns; };
+HpEntry g_hp[128];
+std::atomic<int> g_hpN{ 0 };
+inline uint64_t hp_now()
+{
+    if (xa_in_task()) return xa_task_run_ns_always();
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+}
+int xa_hostprof_id(const char* name) { const int i = g_hpN.fetch_add(1); if (i < 128) g_hp[i].name = name; return i < 128 ? i : 127; }
+XaHostProfScope::XaHostProfScope(int id_) : id(id_), t0(g_xaHostProf ? hp_now() : 0) {}
+XaHostProfScope::~XaHostProfScope() { if (g_xaHostProf) { g_hp[id].calls++; g_hp[id].ns += hp_now() - t0; } }
+void xa_hostprof_report(void)
+{
+    if (!g_xaHostProf) return;
+    const int n = g_hpN.load() < 128 ? g_hpN.load() : 128;
+    fprintf(stderr, "x265amd host profile (scope: calls, ms, us per call):\n");
+    for (int i = 0; i < n; i++)
+        if (g_hp[i].calls) fprintf(stderr, "  %-34s %9llu %9.1f %8.2f\n", g_hp[i].name, (unsigned long long)g_hp[i].calls.load(), g_hp[i].ns.load() / 1e6, g_hp[i].ns.load() / 1e3 / g_hp[i].calls.load());
+}
+extern "C" void x265amd_hostprof_report(void) { xa_hostprof_report(); }

@@ -153,6 +153,16 @@ enum { XA_PH_OTHER = 0, XA_PH_INTRA_SETUP, XA_PH_INTRA_SCAN, XA_PH_INTRA_CAND, X
 void xa_phase(int k);
 void xa_phase_report(void);
 
+/* X265AMD_HOSTPROF=1: host CPU time by named scope (csrc/table_setup.hip: a table of (name, calls, nanoseconds of task running time), printed by
+ * xa_hostprof_report).  XA_HOSTPROF("name") at the top of a scope; the clock is the row task's running time, so parked time does not count. */
+struct XaHostProfScope { int id; uint64_t t0; explicit XaHostProfScope(int id_); ~XaHostProfScope(); };
+int xa_hostprof_id(const char* name);
+void xa_hostprof_report(void);
+extern bool g_xaHostProf;
+#define XA_HOSTPROF_CAT2(a, b) a##b
+#define XA_HOSTPROF_CAT(a, b) XA_HOSTPROF_CAT2(a, b)
+#define XA_HOSTPROF(name) static const int XA_HOSTPROF_CAT(xa_hp_id_, __LINE__) = xa_hostprof_id(name); XaHostProfScope XA_HOSTPROF_CAT(xa_hp_, __LINE__)(XA_HOSTPROF_CAT(xa_hp_id_, __LINE__))
+
 /* device address of the centre (MVD 0) of x265amd_me_ctx's MV cost table for `qp` (BitCost::s_costs[qp]) */
 const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp);
 

@@ -46,6 +46,7 @@ int xa_in_task(void);
 int xa_worker_count(void);
 /* X265AMD_TIMING: time the calling task has spent running (up to its last resume); totals over all workers: running, looking for a task that can run, switches */
 uint64_t xa_task_run_ns(void);
+uint64_t xa_task_run_ns_always(void);     /* the same whether or not X265AMD_TIMING is set (X265AMD_HOSTPROF) */
 void** xa_task_slot(void);                  /* a pointer slot of the calling task, NULL at its start (NULL outside a task) */
 uint64_t* xa_task_mark(void);               /* a word of the calling task for the caller's own bookkeeping (NULL outside a task) */
 void xa_sched_stats(uint64_t out[3]);

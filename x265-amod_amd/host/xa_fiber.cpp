@@ -56,7 +56,7 @@ struct Fiber
 
 struct Worker { void* sp = nullptr; Fiber* cur = nullptr; };
 std::atomic<uint64_t> g_busyNs{ 0 }, g_idleNs{ 0 }, g_switches{ 0 };
-const bool g_stats = getenv("X265AMD_TIMING") != nullptr;
+const bool g_stats = getenv("X265AMD_TIMING") != nullptr || getenv("X265AMD_HOSTPROF") != nullptr;
 inline uint64_t now_ns() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
 
 struct Sched
@@ -276,6 +276,7 @@ void xa_counter_free(volatile uint64_t* c)
 int xa_worker_count(void) { start_workers(); return sched().numWorkers; }
 uint64_t xa_task_run_ns(void) { Worker* w = current_worker(); return w && w->cur ? w->cur->runNs + (g_stats ? now_ns() - w->cur->stintStart : 0) : 0; }
 void** xa_task_slot(void) { Worker* w = current_worker(); return w && w->cur ? &w->cur->userSlot : nullptr; }
+uint64_t xa_task_run_ns_always(void) { Worker* w = current_worker(); return w && w->cur ? w->cur->runNs + (now_ns() - w->cur->stintStart) : 0; }
 uint64_t* xa_task_mark(void) { Worker* w = current_worker(); return w && w->cur ? &w->cur->userMark : nullptr; }
 void xa_sched_stats(uint64_t out[3]) { out[0] = g_busyNs.load(); out[1] = g_idleNs.load(); out[2] = g_switches.load(); }
 int xa_in_task(void) { Worker* w = current_worker(); return w && w->cur; }
