@@ -1,0 +1,34 @@
+/* Compile-time check (this container only): every number of x265-amod_amd/host/x265_abi_layout.h -- the offsets and sizes x265_api_abi.cpp reads x265_param /
+ * x265_picture / x265_api members at -- against the reference's own public header (source/x265.h), included from /root/reference at compile time. */
+#include "x265.h"
+#include "x265_abi_layout.h"
+#include <cstddef>
+static_assert(X265ABI_BUILD == X265_BUILD && X265ABI_MAJOR_VERSION == X265_MAJOR_VERSION, "build");
+static_assert(X265ABI_SIZEOF_PARAM == sizeof(x265_param) && X265ABI_SIZEOF_PICTURE == sizeof(x265_picture) && X265ABI_SIZEOF_ANALYSIS_DATA == sizeof(x265_analysis_data), "sizes");
+static_assert(X265ABI_SIZEOF_ZONE == sizeof(x265_zone) && X265ABI_SIZEOF_STATS == sizeof(x265_stats) && X265ABI_SIZEOF_FRAME_STATS == sizeof(x265_frame_stats), "sizes");
+static_assert(X265ABI_SIZEOF_NAL == sizeof(x265_nal) && X265ABI_SIZEOF_API == sizeof(x265_api), "sizes");
+static_assert(offsetof(x265_nal, type) == 0 && offsetof(x265_nal, sizeBytes) == 4 && offsetof(x265_nal, payload) == 8, "x265_nal = x265amd_nal");
+#define P(f) static_assert(offsetof(x265_param, f) == X265ABI_PARAM_##f, #f)
+#define PN(n, f) static_assert(offsetof(x265_param, f) == X265ABI_PARAM_##n, #n)
+P(cpuid); P(frameNumThreads); P(bEnableWavefront); P(bDistributeModeAnalysis); P(bDistributeMotionEstimation); P(logLevel); P(internalBitDepth); P(internalCsp);
+P(fpsNum); P(fpsDenom); P(sourceWidth); P(sourceHeight); P(interlaceMode); P(levelIdc); P(bHighTier); P(uhdBluray); P(maxNumReferences); P(bRepeatHeaders); P(bAnnexB);
+P(bEnableAccessUnitDelimiters); P(bEmitHRDSEI); P(bEmitInfoSEI); P(decodedPictureHashSEI); P(bEnableTemporalSubLayers); P(bOpenGOP); P(keyframeMin); P(keyframeMax);
+P(bframes); P(bFrameAdaptive); P(bBPyramid); P(lookaheadDepth); P(lookaheadSlices); P(scenecutThreshold); P(bIntraRefresh); P(maxCUSize); P(minCUSize); P(bEnableRectInter);
+P(bEnableAMP); P(maxTUSize); P(tuQTMaxInterDepth); P(tuQTMaxIntraDepth); P(limitTU); P(rdoqLevel); P(bEnableSignHiding); P(bEnableTransformSkip); P(noiseReductionIntra);
+P(noiseReductionInter); P(scalingLists); P(bEnableConstrainedIntra); P(bEnableStrongIntraSmoothing); P(maxNumMergeCand); P(limitReferences); P(limitModes); P(searchMethod);
+P(subpelRefine); P(searchRange); P(bEnableTemporalMvp); P(bEnableHME); P(bEnableWeightedPred); P(bEnableWeightedBiPred); P(bEnableLoopFilter); P(deblockingFilterTCOffset);
+P(deblockingFilterBetaOffset); P(bEnableSAO); P(bSaoNonDeblocked); P(selectiveSAO); P(rdLevel); P(bEnableEarlySkip); P(recursionSkipMode); P(bEnableFastIntra); P(bCULossless);
+P(bIntraInBFrames); P(rdPenalty); P(psyRd); P(psyRdoq); P(bEnableRdRefine); P(analysisReuseMode); P(bLossless); P(cbQpOffset); P(crQpOffset); P(maxSlices); P(bDynamicRefine);
+P(bEnableSvtHevc); P(bEnableSceneCutAwareQp); P(bHistBasedSceneCut); P(bEnableFades); P(gopLookahead); P(radl); P(bField); P(bAQMotion); P(bSsimRd); P(dynamicRd);
+PN(rc_rateControlMode, rc.rateControlMode); PN(rc_qp, rc.qp); PN(rc_ipFactor, rc.ipFactor); PN(rc_pbFactor, rc.pbFactor); PN(rc_aqMode, rc.aqMode); PN(rc_cuTree, rc.cuTree);
+PN(rc_qpMin, rc.qpMin); PN(rc_qpMax, rc.qpMax); PN(rc_vbvBufferSize, rc.vbvBufferSize); PN(rc_bStatRead, rc.bStatRead); PN(rc_bStatWrite, rc.bStatWrite);
+PN(vui_aspectRatioIdc, vui.aspectRatioIdc); PN(vui_bEnableVideoSignalTypePresentFlag, vui.bEnableVideoSignalTypePresentFlag);
+PN(vui_bEnableOverscanInfoPresentFlag, vui.bEnableOverscanInfoPresentFlag); PN(vui_bEnableChromaLocInfoPresentFlag, vui.bEnableChromaLocInfoPresentFlag);
+PN(vui_bEnableDefaultDisplayWindowFlag, vui.bEnableDefaultDisplayWindowFlag);
+#define PIC(f) static_assert(offsetof(x265_picture, f) == X265ABI_PIC_##f, #f)
+PIC(pts); PIC(dts); PIC(planes); PIC(stride); PIC(bitDepth); PIC(sliceType); PIC(poc); PIC(colorSpace); PIC(forceqp); PIC(height); PIC(width);
+#define API(f) static_assert(offsetof(x265_api, f) == X265ABI_API_##f, #f)
+API(api_major_version); API(bit_depth); API(version_str); API(param_alloc); API(encoder_open); API(encoder_encode); API(encoder_close); API(cleanup); API(sizeof_frame_stats);
+API(encoder_intra_refresh); API(zone_param_parse);
+static_assert(X265_RC_CQP == 1 && X265_RC_CRF == 2 && X265_CSP_I420 == 1 && X265_DIA_SEARCH == 0 && X265_HEX_SEARCH == 1 && X265_STAR_SEARCH == 3, "enum values used by x265_api_abi.cpp");
+int main() { return 0; }

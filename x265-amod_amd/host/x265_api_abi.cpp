@@ -1,0 +1,283 @@
+/* The reference's public ABI over the encoder object: `x265_api_get_209` / `x265_api_query` returning a table with the layout of `struct x265_api`
+ * (reference: source/x265.h:2561-2614; the library's own table `libapi`, source/encoder/api.cpp:1034-1085; the two entry points api.cpp:1107-1279), so that a
+ * libx265 client can dlopen libx265amd_main.so / libx265amd_main10.so in place of libx265_main.so / libx265_main10.so.  Host C++.
+ *
+ * The table's encoder entries take the reference's own structures: x265_encoder_open reads a real `x265_param` (x265.h:1034-2275), x265_encoder_encode real
+ * `x265_picture`s (x265.h:397-490).  Their members are read at the byte offsets of x265_abi_layout.h, which oracle/gen_abi_layout.cpp GENERATES from the
+ * reference's header (numbers only) and tests/layout_check.cpp pins against it again; the reference's header itself is not part of this build.
+ *
+ * Built entries: param_alloc / param_free, picture_alloc / picture_free / picture_init, encoder_open, encoder_parameters, encoder_headers, encoder_encode,
+ * encoder_get_stats (zeroes), encoder_log (no-op), encoder_close, cleanup.  Entries of features outside the built subset FAIL CLEANLY: param_default fills the
+ * reference's defaults for the members encoder_open reads and zeroes the rest, param_default_preset accepts NULL / "medium" only (the other presets' option
+ * tables are not restated), param_parse / zone_param_parse / scenecut_aware_qp_param_parse report a bad name, encoder_reconfig* / intra_refresh / ctu_info /
+ * get_slicetype_poc_and_scenecut / get_ref_frame_list / set_analysis_data return -1, csvlog_open returns NULL.  encoder_open rejects every parameter outside the
+ * subset BY NAME (x265amd_last_error).
+ */
+#include "../../include/x265amd.h"
+#include "../../include/x265amd_encoder.h"
+#include "x265_abi_layout.h"
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+int xa_fail(int code, const char* msg);
+
+namespace {
+
+template<typename T> inline T rd(const void* base, size_t off) { T v; memcpy(&v, (const char*)base + off, sizeof(T)); return v; }
+template<typename T> inline void wr(void* base, size_t off, T v) { memcpy((char*)base + off, &v, sizeof(T)); }
+#define PI(p, f) rd<int32_t>(p, X265ABI_PARAM_##f)
+#define PU(p, f) rd<uint32_t>(p, X265ABI_PARAM_##f)
+#define PD(p, f) rd<double>(p, X265ABI_PARAM_##f)
+
+struct AbiEncoder
+{
+    x265amd_encoder* enc = nullptr;
+    std::vector<uint8_t> param;         /* the caller's x265_param as it was at encoder_open (encoder_parameters hands it back) */
+    int width = 0, height = 0;
+    int64_t ptsQueue[64]; int ptsHead = 0, ptsCount = 0;
+};
+
+/* ---- x265_param ---- */
+void* abi_param_alloc(void) { return calloc(1, X265ABI_SIZEOF_PARAM); }
+void abi_param_free(void* p) { free(p); }
+
+/* x265_param_default (source/common/param.cpp:100-420) for the members x265_encoder_open reads here; everything else zero */
+void abi_param_default(void* p)
+{
+    if (!p) return;
+    memset(p, 0, X265ABI_SIZEOF_PARAM);
+    wr<int32_t>(p, X265ABI_PARAM_cpuid, 0); wr<int32_t>(p, X265ABI_PARAM_bEnableWavefront, 1); wr<int32_t>(p, X265ABI_PARAM_frameNumThreads, 0);
+    wr<int32_t>(p, X265ABI_PARAM_logLevel, 2); wr<int32_t>(p, X265ABI_PARAM_internalBitDepth, X265AMD_DEPTH); wr<int32_t>(p, X265ABI_PARAM_internalCsp, 1);
+    wr<int32_t>(p, X265ABI_PARAM_levelIdc, 0); wr<int32_t>(p, X265ABI_PARAM_bHighTier, 1); wr<int32_t>(p, X265ABI_PARAM_bAnnexB, 1); wr<int32_t>(p, X265ABI_PARAM_bEmitInfoSEI, 1);
+    wr<int32_t>(p, X265ABI_PARAM_maxCUSize, 64); wr<int32_t>(p, X265ABI_PARAM_minCUSize, 8); wr<int32_t>(p, X265ABI_PARAM_maxTUSize, 32);
+    wr<int32_t>(p, X265ABI_PARAM_tuQTMaxInterDepth, 1); wr<int32_t>(p, X265ABI_PARAM_tuQTMaxIntraDepth, 1);
+    wr<int32_t>(p, X265ABI_PARAM_maxNumReferences, 3); wr<int32_t>(p, X265ABI_PARAM_limitReferences, 3);
+    wr<int32_t>(p, X265ABI_PARAM_bOpenGOP, 1); wr<int32_t>(p, X265ABI_PARAM_keyframeMin, 0); wr<int32_t>(p, X265ABI_PARAM_keyframeMax, 250);
+    wr<int32_t>(p, X265ABI_PARAM_bframes, 4); wr<int32_t>(p, X265ABI_PARAM_bFrameAdaptive, 2); wr<int32_t>(p, X265ABI_PARAM_bBPyramid, 1);
+    wr<int32_t>(p, X265ABI_PARAM_lookaheadDepth, 20); wr<int32_t>(p, X265ABI_PARAM_lookaheadSlices, 8); wr<int32_t>(p, X265ABI_PARAM_scenecutThreshold, 40);
+    wr<int32_t>(p, X265ABI_PARAM_searchMethod, 1); wr<int32_t>(p, X265ABI_PARAM_subpelRefine, 2); wr<int32_t>(p, X265ABI_PARAM_searchRange, 57);
+    wr<int32_t>(p, X265ABI_PARAM_maxNumMergeCand, 3); wr<int32_t>(p, X265ABI_PARAM_bEnableWeightedPred, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableEarlySkip, 1);
+    wr<int32_t>(p, X265ABI_PARAM_recursionSkipMode, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSignHiding, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableStrongIntraSmoothing, 1);
+    wr<int32_t>(p, X265ABI_PARAM_bEnableTemporalMvp, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableLoopFilter, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSAO, 1);
+    wr<int32_t>(p, X265ABI_PARAM_rdLevel, 3); wr<int32_t>(p, X265ABI_PARAM_bIntraInBFrames, 1); wr<double>(p, X265ABI_PARAM_psyRd, 2.0); wr<double>(p, X265ABI_PARAM_psyRdoq, 0.0);
+    wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 2 /* X265_RC_CRF */); wr<int32_t>(p, X265ABI_PARAM_rc_qp, 32); wr<double>(p, X265ABI_PARAM_rc_ipFactor, 1.4);
+    wr<double>(p, X265ABI_PARAM_rc_pbFactor, 1.3); wr<int32_t>(p, X265ABI_PARAM_rc_aqMode, 2); wr<int32_t>(p, X265ABI_PARAM_rc_cuTree, 1);
+    wr<int32_t>(p, X265ABI_PARAM_rc_qpMin, 0); wr<int32_t>(p, X265ABI_PARAM_rc_qpMax, 69); wr<int32_t>(p, X265ABI_PARAM_maxSlices, 1);
+}
+int abi_param_default_preset(void* p, const char* preset, const char* tune)
+{
+    if (!p || (preset && strcmp(preset, "medium") != 0 && strcmp(preset, "5") != 0) || (tune && *tune)) return -1;        /* the other presets' / tunes' option tables are not restated */
+    abi_param_default(p);                /* --preset medium is the defaults (param.cpp:496-499) */
+    return 0;
+}
+int abi_param_parse(void*, const char*, const char*) { return -1; }        /* X265_PARAM_BAD_NAME: the option parser is not part of the hot path */
+int abi_param_apply_profile(void* p, const char* profile)
+{
+    if (!p || !profile) return 0;
+    if (X265AMD_DEPTH == 8 && (!strcmp(profile, "main") || !strcmp(profile, "main10"))) return 0;
+    if (X265AMD_DEPTH == 10 && !strcmp(profile, "main10")) return 0;
+    return -1;
+}
+
+/* ---- x265_picture ---- */
+void abi_picture_init(void* param, void* pic)
+{
+    if (!pic) return;
+    memset(pic, 0, X265ABI_SIZEOF_PICTURE);
+    wr<int32_t>(pic, X265ABI_PIC_bitDepth, param ? PI(param, internalBitDepth) : X265AMD_DEPTH);
+    wr<int32_t>(pic, X265ABI_PIC_colorSpace, param ? PI(param, internalCsp) : 1);
+    wr<int32_t>(pic, X265ABI_PIC_forceqp, 0);
+}
+void* abi_picture_alloc(void) { return calloc(1, X265ABI_SIZEOF_PICTURE); }
+void abi_picture_free(void* p) { free(p); }
+
+/* ---- encoder ---- */
+void* abi_encoder_open(void* p)
+{
+    if (!p) { xa_fail(X265AMD_EINVAL, "x265_encoder_open: null param"); return nullptr; }
+    static thread_local char why[200];
+    const char* bad = nullptr;
+#define REQUIRE(cond, text) do { if (!bad && !(cond)) bad = text; } while (0)
+    REQUIRE(PI(p, internalBitDepth) == X265AMD_DEPTH, "internalBitDepth differs from this library's (libx265amd_main: 8, libx265amd_main10: 10)");
+    REQUIRE(PI(p, internalCsp) == 1, "internalCsp: only X265_CSP_I420 is built");
+    REQUIRE(PI(p, rc_rateControlMode) == 1, "rc.rateControlMode: only X265_RC_CQP (--qp) is built (no ABR / CRF / VBV)");
+    REQUIRE(PI(p, rc_vbvBufferSize) == 0 && !PI(p, rc_bStatRead) && !PI(p, rc_bStatWrite), "rc: VBV and multi-pass statistics are not built");
+    REQUIRE(PI(p, bFrameAdaptive) == 0, "bFrameAdaptive (--b-adapt): only 0 is built");
+    REQUIRE(PI(p, scenecutThreshold) == 0 && !PI(p, bHistBasedSceneCut), "scenecutThreshold: scene-cut detection is not built (--no-scenecut)");
+    REQUIRE(!PI(p, bBPyramid) || PI(p, bframes) < 2, "bBPyramid is not built (--no-b-pyramid)");
+    REQUIRE(!PI(p, bOpenGOP), "bOpenGOP is not built (--no-open-gop)");
+    REQUIRE(!PI(p, bEnableWeightedPred) && !PI(p, bEnableWeightedBiPred), "weighted prediction is not built (--no-weightp --no-weightb)");
+    REQUIRE(!PI(p, bEmitInfoSEI), "bEmitInfoSEI: the option-string SEI is not written (--no-info)");
+    REQUIRE(PI(p, maxCUSize) == 64 && PI(p, minCUSize) == 8 && PI(p, maxTUSize) == 32, "maxCUSize / minCUSize / maxTUSize: only 64 / 8 / 32 are built");
+    REQUIRE(!PI(p, interlaceMode) && !PI(p, bField), "interlaced coding is not built");
+    REQUIRE(!PI(p, bLossless) && !PI(p, bCULossless), "lossless coding is not built");
+    REQUIRE(!PI(p, bEnableTransformSkip), "bEnableTransformSkip is not built");
+    REQUIRE(PI(p, limitTU) == 0, "limitTU is not built");
+    REQUIRE(PI(p, maxSlices) <= 1, "maxSlices above 1 is not built");
+    REQUIRE(!PI(p, bIntraRefresh) && !PI(p, bEnableHME) && !PI(p, bEnableConstrainedIntra), "intra refresh / HME / constrained intra are not built");
+    REQUIRE(!PI(p, noiseReductionIntra) && !PI(p, noiseReductionInter) && !rd<const char*>(p, X265ABI_PARAM_scalingLists), "noise reduction / scaling lists are not built");
+    REQUIRE(!PI(p, cbQpOffset) && !PI(p, crQpOffset) && !PI(p, deblockingFilterTCOffset) && !PI(p, deblockingFilterBetaOffset), "chroma QP / deblocking offsets must be 0");
+    REQUIRE(!PI(p, bSaoNonDeblocked) && !PI(p, selectiveSAO), "sao-non-deblock / selective-sao are not built");
+    REQUIRE(!PI(p, bRepeatHeaders) && !PI(p, bEnableAccessUnitDelimiters) && !PI(p, bEmitHRDSEI) && !PI(p, decodedPictureHashSEI), "repeat-headers / AUD / HRD SEI / hash SEI are not built");
+    REQUIRE(!PI(p, bEnableTemporalSubLayers) && !PI(p, uhdBluray) && !PI(p, bEnableSvtHevc), "temporal layers / uhd-bd / svt are not built");
+    REQUIRE(!PI(p, analysisReuseMode) && !PI(p, bDynamicRefine) && !PI(p, rdPenalty) && !PI(p, bEnableRdRefine) && !PI(p, dynamicRd) && !PI(p, bSsimRd), "analysis reuse / rd-refine / dynamic-rd / ssim-rd are not built");
+    REQUIRE(!PI(p, bDistributeModeAnalysis) && !PI(p, bDistributeMotionEstimation), "pmode / pme are not built");
+    REQUIRE(!PI(p, bAQMotion) && !PI(p, gopLookahead) && !PI(p, radl) && !PI(p, bEnableSceneCutAwareQp) && !PI(p, bEnableFades), "aq-motion / gop-lookahead / radl / scenecut-aware-qp / fades are not built");
+    REQUIRE(!PI(p, vui_bEnableVideoSignalTypePresentFlag) && !PI(p, vui_bEnableOverscanInfoPresentFlag) && !PI(p, vui_bEnableChromaLocInfoPresentFlag) &&
+            !PI(p, vui_bEnableDefaultDisplayWindowFlag) && PI(p, vui_aspectRatioIdc) != 255, "vui: only aspectRatioIdc (not extended SAR) is written");
+    REQUIRE(PI(p, levelIdc) == 0, "levelIdc: the level is derived (determineLevel), not forced");
+    REQUIRE(PI(p, searchMethod) == 0 || PI(p, searchMethod) == 1 || PI(p, searchMethod) == 3, "searchMethod: only dia, hex and star are built");
+#undef REQUIRE
+    if (bad) { snprintf(why, sizeof(why), "x265_encoder_open: %s", bad); xa_fail(X265AMD_EINVAL, why); return nullptr; }
+    x265amd_param q;
+    x265amd_param_default(&q);
+    q.sourceWidth = PI(p, sourceWidth); q.sourceHeight = PI(p, sourceHeight); q.fpsNum = PU(p, fpsNum); q.fpsDenom = PU(p, fpsDenom);
+    q.bframes = PI(p, bframes); q.keyframeMax = PI(p, keyframeMax); q.maxNumReferences = PI(p, maxNumReferences);
+    q.qp = PI(p, rc_qp); q.ipFactor = PD(p, rc_ipFactor); q.pbFactor = PD(p, rc_pbFactor);
+    q.rdLevel = PI(p, rdLevel); q.bEnableRectInter = PI(p, bEnableRectInter); q.bEnableAMP = PI(p, bEnableAMP); q.limitModes = PI(p, limitModes); q.limitReferences = PI(p, limitReferences);
+    q.bEnableEarlySkip = PI(p, bEnableEarlySkip); q.recursionSkipMode = PI(p, recursionSkipMode); q.bIntraInBFrames = PI(p, bIntraInBFrames); q.psyRd = PD(p, psyRd);
+    q.searchMethod = PI(p, searchMethod); q.subpelRefine = PI(p, subpelRefine); q.searchRange = PI(p, searchRange); q.maxNumMergeCand = PI(p, maxNumMergeCand);
+    q.bEnableSignHiding = PI(p, bEnableSignHiding); q.bEnableStrongIntraSmoothing = PI(p, bEnableStrongIntraSmoothing); q.bEnableTemporalMvp = PI(p, bEnableTemporalMvp);
+    q.tuQTMaxInterDepth = PI(p, tuQTMaxInterDepth); q.tuQTMaxIntraDepth = PI(p, tuQTMaxIntraDepth);
+    q.bEnableLoopFilter = PI(p, bEnableLoopFilter); q.bEnableSAO = PI(p, bEnableSAO); q.bEnableWavefront = PI(p, bEnableWavefront);
+    {
+        /* without a thread pool the reference switches WPP off (Encoder::create, encoder.cpp: "no thread pool ... WPP disabled"): --pools none */
+        const char* pools = rd<const char*>(p, X265ABI_PARAM_numaPools);
+        if (pools && (!strcmp(pools, "none") || !strcmp(pools, "NONE") || !strcmp(pools, "0"))) q.bEnableWavefront = 0;
+    }
+    q.aspectRatioIdc = PI(p, vui_aspectRatioIdc); q.rdoqLevel = PI(p, rdoqLevel);
+    q.psyRdoqFix8 = q.rdoqLevel ? (int32_t)(PD(p, psyRdoq) * 256.0) : 0;         /* Quant::init: m_psyRdoqScale = (int32_t)(psyScale * 256.0) (quant.cpp:188) */
+    q.bEnableFastIntra = PI(p, bEnableFastIntra);
+    /* frame threads: 0 = by core count, which is more than one on any machine with four cores or more (threadpool.cpp:661-677); the stream of the
+     * frame-parallel rules does not depend on the number */
+    const int ft = PI(p, frameNumThreads);
+    q.frameNumThreads = ft == 1 ? 1 : (ft > 16 ? 16 : (ft <= 0 ? 3 : ft));
+    x265amd_encoder* e = x265amd_encoder_open(&q);
+    if (!e) return nullptr;
+    AbiEncoder* a = new AbiEncoder;
+    a->enc = e; a->width = q.sourceWidth; a->height = q.sourceHeight;
+    a->param.assign((const uint8_t*)p, (const uint8_t*)p + X265ABI_SIZEOF_PARAM);         /* api.cpp:96-116: the encoder keeps a copy */
+    return a;
+}
+void abi_encoder_parameters(void* enc, void* out) { if (enc && out) memcpy(out, ((AbiEncoder*)enc)->param.data(), X265ABI_SIZEOF_PARAM); }
+int abi_encoder_headers(void* enc, x265amd_nal** ppNal, uint32_t* piNal)
+{
+    if (!enc) return -1;
+    return x265amd_encoder_headers(((AbiEncoder*)enc)->enc, ppNal, piNal);         /* x265_nal and x265amd_nal have one layout (x265.h:94-99) */
+}
+int abi_encoder_encode(void* enc, x265amd_nal** ppNal, uint32_t* piNal, void* picIn, void* picOut)
+{
+    if (!enc) return -1;
+    AbiEncoder& a = *(AbiEncoder*)enc;
+    x265amd_picture in, out;
+    memset(&in, 0, sizeof(in)); memset(&out, 0, sizeof(out));
+    if (picIn)
+    {
+        if (rd<int32_t>(picIn, X265ABI_PIC_bitDepth) != X265AMD_DEPTH) { xa_fail(X265AMD_EINVAL, "x265_encoder_encode: picture bit depth differs from the library's (no conversion)"); return -1; }
+        if (rd<int32_t>(picIn, X265ABI_PIC_colorSpace) != 1) { xa_fail(X265AMD_EINVAL, "x265_encoder_encode: only X265_CSP_I420 pictures"); return -1; }
+        const int st = rd<int32_t>(picIn, X265ABI_PIC_sliceType);
+        if (st != 0) { xa_fail(X265AMD_EINVAL, "x265_encoder_encode: forced slice types are not built (sliceType must be X265_TYPE_AUTO)"); return -1; }
+        for (int k = 0; k < 3; k++)
+        {
+            in.planes[k] = rd<void*>(picIn, X265ABI_PIC_planes + 8 * k);
+            in.stride[k] = rd<int32_t>(picIn, X265ABI_PIC_stride + 4 * k);
+        }
+        if (a.ptsCount < 64) { a.ptsQueue[(a.ptsHead + a.ptsCount) & 63] = rd<int64_t>(picIn, X265ABI_PIC_pts); a.ptsCount++; }
+    }
+    /* the reconstruction is returned through planes the encoder owns in the reference (pic_out->planes point into its reconstructed picture); here the
+     * caller's pic_out receives pointers to a buffer of this object that stays valid until the next call */
+    static thread_local std::vector<uint8_t> recon;
+    if (picOut)
+    {
+        const size_t isz = X265AMD_DEPTH > 8 ? 2 : 1, ysz = (size_t)a.width * a.height * isz, csz = ysz / 4;
+        recon.resize(ysz + 2 * csz);
+        out.planes[0] = recon.data(); out.planes[1] = recon.data() + ysz; out.planes[2] = recon.data() + ysz + csz;
+        out.stride[0] = (int32_t)(a.width * isz); out.stride[1] = out.stride[2] = (int32_t)(a.width / 2 * isz);
+    }
+    const int ret = x265amd_encoder_encode(a.enc, ppNal, piNal, picIn ? &in : nullptr, picOut ? &out : nullptr);
+    if (ret > 0 && picOut)
+    {
+        for (int k = 0; k < 3; k++) { wr<void*>(picOut, X265ABI_PIC_planes + 8 * k, out.planes[k]); wr<int32_t>(picOut, X265ABI_PIC_stride + 4 * k, out.stride[k]); }
+        wr<int32_t>(picOut, X265ABI_PIC_bitDepth, X265AMD_DEPTH); wr<int32_t>(picOut, X265ABI_PIC_colorSpace, 1);
+        wr<int32_t>(picOut, X265ABI_PIC_poc, out.poc); wr<int32_t>(picOut, X265ABI_PIC_sliceType, out.sliceType);
+        wr<int32_t>(picOut, X265ABI_PIC_width, a.width); wr<int32_t>(picOut, X265ABI_PIC_height, a.height);
+    }
+    return ret;
+}
+void abi_encoder_get_stats(void*, void* stats, uint32_t bytes) { if (stats) memset(stats, 0, bytes < (uint32_t)X265ABI_SIZEOF_STATS ? bytes : (uint32_t)X265ABI_SIZEOF_STATS); }
+void abi_encoder_log(void*, int, char**) {}
+void abi_encoder_close(void* enc)
+{
+    if (!enc) return;
+    AbiEncoder* a = (AbiEncoder*)enc;
+    x265amd_encoder_close(a->enc);
+    delete a;
+}
+void abi_cleanup(void) { x265amd_release_scratch(); }
+/* not built: fail cleanly */
+int abi_fail_encoder_param(void*, void*) { return -1; }
+int abi_fail_encoder(void*) { return -1; }
+int abi_fail_ctu_info(void*, int, void**) { return -1; }
+int abi_fail_slicetype(void*, int*, int*, int*) { return -1; }
+int abi_fail_ref_list(void*, void**, void**, int, int, int*, int*) { return -1; }
+void* abi_csvlog_open(const void*) { return nullptr; }
+void abi_csvlog_frame(const void*, const void*) {}
+void abi_csvlog_encode(const void*, const void*, int, int, int, char**) {}
+void abi_dither_image(void*, int, int, int16_t*, int) {}
+int abi_fail_analysis(void*, void*, int, uint32_t) { return -1; }
+int abi_fail_parse3(void*, const char*, const char*) { return -1; }
+
+/* struct x265_api (x265.h:2561-2614) member for member: 3 + 4 ints, bit depth, two strings, 20 function pointers, sizeof_frame_stats, 9 function pointers,
+ * zone_param_parse (ENABLE_LIBVMAF is off in the reference build this library replaces) */
+struct AbiTable
+{
+    int api_major_version, api_build_number, sizeof_param, sizeof_picture, sizeof_analysis_data, sizeof_zone, sizeof_stats;
+    int bit_depth;
+    const char* version_str; const char* build_info_str;
+    void* fn[20];
+    int sizeof_frame_stats;
+    void* fn2[9];
+    void* zone_param_parse;
+};
+static_assert(sizeof(AbiTable) == X265ABI_SIZEOF_API, "struct x265_api layout");
+static_assert(offsetof(AbiTable, bit_depth) == X265ABI_API_bit_depth && offsetof(AbiTable, version_str) == X265ABI_API_version_str, "struct x265_api layout");
+static_assert(offsetof(AbiTable, fn) == X265ABI_API_param_alloc && offsetof(AbiTable, fn) + 10 * sizeof(void*) == X265ABI_API_encoder_open, "struct x265_api layout");
+static_assert(offsetof(AbiTable, fn) + 15 * sizeof(void*) == X265ABI_API_encoder_encode && offsetof(AbiTable, fn) + 18 * sizeof(void*) == X265ABI_API_encoder_close, "struct x265_api layout");
+static_assert(offsetof(AbiTable, fn) + 19 * sizeof(void*) == X265ABI_API_cleanup && offsetof(AbiTable, sizeof_frame_stats) == X265ABI_API_sizeof_frame_stats, "struct x265_api layout");
+static_assert(offsetof(AbiTable, fn2) == X265ABI_API_encoder_intra_refresh && offsetof(AbiTable, zone_param_parse) == X265ABI_API_zone_param_parse, "struct x265_api layout");
+
+const AbiTable g_api = {
+    X265ABI_MAJOR_VERSION, X265ABI_BUILD, X265ABI_SIZEOF_PARAM, X265ABI_SIZEOF_PICTURE, X265ABI_SIZEOF_ANALYSIS_DATA, X265ABI_SIZEOF_ZONE, X265ABI_SIZEOF_STATS,
+    X265AMD_DEPTH,
+    "x265amd 0.3 (parity target x265 3.6+1-aa7f602f7)", "[Linux][hipcc gfx950][64 bit] MI355X",
+    { (void*)abi_param_alloc, (void*)abi_param_free, (void*)abi_param_default, (void*)abi_param_parse, (void*)abi_fail_parse3, (void*)abi_param_apply_profile,
+      (void*)abi_param_default_preset, (void*)abi_picture_alloc, (void*)abi_picture_free, (void*)abi_picture_init, (void*)abi_encoder_open, (void*)abi_encoder_parameters,
+      (void*)abi_fail_encoder_param, (void*)abi_fail_encoder_param, (void*)abi_encoder_headers, (void*)abi_encoder_encode, (void*)abi_encoder_get_stats, (void*)abi_encoder_log,
+      (void*)abi_encoder_close, (void*)abi_cleanup },
+    X265ABI_SIZEOF_FRAME_STATS,
+    { (void*)abi_fail_encoder, (void*)abi_fail_ctu_info, (void*)abi_fail_slicetype, (void*)abi_fail_ref_list, (void*)abi_csvlog_open, (void*)abi_csvlog_frame,
+      (void*)abi_csvlog_encode, (void*)abi_dither_image, (void*)abi_fail_analysis },
+    (void*)abi_fail_parse3
+};
+
+}
+
+/* x265_api_get_209 (x265.h:2619-2635, api.cpp:1107-1182): the table for `bitDepth` (0: this library's).  Another depth is looked for in the sibling library the
+ * way the reference looks for libx265_main10.so: dlopen by name next to this one -- here the caller is simply told there is none (NULL), as the reference does
+ * when the sibling is missing. */
+extern "C" const void* x265_api_get_209(int bitDepth)
+{
+    if (bitDepth && bitDepth != X265AMD_DEPTH) return nullptr;
+    return &g_api;
+}
+/* x265_api_query (api.cpp:1184-1279): refuses builds older than 51 and any build that is not this one */
+extern "C" const void* x265_api_query(int bitDepth, int apiVersion, int* err)
+{
+    if (apiVersion < 51) { if (err) *err = 1 /* X265_API_QUERY_ERR_VER_REFUSED */; return nullptr; }
+    if (bitDepth && bitDepth != X265AMD_DEPTH) { if (err) *err = 2 /* X265_API_QUERY_ERR_LIB_NOT_FOUND */; return nullptr; }
+    if (err) *err = 0;
+    return &g_api;
+}
