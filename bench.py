@@ -44,10 +44,11 @@ BFRAMES, REFS, QP = 4, 3, 30
 
 # x265amd_param fields that differ from x265amd_param_default, and the same settings on the reference's command line
 # frameNumThreads > 1: the reference's frame-parallel rules, i.e. what its default (--frame-threads 0 = by core count) gives on any machine with four cores or more
-ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5)
+ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5,
+               scenecutThreshold=40, lookaheadDepth=20)
 REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "0",
-           "--no-b-pyramid", "--no-scenecut", "--rd", "3", "--sao", "--wpp", "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", str(REFS), "--max-merge", "3",
-           "--no-info", "--no-open-gop", "--rc-lookahead", "5", "--lookahead-slices", "0"]
+           "--no-b-pyramid", "--scenecut", "40", "--rd", "3", "--sao", "--wpp", "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", str(REFS), "--max-merge", "3",
+           "--no-info", "--no-open-gop", "--rc-lookahead", "20", "--lookahead-slices", "0"]
 
 
 def bench_clip(first, count, gop=0):
@@ -303,8 +304,8 @@ def main():
                                          "bit_exact_vs_reference_encoder": None if ref60 is None else bool(ref60["default"]["stream"] == stream60),
                                          "cpu_baseline": None if ref60 is None else {"value": 60 / ref60["default"]["seconds"], "cores": ref60["cores"], "kind": "reference",
                                                                                      "says": ref60["default"]["says"], "frame_threads_1": 60 / ref60["f1"]["seconds"]},
-                                         "note": "the same clip generator and options over 60 frames: the noise field is re-seeded at frames 24 and 48 (no scene-cut detection on either side: "
-                                                 "those pictures are coded as P / B pictures whose CUs end up intra coded)"}
+                                         "note": "the same clip generator and options over 60 frames: the noise field is re-seeded at frames 24 and 48; both encoders run "
+                                                 "scene-cut detection (--scenecut 40, --rc-lookahead 20) and place an I picture at 24 (min-keyint not reached) and an IDR picture at 48"}
             del frames60, stream60
         except Exception as exc:       # the bench line stands on its own
             line["scene_change_clip"] = {"error": repr(exc)}

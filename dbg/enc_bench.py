@@ -14,3 +14,5 @@ stream, dt = bench.encode(T, L, frames, 0, 0, sync)
 print("frames", N, "seconds %.3f" % dt, "fps %.2f" % (N / dt), "bytes", len(stream), hashlib.md5(stream).hexdigest())
 if os.environ.get("X265AMD_QUEUE_PROF"):
     L.lib.x265amd_queue_profile_report()
+if os.environ.get("X265AMD_HOSTPROF"):
+    L.lib.x265amd_hostprof_report()

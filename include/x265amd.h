@@ -401,6 +401,22 @@ int x265amd_coeff_bits(void* stream, const x265amd_coeff_bits_job* d_jobs, int n
  * the lanes lay out from the levels which bins every context codes, then one lane per context walks its own bins -- instead of one lane coding all of them in
  * turn.  Same bits, same adapted contexts.  The form the fused intra steps use on the device (csrc/entropy_dev.h) */
 int x265amd_coeff_bits_wave(void* stream, const x265amd_coeff_bits_job* d_jobs, int n, uint64_t* d_bits);
+/* The bits of a whole INTRA CU, a wavefront per CU (csrc/intra_cu_dev.h): what Search::checkIntra / encodeIntraInInter count once the CU's modes and levels are
+ * decided (search.cpp:1236-1287, :1454-1507: skip flag + pred mode in P / B slices, codePartSize, codePredInfo, codeCoeff with the coded block flags and the
+ * coefficients of every unit), for one transform unit per CU (8x8 .. 32x32) or the 8x8 CU coded NxN; 4:2:0, no delta QP / transform skip.  The piece that lets a CU's
+ * decision, and the contexts the next CU starts from, be made on the device.  lev_*: device addresses of the units' levels. */
+typedef struct x265amd_intra_cu_bits_job
+{
+    uint8_t ctx[X265AMD_CTX_STRIDE];        /* the CU's start contexts */
+    uint64_t frac_bits;                     /* the coder's fraction at the CU's start (only its low 15 bits count: resetBits) */
+    uint8_t log2_cu, nxn, code_part_size, inter_slice, skip_ctx, sign_hide, chroma_dir, cbf_u, cbf_v;
+    uint8_t subdiv_flag;                    /* one unit, and the tree could have split (tu-intra-depth > 1): the subdivision flag (0) is coded */
+    uint8_t reserved[2];
+    uint8_t luma_dir[4], cbf_y[4], preds[4][3];
+    uint64_t lev_y[4], lev_u, lev_v;
+} x265amd_intra_cu_bits_job;
+typedef struct x265amd_intra_cu_bits_out { uint8_t ctx[X265AMD_CTX_STRIDE]; uint64_t frac_bits, mv_frac, skip_frac; } x265amd_intra_cu_bits_out;
+int x265amd_intra_cu_bits(void* stream, const x265amd_intra_cu_bits_job* d_jobs, int n, x265amd_intra_cu_bits_out* d_out);
 /* host-pointer forms (parity surface) */
 void x265amd_est_bit_host(const uint8_t* ctx, int log2TrSize, int isLuma, int32_t* est);
 uint64_t x265amd_code_coeff_bits(const int16_t* coeff, int log2TrSize, int ttype, int bIntra, int dirMode, int signHide, uint8_t* ctx);
@@ -663,6 +679,11 @@ typedef struct x265amd_inter_search_params
     int32_t lazy_sync;                                      /* device job queues only, non-zero: the call returns with the final predictions enqueued, not finished -- the
                                                              * decisions are final, and the caller's next command on the queue (the measurement of the prediction tile) is
                                                              * ordered behind them.  0 (every public caller): the call returns with everything done */
+    int32_t lowres_blocks_in_row;                           /* Lowres::maxBlocksInRow of the fields below */
+    uint64_t lowres_mvs[2][16];                             /* HOST address of the lookahead's motion field of the current picture towards reference r of list l
+                                                             * (Lowres::lowresMvs[l][|poc - refPoc|], int16_t[blocks][2], lowres full-pel x 4 as the lookahead keeps
+                                                             * them), or 0 where the lookahead has not searched that distance: Search::getLowresMV
+                                                             * (search.cpp:1968-1989), one more search candidate per PU when it is not zero (:2102-2107, :2413-2418) */
 } x265amd_inter_search_params;
 typedef struct x265amd_inter_cu { int16_t x, y; uint8_t log2_size, part_size; uint8_t reserved[2]; } x265amd_inter_cu;
 typedef struct x265amd_pu_result

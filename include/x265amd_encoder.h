@@ -53,7 +53,13 @@ typedef struct x265amd_param
                                              * candidates beyond are left out (search.cpp:1934, :2009; analysis.cpp:2803, :2933), SAO is never switched off from
                                              * picture to picture (sao.cpp:264).  The stream is the same for every value > 1; the number of pictures in flight is the
                                              * library's own choice (X265AMD_FRAME_THREADS) */
-    int32_t reserved[2];
+    int32_t scenecutThreshold;              /* param.scenecutThreshold (--scenecut; the preset's 40): 0 = no scene-cut detection.  > 0: the lookahead's scene-cut decision
+                                             * (Lookahead::slicetypeAnalyse / scenecut / scenecutInternal, slicetype.cpp:2603-3047, with bFrameAdaptive 0) on the
+                                             * lowres cost estimates (x265amd_lowres_*): a scene change becomes an I picture (IDR when keyframeMin pictures have passed
+                                             * since the last keyframe), the picture before it P.  scenecutBias is the reference's default (5) */
+    int32_t lookaheadDepth;                 /* param.lookaheadDepth (--rc-lookahead): pictures the slice-type decision looks at (only read when scenecutThreshold > 0) */
+    int32_t keyframeMin;                    /* param.keyframeMin (--min-keyint); 0 = the reference's default min(fps, keyframeMax / 10) (encoder.cpp:3658-3663) */
+    int32_t reserved;
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -1963,7 +1963,9 @@ def inter_search_run_ref(R, c):
 
 
 INTER_CU_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("log2", "u1"), ("part", "u1"), ("reserved", "u1", 2)])
-INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16)), ("frame_parallel", "<i4"), ("lazy_sync", "<i4")])
+INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16)), ("frame_parallel", "<i4"), ("lazy_sync", "<i4"),
+                        ("lowres_blocks_in_row", "<i4"), ("lowres_mvs", "<u8", (2, 16))])
+assert INTER_SP_DT.itemsize == 416
 
 
 def inter_search_run_hip(L, me, c):
@@ -3017,7 +3019,8 @@ class EncParam(C.Structure):
                 ("searchMethod", C.c_int32), ("subpelRefine", C.c_int32), ("searchRange", C.c_int32), ("maxNumMergeCand", C.c_int32),
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
-                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
+                ("keyframeMin", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EncNal(C.Structure):
@@ -3211,6 +3214,71 @@ FULL_CASES = {
 def full_case_frames(tag):
     (w, h), n, depth, cfg_id, _, _ = FULL_CASES[tag]
     return survey_clip(w, h, depth, cfg_id, 0, n)
+
+
+# ---- scene-cut detection of the lookahead (x265amd_param.scenecutThreshold): clips whose content changes at given frames ----
+def scene_clip(w, h, nframes, cuts, depth=8):
+    """display-order (Y, U, V) planes: smooth integer gradients plus a noise field that moves with them (2 samples right, 1 down per frame); from every frame number
+    in `cuts` on the gradients take other periods / phases and the noise field is a new one -- what the lookahead's cost estimates see as a scene change"""
+    def tri(a, period):
+        a = a % period
+        return np.minimum(a, period - a)
+    sc8 = 1 << (depth - 8)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    frames = []
+    for t in range(nframes):
+        scene = sum(1 for c in cuts if t >= c)
+        noise = np.random.default_rng(w * 1000003 + h * 1009 + 7919 * scene).integers(-10, 11, (h + 64, w + 128))
+        px, py = 160 + 96 * (scene % 3), 128 + 64 * ((scene + 1) % 3)
+        v = np.arange(h, dtype=np.int64)[:, None] + t + 37 * scene
+        u = np.arange(w, dtype=np.int64)[None, :] + 2 * t + 91 * scene
+        luma = 50 + 40 * (scene % 2) + (tri(u, px) * 90) // (px // 2) + (tri(v, py) * 60) // (py // 2) + noise[t:t + h, 2 * t:2 * t + w]
+        vc = np.arange(h // 2, dtype=np.int64)[:, None] + t // 2
+        uc = np.arange(w // 2, dtype=np.int64)[None, :] + t
+        cb = 96 + 20 * (scene % 2) + (tri(uc, 320) * 48) // 160 + (tri(vc, 224) * 16) // 112
+        cr = 150 - 25 * (scene % 2) - (tri(uc + 100, 360) * 40) // 180 + (tri(vc + 50, 256) * 16) // 128
+        frames.append([np.clip(luma * sc8, 0, pmax).astype(dt), np.clip(cb * sc8, 0, pmax).astype(dt), np.clip(cr * sc8, 0, pmax).astype(dt)])
+    return frames
+
+
+SC_CLI = ["--preset", "medium", "--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--scenecut", "40", "--keyint", "250", "--rd", "3",
+          "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", "3", "--max-merge", "3", "--no-info", "--no-open-gop", "--lookahead-slices", "0", "--no-b-pyramid", "--sao", "--wpp",
+          "--pools", "4", "--frame-threads", "3"]
+SC_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3, scenecutThreshold=40)
+# tag -> ((w, h), frames, depth, scene changes, x265amd_param fields, the reference's command line behind SC_CLI)
+SC_CASES = {
+    "sc_i/": ((320, 192), 16, 8, [7], dict(SC_BASE, bframes=4, lookaheadDepth=5), ["--bframes", "4", "--rc-lookahead", "5"]),                    # a cut inside a mini-GOP: non-IDR I picture (min-keyint not reached)
+    "sc_idr/": ((320, 192), 16, 8, [6, 12], dict(SC_BASE, bframes=3, lookaheadDepth=8, keyframeMin=4), ["--bframes", "3", "--rc-lookahead", "8", "--min-keyint", "4"]),
+    "sc_p/": ((320, 192), 14, 8, [5], dict(SC_BASE, bframes=0, lookaheadDepth=4), ["--bframes", "0", "--rc-lookahead", "4"]),
+    "sc_none/": ((320, 192), 12, 8, [], dict(SC_BASE, bframes=4, lookaheadDepth=20), ["--bframes", "4", "--rc-lookahead", "20"]),                 # no cut: the decision must not invent one
+    "sc_hbd/": ((320, 192), 12, 10, [5], dict(SC_BASE, bframes=2, lookaheadDepth=5), ["--bframes", "2", "--rc-lookahead", "5"]),
+    "sc_flash/": ((320, 192), 16, 8, [6, 7], dict(SC_BASE, bframes=4, lookaheadDepth=10), ["--bframes", "4", "--rc-lookahead", "10"]),            # a one-frame flash
+}
+
+
+def stream_diff(got, want):
+    """where two Annex-B streams part: '' when equal, else the NAL (index, type, size) and the byte inside it"""
+    got, want = bytes(bytearray(got)), bytes(bytearray(want))
+    if got == want:
+        return ""
+    n = min(len(got), len(want))
+    at = next((i for i in range(n) if got[i] != want[i]), n)
+    starts, i = [], 0
+    while True:
+        i = want.find(b"\x00\x00\x01", i)
+        if i < 0:
+            break
+        starts.append(i + 3); i += 3
+    k = max([j for j, s_ in enumerate(starts) if s_ <= at] or [0])
+    end = (starts[k + 1] - 3) if k + 1 < len(starts) else len(want)
+    return "lengths %d / %d; first difference at byte %d: NAL %d of %d (type %d, %d bytes), byte %d of it: got %s want %s" % (
+        len(got), len(want), at, k, len(starts), (want[starts[k]] >> 1) & 63, end - starts[k], at - starts[k], got[at:at + 8].hex(), want[at:at + 8].hex())
+
+
+def scene_case_frames(tag):
+    (w, h), n, depth, cuts, _, _ = SC_CASES[tag]
+    return scene_clip(w, h, n, cuts, depth)
 
 
 # ---- lookahead lowres pipeline (x265amd_lowres_init / x265amd_lowres_intra_costs vs Lowres::init / LookaheadTLD::lowresIntraEstimate) ----

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 168 and T.EncParam.frameNumThreads.offset == 156 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -224,3 +224,30 @@ def test_gop_sharded_encode_one_rank():
     stream = gs.encode_sharded(len(frames), 4, encode_gop, lambda: T.frame_stream_headers(L, bframes=2, deblock=True).tobytes())
     want = g["keyint/stream"]
     assert len(stream) == len(want) and hashlib.md5(stream).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+
+
+SC_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_sc_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.SC_CASES))
+def test_scene_cut_detection(tag):
+    """x265amd_param.scenecutThreshold > 0: the lookahead's slice-type decision with scene-cut detection (Lookahead::slicetypeDecide / slicetypeAnalyse / scenecut /
+    scenecutInternal, slicetype.cpp:1802-3047, with --b-adapt 0) on the lowres cost estimates: the reference encoder's stream for clips with scene changes -- an I
+    picture that is no keyframe (min-keyint not reached), IDR pictures (--min-keyint 4), a one-frame flash, no B frames (where the reference never detects a cut),
+    no cut at all, 10-bit.  Golden data: tests/golden/make_golden.py sc."""
+    g = np.load(SC_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.SC_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.scene_case_frames(tag), w, h, **cfg)
+    want_types = [str(t) for t in g[tag + "types"]]
+    names = {1: "I", 2: "i", 3: "P", 5: "b"}
+    got_types, idr = [], 0
+    for (poc, st, _, _) in coded:
+        if st == 1:
+            idr = poc
+        got_types.append("%d:%s" % (poc - idr, names[st]))
+    assert got_types == want_types, "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])

@@ -43,7 +43,8 @@ def test_hip_intra_in_inter_matches_reference_golden():
 
 # ---- Search::checkIntra: (depth, seed, slice type (2 I, 1 P, 0 B), psy-rd, strong intra smoothing) ----
 CHECK_CASES = [(8, 701, 2, 2.0, 1), (8, 702, 2, 0.0, 1), (10, 703, 2, 2.0, 0), (8, 704, 1, 2.0, 1), (10, 705, 2, 1.0, 1), (8, 706, 2, 2.0, 1),
-               (8, 707, 2, 2.0, 1, 4), (8, 708, 1, 0.0, 1, 4), (10, 709, 2, 2.0, 1, 4)]           # 6th field: tu-intra-depth 4 (three levels of transform splits)
+               (8, 707, 2, 2.0, 1, 4), (8, 708, 1, 0.0, 1, 4), (10, 709, 2, 2.0, 1, 4),           # 6th field: tu-intra-depth 4 (three levels of transform splits)
+               (8, 711, 1, 2.0, 1), (8, 722, 0, 2.0, 1)]                                           # P / B slices without delta QP (tests/test_intra_cu_bits.py)
 CHECK_GOLD_PATH = os.path.join(T.GOLDEN_DIR, "check_intra_golden.npz")
 
 

@@ -50,7 +50,7 @@ def test_api_table(depth):
 
 
 def test_encoder_open_names_what_it_rejects():
-    """param_default gives the reference's defaults (CRF, b-adapt 2, scenecut 40 ...): outside the built subset, and encoder_open says which member"""
+    """param_default gives the reference's defaults (CRF, b-adapt 2, lookahead slices, B pyramid ...): outside the built subset, and encoder_open says which member"""
     lib = table(8)
     api = lib.x265_api_get_209(8).contents
     alloc = C.CFUNCTYPE(C.c_void_p)(api.fn[0]); free = C.CFUNCTYPE(None, C.c_void_p)(api.fn[1]); default = C.CFUNCTYPE(None, C.c_void_p)(api.fn[2])
@@ -68,7 +68,9 @@ def test_encoder_open_names_what_it_rejects():
     buf[LAYOUT["PARAM_rc_rateControlMode"]] = 1
     assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_bFrameAdaptive"]] = 0
-    assert not opn(p) and b"scenecutThreshold" in lib.x265amd_last_error()
+    assert not opn(p) and b"lookaheadSlices" in lib.x265amd_last_error()       # scene-cut detection itself is built; its cost estimates in slices are not
+    buf[LAYOUT["PARAM_lookaheadSlices"]] = 0
+    assert not opn(p) and b"bBPyramid" in lib.x265amd_last_error()
     free(p)
 
 

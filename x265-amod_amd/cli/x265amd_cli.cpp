@@ -5,6 +5,7 @@
  *     x265amd --input clip.y4m -o out.hevc [--recon rec.yuv] [--qp N] [--bframes N] [--keyint N] [--ref N] [--rd 2..6] [--rect] [--amp]
  *             [--limit-modes] [--limit-refs N] [--[no-]early-skip] [--rskip 0|1] [--psy-rd F] [--[no-]b-intra] [--me dia|hex|star] [--subme N]
  *             [--merange N] [--max-merge N] [--rdoq-level N] [--psy-rdoq F] [--[no-]deblock] [--[no-]sao] [--[no-]wpp] [--frames N]
+ *             [--scenecut N | --no-scenecut] [--rc-lookahead N] [--min-keyint N]
  *
  * Like the reference (source/encoder/api.cpp:1107-1182, x265_api_get) the pixel depth selects the library: libx265amd_main.so for 8-bit input,
  * libx265amd_main10.so for 10-bit, loaded with dlopen from the directory of this program's ../lib.  Host C++ only; all device work is the library's. */
@@ -102,7 +103,7 @@ int main(int argc, char** argv)
         else if (a == "--recon" || a == "-r") recon = val();
         else if (a == "--frames" || a == "-f") frames = atoi(val());
         else if (a == "--rect" || a == "--amp" || a == "--limit-modes" || a == "--early-skip" || a == "--no-early-skip" || a == "--b-intra" || a == "--no-b-intra" ||
-                 a == "--deblock" || a == "--no-deblock" || a == "--sao" || a == "--no-sao" || a == "--wpp" || a == "--no-wpp" || a == "--no-rect" || a == "--no-amp" || a == "--fast-intra" || a == "--no-fast-intra")
+                 a == "--deblock" || a == "--no-deblock" || a == "--sao" || a == "--no-sao" || a == "--wpp" || a == "--no-wpp" || a == "--no-rect" || a == "--no-amp" || a == "--fast-intra" || a == "--no-fast-intra" || a == "--no-scenecut")
             opts.push_back({ a, "" });
         else if (a.rfind("--", 0) == 0) opts.push_back({ a, val() });
         else { fprintf(stderr, "x265amd: unknown argument %s\n", a.c_str()); return 2; }
@@ -128,6 +129,10 @@ int main(int argc, char** argv)
         if (k == "--qp") p.qp = atoi(v);
         else if (k == "--bframes") p.bframes = atoi(v);
         else if (k == "--keyint") p.keyframeMax = atoi(v);
+        else if (k == "--min-keyint") p.keyframeMin = atoi(v);
+        else if (k == "--scenecut") p.scenecutThreshold = atoi(v);
+        else if (k == "--no-scenecut") p.scenecutThreshold = 0;
+        else if (k == "--rc-lookahead") p.lookaheadDepth = atoi(v);
         else if (k == "--ref") p.maxNumReferences = atoi(v);
         else if (k == "--rd") p.rdLevel = atoi(v);
         else if (k == "--rect") p.bEnableRectInter = 1;

@@ -19,6 +19,12 @@ __shared__ long long xa_stage_prev;
 #else
 #define XA_STAGE(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_stage_acc[k] += (unsigned long long)(t_ - xa_stage_prev); xa_stage_prev = t_; } } while (0)
 #endif
+/* the fused intra command's stages on a clock of its own (the chains' stamps above do not disturb it): [kind][stage], thread 0 */
+__shared__ unsigned long long xa_nxn_acc[4][10];
+__shared__ long long xa_nxn_prev;
+__shared__ int xa_nxn_kind;
+#define XA_NXN_START(kind) do { if (threadIdx.x == 0) { xa_nxn_kind = (kind); xa_nxn_prev = wall_clock64(); } } while (0)
+#define XA_NXN(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_nxn_acc[xa_nxn_kind][k] += (unsigned long long)(t_ - xa_nxn_prev); xa_nxn_prev = t_; } } while (0)
 #include "tu_dev.h"
 #include "intra_dev.h"
 #include "mc_dev.h"
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid < 32) s_bytes[tid] = 0;
     if (tid == 0) xa_bytes_acc = 0;
     if (tid < 22) xa_stage_acc[tid] = 0;
+    if (tid < 40) (&xa_nxn_acc[0][0])[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
     if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
     __syncthreads();
@@ -580,6 +587,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     __syncthreads();
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid < 32) xa_sys_store(&rh->bytes[tid], rh->bytes[tid] + s_bytes[tid]);
+    if (tid >= 64 && tid < 104) xa_sys_store(&rh->nxn[tid - 64], rh->nxn[tid - 64] + (&xa_nxn_acc[0][0])[tid - 64]);
     if (tid == 32) xa_sys_store(&rh->resident, rh->resident + (unsigned long long)(wall_clock64() - tResident0));
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
 }
@@ -742,6 +750,19 @@ struct Server
                 tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5, tot[54] / 1e5, tot[55] / 1e5);
         fprintf(stderr, "  stages of the NxN step (ms): record + predictors %.1f, scan %.1f, candidate list %.1f, chains %.1f, bits %.1f, choice + blocks + measurements + chroma %.1f\n",
                 tot[56] / 1e5, tot[57] / 1e5, tot[58] / 1e5, tot[59] / 1e5, tot[60] / 1e5, tot[61] / 1e5);
+        {
+            uint64_t nx[40] = { 0 };
+            for (int i = 0; i < numQueues; i++) for (int k = 0; k < 40; k++) nx[k] += hosts[i].nxn[k];
+            static const char* const kinds[4] = { "4 x 4x4", "1 x 8x8", "1 x 16x16", "1 x 32x32" };
+            for (int kd = 0; kd < 4; kd++)
+            {
+                uint64_t t = 0; for (int k = 0; k < 10; k++) t += nx[kd * 10 + k];
+                if (!t) continue;
+                fprintf(stderr, "  intra_nxn %-10s (ms): record %.1f, predictors %.1f, scan %.1f, neighbours -> lds + candidate list %.1f, chains + bits (wave 0) %.1f, waiting for the other waves %.1f, "
+                        "choice %.1f, winner's blocks %.1f, luma measurements %.1f, chroma %.1f\n", kinds[kd], nx[kd * 10] / 1e5, nx[kd * 10 + 1] / 1e5, nx[kd * 10 + 2] / 1e5, nx[kd * 10 + 3] / 1e5,
+                        nx[kd * 10 + 4] / 1e5, nx[kd * 10 + 5] / 1e5, nx[kd * 10 + 6] / 1e5, nx[kd * 10 + 7] / 1e5, nx[kd * 10 + 8] / 1e5, nx[kd * 10 + 9] / 1e5);
+            }
+        }
         static const char* const sized[11] = { "scan / pu 4", "scan / pu 8", "scan / pu 16", "scan / pu 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };
         for (int b = 20; b < 31; b++)

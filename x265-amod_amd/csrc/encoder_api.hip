@@ -31,7 +31,7 @@
 namespace {
 
 typedef x265amd_pixel pixel;
-enum { TYPE_IDR = 1, TYPE_P = 3, TYPE_B = 5 };          /* X265_TYPE_IDR / _P / _B (x265.h:255-261) */
+enum { TYPE_AUTO = 0, TYPE_IDR = 1, TYPE_I = 2, TYPE_P = 3, TYPE_B = 5 };          /* X265_TYPE_* (x265.h:572-577) */
 enum { RD_TILE_ELEMS = 4096 + 2 * 1024 };
 
 struct Pic;
@@ -63,8 +63,14 @@ struct Pic
     std::vector<int> analysedCols;
     std::atomic<bool> failed{ false };
     const pixel* finalPlanes() const { return dFin ? dFin : dRec; }
-    Pic() { memset(refPoc, 0, sizeof(refPoc)); }
-    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
+    /* Lowres (common/lowres.h) as far as the slice-type decision reads it: the four half-resolution planes, the intra costs per 8x8 block, the frame cost
+     * estimates by distance to the reference (costEst[d][0]: P cost against the picture d before; [0][0]: intra), the scene-cut mark */
+    pixel* dLowres = nullptr; int32_t* dIntraCost = nullptr;
+    int64_t costEst[18]; int intraMbs[18];
+    std::vector<int16_t> lowMvs[18];        /* Lowres::lowresMvs[0][d]: the motion field of the P estimate against the picture d before (the encoder's searches take a candidate from it) */
+    bool bScenecut = false, bKeyframe = false;
+    Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; } }
+    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x) { std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x; }
     int published(int row) const { const int v = (int)*finalX[row]; std::atomic_thread_fence(std::memory_order_acquire); return v; }
     void fail()         /* whoever waits for this picture is released */
@@ -114,6 +120,7 @@ struct x265amd_encoder
         if (dSaoParams) (void)hipFree(dSaoParams);
         if (dDbUnits) (void)hipFree(dDbUnits);
         xa_scratch_free(dSaoTmp);
+        if (laStream) (void)hipStreamDestroy(laStream);
     }
     uint64_t planeAddr(const pixel* base, int k) const { return (uint64_t)(uintptr_t)(base + org[k]); }
 
@@ -123,6 +130,19 @@ struct x265amd_encoder
     int prepare(const PicP& pic);
     int runFrame(const PicP& pic, std::shared_future<int> prev);
     int runFrameParallel(const PicP& pic);
+    /* ---- the lookahead (slicetype.cpp): only when param.scenecutThreshold > 0 ---- */
+    bool lookahead = false;
+    int keyframeMin = 1, lowW = 0, lowH = 0, lowCuW = 0, lowCuH = 0, lowBlocks = 0;
+    intptr_t lowStride = 0; size_t lowPlaneElems = 0, lowOrg = 0;
+    PicP lastNonB;                                      /* Lookahead::m_lastNonB */
+    bool isSceneTransition = false;                     /* Lookahead::m_isSceneTransition */
+    hipStream_t laStream = nullptr;
+    int lowresInit(Pic& pic);
+    int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
+    bool scenecutInternal(std::vector<Pic*>& frames, int p0, int p1, bool real, int& rc);
+    bool scenecut(std::vector<Pic*>& frames, int p0, int p1, bool real, int numFrames, int& rc);
+    int slicetypeAnalyse(std::vector<Pic*>& frames);
+    int decideLookahead(bool flush);
     int filterRows(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
     int filterRowsCols(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
 };
@@ -233,6 +253,24 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     e->maxDecPicBuffering = std::min(16, std::max(e->numReorderPics + 2, p->maxNumReferences) + 1);
     if (p->firstFrame < 0) { xa_fail(X265AMD_EINVAL, "encoder_open: firstFrame"); return nullptr; }
     e->frameCount = p->firstFrame; e->lastKeyframe = p->firstFrame - p->keyframeMax; e->lastIDR = p->firstFrame;
+    if (p->scenecutThreshold < 0 || p->scenecutThreshold > 100 || p->lookaheadDepth < 0 || p->lookaheadDepth > 250 || p->keyframeMin < 0 || p->keyframeMin > p->keyframeMax)
+    { xa_fail(X265AMD_EINVAL, "encoder_open: scenecutThreshold outside 0..100, lookaheadDepth outside 0..250 or keyframeMin outside 0..keyframeMax"); return nullptr; }
+    e->lookahead = p->scenecutThreshold > 0;
+    {
+        /* Encoder::configure (encoder.cpp:3658-3663) */
+        int kmin = p->keyframeMin;
+        if (!kmin) { const double fps = (double)p->fpsNum / p->fpsDenom; kmin = std::min((int)fps, p->keyframeMax / 10); }
+        e->keyframeMin = std::max(1, kmin);
+        /* Lowres::create (lowres.cpp:52-110): half size rounded up to whole 8x8 blocks, the picture's margins, stride a multiple of 32 */
+        e->lowCuW = (e->W / 2 + 7) >> 3; e->lowCuH = (e->H / 2 + 7) >> 3;
+        e->lowW = e->lowCuW * 8; e->lowH = e->lowCuH * 8;
+        e->lowBlocks = (e->lowCuW > 2 && e->lowCuH > 2) ? (e->lowCuW - 2) * (e->lowCuH - 2) : e->lowCuW * e->lowCuH;
+        e->lowStride = e->W / 2 + 2 * e->marginX;
+        e->lowStride += (32 - (e->lowStride & 31)) & 31;
+        e->lowPlaneElems = (size_t)(e->lowH + 2 * e->marginY) * e->lowStride;
+        e->lowOrg = (size_t)e->marginY * e->lowStride + e->marginX;
+        if (e->lookahead && hipStreamCreateWithFlags(&e->laStream, hipStreamNonBlocking) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder_open: stream"); return nullptr; }
+    }
     {
         /* pictures whose references are complete are analysed concurrently (B frames of a mini-GOP, the next P): the reference's frame threads, but
          * a picture only starts when its references are final, so the output does not depend on the thread count */
@@ -342,6 +380,231 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic)
         if (hipMemset(pic.dFin, 0, picElems * sizeof(pixel)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
     }
     return 0;
+}
+
+/* ---- the lookahead's slice-type decision with scene-cut detection (param.scenecutThreshold > 0, bFrameAdaptive 0) ----
+ * Lowres::init + LookaheadTLD::lowresIntraEstimate for every picture handed in (lowres.cpp:337-403, slicetype.cpp:715-824): x265amd_lowres_init,
+ * x265amd_lowres_intra_costs; costEst[0][0] = the intra costs of the blocks that are not on the picture's edge. */
+int x265amd_encoder::lowresInit(Pic& pic)
+{
+    if (xa_scratch_alloc((void**)&pic.dLowres, lowPlaneElems * 4 * sizeof(pixel)) != hipSuccess || xa_scratch_alloc((void**)&pic.dIntraCost, (size_t)lowCuW * lowCuH * 4 + (size_t)lowCuW * lowCuH) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+    if (hipMemsetAsync(pic.dLowres, 0, lowPlaneElems * 4 * sizeof(pixel), laStream) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+    pixel* planes[4];
+    for (int k = 0; k < 4; k++) planes[k] = pic.dLowres + (size_t)k * lowPlaneElems + lowOrg;
+    int rc = x265amd_lowres_init(laStream, pic.dSrc + org[0], stride, lowW, lowH, planes, lowStride, marginX, marginY);
+    if (rc != X265AMD_OK) return rc;
+    const int lambda = X265AMD_DEPTH > 8 ? 16 : 1;          /* (int)x265_lambda_tab[X265_LOOKAHEAD_QP], X265_LOOKAHEAD_QP = 12 + 6 * (depth - 8) (common.h:213) */
+    uint8_t* dMode = (uint8_t*)(pic.dIntraCost + (size_t)lowCuW * lowCuH);
+    rc = x265amd_lowres_intra_costs(laStream, planes[0], lowStride, lowCuW, lowCuH, lambda, pic.dIntraCost, dMode);
+    if (rc != X265AMD_OK) return rc;
+    std::vector<int32_t> ic((size_t)lowCuW * lowCuH);
+    if (hipMemcpyAsync(ic.data(), pic.dIntraCost, ic.size() * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder_encode: lowres intra costs");
+    int64_t est = 0;
+    const bool all = lowCuW <= 2 || lowCuH <= 2;
+    for (int y = 0; y < lowCuH; y++)
+        for (int x = 0; x < lowCuW; x++)
+            if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) est += ic[(size_t)y * lowCuW + x];
+    pic.costEst[0] = est;
+    return X265AMD_OK;
+}
+
+/* CostEstimateGroup::singleCost(p0, p1, b = p1) -> estimateFrameCost (slicetype.cpp:3882-4075) for a P candidate `dist` pictures behind its reference: the block
+ * loop is x265amd_lowres_frame_cost (motion search of list 0 included: every (picture, distance) pair is estimated once); costEst / intraMbs are the sums over the
+ * blocks that are not on the picture's edge (estimateCUCost's tail, :4220-4248) */
+int x265amd_encoder::frameCostP(Pic& b, Pic& ref, int dist)
+{
+    if (dist < 1 || dist > 17) return xa_fail(X265AMD_EINVAL, "encoder: lookahead distance");
+    if (b.costEst[dist] >= 0) return X265AMD_OK;
+    const size_t ncu = (size_t)lowCuW * lowCuH;
+    struct Scratch { void* p = nullptr; ~Scratch() { xa_scratch_free(p); } } dMvs, dMvc, dLc, dBc, dProg;
+    if (xa_scratch_alloc(&dMvs.p, ncu * 4) != hipSuccess || xa_scratch_alloc(&dMvc.p, ncu * 4) != hipSuccess || xa_scratch_alloc(&dLc.p, ncu * 2) != hipSuccess ||
+        xa_scratch_alloc(&dBc.p, ncu * 4) != hipSuccess || xa_scratch_alloc(&dProg.p, (size_t)lowCuH * 4) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder: device allocation");
+    const pixel* ref0[4];
+    for (int k = 0; k < 4; k++) ref0[k] = ref.dLowres + (size_t)k * lowPlaneElems + lowOrg;
+    if (hipMemsetAsync(dProg.p, 0, (size_t)lowCuH * 4, laStream) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: memset");
+    int rc = x265amd_lowres_frame_cost(laStream, me, b.dLowres + lowOrg, ref0, nullptr, lowStride, lowCuW, lowCuH, 1, 0, b.dIntraCost, (int16_t*)dMvs.p, (int32_t*)dMvc.p, nullptr, nullptr,
+                                       (uint16_t*)dLc.p, (int32_t*)dBc.p, (int32_t*)dProg.p);
+    if (rc != X265AMD_OK) return rc;
+    std::vector<int32_t> bc(ncu); std::vector<uint16_t> lc(ncu);
+    b.lowMvs[dist].resize(ncu * 2);
+    if (hipMemcpyAsync(bc.data(), dBc.p, ncu * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess || hipMemcpyAsync(lc.data(), dLc.p, ncu * 2, hipMemcpyDeviceToHost, laStream) != hipSuccess ||
+        hipMemcpyAsync(b.lowMvs[dist].data(), dMvs.p, ncu * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess ||
+        hipStreamSynchronize(laStream) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
+    int64_t est = 0; int imb = 0;
+    const bool all = lowCuW <= 2 || lowCuH <= 2;
+    for (int y = 0; y < lowCuH; y++)
+        for (int x = 0; x < lowCuW; x++)
+            if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) { est += bc[(size_t)y * lowCuW + x]; imb += (lc[(size_t)y * lowCuW + x] >> 14) == 0; }
+    b.costEst[dist] = est; b.intraMbs[dist] = imb;
+    return X265AMD_OK;
+}
+
+/* Lookahead::scenecutInternal (slicetype.cpp:3016-3047): float / double arithmetic as written there */
+bool x265amd_encoder::scenecutInternal(std::vector<Pic*>& frames, int p0, int p1, bool real, int& rc)
+{
+    Pic* frame = frames[p1];
+    if (rc == X265AMD_OK) rc = frameCostP(*frame, *frames[p0], p1 - p0);
+    if (rc != X265AMD_OK) return false;
+    const int64_t icost = frame->costEst[0], pcost = frame->costEst[p1 - p0];
+    const int gopSize = (frame->poc - lastKeyframe) % p.keyframeMax;
+    const float threshMax = (float)(p.scenecutThreshold / 100.0);
+    float threshMin = (float)(threshMax * 0.25);
+    double bias = 5.0 / 100;            /* param.scenecutBias: the default, scaled in Encoder::configure (encoder.cpp:3948) */
+    if (real)
+    {
+        if (keyframeMin == p.keyframeMax) threshMin = threshMax;
+        if (gopSize <= keyframeMin / 4) bias = threshMin / 4;
+        else if (gopSize <= keyframeMin) bias = threshMin * gopSize / keyframeMin;
+        else bias = threshMin + (threshMax - threshMin) * (gopSize - keyframeMin) / (p.keyframeMax - keyframeMin);
+    }
+    return pcost >= (1.0 - bias) * icost;
+}
+
+/* Lookahead::scenecut (slicetype.cpp:2921-3014) */
+bool x265amd_encoder::scenecut(std::vector<Pic*>& frames, int p0, int p1, bool real, int numFrames, int& rc)
+{
+    if (real && p.bframes)
+    {
+        const int origmaxp1 = p0 + 1 + p.bframes, maxp1 = std::min(origmaxp1, numFrames);
+        bool fluctuate = false, noScenecuts = false;
+        int64_t avgSatdCost = 0;
+        if (frames[p0]->costEst[p1 - p0] > -1) avgSatdCost = frames[p0]->costEst[p1 - p0];
+        int cnt = 1;
+        for (int cp1 = p1; cp1 <= maxp1; cp1++)
+        {
+            if (!scenecutInternal(frames, p0, cp1, false, rc))
+            {
+                for (int i = cp1; i > p0; i--) { frames[i]->bScenecut = false; noScenecuts = false; }
+            }
+            else if (scenecutInternal(frames, cp1 - 1, cp1, false, rc)) { frames[cp1]->bScenecut = true; noScenecuts = true; }
+            if (rc != X265AMD_OK) return false;
+            avgSatdCost += frames[cp1]->costEst[cp1 - p0];
+            cnt++;
+        }
+        if (noScenecuts)
+        {
+            fluctuate = false;
+            avgSatdCost /= cnt;
+            for (int i = p1; i <= maxp1; i++)
+            {
+                const int64_t curCost = frames[i]->costEst[i - p0], prevCost = frames[i - 1]->costEst[i - 1 - p0];
+                if (fabs((double)(curCost - avgSatdCost)) > 0.1 * avgSatdCost || fabs((double)(curCost - prevCost)) > 0.1 * prevCost)
+                {
+                    fluctuate = true;
+                    if (!isSceneTransition && frames[i]->bScenecut)
+                    {
+                        isSceneTransition = true;
+                        for (int j = i + 1; j <= maxp1; j++) frames[j]->bScenecut = false;
+                        break;
+                    }
+                }
+                frames[i]->bScenecut = false;
+            }
+        }
+        if (!fluctuate && !noScenecuts) isSceneTransition = false;
+    }
+    if (!frames[p1]->bScenecut) return false;
+    return scenecutInternal(frames, p0, p1, real, rc);
+}
+
+/* Lookahead::slicetypeAnalyse(frames, bKeyframe = false) (slicetype.cpp:2603-2919) for bFrameAdaptive 0, closed GOPs, no cuTree / VBV / zones / gop-lookahead:
+ * frames[0] = the last non-B picture, frames[1..] = the undecided pictures of the window */
+int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
+{
+    const int maxSearch = std::min(p.lookaheadDepth, 250);
+    int framecnt = 0;
+    for (; framecnt < maxSearch; framecnt++)
+        if (framecnt + 1 >= (int)frames.size() || frames[framecnt + 1]->type != TYPE_AUTO) break;
+    if (!framecnt) return X265AMD_OK;
+    frames.resize((size_t)framecnt + 1);
+    const int keyFrameLimit = p.keyframeMax + lastKeyframe - frames[0]->poc - 1, keyintLimit = keyFrameLimit;
+    const int origNumFrames = std::min(framecnt, keyintLimit);
+    int numFrames = origNumFrames;
+    if (numFrames == 0) { frames[1]->type = TYPE_I; return X265AMD_OK; }
+    int rc = X265AMD_OK;
+    const bool isScenecut = scenecut(frames, 0, 1, true, origNumFrames, rc);
+    if (rc != X265AMD_OK) return rc;
+    if (isScenecut) { frames[1]->type = TYPE_I; return X265AMD_OK; }
+    int resetStart;
+    if (p.bframes)
+    {
+        const int numBFrames = std::min(numFrames - 1, p.bframes);
+        for (int j = 1; j < numFrames; j++) frames[j]->type = (j % (numBFrames + 1)) ? TYPE_B : TYPE_P;
+        frames[numFrames]->type = TYPE_P;
+        int numAnalyzed = numFrames;
+        /* Check scenecut on the first minigop. */
+        for (int j = 1; j < numBFrames + 1; j++)
+        {
+            const bool cut = scenecut(frames, j, j + 1, false, origNumFrames, rc);
+            if (rc != X265AMD_OK) return rc;
+            if (cut) { frames[j]->type = TYPE_P; numAnalyzed = j; break; }
+        }
+        resetStart = std::min(numBFrames + 2, numAnalyzed + 1);
+    }
+    else
+    {
+        for (int j = 1; j <= numFrames; j++) frames[j]->type = TYPE_P;
+        resetStart = 2;
+    }
+    for (int j = keyintLimit + 1; j <= numFrames; j += p.keyframeMax) { frames[j]->type = TYPE_I; resetStart = std::min(resetStart, j + 1); }
+    const int maxp1 = std::min(p.bframes + 1, origNumFrames);
+    /* Restore frame types for all frames that haven't actually been decided yet. */
+    for (int j = resetStart; j <= numFrames; j++)
+    {
+        frames[j]->type = TYPE_AUTO;
+        if (j <= maxp1 && frames[j]->bScenecut && isSceneTransition) isSceneTransition = false;
+    }
+    return X265AMD_OK;
+}
+
+/* Lookahead::slicetypeDecide (slicetype.cpp:1802-2400) as far as the built subset goes: runs when the input queue holds lookaheadDepth pictures (Lookahead::findJob,
+ * m_fullQueueSize; one picture is enough once the caller flushes), types the next mini-GOP and moves it to `ready` in coding order.  Returns 0, or an error code. */
+int x265amd_encoder::decideLookahead(bool flush)
+{
+    const int fullQueue = flush ? 1 : std::max(1, p.lookaheadDepth);
+    while ((int)input.size() >= fullQueue)
+    {
+        const int maxSearch = std::max(1, std::min(p.lookaheadDepth, 250));
+        std::vector<Pic*> frames;
+        frames.push_back(lastNonB.get());
+        for (int j = 0; j < maxSearch && j < (int)input.size(); j++) frames.push_back(input[j].get());
+        if (lastNonB)
+        {
+            const int rc = slicetypeAnalyse(frames);
+            if (rc != X265AMD_OK) return rc;
+        }
+        const int nlist = std::min((int)input.size(), p.bframes + 2);
+        int b = 0;
+        for (;; b++)
+        {
+            Pic& frm = *input[b];
+            if (frm.poc - lastKeyframe >= p.keyframeMax && (frm.type == TYPE_AUTO || frm.type == TYPE_I)) frm.type = TYPE_IDR;
+            if (frm.type == TYPE_I && frm.poc - lastKeyframe >= keyframeMin) frm.type = TYPE_IDR;         /* closed GOPs: a keyframe is an IDR picture */
+            if (frm.type == TYPE_IDR)
+            {
+                lastKeyframe = frm.poc; frm.bKeyframe = true;
+                if (b > 0) { input[b - 1]->type = TYPE_P; b--; }
+            }
+            Pic& cur = *input[b];          /* (after the step back the tests below see the keyframe in the reference: they do nothing for it; the loop ends at the P picture) */
+            if (&cur == &frm)
+            {
+                if (b == p.bframes || b + 1 >= nlist) { if (frm.type == TYPE_AUTO || frm.type == TYPE_B) frm.type = TYPE_P; }
+                if (frm.type == TYPE_AUTO) frm.type = TYPE_B;
+                else if (frm.type != TYPE_B) break;
+            }
+            else break;
+        }
+        lastNonB = input[b];
+        ready.push_back(input[b]);
+        for (int i = 0; i < b; i++) ready.push_back(input[i]);
+        input.erase(input.begin(), input.begin() + b + 1);
+        first = false;
+    }
+    return X265AMD_OK;
 }
 
 /* Lookahead::slicetypeDecide with bFrameAdaptive 0 and no scenecut (slicetype.cpp:1929-2040): the next mini-GOP, moved to `ready` in coding order */
@@ -472,6 +735,13 @@ static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
     sp.search_method = p.searchMethod; sp.subpel_refine = p.subpelRefine; sp.search_range = p.searchRange; sp.qp = pic.sliceQp; sp.chroma_mc = 1;
     sp.frame_parallel = e.frameParallel;
     memcpy(sp.ref_pic, refPic, sizeof(sp.ref_pic));
+    sp.lowres_blocks_in_row = e.lowCuW;
+    for (int l = 0; l < 2; l++)
+        for (size_t r = 0; r < lists[l].size(); r++)
+        {
+            const int diffPoc = abs(pic.poc - lists[l][r]->poc);
+            if (l == 0 && diffPoc <= p.bframes + 1 && diffPoc < 18 && !pic.lowMvs[diffPoc].empty()) sp.lowres_mvs[l][r] = (uint64_t)(uintptr_t)pic.lowMvs[diffPoc].data();
+        }
 
     x265amd_slice_info& si = c.si;
     memset(&si, 0, sizeof(si));
@@ -1054,11 +1324,13 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     {
         PicP pic(new Pic);
         pic->poc = e->frameCount++;
-        const int rc = e->uploadPicture(picIn, *pic);
+        int rc = e->uploadPicture(picIn, *pic);
         if (rc) return -1;
+        if (e->lookahead && (rc = e->lowresInit(*pic)) != X265AMD_OK) return -1;
         e->input.push_back(pic);
     }
-    e->decideMiniGop(picIn == nullptr);
+    if (e->lookahead) { if (e->decideLookahead(picIn == nullptr) != X265AMD_OK) return -1; }
+    else e->decideMiniGop(picIn == nullptr);
     /* start every typed picture: preparation in coding order here, the frame itself as a task */
     while (!e->ready.empty())
     {

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "entropy_dev.h"
+#include "intra_cu_dev.h"
 #include "xa_queue.h"
 
 static const uint8_t h_ctxInit[3][X265AMD_CTX_COUNT] = {      /* [slice type: 0 B, 1 P, 2 I][context] */
@@ -94,9 +95,52 @@ __global__ __launch_bounds__(64 * CB4_WAVES) void k_coeff_bits_wave(const x265am
     for (int b = lane; b < X265AMD_CTX_STRIDE; b += 64) reinterpret_cast<uint8_t*>(j.ctx_out)[b] = s_ctx[wv][b];
 }
 
+/* the bits of a whole intra CU (intra_cu_dev.h): a wavefront per CU */
+__global__ __launch_bounds__(64 * CB4_WAVES) void k_intra_cu_bits(const x265amd_intra_cu_bits_job* jobs, int n, x265amd_intra_cu_bits_out* out)
+{
+    __shared__ uint8_t s_ctx[CB4_WAVES][X265AMD_CTX_STRIDE];
+    __shared__ uint32_t s_step[256];
+    __shared__ uint32_t s_enBits[128];
+    __shared__ uint8_t s_enLps[64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_step[i] = en_step.v[i];
+    if (threadIdx.x < 128) s_enBits[threadIdx.x] = en_bits[threadIdx.x];
+    if (threadIdx.x < 64) s_enLps[threadIdx.x] = en_lpsNext[threadIdx.x];
+    __syncthreads();
+    const int ji = blockIdx.x * CB4_WAVES + wv;
+    if (ji >= n) return;
+    const x265amd_intra_cu_bits_job& j = jobs[ji];
+    for (int b = lane; b < X265AMD_CTX_STRIDE; b += 64) s_ctx[wv][b] = j.ctx[b];
+    IntraCuBitsIn in;
+    in.log2_cu = j.log2_cu; in.nxn = j.nxn; in.code_part_size = j.code_part_size; in.inter_slice = j.inter_slice; in.skip_ctx = j.skip_ctx; in.sign_hide = j.sign_hide;
+    in.chroma_dir = j.chroma_dir; in.cbf_u = j.cbf_u; in.cbf_v = j.cbf_v; in.subdiv_flag = j.subdiv_flag;
+    for (int k = 0; k < 4; k++)
+    {
+        in.luma_dir[k] = j.luma_dir[k]; in.cbf_y[k] = j.cbf_y[k]; in.lev_y[k] = reinterpret_cast<const int16_t*>(j.lev_y[k]);
+        for (int i = 0; i < 3; i++) in.preds[k][i] = j.preds[k][i];
+    }
+    in.lev_u = reinterpret_cast<const int16_t*>(j.lev_u); in.lev_v = reinterpret_cast<const int16_t*>(j.lev_v);
+    xa_wave_sync();
+    uint64_t mvf = 0, skipf = 0;
+    const uint64_t frac = wave_intra_cu_bits(in, s_ctx[wv], j.frac_bits, &mvf, &skipf, s_step, EnTabs{ s_enBits, s_enLps }, lane);
+    xa_wave_sync();
+    for (int b = lane; b < X265AMD_CTX_STRIDE; b += 64) out[ji].ctx[b] = s_ctx[wv][b];
+    if (lane == 0) { out[ji].frac_bits = frac; out[ji].mv_frac = mvf; out[ji].skip_frac = skipf; }
+}
+
 /* =========================================================================================================
  * host side
  * ======================================================================================================= */
+extern "C" int x265amd_intra_cu_bits(void* stream, const x265amd_intra_cu_bits_job* d_jobs, int n, x265amd_intra_cu_bits_out* d_out)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!d_jobs || !d_out) return xa_fail(X265AMD_EINVAL, "x265amd_intra_cu_bits: bad arguments");
+    hipLaunchKernelGGL(k_intra_cu_bits, dim3((n + CB4_WAVES - 1) / CB4_WAVES), dim3(64 * CB4_WAVES), 0, (hipStream_t)stream, d_jobs, n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
 extern "C" int x265amd_coeff_bits_wave(void* stream, const x265amd_coeff_bits_job* d_jobs, int n, uint64_t* d_bits)
 {
     if (n <= 0) return X265AMD_OK;

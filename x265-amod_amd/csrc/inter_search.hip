@@ -217,6 +217,14 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                     if (!allowed(w.cu, pidx, list, ref)) continue;
                     XA_HOSTPROF("is.amvp_candidates");
                     w.numMvc[list][ref] = x265amd_amvp_candidates(I, cur, col, c.x, c.y, c.log2_size, c.part_size, pidx, list, ref, w.amvp[list][ref], w.mvc[list][ref]);
+                    if (S->lowres_mvs[list][ref])
+                    {
+                        /* getLowresMV: the lookahead's vector of the 16x16 block under the PU's centre, scaled up */
+                        const int16_t (*lm)[2] = reinterpret_cast<const int16_t (*)[2]>((uintptr_t)S->lowres_mvs[list][ref]);
+                        const size_t idx = (size_t)((w.g.y + w.g.h / 2) >> 4) * S->lowres_blocks_in_row + ((w.g.x + w.g.w / 2) >> 4);
+                        const int16_t lx = (int16_t)(lm[idx][0] * 2), ly = (int16_t)(lm[idx][1] * 2);
+                        if (lx || ly) { int16_t* m = w.mvc[list][ref][w.numMvc[list][ref]++]; m[0] = lx; m[1] = ly; }
+                    }
                     w.mvpJob0[list][ref] = -1;
                     const int16_t (*a)[2] = w.amvp[list][ref];
                     if (!(a[0][0] == a[1][0] && a[0][1] == a[1][1]))

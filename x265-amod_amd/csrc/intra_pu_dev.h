@@ -134,6 +134,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ uint8_t s_winMode[4];
     __shared__ uint32_t s_pickSa8d;
     XA_STAGE(15);
+    XA_NXN_START(0);
     __shared__ x265amd_intra_nxn_job sP;           /* the job record: 896 bytes, indexed by the unit -- in LDS, not in registers */
     static_assert(sizeof(x265amd_intra_nxn_job) % 8 == 0, "job records are sequences of 64-bit words");
     __syncthreads();
@@ -156,6 +157,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     const int maxCand = P.max_cand > 16 ? 16 : P.max_cand;
     const int numUnits = P.num_units ? P.num_units : 4, unitLog2 = P.unit_log2 ? P.unit_log2 : 2, N = 1 << unitLog2;
     const int cbfCtx = CTX_QT_CBF + (numUnits == 1 ? 1 : 0);                               /* C_QT_CBF + !tuDepth */
+    XA_NXN_START(numUnits == 1 ? unitLog2 - 2 : 0);          /* (the record's load goes to kind 0 / stage 0 .. never mind: it is counted below from here) */
+    XA_NXN(0);
     for (int k = 0; k < numUnits; k++)
     {
         const x265amd_intra_tu_job& T = P.tmpl[k];
@@ -170,6 +173,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         else { p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
         XA_STAGE(16);
+        XA_NXN(1);
         {
             x265amd_intra_job sj;
             sj.recon = T.nb; sj.fenc = T.tu.fenc; sj.avail = T.avail; sj.recon_stride = T.nb_stride; sj.fenc_stride = T.tu.fenc_stride;
@@ -178,6 +182,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         __syncthreads();
         XA_STAGE(17);
+        XA_NXN(2);
         {
             const IntraScanLds& sc = *reinterpret_cast<const IntraScanLds*>(smem);
             for (int i = tid; i <= 4 * N; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
@@ -207,6 +212,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         __syncthreads();
         XA_STAGE(18);
+        XA_NXN(3);
         const int n = S.num;
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
         IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
@@ -243,7 +249,9 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             }
         }
         XA_STAGE(20);
+        XA_NXN(4);
         __syncthreads();
+        XA_NXN(5);
         if (tid == 0)
         {
             int w = 0;
@@ -253,6 +261,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             po->mode[k] = S.modes[w]; po->num_cand[k] = (uint8_t)n; po->res[k] = s_res[w];
         }
         __syncthreads();
+        XA_NXN(6);
         {
             /* the winner's blocks: reconstruction into the picture and the layer tile, prediction into the prediction tile; its levels to the host */
             const int w = s_win;
@@ -273,6 +282,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
         }
         XA_STAGE(21);
+        XA_NXN(7);
     }
     /* the CU's luma measurements on the finished 8x8 block: psy energy of the reconstruction, residual energy of the prediction */
     __syncthreads();
@@ -284,6 +294,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         const uint64_t sse = wave_sse_pp(f, T0.tu.fenc_stride, reinterpret_cast<const pixel*>(P.pred_dst[0]), 64, 8, lane);
         if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
     }
+    XA_NXN(8);
     if (!P.do_chroma) return;
     /* ---- estIntraPredChromaQT for the one block per plane (4x4 for an 8x8 CU, N/2 for a larger single unit): a wavefront per mode ---- */
     __shared__ x265amd_tu_result s_cres[5][2];
@@ -367,6 +378,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             clOut[pl * cn2 + i] = lv[i];
         }
     }
+    __syncthreads();
+    XA_NXN(9);
 }
 
 #endif

@@ -59,6 +59,8 @@ struct alignas(128) XaRingHost
                                                    DESIGN.md section 5); always counted, written when the workgroup leaves */
     uint64_t resident;                          /* ticks of the 100 MHz clock between the workgroup's start and its exit, summed over server generations */
     uint64_t pad2[15];
+    uint64_t nxn[40];                           /* X265AMD_QUEUE_PROF: the fused intra command by kind (four 4x4 units / one unit of 8 / 16 / 32) x stage: ticks */
+    uint64_t pad3[8];
 };
 
 struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, second array, results, extra, count) shapes of the job-list kernels */
