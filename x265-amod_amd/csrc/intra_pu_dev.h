@@ -123,6 +123,8 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
     }
 }
 
+#include "intra_nxn4_dev.h"
+
 /* x265amd_intra_nxn (include/x265amd.h): the four 4x4 prediction units of an 8x8 NxN CU, decisions included, by one workgroup. */
 XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_out* po, char* smem, int tid, int nthr)
 {
@@ -141,6 +143,12 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_job) / 8); i += nthr)
         reinterpret_cast<uint64_t*>(&sP)[i] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(pj) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
+    if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture)
+    {
+        /* the NxN CU proper: its own form, nothing but LDS and registers between the first and the last instruction (intra_nxn4_dev.h) */
+        block_intra_nxn4(sP, po, *reinterpret_cast<Nxn4Lds*>(smem), S, tid, nthr);
+        return;
+    }
     /* the estimator's tables beside it: the lanes that count bits look them up bin after bin */
     __shared__ uint32_t s_enBits[128];
     __shared__ uint8_t s_enLps[64];
