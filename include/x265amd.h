@@ -366,7 +366,24 @@ typedef struct x265amd_intra_nxn_job
     uint64_t recon_dst[4];          /* optional (0: none): a third place for the winners' luma reconstruction, stride 64 (the mode's reconstruction tile) */
     uint64_t levels_dst, clevels_dst;   /* one unit larger than 8x8 (unit_log2 4: a 16x16 CU coded 2Nx2N, chroma blocks 8x8): where the winner's luma levels (N x N) and
                                          * the chroma winner's levels (U then V, N/2 x N/2 each) go instead of the result record's arrays; 0: the record */
+    /* ---- the CU as a link of a chain the device runs without the host: the 8x8 CUs of a 16x16 block of an I picture (Analysis::compressIntraCU's four sub-CUs,
+     * analysis.cpp:514-668).  Every CU is two commands queued in advance on two job queues: role 1, this record with four units (the NxN evaluation), and role 2,
+     * one 8x8 unit (2Nx2N).  Role 1 waits for role 2's record, counts both evaluations' bits (x265amd_intra_cu_bits' walk), compares the costs as checkBestMode
+     * does, puts the winner's samples into the picture, writes the CU's result for the host and hands contexts, fraction and luma modes to the next CU through the
+     * chain record.  Neither waits for the host between the CUs. ---- */
+    uint64_t chain;             /* 0: not chained; else the device address of the x265amd_intra_chain record the two workgroups share */
+    uint64_t peer;              /* the x265amd_intra_peer record of this CU: role 2 fills it (its `out` argument is ignored), role 1 waits for it */
+    uint64_t cu_out;            /* role 1: the host-visible x265amd_intra_cu8_result */
+    uint64_t peer_recon[3];     /* role 1: where role 2 leaves its reconstruction (luma, stride 64; U, V, stride 32) */
+    uint64_t win_dst[3];        /* role 1: where the winner's reconstruction goes beside the picture (same strides) */
+    uint64_t chain_token;       /* the chain's count before this CU: the command starts when chain.seq >= chain_token; role 1 leaves chain_token + 1 */
+    uint8_t chain_role;         /* 0 none, 1, 2 */
+    uint8_t chain_first;        /* 1: the first CU of the block -- contexts, fraction and neighbour modes are this record's; 0: the chain's */
+    uint8_t mode_src[4];        /* for left_mode[0], left_mode[1], above_mode[0], above_mode[1]: 0xFF = this record's value, else (CU << 2 | unit) of chain.mode */
+    uint8_t chain_index;        /* this CU's row of chain.mode (0..3) */
+    uint8_t reserved2;
 } x265amd_intra_nxn_job;
+typedef struct x265amd_intra_chain { uint64_t seq, frac; uint8_t ctx[X265AMD_CTX_STRIDE]; uint8_t mode[4][4]; } x265amd_intra_chain;
 typedef struct x265amd_intra_nxn_out
 {
     uint8_t mode[4], num_cand[4]; x265amd_tu_result res[4]; int16_t levels[4][16];
@@ -376,6 +393,19 @@ typedef struct x265amd_intra_nxn_out
     x265amd_tu_result cres[2];
     int16_t clevels[2][16];
 } x265amd_intra_nxn_out;            /* 408 bytes */
+typedef struct x265amd_intra_peer { x265amd_intra_nxn_out out; uint64_t ready; } x265amd_intra_peer;     /* ready = chain_token + 1 when `out` is complete */
+typedef struct x265amd_intra_cu8_result
+{
+    uint64_t rd_cost, frac_bits;        /* of the winner: Mode::rdCost, the coder's fraction behind the CU */
+    uint64_t other_cost;                /* the losing evaluation's cost */
+    uint32_t total_bits, mv_bits, coeff_bits, psy_energy, res_energy, luma_dist, chroma_dist;
+    uint32_t status;                    /* 1: done; 2: gave up waiting for the chain or the peer (the host must fail the picture) */
+    uint8_t part_size;                  /* 0 2Nx2N, 3 NxN */
+    uint8_t chroma_dir;                 /* as CUData stores it: 36 = derived from luma */
+    uint8_t cbf_u, cbf_v, luma_dir[4], cbf_y[4], reserved[4];
+    uint8_t ctx[X265AMD_CTX_STRIDE];    /* the contexts behind the CU */
+    int16_t levels[96];                 /* luma (NxN: unit k at 16 k), then U, V */
+} x265amd_intra_cu8_result;             /* 424 bytes */
 int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_job, x265amd_intra_nxn_out* d_out);
 
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */

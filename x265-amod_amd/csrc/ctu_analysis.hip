@@ -972,7 +972,70 @@ struct Analyzer
             split.predTile = predTile(depth, PRED_SPLIT); split.reconTile = reconTile(depth, PRED_SPLIT);
             const int n4 = 16 >> depth, half = size >> 1, h4n = n4 >> 1;
             const Snap* nextContext = &d.cur;
-            for (int q = 0; q < 4; q++)
+            /* a 16x16 block's four 8x8 CUs: decided on the device one after the other, the host reads the four results (intra_rd.hip: xa_intra_quad8_ws) */
+            bool chained = false;
+            if (log2 == 4 && mightNotSplit && xa_is_queue(st))
+            {
+                x265amd_intra_cu8_result r4[4];
+                const uint64_t tilesN[2] = { tileAddr(predTile(depth + 1, PRED_INTRA_NxN)), tileAddr(reconTile(depth + 1, PRED_INTRA_NxN)) };
+                const uint64_t tiles2[2] = { tileAddr(predTile(depth + 1, PRED_INTRA)), tileAddr(reconTile(depth + 1, PRED_INTRA)) };
+                const int qrc = xa_intra_quad8_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, x, y, qp, d.cur.ctx, d.cur.frac,
+                                                  tileAddr(split.reconTile), tilesN, tiles2, r4, &intraWs);
+                if (qrc < 0) return err = qrc;
+                if (qrc == 0)
+                {
+                    chained = true;
+                    if (const char* lg = getenv("X265AMD_CHAIN_LOG"))
+                    {
+                        int lx = -1, ly = -1;
+                        if (sscanf(lg, "%d,%d", &lx, &ly) == 2 && (lx & ~15) == x && (ly & ~15) == y)
+                            for (int q = 0; q < 4; q++)
+                                fprintf(stderr, "chain (%d,%d) cu %d: part %d dirs %d %d %d %d chroma %d cbf %d%d%d%d %d %d rd %llu other %llu bits %u mv %u dist %u+%u psy %u res %u frac %llu\n", x, y, q,
+                                        r4[q].part_size, r4[q].luma_dir[0], r4[q].luma_dir[1], r4[q].luma_dir[2], r4[q].luma_dir[3], r4[q].chroma_dir, r4[q].cbf_y[0], r4[q].cbf_y[1],
+                                        r4[q].cbf_y[2], r4[q].cbf_y[3], r4[q].cbf_u, r4[q].cbf_v, (unsigned long long)r4[q].rd_cost, (unsigned long long)r4[q].other_cost, r4[q].total_bits,
+                                        r4[q].mv_bits, r4[q].luma_dist, r4[q].chroma_dist, r4[q].psy_energy, r4[q].res_energy, (unsigned long long)r4[q].frac_bits);
+                    }
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const x265amd_intra_cu8_result& r = r4[q];
+                        const int cx = x + (q & 1) * 8, cy = y + (q >> 1) * 8;
+                        const bool nxn = r.part_size != 0;
+                        const bool anyY = r.cbf_y[0] || r.cbf_y[1] || r.cbf_y[2] || r.cbf_y[3];
+                        for (int k = 0; k < 4; k++)
+                        {
+                            x265amd_cu_unit u;
+                            memset(&u, 0, sizeof(u));
+                            u.depth = (uint8_t)(depth + 1); u.pred_mode = X265AMD_MODE_INTRA; u.part_size = r.part_size; u.tu_depth = nxn ? 1 : 0;
+                            u.luma_dir = r.luma_dir[k]; u.chroma_dir = r.chroma_dir; u.qp = (int8_t)qp; u.ref_idx[0] = u.ref_idx[1] = -1;
+                            if (nxn)
+                            {
+                                /* CUData::m_cbf after checkIntra: the unit's own flag one level down, the CU's flag (depth 0) on its first unit only */
+                                u.cbf[0] = (uint8_t)((r.cbf_y[k] ? 2 : 0) | (k == 0 && anyY ? 1 : 0));
+                                u.cbf[1] = (uint8_t)((r.cbf_u ? 2 : 0) | (k == 0 && r.cbf_u ? 1 : 0));
+                                u.cbf[2] = (uint8_t)((r.cbf_v ? 2 : 0) | (k == 0 && r.cbf_v ? 1 : 0));
+                            }
+                            else { u.cbf[0] = r.cbf_y[0] ? 1 : 0; u.cbf[1] = r.cbf_u ? 1 : 0; u.cbf[2] = r.cbf_v ? 1 : 0; }
+                            const int idx = ((q >> 1) * h4n + (k >> 1)) * n4 + (q & 1) * h4n + (k & 1);
+                            split.u[idx] = u;
+                            memset(&split.m[idx], 0, sizeof(x265amd_mv_unit));
+                            split.m[idx].pred_mode = X265AMD_MODE_INTRA; split.m[idx].ref_idx[0] = split.m[idx].ref_idx[1] = -1;
+                            /* CUData::copyToPic of the sub-CU */
+                            units[((cy >> 2) + (k >> 1)) * w4 + (cx >> 2) + (k & 1)] = u;
+                            cur[((cy >> 2) + (k >> 1)) * w4 + (cx >> 2) + (k & 1)] = split.m[idx];
+                        }
+                        split.rdCost += r.rd_cost; split.psyEnergy += r.psy_energy; split.resEnergy += r.res_energy;
+                        split.lumaDistortion += r.luma_dist; split.chromaDistortion += r.chroma_dist; split.distortion += r.luma_dist + r.chroma_dist;
+                        split.totalBits += r.total_bits; split.mvBits += r.mv_bits; split.coeffBits += r.coeff_bits;
+                        memcpy(&split.coeff[(size_t)q * 64], r.levels, sizeof(int16_t) * 64);
+                        memcpy(&split.coeff[4096 + (size_t)q * 16], r.levels + 64, sizeof(int16_t) * 16);
+                        memcpy(&split.coeff[5120 + (size_t)q * 16], r.levels + 80, sizeof(int16_t) * 16);
+                    }
+                    memcpy(split.contexts.ctx, r4[3].ctx, X265AMD_CTX_STRIDE);
+                    split.contexts.frac = r4[3].frac_bits;
+                    nextContext = &split.contexts;
+                }
+            }
+            for (int q = 0; q < 4 && !chained; q++)
             {
                 const int cx = x + (q & 1) * half, cy = y + (q >> 1) * half;
                 if (cx < I->pic_width && cy < I->pic_height)
@@ -980,6 +1043,18 @@ struct Analyzer
                     md[depth + 1].cur = *nextContext;
                     if (compressIntra(cx, cy, depth + 1)) return err;
                     const Mode& nb = *md[depth + 1].best;
+                    if (const char* lg = depth == 2 ? getenv("X265AMD_CHAIN_LOG") : nullptr)
+                    {
+                        int lx = -1, ly = -1;
+                        if (sscanf(lg, "%d,%d", &lx, &ly) == 2 && (lx & ~15) == x && (ly & ~15) == y)
+                        {
+                            const Mode& a = md[depth + 1].pred[PRED_INTRA]; const Mode& b = md[depth + 1].pred[PRED_INTRA_NxN];
+                            fprintf(stderr, "one by one (%d,%d) cu %d: part %d dirs %d %d %d %d chroma %d cbf %d %d %d %d %d %d rd %llu (2Nx2N %llu NxN %llu) bits %u mv %u dist %u+%u psy %u res %u frac %llu\n", x, y, q,
+                                    nb.u[0].part_size, nb.u[0].luma_dir, nb.u[1].luma_dir, nb.u[2].luma_dir, nb.u[3].luma_dir, nb.u[0].chroma_dir, nb.u[0].cbf[0], nb.u[1].cbf[0], nb.u[2].cbf[0],
+                                    nb.u[3].cbf[0], nb.u[0].cbf[1], nb.u[0].cbf[2], (unsigned long long)nb.rdCost, (unsigned long long)a.rdCost, (unsigned long long)b.rdCost, nb.totalBits, nb.mvBits,
+                                    (unsigned)nb.lumaDistortion, (unsigned)nb.chromaDistortion, nb.psyEnergy, (unsigned)nb.resEnergy, (unsigned long long)nb.contexts.frac);
+                        }
+                    }
                     for (int yy = 0; yy < h4n; yy++)
                         for (int xx = 0; xx < h4n; xx++)
                         {

@@ -17,6 +17,7 @@
 #include "tu_dev.h"
 #include "intra_dev.h"
 #include "entropy_dev.h"
+#include "intra_cu_dev.h"
 
 struct Nxn4Tabs
 {
@@ -346,7 +347,152 @@ struct Nxn4Lds
     uint8_t ctxw[5][X265AMD_CTX_STRIDE];
     uint32_t step[256], enBits[128];
     uint8_t enLps[64];
+    /* the CU's own results, kept for the decision of a chained CU */
+    x265amd_tu_result ures[4];
+    uint8_t preds[4][4];
+    uint32_t psyNxn, resNxn, cw;
+    /* a chained CU: the other evaluation's record, the two final context sets, their fractions */
+    x265amd_intra_nxn_out peerOut;
+    uint8_t fctx[2][X265AMD_CTX_STRIDE];
+    uint64_t ffrac[2], fmv[2];
+    int peerOk;
 };
+
+/* CUData::getAllowedChromaDir (cudata.cpp:889-907) -> the mode number as the CU stores it (36: derived) for place `idx` of the list */
+XA_DEV uint32_t nxn4_chroma_stored(uint32_t lumaDir, uint32_t idx)
+{
+    uint32_t list[5] = { 0, 26, 10, 1, 36 };
+    for (int i = 0; i < 4; i++) if (lumaDir == list[i]) { list[i] = 34; break; }
+    return list[idx < 5 ? idx : 4];
+}
+
+/* The decision of a chained CU (role 1), with this workgroup's NxN evaluation in S and the other workgroup's 2Nx2N evaluation in its peer record: both CUs' bits as
+ * Search::checkIntra counts them at its end (search.cpp:1254-1275), the costs (RDCost::calcRdCost / calcPsyRdCost, rdcost.h:89-123), the comparison of checkBestMode
+ * in the order 2Nx2N, NxN (analysis.cpp:3670-3692: the later one only wins when strictly cheaper); then the winner's samples to the picture and the parent's tile, the
+ * CU's result to the host, contexts / fraction / modes to the chain. */
+XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int nthr)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    x265amd_intra_peer* peer = reinterpret_cast<x265amd_intra_peer*>(P.peer);
+    x265amd_intra_chain* ch = reinterpret_cast<x265amd_intra_chain*>(P.chain);
+    x265amd_intra_cu8_result* out = reinterpret_cast<x265amd_intra_cu8_result*>(P.cu_out);
+    __syncthreads();
+    if (tid == 0)
+    {
+        bool ok = xa_chain_wait(&peer->ready, P.chain_token + 1);
+        if (ok && __hip_atomic_load(&peer->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ~0ull) ok = false;      /* the other side gave up */
+        S.peerOk = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!S.peerOk)
+    {
+        if (tid == 0) { out->status = 2; xa_chain_publish(&ch->seq, P.chain_token + 1); }
+        return;
+    }
+    for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_out) / 8); i += nthr) reinterpret_cast<uint64_t*>(&S.peerOut)[i] = reinterpret_cast<const uint64_t*>(&peer->out)[i];
+    for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) { S.fctx[0][i] = P.ctx[i]; S.fctx[1][i] = P.ctx[i]; }
+    __syncthreads();
+    const x265amd_intra_nxn_out& Q = S.peerOut;
+    const uint32_t chromaN = nxn4_chroma_stored(S.winMode[0], S.cw), chroma2 = nxn4_chroma_stored(Q.mode[0], Q.chroma_best);
+    if (wv < 2)
+    {
+        /* wavefront 0: the NxN CU; wavefront 1: the 2Nx2N CU */
+        IntraCuBitsIn in;
+        in.log2_cu = 3; in.nxn = wv == 0; in.code_part_size = 1; in.inter_slice = 0; in.skip_ctx = 0; in.sign_hide = P.tmpl[0].tu.sign_hide; in.subdiv_flag = 0;
+        if (wv == 0)
+        {
+            in.chroma_dir = (uint8_t)chromaN; in.cbf_u = S.cres[S.cw][0].num_sig != 0; in.cbf_v = S.cres[S.cw][1].num_sig != 0;
+            for (int k = 0; k < 4; k++)
+            {
+                in.luma_dir[k] = S.winMode[k]; in.cbf_y[k] = S.ures[k].num_sig != 0; in.lev_y[k] = S.lev + 16 * k;
+                for (int i = 0; i < 3; i++) in.preds[k][i] = S.preds[k][i];
+            }
+            in.lev_u = S.clev[S.cw][0]; in.lev_v = S.clev[S.cw][1];
+        }
+        else
+        {
+            in.chroma_dir = (uint8_t)chroma2; in.cbf_u = Q.cres[0].num_sig != 0; in.cbf_v = Q.cres[1].num_sig != 0;
+            for (int k = 0; k < 4; k++)
+            {
+                in.luma_dir[k] = Q.mode[0]; in.cbf_y[k] = Q.res[0].num_sig != 0; in.lev_y[k] = &Q.levels[0][0];
+                for (int i = 0; i < 3; i++) in.preds[k][i] = S.preds[0][i];         /* the CU's predictors = its first unit's */
+            }
+            in.lev_u = Q.clevels[0]; in.lev_v = Q.clevels[1];
+        }
+        uint64_t mvf = 0, skipf = 0;
+        const uint64_t frac = wave_intra_cu_bits(in, S.fctx[wv], P.scan_frac, &mvf, &skipf, S.step, EnTabs{ S.enBits, S.enLps }, lane);
+        if (lane == 0) { S.ffrac[wv] = frac; S.fmv[wv] = mvf; }
+    }
+    __syncthreads();
+    /* the two costs */
+    const uint32_t lumaN = (uint32_t)(S.ures[0].nz_dist + S.ures[1].nz_dist + S.ures[2].nz_dist + S.ures[3].nz_dist);
+    const uint32_t chromaDN = (uint32_t)(S.cres[S.cw][0].nz_dist + S.cres[S.cw][1].nz_dist), chromaD2 = (uint32_t)(Q.cres[0].nz_dist + Q.cres[1].nz_dist);
+    const uint32_t luma2 = (uint32_t)Q.res[0].nz_dist;
+    const uint32_t psyN = P.psy_scale ? S.psyNxn : 0u, psy2 = P.psy_scale ? Q.res[0].nz_energy : 0u;
+    const uint32_t bitsN = (uint32_t)(S.ffrac[0] >> 15), bits2 = (uint32_t)(S.ffrac[1] >> 15);
+    const uint64_t distN = (uint64_t)lumaN + chromaDN, dist2 = (uint64_t)luma2 + chromaD2;        /* sse_t sums: an 8x8 CU's stay far below 32 bits at either depth */
+    const uint64_t costN = P.psy_scale ? distN + ((P.psy_scale * (uint64_t)psyN) >> 24) + (((uint64_t)bitsN * P.lambda2) >> 8) : distN + (((uint64_t)bitsN * P.lambda2 + 128) >> 8);
+    const uint64_t cost2 = P.psy_scale ? dist2 + ((P.psy_scale * (uint64_t)psy2) >> 24) + (((uint64_t)bits2 * P.lambda2) >> 8) : dist2 + (((uint64_t)bits2 * P.lambda2 + 128) >> 8);
+    const bool nxnWins = costN < cost2;
+    const int win = nxnWins ? 0 : 1;
+    /* the winner's samples: the picture and the parent's tile */
+    {
+        const x265amd_intra_tu_job& T0 = P.tmpl[0];
+        pixel* pic = reinterpret_cast<pixel*>(T0.nb);
+        pixel* dstY = reinterpret_cast<pixel*>(P.win_dst[0]);
+        const pixel* peerY = reinterpret_cast<const pixel*>(P.peer_recon[0]);
+        if (tid < 64)
+        {
+            const int y = tid >> 3, x = tid & 7;
+            const pixel v = nxnWins ? S.frame[(y + 1) * 17 + x + 1] : peerY[y * 64 + x];
+            pic[(long)y * T0.nb_stride + x] = v;
+            dstY[y * 64 + x] = v;
+        }
+        else if (tid < 96)
+        {
+            const int pl = (tid - 64) >> 4, i = tid & 15, y = i >> 2, x = i & 3;
+            const x265amd_intra_tu_job& C = P.ctmpl[pl];
+            const pixel v = nxnWins ? S.crec[S.cw][pl][i] : reinterpret_cast<const pixel*>(P.peer_recon[1 + pl])[y * 32 + x];
+            reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = v;
+            reinterpret_cast<pixel*>(P.win_dst[1 + pl])[y * 32 + x] = v;
+        }
+        /* the host's record */
+        else if (tid < 96 + 96)
+        {
+            const int i = tid - 96;
+            int16_t v;
+            if (i < 64) v = nxnWins ? S.lev[i] : Q.levels[0][i];
+            else v = nxnWins ? S.clev[S.cw][(i - 64) >> 4][i & 15] : Q.clevels[(i - 64) >> 4][i & 15];
+            out->levels[i] = v;
+        }
+        else if (tid < 192 + X265AMD_CTX_STRIDE)
+        {
+            const int i = tid - 192;
+            const uint8_t v = S.fctx[win][i];
+            out->ctx[i] = v; ch->ctx[i] = v;
+        }
+    }
+    if (tid == 0)
+    {
+        out->rd_cost = nxnWins ? costN : cost2; out->other_cost = nxnWins ? cost2 : costN; out->frac_bits = S.ffrac[win];
+        const uint32_t tb = nxnWins ? bitsN : bits2, mvb = (uint32_t)(S.fmv[win] >> 15);
+        out->total_bits = tb; out->mv_bits = mvb; out->coeff_bits = tb - mvb;
+        out->psy_energy = nxnWins ? psyN : psy2; out->res_energy = nxnWins ? S.resNxn : (uint32_t)Q.res[0].zero_dist;
+        out->luma_dist = nxnWins ? lumaN : luma2; out->chroma_dist = nxnWins ? chromaDN : chromaD2;
+        out->part_size = nxnWins ? 3 : 0; out->chroma_dir = (uint8_t)(nxnWins ? chromaN : chroma2);
+        out->cbf_u = nxnWins ? (S.cres[S.cw][0].num_sig != 0) : (Q.cres[0].num_sig != 0); out->cbf_v = nxnWins ? (S.cres[S.cw][1].num_sig != 0) : (Q.cres[1].num_sig != 0);
+        for (int k = 0; k < 4; k++)
+        {
+            const uint8_t m = nxnWins ? S.winMode[k] : Q.mode[0];
+            out->luma_dir[k] = m; ch->mode[P.chain_index & 3][k] = m;
+            out->cbf_y[k] = nxnWins ? (S.ures[k].num_sig != 0) : (Q.res[0].num_sig != 0);
+        }
+        ch->frac = S.ffrac[win];
+        out->status = 1;
+    }
+    __syncthreads();
+    if (tid == 0) xa_chain_publish(&ch->seq, P.chain_token + 1);
+}
 
 XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_out* po, Nxn4Lds& S, IntraPuShared& L, int tid, int nthr)
 {
@@ -354,6 +500,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
     const x265amd_intra_tu_job& T0 = P.tmpl[0];
     const long ps = T0.nb_stride;
     pixel* pic = reinterpret_cast<pixel*>(T0.nb);                   /* the CU's first sample in the reconstructed plane */
+    const bool chained = P.chain != 0 && P.chain_role == 1;          /* the picture, the tiles and the result wait for the decision between this and the other evaluation */
     XA_NXN_START(0);
     /* ---- tables, the source block, the neighbourhood ---- */
     nxn4_fill_tabs(S.tb, tid);
@@ -410,6 +557,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
             else { p0 = 0; p1 = 1; p2 = 26; }
         }
         else { p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
+        if (tid == 0) { S.preds[k][0] = (uint8_t)p0; S.preds[k][1] = (uint8_t)p1; S.preds[k][2] = (uint8_t)p2; }
         /* every wavefront gathers the unit's neighbours for itself */
         const int dc = nxn4_neighbours(org, 17, (uint32_t)P.tmpl[k].avail, ref, sw, lane);
         xa_wave_sync();
@@ -482,10 +630,10 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
             {
                 const uint8_t mode = L.modes[w];
                 S.winMode[k] = mode;
-                po->mode[k] = mode; po->num_cand[k] = (uint8_t)n;
                 x265amd_tu_result r;
                 r.num_sig = mine.numSig; r.zero_energy = mine.zeroEnergy; r.nz_energy = mine.nzEnergy; r.reserved = 0; r.zero_dist = mine.zeroDist; r.nz_dist = mine.nzDist;
-                po->res[k] = r;
+                S.ures[k] = r;
+                if (!chained) { po->mode[k] = mode; po->num_cand[k] = (uint8_t)n; po->res[k] = r; }
             }
         }
         __syncthreads();
@@ -496,16 +644,23 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
     if (tid < 64)
     {
         const int y = tid >> 3, x = tid & 7, k = (y >> 2) * 2 + (x >> 2), yy = y & 3, xx = x & 3;
-        const pixel v = S.frame[(y + 1) * 17 + x + 1];
-        pic[(long)y * ps + x] = v;
-        reinterpret_cast<pixel*>(P.layer_dst[k])[yy * 64 + xx] = v;
-        if (P.recon_dst[k]) reinterpret_cast<pixel*>(P.recon_dst[k])[yy * 64 + xx] = v;
-        reinterpret_cast<pixel*>(P.pred_dst[k])[yy * 64 + xx] = S.pred[y * 8 + x];
-        int16_t* lvOut = P.levels_dst ? reinterpret_cast<int16_t*>(P.levels_dst) : &po->levels[0][0];
-        lvOut[tid] = S.lev[tid];
+        if (!chained)
+        {
+            const pixel v = S.frame[(y + 1) * 17 + x + 1];
+            pic[(long)y * ps + x] = v;
+            reinterpret_cast<pixel*>(P.layer_dst[k])[yy * 64 + xx] = v;
+            if (P.recon_dst[k]) reinterpret_cast<pixel*>(P.recon_dst[k])[yy * 64 + xx] = v;
+            reinterpret_cast<pixel*>(P.pred_dst[k])[yy * 64 + xx] = S.pred[y * 8 + x];
+            int16_t* lvOut = P.levels_dst ? reinterpret_cast<int16_t*>(P.levels_dst) : &po->levels[0][0];
+            lvOut[tid] = S.lev[tid];
+        }
         const int psy = wave_psy_cost(S.fenc, 8, S.frame + 18, 17, 1, lane);
         const uint64_t sse = wave_sse_pp(S.fenc, 8, S.pred, 8, 8, lane);
-        if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
+        if (lane == 0)
+        {
+            S.psyNxn = (uint32_t)psy; S.resNxn = (uint32_t)sse;
+            if (!chained) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
+        }
     }
     XA_NXN(8);
     if (!P.do_chroma) return;
@@ -575,10 +730,10 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         }
         if (tid == 0)
         {
-            po->chroma_best = (uint32_t)w; po->chroma_reserved = 0;
-            po->cres[0] = S.cres[w][0]; po->cres[1] = S.cres[w][1];
+            S.cw = (uint32_t)w;
+            if (!chained) { po->chroma_best = (uint32_t)w; po->chroma_reserved = 0; po->cres[0] = S.cres[w][0]; po->cres[1] = S.cres[w][1]; }
         }
-        if (tid < 32)
+        if (tid < 32 && !chained)
         {
             const int pl = tid >> 4, i = tid & 15, y = i >> 2, x = i & 3;
             const x265amd_intra_tu_job& C = P.ctmpl[pl];
@@ -589,6 +744,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         }
     }
     XA_NXN(9);
+    if (chained) nxn4_decide(P, S, tid, nthr);
 }
 
 #endif

@@ -123,6 +123,64 @@ XA_DEV void block_intra_pu(const x265amd_intra_pu_job* pj, x265amd_intra_pu_out*
     }
 }
 
+/* ---- a CU as a link of a device-run chain (include/x265amd.h: x265amd_intra_nxn_job.chain) ---- */
+#define XA_CHAIN_TIMEOUT_TICKS 200000000ll         /* two seconds of the 100 MHz clock: a chain that stands this long is broken, and the host is told rather than left waiting */
+
+/* waits (one lane) until *word >= want; false when it gives up */
+XA_DEV bool xa_chain_wait(const uint64_t* word, uint64_t want)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+    {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > XA_CHAIN_TIMEOUT_TICKS) return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return true;
+}
+/* everything this workgroup has written is visible to the other before `word` changes (called by one lane after a barrier that follows the writes) */
+XA_DEV void xa_chain_publish(uint64_t* word, uint64_t value)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* the command's start as a link: wait for the CU before it, then take contexts, fraction and neighbour modes from the chain (sP: the record's copy in LDS).
+ * Returns false when the wait was given up. */
+XA_DEV bool nxn_chain_begin(x265amd_intra_nxn_job& sP, int tid, int nthr)
+{
+    __shared__ int s_chainOk;
+    x265amd_intra_chain* ch = reinterpret_cast<x265amd_intra_chain*>(sP.chain);
+    if (sP.chain_first) return true;
+    if (tid == 0) s_chainOk = xa_chain_wait(&ch->seq, sP.chain_token) ? 1 : 0;
+    __syncthreads();
+    if (!s_chainOk) return false;
+    const uint64_t frac = ch->frac & 32767;
+    uint8_t m[4];
+    for (int i = 0; i < 4; i++)
+    {
+        const uint8_t src = sP.mode_src[i];
+        m[i] = src == 0xFF ? (i < 2 ? sP.left_mode[i] : sP.above_mode[i - 2]) : ch->mode[src >> 2][src & 3];
+    }
+    __syncthreads();
+    for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) sP.ctx[i] = ch->ctx[i];
+    if (tid == 0)
+    {
+        sP.left_mode[0] = m[0]; sP.left_mode[1] = m[1]; sP.above_mode[0] = m[2]; sP.above_mode[1] = m[3];
+        sP.scan_frac = (uint32_t)frac;
+        /* what codeIntraLumaQT finds in front of the first unit's direction in an I slice: the partition size bin (2Nx2N: 1, NxN: 0) */
+        const uint32_t bin = (sP.num_units == 0 || sP.num_units == 4) ? 0u : 1u;
+        sP.frac_start[0] = frac + en_bits[ch->ctx[8] ^ bin];
+        sP.frac_start[1] = sP.frac_start[2] = sP.frac_start[3] = frac;
+    }
+    __syncthreads();
+    return true;
+}
+
+#include "intra_cu_dev.h"
 #include "intra_nxn4_dev.h"
 
 /* x265amd_intra_nxn (include/x265amd.h): the four 4x4 prediction units of an 8x8 NxN CU, decisions included, by one workgroup. */
@@ -143,6 +201,20 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_job) / 8); i += nthr)
         reinterpret_cast<uint64_t*>(&sP)[i] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(pj) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
+    if (sP.chain)
+    {
+        if (!nxn_chain_begin(sP, tid, nthr))
+        {
+            /* the chain stands: say so where the host looks, and let whoever waits for this command see it */
+            if (tid == 0)
+            {
+                if (sP.chain_role == 1) reinterpret_cast<x265amd_intra_cu8_result*>(sP.cu_out)->status = 2;
+                else xa_chain_publish(&reinterpret_cast<x265amd_intra_peer*>(sP.peer)->ready, ~0ull);
+            }
+            return;
+        }
+        if (sP.chain_role == 2) po = &reinterpret_cast<x265amd_intra_peer*>(sP.peer)->out;
+    }
     if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture)
     {
         /* the NxN CU proper: its own form, nothing but LDS and registers between the first and the last instruction (intra_nxn4_dev.h) */
@@ -388,6 +460,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     }
     __syncthreads();
     XA_NXN(9);
+    /* the other evaluation of a chained CU: the record and the tiles are complete */
+    if (P.chain && P.chain_role == 2 && tid == 0) xa_chain_publish(&reinterpret_cast<x265amd_intra_peer*>(P.peer)->ready, P.chain_token + 1);
 }
 
 #endif

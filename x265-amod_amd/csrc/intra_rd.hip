@@ -15,6 +15,8 @@
 #include "xa_queue.h"
 #include "../host/cabac_coder.h"
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -44,6 +46,30 @@ inline unsigned zUnit(int ux, int uy)           /* z-order of unit (ux, uy) insi
     return r;
 }
 
+/* The device-side records of a chain of 8x8 CUs (four x265amd_intra_peer + one x265amd_intra_chain) come from a list of their own, not from the pools: the counts in them
+ * only ever grow (one counter for the process), so whatever a workgroup still holds of such a record from an earlier chain is an OLDER count and at worst makes it look
+ * again -- memory that had been pixels or levels before could read as a count from the future. */
+static std::mutex g_chainLock;
+static std::vector<void*> g_chainFree;
+static const size_t kChainBlock = 4 * sizeof(x265amd_intra_peer) + sizeof(x265amd_intra_chain);
+static void* chain_block_get()
+{
+    {
+        std::lock_guard<std::mutex> g(g_chainLock);
+        if (!g_chainFree.empty()) { void* p = g_chainFree.back(); g_chainFree.pop_back(); return p; }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, kChainBlock) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kChainBlock) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    return p;
+}
+static void chain_block_put(void* p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> g(g_chainLock);
+    g_chainFree.push_back(p);
+}
+
 struct IntraRd
 {
     hipStream_t st;
@@ -69,6 +95,12 @@ struct IntraRd
     struct Ahead { bool on = false; int x = 0, y = 0; } ahead;
     DevBuf dCand2, dCoeffDev2; XaMapped dNxnJob2; XaMappedOut dNxnOut2;
     XaMappedOut dDevLevels, dDevCLevels;                /* the device-decided 16x16 unit: its 256 luma levels, the chroma winner's 2 x 64 */
+    /* The four 8x8 CUs of a 16x16 block of an I picture as a chain the device runs by itself (xa_intra_quad8_ws; include/x265amd.h: x265amd_intra_nxn_job.chain):
+     * eight job records queued in advance (per CU the NxN evaluation on this queue, the 2Nx2N evaluation on the second), the chain and peer records in device
+     * memory, the four results the host reads, the count of chained CUs so far (the chain's tokens never repeat). */
+    XaMapped qJobs; XaMappedOut qOut;
+    void* qBlock = nullptr;                             /* four peer records and the chain record: memory that is never anything else (chain_block_get) */
+    ~IntraRd();
     /* A 16x16 CU's 2Nx2N evaluation started BEFORE the recursion into its four 8x8 CUs, on a third queue, and collected after it (xa_check_intra_begin_ws):
      * it reads only what lies outside the CU and writes only its own tiles (no_picture), so it runs beside the sub-CUs, which own the picture meanwhile. */
     struct Big { void* q = nullptr; bool on = false, owned = false; int x = 0, y = 0; DevBuf cand, coeffDev; XaMapped job; XaMappedOut out, levels, clevels; } big[2];    /* [0] 16x16 (third queue), [1] 32x32 (fourth) */
@@ -929,6 +961,8 @@ struct IntraRd
     }
 };
 
+IntraRd::~IntraRd() { chain_block_put(qBlock); }
+
 } // namespace
 
 /* shared body: kind 0 = checkIntraInInter + encodeIntraInInter, kind 1 = checkIntra(part_size) */
@@ -1273,6 +1307,115 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (!ws) delete ip;
     xa_phase(XA_PH_INTRA_FINAL);
     return rc;
+}
+
+/* The four 8x8 CUs of the 16x16 block at (x, y) of an I picture, decided on the device one after the other without the host between them (Analysis::compressIntraCU's
+ * loop over the sub-CUs at the last depth, analysis.cpp:596-640, with checkIntra 2Nx2N and NxN per CU, search.cpp:1236-1287).  ctx / frac: the contexts the first CU
+ * starts from; split_recon: the parent's reconstruction tile (the winners' samples go there and into the picture); tiles2: prediction / reconstruction tiles for the
+ * 2Nx2N evaluations.  results[4] in CU order.  Returns 0, 1 when the chain does not apply here (the caller takes the CUs one by one), or an error code. */
+int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
+                      intptr_t stride, intptr_t cstride, int x, int y, int qp, const uint8_t* ctx, uint64_t frac, uint64_t split_recon, const uint64_t tilesN[2],
+                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws)
+{
+    static const bool on = !(getenv("X265AMD_INTRA_CHAIN") && atoi(getenv("X265AMD_INTRA_CHAIN")) == 0);
+    if (!on || !ws || !*ws || !xa_is_queue(stream)) return 1;
+    IntraRd& R = *static_cast<IntraRd*>(*ws);
+    void* helper = xa_queue_helper(stream);
+    if (!helper || !R.dCand2.p || !R.dLayer.p || !R.dCand.p || R.ahead.on) return 1;
+    if (si->slice_type != 2 || si->use_dqp || si->tq_bypass_enabled || rp->rdoq_level || si->tu_max_depth_intra != 1 || si->tu_log2_min != 2 || si->tu_log2_max < 3 || si->max_cu_depth != 3 ||
+        2 + rp->rd_level + 2 > IntraRd::MAX_JOBS || x + 16 > si->pic_width || y + 16 > si->pic_height || (x & 15) || (y & 15))
+        return 1;
+    if (!R.qJobs.p)
+    {
+        if (R.qJobs.alloc(8 * sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.qOut.alloc(4 * sizeof(x265amd_intra_cu8_result)) != hipSuccess || !(R.qBlock = chain_block_get()))
+            return xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
+    }
+    R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
+    R.log2 = 3; R.size = 8; R.depth = 3; R.qp = qp; R.err = 0; R.helper = helper;
+    {
+        static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
+                                                 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+        const int bd = 6 * (X265AMD_DEPTH - 8);
+        const int qpQuant = qp < 0 ? 0 : (qp > 51 ? 51 : qp);
+        int qpC = qpQuant > 57 ? 57 : qpQuant;
+        if (qpC >= 30) qpC = chromaScale[qpC];
+        R.qpLumaScaled = qpQuant + bd; R.qpChromaScaled = qpC + bd;
+    }
+    uint64_t rd[6];
+    x265amd_rdcost(qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+    R.lambda2 = rd[0]; R.lambda = rd[1]; R.psyRd = (uint32_t)rd[2];
+    memset(&R.cur, 0, sizeof(R.cur));
+    memcpy(R.cur.ctx, ctx, X265AMD_CTX_COUNT);
+    R.cur.frac = frac;
+    x265amd_cabac* coder = x265amd_cabac_open(si, units, 1);
+    if (!coder) return xa_fail(X265AMD_EINVAL, "intra rd: slice description");
+    R.c = coder;
+    x265amd_intra_nxn_job* jobs = static_cast<x265amd_intra_nxn_job*>(R.qJobs.p);
+    x265amd_intra_cu8_result* outs = static_cast<x265amd_intra_cu8_result*>(R.qOut.p);
+    x265amd_intra_peer* peers = static_cast<x265amd_intra_peer*>(R.qBlock);
+    x265amd_intra_chain* chainRec = reinterpret_cast<x265amd_intra_chain*>(peers + 4);
+    const size_t isz = sizeof(pixel);
+    /* The chain's counts never repeat, in any chain of the process: records come from the pools, and a workgroup that looks at one may still hold (in its L2) what an
+     * earlier chain left there -- an old count is smaller than every new one and only makes the reader look again. */
+    static std::atomic<uint64_t> tokens{ 1 };
+    const uint64_t token0 = tokens.fetch_add(4);
+    for (int i = 0; i < 4; i++)
+    {
+        R.cuX = x + 8 * (i & 1); R.cuY = y + 8 * (i >> 1);
+        /* the CU as initSubCU + setPredModeSubParts leave it (the caller writes the decided CU over it afterwards) */
+        for (int k = 0; k < 4; k++)
+        {
+            x265amd_cu_unit& u = R.U(R.cuX + 4 * (k & 1), R.cuY + 4 * (k >> 1));
+            memset(&u, 0, sizeof(u));
+            u.depth = 3; u.pred_mode = X265AMD_MODE_INTRA; u.luma_dir = 1; u.chroma_dir = 36; u.qp = (int8_t)qp; u.ref_idx[0] = u.ref_idx[1] = -1;
+        }
+        x265amd_cu_unit& u0 = R.U(R.cuX, R.cuY);
+        const uint8_t keepPart = u0.part_size;
+        for (int role = 1; role <= 2; role++)
+        {
+            x265amd_intra_nxn_job nj;
+            const int partSize = role == 1 ? 3 : 0;
+            R.range[0] = partSize ? 2 : 3; R.range[1] = si->tu_log2_max;
+            u0.part_size = (uint8_t)partSize;
+            if (role == 1) R.buildDevJob(nj, 3, rp->rd_level, tilesN[0], tilesN[1], (uint64_t)(uintptr_t)R.dCand.p, (uint64_t)(uintptr_t)R.dCoeffDev.p);
+            else R.buildDevJob(nj, 0, rp->rd_level, tiles2[0], tiles2[1], (uint64_t)(uintptr_t)R.dCand2.p, (uint64_t)(uintptr_t)R.dCoeffDev2.p);
+            nj.no_picture = role == 2;
+            nj.chain = (uint64_t)(uintptr_t)chainRec; nj.peer = (uint64_t)(uintptr_t)&peers[i]; nj.cu_out = (uint64_t)(uintptr_t)&outs[i];
+            nj.chain_token = token0 + i; nj.chain_role = (uint8_t)role; nj.chain_first = i == 0; nj.chain_index = (uint8_t)i;
+            /* the neighbour modes inside the block are the chain's: left of units 0 / 2 = units 1 / 3 of the CU to the left, above of units 0 / 1 = units 2 / 3 of the CU above */
+            nj.mode_src[0] = (i & 1) ? (uint8_t)(((i - 1) << 2) | 1) : 0xFF; nj.mode_src[1] = (i & 1) ? (uint8_t)(((i - 1) << 2) | 3) : 0xFF;
+            nj.mode_src[2] = (i & 2) ? (uint8_t)(((i - 2) << 2) | 2) : 0xFF; nj.mode_src[3] = (i & 2) ? (uint8_t)(((i - 2) << 2) | 3) : 0xFF;
+            if (role == 1)
+            {
+                nj.peer_recon[0] = tiles2[1];
+                nj.win_dst[0] = split_recon + ((size_t)(8 * (i >> 1)) * 64 + 8 * (i & 1)) * isz;
+                for (int pl = 0; pl < 2; pl++)
+                {
+                    nj.peer_recon[1 + pl] = tiles2[1] + (4096 + (size_t)pl * 1024) * isz;
+                    nj.win_dst[1 + pl] = split_recon + (4096 + (size_t)pl * 1024 + (size_t)(4 * (i >> 1)) * 32 + 4 * (i & 1)) * isz;
+                }
+            }
+            memcpy(&jobs[2 * i + (role - 1)], &nj, sizeof(nj));
+        }
+        u0.part_size = keepPart;
+        outs[i].status = 0;
+    }
+    x265amd_cabac_close(coder);
+    R.c = nullptr;
+    /* what this queue has written is out before the other workgroup looks (a signalling command releases), and that one looks (acquire) */
+    int rc = X265AMD_OK;
+    if (xa_stream_sync(stream) != hipSuccess || xa_stream_fence(helper, XA_CMD_ACQUIRE) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain fence");
+    for (int i = 0; i < 4 && rc == X265AMD_OK; i++)
+        if (x265amd_intra_nxn(helper, &jobs[2 * i + 1], &peers[i].out) != X265AMD_OK || x265amd_intra_nxn(stream, &jobs[2 * i], (x265amd_intra_nxn_out*)R.dNxnOut.p) != X265AMD_OK)
+            rc = xa_fail(X265AMD_EHIP, "intra rd: chain commands");
+    if (rc == X265AMD_OK && xa_stream_sync(stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain");
+    if (rc != X265AMD_OK) return rc;
+    for (int i = 0; i < 4; i++)
+    {
+        memcpy(&results[i], &outs[i], sizeof(results[i]));
+        if (results[i].status != 1) return xa_fail(X265AMD_EHIP, "intra rd: the device gave up waiting inside a chain of 8x8 CUs");
+    }
+    return X265AMD_OK;
 }
 
 void xa_intra_ws_free(void* ws)
