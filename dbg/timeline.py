@@ -1,14 +1,12 @@
 # per-picture timeline of the last encode in an X265AMD_TIMING=1 log: dbg/timeline.py log
 import re, sys, collections
 rows = []
-for l in open(sys.argv[1]):
+lines = open(sys.argv[1]).read().splitlines()
+if "---- timed encode ----" in lines: lines = lines[len(lines) - 1 - lines[::-1].index("---- timed encode ----"):]      # dbg/enc_bench.py, enc_clip60.py: only the timed encode
+for l in lines:
     m = re.match(r'x265amd: row: poc (\d+) row (\d+) start ([\d.]+) queue ([\d.]+) end ([\d.]+) ran ([\d.]+)', l)
     if m: rows.append(tuple(float(x) for x in m.groups()))
-encs = [[]]; prev = 0
-for r in rows:
-    if r[2] < prev - 300: encs.append([])
-    encs[-1].append(r); prev = max(prev, r[4]) if r[2] >= prev - 300 else r[4]
-e = encs[-1]
+e = rows
 by = collections.defaultdict(list)
 for r in e: by[int(r[0])].append(r)
 t0 = min(r[2] for r in e)

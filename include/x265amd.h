@@ -393,7 +393,13 @@ typedef struct x265amd_intra_nxn_out
     x265amd_tu_result cres[2];
     int16_t clevels[2][16];
 } x265amd_intra_nxn_out;            /* 408 bytes */
-typedef struct x265amd_intra_peer { x265amd_intra_nxn_out out; uint64_t ready; } x265amd_intra_peer;     /* ready = chain_token + 1 when `out` is complete */
+typedef struct x265amd_intra_peer
+{
+    x265amd_intra_nxn_out out; uint64_t ready;      /* ready = chain_token + 1 when the record is complete */
+    /* role 2 counts its own CU's bits while role 1 is still evaluating (the walk of x265amd_intra_cu_bits): the contexts and the coder's fraction behind the CU coded
+     * 2Nx2N, the fraction behind its prediction info */
+    uint8_t fctx[X265AMD_CTX_STRIDE]; uint64_t ffrac, fmv;
+} x265amd_intra_peer;
 typedef struct x265amd_intra_cu8_result
 {
     uint64_t rd_cost, frac_bits;        /* of the winner: Mode::rdCost, the coder's fraction behind the CU */
@@ -407,6 +413,9 @@ typedef struct x265amd_intra_cu8_result
     int16_t levels[96];                 /* luma (NxN: unit k at 16 k), then U, V */
 } x265amd_intra_cu8_result;             /* 424 bytes */
 int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_job, x265amd_intra_nxn_out* d_out);
+/* n records stride_bytes apart run one after the other by the same workgroup as ONE launch / command (chained CUs: the records of one role; d_out is only written by
+ * records that are not chained) */
+int x265amd_intra_nxn_list(void* stream, const x265amd_intra_nxn_job* d_jobs, int n, size_t stride_bytes, x265amd_intra_nxn_out* d_out);
 
 /* x265amd_tu_chain with Quant::m_rdoqLevel != 0: d_rdoq[i] belongs to d_jobs[i] */
 int x265amd_tu_chain_rdoq(void* stream, const x265amd_tu_job* d_jobs, const x265amd_tu_rdoq* d_rdoq, int n, x265amd_tu_result* d_out);

@@ -1540,7 +1540,8 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         std::vector<Row> rowsArg((size_t)ctuH);
         std::vector<XaTask> tasks((size_t)ctuH);
         static std::atomic<uint64_t> frameSeq{ 0 };
-        const uint64_t seq = frameSeq.fetch_add(1);         /* analyses start in coding order: older pictures' rows go first */
+        const uint64_t seqCall = frameSeq.fetch_add(1);     /* analyses start in coding order: older pictures' rows go first */
+        const uint64_t seq = hooks && hooks->order ? hooks->order : seqCall;
         auto rowReady = [](void* c) -> int {
             Row* r = (Row*)c; Frame& f = *r->f;
             if (f.firstErr.load() != X265AMD_OK) return 1;

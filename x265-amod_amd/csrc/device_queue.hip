@@ -21,6 +21,10 @@ __shared__ long long xa_stage_prev;
 #endif
 /* the fused intra command's stages on a clock of its own (the chains' stamps above do not disturb it): [kind][stage], thread 0 */
 __shared__ unsigned long long xa_nxn_acc[4][10];
+__shared__ unsigned long long xa_chain_acc[8];
+__shared__ long long xa_chain_prev;
+#define XA_CHAIN_START() do { if (threadIdx.x == 0) xa_chain_prev = wall_clock64(); } while (0)
+#define XA_CHAIN(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_chain_acc[k] += (unsigned long long)(t_ - xa_chain_prev); xa_chain_prev = t_; } } while (0)
 __shared__ long long xa_nxn_prev;
 __shared__ int xa_nxn_kind;
 #define XA_NXN_START(kind) do { if (threadIdx.x == 0) { xa_nxn_kind = (kind); xa_nxn_prev = wall_clock64(); } } while (0)
@@ -331,7 +335,9 @@ __device__ __noinline__ void xa_op_intra_pu(const XaCmd& c, int tid)
 __device__ __noinline__ void xa_op_intra_nxn(const XaCmd& c, int tid)
 {
     const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
-    block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(a.a), reinterpret_cast<x265amd_intra_nxn_out*>(a.b), xa_smem, tid, 64 * XA_SERVER_WAVES);
+    /* a.n records a.c bytes apart, one after the other (the chained CUs of a block: include/x265amd.h, x265amd_intra_nxn_list) */
+    for (int i = 0; i < (a.n > 0 ? a.n : 1); i++)
+        block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(a.a + (uint64_t)i * a.c), reinterpret_cast<x265amd_intra_nxn_out*>(a.b), xa_smem, tid, 64 * XA_SERVER_WAVES);
 }
 
 /* the groups of a launch one after the other: each stages its window, its jobs go to the wavefronts */
@@ -438,6 +444,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid == 0) xa_bytes_acc = 0;
     if (tid < 22) xa_stage_acc[tid] = 0;
     if (tid < 40) (&xa_nxn_acc[0][0])[tid] = 0;
+    if (tid < 8) xa_chain_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
     if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
     __syncthreads();
@@ -588,6 +595,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid < 32) xa_sys_store(&rh->bytes[tid], rh->bytes[tid] + s_bytes[tid]);
     if (tid >= 64 && tid < 104) xa_sys_store(&rh->nxn[tid - 64], rh->nxn[tid - 64] + (&xa_nxn_acc[0][0])[tid - 64]);
+    if (tid >= 104 && tid < 112) xa_sys_store(&rh->chain[tid - 104], rh->chain[tid - 104] + xa_chain_acc[tid - 104]);
     if (tid == 32) xa_sys_store(&rh->resident, rh->resident + (unsigned long long)(wall_clock64() - tResident0));
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
 }
@@ -762,6 +770,13 @@ struct Server
                         "choice %.1f, winner's blocks %.1f, luma measurements %.1f, chroma %.1f\n", kinds[kd], nx[kd * 10] / 1e5, nx[kd * 10 + 1] / 1e5, nx[kd * 10 + 2] / 1e5, nx[kd * 10 + 3] / 1e5,
                         nx[kd * 10 + 4] / 1e5, nx[kd * 10 + 5] / 1e5, nx[kd * 10 + 6] / 1e5, nx[kd * 10 + 7] / 1e5, nx[kd * 10 + 8] / 1e5, nx[kd * 10 + 9] / 1e5);
             }
+        }
+        {
+            uint64_t cx[8] = { 0 };
+            for (int i = 0; i < numQueues; i++) for (int k = 0; k < 8; k++) cx[k] += hosts[i].chain[k];
+            if (cx[3])
+                fprintf(stderr, "  chained 8x8 CUs (ms): the deciding command waiting for the chain %.1f, the other command waiting for the chain %.1f, waiting for the other evaluation %.1f, "
+                        "its record + both CUs' bits %.1f, costs + the winner's samples + the result %.1f, publishing %.1f\n", cx[0] / 1e5, cx[1] / 1e5, cx[2] / 1e5, cx[3] / 1e5, cx[4] / 1e5, cx[5] / 1e5);
         }
         static const char* const sized[11] = { "scan / pu 4", "scan / pu 8", "scan / pu 16", "scan / pu 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };

@@ -39,6 +39,8 @@ typedef std::shared_ptr<Pic> PicP;
 struct Pic
 {
     int poc = 0, type = 0, sliceQp = 0;
+    uint64_t codingOrder = 0;                           /* its place in coding order (the row tasks' priority) */
+    bool started = false;
     bool hasReferences = false;
     pixel* dSrc = nullptr; pixel* dRec = nullptr;       /* flat Y | U | V padded buffers (pooled device memory) */
     std::vector<x265amd_cu_unit> units;
@@ -97,8 +99,10 @@ struct x265amd_encoder
     int frameCount = 0, lastKeyframe = 0, lastIDR = 0;
     bool first = true;
     std::deque<PicP> input;                             /* display order, not yet typed */
-    std::deque<PicP> ready;                             /* coding order, typed, not yet started */
-    std::deque<PicP> inflight;                          /* coding order, frame tasks running */
+    std::deque<PicP> ready;                             /* coding order, typed, not yet prepared */
+    std::deque<PicP> inflight;                          /* coding order: prepared pictures, their frame tasks running or (frame-parallel only) still to start */
+    uint64_t codingCount = 0;
+    int running = 0;                                    /* frame tasks started and not yet collected */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
     bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
@@ -1296,7 +1300,7 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     static const bool colsOff = getenv("X265AMD_FILTER_COLS") && atoi(getenv("X265AMD_FILTER_COLS")) == 0;
     const bool byCols = !colsOff && p.bEnableWavefront && (p.bEnableLoopFilter || p.bEnableSAO) && ctuH > 1 && ctuW > 1;
     std::thread filters([&, byCols] { xa_thread_device(); filterRc = byCols ? filterRowsCols(pic, fc.si, fc.info, sparams, saoFlags) : filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) pic.fail(); });
-    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait };
+    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, pic.codingOrder + 1 };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
                                sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);
@@ -1331,14 +1335,19 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     }
     if (e->lookahead) { if (e->decideLookahead(picIn == nullptr) != X265AMD_OK) return -1; }
     else e->decideMiniGop(picIn == nullptr);
-    /* start every typed picture: preparation in coding order here, the frame itself as a task */
+    /* every typed picture is prepared in coding order here (DPB::prepareEncode is bookkeeping: it does not wait for any picture to be coded); the frame itself is a task */
     while (!e->ready.empty())
     {
         PicP pic = e->ready.front();
         e->ready.pop_front();
         if (e->prepare(pic)) return -1;
+        pic->codingOrder = e->codingCount++;
+        e->inflight.push_back(pic);
+    }
+    const bool timing = getenv("X265AMD_TIMING") != nullptr;
+    auto start = [e, timing](const PicP& pic) {
         std::shared_future<int> prev = e->lastTask;
-        const bool timing = getenv("X265AMD_TIMING") != nullptr;
+        pic->started = true;
         pic->done = std::async(std::launch::async, [e, pic, prev, timing]() {
             xa_thread_device();
             const auto t0 = std::chrono::steady_clock::now();
@@ -1349,15 +1358,30 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
             return rc;
         }).share();
         e->lastTask = pic->done;
-        e->inflight.push_back(pic);
-        if (e->frameThreads <= 1) pic->done.wait();
+        e->running++;
+    };
+    /* Tasks start in coding order while fewer than frameThreads + 1 run.  Coded in parallel, a picture without references does not wait for its turn: nothing it needs
+     * comes from another picture, and an I picture takes as long as a dozen of the others -- started when the lookahead hands it over, it is coded beside the pictures
+     * in front of it instead of holding up the ones behind it (X265AMD_EARLY_I=0: in turn).  Output stays in coding order. */
+    static const bool earlyI = !(getenv("X265AMD_EARLY_I") && atoi(getenv("X265AMD_EARLY_I")) == 0);
+    for (auto& q : e->inflight)
+    {
+        if (q->started) continue;
+        if (e->running <= e->frameThreads) { start(q); if (e->frameThreads <= 1) q->done.wait(); continue; }
+        if (!(e->frameParallel && earlyI)) break;
+        if (q->type == TYPE_IDR || q->type == TYPE_I) start(q);
     }
     if (e->inflight.empty()) return 0;
     PicP front = e->inflight.front();
-    const bool mustWait = !picIn || (int)e->inflight.size() > e->frameThreads + 1;
+    if (!front->started) { xa_fail(X265AMD_EINVAL, "encoder_encode: the first picture in coding order has no task"); return -1; }
+    int waiting = 0;
+    for (auto& q : e->inflight) waiting += !q->started;
+    /* the caller is held when enough pictures run and enough wait behind them (the lookahead may run ahead of the frame tasks by a window of its own) */
+    const bool mustWait = !picIn || (e->running > e->frameThreads && waiting > 2 * e->p.lookaheadDepth + 8);
     if (!mustWait && front->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return 0;
     const int rc = front->done.get();
     e->inflight.pop_front();
+    e->running--;
     if (rc) { xa_fail(rc, "encoder_encode: a frame task failed"); return -1; }
     e->outBytes.swap(front->nalBytes);
     splitNals(e->outBytes, e->nals);

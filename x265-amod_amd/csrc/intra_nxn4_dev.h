@@ -356,7 +356,25 @@ struct Nxn4Lds
     uint8_t fctx[2][X265AMD_CTX_STRIDE];
     uint64_t ffrac[2], fmv[2];
     int peerOk;
+    /* the chained CU's own bits, counted beside the evaluation by the last wavefront: the luma part's running contexts and fraction, the fraction behind the luma
+     * prediction info; the chroma modes' fractions as the chroma decision counted them */
+    uint8_t runCtx[X265AMD_CTX_STRIDE];
+    uint64_t runFrac, runMv;
+    uint64_t cfrac[5];
 };
+
+/* a decided luma unit's share of the CU's bits on the running contexts: its coded block flag (C_QT_CBF + 0: one level down) and its coefficients -- one wavefront */
+XA_DEV void nxn4_count_unit(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int k, const EnTabs& tabs, int lane)
+{
+    const uint32_t cbf = S.ures[k].num_sig != 0;
+    uint64_t add = 0;
+    if (lane == 0) add = cb_bin_t(tabs, S.runCtx + CTX_QT_CBF, cbf);
+    xa_wave_sync();
+    if (cbf) add += wave_coeff_bits_4x4(S.runCtx, S.runCtx, S.lev + 16 * k, 0, 1, (int)S.winMode[k], P.tmpl[0].tu.sign_hide, S.step, lane);
+    xa_wave_sync();
+    if (lane == 0) S.runFrac += add;
+    xa_wave_sync();
+}
 
 /* CUData::getAllowedChromaDir (cudata.cpp:889-907) -> the mode number as the CU stores it (36: derived) for place `idx` of the list */
 XA_DEV uint32_t nxn4_chroma_stored(uint32_t lumaDir, uint32_t idx)
@@ -377,6 +395,7 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
     x265amd_intra_chain* ch = reinterpret_cast<x265amd_intra_chain*>(P.chain);
     x265amd_intra_cu8_result* out = reinterpret_cast<x265amd_intra_cu8_result*>(P.cu_out);
     __syncthreads();
+    XA_CHAIN_START();
     if (tid == 0)
     {
         bool ok = xa_chain_wait(&peer->ready, P.chain_token + 1);
@@ -384,46 +403,31 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
         S.peerOk = ok ? 1 : 0;
     }
     __syncthreads();
+    XA_CHAIN(2);
     if (!S.peerOk)
     {
         if (tid == 0) { out->status = 2; xa_chain_publish(&ch->seq, P.chain_token + 1); }
         return;
     }
     for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_out) / 8); i += nthr) reinterpret_cast<uint64_t*>(&S.peerOut)[i] = reinterpret_cast<const uint64_t*>(&peer->out)[i];
-    for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) { S.fctx[0][i] = P.ctx[i]; S.fctx[1][i] = P.ctx[i]; }
-    __syncthreads();
+    /* both CUs' bits are counted already: the other CU's by its workgroup (the peer record), this one's by the last wavefront beside the evaluation -- what is left is
+     * the chroma mode's share, which the chroma decision counted on contexts that are chroma's alone */
     const x265amd_intra_nxn_out& Q = S.peerOut;
     const uint32_t chromaN = nxn4_chroma_stored(S.winMode[0], S.cw), chroma2 = nxn4_chroma_stored(Q.mode[0], Q.chroma_best);
-    if (wv < 2)
+    for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr)
     {
-        /* wavefront 0: the NxN CU; wavefront 1: the 2Nx2N CU */
-        IntraCuBitsIn in;
-        in.log2_cu = 3; in.nxn = wv == 0; in.code_part_size = 1; in.inter_slice = 0; in.skip_ctx = 0; in.sign_hide = P.tmpl[0].tu.sign_hide; in.subdiv_flag = 0;
-        if (wv == 0)
-        {
-            in.chroma_dir = (uint8_t)chromaN; in.cbf_u = S.cres[S.cw][0].num_sig != 0; in.cbf_v = S.cres[S.cw][1].num_sig != 0;
-            for (int k = 0; k < 4; k++)
-            {
-                in.luma_dir[k] = S.winMode[k]; in.cbf_y[k] = S.ures[k].num_sig != 0; in.lev_y[k] = S.lev + 16 * k;
-                for (int i = 0; i < 3; i++) in.preds[k][i] = S.preds[k][i];
-            }
-            in.lev_u = S.clev[S.cw][0]; in.lev_v = S.clev[S.cw][1];
-        }
-        else
-        {
-            in.chroma_dir = (uint8_t)chroma2; in.cbf_u = Q.cres[0].num_sig != 0; in.cbf_v = Q.cres[1].num_sig != 0;
-            for (int k = 0; k < 4; k++)
-            {
-                in.luma_dir[k] = Q.mode[0]; in.cbf_y[k] = Q.res[0].num_sig != 0; in.lev_y[k] = &Q.levels[0][0];
-                for (int i = 0; i < 3; i++) in.preds[k][i] = S.preds[0][i];         /* the CU's predictors = its first unit's */
-            }
-            in.lev_u = Q.clevels[0]; in.lev_v = Q.clevels[1];
-        }
-        uint64_t mvf = 0, skipf = 0;
-        const uint64_t frac = wave_intra_cu_bits(in, S.fctx[wv], P.scan_frac, &mvf, &skipf, S.step, EnTabs{ S.enBits, S.enLps }, lane);
-        if (lane == 0) { S.ffrac[wv] = frac; S.fmv[wv] = mvf; }
+        const uint8_t c = S.ctxw[S.cw][i];
+        S.fctx[0][i] = c != P.ctx[i] ? c : S.runCtx[i];
+        S.fctx[1][i] = peer->fctx[i];
+    }
+    if (tid == 0)
+    {
+        S.ffrac[0] = S.runFrac + (S.cfrac[S.cw] - P.scan_frac);
+        S.fmv[0] = (uint64_t)P.scan_frac + S.runMv + S.enBits[P.ctx[14] ^ (chromaN == 36 ? 0u : 1u)] + (chromaN != 36 ? (2ull << 15) : 0ull);
+        S.ffrac[1] = peer->ffrac; S.fmv[1] = peer->fmv;
     }
     __syncthreads();
+    XA_CHAIN(3);
     /* the two costs */
     const uint32_t lumaN = (uint32_t)(S.ures[0].nz_dist + S.ures[1].nz_dist + S.ures[2].nz_dist + S.ures[3].nz_dist);
     const uint32_t chromaDN = (uint32_t)(S.cres[S.cw][0].nz_dist + S.cres[S.cw][1].nz_dist), chromaD2 = (uint32_t)(Q.cres[0].nz_dist + Q.cres[1].nz_dist);
@@ -491,7 +495,9 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
         out->status = 1;
     }
     __syncthreads();
+    XA_CHAIN(4);
     if (tid == 0) xa_chain_publish(&ch->seq, P.chain_token + 1);
+    XA_CHAIN(5);
 }
 
 XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_out* po, Nxn4Lds& S, IntraPuShared& L, int tid, int nthr)
@@ -544,6 +550,16 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
     __syncthreads();
     XA_NXN(0);
     pixel* ref = S.ref[wv]; pixel* sw = S.sw[wv];
+    /* a chained CU keeps its last wavefront out of the evaluation: it counts the decided units' bits on the running contexts while the others go on (the coefficient
+     * contexts of the luma units move from unit to unit, so the candidates' estimates -- all from the start contexts -- do not serve) */
+    const int lw = chained ? nwv - 1 : nwv;
+    const bool worker = wv < lw;
+    if (chained)
+    {
+        for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) S.runCtx[i] = P.ctx[i];
+        if (tid == 0) { S.runFrac = P.scan_frac; S.runMv = 0; }
+        __syncthreads();
+    }
     for (int k = 0; k < 4; k++)
     {
         const int ux = 4 * (k & 1), uy = 4 * (k >> 1);
@@ -566,7 +582,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         const int f = S.fenc[(uy + y) * 8 + ux + x];
         const int srcEnergy = nxn4_energy(f, lane);
         /* the scan: a group per mode, SATD of the residual (cu[4x4].sa8d = satd_4x4, pixel.cpp:1171) */
-        for (int m0 = 0; m0 < 35; m0 += 4 * nwv)
+        for (int m0 = 0; m0 < 35 && worker; m0 += 4 * lw)
         {
             const int mode = m0 + wv * 4 + grp, m = mode < 35 ? mode : 34;
             int v = f - nxn4_pred_sample(ref, sw, S.tb, m, dc, y, x, true);
@@ -580,12 +596,14 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         __syncthreads();
         XA_NXN(3);
         const int n = L.num;
+        /* (a chained CU's last wavefront: the unit before this one joins the CU's bit count while the candidates run -- the longest stretch between two barriers) */
+        if (!worker && k > 0) nxn4_count_unit(P, S, k - 1, tabs, lane);
         /* the candidates' chains: candidate c = group * waves + wavefront (the first eight one per wavefront) */
         Chain4 mine = {};
         int myCand = -1;
-        for (int c0 = 0; c0 < n; c0 += 4 * nwv)
+        for (int c0 = 0; c0 < n && worker; c0 += 4 * lw)
         {
-            const int c = c0 + grp * nwv + wv;
+            const int c = c0 + grp * lw + wv;
             const int cc = c < n ? c : n - 1;
             const uint32_t mode = L.modes[cc];
             const int p = nxn4_pred_sample(ref, sw, S.tb, (int)mode, dc, y, x, true);
@@ -671,6 +689,25 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         for (int i = 0; i < 4; i++) if (lumaDir == list[i]) { list[i] = 34; break; }
         const int mi = wv * 4 + grp;                            /* modes 0..3 on wavefront 0, mode 4 on wavefront 1 */
         Chain4 chU = {}, chV = {};
+        if (chained && wv == nwv - 1)
+        {
+            /* the last luma unit, then the bins in front of the transform tree: partition size, the four prev_intra_luma_pred_flags and the mode bits (codePredInfo) */
+            nxn4_count_unit(P, S, 3, tabs, lane);
+            if (lane == 0)
+            {
+                uint8_t* cw = S.runCtx;
+                uint64_t pi = cb_bin_t(tabs, cw + 8, 0u);                           /* C_PART_SIZE: NxN */
+                for (int j = 0; j < 4; j++)
+                {
+                    const uint32_t d = S.winMode[j];
+                    const int pidx = d == S.preds[j][0] ? 0 : (d == S.preds[j][1] ? 1 : (d == S.preds[j][2] ? 2 : -1));
+                    pi += cb_bin_t(tabs, cw + 13, pidx != -1 ? 1u : 0u);             /* C_ADI: the four flags one after the other */
+                    pi += (uint64_t)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
+                }
+                /* S.runMv: what the luma prediction info adds to the start fraction (the chroma mode's share joins when it is known) */
+                S.runMv = pi; S.runFrac += pi;
+            }
+        }
         if (wv < 2)
         {
             const int m = mi < 5 ? mi : 4;
@@ -719,6 +756,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
                 frac += coeffFrac;
                 const unsigned long long dist = (unsigned long long)chU.nzDist + chV.nzDist, energy = (unsigned long long)chU.nzEnergy + chV.nzEnergy;
                 const unsigned long long bits = (uint32_t)(frac >> 15);
+                S.cfrac[m] = frac;
                 S.cost[m] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
             }
         }

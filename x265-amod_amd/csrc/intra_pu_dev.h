@@ -155,8 +155,10 @@ XA_DEV bool nxn_chain_begin(x265amd_intra_nxn_job& sP, int tid, int nthr)
     __shared__ int s_chainOk;
     x265amd_intra_chain* ch = reinterpret_cast<x265amd_intra_chain*>(sP.chain);
     if (sP.chain_first) return true;
+    XA_CHAIN_START();
     if (tid == 0) s_chainOk = xa_chain_wait(&ch->seq, sP.chain_token) ? 1 : 0;
     __syncthreads();
+    XA_CHAIN(sP.chain_role == 1 ? 0 : 1);
     if (!s_chainOk) return false;
     const uint64_t frac = ch->frac & 32767;
     uint8_t m[4];
@@ -193,6 +195,9 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ int s_win;
     __shared__ uint8_t s_winMode[4];
     __shared__ uint32_t s_pickSa8d;
+    __shared__ uint8_t s_preds0[4];                 /* a chained CU (role 2): the first unit's predictors and the chroma modes' fractions, for the CU's own bit count */
+    __shared__ unsigned long long s_cfrac[5];
+    __shared__ uint32_t s_numSig0;
     XA_STAGE(15);
     XA_NXN_START(0);
     __shared__ x265amd_intra_nxn_job sP;           /* the job record: 896 bytes, indexed by the unit -- in LDS, not in registers */
@@ -252,6 +257,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             else { p0 = 0; p1 = 1; p2 = 26; }
         }
         else { p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
+        if (k == 0 && tid == 0) { s_preds0[0] = (uint8_t)p0; s_preds0[1] = (uint8_t)p1; s_preds0[2] = (uint8_t)p2; }
         XA_STAGE(16);
         XA_NXN(1);
         {
@@ -339,6 +345,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             for (int i = 0; i < n; i++) if (s_cost[i] < best) { best = s_cost[i]; w = i; }
             s_win = w; s_winMode[k] = S.modes[w];
             po->mode[k] = S.modes[w]; po->num_cand[k] = (uint8_t)n; po->res[k] = s_res[w];
+            if (k == 0) s_numSig0 = s_res[w].num_sig;
         }
         __syncthreads();
         XA_NXN(6);
@@ -429,6 +436,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             unsigned long long dist = 0, energy = 0;
             for (int pl = 0; pl < 2; pl++) { dist += s_cres[wv][pl].nz_dist; energy += s_cres[wv][pl].nz_energy; }
             const unsigned long long bits = (uint32_t)(frac >> 15);
+            s_cfrac[wv] = frac;
             s_cost[wv] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
         }
     }
@@ -460,8 +468,47 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     }
     __syncthreads();
     XA_NXN(9);
-    /* the other evaluation of a chained CU: the record and the tiles are complete */
-    if (P.chain && P.chain_role == 2 && tid == 0) xa_chain_publish(&reinterpret_cast<x265amd_intra_peer*>(P.peer)->ready, P.chain_token + 1);
+    /* the other evaluation of a chained CU (one 8x8 unit): its own bits as Search::checkIntra counts them at its end (intra_cu_dev.h's walk), while the deciding
+     * workgroup is still busy -- the luma part on the start contexts, the chroma part as the chroma decision left it (chroma's contexts are nobody else's, and a sum
+     * of bins does not care for their order) */
+    if (P.chain && P.chain_role == 2)
+    {
+        x265amd_intra_peer* peer = reinterpret_cast<x265amd_intra_peer*>(P.peer);
+        const int cwIdx = s_win;
+        uint8_t* run = s_ctxw[5];
+        if (wv == 0)
+        {
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) run[b] = P.ctx[b];
+            xa_wave_sync();
+            const uint32_t mode = s_winMode[0];
+            const uint32_t numSigY = s_numSig0;
+            unsigned long long frac = P.scan_frac, mvf = 0;
+            if (lane == 0)
+            {
+                frac += cb_bin_t(tabs, run + 8, 1u);                                                   /* C_PART_SIZE: 2Nx2N */
+                const int pidx = mode == s_preds0[0] ? 0 : (mode == s_preds0[1] ? 1 : (mode == s_preds0[2] ? 2 : -1));
+                frac += cb_bin_t(tabs, run + 13, pidx != -1 ? 1u : 0u);
+                frac += (unsigned long long)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
+                const uint32_t listed = s_cmode[cwIdx];
+                mvf = frac + s_enBits[P.ctx[14] ^ (listed == 36 ? 0u : 1u)] + (listed != 36 ? (2ull << 15) : 0ull);
+                frac += cb_bin_t(tabs, run + CTX_QT_CBF + 1, numSigY != 0 ? 1u : 0u);
+            }
+            xa_wave_sync();
+            frac = __shfl(frac, 0, 64); mvf = __shfl(mvf, 0, 64);
+            if (numSigY) frac += wave_coeff_bits(run, run, P.levels_dst ? reinterpret_cast<const int16_t*>(P.levels_dst) : &po->levels[0][0], unitLog2, 0, 1, (int)mode, P.tmpl[0].tu.sign_hide, s_step, lane);
+            xa_wave_sync();
+            frac += s_cfrac[cwIdx] - P.scan_frac;
+            /* the chroma decision's contexts over the luma walk's: what it moved is chroma's alone */
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE)
+            {
+                const uint8_t c = s_ctxw[cwIdx][b];
+                peer->fctx[b] = c != P.ctx[b] ? c : run[b];
+            }
+            if (lane == 0) { peer->ffrac = frac; peer->fmv = mvf; }
+        }
+        __syncthreads();
+        if (tid == 0) xa_chain_publish(&peer->ready, P.chain_token + 1);
+    }
 }
 
 #endif

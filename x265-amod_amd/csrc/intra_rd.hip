@@ -1405,9 +1405,10 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     /* what this queue has written is out before the other workgroup looks (a signalling command releases), and that one looks (acquire) */
     int rc = X265AMD_OK;
     if (xa_stream_sync(stream) != hipSuccess || xa_stream_fence(helper, XA_CMD_ACQUIRE) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain fence");
-    for (int i = 0; i < 4 && rc == X265AMD_OK; i++)
-        if (x265amd_intra_nxn(helper, &jobs[2 * i + 1], &peers[i].out) != X265AMD_OK || x265amd_intra_nxn(stream, &jobs[2 * i], (x265amd_intra_nxn_out*)R.dNxnOut.p) != X265AMD_OK)
-            rc = xa_fail(X265AMD_EHIP, "intra rd: chain commands");
+    /* one command per role: the four records of a role run one after the other in the same workgroup */
+    if (rc == X265AMD_OK && (x265amd_intra_nxn_list(helper, &jobs[1], 4, 2 * sizeof(x265amd_intra_nxn_job), &peers[0].out) != X265AMD_OK ||
+                             x265amd_intra_nxn_list(stream, &jobs[0], 4, 2 * sizeof(x265amd_intra_nxn_job), (x265amd_intra_nxn_out*)R.dNxnOut.p) != X265AMD_OK))
+        rc = xa_fail(X265AMD_EHIP, "intra rd: chain commands");
     if (rc == X265AMD_OK && xa_stream_sync(stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain");
     if (rc != X265AMD_OK) return rc;
     for (int i = 0; i < 4; i++)

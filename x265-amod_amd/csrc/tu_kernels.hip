@@ -87,10 +87,11 @@ __global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_pu(const x265amd_
     block_intra_pu(job, out, res, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
 }
 
-__global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_nxn(const x265amd_intra_nxn_job* job, x265amd_intra_nxn_out* out)
+__global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_nxn(const x265amd_intra_nxn_job* job, x265amd_intra_nxn_out* out, int n, long strideBytes)
 {
     extern __shared__ __attribute__((aligned(16))) char tu_smem[];
-    block_intra_nxn(job, out, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
+    for (int i = 0; i < n; i++)
+        block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(reinterpret_cast<const char*>(job) + (size_t)i * strideBytes), out, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
 }
 
 /* =========================================================================================================
@@ -181,7 +182,19 @@ extern "C" int x265amd_intra_nxn(void* stream, const x265amd_intra_nxn_job* d_jo
     if (rc) return rc;
     const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_job, (uint64_t)(uintptr_t)d_out, 0, 0, 1 };
     hipError_t e;
-    XA_LAUNCH(e, stream, XA_OP_INTRA_NXN, 1, qa, k_intra_nxn, dim3(1), dim3(64 * INTRA_PU_WAVES), kIntraPuLds, d_job, d_out);
+    XA_LAUNCH(e, stream, XA_OP_INTRA_NXN, 1, qa, k_intra_nxn, dim3(1), dim3(64 * INTRA_PU_WAVES), kIntraPuLds, d_job, d_out, 1, 0l);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_intra_nxn_list(void* stream, const x265amd_intra_nxn_job* d_jobs, int n, size_t stride_bytes, x265amd_intra_nxn_out* d_out)
+{
+    if (!d_jobs || !d_out || n < 1 || n > 64 || (stride_bytes & 7)) return xa_fail(X265AMD_EINVAL, "x265amd_intra_nxn_list: bad arguments");
+    int rc = xa_is_queue(stream) ? X265AMD_OK : tu_configure();
+    if (rc) return rc;
+    const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)d_jobs, (uint64_t)(uintptr_t)d_out, (uint64_t)stride_bytes, 0, n };
+    hipError_t e;
+    XA_LAUNCH(e, stream, XA_OP_INTRA_NXN, 1, qa, k_intra_nxn, dim3(1), dim3(64 * INTRA_PU_WAVES), kIntraPuLds, d_jobs, d_out, n, (long)stride_bytes);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
 }

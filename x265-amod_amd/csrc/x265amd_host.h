@@ -101,6 +101,9 @@ struct XaRowHooks
      * that reads reference samples (xa_ref_guard_*): the per-CTU gate covers ordinary vectors, this covers the long ones. */
     int (*ctu_wait)(void* ctx, int row, int col); void (*before_ctu)(void* ctx, int row, int col); void (*after_ctu)(void* ctx, int row, int col);
     int (*ref_wait)(void* ctx, int pic, int y_min, int y_max, int x_max);
+    /* the picture's place in coding order + 1 (0: take the order of the calls): its rows' priority among the row tasks of all pictures in flight -- a picture
+     * started ahead of its turn (an I picture: nothing to wait for) must not push aside the rows of the pictures everybody else waits for */
+    uint64_t order;
 };
 /* the guards (csrc/ctu_analysis.hip): wait until the row task's hooks (if it has any) let the jobs' reference samples be read; 0, or -1 when a picture failed */
 int xa_ref_guard_mc(const x265amd_mc_job* jobs, int n);

@@ -60,7 +60,8 @@ struct alignas(128) XaRingHost
     uint64_t resident;                          /* ticks of the 100 MHz clock between the workgroup's start and its exit, summed over server generations */
     uint64_t pad2[15];
     uint64_t nxn[40];                           /* X265AMD_QUEUE_PROF: the fused intra command by kind (four 4x4 units / one unit of 8 / 16 / 32) x stage: ticks */
-    uint64_t pad3[8];
+    uint64_t chain[8];                          /* X265AMD_QUEUE_PROF: chained 8x8 CUs, ticks: [0] the deciding command waiting for the chain, [1] the other command waiting for
+                                                   the chain, [2] waiting for the other evaluation, [3] its record + both CUs' bits, [4] costs + the winner's samples + result, [5] publishing */
 };
 
 struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, second array, results, extra, count) shapes of the job-list kernels */
