@@ -59,8 +59,10 @@ def bench_clip(first, count, gop=0):
     return T.survey_clip(W, H, 8, 2, first, count, gop)
 
 
-def encode(T, L, frames, first_frame, keyint, sync, timed=True):
-    """the clip through the encoder object; returns (byte stream, seconds of the encode loop).  `sync` brackets the timed region."""
+def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
+    """the clip through the encoder object; returns (byte stream, seconds of the encode loop).  `sync` brackets the timed region.
+    shard = (rank, world): frame per GPU with row publication -- this object codes the pictures whose place in coding order is rank modulo
+    world, a pump thread beside the encode loop broadcasts / imports every finished CTU row (x265-amod_amd/frame_rows.py); the stream holds the owned pictures only."""
     lib = L.lib
     lib.x265amd_encoder_open.restype = C.c_void_p
     lib.x265amd_encoder_open.argtypes = [C.POINTER(T.EncParam)]
@@ -77,6 +79,8 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True):
     prm.firstFrame = first_frame
     if keyint:
         prm.keyframeMax = keyint
+    if shard:
+        prm.shardRank, prm.shardCount = shard
     enc = lib.x265amd_encoder_open(C.byref(prm))
     if not enc:
         raise SystemExit("x265amd_encoder_open: %s" % lib.x265amd_last_error().decode())
@@ -97,7 +101,25 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True):
     try:
         if timed:
             sync()
+        pump_thread, pump_err = None, []
+        if shard:
+            import threading
+            import torch
+            import __graft_entry__ as g
+            fr = g.load_package().frame_rows
+            dev = "cuda:%d" % torch.cuda.current_device()
+
+            def run_pump():
+                try:
+                    torch.cuda.set_device(dev)
+                    rows = fr.EncoderRows(lib, enc, dev)
+                    fr.pump(rows.export_row, rows.import_row, rows.shapes, len(pics), rows.rows, dev, rank=shard[0], world=shard[1])
+                except BaseException as exc:        # noqa: B902
+                    pump_err.append(repr(exc))
+            pump_thread = threading.Thread(target=run_pump)
         t0 = time.perf_counter()
+        if pump_thread:
+            pump_thread.start()
         for pic, _ in pics:
             ret = lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), C.byref(pic), None)
             assert ret >= 0, lib.x265amd_last_error()
@@ -113,6 +135,10 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True):
             coded += 1
             for i in range(nnal.value):
                 stream.extend(bytes(nal[i].payload[:nal[i].sizeBytes]))
+        if pump_thread:
+            pump_thread.join()
+            if pump_err:
+                raise SystemExit("the row pump failed: %s" % pump_err[0])
         if timed:
             sync()
         dt = time.perf_counter() - t0
@@ -212,6 +238,8 @@ def main():
     ap.add_argument("--no-kernel-workload", action="store_true", help="skip bench_kernels.py (profiling passes of the encoder alone)")
     ap.add_argument("--res", choices=["1080p", "2160p"], default="1080p", help="1080p = BASELINE.json configs[1] (the bench line); 2160p: the same encode at 3840x2160 (informational)")
     ap.add_argument("--no-2160p", action="store_true", help="skip the 3840x2160 encode that the 1080p single-GPU run reports beside the bench line (`also_2160p`)")
+    ap.add_argument("--shard", choices=["gops", "frames"], default="gops", help="--gpus N > 1: gops = a closed GOP per GPU (weak scaling, no data-path exchange); frames = ONE clip, picture k in "
+                    "coding order coded by rank k mod N, finished CTU rows broadcast over RCCL (strong scaling; SURVEY section 8e as written, DESIGN.md section 6)")
     ap.add_argument("--no-scene-clip", action="store_true", help="skip the 60-frame clip with both re-seeds inside that the 1080p single-GPU run reports beside the bench line (`scene_change_clip`)")
     args = ap.parse_args()
 
@@ -240,12 +268,17 @@ def main():
 
     L = T.load_hip(8)
     K, Wm = args.steps, args.warmup
-    # rank r codes GOP r: frames r K .. r K + K - 1 of the clip, IDR first (closed GOPs need nothing from each other)
-    frames = bench_clip(0, K, gop=rank)
+    # --shard gops: rank r codes GOP r, frames r K .. r K + K - 1 of the clip, IDR first (closed GOPs need nothing from each other);
+    # --shard frames: every rank is fed the same K frames and codes the pictures whose place in coding order is its rank modulo the world
+    by_frames = args.shard == "frames"
+    frames = bench_clip(0, K, gop=0 if by_frames else rank)
     if Wm > 0:
         encode(T, L, bench_clip(0, Wm), 0, 0, sync, timed=False)
     queue_stats(L, True)                 # the counters of the resident kernel from here on: the timed encode alone
-    stream, dt = encode(T, L, frames, rank * K, K if world > 1 else 0, sync)
+    if by_frames:
+        stream, dt = encode(T, L, frames, 0, 0, sync, shard=(rank, world))
+    else:
+        stream, dt = encode(T, L, frames, rank * K, K if world > 1 else 0, sync)
     qstats = queue_stats(L, True)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -278,13 +311,14 @@ def main():
         alg = payload * (2 * n_i + (2 + min(REFS, 2)) * n_p + 4 * n_b)                        # short clip: P frames see up to the pictures coded so far
         line = {
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
-            "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "value": (K if by_frames else world * K) / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,
+            "higher_is_better": True, "scaling": "strong" if by_frames and world > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + fixed mini-GOPs of %d B frames), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
                                    "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
-                                   "the lookahead's decisions fixed (no b-adapt / scenecut / AQ / cutree / weighted prediction: not built yet, switched off on both sides)" % (W, H, K, BFRAMES, REFS, QP),
-                       "frames_per_step_per_gpu": 1, "parallelism": "closed GOP per GPU x%d" % world if world > 1 else "one encoder object",
+                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20) and the rest of the lookahead's decisions fixed (b-adapt 0; AQ / cutree are off in CQP by the reference's own rules; "
+                                   "no weighted prediction, B pyramid, open GOP: not built, switched off on both sides)" % (W, H, K, BFRAMES, REFS, QP),
+                       "frames_per_step_per_gpu": 1, "parallelism": ("picture k in coding order on GPU k mod %d, CTU rows broadcast over RCCL" % world if by_frames else "closed GOP per GPU x%d" % world) if world > 1 else "one encoder object",
                        "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},
             "bit_exact_vs_reference_encoder": same,
             "stream": {"bytes_per_gop": [s[0] for s in sizes], "md5_per_gop": [s[1] for s in sizes]},

@@ -59,6 +59,11 @@ typedef struct x265amd_param
                                              * since the last keyframe), the picture before it P.  scenecutBias is the reference's default (5) */
     int32_t lookaheadDepth;                 /* param.lookaheadDepth (--rc-lookahead): pictures the slice-type decision looks at (only read when scenecutThreshold > 0) */
     int32_t keyframeMin;                    /* param.keyframeMin (--min-keyint); 0 = the reference's default min(fps, keyframeMax / 10) (encoder.cpp:3658-3663) */
+    int32_t shardRank, shardCount;          /* frame-per-GPU: with shardCount > 1 this object codes the pictures whose place in CODING order
+                                             * k satisfies k % shardCount == shardRank (the reference's frame k -> frame encoder k mod G, encoder.cpp:1872) and
+                                             * takes the others' finished CTU rows from the objects that code them (x265amd_encoder_export_row / _import_row).
+                                             * Every object of the set is fed every picture (slice types, DPB and reference lists are decided identically by all);
+                                             * the stream is the owners' NAL units in coding order.  0 / 0 or count 1: one object codes everything */
     int32_t reserved;
 } x265amd_param;
 
@@ -82,6 +87,35 @@ int x265amd_encoder_headers(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t
  * pic_out's planes when pic_out is given), 0 when none is ready yet (or the flush is complete), -1 on error. */
 int x265amd_encoder_encode(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t* pi_nal, const x265amd_picture* pic_in, x265amd_picture* pic_out);
 void x265amd_encoder_close(x265amd_encoder* enc);
+
+/* ---- frame-per-GPU: a finished CTU row travels from the object that codes a picture to the objects that reference it ----
+ * What a reference picture's consumers read, published at the reference's m_reconRowFlag point (framefilter.cpp:654-664; consumers wait at
+ * frameencoder.cpp:893-908): the filtered samples of the CTU row in the three planes with their side margins (and the top / bottom margin with the first / last
+ * row), and the row's unit and motion records (the co-located motion field, cudata.cpp:1858-1862; the depths topSkipMinDepth reads).  The flat picture buffers of all
+ * objects of a set have one geometry, so a row is three byte ranges of the picture buffer plus two ranges of the host maps. */
+typedef struct x265amd_row_export
+{
+    uint64_t coding_index; int32_t ctu_row, reserved;
+    const void* src[3];                 /* DEVICE memory: where the row's bytes of plane 0 / 1 / 2 are read from -- the exporting object's picture, or wherever the
+                                         * transport has put them on the importing side (a receive buffer) */
+    uint64_t plane_offset[3], plane_bytes[3];       /* the row's byte range in each plane, relative to the start of the picture's flat buffer (Y | U | V, padded):
+                                                     * where the importing object puts them */
+    const void* units; uint64_t units_bytes;        /* HOST memory: the row's x265amd_cu_unit / x265amd_mv_unit records */
+    const void* motion; uint64_t motion_bytes;
+    uint64_t map_offset_units, map_offset_motion;   /* where those records sit in the importing object's maps (bytes) */
+} x265amd_row_export;
+/* The object that codes picture `coding_index`: blocks until CTU row `ctu_row` of it is final (at most timeout_ms), then describes it.  Returns 0; 1 when the picture is
+ * not known yet (not handed over by the lookahead: ask again); -1 on error / time-out / a failed picture.  The described memory stays valid while the picture can be
+ * referenced. */
+int x265amd_encoder_export_row(x265amd_encoder* enc, uint64_t coding_index, int ctu_row, x265amd_row_export* out, int timeout_ms);
+/* An object that does not code the picture: copies the row in (src[] may be another object's picture -- the same device or a peer of this process -- or the buffer
+ * this rank received the row in) and opens the gates of the pictures that wait for it.  Same return values. */
+int x265amd_encoder_import_row(x265amd_encoder* enc, const x265amd_row_export* row);
+/* the ranges of CTU row `ctu_row` (offsets and byte counts; no addresses): what an importing rank sizes its receive buffers by.  Returns 0 or -1. */
+int x265amd_encoder_row_geometry(const x265amd_encoder* enc, int ctu_row, x265amd_row_export* out);
+/* the number of CTU rows of a picture, and whether this object codes picture `coding_index` */
+int x265amd_encoder_ctu_rows(const x265amd_encoder* enc);
+int x265amd_encoder_owns(const x265amd_encoder* enc, uint64_t coding_index);
 
 #ifdef __cplusplus
 }

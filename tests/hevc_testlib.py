@@ -3020,7 +3020,12 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("reserved", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
+    _fields_ = [("coding_index", C.c_uint64), ("ctu_row", C.c_int32), ("reserved", C.c_int32), ("src", C.c_void_p * 3), ("plane_offset", C.c_uint64 * 3), ("plane_bytes", C.c_uint64 * 3),
+                ("units", C.c_void_p), ("units_bytes", C.c_uint64), ("motion", C.c_void_p), ("motion_bytes", C.c_uint64), ("map_offset_units", C.c_uint64), ("map_offset_motion", C.c_uint64)]
 
 
 class EncNal(C.Structure):
@@ -3087,6 +3092,122 @@ def encoder_run(L, planes_per_frame, width, height, want_headers=True, **overrid
                 break
     finally:
         lib.x265amd_encoder_close(enc)
+    return np.frombuffer(bytes(stream), np.uint8), coded
+
+
+def encoder_run_sharded(L, planes_per_frame, width, height, count, **overrides):
+    """`count` encoder objects on one GPU, object r coding the pictures whose place in coding order is r modulo count (x265amd_param.shardRank / shardCount); a pump
+    thread carries every finished CTU row from the object that codes it to the others (x265amd_encoder_export_row / _import_row, the calls
+    x265-amod_amd/frame_rows.py makes between ranks).  Returns (the stream assembled from the owners' NAL units in coding order, coded pictures as encoder_run gives
+    them, taken from the owners)"""
+    import threading
+    lib = L.lib
+    lib.x265amd_encoder_open.restype = C.c_void_p
+    lib.x265amd_encoder_open.argtypes = [C.POINTER(EncParam)]
+    lib.x265amd_encoder_headers.argtypes = [C.c_void_p, C.POINTER(C.POINTER(EncNal)), C.POINTER(C.c_uint32)]
+    lib.x265amd_encoder_encode.argtypes = [C.c_void_p, C.POINTER(C.POINTER(EncNal)), C.POINTER(C.c_uint32), C.POINTER(EncPicture), C.POINTER(EncPicture)]
+    lib.x265amd_encoder_close.argtypes = [C.c_void_p]
+    lib.x265amd_param_default.argtypes = [C.POINTER(EncParam)]
+    lib.x265amd_encoder_export_row.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(RowExport), C.c_int]
+    lib.x265amd_encoder_import_row.argtypes = [C.c_void_p, C.POINTER(RowExport)]
+    lib.x265amd_encoder_ctu_rows.argtypes = [C.c_void_p]
+    lib.x265amd_last_error.restype = C.c_char_p
+    encs = []
+    for r in range(count):
+        prm = EncParam()
+        lib.x265amd_param_default(C.byref(prm))
+        prm.sourceWidth, prm.sourceHeight = width, height
+        for k, v in overrides.items():
+            setattr(prm, k, v)
+        prm.shardRank, prm.shardCount = r, count
+        enc = lib.x265amd_encoder_open(C.byref(prm))
+        assert enc, lib.x265amd_last_error()
+        encs.append(enc)
+    header = bytearray()
+    nal = C.POINTER(EncNal)(); nnal = C.c_uint32(0)
+    assert lib.x265amd_encoder_headers(encs[0], C.byref(nal), C.byref(nnal)) > 0
+    for i in range(nnal.value):
+        header += bytes(nal[i].payload[:nal[i].sizeBytes])
+    dt = planes_per_frame[0][0].dtype
+    n = len(planes_per_frame)
+    outputs = [[] for _ in range(count)]          # per object: (nal bytes, (poc, type, qp, planes)) per coded picture, coding order
+    errors = []
+
+    def feeder(r):
+        try:
+            enc = encs[r]
+            nal = C.POINTER(EncNal)(); nnal = C.c_uint32(0)
+
+            def call(pic):
+                bufs = [np.zeros((height, width), dt), np.zeros((height // 2, width // 2), dt), np.zeros((height // 2, width // 2), dt)]
+                out = EncPicture()
+                for k in range(3):
+                    out.planes[k] = bufs[k].ctypes.data; out.stride[k] = bufs[k].strides[0]
+                ret = lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), C.byref(pic) if pic is not None else None, C.byref(out))
+                assert ret >= 0, lib.x265amd_last_error()
+                if ret:
+                    outputs[r].append((b"".join(bytes(nal[i].payload[:nal[i].sizeBytes]) for i in range(nnal.value)), (out.poc, out.sliceType, out.qp, bufs)))
+                return ret
+            for planes in planes_per_frame:
+                pic = EncPicture()
+                keep = [np.ascontiguousarray(pl) for pl in planes]
+                for k in range(3):
+                    pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
+                call(pic)
+            while call(None):
+                pass
+        except BaseException as exc:        # noqa: B902
+            errors.append(("feeder %d" % r, repr(exc)))
+
+    def pump():
+        try:
+            import time
+            rows = lib.x265amd_encoder_ctu_rows(encs[0])
+            for k in range(n):
+                src = k % count
+                for row in range(rows):
+                    d = RowExport()
+                    while True:
+                        rc = lib.x265amd_encoder_export_row(encs[src], k, row, C.byref(d), 120000)
+                        assert rc >= 0, lib.x265amd_last_error()
+                        if rc == 0 or errors:
+                            break
+                        time.sleep(0.0005)
+                    for r in range(count):
+                        while r != src and not errors:
+                            rc = lib.x265amd_encoder_import_row(encs[r], C.byref(d))
+                            assert rc >= 0, lib.x265amd_last_error()
+                            if rc == 0:
+                                break
+                            time.sleep(0.0005)
+                    if errors:
+                        return
+        except BaseException as exc:        # noqa: B902
+            errors.append(("pump", repr(exc)))
+
+    threads = [threading.Thread(target=feeder, args=(r,)) for r in range(count)] + [threading.Thread(target=pump)]
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(600)
+        assert not errors, errors
+        assert all(not t.is_alive() for t in threads), "a feeder or the pump did not finish"
+    finally:
+        if all(not t.is_alive() for t in threads):
+            for enc in encs:
+                lib.x265amd_encoder_close(enc)
+    assert all(len(o) == n for o in outputs), [len(o) for o in outputs]
+    stream = bytearray(header)
+    coded = []
+    for k in range(n):
+        nalBytes, rec = outputs[k % count][k]
+        stream += nalBytes
+        coded.append(rec)
+        for r in range(count):
+            if r != k % count:
+                assert outputs[r][k][0] == b"", "an object emitted NAL units for a picture it does not code"
+                assert outputs[r][k][1][:3] == rec[:3] and all(np.array_equal(a, b) for a, b in zip(outputs[r][k][1][3], rec[3])), "the imported picture differs from the owner's"
     return np.frombuffer(bytes(stream), np.uint8), coded
 
 

@@ -85,3 +85,77 @@ def test_gop_sharding_schedule_and_gather_world2():
     out = mgr.dict()
     mp.spawn(_gop_worker, args=(2, port, out), nprocs=2, join=True)
     assert out[0] and out[1]
+
+
+# ---- frame-per-GPU with row publication (x265-amod_amd/frame_rows.py): the schedule, with arrays standing in for the encoder objects ----
+ROWS, PICS = 5, 7
+
+
+def _row_bytes(k, row, i, n):
+    return torch.from_numpy(np.random.default_rng(k * 1000 + row * 10 + i).integers(0, 256, n, dtype=np.uint8))
+
+
+def _shapes(row):
+    # first / last rows carry the top / bottom margin: three row geometries, as in the encoder
+    return [4096 + (512 if row in (0, ROWS - 1) else 0), 1024, 1024, 160, 96]
+
+
+class _FakeEncoder:
+    """holds the rows it has (its own and the imported ones); a row of picture k can only be coded when rows <= row + 1 of picture k - 1 are there"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.have, self.order = rank, world, {}, []
+
+    def export_row(self, k, row):
+        assert k % self.world == self.rank
+        if k:
+            for r in range(min(row + 2, ROWS)):
+                assert (k - 1, r) in self.have, "row %d of picture %d coded before row %d of its reference arrived" % (row, k, r)
+        t = [_row_bytes(k, row, i, n) for i, n in enumerate(_shapes(row))]
+        self.have[(k, row)] = [x.clone() for x in t]
+        self.order.append((k, row, "export"))
+        return t
+
+    def import_row(self, k, row, tensors):
+        assert k % self.world != self.rank and (k, row) not in self.have
+        self.have[(k, row)] = [x.clone() for x in tensors]
+        self.order.append((k, row, "import"))
+
+
+def _rows_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    fr = g.load_package().frame_rows
+    enc = _FakeEncoder(rank, world)
+    fr.pump(enc.export_row, enc.import_row, _shapes, PICS, ROWS, "cpu")
+    ok = len(enc.have) == PICS * ROWS
+    for (k, row), t in enc.have.items():
+        ok &= all(torch.equal(a, _row_bytes(k, row, i, n)) for i, (a, n) in enumerate(zip(t, _shapes(row))))
+    # every rank saw the rows in coding order, top row first, and took part in every one of them
+    ok &= [(k, r) for k, r, _ in enc.order] == [(k, r) for k in range(PICS) for r in range(ROWS)]
+    ok &= all((what == "export") == (fr.owner_of(k, world) == rank) for k, r, what in enc.order)
+    dist.barrier()
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_row_publication_schedule_gloo_world2():
+    """x265-amod_amd/frame_rows.py: picture k in coding order is coded by rank k % 2; each finished CTU row is broadcast by its owner and imported by the other rank
+    before that rank codes the rows that reference it"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rows_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] and out[1]
+
+
+def test_row_publication_single_rank_is_a_no_op():
+    import __graft_entry__ as g
+    fr = g.load_package().frame_rows
+    enc = _FakeEncoder(0, 1)
+    fr.pump(enc.export_row, enc.import_row, _shapes, 3, ROWS, "cpu", rank=0, world=1)
+    assert len(enc.have) == 3 * ROWS and all(w == "export" for _, _, w in enc.order)

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 184 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -251,3 +251,24 @@ def test_scene_cut_detection(tag):
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
         assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
     assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,count", [("ft_b/", 2), ("sc_i/", 2), ("ft_vp/", 3)])
+def test_frame_per_gpu_objects_alternate_pictures(tag, count):
+    """SURVEY section 8e as written, on one GPU: `count` encoder objects, object r coding the pictures whose place in coding order is r modulo count, every finished
+    CTU row carried from its owner to the others through x265amd_encoder_export_row / _import_row (what x265-amod_amd/frame_rows.py broadcasts between ranks).
+    The owners' NAL units in coding order are the single object's stream -- the reference's -- and every object ends up with the same reconstructions."""
+    if tag in T.SC_CASES:
+        g = np.load(SC_GOLD)
+        (w, h), n, depth, _, cfg, _ = T.SC_CASES[tag]
+        frames = T.scene_case_frames(tag)
+    else:
+        g = np.load(FT_GOLD)
+        (w, h), n, depth, kind, cfg, _ = T.FT_CASES[tag]
+        frames = T.encoder_ft_frames(tag)
+    stream, coded = T.encoder_run_sharded(T.load_hip(depth), frames, w, h, count, **cfg)
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc

@@ -7,3 +7,4 @@ fails loudly if the HIP library has not been built.
 from .capi import load, lib_path, X265AmdError  # noqa: F401
 from . import frame_shard  # noqa: F401
 from . import gop_shard  # noqa: F401
+from . import frame_rows  # noqa: F401

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <future>
@@ -41,6 +42,8 @@ struct Pic
     int poc = 0, type = 0, sliceQp = 0;
     uint64_t codingOrder = 0;                           /* its place in coding order (the row tasks' priority) */
     bool started = false;
+    bool owned = true;                                  /* frame-per-GPU: coded by this object; else its rows are imported (importedRows under `mu`) */
+    int importedRows = 0;
     bool hasReferences = false;
     pixel* dSrc = nullptr; pixel* dRec = nullptr;       /* flat Y | U | V padded buffers (pooled device memory) */
     std::vector<x265amd_cu_unit> units;
@@ -103,6 +106,10 @@ struct x265amd_encoder
     std::deque<PicP> inflight;                          /* coding order: prepared pictures, their frame tasks running or (frame-parallel only) still to start */
     uint64_t codingCount = 0;
     int running = 0;                                    /* frame tasks started and not yet collected */
+    std::mutex importMu;
+    hipStream_t importStream = nullptr;                 /* frame-per-GPU: rows of pictures coded elsewhere are copied in on it */
+    std::mutex byCodingMu;
+    std::map<uint64_t, PicP> byCoding;                  /* the last pictures by their place in coding order (row export / import) */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
     bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
@@ -125,6 +132,7 @@ struct x265amd_encoder
         if (dDbUnits) (void)hipFree(dDbUnits);
         xa_scratch_free(dSaoTmp);
         if (laStream) (void)hipStreamDestroy(laStream);
+        if (importStream) (void)hipStreamDestroy(importStream);
     }
     uint64_t planeAddr(const pixel* base, int k) const { return (uint64_t)(uintptr_t)(base + org[k]); }
 
@@ -259,6 +267,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     e->frameCount = p->firstFrame; e->lastKeyframe = p->firstFrame - p->keyframeMax; e->lastIDR = p->firstFrame;
     if (p->scenecutThreshold < 0 || p->scenecutThreshold > 100 || p->lookaheadDepth < 0 || p->lookaheadDepth > 250 || p->keyframeMin < 0 || p->keyframeMin > p->keyframeMax)
     { xa_fail(X265AMD_EINVAL, "encoder_open: scenecutThreshold outside 0..100, lookaheadDepth outside 0..250 or keyframeMin outside 0..keyframeMax"); return nullptr; }
+    if (p->shardCount < 0 || p->shardCount > 64 || (p->shardCount > 1 && (p->shardRank < 0 || p->shardRank >= p->shardCount || p->frameNumThreads <= 1)))
+    { xa_fail(X265AMD_EINVAL, "encoder_open: shardRank / shardCount (frame-per-GPU needs 0 <= rank < count and frameNumThreads > 1: rows are published by pictures coded in parallel)"); return nullptr; }
     e->lookahead = p->scenecutThreshold > 0;
     {
         /* Encoder::configure (encoder.cpp:3658-3663) */
@@ -316,6 +326,91 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     if (!n || n > e->headerBytes.size()) { xa_fail(X265AMD_EINVAL, "encoder_open: stream headers"); return nullptr; }
     e->headerBytes.resize(n);
     return e.release();
+}
+
+/* ---- frame-per-GPU: rows of a picture between the objects of a set (include/x265amd_encoder.h) ---- */
+static PicP picByCoding(x265amd_encoder* e, uint64_t k)
+{
+    std::lock_guard<std::mutex> lk(e->byCodingMu);
+    auto it = e->byCoding.find(k);
+    return it == e->byCoding.end() ? PicP() : it->second;
+}
+static void rowRanges(const x265amd_encoder& e, int row, uint64_t off[3], uint64_t bytes[3])
+{
+    for (int k = 0; k < 3; k++)
+    {
+        const int sh = k ? 1 : 0, my = e.marginY >> sh, mx = e.marginX >> sh, h = e.H >> sh, rowH = 64 >> sh;
+        const intptr_t st = k ? e.cstride : e.stride;
+        const int y0 = row == 0 ? -my : row * rowH, y1 = row == e.ctuH - 1 ? h + my : std::min(h, (row + 1) * rowH);
+        const int64_t first = (int64_t)e.org[k] + (int64_t)y0 * st - mx;
+        off[k] = (uint64_t)first * sizeof(pixel);
+        bytes[k] = (uint64_t)((int64_t)(y1 - y0) * st) * sizeof(pixel);
+    }
+}
+extern "C" int x265amd_encoder_ctu_rows(const x265amd_encoder* e) { return e ? e->ctuH : -1; }
+extern "C" int x265amd_encoder_row_geometry(const x265amd_encoder* e, int row, x265amd_row_export* out)
+{
+    if (!e || !out || row < 0 || row >= e->ctuH) return xa_fail(X265AMD_EINVAL, "encoder_row_geometry: bad arguments"), -1;
+    memset(out, 0, sizeof(*out));
+    out->ctu_row = row;
+    rowRanges(*e, row, out->plane_offset, out->plane_bytes);
+    const size_t u0 = (size_t)row * 16 * e->w4, u1 = (size_t)std::min(e->h4, (row + 1) * 16) * e->w4;
+    out->units_bytes = (u1 - u0) * sizeof(x265amd_cu_unit); out->map_offset_units = u0 * sizeof(x265amd_cu_unit);
+    out->motion_bytes = (u1 - u0) * sizeof(x265amd_mv_unit); out->map_offset_motion = u0 * sizeof(x265amd_mv_unit);
+    return 0;
+}
+extern "C" int x265amd_encoder_owns(const x265amd_encoder* e, uint64_t k) { return e ? (e->p.shardCount <= 1 || (int)(k % (uint64_t)e->p.shardCount) == e->p.shardRank) : 0; }
+extern "C" int x265amd_encoder_export_row(x265amd_encoder* e, uint64_t codingIndex, int row, x265amd_row_export* out, int timeoutMs)
+{
+    if (!e || !out || row < 0 || row >= e->ctuH) return xa_fail(X265AMD_EINVAL, "encoder_export_row: bad arguments"), -1;
+    if (!e->frameParallel) return xa_fail(X265AMD_EINVAL, "encoder_export_row: rows are published by objects that code pictures in parallel (frameNumThreads > 1)"), -1;
+    PicP pic = picByCoding(e, codingIndex);
+    if (!pic) return 1;
+    if (!pic->owned) return xa_fail(X265AMD_EINVAL, "encoder_export_row: this object does not code that picture"), -1;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (pic->published(row) < e->W)
+    {
+        if (pic->failed.load()) return xa_fail(X265AMD_EHIP, "encoder_export_row: the picture failed"), -1;
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeoutMs) return xa_fail(X265AMD_EHIP, "encoder_export_row: time-out"), -1;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    memset(out, 0, sizeof(*out));
+    out->coding_index = codingIndex; out->ctu_row = row;
+    rowRanges(*e, row, out->plane_offset, out->plane_bytes);
+    for (int k = 0; k < 3; k++) out->src[k] = (const uint8_t*)pic->finalPlanes() + out->plane_offset[k];
+    const size_t u0 = (size_t)row * 16 * e->w4, u1 = (size_t)std::min(e->h4, (row + 1) * 16) * e->w4;
+    out->units = pic->units.data() + u0; out->units_bytes = (u1 - u0) * sizeof(x265amd_cu_unit); out->map_offset_units = u0 * sizeof(x265amd_cu_unit);
+    out->motion = pic->motion.data() + u0; out->motion_bytes = (u1 - u0) * sizeof(x265amd_mv_unit); out->map_offset_motion = u0 * sizeof(x265amd_mv_unit);
+    return 0;
+}
+extern "C" int x265amd_encoder_import_row(x265amd_encoder* e, const x265amd_row_export* in)
+{
+    if (!e || !in || in->ctu_row < 0 || in->ctu_row >= e->ctuH || !in->src[0] || !in->src[1] || !in->src[2] || !in->units || !in->motion) return xa_fail(X265AMD_EINVAL, "encoder_import_row: bad arguments"), -1;
+    PicP pic = picByCoding(e, in->coding_index);
+    if (!pic) return 1;
+    if (pic->owned) return xa_fail(X265AMD_EINVAL, "encoder_import_row: this object codes that picture itself"), -1;
+    uint64_t off[3], bytes[3];
+    rowRanges(*e, in->ctu_row, off, bytes);
+    for (int k = 0; k < 3; k++)
+        if (off[k] != in->plane_offset[k] || bytes[k] != in->plane_bytes[k]) return xa_fail(X265AMD_EINVAL, "encoder_import_row: the row comes from a picture of another geometry"), -1;
+    if (in->map_offset_units + in->units_bytes > pic->units.size() * sizeof(x265amd_cu_unit) || in->map_offset_motion + in->motion_bytes > pic->motion.size() * sizeof(x265amd_mv_unit))
+        return xa_fail(X265AMD_EINVAL, "encoder_import_row: map range"), -1;
+    xa_thread_device();
+    uint8_t* dst = (uint8_t*)(pic->dFin ? pic->dFin : pic->dRec);
+    {
+        /* a stream of the object's own, waited for: a device-to-device hipMemcpy may return before the bytes have landed, and the counter below lets readers in */
+        std::lock_guard<std::mutex> lk(e->importMu);
+        if (!e->importStream && hipStreamCreateWithFlags(&e->importStream, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_import_row: stream"), -1;
+        for (int k = 0; k < 3; k++)
+            if (hipMemcpyAsync(dst + off[k], in->src[k], bytes[k], hipMemcpyDefault, e->importStream) != hipSuccess) { pic->fail(); return xa_fail(X265AMD_EHIP, "encoder_import_row: copy"), -1; }
+        if (hipStreamSynchronize(e->importStream) != hipSuccess) { pic->fail(); return xa_fail(X265AMD_EHIP, "encoder_import_row: copy"), -1; }
+    }
+    memcpy((uint8_t*)pic->units.data() + in->map_offset_units, in->units, in->units_bytes);
+    memcpy((uint8_t*)pic->motion.data() + in->map_offset_motion, in->motion, in->motion_bytes);
+    pic->publish(in->ctu_row, e->W);
+    { std::lock_guard<std::mutex> lk(pic->mu); pic->importedRows++; }
+    pic->cv.notify_all();
+    return 0;
 }
 
 extern "C" void x265amd_encoder_close(x265amd_encoder* e) { delete e; }
@@ -1342,7 +1437,9 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         e->ready.pop_front();
         if (e->prepare(pic)) return -1;
         pic->codingOrder = e->codingCount++;
+        pic->owned = e->p.shardCount <= 1 || (int)(pic->codingOrder % (uint64_t)e->p.shardCount) == e->p.shardRank;
         e->inflight.push_back(pic);
+        { std::lock_guard<std::mutex> lk(e->byCodingMu); e->byCoding[pic->codingOrder] = pic; while (e->byCoding.size() > 64) e->byCoding.erase(e->byCoding.begin()); }
     }
     const bool timing = getenv("X265AMD_TIMING") != nullptr;
     auto start = [e, timing](const PicP& pic) {
@@ -1351,6 +1448,16 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         pic->done = std::async(std::launch::async, [e, pic, prev, timing]() {
             xa_thread_device();
             const auto t0 = std::chrono::steady_clock::now();
+            if (!pic->owned)
+            {
+                /* another object codes this picture: its rows arrive through x265amd_encoder_import_row */
+                std::unique_lock<std::mutex> lk(pic->mu);
+                const bool ok = pic->cv.wait_for(lk, std::chrono::seconds(300), [&] { return pic->importedRows >= e->ctuH || pic->failed.load(); });
+                if (!ok || pic->failed.load()) { lk.unlock(); pic->fail(); return xa_fail(X265AMD_EHIP, "encoder: a picture coded elsewhere did not arrive"); }
+                lk.unlock();
+                xa_scratch_free(pic->dSrc); pic->dSrc = nullptr;
+                return (int)X265AMD_OK;
+            }
             const int rc = e->frameParallel ? e->runFrameParallel(pic) : e->runFrame(pic, prev);
             if (timing)
                 fprintf(stderr, "x265amd: poc %d type %d qp %d: %.2f ms\n", pic->poc, pic->type, pic->sliceQp,

@@ -360,8 +360,74 @@ struct Nxn4Lds
      * prediction info; the chroma modes' fractions as the chroma decision counted them */
     uint8_t runCtx[X265AMD_CTX_STRIDE];
     uint64_t runFrac, runMv;
-    uint64_t cfrac[5];
+    uint64_t cfrac[5], ccoef[5];
 };
+
+/* estIntraPredChromaQT for the one 4x4 block per plane of an 8x8 CU (search.cpp:1754-1889): the five listed modes, a group of sixteen lanes each (cwv 0: modes 0..3,
+ * cwv 1: mode 4), one plane per call -- U (pl 0: from a copy of the start contexts), then V (pl 1: on the contexts U has moved, and the mode's cost).  Reads S.cref /
+ * S.csw / S.cfenc and the tables; leaves per mode S.crec, S.clev, S.cres, S.ctxw (the contexts behind the mode's bins), S.cfrac (the coder's fraction behind them, from
+ * P.scan_frac) and S.cost.  Two calls with a wavefront-level fence between them; the caller synchronises the workgroup and picks. */
+XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint32_t list[5], uint32_t lumaDir, int pl, const EnTabs& tabs, int lane, int cwv, int grp, int l)
+{
+    const int mi = cwv * 4 + grp, m = mi < 5 ? mi : 4;
+    const uint32_t listed = list[m], mode = listed == 36 ? lumaDir : listed;
+    const int scanType = mode >= 22 && mode <= 30 ? 1 : (mode >= 6 && mode <= 14 ? 2 : 0);
+    const int y = l >> 2, x = l & 3;
+    uint8_t* cw = S.ctxw[m];
+    if (pl == 0)
+    {
+        if (mi < 5) for (int b = l; b < X265AMD_CTX_STRIDE; b += 16) cw[b] = P.ctx[b];
+        if (mi < 5 && l == 0) S.ccoef[m] = 0;
+        xa_wave_sync();
+    }
+    const x265amd_intra_tu_job& C = P.ctmpl[pl];
+    const Q4 qC = q4_make(C.tu.qp_scaled, C.tu.slice_type);
+    const pixel* cr = S.cref[pl];
+    const int part = l < 4 ? (int)cr[1 + l] + (int)cr[9 + l] : 0;
+    int s = part;
+    s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x4E, 0xf, 0xf, true);
+    const int dc = (__shfl(s, lane & 48, 64) + 4) >> 3;
+    const int f = S.cfenc[pl][l];
+    const int p = nxn4_pred_sample(cr, S.csw[pl], S.tb, (int)mode, dc, y, x, false);
+    const Chain4 ch = grp16_chain4(f, p, 0, qC, C.tu.sign_hide, scanType, S.tb, nxn4_energy(f, lane), lane);
+    const int lvScan = __shfl(ch.lv, (lane & 48) + S.tb.scan[scanType][l], 64);
+    if (mi < 5)
+    {
+        const uint32_t cf = ch.numSig ? grp16_coeff_bits4(cw, cw, lvScan, 0, scanType, C.tu.sign_hide, S.step, S.tb, lane) : 0u;
+        S.crec[m][pl][l] = (pixel)ch.rec; S.clev[m][pl][l] = (int16_t)ch.lv;
+        if (l == 0)
+        {
+            x265amd_tu_result r;
+            r.num_sig = ch.numSig; r.zero_energy = ch.zeroEnergy; r.nz_energy = ch.nzEnergy; r.reserved = 0; r.zero_dist = ch.zeroDist; r.nz_dist = ch.nzDist;
+            S.cres[m][pl] = r;
+            S.ccoef[m] += cf;
+        }
+    }
+    xa_wave_sync();
+    if (pl == 1 && mi < 5 && l == 0)
+    {
+        const x265amd_tu_result rU = S.cres[m][0], rV = S.cres[m][1];
+        unsigned long long frac = P.scan_frac;
+        frac += cb_bin_t(tabs, cw + 14, listed == 36 ? 0u : 1u);                                /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
+        if (listed != 36) frac += 2ull << 15;
+        frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, rU.num_sig != 0 ? 1u : 0u);                 /* the two coded block flags share a context */
+        frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, rV.num_sig != 0 ? 1u : 0u);
+        frac += S.ccoef[m];
+        const unsigned long long dist = rU.nz_dist + rV.nz_dist, energy = (unsigned long long)rU.nz_energy + rV.nz_energy;
+        const unsigned long long bits = (uint32_t)(frac >> 15);
+        S.cfrac[m] = frac;
+        S.cost[m] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
+    }
+}
+/* both planes by wavefronts 0 and 1 of the caller */
+XA_DEV void nxn4_chroma_modes(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint32_t list[5], uint32_t lumaDir, const EnTabs& tabs, int lane, int wv, int grp, int l)
+{
+    if (wv >= 2) return;
+    nxn4_chroma_plane(P, S, list, lumaDir, 0, tabs, lane, wv, grp, l);
+    xa_wave_sync();
+    nxn4_chroma_plane(P, S, list, lumaDir, 1, tabs, lane, wv, grp, l);
+}
 
 /* a decided luma unit's share of the CU's bits on the running contexts: its coded block flag (C_QT_CBF + 0: one level down) and its coefficients -- one wavefront */
 XA_DEV void nxn4_count_unit(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int k, const EnTabs& tabs, int lane)
@@ -687,8 +753,6 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         const uint32_t lumaDir = S.winMode[0];
         uint32_t list[5] = { 0, 26, 10, 1, 36 };                /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
         for (int i = 0; i < 4; i++) if (lumaDir == list[i]) { list[i] = 34; break; }
-        const int mi = wv * 4 + grp;                            /* modes 0..3 on wavefront 0, mode 4 on wavefront 1 */
-        Chain4 chU = {}, chV = {};
         if (chained && wv == nwv - 1)
         {
             /* the last luma unit, then the bins in front of the transform tree: partition size, the four prev_intra_luma_pred_flags and the mode bits (codePredInfo) */
@@ -708,58 +772,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
                 S.runMv = pi; S.runFrac += pi;
             }
         }
-        if (wv < 2)
-        {
-            const int m = mi < 5 ? mi : 4;
-            const uint32_t listed = list[m], mode = listed == 36 ? lumaDir : listed;
-            const int scanType = mode >= 22 && mode <= 30 ? 1 : (mode >= 6 && mode <= 14 ? 2 : 0);
-            const int y = l >> 2, x = l & 3;
-            uint8_t* cw = S.ctxw[m];
-            if (mi < 5) for (int b = l; b < X265AMD_CTX_STRIDE; b += 16) cw[b] = P.ctx[b];
-            xa_wave_sync();
-            unsigned long long coeffFrac = 0;
-            for (int pl = 0; pl < 2; pl++)
-            {
-                const x265amd_intra_tu_job& C = P.ctmpl[pl];
-                const Q4 qC = q4_make(C.tu.qp_scaled, C.tu.slice_type);
-                const pixel* cr = S.cref[pl];
-                const int part = l < 4 ? (int)cr[1 + l] + (int)cr[9 + l] : 0;
-                int s = part;
-                s += __builtin_amdgcn_update_dpp(0, s, 0xB1, 0xf, 0xf, true);
-                s += __builtin_amdgcn_update_dpp(0, s, 0x4E, 0xf, 0xf, true);
-                const int dc = (__shfl(s, lane & 48, 64) + 4) >> 3;
-                const int f = S.cfenc[pl][l];
-                const int p = nxn4_pred_sample(cr, S.csw[pl], S.tb, (int)mode, dc, y, x, false);
-                const Chain4 ch = grp16_chain4(f, p, 0, qC, C.tu.sign_hide, scanType, S.tb, nxn4_energy(f, lane), lane);
-                const int lvScan = __shfl(ch.lv, (lane & 48) + S.tb.scan[scanType][l], 64);
-                if (mi < 5)
-                {
-                    if (ch.numSig) coeffFrac += grp16_coeff_bits4(cw, cw, lvScan, 0, scanType, C.tu.sign_hide, S.step, S.tb, lane);
-                    S.crec[m][pl][l] = (pixel)ch.rec; S.clev[m][pl][l] = (int16_t)ch.lv;
-                    if (l == 0)
-                    {
-                        x265amd_tu_result r;
-                        r.num_sig = ch.numSig; r.zero_energy = ch.zeroEnergy; r.nz_energy = ch.nzEnergy; r.reserved = 0; r.zero_dist = ch.zeroDist; r.nz_dist = ch.nzDist;
-                        S.cres[m][pl] = r;
-                    }
-                }
-                xa_wave_sync();
-                if (pl == 0) chU = ch; else chV = ch;
-            }
-            if (mi < 5 && l == 0)
-            {
-                unsigned long long frac = P.scan_frac;
-                frac += cb_bin_t(tabs, cw + 14, listed == 36 ? 0u : 1u);                                /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
-                if (listed != 36) frac += 2ull << 15;
-                frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, chU.numSig != 0 ? 1u : 0u);                 /* the two coded block flags share a context */
-                frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, chV.numSig != 0 ? 1u : 0u);
-                frac += coeffFrac;
-                const unsigned long long dist = (unsigned long long)chU.nzDist + chV.nzDist, energy = (unsigned long long)chU.nzEnergy + chV.nzEnergy;
-                const unsigned long long bits = (uint32_t)(frac >> 15);
-                S.cfrac[m] = frac;
-                S.cost[m] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
-            }
-        }
+        nxn4_chroma_modes(P, S, list, lumaDir, tabs, lane, wv, grp, l);
         __syncthreads();
         int w = 0;
         {

@@ -402,6 +402,50 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         s_cmode[tid] = (uint8_t)list[tid];
     }
     __syncthreads();
+    if (cLog2 == 2)
+    {
+        /* 4x4 chroma blocks (an 8x8 CU): the sixteen-lane chains of intra_nxn4_dev.h, a group per mode -- the dynamic LDS is free, the luma chains are done */
+        Nxn4Lds& S4 = *reinterpret_cast<Nxn4Lds*>(smem);
+        nxn4_fill_tabs(S4.tb, tid);
+        if (tid < 128) S4.enBits[tid] = s_enBits[tid];
+        if (tid < 64) S4.enLps[tid] = s_enLps[tid];
+        for (int i = tid; i < 256; i += nthr) S4.step[i] = s_step[i];
+        if (wv == nwv - 1)
+            for (int pl = 0; pl < 2; pl++)
+            {
+                const x265amd_intra_tu_job& C = P.ctmpl[pl];
+                (void)nxn4_neighbours(reinterpret_cast<const pixel*>(C.nb), (int)C.nb_stride, (uint32_t)C.avail, S4.cref[pl], S4.csw[pl], lane);
+                if (lane < 16) S4.cfenc[pl][lane] = s_cfenc[pl][lane];
+            }
+        __syncthreads();
+        uint32_t list[5];
+        for (int i = 0; i < 5; i++) list[i] = s_cmode[i];
+        nxn4_chroma_modes(P, S4, list, lumaDir, EnTabs{ S4.enBits, S4.enLps }, lane, wv, lane >> 4, lane & 15);
+        __syncthreads();
+        int w = 0;
+        {
+            unsigned long long best = ~0ull;
+            for (int i = 0; i < 5; i++) if (S4.cost[i] < best) { best = S4.cost[i]; w = i; }
+        }
+        if (tid == 0)
+        {
+            s_win = w;
+            po->chroma_best = (uint32_t)w; po->chroma_reserved = P.pick_sa8d ? s_pickSa8d : 0;
+            po->cres[0] = S4.cres[w][0]; po->cres[1] = S4.cres[w][1];
+        }
+        if (tid < 5) s_cfrac[tid] = S4.cfrac[tid];
+        for (int b = tid; b < X265AMD_CTX_STRIDE; b += nthr) s_ctxw[w][b] = S4.ctxw[w][b];
+        if (tid >= 64 && tid < 96)
+        {
+            const int pl = (tid - 64) >> 4, i = tid & 15, y = i >> 2, x = i & 3;
+            const x265amd_intra_tu_job& C = P.ctmpl[pl];
+            int16_t* clOut = P.clevels_dst ? reinterpret_cast<int16_t*>(P.clevels_dst) : &po->clevels[0][0];
+            reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = S4.crec[w][pl][i];
+            if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = S4.crec[4][pl][i];
+            clOut[pl * 16 + i] = S4.clev[w][pl][i];
+        }
+    }
+    else {
     if (wv < 5)
     {
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
@@ -465,6 +509,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = last[y * C.tu.recon_stride + x];
             clOut[pl * cn2 + i] = lv[i];
         }
+    }
     }
     __syncthreads();
     XA_NXN(9);
