@@ -361,12 +361,13 @@ struct Nxn4Lds
     uint8_t runCtx[X265AMD_CTX_STRIDE];
     uint64_t runFrac, runMv;
     uint64_t cfrac[5], ccoef[5];
+    unsigned long long ccost[5];                 /* the chroma modes' costs (apart from the luma candidates': the two decisions overlap) */
 };
 
 /* estIntraPredChromaQT for the one 4x4 block per plane of an 8x8 CU (search.cpp:1754-1889): the five listed modes, a group of sixteen lanes each (cwv 0: modes 0..3,
  * cwv 1: mode 4), one plane per call -- U (pl 0: from a copy of the start contexts), then V (pl 1: on the contexts U has moved, and the mode's cost).  Reads S.cref /
  * S.csw / S.cfenc and the tables; leaves per mode S.crec, S.clev, S.cres, S.ctxw (the contexts behind the mode's bins), S.cfrac (the coder's fraction behind them, from
- * P.scan_frac) and S.cost.  Two calls with a wavefront-level fence between them; the caller synchronises the workgroup and picks. */
+ * P.scan_frac) and S.ccost.  Two calls with a wavefront-level fence between them; the caller synchronises the workgroup and picks. */
 XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint32_t list[5], uint32_t lumaDir, int pl, const EnTabs& tabs, int lane, int cwv, int grp, int l)
 {
     const int mi = cwv * 4 + grp, m = mi < 5 ? mi : 4;
@@ -417,7 +418,7 @@ XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const 
         const unsigned long long dist = rU.nz_dist + rV.nz_dist, energy = (unsigned long long)rU.nz_energy + rV.nz_energy;
         const unsigned long long bits = (uint32_t)(frac >> 15);
         S.cfrac[m] = frac;
-        S.cost[m] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
+        S.ccost[m] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
     }
 }
 /* both planes by wavefronts 0 and 1 of the caller */
@@ -618,8 +619,13 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
     pixel* ref = S.ref[wv]; pixel* sw = S.sw[wv];
     /* a chained CU keeps its last wavefront out of the evaluation: it counts the decided units' bits on the running contexts while the others go on (the coefficient
      * contexts of the luma units move from unit to unit, so the candidates' estimates -- all from the start contexts -- do not serve) */
-    const int lw = chained ? nwv - 1 : nwv;
+    /* Eight wavefronts: five evaluate the luma units (twenty groups: the 35 modes of the scan in two rounds, up to twenty candidates side by side), two run the
+     * chroma decision beside luma units 1 and 2 (its mode list needs only the first unit's direction), the last one counts bits when the CU is chained.  Fewer
+     * wavefronts: all of them on the luma units, the chroma decision behind them. */
+    const bool overlap = nwv >= 8 && P.do_chroma;
+    const int lw = overlap ? 5 : (chained ? nwv - 1 : nwv);
     const bool worker = wv < lw;
+    const bool chromaWave = overlap && (wv == 5 || wv == 6);
     if (chained)
     {
         for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) S.runCtx[i] = P.ctx[i];
@@ -663,7 +669,14 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         XA_NXN(3);
         const int n = L.num;
         /* (a chained CU's last wavefront: the unit before this one joins the CU's bit count while the candidates run -- the longest stretch between two barriers) */
-        if (!worker && k > 0) nxn4_count_unit(P, S, k - 1, tabs, lane);
+        if (chained && wv == nwv - 1 && k > 0) nxn4_count_unit(P, S, k - 1, tabs, lane);
+        if (chromaWave && (k == 1 || k == 2))
+        {
+            const uint32_t lumaDir0 = S.winMode[0];
+            uint32_t clist[5] = { 0, 26, 10, 1, 36 };               /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
+            for (int i = 0; i < 4; i++) if (lumaDir0 == clist[i]) { clist[i] = 34; break; }
+            nxn4_chroma_plane(P, S, clist, lumaDir0, k - 1, tabs, lane, wv - 5, grp, l);
+        }
         /* the candidates' chains: candidate c = group * waves + wavefront (the first eight one per wavefront) */
         Chain4 mine = {};
         int myCand = -1;
@@ -772,12 +785,12 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
                 S.runMv = pi; S.runFrac += pi;
             }
         }
-        nxn4_chroma_modes(P, S, list, lumaDir, tabs, lane, wv, grp, l);
+        if (!overlap) nxn4_chroma_modes(P, S, list, lumaDir, tabs, lane, wv, grp, l);
         __syncthreads();
         int w = 0;
         {
             unsigned long long best = ~0ull;
-            for (int i = 0; i < 5; i++) if (S.cost[i] < best) { best = S.cost[i]; w = i; }
+            for (int i = 0; i < 5; i++) if (S.ccost[i] < best) { best = S.ccost[i]; w = i; }
         }
         if (tid == 0)
         {
