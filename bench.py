@@ -45,8 +45,8 @@ BFRAMES, REFS, QP = 4, 3, 30
 # x265amd_param fields that differ from x265amd_param_default, and the same settings on the reference's command line
 # frameNumThreads > 1: the reference's frame-parallel rules, i.e. what its default (--frame-threads 0 = by core count) gives on any machine with four cores or more
 ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5,
-               scenecutThreshold=40, lookaheadDepth=20)
-REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "0",
+               scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2)
+REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "2",
            "--no-b-pyramid", "--scenecut", "40", "--rd", "3", "--sao", "--wpp", "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", str(REFS), "--max-merge", "3",
            "--no-info", "--no-open-gop", "--rc-lookahead", "20", "--lookahead-slices", "0"]
 
@@ -313,10 +313,10 @@ def main():
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
             "value": (K if by_frames else world * K) / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,
             "higher_is_better": True, "scaling": "strong" if by_frames and world > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + fixed mini-GOPs of %d B frames), encoded END TO END by the encoder object "
+            "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + mini-GOPs of up to %d B frames chosen by the lookahead's trellis, --b-adapt 2), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
                                    "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
-                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20) and the rest of the lookahead's decisions fixed (b-adapt 0; AQ / cutree are off in CQP by the reference's own rules; "
+                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20) and and the B-frame trellis (--b-adapt 2) as the preset has them (AQ / cutree are off in CQP by the reference's own rules; "
                                    "no weighted prediction, B pyramid, open GOP: not built, switched off on both sides)" % (W, H, K, BFRAMES, REFS, QP),
                        "frames_per_step_per_gpu": 1, "parallelism": ("picture k in coding order on GPU k mod %d, CTU rows broadcast over RCCL" % world if by_frames else "closed GOP per GPU x%d" % world) if world > 1 else "one encoder object",
                        "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},

@@ -1007,6 +1007,19 @@ int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pi
                               const int32_t* d_intra_cost, int16_t* d_mvs0, int32_t* d_mv_costs0, int16_t* d_mvs1, int32_t* d_mv_costs1,
                               uint16_t* d_lowres_costs, int32_t* d_bcost, int32_t* d_progress);
 
+/* Many estimates of pictures of one size as ONE launch (the lookahead's batches, slicetype.cpp:2668-2734: every picture of the window against the pictures up to
+ * bframes + 1 before and behind it): job i is what x265amd_lowres_frame_cost takes for one estimate (d_ref1[0] == NULL: a P estimate).  Estimates of one call must not
+ * search the same motion field.  Returns when all of them are done. */
+typedef struct x265amd_lowres_cost_job
+{
+    const x265amd_pixel* d_fenc; const x265amd_pixel* d_ref0[4]; const x265amd_pixel* d_ref1[4];
+    const int32_t* d_intra_cost;
+    int16_t* d_mvs0; int32_t* d_mv_costs0; int16_t* d_mvs1; int32_t* d_mv_costs1;
+    uint16_t* d_lowres_costs; int32_t* d_bcost;
+    int32_t do_search0, do_search1;
+} x265amd_lowres_cost_job;
+int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265amd_lowres_cost_job* jobs, int n, intptr_t stride, int width_in_cu, int height_in_cu);
+
 /* x265amd_aq_energy = LookaheadTLD::acEnergyCu for every quantisation group of a source picture (reference: source/encoder/slicetype.cpp:48-92, :264-283):
  * d_energy[group] (raster order, ceil(width / qg) groups per row; qg_size 16 or 8) = AC energy of the luma block + the two 4:2:0 chroma blocks;
  * d_wp[0..2] = Lowres::wp_sum[plane], d_wp[3..5] = wp_ssd[plane] (sums over all groups).  planes: HOST array of the device addresses of sample (0,0)

@@ -64,7 +64,10 @@ typedef struct x265amd_param
                                              * takes the others' finished CTU rows from the objects that code them (x265amd_encoder_export_row / _import_row).
                                              * Every object of the set is fed every picture (slice types, DPB and reference lists are decided identically by all);
                                              * the stream is the owners' NAL units in coding order.  0 / 0 or count 1: one object codes everything */
-    int32_t reserved;
+    int32_t bFrameAdaptive;                 /* param.bFrameAdaptive (--b-adapt): 0 fixed mini-GOPs of `bframes` B pictures; 2 the trellis (Lookahead::slicetypeAnalyse with
+                                             * slicetypePath / slicetypePathCost, slicetype.cpp:2776-2795, :3218-3313) on P and B cost estimates of the lowres pictures,
+                                             * every pair of the window searched in advance as the reference's batch does with four pool workers or more.  1 (fast)
+                                             * is not built */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -3020,7 +3020,7 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("reserved", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3395,6 +3395,26 @@ def stream_diff(got, want):
     end = (starts[k + 1] - 3) if k + 1 < len(starts) else len(want)
     return "lengths %d / %d; first difference at byte %d: NAL %d of %d (type %d, %d bytes), byte %d of it: got %s want %s" % (
         len(got), len(want), at, k, len(starts), (want[starts[k]] >> 1) & 63, end - starts[k], at - starts[k], got[at:at + 8].hex(), want[at:at + 8].hex())
+
+
+# --b-adapt 2 (the trellis): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of BA_CLI)
+BA_CLI = [o if o != "0" or SC_CLI[i - 1] != "--b-adapt" else "2" for i, o in enumerate(SC_CLI)]
+BA_BASE = dict(SC_BASE, bFrameAdaptive=2)
+BA_CASES = {
+    "ba2_drift/": ((320, 192), 20, 8, ("api", None), dict(BA_BASE, bframes=4, lookaheadDepth=10), ["--bframes", "4", "--rc-lookahead", "10"]),            # textured picture drifting: B pictures pay
+    "ba2_cut/": ((320, 192), 18, 8, ("scene", [9]), dict(BA_BASE, bframes=3, lookaheadDepth=8), ["--bframes", "3", "--rc-lookahead", "8"]),                # a scene cut inside
+    "ba2_nosc/": ((320, 192), 14, 8, ("ft", None), dict(BA_BASE, bframes=4, lookaheadDepth=6, scenecutThreshold=0), ["--bframes", "4", "--rc-lookahead", "6", "--no-scenecut"]),   # accelerating motion, no scene-cut detection
+    "ba2_hbd/": ((256, 192), 12, 10, ("api", None), dict(BA_BASE, bframes=2, lookaheadDepth=5), ["--bframes", "2", "--rc-lookahead", "5"]),
+}
+
+
+def ba_case_frames(tag):
+    (w, h), n, depth, (kind, arg), _, _ = BA_CASES[tag]
+    if kind == "scene":
+        return scene_clip(w, h, n, arg, depth)
+    if kind == "ft":
+        return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
+    return encoder_api_clip(tag, w, h, n, depth)
 
 
 def scene_case_frames(tag):

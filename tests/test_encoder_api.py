@@ -272,3 +272,42 @@ def test_frame_per_gpu_objects_alternate_pictures(tag, count):
     for (poc, _, _, planes) in coded:
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
         assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+
+
+BA_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_ba_golden.npz")
+
+
+def test_b_adapt_golden_has_varied_mini_gops():
+    g = np.load(BA_GOLD)
+    runs = set()
+    for tag in T.BA_CASES:
+        n = 0
+        for t in g[tag + "types"][1:]:
+            if str(t).endswith(":b"):
+                n += 1
+            else:
+                runs.add(n); n = 0
+    assert {0, 1, 2, 3, 4} <= runs | {0}, runs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.BA_CASES))
+def test_b_adapt_trellis(tag):
+    """x265amd_param.bFrameAdaptive = 2: the lookahead's trellis over P / B paths (Lookahead::slicetypeAnalyse with slicetypePath / slicetypePathCost, slicetype.cpp:2776-2795,
+    :3218-3313) on P and B cost estimates, every pair of the window searched in advance (the reference's batch with --pools 4), the estimates' motion fields of both lists as
+    search candidates of the encoder: the reference encoder's stream with --b-adapt 2 -- mini-GOPs of varying length, a scene cut, no scene-cut detection, 10-bit.
+    Golden data: tests/golden/make_golden.py ba."""
+    g = np.load(BA_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.BA_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.ba_case_frames(tag), w, h, **cfg)
+    names = {1: "I", 2: "i", 3: "P", 5: "b"}
+    got_types, idr = [], 0
+    for (poc, st, _, _) in coded:
+        if st == 1:
+            idr = poc
+        got_types.append("%d:%s" % (poc - idr, names[st]))
+    assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])

@@ -66,9 +66,10 @@ def test_encoder_open_names_what_it_rejects():
     buf[LAYOUT["PARAM_sourceWidth"]] = 64; buf[LAYOUT["PARAM_sourceHeight"]] = 64; buf[LAYOUT["PARAM_fpsNum"]] = 30; buf[LAYOUT["PARAM_fpsDenom"]] = 1
     assert not opn(p) and b"rc.rateControlMode" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_rc_rateControlMode"]] = 1
+    assert not opn(p) and b"lookaheadSlices" in lib.x265amd_last_error()       # --b-adapt 2 (the default) and scene-cut detection are built; the lookahead in slices is not
+    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 1
     assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
-    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 0
-    assert not opn(p) and b"lookaheadSlices" in lib.x265amd_last_error()       # scene-cut detection itself is built; its cost estimates in slices are not
+    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2       # scene-cut detection itself is built; its cost estimates in slices are not
     buf[LAYOUT["PARAM_lookaheadSlices"]] = 0
     assert not opn(p) and b"bBPyramid" in lib.x265amd_last_error()
     free(p)

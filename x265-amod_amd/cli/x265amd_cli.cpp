@@ -5,7 +5,7 @@
  *     x265amd --input clip.y4m -o out.hevc [--recon rec.yuv] [--qp N] [--bframes N] [--keyint N] [--ref N] [--rd 2..6] [--rect] [--amp]
  *             [--limit-modes] [--limit-refs N] [--[no-]early-skip] [--rskip 0|1] [--psy-rd F] [--[no-]b-intra] [--me dia|hex|star] [--subme N]
  *             [--merange N] [--max-merge N] [--rdoq-level N] [--psy-rdoq F] [--[no-]deblock] [--[no-]sao] [--[no-]wpp] [--frames N]
- *             [--scenecut N | --no-scenecut] [--rc-lookahead N] [--min-keyint N]
+ *             [--scenecut N | --no-scenecut] [--rc-lookahead N] [--min-keyint N] [--b-adapt 0|2]
  *
  * Like the reference (source/encoder/api.cpp:1107-1182, x265_api_get) the pixel depth selects the library: libx265amd_main.so for 8-bit input,
  * libx265amd_main10.so for 10-bit, loaded with dlopen from the directory of this program's ../lib.  Host C++ only; all device work is the library's. */
@@ -133,6 +133,7 @@ int main(int argc, char** argv)
         else if (k == "--scenecut") p.scenecutThreshold = atoi(v);
         else if (k == "--no-scenecut") p.scenecutThreshold = 0;
         else if (k == "--rc-lookahead") p.lookaheadDepth = atoi(v);
+        else if (k == "--b-adapt") p.bFrameAdaptive = atoi(v);
         else if (k == "--ref") p.maxNumReferences = atoi(v);
         else if (k == "--rd") p.rdLevel = atoi(v);
         else if (k == "--rect") p.bEnableRectInter = 1;

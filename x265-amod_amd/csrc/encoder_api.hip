@@ -72,9 +72,12 @@ struct Pic
      * estimates by distance to the reference (costEst[d][0]: P cost against the picture d before; [0][0]: intra), the scene-cut mark */
     pixel* dLowres = nullptr; int32_t* dIntraCost = nullptr;
     int64_t costEst[18]; int intraMbs[18];
-    std::vector<int16_t> lowMvs[18];        /* Lowres::lowresMvs[0][d]: the motion field of the P estimate against the picture d before (the encoder's searches take a candidate from it) */
+    std::vector<int16_t> lowMvs[18];        /* Lowres::lowresMvs[0][d]: the motion field of the estimates against the picture d before (the encoder's searches take a candidate from it) */
+    std::vector<int16_t> lowMvs1[18];       /* Lowres::lowresMvs[1][d]: against the picture d behind (B estimates: --b-adapt 2) */
+    std::vector<int32_t> lowMvc[18], lowMvc1[18];   /* Lowres::lowresMvCosts: read again when a later estimate uses a field that exists */
+    int64_t cost2[18][18];                  /* Lowres::costEst[b - p0][p1 - b] (B estimates scaled as estimateFrameCost does); [d][0] is costEst[d] */
     bool bScenecut = false, bKeyframe = false;
-    Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; } }
+    Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = -1; } }
     ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x) { std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x; }
     int published(int row) const { const int v = (int)*finalX[row]; std::atomic_thread_fence(std::memory_order_acquire); return v; }
@@ -125,6 +128,9 @@ struct x265amd_encoder
     ~x265amd_encoder()
     {
         for (auto& q : inflight) if (q->done.valid()) q->done.wait();
+        if (getenv("X265AMD_TIMING") && lookahead)
+            fprintf(stderr, "x265amd: lookahead: %.1f ms in lowres planes + intra costs, %.1f ms in the slice-type decision (%llu estimates, %llu motion searches; %llu batches %.1f ms, %llu single estimates %.1f ms)\n", laInitMs, laDecideMs,
+                    (unsigned long long)laJobs, (unsigned long long)laSearches, (unsigned long long)laBatches, laBatchMs, (unsigned long long)laSingles, laSingleMs);
         if (me) x265amd_me_close(me);
         if (dSaoCount) (void)hipFree(dSaoCount);
         if (dSaoOrg) (void)hipFree(dSaoOrg);
@@ -151,6 +157,14 @@ struct x265amd_encoder
     hipStream_t laStream = nullptr;
     int lowresInit(Pic& pic);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
+    int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
+    struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
+                     void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; std::vector<int32_t> bc; std::vector<uint16_t> lc; };
+    int frameCostMany(std::vector<CostJob>& jobs);
+    double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0;
+    int frameCost(std::vector<Pic*>& frames, int p0, int p1, int b, int64_t& score);       /* CostEstimateGroup::singleCost(p0, p1, b): P (p1 == b) or B estimate */
+    int64_t slicetypePathCost(std::vector<Pic*>& frames, const char* path, int64_t threshold, int& rc);
+    void slicetypePath(std::vector<Pic*>& frames, int length, char (*best_paths)[251], int& rc);
     bool scenecutInternal(std::vector<Pic*>& frames, int p0, int p1, bool real, int& rc);
     bool scenecut(std::vector<Pic*>& frames, int p0, int p1, bool real, int numFrames, int& rc);
     int slicetypeAnalyse(std::vector<Pic*>& frames);
@@ -269,7 +283,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     { xa_fail(X265AMD_EINVAL, "encoder_open: scenecutThreshold outside 0..100, lookaheadDepth outside 0..250 or keyframeMin outside 0..keyframeMax"); return nullptr; }
     if (p->shardCount < 0 || p->shardCount > 64 || (p->shardCount > 1 && (p->shardRank < 0 || p->shardRank >= p->shardCount || p->frameNumThreads <= 1)))
     { xa_fail(X265AMD_EINVAL, "encoder_open: shardRank / shardCount (frame-per-GPU needs 0 <= rank < count and frameNumThreads > 1: rows are published by pictures coded in parallel)"); return nullptr; }
-    e->lookahead = p->scenecutThreshold > 0;
+    if (p->bFrameAdaptive != 0 && p->bFrameAdaptive != 2) { xa_fail(X265AMD_EINVAL, "encoder_open: bFrameAdaptive: 0 (fixed mini-GOPs) and 2 (trellis) are built"); return nullptr; }
+    e->lookahead = p->scenecutThreshold > 0 || (p->bFrameAdaptive && p->bframes);
     {
         /* Encoder::configure (encoder.cpp:3658-3663) */
         int kmin = p->keyframeMin;
@@ -514,32 +529,145 @@ int x265amd_encoder::lowresInit(Pic& pic)
  * blocks that are not on the picture's edge (estimateCUCost's tail, :4220-4248) */
 int x265amd_encoder::frameCostP(Pic& b, Pic& ref, int dist)
 {
-    if (dist < 1 || dist > 17) return xa_fail(X265AMD_EINVAL, "encoder: lookahead distance");
-    if (b.costEst[dist] >= 0) return X265AMD_OK;
+    int64_t score;
+    return frameCostAt(b, ref, nullptr, dist, 0, score);
+}
+
+/* CostEstimateGroup::estimateFrameCost (slicetype.cpp:3975-4075) for candidate `fenc` against `ref0` d0 pictures before it and, for a B estimate, `ref1` d1 pictures behind
+ * it: the searches a field still lacks run inside the block loop (bDoSearch), fields that exist are read again; the sum over the blocks that are not on the picture's
+ * edge, scaled by 100 / (130 + bFrameBias) for a B estimate; intra blocks are counted for P estimates only */
+int x265amd_encoder::frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score)
+{
+    if (d0 < 1 || d0 > 17 || d1 < 0 || d1 > 17 || (d1 > 0) != (ref1 != nullptr)) return xa_fail(X265AMD_EINVAL, "encoder: lookahead distance");
+    if (fenc.cost2[d0][d1] >= 0) { score = fenc.cost2[d0][d1]; return X265AMD_OK; }
+    std::vector<CostJob> one(1);
+    one[0].fenc = &fenc; one[0].ref0 = &ref0; one[0].ref1 = ref1; one[0].d0 = d0; one[0].d1 = d1;
+    const int rc = frameCostMany(one);
+    score = fenc.cost2[d0][d1];
+    return rc;
+}
+
+/* Independent estimates side by side: every job on one of a handful of streams (the block loop of an estimate is a few dozen wavefronts chained row to row -- latency,
+ * not throughput: a dozen of them overlap on the device), one wait for all, then the host sums.  Jobs of one call must not share a motion field they search or a cost
+ * they fill (the callers' batches are by (picture, distance) pairs). */
+int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
+{
+    if (jobs.empty()) return X265AMD_OK;
     const size_t ncu = (size_t)lowCuW * lowCuH;
-    struct Scratch { void* p = nullptr; ~Scratch() { xa_scratch_free(p); } } dMvs, dMvc, dLc, dBc, dProg;
-    if (xa_scratch_alloc(&dMvs.p, ncu * 4) != hipSuccess || xa_scratch_alloc(&dMvc.p, ncu * 4) != hipSuccess || xa_scratch_alloc(&dLc.p, ncu * 2) != hipSuccess ||
-        xa_scratch_alloc(&dBc.p, ncu * 4) != hipSuccess || xa_scratch_alloc(&dProg.p, (size_t)lowCuH * 4) != hipSuccess)
-        return xa_fail(X265AMD_EHIP, "encoder: device allocation");
-    const pixel* ref0[4];
-    for (int k = 0; k < 4; k++) ref0[k] = ref.dLowres + (size_t)k * lowPlaneElems + lowOrg;
-    if (hipMemsetAsync(dProg.p, 0, (size_t)lowCuH * 4, laStream) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: memset");
-    int rc = x265amd_lowres_frame_cost(laStream, me, b.dLowres + lowOrg, ref0, nullptr, lowStride, lowCuW, lowCuH, 1, 0, b.dIntraCost, (int16_t*)dMvs.p, (int32_t*)dMvc.p, nullptr, nullptr,
-                                       (uint16_t*)dLc.p, (int32_t*)dBc.p, (int32_t*)dProg.p);
-    if (rc != X265AMD_OK) return rc;
-    std::vector<int32_t> bc(ncu); std::vector<uint16_t> lc(ncu);
-    b.lowMvs[dist].resize(ncu * 2);
-    if (hipMemcpyAsync(bc.data(), dBc.p, ncu * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess || hipMemcpyAsync(lc.data(), dLc.p, ncu * 2, hipMemcpyDeviceToHost, laStream) != hipSuccess ||
-        hipMemcpyAsync(b.lowMvs[dist].data(), dMvs.p, ncu * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess ||
-        hipStreamSynchronize(laStream) != hipSuccess)
-        return xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
-    int64_t est = 0; int imb = 0;
-    const bool all = lowCuW <= 2 || lowCuH <= 2;
-    for (int y = 0; y < lowCuH; y++)
-        for (int x = 0; x < lowCuW; x++)
-            if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) { est += bc[(size_t)y * lowCuW + x]; imb += (lc[(size_t)y * lowCuW + x] >> 14) == 0; }
-    b.costEst[dist] = est; b.intraMbs[dist] = imb;
-    return X265AMD_OK;
+    int rc = X265AMD_OK;
+    const auto tb0 = std::chrono::steady_clock::now();
+    struct Tm { x265amd_encoder* e; std::chrono::steady_clock::time_point t0; size_t n; ~Tm() { const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (n > 1) { e->laBatchMs += ms; e->laBatches++; } else { e->laSingleMs += ms; e->laSingles++; } } } tm_{ this, tb0, jobs.size() };
+    std::vector<x265amd_lowres_cost_job> kj(jobs.size());
+    size_t issued = 0;
+    for (size_t k = 0; k < jobs.size() && rc == X265AMD_OK; k++)
+    {
+        CostJob& j = jobs[k];
+        Pic& fenc = *j.fenc;
+        j.search0 = fenc.lowMvs[j.d0].empty(); j.search1 = j.d1 > 0 && fenc.lowMvs1[j.d1].empty();
+        laJobs++; laSearches += (j.search0 ? 1 : 0) + (j.search1 ? 1 : 0);
+        void** bufs[6] = { &j.dMvs, &j.dMvc, &j.dLc, &j.dBc, &j.dMvs1, &j.dMvc1 };
+        const size_t sizes[6] = { ncu * 4, ncu * 4, ncu * 2, ncu * 4, ncu * 4, ncu * 4 };
+        for (int b = 0; b < (j.d1 > 0 ? 6 : 4); b++) if (xa_scratch_alloc(bufs[b], sizes[b]) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "encoder: device allocation");
+        issued = k + 1;
+        if (rc != X265AMD_OK) break;
+        x265amd_lowres_cost_job& q = kj[k];
+        memset(&q, 0, sizeof(q));
+        q.d_fenc = fenc.dLowres + lowOrg;
+        for (int t = 0; t < 4; t++) { q.d_ref0[t] = j.ref0->dLowres + (size_t)t * lowPlaneElems + lowOrg; q.d_ref1[t] = j.ref1 ? j.ref1->dLowres + (size_t)t * lowPlaneElems + lowOrg : nullptr; }
+        q.d_intra_cost = fenc.dIntraCost;
+        q.d_mvs0 = (int16_t*)j.dMvs; q.d_mv_costs0 = (int32_t*)j.dMvc; q.d_mvs1 = (int16_t*)j.dMvs1; q.d_mv_costs1 = (int32_t*)j.dMvc1;
+        q.d_lowres_costs = (uint16_t*)j.dLc; q.d_bcost = (int32_t*)j.dBc; q.do_search0 = j.search0; q.do_search1 = j.search1;
+        bool ok = true;
+        if (!j.search0) ok = hipMemcpyAsync(j.dMvs, fenc.lowMvs[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
+                             hipMemcpyAsync(j.dMvc, fenc.lowMvc[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
+        if (ok && j.d1 > 0 && !j.search1) ok = hipMemcpyAsync(j.dMvs1, fenc.lowMvs1[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
+                                               hipMemcpyAsync(j.dMvc1, fenc.lowMvc1[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
+        if (!ok) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost set-up");
+    }
+    /* one launch for all of them (blockIdx.y = the estimate): the device runs as many block rows side by side as it holds */
+    if (rc == X265AMD_OK) rc = x265amd_lowres_frame_cost_batch(laStream, me, kj.data(), (int)jobs.size(), lowStride, lowCuW, lowCuH);
+    for (size_t k = 0; k < issued && rc == X265AMD_OK; k++)
+    {
+        CostJob& j = jobs[k];
+        Pic& fenc = *j.fenc;
+        j.bc.resize(ncu); j.lc.resize(ncu);
+        bool ok = hipMemcpyAsync(j.bc.data(), j.dBc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(j.lc.data(), j.dLc, ncu * 2, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+        if (ok && j.search0)
+        {
+            fenc.lowMvs[j.d0].resize(ncu * 2); fenc.lowMvc[j.d0].resize(ncu);
+            ok = hipMemcpyAsync(fenc.lowMvs[j.d0].data(), j.dMvs, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(fenc.lowMvc[j.d0].data(), j.dMvc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+        }
+        if (ok && j.search1)
+        {
+            fenc.lowMvs1[j.d1].resize(ncu * 2); fenc.lowMvc1[j.d1].resize(ncu);
+            ok = hipMemcpyAsync(fenc.lowMvs1[j.d1].data(), j.dMvs1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(fenc.lowMvc1[j.d1].data(), j.dMvc1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+        }
+        if (!ok) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
+    }
+    if (hipStreamSynchronize(laStream) != hipSuccess && rc == X265AMD_OK) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
+    for (size_t k = 0; k < issued; k++)
+    {
+        CostJob& j = jobs[k];
+        void* bufs[6] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
+        for (void* b : bufs) xa_scratch_free(b);
+        if (rc != X265AMD_OK) { if (j.search0) { j.fenc->lowMvs[j.d0].clear(); j.fenc->lowMvc[j.d0].clear(); } if (j.search1) { j.fenc->lowMvs1[j.d1].clear(); j.fenc->lowMvc1[j.d1].clear(); } continue; }
+        int64_t est = 0; int imb = 0;
+        const bool all = lowCuW <= 2 || lowCuH <= 2;
+        for (int y = 0; y < lowCuH; y++)
+            for (int x = 0; x < lowCuW; x++)
+                if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) { est += j.bc[(size_t)y * lowCuW + x]; imb += (j.lc[(size_t)y * lowCuW + x] >> 14) == 0; }
+        if (j.d1 > 0) est = est * 100 / (130 + 0);          /* param.bFrameBias: the default */
+        j.fenc->cost2[j.d0][j.d1] = est;
+        if (j.d1 == 0) { j.fenc->costEst[j.d0] = est; j.fenc->intraMbs[j.d0] = imb; }
+    }
+    return rc;
+}
+int x265amd_encoder::frameCost(std::vector<Pic*>& frames, int p0, int p1, int b, int64_t& score)
+{
+    return frameCostAt(*frames[b], *frames[p0], p1 > b ? frames[p1] : nullptr, b - p0, p1 - b, score);
+}
+
+/* Lookahead::slicetypePathCost (slicetype.cpp:3268-3313), no B pyramid */
+int64_t x265amd_encoder::slicetypePathCost(std::vector<Pic*>& frames, const char* path, int64_t threshold, int& rc)
+{
+    int64_t cost = 0;
+    int loc = 1, cur_p = 0;
+    path--;             /* the first path element is really the second frame */
+    while (path[loc] && rc == X265AMD_OK)
+    {
+        int next_p = loc;
+        while (path[next_p] != 'P') next_p++;
+        int64_t c = 0;
+        rc = frameCost(frames, cur_p, next_p, next_p, c);
+        cost += c;
+        if (cost > threshold) break;
+        for (int next_b = loc; next_b < next_p && cost < threshold && rc == X265AMD_OK; next_b++)
+        {
+            rc = frameCost(frames, cur_p, next_p, next_b, c);
+            cost += c;
+        }
+        loc = next_p + 1;
+        cur_p = next_p;
+    }
+    return cost;
+}
+/* Lookahead::slicetypePath (slicetype.cpp:3218-3245) */
+void x265amd_encoder::slicetypePath(std::vector<Pic*>& frames, int length, char (*best_paths)[251], int& rc)
+{
+    char paths[2][251];
+    const int num_paths = std::min(p.bframes + 1, length);
+    int64_t best_cost = 1LL << 62;
+    int idx = 0;
+    for (int path = 0; path < num_paths && rc == X265AMD_OK; path++)
+    {
+        const int len = length - (path + 1);
+        memcpy(paths[idx], best_paths[len % 17], len);
+        memset(paths[idx] + len, 'B', path);
+        strcpy(paths[idx] + len + path, "P");
+        const int64_t cost = slicetypePathCost(frames, paths[idx], best_cost, rc);
+        if (cost < best_cost) { best_cost = cost; idx ^= 1; }
+    }
+    memcpy(best_paths[length % 17], paths[idx ^ 1], length);
 }
 
 /* Lookahead::scenecutInternal (slicetype.cpp:3016-3047): float / double arithmetic as written there */
@@ -625,14 +753,71 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
     int numFrames = origNumFrames;
     if (numFrames == 0) { frames[1]->type = TYPE_I; return X265AMD_OK; }
     int rc = X265AMD_OK;
-    const bool isScenecut = scenecut(frames, 0, 1, true, origNumFrames, rc);
+    if (p.bFrameAdaptive == 2 && p.bframes)
+    {
+        /* m_bBatchMotionSearch (slicetype.cpp:2668-2694; it stays on with a pool of four workers or more): every picture of the window is searched against the pictures
+         * 1 .. bframes + 1 before it and, where the window allows, the same distance behind it -- whether or not the trellis below will ask for that pair.  The fields
+         * stay with the pictures: the encoder's searches take candidates from them (Search::getLowresMV) */
+        std::vector<CostJob> jobs;
+        for (int b = 2; b < numFrames; b++)
+            for (int i = 1; i <= p.bframes + 1; i++)
+            {
+                const int p0 = b - i;
+                if (p0 < 0 || !frames[b]->lowMvs[i].empty()) continue;
+                int p1 = b + i;
+                if (p1 >= numFrames || !frames[b]->lowMvs1[i].empty()) p1 = b;
+                if (frames[b]->cost2[i][p1 - b] >= 0) continue;
+                CostJob j;
+                j.fenc = frames[b]; j.ref0 = frames[p0]; j.ref1 = p1 > b ? frames[p1] : nullptr; j.d0 = i; j.d1 = p1 - b;
+                jobs.push_back(j);
+            }
+        rc = frameCostMany(jobs);
+        if (rc != X265AMD_OK) return rc;
+        /* ... and every cost the trellis can ask for of these pictures, side by side (m_bBatchFrameCosts, :2696-2734: nothing but a cache -- the reference fills it
+         * with a pool of more than twelve workers, and one by one on demand otherwise) */
+        jobs.clear();
+        for (int b = 2; b < numFrames; b++)
+            for (int i = 1; i <= p.bframes + 1; i++)
+            {
+                if (b < i || frames[b]->lowMvs[i].empty()) continue;
+                for (int jj = 0; jj <= p.bframes; jj++)
+                {
+                    const int p1 = b + jj;
+                    if (p1 >= numFrames) break;
+                    if ((jj && frames[b]->lowMvs1[jj].empty()) || frames[b]->cost2[i][jj] >= 0) continue;
+                    CostJob j;
+                    j.fenc = frames[b]; j.ref0 = frames[b - i]; j.ref1 = jj ? frames[p1] : nullptr; j.d0 = i; j.d1 = jj;
+                    jobs.push_back(j);
+                }
+            }
+        rc = frameCostMany(jobs);
+        if (rc != X265AMD_OK) return rc;
+    }
+    const bool isScenecut = scenecut(frames, 0, 1, true, origNumFrames, rc);       /* (run whatever the threshold: its estimates and marks stay) */
     if (rc != X265AMD_OK) return rc;
-    if (isScenecut) { frames[1]->type = TYPE_I; return X265AMD_OK; }
+    if (p.scenecutThreshold > 0 && isScenecut) { frames[1]->type = TYPE_I; return X265AMD_OK; }
     int resetStart;
     if (p.bframes)
     {
-        const int numBFrames = std::min(numFrames - 1, p.bframes);
-        for (int j = 1; j < numFrames; j++) frames[j]->type = (j % (numBFrames + 1)) ? TYPE_B : TYPE_P;
+        int numBFrames = std::min(numFrames - 1, p.bframes);
+        if (p.bFrameAdaptive == 2)
+        {
+            /* X265_B_ADAPT_TRELLIS (slicetype.cpp:2776-2795): the cheapest path of P / B decisions through the window */
+            numBFrames = 0;
+            if (numFrames > 1)
+            {
+                static thread_local char best_paths[17][251];
+                memset(best_paths, 0, sizeof(best_paths));
+                strcpy(best_paths[1], "P");
+                const int best_path_index = numFrames % 17;
+                for (int j = 2; j <= numFrames && rc == X265AMD_OK; j++) slicetypePath(frames, j, best_paths, rc);
+                if (rc != X265AMD_OK) return rc;
+                numBFrames = (int)strspn(best_paths[best_path_index], "B");
+                for (int j = 1; j < numFrames; j++) frames[j]->type = best_paths[best_path_index][j - 1] == 'B' ? TYPE_B : TYPE_P;
+            }
+        }
+        else
+            for (int j = 1; j < numFrames; j++) frames[j]->type = (j % (numBFrames + 1)) ? TYPE_B : TYPE_P;
         frames[numFrames]->type = TYPE_P;
         int numAnalyzed = numFrames;
         /* Check scenecut on the first minigop. */
@@ -839,7 +1024,8 @@ static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
         for (size_t r = 0; r < lists[l].size(); r++)
         {
             const int diffPoc = abs(pic.poc - lists[l][r]->poc);
-            if (l == 0 && diffPoc <= p.bframes + 1 && diffPoc < 18 && !pic.lowMvs[diffPoc].empty()) sp.lowres_mvs[l][r] = (uint64_t)(uintptr_t)pic.lowMvs[diffPoc].data();
+            const std::vector<int16_t>& f = l ? pic.lowMvs1[diffPoc < 18 ? diffPoc : 0] : pic.lowMvs[diffPoc < 18 ? diffPoc : 0];
+            if (diffPoc <= p.bframes + 1 && diffPoc < 18 && !f.empty()) sp.lowres_mvs[l][r] = (uint64_t)(uintptr_t)f.data();
         }
 
     x265amd_slice_info& si = c.si;
@@ -1425,11 +1611,15 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         pic->poc = e->frameCount++;
         int rc = e->uploadPicture(picIn, *pic);
         if (rc) return -1;
+        const auto tl0 = std::chrono::steady_clock::now();
         if (e->lookahead && (rc = e->lowresInit(*pic)) != X265AMD_OK) return -1;
+        e->laInitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
         e->input.push_back(pic);
     }
+    const auto tl1 = std::chrono::steady_clock::now();
     if (e->lookahead) { if (e->decideLookahead(picIn == nullptr) != X265AMD_OK) return -1; }
     else e->decideMiniGop(picIn == nullptr);
+    e->laDecideMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl1).count();
     /* every typed picture is prepared in coding order here (DPB::prepareEncode is bookkeeping: it does not wait for any picture to be coded); the frame itself is a task */
     while (!e->ready.empty())
     {

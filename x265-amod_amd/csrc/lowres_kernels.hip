@@ -269,25 +269,47 @@ XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, in
     return bcost;
 }
 
+XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pixel* buf, pixel* buf2);
 __global__ __launch_bounds__(64) void k_lowres_cost(LowresCostParams p)
 {
     __shared__ pixel fencT[64];
     __shared__ pixel buf[64];
     __shared__ pixel buf2[64];
+    lowres_cost_row(p, (int)blockIdx.x, fencT, buf, buf2);
+}
+/* many estimates as one launch: blockIdx.y = the estimate, blockIdx.x = its block row (bottom row first).  A row waits only for the row dispatched before it, so the
+ * rows of an estimate need not all be resident: thousands of rows (hundreds of estimates) go into one grid and the device runs as many side by side as it holds */
+__global__ __launch_bounds__(64) void k_lowres_cost_batch(const LowresCostParams* jobs)
+{
+    __shared__ pixel fencT[64];
+    __shared__ pixel buf[64];
+    __shared__ pixel buf2[64];
+    __shared__ LowresCostParams sp;
+    static_assert(sizeof(LowresCostParams) % 8 == 0, "copied in 64-bit words");
+    for (int i = threadIdx.x; i < (int)(sizeof(LowresCostParams) / 8); i += 64) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(jobs + blockIdx.y)[i];
+    __syncthreads();
+    if ((int)blockIdx.x >= sp.heightInCU) return;
+    lowres_cost_row(sp, (int)blockIdx.x, fencT, buf, buf2);
+}
+XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pixel* buf, pixel* buf2)
+{
     const int lane = xa_lane();
-    const int cuY = p.heightInCU - 1 - (int)blockIdx.x;            /* bottom row first */
+    const int cuY = p.heightInCU - 1 - row;            /* bottom row first */
     const bool lastRow = cuY == p.heightInCU - 1;
     const int W = p.widthInCU;
     LrBlock b;
     b.fencT = fencT; b.buf = buf; b.p = &p; b.lane = lane;
     for (int cuX = W - 1; cuX >= 0; cuX--)
     {
-        if (!lastRow)
+        /* (an estimate that only measures -- both motion fields exist -- has no order between its blocks: the neighbours' vectors are read, not made) */
+        if (!lastRow && (p.doSearch[0] || p.doSearch[1]))
         {
             const int need = cuX > 0 ? cuX - 1 : 0;
-            if (lane == 0) while (__atomic_load_n(&p.progress[cuY + 1], __ATOMIC_ACQUIRE) > need) __builtin_amdgcn_s_sleep(2);
+            /* the spin reads the word with a relaxed load at agent scope -- an acquire in the loop invalidates the caches on every look, and with hundreds of
+             * estimates in one grid thousands of waiting rows did nothing else --, one acquire fence follows when the row may go on */
+            if (lane == 0) while (__hip_atomic_load(&p.progress[cuY + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > need) __builtin_amdgcn_s_sleep(8);
             xa_wave_sync();
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const int cuXY = cuX + cuY * W;
         b.off = 8L * cuX + 8L * cuY * p.stride;
@@ -369,10 +391,53 @@ __global__ __launch_bounds__(64) void k_lowres_cost(LowresCostParams p)
         {
             p.bcost[cuXY] = bcost;
             p.lowresCosts[cuXY] = (uint16_t)(min(bcost, 0x3FFF) | (listused << 14));
-            __threadfence();
-            __atomic_store_n(&p.progress[cuY], cuX, __ATOMIC_RELEASE);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&p.progress[cuY], cuX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+extern "C" int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265amd_lowres_cost_job* jobs, int n, intptr_t stride, int width_in_cu, int height_in_cu)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!me || !jobs || width_in_cu <= 0 || height_in_cu <= 0 || n > 65535) return xa_fail(X265AMD_EINVAL, "x265amd_lowres_frame_cost_batch: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LowresCostParams> ps((size_t)n);
+    void* dParams = nullptr; void* dProgress = nullptr;
+    if (xa_scratch_alloc(&dParams, sizeof(LowresCostParams) * n) != hipSuccess || xa_scratch_alloc(&dProgress, sizeof(int32_t) * (size_t)n * height_in_cu) != hipSuccess)
+    { xa_scratch_free(dParams); xa_scratch_free(dProgress); return xa_fail(X265AMD_EHIP, "x265amd_lowres_frame_cost_batch: device allocation"); }
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_lowres_cost_job& j = jobs[i];
+        if (!j.d_fenc || !j.d_ref0[0] || !j.d_intra_cost || !j.d_mvs0 || !j.d_mv_costs0 || !j.d_lowres_costs || !j.d_bcost || (j.d_ref1[0] && (!j.d_mvs1 || !j.d_mv_costs1)))
+        { xa_scratch_free(dParams); xa_scratch_free(dProgress); return xa_fail(X265AMD_EINVAL, "x265amd_lowres_frame_cost_batch: bad job"); }
+        LowresCostParams& p = ps[(size_t)i];
+        memset(&p, 0, sizeof(p));
+        p.fenc = (const pixel*)j.d_fenc;
+        for (int k = 0; k < 4; k++) { p.ref[0][k] = (const pixel*)j.d_ref0[k]; p.ref[1][k] = (const pixel*)j.d_ref1[k]; }
+        p.stride = (long)stride; p.widthInCU = width_in_cu; p.heightInCU = height_in_cu; p.bidir = j.d_ref1[0] != nullptr;
+        p.doSearch[0] = j.do_search0 != 0; p.doSearch[1] = p.bidir && j.do_search1;
+        p.merange = 16;
+        p.intraCost = j.d_intra_cost;
+        p.mvs[0] = j.d_mvs0; p.mvCosts[0] = j.d_mv_costs0; p.mvs[1] = j.d_mvs1; p.mvCosts[1] = j.d_mv_costs1;
+        p.lowresCosts = j.d_lowres_costs; p.bcost = j.d_bcost;
+        p.cost = xa_me_device_mvcost(me, 12 + 6 * (XA_DEPTH - 8));
+        p.progress = (int*)dProgress + (size_t)i * height_in_cu;
+    }
+    std::vector<int32_t> init((size_t)n * height_in_cu, width_in_cu);
+    hipError_t e = hipMemcpyAsync(dProgress, init.data(), sizeof(int32_t) * init.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(dParams, ps.data(), sizeof(LowresCostParams) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(k_lowres_cost_batch, dim3(height_in_cu, n), dim3(64), 0, st, (const LowresCostParams*)dParams);
+        e = hipGetLastError();
+    }
+    /* the records and the rows' progress words are read until the kernel ends: the caller's wait for the results is ours too */
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    xa_scratch_free(dParams); xa_scratch_free(dProgress);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
 }
 
 extern "C" int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref0[4],
