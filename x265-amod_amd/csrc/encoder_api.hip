@@ -771,25 +771,51 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
                 j.fenc = frames[b]; j.ref0 = frames[p0]; j.ref1 = p1 > b ? frames[p1] : nullptr; j.d0 = i; j.d1 = p1 - b;
                 jobs.push_back(j);
             }
+        /* (the first picture of the window is not in the reference's batch: its estimate against the last non-B picture is what the scene-cut check and every path
+         * of the trellis start with) */
+        if (frames[1]->lowMvs[1].empty()) { CostJob j; j.fenc = frames[1]; j.ref0 = frames[0]; j.d0 = 1; jobs.push_back(j); }
+        /* ... nor is the last one, the P picture every path ends with (see below for why searching ahead of the trellis is safe) */
+        for (int i = 1; i <= p.bframes + 1 && i <= numFrames && numFrames > 1; i++)
+            if (frames[numFrames]->lowMvs[i].empty()) { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; jobs.push_back(j); }
+        rc = frameCostMany(jobs);
+        if (rc != X265AMD_OK) return rc;
+        /* What the batch leaves to the trellis -- the fields towards pictures behind that it pairs with no distance before (the first picture's; every picture's towards
+         * the window's last) -- searched side by side as well instead of one estimate at a time when a path asks.  A field the reference never comes to search (a path
+         * given up early) is never read by the encoder either: a picture is coded with the reference pictures of the path that won, and that path was priced to its end. */
+        jobs.clear();
+        for (int b = 1; b < numFrames; b++)
+            for (int jj = 1; jj <= p.bframes; jj++)
+            {
+                const int p1 = b + jj;
+                if (p1 > numFrames) break;
+                if (!frames[b]->lowMvs1[jj].empty() || frames[b]->lowMvs[1].empty()) continue;
+                CostJob j;
+                j.fenc = frames[b]; j.ref0 = frames[b - 1]; j.ref1 = frames[p1]; j.d0 = 1; j.d1 = jj;
+                jobs.push_back(j);
+            }
         rc = frameCostMany(jobs);
         if (rc != X265AMD_OK) return rc;
         /* ... and every cost the trellis can ask for of these pictures, side by side (m_bBatchFrameCosts, :2696-2734: nothing but a cache -- the reference fills it
          * with a pool of more than twelve workers, and one by one on demand otherwise) */
         jobs.clear();
-        for (int b = 2; b < numFrames; b++)
+        for (int b = 1; b < numFrames; b++)
             for (int i = 1; i <= p.bframes + 1; i++)
             {
                 if (b < i || frames[b]->lowMvs[i].empty()) continue;
                 for (int jj = 0; jj <= p.bframes; jj++)
                 {
                     const int p1 = b + jj;
-                    if (p1 >= numFrames) break;
+                    if (p1 > numFrames) break;
                     if ((jj && frames[b]->lowMvs1[jj].empty()) || frames[b]->cost2[i][jj] >= 0) continue;
                     CostJob j;
                     j.fenc = frames[b]; j.ref0 = frames[b - i]; j.ref1 = jj ? frames[p1] : nullptr; j.d0 = i; j.d1 = jj;
                     jobs.push_back(j);
                 }
             }
+        /* the last picture of the window as a P picture at every distance (the trellis' path ends) */
+        for (int i = 1; i <= p.bframes + 1 && i <= numFrames; i++)
+            if (!frames[numFrames]->lowMvs[i].empty() && frames[numFrames]->cost2[i][0] < 0)
+            { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; jobs.push_back(j); }
         rc = frameCostMany(jobs);
         if (rc != X265AMD_OK) return rc;
     }
