@@ -148,6 +148,17 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
     return bytes(stream), dt
 
 
+def nal_count(stream, nal_type):
+    """NAL units of one type in an Annex-B stream"""
+    n, i = 0, 0
+    while True:
+        i = stream.find(b"\x00\x00\x01", i)
+        if i < 0 or i + 3 >= len(stream):
+            return n
+        n += ((stream[i + 3] >> 1) & 63) == nal_type
+        i += 3
+
+
 def queue_stats(L, reset):
     """x265amd_queue_stats (include/x265amd.h): the counters of the resident kernel k_job_server since the last reset"""
     out = (C.c_uint64 * 106)()
@@ -306,7 +317,7 @@ def main():
         # algorithmic bytes of a frame = payload x (source read + reconstruction write + distinct reference pictures read)
         payload = W * H * 3 // 2
         n_i = 1
-        n_b = sum(1 for t in range(1, K) if t % (BFRAMES + 1) != 0 and t != K - 1)          # fixed mini-GOPs: P every BFRAMES + 1 frames, the last frame a P
+        n_b = nal_count(stream, 0)                                                          # TRAIL_N slices: the B pictures the lookahead chose (--b-adapt 2)
         n_p = K - n_i - n_b
         alg = payload * (2 * n_i + (2 + min(REFS, 2)) * n_p + 4 * n_b)                        # short clip: P frames see up to the pictures coded so far
         line = {
