@@ -1687,12 +1687,19 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
      * comes from another picture, and an I picture takes as long as a dozen of the others -- started when the lookahead hands it over, it is coded beside the pictures
      * in front of it instead of holding up the ones behind it (X265AMD_EARLY_I=0: in turn).  Output stays in coding order. */
     static const bool earlyI = !(getenv("X265AMD_EARLY_I") && atoi(getenv("X265AMD_EARLY_I")) == 0);
+    static const bool earlyP = !(getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 0);
+    static const int earlyPMax = getenv("X265AMD_EARLY_P_MAX") ? atoi(getenv("X265AMD_EARLY_P_MAX")) : 6;
     for (auto& q : e->inflight)
     {
         if (q->started) continue;
-        if (e->running <= e->frameThreads) { start(q); if (e->frameThreads <= 1) q->done.wait(); continue; }
+        /* the first picture in coding order always runs: it is the one collected next, whatever started ahead of its turn */
+        if (e->running <= e->frameThreads || q == e->inflight.front()) { start(q); if (e->frameThreads <= 1) q->done.wait(); continue; }
         if (!(e->frameParallel && earlyI)) break;
         if (q->type == TYPE_IDR || q->type == TYPE_I) start(q);
+        /* The P pictures are the chain every other picture hangs on (each follows its reference by a few CTU rows, the B pictures between two of them follow both): a P
+         * picture held back until the B pictures in front of it have been collected starts with nothing to trail and takes its full latency, so it starts when the
+         * lookahead hands it over, too (every picture it references is in front of it in coding order and therefore started; X265AMD_EARLY_P=0: in turn). */
+        else if (earlyP && q->type == TYPE_P && e->running <= e->frameThreads + earlyPMax) start(q);
     }
     if (e->inflight.empty()) return 0;
     PicP front = e->inflight.front();
