@@ -68,6 +68,11 @@ typedef struct x265amd_param
                                              * slicetypePath / slicetypePathCost, slicetype.cpp:2776-2795, :3218-3313) on P and B cost estimates of the lowres pictures,
                                              * every pair of the window searched in advance as the reference's batch does with four pool workers or more.  1 (fast)
                                              * is not built */
+    int32_t bOpenGOP;                       /* param.bOpenGOP (--open-gop, the reference's default; 0 = --no-open-gop): keyframes after the first are I pictures with
+                                             * NAL type CRA instead of IDR (Lookahead::slicetypeDecide, slicetype.cpp:1956-1993; DPB::getNalUnitType, dpb.cpp:486-506):
+                                             * the POC count runs on, the B pictures in front of a keyframe stay B (leading pictures, RASL_N) and reference across it,
+                                             * the pictures before the keyframe leave the DPB with the first picture after it in output order (decodingRefreshMarking,
+                                             * dpb.cpp:357-399); the lookahead's window reaches one picture beyond the keyframe interval (slicetype.cpp:2660-2661) */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -3020,7 +3020,7 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3406,6 +3406,27 @@ BA_CASES = {
     "ba2_nosc/": ((320, 192), 14, 8, ("ft", None), dict(BA_BASE, bframes=4, lookaheadDepth=6, scenecutThreshold=0), ["--bframes", "4", "--rc-lookahead", "6", "--no-scenecut"]),   # accelerating motion, no scene-cut detection
     "ba2_hbd/": ((256, 192), 12, 10, ("api", None), dict(BA_BASE, bframes=2, lookaheadDepth=5), ["--bframes", "2", "--rc-lookahead", "5"]),
 }
+
+
+# --open-gop (the reference's default): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of OG_CLI)
+OG_CLI = [o for o in BA_CLI if o != "--no-open-gop"] + ["--open-gop"]
+OG_BASE = dict(BA_BASE, bOpenGOP=1)
+OG_CASES = {
+    "og_cut/": ((320, 192), 18, 8, ("scene", [6, 12]), dict(OG_BASE, bframes=3, lookaheadDepth=8, keyframeMin=4), ["--bframes", "3", "--rc-lookahead", "8", "--min-keyint", "4"]),     # scene cuts: CRA pictures
+    "og_keyint/": ((320, 192), 20, 8, ("api", None), dict(OG_BASE, bframes=3, lookaheadDepth=5, keyframeMax=7, keyframeMin=7, bFrameAdaptive=0, scenecutThreshold=0),
+                   ["--bframes", "3", "--rc-lookahead", "5", "--keyint", "7", "--min-keyint", "7", "--b-adapt", "0", "--no-scenecut"]),     # fixed mini-GOPs: B pictures in front of every keyframe (RASL)
+    "og_keyint_ba/": ((320, 192), 22, 8, ("api", None), dict(OG_BASE, bframes=4, lookaheadDepth=10, keyframeMax=9, keyframeMin=2), ["--bframes", "4", "--rc-lookahead", "10", "--keyint", "9", "--min-keyint", "2"]),   # the trellis across keyframes
+    "og_hbd/": ((256, 192), 14, 10, ("ft", None), dict(OG_BASE, bframes=2, lookaheadDepth=5, keyframeMax=6, keyframeMin=3), ["--bframes", "2", "--rc-lookahead", "5", "--keyint", "6", "--min-keyint", "3"]),
+}
+
+
+def og_case_frames(tag):
+    (w, h), n, depth, (kind, arg), _, _ = OG_CASES[tag]
+    if kind == "scene":
+        return scene_clip(w, h, n, arg, depth)
+    if kind == "ft":
+        return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
+    return encoder_api_clip(tag, w, h, n, depth)
 
 
 def ba_case_frames(tag):

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 184 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 192 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -288,6 +288,42 @@ def test_b_adapt_golden_has_varied_mini_gops():
             else:
                 runs.add(n); n = 0
     assert {0, 1, 2, 3, 4} <= runs | {0}, runs
+
+
+OG_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_og_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.OG_CASES))
+def test_open_gop(tag):
+    """x265amd_param.bOpenGOP = 1 (--open-gop, the reference's default): keyframes after the first are I pictures of NAL type CRA (slicetype.cpp:1956-1993, dpb.cpp:486-506), the B
+    pictures in front of a keyframe stay B (RASL_N) and reference across it, the pictures before the keyframe leave the DPB with the first picture behind it in output order
+    (dpb.cpp:357-399), the lookahead's window reaches one picture beyond the keyframe interval (slicetype.cpp:2660-2661): the reference encoder's stream at scene cuts, with fixed
+    mini-GOPs across keyframes, with the trellis across keyframes, 10-bit.  Golden data: tests/golden/make_golden.py og."""
+    g = np.load(OG_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.OG_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.og_case_frames(tag), w, h, **cfg)
+    names = {1: "I", 2: "i", 3: "P", 5: "b"}
+    got_types = ["%d:%s" % (poc, names[st]) for (poc, st, _, _) in coded]
+    assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+
+
+def test_open_gop_golden_has_leading_pictures():
+    """the golden streams hold what the cases are there for: CRA NAL units (type 21) and leading pictures (RASL_N, type 8)"""
+    g = np.load(OG_GOLD)
+    for tag, want in (("og_cut/", {21}), ("og_keyint/", {21, 8}), ("og_keyint_ba/", {21, 8}), ("og_hbd/", {21})):
+        b = bytes(bytearray(g[tag + "stream"]))
+        types, i = set(), 0
+        while True:
+            i = b.find(b"\x00\x00\x01", i)
+            if i < 0:
+                break
+            types.add((b[i + 3] >> 1) & 63); i += 3
+        assert want <= types, (tag, types)
 
 
 @pytest.mark.gpu

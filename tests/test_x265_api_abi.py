@@ -105,6 +105,8 @@ ABI_CASES = {
     "sao_bframes/": ("frame_pipeline_golden.npz", None, ["--bframes", "2", "--rc-lookahead", "5", "--no-b-pyramid", "--sao"]),
     "hbd_b/": ("encoder_api_golden.npz", ((192, 136), 7), ["--bframes", "2", "--rc-lookahead", "5", "--no-b-pyramid", "--sao", "--rect", "--amp"]),
     "wvga/": ("encoder_api_golden.npz", ((832, 480), 5), ["--bframes", "2", "--rc-lookahead", "5", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"]),
+    # open GOPs, the trellis and scene-cut detection through the table: the command line of tests/hevc_testlib.py OG_CASES as it stands
+    "og_keyint_ba/": ("encoder_og_golden.npz", "og", None),
 }
 
 
@@ -115,7 +117,12 @@ def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
     depth = 10 if tag.startswith("hbd") else 8
     driver = os.path.join(T.REF_DIR, "x265_abi_driver%d" % depth)
     assert os.path.exists(driver), "oracle/build_ref.sh builds oracle/_ref/x265_abi_driver{8,10} (it travels to the GPU box with the snapshot)"
-    if clip is None:
+    cli = None
+    if clip == "og":
+        (w, h), n, depth, _, _, extra = T.OG_CASES[tag]
+        frames = T.og_case_frames(tag)
+        cli = list(T.OG_CLI)
+    elif clip is None:
         frames, stride, cstride, org = T.frame_clip_b(8)
         frames = [T.frame_planes(f, stride, cstride, org) for f in frames]
         w, h = T.MC_W, T.MC_H
@@ -123,8 +130,9 @@ def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
         (w, h), n = clip
         frames = T.encoder_api_clip(tag, w, h, n, depth)
     want = np.load(os.path.join(T.GOLDEN_DIR, gold))[tag + "stream"]
-    cli = [a for a in T.FRAME_CLI_ARGS if a not in ("--no-deblock", "--no-sao")]
-    if "--wpp" in extra:
+    if cli is None:
+        cli = [a for a in T.FRAME_CLI_ARGS if a not in ("--no-deblock", "--no-sao")]
+    if "--wpp" in extra and "--no-wpp" in cli:
         cli = [a for a in cli if a != "--no-wpp"]
     lib = os.path.join(T.PKG_DIR, "lib", "libx265amd_main.so" if depth == 8 else "libx265amd_main10.so")
     _write_y4m(tmp_path / "clip.y4m", frames, w, h, depth)

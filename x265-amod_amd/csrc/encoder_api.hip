@@ -51,6 +51,7 @@ struct Pic
     int32_t refPoc[2][16];
     /* what DPB::prepareEncode decided for this picture (coding order, main thread) */
     int nalType = 0, lastIDR = 0;
+    bool rpsUsed = true;                                /* used_by_curr_pic flags of the picture's RPS: off for an IRAP picture (DPB::computeRPS, dpb.cpp:320) */
     std::vector<PicP> neg, pos, lists[2];
     /* the frame task: result code when the picture is completely coded (reconstruction final, NAL written) */
     std::shared_future<int> done;
@@ -103,6 +104,8 @@ struct x265amd_encoder
     int qpConstant[3] = { 0, 0, 0 };                    /* indexed by slice type 0 B, 1 P, 2 I */
     int maxDecPicBuffering = 0, numReorderPics = 0;
     int frameCount = 0, lastKeyframe = 0, lastIDR = 0;
+    bool haveKeyframe = false, refreshPending = false;  /* open GOPs: a keyframe has been typed (the first one is an IDR picture); DPB::m_bRefreshPending */
+    int pocCRA = 0;                                     /* DPB::m_pocCRA */
     bool first = true;
     std::deque<PicP> input;                             /* display order, not yet typed */
     std::deque<PicP> ready;                             /* coding order, typed, not yet prepared */
@@ -751,7 +754,8 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
     const int keyFrameLimit = p.keyframeMax + lastKeyframe - frames[0]->poc - 1, keyintLimit = keyFrameLimit;
     const int origNumFrames = std::min(framecnt, keyintLimit);
     int numFrames = origNumFrames;
-    if (numFrames == 0) { frames[1]->type = TYPE_I; return X265AMD_OK; }
+    if (p.bOpenGOP && numFrames < framecnt) numFrames++;           /* open GOPs: the window takes in the keyframe (slicetype.cpp:2660-2661) */
+    else if (numFrames == 0) { frames[1]->type = TYPE_I; return X265AMD_OK; }
     int rc = X265AMD_OK;
     if (p.bFrameAdaptive == 2 && p.bframes)
     {
@@ -892,11 +896,16 @@ int x265amd_encoder::decideLookahead(bool flush)
         for (;; b++)
         {
             Pic& frm = *input[b];
-            if (frm.poc - lastKeyframe >= p.keyframeMax && (frm.type == TYPE_AUTO || frm.type == TYPE_I)) frm.type = TYPE_IDR;
-            if (frm.type == TYPE_I && frm.poc - lastKeyframe >= keyframeMin) frm.type = TYPE_IDR;         /* closed GOPs: a keyframe is an IDR picture */
+            if (frm.poc - lastKeyframe >= p.keyframeMax && (frm.type == TYPE_AUTO || frm.type == TYPE_I)) frm.type = p.bOpenGOP && haveKeyframe ? TYPE_I : TYPE_IDR;
+            if (frm.type == TYPE_I && frm.poc - lastKeyframe >= keyframeMin)
+            {
+                /* closed GOPs: a keyframe is an IDR picture; open GOPs: it stays an I picture (CRA) and the B pictures in front of it stay (slicetype.cpp:1985-1994) */
+                if (p.bOpenGOP) { lastKeyframe = frm.poc; frm.bKeyframe = true; haveKeyframe = true; }
+                else frm.type = TYPE_IDR;
+            }
             if (frm.type == TYPE_IDR)
             {
-                lastKeyframe = frm.poc; frm.bKeyframe = true;
+                lastKeyframe = frm.poc; frm.bKeyframe = true; haveKeyframe = true;
                 if (b > 0) { input[b - 1]->type = TYPE_P; b--; }
             }
             Pic& cur = *input[b];          /* (after the step back the tests below see the keyframe in the reference: they do nothing for it; the loop ends at the P picture) */
@@ -927,12 +936,18 @@ void x265amd_encoder::decideMiniGop(bool flush)
         for (;; b++)
         {
             Pic& frm = *input[b];
-            if (frm.poc - lastKeyframe >= p.keyframeMax) frm.type = TYPE_IDR;
+            if (frm.poc - lastKeyframe >= p.keyframeMax) frm.type = p.bOpenGOP && haveKeyframe ? TYPE_I : TYPE_IDR;
+            if (frm.type == TYPE_I)
+            {
+                /* open GOP: the keyframe is an I picture (CRA) that ends the mini-GOP; the B pictures in front of it stay and reference across it */
+                lastKeyframe = frm.poc; frm.bKeyframe = true;
+                break;
+            }
             if (frm.type == TYPE_IDR)
             {
                 /* closed GOP: the frame before a keyframe becomes P and ends the mini-GOP; the keyframe opens the next one */
                 if (b > 0) { input[b - 1]->type = TYPE_P; b--; break; }
-                lastKeyframe = frm.poc;
+                lastKeyframe = frm.poc; frm.bKeyframe = true; haveKeyframe = true;
                 break;
             }
             if (b == p.bframes || b + 1 >= (int)input.size()) { frm.type = TYPE_P; break; }
@@ -952,13 +967,33 @@ int x265amd_encoder::prepare(const PicP& picp)
 {
     Pic& pic = *picp;
     const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
-    pic.nalType = pic.type == TYPE_IDR ? 20 : (pic.type == TYPE_B ? 0 : 1);      /* IDR_N_LP, TRAIL_N, TRAIL_R */
-    if (pic.type == TYPE_IDR) lastIDR = pic.poc;
+    /* DPB::getNalUnitType (dpb.cpp:486-506): IDR_N_LP 20; a keyframe of an open GOP CRA 21; pictures in front of the last CRA picture in output order RASL 9 / 8,
+     * in front of the last IDR picture RADL 7 / 6; the rest TRAIL 1 / 0 (the second number: B pictures, which nobody references, prepareEncode dpb.cpp:156-172) */
+    int nal;
+    if (pic.type == TYPE_IDR) nal = 20;
+    else if (pic.bKeyframe && p.bOpenGOP) nal = 21;
+    else if (pocCRA && pic.poc < pocCRA) nal = 9;
+    else if (lastIDR && pic.poc < lastIDR) nal = 7;
+    else nal = 1;
+    if (pic.type == TYPE_B && nal < 16) nal--;
+    pic.nalType = nal;
+    pic.rpsUsed = !(nal >= 16 && nal <= 23);
+    if (nal == 20) lastIDR = pic.poc;
     pic.lastIDR = lastIDR;
     pic.hasReferences = pic.type != TYPE_B;
     /* recycleUnreferenced: pictures nobody references leave the list */
     picList.erase(std::remove_if(picList.begin(), picList.end(), [](const PicP& q) { return !q->hasReferences; }), picList.end());
-    if (pic.type == TYPE_IDR) { for (auto& q : picList) q->hasReferences = false; }                 /* decodingRefreshMarking */
+    /* decodingRefreshMarking (dpb.cpp:357-399): an IDR picture empties the buffer; after a CRA picture the first picture behind it in output order does, keeping the CRA picture */
+    if (nal == 20) { for (auto& q : picList) q->hasReferences = false; }
+    else
+    {
+        if (refreshPending && pic.poc > pocCRA)
+        {
+            for (auto& q : picList) if (q->poc != pocCRA) q->hasReferences = false;
+            refreshPending = false;
+        }
+        if (nal == 21) { refreshPending = true; pocCRA = pic.poc; }
+    }
     std::vector<PicP> rps;                                                                              /* computeRPS */
     for (auto& q : picList)
     {
@@ -1082,8 +1117,8 @@ static int sliceNal(const x265amd_encoder& e, Pic& pic, const FrameCtx& c, const
     h.num_negative = (int32_t)pic.neg.size(); h.num_positive = (int32_t)pic.pos.size();
     {
         int j = 0;
-        for (const PicP& q : pic.neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
-        for (const PicP& q : pic.pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = 1; }
+        for (const PicP& q : pic.neg) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = pic.rpsUsed; }
+        for (const PicP& q : pic.pos) { h.delta_poc[j] = q->poc - pic.poc; h.used[j++] = pic.rpsUsed; }
     }
     h.temporal_mvp_enabled = p.bEnableTemporalMvp != 0;
     h.use_sao = p.bEnableSAO != 0; h.sao_luma = saoFlags[0]; h.sao_chroma = saoFlags[1];
