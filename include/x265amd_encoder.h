@@ -8,7 +8,8 @@
  * per-frame calls into the frame pipeline (x265amd_analyse_frame, deblocking, SAO, border extension, slice NAL) and the stream headers.
  *
  * Built subset (everything else is rejected by x265amd_encoder_open with NULL + x265amd_last_error): 4:2:0, bit depth of the library,
- * constant QP (rc.rateControlMode = X265_RC_CQP), fixed mini-GOPs (bFrameAdaptive 0, no scenecut, no B-pyramid, closed GOPs), no AQ /
+ * constant QP (rc.rateControlMode = X265_RC_CQP), mini-GOPs fixed or chosen by the lookahead's trellis (bFrameAdaptive 0 / 2), scene-cut detection, open or
+ * closed GOPs, no B-pyramid, no AQ /
  * cutree / weighted prediction, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
  * is the reference encoder's (tests/test_encoder_api.py compares whole streams with the reference command line program's). */
 #ifndef X265AMD_ENCODER_H
@@ -25,7 +26,7 @@ typedef struct x265amd_param
     int32_t sourceWidth, sourceHeight;      /* luma samples; multiples of 8 */
     uint32_t fpsNum, fpsDenom;
     int32_t bframes;                        /* consecutive B frames of a mini-GOP (0..16); bFrameAdaptive is 0 */
-    int32_t keyframeMax;                    /* IDR interval (closed GOP) */
+    int32_t keyframeMax;                    /* keyframe interval (--keyint): IDR pictures with closed GOPs, CRA pictures with bOpenGOP */
     int32_t maxNumReferences;               /* --ref */
     int32_t qp;                             /* rc.qp (CQP) */
     double ipFactor, pbFactor;              /* rc.ipFactor / rc.pbFactor: QP offsets of I and B slices */
