@@ -74,6 +74,11 @@ typedef struct x265amd_param
                                              * the POC count runs on, the B pictures in front of a keyframe stay B (leading pictures, RASL_N) and reference across it,
                                              * the pictures before the keyframe leave the DPB with the first picture after it in output order (decodingRefreshMarking,
                                              * dpb.cpp:357-399); the lookahead's window reaches one picture beyond the keyframe interval (slicetype.cpp:2660-2661) */
+    int32_t bBPyramid;                      /* param.bBPyramid (--b-pyramid, the reference's default; 0 = --no-b-pyramid): in a mini-GOP of two B pictures or more the middle
+                                             * one is a reference picture (Lookahead::placeBref, slicetype.cpp:1755-1762, :2372-2376): coded right behind the P picture,
+                                             * NAL type TRAIL_R, slice QP between P and B (ratecontrol.cpp:1594-1595), referenced by the B pictures on either side of it
+                                             * (two L1 references at most, dpb.cpp:273) and by later pictures while it stays in the DPB; two reorder pictures in the
+                                             * VPS / SPS (level.cpp:295); the trellis prices the B pictures against it (slicetype.cpp:3291-3302) */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

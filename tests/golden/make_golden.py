@@ -635,12 +635,13 @@ def make_encoder_ba_golden():
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "encoder_ba_golden.npz"), **out)
 
 
-def make_encoder_og_golden():
-    """the same with open GOPs (T.OG_CASES: CRA keyframes, leading pictures) -> tests/golden/encoder_og_golden.npz"""
+def make_encoder_og_golden(cases=None, frames_of=None, cli=None, name="encoder_og_golden.npz"):
+    """the same with open GOPs (T.OG_CASES: CRA keyframes, leading pictures) -> tests/golden/encoder_og_golden.npz; with a B pyramid (T.BP_CASES) -> encoder_bp_golden.npz"""
     import subprocess, tempfile, hashlib
     out = {}
-    for tag, ((w, h), nframes, depth, _, _, extra) in T.OG_CASES.items():
-        planes = T.og_case_frames(tag)
+    cases = cases or T.OG_CASES; frames_of = frames_of or T.og_case_frames; cli = cli or T.OG_CLI
+    for tag, ((w, h), nframes, depth, _, _, extra) in cases.items():
+        planes = frames_of(tag)
         with tempfile.TemporaryDirectory() as d:
             with open(os.path.join(d, "clip.y4m"), "wb") as f:
                 f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
@@ -649,7 +650,7 @@ def make_encoder_og_golden():
                     for pl in fr:
                         f.write(np.ascontiguousarray(pl).tobytes())
             exe = os.path.join(T.REF_DIR, "x265_ref%d" % depth)
-            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv", "--csv", "log.csv", "--csv-log-level", "1"] + T.OG_CLI + extra, cwd=d, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv", "--csv", "log.csv", "--csv-log-level", "1"] + cli + extra, cwd=d, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
             fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
@@ -663,12 +664,14 @@ def make_encoder_og_golden():
             out[tag + "recon_md5"] = np.array([hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)])
             out[tag + "types"] = np.array(types)
             print(tag, len(out[tag + "stream"]), "bytes", " ".join(types))
-    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "encoder_og_golden.npz"), **out)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, name), **out)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "og":
         make_encoder_og_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "bp":
+        make_encoder_og_golden(T.BP_CASES, T.bp_case_frames, T.BP_CLI, "encoder_bp_golden.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "sc":
         make_encoder_sc_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "ba":

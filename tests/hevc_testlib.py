@@ -3020,7 +3020,7 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3422,6 +3422,29 @@ OG_CASES = {
 
 def og_case_frames(tag):
     (w, h), n, depth, (kind, arg), _, _ = OG_CASES[tag]
+    if kind == "scene":
+        return scene_clip(w, h, n, arg, depth)
+    if kind == "ft":
+        return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
+    return encoder_api_clip(tag, w, h, n, depth)
+
+
+# --b-pyramid (the reference's default): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of BP_CLI)
+BP_CLI = [o for o in BA_CLI if o != "--no-b-pyramid"] + ["--b-pyramid"]
+BP_BASE = dict(BA_BASE, bBPyramid=1)
+BP_CASES = {
+    "bp_fixed/": ((320, 192), 15, 8, ("api", None), dict(BP_BASE, bframes=3, lookaheadDepth=5, bFrameAdaptive=0, scenecutThreshold=0), ["--bframes", "3", "--rc-lookahead", "5", "--b-adapt", "0", "--no-scenecut"]),
+    "bp_ba2/": ((320, 192), 20, 8, ("api", None), dict(BP_BASE, bframes=4, lookaheadDepth=10), ["--bframes", "4", "--rc-lookahead", "10"]),           # the trellis prices the pyramid
+    "bp_og_cut/": ((320, 192), 18, 8, ("scene", [9]), dict(BP_BASE, bframes=3, lookaheadDepth=8, bOpenGOP=1, keyframeMax=14, keyframeMin=2),
+                   ["--bframes", "3", "--rc-lookahead", "8", "--open-gop", "--keyint", "14", "--min-keyint", "2"]),     # with open GOPs: a scene cut and an interval keyframe
+    "bp_ft/": ((320, 192), 26, 8, ("ft", None), dict(BP_BASE, bframes=4, lookaheadDepth=10), ["--bframes", "4", "--rc-lookahead", "10"]),            # accelerating motion: mini-GOPs of varying length over several windows
+    "bp_deep/": ((320, 192), 30, 8, ("scene", [17]), dict(BP_BASE, bframes=6, lookaheadDepth=15, maxNumReferences=4, bOpenGOP=1), ["--bframes", "6", "--rc-lookahead", "15", "--ref", "4", "--open-gop"]),
+    "bp_hbd/": ((256, 192), 12, 10, ("ft", None), dict(BP_BASE, bframes=3, lookaheadDepth=5, bFrameAdaptive=0), ["--bframes", "3", "--rc-lookahead", "5", "--b-adapt", "0"]),
+}
+
+
+def bp_case_frames(tag):
+    (w, h), n, depth, (kind, arg), _, _ = BP_CASES[tag]
     if kind == "scene":
         return scene_clip(w, h, n, arg, depth)
     if kind == "ft":

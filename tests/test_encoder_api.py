@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 192 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 192 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -305,6 +305,32 @@ def test_open_gop(tag):
     stream, coded = T.encoder_run(T.load_hip(depth), T.og_case_frames(tag), w, h, **cfg)
     names = {1: "I", 2: "i", 3: "P", 5: "b"}
     got_types = ["%d:%s" % (poc, names[st]) for (poc, st, _, _) in coded]
+    assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+
+
+BP_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_bp_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.BP_CASES))
+def test_b_pyramid(tag):
+    """x265amd_param.bBPyramid = 1 (--b-pyramid, the reference's default): the middle B picture of a mini-GOP of two or more is a reference picture (Lookahead::placeBref,
+    slicetype.cpp:1755-1762, :2372-2376) coded right behind the P picture with a QP between P and B (ratecontrol.cpp:1594-1595), up to two L1 references (dpb.cpp:273), two
+    reorder pictures in the VPS / SPS (level.cpp:295), the trellis pricing B pictures against it (slicetype.cpp:3291-3302): the reference encoder's stream with fixed mini-GOPs,
+    with the trellis, with open GOPs and a scene cut, 10-bit.  Golden data: tests/golden/make_golden.py bp."""
+    g = np.load(BP_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.BP_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.bp_case_frames(tag), w, h, **cfg)
+    names = {1: "I", 2: "i", 3: "P", 4: "B", 5: "b"}
+    got_types, idr = [], 0
+    for (poc, st, _, _) in coded:
+        if st == 1:
+            idr = poc           # the reference's log counts from the last IDR picture
+        got_types.append("%d:%s" % (poc - idr, names[st]))
     assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
     for (poc, _, _, planes) in coded:
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()

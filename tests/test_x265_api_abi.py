@@ -71,7 +71,7 @@ def test_encoder_open_names_what_it_rejects():
     assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2       # scene-cut detection itself is built; its cost estimates in slices are not
     buf[LAYOUT["PARAM_lookaheadSlices"]] = 0
-    assert not opn(p) and b"bBPyramid" in lib.x265amd_last_error()
+    assert not opn(p) and b"weighted prediction" in lib.x265amd_last_error()       # the B pyramid and open GOPs (the defaults) are built
     free(p)
 
 
@@ -107,6 +107,7 @@ ABI_CASES = {
     "wvga/": ("encoder_api_golden.npz", ((832, 480), 5), ["--bframes", "2", "--rc-lookahead", "5", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"]),
     # open GOPs, the trellis and scene-cut detection through the table: the command line of tests/hevc_testlib.py OG_CASES as it stands
     "og_keyint_ba/": ("encoder_og_golden.npz", "og", None),
+    "bp_deep/": ("encoder_bp_golden.npz", "bp", None),          # B pyramid + open GOPs + the trellis + a scene cut: --preset medium's GOP structure but for weighted prediction and lookahead slices
 }
 
 
@@ -118,10 +119,10 @@ def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
     driver = os.path.join(T.REF_DIR, "x265_abi_driver%d" % depth)
     assert os.path.exists(driver), "oracle/build_ref.sh builds oracle/_ref/x265_abi_driver{8,10} (it travels to the GPU box with the snapshot)"
     cli = None
-    if clip == "og":
-        (w, h), n, depth, _, _, extra = T.OG_CASES[tag]
-        frames = T.og_case_frames(tag)
-        cli = list(T.OG_CLI)
+    if clip in ("og", "bp"):
+        (w, h), n, depth, _, _, extra = (T.OG_CASES if clip == "og" else T.BP_CASES)[tag]
+        frames = (T.og_case_frames if clip == "og" else T.bp_case_frames)(tag)
+        cli = list(T.OG_CLI if clip == "og" else T.BP_CLI)
     elif clip is None:
         frames, stride, cstride, org = T.frame_clip_b(8)
         frames = [T.frame_planes(f, stride, cstride, org) for f in frames]

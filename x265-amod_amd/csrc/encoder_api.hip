@@ -32,7 +32,8 @@
 namespace {
 
 typedef x265amd_pixel pixel;
-enum { TYPE_AUTO = 0, TYPE_IDR = 1, TYPE_I = 2, TYPE_P = 3, TYPE_B = 5 };          /* X265_TYPE_* (x265.h:572-577) */
+enum { TYPE_AUTO = 0, TYPE_IDR = 1, TYPE_I = 2, TYPE_P = 3, TYPE_BREF = 4, TYPE_B = 5 };          /* X265_TYPE_* (x265.h:572-577) */
+static inline bool isBType(int t) { return t == TYPE_B || t == TYPE_BREF; }         /* IS_X265_TYPE_B */
 enum { RD_TILE_ELEMS = 4096 + 2 * 1024 };
 
 struct Pic;
@@ -159,6 +160,7 @@ struct x265amd_encoder
     bool isSceneTransition = false;                     /* Lookahead::m_isSceneTransition */
     hipStream_t laStream = nullptr;
     int lowresInit(Pic& pic);
+    void pushMiniGop(int b);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
     struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
@@ -278,7 +280,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     e->qpConstant[0] = clipQp((int)(p->qp + pbOffset + 0.5));
     if (e->qpConstant[0] > 51 || e->qpConstant[2] > 51) { xa_fail(X265AMD_EINVAL, "encoder_open: slice QP above 51"); return nullptr; }
     /* level.cpp:290-296 */
-    e->numReorderPics = p->bframes ? 1 : 0;
+    e->numReorderPics = (p->bBPyramid && p->bframes > 1) ? 2 : (p->bframes ? 1 : 0);           /* enforceLevel (level.cpp:295-296) */
     e->maxDecPicBuffering = std::min(16, std::max(e->numReorderPics + 2, p->maxNumReferences) + 1);
     if (p->firstFrame < 0) { xa_fail(X265AMD_EINVAL, "encoder_open: firstFrame"); return nullptr; }
     e->frameCount = p->firstFrame; e->lastKeyframe = p->firstFrame - p->keyframeMax; e->lastIDR = p->firstFrame;
@@ -644,11 +646,20 @@ int64_t x265amd_encoder::slicetypePathCost(std::vector<Pic*>& frames, const char
         rc = frameCost(frames, cur_p, next_p, next_p, c);
         cost += c;
         if (cost > threshold) break;
-        for (int next_b = loc; next_b < next_p && cost < threshold && rc == X265AMD_OK; next_b++)
+        if (p.bBPyramid && next_p - cur_p > 2)
         {
-            rc = frameCost(frames, cur_p, next_p, next_b, c);
-            cost += c;
+            /* the middle B picture is a reference: the ones in front of it are priced between cur_p and it, the ones behind between it and next_p (slicetype.cpp:3291-3302) */
+            const int middle = cur_p + (next_p - cur_p) / 2;
+            if (rc == X265AMD_OK) { rc = frameCost(frames, cur_p, next_p, middle, c); cost += c; }
+            for (int next_b = loc; next_b < middle && cost < threshold && rc == X265AMD_OK; next_b++) { rc = frameCost(frames, cur_p, middle, next_b, c); cost += c; }
+            for (int next_b = middle + 1; next_b < next_p && cost < threshold && rc == X265AMD_OK; next_b++) { rc = frameCost(frames, middle, next_p, next_b, c); cost += c; }
         }
+        else
+            for (int next_b = loc; next_b < next_p && cost < threshold && rc == X265AMD_OK; next_b++)
+            {
+                rc = frameCost(frames, cur_p, next_p, next_b, c);
+                cost += c;
+            }
         loc = next_p + 1;
         cur_p = next_p;
     }
@@ -779,7 +790,9 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
          * of the trellis start with) */
         if (frames[1]->lowMvs[1].empty()) { CostJob j; j.fenc = frames[1]; j.ref0 = frames[0]; j.d0 = 1; jobs.push_back(j); }
         /* ... nor is the last one, the P picture every path ends with (see below for why searching ahead of the trellis is safe) */
-        for (int i = 1; i <= p.bframes + 1 && i <= numFrames && numFrames > 1; i++)
+        /* (with a B pyramid the encoder's pictures reference B pictures the trellis priced them against differently -- its "middle" is not the mini-GOP's -- so which
+         * fields exist when a picture is coded is no longer "those of the winning path": nothing is searched ahead of the trellis then, it searches as it asks) */
+        for (int i = 1; i <= p.bframes + 1 && i <= numFrames && numFrames > 1 && !p.bBPyramid; i++)
             if (frames[numFrames]->lowMvs[i].empty()) { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; jobs.push_back(j); }
         rc = frameCostMany(jobs);
         if (rc != X265AMD_OK) return rc;
@@ -787,7 +800,7 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
          * the window's last) -- searched side by side as well instead of one estimate at a time when a path asks.  A field the reference never comes to search (a path
          * given up early) is never read by the encoder either: a picture is coded with the reference pictures of the path that won, and that path was priced to its end. */
         jobs.clear();
-        for (int b = 1; b < numFrames; b++)
+        for (int b = 1; b < numFrames && !p.bBPyramid; b++)
             for (int jj = 1; jj <= p.bframes; jj++)
             {
                 const int p1 = b + jj;
@@ -875,6 +888,18 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
     return X265AMD_OK;
 }
 
+/* The typed mini-GOP input[0 .. b] goes to `ready` in coding order (slicetype.cpp:2372-2376, :2443-2470): with a B pyramid and two B pictures or more the middle one
+ * becomes a reference (Lookahead::placeBref: index (0 + b) / 2); the non-B picture first, then the referenced B picture, then the other B pictures in display order */
+void x265amd_encoder::pushMiniGop(int b)
+{
+    if (p.bBPyramid && b > 1) input[b / 2]->type = TYPE_BREF;
+    ready.push_back(input[b]);
+    for (int i = 0; i < b; i++) if (input[i]->type == TYPE_BREF) ready.push_back(input[i]);
+    for (int i = 0; i < b; i++) if (input[i]->type != TYPE_BREF) ready.push_back(input[i]);
+    input.erase(input.begin(), input.begin() + b + 1);
+    first = false;
+}
+
 /* Lookahead::slicetypeDecide (slicetype.cpp:1802-2400) as far as the built subset goes: runs when the input queue holds lookaheadDepth pictures (Lookahead::findJob,
  * m_fullQueueSize; one picture is enough once the caller flushes), types the next mini-GOP and moves it to `ready` in coding order.  Returns 0, or an error code. */
 int x265amd_encoder::decideLookahead(bool flush)
@@ -918,10 +943,7 @@ int x265amd_encoder::decideLookahead(bool flush)
             else break;
         }
         lastNonB = input[b];
-        ready.push_back(input[b]);
-        for (int i = 0; i < b; i++) ready.push_back(input[i]);
-        input.erase(input.begin(), input.begin() + b + 1);
-        first = false;
+        pushMiniGop(b);
     }
     return X265AMD_OK;
 }
@@ -953,11 +975,7 @@ void x265amd_encoder::decideMiniGop(bool flush)
             if (b == p.bframes || b + 1 >= (int)input.size()) { frm.type = TYPE_P; break; }
             frm.type = TYPE_B;
         }
-        /* coding order: the non-B frame first, then the B frames in display order */
-        ready.push_back(input[b]);
-        for (int i = 0; i < b; i++) ready.push_back(input[i]);
-        input.erase(input.begin(), input.begin() + b + 1);
-        first = false;
+        pushMiniGop(b);
         if (!flush) return;
     }
 }
@@ -966,7 +984,7 @@ void x265amd_encoder::decideMiniGop(bool flush)
 int x265amd_encoder::prepare(const PicP& picp)
 {
     Pic& pic = *picp;
-    const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
+    const int stype = isBType(pic.type) ? 0 : pic.type == TYPE_P ? 1 : 2;
     /* DPB::getNalUnitType (dpb.cpp:486-506): IDR_N_LP 20; a keyframe of an open GOP CRA 21; pictures in front of the last CRA picture in output order RASL 9 / 8,
      * in front of the last IDR picture RADL 7 / 6; the rest TRAIL 1 / 0 (the second number: B pictures, which nobody references, prepareEncode dpb.cpp:156-172) */
     int nal;
@@ -1008,13 +1026,13 @@ int x265amd_encoder::prepare(const PicP& picp)
     std::sort(pic.pos.begin(), pic.pos.end(), [](const PicP& a, const PicP& b) { return a->poc < b->poc; });
     if (stype != 2)
     {
-        const int n0 = std::min(std::max(1, (int)pic.neg.size()), p.maxNumReferences), n1 = stype == 0 ? std::min(1, (int)pic.pos.size()) : 0;
+        const int n0 = std::min(std::max(1, (int)pic.neg.size()), p.maxNumReferences), n1 = stype == 0 ? std::min(p.bBPyramid ? 2 : 1, (int)pic.pos.size()) : 0;       /* dpb.cpp:269-273 */
         std::vector<PicP> l0(pic.neg), l1(pic.pos);
         l0.insert(l0.end(), pic.pos.begin(), pic.pos.end()); l1.insert(l1.end(), pic.neg.begin(), pic.neg.end());
         if ((int)l0.size() < n0 || (int)l1.size() < n1 || (stype == 0 && !n1)) return xa_fail(X265AMD_EINVAL, "encoder_encode: reference lists");
         pic.lists[0].assign(l0.begin(), l0.begin() + n0); pic.lists[1].assign(l1.begin(), l1.begin() + n1);
     }
-    pic.sliceQp = qpConstant[stype];                    /* rateControlStart, CQP */
+    pic.sliceQp = pic.type == TYPE_BREF ? (qpConstant[0] + qpConstant[1]) / 2 : qpConstant[stype];                    /* rateControlStart, CQP (ratecontrol.cpp:1594-1597: a referenced B picture lies between B and P) */
     picList.insert(picList.begin(), picp);              /* PicList::pushFront */
     if (frameParallel)
     {
@@ -1047,7 +1065,7 @@ struct FrameCtx
 static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
 {
     const x265amd_param& p = e.p;
-    const int stype = pic.type == TYPE_B ? 0 : pic.type == TYPE_P ? 1 : 2;
+    const int stype = isBType(pic.type) ? 0 : pic.type == TYPE_P ? 1 : 2;
     c.stype = stype;
     const std::vector<PicP>* lists = pic.lists;
     std::vector<Pic*> index;
