@@ -78,8 +78,14 @@ struct Pic
     std::vector<int16_t> lowMvs1[18];       /* Lowres::lowresMvs[1][d]: against the picture d behind (B estimates: --b-adapt 2) */
     std::vector<int32_t> lowMvc[18], lowMvc1[18];   /* Lowres::lowresMvCosts: read again when a later estimate uses a field that exists */
     int64_t cost2[18][18];                  /* Lowres::costEst[b - p0][p1 - b] (B estimates scaled as estimateFrameCost does); [d][0] is costEst[d] */
+    /* Searched ahead of the trellis, not yet the picture's: fields and estimates the reference makes one at a time when a path asks for them (if it ever does).  They are made
+     * side by side in advance and become the picture's -- lowMvs / cost2 / costEst / intraMbs -- at the moment the reference would have made them (x265amd_encoder::frameCostAt),
+     * so what exists when a picture is coded, or when the scene-cut check looks for an estimate, is what exists in the reference */
+    std::vector<int16_t> specMvs[18], specMvs1[18];
+    std::vector<int32_t> specMvc[18], specMvc1[18];
+    int64_t specCost2[18][18]; int specIntraMbs[18];
     bool bScenecut = false, bKeyframe = false;
-    Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = -1; } }
+    Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
     ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x) { std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x; }
     int published(int row) const { const int v = (int)*finalX[row]; std::atomic_thread_fence(std::memory_order_acquire); return v; }
@@ -163,7 +169,7 @@ struct x265amd_encoder
     void pushMiniGop(int b);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
-    struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
+    struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
                      void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; std::vector<int32_t> bc; std::vector<uint16_t> lc; };
     int frameCostMany(std::vector<CostJob>& jobs);
     double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0;
@@ -545,6 +551,15 @@ int x265amd_encoder::frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1
 {
     if (d0 < 1 || d0 > 17 || d1 < 0 || d1 > 17 || (d1 > 0) != (ref1 != nullptr)) return xa_fail(X265AMD_EINVAL, "encoder: lookahead distance");
     if (fenc.cost2[d0][d1] >= 0) { score = fenc.cost2[d0][d1]; return X265AMD_OK; }
+    /* the reference makes this estimate now, with the searches its fields still lack: what was searched ahead becomes the picture's */
+    if (fenc.lowMvs[d0].empty() && !fenc.specMvs[d0].empty()) { fenc.lowMvs[d0].swap(fenc.specMvs[d0]); fenc.lowMvc[d0].swap(fenc.specMvc[d0]); }
+    if (d1 > 0 && fenc.lowMvs1[d1].empty() && !fenc.specMvs1[d1].empty()) { fenc.lowMvs1[d1].swap(fenc.specMvs1[d1]); fenc.lowMvc1[d1].swap(fenc.specMvc1[d1]); }
+    if (fenc.specCost2[d0][d1] >= 0 && !fenc.lowMvs[d0].empty() && (d1 == 0 || !fenc.lowMvs1[d1].empty()))
+    {
+        score = fenc.cost2[d0][d1] = fenc.specCost2[d0][d1];
+        if (d1 == 0) { fenc.costEst[d0] = score; fenc.intraMbs[d0] = fenc.specIntraMbs[d0]; }
+        return X265AMD_OK;
+    }
     std::vector<CostJob> one(1);
     one[0].fenc = &fenc; one[0].ref0 = &ref0; one[0].ref1 = ref1; one[0].d0 = d0; one[0].d1 = d1;
     const int rc = frameCostMany(one);
@@ -568,7 +583,15 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
     {
         CostJob& j = jobs[k];
         Pic& fenc = *j.fenc;
-        j.search0 = fenc.lowMvs[j.d0].empty(); j.search1 = j.d1 > 0 && fenc.lowMvs1[j.d1].empty();
+        if (!j.spec)
+        {
+            /* made for good now: a field searched ahead of its time is the one this estimate would search */
+            if (fenc.lowMvs[j.d0].empty() && !fenc.specMvs[j.d0].empty()) { fenc.lowMvs[j.d0].swap(fenc.specMvs[j.d0]); fenc.lowMvc[j.d0].swap(fenc.specMvc[j.d0]); }
+            if (j.d1 > 0 && fenc.lowMvs1[j.d1].empty() && !fenc.specMvs1[j.d1].empty()) { fenc.lowMvs1[j.d1].swap(fenc.specMvs1[j.d1]); fenc.lowMvc1[j.d1].swap(fenc.specMvc1[j.d1]); }
+        }
+        /* (an estimate made ahead of its time reads and fills the fields made ahead of their time as well as the picture's own) */
+        const bool have0 = !fenc.lowMvs[j.d0].empty() || (j.spec && !fenc.specMvs[j.d0].empty()), have1 = j.d1 > 0 && (!fenc.lowMvs1[j.d1].empty() || (j.spec && !fenc.specMvs1[j.d1].empty()));
+        j.search0 = !have0; j.search1 = j.d1 > 0 && !have1;
         laJobs++; laSearches += (j.search0 ? 1 : 0) + (j.search1 ? 1 : 0);
         void** bufs[6] = { &j.dMvs, &j.dMvc, &j.dLc, &j.dBc, &j.dMvs1, &j.dMvc1 };
         const size_t sizes[6] = { ncu * 4, ncu * 4, ncu * 2, ncu * 4, ncu * 4, ncu * 4 };
@@ -583,10 +606,11 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         q.d_mvs0 = (int16_t*)j.dMvs; q.d_mv_costs0 = (int32_t*)j.dMvc; q.d_mvs1 = (int16_t*)j.dMvs1; q.d_mv_costs1 = (int32_t*)j.dMvc1;
         q.d_lowres_costs = (uint16_t*)j.dLc; q.d_bcost = (int32_t*)j.dBc; q.do_search0 = j.search0; q.do_search1 = j.search1;
         bool ok = true;
-        if (!j.search0) ok = hipMemcpyAsync(j.dMvs, fenc.lowMvs[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
-                             hipMemcpyAsync(j.dMvc, fenc.lowMvc[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
-        if (ok && j.d1 > 0 && !j.search1) ok = hipMemcpyAsync(j.dMvs1, fenc.lowMvs1[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
-                                               hipMemcpyAsync(j.dMvc1, fenc.lowMvc1[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
+        const bool own0 = !fenc.lowMvs[j.d0].empty(), own1 = j.d1 > 0 && !fenc.lowMvs1[j.d1].empty();
+        if (!j.search0) ok = hipMemcpyAsync(j.dMvs, (own0 ? fenc.lowMvs : fenc.specMvs)[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
+                             hipMemcpyAsync(j.dMvc, (own0 ? fenc.lowMvc : fenc.specMvc)[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
+        if (ok && j.d1 > 0 && !j.search1) ok = hipMemcpyAsync(j.dMvs1, (own1 ? fenc.lowMvs1 : fenc.specMvs1)[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
+                                               hipMemcpyAsync(j.dMvc1, (own1 ? fenc.lowMvc1 : fenc.specMvc1)[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
         if (!ok) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost set-up");
     }
     /* one launch for all of them (blockIdx.y = the estimate): the device runs as many block rows side by side as it holds */
@@ -599,13 +623,15 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         bool ok = hipMemcpyAsync(j.bc.data(), j.dBc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(j.lc.data(), j.dLc, ncu * 2, hipMemcpyDeviceToHost, laStream) == hipSuccess;
         if (ok && j.search0)
         {
-            fenc.lowMvs[j.d0].resize(ncu * 2); fenc.lowMvc[j.d0].resize(ncu);
-            ok = hipMemcpyAsync(fenc.lowMvs[j.d0].data(), j.dMvs, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(fenc.lowMvc[j.d0].data(), j.dMvc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+            std::vector<int16_t>& mv = (j.spec ? fenc.specMvs : fenc.lowMvs)[j.d0]; std::vector<int32_t>& mc = (j.spec ? fenc.specMvc : fenc.lowMvc)[j.d0];
+            mv.resize(ncu * 2); mc.resize(ncu);
+            ok = hipMemcpyAsync(mv.data(), j.dMvs, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(mc.data(), j.dMvc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
         }
         if (ok && j.search1)
         {
-            fenc.lowMvs1[j.d1].resize(ncu * 2); fenc.lowMvc1[j.d1].resize(ncu);
-            ok = hipMemcpyAsync(fenc.lowMvs1[j.d1].data(), j.dMvs1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(fenc.lowMvc1[j.d1].data(), j.dMvc1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+            std::vector<int16_t>& mv = (j.spec ? fenc.specMvs1 : fenc.lowMvs1)[j.d1]; std::vector<int32_t>& mc = (j.spec ? fenc.specMvc1 : fenc.lowMvc1)[j.d1];
+            mv.resize(ncu * 2); mc.resize(ncu);
+            ok = hipMemcpyAsync(mv.data(), j.dMvs1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(mc.data(), j.dMvc1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
         }
         if (!ok) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
     }
@@ -615,13 +641,19 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         CostJob& j = jobs[k];
         void* bufs[6] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
         for (void* b : bufs) xa_scratch_free(b);
-        if (rc != X265AMD_OK) { if (j.search0) { j.fenc->lowMvs[j.d0].clear(); j.fenc->lowMvc[j.d0].clear(); } if (j.search1) { j.fenc->lowMvs1[j.d1].clear(); j.fenc->lowMvc1[j.d1].clear(); } continue; }
+        if (rc != X265AMD_OK)
+        {
+            if (j.search0) { (j.spec ? j.fenc->specMvs : j.fenc->lowMvs)[j.d0].clear(); (j.spec ? j.fenc->specMvc : j.fenc->lowMvc)[j.d0].clear(); }
+            if (j.search1) { (j.spec ? j.fenc->specMvs1 : j.fenc->lowMvs1)[j.d1].clear(); (j.spec ? j.fenc->specMvc1 : j.fenc->lowMvc1)[j.d1].clear(); }
+            continue;
+        }
         int64_t est = 0; int imb = 0;
         const bool all = lowCuW <= 2 || lowCuH <= 2;
         for (int y = 0; y < lowCuH; y++)
             for (int x = 0; x < lowCuW; x++)
                 if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) { est += j.bc[(size_t)y * lowCuW + x]; imb += (j.lc[(size_t)y * lowCuW + x] >> 14) == 0; }
         if (j.d1 > 0) est = est * 100 / (130 + 0);          /* param.bFrameBias: the default */
+        if (j.spec) { j.fenc->specCost2[j.d0][j.d1] = est; if (j.d1 == 0) j.fenc->specIntraMbs[j.d0] = imb; continue; }
         j.fenc->cost2[j.d0][j.d1] = est;
         if (j.d1 == 0) { j.fenc->costEst[j.d0] = est; j.fenc->intraMbs[j.d0] = imb; }
     }
@@ -789,50 +821,53 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
         /* (the first picture of the window is not in the reference's batch: its estimate against the last non-B picture is what the scene-cut check and every path
          * of the trellis start with) */
         if (frames[1]->lowMvs[1].empty()) { CostJob j; j.fenc = frames[1]; j.ref0 = frames[0]; j.d0 = 1; jobs.push_back(j); }
-        /* ... nor is the last one, the P picture every path ends with (see below for why searching ahead of the trellis is safe) */
-        /* (with a B pyramid the encoder's pictures reference B pictures the trellis priced them against differently -- its "middle" is not the mini-GOP's -- so which
-         * fields exist when a picture is coded is no longer "those of the winning path": nothing is searched ahead of the trellis then, it searches as it asks) */
-        for (int i = 1; i <= p.bframes + 1 && i <= numFrames && numFrames > 1 && !p.bBPyramid; i++)
-            if (frames[numFrames]->lowMvs[i].empty()) { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; jobs.push_back(j); }
+        /* ... nor is the last one, the P picture every path ends with: searched now, side by side with the batch, but AHEAD OF ITS TIME (CostJob::spec) -- the field and the
+         * estimate wait in the picture's spec* members until the trellis asks for them, as everything below does */
+        auto hasL0 = [](const Pic* f, int d) { return !f->lowMvs[d].empty() || !f->specMvs[d].empty(); };
+        auto hasL1 = [](const Pic* f, int d) { return !f->lowMvs1[d].empty() || !f->specMvs1[d].empty(); };
+        for (int i = 1; i <= p.bframes + 1 && i <= numFrames && numFrames > 1; i++)
+            if (!hasL0(frames[numFrames], i)) { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; j.spec = true; jobs.push_back(j); }
         rc = frameCostMany(jobs);
         if (rc != X265AMD_OK) return rc;
         /* What the batch leaves to the trellis -- the fields towards pictures behind that it pairs with no distance before (the first picture's; every picture's towards
-         * the window's last) -- searched side by side as well instead of one estimate at a time when a path asks.  A field the reference never comes to search (a path
-         * given up early) is never read by the encoder either: a picture is coded with the reference pictures of the path that won, and that path was priced to its end. */
+         * the window's last) -- searched side by side as well instead of one estimate at a time when a path asks.  Whether the reference ever makes one of them depends on
+         * the paths it prices and where it gives them up, and with a B pyramid the encoder's pictures reference pictures the trellis did not price them against: so they
+         * are made ahead of their time, and only what a path asks for becomes the picture's (frameCostAt). */
         jobs.clear();
-        for (int b = 1; b < numFrames && !p.bBPyramid; b++)
+        for (int b = 1; b < numFrames; b++)
             for (int jj = 1; jj <= p.bframes; jj++)
             {
                 const int p1 = b + jj;
                 if (p1 > numFrames) break;
-                if (!frames[b]->lowMvs1[jj].empty() || frames[b]->lowMvs[1].empty()) continue;
+                if (hasL1(frames[b], jj) || !hasL0(frames[b], 1)) continue;
                 CostJob j;
-                j.fenc = frames[b]; j.ref0 = frames[b - 1]; j.ref1 = frames[p1]; j.d0 = 1; j.d1 = jj;
+                j.fenc = frames[b]; j.ref0 = frames[b - 1]; j.ref1 = frames[p1]; j.d0 = 1; j.d1 = jj; j.spec = true;
                 jobs.push_back(j);
             }
         rc = frameCostMany(jobs);
         if (rc != X265AMD_OK) return rc;
-        /* ... and every cost the trellis can ask for of these pictures, side by side (m_bBatchFrameCosts, :2696-2734: nothing but a cache -- the reference fills it
-         * with a pool of more than twelve workers, and one by one on demand otherwise) */
+        /* ... and every cost the trellis can ask for of these pictures, side by side.  Those of m_bBatchFrameCosts (:2696-2734: pictures 2 .. numFrames - 1 against fields
+         * that exist, the picture behind inside the window; the reference fills them with a pool of more than twelve workers) are the pictures' at once, the rest wait */
         jobs.clear();
         for (int b = 1; b < numFrames; b++)
             for (int i = 1; i <= p.bframes + 1; i++)
             {
-                if (b < i || frames[b]->lowMvs[i].empty()) continue;
+                if (b < i || !hasL0(frames[b], i)) continue;
                 for (int jj = 0; jj <= p.bframes; jj++)
                 {
                     const int p1 = b + jj;
                     if (p1 > numFrames) break;
-                    if ((jj && frames[b]->lowMvs1[jj].empty()) || frames[b]->cost2[i][jj] >= 0) continue;
+                    if ((jj && !hasL1(frames[b], jj)) || frames[b]->cost2[i][jj] >= 0 || frames[b]->specCost2[i][jj] >= 0) continue;
                     CostJob j;
                     j.fenc = frames[b]; j.ref0 = frames[b - i]; j.ref1 = jj ? frames[p1] : nullptr; j.d0 = i; j.d1 = jj;
+                    j.spec = !(b >= 2 && p1 < numFrames && !frames[b]->lowMvs[i].empty() && (!jj || !frames[b]->lowMvs1[jj].empty()));
                     jobs.push_back(j);
                 }
             }
         /* the last picture of the window as a P picture at every distance (the trellis' path ends) */
         for (int i = 1; i <= p.bframes + 1 && i <= numFrames; i++)
-            if (!frames[numFrames]->lowMvs[i].empty() && frames[numFrames]->cost2[i][0] < 0)
-            { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; jobs.push_back(j); }
+            if (hasL0(frames[numFrames], i) && frames[numFrames]->cost2[i][0] < 0 && frames[numFrames]->specCost2[i][0] < 0)
+            { CostJob j; j.fenc = frames[numFrames]; j.ref0 = frames[numFrames - i]; j.d0 = i; j.spec = true; jobs.push_back(j); }
         rc = frameCostMany(jobs);
         if (rc != X265AMD_OK) return rc;
     }
