@@ -1017,6 +1017,9 @@ typedef struct x265amd_lowres_cost_job
     int16_t* d_mvs0; int32_t* d_mv_costs0; int16_t* d_mvs1; int32_t* d_mv_costs1;
     uint16_t* d_lowres_costs; int32_t* d_bcost;
     int32_t do_search0, do_search1;
+    int32_t rows_per_slice, num_slices;     /* num_slices > 1: the estimate in cooperative slices (the reference's estimates outside its batches, param.lookaheadSlices:
+                                             * Lookahead::m_numRowsPerSlice / m_numCoopSlices, slicetype.cpp:1047-1054): block rows [k rows_per_slice, (k + 1) rows_per_slice), the
+                                             * last slice to the bottom, are searched independently -- a slice's bottom row takes no predictors from below.  0 / 0: one chain */
 } x265amd_lowres_cost_job;
 int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265amd_lowres_cost_job* jobs, int n, intptr_t stride, int width_in_cu, int height_in_cu);
 

@@ -79,6 +79,10 @@ typedef struct x265amd_param
                                              * NAL type TRAIL_R, slice QP between P and B (ratecontrol.cpp:1594-1595), referenced by the B pictures on either side of it
                                              * (two L1 references at most, dpb.cpp:273) and by later pictures while it stays in the DPB; two reorder pictures in the
                                              * VPS / SPS (level.cpp:295); the trellis prices the B pictures against it (slicetype.cpp:3291-3302) */
+    int32_t lookaheadSlices;                /* param.lookaheadSlices (--lookahead-slices; the reference's default 8, 0 and 1 = off; off below 720 lines whatever it says):
+                                             * the lookahead's estimates outside its batches run in cooperative slices of max(rows / slices, 10) block rows
+                                             * (slicetype.cpp:1035-1059, :3957-3970, :4004-4036) -- a slice's bottom row takes no motion predictors from the row below, so
+                                             * the fields (the encoder's search candidates) and costs differ from the whole-picture ones */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -3020,7 +3020,7 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3450,6 +3450,28 @@ def bp_case_frames(tag):
     if kind == "ft":
         return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
     return encoder_api_clip(tag, w, h, n, depth)
+
+
+# --lookahead-slices (the reference's default 8; only from 720 lines up): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of LS_CLI)
+LS_CLI = [o for i, o in enumerate(BA_CLI) if o not in ("--lookahead-slices", "--no-open-gop", "--no-b-pyramid") and BA_CLI[i - 1] != "--lookahead-slices"] + ["--open-gop", "--b-pyramid"]
+LS_BASE = dict(BA_BASE, bOpenGOP=1, bBPyramid=1)
+LS_CASES = {
+    # the preset's GOP structure as it comes: --b-adapt 2, --bframes 4, B pyramid, open GOPs, scene-cut detection, --lookahead-slices 8 (1280x720: 45 block rows, 4 slices of 11)
+    "ls_medium/": ((1280, 720), 14, 8, ("ft", None), dict(LS_BASE, bframes=4, lookaheadDepth=8, lookaheadSlices=8), ["--bframes", "4", "--rc-lookahead", "8", "--lookahead-slices", "8"]),
+    "ls_sc/": ((1280, 720), 12, 8, ("ft_cut", 7), dict(LS_BASE, bframes=3, lookaheadDepth=6, lookaheadSlices=3, bFrameAdaptive=0, bBPyramid=0),
+               ["--bframes", "3", "--rc-lookahead", "6", "--lookahead-slices", "3", "--b-adapt", "0", "--no-b-pyramid"]),          # fixed mini-GOPs: every estimate is the scene-cut check's, all in slices (3 of 15 rows)
+}
+
+
+def ls_case_frames(tag):
+    (w, h), n, depth, (kind, arg), _, _ = LS_CASES[tag]
+    if kind == "survey_cut":        # the noise field changes and the picture jumps at frame `arg`
+        return survey_clip(w, h, depth, 2, 0, arg, 0) + survey_clip(w, h, depth, 2, 40, n - arg, 3)
+    if kind == "ft_cut":            # accelerating motion, then another scene
+        return encoder_ft_clip(w, h, arg, depth, dy0=2, dy_inc=2, dx_step=4) + survey_clip(w, h, depth, 2, 40, n - arg, 3)
+    if kind == "ft":
+        return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
+    return survey_clip(w, h, depth, 2, 0, n, 0)
 
 
 def ba_case_frames(tag):

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 192 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 200 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -331,6 +331,28 @@ def test_b_pyramid(tag):
         if st == 1:
             idr = poc           # the reference's log counts from the last IDR picture
         got_types.append("%d:%s" % (poc - idr, names[st]))
+    assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+
+
+LS_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_ls_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.LS_CASES))
+def test_lookahead_slices(tag):
+    """x265amd_param.lookaheadSlices (--lookahead-slices, the reference's default 8, active from 720 lines): the lookahead's estimates outside its batches run in cooperative slices
+    (slicetype.cpp:1035-1059, :3957-3970, :4004-4036) -- a slice's bottom block row takes no motion predictors from the row below --, the batch searches whole pictures: the reference
+    encoder's stream at 1280x720 with the preset's GOP structure as it comes (--b-adapt 2, B pyramid, open GOPs, scene-cut detection, 8 slices asked = 4 of 11 rows), and with fixed
+    mini-GOPs where every estimate is the scene-cut check's (3 slices of 15 rows).  Both streams differ from the ones without slices.  Golden data: tests/golden/make_golden.py ls."""
+    g = np.load(LS_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.LS_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.ls_case_frames(tag), w, h, **cfg)
+    names = {1: "I", 2: "i", 3: "P", 4: "B", 5: "b"}
+    got_types = ["%d:%s" % (poc, names[st]) for (poc, st, _, _) in coded]
     assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
     for (poc, _, _, planes) in coded:
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()

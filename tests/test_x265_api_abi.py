@@ -66,12 +66,13 @@ def test_encoder_open_names_what_it_rejects():
     buf[LAYOUT["PARAM_sourceWidth"]] = 64; buf[LAYOUT["PARAM_sourceHeight"]] = 64; buf[LAYOUT["PARAM_fpsNum"]] = 30; buf[LAYOUT["PARAM_fpsDenom"]] = 1
     assert not opn(p) and b"rc.rateControlMode" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_rc_rateControlMode"]] = 1
-    assert not opn(p) and b"lookaheadSlices" in lib.x265amd_last_error()       # --b-adapt 2 (the default) and scene-cut detection are built; the lookahead in slices is not
     buf[LAYOUT["PARAM_bFrameAdaptive"]] = 1
     assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
-    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2       # scene-cut detection itself is built; its cost estimates in slices are not
-    buf[LAYOUT["PARAM_lookaheadSlices"]] = 0
-    assert not opn(p) and b"weighted prediction" in lib.x265amd_last_error()       # the B pyramid and open GOPs (the defaults) are built
+    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2
+    # --b-adapt 2, scene-cut detection, the lookahead in slices, the B pyramid and open GOPs (the defaults) are built; weighted prediction is not
+    assert not opn(p) and b"weighted prediction" in lib.x265amd_last_error()
+    buf[LAYOUT["PARAM_bEnableWeightedPred"]] = 0; buf[LAYOUT["PARAM_bEnableWeightedBiPred"]] = 0
+    assert not opn(p) and b"bEmitInfoSEI" in lib.x265amd_last_error()
     free(p)
 
 
@@ -107,6 +108,7 @@ ABI_CASES = {
     "wvga/": ("encoder_api_golden.npz", ((832, 480), 5), ["--bframes", "2", "--rc-lookahead", "5", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"]),
     # open GOPs, the trellis and scene-cut detection through the table: the command line of tests/hevc_testlib.py OG_CASES as it stands
     "og_keyint_ba/": ("encoder_og_golden.npz", "og", None),
+    "ls_medium/": ("encoder_ls_golden.npz", "ls", None),        # 1280x720: the lookahead in slices as well
     "bp_deep/": ("encoder_bp_golden.npz", "bp", None),          # B pyramid + open GOPs + the trellis + a scene cut: --preset medium's GOP structure but for weighted prediction and lookahead slices
 }
 
@@ -119,10 +121,11 @@ def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
     driver = os.path.join(T.REF_DIR, "x265_abi_driver%d" % depth)
     assert os.path.exists(driver), "oracle/build_ref.sh builds oracle/_ref/x265_abi_driver{8,10} (it travels to the GPU box with the snapshot)"
     cli = None
-    if clip in ("og", "bp"):
-        (w, h), n, depth, _, _, extra = (T.OG_CASES if clip == "og" else T.BP_CASES)[tag]
-        frames = (T.og_case_frames if clip == "og" else T.bp_case_frames)(tag)
-        cli = list(T.OG_CLI if clip == "og" else T.BP_CLI)
+    if clip in ("og", "bp", "ls"):
+        cases, frames_of, base = {"og": (T.OG_CASES, T.og_case_frames, T.OG_CLI), "bp": (T.BP_CASES, T.bp_case_frames, T.BP_CLI), "ls": (T.LS_CASES, T.ls_case_frames, T.LS_CLI)}[clip]
+        (w, h), n, depth, _, _, extra = cases[tag]
+        frames = frames_of(tag)
+        cli = list(base)
     elif clip is None:
         frames, stride, cstride, org = T.frame_clip_b(8)
         frames = [T.frame_planes(f, stride, cstride, org) for f in frames]

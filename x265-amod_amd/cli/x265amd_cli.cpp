@@ -134,6 +134,7 @@ int main(int argc, char** argv)
         else if (k == "--no-scenecut") p.scenecutThreshold = 0;
         else if (k == "--rc-lookahead") p.lookaheadDepth = atoi(v);
         else if (k == "--b-adapt") p.bFrameAdaptive = atoi(v);
+        else if (k == "--lookahead-slices") p.lookaheadSlices = atoi(v);
         else if (k == "--open-gop") p.bOpenGOP = 1;
         else if (k == "--b-pyramid") p.bBPyramid = 1;
         else if (k == "--no-b-pyramid") p.bBPyramid = 0;

@@ -160,6 +160,7 @@ struct x265amd_encoder
     int runFrameParallel(const PicP& pic);
     /* ---- the lookahead (slicetype.cpp): only when param.scenecutThreshold > 0 ---- */
     bool lookahead = false;
+    int laRowsPerSlice = 0, laNumSlices = 1;            /* Lookahead::m_numRowsPerSlice / m_numCoopSlices (slicetype.cpp:1035-1059) */
     int keyframeMin = 1, lowW = 0, lowH = 0, lowCuW = 0, lowCuH = 0, lowBlocks = 0;
     intptr_t lowStride = 0; size_t lowPlaneElems = 0, lowOrg = 0;
     PicP lastNonB;                                      /* Lookahead::m_lastNonB */
@@ -169,7 +170,7 @@ struct x265amd_encoder
     void pushMiniGop(int b);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
-    struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
+    struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool whole = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
                      void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; std::vector<int32_t> bc; std::vector<uint16_t> lc; };
     int frameCostMany(std::vector<CostJob>& jobs);
     double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0;
@@ -303,6 +304,11 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         e->keyframeMin = std::max(1, kmin);
         /* Lowres::create (lowres.cpp:52-110): half size rounded up to whole 8x8 blocks, the picture's margins, stride a multiple of 32 */
         e->lowCuW = (e->W / 2 + 7) >> 3; e->lowCuH = (e->H / 2 + 7) >> 3;
+        if (p->lookaheadSlices > 1 && e->H >= 720)
+        {
+            e->laRowsPerSlice = std::min(std::max(e->lowCuH / p->lookaheadSlices, 10), e->lowCuH);
+            e->laNumSlices = e->lowCuH / e->laRowsPerSlice;
+        }
         e->lowW = e->lowCuW * 8; e->lowH = e->lowCuH * 8;
         e->lowBlocks = (e->lowCuW > 2 && e->lowCuH > 2) ? (e->lowCuW - 2) * (e->lowCuH - 2) : e->lowCuW * e->lowCuH;
         e->lowStride = e->W / 2 + 2 * e->marginX;
@@ -583,9 +589,10 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
     {
         CostJob& j = jobs[k];
         Pic& fenc = *j.fenc;
-        if (!j.spec)
+        if (!j.spec && (!j.whole || laNumSlices <= 1))
         {
-            /* made for good now: a field searched ahead of its time is the one this estimate would search */
+            /* made for good now: a field searched ahead of its time is the one this estimate would search (with cooperative slices only if this estimate is one of those
+             * the reference makes in slices too: its batch searches whole pictures) */
             if (fenc.lowMvs[j.d0].empty() && !fenc.specMvs[j.d0].empty()) { fenc.lowMvs[j.d0].swap(fenc.specMvs[j.d0]); fenc.lowMvc[j.d0].swap(fenc.specMvc[j.d0]); }
             if (j.d1 > 0 && fenc.lowMvs1[j.d1].empty() && !fenc.specMvs1[j.d1].empty()) { fenc.lowMvs1[j.d1].swap(fenc.specMvs1[j.d1]); fenc.lowMvc1[j.d1].swap(fenc.specMvc1[j.d1]); }
         }
@@ -605,6 +612,7 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         q.d_intra_cost = fenc.dIntraCost;
         q.d_mvs0 = (int16_t*)j.dMvs; q.d_mv_costs0 = (int32_t*)j.dMvc; q.d_mvs1 = (int16_t*)j.dMvs1; q.d_mv_costs1 = (int32_t*)j.dMvc1;
         q.d_lowres_costs = (uint16_t*)j.dLc; q.d_bcost = (int32_t*)j.dBc; q.do_search0 = j.search0; q.do_search1 = j.search1;
+        if (!j.whole && laNumSlices > 1) { q.rows_per_slice = laRowsPerSlice; q.num_slices = laNumSlices; }
         bool ok = true;
         const bool own0 = !fenc.lowMvs[j.d0].empty(), own1 = j.d1 > 0 && !fenc.lowMvs1[j.d1].empty();
         if (!j.search0) ok = hipMemcpyAsync(j.dMvs, (own0 ? fenc.lowMvs : fenc.specMvs)[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
@@ -654,6 +662,9 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
                 if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) { est += j.bc[(size_t)y * lowCuW + x]; imb += (j.lc[(size_t)y * lowCuW + x] >> 14) == 0; }
         if (j.d1 > 0) est = est * 100 / (130 + 0);          /* param.bFrameBias: the default */
         if (j.spec) { j.fenc->specCost2[j.d0][j.d1] = est; if (j.d1 == 0) j.fenc->specIntraMbs[j.d0] = imb; continue; }
+        /* a field made for good replaces whatever was made ahead of its time for the same pair, and the estimates that were built on that */
+        if (j.search0) { j.fenc->specMvs[j.d0].clear(); j.fenc->specMvc[j.d0].clear(); for (int t = 0; t < 18; t++) j.fenc->specCost2[j.d0][t] = -1; }
+        if (j.search1) { j.fenc->specMvs1[j.d1].clear(); j.fenc->specMvc1[j.d1].clear(); for (int t = 0; t < 18; t++) j.fenc->specCost2[t][j.d1] = -1; }
         j.fenc->cost2[j.d0][j.d1] = est;
         if (j.d1 == 0) { j.fenc->costEst[j.d0] = est; j.fenc->intraMbs[j.d0] = imb; }
     }
@@ -815,7 +826,7 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
                 if (p1 >= numFrames || !frames[b]->lowMvs1[i].empty()) p1 = b;
                 if (frames[b]->cost2[i][p1 - b] >= 0) continue;
                 CostJob j;
-                j.fenc = frames[b]; j.ref0 = frames[p0]; j.ref1 = p1 > b ? frames[p1] : nullptr; j.d0 = i; j.d1 = p1 - b;
+                j.fenc = frames[b]; j.ref0 = frames[p0]; j.ref1 = p1 > b ? frames[p1] : nullptr; j.d0 = i; j.d1 = p1 - b; j.whole = true;         /* (batch mode: no cooperative slices, :4004) */
                 jobs.push_back(j);
             }
         /* (the first picture of the window is not in the reference's batch: its estimate against the last non-B picture is what the scene-cut check and every path
@@ -1776,6 +1787,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
      * in front of it instead of holding up the ones behind it (X265AMD_EARLY_I=0: in turn).  Output stays in coding order. */
     static const bool earlyI = !(getenv("X265AMD_EARLY_I") && atoi(getenv("X265AMD_EARLY_I")) == 0);
     static const bool earlyP = !(getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 0);
+    static const bool earlyBref = !(getenv("X265AMD_EARLY_BREF") && atoi(getenv("X265AMD_EARLY_BREF")) == 0);      /* a referenced B picture is a link of the same chain */
     static const int earlyPMax = getenv("X265AMD_EARLY_P_MAX") ? atoi(getenv("X265AMD_EARLY_P_MAX")) : 6;
     for (auto& q : e->inflight)
     {
@@ -1787,7 +1799,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         /* The P pictures are the chain every other picture hangs on (each follows its reference by a few CTU rows, the B pictures between two of them follow both): a P
          * picture held back until the B pictures in front of it have been collected starts with nothing to trail and takes its full latency, so it starts when the
          * lookahead hands it over, too (every picture it references is in front of it in coding order and therefore started; X265AMD_EARLY_P=0: in turn). */
-        else if (earlyP && q->type == TYPE_P && e->running <= e->frameThreads + earlyPMax) start(q);
+        else if (earlyP && (q->type == TYPE_P || (earlyBref && q->type == TYPE_BREF)) && e->running <= e->frameThreads + earlyPMax) start(q);
     }
     if (e->inflight.empty()) return 0;
     PicP front = e->inflight.front();

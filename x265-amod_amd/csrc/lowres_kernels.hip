@@ -127,6 +127,8 @@ struct LowresCostParams
     uint16_t* lowresCosts; int32_t* bcost;
     const uint16_t* cost;                       /* MV cost table centre */
     int* progress;                              /* per row: the leftmost finished block (widthInCU = none yet) */
+    int rowsPerSlice, numSlices;                /* cooperative slices (CostEstimateGroup::processTasks, slicetype.cpp:3957-3970): numSlices > 1 = block rows [k rowsPerSlice, (k + 1) rowsPerSlice)
+                                                 * (the last slice to the bottom) are chains of their own: a slice's bottom row takes no predictors from the row below */
 };
 
 struct LrBlock
@@ -295,7 +297,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
 {
     const int lane = xa_lane();
     const int cuY = p.heightInCU - 1 - row;            /* bottom row first */
-    const bool lastRow = cuY == p.heightInCU - 1;
+    const bool lastRow = cuY == p.heightInCU - 1 || (p.numSlices > 1 && (cuY + 1) % p.rowsPerSlice == 0 && (cuY + 1) / p.rowsPerSlice < p.numSlices);
     const int W = p.widthInCU;
     LrBlock b;
     b.fencT = fencT; b.buf = buf; b.p = &p; b.lane = lane;
@@ -423,6 +425,7 @@ extern "C" int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me,
         p.lowresCosts = j.d_lowres_costs; p.bcost = j.d_bcost;
         p.cost = xa_me_device_mvcost(me, 12 + 6 * (XA_DEPTH - 8));
         p.progress = (int*)dProgress + (size_t)i * height_in_cu;
+        p.rowsPerSlice = j.rows_per_slice; p.numSlices = j.rows_per_slice > 0 ? j.num_slices : 0;
     }
     std::vector<int32_t> init((size_t)n * height_in_cu, width_in_cu);
     hipError_t e = hipMemcpyAsync(dProgress, init.data(), sizeof(int32_t) * init.size(), hipMemcpyHostToDevice, st);
