@@ -1565,6 +1565,13 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 st = own;
             }
             {
+                /* the last rows of a picture are what the pictures behind it wait for (and a cut last row is a picture's slowest): their waits for the device poll a
+                 * while before the task parks (X265AMD_SPIN_US: microseconds, X265AMD_SPIN_ROWS: how many rows from the bottom; 0 = park at once) */
+                static const int spinUs = getenv("X265AMD_SPIN_US") ? atoi(getenv("X265AMD_SPIN_US")) : 0;
+                static const int spinRows = getenv("X265AMD_SPIN_ROWS") ? atoi(getenv("X265AMD_SPIN_ROWS")) : 1;
+                if (spinUs > 0 && row >= f.ctuH - spinRows) xa_task_spin_ns((uint64_t)spinUs * 1000);
+            }
+            {
                 static const char* const lg = getenv("X265AMD_QUEUE_LOG");
                 int lp = -1, lr = -1;
                 if (lg && sscanf(lg, "%d,%d", &lp, &lr) == 2 && lp == f.poc && lr == row && st && !own) xa_queue_log(st, lp, lr);

@@ -43,6 +43,10 @@ void xa_fiber_set_thread_init(void (*fn)(void));
 /* general condition: an ordinary thread polls it; a task is parked and the condition is evaluated by whichever worker holds the task at that moment */
 void xa_wait_until(XaPred pred, void* ctx);
 int xa_in_task(void);
+/* inside a task: from now on its counter waits poll for up to `ns` nanoseconds before the task parks (0: park at once).  For the few tasks everything else waits
+ * for -- the cut last CTU row of a picture that others reference: hundreds of device answers per CTU, each a few microseconds away, and a parked task comes back only
+ * when a worker is free to look */
+void xa_task_spin_ns(uint64_t ns);
 int xa_worker_count(void);
 /* X265AMD_TIMING: time the calling task has spent running (up to its last resume); totals over all workers: running, looking for a task that can run, switches */
 uint64_t xa_task_run_ns(void);

@@ -51,6 +51,7 @@ struct Fiber
     uint64_t stintStart = 0;            /* when it was last resumed */
     uint64_t userMark = 0;              /* for the caller's phase accounting */
     void* userSlot = nullptr;           /* a pointer of the caller's (the row's reference-picture guard) */
+    uint64_t spinNs = 0;                /* xa_task_spin_ns: how long a wait polls before the task parks */
     struct Worker* worker = nullptr;    /* the worker running it now */
 };
 
@@ -280,6 +281,7 @@ uint64_t xa_task_run_ns_always(void) { Worker* w = current_worker(); return w &&
 uint64_t* xa_task_mark(void) { Worker* w = current_worker(); return w && w->cur ? &w->cur->userMark : nullptr; }
 void xa_sched_stats(uint64_t out[3]) { out[0] = g_busyNs.load(); out[1] = g_idleNs.load(); out[2] = g_switches.load(); }
 int xa_in_task(void) { Worker* w = current_worker(); return w && w->cur; }
+void xa_task_spin_ns(uint64_t ns) { Worker* w = current_worker(); if (w && w->cur) w->cur->spinNs = ns; }
 
 void xa_tasks_run(const XaTask* tasks, int n)
 {
@@ -305,7 +307,7 @@ void xa_tasks_run(const XaTask* tasks, int n)
                 int expect = ST_EMPTY;
                 if (f.state.load(std::memory_order_acquire) != ST_EMPTY || !f.state.compare_exchange_strong(expect, ST_RUNNING, std::memory_order_acq_rel)) continue;
                 f.task = tasks[k]; f.group = &grp; f.pred = nullptr; f.predCtx = nullptr; f.sp = nullptr; f.stack = nullptr; f.scratchList = nullptr; f.worker = nullptr;
-                f.waitCounter.store(nullptr); f.waitValue.store(0); f.deadlineNs.store(0); f.runNs = 0; f.userMark = 0; f.userSlot = nullptr;
+                f.waitCounter.store(nullptr); f.waitValue.store(0); f.deadlineNs.store(0); f.runNs = 0; f.userMark = 0; f.userSlot = nullptr; f.spinNs = 0;
                 int hw = S.highWater.load(std::memory_order_acquire);
                 while (hw < i + 1 && !S.highWater.compare_exchange_weak(hw, i + 1, std::memory_order_acq_rel)) {}
                 S.live.fetch_add(1, std::memory_order_acq_rel);
@@ -331,6 +333,7 @@ void xa_wait_counter(const volatile uint64_t* counter, uint64_t value)
     {
         Fiber* f = w->cur;
         f->pred = nullptr;
+        if (f->spinNs) { const uint64_t t1 = now_ns() + f->spinNs; while (*counter < value && now_ns() < t1) _mm_pause(); if (*counter >= value) return; }
         do
         {
             f->waitValue.store(value, std::memory_order_release); f->waitCounter.store(counter, std::memory_order_release);
@@ -357,6 +360,7 @@ int xa_wait_counter_deadline(const volatile uint64_t* counter, uint64_t value, u
         Fiber* f = w->cur;
         f->pred = nullptr;
         int rc = 0;
+        if (f->spinNs) { const uint64_t t1 = now_ns() + f->spinNs; while (*counter < value && now_ns() < t1) _mm_pause(); if (*counter >= value) return 0; }
         do
         {
             f->deadlineNs.store(deadline, std::memory_order_release);
