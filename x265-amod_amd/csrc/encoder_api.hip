@@ -1787,7 +1787,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
      * in front of it instead of holding up the ones behind it (X265AMD_EARLY_I=0: in turn).  Output stays in coding order. */
     static const bool earlyI = !(getenv("X265AMD_EARLY_I") && atoi(getenv("X265AMD_EARLY_I")) == 0);
     static const bool earlyP = !(getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 0);
-    static const bool earlyBref = !(getenv("X265AMD_EARLY_BREF") && atoi(getenv("X265AMD_EARLY_BREF")) == 0);      /* a referenced B picture is a link of the same chain */
+    static const bool earlyBref = getenv("X265AMD_EARLY_BREF") && atoi(getenv("X265AMD_EARLY_BREF")) != 0;      /* a referenced B picture is a link of the same chain */
     static const int earlyPMax = getenv("X265AMD_EARLY_P_MAX") ? atoi(getenv("X265AMD_EARLY_P_MAX")) : 6;
     for (auto& q : e->inflight)
     {
