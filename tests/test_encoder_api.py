@@ -254,12 +254,16 @@ def test_scene_cut_detection(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,count", [("ft_b/", 2), ("sc_i/", 2), ("ft_vp/", 3)])
+@pytest.mark.parametrize("tag,count", [("ft_b/", 2), ("sc_i/", 2), ("ft_vp/", 3), ("bp_deep/", 2), ("bp_og_cut/", 3)])
 def test_frame_per_gpu_objects_alternate_pictures(tag, count):
     """SURVEY section 8e as written, on one GPU: `count` encoder objects, object r coding the pictures whose place in coding order is r modulo count, every finished
     CTU row carried from its owner to the others through x265amd_encoder_export_row / _import_row (what x265-amod_amd/frame_rows.py broadcasts between ranks).
     The owners' NAL units in coding order are the single object's stream -- the reference's -- and every object ends up with the same reconstructions."""
-    if tag in T.SC_CASES:
+    if tag in T.BP_CASES:           # B pyramid, open GOPs, the trellis: referenced B pictures' rows travel like the P pictures', leading pictures reference across a CRA picture
+        g = np.load(os.path.join(T.GOLDEN_DIR, "encoder_bp_golden.npz"))
+        (w, h), n, depth, _, cfg, _ = T.BP_CASES[tag]
+        frames = T.bp_case_frames(tag)
+    elif tag in T.SC_CASES:
         g = np.load(SC_GOLD)
         (w, h), n, depth, _, cfg, _ = T.SC_CASES[tag]
         frames = T.scene_case_frames(tag)
