@@ -45,8 +45,8 @@ BFRAMES, REFS, QP = 4, 3, 30
 # x265amd_param fields that differ from x265amd_param_default, and the same settings on the reference's command line
 # frameNumThreads > 1: the reference's frame-parallel rules, i.e. what its default (--frame-threads 0 = by core count) gives on any machine with four cores or more
 ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5,
-               scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2, bOpenGOP=1, bBPyramid=1, lookaheadSlices=8)
-REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "2",
+               scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2, bOpenGOP=1, bBPyramid=1, lookaheadSlices=8, bEnableWeightedPred=1)
+REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "2",
            "--b-pyramid", "--scenecut", "40", "--rd", "3", "--sao", "--wpp", "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", str(REFS), "--max-merge", "3",
            "--no-info", "--open-gop", "--rc-lookahead", "20", "--lookahead-slices", "8"]
 

@@ -926,6 +926,9 @@ typedef struct x265amd_slice_header
     int32_t deblocking_disabled;    /* pps.bPicDisableDeblockingFilter */
     int32_t slfase_flag;            /* slice.m_sLFaseFlag */
     int32_t wpp;                    /* entry points are written; one sub-stream per CTU row */
+    int32_t weighted_pred;          /* pps.bUseWeightPred: a P slice carries pred_weight_table() (Entropy::codePredWeightTable, entropy.cpp:1358-1429) -- here always the table of a slice
+                                     * without weights: the two denominators and a zero luma and chroma flag per L0 reference */
+    int32_t luma_log2_weight_denom, chroma_log2_weight_denom;
 } x265amd_slice_header;
 /* substreams: the raw (unescaped) CABAC sub-streams back to back, sizes[i] bytes each.  Returns the NAL size in bytes (written when it fits). */
 size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const uint8_t* substreams, const uint32_t* sizes, int num_substreams, uint8_t* out, size_t cap);
@@ -1020,8 +1023,23 @@ typedef struct x265amd_lowres_cost_job
     int32_t rows_per_slice, num_slices;     /* num_slices > 1: the estimate in cooperative slices (the reference's estimates outside its batches, param.lookaheadSlices:
                                              * Lookahead::m_numRowsPerSlice / m_numCoopSlices, slicetype.cpp:1047-1054): block rows [k rows_per_slice, (k + 1) rows_per_slice), the
                                              * last slice to the bottom, are searched independently -- a slice's bottom row takes no predictors from below.  0 / 0: one chain */
+    const x265amd_pixel* d_ref0w[4];        /* weighted copies of d_ref0's planes (LookaheadTLD::weightsAnalyse chose a weight): list 0's motion search reads these, everything
+                                             * else d_ref0 (estimateCUCost: wfref0 for the search, fref0 for the bi-directional candidates).  [0] NULL: none */
 } x265amd_lowres_cost_job;
 int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265amd_lowres_cost_job* jobs, int n, intptr_t stride, int width_in_cu, int height_in_cu);
+
+/* Weighted prediction, the measurements of the analysis (reference: LookaheadTLD::weightCostLuma, source/encoder/slicetype.cpp:826-858; weightCost's luma branch and mcLuma,
+ * source/encoder/weightPrediction.cpp:58-90, :172-218): costs[i] = the sum over the 8x8 blocks of the lowres picture (width x height samples, width a multiple of 8; the last block
+ * row reads into the planes' margin as the reference does) of min(SATD(source block, reference block weighted by candidate i), d_intra_cost[block]) -- d_intra_cost NULL: the SATD
+ * alone.  d_ref: the four lowres planes of the reference (fpel, H, V, C; only [0] is read when d_mvs is NULL); d_mvs: Lowres::lowresMvs of the pair (x, y int16 per block) -- the
+ * reference block is motion compensated with the block's vector clipped to the picture + 8 samples (Lowres::lowresMC), NULL: the co-located block.  A candidate: present 0 = no
+ * weighting; else weight_pp_c's arguments (pixel.cpp:519-538) as the callers pass them: w0 = inputWeight, round = (denom ? 1 << (denom - 1) : 0) << (14 - depth), shift = denom +
+ * 14 - depth, offset = inputOffset << (depth - 8).  Returns when the sums are in `costs` (host memory). */
+typedef struct x265amd_weight_cand { int32_t present, w0, round, shift, offset; } x265amd_weight_cand;
+int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
+                                intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs);
+/* weight_pp_c over `count` samples of a buffer (the weighted copies of a reference's four lowres planes, margins included: slicetype.cpp:971-975).  Asynchronous. */
+int x265amd_weight_buffer(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, size_t count, int w0, int round, int shift, int offset);
 
 /* x265amd_aq_energy = LookaheadTLD::acEnergyCu for every quantisation group of a source picture (reference: source/encoder/slicetype.cpp:48-92, :264-283):
  * d_energy[group] (raster order, ceil(width / qg) groups per row; qg_size 16 or 8) = AC energy of the luma block + the two 4:2:0 chroma blocks;

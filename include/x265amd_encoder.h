@@ -83,6 +83,14 @@ typedef struct x265amd_param
                                              * the lookahead's estimates outside its batches run in cooperative slices of max(rows / slices, 10) block rows
                                              * (slicetype.cpp:1035-1059, :3957-3970, :4004-4036) -- a slice's bottom row takes no motion predictors from the row below, so
                                              * the fields (the encoder's search candidates) and costs differ from the whole-picture ones */
+    int32_t bEnableWeightedPred;            /* param.bEnableWeightedPred (--weightp, the reference's default; needs the lookahead: scenecutThreshold > 0 or bFrameAdaptive 2).
+                                             * THE DECISION IS BUILT, THE WEIGHTED PATHS ARE NOT: every picture's sums and squared sums (LookaheadTLD::calcAdaptiveQuantFrame,
+                                             * slicetype.cpp:507-513, :678-700), the lookahead's and the slice's tests whether a picture and its first reference differ in mean or
+                                             * variance (LookaheadTLD::weightsAnalyse, slicetype.cpp:879-916; weightAnalyse, weightPrediction.cpp:262-311), the chroma denominator
+                                             * (:284-290), pps.weighted_pred_flag and the P slices' pred_weight_table() without weights.  A picture that passes neither early exit would
+                                             * start the weight search (motion-compensated costs of candidate weights): x265amd_encoder_encode fails with a message that says so --
+                                             * clips with fades need bEnableWeightedPred = 0 (--no-weightp) on both sides until that is built.  On the others the stream is the
+                                             * reference's with weighted prediction on */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

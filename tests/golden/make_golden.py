@@ -670,6 +670,8 @@ def make_encoder_og_golden(cases=None, frames_of=None, cli=None, name="encoder_o
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "og":
         make_encoder_og_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "wp":
+        make_encoder_og_golden(T.WP_CASES, T.wp_case_frames, T.WP_CLI, "encoder_wp_golden.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "ls":
         make_encoder_og_golden(T.LS_CASES, T.ls_case_frames, T.LS_CLI, "encoder_ls_golden.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "bp":

@@ -2853,7 +2853,7 @@ SLICE_HEADER_DT = np.dtype([(n, "<i4") for n in ("nal_unit_type", "temporal_id_p
                            [(n, "<i4") for n in ("temporal_mvp_enabled", "use_sao", "sao_luma", "sao_chroma", "selective_sao")] +
                            [("num_ref_idx", "<i4", 2), ("num_ref_idx_default", "<i4", 2)] +
                            [(n, "<i4") for n in ("col_from_l0", "col_ref_idx", "max_num_merge_cand", "slice_qp", "pps_init_qp", "chroma_qp_offsets_present", "cb_qp_offset",
-                                                 "cr_qp_offset", "deblocking_disabled", "slfase_flag", "wpp")])
+                                                 "cr_qp_offset", "deblocking_disabled", "slfase_flag", "wpp", "weighted_pred", "luma_log2_weight_denom", "chroma_log2_weight_denom")])
 
 
 def frame_clip_b(depth=8):
@@ -3020,7 +3020,7 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3472,6 +3472,25 @@ def ls_case_frames(tag):
     if kind == "ft":
         return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
     return survey_clip(w, h, depth, 2, 0, n, 0)
+
+
+# --weightp (the reference's default): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of WP_CLI).  The decision is built, the weighted
+# paths are not: clips on which the reference's analysis ends without weights
+WP_CLI = [o for o in LS_CLI if o != "--no-weightp"] + ["--weightp"]
+WP_BASE = dict(LS_BASE, bEnableWeightedPred=1)
+WP_CASES = {
+    "wp_ft/": ((320, 192), 16, 8, ("ft", None), dict(WP_BASE, bframes=4, lookaheadDepth=8), ["--bframes", "4", "--rc-lookahead", "8"]),
+    "wp_api_hbd/": ((256, 192), 12, 10, ("api", None), dict(WP_BASE, bframes=3, lookaheadDepth=6, maxNumReferences=2), ["--bframes", "3", "--rc-lookahead", "6", "--ref", "2"]),
+    # the whole preset: --preset medium --qp 30 at 1280x720, nothing switched off but the option-string SEI
+    "wp_medium/": ((1280, 720), 12, 8, ("ft", None), dict(WP_BASE, bframes=4, lookaheadDepth=20, lookaheadSlices=8), []),
+}
+
+
+def wp_case_frames(tag):
+    (w, h), n, depth, (kind, arg), _, _ = WP_CASES[tag]
+    if kind == "ft":
+        return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
+    return encoder_api_clip(tag, w, h, n, depth)
 
 
 def ba_case_frames(tag):

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 200 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 200 and T.EncParam.bEnableWeightedPred.offset == 196 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -355,6 +355,28 @@ def test_lookahead_slices(tag):
     g = np.load(LS_GOLD)
     (w, h), n, depth, _, cfg, _ = T.LS_CASES[tag]
     stream, coded = T.encoder_run(T.load_hip(depth), T.ls_case_frames(tag), w, h, **cfg)
+    names = {1: "I", 2: "i", 3: "P", 4: "B", 5: "b"}
+    got_types = ["%d:%s" % (poc, names[st]) for (poc, st, _, _) in coded]
+    assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+
+
+WP_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_wp_golden.npz")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.WP_CASES))
+def test_weightp_without_weights(tag):
+    """x265amd_param.bEnableWeightedPred = 1 (--weightp, the reference's default) on clips where the reference's analysis ends without weights: every picture's sums and squared
+    sums (calcAdaptiveQuantFrame, slicetype.cpp:507-513, :678-700), the lookahead's weight analysis before every list-0 search (LookaheadTLD::weightsAnalyse, :879-978) and the
+    slice's (weightAnalyse, weightPrediction.cpp:222-311, as far as its early exits), pps.weighted_pred_flag, pred_weight_table() with the denominators the analysis leaves.
+    wp_medium/ is `--preset medium --qp 30` with nothing switched off but the option-string SEI.  Golden data: tests/golden/make_golden.py wp."""
+    g = np.load(WP_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.WP_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.wp_case_frames(tag), w, h, **cfg)
     names = {1: "I", 2: "i", 3: "P", 4: "B", 5: "b"}
     got_types = ["%d:%s" % (poc, names[st]) for (poc, st, _, _) in coded]
     assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"

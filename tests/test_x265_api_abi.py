@@ -69,9 +69,8 @@ def test_encoder_open_names_what_it_rejects():
     buf[LAYOUT["PARAM_bFrameAdaptive"]] = 1
     assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2
-    # --b-adapt 2, scene-cut detection, the lookahead in slices, the B pyramid and open GOPs (the defaults) are built; weighted prediction is not
-    assert not opn(p) and b"weighted prediction" in lib.x265amd_last_error()
-    buf[LAYOUT["PARAM_bEnableWeightedPred"]] = 0; buf[LAYOUT["PARAM_bEnableWeightedBiPred"]] = 0
+    # --b-adapt 2, scene-cut detection, the lookahead in slices, the B pyramid and open GOPs (the defaults) are built
+    # (weighted prediction for P pictures: the analysis is built; weighted bi-prediction is off in the preset)
     assert not opn(p) and b"bEmitInfoSEI" in lib.x265amd_last_error()
     free(p)
 
@@ -108,6 +107,7 @@ ABI_CASES = {
     "wvga/": ("encoder_api_golden.npz", ((832, 480), 5), ["--bframes", "2", "--rc-lookahead", "5", "--no-b-pyramid", "--sao", "--wpp", "--pools", "4"]),
     # open GOPs, the trellis and scene-cut detection through the table: the command line of tests/hevc_testlib.py OG_CASES as it stands
     "og_keyint_ba/": ("encoder_og_golden.npz", "og", None),
+    "wp_medium/": ("encoder_wp_golden.npz", "wp", None),        # --preset medium --qp 30 as it comes (weighted prediction on: a clip whose analysis ends without weights)
     "ls_medium/": ("encoder_ls_golden.npz", "ls", None),        # 1280x720: the lookahead in slices as well
     "bp_deep/": ("encoder_bp_golden.npz", "bp", None),          # B pyramid + open GOPs + the trellis + a scene cut: --preset medium's GOP structure but for weighted prediction and lookahead slices
 }
@@ -121,8 +121,9 @@ def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
     driver = os.path.join(T.REF_DIR, "x265_abi_driver%d" % depth)
     assert os.path.exists(driver), "oracle/build_ref.sh builds oracle/_ref/x265_abi_driver{8,10} (it travels to the GPU box with the snapshot)"
     cli = None
-    if clip in ("og", "bp", "ls"):
-        cases, frames_of, base = {"og": (T.OG_CASES, T.og_case_frames, T.OG_CLI), "bp": (T.BP_CASES, T.bp_case_frames, T.BP_CLI), "ls": (T.LS_CASES, T.ls_case_frames, T.LS_CLI)}[clip]
+    if clip in ("og", "bp", "ls", "wp"):
+        cases, frames_of, base = {"og": (T.OG_CASES, T.og_case_frames, T.OG_CLI), "bp": (T.BP_CASES, T.bp_case_frames, T.BP_CLI), "ls": (T.LS_CASES, T.ls_case_frames, T.LS_CLI),
+                                  "wp": (T.WP_CASES, T.wp_case_frames, T.WP_CLI)}[clip]
         (w, h), n, depth, _, _, extra = cases[tag]
         frames = frames_of(tag)
         cli = list(base)

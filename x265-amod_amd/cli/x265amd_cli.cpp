@@ -103,7 +103,7 @@ int main(int argc, char** argv)
         else if (a == "--recon" || a == "-r") recon = val();
         else if (a == "--frames" || a == "-f") frames = atoi(val());
         else if (a == "--rect" || a == "--amp" || a == "--limit-modes" || a == "--early-skip" || a == "--no-early-skip" || a == "--b-intra" || a == "--no-b-intra" ||
-                 a == "--deblock" || a == "--no-deblock" || a == "--sao" || a == "--no-sao" || a == "--wpp" || a == "--no-wpp" || a == "--no-rect" || a == "--no-amp" || a == "--fast-intra" || a == "--no-fast-intra" || a == "--no-scenecut" || a == "--open-gop" || a == "--no-open-gop" || a == "--b-pyramid" || a == "--no-b-pyramid")
+                 a == "--deblock" || a == "--no-deblock" || a == "--sao" || a == "--no-sao" || a == "--wpp" || a == "--no-wpp" || a == "--no-rect" || a == "--no-amp" || a == "--fast-intra" || a == "--no-fast-intra" || a == "--no-scenecut" || a == "--open-gop" || a == "--no-open-gop" || a == "--b-pyramid" || a == "--no-b-pyramid" || a == "--weightp" || a == "--no-weightp")
             opts.push_back({ a, "" });
         else if (a.rfind("--", 0) == 0) opts.push_back({ a, val() });
         else { fprintf(stderr, "x265amd: unknown argument %s\n", a.c_str()); return 2; }
@@ -136,6 +136,8 @@ int main(int argc, char** argv)
         else if (k == "--b-adapt") p.bFrameAdaptive = atoi(v);
         else if (k == "--lookahead-slices") p.lookaheadSlices = atoi(v);
         else if (k == "--open-gop") p.bOpenGOP = 1;
+        else if (k == "--weightp") p.bEnableWeightedPred = 1;
+        else if (k == "--no-weightp") p.bEnableWeightedPred = 0;
         else if (k == "--b-pyramid") p.bBPyramid = 1;
         else if (k == "--no-b-pyramid") p.bBPyramid = 0;
         else if (k == "--no-open-gop") p.bOpenGOP = 0;

@@ -84,6 +84,8 @@ struct Pic
     std::vector<int16_t> specMvs[18], specMvs1[18];
     std::vector<int32_t> specMvc[18], specMvc1[18];
     int64_t specCost2[18][18]; int specIntraMbs[18];
+    uint64_t wpSum[3] = { 0, 0, 0 }, wpSsd[3] = { 0, 0, 0 };      /* Lowres::wp_sum / wp_ssd (bEnableWeightedPred) */
+    int lumaDenom = 7, chromaDenom = 7;                    /* the slice's pred_weight_table denominators (weightAnalyse) */
     bool bScenecut = false, bKeyframe = false;
     Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
     ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
@@ -168,10 +170,12 @@ struct x265amd_encoder
     hipStream_t laStream = nullptr;
     int lowresInit(Pic& pic);
     void pushMiniGop(int b);
+    int lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& scale, int& denom, int& offset);
+    int sliceWeights(Pic& pic, bool& weighted);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
     struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool whole = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
-                     void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; std::vector<int32_t> bc; std::vector<uint16_t> lc; };
+                     void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; void* dW = nullptr; std::vector<int32_t> bc; std::vector<uint16_t> lc; };
     int frameCostMany(std::vector<CostJob>& jobs);
     double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0;
     int frameCost(std::vector<Pic*>& frames, int p0, int p1, int b, int64_t& score);       /* CostEstimateGroup::singleCost(p0, p1, b): P (p1 == b) or B estimate */
@@ -234,6 +238,7 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.amp = p.bEnableAMP != 0; s.sao = p.bEnableSAO != 0; s.temporal_mvp = p.bEnableTemporalMvp != 0; s.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0;
     s.aspect_ratio_idc = p.aspectRatioIdc;
     s.emit_timing_info = 1; s.num_units_in_tick = p.fpsDenom; s.time_scale = p.fpsNum;
+    s.weighted_pred = p.bEnableWeightedPred != 0;
     s.sign_hide = p.bEnableSignHiding != 0; s.num_ref_idx_default[0] = s.num_ref_idx_default[1] = 1; s.init_qp_minus26 = 0;
     s.wpp = p.bEnableWavefront != 0; s.loop_filter_across_slices = 1;
     s.deblocking_filter_control_present = !p.bEnableLoopFilter; s.pic_disable_deblocking = !p.bEnableLoopFilter;
@@ -297,6 +302,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     { xa_fail(X265AMD_EINVAL, "encoder_open: shardRank / shardCount (frame-per-GPU needs 0 <= rank < count and frameNumThreads > 1: rows are published by pictures coded in parallel)"); return nullptr; }
     if (p->bFrameAdaptive != 0 && p->bFrameAdaptive != 2) { xa_fail(X265AMD_EINVAL, "encoder_open: bFrameAdaptive: 0 (fixed mini-GOPs) and 2 (trellis) are built"); return nullptr; }
     e->lookahead = p->scenecutThreshold > 0 || (p->bFrameAdaptive && p->bframes);
+    if (p->bEnableWeightedPred && !e->lookahead) { xa_fail(X265AMD_EINVAL, "encoder_open: bEnableWeightedPred needs the lookahead (scenecutThreshold > 0 or bFrameAdaptive 2 with B frames)"); return nullptr; }
     {
         /* Encoder::configure (encoder.cpp:3658-3663) */
         int kmin = p->keyframeMin;
@@ -538,6 +544,199 @@ int x265amd_encoder::lowresInit(Pic& pic)
         for (int x = 0; x < lowCuW; x++)
             if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) est += ic[(size_t)y * lowCuW + x];
     pic.costEst[0] = est;
+    if (p.bEnableWeightedPred)
+    {
+        /* LookaheadTLD::calcAdaptiveQuantFrame with AQ off (slicetype.cpp:507-513): acEnergyCu over every 16x16 block for Lowres::wp_sum / wp_ssd, then :678-700 */
+        const int bw = (W + 15) / 16, bh = (H + 15) / 16;
+        void* dEnergy = nullptr; void* dWp = nullptr;
+        if (xa_scratch_alloc(&dEnergy, (size_t)bw * bh * 4) != hipSuccess || xa_scratch_alloc(&dWp, 6 * 8) != hipSuccess)
+        { xa_scratch_free(dEnergy); xa_scratch_free(dWp); return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation"); }
+        const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
+        uint64_t wp[6];
+        rc = x265amd_aq_energy(laStream, srcP, stride, cstride, W, H, 16, (uint32_t*)dEnergy, (uint64_t*)dWp);
+        if (rc == X265AMD_OK && (hipMemcpyAsync(wp, dWp, sizeof(wp), hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess))
+            rc = xa_fail(X265AMD_EHIP, "encoder_encode: picture sums");
+        xa_scratch_free(dEnergy); xa_scratch_free(dWp);
+        if (rc != X265AMD_OK) return rc;
+        const int maxCol = ((W + 8) >> 4) << 4, maxRow = ((H + 8) >> 4) << 4;
+        const int width[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, height[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
+        for (int i = 0; i < 3; i++)
+        {
+            const uint64_t sum = wp[i], ssd = wp[3 + i];
+            pic.wpSum[i] = sum;
+            pic.wpSsd[i] = ssd - (sum * sum + (uint64_t)((width[i] * height[i]) / 2)) / (uint64_t)(width[i] * height[i]);
+        }
+    }
+    return X265AMD_OK;
+}
+
+namespace {
+/* bs_size_ue / bs_size_se (common/bitstream.h:94-136) */
+inline int bitSizeOf(unsigned v) { int n = 1; while (v > 1) { v >>= 1; n += 2; } return n; }
+inline int bsSizeUe(unsigned val) { return bitSizeOf(val + 1); }
+inline int bsSizeSe(int val) { int tmp = 1 - val * 2; if (tmp < 0) tmp = val * 2; return tmp < 256 ? bitSizeOf((unsigned)tmp) : bitSizeOf((unsigned)(tmp >> 8)) + 16; }
+/* weight_pp_c's arguments for a WeightParam as weightCostLuma / weightCost pass them */
+inline x265amd_weight_cand weightCand(int scale, int denom, int offset)
+{
+    const int correction = 14 - X265AMD_DEPTH;
+    x265amd_weight_cand c;
+    c.present = 1; c.w0 = scale; c.round = (denom ? 1 << (denom - 1) : 0) << correction; c.shift = denom + correction; c.offset = offset << (X265AMD_DEPTH - 8);
+    return c;
+}
+}
+
+/* LookaheadTLD::weightsAnalyse (slicetype.cpp:879-978) before a list-0 search of `fenc` against `ref`: the early exit when the two do not differ in mean or variance; else the
+ * unweighted cost against one candidate (scale from the variances, offset from the means), a smaller denominator if the scale is even, and the 0.998 test.  weighted: the
+ * reference's four planes are weighted for the search (scale / 2^denom, offset) */
+int x265amd_encoder::lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& scale, int& denom, int& offset)
+{
+    static const float epsilon = 1.f / 128.f;
+    weighted = false;
+    float guessScale, fencMean, refMean;
+    if (fenc.wpSsd[0] && ref.wpSsd[0]) guessScale = sqrtf((float)fenc.wpSsd[0] / ref.wpSsd[0]);
+    else guessScale = 1.0f;
+    fencMean = (float)fenc.wpSum[0] / (lowH * lowW) / (1 << (X265AMD_DEPTH - 8));
+    refMean = (float)ref.wpSum[0] / (lowH * lowW) / (1 << (X265AMD_DEPTH - 8));
+    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon) return X265AMD_OK;
+    int minoff = 0, minscale, mindenom;
+    unsigned int minscore = 0, origscore = 1;
+    int found = 0;
+    {
+        /* WeightParam::setFromWeightAndOffset((int)(guessScale * 128 + 0.5f), 0, 7, true) (slice.h:304-316) */
+        int w = (int)(guessScale * 128 + 0.5f), d = 7;
+        while (d > 0 && w > 127) { d--; w >>= 1; }
+        w = std::min(w, 127);
+        mindenom = d; minscale = w;
+    }
+    int curScale = minscale;
+    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
+    if (curOffset < -128 || curOffset > 127)
+    {
+        curOffset = std::max(-128, std::min(127, curOffset));
+        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
+        curScale = std::max(0, std::min(127, curScale));
+    }
+    x265amd_weight_cand cands[2];
+    memset(cands, 0, sizeof(cands));
+    cands[1] = weightCand(curScale, mindenom, curOffset);
+    uint32_t costs[2] = { 0, 0 };
+    const pixel* refPlanes[4];
+    for (int t = 0; t < 4; t++) refPlanes[t] = ref.dLowres + (size_t)t * lowPlaneElems + lowOrg;
+    const int rc = x265amd_lowres_weight_costs(laStream, fenc.dLowres + lowOrg, refPlanes, nullptr, fenc.dIntraCost, lowStride, lowW, lowH, cands, 2, costs);
+    if (rc != X265AMD_OK) return rc;
+    origscore = minscore = costs[0];
+    if (!minscore) return X265AMD_OK;
+    const unsigned int sc = costs[1];
+    if (sc < minscore) { minscore = sc; minscale = curScale; minoff = curOffset; found = 1; }
+    if (mindenom > 0 && !(minscale & 1))
+    {
+        const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
+        const int shift = std::min(idx, mindenom);
+        mindenom -= shift; minscale >>= shift;
+    }
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return X265AMD_OK;
+    weighted = true; scale = minscale; denom = mindenom; offset = minoff;
+    return X265AMD_OK;
+}
+
+/* weightAnalyse (weightPrediction.cpp:222-470) for a P picture: list 0's first reference.  The chroma denominator that fits both chroma scale guesses; luma: the early exit, else
+ * the reference motion compensated with the lookahead's vectors of that distance (mcLuma) against every candidate scale (+-4 around the guess) and offset (+-2 around the
+ * mean's), each with the slice header's cost, a smaller denominator if the scale is even, the 0.998 test.  Without a luma weight chroma is not looked at.  weighted: the
+ * analysis chose a luma weight */
+int x265amd_encoder::sliceWeights(Pic& pic, bool& weighted)
+{
+    weighted = false;
+    Pic& ref = *pic.lists[0][0];
+    const float epsilon = 1.f / 128.f;
+    const int w16 = ((W + 15) >> 4) << 4, h16 = ((H + 15) >> 4) << 4;
+    int numpixels[3];
+    numpixels[0] = w16 * h16; numpixels[1] = numpixels[2] = numpixels[0] >> 2;
+    float guessScale[3], fencMean[3], refMean[3];
+    for (int plane = 0; plane < 3; plane++)
+    {
+        const uint64_t fencVar = pic.wpSsd[plane] + !ref.wpSsd[plane], refVar = ref.wpSsd[plane] + !ref.wpSsd[plane];
+        guessScale[plane] = sqrt((float)fencVar / refVar);
+        fencMean[plane] = (float)pic.wpSum[plane] / (numpixels[plane]) / (1 << (X265AMD_DEPTH - 8));
+        refMean[plane] = (float)ref.wpSum[plane] / (numpixels[plane]) / (1 << (X265AMD_DEPTH - 8));
+    }
+    int chromaDenom = 7;
+    const int lumaDenom = 7;
+    while (chromaDenom > 0)
+    {
+        const float thresh = 127.f / (1 << chromaDenom);
+        if (guessScale[1] < thresh && guessScale[2] < thresh) break;
+        chromaDenom--;
+    }
+    pic.lumaDenom = lumaDenom; pic.chromaDenom = chromaDenom;
+    if (fabsf(refMean[0] - fencMean[0]) < 0.5f && fabsf(1.f - guessScale[0]) < epsilon) return X265AMD_OK;
+    const int denom = lumaDenom;
+    int mindenom, minscale, minoff = 0;
+    {
+        int w = (int)(guessScale[0] * (1 << denom) + 0.5f), d = denom;
+        while (d > 0 && w > 127) { d--; w >>= 1; }           /* bNormalize = !list */
+        w = std::min(w, 127);
+        mindenom = d; minscale = w;
+    }
+    const int diffPoc = abs(pic.poc - ref.poc);
+    const bool haveMvs = diffPoc <= p.bframes + 1 && diffPoc < 18 && !pic.lowMvs[diffPoc].empty();
+    /* the candidates in the order the reference tries them */
+    struct Cand { int scale, off, startOffset, iter; };
+    std::vector<Cand> order;
+    std::vector<x265amd_weight_cand> cands(1);
+    memset(&cands[0], 0, sizeof(cands[0]));
+    const int startScale = std::max(0, std::min(127, minscale - 4)), endScale = std::max(0, std::min(127, minscale + 4));
+    for (int scale = startScale; scale <= endScale; scale++)
+    {
+        const int deltaWeight = scale - (1 << mindenom);
+        if (deltaWeight > 127 || deltaWeight <= -128) continue;
+        int curScale = scale;
+        int curOffset = (int)(fencMean[0] - refMean[0] * curScale / (1 << mindenom) + 0.5f);
+        if (curOffset < -128 || curOffset > 127)
+        {
+            curOffset = std::max(-128, std::min(127, curOffset));
+            curScale = (int)((1 << mindenom) * (fencMean[0] - curOffset) / refMean[0] + 0.5f);
+            curScale = std::max(0, std::min(127, curScale));
+        }
+        const int startOffset = std::max(-128, std::min(127, curOffset - 2)), endOffset = std::max(-128, std::min(127, curOffset + 2));
+        for (int off = startOffset; off <= endOffset; off++) { order.push_back({ curScale, off, startOffset, scale }); cands.push_back(weightCand(curScale, mindenom, off)); }
+    }
+    void* dMvs = nullptr;
+    if (haveMvs)
+    {
+        if (xa_scratch_alloc(&dMvs, pic.lowMvs[diffPoc].size() * 2) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+        if (hipMemcpyAsync(dMvs, pic.lowMvs[diffPoc].data(), pic.lowMvs[diffPoc].size() * 2, hipMemcpyHostToDevice, laStream) != hipSuccess)
+        { xa_scratch_free(dMvs); return xa_fail(X265AMD_EHIP, "encoder_encode: lowres vectors"); }
+    }
+    std::vector<uint32_t> costs(cands.size(), 0);
+    const pixel* refPlanes[4];
+    for (int t = 0; t < 4; t++) refPlanes[t] = ref.dLowres + (size_t)t * lowPlaneElems + lowOrg;
+    const int rc = x265amd_lowres_weight_costs(laStream, pic.dLowres + lowOrg, refPlanes, (const int16_t*)dMvs, pic.dIntraCost, lowStride, lowW, lowH, cands.data(), (int)cands.size(), costs.data());
+    xa_scratch_free(dMvs);
+    if (rc != X265AMD_OK) return rc;
+    const uint32_t origscore = costs[0];
+    if (!origscore) return X265AMD_OK;
+    uint32_t minscore = origscore;
+    bool bFound = false;
+    const int lambda = X265AMD_DEPTH > 8 ? 16 : 1;          /* (int)x265_lambda_tab[X265_LOOKAHEAD_QP] */
+    for (size_t k = 0; k < order.size(); k++)
+    {
+        const Cand& c = order[k];
+        /* sliceHeaderCost(&wsp, lambda, 0) */
+        const int hdr = lambda * (10 + bsSizeUe((unsigned)mindenom) * 2 + 2 * (bsSizeSe(c.scale) + bsSizeSe(c.off)));
+        const uint32_t sc = costs[k + 1] + (uint32_t)hdr;
+        if (sc < minscore) { minscore = sc; minscale = c.scale; minoff = c.off; bFound = true; }
+        /* "Don't check any more offsets if the previous one had a lower cost than the current one": the rest of this scale's offsets are skipped */
+        if (minoff == c.startOffset && c.off != c.startOffset)
+            while (k + 1 < order.size() && order[k + 1].iter == c.iter) k++;
+    }
+    if (mindenom > 0 && !(minscale & 1))
+    {
+        const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
+        const int shift = std::min(idx, mindenom);
+        mindenom -= shift; minscale >>= shift;
+    }
+    if (!bFound || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f) return X265AMD_OK;
+    weighted = true;
     return X265AMD_OK;
 }
 
@@ -599,6 +798,12 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         /* (an estimate made ahead of its time reads and fills the fields made ahead of their time as well as the picture's own) */
         const bool have0 = !fenc.lowMvs[j.d0].empty() || (j.spec && !fenc.specMvs[j.d0].empty()), have1 = j.d1 > 0 && (!fenc.lowMvs1[j.d1].empty() || (j.spec && !fenc.specMvs1[j.d1].empty()));
         j.search0 = !have0; j.search1 = j.d1 > 0 && !have1;
+        bool weighted = false; int wScale = 0, wDenom = 0, wOffset = 0;
+        if (p.bEnableWeightedPred && j.search0)
+        {
+            rc = lookaheadWeights(fenc, *j.ref0, weighted, wScale, wDenom, wOffset);
+            if (rc != X265AMD_OK) break;
+        }
         laJobs++; laSearches += (j.search0 ? 1 : 0) + (j.search1 ? 1 : 0);
         void** bufs[6] = { &j.dMvs, &j.dMvc, &j.dLc, &j.dBc, &j.dMvs1, &j.dMvc1 };
         const size_t sizes[6] = { ncu * 4, ncu * 4, ncu * 2, ncu * 4, ncu * 4, ncu * 4 };
@@ -613,6 +818,15 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         q.d_mvs0 = (int16_t*)j.dMvs; q.d_mv_costs0 = (int32_t*)j.dMvc; q.d_mvs1 = (int16_t*)j.dMvs1; q.d_mv_costs1 = (int32_t*)j.dMvc1;
         q.d_lowres_costs = (uint16_t*)j.dLc; q.d_bcost = (int32_t*)j.dBc; q.do_search0 = j.search0; q.do_search1 = j.search1;
         if (!j.whole && laNumSlices > 1) { q.rows_per_slice = laRowsPerSlice; q.num_slices = laNumSlices; }
+        if (weighted)
+        {
+            /* the four planes weighted, margins included, for this estimate's list-0 search (slicetype.cpp:962-977) */
+            const int correction = 14 - X265AMD_DEPTH;
+            if (xa_scratch_alloc(&j.dW, lowPlaneElems * 4 * sizeof(pixel)) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: device allocation"); break; }
+            rc = x265amd_weight_buffer(laStream, j.ref0->dLowres, (pixel*)j.dW, lowPlaneElems * 4, wScale, (wDenom ? 1 << (wDenom - 1) : 0) << correction, wDenom + correction, wOffset << (X265AMD_DEPTH - 8));
+            if (rc != X265AMD_OK) break;
+            for (int t = 0; t < 4; t++) q.d_ref0w[t] = (pixel*)j.dW + (size_t)t * lowPlaneElems + lowOrg;
+        }
         bool ok = true;
         const bool own0 = !fenc.lowMvs[j.d0].empty(), own1 = j.d1 > 0 && !fenc.lowMvs1[j.d1].empty();
         if (!j.search0) ok = hipMemcpyAsync(j.dMvs, (own0 ? fenc.lowMvs : fenc.specMvs)[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
@@ -647,7 +861,7 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
     for (size_t k = 0; k < issued; k++)
     {
         CostJob& j = jobs[k];
-        void* bufs[6] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
+        void* bufs[7] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1, j.dW };
         for (void* b : bufs) xa_scratch_free(b);
         if (rc != X265AMD_OK)
         {
@@ -1078,6 +1292,14 @@ int x265amd_encoder::prepare(const PicP& picp)
         if ((int)l0.size() < n0 || (int)l1.size() < n1 || (stype == 0 && !n1)) return xa_fail(X265AMD_EINVAL, "encoder_encode: reference lists");
         pic.lists[0].assign(l0.begin(), l0.begin() + n0); pic.lists[1].assign(l1.begin(), l1.begin() + n1);
     }
+    if (p.bEnableWeightedPred && stype == 1)
+    {
+        bool weighted = false;
+        const int rcw = sliceWeights(pic, weighted);
+        if (rcw != X265AMD_OK) return rcw;
+        if (weighted)
+            return xa_fail(X265AMD_EINVAL, "encoder_encode: the weight analysis chose a weight for this P picture (a fade); coding with weights is not built -- bEnableWeightedPred = 0 (--no-weightp) on both sides");
+    }
     pic.sliceQp = pic.type == TYPE_BREF ? (qpConstant[0] + qpConstant[1]) / 2 : qpConstant[stype];                    /* rateControlStart, CQP (ratecontrol.cpp:1594-1597: a referenced B picture lies between B and P) */
     picList.insert(picList.begin(), picp);              /* PicList::pushFront */
     if (frameParallel)
@@ -1191,6 +1413,7 @@ static int sliceNal(const x265amd_encoder& e, Pic& pic, const FrameCtx& c, const
     h.slice_qp = pic.sliceQp; h.pps_init_qp = 26; h.deblocking_disabled = !p.bEnableLoopFilter;
     h.slfase_flag = (0x5f4e4a53u >> (pic.poc % 31)) & 1;                                              /* SLFASE_CONSTANT (dpb.cpp:294) */
     h.wpp = p.bEnableWavefront != 0;
+    h.weighted_pred = p.bEnableWeightedPred != 0; h.luma_log2_weight_denom = pic.lumaDenom; h.chroma_log2_weight_denom = pic.chromaDenom;
     size_t dataBytes = 0;
     for (int s = 0; s < nsub; s++) dataBytes += sizes[s];
     pic.nalBytes.assign(dataBytes * 3 / 2 + 4096, 0);

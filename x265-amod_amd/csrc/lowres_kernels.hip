@@ -120,6 +120,7 @@ extern "C" int x265amd_lowres_intra_costs(void* stream, const x265amd_pixel* d_p
 struct LowresCostParams
 {
     const pixel* fenc; const pixel* ref[2][4];     /* sample (0,0) of the planes: fenc fpel; per list fpel, H, V, C */
+    const pixel* refW[4];                          /* weighted copies of list 0's planes for its motion search (estimateCUCost's wfref0), or NULL */
     long stride;
     int widthInCU, heightInCU, bidir, doSearch[2], merange;
     const int32_t* intraCost;
@@ -136,6 +137,7 @@ struct LrBlock
     pixel* fencT; pixel* buf;                   /* LDS: source block, candidate block */
     const LowresCostParams* p;
     int list, lane;
+    const pixel* const* planes;                 /* the planes lr_fetch reads: the list's, or list 0's weighted copies while it is searched */
     long off;                                   /* blockOffset */
     int mvpx, mvpy;
 };
@@ -145,7 +147,7 @@ XA_DEV int lr_mvcost(const LrBlock& b, int qx, int qy) { return (uint16_t)(b.p->
 /* lowresMC: the candidate block of quarter-pel MV (qx, qy) into b.buf (stride 8) */
 XA_DEV void lr_fetch(const LrBlock& b, int qx, int qy)
 {
-    const pixel* const* plane = b.p->ref[b.list];
+    const pixel* const* plane = b.planes;
     const int lx = b.lane & 7, ly = b.lane >> 3;
     const int hpelA = (qy & 2) | ((qx & 2) >> 1);
     const pixel* a = plane[hpelA] + b.off + (qx >> 2) + (long)(qy >> 2) * b.p->stride;
@@ -323,7 +325,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         int mvx[2] = { 0, 0 }, mvy[2] = { 0, 0 };
         for (int i = 0; i < 1 + p.bidir; i++)
         {
-            b.list = i;
+            b.list = i; b.planes = (i == 0 && p.refW[0]) ? p.refW : p.ref[i];
             int fencCost;
             if (!p.doSearch[i])
             {
@@ -368,9 +370,9 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         if (p.bidir)
         {
             /* avg(l0-mv, l1-mv), then the co-located average */
-            b.list = 0; lr_fetch(b, mvx[0], mvy[0]);
+            b.list = 0; b.planes = p.ref[0]; lr_fetch(b, mvx[0], mvy[0]);
             const int a0 = buf[lane];
-            b.list = 1; lr_fetch(b, mvx[1], mvy[1]);
+            b.list = 1; b.planes = p.ref[1]; lr_fetch(b, mvx[1], mvy[1]);
             xa_wave_sync();
             buf2[lane] = (pixel)((a0 + buf[lane] + 1) >> 1);
             xa_wave_sync();
@@ -426,6 +428,7 @@ extern "C" int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me,
         p.cost = xa_me_device_mvcost(me, 12 + 6 * (XA_DEPTH - 8));
         p.progress = (int*)dProgress + (size_t)i * height_in_cu;
         p.rowsPerSlice = j.rows_per_slice; p.numSlices = j.rows_per_slice > 0 ? j.num_slices : 0;
+        for (int k = 0; k < 4; k++) p.refW[k] = j.d_ref0w[0] ? (const pixel*)j.d_ref0w[k] : nullptr;
     }
     std::vector<int32_t> init((size_t)n * height_in_cu, width_in_cu);
     hipError_t e = hipMemcpyAsync(dProgress, init.data(), sizeof(int32_t) * init.size(), hipMemcpyHostToDevice, st);
@@ -469,6 +472,101 @@ extern "C" int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const
     XA_HIP_CHECK(hipMemcpyAsync(d_progress, init.data(), sizeof(int32_t) * height_in_cu, hipMemcpyHostToDevice, st));
     XA_HIP_CHECK(hipStreamSynchronize(st));
     hipLaunchKernelGGL(k_lowres_cost, dim3(height_in_cu), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+
+/* ---------------- weighted prediction, the analysis' measurements ----------------
+ * weightCostLuma (slicetype.cpp:826-858) and weightCost's luma branch (weightPrediction.cpp:172-218): the sum over the picture's 8x8 lowres blocks of
+ * min(SATD(source block, reference block), intra cost of the block), the reference block optionally motion compensated with the lookahead's vectors (mcLuma,
+ * weightPrediction.cpp:58-90: the vector clipped to the picture + 8 samples, Lowres::lowresMC) and optionally weighted (weight_pp_c, pixel.cpp:519-538).
+ * blockIdx.x = the block, blockIdx.y = the candidate weight: every candidate of a decision in one launch (the reference tries them one after the other; a
+ * candidate's sum does not depend on the others).  The sums are uint32 and wrap like the reference's. */
+struct WeightCostParams
+{
+    const pixel* fenc; const pixel* ref[4]; long stride; int width, height, blocksX;
+    const int16_t* mvs; const int32_t* intraCost; const x265amd_weight_cand* cands; uint32_t* costs;
+};
+__global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
+{
+    __shared__ pixel fencT[64];
+    __shared__ pixel refT[64];
+    const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
+    const int cu = blockIdx.x, bx = cu % p.blocksX, by = cu / p.blocksX;
+    const int x = bx * 8, y = by * 8;
+    const long off = (long)y * p.stride + x;
+    fencT[lane] = p.fenc[off + (long)ly * p.stride + lx];
+    int v;
+    if (p.mvs)
+    {
+        const int v32 = reinterpret_cast<const int*>(p.mvs)[cu];
+        int qx = (int16_t)(v32 & 0xFFFF), qy = (int16_t)(v32 >> 16);
+        qx = min(max(qx, (-x - 8) * 4), (p.width - x - 1 + 8) * 4);
+        qy = min(max(qy, (-y - 8) * 4), (p.height - y - 1 + 8) * 4);
+        const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+        const pixel* a = p.ref[hpelA] + off + (qx >> 2) + (long)(qy >> 2) * p.stride;
+        v = a[(long)ly * p.stride + lx];
+        if ((qx | qy) & 1)
+        {
+            const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
+            const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
+            const pixel* c = p.ref[hpelB] + off + (qx2 >> 2) + (long)(qy2 >> 2) * p.stride;
+            v = (v + c[(long)ly * p.stride + lx] + 1) >> 1;
+        }
+    }
+    else
+        v = p.ref[0][off + (long)ly * p.stride + lx];
+    const x265amd_weight_cand w = p.cands[blockIdx.y];
+    if (w.present)
+    {
+        const int val = (int16_t)(v << (XA_IF_INTERNAL_PREC - XA_DEPTH));
+        v = xa_clip3(0, XA_PIXEL_MAX, ((w.w0 * val + w.round) >> w.shift) + w.offset);
+    }
+    refT[lane] = (pixel)v;
+    xa_wave_sync();
+    int c = xa_wave_satd(refT, 8, fencT, 8, 8, 8, lane);
+    if (p.intraCost) c = min(c, p.intraCost[cu]);
+    if (lane == 0) atomicAdd(&p.costs[blockIdx.y], (uint32_t)c);
+}
+extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
+                                           intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs)
+{
+    if (!d_fenc || !d_ref || !d_ref[0] || (d_mvs && (!d_ref[1] || !d_ref[2] || !d_ref[3])) || !cands || !costs || n <= 0 || n > 256 || width <= 0 || height <= 0 || (width & 7))
+        return xa_fail(X265AMD_EINVAL, "x265amd_lowres_weight_costs: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    void* dC = nullptr; void* dOut = nullptr;
+    if (xa_scratch_alloc(&dC, sizeof(x265amd_weight_cand) * n) != hipSuccess || xa_scratch_alloc(&dOut, 4 * (size_t)n) != hipSuccess)
+    { xa_scratch_free(dC); xa_scratch_free(dOut); return xa_fail(X265AMD_EHIP, "x265amd_lowres_weight_costs: device allocation"); }
+    WeightCostParams p;
+    memset(&p, 0, sizeof(p));
+    p.fenc = (const pixel*)d_fenc;
+    for (int k = 0; k < 4; k++) p.ref[k] = (const pixel*)d_ref[k];
+    p.stride = (long)stride; p.width = width; p.height = height; p.blocksX = width >> 3;
+    p.mvs = d_mvs; p.intraCost = d_intra_cost; p.cands = (const x265amd_weight_cand*)dC; p.costs = (uint32_t*)dOut;
+    const int blocksY = (height + 7) >> 3;
+    hipError_t e = hipMemcpyAsync(dC, cands, sizeof(x265amd_weight_cand) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, 4 * (size_t)n, st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_lowres_weight_cost, dim3(p.blocksX * blocksY, n), dim3(64), 0, st, p); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(costs, dOut, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    xa_scratch_free(dC); xa_scratch_free(dOut);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+/* weight_pp_c over a whole padded buffer (LookaheadTLD::weightsAnalyse's weighted copies of the four lowres planes, slicetype.cpp:971-975) */
+__global__ void k_weight_buffer(const pixel* src, pixel* dst, size_t n, int w0, int round, int shift, int offset)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int val = (int16_t)((int)src[i] << (XA_IF_INTERNAL_PREC - XA_DEPTH));
+    dst[i] = (pixel)xa_clip3(0, XA_PIXEL_MAX, ((w0 * val + round) >> shift) + offset);
+}
+extern "C" int x265amd_weight_buffer(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, size_t count, int w0, int round, int shift, int offset)
+{
+    if (!d_src || !d_dst || !count) return xa_fail(X265AMD_EINVAL, "x265amd_weight_buffer: bad arguments");
+    hipLaunchKernelGGL(k_weight_buffer, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const pixel*)d_src, (pixel*)d_dst, count, w0, round, shift, offset);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;

@@ -238,6 +238,13 @@ extern "C" size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const u
         if (sliceType == 0) b.flag(h->col_from_l0 != 0);
         if (sliceType != 2 && ((h->col_from_l0 && h->num_ref_idx[0] > 1) || (!h->col_from_l0 && h->num_ref_idx[1] > 1))) b.ue((uint32_t)h->col_ref_idx);
     }
+    if (sliceType == 1 && h->weighted_pred)
+    {
+        /* pred_weight_table() of a slice whose analysis chose no weights (weightAnalyse ends with wtPresent 0 everywhere): the denominators, then a luma and a chroma flag per reference */
+        b.ue((uint32_t)h->luma_log2_weight_denom); b.se(h->chroma_log2_weight_denom - h->luma_log2_weight_denom);
+        for (int r = 0; r < h->num_ref_idx[0]; r++) b.flag(false);
+        for (int r = 0; r < h->num_ref_idx[0]; r++) b.flag(false);
+    }
     if (sliceType != 2) b.ue((uint32_t)(5 - h->max_num_merge_cand));
     b.se(h->slice_qp - h->pps_init_qp);
     if (h->chroma_qp_offsets_present) { b.se(h->cb_qp_offset); b.se(h->cr_qp_offset); }
