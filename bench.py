@@ -46,9 +46,9 @@ BFRAMES, REFS, QP = 4, 3, 30
 # frameNumThreads > 1: the reference's frame-parallel rules, i.e. what its default (--frame-threads 0 = by core count) gives on any machine with four cores or more
 ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5,
                scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2, bOpenGOP=1, bBPyramid=1, lookaheadSlices=8, bEnableWeightedPred=1)
-REF_CLI = ["--preset", "medium", "--qp", str(QP), "--aq-mode", "0", "--no-cutree", "--weightp", "--no-weightb", "--bframes", str(BFRAMES), "--b-adapt", "2",
-           "--b-pyramid", "--scenecut", "40", "--rd", "3", "--sao", "--wpp", "--rdoq-level", "0", "--psy-rdoq", "0", "--ref", str(REFS), "--max-merge", "3",
-           "--no-info", "--open-gop", "--rc-lookahead", "20", "--lookahead-slices", "8"]
+# Every value of ENC_CFG is the preset's: the reference runs `--preset medium --qp 30` as it comes (checked: the long form with every option spelled out gives the same stream);
+# --no-info leaves out the SEI NAL unit that carries the reference build's version and option string
+REF_CLI = ["--preset", "medium", "--qp", str(QP), "--no-info"]
 
 
 def bench_clip(first, count, gop=0):
@@ -327,8 +327,8 @@ def main():
             "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + mini-GOPs of up to %d B frames chosen by the lookahead's trellis, --b-adapt 2), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
                                    "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
-                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20), the B-frame trellis (--b-adapt 2), the B pyramid, open GOPs and the lookahead's slices (--lookahead-slices 8) as the preset has them (AQ / cutree are off in CQP by the reference's own rules; "
-                                   "weighted prediction is not built and switched off on both sides: --no-weightp is what separates the command line from plain --preset medium --qp 30)" % (W, H, K, BFRAMES, REFS, QP),
+                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20), the B-frame trellis (--b-adapt 2), the B pyramid, open GOPs, the lookahead's slices (--lookahead-slices 8) and weighted prediction's analysis (--weightp: no weights chosen on these clips; "
+                                   "coding with weights is not built) as the preset has them (AQ / cutree are off in CQP by the reference's own rules): the reference runs plain --preset medium --qp 30" % (W, H, K, BFRAMES, REFS, QP),
                        "frames_per_step_per_gpu": 1, "parallelism": ("picture k in coding order on GPU k mod %d, CTU rows broadcast over RCCL" % world if by_frames else "closed GOP per GPU x%d" % world) if world > 1 else "one encoder object",
                        "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},
             "bit_exact_vs_reference_encoder": same,

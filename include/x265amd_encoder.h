@@ -84,13 +84,16 @@ typedef struct x265amd_param
                                              * (slicetype.cpp:1035-1059, :3957-3970, :4004-4036) -- a slice's bottom row takes no motion predictors from the row below, so
                                              * the fields (the encoder's search candidates) and costs differ from the whole-picture ones */
     int32_t bEnableWeightedPred;            /* param.bEnableWeightedPred (--weightp, the reference's default; needs the lookahead: scenecutThreshold > 0 or bFrameAdaptive 2).
-                                             * THE DECISION IS BUILT, THE WEIGHTED PATHS ARE NOT: every picture's sums and squared sums (LookaheadTLD::calcAdaptiveQuantFrame,
-                                             * slicetype.cpp:507-513, :678-700), the lookahead's and the slice's tests whether a picture and its first reference differ in mean or
-                                             * variance (LookaheadTLD::weightsAnalyse, slicetype.cpp:879-916; weightAnalyse, weightPrediction.cpp:262-311), the chroma denominator
-                                             * (:284-290), pps.weighted_pred_flag and the P slices' pred_weight_table() without weights.  A picture that passes neither early exit would
-                                             * start the weight search (motion-compensated costs of candidate weights): x265amd_encoder_encode fails with a message that says so --
-                                             * clips with fades need bEnableWeightedPred = 0 (--no-weightp) on both sides until that is built.  On the others the stream is the
-                                             * reference's with weighted prediction on */
+                                             * THE DECISION IS BUILT, CODING WITH WEIGHTS IS NOT: every picture's sums and squared sums (LookaheadTLD::calcAdaptiveQuantFrame,
+                                             * slicetype.cpp:507-513, :678-700); the lookahead's weight analysis before every list-0 search (LookaheadTLD::weightsAnalyse,
+                                             * slicetype.cpp:879-978: the candidate's cost against the unweighted one, x265amd_lowres_weight_costs) with the reference's lowres
+                                             * planes weighted for that search when it picks a weight; the slice's analysis for P pictures (weightAnalyse,
+                                             * weightPrediction.cpp:222-470: luma against list 0's first reference, motion compensated with the lookahead's vectors, every
+                                             * candidate scale and offset with the slice header's cost); pps.weighted_pred_flag and the P slices' pred_weight_table().  When the
+                                             * slice's analysis ends without a weight -- the usual case -- the stream is the reference's with weighted prediction on (the chroma
+                                             * planes are only analysed behind a luma weight).  When it picks one (fades), x265amd_encoder_encode fails and names the weight:
+                                             * weighted motion compensation and weighted reference planes for the searches are the next step; such clips need
+                                             * bEnableWeightedPred = 0 (--no-weightp) on both sides until then */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -664,6 +664,20 @@ def make_encoder_og_golden(cases=None, frames_of=None, cli=None, name="encoder_o
             out[tag + "recon_md5"] = np.array([hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)])
             out[tag + "types"] = np.array(types)
             print(tag, len(out[tag + "stream"]), "bytes", " ".join(types))
+    if name == "encoder_wp_golden.npz":
+        # the fade clip: what the reference's weight analysis logs for its first weighted P picture (--log-level full: "poc: N weights: [L0:R0 Y{scale/2^denom+offset}...")
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "clip.y4m"), "wb") as f:
+                f.write(b"YUV4MPEG2 W320 H192 F30:1 Ip A1:1 C420\n")
+                for fr in T.wp_fade_frames():
+                    f.write(b"FRAME\n")
+                    for pl in fr:
+                        f.write(np.ascontiguousarray(pl).tobytes())
+            r = subprocess.run([os.path.join(T.REF_DIR, "x265_ref8"), "--input", "clip.y4m", "-o", "out.hevc", "--log-level", "full"] + T.WP_CLI + T.WP_FADE_CLI, cwd=d, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            lines = [l.split("]:", 1)[1].strip() for l in r.stderr.splitlines() if "weights:" in l]
+            out["wp_fade/weights"] = np.array(lines)
+            print("wp_fade/", lines[:3])
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, name), **out)
 
 

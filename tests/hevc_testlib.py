@@ -3486,6 +3486,20 @@ WP_CASES = {
 }
 
 
+def wp_fade_frames():
+    """a fade: the accelerating-texture clip with its luma scaled towards black by 4.5 % per frame (320x192, 14 frames, 8-bit) -- the reference's weight analysis picks a
+    weight for the first P picture already"""
+    out = []
+    for k, f in enumerate(encoder_ft_clip(320, 192, 14, 8, dy0=2, dy_inc=2, dx_step=4)):
+        y = np.clip((f[0].astype(np.float64) - 16) * (1.0 - 0.045 * k) + 16 + 0.5, 0, 255).astype(np.uint8)
+        out.append([y, f[1], f[2]])
+    return out
+
+
+WP_FADE_CFG = dict(WP_BASE, bframes=3, lookaheadDepth=8)
+WP_FADE_CLI = ["--bframes", "3", "--rc-lookahead", "8"]
+
+
 def wp_case_frames(tag):
     (w, h), n, depth, (kind, arg), _, _ = WP_CASES[tag]
     if kind == "ft":

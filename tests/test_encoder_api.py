@@ -386,6 +386,20 @@ def test_weightp_without_weights(tag):
     assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
 
 
+@pytest.mark.gpu
+def test_weightp_fade_is_refused_with_the_reference_s_weight():
+    """A fade: the reference's analysis picks a luma weight for the first P picture.  Coding with weights is not built, so the encode must fail -- naming the weight the analysis chose,
+    which is the one the reference logs for that picture (weightAnalyse with the reference motion compensated by the lookahead's vectors, themselves searched on the weighted lowres
+    planes LookaheadTLD::weightsAnalyse made: the whole decision path runs before the refusal)."""
+    g = np.load(WP_GOLD)
+    want = str(g["wp_fade/weights"][0])                       # e.g. "poc: 1 weights: [L0:R0 Y{61/64+1}]"
+    poc = int(want.split()[1]); luma = want[want.index("Y{"):want.index("}") + 1]
+    with pytest.raises(AssertionError) as err:
+        T.encoder_run(T.load_hip(8), T.wp_fade_frames(), 320, 192, **T.WP_FADE_CFG)
+    msg = str(err.value)
+    assert "coding with weights is not built" in msg and ("P picture poc %d " % poc) in msg and luma in msg, msg
+
+
 def test_open_gop_golden_has_leading_pictures():
     """the golden streams hold what the cases are there for: CRA NAL units (type 21) and leading pictures (RASL_N, type 8)"""
     g = np.load(OG_GOLD)

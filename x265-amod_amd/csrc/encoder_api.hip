@@ -171,7 +171,7 @@ struct x265amd_encoder
     int lowresInit(Pic& pic);
     void pushMiniGop(int b);
     int lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& scale, int& denom, int& offset);
-    int sliceWeights(Pic& pic, bool& weighted);
+    int sliceWeights(Pic& pic, bool& weighted, int* picked = nullptr);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
     struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool whole = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
@@ -643,7 +643,7 @@ int x265amd_encoder::lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& 
  * the reference motion compensated with the lookahead's vectors of that distance (mcLuma) against every candidate scale (+-4 around the guess) and offset (+-2 around the
  * mean's), each with the slice header's cost, a smaller denominator if the scale is even, the 0.998 test.  Without a luma weight chroma is not looked at.  weighted: the
  * analysis chose a luma weight */
-int x265amd_encoder::sliceWeights(Pic& pic, bool& weighted)
+int x265amd_encoder::sliceWeights(Pic& pic, bool& weighted, int* picked)
 {
     weighted = false;
     Pic& ref = *pic.lists[0][0];
@@ -737,6 +737,7 @@ int x265amd_encoder::sliceWeights(Pic& pic, bool& weighted)
     }
     if (!bFound || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f) return X265AMD_OK;
     weighted = true;
+    if (picked) { picked[0] = minscale; picked[1] = mindenom; picked[2] = minoff; }
     return X265AMD_OK;
 }
 
@@ -1294,11 +1295,17 @@ int x265amd_encoder::prepare(const PicP& picp)
     }
     if (p.bEnableWeightedPred && stype == 1)
     {
-        bool weighted = false;
-        const int rcw = sliceWeights(pic, weighted);
+        bool weighted = false; int picked[3] = { 0, 0, 0 };
+        const int rcw = sliceWeights(pic, weighted, picked);
         if (rcw != X265AMD_OK) return rcw;
         if (weighted)
-            return xa_fail(X265AMD_EINVAL, "encoder_encode: the weight analysis chose a weight for this P picture (a fade); coding with weights is not built -- bEnableWeightedPred = 0 (--no-weightp) on both sides");
+        {
+            /* (the reference's --log-level full line for the picture: "poc: N weights: [L0:R0 Y{scale/2^denom+offset}") */
+            static thread_local char msg[320];
+            snprintf(msg, sizeof(msg), "encoder_encode: the weight analysis chose a luma weight for the P picture poc %d against poc %d: Y{%d/%d%+d}; coding with weights is not built -- "
+                     "bEnableWeightedPred = 0 (--no-weightp) on both sides", pic.poc, pic.lists[0][0]->poc, picked[0], 1 << picked[1], picked[2]);
+            return xa_fail(X265AMD_EINVAL, msg);
+        }
     }
     pic.sliceQp = pic.type == TYPE_BREF ? (qpConstant[0] + qpConstant[1]) / 2 : qpConstant[stype];                    /* rateControlStart, CQP (ratecontrol.cpp:1594-1597: a referenced B picture lies between B and P) */
     picList.insert(picList.begin(), picp);              /* PicList::pushFront */
