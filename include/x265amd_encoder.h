@@ -9,8 +9,8 @@
  *
  * Built subset (everything else is rejected by x265amd_encoder_open with NULL + x265amd_last_error): 4:2:0, bit depth of the library,
  * constant QP (rc.rateControlMode = X265_RC_CQP), mini-GOPs fixed or chosen by the lookahead's trellis (bFrameAdaptive 0 / 2), scene-cut detection, open or
- * closed GOPs, no B-pyramid, no AQ /
- * cutree / weighted prediction, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
+ * closed GOPs, the B pyramid, the lookahead in slices, weighted prediction's analysis (no coding with weights), no AQ /
+ * cutree, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
  * is the reference encoder's (tests/test_encoder_api.py compares whole streams with the reference command line program's). */
 #ifndef X265AMD_ENCODER_H
 #define X265AMD_ENCODER_H
