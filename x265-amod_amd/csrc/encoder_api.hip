@@ -162,6 +162,7 @@ struct x265amd_encoder
     int runFrameParallel(const PicP& pic);
     /* ---- the lookahead (slicetype.cpp): only when param.scenecutThreshold > 0 ---- */
     bool lookahead = false;
+    void* wpEnergy = nullptr; void* wpSums = nullptr; void* wpSumsHost = nullptr; void* wpMvs = nullptr;      /* weighted prediction's device / mapped buffers: the encoder's for good (never back to the pools) */
     int laRowsPerSlice = 0, laNumSlices = 1;            /* Lookahead::m_numRowsPerSlice / m_numCoopSlices (slicetype.cpp:1035-1059) */
     int keyframeMin = 1, lowW = 0, lowH = 0, lowCuW = 0, lowCuH = 0, lowBlocks = 0;
     intptr_t lowStride = 0; size_t lowPlaneElems = 0, lowOrg = 0;
@@ -544,20 +545,22 @@ int x265amd_encoder::lowresInit(Pic& pic)
         for (int x = 0; x < lowCuW; x++)
             if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) est += ic[(size_t)y * lowCuW + x];
     pic.costEst[0] = est;
-    if (p.bEnableWeightedPred)
+    static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");          /* debugging aid: letters s / l / p switch the sums, the lookahead's analysis, the slice's analysis off */
+    if (p.bEnableWeightedPred && !(dbgWp && strchr(dbgWp, 's')))
     {
         /* LookaheadTLD::calcAdaptiveQuantFrame with AQ off (slicetype.cpp:507-513): acEnergyCu over every 16x16 block for Lowres::wp_sum / wp_ssd, then :678-700 */
         const int bw = (W + 15) / 16, bh = (H + 15) / 16;
-        void* dEnergy = nullptr; void* dWp = nullptr;
-        if (xa_scratch_alloc(&dEnergy, (size_t)bw * bh * 4) != hipSuccess || xa_scratch_alloc(&dWp, 6 * 8) != hipSuccess)
-        { xa_scratch_free(dEnergy); xa_scratch_free(dWp); return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation"); }
+        if (!wpEnergy && (xa_scratch_alloc(&wpEnergy, (size_t)bw * bh * 4) != hipSuccess || xa_scratch_alloc(&wpSums, 6 * 8) != hipSuccess || xa_mapped_alloc(&wpSumsHost, 6 * 8, true) != hipSuccess ||
+                          xa_mapped_alloc(&wpMvs, (size_t)lowCuW * lowCuH * 4, false) != hipSuccess))
+            return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+        void* dEnergy = wpEnergy; void* dWp = wpSums;
         const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
         uint64_t wp[6];
         rc = x265amd_aq_energy(laStream, srcP, stride, cstride, W, H, 16, (uint32_t*)dEnergy, (uint64_t*)dWp);
-        if (rc == X265AMD_OK && (hipMemcpyAsync(wp, dWp, sizeof(wp), hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess))
+        if (rc == X265AMD_OK && (hipMemcpyAsync(wpSumsHost, dWp, sizeof(wp), hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess))
             rc = xa_fail(X265AMD_EHIP, "encoder_encode: picture sums");
-        xa_scratch_free(dEnergy); xa_scratch_free(dWp);
         if (rc != X265AMD_OK) return rc;
+        memcpy(wp, wpSumsHost, sizeof(wp));
         const int maxCol = ((W + 8) >> 4) << 4, maxRow = ((H + 8) >> 4) << 4;
         const int width[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, height[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
         for (int i = 0; i < 3; i++)
@@ -703,15 +706,15 @@ int x265amd_encoder::sliceWeights(Pic& pic, bool& weighted, int* picked)
     void* dMvs = nullptr;
     if (haveMvs)
     {
-        if (xa_scratch_alloc(&dMvs, pic.lowMvs[diffPoc].size() * 2) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
-        if (hipMemcpyAsync(dMvs, pic.lowMvs[diffPoc].data(), pic.lowMvs[diffPoc].size() * 2, hipMemcpyHostToDevice, laStream) != hipSuccess)
-        { xa_scratch_free(dMvs); return xa_fail(X265AMD_EHIP, "encoder_encode: lowres vectors"); }
+        /* (a record the host writes in place: no copy from pageable memory) */
+        if (!wpMvs || pic.lowMvs[diffPoc].size() * 2 > (size_t)lowCuW * lowCuH * 4) return xa_fail(X265AMD_EHIP, "encoder_encode: lowres vectors");
+        dMvs = wpMvs;
+        memcpy(dMvs, pic.lowMvs[diffPoc].data(), pic.lowMvs[diffPoc].size() * 2);
     }
     std::vector<uint32_t> costs(cands.size(), 0);
     const pixel* refPlanes[4];
     for (int t = 0; t < 4; t++) refPlanes[t] = ref.dLowres + (size_t)t * lowPlaneElems + lowOrg;
     const int rc = x265amd_lowres_weight_costs(laStream, pic.dLowres + lowOrg, refPlanes, (const int16_t*)dMvs, pic.dIntraCost, lowStride, lowW, lowH, cands.data(), (int)cands.size(), costs.data());
-    xa_scratch_free(dMvs);
     if (rc != X265AMD_OK) return rc;
     const uint32_t origscore = costs[0];
     if (!origscore) return X265AMD_OK;
@@ -800,7 +803,8 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         const bool have0 = !fenc.lowMvs[j.d0].empty() || (j.spec && !fenc.specMvs[j.d0].empty()), have1 = j.d1 > 0 && (!fenc.lowMvs1[j.d1].empty() || (j.spec && !fenc.specMvs1[j.d1].empty()));
         j.search0 = !have0; j.search1 = j.d1 > 0 && !have1;
         bool weighted = false; int wScale = 0, wDenom = 0, wOffset = 0;
-        if (p.bEnableWeightedPred && j.search0)
+        static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");
+        if (p.bEnableWeightedPred && j.search0 && !(dbgWp && strchr(dbgWp, 'l')))
         {
             rc = lookaheadWeights(fenc, *j.ref0, weighted, wScale, wDenom, wOffset);
             if (rc != X265AMD_OK) break;
@@ -1293,7 +1297,8 @@ int x265amd_encoder::prepare(const PicP& picp)
         if ((int)l0.size() < n0 || (int)l1.size() < n1 || (stype == 0 && !n1)) return xa_fail(X265AMD_EINVAL, "encoder_encode: reference lists");
         pic.lists[0].assign(l0.begin(), l0.begin() + n0); pic.lists[1].assign(l1.begin(), l1.begin() + n1);
     }
-    if (p.bEnableWeightedPred && stype == 1)
+    static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");
+    if (p.bEnableWeightedPred && stype == 1 && !(dbgWp && strchr(dbgWp, 'p')))
     {
         bool weighted = false; int picked[3] = { 0, 0, 0 };
         const int rcw = sliceWeights(pic, weighted, picked);

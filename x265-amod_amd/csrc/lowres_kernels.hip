@@ -491,68 +491,78 @@ struct WeightCostParams
 };
 __global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
 {
+    /* a few dozen wavefronts per candidate, each walking its share of the blocks and leaving one partial sum: no flood of one-block workgroups, no atomics */
     __shared__ pixel fencT[64];
     __shared__ pixel refT[64];
     const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
-    const int cu = blockIdx.x, bx = cu % p.blocksX, by = cu / p.blocksX;
-    const int x = bx * 8, y = by * 8;
-    const long off = (long)y * p.stride + x;
-    fencT[lane] = p.fenc[off + (long)ly * p.stride + lx];
-    int v;
-    if (p.mvs)
-    {
-        const int v32 = reinterpret_cast<const int*>(p.mvs)[cu];
-        int qx = (int16_t)(v32 & 0xFFFF), qy = (int16_t)(v32 >> 16);
-        qx = min(max(qx, (-x - 8) * 4), (p.width - x - 1 + 8) * 4);
-        qy = min(max(qy, (-y - 8) * 4), (p.height - y - 1 + 8) * 4);
-        const int hpelA = (qy & 2) | ((qx & 2) >> 1);
-        const pixel* a = p.ref[hpelA] + off + (qx >> 2) + (long)(qy >> 2) * p.stride;
-        v = a[(long)ly * p.stride + lx];
-        if ((qx | qy) & 1)
-        {
-            const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
-            const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
-            const pixel* c = p.ref[hpelB] + off + (qx2 >> 2) + (long)(qy2 >> 2) * p.stride;
-            v = (v + c[(long)ly * p.stride + lx] + 1) >> 1;
-        }
-    }
-    else
-        v = p.ref[0][off + (long)ly * p.stride + lx];
     const x265amd_weight_cand w = p.cands[blockIdx.y];
-    if (w.present)
+    const int numBlocks = p.blocksX * ((p.height + 7) >> 3);
+    uint32_t sum = 0;
+    for (int cu = blockIdx.x; cu < numBlocks; cu += gridDim.x)
     {
-        const int val = (int16_t)(v << (XA_IF_INTERNAL_PREC - XA_DEPTH));
-        v = xa_clip3(0, XA_PIXEL_MAX, ((w.w0 * val + w.round) >> w.shift) + w.offset);
+        const int bx = cu % p.blocksX, by = cu / p.blocksX;
+        const int x = bx * 8, y = by * 8;
+        const long off = (long)y * p.stride + x;
+        xa_wave_sync();
+        fencT[lane] = p.fenc[off + (long)ly * p.stride + lx];
+        int v;
+        if (p.mvs)
+        {
+            const int v32 = reinterpret_cast<const int*>(p.mvs)[cu];
+            int qx = (int16_t)(v32 & 0xFFFF), qy = (int16_t)(v32 >> 16);
+            qx = min(max(qx, (-x - 8) * 4), (p.width - x - 1 + 8) * 4);
+            qy = min(max(qy, (-y - 8) * 4), (p.height - y - 1 + 8) * 4);
+            const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+            const pixel* a = p.ref[hpelA] + off + (qx >> 2) + (long)(qy >> 2) * p.stride;
+            v = a[(long)ly * p.stride + lx];
+            if ((qx | qy) & 1)
+            {
+                const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
+                const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
+                const pixel* c = p.ref[hpelB] + off + (qx2 >> 2) + (long)(qy2 >> 2) * p.stride;
+                v = (v + c[(long)ly * p.stride + lx] + 1) >> 1;
+            }
+        }
+        else
+            v = p.ref[0][off + (long)ly * p.stride + lx];
+        if (w.present)
+        {
+            const int val = (int16_t)(v << (XA_IF_INTERNAL_PREC - XA_DEPTH));
+            v = xa_clip3(0, XA_PIXEL_MAX, ((w.w0 * val + w.round) >> w.shift) + w.offset);
+        }
+        refT[lane] = (pixel)v;
+        xa_wave_sync();
+        int c = xa_wave_satd(refT, 8, fencT, 8, 8, 8, lane);
+        if (p.intraCost) c = min(c, p.intraCost[cu]);
+        sum += (uint32_t)c;
     }
-    refT[lane] = (pixel)v;
-    xa_wave_sync();
-    int c = xa_wave_satd(refT, 8, fencT, 8, 8, 8, lane);
-    if (p.intraCost) c = min(c, p.intraCost[cu]);
-    if (lane == 0) atomicAdd(&p.costs[blockIdx.y], (uint32_t)c);
+    if (lane == 0) p.costs[blockIdx.y * gridDim.x + blockIdx.x] = sum;
 }
+enum { kWeightCostParts = 48 };
 extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
                                            intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs)
 {
     if (!d_fenc || !d_ref || !d_ref[0] || (d_mvs && (!d_ref[1] || !d_ref[2] || !d_ref[3])) || !cands || !costs || n <= 0 || n > 256 || width <= 0 || height <= 0 || (width & 7))
         return xa_fail(X265AMD_EINVAL, "x265amd_lowres_weight_costs: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    void* dC = nullptr; void* dOut = nullptr;
-    if (xa_scratch_alloc(&dC, sizeof(x265amd_weight_cand) * n) != hipSuccess || xa_scratch_alloc(&dOut, 4 * (size_t)n) != hipSuccess)
-    { xa_scratch_free(dC); xa_scratch_free(dOut); return xa_fail(X265AMD_EHIP, "x265amd_lowres_weight_costs: device allocation"); }
+    /* the candidates go to the device through a record the host writes in place, the partial sums come back in pinned memory the kernel writes: no copies.  The two blocks are
+     * the calling thread's for good */
+    static thread_local void* mC = nullptr; static thread_local void* mOut = nullptr;
+    if (!mC && (xa_mapped_alloc(&mC, sizeof(x265amd_weight_cand) * 256, false) != hipSuccess || xa_mapped_alloc(&mOut, 4 * 256 * kWeightCostParts, true) != hipSuccess))
+    { xa_mapped_free(mC); xa_mapped_free(mOut); mC = mOut = nullptr; return xa_fail(X265AMD_EHIP, "x265amd_lowres_weight_costs: allocation"); }
+    memcpy(mC, cands, sizeof(x265amd_weight_cand) * n);
     WeightCostParams p;
     memset(&p, 0, sizeof(p));
     p.fenc = (const pixel*)d_fenc;
     for (int k = 0; k < 4; k++) p.ref[k] = (const pixel*)d_ref[k];
     p.stride = (long)stride; p.width = width; p.height = height; p.blocksX = width >> 3;
-    p.mvs = d_mvs; p.intraCost = d_intra_cost; p.cands = (const x265amd_weight_cand*)dC; p.costs = (uint32_t*)dOut;
-    const int blocksY = (height + 7) >> 3;
-    hipError_t e = hipMemcpyAsync(dC, cands, sizeof(x265amd_weight_cand) * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, 4 * (size_t)n, st);
-    if (e == hipSuccess) { hipLaunchKernelGGL(k_lowres_weight_cost, dim3(p.blocksX * blocksY, n), dim3(64), 0, st, p); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipMemcpyAsync(costs, dOut, 4 * (size_t)n, hipMemcpyDeviceToHost, st);
+    p.mvs = d_mvs; p.intraCost = d_intra_cost; p.cands = (const x265amd_weight_cand*)mC; p.costs = (uint32_t*)mOut;
+    hipLaunchKernelGGL(k_lowres_weight_cost, dim3(kWeightCostParts, n), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    xa_scratch_free(dC); xa_scratch_free(dOut);
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    const uint32_t* part = (const uint32_t*)mOut;
+    for (int i = 0; i < n; i++) { uint32_t t = 0; for (int k = 0; k < kWeightCostParts; k++) t += part[i * kWeightCostParts + k]; costs[i] = t; }
     return X265AMD_OK;
 }
 /* weight_pp_c over a whole padded buffer (LookaheadTLD::weightsAnalyse's weighted copies of the four lowres planes, slicetype.cpp:971-975) */
