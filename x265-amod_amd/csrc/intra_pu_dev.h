@@ -135,7 +135,10 @@ XA_DEV bool xa_chain_wait(const uint64_t* word, uint64_t want)
         __builtin_amdgcn_s_sleep(2);
         if (wall_clock64() - t0 > XA_CHAIN_TIMEOUT_TICKS) return false;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    /* SYSTEM scope, on both sides: with agent-scope fences here the two workgroups of a chained CU (usually on different XCDs) lost each other's writes whenever another
+     * kernel ran atomics on the device at the same time -- eleven runs out of twelve under a flood of them, one in five beside the first form of the weight-cost kernel
+     * (X265AMD_WP_FLOOD=1,11040 with dbg/wp_md5.py reproduces it when this says "agent").  Measured cost: none outside the noise */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __builtin_amdgcn_s_dcache_inv();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return true;
@@ -144,7 +147,8 @@ XA_DEV bool xa_chain_wait(const uint64_t* word, uint64_t want)
 XA_DEV void xa_chain_publish(uint64_t* word, uint64_t value)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          /* system scope: see xa_chain_wait */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -538,6 +538,17 @@ __global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
     }
     if (lane == 0) p.costs[blockIdx.y * gridDim.x + blockIdx.x] = sum;
 }
+/* debugging aid (X265AMD_WP_FLOOD=<mode>,<workgroups>): the dispatch pattern of this kernel's first form -- thousands of one-wave workgroups, mode 1: each ending in an atomicAdd on
+ * one word, mode 2: each reading a little memory, mode 0: nothing at all -- beside whatever else runs; DESIGN.md section 8 (the intra chain's open sensitivity) */
+__global__ __launch_bounds__(64) void k_flood(uint32_t* word, int mode, const uint32_t* src)
+{
+    __shared__ uint32_t t[64];
+    t[threadIdx.x] = mode == 2 ? src[(blockIdx.x * 64 + threadIdx.x) & 1023] : threadIdx.x;
+    __syncthreads();
+    uint32_t v = t[63 - threadIdx.x];
+    v = xa_wave_sum(v);
+    if (mode == 1 && threadIdx.x == 0) atomicAdd(word + (blockIdx.y & 63), v);
+}
 enum { kWeightCostParts = 48 };
 extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
                                            intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs)
@@ -557,6 +568,15 @@ extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_
     for (int k = 0; k < 4; k++) p.ref[k] = (const pixel*)d_ref[k];
     p.stride = (long)stride; p.width = width; p.height = height; p.blocksX = width >> 3;
     p.mvs = d_mvs; p.intraCost = d_intra_cost; p.cands = (const x265amd_weight_cand*)mC; p.costs = (uint32_t*)mOut;
+    static const char* const flood = getenv("X265AMD_WP_FLOOD");
+    if (flood)
+    {
+        static thread_local void* dF = nullptr;
+        int mode = 1, wgs = 11040;
+        sscanf(flood, "%d,%d", &mode, &wgs);
+        if (!dF && xa_scratch_alloc(&dF, 8192) != hipSuccess) dF = nullptr;
+        if (dF) hipLaunchKernelGGL(k_flood, dim3(wgs / 46 > 0 ? wgs / 46 : 1, 46), dim3(64), 0, st, (uint32_t*)dF, mode, (const uint32_t*)dF + 1024);
+    }
     hipLaunchKernelGGL(k_lowres_weight_cost, dim3(kWeightCostParts, n), dim3(64), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
