@@ -313,7 +313,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
              * estimates in one grid thousands of waiting rows did nothing else --, one acquire fence follows when the row may go on */
             if (lane == 0) while (__hip_atomic_load(&p.progress[cuY + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > need) __builtin_amdgcn_s_sleep(8);
             xa_wave_sync();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
         const int cuXY = cuX + cuY * W;
         b.off = 8L * cuX + 8L * cuY * p.stride;
@@ -395,7 +395,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         {
             p.bcost[cuXY] = bcost;
             p.lowresCosts[cuXY] = (uint16_t)(min(bcost, 0x3FFF) | (listused << 14));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             __hip_atomic_store(&p.progress[cuY], cuX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
