@@ -400,6 +400,23 @@ def test_weightp_fade_is_refused_with_the_reference_s_weight():
     assert "coding with weights is not built" in msg and ("P picture poc %d " % poc) in msg and luma in msg, msg
 
 
+@pytest.mark.gpu
+def test_intra_chain_beside_a_flood_of_atomics():
+    """Regression test for the fence scope of the device-run chain of 8x8 intra CUs: thousands of one-wave workgroups that each end in an atomicAdd, launched
+    beside the I picture (X265AMD_WP_FLOOD, read by x265amd_lowres_weight_costs at every call), made that picture come out different in eleven runs of twelve while the chain's
+    workgroups synchronised with agent-scope fences.  Four encodes, each must be the reference's stream."""
+    g = np.load(WP_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.WP_CASES["wp_ft/"]
+    frames = T.wp_case_frames("wp_ft/")
+    os.environ["X265AMD_WP_FLOOD"] = "1,11040"
+    try:
+        for k in range(4):
+            stream, _ = T.encoder_run(T.load_hip(depth), frames, w, h, **cfg)
+            assert not T.stream_diff(stream, g["wp_ft/stream"]), "encode %d: %s" % (k, T.stream_diff(stream, g["wp_ft/stream"]))
+    finally:
+        del os.environ["X265AMD_WP_FLOOD"]
+
+
 def test_open_gop_golden_has_leading_pictures():
     """the golden streams hold what the cases are there for: CRA NAL units (type 21) and leading pictures (RASL_N, type 8)"""
     g = np.load(OG_GOLD)

@@ -568,7 +568,7 @@ extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_
     for (int k = 0; k < 4; k++) p.ref[k] = (const pixel*)d_ref[k];
     p.stride = (long)stride; p.width = width; p.height = height; p.blocksX = width >> 3;
     p.mvs = d_mvs; p.intraCost = d_intra_cost; p.cands = (const x265amd_weight_cand*)mC; p.costs = (uint32_t*)mOut;
-    static const char* const flood = getenv("X265AMD_WP_FLOOD");
+    const char* const flood = getenv("X265AMD_WP_FLOOD");          /* (read at every call: tests/test_encoder_api.py switches it on for one encode) */
     if (flood)
     {
         static thread_local void* dF = nullptr;
