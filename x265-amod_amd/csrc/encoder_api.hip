@@ -536,6 +536,21 @@ int x265amd_encoder::lowresInit(Pic& pic)
     uint8_t* dMode = (uint8_t*)(pic.dIntraCost + (size_t)lowCuW * lowCuH);
     rc = x265amd_lowres_intra_costs(laStream, planes[0], lowStride, lowCuW, lowCuH, lambda, pic.dIntraCost, dMode);
     if (rc != X265AMD_OK) return rc;
+    /* the picture's sums for the weight analysis are measured in front of the one wait of this function */
+    static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");          /* debugging aid: letters s / l / p switch the sums, the lookahead's analysis, the slice's analysis off */
+    const bool sums = p.bEnableWeightedPred && !(dbgWp && strchr(dbgWp, 's'));
+    if (sums)
+    {
+        /* LookaheadTLD::calcAdaptiveQuantFrame with AQ off (slicetype.cpp:507-513): acEnergyCu over every 16x16 block for Lowres::wp_sum / wp_ssd, then :678-700 */
+        const int bw = (W + 15) / 16, bh = (H + 15) / 16;
+        if (!wpEnergy && (xa_scratch_alloc(&wpEnergy, (size_t)bw * bh * 4) != hipSuccess || xa_scratch_alloc(&wpSums, 6 * 8) != hipSuccess || xa_mapped_alloc(&wpSumsHost, 6 * 8, true) != hipSuccess ||
+                          xa_mapped_alloc(&wpMvs, (size_t)lowCuW * lowCuH * 4, false) != hipSuccess))
+            return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+        const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
+        rc = x265amd_aq_energy(laStream, srcP, stride, cstride, W, H, 16, (uint32_t*)wpEnergy, (uint64_t*)wpSums);
+        if (rc == X265AMD_OK && hipMemcpyAsync(wpSumsHost, wpSums, 6 * 8, hipMemcpyDeviceToHost, laStream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "encoder_encode: picture sums");
+        if (rc != X265AMD_OK) return rc;
+    }
     std::vector<int32_t> ic((size_t)lowCuW * lowCuH);
     if (hipMemcpyAsync(ic.data(), pic.dIntraCost, ic.size() * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess)
         return xa_fail(X265AMD_EHIP, "encoder_encode: lowres intra costs");
@@ -545,21 +560,9 @@ int x265amd_encoder::lowresInit(Pic& pic)
         for (int x = 0; x < lowCuW; x++)
             if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) est += ic[(size_t)y * lowCuW + x];
     pic.costEst[0] = est;
-    static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");          /* debugging aid: letters s / l / p switch the sums, the lookahead's analysis, the slice's analysis off */
-    if (p.bEnableWeightedPred && !(dbgWp && strchr(dbgWp, 's')))
+    if (sums)
     {
-        /* LookaheadTLD::calcAdaptiveQuantFrame with AQ off (slicetype.cpp:507-513): acEnergyCu over every 16x16 block for Lowres::wp_sum / wp_ssd, then :678-700 */
-        const int bw = (W + 15) / 16, bh = (H + 15) / 16;
-        if (!wpEnergy && (xa_scratch_alloc(&wpEnergy, (size_t)bw * bh * 4) != hipSuccess || xa_scratch_alloc(&wpSums, 6 * 8) != hipSuccess || xa_mapped_alloc(&wpSumsHost, 6 * 8, true) != hipSuccess ||
-                          xa_mapped_alloc(&wpMvs, (size_t)lowCuW * lowCuH * 4, false) != hipSuccess))
-            return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
-        void* dEnergy = wpEnergy; void* dWp = wpSums;
-        const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
         uint64_t wp[6];
-        rc = x265amd_aq_energy(laStream, srcP, stride, cstride, W, H, 16, (uint32_t*)dEnergy, (uint64_t*)dWp);
-        if (rc == X265AMD_OK && (hipMemcpyAsync(wpSumsHost, dWp, sizeof(wp), hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess))
-            rc = xa_fail(X265AMD_EHIP, "encoder_encode: picture sums");
-        if (rc != X265AMD_OK) return rc;
         memcpy(wp, wpSumsHost, sizeof(wp));
         const int maxCol = ((W + 8) >> 4) << 4, maxRow = ((H + 8) >> 4) << 4;
         const int width[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, height[3] = { maxRow, maxRow >> 1, maxRow >> 1 };

@@ -628,11 +628,22 @@ __global__ __launch_bounds__(64) void k_aq_energy(const pixel* y, const pixel* u
         }
         sum = xa_wave_sum(sum); sqr = xa_wave_sum(sqr);
         total += sqr - (uint32_t)(((unsigned long long)sum * sum) >> (2 * log2n));
-        if (lane == 0) { atomicAdd(&wp[plane], (unsigned long long)sum); atomicAdd(&wp[3 + plane], (unsigned long long)sqr); }
+        /* (partial sums, added up by k_aq_reduce: six atomics per block on six words were half a millisecond per 1080p picture -- and a flood of atomics beside the encoder) */
+        if (lane == 0) { wp[(size_t)blk * 6 + plane] = (unsigned long long)sum; wp[(size_t)blk * 6 + 3 + plane] = (unsigned long long)sqr; }
     }
     if (lane == 0) energy[blk] = total;
 }
 
+__global__ __launch_bounds__(256) void k_aq_reduce(const unsigned long long* part, int numBlocks, unsigned long long* wp)
+{
+    __shared__ unsigned long long t[256];
+    unsigned long long a = 0;
+    for (int i = threadIdx.x; i < numBlocks; i += 256) a += part[(size_t)i * 6 + blockIdx.x];
+    t[threadIdx.x] = a;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if ((int)threadIdx.x < k) t[threadIdx.x] += t[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) wp[blockIdx.x] = t[0];
+}
 extern "C" int x265amd_aq_energy(void* stream, const uint64_t planes[3], intptr_t stride, intptr_t cstride, int width, int height, int qg_size,
                                  uint32_t* d_energy, uint64_t* d_wp)
 {
@@ -640,9 +651,18 @@ extern "C" int x265amd_aq_energy(void* stream, const uint64_t planes[3], intptr_
         return xa_fail(X265AMD_EINVAL, "x265amd_aq_energy: bad arguments");
     const int bw = (width + qg_size - 1) / qg_size, bh = (height + qg_size - 1) / qg_size;
     hipStream_t st = (hipStream_t)stream;
-    XA_HIP_CHECK(hipMemsetAsync(d_wp, 0, 6 * sizeof(uint64_t), st));
+    /* the blocks' partial sums: a block of the calling thread's, kept (it grows with the picture size) */
+    static thread_local void* dPart = nullptr; static thread_local size_t partBytes = 0;
+    const size_t need = (size_t)bw * bh * 6 * sizeof(unsigned long long);
+    if (need > partBytes)
+    {
+        if (dPart) { (void)hipStreamSynchronize(st); xa_scratch_free(dPart); dPart = nullptr; partBytes = 0; }
+        if (xa_scratch_alloc(&dPart, need) != hipSuccess) return xa_fail(X265AMD_EHIP, "x265amd_aq_energy: device allocation");
+        partBytes = need;
+    }
     hipLaunchKernelGGL(k_aq_energy, dim3(bw * bh), dim3(64), 0, st, (const pixel*)(uintptr_t)planes[0], (const pixel*)(uintptr_t)planes[1], (const pixel*)(uintptr_t)planes[2],
-                       (long)stride, (long)cstride, bw, bw * bh, qg_size, d_energy, (unsigned long long*)d_wp);
+                       (long)stride, (long)cstride, bw, bw * bh, qg_size, d_energy, (unsigned long long*)dPart);
+    hipLaunchKernelGGL(k_aq_reduce, dim3(6), dim3(256), 0, st, (const unsigned long long*)dPart, bw * bh, (unsigned long long*)d_wp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
