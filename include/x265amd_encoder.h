@@ -8,7 +8,7 @@
  * per-frame calls into the frame pipeline (x265amd_analyse_frame, deblocking, SAO, border extension, slice NAL) and the stream headers.
  *
  * Built subset (everything else is rejected by x265amd_encoder_open with NULL + x265amd_last_error): 4:2:0, bit depth of the library,
- * constant QP (rc.rateControlMode = X265_RC_CQP), mini-GOPs fixed or chosen by the lookahead's trellis (bFrameAdaptive 0 / 2), scene-cut detection, open or
+ * constant QP (rc.rateControlMode = X265_RC_CQP), mini-GOPs fixed or chosen by the lookahead (bFrameAdaptive 0 / 1 / 2), scene-cut detection, open or
  * closed GOPs, the B pyramid, the lookahead in slices, weighted prediction's analysis (no coding with weights), no AQ /
  * cutree, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
  * is the reference encoder's (tests/test_encoder_api.py compares whole streams with the reference command line program's). */
@@ -67,8 +67,8 @@ typedef struct x265amd_param
                                              * the stream is the owners' NAL units in coding order.  0 / 0 or count 1: one object codes everything */
     int32_t bFrameAdaptive;                 /* param.bFrameAdaptive (--b-adapt): 0 fixed mini-GOPs of `bframes` B pictures; 2 the trellis (Lookahead::slicetypeAnalyse with
                                              * slicetypePath / slicetypePathCost, slicetype.cpp:2776-2795, :3218-3313) on P and B cost estimates of the lowres pictures,
-                                             * every pair of the window searched in advance as the reference's batch does with four pool workers or more.  1 (fast)
-                                             * is not built */
+                                             * every pair of the window searched in advance as the reference's batch does with four pool workers or more; 1 the fast
+                                             * decision (X265_B_ADAPT_FAST, slicetype.cpp:2796-2848: pictures in pairs, estimates made when they are asked for) */
     int32_t bOpenGOP;                       /* param.bOpenGOP (--open-gop, the reference's default; 0 = --no-open-gop): keyframes after the first are I pictures with
                                              * NAL type CRA instead of IDR (Lookahead::slicetypeDecide, slicetype.cpp:1956-1993; DPB::getNalUnitType, dpb.cpp:486-506):
                                              * the POC count runs on, the B pictures in front of a keyframe stay B (leading pictures, RASL_N) and reference across it,

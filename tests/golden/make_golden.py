@@ -684,6 +684,10 @@ def make_encoder_og_golden(cases=None, frames_of=None, cli=None, name="encoder_o
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "og":
         make_encoder_og_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "b1":
+        sel = {k: v for k, v in T.B1_CASES.items() if k != "ba1_medium/"}
+        make_encoder_og_golden(sel, T.b1_case_frames, T.B1_CLI, "encoder_b1_golden.npz")
+        make_encoder_og_golden({"ba1_medium/": T.B1_CASES["ba1_medium/"]}, T.b1_case_frames, T.WP_CLI, "encoder_b1m_golden.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "wp":
         make_encoder_og_golden(T.WP_CASES, T.wp_case_frames, T.WP_CLI, "encoder_wp_golden.npz")
     elif len(sys.argv) > 1 and sys.argv[1] == "ls":

@@ -3507,6 +3507,27 @@ def wp_case_frames(tag):
     return encoder_api_clip(tag, w, h, n, depth)
 
 
+# --b-adapt 1 (fast): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of B1_CLI)
+B1_CLI = [o if o != "2" or BA_CLI[i - 1] != "--b-adapt" else "1" for i, o in enumerate(BA_CLI)]
+B1_BASE = dict(BA_BASE, bFrameAdaptive=1)
+B1_CASES = {
+    "ba1_drift/": ((320, 192), 20, 8, ("api", None), dict(B1_BASE, bframes=4, lookaheadDepth=10), ["--bframes", "4", "--rc-lookahead", "10"]),
+    "ba1_cut/": ((320, 192), 18, 8, ("scene", [9]), dict(B1_BASE, bframes=3, lookaheadDepth=8), ["--bframes", "3", "--rc-lookahead", "8"]),
+    "ba1_ft_hbd/": ((256, 192), 14, 10, ("ft", None), dict(B1_BASE, bframes=4, lookaheadDepth=6), ["--bframes", "4", "--rc-lookahead", "6"]),
+    # with everything else of the preset: B pyramid, open GOPs, the lookahead in slices (every estimate of --b-adapt 1 is made when asked for, i.e. in slices), weighted prediction
+    "ba1_medium/": ((1280, 720), 12, 8, ("ft", None), dict(WP_BASE, bFrameAdaptive=1, bframes=4, lookaheadDepth=20, lookaheadSlices=8), ["--b-adapt", "1"]),
+}
+
+
+def b1_case_frames(tag):
+    (w, h), n, depth, (kind, arg), _, _ = B1_CASES[tag]
+    if kind == "scene":
+        return scene_clip(w, h, n, arg, depth)
+    if kind == "ft":
+        return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
+    return encoder_api_clip(tag, w, h, n, depth)
+
+
 def ba_case_frames(tag):
     (w, h), n, depth, (kind, arg), _, _ = BA_CASES[tag]
     if kind == "scene":

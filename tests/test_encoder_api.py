@@ -417,6 +417,29 @@ def test_intra_chain_beside_a_flood_of_atomics():
         del os.environ["X265AMD_WP_FLOOD"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.B1_CASES))
+def test_b_adapt_fast(tag):
+    """x265amd_param.bFrameAdaptive = 1 (--b-adapt 1, X265_B_ADAPT_FAST, slicetype.cpp:2796-2848): pictures taken in pairs -- two P pictures when half the second one's blocks are intra,
+    P when P P is cheaper than B P, else B pictures while the P picture behind them stays cheap (estimates with the intra penalty of estimateFrameCost, :4069-4071), every estimate made
+    when it is asked for (no batch): the reference encoder's stream on a drifting texture, across a scene cut, 10-bit, and with the rest of the preset (B pyramid, open GOPs, the
+    lookahead in slices, weighted prediction) at 1280x720.  Golden data: tests/golden/make_golden.py b1."""
+    g = np.load(os.path.join(T.GOLDEN_DIR, "encoder_b1m_golden.npz" if tag == "ba1_medium/" else "encoder_b1_golden.npz"))
+    (w, h), n, depth, _, cfg, _ = T.B1_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.b1_case_frames(tag), w, h, **cfg)
+    names = {1: "I", 2: "i", 3: "P", 4: "B", 5: "b"}
+    got_types, idr = [], 0
+    for (poc, st, _, _) in coded:
+        if st == 1:
+            idr = poc
+        got_types.append("%d:%s" % (poc - idr, names[st]))
+    assert got_types == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
+
+
 def test_open_gop_golden_has_leading_pictures():
     """the golden streams hold what the cases are there for: CRA NAL units (type 21) and leading pictures (RASL_N, type 8)"""
     g = np.load(OG_GOLD)

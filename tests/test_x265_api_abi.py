@@ -66,7 +66,7 @@ def test_encoder_open_names_what_it_rejects():
     buf[LAYOUT["PARAM_sourceWidth"]] = 64; buf[LAYOUT["PARAM_sourceHeight"]] = 64; buf[LAYOUT["PARAM_fpsNum"]] = 30; buf[LAYOUT["PARAM_fpsDenom"]] = 1
     assert not opn(p) and b"rc.rateControlMode" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_rc_rateControlMode"]] = 1
-    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 1
+    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 3
     assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
     buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2
     # --b-adapt 2, scene-cut detection, the lookahead in slices, the B pyramid and open GOPs (the defaults) are built

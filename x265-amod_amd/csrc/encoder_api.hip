@@ -301,7 +301,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     { xa_fail(X265AMD_EINVAL, "encoder_open: scenecutThreshold outside 0..100, lookaheadDepth outside 0..250 or keyframeMin outside 0..keyframeMax"); return nullptr; }
     if (p->shardCount < 0 || p->shardCount > 64 || (p->shardCount > 1 && (p->shardRank < 0 || p->shardRank >= p->shardCount || p->frameNumThreads <= 1)))
     { xa_fail(X265AMD_EINVAL, "encoder_open: shardRank / shardCount (frame-per-GPU needs 0 <= rank < count and frameNumThreads > 1: rows are published by pictures coded in parallel)"); return nullptr; }
-    if (p->bFrameAdaptive != 0 && p->bFrameAdaptive != 2) { xa_fail(X265AMD_EINVAL, "encoder_open: bFrameAdaptive: 0 (fixed mini-GOPs) and 2 (trellis) are built"); return nullptr; }
+    if (p->bFrameAdaptive < 0 || p->bFrameAdaptive > 2) { xa_fail(X265AMD_EINVAL, "encoder_open: bFrameAdaptive: 0 (fixed mini-GOPs), 1 (fast) or 2 (trellis)"); return nullptr; }
     e->lookahead = p->scenecutThreshold > 0 || (p->bFrameAdaptive && p->bframes);
     if (p->bEnableWeightedPred && !e->lookahead) { xa_fail(X265AMD_EINVAL, "encoder_open: bEnableWeightedPred needs the lookahead (scenecutThreshold > 0 or bFrameAdaptive 2 with B frames)"); return nullptr; }
     {
@@ -1126,6 +1126,46 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
                 numBFrames = (int)strspn(best_paths[best_path_index], "B");
                 for (int j = 1; j < numFrames; j++) frames[j]->type = best_paths[best_path_index][j - 1] == 'B' ? TYPE_B : TYPE_P;
             }
+        }
+        else if (p.bFrameAdaptive == 1)
+        {
+            /* X265_B_ADAPT_FAST (slicetype.cpp:2796-2848): pictures in pairs -- two P pictures when half the second one's blocks are intra, a P picture when P P is cheaper than B P,
+             * else B pictures for as long as the P picture behind them stays cheap; every estimate made when it is asked for (no batch: slicetype.cpp:1024) */
+            const int cuCount = lowBlocks;
+            auto cost = [&](int p0, int p1, int b, bool intraPenalty, int64_t& out) -> int {
+                int64_t sc = 0;
+                const int r = frameCost(frames, p0, p1, b, sc);
+                if (r != X265AMD_OK) return r;
+                if (intraPenalty) sc += sc * frames[b]->intraMbs[b - p0] / (cuCount * 8);          /* estimateFrameCost's "arbitrary penalty for I-blocks after B-frames" (:4069-4071) */
+                out = sc;
+                return X265AMD_OK;
+            };
+            for (int i = 0; i <= numFrames - 2 && rc == X265AMD_OK; )
+            {
+                int64_t cost1p0 = 0, cost2p0 = 0, cost1b1 = 0, cost2p1 = 0;
+                if ((rc = cost(i + 0, i + 2, i + 2, true, cost2p1)) != X265AMD_OK) break;
+                if (frames[i + 2]->intraMbs[2] > cuCount / 2) { frames[i + 1]->type = TYPE_P; frames[i + 2]->type = TYPE_P; i += 2; continue; }
+                if ((rc = cost(i + 0, i + 2, i + 1, false, cost1b1)) != X265AMD_OK || (rc = cost(i + 0, i + 1, i + 1, false, cost1p0)) != X265AMD_OK ||
+                    (rc = cost(i + 1, i + 2, i + 2, false, cost2p0)) != X265AMD_OK) break;
+                if (cost1p0 + cost2p0 < cost1b1 + cost2p1) { frames[i + 1]->type = TYPE_P; i += 1; continue; }
+                frames[i + 1]->type = TYPE_B;
+                int j;
+                for (j = i + 2; j <= std::min(i + p.bframes, numFrames - 1); j++)
+                {
+                    const int64_t pthresh = std::max(300 - (50 - 0) * (j - i - 1), 300 / 10);          /* INTER_THRESH, P_SENS_BIAS with bFrameBias 0 */
+                    int64_t pcost = 0;
+                    if ((rc = cost(i + 0, j + 1, j + 1, true, pcost)) != X265AMD_OK) break;
+                    if (pcost > pthresh * cuCount || frames[j + 1]->intraMbs[j - i + 1] > cuCount / 3) break;
+                    frames[j]->type = TYPE_B;
+                }
+                if (rc != X265AMD_OK) break;
+                frames[j]->type = TYPE_P;
+                i = j;
+            }
+            if (rc != X265AMD_OK) return rc;
+            frames[numFrames]->type = TYPE_P;
+            numBFrames = 0;
+            while (numBFrames < numFrames && frames[numBFrames + 1]->type == TYPE_B) numBFrames++;
         }
         else
             for (int j = 1; j < numFrames; j++) frames[j]->type = (j % (numBFrames + 1)) ? TYPE_B : TYPE_P;

@@ -105,7 +105,7 @@ void* abi_encoder_open(void* p)
     REQUIRE(PI(p, internalCsp) == 1, "internalCsp: only X265_CSP_I420 is built");
     REQUIRE(PI(p, rc_rateControlMode) == 1, "rc.rateControlMode: only X265_RC_CQP (--qp) is built (no ABR / CRF / VBV)");
     REQUIRE(PI(p, rc_vbvBufferSize) == 0 && !PI(p, rc_bStatRead) && !PI(p, rc_bStatWrite), "rc: VBV and multi-pass statistics are not built");
-    REQUIRE(PI(p, bFrameAdaptive) == 0 || PI(p, bFrameAdaptive) == 2, "bFrameAdaptive (--b-adapt): 0 and 2 are built, 1 (fast) is not");
+    REQUIRE(PI(p, bFrameAdaptive) >= 0 && PI(p, bFrameAdaptive) <= 2, "bFrameAdaptive (--b-adapt): 0, 1 or 2");
     REQUIRE(!PI(p, bHistBasedSceneCut), "bHistBasedSceneCut: histogram scene-cut detection is not built");
     REQUIRE(!PI(p, bEnableWeightedBiPred), "weighted bi-prediction is not built (--no-weightb)");
     REQUIRE(!PI(p, bEmitInfoSEI), "bEmitInfoSEI: the option-string SEI is not written (--no-info)");
