@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, hevc_testlib as T, bench
 L = T.load_hip(8)
 N = int(sys.argv[1]); Wm = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-os.environ.setdefault("X265AMD_FRAME_THREADS", str(bench.BFRAMES + 2))
+# (frame threads: the library default, as bench.py runs it)
 sync = torch.cuda.synchronize
 if Wm: bench.encode(T, L, bench.bench_clip(0, Wm), 0, 0, sync, timed=False)
 frames = bench.bench_clip(0, N)

@@ -22,6 +22,7 @@
 #include "inter_common.h"
 #include "xa_queue.h"
 #include "../host/cabac_coder.h"
+#include "inter_chain_dev.h"
 #include <string.h>
 #include <vector>
 
@@ -38,6 +39,7 @@ using namespace xa_inter;
 static double g_stageMs[8];
 static const char* const g_stageName[8] = { "merge", "search", "rdInter", "rdIntra", "bidir", "copies", "intraSlice", "other" };
 static bool g_timing = getenv("X265AMD_TIMING") != nullptr;
+static std::atomic<uint64_t> g_chainStat[4], g_chainTicks[8], g_cuStat[2][4][4];      /* [B / P][depth][skipped on the device, merge check on the host, search, intra try] */     /* X265AMD_TIMING: skip chains run, CUs they skipped, stops (not a skip / vector beyond what is published); the device's stage clock */
 struct StageTimer
 {
     int k; std::chrono::steady_clock::time_point t0;
@@ -88,6 +90,63 @@ int xa_ref_guard_me(const x265amd_me_job* jobs, const int* pics, int n)
         if (xa_ref_guard_wait(pics[i], j.y + j.mvmin[1] - 8, j.y + j.h + j.mvmax[1] + 8, j.x + j.w + j.mvmax[0] + 10)) return -1;
     }
     return 0;
+}
+
+/* ---- device-resident motion maps (inter_chain_dev.h): a host motion field (x265amd_mv_unit array) may have a mirror in device memory the host writes through the BAR;
+ * the encoder object registers one per picture, frame-level callers without one get a temporary mirror (xa_analyse_frame) ---- */
+namespace {
+/* blocks are never given back to the runtime while the process lives (hipFree waits for the device, and the job server's kernel is resident): an entry
+ * without a host field is a free block of `units` units */
+struct DevMapEntry { std::atomic<const void*> host{ nullptr }; void* dev = nullptr; size_t units = 0; };
+DevMapEntry g_devMaps[512];
+std::mutex g_devMapM;
+}
+void* xa_devmap_register(const x265amd_mv_unit* host, size_t units)
+{
+    if (!host || !units || !xa_queues_enabled()) return nullptr;
+    std::lock_guard<std::mutex> g(g_devMapM);
+    DevMapEntry* blank = nullptr;
+    for (DevMapEntry& e : g_devMaps)
+    {
+        if (e.host.load(std::memory_order_relaxed)) continue;
+        if (e.dev && e.units == units) { e.host.store(host, std::memory_order_release); return e.dev; }
+        if (!e.dev && !blank) blank = &e;
+    }
+    if (!blank) return nullptr;
+    void* d = nullptr;
+    if (hipExtMallocWithFlags(&d, units * sizeof(XaMapUnit), hipDeviceMallocUncached) != hipSuccess) return nullptr;
+    blank->dev = d; blank->units = units;
+    blank->host.store(host, std::memory_order_release);
+    return d;
+}
+void xa_devmap_unregister(const x265amd_mv_unit* host)
+{
+    if (!host) return;
+    std::lock_guard<std::mutex> g(g_devMapM);
+    for (DevMapEntry& e : g_devMaps)
+        if (e.host.load(std::memory_order_relaxed) == host) { e.host.store(nullptr, std::memory_order_release); return; }
+}
+void* xa_devmap_find(const x265amd_mv_unit* host)
+{
+    if (!host) return nullptr;
+    for (DevMapEntry& e : g_devMaps) if (e.host.load(std::memory_order_acquire) == host) return e.dev;
+    return nullptr;
+}
+static inline void devmap_store(XaMapUnit* d, const x265amd_mv_unit& v, int depth)
+{
+    union { XaMapUnit u; uint64_t w[2]; } t;
+    t.w[0] = t.w[1] = 0;
+    t.u.pred_mode = v.pred_mode; t.u.inter_dir = v.inter_dir; t.u.ref_idx[0] = v.ref_idx[0]; t.u.ref_idx[1] = v.ref_idx[1];
+    t.u.mv[0][0] = v.mv[0][0]; t.u.mv[0][1] = v.mv[0][1]; t.u.mv[1][0] = v.mv[1][0]; t.u.mv[1][1] = v.mv[1][1]; t.u.depth = (uint8_t)depth;
+    volatile uint64_t* q = reinterpret_cast<volatile uint64_t*>(d);
+    q[0] = t.w[0]; q[1] = t.w[1];
+}
+/* rows [y4a, y4b) of a host field into its mirror (a picture whose rows arrive from another process: x265amd_encoder_import_row) */
+void xa_devmap_push_rows(const x265amd_mv_unit* host, const x265amd_cu_unit* units, int w4, int y4a, int y4b)
+{
+    XaMapUnit* d = (XaMapUnit*)xa_devmap_find(host);
+    if (!d) return;
+    for (int i = y4a * w4; i < y4b * w4; i++) devmap_store(d + i, host[i], units ? units[i].depth : 0);
 }
 
 namespace {
@@ -156,6 +215,256 @@ struct Analyzer
     int err;
     void* intraWs = nullptr;                /* the intra RD's working set, kept for the CUs of this CTU (intra_rd.hip) */
     ~Analyzer() { xa_intra_ws_free(intraWs); }
+
+    /* ---- the device-resident motion map and the skip chain (inter_chain_dev.h) ---- */
+    XaMapUnit* dCur = nullptr; const XaMapUnit* dCol = nullptr;
+    struct Chain
+    {
+        bool on = false;
+        XaChainNode nodes[XA_CHAIN_MAX_NODES + 3]; int numNodes = 0;
+        uint8_t status[XA_CHAIN_MAX_NODES + 3] = {};    /* 0 not run, 1 skipped on the device, 2 the chain stopped here */
+        XaChainCuOut res[XA_CHAIN_MAX_NODES + 3];
+        XaMapped mJob, mNodes; XaMappedOut mOut; DevBuf dScratch;
+        bool nodesPushed = false;
+        uint64_t stopFrac = 0; uint8_t stopCtx[X265AMD_CTX_STRIDE];     /* the device's coder state where the last chain stopped (X265AMD_CHAIN_VERIFY) */
+        int stopNode = -1;
+        XaChainStop stop;                               /* the merge check of the CU the last chain stopped at, when the device made it */
+        int frNode[4]; bool frDirty[4];                 /* the host's recursion: node and "something below it was decided on the host" per depth */
+        bool lastDevComplete = false;                   /* of the compress() call that has just returned: everything in its area is the device's */
+        uint64_t runs = 0, skipped = 0;
+    } chain;
+    int buildNodes(int x, int y, int depth, int parent)
+    {
+        const int idx = chain.numNodes++;
+        const int size = 64 >> depth;
+        XaChainNode& n = chain.nodes[idx];
+        n.x = (int16_t)x; n.y = (int16_t)y; n.log2 = (uint8_t)(6 - depth); n.parent = (uint8_t)(parent < 0 ? 255 : parent);
+        const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
+        const bool checked = mightNotSplit && (uint32_t)depth >= topSkipMinDepth(x, y, depth);
+        n.flags = (uint8_t)((checked ? 1 : 0) | (mightNotSplit && !checked && depth < si->max_cu_depth ? 2 : 0));
+        if (depth < si->max_cu_depth)
+            for (int q = 0; q < 4; q++)
+            {
+                const int cx = x + (q & 1) * (size >> 1), cy = y + (q >> 1) * (size >> 1);
+                if (cx < I->pic_width && cy < I->pic_height) buildNodes(cx, cy, depth + 1, idx);
+            }
+        chain.nodes[idx].next = (uint8_t)chain.numNodes;
+        return idx;
+    }
+    /* the chain from `node` to the end of the innermost enclosing CU that has something decided on the host (its reconstruction tiles are the host's to keep) */
+    int runChain(int node, int depth)
+    {
+        XA_HOSTPROF("an.runChain");
+        int end = chain.numNodes;
+        for (int k = depth - 1; k >= 0; k--) if (chain.frDirty[k]) { end = chain.nodes[chain.frNode[k]].next; break; }
+        if (!chain.mJob.p && (chain.mJob.alloc(sizeof(XaChainJob)) != hipSuccess || chain.mNodes.alloc(sizeof(chain.nodes)) != hipSuccess || chain.mOut.alloc(sizeof(XaChainOut)) != hipSuccess))
+            return fail("chain records");
+        if (!chain.nodesPushed)
+        {
+            volatile uint64_t* d = (volatile uint64_t*)chain.mNodes.p; const uint64_t* s = (const uint64_t*)chain.nodes;
+            for (int i = 0; i < chain.numNodes; i++) d[i] = s[i];
+            chain.nodesPushed = true;
+        }
+        XaChainJob J;
+        memset(&J, 0, sizeof(J));
+        J.info = *I;
+        memcpy(J.ref_pic, S->ref_pic, sizeof(J.ref_pic));
+        J.planes = (uint64_t)(uintptr_t)dPlanes.p; J.cur = (uint64_t)(uintptr_t)dCur; J.col = (uint64_t)(uintptr_t)dCol;
+        J.tiles = (uint64_t)(uintptr_t)dTiles.p; J.tile_bytes = tileBytes; J.out = (uint64_t)(uintptr_t)chain.mOut.p; J.nodes = (uint64_t)(uintptr_t)chain.mNodes.p;
+        J.stride = (int32_t)stride; J.cstride = (int32_t)cstride; J.num_pics = numPics; J.w4 = w4;
+        J.start = node; J.end = end; J.num_nodes = chain.numNodes;
+        J.tiles_per_depth = 2 * NUM_PRED + 6; J.cand_tile0 = 2 * NUM_PRED; J.split_recon_tile = NUM_PRED + PRED_SPLIT;
+        J.skip_recon_tile = NUM_PRED + PRED_SKIP; J.merge_recon_tile = NUM_PRED + PRED_MERGE;
+        J.frame_parallel = S->frame_parallel; J.search_range = S->search_range; J.chroma_sa8d = A->rd_level >= 3; J.slice_type = si->slice_type;
+        {
+            /* Quant::setQPforQuant (quant.cpp:221-244), chroma QP offsets 0: as make_plan (inter_rd.hip) */
+            static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
+                                                     32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+            const int qpQuant = qp < 0 ? 0 : (qp > 51 ? 51 : qp), bd = 6 * (X265AMD_DEPTH - 8);
+            int qpC = qpQuant < -bd ? -bd : (qpQuant > 57 ? 57 : qpQuant);
+            if (qpC >= 30) qpC = chromaScale[qpC];
+            J.qp_luma = qpQuant + bd; J.qp_chroma = qpC + bd;
+        }
+        J.tu_log2_max = si->tu_log2_max;
+        J.ctu_x = ctuX; J.ctu_y = ctuY; J.lambda = lambda; J.lambda2 = lambda2; J.psy_rd = psyRd;
+        { static const int dbg = getenv("X265AMD_CHAIN_DBG") ? atoi(getenv("X265AMD_CHAIN_DBG")) : 0; J.dbg = dbg; }
+        J.rd_level = A->rd_level; J.sign_hide = si->sign_hide != 0; J.max_cu_depth = si->max_cu_depth;
+        if (!chain.dScratch.p && chain.dScratch.alloc(x265amd_inter_rd_scratch_bytes()) != hipSuccess) return fail("chain scratch");
+        J.scratch = (uint64_t)(uintptr_t)chain.dScratch.p;
+        J.frac = md[depth].cur.frac; memcpy(J.ctx, md[depth].cur.ctx, X265AMD_CTX_STRIDE);
+        {
+            void** slot = xa_task_slot();
+            const XaRowHooks* h = slot ? (const XaRowHooks*)*slot : nullptr;
+            if (h && h->ref_wait)
+            {
+                J.guard_on = 1; J.guard_r0 = 1; J.guard_r1 = 0; J.guard_need = 0;           /* nothing, unless the gate says what it has waited for */
+                if (h->ctu_reach) h->ctu_reach(h->ctx, ctuY >> 6, ctuX >> 6, &J.guard_r0, &J.guard_r1, &J.guard_need);
+            }
+        }
+        {
+            volatile uint64_t* d = (volatile uint64_t*)chain.mJob.p; const uint64_t* s = (const uint64_t*)&J;
+            for (size_t i = 0; i < sizeof(J) / 8; i++) d[i] = s[i];
+        }
+        const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)chain.mJob.p, 0, 0, 0, 1 };
+        if (xa_q_enqueue(st, XA_OP_INTER_CHAIN, &qa, sizeof(qa), 1, 0) != hipSuccess || xa_stream_sync(st) != hipSuccess) return fail("chain command");
+        const XaChainOut* o = (const XaChainOut*)chain.mOut.p;
+        const uint32_t count = o->count, stopNode = o->stop_node, reason = o->reason;
+        if (count > (uint32_t)chain.numNodes || stopNode > (uint32_t)chain.numNodes) return fail("chain result");
+        for (uint32_t k = 0; k < count; k++)
+        {
+            const XaChainCuOut& c = o->cu[k];
+            if (c.node >= (uint32_t)chain.numNodes) return fail("chain result");
+            chain.res[c.node] = c; chain.status[c.node] = 1;
+        }
+        if (reason != XA_CHAIN_END && stopNode < (uint32_t)chain.numNodes)
+        {
+            chain.status[stopNode] = 2;
+            chain.stopNode = (int)stopNode; chain.stopFrac = o->frac; memcpy(chain.stopCtx, (const void*)o->ctx, X265AMD_CTX_STRIDE);
+            chain.stop.valid = 0;
+            if (o->stop.valid == 1 && o->stop.node == stopNode) memcpy(&chain.stop, (const void*)&o->stop, sizeof(XaChainStop));
+        }
+        chain.runs++; chain.skipped += count;
+        if (g_timing)
+        {
+            g_chainStat[0]++; g_chainStat[1] += count; g_chainStat[2] += reason == XA_CHAIN_NOTSKIP; g_chainStat[3] += reason == XA_CHAIN_GUARD;
+            for (int k = 0; k < 8; k++) g_chainTicks[k] += o->ticks[k];
+        }
+        return 0;
+    }
+    /* the merge check of the CU the chain stopped at, made on the device (the residual mode beat the skip mode): both modes as checkMerge2Nx2N_rd0_4 leaves them */
+    int chainMerge(int node, int x, int y, int depth, bool& taken)
+    {
+        taken = false;
+        static const bool on = !(getenv("X265AMD_CHAIN_MERGE") && atoi(getenv("X265AMD_CHAIN_MERGE")) == 0);
+        if (!on || chain.status[node] != 2 || chain.stopNode != node || chain.stop.valid != 1 || chain.stop.node != (uint32_t)node) return 0;
+        XA_HOSTPROF("an.chainMerge");
+        const XaChainStop& c = chain.stop;
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth, size = 1 << log2, n4 = 16 >> depth;
+        Mode* skip = &d.pred[PRED_SKIP];
+        Mode* merge = &d.pred[PRED_MERGE];
+        skip->initCosts(); merge->initCosts();
+        const int16_t zero[2][2] = { { 0, 0 }, { 0, 0 } };
+        const uint8_t noIdx[2] = { 0, 0 };
+        const int numCand = I->max_num_merge_cand;
+        const uint32_t bits = (uint32_t)(c.cand + (c.cand < numCand - 1));
+        x265amd_cu_measure ms = c.meas; ms.sa8d = c.sa8d; ms.sa8d_luma = c.sa8d_luma;
+        for (Mode* m : { skip, merge })
+        {
+            setInter(*m, depth, 1, c.cand, c.dir, c.ref_idx, c.mv, zero, noIdx);
+            m->sa8dCost = calcRdSADCost(sa8dOf(ms), bits); m->sa8dBits = bits;
+            m->predTile = candTile(depth, c.cand);
+        }
+        skip->reconTile = reconTile(depth, PRED_SKIP); merge->reconTile = reconTile(depth, PRED_MERGE);
+        d.srcMean = 0; d.srcHomo = 0;
+        x265amd_rd_cu rc;
+        memset(&rc, 0, sizeof(rc));
+        rc.x = (int16_t)x; rc.y = (int16_t)y; rc.log2_size = (uint8_t)log2; rc.qp = (int8_t)qp;
+        memcpy(rc.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
+        rc.frac_bits = d.cur.frac;
+        x265amd_rd_result r;
+        const int rcode = x265amd_skip_rd_host(si, &rp, units, &rc, 1, skip->u, &c.meas, &r);
+        if (rcode != X265AMD_OK) return err = rcode;
+        std::fill(skip->coeff.begin(), skip->coeff.end(), 0);
+        skip->rdCost = r.rd_cost; skip->distortion = (sse_t)r.distortion; skip->totalBits = r.total_bits; skip->mvBits = r.mv_bits; skip->coeffBits = r.coeff_bits;
+        skip->psyEnergy = r.psy_energy; skip->lumaDistortion = r.luma_distortion; skip->chromaDistortion = r.chroma_distortion; skip->resEnergy = r.res_energy;
+        memcpy(skip->contexts.ctx, r.ctx, X265AMD_CTX_STRIDE);
+        skip->contexts.frac = r.frac_bits;
+        for (int i = 0; i < n4 * n4; i++) skip->m[i].pred_mode = skip->u[i].pred_mode;
+        /* the residual mode: units as the walk leaves them (one transform unit per plane: tu_depth 0, the coded block flags at depth 0), levels in CUData::m_trCoeff order */
+        for (int i = 0; i < n4 * n4; i++)
+        {
+            x265amd_cu_unit& u = merge->u[i];
+            u.depth = (uint8_t)depth; u.tu_depth = 0; u.cbf[0] = c.cbf[0]; u.cbf[1] = c.cbf[1]; u.cbf[2] = c.cbf[2]; u.pred_mode = X265AMD_MODE_INTER;
+            merge->m[i].pred_mode = X265AMD_MODE_INTER;
+        }
+        std::fill(merge->coeff.begin(), merge->coeff.end(), 0);
+        memcpy(&merge->coeff[0], c.levels, sizeof(int16_t) * size * size);
+        memcpy(&merge->coeff[4096], c.levels + 1024, sizeof(int16_t) * (size >> 1) * (size >> 1));
+        memcpy(&merge->coeff[5120], c.levels + 1280, sizeof(int16_t) * (size >> 1) * (size >> 1));
+        merge->rdCost = c.rd_cost; merge->lumaDistortion = (sse_t)c.luma_dist; merge->chromaDistortion = (sse_t)c.chroma_dist; merge->distortion = (sse_t)(c.luma_dist + c.chroma_dist);
+        merge->totalBits = c.total_bits; merge->mvBits = c.mv_bits; merge->coeffBits = c.coeff_bits; merge->psyEnergy = c.psy_energy; merge->resEnergy = (sse_t)c.meas.sse[0];
+        memset(merge->contexts.ctx, 0, X265AMD_CTX_STRIDE);
+        memcpy(merge->contexts.ctx, c.ctx, X265AMD_CTX_COUNT);
+        merge->contexts.frac = c.frac;
+        d.best = merge->rdCost < skip->rdCost ? merge : skip;
+        /* the winner keeps the candidate's prediction: out of the candidate tiles, which the next merge scan reuses */
+        const int keep = predTile(depth, d.best == merge ? PRED_MERGE : PRED_SKIP);
+        copyTile(keep, candTile(depth, c.cand), 0, 0, size);
+        d.best->predTile = keep;
+        taken = true;
+        return 0;
+    }
+    /* the merge check of a CU decided on the device as a skip: Mode PRED_SKIP as checkMerge leaves it (candidate, costs, contexts) */
+    int chainSkip(int node, int x, int y, int depth, bool& skipped)
+    {
+        skipped = false;
+        if (chain.status[node] == 0) { if (runChain(node, depth)) return err; }
+        static const bool verify = getenv("X265AMD_CHAIN_VERIFY") != nullptr;
+        if (verify && chain.status[node] == 2 && chain.stopNode == node)
+        {
+            /* the device carried the entropy coder's state from CU to CU on its own: where it stopped it must be what the host arrives with */
+            const Snap& h = md[depth].cur;
+            if ((h.frac & 32767) != (chain.stopFrac & 32767) || memcmp(h.ctx, chain.stopCtx, X265AMD_CTX_COUNT))
+            {
+                int first = -1;
+                for (int i = 0; i < X265AMD_CTX_COUNT && first < 0; i++) if (h.ctx[i] != chain.stopCtx[i]) first = i;
+                fprintf(stderr, "x265amd chain verify: poc %d CU (%d,%d) size %d: coder state differs: fraction host %llu device %llu, first context %d (host %d device %d)\n", I->poc, x, y, 64 >> depth,
+                        (unsigned long long)(h.frac & 32767), (unsigned long long)(chain.stopFrac & 32767), first, first >= 0 ? h.ctx[first] : 0, first >= 0 ? chain.stopCtx[first] : 0);
+                return fail("chain verify: the device's entropy state is not the host's");
+            }
+        }
+        if (chain.status[node] != 1) return 0;
+        XA_HOSTPROF("an.chainSkip");
+        const XaChainCuOut& c = chain.res[node];
+        ModeDepth& d = md[depth];
+        const int log2 = 6 - depth;
+        Mode* bestPred = &d.pred[PRED_SKIP];
+        bestPred->initCosts();
+        if (verify)
+        {
+            x265amd_merge_cand cand[5];
+            const int numCand = x265amd_merge_candidates(I, cur, col, x, y, log2, 0, 0, cand);
+            const x265amd_merge_cand& b = cand[c.cand < 5 ? c.cand : 0];
+            bool same = c.cand < numCand && b.dir == c.dir;
+            for (int l = 0; l < 2 && same; l++)
+                if ((c.dir >> l) & 1) same = b.ref_idx[l] == c.ref_idx[l] && b.mv[l][0] == c.mv[l][0] && b.mv[l][1] == c.mv[l][1];
+            if (!same)
+            {
+                fprintf(stderr, "x265amd chain verify: poc %d CU (%d,%d) size %d: device candidate %d dir %d refs %d %d mv (%d,%d) (%d,%d); host candidate dir %d refs %d %d mv (%d,%d) (%d,%d) of %d\n", I->poc, x, y,
+                        1 << log2, c.cand, c.dir, c.ref_idx[0], c.ref_idx[1], c.mv[0][0], c.mv[0][1], c.mv[1][0], c.mv[1][1], b.dir, b.ref_idx[0], b.ref_idx[1], b.mv[0][0], b.mv[0][1],
+                        b.mv[1][0], b.mv[1][1], numCand);
+                return fail("chain verify: the device's merge candidate is not the host's");
+            }
+        }
+        const int16_t zero[2][2] = { { 0, 0 }, { 0, 0 } };
+        const uint8_t noIdx[2] = { 0, 0 };
+        const int numCand = I->max_num_merge_cand;
+        const uint32_t bits = (uint32_t)(c.cand + (c.cand < numCand - 1));
+        setInter(*bestPred, depth, 1, c.cand, c.dir, c.ref_idx, c.mv, zero, noIdx);
+        bestPred->sa8dCost = calcRdSADCost(sa8dOf(c.meas), bits); bestPred->sa8dBits = bits;
+        bestPred->predTile = candTile(depth, c.cand); bestPred->reconTile = reconTile(depth, PRED_SKIP);
+        d.srcMean = c.meas.src_mean; d.srcHomo = c.meas.src_homo;
+        x265amd_rd_cu rc;
+        memset(&rc, 0, sizeof(rc));
+        rc.x = (int16_t)x; rc.y = (int16_t)y; rc.log2_size = (uint8_t)log2; rc.qp = (int8_t)qp;
+        memcpy(rc.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
+        rc.frac_bits = d.cur.frac;
+        x265amd_rd_result r;
+        const int rcode = x265amd_skip_rd_host(si, &rp, units, &rc, 1, bestPred->u, &c.meas, &r);
+        if (rcode != X265AMD_OK) return err = rcode;
+        Mode& m = *bestPred;
+        std::fill(m.coeff.begin(), m.coeff.end(), 0);
+        m.rdCost = r.rd_cost; m.distortion = (sse_t)r.distortion; m.totalBits = r.total_bits; m.mvBits = r.mv_bits; m.coeffBits = r.coeff_bits;
+        m.psyEnergy = r.psy_energy; m.lumaDistortion = r.luma_distortion; m.chromaDistortion = r.chroma_distortion; m.resEnergy = r.res_energy;
+        memcpy(m.contexts.ctx, r.ctx, X265AMD_CTX_STRIDE);
+        m.contexts.frac = r.frac_bits;
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++) m.m[i].pred_mode = m.u[i].pred_mode;
+        d.best = bestPred;
+        skipped = true;
+        return 0;
+    }
 
     uint64_t tileAddr(int t) const { return (uint64_t)(uintptr_t)dTiles.p + (size_t)t * tileBytes; }
     /* tiles: per depth NUM_PRED prediction + NUM_PRED reconstruction tiles, then 5 merge-candidate tiles + 1 scratch tile per depth */
@@ -292,7 +601,7 @@ struct Analyzer
             }
         }
     }
-    void toPicture(const Mode& m, int x, int y, int depth)      /* CUData::copyToPic */
+    void toPicture(const Mode& m, int x, int y, int depth, bool mirror = true)      /* CUData::copyToPic; mirror: also into the device's motion map (not what the device itself decided) */
     {
         const int n4 = 16 >> depth;
         for (int yy = 0; yy < n4; yy++)
@@ -303,6 +612,7 @@ struct Analyzer
                 x265amd_mv_unit v = m.m[yy * n4 + xx];
                 v.pred_mode = m.u[yy * n4 + xx].pred_mode;
                 cur[((y >> 2) + yy) * w4 + (x >> 2) + xx] = v;
+                if (dCur && mirror) devmap_store(dCur + ((y >> 2) + yy) * w4 + (x >> 2) + xx, v, m.u[yy * n4 + xx].depth);
             }
     }
 
@@ -1022,6 +1332,7 @@ struct Analyzer
                             /* CUData::copyToPic of the sub-CU */
                             units[((cy >> 2) + (k >> 1)) * w4 + (cx >> 2) + (k & 1)] = u;
                             cur[((cy >> 2) + (k >> 1)) * w4 + (cx >> 2) + (k & 1)] = split.m[idx];
+                            if (dCur) devmap_store(dCur + ((cy >> 2) + (k >> 1)) * w4 + (cx >> 2) + (k & 1), split.m[idx], u.depth);
                         }
                         split.rdCost += r.rd_cost; split.psyEnergy += r.psy_energy; split.resEnergy += r.res_energy;
                         split.lumaDistortion += r.luma_dist; split.chromaDistortion += r.chroma_dist; split.distortion += r.luma_dist + r.chroma_dist;
@@ -1090,7 +1401,7 @@ struct Analyzer
         return 0;
     }
 
-    int compress(int x, int y, int depth, SplitData& splitOut)
+    int compress(int x, int y, int depth, SplitData& splitOut, int node = 0)
     {
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
@@ -1104,11 +1415,58 @@ struct Analyzer
         d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
         { XA_HOSTPROF("an.initSubCU x13"); for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth); }
         d.pred[PRED_2Nx2N].sa8dCost = 0;                 /* what a parent reads under --limit-modes when 2Nx2N is not searched here */
+        chain.frNode[depth] = node; chain.frDirty[depth] = false;
+        bool devSkip = false, childrenDev = true;
 
         /* Step 1: merge / skip candidates */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
-            if (checkMerge(x, y, depth)) return err;
+            if (chain.on && chainSkip(node, x, y, depth, devSkip)) return err;
+            if (g_timing) g_cuStat[si->slice_type == 1][depth][devSkip ? 0 : 1]++;
+            static const bool verify2 = getenv("X265AMD_CHAIN_VERIFY") && atoi(getenv("X265AMD_CHAIN_VERIFY")) >= 2;
+            if (devSkip && verify2)
+            {
+                /* debugging: the host's own merge check of the CU the device skipped must arrive at the same mode, cost and coder state */
+                const uint64_t devCost = d.best->rdCost; const Snap devCtx = d.best->contexts; const int devCand = d.best->u[0].mvp_idx[0];
+                d.best = nullptr;
+                if (checkMerge(x, y, depth)) return err;
+                if (!d.best || !d.best->isSkipped() || d.best->rdCost != devCost || d.best->u[0].mvp_idx[0] != devCand || d.best->contexts.frac != devCtx.frac ||
+                    memcmp(d.best->contexts.ctx, devCtx.ctx, X265AMD_CTX_COUNT))
+                {
+                    fprintf(stderr, "x265amd chain verify: poc %d CU (%d,%d) size %d: device skip (candidate %d, cost %llu); host %s candidate %d cost %llu\n", I->poc, x, y, size, devCand,
+                            (unsigned long long)devCost, !d.best ? "nothing" : (d.best->isSkipped() ? "skip" : "merge with residual"), d.best ? d.best->u[0].mvp_idx[0] : -1,
+                            (unsigned long long)(d.best ? d.best->rdCost : 0));
+                    return fail("chain verify: the device skipped a CU the host does not skip the same way");
+                }
+            }
+            if (!devSkip)
+            {
+                chain.frDirty[depth] = true;            /* this CU is the host's: what the chain decides below it stays inside it */
+                bool devMerge = false;
+                if (chain.on && chainMerge(node, x, y, depth, devMerge)) return err;
+                static const bool verify3 = getenv("X265AMD_CHAIN_VERIFY") && atoi(getenv("X265AMD_CHAIN_VERIFY")) >= 2;
+                if (devMerge && verify3)
+                {
+                    /* debugging: the host's own merge check must leave the same two modes */
+                    const uint64_t c0 = d.pred[PRED_SKIP].rdCost, c1 = d.pred[PRED_MERGE].rdCost; const Snap s1 = d.pred[PRED_MERGE].contexts;
+                    const uint32_t b1 = d.pred[PRED_MERGE].totalBits, mv1 = d.pred[PRED_MERGE].mvBits; const uint8_t cb[3] = { d.pred[PRED_MERGE].u[0].cbf[0], d.pred[PRED_MERGE].u[0].cbf[1], d.pred[PRED_MERGE].u[0].cbf[2] };
+                    const std::vector<int16_t> lv = d.pred[PRED_MERGE].coeff;
+                    const bool mergeBest = d.best == &d.pred[PRED_MERGE];
+                    d.best = nullptr;
+                    if (checkMerge(x, y, depth)) return err;
+                    const Mode& hm = d.pred[PRED_MERGE];
+                    if (d.pred[PRED_SKIP].rdCost != c0 || hm.rdCost != c1 || hm.totalBits != b1 || hm.mvBits != mv1 || hm.u[0].cbf[0] != cb[0] || hm.u[0].cbf[1] != cb[1] || hm.u[0].cbf[2] != cb[2] ||
+                        hm.contexts.frac != s1.frac || memcmp(hm.contexts.ctx, s1.ctx, X265AMD_CTX_COUNT) || hm.coeff != lv || (d.best == &d.pred[PRED_MERGE]) != mergeBest)
+                    {
+                        fprintf(stderr, "x265amd chain verify: poc %d CU (%d,%d) size %d: merge check differs: skip cost device %llu host %llu, residual mode cost %llu / %llu bits %u / %u mv bits %u / %u "
+                                "cbf %d%d%d / %d%d%d fraction %llu / %llu levels %s best %d / %d\n", I->poc, x, y, size, (unsigned long long)c0, (unsigned long long)d.pred[PRED_SKIP].rdCost,
+                                (unsigned long long)c1, (unsigned long long)hm.rdCost, b1, hm.totalBits, mv1, hm.mvBits, cb[0], cb[1], cb[2], hm.u[0].cbf[0], hm.u[0].cbf[1], hm.u[0].cbf[2],
+                                (unsigned long long)s1.frac, (unsigned long long)hm.contexts.frac, hm.coeff == lv ? "same" : "differ", (int)mergeBest, (int)(d.best == &d.pred[PRED_MERGE]));
+                        return fail("chain verify: the device's merge check is not the host's");
+                    }
+                }
+                if (!devMerge && checkMerge(x, y, depth)) return err;
+            }
             skipModes = A->early_skip && d.best && d.best->isSkipped();
         }
         if (d.best && A->rskip)
@@ -1144,13 +1502,17 @@ struct Analyzer
             const int n4 = 16 >> depth, half = size >> 1, h4n = n4 >> 1;
             const Snap* nextContext = &d.cur;
             splitIntra = false;
+            int childNode = node + 1;                   /* pre-order: the first sub-CU follows its parent, the others follow their elder's subtree */
             for (int q = 0; q < 4; q++)
             {
                 const int cx = x + (q & 1) * half, cy = y + (q >> 1) * half;
                 if (cx < I->pic_width && cy < I->pic_height)
                 {
                     md[depth + 1].cur = *nextContext;
-                    if (compress(cx, cy, depth + 1, splitData[q])) return err;
+                    if (compress(cx, cy, depth + 1, splitData[q], childNode)) return err;
+                    childNode = chain.nodes[childNode].next;
+                    const bool childDev = chain.lastDevComplete;
+                    if (!childDev) { childrenDev = false; chain.frDirty[depth] = true; }
                     const Mode& nb = *md[depth + 1].best;
                     splitIntra |= nb.u[0].pred_mode == X265AMD_MODE_INTRA;
                     for (int yy = 0; yy < h4n; yy++)
@@ -1160,7 +1522,7 @@ struct Analyzer
                             split.m[((q >> 1) * h4n + yy) * n4 + (q & 1) * h4n + xx] = nb.m[yy * h4n + xx];
                         }
                     split.addSubCosts(nb);
-                    copyTile(split.reconTile, nb.reconTile, (q & 1) * half, (q >> 1) * half, half);
+                    if (!childDev) copyTile(split.reconTile, nb.reconTile, (q & 1) * half, (q >> 1) * half, half);     /* the device put its CUs' samples into every enclosing tile itself */
                     const int nc = half * half;
                     memcpy(&split.coeff[(size_t)q * nc], nb.coeff.data(), sizeof(int16_t) * nc);
                     memcpy(&split.coeff[4096 + (size_t)q * nc / 4], nb.coeff.data() + 4096, sizeof(int16_t) * nc / 4);
@@ -1181,6 +1543,7 @@ struct Analyzer
         {
             if (!skipModes)
             {
+                if (g_timing) g_cuStat[si->slice_type == 1][depth][2]++;
                 if (checkInter(x, y, depth, allSplitRefs)) return err;
                 Mode* bestInter = &d.pred[PRED_2Nx2N];
                 if (A->limit_refs & 2)                                                     /* X265_REF_LIMIT_CU */
@@ -1249,6 +1612,7 @@ struct Analyzer
                     const x265amd_cu_unit& b0 = d.best->u[0];
                     if (bTryIntra && (b0.cbf[0] || b0.cbf[1] || b0.cbf[2]) && (!A->limit_refs || splitIntra))
                     {
+                        if (g_timing) g_cuStat[si->slice_type == 1][depth][3]++;
                         if (rdIntra(d.pred[PRED_INTRA], x, y, depth)) return err;
                         checkBestMode(d.pred[PRED_INTRA], depth);
                     }
@@ -1301,19 +1665,36 @@ struct Analyzer
             cs.count[depth] += 1;
             cs.avg_cost[depth] = (temp + d.best->rdCost) / cs.count[depth];
         }
-        toPicture(*d.best, x, y, depth);
-        tileToPicture(d.best->reconTile, x, y, size);
+        /* everything in this CU's area decided (and put in place) by the device: the CU itself skipped there, or a CU that is not coded at this depth whose sub-CUs all are */
+        const bool devComplete = devSkip || (chain.on && !(mightNotSplit && (uint32_t)depth >= minDepth) && d.best == &d.pred[PRED_SPLIT] && childrenDev);
+        toPicture(*d.best, x, y, depth, !devComplete);
+        if (!devComplete) tileToPicture(d.best->reconTile, x, y, size);
+        chain.lastDevComplete = devComplete;
         return 0;
     }
 };
 
 } // namespace
 
+static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                             const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                             const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                             intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
+                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol);
 extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                                           const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                                           const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                                           intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
                                           int16_t* coeff_out, x265amd_ctu_result* out)
+{
+    return compress_ctu_impl(me, stream, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, ctu_addr, ctx_in, frac_in, coeff_out, out,
+                             (XaMapUnit*)xa_devmap_find(cur), (const XaMapUnit*)xa_devmap_find(col));
+}
+static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
+                             const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
+                             const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
+                             intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
+                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol)
 {
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
@@ -1394,7 +1775,17 @@ extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, cons
         memcpy(a.md[0].cur.ctx, ctx_in, X265AMD_CTX_COUNT);
         a.md[0].cur.frac = frac_in;
         SplitData topSplit;
-        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit));
+        a.dCur = dCur; a.dCol = dCol;
+        {
+            /* the skip chain (inter_chain_dev.h): what it assumes of the configuration -- a skipped CU ends there (early skip + recursion skip), one transform size per
+             * plane, plain quantisation -- and a device job queue to run on */
+            static const bool chainEnv = !(getenv("X265AMD_INTER_CHAIN") && atoi(getenv("X265AMD_INTER_CHAIN")) == 0);
+            a.chain.on = chainEnv && si->slice_type != 2 && A->rd_level <= 4 && A->early_skip && A->rskip == 1 && !A->rdoq_level && si->tu_max_depth_inter == 1 && !si->use_dqp &&
+                         xa_is_queue(a.st) && dCur && (dCol || !I->temporal_mvp) && I->max_num_merge_cand >= 1 && I->max_num_merge_cand <= 5 && !dump;
+            if (a.chain.on) a.buildNodes(a.ctuX, a.ctuY, 0, -1);
+            else a.chain.nodes[0].next = 0;
+        }
+        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit, 0));
         if (rc == X265AMD_OK && (xa_stream_fence(a.st, XA_CMD_RELEASE) != hipSuccess || xa_stream_sync(a.st) != hipSuccess)) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)
@@ -1453,6 +1844,19 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
     }
     memset(cu_stat, 0, sizeof(x265amd_cu_stat) * (numCtu + 1));          /* FrameData::reinit */
     const bool wpp = si->wpp != 0;
+    /* the motion fields' mirrors in device memory (inter_chain_dev.h): the encoder object registers them with its pictures; other callers get them for the call */
+    struct TmpMap { const x265amd_mv_unit* h = nullptr; ~TmpMap() { if (h) xa_devmap_unregister(h); } } tmpCur, tmpCol;
+    XaMapUnit* frameDCur = (XaMapUnit*)xa_devmap_find(cur);
+    const XaMapUnit* frameDCol = (const XaMapUnit*)xa_devmap_find(col);
+    if (xa_queues_enabled() && !getenv("X265AMD_DUMP_CTU"))
+    {
+        if (!frameDCur && (frameDCur = (XaMapUnit*)xa_devmap_register(cur, (size_t)w4 * h4)) != nullptr) tmpCur.h = cur;
+        if (col && !frameDCol && si->slice_type != 2 && (frameDCol = (const XaMapUnit*)xa_devmap_register(col, (size_t)w4 * h4)) != nullptr)
+        {
+            tmpCol.h = col;
+            for (int i = 0; i < w4 * h4; i++) devmap_store((XaMapUnit*)frameDCol + i, col[i], 0);
+        }
+    }
     std::vector<x265amd_cabac*> rows(wpp ? ctuH : 1, nullptr);
     for (size_t r = 0; r < rows.size(); r++)
     {
@@ -1473,8 +1877,8 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         }
         x265amd_ctu_result res;
         int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
-        int r = x265amd_compress_ctu_inter(me, st, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
-                                           rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res);
+        int r = compress_ctu_impl(me, st, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
+                                  rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res, frameDCur, frameDCol);
         if (r != X265AMD_OK) return r;
         if (results) results[addr] = res;
         xa_phase(XA_PH_ANALYZER);
@@ -1650,6 +2054,16 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         xa_sched_stats(ss);
         xa_phase_report();
         fprintf(stderr, "x265amd: workers so far: %.1f ms running tasks, %.1f ms looking for one, %llu switches\n", ss[0] / 1e6, ss[1] / 1e6, (unsigned long long)ss[2]);
+        fprintf(stderr, "x265amd: skip chains so far: %llu commands, %llu CUs skipped on the device, stopped %llu times at a CU that is not skipped and %llu times at a vector beyond what is published; "
+                "device ms: candidates %.1f, predictions + SA8D %.1f, choice %.1f, transform units %.1f, rate-distortion %.1f, placing %.1f, coder state %.1f (%llu CUs)\n", (unsigned long long)g_chainStat[0].load(),
+                (unsigned long long)g_chainStat[1].load(), (unsigned long long)g_chainStat[2].load(), (unsigned long long)g_chainStat[3].load(), g_chainTicks[0].load() / 1e5, g_chainTicks[1].load() / 1e5,
+                g_chainTicks[2].load() / 1e5, g_chainTicks[3].load() / 1e5, g_chainTicks[4].load() / 1e5, g_chainTicks[5].load() / 1e5, g_chainTicks[7].load() / 1e5, (unsigned long long)g_chainTicks[6].load());
+        for (int t = 0; t < 2; t++)
+            fprintf(stderr, "x265amd: CUs of %s pictures so far by depth 0..3 (skipped on the device / merge check on the host / searched / intra try): %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu\n",
+                    t ? "P" : "B", (unsigned long long)g_cuStat[t][0][0].load(), (unsigned long long)g_cuStat[t][0][1].load(), (unsigned long long)g_cuStat[t][0][2].load(), (unsigned long long)g_cuStat[t][0][3].load(),
+                    (unsigned long long)g_cuStat[t][1][0].load(), (unsigned long long)g_cuStat[t][1][1].load(), (unsigned long long)g_cuStat[t][1][2].load(), (unsigned long long)g_cuStat[t][1][3].load(),
+                    (unsigned long long)g_cuStat[t][2][0].load(), (unsigned long long)g_cuStat[t][2][1].load(), (unsigned long long)g_cuStat[t][2][2].load(), (unsigned long long)g_cuStat[t][2][3].load(),
+                    (unsigned long long)g_cuStat[t][3][0].load(), (unsigned long long)g_cuStat[t][3][1].load(), (unsigned long long)g_cuStat[t][3][2].load(), (unsigned long long)g_cuStat[t][3][3].load());
         fprintf(stderr, "x265amd: analysis stages (ms):");
         for (int k = 0; k < 5; k++) { fprintf(stderr, " %s %.1f", g_stageName[k], g_stageMs[k]); g_stageMs[k] = 0; }
         fprintf(stderr, "\n");

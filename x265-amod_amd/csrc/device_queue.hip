@@ -36,6 +36,8 @@ __shared__ int xa_nxn_kind;
 #include "measure_dev.h"
 #include "entropy_dev.h"
 #include "intra_pu_dev.h"
+#define XA_CHAIN_DEVICE
+#include "inter_chain_dev.h"
 #include <immintrin.h>
 #include <signal.h>
 #include <atomic>
@@ -340,6 +342,12 @@ __device__ __noinline__ void xa_op_intra_nxn(const XaCmd& c, int tid)
         block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(a.a + (uint64_t)i * a.c), reinterpret_cast<x265amd_intra_nxn_out*>(a.b), xa_smem, tid, 64 * XA_SERVER_WAVES);
 }
 
+__device__ __noinline__ void xa_op_inter_chain(const XaCmd& c, int tid)
+{
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    block_inter_chain(reinterpret_cast<const XaChainJob*>(a.a), xa_smem, tid);
+}
+
 /* the groups of a launch one after the other: each stages its window, its jobs go to the wavefronts */
 template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int tid)
 {
@@ -413,6 +421,9 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
         break;
     case XA_OP_INTRA_NXN:
         xa_op_intra_nxn(c, tid);
+        break;
+    case XA_OP_INTER_CHAIN:
+        xa_op_inter_chain(c, tid);
         break;
     case XA_OP_ME_SEARCH: xa_op_me<0>(c, tid); break;
     case XA_OP_ME_SEARCH_STAR: xa_op_me<1>(c, tid); break;
@@ -564,7 +575,8 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         if (tid == 0)
         {
             const long long te = wall_clock64();
-            s_prof[2 * (s_cmd.op & 31)] += 1; s_prof[2 * (s_cmd.op & 31) + 1] += (unsigned long long)(te - td);
+            const int pslot = s_cmd.op == XA_OP_INTER_CHAIN ? XA_OP_EXIT : (int)(s_cmd.op & 31);      /* 20 command kinds fill [0..39]; the exit command is never counted: its pair serves the chain */
+            s_prof[2 * pslot] += 1; s_prof[2 * pslot + 1] += (unsigned long long)(te - td);
             s_bytes[s_cmd.op & 31] += xa_bytes_acc; xa_bytes_acc = 0;          /* behind the barrier: every lane's contribution is in */
             if (s_cmd.reserved & 16)        /* X265AMD_QUEUE_DEBUG & 16: single-job commands of the three hot kinds by block size */
             {
@@ -740,10 +752,12 @@ struct Server
     void profile_report(bool final)
     {
         static const char* const names[XA_OP_COUNT] = { "nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain",
-                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn" };
-        uint64_t tot[64] = { 0 };
+                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn", "inter_chain" };
+        uint64_t tot[64] = { 0 }, stage[24] = { 0 };
         for (int i = 0; i < numQueues; i++) for (int k = 0; k < 64; k++) tot[k] += hosts[i].prof[k];
+        for (int k = 0; k < 22; k++) stage[k] = tot[40 + k];
         uint64_t cmds = 0, ticks = 0;
+        tot[2 * XA_OP_INTER_CHAIN] = tot[2 * XA_OP_EXIT]; tot[2 * XA_OP_INTER_CHAIN + 1] = tot[2 * XA_OP_EXIT + 1]; tot[2 * XA_OP_EXIT] = tot[2 * XA_OP_EXIT + 1] = 0;     /* the chain is counted in the exit command's pair */
         for (int op = 0; op < XA_OP_COUNT; op++) { cmds += tot[2 * op]; ticks += tot[2 * op + 1]; }
         if (!final && cmds < lastReported + 2000000) return;
         lastReported = cmds;
@@ -754,10 +768,10 @@ struct Server
         for (int op = 0; op < XA_OP_COUNT; op++)
             if (tot[2 * op]) fprintf(stderr, "  %-20s %9llu x %7.2f us = %8.1f ms\n", names[op], (unsigned long long)tot[2 * op], tot[2 * op + 1] / 100.0 / tot[2 * op], tot[2 * op + 1] / 1e5);
         fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
-                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", tot[40] / 1e5, tot[41] / 1e5, tot[42] / 1e5, tot[43] / 1e5, tot[44] / 1e5,
-                tot[45] / 1e5, tot[46] / 1e5, tot[47] / 1e5, tot[48] / 1e5, tot[49] / 1e5, tot[50] / 1e5, tot[51] / 1e5, tot[52] / 1e5, tot[53] / 1e5, tot[54] / 1e5, tot[55] / 1e5);
+                "levels out + sse %.1f, psy %.1f, inverse %.1f, reconstruction %.1f, sse + psy %.1f, result %.1f, pu record / select %.1f, pu scan %.1f, elsewhere %.1f\n", stage[0] / 1e5, stage[1] / 1e5, stage[2] / 1e5, stage[3] / 1e5, stage[4] / 1e5,
+                stage[5] / 1e5, stage[6] / 1e5, stage[7] / 1e5, stage[8] / 1e5, stage[9] / 1e5, stage[10] / 1e5, stage[11] / 1e5, stage[12] / 1e5, stage[13] / 1e5, stage[14] / 1e5, stage[15] / 1e5);
         fprintf(stderr, "  stages of the NxN step (ms): record + predictors %.1f, scan %.1f, candidate list %.1f, chains %.1f, bits %.1f, choice + blocks + measurements + chroma %.1f\n",
-                tot[56] / 1e5, tot[57] / 1e5, tot[58] / 1e5, tot[59] / 1e5, tot[60] / 1e5, tot[61] / 1e5);
+                stage[16] / 1e5, stage[17] / 1e5, stage[18] / 1e5, stage[19] / 1e5, stage[20] / 1e5, stage[21] / 1e5);
         {
             uint64_t nx[40] = { 0 };
             for (int i = 0; i < numQueues; i++) for (int k = 0; k < 40; k++) nx[k] += hosts[i].nxn[k];
@@ -1203,7 +1217,8 @@ extern "C" int x265amd_queue_stats(uint64_t* out, int n, int reset)
         const XaRingHost& h = S.hosts[i];
         for (int k = 0; k < 32; k++)
         {
-            const uint64_t cnt = k < 31 ? h.prof[2 * k] : 0, tk = k < 31 ? h.prof[2 * k + 1] : 0;
+            const int ps = k == XA_OP_INTER_CHAIN ? XA_OP_EXIT : k;         /* the chain is counted in the exit command's pair (the server loop) */
+            const uint64_t cnt = k < 31 && k != XA_OP_EXIT ? h.prof[2 * ps] : 0, tk = k < 31 && k != XA_OP_EXIT ? h.prof[2 * ps + 1] : 0;
             if (k < XA_OP_COUNT) { out[0] += cnt; out[1] += tk; }
             out[4] += h.bytes[k];
             if (10 + 3 * k + 2 < n && k < XA_OP_COUNT) { out[10 + 3 * k] += cnt; out[11 + 3 * k] += tk; out[12 + 3 * k] += h.bytes[k]; }

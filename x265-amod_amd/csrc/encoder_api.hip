@@ -87,8 +87,16 @@ struct Pic
     uint64_t wpSum[3] = { 0, 0, 0 }, wpSsd[3] = { 0, 0, 0 };      /* Lowres::wp_sum / wp_ssd (bEnableWeightedPred) */
     int lumaDenom = 7, chromaDenom = 7;                    /* the slice's pred_weight_table denominators (weightAnalyse) */
     bool bScenecut = false, bKeyframe = false;
+    const x265amd_mv_unit* regMotion = nullptr;        /* the motion field's mirror in device memory (x265amd_host.h: xa_devmap_*): what the skip chain of this and later pictures reads */
+    void registerMotion()
+    {
+        if (regMotion == motion.data()) return;
+        if (regMotion) xa_devmap_unregister(regMotion);
+        regMotion = motion.data();
+        if (!xa_devmap_register(regMotion, motion.size())) regMotion = nullptr;
+    }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
-    ~Pic() { xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
+    ~Pic() { if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x) { std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x; }
     int published(int row) const { const int v = (int)*finalX[row]; std::atomic_thread_fence(std::memory_order_acquire); return v; }
     void fail()         /* whoever waits for this picture is released */
@@ -446,6 +454,7 @@ extern "C" int x265amd_encoder_import_row(x265amd_encoder* e, const x265amd_row_
     }
     memcpy((uint8_t*)pic->units.data() + in->map_offset_units, in->units, in->units_bytes);
     memcpy((uint8_t*)pic->motion.data() + in->map_offset_motion, in->motion, in->motion_bytes);
+    xa_devmap_push_rows(pic->motion.data(), pic->units.data(), e->w4, in->ctu_row * 16, std::min(e->h4, (in->ctu_row + 1) * 16));      /* the field's mirror in device memory */
     pic->publish(in->ctu_row, e->W);
     { std::lock_guard<std::mutex> lk(pic->mu); pic->importedRows++; }
     pic->cv.notify_all();
@@ -1363,6 +1372,7 @@ int x265amd_encoder::prepare(const PicP& picp)
         const size_t nUnits = (size_t)w4 * h4;
         pic.units.assign(nUnits, x265amd_cu_unit()); pic.motion.assign(nUnits, x265amd_mv_unit());
         memset(pic.units.data(), 0, sizeof(x265amd_cu_unit) * nUnits); memset(pic.motion.data(), 0, sizeof(x265amd_mv_unit) * nUnits);
+        pic.registerMotion();
         memset(pic.refPoc, 0, sizeof(pic.refPoc));
         for (int l = 0; l < 2; l++)
             for (size_t r = 0; r < pic.lists[l].size(); r++) pic.refPoc[l][r] = pic.lists[l][r]->poc;
@@ -1648,6 +1658,12 @@ static int gateRefWait(void* ctx, int picIdx, int yMin, int yMax, int xMax)
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return 0;
+}
+/* what gateCtuWait(row, col) has waited for (XaRowHooks::ctu_reach) */
+static void gateCtuReach(void* ctx, int row, int col, int* r0, int* r1, int* need)
+{
+    const x265amd_encoder& e = *((RowGate*)ctx)->e;
+    *need = gateNeed(e, col); *r0 = std::max(0, row - 2); *r1 = std::min(e.ctuH - 1, row + 1);
 }
 static void gateBeforeRow(void*, int) {}
 static void gateBeforeCtu(void* ctx, int row, int col)
@@ -1984,7 +2000,7 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     static const bool colsOff = getenv("X265AMD_FILTER_COLS") && atoi(getenv("X265AMD_FILTER_COLS")) == 0;
     const bool byCols = !colsOff && p.bEnableWavefront && (p.bEnableLoopFilter || p.bEnableSAO) && ctuH > 1 && ctuW > 1;
     std::thread filters([&, byCols] { xa_thread_device(); filterRc = byCols ? filterRowsCols(pic, fc.si, fc.info, sparams, saoFlags) : filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) pic.fail(); });
-    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, pic.codingOrder + 1 };
+    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, pic.codingOrder + 1, gateCtuReach };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
                                sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);

@@ -1069,9 +1069,10 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (kind == 3)
     {
         int started = 0;
-        /* off unless asked for (X265AMD_AHEAD_INTER=1): measured on the bench clip, what the try hides (40 us of device time per CU that gets to it) is eaten by what
-         * starting it costs every unskipped CU (a synchronisation of the row's queue, the job, a queue and its buffers per CTU): last rows 1-4 % SLOWER */
-        static const bool aheadInter = getenv("X265AMD_AHEAD_INTER") && atoi(getenv("X265AMD_AHEAD_INTER")) != 0;
+        /* on unless switched off (X265AMD_AHEAD_INTER=0).  Round 3 measured it 1-4 % slower (what the try hides, 40 us of device time per CU that gets to it, was eaten by
+         * what starting it costs every unskipped CU); since round 4 the CUs that end as skips never get here -- the device's skip chain ends them (inter_chain_dev.h) -- and
+         * a CU that does is searched, predicted and coded while its intra try runs beside: 35.8 -> 40.9 frames/s on the bench clip */
+        static const bool aheadInter = !(getenv("X265AMD_AHEAD_INTER") && atoi(getenv("X265AMD_AHEAD_INTER")) == 0);
         IntraRd::Big& g = R.inter[R.log2 >= 3 && R.log2 <= 5 ? 5 - R.log2 : 0];
         if (aheadInter && R.log2 >= 3 && R.log2 <= 5 && R.devIntraInInter() && xa_is_queue(R.st))
         {

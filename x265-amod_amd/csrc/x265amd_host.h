@@ -104,7 +104,17 @@ struct XaRowHooks
     /* the picture's place in coding order + 1 (0: take the order of the calls): its rows' priority among the row tasks of all pictures in flight -- a picture
      * started ahead of its turn (an I picture: nothing to wait for) must not push aside the rows of the pictures everybody else waits for */
     uint64_t order;
+    /* optional: what ctu_wait(ctx, row, col) has waited for -- the CTU rows *r0 .. *r1 of every reference picture final up to luma column *need (the picture
+     * width: to the end, margin included).  The skip chain checks its vectors against it on the device (inter_chain_dev.h); NULL: nothing is known, every
+     * vector goes through ref_wait on the host */
+    void (*ctu_reach)(void* ctx, int row, int col, int* r0, int* r1, int* need);
 };
+/* device-resident mirrors of motion fields (csrc/ctu_analysis.hip; inter_chain_dev.h): one per host field, written by the host through the BAR as CUs are decided
+ * and by the device's skip chain; NULL when device job queues are off */
+void* xa_devmap_register(const x265amd_mv_unit* host, size_t units);
+void xa_devmap_unregister(const x265amd_mv_unit* host);
+void* xa_devmap_find(const x265amd_mv_unit* host);
+void xa_devmap_push_rows(const x265amd_mv_unit* host, const x265amd_cu_unit* units, int w4, int y4a, int y4b);
 /* the guards (csrc/ctu_analysis.hip): wait until the row task's hooks (if it has any) let the jobs' reference samples be read; 0, or -1 when a picture failed */
 int xa_ref_guard_mc(const x265amd_mc_job* jobs, int n);
 int xa_ref_guard_me(const x265amd_me_job* jobs, const int* pics, int n);

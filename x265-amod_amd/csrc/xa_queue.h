@@ -17,7 +17,7 @@
 enum XaOp
 {
     XA_OP_NOP = 0, XA_OP_EXIT, XA_OP_COPY, XA_OP_COPY2D, XA_OP_FILL, XA_OP_COPY_RECTS, XA_OP_MC, XA_OP_MC_COST, XA_OP_CU_MEASURE, XA_OP_TU_CHAIN, XA_OP_TU_CHAIN_RDOQ,
-    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_INTRA_PU, XA_OP_INTRA_NXN, XA_OP_COUNT
+    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_INTRA_PU, XA_OP_INTRA_NXN, XA_OP_INTER_CHAIN, XA_OP_COUNT
 };
 enum
 {
