@@ -12,9 +12,12 @@ Timed region: W warm-up frames are encoded (untimed, their own encoder object), 
 x265amd_encoder_encode of the K-frame clip to the last flushed NAL unit.  The boundary takes host pictures (as x265_picture does): each input frame
 is uploaded inside the timed region (3.1 MB, about 60 us over PCIe against > 100 ms of analysis).
 
-Multi-GPU (one process per GPU, torch.distributed nccl == RCCL): the path shards by closed GOP -- pictures between two IDR frames depend on nothing
-outside -- so rank r encodes GOP r of the clip (keyint K, x265amd_param.firstFrame = r K) with no data-path collective; the coded GOPs' sizes and
-digests are gathered for the report.  Per-GPU work is fixed: weak scaling.
+Multi-GPU (one process per GPU, torch.distributed nccl == RCCL), two ways:
+  default         rank r encodes closed GOP r of the clip (keyint K, x265amd_param.firstFrame = r K), no data-path collective, the coded GOPs' sizes and digests
+                  are gathered for the report; per-GPU work is fixed: "scaling": "weak";
+  --shard frames  SURVEY section 8e as written: ONE clip, picture k in coding order coded by rank k mod N, every finished CTU row published to the other ranks
+                  (x265amd_encoder_export_row / _import_row, pump: x265-amod_amd/frame_rows.py, ncclBroadcast); total work is fixed: "scaling": "strong".
+The GOP structure is the lookahead's (--b-adapt 2, B pyramid, open GOPs, scene-cut detection: the preset as it comes), not fixed mini-GOPs.
 
 The kernels of the hot path are timed on their own in bench_kernels.py (a frame's worth of motion searches, intra scans, transform chains, merge
 costs, coefficient codings and filters as batches): its figures ride along as `kernel_workload`.  The `roofline` object prices the kernel the timed
@@ -80,7 +83,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
     if keyint:
         prm.keyframeMax = keyint
     if shard:
-        prm.shardRank, prm.shardCount = shard
+        prm.shardRank, prm.shardCount = shard[0], shard[1]
     enc = lib.x265amd_encoder_open(C.byref(prm))
     if not enc:
         raise SystemExit("x265amd_encoder_open: %s" % lib.x265amd_last_error().decode())
@@ -113,7 +116,9 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
                 try:
                     torch.cuda.set_device(dev)
                     rows = fr.EncoderRows(lib, enc, dev)
-                    fr.pump(rows.export_row, rows.import_row, rows.shapes, len(pics), rows.rows, dev, rank=shard[0], world=shard[1])
+                    # one publication stream per owner, pictures nobody references stay home, a row travels as one packed buffer (frame_rows.py)
+                    fr.pump(rows.export_row, rows.import_row, rows.shapes, len(pics), rows.rows, dev, rank=shard[0], world=shard[1], referenced=rows.referenced,
+                            groups=shard[2] if len(shard) > 2 else None)
                 except BaseException as exc:        # noqa: B902
                     pump_err.append(repr(exc))
             pump_thread = threading.Thread(target=run_pump)
@@ -168,7 +173,7 @@ def queue_stats(L, reset):
 
 
 XA_OPS = ["nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain", "intra_tu_chain_rdoq", "intra_scan",
-          "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn"]
+          "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn", "inter_chain", "inter_search"]
 
 
 def job_server_roofline(st, frames_payload_bytes, wall_s):
@@ -287,7 +292,14 @@ def main():
         encode(T, L, bench_clip(0, Wm), 0, 0, sync, timed=False)
     queue_stats(L, True)                 # the counters of the resident kernel from here on: the timed encode alone
     if by_frames:
-        stream, dt = encode(T, L, frames, 0, 0, sync, shard=(rank, world))
+        groups = None
+        if world > 1:
+            # a communicator per source rank (one publication stream per owner: frame_rows.py), brought up before the timed region
+            groups = [dist.new_group(ranks=list(range(world))) for _ in range(world)]
+            for s_, g_ in enumerate(groups):
+                dist.broadcast(torch.zeros(1, dtype=torch.uint8, device="cuda"), src=s_, group=g_)
+            torch.cuda.synchronize()
+        stream, dt = encode(T, L, frames, 0, 0, sync, shard=(rank, world, groups))
     else:
         stream, dt = encode(T, L, frames, rank * K, K if world > 1 else 0, sync)
     qstats = queue_stats(L, True)
@@ -323,7 +335,7 @@ def main():
         line = {
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
             "value": (K if by_frames else world * K) / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,
-            "higher_is_better": True, "scaling": "strong" if by_frames and world > 1 else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if by_frames else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + mini-GOPs of up to %d B frames chosen by the lookahead's trellis, --b-adapt 2), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
                                    "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "

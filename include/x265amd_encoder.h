@@ -145,6 +145,10 @@ int x265amd_encoder_row_geometry(const x265amd_encoder* enc, int ctu_row, x265am
 /* the number of CTU rows of a picture, and whether this object codes picture `coding_index` */
 int x265amd_encoder_ctu_rows(const x265amd_encoder* enc);
 int x265amd_encoder_owns(const x265amd_encoder* enc, uint64_t coding_index);
+/* whether pictures coded later may reference picture `coding_index` (DPB::prepareEncode: every picture but a plain B picture; reference: source/encoder/dpb.cpp:101-140):
+ * 1 yes, 0 no -- its rows need not travel and an object that does not code it does not wait for them --, 2 not known yet (not handed over by the lookahead: ask again),
+ * -1 on error.  The same answer on every object of a set. */
+int x265amd_encoder_is_referenced(x265amd_encoder* enc, uint64_t coding_index);
 
 #ifdef __cplusplus
 }

@@ -75,10 +75,10 @@ int main(int argc, char** argv)
         api->picture_init(p, pic);
         pic->planes[0] = buf.data(); pic->planes[1] = buf.data() + ysz; pic->planes[2] = buf.data() + ysz + csz;
         pic->stride[0] = (int)(w * isz); pic->stride[1] = pic->stride[2] = (int)(w / 2 * isz);
-        pic->bitDepth = depth; pic->pts = frames++;
+        pic->bitDepth = depth; pic->pts = 1000 + 40 * (int64_t)frames; frames++;
         const int r = api->encoder_encode(enc, &nal, &nnal, pic, rec);
         if (r < 0) { fprintf(stderr, "encode\n"); return 3; }
-        if (r) { coded++; for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); }
+        if (r) { coded++; printf("pic %d pts %lld dts %lld\n", rec->poc, (long long)rec->pts, (long long)rec->dts); for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); }
     }
     for (;;)
     {
@@ -86,6 +86,7 @@ int main(int argc, char** argv)
         if (r < 0) { fprintf(stderr, "flush\n"); return 3; }
         if (!r) break;
         coded++;
+        printf("pic %d pts %lld dts %lld\n", rec->poc, (long long)rec->pts, (long long)rec->dts);        /* what a muxing client reads: time stamps behind the B-frame reordering */
         for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, out);
     }
     fclose(out);

@@ -3159,12 +3159,28 @@ def encoder_run_sharded(L, planes_per_frame, width, height, count, **overrides):
         except BaseException as exc:        # noqa: B902
             errors.append(("feeder %d" % r, repr(exc)))
 
-    def pump():
+    lib.x265amd_encoder_is_referenced.argtypes = [C.c_void_p, C.c_uint64]
+    referenced = {}
+    flight = {"now": set(), "most": 0}
+    lock = threading.Lock()
+
+    def pump(src):
+        """the publication stream of object `src` (x265-amod_amd/frame_rows.py: one stream per owner): its pictures in coding order, rows top to bottom; pictures that
+        are no references stay where they are"""
         try:
             import time
             rows = lib.x265amd_encoder_ctu_rows(encs[0])
-            for k in range(n):
-                src = k % count
+            for k in range(src, n, count):
+                while True:
+                    rc = lib.x265amd_encoder_is_referenced(encs[src], k)
+                    assert rc >= 0, lib.x265amd_last_error()
+                    if rc != 2 or errors:
+                        break
+                    time.sleep(0.0005)
+                with lock:
+                    referenced[k] = rc == 1
+                if rc != 1:
+                    continue
                 for row in range(rows):
                     d = RowExport()
                     while True:
@@ -3173,6 +3189,9 @@ def encoder_run_sharded(L, planes_per_frame, width, height, count, **overrides):
                         if rc == 0 or errors:
                             break
                         time.sleep(0.0005)
+                    if row == 0:
+                        with lock:
+                            flight["now"].add(k); flight["most"] = max(flight["most"], len(flight["now"]))
                     for r in range(count):
                         while r != src and not errors:
                             rc = lib.x265amd_encoder_import_row(encs[r], C.byref(d))
@@ -3182,10 +3201,12 @@ def encoder_run_sharded(L, planes_per_frame, width, height, count, **overrides):
                             time.sleep(0.0005)
                     if errors:
                         return
+                with lock:
+                    flight["now"].discard(k)
         except BaseException as exc:        # noqa: B902
-            errors.append(("pump", repr(exc)))
+            errors.append(("pump %d" % src, repr(exc)))
 
-    threads = [threading.Thread(target=feeder, args=(r,)) for r in range(count)] + [threading.Thread(target=pump)]
+    threads = [threading.Thread(target=feeder, args=(r,)) for r in range(count)] + [threading.Thread(target=pump, args=(r,)) for r in range(count)]
     try:
         for t in threads:
             t.start()
@@ -3207,7 +3228,10 @@ def encoder_run_sharded(L, planes_per_frame, width, height, count, **overrides):
         for r in range(count):
             if r != k % count:
                 assert outputs[r][k][0] == b"", "an object emitted NAL units for a picture it does not code"
-                assert outputs[r][k][1][:3] == rec[:3] and all(np.array_equal(a, b) for a, b in zip(outputs[r][k][1][3], rec[3])), "the imported picture differs from the owner's"
+                assert outputs[r][k][1][:3] == rec[:3], "the picture's order / type / QP differs from the owner's"
+                if referenced.get(k):       # a picture nobody references does not travel
+                    assert all(np.array_equal(a, b) for a, b in zip(outputs[r][k][1][3], rec[3])), "the imported picture differs from the owner's"
+    encoder_run_sharded.most_in_flight = flight["most"]      # pictures whose rows were travelling at the same time (one publication stream per owner)
     return np.frombuffer(bytes(stream), np.uint8), coded
 
 

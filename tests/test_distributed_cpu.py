@@ -101,25 +101,42 @@ def _shapes(row):
 
 
 class _FakeEncoder:
-    """holds the rows it has (its own and the imported ones); a row of picture k can only be coded when rows <= row + 1 of picture k - 1 are there"""
+    """holds the rows it has (its own and the imported ones); a row of picture k can only be coded when rows <= row + 1 of picture k - 1 are there.  The LAST row of a
+    picture is held back until row 0 of the NEXT picture -- coded by the other rank, from this picture's first rows -- has arrived: with one ordered stream of
+    (picture, row) pairs that never happens (the pump would be waiting for this very row), with a stream per owner it does"""
 
-    def __init__(self, rank, world):
-        self.rank, self.world, self.have, self.order = rank, world, {}, []
+    def __init__(self, rank, world, skipped=()):
+        import threading
+        self.rank, self.world, self.have, self.order, self.skipped = rank, world, {}, [], set(skipped)
+        self.cv = threading.Condition()
+
+    def _wait_for(self, key, what):
+        with self.cv:
+            assert self.cv.wait_for(lambda: key in self.have, timeout=60), what
 
     def export_row(self, k, row):
         assert k % self.world == self.rank
-        if k:
+        ref = k - 1
+        while ref in self.skipped:          # a picture that does not travel is nobody's reference
+            ref -= 1
+        if ref >= 0 and k not in self.skipped:
             for r in range(min(row + 2, ROWS)):
-                assert (k - 1, r) in self.have, "row %d of picture %d coded before row %d of its reference arrived" % (row, k, r)
+                self._wait_for((ref, r), "row %d of picture %d never arrived (needed by row %d of picture %d)" % (r, ref, row, k))
+        if row == ROWS - 1 and k + 1 < PICS and k + 1 not in self.skipped and self.world > 1:
+            self._wait_for((k + 1, 0), "row 0 of picture %d did not travel before the last row of picture %d" % (k + 1, k))
         t = [_row_bytes(k, row, i, n) for i, n in enumerate(_shapes(row))]
-        self.have[(k, row)] = [x.clone() for x in t]
-        self.order.append((k, row, "export"))
+        with self.cv:
+            self.have[(k, row)] = [x.clone() for x in t]
+            self.order.append((k, row, "export"))
+            self.cv.notify_all()
         return t
 
     def import_row(self, k, row, tensors):
         assert k % self.world != self.rank and (k, row) not in self.have
-        self.have[(k, row)] = [x.clone() for x in tensors]
-        self.order.append((k, row, "import"))
+        with self.cv:
+            self.have[(k, row)] = [x.clone() for x in tensors]
+            self.order.append((k, row, "import"))
+            self.cv.notify_all()
 
 
 def _rows_worker(rank, world, port, out):
@@ -128,13 +145,21 @@ def _rows_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import __graft_entry__ as g
     fr = g.load_package().frame_rows
-    enc = _FakeEncoder(rank, world)
-    fr.pump(enc.export_row, enc.import_row, _shapes, PICS, ROWS, "cpu")
-    ok = len(enc.have) == PICS * ROWS
+    skipped = {3}                           # a picture nobody references: its rows stay with its owner
+    enc = _FakeEncoder(rank, world, skipped)
+    fr.pump(enc.export_row, enc.import_row, _shapes, PICS, ROWS, "cpu", referenced=lambda k: k not in skipped)
+    sent = [k for k in range(PICS) if k not in skipped]
+    ok = set(enc.have) == {(k, r) for k in sent for r in range(ROWS)}
     for (k, row), t in enc.have.items():
         ok &= all(torch.equal(a, _row_bytes(k, row, i, n)) for i, (a, n) in enumerate(zip(t, _shapes(row))))
-    # every rank saw the rows in coding order, top row first, and took part in every one of them
-    ok &= [(k, r) for k, r, _ in enc.order] == [(k, r) for k in range(PICS) for r in range(ROWS)]
+    # per owner the rows arrive in coding order, top row first; between owners they interleave: row 0 of picture k + 1 is there before the last row of picture k
+    for s in range(world):
+        mine = [(k, r) for k, r, _ in enc.order if fr.owner_of(k, world) == s]
+        ok &= mine == [(k, r) for k in sent if fr.owner_of(k, world) == s for r in range(ROWS)]
+    pos = {(k, r): i for i, (k, r, _) in enumerate(enc.order)}
+    for k in sent:
+        if k + 1 in sent:
+            ok &= pos[(k + 1, 0)] < pos[(k, ROWS - 1)]
     ok &= all((what == "export") == (fr.owner_of(k, world) == rank) for k, r, what in enc.order)
     dist.barrier()
     out[rank] = bool(ok)
@@ -159,3 +184,4 @@ def test_row_publication_single_rank_is_a_no_op():
     enc = _FakeEncoder(0, 1)
     fr.pump(enc.export_row, enc.import_row, _shapes, 3, ROWS, "cpu", rank=0, world=1)
     assert len(enc.have) == 3 * ROWS and all(w == "export" for _, _, w in enc.order)
+    assert [(k, r) for k, r, _ in enc.order] == [(k, r) for k in range(3) for r in range(ROWS)]

@@ -145,3 +145,10 @@ def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.fromfile(tmp_path / "out.hevc", np.uint8)
     assert len(got) == len(want) and hashlib.md5(got.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
+    # pic_out's time stamps (pts of the picture, dts behind the B-frame reordering): what the reference library itself hands the same client
+    reflib = os.path.join(T.REF_DIR, "libx265_ref%d.so" % depth)
+    assert os.path.exists(reflib), "oracle/_ref/libx265_ref%d.so is not built" % depth
+    rr = subprocess.run([driver, reflib, str(tmp_path / "clip.y4m"), str(tmp_path / "ref.hevc")] + cli + extra, capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stderr[-2000:]
+    ours, theirs = [l for l in r.stdout.splitlines() if l.startswith("pic ")], [l for l in rr.stdout.splitlines() if l.startswith("pic ")]
+    assert ours and ours == theirs, (ours[:6], theirs[:6])

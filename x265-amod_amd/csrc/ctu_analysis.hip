@@ -23,6 +23,7 @@
 #include "xa_queue.h"
 #include "../host/cabac_coder.h"
 #include "inter_chain_dev.h"
+#include "inter_search_dev.h"
 #include <string.h>
 #include <vector>
 
@@ -232,7 +233,10 @@ struct Analyzer
         int frNode[4]; bool frDirty[4];                 /* the host's recursion: node and "something below it was decided on the host" per depth */
         bool lastDevComplete = false;                   /* of the compress() call that has just returned: everything in its area is the device's */
         uint64_t runs = 0, skipped = 0;
+        XaMapped mSearch, mLuma; XaMappedOut mSearchOut; DevBuf dSearchScratch;     /* the fused search command (inter_search_dev.h) */
+        bool lumaPushed = false;
     } chain;
+    bool fusedRd[4] = { false, false, false, false };      /* per depth: the 2Nx2N mode's rate-distortion came with its search (checkInterFused) */
     int buildNodes(int x, int y, int depth, int parent)
     {
         const int idx = chain.numNodes++;
@@ -336,7 +340,8 @@ struct Analyzer
     {
         taken = false;
         static const bool on = !(getenv("X265AMD_CHAIN_MERGE") && atoi(getenv("X265AMD_CHAIN_MERGE")) == 0);
-        if (!on || chain.status[node] != 2 || chain.stopNode != node || chain.stop.valid != 1 || chain.stop.node != (uint32_t)node) return 0;
+        /* (rd 2 reads the source block's mean and deviation from the merge check's measurement -- complexityCheckCU -- which the device's record does not carry) */
+        if (!on || A->rd_level < 3 || chain.status[node] != 2 || chain.stopNode != node || chain.stop.valid != 1 || chain.stop.node != (uint32_t)node) return 0;
         XA_HOSTPROF("an.chainMerge");
         const XaChainStop& c = chain.stop;
         ModeDepth& d = md[depth];
@@ -842,6 +847,147 @@ struct Analyzer
         const int keep = predTile(depth, d.best == tempPred ? PRED_MERGE : PRED_SKIP);
         copyTile(keep, tiles[bestSadCand], 0, 0, size);
         d.best->predTile = keep;
+        return 0;
+    }
+
+    /* checkInter_rd0_4(2Nx2N) of a CU of a P picture as ONE device command: the predictors' costs, the searches in every allowed reference picture, the choice, the
+     * prediction with its SA8D and (rd 3+, one transform unit per plane) encodeResAndCalcRdInterCU -- inter_search_dev.h.  The host derives what depends on the maps (the
+     * AMVP candidates, the search's extra candidates) and waits once.  false in `used`: not this configuration, the ordinary path runs */
+    int checkInterFused(int x, int y, int depth, uint32_t refMask, bool& used)
+    {
+        used = false;
+        static const bool on = !(getenv("X265AMD_FUSED_SEARCH") && atoi(getenv("X265AMD_FUSED_SEARCH")) == 0);
+        const int log2 = 6 - depth, size = 1 << log2;
+        const int method = S->search_method & 0x7f;
+        if (!on || I->is_inter_b || !xa_is_queue(st) || S->subpel_refine > 2 || (method != X265AMD_ME_DIA && method != X265AMD_ME_HEX && method != X265AMD_ME_STAR) ||
+            I->num_ref_idx[0] < 1 || I->num_ref_idx[0] > XA_SEARCH_MAX_REFS || rp.rdoq_level || si->tu_max_depth_inter != 1 || si->use_dqp || A->rd_level < 3 || log2 > 5)
+            return 0;
+        XA_HOSTPROF("an.checkInterFused (all)");
+        StageTimer timer_(1);
+        ModeDepth& d = md[depth];
+        Mode& inter = d.pred[PRED_2Nx2N];
+        inter.initCosts();
+        inter.predTile = predTile(depth, PRED_2Nx2N); inter.reconTile = reconTile(depth, PRED_2Nx2N);
+        const size_t isz = sizeof(pixel);
+        if (!chain.mSearch.p && (chain.mSearch.alloc(sizeof(XaSearchJob)) != hipSuccess || chain.mLuma.alloc((size_t)numPics * 8) != hipSuccess ||
+                                 chain.mSearchOut.alloc(sizeof(XaSearchOut)) != hipSuccess ||
+                                 chain.dSearchScratch.alloc(8192 + (size_t)2 * XA_SEARCH_MAX_REFS * 4096 * isz + 1536 * (4 + isz) + 256) != hipSuccess))
+            return fail("search records");
+        if (!chain.lumaPushed)
+        {
+            volatile uint64_t* t = (volatile uint64_t*)chain.mLuma.p;
+            for (int i = 0; i < numPics; i++) t[i] = planes[3 * i];
+            chain.lumaPushed = true;
+        }
+        XaSearchJob J;
+        memset(&J, 0, sizeof(J));
+        const int lagPixels = S->frame_parallel ? S->search_range : I->pic_height;
+        x265amd_me_job guardJobs[2 * XA_SEARCH_MAX_REFS]; int guardPics[2 * XA_SEARCH_MAX_REFS]; int ng = 0;
+        for (int ref = 0; ref < I->num_ref_idx[0]; ref++)
+        {
+            const uint32_t m = refMask ? refMask : 0xFFFFFFFFu;
+            if (!((m >> ref) & 1u)) continue;
+            XaSearchRef& R = J.ref[J.num_refs++];
+            int16_t mvc[12][2];
+            R.num_mvc = x265amd_amvp_candidates(I, cur, col, x, y, log2, 0, 0, 0, ref, R.amvp, mvc);
+            if (S->lowres_mvs[0][ref])
+            {
+                /* getLowresMV: the lookahead's vector of the 16x16 block under the PU's centre, scaled up */
+                const int16_t (*lm)[2] = reinterpret_cast<const int16_t (*)[2]>((uintptr_t)S->lowres_mvs[0][ref]);
+                const size_t idx = (size_t)((y + size / 2) >> 4) * S->lowres_blocks_in_row + ((x + size / 2) >> 4);
+                const int16_t lx = (int16_t)(lm[idx][0] * 2), ly = (int16_t)(lm[idx][1] * 2);
+                if (lx || ly) { mvc[R.num_mvc][0] = lx; mvc[R.num_mvc][1] = ly; R.num_mvc++; }
+            }
+            memcpy(R.mvc, mvc, sizeof(R.mvc));
+            R.ref_pic = S->ref_pic[0][ref]; R.ref_idx = ref;
+            /* what the searches may read of this reference picture, whichever predictor wins: wait for it (xa_ref_guard_me) */
+            for (int k = 0; k < 2; k++)
+            {
+                Mv mn, mx;
+                search_range(Mv{ R.amvp[k][0], R.amvp[k][1] }, S->search_range, x, y, I->pic_width, I->pic_height, lagPixels, mn, mx);
+                x265amd_me_job& g = guardJobs[ng];
+                memset(&g, 0, sizeof(g));
+                g.x = (int16_t)x; g.y = (int16_t)y; g.w = (uint8_t)size; g.h = (uint8_t)size;
+                g.mvmin[0] = (int16_t)mn.x; g.mvmin[1] = (int16_t)mn.y; g.mvmax[0] = (int16_t)mx.x; g.mvmax[1] = (int16_t)mx.y;
+                guardPics[ng++] = R.ref_pic;
+            }
+        }
+        if (!J.num_refs) return 0;
+        if (xa_ref_guard_me(guardJobs, guardPics, ng)) return fail("a reference picture failed");
+        J.x = x; J.y = y; J.log2 = log2;
+        J.pic_w = I->pic_width; J.pic_h = I->pic_height; J.stride = (int32_t)stride; J.cstride = (int32_t)cstride; J.num_pics = numPics; J.num_ref_idx0 = I->num_ref_idx[0];
+        J.search_method = S->search_method; J.subme = S->subpel_refine; J.merange = S->search_range; J.me_qp = qp; J.frame_parallel = S->frame_parallel;
+        J.search_range = S->search_range; J.lag_pixels = lagPixels; J.list_sel_bits0 = 1;
+        J.me_lambda = (uint64_t)floor(256.0 * is_lambda(qp));
+        J.mvcost = (uint64_t)(uintptr_t)xa_me_device_mvcost(me, qp); J.bitsize = (uint64_t)(uintptr_t)xa_me_device_bitsize(me); J.me_tables = (uint64_t)(uintptr_t)xa_me_device_tables(me);
+        J.planes = (uint64_t)(uintptr_t)dPlanes.p; J.luma_tab = (uint64_t)(uintptr_t)chain.mLuma.p;
+        J.pred_tile = tileAddr(inter.predTile); J.recon_tile = tileAddr(inter.reconTile); J.scratch = (uint64_t)(uintptr_t)chain.dSearchScratch.p; J.out = (uint64_t)(uintptr_t)chain.mSearchOut.p;
+        J.lambda = lambda; J.lambda2 = lambda2; J.psy_rd = psyRd;
+        {
+            static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
+                                                     32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+            const int qpQuant = qp < 0 ? 0 : (qp > 51 ? 51 : qp), bd = 6 * (X265AMD_DEPTH - 8);
+            int qpC = qpQuant < -bd ? -bd : (qpQuant > 57 ? 57 : qpQuant);
+            if (qpC >= 30) qpC = chromaScale[qpC];
+            J.qp_luma = qpQuant + bd; J.qp_chroma = qpC + bd;
+        }
+        J.sign_hide = si->sign_hide != 0; J.chroma_sa8d = A->rd_level >= 3; J.rd_level = A->rd_level; J.do_rd = 1; J.slice_type = si->slice_type;
+        {
+            const x265amd_cu_unit* l = (x >> 2) > 0 ? &units[(y >> 2) * w4 + (x >> 2) - 1] : nullptr;
+            const x265amd_cu_unit* a = (y >> 2) > 0 ? &units[((y >> 2) - 1) * w4 + (x >> 2)] : nullptr;
+            J.skip_ctx = (l && l->pred_mode == X265AMD_MODE_SKIP) + (a && a->pred_mode == X265AMD_MODE_SKIP);
+        }
+        J.frac = d.cur.frac; memcpy(J.ctx, d.cur.ctx, X265AMD_CTX_STRIDE);
+        if (!xa_me_device_bitsize(me) || !me) return 0;
+        {
+            volatile uint64_t* dd = (volatile uint64_t*)chain.mSearch.p; const uint64_t* ss = (const uint64_t*)&J;
+            for (size_t i = 0; i < sizeof(J) / 8; i++) dd[i] = ss[i];
+        }
+        XaSearchOut* o = (XaSearchOut*)chain.mSearchOut.p;
+        *(volatile uint32_t*)&o->valid = 0;
+        const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)chain.mSearch.p, 0, 0, 0, 1 };
+        xa_phase(XA_PH_ANALYZER);
+        if (xa_q_enqueue(st, XA_OP_INTER_SEARCH, &qa, sizeof(qa), 1, 0) != hipSuccess || xa_stream_sync(st) != hipSuccess) return fail("search command");
+        xa_phase(XA_PH_INTER_SEARCH);
+        if (o->valid != 1 || o->best < 0 || o->best >= J.num_refs) return fail("search result");
+        const XaSearchRef& R = J.ref[o->best];
+        int8_t refs[2] = { (int8_t)R.ref_idx, -1 };
+        int16_t mv[2][2] = { { o->mv[0], o->mv[1] }, { 0, 0 } }, mvd[2][2] = { { (int16_t)(o->mv[0] - o->mvp[0]), (int16_t)(o->mv[1] - o->mvp[1]) }, { 0, 0 } };
+        uint8_t mvpIdx[2] = { (uint8_t)o->mvp_idx, 0 };
+        setInter(inter, depth, 0, o->mvp_idx, 1, refs, mv, mvd, mvpIdx);
+        d.mvCost2Nx2N[0] = o->mv_cost; d.mvCost2Nx2N[1] = 0;
+        memset(&d.det, 0, sizeof(d.det));
+        d.det.cost[0] = o->cost; d.det.cost[1] = 0xFFFFFFFFu; d.det.ref[0] = (int8_t)R.ref_idx; d.det.ref[1] = -1;
+        inter.sa8dBits = o->bits;
+        const uint32_t sa8d = A->rd_level >= 3 ? o->sa8d : o->sa8d_luma;
+        inter.distortion = sa8d;
+        inter.sa8dCost = calcRdSADCost(sa8d, inter.sa8dBits);
+        fusedRd[depth] = false;
+        d.pred[PRED_BIDIR].initCosts(); d.pred[PRED_BIDIR].sa8dCost = kMaxCost; d.pred[PRED_BIDIR].rdCost = kMaxCost;       /* checkBidir2Nx2N in a P slice: nothing to try */
+        if (o->rd_done)
+        {
+            const int n4 = 16 >> depth;
+            for (int i = 0; i < n4 * n4; i++)
+            {
+                x265amd_cu_unit& u = inter.u[i];
+                u.depth = (uint8_t)depth; u.tu_depth = 0; u.cbf[0] = o->cbf[0]; u.cbf[1] = o->cbf[1]; u.cbf[2] = o->cbf[2]; u.pred_mode = X265AMD_MODE_INTER;
+                inter.m[i].pred_mode = X265AMD_MODE_INTER;
+            }
+            std::fill(inter.coeff.begin(), inter.coeff.end(), 0);
+            if (o->cbf[0] || o->cbf[1] || o->cbf[2])
+            {
+                memcpy(&inter.coeff[0], o->levels, sizeof(int16_t) * size * size);
+                memcpy(&inter.coeff[4096], o->levels + 1024, sizeof(int16_t) * (size >> 1) * (size >> 1));
+                memcpy(&inter.coeff[5120], o->levels + 1280, sizeof(int16_t) * (size >> 1) * (size >> 1));
+            }
+            inter.rdCost = o->rd_cost; inter.lumaDistortion = (sse_t)o->luma_dist; inter.chromaDistortion = (sse_t)o->chroma_dist; inter.distortion = (sse_t)(o->luma_dist + o->chroma_dist);
+            inter.totalBits = o->total_bits; inter.mvBits = o->mv_bits; inter.coeffBits = o->coeff_bits; inter.psyEnergy = o->psy_energy; inter.resEnergy = (sse_t)o->res_energy;
+            memset(inter.contexts.ctx, 0, X265AMD_CTX_STRIDE);
+            memcpy(inter.contexts.ctx, (const void*)o->ctx, X265AMD_CTX_COUNT);
+            inter.contexts.frac = o->frac;
+            fusedRd[depth] = true;
+        }
+        used = true;
         return 0;
     }
 
@@ -1544,7 +1690,38 @@ struct Analyzer
             if (!skipModes)
             {
                 if (g_timing) g_cuStat[si->slice_type == 1][depth][2]++;
-                if (checkInter(x, y, depth, allSplitRefs)) return err;
+                bool fused = false;
+                fusedRd[depth] = false;
+                if (!(A->rect || A->amp) && checkInterFused(x, y, depth, allSplitRefs, fused)) return err;
+                if (fused)
+                {
+                    static const bool verifyS = getenv("X265AMD_CHAIN_VERIFY") && atoi(getenv("X265AMD_CHAIN_VERIFY")) >= 2;
+                    if (verifyS)
+                    {
+                        /* debugging: the ordinary search and rate-distortion of the same CU must give the same mode */
+                        const Mode fm = d.pred[PRED_2Nx2N];
+                        if (checkInter(x, y, depth, allSplitRefs)) return err;
+                        Mode& hm = d.pred[PRED_2Nx2N];
+                        const uint64_t hs = hm.sa8dCost; const uint32_t hb = hm.sa8dBits;
+                        if (rdInter(hm, x, y, depth, false)) return err;
+                        if (memcmp(&fm.u[0], &hm.u[0], sizeof(x265amd_cu_unit)) || memcmp(&fm.m[0], &hm.m[0], sizeof(x265amd_mv_unit)) || fm.sa8dCost != hs || fm.sa8dBits != hb ||
+                            (fusedRd[depth] && (fm.rdCost != hm.rdCost || fm.totalBits != hm.totalBits || fm.mvBits != hm.mvBits || fm.coeff != hm.coeff || fm.contexts.frac != hm.contexts.frac ||
+                                                memcmp(fm.contexts.ctx, hm.contexts.ctx, X265AMD_CTX_COUNT) || fm.psyEnergy != hm.psyEnergy || fm.distortion != hm.distortion)))
+                        {
+                            fprintf(stderr, "x265amd search verify: poc %d CU (%d,%d) size %d: device ref %d mv (%d,%d) mvd (%d,%d) mvp %d sa8d cost %llu bits %u rd %llu bits %u/%u cbf %d%d%d dist %llu psy %u; "
+                                    "host ref %d mv (%d,%d) mvd (%d,%d) mvp %d sa8d cost %llu bits %u rd %llu bits %u/%u cbf %d%d%d dist %llu psy %u levels %s contexts %s\n", I->poc, x, y, size,
+                                    fm.u[0].ref_idx[0], fm.m[0].mv[0][0], fm.m[0].mv[0][1], fm.u[0].mvd[0][0], fm.u[0].mvd[0][1], fm.u[0].mvp_idx[0], (unsigned long long)fm.sa8dCost, fm.sa8dBits,
+                                    (unsigned long long)fm.rdCost, fm.totalBits, fm.mvBits, fm.u[0].cbf[0], fm.u[0].cbf[1], fm.u[0].cbf[2], (unsigned long long)fm.distortion, fm.psyEnergy,
+                                    hm.u[0].ref_idx[0], hm.m[0].mv[0][0], hm.m[0].mv[0][1], hm.u[0].mvd[0][0], hm.u[0].mvd[0][1], hm.u[0].mvp_idx[0], (unsigned long long)hs, hb,
+                                    (unsigned long long)hm.rdCost, hm.totalBits, hm.mvBits, hm.u[0].cbf[0], hm.u[0].cbf[1], hm.u[0].cbf[2], (unsigned long long)hm.distortion, hm.psyEnergy,
+                                    fm.coeff == hm.coeff ? "same" : "differ", memcmp(fm.contexts.ctx, hm.contexts.ctx, X265AMD_CTX_COUNT) ? "differ" : "same");
+                            return fail("search verify: the fused search is not the host's");
+                        }
+                        hm.sa8dCost = hs; hm.sa8dBits = hb;
+                        fusedRd[depth] = true;
+                    }
+                }
+                else if (checkInter(x, y, depth, allSplitRefs)) return err;
                 Mode* bestInter = &d.pred[PRED_2Nx2N];
                 if (A->limit_refs & 2)                                                     /* X265_REF_LIMIT_CU */
                 {
@@ -1602,7 +1779,7 @@ struct Analyzer
                 const bool bTryIntra = (!I->is_inter_b || A->b_intra) && log2 != 6;
                 if (A->rd_level >= 3)
                 {
-                    if (rdInter(*bestInter, x, y, depth, false)) return err;
+                    if (!(bestInter == &d.pred[PRED_2Nx2N] && fusedRd[depth]) && rdInter(*bestInter, x, y, depth, false)) return err;
                     checkBestMode(*bestInter, depth);
                     if (I->is_inter_b && bidir.sa8dCost != kMaxCost && bidir.sa8dCost * 16 <= bestInter->sa8dCost * 17)
                     {

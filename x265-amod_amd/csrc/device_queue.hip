@@ -38,6 +38,8 @@ __shared__ int xa_nxn_kind;
 #include "intra_pu_dev.h"
 #define XA_CHAIN_DEVICE
 #include "inter_chain_dev.h"
+#define XA_SEARCH_DEVICE
+#include "inter_search_dev.h"
 #include <immintrin.h>
 #include <signal.h>
 #include <atomic>
@@ -349,12 +351,13 @@ __device__ __noinline__ void xa_op_inter_chain(const XaCmd& c, int tid)
 }
 
 /* the groups of a launch one after the other: each stages its window, its jobs go to the wavefronts */
-template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int tid)
+/* ldsBytes: what of the workgroup's LDS the search may use (the fused search command keeps its own record at the end: inter_search_dev.h) */
+template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int tid, size_t ldsBytes = XA_SERVER_LDS)
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
     const MeParams p = *reinterpret_cast<const MeParams*>(c.args);
     const int groups = (int)c.count;
-    if (WHICH != 2 && me_multi_fits(p, groups, XA_SERVER_WAVES, XA_SERVER_LDS))
+    if (WHICH != 2 && me_multi_fits(p, groups, XA_SERVER_WAVES, ldsBytes))
     {
         /* one job per group (the searches of one prediction unit, a reference picture each): side by side, a wavefront each */
         bool single = true;
@@ -373,6 +376,22 @@ template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int ti
         else block_me_deferred(p, vb, tid, NT);
         __syncthreads();
     }
+}
+
+/* the search bodies for the fused search command (inter_search_dev.h) */
+__device__ __noinline__ void xa_op_me_call(int which, const XaCmd& c, int tid)
+{
+    /* the records the caller has just written are read with scalar loads too: that cache is coherent with nothing */
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (which == 0) xa_op_me<0>(c, tid, XA_SEARCH_LDS_BELOW);
+    else if (which == 1) xa_op_me<1>(c, tid, XA_SEARCH_LDS_BELOW);
+    else xa_op_me<2>(c, tid, XA_SEARCH_LDS_BELOW);
+}
+__device__ __noinline__ void xa_op_inter_search(const XaCmd& c, int tid)
+{
+    const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
+    block_inter_search(reinterpret_cast<const XaSearchJob*>(a.a), xa_smem, tid);
 }
 
 XA_DEV void xa_dispatch(const XaCmd& c, int tid)
@@ -425,6 +444,9 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
     case XA_OP_INTER_CHAIN:
         xa_op_inter_chain(c, tid);
         break;
+    case XA_OP_INTER_SEARCH:
+        xa_op_inter_search(c, tid);
+        break;
     case XA_OP_ME_SEARCH: xa_op_me<0>(c, tid); break;
     case XA_OP_ME_SEARCH_STAR: xa_op_me<1>(c, tid); break;
     case XA_OP_ME_DEFERRED: xa_op_me<2>(c, tid); break;
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     __shared__ XaCmd s_cmd;
     __shared__ int s_go;
     __shared__ unsigned long long s_prof[64];
+    __shared__ unsigned long long s_sized[24];
     XaRingDev* rd = rings + blockIdx.x;
     XaRingHost* rh = hosts + blockIdx.x;
     const int tid = threadIdx.x;
@@ -451,6 +474,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     __shared__ unsigned long long s_bytes[32];
     const long long tResident0 = wall_clock64();
     if (tid < 64) s_prof[tid] = 0;
+    if (tid < 24) s_sized[tid] = 0;
     if (tid < 32) s_bytes[tid] = 0;
     if (tid == 0) xa_bytes_acc = 0;
     if (tid < 22) xa_stage_acc[tid] = 0;
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         if (tid == 0)
         {
             const long long te = wall_clock64();
-            const int pslot = s_cmd.op == XA_OP_INTER_CHAIN ? XA_OP_EXIT : (int)(s_cmd.op & 31);      /* 20 command kinds fill [0..39]; the exit command is never counted: its pair serves the chain */
+            const int pslot = (int)(s_cmd.op & 31) < 31 ? (int)(s_cmd.op & 31) : 30;
             s_prof[2 * pslot] += 1; s_prof[2 * pslot + 1] += (unsigned long long)(te - td);
             s_bytes[s_cmd.op & 31] += xa_bytes_acc; xa_bytes_acc = 0;          /* behind the barrier: every lane's contribution is in */
             if (s_cmd.reserved & 16)        /* X265AMD_QUEUE_DEBUG & 16: single-job commands of the three hot kinds by block size */
@@ -586,7 +610,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                 else if (s_cmd.op == XA_OP_INTRA_PU) b = 20 + (reinterpret_cast<const x265amd_intra_pu_job*>(a.a)->tmpl.tu.log2_tr_size - 2);
                 else if (s_cmd.op == XA_OP_INTRA_TU_CHAIN) b = 24 + (reinterpret_cast<const x265amd_intra_tu_job*>(a.a)->tu.log2_tr_size - 2);
                 else if (s_cmd.op == XA_OP_CU_MEASURE && a.n == 1) b = 28 + (reinterpret_cast<const CuMeasureJob*>(a.a)->log2_size - 3);
-                if (b >= 20 && b < 31) { s_prof[2 * b] += 1; s_prof[2 * b + 1] += (unsigned long long)(te - td); }
+                if (b >= 20 && b < 31) { s_sized[2 * (b - 20)] += 1; s_sized[2 * (b - 20) + 1] += (unsigned long long)(te - td); }
             }
             if (flags & (XA_CMD_RELEASE | XA_CMD_SIGNAL))
             {
@@ -602,8 +626,9 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         if (flags & XA_CMD_SIGNAL) signalled = seen;
     }
     __syncthreads();
-    if (tid < 22) s_prof[40 + tid] = xa_stage_acc[tid];        /* [40..61]: the stages of the transform chains and the fused intra steps */
     __syncthreads();
+    if (tid >= 128 && tid < 150) xa_sys_store(&rh->stage[tid - 128], rh->stage[tid - 128] + xa_stage_acc[tid - 128]);
+    if (tid >= 160 && tid < 184) xa_sys_store(&rh->sized[tid - 160], rh->sized[tid - 160] + s_sized[tid - 160]);
     if (tid < 64) xa_sys_store(&rh->prof[tid], rh->prof[tid] + s_prof[tid]);       /* totals over the server generations (the host clears them) */
     if (tid < 32) xa_sys_store(&rh->bytes[tid], rh->bytes[tid] + s_bytes[tid]);
     if (tid >= 64 && tid < 104) xa_sys_store(&rh->nxn[tid - 64], rh->nxn[tid - 64] + (&xa_nxn_acc[0][0])[tid - 64]);
@@ -752,12 +777,11 @@ struct Server
     void profile_report(bool final)
     {
         static const char* const names[XA_OP_COUNT] = { "nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain",
-                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn", "inter_chain" };
+                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn", "inter_chain", "inter_search" };
         uint64_t tot[64] = { 0 }, stage[24] = { 0 };
         for (int i = 0; i < numQueues; i++) for (int k = 0; k < 64; k++) tot[k] += hosts[i].prof[k];
-        for (int k = 0; k < 22; k++) stage[k] = tot[40 + k];
+        for (int i = 0; i < numQueues; i++) for (int k = 0; k < 22; k++) stage[k] += hosts[i].stage[k];
         uint64_t cmds = 0, ticks = 0;
-        tot[2 * XA_OP_INTER_CHAIN] = tot[2 * XA_OP_EXIT]; tot[2 * XA_OP_INTER_CHAIN + 1] = tot[2 * XA_OP_EXIT + 1]; tot[2 * XA_OP_EXIT] = tot[2 * XA_OP_EXIT + 1] = 0;     /* the chain is counted in the exit command's pair */
         for (int op = 0; op < XA_OP_COUNT; op++) { cmds += tot[2 * op]; ticks += tot[2 * op + 1]; }
         if (!final && cmds < lastReported + 2000000) return;
         lastReported = cmds;
@@ -794,8 +818,12 @@ struct Server
         }
         static const char* const sized[11] = { "scan / pu 4", "scan / pu 8", "scan / pu 16", "scan / pu 32", "intra_tu* 4", "intra_tu* 8", "intra_tu* 16", "intra_tu* 32",
                                                "cu_measure 8", "cu_measure 16", "cu_measure 32" };
-        for (int b = 20; b < 31; b++)
-            if (tot[2 * b]) fprintf(stderr, "  (n = 1) %-12s %9llu x %7.2f us = %8.1f ms\n", sized[b - 20], (unsigned long long)tot[2 * b], tot[2 * b + 1] / 100.0 / tot[2 * b], tot[2 * b + 1] / 1e5);
+        {
+            uint64_t sz[24] = { 0 };
+            for (int i = 0; i < numQueues; i++) for (int k = 0; k < 24; k++) sz[k] += hosts[i].sized[k];
+            for (int b = 0; b < 11; b++)
+                if (sz[2 * b]) fprintf(stderr, "  (n = 1) %-12s %9llu x %7.2f us = %8.1f ms\n", sized[b], (unsigned long long)sz[2 * b], sz[2 * b + 1] / 100.0 / sz[2 * b], sz[2 * b + 1] / 1e5);
+        }
     }
     uint64_t lastReported = 0;
 };
@@ -1217,8 +1245,7 @@ extern "C" int x265amd_queue_stats(uint64_t* out, int n, int reset)
         const XaRingHost& h = S.hosts[i];
         for (int k = 0; k < 32; k++)
         {
-            const int ps = k == XA_OP_INTER_CHAIN ? XA_OP_EXIT : k;         /* the chain is counted in the exit command's pair (the server loop) */
-            const uint64_t cnt = k < 31 && k != XA_OP_EXIT ? h.prof[2 * ps] : 0, tk = k < 31 && k != XA_OP_EXIT ? h.prof[2 * ps + 1] : 0;
+            const uint64_t cnt = k < 31 ? h.prof[2 * k] : 0, tk = k < 31 ? h.prof[2 * k + 1] : 0;
             if (k < XA_OP_COUNT) { out[0] += cnt; out[1] += tk; }
             out[4] += h.bytes[k];
             if (10 + 3 * k + 2 < n && k < XA_OP_COUNT) { out[10 + 3 * k] += cnt; out[11 + 3 * k] += tk; out[12 + 3 * k] += h.bytes[k]; }

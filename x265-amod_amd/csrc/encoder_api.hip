@@ -132,7 +132,8 @@ struct x265amd_encoder
     std::mutex importMu;
     hipStream_t importStream = nullptr;                 /* frame-per-GPU: rows of pictures coded elsewhere are copied in on it */
     std::mutex byCodingMu;
-    std::map<uint64_t, PicP> byCoding;                  /* the last pictures by their place in coding order (row export / import) */
+    std::map<uint64_t, PicP> byCoding;                  /* the pictures in flight (and the last few collected) by their place in coding order (row export / import) */
+    uint64_t collectedCoding = 0;                       /* pictures collected so far (under byCodingMu) */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
     bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
@@ -188,8 +189,8 @@ struct x265amd_encoder
     int frameCostMany(std::vector<CostJob>& jobs);
     double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0;
     int frameCost(std::vector<Pic*>& frames, int p0, int p1, int b, int64_t& score);       /* CostEstimateGroup::singleCost(p0, p1, b): P (p1 == b) or B estimate */
-    int64_t slicetypePathCost(std::vector<Pic*>& frames, const char* path, int64_t threshold, int& rc);
-    void slicetypePath(std::vector<Pic*>& frames, int length, char (*best_paths)[251], int& rc);
+    int64_t planCost(std::vector<Pic*>& frames, const std::vector<uint8_t>& runs, int64_t limit, int& rc);
+    void extendPlans(std::vector<Pic*>& frames, int length, std::vector<std::vector<uint8_t> >& plans, int& rc);
     bool scenecutInternal(std::vector<Pic*>& frames, int p0, int p1, bool real, int& rc);
     bool scenecut(std::vector<Pic*>& frames, int p0, int p1, bool real, int numFrames, int& rc);
     int slicetypeAnalyse(std::vector<Pic*>& frames);
@@ -406,13 +407,30 @@ extern "C" int x265amd_encoder_row_geometry(const x265amd_encoder* e, int row, x
     out->motion_bytes = (u1 - u0) * sizeof(x265amd_mv_unit); out->map_offset_motion = u0 * sizeof(x265amd_mv_unit);
     return 0;
 }
+extern "C" int x265amd_encoder_is_referenced(x265amd_encoder* e, uint64_t k)
+{
+    if (!e) return xa_fail(X265AMD_EINVAL, "encoder_is_referenced: null"), -1;
+    PicP pic = picByCoding(e, k);
+    if (!pic)
+    {
+        std::lock_guard<std::mutex> lk(e->byCodingMu);
+        if (k < e->collectedCoding) return xa_fail(X265AMD_EINVAL, "encoder_is_referenced: that picture has been collected and released"), -1;
+        return 2;
+    }
+    return pic->type != TYPE_B;         /* what DPB::prepareEncode fixes with the slice type: a plain B picture is never a reference */
+}
 extern "C" int x265amd_encoder_owns(const x265amd_encoder* e, uint64_t k) { return e ? (e->p.shardCount <= 1 || (int)(k % (uint64_t)e->p.shardCount) == e->p.shardRank) : 0; }
 extern "C" int x265amd_encoder_export_row(x265amd_encoder* e, uint64_t codingIndex, int row, x265amd_row_export* out, int timeoutMs)
 {
     if (!e || !out || row < 0 || row >= e->ctuH) return xa_fail(X265AMD_EINVAL, "encoder_export_row: bad arguments"), -1;
     if (!e->frameParallel) return xa_fail(X265AMD_EINVAL, "encoder_export_row: rows are published by objects that code pictures in parallel (frameNumThreads > 1)"), -1;
     PicP pic = picByCoding(e, codingIndex);
-    if (!pic) return 1;
+    if (!pic)
+    {
+        std::lock_guard<std::mutex> lk(e->byCodingMu);
+        if (codingIndex < e->collectedCoding) return xa_fail(X265AMD_EINVAL, "encoder_export_row: that picture has been collected and released: the pump is more than eight pictures late"), -1;
+        return 1;
+    }
     if (!pic->owned) return xa_fail(X265AMD_EINVAL, "encoder_export_row: this object does not code that picture"), -1;
     const auto t0 = std::chrono::steady_clock::now();
     while (pic->published(row) < e->W)
@@ -421,6 +439,8 @@ extern "C" int x265amd_encoder_export_row(x265amd_encoder* e, uint64_t codingInd
         if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeoutMs) return xa_fail(X265AMD_EHIP, "encoder_export_row: time-out"), -1;
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
+    /* Pic::fail() sets every counter to the end: a picture that failed before the loop was entered looks published */
+    if (pic->failed.load()) return xa_fail(X265AMD_EHIP, "encoder_export_row: the picture failed"), -1;
     memset(out, 0, sizeof(*out));
     out->coding_index = codingIndex; out->ctu_row = row;
     rowRanges(*e, row, out->plane_offset, out->plane_bytes);
@@ -434,7 +454,12 @@ extern "C" int x265amd_encoder_import_row(x265amd_encoder* e, const x265amd_row_
 {
     if (!e || !in || in->ctu_row < 0 || in->ctu_row >= e->ctuH || !in->src[0] || !in->src[1] || !in->src[2] || !in->units || !in->motion) return xa_fail(X265AMD_EINVAL, "encoder_import_row: bad arguments"), -1;
     PicP pic = picByCoding(e, in->coding_index);
-    if (!pic) return 1;
+    if (!pic)
+    {
+        std::lock_guard<std::mutex> lk(e->byCodingMu);
+        if (in->coding_index < e->collectedCoding) return xa_fail(X265AMD_EINVAL, "encoder_import_row: that picture has been collected and released"), -1;
+        return 1;
+    }
     if (pic->owned) return xa_fail(X265AMD_EINVAL, "encoder_import_row: this object codes that picture itself"), -1;
     uint64_t off[3], bytes[3];
     rowRanges(*e, in->ctu_row, off, bytes);
@@ -906,56 +931,50 @@ int x265amd_encoder::frameCost(std::vector<Pic*>& frames, int p0, int p1, int b,
     return frameCostAt(*frames[b], *frames[p0], p1 > b ? frames[p1] : nullptr, b - p0, p1 - b, score);
 }
 
-/* Lookahead::slicetypePathCost (slicetype.cpp:3268-3313), no B pyramid */
-int64_t x265amd_encoder::slicetypePathCost(std::vector<Pic*>& frames, const char* path, int64_t threshold, int& rc)
+/* The B-frame trellis (X265_B_ADAPT_TRELLIS; what Lookahead::slicetypePath / slicetypePathCost compute, slicetype.cpp:3218-3313).  A plan for the first n pictures of
+ * the window is the list of its mini-GOPs' B runs (a run of k: k B pictures, then their P picture); planCost prices one -- per mini-GOP the P picture against the
+ * mini-GOP's anchor, then its B pictures (with the pyramid: the middle one between anchor and P picture, the ones in front of it between anchor and middle, the ones behind
+ * between middle and P picture) -- and gives up once the sum passes `limit`.  Which estimates are asked for, and in what order, is part of the result (an estimate that
+ * is asked for exists afterwards: frameCostAt), so the order of the additions and of the limit checks is the reference's. */
+int64_t x265amd_encoder::planCost(std::vector<Pic*>& frames, const std::vector<uint8_t>& runs, int64_t limit, int& rc)
 {
-    int64_t cost = 0;
-    int loc = 1, cur_p = 0;
-    path--;             /* the first path element is really the second frame */
-    while (path[loc] && rc == X265AMD_OK)
+    int64_t total = 0;
+    int anchor = 0;
+    for (size_t g = 0; g < runs.size() && rc == X265AMD_OK; g++)
     {
-        int next_p = loc;
-        while (path[next_p] != 'P') next_p++;
+        const int pPic = anchor + runs[g] + 1;
         int64_t c = 0;
-        rc = frameCost(frames, cur_p, next_p, next_p, c);
-        cost += c;
-        if (cost > threshold) break;
-        if (p.bBPyramid && next_p - cur_p > 2)
+        rc = frameCost(frames, anchor, pPic, pPic, c);
+        total += c;
+        if (total > limit) break;
+        if (p.bBPyramid && runs[g] > 1)
         {
-            /* the middle B picture is a reference: the ones in front of it are priced between cur_p and it, the ones behind between it and next_p (slicetype.cpp:3291-3302) */
-            const int middle = cur_p + (next_p - cur_p) / 2;
-            if (rc == X265AMD_OK) { rc = frameCost(frames, cur_p, next_p, middle, c); cost += c; }
-            for (int next_b = loc; next_b < middle && cost < threshold && rc == X265AMD_OK; next_b++) { rc = frameCost(frames, cur_p, middle, next_b, c); cost += c; }
-            for (int next_b = middle + 1; next_b < next_p && cost < threshold && rc == X265AMD_OK; next_b++) { rc = frameCost(frames, middle, next_p, next_b, c); cost += c; }
+            const int middle = anchor + (pPic - anchor) / 2;
+            if (rc == X265AMD_OK) { rc = frameCost(frames, anchor, pPic, middle, c); total += c; }
+            for (int b = anchor + 1; b < middle && total < limit && rc == X265AMD_OK; b++) { rc = frameCost(frames, anchor, middle, b, c); total += c; }
+            for (int b = middle + 1; b < pPic && total < limit && rc == X265AMD_OK; b++) { rc = frameCost(frames, middle, pPic, b, c); total += c; }
         }
         else
-            for (int next_b = loc; next_b < next_p && cost < threshold && rc == X265AMD_OK; next_b++)
-            {
-                rc = frameCost(frames, cur_p, next_p, next_b, c);
-                cost += c;
-            }
-        loc = next_p + 1;
-        cur_p = next_p;
+            for (int b = anchor + 1; b < pPic && total < limit && rc == X265AMD_OK; b++) { rc = frameCost(frames, anchor, pPic, b, c); total += c; }
+        anchor = pPic;
     }
-    return cost;
+    return total;
 }
-/* Lookahead::slicetypePath (slicetype.cpp:3218-3245) */
-void x265amd_encoder::slicetypePath(std::vector<Pic*>& frames, int length, char (*best_paths)[251], int& rc)
+/* the cheapest plan for the first `length` pictures: the cheapest plan of a shorter prefix with one more mini-GOP behind it, the last run growing from 0; the cheapest so
+ * far is the limit of the next one's pricing; the first of equals stays */
+void x265amd_encoder::extendPlans(std::vector<Pic*>& frames, int length, std::vector<std::vector<uint8_t> >& plans, int& rc)
 {
-    char paths[2][251];
-    const int num_paths = std::min(p.bframes + 1, length);
-    int64_t best_cost = 1LL << 62;
-    int idx = 0;
-    for (int path = 0; path < num_paths && rc == X265AMD_OK; path++)
+    const int longest = std::min(p.bframes, length - 1);
+    int64_t cheapest = 1LL << 62;
+    std::vector<uint8_t> winner;
+    for (int run = 0; run <= longest && rc == X265AMD_OK; run++)
     {
-        const int len = length - (path + 1);
-        memcpy(paths[idx], best_paths[len % 17], len);
-        memset(paths[idx] + len, 'B', path);
-        strcpy(paths[idx] + len + path, "P");
-        const int64_t cost = slicetypePathCost(frames, paths[idx], best_cost, rc);
-        if (cost < best_cost) { best_cost = cost; idx ^= 1; }
+        std::vector<uint8_t> plan = plans[length - (run + 1)];
+        plan.push_back((uint8_t)run);
+        const int64_t cost = planCost(frames, plan, cheapest, rc);
+        if (cost < cheapest) { cheapest = cost; winner.swap(plan); }
     }
-    memcpy(best_paths[length % 17], paths[idx ^ 1], length);
+    plans[length] = winner;
 }
 
 /* Lookahead::scenecutInternal (slicetype.cpp:3016-3047): float / double arithmetic as written there */
@@ -1126,14 +1145,18 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
             numBFrames = 0;
             if (numFrames > 1)
             {
-                static thread_local char best_paths[17][251];
-                memset(best_paths, 0, sizeof(best_paths));
-                strcpy(best_paths[1], "P");
-                const int best_path_index = numFrames % 17;
-                for (int j = 2; j <= numFrames && rc == X265AMD_OK; j++) slicetypePath(frames, j, best_paths, rc);
+                std::vector<std::vector<uint8_t> > plans((size_t)numFrames + 1);      /* plans[n]: the cheapest plan for the first n pictures; plans[0] is empty, plans[1] one P picture */
+                plans[1].push_back(0);
+                for (int j = 2; j <= numFrames && rc == X265AMD_OK; j++) extendPlans(frames, j, plans, rc);
                 if (rc != X265AMD_OK) return rc;
-                numBFrames = (int)strspn(best_paths[best_path_index], "B");
-                for (int j = 1; j < numFrames; j++) frames[j]->type = best_paths[best_path_index][j - 1] == 'B' ? TYPE_B : TYPE_P;
+                const std::vector<uint8_t>& plan = plans[numFrames];
+                numBFrames = plan.empty() ? 0 : plan[0];
+                int at = 1;
+                for (size_t g = 0; g < plan.size(); g++)
+                {
+                    for (int k = 0; k < plan[g] && at < numFrames; k++) frames[at++]->type = TYPE_B;
+                    if (at < numFrames) frames[at++]->type = TYPE_P;
+                }
             }
         }
         else if (p.bFrameAdaptive == 1)
@@ -2048,7 +2071,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         pic->codingOrder = e->codingCount++;
         pic->owned = e->p.shardCount <= 1 || (int)(pic->codingOrder % (uint64_t)e->p.shardCount) == e->p.shardRank;
         e->inflight.push_back(pic);
-        { std::lock_guard<std::mutex> lk(e->byCodingMu); e->byCoding[pic->codingOrder] = pic; while (e->byCoding.size() > 64) e->byCoding.erase(e->byCoding.begin()); }
+        { std::lock_guard<std::mutex> lk(e->byCodingMu); e->byCoding[pic->codingOrder] = pic; }      /* stays until the picture has been collected (below): however many pictures are in flight */
     }
     const bool timing = getenv("X265AMD_TIMING") != nullptr;
     auto start = [e, timing](const PicP& pic) {
@@ -2059,7 +2082,9 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
             const auto t0 = std::chrono::steady_clock::now();
             if (!pic->owned)
             {
-                /* another object codes this picture: its rows arrive through x265amd_encoder_import_row */
+                /* another object codes this picture: its rows arrive through x265amd_encoder_import_row -- unless nobody will ever read them (a plain B picture is
+                 * no reference: the row pump does not send it) */
+                if (pic->type == TYPE_B) { xa_scratch_free(pic->dSrc); pic->dSrc = nullptr; return (int)X265AMD_OK; }
                 std::unique_lock<std::mutex> lk(pic->mu);
                 const bool ok = pic->cv.wait_for(lk, std::chrono::seconds(300), [&] { return pic->importedRows >= e->ctuH || pic->failed.load(); });
                 if (!ok || pic->failed.load()) { lk.unlock(); pic->fail(); return xa_fail(X265AMD_EHIP, "encoder: a picture coded elsewhere did not arrive"); }
@@ -2106,6 +2131,12 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     const int rc = front->done.get();
     e->inflight.pop_front();
     e->running--;
+    {
+        /* a collected picture is complete -- every row exported or imported -- so the row pump has no more business with it; a few stay for a pump that asks late */
+        std::lock_guard<std::mutex> lk(e->byCodingMu);
+        e->collectedCoding = front->codingOrder + 1;
+        while (!e->byCoding.empty() && e->byCoding.begin()->first + 8 < e->collectedCoding) e->byCoding.erase(e->byCoding.begin());
+    }
     if (rc) { xa_fail(rc, "encoder_encode: a frame task failed"); return -1; }
     e->outBytes.swap(front->nalBytes);
     splitNals(e->outBytes, e->nals);

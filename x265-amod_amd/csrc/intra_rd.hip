@@ -1415,7 +1415,13 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     for (int i = 0; i < 4; i++)
     {
         memcpy(&results[i], &outs[i], sizeof(results[i]));
-        if (results[i].status != 1) return xa_fail(X265AMD_EHIP, "intra rd: the device gave up waiting inside a chain of 8x8 CUs");
+        if (results[i].status != 1)
+        {
+            /* a command that gave up has left ~0 in a peer's `ready` word: counts only grow, so every later chain on this block would see "the other side gave
+             * up" at once.  The block never goes back to the pool (48 KB lost per failed picture; the picture fails anyway) */
+            R.qBlock = nullptr;
+            return xa_fail(X265AMD_EHIP, "intra rd: the device gave up waiting inside a chain of 8x8 CUs");
+        }
     }
     return X265AMD_OK;
 }

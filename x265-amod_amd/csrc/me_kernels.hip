@@ -27,6 +27,7 @@ struct x265amd_me_ctx
 {
     uint16_t* d_tables = nullptr;           /* ME_QP_COUNT tables of ME_TBL_LEN entries */
     std::vector<uint16_t> h_tables;
+    float* d_bitsize = nullptr;             /* BitCost::s_bitsizes (bitcost.cpp:95-109) for |d| = 0 .. ME_TBL_HALF: the fused search command prices vectors with it (BitCost::bitcost) */
 };
 
 /* =========================================================================================================
@@ -70,6 +71,20 @@ extern "C" x265amd_me_ctx* x265amd_me_open(void)
         delete ctx;
         return nullptr;
     }
+    {
+        /* evaluated as the reference build does (see is_bitsize, inter_common.h) */
+        std::vector<float> bs((size_t)ME_TBL_HALF + 1);
+        const double log2_2 = (double)(float)(2.0 / log(2.0));
+        bs[0] = 0.718f;
+        for (int i = 1; i <= ME_TBL_HALF; i++) bs[i] = (float)(log((double)(float)(i + 1)) * log2_2 + (double)1.718f);
+        if (hipMalloc((void**)&ctx->d_bitsize, bs.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(ctx->d_bitsize, bs.data(), bs.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        {
+            xa_fail(X265AMD_EHIP, "x265amd_me_open: cannot place the vector bit-size table on the device");
+            x265amd_me_close(ctx);
+            return nullptr;
+        }
+    }
     return ctx;
 }
 
@@ -77,6 +92,7 @@ extern "C" void x265amd_me_close(x265amd_me_ctx* ctx)
 {
     if (!ctx) return;
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_bitsize) (void)hipFree(ctx->d_bitsize);
     delete ctx;
 }
 
@@ -86,6 +102,9 @@ const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp)
     if (!ctx || qp < 0 || qp >= ME_QP_COUNT) return nullptr;
     return ctx->d_tables + (size_t)qp * ME_TBL_LEN + ME_TBL_HALF;
 }
+
+const float* xa_me_device_bitsize(x265amd_me_ctx* ctx) { return ctx ? ctx->d_bitsize : nullptr; }
+const uint16_t* xa_me_device_tables(x265amd_me_ctx* ctx) { return ctx ? ctx->d_tables : nullptr; }
 
 extern "C" const uint16_t* x265amd_me_host_mvcost(x265amd_me_ctx* ctx, int qp)
 {

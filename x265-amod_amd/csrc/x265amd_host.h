@@ -181,6 +181,8 @@ extern bool g_xaHostProf;
 
 /* device address of the centre (MVD 0) of x265amd_me_ctx's MV cost table for `qp` (BitCost::s_costs[qp]) */
 const uint16_t* xa_me_device_mvcost(x265amd_me_ctx* ctx, int qp);
+const float* xa_me_device_bitsize(x265amd_me_ctx* ctx);      /* BitCost::s_bitsizes on the device, index |d| */
+const uint16_t* xa_me_device_tables(x265amd_me_ctx* ctx);    /* all MV cost tables (MeParams::tables) */
 
 /* The reference's primitive slots cannot report failure (primitives.h:133-236), so a HIP error inside a
  * per-slot entry point is fatal: there is deliberately no CPU fallback. */

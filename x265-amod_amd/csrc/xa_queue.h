@@ -17,7 +17,7 @@
 enum XaOp
 {
     XA_OP_NOP = 0, XA_OP_EXIT, XA_OP_COPY, XA_OP_COPY2D, XA_OP_FILL, XA_OP_COPY_RECTS, XA_OP_MC, XA_OP_MC_COST, XA_OP_CU_MEASURE, XA_OP_TU_CHAIN, XA_OP_TU_CHAIN_RDOQ,
-    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_INTRA_PU, XA_OP_INTRA_NXN, XA_OP_INTER_CHAIN, XA_OP_COUNT
+    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_INTRA_PU, XA_OP_INTRA_NXN, XA_OP_INTER_CHAIN, XA_OP_INTER_SEARCH, XA_OP_COUNT
 };
 enum
 {
@@ -53,13 +53,15 @@ struct alignas(128) XaRingHost
     uint64_t alive;                             /* hosts[0] only: bumped by the host while queues are in use; an idle workgroup leaves only when this has stood still */
     uint64_t pad1[14];
     uint64_t dbg[64];                           /* X265AMD_QUEUE_DEBUG & 2: what each wavefront was about to touch (dumped on abort) */
-    uint64_t prof[64];                          /* X265AMD_QUEUE_PROF: per command kind [2 * op] count, [2 * op + 1] ticks of the 100 MHz clock (written when the
-                                                   workgroup leaves); [62] ticks spent polling, [63] ticks in fences */
+    uint64_t prof[64];                          /* per command kind [2 * op] count, [2 * op + 1] ticks of the 100 MHz clock (written when the workgroup leaves; op < 31);
+                                                   [62] ticks spent polling, [63] ticks in fences */
     uint64_t bytes[32];                         /* algorithmic bytes per command kind (what each command has to read and write, from its job records: see
                                                    DESIGN.md section 5); always counted, written when the workgroup leaves */
     uint64_t resident;                          /* ticks of the 100 MHz clock between the workgroup's start and its exit, summed over server generations */
     uint64_t pad2[15];
     uint64_t nxn[40];                           /* X265AMD_QUEUE_PROF: the fused intra command by kind (four 4x4 units / one unit of 8 / 16 / 32) x stage: ticks */
+    uint64_t stage[24];                         /* X265AMD_QUEUE_PROF: the stages of the transform chains and the fused intra steps (ticks) */
+    uint64_t sized[24];                         /* X265AMD_QUEUE_DEBUG & 16: single-job commands of the hot kinds by block size: [2 b] count, [2 b + 1] ticks, b = 0..10 */
     uint64_t chain[8];                          /* X265AMD_QUEUE_PROF: chained 8x8 CUs, ticks: [0] the deciding command waiting for the chain, [1] the other command waiting for
                                                    the chain, [2] waiting for the other evaluation, [3] its record + both CUs' bits, [4] costs + the winner's samples + result, [5] publishing */
 };

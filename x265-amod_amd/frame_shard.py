@@ -1,4 +1,7 @@
-"""Frame-parallel sharding across GPUs (reference analogue: frame threads, one frame per
+"""Whole-picture exchange between GPUs for the KERNEL workload only (bench_kernels.py --gpus N): superseded for the encoder by frame_rows.py (rows published as they
+become final, SURVEY.md section 8e as written) -- kept because bench_kernels.py and one gloo test still time / exercise the all_gather form.
+
+Frame-parallel sharding across GPUs (reference analogue: frame threads, one frame per
 FrameEncoder: source/encoder/encoder.cpp:306-328, frameencoder.cpp:285-302).
 
 Frame k in encode order is owned by rank k % world (the reference's m_curEncoder round-robin, encoder.cpp:1872).  The one

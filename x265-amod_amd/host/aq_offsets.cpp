@@ -29,25 +29,26 @@ extern "C" int x265amd_aq_offsets(const uint32_t* energy, int numBlocks, int blo
 {
     if (!energy || !qpAqOffset || !qpCuTreeOffset || !invQscaleFactor || blockCount <= 0 || numBlocks <= 0 || aqMode < 1 || aqMode > 3 || (qgSize != 16 && qgSize != 8) || aqStrength == 0)
         return X265AMD_EINVAL;
-    const float modeOneConst = qgSize == 8 ? 11.427f : 14.427f, modeTwoConst = qgSize == 8 ? 8.f : 11.f;
-    double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0;
-    double bias_strength = 0.f;
+    const float varianceBase = qgSize == 8 ? 11.427f : 14.427f, autoBase = qgSize == 8 ? 8.f : 11.f;
+    /* meanRoot / meanSquare: the picture's averages of the blocks' energy^0.1 and of its square (auto-variance); offset: the block's QP offset */
+    double meanSquare = 0, meanRoot = 0, offset = 0;
+    double darkBias = 0.f;
     double strength = 0.f;
     if (aqMode == 2 || aqMode == 3)
     {
-        const double bit_depth_correction = 1.f / (1 << (2 * (X265AMD_DEPTH - 8)));
+        const double toEightBit = 1.f / (1 << (2 * (X265AMD_DEPTH - 8)));
         for (int b = 0; b < numBlocks; b++)
         {
-            qp_adj = pow(energy[b] * bit_depth_correction + 1, 0.1);
-            qpCuTreeOffset[b] = qp_adj;
-            avg_adj += qp_adj;
-            avg_adj_pow2 += qp_adj * qp_adj;
+            offset = pow(energy[b] * toEightBit + 1, 0.1);
+            qpCuTreeOffset[b] = offset;
+            meanRoot += offset;
+            meanSquare += offset * offset;
         }
-        avg_adj /= blockCount;
-        avg_adj_pow2 /= blockCount;
-        strength = aqStrength * avg_adj;
-        avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - modeTwoConst) / avg_adj;
-        bias_strength = aqBiasStrength * aqStrength;
+        meanRoot /= blockCount;
+        meanSquare /= blockCount;
+        strength = aqStrength * meanRoot;
+        meanRoot = meanRoot - 0.5f * (meanSquare - autoBase) / meanRoot;
+        darkBias = aqBiasStrength * aqStrength;
     }
     else
         strength = aqStrength * 1.0397f;
@@ -55,22 +56,22 @@ extern "C" int x265amd_aq_offsets(const uint32_t* energy, int numBlocks, int blo
     {
         if (aqMode == 3)
         {
-            qp_adj = qpCuTreeOffset[b];
-            qp_adj = strength * (qp_adj - avg_adj) + bias_strength * (1.f - modeTwoConst / (qp_adj * qp_adj));
+            offset = qpCuTreeOffset[b];
+            offset = strength * (offset - meanRoot) + darkBias * (1.f - autoBase / (offset * offset));
         }
         else if (aqMode == 2)
         {
-            qp_adj = qpCuTreeOffset[b];
-            qp_adj = strength * (qp_adj - avg_adj);
+            offset = qpCuTreeOffset[b];
+            offset = strength * (offset - meanRoot);
         }
         else
         {
             const uint32_t e = energy[b] > 1 ? energy[b] : 1;
-            qp_adj = strength * (log2((double)e) - (modeOneConst + 2 * (X265AMD_DEPTH - 8)));
+            offset = strength * (log2((double)e) - (varianceBase + 2 * (X265AMD_DEPTH - 8)));
         }
-        qpAqOffset[b] = qp_adj;
-        qpCuTreeOffset[b] = qp_adj;
-        invQscaleFactor[b] = exp2fix8(qp_adj);
+        qpAqOffset[b] = offset;
+        qpCuTreeOffset[b] = offset;
+        invQscaleFactor[b] = exp2fix8(offset);
     }
     return X265AMD_OK;
 }

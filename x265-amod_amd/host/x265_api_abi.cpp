@@ -37,7 +37,12 @@ struct AbiEncoder
     x265amd_encoder* enc = nullptr;
     std::vector<uint8_t> param;         /* the caller's x265_param as it was at encoder_open (encoder_parameters hands it back) */
     int width = 0, height = 0;
-    int64_t ptsQueue[64]; int ptsHead = 0, ptsCount = 0;
+    /* time stamps (Encoder::encode, encoder.cpp:1695-1697, :2286-2295; Lookahead::slicetypeDecide hands the display-order stamps of a mini-GOP to its pictures in
+     * coding order, slicetype.cpp:2134-2469 -- so the i-th coded picture's m_reorderedPts is the i-th input picture's pts) */
+    std::vector<int64_t> ptsIn;         /* by input (display) order */
+    int64_t prevReordered[2] = { 0, 0 };
+    int bframeDelay = 0;                /* Encoder::m_bframeDelay: 2 with the B pyramid, 1 with B pictures, else 0 (encoder.cpp:3945) */
+    uint64_t coded = 0, idrBase = 0;    /* pictures handed out so far; the display index of the last IDR picture (POC counts from there) */
 };
 
 /* ---- x265_param ---- */
@@ -158,6 +163,7 @@ void* abi_encoder_open(void* p)
     if (!e) return nullptr;
     AbiEncoder* a = new AbiEncoder;
     a->enc = e; a->width = q.sourceWidth; a->height = q.sourceHeight;
+    a->bframeDelay = q.bframes ? (q.bBPyramid ? 2 : 1) : 0;
     a->param.assign((const uint8_t*)p, (const uint8_t*)p + X265ABI_SIZEOF_PARAM);         /* api.cpp:96-116: the encoder keeps a copy */
     return a;
 }
@@ -184,7 +190,7 @@ int abi_encoder_encode(void* enc, x265amd_nal** ppNal, uint32_t* piNal, void* pi
             in.planes[k] = rd<void*>(picIn, X265ABI_PIC_planes + 8 * k);
             in.stride[k] = rd<int32_t>(picIn, X265ABI_PIC_stride + 4 * k);
         }
-        if (a.ptsCount < 64) { a.ptsQueue[(a.ptsHead + a.ptsCount) & 63] = rd<int64_t>(picIn, X265ABI_PIC_pts); a.ptsCount++; }
+        a.ptsIn.push_back(rd<int64_t>(picIn, X265ABI_PIC_pts));
     }
     /* the reconstruction is returned through planes the encoder owns in the reference (pic_out->planes point into its reconstructed picture); here the
      * caller's pic_out receives pointers to a buffer of this object that stays valid until the next call */
@@ -203,6 +209,23 @@ int abi_encoder_encode(void* enc, x265amd_nal** ppNal, uint32_t* piNal, void* pi
         wr<int32_t>(picOut, X265ABI_PIC_bitDepth, X265AMD_DEPTH); wr<int32_t>(picOut, X265ABI_PIC_colorSpace, 1);
         wr<int32_t>(picOut, X265ABI_PIC_poc, out.poc); wr<int32_t>(picOut, X265ABI_PIC_sliceType, out.sliceType);
         wr<int32_t>(picOut, X265ABI_PIC_width, a.width); wr<int32_t>(picOut, X265ABI_PIC_height, a.height);
+    }
+    if (ret > 0)
+    {
+        /* an IDR picture closes what lies before it in display order: everything coded so far */
+        if (out.sliceType == 1) a.idrBase = a.coded;
+        const uint64_t display = a.idrBase + (uint64_t)(out.poc < 0 ? 0 : out.poc);
+        const int64_t pts = display < a.ptsIn.size() ? a.ptsIn[display] : 0;
+        const int64_t reordered = a.coded < a.ptsIn.size() ? a.ptsIn[a.coded] : pts;
+        int64_t dts = reordered;
+        if (a.bframeDelay)
+        {
+            const int64_t delayTime = (size_t)a.bframeDelay < a.ptsIn.size() ? a.ptsIn[a.bframeDelay] - a.ptsIn[0] : 0;
+            dts = a.coded > (uint64_t)a.bframeDelay ? a.prevReordered[(a.coded - a.bframeDelay) % a.bframeDelay] : reordered - delayTime;
+            a.prevReordered[a.coded % a.bframeDelay] = reordered;
+        }
+        a.coded++;
+        if (picOut) { wr<int64_t>(picOut, X265ABI_PIC_pts, pts); wr<int64_t>(picOut, X265ABI_PIC_dts, dts); }
     }
     return ret;
 }
