@@ -101,6 +101,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
             pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
         pics.append((pic, keep))
     coded = 0
+    lib.x265amd_encoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     try:
         if timed:
             sync()
@@ -147,6 +148,8 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
         if timed:
             sync()
         dt = time.perf_counter() - t0
+        st = (C.c_uint64 * 4)()
+        encode.last_stats = list(st) if lib.x265amd_encoder_stats(enc, st, 4) == 0 else None      # I / P / B pictures, the sum of their distinct reference pictures
     finally:
         lib.x265amd_encoder_close(enc)
     assert coded == len(frames), (coded, len(frames))
@@ -177,22 +180,29 @@ XA_OPS = ["nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc
 
 
 def job_server_roofline(st, frames_payload_bytes, wall_s):
-    """the roofline object of the timed region's dominant (and only resident) kernel.  One launch of k_job_server lasts the whole encode: `achieved` = the
-    algorithmic bytes of every command it ran (what each command has to read and write, from the sizes in its job records, counted on the device) / the launch
-    duration by HIP events on its stream.  busy_frac = ticks inside command bodies / resident ticks summed over the workgroups: the rest is polling for the
-    host's next command."""
+    """the roofline object of the timed region's dominant (and only resident) kernel.  One launch of k_job_server lasts the whole encode.  `achieved` = SURVEY section
+    8d's algorithmic bytes of that launch (frame payload x (source + reconstruction + R reference pictures), R from the encoder) / the launch duration by HIP events on
+    its stream; `per_command_bytes` = the sum over its commands of what each has to read and write (counted on the device) over the same duration; busy_frac = ticks
+    inside command bodies / resident ticks summed over the workgroups: the rest is polling for the next command."""
     if not st or not st[6]:
         return None
     kernel_s = st[7] / 1e6
     per_op = {XA_OPS[k]: {"commands": st[10 + 3 * k], "body_ms": st[11 + 3 * k] / 1e5, "algorithmic_MB": st[12 + 3 * k] / 1e6} for k in range(len(XA_OPS)) if st[10 + 3 * k]}
-    achieved = st[4] / kernel_s / 1e9
-    return {"bound": "hbm", "kernel": "k_job_server", "launches": st[6], "workgroups": st[8], "launch_ms": 1000.0 * kernel_s / st[6], "bytes": st[4],
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    launch_s = kernel_s / st[6]
+    achieved = frames_payload_bytes / launch_s / 1e9
+    per_cmd = st[4] / kernel_s / 1e9
+    return {"bound": "hbm", "kernel": "k_job_server", "launches": st[6], "workgroups": st[8], "launch_ms": 1000.0 * launch_s,
+            "bytes": frames_payload_bytes, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "of": "SURVEY section 8d's algorithmic bytes of the launch -- frame payload x (source read + reconstruction write + R distinct reference pictures read), R per picture "
+                  "as the encoder's own reference lists have it (x265amd_encoder_stats) -- over the launch's duration by HIP events on its stream (one launch = the timed encode)",
             "busy_frac": st[1] / st[5] if st[5] else None, "commands": st[0], "body_ms_all_workgroups": st[1] / 1e5, "polling_ms_all_workgroups": st[3] / 1e5,
-            "frame_payload_bytes_8d": frames_payload_bytes, "frac_8d": frames_payload_bytes / wall_s / 1e9 / HBM_PEAK_GBS,
+            "per_command_bytes": {"bytes": st[4], "achieved": per_cmd, "frac": per_cmd / HBM_PEAK_GBS,
+                                  "of": "the sum over the launch's commands of what each has to read and write once (counted on the device from its job records): blocks are read "
+                                        "again by every command that evaluates them, so this is several times the 8d figure"},
             "per_command_kind": per_op,
-            "note": "k_job_server is resident for the whole encode (one launch = the timed region); bytes = sum over its commands of their algorithmic bytes; traffic: "
-                    "the PMC counter passes do not survive a resident kernel (profiles/collect.sh), the per-kernel counter figures of the batched kernels are under kernel_workload"}
+            "note": "k_job_server is resident for the whole encode; the encoder is bound by the latency of the reference's serial decision chain (busy_frac: the share of the "
+                    "workgroups' resident time inside command bodies), not by bandwidth.  traffic: the PMC counter passes do not survive a resident kernel (profiles/collect.sh); "
+                    "the per-kernel counter figures of the batched kernels are under kernel_workload"}
 
 
 def usable_cores():
@@ -331,7 +341,11 @@ def main():
         n_i = 1
         n_b = nal_count(stream, 0) + nal_count(stream, 8)                                                          # TRAIL_N / RASL_N slices: the B pictures the lookahead chose (--b-adapt 2)
         n_p = K - n_i - n_b
-        alg = payload * (2 * n_i + (2 + min(REFS, 2)) * n_p + 4 * n_b)                        # short clip: P frames see up to the pictures coded so far
+        es = getattr(encode, "last_stats", None)
+        if es:
+            alg = payload * (2 * (es[0] + es[1] + es[2]) + es[3])                             # R per picture from the encoder's own reference lists
+        else:
+            alg = payload * (2 * n_i + (2 + min(REFS, 2)) * n_p + 4 * n_b)
         line = {
             "metric": "encoded frames/sec at 1080p & 2160p --preset medium; bit-exact vs CPU ref",
             "value": (K if by_frames else world * K) / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * dt / K,

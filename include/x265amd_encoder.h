@@ -145,6 +145,10 @@ int x265amd_encoder_row_geometry(const x265amd_encoder* enc, int ctu_row, x265am
 /* the number of CTU rows of a picture, and whether this object codes picture `coding_index` */
 int x265amd_encoder_ctu_rows(const x265amd_encoder* enc);
 int x265amd_encoder_owns(const x265amd_encoder* enc, uint64_t coding_index);
+/* counters of the pictures handed over by the lookahead so far (the counterpart of what x265_encoder_get_stats totals, x265.h:2475): out[0] I, out[1] P, out[2] B pictures,
+ * out[3] the sum over them of the DISTINCT reference pictures each reads (DPB::prepareEncode's lists, dpb.cpp:101-290) -- SURVEY section 8d's R per picture, which the
+ * bench's roofline figure is built from.  n: words available (>= 4).  Returns 0 or -1. */
+int x265amd_encoder_stats(const x265amd_encoder* enc, uint64_t* out, int n);
 /* whether pictures coded later may reference picture `coding_index` (DPB::prepareEncode: every picture but a plain B picture; reference: source/encoder/dpb.cpp:101-140):
  * 1 yes, 0 no -- its rows need not travel and an object that does not code it does not wait for them --, 2 not known yet (not handed over by the lookahead: ask again),
  * -1 on error.  The same answer on every object of a set. */

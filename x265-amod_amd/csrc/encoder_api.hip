@@ -134,6 +134,7 @@ struct x265amd_encoder
     std::mutex byCodingMu;
     std::map<uint64_t, PicP> byCoding;                  /* the pictures in flight (and the last few collected) by their place in coding order (row export / import) */
     uint64_t collectedCoding = 0;                       /* pictures collected so far (under byCodingMu) */
+    uint64_t statPictures[3] = { 0, 0, 0 }, statReferences = 0;     /* x265amd_encoder_stats: pictures prepared as I / P / B, the sum of their distinct reference pictures */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
     bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
@@ -396,6 +397,12 @@ static void rowRanges(const x265amd_encoder& e, int row, uint64_t off[3], uint64
     }
 }
 extern "C" int x265amd_encoder_ctu_rows(const x265amd_encoder* e) { return e ? e->ctuH : -1; }
+extern "C" int x265amd_encoder_stats(const x265amd_encoder* e, uint64_t* out, int n)
+{
+    if (!e || !out || n < 4) return xa_fail(X265AMD_EINVAL, "encoder_stats: arguments"), -1;
+    out[0] = e->statPictures[0]; out[1] = e->statPictures[1]; out[2] = e->statPictures[2]; out[3] = e->statReferences;
+    return 0;
+}
 extern "C" int x265amd_encoder_row_geometry(const x265amd_encoder* e, int row, x265amd_row_export* out)
 {
     if (!e || !out || row < 0 || row >= e->ctuH) return xa_fail(X265AMD_EINVAL, "encoder_row_geometry: bad arguments"), -1;
@@ -1364,6 +1371,7 @@ int x265amd_encoder::prepare(const PicP& picp)
     for (const PicP& q : rps) (q->poc < pic.poc ? pic.neg : pic.pos).push_back(q);
     std::sort(pic.neg.begin(), pic.neg.end(), [](const PicP& a, const PicP& b) { return a->poc > b->poc; });           /* RPS::sortDeltaPOC */
     std::sort(pic.pos.begin(), pic.pos.end(), [](const PicP& a, const PicP& b) { return a->poc < b->poc; });
+    if (stype == 2) statPictures[0]++;
     if (stype != 2)
     {
         const int n0 = std::min(std::max(1, (int)pic.neg.size()), p.maxNumReferences), n1 = stype == 0 ? std::min(p.bBPyramid ? 2 : 1, (int)pic.pos.size()) : 0;       /* dpb.cpp:269-273 */
@@ -1371,6 +1379,12 @@ int x265amd_encoder::prepare(const PicP& picp)
         l0.insert(l0.end(), pic.pos.begin(), pic.pos.end()); l1.insert(l1.end(), pic.neg.begin(), pic.neg.end());
         if ((int)l0.size() < n0 || (int)l1.size() < n1 || (stype == 0 && !n1)) return xa_fail(X265AMD_EINVAL, "encoder_encode: reference lists");
         pic.lists[0].assign(l0.begin(), l0.begin() + n0); pic.lists[1].assign(l1.begin(), l1.begin() + n1);
+        {
+            /* x265amd_encoder_stats: the distinct reference pictures this picture reads (SURVEY section 8d's R) */
+            std::vector<const Pic*> seen;
+            for (int l = 0; l < 2; l++) for (const PicP& q : pic.lists[l]) if (std::find(seen.begin(), seen.end(), q.get()) == seen.end()) seen.push_back(q.get());
+            statPictures[stype == 1 ? 1 : 2]++; statReferences += seen.size();
+        }
     }
     static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");
     if (p.bEnableWeightedPred && stype == 1 && !(dbgWp && strchr(dbgWp, 'p')))

@@ -554,6 +554,17 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
         XA_CHAIN_T(0);
         if (S.stop) { reason = S.stop; break; }
         const int nc = S.nc;
+        if (tid == 0)
+        {
+            /* algorithmic bytes of the CU's merge check: nine map units read; per candidate and direction the block with its interpolation border (luma 8 taps, chroma 4), the
+             * prediction written; the source block read once; the winner's units: prediction and source read again */
+            unsigned long long b = 9ull * sizeof(XaMapUnit) + 3ull * size * size / 2 * sizeof(pixel) * 3;
+            for (int i = 0; i < nc; i++)
+                if (S.cand[i].valid)
+                    b += (unsigned long long)((S.cand[i].dir & 1) + ((S.cand[i].dir >> 1) & 1)) * ((unsigned)(size + 7) * (size + 7) + 2u * (unsigned)(size / 2 + 3) * (size / 2 + 3)) * sizeof(pixel) +
+                         3ull * size * size / 2 * sizeof(pixel);
+            XA_BYTES(b);
+        }
         /* ---- every candidate still in the race: its prediction (Predict::motionCompensation) and the SA8D of it, tile by tile over the wavefronts ---- */
         for (int i = tid; i < 5 * 3 * 16; i += NT) (&S.acc[0][0][0])[i] = 0;
         __syncthreads();
@@ -859,6 +870,8 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
             }
             if (tid == 0)
             {
+                /* a skipped CU put in place: its units into the map, its samples into the picture and into the enclosing CUs' tiles, its record to the host */
+                XA_BYTES((unsigned long long)(size >> 2) * (size >> 2) * sizeof(XaMapUnit) + 3ull * size * size / 2 * sizeof(pixel) * (1 + depth) + sizeof(XaChainCuOut));
                 XaChainCuOut o{};
                 o.node = (uint32_t)node; o.cand = (uint8_t)best; o.dir = c.dir; o.ref_idx[0] = u.ref_idx[0]; o.ref_idx[1] = u.ref_idx[1];
                 o.mv[0][0] = u.mv[0][0]; o.mv[0][1] = u.mv[0][1]; o.mv[1][0] = u.mv[1][0]; o.mv[1][1] = u.mv[1][1];

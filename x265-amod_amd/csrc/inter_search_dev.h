@@ -364,6 +364,10 @@ XA_DEV void block_inter_search(const XaSearchJob* jobAddr, char* smem, int tid)
             j.slice_type = 1; j.flags = 3;
         }
     }
+    if (tid == 0)       /* algorithmic bytes besides the searches' own (windows, source tiles, records: counted by their bodies): the record, the predictors' blocks read with
+                         * their interpolation border and written, the winner's prediction, source and units, the result with its levels */
+        XA_BYTES(sizeof(XaSearchJob) + (unsigned long long)2 * nr * ((unsigned)(size + 7) * (size + 7) + (unsigned)size * size) * sizeof(pixel) +
+                 ((unsigned long long)(size + 7) * (size + 7) + 2ull * (size / 2 + 3) * (size / 2 + 3) + 6ull * size * size) * sizeof(pixel) + 256 + 3ull * size * size);
     for (int i = tid; i < 3 * 16; i += NT) (&S.acc[0][0])[i] = 0;
     __syncthreads();
     if (S.best < 0)
