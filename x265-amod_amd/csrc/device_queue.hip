@@ -378,6 +378,25 @@ template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int ti
     }
 }
 
+/* XA_OP_WAIT: this queue goes on when another queue has finished its command number `target` (a release: xa_queue_follow), and looks at memory afresh */
+__device__ __noinline__ void xa_op_wait(const XaCmd& c, int tid)
+{
+    const XaArgsWait a = *reinterpret_cast<const XaArgsWait*>(c.args);
+    if (tid == 0)
+    {
+        const long long t0 = wall_clock64();
+        while (xa_sys_load(reinterpret_cast<const uint64_t*>(a.word)) < a.target)
+        {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ll) break;      /* two seconds: the other queue stands; the host notices (its own waits are bounded) */
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 /* the search bodies for the fused search command (inter_search_dev.h) */
 __device__ __noinline__ void xa_op_me_call(int which, const XaCmd& c, int tid)
 {
@@ -446,6 +465,9 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
         break;
     case XA_OP_INTER_SEARCH:
         xa_op_inter_search(c, tid);
+        break;
+    case XA_OP_WAIT:
+        xa_op_wait(c, tid);
         break;
     case XA_OP_ME_SEARCH: xa_op_me<0>(c, tid); break;
     case XA_OP_ME_SEARCH_STAR: xa_op_me<1>(c, tid); break;
@@ -622,6 +644,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
                 s_prof[63] += (unsigned long long)(wall_clock64() - te);
             }
             if (flags & XA_CMD_SIGNAL) xa_sys_store(&rh->tail, seen);
+            xa_sys_store(&rd->done, seen);          /* for a queue that follows this one (XA_OP_WAIT): behind the release when the command carried one */
         }
         if (flags & XA_CMD_SIGNAL) signalled = seen;
     }
@@ -754,6 +777,7 @@ struct Server
             x.rh->tail = 0; x.rh->state = 0; x.rh->dbg[63] = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].quit) = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].head) = 0;
+            *reinterpret_cast<volatile uint64_t*>(&rings[i].done) = 0;
         }
         _mm_sfence();
         (void)hipEventRecord(ev0, stream);
@@ -777,7 +801,7 @@ struct Server
     void profile_report(bool final)
     {
         static const char* const names[XA_OP_COUNT] = { "nop/fence", "exit", "copy", "copy2d", "fill", "copy_rects", "mc", "mc_cost", "cu_measure", "tu_chain", "tu_chain_rdoq", "intra_tu_chain",
-                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn", "inter_chain", "inter_search" };
+                                                         "intra_tu_chain_rdoq", "intra_scan", "me_search", "me_search_star", "me_deferred", "est_bit", "intra_pu", "intra_nxn", "inter_chain", "inter_search", "wait" };
         uint64_t tot[64] = { 0 }, stage[24] = { 0 };
         for (int i = 0; i < numQueues; i++) for (int k = 0; k < 64; k++) tot[k] += hosts[i].prof[k];
         for (int i = 0; i < numQueues; i++) for (int k = 0; k < 22; k++) stage[k] += hosts[i].stage[k];
@@ -1159,6 +1183,17 @@ hipError_t xa_stream_sync(void* st)
     q->laterMapped.clear();
     q->stagingUsed = 0; q->stagingUsedOut = 0;
     return hipSuccess;
+}
+
+/* everything enqueued on `leader` so far happens before what is enqueued on `follower` from now on -- on the device, neither queue's host waits: the leader gets a
+ * releasing command, the follower a command that polls the leader's count of finished commands and then acquires */
+hipError_t xa_queue_follow(void* follower, void* leader)
+{
+    if (!xa_is_queue(follower) || !xa_is_queue(leader)) return hipErrorInvalidValue;
+    XaQueue* L = as_queue(leader);
+    if (q_push(L, XA_OP_NOP, XA_CMD_RELEASE, 0, nullptr, 0)) return hipErrorUnknown;
+    const XaArgsWait a = { (uint64_t)(uintptr_t)&L->rd->done, L->submitted };
+    return q_push(as_queue(follower), XA_OP_WAIT, 0, 0, &a, sizeof(a)) ? hipErrorUnknown : hipSuccess;
 }
 
 hipError_t xa_stream_fence(void* st, int flags)

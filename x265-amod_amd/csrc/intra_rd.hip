@@ -49,6 +49,15 @@ inline unsigned zUnit(int ux, int uy)           /* z-order of unit (ux, uy) insi
 /* The device-side records of a chain of 8x8 CUs (four x265amd_intra_peer + one x265amd_intra_chain) come from a list of their own, not from the pools: the counts in them
  * only ever grow (one counter for the process), so whatever a workgroup still holds of such a record from an earlier chain is an OLDER count and at worst makes it look
  * again -- memory that had been pixels or levels before could read as a count from the future. */
+/* what the row's queue has written is out before the other queue's workgroup looks: on the device (xa_queue_follow), or -- X265AMD_QUEUE_FOLLOW=0 -- through the host
+ * (the row's queue drained, a signalling command releases; the other queue acquires) */
+static hipError_t xa_follow_or_sync(void* follower, void* leader)
+{
+    static const bool follow = !(getenv("X265AMD_QUEUE_FOLLOW") && atoi(getenv("X265AMD_QUEUE_FOLLOW")) == 0);
+    if (follow) return xa_queue_follow(follower, leader);
+    if (xa_stream_sync(leader) != hipSuccess) return hipErrorUnknown;
+    return xa_stream_fence(follower, XA_CMD_ACQUIRE);
+}
 static std::mutex g_chainLock;
 static std::vector<void*> g_chainFree;
 static const size_t kChainBlock = 4 * sizeof(x265amd_intra_peer) + sizeof(x265amd_intra_chain);
@@ -584,7 +593,7 @@ struct IntraRd
                     buildDevJob(nj, 3, rdLevel, hintPred, hintRecon, (uint64_t)(uintptr_t)dCand2.p, (uint64_t)(uintptr_t)dCoeffDev2.p);
                     U(cuX, cuY).part_size = keep;
                     memcpy(dNxnJob2.p, &nj, sizeof(nj));
-                    if (xa_stream_sync(st) != hipSuccess || xa_stream_fence(helper, XA_CMD_ACQUIRE) != hipSuccess ||
+                    if (xa_follow_or_sync(helper, st) != hipSuccess ||
                         x265amd_intra_nxn(helper, (const x265amd_intra_nxn_job*)dNxnJob2.p, (x265amd_intra_nxn_out*)dNxnOut2.p) != X265AMD_OK)
                         return fail("intra rd: NxN step ahead");
                     ahead.on = true; ahead.x = cuX; ahead.y = cuY;
@@ -1092,7 +1101,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
                 x265amd_intra_nxn_job nj;
                 R.buildInInterJob(nj, d_pred, d_recon, (uint64_t)(uintptr_t)g.cand.p, (uint64_t)(uintptr_t)g.coeffDev.p, g.levels.p, g.clevels.p);
                 memcpy(g.job.p, &nj, sizeof(nj));
-                if (xa_stream_sync(R.st) != hipSuccess || xa_stream_fence(g.q, XA_CMD_ACQUIRE) != hipSuccess ||
+                if (xa_follow_or_sync(g.q, R.st) != hipSuccess ||
                     x265amd_intra_nxn(g.q, (const x265amd_intra_nxn_job*)g.job.p, (x265amd_intra_nxn_out*)g.out.p) != X265AMD_OK)
                     rc = xa_fail(X265AMD_EHIP, "intra rd: intra try ahead");
                 else { g.on = true; g.x = R.cuX; g.y = R.cuY; started = 1; }
@@ -1117,7 +1126,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
             R.buildDevJob(nj, 0, rp->rd_level, d_pred, d_recon, (uint64_t)(uintptr_t)g.cand.p, (uint64_t)(uintptr_t)g.coeffDev.p, g.levels.p, g.clevels.p);
             nj.no_picture = 1;
             memcpy(g.job.p, &nj, sizeof(nj));
-            if (xa_stream_sync(R.st) != hipSuccess || xa_stream_fence(g.q, XA_CMD_ACQUIRE) != hipSuccess ||
+            if (xa_follow_or_sync(g.q, R.st) != hipSuccess ||
                 x265amd_intra_nxn(g.q, (const x265amd_intra_nxn_job*)g.job.p, (x265amd_intra_nxn_out*)g.out.p) != X265AMD_OK)
                 rc = xa_fail(X265AMD_EHIP, "intra rd: large unit step ahead");
             else { g.on = true; g.x = R.cuX; g.y = R.cuY; started = 1; }
@@ -1405,7 +1414,7 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     R.c = nullptr;
     /* what this queue has written is out before the other workgroup looks (a signalling command releases), and that one looks (acquire) */
     int rc = X265AMD_OK;
-    if (xa_stream_sync(stream) != hipSuccess || xa_stream_fence(helper, XA_CMD_ACQUIRE) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain fence");
+    if (xa_follow_or_sync(helper, stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain fence");
     /* one command per role: the four records of a role run one after the other in the same workgroup */
     if (rc == X265AMD_OK && (x265amd_intra_nxn_list(helper, &jobs[1], 4, 2 * sizeof(x265amd_intra_nxn_job), &peers[0].out) != X265AMD_OK ||
                              x265amd_intra_nxn_list(stream, &jobs[0], 4, 2 * sizeof(x265amd_intra_nxn_job), (x265amd_intra_nxn_out*)R.dNxnOut.p) != X265AMD_OK))

@@ -68,6 +68,7 @@ void* xa_queue_helper(void* st);
 void xa_queue_log(void* st, int poc, int row);      /* X265AMD_QUEUE_LOG=poc,row: the command / wait timeline of that row goes to stderr when the queue is given back */
 hipError_t xa_stream_sync(void* st);
 hipError_t xa_stream_fence(void* st, int flags);
+hipError_t xa_queue_follow(void* follower, void* leader);     /* two device job queues: what `leader` holds so far happens before what `follower` gets from now on; no host wait */
 hipError_t xa_copy_async(void* st, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t xa_copy2d_to_mapped_async(void* st, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
 hipError_t xa_fill_async(void* st, void* dst, int value, size_t bytes);

@@ -17,7 +17,7 @@
 enum XaOp
 {
     XA_OP_NOP = 0, XA_OP_EXIT, XA_OP_COPY, XA_OP_COPY2D, XA_OP_FILL, XA_OP_COPY_RECTS, XA_OP_MC, XA_OP_MC_COST, XA_OP_CU_MEASURE, XA_OP_TU_CHAIN, XA_OP_TU_CHAIN_RDOQ,
-    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_INTRA_PU, XA_OP_INTRA_NXN, XA_OP_INTER_CHAIN, XA_OP_INTER_SEARCH, XA_OP_COUNT
+    XA_OP_INTRA_TU_CHAIN, XA_OP_INTRA_TU_CHAIN_RDOQ, XA_OP_INTRA_SCAN, XA_OP_ME_SEARCH, XA_OP_ME_SEARCH_STAR, XA_OP_ME_DEFERRED, XA_OP_EST_BIT, XA_OP_INTRA_PU, XA_OP_INTRA_NXN, XA_OP_INTER_CHAIN, XA_OP_INTER_SEARCH, XA_OP_WAIT, XA_OP_COUNT
 };
 enum
 {
@@ -44,6 +44,8 @@ struct alignas(128) XaRingDev
     XaCmd cmd[XA_RING];
     uint64_t head; uint64_t pad0[15];           /* the doorbell: the number of the command the host waits for (0: none); read with the next slot */
     uint64_t quit; uint64_t pad1[15];
+    uint64_t done; uint64_t pad2[15];           /* written by the workgroup: commands finished (behind a release when the command asked for one): what another queue's
+                                                   XA_OP_WAIT polls -- an order between two queues without the host in between (xa_queue_follow) */
 };
 /* pinned host memory, written by the workgroup, polled by the host thread */
 struct alignas(128) XaRingHost
@@ -70,6 +72,7 @@ struct XaArgsJobs4 { uint64_t a, b, c, d; int32_t n; };      /* the (jobs, secon
 struct XaArgsCopy { uint64_t dst, src, bytes; uint32_t hostDst; };
 struct XaArgsCopy2D { uint64_t dst, src, dpitch, spitch, width, height; };
 struct XaArgsFill { uint64_t dst, bytes; uint32_t value; };
+struct XaArgsWait { uint64_t word, target; };             /* XA_OP_WAIT: until *word >= target (another queue's `done`), then an acquire */
 struct XaArgsRects { uint64_t dst[4], src[4]; int16_t dst_stride[4], src_stride[4], w[4], h[4]; int32_t n; };     /* = XaRects (x265amd_host.h): 100 bytes */
 
 #endif
