@@ -1,6 +1,6 @@
 # X265AMD_QUEUE_LOG=poc,row: summary of the row's command / wait timeline (dbg/qlog_report.py log [first last])
 import sys, re
-names = "NOP EXIT COPY COPY2D FILL COPY_RECTS MC MC_COST CU_MEASURE TU_CHAIN TU_CHAIN_RDOQ INTRA_TU_CHAIN INTRA_TU_CHAIN_RDOQ INTRA_SCAN ME_SEARCH ME_SEARCH_STAR ME_DEFERRED EST_BIT INTRA_PU INTRA_NXN INTER_CHAIN INTER_SEARCH".split()
+names = "NOP EXIT COPY COPY2D FILL COPY_RECTS MC MC_COST CU_MEASURE TU_CHAIN TU_CHAIN_RDOQ INTRA_TU_CHAIN INTRA_TU_CHAIN_RDOQ INTRA_SCAN ME_SEARCH ME_SEARCH_STAR ME_DEFERRED EST_BIT INTRA_PU INTRA_NXN INTER_CHAIN INTER_SEARCH WAIT".split()
 ev = []
 for l in open(sys.argv[1]):
     m = re.match(r"x265amd qlog poc (\d+) row (\d+): ([\d.]+) ([\d.]+) (\w) (\d+)", l)

@@ -2173,7 +2173,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 {
                     const int need = c2 + 2 < ctuW ? c2 + 2 : ctuW;
                     const auto w0 = std::chrono::steady_clock::now();
+                    const int wc = xa_task_wait_class(1);
                     xa_wait_counter(f.done[row - 1], (uint64_t)need);          /* a failing row sets its counter to the end, so this always ends */
+                    xa_task_wait_class(wc);
                     std::atomic_thread_fence(std::memory_order_acquire);
                     xa_prof_dependency_wait((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count());
                 }
@@ -2181,12 +2183,20 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (r2 == X265AMD_OK && !st) r2 = X265AMD_EHIP;
                 /* the reference pictures are published column by column: this CTU follows them (parked on their counters meanwhile) */
                 static const bool ctuLog = getenv("X265AMD_CTU_LOG") != nullptr;
-                static const auto tLog0 = std::chrono::steady_clock::now();
+                static const int ctuLogPoc = ctuLog && getenv("X265AMD_CTU_LOG")[0] == 'p' ? atoi(getenv("X265AMD_CTU_LOG") + 1) : -1;       /* "p9": every row of picture 9; anything else: the last three rows of every picture */
+                static const auto tLog0 = std::chrono::steady_clock::time_point() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double, std::milli>(
+                    floor(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() / 1e6) * 1e6));       /* milliseconds modulo 10^6 of the steady clock: X265AMD_PUB_LOG's clock */
                 const double tA = ctuLog ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count() : 0;
+                const int wc2 = xa_task_wait_class(2);
                 if (r2 == X265AMD_OK && f.hooks && f.hooks->ctu_wait && f.hooks->ctu_wait(f.hooks->ctx, row, c2)) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: a reference picture failed");
+                xa_task_wait_class(wc2);
                 const double tB = ctuLog ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count() : 0;
-                struct CtuLog { bool on; int poc, row, col; double a, b; ~CtuLog() { if (on) fprintf(stderr, "x265amd ctu: poc %d row %d col %d: row-above wait from %.2f, gate passed %.2f, done %.2f\n", poc, row, col, a, b, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count()); } }
-                    ctuLogger{ ctuLog && row >= f.ctuH - 3, f.poc, row, c2, tA, tB };
+                struct CtuLog { bool on; int poc, row, col; double a, b; uint64_t p0[4], run0;
+                                ~CtuLog() { if (!on) return; uint64_t p1[4]; xa_task_parked_ns(p1);
+                                            fprintf(stderr, "x265amd ctu: poc %d row %d col %d: row-above wait from %.2f, gate passed %.2f, done %.2f; in the CTU: running %.2f, waiting for the device %.2f, for reference samples %.2f\n", poc, row, col, a, b,
+                                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tLog0).count(), (xa_task_run_ns_always() - run0) / 1e6, (p1[0] - p0[0]) / 1e6, (p1[3] - p0[3]) / 1e6); } }
+                    ctuLogger{ ctuLog && (ctuLogPoc >= 0 ? f.poc == ctuLogPoc : row >= f.ctuH - 3), f.poc, row, c2, tA, tB, { 0, 0, 0, 0 }, 0 };
+                if (ctuLogger.on) { xa_task_parked_ns(ctuLogger.p0); ctuLogger.run0 = xa_task_run_ns_always(); }
                 if (r2 == X265AMD_OK && f.hooks && f.hooks->before_ctu) f.hooks->before_ctu(f.hooks->ctx, row, c2);
                 if (r2 == X265AMD_OK) r2 = f.doCtu(row * ctuW + c2, st);
                 if (r2 == X265AMD_OK && xa_stream_sync(st) != hipSuccess) r2 = xa_fail(X265AMD_EHIP, "analyse_frame: row stream");

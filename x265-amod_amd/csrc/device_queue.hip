@@ -495,6 +495,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     bool havePre = false;
     __shared__ unsigned long long s_bytes[32];
     const long long tResident0 = wall_clock64();
+    const long long cResident0 = clock64();
     if (tid < 64) s_prof[tid] = 0;
     if (tid < 24) s_sized[tid] = 0;
     if (tid < 32) s_bytes[tid] = 0;
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid < 32) xa_sys_store(&rh->bytes[tid], rh->bytes[tid] + s_bytes[tid]);
     if (tid >= 64 && tid < 104) xa_sys_store(&rh->nxn[tid - 64], rh->nxn[tid - 64] + (&xa_nxn_acc[0][0])[tid - 64]);
     if (tid >= 104 && tid < 112) xa_sys_store(&rh->chain[tid - 104], rh->chain[tid - 104] + xa_chain_acc[tid - 104]);
-    if (tid == 32) xa_sys_store(&rh->resident, rh->resident + (unsigned long long)(wall_clock64() - tResident0));
+    if (tid == 32) { xa_sys_store(&rh->resident, rh->resident + (unsigned long long)(wall_clock64() - tResident0)); xa_sys_store(&rh->cycles, rh->cycles + (unsigned long long)(clock64() - cResident0)); }
     if (tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); xa_sys_store(&rh->state, 0); }
 }
 
@@ -813,6 +814,11 @@ struct Server
                 g_heldNs.load() / 1e6, g_depNs.load() / 1e6, g_waitNs.load() / 1e6, (unsigned long long)g_waits.load(), g_waits.load() ? g_waitNs.load() / 1e3 / g_waits.load() : 0.0);
         fprintf(stderr, "x265amd job server: %llu commands, %.1f ms in command bodies, %.1f ms in fences, %.1f ms polling (all queues; 100 MHz clock)\n", (unsigned long long)cmds,
                 ticks / 1e5, tot[63] / 1e5, tot[62] / 1e5);
+        {
+            uint64_t res = 0, cyc = 0;
+            for (int i = 0; i < numQueues; i++) { res += hosts[i].resident; cyc += hosts[i].cycles; }
+            if (res) fprintf(stderr, "  shader clock while resident: %.0f MHz (s_memtime against the 100 MHz clock, all workgroups)\n", 100.0 * cyc / res);
+        }
         for (int op = 0; op < XA_OP_COUNT; op++)
             if (tot[2 * op]) fprintf(stderr, "  %-20s %9llu x %7.2f us = %8.1f ms\n", names[op], (unsigned long long)tot[2 * op], tot[2 * op + 1] / 100.0 / tot[2 * op], tot[2 * op + 1] / 1e5);
         fprintf(stderr, "  stages of the transform chains as wavefront 0 saw them (ms): record %.1f, neighbours %.1f, prediction %.1f, residual %.1f, transforms %.1f, quantisation %.1f, sign hiding %.1f, "
@@ -1290,7 +1296,7 @@ extern "C" int x265amd_queue_stats(uint64_t* out, int n, int reset)
     out[6] = S.launches; out[7] = (uint64_t)(S.kernelMs * 1000.0); out[8] = (uint64_t)S.numQueues;
     if (reset)
     {
-        for (int i = 0; i < S.numQueues; i++) { memset((void*)S.hosts[i].prof, 0, sizeof(S.hosts[i].prof)); memset((void*)S.hosts[i].bytes, 0, sizeof(S.hosts[i].bytes)); S.hosts[i].resident = 0; }
+        for (int i = 0; i < S.numQueues; i++) { memset((void*)S.hosts[i].prof, 0, sizeof(S.hosts[i].prof)); memset((void*)S.hosts[i].bytes, 0, sizeof(S.hosts[i].bytes)); S.hosts[i].resident = 0; S.hosts[i].cycles = 0; }
         S.kernelMs = 0.0; S.launches = 0;
     }
     return X265AMD_OK;

@@ -97,7 +97,13 @@ struct Pic
     }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
     ~Pic() { if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
-    void publish(int row, int x) { std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x; }
+    void publish(int row, int x)
+    {
+        std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x;
+        static const bool pubLog = getenv("X265AMD_PUB_LOG") != nullptr;      /* with the gate's waits (gateCtuWait): who waited for which publication, and when it came */
+        if (pubLog) fprintf(stderr, "x265amd pub: poc %d row %d x %d at %.2f\n", poc, row, x, pubClockMs());
+    }
+    static double pubClockMs() { return fmod(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(), 1e6); }       /* the clock of X265AMD_CTU_LOG */
     int published(int row) const { const int v = (int)*finalX[row]; std::atomic_thread_fence(std::memory_order_acquire); return v; }
     void fail()         /* whoever waits for this picture is released */
     {
@@ -137,6 +143,8 @@ struct x265amd_encoder
     uint64_t statPictures[3] = { 0, 0, 0 }, statReferences = 0;     /* x265amd_encoder_stats: pictures prepared as I / P / B, the sum of their distinct reference pictures */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
+    double uploadMs = 0;        /* X265AMD_TIMING: the callers' time in uploadPicture */
+    std::atomic<uint64_t> cpuPictureNs{ 0 }, cpuFilterNs{ 0 };      /* X265AMD_TIMING: CPU time of the picture threads and the filter threads (CLOCK_THREAD_CPUTIME_ID) */
     bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
     int refLagRows = 0;                                 /* FrameEncoder::m_refLagRows (frameencoder.cpp:170-175) */
     std::vector<PicP> picList;                          /* front = most recently coded (PicList::pushFront) */
@@ -151,8 +159,11 @@ struct x265amd_encoder
     {
         for (auto& q : inflight) if (q->done.valid()) q->done.wait();
         if (getenv("X265AMD_TIMING") && lookahead)
+        {
+            fprintf(stderr, "x265amd: input: %.1f ms in uploads; cpu of the picture threads %.1f ms, of the filter threads %.1f ms\n", uploadMs, cpuPictureNs.load() / 1e6, cpuFilterNs.load() / 1e6);
             fprintf(stderr, "x265amd: lookahead: %.1f ms in lowres planes + intra costs, %.1f ms in the slice-type decision (%llu estimates, %llu motion searches; %llu batches %.1f ms, %llu single estimates %.1f ms)\n", laInitMs, laDecideMs,
                     (unsigned long long)laJobs, (unsigned long long)laSearches, (unsigned long long)laBatches, laBatchMs, (unsigned long long)laSingles, laSingleMs);
+        }
         if (me) x265amd_me_close(me);
         if (dSaoCount) (void)hipFree(dSaoCount);
         if (dSaoOrg) (void)hipFree(dSaoOrg);
@@ -195,7 +206,7 @@ struct x265amd_encoder
     bool scenecutInternal(std::vector<Pic*>& frames, int p0, int p1, bool real, int& rc);
     bool scenecut(std::vector<Pic*>& frames, int p0, int p1, bool real, int numFrames, int& rc);
     int slicetypeAnalyse(std::vector<Pic*>& frames);
-    int decideLookahead(bool flush);
+    int decideLookahead(bool flush, int maxGops = 1 << 30);
     int filterRows(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
     int filterRowsCols(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
 };
@@ -1249,10 +1260,10 @@ void x265amd_encoder::pushMiniGop(int b)
 
 /* Lookahead::slicetypeDecide (slicetype.cpp:1802-2400) as far as the built subset goes: runs when the input queue holds lookaheadDepth pictures (Lookahead::findJob,
  * m_fullQueueSize; one picture is enough once the caller flushes), types the next mini-GOP and moves it to `ready` in coding order.  Returns 0, or an error code. */
-int x265amd_encoder::decideLookahead(bool flush)
+int x265amd_encoder::decideLookahead(bool flush, int maxGops)
 {
     const int fullQueue = flush ? 1 : std::max(1, p.lookaheadDepth);
-    while ((int)input.size() >= fullQueue)
+    while ((int)input.size() >= fullQueue && maxGops-- > 0)
     {
         const int maxSearch = std::max(1, std::min(p.lookaheadDepth, 250));
         std::vector<Pic*> frames;
@@ -1671,10 +1682,16 @@ static int gateCtuWait(void* ctx, int row, int col)         /* blocking: the tas
     RowGate& g = *(RowGate*)ctx;
     const x265amd_encoder& e = *g.e;
     const int need = gateNeed(e, col), r0 = std::max(0, row - 2), r1 = std::min(e.ctuH - 1, row + 1);
+    static const bool pubLog = getenv("X265AMD_PUB_LOG") != nullptr;
     for (Pic* q : g.refs)
         for (int r = r1; r >= r0; r--)
         {
-            if (q->published(r) < need) xa_wait_counter(q->finalX[r], (uint64_t)need);
+            if (q->published(r) < need)
+            {
+                const double t0 = pubLog ? Pic::pubClockMs() : 0;
+                xa_wait_counter(q->finalX[r], (uint64_t)need);
+                if (pubLog) fprintf(stderr, "x265amd gate: poc %d row %d col %d waited from %.2f to %.2f for poc %d row %d x %d\n", g.pic->poc, row, col, t0, Pic::pubClockMs(), q->poc, r, need);
+            }
             if (q->failed.load(std::memory_order_acquire)) return -1;
         }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -1688,11 +1705,13 @@ static int gateRefWait(void* ctx, int picIdx, int yMin, int yMax, int xMax)
     Pic* q = g.refs[picIdx];
     const int need = xMax >= e.W - 1 ? e.W : std::max(0, xMax + 1);
     const int r0 = std::min(std::max(yMin, 0), e.H - 1) >> 6, r1 = std::min(std::max(yMax, 0), e.H - 1) >> 6;
+    const int wc = xa_task_wait_class(3);
     for (int r = r1; r >= r0; r--)
     {
         if (q->published(r) < need) xa_wait_counter(q->finalX[r], (uint64_t)need);
-        if (q->failed.load(std::memory_order_acquire)) return -1;
+        if (q->failed.load(std::memory_order_acquire)) { xa_task_wait_class(wc); return -1; }
     }
+    xa_task_wait_class(wc);
     std::atomic_thread_fence(std::memory_order_acquire);
     return 0;
 }
@@ -1828,6 +1847,25 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
     return rc;
 }
 
+/* Waiting for a stream without burning a core: hipStreamSynchronize polls flat out, and the filter threads of twenty pictures in flight did that beside the worker
+ * threads -- past the CPU quota of the box (16 cores), where the kernel then freezes every thread of the process for the rest of its 100 ms period (cgroup cpu.stat:
+ * nr_throttled; a dozen milliseconds each time, in the middle of the encode).  An event, a short poll for the common case (the work is a few kernels), then naps. */
+static hipError_t streamWaitPolite(hipStream_t st, hipEvent_t ev)
+{
+    static const bool off = getenv("X265AMD_FILTER_SPIN") && atoi(getenv("X265AMD_FILTER_SPIN")) != 0;
+    if (off || !ev) return hipStreamSynchronize(st);
+    hipError_t e = hipEventRecord(ev, st);
+    if (e != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;)
+    {
+        e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) { for (int k = 0; k < 16; k++) __builtin_ia32_pause(); continue; }
+        struct timespec ts = { 0, 20000 }; nanosleep(&ts, nullptr);
+    }
+}
+
 /* The filter thread of a picture, by columns.  A UNIT is a CTU row r and a range of its CTU columns [c0, c1): the deblocking of the unit's edges (vertical edges
  * right of c0's left boundary up to and including c1's left boundary, then the horizontal edges of the columns, the top one reaching three samples into row
  * r - 1), the SAO statistics and decisions of its CTUs; behind it row r - 1 (and the last row itself) is offset, its borders extended and its columns published
@@ -1845,6 +1883,9 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: stream");
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{ st };
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    struct EventGuard { hipEvent_t e; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } evGuard{ ev };
     const bool sao = p.bEnableSAO != 0, dbl = p.bEnableLoopFilter != 0;
     const size_t nUnits = (size_t)w4 * h4, ctuStat = (size_t)3 * 5 * 32, nstat = (size_t)nctu * ctuStat;
     /* device: deblocking records, SAO parameters.  Pinned host memory the device reads / writes in place (no staging copies, no synchronisation to free a
@@ -1962,7 +2003,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
         numUnits += (int)todo.size(); numSweeps++;
         if (sao)
         {
-            if (hipStreamSynchronize(st) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: sao statistics"); break; }
+            if (streamWaitPolite(st, ev) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: sao statistics"); break; }
             for (const Unit& u : todo)
             {
                 int32_t flags[2] = { 1, 1 };
@@ -1985,7 +2026,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
             if (rc != X265AMD_OK) break;
         }
         if (rc != X265AMD_OK) break;
-        if (hipStreamSynchronize(st) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: row filters"); break; }
+        if (streamWaitPolite(st, ev) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: row filters"); break; }
         for (const Unit& u : todo)
         {
             const int newX = u.c1 == ctuW ? W : 64 * u.c1 - 8;
@@ -1997,6 +2038,10 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
     return rc;
 }
 
+static uint64_t thread_cpu_ns()
+{
+    struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
 int x265amd_encoder::runFrameParallel(const PicP& picp)
 {
     Pic& pic = *picp;
@@ -2036,7 +2081,8 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     /* by columns when there is something to filter and the rows run as a wavefront; the row-by-row form otherwise */
     static const bool colsOff = getenv("X265AMD_FILTER_COLS") && atoi(getenv("X265AMD_FILTER_COLS")) == 0;
     const bool byCols = !colsOff && p.bEnableWavefront && (p.bEnableLoopFilter || p.bEnableSAO) && ctuH > 1 && ctuW > 1;
-    std::thread filters([&, byCols] { xa_thread_device(); filterRc = byCols ? filterRowsCols(pic, fc.si, fc.info, sparams, saoFlags) : filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) pic.fail(); });
+    std::thread filters([&, byCols] { xa_thread_device(); filterRc = byCols ? filterRowsCols(pic, fc.si, fc.info, sparams, saoFlags) : filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) pic.fail();
+                                      cpuFilterNs += thread_cpu_ns(); });
     const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, pic.codingOrder + 1, gateCtuReach };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
@@ -2065,28 +2111,47 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     {
         PicP pic(new Pic);
         pic->poc = e->frameCount++;
+        const auto tu0 = std::chrono::steady_clock::now();
         int rc = e->uploadPicture(picIn, *pic);
         if (rc) return -1;
         const auto tl0 = std::chrono::steady_clock::now();
+        e->uploadMs += std::chrono::duration<double, std::milli>(tl0 - tu0).count();
         if (e->lookahead && (rc = e->lowresInit(*pic)) != X265AMD_OK) return -1;
         e->laInitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl0).count();
         e->input.push_back(pic);
     }
-    const auto tl1 = std::chrono::steady_clock::now();
-    if (e->lookahead) { if (e->decideLookahead(picIn == nullptr) != X265AMD_OK) return -1; }
-    else e->decideMiniGop(picIn == nullptr);
-    e->laDecideMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl1).count();
+    const bool flushing = picIn == nullptr;
+    /* The slice-type decisions.  With pictures coming in, whatever a full queue allows.  When the caller flushes, ONE mini-GOP at a time (below): each decision of
+     * the lookahead takes as long as a P picture, and the pictures of the first mini-GOP have no reason to wait for the decisions about the last -- a clip shorter than
+     * the lookahead is decided entirely while it is flushed, and its first P picture used to start when the last decision was made (X265AMD_FLUSH_DECIDE_ALL=1: that
+     * form).  The decisions themselves do not depend on when they are made. */
+    static const bool decideAll = getenv("X265AMD_FLUSH_DECIDE_ALL") && atoi(getenv("X265AMD_FLUSH_DECIDE_ALL")) != 0;
+    auto decide = [e, flushing]() -> int {
+        const auto tl1 = std::chrono::steady_clock::now();
+        int rc = X265AMD_OK;
+        if (e->lookahead) rc = e->decideLookahead(flushing, flushing && !decideAll ? 1 : 1 << 30);
+        else e->decideMiniGop(flushing);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tl1).count();
+        e->laDecideMs += ms;
+        static const bool timingD = getenv("X265AMD_TIMING") != nullptr;
+        if (timingD && ms > 0.5) fprintf(stderr, "x265amd: decision: %.1f ms, %d pictures typed, %d still in the lookahead%s\n", ms, (int)e->ready.size(), (int)e->input.size(), flushing ? " (flushing)" : "");
+        return rc;
+    };
     /* every typed picture is prepared in coding order here (DPB::prepareEncode is bookkeeping: it does not wait for any picture to be coded); the frame itself is a task */
-    while (!e->ready.empty())
-    {
-        PicP pic = e->ready.front();
-        e->ready.pop_front();
-        if (e->prepare(pic)) return -1;
-        pic->codingOrder = e->codingCount++;
-        pic->owned = e->p.shardCount <= 1 || (int)(pic->codingOrder % (uint64_t)e->p.shardCount) == e->p.shardRank;
-        e->inflight.push_back(pic);
-        { std::lock_guard<std::mutex> lk(e->byCodingMu); e->byCoding[pic->codingOrder] = pic; }      /* stays until the picture has been collected (below): however many pictures are in flight */
-    }
+    auto admit = [e]() -> int {
+        while (!e->ready.empty())
+        {
+            PicP pic = e->ready.front();
+            e->ready.pop_front();
+            if (e->prepare(pic)) return -1;
+            pic->codingOrder = e->codingCount++;
+            pic->owned = e->p.shardCount <= 1 || (int)(pic->codingOrder % (uint64_t)e->p.shardCount) == e->p.shardRank;
+            e->inflight.push_back(pic);
+            { std::lock_guard<std::mutex> lk(e->byCodingMu); e->byCoding[pic->codingOrder] = pic; }      /* stays until the picture has been collected (below): however many pictures are in flight */
+        }
+        return 0;
+    };
+    if (decide() != X265AMD_OK || admit()) return -1;
     const bool timing = getenv("X265AMD_TIMING") != nullptr;
     auto start = [e, timing](const PicP& pic) {
         std::shared_future<int> prev = e->lastTask;
@@ -2107,6 +2172,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
                 return (int)X265AMD_OK;
             }
             const int rc = e->frameParallel ? e->runFrameParallel(pic) : e->runFrame(pic, prev);
+            { struct timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); e->cpuPictureNs += (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec; }
             if (timing)
                 fprintf(stderr, "x265amd: poc %d type %d qp %d: %.2f ms\n", pic->poc, pic->type, pic->sliceQp,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -2122,6 +2188,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     static const bool earlyP = !(getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 0);
     static const bool earlyBref = getenv("X265AMD_EARLY_BREF") && atoi(getenv("X265AMD_EARLY_BREF")) != 0;      /* a referenced B picture is a link of the same chain */
     static const int earlyPMax = getenv("X265AMD_EARLY_P_MAX") ? atoi(getenv("X265AMD_EARLY_P_MAX")) : 6;
+    auto launch = [&]() {
     for (auto& q : e->inflight)
     {
         if (q->started) continue;
@@ -2133,6 +2200,17 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
          * picture held back until the B pictures in front of it have been collected starts with nothing to trail and takes its full latency, so it starts when the
          * lookahead hands it over, too (every picture it references is in front of it in coding order and therefore started; X265AMD_EARLY_P=0: in turn). */
         else if (earlyP && (q->type == TYPE_P || (earlyBref && q->type == TYPE_BREF)) && e->running <= e->frameThreads + earlyPMax) start(q);
+    }
+    };
+    launch();
+    /* flushing: the next mini-GOP is decided while the picture the caller will get next is still being coded */
+    while (flushing && !e->input.empty())
+    {
+        if (!e->inflight.empty() && e->inflight.front()->started && e->inflight.front()->done.wait_for(std::chrono::seconds(0)) == std::future_status::ready) break;
+        const size_t before = e->input.size();
+        if (decide() != X265AMD_OK || admit()) return -1;
+        launch();
+        if (e->input.size() >= before) break;
     }
     if (e->inflight.empty()) return 0;
     PicP front = e->inflight.front();

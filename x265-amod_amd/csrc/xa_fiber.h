@@ -48,6 +48,9 @@ int xa_in_task(void);
  * when a worker is free to look */
 void xa_task_spin_ns(uint64_t ns);
 int xa_worker_count(void);
+/* X265AMD_TIMING: the calling task's waits are booked under a class (0..3; returns the class in force before); xa_task_parked_ns: the totals so far */
+int xa_task_wait_class(int cls);
+void xa_task_parked_ns(uint64_t out[4]);
 /* X265AMD_TIMING: time the calling task has spent running (up to its last resume); totals over all workers: running, looking for a task that can run, switches */
 uint64_t xa_task_run_ns(void);
 uint64_t xa_task_run_ns_always(void);     /* the same whether or not X265AMD_TIMING is set (X265AMD_HOSTPROF) */

@@ -60,7 +60,8 @@ struct alignas(128) XaRingHost
     uint64_t bytes[32];                         /* algorithmic bytes per command kind (what each command has to read and write, from its job records: see
                                                    DESIGN.md section 5); always counted, written when the workgroup leaves */
     uint64_t resident;                          /* ticks of the 100 MHz clock between the workgroup's start and its exit, summed over server generations */
-    uint64_t pad2[15];
+    uint64_t cycles;                            /* shader clock cycles over the same time (s_memtime): cycles / resident x 100 MHz is the clock the workgroup's CU ran at */
+    uint64_t pad2[14];
     uint64_t nxn[40];                           /* X265AMD_QUEUE_PROF: the fused intra command by kind (four 4x4 units / one unit of 8 / 16 / 32) x stage: ticks */
     uint64_t stage[24];                         /* X265AMD_QUEUE_PROF: the stages of the transform chains and the fused intra steps (ticks) */
     uint64_t sized[24];                         /* X265AMD_QUEUE_DEBUG & 16: single-job commands of the hot kinds by block size: [2 b] count, [2 b + 1] ticks, b = 0..10 */

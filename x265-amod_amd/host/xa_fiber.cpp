@@ -52,6 +52,7 @@ struct Fiber
     uint64_t userMark = 0;              /* for the caller's phase accounting */
     void* userSlot = nullptr;           /* a pointer of the caller's (the row's reference-picture guard) */
     uint64_t spinNs = 0;                /* xa_task_spin_ns: how long a wait polls before the task parks */
+    int waitClass = 0; uint64_t parkedNs[4] = { 0, 0, 0, 0 };      /* X265AMD_TIMING: time spent in waits by the class the caller named (xa_task_wait_class) */
     struct Worker* worker = nullptr;    /* the worker running it now */
 };
 
@@ -282,6 +283,8 @@ uint64_t* xa_task_mark(void) { Worker* w = current_worker(); return w && w->cur 
 void xa_sched_stats(uint64_t out[3]) { out[0] = g_busyNs.load(); out[1] = g_idleNs.load(); out[2] = g_switches.load(); }
 int xa_in_task(void) { Worker* w = current_worker(); return w && w->cur; }
 void xa_task_spin_ns(uint64_t ns) { Worker* w = current_worker(); if (w && w->cur) w->cur->spinNs = ns; }
+int xa_task_wait_class(int cls) { Worker* w = current_worker(); if (!(w && w->cur)) return 0; const int old = w->cur->waitClass; w->cur->waitClass = cls & 3; return old; }
+void xa_task_parked_ns(uint64_t out[4]) { Worker* w = current_worker(); for (int k = 0; k < 4; k++) out[k] = w && w->cur ? w->cur->parkedNs[k] : 0; }
 
 void xa_tasks_run(const XaTask* tasks, int n)
 {
@@ -333,7 +336,8 @@ void xa_wait_counter(const volatile uint64_t* counter, uint64_t value)
     {
         Fiber* f = w->cur;
         f->pred = nullptr;
-        if (f->spinNs) { const uint64_t t1 = now_ns() + f->spinNs; while (*counter < value && now_ns() < t1) _mm_pause(); if (*counter >= value) return; }
+        const uint64_t tw0 = g_stats ? now_ns() : 0;
+        if (f->spinNs) { const uint64_t t1 = now_ns() + f->spinNs; while (*counter < value && now_ns() < t1) _mm_pause(); if (*counter >= value) { if (g_stats) f->parkedNs[f->waitClass] += now_ns() - tw0; return; } }
         do
         {
             f->waitValue.store(value, std::memory_order_release); f->waitCounter.store(counter, std::memory_order_release);
@@ -341,6 +345,7 @@ void xa_wait_counter(const volatile uint64_t* counter, uint64_t value)
             xa_ctx_switch(&f->sp, on->sp);          /* parks; resumed (maybe by another worker) when the counter was seen to have reached the value */
         } while (*counter < value);
         f->waitCounter.store(nullptr, std::memory_order_release);
+        if (g_stats) f->parkedNs[f->waitClass] += now_ns() - tw0;
         return;
     }
     for (unsigned spins = 0; *counter < value; spins++)
@@ -360,7 +365,8 @@ int xa_wait_counter_deadline(const volatile uint64_t* counter, uint64_t value, u
         Fiber* f = w->cur;
         f->pred = nullptr;
         int rc = 0;
-        if (f->spinNs) { const uint64_t t1 = now_ns() + f->spinNs; while (*counter < value && now_ns() < t1) _mm_pause(); if (*counter >= value) return 0; }
+        const uint64_t tw0 = g_stats ? now_ns() : 0;
+        if (f->spinNs) { const uint64_t t1 = now_ns() + f->spinNs; while (*counter < value && now_ns() < t1) _mm_pause(); if (*counter >= value) { if (g_stats) f->parkedNs[f->waitClass] += now_ns() - tw0; return 0; } }
         do
         {
             f->deadlineNs.store(deadline, std::memory_order_release);
@@ -371,6 +377,7 @@ int xa_wait_counter_deadline(const volatile uint64_t* counter, uint64_t value, u
         } while (*counter < value);
         f->waitCounter.store(nullptr, std::memory_order_release);
         f->deadlineNs.store(0, std::memory_order_release);
+        if (g_stats) f->parkedNs[f->waitClass] += now_ns() - tw0;
         return rc;
     }
     for (unsigned spins = 0; *counter < value; spins++)
