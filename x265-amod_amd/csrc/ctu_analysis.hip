@@ -40,6 +40,7 @@ using namespace xa_inter;
 static double g_stageMs[8];
 static const char* const g_stageName[8] = { "merge", "search", "rdInter", "rdIntra", "bidir", "copies", "intraSlice", "other" };
 static bool g_timing = getenv("X265AMD_TIMING") != nullptr;
+static std::atomic<uint64_t> g_aheadStat[2];      /* X265AMD_TIMING: searches started ahead, searches collected */
 static std::atomic<uint64_t> g_chainStat[4], g_chainTicks[8], g_cuStat[2][4][4];      /* [B / P][depth][skipped on the device, merge check on the host, search, intra try] */     /* X265AMD_TIMING: skip chains run, CUs they skipped, stops (not a skip / vector beyond what is published); the device's stage clock */
 struct StageTimer
 {
@@ -215,7 +216,7 @@ struct Analyzer
     x265amd_rd_params rp;
     int err;
     void* intraWs = nullptr;                /* the intra RD's working set, kept for the CUs of this CTU (intra_rd.hip) */
-    ~Analyzer() { xa_intra_ws_free(intraWs); }
+    ~Analyzer() { if (chain.ahead.on && xa_queue_aux(st)) (void)xa_stream_sync(xa_queue_aux(st)); xa_intra_ws_free(intraWs); }       /* (a search nobody collected still writes to this CTU's buffers) */
 
     /* ---- the device-resident motion map and the skip chain (inter_chain_dev.h) ---- */
     XaMapUnit* dCur = nullptr; const XaMapUnit* dCol = nullptr;
@@ -233,8 +234,12 @@ struct Analyzer
         int frNode[4]; bool frDirty[4];                 /* the host's recursion: node and "something below it was decided on the host" per depth */
         bool lastDevComplete = false;                   /* of the compress() call that has just returned: everything in its area is the device's */
         uint64_t runs = 0, skipped = 0;
-        XaMapped mSearch, mLuma; XaMappedOut mSearchOut; DevBuf dSearchScratch;     /* the fused search command (inter_search_dev.h) */
+        XaMapped mSearch[2], mLuma; XaMappedOut mSearchOut[2]; DevBuf dSearchScratch[2];     /* the fused search command (inter_search_dev.h): [0] the one the CU waits for, [1] one started ahead */
         bool lumaPushed = false;
+        /* A CU that cannot split has nothing between its merge check and its search: when the chain starts AT such a CU (the CU before it was not skipped, so this
+         * one probably is not either), its search runs beside the chain's merge check on a second queue (xa_queue_aux) and checkInterFused collects it.  A search
+         * nobody asks for -- the CU was skipped after all -- is waited for before its records are used again. */
+        struct Ahead { bool on = false; int x = 0, y = 0, depth = 0; XaSearchJob J; } ahead;
     } chain;
     bool fusedRd[4] = { false, false, false, false };      /* per depth: the 2Nx2N mode's rate-distortion came with its search (checkInterFused) */
     int buildNodes(int x, int y, int depth, int parent)
@@ -853,33 +858,30 @@ struct Analyzer
     /* checkInter_rd0_4(2Nx2N) of a CU of a P picture as ONE device command: the predictors' costs, the searches in every allowed reference picture, the choice, the
      * prediction with its SA8D and (rd 3+, one transform unit per plane) encodeResAndCalcRdInterCU -- inter_search_dev.h.  The host derives what depends on the maps (the
      * AMVP candidates, the search's extra candidates) and waits once.  false in `used`: not this configuration, the ordinary path runs */
-    int checkInterFused(int x, int y, int depth, uint32_t refMask, bool& used)
+    /* the fused search's record for a CU -- everything but the addresses of its buffers; false in `ok`: not this configuration */
+    int fusedBuild(int x, int y, int depth, uint32_t refMask, XaSearchJob& J, bool& ok)
     {
-        used = false;
+        ok = false;
         static const bool on = !(getenv("X265AMD_FUSED_SEARCH") && atoi(getenv("X265AMD_FUSED_SEARCH")) == 0);
         const int log2 = 6 - depth, size = 1 << log2;
         const int method = S->search_method & 0x7f;
         if (!on || I->is_inter_b || !xa_is_queue(st) || S->subpel_refine > 2 || (method != X265AMD_ME_DIA && method != X265AMD_ME_HEX && method != X265AMD_ME_STAR) ||
             I->num_ref_idx[0] < 1 || I->num_ref_idx[0] > XA_SEARCH_MAX_REFS || rp.rdoq_level || si->tu_max_depth_inter != 1 || si->use_dqp || A->rd_level < 3 || log2 > 5)
             return 0;
-        XA_HOSTPROF("an.checkInterFused (all)");
-        StageTimer timer_(1);
-        ModeDepth& d = md[depth];
-        Mode& inter = d.pred[PRED_2Nx2N];
-        inter.initCosts();
-        inter.predTile = predTile(depth, PRED_2Nx2N); inter.reconTile = reconTile(depth, PRED_2Nx2N);
+        if (!xa_me_device_bitsize(me) || !me) return 0;
         const size_t isz = sizeof(pixel);
-        if (!chain.mSearch.p && (chain.mSearch.alloc(sizeof(XaSearchJob)) != hipSuccess || chain.mLuma.alloc((size_t)numPics * 8) != hipSuccess ||
-                                 chain.mSearchOut.alloc(sizeof(XaSearchOut)) != hipSuccess ||
-                                 chain.dSearchScratch.alloc(8192 + (size_t)2 * XA_SEARCH_MAX_REFS * 4096 * isz + 1536 * (4 + isz) + 256) != hipSuccess))
-            return fail("search records");
+        for (int k = 0; k < 2; k++)
+            if (!chain.mSearch[k].p && (chain.mSearch[k].alloc(sizeof(XaSearchJob)) != hipSuccess || chain.mSearchOut[k].alloc(sizeof(XaSearchOut)) != hipSuccess ||
+                                        chain.dSearchScratch[k].alloc(8192 + (size_t)2 * XA_SEARCH_MAX_REFS * 4096 * isz + 1536 * (4 + isz) + 256) != hipSuccess))
+                return fail("search records");
+        if (!chain.mLuma.p && chain.mLuma.alloc((size_t)numPics * 8) != hipSuccess) return fail("search records");
         if (!chain.lumaPushed)
         {
             volatile uint64_t* t = (volatile uint64_t*)chain.mLuma.p;
             for (int i = 0; i < numPics; i++) t[i] = planes[3 * i];
             chain.lumaPushed = true;
         }
-        XaSearchJob J;
+        ModeDepth& d = md[depth];
         memset(&J, 0, sizeof(J));
         const int lagPixels = S->frame_parallel ? S->search_range : I->pic_height;
         x265amd_me_job guardJobs[2 * XA_SEARCH_MAX_REFS]; int guardPics[2 * XA_SEARCH_MAX_REFS]; int ng = 0;
@@ -921,7 +923,7 @@ struct Analyzer
         J.me_lambda = (uint64_t)floor(256.0 * is_lambda(qp));
         J.mvcost = (uint64_t)(uintptr_t)xa_me_device_mvcost(me, qp); J.bitsize = (uint64_t)(uintptr_t)xa_me_device_bitsize(me); J.me_tables = (uint64_t)(uintptr_t)xa_me_device_tables(me);
         J.planes = (uint64_t)(uintptr_t)dPlanes.p; J.luma_tab = (uint64_t)(uintptr_t)chain.mLuma.p;
-        J.pred_tile = tileAddr(inter.predTile); J.recon_tile = tileAddr(inter.reconTile); J.scratch = (uint64_t)(uintptr_t)chain.dSearchScratch.p; J.out = (uint64_t)(uintptr_t)chain.mSearchOut.p;
+        J.pred_tile = tileAddr(predTile(depth, PRED_2Nx2N)); J.recon_tile = tileAddr(reconTile(depth, PRED_2Nx2N));
         J.lambda = lambda; J.lambda2 = lambda2; J.psy_rd = psyRd;
         {
             static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
@@ -938,17 +940,79 @@ struct Analyzer
             J.skip_ctx = (l && l->pred_mode == X265AMD_MODE_SKIP) + (a && a->pred_mode == X265AMD_MODE_SKIP);
         }
         J.frac = d.cur.frac; memcpy(J.ctx, d.cur.ctx, X265AMD_CTX_STRIDE);
-        if (!xa_me_device_bitsize(me) || !me) return 0;
+        ok = true;
+        return 0;
+    }
+    /* the record goes to buffer set `k` and the command to `q`; nobody waits here */
+    int fusedSubmit(XaSearchJob& J, int k, void* q)
+    {
+        J.scratch = (uint64_t)(uintptr_t)chain.dSearchScratch[k].p; J.out = (uint64_t)(uintptr_t)chain.mSearchOut[k].p;
         {
-            volatile uint64_t* dd = (volatile uint64_t*)chain.mSearch.p; const uint64_t* ss = (const uint64_t*)&J;
+            volatile uint64_t* dd = (volatile uint64_t*)chain.mSearch[k].p; const uint64_t* ss = (const uint64_t*)&J;
             for (size_t i = 0; i < sizeof(J) / 8; i++) dd[i] = ss[i];
         }
-        XaSearchOut* o = (XaSearchOut*)chain.mSearchOut.p;
+        XaSearchOut* o = (XaSearchOut*)chain.mSearchOut[k].p;
         *(volatile uint32_t*)&o->valid = 0;
-        const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)chain.mSearch.p, 0, 0, 0, 1 };
-        xa_phase(XA_PH_ANALYZER);
-        if (xa_q_enqueue(st, XA_OP_INTER_SEARCH, &qa, sizeof(qa), 1, 0) != hipSuccess || xa_stream_sync(st) != hipSuccess) return fail("search command");
-        xa_phase(XA_PH_INTER_SEARCH);
+        const XaArgsJobs4 qa = { (uint64_t)(uintptr_t)chain.mSearch[k].p, 0, 0, 0, 1 };
+        if (xa_q_enqueue(q, XA_OP_INTER_SEARCH, &qa, sizeof(qa), 1, 0) != hipSuccess) return fail("search command");
+        return 0;
+    }
+    /* a CU that cannot split, at the head of a chain: its search starts now, beside the merge check (struct Chain::Ahead) */
+    int searchAhead(int x, int y, int depth)
+    {
+        static const bool on = !(getenv("X265AMD_SEARCH_AHEAD") && atoi(getenv("X265AMD_SEARCH_AHEAD")) == 0);
+        void* q = on ? xa_queue_aux(st) : nullptr;
+        if (!q) return 0;
+        if (chain.ahead.on) { chain.ahead.on = false; if (xa_stream_sync(q) != hipSuccess) return fail("search ahead"); }
+        bool ok = false;
+        if (fusedBuild(x, y, depth, 0, chain.ahead.J, ok)) return err;
+        if (!ok) return 0;
+        /* the second queue's workgroup reads what this CTU's queue has been sent so far (the plane table) */
+        if (xa_queue_follow(q, st) != hipSuccess || fusedSubmit(chain.ahead.J, 1, q)) return fail("search ahead");
+        chain.ahead.on = true; chain.ahead.x = x; chain.ahead.y = y; chain.ahead.depth = depth;
+        if (g_timing) g_aheadStat[0]++;
+        return 0;
+    }
+
+    /* checkInter_rd0_4(2Nx2N) of a CU of a P picture as ONE device command: the predictors' costs, the searches in every allowed reference picture, the choice, the
+     * prediction with its SA8D and (rd 3+, one transform unit per plane) encodeResAndCalcRdInterCU -- inter_search_dev.h.  The host derives what depends on the maps (the
+     * AMVP candidates, the search's extra candidates) and waits once.  false in `used`: not this configuration, the ordinary path runs */
+    int checkInterFused(int x, int y, int depth, uint32_t refMask, bool& used)
+    {
+        used = false;
+        XA_HOSTPROF("an.checkInterFused (all)");
+        StageTimer timer_(1);
+        ModeDepth& d = md[depth];
+        Mode& inter = d.pred[PRED_2Nx2N];
+        const int log2 = 6 - depth, size = 1 << log2;
+        XaSearchJob local;
+        const XaSearchJob* Jp = nullptr;
+        int set = 0;
+        if (chain.ahead.on)
+        {
+            /* a search started ahead: this CU's (every reference picture allowed, as here when nothing below restricts them), or one that was never asked for */
+            void* q = xa_queue_aux(st);
+            chain.ahead.on = false;
+            xa_phase(XA_PH_ANALYZER);
+            if (xa_stream_sync(q) != hipSuccess || xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) return fail("search ahead");
+            xa_phase(XA_PH_INTER_SEARCH);
+            if (chain.ahead.x == x && chain.ahead.y == y && chain.ahead.depth == depth && (!refMask || (refMask & ((1u << I->num_ref_idx[0]) - 1)) == ((1u << I->num_ref_idx[0]) - 1)))
+            { Jp = &chain.ahead.J; set = 1; if (g_timing) g_aheadStat[1]++; }
+        }
+        if (!Jp)
+        {
+            bool ok = false;
+            if (fusedBuild(x, y, depth, refMask, local, ok)) return err;
+            if (!ok) return 0;
+            xa_phase(XA_PH_ANALYZER);
+            if (fusedSubmit(local, 0, st) || xa_stream_sync(st) != hipSuccess) return fail("search command");
+            xa_phase(XA_PH_INTER_SEARCH);
+            Jp = &local;
+        }
+        const XaSearchJob& J = *Jp;
+        inter.initCosts();
+        inter.predTile = predTile(depth, PRED_2Nx2N); inter.reconTile = reconTile(depth, PRED_2Nx2N);
+        XaSearchOut* o = (XaSearchOut*)chain.mSearchOut[set].p;
         if (o->valid != 1 || o->best < 0 || o->best >= J.num_refs) return fail("search result");
         const XaSearchRef& R = J.ref[o->best];
         int8_t refs[2] = { (int8_t)R.ref_idx, -1 };
@@ -1567,6 +1631,7 @@ struct Analyzer
         /* Step 1: merge / skip candidates */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
+            if (chain.on && !mightSplit && chain.status[node] == 0 && si->slice_type == 1 && !(A->rect || A->amp) && searchAhead(x, y, depth)) return err;      /* (the conditions of step 3's checkInterFused) */
             if (chain.on && chainSkip(node, x, y, depth, devSkip)) return err;
             if (g_timing) g_cuStat[si->slice_type == 1][depth][devSkip ? 0 : 1]++;
             static const bool verify2 = getenv("X265AMD_CHAIN_VERIFY") && atoi(getenv("X265AMD_CHAIN_VERIFY")) >= 2;
@@ -2110,12 +2175,12 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             std::vector<volatile uint64_t*> done;   /* CTUs finished per row: counters the parked rows below wait on (xa_fiber.h) */
             volatile uint64_t* queuedRows;          /* rows that hold (or have held) a queue */
             std::atomic<int> firstErr{ X265AMD_OK };
-            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc; bool intraOnly, intraTry;
+            const XaRowHooks* hooks; int ctuW, ctuH; bool dumping; int poc; bool intraOnly, intraTry, pSlice;
             std::function<int(int, void*)> doCtu;
             explicit Frame(int rowsN) : done(rowsN) { for (auto& d : done) d = xa_counter_alloc(); queuedRows = xa_counter_alloc(); }
             ~Frame() { for (auto& d : done) xa_counter_free(d); xa_counter_free(queuedRows); }
         } F(ctuH);
-        F.hooks = hooks; F.ctuW = ctuW; F.ctuH = ctuH; F.dumping = dumping; F.poc = I->poc; F.doCtu = doCtu; F.intraOnly = si->slice_type == 2;
+        F.hooks = hooks; F.ctuW = ctuW; F.ctuH = ctuH; F.dumping = dumping; F.poc = I->poc; F.doCtu = doCtu; F.intraOnly = si->slice_type == 2; F.pSlice = si->slice_type == 1;
         F.intraTry = si->slice_type == 1 || (si->slice_type == 0 && A->b_intra);       /* pictures whose CUs try intra beside their inter modes */
         struct Row { Frame* f; int row; };
         std::vector<Row> rowsArg((size_t)ctuH);
@@ -2161,6 +2226,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             void* helper = (f.intraOnly && st && !own) ? xa_queue_try_acquire() : nullptr;
             void* helper2 = helper ? xa_queue_try_acquire() : nullptr;         /* and a third and a fourth: the 16x16 / 32x32 CUs' 2Nx2N evaluations beside their sub-CUs */
             void* helper3 = helper2 ? xa_queue_try_acquire() : nullptr;
+            /* P pictures: a second queue for the searches that start ahead of their CU's merge check (Analyzer::searchAhead) */
+            void* aux = (f.pSlice && st && !own) ? xa_queue_try_acquire() : nullptr;
+            if (aux) xa_queue_set_aux(st, aux);
             if (helper) xa_queue_set_helper(st, helper);
             if (helper2) xa_queue_set_helper(helper, helper2);
             if (helper3) xa_queue_set_helper(helper2, helper3);
@@ -2208,6 +2276,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
             }
             if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;
+            if (aux) { xa_queue_set_aux(st, nullptr); xa_queue_release_helper(aux); }
             if (helper3) { xa_queue_set_helper(helper2, nullptr); xa_queue_release_helper(helper3); }
             if (helper2) { xa_queue_set_helper(helper, nullptr); xa_queue_release_helper(helper2); }
             if (helper) { xa_queue_set_helper(st, nullptr); xa_queue_release_helper(helper); }
@@ -2245,6 +2314,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 "device ms: candidates %.1f, predictions + SA8D %.1f, choice %.1f, transform units %.1f, rate-distortion %.1f, placing %.1f, coder state %.1f (%llu CUs)\n", (unsigned long long)g_chainStat[0].load(),
                 (unsigned long long)g_chainStat[1].load(), (unsigned long long)g_chainStat[2].load(), (unsigned long long)g_chainStat[3].load(), g_chainTicks[0].load() / 1e5, g_chainTicks[1].load() / 1e5,
                 g_chainTicks[2].load() / 1e5, g_chainTicks[3].load() / 1e5, g_chainTicks[4].load() / 1e5, g_chainTicks[5].load() / 1e5, g_chainTicks[7].load() / 1e5, (unsigned long long)g_chainTicks[6].load());
+        fprintf(stderr, "x265amd: searches started ahead of their merge check so far: %llu, collected %llu\n", (unsigned long long)g_aheadStat[0].load(), (unsigned long long)g_aheadStat[1].load());
         for (int t = 0; t < 2; t++)
             fprintf(stderr, "x265amd: CUs of %s pictures so far by depth 0..3 (skipped on the device / merge check on the host / searched / intra try): %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu\n",
                     t ? "P" : "B", (unsigned long long)g_cuStat[t][0][0].load(), (unsigned long long)g_cuStat[t][0][1].load(), (unsigned long long)g_cuStat[t][0][2].load(), (unsigned long long)g_cuStat[t][0][3].load(),

@@ -691,6 +691,7 @@ struct XaQueue
     struct Ev { uint64_t wallNs, runNs; char kind; int op; };
     std::vector<Ev> log; bool logging = false; int logPoc = 0, logRow = 0;
     void* helper = nullptr;             /* a second queue the holder of this one may use beside it (xa_queue_set_helper) */
+    void* aux = nullptr;                /* another one, for the searches a row of a P picture starts ahead (xa_queue_set_aux) */
     uint32_t nextFlags = 0;             /* flags the next command gets on top of its own (xa_q_next_flags) */
     std::vector<void*> laterMapped;     /* pushed-record blocks that commands still in the queue read: back to the pool at the next synchronisation (xa_q_free_mapped_later) */
     void ev(char kind, int op)
@@ -1041,7 +1042,7 @@ void* xa_queue_acquire()
     }
     if (S.start() != 0) return nullptr;
     __atomic_fetch_add(&S.hosts[0].alive, 1, __ATOMIC_RELAXED);
-    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr;
+    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr; f->aux = nullptr;
     S.freeCount = S.freeCount - 1;
     S.refs++;
     xa_scratch_local_begin();           /* the calling thread is the one that uses the queue */
@@ -1062,7 +1063,7 @@ void* xa_queue_try_acquire()
     for (XaQueue& x : S.q) if (!x.busy) { freeN++; if (!f) f = &x; }
     if (!f || freeN <= spare) return nullptr;
     if (S.start() != 0) return nullptr;
-    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr;
+    f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr; f->aux = nullptr;
     S.freeCount = S.freeCount - 1;
     S.refs++;
     f->acquired = std::chrono::steady_clock::now();
@@ -1083,6 +1084,8 @@ void xa_queue_release_helper(void* st)
 }
 void xa_queue_set_helper(void* st, void* helper) { if (xa_is_queue(st)) as_queue(st)->helper = helper; }
 void* xa_queue_helper(void* st) { return xa_is_queue(st) ? as_queue(st)->helper : nullptr; }
+void xa_queue_set_aux(void* st, void* aux) { if (xa_is_queue(st)) as_queue(st)->aux = aux; }
+void* xa_queue_aux(void* st) { return xa_is_queue(st) ? as_queue(st)->aux : nullptr; }
 
 void xa_queue_log(void* st, int poc, int row)
 {

@@ -65,6 +65,8 @@ void* xa_queue_try_acquire();           /* a second queue for the holder of a fi
 void xa_queue_release_helper(void* st);
 void xa_queue_set_helper(void* st, void* helper);       /* the second queue rides on the first: whoever gets `st` finds it with xa_queue_helper */
 void* xa_queue_helper(void* st);
+void xa_queue_set_aux(void* st, void* aux);             /* a further queue riding on `st`, for its holder's own use (ctu_analysis.hip: searches started ahead) */
+void* xa_queue_aux(void* st);
 void xa_queue_log(void* st, int poc, int row);      /* X265AMD_QUEUE_LOG=poc,row: the command / wait timeline of that row goes to stderr when the queue is given back */
 hipError_t xa_stream_sync(void* st);
 hipError_t xa_stream_fence(void* st, int flags);
