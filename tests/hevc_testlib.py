@@ -3339,20 +3339,31 @@ def survey_clip(w, h, depth, cfg_id, first, count, gop=0):
     return frames
 
 
-# the reference command line shared by the full-size cases: a whole preset in CQP with only what the encoder object does not build switched off, frame-parallel rules
-FULL_CLI = ["--qp", "30", "--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut", "--keyint", "250", "--no-info", "--no-open-gop",
-            "--rc-lookahead", "5", "--lookahead-slices", "0", "--no-b-pyramid", "--wpp", "--frame-threads", "3", "--pools", "8"]
-FULL_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3, bframes=4)
-SLOW_TOOLS = dict(bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1)
+# The reference command line of the full-size cases: the preset in CQP as it comes -- adaptive GOPs (trellis), scene-cut detection, open GOPs, B pyramid, lookahead slices,
+# weighted prediction's analysis, the frame threads the reference picks for the machine (three here: frame-parallel rules).  --no-info leaves out the SEI NAL unit with
+# the reference build's version and option string.
+FULL_CLI = ["--qp", "30", "--no-info"]
+# what `--preset medium --qp 30` sets (source/common/param.cpp:140-330: x265_param_default; CQP switches AQ and cutree off, encoder.cpp), as x265amd_param fields
+FULL_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3, bframes=4,
+                 scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2, bOpenGOP=1, bBPyramid=1, lookaheadSlices=8, bEnableWeightedPred=1)
+# --preset slow on top of it (param.cpp:500-514)
+SLOW_TOOLS = dict(bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdLevel=4, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=3, searchMethod=3, maxNumReferences=4, limitModes=1,
+                  lookaheadDepth=25, lookaheadSlices=4)
 VERYSLOW_TOOLS = dict(bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3, rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=4,
                       maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0, limitModes=0)
+# cfg5 keeps the switches of round 3 until --weightb is coded (veryslow turns it on): everything else of the preset
+CFG5_CLI = ["--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut", "--keyint", "250", "--no-open-gop",
+            "--rc-lookahead", "5", "--lookahead-slices", "0", "--no-b-pyramid", "--wpp", "--frame-threads", "3", "--pools", "8"]
+CFG5_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3, bframes=4)
 # tag -> ((w, h), frames, depth, cfg_id of the clip, x265amd_param fields, the reference's command line in front of FULL_CLI)
 FULL_CASES = {
     "cfg3_2160p_slow/": ((3840, 2160), 3, 8, 3, dict(FULL_BASE, **SLOW_TOOLS), ["--preset", "slow"]),                    # BASELINE.json configs[2]
     "cfg4_2160p_main10/": ((3840, 2160), 3, 10, 4, dict(FULL_BASE), ["--preset", "medium"]),                              # configs[3]
-    "cfg5_4320p_veryslow_rd6/": ((7680, 4320), 2, 10, 5, dict(FULL_BASE, **VERYSLOW_TOOLS), ["--preset", "veryslow", "--rd", "6", "--bframes", "4"]),      # configs[4]
+    "cfg5_4320p_veryslow_rd6/": ((7680, 4320), 2, 10, 5, dict(CFG5_BASE, **VERYSLOW_TOOLS), ["--preset", "veryslow", "--rd", "6", "--bframes", "4"] + CFG5_CLI),      # configs[4]
     # rd 2 on a picture of 1080 rows: Analysis::complexityCheckCU is active (analysis.cpp:3536-3559, only for pictures of at least 1080 rows at rd 0-2)
     "fhd_rd2/": ((1920, 1080), 3, 8, 2, dict(FULL_BASE, rdLevel=2, bframes=1), ["--preset", "medium", "--rd", "2", "--bframes", "1"]),
+    # the bench's configuration over sixty frames: both re-seeds of the clip (frames 24 and 48: scene cuts, I pictures inside open GOPs) and ten mini-GOPs of the trellis
+    "fhd_medium_60/": ((1920, 1080), 60, 8, 2, dict(FULL_BASE), ["--preset", "medium"]),
 }
 
 
