@@ -200,9 +200,26 @@ def job_server_roofline(st, frames_payload_bytes, wall_s):
                                   "of": "the sum over the launch's commands of what each has to read and write once (counted on the device from its job records): blocks are read "
                                         "again by every command that evaluates them, so this is several times the 8d figure"},
             "per_command_kind": per_op,
+            "per_command_kind_traffic": command_traffic(),
             "note": "k_job_server is resident for the whole encode; the encoder is bound by the latency of the reference's serial decision chain (busy_frac: the share of the "
-                    "workgroups' resident time inside command bodies), not by bandwidth.  traffic: the PMC counter passes do not survive a resident kernel (profiles/collect.sh); "
-                    "the per-kernel counter figures of the batched kernels are under kernel_workload"}
+                    "workgroups' resident time inside command bodies), not by bandwidth.  traffic: the PMC counter passes serialise dispatches, which a resident kernel does not "
+                    "survive, so the launch itself cannot be counted; per_command_kind_traffic holds what the counters saw of its command kinds when the I picture of this clip "
+                    "was coded with every command as an ordinary launch of the same device code (profiles/collect_traffic.sh, profiles/r04_iframe_traffic.json)"}
+
+
+def command_traffic():
+    """profiles/r04_iframe_traffic.json reduced to {command kind: launches, HBM-side bytes by the counters (low: FETCH_SIZE + WRITE_SIZE as reported; high: FETCH_SIZE doubled,
+    the guide's gfx950 correction for wide requests), algorithmic bytes, ratio}: measured once on a GPU box with the job server off (every command an ordinary launch), not
+    during this run"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r04_iframe_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    out = {}
+    for name, r in t.get("kernels", {}).items():
+        if "command_kind" in r:
+            out[r["command_kind"]] = {k: r[k] for k in ("launches", "hbm_bytes_low", "hbm_bytes_high", "algorithmic_bytes", "traffic_over_algorithmic_low", "traffic_over_algorithmic_high") if k in r}
+    return out or None
 
 
 def usable_cores():
