@@ -5,7 +5,7 @@
 # reduced to profiles-style files under gpurun_out/prof_<tag>/.  usage: bash profiles/collect.sh <tag> [bench args]
 set -u
 TAG=${1:-final}; shift || true
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
