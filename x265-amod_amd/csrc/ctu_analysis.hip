@@ -40,7 +40,7 @@ using namespace xa_inter;
 static double g_stageMs[8];
 static const char* const g_stageName[8] = { "merge", "search", "rdInter", "rdIntra", "bidir", "copies", "intraSlice", "other" };
 static bool g_timing = getenv("X265AMD_TIMING") != nullptr;
-static std::atomic<uint64_t> g_aheadStat[2];      /* X265AMD_TIMING: searches started ahead, searches collected */
+static std::atomic<uint64_t> g_aheadStat[4];      /* X265AMD_TIMING: searches started ahead of a leaf's merge check, searches collected, started behind the merge check of a CU with sub-CUs, results the sub-CUs' restriction ruled out */
 static std::atomic<uint64_t> g_chainStat[4], g_chainTicks[8], g_cuStat[2][4][4];      /* [B / P][depth][skipped on the device, merge check on the host, search, intra try] */     /* X265AMD_TIMING: skip chains run, CUs they skipped, stops (not a skip / vector beyond what is published); the device's stage clock */
 struct StageTimer
 {
@@ -216,7 +216,7 @@ struct Analyzer
     x265amd_rd_params rp;
     int err;
     void* intraWs = nullptr;                /* the intra RD's working set, kept for the CUs of this CTU (intra_rd.hip) */
-    ~Analyzer() { if (chain.ahead.on && xa_queue_aux(st)) (void)xa_stream_sync(xa_queue_aux(st)); xa_intra_ws_free(intraWs); }       /* (a search nobody collected still writes to this CTU's buffers) */
+    ~Analyzer() { for (auto& a : chain.ahead) if (a.on && a.q) (void)xa_stream_sync(a.q); xa_intra_ws_free(intraWs); }       /* (a search nobody collected still writes to this CTU's buffers) */
 
     /* ---- the device-resident motion map and the skip chain (inter_chain_dev.h) ---- */
     XaMapUnit* dCur = nullptr; const XaMapUnit* dCol = nullptr;
@@ -234,12 +234,15 @@ struct Analyzer
         int frNode[4]; bool frDirty[4];                 /* the host's recursion: node and "something below it was decided on the host" per depth */
         bool lastDevComplete = false;                   /* of the compress() call that has just returned: everything in its area is the device's */
         uint64_t runs = 0, skipped = 0;
-        XaMapped mSearch[2], mLuma; XaMappedOut mSearchOut[2]; DevBuf dSearchScratch[2];     /* the fused search command (inter_search_dev.h): [0] the one the CU waits for, [1] one started ahead */
+        XaMapped mSearch[5], mLuma; XaMappedOut mSearchOut[5]; DevBuf dSearchScratch[5];     /* the fused search command (inter_search_dev.h): [0] the one the CU waits for, [1 + depth] one started ahead at that depth */
         bool lumaPushed = false;
         /* A CU that cannot split has nothing between its merge check and its search: when the chain starts AT such a CU (the CU before it was not skipped, so this
          * one probably is not either), its search runs beside the chain's merge check on a second queue (xa_queue_aux) and checkInterFused collects it.  A search
-         * nobody asks for -- the CU was skipped after all -- is waited for before its records are used again. */
-        struct Ahead { bool on = false; int x = 0, y = 0, depth = 0; XaSearchJob J; } ahead;
+         * nobody asks for -- the CU was skipped after all -- is waited for before its records are used again.
+         * A CU that CAN split runs its sub-CUs between the merge check and the search: its search starts behind the merge check on a third queue (every reference picture: the
+         * sub-CUs' restriction is not known yet) and is collected after them -- valid when the winner is a picture the restriction allows (the cheapest of all, first of
+         * equals, is then the cheapest of the allowed ones), else the search runs again. */
+        struct Ahead { bool on = false; int x = 0, y = 0; void* q = nullptr; XaSearchJob J; } ahead[4];
     } chain;
     bool fusedRd[4] = { false, false, false, false };      /* per depth: the 2Nx2N mode's rate-distortion came with its search (checkInterFused) */
     int buildNodes(int x, int y, int depth, int parent)
@@ -855,9 +858,6 @@ struct Analyzer
         return 0;
     }
 
-    /* checkInter_rd0_4(2Nx2N) of a CU of a P picture as ONE device command: the predictors' costs, the searches in every allowed reference picture, the choice, the
-     * prediction with its SA8D and (rd 3+, one transform unit per plane) encodeResAndCalcRdInterCU -- inter_search_dev.h.  The host derives what depends on the maps (the
-     * AMVP candidates, the search's extra candidates) and waits once.  false in `used`: not this configuration, the ordinary path runs */
     /* the fused search's record for a CU -- everything but the addresses of its buffers; false in `ok`: not this configuration */
     int fusedBuild(int x, int y, int depth, uint32_t refMask, XaSearchJob& J, bool& ok)
     {
@@ -870,10 +870,7 @@ struct Analyzer
             return 0;
         if (!xa_me_device_bitsize(me) || !me) return 0;
         const size_t isz = sizeof(pixel);
-        for (int k = 0; k < 2; k++)
-            if (!chain.mSearch[k].p && (chain.mSearch[k].alloc(sizeof(XaSearchJob)) != hipSuccess || chain.mSearchOut[k].alloc(sizeof(XaSearchOut)) != hipSuccess ||
-                                        chain.dSearchScratch[k].alloc(8192 + (size_t)2 * XA_SEARCH_MAX_REFS * 4096 * isz + 1536 * (4 + isz) + 256) != hipSuccess))
-                return fail("search records");
+        (void)isz;
         if (!chain.mLuma.p && chain.mLuma.alloc((size_t)numPics * 8) != hipSuccess) return fail("search records");
         if (!chain.lumaPushed)
         {
@@ -946,6 +943,9 @@ struct Analyzer
     /* the record goes to buffer set `k` and the command to `q`; nobody waits here */
     int fusedSubmit(XaSearchJob& J, int k, void* q)
     {
+        if (!chain.mSearch[k].p && (chain.mSearch[k].alloc(sizeof(XaSearchJob)) != hipSuccess || chain.mSearchOut[k].alloc(sizeof(XaSearchOut)) != hipSuccess ||
+                                    chain.dSearchScratch[k].alloc(8192 + (size_t)2 * XA_SEARCH_MAX_REFS * 4096 * sizeof(pixel) + 1536 * (4 + sizeof(pixel)) + 256) != hipSuccess))
+            return fail("search records");
         J.scratch = (uint64_t)(uintptr_t)chain.dSearchScratch[k].p; J.out = (uint64_t)(uintptr_t)chain.mSearchOut[k].p;
         {
             volatile uint64_t* dd = (volatile uint64_t*)chain.mSearch[k].p; const uint64_t* ss = (const uint64_t*)&J;
@@ -957,20 +957,24 @@ struct Analyzer
         if (xa_q_enqueue(q, XA_OP_INTER_SEARCH, &qa, sizeof(qa), 1, 0) != hipSuccess) return fail("search command");
         return 0;
     }
-    /* a CU that cannot split, at the head of a chain: its search starts now, beside the merge check (struct Chain::Ahead) */
-    int searchAhead(int x, int y, int depth)
+    /* a search started ahead of the point where the reference runs it (struct Chain::Ahead): beside the merge check of a CU that cannot split (leaf: the row's second
+     * queue), or behind the merge check of a CU whose sub-CUs come first (the third queue) */
+    int searchAhead(int x, int y, int depth, bool leaf)
     {
-        static const bool on = !(getenv("X265AMD_SEARCH_AHEAD") && atoi(getenv("X265AMD_SEARCH_AHEAD")) == 0);
-        void* q = on ? xa_queue_aux(st) : nullptr;
+        static const int on = getenv("X265AMD_SEARCH_AHEAD") ? atoi(getenv("X265AMD_SEARCH_AHEAD")) : 3;      /* bit 0: leaves, bit 1: CUs with sub-CUs */
+        if (!(on & (leaf ? 1 : 2))) return 0;
+        void* aux = xa_queue_aux(st);
+        void* q = leaf ? aux : (aux && xa_queue_aux(aux) ? xa_queue_aux(aux) : aux);
         if (!q) return 0;
-        if (chain.ahead.on) { chain.ahead.on = false; if (xa_stream_sync(q) != hipSuccess) return fail("search ahead"); }
+        Chain::Ahead& a = chain.ahead[depth];
+        if (a.on) { a.on = false; if (xa_stream_sync(a.q) != hipSuccess) return fail("search ahead"); }
         bool ok = false;
-        if (fusedBuild(x, y, depth, 0, chain.ahead.J, ok)) return err;
+        if (fusedBuild(x, y, depth, 0, a.J, ok)) return err;
         if (!ok) return 0;
-        /* the second queue's workgroup reads what this CTU's queue has been sent so far (the plane table) */
-        if (xa_queue_follow(q, st) != hipSuccess || fusedSubmit(chain.ahead.J, 1, q)) return fail("search ahead");
-        chain.ahead.on = true; chain.ahead.x = x; chain.ahead.y = y; chain.ahead.depth = depth;
-        if (g_timing) g_aheadStat[0]++;
+        /* the other queue's workgroup reads what this CTU's queue has been sent so far (the plane table) */
+        if (xa_queue_follow(q, st) != hipSuccess || fusedSubmit(a.J, 1 + depth, q)) return fail("search ahead");
+        a.on = true; a.x = x; a.y = y; a.q = q;
+        if (g_timing) g_aheadStat[leaf ? 0 : 2]++;
         return 0;
     }
 
@@ -988,16 +992,21 @@ struct Analyzer
         XaSearchJob local;
         const XaSearchJob* Jp = nullptr;
         int set = 0;
-        if (chain.ahead.on)
+        Chain::Ahead& ah = chain.ahead[depth];
+        if (ah.on)
         {
-            /* a search started ahead: this CU's (every reference picture allowed, as here when nothing below restricts them), or one that was never asked for */
-            void* q = xa_queue_aux(st);
-            chain.ahead.on = false;
+            /* a search started ahead at this depth: this CU's, or one that was never asked for (a leaf the chain skipped) */
+            ah.on = false;
             xa_phase(XA_PH_ANALYZER);
-            if (xa_stream_sync(q) != hipSuccess || xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) return fail("search ahead");
+            if (xa_stream_sync(ah.q) != hipSuccess || xa_stream_fence(st, XA_CMD_ACQUIRE) != hipSuccess) return fail("search ahead");
             xa_phase(XA_PH_INTER_SEARCH);
-            if (chain.ahead.x == x && chain.ahead.y == y && chain.ahead.depth == depth && (!refMask || (refMask & ((1u << I->num_ref_idx[0]) - 1)) == ((1u << I->num_ref_idx[0]) - 1)))
-            { Jp = &chain.ahead.J; set = 1; if (g_timing) g_aheadStat[1]++; }
+            if (ah.x == x && ah.y == y)
+            {
+                const XaSearchOut* ao = (const XaSearchOut*)chain.mSearchOut[1 + depth].p;
+                const bool winnerAllowed = ao->valid == 1 && ao->best >= 0 && ao->best < ah.J.num_refs && (!refMask || ((refMask >> ah.J.ref[ao->best].ref_idx) & 1u));
+                if (winnerAllowed) { Jp = &ah.J; set = 1 + depth; if (g_timing) g_aheadStat[1]++; }
+                else if (g_timing) g_aheadStat[3]++;
+            }
         }
         if (!Jp)
         {
@@ -1631,7 +1640,7 @@ struct Analyzer
         /* Step 1: merge / skip candidates */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
-            if (chain.on && !mightSplit && chain.status[node] == 0 && si->slice_type == 1 && !(A->rect || A->amp) && searchAhead(x, y, depth)) return err;      /* (the conditions of step 3's checkInterFused) */
+            if (chain.on && !mightSplit && chain.status[node] == 0 && si->slice_type == 1 && !(A->rect || A->amp) && searchAhead(x, y, depth, true)) return err;      /* (the conditions of step 3's checkInterFused) */
             if (chain.on && chainSkip(node, x, y, depth, devSkip)) return err;
             if (g_timing) g_cuStat[si->slice_type == 1][depth][devSkip ? 0 : 1]++;
             static const bool verify2 = getenv("X265AMD_CHAIN_VERIFY") && atoi(getenv("X265AMD_CHAIN_VERIFY")) >= 2;
@@ -1704,6 +1713,11 @@ struct Analyzer
                                                      tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
             if (b < 0) return err = b;
         }
+        /* the search of step 3 does not depend on the sub-CUs either, but for the reference pictures they restrict it to: it starts now on a queue of its own and is
+         * collected behind them (searchAhead; valid when its winner is an allowed picture) */
+        if (chain.on && mightSplit && !skipRecursion && mightNotSplit && (uint32_t)depth >= minDepth && !skipModes && si->slice_type == 1 && !(A->rect || A->amp) &&
+            searchAhead(x, y, depth, false))
+            return err;
         /* Step 2: the four sub-blocks in series */
         if (mightSplit && !skipRecursion)
         {
@@ -2228,7 +2242,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             void* helper3 = helper2 ? xa_queue_try_acquire() : nullptr;
             /* P pictures: a second queue for the searches that start ahead of their CU's merge check (Analyzer::searchAhead) */
             void* aux = (f.pSlice && st && !own) ? xa_queue_try_acquire() : nullptr;
+            void* aux2 = aux ? xa_queue_try_acquire() : nullptr;                /* and a third for the searches of CUs whose sub-CUs come first */
             if (aux) xa_queue_set_aux(st, aux);
+            if (aux2) xa_queue_set_aux(aux, aux2);
             if (helper) xa_queue_set_helper(st, helper);
             if (helper2) xa_queue_set_helper(helper, helper2);
             if (helper3) xa_queue_set_helper(helper2, helper3);
@@ -2276,6 +2292,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 if (f.hooks && c2 == ctuW - 1) f.hooks->after_row(f.hooks->ctx, row);
             }
             if (f.firstErr.load() != X265AMD_OK) *f.done[row] = (uint64_t)ctuW;
+            if (aux2) { xa_queue_set_aux(aux, nullptr); xa_queue_release_helper(aux2); }
             if (aux) { xa_queue_set_aux(st, nullptr); xa_queue_release_helper(aux); }
             if (helper3) { xa_queue_set_helper(helper2, nullptr); xa_queue_release_helper(helper3); }
             if (helper2) { xa_queue_set_helper(helper, nullptr); xa_queue_release_helper(helper2); }
@@ -2314,7 +2331,8 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                 "device ms: candidates %.1f, predictions + SA8D %.1f, choice %.1f, transform units %.1f, rate-distortion %.1f, placing %.1f, coder state %.1f (%llu CUs)\n", (unsigned long long)g_chainStat[0].load(),
                 (unsigned long long)g_chainStat[1].load(), (unsigned long long)g_chainStat[2].load(), (unsigned long long)g_chainStat[3].load(), g_chainTicks[0].load() / 1e5, g_chainTicks[1].load() / 1e5,
                 g_chainTicks[2].load() / 1e5, g_chainTicks[3].load() / 1e5, g_chainTicks[4].load() / 1e5, g_chainTicks[5].load() / 1e5, g_chainTicks[7].load() / 1e5, (unsigned long long)g_chainTicks[6].load());
-        fprintf(stderr, "x265amd: searches started ahead of their merge check so far: %llu, collected %llu\n", (unsigned long long)g_aheadStat[0].load(), (unsigned long long)g_aheadStat[1].load());
+        fprintf(stderr, "x265amd: searches started ahead so far: %llu beside a leaf's merge check, %llu behind the merge check of a CU with sub-CUs; collected %llu, ruled out by the sub-CUs' reference pictures %llu\n",
+                (unsigned long long)g_aheadStat[0].load(), (unsigned long long)g_aheadStat[2].load(), (unsigned long long)g_aheadStat[1].load(), (unsigned long long)g_aheadStat[3].load());
         for (int t = 0; t < 2; t++)
             fprintf(stderr, "x265amd: CUs of %s pictures so far by depth 0..3 (skipped on the device / merge check on the host / searched / intra try): %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu %llu/%llu/%llu/%llu\n",
                     t ? "P" : "B", (unsigned long long)g_cuStat[t][0][0].load(), (unsigned long long)g_cuStat[t][0][1].load(), (unsigned long long)g_cuStat[t][0][2].load(), (unsigned long long)g_cuStat[t][0][3].load(),

@@ -144,6 +144,7 @@ struct x265amd_encoder
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
     double uploadMs = 0;        /* X265AMD_TIMING: the callers' time in uploadPicture */
+    double firstInMs = -1;      /* X265AMD_HOLD_UNTIL_FLUSH: when the first picture came in (Pic::pubClockMs) */
     std::atomic<uint64_t> cpuPictureNs{ 0 }, cpuFilterNs{ 0 };      /* X265AMD_TIMING: CPU time of the picture threads and the filter threads (CLOCK_THREAD_CPUTIME_ID) */
     bool frameParallel = false;                         /* param.frameNumThreads > 1: the reference's frame-parallel rules (search.cpp:77-92, sao.cpp:264) */
     int refLagRows = 0;                                 /* FrameEncoder::m_refLagRows (frameencoder.cpp:170-175) */
@@ -2110,6 +2111,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     if (picIn)
     {
         PicP pic(new Pic);
+        if (e->firstInMs < 0) e->firstInMs = Pic::pubClockMs();
         pic->poc = e->frameCount++;
         const auto tu0 = std::chrono::steady_clock::now();
         int rc = e->uploadPicture(picIn, *pic);
@@ -2202,6 +2204,14 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         else if (earlyP && (q->type == TYPE_P || (earlyBref && q->type == TYPE_BREF)) && e->running <= e->frameThreads + earlyPMax) start(q);
     }
     };
+    static const bool holdUntilFlush = getenv("X265AMD_HOLD_UNTIL_FLUSH") != nullptr;      /* an experiment: no picture starts before the caller flushes (what the clip costs when every decision is made beforehand) */
+    if (holdUntilFlush)
+    {
+        if (!flushing) return 0;
+        while (!e->input.empty()) { const size_t before = e->input.size(); if (decide() != X265AMD_OK || admit()) return -1; if (e->input.size() >= before) break; }
+        static bool said = false;
+        if (!said) { said = true; fprintf(stderr, "x265amd: every decision made %.1f ms after the encoder's first picture came in; the pictures start now\n", Pic::pubClockMs() - e->firstInMs); }
+    }
     launch();
     /* flushing: the next mini-GOP is decided while the picture the caller will get next is still being coded */
     while (flushing && !e->input.empty())
