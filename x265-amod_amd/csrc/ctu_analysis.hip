@@ -1620,6 +1620,19 @@ struct Analyzer
         return 0;
     }
 
+    /* the intra try of a CU of a P / B picture starts on a queue of its own (intra_rd.hip: xa_intra_in_inter_begin_ws): 1 started, 0 not this configuration, < 0 an error */
+    int intraBegin(int x, int y, int depth)
+    {
+        const int log2 = 6 - depth;
+        ModeDepth& d = md[depth];
+        x265amd_rd_cu c;
+        memset(&c, 0, sizeof(c));
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.qp = (int8_t)qp;
+        memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
+        c.frac_bits = d.cur.frac;
+        return xa_intra_in_inter_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
+                                          tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+    }
     int compress(int x, int y, int depth, SplitData& splitOut, int node = 0)
     {
         ModeDepth& d = md[depth];
@@ -1635,12 +1648,23 @@ struct Analyzer
         { XA_HOSTPROF("an.initSubCU x13"); for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth); }
         d.pred[PRED_2Nx2N].sa8dCost = 0;                 /* what a parent reads under --limit-modes when 2Nx2N is not searched here */
         chain.frNode[depth] = node; chain.frDirty[depth] = false;
-        bool devSkip = false, childrenDev = true;
+        bool devSkip = false, childrenDev = true, intraBegun = false;
 
         /* Step 1: merge / skip candidates */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
-            if (chain.on && !mightSplit && chain.status[node] == 0 && si->slice_type == 1 && !(A->rect || A->amp) && searchAhead(x, y, depth, true)) return err;      /* (the conditions of step 3's checkInterFused) */
+            if (chain.on && !mightSplit && chain.status[node] == 0 && si->slice_type == 1 && !(A->rect || A->amp))
+            {
+                /* a CU that cannot split at the head of a chain: its search and its intra try start beside the merge check (the conditions of step 3's checkInterFused) */
+                if (searchAhead(x, y, depth, true)) return err;
+                static const bool specIntraOn = !(getenv("X265AMD_INTRA_AHEAD_LEAF") && atoi(getenv("X265AMD_INTRA_AHEAD_LEAF")) == 0);
+                if (specIntraOn && log2 != 6 && xa_is_queue(st))
+                {
+                    const int b = intraBegin(x, y, depth);
+                    if (b < 0) return err = b;
+                    intraBegun = b == 1;
+                }
+            }
             if (chain.on && chainSkip(node, x, y, depth, devSkip)) return err;
             if (g_timing) g_cuStat[si->slice_type == 1][depth][devSkip ? 0 : 1]++;
             static const bool verify2 = getenv("X265AMD_CHAIN_VERIFY") && atoi(getenv("X265AMD_CHAIN_VERIFY")) >= 2;
@@ -1702,15 +1726,9 @@ struct Analyzer
         }
         /* the intra try of step 3 depends on nothing that happens until then: when the CU is not skipped and a queue is to spare it starts now, beside the sub-CUs
          * and the motion searches (intra_rd.hip; a try the analysis does not get to is dropped) */
-        if (mightNotSplit && (uint32_t)depth >= minDepth && !skipModes && (!I->is_inter_b || A->b_intra) && log2 != 6 && xa_is_queue(st))
+        if (!intraBegun && mightNotSplit && (uint32_t)depth >= minDepth && !skipModes && (!I->is_inter_b || A->b_intra) && log2 != 6 && xa_is_queue(st))
         {
-            x265amd_rd_cu c;
-            memset(&c, 0, sizeof(c));
-            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.qp = (int8_t)qp;
-            memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
-            c.frac_bits = d.cur.frac;
-            const int b = xa_intra_in_inter_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
-                                                     tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+            const int b = intraBegin(x, y, depth);
             if (b < 0) return err = b;
         }
         /* the search of step 3 does not depend on the sub-CUs either, but for the reference pictures they restrict it to: it starts now on a queue of its own and is
