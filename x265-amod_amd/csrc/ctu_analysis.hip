@@ -1458,6 +1458,7 @@ struct Analyzer
     /* compressIntraCU (analysis.cpp:514-668) without analysis reuse / split-rd-skip */
     int compressIntra(int x, int y, int depth)
     {
+        XA_HOSTPROF("an.compressIntra (all, children included)");
         ModeDepth& d = md[depth];
         const int log2 = 6 - depth, size = 1 << log2;
         d.best = nullptr;

@@ -1340,6 +1340,7 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
         if (R.qJobs.alloc(8 * sizeof(x265amd_intra_nxn_job)) != hipSuccess || R.qOut.alloc(4 * sizeof(x265amd_intra_cu8_result)) != hipSuccess || !(R.qBlock = chain_block_get()))
             return xa_fail(X265AMD_EHIP, "intra rd: out of device memory");
     }
+    XA_HOSTPROF("quad8 (all but the wait)");
     R.st = (hipStream_t)stream; R.si = si; R.rp = rp; R.units = units; R.w4 = si->pic_width >> 2; R.src = h_src; R.rec = h_rec; R.stride = stride; R.cstride = cstride;
     R.log2 = 3; R.size = 8; R.depth = 3; R.qp = qp; R.err = 0; R.helper = helper;
     {
@@ -1357,7 +1358,8 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     memset(&R.cur, 0, sizeof(R.cur));
     memcpy(R.cur.ctx, ctx, X265AMD_CTX_COUNT);
     R.cur.frac = frac;
-    x265amd_cabac* coder = x265amd_cabac_open(si, units, 1);
+    x265amd_cabac* coder;
+    { XA_HOSTPROF("quad8 cabac_open"); coder = x265amd_cabac_open(si, units, 1); }
     if (!coder) return xa_fail(X265AMD_EINVAL, "intra rd: slice description");
     R.c = coder;
     x265amd_intra_nxn_job* jobs = static_cast<x265amd_intra_nxn_job*>(R.qJobs.p);
@@ -1387,8 +1389,11 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
             const int partSize = role == 1 ? 3 : 0;
             R.range[0] = partSize ? 2 : 3; R.range[1] = si->tu_log2_max;
             u0.part_size = (uint8_t)partSize;
+            {
+            XA_HOSTPROF("quad8 buildDevJob");
             if (role == 1) R.buildDevJob(nj, 3, rp->rd_level, tilesN[0], tilesN[1], (uint64_t)(uintptr_t)R.dCand.p, (uint64_t)(uintptr_t)R.dCoeffDev.p);
             else R.buildDevJob(nj, 0, rp->rd_level, tiles2[0], tiles2[1], (uint64_t)(uintptr_t)R.dCand2.p, (uint64_t)(uintptr_t)R.dCoeffDev2.p);
+            }
             nj.no_picture = role == 2;
             nj.chain = (uint64_t)(uintptr_t)chainRec; nj.peer = (uint64_t)(uintptr_t)&peers[i]; nj.cu_out = (uint64_t)(uintptr_t)&outs[i];
             nj.chain_token = token0 + i; nj.chain_role = (uint8_t)role; nj.chain_first = i == 0; nj.chain_index = (uint8_t)i;
@@ -1405,7 +1410,7 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
                     nj.win_dst[1 + pl] = split_recon + (4096 + (size_t)pl * 1024 + (size_t)(4 * (i >> 1)) * 32 + 4 * (i & 1)) * isz;
                 }
             }
-            memcpy(&jobs[2 * i + (role - 1)], &nj, sizeof(nj));
+            { XA_HOSTPROF("quad8 record push"); memcpy(&jobs[2 * i + (role - 1)], &nj, sizeof(nj)); }
         }
         u0.part_size = keepPart;
         outs[i].status = 0;
