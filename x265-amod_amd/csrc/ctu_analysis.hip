@@ -1467,7 +1467,7 @@ struct Analyzer
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
         /* a 16x16 CU: its 2Nx2N evaluation may start now on a queue of its own and be collected after the four sub-CUs (intra_rd.hip); the comparisons keep
          * the reference's order */
-        bool deferred = false;
+        bool deferred = false, deferredDone = false;
         if ((log2 == 4 || log2 == 5) && mightNotSplit && mightSplit)
         {
             Mode& m = d.pred[PRED_INTRA];
@@ -1509,8 +1509,14 @@ struct Analyzer
                 x265amd_intra_cu8_result r4[4];
                 const uint64_t tilesN[2] = { tileAddr(predTile(depth + 1, PRED_INTRA_NxN)), tileAddr(reconTile(depth + 1, PRED_INTRA_NxN)) };
                 const uint64_t tiles2[2] = { tileAddr(predTile(depth + 1, PRED_INTRA)), tileAddr(reconTile(depth + 1, PRED_INTRA)) };
+                /* while the chain runs the CU's own 2Nx2N evaluation (started on its queue above) is collected: its bits are counted on the host */
+                struct Between { Analyzer* a; int x, y, depth; bool done; int rc; } bt{ this, x, y, depth, false, 0 };
+                static const bool overlap = !(getenv("X265AMD_INTRA_COLLECT_EARLY") && atoi(getenv("X265AMD_INTRA_COLLECT_EARLY")) == 0);
                 const int qrc = xa_intra_quad8_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, x, y, qp, d.cur.ctx, d.cur.frac,
-                                                  tileAddr(split.reconTile), tilesN, tiles2, r4, &intraWs);
+                                                  tileAddr(split.reconTile), tilesN, tiles2, r4, &intraWs,
+                                                  deferred && overlap ? [](void* c) { Between* b = (Between*)c; b->rc = b->a->rdIntra(b->a->md[b->depth].pred[PRED_INTRA], b->x, b->y, b->depth, PRED_INTRA, true, 0); b->done = true; } : (void (*)(void*))nullptr,
+                                                  &bt);
+                if (bt.done) { if (bt.rc) return err; deferredDone = true; }
                 if (qrc < 0) return err = qrc;
                 if (qrc == 0)
                 {
@@ -1610,7 +1616,7 @@ struct Analyzer
             if (deferred)
             {
                 /* now the 2Nx2N result, then the comparisons in the reference's order */
-                if (rdIntra(d.pred[PRED_INTRA], x, y, depth, PRED_INTRA, true, 0)) return err;
+                if (!deferredDone && rdIntra(d.pred[PRED_INTRA], x, y, depth, PRED_INTRA, true, 0)) return err;
                 checkBestMode(d.pred[PRED_INTRA], depth);
                 addSplitFlagCost(*d.best, x, y, depth);
             }

@@ -1325,7 +1325,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
  * 2Nx2N evaluations.  results[4] in CU order.  Returns 0, 1 when the chain does not apply here (the caller takes the CUs one by one), or an error code. */
 int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
                       intptr_t stride, intptr_t cstride, int x, int y, int qp, const uint8_t* ctx, uint64_t frac, uint64_t split_recon, const uint64_t tilesN[2],
-                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws)
+                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws, void (*between)(void*), void* between_ctx)
 {
     static const bool on = !(getenv("X265AMD_INTRA_CHAIN") && atoi(getenv("X265AMD_INTRA_CHAIN")) == 0);
     if (!on || !ws || !*ws || !xa_is_queue(stream)) return 1;
@@ -1424,8 +1424,12 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     if (rc == X265AMD_OK && (x265amd_intra_nxn_list(helper, &jobs[1], 4, 2 * sizeof(x265amd_intra_nxn_job), &peers[0].out) != X265AMD_OK ||
                              x265amd_intra_nxn_list(stream, &jobs[0], 4, 2 * sizeof(x265amd_intra_nxn_job), (x265amd_intra_nxn_out*)R.dNxnOut.p) != X265AMD_OK))
         rc = xa_fail(X265AMD_EHIP, "intra rd: chain commands");
+    /* the chain runs by itself for a while: what the caller has to do meanwhile (collecting the enclosing CU's own evaluation: it uses this working set, whose fields for
+     * the chain are not needed any more -- the results are read from the mapped record below) */
+    if (rc == X265AMD_OK && between) between(between_ctx);
     if (rc == X265AMD_OK && xa_stream_sync(stream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "intra rd: chain");
     if (rc != X265AMD_OK) return rc;
+    outs = static_cast<x265amd_intra_cu8_result*>(static_cast<IntraRd*>(*ws)->qOut.p);
     for (int i = 0; i < 4; i++)
     {
         memcpy(&results[i], &outs[i], sizeof(results[i]));
