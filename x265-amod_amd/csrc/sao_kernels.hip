@@ -20,9 +20,17 @@ XA_DEV int sao_class(int v, int a, int b)            /* SAO::s_eoTable[sign + si
     return e == 2 ? 0 : (e < 2 ? e + 1 : e);
 }
 
+/* One workgroup per (CTU, plane).  The CTU's deblocked samples with a halo of one sample and its source samples are staged in LDS first -- sixteen samples per lane
+ * and load, rows aligned to sixteen (a CTU starts at a multiple of 32 samples in its plane) -- so that the nine neighbours of a sample are LDS reads instead of nine
+ * one-sample loads from the picture (the first form of this kernel: 95 us for a luma CTU, all of it load latency; this one: see profiles/).  Then a lane per sample as
+ * before: the four edge classes' sums and counts in registers, the band class into a histogram per wavefront. */
+constexpr int kSaoTileW = 64 + 32;              /* 16 samples of margin on either side keep every row's loads aligned; only one of each is read */
 __global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, int32_t* offsetOrg)
 {
     __shared__ int sCnt[5 * 32], sOrg[5 * 32];
+    __shared__ int sBand[4][2][32];
+    __shared__ __attribute__((aligned(16))) pixel sRec[66 * kSaoTileW];
+    __shared__ __attribute__((aligned(16))) pixel sSrc[64 * 64];
     const int ctuW = (P.width + 63) >> 6;
     const int plane = blockIdx.y, ctu = (P.ctuRow0 + (int)blockIdx.x / P.ctuCols) * ctuW + P.ctuCol0 + (int)blockIdx.x % P.ctuCols;
     const int cx = ctu % ctuW, cy = ctu / ctuW;
@@ -34,6 +42,37 @@ __global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, 
     const pixel* r0 = P.rec[plane] + (long)tpely * st + lpelx;
     const pixel* f0 = P.fenc[plane] + (long)tpely * st + lpelx;
     for (int i = threadIdx.x; i < 5 * 32; i += blockDim.x) { sCnt[i] = 0; sOrg[i] = 0; }
+    (&sBand[0][0][0])[threadIdx.x] = 0;            /* 4 x 2 x 32 = the workgroup's 256 lanes */
+    {
+        /* rows tpely - 1 .. tpely + ch of the deblocked plane, samples lpelx - 16 .. lpelx + cw + 15 as far as they lie inside the picture (what lies outside is never
+         * classified, and a caller's planes need no margins), and the CTU's source samples: chunks of sixteen samples.  Whether a chunk is sixteen-byte aligned in memory
+         * depends on the plane's origin: the access type says "unaligned", the hardware takes either */
+        constexpr int kChunk = 16;
+        struct __attribute__((packed, aligned(1))) Chunk { pixel v[kChunk]; };
+        const int chunksPerRow = (cw + 2 * kChunk) / kChunk, rows = ch + 2;
+        for (int i = threadIdx.x; i < chunksPerRow * rows; i += blockDim.x)
+        {
+            const int y = i / chunksPerRow, c = i - y * chunksPerRow;
+            const int gy = tpely + y - 1, gx0 = lpelx + (c - 1) * kChunk;
+            if (gy < 0 || gy >= picH) continue;                     /* a row outside the picture is never looked at (aboveUnavail, endYedge) */
+            const pixel* src = r0 + (long)(y - 1) * st + (c - 1) * kChunk;
+            if (gx0 >= 0 && gx0 + kChunk <= picW) *reinterpret_cast<Chunk*>(&sRec[y * kSaoTileW + c * kChunk]) = *reinterpret_cast<const Chunk*>(src);
+            else
+                for (int k = 0; k < kChunk; k++) if (gx0 + k >= 0 && gx0 + k < picW) sRec[y * kSaoTileW + c * kChunk + k] = src[k];      /* nor is a column outside it (x0e, endXedge) */
+        }
+        const int srcChunks = cw / kChunk;          /* cw is a multiple of 4 (widths are multiples of 8); the tail below */
+        for (int i = threadIdx.x; i < srcChunks * ch; i += blockDim.x)
+        {
+            const int y = i / srcChunks, c = i - y * srcChunks;
+            *reinterpret_cast<Chunk*>(&sSrc[y * 64 + c * kChunk]) = *reinterpret_cast<const Chunk*>(f0 + (long)y * st + c * kChunk);
+        }
+        const int tail = cw - srcChunks * kChunk;
+        for (int i = threadIdx.x; i < tail * ch; i += blockDim.x)
+        {
+            const int y = i / tail, x = srcChunks * kChunk + (i - y * tail);
+            sSrc[y * 64 + x] = f0[(long)y * st + x];
+        }
+    }
     __syncthreads();
     const bool atRight = rpelx == picW, atBottom = bpely == picH;
     const int aboveUnavail = !tpely;
@@ -46,43 +85,49 @@ __global__ __launch_bounds__(256) void k_sao_stats(SaoPlanes P, int32_t* count, 
 #pragma unroll
         for (int c = 0; c < 5; c++) { cnt[t][c] = 0; org[t][c] = 0; }
     const int total = cw * ch, rounds = (total + (int)blockDim.x - 1) / (int)blockDim.x;
+    constexpr int TS = kSaoTileW;
     for (int it = 0; it < rounds; it++)         /* uniform trip count: the band step uses wave-wide operations */
     {
         const int i = it * blockDim.x + threadIdx.x;
         const bool live = i < total;
         const int y = live ? i / cw : 0, x = live ? i - y * cw : cw;      /* x = cw lies outside every region */
-        const pixel* r = r0 + (long)y * st + (live ? x : 0);
-        const int v = r[0], d = live ? (int)f0[(long)y * st + x] - v : 0;
-        /* band offset: neighbouring samples mostly share a band, so the wave adds per distinct band, not per lane */
+        const pixel* r = &sRec[(y + 1) * TS + 16 + (live ? x : 0)];
+        const int v = r[0], d = live ? (int)sSrc[y * 64 + x] - v : 0;
+        /* band offset: a histogram per wavefront in LDS, a pair of LDS atomics per sample (lanes of a wavefront that hit the same band are serialised by the LDS, a
+         * hundred cycles at worst; the loop over the wave's distinct bands this replaces cost six microseconds a round on noisy content) */
+        if (x < endXfull && y < endYfull)
         {
-            const int band = (x < endXfull && y < endYfull) ? v >> (XA_DEPTH - 5) : -1;
-            uint64_t todo = __ballot(band >= 0);
-            while (todo)
-            {
-                const int b = __shfl(band, __ffsll((long long)todo) - 1, 64);
-                const uint64_t m = __ballot(band == b);
-                const int sum = xa_wave_sum(band == b ? d : 0);
-                if ((threadIdx.x & 63) == 0) { atomicAdd(&sCnt[4 * 32 + b], __popcll(m)); atomicAdd(&sOrg[4 * 32 + b], sum); }
-                todo &= ~m;
-            }
+            const int band = v >> (XA_DEPTH - 5);
+            atomicAdd(&sBand[threadIdx.x >> 6][0][band], 1);
+            atomicAdd(&sBand[threadIdx.x >> 6][1][band], d);
         }
         const bool inXe = x >= x0e && x < endXedge, inYe = y >= aboveUnavail && y < endYedge;
         int cls;
 #define ACC(t, c) { cls = (c); _Pragma("unroll") for (int k = 0; k < 5; k++) if (cls == k) { cnt[t][k]++; org[t][k] += d; } }
         if (inXe && y < ch - 4 + po) ACC(0, sao_class(v, r[-1], r[1]))
-        if (x < endXfull && inYe) ACC(1, sao_class(v, r[-st], r[st]))
+        if (x < endXfull && inYe) ACC(1, sao_class(v, r[-TS], r[TS]))
         if (inXe && inYe)
         {
-            ACC(2, sao_class(v, r[-st - 1], r[st + 1]))
-            ACC(3, sao_class(v, r[-st + 1], r[st - 1]))
+            ACC(2, sao_class(v, r[-TS - 1], r[TS + 1]))
+            ACC(3, sao_class(v, r[-TS + 1], r[TS - 1]))
         }
 #undef ACC
     }
+    /* the edge classes: summed over the wavefront first (256 lanes adding to the same twenty words one by one is twenty microseconds of LDS serialisation) */
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int c = 0; c < 5; c++)
-            if (cnt[t][c]) { atomicAdd(&sCnt[t * 32 + c], cnt[t][c]); atomicAdd(&sOrg[t * 32 + c], org[t][c]); }
+        {
+            const int cs = xa_wave_sum(cnt[t][c]), os = xa_wave_sum(org[t][c]);
+            if ((threadIdx.x & 63) == 0 && cs) { atomicAdd(&sCnt[t * 32 + c], cs); atomicAdd(&sOrg[t * 32 + c], os); }
+        }
+    __syncthreads();
+    if (threadIdx.x < 32)
+    {
+        sCnt[4 * 32 + threadIdx.x] = sBand[0][0][threadIdx.x] + sBand[1][0][threadIdx.x] + sBand[2][0][threadIdx.x] + sBand[3][0][threadIdx.x];
+        sOrg[4 * 32 + threadIdx.x] = sBand[0][1][threadIdx.x] + sBand[1][1][threadIdx.x] + sBand[2][1][threadIdx.x] + sBand[3][1][threadIdx.x];
+    }
     __syncthreads();
     const size_t base = ((size_t)ctu * 3 + plane) * 5 * 32;
     for (int i = threadIdx.x; i < 5 * 32; i += blockDim.x) { count[base + i] = sCnt[i]; offsetOrg[base + i] = sOrg[i]; }
