@@ -1935,10 +1935,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
             int r = x265amd_sao_apply_rows_cols(st, recP, finP, stride, cstride, W, H, (const x265amd_sao_ctu*)dPar.p, k, k + 1, x0, newX);
             if (r != X265AMD_OK) return r;
         }
-        int r = x265amd_extend_border_band(st, fin + org[0], stride, W, H, marginX, marginY, y0, y1, x0, newX, x0 == 0, newX == W);
-        if (r == X265AMD_OK) r = x265amd_extend_border_band(st, fin + org[1], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2, x0 / 2, newX / 2, x0 == 0, newX == W);
-        if (r == X265AMD_OK) r = x265amd_extend_border_band(st, fin + org[2], cstride, W / 2, H / 2, marginX / 2, marginY / 2, y0 / 2, y1 / 2, x0 / 2, newX / 2, x0 == 0, newX == W);
-        return r;
+        return xa_extend_border_band_420(st, fin + org[0], fin + org[1], fin + org[2], stride, cstride, W, H, marginX, marginY, y0, y1, x0, newX, x0 == 0, newX == W);
     };
     auto limitOf = [&](const std::vector<int>& an, int r) -> int {
         int lim = an[r] == ctuW ? ctuW : an[r] - 1;
@@ -1984,10 +1981,12 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
             {
                 rc = x265amd_deblock_units_rect(&si, &info, pic.units.data(), pic.motion.data(), dbu, y4b, y4e, x4b, x4e);
                 if (rc != X265AMD_OK) break;
-                if (hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
+                /* the edge records are read where the host has just written them (mapped memory: no copy, no launch for it) */
+                static const bool dbCopy = getenv("X265AMD_DEBLOCK_UNITS_COPY") && atoi(getenv("X265AMD_DEBLOCK_UNITS_COPY")) != 0;
+                if (dbCopy && hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
                                      sizeof(x265amd_deblock_unit) * (size_t)(x4e - x4b), (size_t)(y4e - y4b), hipMemcpyHostToDevice, st) != hipSuccess)
                 { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
-                rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, (const x265amd_deblock_unit*)dDb.p, 0, 0, 0, 0, 0, 3, y4b, y4e, c0, c1);
+                rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, 0, 0, 0, 0, 0, 3, y4b, y4e, c0, c1);
                 if (rc != X265AMD_OK) break;
             }
             if (sao)

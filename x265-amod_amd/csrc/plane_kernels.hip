@@ -55,6 +55,36 @@ __global__ __launch_bounds__(256) void k_extend_band(pixel* pic, long stride, in
     for (int x = from + (int)threadIdx.x; x < to; x += blockDim.x) dst[x] = src[min(max(x, 0), width - 1)];
 }
 
+/* the same for the three planes of a 4:2:0 picture in one launch (blockIdx.y: the plane; the chroma planes have half the lines, columns and margins) */
+struct ExtendBand3 { pixel* pic[3]; long stride[3]; int width[3], height[3], marginX[3], marginY[3], y0[3], y1[3], xa[3], xb[3]; int doLeft, doRight; };
+__global__ __launch_bounds__(256) void k_extend_band3(ExtendBand3 E)
+{
+    const int p = blockIdx.y;
+    pixel* pic = E.pic[p];
+    const long stride = E.stride[p];
+    const int width = E.width[p], height = E.height[p], marginX = E.marginX[p], marginY = E.marginY[p], y0 = E.y0[p], y1 = E.y1[p], xa = E.xa[p], xb = E.xb[p];
+    const int lines = (y1 - y0) + (y1 == height ? marginY : 0) + (y0 == 0 ? marginY : 0);
+    if ((int)blockIdx.x >= lines) return;
+    int y = y0 + (int)blockIdx.x;
+    const int bottomLines = y1 == height ? marginY : 0;
+    if (y >= y1 + bottomLines) y = -1 - (y - y1 - bottomLines);
+    if (y >= 0 && y < y1)
+    {
+        pixel* row = pic + (long)y * stride;
+        const pixel l = row[0], r = row[width - 1];
+        for (int i = threadIdx.x; i < marginX; i += blockDim.x)
+        {
+            if (E.doLeft) row[-marginX + i] = l;
+            if (E.doRight) row[width + i] = r;
+        }
+        return;
+    }
+    const pixel* src = pic + (long)(y < 0 ? 0 : height - 1) * stride;
+    pixel* dst = pic + (long)y * stride;
+    const int from = (E.doLeft && xa == 0) ? -marginX : xa, to = (E.doRight && xb == width) ? width + marginX : xb;
+    for (int x = from + (int)threadIdx.x; x < to; x += blockDim.x) dst[x] = src[min(max(x, 0), width - 1)];
+}
+
 __global__ __launch_bounds__(256) void k_weight_plane(const pixel* src, pixel* dst, long stride, int width, int height, int marginX, int marginY,
                                                       int w0, int round, int shift, int offset)
 {
@@ -99,6 +129,30 @@ extern "C" int x265amd_extend_border_band(void* stream, x265amd_pixel* d_pic, in
     const int lines = (y_end - y_begin) + (y_end == height ? marginY : 0) + (y_begin == 0 ? marginY : 0);
     hipLaunchKernelGGL(k_extend_band, dim3(lines), dim3(256), 0, (hipStream_t)stream, (pixel*)d_pic, (long)stride, width, height, marginX, marginY, y_begin, y_end, x_begin, x_end,
                        left, right);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
+/* x265amd_extend_border_band for the three planes of a 4:2:0 picture (luma geometry given; chroma: half of everything) in ONE launch: the filter thread of a picture
+ * calls this per finished unit (csrc/encoder_api.hip: finishCols) */
+int xa_extend_border_band_420(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride, int width, int height, int marginX, int marginY,
+                              int y_begin, int y_end, int x_begin, int x_end, int left, int right)
+{
+    if (!d_y || !d_u || !d_v || width <= 0 || height <= 0 || marginX < 0 || marginY < 0 || y_begin < 0 || y_begin >= y_end || y_end > height || x_begin < 0 || x_begin >= x_end || x_end > width ||
+        ((width | height | marginX | marginY | y_begin | y_end | x_begin | x_end) & 1))
+        return xa_fail(X265AMD_EINVAL, "xa_extend_border_band_420: bad arguments");
+    ExtendBand3 E;
+    for (int p = 0; p < 3; p++)
+    {
+        const int sh = p ? 1 : 0;
+        E.pic[p] = (pixel*)(p == 0 ? d_y : (p == 1 ? d_u : d_v)); E.stride[p] = (long)(p ? cstride : stride);
+        E.width[p] = width >> sh; E.height[p] = height >> sh; E.marginX[p] = marginX >> sh; E.marginY[p] = marginY >> sh;
+        E.y0[p] = y_begin >> sh; E.y1[p] = y_end >> sh; E.xa[p] = x_begin >> sh; E.xb[p] = x_end >> sh;
+    }
+    E.doLeft = left; E.doRight = right;
+    const int lines = (y_end - y_begin) + (y_end == height ? marginY : 0) + (y_begin == 0 ? marginY : 0);
+    hipLaunchKernelGGL(k_extend_band3, dim3(lines, 3), dim3(256), 0, (hipStream_t)stream, E);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     return X265AMD_OK;
