@@ -106,17 +106,38 @@ XA_DEV bool db_luma_segment(int m[4][8], int bs, int qp, int betaOffset, int tcO
     return true;
 }
 
+template<int DIR> XA_DEV void db_edge(const DbParams& P, int x4, int y4);
+
 template<int DIR>
 __global__ __launch_bounds__(256) void k_deblock(DbParams P)
 {
     /* DIR 0: thread = (unit row y4, edge column ex), x4 = 2 ex; DIR 1: thread = (edge row ey, unit column x4), y4 = 2 ey */
-    const int w4 = P.width >> 2, h4 = P.height >> 2;
+    const int w4 = P.width >> 2;
     const int nx = DIR == 0 ? (w4 >> 1) : w4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int iy = t / nx, ix = t - iy * nx;
-    const int x4 = DIR == 0 ? 2 * ix : ix, y4 = P.y4Begin + (DIR == 0 ? iy : 2 * iy);
+    db_edge<DIR>(P, DIR == 0 ? 2 * ix : ix, P.y4Begin + (DIR == 0 ? iy : 2 * iy));
+}
+
+/* A unit of a few CTUs (what the filter thread of a picture coded in parallel launches per sweep: csrc/encoder_api.hip, filterRowsCols) by ONE workgroup: its vertical
+ * edges, a barrier, its horizontal edges -- one launch instead of two, and no ordering between workgroups to wait for.  The same edges in the same order as the two
+ * kernels above. */
+__global__ __launch_bounds__(256) void k_deblock_unit(DbParams P)
+{
+    const int rows = P.y4End - P.y4Begin;
+    const int vx0 = (P.xvBegin + 1) & ~1, nvx = P.xvEnd > vx0 ? (P.xvEnd - vx0 + 1) >> 1 : 0;         /* even unit columns in [xvBegin, xvEnd) */
+    for (int t = threadIdx.x; t < nvx * rows; t += blockDim.x) { const int iy = t / nvx, ix = t - iy * nvx; db_edge<0>(P, vx0 + 2 * ix, P.y4Begin + iy); }
+    __threadfence_block();
+    __syncthreads();
+    const int nhx = P.xhEnd - P.xhBegin, hrows = rows >> 1;
+    for (int t = threadIdx.x; t < nhx * hrows; t += blockDim.x) { const int iy = t / nhx, ix = t - iy * nhx; db_edge<1>(P, P.xhBegin + ix, P.y4Begin + 2 * iy); }
+}
+
+template<int DIR> XA_DEV void db_edge(const DbParams& P, int x4, int y4)
+{
+    const int w4 = P.width >> 2, h4 = P.height >> 2;
     if (y4 >= h4 || y4 >= P.y4End || (DIR == 0 ? x4 == 0 : y4 == 0)) return;
-    if (DIR == 0 ? (x4 < P.xvBegin || x4 >= P.xvEnd) : (x4 < P.xhBegin || x4 >= P.xhEnd)) return;
+    if (DIR == 0 ? (x4 < P.xvBegin || x4 >= P.xvEnd || x4 >= w4) : (x4 < P.xhBegin || x4 >= P.xhEnd || x4 >= w4)) return;
     const x265amd_deblock_unit q = P.units[y4 * w4 + x4];
     const x265amd_deblock_unit p = P.units[DIR == 0 ? y4 * w4 + x4 - 1 : (y4 - 1) * w4 + x4];
     const int bs = db_strength(q, p, q.flags & (DIR ? X265AMD_DB_TU_TOP : X265AMD_DB_TU_LEFT), q.flags & (DIR ? X265AMD_DB_PU_TOP : X265AMD_DB_PU_LEFT));
@@ -205,6 +226,14 @@ extern "C" int x265amd_deblock_rows_cols(void* stream, x265amd_pixel* d_y, x265a
     P.bypassEnabled = bypassEnabled; P.y4Begin = y4_begin; P.y4End = y4_end;
     P.xvBegin = 16 * ctu_col_begin + 1; P.xvEnd = 16 * ctu_col_end + 1; P.xhBegin = 16 * ctu_col_begin; P.xhEnd = 16 * ctu_col_end;
     const int w4 = width >> 2, h4 = y4_end - y4_begin;
+    static const bool fuse = !(getenv("X265AMD_DEBLOCK_FUSED") && atoi(getenv("X265AMD_DEBLOCK_FUSED")) == 0);
+    if (fuse && passes == 3 && ctu_col_end - ctu_col_begin <= 8)
+    {
+        hipLaunchKernelGGL(k_deblock_unit, dim3(1), dim3(256), 0, (hipStream_t)stream, P);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+        return X265AMD_OK;
+    }
     if (passes & 1)
     {
         const int n = (w4 >> 1) * h4;

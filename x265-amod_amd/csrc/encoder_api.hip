@@ -1916,6 +1916,9 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
     auto lap = [&](double& acc) { if (!timing) return; const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(n - tLast).count(); tLast = n; };
     struct Report { const bool& on; double& w; double& k; int& n; int& sw; int poc; ~Report() { if (on) fprintf(stderr, "x265amd: filter units of poc %d: %d units in %d sweeps, %.1f ms waiting for the analysis, %.1f ms filtering\n", poc, n, sw, w, k); } } report{ timing, tWait, tWork, numUnits, numSweeps, pic.poc };
     /* a picture nobody references is waited for by nobody: whole rows */
+    /* the offsets' parameters are read by the kernel where the host wrote them (mapped memory: device memory behind the BAR unless X265AMD_PUSH_RECORDS=0 put the pools
+     * into host memory, where a read per sample would cross PCIe: then they are copied as before) */
+    static const bool parCopy = (getenv("X265AMD_SAO_PARAMS_COPY") && atoi(getenv("X265AMD_SAO_PARAMS_COPY")) != 0) || (getenv("X265AMD_PUSH_RECORDS") && atoi(getenv("X265AMD_PUSH_RECORDS")) == 0);
     static const int minChunkEnv = getenv("X265AMD_FILTER_CHUNK") ? atoi(getenv("X265AMD_FILTER_CHUNK")) : 0;
     const int minChunk = pic.type == TYPE_B ? ctuW : (minChunkEnv > 0 ? minChunkEnv : 2);
     /* the last rows are where a chain of pictures waits for each other (they finish last, and cut CTUs make the last row the slowest): every CTU of them at once */
@@ -1932,7 +1935,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
         const int y0 = k * 64, y1 = std::min(H, y0 + 64);
         if (sao)
         {
-            int r = x265amd_sao_apply_rows_cols(st, recP, finP, stride, cstride, W, H, (const x265amd_sao_ctu*)dPar.p, k, k + 1, x0, newX);
+            int r = x265amd_sao_apply_rows_cols(st, recP, finP, stride, cstride, W, H, parCopy ? (const x265amd_sao_ctu*)dPar.p : (const x265amd_sao_ctu*)hPar.p, k, k + 1, x0, newX);
             if (r != X265AMD_OK) return r;
         }
         return xa_extend_border_band_420(st, fin + org[0], fin + org[1], fin + org[2], stride, cstride, W, H, marginX, marginY, y0, y1, x0, newX, x0 == 0, newX == W);
@@ -2012,7 +2015,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
                 if (rc != X265AMD_OK) break;
                 const size_t off = (size_t)u.r * ctuW + u.c0, n = (size_t)(u.c1 - u.c0);
                 memcpy((x265amd_sao_ctu*)hPar.p + off, sparams.data() + off, sizeof(x265amd_sao_ctu) * n);
-                if (hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + off, (const x265amd_sao_ctu*)hPar.p + off, sizeof(x265amd_sao_ctu) * n, hipMemcpyHostToDevice, st) != hipSuccess)
+                if (parCopy && hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + off, (const x265amd_sao_ctu*)hPar.p + off, sizeof(x265amd_sao_ctu) * n, hipMemcpyHostToDevice, st) != hipSuccess)
                 { rc = xa_fail(X265AMD_EHIP, "encoder: sao upload"); break; }
             }
             if (rc != X265AMD_OK) break;
