@@ -1854,6 +1854,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
 static hipError_t streamWaitPolite(hipStream_t st, hipEvent_t ev)
 {
     static const bool off = getenv("X265AMD_FILTER_SPIN") && atoi(getenv("X265AMD_FILTER_SPIN")) != 0;
+    static const int spinUs = getenv("X265AMD_FILTER_SPIN_US") ? atoi(getenv("X265AMD_FILTER_SPIN_US")) : 30;
     if (off || !ev) return hipStreamSynchronize(st);
     hipError_t e = hipEventRecord(ev, st);
     if (e != hipSuccess) return e;
@@ -1862,7 +1863,7 @@ static hipError_t streamWaitPolite(hipStream_t st, hipEvent_t ev)
     {
         e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
-        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) { for (int k = 0; k < 16; k++) __builtin_ia32_pause(); continue; }
+        if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spinUs)) { for (int k = 0; k < 16; k++) __builtin_ia32_pause(); continue; }
         struct timespec ts = { 0, 20000 }; nanosleep(&ts, nullptr);
     }
 }
@@ -1923,10 +1924,10 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
     const int minChunk = pic.type == TYPE_B ? ctuW : (minChunkEnv > 0 ? minChunkEnv : 2);
     /* the last rows are where a chain of pictures waits for each other (they finish last, and cut CTUs make the last row the slowest): every CTU of them at once */
     auto minChunkOf = [&](int r) { return (pic.type != TYPE_B && r >= ctuH - 3) ? 1 : minChunk; };
-    std::vector<int> doneC((size_t)ctuH, 0), pubX((size_t)ctuH, 0), a((size_t)ctuH, 0);
+    std::vector<int> doneTop((size_t)ctuH, 0), doneFull((size_t)ctuH, 0), pubX((size_t)ctuH, 0), a((size_t)ctuH, 0);
     std::vector<uint8_t> carry((size_t)ctuH * (X265AMD_CTX_STRIDE + 8), 0);
     struct Unit { int r, c0, c1; };
-    std::vector<Unit> todo;
+    std::vector<Unit> todoTop, todoFull;
     int rc = X265AMD_OK;
     /* offsets and borders of the sample columns [pubX[k], newX) of CTU row k (enqueued; published behind the sweep's synchronisation) */
     auto finishCols = [&](int k, int newX) -> int {
@@ -1940,12 +1941,25 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
         }
         return xa_extend_border_band_420(st, fin + org[0], fin + org[1], fin + org[2], stride, cstride, W, H, marginX, marginY, y0, y1, x0, newX, x0 == 0, newX == W);
     };
-    auto limitOf = [&](const std::vector<int>& an, int r) -> int {
-        int lim = an[r] == ctuW ? ctuW : an[r] - 1;
-        if (r + 1 < ctuH) lim = std::min(lim, an[r + 1] == ctuW ? ctuW : an[r + 1] - 1);
-        if (r > 0) lim = std::min(lim, doneC[r - 1]);
+    /* A CTU row's unit in two steps (round 4).  TOP: the vertical edges of the row's first eight lines and its top horizontal edge -- which completes the deblocking of
+     * the row ABOVE -- as soon as the row itself is analysed (nothing of this touches the row's last line, which the row below still reads unfiltered); the row above can
+     * then be offset, extended and published: one CTU row earlier than when everything waited for the row below.  FULL: the other vertical edges, the inner horizontal
+     * edges, the statistics and the decisions, when the row below is analysed (FrameEncoder::m_filterRowDelay).  Vertical edges are decided per four lines and touch only
+     * their own lines, the top horizontal edge touches lines 0-2: the samples are those of the reference's order (X265AMD_FILTER_EARLY_TOP=0: both steps together). */
+    static const bool earlyTop = !(getenv("X265AMD_FILTER_EARLY_TOP") && atoi(getenv("X265AMD_FILTER_EARLY_TOP")) == 0);
+    auto colsOf = [&](const std::vector<int>& an, int r) -> int { return an[r] == ctuW ? ctuW : an[r] - 1; };
+    auto limTop = [&](const std::vector<int>& an, int r) -> int {
+        int lim = colsOf(an, r);
+        if (r > 0) lim = std::min(lim, doneFull[r - 1]);
+        if (!earlyTop && r + 1 < ctuH) lim = std::min(lim, colsOf(an, r + 1));
         return lim;
     };
+    auto limFull = [&](const std::vector<int>& an, int r) -> int {
+        int lim = doneTop[r];
+        if (r + 1 < ctuH) lim = std::min(lim, colsOf(an, r + 1));
+        return lim;
+    };
+    auto chunkOk = [&](int r, int c0, int c1) { return c1 > c0 && (c1 == ctuW || c1 - c0 >= minChunkOf(r)); };
     for (;;)
     {
         {
@@ -1956,10 +1970,11 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
                 bool allDone = true;
                 for (int r = 0; r < ctuH; r++)
                 {
-                    if (doneC[r] == ctuW) continue;
+                    if (doneFull[r] == ctuW) continue;
                     allDone = false;
-                    const int lim = limitOf(pic.analysedCols, r);
-                    if (lim > doneC[r] && (lim == ctuW || lim - doneC[r] >= minChunkOf(r))) return true;
+                    if (chunkOk(r, doneTop[r], limTop(pic.analysedCols, r))) return true;
+                    /* (a FULL step may become possible through the TOP step of the same sweep: the TOP test above covers that case) */
+                    if (chunkOk(r, doneFull[r], limFull(pic.analysedCols, r))) return true;
                 }
                 return allDone;
             };
@@ -1968,46 +1983,64 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
             a = pic.analysedCols;
         }
         lap(tWait);
-        /* ---- one sweep: every unit that is ready, top row first (a unit of row r may follow a unit of row r - 1 of the same sweep: the stream orders them).
-         * First the edges and the statistics of all of them, one synchronisation, then the decisions on the host, then offsets + borders, a second
-         * synchronisation, then the publication: two waits per sweep however many rows are in flight. ---- */
-        todo.clear();
+        /* ---- one sweep: every step that is ready, top row first (the stream orders them: FULL of row r - 1, TOP of row r, FULL of row r).  First the edges and the
+         * statistics of all of them, one synchronisation, then the decisions on the host, then offsets + borders, a second synchronisation, then the publication:
+         * two waits per sweep however many rows are in flight. ---- */
+        todoTop.clear(); todoFull.clear();
         bool all = true;
+        static const bool dbCopy = getenv("X265AMD_DEBLOCK_UNITS_COPY") && atoi(getenv("X265AMD_DEBLOCK_UNITS_COPY")) != 0;
         for (int r = 0; r < ctuH && rc == X265AMD_OK; r++)
         {
-            if (doneC[r] == ctuW) continue;
+            if (doneFull[r] == ctuW) continue;
             all = false;
-            const int c0 = doneC[r], c1 = limitOf(a, r);
-            if (c1 <= c0 || (c1 < ctuW && c1 - c0 < minChunkOf(r))) continue;
-            const int y4b = r * 16, y4e = std::min(h4, y4b + 16), x4b = c0 * 16, x4e = std::min(w4, c1 * 16 + 1);       /* + the unit column right of the boundary edge */
-            if (dbl)
+            const int y4b = r * 16, y4e = std::min(h4, y4b + 16), y4t = std::min(y4e, y4b + 2);
             {
-                rc = x265amd_deblock_units_rect(&si, &info, pic.units.data(), pic.motion.data(), dbu, y4b, y4e, x4b, x4e);
-                if (rc != X265AMD_OK) break;
-                /* the edge records are read where the host has just written them (mapped memory: no copy, no launch for it) */
-                static const bool dbCopy = getenv("X265AMD_DEBLOCK_UNITS_COPY") && atoi(getenv("X265AMD_DEBLOCK_UNITS_COPY")) != 0;
-                if (dbCopy && hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
-                                     sizeof(x265amd_deblock_unit) * (size_t)(x4e - x4b), (size_t)(y4e - y4b), hipMemcpyHostToDevice, st) != hipSuccess)
-                { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
-                rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, 0, 0, 0, 0, 0, 3, y4b, y4e, c0, c1);
-                if (rc != X265AMD_OK) break;
+                const int c0 = doneTop[r], c1 = limTop(a, r);
+                if (chunkOk(r, c0, c1))
+                {
+                    const int x4b = c0 * 16, x4e = std::min(w4, c1 * 16 + 1);       /* + the unit column right of the boundary edge */
+                    if (dbl)
+                    {
+                        /* the edge records of the whole row height (both steps read them) where the kernels read them: mapped memory, no copy */
+                        rc = x265amd_deblock_units_rect(&si, &info, pic.units.data(), pic.motion.data(), dbu, y4b, y4e, x4b, x4e);
+                        if (rc != X265AMD_OK) break;
+                        if (dbCopy && hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
+                                             sizeof(x265amd_deblock_unit) * (size_t)(x4e - x4b), (size_t)(y4e - y4b), hipMemcpyHostToDevice, st) != hipSuccess)
+                        { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
+                        rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, 0, 0, 0, 0, 0, 3, y4b, y4t, c0, c1);
+                        if (rc != X265AMD_OK) break;
+                    }
+                    todoTop.push_back(Unit{ r, c0, c1 });
+                    doneTop[r] = c1;
+                }
             }
-            if (sao)
             {
-                /* every workgroup stores all 160 sums and counts of its (CTU, plane): nothing to clear; the host reads them where the kernel leaves them */
-                rc = x265amd_sao_stats_rows_cols(st, recP, srcP, stride, cstride, W, H, cnt, orgs, r, r + 1, c0, c1);
-                if (rc != X265AMD_OK) break;
+                const int c0 = doneFull[r], c1 = limFull(a, r);
+                if (chunkOk(r, c0, c1))
+                {
+                    if (dbl && y4e > y4t)
+                    {
+                        rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, 0, 0, 0, 0, 0, 3, y4t, y4e, c0, c1);
+                        if (rc != X265AMD_OK) break;
+                    }
+                    if (sao)
+                    {
+                        /* every workgroup stores all 160 sums and counts of its (CTU, plane): nothing to clear; the host reads them where the kernel leaves them */
+                        rc = x265amd_sao_stats_rows_cols(st, recP, srcP, stride, cstride, W, H, cnt, orgs, r, r + 1, c0, c1);
+                        if (rc != X265AMD_OK) break;
+                    }
+                    todoFull.push_back(Unit{ r, c0, c1 });
+                    doneFull[r] = c1;
+                }
             }
-            todo.push_back(Unit{ r, c0, c1 });
-            doneC[r] = c1;
         }
         if (rc != X265AMD_OK) break;
-        if (todo.empty()) { if (all) break; continue; }
-        numUnits += (int)todo.size(); numSweeps++;
-        if (sao)
+        if (todoTop.empty() && todoFull.empty()) { if (all) break; continue; }
+        numUnits += (int)(todoTop.size() + todoFull.size()); numSweeps++;
+        if (sao && !todoFull.empty())
         {
             if (streamWaitPolite(st, ev) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: sao statistics"); break; }
-            for (const Unit& u : todo)
+            for (const Unit& u : todoFull)
             {
                 int32_t flags[2] = { 1, 1 };
                 rc = x265amd_sao_rdo_cols(&si, pic.type != TYPE_B ? 1 : 0, 2, 0, 69, pic.units.data(), cnt, orgs, sparams.data(), flags, u.r, u.c0, u.c1,
@@ -2020,20 +2053,31 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
             }
             if (rc != X265AMD_OK) break;
         }
-        /* final now: row r - 1 (and the last row itself) up to eight samples short of the unit's right end */
-        for (const Unit& u : todo)
+        /* final now: the row above a TOP step (its parameters were decided by its own FULL step, in this sweep at the latest), and the last row behind its FULL step --
+         * up to eight samples short of the step's right end */
+        for (const Unit& u : todoTop)
         {
-            const int newX = u.c1 == ctuW ? W : 64 * u.c1 - 8;
-            if (u.r > 0) rc = finishCols(u.r - 1, newX);
-            if (rc == X265AMD_OK && u.r == ctuH - 1) rc = finishCols(u.r, newX);
+            if (u.r == 0) continue;
+            rc = finishCols(u.r - 1, u.c1 == ctuW ? W : 64 * u.c1 - 8);
+            if (rc != X265AMD_OK) break;
+        }
+        if (rc != X265AMD_OK) break;
+        for (const Unit& u : todoFull)
+        {
+            if (u.r != ctuH - 1) continue;
+            rc = finishCols(u.r, u.c1 == ctuW ? W : 64 * u.c1 - 8);
             if (rc != X265AMD_OK) break;
         }
         if (rc != X265AMD_OK) break;
         if (streamWaitPolite(st, ev) != hipSuccess) { rc = xa_fail(X265AMD_EHIP, "encoder: row filters"); break; }
-        for (const Unit& u : todo)
+        for (const Unit& u : todoTop)
         {
             const int newX = u.c1 == ctuW ? W : 64 * u.c1 - 8;
             if (u.r > 0 && newX > pubX[u.r - 1]) { pubX[u.r - 1] = newX; pic.publish(u.r - 1, newX); }
+        }
+        for (const Unit& u : todoFull)
+        {
+            const int newX = u.c1 == ctuW ? W : 64 * u.c1 - 8;
             if (u.r == ctuH - 1 && newX > pubX[u.r]) { pubX[u.r] = newX; pic.publish(u.r, newX); }
         }
         lap(tWork);
