@@ -2266,8 +2266,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             void* helper2 = helper ? xa_queue_try_acquire() : nullptr;         /* and a third and a fourth: the 16x16 / 32x32 CUs' 2Nx2N evaluations beside their sub-CUs */
             void* helper3 = helper2 ? xa_queue_try_acquire() : nullptr;
             /* P pictures: a second queue for the searches that start ahead of their CU's merge check (Analyzer::searchAhead) */
-            void* aux = (f.pSlice && st && !own) ? xa_queue_try_acquire() : nullptr;
-            void* aux2 = aux ? xa_queue_try_acquire() : nullptr;                /* and a third for the searches of CUs whose sub-CUs come first */
+            static const int auxSpare = getenv("X265AMD_AUX_SPARE") ? atoi(getenv("X265AMD_AUX_SPARE")) : 112;       /* (an I picture started meanwhile needs four queues per row) */
+            void* aux = (f.pSlice && st && !own) ? xa_queue_try_acquire_spare(auxSpare) : nullptr;
+            void* aux2 = aux ? xa_queue_try_acquire_spare(auxSpare) : nullptr;                /* and a third for the searches of CUs whose sub-CUs come first */
             if (aux) xa_queue_set_aux(st, aux);
             if (aux2) xa_queue_set_aux(aux, aux2);
             if (helper) xa_queue_set_helper(st, helper);
@@ -2278,6 +2279,14 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             const auto tQueue = std::chrono::steady_clock::now();
             for (int c2 = 0; c2 < ctuW; c2++)
             {
+                /* a row of an I picture that started while every queue was taken (the picture behind a scene cut starts beside the pictures in front of it) asks again:
+                 * without its second to fourth queue its CTUs take twice as long */
+                if (f.intraOnly && st && !own && !helper3)
+                {
+                    if (!helper) { helper = xa_queue_try_acquire(); if (helper) xa_queue_set_helper(st, helper); }
+                    if (helper && !helper2) { helper2 = xa_queue_try_acquire(); if (helper2) xa_queue_set_helper(helper, helper2); }
+                    if (helper2 && !helper3) { helper3 = xa_queue_try_acquire(); if (helper3) xa_queue_set_helper(helper2, helper3); }
+                }
                 if (row)
                 {
                     const int need = c2 + 2 < ctuW ? c2 + 2 : ctuW;

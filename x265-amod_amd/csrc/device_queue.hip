@@ -1052,12 +1052,16 @@ void* xa_queue_acquire()
 
 /* a second queue for the holder of a first one, if one is free right now: never waits (the rows of a picture take their FIRST queues in row order so that
  * waiting for one always ends; a second queue is a bonus) */
-void* xa_queue_try_acquire()
+void* xa_queue_try_acquire() { return xa_queue_try_acquire_spare(-1); }
+/* ... with the number of queues that must stay free given by the caller (-1: X265AMD_HELPER_SPARE, default 24): the extra queues of a P picture's rows are a
+ * convenience and leave half of the queues alone, the extra queues of an I picture's rows halve its time and take what there is */
+void* xa_queue_try_acquire_spare(int spareWanted)
 {
     Server& S = server();
     std::unique_lock<std::mutex> g(S.m);
     if (S.disabled || S.init() != 0) return nullptr;
-    static const int spare = getenv("X265AMD_HELPER_SPARE") ? atoi(getenv("X265AMD_HELPER_SPARE")) : 24;       /* queues left to the rows that need a first one */
+    static const int spareDefault = getenv("X265AMD_HELPER_SPARE") ? atoi(getenv("X265AMD_HELPER_SPARE")) : 24;       /* queues left to the rows that need a first one */
+    const int spare = spareWanted >= 0 ? spareWanted : spareDefault;
     int freeN = 0;
     XaQueue* f = nullptr;
     for (XaQueue& x : S.q) if (!x.busy) { freeN++; if (!f) f = &x; }

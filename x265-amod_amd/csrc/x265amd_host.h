@@ -67,6 +67,7 @@ void xa_queue_set_helper(void* st, void* helper);       /* the second queue ride
 void* xa_queue_helper(void* st);
 int xa_extend_border_band_420(void* stream, x265amd_pixel* d_y, x265amd_pixel* d_u, x265amd_pixel* d_v, intptr_t stride, intptr_t cstride, int width, int height, int marginX, int marginY,
                               int y_begin, int y_end, int x_begin, int x_end, int left, int right);       /* csrc/plane_kernels.hip: the three planes' margins in one launch */
+void* xa_queue_try_acquire_spare(int spare);          /* xa_queue_try_acquire that leaves at least `spare` queues free (-1: the default) */
 void xa_queue_set_aux(void* st, void* aux);             /* a further queue riding on `st`, for its holder's own use (ctu_analysis.hip: searches started ahead) */
 void* xa_queue_aux(void* st);
 void xa_queue_log(void* st, int poc, int row);      /* X265AMD_QUEUE_LOG=poc,row: the command / wait timeline of that row goes to stderr when the queue is given back */
