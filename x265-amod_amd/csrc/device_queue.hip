@@ -338,6 +338,7 @@ __device__ __noinline__ void xa_op_intra_pu(const XaCmd& c, int tid)
 
 __device__ __noinline__ void xa_op_intra_nxn(const XaCmd& c, int tid)
 {
+    static_assert(XA_SERVER_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)) + sizeof(Nxn4Lds) <= XA_SERVER_LDS, "LDS budget (block_intra_nxn: chromaAhead)");
     const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
     /* a.n records a.c bytes apart, one after the other (the chained CUs of a block: include/x265amd.h, x265amd_intra_nxn_list) */
     for (int i = 0; i < (a.n > 0 ? a.n : 1); i++)

@@ -341,10 +341,10 @@ struct Nxn4Lds
     x265amd_tu_result res[16];
     uint8_t winMode[4];
     /* chroma */
-    pixel cref[2][20], csw[2][20], cfenc[2][16], crec[5][2][16];
-    int16_t clev[5][2][16];
-    x265amd_tu_result cres[5][2];
-    uint8_t ctxw[5][X265AMD_CTX_STRIDE];
+    pixel cref[2][20], csw[2][20], cfenc[2][16], crec[6][2][16];     /* (six: the five listed modes and, when they are evaluated ahead of the luma decision, a derived mode outside them) */
+    int16_t clev[6][2][16];
+    x265amd_tu_result cres[6][2];
+    uint8_t ctxw[6][X265AMD_CTX_STRIDE];
     uint32_t step[256], enBits[128];
     uint8_t enLps[64];
     /* the CU's own results, kept for the decision of a chained CU */
@@ -360,7 +360,7 @@ struct Nxn4Lds
      * prediction info; the chroma modes' fractions as the chroma decision counted them */
     uint8_t runCtx[X265AMD_CTX_STRIDE];
     uint64_t runFrac, runMv;
-    uint64_t cfrac[5], ccoef[5];
+    uint64_t cfrac[6], ccoef[6];
     unsigned long long ccost[5];                 /* the chroma modes' costs (apart from the luma candidates': the two decisions overlap) */
 };
 
@@ -428,6 +428,56 @@ XA_DEV void nxn4_chroma_modes(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const 
     nxn4_chroma_plane(P, S, list, lumaDir, 0, tabs, lane, wv, grp, l);
     xa_wave_sync();
     nxn4_chroma_plane(P, S, list, lumaDir, 1, tabs, lane, wv, grp, l);
+}
+
+/* The same evaluation for chroma modes given by NUMBER, ahead of the luma decision (block_intra_nxn, an 8x8 CU coded 2Nx2N): slot = slot0 + the lane's group, active when
+ * slot < slotEnd; modes[slot] is the prediction mode.  What depends on how the mode will be SIGNALLED -- the bin of intra_chroma_pred_mode and its context -- is left out:
+ * S.cfrac[slot] is the coded block flags' and the coefficients' share alone, S.ctxw[slot] the contexts behind those, and no cost is formed.  One plane per call, U then V. */
+XA_DEV void nxn4_chroma_spec(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint8_t* modes, int slot0, int slotEnd, int pl, const EnTabs& tabs, int lane, int grp, int l)
+{
+    const int slotRaw = slot0 + grp, active = slotRaw < slotEnd, m = active ? slotRaw : slotEnd - 1;
+    const uint32_t mode = modes[m];
+    const int scanType = mode >= 22 && mode <= 30 ? 1 : (mode >= 6 && mode <= 14 ? 2 : 0);
+    const int y = l >> 2, x = l & 3;
+    uint8_t* cw = S.ctxw[m];
+    if (pl == 0)
+    {
+        if (active) for (int b = l; b < X265AMD_CTX_STRIDE; b += 16) cw[b] = P.ctx[b];
+        if (active && l == 0) S.ccoef[m] = 0;
+        xa_wave_sync();
+    }
+    const x265amd_intra_tu_job& C = P.ctmpl[pl];
+    const Q4 qC = q4_make(C.tu.qp_scaled, C.tu.slice_type);
+    const pixel* cr = S.cref[pl];
+    const int part = l < 4 ? (int)cr[1 + l] + (int)cr[9 + l] : 0;
+    int sdc = part;
+    sdc += __builtin_amdgcn_update_dpp(0, sdc, 0xB1, 0xf, 0xf, true);
+    sdc += __builtin_amdgcn_update_dpp(0, sdc, 0x4E, 0xf, 0xf, true);
+    const int dc = (__shfl(sdc, lane & 48, 64) + 4) >> 3;
+    const int f = S.cfenc[pl][l];
+    const int p = nxn4_pred_sample(cr, S.csw[pl], S.tb, (int)mode, dc, y, x, false);
+    const Chain4 ch = grp16_chain4(f, p, 0, qC, C.tu.sign_hide, scanType, S.tb, nxn4_energy(f, lane), lane);
+    const int lvScan = __shfl(ch.lv, (lane & 48) + S.tb.scan[scanType][l], 64);
+    if (active)
+    {
+        const uint32_t cf = ch.numSig ? grp16_coeff_bits4(cw, cw, lvScan, 0, scanType, C.tu.sign_hide, S.step, S.tb, lane) : 0u;
+        S.crec[m][pl][l] = (pixel)ch.rec; S.clev[m][pl][l] = (int16_t)ch.lv;
+        if (l == 0)
+        {
+            x265amd_tu_result r;
+            r.num_sig = ch.numSig; r.zero_energy = ch.zeroEnergy; r.nz_energy = ch.nzEnergy; r.reserved = 0; r.zero_dist = ch.zeroDist; r.nz_dist = ch.nzDist;
+            S.cres[m][pl] = r;
+            S.ccoef[m] += cf;
+        }
+    }
+    xa_wave_sync();
+    if (pl == 1 && active && l == 0)
+    {
+        const x265amd_tu_result rU = S.cres[m][0], rV = S.cres[m][1];
+        uint64_t frac = cb_bin_t(tabs, cw + CTX_QT_CBF + 2, rU.num_sig != 0 ? 1u : 0u);          /* the two coded block flags share a context */
+        frac += cb_bin_t(tabs, cw + CTX_QT_CBF + 2, rV.num_sig != 0 ? 1u : 0u);
+        S.cfrac[m] = frac + S.ccoef[m];
+    }
 }
 
 /* a decided luma unit's share of the CU's bits on the running contexts: its coded block flag (C_QT_CBF + 0: one level down) and its coefficients -- one wavefront */

@@ -8,6 +8,9 @@
 
 /* nb*: the scan's neighbour arrays, kept for the chains; fenc: its copy of the source block (row length N) -- the candidates' chains read the source five times
  * each (residual, two distortions, two psy energies), from here instead of from global memory (a microsecond per dependent read) */
+#ifndef XA_CHROMA_AHEAD_OFF
+#define XA_CHROMA_AHEAD_OFF 0           /* 1: an 8x8 2Nx2N CU's chroma decision behind its luma decision, as before round 4's last hours */
+#endif
 struct IntraPuShared { int32_t sa8d[35]; uint8_t modes[16]; int num; pixel nbRef[136], nbFlt[136]; pixel fenc[32 * 32]; };
 
 /* the candidate list of a prediction unit from its 35 SA8D costs (S.sa8d): called by the first wavefront, all 64 lanes; leaves S.modes / S.num */
@@ -248,6 +251,15 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     const int cbfCtx = CTX_QT_CBF + (numUnits == 1 ? 1 : 0);                               /* C_QT_CBF + !tuDepth */
     XA_NXN_START(numUnits == 1 ? unitLog2 - 2 : 0);          /* (the record's load goes to kind 0 / stage 0 .. never mind: it is counted below from here) */
     XA_NXN(0);
+    /* An 8x8 CU coded 2Nx2N: its chroma decision (one 4x4 block per plane, five listed modes) needs the luma decision only for the DERIVED mode, and four of the five
+     * listed modes are always among planar, vertical, horizontal, DC and 34.  Those five are evaluated by the two wavefronts the luma candidates leave idle (at most six
+     * candidates), BESIDE the luma candidates' chains; behind the luma decision what is left is the signalling's share of the bits (which mode is the derived one) and,
+     * when the luma mode is none of the five, one more evaluation.  The chroma working set lies behind the luma chains' LDS instead of on top of it. */
+    static_assert(XA_WAVE == 64, "");
+    const bool chromaAhead = P.do_chroma && numUnits == 1 && unitLog2 == 3 && !P.pick_sa8d && nwv >= 8 && maxCand <= 6 && !XA_CHROMA_AHEAD_OFF;
+    Nxn4Lds& S4c = *reinterpret_cast<Nxn4Lds*>(smem + (chromaAhead ? (size_t)nwv * (sizeof(TuLds) + sizeof(IntraTuLds)) : 0));
+    __shared__ uint8_t s_specModes[8];
+    if (tid < 8) { const uint8_t fixed5[8] = { 0, 26, 10, 1, 34, 0, 0, 0 }; s_specModes[tid] = fixed5[tid]; }
     for (int k = 0; k < numUnits; k++)
     {
         const x265amd_intra_tu_job& T = P.tmpl[k];
@@ -278,6 +290,23 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             for (int i = tid; i <= 4 * N; i += nthr) { S.nbRef[i] = sc.ref[i]; S.nbFlt[i] = sc.flt[i]; }
             for (int i = tid; i < N * N; i += nthr) S.fenc[i] = sc.fenc[i];
         }
+        if (chromaAhead && wv >= 6)
+        {
+            /* the chroma working set, by the two wavefronts that have nothing to do while the first one makes the candidate list */
+            const int t = tid - 6 * XA_WAVE;
+            nxn4_fill_tabs(S4c.tb, t);
+            S4c.enBits[t] = s_enBits[t];
+            if (t < 64) S4c.enLps[t] = s_enLps[t];
+            S4c.step[t] = s_step[t]; S4c.step[t + 128] = s_step[t + 128];
+            if (wv == 7)
+                for (int pl = 0; pl < 2; pl++)
+                    (void)nxn4_neighbours(reinterpret_cast<const pixel*>(P.ctmpl[pl].nb), (int)P.ctmpl[pl].nb_stride, (uint32_t)P.ctmpl[pl].avail, S4c.cref[pl], S4c.csw[pl], lane);
+            else if (lane < 32)
+            {
+                const int pl = lane >> 4, i = lane & 15;
+                S4c.cfenc[pl][i] = reinterpret_cast<const pixel*>(P.ctmpl[pl].tu.fenc)[(i >> 2) * P.ctmpl[pl].tu.fenc_stride + (i & 3)];
+            }
+        }
         if (tid < 64)
         {
             if (P.pick_sa8d)
@@ -306,7 +335,15 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         const int n = S.num;
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
         IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
-        for (int i = wv; i < n; i += nwv)
+        if (chromaAhead && wv >= 6)
+        {
+            /* U, then V on the contexts U has moved: modes 0 .. 3 of the five by the groups of wavefront 6, the fifth by the first group of wavefront 7 */
+            const EnTabs tabsC{ S4c.enBits, S4c.enLps };
+            nxn4_chroma_spec(P, S4c, s_specModes, (wv - 6) * 4, 5, 0, tabsC, lane, lane >> 4, lane & 15);
+            xa_wave_sync();
+            nxn4_chroma_spec(P, S4c, s_specModes, (wv - 6) * 4, 5, 1, tabsC, lane, lane >> 4, lane & 15);
+        }
+        for (int i = wv; i < n && !(chromaAhead && wv >= 6); i += nwv)
         {
             x265amd_intra_tu_job J = T;
             const uint32_t mode = S.modes[i];
@@ -393,7 +430,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ pixel s_cfenc[2][16];                /* the two source blocks of the 4x4 case, read by the five modes' chains */
     const int cLog2 = numUnits == 1 ? unitLog2 - 1 : 2, CN = 1 << cLog2;
     const uint32_t lumaDir = s_winMode[0];
-    if (cLog2 == 2 && tid >= 64 && tid < 96)
+    if (cLog2 == 2 && !chromaAhead && tid >= 64 && tid < 96)
     {
         const int pl = (tid - 64) >> 4, i = tid & 15;
         s_cfenc[pl][i] = reinterpret_cast<const pixel*>(P.ctmpl[pl].tu.fenc)[(i >> 2) * P.ctmpl[pl].tu.fenc_stride + (i & 3)];
@@ -406,7 +443,74 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         s_cmode[tid] = (uint8_t)list[tid];
     }
     __syncthreads();
-    if (cLog2 == 2)
+    if (cLog2 == 2 && chromaAhead)
+    {
+        /* the five modes 0 / 26 / 10 / 1 / 34 were evaluated beside the luma candidates (slots 0 .. 4 of S4c): which slot serves which place of the list, the one
+         * evaluation that may be missing (a derived mode that is none of the five: slot 5), then per place the signalling's bits on top of the slot's share */
+        Nxn4Lds& S4 = S4c;
+        __shared__ uint8_t s_csrc[5], s_c14[5];
+        __shared__ int s_needExtra;
+        if (tid == 0)
+        {
+            int need = 0;
+            for (int j = 0; j < 5; j++)
+            {
+                const uint32_t listed = s_cmode[j], mode = listed == 36 ? lumaDir : listed;
+                const int src = mode == 0 ? 0 : (mode == 26 ? 1 : (mode == 10 ? 2 : (mode == 1 ? 3 : (mode == 34 ? 4 : 5))));
+                s_csrc[j] = (uint8_t)src; need |= src == 5;
+            }
+            s_needExtra = need;
+            s_specModes[5] = (uint8_t)lumaDir;
+        }
+        __syncthreads();
+        if (s_needExtra && wv == 0)
+        {
+            const EnTabs tabsC{ S4.enBits, S4.enLps };
+            nxn4_chroma_spec(P, S4, s_specModes, 5, 6, 0, tabsC, lane, lane >> 4, lane & 15);
+            xa_wave_sync();
+            nxn4_chroma_spec(P, S4, s_specModes, 5, 6, 1, tabsC, lane, lane >> 4, lane & 15);
+        }
+        __syncthreads();
+        if (tid < 5)
+        {
+            const int src = s_csrc[tid];
+            const uint32_t listed = s_cmode[tid];
+            uint8_t c14 = P.ctx[14];
+            unsigned long long frac = P.scan_frac;
+            frac += cb_bin_t(tabs, &c14, listed == 36 ? 0u : 1u);                                   /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
+            if (listed != 36) frac += 2ull << 15;
+            frac += S4.cfrac[src];                                                                  /* the coded block flags and the coefficients: the slot's share */
+            const x265amd_tu_result rU = S4.cres[src][0], rV = S4.cres[src][1];
+            const unsigned long long dist = rU.nz_dist + rV.nz_dist, energy = (unsigned long long)rU.nz_energy + rV.nz_energy;
+            const unsigned long long bits = (uint32_t)(frac >> 15);
+            s_cfrac[tid] = frac; s_c14[tid] = c14;
+            S4.ccost[tid] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
+        }
+        __syncthreads();
+        int w = 0;
+        {
+            unsigned long long best = ~0ull;
+            for (int i = 0; i < 5; i++) if (S4.ccost[i] < best) { best = S4.ccost[i]; w = i; }
+        }
+        const int sw = s_csrc[w], slast = s_csrc[4];
+        if (tid == 0)
+        {
+            s_win = w;
+            po->chroma_best = (uint32_t)w; po->chroma_reserved = 0;
+            po->cres[0] = S4.cres[sw][0]; po->cres[1] = S4.cres[sw][1];
+        }
+        for (int b = tid; b < X265AMD_CTX_STRIDE; b += nthr) s_ctxw[w][b] = b == 14 ? s_c14[w] : S4.ctxw[sw][b];
+        if (tid >= 64 && tid < 96)
+        {
+            const int pl = (tid - 64) >> 4, i = tid & 15, y = i >> 2, x = i & 3;
+            const x265amd_intra_tu_job& C = P.ctmpl[pl];
+            int16_t* clOut = P.clevels_dst ? reinterpret_cast<int16_t*>(P.clevels_dst) : &po->clevels[0][0];
+            reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = S4.crec[sw][pl][i];
+            if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = S4.crec[slast][pl][i];      /* the last tried mode's samples: the derived mode's */
+            clOut[pl * 16 + i] = S4.clev[sw][pl][i];
+        }
+    }
+    else if (cLog2 == 2)
     {
         /* 4x4 chroma blocks (an 8x8 CU): the sixteen-lane chains of intra_nxn4_dev.h, a group per mode -- the dynamic LDS is free, the luma chains are done */
         Nxn4Lds& S4 = *reinterpret_cast<Nxn4Lds*>(smem);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void k_tu_solo(TuSoloJob j)
 }
 
 #define INTRA_PU_WAVES 8
-constexpr size_t kIntraPuLds = sizeof(IntraScanLds) > INTRA_PU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)) ? sizeof(IntraScanLds) : INTRA_PU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds));
+constexpr size_t kIntraPuLds = (sizeof(IntraScanLds) > INTRA_PU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds)) ? sizeof(IntraScanLds) : INTRA_PU_WAVES * (sizeof(TuLds) + sizeof(IntraTuLds))) + sizeof(Nxn4Lds);      /* + the chroma working set of an 8x8 2Nx2N CU behind the luma chains' (block_intra_nxn: chromaAhead) */
 __global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_pu(const x265amd_intra_pu_job* job, x265amd_intra_pu_out* out, x265amd_tu_result* res)
 {
     extern __shared__ __attribute__((aligned(16))) char tu_smem[];
