@@ -13,10 +13,10 @@ x265amd_encoder_encode of the K-frame clip to the last flushed NAL unit.  The bo
 is uploaded inside the timed region (3.1 MB, about 60 us over PCIe against > 100 ms of analysis).
 
 Multi-GPU (one process per GPU, torch.distributed nccl == RCCL), two ways:
-  default         rank r encodes closed GOP r of the clip (keyint K, x265amd_param.firstFrame = r K), no data-path collective, the coded GOPs' sizes and digests
-                  are gathered for the report; per-GPU work is fixed: "scaling": "weak";
-  --shard frames  SURVEY section 8e as written: ONE clip, picture k in coding order coded by rank k mod N, every finished CTU row published to the other ranks
-                  (x265amd_encoder_export_row / _import_row, pump: x265-amod_amd/frame_rows.py, ncclBroadcast); total work is fixed: "scaling": "strong".
+  default (--shard frames)  SURVEY section 8e as written: ONE clip, picture k in coding order coded by rank k mod N, every finished CTU row published to the other ranks
+                  (x265amd_encoder_export_row / _import_row, pump: x265-amod_amd/frame_rows.py, ncclBroadcast); total work is fixed: "scaling": "strong";
+  --shard gops    rank r encodes closed GOP r of the clip (keyint K, x265amd_param.firstFrame = r K), no data-path collective, the coded GOPs' sizes and digests
+                  are gathered for the report; per-GPU work is fixed: "scaling": "weak".
 The GOP structure is the lookahead's (--b-adapt 2, B pyramid, open GOPs, scene-cut detection: the preset as it comes), not fixed mini-GOPs.
 
 The kernels of the hot path are timed on their own in bench_kernels.py (a frame's worth of motion searches, intra scans, transform chains, merge
@@ -54,15 +54,15 @@ ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, 
 REF_CLI = ["--preset", "medium", "--qp", str(QP), "--no-info"]
 
 
-def bench_clip(first, count, gop=0):
+def bench_clip(first, count, gop=0, depth=8, cfg_id=2):
     """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes (tests/hevc_testlib.py: survey_clip, cfg_id 2 --
     the generator the full-size parity cases use as well): integer arithmetic only, frame t depends on t alone, the noise field is re-seeded every 24th frame.
     gop: the closed GOP a rank codes in a multi-GPU run (its own noise field behind its IDR picture, the same motion: every rank has the same amount of work)."""
     import hevc_testlib as T
-    return T.survey_clip(W, H, 8, 2, first, count, gop)
+    return T.survey_clip(W, H, depth, cfg_id, first, count, gop)
 
 
-def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
+def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=None):
     """the clip through the encoder object; returns (byte stream, seconds of the encode loop).  `sync` brackets the timed region.
     shard = (rank, world): frame per GPU with row publication -- this object codes the pictures whose place in coding order is rank modulo
     world, a pump thread beside the encode loop broadcasts / imports every finished CTU row (x265-amod_amd/frame_rows.py); the stream holds the owned pictures only."""
@@ -77,7 +77,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
     prm = T.EncParam()
     lib.x265amd_param_default(C.byref(prm))
     prm.sourceWidth, prm.sourceHeight = W, H
-    for k, v in ENC_CFG.items():
+    for k, v in (cfg or ENC_CFG).items():
         setattr(prm, k, v)
     prm.firstFrame = first_frame
     if keyint:
@@ -101,6 +101,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
             pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
         pics.append((pic, keep))
     coded = 0
+    marks = []                  # where each coded picture's NAL units start in `stream` (the headers come first)
     lib.x265amd_encoder_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
     try:
         if timed:
@@ -111,15 +112,14 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
             import torch
             import __graft_entry__ as g
             fr = g.load_package().frame_rows
-            dev = "cuda:%d" % torch.cuda.current_device()
+            dev = "cuda:%d" % torch.cuda.current_device()       # read on the encode thread: a new thread starts on device 0
 
             def run_pump():
                 try:
                     torch.cuda.set_device(dev)
                     rows = fr.EncoderRows(lib, enc, dev)
-                    # one publication stream per owner, pictures nobody references stay home, a row travels as one packed buffer (frame_rows.py)
-                    fr.pump(rows.export_row, rows.import_row, rows.shapes, len(pics), rows.rows, dev, rank=shard[0], world=shard[1], referenced=rows.referenced,
-                            groups=shard[2] if len(shard) > 2 else None)
+                    # one pump thread on a stream of its own, the same sequence of collectives on every rank, pictures nobody references stay home (frame_rows.py)
+                    fr.pump(rows.export_row, rows.import_row, rows.shapes, len(pics), rows.rows, dev, rank=shard[0], world=shard[1], referenced=rows.referenced)
                 except BaseException as exc:        # noqa: B902
                     pump_err.append(repr(exc))
             pump_thread = threading.Thread(target=run_pump)
@@ -131,6 +131,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
             assert ret >= 0, lib.x265amd_last_error()
             if ret:
                 coded += 1
+                marks.append(len(stream))
                 for i in range(nnal.value):
                     stream.extend(bytes(nal[i].payload[:nal[i].sizeBytes]))
         while True:
@@ -139,6 +140,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
             if not ret:
                 break
             coded += 1
+            marks.append(len(stream))
             for i in range(nnal.value):
                 stream.extend(bytes(nal[i].payload[:nal[i].sizeBytes]))
         if pump_thread:
@@ -152,7 +154,11 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None):
         encode.last_stats = list(st) if lib.x265amd_encoder_stats(enc, st, 4) == 0 else None      # I / P / B pictures, the sum of their distinct reference pictures
     finally:
         lib.x265amd_encoder_close(enc)
-    assert coded == len(frames), (coded, len(frames))
+    encode.last_marks = marks
+    if shard:
+        assert coded == len(range(shard[0], len(frames), shard[1])), (coded, len(frames), shard)
+    else:
+        assert coded == len(frames), (coded, len(frames))
     return bytes(stream), dt
 
 
@@ -234,26 +240,32 @@ def usable_cores():
     return n
 
 
-def reference_encode(frames):
+def reference_encode(frames, cli=None, depth=8, runs=("default", "f1")):
     """the same clip through the reference encoder (oracle/_ref/x265_ref8: the reference compiled by oracle/build_ref.sh, C primitives, no assembly) on
     this box's host cores, twice: with its defaults (frame threads by core count -- 5 for 1080p on 32 cores or more, threadpool.cpp:661-677: THAT stream is
     the parity target, the encoder object runs with the same frame-parallel rules) and with --frame-threads 1 (informational: one picture at a time; vertical
     motion is then not limited to the lag, so a clip with enough motion codes differently).  Returns a dict or None."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "x265_ref8")
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265_ref%d" % depth)
     if not os.path.exists(exe):
         return None
     d = tempfile.mkdtemp(prefix="x265amd_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         with open(os.path.join(d, "clip.y4m"), "wb") as f:
-            f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420\n" % (W, H))
+            f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 C420%s\n" % (W, H, b"" if depth == 8 else b"p%d" % depth))
             for fr in frames:
                 f.write(b"FRAME\n")
                 for pl in fr:
                     f.write(np.ascontiguousarray(pl).tobytes())
         out = {"cores": usable_cores()}
-        for tag, extra in (("default", []), ("f1", ["--frame-threads", "1"])):
+        # pools16: the thread pool sized by the CPU quota of the GPU boxes (16 cores) instead of the machine's 256 hardware threads -- a process that burns more than
+        # its quota is frozen for the rest of every 100 ms period (DESIGN.md section 4.21) -- with the frame threads the default run picks (so the rules, and the stream, are the same)
+        ft = 6 if H > 2000 else 5
+        variants = {"default": [], "f1": ["--frame-threads", "1"], "pools16": ["--pools", "16", "--frame-threads", str(ft if (os.cpu_count() or 1) >= 32 else 0)]}
+        for tag in runs:
+            extra = variants[tag]
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc"] + REF_CLI + extra, cwd=d, capture_output=True, text=True, timeout=900)
+            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc"] + (cli or REF_CLI) + (["--input-depth", str(depth), "--output-depth", str(depth)] if depth != 8 else []) + extra,
+                               cwd=d, capture_output=True, text=True, timeout=900)
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 return None
@@ -281,8 +293,12 @@ def main():
     ap.add_argument("--no-kernel-workload", action="store_true", help="skip bench_kernels.py (profiling passes of the encoder alone)")
     ap.add_argument("--res", choices=["1080p", "2160p"], default="1080p", help="1080p = BASELINE.json configs[1] (the bench line); 2160p: the same encode at 3840x2160 (informational)")
     ap.add_argument("--no-2160p", action="store_true", help="skip the 3840x2160 encode that the 1080p single-GPU run reports beside the bench line (`also_2160p`)")
-    ap.add_argument("--shard", choices=["gops", "frames"], default="gops", help="--gpus N > 1: gops = a closed GOP per GPU (weak scaling, no data-path exchange); frames = ONE clip, picture k in "
-                    "coding order coded by rank k mod N, finished CTU rows broadcast over RCCL (strong scaling; SURVEY section 8e as written, DESIGN.md section 6)")
+    ap.add_argument("--shard", choices=["gops", "frames"], default="frames", help="--gpus N > 1: frames (the default: SURVEY section 8e as written, DESIGN.md section 6) = ONE clip, picture k in "
+                    "coding order coded by rank k mod N, finished CTU rows broadcast over RCCL (strong scaling); gops = a closed GOP per GPU (weak scaling, no data-path exchange)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend of a multi-process run: nccl = RCCL over xGMI; gloo stages the rows through "
+                    "the host (the one-GPU test of the --shard frames leg: RCCL refuses two ranks on one device)")
+    ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0 (tests/test_encoder_api.py: two processes, one GPU, gloo); set X265AMD_QUEUES so that the ranks' resident workgroups fit side by side")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the 3840x2160 --preset slow and Main 10 encodes that the 1080p single-GPU run reports beside the bench line")
     ap.add_argument("--no-scene-clip", action="store_true", help="skip the 60-frame clip with both re-seeds inside that the 1080p single-GPU run reports beside the bench line (`scene_change_clip`)")
     args = ap.parse_args()
 
@@ -298,10 +314,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     def sync():
         torch.cuda.synchronize()
@@ -319,14 +340,13 @@ def main():
         encode(T, L, bench_clip(0, Wm), 0, 0, sync, timed=False)
     queue_stats(L, True)                 # the counters of the resident kernel from here on: the timed encode alone
     if by_frames:
-        groups = None
         if world > 1:
-            # a communicator per source rank (one publication stream per owner: frame_rows.py), brought up before the timed region
-            groups = [dist.new_group(ranks=list(range(world))) for _ in range(world)]
-            for s_, g_ in enumerate(groups):
-                dist.broadcast(torch.zeros(1, dtype=torch.uint8, device="cuda"), src=s_, group=g_)
+            # the communicator is brought up before the timed region (the first collective of a process group builds its rings)
+            t_ = torch.zeros(world, 4, dtype=torch.int64, device="cuda")
+            dist.all_reduce(t_)
+            dist.broadcast(torch.zeros(16, dtype=torch.uint8, device="cuda"), src=0)
             torch.cuda.synchronize()
-        stream, dt = encode(T, L, frames, 0, 0, sync, shard=(rank, world, groups))
+        stream, dt = encode(T, L, frames, 0, 0, sync, shard=(rank, world) if world > 1 else None)
     else:
         stream, dt = encode(T, L, frames, rank * K, K if world > 1 else 0, sync)
     qstats = queue_stats(L, True)
@@ -336,12 +356,18 @@ def main():
         dt = float(tt.item())
         sizes = [None] * world
         dist.all_gather_object(sizes, (len(stream), hashlib.md5(stream).hexdigest()))
+        if by_frames and os.environ.get("X265AMD_BENCH_STREAM_OUT"):
+            # the one-GPU test of this leg puts the ranks' NAL units back together and compares with the single-object stream
+            with open(os.environ["X265AMD_BENCH_STREAM_OUT"] + ".%d" % rank, "wb") as f_:
+                f_.write(stream)
+            with open(os.environ["X265AMD_BENCH_STREAM_OUT"] + ".%d.marks" % rank, "w") as f_:
+                json.dump(encode.last_marks, f_)
     else:
         sizes = [(len(stream), hashlib.md5(stream).hexdigest())]
 
     line = None
     if rank == 0:
-        ref = None if (world > 1 or args.no_cpu_baseline) else reference_encode(frames)
+        ref = None if (world > 1 or args.no_cpu_baseline) else reference_encode(frames, runs=("default", "f1", "pools16"))
         if ref is not None:
             same = ref["default"]["stream"] == stream
             cpu = {"value": K / ref["default"]["seconds"], "unit": "frames/s", "cores": ref["cores"], "kind": "reference",
@@ -350,7 +376,10 @@ def main():
                              "frame threads at their defaults; by its own 'encoded N frames in T' figure" % (K, ref["cores"], os.cpu_count() or 0),
                    "frame_threads_default": {"frames_per_s": K / ref["default"]["seconds"], "says": ref["default"]["says"], "stream_equals_ours": bool(same)},
                    "frame_threads_1": {"frames_per_s": K / ref["f1"]["seconds"], "says": ref["f1"]["says"],
-                                       "stream_equals_default": bool(ref["default"]["stream"] == ref["f1"]["stream"])}}
+                                       "stream_equals_default": bool(ref["default"]["stream"] == ref["f1"]["stream"])},
+                   "pools16": {"frames_per_s": K / ref["pools16"]["seconds"], "says": ref["pools16"]["says"], "stream_equals_default": bool(ref["default"]["stream"] == ref["pools16"]["stream"]),
+                               "of": "the reference with --pools 16 (its thread pool sized by this box's CPU quota instead of the machine's hardware threads; frame threads as the default run picks them): "
+                                     "the fairer of the two baselines where a quota is in force"}}
         else:
             same, cpu = None, None
         # algorithmic bytes of a frame = payload x (source read + reconstruction write + distinct reference pictures read)
@@ -387,11 +416,11 @@ def main():
         try:
             frames60 = bench_clip(0, 60)
             stream60, dt60 = encode(T, L, frames60, 0, 0, sync)
-            ref60 = reference_encode(frames60)
+            ref60 = reference_encode(frames60, runs=("default", "f1", "pools16"))
             line["scene_change_clip"] = {"value": 60 / dt60, "unit": "frames/s", "frames": 60, "stream_md5": hashlib.md5(stream60).hexdigest(),
                                          "bit_exact_vs_reference_encoder": None if ref60 is None else bool(ref60["default"]["stream"] == stream60),
                                          "cpu_baseline": None if ref60 is None else {"value": 60 / ref60["default"]["seconds"], "cores": ref60["cores"], "kind": "reference",
-                                                                                     "says": ref60["default"]["says"], "frame_threads_1": 60 / ref60["f1"]["seconds"]},
+                                                                                     "says": ref60["default"]["says"], "frame_threads_1": 60 / ref60["f1"]["seconds"], "pools16": 60 / ref60["pools16"]["seconds"]},
                                          "note": "the same clip generator and options over 60 frames: the noise field is re-seeded at frames 24 and 48; both encoders run "
                                                  "scene-cut detection (--scenecut 40, --rc-lookahead 20) and place an I picture at 24 (min-keyint not reached) and an IDR picture at 48"}
             del frames60, stream60
@@ -404,17 +433,41 @@ def main():
             frames4 = bench_clip(0, K)
             encode(T, L, bench_clip(0, 2), 0, 0, sync, timed=False)
             stream4, dt4 = encode(T, L, frames4, 0, 0, sync)
-            ref4 = reference_encode(frames4)
+            ref4 = reference_encode(frames4, runs=("default", "f1", "pools16"))
             line["also_2160p"] = {"value": K / dt4, "unit": "frames/s", "frames": K, "stream_md5": hashlib.md5(stream4).hexdigest(),
                                   "bit_exact_vs_reference_encoder": None if ref4 is None else bool(ref4["default"]["stream"] == stream4),
                                   "cpu_baseline": None if ref4 is None else {"value": K / ref4["default"]["seconds"], "cores": ref4["cores"], "kind": "reference",
-                                                                             "says": ref4["default"]["says"], "frame_threads_1": K / ref4["f1"]["seconds"]},
+                                                                             "says": ref4["default"]["says"], "frame_threads_1": K / ref4["f1"]["seconds"], "pools16": K / ref4["pools16"]["seconds"]},
                                   "note": "the same clip generator, options and comparison at 3840x2160 8-bit (34 CTU rows)"}
             del frames4, stream4
         except Exception as exc:       # the bench line stands on its own
             line["also_2160p"] = {"error": repr(exc)}
         finally:
             W, H = 1920, 1080
+    # ---- BASELINE.json configs[2] and configs[3] at their stated size: 3840x2160 --preset slow (8-bit) and 3840x2160 Main 10 --preset medium, stream compared in the run ----
+    if rank == 0 and world == 1 and args.res == "1080p" and not args.no_extra_configs and not args.no_cpu_baseline:
+        for key, depth, cfg_id, tools, preset in (("also_2160p_slow", 8, 3, T.SLOW_TOOLS, "slow"), ("also_2160p_main10", 10, 4, {}, "medium")):
+            try:
+                W, H = 3840, 2160
+                Kx = min(K, 12)
+                Lx = T.load_hip(depth)
+                cfgx = dict(ENC_CFG, frameNumThreads=6, **tools)
+                framesx = bench_clip(0, Kx, depth=depth, cfg_id=cfg_id)
+                encode(T, Lx, bench_clip(0, 2, depth=depth, cfg_id=cfg_id), 0, 0, sync, timed=False, cfg=cfgx)
+                streamx, dtx = encode(T, Lx, framesx, 0, 0, sync, cfg=cfgx)
+                clix = ["--preset", preset, "--qp", str(QP), "--no-info"]
+                refx = reference_encode(framesx, cli=clix, depth=depth, runs=("default", "pools16"))
+                line[key] = {"value": Kx / dtx, "unit": "frames/s", "frames": Kx, "stream_md5": hashlib.md5(streamx).hexdigest(),
+                             "bit_exact_vs_reference_encoder": None if refx is None else bool(refx["default"]["stream"] == streamx),
+                             "cpu_baseline": None if refx is None else {"value": Kx / refx["default"]["seconds"], "cores": refx["cores"], "kind": "reference", "says": refx["default"]["says"],
+                                                                        "pools16": Kx / refx["pools16"]["seconds"]},
+                             "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(clix),
+                             "note": "BASELINE.json configs[%d] at its stated size (SURVEY 8d's clip, cfg_id %d), %d frames, the preset in CQP as it comes" % (2 if depth == 8 else 3, cfg_id, Kx)}
+                del framesx, streamx
+            except Exception as exc:       # the bench line stands on its own
+                line[key] = {"error": repr(exc)}
+            finally:
+                W, H = 1920, 1080
     # ---- the hot-path kernels on their own (bench_kernels.py): a frame's worth of batched block operations ----
     if not args.no_kernel_workload:
         import bench_kernels

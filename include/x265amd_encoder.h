@@ -134,7 +134,8 @@ typedef struct x265amd_row_export
     uint64_t map_offset_units, map_offset_motion;   /* where those records sit in the importing object's maps (bytes) */
 } x265amd_row_export;
 /* The object that codes picture `coding_index`: blocks until CTU row `ctu_row` of it is final (at most timeout_ms), then describes it.  Returns 0; 1 when the picture is
- * not known yet (not handed over by the lookahead: ask again); -1 on error / time-out / a failed picture.  The described memory stays valid while the picture can be
+ * not known yet (not handed over by the lookahead: ask again); 2 when timeout_ms <= 0 and the row is not final yet (a look instead of a wait: ask again);
+ * -1 on error / time-out / a failed picture.  The described memory stays valid while the picture can be
  * referenced. */
 int x265amd_encoder_export_row(x265amd_encoder* enc, uint64_t coding_index, int ctu_row, x265amd_row_export* out, int timeout_ms);
 /* An object that does not code the picture: copies the row in (src[] may be another object's picture -- the same device or a peer of this process -- or the buffer

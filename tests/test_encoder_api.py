@@ -277,7 +277,6 @@ def test_frame_per_gpu_objects_alternate_pictures(tag, count):
     # (logged, not asserted: these pictures are two to four CTU rows high, less than the reference's row lag, so a picture's first row often cannot start before its
     # reference's last row exists; that rows of different owners DO pass each other is asserted where it is deterministic: tests/test_distributed_cpu.py)
     print("pictures in flight at once (%s, %d objects): %d" % (tag, count, T.encoder_run_sharded.most_in_flight))
-    assert T.encoder_run_sharded.most_in_flight >= 1
     for (poc, _, _, planes) in coded:
         got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
         assert got == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc

@@ -25,6 +25,7 @@
 #include "inter_chain_dev.h"
 #include "inter_search_dev.h"
 #include <string.h>
+#include <immintrin.h>
 #include <vector>
 
 using namespace xa_inter;
@@ -149,6 +150,9 @@ void xa_devmap_push_rows(const x265amd_mv_unit* host, const x265amd_cu_unit* uni
     XaMapUnit* d = (XaMapUnit*)xa_devmap_find(host);
     if (!d) return;
     for (int i = y4a * w4; i < y4b * w4; i++) devmap_store(d + i, host[i], units ? units[i].depth : 0);
+    /* the mirror is written through the write-combining BAR mapping and the caller publishes the rows to OTHER threads next (a release fence drains nothing on
+     * x86): the units must have left this core's buffers before a row task on another core can queue a command that reads them */
+    _mm_sfence();
 }
 
 namespace {

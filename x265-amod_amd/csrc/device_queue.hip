@@ -380,6 +380,7 @@ template<int WHICH> __device__ __noinline__ void xa_op_me(const XaCmd& c, int ti
 }
 
 /* XA_OP_WAIT: this queue goes on when another queue has finished its command number `target` (a release: xa_queue_follow), and looks at memory afresh */
+__shared__ int xa_wait_failed;          /* set by xa_op_wait: the leader stood; the server loop poisons the queue (XaRingHost::fault) */
 __device__ __noinline__ void xa_op_wait(const XaCmd& c, int tid)
 {
     const XaArgsWait a = *reinterpret_cast<const XaArgsWait*>(c.args);
@@ -389,7 +390,9 @@ __device__ __noinline__ void xa_op_wait(const XaCmd& c, int tid)
         while (xa_sys_load(reinterpret_cast<const uint64_t*>(a.word)) < a.target)
         {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 200000000ll) break;      /* two seconds: the other queue stands; the host notices (its own waits are bounded) */
+            /* two seconds: the other queue stands.  Going on would run this queue's commands against whatever the leader has written so far, so the queue
+             * is poisoned instead: nothing behind this command runs, and the host's waits on it fail (q_wait looks at XaRingHost::fault) */
+            if (wall_clock64() - t0 > 200000000ll) { xa_wait_failed = 1; break; }
         }
     }
     __syncthreads();
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid < 40) (&xa_nxn_acc[0][0])[tid] = 0;
     if (tid < 8) xa_chain_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
-    if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; }
+    if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; xa_wait_failed = 0; }
     __syncthreads();
     for (;;)
     {
@@ -606,7 +609,10 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
             pre = tid < 16 ? xa_sys_load(nextSlot + tid) : (tid == 16 ? xa_sys_load(&rd->head) : 0);
             havePre = true;
         }
-        xa_dispatch(s_cmd, tid);
+        /* a queue whose XA_OP_WAIT gave up runs nothing more: its commands still count as finished (the host's ring bookkeeping goes on), their results
+         * stay unwritten and XaRingHost::fault tells every wait on this queue that they are */
+        if (!xa_wait_failed) xa_dispatch(s_cmd, tid);
+        if (s_cmd.op == XA_OP_WAIT && tid == 0 && xa_wait_failed) xa_sys_store(&rh->fault, seen + 1);
         /* before the workgroup reports or publishes, every wavefront's stores have left (results live in host memory, read as soon as the count
          * moves).  Between two commands of the queue the barrier is enough: the CU's vector memory path keeps the order of one workgroup's accesses,
          * which is all the compiler itself relies on for a workgroup-scope release in this execution mode. */
@@ -777,7 +783,7 @@ struct Server
         {
             XaQueue& x = q[i];
             x.submitted = 0; x.lastSignal = 0; x.generation = generation;
-            x.rh->tail = 0; x.rh->state = 0; x.rh->dbg[63] = 0;
+            x.rh->tail = 0; x.rh->state = 0; x.rh->fault = 0; x.rh->dbg[63] = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].quit) = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].head) = 0;
             *reinterpret_cast<volatile uint64_t*>(&rings[i].done) = 0;
@@ -884,10 +890,19 @@ void dump_debug_areas(int)
 
 inline XaQueue* as_queue(void* st) { return reinterpret_cast<XaQueue*>((uintptr_t)st & ~(uintptr_t)1); }
 
+/* a queue whose XA_OP_WAIT timed out (k_job_server: XaRingHost::fault) has skipped every command since: whatever the caller waits for was not produced */
+static int q_faulted(XaQueue* q)
+{
+    const uint64_t f = *reinterpret_cast<const volatile uint64_t*>(&q->rh->fault);
+    if (!f) return 0;
+    fprintf(stderr, "x265amd queue %d: command %llu (XA_OP_WAIT) gave up waiting for the queue it follows; the commands behind it were not run\n", q->idx, (unsigned long long)f);
+    return -1;
+}
+
 int q_wait(XaQueue* q, uint64_t target)
 {
     const volatile uint64_t* tail = &q->rh->tail;
-    if (*tail >= target) return 0;
+    if (*tail >= target) return q_faulted(q);
     q->ev('W', 0);
     struct EvEnd { XaQueue* q; ~EvEnd() { q->ev('R', 0); } } evEnd{ q };
     const auto t0 = std::chrono::steady_clock::now();
@@ -903,7 +918,7 @@ int q_wait(XaQueue* q, uint64_t target)
             return -1;
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        return 0;
+        return q_faulted(q);
     }
     for (unsigned spins = 0;; spins++)
     {
@@ -917,7 +932,7 @@ int q_wait(XaQueue* q, uint64_t target)
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    return 0;
+    return q_faulted(q);
 }
 
 void xa_server_alive();
@@ -1304,7 +1319,9 @@ extern "C" int x265amd_queue_stats(uint64_t* out, int n, int reset)
     out[6] = S.launches; out[7] = (uint64_t)(S.kernelMs * 1000.0); out[8] = (uint64_t)S.numQueues;
     if (reset)
     {
-        for (int i = 0; i < S.numQueues; i++) { memset((void*)S.hosts[i].prof, 0, sizeof(S.hosts[i].prof)); memset((void*)S.hosts[i].bytes, 0, sizeof(S.hosts[i].bytes)); S.hosts[i].resident = 0; S.hosts[i].cycles = 0; }
+        for (int i = 0; i < S.numQueues; i++) { memset((void*)S.hosts[i].prof, 0, sizeof(S.hosts[i].prof)); memset((void*)S.hosts[i].bytes, 0, sizeof(S.hosts[i].bytes)); S.hosts[i].resident = 0; S.hosts[i].cycles = 0;
+                                                   memset((void*)S.hosts[i].stage, 0, sizeof(S.hosts[i].stage)); memset((void*)S.hosts[i].sized, 0, sizeof(S.hosts[i].sized));
+                                                   memset((void*)S.hosts[i].nxn, 0, sizeof(S.hosts[i].nxn)); memset((void*)S.hosts[i].chain, 0, sizeof(S.hosts[i].chain)); }
         S.kernelMs = 0.0; S.launches = 0;
     }
     return X265AMD_OK;

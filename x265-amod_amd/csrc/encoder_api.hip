@@ -12,6 +12,7 @@
 #include "x265amd.h"
 #include "x265amd_encoder.h"
 #include "x265amd_host.h"
+#include <immintrin.h>
 #include "xa_fiber.h"
 #include <math.h>
 #include <stdio.h>
@@ -455,6 +456,7 @@ extern "C" int x265amd_encoder_export_row(x265amd_encoder* e, uint64_t codingInd
     while (pic->published(row) < e->W)
     {
         if (pic->failed.load()) return xa_fail(X265AMD_EHIP, "encoder_export_row: the picture failed"), -1;
+        if (timeoutMs <= 0) return 2;           /* a look, not a wait: the row is not final yet (the one-thread pump of frame_rows.py asks like this) */
         if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeoutMs) return xa_fail(X265AMD_EHIP, "encoder_export_row: time-out"), -1;
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
@@ -2004,6 +2006,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
                         /* the edge records of the whole row height (both steps read them) where the kernels read them: mapped memory, no copy */
                         rc = x265amd_deblock_units_rect(&si, &info, pic.units.data(), pic.motion.data(), dbu, y4b, y4e, x4b, x4e);
                         if (rc != X265AMD_OK) break;
+                        _mm_sfence();       /* the records went through the write-combining BAR mapping: out of this core's buffers before the launch that reads them */
                         if (dbCopy && hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
                                              sizeof(x265amd_deblock_unit) * (size_t)(x4e - x4b), (size_t)(y4e - y4b), hipMemcpyHostToDevice, st) != hipSuccess)
                         { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
@@ -2048,6 +2051,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
                 if (rc != X265AMD_OK) break;
                 const size_t off = (size_t)u.r * ctuW + u.c0, n = (size_t)(u.c1 - u.c0);
                 memcpy((x265amd_sao_ctu*)hPar.p + off, sparams.data() + off, sizeof(x265amd_sao_ctu) * n);
+                _mm_sfence();               /* as for the deblocking records above */
                 if (parCopy && hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + off, (const x265amd_sao_ctu*)hPar.p + off, sizeof(x265amd_sao_ctu) * n, hipMemcpyHostToDevice, st) != hipSuccess)
                 { rc = xa_fail(X265AMD_EHIP, "encoder: sao upload"); break; }
             }

@@ -53,7 +53,9 @@ struct alignas(128) XaRingHost
     uint64_t tail; uint64_t pad0[15];           /* commands finished, as of the last signalling command */
     uint64_t state;                             /* 1 while the workgroup is resident */
     uint64_t alive;                             /* hosts[0] only: bumped by the host while queues are in use; an idle workgroup leaves only when this has stood still */
-    uint64_t pad1[14];
+    uint64_t fault;                             /* sticky: set by the workgroup when an XA_OP_WAIT gave up (the queue it follows stood for two seconds); the commands
+                                                   behind it are then NOT run (they would read what the leader had not written yet), and every host wait on this queue fails */
+    uint64_t pad1[13];
     uint64_t dbg[64];                           /* X265AMD_QUEUE_DEBUG & 2: what each wavefront was about to touch (dumped on abort) */
     uint64_t prof[64];                          /* per command kind [2 * op] count, [2 * op + 1] ticks of the 100 MHz clock (written when the workgroup leaves; op < 31);
                                                    [62] ticks spent polling, [63] ticks in fences */

@@ -6,90 +6,214 @@ One process per GPU, one encoder object per process opened with shardRank = rank
 every picture and decides slice types, DPB and reference lists identically; rank r CODES the pictures whose place k in coding order has k % world == r.
 The one exchange of the path is the row pump below.
 
-**One publication stream per owner** (round 4).  A consumer of picture k + 1 needs the FIRST rows of picture k + 1's references long before picture k's last
-row exists, so rows must not travel in one (picture, row) order over one communicator: every source rank has a process group and a pump thread of its own on
-every rank.  The thread of source s walks the pictures s codes, in coding order, rows top to bottom -- the order in which they become final on s -- and
-broadcasts each row on s's group; the receivers' threads of that group import what arrives.  Streams of different owners never wait for each other, so G
-pictures' rows are in flight at once (what the reference's frame threads do with m_reconRowFlag).  Pictures nobody references (the plain B pictures) are not
-sent: `referenced(k)` says so, identically on every rank.  A row travels as ONE buffer -- the three plane ranges and the two map ranges packed behind each
-other (5 collectives per row became 1) -- torch.distributed's broadcast is ncclBroadcast = RCCL over xGMI on GPUs and gloo in the CPU test.
+**One thread, one communicator, time slots** (round 5; SURVEY 8e: "one all-gather per frame-time slot where each rank contributes the rows it finished").
+A consumer of picture k + 1 needs the FIRST rows of picture k + 1's references long before picture k's last row exists, so rows must not travel in one fixed
+(picture, row) order.  Round 4 gave every owner a communicator and a thread of its own; collectives of several communicators issued from several threads in
+different orders on different ranks can deadlock under NCCL / RCCL (every rank's stream may hold the other's collective behind its own), and the threads shared
+the process's current stream.  Now every rank runs ONE pump thread on a stream of its own and all ranks issue the SAME sequence of collectives:
+
+    slot:  every rank LOOKS (without waiting) which of its own next rows are final        -> header (picture, first row, count, state)
+           the headers are exchanged (one all-reduce of a world x 4 table: works on NCCL and on gloo, device or host tensors)
+           for every rank s with count > 0, in rank order: ONE broadcast of those rows, packed behind each other, from s
+           the receivers import what arrived; a row whose picture the local object does not know yet (its lookahead has not handed it over) is kept and retried
+
+Nobody waits for a row inside a collective, so the streams of different owners never hold each other up: G pictures' rows are in flight at once (what the reference's
+frame threads do with m_reconRowFlag).  Pictures nobody references (the plain B pictures) are not sent (`referenced(k)`).  A rank whose local step failed says so in
+its next header and every rank raises: nobody is left hanging in a collective.  torch.distributed's broadcast is ncclBroadcast = RCCL over xGMI on GPUs and gloo in the
+CPU tests.
 
 The pump is written against callables so that the CPU test can drive it with arrays instead of encoder objects:
-    export_row(k, row) -> list of 1-D uint8 tensors (device tensors for the planes, CPU tensors for the maps), blocking until the row is final
-    import_row(k, row, tensors) -> None
+    export_row(k, row) -> list of 1-D uint8 tensors (device tensors for the planes, CPU tensors for the maps) or None when the row is not final yet (never waits)
+    import_row(k, row, tensors) -> None / True when done, False when the picture is not known here yet (the pump keeps the row and asks again)
     shapes(row) -> the byte counts (the geometry is the same on every rank)
-    referenced(k) -> bool, optional: whether any later picture may reference picture k (False: its rows stay where they are)."""
+    referenced(k) -> True / False, or None while not known yet; optional: whether any later picture may reference picture k (False: its rows stay where they are)."""
 import ctypes as C
-import threading
+import time
 
 import torch
 import torch.distributed as dist
+
+ROWS_PER_SLOT = 4           # at most this many rows of one owner travel in one broadcast
+STATE_MORE, STATE_DONE, STATE_FAILED = 0, 1, 2
 
 
 def owner_of(coding_index, world):
     return coding_index % world
 
 
-def _stream(src, export_row, import_row, shapes, n_pictures, ctu_rows, device, rank, world, group, on_row, referenced, errors):
-    """the publication stream of source rank `src` on this rank: the pictures src codes, in coding order, rows top to bottom"""
-    try:
-        bufs = {}
-        for k in range(src, n_pictures, world):
-            if referenced is not None and not referenced(k):
-                continue
-            for row in range(ctu_rows):
-                sizes = list(shapes(row))
-                key = tuple(sizes)
-                if world > 1 and key not in bufs:       # one packed buffer per row geometry (first / middle / last row differ by their margins)
-                    bufs[key] = torch.empty(sum(sizes), dtype=torch.uint8, device=device)
-                if src == rank:
-                    tensors = export_row(k, row)
-                    if world > 1:
-                        buf, at = bufs[key], 0
-                        for t, n in zip(tensors, sizes):
-                            buf[at:at + n].copy_(t, non_blocking=True)
-                            at += n
-                        dist.broadcast(buf, src=src, group=group)
-                else:
-                    buf = bufs[key]
-                    dist.broadcast(buf, src=src, group=group)
-                    if buf.is_cuda:
-                        torch.cuda.current_stream().synchronize()      # the row is complete before any other stream (the importing object's) reads it
-                    tensors, at = [], 0
-                    for i, n in enumerate(sizes):
-                        part = buf[at:at + n]
-                        tensors.append(part if i < 3 else part.cpu())   # planes stay on the device; the two small maps are host records
-                        at += n
-                    import_row(k, row, tensors)
+class _Cursor:
+    """the rows this rank has still to publish: its pictures in coding order, rows top to bottom, the unreferenced pictures left out"""
+
+    def __init__(self, rank, world, n_pictures, ctu_rows, referenced):
+        self.k, self.row, self.world, self.n, self.rows, self.referenced, self.known = rank, 0, world, n_pictures, ctu_rows, referenced, False
+
+    def done(self):
+        return self.k >= self.n
+
+    def settle(self):
+        """skips pictures that do not travel; False while the answer for the current picture is not known yet"""
+        while self.k < self.n and not self.known:
+            r = True if self.referenced is None else self.referenced(self.k)
+            if r is None:
+                return False
+            if r:
+                self.known = True
+            else:
+                self.k += self.world
+        return True
+
+    def advance(self):
+        self.row += 1
+        if self.row == self.rows:
+            self.row, self.k, self.known = 0, self.k + self.world, False
+
+
+def _pump_world1(export_row, n_pictures, ctu_rows, on_row, referenced):
+    cur = _Cursor(0, 1, n_pictures, ctu_rows, referenced)
+    t_idle = time.monotonic()
+    while not cur.done():
+        if cur.settle() and not cur.done():
+            t = export_row(cur.k, cur.row)
+            if t is not None:
                 if on_row:
-                    on_row(k, row, src)
-    except BaseException as e:          # a stream that dies must not leave the others (and the peers' collectives) hanging without a word
-        errors.append((src, e))
-        raise
+                    on_row(cur.k, cur.row, 0)
+                cur.advance()
+                t_idle = time.monotonic()
+                continue
+        if time.monotonic() - t_idle > 600.0:
+            raise RuntimeError("row pump: nothing became final for 600 s")
+        time.sleep(0.0002)
 
 
-def pump(export_row, import_row, shapes, n_pictures, ctu_rows, device, rank=None, world=None, on_row=None, referenced=None, groups=None):
-    """Runs the publication schedule for pictures 0 .. n_pictures - 1 (coding order): one stream per owner (see the module text).  `groups`: a process group per
-    source rank (every rank calls pump at the same point, so creating them here is collective too)."""
+def pump(export_row, import_row, shapes, n_pictures, ctu_rows, device, rank=None, world=None, on_row=None, referenced=None, group=None, idle_timeout_s=600.0):
+    """Runs the publication schedule for pictures 0 .. n_pictures - 1 (coding order) on the calling thread (see the module text).  `group`: the process group to use
+    (None: the default one).  On a GPU the collectives, the packing copies and the waits run on a stream of this call's own."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    errors = []
     if world == 1:
-        _stream(0, export_row, import_row, shapes, n_pictures, ctu_rows, device, 0, 1, None, on_row, referenced, errors)
+        _pump_world1(export_row, n_pictures, ctu_rows, on_row, referenced)
         return
-    if groups is None:
-        groups = [dist.new_group(ranks=list(range(world))) for _ in range(world)]
-    threads = [threading.Thread(target=_stream, name="rows-of-rank-%d" % s, daemon=True,
-                                args=(s, export_row, import_row, shapes, n_pictures, ctu_rows, device, rank, world, groups[s], on_row, referenced, errors))
-               for s in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    if errors:
-        raise RuntimeError("row pump: the stream of rank %d failed: %r" % errors[0])
+    dev = torch.device(device)
+    stream = None
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)                      # a new thread starts on device 0: the collectives and the waits below belong to THIS rank's device
+        stream = torch.cuda.Stream(dev)
+    ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+    with ctx:
+        _slots(export_row, import_row, shapes, n_pictures, ctu_rows, dev, stream, rank, world, on_row, referenced, group, idle_timeout_s)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _slots(export_row, import_row, shapes, n_pictures, ctu_rows, dev, stream, rank, world, on_row, referenced, group, idle_timeout_s):
+    cur = _Cursor(rank, world, n_pictures, ctu_rows, referenced)
+    state = [STATE_MORE] * world
+    pending = []                    # (k, row, tensors) received but not importable yet
+    failure = None
+    cur_first = (0, 0)
+    t_moved = time.monotonic()
+
+    def local(step):
+        """a local step must not leave the peers hanging in the next collective: its failure travels in the next header"""
+        nonlocal failure
+        if failure is None:
+            try:
+                return step()
+            except BaseException as e:      # noqa: B902
+                failure = e
+        return None
+
+    def try_imports():
+        moved = False
+        keep = []
+        unknown = set()             # a picture refused once is left alone for the rest of this pass: its rows go in in order
+        for k, row, tensors in pending:
+            if k in unknown:
+                keep.append((k, row, tensors))
+            elif failure is None and local(lambda: import_row(k, row, tensors)) is not False and failure is None:
+                moved = True
+                if on_row:
+                    on_row(k, row, owner_of(k, world))
+            else:
+                unknown.add(k)
+                keep.append((k, row, tensors))
+        pending[:] = keep
+        return moved
+
+    while True:
+        # ---- what this rank has ready (a look, never a wait) ----
+        mine = []
+        if failure is None and not cur.done() and local(cur.settle):
+            first = (cur.k, cur.row)
+            while not cur.done() and cur.k == first[0] and len(mine) < ROWS_PER_SLOT:
+                t = local(lambda: export_row(cur.k, cur.row))
+                if t is None:
+                    break
+                mine.append(t)
+                if on_row:
+                    on_row(cur.k, cur.row, rank)
+                cur.advance()
+            if mine:
+                cur_first = first
+        my_state = STATE_FAILED if failure is not None else (STATE_DONE if cur.done() and not mine else STATE_MORE)
+        hdr = torch.zeros(world, 4, dtype=torch.int64)
+        hdr[rank] = torch.tensor([cur_first[0] if mine else 0, cur_first[1] if mine else 0, len(mine), my_state], dtype=torch.int64)
+        hdr = hdr.to(dev)
+        dist.all_reduce(hdr, group=group)               # every rank filled its own line only: the sum is the table
+        table = hdr.cpu().tolist()
+        if any(line[3] == STATE_FAILED for line in table):
+            who = [s for s, line in enumerate(table) if line[3] == STATE_FAILED]
+            if failure is not None:
+                raise RuntimeError("row pump: rank %d failed: %r" % (rank, failure)) from failure
+            raise RuntimeError("row pump: rank(s) %s failed; this rank stops with them" % who)
+        moved = False
+        for s in range(world):
+            k, row0, n, st = table[s]
+            state[s] = st
+            if not n:
+                continue
+            moved = True
+            sizes = [list(shapes(row0 + j)) for j in range(n)]
+            total = sum(sum(z) for z in sizes)
+            buf = torch.empty(total, dtype=torch.uint8, device=dev)
+            if s == rank:
+                at = 0
+                for tensors, z in zip(mine, sizes):
+                    for t, m in zip(tensors, z):
+                        buf[at:at + m].copy_(t, non_blocking=True)
+                        at += m
+            dist.broadcast(buf, src=s, group=group)
+            if s != rank:
+                if stream is not None:
+                    stream.synchronize()            # the rows are complete before any other stream (the importing object's) reads them
+                at = 0
+                for j, z in enumerate(sizes):
+                    tensors = []
+                    for i, m in enumerate(z):
+                        part = buf[at:at + m]
+                        tensors.append(part if i < 3 else part.cpu())       # planes stay on the device; the two small maps are host records
+                        at += m
+                    pending.append((k, row0 + j, tensors))
+            elif stream is not None:
+                stream.synchronize()                # the packing copies have read the picture
+        moved |= try_imports()
+        if all(st == STATE_DONE for st in state) and not pending:
+            return
+        if moved:
+            t_moved = time.monotonic()
+        else:
+            if time.monotonic() - t_moved > idle_timeout_s:
+                failure = failure or RuntimeError("row pump: nothing moved for %.0f s (%d rows kept for pictures this rank does not know yet)" % (idle_timeout_s, len(pending)))
+                continue                           # the next header carries it
+            time.sleep(0.0002)
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -124,36 +248,23 @@ class EncoderRows:
             self._layout[row] = ([int(d.plane_offset[i]) for i in range(3)], [int(d.plane_bytes[i]) for i in range(3)], int(d.units_bytes), int(d.motion_bytes),
                                  int(d.map_offset_units), int(d.map_offset_motion))
 
-    def _wait(self, call, timeout_s=600.0):
-        import time
-        t0 = time.monotonic()
-        while True:
-            rc = call()
-            if rc == 0:
-                return
-            if rc < 0:
-                raise RuntimeError(self.lib.x265amd_last_error().decode())
-            if time.monotonic() - t0 > timeout_s:
-                raise RuntimeError("row pump: the picture did not leave the lookahead within %.0f s" % timeout_s)
-            time.sleep(0.0005)          # the picture has not left the lookahead yet
-
     def referenced(self, k):
-        """whether later pictures may reference picture k (x265amd_encoder_is_referenced): known once the picture has left the lookahead"""
-        import time
-        t0 = time.monotonic()
-        while True:
-            rc = self.lib.x265amd_encoder_is_referenced(self.enc, k)
-            if rc in (0, 1):
-                return bool(rc)
-            if rc < 0:
-                raise RuntimeError(self.lib.x265amd_last_error().decode())
-            if time.monotonic() - t0 > 600.0:
-                raise RuntimeError("row pump: picture %d did not leave the lookahead" % k)
-            time.sleep(0.0005)
+        """whether later pictures may reference picture k (x265amd_encoder_is_referenced); None while the picture has not left the lookahead"""
+        rc = self.lib.x265amd_encoder_is_referenced(self.enc, k)
+        if rc in (0, 1):
+            return bool(rc)
+        if rc < 0:
+            raise RuntimeError(self.lib.x265amd_last_error().decode())
+        return None
 
     def export_row(self, k, row):
+        """the row's tensors, or None while it is not final (x265amd_encoder_export_row with timeout 0: a look, not a wait)"""
         d = RowExport()
-        self._wait(lambda: self.lib.x265amd_encoder_export_row(self.enc, k, row, C.byref(d), 300000))
+        rc = self.lib.x265amd_encoder_export_row(self.enc, k, row, C.byref(d), 0)
+        if rc < 0:
+            raise RuntimeError(self.lib.x265amd_last_error().decode())
+        if rc != 0:
+            return None
         planes = [torch.as_tensor(_DevView(int(d.src[i]), int(d.plane_bytes[i])), device=self.device) for i in range(3)]
         units = torch.frombuffer((C.c_ubyte * d.units_bytes).from_address(d.units), dtype=torch.uint8)
         motion = torch.frombuffer((C.c_ubyte * d.motion_bytes).from_address(d.motion), dtype=torch.uint8)
@@ -167,7 +278,10 @@ class EncoderRows:
             d.src[i] = tensors[i].data_ptr(); d.plane_offset[i] = off[i]; d.plane_bytes[i] = nbytes[i]
         d.units, d.units_bytes, d.map_offset_units = tensors[3].data_ptr(), ub, uo
         d.motion, d.motion_bytes, d.map_offset_motion = tensors[4].data_ptr(), mb, mo
-        self._wait(lambda: self.lib.x265amd_encoder_import_row(self.enc, C.byref(d)))
+        rc = self.lib.x265amd_encoder_import_row(self.enc, C.byref(d))
+        if rc < 0:
+            raise RuntimeError(self.lib.x265amd_last_error().decode())
+        return rc == 0          # False: the picture has not left this object's lookahead yet -- the pump keeps the row and asks again
 
     def _geometry(self, row):
         return self._layout[row]
