@@ -154,11 +154,8 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=
         encode.last_stats = list(st) if lib.x265amd_encoder_stats(enc, st, 4) == 0 else None      # I / P / B pictures, the sum of their distinct reference pictures
     finally:
         lib.x265amd_encoder_close(enc)
-    encode.last_marks = marks
-    if shard:
-        assert coded == len(range(shard[0], len(frames), shard[1])), (coded, len(frames), shard)
-    else:
-        assert coded == len(frames), (coded, len(frames))
+    encode.last_marks = marks           # (a sharded object returns every picture, in coding order; the pictures it does not code come without NAL units)
+    assert coded == len(frames), (coded, len(frames))
     return bytes(stream), dt
 
 

@@ -35,10 +35,11 @@ def test_bench_shard_frames_two_processes_one_gpu(tmp_path):
     for rank in range(2):
         data = open("%s.%d" % (out, rank), "rb").read()
         marks = json.load(open("%s.%d.marks" % (out, rank)))
-        assert len(marks) == len(range(rank, FRAMES, 2))
-        parts.append((data[:marks[0]], [data[a:b] for a, b in zip(marks, marks[1:] + [len(data)])]))
-    assert parts[1][0] == b""                               # the parameter sets come from the rank that codes picture 0
-    together = parts[0][0] + b"".join(parts[k % 2][1][k // 2] for k in range(FRAMES))
+        assert len(marks) == FRAMES                         # every object returns every picture, in coding order: the ones it does not code come without NAL units
+        chunks = [data[a:b] for a, b in zip(marks, marks[1:] + [len(data)])]
+        assert all((len(c) > 0) == (k % 2 == rank) for k, c in enumerate(chunks)), [len(c) for c in chunks]
+        parts.append((data[:marks[0]], chunks))
+    together = parts[0][0] + b"".join(parts[k % 2][1][k] for k in range(FRAMES))
     # the same clip through ONE object in this process (the ranks have left the GPU)
     sys.path.insert(0, ROOT)
     import bench
