@@ -382,6 +382,15 @@ typedef struct x265amd_intra_nxn_job
     uint8_t mode_src[4];        /* for left_mode[0], left_mode[1], above_mode[0], above_mode[1]: 0xFF = this record's value, else (CU << 2 | unit) of chain.mode */
     uint8_t chain_index;        /* this CU's row of chain.mode (0..3) */
     uint8_t reserved2;
+    /* ---- RDOQ (Quant::m_rdoqLevel != 0, --rdoq-level 1 / 2): every transform chain of the command quantises with Quant::rdoQuant (quant.cpp:609-1424).  The bit
+     * estimates Entropy::estBit (entropy.cpp:2220-2390) makes before each transformNxN are made by the command itself, in LDS, from `ctx` -- the candidates of every
+     * unit and the chroma modes all start from m_rqt[depth].cur (search.cpp:356, :853, :1566-1690) -- for (unit size, luma) and (chroma block size, chroma) ---- */
+    int64_t rdoq_lambda2[3];    /* per plane: QpParam::lambda2 / lambda of the plane's scaled QP (x265amd_rdoq_lambda) */
+    int32_t rdoq_lambda[3];
+    int32_t psy_rdoq_scale;     /* Quant::m_psyRdoqScale */
+    uint8_t rdoq_level;         /* 0: plain quantisation (everything above as before) */
+    uint8_t rdoq_tu_depth;      /* cu.m_tuDepth of the units (selects the CBF context in rdoQuant): 1 for the four units of an NxN CU, else 0 */
+    uint8_t reserved3[6];
 } x265amd_intra_nxn_job;
 typedef struct x265amd_intra_chain { uint64_t seq, frac; uint8_t ctx[X265AMD_CTX_STRIDE]; uint8_t mode[4][4]; } x265amd_intra_chain;
 typedef struct x265amd_intra_nxn_out

@@ -3862,14 +3862,15 @@ INTRA_NXN_JOB_DT = np.dtype([("tmpl", INTRA_TU_JOB_DT, 4), ("pred_dst", "<u8", 4
                              ("frac_start", "<u8", 4), ("scan_frac", "<u4"), ("slot_pixels", "<u4"), ("slot_coeffs", "<u4"), ("left_mode", "u1", 2), ("above_mode", "u1", 2),
                              ("ctx", "u1", 160), ("max_cand", "u1"), ("do_chroma", "u1"), ("reserved", "u1", 2), ("pad", "u1", 4), ("ctmpl", INTRA_TU_JOB_DT, 2), ("crecon_dst", "<u8", 2), ("recon_dst", "<u8", 4), ("levels_dst", "<u8"), ("clevels_dst", "<u8"),
                              ("chain", "<u8"), ("peer", "<u8"), ("cu_out", "<u8"), ("peer_recon", "<u8", 3), ("win_dst", "<u8", 3), ("chain_token", "<u8"), ("chain_role", "u1"),
-                             ("chain_first", "u1"), ("mode_src", "u1", 4), ("chain_index", "u1"), ("reserved2", "u1")])
+                             ("chain_first", "u1"), ("mode_src", "u1", 4), ("chain_index", "u1"), ("reserved2", "u1"),
+                             ("rdoq_lambda2", "<i8", 3), ("rdoq_lambda", "<i4", 3), ("psy_rdoq_scale", "<i4"), ("rdoq_level", "u1"), ("rdoq_tu_depth", "u1"), ("reserved3", "u1", 6)])
 INTRA_CHAIN_DT = np.dtype([("seq", "<u8"), ("frac", "<u8"), ("ctx", "u1", 160), ("mode", "u1", (4, 4))])
 INTRA_CU8_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("frac_bits", "<u8"), ("other_cost", "<u8"), ("total_bits", "<u4"), ("mv_bits", "<u4"), ("coeff_bits", "<u4"), ("psy_energy", "<u4"),
                                 ("res_energy", "<u4"), ("luma_dist", "<u4"), ("chroma_dist", "<u4"), ("status", "<u4"), ("part_size", "u1"), ("chroma_dir", "u1"), ("cbf_u", "u1"),
                                 ("cbf_v", "u1"), ("luma_dir", "u1", 4), ("cbf_y", "u1", 4), ("reserved", "u1", 4), ("ctx", "u1", 160), ("levels", "<i2", 96)])
 INTRA_NXN_OUT_DT = np.dtype([("mode", "u1", 4), ("num_cand", "u1", 4), ("res", TU_RESULT_DT, 4), ("levels", "<i2", (4, 16)), ("psy_energy", "<u4"), ("res_energy", "<u4"),
                              ("chroma_best", "<u4"), ("chroma_reserved", "<u4"), ("cres", TU_RESULT_DT, 2), ("clevels", "<i2", (2, 16))])
-assert INTRA_NXN_JOB_DT.itemsize == 1032 and INTRA_NXN_OUT_DT.itemsize == 408 and INTRA_CU8_RESULT_DT.itemsize == 424 and INTRA_CHAIN_DT.itemsize == 192
+assert INTRA_NXN_JOB_DT.itemsize == 1080 and INTRA_NXN_OUT_DT.itemsize == 408 and INTRA_CU8_RESULT_DT.itemsize == 424 and INTRA_CHAIN_DT.itemsize == 192
 
 
 def entropy_bit_tables():

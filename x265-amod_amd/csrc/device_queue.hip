@@ -342,7 +342,7 @@ __device__ __noinline__ void xa_op_intra_nxn(const XaCmd& c, int tid)
     const XaArgsJobs4 a = *reinterpret_cast<const XaArgsJobs4*>(c.args);
     /* a.n records a.c bytes apart, one after the other (the chained CUs of a block: include/x265amd.h, x265amd_intra_nxn_list) */
     for (int i = 0; i < (a.n > 0 ? a.n : 1); i++)
-        block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(a.a + (uint64_t)i * a.c), reinterpret_cast<x265amd_intra_nxn_out*>(a.b), xa_smem, tid, 64 * XA_SERVER_WAVES);
+        block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(a.a + (uint64_t)i * a.c), reinterpret_cast<x265amd_intra_nxn_out*>(a.b), xa_smem, tid, 64 * XA_SERVER_WAVES, XA_SERVER_LDS);
 }
 
 __device__ __noinline__ void xa_op_inter_chain(const XaCmd& c, int tid)

@@ -590,12 +590,15 @@ XA_DEV uint64_t wave_coeff_bits(const uint8_t* ctx, uint8_t* ctxOut, const int16
  * ======================================================================================================= */
 #define EST_WAVES 4
 /* one table of a job list on one wavefront */
+XA_DEV void wave_est_bit(const uint8_t* ctx, int32_t* e, int log2N, int isLuma, int lane);
 XA_DEV void wave_est_bit_job(const x265amd_est_job* jobs, int ji, int lane)
 {
     const x265amd_est_job j = xa_ld_record(jobs + ji);
-    const uint8_t* ctx = reinterpret_cast<const uint8_t*>(j.ctx);
-    int32_t* e = reinterpret_cast<int32_t*>(j.est);
-    const int log2N = j.log2_tr_size, isLuma = j.is_luma;
+    wave_est_bit(reinterpret_cast<const uint8_t*>(j.ctx), reinterpret_cast<int32_t*>(j.est), j.log2_tr_size, j.is_luma, lane);
+}
+/* the table entries Entropy::estBit fills for (log2N, isLuma) from the contexts at ctx (any memory: a fused command makes its tables in LDS) */
+XA_DEV void wave_est_bit(const uint8_t* ctx, int32_t* e, int log2N, int isLuma, int lane)
+{
     /* blockCbpBits [168..181], blockRootCbpBits [182..183], significantCoeffGroupBits [0..3] */
     if (lane < 14) e[168 + lane] = (int32_t)en_bits[ctx[CTX_QT_CBF + (lane >> 1)] ^ (lane & 1)];
     if (lane < 2) e[182 + lane] = (int32_t)en_bits[ctx[CTX_QT_ROOT_CBF] ^ lane];

@@ -193,7 +193,8 @@ XA_DEV bool nxn_chain_begin(x265amd_intra_nxn_job& sP, int tid, int nthr)
 #include "intra_nxn4_dev.h"
 
 /* x265amd_intra_nxn (include/x265amd.h): the four 4x4 prediction units of an 8x8 NxN CU, decisions included, by one workgroup. */
-XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_out* po, char* smem, int tid, int nthr)
+/* smemBytes: the dynamic LDS behind smem (with RDOQ the wavefronts that run chains side by side are as many as fit with their RDOQ areas) */
+XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_out* po, char* smem, int tid, int nthr, int smemBytes)
 {
     __shared__ IntraPuShared S;
     __shared__ x265amd_tu_result s_res[16];
@@ -227,7 +228,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         if (sP.chain_role == 2) po = &reinterpret_cast<x265amd_intra_peer*>(sP.peer)->out;
     }
-    if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture)
+    if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture && !sP.rdoq_level)
     {
         /* the NxN CU proper: its own form, nothing but LDS and registers between the first and the last instruction (intra_nxn4_dev.h) */
         block_intra_nxn4(sP, po, *reinterpret_cast<Nxn4Lds*>(smem), S, tid, nthr);
@@ -256,7 +257,23 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
      * candidates), BESIDE the luma candidates' chains; behind the luma decision what is left is the signalling's share of the bits (which mode is the derived one) and,
      * when the luma mode is none of the five, one more evaluation.  The chroma working set lies behind the luma chains' LDS instead of on top of it. */
     static_assert(XA_WAVE == 64, "");
-    const bool chromaAhead = P.do_chroma && numUnits == 1 && unitLog2 == 3 && !P.pick_sa8d && nwv >= 8 && maxCand <= 6 && !XA_CHROMA_AHEAD_OFF;
+    /* RDOQ: the two bit-estimate tables of the command (luma units, chroma blocks) from its contexts, and how many wavefronts fit with an RDOQ area each */
+    const bool rdoq = P.rdoq_level != 0;
+    __shared__ int32_t s_est[2][184];
+    const int cLog2r = numUnits == 1 ? unitLog2 - 1 : 2;
+    const int perWave = (int)(sizeof(TuLds) + sizeof(IntraTuLds));
+    const int rqBytesL = rdoq_ref_bytes(unitLog2), rqBytesC = rdoq_ref_bytes(cLog2r);
+    const int nwvL = rdoq ? min(nwv, smemBytes / (perWave + rqBytesL)) : nwv, nwvC = rdoq ? min(nwv, smemBytes / (perWave + rqBytesC)) : nwv;
+    if (rdoq)
+    {
+        for (int i = tid; i < 2 * 184; i += nthr) (&s_est[0][0])[i] = 0;
+        __syncthreads();
+        if (wv == 0) wave_est_bit(P.ctx, s_est[0], unitLog2, 1, lane);
+        else if (wv == 1) wave_est_bit(P.ctx, s_est[1], cLog2r, 0, lane);
+        __syncthreads();
+    }
+    const RdoqParams rpL = { s_est[0], P.rdoq_lambda2[0], P.rdoq_lambda[0], P.psy_rdoq_scale, P.rdoq_level, P.rdoq_tu_depth };
+    const bool chromaAhead = P.do_chroma && numUnits == 1 && unitLog2 == 3 && !P.pick_sa8d && nwv >= 8 && maxCand <= 6 && !XA_CHROMA_AHEAD_OFF && !rdoq;
     Nxn4Lds& S4c = *reinterpret_cast<Nxn4Lds*>(smem + (chromaAhead ? (size_t)nwv * (sizeof(TuLds) + sizeof(IntraTuLds)) : 0));
     __shared__ uint8_t s_specModes[8];
     if (tid < 8) { const uint8_t fixed5[8] = { 0, 26, 10, 1, 34, 0, 0, 0 }; s_specModes[tid] = fixed5[tid]; }
@@ -333,8 +350,9 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         XA_STAGE(18);
         XA_NXN(3);
         const int n = S.num;
-        TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
-        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
+        TuLds& s = reinterpret_cast<TuLds*>(smem)[wv < nwvL ? wv : 0];
+        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwvL * sizeof(TuLds))[wv < nwvL ? wv : 0];
+        const RdoqRef rrL = rdoq_ref_at(smem + (size_t)nwvL * perWave + (size_t)(wv < nwvL ? wv : 0) * rqBytesL, unitLog2);
         if (chromaAhead && wv >= 6)
         {
             /* U, then V on the contexts U has moved: modes 0 .. 3 of the five by the groups of wavefront 6, the fifth by the first group of wavefront 7 */
@@ -343,7 +361,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             xa_wave_sync();
             nxn4_chroma_spec(P, S4c, s_specModes, (wv - 6) * 4, 5, 1, tabsC, lane, lane >> 4, lane & 15);
         }
-        for (int i = wv; i < n && !(chromaAhead && wv >= 6); i += nwv)
+        for (int i = wv; i < n && wv < nwvL && !(chromaAhead && wv >= 6); i += nwvL)
         {
             x265amd_intra_tu_job J = T;
             const uint32_t mode = S.modes[i];
@@ -351,7 +369,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             J.tu.fenc = (uint64_t)(uintptr_t)(const void*)S.fenc; J.tu.fenc_stride = N;
             J.tu.pred += (uint64_t)i * P.slot_pixels * sizeof(pixel); J.tu.recon += (uint64_t)i * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)i * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)i * P.slot_coeffs * sizeof(int16_t);
-            wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
+            if (rdoq) wave_intra_tu_chain_body<true>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt, &rrL, &rpL);
+            else wave_intra_tu_chain_body<false>(J, nullptr, &s_res[i], s, ip, nullptr, lane, S.nbRef, S.nbFlt);
             XA_STAGE(19);
             /* the candidate's bits and cost (codeIntraLumaQT, search.cpp:357-400).  The levels are still in this wavefront's LDS.  A 4x4 unit: its contexts as
              * independent state machines across the lanes, straight from the job's context set (a candidate is only priced, nothing is written back) */
@@ -510,7 +529,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             clOut[pl * 16 + i] = S4.clev[sw][pl][i];
         }
     }
-    else if (cLog2 == 2)
+    else if (cLog2 == 2 && !rdoq)
     {
         /* 4x4 chroma blocks (an 8x8 CU): the sixteen-lane chains of intra_nxn4_dev.h, a group per mode -- the dynamic LDS is free, the luma chains are done */
         Nxn4Lds& S4 = *reinterpret_cast<Nxn4Lds*>(smem);
@@ -554,10 +573,12 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
     }
     else {
+    /* (with RDOQ the five modes need five wavefronts with an RDOQ area each: the largest chroma block is 16x16, of which six fit) */
     if (wv < 5)
     {
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
-        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwv * sizeof(TuLds))[wv];
+        IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwvC * sizeof(TuLds))[wv];
+        const RdoqRef rrC = rdoq_ref_at(smem + (size_t)nwvC * perWave + (size_t)wv * rqBytesC, cLog2);
         const uint32_t listed = s_cmode[wv], mode = listed == 36 ? lumaDir : listed;
         for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[wv][b] = P.ctx[b];
         xa_wave_sync();
@@ -571,7 +592,12 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             if (cLog2 == 2) { J.tu.fenc = (uint64_t)(uintptr_t)(const void*)s_cfenc[pl]; J.tu.fenc_stride = 4; }
             J.tu.recon += (uint64_t)(2 * wv + pl) * P.slot_pixels * sizeof(pixel);
             J.tu.coeff += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t); J.tu.resi += (uint64_t)(2 * wv + pl) * P.slot_coeffs * sizeof(int16_t);
-            wave_intra_tu_chain_body<false>(J, nullptr, &s_cres[wv][pl], s, ip, nullptr, lane);
+            if (rdoq)
+            {
+                const RdoqParams rpC = { s_est[1], P.rdoq_lambda2[1 + pl], P.rdoq_lambda[1 + pl], P.psy_rdoq_scale, P.rdoq_level, P.rdoq_tu_depth };
+                wave_intra_tu_chain_body<true>(J, nullptr, &s_cres[wv][pl], s, ip, nullptr, lane, nullptr, nullptr, &rrC, &rpC);
+            }
+            else wave_intra_tu_chain_body<false>(J, nullptr, &s_cres[wv][pl], s, ip, nullptr, lane);
             xa_wave_sync();
             if (s_cres[wv][pl].num_sig) coeffFrac += wave_coeff_bits(s_ctxw[wv], s_ctxw[wv], s.q, cLog2, 1 + pl, 1, (int)mode, P.ctmpl[pl].tu.sign_hide, s_step, lane);
             xa_wave_sync();

@@ -513,6 +513,14 @@ struct IntraRd
                 }
                 nj.do_chroma = 1;
             }
+            if (rp->rdoq_level)
+            {
+                /* RDOQ: the command makes its bit-estimate tables from nj.ctx (m_rqt[depth].cur: where every candidate and every chroma mode starts) */
+                nj.rdoq_level = (uint8_t)rp->rdoq_level; nj.psy_rdoq_scale = rp->psy_rdoq_scale; nj.rdoq_tu_depth = (uint8_t)initTuDepth;
+                x265amd_rdoq_lambda(qpLumaScaled, &nj.rdoq_lambda2[0], &nj.rdoq_lambda[0]);
+                x265amd_rdoq_lambda(qpChromaScaled, &nj.rdoq_lambda2[1], &nj.rdoq_lambda[1]);
+                nj.rdoq_lambda2[2] = nj.rdoq_lambda2[1]; nj.rdoq_lambda[2] = nj.rdoq_lambda[1];
+            }
             if (devLog2 > 3)
             {
                 nj.levels_dst = (uint64_t)(uintptr_t)(levelsBuf ? levelsBuf : dDevLevels.p); nj.clevels_dst = (uint64_t)(uintptr_t)(clevelsBuf ? clevelsBuf : dDevCLevels.p);
@@ -523,7 +531,8 @@ struct IntraRd
     bool devIntraInInter() const
     {
         static const bool on = !(getenv("X265AMD_DEVICE_IININTER") && atoi(getenv("X265AMD_DEVICE_IININTER")) == 0);
-        return on && !rp->rdoq_level && !rp->fast_intra && log2 >= 3 && log2 <= 5 && range[0] == log2 && range[1] >= log2 && !si->tq_bypass_enabled;
+        static const bool devRdoq = !(getenv("X265AMD_DEVICE_RDOQ") && atoi(getenv("X265AMD_DEVICE_RDOQ")) == 0);
+        return on && (!rp->rdoq_level || devRdoq) && !rp->fast_intra && log2 >= 3 && log2 <= 5 && range[0] == log2 && range[1] >= log2 && !si->tq_bypass_enabled;
     }
     void buildInInterJob(x265amd_intra_nxn_job& nj, uint64_t predTileM, uint64_t reconTileM, uint64_t cand, uint64_t coeffDev, void* levelsBuf, void* clevelsBuf)
     {
@@ -549,7 +558,10 @@ struct IntraRd
         /* ... and the 16x16 CU coded 2Nx2N with its one 16x16 unit (chroma blocks 8x8): X265AMD_DEVICE_16=0 leaves it to the prediction-unit step */
         static const bool dev16 = !(getenv("X265AMD_DEVICE_16") && atoi(getenv("X265AMD_DEVICE_16")) == 0);
         static const bool dev32 = !(getenv("X265AMD_DEVICE_32") && atoi(getenv("X265AMD_DEVICE_32")) == 0);
-        const bool deviceNxN = !rp->rdoq_level && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
+        /* RDOQ (round 5): the command makes the bit estimates itself and every chain runs Quant::rdoQuant (x265amd_intra_nxn_job.rdoq_level); X265AMD_DEVICE_RDOQ=0:
+         * scan and chains as separate steps with the estimates from the host's contexts, as before */
+        static const bool devRdoq = !(getenv("X265AMD_DEVICE_RDOQ") && atoi(getenv("X265AMD_DEVICE_RDOQ")) == 0);
+        const bool deviceNxN = (!rp->rdoq_level || devRdoq) && 2 + rdLevel + ((depth + initTuDepth) >> 1) <= MAX_JOBS &&
                                (partSize != 0 ? (log2 == 3 && log2TrSize == 2 && range[0] == 2)
                                               : (dev2Nx2N && (log2 == 3 || (log2 == 4 && dev16) || (log2 == 5 && dev32)) && range[0] == log2 && range[1] >= log2));
         const int devUnits = partSize != 0 ? 4 : 1, devLog2 = partSize != 0 ? 2 : 3, devN = 1 << devLog2;
@@ -1119,7 +1131,8 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
         static const bool dev32 = !(getenv("X265AMD_DEVICE_32") && atoi(getenv("X265AMD_DEVICE_32")) == 0);
         int started = 0;
         IntraRd::Big& g = R.big[R.log2 == 5 ? 1 : 0];
-        if (ahead16 && ((R.log2 == 4 && dev16) || (R.log2 == 5 && dev32)) && g.q && g.cand.p && !g.on && !rp->rdoq_level && R.range[0] == R.log2 && R.range[1] >= R.log2 &&
+        static const bool devRdoq = !(getenv("X265AMD_DEVICE_RDOQ") && atoi(getenv("X265AMD_DEVICE_RDOQ")) == 0);
+        if (ahead16 && ((R.log2 == 4 && dev16) || (R.log2 == 5 && dev32)) && g.q && g.cand.p && !g.on && (!rp->rdoq_level || devRdoq) && R.range[0] == R.log2 && R.range[1] >= R.log2 &&
             2 + rp->rd_level + (R.depth >> 1) <= IntraRd::MAX_JOBS)
         {
             x265amd_intra_nxn_job nj;

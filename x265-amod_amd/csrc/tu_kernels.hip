@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * INTRA_PU_WAVES) void k_intra_nxn(const x265amd
 {
     extern __shared__ __attribute__((aligned(16))) char tu_smem[];
     for (int i = 0; i < n; i++)
-        block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(reinterpret_cast<const char*>(job) + (size_t)i * strideBytes), out, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES);
+        block_intra_nxn(reinterpret_cast<const x265amd_intra_nxn_job*>(reinterpret_cast<const char*>(job) + (size_t)i * strideBytes), out, tu_smem, threadIdx.x, 64 * INTRA_PU_WAVES, (int)kIntraPuLds);
 }
 
 /* =========================================================================================================
