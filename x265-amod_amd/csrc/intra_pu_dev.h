@@ -206,6 +206,11 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ uint8_t s_preds0[4];                 /* a chained CU (role 2): the first unit's predictors and the chroma modes' fractions, for the CU's own bit count */
     __shared__ unsigned long long s_cfrac[5];
     __shared__ uint32_t s_numSig0;
+    /* a chained CU decided in this general form (role 1 with RDOQ: the sixteen-lane form of intra_nxn4_dev.h has no rdoQuant): what the decision needs of the four units */
+    __shared__ uint8_t s_predsAll[4][3];
+    __shared__ x265amd_tu_result s_ures[4];
+    __shared__ int16_t s_lev[64];
+    __shared__ uint32_t s_psyNxn, s_resNxn;
     XA_STAGE(15);
     XA_NXN_START(0);
     __shared__ x265amd_intra_nxn_job sP;           /* the job record: 896 bytes, indexed by the unit -- in LDS, not in registers */
@@ -291,6 +296,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         else { p0 = left; p1 = above; p2 = (left && above) ? 0 : ((left + above) < 2 ? 26 : 1); }
         if (k == 0 && tid == 0) { s_preds0[0] = (uint8_t)p0; s_preds0[1] = (uint8_t)p1; s_preds0[2] = (uint8_t)p2; }
+        if (tid == 0) { s_predsAll[k & 3][0] = (uint8_t)p0; s_predsAll[k & 3][1] = (uint8_t)p1; s_predsAll[k & 3][2] = (uint8_t)p2; }
         XA_STAGE(16);
         XA_NXN(1);
         {
@@ -406,6 +412,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             s_win = w; s_winMode[k] = S.modes[w];
             po->mode[k] = S.modes[w]; po->num_cand[k] = (uint8_t)n; po->res[k] = s_res[w];
             if (k == 0) s_numSig0 = s_res[w].num_sig;
+            s_ures[k & 3] = s_res[w];
         }
         __syncthreads();
         XA_NXN(6);
@@ -425,6 +432,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
                 if (P.recon_dst[k]) reinterpret_cast<pixel*>(P.recon_dst[k])[y * 64 + x] = v;
                 reinterpret_cast<pixel*>(P.pred_dst[k])[y * 64 + x] = prd[y * T.tu.pred_stride + x];
                 lvOut[k * 16 + t] = lv[t];
+                if (numUnits == 4) s_lev[(k * 16 + t) & 63] = lv[t];
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the next unit's neighbours */
         }
@@ -439,7 +447,7 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         const pixel* f = reinterpret_cast<const pixel*>(T0.tu.fenc);
         const int psy = wave_psy_cost(f, T0.tu.fenc_stride, reinterpret_cast<const pixel*>(T0.nb), T0.nb_stride, 1, lane);
         const uint64_t sse = wave_sse_pp(f, T0.tu.fenc_stride, reinterpret_cast<const pixel*>(P.pred_dst[0]), 64, 8, lane);
-        if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; }
+        if (lane == 0) { po->psy_energy = (uint32_t)psy; po->res_energy = (uint32_t)sse; s_psyNxn = (uint32_t)psy; s_resNxn = (uint32_t)sse; }
     }
     XA_NXN(8);
     if (!P.do_chroma) return;
@@ -687,6 +695,137 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         __syncthreads();
         if (tid == 0) xa_chain_publish(&peer->ready, P.chain_token + 1);
+    }
+    /* The decision of a chained CU (role 1) made in this general form -- what nxn4_decide does for the sixteen-lane form: this CU's bits by the walk of
+     * intra_cu_dev.h (Search::checkIntra's count, search.cpp:1254-1275), the other evaluation's record, the two costs, checkBestMode's comparison in the order 2Nx2N,
+     * NxN (analysis.cpp:3670-3692), the winner's samples into the picture and the parent's tile, the CU's result for the host, contexts / fraction / modes to the chain.
+     * The NxN evaluation's luma is in the picture already (the units predict from each other there); its chroma blocks are in the mode's tile. */
+    if (P.chain && P.chain_role == 1 && numUnits == 4 && P.do_chroma)
+    {
+        __shared__ x265amd_intra_nxn_out s_peerOut;
+        __shared__ uint8_t s_fctx[2][X265AMD_CTX_STRIDE];
+        __shared__ uint64_t s_ffrac[2], s_fmv[2];
+        __shared__ int s_peerOk;
+        x265amd_intra_peer* peer = reinterpret_cast<x265amd_intra_peer*>(P.peer);
+        x265amd_intra_chain* ch = reinterpret_cast<x265amd_intra_chain*>(P.chain);
+        x265amd_intra_cu8_result* out = reinterpret_cast<x265amd_intra_cu8_result*>(P.cu_out);
+        const int cwIdx = s_win;
+        const uint32_t chromaN = s_cmode[cwIdx];
+        const x265amd_intra_tu_job& C0 = P.ctmpl[0];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        XA_CHAIN_START();
+        if (wv == 0)
+        {
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_fctx[0][b] = P.ctx[b];
+            xa_wave_sync();
+            IntraCuBitsIn in;
+            in.log2_cu = 3; in.nxn = 1; in.code_part_size = 1; in.inter_slice = 0; in.skip_ctx = 0; in.sign_hide = P.tmpl[0].tu.sign_hide; in.chroma_dir = (uint8_t)chromaN;
+            in.cbf_u = s_cres[cwIdx][0].num_sig != 0; in.cbf_v = s_cres[cwIdx][1].num_sig != 0; in.subdiv_flag = 0;
+            for (int k = 0; k < 4; k++)
+            {
+                in.luma_dir[k] = s_winMode[k]; in.cbf_y[k] = s_ures[k].num_sig != 0; in.lev_y[k] = s_lev + 16 * k;
+                in.preds[k][0] = s_predsAll[k][0]; in.preds[k][1] = s_predsAll[k][1]; in.preds[k][2] = s_predsAll[k][2];
+            }
+            in.lev_u = reinterpret_cast<const int16_t*>(P.ctmpl[0].tu.coeff) + (size_t)(2 * cwIdx + 0) * P.slot_coeffs;
+            in.lev_v = reinterpret_cast<const int16_t*>(P.ctmpl[1].tu.coeff) + (size_t)(2 * cwIdx + 1) * P.slot_coeffs;
+            uint64_t mvf = 0, skipf = 0;
+            const uint64_t frac = wave_intra_cu_bits(in, s_fctx[0], P.scan_frac, &mvf, &skipf, s_step, tabs, lane);
+            if (lane == 0) { s_ffrac[0] = frac; s_fmv[0] = mvf; }
+        }
+        if (tid == 64)
+        {
+            bool ok = xa_chain_wait(&peer->ready, P.chain_token + 1);
+            if (ok && __hip_atomic_load(&peer->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ~0ull) ok = false;      /* the other side gave up */
+            s_peerOk = ok ? 1 : 0;
+        }
+        __syncthreads();
+        XA_CHAIN(2);
+        if (!s_peerOk)
+        {
+            if (tid == 0) { out->status = 2; xa_chain_publish(&ch->seq, P.chain_token + 1); }
+            return;
+        }
+        for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_out) / 8); i += nthr) reinterpret_cast<uint64_t*>(&s_peerOut)[i] = reinterpret_cast<const uint64_t*>(&peer->out)[i];
+        for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) s_fctx[1][i] = peer->fctx[i];
+        if (tid == 0) { s_ffrac[1] = peer->ffrac; s_fmv[1] = peer->fmv; }
+        __syncthreads();
+        XA_CHAIN(3);
+        const x265amd_intra_nxn_out& Q = s_peerOut;
+        const uint32_t chroma2 = nxn4_chroma_stored(Q.mode[0], Q.chroma_best);
+        const uint32_t lumaN = (uint32_t)(s_ures[0].nz_dist + s_ures[1].nz_dist + s_ures[2].nz_dist + s_ures[3].nz_dist);
+        const uint32_t chromaDN = (uint32_t)(s_cres[cwIdx][0].nz_dist + s_cres[cwIdx][1].nz_dist), chromaD2 = (uint32_t)(Q.cres[0].nz_dist + Q.cres[1].nz_dist);
+        const uint32_t luma2 = (uint32_t)Q.res[0].nz_dist;
+        const uint32_t psyN = P.psy_scale ? s_psyNxn : 0u, psy2 = P.psy_scale ? Q.res[0].nz_energy : 0u;
+        const uint32_t bitsN = (uint32_t)(s_ffrac[0] >> 15), bits2 = (uint32_t)(s_ffrac[1] >> 15);
+        const uint64_t distN = (uint64_t)lumaN + chromaDN, dist2 = (uint64_t)luma2 + chromaD2;
+        const uint64_t costN = P.psy_scale ? distN + ((P.psy_scale * (uint64_t)psyN) >> 24) + (((uint64_t)bitsN * P.lambda2) >> 8) : distN + (((uint64_t)bitsN * P.lambda2 + 128) >> 8);
+        const uint64_t cost2 = P.psy_scale ? dist2 + ((P.psy_scale * (uint64_t)psy2) >> 24) + (((uint64_t)bits2 * P.lambda2) >> 8) : dist2 + (((uint64_t)bits2 * P.lambda2 + 128) >> 8);
+        const bool nxnWins = costN < cost2;
+        const int win = nxnWins ? 0 : 1;
+        {
+            const x265amd_intra_tu_job& T0 = P.tmpl[0];
+            pixel* pic = reinterpret_cast<pixel*>(T0.nb);
+            pixel* dstY = reinterpret_cast<pixel*>(P.win_dst[0]);
+            const pixel* peerY = reinterpret_cast<const pixel*>(P.peer_recon[0]);
+            if (tid < 64)
+            {
+                const int y = tid >> 3, x = tid & 7;
+                const pixel v = nxnWins ? pic[(long)y * T0.nb_stride + x] : peerY[y * 64 + x];
+                if (!nxnWins) pic[(long)y * T0.nb_stride + x] = v;
+                dstY[y * 64 + x] = v;
+            }
+            else if (tid < 96)
+            {
+                const int pl = (tid - 64) >> 4, i = tid & 15, y = i >> 2, x = i & 3;
+                const x265amd_intra_tu_job& C = P.ctmpl[pl];
+                const pixel v = nxnWins ? reinterpret_cast<const pixel*>(P.crecon_dst[pl])[y * 32 + x] : reinterpret_cast<const pixel*>(P.peer_recon[1 + pl])[y * 32 + x];
+                reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = v;
+                reinterpret_cast<pixel*>(P.win_dst[1 + pl])[y * 32 + x] = v;
+            }
+            else if (tid < 96 + 96)
+            {
+                const int i = tid - 96;
+                int16_t v;
+                if (i < 64) v = nxnWins ? s_lev[i] : Q.levels[0][i];
+                else
+                {
+                    const int pl = (i - 64) >> 4;
+                    v = nxnWins ? (reinterpret_cast<const int16_t*>(P.ctmpl[pl].tu.coeff) + (size_t)(2 * cwIdx + pl) * P.slot_coeffs)[i & 15] : Q.clevels[pl][i & 15];
+                }
+                out->levels[i] = v;
+            }
+            else if (tid < 192 + X265AMD_CTX_STRIDE)
+            {
+                const int i = tid - 192;
+                const uint8_t v = s_fctx[win][i];
+                out->ctx[i] = v; ch->ctx[i] = v;
+            }
+        }
+        (void)C0;
+        if (tid == 0)
+        {
+            out->rd_cost = nxnWins ? costN : cost2; out->other_cost = nxnWins ? cost2 : costN; out->frac_bits = s_ffrac[win];
+            const uint32_t tb = nxnWins ? bitsN : bits2, mvb = (uint32_t)(s_fmv[win] >> 15);
+            out->total_bits = tb; out->mv_bits = mvb; out->coeff_bits = tb - mvb;
+            out->psy_energy = nxnWins ? psyN : psy2; out->res_energy = nxnWins ? s_resNxn : (uint32_t)Q.res[0].zero_dist;
+            out->luma_dist = nxnWins ? lumaN : luma2; out->chroma_dist = nxnWins ? chromaDN : chromaD2;
+            out->part_size = nxnWins ? 3 : 0; out->chroma_dir = (uint8_t)(nxnWins ? chromaN : chroma2);
+            out->cbf_u = nxnWins ? (s_cres[cwIdx][0].num_sig != 0) : (Q.cres[0].num_sig != 0); out->cbf_v = nxnWins ? (s_cres[cwIdx][1].num_sig != 0) : (Q.cres[1].num_sig != 0);
+            for (int k = 0; k < 4; k++)
+            {
+                const uint8_t m = nxnWins ? s_winMode[k] : Q.mode[0];
+                out->luma_dir[k] = m; ch->mode[P.chain_index & 3][k] = m;
+                out->cbf_y[k] = nxnWins ? (s_ures[k].num_sig != 0) : (Q.res[0].num_sig != 0);
+            }
+            ch->frac = s_ffrac[win];
+            out->status = 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        XA_CHAIN(4);
+        if (tid == 0) xa_chain_publish(&ch->seq, P.chain_token + 1);
+        XA_CHAIN(5);
     }
 }
 

@@ -1345,7 +1345,9 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     IntraRd& R = *static_cast<IntraRd*>(*ws);
     void* helper = xa_queue_helper(stream);
     if (!helper || !R.dCand2.p || !R.dLayer.p || !R.dCand.p || R.ahead.on) return 1;
-    if (si->slice_type != 2 || si->use_dqp || si->tq_bypass_enabled || rp->rdoq_level || si->tu_max_depth_intra != 1 || si->tu_log2_min != 2 || si->tu_log2_max < 3 || si->max_cu_depth != 3 ||
+    /* with RDOQ (round 5) the deciding command runs the general form of the evaluation and its own decision (intra_pu_dev.h); X265AMD_CHAIN_RDOQ=0: CU by CU */
+    static const bool chainRdoq = !(getenv("X265AMD_DEVICE_RDOQ") && atoi(getenv("X265AMD_DEVICE_RDOQ")) == 0) && !(getenv("X265AMD_CHAIN_RDOQ") && atoi(getenv("X265AMD_CHAIN_RDOQ")) == 0);
+    if (si->slice_type != 2 || si->use_dqp || si->tq_bypass_enabled || (rp->rdoq_level && !chainRdoq) || si->tu_max_depth_intra != 1 || si->tu_log2_min != 2 || si->tu_log2_max < 3 || si->max_cu_depth != 3 ||
         2 + rp->rd_level + 2 > IntraRd::MAX_JOBS || x + 16 > si->pic_width || y + 16 > si->pic_height || (x & 15) || (y & 15))
         return 1;
     if (!R.qJobs.p)
