@@ -502,6 +502,8 @@ int x265amd_intra_scan(void* stream, const x265amd_intra_job* d_jobs, int n, int
  * predInterLuma/Chroma Pixel/Short :245-408, addWeightBi/Uni :411-577, Yuv::addAvg yuv.cpp:189-211 and CUData::clipMv
  * cudata.cpp:1915-1928), 4:2:0.  One job = one PU: uni- or bi-prediction from one picture per list, optional explicit
  * weights, luma and/or chroma, written to a caller-owned prediction block. */
+/* WeightParam (source/common/slice.h:288-317): inputWeight, inputOffset, log2WeightDenom, wtPresent -- the layout of x265amd_mc_job.wp's entries */
+typedef struct x265amd_weight { int16_t w, o; uint8_t denom, present; } x265amd_weight;
 typedef struct x265amd_mc_job
 {
     uint64_t dst_y, dst_u, dst_v;       /* device addresses of the PU's top-left sample in the prediction buffers */
@@ -728,6 +730,13 @@ typedef struct x265amd_inter_search_params
                                                              * decisions are final, and the caller's next command on the queue (the measurement of the prediction tile) is
                                                              * ordered behind them.  0 (every public caller): the call returns with everything done */
     int32_t lowres_blocks_in_row;                           /* Lowres::maxBlocksInRow of the fields below */
+    int32_t me_pic[2][16];                                  /* weighted == 0: unused.  Else the plane-table index MotionEstimate searches for reference r of list l
+                                                             * (MotionReference::fpelPlane: the weighted copy of the reference when its luma weight is present,
+                                                             * reference.cpp:51-116; motion.cpp:642, :781, :1599); everything else -- selectMVP's candidates, merge
+                                                             * candidates, final predictions -- reads ref_pic and weights in the prediction (predict.cpp:85-232) */
+    int32_t weighted;                                       /* 0 none; 1: a P slice with pps.bUseWeightPred, 2: a B slice with pps.bUseWeightedBiPred: `wp` holds
+                                                             * slice.m_weightPredTable and every motion compensation of the slice takes its weights from it */
+    x265amd_weight wp[2][16][3];
     uint64_t lowres_mvs[2][16];                             /* HOST address of the lookahead's motion field of the current picture towards reference r of list l
                                                              * (Lowres::lowresMvs[l][|poc - refPoc|], int16_t[blocks][2], lowres full-pel x 4 as the lookahead keeps
                                                              * them), or 0 where the lookahead has not searched that distance: Search::getLowresMV
@@ -935,9 +944,11 @@ typedef struct x265amd_slice_header
     int32_t deblocking_disabled;    /* pps.bPicDisableDeblockingFilter */
     int32_t slfase_flag;            /* slice.m_sLFaseFlag */
     int32_t wpp;                    /* entry points are written; one sub-stream per CTU row */
-    int32_t weighted_pred;          /* pps.bUseWeightPred: a P slice carries pred_weight_table() (Entropy::codePredWeightTable, entropy.cpp:1358-1429) -- here always the table of a slice
-                                     * without weights: the two denominators and a zero luma and chroma flag per L0 reference */
+    int32_t weighted_pred;          /* pps.bUseWeightPred: a P slice carries pred_weight_table() (Entropy::codePredWeightTable, entropy.cpp:1358-1429): the two denominators, a luma
+                                     * and a chroma flag per reference, then the weights of the references whose flags are set (`wp`) */
     int32_t luma_log2_weight_denom, chroma_log2_weight_denom;
+    int32_t weighted_bipred;        /* pps.bUseWeightedBiPred: the same for a B slice, list 0 then list 1 */
+    x265amd_weight wp[2][16][3];    /* slice.m_weightPredTable[list][ref][plane] (all zero: no reference carries weights) */
 } x265amd_slice_header;
 /* substreams: the raw (unescaped) CABAC sub-streams back to back, sizes[i] bytes each.  Returns the NAL size in bytes (written when it fits). */
 size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const uint8_t* substreams, const uint32_t* sizes, int num_substreams, uint8_t* out, size_t cap);
@@ -1047,6 +1058,11 @@ int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265
 typedef struct x265amd_weight_cand { int32_t present, w0, round, shift, offset; } x265amd_weight_cand;
 int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
                                 intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs);
+/* weightAnalyse's chroma planes (weightPrediction.cpp:348-375 with mcChroma :93-159 and weightCost's 4:2:0 chroma branch :205-208): costs[i] = the sum over the 8x8 blocks of the
+ * chroma plane (width x height: the plane clamped to whole 16x16 luma blocks) of SATD(source block, reference block weighted by candidate i); the reference block motion
+ * compensated with the lookahead's field d_mvs (NULL: not) exactly as mcChroma does it.  d_fenc / d_ref: sample (0, 0) of the two pictures' SOURCE chroma planes. */
+int x265amd_chroma_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* d_ref, const int16_t* d_mvs, intptr_t stride, int width, int height,
+                                int low_cu_w, int low_cu_h, const x265amd_weight_cand* cands, int n, uint32_t* costs);
 /* weight_pp_c over `count` samples of a buffer (the weighted copies of a reference's four lowres planes, margins included: slicetype.cpp:971-975).  Asynchronous. */
 int x265amd_weight_buffer(void* stream, const x265amd_pixel* d_src, x265amd_pixel* d_dst, size_t count, int w0, int round, int shift, int offset);
 

@@ -83,17 +83,15 @@ typedef struct x265amd_param
                                              * the lookahead's estimates outside its batches run in cooperative slices of max(rows / slices, 10) block rows
                                              * (slicetype.cpp:1035-1059, :3957-3970, :4004-4036) -- a slice's bottom row takes no motion predictors from the row below, so
                                              * the fields (the encoder's search candidates) and costs differ from the whole-picture ones */
-    int32_t bEnableWeightedPred;            /* param.bEnableWeightedPred (--weightp, the reference's default; needs the lookahead: scenecutThreshold > 0 or bFrameAdaptive 2).
-                                             * THE DECISION IS BUILT, CODING WITH WEIGHTS IS NOT: every picture's sums and squared sums (LookaheadTLD::calcAdaptiveQuantFrame,
-                                             * slicetype.cpp:507-513, :678-700); the lookahead's weight analysis before every list-0 search (LookaheadTLD::weightsAnalyse,
-                                             * slicetype.cpp:879-978: the candidate's cost against the unweighted one, x265amd_lowres_weight_costs) with the reference's lowres
-                                             * planes weighted for that search when it picks a weight; the slice's analysis for P pictures (weightAnalyse,
-                                             * weightPrediction.cpp:222-470: luma against list 0's first reference, motion compensated with the lookahead's vectors, every
-                                             * candidate scale and offset with the slice header's cost); pps.weighted_pred_flag and the P slices' pred_weight_table().  When the
-                                             * slice's analysis ends without a weight -- the usual case -- the stream is the reference's with weighted prediction on (the chroma
-                                             * planes are only analysed behind a luma weight).  When it picks one (fades), x265amd_encoder_encode fails and names the weight:
-                                             * weighted motion compensation and weighted reference planes for the searches are the next step; such clips need
-                                             * bEnableWeightedPred = 0 (--no-weightp) on both sides until then */
+    int32_t bEnableWeightedPred;            /* param.bEnableWeightedPred (--weightp, the reference's default; needs the lookahead: scenecutThreshold > 0 or bFrameAdaptive 2):
+                                             * every picture's sums and squared sums (LookaheadTLD::calcAdaptiveQuantFrame, slicetype.cpp:507-513, :678-700); the lookahead's weight
+                                             * analysis before every list-0 search (LookaheadTLD::weightsAnalyse, slicetype.cpp:879-978); the slice's analysis for P pictures
+                                             * (weightAnalyse, weightPrediction.cpp:222-540: luma on the lowres planes, chroma on the source planes, list 0's first reference,
+                                             * motion compensated with the lookahead's vectors); pps.weighted_pred_flag and pred_weight_table().  A slice whose analysis picks
+                                             * weights is coded with them (round 5): the motion searches read weighted copies of the reference (MotionReference, reference.cpp:
+                                             * 51-185), every prediction is weighted (Predict::motionCompensation, predict.cpp:85-232) */
+    int32_t bEnableWeightedBiPred;          /* param.bEnableWeightedBiPred (--weightb; on in the presets slower and veryslow): the same for B pictures, both lists
+                                             * (pps.weighted_bipred_flag; addWeightBi, predict.cpp:411-518) */
 } x265amd_param;
 
 /* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */

@@ -681,7 +681,47 @@ def make_encoder_og_golden(cases=None, frames_of=None, cli=None, name="encoder_o
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, name), **out)
 
 
+def make_encoder_fade_golden():
+    """the fade clips (hevc_testlib.FADE_CASES) through the reference with --log-level full: the stream, the reconstructions, the frame types, and what its weight analysis logs
+    per picture ("poc: N weights: [L0:R0 Y{scale/2^denom+offset}U{...}V{...}] [L1:R0 ...]")"""
+    import subprocess, tempfile, hashlib
+    out = {}
+    for tag, ((w, h), nframes, depth, _, _, extra) in T.FADE_CASES.items():
+        planes = T.fade_case_frames(tag)
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "clip.y4m"), "wb") as f:
+                f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
+                for fr in planes:
+                    f.write(b"FRAME\n")
+                    for pl in fr:
+                        f.write(np.ascontiguousarray(pl).tobytes())
+            exe = os.path.join(T.REF_DIR, "x265_ref%d" % depth)
+            r = subprocess.run([exe, "--input", "clip.y4m", "-o", "out.hevc", "--recon", "rec.yuv", "--csv", "log.csv", "--csv-log-level", "1", "--log-level", "full"] + T.WP_CLI + extra,
+                               cwd=d, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            rec = np.fromfile(os.path.join(d, "rec.yuv"), np.uint8)
+            fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
+            assert len(rec) == fsz * nframes
+            types = []
+            for line in open(os.path.join(d, "log.csv")).read().splitlines()[1:]:
+                c = [x.strip() for x in line.split(",")]
+                if len(c) > 3 and c[0].isdigit():
+                    types.append("%s:%s" % (c[2], c[1].split("-")[0]))
+            lines = [l.split("]:", 1)[1].strip() for l in r.stderr.splitlines() if "weights:" in l]
+            out[tag + "stream"] = np.frombuffer(open(os.path.join(d, "out.hevc"), "rb").read(), np.uint8)
+            out[tag + "recon_md5"] = np.array([hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() for k in range(nframes)])
+            out[tag + "types"] = np.array(types)
+            out[tag + "weights"] = np.array(lines)
+            print(tag, len(out[tag + "stream"]), "bytes", " ".join(types))
+            for l in lines:
+                print("   ", l)
+    np.savez_compressed(os.path.join(T.GOLDEN_DIR, "encoder_fade_golden.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "fade":
+        make_encoder_fade_golden()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "og":
         make_encoder_og_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "b1":

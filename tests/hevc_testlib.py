@@ -3020,7 +3020,7 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3521,18 +3521,39 @@ WP_CASES = {
 }
 
 
-def wp_fade_frames():
-    """a fade: the accelerating-texture clip with its luma scaled towards black by 4.5 % per frame (320x192, 14 frames, 8-bit) -- the reference's weight analysis picks a
-    weight for the first P picture already"""
+def wp_fade_frames(w=320, h=192, n=14, depth=8, rate=0.045):
+    """a fade: the accelerating-texture clip with its luma scaled towards black by `rate` per frame -- the reference's weight analysis picks a weight for the first P picture
+    already (and, behind the luma weight, chroma weights: mcChroma's vectors make the unweighted chroma planes look different enough)"""
     out = []
-    for k, f in enumerate(encoder_ft_clip(320, 192, 14, 8, dy0=2, dy_inc=2, dx_step=4)):
-        y = np.clip((f[0].astype(np.float64) - 16) * (1.0 - 0.045 * k) + 16 + 0.5, 0, 255).astype(np.uint8)
+    sc = 1 << (depth - 8)
+    dt = np.uint8 if depth == 8 else np.uint16
+    for k, f in enumerate(encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)):
+        y = np.clip((f[0].astype(np.float64) - 16 * sc) * (1.0 - rate * k) + 16 * sc + 0.5, 0, 256 * sc - 1).astype(dt)
         out.append([y, f[1], f[2]])
     return out
 
 
 WP_FADE_CFG = dict(WP_BASE, bframes=3, lookaheadDepth=8)
 WP_FADE_CLI = ["--bframes", "3", "--rc-lookahead", "8"]
+# clips on which the reference's analysis DOES pick weights (round 5: coded with them): tag -> ((w, h), frames, depth, fade per frame, x265amd_param fields, the reference's options
+# on top of WP_CLI).  Golden data (tests/golden/make_golden.py fade): the stream, the reconstructions, the frame types and the reference's "weights:" log lines
+FADE_CASES = {
+    "wp_fade/": ((320, 192), 14, 8, 0.045, WP_FADE_CFG, WP_FADE_CLI),                                                                                  # P pictures only (the trellis finds no use for B)
+    "wp_fade_hbd/": ((320, 192), 12, 10, 0.045, dict(WP_BASE, bframes=2, lookaheadDepth=6), ["--bframes", "2", "--rc-lookahead", "6"]),                 # Main 10
+    # sub-sample refinement with chroma (subme 3): the searches read weighted CHROMA planes too (MotionReference::numInterpPlanes, reference.cpp:56)
+    "wp_fade_sub3/": ((320, 192), 10, 8, 0.04, dict(WP_BASE, bframes=3, lookaheadDepth=8, subpelRefine=3), ["--bframes", "3", "--rc-lookahead", "8", "--subme", "3"]),
+    # B pictures with weights (--weightb): fixed mini-GOPs so that there ARE B pictures in a fade; both lists analysed, bi-prediction weighted (addWeightBi)
+    "wp_fade_b/": ((320, 192), 13, 8, 0.03, dict(WP_BASE, bframes=2, lookaheadDepth=6, bFrameAdaptive=0, bBPyramid=0, bEnableWeightedBiPred=1),
+                   ["--bframes", "2", "--rc-lookahead", "6", "--b-adapt", "0", "--no-b-pyramid", "--weightb"]),
+    # ... and with the bidirectional candidate measured by motionCompensation (chroma SATD, subme 4) and the B pyramid
+    "wp_fade_b4_hbd/": ((256, 192), 11, 10, 0.035, dict(WP_BASE, bframes=3, lookaheadDepth=6, bFrameAdaptive=0, bEnableWeightedBiPred=1, subpelRefine=4),
+                        ["--bframes", "3", "--rc-lookahead", "6", "--b-adapt", "0", "--weightb", "--subme", "4"]),
+}
+
+
+def fade_case_frames(tag):
+    (w, h), n, depth, rate, _, _ = FADE_CASES[tag]
+    return wp_fade_frames(w, h, n, depth, rate)
 
 
 def wp_case_frames(tag):

@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 200 and T.EncParam.bEnableWeightedPred.offset == 196 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 208 and T.EncParam.bEnableWeightedPred.offset == 196 and T.EncParam.bEnableWeightedBiPred.offset == 200 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu
@@ -390,18 +390,40 @@ def test_weightp_without_weights(tag):
     assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
 
 
+FADE_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_fade_golden.npz")
+
+
+def test_fade_golden_has_weights_of_every_kind():
+    g = np.load(FADE_GOLD)
+    lines = [str(l) for tag in T.FADE_CASES for l in g[tag + "weights"]]
+    assert any("U{" in l for l in lines) and any("[L1:R0" in l for l in lines) and any("Y{" in l and "U{" not in l for l in lines)
+    assert any(":b" in str(t) for t in g["wp_fade_b/types"]) and any(":B" in str(t) for t in g["wp_fade_b4_hbd/types"])
+
+
 @pytest.mark.gpu
-def test_weightp_fade_is_refused_with_the_reference_s_weight():
-    """A fade: the reference's analysis picks a luma weight for the first P picture.  Coding with weights is not built, so the encode must fail -- naming the weight the analysis chose,
-    which is the one the reference logs for that picture (weightAnalyse with the reference motion compensated by the lookahead's vectors, themselves searched on the weighted lowres
-    planes LookaheadTLD::weightsAnalyse made: the whole decision path runs before the refusal)."""
-    g = np.load(WP_GOLD)
-    want = str(g["wp_fade/weights"][0])                       # e.g. "poc: 1 weights: [L0:R0 Y{61/64+1}]"
-    poc = int(want.split()[1]); luma = want[want.index("Y{"):want.index("}") + 1]
-    with pytest.raises(AssertionError) as err:
-        T.encoder_run(T.load_hip(8), T.wp_fade_frames(), 320, 192, **T.WP_FADE_CFG)
-    msg = str(err.value)
-    assert "coding with weights is not built" in msg and ("P picture poc %d " % poc) in msg and luma in msg, msg
+@pytest.mark.parametrize("tag", sorted(T.FADE_CASES))
+def test_fade_coded_with_weights(tag, capfd):
+    """Fades: the reference's weight analysis picks weights (luma, chroma behind a luma weight; with --weightb for both lists of a B picture) and codes with them.  Compared:
+    what the analysis decides per picture (weightAnalyse, weightPrediction.cpp:222-540 -- X265AMD_WP_LOG prints the reference's --log-level full line), then the stream and the
+    reconstructions: pred_weight_table() (entropy.cpp:1358-1429), the motion searches on weighted copies of the reference pictures (MotionReference, reference.cpp:51-185; the
+    chroma planes too with subme > 2), every prediction weighted (Predict::motionCompensation, predict.cpp:85-232: addWeightUni / addWeightBi).  This was the refusal test of
+    rounds 3 and 4.  Golden data: tests/golden/make_golden.py fade."""
+    g = np.load(FADE_GOLD)
+    (w, h), n, depth, _, cfg, _ = T.FADE_CASES[tag]
+    os.environ["X265AMD_WP_LOG"] = "1"
+    try:
+        stream, coded = T.encoder_run(T.load_hip(depth), T.fade_case_frames(tag), w, h, **cfg)
+    finally:
+        del os.environ["X265AMD_WP_LOG"]
+    err = capfd.readouterr().err
+    got = {int(l.split()[2]): l.split("x265amd: ", 1)[1].strip() for l in err.splitlines() if l.startswith("x265amd: poc:") and "weights:" in l}
+    want = {int(str(l).split()[1]): str(l).strip() for l in g[tag + "weights"]}
+    assert got == want, "\n".join("poc %d: got %r, the reference %r" % (k, got.get(k), want.get(k)) for k in sorted(set(got) | set(want)) if got.get(k) != want.get(k))
+    names = {1: "I", 2: "i", 3: "P", 4: "B", 5: "b"}
+    assert ["%d:%s" % (poc, names[st]) for (poc, st, _, _) in coded] == [str(t) for t in g[tag + "types"]], "frame types / coding order"
+    for (poc, _, _, planes) in coded:
+        assert hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest() == str(g[tag + "recon_md5"][poc]), "reconstruction of poc %d" % poc
+    assert not T.stream_diff(stream, g[tag + "stream"]), T.stream_diff(stream, g[tag + "stream"])
 
 
 @pytest.mark.gpu

@@ -513,6 +513,13 @@ struct Analyzer
         j.ref1 = (dir & 2) && ref[1] >= 0 ? (int8_t)S->ref_pic[1][ref[1]] : -1;
         j.mv0[0] = mv[0][0]; j.mv0[1] = mv[0][1]; j.mv1[0] = mv[1][0]; j.mv1[1] = mv[1][1];
         j.slice_type = (uint8_t)!I->is_inter_b; j.flags = 3;
+        if (S->weighted)
+        {
+            /* Predict::motionCompensation in a slice with weights (predict.cpp:85-232): pps.bUseWeightPred / bUseWeightedBiPred and the references' table entries */
+            j.flags |= S->weighted == 1 ? 4 : 8;
+            for (int l = 0; l < 2; l++)
+                if (((dir >> l) & 1) && ref[l] >= 0) memcpy(&j.wp[l][0], &S->wp[l][ref[l]][0], sizeof(j.wp[l]));
+        }
         return j;
     }
     /* motionCompensation(luma + chroma) of every PU of an inter mode into its prediction tile (rd 2: the chosen mode's chroma was not predicted yet) */
@@ -869,7 +876,7 @@ struct Analyzer
         static const bool on = !(getenv("X265AMD_FUSED_SEARCH") && atoi(getenv("X265AMD_FUSED_SEARCH")) == 0);
         const int log2 = 6 - depth, size = 1 << log2;
         const int method = S->search_method & 0x7f;
-        if (!on || I->is_inter_b || !xa_is_queue(st) || S->subpel_refine > 2 || (method != X265AMD_ME_DIA && method != X265AMD_ME_HEX && method != X265AMD_ME_STAR) ||
+        if (!on || I->is_inter_b || S->weighted || !xa_is_queue(st) || S->subpel_refine > 2 || (method != X265AMD_ME_DIA && method != X265AMD_ME_HEX && method != X265AMD_ME_STAR) ||
             I->num_ref_idx[0] < 1 || I->num_ref_idx[0] > XA_SEARCH_MAX_REFS || rp.rdoq_level || si->tu_max_depth_inter != 1 || si->use_dqp || A->rd_level < 3 || log2 > 5)
             return 0;
         if (!xa_me_device_bitsize(me) || !me) return 0;
@@ -2065,7 +2072,8 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
             /* the skip chain (inter_chain_dev.h): what it assumes of the configuration -- a skipped CU ends there (early skip + recursion skip), one transform size per
              * plane, plain quantisation -- and a device job queue to run on */
             static const bool chainEnv = !(getenv("X265AMD_INTER_CHAIN") && atoi(getenv("X265AMD_INTER_CHAIN")) == 0);
-            a.chain.on = chainEnv && si->slice_type != 2 && A->rd_level <= 4 && A->early_skip && A->rskip == 1 && !A->rdoq_level && si->tu_max_depth_inter == 1 && !si->use_dqp &&
+            /* (a slice with weights: its predictions are weighted and its searches read weighted copies -- the host path does both; the chain does not) */
+            a.chain.on = chainEnv && !S->weighted && si->slice_type != 2 && A->rd_level <= 4 && A->early_skip && A->rskip == 1 && !A->rdoq_level && si->tu_max_depth_inter == 1 && !si->use_dqp &&
                          xa_is_queue(a.st) && dCur && (dCol || !I->temporal_mvp) && I->max_num_merge_cand >= 1 && I->max_num_merge_cand <= 5 && !dump;
             if (a.chain.on) a.buildNodes(a.ctuX, a.ctuY, 0, -1);
             else a.chain.nodes[0].next = 0;

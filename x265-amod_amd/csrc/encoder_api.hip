@@ -87,6 +87,8 @@ struct Pic
     int64_t specCost2[18][18]; int specIntraMbs[18];
     uint64_t wpSum[3] = { 0, 0, 0 }, wpSsd[3] = { 0, 0, 0 };      /* Lowres::wp_sum / wp_ssd (bEnableWeightedPred) */
     int lumaDenom = 7, chromaDenom = 7;                    /* the slice's pred_weight_table denominators (weightAnalyse) */
+    x265amd_weight wp[2][16][3];                           /* slice.m_weightPredTable (weightAnalyse; all zero without weighted prediction) */
+    bool weighted = false;                                 /* some reference of this slice carries a weight */
     bool bScenecut = false, bKeyframe = false;
     const x265amd_mv_unit* regMotion = nullptr;        /* the motion field's mirror in device memory (x265amd_host.h: xa_devmap_*): what the skip chain of this and later pictures reads */
     void registerMotion()
@@ -96,7 +98,7 @@ struct Pic
         regMotion = motion.data();
         if (!xa_devmap_register(regMotion, motion.size())) regMotion = nullptr;
     }
-    Pic() { memset(refPoc, 0, sizeof(refPoc)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
+    Pic() { memset(refPoc, 0, sizeof(refPoc)); memset(wp, 0, sizeof(wp)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
     ~Pic() { if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x)
     {
@@ -195,7 +197,9 @@ struct x265amd_encoder
     int lowresInit(Pic& pic);
     void pushMiniGop(int b);
     int lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& scale, int& denom, int& offset);
-    int sliceWeights(Pic& pic, bool& weighted, int* picked = nullptr);
+    int sliceWeights(Pic& pic);
+    bool keepSources() const { return p.bEnableWeightedPred || p.bEnableWeightedBiPred; }
+    int weightRows(struct WPlane& wpl, int r0, int r1);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
     struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool whole = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
@@ -262,7 +266,7 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.amp = p.bEnableAMP != 0; s.sao = p.bEnableSAO != 0; s.temporal_mvp = p.bEnableTemporalMvp != 0; s.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0;
     s.aspect_ratio_idc = p.aspectRatioIdc;
     s.emit_timing_info = 1; s.num_units_in_tick = p.fpsDenom; s.time_scale = p.fpsNum;
-    s.weighted_pred = p.bEnableWeightedPred != 0;
+    s.weighted_pred = p.bEnableWeightedPred != 0; s.weighted_bipred = p.bEnableWeightedBiPred != 0;
     s.sign_hide = p.bEnableSignHiding != 0; s.num_ref_idx_default[0] = s.num_ref_idx_default[1] = 1; s.init_qp_minus26 = 0;
     s.wpp = p.bEnableWavefront != 0; s.loop_filter_across_slices = 1;
     s.deblocking_filter_control_present = !p.bEnableLoopFilter; s.pic_disable_deblocking = !p.bEnableLoopFilter;
@@ -326,7 +330,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     { xa_fail(X265AMD_EINVAL, "encoder_open: shardRank / shardCount (frame-per-GPU needs 0 <= rank < count and frameNumThreads > 1: rows are published by pictures coded in parallel)"); return nullptr; }
     if (p->bFrameAdaptive < 0 || p->bFrameAdaptive > 2) { xa_fail(X265AMD_EINVAL, "encoder_open: bFrameAdaptive: 0 (fixed mini-GOPs), 1 (fast) or 2 (trellis)"); return nullptr; }
     e->lookahead = p->scenecutThreshold > 0 || (p->bFrameAdaptive && p->bframes);
-    if (p->bEnableWeightedPred && !e->lookahead) { xa_fail(X265AMD_EINVAL, "encoder_open: bEnableWeightedPred needs the lookahead (scenecutThreshold > 0 or bFrameAdaptive 2 with B frames)"); return nullptr; }
+    if ((p->bEnableWeightedPred || p->bEnableWeightedBiPred) && !e->lookahead) { xa_fail(X265AMD_EINVAL, "encoder_open: bEnableWeightedPred needs the lookahead (scenecutThreshold > 0 or bFrameAdaptive 2 with B frames)"); return nullptr; }
     {
         /* Encoder::configure (encoder.cpp:3658-3663) */
         int kmin = p->keyframeMin;
@@ -593,7 +597,7 @@ int x265amd_encoder::lowresInit(Pic& pic)
     if (rc != X265AMD_OK) return rc;
     /* the picture's sums for the weight analysis are measured in front of the one wait of this function */
     static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");          /* debugging aid: letters s / l / p switch the sums, the lookahead's analysis, the slice's analysis off */
-    const bool sums = p.bEnableWeightedPred && !(dbgWp && strchr(dbgWp, 's'));
+    const bool sums = (p.bEnableWeightedPred || p.bEnableWeightedBiPred) && !(dbgWp && strchr(dbgWp, 's'));
     if (sums)
     {
         /* LookaheadTLD::calcAdaptiveQuantFrame with AQ off (slicetype.cpp:507-513): acEnergyCu over every 16x16 block for Lowres::wp_sum / wp_ssd, then :678-700 */
@@ -700,105 +704,170 @@ int x265amd_encoder::lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& 
     return X265AMD_OK;
 }
 
-/* weightAnalyse (weightPrediction.cpp:222-470) for a P picture: list 0's first reference.  The chroma denominator that fits both chroma scale guesses; luma: the early exit, else
- * the reference motion compensated with the lookahead's vectors of that distance (mcLuma) against every candidate scale (+-4 around the guess) and offset (+-2 around the
- * mean's), each with the slice header's cost, a smaller denominator if the scale is even, the 0.998 test.  Without a luma weight chroma is not looked at.  weighted: the
- * analysis chose a luma weight */
-int x265amd_encoder::sliceWeights(Pic& pic, bool& weighted, int* picked)
+/* weightAnalyse (weightPrediction.cpp:222-540) for a P picture (list 0) or, with weighted bi-prediction, a B picture (both lists): the first reference of each list.  The chroma
+ * denominator that fits both chroma scale guesses; per plane: the early exit, else the reference motion compensated with the lookahead's vectors of that distance (mcLuma on the
+ * lowres planes, mcChroma on the SOURCE chroma planes) against every candidate scale (+-4 around the guess) and offset (+-2 around the mean's), each with the slice header's cost,
+ * a smaller luma denominator if the scale is even, the 0.998 test.  Without a luma weight chroma is not looked at.  Leaves slice.m_weightPredTable in pic.wp and pic.weighted
+ * (some reference carries a weight). */
+int x265amd_encoder::sliceWeights(Pic& pic)
 {
-    weighted = false;
-    Pic& ref = *pic.lists[0][0];
+    pic.weighted = false;
+    memset(pic.wp, 0, sizeof(pic.wp));
+    const int numDirs = isBType(pic.type) ? 2 : 1;
     const float epsilon = 1.f / 128.f;
     const int w16 = ((W + 15) >> 4) << 4, h16 = ((H + 15) >> 4) << 4;
     int numpixels[3];
     numpixels[0] = w16 * h16; numpixels[1] = numpixels[2] = numpixels[0] >> 2;
-    float guessScale[3], fencMean[3], refMean[3];
-    for (int plane = 0; plane < 3; plane++)
-    {
-        const uint64_t fencVar = pic.wpSsd[plane] + !ref.wpSsd[plane], refVar = ref.wpSsd[plane] + !ref.wpSsd[plane];
-        guessScale[plane] = sqrt((float)fencVar / refVar);
-        fencMean[plane] = (float)pic.wpSum[plane] / (numpixels[plane]) / (1 << (X265AMD_DEPTH - 8));
-        refMean[plane] = (float)ref.wpSum[plane] / (numpixels[plane]) / (1 << (X265AMD_DEPTH - 8));
-    }
-    int chromaDenom = 7;
-    const int lumaDenom = 7;
-    while (chromaDenom > 0)
-    {
-        const float thresh = 127.f / (1 << chromaDenom);
-        if (guessScale[1] < thresh && guessScale[2] < thresh) break;
-        chromaDenom--;
-    }
-    pic.lumaDenom = lumaDenom; pic.chromaDenom = chromaDenom;
-    if (fabsf(refMean[0] - fencMean[0]) < 0.5f && fabsf(1.f - guessScale[0]) < epsilon) return X265AMD_OK;
-    const int denom = lumaDenom;
-    int mindenom, minscale, minoff = 0;
-    {
-        int w = (int)(guessScale[0] * (1 << denom) + 0.5f), d = denom;
-        while (d > 0 && w > 127) { d--; w >>= 1; }           /* bNormalize = !list */
-        w = std::min(w, 127);
-        mindenom = d; minscale = w;
-    }
-    const int diffPoc = abs(pic.poc - ref.poc);
-    const bool haveMvs = diffPoc <= p.bframes + 1 && diffPoc < 18 && !pic.lowMvs[diffPoc].empty();
-    /* the candidates in the order the reference tries them */
-    struct Cand { int scale, off, startOffset, iter; };
-    std::vector<Cand> order;
-    std::vector<x265amd_weight_cand> cands(1);
-    memset(&cands[0], 0, sizeof(cands[0]));
-    const int startScale = std::max(0, std::min(127, minscale - 4)), endScale = std::max(0, std::min(127, minscale + 4));
-    for (int scale = startScale; scale <= endScale; scale++)
-    {
-        const int deltaWeight = scale - (1 << mindenom);
-        if (deltaWeight > 127 || deltaWeight <= -128) continue;
-        int curScale = scale;
-        int curOffset = (int)(fencMean[0] - refMean[0] * curScale / (1 << mindenom) + 0.5f);
-        if (curOffset < -128 || curOffset > 127)
-        {
-            curOffset = std::max(-128, std::min(127, curOffset));
-            curScale = (int)((1 << mindenom) * (fencMean[0] - curOffset) / refMean[0] + 0.5f);
-            curScale = std::max(0, std::min(127, curScale));
-        }
-        const int startOffset = std::max(-128, std::min(127, curOffset - 2)), endOffset = std::max(-128, std::min(127, curOffset + 2));
-        for (int off = startOffset; off <= endOffset; off++) { order.push_back({ curScale, off, startOffset, scale }); cands.push_back(weightCand(curScale, mindenom, off)); }
-    }
-    void* dMvs = nullptr;
-    if (haveMvs)
-    {
-        /* (a record the host writes in place: no copy from pageable memory) */
-        if (!wpMvs || pic.lowMvs[diffPoc].size() * 2 > (size_t)lowCuW * lowCuH * 4) return xa_fail(X265AMD_EHIP, "encoder_encode: lowres vectors");
-        dMvs = wpMvs;
-        memcpy(dMvs, pic.lowMvs[diffPoc].data(), pic.lowMvs[diffPoc].size() * 2);
-    }
-    std::vector<uint32_t> costs(cands.size(), 0);
-    const pixel* refPlanes[4];
-    for (int t = 0; t < 4; t++) refPlanes[t] = ref.dLowres + (size_t)t * lowPlaneElems + lowOrg;
-    const int rc = x265amd_lowres_weight_costs(laStream, pic.dLowres + lowOrg, refPlanes, (const int16_t*)dMvs, pic.dIntraCost, lowStride, lowW, lowH, cands.data(), (int)cands.size(), costs.data());
-    if (rc != X265AMD_OK) return rc;
-    const uint32_t origscore = costs[0];
-    if (!origscore) return X265AMD_OK;
-    uint32_t minscore = origscore;
-    bool bFound = false;
+    auto setW = [](x265amd_weight& w, bool present, int scale, int denom, int off) { w.present = present; w.w = (int16_t)scale; w.denom = (uint8_t)denom; w.o = (int16_t)off; };
+    int chromaDenom = 7, lumaDenom = 7;
     const int lambda = X265AMD_DEPTH > 8 ? 16 : 1;          /* (int)x265_lambda_tab[X265_LOOKAHEAD_QP] */
-    for (size_t k = 0; k < order.size(); k++)
+    for (int list = 0; list < numDirs; list++)
     {
-        const Cand& c = order[k];
-        /* sliceHeaderCost(&wsp, lambda, 0) */
-        const int hdr = lambda * (10 + bsSizeUe((unsigned)mindenom) * 2 + 2 * (bsSizeSe(c.scale) + bsSizeSe(c.off)));
-        const uint32_t sc = costs[k + 1] + (uint32_t)hdr;
-        if (sc < minscore) { minscore = sc; minscale = c.scale; minoff = c.off; bFound = true; }
-        /* "Don't check any more offsets if the previous one had a lower cost than the current one": the rest of this scale's offsets are skipped */
-        if (minoff == c.startOffset && c.off != c.startOffset)
-            while (k + 1 < order.size() && order[k + 1].iter == c.iter) k++;
+        x265amd_weight* weights = pic.wp[list][0];
+        Pic& ref = *pic.lists[list][0];
+        const int diffPoc = abs(pic.poc - ref.poc);
+        float guessScale[3], fencMean[3], refMean[3];
+        for (int plane = 0; plane < 3; plane++)
+        {
+            setW(weights[plane], false, 1, 0, 0);
+            const uint64_t fencVar = pic.wpSsd[plane] + !ref.wpSsd[plane], refVar = ref.wpSsd[plane] + !ref.wpSsd[plane];
+            guessScale[plane] = sqrt((float)fencVar / refVar);
+            fencMean[plane] = (float)pic.wpSum[plane] / (numpixels[plane]) / (1 << (X265AMD_DEPTH - 8));
+            refMean[plane] = (float)ref.wpSum[plane] / (numpixels[plane]) / (1 << (X265AMD_DEPTH - 8));
+        }
+        while (!list && chromaDenom > 0)
+        {
+            const float thresh = 127.f / (1 << chromaDenom);
+            if (guessScale[1] < thresh && guessScale[2] < thresh) break;
+            chromaDenom--;
+        }
+        setW(weights[1], false, 1 << chromaDenom, chromaDenom, 0);
+        setW(weights[2], false, 1 << chromaDenom, chromaDenom, 0);
+        void* dMvs = nullptr;           /* the field of the luma analysis serves the chroma planes too */
+        for (int plane = 0; plane < 3; plane++)
+        {
+            const int denom = plane ? chromaDenom : lumaDenom;
+            if (plane && !weights[0].present) break;
+            if (fabsf(refMean[plane] - fencMean[plane]) < 0.5f && fabsf(1.f - guessScale[plane]) < epsilon) { setW(weights[plane], false, 1 << denom, denom, 0); continue; }
+            if (plane)
+            {
+                const int scale = std::max(0, std::min(255, (int)(guessScale[plane] * (1 << denom) + 0.5f)));
+                if (scale > 127) continue;
+                weights[plane].w = (int16_t)scale;
+            }
+            else
+            {
+                /* WeightParam::setFromWeightAndOffset(w, 0, denom, bNormalize = !list) (slice.h:304-316) */
+                int w = (int)(guessScale[plane] * (1 << denom) + 0.5f), d = denom;
+                while (!list && d > 0 && w > 127) { d--; w >>= 1; }
+                w = std::min(w, 127);
+                weights[plane].o = 0; weights[plane].denom = (uint8_t)d; weights[plane].w = (int16_t)w;
+            }
+            int mindenom = weights[plane].denom, minscale = weights[plane].w, minoff = 0;
+            if (!plane && diffPoc <= p.bframes + 1)
+            {
+                const std::vector<int16_t>& f = list ? pic.lowMvs1[diffPoc < 18 ? diffPoc : 0] : pic.lowMvs[diffPoc < 18 ? diffPoc : 0];
+                if (diffPoc < 18 && !f.empty())
+                {
+                    /* (a record the host writes in place: no copy from pageable memory) */
+                    if (!wpMvs || f.size() * 2 > (size_t)lowCuW * lowCuH * 4) return xa_fail(X265AMD_EHIP, "encoder_encode: lowres vectors");
+                    dMvs = wpMvs;
+                    memcpy(dMvs, f.data(), f.size() * 2);
+                }
+            }
+            /* the candidates in the order the reference tries them */
+            struct Cand { int scale, off, startOffset, iter; };
+            std::vector<Cand> order;
+            std::vector<x265amd_weight_cand> cands(1);
+            memset(&cands[0], 0, sizeof(cands[0]));
+            const int startScale = std::max(0, std::min(127, minscale - 4)), endScale = std::max(0, std::min(127, minscale + 4));
+            for (int scale = startScale; scale <= endScale; scale++)
+            {
+                const int deltaWeight = scale - (1 << mindenom);
+                if (deltaWeight > 127 || deltaWeight <= -128) continue;
+                int curScale = scale;
+                int curOffset = (int)(fencMean[plane] - refMean[plane] * curScale / (1 << mindenom) + 0.5f);
+                if (curOffset < -128 || curOffset > 127)
+                {
+                    curOffset = std::max(-128, std::min(127, curOffset));
+                    curScale = (int)((1 << mindenom) * (fencMean[plane] - curOffset) / refMean[plane] + 0.5f);
+                    curScale = std::max(0, std::min(127, curScale));
+                }
+                const int startOffset = std::max(-128, std::min(127, curOffset - 2)), endOffset = std::max(-128, std::min(127, curOffset + 2));
+                for (int off = startOffset; off <= endOffset; off++) { order.push_back({ curScale, off, startOffset, scale }); cands.push_back(weightCand(curScale, mindenom, off)); }
+            }
+            std::vector<uint32_t> costs(cands.size(), 0);
+            int rc;
+            if (!plane)
+            {
+                const pixel* refPlanes[4];
+                for (int t = 0; t < 4; t++) refPlanes[t] = ref.dLowres + (size_t)t * lowPlaneElems + lowOrg;
+                rc = x265amd_lowres_weight_costs(laStream, pic.dLowres + lowOrg, refPlanes, (const int16_t*)dMvs, pic.dIntraCost, lowStride, lowW, lowH, cands.data(), (int)cands.size(), costs.data());
+            }
+            else
+            {
+                if (!pic.dSrc || !ref.dSrc) return xa_fail(X265AMD_EHIP, "encoder_encode: weight analysis without the reference's source picture");
+                const int cw = ((W >> 4) << 4) >> 1, chh = ((H >> 4) << 4) >> 1;
+                rc = x265amd_chroma_weight_costs(laStream, pic.dSrc + org[plane], ref.dSrc + org[plane], (const int16_t*)dMvs, cstride, cw, chh, lowCuW, lowCuH, cands.data(), (int)cands.size(), costs.data());
+            }
+            if (rc != X265AMD_OK) return rc;
+            const uint32_t origscore = costs[0];
+            if (!origscore) { setW(weights[plane], false, 1 << denom, denom, 0); continue; }
+            uint32_t minscore = origscore;
+            bool bFound = false;
+            for (size_t k = 0; k < order.size(); k++)
+            {
+                const Cand& c = order[k];
+                /* sliceHeaderCost(&wsp, lambda, !!plane): four times the lambda for chroma (analysed at full resolution), the denominator counted twice for luma */
+                const int lam = plane ? lambda * 4 : lambda;
+                const int hdr = lam * (10 + bsSizeUe((unsigned)mindenom) * (plane ? 1 : 2) + 2 * (bsSizeSe(c.scale) + bsSizeSe(c.off)));
+                const uint32_t sc = costs[k + 1] + (uint32_t)hdr;
+                if (sc < minscore) { minscore = sc; minscale = c.scale; minoff = c.off; bFound = true; }
+                /* "Don't check any more offsets if the previous one had a lower cost than the current one": the rest of this scale's offsets are skipped */
+                if (minoff == c.startOffset && c.off != c.startOffset)
+                    while (k + 1 < order.size() && order[k + 1].iter == c.iter) k++;
+            }
+            if (!(plane || list) && mindenom > 0 && !(minscale & 1))
+            {
+                const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
+                const int shift = std::min(idx, mindenom);
+                mindenom -= shift; minscale >>= shift;
+            }
+            if (!bFound || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f) setW(weights[plane], false, 1 << denom, denom, 0);
+            else setW(weights[plane], true, minscale, mindenom, minoff);
+        }
+        if (weights[0].present && weights[1].present != weights[2].present)
+        {
+            /* "make sure both chroma channels match" */
+            if (weights[1].present) weights[2] = weights[1]; else weights[1] = weights[2];
+        }
+        lumaDenom = weights[0].denom; chromaDenom = weights[1].denom;
+        for (size_t r = 1; r < pic.lists[list].size(); r++)
+        {
+            setW(pic.wp[list][r][0], false, 1 << lumaDenom, lumaDenom, 0);
+            setW(pic.wp[list][r][1], false, 1 << chromaDenom, chromaDenom, 0);
+            setW(pic.wp[list][r][2], false, 1 << chromaDenom, chromaDenom, 0);
+        }
+        for (int plane = 0; plane < 3; plane++) pic.weighted |= weights[plane].present != 0;
     }
-    if (mindenom > 0 && !(minscale & 1))
+    pic.lumaDenom = pic.wp[0][0][0].denom; pic.chromaDenom = pic.wp[0][0][1].denom;         /* what pred_weight_table() codes once: the first reference's (entropy.cpp:1376-1387) */
+    static const bool wpLog = getenv("X265AMD_WP_LOG") != nullptr;
+    if (wpLog && pic.weighted)
     {
-        const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
-        const int shift = std::min(idx, mindenom);
-        mindenom -= shift; minscale >>= shift;
+        /* the reference's --log-level full line */
+        char buf[512]; int n = snprintf(buf, sizeof(buf), "poc: %d weights:", pic.poc);
+        for (int list = 0; list < numDirs; list++)
+        {
+            const x265amd_weight* w = pic.wp[list][0];
+            if (!(w[0].present || w[1].present || w[2].present)) continue;
+            n += snprintf(buf + n, sizeof(buf) - n, " [L%d:R0 ", list);
+            if (w[0].present) n += snprintf(buf + n, sizeof(buf) - n, "Y{%d/%d%+d}", w[0].w, 1 << w[0].denom, w[0].o);
+            if (w[1].present) n += snprintf(buf + n, sizeof(buf) - n, "U{%d/%d%+d}", w[1].w, 1 << w[1].denom, w[1].o);
+            if (w[2].present) n += snprintf(buf + n, sizeof(buf) - n, "V{%d/%d%+d}", w[2].w, 1 << w[2].denom, w[2].o);
+            n += snprintf(buf + n, sizeof(buf) - n, "]");
+        }
+        fprintf(stderr, "x265amd: %s\n", buf);
     }
-    if (!bFound || (minscale == (1 << mindenom) && minoff == 0) || (float)minscore / origscore > 0.998f) return X265AMD_OK;
-    weighted = true;
-    if (picked) { picked[0] = minscale; picked[1] = mindenom; picked[2] = minoff; }
     return X265AMD_OK;
 }
 
@@ -1401,19 +1470,12 @@ int x265amd_encoder::prepare(const PicP& picp)
         }
     }
     static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");
-    if (p.bEnableWeightedPred && stype == 1 && !(dbgWp && strchr(dbgWp, 'p')))
+    memset(pic.wp, 0, sizeof(pic.wp)); pic.weighted = false;
+    if (((p.bEnableWeightedPred && stype == 1) || (p.bEnableWeightedBiPred && stype == 0)) && !(dbgWp && strchr(dbgWp, 'p')))
     {
-        bool weighted = false; int picked[3] = { 0, 0, 0 };
-        const int rcw = sliceWeights(pic, weighted, picked);
+        /* FrameEncoder::compressFrame (frameencoder.cpp:553-582): weightAnalyse for P slices with --weightp, for B slices with --weightb */
+        const int rcw = sliceWeights(pic);
         if (rcw != X265AMD_OK) return rcw;
-        if (weighted)
-        {
-            /* (the reference's --log-level full line for the picture: "poc: N weights: [L0:R0 Y{scale/2^denom+offset}") */
-            static thread_local char msg[320];
-            snprintf(msg, sizeof(msg), "encoder_encode: the weight analysis chose a luma weight for the P picture poc %d against poc %d: Y{%d/%d%+d}; coding with weights is not built -- "
-                     "bEnableWeightedPred = 0 (--no-weightp) on both sides", pic.poc, pic.lists[0][0]->poc, picked[0], 1 << picked[1], picked[2]);
-            return xa_fail(X265AMD_EINVAL, msg);
-        }
     }
     pic.sliceQp = pic.type == TYPE_BREF ? (qpConstant[0] + qpConstant[1]) / 2 : qpConstant[stype];                    /* rateControlStart, CQP (ratecontrol.cpp:1594-1597: a referenced B picture lies between B and P) */
     picList.insert(picList.begin(), picp);              /* PicList::pushFront */
@@ -1435,15 +1497,28 @@ int x265amd_encoder::prepare(const PicP& picp)
 }
 
 /* what the analysis and the slice header of one picture need, derived from the picture's lists (DPB::prepareEncode has run) */
+/* MotionReference with weights (reference.cpp:51-185): the weighted copy of a reference picture that the motion searches of ONE slice read (luma; chroma too when the
+ * sub-sample refinement measures chroma, subme > 2), made CTU row by CTU row as the reference picture's rows become final (applyWeight).  The copy is the pointwise
+ * weight_pp_c of the padded plane: the margins of the reconstruction repeat its edge samples, so weighting them is what extending the weighted rows gives. */
+struct WPlane
+{
+    Pic* src = nullptr; x265amd_weight w[3]; pixel* buf = nullptr; bool chroma[3] = { false, false, false };
+    std::mutex mu; std::vector<uint8_t> rowDone; hipStream_t st = nullptr;
+    ~WPlane() { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } xa_scratch_free(buf); }
+};
 struct FrameCtx
 {
     int stype = 0;
-    std::vector<uint64_t> planes;           /* reference pictures (distinct), then the reconstruction, then the source: 3 addresses each */
+    std::vector<uint64_t> planes;           /* reference pictures (distinct), then the weighted copies of this slice (wplanes), then the reconstruction, then the source: 3 addresses each */
+    int numRefs = 0;
+    std::vector<std::unique_ptr<WPlane>> wplanes;
+    int32_t mePic[2][16];
     x265amd_mvpred_info info;
     x265amd_inter_search_params sp;
     x265amd_slice_info si;
     x265amd_analysis_params ap;
     const Pic* colPic = nullptr;
+    bool failed = false;
 };
 
 static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
@@ -1465,6 +1540,24 @@ static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
             refPic[l][r] = (int32_t)k;
             if (!e.frameParallel) pic.refPoc[l][r] = q->poc;
         }
+    c.numRefs = (int)index.size();
+    memcpy(c.mePic, refPic, sizeof(c.mePic));
+    if (pic.weighted)
+        for (int l = 0; l < 2; l++)
+            for (size_t r = 0; r < lists[l].size(); r++)
+            {
+                if (!pic.wp[l][r][0].present) continue;         /* MotionReference::init is given weights only when the luma weight is there (frameencoder.cpp:573-577) */
+                std::unique_ptr<WPlane> wpl(new WPlane);
+                wpl->src = lists[l][r].get();
+                memcpy(wpl->w, pic.wp[l][r], sizeof(wpl->w));
+                wpl->rowDone.assign(e.ctuH, 0);
+                if (xa_scratch_alloc((void**)&wpl->buf, e.picElems * sizeof(pixel)) != hipSuccess || hipStreamCreateWithFlags(&wpl->st, hipStreamNonBlocking) != hipSuccess) { c.failed = true; return; }
+                wpl->chroma[0] = true;
+                for (int cc = 1; cc < 3; cc++) wpl->chroma[cc] = p.subpelRefine > 2 && pic.wp[l][r][cc].present;     /* numInterpPlanes (reference.cpp:56) */
+                c.mePic[l][r] = (int32_t)(c.planes.size() / 3);
+                for (int cc = 0; cc < 3; cc++) c.planes.push_back(wpl->chroma[cc] ? e.planeAddr(wpl->buf, cc) : e.planeAddr(wpl->src->finalPlanes(), cc));
+                c.wplanes.push_back(std::move(wpl));
+            }
     for (int cc = 0; cc < 3; cc++) c.planes.push_back(e.planeAddr(pic.dRec, cc));
     for (int cc = 0; cc < 3; cc++) c.planes.push_back(e.planeAddr(pic.dSrc, cc));
 
@@ -1482,6 +1575,8 @@ static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
     sp.search_method = p.searchMethod; sp.subpel_refine = p.subpelRefine; sp.search_range = p.searchRange; sp.qp = pic.sliceQp; sp.chroma_mc = 1;
     sp.frame_parallel = e.frameParallel;
     memcpy(sp.ref_pic, refPic, sizeof(sp.ref_pic));
+    memcpy(sp.me_pic, c.mePic, sizeof(sp.me_pic));
+    if (pic.weighted) { sp.weighted = stype == 1 ? 1 : 2; memcpy(sp.wp, pic.wp, sizeof(sp.wp)); }
     sp.lowres_blocks_in_row = e.lowCuW;
     for (int l = 0; l < 2; l++)
         for (size_t r = 0; r < lists[l].size(); r++)
@@ -1529,7 +1624,8 @@ static int sliceNal(const x265amd_encoder& e, Pic& pic, const FrameCtx& c, const
     h.slice_qp = pic.sliceQp; h.pps_init_qp = 26; h.deblocking_disabled = !p.bEnableLoopFilter;
     h.slfase_flag = (0x5f4e4a53u >> (pic.poc % 31)) & 1;                                              /* SLFASE_CONSTANT (dpb.cpp:294) */
     h.wpp = p.bEnableWavefront != 0;
-    h.weighted_pred = p.bEnableWeightedPred != 0; h.luma_log2_weight_denom = pic.lumaDenom; h.chroma_log2_weight_denom = pic.chromaDenom;
+    h.weighted_pred = p.bEnableWeightedPred != 0; h.weighted_bipred = p.bEnableWeightedBiPred != 0; h.luma_log2_weight_denom = pic.lumaDenom; h.chroma_log2_weight_denom = pic.chromaDenom;
+    memcpy(h.wp, pic.wp, sizeof(h.wp));
     size_t dataBytes = 0;
     for (int s = 0; s < nsub; s++) dataBytes += sizes[s];
     pic.nalBytes.assign(dataBytes * 3 / 2 + 4096, 0);
@@ -1553,6 +1649,9 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
     const std::vector<PicP>* lists = pic.lists;
     FrameCtx fc;
     frameContext(*this, pic, fc);
+    if (fc.failed) return xa_fail(X265AMD_EHIP, "encoder: weighted reference planes");
+    for (auto& wpl : fc.wplanes)            /* one picture at a time: the reference pictures are complete, so are their weighted copies */
+        if (weightRows(*wpl, 0, ctuH - 1) != X265AMD_OK) return X265AMD_EHIP;
     const int stype = fc.stype;
     std::vector<uint64_t>& planes = fc.planes;
     x265amd_mvpred_info& info = fc.info;
@@ -1642,9 +1741,9 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
 
     rc = sliceNal(*this, pic, fc, saoFlags, data, sizes, nsub);
     if (rc) return rc;
-    /* the source is no longer needed; the reconstruction stays while the picture is referenced.  The reference lists are only needed by pictures
-     * that are still to come through their own lists */
-    xa_scratch_free(pic.dSrc); pic.dSrc = nullptr;
+    /* the source is no longer needed (unless the weight analysis of later pictures reads its chroma planes: weightAnalyse works on source pictures); the reconstruction
+     * stays while the picture is referenced.  The reference lists are only needed by pictures that are still to come through their own lists */
+    if (!keepSources()) { xa_scratch_free(pic.dSrc); pic.dSrc = nullptr; }
     return 0;
 }
 
@@ -1652,7 +1751,7 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
  * FrameEncoder::compressFrame as the reference runs it with several frame encoders (frameencoder.cpp:880-960, :1930-1960; framefilter.cpp:559-664): a CTU row
  * of this picture starts when every reference picture has finished the rows down to refLagRows below it, and the in-loop filters follow the analysis row by
  * row so that the rows of this picture become available to the pictures that reference it while its lower rows are still being analysed. */
-struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; };
+struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; FrameCtx* fc = nullptr; };
 
 /* What a CTU may read of a reference picture, and when.  The reference waits for whole rows: row + refLagRows rows of every reference picture before a row
  * starts (frameencoder.cpp:893-908).  What the row's commands can actually read is less -- vectors end searchRange samples below the block (search.cpp:92,
@@ -1704,6 +1803,23 @@ static int gateRefWait(void* ctx, int picIdx, int yMin, int yMax, int xMax)
 {
     RowGate& g = *(RowGate*)ctx;
     const x265amd_encoder& e = *g.e;
+    if (picIdx >= (int)g.refs.size() && g.fc && picIdx - (int)g.refs.size() < (int)g.fc->wplanes.size())
+    {
+        /* a weighted copy (a motion search of a slice with weights): whole CTU rows of the reference picture, then the copy's rows (MotionReference::applyWeight at the
+         * row's start, frameencoder.cpp:900-908) */
+        WPlane& wpl = *g.fc->wplanes[picIdx - (int)g.refs.size()];
+        Pic* q = wpl.src;
+        const int r0 = std::min(std::max(yMin, 0), e.H - 1) >> 6, r1 = std::min(std::max(yMax, 0), e.H - 1) >> 6;
+        const int wc = xa_task_wait_class(3);
+        for (int r = r1; r >= r0; r--)
+        {
+            if (q->published(r) < e.W) xa_wait_counter(q->finalX[r], (uint64_t)e.W);
+            if (q->failed.load(std::memory_order_acquire)) { xa_task_wait_class(wc); return -1; }
+        }
+        xa_task_wait_class(wc);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return g.e->weightRows(wpl, r0, r1) == X265AMD_OK ? 0 : -1;
+    }
     if (picIdx < 0 || picIdx >= (int)g.refs.size()) return 0;          /* the picture itself / the source: not a reference */
     Pic* q = g.refs[picIdx];
     const int need = xMax >= e.W - 1 ? e.W : std::max(0, xMax + 1);
@@ -1750,6 +1866,36 @@ static void gateAfterRow(void* ctx, int row)
     RowGate& g = *(RowGate*)ctx;
     { std::lock_guard<std::mutex> lk(g.pic->mu); g.pic->analysedRows = row + 1; }
     g.pic->cv.notify_all();
+}
+
+/* CTU rows r0 .. r1 of a weighted copy (MotionReference::applyWeight, reference.cpp:118-185): weight_pp_c over the rows' padded lines -- with the first row the top margin, with
+ * the last the bottom margin -- of the planes that carry a weight.  The rows of the reference picture are final (the caller has waited for them). */
+int x265amd_encoder::weightRows(WPlane& wpl, int r0, int r1)
+{
+    std::lock_guard<std::mutex> lk(wpl.mu);
+    bool any = false;
+    xa_thread_device();
+    for (int r = r0; r <= r1; r++)
+    {
+        if (r < 0 || r >= ctuH || wpl.rowDone[r]) continue;
+        for (int cc = 0; cc < 3; cc++)
+        {
+            if (!wpl.chroma[cc]) continue;
+            const int sh = cc ? 1 : 0, h = H >> sh, my = marginY >> sh, mx = marginX >> sh, rows = 64 >> sh;
+            const intptr_t st = cc ? cstride : stride;
+            const int y0 = r == 0 ? -my : rows * r, y1 = r == ctuH - 1 ? h + my : rows * (r + 1);
+            const intptr_t at = (intptr_t)org[cc] + (intptr_t)y0 * st - mx;
+            const x265amd_weight& w = wpl.w[cc];
+            const int correction = 14 - X265AMD_DEPTH;
+            const int rc = x265amd_weight_buffer(wpl.st, wpl.src->finalPlanes() + at, wpl.buf + at, (size_t)(y1 - y0) * st, w.w, (w.denom ? 1 << (w.denom - 1) : 0) << correction,
+                                                 w.denom + correction, w.o * (1 << (X265AMD_DEPTH - 8)));
+            if (rc != X265AMD_OK) return rc;
+        }
+        any = true;
+    }
+    if (any && hipStreamSynchronize(wpl.st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: weighted reference rows");
+    for (int r = std::max(r0, 0); r <= r1 && r < ctuH; r++) wpl.rowDone[r] = 1;
+    return X265AMD_OK;
 }
 
 /* The filter thread of a picture: FrameFilter::processRow / processPostRow for each CTU row as the analysis delivers it.  Row r is deblocked when row r + 1
@@ -2112,7 +2258,8 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     if (!colPic) { noCol.resize(nUnits); memset(noCol.data(), 0, sizeof(x265amd_mv_unit) * nUnits); }
     std::vector<uint8_t> refDepth(2 * nUnits, 0);
     std::vector<int8_t> refQp0(2 * (size_t)nctu, 0);
-    RowGate gate{ this, &pic, {}, &refDepth, nUnits };
+    if (fc.failed) return xa_fail(X265AMD_EHIP, "encoder: weighted reference planes");
+    RowGate gate{ this, &pic, {}, &refDepth, nUnits, &fc };
     for (int l = 0; l < 2; l++)
     {
         for (const PicP& q : lists[l]) if (std::find(gate.refs.begin(), gate.refs.end(), q.get()) == gate.refs.end()) gate.refs.push_back(q.get());
@@ -2149,7 +2296,7 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     }
     arc = sliceNal(*this, pic, fc, saoFlags, data, sizes, nsub);
     if (arc) return rc = arc;
-    xa_scratch_free(pic.dSrc); pic.dSrc = nullptr;
+    if (!keepSources()) { xa_scratch_free(pic.dSrc); pic.dSrc = nullptr; }
     return rc = 0;
 }
 

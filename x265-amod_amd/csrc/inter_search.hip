@@ -117,6 +117,18 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
         j.slice_type = (uint8_t)sliceP; j.flags = (uint8_t)flags; j.metric = (uint8_t)metric; j.chroma_cost = (uint8_t)chromaCost;
         return j;
     };
+    /* a job that stands for Predict::motionCompensation in a slice with weights (predict.cpp:85-232): pps.bUseWeightPred / bUseWeightedBiPred and the table entries of the
+     * references it reads (a picture is at most once in a list).  selectMVP's candidates are NOT such jobs: predInterLumaPixel on the reconstruction (search.cpp:2016) */
+    auto weigh = [&](x265amd_mc_job j) {
+        if (!S->weighted) return j;
+        j.flags |= S->weighted == 1 ? 4 : 8;
+        const int pics[2] = { j.ref0, j.ref1 };
+        for (int l = 0; l < 2; l++)
+            if (pics[l] >= 0)
+                for (int r = 0; r < I->num_ref_idx[l]; r++)
+                    if (S->ref_pic[l][r] == pics[l]) { memcpy(&j.wp[l][0], &S->wp[l][r][0], sizeof(j.wp[l])); break; }
+        return j;
+    };
     /* runs a batch of cost jobs; scratch prediction blocks are carved from one arena */
     auto runCost = [&](std::vector<x265amd_mc_job>& jobs, std::vector<uint32_t>& cost) -> int {
         cost.assign(2 * jobs.size(), 0);
@@ -190,7 +202,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 {
                     const x265amd_merge_cand& m = w.mcand[k];
                     const int p0 = m.ref_idx[0] >= 0 ? S->ref_pic[0][m.ref_idx[0]] : -1, p1 = m.ref_idx[1] >= 0 ? S->ref_pic[1][m.ref_idx[1]] : -1;
-                    cj.push_back(mcJob(w.g, c.x, c.y, !isB, p0, Mv{ m.mv[0][0], m.mv[0][1] }, p1, Mv{ m.mv[1][0], m.mv[1][1] }, chromaSatd ? 3 : 1, 2, chromaSatd));
+                    cj.push_back(weigh(mcJob(w.g, c.x, c.y, !isB, p0, Mv{ m.mv[0][0], m.mv[0][1] }, p1, Mv{ m.mv[1][0], m.mv[1][1] }, chromaSatd ? 3 : 1, 2, chromaSatd)));
                 }
             }
             /* getBlkBits (search.cpp:2649-2700) */
@@ -291,7 +303,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                     j.mvp[0] = (int16_t)mvp.x; j.mvp[1] = (int16_t)mvp.y;
                     memcpy(j.mvc, w.mvc[list][ref], sizeof(int16_t) * 2 * w.numMvc[list][ref]);
                     w.meJob[list][ref] = (int)mj.size();
-                    mj.push_back(j); mjPic.push_back(S->ref_pic[list][ref]);
+                    mj.push_back(j); mjPic.push_back(S->weighted ? S->me_pic[list][ref] : S->ref_pic[list][ref]);        /* MotionEstimate reads MotionReference::fpelPlane: the weighted copy where there is one */
                 }
         }
         std::vector<x265amd_me_result> mres(mj.size());
@@ -380,7 +392,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             {
                 const int p0 = S->ref_pic[0][w.best[0].ref], p1 = S->ref_pic[1][w.best[1].ref];
                 w.bidirJob[0] = (int)bj.size();
-                bj.push_back(mcJob(w.g, c.x, c.y, 0, p0, w.best[0].mv, p1, w.best[1].mv, chromaSatd ? 3 : (1 | 16), 2, chromaSatd));
+                bj.push_back(weigh(mcJob(w.g, c.x, c.y, 0, p0, w.best[0].mv, p1, w.best[1].mv, chromaSatd ? 3 : (1 | 16), 2, chromaSatd)));
                 bool tryZero = w.best[0].mv.x || w.best[0].mv.y || w.best[1].mv.x || w.best[1].mv.y;
                 if (tryZero)
                 {
@@ -394,7 +406,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
                 if (tryZero)
                 {
                     w.bidirJob[1] = (int)bj.size();
-                    bj.push_back(mcJob(w.g, c.x, c.y, 0, p0, Mv{ 0, 0 }, p1, Mv{ 0, 0 }, chromaSatd ? 3 : (1 | 16), 2, chromaSatd));
+                    bj.push_back(weigh(mcJob(w.g, c.x, c.y, 0, p0, Mv{ 0, 0 }, p1, Mv{ 0, 0 }, chromaSatd ? 3 : (1 | 16), 2, chromaSatd)));
                 }
             }
         }
@@ -479,7 +491,7 @@ extern "C" int x265amd_pred_inter_search_ex(x265amd_me_ctx* me, void* stream, co
             if (!(r.inter_dir & 1)) pic0 = -1;
             if (!(r.inter_dir & 2)) pic1 = -1;
             /* final prediction: motionCompensation(cu, pu, *predYuv, true, bChromaMC) into the CU's prediction tile */
-            x265amd_mc_job f = mcJob(w.g, c.x, c.y, !isB, pic0, mv0, pic1, mv1, (S->chroma_mc != 0) ? 3 : 1, 0, 0);
+            x265amd_mc_job f = weigh(mcJob(w.g, c.x, c.y, !isB, pic0, mv0, pic1, mv1, (S->chroma_mc != 0) ? 3 : 1, 0, 0));
             const uint64_t base = d_pred + (size_t)w.cu * pred_bytes_per_cu;
             f.dst_y = base + ((size_t)(w.g.y - c.y) * 64 + (w.g.x - c.x)) * isz;
             f.dst_u = base + (64 * 64 + (size_t)((w.g.y - c.y) / 2) * 32 + (w.g.x - c.x) / 2) * isz;

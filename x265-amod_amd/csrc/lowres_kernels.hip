@@ -488,6 +488,7 @@ struct WeightCostParams
 {
     const pixel* fenc; const pixel* ref[4]; long stride; int width, height, blocksX;
     const int16_t* mvs; const int32_t* intraCost; const x265amd_weight_cand* cands; uint32_t* costs;
+    int chroma, lowCuW, lowCuH;     /* chroma != 0: weightCost's 4:2:0 chroma branch on full-resolution chroma planes with mcChroma (weightPrediction.cpp:93-159, :205-208) */
 };
 __global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
 {
@@ -506,7 +507,23 @@ __global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
         xa_wave_sync();
         fencT[lane] = p.fenc[off + (long)ly * p.stride + lx];
         int v;
-        if (p.mvs)
+        if (p.chroma)
+        {
+            /* mcChroma as the reference has it: the vector of lowres block (row = the block's first SAMPLE row, column = the block's index) for the blocks whose
+             * sample position lies inside the lowres block grid, taken at a quarter for the position and an eighth for the fraction; a plain copy elsewhere */
+            const pixel* a = p.ref[0] + off;
+            if (p.mvs && x < p.lowCuW && y < p.lowCuH)
+            {
+                const int v32 = reinterpret_cast<const int*>(p.mvs)[y * p.lowCuW + bx];
+                int qx = (int16_t)(v32 & 0xFFFF), qy = (int16_t)(v32 >> 16);
+                qx = min(max(qx, (-x - 8) * 4), (p.width - x - 1 + 8) * 4);
+                qy = min(max(qy, (-y - 8) * 4), (p.height - y - 1 + 8) * 4);
+                a += (qx >> 2) + (long)(qy >> 2) * p.stride;
+                v = mc_sample<4, false>(a + (long)ly * p.stride + lx, p.stride, qx & 7, qy & 7);
+            }
+            else v = a[(long)ly * p.stride + lx];
+        }
+        else if (p.mvs)
         {
             const int v32 = reinterpret_cast<const int*>(p.mvs)[cu];
             int qx = (int16_t)(v32 & 0xFFFF), qy = (int16_t)(v32 >> 16);
@@ -577,6 +594,33 @@ extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_
         if (!dF && xa_scratch_alloc(&dF, 8192) != hipSuccess) dF = nullptr;
         if (dF) hipLaunchKernelGGL(k_flood, dim3(wgs / 46 > 0 ? wgs / 46 : 1, 46), dim3(64), 0, st, (uint32_t*)dF, mode, (const uint32_t*)dF + 1024);
     }
+    hipLaunchKernelGGL(k_lowres_weight_cost, dim3(kWeightCostParts, n), dim3(64), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    const uint32_t* part = (const uint32_t*)mOut;
+    for (int i = 0; i < n; i++) { uint32_t t = 0; for (int k = 0; k < kWeightCostParts; k++) t += part[i * kWeightCostParts + k]; costs[i] = t; }
+    return X265AMD_OK;
+}
+/* the chroma planes' form (weightAnalyse's planes 1 and 2, weightPrediction.cpp:348-375): d_fenc / d_ref = sample (0, 0) of the current and the reference picture's SOURCE chroma
+ * plane (margins extended), width x height = the plane clamped to whole 16x16 luma blocks, d_mvs = the lookahead's field of the luma analysis (or NULL), low_cu_w / low_cu_h
+ * = the lowres picture in 8x8 blocks */
+extern "C" int x265amd_chroma_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* d_ref, const int16_t* d_mvs, intptr_t stride, int width, int height,
+                                           int low_cu_w, int low_cu_h, const x265amd_weight_cand* cands, int n, uint32_t* costs)
+{
+    if (!d_fenc || !d_ref || !cands || !costs || n <= 0 || n > 256 || width <= 0 || height <= 0 || (width & 7) || (height & 7))
+        return xa_fail(X265AMD_EINVAL, "x265amd_chroma_weight_costs: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    static thread_local void* mC = nullptr; static thread_local void* mOut = nullptr;
+    if (!mC && (xa_mapped_alloc(&mC, sizeof(x265amd_weight_cand) * 256, false) != hipSuccess || xa_mapped_alloc(&mOut, 4 * 256 * kWeightCostParts, true) != hipSuccess))
+    { xa_mapped_free(mC); xa_mapped_free(mOut); mC = mOut = nullptr; return xa_fail(X265AMD_EHIP, "x265amd_chroma_weight_costs: allocation"); }
+    memcpy(mC, cands, sizeof(x265amd_weight_cand) * n);
+    WeightCostParams p;
+    memset(&p, 0, sizeof(p));
+    p.fenc = (const pixel*)d_fenc; p.ref[0] = (const pixel*)d_ref;
+    p.stride = (long)stride; p.width = width; p.height = height; p.blocksX = width >> 3;
+    p.mvs = d_mvs; p.cands = (const x265amd_weight_cand*)mC; p.costs = (uint32_t*)mOut;
+    p.chroma = 1; p.lowCuW = low_cu_w; p.lowCuH = low_cu_h;
     hipLaunchKernelGGL(k_lowres_weight_cost, dim3(kWeightCostParts, n), dim3(64), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -238,12 +238,28 @@ extern "C" size_t x265amd_write_slice_nal(const x265amd_slice_header* h, const u
         if (sliceType == 0) b.flag(h->col_from_l0 != 0);
         if (sliceType != 2 && ((h->col_from_l0 && h->num_ref_idx[0] > 1) || (!h->col_from_l0 && h->num_ref_idx[1] > 1))) b.ue((uint32_t)h->col_ref_idx);
     }
-    if (sliceType == 1 && h->weighted_pred)
+    if ((sliceType == 1 && h->weighted_pred) || (sliceType == 0 && h->weighted_bipred))
     {
-        /* pred_weight_table() of a slice whose analysis chose no weights (weightAnalyse ends with wtPresent 0 everywhere): the denominators, then a luma and a chroma flag per reference */
+        /* pred_weight_table() as Entropy::codePredWeightTable writes it (entropy.cpp:1358-1429): the denominators once, then per list the luma flags, the chroma flags and the
+         * weights of the references that carry some (chroma offsets as differences from the prediction 128 - ((128 w) >> denom)) */
         b.ue((uint32_t)h->luma_log2_weight_denom); b.se(h->chroma_log2_weight_denom - h->luma_log2_weight_denom);
-        for (int r = 0; r < h->num_ref_idx[0]; r++) b.flag(false);
-        for (int r = 0; r < h->num_ref_idx[0]; r++) b.flag(false);
+        for (int list = 0; list < (sliceType == 0 ? 2 : 1); list++)
+        {
+            for (int r = 0; r < h->num_ref_idx[list]; r++) b.flag(h->wp[list][r][0].present != 0);
+            for (int r = 0; r < h->num_ref_idx[list]; r++) b.flag(h->wp[list][r][1].present != 0);
+            for (int r = 0; r < h->num_ref_idx[list]; r++)
+            {
+                const x265amd_weight* w = h->wp[list][r];
+                if (w[0].present) { b.se(w[0].w - (1 << w[0].denom)); b.se(w[0].o); }
+                if (w[1].present)
+                    for (int plane = 1; plane < 3; plane++)
+                    {
+                        b.se(w[plane].w - (1 << w[1].denom));
+                        const int pred = 128 - ((128 * w[plane].w) >> w[plane].denom);
+                        b.se(w[plane].o - pred);
+                    }
+            }
+        }
     }
     if (sliceType != 2) b.ue((uint32_t)(5 - h->max_num_merge_cand));
     b.se(h->slice_qp - h->pps_init_qp);

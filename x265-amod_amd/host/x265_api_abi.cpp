@@ -112,7 +112,6 @@ void* abi_encoder_open(void* p)
     REQUIRE(PI(p, rc_vbvBufferSize) == 0 && !PI(p, rc_bStatRead) && !PI(p, rc_bStatWrite), "rc: VBV and multi-pass statistics are not built");
     REQUIRE(PI(p, bFrameAdaptive) >= 0 && PI(p, bFrameAdaptive) <= 2, "bFrameAdaptive (--b-adapt): 0, 1 or 2");
     REQUIRE(!PI(p, bHistBasedSceneCut), "bHistBasedSceneCut: histogram scene-cut detection is not built");
-    REQUIRE(!PI(p, bEnableWeightedBiPred), "weighted bi-prediction is not built (--no-weightb)");
     REQUIRE(!PI(p, bEmitInfoSEI), "bEmitInfoSEI: the option-string SEI is not written (--no-info)");
     REQUIRE(PI(p, maxCUSize) == 64 && PI(p, minCUSize) == 8 && PI(p, maxTUSize) == 32, "maxCUSize / minCUSize / maxTUSize: only 64 / 8 / 32 are built");
     REQUIRE(!PI(p, interlaceMode) && !PI(p, bField), "interlaced coding is not built");
@@ -139,7 +138,7 @@ void* abi_encoder_open(void* p)
     x265amd_param_default(&q);
     q.sourceWidth = PI(p, sourceWidth); q.sourceHeight = PI(p, sourceHeight); q.fpsNum = PU(p, fpsNum); q.fpsDenom = PU(p, fpsDenom);
     q.bframes = PI(p, bframes); q.keyframeMax = PI(p, keyframeMax); q.maxNumReferences = PI(p, maxNumReferences);
-    q.scenecutThreshold = PI(p, scenecutThreshold); q.lookaheadDepth = PI(p, lookaheadDepth); q.keyframeMin = PI(p, keyframeMin); q.bFrameAdaptive = PI(p, bFrameAdaptive); q.bOpenGOP = PI(p, bOpenGOP) != 0; q.bBPyramid = PI(p, bBPyramid) != 0; q.lookaheadSlices = PI(p, lookaheadSlices); q.bEnableWeightedPred = PI(p, bEnableWeightedPred) != 0;
+    q.scenecutThreshold = PI(p, scenecutThreshold); q.lookaheadDepth = PI(p, lookaheadDepth); q.keyframeMin = PI(p, keyframeMin); q.bFrameAdaptive = PI(p, bFrameAdaptive); q.bOpenGOP = PI(p, bOpenGOP) != 0; q.bBPyramid = PI(p, bBPyramid) != 0; q.lookaheadSlices = PI(p, lookaheadSlices); q.bEnableWeightedPred = PI(p, bEnableWeightedPred) != 0; q.bEnableWeightedBiPred = PI(p, bEnableWeightedBiPred) != 0;
     q.qp = PI(p, rc_qp); q.ipFactor = PD(p, rc_ipFactor); q.pbFactor = PD(p, rc_pbFactor);
     q.rdLevel = PI(p, rdLevel); q.bEnableRectInter = PI(p, bEnableRectInter); q.bEnableAMP = PI(p, bEnableAMP); q.limitModes = PI(p, limitModes); q.limitReferences = PI(p, limitReferences);
     q.bEnableEarlySkip = PI(p, bEnableEarlySkip); q.recursionSkipMode = PI(p, recursionSkipMode); q.bIntraInBFrames = PI(p, bIntraInBFrames); q.psyRd = PD(p, psyRd);
