@@ -1963,9 +1963,10 @@ def inter_search_run_ref(R, c):
 
 
 INTER_CU_DT = np.dtype([("x", "<i2"), ("y", "<i2"), ("log2", "u1"), ("part", "u1"), ("reserved", "u1", 2)])
+WEIGHT_DT = np.dtype([("w", "<i2"), ("o", "<i2"), ("denom", "u1"), ("present", "u1")])          # x265amd_weight: WeightParam's inputWeight, inputOffset, log2WeightDenom, wtPresent
 INTER_SP_DT = np.dtype([("search_method", "<i4"), ("subpel_refine", "<i4"), ("search_range", "<i4"), ("qp", "<i4"), ("chroma_mc", "<i4"), ("ref_pic", "<i4", (2, 16)), ("frame_parallel", "<i4"), ("lazy_sync", "<i4"),
-                        ("lowres_blocks_in_row", "<i4"), ("lowres_mvs", "<u8", (2, 16))])
-assert INTER_SP_DT.itemsize == 416
+                        ("lowres_blocks_in_row", "<i4"), ("me_pic", "<i4", (2, 16)), ("weighted", "<i4"), ("wp", WEIGHT_DT, (2, 16, 3)), ("pad_wp", "u1", 4), ("lowres_mvs", "<u8", (2, 16))])
+assert INTER_SP_DT.itemsize == 1128 and INTER_SP_DT.fields["me_pic"][1] == 160 and INTER_SP_DT.fields["wp"][1] == 292 and INTER_SP_DT.fields["lowres_mvs"][1] == 872
 
 
 def inter_search_run_hip(L, me, c):
@@ -2853,7 +2854,9 @@ SLICE_HEADER_DT = np.dtype([(n, "<i4") for n in ("nal_unit_type", "temporal_id_p
                            [(n, "<i4") for n in ("temporal_mvp_enabled", "use_sao", "sao_luma", "sao_chroma", "selective_sao")] +
                            [("num_ref_idx", "<i4", 2), ("num_ref_idx_default", "<i4", 2)] +
                            [(n, "<i4") for n in ("col_from_l0", "col_ref_idx", "max_num_merge_cand", "slice_qp", "pps_init_qp", "chroma_qp_offsets_present", "cb_qp_offset",
-                                                 "cr_qp_offset", "deblocking_disabled", "slfase_flag", "wpp", "weighted_pred", "luma_log2_weight_denom", "chroma_log2_weight_denom")])
+                                                 "cr_qp_offset", "deblocking_disabled", "slfase_flag", "wpp", "weighted_pred", "luma_log2_weight_denom", "chroma_log2_weight_denom", "weighted_bipred")] +
+                           [("wp", np.dtype([("w", "<i2"), ("o", "<i2"), ("denom", "u1"), ("present", "u1")]), (2, 16, 3))])
+assert SLICE_HEADER_DT.itemsize == 844
 
 
 def frame_clip_b(depth=8):
@@ -3351,15 +3354,14 @@ SLOW_TOOLS = dict(bEnableEarlySkip=0, bIntraInBFrames=0, bEnableRectInter=1, rdL
                   lookaheadDepth=25, lookaheadSlices=4)
 VERYSLOW_TOOLS = dict(bEnableEarlySkip=0, bEnableAMP=1, bEnableRectInter=1, tuQTMaxInterDepth=3, tuQTMaxIntraDepth=3, rdLevel=6, rdoqLevel=2, psyRdoqFix8=256, subpelRefine=4,
                       maxNumMergeCand=5, searchMethod=3, maxNumReferences=5, limitReferences=0, limitModes=0)
-# cfg5 keeps the switches of round 3 until --weightb is coded (veryslow turns it on): everything else of the preset
-CFG5_CLI = ["--aq-mode", "0", "--no-cutree", "--no-weightp", "--no-weightb", "--b-adapt", "0", "--no-scenecut", "--keyint", "250", "--no-open-gop",
-            "--rc-lookahead", "5", "--lookahead-slices", "0", "--no-b-pyramid", "--wpp", "--frame-threads", "3", "--pools", "8"]
-CFG5_BASE = dict(fpsNum=30, fpsDenom=1, qp=30, aspectRatioIdc=1, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=3, bframes=4)
+# --preset veryslow's GOP side on top of FULL_BASE (param.cpp:536-556): eight B frames, forty pictures of lookahead, no lookahead slices, weighted bi-prediction
+VERYSLOW_GOP = dict(bframes=8, lookaheadDepth=40, lookaheadSlices=0, bEnableWeightedBiPred=1)
 # tag -> ((w, h), frames, depth, cfg_id of the clip, x265amd_param fields, the reference's command line in front of FULL_CLI)
 FULL_CASES = {
-    "cfg3_2160p_slow/": ((3840, 2160), 3, 8, 3, dict(FULL_BASE, **SLOW_TOOLS), ["--preset", "slow"]),                    # BASELINE.json configs[2]
-    "cfg4_2160p_main10/": ((3840, 2160), 3, 10, 4, dict(FULL_BASE), ["--preset", "medium"]),                              # configs[3]
-    "cfg5_4320p_veryslow_rd6/": ((7680, 4320), 2, 10, 5, dict(CFG5_BASE, **VERYSLOW_TOOLS), ["--preset", "veryslow", "--rd", "6", "--bframes", "4"] + CFG5_CLI),      # configs[4]
+    "cfg3_2160p_slow/": ((3840, 2160), 12, 8, 3, dict(FULL_BASE, **SLOW_TOOLS), ["--preset", "slow"]),                   # BASELINE.json configs[2]: I + two mini-GOPs of the trellis
+    "cfg4_2160p_main10/": ((3840, 2160), 12, 10, 4, dict(FULL_BASE), ["--preset", "medium"]),                             # configs[3]: Main 10 over a full B pyramid and more
+    # configs[4] as it comes (round 5: --weightb is coded, nothing is switched off): plain --preset veryslow --rd 6 --qp 30 --no-info
+    "cfg5_4320p_veryslow_rd6/": ((7680, 4320), 3, 10, 5, dict(FULL_BASE, **VERYSLOW_TOOLS, **VERYSLOW_GOP), ["--preset", "veryslow", "--rd", "6"]),
     # rd 2 on a picture of 1080 rows: Analysis::complexityCheckCU is active (analysis.cpp:3536-3559, only for pictures of at least 1080 rows at rd 0-2)
     "fhd_rd2/": ((1920, 1080), 3, 8, 2, dict(FULL_BASE, rdLevel=2, bframes=1), ["--preset", "medium", "--rd", "2", "--bframes", "1"]),
     # the bench's configuration over sixty frames: both re-seeds of the clip (frames 24 and 48: scene cuts, I pictures inside open GOPs) and ten mini-GOPs of the trellis

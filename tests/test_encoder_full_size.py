@@ -1,17 +1,18 @@
 """BASELINE.json's configurations 3, 4 and 5 at their STATED size through the encoder object (include/x265amd_encoder.h), against the reference encoder's stream
 and reconstruction digests (tests/golden/encoder_full_golden.json, made by tests/golden/make_golden.py full with oracle/_ref/x265_ref{8,10}):
 
-  cfg3  3840x2160  8-bit  x265 --preset slow --qp 30 --no-info    (rd 4, RDOQ 2, star / subme 3, 4 references, rect + limit-modes),  3 frames
-  cfg4  3840x2160 10-bit  x265 --preset medium --qp 30 --no-info  (Main 10),                                                      3 frames
+  cfg3  3840x2160  8-bit  x265 --preset slow --qp 30 --no-info    (rd 4, RDOQ 2, star / subme 3, 4 references, rect + limit-modes), 12 frames
+  cfg4  3840x2160 10-bit  x265 --preset medium --qp 30 --no-info  (Main 10),                                                      12 frames
   fhd_medium_60  1920x1080  x265 --preset medium --qp 30 --no-info, 60 frames: the bench's configuration over both re-seeds of the clip (scene cuts at 24 and 48)
   fhd_rd2  1920x1080 --preset medium --rd 2 --bframes 1: Analysis::complexityCheckCU (analysis.cpp:3536-3559) is active only for rd 0-2 on pictures of >= 1080 rows
-  cfg5  7680x4320 10-bit  --preset veryslow tools + rd 6 (AMP, TU depth 3, 5 merge candidates), 2 frames (I P) -- still with the switches of round 3 on the
-        reference's command line (hevc_testlib.CFG5_CLI): veryslow turns --weightb on, and coding with weights is not built
+  cfg5  7680x4320 10-bit  x265 --preset veryslow --rd 6 --qp 30 --no-info, 3 frames: the preset as it comes since round 5 (--weightb is coded; AMP, TU depth 3,
+        5 merge candidates, 5 references, subme 4, eight B frames / forty pictures of lookahead in the decision)
 
-The first four run the reference's presets as they come: the trellis of --b-adapt 2, scene-cut detection, open GOPs, B pyramid, lookahead slices, the analysis of
-weighted prediction (no weight is chosen on these clips), frame-parallel rules (the reference picks three frame threads on the eight cores the fixtures were made on).
+All run the reference's presets as they come: the trellis of --b-adapt 2, scene-cut detection, open GOPs, B pyramid, lookahead slices, weighted prediction
+(no weight is chosen on these clips), frame-parallel rules (the reference picks three frame threads on the eight cores the fixtures were made on).
 Picture-size dependent code is what these pin: 34 / 68 CTU rows in flight and the queues they take, the cut last CTU row (2160 = 33 x 64 + 48, 4320 = 67 x 64 + 32),
-64-bit squared errors of Main 10 (common.h:142-146), the star search's raster over the full window, level / DPB derivation of the headers at these sizes.
+64-bit squared errors of Main 10 (common.h:142-146), the star search's raster over the full window, level / DPB derivation of the headers at these sizes; since
+round 5 cfg3 and cfg4 cover whole mini-GOPs of the trellis with the B pyramid at 2160p (twelve pictures each).
 The clip is SURVEY.md section 8d's generator (hevc_testlib.survey_clip)."""
 import hashlib
 import json

@@ -109,6 +109,9 @@ ABI_CASES = {
     "og_keyint_ba/": ("encoder_og_golden.npz", "og", None),
     "wp_medium/": ("encoder_wp_golden.npz", "wp", None),        # --preset medium --qp 30 as it comes (weighted prediction on: a clip whose analysis ends without weights)
     "ls_medium/": ("encoder_ls_golden.npz", "ls", None),        # 1280x720: the lookahead in slices as well
+    # fades coded WITH weights through the table: P pictures (luma and chroma weights); B pictures with --weightb, Main 10, subme 4
+    "wp_fade/": ("encoder_fade_golden.npz", "fade", None),
+    "wp_fade_b4_hbd/": ("encoder_fade_golden.npz", "fade", None),
     "bp_deep/": ("encoder_bp_golden.npz", "bp", None),          # B pyramid + open GOPs + the trellis + a scene cut: --preset medium's GOP structure but for weighted prediction and lookahead slices
 }
 
@@ -117,13 +120,13 @@ ABI_CASES = {
 @pytest.mark.parametrize("tag", sorted(ABI_CASES))
 def test_libx265_client_encodes_through_our_api_table(tag, tmp_path):
     gold, clip, extra = ABI_CASES[tag]
-    depth = 10 if tag.startswith("hbd") else 8
+    depth = 10 if tag.startswith("hbd") or tag.endswith("_hbd/") else 8
     driver = os.path.join(T.REF_DIR, "x265_abi_driver%d" % depth)
     assert os.path.exists(driver), "oracle/build_ref.sh builds oracle/_ref/x265_abi_driver{8,10} (it travels to the GPU box with the snapshot)"
     cli = None
-    if clip in ("og", "bp", "ls", "wp"):
+    if clip in ("og", "bp", "ls", "wp", "fade"):
         cases, frames_of, base = {"og": (T.OG_CASES, T.og_case_frames, T.OG_CLI), "bp": (T.BP_CASES, T.bp_case_frames, T.BP_CLI), "ls": (T.LS_CASES, T.ls_case_frames, T.LS_CLI),
-                                  "wp": (T.WP_CASES, T.wp_case_frames, T.WP_CLI)}[clip]
+                                  "wp": (T.WP_CASES, T.wp_case_frames, T.WP_CLI), "fade": (T.FADE_CASES, T.fade_case_frames, T.WP_CLI)}[clip]
         (w, h), n, depth, _, _, extra = cases[tag]
         frames = frames_of(tag)
         cli = list(base)
