@@ -121,6 +121,8 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=
                     # one pump thread on a stream of its own, the same sequence of collectives on every rank, pictures nobody references stay home (frame_rows.py)
                     fr.pump(rows.export_row, rows.import_row, rows.shapes, len(pics), rows.rows, dev, rank=shard[0], world=shard[1], referenced=rows.referenced)
                 except BaseException as exc:        # noqa: B902
+                    import traceback
+                    traceback.print_exc()           # at once: the encode loop may sit in the encoder for minutes before anybody asks for pump_err
                     pump_err.append(repr(exc))
             pump_thread = threading.Thread(target=run_pump)
         t0 = time.perf_counter()

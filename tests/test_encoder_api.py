@@ -427,6 +427,29 @@ def test_fade_coded_with_weights(tag, capfd):
 
 
 @pytest.mark.gpu
+def test_device_chains_verified_candidate_by_candidate():
+    """Round 4's two device paths of P / B pictures -- the skip chain (csrc/inter_chain_dev.h) and the fused 2Nx2N search (csrc/inter_search_dev.h) -- checked where they are
+    used: with X265AMD_CHAIN_VERIFY=2 the host repeats, for every CU the device skipped, merged or searched, its own merge check / search / rate-distortion and compares mode,
+    candidate, costs, bits, levels and the entropy coder's state (ctu_analysis.hip: "chain verify"); a difference fails the picture.  The variable is read once per process, so
+    the encode runs in a process of its own: 1280x720, --preset medium's tools, the trellis' mini-GOPs with the B pyramid (tests/hevc_testlib.py LS_CASES ls_medium/)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, hevc_testlib as T\n"
+            "g = np.load(%r)\n"
+            "(w, h), n, depth, _, cfg, _ = T.LS_CASES['ls_medium/']\n"
+            "stream, coded = T.encoder_run(T.load_hip(depth), T.ls_case_frames('ls_medium/'), w, h, **cfg)\n"
+            "assert len(coded) == n and not T.stream_diff(stream, g['ls_medium/stream']), T.stream_diff(stream, g['ls_medium/stream'])\n"
+            "print('verified pictures', len(coded))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.join(T.GOLDEN_DIR, "encoder_ls_golden.npz"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, X265AMD_CHAIN_VERIFY="2", X265AMD_TIMING="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "verified pictures 14" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "chain verify" not in r.stderr, r.stderr[-3000:]
+    import re
+    runs = [int(m.group(1)) for m in re.finditer(r"skip chains so far: (\d+) commands", r.stderr)]
+    ahead = [int(m.group(1)) + int(m.group(2)) for m in re.finditer(r"searches started ahead so far: (\d+) beside a leaf's merge check, (\d+) behind", r.stderr)]
+    assert runs and max(runs) > 100 and ahead and max(ahead) > 0, (runs[-3:], ahead[-3:])           # the paths under test did run
+
+
+@pytest.mark.gpu
 def test_intra_chain_beside_a_flood_of_atomics():
     """Regression test for the fence scope of the device-run chain of 8x8 intra CUs: thousands of one-wave workgroups that each end in an atomicAdd, launched
     beside the I picture (X265AMD_WP_FLOOD, read by x265amd_lowres_weight_costs at every call), made that picture come out different in eleven runs of twelve while the chain's

@@ -40,6 +40,12 @@ def test_survey_clip_is_the_bench_clip():
         for pa, pb in zip(fa, fb):
             assert pa.dtype == np.uint8 and pb.dtype == np.uint16 and np.array_equal(pa.astype(np.uint16) * 4, pb)
     assert not np.array_equal(a[0][0], a[1][0])         # frame 24 is a new scene
+    # The noise field comes from numpy's PCG64 Generator.integers, not from the LCG SURVEY.md section 8d sketches: every fixture and every bench digest of rounds 2-5 is cut
+    # from THESE samples (changing the generator would only re-cut them).  What the survey wants from the LCG -- the same bytes on every machine -- is pinned here instead:
+    # a numpy whose Generator produced other samples fails this test before any stream comparison can mislead.
+    import hashlib
+    assert hashlib.md5(b"".join(p.tobytes() for f in a for p in f)).hexdigest() == "5de17a18fe9e34f38aa983e1b1c57d64"
+    assert hashlib.md5(b"".join(p.tobytes() for p in T.survey_clip(1920, 1080, 8, 2, 0, 1)[0])).hexdigest() == "6609dbfed6d98a57eb053c4dfa39e237"
 
 
 @pytest.mark.gpu

@@ -132,41 +132,57 @@ struct LowresCostParams
                                                  * (the last slice to the bottom) are chains of their own: a slice's bottom row takes no predictors from the row below */
 };
 
+/* Round 5: a candidate block never touches LDS.  The wavefront's lanes are the 64 samples of the 8x8 block in TILE order (lanes 16 t .. 16 t + 15 = the 4x4 tile t,
+ * raster inside it), the source sample sits in a register; a candidate is one (quarter-sample positions: two) global load per lane, its SAD a DPP sum, its SATD the
+ * cross-lane 4x4 Hadamard of each 16-lane row (pixel.cpp:210-297: satd_8x4 twice = the four tiles' sums, each halved -- a tile's sum of absolute Hadamard coefficients is
+ * even).  And the candidates of one step of the search are LOADED TOGETHER: the hexagon's six points, the three of an iteration, the eight of the square, the four of a
+ * sub-sample step cost one memory latency per step instead of one per point (the kernel is latency bound: a wavefront per block row, a block a chain of some thirty
+ * dependent evaluations).  Same values, same comparisons in the same order as before (tests/test_lowres.py). */
 struct LrBlock
 {
-    pixel* fencT; pixel* buf;                   /* LDS: source block, candidate block */
     const LowresCostParams* p;
-    int list, lane;
-    const pixel* const* planes;                 /* the planes lr_fetch reads: the list's, or list 0's weighted copies while it is searched */
+    int list, lane, lx, ly;                     /* lx, ly: this lane's sample inside the block */
+    int f;                                      /* the source sample */
+    const pixel* const* planes;                 /* the planes lr_ld reads: the list's, or list 0's weighted copies while it is searched */
     long off;                                   /* blockOffset */
     int mvpx, mvpy;
 };
 
 XA_DEV int lr_mvcost(const LrBlock& b, int qx, int qy) { return (uint16_t)(b.p->cost[qx - b.mvpx] + b.p->cost[qy - b.mvpy]); }
 
-/* lowresMC: the candidate block of quarter-pel MV (qx, qy) into b.buf (stride 8) */
-XA_DEV void lr_fetch(const LrBlock& b, int qx, int qy)
+/* lowresMC: this lane's sample of the candidate block of quarter-pel MV (qx, qy) */
+XA_DEV int lr_ld(const LrBlock& b, int qx, int qy)
 {
     const pixel* const* plane = b.planes;
-    const int lx = b.lane & 7, ly = b.lane >> 3;
+    const long so = b.off + (long)b.ly * b.p->stride + b.lx;
     const int hpelA = (qy & 2) | ((qx & 2) >> 1);
-    const pixel* a = plane[hpelA] + b.off + (qx >> 2) + (long)(qy >> 2) * b.p->stride;
-    int v = a[(long)ly * b.p->stride + lx];
+    int v = plane[hpelA][so + (qx >> 2) + (long)(qy >> 2) * b.p->stride];
     if ((qx | qy) & 1)
     {
         const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
         const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
-        const pixel* c = plane[hpelB] + b.off + (qx2 >> 2) + (long)(qy2 >> 2) * b.p->stride;
-        v = (v + c[(long)ly * b.p->stride + lx] + 1) >> 1;          /* pixelavg_pp */
+        v = (v + plane[hpelB][so + (qx2 >> 2) + (long)(qy2 >> 2) * b.p->stride] + 1) >> 1;          /* pixelavg_pp */
     }
-    xa_wave_sync();
-    b.buf[b.lane] = (pixel)v;
-    xa_wave_sync();
+    return v;
 }
-XA_DEV int lr_sad_q(const LrBlock& b, int qx, int qy) { lr_fetch(b, qx, qy); return xa_wave_sad(b.fencT, 8, b.buf, 8, 8, 8, b.lane); }
-XA_DEV int lr_satd_q(const LrBlock& b, int qx, int qy) { lr_fetch(b, qx, qy); return xa_wave_satd(b.fencT, 8, b.buf, 8, 8, 8, b.lane); }
-/* full-pel SAD on the fpel plane + MV cost: COST_MV */
-XA_DEV int lr_cost_f(const LrBlock& b, int mx, int my) { return lr_sad_q(b, mx * 4, my * 4) + lr_mvcost(b, mx * 4, my * 4); }
+XA_DEV int lr_sad_v(const LrBlock& b, int v) { return xa_wave_sum(abs(b.f - v)); }
+XA_DEV int lr_satd_v(const LrBlock& b, int v)
+{
+    const int h = xa_lane_had4x4(b.f - v, b.lane);
+    const int s = xa_row16_sum(abs(h)) >> 1;
+    return __builtin_amdgcn_readlane(s, 0) + __builtin_amdgcn_readlane(s, 16) + __builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48);
+}
+XA_DEV int lr_sad_q(const LrBlock& b, int qx, int qy) { return lr_sad_v(b, lr_ld(b, qx, qy)); }
+XA_DEV int lr_satd_q(const LrBlock& b, int qx, int qy) { return lr_satd_v(b, lr_ld(b, qx, qy)); }
+/* N full-pel candidates at once: COST_MV of each (SAD on the fpel plane + MV cost) */
+template<int N> XA_DEV void lr_cost_f_n(const LrBlock& b, const int (&mx)[N], const int (&my)[N], int (&c)[N])
+{
+    int v[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = lr_ld(b, mx[k] * 4, my[k] * 4);
+#pragma unroll
+    for (int k = 0; k < N; k++) c[k] = lr_sad_v(b, v[k]) + lr_mvcost(b, mx[k] * 4, my[k] * 4);
+}
 
 __device__ const int8_t lr_hex2[8][2] = { { -1, -2 }, { -2, 0 }, { -1, 2 }, { 1, 2 }, { 2, 0 }, { 1, -2 }, { -1, -2 }, { -2, 0 } };
 __device__ const uint8_t lr_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
@@ -179,19 +195,26 @@ XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, in
     const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
     int pmx = min(max(qmvpx, qmnx), qmxx), pmy = min(max(qmvpy, qmny), qmxy);       /* clipped */
     const int bestprex = pmx, bestprey = pmy;
-    const int bprecost = lr_sad_q(b, pmx, pmy);
     int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2;                       /* roundToFPel */
+    /* the predictor, its full-sample neighbour and the zero vector: loaded together (the latter two are only priced when the reference prices them) */
+    const int vPre = lr_ld(b, pmx, pmy), vFpel = lr_ld(b, bx * 4, by * 4), vZero = lr_ld(b, 0, 0);
+    const int bprecost = lr_sad_v(b, vPre);
     int bcost = bprecost;
-    if ((pmx | pmy) & 3) bcost = lr_sad_q(b, bx * 4, by * 4) + lr_mvcost(b, bx * 4, by * 4);
+    if ((pmx | pmy) & 3) bcost = lr_sad_v(b, vFpel) + lr_mvcost(b, bx * 4, by * 4);
     if (pmx | pmy)
     {
-        const int c = lr_sad_q(b, 0, 0) + lr_mvcost(b, 0, 0);
+        const int c = lr_sad_v(b, vZero) + lr_mvcost(b, 0, 0);
         if (c < bcost) { bcost = c; bx = 0; by = max(min(0, mxy), mny); }
     }
     auto inRange = [&](int x, int y) { return x >= mnx && x <= mxx && y >= mny && y <= mxy; };
     /* hexagon search (motion.cpp:879-987) */
     {
-        int c0 = lr_cost_f(b, bx - 2, by), c1 = lr_cost_f(b, bx - 1, by + 2), c2 = lr_cost_f(b, bx + 1, by + 2);
+        int c6[6];
+        {
+            const int hx[6] = { bx - 2, bx - 1, bx + 1, bx + 2, bx + 1, bx - 1 }, hy[6] = { by, by + 2, by + 2, by, by - 2, by - 2 };
+            lr_cost_f_n<6>(b, hx, hy, c6);
+        }
+        int c0 = c6[0], c1 = c6[1], c2 = c6[2];
         int packed = bcost << 3;
         if (by >= mny && by <= mxy && (c0 << 3) + 2 < packed) packed = (c0 << 3) + 2;
         if (by + 2 >= mny && by + 2 <= mxy)
@@ -199,7 +222,7 @@ XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, in
             if ((c1 << 3) + 3 < packed) packed = (c1 << 3) + 3;
             if ((c2 << 3) + 4 < packed) packed = (c2 << 3) + 4;
         }
-        c0 = lr_cost_f(b, bx + 2, by); c1 = lr_cost_f(b, bx + 1, by - 2); c2 = lr_cost_f(b, bx - 1, by - 2);
+        c0 = c6[3]; c1 = c6[4]; c2 = c6[5];
         if (by >= mny && by <= mxy && (c0 << 3) + 5 < packed) packed = (c0 << 3) + 5;
         if (by - 2 >= mny && by - 2 <= mxy)
         {
@@ -215,7 +238,10 @@ XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, in
                 for (int i = (merange >> 1) - 1; i > 0 && inRange(bx, by); i--)
                 {
                     int cc[3];
-                    for (int k = 0; k < 3; k++) cc[k] = lr_cost_f(b, bx + lr_hex2[dir + k][0], by + lr_hex2[dir + k][1]);
+                    {
+                        const int hx[3] = { bx + lr_hex2[dir][0], bx + lr_hex2[dir + 1][0], bx + lr_hex2[dir + 2][0] }, hy[3] = { by + lr_hex2[dir][1], by + lr_hex2[dir + 1][1], by + lr_hex2[dir + 2][1] };
+                        lr_cost_f_n<3>(b, hx, hy, cc);
+                    }
                     packed &= ~7;
                     for (int k = 0; k < 3; k++)
                         if (by + lr_hex2[dir + k][1] >= mny && by + lr_hex2[dir + k][1] <= mxy && (cc[k] << 3) + k + 1 < packed) packed = (cc[k] << 3) + k + 1;
@@ -230,16 +256,19 @@ XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, in
         /* square refine */
         int dir = 0;
         const bool upOk = by - 1 >= mny && by - 1 <= mxy, dnOk = by + 1 >= mny && by + 1 <= mxy;
-        int c[4] = { lr_cost_f(b, bx, by - 1), lr_cost_f(b, bx, by + 1), lr_cost_f(b, bx - 1, by), lr_cost_f(b, bx + 1, by) };
-        if (upOk && c[0] < bcost) { bcost = c[0]; dir = 1; }
-        if (dnOk && c[1] < bcost) { bcost = c[1]; dir = 2; }
-        if (c[2] < bcost) { bcost = c[2]; dir = 3; }
-        if (c[3] < bcost) { bcost = c[3]; dir = 4; }
-        int d[4] = { lr_cost_f(b, bx - 1, by - 1), lr_cost_f(b, bx - 1, by + 1), lr_cost_f(b, bx + 1, by - 1), lr_cost_f(b, bx + 1, by + 1) };
-        if (upOk && d[0] < bcost) { bcost = d[0]; dir = 5; }
-        if (dnOk && d[1] < bcost) { bcost = d[1]; dir = 6; }
-        if (upOk && d[2] < bcost) { bcost = d[2]; dir = 7; }
-        if (dnOk && d[3] < bcost) { bcost = d[3]; dir = 8; }
+        int c8[8];
+        {
+            const int sx[8] = { bx, bx, bx - 1, bx + 1, bx - 1, bx - 1, bx + 1, bx + 1 }, sy[8] = { by - 1, by + 1, by, by, by - 1, by + 1, by - 1, by + 1 };
+            lr_cost_f_n<8>(b, sx, sy, c8);
+        }
+        if (upOk && c8[0] < bcost) { bcost = c8[0]; dir = 1; }
+        if (dnOk && c8[1] < bcost) { bcost = c8[1]; dir = 2; }
+        if (c8[2] < bcost) { bcost = c8[2]; dir = 3; }
+        if (c8[3] < bcost) { bcost = c8[3]; dir = 4; }
+        if (upOk && c8[4] < bcost) { bcost = c8[4]; dir = 5; }
+        if (dnOk && c8[5] < bcost) { bcost = c8[5]; dir = 6; }
+        if (upOk && c8[6] < bcost) { bcost = c8[6]; dir = 7; }
+        if (dnOk && c8[7] < bcost) { bcost = c8[7]; dir = 8; }
         bx += lr_square1[dir][0]; by += lr_square1[dir][1];
     }
     int qx, qy;
@@ -248,24 +277,37 @@ XA_DEV int lr_motion_estimate(LrBlock& b, int mnx, int mny, int mxx, int mxy, in
     if (!bcost) bcost = lr_mvcost(b, qx, qy);
     else
     {
-        /* lowres sub-pel refinement (motion.cpp:1496-1525), workload[1]: 4 half-pel SADs, 4 quarter-pel SATDs */
+        /* lowres sub-pel refinement (motion.cpp:1496-1525), workload[1]: 4 half-pel SADs, 4 quarter-pel SATDs -- each group of four loaded together */
         int bdir = 0;
-        for (int i = 1; i <= 4; i++)
         {
-            const int tx = qx + lr_square1[i][0] * 2, ty = qy + lr_square1[i][1] * 2;
-            if (ty < qmny || ty > qmxy) continue;
-            const int c = lr_sad_q(b, tx, ty) + lr_mvcost(b, tx, ty);
-            if (c < bcost) { bcost = c; bdir = i; }
+            int v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = lr_ld(b, qx + lr_square1[i + 1][0] * 2, qy + lr_square1[i + 1][1] * 2);
+#pragma unroll
+            for (int i = 1; i <= 4; i++)
+            {
+                const int tx = qx + lr_square1[i][0] * 2, ty = qy + lr_square1[i][1] * 2;
+                if (ty < qmny || ty > qmxy) continue;
+                const int c = lr_sad_v(b, v[i - 1]) + lr_mvcost(b, tx, ty);
+                if (c < bcost) { bcost = c; bdir = i; }
+            }
         }
         qx += lr_square1[bdir][0] * 2; qy += lr_square1[bdir][1] * 2;
-        bcost = lr_satd_q(b, qx, qy) + lr_mvcost(b, qx, qy);
-        bdir = 0;
-        for (int i = 1; i <= 4; i++)
         {
-            const int tx = qx + lr_square1[i][0], ty = qy + lr_square1[i][1];
-            if (ty < qmny || ty > qmxy) continue;
-            const int c = lr_satd_q(b, tx, ty) + lr_mvcost(b, tx, ty);
-            if (c < bcost) { bcost = c; bdir = i; }
+            const int v0 = lr_ld(b, qx, qy);
+            int v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = lr_ld(b, qx + lr_square1[i + 1][0], qy + lr_square1[i + 1][1]);
+            bcost = lr_satd_v(b, v0) + lr_mvcost(b, qx, qy);
+            bdir = 0;
+#pragma unroll
+            for (int i = 1; i <= 4; i++)
+            {
+                const int tx = qx + lr_square1[i][0], ty = qy + lr_square1[i][1];
+                if (ty < qmny || ty > qmxy) continue;
+                const int c = lr_satd_v(b, v[i - 1]) + lr_mvcost(b, tx, ty);
+                if (c < bcost) { bcost = c; bdir = i; }
+            }
         }
         qx += lr_square1[bdir][0]; qy += lr_square1[bdir][1];
     }
@@ -302,7 +344,9 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
     const bool lastRow = cuY == p.heightInCU - 1 || (p.numSlices > 1 && (cuY + 1) % p.rowsPerSlice == 0 && (cuY + 1) / p.rowsPerSlice < p.numSlices);
     const int W = p.widthInCU;
     LrBlock b;
-    b.fencT = fencT; b.buf = buf; b.p = &p; b.lane = lane;
+    b.p = &p; b.lane = lane;
+    b.ly = ((lane >> 5) << 2) + ((lane >> 2) & 3); b.lx = (((lane >> 4) & 1) << 2) + (lane & 3);        /* tile order: lanes 16 t .. 16 t + 15 are the 4x4 tile t */
+    (void)fencT; (void)buf; (void)buf2;
     for (int cuX = W - 1; cuX >= 0; cuX--)
     {
         /* (an estimate that only measures -- both motion fields exist -- has no order between its blocks: the neighbours' vectors are read, not made) */
@@ -317,9 +361,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         }
         const int cuXY = cuX + cuY * W;
         b.off = 8L * cuX + 8L * cuY * p.stride;
-        xa_wave_sync();
-        fencT[lane] = p.fenc[b.off + (long)(lane >> 3) * p.stride + (lane & 7)];
-        xa_wave_sync();
+        b.f = p.fenc[b.off + (long)b.ly * p.stride + b.lx];
         const int mnx = -cuX * 8 - 8, mny = -cuY * 8 - 8, mxx = (W - cuX - 1) * 8 + 8, mxy = (p.heightInCU - cuY - 1) * 8 + 8;
         int bcost = 1 << 28, listused = 0;          /* MotionEstimate::COST_MAX */
         int mvx[2] = { 0, 0 }, mvy[2] = { 0, 0 };
@@ -353,9 +395,11 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
             if (numc)
             {
                 int mvpcost = 1 << 28;
+                int vc[4];
+                for (int k = 0; k < numc; k++) vc[k] = lr_ld(b, mcx[k], mcy[k]);         /* the (at most four) neighbour vectors' blocks loaded together */
                 for (int k = 0; k < numc; k++)
                 {
-                    const int c = lr_satd_q(b, mcx[k], mcy[k]);
+                    const int c = lr_satd_v(b, vc[k]);
                     if (c < mvpcost) { mvpcost = c; mvpx = mcx[k]; mvpy = mcy[k]; }
                     if (!(mvpx | mvpy) && p.bidir) skipCost = c;
                 }
@@ -370,19 +414,15 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         if (p.bidir)
         {
             /* avg(l0-mv, l1-mv), then the co-located average */
-            b.list = 0; b.planes = p.ref[0]; lr_fetch(b, mvx[0], mvy[0]);
-            const int a0 = buf[lane];
-            b.list = 1; b.planes = p.ref[1]; lr_fetch(b, mvx[1], mvy[1]);
-            xa_wave_sync();
-            buf2[lane] = (pixel)((a0 + buf[lane] + 1) >> 1);
-            xa_wave_sync();
-            int bicost = xa_wave_satd(fencT, 8, buf2, 8, 8, 8, lane);
+            b.list = 0; b.planes = p.ref[0];
+            const int a0 = lr_ld(b, mvx[0], mvy[0]);
+            b.list = 1; b.planes = p.ref[1];
+            const int a1 = lr_ld(b, mvx[1], mvy[1]);
+            const long o = b.off + (long)b.ly * p.stride + b.lx;
+            const int z0 = p.ref[0][0][o], z1 = p.ref[1][0][o];
+            int bicost = lr_satd_v(b, (a0 + a1 + 1) >> 1);
             if (bicost < bcost) { bcost = bicost; listused = 3; }
-            const long o = b.off + (long)(lane >> 3) * p.stride + (lane & 7);
-            xa_wave_sync();
-            buf2[lane] = (pixel)((p.ref[0][0][o] + p.ref[1][0][o] + 1) >> 1);
-            xa_wave_sync();
-            bicost = xa_wave_satd(fencT, 8, buf2, 8, 8, 8, lane);
+            bicost = lr_satd_v(b, (z0 + z1 + 1) >> 1);
             if (bicost < bcost) { bcost = bicost; listused = 3; }
             bcost += 4;
         }
