@@ -54,8 +54,9 @@ __shared__ int xa_nxn_kind;
  * device side
  * ======================================================================================================= */
 extern __shared__ __attribute__((aligned(16))) char xa_smem[];
+__shared__ int xa_q_index;                                            /* the queue this workgroup serves (k_job_server: base + blockIdx.x) */
 __device__ uint64_t* xa_dbg_area[256];                                /* per workgroup: XaRingHost::dbg (debugging aid) */
-#define XA_DBG(c, slot, v) do { if (((c).reserved & 2) && (threadIdx.x & 63) == 0) __hip_atomic_store(&xa_dbg_area[blockIdx.x][((threadIdx.x >> 6) * 8 + (slot)) & 63], (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)      /* aliases tu_smem / me_smem: one dynamic LDS block, laid out per command */
+#define XA_DBG(c, slot, v) do { if (((c).reserved & 2) && (threadIdx.x & 63) == 0) __hip_atomic_store(&xa_dbg_area[xa_q_index][((threadIdx.x >> 6) * 8 + (slot)) & 63], (uint64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)      /* aliases tu_smem / me_smem: one dynamic LDS block, laid out per command */
 
 XA_DEV uint64_t xa_sys_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 XA_DEV void xa_sys_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -486,14 +487,16 @@ XA_DEV void xa_dispatch(const XaCmd& c, int tid)
  * wall clock AND the host's heartbeat (hosts[0].alive: bumped with every queue taken and every 256th command of any queue) has stood still for that
  * long -- nothing resident outlives a host that went away, and no queue of a server in use loses its workgroup because its own row was idle (a queue
  * handed out later would have been written to with nobody reading). */
-__global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* rings, XaRingHost* hosts, long long idleTicks, uint64_t generation)
+__global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* rings, XaRingHost* hosts, long long idleTicks, uint64_t generation, int base)
 {
     __shared__ XaCmd s_cmd;
     __shared__ int s_go;
     __shared__ unsigned long long s_prof[64];
     __shared__ unsigned long long s_sized[24];
-    XaRingDev* rd = rings + blockIdx.x;
-    XaRingHost* rh = hosts + blockIdx.x;
+    /* base: the first queue of this launch (the server's queues are served by two launches: the second starts when the first's queues are all taken -- Server::startSecond) */
+    const int qIdx = base + (int)blockIdx.x;
+    XaRingDev* rd = rings + qIdx;
+    XaRingHost* rh = hosts + qIdx;
     const int tid = threadIdx.x;
     uint64_t seen = 0, signalled = 0, pre = 0, lastAlive = 0;
     bool havePre = false;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
     if (tid < 40) (&xa_nxn_acc[0][0])[tid] = 0;
     if (tid < 8) xa_chain_acc[tid] = 0;
     if (tid == 0) xa_stage_prev = wall_clock64();
-    if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[blockIdx.x] = rh->dbg; xa_wait_failed = 0; }
+    if (tid == 0) { xa_sys_store(&rh->state, 1); xa_dbg_area[qIdx] = rh->dbg; xa_wait_failed = 0; xa_q_index = qIdx; }
     __syncthreads();
     for (;;)
     {
@@ -729,6 +732,14 @@ struct Server
     char* staging = nullptr;
     std::vector<XaQueue> q;
     hipStream_t stream = nullptr;
+    /* The queues are served by TWO launches of the resident kernel (round 5): the first `firstCount` queues from the start, the rest from the moment a queue beyond them is
+     * handed out (queues are taken lowest index first).  A resident workgroup holds a whole compute unit (144 KB of LDS, 256 vector registers per lane): with all 224 resident
+     * from the first picture on, everything else -- the lookahead's cost estimates above all, whose first decision is 384 estimates -- ran on the 32 units left (527 ms at
+     * 2160p against 298 on an idle device, longer than the I picture beside it).  While only the I picture runs, its rows need a fraction of the queues.  The second launch
+     * has a stream of the OTHER extreme priority: like the first it must not share a hardware queue with anything (see init). */
+    hipStream_t stream2 = nullptr;
+    int firstCount = 0;
+    bool running2 = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;        /* around every launch of the resident kernel, on its stream: its duration by HIP events (bench.py's roofline) */
     double kernelMs = 0.0; uint64_t launches = 0;
     bool running = false;
@@ -762,6 +773,18 @@ struct Server
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest) != hipSuccess)
                 if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return -1;
         }
+        {
+            const char* f = getenv("X265AMD_QUEUES_FIRST");
+            /* Measured (profiles/r05_queues_first_sweep.txt): with 96 or 128 first the lookahead's first decision falls from 135 to 89 ms at 1080p (518 -> 499 at 2160p, whose
+             * I picture wants more than that many queues within 170 ms), but the 20-frame encodes are not faster (0.38 -> 0.39 s at 1080p: a queue handed out whose workgroup has
+             * still to find a free compute unit among the lookahead's long-running rows stalls its row) -- so the default stays ONE launch of everything; X265AMD_QUEUES_FIRST=n
+             * is the experiment */
+            firstCount = f ? atoi(f) : n;
+            if (firstCount <= 0 || firstCount > n) firstCount = n;
+            int least = 0, greatest = 0;
+            if (firstCount < n && (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest || hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, least) != hipSuccess))
+            { stream2 = nullptr; firstCount = n; }         /* no second priority to be had: one launch, as before */
+        }
         if (hipFuncSetAttribute((const void*)k_job_server, hipFuncAttributeMaxDynamicSharedMemorySize, XA_SERVER_LDS) != hipSuccess) return -1;
         if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) return -1;
         memset((void*)hosts, 0, sizeof(XaRingHost) * n);
@@ -790,10 +813,20 @@ struct Server
         }
         _mm_sfence();
         (void)hipEventRecord(ev0, stream);
-        hipLaunchKernelGGL(k_job_server, dim3(numQueues), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 60, generation);
+        hipLaunchKernelGGL(k_job_server, dim3(firstCount), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream, rings, hosts, 100000000LL * 60, generation, 0);
         if (hipGetLastError() != hipSuccess) return -1;
         (void)hipEventRecord(ev1, stream);
-        running = true;
+        running = true; running2 = false;
+        return 0;
+    }
+    /* called with the lock held, the first launch running: the queues from firstCount on get their workgroups */
+    int startSecond()
+    {
+        if (running2 || firstCount >= numQueues) return 0;
+        xa_thread_device();
+        hipLaunchKernelGGL(k_job_server, dim3(numQueues - firstCount), dim3(64 * XA_SERVER_WAVES), XA_SERVER_LDS, stream2, rings, hosts, 100000000LL * 60, generation, firstCount);
+        if (hipGetLastError() != hipSuccess) return -1;
+        running2 = true;
         return 0;
     }
     void stop()
@@ -802,7 +835,8 @@ struct Server
         for (int i = 0; i < numQueues; i++) rings[i].quit = 1;
         _mm_sfence();
         (void)hipStreamSynchronize(stream);
-        running = false;
+        if (running2) (void)hipStreamSynchronize(stream2);
+        running = false; running2 = false;
         { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { kernelMs += ms; launches++; } }
         static const bool prof = getenv("X265AMD_QUEUE_PROF") != nullptr;
         if (prof) profile_report(false);
@@ -1056,7 +1090,7 @@ void* xa_queue_acquire()
         }
         if (S.freed.wait_for(g, std::chrono::seconds(120)) == std::cv_status::timeout) return nullptr;
     }
-    if (S.start() != 0) return nullptr;
+    if (S.start() != 0 || (f->idx >= S.firstCount && S.startSecond() != 0)) return nullptr;
     __atomic_fetch_add(&S.hosts[0].alive, 1, __ATOMIC_RELAXED);
     f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr; f->aux = nullptr;
     S.freeCount = S.freeCount - 1;
@@ -1082,7 +1116,7 @@ void* xa_queue_try_acquire_spare(int spareWanted)
     XaQueue* f = nullptr;
     for (XaQueue& x : S.q) if (!x.busy) { freeN++; if (!f) f = &x; }
     if (!f || freeN <= spare) return nullptr;
-    if (S.start() != 0) return nullptr;
+    if (S.start() != 0 || (f->idx >= S.firstCount && S.startSecond() != 0)) return nullptr;
     f->busy = true; f->stagingUsed = 0; f->stagingUsedOut = 0; f->deferred.clear(); f->helper = nullptr; f->aux = nullptr;
     S.freeCount = S.freeCount - 1;
     S.refs++;

@@ -851,7 +851,7 @@ int x265amd_encoder::sliceWeights(Pic& pic)
         for (int plane = 0; plane < 3; plane++) pic.weighted |= weights[plane].present != 0;
     }
     pic.lumaDenom = pic.wp[0][0][0].denom; pic.chromaDenom = pic.wp[0][0][1].denom;         /* what pred_weight_table() codes once: the first reference's (entropy.cpp:1376-1387) */
-    static const bool wpLog = getenv("X265AMD_WP_LOG") != nullptr;
+    const bool wpLog = getenv("X265AMD_WP_LOG") != nullptr;         /* (read per picture: a test switches it on for one encode) */
     if (wpLog && pic.weighted)
     {
         /* the reference's --log-level full line */
