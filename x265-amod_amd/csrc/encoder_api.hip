@@ -349,7 +349,17 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         e->lowStride += (32 - (e->lowStride & 31)) & 31;
         e->lowPlaneElems = (size_t)(e->lowH + 2 * e->marginY) * e->lowStride;
         e->lowOrg = (size_t)e->marginY * e->lowStride + e->marginX;
-        if (e->lookahead && hipStreamCreateWithFlags(&e->laStream, hipStreamNonBlocking) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder_open: stream"); return nullptr; }
+        if (e->lookahead)
+        {
+            /* The lookahead's kernels run for tens of milliseconds (a batch of cost estimates: hundreds of rows chained through progress words), and streams of one priority
+             * share hardware queues: a picture's in-loop filter launch -- one workgroup, microseconds -- queued behind such a batch on the same hardware queue waited for it to END
+             * (k_deblock_unit: 47 ms at worst in round 4's trace), and every picture that references that row waited with it.  Streams of another priority get hardware queues
+             * of their own (device_queue.hip: the resident kernel's is the highest): the lookahead takes the lowest.  X265AMD_LA_PRIORITY=0: the ordinary one, as before. */
+            static const bool laLow = !(getenv("X265AMD_LA_PRIORITY") && atoi(getenv("X265AMD_LA_PRIORITY")) == 0);
+            int least = 0, greatest = 0;
+            if (!laLow || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest || hipStreamCreateWithPriority(&e->laStream, hipStreamNonBlocking, least) != hipSuccess)
+                if (hipStreamCreateWithFlags(&e->laStream, hipStreamNonBlocking) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder_open: stream"); return nullptr; }
+        }
     }
     {
         /* pictures whose references are complete are analysed concurrently (B frames of a mini-GOP, the next P): the reference's frame threads, but
