@@ -6,7 +6,7 @@ requests are under-reported by 2x -- these commands read 1-8 bytes per lane, who
 WRITE_SIZE is uncalibrated (taken as it comes).  Infinity-Cache hits are counted as traffic, not excluded."""
 import csv, glob, json, os, sys, collections
 out, dst = sys.argv[1], sys.argv[2]
-KIND = {"k_intra_nxn": "intra_nxn", "k_copy_rects": "copy_rects", "k_cu_measure": "cu_measure", "k_tu_chain": "tu_chain", "k_intra_tu_chain": "intra_tu_chain", "k_intra_scan": "intra_scan",
+KIND = {"k_intra_nxn": "intra_nxn", "k_copy_rects": "copy_rects", "k_cu_measure": "cu_measure", "k_cu_measure_wg": "cu_measure", "k_tu_chain": "tu_chain", "k_intra_tu_chain": "intra_tu_chain", "k_intra_scan": "intra_scan",
         "k_intra_pu": "intra_pu", "k_motion_compensation": "mc", "k_mc_cost": "mc_cost", "k_me_search": "me_search", "k_me_deferred": "me_deferred", "k_est_bit": "est_bit"}
 def find(sub, pat):
     g = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
@@ -33,6 +33,14 @@ for name, d in sorted(res.items(), key=lambda kv: -(kv[1]["FETCH_SIZE_KB"] + kv[
         if c["algorithmic_bytes"]:
             row["traffic_over_algorithmic_low"] = round(row["hbm_bytes_low"] / c["algorithmic_bytes"], 3)
             row["traffic_over_algorithmic_high"] = round(row["hbm_bytes_high"] / c["algorithmic_bytes"], 3)
+            # per unit of the kind: the two runs do not issue the same NUMBER of units of a kind once P / B pictures are in (with the job server the skip chain and the fused
+            # search stand for most merge checks and searches, which as launches are motion compensations, measurements and transform chains of their own), so the totals
+            # above compare like with like only for the kinds of an I picture; a launch's traffic against a command's own algorithmic bytes does for the others
+            if d["launches"] and c["commands"]:
+                row["hbm_bytes_per_launch_low"] = int(row["hbm_bytes_low"] / d["launches"]); row["hbm_bytes_per_launch_high"] = int(row["hbm_bytes_high"] / d["launches"])
+                row["algorithmic_bytes_per_command"] = int(c["algorithmic_bytes"] / c["commands"])
+                row["per_unit_traffic_over_algorithmic_low"] = round(row["hbm_bytes_per_launch_low"] / max(1, row["algorithmic_bytes_per_command"]), 3)
+                row["per_unit_traffic_over_algorithmic_high"] = round(row["hbm_bytes_per_launch_high"] / max(1, row["algorithmic_bytes_per_command"]), 3)
     rows[name] = row
 tot_low = sum(r["hbm_bytes_low"] for r in rows.values() if "command_kind" in r); tot_high = sum(r["hbm_bytes_high"] for r in rows.values() if "command_kind" in r)
 tot_alg = sum(r["algorithmic_bytes"] for r in rows.values() if "command_kind" in r)
