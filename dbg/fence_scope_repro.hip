@@ -111,6 +111,116 @@ template <bool SYSTEM, bool WAITALL, bool MIX> __global__ __launch_bounds__(128)
     }
 }
 
+__global__ void k_flood(uint32_t* word);
+/* Round 5: what the encoder's chain has and the variants above lack.  Workgroups of EIGHT wavefronts with 144 KB of dynamic LDS (one per compute unit, as the
+ * job server's); per turn the writer's eight wavefronts write FIVE different buffers -- a 64x64 "tile" (device memory, 16-byte stores), an 8x8 block of a 2-D "picture" with a stride
+ * of 2112 bytes (byte stores), the peer record (424 bytes), the chain record (its 160 context bytes as byte stores by 160 lanes, its fraction and sixteen mode bytes by one lane) and a
+ * result record in PINNED HOST memory --, every wavefront waits for its own stores, a barrier, ONE lane releases and stores the flag.  The reader polls, acquires (+ s_dcache_inv) and
+ * reads the chain record's fraction and modes through a wave-uniform address (the compiler makes scalar loads of them, as in nxn_chain_begin), its contexts and the peer record by
+ * lanes, the picture block and the tile by lanes.  Anything that is not the turn's pattern is a lost write. */
+struct Enc
+{
+    uint64_t flag[2][16];
+    uint32_t tile[2][64 * 64 / 4];          /* bytes, written 16 at a time */
+    uint8_t pic[2][8 * 2112];
+    uint32_t peer[2][106];
+    struct Chain { uint64_t frac; uint8_t ctx[160]; uint8_t mode[16]; } chain[2];
+    uint32_t lostWords, lostTurns, gaveUp, xcc[2], lostKind[6];
+};
+__device__ __forceinline__ uint8_t pat8(uint32_t turn, uint32_t who, uint32_t i) { return (uint8_t)(pattern(turn, who, i) >> 7); }
+template <bool SYSTEM> __global__ __launch_bounds__(512) void k_enc_like(Enc* S, uint32_t* hostRes, uint32_t turns, uint32_t stride)
+{
+    extern __shared__ char lds[];
+    const uint32_t who = blockIdx.x == 0 ? 0u : (blockIdx.x == stride ? 1u : 2u);
+    if (who == 2u) return;
+    const uint32_t tid = threadIdx.x, other = who ^ 1u;
+    __shared__ uint32_t s_ok;
+    lds[tid * 200] = (char)tid;                 /* the LDS is really there */
+    if (tid == 0) { uint32_t id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id)); S->xcc[who] = id & 15u; }
+    auto write_all = [&](uint32_t turn) {
+        /* tile: 1024 words as 256 16-byte stores by lanes 0..255; picture block: lanes 256..319, a byte each; peer record: lanes 320..425; chain contexts: lanes 0..159 (bytes) */
+        if (tid < 256) { uint4 v; v.x = pattern(turn, who, 4 * tid); v.y = pattern(turn, who, 4 * tid + 1); v.z = pattern(turn, who, 4 * tid + 2); v.w = pattern(turn, who, 4 * tid + 3); reinterpret_cast<uint4*>(S->tile[who])[tid] = v; }
+        else if (tid < 320) { const uint32_t i = tid - 256; S->pic[who][(i >> 3) * 2112 + (i & 7)] = pat8(turn, who, 5000 + i); }
+        else if (tid < 426) S->peer[who][tid - 320] = pattern(turn, who, 6000 + tid - 320);
+        if (tid < 160) S->chain[who].ctx[tid] = pat8(turn, who, 7000 + tid);
+        if (tid == 511) { S->chain[who].frac = ((uint64_t)turn << 32) | pattern(turn, who, 8000); for (int k = 0; k < 16; k++) S->chain[who].mode[k] = pat8(turn, who, 8100 + k); }
+        if (tid >= 448 && tid < 480) hostRes[who * 64 + tid - 448] = pattern(turn, who, 9000 + tid);        /* pinned host memory, plain stores */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) { fence_release<SYSTEM>(); __hip_atomic_store(&S->flag[who][0], (uint64_t)turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    };
+    for (uint32_t turn = 1; turn <= turns; turn++)
+    {
+        if (who == 0) write_all(turn);
+        if (tid == 0)
+        {
+            const long long t0 = wall_clock64();
+            uint32_t ok = 1;
+            while (__hip_atomic_load(&S->flag[other][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < turn)
+            {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 500000000ll) { ok = 0; break; }
+            }
+            fence_acquire<SYSTEM>();
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) { if (tid == 0) atomicAdd(&S->gaveUp, 1u); return; }
+        /* wave-uniform reads of the chain record (scalar loads), as nxn_chain_begin has them */
+        const Enc::Chain* ch = &S->chain[other];
+        const uint64_t frac = ch->frac;
+        uint32_t kind = 0;
+        if (frac != (((uint64_t)turn << 32) | pattern(turn, other, 8000))) kind = 1;
+        for (int k = 0; k < 16 && !kind; k++) if (ch->mode[k] != pat8(turn, other, 8100 + k)) kind = 2;
+        uint32_t bad = 0;
+        if (tid == 0 && kind) bad = kind;
+        if (tid < 256)
+        {
+            const uint4 v = reinterpret_cast<const uint4*>(S->tile[other])[tid];
+            if (v.x != pattern(turn, other, 4 * tid) || v.y != pattern(turn, other, 4 * tid + 1) || v.z != pattern(turn, other, 4 * tid + 2) || v.w != pattern(turn, other, 4 * tid + 3)) bad = 3;
+        }
+        else if (tid < 320) { const uint32_t i = tid - 256; if (S->pic[other][(i >> 3) * 2112 + (i & 7)] != pat8(turn, other, 5000 + i)) bad = 4; }
+        else if (tid < 426) { if (S->peer[other][tid - 320] != pattern(turn, other, 6000 + tid - 320)) bad = 5; }
+        if (tid < 160 && S->chain[other].ctx[tid] != pat8(turn, other, 7000 + tid)) bad = 6;
+        const uint32_t anyBad = __syncthreads_or((int)bad);
+        if (bad) { atomicAdd(&S->lostWords, 1u); atomicAdd(&S->lostKind[bad - 1], 1u); }
+        if (anyBad && tid == 0) atomicAdd(&S->lostTurns, 1u);
+        if (who == 1) write_all(turn);
+    }
+}
+template <bool SYSTEM> static void run_enc(const char* name, Enc* dE, uint32_t* hRes, uint32_t turns, uint32_t stride, int floodWgs, hipStream_t sPing, hipStream_t sFlood, uint32_t* dWord)
+{
+    CHECK(hipMemset(dE, 0, sizeof(Enc)));
+    CHECK(hipDeviceSynchronize());
+    std::atomic<bool> stop{ false };
+    uint64_t floods = 0;
+    std::thread flooder;
+    if (floodWgs > 0)
+        flooder = std::thread([&] {
+            while (!stop.load())
+            {
+                hipLaunchKernelGGL(k_flood, dim3(floodWgs / 46 > 0 ? floodWgs / 46 : 1, 46), dim3(64), 0, sFlood, dWord);
+                floods++;
+                if ((floods & 7) == 0) (void)hipStreamSynchronize(sFlood);
+            }
+            (void)hipStreamSynchronize(sFlood);
+        });
+    const auto t0 = std::chrono::steady_clock::now();
+    CHECK(hipFuncSetAttribute((const void*)k_enc_like<SYSTEM>, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    hipLaunchKernelGGL((k_enc_like<SYSTEM>), dim3(stride + 1), dim3(512), 144 * 1024, sPing, dE, hRes, turns, stride);
+    CHECK(hipGetLastError());
+    CHECK(hipStreamSynchronize(sPing));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    stop.store(true);
+    if (flooder.joinable()) flooder.join();
+    Enc* h = (Enc*)malloc(sizeof(Enc));
+    CHECK(hipMemcpy(h, dE, sizeof(Enc), hipMemcpyDeviceToHost));
+    printf("%-44s XCC %u / %u: %u turns, %u lost in %u turns (frac %u, modes %u, tile %u, picture %u, peer %u, contexts %u)%s, %.2f us per turn, %llu flood launches\n", name, h->xcc[0], h->xcc[1], turns,
+           h->lostWords, h->lostTurns, h->lostKind[0], h->lostKind[1], h->lostKind[2], h->lostKind[3], h->lostKind[4], h->lostKind[5], h->gaveUp ? " (a side gave up waiting)" : "", us / turns, (unsigned long long)floods);
+    fflush(stdout);
+    free(h);
+}
+
 /* the flood: a one-wave workgroup, a little LDS traffic, an atomicAdd on one of 64 words (csrc/lowres_kernels.hip: k_flood, mode 1) */
 __global__ __launch_bounds__(64) void k_flood(uint32_t* word)
 {
@@ -182,6 +292,17 @@ int main(int argc, char** argv)
         snprintf(name, sizeof(name), "agent, shared lines+late, quiet 0/%u", stride); run<false, false, true>(name, dS, turns, words, stride, 0, sPing, sFlood, dWord);
         snprintf(name, sizeof(name), "agent, shared lines+late, FLOOD 0/%u", stride); run<false, false, true>(name, dS, turns, words, stride, floodWgs, sPing, sFlood, dWord);
         snprintf(name, sizeof(name), "system, shared lines+late, FLOOD 0/%u", stride); run<true, false, true>(name, dS, turns, words, stride, floodWgs, sPing, sFlood, dWord);
+    }
+    /* round 5: the encoder-like hand-over (eight wavefronts, 144 KB LDS, five buffers, pinned host memory among them, scalar loads on the reader) */
+    Enc* dE = nullptr; uint32_t* hRes = nullptr;
+    CHECK(hipMalloc((void**)&dE, sizeof(Enc)));
+    CHECK(hipHostMalloc((void**)&hRes, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+    for (uint32_t stride : { 1u, 4u, 8u })
+    {
+        char name[64];
+        snprintf(name, sizeof(name), "encoder-like, agent scope, quiet, wgs 0/%u", stride);  run_enc<false>(name, dE, hRes, turns, stride, 0, sPing, sFlood, dWord);
+        snprintf(name, sizeof(name), "encoder-like, agent scope, FLOOD, wgs 0/%u", stride);  run_enc<false>(name, dE, hRes, turns, stride, floodWgs, sPing, sFlood, dWord);
+        snprintf(name, sizeof(name), "encoder-like, system scope, FLOOD, wgs 0/%u", stride); run_enc<true>(name, dE, hRes, turns, stride, floodWgs, sPing, sFlood, dWord);
     }
     return 0;
 }
