@@ -390,7 +390,8 @@ typedef struct x265amd_intra_nxn_job
     int32_t psy_rdoq_scale;     /* Quant::m_psyRdoqScale */
     uint8_t rdoq_level;         /* 0: plain quantisation (everything above as before) */
     uint8_t rdoq_tu_depth;      /* cu.m_tuDepth of the units (selects the CBF context in rdoQuant): 1 for the four units of an NxN CU, else 0 */
-    uint8_t reserved3[6];
+    uint8_t rdoq_general;       /* 1: an 8x8 CU coded NxN with RDOQ runs in the general form (a wavefront per candidate) instead of the sixteen-lane form: for comparisons */
+    uint8_t reserved3[5];
 } x265amd_intra_nxn_job;
 typedef struct x265amd_intra_chain { uint64_t seq, frac; uint8_t ctx[X265AMD_CTX_STRIDE]; uint8_t mode[4][4]; } x265amd_intra_chain;
 typedef struct x265amd_intra_nxn_out

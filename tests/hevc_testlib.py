@@ -3886,7 +3886,7 @@ INTRA_NXN_JOB_DT = np.dtype([("tmpl", INTRA_TU_JOB_DT, 4), ("pred_dst", "<u8", 4
                              ("ctx", "u1", 160), ("max_cand", "u1"), ("do_chroma", "u1"), ("reserved", "u1", 2), ("pad", "u1", 4), ("ctmpl", INTRA_TU_JOB_DT, 2), ("crecon_dst", "<u8", 2), ("recon_dst", "<u8", 4), ("levels_dst", "<u8"), ("clevels_dst", "<u8"),
                              ("chain", "<u8"), ("peer", "<u8"), ("cu_out", "<u8"), ("peer_recon", "<u8", 3), ("win_dst", "<u8", 3), ("chain_token", "<u8"), ("chain_role", "u1"),
                              ("chain_first", "u1"), ("mode_src", "u1", 4), ("chain_index", "u1"), ("reserved2", "u1"),
-                             ("rdoq_lambda2", "<i8", 3), ("rdoq_lambda", "<i4", 3), ("psy_rdoq_scale", "<i4"), ("rdoq_level", "u1"), ("rdoq_tu_depth", "u1"), ("reserved3", "u1", 6)])
+                             ("rdoq_lambda2", "<i8", 3), ("rdoq_lambda", "<i4", 3), ("psy_rdoq_scale", "<i4"), ("rdoq_level", "u1"), ("rdoq_tu_depth", "u1"), ("rdoq_general", "u1"), ("reserved3", "u1", 5)])
 INTRA_CHAIN_DT = np.dtype([("seq", "<u8"), ("frac", "<u8"), ("ctx", "u1", 160), ("mode", "u1", (4, 4))])
 INTRA_CU8_RESULT_DT = np.dtype([("rd_cost", "<u8"), ("frac_bits", "<u8"), ("other_cost", "<u8"), ("total_bits", "<u4"), ("mv_bits", "<u4"), ("coeff_bits", "<u4"), ("psy_energy", "<u4"),
                                 ("res_energy", "<u4"), ("luma_dist", "<u4"), ("chroma_dist", "<u4"), ("status", "<u4"), ("part_size", "u1"), ("chroma_dir", "u1"), ("cbf_u", "u1"),

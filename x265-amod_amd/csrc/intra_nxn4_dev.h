@@ -122,6 +122,27 @@ XA_DEV Q4 q4_make(int qpScaled, int sliceType)
 
 struct Chain4 { int lv, pred, rec; uint32_t numSig, nzDist, nzEnergy, zeroDist, zeroEnergy; };
 
+/* RDOQ (round 5): a group's working set for wave_rdo_quant's sixteen-lane form (tu_dev.h) -- the coefficients, the levels and the per-position records of ONE 4x4 block;
+ * the bit-estimate table is the command's (Nxn4Lds::est), read where it lies */
+struct Rq4Area { Tu16 t; int64_t costSig[16], delta[16], costCg[2], tmp[16]; int32_t rateDown[16], sigDelta[16]; };
+static_assert(sizeof(Rq4Area) == 688, "");
+/* what a candidate's chain needs to quantise that way: a: the group's area (null: plain quantisation); fD: the source block's DCT coefficient at this lane's raster
+ * position (psy-rdoq: copy_ps + dct, quant.cpp:436-440) */
+struct Rq4 { Rq4Area* a; const RdoqParams* P; int ttype, dirMode, qpScaled, fD; };
+
+/* the two forward passes of a 4x4 block held one sample per lane (grp_fwd_pass: out[k][j] = sum_n T[k][n] in[j][n]) */
+XA_DEV int grp16_forward4(int r, const int16_t* T, int lane)
+{
+    const int l = lane & 15, base = lane & 48, hi = l >> 2, lo = l & 3;
+    const int tf0 = T[hi * 4], tf1 = T[hi * 4 + 1], tf2 = T[hi * 4 + 2], tf3 = T[hi * 4 + 3];
+    const int g0 = base + lo * 4;
+    const int s1 = 1 + XA_DEPTH - 8;
+    int a0 = __shfl(r, g0, 64), a1 = __shfl(r, g0 + 1, 64), a2 = __shfl(r, g0 + 2, 64), a3 = __shfl(r, g0 + 3, 64);
+    const int b = (int)(int16_t)((tf0 * a0 + tf1 * a1 + tf2 * a2 + tf3 * a3 + (1 << (s1 - 1))) >> s1);
+    a0 = __shfl(b, g0, 64); a1 = __shfl(b, g0 + 1, 64); a2 = __shfl(b, g0 + 2, 64); a3 = __shfl(b, g0 + 3, 64);
+    return (int)(int16_t)((tf0 * a0 + tf1 * a1 + tf2 * a2 + tf3 * a3 + 128) >> 8);
+}
+
 /* the energy term of psyCost_pp for a 4x4 block held one sample per lane (pixel.cpp:744-775): satd against zeros minus a quarter of the sum */
 XA_DEV int nxn4_energy(int v, int lane)
 {
@@ -133,20 +154,32 @@ XA_DEV int nxn4_energy(int v, int lane)
 
 /* the transform chain of one 4x4 candidate on the sixteen lanes of a group: f / p = this lane's source and prediction sample (raster order).  Returns with .lv = the
  * level at this lane's RASTER position; numSig and the measurements are the same in all sixteen lanes. */
-XA_DEV Chain4 grp16_chain4(int f, int p, int dst, const Q4& q, int signHide, int scanType, const Nxn4Tabs& tb, int srcEnergy, int lane)
+template<bool RQ = false>
+XA_DEV Chain4 grp16_chain4(int f, int p, int dst, const Q4& q, int signHide, int scanType, const Nxn4Tabs& tb, int srcEnergy, int lane, const Rq4* rq = nullptr)
 {
     const int l = lane & 15, base = lane & 48, hi = l >> 2, lo = l & 3;
     const int16_t* T = tb.T[dst];
-    const int tf0 = T[hi * 4], tf1 = T[hi * 4 + 1], tf2 = T[hi * 4 + 2], tf3 = T[hi * 4 + 3];
     const int ti0 = T[lo], ti1 = T[4 + lo], ti2 = T[8 + lo], ti3 = T[12 + lo];
     const int r = f - p;
-    /* forward passes (grp_fwd_pass: out[k][j] = sum_n T[k][n] in[j][n]) */
-    const int g0 = base + lo * 4;
-    const int s1 = 1 + XA_DEPTH - 8;
-    int a0 = __shfl(r, g0, 64), a1 = __shfl(r, g0 + 1, 64), a2 = __shfl(r, g0 + 2, 64), a3 = __shfl(r, g0 + 3, 64);
-    const int b = (int)(int16_t)((tf0 * a0 + tf1 * a1 + tf2 * a2 + tf3 * a3 + (1 << (s1 - 1))) >> s1);
-    a0 = __shfl(b, g0, 64); a1 = __shfl(b, g0 + 1, 64); a2 = __shfl(b, g0 + 2, 64); a3 = __shfl(b, g0 + 3, 64);
-    const int c = (int)(int16_t)((tf0 * a0 + tf1 * a1 + tf2 * a2 + tf3 * a3 + 128) >> 8);
+    const int c = grp16_forward4(r, T, lane);
+    int a0, a1, a2, a3;
+    Chain4 o;
+    uint32_t numSig;
+    if constexpr (RQ)
+    {
+        /* Quant::rdoQuant on the group's sixteen lanes: coefficients and levels by raster position in the group's area */
+        Rq4Area& A = *rq->a;
+        const bool usePsy = rq->P->psyRdoqScale != 0 && rq->ttype == 0;
+        A.t.dct[l] = (int16_t)c;
+        if (usePsy) reinterpret_cast<int16_t*>(A.t.deltaU)[l] = (int16_t)rq->fD;
+        xa_wave_sync();
+        RdoqRef rr{ A.costSig, A.delta, A.rateDown, A.sigDelta, A.costCg, A.tmp, const_cast<int32_t*>(rq->P->est) };
+        numSig = wave_rdo_quant<RdoqRef, true, Tu16>(A.t, rr, *rq->P, 2, rq->ttype, 1, rq->dirMode, rq->qpScaled, signHide, usePsy, lane);
+        xa_wave_sync();
+        o.lv = A.t.q[l];
+    }
+    else
+    {
     /* from here to the levels: lane l = scan position l */
     const int cs = __shfl(c, base + tb.scan[scanType][l], 64);
     const int sign = cs < 0 ? -1 : 1;
@@ -155,7 +188,7 @@ XA_DEV Chain4 grp16_chain4(int f, int p, int dst, const Q4& q, int signHide, int
     const int dU = (tmplevel - (level << q.qbits)) >> (q.qbits - 8);
     int lv = xa_clip3(-32768, 32767, level * sign);
     const uint32_t nz = (uint32_t)(__ballot(lv != 0) >> base) & 0xFFFFu;
-    uint32_t numSig = (uint32_t)__popc(nz);
+    numSig = (uint32_t)__popc(nz);
     {
         /* signBitHidingHDQ for the one coefficient group (quant.cpp:247-395), as grp_tu_forward has it */
         const int firstNZ = nz ? __builtin_ctz(nz) : -1, lastNZ = nz ? 31 - __builtin_clz(nz) : -1;
@@ -187,9 +220,9 @@ XA_DEV Chain4 grp16_chain4(int f, int p, int dst, const Q4& q, int signHide, int
         }
         numSig = (uint32_t)((int)numSig + xa_row16_sum(delta));
     }
-    Chain4 o;
     /* back to raster order */
     o.lv = __shfl(lv, base + tb.inv[scanType][l], 64);
+    }
     int resi = 0;
     if (numSig)
     {
@@ -362,14 +395,20 @@ struct Nxn4Lds
     uint64_t runFrac, runMv;
     uint64_t cfrac[6], ccoef[6];
     unsigned long long ccost[5];                 /* the chroma modes' costs (apart from the luma candidates': the two decisions overlap) */
+    /* RDOQ: the command's two bit-estimate tables (luma units, chroma blocks: Entropy::estBit on its start contexts), and where the groups' areas lie (32 of them) */
+    int32_t est[2][184];
+    Rq4Area* rq;
 };
+/* what a command with RDOQ needs behind its Nxn4Lds */
+#define NXN4_RQ_BYTES (32 * (int)sizeof(Rq4Area))
 
 /* estIntraPredChromaQT for the one 4x4 block per plane of an 8x8 CU (search.cpp:1754-1889): the five listed modes, a group of sixteen lanes each (cwv 0: modes 0..3,
  * cwv 1: mode 4), one plane per call -- U (pl 0: from a copy of the start contexts), then V (pl 1: on the contexts U has moved, and the mode's cost).  Reads S.cref /
  * S.csw / S.cfenc and the tables; leaves per mode S.crec, S.clev, S.cres, S.ctxw (the contexts behind the mode's bins), S.cfrac (the coder's fraction behind them, from
  * P.scan_frac) and S.ccost.  Two calls with a wavefront-level fence between them; the caller synchronises the workgroup and picks. */
-XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint32_t list[5], uint32_t lumaDir, int pl, const EnTabs& tabs, int lane, int cwv, int grp, int l)
+XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint32_t list[5], uint32_t lumaDir, int pl, const EnTabs& tabs, int lane, int cwv, int grp, int l, Rq4Area* area = nullptr)
 {
+    const bool rdoq = P.rdoq_level != 0;      /* (then area: the calling group's) */
     const int mi = cwv * 4 + grp, m = mi < 5 ? mi : 4;
     const uint32_t listed = list[m], mode = listed == 36 ? lumaDir : listed;
     const int scanType = mode >= 22 && mode <= 30 ? 1 : (mode >= 6 && mode <= 14 ? 2 : 0);
@@ -391,7 +430,14 @@ XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const 
     const int dc = (__shfl(s, lane & 48, 64) + 4) >> 3;
     const int f = S.cfenc[pl][l];
     const int p = nxn4_pred_sample(cr, S.csw[pl], S.tb, (int)mode, dc, y, x, false);
-    const Chain4 ch = grp16_chain4(f, p, 0, qC, C.tu.sign_hide, scanType, S.tb, nxn4_energy(f, lane), lane);
+    Chain4 ch;
+    if (rdoq)
+    {
+        const RdoqParams rp = { S.est[1], P.rdoq_lambda2[1 + pl], P.rdoq_lambda[1 + pl], P.psy_rdoq_scale, P.rdoq_level, P.rdoq_tu_depth };
+        const Rq4 rq = { area, &rp, 1 + pl, (int)mode, C.tu.qp_scaled, 0 };
+        ch = grp16_chain4<true>(f, p, 0, qC, C.tu.sign_hide, scanType, S.tb, nxn4_energy(f, lane), lane, &rq);
+    }
+    else ch = grp16_chain4(f, p, 0, qC, C.tu.sign_hide, scanType, S.tb, nxn4_energy(f, lane), lane);
     const int lvScan = __shfl(ch.lv, (lane & 48) + S.tb.scan[scanType][l], 64);
     if (mi < 5)
     {
@@ -425,9 +471,10 @@ XA_DEV void nxn4_chroma_plane(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const 
 XA_DEV void nxn4_chroma_modes(const x265amd_intra_nxn_job& P, Nxn4Lds& S, const uint32_t list[5], uint32_t lumaDir, const EnTabs& tabs, int lane, int wv, int grp, int l)
 {
     if (wv >= 2) return;
-    nxn4_chroma_plane(P, S, list, lumaDir, 0, tabs, lane, wv, grp, l);
+    Rq4Area* area = P.rdoq_level ? S.rq + wv * 4 + grp : nullptr;
+    nxn4_chroma_plane(P, S, list, lumaDir, 0, tabs, lane, wv, grp, l, area);
     xa_wave_sync();
-    nxn4_chroma_plane(P, S, list, lumaDir, 1, tabs, lane, wv, grp, l);
+    nxn4_chroma_plane(P, S, list, lumaDir, 1, tabs, lane, wv, grp, l, area);
 }
 
 /* The same evaluation for chroma modes given by NUMBER, ahead of the luma decision (block_intra_nxn, an 8x8 CU coded 2Nx2N): slot = slot0 + the lane's group, active when
@@ -617,14 +664,24 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
     XA_CHAIN(5);
 }
 
-XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_out* po, Nxn4Lds& S, IntraPuShared& L, int tid, int nthr)
+/* rqBase: NXN4_RQ_BYTES of LDS behind S when the command quantises with RDOQ */
+XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_out* po, Nxn4Lds& S, IntraPuShared& L, int tid, int nthr, char* rqBase = nullptr)
 {
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6, l = lane & 15, grp = lane >> 4;
     const x265amd_intra_tu_job& T0 = P.tmpl[0];
     const long ps = T0.nb_stride;
     pixel* pic = reinterpret_cast<pixel*>(T0.nb);                   /* the CU's first sample in the reconstructed plane */
     const bool chained = P.chain != 0 && P.chain_role == 1;          /* the picture, the tiles and the result wait for the decision between this and the other evaluation */
+    const bool rdoq = P.rdoq_level != 0;
     XA_NXN_START(0);
+    if (rdoq)
+    {
+        for (int i = tid; i < 2 * 184; i += nthr) (&S.est[0][0])[i] = 0;
+        if (tid == 0) S.rq = reinterpret_cast<Rq4Area*>(rqBase);
+        __syncthreads();
+        if (wv == 0) wave_est_bit(P.ctx, S.est[0], 2, 1, lane);
+        else if (wv == 1) wave_est_bit(P.ctx, S.est[1], 2, 0, lane);
+    }
     /* ---- tables, the source block, the neighbourhood ---- */
     nxn4_fill_tabs(S.tb, tid);
     if (tid < 128) S.enBits[tid] = en_bits[tid];
@@ -703,6 +760,8 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         const int y = l >> 2, x = l & 3;
         const int f = S.fenc[(uy + y) * 8 + ux + x];
         const int srcEnergy = nxn4_energy(f, lane);
+        const RdoqParams rpL = { S.est[0], P.rdoq_lambda2[0], P.rdoq_lambda[0], P.psy_rdoq_scale, P.rdoq_level, P.rdoq_tu_depth };
+        const int fD = rdoq && P.psy_rdoq_scale ? grp16_forward4(f, S.tb.T[0], lane) : 0;
         /* the scan: a group per mode, SATD of the residual (cu[4x4].sa8d = satd_4x4, pixel.cpp:1171) */
         for (int m0 = 0; m0 < 35 && worker; m0 += 4 * lw)
         {
@@ -725,7 +784,7 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
             const uint32_t lumaDir0 = S.winMode[0];
             uint32_t clist[5] = { 0, 26, 10, 1, 36 };               /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
             for (int i = 0; i < 4; i++) if (lumaDir0 == clist[i]) { clist[i] = 34; break; }
-            nxn4_chroma_plane(P, S, clist, lumaDir0, k - 1, tabs, lane, wv - 5, grp, l);
+            nxn4_chroma_plane(P, S, clist, lumaDir0, k - 1, tabs, lane, wv - 5, grp, l, rdoq ? S.rq + wv * 4 + grp : nullptr);
         }
         /* the candidates' chains: candidate c = group * waves + wavefront (the first eight one per wavefront) */
         Chain4 mine = {};
@@ -737,7 +796,13 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
             const uint32_t mode = L.modes[cc];
             const int p = nxn4_pred_sample(ref, sw, S.tb, (int)mode, dc, y, x, true);
             const int scanType = mode >= 22 && mode <= 30 ? 1 : (mode >= 6 && mode <= 14 ? 2 : 0);
-            const Chain4 ch = grp16_chain4(f, p, 1, qY, signHide, scanType, S.tb, srcEnergy, lane);
+            Chain4 ch;
+            if (rdoq)
+            {
+                const Rq4 rq = { S.rq + wv * 4 + grp, &rpL, 0, (int)mode, T0.tu.qp_scaled, fD };
+                ch = grp16_chain4<true>(f, p, 1, qY, signHide, scanType, S.tb, srcEnergy, lane, &rq);
+            }
+            else ch = grp16_chain4(f, p, 1, qY, signHide, scanType, S.tb, srcEnergy, lane);
             const int lvScan = __shfl(ch.lv, (lane & 48) + S.tb.scan[scanType][l], 64);
             const uint32_t coeffFrac = ch.numSig ? grp16_coeff_bits4(P.ctx, nullptr, lvScan, 1, scanType, signHide, S.step, S.tb, lane) : 0u;
             if (c < n)

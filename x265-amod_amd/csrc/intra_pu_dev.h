@@ -233,10 +233,10 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         if (sP.chain_role == 2) po = &reinterpret_cast<x265amd_intra_peer*>(sP.peer)->out;
     }
-    if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture && !sP.rdoq_level)
+    if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture && (!sP.rdoq_level || !sP.rdoq_general))
     {
         /* the NxN CU proper: its own form, nothing but LDS and registers between the first and the last instruction (intra_nxn4_dev.h) */
-        block_intra_nxn4(sP, po, *reinterpret_cast<Nxn4Lds*>(smem), S, tid, nthr);
+        block_intra_nxn4(sP, po, *reinterpret_cast<Nxn4Lds*>(smem), S, tid, nthr, smem + ((sizeof(Nxn4Lds) + 15) & ~(size_t)15));
         return;
     }
     /* the estimator's tables beside it: the lanes that count bits look them up bin after bin */

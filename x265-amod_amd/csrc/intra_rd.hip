@@ -516,7 +516,9 @@ struct IntraRd
             if (rp->rdoq_level)
             {
                 /* RDOQ: the command makes its bit-estimate tables from nj.ctx (m_rqt[depth].cur: where every candidate and every chroma mode starts) */
+                static const bool nxn4Rdoq = !(getenv("X265AMD_NXN4_RDOQ") && atoi(getenv("X265AMD_NXN4_RDOQ")) == 0);
                 nj.rdoq_level = (uint8_t)rp->rdoq_level; nj.psy_rdoq_scale = rp->psy_rdoq_scale; nj.rdoq_tu_depth = (uint8_t)initTuDepth;
+                nj.rdoq_general = nxn4Rdoq ? 0 : 1;
                 x265amd_rdoq_lambda(qpLumaScaled, &nj.rdoq_lambda2[0], &nj.rdoq_lambda[0]);
                 x265amd_rdoq_lambda(qpChromaScaled, &nj.rdoq_lambda2[1], &nj.rdoq_lambda[1]);
                 nj.rdoq_lambda2[2] = nj.rdoq_lambda2[1]; nj.rdoq_lambda[2] = nj.rdoq_lambda[1];
