@@ -2,7 +2,9 @@
  * coefficient blocks with a plausible shape.  A developer tool (dbg/README.md); nothing in the product, the tests or the bench uses it.
  *
  *   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DX265AMD_DEPTH=8 -Iinclude -Ix265-amod_amd/csrc dbg/rdoq_lat.hip -o dbg/bin/rdoq_lat
- *   dbg/bin/rdoq_lat            -> per size: microseconds per block, cycles per phase, a checksum of all levels (compare two builds of tu_dev.h with it)
+ *   dbg/bin/rdoq_lat [workgroups reps amplitude rdoqLevel ttype qp]
+ *       -> per size: microseconds per block, cycles per phase, a checksum of all levels and counts: build it against two versions of tu_dev.h (-I a checkout of the
+ *          other one) and the checksums say whether they decide alike (dbg/rdoq_lat.sh; profiles/r05_rdoq_latency.txt)
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,6 +18,7 @@ __shared__ unsigned long long rq_acc[16];
 __shared__ unsigned long long rq_t0;
 #define RQ_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (laneIn == 0) { rq_acc[i] += t_ - rq_t0; rq_t0 = t_; } } while (0)
 #define RQ_T0() do { if (laneIn == 0) rq_t0 = __builtin_readcyclecounter(); } while (0)
+#define RQ_FN wave_rdo_quant
 #include "tu_dev.h"
 
 struct Args
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(Args a)
         xa_wave_sync();
         const int dir = (b % 3 == 0) ? 26 : (b % 3 == 1 ? 10 : 1);
         const unsigned long long t0 = __builtin_readcyclecounter();
-        const uint32_t ns = wave_rdo_quant(s, r, P, a.log2N, a.ttype, 1, dir, a.qp, a.signHide, a.psy != 0 && a.ttype == 0, lane);
+        const uint32_t ns = RQ_FN(s, r, P, a.log2N, a.ttype, 1, dir, a.qp, a.signHide, a.psy != 0 && a.ttype == 0, lane);
         const unsigned long long t1 = __builtin_readcyclecounter();
         if (lane == 0) rq_acc[15] += t1 - t0;
         xa_wave_sync();
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(64) void k_rdoq_wave(Args a)
 __global__ __launch_bounds__(64) void k_rdoq_grp16(Args a)
 {
     __shared__ Tu16 t[4];
-    __shared__ int64_t costSig[4][16], delta[4][16], costCg[4][2], tmp[4][16];
+    __shared__ int64_t costSig[4][16], delta[4][16], costCg[4][2];
     __shared__ int32_t rateDown[4][16], sigDelta[4][16], est[184];
     const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
     if (lane < 16) rq_acc[lane] = 0;
@@ -67,9 +70,9 @@ __global__ __launch_bounds__(64) void k_rdoq_grp16(Args a)
         t[g].dct[l] = a.dct[(size_t)b * 16 + l]; reinterpret_cast<int16_t*>(t[g].deltaU)[l] = a.fdct[(size_t)b * 16 + l];
         xa_wave_sync();
         const int dir = (b % 3 == 0) ? 26 : (b % 3 == 1 ? 10 : 1);
-        RdoqRef rr{ costSig[g], delta[g], rateDown[g], sigDelta[g], costCg[g], tmp[g], est };
+        RdoqRef rr{ costSig[g], delta[g], rateDown[g], sigDelta[g], costCg[g], est };
         const unsigned long long t0 = __builtin_readcyclecounter();
-        const uint32_t ns = wave_rdo_quant<RdoqRef, true, Tu16>(t[g], rr, P, 2, a.ttype, 1, dir, a.qp, a.signHide, a.psy != 0 && a.ttype == 0, lane);
+        const uint32_t ns = RQ_FN<RdoqRef, true, Tu16>(t[g], rr, P, 2, a.ttype, 1, dir, a.qp, a.signHide, a.psy != 0 && a.ttype == 0, lane);
         const unsigned long long t1 = __builtin_readcyclecounter();
         if (lane == 0) rq_acc[15] += t1 - t0;
         xa_wave_sync();
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(64) void k_rdoq_grp16(Args a)
     if (lane < 16) atomicAdd(&a.prof[lane], rq_acc[lane]);
 }
 
+static const int tu_quantScales_host[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static uint64_t rng_state = 88172645463325252ull;
@@ -88,6 +92,8 @@ int main(int argc, char** argv)
 {
     const int grid = argc > 1 ? atoi(argv[1]) : 8;
     const int reps = argc > 2 ? atoi(argv[2]) : 4;
+    const double ampMul = argc > 3 ? atof(argv[3]) : 1.0;        /* denser / larger levels */
+    const int rdoqLevel = argc > 4 ? atoi(argv[4]) : 2, ttype = argc > 5 ? atoi(argv[5]) : 0, qpArg = argc > 6 ? atoi(argv[6]) : 30;
     int* estD; std::vector<int> est(184);
     for (int i = 0; i < 184; i++) est[i] = 8000 + (int)(rnd() * 90000);
     CK(hipMalloc(&estD, 184 * 4)); CK(hipMemcpy(estD, est.data(), 184 * 4, hipMemcpyHostToDevice));
@@ -98,12 +104,12 @@ int main(int argc, char** argv)
         if (form == 1 && log2N != 2) continue;
         const int n2 = 1 << (2 * log2N), N = 1 << log2N, nBlocks = 64 * grid;
         /* levels of about 6 at DC falling off with frequency: one level is 2^qbits / quantScale coefficient units */
-        const int qp = 30, per = qp / 6, qbits = 14 + per + 15 - 8 - log2N;
-        const double unit = (double)(1 << qbits) / 26214.0;
+        const int qp = qpArg, per = qp / 6, qbits = 14 + per + 15 - 8 - log2N;
+        const double unit = (double)(1 << qbits) / (double)tu_quantScales_host[qp % 6];
         std::vector<int16_t> dct((size_t)nBlocks * n2), fdct((size_t)nBlocks * n2);
         for (int b = 0; b < nBlocks; b++)
         {
-            const double amp = 2.0 + 8.0 * rnd();
+            const double amp = (2.0 + 8.0 * rnd()) * ampMul;
             for (int i = 0; i < n2; i++)
             {
                 const int y = i >> log2N, x = i & (N - 1);
@@ -119,7 +125,7 @@ int main(int argc, char** argv)
         CK(hipMemcpy(dctD, dct.data(), dct.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(fdctD, fdct.data(), dct.size() * 2, hipMemcpyHostToDevice));
         for (int variant = 0; variant < 2; variant++)       /* 0: psy-rdoq + sign hiding (the slow preset's), 1: neither */
         {
-            Args a = { dctD, fdctD, estD, outD, nsD, profD, log2N, nBlocks, variant == 0, variant == 0 ? 256 : 0, 2, qp, 0, reps };
+            Args a = { dctD, fdctD, estD, outD, nsD, profD, log2N, nBlocks, variant == 0, variant == 0 ? 256 : 0, rdoqLevel, qp, ttype, reps };
             CK(hipMemset(profD, 0, 16 * 8));
             if (form) k_rdoq_grp16<<<grid, 64>>>(a); else k_rdoq_wave<<<grid, 64>>>(a);          /* warm */
             CK(hipDeviceSynchronize());

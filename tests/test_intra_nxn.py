@@ -35,7 +35,7 @@ def expected(O, depth, luma, fenc, chroma, cfenc, ctx, prm, en_bits, lps_next):
         preds_all.append(preds)
         case = dict(plane=np.ascontiguousarray(luma).ravel(), stride=stride, off=y0 * stride + x0, log2=2, flags=np.array(flags_of[k], np.uint8), strong=prm["strong"],
                     fenc=np.ascontiguousarray(fenc[4 * (k >> 1):4 * (k >> 1) + 4, 4 * (k & 1):4 * (k & 1) + 4]), ttype=0, slice=prm["slice"], qp=prm["qp"], signhide=prm["signhide"],
-                    rdoq=0, tudepth=1, psyrdoq=0, ctx=ctx[:T.CTX_COUNT])
+                    rdoq=prm.get("rdoq", 0), tudepth=1, psyrdoq=prm.get("psyrdoq", 0), ctx=ctx[:T.CTX_COUNT])
         sa8d = T.intra_run_host(O, [case])[0][2]
         modes = T.intra_pu_candidates(sa8d, preds, rbits, mpm_base, prm["lambda"], prm["max_cand"])
         per = T.intra_tu_run_host(O, [dict(case, mode=m) for m in modes])
@@ -82,8 +82,8 @@ def expected(O, depth, luma, fenc, chroma, cfenc, ctx, prm, en_bits, lps_next):
         for pl in range(2):
             plane = chroma[pl]
             case = dict(plane=np.ascontiguousarray(plane).ravel(), stride=plane.shape[1], off=8 * plane.shape[1] + 8, log2=2, flags=np.array([1, 1, 1, 1, 1], np.uint8), strong=prm["strong"],
-                        fenc=np.ascontiguousarray(cfenc[pl]), ttype=1 + pl, mode=mode, slice=prm["slice"], qp=prm["qpc"], signhide=prm["signhide"], rdoq=0, tudepth=1, psyrdoq=0,
-                        ctx=ctx[:T.CTX_COUNT])
+                        fenc=np.ascontiguousarray(cfenc[pl]), ttype=1 + pl, mode=mode, slice=prm["slice"], qp=prm["qpc"], signhide=prm["signhide"], rdoq=prm.get("rdoq", 0), tudepth=1,
+                        psyrdoq=prm.get("psyrdoq", 0), ctx=ctx[:T.CTX_COUNT])
             per.append(T.intra_tu_run_host(O, [case])[0])
         for pl in range(2):
             v = 1 if per[pl][0][0] else 0
@@ -133,6 +133,10 @@ def test_hip_intra_nxn(depth):
         prm["lambda"] = int(rng.integers(300, 40000)); prm["lambda2"] = int(rng.integers(2000, 4000000)); prm["psy_scale"] = int(prm["lambda"] * rng.integers(0, 3) * 128)
         for k in range(1, 4):
             prm["frac_start"][k] = prm["scan_frac"]
+        # RDOQ (Quant::rdoQuant with the bit estimates of the command's start contexts) in the later cases: levels 1 and 2, with and without psy-rdoq; every third of
+        # them in the general form (a wavefront per candidate), the others in the sixteen-lane form
+        if it >= 10:
+            prm["rdoq"], prm["psyrdoq"] = 1 + (it & 1), int(rng.choice([0, 256, 1024]))
         want = expected(O, depth, luma, fenc, chroma, cfenc, ctx160, dict(prm), en_bits, lps_next)
 
         d_luma = torch.from_numpy(luma.view(np.uint8).copy()).cuda(); d_fenc = torch.from_numpy(fenc.view(np.uint8).copy()).cuda()
@@ -160,6 +164,12 @@ def test_hip_intra_nxn(depth):
             job[0][f] = prm[f]
         job[0]["frac_start"], job[0]["left_mode"], job[0]["above_mode"] = prm["frac_start"], prm["left_mode"], prm["above_mode"]
         job[0]["slot_pixels"], job[0]["slot_coeffs"], job[0]["ctx"], job[0]["do_chroma"] = 2048, 1024, ctx160, 1
+        if prm.get("rdoq"):
+            job[0]["rdoq_level"], job[0]["psy_rdoq_scale"], job[0]["rdoq_tu_depth"], job[0]["rdoq_general"] = prm["rdoq"], prm["psyrdoq"], 1, int(it % 3 == 0)
+            for pl, q in enumerate((prm["qp"], prm["qpc"], prm["qpc"])):
+                l2, l1 = C.c_int64(0), C.c_int32(0)
+                H.lib.x265amd_rdoq_lambda(q, C.byref(l2), C.byref(l1))
+                job[0]["rdoq_lambda2"][pl], job[0]["rdoq_lambda"][pl] = l2.value, l1.value
         d_job = torch.from_numpy(job.view(np.uint8).copy()).cuda()
         d_out = torch.zeros(T.INTRA_NXN_OUT_DT.itemsize, dtype=torch.uint8, device="cuda")
         assert H.lib.x265amd_intra_nxn(None, C.c_void_p(d_job.data_ptr()), C.c_void_p(d_out.data_ptr())) == 0

@@ -124,8 +124,8 @@ struct Chain4 { int lv, pred, rec; uint32_t numSig, nzDist, nzEnergy, zeroDist, 
 
 /* RDOQ (round 5): a group's working set for wave_rdo_quant's sixteen-lane form (tu_dev.h) -- the coefficients, the levels and the per-position records of ONE 4x4 block;
  * the bit-estimate table is the command's (Nxn4Lds::est), read where it lies */
-struct Rq4Area { Tu16 t; int64_t costSig[16], delta[16], costCg[2], tmp[16]; int32_t rateDown[16], sigDelta[16]; };
-static_assert(sizeof(Rq4Area) == 688, "");
+struct Rq4Area { Tu16 t; int64_t costSig[16], delta[16], costCg[2]; int32_t rateDown[16], sigDelta[16]; };
+static_assert(sizeof(Rq4Area) == 560, "");
 /* what a candidate's chain needs to quantise that way: a: the group's area (null: plain quantisation); fD: the source block's DCT coefficient at this lane's raster
  * position (psy-rdoq: copy_ps + dct, quant.cpp:436-440) */
 struct Rq4 { Rq4Area* a; const RdoqParams* P; int ttype, dirMode, qpScaled, fD; };
@@ -173,7 +173,7 @@ XA_DEV Chain4 grp16_chain4(int f, int p, int dst, const Q4& q, int signHide, int
         A.t.dct[l] = (int16_t)c;
         if (usePsy) reinterpret_cast<int16_t*>(A.t.deltaU)[l] = (int16_t)rq->fD;
         xa_wave_sync();
-        RdoqRef rr{ A.costSig, A.delta, A.rateDown, A.sigDelta, A.costCg, A.tmp, const_cast<int32_t*>(rq->P->est) };
+        RdoqRef rr{ A.costSig, A.delta, A.rateDown, A.sigDelta, A.costCg, const_cast<int32_t*>(rq->P->est) };
         numSig = wave_rdo_quant<RdoqRef, true, Tu16>(A.t, rr, *rq->P, 2, rq->ttype, 1, rq->dirMode, rq->qpScaled, signHide, usePsy, lane);
         xa_wave_sync();
         o.lv = A.t.q[l];

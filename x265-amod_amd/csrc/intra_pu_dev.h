@@ -358,7 +358,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         const int n = S.num;
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv < nwvL ? wv : 0];
         IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwvL * sizeof(TuLds))[wv < nwvL ? wv : 0];
-        const RdoqRef rrL = rdoq_ref_at(smem + (size_t)nwvL * perWave + (size_t)(wv < nwvL ? wv : 0) * rqBytesL, unitLog2);
+        RdoqRef rrL = rdoq_ref_at(smem + (size_t)nwvL * perWave + (size_t)(wv < nwvL ? wv : 0) * rqBytesL, unitLog2);
+        rrL.est = s_est[0];             /* (the command's table is in LDS already: read where it lies) */
         if (chromaAhead && wv >= 6)
         {
             /* U, then V on the contexts U has moved: modes 0 .. 3 of the five by the groups of wavefront 6, the fifth by the first group of wavefront 7 */
@@ -586,7 +587,8 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     {
         TuLds& s = reinterpret_cast<TuLds*>(smem)[wv];
         IntraTuLds& ip = reinterpret_cast<IntraTuLds*>(smem + nwvC * sizeof(TuLds))[wv];
-        const RdoqRef rrC = rdoq_ref_at(smem + (size_t)nwvC * perWave + (size_t)wv * rqBytesC, cLog2);
+        RdoqRef rrC = rdoq_ref_at(smem + (size_t)nwvC * perWave + (size_t)wv * rqBytesC, cLog2);
+        rrC.est = s_est[1];
         const uint32_t listed = s_cmode[wv], mode = listed == 36 ? lumaDir : listed;
         for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[wv][b] = P.ctx[b];
         xa_wave_sync();
