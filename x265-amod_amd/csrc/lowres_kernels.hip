@@ -353,11 +353,12 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         if (!lastRow && (p.doSearch[0] || p.doSearch[1]))
         {
             const int need = cuX > 0 ? cuX - 1 : 0;
-            /* the spin reads the word with a relaxed load at agent scope -- an acquire in the loop invalidates the caches on every look, and with hundreds of
-             * estimates in one grid thousands of waiting rows did nothing else --, one acquire fence follows when the row may go on */
+            /* What crosses from one wavefront to another inside the launch is a handful of words per block -- the progress word and the neighbours' vectors --, and
+             * every one of them is stored and loaded by relaxed atomics at agent scope (write-through / past the caches).  So NO cache maintenance is needed: the
+             * acquire fence that stood here (invalidating the L2's lines of the planes for every block) and the release fence at the end of a block (writing the L2
+             * back) were what made a batch of many estimates ten times slower per block than one estimate alone (round 5: section 4.25 of DESIGN.md). */
             if (lane == 0) while (__hip_atomic_load(&p.progress[cuY + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > need) __builtin_amdgcn_s_sleep(8);
             xa_wave_sync();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
         const int cuXY = cuX + cuY * W;
         b.off = 8L * cuX + 8L * cuY * p.stride;
@@ -381,7 +382,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
             const int16_t* mv = p.mvs[i];
             /* written by other wavefronts during this launch: read past the caches */
             auto add = [&](int idx) {
-                const int v = __atomic_load_n(reinterpret_cast<const int*>(mv) + idx, __ATOMIC_RELAXED);
+                const int v = __hip_atomic_load(reinterpret_cast<const int*>(mv) + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 mcx[numc] = (int16_t)(v & 0xFFFF); mcy[numc] = (int16_t)(v >> 16); numc++;
             };
             if (cuX < W - 1) add(cuXY + 1);
@@ -408,7 +409,12 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
             fencCost = lr_motion_estimate(b, mnx, mny, mxx, mxy, mvpx, mvpy, p.merange, ox, oy);
             if (skipCost < 64 && skipCost < fencCost && p.bidir) { fencCost = skipCost; ox = 0; oy = 0; }
             mvx[i] = ox; mvy[i] = oy;
-            if (lane == 0) { p.mvs[i][2 * cuXY] = (int16_t)ox; p.mvs[i][2 * cuXY + 1] = (int16_t)oy; p.mvCosts[i][cuXY] = fencCost; }
+            if (lane == 0)
+            {
+                /* (the vector as ONE word, written through: the rows above and the next block of this row read it during the launch) */
+                __hip_atomic_store(reinterpret_cast<int*>(p.mvs[i]) + cuXY, (int)(((uint32_t)ox & 0xFFFFu) | ((uint32_t)oy << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p.mvCosts[i][cuXY] = fencCost;
+            }
             if (fencCost < bcost) { bcost = fencCost; listused = i + 1; }
         }
         if (p.bidir)
@@ -435,7 +441,7 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         {
             p.bcost[cuXY] = bcost;
             p.lowresCosts[cuXY] = (uint16_t)(min(bcost, 0x3FFF) | (listused << 14));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the vectors' stores have arrived before the progress word leaves: a wait, no cache write-back */
             __hip_atomic_store(&p.progress[cuY], cuX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
