@@ -1048,6 +1048,11 @@ typedef struct x265amd_lowres_cost_job
                                              * else d_ref0 (estimateCUCost: wfref0 for the search, fref0 for the bi-directional candidates).  [0] NULL: none */
 } x265amd_lowres_cost_job;
 int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265amd_lowres_cost_job* jobs, int n, intptr_t stride, int width_in_cu, int height_in_cu);
+/* The caller's sums over the blocks of finished estimates (estimateCUCost's tail and estimateFrameCost, slicetype.cpp:4220-4248, :4062-4067), made on the device so that only
+ * two numbers per estimate come back: sums[2 i] = the sum of jobs[i].d_bcost over the blocks that are not on the picture's edge (every block when the picture is two blocks or
+ * less wide or high), sums[2 i + 1] = how many of those blocks have the list field of d_lowres_costs (bits 14-15) zero -- the intra blocks.  Only d_bcost and d_lowres_costs
+ * of a job are looked at.  sums: HOST memory, 2 n values; returns when they are there. */
+int x265amd_lowres_cost_sums(void* stream, const x265amd_lowres_cost_job* jobs, int n, int width_in_cu, int height_in_cu, int64_t* sums);
 
 /* Weighted prediction, the measurements of the analysis (reference: LookaheadTLD::weightCostLuma, source/encoder/slicetype.cpp:826-858; weightCost's luma branch and mcLuma,
  * source/encoder/weightPrediction.cpp:58-90, :172-218): costs[i] = the sum over the 8x8 blocks of the lowres picture (width x height samples, width a multiple of 8; the last block
@@ -1059,6 +1064,14 @@ int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me, const x265
 typedef struct x265amd_weight_cand { int32_t present, w0, round, shift, offset; } x265amd_weight_cand;
 int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
                                 intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs);
+/* Many decisions' measurements as one launch (the lookahead's weightsAnalyse of every motion search of a batch, slicetype.cpp:860-990): job i = one picture pair with its two
+ * candidates (cands[0]: as a rule "no weighting", cands[1]: the guess); costs[2 i], costs[2 i + 1] = what x265amd_lowres_weight_costs returns for them.  costs: HOST memory. */
+typedef struct x265amd_weight_cost_job
+{
+    const x265amd_pixel* d_fenc; const x265amd_pixel* d_ref[4]; const int16_t* d_mvs; const int32_t* d_intra_cost;
+    x265amd_weight_cand cands[2];
+} x265amd_weight_cost_job;
+int x265amd_lowres_weight_costs_many(void* stream, const x265amd_weight_cost_job* jobs, int n, intptr_t stride, int width, int height, uint32_t* costs);
 /* weightAnalyse's chroma planes (weightPrediction.cpp:348-375 with mcChroma :93-159 and weightCost's 4:2:0 chroma branch :205-208): costs[i] = the sum over the 8x8 blocks of the
  * chroma plane (width x height: the plane clamped to whole 16x16 luma blocks) of SATD(source block, reference block weighted by candidate i); the reference block motion
  * compensated with the lookahead's field d_mvs (NULL: not) exactly as mcChroma does it.  d_fenc / d_ref: sample (0, 0) of the two pictures' SOURCE chroma planes. */

@@ -64,6 +64,39 @@ def test_hip_lowres_frame_cost_matches_reference_golden(k):
     assert int(got["sums"][0]) == int(want[0]) and int(got["sums"][2]) == int(want[2]), (got["sums"], want)
 
 
+@pytest.mark.gpu
+def test_hip_lowres_cost_sums_are_the_callers_sums():
+    """x265amd_lowres_cost_sums against the reference golden's own sums (estimateFrameCost's score before the B scaling, and its intra block count) and against the
+    caller's reduction written out in numpy, several estimates in one call, for a picture of two block rows as well"""
+    import ctypes as C
+    import torch
+    g = np.load(COST_GOLD)
+    L = T.load_hip(8)
+    JOB = np.dtype([("d_fenc", "<u8"), ("d_ref0", "<u8", 4), ("d_ref1", "<u8", 4), ("d_intra_cost", "<u8"), ("d_mvs0", "<u8"), ("d_mv_costs0", "<u8"), ("d_mvs1", "<u8"),
+                    ("d_mv_costs1", "<u8"), ("d_lowres_costs", "<u8"), ("d_bcost", "<u8"), ("do_search0", "<i4"), ("do_search1", "<i4"), ("rows_per_slice", "<i4"),
+                    ("num_slices", "<i4"), ("d_ref0w", "<u8", 4)])
+    for k in (0, 2, 3):
+        depth, seed, crop, p0, b, p1 = COST_CASES[k]
+        c = T.lowres_cost_case(depth, seed, crop)
+        lc = g["%d/lowres_costs" % k]
+        rng = np.random.default_rng(900 + k)
+        variants = [(lc, rng.integers(0, 1 << 14, lc.size).astype(np.int32)) for _ in range(3)]
+        variants.append((rng.integers(0, 1 << 16, lc.size).astype(np.uint16), rng.integers(0, 1 << 20, lc.size).astype(np.int32)))
+        for (wcu, hcu) in ((c["wcu"], c["hcu"]), (c["wcu"], 2)):
+            n = wcu * hcu
+            jobs = np.zeros(len(variants), JOB); keep = []
+            for i, (l, bc) in enumerate(variants):
+                dl, db = torch.from_numpy(l[:n].view(np.int16).copy()).cuda(), torch.from_numpy(bc[:n].copy()).cuda()
+                keep += [dl, db]
+                jobs[i]["d_lowres_costs"], jobs[i]["d_bcost"] = dl.data_ptr(), db.data_ptr()
+            sums = np.zeros(2 * len(variants), np.int64)
+            assert L.lib.x265amd_lowres_cost_sums(None, jobs.ctypes.data_as(C.c_void_p), len(variants), wcu, hcu, sums.ctypes.data_as(C.c_void_p)) == 0
+            for i, (l, bc) in enumerate(variants):
+                cc = dict(c, wcu=wcu, hcu=hcu)
+                score, est, intra_mbs, _ = T.lowres_cost_sums(cc, l[:n], bc[:n], False)
+                assert (int(sums[2 * i]), int(sums[2 * i + 1])) == (est, intra_mbs), (k, wcu, hcu, i)
+
+
 AQ_GOLD = os.path.join(T.GOLDEN_DIR, "aq_energy_golden.npz")
 AQ_CASES = [(8, 41, T.MC_W, T.MC_H, 16), (8, 42, T.MC_W - 8, T.MC_H - 24, 16), (8, 43, T.MC_W, T.MC_H, 8), (10, 44, T.MC_W - 40, T.MC_H, 16), (10, 45, T.MC_W, T.MC_H - 8, 8)]
 

@@ -162,11 +162,13 @@ struct x265amd_encoder
     ~x265amd_encoder()
     {
         for (auto& q : inflight) if (q->done.valid()) q->done.wait();
+        laFieldsFree();
         if (getenv("X265AMD_TIMING") && lookahead)
         {
             fprintf(stderr, "x265amd: input: %.1f ms in uploads; cpu of the picture threads %.1f ms, of the filter threads %.1f ms\n", uploadMs, cpuPictureNs.load() / 1e6, cpuFilterNs.load() / 1e6);
             fprintf(stderr, "x265amd: lookahead: %.1f ms in lowres planes + intra costs, %.1f ms in the slice-type decision (%llu estimates, %llu motion searches; %llu batches %.1f ms, %llu single estimates %.1f ms)\n", laInitMs, laDecideMs,
                     (unsigned long long)laJobs, (unsigned long long)laSearches, (unsigned long long)laBatches, laBatchMs, (unsigned long long)laSingles, laSingleMs);
+            fprintf(stderr, "x265amd: lookahead estimates by phase: set-up %.1f ms, launch call %.1f, read-back issued %.1f, waited for %.1f, host sums %.1f; %llu weight guesses measured\n", laPhaseMs[0], laPhaseMs[1], laPhaseMs[2], laPhaseMs[3], laPhaseMs[4], (unsigned long long)laWeightJobs);
         }
         if (me) x265amd_me_close(me);
         if (dSaoCount) (void)hipFree(dSaoCount);
@@ -196,16 +198,35 @@ struct x265amd_encoder
     hipStream_t laStream = nullptr;
     int lowresInit(Pic& pic);
     void pushMiniGop(int b);
-    int lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& scale, int& denom, int& offset);
+    struct LaWeight { int minscale = 0, mindenom = 0, curScale = 0, curOffset = 0; };
+    bool lookaheadWeightGuess(Pic& fenc, Pic& ref, LaWeight& g);
+    void lookaheadWeightDecide(const LaWeight& g, const uint32_t costs[2], bool& weighted, int& scale, int& denom, int& offset);
     int sliceWeights(Pic& pic);
     bool keepSources() const { return p.bEnableWeightedPred || p.bEnableWeightedBiPred; }
     int weightRows(struct WPlane& wpl, int r0, int r1);
     int frameCostP(Pic& b, Pic& ref, int dist);         /* CostEstimateGroup::singleCost(p0, p1 = b, b) */
     int frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1, int64_t& score);
     struct CostJob { Pic* fenc = nullptr; Pic* ref0 = nullptr; Pic* ref1 = nullptr; int d0 = 0, d1 = 0; bool spec = false; bool whole = false; bool search0 = false, search1 = false; void* dMvs = nullptr; void* dMvc = nullptr; void* dMvs1 = nullptr;
-                     void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; void* dW = nullptr; std::vector<int32_t> bc; std::vector<uint16_t> lc; };
+                     void* dMvc1 = nullptr; void* dLc = nullptr; void* dBc = nullptr; void* dW = nullptr; };
     int frameCostMany(std::vector<CostJob>& jobs);
-    double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0;
+    /* The motion fields' DEVICE copies, by the address of the host copy (Pic::lowMvs and its kin: swapped between vectors, never copied; filled by one place only, the
+     * read-back of a search in frameCostMany, which enters the search's own device buffers here -- whatever stood under that address before is replaced): an estimate
+     * that reads a field finds it on the device instead of uploading 2 x 130 KB of pageable memory (a 2160p first decision: 51 ms of them).  Bounded: beyond
+     * LA_FIELDS_MAX entries the least recently used quarter goes (a field that is gone is uploaded again). */
+    struct DevField { void* mv; void* mc; uint64_t used; };
+    std::map<const void*, DevField> laFields;
+    uint64_t laFieldClock = 0;
+    static const size_t LA_FIELDS_MAX = 2048;
+    /* the lookahead's device buffers -- fields and per-estimate cost arrays, all of one size (a 32-bit word per lowres block) -- come from chunks of 64 of them: a first
+     * decision of a few hundred estimates asks for a thousand buffers at once, and a cold general pool answered with a thousand hipMallocs (50 ms at 2160p) */
+    std::vector<void*> laFreeBufs, laChunks;
+    void* laBuf();
+    void laBufPut(void* p) { if (p) laFreeBufs.push_back(p); }
+    void laFieldPut(const void* key, void* mv, void* mc);
+    void laFieldsTrim();
+    void laFieldsFree();
+    double laPhaseMs[5] = { 0, 0, 0, 0, 0 };        /* frameCostMany: set-up, the launch call, issuing the read-back, waiting for it, the host sums */
+    double laInitMs = 0, laDecideMs = 0, laBatchMs = 0, laSingleMs = 0; uint64_t laJobs = 0, laSearches = 0, laBatches = 0, laSingles = 0, laWeightJobs = 0;
     int frameCost(std::vector<Pic*>& frames, int p0, int p1, int b, int64_t& score);       /* CostEstimateGroup::singleCost(p0, p1, b): P (p1 == b) or B estimate */
     int64_t planCost(std::vector<Pic*>& frames, const std::vector<uint8_t>& runs, int64_t limit, int& rc);
     void extendPlans(std::vector<Pic*>& frames, int length, std::vector<std::vector<uint8_t> >& plans, int& rc);
@@ -663,57 +684,52 @@ inline x265amd_weight_cand weightCand(int scale, int denom, int offset)
 /* LookaheadTLD::weightsAnalyse (slicetype.cpp:879-978) before a list-0 search of `fenc` against `ref`: the early exit when the two do not differ in mean or variance; else the
  * unweighted cost against one candidate (scale from the variances, offset from the means), a smaller denominator if the scale is even, and the 0.998 test.  weighted: the
  * reference's four planes are weighted for the search (scale / 2^denom, offset) */
-int x265amd_encoder::lookaheadWeights(Pic& fenc, Pic& ref, bool& weighted, int& scale, int& denom, int& offset)
+/* (in two halves, so that the measurements of every search of a batch go out as one launch: the guess -- false: the early exit, no weight --, then the decision from
+ * the two costs) */
+bool x265amd_encoder::lookaheadWeightGuess(Pic& fenc, Pic& ref, LaWeight& g)
 {
     static const float epsilon = 1.f / 128.f;
-    weighted = false;
     float guessScale, fencMean, refMean;
     if (fenc.wpSsd[0] && ref.wpSsd[0]) guessScale = sqrtf((float)fenc.wpSsd[0] / ref.wpSsd[0]);
     else guessScale = 1.0f;
     fencMean = (float)fenc.wpSum[0] / (lowH * lowW) / (1 << (X265AMD_DEPTH - 8));
     refMean = (float)ref.wpSum[0] / (lowH * lowW) / (1 << (X265AMD_DEPTH - 8));
-    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon) return X265AMD_OK;
-    int minoff = 0, minscale, mindenom;
-    unsigned int minscore = 0, origscore = 1;
-    int found = 0;
+    if (fabsf(refMean - fencMean) < 0.5f && fabsf(1.f - guessScale) < epsilon) return false;
     {
         /* WeightParam::setFromWeightAndOffset((int)(guessScale * 128 + 0.5f), 0, 7, true) (slice.h:304-316) */
         int w = (int)(guessScale * 128 + 0.5f), d = 7;
         while (d > 0 && w > 127) { d--; w >>= 1; }
         w = std::min(w, 127);
-        mindenom = d; minscale = w;
+        g.mindenom = d; g.minscale = w;
     }
-    int curScale = minscale;
-    int curOffset = (int)(fencMean - refMean * curScale / (1 << mindenom) + 0.5f);
-    if (curOffset < -128 || curOffset > 127)
+    g.curScale = g.minscale;
+    g.curOffset = (int)(fencMean - refMean * g.curScale / (1 << g.mindenom) + 0.5f);
+    if (g.curOffset < -128 || g.curOffset > 127)
     {
-        curOffset = std::max(-128, std::min(127, curOffset));
-        curScale = (int)((1 << mindenom) * (fencMean - curOffset) / refMean + 0.5f);
-        curScale = std::max(0, std::min(127, curScale));
+        g.curOffset = std::max(-128, std::min(127, g.curOffset));
+        g.curScale = (int)((1 << g.mindenom) * (fencMean - g.curOffset) / refMean + 0.5f);
+        g.curScale = std::max(0, std::min(127, g.curScale));
     }
-    x265amd_weight_cand cands[2];
-    memset(cands, 0, sizeof(cands));
-    cands[1] = weightCand(curScale, mindenom, curOffset);
-    uint32_t costs[2] = { 0, 0 };
-    const pixel* refPlanes[4];
-    for (int t = 0; t < 4; t++) refPlanes[t] = ref.dLowres + (size_t)t * lowPlaneElems + lowOrg;
-    const int rc = x265amd_lowres_weight_costs(laStream, fenc.dLowres + lowOrg, refPlanes, nullptr, fenc.dIntraCost, lowStride, lowW, lowH, cands, 2, costs);
-    if (rc != X265AMD_OK) return rc;
-    origscore = minscore = costs[0];
-    if (!minscore) return X265AMD_OK;
+    return true;
+}
+void x265amd_encoder::lookaheadWeightDecide(const LaWeight& g, const uint32_t costs[2], bool& weighted, int& scale, int& denom, int& offset)
+{
+    weighted = false;
+    int minoff = 0, minscale = g.minscale, mindenom = g.mindenom;
+    unsigned int minscore = costs[0], origscore = costs[0];
+    int found = 0;
+    if (!minscore) return;
     const unsigned int sc = costs[1];
-    if (sc < minscore) { minscore = sc; minscale = curScale; minoff = curOffset; found = 1; }
+    if (sc < minscore) { minscore = sc; minscale = g.curScale; minoff = g.curOffset; found = 1; }
     if (mindenom > 0 && !(minscale & 1))
     {
         const int idx = minscale ? __builtin_ctz((unsigned)minscale) : 32;
         const int shift = std::min(idx, mindenom);
         mindenom -= shift; minscale >>= shift;
     }
-    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return X265AMD_OK;
+    if (!found || (minscale == 1 << mindenom && minoff == 0) || (float)minscore / origscore > 0.998f) return;
     weighted = true; scale = minscale; denom = mindenom; offset = minoff;
-    return X265AMD_OK;
 }
-
 /* weightAnalyse (weightPrediction.cpp:222-540) for a P picture (list 0) or, with weighted bi-prediction, a B picture (both lists): the first reference of each list.  The chroma
  * denominator that fits both chroma scale guesses; per plane: the early exit, else the reference motion compensated with the lookahead's vectors of that distance (mcLuma on the
  * lowres planes, mcChroma on the SOURCE chroma planes) against every candidate scale (+-4 around the guess) and offset (+-2 around the mean's), each with the slice header's cost,
@@ -913,6 +929,45 @@ int x265amd_encoder::frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1
     return rc;
 }
 
+void* x265amd_encoder::laBuf()
+{
+    if (laFreeBufs.empty())
+    {
+        const size_t one = (((size_t)lowCuW * lowCuH * 4) + 255) & ~(size_t)255;
+        void* chunk = nullptr;
+        if (hipMalloc(&chunk, one * 64) != hipSuccess) return nullptr;
+        laChunks.push_back(chunk);
+        for (int i = 63; i >= 0; i--) laFreeBufs.push_back((char*)chunk + one * i);
+    }
+    void* p = laFreeBufs.back();
+    laFreeBufs.pop_back();
+    return p;
+}
+void x265amd_encoder::laFieldPut(const void* key, void* mv, void* mc)
+{
+    auto it = laFields.find(key);
+    if (it != laFields.end()) { laBufPut(it->second.mv); laBufPut(it->second.mc); it->second = DevField{ mv, mc, ++laFieldClock }; }
+    else laFields.emplace(key, DevField{ mv, mc, ++laFieldClock });
+}
+/* (called when nothing of the lookahead's is in flight: behind frameCostMany's wait) */
+void x265amd_encoder::laFieldsTrim()
+{
+    if (laFields.size() <= LA_FIELDS_MAX) return;
+    std::vector<uint64_t> ages;
+    for (auto& f : laFields) ages.push_back(f.second.used);
+    std::nth_element(ages.begin(), ages.begin() + ages.size() / 4, ages.end());
+    const uint64_t cut = ages[ages.size() / 4];
+    for (auto it = laFields.begin(); it != laFields.end();)
+        if (it->second.used < cut) { laBufPut(it->second.mv); laBufPut(it->second.mc); it = laFields.erase(it); } else ++it;
+}
+void x265amd_encoder::laFieldsFree()
+{
+    laFields.clear();
+    laFreeBufs.clear();
+    for (void* c : laChunks) (void)hipFree(c);
+    laChunks.clear();
+}
+
 /* Independent estimates side by side: every job on one of a handful of streams (the block loop of an estimate is a few dozen wavefronts chained row to row -- latency,
  * not throughput: a dozen of them overlap on the device), one wait for all, then the host sums.  Jobs of one call must not share a motion field they search or a cost
  * they fill (the callers' batches are by (picture, distance) pairs). */
@@ -925,7 +980,28 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
     struct Tm { x265amd_encoder* e; std::chrono::steady_clock::time_point t0; size_t n; ~Tm() { const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (n > 1) { e->laBatchMs += ms; e->laBatches++; } else { e->laSingleMs += ms; e->laSingles++; } } } tm_{ this, tb0, jobs.size() };
     std::vector<x265amd_lowres_cost_job> kj(jobs.size());
     size_t issued = 0;
-    for (size_t k = 0; k < jobs.size() && rc == X265AMD_OK; k++)
+    /* a field that exists is read where its device copy lies (laFields); one that has none (evicted) is uploaded once and entered */
+    auto shared = [&](const std::vector<int16_t>& mv, const std::vector<int32_t>& mc, void*& dMv, void*& dMc) -> bool {
+        auto it = laFields.find(mv.data());
+        if (it == laFields.end())
+        {
+            void* a = laBuf(); void* b = laBuf();
+            if (!a || !b) { laBufPut(a); laBufPut(b); return false; }
+            laFieldPut(mv.data(), a, b);
+            it = laFields.find(mv.data());
+            if (hipMemcpyAsync(a, mv.data(), ncu * 4, hipMemcpyHostToDevice, laStream) != hipSuccess || hipMemcpyAsync(b, mc.data(), ncu * 4, hipMemcpyHostToDevice, laStream) != hipSuccess) return false;
+        }
+        it->second.used = ++laFieldClock;
+        dMv = it->second.mv; dMc = it->second.mc;
+        return true;
+    };
+    auto tph = std::chrono::steady_clock::now();
+    auto phase = [&](int i) { const auto t = std::chrono::steady_clock::now(); laPhaseMs[i] += std::chrono::duration<double, std::milli>(t - tph).count(); tph = t; };
+    /* first what every estimate searches, and for the list-0 searches the lookahead's weight guess: their measurements (two candidates each) go out as ONE launch */
+    std::vector<LaWeight> lw(jobs.size());
+    std::vector<int> wAt(jobs.size(), -1);
+    std::vector<x265amd_weight_cost_job> wj;
+    for (size_t k = 0; k < jobs.size(); k++)
     {
         CostJob& j = jobs[k];
         Pic& fenc = *j.fenc;
@@ -939,17 +1015,34 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         /* (an estimate made ahead of its time reads and fills the fields made ahead of their time as well as the picture's own) */
         const bool have0 = !fenc.lowMvs[j.d0].empty() || (j.spec && !fenc.specMvs[j.d0].empty()), have1 = j.d1 > 0 && (!fenc.lowMvs1[j.d1].empty() || (j.spec && !fenc.specMvs1[j.d1].empty()));
         j.search0 = !have0; j.search1 = j.d1 > 0 && !have1;
-        bool weighted = false; int wScale = 0, wDenom = 0, wOffset = 0;
         static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");
-        if (p.bEnableWeightedPred && j.search0 && !(dbgWp && strchr(dbgWp, 'l')))
+        if (p.bEnableWeightedPred && j.search0 && !(dbgWp && strchr(dbgWp, 'l')) && lookaheadWeightGuess(fenc, *j.ref0, lw[k]))
         {
-            rc = lookaheadWeights(fenc, *j.ref0, weighted, wScale, wDenom, wOffset);
-            if (rc != X265AMD_OK) break;
+            x265amd_weight_cost_job w;
+            memset(&w, 0, sizeof(w));
+            w.d_fenc = fenc.dLowres + lowOrg; w.d_intra_cost = fenc.dIntraCost;
+            for (int t = 0; t < 4; t++) w.d_ref[t] = j.ref0->dLowres + (size_t)t * lowPlaneElems + lowOrg;
+            w.cands[1] = weightCand(lw[k].curScale, lw[k].mindenom, lw[k].curOffset);
+            wAt[k] = (int)wj.size();
+            wj.push_back(w);
         }
         laJobs++; laSearches += (j.search0 ? 1 : 0) + (j.search1 ? 1 : 0);
-        void** bufs[6] = { &j.dMvs, &j.dMvc, &j.dLc, &j.dBc, &j.dMvs1, &j.dMvc1 };
-        const size_t sizes[6] = { ncu * 4, ncu * 4, ncu * 2, ncu * 4, ncu * 4, ncu * 4 };
-        for (int b = 0; b < (j.d1 > 0 ? 6 : 4); b++) if (xa_scratch_alloc(bufs[b], sizes[b]) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "encoder: device allocation");
+    }
+    std::vector<uint32_t> wCosts(2 * wj.size() + 2);
+    laWeightJobs += wj.size();
+    if (!wj.empty()) rc = x265amd_lowres_weight_costs_many(laStream, wj.data(), (int)wj.size(), lowStride, lowW, lowH, wCosts.data());
+    for (size_t k = 0; k < jobs.size() && rc == X265AMD_OK; k++)
+    {
+        CostJob& j = jobs[k];
+        Pic& fenc = *j.fenc;
+        bool weighted = false; int wScale = 0, wDenom = 0, wOffset = 0;
+        if (wAt[k] >= 0) lookaheadWeightDecide(lw[k], &wCosts[2 * wAt[k]], weighted, wScale, wDenom, wOffset);
+        /* the estimate's own buffers: its costs, and the fields it searches (the fields it reads are the call's shared copies) */
+        void** bufs[6] = { &j.dLc, &j.dBc, &j.dMvs, &j.dMvc, &j.dMvs1, &j.dMvc1 };
+        const size_t sizes[6] = { ncu * 2, ncu * 4, ncu * 4, ncu * 4, ncu * 4, ncu * 4 };
+        const bool want[6] = { true, true, j.search0, j.search0, j.search1, j.search1 };
+        (void)sizes;
+        for (int b = 0; b < 6; b++) if (want[b] && !(*bufs[b] = laBuf())) rc = xa_fail(X265AMD_EHIP, "encoder: device allocation");
         issued = k + 1;
         if (rc != X265AMD_OK) break;
         x265amd_lowres_cost_job& q = kj[k];
@@ -957,7 +1050,6 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         q.d_fenc = fenc.dLowres + lowOrg;
         for (int t = 0; t < 4; t++) { q.d_ref0[t] = j.ref0->dLowres + (size_t)t * lowPlaneElems + lowOrg; q.d_ref1[t] = j.ref1 ? j.ref1->dLowres + (size_t)t * lowPlaneElems + lowOrg : nullptr; }
         q.d_intra_cost = fenc.dIntraCost;
-        q.d_mvs0 = (int16_t*)j.dMvs; q.d_mv_costs0 = (int32_t*)j.dMvc; q.d_mvs1 = (int16_t*)j.dMvs1; q.d_mv_costs1 = (int32_t*)j.dMvc1;
         q.d_lowres_costs = (uint16_t*)j.dLc; q.d_bcost = (int32_t*)j.dBc; q.do_search0 = j.search0; q.do_search1 = j.search1;
         if (!j.whole && laNumSlices > 1) { q.rows_per_slice = laRowsPerSlice; q.num_slices = laNumSlices; }
         if (weighted)
@@ -971,51 +1063,59 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         }
         bool ok = true;
         const bool own0 = !fenc.lowMvs[j.d0].empty(), own1 = j.d1 > 0 && !fenc.lowMvs1[j.d1].empty();
-        if (!j.search0) ok = hipMemcpyAsync(j.dMvs, (own0 ? fenc.lowMvs : fenc.specMvs)[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
-                             hipMemcpyAsync(j.dMvc, (own0 ? fenc.lowMvc : fenc.specMvc)[j.d0].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
-        if (ok && j.d1 > 0 && !j.search1) ok = hipMemcpyAsync(j.dMvs1, (own1 ? fenc.lowMvs1 : fenc.specMvs1)[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess &&
-                                               hipMemcpyAsync(j.dMvc1, (own1 ? fenc.lowMvc1 : fenc.specMvc1)[j.d1].data(), ncu * 4, hipMemcpyHostToDevice, laStream) == hipSuccess;
+        void* f0 = j.dMvs; void* c0 = j.dMvc; void* f1 = j.dMvs1; void* c1 = j.dMvc1;
+        if (!j.search0) ok = shared((own0 ? fenc.lowMvs : fenc.specMvs)[j.d0], (own0 ? fenc.lowMvc : fenc.specMvc)[j.d0], f0, c0);
+        if (ok && j.d1 > 0 && !j.search1) ok = shared((own1 ? fenc.lowMvs1 : fenc.specMvs1)[j.d1], (own1 ? fenc.lowMvc1 : fenc.specMvc1)[j.d1], f1, c1);
+        q.d_mvs0 = (int16_t*)f0; q.d_mv_costs0 = (int32_t*)c0; q.d_mvs1 = (int16_t*)f1; q.d_mv_costs1 = (int32_t*)c1;
         if (!ok) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost set-up");
     }
+    phase(0);
     /* one launch for all of them (blockIdx.y = the estimate): the device runs as many block rows side by side as it holds */
     if (rc == X265AMD_OK) rc = x265amd_lowres_frame_cost_batch(laStream, me, kj.data(), (int)jobs.size(), lowStride, lowCuW, lowCuH);
+    /* the sums over the blocks, on the device too: two numbers per estimate come back instead of its two cost arrays */
+    std::vector<int64_t> sums(2 * jobs.size());
+    if (rc == X265AMD_OK) rc = x265amd_lowres_cost_sums(laStream, kj.data(), (int)issued, lowCuW, lowCuH, sums.data());
+    phase(1);
     for (size_t k = 0; k < issued && rc == X265AMD_OK; k++)
     {
         CostJob& j = jobs[k];
         Pic& fenc = *j.fenc;
-        j.bc.resize(ncu); j.lc.resize(ncu);
-        bool ok = hipMemcpyAsync(j.bc.data(), j.dBc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(j.lc.data(), j.dLc, ncu * 2, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+        bool ok = true;
         if (ok && j.search0)
         {
             std::vector<int16_t>& mv = (j.spec ? fenc.specMvs : fenc.lowMvs)[j.d0]; std::vector<int32_t>& mc = (j.spec ? fenc.specMvc : fenc.lowMvc)[j.d0];
             mv.resize(ncu * 2); mc.resize(ncu);
             ok = hipMemcpyAsync(mv.data(), j.dMvs, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(mc.data(), j.dMvc, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+            if (ok) { laFieldPut(mv.data(), j.dMvs, j.dMvc); j.dMvs = j.dMvc = nullptr; }            /* the search's buffers ARE the field's device copy from now on */
         }
         if (ok && j.search1)
         {
             std::vector<int16_t>& mv = (j.spec ? fenc.specMvs1 : fenc.lowMvs1)[j.d1]; std::vector<int32_t>& mc = (j.spec ? fenc.specMvc1 : fenc.lowMvc1)[j.d1];
             mv.resize(ncu * 2); mc.resize(ncu);
             ok = hipMemcpyAsync(mv.data(), j.dMvs1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipMemcpyAsync(mc.data(), j.dMvc1, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess;
+            if (ok) { laFieldPut(mv.data(), j.dMvs1, j.dMvc1); j.dMvs1 = j.dMvc1 = nullptr; }
         }
         if (!ok) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
     }
+    phase(2);
     if (hipStreamSynchronize(laStream) != hipSuccess && rc == X265AMD_OK) rc = xa_fail(X265AMD_EHIP, "encoder: lowres frame cost");
+    phase(3);
+    struct Ph { decltype(phase)& f; ~Ph() { f(4); } } ph_{ phase };
+    laFieldsTrim();
     for (size_t k = 0; k < issued; k++)
     {
         CostJob& j = jobs[k];
-        void* bufs[7] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1, j.dW };
-        for (void* b : bufs) xa_scratch_free(b);
+        void* bufs[6] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
+        for (void* b : bufs) laBufPut(b);
+        xa_scratch_free(j.dW);
+        j.dMvs = j.dMvc = j.dLc = j.dBc = j.dMvs1 = j.dMvc1 = j.dW = nullptr;
         if (rc != X265AMD_OK)
         {
             if (j.search0) { (j.spec ? j.fenc->specMvs : j.fenc->lowMvs)[j.d0].clear(); (j.spec ? j.fenc->specMvc : j.fenc->lowMvc)[j.d0].clear(); }
             if (j.search1) { (j.spec ? j.fenc->specMvs1 : j.fenc->lowMvs1)[j.d1].clear(); (j.spec ? j.fenc->specMvc1 : j.fenc->lowMvc1)[j.d1].clear(); }
             continue;
         }
-        int64_t est = 0; int imb = 0;
-        const bool all = lowCuW <= 2 || lowCuH <= 2;
-        for (int y = 0; y < lowCuH; y++)
-            for (int x = 0; x < lowCuW; x++)
-                if (all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1)) { est += j.bc[(size_t)y * lowCuW + x]; imb += (j.lc[(size_t)y * lowCuW + x] >> 14) == 0; }
+        int64_t est = sums[2 * k]; const int imb = (int)sums[2 * k + 1];
         if (j.d1 > 0) est = est * 100 / (130 + 0);          /* param.bFrameBias: the default */
         if (j.spec) { j.fenc->specCost2[j.d0][j.d1] = est; if (j.d1 == 0) j.fenc->specIntraMbs[j.d0] = imb; continue; }
         /* a field made for good replaces whatever was made ahead of its time for the same pair, and the estimates that were built on that */

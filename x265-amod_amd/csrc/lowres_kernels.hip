@@ -492,6 +492,53 @@ extern "C" int x265amd_lowres_frame_cost_batch(void* stream, x265amd_me_ctx* me,
     return X265AMD_OK;
 }
 
+/* x265amd_lowres_cost_sums: a workgroup per estimate */
+struct LowresSumJob { const int32_t* bcost; const uint16_t* lc; };
+__global__ __launch_bounds__(256) void k_lowres_cost_sums(const LowresSumJob* jobs, int W, int H, long long* out)
+{
+    __shared__ long long s_est[4];
+    __shared__ int s_imb[4];
+    const LowresSumJob j = jobs[blockIdx.x];
+    const bool all = W <= 2 || H <= 2;
+    long long est = 0; int imb = 0;
+    for (int i = threadIdx.x; i < W * H; i += 256)
+    {
+        const int y = i / W, x = i - y * W;
+        if (all || (x > 0 && x < W - 1 && y > 0 && y < H - 1)) { est += j.bcost[i]; imb += (j.lc[i] >> 14) == 0; }
+    }
+    est = xa_wave_sum(est); imb = xa_wave_sum(imb);
+    if ((threadIdx.x & 63) == 0) { s_est[threadIdx.x >> 6] = est; s_imb[threadIdx.x >> 6] = imb; }
+    __syncthreads();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = s_est[0] + s_est[1] + s_est[2] + s_est[3]; out[2 * blockIdx.x + 1] = s_imb[0] + s_imb[1] + s_imb[2] + s_imb[3]; }
+}
+extern "C" int x265amd_lowres_cost_sums(void* stream, const x265amd_lowres_cost_job* jobs, int n, int width_in_cu, int height_in_cu, int64_t* sums)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!jobs || !sums || width_in_cu <= 0 || height_in_cu <= 0) return xa_fail(X265AMD_EINVAL, "x265amd_lowres_cost_sums: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<LowresSumJob> js((size_t)n);
+    for (int i = 0; i < n; i++)
+    {
+        if (!jobs[i].d_bcost || !jobs[i].d_lowres_costs) return xa_fail(X265AMD_EINVAL, "x265amd_lowres_cost_sums: bad job");
+        js[(size_t)i].bcost = jobs[i].d_bcost; js[(size_t)i].lc = jobs[i].d_lowres_costs;
+    }
+    void* dJobs = nullptr; void* dOut = nullptr;
+    if (xa_scratch_alloc(&dJobs, sizeof(LowresSumJob) * n) != hipSuccess || xa_scratch_alloc(&dOut, sizeof(long long) * 2 * n) != hipSuccess)
+    { xa_scratch_free(dJobs); xa_scratch_free(dOut); return xa_fail(X265AMD_EHIP, "x265amd_lowres_cost_sums: device allocation"); }
+    hipError_t e = hipMemcpyAsync(dJobs, js.data(), sizeof(LowresSumJob) * n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          /* (js is pageable and goes out of scope) */
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(k_lowres_cost_sums, dim3(n), dim3(256), 0, st, (const LowresSumJob*)dJobs, width_in_cu, height_in_cu, (long long*)dOut);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(sums, dOut, sizeof(long long) * 2 * n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    xa_scratch_free(dJobs); xa_scratch_free(dOut);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    return X265AMD_OK;
+}
+
 extern "C" int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref0[4],
                                          const x265amd_pixel* const d_ref1[4], intptr_t stride, int width_in_cu, int height_in_cu, int do_search0, int do_search1,
                                          const int32_t* d_intra_cost, int16_t* d_mvs0, int32_t* d_mv_costs0, int16_t* d_mvs1, int32_t* d_mv_costs1,
@@ -530,17 +577,16 @@ extern "C" int x265amd_lowres_frame_cost(void* stream, x265amd_me_ctx* me, const
  * weightPrediction.cpp:58-90: the vector clipped to the picture + 8 samples, Lowres::lowresMC) and optionally weighted (weight_pp_c, pixel.cpp:519-538).
  * blockIdx.x = the block, blockIdx.y = the candidate weight: every candidate of a decision in one launch (the reference tries them one after the other; a
  * candidate's sum does not depend on the others).  The sums are uint32 and wrap like the reference's. */
+enum { kWeightCostParts = 48 };
 struct WeightCostParams
 {
     const pixel* fenc; const pixel* ref[4]; long stride; int width, height, blocksX;
     const int16_t* mvs; const int32_t* intraCost; const x265amd_weight_cand* cands; uint32_t* costs;
     int chroma, lowCuW, lowCuH;     /* chroma != 0: weightCost's 4:2:0 chroma branch on full-resolution chroma planes with mcChroma (weightPrediction.cpp:93-159, :205-208) */
 };
-__global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
+XA_DEV void lowres_weight_cost_body(const WeightCostParams& p, pixel* fencT, pixel* refT)
 {
     /* a few dozen wavefronts per candidate, each walking its share of the blocks and leaving one partial sum: no flood of one-block workgroups, no atomics */
-    __shared__ pixel fencT[64];
-    __shared__ pixel refT[64];
     const int lane = threadIdx.x, lx = lane & 7, ly = lane >> 3;
     const x265amd_weight_cand w = p.cands[blockIdx.y];
     const int numBlocks = p.blocksX * ((p.height + 7) >> 3);
@@ -601,6 +647,23 @@ __global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
     }
     if (lane == 0) p.costs[blockIdx.y * gridDim.x + blockIdx.x] = sum;
 }
+__global__ __launch_bounds__(64) void k_lowres_weight_cost(WeightCostParams p)
+{
+    __shared__ pixel fencT[64];
+    __shared__ pixel refT[64];
+    lowres_weight_cost_body(p, fencT, refT);
+}
+/* many decisions' candidates as one launch: blockIdx.z = the decision (its own pictures, candidates and sums) */
+__global__ __launch_bounds__(64) void k_lowres_weight_cost_many(const WeightCostParams* jobs)
+{
+    __shared__ pixel fencT[64];
+    __shared__ pixel refT[64];
+    __shared__ WeightCostParams sp;
+    static_assert(sizeof(WeightCostParams) % 8 == 0, "copied in 64-bit words");
+    for (int i = threadIdx.x; i < (int)(sizeof(WeightCostParams) / 8); i += 64) reinterpret_cast<uint64_t*>(&sp)[i] = reinterpret_cast<const uint64_t*>(jobs + blockIdx.z)[i];
+    __syncthreads();
+    lowres_weight_cost_body(sp, fencT, refT);
+}
 /* debugging aid (X265AMD_WP_FLOOD=<mode>,<workgroups>): the dispatch pattern of this kernel's first form -- thousands of one-wave workgroups, mode 1: each ending in an atomicAdd on
  * one word, mode 2: each reading a little memory, mode 0: nothing at all -- beside whatever else runs; DESIGN.md section 8 (the intra chain's open sensitivity) */
 __global__ __launch_bounds__(64) void k_flood(uint32_t* word, int mode, const uint32_t* src)
@@ -612,7 +675,6 @@ __global__ __launch_bounds__(64) void k_flood(uint32_t* word, int mode, const ui
     v = xa_wave_sum(v);
     if (mode == 1 && threadIdx.x == 0) atomicAdd(word + (blockIdx.y & 63), v);
 }
-enum { kWeightCostParts = 48 };
 extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_fenc, const x265amd_pixel* const d_ref[4], const int16_t* d_mvs, const int32_t* d_intra_cost,
                                            intptr_t stride, int width, int height, const x265amd_weight_cand* cands, int n, uint32_t* costs)
 {
@@ -646,6 +708,46 @@ extern "C" int x265amd_lowres_weight_costs(void* stream, const x265amd_pixel* d_
     if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
     const uint32_t* part = (const uint32_t*)mOut;
     for (int i = 0; i < n; i++) { uint32_t t = 0; for (int k = 0; k < kWeightCostParts; k++) t += part[i * kWeightCostParts + k]; costs[i] = t; }
+    return X265AMD_OK;
+}
+extern "C" int x265amd_lowres_weight_costs_many(void* stream, const x265amd_weight_cost_job* jobs, int n, intptr_t stride, int width, int height, uint32_t* costs)
+{
+    if (n <= 0) return X265AMD_OK;
+    if (!jobs || !costs || n > 65535 || width <= 0 || height <= 0 || (width & 7)) return xa_fail(X265AMD_EINVAL, "x265amd_lowres_weight_costs_many: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytesP = sizeof(WeightCostParams) * n, bytesC = sizeof(x265amd_weight_cand) * 2 * n, bytesO = sizeof(uint32_t) * 2 * kWeightCostParts * n;
+    void* dev = nullptr;
+    if (xa_scratch_alloc(&dev, bytesP + bytesC + bytesO) != hipSuccess) return xa_fail(X265AMD_EHIP, "x265amd_lowres_weight_costs_many: device allocation");
+    std::vector<char> host(bytesP + bytesC);
+    WeightCostParams* ps = reinterpret_cast<WeightCostParams*>(host.data());
+    x265amd_weight_cand* cs = reinterpret_cast<x265amd_weight_cand*>(host.data() + bytesP);
+    for (int i = 0; i < n; i++)
+    {
+        const x265amd_weight_cost_job& j = jobs[i];
+        if (!j.d_fenc || !j.d_ref[0] || (j.d_mvs && (!j.d_ref[1] || !j.d_ref[2] || !j.d_ref[3]))) { xa_scratch_free(dev); return xa_fail(X265AMD_EINVAL, "x265amd_lowres_weight_costs_many: bad job"); }
+        WeightCostParams& p = ps[i];
+        memset(&p, 0, sizeof(p));
+        p.fenc = (const pixel*)j.d_fenc;
+        for (int k = 0; k < 4; k++) p.ref[k] = (const pixel*)j.d_ref[k];
+        p.stride = (long)stride; p.width = width; p.height = height; p.blocksX = width >> 3;
+        p.mvs = j.d_mvs; p.intraCost = j.d_intra_cost;
+        p.cands = reinterpret_cast<const x265amd_weight_cand*>((char*)dev + bytesP) + 2 * i;
+        p.costs = reinterpret_cast<uint32_t*>((char*)dev + bytesP + bytesC) + 2 * kWeightCostParts * i;
+        cs[2 * i] = j.cands[0]; cs[2 * i + 1] = j.cands[1];
+    }
+    std::vector<uint32_t> part((size_t)2 * kWeightCostParts * n);
+    hipError_t e = hipMemcpyAsync(dev, host.data(), host.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(k_lowres_weight_cost_many, dim3(kWeightCostParts, 2, n), dim3(64), 0, st, (const WeightCostParams*)dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(part.data(), (char*)dev + bytesP + bytesC, bytesO, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    xa_scratch_free(dev);
+    if (e != hipSuccess) return xa_fail(X265AMD_EHIP, hipGetErrorString(e));
+    for (int i = 0; i < 2 * n; i++) { uint32_t t = 0; for (int k = 0; k < kWeightCostParts; k++) t += part[(size_t)i * kWeightCostParts + k]; costs[i] = t; }
     return X265AMD_OK;
 }
 /* the chroma planes' form (weightAnalyse's planes 1 and 2, weightPrediction.cpp:348-375): d_fenc / d_ref = sample (0, 0) of the current and the reference picture's SOURCE chroma
