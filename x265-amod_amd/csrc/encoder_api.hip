@@ -2391,7 +2391,12 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     const bool byCols = !colsOff && p.bEnableWavefront && (p.bEnableLoopFilter || p.bEnableSAO) && ctuH > 1 && ctuW > 1;
     std::thread filters([&, byCols] { xa_thread_device(); filterRc = byCols ? filterRowsCols(pic, fc.si, fc.info, sparams, saoFlags) : filterRows(pic, fc.si, fc.info, sparams, saoFlags); if (filterRc) pic.fail();
                                       cpuFilterNs += thread_cpu_ns(); });
-    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, pic.codingOrder + 1, gateCtuReach };
+    /* the rows' priority among the row tasks of all pictures in flight: the picture's place in coding order -- an I picture some places earlier (X265AMD_I_BOOST): its
+     * chain of 8x8 CUs is the longest thing in flight, nothing it needs comes from another picture, and the pictures behind the scene cut wait for it */
+    static const uint64_t iBoost = getenv("X265AMD_I_BOOST") ? (uint64_t)atoi(getenv("X265AMD_I_BOOST")) : 0;
+    const bool isI = pic.type == TYPE_IDR || pic.type == TYPE_I;
+    const uint64_t rowOrder = isI ? (pic.codingOrder + 1 > iBoost ? pic.codingOrder + 1 - iBoost : 1) : pic.codingOrder + 1;
+    const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, rowOrder, gateCtuReach };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
                                sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);
@@ -2465,6 +2470,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     auto start = [e, timing](const PicP& pic) {
         std::shared_future<int> prev = e->lastTask;
         pic->started = true;
+        if (timing) fprintf(stderr, "x265amd: poc %d handed to a frame task at %.1f ms (%d running)\n", pic->poc, Pic::pubClockMs(), e->running);
         pic->done = std::async(std::launch::async, [e, pic, prev, timing]() {
             xa_thread_device();
             const auto t0 = std::chrono::steady_clock::now();
@@ -2497,7 +2503,12 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     static const bool earlyP = !(getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 0);
     static const bool earlyBref = getenv("X265AMD_EARLY_BREF") && atoi(getenv("X265AMD_EARLY_BREF")) != 0;      /* a referenced B picture is a link of the same chain */
     static const int earlyPMax = getenv("X265AMD_EARLY_P_MAX") ? atoi(getenv("X265AMD_EARLY_P_MAX")) : 6;
+    /* (measured, profiles/r05_early_b_sweep.txt: 2160p clips 15-22 % shorter with 12, 8-bit, Main 10 and --preset slow alike; the 1080p clips unchanged or -- the
+     * sixty-frame clip with its two scene cuts -- 15 % longer: there an I picture behind a scene cut shares the device with a dozen pictures more.  So: by size) */
+    const int earlyBMax = getenv("X265AMD_EARLY_B_MAX") ? atoi(getenv("X265AMD_EARLY_B_MAX")) : (e->ctuH > 24 ? 12 : 0);
     auto launch = [&]() {
+    const bool headLong = !e->inflight.empty() && (e->inflight.front()->type == TYPE_IDR || e->inflight.front()->type == TYPE_I) && e->inflight.front()->started &&
+                          e->inflight.front()->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready;
     for (auto& q : e->inflight)
     {
         if (q->started) continue;
@@ -2509,6 +2520,12 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
          * picture held back until the B pictures in front of it have been collected starts with nothing to trail and takes its full latency, so it starts when the
          * lookahead hands it over, too (every picture it references is in front of it in coding order and therefore started; X265AMD_EARLY_P=0: in turn). */
         else if (earlyP && (q->type == TYPE_P || (earlyBref && q->type == TYPE_BREF)) && e->running <= e->frameThreads + earlyPMax) start(q);
+        /* The B pictures, too (round 5), while an I picture that still runs holds the head of the coding order: `running` counts every picture that trails it and is not
+         * collected yet (collection is in coding order), and the B pictures of the mini-GOPs whose P pictures ran already waited for the I picture's END although their
+         * references were rows ahead of them -- at 2160p a third of a twenty-frame clip, at --preset slow more.  How many pictures run side by side changes nothing in
+         * what they code (the vertical reach of the vectors follows from the parameter frameNumThreads, not from this count): up to X265AMD_EARLY_B_MAX more than the
+         * parameter (0: in turn).  Only then, and only for large pictures (see earlyBMax above). */
+        else if (earlyBMax > 0 && headLong && e->running <= e->frameThreads + earlyBMax) start(q);
     }
     };
     static const bool holdUntilFlush = getenv("X265AMD_HOLD_UNTIL_FLUSH") != nullptr;      /* an experiment: no picture starts before the caller flushes (what the clip costs when every decision is made beforehand) */
