@@ -402,8 +402,8 @@ def main():
             "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + mini-GOPs of up to %d B frames chosen by the lookahead's trellis, --b-adapt 2), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
                                    "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
-                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20), the B-frame trellis (--b-adapt 2), the B pyramid, open GOPs, the lookahead's slices (--lookahead-slices 8) and weighted prediction's analysis (--weightp: no weights chosen on these clips; "
-                                   "coding with weights is not built) as the preset has them (AQ / cutree are off in CQP by the reference's own rules): the reference runs plain --preset medium --qp 30" % (W, H, K, BFRAMES, REFS, QP),
+                                   "scene-cut detection (--scenecut 40, --rc-lookahead 20), the B-frame trellis (--b-adapt 2), the B pyramid, open GOPs, the lookahead's slices (--lookahead-slices 8) and weighted prediction (--weightp: the analysis runs, no weights are chosen on these clips; "
+                                   "clips with fades are coded with weights in tests/test_encoder_api.py) as the preset has them (AQ / cutree are off in CQP by the reference's own rules): the reference runs plain --preset medium --qp 30" % (W, H, K, BFRAMES, REFS, QP),
                        "frames_per_step_per_gpu": 1, "parallelism": ("picture k in coding order on GPU k mod %d, CTU rows broadcast over RCCL" % world if by_frames else "closed GOP per GPU x%d" % world) if world > 1 else "one encoder object",
                        "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},
             "bit_exact_vs_reference_encoder": same,
