@@ -2293,6 +2293,14 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
             {
                 /* a row of an I picture that started while every queue was taken (the picture behind a scene cut starts beside the pictures in front of it) asks again:
                  * without its second to fourth queue its CTUs take twice as long */
+                /* a row of a P picture likewise: the rows that started while an I picture held the queues (in lockstep behind it) are the ones still running when it has
+                 * ended -- the tail of the clip, where every link is a last-column CTU searched CU by CU -- and the searches ahead of the merge checks need the second and third queue */
+                static const bool auxRetry = !(getenv("X265AMD_AUX_RETRY") && atoi(getenv("X265AMD_AUX_RETRY")) == 0);
+                if (auxRetry && f.pSlice && st && !own && !aux2)
+                {
+                    if (!aux) { aux = xa_queue_try_acquire_spare(auxSpare); if (aux) xa_queue_set_aux(st, aux); }
+                    if (aux && !aux2) { aux2 = xa_queue_try_acquire_spare(auxSpare); if (aux2) xa_queue_set_aux(aux, aux2); }
+                }
                 if (f.intraOnly && st && !own && !helper3)
                 {
                     if (!helper) { helper = xa_queue_try_acquire(); if (helper) xa_queue_set_helper(st, helper); }
