@@ -97,6 +97,64 @@ def test_hip_lowres_cost_sums_are_the_callers_sums():
                 assert (int(sums[2 * i]), int(sums[2 * i + 1])) == (est, intra_mbs), (k, wcu, hcu, i)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [8, 10])
+def test_hip_lowres_weight_costs_one_and_many(depth):
+    """x265amd_lowres_weight_costs and its many-decisions form against the oracle's pieces in the reference's order (weightCostLuma, slicetype.cpp:826-858): the reference plane
+    weighted by weight_pp_c, per 8x8 block min(satd_8x8(source, weighted reference), intra cost), uint32 sum -- unweighted, weighted, with and without the intra costs"""
+    import ctypes as C
+    import torch
+    L, O = T.load_hip(depth), T.load_oracle(depth)
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    rng = np.random.default_rng(7700 + depth)
+    W, H, stride = 96, 56, 128
+    CAND = np.dtype([("present", "<i4"), ("w0", "<i4"), ("round", "<i4"), ("shift", "<i4"), ("offset", "<i4")])
+    JOB = np.dtype([("d_fenc", "<u8"), ("d_ref", "<u8", 4), ("d_mvs", "<u8"), ("d_intra_cost", "<u8"), ("cands", CAND, 2)])
+    assert JOB.itemsize == 96
+
+    def cand(scale, denom, off):
+        corr = 14 - depth
+        return (1, scale, (1 << (denom - 1) if denom else 0) << corr, denom + corr, off << (depth - 8))
+
+    pairs, keep, want = [], [], []
+    for k in range(5):
+        base = np.clip(np.kron(rng.integers(0, pmax + 1, (H // 8 + 1, stride // 8)), np.ones((8, 8), np.int64)) + rng.integers(-20, 21, (H + 8, stride)) * (1 << (depth - 8)), 0, pmax)
+        ref = base.astype(dt)
+        fenc = np.clip(base * (0.6 + 0.1 * k) + 5 * k + rng.integers(-6, 7, base.shape), 0, pmax).astype(dt)
+        intra = rng.integers(0, 3000, (H // 8) * (W // 8)).astype(np.int32) if k & 1 else None
+        c2 = [(0, 0, 0, 0, 0), cand(int(rng.integers(30, 127)), int(rng.integers(0, 8)), int(rng.integers(-20, 21)))]
+        exp = []
+        for c in c2:
+            wref = ref.copy()
+            if c[0]:
+                O.lib.orc_weight_pp(T._ptr(ref), T._ptr(wref), C.c_int64(stride), stride, H + 8, c[1], c[2], c[3], c[4])
+            tot = 0
+            for by in range(H // 8):
+                for bx in range(W // 8):
+                    v = O.call("satd", 1, wref[8 * by:8 * by + 8, 8 * bx:8 * bx + 8].copy(), 8, fenc[8 * by:8 * by + 8, 8 * bx:8 * bx + 8].copy(), 8)
+                    tot += min(v, int(intra[by * (W // 8) + bx])) if intra is not None else v
+            exp.append(tot & 0xFFFFFFFF)
+        d_f, d_r = torch.from_numpy(fenc.view(np.uint8).copy()).cuda(), torch.from_numpy(ref.view(np.uint8).copy()).cuda()
+        d_i = torch.from_numpy(intra).cuda() if intra is not None else None
+        keep += [d_f, d_r, d_i]
+        pairs.append((d_f, d_r, d_i, c2)); want.append(exp)
+        # one decision
+        cands = np.array(c2, CAND); costs = np.zeros(2, np.uint32)
+        refs = (C.c_void_p * 4)(d_r.data_ptr(), None, None, None)
+        assert L.lib.x265amd_lowres_weight_costs(None, C.c_void_p(d_f.data_ptr()), refs, None, C.c_void_p(d_i.data_ptr()) if d_i is not None else None, C.c_int64(stride), W, H,
+                                                 cands.ctypes.data_as(C.c_void_p), 2, costs.ctypes.data_as(C.c_void_p)) == 0, L.lib.x265amd_last_error()
+        assert [int(v) for v in costs] == exp, (k, costs, exp)
+    # the five decisions at once
+    jobs = np.zeros(len(pairs), JOB)
+    for i, (d_f, d_r, d_i, c2) in enumerate(pairs):
+        jobs[i]["d_fenc"], jobs[i]["d_ref"][0], jobs[i]["d_intra_cost"] = d_f.data_ptr(), d_r.data_ptr(), d_i.data_ptr() if d_i is not None else 0
+        jobs[i]["cands"] = np.array(c2, CAND)
+    costs = np.zeros(2 * len(pairs), np.uint32)
+    assert L.lib.x265amd_lowres_weight_costs_many(None, jobs.ctypes.data_as(C.c_void_p), len(pairs), C.c_int64(stride), W, H, costs.ctypes.data_as(C.c_void_p)) == 0, L.lib.x265amd_last_error()
+    assert [int(v) for v in costs] == [v for e in want for v in e]
+
+
 AQ_GOLD = os.path.join(T.GOLDEN_DIR, "aq_energy_golden.npz")
 AQ_CASES = [(8, 41, T.MC_W, T.MC_H, 16), (8, 42, T.MC_W - 8, T.MC_H - 24, 16), (8, 43, T.MC_W, T.MC_H, 8), (10, 44, T.MC_W - 40, T.MC_H, 16), (10, 45, T.MC_W, T.MC_H - 8, 8)]
 
