@@ -1,6 +1,6 @@
 """bench.py's `--shard frames` leg (SURVEY.md section 8e as written: picture k in coding order on rank k mod N, finished CTU rows published to the other ranks by
 x265-amod_amd/frame_rows.py) run for real: TWO PROCESSES, real encoder objects, real torch.distributed -- on the ONE GPU of the test box, so over the gloo backend (the rows
-are staged through the host: RCCL refuses two ranks on one device) with both ranks on cuda:0 and sixty-four resident workgroups each (a quarter of the compute units per process: room for both processes' lookahead and filter kernels beside them).  The owners' NAL units put back in
+are staged through the host: RCCL refuses two ranks on one device) with both ranks on cuda:0 and twenty-four resident workgroups each.  (With sixty-four each -- half of the device held by two processes' resident kernels -- four runs in ten stood still: one process's ordinary launches, the in-loop filters', were not scheduled for tens of seconds; with twenty-four, and with none, twelve runs of twelve pass (dbg/shard_dbg.sh).  One process per GPU, the real arrangement, has no second resident kernel beside it.)  The owners' NAL units put back in
 coding order must be the single object's stream of the same clip.  The NCCL transport itself needs two GPUs and is not run here; the schedule of collectives is the same."""
 import json
 import os
@@ -23,7 +23,7 @@ def test_bench_shard_frames_two_processes_one_gpu(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "stream")
-    env = dict(os.environ, X265AMD_QUEUES="64", X265AMD_BENCH_STREAM_OUT=out, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, X265AMD_QUEUES="24", X265AMD_BENCH_STREAM_OUT=out, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", str(FRAMES), "--warmup", "0", "--shard", "frames", "--backend", "gloo", "--one-gpu",
            "--no-kernel-workload", "--no-cpu-baseline"]

@@ -2123,6 +2123,10 @@ static hipError_t streamWaitPolite(hipStream_t st, hipEvent_t ev)
         if (e != hipErrorNotReady) return e;
         if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spinUs)) { for (int k = 0; k < 16; k++) __builtin_ia32_pause(); continue; }
         struct timespec ts = { 0, 20000 }; nanosleep(&ts, nullptr);
+        /* a filter stream that stands for seconds: say so once (the kernels behind the event are a few microseconds each) */
+        static std::atomic<int> said{ 0 };
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3) && said.fetch_add(1) < 4)
+            fprintf(stderr, "x265amd: a filter stream has not reached its event for 3 s (stream %p, hipStreamQuery says %s)\n", (void*)st, hipGetErrorName(hipStreamQuery(st)));
     }
 }
 
@@ -2480,7 +2484,8 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
                  * no reference: the row pump does not send it) */
                 if (pic->type == TYPE_B) { xa_scratch_free(pic->dSrc); pic->dSrc = nullptr; return (int)X265AMD_OK; }
                 std::unique_lock<std::mutex> lk(pic->mu);
-                const bool ok = pic->cv.wait_for(lk, std::chrono::seconds(300), [&] { return pic->importedRows >= e->ctuH || pic->failed.load(); });
+                static const int importWaitS = getenv("X265AMD_IMPORT_WAIT_S") ? atoi(getenv("X265AMD_IMPORT_WAIT_S")) : 300;       /* (debugging a stalled pump: a short wait shows where it stands) */
+                const bool ok = pic->cv.wait_for(lk, std::chrono::seconds(importWaitS), [&] { return pic->importedRows >= e->ctuH || pic->failed.load(); });
                 if (!ok || pic->failed.load()) { lk.unlock(); pic->fail(); return xa_fail(X265AMD_EHIP, "encoder: a picture coded elsewhere did not arrive"); }
                 lk.unlock();
                 xa_scratch_free(pic->dSrc); pic->dSrc = nullptr;
