@@ -538,10 +538,16 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
             clOut[pl * 16 + i] = S4.clev[sw][pl][i];
         }
     }
-    else if (cLog2 == 2 && !rdoq)
+    else if (cLog2 == 2)
     {
-        /* 4x4 chroma blocks (an 8x8 CU): the sixteen-lane chains of intra_nxn4_dev.h, a group per mode -- the dynamic LDS is free, the luma chains are done */
+        /* 4x4 chroma blocks (an 8x8 CU): the sixteen-lane chains of intra_nxn4_dev.h, a group per mode -- the dynamic LDS is free, the luma chains are done.  With RDOQ
+         * (round 5) the groups quantise through wave_rdo_quant's sixteen-lane form: the chroma table of this command and eight group areas behind the header */
         Nxn4Lds& S4 = *reinterpret_cast<Nxn4Lds*>(smem);
+        if (rdoq)
+        {
+            for (int i = tid; i < 184; i += nthr) S4.est[1][i] = s_est[1][i];
+            if (tid == 0) S4.rq = reinterpret_cast<Rq4Area*>(smem + ((sizeof(Nxn4Lds) + 15) & ~(size_t)15));
+        }
         nxn4_fill_tabs(S4.tb, tid);
         if (tid < 128) S4.enBits[tid] = s_enBits[tid];
         if (tid < 64) S4.enLps[tid] = s_enLps[tid];
