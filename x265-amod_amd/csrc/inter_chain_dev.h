@@ -747,6 +747,7 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
                 }
             }
             __syncthreads();
+            XA_CHAIN_T(3);          /* (the 64x64 CU's "does anything quantise to a level" pass and its measurement: transform units' time, not the placing behind it) */
         }
         else
         {
