@@ -16,9 +16,18 @@ if Wm: bench.encode(T, L, bench.bench_clip(0, Wm, depth=depth, cfg_id=cfg_id), 0
 frames = bench.bench_clip(0, N, depth=depth, cfg_id=cfg_id)
 bench.queue_stats(L, True)
 sys.stderr.write("---- timed encode ----\n")
+def _cpustat():
+    try:
+        t = open('/sys/fs/cgroup/cpu.stat').read().split(); return {t[i]: int(t[i + 1]) for i in range(0, len(t) - 1, 2)}
+    except OSError:
+        return {}
+s0 = _cpustat()
 c0 = os.times()
 stream, dt = bench.encode(T, L, frames, 0, 0, sync, cfg=cfg)
 c1 = os.times()
+s1 = _cpustat()
+if s0 and os.environ.get('X265AMD_TIMING'):
+    sys.stderr.write('cgroup during the timed encode: %d periods, %d of them throttled, %.1f ms of thread time held back\n' % (s1['nr_periods'] - s0['nr_periods'], s1['nr_throttled'] - s0['nr_throttled'], (s1['throttled_usec'] - s0['throttled_usec']) / 1e3))
 sys.stderr.write("process cpu during the timed encode: %.2f s user + %.2f s system = %.1f cores on average\n" % (c1[0] - c0[0], c1[1] - c0[1], (c1[0] - c0[0] + c1[1] - c0[1]) / dt))
 print("frames", N, "seconds %.3f" % dt, "fps %.2f" % (N / dt), "bytes", len(stream), hashlib.md5(stream).hexdigest())
 if os.environ.get("X265AMD_QUEUE_PROF"):
