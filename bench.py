@@ -302,6 +302,7 @@ def main():
                     "the host (the one-GPU test of the --shard frames leg: RCCL refuses two ranks on one device)")
     ap.add_argument("--one-gpu", action="store_true", help="every rank uses cuda:0 (tests/test_encoder_api.py: two processes, one GPU, gloo); set X265AMD_QUEUES so that the ranks' resident workgroups fit side by side")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the 3840x2160 --preset slow and Main 10 encodes that the 1080p single-GPU run reports beside the bench line")
+    ap.add_argument("--no-8k", action="store_true", help="skip the three 7680x4320 --preset veryslow --rd 6 frames (BASELINE configs[4]) among the extra configurations: they add about two minutes")
     ap.add_argument("--no-scene-clip", action="store_true", help="skip the 60-frame clip with both re-seeds inside that the 1080p single-GPU run reports beside the bench line (`scene_change_clip`)")
     args = ap.parse_args()
 
@@ -449,23 +450,30 @@ def main():
             W, H = 1920, 1080
     # ---- BASELINE.json configs[2] and configs[3] at their stated size: 3840x2160 --preset slow (8-bit) and 3840x2160 Main 10 --preset medium, stream compared in the run ----
     if rank == 0 and world == 1 and args.res == "1080p" and not args.no_extra_configs and not args.no_cpu_baseline:
-        for key, depth, cfg_id, tools, preset in (("also_2160p_slow", 8, 3, T.SLOW_TOOLS, "slow"), ("also_2160p_main10", 10, 4, {}, "medium")):
+        # (configs[4], 7680x4320 10-bit --preset veryslow --rd 6, rides along since round 5's end with three frames -- I, P and a B picture: it goes CU by CU through the host's path,
+        #  what the line says is where that stands against the reference, not a figure anybody has worked on)
+        extra = (("also_2160p_slow", 8, 3, T.SLOW_TOOLS, ["--preset", "slow"], (3840, 2160), 12, 2, 2),
+                 ("also_2160p_main10", 10, 4, {}, ["--preset", "medium"], (3840, 2160), 12, 2, 3),
+                 ("also_4320p_veryslow_rd6", 10, 5, dict(T.VERYSLOW_TOOLS, **T.VERYSLOW_GOP), ["--preset", "veryslow", "--rd", "6"], (7680, 4320), 3, 1, 4))
+        for key, depth, cfg_id, tools, presetCli, size, kmax, kwarm, cfgIndex in extra:
+            if key == "also_4320p_veryslow_rd6" and args.no_8k:
+                continue
             try:
-                W, H = 3840, 2160
-                Kx = min(K, 12)
+                W, H = size
+                Kx = min(K, kmax)
                 Lx = T.load_hip(depth)
                 cfgx = dict(ENC_CFG, frameNumThreads=6, **tools)
                 framesx = bench_clip(0, Kx, depth=depth, cfg_id=cfg_id)
-                encode(T, Lx, bench_clip(0, 2, depth=depth, cfg_id=cfg_id), 0, 0, sync, timed=False, cfg=cfgx)
+                encode(T, Lx, bench_clip(0, kwarm, depth=depth, cfg_id=cfg_id), 0, 0, sync, timed=False, cfg=cfgx)
                 streamx, dtx = encode(T, Lx, framesx, 0, 0, sync, cfg=cfgx)
-                clix = ["--preset", preset, "--qp", str(QP), "--no-info"]
+                clix = presetCli + ["--qp", str(QP), "--no-info"]
                 refx = reference_encode(framesx, cli=clix, depth=depth, runs=("default", "pools16"))
                 line[key] = {"value": Kx / dtx, "unit": "frames/s", "frames": Kx, "stream_md5": hashlib.md5(streamx).hexdigest(),
                              "bit_exact_vs_reference_encoder": None if refx is None else bool(refx["default"]["stream"] == streamx),
                              "cpu_baseline": None if refx is None else {"value": Kx / refx["default"]["seconds"], "cores": refx["cores"], "kind": "reference", "says": refx["default"]["says"],
                                                                         "pools16": Kx / refx["pools16"]["seconds"]},
                              "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(clix),
-                             "note": "BASELINE.json configs[%d] at its stated size (SURVEY 8d's clip, cfg_id %d), %d frames, the preset in CQP as it comes" % (2 if depth == 8 else 3, cfg_id, Kx)}
+                             "note": "BASELINE.json configs[%d] at its stated size (SURVEY 8d's clip, cfg_id %d), %d frames, the preset in CQP as it comes" % (cfgIndex, cfg_id, Kx)}
                 del framesx, streamx
             except Exception as exc:       # the bench line stands on its own
                 line[key] = {"error": repr(exc)}

@@ -1,5 +1,5 @@
 # any of the bench's configurations through the encoder object with timing / queue profile:
-#   dbg/enc_cfg.py WxH medium|slow 8|10 N [warm]      (X265AMD_TIMING=1 X265AMD_QUEUE_PROF=1 X265AMD_HOSTPROF=1)
+#   dbg/enc_cfg.py WxH medium|slow|veryslow 8|10 N [warm]   (veryslow: --preset veryslow --rd 6, BASELINE configs[4])      (X265AMD_TIMING=1 X265AMD_QUEUE_PROF=1 X265AMD_HOSTPROF=1)
 import sys, os, hashlib
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,8 +9,8 @@ preset, depth, N = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 Wm = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 bench.W, bench.H = w, h
 L = T.load_hip(depth)
-cfg = dict(bench.ENC_CFG, frameNumThreads=6 if h > 2000 else 5, **(T.SLOW_TOOLS if preset == "slow" else {}))
-cfg_id = {("medium", 8): 2, ("slow", 8): 3, ("medium", 10): 4}.get((preset, depth), 2)
+cfg = dict(bench.ENC_CFG, frameNumThreads=6 if h > 2000 else 5, **(T.SLOW_TOOLS if preset == "slow" else dict(T.VERYSLOW_TOOLS, **T.VERYSLOW_GOP) if preset == "veryslow" else {}))
+cfg_id = {("medium", 8): 2, ("slow", 8): 3, ("medium", 10): 4, ("veryslow", 10): 5}.get((preset, depth), 2)
 sync = torch.cuda.synchronize
 if Wm: bench.encode(T, L, bench.bench_clip(0, Wm, depth=depth, cfg_id=cfg_id), 0, 0, sync, timed=False, cfg=cfg)
 frames = bench.bench_clip(0, N, depth=depth, cfg_id=cfg_id)
