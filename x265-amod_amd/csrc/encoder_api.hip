@@ -2505,7 +2505,9 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
      * comes from another picture, and an I picture takes as long as a dozen of the others -- started when the lookahead hands it over, it is coded beside the pictures
      * in front of it instead of holding up the ones behind it (X265AMD_EARLY_I=0: in turn).  Output stays in coding order. */
     static const bool earlyI = !(getenv("X265AMD_EARLY_I") && atoi(getenv("X265AMD_EARLY_I")) == 0);
+    static const int earlyIMax = getenv("X265AMD_EARLY_I_MAX") ? atoi(getenv("X265AMD_EARLY_I_MAX")) : 1 << 20;
     static const bool earlyP = !(getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 0);
+    static const bool earlyPAlways = getenv("X265AMD_EARLY_P") && atoi(getenv("X265AMD_EARLY_P")) == 2;
     static const bool earlyBref = getenv("X265AMD_EARLY_BREF") && atoi(getenv("X265AMD_EARLY_BREF")) != 0;      /* a referenced B picture is a link of the same chain */
     static const int earlyPMax = getenv("X265AMD_EARLY_P_MAX") ? atoi(getenv("X265AMD_EARLY_P_MAX")) : 6;
     /* (measured, profiles/r05_early_b_sweep.txt: 2160p clips 15-22 % shorter with 12, 8-bit, Main 10 and --preset slow alike; the 1080p clips unchanged or -- the
@@ -2520,11 +2522,22 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         /* the first picture in coding order always runs: it is the one collected next, whatever started ahead of its turn */
         if (e->running <= e->frameThreads || q == e->inflight.front()) { start(q); if (e->frameThreads <= 1) q->done.wait(); continue; }
         if (!(e->frameParallel && earlyI)) break;
-        if (q->type == TYPE_IDR || q->type == TYPE_I) start(q);
+        if (q->type == TYPE_IDR || q->type == TYPE_I)
+        {
+            /* (X265AMD_EARLY_I_MAX: no more of them at once than this -- an experiment of round 5's end: while P pictures started ahead of their turn all the time, a limit
+             * of one helped a long 2160p clip; with the P pictures held to their turn outside an I picture's time it does not, and there is none.  profiles/r05_sched_sweep.txt) */
+            int runningI = 0;
+            for (auto& o : e->inflight)
+                if (o->started && (o->type == TYPE_IDR || o->type == TYPE_I) && o->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) runningI++;
+            if (runningI < earlyIMax) start(q);
+        }
         /* The P pictures are the chain every other picture hangs on (each follows its reference by a few CTU rows, the B pictures between two of them follow both): a P
          * picture held back until the B pictures in front of it have been collected starts with nothing to trail and takes its full latency, so it starts when the
          * lookahead hands it over, too (every picture it references is in front of it in coding order and therefore started; X265AMD_EARLY_P=0: in turn). */
-        else if (earlyP && (q->type == TYPE_P || (earlyBref && q->type == TYPE_BREF)) && e->running <= e->frameThreads + earlyPMax) start(q);
+        /* (round 5's end: like the B pictures below, only while a running I picture holds the head of the coding order -- X265AMD_EARLY_P=2: always, as round 4 had it.
+         * With P pictures ahead of their turn ALL the time a long clip stood at 52 frames/s where it reaches 100 without: the pictures far ahead held the places
+         * and the queues that the pictures collected next were waiting for; profiles/r05_sched_sweep.txt) */
+        else if (earlyP && (headLong || earlyPAlways) && (q->type == TYPE_P || (earlyBref && q->type == TYPE_BREF)) && e->running <= e->frameThreads + earlyPMax) start(q);
         /* The B pictures, too (round 5), while an I picture that still runs holds the head of the coding order: `running` counts every picture that trails it and is not
          * collected yet (collection is in coding order), and the B pictures of the mini-GOPs whose P pictures ran already waited for the I picture's END although their
          * references were rows ahead of them -- at 2160p a third of a twenty-frame clip, at --preset slow more.  How many pictures run side by side changes nothing in
