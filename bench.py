@@ -430,6 +430,20 @@ def main():
             del frames60, stream60
         except Exception as exc:       # the bench line stands on its own
             line["scene_change_clip"] = {"error": repr(exc)}
+        # ---- and a LONG clip of the same generator (a scene cut's I picture every 24 frames): what an encode that is not over after one I picture gets ----
+        try:
+            n_long = 240
+            framesL = bench_clip(0, n_long)
+            streamL, dtL = encode(T, L, framesL, 0, 0, sync)
+            refL = reference_encode(framesL, runs=("default", "pools16"))
+            line["long_clip"] = {"value": n_long / dtL, "unit": "frames/s", "frames": n_long, "stream_md5": hashlib.md5(streamL).hexdigest(),
+                                 "bit_exact_vs_reference_encoder": None if refL is None else bool(refL["default"]["stream"] == streamL),
+                                 "cpu_baseline": None if refL is None else {"value": n_long / refL["default"]["seconds"], "cores": refL["cores"], "kind": "reference",
+                                                                            "says": refL["default"]["says"], "pools16": n_long / refL["pools16"]["seconds"]},
+                                 "note": "the same clip generator and options over %d frames at 1920x1080: the noise field is re-seeded every 24th frame, both encoders place an I picture there" % n_long}
+            del framesL, streamL
+        except Exception as exc:
+            line["long_clip"] = {"error": repr(exc)}
     # ---- the same encode at 3840x2160 (BASELINE.json's metric names both sizes; the bench line is the 1080p one): reported beside it, never instead of it ----
     if rank == 0 and world == 1 and args.res == "1080p" and not args.no_2160p and not args.no_cpu_baseline:
         try:
