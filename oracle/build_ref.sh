@@ -15,6 +15,7 @@
 #   oracle/_ref/x265_refD         CLI
 #   oracle/_ref/librefprimsD.so   tiny C-ABI driver (oracle/refprims.cpp) around the reference primitive table
 #   oracle/_ref/x265_dropinD      reference encoder + optional x265amd_setup_primitives() override (oracle/ref_encode_with_table.cpp)
+#   oracle/_ref/x265_rc_dumpD     the reference encoder + a per-picture record of its rate control's and lookahead's decisions (oracle/ref_rc_dump.cpp)
 #   oracle/_ref/x265_abi_driverD  a libx265 client over another library's x265_api table (oracle/abi_driver.cpp; tests/test_x265_api_abi.py)
 set -euo pipefail
 REF=${X265_REFERENCE:-/root/reference}
@@ -63,6 +64,8 @@ build_depth() {
     g++ $FLAGS -o "$OUT/x265_dropin$D" "$HERE/ref_encode_with_table.cpp" $objs -lpthread -ldl
     # a libx265 client that fills x265_param with the reference's own functions and encodes through ANOTHER library's x265_api table (our file + reference objects)
     g++ $FLAGS -o "$OUT/x265_abi_driver$D" "$HERE/abi_driver.cpp" $objs -lpthread -ldl
+    # the reference encoder with its lookahead's and rate control's decisions per picture written out (our file + reference objects; CRF / AQ / cuTree ground truth)
+    g++ $FLAGS -o "$OUT/x265_rc_dump$D" "$HERE/ref_rc_dump.cpp" $objs -lpthread -ldl
 }
 for D in 8 10; do build_depth $D; done
 echo "oracle/_ref built: $(ls "$OUT" | tr '\n' ' ')"

@@ -1839,4 +1839,77 @@ int ref_aq_frame(const pixel* y, const pixel* u, const pixel* v, intptr_t stride
     return n;
 }
 
+/* ---- cuTree: the reference's own Lookahead::cuTree (slicetype.cpp:3399-3500, with estimateCUPropagate, cuTreeFinish and primitives.propagateCost) on Lowres objects whose
+ * cost estimates are handed in: n = numframes + 1 pictures (frames[0] = the last non-B picture), per picture the slice type, Lowres::intraCost, invQscaleFactor, qpAqOffset,
+ * qpCuTreeOffset (in / out), propagateCost (in / out), weightedCostDelta[18]; numEst estimates (p0, p1, b) with lowresCosts and the two motion fields, entered as if
+ * estimateFrameCost had made them (costEst >= 0, rowSatds set: singleCost finds them and does nothing).  Arrays per 8x8 block of the half-resolution picture. ---- */
+namespace {
+struct TreeLookahead : public Lookahead
+{
+    TreeLookahead(x265_param* p) : Lookahead(p, NULL) {}
+    void tree(Lowres** frames, int numframes, bool bIntra) { cuTree(frames, numframes, bIntra); }
+    int64_t recalc(Lowres** frames, int p0, int p1, int b) { return frameCostRecalculate(frames, p0, p1, b); }
+};
+}
+int ref_cutree(int width, int height, int bframes, int bpyramid, int weightb, int lookaheadDepth, double qCompress, int fpsNum, int fpsDenom, int numframes, int bIntra,
+               const int32_t* sliceTypes, const int32_t* intraCost, const int32_t* invQscale, const double* qpAq, double* qpCuTree, uint16_t* propagate, const double* weightedCostDelta,
+               int numEst, const int32_t* estIdx, const uint16_t* lowresCosts, const int16_t* mvs0, const int16_t* mvs1, int64_t* recalc)
+{
+    ensure();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = width; param->sourceHeight = height; param->internalCsp = X265_CSP_I420; param->bframes = bframes; param->bBPyramid = bpyramid;
+    param->bEnableWeightedPred = 0; param->bEnableWeightedBiPred = weightb; param->rc.aqMode = 2; param->rc.cuTree = 1; param->lookaheadSlices = 0; param->bEnableHME = 0;
+    param->rc.qCompress = qCompress; param->fpsNum = fpsNum; param->fpsDenom = fpsDenom; param->lookaheadDepth = lookaheadDepth; param->rc.hevcAq = 0;
+    param->maxSlices = 1; param->bFrameBias = 0; param->rc.qgSize = 32; param->bEnableTemporalFilter = 0; param->rc.vbvBufferSize = 0;
+    TreeLookahead* la = new TreeLookahead(param);
+    if (!la->create()) return -1;
+    const int n = numframes + 1;
+    const int wcu = la->m_8x8Width, hcu = la->m_8x8Height, ncu = wcu * hcu;
+    std::vector<Lowres*> frames(n + 2, (Lowres*)NULL);
+    std::vector<PicYuv*> pics(n);
+    for (int k = 0; k < n; k++)
+    {
+        pics[k] = new PicYuv;
+        pics[k]->m_param = param; pics[k]->m_picWidth = width; pics[k]->m_picHeight = height; pics[k]->m_lumaMarginX = 96; pics[k]->m_lumaMarginY = 80;
+        pics[k]->m_stride = width + 192; pics[k]->m_picOrg[0] = NULL;
+        Lowres* f = new Lowres();
+        if (!f->create(param, pics[k], param->rc.qgSize)) return -1;
+        f->frameNum = k; f->sliceType = sliceTypes[k];
+        memset(f->costEst, -1, sizeof(f->costEst)); memset(f->costEstAq, -1, sizeof(f->costEstAq));
+        for (int y = 0; y < bframes + 2; y++) for (int x = 0; x < bframes + 2; x++) f->rowSatds[y][x][0] = -1;
+        for (int i = 0; i < bframes + 2; i++) { f->lowresMvs[0][i][0].x = 0x7FFF; f->lowresMvs[1][i][0].x = 0x7FFF; }
+        memcpy(f->intraCost, intraCost + (size_t)k * ncu, sizeof(int32_t) * ncu);
+        memcpy(f->invQscaleFactor, invQscale + (size_t)k * ncu, sizeof(int32_t) * ncu);
+        memcpy(f->qpAqOffset, qpAq + (size_t)k * ncu, sizeof(double) * ncu);
+        memcpy(f->qpCuTreeOffset, qpCuTree + (size_t)k * ncu, sizeof(double) * ncu);
+        memcpy(f->propagateCost, propagate + (size_t)k * ncu, sizeof(uint16_t) * ncu);
+        for (int i = 0; i < bframes + 2 && i < 18; i++) f->weightedCostDelta[i] = weightedCostDelta[(size_t)k * 18 + i];
+        frames[k] = f;
+    }
+    for (int e = 0; e < numEst; e++)
+    {
+        const int p0 = estIdx[3 * e], p1 = estIdx[3 * e + 1], b = estIdx[3 * e + 2];
+        Lowres* f = frames[b];
+        f->costEst[b - p0][p1 - b] = 1; f->costEstAq[b - p0][p1 - b] = 1; f->rowSatds[b - p0][p1 - b][0] = 0;
+        memcpy(f->lowresCosts[b - p0][p1 - b], lowresCosts + (size_t)e * ncu, sizeof(uint16_t) * ncu);
+        if (b > p0) for (int i = 0; i < ncu; i++) { f->lowresMvs[0][b - p0][i].x = mvs0[((size_t)e * ncu + i) * 2]; f->lowresMvs[0][b - p0][i].y = mvs0[((size_t)e * ncu + i) * 2 + 1]; }
+        if (p1 > b) for (int i = 0; i < ncu; i++) { f->lowresMvs[1][p1 - b][i].x = mvs1[((size_t)e * ncu + i) * 2]; f->lowresMvs[1][p1 - b][i].y = mvs1[((size_t)e * ncu + i) * 2 + 1]; }
+    }
+    la->tree(frames.data(), numframes, bIntra != 0);
+    for (int k = 0; k < n; k++)
+    {
+        memcpy(qpCuTree + (size_t)k * ncu, frames[k]->qpCuTreeOffset, sizeof(double) * ncu);
+        memcpy(propagate + (size_t)k * ncu, frames[k]->propagateCost, sizeof(uint16_t) * ncu);
+    }
+    /* frameCostRecalculate of every estimate handed in whose picture is not a B picture */
+    for (int e = 0; e < numEst && recalc; e++)
+    {
+        const int p0 = estIdx[3 * e], p1 = estIdx[3 * e + 1], b = estIdx[3 * e + 2];
+        recalc[e] = frames[b]->sliceType == X265_TYPE_B ? -1 : la->recalc(frames.data(), p0, p1, b);
+    }
+    for (int k = 0; k < n; k++) { frames[k]->destroy(param); delete frames[k]; delete pics[k]; }
+    return ncu;
+}
+
 } /* extern "C" */

@@ -718,7 +718,62 @@ def make_encoder_fade_golden():
     np.savez_compressed(os.path.join(T.GOLDEN_DIR, "encoder_fade_golden.npz"), **out)
 
 
+# ---- rate control (tests/test_ratecontrol.py): cuTree digests from the reference's own Lookahead::cuTree, and records of whole reference encodes ----
+RC_ENCODES = [
+    ("scene 320x192 x30, the preset as it comes", "scene", (320, 192, 30), [], dict()),
+    ("survey 416x240 x40 (a scene change at 24)", "survey", (416, 240, 40), [], dict()),
+    ("crf 22, two B pictures", "survey", (416, 240, 30), ["crf=22", "bframes=2"], dict(rf=22.0, bframes=2)),
+    ("no B pyramid, keyframes every 12", "api", (320, 192, 30), ["b-pyramid=0", "keyint=12", "min-keyint=12"], dict(keyint=12)),
+    ("no B pictures", "survey", (416, 240, 20), ["bframes=0"], dict(bframes=0)),
+    ("no cuTree: the blurred-complexity branch", "survey", (416, 240, 30), ["cutree=0", "qcomp=0.7"], dict(cutree=0, qcomp=0.7)),
+]
+
+
+def _rc_clip(kind, w, h, n):
+    if kind == "scene":
+        return T.scene_clip(w, h, n, [n // 2])
+    if kind == "survey":
+        return T.survey_clip(w, h, 8, 2, 0, n)
+    return T.encoder_api_clip("rc", w, h, n)
+
+
+def make_ratecontrol_golden():
+    import ratecontrol_lib as RL
+    R = T.load_ref(8)
+    out = {"reference": "DJATOM/x265-aMod 3.6+1-aa7f602f7 [noasm]", "cutree": [], "rc": [], "cu_qp": []}
+    for seed, kw in RL.CUTREE_CASES:
+        c = RL.cutree_case(seed, **kw)
+        tree, prop, recalc = RL.cutree_run_ref(R, c)
+        out["cutree"].append(RL.digest(tree, prop, recalc))
+    for k, (what, kind, (w, h, n), opts, rc) in enumerate(RC_ENCODES):
+        recs, stream = RL.reference_rc_records(_rc_clip(kind, w, h, n), w, h, 8, "medium", opts, "/tmp/rc_golden_%d" % k)
+        keep = [dict(poc=r["poc"], type=r["type"], referenced=r["referenced"], slice_qp=r["slice_qp"], scenecut=r["scenecut"], ref_poc=r["ref_poc"], satd=r["satd"],
+                     qp_rc_bits=str(int(np.float64(r["qp_rc"]).view(np.uint64)))) for r in recs]
+        out["rc"].append(dict(what=what, w=w, h=h, rc=rc, records=keep))
+        print(what, len(stream), "bytes;", " ".join("%d:%d/%.3f" % (r["poc"], r["slice_qp"], r["qp_rc"]) for r in recs[:12]))
+        if k == 1:
+            # the QP of the CUs that carry one: CUs of 64 or 32 samples (the quantisation group's depth and above) with a luma residual
+            for r in recs[:14]:
+                offs = r["cutree"] if r["referenced"] else r["aq"]
+                cus = []
+                for y in range(0, h, 32):
+                    for x in range(0, w, 32):
+                        d = int(r["depth"][y // 4, x // 4])
+                        if d > 1 or (d == 0 and (x % 64 or y % 64)) or not r["cbf"][y // 4, x // 4] or x + (64 >> d) > w or y + (64 >> d) > h:
+                            continue
+                        cus.append((x, y, 64 >> d, int(r["qp"][y // 4, x // 4])))
+                if cus:
+                    out["cu_qp"].append(dict(poc=r["poc"], w=w, h=h, base_bits=str(int(np.float64(r["qp_rc"]).view(np.uint64))),
+                                             offsets_bits=[str(int(v)) for v in offs.view(np.uint64)], cus=cus))
+            print("   CUs with a coded QP:", sum(len(c["cus"]) for c in out["cu_qp"]))
+    with open(os.path.join(T.GOLDEN_DIR, "ratecontrol_golden.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rc":
+        make_ratecontrol_golden()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fade":
         make_encoder_fade_golden()
         sys.exit(0)

@@ -1,0 +1,71 @@
+"""The rate-control host code (include/x265amd_ratecontrol.h; x265-amod_amd/host/fm_ratecontrol.cpp): cuTree, the constant-rate-factor branch of RateControl and the QP of a CU
+against the reference's own objects (when oracle/_ref is present) and against golden data made from them (tests/golden/make_golden.py).  Double-precision results are compared
+bit for bit.  No GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hevc_testlib as T
+import ratecontrol_lib as RL
+
+GOLD = os.path.join(T.GOLDEN_DIR, "ratecontrol_golden.json")
+needs_ref = pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")
+
+
+@needs_ref
+@pytest.mark.parametrize("k", range(len(RL.CUTREE_CASES)))
+def test_cutree_matches_the_references_lookahead(k):
+    """x265amd_cutree on seeded windows of pictures against Lookahead::cuTree run on Lowres objects holding the same arrays: every picture's qpCuTreeOffset (doubles, bit for
+    bit) and propagateCost, the order in which estimates are asked for, and frameCostRecalculate of every non-B estimate"""
+    seed, kw = RL.CUTREE_CASES[k]
+    c = RL.cutree_case(seed, **kw)
+    want = RL.cutree_run_ref(T.load_ref(8), c)
+    got = RL.cutree_run_prod(T.load_hip(8), c)
+    assert np.array_equal(got[1], want[1]), np.argwhere(got[1] != want[1])[:5].tolist()
+    assert np.array_equal(got[0].view(np.uint64), want[0].view(np.uint64)), (np.argwhere(got[0] != want[0])[:5].tolist(), float(np.abs(got[0] - want[0]).max()))
+    assert np.array_equal(got[2], want[2]), (got[2].tolist(), want[2].tolist())
+    assert len(c["est"]) == 0 or not np.array_equal(got[0], c["qp_cutree"])      # the case did something
+
+
+@pytest.mark.parametrize("k", range(len(RL.CUTREE_CASES)))
+def test_cutree_matches_golden(k):
+    g = json.load(open(GOLD))
+    seed, kw = RL.CUTREE_CASES[k]
+    c = RL.cutree_case(seed, **kw)
+    got = RL.cutree_run_prod(T.load_hip(8), c)
+    assert RL.digest(got[0], got[1], got[2]) == g["cutree"][k]
+
+
+def _rc_cases():
+    g = json.load(open(GOLD))
+    return g["rc"]
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_crf_qps_match_reference_encodes(k):
+    """x265amd_rc_start replayed over the pictures of whole reference encodes (plain --preset medium = CRF 28 + AQ + cuTree; other rate factors, GOP shapes, scene cuts): the
+    slice QP and FrameData::m_avgQpRc (a double, the base of every CU's QP) of every picture, bit for bit"""
+    case = _rc_cases()[k]
+    recs = [dict(r) for r in case["records"]]
+    out = RL.rc_replay(T.load_hip(8), recs, case["w"], case["h"], **case["rc"])
+    for r, (qp, avg) in zip(recs, out):
+        assert qp == r["slice_qp"] and np.float64(avg).view(np.uint64) == np.uint64(int(r["qp_rc_bits"])), (r["poc"], qp, avg, r["slice_qp"])
+
+
+def test_cu_qp_matches_reference_encodes():
+    """x265amd_cu_qp (Analysis::calculateQpforCuSize) against the QPs the reference coded: a CU with residual at the quantisation group's depth carries exactly that QP"""
+    import ctypes as C
+    g = json.load(open(GOLD))
+    lib = T.load_hip(8).lib
+    n = 0
+    for case in g["cu_qp"]:
+        offs = np.array(case["offsets_bits"], np.uint64).view(np.float64)
+        base = np.array([case["base_bits"]], np.uint64).view(np.float64)[0]
+        for (x, y, size, want) in case["cus"]:
+            got = lib.x265amd_cu_qp(C.c_double(base), T._ptr(offs), case["w"], case["h"], x, y, size, 0, 69)
+            got = min(got, 51)      # Search::setLambdaFromQP hands back the QP clipped to the range the syntax carries
+            assert got == want, (case["poc"], x, y, size, got, want)
+            n += 1
+    assert n > 100

@@ -30,7 +30,10 @@ build_one() {
     for f in $HOSTSRCS; do
         local o=$OUT/$(basename "$f" .cpp).$depth.host.o
         rm -f "$o"
-        g++ -O2 -std=c++17 -fPIC -Wall -I"$HERE/../include" -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
+        # fm_*.cpp: double-precision arithmetic that has to come out like the reference's, which is compiled -O2 -ffast-math (source/CMakeLists.txt:226-240)
+        local fm=""
+        case "$(basename "$f")" in fm_*) fm="-ffast-math";; esac
+        g++ -O2 $fm -std=c++17 -fPIC -Wall -I"$HERE/../include" -DX265AMD_DEPTH=$depth -c "$f" -o "$o" &
         pids="$pids $!"
         objs="$objs $o"
     done
