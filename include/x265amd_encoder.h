@@ -8,9 +8,9 @@
  * per-frame calls into the frame pipeline (x265amd_analyse_frame, deblocking, SAO, border extension, slice NAL) and the stream headers.
  *
  * Built subset (everything else is rejected by x265amd_encoder_open with NULL + x265amd_last_error): 4:2:0, bit depth of the library,
- * constant QP (rc.rateControlMode = X265_RC_CQP), mini-GOPs fixed or chosen by the lookahead (bFrameAdaptive 0 / 1 / 2), scene-cut detection, open or
- * closed GOPs, the B pyramid, the lookahead in slices, weighted prediction's analysis (no coding with weights), no AQ /
- * cutree, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
+ * constant QP or constant rate factor (rc.rateControlMode = X265_RC_CQP / X265_RC_CRF; no ABR, VBV or second pass), adaptive quantisation (aq-mode 0-3) and cuTree,
+ * mini-GOPs fixed or chosen by the lookahead (bFrameAdaptive 0 / 1 / 2), scene-cut detection, open or
+ * closed GOPs, the B pyramid, the lookahead in slices, weighted prediction, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
  * is the reference encoder's (tests/test_encoder_api.py compares whole streams with the reference command line program's). */
 #ifndef X265AMD_ENCODER_H
 #define X265AMD_ENCODER_H
@@ -92,9 +92,28 @@ typedef struct x265amd_param
                                              * 51-185), every prediction is weighted (Predict::motionCompensation, predict.cpp:85-232) */
     int32_t bEnableWeightedBiPred;          /* param.bEnableWeightedBiPred (--weightb; on in the presets slower and veryslow): the same for B pictures, both lists
                                              * (pps.weighted_bipred_flag; addWeightBi, predict.cpp:411-518) */
+    /* ---- rate control as the presets come (round 6) ---- */
+    int32_t rateControlMode;                /* param.rc.rateControlMode with the reference's numbers (x265.h X265_RC_*): X265AMD_RC_CQP 1 = constant QP (`qp` above; also what 0 means);
+                                             * X265AMD_RC_CRF 2 = constant rate factor, the reference's default: RateControl::rateControlStart / rateEstimateQscale / getQScale
+                                             * (ratecontrol.cpp:1334-1643, :1900-2375, :2931-2954) without VBV, zones or a second pass -- every picture's QP follows from the slice
+                                             * types, the scene-cut marks and the QPs of the pictures before it (ABR 0 is not built) */
+    double rfConstant;                      /* param.rc.rfConstant (--crf; 28) */
+    double aqStrength;                      /* param.rc.aqStrength (--aq-strength; 1.0) */
+    double qCompress;                       /* param.rc.qCompress (--qcomp; 0.6): cuTree's strength 5 (1 - qcomp) and, without cuTree, the exponent of the blurred complexity */
+    int32_t aqMode;                         /* param.rc.aqMode (--aq-mode): 0 off, 1 variance, 2 auto-variance (the default), 3 auto-variance biased to dark scenes
+                                             * (LookaheadTLD::calcAdaptiveQuantFrame, slicetype.cpp:452-713): a QP offset per 16x16 block, the QP of a CU = the picture's
+                                             * QP + the mean offset of the blocks under its quantisation group (Analysis::calculateQpforCuSize, analysis.cpp:3634-3714),
+                                             * cu_qp_delta in the stream (pps.cu_qp_delta_enabled_flag, diff_cu_qp_delta_depth from qgSize) */
+    int32_t cuTree;                         /* param.rc.cuTree (--cutree, the default; needs the lookahead and aqMode != 0 as in the reference's presets): Lookahead::cuTree /
+                                             * estimateCUPropagate / cuTreeFinish (slicetype.cpp:3399-3800) on the lookahead's block costs and motion fields: referenced
+                                             * pictures take their block offsets from it */
+    int32_t qgSize;                         /* param.rc.qgSize (--qg-size): 64 or 32 (the default); 16 and 8 are not built */
+    int32_t reservedRc;
 } x265amd_param;
+enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 
-/* x265_param_default + --preset medium for the fields above, CQP 30, --bframes 0 */
+/* x265_param_default + --preset medium for the fields above, but CQP 30 without adaptive quantisation and cuTree, --bframes 0 (what the block-level tests build on);
+ * the preset's own rate control is rateControlMode = X265AMD_RC_CRF, rfConstant 28, aqMode 2, aqStrength 1, cuTree 1, qCompress 0.6, qgSize 32 */
 void x265amd_param_default(x265amd_param* p);
 
 typedef struct x265amd_nal { uint32_t type; uint32_t sizeBytes; uint8_t* payload; } x265amd_nal;      /* x265_nal (x265.h:94-99) */

@@ -3023,7 +3023,9 @@ class EncParam(C.Structure):
                 ("bEnableSignHiding", C.c_int32), ("bEnableStrongIntraSmoothing", C.c_int32), ("bEnableTemporalMvp", C.c_int32),
                 ("tuQTMaxInterDepth", C.c_int32), ("tuQTMaxIntraDepth", C.c_int32), ("bEnableLoopFilter", C.c_int32), ("bEnableSAO", C.c_int32),
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
-                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32)]
+                ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
+                ("rateControlMode", C.c_int32), ("rfConstant", C.c_double), ("aqStrength", C.c_double), ("qCompress", C.c_double), ("aqMode", C.c_int32), ("cuTree", C.c_int32),
+                ("qgSize", C.c_int32), ("reservedRc", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)

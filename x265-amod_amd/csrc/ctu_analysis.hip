@@ -219,8 +219,106 @@ struct Analyzer
     uint64_t lambda2, lambda; uint32_t psyRd;
     x265amd_rd_params rp;
     int err;
+    /* ---- delta QP (pps.bUseDQP): `qp` above is the QP in force -- what Search::setLambdaFromQP was last called with (search.cpp:177-187): the lambdas, the quantiser and the
+     * motion costs follow it.  A CU's own QP is the value in force when compress() is entered: set by its parent for a CU at the quantisation groups' depth or above, inherited
+     * from its group below that. ---- */
+    const int8_t* cuQp = nullptr;           /* this CTU's group QPs (xa_analyse_frame's cu_qp): [0] the 64x64 CU, [1 + q] its 32x32 CUs */
+    int ctuQp = 0;                          /* CUData::m_qp[0] of the CTU as compressCTU sets it (topSkipMinDepth's currentQP) */
+    x265amd_cabac* qpCoder = nullptr;       /* a bit-counting coder on the picture map: getRefQP and the price of cu_qp_delta (checkDQPForSplitPred) */
+    int setLambdaFromQP(int q)
+    {
+        /* (a QP above 51 -- lambdas from the QP, the quantiser from 51 -- needs the two kept apart through every command record: not built, refused) */
+        if (q < 0 || q > 51) return fail("a CU's QP outside 0..51 (QPs above 51, where the lambda's QP and the quantiser's differ, are not built)");
+        qp = q;
+        uint64_t rd[6];
+        x265amd_rdcost(qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
+        lambda2 = rd[0]; lambda = rd[1]; psyRd = (uint32_t)rd[2];
+        return 0;
+    }
+    /* Analysis::calculateQpforCuSize of the sub-CU q of the CU at `depth` -- when that is a quantisation group's CU (analysis.cpp:1363-1364); else the QP in force stays */
+    int childQp(int depth, int q)
+    {
+        if (!si->use_dqp || depth + 1 > si->max_cu_dqp_depth) return 0;
+        return setLambdaFromQP(cuQp[1 + q]);          /* (max_cu_dqp_depth 1: the children of the CTU) */
+    }
+    /* the price of cu_qp_delta for the mode's first unit (Entropy::codeDeltaQP(cu, 0) in bit-counting mode: mode.contexts.resetBits(); codeDeltaQP; getNumberOfWrittenBits) */
+    int addDeltaQpBits(Mode& m, int x, int y)
+    {
+        if (!qpCoder)
+        {
+            if (!(qpCoder = x265amd_cabac_open(si, units, 1))) return fail("delta QP: coder");
+            qpCoder->ctuInProgress = true;          /* the analysis of a CTU asks (cabac_coder.h: lastQP) */
+        }
+        if (A->rd_level >= 3)
+        {
+            x265amd_cu_unit& at = units[(y >> 2) * w4 + (x >> 2)];
+            const int8_t saved = at.qp;
+            at.qp = m.u[0].qp;
+            memcpy(qpCoder->ctx, m.contexts.ctx, X265AMD_CTX_STRIDE);
+            qpCoder->fracBits = m.contexts.frac & 32767;    /* resetBits() */
+            qpCoder->deltaQP(x, y);
+            at.qp = saved;
+            m.totalBits += (uint32_t)(qpCoder->fracBits >> 15);
+            memcpy(m.contexts.ctx, qpCoder->ctx, X265AMD_CTX_STRIDE);
+            m.contexts.frac = qpCoder->fracBits;
+        }
+        else m.totalBits++;
+        updateModeCost(m);
+        return 0;
+    }
+    /* Search::checkDQP (search.cpp:3974-4003) as the merge checks call it on their winner (analysis.cpp:2879, :3019) -- for the mode with a residual a second time: the walk
+     * of encodeResAndCalcRdInterCU has priced cu_qp_delta already (inter_rd.hip), and the reference adds it again here */
+    int checkDQP(Mode& m, int x, int y, int depth)
+    {
+        if (!si->use_dqp || depth > si->max_cu_dqp_depth) return 0;
+        if (m.u[0].cbf[0] || m.u[0].cbf[1] || m.u[0].cbf[2]) return addDeltaQpBits(m, x, y);
+        if (!qpCoder)
+        {
+            if (!(qpCoder = x265amd_cabac_open(si, units, 1))) return fail("delta QP: coder");
+            qpCoder->ctuInProgress = true;
+        }
+        const int8_t refQp = (int8_t)qpCoder->refQP(x, y);
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++) m.u[i].qp = refQp;
+        return 0;
+    }
+    /* Search::checkDQPForSplitPred (search.cpp:4005-4050) on the mode at (x, y): at the quantisation groups' depth the price of cu_qp_delta when anything in the CU carries a
+     * residual -- added whatever the mode is, as the reference does -- and the QP of the CUs in front of the first one with a residual (all of them if there is none) set to
+     * the predicted QP, which is what a decoder takes for them */
+    int checkDQPForSplitPred(Mode& m, int x, int y, int depth)
+    {
+        if (!si->use_dqp || depth != si->max_cu_dqp_depth) return 0;
+        if (!qpCoder)
+        {
+            if (!(qpCoder = x265amd_cabac_open(si, units, 1))) return fail("delta QP: coder");
+            qpCoder->ctuInProgress = true;
+        }
+        const int n4 = 16 >> depth;
+        bool hasResidual = false;
+        for (int i = 0; i < n4 * n4 && !hasResidual; i++) hasResidual = m.u[i].cbf[0] || m.u[i].cbf[1] || m.u[i].cbf[2];
+        const int8_t refQp = (int8_t)qpCoder->refQP(x, y);
+        if (hasResidual)
+        {
+            if (addDeltaQpBits(m, x, y)) return err;
+            /* CUData::setQPSubCUs (cudata.cpp:1012-1032): CUs in coding order until the first with a residual */
+            bool done = false;
+            std::function<void(int, int, int)> walk = [&](int ux, int uy, int d) {
+                if (done) return;
+                const int s4 = 16 >> d;
+                if (x + ux * 4 >= I->pic_width || y + uy * 4 >= I->pic_height) return;
+                const x265amd_cu_unit& u0 = m.u[uy * n4 + ux];
+                if (u0.depth > d) { for (int q = 0; q < 4; q++) walk(ux + (q & 1) * (s4 >> 1), uy + (q >> 1) * (s4 >> 1), d + 1); return; }
+                if (u0.cbf[0] || u0.cbf[1] || u0.cbf[2]) { done = true; return; }
+                for (int yy = 0; yy < s4; yy++) for (int xx = 0; xx < s4; xx++) m.u[(uy + yy) * n4 + ux + xx].qp = refQp;
+            };
+            walk(0, 0, depth);
+        }
+        else
+            for (int i = 0; i < n4 * n4; i++) m.u[i].qp = refQp;
+        return 0;
+    }
     void* intraWs = nullptr;                /* the intra RD's working set, kept for the CUs of this CTU (intra_rd.hip) */
-    ~Analyzer() { for (auto& a : chain.ahead) if (a.on && a.q) (void)xa_stream_sync(a.q); xa_intra_ws_free(intraWs); }       /* (a search nobody collected still writes to this CTU's buffers) */
+    ~Analyzer() { for (auto& a : chain.ahead) if (a.on && a.q) (void)xa_stream_sync(a.q); xa_intra_ws_free(intraWs); if (qpCoder) x265amd_cabac_close(qpCoder); }       /* (a search nobody collected still writes to this CTU's buffers) */
 
     /* ---- the device-resident motion map and the skip chain (inter_chain_dev.h) ---- */
     XaMapUnit* dCur = nullptr; const XaMapUnit* dCol = nullptr;
@@ -738,7 +836,9 @@ struct Analyzer
     /* ---- Analysis helpers ---- */
     uint32_t topSkipMinDepth(int x, int y, int depth)
     {
-        const int currentQP = qp;
+        /* parentCTU.m_qp[0] (analysis.cpp:3432) -- and parentCTU IS the picture's CTU record (frameencoder.cpp:1490): what compressCTU set for the whole CTU until the first
+         * CU of the CTU has been copied to the picture, that CU's QP afterwards */
+        const int currentQP = si->use_dqp ? units[(ctuY >> 2) * w4 + (ctuX >> 2)].qp : ctuQp;
         int previousQP = currentQP;
         uint32_t minDepth0 = 4, minDepth1 = 4, sum = 0;
         int numRefs = 0;
@@ -866,7 +966,7 @@ struct Analyzer
         const int keep = predTile(depth, d.best == tempPred ? PRED_MERGE : PRED_SKIP);
         copyTile(keep, tiles[bestSadCand], 0, 0, size);
         d.best->predTile = keep;
-        return 0;
+        return checkDQP(*d.best, x, y, depth);
     }
 
     /* the fused search's record for a CU -- everything but the addresses of its buffers; false in `ok`: not this configuration */
@@ -1300,7 +1400,7 @@ struct Analyzer
                 if (tempPred->rdCost < bestPred->rdCost) std::swap(tempPred, bestPred);
             }
         }
-        if (bestPred->rdCost < kMaxCost) d.best = bestPred;
+        if (bestPred->rdCost < kMaxCost) { d.best = bestPred; return checkDQP(*bestPred, x, y, depth); }
         return 0;
     }
 
@@ -1313,6 +1413,7 @@ struct Analyzer
         const bool mightSplit = depth < si->max_cu_depth;
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
         bool skipModes = false, skipRecursion = false, splitIntra = true;
+        const int myQp = qp;                    /* the `qp` argument of compressInterCU_rd5_6 */
         SplitData splitData[4];
         memset(splitData, 0, sizeof(splitData));
         d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
@@ -1350,6 +1451,7 @@ struct Analyzer
                 if (cx < I->pic_width && cy < I->pic_height)
                 {
                     md[depth + 1].cur = *nextContext;
+                    if (childQp(depth, q)) return err;
                     if (compress56(cx, cy, depth + 1, splitData[q])) return err;
                     const Mode& nb = *md[depth + 1].best;
                     splitIntra |= nb.u[0].pred_mode == X265AMD_MODE_INTRA;
@@ -1374,11 +1476,13 @@ struct Analyzer
             split.contexts = *nextContext;
             if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
             else updateModeCost(split);
+            if (checkDQPForSplitPred(split, x, y, depth)) return err;          /* analysis.cpp:2082 */
         }
         allSplitRefs = splitData[0].splitRefs | splitData[1].splitRefs | splitData[2].splitRefs | splitData[3].splitRefs;
         /* Step 3: bi-prediction, rectangular / asymmetric partitions and intra at the current depth */
         if (mightNotSplit)
         {
+            if (si->use_dqp && depth <= si->max_cu_dqp_depth && si->max_cu_dqp_depth != 0 && setLambdaFromQP(myQp)) return err;       /* analysis.cpp:2105-2106 */
             if (!skipModes)
             {
                 if (A->limit_refs & 2)
@@ -1589,6 +1693,7 @@ struct Analyzer
                 if (cx < I->pic_width && cy < I->pic_height)
                 {
                     md[depth + 1].cur = *nextContext;
+                    if (childQp(depth, q)) return err;
                     if (compressIntra(cx, cy, depth + 1)) return err;
                     const Mode& nb = *md[depth + 1].best;
                     if (const char* lg = depth == 2 ? getenv("X265AMD_CHAIN_LOG") : nullptr)
@@ -1631,6 +1736,7 @@ struct Analyzer
                 checkBestMode(d.pred[PRED_INTRA], depth);
                 addSplitFlagCost(*d.best, x, y, depth);
             }
+            if (checkDQPForSplitPred(split, x, y, depth)) return err;          /* analysis.cpp:642 */
             checkBestMode(split, depth);
         }
         toPicture(*d.best, x, y, depth);
@@ -1659,6 +1765,7 @@ struct Analyzer
         const bool mightSplit = depth < si->max_cu_depth;
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
         const uint32_t minDepth = topSkipMinDepth(x, y, depth);
+        const int myQp = qp;                    /* the `qp` argument of compressInterCU_rd0_4 */
         bool skipModes = false, skipRecursion = false, splitIntra = true;
         SplitData splitData[4];
         memset(splitData, 0, sizeof(splitData));
@@ -1770,6 +1877,7 @@ struct Analyzer
                 if (cx < I->pic_width && cy < I->pic_height)
                 {
                     md[depth + 1].cur = *nextContext;
+                    if (childQp(depth, q)) return err;
                     if (compress(cx, cy, depth + 1, splitData[q], childNode)) return err;
                     childNode = chain.nodes[childNode].next;
                     const bool childDev = chain.lastDevComplete;
@@ -1802,6 +1910,8 @@ struct Analyzer
         /* Step 3: ME and RD at the current depth */
         if (mightNotSplit && (uint32_t)depth >= minDepth)
         {
+            /* (the sub-CUs left their own QP in force: analysis.cpp:1413-1414) */
+            if (si->use_dqp && depth <= si->max_cu_dqp_depth && si->max_cu_dqp_depth != 0 && setLambdaFromQP(myQp)) return err;
             if (!skipModes)
             {
                 if (g_timing) g_cuStat[si->slice_type == 1][depth][2]++;
@@ -1939,6 +2049,7 @@ struct Analyzer
             Mode& split = d.pred[PRED_SPLIT];
             if (!d.best) d.best = &split;
             else checkBestMode(split, depth);
+            if (checkDQPForSplitPred(*d.best, x, y, depth)) return err;       /* (on the winner, whatever it is: analysis.cpp:1755) */
         }
         /* which motion references the parent CU should search (X265_REF_LIMIT_DEPTH) */
         memset(&splitOut, 0, sizeof(splitOut));
@@ -1972,7 +2083,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
                              const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                              const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                              intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
-                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol);
+                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol, const int8_t* cu_qp = nullptr);
 extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                                           const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                                           const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
@@ -1986,13 +2097,13 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
                              const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                              const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                              intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
-                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol)
+                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol, const int8_t* cu_qp)
 {
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
-    if (A->rdoq_level < 0 || A->rdoq_level > 2 || A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || si->use_dqp || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
-        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 2-6, no delta QP, rskip 0/1)");
+    if (A->rdoq_level < 0 || A->rdoq_level > 2 || A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || (si->use_dqp && (!cu_qp || si->max_cu_dqp_depth < 0 || si->max_cu_dqp_depth > 1)) || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 2-6, delta QP with the quantisation groups' QPs handed in and groups of 64 or 32 samples, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
     /* debugging aid: X265AMD_DUMP_CTU=<dir> X265AMD_DUMP_POC=<poc> X265AMD_DUMP_MARGIN=<mx>,<my> writes every input of this call (before) and its outputs
      * (after) to <dir>/ctu_<addr>.bin so that the reference's compressCTU can be run on exactly the same state (dbg/ctu_replay.py) */
@@ -2037,6 +2148,8 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
     a.refDepth = ref_depth; a.refQp0 = ref_qp0; a.planes = h_planes; a.numPics = num_pics; a.stride = stride; a.cstride = cstride;
     a.cuStat = cu_stat; a.ctuAddr = ctu_addr; a.ctuW = (I->pic_width + 63) >> 6; a.w4 = I->pic_width >> 2; a.h4 = I->pic_height >> 2;
     a.ctuX = (ctu_addr % a.ctuW) * 64; a.ctuY = (ctu_addr / a.ctuW) * 64; a.qp = si->slice_qp; a.err = 0;
+    if (si->use_dqp) { a.cuQp = cu_qp + (size_t)ctu_addr * (si->max_cu_dqp_depth >= 1 ? 5 : 1); a.qp = a.cuQp[0]; }           /* compressCTU: calculateQpforCuSize(ctu, cuGeom) (analysis.cpp:149) */
+    a.ctuQp = a.qp;
     int rc = X265AMD_OK;
     if (a.ctuX >= I->pic_width || a.ctuY >= I->pic_height || ctu_addr < 0) rc = xa_fail(X265AMD_EINVAL, "compress_ctu_inter: CTU address");
     a.tileBytes = (size_t)kTileElems * sizeof(pixel);
@@ -2049,9 +2162,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
         rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: plane table upload");
     if (rc == X265AMD_OK)
     {
-        uint64_t rd[6];
-        x265amd_rdcost(a.qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
-        a.lambda2 = rd[0]; a.lambda = rd[1]; a.psyRd = (uint32_t)rd[2];
+        if (a.setLambdaFromQP(a.qp)) rc = a.err;
         a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = A->strong_intra_smoothing;
         a.rp.rdoq_level = A->rdoq_level; a.rp.psy_rdoq_scale = A->rdoq_level ? A->psy_rdoq_scale : 0; a.rp.fast_intra = A->fast_intra != 0;
         /* CUData::initCTU: nothing of this CTU is decided yet */
@@ -2078,7 +2189,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
             if (a.chain.on) a.buildNodes(a.ctuX, a.ctuY, 0, -1);
             else a.chain.nodes[0].next = 0;
         }
-        rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit, 0));
+        if (rc == X265AMD_OK) rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit, 0));
         if (rc == X265AMD_OK && (xa_stream_fence(a.st, XA_CMD_RELEASE) != hipSuccess || xa_stream_sync(a.st) != hipSuccess)) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)
@@ -2124,7 +2235,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
-                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks)
+                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks, const int8_t* cu_qp)
 {
     if (!I || !si || !units || !cur || !cu_stat || !coeff_out) return xa_fail(X265AMD_EINVAL, "analyse_frame: null argument");
     const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2, h4 = si->pic_height >> 2;
@@ -2171,7 +2282,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         x265amd_ctu_result res;
         int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
         int r = compress_ctu_impl(me, st, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
-                                  rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res, frameDCur, frameDCol);
+                                  rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res, frameDCur, frameDCol, cu_qp);
         if (r != X265AMD_OK) return r;
         if (results) results[addr] = res;
         xa_phase(XA_PH_ANALYZER);

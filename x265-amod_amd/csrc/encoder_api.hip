@@ -12,6 +12,7 @@
 #include "x265amd.h"
 #include "x265amd_encoder.h"
 #include "x265amd_host.h"
+#include "x265amd_ratecontrol.h"
 #include <immintrin.h>
 #include "xa_fiber.h"
 #include <math.h>
@@ -36,6 +37,33 @@ typedef x265amd_pixel pixel;
 enum { TYPE_AUTO = 0, TYPE_IDR = 1, TYPE_I = 2, TYPE_P = 3, TYPE_BREF = 4, TYPE_B = 5 };          /* X265_TYPE_* (x265.h:572-577) */
 static inline bool isBType(int t) { return t == TYPE_B || t == TYPE_BREF; }         /* IS_X265_TYPE_B */
 enum { RD_TILE_ELEMS = 4096 + 2 * 1024 };
+
+/* The lookahead's device buffers -- motion fields and per-estimate cost arrays, all of one size (a 32-bit word per lowres block) -- come from chunks of 64 of them: a first
+ * decision of a few hundred estimates asks for a thousand buffers at once, and a cold general pool answered with a thousand hipMallocs (50 ms at 2160p).  Shared by the encoder
+ * and its pictures: a picture keeps the block costs of its estimates on the device (cuTree reads them back when it asks for one) and hands them back when it goes, from
+ * whatever thread that happens on. */
+struct LaPool
+{
+    std::mutex mu;
+    size_t one = 0;
+    std::vector<void*> freeBufs, chunks;
+    ~LaPool() { for (void* c : chunks) (void)hipFree(c); }
+    void* get()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (freeBufs.empty())
+        {
+            void* chunk = nullptr;
+            if (!one || hipMalloc(&chunk, one * 64) != hipSuccess) return nullptr;
+            chunks.push_back(chunk);
+            for (int i = 63; i >= 0; i--) freeBufs.push_back((char*)chunk + one * i);
+        }
+        void* p = freeBufs.back();
+        freeBufs.pop_back();
+        return p;
+    }
+    void put(void* p) { if (!p) return; std::lock_guard<std::mutex> lk(mu); freeBufs.push_back(p); }
+};
 
 struct Pic;
 typedef std::shared_ptr<Pic> PicP;
@@ -90,6 +118,20 @@ struct Pic
     x265amd_weight wp[2][16][3];                           /* slice.m_weightPredTable (weightAnalyse; all zero without weighted prediction) */
     bool weighted = false;                                 /* some reference of this slice carries a weight */
     bool bScenecut = false, bKeyframe = false;
+    /* ---- rate control other than constant QP (round 6): what adaptive quantisation and cuTree keep of a picture's Lowres (common/lowres.h) ---- */
+    std::vector<int32_t> intraCostHost;                     /* Lowres::intraCost per lowres block (read back once, in lowresInit) */
+    std::vector<double> qpAqOffset, qpCuTreeOffset;         /* Lowres::qpAqOffset / qpCuTreeOffset per 16x16 block (the lowres block grid) */
+    std::vector<int32_t> invQscale;                         /* Lowres::invQscaleFactor */
+    std::vector<uint16_t> propagateCost;                    /* Lowres::propagateCost */
+    /* Lowres::lowresCosts[d0][d1] of the estimates made so far (key d0 * 32 + d1): on the device where the estimate left them (dLc; dSpecLc: of estimates made ahead of their
+     * time, see specCost2), on the host once cuTree has asked for them */
+    std::map<int, void*> dLc, dSpecLc;
+    std::map<int, std::vector<uint16_t> > lcHost;
+    std::shared_ptr<LaPool> pool;
+    void dropLc(std::map<int, void*>& m, int key) { auto it = m.find(key); if (it != m.end()) { if (pool) pool->put(it->second); m.erase(it); } }
+    double avgQpRc = 0;                                     /* FrameData::m_avgQpRc: the rate control's QP before rounding (rateControlStart) */
+    bool bLastMiniGopBFrame = false;
+    std::vector<int8_t> cuQp;                               /* Analysis::calculateQpforCuSize per quantisation group down to pps.maxCuDQPDepth: per CTU 1 + 4 (+ 16) values in z order */
     const x265amd_mv_unit* regMotion = nullptr;        /* the motion field's mirror in device memory (x265amd_host.h: xa_devmap_*): what the skip chain of this and later pictures reads */
     void registerMotion()
     {
@@ -99,7 +141,7 @@ struct Pic
         if (!xa_devmap_register(regMotion, motion.size())) regMotion = nullptr;
     }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); memset(wp, 0, sizeof(wp)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
-    ~Pic() { if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
+    ~Pic() { if (pool) { for (auto& e : dLc) pool->put(e.second); for (auto& e : dSpecLc) pool->put(e.second); } if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x)
     {
         std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x;
@@ -171,6 +213,7 @@ struct x265amd_encoder
             fprintf(stderr, "x265amd: lookahead estimates by phase: set-up %.1f ms, launch call %.1f, read-back issued %.1f, waited for %.1f, host sums %.1f; %llu weight guesses measured\n", laPhaseMs[0], laPhaseMs[1], laPhaseMs[2], laPhaseMs[3], laPhaseMs[4], (unsigned long long)laWeightJobs);
         }
         if (me) x265amd_me_close(me);
+        if (rateCtl) x265amd_rc_close(rateCtl);
         if (dSaoCount) (void)hipFree(dSaoCount);
         if (dSaoOrg) (void)hipFree(dSaoOrg);
         if (dSaoParams) (void)hipFree(dSaoParams);
@@ -217,11 +260,10 @@ struct x265amd_encoder
     std::map<const void*, DevField> laFields;
     uint64_t laFieldClock = 0;
     static const size_t LA_FIELDS_MAX = 2048;
-    /* the lookahead's device buffers -- fields and per-estimate cost arrays, all of one size (a 32-bit word per lowres block) -- come from chunks of 64 of them: a first
-     * decision of a few hundred estimates asks for a thousand buffers at once, and a cold general pool answered with a thousand hipMallocs (50 ms at 2160p) */
-    std::vector<void*> laFreeBufs, laChunks;
-    void* laBuf();
-    void laBufPut(void* p) { if (p) laFreeBufs.push_back(p); }
+    /* the lookahead's device buffers (LaPool above) */
+    std::shared_ptr<LaPool> laPool;
+    void* laBuf() { return laPool->get(); }
+    void laBufPut(void* p) { laPool->put(p); }
     void laFieldPut(const void* key, void* mv, void* mc);
     void laFieldsTrim();
     void laFieldsFree();
@@ -232,8 +274,19 @@ struct x265amd_encoder
     void extendPlans(std::vector<Pic*>& frames, int length, std::vector<std::vector<uint8_t> >& plans, int& rc);
     bool scenecutInternal(std::vector<Pic*>& frames, int p0, int p1, bool real, int& rc);
     bool scenecut(std::vector<Pic*>& frames, int p0, int p1, bool real, int numFrames, int& rc);
-    int slicetypeAnalyse(std::vector<Pic*>& frames);
+    int slicetypeAnalyse(std::vector<Pic*>& frames, bool bKeyframe = false);
     int decideLookahead(bool flush, int maxGops = 1 << 30);
+    /* ---- rate control other than constant QP (round 6; include/x265amd_ratecontrol.h) ---- */
+    x265amd_rc* rateCtl = nullptr;                         /* RateControl, the constant-rate-factor branch */
+    bool useDqp = false; int maxCuDqpDepth = 0;         /* pps.bUseDQP / maxCuDQPDepth (encoder.cpp:3461-3469: with adaptive quantisation) */
+    bool aqOn = false;
+    void* aqEnergy = nullptr; void* aqEnergyHost = nullptr; void* aqSums = nullptr;      /* x265amd_aq_energy's outputs (the encoder's for good) */
+    x265amd_cutree_params treeParams;
+    int adaptiveQuant(Pic& pic);
+    int runCuTree(std::vector<Pic*>& frames, int numframes, bool bIntra);
+    static int cuTreeEstimate(void* ctx, int p0, int p1, int b, const uint16_t** lc, const int16_t** mvs0, const int16_t** mvs1);
+    int64_t estimatedPictureCost(Pic& pic);
+    void cuQpTable(Pic& pic);
     int filterRows(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
     int filterRowsCols(Pic& pic, const x265amd_slice_info& si, const x265amd_mvpred_info& info, std::vector<x265amd_sao_ctu>& sparams, int32_t* saoFlags);
 };
@@ -244,7 +297,8 @@ extern "C" void x265amd_param_default(x265amd_param* p)
     if (!p) return;
     memset(p, 0, sizeof(*p));
     p->fpsNum = 25; p->fpsDenom = 1;
-    p->bframes = 0; p->keyframeMax = 250; p->maxNumReferences = 3; p->qp = 30; p->ipFactor = 1.4; p->pbFactor = 1.3;
+    p->bframes = 0; p->keyframeMax = 250; p->maxNumReferences = 3; p->qp = 30; p->ipFactor = 1.4f; p->pbFactor = 1.3f;      /* (float literals, as common/param.cpp:276-277 has them) */
+    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32;
     p->rdLevel = 3; p->limitReferences = 3; p->bEnableEarlySkip = 1; p->recursionSkipMode = 1; p->bIntraInBFrames = 1; p->psyRd = 2.0;
     p->searchMethod = X265AMD_ME_HEX; p->subpelRefine = 2; p->searchRange = 57; p->maxNumMergeCand = 3;
     p->bEnableSignHiding = 1; p->bEnableStrongIntraSmoothing = 1; p->bEnableTemporalMvp = 1; p->tuQTMaxInterDepth = 1; p->tuQTMaxIntraDepth = 1;
@@ -289,6 +343,7 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.emit_timing_info = 1; s.num_units_in_tick = p.fpsDenom; s.time_scale = p.fpsNum;
     s.weighted_pred = p.bEnableWeightedPred != 0; s.weighted_bipred = p.bEnableWeightedBiPred != 0;
     s.sign_hide = p.bEnableSignHiding != 0; s.num_ref_idx_default[0] = s.num_ref_idx_default[1] = 1; s.init_qp_minus26 = 0;
+    s.use_dqp = useDqp; s.max_cu_dqp_depth = maxCuDqpDepth;           /* Encoder::initPPS (encoder.cpp:3424-3445) */
     s.wpp = p.bEnableWavefront != 0; s.loop_filter_across_slices = 1;
     s.deblocking_filter_control_present = !p.bEnableLoopFilter; s.pic_disable_deblocking = !p.bEnableLoopFilter;
 }
@@ -307,7 +362,17 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->bframes >= 0 && p->bframes <= 16, "bframes outside 0..16");
         XA_REQUIRE(p->keyframeMax >= 1, "keyframeMax below 1");
         XA_REQUIRE(p->maxNumReferences >= 1 && p->maxNumReferences <= 8, "maxNumReferences outside 1..8");
-        XA_REQUIRE(p->qp >= 0 && p->qp <= 51, "qp outside 0..51 (constant QP is the only rate control built)");
+        XA_REQUIRE(p->rateControlMode == 0 || p->rateControlMode == X265AMD_RC_CQP || p->rateControlMode == X265AMD_RC_CRF, "rc.rateControlMode: constant QP (1) and constant rate factor (2) are built, ABR (0 with a bitrate) is not");
+        XA_REQUIRE(p->rateControlMode == X265AMD_RC_CRF || (p->qp >= 0 && p->qp <= 51), "qp outside 0..51");
+        XA_REQUIRE(p->rateControlMode != X265AMD_RC_CRF || (p->rfConstant >= 0 && p->rfConstant <= 51), "rfConstant outside 0..51");
+        XA_REQUIRE(p->aqMode >= 0 && p->aqMode <= 3, "aqMode outside 0..3 (the edge-based modes are not built)");
+        XA_REQUIRE(!p->aqMode || p->aqStrength > 0, "aqStrength must be positive with aqMode (0 switches adaptive quantisation off in the reference: say aqMode 0)");
+        XA_REQUIRE(!p->aqMode || p->qgSize == 32 || p->qgSize == 64, "qgSize: 64 and 32 are built");
+        XA_REQUIRE(!p->cuTree || p->aqMode, "cuTree needs adaptive quantisation (Encoder::configure switches it on with cuTree; say aqMode)");
+        XA_REQUIRE(!p->cuTree || p->rateControlMode == X265AMD_RC_CRF, "cuTree needs rate control (the reference switches it off under constant QP, encoder.cpp:3721-3728)");
+        XA_REQUIRE(!p->cuTree || p->lookaheadDepth > 0, "cuTree needs the lookahead (lookaheadDepth > 0)");
+        XA_REQUIRE(!(p->aqMode && p->rateControlMode != X265AMD_RC_CRF), "adaptive quantisation needs rate control (the reference switches it off under constant QP, encoder.cpp:3721-3728)");
+        XA_REQUIRE(!(p->rateControlMode == X265AMD_RC_CRF && p->shardCount > 1), "frame-per-GPU with rate control is not built");
         XA_REQUIRE(p->rdLevel >= 2 && p->rdLevel <= 6, "rdLevel outside 2..6 (rd 0-1 are not built)");
         XA_REQUIRE(p->maxNumMergeCand >= 1 && p->maxNumMergeCand <= 5, "maxNumMergeCand outside 1..5");
         XA_REQUIRE(p->tuQTMaxInterDepth >= 1 && p->tuQTMaxInterDepth <= 4, "tuQTMaxInterDepth outside 1..4");
@@ -350,7 +415,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     if (p->shardCount < 0 || p->shardCount > 64 || (p->shardCount > 1 && (p->shardRank < 0 || p->shardRank >= p->shardCount || p->frameNumThreads <= 1)))
     { xa_fail(X265AMD_EINVAL, "encoder_open: shardRank / shardCount (frame-per-GPU needs 0 <= rank < count and frameNumThreads > 1: rows are published by pictures coded in parallel)"); return nullptr; }
     if (p->bFrameAdaptive < 0 || p->bFrameAdaptive > 2) { xa_fail(X265AMD_EINVAL, "encoder_open: bFrameAdaptive: 0 (fixed mini-GOPs), 1 (fast) or 2 (trellis)"); return nullptr; }
-    e->lookahead = p->scenecutThreshold > 0 || (p->bFrameAdaptive && p->bframes);
+    e->lookahead = p->scenecutThreshold > 0 || (p->bFrameAdaptive && p->bframes) || p->cuTree || p->aqMode;
     if ((p->bEnableWeightedPred || p->bEnableWeightedBiPred) && !e->lookahead) { xa_fail(X265AMD_EINVAL, "encoder_open: bEnableWeightedPred needs the lookahead (scenecutThreshold > 0 or bFrameAdaptive 2 with B frames)"); return nullptr; }
     {
         /* Encoder::configure (encoder.cpp:3658-3663) */
@@ -410,6 +475,25 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     }
     e->me = x265amd_me_open();
     if (!e->me) return nullptr;
+    e->laPool.reset(new LaPool);
+    e->laPool->one = (((size_t)e->lowCuW * e->lowCuH * 4) + 255) & ~(size_t)255;
+    /* adaptive quantisation, cuTree, the rate factor (Encoder::configure / initPPS, RateControl::RateControl, Lookahead::Lookahead) */
+    e->aqOn = p->aqMode != 0 && p->rateControlMode == X265AMD_RC_CRF;
+    e->useDqp = e->aqOn;
+    e->maxCuDqpDepth = e->aqOn ? (p->qgSize == 64 ? 0 : 1) : 0;
+    memset(&e->treeParams, 0, sizeof(e->treeParams));
+    e->treeParams.width8 = e->lowCuW; e->treeParams.height8 = e->lowCuH; e->treeParams.fps_num = p->fpsNum; e->treeParams.fps_denom = p->fpsDenom;
+    e->treeParams.b_pyramid = p->bBPyramid != 0; e->treeParams.weighted_bipred = p->bEnableWeightedBiPred != 0; e->treeParams.lookahead_depth = p->lookaheadDepth;
+    e->treeParams.strength = 5.0 * (1.0 - p->qCompress);
+    if (p->rateControlMode == X265AMD_RC_CRF)
+    {
+        x265amd_rc_params rp;
+        memset(&rp, 0, sizeof(rp));
+        rp.width = e->W; rp.height = e->H; rp.fps_num = p->fpsNum; rp.fps_denom = p->fpsDenom; rp.bframes = p->bframes; rp.keyframe_max = p->keyframeMax; rp.cu_tree = p->cuTree != 0;
+        rp.qp_min = 0; rp.qp_max = 69; rp.rf_constant = p->rfConstant; rp.q_compress = p->qCompress; rp.ip_factor = p->ipFactor; rp.pb_factor = p->pbFactor;
+        e->rateCtl = x265amd_rc_open(&rp);
+        if (!e->rateCtl) { xa_fail(X265AMD_EINVAL, "encoder_open: rate control parameters"); return nullptr; }
+    }
     const size_t nstat = (size_t)e->nctu * 3 * 5 * 32;
     if (hipMalloc((void**)&e->dSaoCount, nstat * 4) != hipSuccess || hipMalloc((void**)&e->dSaoOrg, nstat * 4) != hipSuccess ||
         hipMalloc((void**)&e->dSaoParams, sizeof(x265amd_sao_ctu) * e->nctu) != hipSuccess ||
@@ -629,7 +713,7 @@ int x265amd_encoder::lowresInit(Pic& pic)
     /* the picture's sums for the weight analysis are measured in front of the one wait of this function */
     static const char* const dbgWp = getenv("X265AMD_WP_DEBUG");          /* debugging aid: letters s / l / p switch the sums, the lookahead's analysis, the slice's analysis off */
     const bool sums = (p.bEnableWeightedPred || p.bEnableWeightedBiPred) && !(dbgWp && strchr(dbgWp, 's'));
-    if (sums)
+    if (sums && !aqOn)
     {
         /* LookaheadTLD::calcAdaptiveQuantFrame with AQ off (slicetype.cpp:507-513): acEnergyCu over every 16x16 block for Lowres::wp_sum / wp_ssd, then :678-700 */
         const int bw = (W + 15) / 16, bh = (H + 15) / 16;
@@ -641,9 +725,19 @@ int x265amd_encoder::lowresInit(Pic& pic)
         if (rc == X265AMD_OK && hipMemcpyAsync(wpSumsHost, wpSums, 6 * 8, hipMemcpyDeviceToHost, laStream) != hipSuccess) rc = xa_fail(X265AMD_EHIP, "encoder_encode: picture sums");
         if (rc != X265AMD_OK) return rc;
     }
+    if (aqOn && (rc = adaptiveQuant(pic)) != X265AMD_OK) return rc;
     std::vector<int32_t> ic((size_t)lowCuW * lowCuH);
     if (hipMemcpyAsync(ic.data(), pic.dIntraCost, ic.size() * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess || hipStreamSynchronize(laStream) != hipSuccess)
         return xa_fail(X265AMD_EHIP, "encoder_encode: lowres intra costs");
+    if (aqOn)
+    {
+        /* the rest of calcAdaptiveQuantFrame (slicetype.cpp:513-640) on the block energies that have arrived with the intra costs */
+        const int bw = (W + 15) / 16, bh = (H + 15) / 16, nb = bw * bh;
+        pic.qpAqOffset.assign((size_t)nb, 0.0); pic.qpCuTreeOffset.assign((size_t)nb, 0.0); pic.invQscale.assign((size_t)nb, 256);
+        rc = x265amd_aq_offsets((const uint32_t*)aqEnergyHost, nb, lowCuW * lowCuH, p.aqMode, p.aqStrength, 1.0, 16, pic.qpAqOffset.data(), pic.qpCuTreeOffset.data(), pic.invQscale.data());
+        if (rc != X265AMD_OK) return xa_fail(rc, "encoder_encode: adaptive quantisation");
+        if (p.cuTree) { pic.intraCostHost = ic; pic.propagateCost.assign((size_t)lowCuW * lowCuH, 0); }
+    }
     int64_t est = 0;
     const bool all = lowCuW <= 2 || lowCuH <= 2;
     for (int y = 0; y < lowCuH; y++)
@@ -653,7 +747,7 @@ int x265amd_encoder::lowresInit(Pic& pic)
     if (sums)
     {
         uint64_t wp[6];
-        memcpy(wp, wpSumsHost, sizeof(wp));
+        memcpy(wp, aqOn ? (const void*)((const char*)aqEnergyHost + (size_t)((W + 15) / 16) * ((H + 15) / 16) * 4) : wpSumsHost, sizeof(wp));
         const int maxCol = ((W + 8) >> 4) << 4, maxRow = ((H + 8) >> 4) << 4;
         const int width[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, height[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
         for (int i = 0; i < 3; i++)
@@ -663,6 +757,25 @@ int x265amd_encoder::lowresInit(Pic& pic)
             pic.wpSsd[i] = ssd - (sum * sum + (uint64_t)((width[i] * height[i]) / 2)) / (uint64_t)(width[i] * height[i]);
         }
     }
+    return X265AMD_OK;
+}
+
+/* LookaheadTLD::calcAdaptiveQuantFrame's block loop (slicetype.cpp:560-600): acEnergyCu of every 16x16 block (luma + both chroma blocks) and the picture's sums for the weight
+ * analysis, enqueued on the lookahead's stream with their read-back; the caller waits for the stream once (lowresInit) and turns the energies into offsets */
+int x265amd_encoder::adaptiveQuant(Pic& pic)
+{
+    const int bw = (W + 15) / 16, bh = (H + 15) / 16;
+    const size_t nb = (size_t)bw * bh;
+    if (!aqEnergy && (xa_scratch_alloc(&aqEnergy, nb * 4) != hipSuccess || xa_scratch_alloc(&aqSums, 6 * 8) != hipSuccess || xa_mapped_alloc(&aqEnergyHost, nb * 4 + 6 * 8, true) != hipSuccess))
+        return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+    if ((p.bEnableWeightedPred || p.bEnableWeightedBiPred) && !wpMvs && xa_mapped_alloc(&wpMvs, (size_t)lowCuW * lowCuH * 4, false) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+    const uint64_t srcP[3] = { planeAddr(pic.dSrc, 0), planeAddr(pic.dSrc, 1), planeAddr(pic.dSrc, 2) };
+    int rc = x265amd_aq_energy(laStream, srcP, stride, cstride, W, H, 16, (uint32_t*)aqEnergy, (uint64_t*)aqSums);
+    if (rc != X265AMD_OK) return rc;
+    if (hipMemcpyAsync(aqEnergyHost, aqEnergy, nb * 4, hipMemcpyDeviceToHost, laStream) != hipSuccess ||
+        hipMemcpyAsync((char*)aqEnergyHost + nb * 4, aqSums, 6 * 8, hipMemcpyDeviceToHost, laStream) != hipSuccess)
+        return xa_fail(X265AMD_EHIP, "encoder_encode: block energies");
     return X265AMD_OK;
 }
 
@@ -919,6 +1032,12 @@ int x265amd_encoder::frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1
     if (fenc.specCost2[d0][d1] >= 0 && !fenc.lowMvs[d0].empty() && (d1 == 0 || !fenc.lowMvs1[d1].empty()))
     {
         score = fenc.cost2[d0][d1] = fenc.specCost2[d0][d1];
+        {
+            /* ... and its block costs (cuTree) */
+            const int key = d0 * 32 + d1;
+            auto it = fenc.dSpecLc.find(key);
+            if (it != fenc.dSpecLc.end()) { fenc.dropLc(fenc.dLc, key); fenc.dLc[key] = it->second; fenc.dSpecLc.erase(it); fenc.lcHost.erase(key); }
+        }
         if (d1 == 0) { fenc.costEst[d0] = score; fenc.intraMbs[d0] = fenc.specIntraMbs[d0]; }
         return X265AMD_OK;
     }
@@ -929,20 +1048,6 @@ int x265amd_encoder::frameCostAt(Pic& fenc, Pic& ref0, Pic* ref1, int d0, int d1
     return rc;
 }
 
-void* x265amd_encoder::laBuf()
-{
-    if (laFreeBufs.empty())
-    {
-        const size_t one = (((size_t)lowCuW * lowCuH * 4) + 255) & ~(size_t)255;
-        void* chunk = nullptr;
-        if (hipMalloc(&chunk, one * 64) != hipSuccess) return nullptr;
-        laChunks.push_back(chunk);
-        for (int i = 63; i >= 0; i--) laFreeBufs.push_back((char*)chunk + one * i);
-    }
-    void* p = laFreeBufs.back();
-    laFreeBufs.pop_back();
-    return p;
-}
 void x265amd_encoder::laFieldPut(const void* key, void* mv, void* mc)
 {
     auto it = laFields.find(key);
@@ -962,10 +1067,8 @@ void x265amd_encoder::laFieldsTrim()
 }
 void x265amd_encoder::laFieldsFree()
 {
+    for (auto& f : laFields) { laBufPut(f.second.mv); laBufPut(f.second.mc); }
     laFields.clear();
-    laFreeBufs.clear();
-    for (void* c : laChunks) (void)hipFree(c);
-    laChunks.clear();
 }
 
 /* Independent estimates side by side: every job on one of a handful of streams (the block loop of an estimate is a few dozen wavefronts chained row to row -- latency,
@@ -1105,10 +1208,19 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
     for (size_t k = 0; k < issued; k++)
     {
         CostJob& j = jobs[k];
-        void* bufs[6] = { j.dMvs, j.dMvc, j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
+        void* keepLc = (rc == X265AMD_OK && p.cuTree) ? j.dLc : nullptr;            /* Lowres::lowresCosts[d0][d1]: stays with the picture (cuTree reads it) */
+        void* bufs[6] = { j.dMvs, j.dMvc, keepLc ? nullptr : j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
         for (void* b : bufs) laBufPut(b);
         xa_scratch_free(j.dW);
         j.dMvs = j.dMvc = j.dLc = j.dBc = j.dMvs1 = j.dMvc1 = j.dW = nullptr;
+        if (keepLc)
+        {
+            const int key = j.d0 * 32 + j.d1;
+            std::map<int, void*>& m = j.spec ? j.fenc->dSpecLc : j.fenc->dLc;
+            j.fenc->dropLc(m, key);
+            m[key] = keepLc;
+            if (!j.spec) j.fenc->lcHost.erase(key);
+        }
         if (rc != X265AMD_OK)
         {
             if (j.search0) { (j.spec ? j.fenc->specMvs : j.fenc->lowMvs)[j.d0].clear(); (j.spec ? j.fenc->specMvc : j.fenc->lowMvc)[j.d0].clear(); }
@@ -1119,8 +1231,8 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
         if (j.d1 > 0) est = est * 100 / (130 + 0);          /* param.bFrameBias: the default */
         if (j.spec) { j.fenc->specCost2[j.d0][j.d1] = est; if (j.d1 == 0) j.fenc->specIntraMbs[j.d0] = imb; continue; }
         /* a field made for good replaces whatever was made ahead of its time for the same pair, and the estimates that were built on that */
-        if (j.search0) { j.fenc->specMvs[j.d0].clear(); j.fenc->specMvc[j.d0].clear(); for (int t = 0; t < 18; t++) j.fenc->specCost2[j.d0][t] = -1; }
-        if (j.search1) { j.fenc->specMvs1[j.d1].clear(); j.fenc->specMvc1[j.d1].clear(); for (int t = 0; t < 18; t++) j.fenc->specCost2[t][j.d1] = -1; }
+        if (j.search0) { j.fenc->specMvs[j.d0].clear(); j.fenc->specMvc[j.d0].clear(); for (int t = 0; t < 18; t++) { j.fenc->specCost2[j.d0][t] = -1; j.fenc->dropLc(j.fenc->dSpecLc, j.d0 * 32 + t); } }
+        if (j.search1) { j.fenc->specMvs1[j.d1].clear(); j.fenc->specMvc1[j.d1].clear(); for (int t = 0; t < 18; t++) { j.fenc->specCost2[t][j.d1] = -1; j.fenc->dropLc(j.fenc->dSpecLc, t * 32 + j.d1); } }
         j.fenc->cost2[j.d0][j.d1] = est;
         if (j.d1 == 0) { j.fenc->costEst[j.d0] = est; j.fenc->intraMbs[j.d0] = imb; }
     }
@@ -1245,15 +1357,16 @@ bool x265amd_encoder::scenecut(std::vector<Pic*>& frames, int p0, int p1, bool r
     return scenecutInternal(frames, p0, p1, real, rc);
 }
 
-/* Lookahead::slicetypeAnalyse(frames, bKeyframe = false) (slicetype.cpp:2603-2919) for bFrameAdaptive 0, closed GOPs, no cuTree / VBV / zones / gop-lookahead:
- * frames[0] = the last non-B picture, frames[1..] = the undecided pictures of the window */
-int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
+/* Lookahead::slicetypeAnalyse(frames, bKeyframe) (slicetype.cpp:2603-2919) without VBV / zones / gop-lookahead: frames[0] = the last non-B picture, frames[1..] = the
+ * undecided pictures of the window.  bKeyframe: the pass behind a keyframe's mini-GOP that cuTree adds (slicetype.cpp:2469-2483): the same analysis with the keyframe as
+ * frames[0], cuTree down to the keyframe itself, and every type taken back afterwards */
+int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames, bool bKeyframe)
 {
     const int maxSearch = std::min(p.lookaheadDepth, 250);
     int framecnt = 0;
     for (; framecnt < maxSearch; framecnt++)
         if (framecnt + 1 >= (int)frames.size() || frames[framecnt + 1]->type != TYPE_AUTO) break;
-    if (!framecnt) return X265AMD_OK;
+    if (!framecnt) return p.cuTree ? runCuTree(frames, 0, bKeyframe) : X265AMD_OK;
     frames.resize((size_t)framecnt + 1);
     const int keyFrameLimit = p.keyframeMax + lastKeyframe - frames[0]->poc - 1, keyintLimit = keyFrameLimit;
     const int origNumFrames = std::min(framecnt, keyintLimit);
@@ -1410,13 +1523,15 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
             if (rc != X265AMD_OK) return rc;
             if (cut) { frames[j]->type = TYPE_P; numAnalyzed = j; break; }
         }
-        resetStart = std::min(numBFrames + 2, numAnalyzed + 1);
+        resetStart = bKeyframe ? 1 : std::min(numBFrames + 2, numAnalyzed + 1);
     }
     else
     {
         for (int j = 1; j <= numFrames; j++) frames[j]->type = TYPE_P;
-        resetStart = 2;
+        resetStart = bKeyframe ? 1 : 2;
     }
+    /* cuTree on the window as it is typed now (slicetype.cpp:2893-2894) */
+    if (p.cuTree && (rc = runCuTree(frames, std::min(numFrames, p.keyframeMax), bKeyframe)) != X265AMD_OK) return rc;
     for (int j = keyintLimit + 1; j <= numFrames; j += p.keyframeMax) { frames[j]->type = TYPE_I; resetStart = std::min(resetStart, j + 1); }
     const int maxp1 = std::min(p.bframes + 1, origNumFrames);
     /* Restore frame types for all frames that haven't actually been decided yet. */
@@ -1428,11 +1543,62 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames)
     return X265AMD_OK;
 }
 
+/* CostEstimateGroup::singleCost(p0, p1, b) for Lookahead::cuTree (x265amd_cutree's callback): the estimate is made if it does not exist (with the searches its fields
+ * lack), its block costs come back from the device once, the fields are the picture's */
+namespace { struct TreeCtx { x265amd_encoder* e; std::vector<Pic*>* frames; }; }
+int x265amd_encoder::cuTreeEstimate(void* ctx, int p0, int p1, int b, const uint16_t** lc, const int16_t** mvs0, const int16_t** mvs1)
+{
+    TreeCtx& t = *(TreeCtx*)ctx;
+    x265amd_encoder& e = *t.e;
+    std::vector<Pic*>& frames = *t.frames;
+    if (p0 < 0 || b < p0 || p1 < b || p1 >= (int)frames.size() || b - p0 > 17 || p1 - b > 17 || b == p0) return xa_fail(X265AMD_EINVAL, "encoder: cuTree estimate");
+    int64_t score = 0;
+    const int rc = e.frameCost(frames, p0, p1, b, score);
+    if (rc != X265AMD_OK) return rc;
+    Pic& f = *frames[b];
+    const int d0 = b - p0, d1 = p1 - b, key = d0 * 32 + d1;
+    auto h = f.lcHost.find(key);
+    if (h == f.lcHost.end())
+    {
+        auto d = f.dLc.find(key);
+        if (d == f.dLc.end()) return xa_fail(X265AMD_EHIP, "encoder: cuTree: the block costs of an estimate are gone");
+        std::vector<uint16_t> v((size_t)e.lowCuW * e.lowCuH);
+        if (hipMemcpyAsync(v.data(), d->second, v.size() * 2, hipMemcpyDeviceToHost, e.laStream) != hipSuccess || hipStreamSynchronize(e.laStream) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder: cuTree: block costs");
+        h = f.lcHost.emplace(key, std::move(v)).first;
+    }
+    *lc = h->second.data();
+    *mvs0 = f.lowMvs[d0].empty() ? nullptr : f.lowMvs[d0].data();
+    *mvs1 = d1 > 0 && !f.lowMvs1[d1].empty() ? f.lowMvs1[d1].data() : nullptr;
+    return 0;
+}
+/* Lookahead::cuTree(frames, numframes, bIntra) (slicetype.cpp:3399-3500): host/fm_ratecontrol.cpp on the pictures' host arrays */
+int x265amd_encoder::runCuTree(std::vector<Pic*>& frames, int numframes, bool bIntra)
+{
+    if (numframes >= (int)frames.size()) numframes = (int)frames.size() - 1;
+    std::vector<x265amd_cutree_frame> recs(frames.size());
+    std::vector<x265amd_cutree_frame*> ptrs(frames.size());
+    for (size_t k = 0; k < frames.size(); k++)
+    {
+        Pic& f = *frames[k];
+        if (f.intraCostHost.empty() || f.qpAqOffset.empty()) return xa_fail(X265AMD_EINVAL, "encoder: cuTree: a picture without block offsets");
+        x265amd_cutree_frame& r = recs[k];
+        memset(&r, 0, sizeof(r));
+        r.slice_type = f.type; r.intra_cost = f.intraCostHost.data(); r.inv_qscale = f.invQscale.data(); r.qp_aq_offset = f.qpAqOffset.data();
+        r.qp_cutree_offset = f.qpCuTreeOffset.data(); r.propagate_cost = f.propagateCost.data(); r.weighted_cost_delta = nullptr;       /* (Lowres::weightedCostDelta is an integer quotient below one: always 0, slicetype.cpp:964) */
+        ptrs[k] = &r;
+    }
+    TreeCtx ctx{ this, &frames };
+    const int rc = x265amd_cutree(&treeParams, ptrs.data(), numframes, bIntra, cuTreeEstimate, &ctx);
+    return rc == X265AMD_OK ? X265AMD_OK : xa_fail(rc, "encoder: cuTree");
+}
+
 /* The typed mini-GOP input[0 .. b] goes to `ready` in coding order (slicetype.cpp:2372-2376, :2443-2470): with a B pyramid and two B pictures or more the middle one
  * becomes a reference (Lookahead::placeBref: index (0 + b) / 2); the non-B picture first, then the referenced B picture, then the other B pictures in display order */
 void x265amd_encoder::pushMiniGop(int b)
 {
     if (p.bBPyramid && b > 1) input[b / 2]->type = TYPE_BREF;
+    if (b > 0) input[b - 1]->bLastMiniGopBFrame = true;
     ready.push_back(input[b]);
     for (int i = 0; i < b; i++) if (input[i]->type == TYPE_BREF) ready.push_back(input[i]);
     for (int i = 0; i < b; i++) if (input[i]->type != TYPE_BREF) ready.push_back(input[i]);
@@ -1451,6 +1617,7 @@ int x265amd_encoder::decideLookahead(bool flush, int maxGops)
         std::vector<Pic*> frames;
         frames.push_back(lastNonB.get());
         for (int j = 0; j < maxSearch && j < (int)input.size(); j++) frames.push_back(input[j].get());
+        const int windowCount = (int)frames.size() - 1;         /* the reference's maxSearch: the pictures this decision looks at */
         if (lastNonB)
         {
             const int rc = slicetypeAnalyse(frames);
@@ -1482,8 +1649,54 @@ int x265amd_encoder::decideLookahead(bool flush, int maxGops)
             }
             else break;
         }
+        if (p.rateControlMode == X265AMD_RC_CRF)
+        {
+            /* "calculate the frame costs ahead of time for estimateFrameCost while we still have lowres" (slicetype.cpp:2396-2440): the estimate of every picture of the
+             * mini-GOP against the pictures it will reference -- made now if the decision above did not need it, with the searches its fields lack (the encoder's searches
+             * take candidates from those fields, and cuTree and the rate control read the estimates) */
+            if (p.bBPyramid && b > 1) input[b / 2]->type = TYPE_BREF;          /* placeBref comes first (:2386-2389) */
+            std::vector<Pic*> est;
+            est.push_back(lastNonB.get());
+            for (int i = 0; i <= b; i++) est.push_back(input[i].get());
+            int64_t score = 0;
+            const int p1n = b + 1;
+            const bool isI = est[p1n]->type == TYPE_I || est[p1n]->type == TYPE_IDR;
+            if (!isI && est[0])
+            {
+                const int rc = frameCost(est, 0, p1n, p1n, score);
+                if (rc != X265AMD_OK) return rc;
+            }
+            if (b && est[0])
+            {
+                int p0 = 0;
+                bool isp0available = est[p1n]->type != TYPE_IDR;
+                for (int bb = 1; bb <= b; bb++)
+                {
+                    if (!isp0available) p0 = bb;
+                    int p1;
+                    if (est[bb]->type == TYPE_B) for (p1 = bb; est[p1]->type == TYPE_B; p1++) { }
+                    else p1 = b + 1;
+                    if (p0 != bb)
+                    {
+                        const int rc = frameCost(est, p0, p1, bb, score);
+                        if (rc != X265AMD_OK) return rc;
+                    }
+                    if (est[bb]->type == TYPE_BREF) { p0 = bb; isp0available = true; }
+                }
+            }
+        }
         lastNonB = input[b];
         pushMiniGop(b);
+        if (p.cuTree && (lastNonB->type == TYPE_I || lastNonB->type == TYPE_IDR))
+        {
+            /* the keyframe's own pass (slicetype.cpp:2469-2483): the pictures of the window that are left, behind the keyframe */
+            std::vector<Pic*> kf;
+            kf.push_back(lastNonB.get());
+            const int left = windowCount - (b + 1);
+            for (int j = 0; j < left && j < (int)input.size(); j++) kf.push_back(input[j].get());
+            const int rc = slicetypeAnalyse(kf, true);
+            if (rc != X265AMD_OK) return rc;
+        }
     }
     return X265AMD_OK;
 }
@@ -1587,6 +1800,28 @@ int x265amd_encoder::prepare(const PicP& picp)
         const int rcw = sliceWeights(pic);
         if (rcw != X265AMD_OK) return rcw;
     }
+    if (rateCtl)
+    {
+        /* RateControl::rateControlStart, constant rate factor (coding order is the reference's m_startEndOrder; nothing it reads depends on how a picture was coded) */
+        x265amd_rc_frame f;
+        memset(&f, 0, sizeof(f));
+        f.slice_type = stype; f.is_referenced = pic.type != TYPE_B; f.poc = pic.poc; f.scenecut = pic.bScenecut; f.last_minigop_b = pic.bLastMiniGopBFrame;
+        if (stype != 2) f.ref0_scenecut = pic.lists[0][0]->bScenecut;
+        f.satd_cost = estimatedPictureCost(pic);
+        if (stype == 0)
+            for (int l = 0; l < 2; l++)
+            {
+                const Pic& q = *pic.lists[l][0];
+                f.ref_slice_type[l] = isBType(q.type) ? 0 : q.type == TYPE_P ? 1 : 2; f.ref_poc[l] = q.poc; f.ref_is_referenced[l] = q.type != TYPE_B; f.ref_avg_qp_rc[l] = q.avgQpRc;
+            }
+        const int qp = x265amd_rc_start(rateCtl, &f, &pic.avgQpRc);
+        if (qp < 0) return xa_fail(X265AMD_EINVAL, "encoder_encode: rate control");
+        pic.sliceQp = std::min(qp, 51);             /* FrameEncoder::compressFrame clips the slice QP to the range the syntax carries (frameencoder.cpp:612) */
+        if (useDqp) cuQpTable(pic);
+        static const bool rcLog = getenv("X265AMD_RC_LOG") != nullptr;
+        if (rcLog) fprintf(stderr, "x265amd rc: poc %d type %d qp %d avgQpRc %.9f satd %lld scenecut %d\n", pic.poc, pic.type, pic.sliceQp, pic.avgQpRc, (long long)f.satd_cost, (int)pic.bScenecut);
+    }
+    else
     pic.sliceQp = pic.type == TYPE_BREF ? (qpConstant[0] + qpConstant[1]) / 2 : qpConstant[stype];                    /* rateControlStart, CQP (ratecontrol.cpp:1594-1597: a referenced B picture lies between B and P) */
     picList.insert(picList.begin(), picp);              /* PicList::pushFront */
     if (frameParallel)
@@ -1604,6 +1839,60 @@ int x265amd_encoder::prepare(const PicP& picp)
         pic.analysedCols.assign(ctuH, 0);
     }
     return 0;
+}
+
+/* Lookahead::getEstimatedPictureCost (slicetype.cpp:1327-1439) as far as the constant rate factor reads it (Lowres::satdCost: RateControl only asks whether it is zero unless
+ * cuTree is off): I and P pictures -- with cuTree the estimate's block costs rescaled by the cuTree offsets (frameCostRecalculate), without it the plain estimate (the
+ * reference's costEstAq differs from it by the AQ weights; B pictures, whose QP does not read it, get the plain estimate too) */
+int64_t x265amd_encoder::estimatedPictureCost(Pic& pic)
+{
+    const int stype = isBType(pic.type) ? 0 : pic.type == TYPE_P ? 1 : 2;
+    if (stype == 2)
+    {
+        if (!p.cuTree || pic.intraCostHost.empty()) return std::max<int64_t>(pic.costEst[0], 1);
+        std::vector<uint16_t> lc(pic.intraCostHost.size());
+        for (size_t i = 0; i < lc.size(); i++) lc[i] = (uint16_t)std::min(pic.intraCostHost[i], (1 << 14) - 1);        /* lowresIntraEstimate: lowresCosts[0][0] (slicetype.cpp:806) */
+        return x265amd_frame_cost_recalculate(&treeParams, lc.data(), pic.qpCuTreeOffset.data());
+    }
+    const int d0 = pic.poc - pic.lists[0][0]->poc;
+    if (stype == 1 && p.cuTree && d0 > 0 && d0 < 18)
+    {
+        const int key = d0 * 32;
+        auto h = pic.lcHost.find(key);
+        if (h == pic.lcHost.end())
+        {
+            auto d = pic.dLc.find(key);
+            if (d != pic.dLc.end())
+            {
+                std::vector<uint16_t> v((size_t)lowCuW * lowCuH);
+                if (hipMemcpyAsync(v.data(), d->second, v.size() * 2, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipStreamSynchronize(laStream) == hipSuccess)
+                    h = pic.lcHost.emplace(key, std::move(v)).first;
+            }
+        }
+        if (h != pic.lcHost.end()) return x265amd_frame_cost_recalculate(&treeParams, h->second.data(), pic.qpCuTreeOffset.data());
+    }
+    if (d0 > 0 && d0 < 18 && pic.costEst[d0] > 0) return pic.costEst[d0];
+    return 1;
+}
+
+/* Analysis::calculateQpforCuSize (analysis.cpp:3634-3714) for every quantisation group of the picture, ahead of the analysis: per CTU the QP of the 64x64 CU, then (qgSize 32)
+ * of its four 32x32 CUs in z order -- values up to 69 (what setLambdaFromQP is given; it clips the QP that is coded to 51).  A referenced picture with cuTree takes the cuTree
+ * offsets, every other picture the adaptive quantisation's. */
+void x265amd_encoder::cuQpTable(Pic& pic)
+{
+    const int per = maxCuDqpDepth >= 1 ? 5 : 1;
+    pic.cuQp.assign((size_t)nctu * per, (int8_t)pic.sliceQp);
+    const double* offs = (p.cuTree && pic.type != TYPE_B) ? pic.qpCuTreeOffset.data() : pic.qpAqOffset.data();
+    for (int a = 0; a < nctu; a++)
+    {
+        const int x = (a % ctuW) * 64, y = (a / ctuW) * 64;
+        pic.cuQp[(size_t)a * per] = (int8_t)x265amd_cu_qp(pic.avgQpRc, offs, W, H, x, y, 64, 0, 69);
+        for (int q = 0; q < 4 && per == 5; q++)
+        {
+            const int cx = x + (q & 1) * 32, cy = y + (q >> 1) * 32;
+            if (cx < W && cy < H) pic.cuQp[(size_t)a * per + 1 + q] = (int8_t)x265amd_cu_qp(pic.avgQpRc, offs, W, H, cx, cy, 32, 0, 69);
+        }
+    }
 }
 
 /* what the analysis and the slice header of one picture need, derived from the picture's lists (DPB::prepareEncode has run) */
@@ -1701,6 +1990,7 @@ static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
     si.pic_width = e.W; si.pic_height = e.H; si.slice_type = stype; si.slice_qp = pic.sliceQp;
     si.num_ref_idx[0] = info.num_ref_idx[0]; si.num_ref_idx[1] = info.num_ref_idx[1];
     si.max_num_merge_cand = p.maxNumMergeCand; si.sign_hide = p.bEnableSignHiding != 0; si.wpp = p.bEnableWavefront != 0;
+    si.use_dqp = e.useDqp; si.max_cu_dqp_depth = e.maxCuDqpDepth;
     si.max_cu_depth = 3; si.max_amp_depth = p.bEnableAMP ? 3 : 0; si.tu_log2_min = 2; si.tu_log2_max = 5;
     si.tu_max_depth_inter = p.tuQTMaxInterDepth; si.tu_max_depth_intra = p.tuQTMaxIntraDepth;
 
@@ -1783,7 +2073,7 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
         {
             const Pic* q = lists[l][0].get();
             for (size_t i = 0; i < nUnits; i++) refDepth[l * nUnits + i] = q->units[i].depth;
-            for (int i = 0; i < nctu; i++) refQp0[(size_t)l * nctu + i] = (int8_t)q->sliceQp;
+            for (int i = 0; i < nctu; i++) refQp0[(size_t)l * nctu + i] = useDqp ? q->units[(size_t)(i / ctuW) * 16 * w4 + (size_t)(i % ctuW) * 16].qp : (int8_t)q->sliceQp;      /* CUData::m_qp[0] of the co-located CTU */
         }
     std::vector<x265amd_cu_stat> stat((size_t)nctu + 1);
     memset(stat.data(), 0, sizeof(x265amd_cu_stat) * stat.size());
@@ -1792,9 +2082,10 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
     std::vector<uint32_t> sizes((size_t)ctuH + 1, 0);
     int nsub = 0;
     const bool sao = p.bEnableSAO != 0;
-    int rc = x265amd_analyse_frame(me, st, &info, &sp, &si, &ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
-                                   refDepth.data(), refQp0.data(), planes.data(), (int)(planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
-                                   sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub);
+    if (useDqp && pic.cuQp.empty()) return xa_fail(X265AMD_EINVAL, "encoder: the picture has no CU QPs");
+    int rc = xa_analyse_frame(me, st, &info, &sp, &si, &ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
+                              refDepth.data(), refQp0.data(), planes.data(), (int)(planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
+                              sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, nullptr, useDqp ? pic.cuQp.data() : nullptr);
     if (rc != X265AMD_OK) return rc;
     if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: analysis");
 
@@ -1861,7 +2152,7 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
  * FrameEncoder::compressFrame as the reference runs it with several frame encoders (frameencoder.cpp:880-960, :1930-1960; framefilter.cpp:559-664): a CTU row
  * of this picture starts when every reference picture has finished the rows down to refLagRows below it, and the in-loop filters follow the analysis row by
  * row so that the rows of this picture become available to the pictures that reference it while its lower rows are still being analysed. */
-struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; FrameCtx* fc = nullptr; };
+struct RowGate { x265amd_encoder* e; Pic* pic; std::vector<Pic*> refs; std::vector<uint8_t>* refDepth; size_t nUnits; FrameCtx* fc = nullptr; std::vector<int8_t>* refQp0 = nullptr; };
 
 /* What a CTU may read of a reference picture, and when.  The reference waits for whole rows: row + refLagRows rows of every reference picture before a row
  * starts (frameencoder.cpp:893-908).  What the row's commands can actually read is less -- vectors end searchRange samples below the block (search.cpp:92,
@@ -1963,6 +2254,8 @@ static void gateBeforeCtu(void* ctx, int row, int col)
             const int y0 = row * 16, y1 = std::min(e.h4, y0 + 16), x0 = col * 16, x1 = std::min(e.w4, x0 + 16);
             for (int y = y0; y < y1; y++)
                 for (int x = x0; x < x1; x++) (*g.refDepth)[l * g.nUnits + (size_t)y * e.w4 + x] = q->units[(size_t)y * e.w4 + x].depth;
+            /* ... and its first unit's QP (topSkipMinDepth's previousQP: CUData::m_qp[0] of that CTU as it was coded) */
+            if (e.useDqp && g.refQp0) (*g.refQp0)[(size_t)l * e.nctu + (size_t)row * e.ctuW + col] = q->units[(size_t)y0 * e.w4 + x0].qp;
         }
 }
 static void gateAfterCtu(void* ctx, int row, int col)
@@ -2373,7 +2666,8 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     std::vector<uint8_t> refDepth(2 * nUnits, 0);
     std::vector<int8_t> refQp0(2 * (size_t)nctu, 0);
     if (fc.failed) return xa_fail(X265AMD_EHIP, "encoder: weighted reference planes");
-    RowGate gate{ this, &pic, {}, &refDepth, nUnits, &fc };
+    RowGate gate{ this, &pic, {}, &refDepth, nUnits, &fc, &refQp0 };
+    if (useDqp && pic.cuQp.empty()) return xa_fail(X265AMD_EINVAL, "encoder: the picture has no CU QPs");
     for (int l = 0; l < 2; l++)
     {
         for (const PicP& q : lists[l]) if (std::find(gate.refs.begin(), gate.refs.end(), q.get()) == gate.refs.end()) gate.refs.push_back(q.get());
@@ -2403,7 +2697,7 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, rowOrder, gateCtuReach };
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
-                               sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks);
+                               sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks, useDqp ? pic.cuQp.data() : nullptr);
     if (arc != X265AMD_OK) pic.fail();
     filters.join();
     if (arc != X265AMD_OK) return rc = arc;
@@ -2427,6 +2721,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     if (picIn)
     {
         PicP pic(new Pic);
+        pic->pool = e->laPool;
         if (e->firstInMs < 0) e->firstInMs = Pic::pubClockMs();
         pic->poc = e->frameCount++;
         const auto tu0 = std::chrono::steady_clock::now();
@@ -2582,6 +2877,36 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         while (!e->byCoding.empty() && e->byCoding.begin()->first + 8 < e->collectedCoding) e->byCoding.erase(e->byCoding.begin());
     }
     if (rc) { xa_fail(rc, "encoder_encode: a frame task failed"); return -1; }
+    if (const char* dumpPath = getenv("X265AMD_RC_DUMP"))
+    {
+        /* debugging aid: the picture's record in the layout of oracle/ref_rc_dump.cpp (the reference's decisions for the same picture), appended to the file named */
+        if (FILE* f = fopen(dumpPath, "ab"))
+        {
+            const Pic& q = *front;
+            const int blocks16 = ((e->W + 15) / 16) * ((e->H + 15) / 16), lowresBlocks = e->lowCuW * e->lowCuH;
+            int32_t hdr[44];
+            memset(hdr, 0, sizeof(hdr));
+            hdr[0] = 0x52434450; hdr[1] = q.poc; hdr[2] = q.type; hdr[3] = q.type != TYPE_B; hdr[4] = q.sliceQp; hdr[5] = q.bScenecut;
+            for (int l = 0; l < 2; l++) { hdr[6 + l] = (int32_t)q.lists[l].size(); for (size_t r = 0; r < q.lists[l].size() && r < 16; r++) hdr[8 + 16 * l + r] = q.lists[l][r]->poc; }
+            hdr[40] = e->w4; hdr[41] = e->h4; hdr[42] = blocks16; hdr[43] = lowresBlocks;
+            fwrite(hdr, sizeof(hdr), 1, f);
+            const int64_t satd = 0; fwrite(&satd, 8, 1, f);
+            const double qq[2] = { q.avgQpRc, 0 }; fwrite(qq, 8, 2, f);
+            std::vector<double> zd((size_t)blocks16, 0.0); std::vector<int32_t> zi((size_t)std::max(blocks16, lowresBlocks), 0); std::vector<uint16_t> zs((size_t)lowresBlocks, 0);
+            fwrite(q.qpAqOffset.size() == (size_t)blocks16 ? q.qpAqOffset.data() : zd.data(), 8, blocks16, f);
+            fwrite(q.qpCuTreeOffset.size() == (size_t)blocks16 ? q.qpCuTreeOffset.data() : zd.data(), 8, blocks16, f);
+            fwrite(q.invQscale.size() == (size_t)blocks16 ? q.invQscale.data() : zi.data(), 4, blocks16, f);
+            fwrite(q.intraCostHost.size() == (size_t)lowresBlocks ? q.intraCostHost.data() : zi.data(), 4, lowresBlocks, f);
+            fwrite(q.propagateCost.size() == (size_t)lowresBlocks ? q.propagateCost.data() : zs.data(), 2, lowresBlocks, f);
+            const size_t n = (size_t)e->w4 * e->h4;
+            std::vector<uint8_t> b(n);
+            for (size_t i = 0; i < n; i++) b[i] = (uint8_t)q.units[i].qp; fwrite(b.data(), 1, n, f);
+            for (size_t i = 0; i < n; i++) b[i] = q.units[i].depth; fwrite(b.data(), 1, n, f);
+            for (size_t i = 0; i < n; i++) b[i] = q.units[i].pred_mode; fwrite(b.data(), 1, n, f);
+            for (size_t i = 0; i < n; i++) b[i] = q.units[i].cbf[0]; fwrite(b.data(), 1, n, f);
+            fclose(f);
+        }
+    }
     e->outBytes.swap(front->nalBytes);
     splitNals(e->outBytes, e->nals);
     if (picOut)

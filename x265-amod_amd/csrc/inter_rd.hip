@@ -532,6 +532,7 @@ static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_par
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: lossless coding is not supported");
     const int w4 = si->pic_width >> 2;
     x265amd_cabac* coder = x265amd_cabac_open(si, units, 1);
+    if (coder) coder->ctuInProgress = true;          /* the analysis of a CTU asks (cabac_coder.h: lastQP) */
     if (!coder) return xa_fail(X265AMD_EINVAL, "inter_residual_rd: slice description");
     memset(sel, 0xFF, (size_t)RD_SEL_BYTES * n);
     std::vector<int16_t> coeffCu(4096 + 2048);
@@ -697,6 +698,7 @@ extern "C" int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_
     if (si->tq_bypass_enabled) return xa_fail(X265AMD_EINVAL, "skip_rd: lossless coding is not supported");
     const int w4 = si->pic_width >> 2;
     x265amd_cabac* coder = x265amd_cabac_open(si, units, 1);
+    if (coder) coder->ctuInProgress = true;          /* the analysis of a CTU asks (cabac_coder.h: lastQP) */
     if (!coder) return xa_fail(X265AMD_EINVAL, "skip_rd: slice description");
     std::vector<x265amd_cu_unit> saved(256);
     for (int i = 0; i < n; i++)

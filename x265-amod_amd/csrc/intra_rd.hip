@@ -1065,6 +1065,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     if (rc == X265AMD_OK && rp->rdoq_level && xa_fill_async(R.st, R.dEst.p, 0, sizeof(x265amd_est_bits)) != hipSuccess)         /* the table is only read by RDOQ */
         rc = xa_fail(X265AMD_EHIP, "intra rd: fill");
     x265amd_cabac* coder = rc == X265AMD_OK ? x265amd_cabac_open(si, units, 1) : nullptr;
+    if (coder) coder->ctuInProgress = true;          /* the analysis of a CTU asks (cabac_coder.h: lastQP) */
     if (rc == X265AMD_OK && !coder) rc = xa_fail(X265AMD_EINVAL, "intra rd: slice description");
     if (rc != X265AMD_OK) { if (coder) x265amd_cabac_close(coder); if (!ws) delete ip; return rc; }
     R.c = coder;
@@ -1377,6 +1378,7 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     R.cur.frac = frac;
     x265amd_cabac* coder;
     { XA_HOSTPROF("quad8 cabac_open"); coder = x265amd_cabac_open(si, units, 1); }
+    if (coder) coder->ctuInProgress = true;          /* the analysis of a CTU asks (cabac_coder.h: lastQP) */
     if (!coder) return xa_fail(X265AMD_EINVAL, "intra rd: slice description");
     R.c = coder;
     x265amd_intra_nxn_job* jobs = static_cast<x265amd_intra_nxn_job*>(R.qJobs.p);

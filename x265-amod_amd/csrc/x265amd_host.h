@@ -128,7 +128,9 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
-                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks);
+                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks, const int8_t* cu_qp = nullptr);
+/* cu_qp (with si->use_dqp): Analysis::calculateQpforCuSize for every quantisation group, per CTU in z order -- 1 value (max_cu_dqp_depth 0) or 1 + 4 (depth 1): the QP of the
+ * 64x64 CU, then of its four 32x32 CUs; the encoder object fills it from the rate control's QP and the adaptive quantisation / cuTree offsets of the picture */
 
 /* x265amd_check_intra / x265amd_intra_in_inter with a working set the caller keeps between the CUs of one CTU (csrc/intra_rd.hip): *ws starts as NULL */
 int xa_check_intra_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,

@@ -581,7 +581,13 @@ struct x265amd_cabac
         const int lq = l ? l->qp : lastQP(x, y), aq = a ? a->qp : lastQP(x, y);
         return (lq + aq + 1) >> 1;
     }
-    /* CUData::getLastCodedQP (cudata.cpp:857-887): QP of the CU coded just before the quantisation group */
+    /* CUData::getLastCodedQP (cudata.cpp:857-887): QP of the CU coded just before the quantisation group.  getLastValidPartIdx steps backwards over the CTU's units: a unit
+     * that carries no CU (MODE_NONE) is stepped over together with the block its m_cuDepth names.  Units outside the picture are such units, and what the reference's CTU
+     * arrays hold for them depends on how far the CTU has come: CUData::initCTU clears the depths (a step of the whole CTU), and the copyToPic of the smallest CU that has
+     * the unit's block as an absent sub-CU writes that sub-CU's depth (setEmptyPart, cudata.cpp:422-427) -- so in a finished CTU the unit's depth is that of the largest
+     * block around it whose corner lies outside the picture, and in the CTU under analysis (ctuInProgress) that only holds once the CU with the absent sub-CU is complete,
+     * i.e. when it does not contain the quantisation group the question is asked for. */
+    bool ctuInProgress = false;     /* the analysis asks (Search::checkDQP / checkDQPForSplitPred on the CTU being compressed); false: the CTU is complete (Entropy::encodeCTU) */
     int lastQP(int x, int y)
     {
         const int qg = 64 >> si.max_cu_dqp_depth;
@@ -591,16 +597,38 @@ struct x265amd_cabac
         for (int addr = ctuAddr;; )
         {
             const int bx = (addr % ctuW) * 64, by = (addr / ctuW) * 64;
+            const bool inProgress = ctuInProgress && addr == ctuAddr;
             while (z >= 0)
             {
                 /* unit z of this CTU */
                 int ux = 0, uy = 0;
                 for (int b = 0; b < 4; b++) { ux |= ((z >> (2 * b)) & 1) << b; uy |= ((z >> (2 * b + 1)) & 1) << b; }
-                const x265amd_cu_unit* u = at((bx >> 2) + ux, (by >> 2) + uy);
-                if (coded(u)) return u->qp;
-                /* a unit outside the picture: the reference's CTU arrays hold depth 0 there (CUData::initCTU), so getLastValidPartIdx
-                 * steps over the whole CTU (cudata.cpp:857-869) */
-                z -= 256;
+                const int px = bx + ux * 4, py = by + uy * 4;
+                int depth = 0;
+                if (px < si.pic_width && py < si.pic_height)
+                {
+                    const x265amd_cu_unit* u = at(px >> 2, py >> 2);
+                    if (coded(u)) return u->qp;
+                    depth = u->depth;
+                }
+                else
+                {
+                    int d = 1;
+                    for (; d < 4; d++)
+                    {
+                        const int sz = 64 >> d;
+                        if (bx + ((ux * 4) & ~(sz - 1)) >= si.pic_width || by + ((uy * 4) & ~(sz - 1)) >= si.pic_height) break;
+                    }
+                    depth = d;
+                    if (inProgress)
+                    {
+                        /* the CU that has this block as an absent sub-CU: complete unless the group asked for lies in it */
+                        const int psz = 64 >> (d - 1);
+                        const int ox = bx + ((ux * 4) & ~(psz - 1)), oy = by + ((uy * 4) & ~(psz - 1));
+                        if (gx >= ox && gx < ox + psz && gy >= oy && gy < oy + psz) depth = 0;
+                    }
+                }
+                z -= 256 >> (2 * depth);
             }
             if (addr > 0 && !(si.wpp && !(addr % ctuW))) { addr--; z = 255; }
             else return si.slice_qp;
