@@ -849,7 +849,15 @@ size_t ref_encode_ctus(const RefSliceInfo* si, const RefCuUnit* units, const int
         for (uint32_t z = 0; z < 256; z++)
         {
             const int x = cx + g_zscanToPelX[z], y = cy + g_zscanToPelY[z];
-            if (x >= width || y >= height) { ctu.m_predMode[z] = MODE_NONE; ctu.m_cuDepth[z] = 0; continue; }
+            if (x >= width || y >= height)
+            {
+                /* what the encoder leaves there when the CTU is complete: the copyToPic of the smallest CU that has the unit's block as an absent sub-CU has written that
+                 * sub-CU's depth (CUData::setEmptyPart, cudata.cpp:422-427) -- the largest block around the unit whose corner lies outside the picture.  getLastCodedQP steps
+                 * over such units by that block (cudata.cpp:857-869). */
+                int d = 1;
+                for (; d < 4; d++) { const int sz = 64 >> d; if ((x & ~(sz - 1)) >= width || (y & ~(sz - 1)) >= height) break; }
+                ctu.m_predMode[z] = MODE_NONE; ctu.m_cuDepth[z] = (uint8_t)d; continue;
+            }
             const RefCuUnit& u = units[(y >> 2) * w4 + (x >> 2)];
             ctu.m_cuDepth[z] = u.depth; ctu.m_log2CUSize[z] = (uint8_t)(6 - u.depth);
             ctu.m_predMode[z] = u.predMode == 1 ? MODE_INTER : (u.predMode == 2 ? MODE_INTRA : (u.predMode == 3 ? MODE_SKIP : MODE_NONE));

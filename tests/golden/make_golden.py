@@ -770,7 +770,29 @@ def make_ratecontrol_golden():
         json.dump(out, f)
 
 
+# ---- final entropy coding (tests/test_cabac.py): digests of the reference's own Entropy::encodeCTU ... finishSlice on the seeded pictures ----
+def make_cabac_golden():
+    import hashlib
+    CASES = [(1, 128, 128, 2), (2, 200, 136, 1), (3, 264, 72, 0), (4, 64, 64, 0), (5, 136, 200, 1), (6, 192, 128, 0), (7, 128, 64, 2), (8, 320, 192, 0)]       # tests/test_cabac.py
+    out = {}
+    for depth in (8, 10):
+        R = T.load_ref(depth)
+        out[str(depth)] = {}
+        for i, (seed, w, h, st) in enumerate(CASES):
+            for dense in (False, True):
+                res = T.cabac_run_ref(R, T.cabac_case(seed + 100 * dense, w, h, st, dense))
+                hh = hashlib.sha256()
+                hh.update(res[0].tobytes()); hh.update(res[1].tobytes()); hh.update(res[2].tobytes())
+                out[str(depth)]["%d/%d" % (i, int(dense))] = hh.hexdigest()
+    with open(os.path.join(T.GOLDEN_DIR, "cabac_golden.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("cabac golden:", sum(len(v) for v in out.values()), "digests")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cabac":
+        make_cabac_golden()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rc":
         make_ratecontrol_golden()
         sys.exit(0)
