@@ -539,17 +539,22 @@ def make_encoder_ft_golden():
     print("wrote encoder_ft_golden.npz")
 
 
-def make_encoder_full_golden(only=None):
+def make_encoder_preset_golden(only=None):
+    """the presets as they come (CRF 28 + aq-mode 2 + cuTree: no --qp) -> tests/golden/encoder_preset_golden.json"""
+    make_encoder_full_golden(only, T.PRESET_CASES, T.PRESET_CLI, "encoder_preset_golden.json")
+
+
+def make_encoder_full_golden(only=None, cases=None, tail=None, name="encoder_full_golden.json"):
     """BASELINE.json's configurations 3-5 at their stated size (and an rd 2 clip of 1080 rows for complexityCheckCU): the reference encoder's stream digest + size and
     the digest of every reconstructed picture -> tests/golden/encoder_full_golden.json.  The clips are SURVEY.md section 8d's generator (hevc_testlib.survey_clip)."""
     import subprocess, tempfile, hashlib, time
-    path = os.path.join(T.GOLDEN_DIR, "encoder_full_golden.json")
+    path = os.path.join(T.GOLDEN_DIR, name)
     out = json.load(open(path)) if os.path.exists(path) else {}
-    for tag, ((w, h), nframes, depth, cfg_id, _, extra) in T.FULL_CASES.items():
+    for tag, ((w, h), nframes, depth, cfg_id, _, extra) in (cases or T.FULL_CASES).items():
         if only and tag not in only:
             continue
         planes = T.full_case_frames(tag)
-        cli = extra + T.FULL_CLI
+        cli = extra + (tail if tail is not None else T.FULL_CLI)
         with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
             with open(os.path.join(d, "clip.y4m"), "wb") as f:
                 f.write(b"YUV4MPEG2 W%d H%d F30:1 Ip A1:1 %s\n" % (w, h, b"C420p10" if depth == 10 else b"C420"))
@@ -819,5 +824,7 @@ if __name__ == "__main__":
         make_encoder_ft_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "full":
         make_encoder_full_golden(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "preset":
+        make_encoder_preset_golden(sys.argv[2:] or None)
     else:
         main()

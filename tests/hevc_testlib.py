@@ -3372,8 +3372,23 @@ FULL_CASES = {
 
 
 def full_case_frames(tag):
-    (w, h), n, depth, cfg_id, _, _ = FULL_CASES[tag]
+    (w, h), n, depth, cfg_id, _, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag])
     return survey_clip(w, h, depth, cfg_id, 0, n)
+
+
+# ---- the presets AS THEY COME (round 6): no --qp on the reference's command line, i.e. rc.rateControlMode = X265_RC_CRF with rfConstant 28, aq-mode 2, cuTree
+# (source/common/param.cpp:266-290) -- BASELINE.json's metric is quoted on exactly this.  PRESET_CLI is everything behind the preset's name. ----
+PRESET_CLI = ["--no-info"]
+PRESET_RC = dict(rateControlMode=2, rfConstant=28.0, aqMode=2, aqStrength=1.0, cuTree=1, qCompress=0.6, qgSize=32)
+PRESET_BASE = dict({k: v for k, v in FULL_BASE.items() if k != "qp"}, **PRESET_RC)
+PRESET_CASES = {
+    "crf_wqvga_medium_30/": ((416, 240), 30, 8, 2, dict(PRESET_BASE), ["--preset", "medium"]),                       # cut CTUs right and below, a scene change at 24
+    "crf_fhd_medium_60/": ((1920, 1080), 60, 8, 2, dict(PRESET_BASE), ["--preset", "medium"]),                      # BASELINE.json configs[1] / the metric's first size
+    "crf_2160p_medium_20/": ((3840, 2160), 20, 8, 2, dict(PRESET_BASE), ["--preset", "medium"]),                    # the metric's second size
+    "crf_cfg3_2160p_slow/": ((3840, 2160), 12, 8, 3, dict(PRESET_BASE, **SLOW_TOOLS), ["--preset", "slow"]),        # configs[2]
+    "crf_cfg4_2160p_main10/": ((3840, 2160), 12, 10, 4, dict(PRESET_BASE), ["--preset", "medium"]),                  # configs[3]
+    "crf_cfg5_4320p_veryslow_rd6/": ((7680, 4320), 3, 10, 5, dict(PRESET_BASE, **VERYSLOW_TOOLS, **VERYSLOW_GOP), ["--preset", "veryslow", "--rd", "6"]),       # configs[4]
+}
 
 
 # ---- scene-cut detection of the lookahead (x265amd_param.scenecutThreshold): clips whose content changes at given frames ----

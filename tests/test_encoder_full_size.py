@@ -24,6 +24,7 @@ import pytest
 import hevc_testlib as T
 
 GOLD = os.path.join(T.GOLDEN_DIR, "encoder_full_golden.json")
+PRESET_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_preset_golden.json")
 
 
 def test_full_size_golden_present():
@@ -53,6 +54,31 @@ def test_survey_clip_is_the_bench_clip():
 def test_encoder_object_full_size(tag):
     g = json.load(open(GOLD))[tag]
     (w, h), n, depth, cfg_id, cfg, _ = T.FULL_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(tag), w, h, **cfg)
+    assert len(coded) == n
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == g["recon_md5"][poc], "reconstruction of poc %d" % poc
+    assert len(stream) == g["stream_bytes"] and hashlib.md5(stream.tobytes()).hexdigest() == g["stream_md5"]
+
+
+# ---- the presets as they come (round 6): the reference's command line is `--preset <p> --no-info` and nothing else -- constant rate factor 28, aq-mode 2, cuTree ----
+def test_preset_golden_present_and_cut_without_a_qp():
+    g = json.load(open(PRESET_GOLD))
+    for tag, ((w, h), n, depth, cfg_id, cfg, cli) in T.PRESET_CASES.items():
+        assert tag in g and len(g[tag]["recon_md5"]) == n and g[tag]["stream_bytes"] > 0, tag
+        assert "--qp" not in g[tag]["reference_command_line"] and "--crf" not in g[tag]["reference_command_line"] and "qp" not in cfg, tag
+        assert cfg["rateControlMode"] == 2 and cfg["aqMode"] == 2 and cfg["cuTree"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.PRESET_CASES))
+def test_encoder_object_presets_as_they_come(tag):
+    """BASELINE.json's configurations with their literal rate control: the whole byte stream and every reconstructed picture equal the reference command line
+    encoder's for `--preset medium` (1080p 60 frames, 2160p 20 frames, Main 10), `--preset slow` and `--preset veryslow --rd 6` -- CRF's picture QPs, the adaptive
+    quantisation and cuTree offsets of every 16x16 block, the QP of every CU and cu_qp_delta in the slice data"""
+    g = json.load(open(PRESET_GOLD))[tag]
+    (w, h), n, depth, cfg_id, cfg, _ = T.PRESET_CASES[tag]
     stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(tag), w, h, **cfg)
     assert len(coded) == n
     for (poc, _, _, planes) in coded:
