@@ -43,15 +43,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0                # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BFRAMES, REFS, QP = 4, 3, 30
+BFRAMES, REFS, CRF = 4, 3, 28
 
 # x265amd_param fields that differ from x265amd_param_default, and the same settings on the reference's command line
 # frameNumThreads > 1: the reference's frame-parallel rules, i.e. what its default (--frame-threads 0 = by core count) gives on any machine with four cores or more
-ENC_CFG = dict(fpsNum=30, fpsDenom=1, qp=QP, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5,
-               scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2, bOpenGOP=1, bBPyramid=1, lookaheadSlices=8, bEnableWeightedPred=1)
-# Every value of ENC_CFG is the preset's: the reference runs `--preset medium --qp 30` as it comes (checked: the long form with every option spelled out gives the same stream);
-# --no-info leaves out the SEI NAL unit that carries the reference build's version and option string
-REF_CLI = ["--preset", "medium", "--qp", str(QP), "--no-info"]
+ENC_CFG = dict(fpsNum=30, fpsDenom=1, aspectRatioIdc=1, bframes=BFRAMES, bEnableLoopFilter=1, bEnableSAO=1, bEnableWavefront=1, frameNumThreads=5,
+               scenecutThreshold=40, lookaheadDepth=20, bFrameAdaptive=2, bOpenGOP=1, bBPyramid=1, lookaheadSlices=8, bEnableWeightedPred=1,
+               rateControlMode=2, rfConstant=float(CRF), aqMode=2, aqStrength=1.0, cuTree=1, qCompress=0.6, qgSize=32)
+# Every value of ENC_CFG is the preset's, its rate control included (round 6): the reference runs plain `--preset medium` -- constant rate factor 28, --aq-mode 2, cuTree
+# (source/common/param.cpp:266-290) -- which is the command line BASELINE.json's metric names; --no-info leaves out the SEI NAL unit that carries the reference build's version
+# and option string
+REF_CLI = ["--preset", "medium", "--no-info"]
 
 
 def bench_clip(first, count, gop=0, depth=8, cfg_id=2):
@@ -306,6 +308,17 @@ def main():
     ap.add_argument("--no-scene-clip", action="store_true", help="skip the 60-frame clip with both re-seeds inside that the 1080p single-GPU run reports beside the bench line (`scene_change_clip`)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # run plainly with --gpus N: start the N ranks (one process per GPU) BEFORE anything here touches the GPU, relay rank 0's line, leave with the launcher's code --
+        # never a one-GPU run that calls itself N GPUs
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     import hevc_testlib as T
@@ -314,6 +327,8 @@ def main():
         W, H = 3840, 2160
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.one_gpu:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -402,9 +417,10 @@ def main():
             "higher_is_better": True, "scaling": "strong" if by_frames else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d 8-bit 4:2:0 synthetic clip, %d frames per GPU (I + mini-GOPs of up to %d B frames chosen by the lookahead's trellis, --b-adapt 2), encoded END TO END by the encoder object "
                                    "(x265amd_encoder_open / encode / close): --preset medium analysis settings (CTU 64, rd 3, hex / merange 57 / subme 2, %d references, "
-                                   "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; CQP %d with "
+                                   "3 merge candidates, early skip, rskip, psy-rd 2.0, sign hiding, TU depth 1), deblocking, SAO, WPP, frame-parallel rules (the reference's default frame threads), CABAC, Annex-B stream; the preset's own rate "
+                                   "control -- constant rate factor %d, adaptive quantisation (--aq-mode 2), cuTree, a QP per 32x32 quantisation group (cu_qp_delta) -- with "
                                    "scene-cut detection (--scenecut 40, --rc-lookahead 20), the B-frame trellis (--b-adapt 2), the B pyramid, open GOPs, the lookahead's slices (--lookahead-slices 8) and weighted prediction (--weightp: the analysis runs, no weights are chosen on these clips; "
-                                   "clips with fades are coded with weights in tests/test_encoder_api.py) as the preset has them (AQ / cutree are off in CQP by the reference's own rules): the reference runs plain --preset medium --qp 30" % (W, H, K, BFRAMES, REFS, QP),
+                                   "clips with fades are coded with weights in tests/test_encoder_api.py) as the preset has them: the reference runs plain --preset medium" % (W, H, K, BFRAMES, REFS, CRF),
                        "frames_per_step_per_gpu": 1, "parallelism": ("picture k in coding order on GPU k mod %d, CTU rows broadcast over RCCL" % world if by_frames else "closed GOP per GPU x%d" % world) if world > 1 else "one encoder object",
                        "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(REF_CLI)},
             "bit_exact_vs_reference_encoder": same,
@@ -480,14 +496,14 @@ def main():
                 framesx = bench_clip(0, Kx, depth=depth, cfg_id=cfg_id)
                 encode(T, Lx, bench_clip(0, kwarm, depth=depth, cfg_id=cfg_id), 0, 0, sync, timed=False, cfg=cfgx)
                 streamx, dtx = encode(T, Lx, framesx, 0, 0, sync, cfg=cfgx)
-                clix = presetCli + ["--qp", str(QP), "--no-info"]
+                clix = presetCli + ["--no-info"]
                 refx = reference_encode(framesx, cli=clix, depth=depth, runs=("default", "pools16"))
                 line[key] = {"value": Kx / dtx, "unit": "frames/s", "frames": Kx, "stream_md5": hashlib.md5(streamx).hexdigest(),
                              "bit_exact_vs_reference_encoder": None if refx is None else bool(refx["default"]["stream"] == streamx),
                              "cpu_baseline": None if refx is None else {"value": Kx / refx["default"]["seconds"], "cores": refx["cores"], "kind": "reference", "says": refx["default"]["says"],
                                                                         "pools16": Kx / refx["pools16"]["seconds"]},
                              "reference_command_line": "x265 --input clip.y4m -o out.hevc " + " ".join(clix),
-                             "note": "BASELINE.json configs[%d] at its stated size (SURVEY 8d's clip, cfg_id %d), %d frames, the preset in CQP as it comes" % (cfgIndex, cfg_id, Kx)}
+                             "note": "BASELINE.json configs[%d] at its stated size (SURVEY 8d's clip, cfg_id %d), %d frames, the preset as it comes (CRF 28, aq-mode 2, cuTree)" % (cfgIndex, cfg_id, Kx)}
                 del framesx, streamx
             except Exception as exc:       # the bench line stands on its own
                 line[key] = {"error": repr(exc)}

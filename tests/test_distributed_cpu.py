@@ -89,6 +89,8 @@ def test_gop_sharding_schedule_and_gather_world2():
 
 # ---- frame-per-GPU with row publication (x265-amod_amd/frame_rows.py): the schedule, with arrays standing in for the encoder objects ----
 ROWS, PICS = 5, 7
+if os.environ.get("X265AMD_TEST_PICS"):
+    PICS = int(os.environ["X265AMD_TEST_PICS"])
 
 
 def _row_bytes(k, row, i, n):
@@ -172,7 +174,8 @@ def _rows_worker(rank, world, port, out):
     import __graft_entry__ as g
     fr = g.load_package().frame_rows
     skipped = {3}                           # a picture nobody references: its rows stay with its owner
-    late = {min(k for k in range(4, PICS) if k % world != rank and k not in skipped)} if rank == 1 else ()
+    pick = max if os.environ.get("X265AMD_TEST_LATE_LAST") else min      # the LAST picture this rank receives: its rows are still pending when every sender is done
+    late = {pick(k for k in range(4, PICS) if k % world != rank and k not in skipped)} if rank == 1 else ()
     enc = _FakeEncoder(rank, world, skipped, late=late)
     answers = {}
 
@@ -216,6 +219,21 @@ def test_row_publication_schedule_gloo_world3():
     """the same schedule with three owners: picture k's rows come from rank k % 3 and reach both others"""
     out = _spawn_rows(3)
     assert out[0] and out[1] and out[2]
+
+
+def test_row_publication_last_picture_late_on_a_receiver(monkeypatch):
+    """the last referenced picture is not known to rank 1 when its rows arrive -- they stay pending while every sender has nothing left to send.  The pump
+    must keep ALL ranks in its slots until rank 1 has imported them (a rank that leaves alone hangs the others' next collective), and every row must arrive"""
+    monkeypatch.setenv("X265AMD_TEST_LATE_LAST", "1")
+    out = _spawn_rows(2)
+    assert out[0] and out[1]
+
+
+def test_row_publication_schedule_gloo_world8(monkeypatch):
+    """the schedule of an eight-GPU node: picture k's rows come from rank k % 8 and reach the seven others (the same fake encoders; 16 pictures so that every rank owns two)"""
+    monkeypatch.setenv("X265AMD_TEST_PICS", "16")           # (the spawned ranks import this module afresh)
+    out = _spawn_rows(8)
+    assert all(out[r] for r in range(8))
 
 
 def _failing_worker(rank, world, port, out):

@@ -63,6 +63,10 @@ struct LaPool
         return p;
     }
     void put(void* p) { if (!p) return; std::lock_guard<std::mutex> lk(mu); freeBufs.push_back(p); }
+    /* the motion fields of pictures that are gone (their host vectors' addresses: the keys of x265amd_encoder::laFields): the encoder drops the fields' device copies
+     * the next time it looks (a later vector at the same heap address must not find them) */
+    std::vector<const void*> deadFields;
+    void dead(const void* key) { if (!key) return; std::lock_guard<std::mutex> lk(mu); deadFields.push_back(key); }
 };
 
 struct Pic;
@@ -141,7 +145,8 @@ struct Pic
         if (!xa_devmap_register(regMotion, motion.size())) regMotion = nullptr;
     }
     Pic() { memset(refPoc, 0, sizeof(refPoc)); memset(wp, 0, sizeof(wp)); for (int i = 0; i < 18; i++) { costEst[i] = -1; intraMbs[i] = 0; specIntraMbs[i] = 0; for (int j = 0; j < 18; j++) cost2[i][j] = specCost2[i][j] = -1; } }
-    ~Pic() { if (pool) { for (auto& e : dLc) pool->put(e.second); for (auto& e : dSpecLc) pool->put(e.second); } if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
+    ~Pic() { if (pool) { for (auto& e : dLc) pool->put(e.second); for (auto& e : dSpecLc) pool->put(e.second);
+                         for (int i = 0; i < 18; i++) for (const std::vector<int16_t>* v : { &lowMvs[i], &lowMvs1[i], &specMvs[i], &specMvs1[i] }) if (!v->empty()) pool->dead(v->data()); } if (regMotion) xa_devmap_unregister(regMotion); xa_scratch_free(dSrc); xa_scratch_free(dRec); xa_scratch_free(dFin); xa_scratch_free(dLowres); xa_scratch_free(dIntraCost); for (volatile uint64_t* c : finalX) xa_counter_free(c); }
     void publish(int row, int x)
     {
         std::atomic_thread_fence(std::memory_order_release); *finalX[row] = (uint64_t)x;
@@ -372,7 +377,6 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(!p->cuTree || p->rateControlMode == X265AMD_RC_CRF, "cuTree needs rate control (the reference switches it off under constant QP, encoder.cpp:3721-3728)");
         XA_REQUIRE(!p->cuTree || p->lookaheadDepth > 0, "cuTree needs the lookahead (lookaheadDepth > 0)");
         XA_REQUIRE(!(p->aqMode && p->rateControlMode != X265AMD_RC_CRF), "adaptive quantisation needs rate control (the reference switches it off under constant QP, encoder.cpp:3721-3728)");
-        XA_REQUIRE(!(p->rateControlMode == X265AMD_RC_CRF && p->shardCount > 1), "frame-per-GPU with rate control is not built");
         XA_REQUIRE(p->rdLevel >= 2 && p->rdLevel <= 6, "rdLevel outside 2..6 (rd 0-1 are not built)");
         XA_REQUIRE(p->maxNumMergeCand >= 1 && p->maxNumMergeCand <= 5, "maxNumMergeCand outside 1..5");
         XA_REQUIRE(p->tuQTMaxInterDepth >= 1 && p->tuQTMaxInterDepth <= 4, "tuQTMaxInterDepth outside 1..4");
@@ -1057,6 +1061,16 @@ void x265amd_encoder::laFieldPut(const void* key, void* mv, void* mc)
 /* (called when nothing of the lookahead's is in flight: behind frameCostMany's wait) */
 void x265amd_encoder::laFieldsTrim()
 {
+    {
+        /* fields of pictures that have gone since the last look */
+        std::vector<const void*> dead;
+        { std::lock_guard<std::mutex> lk(laPool->mu); dead.swap(laPool->deadFields); }
+        for (const void* k : dead)
+        {
+            auto it = laFields.find(k);
+            if (it != laFields.end()) { laBufPut(it->second.mv); laBufPut(it->second.mc); laFields.erase(it); }
+        }
+    }
     if (laFields.size() <= LA_FIELDS_MAX) return;
     std::vector<uint64_t> ages;
     for (auto& f : laFields) ages.push_back(f.second.used);
@@ -1077,6 +1091,7 @@ void x265amd_encoder::laFieldsFree()
 int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
 {
     if (jobs.empty()) return X265AMD_OK;
+    laFieldsTrim();             /* (nothing of the lookahead's is in flight here either) */
     const size_t ncu = (size_t)lowCuW * lowCuH;
     int rc = X265AMD_OK;
     const auto tb0 = std::chrono::steady_clock::now();
@@ -1092,7 +1107,8 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
             if (!a || !b) { laBufPut(a); laBufPut(b); return false; }
             laFieldPut(mv.data(), a, b);
             it = laFields.find(mv.data());
-            if (hipMemcpyAsync(a, mv.data(), ncu * 4, hipMemcpyHostToDevice, laStream) != hipSuccess || hipMemcpyAsync(b, mc.data(), ncu * 4, hipMemcpyHostToDevice, laStream) != hipSuccess) return false;
+            if (hipMemcpyAsync(a, mv.data(), ncu * 4, hipMemcpyHostToDevice, laStream) != hipSuccess || hipMemcpyAsync(b, mc.data(), ncu * 4, hipMemcpyHostToDevice, laStream) != hipSuccess)
+            { laBufPut(a); laBufPut(b); laFields.erase(mv.data()); return false; }           /* (no entry for a field that did not arrive) */
         }
         it->second.used = ++laFieldClock;
         dMv = it->second.mv; dMc = it->second.mc;
@@ -2777,13 +2793,14 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
             {
                 /* another object codes this picture: its rows arrive through x265amd_encoder_import_row -- unless nobody will ever read them (a plain B picture is
                  * no reference: the row pump does not send it) */
-                if (pic->type == TYPE_B) { xa_scratch_free(pic->dSrc); pic->dSrc = nullptr; return (int)X265AMD_OK; }
+                if (pic->type == TYPE_B) { if (!e->keepSources()) { xa_scratch_free(pic->dSrc); pic->dSrc = nullptr; } return (int)X265AMD_OK; }
                 std::unique_lock<std::mutex> lk(pic->mu);
                 static const int importWaitS = getenv("X265AMD_IMPORT_WAIT_S") ? atoi(getenv("X265AMD_IMPORT_WAIT_S")) : 300;       /* (debugging a stalled pump: a short wait shows where it stands) */
                 const bool ok = pic->cv.wait_for(lk, std::chrono::seconds(importWaitS), [&] { return pic->importedRows >= e->ctuH || pic->failed.load(); });
                 if (!ok || pic->failed.load()) { lk.unlock(); pic->fail(); return xa_fail(X265AMD_EHIP, "encoder: a picture coded elsewhere did not arrive"); }
                 lk.unlock();
-                xa_scratch_free(pic->dSrc); pic->dSrc = nullptr;
+                /* (weightAnalyse of later pictures reads the chroma planes of its references' SOURCE pictures on every object of the set: sliceWeights) */
+                if (!e->keepSources()) { xa_scratch_free(pic->dSrc); pic->dSrc = nullptr; }
                 return (int)X265AMD_OK;
             }
             const int rc = e->frameParallel ? e->runFrameParallel(pic) : e->runFrame(pic, prev);

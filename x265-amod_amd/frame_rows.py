@@ -163,7 +163,9 @@ def _slots(export_row, import_row, shapes, n_pictures, ctu_rows, dev, stream, ra
                 cur.advance()
             if mine:
                 cur_first = first
-        my_state = STATE_FAILED if failure is not None else (STATE_DONE if cur.done() and not mine else STATE_MORE)
+        # DONE means: nothing left to send AND nothing received that is still waiting for its picture -- the end of the pump is decided from the exchanged table alone
+        # (below), so a rank that still holds rows keeps every rank in the loop with it instead of walking into the next collective alone
+        my_state = STATE_FAILED if failure is not None else (STATE_DONE if cur.done() and not mine and not pending else STATE_MORE)
         hdr = torch.zeros(world, 4, dtype=torch.int64)
         hdr[rank] = torch.tensor([cur_first[0] if mine else 0, cur_first[1] if mine else 0, len(mine), my_state], dtype=torch.int64)
         hdr = hdr.to(dev)
@@ -205,8 +207,8 @@ def _slots(export_row, import_row, shapes, n_pictures, ctu_rows, dev, stream, ra
             elif stream is not None:
                 stream.synchronize()                # the packing copies have read the picture
         moved |= try_imports()
-        if all(st == STATE_DONE for st in state) and not pending:
-            return
+        if all(line[3] == STATE_DONE and line[2] == 0 for line in table):
+            return                                  # every rank said so in THIS slot and nothing travelled in it: nothing new can be pending anywhere
         if moved:
             t_moved = time.monotonic()
         else:
