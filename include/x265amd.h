@@ -355,7 +355,8 @@ typedef struct x265amd_intra_nxn_job
     uint8_t pick_sa8d;              /* 1 (one unit): no candidate list -- the unit's mode is Search::checkIntraInInter's choice (search.cpp:1291-1452): the cheapest of the 35 by
                                      * SA8D + mode bits, DC first, then planar, then the angular modes, strict improvement; its chain, its bits and the chroma decision
                                      * follow as for a list of one (encodeIntraInInter); the result record's chroma_reserved carries the mode's SA8D */
-    uint8_t reserved[2];
+    uint8_t reserved[2];            /* a chained CU under pps.bUseDQP (role 1): [0] != 0: cu_qp_delta is counted with the coefficients of an evaluation that has any (Search::checkIntra's
+                                     * codeCoeff with bCodeDQP, search.cpp:1266-1268); [1]: its value as Entropy::codeDeltaQP codes it (int8: the group's QP minus its prediction, wrapped) */
     /* do_chroma: Search::estIntraPredChromaQT for the CU's one 4x4 block per chroma plane in the same launch (search.cpp:1754-1889): the five allowed modes (planar,
      * vertical, horizontal, DC with the one equal to the first unit's luma mode replaced by 34, then the luma mode itself), each a wavefront running the U and the V
      * chain and counting the mode's bits -- intra_chroma_pred_mode, the two coded block flags, U's and V's coefficients, on the contexts `ctx` from scan_frac --; the first

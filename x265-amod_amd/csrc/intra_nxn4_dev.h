@@ -591,6 +591,46 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
         S.ffrac[1] = peer->ffrac; S.fmv[1] = peer->fmv;
     }
     __syncthreads();
+    if (P.reserved[0])
+    {
+        /* cu_qp_delta (Entropy::codeDeltaQP, entropy.cpp:1737-1756) behind the coded block flags of an evaluation that has coefficients: its bins' contexts (16, 17) are nobody
+         * else's, so adding them here is adding them where the reference codes them */
+        if (tid == 0)
+        {
+            const int dqp = (int)(int8_t)P.reserved[1];
+            const uint32_t a = (uint32_t)(dqp < 0 ? -dqp : dqp);
+            bool any[2];
+            any[0] = S.ures[0].num_sig || S.ures[1].num_sig || S.ures[2].num_sig || S.ures[3].num_sig || S.cres[S.cw][0].num_sig || S.cres[S.cw][1].num_sig;
+            any[1] = Q.res[0].num_sig || Q.cres[0].num_sig || Q.cres[1].num_sig;
+            for (int c = 0; c < 2; c++)
+            {
+                if (!any[c]) continue;
+                uint8_t* cx = S.fctx[c];
+                uint64_t f = S.ffrac[c];
+                const uint32_t first = a ? 1u : 0u;
+                f += cb_bin(&cx[16], first);
+                if (a)
+                {
+                    /* writeUnaryMaxSymbol(min(a, 5), ctx 16, offset 1, max 5) */
+                    uint32_t sym = a < 5 ? a : 5;
+                    const bool codeLast = 5 > sym;
+                    while (--sym) f += cb_bin(&cx[17], 1u);
+                    if (codeLast) f += cb_bin(&cx[17], 0u);
+                    if (a >= 5)
+                    {
+                        /* writeEpExGolomb(a - 5, 0): bypass bins */
+                        uint32_t symbol = a - 5, count = 0, n = 0;
+                        while (symbol >= (1u << count)) { n++; symbol -= 1u << count; count++; }
+                        n += 1 + count;
+                        f += (uint64_t)32768 * n;
+                    }
+                    f += 32768;         /* the sign */
+                }
+                S.ffrac[c] = f;
+            }
+        }
+        __syncthreads();
+    }
     XA_CHAIN(3);
     /* the two costs */
     const uint32_t lumaN = (uint32_t)(S.ures[0].nz_dist + S.ures[1].nz_dist + S.ures[2].nz_dist + S.ures[3].nz_dist);

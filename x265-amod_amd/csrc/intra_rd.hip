@@ -1350,7 +1350,10 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
     if (!helper || !R.dCand2.p || !R.dLayer.p || !R.dCand.p || R.ahead.on) return 1;
     /* with RDOQ (round 5) the deciding command runs the general form of the evaluation and its own decision (intra_pu_dev.h); X265AMD_CHAIN_RDOQ=0: CU by CU */
     static const bool chainRdoq = !(getenv("X265AMD_DEVICE_RDOQ") && atoi(getenv("X265AMD_DEVICE_RDOQ")) == 0) && !(getenv("X265AMD_CHAIN_RDOQ") && atoi(getenv("X265AMD_CHAIN_RDOQ")) == 0);
-    if (si->slice_type != 2 || si->use_dqp || si->tq_bypass_enabled || (rp->rdoq_level && !chainRdoq) || si->tu_max_depth_intra != 1 || si->tu_log2_min != 2 || si->tu_log2_max < 3 || si->max_cu_depth != 3 ||
+    /* delta QP (round 6): the CUs of the chain lie below the quantisation groups' depth, so no QP changes inside it -- but Search::checkIntra counts cu_qp_delta with
+     * the coefficients of every CU that has any (codeCoeff with bCodeDQP, search.cpp:1266-1268): the deciding command adds those bins (nxn4_decide), the value is the
+     * group's, known here */
+    if (si->slice_type != 2 || (si->use_dqp && si->max_cu_dqp_depth > 1) || si->tq_bypass_enabled || (rp->rdoq_level && !chainRdoq) || si->tu_max_depth_intra != 1 || si->tu_log2_min != 2 || si->tu_log2_max < 3 || si->max_cu_depth != 3 ||
         2 + rp->rd_level + 2 > IntraRd::MAX_JOBS || x + 16 > si->pic_width || y + 16 > si->pic_height || (x & 15) || (y & 15))
         return 1;
     if (!R.qJobs.p)
@@ -1416,6 +1419,14 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
             nj.no_picture = role == 2;
             nj.chain = (uint64_t)(uintptr_t)chainRec; nj.peer = (uint64_t)(uintptr_t)&peers[i]; nj.cu_out = (uint64_t)(uintptr_t)&outs[i];
             nj.chain_token = token0 + i; nj.chain_role = (uint8_t)role; nj.chain_first = i == 0; nj.chain_index = (uint8_t)i;
+            if (si->use_dqp)
+            {
+                /* Entropy::codeDeltaQP's value for the CUs of this block (entropy.cpp:1737-1756): the group's QP against its prediction, wrapped */
+                const int bd = 6 * (X265AMD_DEPTH - 8);
+                int dqp = qp - coder->refQP(x, y);
+                dqp = (dqp + 78 + bd + (bd / 2)) % (52 + bd) - 26 - (bd / 2);
+                nj.reserved[0] = 1; nj.reserved[1] = (uint8_t)(int8_t)dqp;
+            }
             /* the neighbour modes inside the block are the chain's: left of units 0 / 2 = units 1 / 3 of the CU to the left, above of units 0 / 1 = units 2 / 3 of the CU above */
             nj.mode_src[0] = (i & 1) ? (uint8_t)(((i - 1) << 2) | 1) : 0xFF; nj.mode_src[1] = (i & 1) ? (uint8_t)(((i - 1) << 2) | 3) : 0xFF;
             nj.mode_src[2] = (i & 2) ? (uint8_t)(((i - 2) << 2) | 2) : 0xFF; nj.mode_src[3] = (i & 2) ? (uint8_t)(((i - 2) << 2) | 3) : 0xFF;
