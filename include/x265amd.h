@@ -984,6 +984,9 @@ typedef struct x265amd_stream_params
 } x265amd_stream_params;
 /* Returns the size of the three NAL units in bytes (written to out when it fits), 0 on bad arguments. */
 size_t x265amd_write_stream_headers(const x265amd_stream_params* p, uint8_t* out, size_t cap);
+/* the user-data SEI NAL unit (prefix SEI, payload type 5 with the reference's UUID) that carries the encoder's name and option string behind the parameter sets when
+ * param.bEmitInfoSEI is set (reference: source/encoder/encoder.cpp:3260-3280, sei.h:89-117); returns its size behind a 4-byte start code, 0 when it does not fit */
+size_t x265amd_write_info_sei(const char* text, uint8_t* out, size_t cap);
 
 /* FrameEncoder::encodeSlice (reference: source/encoder/frameencoder.cpp:1298-1370): the final CABAC pass over a decided picture -> sub-streams
  * (one per CTU row when si->wpp, else one).  sao / sao_flags (may be NULL): the SAO parameters of every CTU (reserved[0] = merge mode: 0 none,

@@ -108,7 +108,9 @@ typedef struct x265amd_param
                                              * estimateCUPropagate / cuTreeFinish (slicetype.cpp:3399-3800) on the lookahead's block costs and motion fields: referenced
                                              * pictures take their block offsets from it */
     int32_t qgSize;                         /* param.rc.qgSize (--qg-size): 64 or 32 (the default); 16 and 8 are not built */
-    int32_t reservedRc;
+    int32_t bEmitInfoSEI;                   /* param.bEmitInfoSEI (--info, the reference's default): a user-data SEI NAL unit behind the parameter sets that names the encoder and its
+                                             * options (Encoder::getStreamHeaders, encoder.cpp:3260-3280).  The reference's text carries ITS version and build strings, so this
+                                             * unit is the one part of a stream that can never be byte-equal between two builds of anything: every parity test runs --no-info */
 } x265amd_param;
 enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 

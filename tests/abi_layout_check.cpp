@@ -21,6 +21,7 @@ P(deblockingFilterBetaOffset); P(bEnableSAO); P(bSaoNonDeblocked); P(selectiveSA
 P(bIntraInBFrames); P(rdPenalty); P(psyRd); P(psyRdoq); P(bEnableRdRefine); P(analysisReuseMode); P(bLossless); P(cbQpOffset); P(crQpOffset); P(maxSlices); P(bDynamicRefine);
 P(bEnableSvtHevc); P(bEnableSceneCutAwareQp); P(bHistBasedSceneCut); P(bEnableFades); P(gopLookahead); P(radl); P(bField); P(bAQMotion); P(bSsimRd); P(dynamicRd);
 PN(rc_rateControlMode, rc.rateControlMode); PN(rc_qp, rc.qp); PN(rc_ipFactor, rc.ipFactor); PN(rc_pbFactor, rc.pbFactor); PN(rc_aqMode, rc.aqMode); PN(rc_cuTree, rc.cuTree);
+PN(rc_rfConstant, rc.rfConstant); PN(rc_aqStrength, rc.aqStrength); PN(rc_qCompress, rc.qCompress); PN(rc_qpStep, rc.qpStep); PN(rc_vbvMaxBitrate, rc.vbvMaxBitrate); PN(rc_hevcAq, rc.hevcAq); PN(rc_qgSize, rc.qgSize);
 PN(rc_qpMin, rc.qpMin); PN(rc_qpMax, rc.qpMax); PN(rc_vbvBufferSize, rc.vbvBufferSize); PN(rc_bStatRead, rc.bStatRead); PN(rc_bStatWrite, rc.bStatWrite);
 PN(vui_aspectRatioIdc, vui.aspectRatioIdc); PN(vui_bEnableVideoSignalTypePresentFlag, vui.bEnableVideoSignalTypePresentFlag);
 PN(vui_bEnableOverscanInfoPresentFlag, vui.bEnableOverscanInfoPresentFlag); PN(vui_bEnableChromaLocInfoPresentFlag, vui.bEnableChromaLocInfoPresentFlag);

@@ -3025,7 +3025,7 @@ class EncParam(C.Structure):
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
                 ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
                 ("rateControlMode", C.c_int32), ("rfConstant", C.c_double), ("aqStrength", C.c_double), ("qCompress", C.c_double), ("aqMode", C.c_int32), ("cuTree", C.c_int32),
-                ("qgSize", C.c_int32), ("reservedRc", C.c_int32)]
+                ("qgSize", C.c_int32), ("bEmitInfoSEI", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3385,9 +3385,10 @@ PRESET_CASES = {
     "crf_wqvga_medium_30/": ((416, 240), 30, 8, 2, dict(PRESET_BASE), ["--preset", "medium"]),                       # cut CTUs right and below, a scene change at 24
     "crf_fhd_medium_60/": ((1920, 1080), 60, 8, 2, dict(PRESET_BASE), ["--preset", "medium"]),                      # BASELINE.json configs[1] / the metric's first size
     "crf_2160p_medium_20/": ((3840, 2160), 20, 8, 2, dict(PRESET_BASE), ["--preset", "medium"]),                    # the metric's second size
-    "crf_cfg3_2160p_slow/": ((3840, 2160), 12, 8, 3, dict(PRESET_BASE, **SLOW_TOOLS), ["--preset", "slow"]),        # configs[2]
-    "crf_cfg4_2160p_main10/": ((3840, 2160), 12, 10, 4, dict(PRESET_BASE), ["--preset", "medium"]),                  # configs[3]
-    "crf_cfg5_4320p_veryslow_rd6/": ((7680, 4320), 3, 10, 5, dict(PRESET_BASE, **VERYSLOW_TOOLS, **VERYSLOW_GOP), ["--preset", "veryslow", "--rd", "6"]),       # configs[4]
+    "crf_cfg3_2160p_slow/": ((3840, 2160), 26, 8, 3, dict(PRESET_BASE, **SLOW_TOOLS), ["--preset", "slow"]),        # configs[2]: over the clip's re-seed at 24 (a scene cut)
+    "crf_cfg4_2160p_main10/": ((3840, 2160), 26, 10, 4, dict(PRESET_BASE), ["--preset", "medium"]),                  # configs[3]
+    # configs[4]: ten pictures -- the I picture and a whole mini-GOP of eight B pictures with its pyramid (--preset veryslow: bframes 8, --weightb)
+    "crf_cfg5_4320p_veryslow_rd6/": ((7680, 4320), 10, 10, 5, dict(PRESET_BASE, **VERYSLOW_TOOLS, **VERYSLOW_GOP), ["--preset", "veryslow", "--rd", "6"]),
 }
 
 

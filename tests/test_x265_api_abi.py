@@ -49,30 +49,173 @@ def test_api_table(depth):
     assert lib.x265_api_query(depth, 209, C.byref(err)) and err.value == 0
 
 
+def _fns(lib, depth=8):
+    api = lib.x265_api_get_209(depth).contents
+    return dict(alloc=C.CFUNCTYPE(C.c_void_p)(api.fn[0]), free=C.CFUNCTYPE(None, C.c_void_p)(api.fn[1]), default=C.CFUNCTYPE(None, C.c_void_p)(api.fn[2]),
+                parse=C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p)(api.fn[3]), preset=C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p)(api.fn[6]),
+                open=C.CFUNCTYPE(C.c_void_p, C.c_void_p)(api.fn[10]), api=api)
+
+
 def test_encoder_open_names_what_it_rejects():
-    """param_default gives the reference's defaults (CRF, b-adapt 2, lookahead slices, B pyramid ...): outside the built subset, and encoder_open says which member"""
+    """param_default gives the reference's defaults -- CRF 28, aq-mode 2, cuTree, b-adapt 2, lookahead slices, B pyramid, the info SEI: all built since round 6 (the GPU test below
+    opens and encodes with them).  What lies outside the built subset is refused BY NAME before anything touches a device"""
     lib = table(8)
-    api = lib.x265_api_get_209(8).contents
-    alloc = C.CFUNCTYPE(C.c_void_p)(api.fn[0]); free = C.CFUNCTYPE(None, C.c_void_p)(api.fn[1]); default = C.CFUNCTYPE(None, C.c_void_p)(api.fn[2])
-    preset = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p)(api.fn[6]); parse = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p)(api.fn[3])
-    opn = C.CFUNCTYPE(C.c_void_p, C.c_void_p)(api.fn[10])
+    f = _fns(lib)
     lib.x265amd_last_error.restype = C.c_char_p
-    p = alloc()
-    default(p)
+    p = f["alloc"]()
+    f["default"](p)
     buf = (C.c_ubyte * LAYOUT["SIZEOF_PARAM"]).from_address(p)
     rd = lambda name: int.from_bytes(bytes(buf[LAYOUT["PARAM_" + name]:LAYOUT["PARAM_" + name] + 4]), "little", signed=True)
-    assert (rd("bframes"), rd("bFrameAdaptive"), rd("scenecutThreshold"), rd("maxNumReferences"), rd("rdLevel"), rd("searchRange"), rd("rc_rateControlMode")) == (4, 2, 40, 3, 3, 57, 2)
-    assert preset(p, b"medium", None) == 0 and preset(p, b"veryslow", None) == -1 and parse(p, b"qp", b"30") == -1
-    buf[LAYOUT["PARAM_sourceWidth"]] = 64; buf[LAYOUT["PARAM_sourceHeight"]] = 64; buf[LAYOUT["PARAM_fpsNum"]] = 30; buf[LAYOUT["PARAM_fpsDenom"]] = 1
-    assert not opn(p) and b"rc.rateControlMode" in lib.x265amd_last_error()
-    buf[LAYOUT["PARAM_rc_rateControlMode"]] = 1
-    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 3
-    assert not opn(p) and b"bFrameAdaptive" in lib.x265amd_last_error()
-    buf[LAYOUT["PARAM_bFrameAdaptive"]] = 2
-    # --b-adapt 2, scene-cut detection, the lookahead in slices, the B pyramid and open GOPs (the defaults) are built
-    # (weighted prediction for P pictures: the analysis is built; weighted bi-prediction is off in the preset)
-    assert not opn(p) and b"bEmitInfoSEI" in lib.x265amd_last_error()
-    free(p)
+    wr = lambda name, v: buf.__setitem__(slice(LAYOUT["PARAM_" + name], LAYOUT["PARAM_" + name] + 4), list(int(v).to_bytes(4, "little", signed=True)))
+    assert (rd("bframes"), rd("bFrameAdaptive"), rd("scenecutThreshold"), rd("maxNumReferences"), rd("rdLevel"), rd("searchRange"), rd("rc_rateControlMode"), rd("rc_aqMode"), rd("rc_cuTree"), rd("bEmitInfoSEI")) == (4, 2, 40, 3, 3, 57, 2, 2, 1, 1)
+    wr("sourceWidth", 64); wr("sourceHeight", 64); wr("fpsNum", 30); wr("fpsDenom", 1)
+    for name, value, word in (("rc_rateControlMode", 0, b"rc.rateControlMode"), ("bFrameAdaptive", 3, b"bFrameAdaptive"), ("rc_hevcAq", 1, b"hevc-aq"), ("maxCUSize", 32, b"maxCUSize"),
+                              ("limitTU", 4, b"limitTU"), ("bEnableTransformSkip", 1, b"bEnableTransformSkip"), ("searchMethod", 2, b"searchMethod")):
+        keep = rd(name)
+        wr(name, value)
+        assert not f["open"](p) and word in lib.x265amd_last_error(), (name, lib.x265amd_last_error())
+        wr(name, keep)
+    f["free"](p)
+
+
+PRESETS = ["ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo"]
+# the members x265_encoder_open reads or refuses by name (x265_api_abi.cpp) and the option tables / parser write: name -> bytes
+_MEMBERS_I = ["bEnableWavefront", "frameNumThreads", "internalBitDepth", "internalCsp", "bOpenGOP", "keyframeMin", "keyframeMax", "bframes", "bFrameAdaptive", "bBPyramid", "lookaheadDepth",
+              "lookaheadSlices", "scenecutThreshold", "maxCUSize", "minCUSize", "maxTUSize", "bEnableRectInter", "bEnableAMP", "tuQTMaxInterDepth", "tuQTMaxIntraDepth", "limitTU", "rdoqLevel",
+              "bEnableSignHiding", "bEnableTransformSkip", "bEnableStrongIntraSmoothing", "maxNumMergeCand", "limitReferences", "limitModes", "searchMethod", "subpelRefine", "searchRange",
+              "bEnableTemporalMvp", "bEnableWeightedPred", "bEnableWeightedBiPred", "bEnableLoopFilter", "bEnableSAO", "rdLevel", "bEnableEarlySkip", "recursionSkipMode", "bEnableFastIntra",
+              "bIntraInBFrames", "maxNumReferences", "bEmitInfoSEI", "bAnnexB", "maxSlices", "rc_rateControlMode", "rc_qp", "rc_aqMode", "rc_cuTree", "rc_qpMin", "rc_qpMax", "rc_qgSize", "rc_hevcAq",
+              "rc_qpStep", "rc_vbvBufferSize", "rc_vbvMaxBitrate", "rc_bitrate", "bLossless", "bRepeatHeaders", "levelIdc"]
+_MEMBERS_D = ["psyRd", "psyRdoq", "rc_ipFactor", "rc_pbFactor", "rc_rfConstant", "rc_aqStrength", "rc_qCompress"]
+
+
+def _members(p):
+    buf = (C.c_ubyte * LAYOUT["SIZEOF_PARAM"]).from_address(p)
+    out = {}
+    for n in _MEMBERS_I:
+        out[n] = int.from_bytes(bytes(buf[LAYOUT["PARAM_" + n]:LAYOUT["PARAM_" + n] + 4]), "little", signed=True)
+    for n in _MEMBERS_D:
+        out[n] = bytes(buf[LAYOUT["PARAM_" + n]:LAYOUT["PARAM_" + n] + 8]).hex()
+    return out
+
+
+def _reference_api():
+    R = C.CDLL(T.ref_lib_path(8)) if hasattr(T, "ref_lib_path") else C.CDLL(os.path.join(T.REF_DIR, "libx265_ref8.so"))
+    R.x265_param_alloc.restype = C.c_void_p
+    R.x265_param_free.argtypes = [C.c_void_p]
+    R.x265_param_default_preset.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    R.x265_param_parse.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    return R
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")
+@pytest.mark.parametrize("preset", PRESETS + ["0", "9", "6"])
+def test_param_default_preset_matches_the_references(preset):
+    """our table's x265_param_default_preset against the reference library's own, for all ten presets (by name and by number) and the two tunes restated: every member that
+    x265_encoder_open reads or the option tables write holds the same bytes (doubles bit for bit: rc.ipFactor is the float literal 1.4f widened)"""
+    R, f = _reference_api(), _fns(table(8))
+    for tune in (None, b"psnr", b"ssim"):
+        a, b = R.x265_param_alloc(), f["alloc"]()
+        assert R.x265_param_default_preset(a, preset.encode(), tune) == 0 and f["preset"](b, preset.encode(), tune) == 0
+        ma, mb = _members(a), _members(b)
+        assert ma == mb, {k: (ma[k], mb[k]) for k in ma if ma[k] != mb[k]}
+        R.x265_param_free(a); f["free"](b)
+    b = f["alloc"]()
+    assert f["preset"](b, b"nosuchpreset", None) == -1 and f["preset"](b, b"medium", b"grain") == -1
+    f["free"](b)
+
+
+PARSE_CASES = [("crf", "23.5"), ("qp", "30"), ("bframes", "3"), ("b-adapt", "1"), ("no-b-pyramid", None), ("open-gop", "0"), ("keyint", "120"), ("min-keyint", "12"), ("ref", "4"),
+               ("rd", "4"), ("rdoq-level", "2"), ("psy-rd", "1.5"), ("psy-rdoq", "1.0"), ("me", "star"), ("me", "0"), ("subme", "3"), ("merange", "44"), ("max-merge", "4"),
+               ("rect", None), ("amp", "1"), ("no-sao", None), ("no-deblock", None), ("no-wpp", None), ("weightb", None), ("no-weightp", None), ("aq-mode", "3"), ("aq-strength", "0.8"),
+               ("no-cutree", None), ("qcomp", "0.7"), ("ipratio", "1.3"), ("pbratio", "1.2"), ("qg-size", "64"), ("rc-lookahead", "30"), ("lookahead-slices", "0"), ("scenecut", "0"),
+               ("tu-intra-depth", "2"), ("tu-inter-depth", "3"), ("limit-refs", "1"), ("limit-modes", None), ("no-early-skip", None), ("rskip", "0"), ("b-intra", "0"), ("no-signhide", None),
+               ("no-strong-intra-smoothing", None), ("no-temporal-mvp", None), ("fast-intra", None), ("no-info", None), ("frame-threads", "2"), ("bitrate", "1000"), ("qpmin", "10"), ("qpmax", "40"),
+               ("rd", "x"), ("nosuchoption", "1")]
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")
+def test_param_parse_matches_the_references():
+    """x265_param_parse through our table against the reference library's own, option by option on a fresh `medium` param: the same return code and the same members"""
+    R, f = _reference_api(), _fns(table(8))
+    for name, value in PARSE_CASES:
+        a, b = R.x265_param_alloc(), f["alloc"]()
+        R.x265_param_default_preset(a, b"medium", None); f["preset"](b, b"medium", None)
+        v = value.encode() if value is not None else None
+        ra, rb = R.x265_param_parse(a, name.encode(), v), f["parse"](b, name.encode(), v)
+        assert ra == rb, (name, value, ra, rb)
+        ma, mb = _members(a), _members(b)
+        assert ma == mb, (name, value, {k: (ma[k], mb[k]) for k in ma if ma[k] != mb[k]})
+        R.x265_param_free(a); f["free"](b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["medium", "slow"])
+def test_param_default_preset_opens_and_encodes(preset):
+    """x265_api.param_default_preset + a picture size must open and encode -- the reference's defaults as they come: CRF 28, aq-mode 2, cuTree, the info SEI.  The
+    parameter sets are followed by the user-data SEI unit (NAL type 39); with --no-info the stream is the encoder object's own for the same settings (compared with the
+    reference's in tests/test_encoder_full_size.py)"""
+    lib = table(8)
+    f = _fns(lib)
+    api = f["api"]
+    lib.x265amd_last_error.restype = C.c_char_p
+    headers = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32))(api.fn[12])
+    encode = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p)(api.fn[15])
+    close = C.CFUNCTYPE(None, C.c_void_p)(api.fn[18])
+    pic_alloc = C.CFUNCTYPE(C.c_void_p)(api.fn[7]); pic_init = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)(api.fn[9])
+    w, h, n = 416, 240, 12
+    frames = T.survey_clip(w, h, 8, 2, 0, n)
+    streams = {}
+    for info in (1, 0):
+        p = f["alloc"]()
+        assert f["preset"](p, preset.encode(), None) == 0
+        assert f["parse"](p, b"input-res", b"%dx%d" % (w, h)) == 0 and f["parse"](p, b"fps", b"30") == 0
+        if not info:
+            assert f["parse"](p, b"no-info", None) == 0
+        enc = f["open"](p)
+        assert enc, lib.x265amd_last_error()
+        nal = C.POINTER(T.EncNal)(); nnal = C.c_uint32(0)
+        assert headers(enc, C.byref(nal), C.byref(nnal)) > 0
+        types = [nal[i].type for i in range(nnal.value)]
+        assert types == ([32, 33, 34, 39] if info else [32, 33, 34]), types
+        out = bytearray()
+        if info:
+            sei = bytes(nal[3].payload[:nal[3].sizeBytes])
+            assert b"x265amd" in sei and b"crf=28" in sei and b"cutree=1" in sei
+        for i in range(nnal.value if not info else 3):
+            out += bytes(nal[i].payload[:nal[i].sizeBytes])
+        pic = pic_alloc(); pic_init(p, pic)
+        pbuf = (C.c_ubyte * LAYOUT["SIZEOF_PICTURE"]).from_address(pic)
+        coded = 0
+        for t in range(n + 1):
+            if t < n:
+                keep = [np.ascontiguousarray(pl) for pl in frames[t]]
+                for k in range(3):
+                    pbuf[LAYOUT["PIC_planes"] + 8 * k:LAYOUT["PIC_planes"] + 8 * k + 8] = list(int(keep[k].ctypes.data).to_bytes(8, "little"))
+                    pbuf[LAYOUT["PIC_stride"] + 4 * k:LAYOUT["PIC_stride"] + 4 * k + 4] = list(int(keep[k].strides[0]).to_bytes(4, "little"))
+                pbuf[LAYOUT["PIC_pts"]:LAYOUT["PIC_pts"] + 8] = list(int(t).to_bytes(8, "little"))
+                r = encode(enc, C.byref(nal), C.byref(nnal), pic, None)
+                assert r >= 0, lib.x265amd_last_error()
+                if r:
+                    coded += 1
+                    for i in range(nnal.value):
+                        out += bytes(nal[i].payload[:nal[i].sizeBytes])
+            else:
+                while True:
+                    r = encode(enc, C.byref(nal), C.byref(nnal), None, None)
+                    assert r >= 0, lib.x265amd_last_error()
+                    if not r:
+                        break
+                    coded += 1
+                    for i in range(nnal.value):
+                        out += bytes(nal[i].payload[:nal[i].sizeBytes])
+        assert coded == n
+        close(enc); f["free"](p)
+        streams[info] = bytes(out)
+    assert streams[1] == streams[0]            # (the SEI unit left out of the first: everything else is the same stream)
+    cfg = dict(T.PRESET_BASE, aspectRatioIdc=0, **(T.SLOW_TOOLS if preset == "slow" else {}))
+    own, _ = T.encoder_run(T.load_hip(8), frames, w, h, **cfg)
+    assert bytes(own) == streams[0]
 
 
 @pytest.mark.needs_ref

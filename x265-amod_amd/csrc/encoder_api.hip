@@ -510,6 +510,25 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     const size_t n = x265amd_write_stream_headers(&sp, e->headerBytes.data(), e->headerBytes.size());
     if (!n || n > e->headerBytes.size()) { xa_fail(X265AMD_EINVAL, "encoder_open: stream headers"); return nullptr; }
     e->headerBytes.resize(n);
+    if (p->bEmitInfoSEI)
+    {
+        /* Encoder::getStreamHeaders' fourth unit (encoder.cpp:3260-3280): who coded this and with what -- the reference's own text names ITS build, this one names this library */
+        char text[1024];
+        snprintf(text, sizeof(text), "x265amd (x265 build 209 interface) - %s - H.265/HEVC codec on AMD Instinct MI355X - options: %dx%d fps=%u/%u bitdepth=%d %s=%g aq-mode=%d aq-strength=%.2f "
+                 "cutree=%d qcomp=%.2f qg-size=%d bframes=%d b-adapt=%d b-pyramid=%d open-gop=%d keyint=%d min-keyint=%d scenecut=%d rc-lookahead=%d lookahead-slices=%d ref=%d limit-refs=%d "
+                 "rd=%d rdoq-level=%d psy-rd=%.2f me=%d subme=%d merange=%d max-merge=%d rect=%d amp=%d limit-modes=%d early-skip=%d rskip=%d weightp=%d weightb=%d sao=%d deblock=%d wpp=%d "
+                 "tu-intra-depth=%d tu-inter-depth=%d signhide=%d strong-intra-smoothing=%d temporal-mvp=%d b-intra=%d fast-intra=%d",
+                 x265amd_version(), p->sourceWidth, p->sourceHeight, p->fpsNum, p->fpsDenom, X265AMD_DEPTH, p->rateControlMode == X265AMD_RC_CRF ? "crf" : "qp",
+                 p->rateControlMode == X265AMD_RC_CRF ? p->rfConstant : (double)p->qp, e->aqOn ? p->aqMode : 0, p->aqStrength, p->cuTree != 0, p->qCompress, p->qgSize, p->bframes, p->bFrameAdaptive,
+                 p->bBPyramid != 0, p->bOpenGOP != 0, p->keyframeMax, e->keyframeMin, p->scenecutThreshold, p->lookaheadDepth, p->lookaheadSlices, p->maxNumReferences, p->limitReferences,
+                 p->rdLevel, p->rdoqLevel, p->psyRd, p->searchMethod, p->subpelRefine, p->searchRange, p->maxNumMergeCand, p->bEnableRectInter != 0, p->bEnableAMP != 0, p->limitModes != 0,
+                 p->bEnableEarlySkip != 0, p->recursionSkipMode, p->bEnableWeightedPred != 0, p->bEnableWeightedBiPred != 0, p->bEnableSAO != 0, p->bEnableLoopFilter != 0, p->bEnableWavefront != 0,
+                 p->tuQTMaxIntraDepth, p->tuQTMaxInterDepth, p->bEnableSignHiding != 0, p->bEnableStrongIntraSmoothing != 0, p->bEnableTemporalMvp != 0, p->bIntraInBFrames != 0, p->bEnableFastIntra != 0);
+        uint8_t sei[1400];
+        const size_t m = x265amd_write_info_sei(text, sei, sizeof(sei));
+        if (!m) { xa_fail(X265AMD_EINVAL, "encoder_open: info SEI"); return nullptr; }
+        e->headerBytes.insert(e->headerBytes.end(), sei, sei + m);
+    }
     return e.release();
 }
 

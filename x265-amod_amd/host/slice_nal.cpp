@@ -68,6 +68,29 @@ void profileTier(Bits& b, const x265amd_stream_params* p)
 
 }
 
+/* The user-data SEI NAL unit that names the encoder and its options (Encoder::getStreamHeaders, encoder.cpp:3260-3280; SEIuserDataUnregistered, sei.h:89-117; SEI::writeSEImessages,
+ * sei.cpp:35-75): prefix SEI (NAL type 39), payload type 5, the reference's UUID, the text, rbsp trailing bits.  Returns the unit's size behind a 4-byte start code, 0 when
+ * it does not fit. */
+extern "C" size_t x265amd_write_info_sei(const char* text, uint8_t* out, size_t cap)
+{
+    if (!text || !out) return 0;
+    static const uint8_t uuid[16] = { 0x2C, 0xA2, 0xDE, 0x09, 0xB5, 0x17, 0x47, 0xDB, 0xBB, 0x55, 0xA4, 0xFE, 0x7F, 0xC2, 0xFC, 0x4E };
+    const size_t len = strlen(text);
+    Bits b;
+    b.put(5, 8);                                    /* payload type: user_data_unregistered */
+    size_t size = 16 + len;
+    for (; size >= 0xff; size -= 0xff) b.put(0xff, 8);
+    b.put((uint32_t)size, 8);
+    for (int i = 0; i < 16; i++) b.put(uuid[i], 8);
+    for (size_t i = 0; i < len; i++) b.put((uint8_t)text[i], 8);
+    b.align();                                      /* rbsp_trailing_bits */
+    std::vector<uint8_t> nal;
+    serialize(nal, 39, 1, true, b.out);
+    if (nal.size() > cap) return 0;
+    memcpy(out, nal.data(), nal.size());
+    return nal.size();
+}
+
 /* Encoder::getStreamHeaders (encoder.cpp:3234-3259): VPS, SPS and PPS NAL units, each behind a 4-byte start code.
  * Entropy::codeVPS / codeSPS / codeVUI / codePPS (entropy.cpp:233-378, :431-502); no scaling lists, no SPS reference picture sets, no HRD. */
 extern "C" size_t x265amd_write_stream_headers(const x265amd_stream_params* p, uint8_t* out, size_t cap)

@@ -68,17 +68,165 @@ void abi_param_default(void* p)
     wr<int32_t>(p, X265ABI_PARAM_recursionSkipMode, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSignHiding, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableStrongIntraSmoothing, 1);
     wr<int32_t>(p, X265ABI_PARAM_bEnableTemporalMvp, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableLoopFilter, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSAO, 1);
     wr<int32_t>(p, X265ABI_PARAM_rdLevel, 3); wr<int32_t>(p, X265ABI_PARAM_bIntraInBFrames, 1); wr<double>(p, X265ABI_PARAM_psyRd, 2.0); wr<double>(p, X265ABI_PARAM_psyRdoq, 0.0);
-    wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 2 /* X265_RC_CRF */); wr<int32_t>(p, X265ABI_PARAM_rc_qp, 32); wr<double>(p, X265ABI_PARAM_rc_ipFactor, 1.4);
-    wr<double>(p, X265ABI_PARAM_rc_pbFactor, 1.3); wr<int32_t>(p, X265ABI_PARAM_rc_aqMode, 2); wr<int32_t>(p, X265ABI_PARAM_rc_cuTree, 1);
+    wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 2 /* X265_RC_CRF */); wr<int32_t>(p, X265ABI_PARAM_rc_qp, 32); wr<double>(p, X265ABI_PARAM_rc_ipFactor, 1.4f);
+    wr<double>(p, X265ABI_PARAM_rc_pbFactor, 1.3f); wr<int32_t>(p, X265ABI_PARAM_rc_aqMode, 2); wr<int32_t>(p, X265ABI_PARAM_rc_cuTree, 1);
+    wr<double>(p, X265ABI_PARAM_rc_rfConstant, 28); wr<double>(p, X265ABI_PARAM_rc_aqStrength, 1.0); wr<double>(p, X265ABI_PARAM_rc_qCompress, 0.6);
+    wr<int32_t>(p, X265ABI_PARAM_rc_qgSize, 32); wr<int32_t>(p, X265ABI_PARAM_rc_qpStep, 4);
     wr<int32_t>(p, X265ABI_PARAM_rc_qpMin, 0); wr<int32_t>(p, X265ABI_PARAM_rc_qpMax, 69); wr<int32_t>(p, X265ABI_PARAM_maxSlices, 1);
 }
+/* x265_param_default_preset (source/common/param.cpp:405-600): the ten presets' option tables and the tunes that only touch members read here (psnr, ssim).  Members outside
+ * the built subset are written as the reference writes them -- maxCUSize 32 of ultrafast / superfast, limitTU of slower, transform skip of placebo: x265_encoder_open names
+ * what it cannot code. */
 int abi_param_default_preset(void* p, const char* preset, const char* tune)
 {
-    if (!p || (preset && strcmp(preset, "medium") != 0 && strcmp(preset, "5") != 0) || (tune && *tune)) return -1;        /* the other presets' / tunes' option tables are not restated */
-    abi_param_default(p);                /* --preset medium is the defaults (param.cpp:496-499) */
+    if (!p) return -1;
+    abi_param_default(p);
+#define SI(f, v) wr<int32_t>(p, X265ABI_PARAM_##f, v)
+#define SD(f, v) wr<double>(p, X265ABI_PARAM_##f, v)
+    if (preset)
+    {
+        static const char* const names[] = { "ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "slow", "slower", "veryslow", "placebo" };
+        char* end;
+        const long i = strtol(preset, &end, 10);
+        if (*end == 0 && i >= 0 && i < 10) preset = names[i];
+        if (!strcmp(preset, "ultrafast"))
+        {
+            SI(maxNumMergeCand, 2); SI(bIntraInBFrames, 0); SI(lookaheadDepth, 5); SI(scenecutThreshold, 0); SI(maxCUSize, 32); SI(minCUSize, 16); SI(bframes, 3); SI(bFrameAdaptive, 0);
+            SI(subpelRefine, 0); SI(searchMethod, 0); SI(bEnableSAO, 0); SI(bEnableSignHiding, 0); SI(bEnableWeightedPred, 0); SI(rdLevel, 2); SI(maxNumReferences, 1); SI(limitReferences, 0);
+            SD(rc_aqStrength, 0.0); SI(rc_aqMode, 0); SI(rc_hevcAq, 0); SI(rc_qgSize, 32); SI(bEnableFastIntra, 1);
+        }
+        else if (!strcmp(preset, "superfast"))
+        {
+            SI(maxNumMergeCand, 2); SI(bIntraInBFrames, 0); SI(lookaheadDepth, 10); SI(maxCUSize, 32); SI(bframes, 3); SI(bFrameAdaptive, 0); SI(subpelRefine, 1); SI(bEnableWeightedPred, 0);
+            SI(rdLevel, 2); SI(maxNumReferences, 1); SI(limitReferences, 0); SD(rc_aqStrength, 0.0); SI(rc_aqMode, 0); SI(rc_hevcAq, 0); SI(rc_qgSize, 32); SI(bEnableSAO, 0); SI(bEnableFastIntra, 1);
+        }
+        else if (!strcmp(preset, "veryfast"))
+        { SI(maxNumMergeCand, 2); SI(bIntraInBFrames, 0); SI(lookaheadDepth, 15); SI(bFrameAdaptive, 0); SI(subpelRefine, 1); SI(rdLevel, 2); SI(maxNumReferences, 2); SI(rc_qgSize, 32); SI(bEnableFastIntra, 1); }
+        else if (!strcmp(preset, "faster"))
+        { SI(maxNumMergeCand, 2); SI(bIntraInBFrames, 0); SI(lookaheadDepth, 15); SI(bFrameAdaptive, 0); SI(rdLevel, 2); SI(maxNumReferences, 2); SI(bEnableFastIntra, 1); }
+        else if (!strcmp(preset, "fast"))
+        { SI(maxNumMergeCand, 2); SI(bEnableEarlySkip, 0); SI(bIntraInBFrames, 0); SI(lookaheadDepth, 15); SI(bFrameAdaptive, 0); SI(rdLevel, 2); SI(maxNumReferences, 3); SI(bEnableFastIntra, 1); }
+        else if (!strcmp(preset, "medium")) { }
+        else if (!strcmp(preset, "slow"))
+        {
+            SI(bEnableEarlySkip, 0); SI(bIntraInBFrames, 0); SI(bEnableRectInter, 1); SI(lookaheadDepth, 25); SI(rdLevel, 4); SI(rdoqLevel, 2); SD(psyRdoq, 1.0); SI(subpelRefine, 3);
+            SI(searchMethod, 3); SI(maxNumReferences, 4); SI(limitModes, 1); SI(lookaheadSlices, 4);
+        }
+        else if (!strcmp(preset, "slower"))
+        {
+            SI(bEnableEarlySkip, 0); SI(bEnableWeightedBiPred, 1); SI(bEnableAMP, 1); SI(bEnableRectInter, 1); SI(lookaheadDepth, 40); SI(bframes, 8); SI(tuQTMaxInterDepth, 3); SI(tuQTMaxIntraDepth, 3);
+            SI(rdLevel, 6); SI(rdoqLevel, 2); SD(psyRdoq, 1.0); SI(subpelRefine, 4); SI(maxNumMergeCand, 4); SI(searchMethod, 3); SI(maxNumReferences, 5); SI(limitModes, 1); SI(limitReferences, 1);
+            SI(lookaheadSlices, 0); SI(limitTU, 4);
+        }
+        else if (!strcmp(preset, "veryslow"))
+        {
+            SI(bEnableEarlySkip, 0); SI(bEnableWeightedBiPred, 1); SI(bEnableAMP, 1); SI(bEnableRectInter, 1); SI(lookaheadDepth, 40); SI(bframes, 8); SI(tuQTMaxInterDepth, 3); SI(tuQTMaxIntraDepth, 3);
+            SI(rdLevel, 6); SI(rdoqLevel, 2); SD(psyRdoq, 1.0); SI(subpelRefine, 4); SI(maxNumMergeCand, 5); SI(searchMethod, 3); SI(maxNumReferences, 5); SI(limitReferences, 0); SI(limitModes, 0);
+            SI(lookaheadSlices, 0); SI(limitTU, 0);
+        }
+        else if (!strcmp(preset, "placebo"))
+        {
+            SI(bEnableEarlySkip, 0); SI(bEnableWeightedBiPred, 1); SI(bEnableAMP, 1); SI(bEnableRectInter, 1); SI(lookaheadDepth, 60); SI(searchRange, 92); SI(bframes, 8); SI(tuQTMaxInterDepth, 4);
+            SI(tuQTMaxIntraDepth, 4); SI(rdLevel, 6); SI(rdoqLevel, 2); SD(psyRdoq, 1.0); SI(subpelRefine, 5); SI(maxNumMergeCand, 5); SI(searchMethod, 3); SI(bEnableTransformSkip, 1);
+            SI(recursionSkipMode, 0); SI(maxNumReferences, 5); SI(limitReferences, 0); SI(lookaheadSlices, 0);
+        }
+        else return -1;
+    }
+    if (tune && *tune)
+    {
+        if (!strcmp(tune, "psnr")) { SD(rc_aqStrength, 0.0); SD(psyRd, 0.0); SD(psyRdoq, 0.0); }
+        else if (!strcmp(tune, "ssim")) { SI(rc_aqMode, 2); SD(psyRd, 0.0); SD(psyRdoq, 0.0); }
+        else return -1;         /* grain / fastdecode / zerolatency / animation / vmaf reach members this library does not read */
+    }
     return 0;
 }
-int abi_param_parse(void*, const char*, const char*) { return -1; }        /* X265_PARAM_BAD_NAME: the option parser is not part of the hot path */
+
+/* x265_param_parse (source/common/param.cpp:845-1420) for the options whose members x265_encoder_open reads here: the long names of the reference's command line, "no-<name>"
+ * for the switches, NULL or "" = true.  Returns 0, X265_PARAM_BAD_NAME (-1) for a name that is not restated, X265_PARAM_BAD_VALUE (-2). */
+int abi_param_parse(void* p, const char* name, const char* value)
+{
+    if (!p || !name) return -1;
+    char nm[64];
+    size_t n = 0;
+    for (; name[n] && n + 1 < sizeof(nm); n++) nm[n] = name[n] == '_' ? '-' : name[n];
+    nm[n] = 0;
+    const char* key = nm;
+    if (key[0] == '-' && key[1] == '-') key += 2;
+    bool neg = false;
+    if (!strncmp(key, "no-", 3)) { neg = true; key += 3; }
+    auto truth = [&](bool& bad) -> int {
+        if (!value || !*value || !strcmp(value, "1") || !strcmp(value, "true") || !strcmp(value, "yes")) return neg ? 0 : 1;
+        if (!strcmp(value, "0") || !strcmp(value, "false") || !strcmp(value, "no")) return neg ? 1 : 0;
+        bad = true; return 0;
+    };
+    auto num = [&](bool& bad) -> int { if (!value || !*value) { bad = true; return 0; } char* e; const long v = strtol(value, &e, 0); if (*e) bad = true; return (int)v; };
+    auto real = [&](bool& bad) -> double { if (!value || !*value) { bad = true; return 0; } char* e; const double v = strtod(value, &e); if (*e) bad = true; return v; };
+    bool bad = false;
+    static const struct { const char* name; size_t off; } switches[] = {
+        { "wpp", X265ABI_PARAM_bEnableWavefront }, { "open-gop", X265ABI_PARAM_bOpenGOP }, { "b-pyramid", X265ABI_PARAM_bBPyramid }, { "rect", X265ABI_PARAM_bEnableRectInter },
+        { "amp", X265ABI_PARAM_bEnableAMP }, { "signhide", X265ABI_PARAM_bEnableSignHiding }, { "strong-intra-smoothing", X265ABI_PARAM_bEnableStrongIntraSmoothing },
+        { "temporal-mvp", X265ABI_PARAM_bEnableTemporalMvp }, { "weightp", X265ABI_PARAM_bEnableWeightedPred }, { "weightb", X265ABI_PARAM_bEnableWeightedBiPred },
+        { "deblock", X265ABI_PARAM_bEnableLoopFilter }, { "sao", X265ABI_PARAM_bEnableSAO }, { "early-skip", X265ABI_PARAM_bEnableEarlySkip }, { "fast-intra", X265ABI_PARAM_bEnableFastIntra },
+        { "b-intra", X265ABI_PARAM_bIntraInBFrames }, { "limit-modes", X265ABI_PARAM_limitModes }, { "cutree", X265ABI_PARAM_rc_cuTree }, { "info", X265ABI_PARAM_bEmitInfoSEI },
+        { "annexb", X265ABI_PARAM_bAnnexB }, { "repeat-headers", X265ABI_PARAM_bRepeatHeaders }, { "tskip", X265ABI_PARAM_bEnableTransformSkip }, { "lossless", X265ABI_PARAM_bLossless } };
+    for (const auto& sw : switches)
+        if (!strcmp(key, sw.name)) { const int v = truth(bad); if (bad) return -2; wr<int32_t>(p, sw.off, v); return 0; }
+    if (neg) return -1;
+    static const struct { const char* name; size_t off; } ints[] = {
+        { "frame-threads", X265ABI_PARAM_frameNumThreads }, { "bframes", X265ABI_PARAM_bframes }, { "b-adapt", X265ABI_PARAM_bFrameAdaptive }, { "rc-lookahead", X265ABI_PARAM_lookaheadDepth },
+        { "lookahead-slices", X265ABI_PARAM_lookaheadSlices }, { "scenecut", X265ABI_PARAM_scenecutThreshold }, { "keyint", X265ABI_PARAM_keyframeMax }, { "min-keyint", X265ABI_PARAM_keyframeMin },
+        { "ref", X265ABI_PARAM_maxNumReferences }, { "limit-refs", X265ABI_PARAM_limitReferences }, { "rd", X265ABI_PARAM_rdLevel }, { "rdoq-level", X265ABI_PARAM_rdoqLevel },
+        { "subme", X265ABI_PARAM_subpelRefine }, { "merange", X265ABI_PARAM_searchRange }, { "max-merge", X265ABI_PARAM_maxNumMergeCand }, { "tu-intra-depth", X265ABI_PARAM_tuQTMaxIntraDepth },
+        { "tu-inter-depth", X265ABI_PARAM_tuQTMaxInterDepth }, { "limit-tu", X265ABI_PARAM_limitTU }, { "rskip", X265ABI_PARAM_recursionSkipMode }, { "aq-mode", X265ABI_PARAM_rc_aqMode },
+        { "qg-size", X265ABI_PARAM_rc_qgSize }, { "ctu", X265ABI_PARAM_maxCUSize }, { "min-cu-size", X265ABI_PARAM_minCUSize }, { "max-tu-size", X265ABI_PARAM_maxTUSize },
+        { "slices", X265ABI_PARAM_maxSlices }, { "level-idc", X265ABI_PARAM_levelIdc }, { "log-level", X265ABI_PARAM_logLevel }, { "qpmin", X265ABI_PARAM_rc_qpMin }, { "qpmax", X265ABI_PARAM_rc_qpMax },
+        { "qpstep", X265ABI_PARAM_rc_qpStep }, { "vbv-bufsize", X265ABI_PARAM_rc_vbvBufferSize }, { "vbv-maxrate", X265ABI_PARAM_rc_vbvMaxBitrate } };
+    for (const auto& it : ints)
+        if (!strcmp(key, it.name)) { const int v = num(bad); wr<int32_t>(p, it.off, v); return bad ? -2 : 0; }          /* (the reference stores what atoi made of a bad value, too) */
+    static const struct { const char* name; size_t off; } reals[] = {
+        { "psy-rd", X265ABI_PARAM_psyRd }, { "psy-rdoq", X265ABI_PARAM_psyRdoq }, { "aq-strength", X265ABI_PARAM_rc_aqStrength }, { "qcomp", X265ABI_PARAM_rc_qCompress },
+        { "ipratio", X265ABI_PARAM_rc_ipFactor }, { "pbratio", X265ABI_PARAM_rc_pbFactor } };
+    for (const auto& it : reals)
+        if (!strcmp(key, it.name)) { const double v = real(bad); wr<double>(p, it.off, v); return bad ? -2 : 0; }
+    if (!strcmp(key, "crf")) { const double v = real(bad); if (bad) return -2; wr<double>(p, X265ABI_PARAM_rc_rfConstant, v); wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 2); return 0; }
+    if (!strcmp(key, "qp")) { const int v = num(bad); if (bad) return -2; wr<int32_t>(p, X265ABI_PARAM_rc_qp, v); wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 1); return 0; }
+    if (!strcmp(key, "bitrate")) { const int v = num(bad); if (bad) return -2; wr<int32_t>(p, X265ABI_PARAM_rc_bitrate, v); wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 0); return 0; }
+    if (!strcmp(key, "me"))
+    {
+        static const char* const me[] = { "dia", "hex", "umh", "star", "sea", "full" };
+        if (!value) return -2;
+        for (int i = 0; i < 6; i++) if (!strcmp(value, me[i])) { wr<int32_t>(p, X265ABI_PARAM_searchMethod, i); return 0; }
+        const int v = num(bad); if (bad || v < 0 || v > 5) return -2;
+        wr<int32_t>(p, X265ABI_PARAM_searchMethod, v); return 0;
+    }
+    if (!strcmp(key, "fps"))
+    {
+        if (!value) return -2;
+        unsigned a = 0, b = 0;
+        if (sscanf(value, "%u/%u", &a, &b) == 2 && a && b) { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, a); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, b); return 0; }
+        const double f = real(bad); if (bad || f <= 0) return -2;
+        if (f == (int)f) { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, (uint32_t)f); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, 1); }
+        else { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, (uint32_t)(f * 1000 + .5)); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, 1000); }
+        return 0;
+    }
+    if (!strcmp(key, "input-res"))
+    {
+        int w = 0, h = 0;
+        if (!value || sscanf(value, "%dx%d", &w, &h) != 2) return -2;
+        wr<int32_t>(p, X265ABI_PARAM_sourceWidth, w); wr<int32_t>(p, X265ABI_PARAM_sourceHeight, h); return 0;
+    }
+    if (!strcmp(key, "pools") || !strcmp(key, "numa-pools"))
+    {
+        /* the string is kept for the life of the param, as strdup in the reference (param.cpp:949); x265_param_free does not own it either */
+        wr<const char*>(p, X265ABI_PARAM_numaPools, value ? strdup(value) : nullptr); return 0;
+    }
+    if (!strcmp(key, "sar"))
+    {
+        const int v = num(bad); if (bad) return -2;
+        wr<int32_t>(p, X265ABI_PARAM_vui_aspectRatioIdc, v); return 0;
+    }
+    return -1;
+}
 int abi_param_apply_profile(void* p, const char* profile)
 {
     if (!p || !profile) return 0;
@@ -108,11 +256,11 @@ void* abi_encoder_open(void* p)
 #define REQUIRE(cond, text) do { if (!bad && !(cond)) bad = text; } while (0)
     REQUIRE(PI(p, internalBitDepth) == X265AMD_DEPTH, "internalBitDepth differs from this library's (libx265amd_main: 8, libx265amd_main10: 10)");
     REQUIRE(PI(p, internalCsp) == 1, "internalCsp: only X265_CSP_I420 is built");
-    REQUIRE(PI(p, rc_rateControlMode) == 1, "rc.rateControlMode: only X265_RC_CQP (--qp) is built (no ABR / CRF / VBV)");
+    REQUIRE(PI(p, rc_rateControlMode) == 1 || PI(p, rc_rateControlMode) == 2, "rc.rateControlMode: X265_RC_CQP (--qp) and X265_RC_CRF (--crf) are built, ABR (--bitrate) is not");
+    REQUIRE(!PI(p, rc_hevcAq) && PI(p, rc_vbvMaxBitrate) == 0, "rc: hevc-aq and VBV are not built");
     REQUIRE(PI(p, rc_vbvBufferSize) == 0 && !PI(p, rc_bStatRead) && !PI(p, rc_bStatWrite), "rc: VBV and multi-pass statistics are not built");
     REQUIRE(PI(p, bFrameAdaptive) >= 0 && PI(p, bFrameAdaptive) <= 2, "bFrameAdaptive (--b-adapt): 0, 1 or 2");
     REQUIRE(!PI(p, bHistBasedSceneCut), "bHistBasedSceneCut: histogram scene-cut detection is not built");
-    REQUIRE(!PI(p, bEmitInfoSEI), "bEmitInfoSEI: the option-string SEI is not written (--no-info)");
     REQUIRE(PI(p, maxCUSize) == 64 && PI(p, minCUSize) == 8 && PI(p, maxTUSize) == 32, "maxCUSize / minCUSize / maxTUSize: only 64 / 8 / 32 are built");
     REQUIRE(!PI(p, interlaceMode) && !PI(p, bField), "interlaced coding is not built");
     REQUIRE(!PI(p, bLossless) && !PI(p, bCULossless), "lossless coding is not built");
@@ -140,6 +288,15 @@ void* abi_encoder_open(void* p)
     q.bframes = PI(p, bframes); q.keyframeMax = PI(p, keyframeMax); q.maxNumReferences = PI(p, maxNumReferences);
     q.scenecutThreshold = PI(p, scenecutThreshold); q.lookaheadDepth = PI(p, lookaheadDepth); q.keyframeMin = PI(p, keyframeMin); q.bFrameAdaptive = PI(p, bFrameAdaptive); q.bOpenGOP = PI(p, bOpenGOP) != 0; q.bBPyramid = PI(p, bBPyramid) != 0; q.lookaheadSlices = PI(p, lookaheadSlices); q.bEnableWeightedPred = PI(p, bEnableWeightedPred) != 0; q.bEnableWeightedBiPred = PI(p, bEnableWeightedBiPred) != 0;
     q.qp = PI(p, rc_qp); q.ipFactor = PD(p, rc_ipFactor); q.pbFactor = PD(p, rc_pbFactor);
+    q.rateControlMode = PI(p, rc_rateControlMode); q.rfConstant = PD(p, rc_rfConstant); q.qCompress = PD(p, rc_qCompress); q.qgSize = PI(p, rc_qgSize);
+    q.aqMode = PI(p, rc_aqMode); q.aqStrength = PD(p, rc_aqStrength); q.cuTree = PI(p, rc_cuTree) != 0;
+    q.bEmitInfoSEI = PI(p, bEmitInfoSEI) != 0;
+    if (q.rateControlMode == X265AMD_RC_CQP) { q.aqMode = 0; q.cuTree = 0; }                /* Encoder::configure (encoder.cpp:3721-3728) */
+    else
+    {
+        if (q.aqMode && q.aqStrength == 0) q.aqMode = 0;          /* (no offsets: the reference keeps delta QP switched on with all-zero offsets; say aqStrength > 0) */
+        if (!q.aqMode && q.cuTree) { xa_fail(X265AMD_EINVAL, "x265_encoder_open: cuTree without adaptive quantisation (aq-strength 0) is not built"); return nullptr; }
+    }
     q.rdLevel = PI(p, rdLevel); q.bEnableRectInter = PI(p, bEnableRectInter); q.bEnableAMP = PI(p, bEnableAMP); q.limitModes = PI(p, limitModes); q.limitReferences = PI(p, limitReferences);
     q.bEnableEarlySkip = PI(p, bEnableEarlySkip); q.recursionSkipMode = PI(p, recursionSkipMode); q.bIntraInBFrames = PI(p, bIntraInBFrames); q.psyRd = PD(p, psyRd);
     q.searchMethod = PI(p, searchMethod); q.subpelRefine = PI(p, subpelRefine); q.searchRange = PI(p, searchRange); q.maxNumMergeCand = PI(p, maxNumMergeCand);
