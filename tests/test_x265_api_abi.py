@@ -159,7 +159,7 @@ def test_param_default_preset_opens_and_encodes(preset):
     f = _fns(lib)
     api = f["api"]
     lib.x265amd_last_error.restype = C.c_char_p
-    headers = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32))(api.fn[12])
+    headers = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32))(api.fn[14])
     encode = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p)(api.fn[15])
     close = C.CFUNCTYPE(None, C.c_void_p)(api.fn[18])
     pic_alloc = C.CFUNCTYPE(C.c_void_p)(api.fn[7]); pic_init = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)(api.fn[9])
