@@ -798,7 +798,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cabac":
         make_cabac_golden()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "rc":
+    if len(sys.argv) > 1 and sys.argv[1] == "rcrecords":
         make_ratecontrol_golden()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fade":
@@ -826,5 +826,7 @@ if __name__ == "__main__":
         make_encoder_full_golden(sys.argv[2:] or None)
     elif len(sys.argv) > 1 and sys.argv[1] == "preset":
         make_encoder_preset_golden(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "rc":
+        make_encoder_full_golden(sys.argv[2:] or None, T.RC_CASES, T.PRESET_CLI, "encoder_rc_golden.json")
     else:
         main()

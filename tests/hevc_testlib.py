@@ -3372,7 +3372,7 @@ FULL_CASES = {
 
 
 def full_case_frames(tag):
-    (w, h), n, depth, cfg_id, _, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag])
+    (w, h), n, depth, cfg_id, _, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag] if tag in PRESET_CASES else RC_CASES[tag])
     return survey_clip(w, h, depth, cfg_id, 0, n)
 
 
@@ -3942,3 +3942,23 @@ def luma_mpm(left, above):
     if left == above:
         return [left, ((left - 2 + 31) & 31) + 2, ((left - 2 + 1) & 31) + 2] if left >= 2 else [0, 1, 26]
     return [left, above, 0 if (left and above) else (26 if left + above < 2 else 1)]
+
+
+# ---- the rate control's own options around the preset (tests/test_encoder_api.py): small clips (cut CTUs right and below, the clip's scene change at 24), the reference's
+# command line = --preset medium + the options + PRESET_CLI ----
+RC_CASES = {
+    "rc_crf20/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, rfConstant=20.0), ["--preset", "medium", "--crf", "20"]),
+    "rc_crf36/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, rfConstant=36.0), ["--preset", "medium", "--crf", "36"]),
+    "rc_no_cutree/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, cuTree=0), ["--preset", "medium", "--no-cutree"]),                 # the blurred-complexity branch: QPs follow the estimates
+    "rc_no_cutree_qcomp/": ((448, 256), 30, 8, 2, dict(PRESET_BASE, cuTree=0, qCompress=0.8, bframes=2), ["--preset", "medium", "--no-cutree", "--qcomp", "0.8", "--bframes", "2"]),
+    "rc_aq1/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, aqMode=1), ["--preset", "medium", "--aq-mode", "1"]),
+    "rc_aq3_strength/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, aqMode=3, aqStrength=1.5), ["--preset", "medium", "--aq-mode", "3", "--aq-strength", "1.5"]),
+    "rc_qg64/": ((448, 256), 26, 8, 2, dict(PRESET_BASE, qgSize=64), ["--preset", "medium", "--qg-size", "64"]),
+    "rc_qcomp_strength/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, qCompress=0.8), ["--preset", "medium", "--qcomp", "0.8"]),   # cuTree's strength 5 (1 - qcomp)
+    "rc_no_bframes/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, bframes=0), ["--preset", "medium", "--bframes", "0"]),
+    "rc_no_pyramid_keyint/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, bBPyramid=0, keyframeMax=12, keyframeMin=12), ["--preset", "medium", "--no-b-pyramid", "--keyint", "12", "--min-keyint", "12"]),
+    "rc_closed_gop/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, bOpenGOP=0, keyframeMax=10, keyframeMin=5), ["--preset", "medium", "--no-open-gop", "--keyint", "10", "--min-keyint", "5"]),
+    "rc_slow_hbd/": ((416, 240), 20, 10, 4, dict(PRESET_BASE, **SLOW_TOOLS), ["--preset", "slow"]),
+    "rc_rd5/": ((416, 240), 14, 8, 2, dict(PRESET_BASE, rdLevel=5), ["--preset", "medium", "--rd", "5"]),                      # compressInterCU_rd5_6 with delta QP
+    "rc_rd2/": ((416, 240), 14, 8, 2, dict(PRESET_BASE, rdLevel=2), ["--preset", "medium", "--rd", "2"]),
+}

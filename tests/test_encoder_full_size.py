@@ -25,6 +25,7 @@ import hevc_testlib as T
 
 GOLD = os.path.join(T.GOLDEN_DIR, "encoder_full_golden.json")
 PRESET_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_preset_golden.json")
+RC_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_rc_golden.json")
 
 
 def test_full_size_golden_present():
@@ -79,6 +80,28 @@ def test_encoder_object_presets_as_they_come(tag):
     quantisation and cuTree offsets of every 16x16 block, the QP of every CU and cu_qp_delta in the slice data"""
     g = json.load(open(PRESET_GOLD))[tag]
     (w, h), n, depth, cfg_id, cfg, _ = T.PRESET_CASES[tag]
+    stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(tag), w, h, **cfg)
+    assert len(coded) == n
+    for (poc, _, _, planes) in coded:
+        got = hashlib.md5(b"".join(np.ascontiguousarray(p).tobytes() for p in planes)).hexdigest()
+        assert got == g["recon_md5"][poc], "reconstruction of poc %d" % poc
+    assert len(stream) == g["stream_bytes"] and hashlib.md5(stream.tobytes()).hexdigest() == g["stream_md5"]
+
+
+def test_rc_golden_present():
+    g = json.load(open(RC_GOLD))
+    for tag, ((w, h), n, depth, cfg_id, cfg, cli) in T.RC_CASES.items():
+        assert tag in g and len(g[tag]["recon_md5"]) == n and "--qp" not in g[tag]["reference_command_line"], tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.RC_CASES))
+def test_encoder_object_rate_control_options(tag):
+    """the rate control's own options around the preset, stream and reconstruction against the reference command line encoder's: other rate factors, cuTree off (the
+    rate factor's blurred-complexity branch, fed by the AQ-weighted estimates), aq-mode 1 and 3, another strength, quantisation groups of 64, qcomp (cuTree's strength),
+    no B pictures, no pyramid, short and closed GOPs, --preset slow in Main 10, rd 5 and rd 2 with delta QP"""
+    g = json.load(open(RC_GOLD))[tag]
+    (w, h), n, depth, cfg_id, cfg, _ = T.RC_CASES[tag]
     stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(tag), w, h, **cfg)
     assert len(coded) == n
     for (poc, _, _, planes) in coded:

@@ -45,7 +45,8 @@ int x265amd_encoder::lowresInit(Pic& pic)
         pic.qpAqOffset.assign((size_t)nb, 0.0); pic.qpCuTreeOffset.assign((size_t)nb, 0.0); pic.invQscale.assign((size_t)nb, 256);
         rc = x265amd_aq_offsets((const uint32_t*)aqEnergyHost, nb, lowCuW * lowCuH, p.aqMode, p.aqStrength, 1.0, 16, pic.qpAqOffset.data(), pic.qpCuTreeOffset.data(), pic.invQscale.data());
         if (rc != X265AMD_OK) return xa_fail(rc, "encoder_encode: adaptive quantisation");
-        if (p.cuTree) { pic.intraCostHost = ic; pic.propagateCost.assign((size_t)lowCuW * lowCuH, 0); }
+        pic.intraCostHost = ic;
+        if (p.cuTree) pic.propagateCost.assign((size_t)lowCuW * lowCuH, 0);
     }
     int64_t est = 0;
     const bool all = lowCuW <= 2 || lowCuH <= 2;
@@ -529,8 +530,10 @@ int x265amd_encoder::frameCostMany(std::vector<CostJob>& jobs)
     for (size_t k = 0; k < issued; k++)
     {
         CostJob& j = jobs[k];
-        void* keepLc = (rc == X265AMD_OK && p.cuTree) ? j.dLc : nullptr;            /* Lowres::lowresCosts[d0][d1]: stays with the picture (cuTree reads it) */
-        void* bufs[6] = { j.dMvs, j.dMvc, keepLc ? nullptr : j.dLc, j.dBc, j.dMvs1, j.dMvc1 };
+        /* what the rate control reads of an estimate's blocks stays with the picture: with cuTree Lowres::lowresCosts[d0][d1] (cost capped at 14 bits + the lists used), without
+         * it -- Lowres::costEstAq of a P estimate, the rate factor's complexity measure -- the blocks' uncapped costs */
+        void* keepLc = rc != X265AMD_OK ? nullptr : (p.cuTree ? j.dLc : (rateCtl && j.d1 == 0 ? j.dBc : nullptr));
+        void* bufs[6] = { j.dMvs, j.dMvc, keepLc == j.dLc ? nullptr : j.dLc, keepLc == j.dBc ? nullptr : j.dBc, j.dMvs1, j.dMvc1 };
         for (void* b : bufs) laBufPut(b);
         xa_scratch_free(j.dW);
         j.dMvs = j.dMvc = j.dLc = j.dBc = j.dMvs1 = j.dMvc1 = j.dW = nullptr;

@@ -111,35 +111,57 @@ int x265amd_encoder::prepare(const PicP& picp)
     return 0;
 }
 
-/* Lookahead::getEstimatedPictureCost (slicetype.cpp:1327-1439) as far as the constant rate factor reads it (Lowres::satdCost: RateControl only asks whether it is zero unless
- * cuTree is off): I and P pictures -- with cuTree the estimate's block costs rescaled by the cuTree offsets (frameCostRecalculate), without it the plain estimate (the
- * reference's costEstAq differs from it by the AQ weights; B pictures, whose QP does not read it, get the plain estimate too) */
+/* Lookahead::getEstimatedPictureCost (slicetype.cpp:1327-1439) as far as the constant rate factor reads it (Lowres::satdCost; with cuTree RateControl only asks whether it is
+ * zero, without it the value is the rate factor's complexity measure): I and P pictures -- with cuTree the estimate's block costs rescaled by the cuTree offsets
+ * (frameCostRecalculate), without it the estimate weighted by the adaptive quantisation's factors (costEstAq), the plain estimate without either; B pictures, whose QP does not
+ * read it, get the plain estimate */
 int64_t x265amd_encoder::estimatedPictureCost(Pic& pic)
 {
     const int stype = isBType(pic.type) ? 0 : pic.type == TYPE_P ? 1 : 2;
+    const size_t ncu = (size_t)lowCuW * lowCuH;
+    const bool all = lowCuW <= 2 || lowCuH <= 2;
+    auto inner = [&](size_t i) { const int x = (int)(i % lowCuW), y = (int)(i / lowCuW); return all || (x > 0 && x < lowCuW - 1 && y > 0 && y < lowCuH - 1); };
     if (stype == 2)
     {
-        if (!p.cuTree || pic.intraCostHost.empty()) return std::max<int64_t>(pic.costEst[0], 1);
-        std::vector<uint16_t> lc(pic.intraCostHost.size());
-        for (size_t i = 0; i < lc.size(); i++) lc[i] = (uint16_t)std::min(pic.intraCostHost[i], (1 << 14) - 1);        /* lowresIntraEstimate: lowresCosts[0][0] (slicetype.cpp:806) */
-        return x265amd_frame_cost_recalculate(&treeParams, lc.data(), pic.qpCuTreeOffset.data());
+        if (pic.intraCostHost.size() != ncu) return std::max<int64_t>(pic.costEst[0], 1);
+        if (p.cuTree)
+        {
+            std::vector<uint16_t> lc(ncu);
+            for (size_t i = 0; i < ncu; i++) lc[i] = (uint16_t)std::min(pic.intraCostHost[i], (1 << 14) - 1);        /* lowresIntraEstimate: lowresCosts[0][0] (slicetype.cpp:806) */
+            return x265amd_frame_cost_recalculate(&treeParams, lc.data(), pic.qpCuTreeOffset.data());
+        }
+        /* Lowres::costEstAq[0][0] (slicetype.cpp:809-823) */
+        int64_t sum = 0;
+        for (size_t i = 0; i < ncu; i++) if (inner(i)) sum += pic.invQscale.size() == ncu ? (pic.intraCostHost[i] * pic.invQscale[i] + 128) >> 8 : pic.intraCostHost[i];
+        return sum;
     }
     const int d0 = pic.poc - pic.lists[0][0]->poc;
-    if (stype == 1 && p.cuTree && d0 > 0 && d0 < 18)
+    if (stype == 1 && d0 > 0 && d0 < 18)
     {
         const int key = d0 * 32;
-        auto h = pic.lcHost.find(key);
-        if (h == pic.lcHost.end())
+        auto d = pic.dLc.find(key);
+        if (p.cuTree)
         {
-            auto d = pic.dLc.find(key);
-            if (d != pic.dLc.end())
+            auto h = pic.lcHost.find(key);
+            if (h == pic.lcHost.end() && d != pic.dLc.end())
             {
-                std::vector<uint16_t> v((size_t)lowCuW * lowCuH);
-                if (hipMemcpyAsync(v.data(), d->second, v.size() * 2, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipStreamSynchronize(laStream) == hipSuccess)
+                std::vector<uint16_t> v(ncu);
+                if (hipMemcpyAsync(v.data(), d->second, ncu * 2, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipStreamSynchronize(laStream) == hipSuccess)
                     h = pic.lcHost.emplace(key, std::move(v)).first;
             }
+            if (h != pic.lcHost.end()) return x265amd_frame_cost_recalculate(&treeParams, h->second.data(), pic.qpCuTreeOffset.data());
         }
-        if (h != pic.lcHost.end()) return x265amd_frame_cost_recalculate(&treeParams, h->second.data(), pic.qpCuTreeOffset.data());
+        else if (d != pic.dLc.end() && pic.invQscale.size() == ncu)
+        {
+            /* Lowres::costEstAq[d0][0] (estimateCUCost, slicetype.cpp:4218-4233): the blocks' costs weighted by the adaptive quantisation's factors */
+            std::vector<int32_t> bc(ncu);
+            if (hipMemcpyAsync(bc.data(), d->second, ncu * 4, hipMemcpyDeviceToHost, laStream) == hipSuccess && hipStreamSynchronize(laStream) == hipSuccess)
+            {
+                int64_t sum = 0;
+                for (size_t i = 0; i < ncu; i++) if (inner(i)) sum += (bc[i] * pic.invQscale[i] + 128) >> 8;
+                return sum;
+            }
+        }
     }
     if (d0 > 0 && d0 < 18 && pic.costEst[d0] > 0) return pic.costEst[d0];
     return 1;
