@@ -800,7 +800,8 @@ typedef struct x265amd_rd_cu
     int16_t x, y;                   /* luma position of the CU in the picture */
     uint8_t log2_size;              /* 3..6 */
     int8_t qp;                      /* the CU's QP (setLambdaFromQP: RD lambdas and quantiser) */
-    uint8_t reserved[2];
+    uint8_t reserved[2];            /* [0]: the QP of the LAMBDAS when it is not `qp` (0: it is).  Search::setLambdaFromQP (search.cpp:177-187) takes the lambdas from the QP the rate
+                                     * control asks for, which adaptive quantisation can push up to 69, and clips the quantiser's (and the coded) QP to 51: above 51 the two differ */
     uint64_t frac_bits;             /* m_rqt[depth].cur.m_fracBits on entry (only its low 15 bits matter) */
     uint8_t ctx[X265AMD_CTX_STRIDE];/* m_rqt[depth].cur context states on entry */
 } x265amd_rd_cu;                    /* 176 bytes */

@@ -3961,4 +3961,9 @@ RC_CASES = {
     "rc_slow_hbd/": ((416, 240), 20, 10, 4, dict(PRESET_BASE, **SLOW_TOOLS), ["--preset", "slow"]),
     "rc_rd5/": ((416, 240), 14, 8, 2, dict(PRESET_BASE, rdLevel=5), ["--preset", "medium", "--rd", "5"]),                      # compressInterCU_rd5_6 with delta QP
     "rc_rd2/": ((416, 240), 14, 8, 2, dict(PRESET_BASE, rdLevel=2), ["--preset", "medium", "--rd", "2"]),
+    # QPs above 51: the B pictures' rate-control QP passes 51 and the block offsets push CUs further -- the lambdas follow the QP asked for (up to 69), the quantiser
+    # and the coded QP stop at 51 (Search::setLambdaFromQP, search.cpp:177-187)
+    "rc_crf46/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, rfConstant=46.0), ["--preset", "medium", "--crf", "46"]),
+    "rc_crf51_aq3/": ((448, 256), 26, 8, 2, dict(PRESET_BASE, rfConstant=51.0, aqMode=3, aqStrength=2.0), ["--preset", "medium", "--crf", "51", "--aq-mode", "3", "--aq-strength", "2.0"]),
+    "rc_crf44_hbd_slow/": ((416, 240), 20, 10, 4, dict(PRESET_BASE, rfConstant=44.0, **SLOW_TOOLS), ["--preset", "slow", "--crf", "44"]),
 }

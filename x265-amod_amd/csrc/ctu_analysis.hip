@@ -225,16 +225,20 @@ struct Analyzer
     const int8_t* cuQp = nullptr;           /* this CTU's group QPs (xa_analyse_frame's cu_qp): [0] the 64x64 CU, [1 + q] its 32x32 CUs */
     int ctuQp = 0;                          /* CUData::m_qp[0] of the CTU as compressCTU sets it (topSkipMinDepth's currentQP) */
     x265amd_cabac* qpCoder = nullptr;       /* a bit-counting coder on the picture map: getRefQP and the price of cu_qp_delta (checkDQPForSplitPred) */
+    int lambdaQp = 0;                       /* the QP setLambdaFromQP was given (up to 69): the lambdas' and the motion costs'; `qp` is the quantiser's and the coded one, clipped to 51 */
     int setLambdaFromQP(int q)
     {
-        /* (a QP above 51 -- lambdas from the QP, the quantiser from 51 -- needs the two kept apart through every command record: not built, refused) */
-        if (q < 0 || q > 51) return fail("a CU's QP outside 0..51 (QPs above 51, where the lambda's QP and the quantiser's differ, are not built)");
-        qp = q;
+        if (q < 0 || q > 69) return fail("a CU's QP outside 0..69");
+        lambdaQp = q;
+        qp = q > 51 ? 51 : q;
+        /* (the device-run inter chains carry one QP: none of them is on under delta QP, and without it no QP passes 51 -- the slice QP is clipped) */
+        if (lambdaQp != qp && chain.on) return fail("a QP above 51 on a device-run chain");
         uint64_t rd[6];
-        x265amd_rdcost(qp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
+        x265amd_rdcost(lambdaQp, si->slice_type, A->psy_rd, 0, 0, 0, rd);
         lambda2 = rd[0]; lambda = rd[1]; psyRd = (uint32_t)rd[2];
         return 0;
     }
+    void cuQp2(x265amd_rd_cu& c) const { c.qp = (int8_t)qp; c.reserved[0] = (uint8_t)(lambdaQp != qp ? lambdaQp : 0); }
     /* Analysis::calculateQpforCuSize of the sub-CU q of the CU at `depth` -- when that is a quantisation group's CU (analysis.cpp:1363-1364); else the QP in force stays */
     int childQp(int depth, int q)
     {
@@ -474,7 +478,7 @@ struct Analyzer
         d.srcMean = 0; d.srcHomo = 0;
         x265amd_rd_cu rc;
         memset(&rc, 0, sizeof(rc));
-        rc.x = (int16_t)x; rc.y = (int16_t)y; rc.log2_size = (uint8_t)log2; rc.qp = (int8_t)qp;
+        rc.x = (int16_t)x; rc.y = (int16_t)y; rc.log2_size = (uint8_t)log2; cuQp2(rc);
         memcpy(rc.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
         rc.frac_bits = d.cur.frac;
         x265amd_rd_result r;
@@ -562,7 +566,7 @@ struct Analyzer
         d.srcMean = c.meas.src_mean; d.srcHomo = c.meas.src_homo;
         x265amd_rd_cu rc;
         memset(&rc, 0, sizeof(rc));
-        rc.x = (int16_t)x; rc.y = (int16_t)y; rc.log2_size = (uint8_t)log2; rc.qp = (int8_t)qp;
+        rc.x = (int16_t)x; rc.y = (int16_t)y; rc.log2_size = (uint8_t)log2; cuQp2(rc);
         memcpy(rc.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
         rc.frac_bits = d.cur.frac;
         x265amd_rd_result r;
@@ -745,7 +749,7 @@ struct Analyzer
         StageTimer timer_(2);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
-        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); cuQp2(c);
         memcpy(c.ctx, md[depth].cur.ctx, X265AMD_CTX_COUNT);
         c.frac_bits = md[depth].cur.frac;
         x265amd_rd_result r;
@@ -776,7 +780,7 @@ struct Analyzer
         StageTimer timer_(2);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
-        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); cuQp2(c);
         memcpy(c.ctx, md[depth].cur.ctx, X265AMD_CTX_COUNT);
         c.frac_bits = md[depth].cur.frac;
         x265amd_rd_result rs, rm;
@@ -807,7 +811,7 @@ struct Analyzer
         StageTimer timer_(3);
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
-        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); c.qp = (int8_t)qp;
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)(6 - depth); cuQp2(c);
         memcpy(c.ctx, md[depth].cur.ctx, X265AMD_CTX_COUNT);
         c.frac_bits = md[depth].cur.frac;
         x265amd_rd_result r;
@@ -1026,10 +1030,10 @@ struct Analyzer
         if (xa_ref_guard_me(guardJobs, guardPics, ng)) return fail("a reference picture failed");
         J.x = x; J.y = y; J.log2 = log2;
         J.pic_w = I->pic_width; J.pic_h = I->pic_height; J.stride = (int32_t)stride; J.cstride = (int32_t)cstride; J.num_pics = numPics; J.num_ref_idx0 = I->num_ref_idx[0];
-        J.search_method = S->search_method; J.subme = S->subpel_refine; J.merange = S->search_range; J.me_qp = qp; J.frame_parallel = S->frame_parallel;
+        J.search_method = S->search_method; J.subme = S->subpel_refine; J.merange = S->search_range; J.me_qp = lambdaQp; J.frame_parallel = S->frame_parallel;
         J.search_range = S->search_range; J.lag_pixels = lagPixels; J.list_sel_bits0 = 1;
-        J.me_lambda = (uint64_t)floor(256.0 * is_lambda(qp));
-        J.mvcost = (uint64_t)(uintptr_t)xa_me_device_mvcost(me, qp); J.bitsize = (uint64_t)(uintptr_t)xa_me_device_bitsize(me); J.me_tables = (uint64_t)(uintptr_t)xa_me_device_tables(me);
+        J.me_lambda = (uint64_t)floor(256.0 * is_lambda(lambdaQp));
+        J.mvcost = (uint64_t)(uintptr_t)xa_me_device_mvcost(me, lambdaQp); J.bitsize = (uint64_t)(uintptr_t)xa_me_device_bitsize(me); J.me_tables = (uint64_t)(uintptr_t)xa_me_device_tables(me);
         J.planes = (uint64_t)(uintptr_t)dPlanes.p; J.luma_tab = (uint64_t)(uintptr_t)chain.mLuma.p;
         J.pred_tile = tileAddr(predTile(depth, PRED_2Nx2N)); J.recon_tile = tileAddr(reconTile(depth, PRED_2Nx2N));
         J.lambda = lambda; J.lambda2 = lambda2; J.psy_rd = psyRd;
@@ -1192,7 +1196,7 @@ struct Analyzer
         int32_t bits = 0;
         x265amd_me_detail& det = d.det;
         x265amd_inter_search_params sp = *S;
-        sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
+        sp.qp = lambdaQp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         static const bool lazyMc = !(getenv("X265AMD_LAZY_MC") && atoi(getenv("X265AMD_LAZY_MC")) == 0);
         sp.lazy_sync = !searchOnly && lazyMc;       /* the measurement below waits for the final prediction */
         const uint32_t masks[2] = { refMask, 0 };
@@ -1303,7 +1307,7 @@ struct Analyzer
         x265amd_pu_result pu[2];
         int32_t bits = 0;
         x265amd_inter_search_params sp = *S;
-        sp.qp = qp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
+        sp.qp = lambdaQp; sp.chroma_mc = A->rd_level >= 3;        /* bChromaMC = m_bChromaSa8d: below rd 3 the search is luma only (no chroma SATD either) */
         static const bool lazyMc = !(getenv("X265AMD_LAZY_MC") && atoi(getenv("X265AMD_LAZY_MC")) == 0);
         sp.lazy_sync = !searchOnly && lazyMc;
         int rc = x265amd_pred_inter_search_ex(me, st, I, &sp, cur, col, planes, numPics, stride, cstride, &c, 1, pu, &bits, tileAddr(m.predTile), tileBytes, nullptr, refMasks);
@@ -1588,7 +1592,7 @@ struct Analyzer
             Mode& m = d.pred[PRED_INTRA];
             x265amd_rd_cu c;
             memset(&c, 0, sizeof(c));
-            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.qp = (int8_t)qp;
+            c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; cuQp2(c);
             memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
             c.frac_bits = d.cur.frac;
             const int b = xa_check_intra_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
@@ -1630,7 +1634,7 @@ struct Analyzer
                 const int qrc = xa_intra_quad8_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, x, y, qp, d.cur.ctx, d.cur.frac,
                                                   tileAddr(split.reconTile), tilesN, tiles2, r4, &intraWs,
                                                   deferred && overlap ? [](void* c) { Between* b = (Between*)c; b->rc = b->a->rdIntra(b->a->md[b->depth].pred[PRED_INTRA], b->x, b->y, b->depth, PRED_INTRA, true, 0); b->done = true; } : (void (*)(void*))nullptr,
-                                                  &bt);
+                                                  &bt, lambdaQp != qp ? lambdaQp : 0);
                 if (bt.done) { if (bt.rc) return err; deferredDone = true; }
                 if (qrc < 0) return err = qrc;
                 if (qrc == 0)
@@ -1751,7 +1755,7 @@ struct Analyzer
         ModeDepth& d = md[depth];
         x265amd_rd_cu c;
         memset(&c, 0, sizeof(c));
-        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; c.qp = (int8_t)qp;
+        c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; cuQp2(c);
         memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
         c.frac_bits = d.cur.frac;
         return xa_intra_in_inter_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,

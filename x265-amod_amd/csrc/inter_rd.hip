@@ -388,6 +388,8 @@ struct DevBuf
 
 } // namespace
 
+/* the QP of a CU's lambdas (x265amd_rd_cu.reserved[0] when it differs from the quantiser's: QPs above 51) */
+static inline int lambda_qp(const x265amd_rd_cu& cu) { return cu.reserved[0] ? (int)cu.reserved[0] : (int)cu.qp; }
 /* RDCost::setQP for one CU */
 static void rd_lambdas(const x265amd_slice_info* si, const x265amd_rd_params* rp, int qp, Walker& w)
 {
@@ -553,7 +555,7 @@ static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_par
             memcpy(&units[((P.y >> 2) + yy) * w4 + (P.x >> 2)], &mine[yy * u4], sizeof(x265amd_cu_unit) * u4);
         }
         Walker w(*coder, P, res, (const int16_t*)((const char*)levels + levels_stride_bytes * i));
-        rd_lambdas(si, rp, P.qp, w);
+        rd_lambdas(si, rp, lambda_qp(cu), w);
         for (int yy = 0; yy < u4; yy++)
             for (int xx = 0; xx < u4; xx++)
             {
@@ -677,14 +679,14 @@ extern "C" void x265amd_inter_rd_finish(const x265amd_slice_info* si, const x265
         const x265amd_cu_measure& m1 = final_meas[i];
         x265amd_rd_result& r = out[i];
         uint64_t rd[6];
-        x265amd_rdcost(cus[i].qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+        x265amd_rdcost(lambda_qp(cus[i]), si->slice_type, rp->psy_rd, 0, 0, 0, rd);
         const sse_t bestLumaDist = (sse_t)m1.sse[0];
         sse_t bestChromaDist = (sse_t)m1.sse[1];
         bestChromaDist += (sse_t)m1.sse[2];
         const sse_t distortion = bestLumaDist + bestChromaDist;
         r.luma_distortion = (uint32_t)bestLumaDist; r.chroma_distortion = (uint32_t)bestChromaDist; r.distortion = distortion;
         r.psy_energy = rd[2] ? m1.psy : 0;
-        x265amd_rdcost(cus[i].qp, si->slice_type, rp->psy_rd, distortion, r.total_bits, r.psy_energy, rd);
+        x265amd_rdcost(lambda_qp(cus[i]), si->slice_type, rp->psy_rd, distortion, r.total_bits, r.psy_energy, rd);
         r.rd_cost = rd[2] ? rd[4] : rd[3];
     }
 }
@@ -741,10 +743,10 @@ extern "C" int x265amd_skip_rd_host(const x265amd_slice_info* si, const x265amd_
         chroma += (sse_t)m.sse[2];
         const sse_t distortion = luma + chroma;
         uint64_t rd[6];
-        x265amd_rdcost(cu.qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+        x265amd_rdcost(lambda_qp(cu), si->slice_type, rp->psy_rd, 0, 0, 0, rd);
         r.luma_distortion = (uint32_t)luma; r.chroma_distortion = (uint32_t)chroma; r.distortion = distortion; r.res_energy = (uint32_t)luma;
         r.psy_energy = rd[2] ? m.psy : 0;
-        x265amd_rdcost(cu.qp, si->slice_type, rp->psy_rd, distortion, r.total_bits, r.psy_energy, rd);
+        x265amd_rdcost(lambda_qp(cu), si->slice_type, rp->psy_rd, distortion, r.total_bits, r.psy_energy, rd);
         r.rd_cost = rd[2] ? rd[4] : rd[3];
         memcpy(r.ctx, coder->ctx, X265AMD_CTX_COUNT);
         r.frac_bits = coder->fracBits;

@@ -1072,7 +1072,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
     for (int l = 0; l < 4; l++) R.coeffL[l].assign(4096, 0);
     for (int p = 0; p < 2; p++) { R.coeffC[p].assign(1024, 0); R.coeffCBest[p].assign(1024, 0); }
     uint64_t rd[6];
-    x265amd_rdcost(R.qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+    x265amd_rdcost(cu->reserved[0] ? (int)cu->reserved[0] : R.qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);          /* (the lambdas' QP: x265amd_rd_cu.reserved[0] above 51) */
     R.lambda2 = rd[0]; R.lambda = rd[1]; R.psyRd = (uint32_t)rd[2];
     memset(&R.cur, 0, sizeof(R.cur));
     memcpy(R.cur.ctx, cu->ctx, X265AMD_CTX_COUNT);
@@ -1341,7 +1341,7 @@ static int intra_cu_impl(int kind, int partSize, void* stream, const x265amd_sli
  * 2Nx2N evaluations.  results[4] in CU order.  Returns 0, 1 when the chain does not apply here (the caller takes the CUs one by one), or an error code. */
 int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
                       intptr_t stride, intptr_t cstride, int x, int y, int qp, const uint8_t* ctx, uint64_t frac, uint64_t split_recon, const uint64_t tilesN[2],
-                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws, void (*between)(void*), void* between_ctx)
+                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws, void (*between)(void*), void* between_ctx, int lambda_qp)
 {
     static const bool on = !(getenv("X265AMD_INTRA_CHAIN") && atoi(getenv("X265AMD_INTRA_CHAIN")) == 0);
     if (!on || !ws || !*ws || !xa_is_queue(stream)) return 1;
@@ -1374,7 +1374,7 @@ int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_
         R.qpLumaScaled = qpQuant + bd; R.qpChromaScaled = qpC + bd;
     }
     uint64_t rd[6];
-    x265amd_rdcost(qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
+    x265amd_rdcost(lambda_qp > 0 ? lambda_qp : qp, si->slice_type, rp->psy_rd, 0, 0, 0, rd);
     R.lambda2 = rd[0]; R.lambda = rd[1]; R.psyRd = (uint32_t)rd[2];
     memset(&R.cur, 0, sizeof(R.cur));
     memcpy(R.cur.ctx, ctx, X265AMD_CTX_COUNT);

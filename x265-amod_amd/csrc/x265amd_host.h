@@ -149,7 +149,8 @@ int xa_intra_in_inter_begin_ws(void* stream, const x265amd_slice_info* si, const
 void xa_intra_ws_hint_nxn(void** ws, uint64_t d_pred_nxn, uint64_t d_recon_nxn);
 int xa_intra_quad8_ws(void* stream, const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const uint64_t* h_src, const uint64_t* h_rec,
                       intptr_t stride, intptr_t cstride, int x, int y, int qp, const uint8_t* ctx, uint64_t frac, uint64_t split_recon, const uint64_t tilesN[2],
-                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws, void (*between)(void*) = nullptr, void* between_ctx = nullptr);
+                      const uint64_t tiles2[2], x265amd_intra_cu8_result* results, void** ws, void (*between)(void*) = nullptr, void* between_ctx = nullptr, int lambda_qp = 0);
+/* (lambda_qp: the QP of the lambdas when it is not `qp` -- QPs above 51, x265amd_rd_cu.reserved[0]; 0: it is) */
 /* starts the 2Nx2N evaluation of a 16x16 CU on the stream's third queue (the helper's helper) and returns 1, or returns 0 when that is not possible (then nothing
  * has happened); < 0: error.  The caller evaluates the CU's sub-CUs, then calls xa_check_intra_ws(.., part_size 0, ..) for the same CU with the same tiles, which
  * collects the result.  The contexts in `cu` are those the later call passes. */
