@@ -1110,6 +1110,9 @@ void x265amd_hostprof_report(void);
  * kernel launches (environment: X265AMD_QUEUES = number of queues, default 128, 0 = launches on HIP streams as before).  The self test pushes `rounds`
  * rounds of copies, fills and rectangle copies through `numQueues` queues from as many host threads and compares every byte that comes back. */
 int x265amd_queue_selftest(int rounds, int numQueues);
+/* ... and what happens to a queue whose XA_OP_WAIT gives up (two seconds without the queue it follows getting there): the commands behind the wait are not run and every
+ * host wait on the queue fails -- until the queue is released; its next owner starts clean (XA_CMD_RESET).  Takes about two seconds.  0: both halves behaved */
+int x265amd_queue_selftest_wait_fault(void);
 /* A queue handle for the `stream` argument of the orchestrating entry points (x265amd_pred_inter_search, x265amd_inter_residual_rd, x265amd_skip_rd,
  * x265amd_intra_in_inter, x265amd_check_intra, x265amd_compress_ctu_inter): they return with the queue drained.  NULL when none is free.  While a
  * queue is held a workgroup is resident on the device: release it before anything that synchronises the whole device. */

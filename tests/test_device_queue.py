@@ -24,6 +24,16 @@ def test_queue_selftest(depth):
 
 
 @pytest.mark.gpu
+def test_a_wait_that_gives_up_poisons_its_owner_only():
+    """XA_OP_WAIT bounds its wait (two seconds); a queue whose wait gave up runs nothing more and fails every host wait -- for the owner it happened to: released and handed out
+    again (the resident kernel still running) the queue starts clean (XA_CMD_RESET, csrc/device_queue.hip: xa_queue_clear_fault)"""
+    L = T.load_hip(8)
+    L.lib.x265amd_last_error.restype = C.c_char_p
+    assert L.lib.x265amd_queue_selftest_wait_fault() == 0, L.lib.x265amd_last_error().decode()
+    assert L.lib.x265amd_queue_selftest(20, 4) == 0, L.lib.x265amd_last_error().decode()
+
+
+@pytest.mark.gpu
 def test_stream_path_still_reproduces_reference_stream():
     env = dict(os.environ, X265AMD_QUEUES="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(T.ROOT, "tests", "test_encoder_api.py"),

@@ -254,7 +254,7 @@ def test_scene_cut_detection(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,count", [("ft_b/", 2), ("sc_i/", 2), ("ft_vp/", 3), ("bp_deep/", 2), ("bp_og_cut/", 3)])
+@pytest.mark.parametrize("tag,count", [("ft_b/", 2), ("sc_i/", 2), ("ft_vp/", 3), ("bp_deep/", 2), ("bp_og_cut/", 3), ("wp_fade_b/", 2), ("wp_fade_sub3/", 3)])
 def test_frame_per_gpu_objects_alternate_pictures(tag, count):
     """SURVEY section 8e as written, on one GPU: `count` encoder objects, object r coding the pictures whose place in coding order is r modulo count, every finished
     CTU row carried from its owner to the others through x265amd_encoder_export_row / _import_row (what x265-amod_amd/frame_rows.py broadcasts between ranks).
@@ -267,6 +267,10 @@ def test_frame_per_gpu_objects_alternate_pictures(tag, count):
         g = np.load(SC_GOLD)
         (w, h), n, depth, _, cfg, _ = T.SC_CASES[tag]
         frames = T.scene_case_frames(tag)
+    elif tag in T.FADE_CASES:       # fades: every object runs the weight analysis of every picture on the SOURCE pictures of its references, also of those coded elsewhere
+        g = np.load(FADE_GOLD)
+        (w, h), n, depth, _, cfg, _ = T.FADE_CASES[tag]
+        frames = T.fade_case_frames(tag)
     else:
         g = np.load(FT_GOLD)
         (w, h), n, depth, kind, cfg, _ = T.FT_CASES[tag]

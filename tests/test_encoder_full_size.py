@@ -88,6 +88,30 @@ def test_encoder_object_presets_as_they_come(tag):
     assert len(stream) == g["stream_bytes"] and hashlib.md5(stream.tobytes()).hexdigest() == g["stream_md5"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["crf_wqvga_medium_30", "crf_fhd_medium_60"])
+def test_device_chains_verified_under_delta_qp(tag):
+    """The device-run paths of P / B pictures under the preset's rate control (delta QP: a QP per quantisation group, cu_qp_delta priced in the residual modes, the predicted
+    QP of each group and topSkipMinDepth's QP test tracked on the device -- DESIGN.md section 4.27): with X265AMD_CHAIN_VERIFY=2 the host repeats every skipped CU, every
+    device-made merge check and every fused search on its own path and compares mode, candidate, costs, bits, levels, QPs and the entropy coder's state.  A process of its own
+    (the variable is read once); the stream must be the reference's and the paths must have run."""
+    import subprocess
+    import sys
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); import numpy as np, hevc_testlib as T\n"
+            "g = json.load(open(%r))[%r]\n"
+            "(w, h), n, depth, cfg_id, cfg, _ = T.PRESET_CASES[%r]\n"
+            "stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(%r), w, h, **cfg)\n"
+            "assert len(coded) == n and hashlib.md5(stream.tobytes()).hexdigest() == g['stream_md5']\n"
+            "print('verified pictures', len(coded))\n") % (os.path.dirname(os.path.abspath(__file__)), PRESET_GOLD, tag, tag, tag)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, X265AMD_CHAIN_VERIFY="2", X265AMD_TIMING="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "verified pictures" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "chain verify" not in r.stderr and "search verify" not in r.stderr, r.stderr[-3000:]
+    import re
+    runs = [int(m.group(1)) for m in re.finditer(r"skip chains so far: (\d+) commands", r.stderr)]
+    ahead = [int(m.group(1)) + int(m.group(2)) for m in re.finditer(r"searches started ahead so far: (\d+) beside a leaf's merge check, (\d+) behind", r.stderr)]
+    assert runs and max(runs) > 100 and ahead and max(ahead) > 0, (runs[-3:], ahead[-3:])           # the paths under test did run under delta QP
+
+
 def test_rc_golden_present():
     g = json.load(open(RC_GOLD))
     for tag, ((w, h), n, depth, cfg_id, cfg, cli) in T.RC_CASES.items():

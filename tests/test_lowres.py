@@ -65,6 +65,68 @@ def test_hip_lowres_frame_cost_matches_reference_golden(k):
 
 
 @pytest.mark.gpu
+def test_hip_lowres_frame_cost_many_estimates_in_one_batch_repeatedly():
+    """The row chain's hand-over inside ONE launch (csrc/lowres_kernels.hip: lowres_cost_row -- a row's vectors and its progress word cross to the wavefront of the row above
+    as agent-scope atomics behind a bare s_waitcnt, no cache-wide fence since round 5): sixty estimates of the golden cases' pictures in one batch, every one with buffers of its
+    own, five batches in a row while the previous batch's buffers are still warm in the caches -- every estimate of every batch must be the reference's, bit for bit."""
+    import ctypes as C
+    import torch
+    g = np.load(COST_GOLD)
+    JOB = np.dtype([("d_fenc", "<u8"), ("d_ref0", "<u8", 4), ("d_ref1", "<u8", 4), ("d_intra_cost", "<u8"), ("d_mvs0", "<u8"), ("d_mv_costs0", "<u8"), ("d_mvs1", "<u8"),
+                    ("d_mv_costs1", "<u8"), ("d_lowres_costs", "<u8"), ("d_bcost", "<u8"), ("do_search0", "<i4"), ("do_search1", "<i4"), ("rows_per_slice", "<i4"),
+                    ("num_slices", "<i4"), ("d_ref0w", "<u8", 4)])
+    for k in (0, 2):
+        depth, seed, crop, p0, b, p1 = COST_CASES[k]
+        c = T.lowres_cost_case(depth, seed, crop)
+        L = T.load_hip(depth); me = T.HipME(depth)
+        isz = c["lumas"][0].dtype.itemsize
+        lw, lh = c["wcu"] * 8, c["hcu"] * 8
+        lstride = (c["W"] // 2) + 2 * T.MC_MX
+        lstride += (32 - (lstride & 31)) & 31
+        rows = lh + 2 * T.MC_MY
+        o = (T.MC_MY * lstride + T.MC_MX) * isz
+        ncu = c["wcu"] * c["hcu"]
+        planes, intra = [], []
+        for f in range(3):
+            d_src = torch.from_numpy(c["lumas"][f].view(np.uint8)).cuda()
+            d_pl = [torch.zeros(rows * lstride * isz, dtype=torch.uint8, device="cuda") for _ in range(4)]
+            ptrs = (C.c_void_p * 4)(*[q.data_ptr() + o for q in d_pl])
+            assert L.lib.x265amd_lowres_init(None, C.c_void_p(d_src.data_ptr() + (T.MC_MY * c["stride"] + T.MC_MX) * isz), C.c_int64(c["stride"]), lw, lh, ptrs, C.c_int64(lstride),
+                                             T.MC_MX, T.MC_MY) == 0
+            d_cost = torch.zeros(ncu, dtype=torch.int32, device="cuda"); d_mode = torch.zeros(ncu, dtype=torch.uint8, device="cuda")
+            assert L.lib.x265amd_lowres_intra_costs(None, C.c_void_p(d_pl[0].data_ptr() + o), C.c_int64(lstride), c["wcu"], c["hcu"], T.LOWRES_LAMBDA[depth],
+                                                    C.c_void_p(d_cost.data_ptr()), C.c_void_p(d_mode.data_ptr())) == 0
+            planes.append(d_pl); intra.append(d_cost)
+        torch.cuda.synchronize()
+        bidir = p1 > b
+        N = 60
+        for rep in range(5):
+            jobs = np.zeros(N, JOB); bufs = []
+            for i in range(N):
+                mv = [torch.zeros(ncu * 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+                mc = [torch.zeros(ncu, dtype=torch.int32, device="cuda") for _ in range(2)]
+                lc = torch.zeros(ncu, dtype=torch.int16, device="cuda"); bc = torch.zeros(ncu, dtype=torch.int32, device="cuda")
+                bufs.append((mv, mc, lc, bc))
+                j = jobs[i]
+                j["d_fenc"] = planes[b][0].data_ptr() + o
+                j["d_ref0"] = [q.data_ptr() + o for q in planes[p0]]
+                if bidir:
+                    j["d_ref1"] = [q.data_ptr() + o for q in planes[p1]]
+                    j["d_mvs1"], j["d_mv_costs1"], j["do_search1"] = mv[1].data_ptr(), mc[1].data_ptr(), 1
+                j["d_intra_cost"] = intra[b].data_ptr()
+                j["d_mvs0"], j["d_mv_costs0"], j["do_search0"] = mv[0].data_ptr(), mc[0].data_ptr(), 1
+                j["d_lowres_costs"], j["d_bcost"] = lc.data_ptr(), bc.data_ptr()
+            assert L.lib.x265amd_lowres_frame_cost_batch(None, me.ctx, jobs.ctypes.data_as(C.c_void_p), N, C.c_int64(lstride), c["wcu"], c["hcu"]) == 0, L.lib.x265amd_last_error()
+            torch.cuda.synchronize()
+            for i, (mv, mc, lc, bc) in enumerate(bufs):
+                got_lc = lc.cpu().numpy().view(np.uint16)
+                assert np.array_equal(got_lc, g["%d/lowres_costs" % k]), (k, rep, i, np.argwhere(got_lc != g["%d/lowres_costs" % k])[:4].tolist())
+                for l in range(2 if bidir else 1):
+                    assert np.array_equal(mv[l].cpu().numpy().reshape(ncu, 2), g["%d/mvs" % k][l]), (k, rep, i, l)
+                    assert np.array_equal(mc[l].cpu().numpy(), g["%d/mv_costs" % k][l]), (k, rep, i, l)
+
+
+@pytest.mark.gpu
 def test_hip_lowres_cost_sums_are_the_callers_sums():
     """x265amd_lowres_cost_sums against the reference golden's own sums (estimateFrameCost's score before the B scaling, and its intra block count) and against the
     caller's reduction written out in numpy, several estimates in one call, for a picture of two block rows as well"""

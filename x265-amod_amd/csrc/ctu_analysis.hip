@@ -337,6 +337,7 @@ struct Analyzer
         uint64_t stopFrac = 0; uint8_t stopCtx[X265AMD_CTX_STRIDE];     /* the device's coder state where the last chain stopped (X265AMD_CHAIN_VERIFY) */
         int stopNode = -1;
         XaChainStop stop;                               /* the merge check of the CU the last chain stopped at, when the device made it */
+        uint8_t usedFlags[4] = { 0, 0, 0, 0 };          /* per depth of the host's recursion: the node flags (bits 0-1) it went by */
         int frNode[4]; bool frDirty[4];                 /* the host's recursion: node and "something below it was decided on the host" per depth */
         bool lastDevComplete = false;                   /* of the compress() call that has just returned: everything in its area is the device's */
         uint64_t runs = 0, skipped = 0;
@@ -358,8 +359,13 @@ struct Analyzer
         XaChainNode& n = chain.nodes[idx];
         n.x = (int16_t)x; n.y = (int16_t)y; n.log2 = (uint8_t)(6 - depth); n.parent = (uint8_t)(parent < 0 ? 255 : parent);
         const bool mightNotSplit = x + size <= I->pic_width && y + size <= I->pic_height;
-        const bool checked = mightNotSplit && (uint32_t)depth >= topSkipMinDepth(x, y, depth);
-        n.flags = (uint8_t)((checked ? 1 : 0) | (mightNotSplit && !checked && depth < si->max_cu_depth ? 2 : 0));
+        n.flags = 0;
+        for (int ge = 1; ge >= 0; ge--)
+        {
+            /* (the QP test of topSkipMinDepth follows the CTU's first unit, which the CUs coded on the way change under delta QP: both answers, the device picks) */
+            const bool checked = mightNotSplit && (uint32_t)depth >= topSkipMinDepth(x, y, depth, ge);
+            n.flags |= (uint8_t)(((checked ? 1 : 0) | (mightNotSplit && !checked && depth < si->max_cu_depth ? 2 : 0)) << (ge ? 0 : 2));
+        }
         if (depth < si->max_cu_depth)
             for (int q = 0; q < 4; q++)
             {
@@ -410,6 +416,52 @@ struct Analyzer
         if (!chain.dScratch.p && chain.dScratch.alloc(x265amd_inter_rd_scratch_bytes()) != hipSuccess) return fail("chain scratch");
         J.scratch = (uint64_t)(uintptr_t)chain.dScratch.p;
         J.frac = md[depth].cur.frac; memcpy(J.ctx, md[depth].cur.ctx, X265AMD_CTX_STRIDE);
+        J.previous_qp = refQp0[ctuAddr];
+        J.first_qp = si->use_dqp ? units[(ctuY >> 2) * w4 + (ctuX >> 2)].qp : ctuQp;
+        memcpy(J.anc_flags, chain.usedFlags, 4);
+        if (si->use_dqp)
+        {
+            if (!qpCoder)
+            {
+                if (!(qpCoder = x265amd_cabac_open(si, units, 1))) return fail("delta QP: coder");
+                qpCoder->ctuInProgress = true;
+            }
+            J.use_dqp = 1; J.max_dqp_depth = si->max_cu_dqp_depth;
+            J.prev_qp = qpCoder->lastQP(ctuX, ctuY);
+            static const uint8_t chromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31,
+                                                     32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+            const int bd = 6 * (X265AMD_DEPTH - 8);
+            for (int k = 0; k < (si->max_cu_dqp_depth ? 5 : 1); k++)
+            {
+                XaChainJob::QpSet& q = J.qps[k];
+                const int qv = cuQp[k];              /* (not above 51 on a CTU the chain runs on: compress_ctu_impl) */
+                uint64_t rd[6];
+                x265amd_rdcost(qv, si->slice_type, A->psy_rd, 0, 0, 0, rd);
+                q.lambda2 = rd[0]; q.lambda = rd[1]; q.psy_rd = (uint32_t)rd[2]; q.qp = qv;
+                int qpC = qv < -bd ? -bd : (qv > 57 ? 57 : qv);
+                if (qpC >= 30) qpC = chromaScale[qpC];
+                q.qp_luma = qv + bd; q.qp_chroma = qpC + bd;
+            }
+            J.last_src[0] = -1;
+            for (int k = 1; k < 4 && si->max_cu_dqp_depth; k++)
+            {
+                const int gx = ctuX + (k & 1) * 32, gy = ctuY + (k >> 1) * 32;
+                J.last_src[k] = -1;
+                if (gx >= I->pic_width || gy >= I->pic_height) continue;
+                int px = 0, py = 0;
+                if (qpCoder->lastQPUnitInCtu(gx, gy, px, py))
+                {
+                    J.last_src[k] = (int8_t)(((py - ctuY) >> 5) * 2 + ((px - ctuX) >> 5));
+                    J.last_val[k] = units[(py >> 2) * w4 + (px >> 2)].qp;
+                }
+                if (k & 1) J.left_val[k] = units[(gy >> 2) * w4 + (gx >> 2) - 1].qp;
+                if (k & 2) J.above_val[k] = units[((gy >> 2) - 1) * w4 + (gx >> 2)].qp;
+            }
+            /* a chain that starts inside a quantisation group ends with the group: what the group's CUs leave in the QP records is then the host's to say (checkDQPForSplitPred) */
+            int a = node;
+            while (chain.nodes[a].parent != 255 && 6 - chain.nodes[a].log2 > si->max_cu_dqp_depth) a = chain.nodes[a].parent;
+            if (a != node && (chain.nodes[a].x != chain.nodes[node].x || chain.nodes[a].y != chain.nodes[node].y) && chain.nodes[a].next < end) { end = chain.nodes[a].next; J.end = end; }
+        }
         {
             void** slot = xa_task_slot();
             const XaRowHooks* h = slot ? (const XaRowHooks*)*slot : nullptr;
@@ -512,7 +564,7 @@ struct Analyzer
         copyTile(keep, candTile(depth, c.cand), 0, 0, size);
         d.best->predTile = keep;
         taken = true;
-        return 0;
+        return checkDQP(*d.best, x, y, depth);              /* analysis.cpp:2879 */
     }
     /* the merge check of a CU decided on the device as a skip: Mode PRED_SKIP as checkMerge leaves it (candidate, costs, contexts) */
     int chainSkip(int node, int x, int y, int depth, bool& skipped)
@@ -582,7 +634,7 @@ struct Analyzer
         for (int i = 0; i < n4 * n4; i++) m.m[i].pred_mode = m.u[i].pred_mode;
         d.best = bestPred;
         skipped = true;
-        return 0;
+        return checkDQP(*bestPred, x, y, depth);           /* analysis.cpp:2879 */
     }
 
     uint64_t tileAddr(int t) const { return (uint64_t)(uintptr_t)dTiles.p + (size_t)t * tileBytes; }
@@ -838,7 +890,7 @@ struct Analyzer
     }
 
     /* ---- Analysis helpers ---- */
-    uint32_t topSkipMinDepth(int x, int y, int depth)
+    uint32_t topSkipMinDepth(int x, int y, int depth, int ge = -1)         /* ge: the QP test's answer given (the skip chain's node table), -1: as the records say */
     {
         /* parentCTU.m_qp[0] (analysis.cpp:3432) -- and parentCTU IS the picture's CTU record (frameencoder.cpp:1490): what compressCTU set for the whole CTU until the first
          * CU of the CTU has been copied to the picture, that CU's QP afterwards */
@@ -866,7 +918,7 @@ struct Analyzer
         if (!numRefs) return 0;
         uint32_t minDepth = minDepth0 < minDepth1 ? minDepth0 : minDepth1;
         const uint32_t thresh = minDepth * numRefs * ((uint32_t)(size >> 2) * (size >> 2) >> 2);
-        if (minDepth && currentQP >= previousQP && (sum <= thresh + (thresh >> 1))) minDepth -= 1;
+        if (minDepth && (ge < 0 ? currentQP >= previousQP : ge != 0) && (sum <= thresh + (thresh >> 1))) minDepth -= 1;
         return minDepth;
     }
     bool recursionDepthCheck(int depth, const Mode& best)
@@ -981,7 +1033,7 @@ struct Analyzer
         const int log2 = 6 - depth, size = 1 << log2;
         const int method = S->search_method & 0x7f;
         if (!on || I->is_inter_b || S->weighted || !xa_is_queue(st) || S->subpel_refine > 2 || (method != X265AMD_ME_DIA && method != X265AMD_ME_HEX && method != X265AMD_ME_STAR) ||
-            I->num_ref_idx[0] < 1 || I->num_ref_idx[0] > XA_SEARCH_MAX_REFS || rp.rdoq_level || si->tu_max_depth_inter != 1 || si->use_dqp || A->rd_level < 3 || log2 > 5)
+            I->num_ref_idx[0] < 1 || I->num_ref_idx[0] > XA_SEARCH_MAX_REFS || rp.rdoq_level || si->tu_max_depth_inter != 1 || A->rd_level < 3 || log2 > 5)
             return 0;
         if (!xa_me_device_bitsize(me) || !me) return 0;
         const size_t isz = sizeof(pixel);
@@ -1052,6 +1104,20 @@ struct Analyzer
             J.skip_ctx = (l && l->pred_mode == X265AMD_MODE_SKIP) + (a && a->pred_mode == X265AMD_MODE_SKIP);
         }
         J.frac = d.cur.frac; memcpy(J.ctx, d.cur.ctx, X265AMD_CTX_STRIDE);
+        if (si->use_dqp)
+        {
+            /* Entropy::codeDeltaQP's value (entropy.cpp:1737-1756): the QP in force against the group's prediction -- which nothing inside the group moves, so it can be
+             * taken before the CU's merge check and before its sub-CUs (searchAhead) */
+            if (!qpCoder)
+            {
+                if (!(qpCoder = x265amd_cabac_open(si, units, 1))) return fail("delta QP: coder");
+                qpCoder->ctuInProgress = true;
+            }
+            const int bd = 6 * (X265AMD_DEPTH - 8);
+            int dqp = qp - qpCoder->refQP(x, y);
+            dqp = (dqp + 78 + bd + (bd / 2)) % (52 + bd) - 26 - (bd / 2);
+            J.dqp = (1 << 16) | (depth <= si->max_cu_dqp_depth ? 1 << 17 : 0) | (uint8_t)(int8_t)dqp;
+        }
         ok = true;
         return 0;
     }
@@ -1173,6 +1239,12 @@ struct Analyzer
             memset(inter.contexts.ctx, 0, X265AMD_CTX_STRIDE);
             memcpy(inter.contexts.ctx, (const void*)o->ctx, X265AMD_CTX_COUNT);
             inter.contexts.frac = o->frac;
+            if (si->use_dqp && depth <= si->max_cu_dqp_depth && !(o->cbf[0] || o->cbf[1] || o->cbf[2]))
+            {
+                /* checkDQP of a CU without a residual: setQPSubParts(getRefQP) (search.cpp:3996-3999) */
+                const int8_t refQp = (int8_t)qpCoder->refQP(x, y);
+                for (int i = 0; i < n4 * n4; i++) inter.u[i].qp = refQp;
+            }
             fusedRd[depth] = true;
         }
         used = true;
@@ -1777,6 +1849,13 @@ struct Analyzer
         { XA_HOSTPROF("an.initSubCU x13"); for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth); }
         d.pred[PRED_2Nx2N].sa8dCost = 0;                 /* what a parent reads under --limit-modes when 2Nx2N is not searched here */
         chain.frNode[depth] = node; chain.frDirty[depth] = false;
+        {
+            const bool checked = mightNotSplit && (uint32_t)depth >= minDepth;
+            chain.usedFlags[depth] = (uint8_t)(checked ? 1 : (mightNotSplit && mightSplit ? 2 : 0));
+            /* the device walks the CTU's tree by the same rule (XaChainNode::flags): where it has been, the host must arrive the same way */
+            if (chain.on && ((!checked && chain.status[node] != 0) || (checked && chain.status[node] == 0 && mightSplit && node + 1 < chain.numNodes && chain.status[node + 1] != 0)))
+                return fail("skip chain: the device's walk through the CTU is not the host's");
+        }
         bool devSkip = false, childrenDev = true, intraBegun = false;
 
         /* Step 1: merge / skip candidates */
@@ -2188,7 +2267,15 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
              * plane, plain quantisation -- and a device job queue to run on */
             static const bool chainEnv = !(getenv("X265AMD_INTER_CHAIN") && atoi(getenv("X265AMD_INTER_CHAIN")) == 0);
             /* (a slice with weights: its predictions are weighted and its searches read weighted copies -- the host path does both; the chain does not) */
-            a.chain.on = chainEnv && !S->weighted && si->slice_type != 2 && A->rd_level <= 4 && A->early_skip && A->rskip == 1 && !A->rdoq_level && si->tu_max_depth_inter == 1 && !si->use_dqp &&
+            /* under delta QP: cu_qp_delta is priced as rd 3-4 price it, and the device carries one QP for the quantiser and the lambdas (none of the CTU's above 51) */
+            bool dqpOk = true;
+            if (si->use_dqp)
+            {
+                static const bool chainDqp = !(getenv("X265AMD_CHAIN_DQP") && atoi(getenv("X265AMD_CHAIN_DQP")) == 0);
+                dqpOk = chainDqp && A->rd_level >= 3;
+                for (int k = 0; k < (si->max_cu_dqp_depth ? 5 : 1); k++) dqpOk = dqpOk && a.cuQp[k] <= 51;
+            }
+            a.chain.on = chainEnv && !S->weighted && si->slice_type != 2 && A->rd_level <= 4 && A->early_skip && A->rskip == 1 && !A->rdoq_level && si->tu_max_depth_inter == 1 && dqpOk &&
                          xa_is_queue(a.st) && dCur && (dCol || !I->temporal_mvp) && I->max_num_merge_cand >= 1 && I->max_num_merge_cand <= 5 && !dump;
             if (a.chain.on) a.buildNodes(a.ctuX, a.ctuY, 0, -1);
             else a.chain.nodes[0].next = 0;

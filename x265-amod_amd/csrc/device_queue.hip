@@ -614,6 +614,13 @@ __global__ __launch_bounds__(64 * XA_SERVER_WAVES) void k_job_server(XaRingDev* 
         }
         /* a queue whose XA_OP_WAIT gave up runs nothing more: its commands still count as finished (the host's ring bookkeeping goes on), their results
          * stay unwritten and XaRingHost::fault tells every wait on this queue that they are */
+        if (flags & XA_CMD_RESET)
+        {
+            /* the poison of a wait that gave up ends with the owner it happened to (xa_queue_acquire sends this in front of a new owner's first command) */
+            __syncthreads();
+            if (tid == 0) { xa_wait_failed = 0; xa_sys_store(&rh->fault, 0ull); }
+            __syncthreads();
+        }
         if (!xa_wait_failed) xa_dispatch(s_cmd, tid);
         if (s_cmd.op == XA_OP_WAIT && tid == 0 && xa_wait_failed) xa_sys_store(&rh->fault, seen + 1);
         /* before the workgroup reports or publishes, every wavefront's stores have left (results live in host memory, read as soon as the count
@@ -1067,6 +1074,18 @@ bool xa_queues_enabled()
     return !S.disabled && S.init() == 0;
 }
 
+/* A queue whose XA_OP_WAIT gave up skips every command behind it and says so to every wait (XaRingHost::fault).  That ends with the owner it happened to: the next one
+ * starts with a command that clears the workgroup's flag and the fault word, and waits for it (rare: the queue stood for two seconds under its last owner). */
+static void xa_queue_clear_fault(void* st)
+{
+    XaQueue* q = as_queue(st);
+    if (!*reinterpret_cast<const volatile uint64_t*>(&q->rh->fault)) return;
+    fprintf(stderr, "x265amd queue %d: handed out again after a wait that gave up; the fault is cleared for its new owner\n", q->idx);
+    if (xa_q_enqueue(st, XA_OP_NOP, nullptr, 0, 1, XA_CMD_RESET | XA_CMD_SIGNAL) != hipSuccess) return;
+    const volatile uint64_t* fw = &q->rh->fault;
+    for (int i = 0; i < 20000 && *fw; i++) std::this_thread::sleep_for(std::chrono::microseconds(100));
+}
+
 void* xa_queue_acquire()
 {
     Server& S = server();
@@ -1097,7 +1116,10 @@ void* xa_queue_acquire()
     S.refs++;
     xa_scratch_local_begin();           /* the calling thread is the one that uses the queue */
     f->acquired = std::chrono::steady_clock::now();
-    return reinterpret_cast<void*>((uintptr_t)f | 1);
+    void* st = reinterpret_cast<void*>((uintptr_t)f | 1);
+    g.unlock();
+    xa_queue_clear_fault(st);
+    return st;
 }
 
 /* a second queue for the holder of a first one, if one is free right now: never waits (the rows of a picture take their FIRST queues in row order so that
@@ -1121,7 +1143,10 @@ void* xa_queue_try_acquire_spare(int spareWanted)
     S.freeCount = S.freeCount - 1;
     S.refs++;
     f->acquired = std::chrono::steady_clock::now();
-    return reinterpret_cast<void*>((uintptr_t)f | 1);
+    void* st = reinterpret_cast<void*>((uintptr_t)f | 1);
+    g.unlock();
+    xa_queue_clear_fault(st);
+    return st;
 }
 void xa_queue_release_helper(void* st)
 {
@@ -1424,6 +1449,47 @@ extern "C" double x265amd_queue_rtt_ns(int iters, int mode)
 }
 
 /* ---- self test (tests/test_device_queue.py): copies, fills and rectangle copies through a queue against the same through a stream ---- */
+extern "C" int x265amd_queue_selftest_wait_fault(void)
+{
+    void* keep = xa_queue_acquire();            /* held throughout: the resident kernel stays (a restart would clear every fault by itself) */
+    void* a = keep ? xa_queue_acquire() : nullptr;
+    void* b = a ? xa_queue_acquire() : nullptr;
+    if (!a || !b) { if (a) xa_queue_release(a); if (keep) xa_queue_release(keep); return xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: no queue"); }
+    void* d = nullptr;
+    if (xa_scratch_alloc(&d, 4096) != hipSuccess) { xa_queue_release(a); xa_queue_release(b); xa_queue_release(keep); return xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: memory"); }
+    const int idxA = as_queue(a)->idx;
+    /* `a` waits for a count `b` never reaches */
+    const XaArgsWait w = { (uint64_t)(uintptr_t)&as_queue(b)->rd->done, as_queue(b)->submitted + 1000 };
+    int rc = X265AMD_OK;
+    uint8_t back[64];
+    if (q_push(as_queue(a), XA_OP_WAIT, 0, 0, &w, sizeof(w))) rc = xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: push");
+    if (rc == X265AMD_OK)
+    {
+        (void)xa_fill_async(a, d, 0x5a, 64);
+        if (xa_stream_sync(a) == hipSuccess) rc = xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: the wait behind a stalled queue did not fail");
+    }
+    xa_queue_release(a); xa_queue_release(b);
+    if (rc == X265AMD_OK)
+    {
+        /* the same queue again (the first free one): a new owner, no fault */
+        a = xa_queue_acquire();
+        if (!a) rc = xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: no queue the second time");
+        else
+        {
+            if (as_queue(a)->idx != idxA) rc = xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: another queue was handed out");
+            else if (xa_fill_async(a, d, 0xa5, 64) != hipSuccess || xa_copy_async(a, back, d, 64, hipMemcpyDeviceToHost) != hipSuccess || xa_stream_fence(a, XA_CMD_RELEASE) != hipSuccess ||
+                     xa_stream_sync(a) != hipSuccess)
+                rc = xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: the queue's next owner inherited the fault");
+            else
+                for (int i = 0; i < 64; i++) if (back[i] != 0xa5) rc = xa_fail(X265AMD_EHIP, "queue_selftest_wait_fault: the next owner's commands did not run");
+            xa_queue_release(a);
+        }
+    }
+    xa_scratch_free(d);
+    xa_queue_release(keep);
+    return rc;
+}
+
 extern "C" int x265amd_queue_selftest(int rounds, int numQueues)
 {
     if (rounds <= 0 || numQueues <= 0) return xa_fail(X265AMD_EINVAL, "queue_selftest: arguments");

@@ -25,7 +25,9 @@
 struct alignas(16) XaMapUnit { uint8_t pred_mode, inter_dir; int8_t ref_idx[2]; int16_t mv[2][2]; uint8_t depth, pad[3]; };
 
 struct XaChainNode { int16_t x, y; uint8_t log2, flags, next, parent; };       /* flags: 1 = merge check at this depth (inside the picture, depth >= topSkipMinDepth);
-                                                                                   2 = inside the picture but not coded at this depth: the split flag (1) is counted behind its sub-CUs */
+                                                                                   2 = inside the picture but not coded at this depth: the split flag (1) is counted behind its sub-CUs.
+                                                                                   Bits 0-1 hold when the CTU's QP is not below the reference picture's (topSkipMinDepth's currentQP >=
+                                                                                   previousQP, analysis.cpp:3432-3470), bits 2-3 the same two flags when it is */
 enum { XA_CHAIN_END = 0, XA_CHAIN_NOTSKIP = 1, XA_CHAIN_GUARD = 2 };            /* why the chain stopped */
 enum { XA_CHAIN_MAX_NODES = 85 };
 
@@ -74,6 +76,17 @@ struct alignas(8) XaChainJob
     uint64_t scratch;                       /* levels / residual / reconstruction dumps of the winner's transform units (x265amd_inter_rd_scratch_bytes) */
     uint64_t frac;                          /* the entropy coder's state the first CU of the chain starts from (Entropy::m_fracBits, contexts) */
     uint8_t ctx[X265AMD_CTX_STRIDE];
+    /* ---- delta QP (PPS cu_qp_delta_enabled; section 4.27 of DESIGN.md).  Quantisation group k of the CTU: 0 when the groups are CTUs, else the 32x32 quadrant ---- */
+    int32_t use_dqp, max_dqp_depth;
+    int32_t first_qp;                       /* the QP of the CTU's first unit in the picture's records as the chain starts (topSkipMinDepth's currentQP) */
+    int32_t previous_qp;                    /* ... and what it is compared with: the first reference picture's CTU (previousQP) */
+    int32_t prev_qp;                        /* CUData::getLastCodedQP in front of the CTU */
+    int32_t dqp_reserved;
+    struct QpSet { uint64_t lambda, lambda2; uint32_t psy_rd; int32_t qp_luma, qp_chroma, qp; } qps[5];       /* [0] the 64x64 CU, [1 + k] group k and everything inside it */
+    int8_t last_src[4];                     /* getLastCodedQP in front of group k: the group whose unit it arrives at, -1: the one in front of the CTU (picture geometry alone) */
+    int8_t last_val[4], left_val[4], above_val[4];      /* those units' QPs in the picture's records, for groups complete before the chain starts (the chain knows the ones it completes) */
+    uint8_t anc_flags[4];                   /* per depth: the flags (bits 0-1) the host's recursion used for the start node's ancestors */
+    uint8_t dqp_pad[4];
 };
 
 #ifdef XA_CHAIN_DEVICE
@@ -99,6 +112,9 @@ struct ChainLds
     uint32_t rdBits[3], rdPsy, rdCbf[3], rdPad; uint64_t rdCost, rdLuma, rdChroma;     /* the residual mode when it wins: bits (total, prediction info, skip flag), psy energy, coded block flags, cost, distortions */
     uint32_t step[256];
     unsigned long long ticks[8]; long long tprev;       /* stage clock (thread 0): candidates, predictions, measurements, units, RD, placing, CUs, - */
+    uint8_t used[XA_CHAIN_MAX_NODES + 3];               /* the flags (bits 0-1) each node was visited with */
+    int firstQp, dqp, dqpTwice;                         /* the CTU's first unit's QP as the recursion would find it; the current CU's cu_qp_delta and whether checkDQP prices it again */
+    int qgVal[4]; uint32_t qgDone;                      /* groups this chain has completed (all skipped): every unit carries the group's predicted QP */
 };
 #define XA_CHAIN_HEADER 8192
 #define XA_CHAIN_T(k) do { if (tid == 0) { const long long t_ = wall_clock64(); S.ticks[k] += (unsigned long long)(t_ - S.tprev); S.tprev = t_; } } while (0)
@@ -380,6 +396,39 @@ XA_DEV void chain_split_flag(const XaChainJob& J, uint8_t* ctx, uint64_t& frac, 
     frac += cb_bin(ctx + CC_SPLIT + chain_split_ctx(J, x, y, depth), flag);
 }
 
+/* Entropy::codeDeltaQP's bins (entropy.cpp:1737-1756) in counting mode: the first bin on context 16, the rest of the unary prefix (to 5) on 17, EG0 suffix and sign in bypass */
+XA_DEV uint64_t chain_dqp_bits(uint8_t* cx, int dqp)
+{
+    const uint32_t a = (uint32_t)(dqp < 0 ? -dqp : dqp);
+    uint64_t f = cb_bin(&cx[16], a ? 1u : 0u);
+    if (a)
+    {
+        uint32_t sym = a < 5 ? a : 5;
+        const bool codeLast = 5 > sym;
+        while (--sym) f += cb_bin(&cx[17], 1u);
+        if (codeLast) f += cb_bin(&cx[17], 0u);
+        if (a >= 5)
+        {
+            uint32_t symbol = a - 5, count = 0, n = 0;
+            while (symbol >= (1u << count)) { n++; symbol -= 1u << count; count++; }
+            f += (uint64_t)32768 * (n + 1 + count);
+        }
+        f += 32768;         /* the sign */
+    }
+    return f;
+}
+/* CUData::getRefQP (cudata.cpp:814-855) of quantisation group k from what the job says about the groups in front of it and what the chain has completed itself */
+XA_DEV int chain_qg_qp(const ChainLds& S, int j, int hostVal) { return (S.qgDone >> j) & 1u ? S.qgVal[j] : hostVal; }
+XA_DEV int chain_ref_qp(const ChainLds& S, int k)
+{
+    const XaChainJob& J = S.job;
+    const int last = J.last_src[k] < 0 ? J.prev_qp : chain_qg_qp(S, J.last_src[k], J.last_val[k]);
+    if (J.max_dqp_depth == 0 || k == 0) return last;
+    const int l = (k & 1) ? chain_qg_qp(S, k - 1, J.left_val[k]) : last;
+    const int a = (k & 2) ? chain_qg_qp(S, k - 2, J.above_val[k]) : last;
+    return (l + a + 1) >> 1;
+}
+
 /* encodeResAndCalcRdSkipCU and encodeResAndCalcRdInterCU (search.cpp:2770-2975) of the chosen merge candidate of a CU with one transform unit per plane (8x8 ..
  * 32x32: the residual quad-tree is its root), from the units' results S.tr[] and levels, and the choice between them as checkMerge2Nx2N_rd0_4 makes it
  * (analysis.cpp:2852-2880: the residual mode only when strictly cheaper).  Host form: x265amd_skip_rd_host, inter_rd_walk_impl, x265amd_inter_rd_finish (inter_rd.hip).
@@ -457,6 +506,8 @@ XA_DEV void chain_merge_rd(ChainLds& S, int x, int y, int log2, int best, int la
         fD += cb_bin(S.ctxD + CC_QT_CBF + 2, cbf[1]);
         fD += cb_bin(S.ctxD + CC_QT_CBF + 2, cbf[2]);
         if (cbf[1] | cbf[2]) fD += cb_bin(S.ctxD + CC_QT_CBF + 1, cbf[0]);
+        /* cu_qp_delta with the first coded block flag (encodeTransform with bCodeDQP, entropy.cpp:1207-1222) */
+        if (J.use_dqp) fD += chain_dqp_bits(S.ctxD, S.dqp);
     }
     xa_wave_sync();
     fD = __shfl(fD, 0, 64);
@@ -465,17 +516,28 @@ XA_DEV void chain_merge_rd(ChainLds& S, int x, int y, int log2, int best, int la
         if (cbf[p]) fD += wave_coeff_bits(S.ctxD, S.ctxD, reinterpret_cast<const int16_t*>(S.tu[p].coeff), logs[p], p, 0, 0, J.sign_hide, S.step, lane);
         xa_wave_sync();
     }
+    const uint32_t bits0 = (uint32_t)(fD >> 15);
+    uint32_t again = 0;
+    if (J.use_dqp && S.dqpTwice)
+    {
+        /* Search::checkDQP inside encodeResAndCalcRdInterCU (search.cpp:3974-4003) for a CU at or above the groups' depth: resetBits(), codeDeltaQP, the bits added */
+        if (lane == 0) S.fracD = (fD & 32767) + chain_dqp_bits(S.ctxD, S.dqp);
+        xa_wave_sync();
+        fD = S.fracD;
+        again = (uint32_t)(fD >> 15);
+    }
     chain_sse_t dist = 0;
     dist += cbf[0] ? (chain_sse_t)S.tr[0].nz_dist : (chain_sse_t)S.tr[0].zero_dist;
     chain_sse_t cd = cbf[1] ? (chain_sse_t)S.tr[1].nz_dist : (chain_sse_t)S.tr[1].zero_dist;
     cd += cbf[2] ? (chain_sse_t)S.tr[2].nz_dist : (chain_sse_t)S.tr[2].zero_dist;
     dist += cd;
     const uint32_t psy = J.psy_rd ? (cbf[0] ? S.tr[0].nz_energy : S.tr[0].zero_energy) : 0;
-    const uint64_t mergeCost = chain_cost(J, dist, (uint32_t)(fD >> 15), psy);
+    const uint32_t totalBits = bits0 + again;
+    const uint64_t mergeCost = chain_cost(J, dist, totalBits, psy);
     if (lane == 0)
     {
         S.skipWins = mergeCost < skipCost ? 0 : 1;
-        S.fracD = fD; S.rdBits[0] = (uint32_t)(fD >> 15); S.rdPsy = psy; S.rdCbf[0] = cbf[0]; S.rdCbf[1] = cbf[1]; S.rdCbf[2] = cbf[2];
+        S.fracD = fD; S.rdBits[0] = totalBits; S.rdPad = again; S.rdPsy = psy; S.rdCbf[0] = cbf[0]; S.rdCbf[1] = cbf[1]; S.rdCbf[2] = cbf[2];
         S.rdCost = mergeCost; S.rdLuma = (uint64_t)(dist - cd); S.rdChroma = (uint64_t)cd;
     }
 }
@@ -501,13 +563,19 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
         const uint64_t* src = reinterpret_cast<const uint64_t*>(S.job.nodes);
         uint64_t* dst = reinterpret_cast<uint64_t*>(S.nodes);
         for (int i = tid; i < S.job.num_nodes; i += NT) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (tid == 0) { S.count = 0; S.stop = 0; S.frac = S.job.frac; for (int k = 0; k < 8; k++) S.ticks[k] = 0; S.tprev = wall_clock64(); }
+        if (tid == 0)
+        {
+            S.count = 0; S.stop = 0; S.frac = S.job.frac; for (int k = 0; k < 8; k++) S.ticks[k] = 0; S.tprev = wall_clock64();
+            S.firstQp = S.job.first_qp; S.qgDone = 0; S.dqp = 0; S.dqpTwice = 0; S.rdPad = 0;
+        }
         for (int i = tid; i < 256; i += NT) S.step[i] = en_step.v[i];
         if (tid == 1) __hip_atomic_store(reinterpret_cast<uint64_t*>(&reinterpret_cast<XaChainOut*>(S.job.out)->stop), (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (int i = tid; i < X265AMD_CTX_STRIDE; i += NT) S.ctx[i] = S.job.ctx[i];
     }
     __syncthreads();
     const XaChainJob& J = S.job;
+    if (tid == 0)
+        for (int p = S.nodes[J.start].parent; p != 255; p = S.nodes[p].parent) S.used[p] = J.anc_flags[(6 - S.nodes[p].log2) & 3];      /* the host's recursion came through these */
     const uint64_t* planes = reinterpret_cast<const uint64_t*>(J.planes);
     const uint64_t* srcPlanes = planes + 3 * (J.num_pics - 1);
     const uint64_t* recPlanes = planes + 3 * (J.num_pics - 2);
@@ -517,8 +585,27 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
     while (node < J.end)
     {
         const XaChainNode N = S.nodes[node];
-        if (!(N.flags & 1)) { node++; continue; }       /* not coded at this depth: into its first sub-CU */
+        /* topSkipMinDepth's QP test reads the CTU's first unit as the picture's records hold it when the recursion arrives here (S.firstQp) */
+        const int flags = S.firstQp >= J.previous_qp ? N.flags & 3 : (N.flags >> 2) & 3;
+        if (tid == 0) S.used[node] = (uint8_t)flags;
+        if (!(flags & 1)) { node++; continue; }       /* not coded at this depth: into its first sub-CU */
         const int x = N.x, y = N.y, log2 = N.log2, size = 1 << log2, depth = 6 - log2;
+        /* the quantisation group of the CU and the QP in force for it: lambdas, quantiser, cu_qp_delta */
+        const int qg = J.max_dqp_depth == 0 ? 0 : ((y - J.ctu_y) >> 5) * 2 + ((x - J.ctu_x) >> 5);
+        if (J.use_dqp)
+        {
+            __syncthreads();
+            if (tid == 0)
+            {
+                const XaChainJob::QpSet q = J.qps[J.max_dqp_depth == 0 || depth == 0 ? 0 : 1 + qg];
+                XaChainJob& W = S.job;
+                W.lambda = q.lambda; W.lambda2 = q.lambda2; W.psy_rd = q.psy_rd; W.qp_luma = q.qp_luma; W.qp_chroma = q.qp_chroma;
+                const int bd = 6 * (X265AMD_DEPTH - 8);
+                S.dqp = (q.qp - chain_ref_qp(S, depth == 0 ? 0 : qg) + 78 + bd + (bd / 2)) % (52 + bd) - 26 - (bd / 2);
+                S.dqpTwice = depth <= J.max_dqp_depth;
+            }
+            __syncthreads();
+        }
         /* ---- candidates, their jobs ---- */
         if (wv == 0)
         {
@@ -829,7 +916,7 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
                     h.valid = 1; h.node = (uint32_t)node; h.cand = (uint8_t)best; h.dir = c.dir;
                     for (int l = 0; l < 2; l++) { const bool used = (c.dir >> l) & 1; h.ref_idx[l] = used ? c.ref_idx[l] : -1; h.mv[l][0] = used ? c.mv[l][0] : 0; h.mv[l][1] = used ? c.mv[l][1] : 0; }
                     h.cbf[0] = (uint8_t)S.rdCbf[0]; h.cbf[1] = (uint8_t)S.rdCbf[1]; h.cbf[2] = (uint8_t)S.rdCbf[2]; h.reserved0 = 0;
-                    h.total_bits = S.rdBits[0]; h.mv_bits = S.rdBits[1]; h.coeff_bits = S.rdBits[0] - S.rdBits[1] - S.rdBits[2]; h.psy_energy = S.rdPsy;
+                    h.total_bits = S.rdBits[0]; h.mv_bits = S.rdBits[1]; h.coeff_bits = S.rdBits[0] - S.rdPad - S.rdBits[1] - S.rdBits[2]; h.psy_energy = S.rdPsy;
                     h.sa8d = S.meas[best].sa8d; h.sa8d_luma = S.meas[best].sa8d_luma;
                     h.rd_cost = S.rdCost; h.luma_dist = S.rdLuma; h.chroma_dist = S.rdChroma; h.frac = S.fracD; h.meas = S.meas[best];
                     static_assert(sizeof(Head) == offsetof(XaChainStop, ctx), "the stop record's head");
@@ -893,9 +980,34 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
             uint64_t f = S.fracS;
             if (depth < J.max_cu_depth) chain_split_flag(J, S.ctx, f, x, y, depth, 0);
             for (int p = N.parent; p != 255 && S.nodes[p].next == N.next; p = S.nodes[p].parent)
-                if (S.nodes[p].flags & 2) chain_split_flag(J, S.ctx, f, S.nodes[p].x, S.nodes[p].y, 6 - S.nodes[p].log2, 1);
+                if (S.used[p] & 2) chain_split_flag(J, S.ctx, f, S.nodes[p].x, S.nodes[p].y, 6 - S.nodes[p].log2, 1);
             S.frac = f;
             S.ticks[6] += 1;
+            if (J.use_dqp)
+            {
+                /* what the skipped CU leaves in the picture's QP records (Search::checkDQP: a CU without a residual at or above the groups' depth takes the predicted QP; a
+                 * group whose CUs are all skipped takes it through checkDQPForSplitPred when its last CU is done) */
+                const bool origin = x == J.ctu_x && y == J.ctu_y;
+                if (depth <= J.max_dqp_depth)
+                {
+                    const int r = chain_ref_qp(S, depth == 0 ? 0 : qg);
+                    if (depth == 0) { for (int k = 0; k < 4; k++) S.qgVal[k] = r; S.qgDone = 15; }
+                    else { S.qgVal[qg] = r; S.qgDone |= 1u << qg; }
+                    if (origin) S.firstQp = r;
+                }
+                else
+                {
+                    if (origin) S.firstQp = J.qps[J.max_dqp_depth == 0 ? 0 : 1 + qg].qp;
+                    int a = N.parent;
+                    while (a != 255 && 6 - S.nodes[a].log2 > J.max_dqp_depth) a = S.nodes[a].parent;
+                    if (a != 255 && S.nodes[a].next == N.next)
+                    {
+                        const int r = chain_ref_qp(S, qg);
+                        S.qgVal[qg] = r; S.qgDone |= 1u << qg;
+                        if (S.nodes[a].x == J.ctu_x && S.nodes[a].y == J.ctu_y) S.firstQp = r;
+                    }
+                }
+            }
         }
         __syncthreads();
         XA_CHAIN_T(7);

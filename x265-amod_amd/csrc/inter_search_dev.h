@@ -30,6 +30,8 @@ struct alignas(8) XaSearchJob
     uint64_t lambda, lambda2;               /* RDCost::m_lambda / m_lambda2 */
     uint32_t psy_rd;
     int32_t qp_luma, qp_chroma, sign_hide, chroma_sa8d, rd_level, skip_ctx, do_rd, slice_type;
+    int32_t dqp;                            /* delta QP (PPS cu_qp_delta_enabled): bits 0-7 the CU's cu_qp_delta as Entropy::codeDeltaQP wraps it (int8), bit 16 on, bit 17 the CU is a
+                                             * quantisation group or above it (Search::checkDQP prices the syntax element a second time); 0: no delta QP */
     uint64_t frac;                          /* the coder's state in front of the CU (m_rqt[depth].cur) */
     uint8_t ctx[X265AMD_CTX_STRIDE];
 };
@@ -184,6 +186,8 @@ XA_DEV void search_inter_rd(SearchLds& S, int log2, int lane)
             fD += cb_bin(S.ctxD + CC_QT_CBF + 2, cbf[1]);
             fD += cb_bin(S.ctxD + CC_QT_CBF + 2, cbf[2]);
             if (cbf[1] | cbf[2]) fD += cb_bin(S.ctxD + CC_QT_CBF + 1, cbf[0]);
+            /* cu_qp_delta with the first coded block flag (encodeTransform with bCodeDQP: any CU that has a residual, entropy.cpp:1207-1222) */
+            if (J.dqp) fD += chain_dqp_bits(S.ctxD, (int)(int8_t)(J.dqp & 0xff));
         }
     }
     xa_wave_sync();
@@ -202,8 +206,16 @@ XA_DEV void search_inter_rd(SearchLds& S, int log2, int lane)
     const uint32_t psy = J.psy_rd ? (cbf[0] ? S.tr[0].nz_energy : S.tr[0].zero_energy) : 0;
     if (lane == 0)
     {
-        S.fracD = fD; S.rdBits[0] = (uint32_t)(fD >> 15); S.rdPsy = psy; S.rdCbf[0] = cbf[0]; S.rdCbf[1] = cbf[1]; S.rdCbf[2] = cbf[2];
-        S.rdCost = search_cost(J, dist, (uint32_t)(fD >> 15), psy); S.rdLuma = (uint64_t)(dist - cd); S.rdChroma = (uint64_t)cd;
+        uint32_t bits = (uint32_t)(fD >> 15), again = 0;
+        if (rootCbf && (J.dqp >> 17))
+        {
+            /* Search::checkDQP (search.cpp:3974-4003) of a CU at or above the quantisation groups' depth: resetBits(), codeDeltaQP, the bits added to the mode's */
+            fD = (fD & 32767) + chain_dqp_bits(S.ctxD, (int)(int8_t)(J.dqp & 0xff));
+            again = (uint32_t)(fD >> 15);
+            bits += again;
+        }
+        S.fracD = fD; S.rdBits[0] = bits; S.rdPad = again; S.rdPsy = psy; S.rdCbf[0] = cbf[0]; S.rdCbf[1] = cbf[1]; S.rdCbf[2] = cbf[2];
+        S.rdCost = search_cost(J, dist, bits, psy); S.rdLuma = (uint64_t)(dist - cd); S.rdChroma = (uint64_t)cd;
     }
 }
 
@@ -491,7 +503,7 @@ XA_DEV void block_inter_search(const XaSearchJob* jobAddr, char* smem, int tid)
         h.valid = 1; h.best = S.best; h.mv[0] = (int16_t)S.bestMv[0]; h.mv[1] = (int16_t)S.bestMv[1]; h.mvp[0] = (int16_t)S.bestMvp[0]; h.mvp[1] = (int16_t)S.bestMvp[1];
         h.mvp_idx = S.bestMvpIdx; h.bits = S.bestBits; h.cost = S.bestCost; h.mv_cost = S.bestMvCost; h.sa8d = S.sa8d; h.sa8d_luma = S.sa8dLuma;
         h.cbf[0] = doRd ? (uint8_t)S.rdCbf[0] : 0; h.cbf[1] = doRd ? (uint8_t)S.rdCbf[1] : 0; h.cbf[2] = doRd ? (uint8_t)S.rdCbf[2] : 0; h.rd_done = doRd ? 1 : 0;
-        h.total_bits = doRd ? S.rdBits[0] : 0; h.mv_bits = doRd ? S.rdBits[1] : 0; h.coeff_bits = doRd ? S.rdBits[0] - S.rdBits[1] - S.rdBits[2] : 0;
+        h.total_bits = doRd ? S.rdBits[0] : 0; h.mv_bits = doRd ? S.rdBits[1] : 0; h.coeff_bits = doRd ? S.rdBits[0] - S.rdPad - S.rdBits[1] - S.rdBits[2] : 0;
         h.psy_energy = doRd ? S.rdPsy : 0; h.res_energy = doRd ? (uint32_t)S.tr[0].zero_dist : 0; h.reserved1 = 0;
         h.rd_cost = doRd ? S.rdCost : 0; h.luma_dist = doRd ? S.rdLuma : 0; h.chroma_dist = doRd ? S.rdChroma : 0; h.frac = doRd ? S.fracD : 0;
         static_assert(sizeof(Head) == offsetof(XaSearchOut, ctx), "the search result's head");

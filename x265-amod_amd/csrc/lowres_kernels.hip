@@ -441,6 +441,13 @@ XA_DEV void lowres_cost_row(const LowresCostParams& p, int row, pixel* fencT, pi
         {
             p.bcost[cuXY] = bcost;
             p.lowresCosts[cuXY] = (uint16_t)(min(bcost, 0x3FFF) | (listused << 14));
+            /* INVARIANT of this hand-over (round 5, section 4.25 of DESIGN.md): every word another wavefront of the launch reads -- the row's vectors (mvs) and the progress
+             * word -- is written and read with AGENT-SCOPE ATOMICS, which go to the L2 past the per-CU caches; bcost / lowresCosts / mvCosts above are plain stores because
+             * nobody inside the launch reads them.  A new cross-row read MUST be such an atomic too: there is no release / acquire fence here to cover a plain one.
+             * The wait below orders the vectors' stores in front of the progress word only because stores count in vmcnt on this ISA (gfx9 family; gfx10+ has vscnt). */
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "lowres_cost_row's hand-over relies on gfx950's vmcnt covering stores"
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* the vectors' stores have arrived before the progress word leaves: a wait, no cache write-back */
             __hip_atomic_store(&p.progress[cuY], cuX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -23,7 +23,8 @@ enum
 {
     XA_CMD_ACQUIRE = 1,     /* before the command: make other workgroups' / kernels' / copy engines' writes visible (agent-scope acquire) */
     XA_CMD_RELEASE = 2,     /* after the command: make this workgroup's device-memory writes visible to them (agent-scope release) */
-    XA_CMD_SIGNAL = 4       /* after the command: publish the count of finished commands to the host */
+    XA_CMD_SIGNAL = 4,      /* after the command: publish the count of finished commands to the host */
+    XA_CMD_RESET = 8        /* before the command: a new owner takes the queue -- what an XA_OP_WAIT that gave up left behind (the workgroup's flag, XaRingHost::fault) is the last owner's */
 };
 
 #define XA_RING 64              /* commands per queue ring */

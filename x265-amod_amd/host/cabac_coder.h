@@ -634,6 +634,37 @@ struct x265amd_cabac
             else return si.slice_qp;
         }
     }
+    /* where lastQP(x, y) ends when every unit of the picture in front of the group carries a CU (true of any group the analysis has reached): the unit's position, false when
+     * the walk leaves the CTU (the answer is then lastQP's of the CTU's origin).  Picture geometry alone -- the device-run skip chain is told (inter_chain_dev.h: last_src) */
+    bool lastQPUnitInCtu(int x, int y, int& px, int& py) const
+    {
+        const int qg = 64 >> si.max_cu_dqp_depth;
+        const int gx = x & ~(qg - 1), gy = y & ~(qg - 1);
+        const int bx = gx & ~63, by = gy & ~63;
+        int z = (int)zorder((gx & 63) >> 2, (gy & 63) >> 2) - 1;
+        while (z >= 0)
+        {
+            int ux = 0, uy = 0;
+            for (int b = 0; b < 4; b++) { ux |= ((z >> (2 * b)) & 1) << b; uy |= ((z >> (2 * b + 1)) & 1) << b; }
+            px = bx + ux * 4; py = by + uy * 4;
+            if (px < si.pic_width && py < si.pic_height) return true;
+            int d = 1;
+            for (; d < 4; d++)
+            {
+                const int sz = 64 >> d;
+                if (bx + ((ux * 4) & ~(sz - 1)) >= si.pic_width || by + ((uy * 4) & ~(sz - 1)) >= si.pic_height) break;
+            }
+            int depth = d;
+            if (ctuInProgress)
+            {
+                const int psz = 64 >> (d - 1);
+                const int ox = bx + ((ux * 4) & ~(psz - 1)), oy = by + ((uy * 4) & ~(psz - 1));
+                if (gx >= ox && gx < ox + psz && gy >= oy && gy < oy + psz) depth = 0;
+            }
+            z -= 256 >> (2 * depth);
+        }
+        return false;
+    }
     void deltaQP(int x, int y)
     {
         const x265amd_cu_unit& u = U(x >> 2, y >> 2);
