@@ -89,7 +89,7 @@ def test_encoder_object_presets_as_they_come(tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["crf_wqvga_medium_30", "crf_fhd_medium_60"])
+@pytest.mark.parametrize("tag", ["crf_wqvga_medium_30/", "crf_fhd_medium_60/"])
 def test_device_chains_verified_under_delta_qp(tag):
     """The device-run paths of P / B pictures under the preset's rate control (delta QP: a QP per quantisation group, cu_qp_delta priced in the residual modes, the predicted
     QP of each group and topSkipMinDepth's QP test tracked on the device -- DESIGN.md section 4.27): with X265AMD_CHAIN_VERIFY=2 the host repeats every skipped CU, every
