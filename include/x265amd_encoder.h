@@ -167,7 +167,8 @@ int x265amd_encoder_ctu_rows(const x265amd_encoder* enc);
 int x265amd_encoder_owns(const x265amd_encoder* enc, uint64_t coding_index);
 /* counters of the pictures handed over by the lookahead so far (the counterpart of what x265_encoder_get_stats totals, x265.h:2475): out[0] I, out[1] P, out[2] B pictures,
  * out[3] the sum over them of the DISTINCT reference pictures each reads (DPB::prepareEncode's lists, dpb.cpp:101-290) -- SURVEY section 8d's R per picture, which the
- * bench's roofline figure is built from.  n: words available (>= 4).  Returns 0 or -1. */
+ * bench's roofline figure is built from.  With n >= 13 also, of the pictures HANDED OUT so far by I / P / B: out[4..6] their number, out[7..9] the bits of their NAL units,
+ * out[10..12] the sums of their average QPs (IEEE doubles, bit for bit in the words) -- x265_stats' statsI / statsP / statsB.  n: words available (>= 4).  Returns 0 or -1. */
 int x265amd_encoder_stats(const x265amd_encoder* enc, uint64_t* out, int n);
 /* whether pictures coded later may reference picture `coding_index` (DPB::prepareEncode: every picture but a plain B picture; reference: source/encoder/dpb.cpp:101-140):
  * 1 yes, 0 no -- its rows need not travel and an object that does not code it does not wait for them --, 2 not known yet (not handed over by the lookahead: ask again),

@@ -31,5 +31,12 @@ PIC(pts); PIC(dts); PIC(planes); PIC(stride); PIC(bitDepth); PIC(sliceType); PIC
 #define API(f) static_assert(offsetof(x265_api, f) == X265ABI_API_##f, #f)
 API(api_major_version); API(bit_depth); API(version_str); API(param_alloc); API(encoder_open); API(encoder_encode); API(encoder_close); API(cleanup); API(sizeof_frame_stats);
 API(encoder_intra_refresh); API(zone_param_parse);
+P(csvfn); P(csvfpt); P(csvLogLevel); P(maxCLL); P(maxFALL);
+#define ST(f) static_assert(offsetof(x265_stats, f) == X265ABI_STATS_##f, #f)
+ST(globalPsnrY); ST(globalSsim); ST(elapsedEncodeTime); ST(elapsedVideoTime); ST(bitrate); ST(accBits); ST(encodedPictureCount); ST(totalWPFrames); ST(statsI); ST(statsP); ST(statsB);
+ST(maxCLL); ST(maxFALL);
+#define SST(f) static_assert(offsetof(x265_sliceType_stats, f) == X265ABI_SLICESTATS_##f, #f)
+SST(avgQp); SST(bitrate); SST(psnrY); SST(ssim); SST(numPics);
+static_assert(sizeof(x265_sliceType_stats) == X265ABI_SIZEOF_SLICESTATS && sizeof(x265_stats) == X265ABI_SIZEOF_STATS, "x265_stats");
 static_assert(X265_RC_CQP == 1 && X265_RC_CRF == 2 && X265_CSP_I420 == 1 && X265_DIA_SEARCH == 0 && X265_HEX_SEARCH == 1 && X265_STAR_SEARCH == 3, "enum values used by x265_api_abi.cpp");
 int main() { return 0; }

@@ -170,28 +170,42 @@ def test_cli_is_built():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["sao_bframes/", "hbd_b/"])
+@pytest.mark.parametrize("tag", ["crf_wqvga_medium_30/", "rc_no_pyramid_keyint/", "rc_crf44_hbd_slow/"])
 def test_command_line_program_reproduces_reference_stream(tag, tmp_path):
-    """x265-amod_amd/bin/x265amd (y4m in, .hevc + reconstruction out; it loads the 8- or 10-bit library by the input's depth) against the reference
-    command line program's output for the same clip and options"""
+    """x265-amod_amd/bin/x265amd is a client of the library's `x265_api` table as the reference's program is of its own (preset tables, x265_param_parse, encoder_open / encode):
+    given THE REFERENCE'S COMMAND LINE -- `--preset medium --no-info`, options of the rate control and the GOP, `--preset slow --crf 44` on a 10-bit clip (it loads the library by
+    the input's depth) -- it writes the reference's bytes (tests/golden: encoder_preset_golden.json, encoder_rc_golden.json, cut by make_golden.py with the same arguments);
+    the reconstruction as YUV4MPEG2 in display order (IDR pictures restart the POC: rc_no_pyramid_keyint/) and the summary line of the CSV log."""
+    import json
     import subprocess
-    if tag == "hbd_b/":
-        (w, h), n, _ = EDGE_CONFIGS[tag]
-        frames, depth = T.encoder_api_clip(tag, w, h, n, 10), 10
-        want = np.load(EDGE_GOLD)[tag + "stream"]
-        opts = ["--bframes", "2", "--sao", "--rect", "--amp", "--no-wpp"]
-    else:
-        w, h, depth = T.MC_W, T.MC_H, 8
-        frames = display_frames(tag)
-        want = np.load(GOLD_PATH)[tag + "stream"]
-        opts = ["--bframes", "2", "--sao", "--no-wpp"]
+    gold = os.path.join(T.GOLDEN_DIR, "encoder_preset_golden.json" if tag in T.PRESET_CASES else "encoder_rc_golden.json")
+    g = json.load(open(gold))[tag]
+    (w, h), n, depth, cfg_id, _, cli = (T.PRESET_CASES[tag] if tag in T.PRESET_CASES else T.RC_CASES[tag])
+    frames = T.full_case_frames(tag)
     _write_y4m(tmp_path / "clip.y4m", frames, w, h, depth)
-    r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc"), "--recon", str(tmp_path / "rec.yuv"), "--qp", "30"] + opts,
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc"), "--recon", str(tmp_path / "rec.y4m"), "--csv", str(tmp_path / "log.csv")] + cli + T.PRESET_CLI,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.fromfile(tmp_path / "out.hevc", np.uint8)
-    assert len(got) == len(want) and hashlib.md5(got.tobytes()).hexdigest() == hashlib.md5(want.tobytes()).hexdigest()
-    assert os.path.getsize(tmp_path / "rec.yuv") == len(frames) * w * h * 3 // 2 * (2 if depth == 10 else 1)
+    assert len(got) == g["stream_bytes"] and hashlib.md5(got.tobytes()).hexdigest() == g["stream_md5"]
+    # the reconstruction: a YUV4MPEG2 header, then every picture in display order behind its FRAME line
+    rec = open(tmp_path / "rec.y4m", "rb").read()
+    head, body = rec.split(b"\n", 1)
+    assert head == b"YUV4MPEG2 W%d H%d F30:1 Ip C420%s" % (w, h, b"p10" if depth == 10 else b"")
+    fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
+    assert len(body) == n * (fsz + 6)
+    for k in range(n):
+        assert body[k * (fsz + 6):k * (fsz + 6) + 6] == b"FRAME\n"
+        assert hashlib.md5(body[k * (fsz + 6) + 6:(k + 1) * (fsz + 6)]).hexdigest() == g["recon_md5"][k], "reconstruction of picture %d in display order" % k
+    # the CSV log: the reference's summary header and one line whose counts and bits are the stream's
+    lines = open(tmp_path / "log.csv").read().splitlines()
+    assert len(lines) == 2 and lines[0].startswith("Command, Date/Time, Elapsed Time, FPS, Bitrate, Y PSNR,") and lines[0].endswith(" Version")
+    cells = [c.strip() for c in lines[1].split('"')[2].split(",")]         # behind the quoted command line
+    counts = [int(cells[k]) for k in (11, 18, 25) if cells[k] != "-"]
+    assert sum(counts) == n, cells
+    kbps = float(cells[4])
+    picture_bytes = kbps * 1000.0 / 8.0 * (n / 30.0)
+    assert g["stream_bytes"] - 130 <= picture_bytes <= g["stream_bytes"] + 2, (kbps, picture_bytes, g["stream_bytes"])      # (the stream's VPS / SPS / PPS are not any picture's bits)
 
 
 @pytest.mark.gpu

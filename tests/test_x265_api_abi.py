@@ -131,7 +131,7 @@ PARSE_CASES = [("crf", "23.5"), ("qp", "30"), ("bframes", "3"), ("b-adapt", "1")
                ("no-cutree", None), ("qcomp", "0.7"), ("ipratio", "1.3"), ("pbratio", "1.2"), ("qg-size", "64"), ("rc-lookahead", "30"), ("lookahead-slices", "0"), ("scenecut", "0"),
                ("tu-intra-depth", "2"), ("tu-inter-depth", "3"), ("limit-refs", "1"), ("limit-modes", None), ("no-early-skip", None), ("rskip", "0"), ("b-intra", "0"), ("no-signhide", None),
                ("no-strong-intra-smoothing", None), ("no-temporal-mvp", None), ("fast-intra", None), ("no-info", None), ("frame-threads", "2"), ("bitrate", "1000"), ("qpmin", "10"), ("qpmax", "40"),
-               ("rd", "x"), ("nosuchoption", "1")]
+               ("no-scenecut", None), ("sar", "1"), ("input-res", "416x240"), ("fps", "30000/1001"), ("fps", "25"), ("rd", "x"), ("nosuchoption", "1")]
 
 
 @pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")

@@ -270,6 +270,8 @@ extern "C" int x265amd_encoder_stats(const x265amd_encoder* e, uint64_t* out, in
 {
     if (!e || !out || n < 4) return xa_fail(X265AMD_EINVAL, "encoder_stats: arguments"), -1;
     out[0] = e->statPictures[0]; out[1] = e->statPictures[1]; out[2] = e->statPictures[2]; out[3] = e->statReferences;
+    if (n >= 13)
+        for (int t = 0; t < 3; t++) { out[4 + t] = e->statEmitted[t]; out[7 + t] = e->statBits[t]; memcpy(&out[10 + t], &e->statQpSum[t], 8); }
     return 0;
 }
 extern "C" int x265amd_encoder_row_geometry(const x265amd_encoder* e, int row, x265amd_row_export* out)
@@ -628,6 +630,18 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     }
     e->outBytes.swap(front->nalBytes);
     splitNals(e->outBytes, e->nals);
+    if (!e->outBytes.empty())
+    {
+        /* what x265_encoder_get_stats totals per slice type (Encoder::finishFrameStats, encoder.cpp:2960-3060): the access unit's bits and the picture's average QP -- the mean of
+         * its CUs' QPs weighted by their size (FrameEncoder::collectCTUStatistics; taken over the picture's own 4x4 units here, the reference also counts the absent units of
+         * cut CTUs) */
+        const int t = front->type == TYPE_B || front->type == TYPE_BREF ? 2 : (front->type == TYPE_P ? 1 : 0);
+        const size_t n = (size_t)e->w4 * e->h4;
+        double q = 0;
+        if (e->useDqp && front->units.size() >= n) { int64_t sum = 0; for (size_t i = 0; i < n; i++) sum += front->units[i].qp; q = (double)sum / (double)n; }
+        else q = front->sliceQp;
+        e->statEmitted[t]++; e->statBits[t] += (uint64_t)e->outBytes.size() * 8; e->statQpSum[t] += q;
+    }
     if (picOut)
     {
         e->staging.resize(e->picElems);

@@ -190,6 +190,7 @@ struct x265amd_encoder
     std::map<uint64_t, PicP> byCoding;                  /* the pictures in flight (and the last few collected) by their place in coding order (row export / import) */
     uint64_t collectedCoding = 0;                       /* pictures collected so far (under byCodingMu) */
     uint64_t statPictures[3] = { 0, 0, 0 }, statReferences = 0;     /* x265amd_encoder_stats: pictures prepared as I / P / B, the sum of their distinct reference pictures */
+    uint64_t statEmitted[3] = { 0, 0, 0 }, statBits[3] = { 0, 0, 0 }; double statQpSum[3] = { 0, 0, 0 };       /* ... and of the pictures handed out: count, NAL bits, the sum of their average QPs, by I / P / B */
     std::shared_future<int> lastTask;                   /* the previous picture's task: in-loop filters and SAO run in coding order */
     int frameThreads = 1;
     double uploadMs = 0;        /* X265AMD_TIMING: the callers' time in uploadPicture */

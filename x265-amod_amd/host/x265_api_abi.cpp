@@ -16,10 +16,12 @@
 #include "../../include/x265amd.h"
 #include "../../include/x265amd_encoder.h"
 #include "x265_abi_layout.h"
+#include "x265_api_table.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 int xa_fail(int code, const char* msg);
@@ -42,7 +44,10 @@ struct AbiEncoder
     std::vector<int64_t> ptsIn;         /* by input (display) order */
     int64_t prevReordered[2] = { 0, 0 };
     int bframeDelay = 0;                /* Encoder::m_bframeDelay: 2 with the B pyramid, 1 with B pictures, else 0 (encoder.cpp:3945) */
-    uint64_t coded = 0, idrBase = 0;    /* pictures handed out so far; the display index of the last IDR picture (POC counts from there) */
+    uint64_t coded = 0;                 /* pictures handed out so far */
+    double fps = 25.0;
+    struct timespec opened = { 0, 0 };   /* x265_stats.elapsedEncodeTime counts from encoder_open */
+    std::vector<uint8_t> recon;         /* the reconstruction handed out by the last encoder_encode: valid until the next call on this encoder (the reference hands out its own picture) */
 };
 
 /* ---- x265_param ---- */
@@ -171,6 +176,7 @@ int abi_param_parse(void* p, const char* name, const char* value)
         { "annexb", X265ABI_PARAM_bAnnexB }, { "repeat-headers", X265ABI_PARAM_bRepeatHeaders }, { "tskip", X265ABI_PARAM_bEnableTransformSkip }, { "lossless", X265ABI_PARAM_bLossless } };
     for (const auto& sw : switches)
         if (!strcmp(key, sw.name)) { const int v = truth(bad); if (bad) return -2; wr<int32_t>(p, sw.off, v); return 0; }
+    if (neg && !strcmp(key, "scenecut")) { wr<int32_t>(p, X265ABI_PARAM_scenecutThreshold, 0); return 0; }          /* --no-scenecut (param.cpp: atobool of "false") */
     if (neg) return -1;
     static const struct { const char* name; size_t off; } ints[] = {
         { "frame-threads", X265ABI_PARAM_frameNumThreads }, { "bframes", X265ABI_PARAM_bframes }, { "b-adapt", X265ABI_PARAM_bFrameAdaptive }, { "rc-lookahead", X265ABI_PARAM_lookaheadDepth },
@@ -234,6 +240,8 @@ int abi_param_apply_profile(void* p, const char* profile)
     if (X265AMD_DEPTH == 10 && !strcmp(profile, "main10")) return 0;
     return -1;
 }
+
+const char* const g_versionStr = "x265amd 0.3 (parity target x265 3.6+1-aa7f602f7)";
 
 /* ---- x265_picture ---- */
 void abi_picture_init(void* param, void* pic)
@@ -321,6 +329,8 @@ void* abi_encoder_open(void* p)
     a->enc = e; a->width = q.sourceWidth; a->height = q.sourceHeight;
     a->bframeDelay = q.bframes ? (q.bBPyramid ? 2 : 1) : 0;
     a->param.assign((const uint8_t*)p, (const uint8_t*)p + X265ABI_SIZEOF_PARAM);         /* api.cpp:96-116: the encoder keeps a copy */
+    a->fps = (double)q.fpsNum / (double)q.fpsDenom;
+    clock_gettime(CLOCK_MONOTONIC, &a->opened);
     return a;
 }
 void abi_encoder_parameters(void* enc, void* out) { if (enc && out) memcpy(out, ((AbiEncoder*)enc)->param.data(), X265ABI_SIZEOF_PARAM); }
@@ -349,8 +359,8 @@ int abi_encoder_encode(void* enc, x265amd_nal** ppNal, uint32_t* piNal, void* pi
         a.ptsIn.push_back(rd<int64_t>(picIn, X265ABI_PIC_pts));
     }
     /* the reconstruction is returned through planes the encoder owns in the reference (pic_out->planes point into its reconstructed picture); here the
-     * caller's pic_out receives pointers to a buffer of this object that stays valid until the next call */
-    static thread_local std::vector<uint8_t> recon;
+     * caller's pic_out receives pointers to a buffer of this encoder that stays valid until its next call */
+    std::vector<uint8_t>& recon = a.recon;
     if (picOut)
     {
         const size_t isz = X265AMD_DEPTH > 8 ? 2 : 1, ysz = (size_t)a.width * a.height * isz, csz = ysz / 4;
@@ -368,9 +378,8 @@ int abi_encoder_encode(void* enc, x265amd_nal** ppNal, uint32_t* piNal, void* pi
     }
     if (ret > 0)
     {
-        /* an IDR picture closes what lies before it in display order: everything coded so far */
-        if (out.sliceType == 1) a.idrBase = a.coded;
-        const uint64_t display = a.idrBase + (uint64_t)(out.poc < 0 ? 0 : out.poc);
+        /* the picture's POC is its place in display order from the first picture on (Frame::m_poc; the slice header's count restarts at an IDR picture, this one does not) */
+        const uint64_t display = (uint64_t)(out.poc < 0 ? 0 : out.poc);
         const int64_t pts = display < a.ptsIn.size() ? a.ptsIn[display] : 0;
         const int64_t reordered = a.coded < a.ptsIn.size() ? a.ptsIn[a.coded] : pts;
         int64_t dts = reordered;
@@ -385,7 +394,44 @@ int abi_encoder_encode(void* enc, x265amd_nal** ppNal, uint32_t* piNal, void* pi
     }
     return ret;
 }
-void abi_encoder_get_stats(void*, void* stats, uint32_t bytes) { if (stats) memset(stats, 0, bytes < (uint32_t)X265ABI_SIZEOF_STATS ? bytes : (uint32_t)X265ABI_SIZEOF_STATS); }
+/* x265_encoder_get_stats (Encoder::fetchStats, encoder.cpp:2870-2960): what this encoder counts -- pictures, bits and average QP by slice type, the times and the bit rate.
+ * PSNR / SSIM (off unless asked for, and then not built), the light levels and the weighted-frame count stay 0. */
+void abi_encoder_get_stats(void* enc, void* stats, uint32_t bytes)
+{
+    if (!stats) return;
+    uint8_t st[X265ABI_SIZEOF_STATS];
+    memset(st, 0, sizeof(st));
+    if (enc)
+    {
+        AbiEncoder& a = *(AbiEncoder*)enc;
+        uint64_t w[13] = { 0 };
+        if (x265amd_encoder_stats(a.enc, w, 13) == 0)
+        {
+            uint64_t pics = 0, bits = 0;
+            static const size_t at[3] = { X265ABI_STATS_statsI, X265ABI_STATS_statsP, X265ABI_STATS_statsB };
+            for (int t = 0; t < 3; t++)
+            {
+                double qsum; memcpy(&qsum, &w[10 + t], 8);
+                const uint64_t n = w[4 + t];
+                pics += n; bits += w[7 + t];
+                wr<uint32_t>(st, at[t] + X265ABI_SLICESTATS_numPics, (uint32_t)n);
+                if (n)
+                {
+                    wr<double>(st, at[t] + X265ABI_SLICESTATS_avgQp, qsum / (double)n);
+                    /* EncStats: bitrate of the type's pictures at the frame rate, in kbps (encoder.cpp:2885: m_accBits * scale / m_numPics, scale = fps / 1000) */
+                    wr<double>(st, at[t] + X265ABI_SLICESTATS_bitrate, (double)w[7 + t] * a.fps / 1000.0 / (double)n);
+                }
+            }
+            struct timespec now; clock_gettime(CLOCK_MONOTONIC, &now);
+            const double elapsed = (double)(now.tv_sec - a.opened.tv_sec) + 1e-9 * (double)(now.tv_nsec - a.opened.tv_nsec);
+            const double video = (double)pics / a.fps;
+            wr<double>(st, X265ABI_STATS_elapsedEncodeTime, elapsed); wr<double>(st, X265ABI_STATS_elapsedVideoTime, video);
+            wr<double>(st, X265ABI_STATS_bitrate, video > 0 ? 0.001 * (double)bits / video : 0.0);
+            wr<uint64_t>(st, X265ABI_STATS_accBits, bits); wr<uint32_t>(st, X265ABI_STATS_encodedPictureCount, (uint32_t)pics);
+        }
+    }
+    memcpy(stats, st, bytes < (uint32_t)X265ABI_SIZEOF_STATS ? bytes : (uint32_t)X265ABI_SIZEOF_STATS);
+}
 void abi_encoder_log(void*, int, char**) {}
 void abi_encoder_close(void* enc)
 {
@@ -401,25 +447,61 @@ int abi_fail_encoder(void*) { return -1; }
 int abi_fail_ctu_info(void*, int, void**) { return -1; }
 int abi_fail_slicetype(void*, int*, int*, int*) { return -1; }
 int abi_fail_ref_list(void*, void**, void**, int, int, int*, int*) { return -1; }
-void* abi_csvlog_open(const void*) { return nullptr; }
+/* x265_csvlog_open / x265_csvlog_encode (api.cpp:1281-1403, :1511-1636) at the default log level (csvLogLevel 0: one summary line per encode; the per-frame levels 1 and 2
+ * are not built: NULL): a new file gets the header line, an existing one is appended to */
+static const char* const kSummaryHeader =
+    "Command, Date/Time, Elapsed Time, FPS, Bitrate, "
+    "Y PSNR, U PSNR, V PSNR, Global PSNR, SSIM, SSIM (dB), "
+    "I count, I ave-QP, I kbps, I-PSNR Y, I-PSNR U, I-PSNR V, I-SSIM (dB), "
+    "P count, P ave-QP, P kbps, P-PSNR Y, P-PSNR U, P-PSNR V, P-SSIM (dB), "
+    "B count, B ave-QP, B kbps, B-PSNR Y, B-PSNR U, B-PSNR V, B-SSIM (dB), ";
+void* abi_csvlog_open(const void* p)
+{
+    if (!p) return nullptr;
+    const char* fn = rd<const char*>(p, X265ABI_PARAM_csvfn);
+    if (!fn || PI(p, csvLogLevel) != 0) { xa_fail(X265AMD_EINVAL, "x265_csvlog_open: no file name, or a per-frame log level (only the summary level 0 is built)"); return nullptr; }
+    if (FILE* f = fopen(fn, "r")) { fclose(f); return fopen(fn, "ab"); }
+    FILE* f = fopen(fn, "wb");
+    if (!f) return nullptr;
+    fputs(kSummaryHeader, f);
+    if (rd<uint16_t>(p, X265ABI_PARAM_maxCLL) || rd<uint16_t>(p, X265ABI_PARAM_maxFALL)) fputs("MaxCLL, MaxFALL,", f);
+    fputs(" Version\n", f);
+    return f;
+}
 void abi_csvlog_frame(const void*, const void*) {}
-void abi_csvlog_encode(const void*, const void*, int, int, int, char**) {}
+void abi_csvlog_encode(const void* p, const void* stats, int, int, int argc, char** argv)
+{
+    FILE* f = p ? rd<FILE*>(p, X265ABI_PARAM_csvfpt) : nullptr;
+    if (!f || !stats || PI(p, csvLogLevel) != 0) return;
+    fputc('"', f);
+    for (int i = 1; i < argc; i++) { fputc(' ', f); fputs(argv[i], f); }         /* (without a command line the reference prints the option string; that string is not built) */
+    fputc('"', f);
+    time_t now; time(&now);
+    char buffer[200];
+    strftime(buffer, 128, "%c", localtime(&now));
+    fprintf(f, ", %s, ", buffer);
+    const double elapsed = rd<double>(stats, X265ABI_STATS_elapsedEncodeTime);
+    const uint32_t pics = rd<uint32_t>(stats, X265ABI_STATS_encodedPictureCount);
+    fprintf(f, "%.2f, %.2f, %.2f,", elapsed, elapsed > 0 ? pics / elapsed : 0.0, rd<double>(stats, X265ABI_STATS_bitrate));
+    fprintf(f, " -, -, -, -,");          /* PSNR: not measured */
+    fprintf(f, " -, -,");                /* SSIM */
+    static const size_t at[3] = { X265ABI_STATS_statsI, X265ABI_STATS_statsP, X265ABI_STATS_statsB };
+    for (int t = 0; t < 3; t++)
+    {
+        const uint32_t n = rd<uint32_t>(stats, at[t] + X265ABI_SLICESTATS_numPics);
+        if (n) fprintf(f, " %-6u, %2.2lf, %-8.2lf, -, -, -, -,", n, rd<double>(stats, at[t] + X265ABI_SLICESTATS_avgQp), rd<double>(stats, at[t] + X265ABI_SLICESTATS_bitrate));
+        else fprintf(f, " -, -, -, -, -, -, -,");
+    }
+    if (rd<uint16_t>(p, X265ABI_PARAM_maxCLL) || rd<uint16_t>(p, X265ABI_PARAM_maxFALL)) fprintf(f, " %-6u, %-6u,", 0u, 0u);
+    fprintf(f, " %s\n", g_versionStr);
+}
 void abi_dither_image(void*, int, int, int16_t*, int) {}
 int abi_fail_analysis(void*, void*, int, uint32_t) { return -1; }
 int abi_fail_parse3(void*, const char*, const char*) { return -1; }
 
 /* struct x265_api (x265.h:2561-2614) member for member: 3 + 4 ints, bit depth, two strings, 20 function pointers, sizeof_frame_stats, 9 function pointers,
  * zone_param_parse (ENABLE_LIBVMAF is off in the reference build this library replaces) */
-struct AbiTable
-{
-    int api_major_version, api_build_number, sizeof_param, sizeof_picture, sizeof_analysis_data, sizeof_zone, sizeof_stats;
-    int bit_depth;
-    const char* version_str; const char* build_info_str;
-    void* fn[20];
-    int sizeof_frame_stats;
-    void* fn2[9];
-    void* zone_param_parse;
-};
+typedef X265ApiTable AbiTable;          /* x265_api_table.h */
 static_assert(sizeof(AbiTable) == X265ABI_SIZEOF_API, "struct x265_api layout");
 static_assert(offsetof(AbiTable, bit_depth) == X265ABI_API_bit_depth && offsetof(AbiTable, version_str) == X265ABI_API_version_str, "struct x265_api layout");
 static_assert(offsetof(AbiTable, fn) == X265ABI_API_param_alloc && offsetof(AbiTable, fn) + 10 * sizeof(void*) == X265ABI_API_encoder_open, "struct x265_api layout");
@@ -430,7 +512,7 @@ static_assert(offsetof(AbiTable, fn2) == X265ABI_API_encoder_intra_refresh && of
 const AbiTable g_api = {
     X265ABI_MAJOR_VERSION, X265ABI_BUILD, X265ABI_SIZEOF_PARAM, X265ABI_SIZEOF_PICTURE, X265ABI_SIZEOF_ANALYSIS_DATA, X265ABI_SIZEOF_ZONE, X265ABI_SIZEOF_STATS,
     X265AMD_DEPTH,
-    "x265amd 0.3 (parity target x265 3.6+1-aa7f602f7)", "[Linux][hipcc gfx950][64 bit] MI355X",
+    g_versionStr, "[Linux][hipcc gfx950][64 bit] MI355X",
     { (void*)abi_param_alloc, (void*)abi_param_free, (void*)abi_param_default, (void*)abi_param_parse, (void*)abi_fail_parse3, (void*)abi_param_apply_profile,
       (void*)abi_param_default_preset, (void*)abi_picture_alloc, (void*)abi_picture_free, (void*)abi_picture_init, (void*)abi_encoder_open, (void*)abi_encoder_parameters,
       (void*)abi_fail_encoder_param, (void*)abi_fail_encoder_param, (void*)abi_encoder_headers, (void*)abi_encoder_encode, (void*)abi_encoder_get_stats, (void*)abi_encoder_log,
