@@ -3316,6 +3316,31 @@ def encoder_ft_frames(tag):
 
 
 # ---- BASELINE.json's configurations at their stated size (SURVEY.md section 8d's synthetic clip) ----
+_LCG_FIELDS = {}
+
+
+def lcg_noise_field(seed, rows, cols):
+    """SURVEY.md section 8d's noise: a 32-bit linear congruential generator x' = 1664525 x + 1013904223 (mod 2^32) started at `seed`, one step per sample in raster order, the
+    sample = its state's top 24 bits scaled to -12 .. 12.  Integer arithmetic only -- no library's random stream is involved, every machine gets these bytes.  Computed without
+    a loop over the samples by doubling: when the states of samples 0 .. L-1 are known as A[n] seed + C[n], those of L .. 2L-1 follow from the jump by L (aL, cL)."""
+    key = (seed & 0xFFFFFFFF, rows, cols)
+    if key in _LCG_FIELDS:
+        return _LCG_FIELDS[key]
+    n = rows * cols
+    M = np.uint64(0xFFFFFFFF)
+    A = np.ones(1, np.uint64); Cc = np.zeros(1, np.uint64)
+    aL, cL = np.uint64(1664525), np.uint64(1013904223)
+    while len(A) < n:
+        A = np.concatenate([A, (A * aL) & M]); Cc = np.concatenate([Cc, (Cc * aL + cL) & M])
+        aL, cL = (aL * aL) & M, (aL * cL + cL) & M
+    x = (A[:n] * np.uint64(seed & 0xFFFFFFFF) + Cc[:n]) & M
+    field = (((x >> np.uint64(8)) * np.uint64(25)) >> np.uint64(24)).astype(np.int64).reshape(rows, cols) - 12
+    if len(_LCG_FIELDS) >= 2:
+        _LCG_FIELDS.pop(next(iter(_LCG_FIELDS)))
+    _LCG_FIELDS[key] = field
+    return field
+
+
 def survey_clip(w, h, depth, cfg_id, first, count, gop=0):
     """frames first .. first + count - 1 (display order) of the synthetic clip SURVEY.md section 8d prescribes: luma = a smooth 2-D integer gradient shifted by
     (2t, t) samples plus a noise field in [-12, 12] (times 4 for 10-bit samples) that moves with it (motion estimation has real work, every block carries a
@@ -3331,7 +3356,7 @@ def survey_clip(w, h, depth, cfg_id, first, count, gop=0):
     frames = []
     for t in range(first, first + count):
         epoch = t // 24
-        noise = np.random.default_rng(0x9E3779B9 ^ (cfg_id << 8) ^ (epoch << 20) ^ (gop << 12)).integers(-12, 13, (h + 64, w + 128))     # indexed by the moving coordinates
+        noise = lcg_noise_field(0x9E3779B9 ^ (cfg_id << 8) ^ (epoch << 20) ^ (gop << 12), h + 64, w + 128)     # indexed by the moving coordinates
         tt = t % 24
         v = np.arange(h, dtype=np.int64)[:, None] + tt + 24 * epoch
         u = np.arange(w, dtype=np.int64)[None, :] + 2 * tt + 48 * epoch

@@ -42,12 +42,18 @@ def test_survey_clip_is_the_bench_clip():
         for pa, pb in zip(fa, fb):
             assert pa.dtype == np.uint8 and pb.dtype == np.uint16 and np.array_equal(pa.astype(np.uint16) * 4, pb)
     assert not np.array_equal(a[0][0], a[1][0])         # frame 24 is a new scene
-    # The noise field comes from numpy's PCG64 Generator.integers, not from the LCG SURVEY.md section 8d sketches: every fixture and every bench digest of rounds 2-5 is cut
-    # from THESE samples (changing the generator would only re-cut them).  What the survey wants from the LCG -- the same bytes on every machine -- is pinned here instead:
-    # a numpy whose Generator produced other samples fails this test before any stream comparison can mislead.
+    # The noise field is SURVEY.md section 8d's 32-bit LCG (hevc_testlib.lcg_noise_field: integer arithmetic alone, no library's random stream) since round 6; rounds 2-5 drew it
+    # from numpy's PCG64 and pinned the bytes here.  The digests stay: they say at once when somebody changes the generator without re-cutting the fixtures.
     import hashlib
-    assert hashlib.md5(b"".join(p.tobytes() for f in a for p in f)).hexdigest() == "5de17a18fe9e34f38aa983e1b1c57d64"
-    assert hashlib.md5(b"".join(p.tobytes() for p in T.survey_clip(1920, 1080, 8, 2, 0, 1)[0])).hexdigest() == "6609dbfed6d98a57eb053c4dfa39e237"
+    assert hashlib.md5(b"".join(p.tobytes() for f in a for p in f)).hexdigest() == "770c659ce3b028ad7186a5df3553239f"
+    assert hashlib.md5(b"".join(p.tobytes() for p in T.survey_clip(1920, 1080, 8, 2, 0, 1)[0])).hexdigest() == "191db4663f5547c0fdae4dbc00192103"
+    # ... and the generator against its definition, sample by sample
+    x, want = 0x1234ABCD, []
+    for _ in range(5000):
+        want.append((((x >> 8) * 25) >> 24) - 12)
+        x = (1664525 * x + 1013904223) & 0xFFFFFFFF
+    got = T.lcg_noise_field(0x1234ABCD, 50, 100).ravel().tolist()
+    assert got == want and min(got) == -12 and max(got) == 12
 
 
 @pytest.mark.gpu
