@@ -211,17 +211,17 @@ def job_server_roofline(st, frames_payload_bytes, wall_s):
             "note": "k_job_server is resident for the whole encode; the encoder is bound by the latency of the reference's serial decision chain (busy_frac: the share of the "
                     "workgroups' resident time inside command bodies), not by bandwidth.  traffic: the PMC counter passes serialise dispatches, which a resident kernel does not "
                     "survive, so the launch itself cannot be counted; per_command_kind_traffic holds what the counters saw of its command kinds when five pictures of this clip "
-                    "were coded with every command as an ordinary launch of the same device code (profiles/collect_traffic.sh 5, profiles/r05_p_pictures_traffic.json)"}
+                    "were coded with every command as an ordinary launch of the same device code (profiles/collect_traffic.sh 5, profiles/r06_p_pictures_traffic.json)"}
 
 
 def command_traffic():
-    """profiles/r05_p_pictures_traffic.json (I P B B B of this clip; round 4: the I picture alone) reduced to {command kind: launches, HBM-side bytes by the counters (low: FETCH_SIZE +
+    """profiles/r06_p_pictures_traffic.json (I P B B B of this clip; round 4: the I picture alone) reduced to {command kind: launches, HBM-side bytes by the counters (low: FETCH_SIZE +
     WRITE_SIZE as reported; high: FETCH_SIZE doubled, the guide's gfx950 correction for wide requests), algorithmic bytes, ratio of the totals, and -- because with the job
     server off the P / B pictures issue other NUMBERS of units per kind -- a launch's traffic against a command's own algorithmic bytes}: measured once on a GPU box with every
     command an ordinary launch of the same device code (profiles/collect_traffic.sh 5), not during this run.  The skip chain and the fused search exist as job-server commands
     only and cannot be launched for the counters."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r05_p_pictures_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r06_p_pictures_traffic.json")))
     except (OSError, ValueError):
         return None
     out = {}
