@@ -31,6 +31,52 @@ MAX_WIN = (192, 192)
 HBM_PEAK_GBS = 8000.0                # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+
+class _PlaneExchange:
+    """Whole-picture exchange between GPUs for THIS kernel workload only (--gpus N): picture k in encode order belongs to rank k % world, and after a step every rank holds
+    the padded plane set of every rank's picture (one all_gather per step over torch.distributed).  The encoder does not work this way: its ranks publish finished CTU ROWS
+    (x265-amod_amd/frame_rows.py, SURVEY.md section 8e as written)."""
+
+    @staticmethod
+    def frames_of_step(step, world):
+        return [step * world + r for r in range(world)]
+
+    class ReferenceRing:
+        def __init__(self, depth):
+            self.depth = depth
+            self.pics = {}
+
+        def put(self, idx, plane):
+            self.pics[idx] = plane
+            for k in sorted(self.pics):
+                if len(self.pics) <= self.depth:
+                    break
+                del self.pics[k]
+
+        def get(self, idx):
+            return self.pics[idx]
+
+        def has(self, idx):
+            return idx in self.pics
+
+    @staticmethod
+    def publish_step(local_plane, step, ring, gather_buf=None):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        if world == 1:
+            ring.put(step, local_plane)
+            return None
+        if gather_buf is None:
+            gather_buf = torch.empty(world * local_plane.numel(), dtype=local_plane.dtype, device=local_plane.device)
+        dist.all_gather_into_tensor(gather_buf, local_plane.reshape(-1))
+        n = local_plane.numel()
+        for r, idx in enumerate(_PlaneExchange.frames_of_step(step, world)):
+            ring.put(idx, gather_buf[r * n:(r + 1) * n].clone() if r != rank else local_plane)
+        return gather_buf
+
+
 def lcg_noise(shape, seed):
     """integer-only noise in [-12, 12] (SURVEY.md section 8d generator)"""
     n = shape[0] * shape[1]
@@ -572,8 +618,7 @@ def run(args, with_encoder_samples=False):
 
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
-    import __graft_entry__ as entry
-    fs = entry.load_package().frame_shard
+    fs = _PlaneExchange
     ring, gather = fs.ReferenceRing(depth=NUM_REFS * max(world, 1) + world), [None]
     NK = 10
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(NK + 1)] for _ in range(args.steps)]

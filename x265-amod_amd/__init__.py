@@ -5,6 +5,5 @@ thin loader used by tests, bench.py and __graft_entry__.py.  It never falls back
 fails loudly if the HIP library has not been built.
 """
 from .capi import load, lib_path, X265AmdError  # noqa: F401
-from . import frame_shard  # noqa: F401
 from . import gop_shard  # noqa: F401
 from . import frame_rows  # noqa: F401
