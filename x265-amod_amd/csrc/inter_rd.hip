@@ -93,6 +93,19 @@ struct Walker
     /* RDOQ: the transform units are not quantised ahead of the walk; `demand(first job, count, luma?, size, tuDepth)` runs them when the walk reaches them,
      * under the entropy state it has then (it fills res / levels for those jobs) */
     std::function<int(int, int, bool, int, int, const uint8_t*)> demand;
+    /* ... and a node's three units at once: demandNode(luma job, U job, V job, luma size, chroma size, tuDepth, contexts) -- the three run side by side on the device and the
+     * walk waits once.  Sound because the chroma units' RDOQ tables are made from CHROMA contexts only (Entropy::estBit with bIsLuma false: coded block flags, significance,
+     * greater-than, last position of the chroma sets), and nothing between the node's start and the point where the reference makes them (search.cpp:3397, behind the luma
+     * unit's coefficients) moves one of those: the luma unit codes luma contexts.  The walk still compares the contexts when it gets there (chromaEstSame) and asks again
+     * if they ever differ. */
+    std::function<int(int, int, int, int, int, int, const uint8_t*)> demandNode;
+    /* the contexts Entropy::estBit reads for a chroma unit (entropy.cpp:2236-2350 with bIsLuma false; device form: wave_est_bit) */
+    static bool chromaEstSame(const uint8_t* a, const uint8_t* b)
+    {
+        return !memcmp(a + C_QT_CBF, b + C_QT_CBF, 7) && a[C_QT_ROOT_CBF] == b[C_QT_ROOT_CBF] && !memcmp(a + C_SIG_CG + 2, b + C_SIG_CG + 2, 2) &&
+               !memcmp(a + C_SIG + 27, b + C_SIG + 27, 15) && !memcmp(a + C_ONE + 16, b + C_ONE + 16, 8) && !memcmp(a + C_ABS + 4, b + C_ABS + 4, 2) &&
+               !memcmp(a + C_LAST_X + 15, b + C_LAST_X + 15, 3) && !memcmp(a + C_LAST_X + 18 + 15, b + C_LAST_X + 18 + 15, 3);
+    }
     int err = 0;
 
     Walker(x265amd_cabac& coder, const CuPlan& plan, const x265amd_tu_result* r, const int16_t* lv) : c(coder), P(plan), res(r), levels(lv) {}
@@ -165,10 +178,21 @@ struct Walker
 
         store(rqtRoot[depth]);
 
+        uint8_t nodeStartCtx[X265AMD_CTX_STRIDE];
+        bool chromaAhead = false;
         if (bCheckFull)
         {
             setTuDepth(x, y, trSize, tuDepth);
-            if (demand && !err) err = demand(nodeJob(0, log2TrSize, x, y), 1, true, log2TrSize, tuDepth, c.ctx);
+            if (demand && !err)
+            {
+                if (codeChroma && demandNode)
+                {
+                    memcpy(nodeStartCtx, c.ctx, X265AMD_CTX_COUNT);
+                    err = demandNode(nodeJob(0, log2TrSize, x, y), nodeJob(1, log2TrSizeC, x, y), nodeJob(2, log2TrSizeC, x, y), log2TrSize, log2TrSizeC, tuDepth, c.ctx);
+                    chromaAhead = !err;
+                }
+                else err = demand(nodeJob(0, log2TrSize, x, y), 1, true, log2TrSize, tuDepth, c.ctx);
+            }
             {
                 const x265amd_tu_result& r = nodeResult(0, log2TrSize, x, y);
                 cbfFlag[0] = r.num_sig != 0;
@@ -202,8 +226,11 @@ struct Walker
                     if (p == 1 && demand && !err)
                     {
                         memcpy(fullChromaCtx, c.ctx, X265AMD_CTX_COUNT);
-                        err = demand(nodeJob(1, log2TrSizeC, x, y), 1, false, log2TrSizeC, tuDepth, c.ctx);
-                        if (!err) err = demand(nodeJob(2, log2TrSizeC, x, y), 1, false, -log2TrSizeC, tuDepth, c.ctx);      /* negative size: keep the table */
+                        if (!(chromaAhead && chromaEstSame(nodeStartCtx, c.ctx)))
+                        {
+                            err = demand(nodeJob(1, log2TrSizeC, x, y), 1, false, log2TrSizeC, tuDepth, c.ctx);
+                            if (!err) err = demand(nodeJob(2, log2TrSizeC, x, y), 1, false, -log2TrSizeC, tuDepth, c.ctx);      /* negative size: keep the table */
+                        }
                     }
                     const x265amd_tu_result& r = nodeResult(p, log2TrSizeC, x, y);
                     cbfFlag[p] = r.num_sig != 0;
@@ -512,7 +539,11 @@ static int inter_rd_plan_levels(const x265amd_slice_info* si, const x265amd_rd_c
 }
 
 /* runs jobs [first, first + count) of CU i now (RDOQ): ctx = the walk's entropy state */
-typedef std::function<int(int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth)> RdoqDemand;
+struct RdoqDemand
+{
+    std::function<int(int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth)> unit;
+    std::function<int(int i, const uint8_t* ctx, int jobY, int jobU, int jobV, int log2TrSize, int log2TrSizeC, int tuDepth)> node;      /* may be empty */
+};
 static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_params* rp, x265amd_cu_unit* units, const x265amd_rd_cu* cus, int n,
                               x265amd_cu_unit* cu_units, const x265amd_tu_result* res, const int16_t* levels, size_t levels_stride_bytes,
                               const x265amd_cu_measure* zero_meas, uint8_t* sel, x265amd_rd_result* out, int16_t* coeff_out, const RdoqDemand* demand);
@@ -570,7 +601,11 @@ static int inter_rd_walk_impl(const x265amd_slice_info* si, const x265amd_rd_par
         w.load(cur);
         Cost costs = { 0, 0, 0, 0 };
         if (demand)
-            w.demand = [&, i](int first, int count, bool luma, int log2TrSize, int tuDepth, const uint8_t* ctx) { return (*demand)(i, ctx, first, count, luma, log2TrSize, tuDepth); };
+        {
+            w.demand = [&, i](int first, int count, bool luma, int log2TrSize, int tuDepth, const uint8_t* ctx) { return demand->unit(i, ctx, first, count, luma, log2TrSize, tuDepth); };
+            if (demand->node)
+                w.demandNode = [&, i](int jy, int ju, int jv, int l2, int l2c, int tuDepth, const uint8_t* ctx) { return demand->node(i, ctx, jy, ju, jv, l2, l2c, tuDepth); };
+        }
         w.estimateResidualQT(P.x, P.y, 0, costs);
         if (w.err) { x265amd_cabac_close(coder); return w.err; }
 
@@ -901,8 +936,9 @@ static int inter_residual_rd_impl(void* stream_, const x265amd_slice_info* si, c
 
     /* ---- the walk ---- */
     std::vector<uint8_t> sel((size_t)RD_SEL_BYTES * n);
-    XaMapped mCtx, mEstJob, mRdoq;
-    DevBuf dEst;
+    XaMapped mCtx, mEstJob, mRdoq, mNodeCtx, mNodeEst, mNodeRq, mNodeJobs;
+    XaMappedOut mNodeRes;
+    DevBuf dEst, dEst2;
     RdoqDemand demandFn;
     if (rdoq)
     {
@@ -911,7 +947,7 @@ static int inter_residual_rd_impl(void* stream_, const x265amd_slice_info* si, c
         XA_HIP_CHECK(mCtx.alloc(X265AMD_CTX_STRIDE)); XA_HIP_CHECK(mEstJob.alloc(sizeof(x265amd_est_job))); XA_HIP_CHECK(mRdoq.alloc(sizeof(x265amd_tu_rdoq)));
         XA_HIP_CHECK(dEst.alloc(sizeof(x265amd_est_bits)));
         XA_HIP_CHECK(xa_fill_async(stream_, dEst.p, 0, sizeof(x265amd_est_bits)));
-        demandFn = [&](int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth) -> int {
+        demandFn.unit = [&](int i, const uint8_t* ctx, int first, int count, bool luma, int log2TrSize, int tuDepth) -> int {
             const x265amd_tu_job* jobs = (const x265amd_tu_job*)mJobs.p;
             for (int k = first; k < first + count; k++)
             {
@@ -939,6 +975,53 @@ static int inter_residual_rd_impl(void* stream_, const x265amd_slice_info* si, c
             }
             return X265AMD_OK;
         };
+        /* a node's three units as two commands and one wait: both tables (luma, chroma) by two wavefronts of one est_bit command, the three chains by three wavefronts of
+         * one tu_chain_rdoq command -- the job records are copied side by side for that (they lie apart in the plan), the results go back to their places */
+        static const bool together = !(getenv("X265AMD_RDOQ_TOGETHER") && atoi(getenv("X265AMD_RDOQ_TOGETHER")) == 0);
+        if (together)
+        {
+            XA_HIP_CHECK(mNodeCtx.alloc(X265AMD_CTX_STRIDE)); XA_HIP_CHECK(mNodeEst.alloc(2 * sizeof(x265amd_est_job))); XA_HIP_CHECK(mNodeRq.alloc(3 * sizeof(x265amd_tu_rdoq)));
+            XA_HIP_CHECK(mNodeJobs.alloc(3 * sizeof(x265amd_tu_job))); XA_HIP_CHECK(mNodeRes.alloc(3 * sizeof(x265amd_tu_result)));
+            XA_HIP_CHECK(dEst2.alloc(2 * sizeof(x265amd_est_bits)));
+            XA_HIP_CHECK(xa_fill_async(stream_, dEst2.p, 0, 2 * sizeof(x265amd_est_bits)));
+            demandFn.node = [&](int i, const uint8_t* ctx, int jy, int ju, int jv, int log2TrSize, int log2TrSizeC, int tuDepth) -> int {
+                const x265amd_tu_job* jobs = (const x265amd_tu_job*)mJobs.p;
+                const int idx[3] = { jy, ju, jv };
+                memcpy(mNodeCtx.p, ctx, X265AMD_CTX_COUNT);
+                x265amd_est_job* ej = (x265amd_est_job*)mNodeEst.p;
+                memset(ej, 0, 2 * sizeof(*ej));
+                char* tables = (char*)dEst2.p;
+                for (int t = 0; t < 2; t++)
+                {
+                    ej[t].ctx = (uint64_t)(uintptr_t)mNodeCtx.p; ej[t].est = (uint64_t)(uintptr_t)(tables + (size_t)t * sizeof(x265amd_est_bits));
+                    ej[t].log2_tr_size = (uint8_t)(t ? log2TrSizeC : log2TrSize); ej[t].is_luma = t ? 0 : 1;
+                }
+                int r = x265amd_est_bit(stream_, ej, 2);
+                if (r != X265AMD_OK) return r;
+                x265amd_tu_job* nj = (x265amd_tu_job*)mNodeJobs.p;
+                x265amd_tu_rdoq* rq = (x265amd_tu_rdoq*)mNodeRq.p;
+                memset(rq, 0, 3 * sizeof(*rq));
+                for (int k = 0; k < 3; k++)
+                {
+                    nj[k] = jobs[idx[k]];
+                    rq[k].est_bits = (uint64_t)(uintptr_t)(tables + (size_t)(k ? 1 : 0) * sizeof(x265amd_est_bits));
+                    x265amd_rdoq_lambda(nj[k].qp_scaled, &rq[k].lambda2, &rq[k].lambda);
+                    rq[k].psy_rdoq_scale = rp->psy_rdoq_scale; rq[k].rdoq_level = (uint8_t)rp->rdoq_level; rq[k].tu_depth = (uint8_t)tuDepth;
+                }
+                r = x265amd_tu_chain_rdoq(stream_, nj, rq, 3, (x265amd_tu_result*)mNodeRes.p);
+                if (r != X265AMD_OK) return r;
+                for (int k = 0; k < 3; k++)
+                {
+                    const size_t nCoeff = (size_t)1 << (2 * nj[k].log2_tr_size);
+                    const size_t off = (size_t)(nj[k].coeff - (uint64_t)(uintptr_t)scratch);
+                    char* dst = (char*)mLevels.p + (size_t)RD_SCRATCH_ELEMS * 2 * i + (off - perCuBytes * i);
+                    if (xa_copy_async(stream_, dst, (const void*)(uintptr_t)nj[k].coeff, nCoeff * 2, hipMemcpyDeviceToHost) != hipSuccess) return xa_fail(X265AMD_EHIP, "inter_residual_rd: RDOQ node");
+                }
+                if (xa_stream_sync(stream_) != hipSuccess) return xa_fail(X265AMD_EHIP, "inter_residual_rd: RDOQ node");
+                for (int k = 0; k < 3; k++) ((x265amd_tu_result*)mRes.p)[idx[k]] = ((const x265amd_tu_result*)mNodeRes.p)[k];
+                return X265AMD_OK;
+            };
+        }
     }
     rc = inter_rd_walk_impl(si, rp, units, cus, n, cu_units, (const x265amd_tu_result*)mRes.p, (const int16_t*)mLevels.p, (size_t)RD_SCRATCH_ELEMS * 2, meas, sel.data(), out,
                             coeff_out, rdoq ? &demandFn : nullptr);
