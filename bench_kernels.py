@@ -81,7 +81,7 @@ def lcg_noise(shape, seed):
     """integer-only noise in [-12, 12] (SURVEY.md section 8d generator)"""
     n = shape[0] * shape[1]
     idx = np.arange(n, dtype=np.uint64)
-    v = (idx * np.uint64(6364136223846793005) + np.uint64(seed) * np.uint64(1442695040888963407)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    v = idx * np.uint64(6364136223846793005) + np.uint64((int(seed) * 1442695040888963407) & 0xFFFFFFFFFFFFFFFF)         # (array arithmetic wraps modulo 2^64; the scalar product is reduced here)
     v ^= v >> np.uint64(33)
     v = (v * np.uint64(0xFF51AFD7ED558CCD)) & np.uint64(0xFFFFFFFFFFFFFFFF)
     v ^= v >> np.uint64(29)
