@@ -183,7 +183,8 @@ def test_command_line_program_reproduces_reference_stream(tag, tmp_path):
     (w, h), n, depth, cfg_id, _, cli = (T.PRESET_CASES[tag] if tag in T.PRESET_CASES else T.RC_CASES[tag])
     frames = T.full_case_frames(tag)
     _write_y4m(tmp_path / "clip.y4m", frames, w, h, depth)
-    r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc"), "--recon", str(tmp_path / "rec.y4m"), "--csv", str(tmp_path / "log.csv")] + cli + T.PRESET_CLI,
+    # (switches in front of short options: `--no-info -o out.hevc -r rec.y4m` -- an option's value is never another option)
+    r = subprocess.run([CLI] + cli + T.PRESET_CLI + ["-o", str(tmp_path / "out.hevc"), "-r", str(tmp_path / "rec.y4m"), "--csv", str(tmp_path / "log.csv"), "--input", str(tmp_path / "clip.y4m")],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.fromfile(tmp_path / "out.hevc", np.uint8)

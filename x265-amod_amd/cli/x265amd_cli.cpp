@@ -17,6 +17,7 @@
  * x265_picture / x265_nal are touched through the member offsets generated from the reference's header (host/x265_abi_layout.h: numbers only).  Host C++ only. */
 #include "../host/x265_abi_layout.h"
 #include "../host/x265_api_table.h"
+#include <ctype.h>
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -120,6 +121,7 @@ int main(int argc, char** argv)
     const char* input = nullptr; const char* output = nullptr; const char* recon = nullptr; const char* preset = nullptr; const char* tune = nullptr; const char* csv = nullptr;
     int frames = 0;
     std::vector<std::pair<std::string, const char*>> opts;         /* every other option, with the argument behind it if there is one */
+    bool lastGeneric = false;
     for (int i = 1; i < argc; i++)
     {
         std::string a = argv[i];
@@ -134,9 +136,11 @@ int main(int argc, char** argv)
         else if (a == "--input-depth" || a == "--output-depth" || a == "-D") (void)val();         /* the depth is the input file's and the library's */
         else if (a == "--no-progress" || a == "--progress") { }
         else if (a == "-F") opts.push_back({ "--frame-threads", val() });
-        else if (a.rfind("--", 0) == 0) opts.push_back({ a, i + 1 < argc && strncmp(argv[i + 1], "--", 2) && strcmp(argv[i + 1], "-o") ? argv[i + 1] : nullptr });
-        else if (!opts.empty() && opts.back().second == argv[i]) { }                               /* the argument of the option before it */
+        else if (a.rfind("--", 0) == 0) { opts.push_back({ a, nullptr }); lastGeneric = true; continue; }
+        else if (lastGeneric && !opts.empty() && !opts.back().second && (a[0] != '-' || (a.size() > 1 && (isdigit((unsigned char)a[1]) || a[1] == '.'))))
+            opts.back().second = argv[i];                                                          /* the argument of the option before it (a number may be negative) */
         else { fprintf(stderr, "x265amd: unknown argument %s\n", a.c_str()); return 2; }
+        lastGeneric = false;
     }
     if (!input || !output) { fprintf(stderr, "usage: x265amd --input clip.y4m -o out.hevc [--preset name] [--tune name] [options]\n"); return 2; }
     Y4m y;
