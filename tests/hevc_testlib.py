@@ -3991,4 +3991,9 @@ RC_CASES = {
     "rc_crf46/": ((416, 240), 30, 8, 2, dict(PRESET_BASE, rfConstant=46.0), ["--preset", "medium", "--crf", "46"]),
     "rc_crf51_aq3/": ((448, 256), 26, 8, 2, dict(PRESET_BASE, rfConstant=51.0, aqMode=3, aqStrength=2.0), ["--preset", "medium", "--crf", "51", "--aq-mode", "3", "--aq-strength", "2.0"]),
     "rc_crf44_hbd_slow/": ((416, 240), 20, 10, 4, dict(PRESET_BASE, rfConstant=44.0, **SLOW_TOOLS), ["--preset", "slow", "--crf", "44"]),
+    # cuTree WITHOUT adaptive quantisation (Encoder::configure keeps aq-mode on at strength 0: zero offsets, delta QP from cuTree alone, encoder.cpp:3730-3734; slicetype.cpp:483-505):
+    # --tune psnr (aq-strength 0, no psy-rd), --aq-mode 0; and neither: plain constant rate factor, no delta QP at all
+    "rc_tune_psnr/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, aqStrength=0.0, psyRd=0.0), ["--preset", "medium", "--tune", "psnr"]),
+    "rc_aq0_cutree/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, aqMode=0), ["--preset", "medium", "--aq-mode", "0"]),
+    "rc_plain_crf/": ((448, 256), 26, 8, 2, dict(PRESET_BASE, aqMode=0, cuTree=0), ["--preset", "medium", "--aq-mode", "0", "--no-cutree"]),
 }

@@ -70,6 +70,14 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
 extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
 {
     if (!p) { xa_fail(X265AMD_EINVAL, "encoder_open: null param"); return nullptr; }
+    /* Encoder::configure's rules for the rate control's switches (encoder.cpp:3721-3754): constant QP switches adaptive quantisation and cuTree off; cuTree without AQ gets
+     * aq-mode 1 at strength 0 (cuTree needs the offset arrays; delta QP is on); strength 0 without cuTree is no AQ at all */
+    x265amd_param norm = *p;
+    if (norm.rateControlMode != X265AMD_RC_CRF) { norm.aqMode = 0; norm.cuTree = 0; }
+    if (norm.lookaheadDepth == 0) norm.cuTree = 0;
+    if (!norm.aqMode && norm.cuTree) { norm.aqMode = 1; norm.aqStrength = 0.0; }
+    if (norm.aqStrength == 0 && !norm.cuTree) norm.aqMode = 0;
+    p = &norm;
     if (p->sourceWidth < 16 || p->sourceHeight < 16 || (p->sourceWidth & 7) || (p->sourceHeight & 7) || p->sourceWidth > 8192 || p->sourceHeight > 4320)
     { xa_fail(X265AMD_EINVAL, "encoder_open: picture size must be a multiple of 8 (16..8192 x 16..4320)"); return nullptr; }
     {
@@ -85,7 +93,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->rateControlMode == X265AMD_RC_CRF || (p->qp >= 0 && p->qp <= 51), "qp outside 0..51");
         XA_REQUIRE(p->rateControlMode != X265AMD_RC_CRF || (p->rfConstant >= 0 && p->rfConstant <= 51), "rfConstant outside 0..51");
         XA_REQUIRE(p->aqMode >= 0 && p->aqMode <= 3, "aqMode outside 0..3 (the edge-based modes are not built)");
-        XA_REQUIRE(!p->aqMode || p->aqStrength > 0, "aqStrength must be positive with aqMode (0 switches adaptive quantisation off in the reference: say aqMode 0)");
+        XA_REQUIRE(!p->aqMode || p->aqStrength >= 0, "aqStrength negative");
         XA_REQUIRE(!p->aqMode || p->qgSize == 32 || p->qgSize == 64, "qgSize: 64 and 32 are built");
         XA_REQUIRE(!p->cuTree || p->aqMode, "cuTree needs adaptive quantisation (Encoder::configure switches it on with cuTree; say aqMode)");
         XA_REQUIRE(!p->cuTree || p->rateControlMode == X265AMD_RC_CRF, "cuTree needs rate control (the reference switches it off under constant QP, encoder.cpp:3721-3728)");

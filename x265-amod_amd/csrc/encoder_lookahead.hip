@@ -43,7 +43,9 @@ int x265amd_encoder::lowresInit(Pic& pic)
         /* the rest of calcAdaptiveQuantFrame (slicetype.cpp:513-640) on the block energies that have arrived with the intra costs */
         const int bw = (W + 15) / 16, bh = (H + 15) / 16, nb = bw * bh;
         pic.qpAqOffset.assign((size_t)nb, 0.0); pic.qpCuTreeOffset.assign((size_t)nb, 0.0); pic.invQscale.assign((size_t)nb, 256);
-        rc = x265amd_aq_offsets((const uint32_t*)aqEnergyHost, nb, lowCuW * lowCuH, p.aqMode, p.aqStrength, 1.0, 16, pic.qpAqOffset.data(), pic.qpCuTreeOffset.data(), pic.invQscale.data());
+        /* (strength 0 -- cuTree without adaptive quantisation, --tune psnr: the arrays stay zero / 256, slicetype.cpp:483-505; the energies were only needed for the picture's sums) */
+        if (p.aqStrength != 0)
+            rc = x265amd_aq_offsets((const uint32_t*)aqEnergyHost, nb, lowCuW * lowCuH, p.aqMode, p.aqStrength, 1.0, 16, pic.qpAqOffset.data(), pic.qpCuTreeOffset.data(), pic.invQscale.data());
         if (rc != X265AMD_OK) return xa_fail(rc, "encoder_encode: adaptive quantisation");
         pic.intraCostHost = ic;
         if (p.cuTree) pic.propagateCost.assign((size_t)lowCuW * lowCuH, 0);

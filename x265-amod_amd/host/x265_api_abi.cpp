@@ -299,12 +299,7 @@ void* abi_encoder_open(void* p)
     q.rateControlMode = PI(p, rc_rateControlMode); q.rfConstant = PD(p, rc_rfConstant); q.qCompress = PD(p, rc_qCompress); q.qgSize = PI(p, rc_qgSize);
     q.aqMode = PI(p, rc_aqMode); q.aqStrength = PD(p, rc_aqStrength); q.cuTree = PI(p, rc_cuTree) != 0;
     q.bEmitInfoSEI = PI(p, bEmitInfoSEI) != 0;
-    if (q.rateControlMode == X265AMD_RC_CQP) { q.aqMode = 0; q.cuTree = 0; }                /* Encoder::configure (encoder.cpp:3721-3728) */
-    else
-    {
-        if (q.aqMode && q.aqStrength == 0) q.aqMode = 0;          /* (no offsets: the reference keeps delta QP switched on with all-zero offsets; say aqStrength > 0) */
-        if (!q.aqMode && q.cuTree) { xa_fail(X265AMD_EINVAL, "x265_encoder_open: cuTree without adaptive quantisation (aq-strength 0) is not built"); return nullptr; }
-    }
+    /* (Encoder::configure's rules for these switches, encoder.cpp:3721-3754, are x265amd_encoder_open's) */
     q.rdLevel = PI(p, rdLevel); q.bEnableRectInter = PI(p, bEnableRectInter); q.bEnableAMP = PI(p, bEnableAMP); q.limitModes = PI(p, limitModes); q.limitReferences = PI(p, limitReferences);
     q.bEnableEarlySkip = PI(p, bEnableEarlySkip); q.recursionSkipMode = PI(p, recursionSkipMode); q.bIntraInBFrames = PI(p, bIntraInBFrames); q.psyRd = PD(p, psyRd);
     q.searchMethod = PI(p, searchMethod); q.subpelRefine = PI(p, subpelRefine); q.searchRange = PI(p, searchRange); q.maxNumMergeCand = PI(p, maxNumMergeCand);
