@@ -32,6 +32,7 @@ PIC(pts); PIC(dts); PIC(planes); PIC(stride); PIC(bitDepth); PIC(sliceType); PIC
 API(api_major_version); API(bit_depth); API(version_str); API(param_alloc); API(encoder_open); API(encoder_encode); API(encoder_close); API(cleanup); API(sizeof_frame_stats);
 API(encoder_intra_refresh); API(zone_param_parse);
 P(csvfn); P(csvfpt); P(csvLogLevel); P(maxCLL); P(maxFALL);
+PN(rc_bEnableGrain, rc.bEnableGrain); PN(rc_bEnableConstVbv, rc.bEnableConstVbv);
 #define ST(f) static_assert(offsetof(x265_stats, f) == X265ABI_STATS_##f, #f)
 ST(globalPsnrY); ST(globalSsim); ST(elapsedEncodeTime); ST(elapsedVideoTime); ST(bitrate); ST(accBits); ST(encodedPictureCount); ST(totalWPFrames); ST(statsI); ST(statsP); ST(statsB);
 ST(maxCLL); ST(maxFALL);

@@ -3996,4 +3996,10 @@ RC_CASES = {
     "rc_tune_psnr/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, aqStrength=0.0, psyRd=0.0), ["--preset", "medium", "--tune", "psnr"]),
     "rc_aq0_cutree/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, aqMode=0), ["--preset", "medium", "--aq-mode", "0"]),
     "rc_plain_crf/": ((448, 256), 26, 8, 2, dict(PRESET_BASE, aqMode=0, cuTree=0), ["--preset", "medium", "--aq-mode", "0", "--no-cutree"]),
+    # the other tunes whose members the encoder reads (param.cpp:586-649)
+    "rc_tune_ssim/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, psyRd=0.0), ["--preset", "medium", "--tune", "ssim"]),
+    "rc_tune_fastdecode/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, bEnableLoopFilter=0, bEnableSAO=0, bEnableWeightedPred=0, bIntraInBFrames=0), ["--preset", "medium", "--tune", "fastdecode"]),
+    "rc_ft1/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, frameNumThreads=1), ["--preset", "medium", "--frame-threads", "1"]),       # one frame thread WITH wavefronts: SAO's switch-off by the picture before (sao.cpp:264)
+    "rc_tune_zerolatency/": ((416, 240), 26, 8, 2, dict(PRESET_BASE, bFrameAdaptive=0, bframes=0, lookaheadDepth=0, scenecutThreshold=0, cuTree=0, frameNumThreads=1),
+                             ["--preset", "medium", "--tune", "zerolatency"]),
 }

@@ -85,7 +85,8 @@ _MEMBERS_I = ["bEnableWavefront", "frameNumThreads", "internalBitDepth", "intern
               "bEnableSignHiding", "bEnableTransformSkip", "bEnableStrongIntraSmoothing", "maxNumMergeCand", "limitReferences", "limitModes", "searchMethod", "subpelRefine", "searchRange",
               "bEnableTemporalMvp", "bEnableWeightedPred", "bEnableWeightedBiPred", "bEnableLoopFilter", "bEnableSAO", "rdLevel", "bEnableEarlySkip", "recursionSkipMode", "bEnableFastIntra",
               "bIntraInBFrames", "maxNumReferences", "bEmitInfoSEI", "bAnnexB", "maxSlices", "rc_rateControlMode", "rc_qp", "rc_aqMode", "rc_cuTree", "rc_qpMin", "rc_qpMax", "rc_qgSize", "rc_hevcAq",
-              "rc_qpStep", "rc_vbvBufferSize", "rc_vbvMaxBitrate", "rc_bitrate", "bLossless", "bRepeatHeaders", "levelIdc"]
+              "rc_qpStep", "rc_vbvBufferSize", "rc_vbvMaxBitrate", "rc_bitrate", "bLossless", "bRepeatHeaders", "levelIdc", "rc_bEnableGrain", "rc_bEnableConstVbv",
+              "deblockingFilterBetaOffset", "deblockingFilterTCOffset", "bHistBasedSceneCut"]
 _MEMBERS_D = ["psyRd", "psyRdoq", "rc_ipFactor", "rc_pbFactor", "rc_rfConstant", "rc_aqStrength", "rc_qCompress"]
 
 
@@ -111,17 +112,17 @@ def _reference_api():
 @pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")
 @pytest.mark.parametrize("preset", PRESETS + ["0", "9", "6"])
 def test_param_default_preset_matches_the_references(preset):
-    """our table's x265_param_default_preset against the reference library's own, for all ten presets (by name and by number) and the two tunes restated: every member that
+    """our table's x265_param_default_preset against the reference library's own, for all ten presets (by name and by number) and every tune: every member that
     x265_encoder_open reads or the option tables write holds the same bytes (doubles bit for bit: rc.ipFactor is the float literal 1.4f widened)"""
     R, f = _reference_api(), _fns(table(8))
-    for tune in (None, b"psnr", b"ssim"):
+    for tune in (None, b"psnr", b"ssim", b"fastdecode", b"zero-latency", b"grain", b"animation", b"vmaf"):
         a, b = R.x265_param_alloc(), f["alloc"]()
         assert R.x265_param_default_preset(a, preset.encode(), tune) == 0 and f["preset"](b, preset.encode(), tune) == 0
         ma, mb = _members(a), _members(b)
         assert ma == mb, {k: (ma[k], mb[k]) for k in ma if ma[k] != mb[k]}
         R.x265_param_free(a); f["free"](b)
     b = f["alloc"]()
-    assert f["preset"](b, b"nosuchpreset", None) == -1 and f["preset"](b, b"medium", b"grain") == -1
+    assert f["preset"](b, b"nosuchpreset", None) == -1 and f["preset"](b, b"medium", b"nosuchtune") == -1
     f["free"](b)
 
 

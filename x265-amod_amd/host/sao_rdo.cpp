@@ -333,8 +333,10 @@ static int sao_rdo_range(const x265amd_slice_info* si, int referenced, int frame
         R->store(R->cur);
     }
     if (carry) memcpy(carry, &R->cur, sizeof(Snap));
-    /* rdoSaoUnitRowEnd */
-    if (whole)
+    /* rdoSaoUnitRowEnd -- which the reference only reaches WITHOUT wavefronts: with them FrameFilter::processRow asks whether every row's reconstruction flag is set before it has
+     * set the last row's own (framefilter.cpp:622-647 against :650-664), so the rates stay at their initial zero and SAO is never switched off by the picture before
+     * (seen in the reference's own objects: all eight rates 0.000 after every picture of a --frame-threads 1 encode; the fixture rc_ft1/ pins it) */
+    if (whole && !si->wpp)
     {
         depth_sao_rate[refDepth] = sao_flags[0] ? numNoSao[0] / (double)numCtu : 1.0;
         depth_sao_rate[4 + refDepth] = sao_flags[1] ? numNoSao[1] / (double)numCtu : 1.0;

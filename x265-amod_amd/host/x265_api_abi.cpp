@@ -141,7 +141,23 @@ int abi_param_default_preset(void* p, const char* preset, const char* tune)
     {
         if (!strcmp(tune, "psnr")) { SD(rc_aqStrength, 0.0); SD(psyRd, 0.0); SD(psyRdoq, 0.0); }
         else if (!strcmp(tune, "ssim")) { SI(rc_aqMode, 2); SD(psyRd, 0.0); SD(psyRdoq, 0.0); }
-        else return -1;         /* grain / fastdecode / zerolatency / animation / vmaf reach members this library does not read */
+        else if (!strcmp(tune, "fastdecode") || !strcmp(tune, "fast-decode")) { SI(bEnableLoopFilter, 0); SI(bEnableSAO, 0); SI(bEnableWeightedPred, 0); SI(bEnableWeightedBiPred, 0); SI(bIntraInBFrames, 0); }
+        else if (!strcmp(tune, "zerolatency") || !strcmp(tune, "zero-latency"))
+        { SI(bFrameAdaptive, 0); SI(bframes, 0); SI(lookaheadDepth, 0); SI(scenecutThreshold, 0); SI(bHistBasedSceneCut, 0); SI(rc_cuTree, 0); SI(frameNumThreads, 1); }
+        else if (!strcmp(tune, "grain"))
+        {
+            /* (encoder_open refuses rc.bEnableGrain: its rate control is not built; the table still says what the reference's says) */
+            SD(rc_ipFactor, 1.1); SD(rc_pbFactor, 1.0); SI(rc_cuTree, 0); SI(rc_aqMode, 0); SI(rc_hevcAq, 0); SI(rc_qpStep, 1); SI(rc_bEnableGrain, 1); SI(recursionSkipMode, 0);
+            SD(psyRd, 4.0); SD(psyRdoq, 10.0); SI(bEnableSAO, 0); SI(rc_bEnableConstVbv, 1);
+        }
+        else if (!strcmp(tune, "animation"))
+        {
+            const int bf = PI(p, bframes);
+            SI(bframes, (bf + 2) >= PI(p, lookaheadDepth) ? bf : bf + 2);
+            SD(psyRd, 0.4); SD(rc_aqStrength, 0.4); SI(deblockingFilterBetaOffset, 1); SI(deblockingFilterTCOffset, 1);
+        }
+        else if (!strcmp(tune, "vmaf")) { }
+        else return -1;
     }
     return 0;
 }
@@ -266,6 +282,7 @@ void* abi_encoder_open(void* p)
     REQUIRE(PI(p, internalCsp) == 1, "internalCsp: only X265_CSP_I420 is built");
     REQUIRE(PI(p, rc_rateControlMode) == 1 || PI(p, rc_rateControlMode) == 2, "rc.rateControlMode: X265_RC_CQP (--qp) and X265_RC_CRF (--crf) are built, ABR (--bitrate) is not");
     REQUIRE(!PI(p, rc_hevcAq) && PI(p, rc_vbvMaxBitrate) == 0, "rc: hevc-aq and VBV are not built");
+    REQUIRE(!PI(p, rc_bEnableGrain), "rc.bEnableGrain (--tune grain): the grain rate control is not built");
     REQUIRE(PI(p, rc_vbvBufferSize) == 0 && !PI(p, rc_bStatRead) && !PI(p, rc_bStatWrite), "rc: VBV and multi-pass statistics are not built");
     REQUIRE(PI(p, bFrameAdaptive) >= 0 && PI(p, bFrameAdaptive) <= 2, "bFrameAdaptive (--b-adapt): 0, 1 or 2");
     REQUIRE(!PI(p, bHistBasedSceneCut), "bHistBasedSceneCut: histogram scene-cut detection is not built");
