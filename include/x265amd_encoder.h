@@ -111,6 +111,11 @@ typedef struct x265amd_param
     int32_t bEmitInfoSEI;                   /* param.bEmitInfoSEI (--info, the reference's default): a user-data SEI NAL unit behind the parameter sets that names the encoder and its
                                              * options (Encoder::getStreamHeaders, encoder.cpp:3260-3280).  The reference's text carries ITS version and build strings, so this
                                              * unit is the one part of a stream that can never be byte-equal between two builds of anything: every parity test runs --no-info */
+    int32_t qpMin, qpMax;                   /* param.rc.qpMin / qpMax (--qpmin / --qpmax; 0 / 69): the range of the rate control's QP and of every CU's (ratecontrol.cpp clipQscale,
+                                             * analysis.cpp:3712) */
+    int32_t bRepeatHeaders;                 /* param.bRepeatHeaders (--repeat-headers; Encoder::configure switches it on for all-intra encodes, --keyint 1): VPS / SPS / PPS in front
+                                             * of every keyframe's slice units (Encoder::encode, encoder.cpp:2035-2045) */
+    int32_t reserved2;
 } x265amd_param;
 enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 

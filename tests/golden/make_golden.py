@@ -826,6 +826,8 @@ if __name__ == "__main__":
         make_encoder_full_golden(sys.argv[2:] or None)
     elif len(sys.argv) > 1 and sys.argv[1] == "preset":
         make_encoder_preset_golden(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "cli":
+        make_encoder_full_golden(sys.argv[2:] or None, T.CLI_CASES, T.PRESET_CLI, "encoder_cli_golden.json")
     elif len(sys.argv) > 1 and sys.argv[1] == "rc":
         make_encoder_full_golden(sys.argv[2:] or None, T.RC_CASES, T.PRESET_CLI, "encoder_rc_golden.json")
     else:

@@ -3025,7 +3025,7 @@ class EncParam(C.Structure):
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
                 ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
                 ("rateControlMode", C.c_int32), ("rfConstant", C.c_double), ("aqStrength", C.c_double), ("qCompress", C.c_double), ("aqMode", C.c_int32), ("cuTree", C.c_int32),
-                ("qgSize", C.c_int32), ("bEmitInfoSEI", C.c_int32)]
+                ("qgSize", C.c_int32), ("bEmitInfoSEI", C.c_int32), ("qpMin", C.c_int32), ("qpMax", C.c_int32), ("bRepeatHeaders", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3397,7 +3397,7 @@ FULL_CASES = {
 
 
 def full_case_frames(tag):
-    (w, h), n, depth, cfg_id, _, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag] if tag in PRESET_CASES else RC_CASES[tag])
+    (w, h), n, depth, cfg_id, _, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag] if tag in PRESET_CASES else RC_CASES[tag] if tag in RC_CASES else CLI_CASES[tag])
     return survey_clip(w, h, depth, cfg_id, 0, n)
 
 
@@ -3552,6 +3552,59 @@ def ls_case_frames(tag):
     if kind == "ft":
         return encoder_ft_clip(w, h, n, depth, dy0=2, dy_inc=2, dx_step=4)
     return survey_clip(w, h, depth, 2, 0, n, 0)
+
+
+# Command lines as a user of the reference types them, through the command line program alone (x265-amod_amd/bin/x265amd -> the library's x265_api table -> its preset tables and
+# x265_param_parse): tag -> ((w, h), frames, depth, cfg_id of the clip, unused, the reference's options).  `--no-info` is added on both sides.  Golden data:
+# tests/golden/make_golden.py cli -> encoder_cli_golden.json.  What encoder_open refuses is listed in CLI_REFUSED with the words its error must contain.
+CLI_CASES = {
+    "cli_veryfast/": ((416, 240), 20, 8, 2, {}, ["--preset", "veryfast"]),
+    "cli_faster/": ((416, 240), 20, 8, 2, {}, ["--preset", "faster"]),
+    "cli_fast/": ((416, 240), 20, 8, 2, {}, ["--preset", "fast"]),
+    "cli_veryslow/": ((416, 240), 14, 8, 2, {}, ["--preset", "veryslow"]),
+    "cli_odd_size/": ((424, 232), 20, 8, 2, {}, ["--preset", "medium"]),                        # not a multiple of 16: partial AQ blocks, a lowres picture of odd block counts
+    "cli_rect_amp/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--rect", "--amp"]),
+    "cli_crf12/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--crf", "12"]),
+    "cli_all_intra/": ((416, 240), 8, 8, 2, {}, ["--preset", "medium", "--keyint", "1"]),
+    "cli_badapt1_b6/": ((416, 240), 24, 8, 2, {}, ["--preset", "medium", "--b-adapt", "1", "--bframes", "6"]),
+    "cli_nowpp_ft2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "2"]),
+    "cli_weightb/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--weightb"]),
+    "cli_ref1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--ref", "1"]),
+    "cli_hbd_ssim/": ((416, 240), 16, 10, 4, {}, ["--preset", "medium", "--tune", "ssim"]),
+    "cli_star_subme4/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--me", "star", "--subme", "4", "--merange", "25"]),
+    "cli_rdoq2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--rdoq-level", "2", "--psy-rdoq", "1.0"]),
+    "cli_keyint10/": ((416, 240), 26, 8, 2, {}, ["--preset", "medium", "--no-scenecut", "--keyint", "10"]),
+    "cli_qpmax30/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qpmax", "30"]),
+    "cli_ratios/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--ipratio", "1.2", "--pbratio", "1.5"]),
+    "cli_slow_fastdecode/": ((416, 240), 16, 8, 2, {}, ["--preset", "slow", "--tune", "fastdecode"]),
+    "cli_hbd_aq3/": ((416, 240), 16, 10, 4, {}, ["--preset", "medium", "--aq-mode", "3"]),
+    "cli_repeat_headers/": ((416, 240), 26, 8, 2, {}, ["--preset", "medium", "--repeat-headers", "--keyint", "10", "--no-scenecut"]),
+    "cli_zerolatency/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--tune", "zerolatency"]),
+    "cli_fast_psnr/": ((416, 240), 20, 8, 2, {}, ["--preset", "fast", "--tune", "psnr"]),
+    "cli_closed_fixed/": ((416, 240), 26, 8, 2, {}, ["--preset", "medium", "--no-open-gop", "--bframes", "3", "--b-adapt", "0", "--no-b-pyramid", "--keyint", "15", "--min-keyint", "15"]),
+    "cli_no_filters/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-sao", "--no-deblock"]),
+    "cli_no_tools/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-signhide", "--no-strong-intra-smoothing", "--no-temporal-mvp", "--no-early-skip", "--rskip", "0"]),
+    "cli_tu2_rd4/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--max-merge", "5", "--tu-intra-depth", "2", "--tu-inter-depth", "2", "--rd", "4"]),
+    "cli_ref4_nolimit/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--limit-refs", "0", "--ref", "4"]),
+    "cli_qg64_crf33/": ((448, 256), 16, 8, 2, {}, ["--preset", "medium", "--qg-size", "64", "--crf", "33"]),
+    "cli_hbd_fast/": ((416, 240), 16, 10, 4, {}, ["--preset", "fast"]),
+    "cli_qpmin20/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--crf", "14", "--qpmin", "20"]),
+    "cli_ft1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--frame-threads", "1"]),
+    "cli_la40_b8/": ((416, 240), 30, 8, 2, {}, ["--preset", "medium", "--rc-lookahead", "40", "--bframes", "8"]),
+    "cli_aq1_nocutree/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-cutree", "--aq-mode", "1", "--aq-strength", "0.5"]),
+    "cli_qp_const/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qp", "27"]),
+}
+# what the command line program must refuse, with words of the reason (x265amd_last_error)
+CLI_REFUSED = {
+    "ultrafast": (["--preset", "ultrafast"], "maxCUSize"),
+    "slower": (["--preset", "slower"], "limitTU"),
+    "placebo": (["--preset", "placebo"], "TransformSkip"),
+    "bitrate": (["--preset", "medium", "--bitrate", "1000"], "rateControlMode"),
+    "grain": (["--preset", "medium", "--tune", "grain"], "Grain"),
+    "umh": (["--preset", "medium", "--me", "umh"], "searchMethod"),
+    "qg16": (["--preset", "medium", "--qg-size", "16"], "qgSize"),
+    "nosuchoption": (["--preset", "medium", "--no-such-option"], "unknown option"),
+}
 
 
 # --weightp (the reference's default): tag -> ((w, h), frames, depth, clip, x265amd_param fields, the reference's options on top of WP_CLI).  The decision is built, the weighted

@@ -209,6 +209,51 @@ def test_command_line_program_reproduces_reference_stream(tag, tmp_path):
     assert g["stream_bytes"] - 130 <= picture_bytes <= g["stream_bytes"] + 2, (kbps, picture_bytes, g["stream_bytes"])      # (the stream's VPS / SPS / PPS are not any picture's bits)
 
 
+CLI_GOLD = os.path.join(T.GOLDEN_DIR, "encoder_cli_golden.json")
+
+
+def test_cli_golden_present():
+    import json
+    g = json.load(open(CLI_GOLD))
+    for tag, ((w, h), n, depth, _, _, cli) in T.CLI_CASES.items():
+        assert tag in g and len(g[tag]["recon_md5"]) == n and g[tag]["reference_command_line"] == " ".join(cli + T.PRESET_CLI), tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(T.CLI_CASES))
+def test_command_lines_as_a_user_types_them(tag, tmp_path):
+    """A matrix of reference command lines through the command line program alone -- other presets as they come, tunes, GOP and motion options, rate-control limits, 10-bit,
+    a picture size that is no multiple of 16: the stream and every reconstructed picture equal the reference program's for the SAME arguments (tests/hevc_testlib.py CLI_CASES;
+    nothing of the configuration is restated on the test's side)."""
+    import json
+    import subprocess
+    g = json.load(open(CLI_GOLD))[tag]
+    (w, h), n, depth, cfg_id, _, cli = T.CLI_CASES[tag]
+    _write_y4m(tmp_path / "clip.y4m", T.full_case_frames(tag), w, h, depth)
+    r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc"), "--recon", str(tmp_path / "rec.yuv")] + cli + T.PRESET_CLI,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(tmp_path / "out.hevc", np.uint8)
+    rec = np.fromfile(tmp_path / "rec.yuv", np.uint8)
+    fsz = w * h * 3 // 2 * (2 if depth == 10 else 1)
+    assert len(rec) == n * fsz
+    for k in range(n):
+        assert hashlib.md5(rec[k * fsz:(k + 1) * fsz].tobytes()).hexdigest() == g["recon_md5"][k], "reconstruction of picture %d in display order" % k
+    assert len(got) == g["stream_bytes"] and hashlib.md5(got.tobytes()).hexdigest() == g["stream_md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", sorted(T.CLI_REFUSED))
+def test_command_lines_outside_the_built_subset_are_refused_by_name(what, tmp_path):
+    """what is not built is refused at encoder_open with the member's name (never coded differently from the reference): the other CTU sizes, limit-tu, transform skip, ABR, the
+    grain tune's rate control, the UMH search, small quantisation groups -- and an option nobody knows"""
+    import subprocess
+    cli, word = T.CLI_REFUSED[what]
+    _write_y4m(tmp_path / "clip.y4m", T.survey_clip(416, 240, 8, 2, 0, 3), 416, 240, 8)
+    r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc")] + cli + T.PRESET_CLI, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and word.lower() in r.stderr.lower(), (r.returncode, r.stderr[-600:])
+
+
 @pytest.mark.gpu
 def test_closed_gops_encode_independently():
     """the unit of multi-GPU sharding: the pictures between two IDR frames depend on nothing outside, so two encoder objects (as two ranks would hold them) coding

@@ -184,8 +184,13 @@ int main(int argc, char** argv)
         recHeader = (size_t)fprintf(rec, "YUV4MPEG2 W%d H%d F%u:%u Ip C420%s\n", y.width, y.height, y.fpsNum, y.fpsDen, y.depth > 8 ? "p10" : "");
     }
     Nal* nal = nullptr; uint32_t nnal = 0;
-    if (api.encoder_headers(enc, &nal, &nnal) < 0) { fprintf(stderr, "x265amd: %s\n", api.last_error()); return 1; }
-    for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, out);
+    /* the parameter sets once in front -- unless the encoder repeats them with every keyframe (x265.cpp: the program asks x265_encoder_parameters what configure made of it) */
+    ((void (*)(void*, void*))api.t->fn[X265API_ENCODER_PARAMETERS])(enc, p);
+    if (!rd<int32_t>(p, X265ABI_PARAM_bRepeatHeaders))
+    {
+        if (api.encoder_headers(enc, &nal, &nnal) < 0) { fprintf(stderr, "x265amd: %s\n", api.last_error()); return 1; }
+        for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, out);
+    }
 
     const int isz = y.depth > 8 ? 2 : 1;
     std::vector<uint8_t> buf;

@@ -17,7 +17,7 @@ extern "C" void x265amd_param_default(x265amd_param* p)
     memset(p, 0, sizeof(*p));
     p->fpsNum = 25; p->fpsDenom = 1;
     p->bframes = 0; p->keyframeMax = 250; p->maxNumReferences = 3; p->qp = 30; p->ipFactor = 1.4f; p->pbFactor = 1.3f;      /* (float literals, as common/param.cpp:276-277 has them) */
-    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32;
+    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32; p->qpMin = 0; p->qpMax = 69;
     p->rdLevel = 3; p->limitReferences = 3; p->bEnableEarlySkip = 1; p->recursionSkipMode = 1; p->bIntraInBFrames = 1; p->psyRd = 2.0;
     p->searchMethod = X265AMD_ME_HEX; p->subpelRefine = 2; p->searchRange = 57; p->maxNumMergeCand = 3;
     p->bEnableSignHiding = 1; p->bEnableStrongIntraSmoothing = 1; p->bEnableTemporalMvp = 1; p->tuQTMaxInterDepth = 1; p->tuQTMaxIntraDepth = 1;
@@ -37,6 +37,7 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.progressive_source = 1; s.frame_only_constraint = 1;
     s.bit_depth_constraint = X265AMD_DEPTH; s.chroma_format_constraint = 1; s.lower_bit_rate_constraint = 1;
     s.intra_constraint = p.keyframeMax <= 1;
+    if (s.intra_constraint) { s.profile_idc = 4; s.profile_compatibility_flags = 1u << 4; }         /* Main Intra / Main 10 Intra: the range extensions' profile with its constraint flags (level.cpp:84-107) */
     const uint32_t lumaSamples = (uint32_t)(W * H);
     const uint32_t samplesPerSec = (uint32_t)(lumaSamples * ((double)p.fpsNum / p.fpsDenom));
     s.level_idc = 255;
@@ -73,6 +74,12 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     /* Encoder::configure's rules for the rate control's switches (encoder.cpp:3721-3754): constant QP switches adaptive quantisation and cuTree off; cuTree without AQ gets
      * aq-mode 1 at strength 0 (cuTree needs the offset arrays; delta QP is on); strength 0 without cuTree is no AQ at all */
     x265amd_param norm = *p;
+    if (norm.keyframeMax <= 1 && norm.keyframeMax >= 0)
+    {
+        /* all-intra encodes (encoder.cpp:3636-3658): no lookahead, no B pictures, no cuTree, no weights, one reference, the parameter sets with every picture */
+        norm.keyframeMax = 1; norm.keyframeMin = 1; norm.bFrameAdaptive = 0; norm.bframes = 0; norm.bOpenGOP = 0; norm.bRepeatHeaders = 1; norm.lookaheadDepth = 0;
+        norm.scenecutThreshold = 0; norm.cuTree = 0; norm.bEnableWeightedPred = 0; norm.bEnableWeightedBiPred = 0; norm.maxNumReferences = 1;
+    }
     if (norm.rateControlMode != X265AMD_RC_CRF) { norm.aqMode = 0; norm.cuTree = 0; }
     if (norm.lookaheadDepth == 0) norm.cuTree = 0;
     if (!norm.aqMode && norm.cuTree) { norm.aqMode = 1; norm.aqStrength = 0.0; }
@@ -93,6 +100,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->rateControlMode == X265AMD_RC_CRF || (p->qp >= 0 && p->qp <= 51), "qp outside 0..51");
         XA_REQUIRE(p->rateControlMode != X265AMD_RC_CRF || (p->rfConstant >= 0 && p->rfConstant <= 51), "rfConstant outside 0..51");
         XA_REQUIRE(p->aqMode >= 0 && p->aqMode <= 3, "aqMode outside 0..3 (the edge-based modes are not built)");
+        XA_REQUIRE(p->qpMin >= 0 && p->qpMin <= p->qpMax && p->qpMax <= 69, "qpMin / qpMax outside 0..69 (or crossed)");
         XA_REQUIRE(!p->aqMode || p->aqStrength >= 0, "aqStrength negative");
         XA_REQUIRE(!p->aqMode || p->qgSize == 32 || p->qgSize == 64, "qgSize: 64 and 32 are built");
         XA_REQUIRE(!p->cuTree || p->aqMode, "cuTree needs adaptive quantisation (Encoder::configure switches it on with cuTree; say aqMode)");
@@ -216,7 +224,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         x265amd_rc_params rp;
         memset(&rp, 0, sizeof(rp));
         rp.width = e->W; rp.height = e->H; rp.fps_num = p->fpsNum; rp.fps_denom = p->fpsDenom; rp.bframes = p->bframes; rp.keyframe_max = p->keyframeMax; rp.cu_tree = p->cuTree != 0;
-        rp.qp_min = 0; rp.qp_max = 69; rp.rf_constant = p->rfConstant; rp.q_compress = p->qCompress; rp.ip_factor = p->ipFactor; rp.pb_factor = p->pbFactor;
+        rp.qp_min = p->qpMin; rp.qp_max = p->qpMax; rp.rf_constant = p->rfConstant; rp.q_compress = p->qCompress; rp.ip_factor = p->ipFactor; rp.pb_factor = p->pbFactor;
         e->rateCtl = x265amd_rc_open(&rp);
         if (!e->rateCtl) { xa_fail(X265AMD_EINVAL, "encoder_open: rate control parameters"); return nullptr; }
     }
@@ -378,20 +386,19 @@ extern "C" void x265amd_encoder_close(x265amd_encoder* e) { delete e; }
 /* splits a byte stream of NAL units behind 4-byte start codes into x265_nal records (payload includes the start code, as the reference's do) */
 static void splitNals(std::vector<uint8_t>& bytes, std::vector<x265amd_nal>& nals)
 {
+    /* NAL units behind start codes of four bytes (the first unit of an access unit, parameter sets) or three (NALList::serialize, nal.cpp:85-160).  Emulation prevention keeps
+     * 00 00 01 out of every payload. */
     nals.clear();
-    size_t start = 0;
-    for (size_t i = 4; i + 4 <= bytes.size() + 1; i++)
+    std::vector<size_t> starts;
+    for (size_t i = 0; i + 3 <= bytes.size(); i++)
+        if (!bytes[i] && !bytes[i + 1] && bytes[i + 2] == 1) { starts.push_back(i > 0 && !bytes[i - 1] && (starts.empty() || starts.back() + 3 <= i - 1) ? i - 1 : i); i += 2; }
+    for (size_t k = 0; k < starts.size(); k++)
     {
-        const bool sc = i + 4 <= bytes.size() && !bytes[i] && !bytes[i + 1] && !bytes[i + 2] && bytes[i + 3] == 1;
-        if (sc || i + 4 > bytes.size())
-        {
-            const size_t end = sc ? i : bytes.size();
-            x265amd_nal n;
-            n.type = (bytes[start + 4] >> 1) & 63; n.sizeBytes = (uint32_t)(end - start); n.payload = bytes.data() + start;
-            nals.push_back(n);
-            start = end;
-            if (!sc) break;
-        }
+        const size_t start = starts[k], end = k + 1 < starts.size() ? starts[k + 1] : bytes.size();
+        const size_t hdr = start + (bytes[start + 2] == 1 ? 3 : 4);
+        x265amd_nal n;
+        n.type = (bytes[hdr] >> 1) & 63; n.sizeBytes = (uint32_t)(end - start); n.payload = bytes.data() + start;
+        nals.push_back(n);
     }
 }
 
@@ -637,6 +644,19 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         }
     }
     e->outBytes.swap(front->nalBytes);
+    /* --repeat-headers (and every all-intra encode): the parameter sets in front of a keyframe's slice units (FrameEncoder::compressFrame, frameencoder.cpp:465-480) */
+    if (e->p.bRepeatHeaders && front->bKeyframe && !e->outBytes.empty())
+    {
+        /* ... and the slice units are no longer the first of their access unit: start codes of three bytes (nal.cpp:110-118) */
+        std::vector<uint8_t> au(e->headerBytes);
+        const std::vector<uint8_t>& b = e->outBytes;
+        for (size_t i = 0; i < b.size(); i++)
+        {
+            if (i + 4 <= b.size() && !b[i] && !b[i + 1] && !b[i + 2] && b[i + 3] == 1) continue;         /* the zero_byte in front of a start code goes */
+            au.push_back(b[i]);
+        }
+        e->outBytes.swap(au);
+    }
     splitNals(e->outBytes, e->nals);
     if (!e->outBytes.empty())
     {

@@ -226,7 +226,7 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
             return xa_fail(X265AMD_EHIP, "encoder: sao download");
         std::vector<x265amd_sao_ctu> sparams((size_t)nctu);
         memset(sparams.data(), 0, sizeof(x265amd_sao_ctu) * nctu);
-        rc = x265amd_sao_rdo(&si, pic.type != TYPE_B ? 1 : 0, 1, 0, 69,       /* IS_REFERENCED: fixed by the type (hasReferences changes as later pictures are prepared) */
+        rc = x265amd_sao_rdo(&si, pic.type != TYPE_B ? 1 : 0, 1, p.qpMin, p.qpMax,       /* IS_REFERENCED: fixed by the type (hasReferences changes as later pictures are prepared) */
                              pic.units.data(), cnt.data(), orgs.data(), depthSaoRate, sparams.data(), saoFlags);
         if (rc != X265AMD_OK) return rc;
         if (hipMemcpyAsync(dSaoParams, sparams.data(), sizeof(x265amd_sao_ctu) * nctu, hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -493,7 +493,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
             { rc = xa_fail(X265AMD_EHIP, "encoder: sao download"); break; }
             stamp(3);
             int32_t flags[2] = { 1, 1 };
-            rc = x265amd_sao_rdo_rows(&si, pic.type != TYPE_B ? 1 : 0, 2, 0, 69, pic.units.data(), cnt.data(), orgs.data(), unusedRate, sparams.data(), flags, r, r + 1);
+            rc = x265amd_sao_rdo_rows(&si, pic.type != TYPE_B ? 1 : 0, 2, p.qpMin, p.qpMax, pic.units.data(), cnt.data(), orgs.data(), unusedRate, sparams.data(), flags, r, r + 1);
             if (rc != X265AMD_OK) break;
             if (hipMemcpyAsync((x265amd_sao_ctu*)dPar.p + (size_t)r * ctuW, sparams.data() + (size_t)r * ctuW, sizeof(x265amd_sao_ctu) * ctuW, hipMemcpyHostToDevice, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
@@ -707,7 +707,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
             for (const Unit& u : todoFull)
             {
                 int32_t flags[2] = { 1, 1 };
-                rc = x265amd_sao_rdo_cols(&si, pic.type != TYPE_B ? 1 : 0, 2, 0, 69, pic.units.data(), cnt, orgs, sparams.data(), flags, u.r, u.c0, u.c1,
+                rc = x265amd_sao_rdo_cols(&si, pic.type != TYPE_B ? 1 : 0, 2, p.qpMin, p.qpMax, pic.units.data(), cnt, orgs, sparams.data(), flags, u.r, u.c0, u.c1,
                                           carry.data() + (size_t)u.r * (X265AMD_CTX_STRIDE + 8));
                 if (rc != X265AMD_OK) break;
                 const size_t off = (size_t)u.r * ctuW + u.c0, n = (size_t)(u.c1 - u.c0);

@@ -178,11 +178,11 @@ void x265amd_encoder::cuQpTable(Pic& pic)
     for (int a = 0; a < nctu; a++)
     {
         const int x = (a % ctuW) * 64, y = (a / ctuW) * 64;
-        pic.cuQp[(size_t)a * per] = (int8_t)x265amd_cu_qp(pic.avgQpRc, offs, W, H, x, y, 64, 0, 69);
+        pic.cuQp[(size_t)a * per] = (int8_t)x265amd_cu_qp(pic.avgQpRc, offs, W, H, x, y, 64, p.qpMin, p.qpMax);
         for (int q = 0; q < 4 && per == 5; q++)
         {
             const int cx = x + (q & 1) * 32, cy = y + (q >> 1) * 32;
-            if (cx < W && cy < H) pic.cuQp[(size_t)a * per + 1 + q] = (int8_t)x265amd_cu_qp(pic.avgQpRc, offs, W, H, cx, cy, 32, 0, 69);
+            if (cx < W && cy < H) pic.cuQp[(size_t)a * per + 1 + q] = (int8_t)x265amd_cu_qp(pic.avgQpRc, offs, W, H, cx, cy, 32, p.qpMin, p.qpMax);
         }
     }
 }

@@ -296,7 +296,7 @@ void* abi_encoder_open(void* p)
     REQUIRE(!PI(p, noiseReductionIntra) && !PI(p, noiseReductionInter) && !rd<const char*>(p, X265ABI_PARAM_scalingLists), "noise reduction / scaling lists are not built");
     REQUIRE(!PI(p, cbQpOffset) && !PI(p, crQpOffset) && !PI(p, deblockingFilterTCOffset) && !PI(p, deblockingFilterBetaOffset), "chroma QP / deblocking offsets must be 0");
     REQUIRE(!PI(p, bSaoNonDeblocked) && !PI(p, selectiveSAO), "sao-non-deblock / selective-sao are not built");
-    REQUIRE(!PI(p, bRepeatHeaders) && !PI(p, bEnableAccessUnitDelimiters) && !PI(p, bEmitHRDSEI) && !PI(p, decodedPictureHashSEI), "repeat-headers / AUD / HRD SEI / hash SEI are not built");
+    REQUIRE(!PI(p, bEnableAccessUnitDelimiters) && !PI(p, bEmitHRDSEI) && !PI(p, decodedPictureHashSEI), "AUD / HRD SEI / hash SEI are not built");
     REQUIRE(!PI(p, bEnableTemporalSubLayers) && !PI(p, uhdBluray) && !PI(p, bEnableSvtHevc), "temporal layers / uhd-bd / svt are not built");
     REQUIRE(!PI(p, analysisReuseMode) && !PI(p, bDynamicRefine) && !PI(p, rdPenalty) && !PI(p, bEnableRdRefine) && !PI(p, dynamicRd) && !PI(p, bSsimRd), "analysis reuse / rd-refine / dynamic-rd / ssim-rd are not built");
     REQUIRE(!PI(p, bDistributeModeAnalysis) && !PI(p, bDistributeMotionEstimation), "pmode / pme are not built");
@@ -315,7 +315,7 @@ void* abi_encoder_open(void* p)
     q.qp = PI(p, rc_qp); q.ipFactor = PD(p, rc_ipFactor); q.pbFactor = PD(p, rc_pbFactor);
     q.rateControlMode = PI(p, rc_rateControlMode); q.rfConstant = PD(p, rc_rfConstant); q.qCompress = PD(p, rc_qCompress); q.qgSize = PI(p, rc_qgSize);
     q.aqMode = PI(p, rc_aqMode); q.aqStrength = PD(p, rc_aqStrength); q.cuTree = PI(p, rc_cuTree) != 0;
-    q.bEmitInfoSEI = PI(p, bEmitInfoSEI) != 0;
+    q.bEmitInfoSEI = PI(p, bEmitInfoSEI) != 0; q.bRepeatHeaders = PI(p, bRepeatHeaders) != 0; q.qpMin = PI(p, rc_qpMin); q.qpMax = PI(p, rc_qpMax);
     /* (Encoder::configure's rules for these switches, encoder.cpp:3721-3754, are x265amd_encoder_open's) */
     q.rdLevel = PI(p, rdLevel); q.bEnableRectInter = PI(p, bEnableRectInter); q.bEnableAMP = PI(p, bEnableAMP); q.limitModes = PI(p, limitModes); q.limitReferences = PI(p, limitReferences);
     q.bEnableEarlySkip = PI(p, bEnableEarlySkip); q.recursionSkipMode = PI(p, recursionSkipMode); q.bIntraInBFrames = PI(p, bIntraInBFrames); q.psyRd = PD(p, psyRd);
@@ -341,6 +341,7 @@ void* abi_encoder_open(void* p)
     a->enc = e; a->width = q.sourceWidth; a->height = q.sourceHeight;
     a->bframeDelay = q.bframes ? (q.bBPyramid ? 2 : 1) : 0;
     a->param.assign((const uint8_t*)p, (const uint8_t*)p + X265ABI_SIZEOF_PARAM);         /* api.cpp:96-116: the encoder keeps a copy */
+    if (q.keyframeMax >= 0 && q.keyframeMax <= 1) wr<int32_t>(a->param.data(), X265ABI_PARAM_bRepeatHeaders, 1);          /* ... as Encoder::configure left it: x265_encoder_parameters tells the caller (the reference's program asks before it writes the headers) */
     a->fps = (double)q.fpsNum / (double)q.fpsDenom;
     clock_gettime(CLOCK_MONOTONIC, &a->opened);
     return a;
