@@ -3593,6 +3593,30 @@ CLI_CASES = {
     "cli_la40_b8/": ((416, 240), 30, 8, 2, {}, ["--preset", "medium", "--rc-lookahead", "40", "--bframes", "8"]),
     "cli_aq1_nocutree/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-cutree", "--aq-mode", "1", "--aq-strength", "0.5"]),
     "cli_qp_const/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qp", "27"]),
+    "cli_720p_medium/": ((1280, 720), 16, 8, 2, {}, ["--preset", "medium"]),                     # the lookahead's cooperative slices under the rate control
+    "cli_720p_fast_noslices/": ((1280, 720), 12, 8, 2, {}, ["--preset", "fast", "--lookahead-slices", "0"]),
+    "cli_480p_slow/": ((832, 480), 12, 8, 3, {}, ["--preset", "slow"]),
+    "cli_hbd_veryslow/": ((416, 240), 10, 10, 5, {}, ["--preset", "veryslow"]),
+    "cli_crf4/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--crf", "4"]),
+    "cli_crf51/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--crf", "51"]),
+    "cli_keyint2/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--keyint", "2", "--min-keyint", "1"]),
+    "cli_b16/": ((416, 240), 40, 8, 2, {}, ["--preset", "medium", "--bframes", "16", "--rc-lookahead", "40"]),
+    "cli_b1_nopyr/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--bframes", "1", "--no-b-pyramid"]),
+    "cli_dia_subme0/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--me", "dia", "--subme", "0", "--merange", "8"]),
+    "cli_subme7/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--subme", "7"]),
+    "cli_rd6/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--rd", "6"]),
+    "cli_rd5_rdoq1/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--rd", "5", "--rdoq-level", "1"]),
+    "cli_nopsy_rdoq2/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--psy-rd", "0", "--psy-rdoq", "0", "--rdoq-level", "2"]),
+    "cli_rect_limit/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--rect", "--limit-modes"]),
+    "cli_tu4/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--tu-intra-depth", "4", "--tu-inter-depth", "4"]),
+    "cli_sar2/": ((416, 240), 8, 8, 2, {}, ["--preset", "medium", "--sar", "2"]),
+    "cli_pools_none/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--pools", "none"]),
+    "cli_ft4/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--frame-threads", "4"]),
+    "cli_aq_strong/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--aq-strength", "3.0"]),
+    "cli_qcomp1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qcomp", "1.0"]),
+    "cli_qcomp05_nocutree/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qcomp", "0.5", "--no-cutree"]),
+    "cli_slow_norect/": ((416, 240), 12, 8, 2, {}, ["--preset", "slow", "--no-rect", "--no-limit-modes"]),
+    "cli_hbd_slow_crf20/": ((416, 240), 10, 10, 4, {}, ["--preset", "slow", "--crf", "20"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {

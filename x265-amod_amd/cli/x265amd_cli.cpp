@@ -164,10 +164,8 @@ int main(int argc, char** argv)
     for (auto& o : opts)
     {
         const char* name = o.first.c_str() + 2;
-        /* an option that stands alone (a switch) parses without a value; one that wants a value says so (X265_PARAM_BAD_VALUE) and gets the argument behind it */
-        int r = api.param_parse(p, name, nullptr);
-        if (r == -2 && o.second) r = api.param_parse(p, name, o.second);
-        else if (r == 0 && o.second) { fprintf(stderr, "x265amd: %s takes no value (%s)\n", o.first.c_str(), o.second); return 2; }
+        /* the argument behind an option, if there is one, is its value; an option that stands alone is a switch (x265_param_parse takes NULL as "true") */
+        const int r = api.param_parse(p, name, o.second);
         if (r == -1) { fprintf(stderr, "x265amd: unknown option %s\n", o.first.c_str()); return 2; }
         if (r) { fprintf(stderr, "x265amd: bad value for %s: %s\n", o.first.c_str(), o.second ? o.second : "(none)"); return 2; }
     }
