@@ -3396,8 +3396,48 @@ FULL_CASES = {
 }
 
 
+def torture_clip(kind, w, h, depth, n):
+    """content the survey clip does not have (integer arithmetic only): `noise` -- every sample uniform over the whole range, new every picture (nothing predicts, escapes and
+    large levels everywhere); `flat` -- black, then white, then mid grey pictures with one moving square; `edges` -- a high-contrast checkerboard of 8x8 and 3x3 cells sliding
+    by (3, 1) with saturated samples; `static` -- one textured picture repeated (everything skips); `jump` -- texture moving 72 samples per picture (beyond the search range);
+    `dark` -- a dim noisy gradient (adaptive quantisation's dark-scene bias, low variances)"""
+    sc = 1 << (depth - 8)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    frames = []
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.int64)
+    cy, cx = np.mgrid[0:h // 2, 0:w // 2].astype(np.int64)
+    for t in range(n):
+        if kind == "noise":
+            f = lcg_noise_field(0xC0FFEE + 977 * t, h + h // 2, w)
+            x = lcg_noise_field(0xBADF00D + 131 * t, h + h // 2, w)
+            full = ((f + 12) * 25 + (x + 12)) % 256                      # 0 .. 255 from two draws of 0 .. 24
+            y = full[:h]; u = full[h:h + h // 2, :w // 2]; v = full[h:h + h // 2, w // 2:]
+        elif kind == "flat":
+            base = (0, 255, 128)[(t // 3) % 3]
+            y = np.full((h, w), base, np.int64); u = np.full((h // 2, w // 2), 128, np.int64); v = u.copy()
+            y[40 + 3 * t:72 + 3 * t, 60 + 5 * t:92 + 5 * t] = 255 - base
+        elif kind == "edges":
+            a = (((xx + 3 * t) // 8 + (yy + t) // 8) & 1) * 255
+            b = (((xx + 3 * t) // 3 + (yy + t) // 3) & 1) * 255
+            y = np.where((yy // 48) & 1, b, a)
+            u = 128 + (((cx + t) // 16) & 1) * 90 - 45; v = 128 - (((cy + t) // 12) & 1) * 100 + 50
+        elif kind == "static":
+            y = 40 + ((xx * 7 + yy * 13) % 97) + lcg_noise_field(0x5747, h, w); u = 100 + (cx % 31); v = 150 - (cy % 29)
+        elif kind == "jump":
+            y = 50 + (((xx + 72 * t) * 5 + yy * 3) % 131) + lcg_noise_field(0x4A554D50, h, w + 72 * n)[:, 72 * t:72 * t + w]; u = 110 + ((cx + 36 * t) % 23); v = 140 - ((cy + 5 * t) % 19)
+        elif kind == "dark":
+            y = 4 + (xx + 2 * t) // 40 + (lcg_noise_field(0xDA4C + t // 24, h + 32, w + 64)[t % 24:t % 24 + h, 2 * (t % 24):2 * (t % 24) + w] + 12) // 8; u = 128 + (cx // 64); v = 128 - (cy // 64)
+        else:
+            raise ValueError(kind)
+        frames.append([np.clip(np.asarray(p, np.int64) * sc, 0, pmax).astype(dt) for p in (y, u, v)])
+    return frames
+
+
 def full_case_frames(tag):
-    (w, h), n, depth, cfg_id, _, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag] if tag in PRESET_CASES else RC_CASES[tag] if tag in RC_CASES else CLI_CASES[tag])
+    (w, h), n, depth, cfg_id, extra, _ = (FULL_CASES[tag] if tag in FULL_CASES else PRESET_CASES[tag] if tag in PRESET_CASES else RC_CASES[tag] if tag in RC_CASES else CLI_CASES[tag])
+    if tag in CLI_CASES and isinstance(extra, dict) and "clip" in extra:
+        return torture_clip(extra["clip"], w, h, depth, n)
     return survey_clip(w, h, depth, cfg_id, 0, n)
 
 
@@ -3617,6 +3657,20 @@ CLI_CASES = {
     "cli_qcomp05_nocutree/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qcomp", "0.5", "--no-cutree"]),
     "cli_slow_norect/": ((416, 240), 12, 8, 2, {}, ["--preset", "slow", "--no-rect", "--no-limit-modes"]),
     "cli_hbd_slow_crf20/": ((416, 240), 10, 10, 4, {}, ["--preset", "slow", "--crf", "20"]),
+    # other content (torture_clip): nothing predictable, flat pictures, sharp edges with saturated samples, a still picture, motion beyond the search range, a dark scene
+    "cli_noise_medium/": ((416, 240), 8, 8, 2, {"clip": "noise"}, ["--preset", "medium"]),
+    "cli_noise_slow_hbd/": ((416, 240), 6, 10, 4, {"clip": "noise"}, ["--preset", "slow"]),
+    "cli_noise_crf45/": ((416, 240), 8, 8, 2, {"clip": "noise"}, ["--preset", "medium", "--crf", "45"]),
+    "cli_flat_medium/": ((416, 240), 12, 8, 2, {"clip": "flat"}, ["--preset", "medium"]),
+    "cli_flat_veryslow/": ((416, 240), 10, 8, 2, {"clip": "flat"}, ["--preset", "veryslow"]),
+    "cli_edges_medium/": ((416, 240), 12, 8, 2, {"clip": "edges"}, ["--preset", "medium"]),
+    "cli_edges_slow/": ((416, 240), 10, 8, 2, {"clip": "edges"}, ["--preset", "slow"]),
+    "cli_edges_hbd_fast/": ((416, 240), 10, 10, 4, {"clip": "edges"}, ["--preset", "fast"]),
+    "cli_static_medium/": ((416, 240), 16, 8, 2, {"clip": "static"}, ["--preset", "medium"]),
+    "cli_jump_medium/": ((416, 240), 12, 8, 2, {"clip": "jump"}, ["--preset", "medium"]),
+    "cli_jump_slow/": ((416, 240), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
+    "cli_dark_aq3/": ((416, 240), 16, 8, 2, {"clip": "dark"}, ["--preset", "medium", "--aq-mode", "3"]),
+    "cli_dark_medium_hbd/": ((416, 240), 12, 10, 4, {"clip": "dark"}, ["--preset", "medium"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {
