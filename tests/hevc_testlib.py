@@ -3671,6 +3671,10 @@ CLI_CASES = {
     "cli_jump_slow/": ((416, 240), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
     "cli_dark_aq3/": ((416, 240), 16, 8, 2, {"clip": "dark"}, ["--preset", "medium", "--aq-mode", "3"]),
     "cli_dark_medium_hbd/": ((416, 240), 12, 10, 4, {"clip": "dark"}, ["--preset", "medium"]),
+    "cli_fhd_noise/": ((1920, 1080), 6, 8, 2, {"clip": "noise"}, ["--preset", "medium"]),
+    "cli_fhd_edges/": ((1920, 1080), 8, 8, 2, {"clip": "edges"}, ["--preset", "medium"]),
+    "cli_720p_jump_slow/": ((1280, 720), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
+    "cli_fhd_static_hbd/": ((1920, 1080), 10, 10, 4, {"clip": "static"}, ["--preset", "medium"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {
