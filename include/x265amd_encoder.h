@@ -116,6 +116,15 @@ typedef struct x265amd_param
     int32_t bRepeatHeaders;                 /* param.bRepeatHeaders (--repeat-headers; Encoder::configure switches it on for all-intra encodes, --keyint 1): VPS / SPS / PPS in front
                                              * of every keyframe's slice units (Encoder::encode, encoder.cpp:2035-2045) */
     int32_t reserved2;
+    /* param.vui (x265.h: the video usability information of the SPS, Encoder::initSPS encoder.cpp:3388-3423; aspectRatioIdc is further up): signalling only, nothing here changes a
+     * coded sample.  --sar W:H (aspectRatioIdc 255), --overscan, --videoformat, --range, --colorprim, --transfer, --colormatrix, --chromaloc, --display-window */
+    int32_t vuiSarWidth, vuiSarHeight;
+    int32_t vuiOverscanInfoPresent, vuiOverscanAppropriate;
+    int32_t vuiVideoSignalTypePresent, vuiVideoFormat, vuiFullRange;                 /* videoFormat 5 = unspecified */
+    int32_t vuiColorDescriptionPresent, vuiColorPrimaries, vuiTransfer, vuiMatrix;   /* 2 = unspecified */
+    int32_t vuiChromaLocPresent, vuiChromaLocTop, vuiChromaLocBottom;
+    int32_t vuiDisplayWindow, vuiDispWinLeft, vuiDispWinRight, vuiDispWinTop, vuiDispWinBottom;
+    int32_t reserved3;
 } x265amd_param;
 enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 

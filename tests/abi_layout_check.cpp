@@ -33,6 +33,7 @@ API(api_major_version); API(bit_depth); API(version_str); API(param_alloc); API(
 API(encoder_intra_refresh); API(zone_param_parse);
 P(csvfn); P(csvfpt); P(csvLogLevel); P(maxCLL); P(maxFALL);
 PN(rc_bEnableGrain, rc.bEnableGrain); PN(rc_bEnableConstVbv, rc.bEnableConstVbv);
+PN(vui_bEnableOverscanAppropriateFlag, vui.bEnableOverscanAppropriateFlag); PN(vui_videoFormat, vui.videoFormat); PN(vui_bEnableVideoFullRangeFlag, vui.bEnableVideoFullRangeFlag); PN(vui_bEnableColorDescriptionPresentFlag, vui.bEnableColorDescriptionPresentFlag); PN(vui_colorPrimaries, vui.colorPrimaries); PN(vui_transferCharacteristics, vui.transferCharacteristics); PN(vui_matrixCoeffs, vui.matrixCoeffs); PN(vui_chromaSampleLocTypeTopField, vui.chromaSampleLocTypeTopField); PN(vui_chromaSampleLocTypeBottomField, vui.chromaSampleLocTypeBottomField); PN(vui_defDispWinLeftOffset, vui.defDispWinLeftOffset); PN(vui_defDispWinRightOffset, vui.defDispWinRightOffset); PN(vui_defDispWinTopOffset, vui.defDispWinTopOffset); PN(vui_defDispWinBottomOffset, vui.defDispWinBottomOffset);
 #define ST(f) static_assert(offsetof(x265_stats, f) == X265ABI_STATS_##f, #f)
 ST(globalPsnrY); ST(globalSsim); ST(elapsedEncodeTime); ST(elapsedVideoTime); ST(bitrate); ST(accBits); ST(encodedPictureCount); ST(totalWPFrames); ST(statsI); ST(statsP); ST(statsB);
 ST(maxCLL); ST(maxFALL);

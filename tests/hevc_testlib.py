@@ -3025,7 +3025,10 @@ class EncParam(C.Structure):
                 ("bEnableWavefront", C.c_int32), ("aspectRatioIdc", C.c_int32), ("rdoqLevel", C.c_int32), ("psyRdoqFix8", C.c_int32), ("bEnableFastIntra", C.c_int32), ("firstFrame", C.c_int32), ("frameNumThreads", C.c_int32), ("scenecutThreshold", C.c_int32), ("lookaheadDepth", C.c_int32),
                 ("keyframeMin", C.c_int32), ("shardRank", C.c_int32), ("shardCount", C.c_int32), ("bFrameAdaptive", C.c_int32), ("bOpenGOP", C.c_int32), ("bBPyramid", C.c_int32), ("lookaheadSlices", C.c_int32), ("bEnableWeightedPred", C.c_int32), ("bEnableWeightedBiPred", C.c_int32),
                 ("rateControlMode", C.c_int32), ("rfConstant", C.c_double), ("aqStrength", C.c_double), ("qCompress", C.c_double), ("aqMode", C.c_int32), ("cuTree", C.c_int32),
-                ("qgSize", C.c_int32), ("bEmitInfoSEI", C.c_int32), ("qpMin", C.c_int32), ("qpMax", C.c_int32), ("bRepeatHeaders", C.c_int32), ("reserved2", C.c_int32)]
+                ("qgSize", C.c_int32), ("bEmitInfoSEI", C.c_int32), ("qpMin", C.c_int32), ("qpMax", C.c_int32), ("bRepeatHeaders", C.c_int32), ("reserved2", C.c_int32), ("vuiSarWidth", C.c_int32), ("vuiSarHeight", C.c_int32), ("vuiOverscanInfoPresent", C.c_int32),
+                ("vuiOverscanAppropriate", C.c_int32), ("vuiVideoSignalTypePresent", C.c_int32), ("vuiVideoFormat", C.c_int32), ("vuiFullRange", C.c_int32), ("vuiColorDescriptionPresent", C.c_int32),
+                ("vuiColorPrimaries", C.c_int32), ("vuiTransfer", C.c_int32), ("vuiMatrix", C.c_int32), ("vuiChromaLocPresent", C.c_int32), ("vuiChromaLocTop", C.c_int32), ("vuiChromaLocBottom", C.c_int32),
+                ("vuiDisplayWindow", C.c_int32), ("vuiDispWinLeft", C.c_int32), ("vuiDispWinRight", C.c_int32), ("vuiDispWinTop", C.c_int32), ("vuiDispWinBottom", C.c_int32), ("reserved3", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3675,6 +3678,11 @@ CLI_CASES = {
     "cli_fhd_edges/": ((1920, 1080), 8, 8, 2, {"clip": "edges"}, ["--preset", "medium"]),
     "cli_720p_jump_slow/": ((1280, 720), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
     "cli_fhd_static_hbd/": ((1920, 1080), 10, 10, 4, {"clip": "static"}, ["--preset", "medium"]),
+    # the video usability information (signalling only): colour description, range, HDR-style transfer with a chroma location, an extended sample aspect ratio with overscan,
+    # video format and a display window
+    "cli_vui_bt709/": ((416, 240), 4, 8, 2, {}, ["--preset", "medium", "--colorprim", "bt709", "--transfer", "bt709", "--colormatrix", "bt709", "--range", "limited"]),
+    "cli_vui_hdr_hbd/": ((416, 240), 4, 10, 4, {}, ["--preset", "medium", "--colorprim", "bt2020", "--transfer", "smpte2084", "--colormatrix", "bt2020nc", "--chromaloc", "2", "--range", "full"]),
+    "cli_vui_sar_window/": ((416, 240), 4, 8, 2, {}, ["--preset", "medium", "--sar", "7:5", "--overscan", "crop", "--videoformat", "pal", "--display-window", "8,4,8,4"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {

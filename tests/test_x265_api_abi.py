@@ -86,7 +86,10 @@ _MEMBERS_I = ["bEnableWavefront", "frameNumThreads", "internalBitDepth", "intern
               "bEnableTemporalMvp", "bEnableWeightedPred", "bEnableWeightedBiPred", "bEnableLoopFilter", "bEnableSAO", "rdLevel", "bEnableEarlySkip", "recursionSkipMode", "bEnableFastIntra",
               "bIntraInBFrames", "maxNumReferences", "bEmitInfoSEI", "bAnnexB", "maxSlices", "rc_rateControlMode", "rc_qp", "rc_aqMode", "rc_cuTree", "rc_qpMin", "rc_qpMax", "rc_qgSize", "rc_hevcAq",
               "rc_qpStep", "rc_vbvBufferSize", "rc_vbvMaxBitrate", "rc_bitrate", "bLossless", "bRepeatHeaders", "levelIdc", "rc_bEnableGrain", "rc_bEnableConstVbv",
-              "deblockingFilterBetaOffset", "deblockingFilterTCOffset", "bHistBasedSceneCut"]
+              "deblockingFilterBetaOffset", "deblockingFilterTCOffset", "bHistBasedSceneCut", "vui_aspectRatioIdc", "vui_sarWidth", "vui_sarHeight", "vui_bEnableOverscanInfoPresentFlag",
+              "vui_bEnableOverscanAppropriateFlag", "vui_bEnableVideoSignalTypePresentFlag", "vui_videoFormat", "vui_bEnableVideoFullRangeFlag", "vui_bEnableColorDescriptionPresentFlag",
+              "vui_colorPrimaries", "vui_transferCharacteristics", "vui_matrixCoeffs", "vui_bEnableChromaLocInfoPresentFlag", "vui_chromaSampleLocTypeTopField",
+              "vui_chromaSampleLocTypeBottomField", "vui_bEnableDefaultDisplayWindowFlag", "vui_defDispWinLeftOffset", "vui_defDispWinRightOffset", "vui_defDispWinTopOffset", "vui_defDispWinBottomOffset"]
 _MEMBERS_D = ["psyRd", "psyRdoq", "rc_ipFactor", "rc_pbFactor", "rc_rfConstant", "rc_aqStrength", "rc_qCompress"]
 
 
@@ -132,7 +135,9 @@ PARSE_CASES = [("crf", "23.5"), ("qp", "30"), ("bframes", "3"), ("b-adapt", "1")
                ("no-cutree", None), ("qcomp", "0.7"), ("ipratio", "1.3"), ("pbratio", "1.2"), ("qg-size", "64"), ("rc-lookahead", "30"), ("lookahead-slices", "0"), ("scenecut", "0"),
                ("tu-intra-depth", "2"), ("tu-inter-depth", "3"), ("limit-refs", "1"), ("limit-modes", None), ("no-early-skip", None), ("rskip", "0"), ("b-intra", "0"), ("no-signhide", None),
                ("no-strong-intra-smoothing", None), ("no-temporal-mvp", None), ("fast-intra", None), ("no-info", None), ("frame-threads", "2"), ("bitrate", "1000"), ("qpmin", "10"), ("qpmax", "40"),
-               ("no-scenecut", None), ("sar", "1"), ("input-res", "416x240"), ("fps", "30000/1001"), ("fps", "25"), ("rd", "x"), ("nosuchoption", "1")]
+               ("no-scenecut", None), ("sar", "1"), ("sar", "16:11"), ("sar", "7:5"), ("sar", "x"), ("colorprim", "bt2020"), ("colorprim", "9"), ("colorprim", "nosuch"), ("transfer", "smpte2084"),
+               ("colormatrix", "bt2020nc"), ("range", "full"), ("range", "limited"), ("videoformat", "ntsc"), ("chromaloc", "2"), ("overscan", "crop"), ("overscan", "show"), ("overscan", "what"),
+               ("display-window", "8,4,8,4"), ("display-window", "8,4"), ("input-res", "416x240"), ("fps", "30000/1001"), ("fps", "25"), ("rd", "x"), ("nosuchoption", "1")]
 
 
 @pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")

@@ -17,7 +17,7 @@ extern "C" void x265amd_param_default(x265amd_param* p)
     memset(p, 0, sizeof(*p));
     p->fpsNum = 25; p->fpsDenom = 1;
     p->bframes = 0; p->keyframeMax = 250; p->maxNumReferences = 3; p->qp = 30; p->ipFactor = 1.4f; p->pbFactor = 1.3f;      /* (float literals, as common/param.cpp:276-277 has them) */
-    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32; p->qpMin = 0; p->qpMax = 69;
+    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32; p->qpMin = 0; p->qpMax = 69; p->vuiVideoFormat = 5; p->vuiColorPrimaries = 2; p->vuiTransfer = 2; p->vuiMatrix = 2;
     p->rdLevel = 3; p->limitReferences = 3; p->bEnableEarlySkip = 1; p->recursionSkipMode = 1; p->bIntraInBFrames = 1; p->psyRd = 2.0;
     p->searchMethod = X265AMD_ME_HEX; p->subpelRefine = 2; p->searchRange = 57; p->maxNumMergeCand = 3;
     p->bEnableSignHiding = 1; p->bEnableStrongIntraSmoothing = 1; p->bEnableTemporalMvp = 1; p->tuQTMaxInterDepth = 1; p->tuQTMaxIntraDepth = 1;
@@ -59,7 +59,13 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.log2_min_cu_size = 3; s.log2_diff_max_min_cu_size = 3; s.tu_log2_min = 2; s.tu_log2_max = 5;
     s.tu_max_depth_inter = p.tuQTMaxInterDepth; s.tu_max_depth_intra = p.tuQTMaxIntraDepth;
     s.amp = p.bEnableAMP != 0; s.sao = p.bEnableSAO != 0; s.temporal_mvp = p.bEnableTemporalMvp != 0; s.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0;
-    s.aspect_ratio_idc = p.aspectRatioIdc;
+    s.aspect_ratio_idc = p.aspectRatioIdc; s.sar_width = p.vuiSarWidth; s.sar_height = p.vuiSarHeight;
+    s.overscan_info_present = p.vuiOverscanInfoPresent != 0; s.overscan_appropriate = p.vuiOverscanAppropriate != 0;
+    s.video_signal_type_present = p.vuiVideoSignalTypePresent != 0; s.video_format = p.vuiVideoFormat; s.video_full_range = p.vuiFullRange != 0;
+    s.colour_description_present = p.vuiColorDescriptionPresent != 0; s.colour_primaries = p.vuiColorPrimaries; s.transfer_characteristics = p.vuiTransfer; s.matrix_coefficients = p.vuiMatrix;
+    s.chroma_loc_info_present = p.vuiChromaLocPresent != 0; s.chroma_sample_loc_top = p.vuiChromaLocTop; s.chroma_sample_loc_bottom = p.vuiChromaLocBottom;
+    s.default_display_window = p.vuiDisplayWindow != 0;
+    s.def_disp_win_offsets[0] = p.vuiDispWinLeft; s.def_disp_win_offsets[1] = p.vuiDispWinRight; s.def_disp_win_offsets[2] = p.vuiDispWinTop; s.def_disp_win_offsets[3] = p.vuiDispWinBottom;
     s.emit_timing_info = 1; s.num_units_in_tick = p.fpsDenom; s.time_scale = p.fpsNum;
     s.weighted_pred = p.bEnableWeightedPred != 0; s.weighted_bipred = p.bEnableWeightedBiPred != 0;
     s.sign_hide = p.bEnableSignHiding != 0; s.num_ref_idx_default[0] = s.num_ref_idx_default[1] = 1; s.init_qp_minus26 = 0;
@@ -101,6 +107,9 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->rateControlMode != X265AMD_RC_CRF || (p->rfConstant >= 0 && p->rfConstant <= 51), "rfConstant outside 0..51");
         XA_REQUIRE(p->aqMode >= 0 && p->aqMode <= 3, "aqMode outside 0..3 (the edge-based modes are not built)");
         XA_REQUIRE(p->qpMin >= 0 && p->qpMin <= p->qpMax && p->qpMax <= 69, "qpMin / qpMax outside 0..69 (or crossed)");
+        XA_REQUIRE(p->aspectRatioIdc >= 0 && (p->aspectRatioIdc <= 16 || p->aspectRatioIdc == 255), "aspectRatioIdc outside 0..16 / 255");
+        XA_REQUIRE(p->vuiVideoFormat >= 0 && p->vuiVideoFormat <= 5 && p->vuiColorPrimaries >= 0 && p->vuiColorPrimaries <= 255 && p->vuiTransfer >= 0 && p->vuiTransfer <= 255 &&
+                   p->vuiMatrix >= 0 && p->vuiMatrix <= 255 && p->vuiChromaLocTop >= 0 && p->vuiChromaLocTop <= 5 && p->vuiChromaLocBottom >= 0 && p->vuiChromaLocBottom <= 5, "vui: a value outside its range");
         XA_REQUIRE(!p->aqMode || p->aqStrength >= 0, "aqStrength negative");
         XA_REQUIRE(!p->aqMode || p->qgSize == 32 || p->qgSize == 64, "qgSize: 64 and 32 are built");
         XA_REQUIRE(!p->cuTree || p->aqMode, "cuTree needs adaptive quantisation (Encoder::configure switches it on with cuTree; say aqMode)");

@@ -73,6 +73,8 @@ void abi_param_default(void* p)
     wr<int32_t>(p, X265ABI_PARAM_recursionSkipMode, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSignHiding, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableStrongIntraSmoothing, 1);
     wr<int32_t>(p, X265ABI_PARAM_bEnableTemporalMvp, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableLoopFilter, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSAO, 1);
     wr<int32_t>(p, X265ABI_PARAM_rdLevel, 3); wr<int32_t>(p, X265ABI_PARAM_bIntraInBFrames, 1); wr<double>(p, X265ABI_PARAM_psyRd, 2.0); wr<double>(p, X265ABI_PARAM_psyRdoq, 0.0);
+    wr<int32_t>(p, X265ABI_PARAM_vui_videoFormat, 5); wr<int32_t>(p, X265ABI_PARAM_vui_colorPrimaries, 2); wr<int32_t>(p, X265ABI_PARAM_vui_transferCharacteristics, 2);
+    wr<int32_t>(p, X265ABI_PARAM_vui_matrixCoeffs, 2);         /* unspecified (param.cpp:358-366) */
     wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 2 /* X265_RC_CRF */); wr<int32_t>(p, X265ABI_PARAM_rc_qp, 32); wr<double>(p, X265ABI_PARAM_rc_ipFactor, 1.4f);
     wr<double>(p, X265ABI_PARAM_rc_pbFactor, 1.3f); wr<int32_t>(p, X265ABI_PARAM_rc_aqMode, 2); wr<int32_t>(p, X265ABI_PARAM_rc_cuTree, 1);
     wr<double>(p, X265ABI_PARAM_rc_rfConstant, 28); wr<double>(p, X265ABI_PARAM_rc_aqStrength, 1.0); wr<double>(p, X265ABI_PARAM_rc_qCompress, 0.6);
@@ -242,10 +244,67 @@ int abi_param_parse(void* p, const char* name, const char* value)
         /* the string is kept for the life of the param, as strdup in the reference (param.cpp:949); x265_param_free does not own it either */
         wr<const char*>(p, X265ABI_PARAM_numaPools, value ? strdup(value) : nullptr); return 0;
     }
+    /* the video usability information's options (param.cpp:1173-1240): names from the header's tables, or numbers */
+    auto byName = [&](const char* const* names, bool& err) -> int {
+        if (!value) { err = true; return 0; }
+        for (int i = 0; names[i]; i++) if (!strcmp(value, names[i])) return i;
+        return num(err);
+    };
+    static const char* const sarNames[] = { "unknown", "1:1", "12:11", "10:11", "16:11", "40:33", "24:11", "20:11", "32:11", "80:33", "18:11", "15:11", "64:33", "160:99", "4:3", "3:2", "2:1", 0 };
+    static const char* const formatNames[] = { "component", "pal", "ntsc", "secam", "mac", "unknown", 0 };
+    static const char* const rangeNames[] = { "limited", "full", 0 };
+    static const char* const primNames[] = { "reserved", "bt709", "unknown", "reserved", "bt470m", "bt470bg", "smpte170m", "smpte240m", "film", "bt2020", "smpte428", "smpte431", "smpte432", 0 };
+    static const char* const transferNames[] = { "reserved", "bt709", "unknown", "reserved", "bt470m", "bt470bg", "smpte170m", "smpte240m", "linear", "log100", "log316", "iec61966-2-4", "bt1361e",
+                                                 "iec61966-2-1", "bt2020-10", "bt2020-12", "smpte2084", "smpte428", "arib-std-b67", 0 };
+    static const char* const matrixNames[] = { "gbr", "bt709", "unknown", "", "fcc", "bt470bg", "smpte170m", "smpte240m", "ycgco", "bt2020nc", "bt2020c", "smpte2085", "chroma-derived-nc", "chroma-derived-c", "ictcp", 0 };
     if (!strcmp(key, "sar"))
     {
-        const int v = num(bad); if (bad) return -2;
-        wr<int32_t>(p, X265ABI_PARAM_vui_aspectRatioIdc, v); return 0;
+        int v = byName(sarNames, bad);
+        if (bad)
+        {
+            int w = 0, h = 0;
+            v = 255;            /* X265_EXTENDED_SAR */
+            bad = !value || sscanf(value, "%d:%d", &w, &h) != 2;
+            if (!bad) { wr<int32_t>(p, X265ABI_PARAM_vui_sarWidth, w); wr<int32_t>(p, X265ABI_PARAM_vui_sarHeight, h); }
+        }
+        wr<int32_t>(p, X265ABI_PARAM_vui_aspectRatioIdc, v); return bad ? -2 : 0;
+    }
+    if (!strcmp(key, "overscan"))
+    {
+        if (value && !strcmp(value, "show")) wr<int32_t>(p, X265ABI_PARAM_vui_bEnableOverscanInfoPresentFlag, 1);
+        else if (value && !strcmp(value, "crop")) { wr<int32_t>(p, X265ABI_PARAM_vui_bEnableOverscanInfoPresentFlag, 1); wr<int32_t>(p, X265ABI_PARAM_vui_bEnableOverscanAppropriateFlag, 1); }
+        else if (value && !strcmp(value, "unknown")) wr<int32_t>(p, X265ABI_PARAM_vui_bEnableOverscanInfoPresentFlag, 0);
+        else return -2;
+        return 0;
+    }
+    if (!strcmp(key, "videoformat")) { wr<int32_t>(p, X265ABI_PARAM_vui_bEnableVideoSignalTypePresentFlag, 1); wr<int32_t>(p, X265ABI_PARAM_vui_videoFormat, byName(formatNames, bad)); return bad ? -2 : 0; }
+    if (!strcmp(key, "range")) { wr<int32_t>(p, X265ABI_PARAM_vui_bEnableVideoSignalTypePresentFlag, 1); wr<int32_t>(p, X265ABI_PARAM_vui_bEnableVideoFullRangeFlag, byName(rangeNames, bad)); return bad ? -2 : 0; }
+    if (!strcmp(key, "colorprim") || !strcmp(key, "transfer") || !strcmp(key, "colormatrix"))
+    {
+        wr<int32_t>(p, X265ABI_PARAM_vui_bEnableVideoSignalTypePresentFlag, 1); wr<int32_t>(p, X265ABI_PARAM_vui_bEnableColorDescriptionPresentFlag, 1);
+        if (key[0] == 'c' && key[5] == 'p') wr<int32_t>(p, X265ABI_PARAM_vui_colorPrimaries, byName(primNames, bad));
+        else if (key[0] == 't') wr<int32_t>(p, X265ABI_PARAM_vui_transferCharacteristics, byName(transferNames, bad));
+        else wr<int32_t>(p, X265ABI_PARAM_vui_matrixCoeffs, byName(matrixNames, bad));
+        return bad ? -2 : 0;
+    }
+    if (!strcmp(key, "chromaloc"))
+    {
+        if (!value) return -2;
+        wr<int32_t>(p, X265ABI_PARAM_vui_bEnableChromaLocInfoPresentFlag, 1);
+        wr<int32_t>(p, X265ABI_PARAM_vui_chromaSampleLocTypeTopField, atoi(value)); wr<int32_t>(p, X265ABI_PARAM_vui_chromaSampleLocTypeBottomField, atoi(value));
+        return 0;
+    }
+    if (!strcmp(key, "display-window") || !strcmp(key, "crop-rect"))
+    {
+        int l = 0, t = 0, r = 0, b = 0;
+        wr<int32_t>(p, X265ABI_PARAM_vui_bEnableDefaultDisplayWindowFlag, 1);
+        /* (sscanf straight into the members in the reference: what it got before it failed stays) */
+        const int got = value ? sscanf(value, "%d,%d,%d,%d", &l, &t, &r, &b) : 0;
+        if (got >= 1) wr<int32_t>(p, X265ABI_PARAM_vui_defDispWinLeftOffset, l);
+        if (got >= 2) wr<int32_t>(p, X265ABI_PARAM_vui_defDispWinTopOffset, t);
+        if (got >= 3) wr<int32_t>(p, X265ABI_PARAM_vui_defDispWinRightOffset, r);
+        if (got >= 4) wr<int32_t>(p, X265ABI_PARAM_vui_defDispWinBottomOffset, b);
+        return got == 4 ? 0 : -2;
     }
     return -1;
 }
@@ -301,8 +360,6 @@ void* abi_encoder_open(void* p)
     REQUIRE(!PI(p, analysisReuseMode) && !PI(p, bDynamicRefine) && !PI(p, rdPenalty) && !PI(p, bEnableRdRefine) && !PI(p, dynamicRd) && !PI(p, bSsimRd), "analysis reuse / rd-refine / dynamic-rd / ssim-rd are not built");
     REQUIRE(!PI(p, bDistributeModeAnalysis) && !PI(p, bDistributeMotionEstimation), "pmode / pme are not built");
     REQUIRE(!PI(p, bAQMotion) && !PI(p, gopLookahead) && !PI(p, radl) && !PI(p, bEnableSceneCutAwareQp) && !PI(p, bEnableFades), "aq-motion / gop-lookahead / radl / scenecut-aware-qp / fades are not built");
-    REQUIRE(!PI(p, vui_bEnableVideoSignalTypePresentFlag) && !PI(p, vui_bEnableOverscanInfoPresentFlag) && !PI(p, vui_bEnableChromaLocInfoPresentFlag) &&
-            !PI(p, vui_bEnableDefaultDisplayWindowFlag) && PI(p, vui_aspectRatioIdc) != 255, "vui: only aspectRatioIdc (not extended SAR) is written");
     REQUIRE(PI(p, levelIdc) == 0, "levelIdc: the level is derived (determineLevel), not forced");
     REQUIRE(PI(p, searchMethod) == 0 || PI(p, searchMethod) == 1 || PI(p, searchMethod) == 3, "searchMethod: only dia, hex and star are built");
 #undef REQUIRE
@@ -329,6 +386,14 @@ void* abi_encoder_open(void* p)
         if (pools && (!strcmp(pools, "none") || !strcmp(pools, "NONE") || !strcmp(pools, "0"))) q.bEnableWavefront = 0;
     }
     q.aspectRatioIdc = PI(p, vui_aspectRatioIdc); q.rdoqLevel = PI(p, rdoqLevel);
+    q.vuiSarWidth = PI(p, vui_sarWidth); q.vuiSarHeight = PI(p, vui_sarHeight);
+    q.vuiOverscanInfoPresent = PI(p, vui_bEnableOverscanInfoPresentFlag); q.vuiOverscanAppropriate = PI(p, vui_bEnableOverscanAppropriateFlag);
+    q.vuiVideoSignalTypePresent = PI(p, vui_bEnableVideoSignalTypePresentFlag); q.vuiVideoFormat = PI(p, vui_videoFormat); q.vuiFullRange = PI(p, vui_bEnableVideoFullRangeFlag);
+    q.vuiColorDescriptionPresent = PI(p, vui_bEnableColorDescriptionPresentFlag); q.vuiColorPrimaries = PI(p, vui_colorPrimaries); q.vuiTransfer = PI(p, vui_transferCharacteristics);
+    q.vuiMatrix = PI(p, vui_matrixCoeffs);
+    q.vuiChromaLocPresent = PI(p, vui_bEnableChromaLocInfoPresentFlag); q.vuiChromaLocTop = PI(p, vui_chromaSampleLocTypeTopField); q.vuiChromaLocBottom = PI(p, vui_chromaSampleLocTypeBottomField);
+    q.vuiDisplayWindow = PI(p, vui_bEnableDefaultDisplayWindowFlag); q.vuiDispWinLeft = PI(p, vui_defDispWinLeftOffset); q.vuiDispWinRight = PI(p, vui_defDispWinRightOffset);
+    q.vuiDispWinTop = PI(p, vui_defDispWinTopOffset); q.vuiDispWinBottom = PI(p, vui_defDispWinBottomOffset);
     q.psyRdoqFix8 = q.rdoqLevel ? (int32_t)(PD(p, psyRdoq) * 256.0) : 0;         /* Quant::init: m_psyRdoqScale = (int32_t)(psyScale * 256.0) (quant.cpp:188) */
     q.bEnableFastIntra = PI(p, bEnableFastIntra);
     /* frame threads: 0 = by core count, which is more than one on any machine with four cores or more (threadpool.cpp:661-677); the stream of the
