@@ -988,6 +988,13 @@ size_t x265amd_write_stream_headers(const x265amd_stream_params* p, uint8_t* out
 /* the user-data SEI NAL unit (prefix SEI, payload type 5 with the reference's UUID) that carries the encoder's name and option string behind the parameter sets when
  * param.bEmitInfoSEI is set (reference: source/encoder/encoder.cpp:3260-3280, sei.h:89-117); returns its size behind a 4-byte start code, 0 when it does not fit */
 size_t x265amd_write_info_sei(const char* text, uint8_t* out, size_t cap);
+/* one SEI message as a NAL unit of its own (prefix 39 / suffix 40; SEI::writeSEImessages, sei.cpp:39-73) and the access unit delimiter (Entropy::codeAUD; slice_type 0 B, 1 P, 2 I):
+ * host code, the unit's size or 0 */
+size_t x265amd_write_sei(int suffix, int payload_type, const uint8_t* payload, size_t n, uint8_t* out, size_t cap);
+size_t x265amd_write_aud(int slice_type, uint8_t* out, size_t cap);
+/* the decoded picture hash SEI's payload for a reconstructed 4:2:0 picture in host memory (--hash: method 1 MD5, 2 CRC, 3 checksum; H.265 D.3.19 as the reference computes it,
+ * frameencoder.cpp:1228-1296): hash_type + the three planes' digests; host code (host/picture_hash.cpp).  Returns the payload's size or 0 */
+size_t x265amd_picture_hash(int method, const void* const planes[3], const intptr_t strides[3], int width, int height, int depth, int ctu_size, uint8_t* payload, size_t cap);
 
 /* FrameEncoder::encodeSlice (reference: source/encoder/frameencoder.cpp:1298-1370): the final CABAC pass over a decided picture -> sub-streams
  * (one per CTU row when si->wpp, else one).  sao / sao_flags (may be NULL): the SAO parameters of every CTU (reserved[0] = merge mode: 0 none,

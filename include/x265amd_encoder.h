@@ -125,6 +125,16 @@ typedef struct x265amd_param
     int32_t vuiChromaLocPresent, vuiChromaLocTop, vuiChromaLocBottom;
     int32_t vuiDisplayWindow, vuiDispWinLeft, vuiDispWinRight, vuiDispWinTop, vuiDispWinBottom;
     int32_t reserved3;
+    /* units around the slices (signalling only) */
+    int32_t bEnableAccessUnitDelimiters;    /* param.bEnableAccessUnitDelimiters (--aud): an access unit delimiter in front of every picture but the first -- of every picture with
+                                             * bRepeatHeaders (frameencoder.cpp:497-506) */
+    int32_t bEmitHDR10SEI, bEmitCLL;        /* param.bEmitHDR10SEI (--hdr10; x265_check_params switches it on with any of the values below), param.bEmitCLL (--cll, the default):
+                                             * the content light level and mastering display colour volume SEI units behind the parameter sets (encoder.cpp:3264-3282) */
+    int32_t maxCLL, maxFALL;                /* --max-cll "cll,fall" */
+    int32_t hasMasteringDisplay;            /* --master-display "G(x,y)B(x,y)R(x,y)WP(x,y)L(max,min)": the ten numbers below */
+    uint32_t masteringDisplay[10];
+    int32_t decodedPictureHashSEI;          /* param.decodedPictureHashSEI (--hash): 0 none, 1 MD5, 2 CRC, 3 checksum of each reconstructed picture in a suffix SEI unit */
+    int32_t reserved4;
 } x265amd_param;
 enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 

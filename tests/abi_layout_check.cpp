@@ -31,7 +31,7 @@ PIC(pts); PIC(dts); PIC(planes); PIC(stride); PIC(bitDepth); PIC(sliceType); PIC
 #define API(f) static_assert(offsetof(x265_api, f) == X265ABI_API_##f, #f)
 API(api_major_version); API(bit_depth); API(version_str); API(param_alloc); API(encoder_open); API(encoder_encode); API(encoder_close); API(cleanup); API(sizeof_frame_stats);
 API(encoder_intra_refresh); API(zone_param_parse);
-P(csvfn); P(csvfpt); P(csvLogLevel); P(maxCLL); P(maxFALL);
+P(csvfn); P(csvfpt); P(csvLogLevel); P(maxCLL); P(maxFALL); P(bEmitHDR10SEI); P(bEmitCLL); P(masteringDisplayColorVolume);
 PN(rc_bEnableGrain, rc.bEnableGrain); PN(rc_bEnableConstVbv, rc.bEnableConstVbv);
 PN(vui_bEnableOverscanAppropriateFlag, vui.bEnableOverscanAppropriateFlag); PN(vui_videoFormat, vui.videoFormat); PN(vui_bEnableVideoFullRangeFlag, vui.bEnableVideoFullRangeFlag); PN(vui_bEnableColorDescriptionPresentFlag, vui.bEnableColorDescriptionPresentFlag); PN(vui_colorPrimaries, vui.colorPrimaries); PN(vui_transferCharacteristics, vui.transferCharacteristics); PN(vui_matrixCoeffs, vui.matrixCoeffs); PN(vui_chromaSampleLocTypeTopField, vui.chromaSampleLocTypeTopField); PN(vui_chromaSampleLocTypeBottomField, vui.chromaSampleLocTypeBottomField); PN(vui_defDispWinLeftOffset, vui.defDispWinLeftOffset); PN(vui_defDispWinRightOffset, vui.defDispWinRightOffset); PN(vui_defDispWinTopOffset, vui.defDispWinTopOffset); PN(vui_defDispWinBottomOffset, vui.defDispWinBottomOffset);
 #define ST(f) static_assert(offsetof(x265_stats, f) == X265ABI_STATS_##f, #f)

@@ -3028,7 +3028,9 @@ class EncParam(C.Structure):
                 ("qgSize", C.c_int32), ("bEmitInfoSEI", C.c_int32), ("qpMin", C.c_int32), ("qpMax", C.c_int32), ("bRepeatHeaders", C.c_int32), ("reserved2", C.c_int32), ("vuiSarWidth", C.c_int32), ("vuiSarHeight", C.c_int32), ("vuiOverscanInfoPresent", C.c_int32),
                 ("vuiOverscanAppropriate", C.c_int32), ("vuiVideoSignalTypePresent", C.c_int32), ("vuiVideoFormat", C.c_int32), ("vuiFullRange", C.c_int32), ("vuiColorDescriptionPresent", C.c_int32),
                 ("vuiColorPrimaries", C.c_int32), ("vuiTransfer", C.c_int32), ("vuiMatrix", C.c_int32), ("vuiChromaLocPresent", C.c_int32), ("vuiChromaLocTop", C.c_int32), ("vuiChromaLocBottom", C.c_int32),
-                ("vuiDisplayWindow", C.c_int32), ("vuiDispWinLeft", C.c_int32), ("vuiDispWinRight", C.c_int32), ("vuiDispWinTop", C.c_int32), ("vuiDispWinBottom", C.c_int32), ("reserved3", C.c_int32)]
+                ("vuiDisplayWindow", C.c_int32), ("vuiDispWinLeft", C.c_int32), ("vuiDispWinRight", C.c_int32), ("vuiDispWinTop", C.c_int32), ("vuiDispWinBottom", C.c_int32), ("reserved3", C.c_int32),
+                ("bEnableAccessUnitDelimiters", C.c_int32), ("bEmitHDR10SEI", C.c_int32), ("bEmitCLL", C.c_int32), ("maxCLL", C.c_int32), ("maxFALL", C.c_int32), ("hasMasteringDisplay", C.c_int32),
+                ("masteringDisplay", C.c_uint32 * 10), ("decodedPictureHashSEI", C.c_int32), ("reserved4", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3683,6 +3685,13 @@ CLI_CASES = {
     "cli_vui_bt709/": ((416, 240), 4, 8, 2, {}, ["--preset", "medium", "--colorprim", "bt709", "--transfer", "bt709", "--colormatrix", "bt709", "--range", "limited"]),
     "cli_vui_hdr_hbd/": ((416, 240), 4, 10, 4, {}, ["--preset", "medium", "--colorprim", "bt2020", "--transfer", "smpte2084", "--colormatrix", "bt2020nc", "--chromaloc", "2", "--range", "full"]),
     "cli_vui_sar_window/": ((416, 240), 4, 8, 2, {}, ["--preset", "medium", "--sar", "7:5", "--overscan", "crop", "--videoformat", "pal", "--display-window", "8,4,8,4"]),
+    # units around the slices: HDR10's SEI units with repeated parameter sets, access unit delimiters, the decoded picture hash in its three forms
+    "cli_hdr10_hbd/": ((416, 240), 12, 10, 4, {}, ["--preset", "medium", "--colorprim", "bt2020", "--transfer", "smpte2084", "--colormatrix", "bt2020nc", "--master-display",
+                                                   "G(13250,34500)B(7500,3000)R(34000,16000)WP(15635,16450)L(10000000,5)", "--max-cll", "1000,400", "--repeat-headers", "--keyint", "6", "--no-scenecut"]),
+    "cli_aud_md5/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--aud", "--hash", "1"]),
+    "cli_crc_hbd_odd/": ((424, 232), 8, 10, 4, {}, ["--preset", "medium", "--hash", "2"]),
+    "cli_checksum_aud_repeat/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--hash", "3", "--aud", "--repeat-headers"]),
+    "cli_maxcll_only/": ((416, 240), 4, 8, 2, {}, ["--preset", "medium", "--max-cll", "600,0"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {

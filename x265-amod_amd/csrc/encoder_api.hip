@@ -17,7 +17,7 @@ extern "C" void x265amd_param_default(x265amd_param* p)
     memset(p, 0, sizeof(*p));
     p->fpsNum = 25; p->fpsDenom = 1;
     p->bframes = 0; p->keyframeMax = 250; p->maxNumReferences = 3; p->qp = 30; p->ipFactor = 1.4f; p->pbFactor = 1.3f;      /* (float literals, as common/param.cpp:276-277 has them) */
-    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32; p->qpMin = 0; p->qpMax = 69; p->vuiVideoFormat = 5; p->vuiColorPrimaries = 2; p->vuiTransfer = 2; p->vuiMatrix = 2;
+    p->rateControlMode = X265AMD_RC_CQP; p->rfConstant = 28; p->aqStrength = 1.0; p->qCompress = 0.6; p->aqMode = 0; p->cuTree = 0; p->qgSize = 32; p->qpMin = 0; p->qpMax = 69; p->vuiVideoFormat = 5; p->vuiColorPrimaries = 2; p->vuiTransfer = 2; p->vuiMatrix = 2; p->bEmitCLL = 1;
     p->rdLevel = 3; p->limitReferences = 3; p->bEnableEarlySkip = 1; p->recursionSkipMode = 1; p->bIntraInBFrames = 1; p->psyRd = 2.0;
     p->searchMethod = X265AMD_ME_HEX; p->subpelRefine = 2; p->searchRange = 57; p->maxNumMergeCand = 3;
     p->bEnableSignHiding = 1; p->bEnableStrongIntraSmoothing = 1; p->bEnableTemporalMvp = 1; p->tuQTMaxInterDepth = 1; p->tuQTMaxIntraDepth = 1;
@@ -86,6 +86,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         norm.keyframeMax = 1; norm.keyframeMin = 1; norm.bFrameAdaptive = 0; norm.bframes = 0; norm.bOpenGOP = 0; norm.bRepeatHeaders = 1; norm.lookaheadDepth = 0;
         norm.scenecutThreshold = 0; norm.cuTree = 0; norm.bEnableWeightedPred = 0; norm.bEnableWeightedBiPred = 0; norm.maxNumReferences = 1;
     }
+    /* the HDR10 SEI units come with the parameter sets at every keyframe ("Turning on repeat-headers for HDR compatibility", encoder.cpp:4347-4353) */
+    if (norm.bEmitHDR10SEI || norm.hasMasteringDisplay || norm.maxCLL || norm.maxFALL) { norm.bEmitHDR10SEI = 1; norm.bRepeatHeaders = 1; }
     if (norm.rateControlMode != X265AMD_RC_CRF) { norm.aqMode = 0; norm.cuTree = 0; }
     if (norm.lookaheadDepth == 0) norm.cuTree = 0;
     if (!norm.aqMode && norm.cuTree) { norm.aqMode = 1; norm.aqStrength = 0.0; }
@@ -108,6 +110,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->aqMode >= 0 && p->aqMode <= 3, "aqMode outside 0..3 (the edge-based modes are not built)");
         XA_REQUIRE(p->qpMin >= 0 && p->qpMin <= p->qpMax && p->qpMax <= 69, "qpMin / qpMax outside 0..69 (or crossed)");
         XA_REQUIRE(p->aspectRatioIdc >= 0 && (p->aspectRatioIdc <= 16 || p->aspectRatioIdc == 255), "aspectRatioIdc outside 0..16 / 255");
+        XA_REQUIRE(p->decodedPictureHashSEI >= 0 && p->decodedPictureHashSEI <= 3 && p->maxCLL >= 0 && p->maxCLL <= 65535 && p->maxFALL >= 0 && p->maxFALL <= 65535, "decodedPictureHashSEI outside 0..3 or a light level outside 16 bits");
         XA_REQUIRE(p->vuiVideoFormat >= 0 && p->vuiVideoFormat <= 5 && p->vuiColorPrimaries >= 0 && p->vuiColorPrimaries <= 255 && p->vuiTransfer >= 0 && p->vuiTransfer <= 255 &&
                    p->vuiMatrix >= 0 && p->vuiMatrix <= 255 && p->vuiChromaLocTop >= 0 && p->vuiChromaLocTop <= 5 && p->vuiChromaLocBottom >= 0 && p->vuiChromaLocBottom <= 5, "vui: a value outside its range");
         XA_REQUIRE(!p->aqMode || p->aqStrength >= 0, "aqStrength negative");
@@ -249,6 +252,27 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     const size_t n = x265amd_write_stream_headers(&sp, e->headerBytes.data(), e->headerBytes.size());
     if (!n || n > e->headerBytes.size()) { xa_fail(X265AMD_EINVAL, "encoder_open: stream headers"); return nullptr; }
     e->headerBytes.resize(n);
+    if (p->bEmitHDR10SEI || p->hasMasteringDisplay || p->maxCLL || p->maxFALL)
+    {
+        /* Encoder::getStreamHeaders (encoder.cpp:3264-3282): content light level (payload type 144), then the mastering display colour volume (137) */
+        uint8_t sei[64], payload[24];
+        if (p->bEmitCLL)
+        {
+            payload[0] = (uint8_t)(p->maxCLL >> 8); payload[1] = (uint8_t)p->maxCLL; payload[2] = (uint8_t)(p->maxFALL >> 8); payload[3] = (uint8_t)p->maxFALL;
+            const size_t m = x265amd_write_sei(0, 144, payload, 4, sei, sizeof(sei));
+            if (!m) { xa_fail(X265AMD_EINVAL, "encoder_open: content light level SEI"); return nullptr; }
+            e->headerBytes.insert(e->headerBytes.end(), sei, sei + m);
+        }
+        if (p->hasMasteringDisplay)
+        {
+            for (int i = 0; i < 8; i++) { payload[2 * i] = (uint8_t)(p->masteringDisplay[i] >> 8); payload[2 * i + 1] = (uint8_t)p->masteringDisplay[i]; }
+            for (int i = 0; i < 2; i++)
+                for (int k = 0; k < 4; k++) payload[16 + 4 * i + k] = (uint8_t)(p->masteringDisplay[8 + i] >> (24 - 8 * k));
+            const size_t m = x265amd_write_sei(0, 137, payload, 24, sei, sizeof(sei));
+            if (!m) { xa_fail(X265AMD_EINVAL, "encoder_open: mastering display SEI"); return nullptr; }
+            e->headerBytes.insert(e->headerBytes.end(), sei, sei + m);
+        }
+    }
     if (p->bEmitInfoSEI)
     {
         /* Encoder::getStreamHeaders' fourth unit (encoder.cpp:3260-3280): who coded this and with what -- the reference's own text names ITS build, this one names this library */
@@ -654,10 +678,20 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     }
     e->outBytes.swap(front->nalBytes);
     /* --repeat-headers (and every all-intra encode): the parameter sets in front of a keyframe's slice units (FrameEncoder::compressFrame, frameencoder.cpp:465-480) */
-    if (e->p.bRepeatHeaders && front->bKeyframe && !e->outBytes.empty())
+    const bool withAud = e->p.bEnableAccessUnitDelimiters && (front->poc || e->p.bRepeatHeaders) && !e->outBytes.empty();
+    const bool withHeaders = e->p.bRepeatHeaders && front->bKeyframe && !e->outBytes.empty();
+    if (withAud || withHeaders)
     {
-        /* ... and the slice units are no longer the first of their access unit: start codes of three bytes (nal.cpp:110-118) */
-        std::vector<uint8_t> au(e->headerBytes);
+        /* ... and the slice units are no longer the first of their access unit: start codes of three bytes (nal.cpp:110-118).  --aud: the delimiter opens the access unit
+         * (frameencoder.cpp:497-506), the parameter sets follow it */
+        std::vector<uint8_t> au;
+        if (withAud)
+        {
+            uint8_t aud[16];
+            const size_t m = x265amd_write_aud(isBType(front->type) ? 0 : front->type == TYPE_P ? 1 : 2, aud, sizeof(aud));
+            au.insert(au.end(), aud, aud + m);
+        }
+        if (withHeaders) au.insert(au.end(), e->headerBytes.begin(), e->headerBytes.end());
         const std::vector<uint8_t>& b = e->outBytes;
         for (size_t i = 0; i < b.size(); i++)
         {
@@ -665,6 +699,21 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
             au.push_back(b[i]);
         }
         e->outBytes.swap(au);
+    }
+    bool haveStaging = false;
+    if (e->p.decodedPictureHashSEI && !e->outBytes.empty())
+    {
+        /* --hash: the digest of the finished picture in a suffix SEI unit behind its slice units (FrameEncoder::writeTrailingSEIMessages, frameencoder.cpp:418-460) */
+        e->staging.resize(e->picElems);
+        if (hipMemcpy(e->staging.data(), front->finalPlanes(), e->picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder: recon download"); return -1; }
+        haveStaging = true;
+        const void* planes[3] = { e->staging.data() + e->org[0], e->staging.data() + e->org[1], e->staging.data() + e->org[2] };
+        const intptr_t strides[3] = { (intptr_t)(e->stride * sizeof(pixel)), (intptr_t)(e->cstride * sizeof(pixel)), (intptr_t)(e->cstride * sizeof(pixel)) };
+        uint8_t payload[64], sei[96];
+        const size_t n = x265amd_picture_hash(e->p.decodedPictureHashSEI, planes, strides, e->W, e->H, X265AMD_DEPTH, 64, payload, sizeof(payload));
+        const size_t m = n ? x265amd_write_sei(1, 132, payload, n, sei, sizeof(sei)) : 0;
+        if (!m) { xa_fail(X265AMD_EINVAL, "encoder: picture hash SEI"); return -1; }
+        e->outBytes.insert(e->outBytes.end(), sei, sei + m);
     }
     splitNals(e->outBytes, e->nals);
     if (!e->outBytes.empty())
@@ -682,7 +731,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
     if (picOut)
     {
         e->staging.resize(e->picElems);
-        if (hipMemcpy(e->staging.data(), front->finalPlanes(), e->picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder: recon download"); return -1; }
+        if (!haveStaging && hipMemcpy(e->staging.data(), front->finalPlanes(), e->picElems * sizeof(pixel), hipMemcpyDeviceToHost) != hipSuccess) { xa_fail(X265AMD_EHIP, "encoder: recon download"); return -1; }
         for (int k = 0; k < 3; k++)
         {
             if (!picOut->planes[k]) continue;

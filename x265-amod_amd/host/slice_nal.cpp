@@ -85,7 +85,41 @@ extern "C" size_t x265amd_write_info_sei(const char* text, uint8_t* out, size_t 
     for (size_t i = 0; i < len; i++) b.put((uint8_t)text[i], 8);
     b.align();                                      /* rbsp_trailing_bits */
     std::vector<uint8_t> nal;
-    serialize(nal, 39, 1, true, b.out);
+    serialize(nal, 39, 1, false, b.out);            /* (never the first unit of its list: a start code of three bytes, nal.cpp:110-118) */
+    if (nal.size() > cap) return 0;
+    memcpy(out, nal.data(), nal.size());
+    return nal.size();
+}
+
+/* An SEI unit with one message (SEI::writeSEImessages, sei.cpp:39-73): payload type and size in their 0xff-escaped form, the payload, rbsp trailing bits; prefix (NAL type 39) or
+ * suffix (40), behind a start code of three bytes (it is never the first unit of an access unit).  Returns the unit's size, 0 when it does not fit. */
+extern "C" size_t x265amd_write_sei(int suffix, int payload_type, const uint8_t* payload, size_t n, uint8_t* out, size_t cap)
+{
+    if (!out || (n && !payload) || payload_type < 0) return 0;
+    Bits b;
+    int t = payload_type;
+    for (; t >= 0xff; t -= 0xff) b.put(0xff, 8);
+    b.put((uint32_t)t, 8);
+    size_t size = n;
+    for (; size >= 0xff; size -= 0xff) b.put(0xff, 8);
+    b.put((uint32_t)size, 8);
+    for (size_t i = 0; i < n; i++) b.put(payload[i], 8);
+    b.align();
+    std::vector<uint8_t> nal;
+    serialize(nal, suffix ? 40 : 39, 1, false, b.out);
+    if (nal.size() > cap) return 0;
+    memcpy(out, nal.data(), nal.size());
+    return nal.size();
+}
+/* the access unit delimiter (Entropy::codeAUD, entropy.cpp:570-591): pic_type 0 / 1 / 2 for I / P / B, behind a start code of four bytes (it opens its access unit) */
+extern "C" size_t x265amd_write_aud(int slice_type, uint8_t* out, size_t cap)
+{
+    if (!out) return 0;
+    Bits b;
+    b.put((uint32_t)(slice_type == 2 ? 0 : slice_type == 1 ? 1 : 2), 3);       /* x265amd_slice_info.slice_type: 0 B, 1 P, 2 I */
+    b.align();
+    std::vector<uint8_t> nal;
+    serialize(nal, 35, 1, true, b.out);
     if (nal.size() > cap) return 0;
     memcpy(out, nal.data(), nal.size());
     return nal.size();

@@ -73,6 +73,7 @@ void abi_param_default(void* p)
     wr<int32_t>(p, X265ABI_PARAM_recursionSkipMode, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSignHiding, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableStrongIntraSmoothing, 1);
     wr<int32_t>(p, X265ABI_PARAM_bEnableTemporalMvp, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableLoopFilter, 1); wr<int32_t>(p, X265ABI_PARAM_bEnableSAO, 1);
     wr<int32_t>(p, X265ABI_PARAM_rdLevel, 3); wr<int32_t>(p, X265ABI_PARAM_bIntraInBFrames, 1); wr<double>(p, X265ABI_PARAM_psyRd, 2.0); wr<double>(p, X265ABI_PARAM_psyRdoq, 0.0);
+    wr<int32_t>(p, X265ABI_PARAM_bEmitCLL, 1);
     wr<int32_t>(p, X265ABI_PARAM_vui_videoFormat, 5); wr<int32_t>(p, X265ABI_PARAM_vui_colorPrimaries, 2); wr<int32_t>(p, X265ABI_PARAM_vui_transferCharacteristics, 2);
     wr<int32_t>(p, X265ABI_PARAM_vui_matrixCoeffs, 2);         /* unspecified (param.cpp:358-366) */
     wr<int32_t>(p, X265ABI_PARAM_rc_rateControlMode, 2 /* X265_RC_CRF */); wr<int32_t>(p, X265ABI_PARAM_rc_qp, 32); wr<double>(p, X265ABI_PARAM_rc_ipFactor, 1.4f);
@@ -191,7 +192,8 @@ int abi_param_parse(void* p, const char* name, const char* value)
         { "temporal-mvp", X265ABI_PARAM_bEnableTemporalMvp }, { "weightp", X265ABI_PARAM_bEnableWeightedPred }, { "weightb", X265ABI_PARAM_bEnableWeightedBiPred },
         { "deblock", X265ABI_PARAM_bEnableLoopFilter }, { "sao", X265ABI_PARAM_bEnableSAO }, { "early-skip", X265ABI_PARAM_bEnableEarlySkip }, { "fast-intra", X265ABI_PARAM_bEnableFastIntra },
         { "b-intra", X265ABI_PARAM_bIntraInBFrames }, { "limit-modes", X265ABI_PARAM_limitModes }, { "cutree", X265ABI_PARAM_rc_cuTree }, { "info", X265ABI_PARAM_bEmitInfoSEI },
-        { "annexb", X265ABI_PARAM_bAnnexB }, { "repeat-headers", X265ABI_PARAM_bRepeatHeaders }, { "tskip", X265ABI_PARAM_bEnableTransformSkip }, { "lossless", X265ABI_PARAM_bLossless } };
+        { "annexb", X265ABI_PARAM_bAnnexB }, { "repeat-headers", X265ABI_PARAM_bRepeatHeaders }, { "aud", X265ABI_PARAM_bEnableAccessUnitDelimiters }, { "hdr10", X265ABI_PARAM_bEmitHDR10SEI },
+        { "hdr", X265ABI_PARAM_bEmitHDR10SEI }, { "cll", X265ABI_PARAM_bEmitCLL }, { "tskip", X265ABI_PARAM_bEnableTransformSkip }, { "lossless", X265ABI_PARAM_bLossless } };
     for (const auto& sw : switches)
         if (!strcmp(key, sw.name)) { const int v = truth(bad); if (bad) return -2; wr<int32_t>(p, sw.off, v); return 0; }
     if (neg && !strcmp(key, "scenecut")) { wr<int32_t>(p, X265ABI_PARAM_scenecutThreshold, 0); return 0; }          /* --no-scenecut (param.cpp: atobool of "false") */
@@ -287,6 +289,16 @@ int abi_param_parse(void* p, const char* name, const char* value)
         else wr<int32_t>(p, X265ABI_PARAM_vui_matrixCoeffs, byName(matrixNames, bad));
         return bad ? -2 : 0;
     }
+    if (!strcmp(key, "hash")) { if (!value) return -2; wr<int32_t>(p, X265ABI_PARAM_decodedPictureHashSEI, atoi(value)); return 0; }
+    if (!strcmp(key, "master-display")) { wr<const char*>(p, X265ABI_PARAM_masteringDisplayColorVolume, value ? strdup(value) : nullptr); return value ? 0 : -2; }
+    if (!strcmp(key, "max-cll"))
+    {
+        unsigned short a = 0, b = 0;
+        const int got = value ? sscanf(value, "%hu,%hu", &a, &b) : 0;
+        if (got >= 1) wr<uint16_t>(p, X265ABI_PARAM_maxCLL, a);
+        if (got >= 2) wr<uint16_t>(p, X265ABI_PARAM_maxFALL, b);
+        return got == 2 ? 0 : -2;
+    }
     if (!strcmp(key, "chromaloc"))
     {
         if (!value) return -2;
@@ -355,7 +367,7 @@ void* abi_encoder_open(void* p)
     REQUIRE(!PI(p, noiseReductionIntra) && !PI(p, noiseReductionInter) && !rd<const char*>(p, X265ABI_PARAM_scalingLists), "noise reduction / scaling lists are not built");
     REQUIRE(!PI(p, cbQpOffset) && !PI(p, crQpOffset) && !PI(p, deblockingFilterTCOffset) && !PI(p, deblockingFilterBetaOffset), "chroma QP / deblocking offsets must be 0");
     REQUIRE(!PI(p, bSaoNonDeblocked) && !PI(p, selectiveSAO), "sao-non-deblock / selective-sao are not built");
-    REQUIRE(!PI(p, bEnableAccessUnitDelimiters) && !PI(p, bEmitHRDSEI) && !PI(p, decodedPictureHashSEI), "AUD / HRD SEI / hash SEI are not built");
+    REQUIRE(!PI(p, bEmitHRDSEI), "the HRD SEI (bEmitHRDSEI) is not built");
     REQUIRE(!PI(p, bEnableTemporalSubLayers) && !PI(p, uhdBluray) && !PI(p, bEnableSvtHevc), "temporal layers / uhd-bd / svt are not built");
     REQUIRE(!PI(p, analysisReuseMode) && !PI(p, bDynamicRefine) && !PI(p, rdPenalty) && !PI(p, bEnableRdRefine) && !PI(p, dynamicRd) && !PI(p, bSsimRd), "analysis reuse / rd-refine / dynamic-rd / ssim-rd are not built");
     REQUIRE(!PI(p, bDistributeModeAnalysis) && !PI(p, bDistributeMotionEstimation), "pmode / pme are not built");
@@ -386,6 +398,24 @@ void* abi_encoder_open(void* p)
         if (pools && (!strcmp(pools, "none") || !strcmp(pools, "NONE") || !strcmp(pools, "0"))) q.bEnableWavefront = 0;
     }
     q.aspectRatioIdc = PI(p, vui_aspectRatioIdc); q.rdoqLevel = PI(p, rdoqLevel);
+    q.bEnableAccessUnitDelimiters = PI(p, bEnableAccessUnitDelimiters) != 0; q.decodedPictureHashSEI = PI(p, decodedPictureHashSEI);
+    q.maxCLL = rd<uint16_t>(p, X265ABI_PARAM_maxCLL); q.maxFALL = rd<uint16_t>(p, X265ABI_PARAM_maxFALL); q.bEmitCLL = PI(p, bEmitCLL) != 0;
+    {
+        /* x265_check_params (param.cpp:1875-1876): any of the values switches the SEI units on; SEIMasteringDisplayColorVolume::parse (sei.h:205-213) */
+        const char* md = rd<const char*>(p, X265ABI_PARAM_masteringDisplayColorVolume);
+        q.bEmitHDR10SEI = PI(p, bEmitHDR10SEI) != 0 || md || q.maxCLL || q.maxFALL;
+        unsigned short v[8]; unsigned l[2];
+        if (md)
+        {
+            if (sscanf(md, "G(%hu,%hu)B(%hu,%hu)R(%hu,%hu)WP(%hu,%hu)L(%u,%u)", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &l[0], &l[1]) == 10)
+            {
+                q.hasMasteringDisplay = 1;
+                for (int i = 0; i < 8; i++) q.masteringDisplay[i] = v[i];
+                q.masteringDisplay[8] = l[0]; q.masteringDisplay[9] = l[1];
+            }
+            else fprintf(stderr, "x265amd [warning]: unable to parse mastering display color volume info\n");
+        }
+    }
     q.vuiSarWidth = PI(p, vui_sarWidth); q.vuiSarHeight = PI(p, vui_sarHeight);
     q.vuiOverscanInfoPresent = PI(p, vui_bEnableOverscanInfoPresentFlag); q.vuiOverscanAppropriate = PI(p, vui_bEnableOverscanAppropriateFlag);
     q.vuiVideoSignalTypePresent = PI(p, vui_bEnableVideoSignalTypePresentFlag); q.vuiVideoFormat = PI(p, vui_videoFormat); q.vuiFullRange = PI(p, vui_bEnableVideoFullRangeFlag);
@@ -406,7 +436,7 @@ void* abi_encoder_open(void* p)
     a->enc = e; a->width = q.sourceWidth; a->height = q.sourceHeight;
     a->bframeDelay = q.bframes ? (q.bBPyramid ? 2 : 1) : 0;
     a->param.assign((const uint8_t*)p, (const uint8_t*)p + X265ABI_SIZEOF_PARAM);         /* api.cpp:96-116: the encoder keeps a copy */
-    if (q.keyframeMax >= 0 && q.keyframeMax <= 1) wr<int32_t>(a->param.data(), X265ABI_PARAM_bRepeatHeaders, 1);          /* ... as Encoder::configure left it: x265_encoder_parameters tells the caller (the reference's program asks before it writes the headers) */
+    if ((q.keyframeMax >= 0 && q.keyframeMax <= 1) || q.bEmitHDR10SEI) wr<int32_t>(a->param.data(), X265ABI_PARAM_bRepeatHeaders, 1);          /* ... as Encoder::configure left it: x265_encoder_parameters tells the caller (the reference's program asks before it writes the headers) */
     a->fps = (double)q.fpsNum / (double)q.fpsDenom;
     clock_gettime(CLOCK_MONOTONIC, &a->opened);
     return a;
