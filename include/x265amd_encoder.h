@@ -135,6 +135,7 @@ typedef struct x265amd_param
     uint32_t masteringDisplay[10];
     int32_t decodedPictureHashSEI;          /* param.decodedPictureHashSEI (--hash): 0 none, 1 MD5, 2 CRC, 3 checksum of each reconstructed picture in a suffix SEI unit */
     int32_t reserved4;
+    int32_t deblockingFilterTCOffset, deblockingFilterBetaOffset;      /* param.deblockingFilter*Offset (--deblock tc:beta, each -6 .. 6): pps_tc_offset_div2 / pps_beta_offset_div2 */
 } x265amd_param;
 enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 

@@ -3030,7 +3030,7 @@ class EncParam(C.Structure):
                 ("vuiColorPrimaries", C.c_int32), ("vuiTransfer", C.c_int32), ("vuiMatrix", C.c_int32), ("vuiChromaLocPresent", C.c_int32), ("vuiChromaLocTop", C.c_int32), ("vuiChromaLocBottom", C.c_int32),
                 ("vuiDisplayWindow", C.c_int32), ("vuiDispWinLeft", C.c_int32), ("vuiDispWinRight", C.c_int32), ("vuiDispWinTop", C.c_int32), ("vuiDispWinBottom", C.c_int32), ("reserved3", C.c_int32),
                 ("bEnableAccessUnitDelimiters", C.c_int32), ("bEmitHDR10SEI", C.c_int32), ("bEmitCLL", C.c_int32), ("maxCLL", C.c_int32), ("maxFALL", C.c_int32), ("hasMasteringDisplay", C.c_int32),
-                ("masteringDisplay", C.c_uint32 * 10), ("decodedPictureHashSEI", C.c_int32), ("reserved4", C.c_int32)]
+                ("masteringDisplay", C.c_uint32 * 10), ("decodedPictureHashSEI", C.c_int32), ("reserved4", C.c_int32), ("deblockingFilterTCOffset", C.c_int32), ("deblockingFilterBetaOffset", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3692,6 +3692,9 @@ CLI_CASES = {
     "cli_crc_hbd_odd/": ((424, 232), 8, 10, 4, {}, ["--preset", "medium", "--hash", "2"]),
     "cli_checksum_aud_repeat/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--hash", "3", "--aud", "--repeat-headers"]),
     "cli_maxcll_only/": ((416, 240), 4, 8, 2, {}, ["--preset", "medium", "--max-cll", "600,0"]),
+    "cli_deblock_offsets/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--deblock", "-2:3"]),
+    "cli_animation/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--tune", "animation"]),
+    "cli_animation_hbd_slow/": ((416, 240), 12, 10, 4, {}, ["--preset", "slow", "--tune", "animation"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {
@@ -3700,6 +3703,7 @@ CLI_REFUSED = {
     "placebo": (["--preset", "placebo"], "TransformSkip"),
     "bitrate": (["--preset", "medium", "--bitrate", "1000"], "rateControlMode"),
     "grain": (["--preset", "medium", "--tune", "grain"], "Grain"),
+    "chroma_qp": (["--preset", "medium", "--cbqpoffs", "2"], "unknown option"),
     "umh": (["--preset", "medium", "--me", "umh"], "searchMethod"),
     "qg16": (["--preset", "medium", "--qg-size", "16"], "qgSize"),
     "nosuchoption": (["--preset", "medium", "--no-such-option"], "unknown option"),

@@ -71,7 +71,8 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.sign_hide = p.bEnableSignHiding != 0; s.num_ref_idx_default[0] = s.num_ref_idx_default[1] = 1; s.init_qp_minus26 = 0;
     s.use_dqp = useDqp; s.max_cu_dqp_depth = maxCuDqpDepth;           /* Encoder::initPPS (encoder.cpp:3424-3445) */
     s.wpp = p.bEnableWavefront != 0; s.loop_filter_across_slices = 1;
-    s.deblocking_filter_control_present = !p.bEnableLoopFilter; s.pic_disable_deblocking = !p.bEnableLoopFilter;
+    s.deblocking_filter_control_present = !p.bEnableLoopFilter || p.deblockingFilterBetaOffset || p.deblockingFilterTCOffset; s.pic_disable_deblocking = !p.bEnableLoopFilter;          /* Encoder::initPPS (encoder.cpp:3458-3461) */
+    s.beta_offset_div2 = p.deblockingFilterBetaOffset; s.tc_offset_div2 = p.deblockingFilterTCOffset;
 }
 
 extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
@@ -110,6 +111,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->aqMode >= 0 && p->aqMode <= 3, "aqMode outside 0..3 (the edge-based modes are not built)");
         XA_REQUIRE(p->qpMin >= 0 && p->qpMin <= p->qpMax && p->qpMax <= 69, "qpMin / qpMax outside 0..69 (or crossed)");
         XA_REQUIRE(p->aspectRatioIdc >= 0 && (p->aspectRatioIdc <= 16 || p->aspectRatioIdc == 255), "aspectRatioIdc outside 0..16 / 255");
+        XA_REQUIRE(p->deblockingFilterTCOffset >= -6 && p->deblockingFilterTCOffset <= 6 && p->deblockingFilterBetaOffset >= -6 && p->deblockingFilterBetaOffset <= 6, "deblocking offsets outside -6..6");
         XA_REQUIRE(p->decodedPictureHashSEI >= 0 && p->decodedPictureHashSEI <= 3 && p->maxCLL >= 0 && p->maxCLL <= 65535 && p->maxFALL >= 0 && p->maxFALL <= 65535, "decodedPictureHashSEI outside 0..3 or a light level outside 16 bits");
         XA_REQUIRE(p->vuiVideoFormat >= 0 && p->vuiVideoFormat <= 5 && p->vuiColorPrimaries >= 0 && p->vuiColorPrimaries <= 255 && p->vuiTransfer >= 0 && p->vuiTransfer <= 255 &&
                    p->vuiMatrix >= 0 && p->vuiMatrix <= 255 && p->vuiChromaLocTop >= 0 && p->vuiChromaLocTop <= 5 && p->vuiChromaLocBottom >= 0 && p->vuiChromaLocBottom <= 5, "vui: a value outside its range");

@@ -207,7 +207,7 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
         if (rc != X265AMD_OK) return rc;
         if (hipMemcpyAsync(dDbUnits, dbu.data(), sizeof(x265amd_deblock_unit) * nUnits, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
             return xa_fail(X265AMD_EHIP, "encoder: deblock upload");
-        rc = x265amd_deblock_picture(st, recY, recU, recV, stride, cstride, W, H, dDbUnits, 0, 0, 0, 0, 0, 3);
+        rc = x265amd_deblock_picture(st, recY, recU, recV, stride, cstride, W, H, dDbUnits, p.deblockingFilterBetaOffset, p.deblockingFilterTCOffset, 0, 0, 0, 3);
         if (rc != X265AMD_OK) return rc;
         if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: deblock");
     }
@@ -479,7 +479,7 @@ int x265amd_encoder::filterRows(Pic& pic, const x265amd_slice_info& si, const x2
                 hipStreamSynchronize(st) != hipSuccess)
             { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
             stamp(1);
-            rc = x265amd_deblock_rows(st, recY, recU, recV, stride, cstride, W, H, (const x265amd_deblock_unit*)dDb.p, 0, 0, 0, 0, 0, 3, y4b, y4e);
+            rc = x265amd_deblock_rows(st, recY, recU, recV, stride, cstride, W, H, (const x265amd_deblock_unit*)dDb.p, p.deblockingFilterBetaOffset, p.deblockingFilterTCOffset, 0, 0, 0, 3, y4b, y4e);
             if (rc != X265AMD_OK) break;
         }
         if (sao)
@@ -671,7 +671,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
                         if (dbCopy && hipMemcpy2DAsync((x265amd_deblock_unit*)dDb.p + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4, dbu + (size_t)y4b * w4 + x4b, sizeof(x265amd_deblock_unit) * w4,
                                              sizeof(x265amd_deblock_unit) * (size_t)(x4e - x4b), (size_t)(y4e - y4b), hipMemcpyHostToDevice, st) != hipSuccess)
                         { rc = xa_fail(X265AMD_EHIP, "encoder: deblock upload"); break; }
-                        rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, 0, 0, 0, 0, 0, 3, y4b, y4t, c0, c1);
+                        rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, p.deblockingFilterBetaOffset, p.deblockingFilterTCOffset, 0, 0, 0, 3, y4b, y4t, c0, c1);
                         if (rc != X265AMD_OK) break;
                     }
                     todoTop.push_back(Unit{ r, c0, c1 });
@@ -684,7 +684,7 @@ int x265amd_encoder::filterRowsCols(Pic& pic, const x265amd_slice_info& si, cons
                 {
                     if (dbl && y4e > y4t)
                     {
-                        rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, 0, 0, 0, 0, 0, 3, y4t, y4e, c0, c1);
+                        rc = x265amd_deblock_rows_cols(st, recY, recU, recV, stride, cstride, W, H, dbCopy ? (const x265amd_deblock_unit*)dDb.p : dbu, p.deblockingFilterBetaOffset, p.deblockingFilterTCOffset, 0, 0, 0, 3, y4t, y4e, c0, c1);
                         if (rc != X265AMD_OK) break;
                     }
                     if (sao)

@@ -194,6 +194,15 @@ int abi_param_parse(void* p, const char* name, const char* value)
         { "b-intra", X265ABI_PARAM_bIntraInBFrames }, { "limit-modes", X265ABI_PARAM_limitModes }, { "cutree", X265ABI_PARAM_rc_cuTree }, { "info", X265ABI_PARAM_bEmitInfoSEI },
         { "annexb", X265ABI_PARAM_bAnnexB }, { "repeat-headers", X265ABI_PARAM_bRepeatHeaders }, { "aud", X265ABI_PARAM_bEnableAccessUnitDelimiters }, { "hdr10", X265ABI_PARAM_bEmitHDR10SEI },
         { "hdr", X265ABI_PARAM_bEmitHDR10SEI }, { "cll", X265ABI_PARAM_bEmitCLL }, { "tskip", X265ABI_PARAM_bEnableTransformSkip }, { "lossless", X265ABI_PARAM_bLossless } };
+    if (!strcmp(key, "deblock") && !neg && value)
+    {
+        /* --deblock tc:beta | tc,beta | tc | a truth value (param.cpp:1083-1097) */
+        int tc = 0, beta = 0;
+        if (sscanf(value, "%d:%d", &tc, &beta) == 2 || sscanf(value, "%d,%d", &tc, &beta) == 2)
+        { wr<int32_t>(p, X265ABI_PARAM_deblockingFilterTCOffset, tc); wr<int32_t>(p, X265ABI_PARAM_deblockingFilterBetaOffset, beta); wr<int32_t>(p, X265ABI_PARAM_bEnableLoopFilter, 1); return 0; }
+        if (sscanf(value, "%d", &tc) == 1)
+        { wr<int32_t>(p, X265ABI_PARAM_deblockingFilterTCOffset, tc); wr<int32_t>(p, X265ABI_PARAM_deblockingFilterBetaOffset, tc); wr<int32_t>(p, X265ABI_PARAM_bEnableLoopFilter, 1); return 0; }
+    }
     for (const auto& sw : switches)
         if (!strcmp(key, sw.name)) { const int v = truth(bad); if (bad) return -2; wr<int32_t>(p, sw.off, v); return 0; }
     if (neg && !strcmp(key, "scenecut")) { wr<int32_t>(p, X265ABI_PARAM_scenecutThreshold, 0); return 0; }          /* --no-scenecut (param.cpp: atobool of "false") */
@@ -365,7 +374,7 @@ void* abi_encoder_open(void* p)
     REQUIRE(PI(p, maxSlices) <= 1, "maxSlices above 1 is not built");
     REQUIRE(!PI(p, bIntraRefresh) && !PI(p, bEnableHME) && !PI(p, bEnableConstrainedIntra), "intra refresh / HME / constrained intra are not built");
     REQUIRE(!PI(p, noiseReductionIntra) && !PI(p, noiseReductionInter) && !rd<const char*>(p, X265ABI_PARAM_scalingLists), "noise reduction / scaling lists are not built");
-    REQUIRE(!PI(p, cbQpOffset) && !PI(p, crQpOffset) && !PI(p, deblockingFilterTCOffset) && !PI(p, deblockingFilterBetaOffset), "chroma QP / deblocking offsets must be 0");
+    REQUIRE(!PI(p, cbQpOffset) && !PI(p, crQpOffset), "chroma QP offsets (cbQpOffset / crQpOffset) must be 0");
     REQUIRE(!PI(p, bSaoNonDeblocked) && !PI(p, selectiveSAO), "sao-non-deblock / selective-sao are not built");
     REQUIRE(!PI(p, bEmitHRDSEI), "the HRD SEI (bEmitHRDSEI) is not built");
     REQUIRE(!PI(p, bEnableTemporalSubLayers) && !PI(p, uhdBluray) && !PI(p, bEnableSvtHevc), "temporal layers / uhd-bd / svt are not built");
@@ -398,6 +407,7 @@ void* abi_encoder_open(void* p)
         if (pools && (!strcmp(pools, "none") || !strcmp(pools, "NONE") || !strcmp(pools, "0"))) q.bEnableWavefront = 0;
     }
     q.aspectRatioIdc = PI(p, vui_aspectRatioIdc); q.rdoqLevel = PI(p, rdoqLevel);
+    q.deblockingFilterTCOffset = PI(p, deblockingFilterTCOffset); q.deblockingFilterBetaOffset = PI(p, deblockingFilterBetaOffset);
     q.bEnableAccessUnitDelimiters = PI(p, bEnableAccessUnitDelimiters) != 0; q.decodedPictureHashSEI = PI(p, decodedPictureHashSEI);
     q.maxCLL = rd<uint16_t>(p, X265ABI_PARAM_maxCLL); q.maxFALL = rd<uint16_t>(p, X265ABI_PARAM_maxFALL); q.bEmitCLL = PI(p, bEmitCLL) != 0;
     {
