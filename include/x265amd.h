@@ -793,14 +793,15 @@ typedef struct x265amd_rd_params
                                      * (Entropy::estBit before each Quant::transformNxN, search.cpp:355, :852, :3272, :3397), one launch per unit */
     int32_t psy_rdoq_scale;         /* Quant::m_psyRdoqScale = (int)(param.psyRdoq * 256) */
     int32_t fast_intra;             /* param.bEnableFastIntra: checkIntraInInter samples every fifth angle and refines (search.cpp:1401-1434) */
-    int32_t reserved;
+    int32_t limit_tu;               /* param.limitTU 0, 2, 3, 4 (1 is not built): the inter residual quadtree stops early (search.cpp:3136-3142, :3209-3216, :3713-3726) */
 } x265amd_rd_params;                /* 32 bytes */
 typedef struct x265amd_rd_cu
 {
     int16_t x, y;                   /* luma position of the CU in the picture */
     uint8_t log2_size;              /* 3..6 */
     int8_t qp;                      /* the CU's QP (setLambdaFromQP: RD lambdas and quantiser) */
-    uint8_t reserved[2];            /* [0]: the QP of the LAMBDAS when it is not `qp` (0: it is).  Search::setLambdaFromQP (search.cpp:177-187) takes the lambdas from the QP the rate
+    uint8_t reserved[2];            /* [1]: with limit_tu 3 / 4, Search::m_maxTUDepth + 1 as the analysis has it when the CU's residual is coded (0: no limit).
+                                     * [0]: the QP of the LAMBDAS when it is not `qp` (0: it is).  Search::setLambdaFromQP (search.cpp:177-187) takes the lambdas from the QP the rate
                                      * control asks for, which adaptive quantisation can push up to 69, and clips the quantiser's (and the coded) QP to 51: above 51 the two differ */
     uint64_t frac_bits;             /* m_rqt[depth].cur.m_fracBits on entry (only its low 15 bits matter) */
     uint8_t ctx[X265AMD_CTX_STRIDE];/* m_rqt[depth].cur context states on entry */
@@ -900,7 +901,7 @@ typedef struct x265amd_analysis_params
     int32_t strong_intra_smoothing;             /* sps.bUseStrongIntraSmoothing */
     int32_t use_sao;                            /* slice.m_bUseSao: x265amd_analyse_frame only (the row coder counts bits only when SAO is on) */
     int32_t rdoq_level, psy_rdoq_scale;         /* param.rdoqLevel, (int)(param.psyRdoq * 256) */
-    int32_t fast_intra, reserved;               /* param.bEnableFastIntra */
+    int32_t fast_intra, limit_tu;               /* param.bEnableFastIntra, param.limitTU (0, 2, 3, 4) */
 } x265amd_analysis_params;          /* 64 bytes */
 typedef struct x265amd_cu_stat { uint32_t count[4]; uint32_t pad[2]; uint64_t avg_cost[4]; } x265amd_cu_stat;     /* FrameData::RCStatCU count / avgCost per depth */
 typedef struct x265amd_ctu_result { uint64_t rd_cost, distortion, frac_bits; uint32_t total_bits, reserved; uint8_t ctx[X265AMD_CTX_STRIDE]; } x265amd_ctu_result;

@@ -136,6 +136,9 @@ typedef struct x265amd_param
     int32_t decodedPictureHashSEI;          /* param.decodedPictureHashSEI (--hash): 0 none, 1 MD5, 2 CRC, 3 checksum of each reconstructed picture in a suffix SEI unit */
     int32_t reserved4;
     int32_t deblockingFilterTCOffset, deblockingFilterBetaOffset;      /* param.deblockingFilter*Offset (--deblock tc:beta, each -6 .. 6): pps_tc_offset_div2 / pps_beta_offset_div2 */
+    int32_t limitTU;                        /* param.limitTU (--limit-tu; --preset slower has 4): 0, 2 (depth first), 3 (neighbourhood), 4 (both); 1 (breadth first) is not built.
+                                             * Needs tuQTMaxInterDepth > 1 (else it is switched off, encoder.cpp:4103-4107) */
+    int32_t reserved5;
 } x265amd_param;
 enum { X265AMD_RC_CQP = 1, X265AMD_RC_CRF = 2 };
 

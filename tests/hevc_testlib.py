@@ -3030,7 +3030,7 @@ class EncParam(C.Structure):
                 ("vuiColorPrimaries", C.c_int32), ("vuiTransfer", C.c_int32), ("vuiMatrix", C.c_int32), ("vuiChromaLocPresent", C.c_int32), ("vuiChromaLocTop", C.c_int32), ("vuiChromaLocBottom", C.c_int32),
                 ("vuiDisplayWindow", C.c_int32), ("vuiDispWinLeft", C.c_int32), ("vuiDispWinRight", C.c_int32), ("vuiDispWinTop", C.c_int32), ("vuiDispWinBottom", C.c_int32), ("reserved3", C.c_int32),
                 ("bEnableAccessUnitDelimiters", C.c_int32), ("bEmitHDR10SEI", C.c_int32), ("bEmitCLL", C.c_int32), ("maxCLL", C.c_int32), ("maxFALL", C.c_int32), ("hasMasteringDisplay", C.c_int32),
-                ("masteringDisplay", C.c_uint32 * 10), ("decodedPictureHashSEI", C.c_int32), ("reserved4", C.c_int32), ("deblockingFilterTCOffset", C.c_int32), ("deblockingFilterBetaOffset", C.c_int32)]
+                ("masteringDisplay", C.c_uint32 * 10), ("decodedPictureHashSEI", C.c_int32), ("reserved4", C.c_int32), ("deblockingFilterTCOffset", C.c_int32), ("deblockingFilterBetaOffset", C.c_int32), ("limitTU", C.c_int32), ("reserved5", C.c_int32)]
 
 
 class RowExport(C.Structure):       # x265amd_row_export (include/x265amd_encoder.h)
@@ -3695,11 +3695,19 @@ CLI_CASES = {
     "cli_deblock_offsets/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--deblock", "-2:3"]),
     "cli_animation/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--tune", "animation"]),
     "cli_animation_hbd_slow/": ((416, 240), 12, 10, 4, {}, ["--preset", "slow", "--tune", "animation"]),
+    # --limit-tu: the inter residual quadtree bounded by the CU's first quarter (2), by the neighbouring and co-located CTUs' records (3), by both (4: --preset slower)
+    "cli_slower/": ((416, 240), 12, 8, 2, {}, ["--preset", "slower"]),
+    "cli_slower_hbd/": ((416, 240), 8, 10, 4, {}, ["--preset", "slower"]),
+    "cli_limit_tu2/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--limit-tu", "2", "--tu-inter-depth", "3"]),
+    "cli_limit_tu3/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--limit-tu", "3", "--tu-inter-depth", "3", "--tu-intra-depth", "3"]),
+    "cli_limit_tu4_rdoq/": ((416, 240), 12, 8, 2, {}, ["--preset", "slow", "--limit-tu", "4", "--tu-inter-depth", "2"]),
+    "cli_limit_tu_off/": ((416, 240), 8, 8, 2, {}, ["--preset", "medium", "--limit-tu", "4"]),           # tu-inter-depth 1: switched off by the configuration
+    "cli_slower_edges/": ((416, 240), 8, 8, 2, {"clip": "edges"}, ["--preset", "slower"]),
 }
 # what the command line program must refuse, with words of the reason (x265amd_last_error)
 CLI_REFUSED = {
     "ultrafast": (["--preset", "ultrafast"], "maxCUSize"),
-    "slower": (["--preset", "slower"], "limitTU"),
+    "limit_tu_1": (["--preset", "medium", "--limit-tu", "1", "--tu-inter-depth", "3"], "limitTU"),
     "placebo": (["--preset", "placebo"], "TransformSkip"),
     "bitrate": (["--preset", "medium", "--bitrate", "1000"], "rateControlMode"),
     "grain": (["--preset", "medium", "--tune", "grain"], "Grain"),

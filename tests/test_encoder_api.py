@@ -43,7 +43,7 @@ def display_frames(tag):
 
 def test_param_struct_matches_header():
     import ctypes
-    assert ctypes.sizeof(T.EncParam) == 424 and T.EncParam.deblockingFilterBetaOffset.offset == 420 and T.EncParam.decodedPictureHashSEI.offset == 408 and T.EncParam.vuiVideoFormat.offset == 284 and T.EncParam.qpMin.offset == 248 and T.EncParam.bRepeatHeaders.offset == 256 and T.EncParam.rateControlMode.offset == 204 and T.EncParam.rfConstant.offset == 208 and T.EncParam.aqMode.offset == 232 and T.EncParam.qgSize.offset == 240 and T.EncParam.bEnableWeightedPred.offset == 196 and T.EncParam.bEnableWeightedBiPred.offset == 200 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
+    assert ctypes.sizeof(T.EncParam) == 432 and T.EncParam.limitTU.offset == 424 and T.EncParam.deblockingFilterBetaOffset.offset == 420 and T.EncParam.decodedPictureHashSEI.offset == 408 and T.EncParam.vuiVideoFormat.offset == 284 and T.EncParam.qpMin.offset == 248 and T.EncParam.bRepeatHeaders.offset == 256 and T.EncParam.rateControlMode.offset == 204 and T.EncParam.rfConstant.offset == 208 and T.EncParam.aqMode.offset == 232 and T.EncParam.qgSize.offset == 240 and T.EncParam.bEnableWeightedPred.offset == 196 and T.EncParam.bEnableWeightedBiPred.offset == 200 and T.EncParam.bOpenGOP.offset == 184 and T.EncParam.bBPyramid.offset == 188 and T.EncParam.lookaheadSlices.offset == 192 and T.EncParam.shardCount.offset == 176 and T.EncParam.frameNumThreads.offset == 156 and T.EncParam.keyframeMin.offset == 168 and ctypes.sizeof(T.EncNal) == 16 and ctypes.sizeof(T.EncPicture) == 48
 
 
 @pytest.mark.gpu

@@ -238,7 +238,45 @@ struct Analyzer
         lambda2 = rd[0]; lambda = rd[1]; psyRd = (uint32_t)rd[2];
         return 0;
     }
-    void cuQp2(x265amd_rd_cu& c) const { c.qp = (int8_t)qp; c.reserved[0] = (uint8_t)(lambdaQp != qp ? lambdaQp : 0); }
+    void cuQp2(x265amd_rd_cu& c) const { c.qp = (int8_t)qp; c.reserved[0] = (uint8_t)(lambdaQp != qp ? lambdaQp : 0); c.reserved[1] = (uint8_t)(maxTUDepth + 1); }
+    /* --limit-tu 3 / 4: Search::m_maxTUDepth as the recursion leaves it (loaded for every CU of 16x16 and up, never restored: a CU's own modes behind its sub-CUs see the
+     * last sub-CU's value), and the per-CTU records it is loaded from (CUData::m_refTuDepth[geomRecurId]: the deepest transform unit of the CU decided at that place) */
+    int maxTUDepth = -1;
+    const XaTuRecs* tuRecs = nullptr;
+    static int geomId(int lx, int ly, int depth) { return depth == 0 ? 0 : depth == 1 ? 1 + (ly >> 5) * 2 + (lx >> 5) : 5 + (ly >> 4) * 4 + (lx >> 4); }        /* calcCTUGeoms: raster inside a depth */
+    /* Analysis::loadTUDepth (analysis.cpp:375-424) */
+    void loadTUDepth(int x, int y, int depth)
+    {
+        if (A->limit_tu < 3 || depth > 2 || !tuRecs) return;
+        const int id = geomId(x - ctuX, y - ctuY, depth);
+        float predDepth = 0;
+        int count = 0;
+        auto add = [&](const int8_t* recs, int addr) { predDepth += recs[(size_t)addr * 21 + id]; count++; };
+        add(tuRecs->ref[0], ctuAddr);
+        if (I->is_inter_b) add(tuRecs->ref[1], ctuAddr);
+        const int cx = ctuAddr % ctuW;
+        if (ctuAddr >= ctuW)
+        {
+            add(tuRecs->cur, ctuAddr - ctuW);
+            if (cx > 0) add(tuRecs->cur, ctuAddr - ctuW - 1);
+            if (cx < ctuW - 1) add(tuRecs->cur, ctuAddr - ctuW + 1);
+        }
+        if (cx > 0) add(tuRecs->cur, ctuAddr - 1);
+        predDepth /= count;
+        if (predDepth == 0) maxTUDepth = 0;
+        else if (predDepth < 1) maxTUDepth = 1;
+        else if (predDepth >= 1 && predDepth <= 1.5) maxTUDepth = 2;
+        else if (predDepth > 1.5 && predDepth <= 2.5) maxTUDepth = 3;
+        else maxTUDepth = -1;
+    }
+    void saveTUDepth(const Mode& m, int x, int y, int depth)
+    {
+        if (A->limit_tu < 3 || depth > 2 || !tuRecs) return;
+        int8_t v = -1;
+        const int n4 = 16 >> depth;
+        for (int i = 0; i < n4 * n4; i++) v = std::max<int8_t>(v, (int8_t)m.u[i].tu_depth);
+        tuRecs->cur[(size_t)ctuAddr * 21 + geomId(x - ctuX, y - ctuY, depth)] = v;
+    }
     /* Analysis::calculateQpforCuSize of the sub-CU q of the CU at `depth` -- when that is a quantisation group's CU (analysis.cpp:1363-1364); else the QP in force stays */
     int childQp(int depth, int q)
     {
@@ -1495,6 +1533,7 @@ struct Analyzer
         d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
         for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth);
         d.pred[PRED_2Nx2N].rdCost = 0;
+        loadTUDepth(x, y, depth);           /* analysis.cpp:1907-1908 */
         uint32_t allSplitRefs = 0;
         auto rootCbf = [](const Mode& m) { return m.u[0].cbf[0] || m.u[0].cbf[1] || m.u[0].cbf[2]; };
         auto interRd = [&](int part, int slot, uint32_t m0, uint32_t m1) -> int {          /* checkInter_rd5_6 + checkBestMode */
@@ -1626,6 +1665,7 @@ struct Analyzer
             }
             if (mightSplit) addSplitFlagCost(*d.best, x, y, depth);
         }
+        if (mightNotSplit && d.best) saveTUDepth(*d.best, x, y, depth);          /* (before the split is compared: analysis.cpp:2329-2339) */
         if (mightSplit && !skipRecursion)
         {
             Mode& split = d.pred[PRED_SPLIT];
@@ -1815,6 +1855,7 @@ struct Analyzer
             if (checkDQPForSplitPred(split, x, y, depth)) return err;          /* analysis.cpp:642 */
             checkBestMode(split, depth);
         }
+        saveTUDepth(*d.best, x, y, depth);          /* analysis.cpp:653-659 (I slices leave the records the P pictures behind them load) */
         toPicture(*d.best, x, y, depth);
         if (d.best != &d.pred[PRED_SPLIT]) tileToPicture(d.best->reconTile, x, y, size);
         return 0;
@@ -1848,6 +1889,7 @@ struct Analyzer
         d.mvCost2Nx2N[0] = d.mvCost2Nx2N[1] = 0;
         { XA_HOSTPROF("an.initSubCU x13"); for (int k = 0; k < NUM_PRED; k++) initSubCU(d.pred[k], depth); }
         d.pred[PRED_2Nx2N].sa8dCost = 0;                 /* what a parent reads under --limit-modes when 2Nx2N is not searched here */
+        loadTUDepth(x, y, depth);           /* analysis.cpp:1201-1202 */
         chain.frNode[depth] = node; chain.frDirty[depth] = false;
         {
             const bool checked = mightNotSplit && (uint32_t)depth >= minDepth;
@@ -2154,6 +2196,7 @@ struct Analyzer
         /* everything in this CU's area decided (and put in place) by the device: the CU itself skipped there, or a CU that is not coded at this depth whose sub-CUs all are */
         const bool devComplete = devSkip || (chain.on && !(mightNotSplit && (uint32_t)depth >= minDepth) && d.best == &d.pred[PRED_SPLIT] && childrenDev);
         toPicture(*d.best, x, y, depth, !devComplete);
+        if (mightNotSplit) saveTUDepth(*d.best, x, y, depth);            /* analysis.cpp:1796-1805 */
         if (!devComplete) tileToPicture(d.best->reconTile, x, y, size);
         chain.lastDevComplete = devComplete;
         return 0;
@@ -2166,7 +2209,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
                              const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                              const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                              intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
-                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol, const int8_t* cu_qp = nullptr);
+                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol, const int8_t* cu_qp = nullptr, const XaTuRecs* tu_recs = nullptr);
 extern "C" int x265amd_compress_ctu_inter(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                                           const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                                           const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
@@ -2180,11 +2223,14 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
                              const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                              const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                              intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int ctu_addr, const uint8_t* ctx_in, uint64_t frac_in,
-                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol, const int8_t* cu_qp)
+                             int16_t* coeff_out, x265amd_ctu_result* out, XaMapUnit* dCur, const XaMapUnit* dCol, const int8_t* cu_qp, const XaTuRecs* tu_recs)
 {
     if ((!me && si && si->slice_type != 2) || !I || !S || !si || !A || !units || !cur || !ref_depth || !ref_qp0 || !h_planes || !cu_stat || !ctx_in || !out || num_pics < 2)
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: null argument");
     if (si->slice_type != 2 && (si->slice_type == 0) != (I->is_inter_b != 0)) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: slice type");
+    if (A->limit_tu < 0 || A->limit_tu > 4 || A->limit_tu == 1) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: limit_tu 1 (the breadth-first form) is not built");
+    if (A->limit_tu >= 3 && (!tu_recs || !tu_recs->cur || (si->slice_type != 2 && !tu_recs->ref[0]) || (si->slice_type == 0 && !tu_recs->ref[1])))
+        return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: limit_tu 3 / 4 needs the pictures' transform depth records (the encoder object keeps them)");
     if (A->rdoq_level < 0 || A->rdoq_level > 2 || A->rd_level < 2 || A->rd_level > 6 || (A->rd_level > 4 && A->rskip == 2) || A->limit_refs < 0 || A->limit_refs > 3 || (si->use_dqp && (!cu_qp || si->max_cu_dqp_depth < 0 || si->max_cu_dqp_depth > 1)) || si->tq_bypass_enabled || (A->rskip != 0 && A->rskip != 1))
         return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: configuration outside the built subset (rd 2-6, delta QP with the quantisation groups' QPs handed in and groups of 64 or 32 samples, rskip 0/1)");
     if ((I->pic_width & 7) || (I->pic_height & 7) || I->pic_width != si->pic_width || I->pic_height != si->pic_height) return xa_fail(X265AMD_EINVAL, "compress_ctu_inter: picture size");
@@ -2228,6 +2274,8 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
     { XA_HOSTPROF("ctu.new Analyzer"); an = new Analyzer; }
     Analyzer& a = *an;
     a.me = me; a.st = (hipStream_t)stream; a.I = I; a.S = S; a.si = si; a.A = A; a.units = units; a.cur = cur; a.col = col;
+    a.tuRecs = tu_recs;
+    if (tu_recs && tu_recs->cur) memset(tu_recs->cur + (size_t)ctu_addr * 21, -1, 21);          /* CUData::initCTU (cudata.cpp:312-313) */
     a.refDepth = ref_depth; a.refQp0 = ref_qp0; a.planes = h_planes; a.numPics = num_pics; a.stride = stride; a.cstride = cstride;
     a.cuStat = cu_stat; a.ctuAddr = ctu_addr; a.ctuW = (I->pic_width + 63) >> 6; a.w4 = I->pic_width >> 2; a.h4 = I->pic_height >> 2;
     a.ctuX = (ctu_addr % a.ctuW) * 64; a.ctuY = (ctu_addr / a.ctuW) * 64; a.qp = si->slice_qp; a.err = 0;
@@ -2246,6 +2294,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
     if (rc == X265AMD_OK)
     {
         if (a.setLambdaFromQP(a.qp)) rc = a.err;
+        a.rp.limit_tu = A->limit_tu;
         a.rp.psy_rd = A->psy_rd; a.rp.rd_level = A->rd_level; a.rp.strong_intra_smoothing = A->strong_intra_smoothing;
         a.rp.rdoq_level = A->rdoq_level; a.rp.psy_rdoq_scale = A->rdoq_level ? A->psy_rdoq_scale : 0; a.rp.fast_intra = A->fast_intra != 0;
         /* CUData::initCTU: nothing of this CTU is decided yet */
@@ -2326,7 +2375,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
-                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks, const int8_t* cu_qp)
+                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks, const int8_t* cu_qp, const XaTuRecs* tu_recs)
 {
     if (!I || !si || !units || !cur || !cu_stat || !coeff_out) return xa_fail(X265AMD_EINVAL, "analyse_frame: null argument");
     const int ctuW = (si->pic_width + 63) >> 6, ctuH = (si->pic_height + 63) >> 6, numCtu = ctuW * ctuH, w4 = si->pic_width >> 2, h4 = si->pic_height >> 2;
@@ -2373,7 +2422,7 @@ int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info
         x265amd_ctu_result res;
         int16_t* coeff = coeff_out + (size_t)addr * kTileElems;
         int r = compress_ctu_impl(me, st, I, S, si, A, units, cur, col, ref_depth, ref_qp0, h_planes, num_pics, stride, cstride, cu_stat, addr,
-                                  rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res, frameDCur, frameDCol, cu_qp);
+                                  rowCoder->ctx, A->use_sao ? rowCoder->fracBits : 0, coeff, &res, frameDCur, frameDCol, cu_qp, tu_recs);
         if (r != X265AMD_OK) return r;
         if (results) results[addr] = res;
         xa_phase(XA_PH_ANALYZER);

@@ -89,6 +89,7 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     }
     /* the HDR10 SEI units come with the parameter sets at every keyframe ("Turning on repeat-headers for HDR compatibility", encoder.cpp:4347-4353) */
     if (norm.bEmitHDR10SEI || norm.hasMasteringDisplay || norm.maxCLL || norm.maxFALL) { norm.bEmitHDR10SEI = 1; norm.bRepeatHeaders = 1; }
+    if (norm.limitTU && norm.tuQTMaxInterDepth < 2) norm.limitTU = 0;          /* "limit-tu disabled, requires tu-inter-depth > 1" (encoder.cpp:4103-4107) */
     if (norm.rateControlMode != X265AMD_RC_CRF) { norm.aqMode = 0; norm.cuTree = 0; }
     if (norm.lookaheadDepth == 0) norm.cuTree = 0;
     if (!norm.aqMode && norm.cuTree) { norm.aqMode = 1; norm.aqStrength = 0.0; }
@@ -112,6 +113,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
         XA_REQUIRE(p->qpMin >= 0 && p->qpMin <= p->qpMax && p->qpMax <= 69, "qpMin / qpMax outside 0..69 (or crossed)");
         XA_REQUIRE(p->aspectRatioIdc >= 0 && (p->aspectRatioIdc <= 16 || p->aspectRatioIdc == 255), "aspectRatioIdc outside 0..16 / 255");
         XA_REQUIRE(p->deblockingFilterTCOffset >= -6 && p->deblockingFilterTCOffset <= 6 && p->deblockingFilterBetaOffset >= -6 && p->deblockingFilterBetaOffset <= 6, "deblocking offsets outside -6..6");
+        XA_REQUIRE(p->limitTU == 0 || (p->limitTU >= 2 && p->limitTU <= 4), "limitTU: 0, 2, 3 and 4 are built (1, the breadth-first form, is not)");
+        XA_REQUIRE(p->limitTU < 3 || p->shardCount <= 1, "limitTU 3 / 4 with pictures coded on several GPUs is not built (the transform depth records do not travel)");
         XA_REQUIRE(p->decodedPictureHashSEI >= 0 && p->decodedPictureHashSEI <= 3 && p->maxCLL >= 0 && p->maxCLL <= 65535 && p->maxFALL >= 0 && p->maxFALL <= 65535, "decodedPictureHashSEI outside 0..3 or a light level outside 16 bits");
         XA_REQUIRE(p->vuiVideoFormat >= 0 && p->vuiVideoFormat <= 5 && p->vuiColorPrimaries >= 0 && p->vuiColorPrimaries <= 255 && p->vuiTransfer >= 0 && p->vuiTransfer <= 255 &&
                    p->vuiMatrix >= 0 && p->vuiMatrix <= 255 && p->vuiChromaLocTop >= 0 && p->vuiChromaLocTop <= 5 && p->vuiChromaLocBottom >= 0 && p->vuiChromaLocBottom <= 5, "vui: a value outside its range");

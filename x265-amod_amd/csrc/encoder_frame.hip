@@ -107,7 +107,7 @@ static void frameContext(const x265amd_encoder& e, Pic& pic, FrameCtx& c)
     ap.psy_rd = p.psyRd; ap.rd_level = p.rdLevel; ap.early_skip = p.bEnableEarlySkip != 0; ap.rskip = p.recursionSkipMode; ap.limit_refs = p.limitReferences;
     ap.b_intra = p.bIntraInBFrames != 0; ap.rect = p.bEnableRectInter != 0; ap.amp = p.bEnableAMP != 0; ap.limit_modes = p.limitModes != 0;
     ap.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0; ap.use_sao = p.bEnableSAO != 0;
-    ap.fast_intra = p.bEnableFastIntra != 0;
+    ap.fast_intra = p.bEnableFastIntra != 0; ap.limit_tu = p.limitTU;
     ap.rdoq_level = p.rdoqLevel; ap.psy_rdoq_scale = p.rdoqLevel ? p.psyRdoqFix8 : 0;      /* encoder.cpp:3667: no psy-rdoq without RDOQ */
 }
 
@@ -191,9 +191,16 @@ int x265amd_encoder::runFrame(const PicP& picp, std::shared_future<int> prev)
     int nsub = 0;
     const bool sao = p.bEnableSAO != 0;
     if (useDqp && pic.cuQp.empty()) return xa_fail(X265AMD_EINVAL, "encoder: the picture has no CU QPs");
+    XaTuRecs tuRecs = { nullptr, { nullptr, nullptr } };
+    if (p.limitTU >= 3)
+    {
+        pic.tuRecs.assign((size_t)nctu * 21, -1);
+        tuRecs.cur = pic.tuRecs.data();
+        for (int l = 0; l < 2; l++) if (!pic.lists[l].empty() && pic.lists[l][0]->tuRecs.size() == pic.tuRecs.size()) tuRecs.ref[l] = pic.lists[l][0]->tuRecs.data();
+    }
     int rc = xa_analyse_frame(me, st, &info, &sp, &si, &ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                               refDepth.data(), refQp0.data(), planes.data(), (int)(planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
-                              sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, nullptr, useDqp ? pic.cuQp.data() : nullptr);
+                              sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, nullptr, useDqp ? pic.cuQp.data() : nullptr, p.limitTU >= 3 ? &tuRecs : nullptr);
     if (rc != X265AMD_OK) return rc;
     if (hipStreamSynchronize(st) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder: analysis");
 
@@ -803,9 +810,16 @@ int x265amd_encoder::runFrameParallel(const PicP& picp)
     const bool isI = pic.type == TYPE_IDR || pic.type == TYPE_I;
     const uint64_t rowOrder = isI ? (pic.codingOrder + 1 > iBoost ? pic.codingOrder + 1 - iBoost : 1) : pic.codingOrder + 1;
     const XaRowHooks hooks{ &gate, gateRowReady, gateBeforeRow, gateAfterRow, gateCtuWait, gateBeforeCtu, gateAfterCtu, gateRefWait, rowOrder, gateCtuReach };
+    XaTuRecs tuRecs = { nullptr, { nullptr, nullptr } };
+    if (p.limitTU >= 3)
+    {
+        /* (the records were sized when the picture was prepared: pictures coded beside this one read them CTU by CTU behind the gate) */
+        tuRecs.cur = pic.tuRecs.data();
+        for (int l = 0; l < 2; l++) if (!lists[l].empty() && lists[l][0]->tuRecs.size() == pic.tuRecs.size()) tuRecs.ref[l] = lists[l][0]->tuRecs.data();
+    }
     int arc = xa_analyse_frame(me, st, &fc.info, &fc.sp, &fc.si, &fc.ap, pic.units.data(), pic.motion.data(), colPic ? colPic->motion.data() : noCol.data(),
                                refDepth.data(), refQp0.data(), fc.planes.data(), (int)(fc.planes.size() / 3), stride, cstride, stat.data(), coeff.data(), nullptr,
-                               sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks, useDqp ? pic.cuQp.data() : nullptr);
+                               sao ? nullptr : data.data(), data.size(), sizes.data(), &nsub, &hooks, useDqp ? pic.cuQp.data() : nullptr, p.limitTU >= 3 ? &tuRecs : nullptr);
     if (arc != X265AMD_OK) pic.fail();
     filters.join();
     if (arc != X265AMD_OK) return rc = arc;

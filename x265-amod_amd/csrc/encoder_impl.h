@@ -120,6 +120,7 @@ struct Pic
     x265amd_weight wp[2][16][3];                           /* slice.m_weightPredTable (weightAnalyse; all zero without weighted prediction) */
     bool weighted = false;                                 /* some reference of this slice carries a weight */
     bool bScenecut = false, bKeyframe = false;
+    std::vector<int8_t> tuRecs;         /* --limit-tu 3 / 4: CUData::m_refTuDepth of every CTU (XaTuRecs) */
     /* ---- rate control other than constant QP (round 6): what adaptive quantisation and cuTree keep of a picture's Lowres (common/lowres.h) ---- */
     std::vector<int32_t> intraCostHost;                     /* Lowres::intraCost per lowres block (read back once, in lowresInit) */
     std::vector<double> qpAqOffset, qpCuTreeOffset;         /* Lowres::qpAqOffset / qpCuTreeOffset per 16x16 block (the lowres block grid) */

@@ -104,6 +104,7 @@ int x265amd_encoder::prepare(const PicP& picp)
         memset(pic.refPoc, 0, sizeof(pic.refPoc));
         for (int l = 0; l < 2; l++)
             for (size_t r = 0; r < pic.lists[l].size(); r++) pic.refPoc[l][r] = pic.lists[l][r]->poc;
+        if (p.limitTU >= 3) pic.tuRecs.assign((size_t)nctu * 21, -1);
         pic.finalX.resize(ctuH);
         for (int r = 0; r < ctuH; r++) pic.finalX[r] = xa_counter_alloc();
         pic.analysedCols.assign(ctuH, 0);

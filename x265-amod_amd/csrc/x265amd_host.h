@@ -124,11 +124,16 @@ void xa_devmap_push_rows(const x265amd_mv_unit* host, const x265amd_cu_unit* uni
 /* the guards (csrc/ctu_analysis.hip): wait until the row task's hooks (if it has any) let the jobs' reference samples be read; 0, or -1 when a picture failed */
 int xa_ref_guard_mc(const x265amd_mc_job* jobs, int n);
 int xa_ref_guard_me(const x265amd_me_job* jobs, const int* pics, int n);
+/* --limit-tu 3 / 4: CUData::m_refTuDepth of every CTU (21 values each: the CUs of depth 0, 1 and 2 in raster order inside a depth; -1: nothing decided there) -- this picture's,
+ * written as CUs are decided and read from the CTUs to the left and above, and those of the first reference picture of each list (read at the co-located CTU, which is coded
+ * by then: the CTU gate) */
+struct XaTuRecs { int8_t* cur; const int8_t* ref[2]; };
 int xa_analyse_frame(x265amd_me_ctx* me, void* stream, const x265amd_mvpred_info* I, const x265amd_inter_search_params* S,
                      const x265amd_slice_info* si, const x265amd_analysis_params* A, x265amd_cu_unit* units, x265amd_mv_unit* cur,
                      const x265amd_mv_unit* col, const uint8_t* ref_depth, const int8_t* ref_qp0, const uint64_t* h_planes, int num_pics,
                      intptr_t stride, intptr_t cstride, x265amd_cu_stat* cu_stat, int16_t* coeff_out, x265amd_ctu_result* results,
-                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks, const int8_t* cu_qp = nullptr);
+                     uint8_t* slice_data, size_t cap, uint32_t* substream_sizes, int* num_substreams, const XaRowHooks* hooks, const int8_t* cu_qp = nullptr,
+                     const XaTuRecs* tu_recs = nullptr);
 /* cu_qp (with si->use_dqp): Analysis::calculateQpforCuSize for every quantisation group, per CTU in z order -- 1 value (max_cu_dqp_depth 0) or 1 + 4 (depth 1): the QP of the
  * 64x64 CU, then of its four 32x32 CUs; the encoder object fills it from the rate control's QP and the adaptive quantisation / cuTree offsets of the picture */
 

@@ -370,7 +370,6 @@ void* abi_encoder_open(void* p)
     REQUIRE(!PI(p, interlaceMode) && !PI(p, bField), "interlaced coding is not built");
     REQUIRE(!PI(p, bLossless) && !PI(p, bCULossless), "lossless coding is not built");
     REQUIRE(!PI(p, bEnableTransformSkip), "bEnableTransformSkip is not built");
-    REQUIRE(PI(p, limitTU) == 0, "limitTU is not built");
     REQUIRE(PI(p, maxSlices) <= 1, "maxSlices above 1 is not built");
     REQUIRE(!PI(p, bIntraRefresh) && !PI(p, bEnableHME) && !PI(p, bEnableConstrainedIntra), "intra refresh / HME / constrained intra are not built");
     REQUIRE(!PI(p, noiseReductionIntra) && !PI(p, noiseReductionInter) && !rd<const char*>(p, X265ABI_PARAM_scalingLists), "noise reduction / scaling lists are not built");
@@ -407,6 +406,7 @@ void* abi_encoder_open(void* p)
         if (pools && (!strcmp(pools, "none") || !strcmp(pools, "NONE") || !strcmp(pools, "0"))) q.bEnableWavefront = 0;
     }
     q.aspectRatioIdc = PI(p, vui_aspectRatioIdc); q.rdoqLevel = PI(p, rdoqLevel);
+    q.limitTU = PI(p, limitTU);
     q.deblockingFilterTCOffset = PI(p, deblockingFilterTCOffset); q.deblockingFilterBetaOffset = PI(p, deblockingFilterBetaOffset);
     q.bEnableAccessUnitDelimiters = PI(p, bEnableAccessUnitDelimiters) != 0; q.decodedPictureHashSEI = PI(p, decodedPictureHashSEI);
     q.maxCLL = rd<uint16_t>(p, X265ABI_PARAM_maxCLL); q.maxFALL = rd<uint16_t>(p, X265ABI_PARAM_maxFALL); q.bEmitCLL = PI(p, bEmitCLL) != 0;
