@@ -70,7 +70,7 @@ def test_encoder_open_names_what_it_rejects():
     assert (rd("bframes"), rd("bFrameAdaptive"), rd("scenecutThreshold"), rd("maxNumReferences"), rd("rdLevel"), rd("searchRange"), rd("rc_rateControlMode"), rd("rc_aqMode"), rd("rc_cuTree"), rd("bEmitInfoSEI")) == (4, 2, 40, 3, 3, 57, 2, 2, 1, 1)
     wr("sourceWidth", 64); wr("sourceHeight", 64); wr("fpsNum", 30); wr("fpsDenom", 1)
     for name, value, word in (("rc_rateControlMode", 0, b"rc.rateControlMode"), ("bFrameAdaptive", 3, b"bFrameAdaptive"), ("rc_hevcAq", 1, b"hevc-aq"), ("maxCUSize", 32, b"maxCUSize"),
-                              ("limitTU", 4, b"limitTU"), ("bEnableTransformSkip", 1, b"bEnableTransformSkip"), ("searchMethod", 2, b"searchMethod")):
+                              ("rc_bEnableGrain", 1, b"rc.bEnableGrain"), ("bEnableTransformSkip", 1, b"bEnableTransformSkip"), ("searchMethod", 2, b"searchMethod")):
         keep = rd(name)
         wr(name, value)
         assert not f["open"](p) and word in lib.x265amd_last_error(), (name, lib.x265amd_last_error())
