@@ -1707,8 +1707,19 @@ struct Analyzer
             c.x = (int16_t)x; c.y = (int16_t)y; c.log2_size = (uint8_t)log2; cuQp2(c);
             memcpy(c.ctx, d.cur.ctx, X265AMD_CTX_COUNT);
             c.frac_bits = d.cur.frac;
-            const int b = xa_check_intra_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
-                                                  tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+            int b;
+            if (log2 == 5)
+            {
+                XA_HOSTPROF("an.intra begin 32");
+                b = xa_check_intra_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
+                                            tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+            }
+            else
+            {
+                XA_HOSTPROF("an.intra begin 16");
+                b = xa_check_intra_begin_ws(st, si, &rp, units, planes + 3 * (numPics - 1), planes + 3 * (numPics - 2), stride, cstride, &c,
+                                            tileAddr(predTile(depth, PRED_INTRA)), tileAddr(reconTile(depth, PRED_INTRA)), &intraWs);
+            }
             if (b < 0) return err = b;
             deferred = b == 1;
             (void)m;
@@ -1751,6 +1762,7 @@ struct Analyzer
                 if (qrc < 0) return err = qrc;
                 if (qrc == 0)
                 {
+                    XA_HOSTPROF("an.compressIntra chain results");
                     chained = true;
                     if (const char* lg = getenv("X265AMD_CHAIN_LOG"))
                     {
@@ -1845,6 +1857,7 @@ struct Analyzer
             split.contexts = *nextContext;
             if (mightNotSplit) addSplitFlagCost(split, x, y, depth);
             else updateModeCost(split);
+            XA_HOSTPROF("an.compressIntra collect + compare");
             if (deferred)
             {
                 /* now the 2Nx2N result, then the comparisons in the reference's order */
@@ -1855,6 +1868,7 @@ struct Analyzer
             if (checkDQPForSplitPred(split, x, y, depth)) return err;          /* analysis.cpp:642 */
             checkBestMode(split, depth);
         }
+        XA_HOSTPROF("an.compressIntra tail (toPicture)");
         saveTUDepth(*d.best, x, y, depth);          /* analysis.cpp:653-659 (I slices leave the records the P pictures behind them load) */
         toPicture(*d.best, x, y, depth);
         if (d.best != &d.pred[PRED_SPLIT]) tileToPicture(d.best->reconTile, x, y, size);
@@ -2273,6 +2287,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
     Analyzer* an;
     { XA_HOSTPROF("ctu.new Analyzer"); an = new Analyzer; }
     Analyzer& a = *an;
+    XA_HOSTPROF("ctu.all but new / delete");
     a.me = me; a.st = (hipStream_t)stream; a.I = I; a.S = S; a.si = si; a.A = A; a.units = units; a.cur = cur; a.col = col;
     a.tuRecs = tu_recs;
     if (tu_recs && tu_recs->cur) memset(tu_recs->cur + (size_t)ctu_addr * 21, -1, 21);          /* CUData::initCTU (cudata.cpp:312-313) */
@@ -2330,6 +2345,7 @@ static int compress_ctu_impl(x265amd_me_ctx* me, void* stream, const x265amd_mvp
             else a.chain.nodes[0].next = 0;
         }
         if (rc == X265AMD_OK) rc = si->slice_type == 2 ? a.compressIntra(a.ctuX, a.ctuY, 0) : (A->rd_level > 4 ? a.compress56(a.ctuX, a.ctuY, 0, topSplit) : a.compress(a.ctuX, a.ctuY, 0, topSplit, 0));
+        XA_HOSTPROF("ctu.final fence + sync");
         if (rc == X265AMD_OK && (xa_stream_fence(a.st, XA_CMD_RELEASE) != hipSuccess || xa_stream_sync(a.st) != hipSuccess)) rc = xa_fail(X265AMD_EHIP, "compress_ctu_inter: synchronize");
     }
     if (rc == X265AMD_OK)

@@ -11,24 +11,38 @@
 #ifndef XA_PREFETCH_SLOT
 #define XA_PREFETCH_SLOT 0          /* fetching the next slot while a command runs: measured, no gain (the load competes with the command's own first loads) */
 #endif
-/* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside" */
+/* stage stamps (X265AMD_QUEUE_PROF): thread 0 of the workgroup adds the time since its previous stamp to the stage's total; [15] is "outside".  A stamp is a clock read
+ * and an LDS update by the wavefront everybody else waits for at the next barrier -- forty of them in an 8x8 CU of an I picture -- so they are compiled in only when the
+ * library is built for that report (X265AMD_EXTRA_FLAGS=-DXA_PROFILE_STAGES bash build.sh); otherwise the report's stage lines read zero. */
 __shared__ unsigned long long xa_stage_acc[22];      /* [0..15] transform chains and the prediction-unit step, [16..21] the NxN step */
 __shared__ long long xa_stage_prev;
-#ifdef XA_NO_STAGES
-#define XA_STAGE(k)
-#else
-#define XA_STAGE(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_stage_acc[k] += (unsigned long long)(t_ - xa_stage_prev); xa_stage_prev = t_; } } while (0)
-#endif
 /* the fused intra command's stages on a clock of its own (the chains' stamps above do not disturb it): [kind][stage], thread 0 */
 __shared__ unsigned long long xa_nxn_acc[4][10];
 __shared__ unsigned long long xa_chain_acc[8];
 __shared__ long long xa_chain_prev;
-#define XA_CHAIN_START() do { if (threadIdx.x == 0) xa_chain_prev = wall_clock64(); } while (0)
-#define XA_CHAIN(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_chain_acc[k] += (unsigned long long)(t_ - xa_chain_prev); xa_chain_prev = t_; } } while (0)
 __shared__ long long xa_nxn_prev;
 __shared__ int xa_nxn_kind;
+#ifdef XA_PROFILE_STAGES
+#define XA_STAGE(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_stage_acc[k] += (unsigned long long)(t_ - xa_stage_prev); xa_stage_prev = t_; } } while (0)
+#define XA_CHAIN_START() do { if (threadIdx.x == 0) xa_chain_prev = wall_clock64(); } while (0)
+#define XA_CHAIN(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_chain_acc[k] += (unsigned long long)(t_ - xa_chain_prev); xa_chain_prev = t_; } } while (0)
 #define XA_NXN_START(kind) do { if (threadIdx.x == 0) { xa_nxn_kind = (kind); xa_nxn_prev = wall_clock64(); } } while (0)
 #define XA_NXN(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_nxn_acc[xa_nxn_kind][k] += (unsigned long long)(t_ - xa_nxn_prev); xa_nxn_prev = t_; } } while (0)
+#define XA_LINK_START()
+#define XA_LINK(k)
+#define XA_LINK_T(k)
+#else
+#define XA_STAGE(k)
+#define XA_CHAIN_START()
+#define XA_CHAIN(k)
+#define XA_NXN_START(kind)
+#define XA_NXN(k)
+/* what stays in every build: the two waits of a chained 8x8 CU that say which of its two evaluations the chain waits for ([6] the deciding command for the other
+ * evaluation, [7] the other command for the chain): two clock reads per CU by a lane that is waiting anyway */
+#define XA_LINK_START() do { if (threadIdx.x == 0) xa_chain_prev = wall_clock64(); } while (0)
+#define XA_LINK(k) do { if (threadIdx.x == 0) xa_chain_acc[k] += (unsigned long long)(wall_clock64() - xa_chain_prev); } while (0)
+#define XA_LINK_T(k) do { if (threadIdx.x == 0) { const long long t_ = wall_clock64(); xa_chain_acc[k] += (unsigned long long)(t_ - xa_chain_prev); xa_chain_prev = t_; } } while (0)
+#endif
 #include "tu_dev.h"
 #include "intra_dev.h"
 #include "mc_dev.h"
@@ -891,6 +905,9 @@ struct Server
         {
             uint64_t cx[8] = { 0 };
             for (int i = 0; i < numQueues; i++) for (int k = 0; k < 8; k++) cx[k] += hosts[i].chain[k];
+            if (cx[6] || cx[7])
+                fprintf(stderr, "  chained 8x8 CUs (ms, all workgroups): the deciding command: its evaluation %.1f, waiting for the other evaluation %.1f, the decision up to the chain's word %.1f; "
+                        "the other command: waiting for the chain %.1f, its evaluation up to its word %.1f\n", cx[5] / 1e5, cx[6] / 1e5, cx[4] / 1e5, cx[7] / 1e5, cx[3] / 1e5);
             if (cx[3])
                 fprintf(stderr, "  chained 8x8 CUs (ms): the deciding command waiting for the chain %.1f, the other command waiting for the chain %.1f, waiting for the other evaluation %.1f, "
                         "its record + both CUs' bits %.1f, costs + the winner's samples + the result %.1f, publishing %.1f\n", cx[0] / 1e5, cx[1] / 1e5, cx[2] / 1e5, cx[3] / 1e5, cx[4] / 1e5, cx[5] / 1e5);

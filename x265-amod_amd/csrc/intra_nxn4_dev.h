@@ -560,12 +560,14 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
     x265amd_intra_cu8_result* out = reinterpret_cast<x265amd_intra_cu8_result*>(P.cu_out);
     __syncthreads();
     XA_CHAIN_START();
+    XA_LINK_T(5);
     if (tid == 0)
     {
         bool ok = xa_chain_wait(&peer->ready, P.chain_token + 1);
         if (ok && __hip_atomic_load(&peer->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ~0ull) ok = false;      /* the other side gave up */
         S.peerOk = ok ? 1 : 0;
     }
+    XA_LINK_T(6);
     __syncthreads();
     XA_CHAIN(2);
     if (!S.peerOk)
@@ -664,22 +666,29 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
             reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = v;
             reinterpret_cast<pixel*>(P.win_dst[1 + pl])[y * 32 + x] = v;
         }
-        /* the host's record */
-        else if (tid < 96 + 96)
-        {
-            const int i = tid - 96;
-            int16_t v;
-            if (i < 64) v = nxnWins ? S.lev[i] : Q.levels[0][i];
-            else v = nxnWins ? S.clev[S.cw][(i - 64) >> 4][i & 15] : Q.clevels[(i - 64) >> 4][i & 15];
-            out->levels[i] = v;
-        }
-        else if (tid < 192 + X265AMD_CTX_STRIDE)
-        {
-            const int i = tid - 192;
-            const uint8_t v = S.fctx[win][i];
-            out->ctx[i] = v; ch->ctx[i] = v;
-        }
+        else if (tid >= 192 && tid < 192 + X265AMD_CTX_STRIDE) ch->ctx[tid - 192] = S.fctx[win][tid - 192];
     }
+    /* what the next CU of the chain takes is out first, and the chain goes on; the host's record (pinned host memory: its stores cross the bus, and the release in front
+     * of the chain's word would wait for every one of them) is written behind that -- the host reads it when the command is over */
+    if (tid == 0)
+    {
+        for (int k = 0; k < 4; k++) ch->mode[P.chain_index & 3][k] = nxnWins ? S.winMode[k] : Q.mode[0];
+        ch->frac = S.ffrac[win];
+    }
+    __syncthreads();
+    XA_CHAIN(4);
+    if (tid == 0) xa_chain_publish(&ch->seq, P.chain_token + 1);
+    XA_CHAIN(5);
+    XA_LINK_T(4);
+    if (tid >= 96 && tid < 96 + 96)
+    {
+        const int i = tid - 96;
+        int16_t v;
+        if (i < 64) v = nxnWins ? S.lev[i] : Q.levels[0][i];
+        else v = nxnWins ? S.clev[S.cw][(i - 64) >> 4][i & 15] : Q.clevels[(i - 64) >> 4][i & 15];
+        out->levels[i] = v;
+    }
+    else if (tid >= 192 && tid < 192 + X265AMD_CTX_STRIDE) out->ctx[tid - 192] = S.fctx[win][tid - 192];
     if (tid == 0)
     {
         out->rd_cost = nxnWins ? costN : cost2; out->other_cost = nxnWins ? cost2 : costN; out->frac_bits = S.ffrac[win];
@@ -692,16 +701,11 @@ XA_DEV void nxn4_decide(const x265amd_intra_nxn_job& P, Nxn4Lds& S, int tid, int
         for (int k = 0; k < 4; k++)
         {
             const uint8_t m = nxnWins ? S.winMode[k] : Q.mode[0];
-            out->luma_dir[k] = m; ch->mode[P.chain_index & 3][k] = m;
+            out->luma_dir[k] = m;
             out->cbf_y[k] = nxnWins ? (S.ures[k].num_sig != 0) : (Q.res[0].num_sig != 0);
         }
-        ch->frac = S.ffrac[win];
         out->status = 1;
     }
-    __syncthreads();
-    XA_CHAIN(4);
-    if (tid == 0) xa_chain_publish(&ch->seq, P.chain_token + 1);
-    XA_CHAIN(5);
 }
 
 /* rqBase: NXN4_RQ_BYTES of LDS behind S when the command quantises with RDOQ */
@@ -743,10 +747,11 @@ XA_DEV void block_intra_nxn4(const x265amd_intra_nxn_job& P, x265amd_intra_nxn_o
         else { x = -1; y = i - 17; have = y < 4 ? ((a0 >> 1) & 1) : (y < 8 ? ((a0 | (a2 >> 1)) & 1) : (y < 12 ? (a2 & 1) : false)); }
         S.frame[(y + 1) * 17 + x + 1] = have ? pic[(long)y * ps + x] : (pixel)0;
     }
-    if (P.do_chroma && wv == nwv - 1)
+    if (P.do_chroma && wv >= nwv - 2)
     {
-        /* the two chroma blocks' neighbours and source samples (initAdiPatternChroma: no smoothing) */
-        for (int pl = 0; pl < 2; pl++)
+        /* the two chroma blocks' neighbours and source samples (initAdiPatternChroma: no smoothing): a wavefront per plane, so that their reads of the picture are one
+         * round trip and not two (one wavefront alone takes them one after the other) */
+        for (int pl = nwv >= 2 ? wv - (nwv - 2) : 0; pl < (nwv >= 2 ? wv - (nwv - 2) + 1 : 2); pl++)
         {
             const x265amd_intra_tu_job& C = P.ctmpl[pl];
             (void)nxn4_neighbours(reinterpret_cast<const pixel*>(C.nb), (int)C.nb_stride, (uint32_t)C.avail, S.cref[pl], S.csw[pl], lane);

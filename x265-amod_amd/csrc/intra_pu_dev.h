@@ -161,23 +161,25 @@ XA_DEV bool nxn_chain_begin(x265amd_intra_nxn_job& sP, int tid, int nthr)
 {
     __shared__ int s_chainOk;
     x265amd_intra_chain* ch = reinterpret_cast<x265amd_intra_chain*>(sP.chain);
+    XA_LINK_START();
     if (sP.chain_first) return true;
     XA_CHAIN_START();
     if (tid == 0) s_chainOk = xa_chain_wait(&ch->seq, sP.chain_token) ? 1 : 0;
+    if (sP.chain_role != 1) XA_LINK_T(7);
     __syncthreads();
     XA_CHAIN(sP.chain_role == 1 ? 0 : 1);
     if (!s_chainOk) return false;
-    const uint64_t frac = ch->frac & 32767;
-    uint8_t m[4];
-    for (int i = 0; i < 4; i++)
-    {
-        const uint8_t src = sP.mode_src[i];
-        m[i] = src == 0xFF ? (i < 2 ? sP.left_mode[i] : sP.above_mode[i - 2]) : ch->mode[src >> 2][src & 3];
-    }
-    __syncthreads();
     for (int i = tid; i < X265AMD_CTX_STRIDE; i += nthr) sP.ctx[i] = ch->ctx[i];
     if (tid == 0)
     {
+        /* (the record's mode fields are read and written by this lane alone) */
+        const uint64_t frac = ch->frac & 32767;
+        uint8_t m[4];
+        for (int i = 0; i < 4; i++)
+        {
+            const uint8_t src = sP.mode_src[i];
+            m[i] = src == 0xFF ? (i < 2 ? sP.left_mode[i] : sP.above_mode[i - 2]) : ch->mode[src >> 2][src & 3];
+        }
         sP.left_mode[0] = m[0]; sP.left_mode[1] = m[1]; sP.above_mode[0] = m[2]; sP.above_mode[1] = m[3];
         sP.scan_frac = (uint32_t)frac;
         /* what codeIntraLumaQT finds in front of the first unit's direction in an I slice: the partition size bin (2Nx2N: 1, NxN: 0) */
@@ -213,12 +215,24 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ uint32_t s_psyNxn, s_resNxn;
     XA_STAGE(15);
     XA_NXN_START(0);
-    __shared__ x265amd_intra_nxn_job sP;           /* the job record: 896 bytes, indexed by the unit -- in LDS, not in registers */
+    __shared__ x265amd_intra_nxn_job sP;           /* the job record: about a kilobyte, indexed by the unit -- in LDS, not in registers */
     static_assert(sizeof(x265amd_intra_nxn_job) % 8 == 0, "job records are sequences of 64-bit words");
     __syncthreads();
     for (int i = tid; i < (int)(sizeof(x265amd_intra_nxn_job) / 8); i += nthr)
         reinterpret_cast<uint64_t*>(&sP)[i] = __hip_atomic_load(reinterpret_cast<const uint64_t*>(pj) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
+    /* the estimator's tables beside it: the lanes that count bits look them up bin after bin.  (Filled BEFORE a chained CU waits for the CU in front of it: the other
+     * evaluation of a chained CU has nothing else to do then, and what it does after the wait is the chain's critical path.) */
+    __shared__ uint32_t s_enBits[128];
+    __shared__ uint8_t s_enLps[64];
+    __shared__ uint32_t s_step[256];               /* bits and next state per (state, bin): the one look-up of the per-context walks (wave_coeff_bits_4x4) */
+    const bool nxn4Form = (sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture && (!sP.rdoq_level || !sP.rdoq_general);
+    if (!nxn4Form)
+    {
+        if (tid < 128) s_enBits[tid] = en_bits[tid];
+        if (tid < 64) s_enLps[tid] = en_lpsNext[tid];
+        for (int i = tid; i < 256; i += nthr) s_step[i] = en_step.v[i];
+    }
     if (sP.chain)
     {
         if (!nxn_chain_begin(sP, tid, nthr))
@@ -233,19 +247,12 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
         }
         if (sP.chain_role == 2) po = &reinterpret_cast<x265amd_intra_peer*>(sP.peer)->out;
     }
-    if ((sP.num_units == 0 || sP.num_units == 4) && (sP.unit_log2 == 0 || sP.unit_log2 == 2) && !sP.pick_sa8d && !sP.no_picture && (!sP.rdoq_level || !sP.rdoq_general))
+    if (nxn4Form)
     {
         /* the NxN CU proper: its own form, nothing but LDS and registers between the first and the last instruction (intra_nxn4_dev.h) */
         block_intra_nxn4(sP, po, *reinterpret_cast<Nxn4Lds*>(smem), S, tid, nthr, smem + ((sizeof(Nxn4Lds) + 15) & ~(size_t)15));
         return;
     }
-    /* the estimator's tables beside it: the lanes that count bits look them up bin after bin */
-    __shared__ uint32_t s_enBits[128];
-    __shared__ uint8_t s_enLps[64];
-    __shared__ uint32_t s_step[256];               /* bits and next state per (state, bin): the one look-up of the per-context walks (wave_coeff_bits_4x4) */
-    if (tid < 128) s_enBits[tid] = en_bits[tid];
-    if (tid < 64) s_enLps[tid] = en_lpsNext[tid];
-    for (int i = tid; i < 256; i += nthr) s_step[i] = en_step.v[i];
     const EnTabs tabs{ s_enBits, s_enLps };
     const x265amd_intra_nxn_job& P = sP;
     const int lane = tid & 63, wv = tid >> 6, nwv = nthr >> 6;
@@ -458,6 +465,123 @@ XA_DEV void block_intra_nxn(const x265amd_intra_nxn_job* pj, x265amd_intra_nxn_o
     __shared__ pixel s_cfenc[2][16];                /* the two source blocks of the 4x4 case, read by the five modes' chains */
     const int cLog2 = numUnits == 1 ? unitLog2 - 1 : 2, CN = 1 << cLog2;
     const uint32_t lumaDir = s_winMode[0];
+    if (chromaAhead && P.chain && P.chain_role == 2)
+    {
+        /* The other evaluation of a chained CU is what the chain waits for (the deciding command stands five microseconds per CU: XA_LINK), so its tail is ONE barrier
+         * interval instead of six with the CU's bit count behind them: the last wavefront counts the luma share of the CU's bits (Search::checkIntra's count at its end,
+         * search.cpp:1254-1275: partition size, prediction info, the coded block flag and the coefficients on a copy of the start contexts) while the first one makes
+         * the chroma decision of the branch below with wavefront-level fences; then the sums, the merged contexts, and the word the deciding command waits for. */
+        __shared__ uint8_t s_ftSrc[5], s_ftC14[5];
+        __shared__ unsigned long long s_ftFrac, s_ftMv;
+        Nxn4Lds& S4 = S4c;
+        x265amd_intra_peer* peer = reinterpret_cast<x265amd_intra_peer*>(P.peer);
+        uint8_t* run = s_ctxw[5];
+        if (wv == nwv - 1)
+        {
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) run[b] = P.ctx[b];
+            xa_wave_sync();
+            const uint32_t mode = s_winMode[0];
+            const uint32_t numSigY = s_numSig0;
+            unsigned long long frac = P.scan_frac, mvf = 0;
+            if (lane == 0)
+            {
+                frac += cb_bin_t(tabs, run + 8, 1u);                                                   /* C_PART_SIZE: 2Nx2N */
+                const int pidx = mode == s_preds0[0] ? 0 : (mode == s_preds0[1] ? 1 : (mode == s_preds0[2] ? 2 : -1));
+                frac += cb_bin_t(tabs, run + 13, pidx != -1 ? 1u : 0u);
+                frac += (unsigned long long)(pidx != -1 ? 1 + (pidx != 0) : 5) << 15;
+                mvf = frac;                                                                            /* (the chroma mode's share joins below) */
+                frac += cb_bin_t(tabs, run + CTX_QT_CBF + 1, numSigY != 0 ? 1u : 0u);
+            }
+            xa_wave_sync();
+            frac = __shfl(frac, 0, 64); mvf = __shfl(mvf, 0, 64);
+            if (numSigY) frac += wave_coeff_bits(run, run, P.levels_dst ? reinterpret_cast<const int16_t*>(P.levels_dst) : &po->levels[0][0], unitLog2, 0, 1, (int)mode, P.tmpl[0].tu.sign_hide, s_step, lane);
+            xa_wave_sync();
+            if (lane == 0) { s_ftFrac = frac; s_ftMv = mvf; }
+        }
+        else if (wv == 0)
+        {
+            int src = 0;
+            uint32_t listed = 0;
+            if (lane < 5)
+            {
+                uint32_t list[5] = { 0, 26, 10, 1, 36 };                /* CUData::getAllowedChromaDir (cudata.cpp:889-907) */
+                for (int i = 0; i < 4; i++) if (lumaDir == list[i]) { list[i] = 34; break; }
+                listed = list[lane];
+                s_cmode[lane] = (uint8_t)listed;
+                const uint32_t mode = listed == 36 ? lumaDir : listed;
+                src = mode == 0 ? 0 : (mode == 26 ? 1 : (mode == 10 ? 2 : (mode == 1 ? 3 : (mode == 34 ? 4 : 5))));
+                s_ftSrc[lane] = (uint8_t)src;
+            }
+            if (lane == 0) s_specModes[5] = (uint8_t)lumaDir;
+            const bool need = __ballot(lane < 5 && src == 5) != 0;
+            xa_wave_sync();
+            const EnTabs tabsC{ S4.enBits, S4.enLps };
+            if (need)
+            {
+                nxn4_chroma_spec(P, S4, s_specModes, 5, 6, 0, tabsC, lane, lane >> 4, lane & 15);
+                xa_wave_sync();
+                nxn4_chroma_spec(P, S4, s_specModes, 5, 6, 1, tabsC, lane, lane >> 4, lane & 15);
+                xa_wave_sync();
+            }
+            if (lane < 5)
+            {
+                uint8_t c14 = P.ctx[14];
+                unsigned long long frac = P.scan_frac;
+                frac += cb_bin_t(tabs, &c14, listed == 36 ? 0u : 1u);                                   /* C_CHROMA_PRED (codeIntraDirChroma, entropy.cpp:1644-1664) */
+                if (listed != 36) frac += 2ull << 15;
+                frac += S4.cfrac[src];                                                                  /* the coded block flags and the coefficients: the slot's share */
+                const x265amd_tu_result rU = S4.cres[src][0], rV = S4.cres[src][1];
+                const unsigned long long dist = rU.nz_dist + rV.nz_dist, energy = (unsigned long long)rU.nz_energy + rV.nz_energy;
+                const unsigned long long bits = (uint32_t)(frac >> 15);
+                s_cfrac[lane] = frac; s_ftC14[lane] = c14;
+                S4.ccost[lane] = P.psy_scale ? dist + ((P.psy_scale * energy) >> 24) + ((bits * P.lambda2) >> 8) : dist + ((bits * P.lambda2 + 128) >> 8);
+            }
+            xa_wave_sync();
+            int w = 0;
+            {
+                unsigned long long best = ~0ull;
+                for (int i = 0; i < 5; i++) if (S4.ccost[i] < best) { best = S4.ccost[i]; w = i; }
+            }
+            const int sw = s_ftSrc[w], slast = s_ftSrc[4];
+            if (lane == 0)
+            {
+                s_win = w;
+                po->chroma_best = (uint32_t)w; po->chroma_reserved = 0;
+                po->cres[0] = S4.cres[sw][0]; po->cres[1] = S4.cres[sw][1];
+            }
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE) s_ctxw[w][b] = b == 14 ? s_ftC14[w] : S4.ctxw[sw][b];
+            if (lane < 32)
+            {
+                const int pl = lane >> 4, i = lane & 15, y = i >> 2, x = i & 3;
+                const x265amd_intra_tu_job& C = P.ctmpl[pl];
+                int16_t* clOut = P.clevels_dst ? reinterpret_cast<int16_t*>(P.clevels_dst) : &po->clevels[0][0];
+                reinterpret_cast<pixel*>(P.crecon_dst[pl])[y * 32 + x] = S4.crec[sw][pl][i];
+                if (!P.no_picture) reinterpret_cast<pixel*>(C.nb)[(long)y * C.nb_stride + x] = S4.crec[slast][pl][i];      /* the last tried mode's samples: the derived mode's */
+                clOut[pl * 16 + i] = S4.clev[sw][pl][i];
+            }
+        }
+        __syncthreads();
+        if (wv == 0)
+        {
+            const int cwIdx = s_win;
+            const uint32_t listedW = s_cmode[cwIdx];
+            /* the chroma decision's contexts over the luma walk's: what it moved is chroma's alone */
+            for (int b = lane; b < X265AMD_CTX_STRIDE; b += XA_WAVE)
+            {
+                const uint8_t c = s_ctxw[cwIdx][b];
+                peer->fctx[b] = c != P.ctx[b] ? c : run[b];
+            }
+            if (lane == 0)
+            {
+                peer->ffrac = s_ftFrac + (s_cfrac[cwIdx] - P.scan_frac);
+                peer->fmv = s_ftMv + s_enBits[P.ctx[14] ^ (listedW == 36 ? 0u : 1u)] + (listedW != 36 ? (2ull << 15) : 0ull);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) xa_chain_publish(&peer->ready, P.chain_token + 1);
+        XA_LINK_T(3);
+        return;
+    }
     if (cLog2 == 2 && !chromaAhead && tid >= 64 && tid < 96)
     {
         const int pl = (tid - 64) >> 4, i = tid & 15;

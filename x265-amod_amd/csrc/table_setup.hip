@@ -343,15 +343,17 @@ void xa_copy_rects(void* st, const XaRects& r)
 /* ---- X265AMD_HOSTPROF (x265amd_host.h) ---- */
 #include "xa_fiber.h"
 #include <atomic>
+#include <string.h>
 #include <time.h>
 bool g_xaHostProf = getenv("X265AMD_HOSTPROF") != nullptr;
 namespace {
 struct HpEntry { const char* name; std::atomic<uint64_t> calls, ns; };
 HpEntry g_hp[128];
 std::atomic<int> g_hpN{ 0 };
+const bool g_hpWall = getenv("X265AMD_HOSTPROF") && !strcmp(getenv("X265AMD_HOSTPROF"), "wall");      /* X265AMD_HOSTPROF=wall: the scopes on the wall clock (parked time included) */
 inline uint64_t hp_now()
 {
-    if (xa_in_task()) return xa_task_run_ns_always();
+    if (!g_hpWall && xa_in_task()) return xa_task_run_ns_always();
     struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 }
