@@ -450,6 +450,10 @@ struct Analyzer
         J.tu_log2_max = si->tu_log2_max;
         J.ctu_x = ctuX; J.ctu_y = ctuY; J.lambda = lambda; J.lambda2 = lambda2; J.psy_rd = psyRd;
         { static const int dbg = getenv("X265AMD_CHAIN_DBG") ? atoi(getenv("X265AMD_CHAIN_DBG")) : 0; J.dbg = dbg; }
+        /* the 64x64 CU with levels decided on the device (chain_merge_rd64): built, verified candidate by candidate (X265AMD_CHAIN_VERIFY=2) and measured as no gain -- the
+         * twelve units' chains take on the device what the host's two round trips took, and the pictures' links are the last column's searched CTUs either way -- so it
+         * stays off unless asked for (X265AMD_CHAIN_64=1); the host's merge check goes on from the device's candidate instead (chainMergeFrom) */
+        { static const bool on64 = getenv("X265AMD_CHAIN_64") && atoi(getenv("X265AMD_CHAIN_64")) != 0; J.chain64_off = !on64; }
         J.rd_level = A->rd_level; J.sign_hide = si->sign_hide != 0; J.max_cu_depth = si->max_cu_depth;
         if (!chain.dScratch.p && chain.dScratch.alloc(x265amd_inter_rd_scratch_bytes()) != hipSuccess) return fail("chain scratch");
         J.scratch = (uint64_t)(uintptr_t)chain.dScratch.p;
@@ -530,6 +534,7 @@ struct Analyzer
             chain.stopNode = (int)stopNode; chain.stopFrac = o->frac; memcpy(chain.stopCtx, (const void*)o->ctx, X265AMD_CTX_STRIDE);
             chain.stop.valid = 0;
             if (o->stop.valid == 1 && o->stop.node == stopNode) memcpy(&chain.stop, (const void*)&o->stop, sizeof(XaChainStop));
+            else if (o->stop.valid == 2 && o->stop.node == stopNode) memcpy(&chain.stop, (const void*)&o->stop, offsetof(XaChainStop, ctx));     /* (the head alone: chainMergeFrom) */
         }
         chain.runs++; chain.skipped += count;
         if (g_timing)
@@ -603,6 +608,44 @@ struct Analyzer
         d.best->predTile = keep;
         taken = true;
         return checkDQP(*d.best, x, y, depth);              /* analysis.cpp:2879 */
+    }
+    /* the merge check of a 64x64 CU the chain stopped at with a level somewhere in its residual (XaChainStop::valid 2): the device has predicted and ranked the candidates
+     * as checkMerge2Nx2N_rd0_4 does (the chain's own choice of every skipped CU), so the check goes on from the chosen candidate -- its prediction lies in its tile --
+     * with the two modes' rate-distortion (rdMergePair); one wait less than checkMerge's own predictions and measurements */
+    int chainMergeFrom(int node, int x, int y, int depth, bool& taken)
+    {
+        taken = false;
+        static const bool on = !(getenv("X265AMD_CHAIN_MERGE_FROM") && atoi(getenv("X265AMD_CHAIN_MERGE_FROM")) == 0);
+        if (!on || A->rd_level < 3 || rp.rdoq_level || chain.status[node] != 2 || chain.stopNode != node || chain.stop.valid != 2 || chain.stop.node != (uint32_t)node) return 0;
+        XA_HOSTPROF("an.chainMergeFrom");
+        const XaChainStop& c = chain.stop;
+        ModeDepth& d = md[depth];
+        const int size = 64 >> depth;
+        Mode* bestPred = &d.pred[PRED_SKIP];
+        Mode* tempPred = &d.pred[PRED_MERGE];
+        tempPred->initCosts(); bestPred->initCosts();
+        const int16_t zero[2][2] = { { 0, 0 }, { 0, 0 } };
+        const uint8_t noIdx[2] = { 0, 0 };
+        const int numCand = I->max_num_merge_cand;
+        const uint32_t bits = (uint32_t)(c.cand + (c.cand < numCand - 1));
+        x265amd_cu_measure ms;
+        memset(&ms, 0, sizeof(ms));
+        ms.sa8d = c.sa8d; ms.sa8d_luma = c.sa8d_luma;
+        for (Mode* m : { bestPred, tempPred })
+        {
+            setInter(*m, depth, 1, c.cand, c.dir, c.ref_idx, c.mv, zero, noIdx);
+            m->sa8dCost = calcRdSADCost(sa8dOf(ms), bits); m->sa8dBits = bits;
+            m->predTile = candTile(depth, c.cand);
+        }
+        bestPred->reconTile = reconTile(depth, PRED_SKIP); tempPred->reconTile = reconTile(depth, PRED_MERGE);
+        d.srcMean = 0; d.srcHomo = 0;          /* (read at rd 2 only) */
+        if (rdMergePair(*bestPred, *tempPred, x, y, depth)) return err;
+        d.best = tempPred->rdCost < bestPred->rdCost ? tempPred : bestPred;
+        const int keep = predTile(depth, d.best == tempPred ? PRED_MERGE : PRED_SKIP);
+        copyTile(keep, candTile(depth, c.cand), 0, 0, size);
+        d.best->predTile = keep;
+        taken = true;
+        return checkDQP(*d.best, x, y, depth);
     }
     /* the merge check of a CU decided on the device as a skip: Mode PRED_SKIP as checkMerge leaves it (candidate, costs, contexts) */
     int chainSkip(int node, int x, int y, int depth, bool& skipped)
@@ -1973,7 +2016,26 @@ struct Analyzer
                         return fail("chain verify: the device's merge check is not the host's");
                     }
                 }
-                if (!devMerge && checkMerge(x, y, depth)) return err;
+                bool devFrom = false;
+                if (!devMerge && chain.on && chainMergeFrom(node, x, y, depth, devFrom)) return err;
+                if (devFrom && verify3)
+                {
+                    /* debugging: the host's own merge check, candidates and all, must leave the same two modes */
+                    const uint64_t c0 = d.pred[PRED_SKIP].rdCost, c1 = d.pred[PRED_MERGE].rdCost, s0 = d.pred[PRED_MERGE].sa8dCost; const Snap s1 = d.best->contexts;
+                    const int cand0 = d.pred[PRED_MERGE].u[0].mvp_idx[0]; const bool mergeBest = d.best == &d.pred[PRED_MERGE];
+                    d.best = nullptr;
+                    if (checkMerge(x, y, depth)) return err;
+                    if (!d.best || d.pred[PRED_SKIP].rdCost != c0 || d.pred[PRED_MERGE].rdCost != c1 || d.pred[PRED_MERGE].sa8dCost != s0 || d.pred[PRED_MERGE].u[0].mvp_idx[0] != cand0 ||
+                        (d.best == &d.pred[PRED_MERGE]) != mergeBest || d.best->contexts.frac != s1.frac || memcmp(d.best->contexts.ctx, s1.ctx, X265AMD_CTX_COUNT))
+                    {
+                        fprintf(stderr, "x265amd chain verify: poc %d CU (%d,%d) size %d: merge check from the device's candidate %d differs: skip cost %llu / %llu, residual mode %llu / %llu, sa8d cost %llu / %llu, "
+                                "candidate %d, best %d / %d\n", I->poc, x, y, size, cand0, (unsigned long long)c0, (unsigned long long)d.pred[PRED_SKIP].rdCost, (unsigned long long)c1,
+                                (unsigned long long)d.pred[PRED_MERGE].rdCost, (unsigned long long)s0, (unsigned long long)d.pred[PRED_MERGE].sa8dCost, d.pred[PRED_MERGE].u[0].mvp_idx[0], (int)mergeBest,
+                                (int)(d.best == &d.pred[PRED_MERGE]));
+                        return fail("chain verify: the merge check from the device's candidate is not the host's");
+                    }
+                }
+                if (!devMerge && !devFrom && checkMerge(x, y, depth)) return err;
             }
             skipModes = A->early_skip && d.best && d.best->isSkipped();
         }

@@ -51,6 +51,13 @@ struct XaChainStop
     uint8_t ctx[X265AMD_CTX_STRIDE];
     int16_t levels[1024 + 2 * 256];         /* Y (N x N), U, V (N/2 x N/2 each, from [1024] and [1280]) */
 };
+/* the stop record's head as one store sequence (xa_st_result): everything in front of XaChainStop::ctx */
+struct alignas(8) XaChainStopHead
+{
+    uint32_t valid, node; uint8_t cand, dir; int8_t ref_idx[2]; int16_t mv[2][2]; uint8_t cbf[3], reserved0;
+    uint32_t total_bits, mv_bits, coeff_bits, psy_energy, sa8d, sa8d_luma; uint64_t rd_cost, luma_dist, chroma_dist, frac; x265amd_cu_measure meas;
+};
+static_assert(sizeof(XaChainStopHead) == offsetof(XaChainStop, ctx), "the stop record's head");
 struct XaChainOut { uint32_t count, stop_node, reason, reserved; uint64_t frac; uint64_t ticks[8]; uint8_t ctx[X265AMD_CTX_STRIDE]; XaChainStop stop; XaChainCuOut cu[XA_CHAIN_MAX_NODES]; };     /* frac / ctx: the coder's state where the chain stopped */
 
 struct alignas(8) XaChainJob
@@ -65,7 +72,7 @@ struct alignas(8) XaChainJob
     int32_t stride, cstride, num_pics, w4;
     int32_t start, end, num_nodes;
     int32_t tiles_per_depth, cand_tile0, split_recon_tile;      /* tile index = depth * tiles_per_depth + ... */
-    int32_t skip_recon_tile, merge_recon_tile, reserved2;
+    int32_t skip_recon_tile, merge_recon_tile, chain64_off;     /* chain64_off: a CU above the largest transform with a level somewhere goes to the host at once (the default; X265AMD_CHAIN_64=1: chain_merge_rd64) */
     int32_t frame_parallel, search_range, chroma_sa8d, slice_type, qp_luma, qp_chroma, tu_log2_max;
     int32_t guard_on, guard_r0, guard_r1, guard_need;           /* reference rows guard_r0 .. guard_r1 are final up to column guard_need (the picture width: all of them) */
     int32_t ctu_x, ctu_y, reserved1;
@@ -104,10 +111,10 @@ struct ChainLds
     int nc, stop, best, anyLevel, count, skipWins;
     unsigned int acc[5][3][16];         /* candidates' Hadamard sums per plane and 16x16 group */
     unsigned long long red[XA_SERVER_WAVES];
-    x265amd_tu_job tu[3];               /* the winner's transform units: Y, U, V */
-    x265amd_tu_result tr[3];
+    x265amd_tu_job tu[12];              /* the winner's transform units: Y, U, V -- or, a CU one size above the largest transform, its four luma units, then U's four, then V's */
+    x265amd_tu_result tr[12];
     uint64_t frac;                      /* the coder's state in front of the current CU */
-    uint8_t ctx[X265AMD_CTX_STRIDE], ctxS[X265AMD_CTX_STRIDE], ctxB[X265AMD_CTX_STRIDE], ctxD[X265AMD_CTX_STRIDE];
+    uint8_t ctx[X265AMD_CTX_STRIDE], ctxS[X265AMD_CTX_STRIDE], ctxB[X265AMD_CTX_STRIDE], ctxD[X265AMD_CTX_STRIDE], ctxQ[X265AMD_CTX_STRIDE];
     uint64_t fracS, fracD;
     uint32_t rdBits[3], rdPsy, rdCbf[3], rdPad; uint64_t rdCost, rdLuma, rdChroma;     /* the residual mode when it wins: bits (total, prediction info, skip flag), psy energy, coded block flags, cost, distortions */
     uint32_t step[256];
@@ -542,6 +549,162 @@ XA_DEV void chain_merge_rd(ChainLds& S, int x, int y, int log2, int best, int la
     }
 }
 
+/* The same decision for a CU one size above the largest transform (64x64 with 32x32 transforms): its residual is a tree of four nodes one level down, each a luma
+ * unit and the two chroma units under it (S.tu / S.tr: Y 0..3, U 4..7, V 8..11 in z-order).  estimateResidualQT at the root cannot code the CU as one node, so it is
+ * splitTU alone (search.cpp:3126-3176, :3178-3497): every node starts from the state the node before it left -- which is the CU's start state plus the coded block flags
+ * coded so far, because each node's coefficient contexts are dropped again (load(rqtRoot), :3652) -- the nodes' bits are their coefficients' alone (no subdivision flag
+ * to choose), and the flags of the whole tree are priced once from the CU's start state (codeInterSubdivCbfQT, :3859-3887).  Then the cost of signalling nothing and
+ * the CU's real bit count (Entropy::encodeTransform, entropy.cpp:930-1063: chroma flags of the root, then per node its chroma flags when the root's are set, its luma
+ * flag, cu_qp_delta with the first node that has anything, its coefficients).  Only S.skipWins is the caller's: a residual mode that wins goes back to the host. */
+XA_DEV void chain_merge_rd64(ChainLds& S, int x, int y, int log2, int best, int lane, uint32_t sig)
+{
+    const XaChainJob& J = S.job;
+    const uint32_t numCand = (uint32_t)J.info.max_num_merge_cand;
+    const int L = log2 - 1, C = L - 1;
+    for (int i = lane; i < X265AMD_CTX_STRIDE; i += 64) { const uint8_t v = S.ctx[i]; S.ctxS[i] = v; S.ctxB[i] = v; S.ctxD[i] = v; S.ctxQ[i] = v; }
+    xa_wave_sync();
+    const int skipCtx = chain_skip_ctx(J, x, y);
+    /* sig: the units that have levels (bit k); the others' share of every sum is what the prediction leaves, which the CU's measurement has for the whole CU */
+    const x265amd_cu_measure m0 = S.meas[best];
+    const chain_sse_t predDist = (chain_sse_t)((chain_sse_t)m0.sse[0] + (chain_sse_t)m0.sse[1] + (chain_sse_t)m0.sse[2]);
+    const uint32_t predPsy = J.psy_rd ? m0.psy : 0;
+    /* ---- the skip mode ---- */
+    uint64_t fS = S.frac & 32767;
+    if (lane == 0)
+    {
+        fS += cb_bin(S.ctxS + CC_SKIP + skipCtx, 1);
+        fS += chain_merge_index(S.ctxS, (uint32_t)best, numCand);
+        S.fracS = fS;
+    }
+    xa_wave_sync();
+    fS = S.fracS;
+    const uint64_t skipCost = chain_cost(J, predDist, (uint32_t)(fS >> 15), predPsy);
+    /* ---- the residual mode: the four nodes ---- */
+    uint32_t cbf[12];
+    uint32_t treeBits = 0, treeEnergy = predPsy;
+    chain_sse_t treeDist = predDist;
+    uint64_t fN = S.frac & 32767;               /* the state a node starts from: S.ctxQ and this fraction */
+    for (int q = 0; q < 4; q++)
+    {
+        uint64_t fB = fN & 32767;               /* resetBits() in front of the luma unit */
+        for (int p = 0; p < 3; p++)
+        {
+            const int k = p * 4 + q, lg = p ? C : L;
+            if (!((sig >> k) & 1)) { cbf[k] = 0; continue; }
+            const x265amd_tu_result r = S.tr[k];
+            uint32_t c = r.num_sig != 0;
+            const uint32_t latest = (uint32_t)(fB >> 15);
+            if (c) fB += wave_coeff_bits(S.ctxB, S.ctxB, reinterpret_cast<const int16_t*>(S.tu[k].coeff), lg, p, 0, 0, J.sign_hide, S.step, lane);
+            xa_wave_sync();
+            uint32_t single = (uint32_t)(fB >> 15) - (p ? latest : 0);
+            const chain_sse_t zeroDist = (chain_sse_t)r.zero_dist;
+            const uint32_t zeroEnergy = J.psy_rd ? r.zero_energy : 0;
+            chain_sse_t dist = zeroDist;
+            uint32_t energy = zeroEnergy;
+            if (c)
+            {
+                const uint8_t st = S.ctxB[CC_QT_CBF + (p ? 3 : 0)];                 /* estimateCbfBits one level down: ctxCbf[ttype][1] */
+                const uint32_t nzCbfBits = (uint32_t)(((fB & 32767) + en_bits[st ^ 1]) >> 15), nullBits = (uint32_t)(((fB & 32767) + en_bits[st ^ 0]) >> 15);
+                const chain_sse_t nzDist = (chain_sse_t)r.nz_dist;
+                const uint32_t nzEnergy = J.psy_rd ? r.nz_energy : 0;
+                const uint64_t singleCost = chain_cost(J, nzDist, nzCbfBits + single, nzEnergy), nullCost = chain_cost(J, zeroDist, nullBits, zeroEnergy);
+                if (nullCost < singleCost) { c = 0; single = 0; }
+                else { dist = nzDist; energy = nzEnergy; }
+            }
+            else single = 0;
+            cbf[k] = c;
+            treeBits += single; treeDist = treeDist - zeroDist + dist;
+            if (!p) treeEnergy = treeEnergy - zeroEnergy + energy;
+        }
+        /* load(rqtRoot), resetBits(), the node's three flags: what the next node starts from */
+        for (int i = lane; i < X265AMD_CTX_STRIDE; i += 64) S.ctxB[i] = S.ctxQ[i];
+        xa_wave_sync();
+        if (lane == 0)
+        {
+            uint64_t f = fN & 32767;
+            f += cb_bin(S.ctxB + CC_QT_CBF + 3, cbf[4 + q]);
+            f += cb_bin(S.ctxB + CC_QT_CBF + 3, cbf[8 + q]);
+            f += cb_bin(S.ctxB + CC_QT_CBF + 0, cbf[q]);
+            S.fracD = f;
+        }
+        xa_wave_sync();
+        fN = S.fracD;
+        for (int i = lane; i < X265AMD_CTX_STRIDE; i += 64) S.ctxQ[i] = S.ctxB[i];
+        xa_wave_sync();
+    }
+    const uint32_t ycbf = cbf[0] | cbf[1] | cbf[2] | cbf[3], ucbf = cbf[4] | cbf[5] | cbf[6] | cbf[7], vcbf = cbf[8] | cbf[9] | cbf[10] | cbf[11];
+    /* the tree's flags from the CU's start state (splitTU's tail) */
+    for (int i = lane; i < X265AMD_CTX_STRIDE; i += 64) S.ctxQ[i] = S.ctx[i];
+    xa_wave_sync();
+    if (lane == 0)
+    {
+        uint64_t f = S.frac & 32767;
+        f += cb_bin(S.ctxQ + CC_QT_CBF + 2, ucbf);
+        f += cb_bin(S.ctxQ + CC_QT_CBF + 2, vcbf);
+        for (int q = 0; q < 4; q++)
+        {
+            if (ucbf) f += cb_bin(S.ctxQ + CC_QT_CBF + 3, cbf[4 + q]);
+            if (vcbf) f += cb_bin(S.ctxQ + CC_QT_CBF + 3, cbf[8 + q]);
+            f += cb_bin(S.ctxQ + CC_QT_CBF + 0, cbf[q]);
+        }
+        S.fracD = f;
+    }
+    xa_wave_sync();
+    treeBits += (uint32_t)(S.fracD >> 15);
+    const uint64_t treeCost = chain_cost(J, treeDist, treeBits, treeEnergy);
+    /* the cost of not signalling any residual (search.cpp:2869-2895) */
+    const uint32_t cbf0Bits = (uint32_t)(((S.frac & 32767) + en_bits[S.ctx[CC_QT_ROOT_CBF] ^ 0]) >> 15);
+    if (chain_cost(J, predDist, cbf0Bits, predPsy) < treeCost || !(ycbf | ucbf | vcbf)) { if (lane == 0) S.skipWins = 1; return; }       /* the residual mode has become the skip mode: not cheaper */
+    /* ---- the bits of the CU coded with its residual (search.cpp:2900-2930) ---- */
+    uint64_t fD = S.frac & 32767;
+    if (lane == 0)
+    {
+        fD += cb_bin(S.ctxD + CC_SKIP + skipCtx, 0);
+        fD += cb_bin(S.ctxD + CC_PRED_MODE, 0);
+        fD += cb_bin(S.ctxD + CC_PART_SIZE, 1);
+        fD += cb_bin(S.ctxD + CC_MERGE_FLAG, 1);
+        fD += chain_merge_index(S.ctxD, (uint32_t)best, numCand);
+        fD += cb_bin(S.ctxD + CC_QT_CBF + 2, ucbf);
+        fD += cb_bin(S.ctxD + CC_QT_CBF + 2, vcbf);
+    }
+    bool dqpPending = J.use_dqp != 0;
+    for (int q = 0; q < 4; q++)
+    {
+        const bool any = (cbf[q] | cbf[4 + q] | cbf[8 + q]) != 0;
+        if (lane == 0)
+        {
+            if (ucbf) fD += cb_bin(S.ctxD + CC_QT_CBF + 3, cbf[4 + q]);
+            if (vcbf) fD += cb_bin(S.ctxD + CC_QT_CBF + 3, cbf[8 + q]);
+            fD += cb_bin(S.ctxD + CC_QT_CBF + 0, cbf[q]);
+            if (any && dqpPending) fD += chain_dqp_bits(S.ctxD, S.dqp);          /* cu_qp_delta with the first node that has anything (entropy.cpp:1207-1222) */
+        }
+        if (any) dqpPending = false;
+        xa_wave_sync();
+        fD = __shfl(fD, 0, 64);
+        for (int p = 0; p < 3; p++)
+        {
+            const int k = p * 4 + q;
+            if (cbf[k]) fD += wave_coeff_bits(S.ctxD, S.ctxD, reinterpret_cast<const int16_t*>(S.tu[k].coeff), p ? C : L, p, 0, 0, J.sign_hide, S.step, lane);
+            xa_wave_sync();
+        }
+    }
+    const uint32_t bits0 = (uint32_t)(fD >> 15);
+    uint32_t again = 0;
+    if (J.use_dqp && S.dqpTwice)
+    {
+        /* Search::checkDQP inside encodeResAndCalcRdInterCU (search.cpp:3974-4003): resetBits(), codeDeltaQP, the bits added */
+        if (lane == 0) S.fracD = (fD & 32767) + chain_dqp_bits(S.ctxD, S.dqp);
+        xa_wave_sync();
+        again = (uint32_t)(S.fracD >> 15);
+    }
+    chain_sse_t dist = predDist;
+    uint32_t psy = predPsy;
+    for (int k = 0; k < 12; k++) if (cbf[k]) dist = dist - (chain_sse_t)S.tr[k].zero_dist + (chain_sse_t)S.tr[k].nz_dist;
+    if (J.psy_rd) for (int k = 0; k < 4; k++) if (cbf[k]) psy = psy - S.tr[k].zero_energy + S.tr[k].nz_energy;
+    const uint64_t mergeCost = chain_cost(J, dist, bits0 + again, psy);
+    if (lane == 0) S.skipWins = mergeCost < skipCost ? 0 : 1;
+}
+
 XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
 {
     constexpr int NT = 64 * XA_SERVER_WAVES;
@@ -780,6 +943,11 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
                     pred = tile + 4096 + (size_t)(p - 1) * 1024 + (size_t)ty * n * 32 + tx * n; ps = 32; lg = C; tt = p; qp = J.qp_chroma;
                 }
             };
+            /* A level somewhere: most of these CUs still end as skips -- every unit's flag falls to its rate-distortion check, or signalling nothing is cheaper than the
+             * tree -- so a CU one size above the largest transform (four luma units) is decided here all the same: the pass below notes WHICH units have levels
+             * (S.anyLevel: bit k for unit k), those units' full chains run behind the CU's measurement, and one wavefront walks the tree (chain_merge_rd64).  A residual
+             * mode that WINS is the host's, as is every other tree: it gets the candidate to go on with (valid 2). */
+            const bool tree = nLuma == 4 && L == 5 && XA_SERVER_WAVES >= 8 && !J.chain64_off;
             /* the large units by the whole workgroup, one after the other; the others a wavefront each */
             int small = 0;
             for (int k = 0; k < total; k++)
@@ -790,22 +958,38 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
                 {
                     __syncthreads();
                     const uint32_t ns = chain_tu_levels(TL[XA_SERVER_WAVES], fenc, fs, pred, ps, lg, tt, J.slice_type, qp, XaBlock{ tid, NT, S.red });
-                    if (ns && tid == 0) S.anyLevel = 1;
+                    if (ns && tid == 0) S.anyLevel |= 1 << k;
                     __syncthreads();
-                    if (S.anyLevel) break;
+                    if (S.anyLevel && !tree) break;
                 }
                 else
                 {
                     if ((small % XA_SERVER_WAVES) == wv)
                     {
                         const uint32_t ns = chain_tu_levels(TL[wv], fenc, fs, pred, ps, lg, tt, J.slice_type, qp, XaWave{ lane });
-                        if (ns && lane == 0) atomicOr(&S.anyLevel, 1);
+                        if (ns && lane == 0) atomicOr(&S.anyLevel, 1 << k);
                     }
                     small++;
                 }
             }
             __syncthreads();
-            if (S.anyLevel) { reason = XA_CHAIN_NOTSKIP; break; }
+            const uint32_t sig = (uint32_t)S.anyLevel;
+            auto hand_over = [&]() {
+                /* the host's to walk -- but the merge check's first half is done: the candidate it goes on with and that candidate's SA8D figures (valid 2: nothing else
+                 * of the record is filled; the candidates' predictions lie in their tiles) */
+                if (tid == 64)
+                {
+                    const ChainCand c = S.cand[best];
+                    XaChainStopHead h{};
+                    h.valid = 2; h.node = (uint32_t)node; h.cand = (uint8_t)best; h.dir = c.dir;
+                    for (int l = 0; l < 2; l++) { const bool used = (c.dir >> l) & 1; h.ref_idx[l] = used ? c.ref_idx[l] : -1; h.mv[l][0] = used ? c.mv[l][0] : 0; h.mv[l][1] = used ? c.mv[l][1] : 0; }
+                    h.sa8d = S.meas[best].sa8d; h.sa8d_luma = S.meas[best].sa8d_luma;
+                    xa_st_result(reinterpret_cast<XaChainStopHead*>(&out->stop), h);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            };
+            if (sig && !tree) { hand_over(); reason = XA_CHAIN_NOTSKIP; break; }
             /* the skip mode's distortion and psy energy: the prediction against the source */
             if (tid == 0)
             {
@@ -820,6 +1004,52 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
             __syncthreads();
             block_cu_measure_job(S.mj, &S.meas[best], ML, tid, NT);
             __syncthreads();
+            if (sig)
+            {
+                /* the units with levels: their full chains (the luma units by the whole workgroup one after the other, the chroma units a wavefront each), then the tree */
+                if (tid < 12)
+                {
+                    const int k = tid, p = k >> 2;
+                    x265amd_tu_job& j = S.tu[k];
+                    j = x265amd_tu_job{};
+                    S.tr[k] = x265amd_tu_result{};
+                    if ((sig >> k) & 1)
+                    {
+                        const pixel* fenc; const pixel* pred; int fs, ps, lg, tt, qp;
+                        geo(k, fenc, fs, pred, ps, lg, tt, qp);
+                        const int n = 1 << lg;
+                        const uint64_t off = p ? 4096 + (uint64_t)(k - 4) * 256 : (uint64_t)k * 1024;         /* elements: four luma units, then U's four, then V's */
+                        j.fenc = (uint64_t)(uintptr_t)fenc; j.pred = (uint64_t)(uintptr_t)pred;
+                        j.coeff = J.scratch + off * 2;
+                        j.resi = J.scratch + 6144 * 2 + off * 2;
+                        j.recon = J.scratch + 6144 * 4 + off * isz;
+                        j.fenc_stride = fs; j.pred_stride = ps; j.resi_stride = n; j.recon_stride = n;
+                        j.log2_tr_size = (uint8_t)lg; j.ttype = (uint8_t)tt; j.intra = 0; j.dir_mode = 0; j.slice_type = (uint8_t)J.slice_type;
+                        j.qp_scaled = (uint8_t)qp; j.sign_hide = (uint8_t)J.sign_hide;
+                    }
+                }
+                __syncthreads();
+                for (int k = 0; k < 4; k++)
+                    if ((sig >> k) & 1)
+                    {
+                        grp_tu_measure<false>(TL[XA_SERVER_WAVES], nullptr, S.tu[k], nullptr, reinterpret_cast<const pixel*>(S.tu[k].pred), 64, &S.tr[k], XaBlock{ tid, NT, S.red });
+                        __syncthreads();
+                    }
+                {
+                    int idx = 0;
+                    for (int k = 4; k < 12; k++)
+                        if ((sig >> k) & 1)
+                        {
+                            if (idx == wv) wave_tu_measure<false>(TL[wv], nullptr, S.tu[k], nullptr, reinterpret_cast<const pixel*>(S.tu[k].pred), 32, &S.tr[k], lane);
+                            idx++;
+                        }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (wv == 0) chain_merge_rd64(S, x, y, log2, best, lane, sig);
+                __syncthreads();
+                if (!S.skipWins) { hand_over(); reason = XA_CHAIN_NOTSKIP; break; }
+            }
             if (wv == 0)
             {
                 /* the skip mode's coder state (the residual mode equals it) */
@@ -908,19 +1138,14 @@ XA_DEV void block_inter_chain(const XaChainJob* jobAddr, char* smem, int tid)
                 if (tid == 64)
                 {
                     const ChainCand c = S.cand[best];
-                    struct alignas(8) Head
-                    {
-                        uint32_t valid, node; uint8_t cand, dir; int8_t ref_idx[2]; int16_t mv[2][2]; uint8_t cbf[3], reserved0;
-                        uint32_t total_bits, mv_bits, coeff_bits, psy_energy, sa8d, sa8d_luma; uint64_t rd_cost, luma_dist, chroma_dist, frac; x265amd_cu_measure meas;
-                    } h;
+                    XaChainStopHead h;
                     h.valid = 1; h.node = (uint32_t)node; h.cand = (uint8_t)best; h.dir = c.dir;
                     for (int l = 0; l < 2; l++) { const bool used = (c.dir >> l) & 1; h.ref_idx[l] = used ? c.ref_idx[l] : -1; h.mv[l][0] = used ? c.mv[l][0] : 0; h.mv[l][1] = used ? c.mv[l][1] : 0; }
                     h.cbf[0] = (uint8_t)S.rdCbf[0]; h.cbf[1] = (uint8_t)S.rdCbf[1]; h.cbf[2] = (uint8_t)S.rdCbf[2]; h.reserved0 = 0;
                     h.total_bits = S.rdBits[0]; h.mv_bits = S.rdBits[1]; h.coeff_bits = S.rdBits[0] - S.rdPad - S.rdBits[1] - S.rdBits[2]; h.psy_energy = S.rdPsy;
                     h.sa8d = S.meas[best].sa8d; h.sa8d_luma = S.meas[best].sa8d_luma;
                     h.rd_cost = S.rdCost; h.luma_dist = S.rdLuma; h.chroma_dist = S.rdChroma; h.frac = S.fracD; h.meas = S.meas[best];
-                    static_assert(sizeof(Head) == offsetof(XaChainStop, ctx), "the stop record's head");
-                    xa_st_result(reinterpret_cast<Head*>(sp), h);
+                    xa_st_result(reinterpret_cast<XaChainStopHead*>(sp), h);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
