@@ -64,8 +64,10 @@ def bench_clip(first, count, gop=0, depth=8, cfg_id=2):
     return T.survey_clip(W, H, depth, cfg_id, first, count, gop)
 
 
-def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=None):
+def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=None, host_input=False):
     """the clip through the encoder object; returns (byte stream, seconds of the encode loop).  `sync` brackets the timed region.
+    The frames are on the GPU before the timed region starts and go in through x265amd_encoder_encode_device (include/x265amd_encoder.h); host_input: they stay host
+    arrays and go in through x265amd_encoder_encode, padded on the host and sent over the bus inside the timed region (the reference API's form: reported beside the value).
     shard = (rank, world): frame per GPU with row publication -- this object codes the pictures whose place in coding order is rank modulo
     world, a pump thread beside the encode loop broadcasts / imports every finished CTU row (x265-amod_amd/frame_rows.py); the stream holds the owned pictures only."""
     lib = L.lib
@@ -73,9 +75,11 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=
     lib.x265amd_encoder_open.argtypes = [C.POINTER(T.EncParam)]
     lib.x265amd_encoder_headers.argtypes = [C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32)]
     lib.x265amd_encoder_encode.argtypes = [C.c_void_p, C.POINTER(C.POINTER(T.EncNal)), C.POINTER(C.c_uint32), C.POINTER(T.EncPicture), C.POINTER(T.EncPicture)]
+    lib.x265amd_encoder_encode_device.argtypes = lib.x265amd_encoder_encode.argtypes
     lib.x265amd_encoder_close.argtypes = [C.c_void_p]
     lib.x265amd_param_default.argtypes = [C.POINTER(T.EncParam)]
     lib.x265amd_last_error.restype = C.c_char_p
+    encode_fn = lib.x265amd_encoder_encode if host_input else lib.x265amd_encoder_encode_device
     prm = T.EncParam()
     lib.x265amd_param_default(C.byref(prm))
     prm.sourceWidth, prm.sourceHeight = W, H
@@ -99,8 +103,14 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=
     for planes in frames:
         pic = T.EncPicture()
         keep = [np.ascontiguousarray(pl) for pl in planes]
-        for k in range(3):
-            pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
+        if host_input:
+            for k in range(3):
+                pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
+        else:
+            import torch
+            keep = [torch.from_numpy(k.view(np.uint8).reshape(k.shape[0], -1)).cuda() for k in keep]         # (bytes: torch has no unsigned 16-bit type)
+            for k in range(3):
+                pic.planes[k] = keep[k].data_ptr(); pic.stride[k] = keep[k].stride(0)
         pics.append((pic, keep))
     coded = 0
     marks = []                  # where each coded picture's NAL units start in `stream` (the headers come first)
@@ -131,7 +141,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=
         if pump_thread:
             pump_thread.start()
         for pic, _ in pics:
-            ret = lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), C.byref(pic), None)
+            ret = encode_fn(enc, C.byref(nal), C.byref(nnal), C.byref(pic), None)
             assert ret >= 0, lib.x265amd_last_error()
             if ret:
                 coded += 1
@@ -139,7 +149,7 @@ def encode(T, L, frames, first_frame, keyint, sync, timed=True, shard=None, cfg=
                 for i in range(nnal.value):
                     stream.extend(bytes(nal[i].payload[:nal[i].sizeBytes]))
         while True:
-            ret = lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), None, None)
+            ret = encode_fn(enc, C.byref(nal), C.byref(nnal), None, None)
             assert ret >= 0, lib.x265amd_last_error()
             if not ret:
                 break
@@ -431,6 +441,14 @@ def main():
                             "note": "SURVEY 8d's end-to-end figure: frame payload x (source read + reconstruction write + reference pictures read); the encoder is bound "
                                     "by the latency of the reference's serial decision chain, not by bandwidth"},
         }
+    # ---- the same encode with the frames handed over as HOST buffers (the reference API's form): padded on the host and sent over the bus inside the timed region ----
+    if rank == 0 and world == 1:
+        try:
+            stream_h, dt_h = encode(T, L, frames, 0, 0, sync, host_input=True)
+            line["host_input"] = {"value": K / dt_h, "unit": "frames/s", "stream_equals": bool(stream_h == stream),
+                                  "note": "x265amd_encoder_encode with x265_picture-style host planes: the PCIe-inclusive rate; `value` is x265amd_encoder_encode_device with the frames in HBM before the timed region"}
+        except Exception as exc:         # noqa: BLE001
+            line["host_input"] = {"error": repr(exc)}
     # ---- SURVEY.md section 8d's whole clip: 60 frames with both re-seeds of the noise field inside (pictures with new content everywhere) ----
     if rank == 0 and world == 1 and args.res == "1080p" and not args.no_scene_clip and not args.no_cpu_baseline:
         try:

@@ -162,6 +162,11 @@ int x265amd_encoder_headers(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t
 /* pic_in == NULL flushes.  Returns 1 when a coded picture was emitted (its NAL units in *pp_nal, its reconstruction copied to
  * pic_out's planes when pic_out is given), 0 when none is ready yet (or the flush is complete), -1 on error. */
 int x265amd_encoder_encode(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t* pi_nal, const x265amd_picture* pic_in, x265amd_picture* pic_out);
+/* The same call with the input picture ALREADY ON THE DEVICE: pic_in->planes are device addresses (hipMalloc memory of the encoder's device; strides in bytes as above),
+ * read by a device-to-device copy and a margin kernel instead of being padded on the host and sent over the bus.  There is no counterpart in the reference's API (x265_picture
+ * holds host pointers, x265.h:397-490): this is the form for callers whose frames are made or decoded on the GPU, and the one bench.py times ("inputs already resident in
+ * HBM when the timed region starts").  Everything else -- pic_out, the NAL units, flushing with pic_in == NULL -- as x265amd_encoder_encode. */
+int x265amd_encoder_encode_device(x265amd_encoder* enc, x265amd_nal** pp_nal, uint32_t* pi_nal, const x265amd_picture* pic_in, x265amd_picture* pic_out);
 void x265amd_encoder_close(x265amd_encoder* enc);
 
 /* ---- frame-per-GPU: a finished CTU row travels from the object that codes a picture to the objects that reference it ----

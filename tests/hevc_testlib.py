@@ -3046,10 +3046,12 @@ class EncPicture(C.Structure):
     _fields_ = [("planes", C.c_void_p * 3), ("stride", C.c_int32 * 3), ("poc", C.c_int32), ("sliceType", C.c_int32), ("qp", C.c_int32)]
 
 
-def encoder_run(L, planes_per_frame, width, height, want_headers=True, **overrides):
+def encoder_run(L, planes_per_frame, width, height, want_headers=True, input_on_device=False, **overrides):
     """x265amd_encoder_open -> headers -> encode every frame -> flush -> close.  planes_per_frame: per frame (Y, U, V) arrays in display order.
+    input_on_device: the frames are put on the GPU first (torch) and go in through x265amd_encoder_encode_device.
     Returns (whole byte stream, [(poc, slice type, qp, recon planes)] in coding order)"""
     lib = L.lib
+    lib.x265amd_encoder_encode_device.argtypes = [C.c_void_p, C.POINTER(C.POINTER(EncNal)), C.POINTER(C.c_uint32), C.POINTER(EncPicture), C.POINTER(EncPicture)]
     lib.x265amd_encoder_open.restype = C.c_void_p
     lib.x265amd_encoder_open.argtypes = [C.POINTER(EncParam)]
     lib.x265amd_encoder_headers.argtypes = [C.c_void_p, C.POINTER(C.POINTER(EncNal)), C.POINTER(C.c_uint32)]
@@ -3092,10 +3094,18 @@ def encoder_run(L, planes_per_frame, width, height, want_headers=True, **overrid
         for planes in planes_per_frame:
             pic = EncPicture()
             keep = [np.ascontiguousarray(pl) for pl in planes]
-            for k in range(3):
-                pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
+            if input_on_device:
+                import torch
+                keep = [torch.from_numpy(k.view(np.uint8).reshape(k.shape[0], -1)).cuda() for k in keep]         # (bytes: torch has no unsigned 16-bit type)
+                torch.cuda.synchronize()
+                for k in range(3):
+                    pic.planes[k] = keep[k].data_ptr(); pic.stride[k] = keep[k].stride(0)
+            else:
+                for k in range(3):
+                    pic.planes[k] = keep[k].ctypes.data; pic.stride[k] = keep[k].strides[0]
             out, bufs = out_picture()
-            take(lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), C.byref(pic), C.byref(out)), out, bufs)
+            fn = lib.x265amd_encoder_encode_device if input_on_device else lib.x265amd_encoder_encode
+            take(fn(enc, C.byref(nal), C.byref(nnal), C.byref(pic), C.byref(out)), out, bufs)
         while True:
             out, bufs = out_picture()
             if not take(lib.x265amd_encoder_encode(enc, C.byref(nal), C.byref(nnal), None, C.byref(out)), out, bufs):

@@ -255,6 +255,24 @@ def test_command_lines_outside_the_built_subset_are_refused_by_name(what, tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("depth", [8, 10])
+def test_input_pictures_on_the_device_give_the_same_stream(depth):
+    """x265amd_encoder_encode_device (include/x265amd_encoder.h): frames that are device memory already -- copied device to device, margins by the border kernel -- code to
+    the bytes and the reconstruction of the same frames handed over as host buffers (whose margins the host pads); a size that is no multiple of the CTU, the preset's rate
+    control (the lookahead reads the same source planes)"""
+    w, h, n = 416, 240, 6
+    frames = T.survey_clip(w, h, depth, 2, 0, n)
+    cfg = dict(fpsNum=30, fpsDenom=1)
+    a, ca = T.encoder_run(T.load_hip(depth), frames, w, h, **cfg)
+    b, cb = T.encoder_run(T.load_hip(depth), frames, w, h, input_on_device=True, **cfg)
+    assert len(a) == len(b) and hashlib.md5(a.tobytes()).hexdigest() == hashlib.md5(b.tobytes()).hexdigest()
+    assert [(c[0], c[1], c[2]) for c in ca] == [(c[0], c[1], c[2]) for c in cb]
+    for x, y in zip(ca, cb):
+        for k in range(3):
+            assert np.array_equal(x[3][k], y[3][k])
+
+
+@pytest.mark.gpu
 def test_closed_gops_encode_independently():
     """the unit of multi-GPU sharding: the pictures between two IDR frames depend on nothing outside, so two encoder objects (as two ranks would hold them) coding
     GOP 0 (frames 0-3) and GOP 1 (frames 4-6, firstFrame = 4) give, concatenated, the single-encoder stream of the reference for --keyint 4"""

@@ -450,8 +450,34 @@ extern "C" int x265amd_encoder_headers(x265amd_encoder* e, x265amd_nal** ppNal, 
 }
 
 /* ---- pictures ---- */
-int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic)
+int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic, bool onDevice)
 {
+    if (onDevice)
+    {
+        /* the planes are device memory: the picture area by a device-to-device copy, the margins by the kernel that extends the reconstructed planes (the same edge
+         * replication: PicYuv::copyFromPicture pads, extendPicBorder); what lies outside the margins is zero as in the host form */
+        if (xa_scratch_alloc((void**)&pic.dSrc, picElems * sizeof(pixel)) != hipSuccess || xa_scratch_alloc((void**)&pic.dRec, picElems * sizeof(pixel)) != hipSuccess)
+            return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+        if (hipMemsetAsync(pic.dSrc, 0, picElems * sizeof(pixel), nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+        for (int k = 0; k < 3; k++)
+        {
+            const int w = k ? W / 2 : W, h = k ? H / 2 : H, mx = k ? marginX / 2 : marginX, my = k ? marginY / 2 : marginY;
+            const intptr_t st = k ? cstride : stride;
+            if (!in->planes[k] || in->stride[k] < (int)(w * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
+            if (hipMemcpy2DAsync(pic.dSrc + org[k], (size_t)st * sizeof(pixel), in->planes[k], (size_t)in->stride[k], (size_t)w * sizeof(pixel), (size_t)h, hipMemcpyDeviceToDevice, nullptr) != hipSuccess)
+                return xa_fail(X265AMD_EHIP, "encoder_encode: the input picture is not device memory of this device");
+            if (x265amd_extend_pic_border(nullptr, (x265amd_pixel*)(pic.dSrc + org[k]), st, w, h, mx, my) != X265AMD_OK) return -1;
+        }
+        if (hipMemsetAsync(pic.dRec, 0, picElems * sizeof(pixel), nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+        if (frameParallel && p.bEnableSAO)
+        {
+            if (xa_scratch_alloc((void**)&pic.dFin, picElems * sizeof(pixel)) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
+            if (hipMemsetAsync(pic.dFin, 0, picElems * sizeof(pixel), nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
+        }
+        /* the frame tasks run on their own non-blocking streams: make sure the picture is in place before one can start */
+        if (hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: the input picture's copy");
+        return 0;
+    }
     /* the picture area of each plane with its margins filled by edge replication (PicYuv::copyFromPicture pads, extendPicBorder) */
     staging.assign(picElems, 0);
     for (int k = 0; k < 3; k++)
@@ -486,7 +512,16 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic)
     return 0;
 }
 
+static int encoder_encode_impl(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal, const x265amd_picture* picIn, x265amd_picture* picOut, bool inputOnDevice);
 extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal, const x265amd_picture* picIn, x265amd_picture* picOut)
+{
+    return encoder_encode_impl(e, ppNal, piNal, picIn, picOut, false);
+}
+extern "C" int x265amd_encoder_encode_device(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal, const x265amd_picture* picIn, x265amd_picture* picOut)
+{
+    return encoder_encode_impl(e, ppNal, piNal, picIn, picOut, true);
+}
+static int encoder_encode_impl(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t* piNal, const x265amd_picture* picIn, x265amd_picture* picOut, bool inputOnDevice)
 {
     if (!e) return xa_fail(X265AMD_EINVAL, "encoder_encode: null encoder");
     if (ppNal) *ppNal = nullptr;
@@ -498,7 +533,7 @@ extern "C" int x265amd_encoder_encode(x265amd_encoder* e, x265amd_nal** ppNal, u
         if (e->firstInMs < 0) e->firstInMs = Pic::pubClockMs();
         pic->poc = e->frameCount++;
         const auto tu0 = std::chrono::steady_clock::now();
-        int rc = e->uploadPicture(picIn, *pic);
+        int rc = e->uploadPicture(picIn, *pic, inputOnDevice);
         if (rc) return -1;
         const auto tl0 = std::chrono::steady_clock::now();
         e->uploadMs += std::chrono::duration<double, std::milli>(tl0 - tu0).count();

@@ -231,7 +231,7 @@ struct x265amd_encoder
     uint64_t planeAddr(const pixel* base, int k) const { return (uint64_t)(uintptr_t)(base + org[k]); }
 
     void fillStreamParams(x265amd_stream_params& s) const;
-    int uploadPicture(const x265amd_picture* in, Pic& pic);
+    int uploadPicture(const x265amd_picture* in, Pic& pic, bool onDevice = false);
     void decideMiniGop(bool flush);
     int prepare(const PicP& pic);
     int runFrame(const PicP& pic, std::shared_future<int> prev);
