@@ -7,7 +7,7 @@ out, tag = sys.argv[1], sys.argv[2]
 rnd = sys.argv[3] if len(sys.argv) > 3 else "r01"
 def find(sub, pat):
     g = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None          # (gpurun_out/ keeps earlier collections' files: the newest is this one's)
 ks = find("kt", "*kernel_stats.csv")
 if ks: shutil.copy(ks, os.path.join(out, "%s_%s_kernel_stats.csv" % (rnd, tag)))
 res = collections.defaultdict(dict)
