@@ -118,6 +118,34 @@ def test_device_chains_verified_under_delta_qp(tag):
     assert runs and max(runs) > 100 and ahead and max(ahead) > 0, (runs[-3:], ahead[-3:])           # the paths under test did run under delta QP
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["crf_wqvga_medium_30/", "crf_cfg4_2160p_main10/"])
+def test_device_decision_of_64x64_cus_with_levels_verified(tag):
+    """a 64x64 CU whose residual has a level somewhere decided on the device (the flagged units' full chains, the residual tree's rate-distortion walk:
+    chain_merge_rd64) -- off by default since it gains nothing, asked for here (X265AMD_CHAIN_64=1) so that it does not rot: under X265AMD_CHAIN_VERIFY=2 every CU it skips is
+    repeated by the host's own merge check (mode, candidate, cost, coder state) and every CU it hands back goes on from the device's candidate, compared the same way; the
+    stream must be the reference's (8-bit at 416x240, Main 10 at 3840x2160)"""
+    import subprocess
+    import sys
+    if tag not in T.PRESET_CASES:
+        pytest.skip("no such preset case")
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r); import numpy as np, hevc_testlib as T\n"
+            "g = json.load(open(%r))[%r]\n"
+            "(w, h), n, depth, cfg_id, cfg, _ = T.PRESET_CASES[%r]\n"
+            "n = min(n, 8)\n"
+            "stream, coded = T.encoder_run(T.load_hip(depth), T.full_case_frames(%r)[:n], w, h, **cfg)\n"
+            "print('verified pictures', len(coded))\n") % (os.path.dirname(os.path.abspath(__file__)), PRESET_GOLD, tag, tag, tag)
+    env = dict(os.environ, X265AMD_CHAIN_VERIFY="2", X265AMD_CHAIN_64="1", X265AMD_TIMING="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0 and "verified pictures 8" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "chain verify" not in r.stderr and "search verify" not in r.stderr, r.stderr[-3000:]
+    # the same eight frames without the switches: the same bytes (a clip cut short has no golden stream of its own)
+    code2 = code.replace("print('verified pictures', len(coded))", "print('md5', hashlib.md5(stream.tobytes()).hexdigest())")
+    a = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, X265AMD_CHAIN_64="1"), capture_output=True, text=True, timeout=2400)
+    b = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ), capture_output=True, text=True, timeout=2400)
+    assert a.returncode == 0 and b.returncode == 0 and "md5" in a.stdout and a.stdout.strip().splitlines()[-1] == b.stdout.strip().splitlines()[-1], (a.stdout[-300:], b.stdout[-300:], a.stderr[-1500:])
+
+
 def test_rc_golden_present():
     g = json.load(open(RC_GOLD))
     for tag, ((w, h), n, depth, cfg_id, cfg, cli) in T.RC_CASES.items():
