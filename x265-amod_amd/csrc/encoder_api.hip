@@ -478,14 +478,19 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic, bool onD
         if (hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: the input picture's copy");
         return 0;
     }
-    /* the picture area of each plane with its margins filled by edge replication (PicYuv::copyFromPicture pads, extendPicBorder) */
-    staging.assign(picElems, 0);
+    /* the picture area of each plane with its margins filled by edge replication (PicYuv::copyFromPicture pads, extendPicBorder): put together in a pinned buffer of the
+     * encoder's own (the copy below goes straight from it; what lies outside the margins was zeroed once and is never written) */
+    if (!uploadBuf)
+    {
+        if (hipHostMalloc((void**)&uploadBuf, picElems * sizeof(pixel), hipHostMallocDefault) != hipSuccess) { uploadBuf = nullptr; return xa_fail(X265AMD_EHIP, "encoder_encode: pinned input buffer"); }
+        memset(uploadBuf, 0, picElems * sizeof(pixel));
+    }
     for (int k = 0; k < 3; k++)
     {
         const int w = k ? W / 2 : W, h = k ? H / 2 : H, mx = k ? marginX / 2 : marginX, my = k ? marginY / 2 : marginY;
         const intptr_t st = k ? cstride : stride;
         if (!in->planes[k] || in->stride[k] < (int)(w * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
-        pixel* base = staging.data() + org[k];
+        pixel* base = uploadBuf + org[k];
         for (int y = 0; y < h; y++)
         {
             const pixel* src = (const pixel*)((const uint8_t*)in->planes[k] + (size_t)y * in->stride[k]);
@@ -501,7 +506,7 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic, bool onD
     }
     if (xa_scratch_alloc((void**)&pic.dSrc, picElems * sizeof(pixel)) != hipSuccess || xa_scratch_alloc((void**)&pic.dRec, picElems * sizeof(pixel)) != hipSuccess)
         return xa_fail(X265AMD_EHIP, "encoder_encode: device allocation");
-    if (hipMemcpy(pic.dSrc, staging.data(), picElems * sizeof(pixel), hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: upload");
+    if (hipMemcpy(pic.dSrc, uploadBuf, picElems * sizeof(pixel), hipMemcpyHostToDevice) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: upload");
     /* the frame tasks run on their own non-blocking streams: make sure the picture is in place before one can start */
     if (hipMemset(pic.dRec, 0, picElems * sizeof(pixel)) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
     if (frameParallel && p.bEnableSAO)

@@ -204,6 +204,7 @@ struct x265amd_encoder
     std::vector<uint8_t> headerBytes, outBytes;
     std::vector<x265amd_nal> nals;
     std::vector<pixel> staging;
+    pixel* uploadBuf = nullptr;         /* pinned: the padded input picture as uploadPicture puts it together (hipHostFree in the destructor) */
     int32_t* dSaoCount = nullptr; int32_t* dSaoOrg = nullptr; x265amd_sao_ctu* dSaoParams = nullptr; x265amd_deblock_unit* dDbUnits = nullptr;
     pixel* dSaoTmp = nullptr;
 
@@ -211,6 +212,7 @@ struct x265amd_encoder
     {
         for (auto& q : inflight) if (q->done.valid()) q->done.wait();
         laFieldsFree();
+        if (uploadBuf) (void)hipHostFree(uploadBuf);
         if (getenv("X265AMD_TIMING") && lookahead)
         {
             fprintf(stderr, "x265amd: input: %.1f ms in uploads; cpu of the picture threads %.1f ms, of the filter threads %.1f ms\n", uploadMs, cpuPictureNs.load() / 1e6, cpuFilterNs.load() / 1e6);
