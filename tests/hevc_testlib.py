@@ -3625,6 +3625,12 @@ CLI_CASES = {
     "cli_nowpp_ft2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "2"]),
     "cli_weightb/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--weightb"]),
     "cli_ref1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--ref", "1"]),
+    # (the options the parser knows and no case had walked through the preset's rate control yet)
+    "cli_b_intra/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--b-intra"]),
+    "cli_fast_intra/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--fast-intra"]),
+    "cli_qpstep2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--qpstep", "2"]),
+    "cli_no_weightp/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-weightp"]),
+    "cli_slow_b_intra_hbd/": ((416, 240), 12, 10, 4, {}, ["--preset", "slow", "--b-intra", "--fast-intra"]),
     "cli_hbd_ssim/": ((416, 240), 16, 10, 4, {}, ["--preset", "medium", "--tune", "ssim"]),
     "cli_star_subme4/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--me", "star", "--subme", "4", "--merange", "25"]),
     "cli_rdoq2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--rdoq-level", "2", "--psy-rdoq", "1.0"]),
@@ -3725,6 +3731,9 @@ CLI_REFUSED = {
     "umh": (["--preset", "medium", "--me", "umh"], "searchMethod"),
     "qg16": (["--preset", "medium", "--qg-size", "16"], "qgSize"),
     "nosuchoption": (["--preset", "medium", "--no-such-option"], "unknown option"),
+    "max_tu16": (["--preset", "medium", "--max-tu-size", "16"], "maxTUSize"),
+    "min_cu16": (["--preset", "medium", "--min-cu-size", "16"], "minCUSize"),
+    "level41": (["--preset", "medium", "--level-idc", "41"], "levelIdc"),      # (with a rate factor the reference turns VBV on for a forced level: level.cpp:393-404)
 }
 
 
