@@ -10,7 +10,7 @@
  * Built subset (everything else is rejected by x265amd_encoder_open with NULL + x265amd_last_error): 4:2:0, bit depth of the library,
  * constant QP or constant rate factor (rc.rateControlMode = X265_RC_CQP / X265_RC_CRF; no ABR, VBV or second pass), adaptive quantisation (aq-mode 0-3) and cuTree,
  * mini-GOPs fixed or chosen by the lookahead (bFrameAdaptive 0 / 1 / 2), scene-cut detection, open or
- * closed GOPs, the B pyramid, the lookahead in slices, weighted prediction, CTU 64 / min CU 8, one slice, picture sizes that are multiples of 8.  Within that subset the byte stream
+ * closed GOPs, the B pyramid, the lookahead in slices, weighted prediction, CTU 64 / min CU 8, one slice, even picture sizes (a size that is no multiple of 8 is coded padded to one, the SPS's conformance window takes the pad off: encoder.cpp:4081-4090).  Within that subset the byte stream
  * is the reference encoder's (tests/test_encoder_api.py compares whole streams with the reference command line program's). */
 #ifndef X265AMD_ENCODER_H
 #define X265AMD_ENCODER_H
@@ -23,7 +23,7 @@ extern "C" {
 /* the fields of x265_param (x265.h:1034-2275) the built subset reads, under the reference's names */
 typedef struct x265amd_param
 {
-    int32_t sourceWidth, sourceHeight;      /* luma samples; multiples of 8 */
+    int32_t sourceWidth, sourceHeight;      /* luma samples; even */
     uint32_t fpsNum, fpsDenom;
     int32_t bframes;                        /* consecutive B frames of a mini-GOP (0..16); bFrameAdaptive is 0 */
     int32_t keyframeMax;                    /* keyframe interval (--keyint): IDR pictures with closed GOPs, CRA pictures with bOpenGOP */

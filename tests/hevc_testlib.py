@@ -3625,6 +3625,10 @@ CLI_CASES = {
     "cli_nowpp_ft2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "2"]),
     "cli_weightb/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--weightb"]),
     "cli_ref1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--ref", "1"]),
+    # sizes that are no multiple of the smallest CU: coded padded, the SPS's conformance window takes the pad off (and the reconstruction handed out is the window's)
+    "cli_w420_h236/": ((420, 236), 16, 8, 2, {}, ["--preset", "medium"]),
+    "cli_w418_h238_hbd/": ((418, 238), 12, 10, 4, {}, ["--preset", "slow"]),
+    "cli_w854_h480/": ((854, 480), 10, 8, 2, {}, ["--preset", "fast"]),
     # (the options the parser knows and no case had walked through the preset's rate control yet)
     "cli_b_intra/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--b-intra"]),
     "cli_fast_intra/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--fast-intra"]),

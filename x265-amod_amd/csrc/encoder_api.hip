@@ -56,6 +56,7 @@ void x265amd_encoder::fillStreamParams(x265amd_stream_params& s) const
     s.max_temporal_sub_layers = 1;
     s.max_dec_pic_buffering[0] = maxDecPicBuffering; s.num_reorder_pics[0] = numReorderPics; s.max_latency_increase[0] = p.bframes;
     s.chroma_format_idc = 1; s.pic_width = W; s.pic_height = H; s.bit_depth = X265AMD_DEPTH; s.log2_max_poc_lsb = 8;
+    s.conformance_window = W != srcW || H != srcH; s.conf_win_offsets[1] = W - srcW; s.conf_win_offsets[3] = H - srcH;
     s.log2_min_cu_size = 3; s.log2_diff_max_min_cu_size = 3; s.tu_log2_min = 2; s.tu_log2_max = 5;
     s.tu_max_depth_inter = p.tuQTMaxInterDepth; s.tu_max_depth_intra = p.tuQTMaxIntraDepth;
     s.amp = p.bEnableAMP != 0; s.sao = p.bEnableSAO != 0; s.temporal_mvp = p.bEnableTemporalMvp != 0; s.strong_intra_smoothing = p.bEnableStrongIntraSmoothing != 0;
@@ -95,8 +96,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     if (!norm.aqMode && norm.cuTree) { norm.aqMode = 1; norm.aqStrength = 0.0; }
     if (norm.aqStrength == 0 && !norm.cuTree) norm.aqMode = 0;
     p = &norm;
-    if (p->sourceWidth < 16 || p->sourceHeight < 16 || (p->sourceWidth & 7) || (p->sourceHeight & 7) || p->sourceWidth > 8192 || p->sourceHeight > 4320)
-    { xa_fail(X265AMD_EINVAL, "encoder_open: picture size must be a multiple of 8 (16..8192 x 16..4320)"); return nullptr; }
+    if (p->sourceWidth < 16 || p->sourceHeight < 16 || (p->sourceWidth & 1) || (p->sourceHeight & 1) || p->sourceWidth > 8192 || p->sourceHeight > 4320)
+    { xa_fail(X265AMD_EINVAL, "encoder_open: picture size must be even (4:2:0) and within 16..8192 x 16..4320"); return nullptr; }
     {
         /* every field outside the built subset is named (the reference logs "x265 [error]: <what>" per field, encoder/api.cpp:96-239 -> x265_check_params) */
         static thread_local char why[160];
@@ -141,7 +142,10 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     xa_bind_device();           /* the threads of this library work on the opening thread's GPU */
     std::unique_ptr<x265amd_encoder> e(new x265amd_encoder);
     e->p = *p;
-    e->W = p->sourceWidth; e->H = p->sourceHeight; e->w4 = e->W / 4; e->h4 = e->H / 4;
+    /* a size that is no multiple of the smallest CU is coded padded to one, the pad replicating the last column / row, and the SPS's conformance window takes it off again
+     * (Encoder::configure, encoder.cpp:4081-4090, :4300-4308; PicYuv::copyFromPicture) */
+    e->srcW = p->sourceWidth; e->srcH = p->sourceHeight;
+    e->W = (p->sourceWidth + 7) & ~7; e->H = (p->sourceHeight + 7) & ~7; e->w4 = e->W / 4; e->h4 = e->H / 4;
     e->ctuW = (e->W + 63) / 64; e->ctuH = (e->H + 63) / 64; e->nctu = e->ctuW * e->ctuH;
     e->stride = e->W + 2 * e->marginX; e->cstride = e->W / 2 + e->marginX;
     const size_t ysz = (size_t)(e->H + 2 * e->marginY) * e->stride, csz = (size_t)(e->H / 2 + e->marginY) * e->cstride;
@@ -463,9 +467,12 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic, bool onD
         {
             const int w = k ? W / 2 : W, h = k ? H / 2 : H, mx = k ? marginX / 2 : marginX, my = k ? marginY / 2 : marginY;
             const intptr_t st = k ? cstride : stride;
-            if (!in->planes[k] || in->stride[k] < (int)(w * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
-            if (hipMemcpy2DAsync(pic.dSrc + org[k], (size_t)st * sizeof(pixel), in->planes[k], (size_t)in->stride[k], (size_t)w * sizeof(pixel), (size_t)h, hipMemcpyDeviceToDevice, nullptr) != hipSuccess)
+            const int sw = k ? srcW / 2 : srcW, sh = k ? srcH / 2 : srcH;
+            if (!in->planes[k] || in->stride[k] < (int)(sw * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
+            if (hipMemcpy2DAsync(pic.dSrc + org[k], (size_t)st * sizeof(pixel), in->planes[k], (size_t)in->stride[k], (size_t)sw * sizeof(pixel), (size_t)sh, hipMemcpyDeviceToDevice, nullptr) != hipSuccess)
                 return xa_fail(X265AMD_EHIP, "encoder_encode: the input picture is not device memory of this device");
+            /* the pad up to the coded size first (the same kernel with the pad as its margin: what it writes left of and above the picture the second call overwrites) */
+            if ((sw != w || sh != h) && x265amd_extend_pic_border(nullptr, (x265amd_pixel*)(pic.dSrc + org[k]), st, sw, sh, w - sw, h - sh) != X265AMD_OK) return -1;
             if (x265amd_extend_pic_border(nullptr, (x265amd_pixel*)(pic.dSrc + org[k]), st, w, h, mx, my) != X265AMD_OK) return -1;
         }
         if (hipMemsetAsync(pic.dRec, 0, picElems * sizeof(pixel), nullptr) != hipSuccess) return xa_fail(X265AMD_EHIP, "encoder_encode: memset");
@@ -489,13 +496,15 @@ int x265amd_encoder::uploadPicture(const x265amd_picture* in, Pic& pic, bool onD
     {
         const int w = k ? W / 2 : W, h = k ? H / 2 : H, mx = k ? marginX / 2 : marginX, my = k ? marginY / 2 : marginY;
         const intptr_t st = k ? cstride : stride;
-        if (!in->planes[k] || in->stride[k] < (int)(w * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
+        const int sw = k ? srcW / 2 : srcW, sh = k ? srcH / 2 : srcH;            /* what the caller hands over; w x h is what is coded */
+        if (!in->planes[k] || in->stride[k] < (int)(sw * sizeof(pixel))) return xa_fail(X265AMD_EINVAL, "encoder_encode: input plane");
         pixel* base = uploadBuf + org[k];
         for (int y = 0; y < h; y++)
         {
-            const pixel* src = (const pixel*)((const uint8_t*)in->planes[k] + (size_t)y * in->stride[k]);
+            const pixel* src = (const pixel*)((const uint8_t*)in->planes[k] + (size_t)(y < sh ? y : sh - 1) * in->stride[k]);
             pixel* row = base + (intptr_t)y * st;
-            memcpy(row, src, sizeof(pixel) * w);
+            memcpy(row, src, sizeof(pixel) * sw);
+            for (int x = sw; x < w; x++) row[x] = row[sw - 1];
             for (int x = 1; x <= mx; x++) { row[-x] = row[0]; row[w - 1 + x] = row[w - 1]; }
         }
         for (int y = 1; y <= my; y++)
@@ -780,7 +789,7 @@ static int encoder_encode_impl(x265amd_encoder* e, x265amd_nal** ppNal, uint32_t
         for (int k = 0; k < 3; k++)
         {
             if (!picOut->planes[k]) continue;
-            const int w = k ? e->W / 2 : e->W, hh = k ? e->H / 2 : e->H;
+            const int w = k ? e->srcW / 2 : e->srcW, hh = k ? e->srcH / 2 : e->srcH;           /* the picture inside the conformance window: what the caller's planes hold */
             const intptr_t st = k ? e->cstride : e->stride;
             for (int y = 0; y < hh; y++)
                 memcpy((uint8_t*)picOut->planes[k] + (size_t)y * picOut->stride[k], e->staging.data() + e->org[k] + (intptr_t)y * st, sizeof(pixel) * w);

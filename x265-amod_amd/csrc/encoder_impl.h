@@ -171,6 +171,7 @@ struct x265amd_encoder
     x265amd_param p;
     x265amd_me_ctx* me = nullptr;
     int W = 0, H = 0, w4 = 0, h4 = 0, ctuW = 0, ctuH = 0, nctu = 0;
+    int srcW = 0, srcH = 0;             /* x265amd_param's size; W x H is what is coded: srcW x srcH padded to multiples of 8 */
     int marginX = 96, marginY = 80;
     intptr_t stride = 0, cstride = 0;
     size_t org[3] = { 0, 0, 0 }, picElems = 0;
