@@ -3625,6 +3625,17 @@ CLI_CASES = {
     "cli_nowpp_ft2/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "2"]),
     "cli_weightb/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--weightb"]),
     "cli_ref1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--ref", "1"]),
+    # frame rates: the rate factor's base, cuTree's strength and the lookahead's frame durations all hang on fps (the clip's file says 30)
+    "cli_fps_ntsc_film/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--fps", "24000/1001"]),
+    "cli_fps60/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--fps", "60"]),
+    "cli_fps12_5_slow/": ((416, 240), 14, 8, 2, {}, ["--preset", "slow", "--fps", "12.5"]),
+    # small pictures (the reference's input readers take nothing below 64x64; a picture of ONE CTU is refused: CLI_REFUSED): two by one CTUs with a partial column and row
+    # (a picture of one CTU row or fewer than three CTU columns is coded without wavefronts, and without them the frame threads are half the rows: encoder.cpp:249-254)
+    "cli_nowpp_ft1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "1"]),
+    "cli_128x128/": ((128, 128), 12, 8, 2, {}, ["--preset", "medium"]),
+    "cli_128x256/": ((128, 256), 12, 8, 2, {}, ["--preset", "medium"]),
+    "cli_256x64/": ((256, 64), 12, 8, 2, {}, ["--preset", "medium"]),
+    "cli_136x72_hbd/": ((136, 72), 12, 10, 4, {}, ["--preset", "medium"]),
     # sizes that are no multiple of the smallest CU: coded padded, the SPS's conformance window takes the pad off (and the reconstruction handed out is the window's)
     "cli_w420_h236/": ((420, 236), 16, 8, 2, {}, ["--preset", "medium"]),
     "cli_w418_h238_hbd/": ((418, 238), 12, 10, 4, {}, ["--preset", "slow"]),
@@ -3737,7 +3748,8 @@ CLI_REFUSED = {
     "nosuchoption": (["--preset", "medium", "--no-such-option"], "unknown option"),
     "max_tu16": (["--preset", "medium", "--max-tu-size", "16"], "maxTUSize"),
     "min_cu16": (["--preset", "medium", "--min-cu-size", "16"], "minCUSize"),
-    "level41": (["--preset", "medium", "--level-idc", "41"], "levelIdc"),      # (with a rate factor the reference turns VBV on for a forced level: level.cpp:393-404)
+    "level41": (["--preset", "medium", "--level-idc", "41"], "levelIdc"),
+    "one_ctu": (["--preset", "medium"], "single CTU"),           # (on a 64x64 clip: tests/test_encoder_api.py)      # (with a rate factor the reference turns VBV on for a forced level: level.cpp:393-404)
 }
 
 

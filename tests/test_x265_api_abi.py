@@ -90,7 +90,7 @@ _MEMBERS_I = ["bEnableWavefront", "frameNumThreads", "internalBitDepth", "intern
               "vui_bEnableOverscanAppropriateFlag", "vui_bEnableVideoSignalTypePresentFlag", "vui_videoFormat", "vui_bEnableVideoFullRangeFlag", "vui_bEnableColorDescriptionPresentFlag",
               "vui_colorPrimaries", "vui_transferCharacteristics", "vui_matrixCoeffs", "vui_bEnableChromaLocInfoPresentFlag", "vui_chromaSampleLocTypeTopField",
               "vui_chromaSampleLocTypeBottomField", "vui_bEnableDefaultDisplayWindowFlag", "vui_defDispWinLeftOffset", "vui_defDispWinRightOffset", "vui_defDispWinTopOffset", "vui_defDispWinBottomOffset", "bEnableAccessUnitDelimiters", "decodedPictureHashSEI",
-              "bEmitHDR10SEI", "bEmitCLL"]
+              "bEmitHDR10SEI", "bEmitCLL", "fpsNum", "fpsDenom", "sourceWidth", "sourceHeight"]
 _MEMBERS_D = ["psyRd", "psyRdoq", "rc_ipFactor", "rc_pbFactor", "rc_rfConstant", "rc_aqStrength", "rc_qCompress"]
 
 
@@ -138,7 +138,7 @@ PARSE_CASES = [("crf", "23.5"), ("qp", "30"), ("bframes", "3"), ("b-adapt", "1")
                ("no-strong-intra-smoothing", None), ("no-temporal-mvp", None), ("fast-intra", None), ("no-info", None), ("frame-threads", "2"), ("bitrate", "1000"), ("qpmin", "10"), ("qpmax", "40"),
                ("no-scenecut", None), ("sar", "1"), ("sar", "16:11"), ("sar", "7:5"), ("sar", "x"), ("colorprim", "bt2020"), ("colorprim", "9"), ("colorprim", "nosuch"), ("transfer", "smpte2084"),
                ("colormatrix", "bt2020nc"), ("range", "full"), ("range", "limited"), ("videoformat", "ntsc"), ("chromaloc", "2"), ("overscan", "crop"), ("overscan", "show"), ("overscan", "what"),
-               ("display-window", "8,4,8,4"), ("display-window", "8,4"), ("aud", None), ("hash", "2"), ("deblock", "-2:1"), ("deblock", "3,-3"), ("deblock", "2"), ("deblock", "false"), ("deblock", None), ("hdr10", None), ("no-cll", None), ("max-cll", "1000,400"), ("max-cll", "7"), ("input-res", "416x240"), ("fps", "30000/1001"), ("fps", "25"), ("rd", "x"), ("nosuchoption", "1")]
+               ("display-window", "8,4,8,4"), ("display-window", "8,4"), ("aud", None), ("hash", "2"), ("deblock", "-2:1"), ("deblock", "3,-3"), ("deblock", "2"), ("deblock", "false"), ("deblock", None), ("hdr10", None), ("no-cll", None), ("max-cll", "1000,400"), ("max-cll", "7"), ("input-res", "416x240"), ("fps", "30000/1001"), ("fps", "25"), ("fps", "60"), ("fps", "23.976"), ("fps", "12.5"), ("rd", "x"), ("nosuchoption", "1")]
 
 
 @pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref (the reference build) is not present")

@@ -95,9 +95,15 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     if (norm.lookaheadDepth == 0) norm.cuTree = 0;
     if (!norm.aqMode && norm.cuTree) { norm.aqMode = 1; norm.aqStrength = 0.0; }
     if (norm.aqStrength == 0 && !norm.cuTree) norm.aqMode = 0;
+    /* Encoder::create (encoder.cpp:249-254): "Do not allow WPP if only one row or fewer than 3 columns, it is pointless and unstable" */
+    if ((((norm.sourceHeight + 7) & ~7) + 63) / 64 == 1 || (((norm.sourceWidth + 7) & ~7) + 63) / 64 < 3) norm.bEnableWavefront = 0;
     p = &norm;
     if (p->sourceWidth < 16 || p->sourceHeight < 16 || (p->sourceWidth & 1) || (p->sourceHeight & 1) || p->sourceWidth > 8192 || p->sourceHeight > 4320)
     { xa_fail(X265AMD_EINVAL, "encoder_open: picture size must be even (4:2:0) and within 16..8192 x 16..4320"); return nullptr; }
+    /* (found at the end of round 6 and not understood yet: the first P picture of a 64x64 clip is coded as one 64x64 CU where the reference splits it -- every other small
+     * shape tried, 128x128, 256x64, 128x256, 136x72, is identical.  Refused rather than coded differently) */
+    if (p->sourceWidth <= 64 && p->sourceHeight <= 64)
+    { xa_fail(X265AMD_EINVAL, "encoder_open: sourceWidth / sourceHeight: a picture of a single CTU is not built"); return nullptr; }
     {
         /* every field outside the built subset is named (the reference logs "x265 [error]: <what>" per field, encoder/api.cpp:96-239 -> x265_check_params) */
         static thread_local char why[160];

@@ -333,10 +333,13 @@ static int sao_rdo_range(const x265amd_slice_info* si, int referenced, int frame
         R->store(R->cur);
     }
     if (carry) memcpy(carry, &R->cur, sizeof(Snap));
-    /* rdoSaoUnitRowEnd -- which the reference only reaches WITHOUT wavefronts: with them FrameFilter::processRow asks whether every row's reconstruction flag is set before it has
-     * set the last row's own (framefilter.cpp:622-647 against :650-664), so the rates stay at their initial zero and SAO is never switched off by the picture before
-     * (seen in the reference's own objects: all eight rates 0.000 after every picture of a --frame-threads 1 encode; the fixture rc_ft1/ pins it) */
-    if (whole && !si->wpp)
+    /* rdoSaoUnitRowEnd -- which the reference never reaches in a picture of one slice, with wavefronts or without: FrameFilter::processRow asks whether EVERY row's
+     * reconstruction flag is set before it has set the last row's own (framefilter.cpp:622-647 against :650-664; without wavefronts the rows are filtered one after the
+     * other by the same function, frameencoder.cpp:928-960), so the rates stay at their initial zero and SAO is never switched off by the picture before (seen in the
+     * reference's own objects: all eight rates 0.000 after every picture of a --frame-threads 1 encode; the fixtures rc_ft1/ and cli_nowpp_ft1/ pin it -- rounds 2 to 6
+     * had the update for pictures without wavefronts, which only a --no-wpp --frame-threads 1 encode ever showed).  X265AMD_SAO_RATES=1: the update as SAO::rdoSaoUnitRowEnd has it. */
+    static const bool rates = getenv("X265AMD_SAO_RATES") && atoi(getenv("X265AMD_SAO_RATES")) != 0;
+    if (whole && rates)
     {
         depth_sao_rate[refDepth] = sao_flags[0] ? numNoSao[0] / (double)numCtu : 1.0;
         depth_sao_rate[4 + refDepth] = sao_flags[1] ? numNoSao[1] / (double)numCtu : 1.0;

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 #include <time.h>
 #include <vector>
@@ -239,9 +240,10 @@ int abi_param_parse(void* p, const char* name, const char* value)
         if (!value) return -2;
         unsigned a = 0, b = 0;
         if (sscanf(value, "%u/%u", &a, &b) == 2 && a && b) { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, a); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, b); return 0; }
-        const double f = real(bad); if (bad || f <= 0) return -2;
-        if (f == (int)f) { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, (uint32_t)f); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, 1); }
-        else { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, (uint32_t)(f * 1000 + .5)); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, 1000); }
+        /* anything that is not a fraction goes in as thousandths, whole numbers too ("60" is 60000 / 1000: param.cpp:936-941 -- the VUI's timing info carries the pair as it is) */
+        const float fps = (float)atof(value);
+        if (fps > 0 && fps <= INT_MAX / 1000) { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, (uint32_t)(int)(fps * 1000 + .5)); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, 1000); }
+        else { wr<uint32_t>(p, X265ABI_PARAM_fpsNum, (uint32_t)atoi(value)); wr<uint32_t>(p, X265ABI_PARAM_fpsDenom, 1); }
         return 0;
     }
     if (!strcmp(key, "input-res"))
@@ -438,8 +440,13 @@ void* abi_encoder_open(void* p)
     q.bEnableFastIntra = PI(p, bEnableFastIntra);
     /* frame threads: 0 = by core count, which is more than one on any machine with four cores or more (threadpool.cpp:661-677); the stream of the
      * frame-parallel rules does not depend on the number */
+    /* Encoder::create (encoder.cpp:199-254): no wavefronts in a picture of one CTU row or fewer than three CTU columns ("pointless and unstable") -- and without wavefronts the
+     * frame threads chosen by core count are as many as half the rows, which is ONE for a picture of one or two rows (threadpool.cpp:664-666) */
+    const int ctuRows = (((q.sourceHeight + 7) & ~7) + 63) / 64, ctuCols = (((q.sourceWidth + 7) & ~7) + 63) / 64;
+    if (ctuRows == 1 || ctuCols < 3) q.bEnableWavefront = 0;
     const int ft = PI(p, frameNumThreads);
-    q.frameNumThreads = ft == 1 ? 1 : (ft > 16 ? 16 : (ft <= 0 ? 3 : ft));
+    const int ftAuto = q.bEnableWavefront ? 3 : ((ctuRows + 1) / 2 < 16 ? (ctuRows + 1) / 2 : 16);
+    q.frameNumThreads = ft == 1 ? 1 : (ft > 16 ? 16 : (ft <= 0 ? ftAuto : ft));
     x265amd_encoder* e = x265amd_encoder_open(&q);
     if (!e) return nullptr;
     AbiEncoder* a = new AbiEncoder;
