@@ -3631,6 +3631,19 @@ CLI_CASES = {
     "cli_fps12_5_slow/": ((416, 240), 14, 8, 2, {}, ["--preset", "slow", "--fps", "12.5"]),
     # small pictures (the reference's input readers take nothing below 64x64; a picture of ONE CTU is refused: CLI_REFUSED): two by one CTUs with a partial column and row
     # (a picture of one CTU row or fewer than three CTU columns is coded without wavefronts, and without them the frame threads are half the rows: encoder.cpp:249-254)
+    # (more lines a user types)
+    "cli_keyint_inf/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--keyint", "-1"]),
+    "cli_bframes0/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--bframes", "0"]),
+    "cli_bframes1_badapt0/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--bframes", "1", "--b-adapt", "0"]),
+    "cli_rclookahead3/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--rc-lookahead", "3", "--bframes", "2"]),
+    "cli_laslices0/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--lookahead-slices", "0"]),
+    "cli_scenecut80/": ((416, 240), 30, 8, 2, {}, ["--preset", "medium", "--scenecut", "80"]),
+    "cli_crf28_5/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--crf", "28.5"]),
+    "cli_crf1/": ((416, 240), 10, 8, 2, {}, ["--preset", "medium", "--crf", "1"]),
+    "cli_merange16_ref6/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--merange", "16", "--ref", "6"]),
+    "cli_maxmerge5/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--max-merge", "5"]),
+    "cli_nopsy/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--psy-rd", "0", "--psy-rdoq", "0"]),
+    "cli_nowpp/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp"]),
     "cli_nowpp_ft1/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "1"]),
     "cli_128x128/": ((128, 128), 12, 8, 2, {}, ["--preset", "medium"]),
     "cli_128x256/": ((128, 256), 12, 8, 2, {}, ["--preset", "medium"]),

@@ -82,6 +82,8 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
     /* Encoder::configure's rules for the rate control's switches (encoder.cpp:3721-3754): constant QP switches adaptive quantisation and cuTree off; cuTree without AQ gets
      * aq-mode 1 at strength 0 (cuTree needs the offset arrays; delta QP is on); strength 0 without cuTree is no AQ at all */
     x265amd_param norm = *p;
+    /* --keyint -1 (encoder.cpp:3627-3635): "only one I frame at the start of the stream": an infinite GOP distance and no adaptive I frame placement */
+    if (norm.keyframeMax < 0) { norm.keyframeMax = INT_MAX; norm.scenecutThreshold = 0; }
     if (norm.keyframeMax <= 1 && norm.keyframeMax >= 0)
     {
         /* all-intra encodes (encoder.cpp:3636-3658): no lookahead, no B pictures, no cuTree, no weights, one reference, the parameter sets with every picture */

@@ -13,6 +13,7 @@
 #include "x265amd_ratecontrol.h"
 #include <immintrin.h>
 #include "xa_fiber.h"
+#include <limits.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>

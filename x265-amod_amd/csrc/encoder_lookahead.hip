@@ -622,7 +622,7 @@ bool x265amd_encoder::scenecutInternal(std::vector<Pic*>& frames, int p0, int p1
     if (rc == X265AMD_OK) rc = frameCostP(*frame, *frames[p0], p1 - p0);
     if (rc != X265AMD_OK) return false;
     const int64_t icost = frame->costEst[0], pcost = frame->costEst[p1 - p0];
-    const int gopSize = (frame->poc - lastKeyframe) % p.keyframeMax;
+    const int gopSize = (int)(((int64_t)frame->poc - lastKeyframe) % p.keyframeMax);
     const float threshMax = (float)(p.scenecutThreshold / 100.0);
     float threshMin = (float)(threshMax * 0.25);
     double bias = 5.0 / 100;            /* param.scenecutBias: the default, scaled in Encoder::configure (encoder.cpp:3948) */
@@ -694,7 +694,7 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames, bool bKeyframe)
         if (framecnt + 1 >= (int)frames.size() || frames[framecnt + 1]->type != TYPE_AUTO) break;
     if (!framecnt) return p.cuTree ? runCuTree(frames, 0, bKeyframe) : X265AMD_OK;
     frames.resize((size_t)framecnt + 1);
-    const int keyFrameLimit = p.keyframeMax + lastKeyframe - frames[0]->poc - 1, keyintLimit = keyFrameLimit;
+    const int keyFrameLimit = (int)std::min<int64_t>((int64_t)p.keyframeMax + lastKeyframe - frames[0]->poc - 1, INT_MAX / 2), keyintLimit = keyFrameLimit;
     const int origNumFrames = std::min(framecnt, keyintLimit);
     int numFrames = origNumFrames;
     if (p.bOpenGOP && numFrames < framecnt) numFrames++;           /* open GOPs: the window takes in the keyframe (slicetype.cpp:2660-2661) */
@@ -858,7 +858,7 @@ int x265amd_encoder::slicetypeAnalyse(std::vector<Pic*>& frames, bool bKeyframe)
     }
     /* cuTree on the window as it is typed now (slicetype.cpp:2893-2894) */
     if (p.cuTree && (rc = runCuTree(frames, std::min(numFrames, p.keyframeMax), bKeyframe)) != X265AMD_OK) return rc;
-    for (int j = keyintLimit + 1; j <= numFrames; j += p.keyframeMax) { frames[j]->type = TYPE_I; resetStart = std::min(resetStart, j + 1); }
+    for (int64_t j = (int64_t)keyintLimit + 1; j <= numFrames; j += p.keyframeMax) { frames[j]->type = TYPE_I; resetStart = std::min(resetStart, (int)j + 1); }
     const int maxp1 = std::min(p.bframes + 1, origNumFrames);
     /* Restore frame types for all frames that haven't actually been decided yet. */
     for (int j = resetStart; j <= numFrames; j++)
@@ -954,8 +954,8 @@ int x265amd_encoder::decideLookahead(bool flush, int maxGops)
         for (;; b++)
         {
             Pic& frm = *input[b];
-            if (frm.poc - lastKeyframe >= p.keyframeMax && (frm.type == TYPE_AUTO || frm.type == TYPE_I)) frm.type = p.bOpenGOP && haveKeyframe ? TYPE_I : TYPE_IDR;
-            if (frm.type == TYPE_I && frm.poc - lastKeyframe >= keyframeMin)
+            if ((int64_t)frm.poc - lastKeyframe >= p.keyframeMax && (frm.type == TYPE_AUTO || frm.type == TYPE_I)) frm.type = p.bOpenGOP && haveKeyframe ? TYPE_I : TYPE_IDR;
+            if (frm.type == TYPE_I && (int64_t)frm.poc - lastKeyframe >= keyframeMin)
             {
                 /* closed GOPs: a keyframe is an IDR picture; open GOPs: it stays an I picture (CRA) and the B pictures in front of it stay (slicetype.cpp:1985-1994) */
                 if (p.bOpenGOP) { lastKeyframe = frm.poc; frm.bKeyframe = true; haveKeyframe = true; }
@@ -1037,7 +1037,7 @@ void x265amd_encoder::decideMiniGop(bool flush)
         for (;; b++)
         {
             Pic& frm = *input[b];
-            if (frm.poc - lastKeyframe >= p.keyframeMax) frm.type = p.bOpenGOP && haveKeyframe ? TYPE_I : TYPE_IDR;
+            if ((int64_t)frm.poc - lastKeyframe >= p.keyframeMax) frm.type = p.bOpenGOP && haveKeyframe ? TYPE_I : TYPE_IDR;
             if (frm.type == TYPE_I)
             {
                 /* open GOP: the keyframe is an I picture (CRA) that ends the mini-GOP; the B pictures in front of it stay and reference across it */
