@@ -176,7 +176,7 @@ def test_param_default_preset_opens_and_encodes(preset):
     for info in (1, 0):
         p = f["alloc"]()
         assert f["preset"](p, preset.encode(), None) == 0
-        assert f["parse"](p, b"input-res", b"%dx%d" % (w, h)) == 0 and f["parse"](p, b"fps", b"30") == 0
+        assert f["parse"](p, b"input-res", b"%dx%d" % (w, h)) == 0 and f["parse"](p, b"fps", b"30/1") == 0          # (a fraction, as a file header gives it: "30" alone is 30000 / 1000 in the VUI, param.cpp:936-941)
         if not info:
             assert f["parse"](p, b"no-info", None) == 0
         enc = f["open"](p)
