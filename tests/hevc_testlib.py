@@ -3631,6 +3631,17 @@ CLI_CASES = {
     "cli_fps12_5_slow/": ((416, 240), 14, 8, 2, {}, ["--preset", "slow", "--fps", "12.5"]),
     # small pictures (the reference's input readers take nothing below 64x64; a picture of ONE CTU is refused: CLI_REFUSED): two by one CTUs with a partial column and row
     # (a picture of one CTU row or fewer than three CTU columns is coded without wavefronts, and without them the frame threads are half the rows: encoder.cpp:249-254)
+    # (presets with options on top)
+    "cli_veryfast_crf20_hbd/": ((416, 240), 16, 10, 4, {}, ["--preset", "veryfast", "--crf", "20"]),
+    "cli_veryslow_b3/": ((416, 240), 12, 8, 2, {}, ["--preset", "veryslow", "--bframes", "3"]),
+    "cli_fast_fastdecode/": ((416, 240), 16, 8, 2, {}, ["--preset", "fast", "--tune", "fastdecode"]),
+    "cli_faster_nofilters/": ((416, 240), 16, 8, 2, {}, ["--preset", "faster", "--no-sao", "--no-deblock"]),
+    "cli_slow_rd6/": ((416, 240), 10, 8, 2, {}, ["--preset", "slow", "--rd", "6"]),
+    "cli_tu3_limit4/": ((416, 240), 12, 8, 2, {}, ["--preset", "medium", "--tu-inter-depth", "3", "--tu-intra-depth", "3", "--limit-tu", "4"]),
+    "cli_weightb_b8/": ((416, 240), 24, 8, 2, {}, ["--preset", "medium", "--weightb", "--bframes", "8"]),
+    "cli_slower_psnr_hbd/": ((416, 240), 10, 10, 4, {}, ["--preset", "slower", "--tune", "psnr"]),
+    "cli_medium_720p_ft2/": ((1280, 720), 10, 8, 2, {}, ["--preset", "medium", "--frame-threads", "2"]),
+    "cli_fast_1366x768/": ((1366, 768), 6, 8, 2, {}, ["--preset", "fast"]),
     # (more lines a user types)
     "cli_keyint_inf/": ((416, 240), 20, 8, 2, {}, ["--preset", "medium", "--keyint", "-1"]),
     "cli_bframes0/": ((416, 240), 16, 8, 2, {}, ["--preset", "medium", "--bframes", "0"]),
@@ -3720,6 +3731,16 @@ CLI_CASES = {
     "cli_jump_slow/": ((416, 240), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
     "cli_dark_aq3/": ((416, 240), 16, 8, 2, {"clip": "dark"}, ["--preset", "medium", "--aq-mode", "3"]),
     "cli_dark_medium_hbd/": ((416, 240), 12, 10, 4, {"clip": "dark"}, ["--preset", "medium"]),
+    "cli_static_keyint_inf/": ((416, 240), 20, 8, 2, {"clip": "static"}, ["--preset", "medium", "--keyint", "-1"]),
+    "cli_flat_crf1_hbd/": ((416, 240), 8, 10, 4, {"clip": "flat"}, ["--preset", "medium", "--crf", "1"]),
+    "cli_noise_veryfast_b0/": ((416, 240), 10, 8, 2, {"clip": "noise"}, ["--preset", "veryfast", "--bframes", "0"]),
+    "cli_edges_slower/": ((416, 240), 8, 8, 2, {"clip": "edges"}, ["--preset", "slower"]),
+    "cli_jump_faster_ref5/": ((416, 240), 12, 8, 2, {"clip": "jump"}, ["--preset", "faster", "--ref", "5"]),
+    "cli_dark_crf40_psnr/": ((416, 240), 16, 8, 2, {"clip": "dark"}, ["--preset", "medium", "--crf", "40", "--tune", "psnr"]),
+    "cli_edges_odd_size/": ((420, 236), 10, 8, 2, {"clip": "edges"}, ["--preset", "medium"]),
+    "cli_noise_allintra_hbd/": ((416, 240), 6, 10, 4, {"clip": "noise"}, ["--preset", "medium", "--keyint", "1"]),
+    "cli_static_nowpp_ft1/": ((416, 240), 16, 8, 2, {"clip": "static"}, ["--preset", "medium", "--no-wpp", "--frame-threads", "1"]),
+    "cli_jump_fps60/": ((416, 240), 16, 8, 2, {"clip": "jump"}, ["--preset", "medium", "--fps", "60"]),
     "cli_fhd_noise/": ((1920, 1080), 6, 8, 2, {"clip": "noise"}, ["--preset", "medium"]),
     "cli_fhd_edges/": ((1920, 1080), 8, 8, 2, {"clip": "edges"}, ["--preset", "medium"]),
     "cli_720p_jump_slow/": ((1280, 720), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
