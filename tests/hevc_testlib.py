@@ -3741,6 +3741,13 @@ CLI_CASES = {
     "cli_noise_allintra_hbd/": ((416, 240), 6, 10, 4, {"clip": "noise"}, ["--preset", "medium", "--keyint", "1"]),
     "cli_static_nowpp_ft1/": ((416, 240), 16, 8, 2, {"clip": "static"}, ["--preset", "medium", "--no-wpp", "--frame-threads", "1"]),
     "cli_jump_fps60/": ((416, 240), 16, 8, 2, {"clip": "jump"}, ["--preset", "medium", "--fps", "60"]),
+    # (the round's last options at the large sizes)
+    "cli_uhd_nowpp_ft1/": ((3840, 2160), 4, 8, 2, {}, ["--preset", "medium", "--no-wpp", "--frame-threads", "1"]),
+    "cli_uhd_fps60/": ((3840, 2160), 5, 8, 2, {}, ["--preset", "medium", "--fps", "60"]),
+    "cli_uhd_odd_size/": ((3838, 2158), 4, 8, 2, {}, ["--preset", "fast"]),
+    "cli_fhd_b0_noslices/": ((1920, 1080), 8, 8, 2, {}, ["--preset", "medium", "--bframes", "0", "--lookahead-slices", "0"]),
+    "cli_fhd_zerolatency/": ((1920, 1080), 8, 8, 2, {}, ["--preset", "medium", "--tune", "zerolatency"]),
+    "cli_fhd_keyint_inf/": ((1920, 1080), 8, 8, 2, {}, ["--preset", "medium", "--keyint", "-1"]),
     "cli_fhd_noise/": ((1920, 1080), 6, 8, 2, {"clip": "noise"}, ["--preset", "medium"]),
     "cli_fhd_edges/": ((1920, 1080), 8, 8, 2, {"clip": "edges"}, ["--preset", "medium"]),
     "cli_720p_jump_slow/": ((1280, 720), 8, 8, 2, {"clip": "jump"}, ["--preset", "slow"]),
@@ -3783,6 +3790,7 @@ CLI_REFUSED = {
     "max_tu16": (["--preset", "medium", "--max-tu-size", "16"], "maxTUSize"),
     "min_cu16": (["--preset", "medium", "--min-cu-size", "16"], "minCUSize"),
     "level41": (["--preset", "medium", "--level-idc", "41"], "levelIdc"),
+    "fhd_b0_slices": (["--preset", "medium", "--bframes", "0"], "lookaheadSlices"),       # (on a 1920x1080 clip; with --lookahead-slices 0 it is a CLI_CASES line)
     "one_ctu": (["--preset", "medium"], "single CTU"),           # (on a 64x64 clip: tests/test_encoder_api.py)      # (with a rate factor the reference turns VBV on for a forced level: level.cpp:393-404)
 }
 

@@ -249,7 +249,7 @@ def test_command_lines_outside_the_built_subset_are_refused_by_name(what, tmp_pa
     grain tune's rate control, the UMH search, small quantisation groups -- and an option nobody knows"""
     import subprocess
     cli, word = T.CLI_REFUSED[what]
-    w, h = (64, 64) if what == "one_ctu" else (416, 240)          # (the size is the clip file's)
+    w, h = (64, 64) if what == "one_ctu" else ((1920, 1080) if what == "fhd_b0_slices" else (416, 240))          # (the size is the clip file's)
     _write_y4m(tmp_path / "clip.y4m", T.survey_clip(w, h, 8, 2, 0, 3), w, h, 8)
     r = subprocess.run([CLI, "--input", str(tmp_path / "clip.y4m"), "-o", str(tmp_path / "out.hevc")] + cli + T.PRESET_CLI, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and word.lower() in r.stderr.lower(), (r.returncode, r.stderr[-600:])

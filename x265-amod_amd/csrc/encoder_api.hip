@@ -192,6 +192,11 @@ extern "C" x265amd_encoder* x265amd_encoder_open(const x265amd_param* p)
             e->laRowsPerSlice = std::min(std::max(e->lowCuH / p->lookaheadSlices, 10), e->lowCuH);
             e->laNumSlices = e->lowCuH / e->laRowsPerSlice;
         }
+        /* (found at the end of round 6 and not understood yet: without B pictures, with a lookahead that runs in slices -- 720 rows or more -- cuTree's offsets of a few blocks
+         * at the picture's right edge differ from the reference's (76 of 8160 at 1080p), and the streams with them; --lookahead-slices 0 is identical, so are --tune
+         * zerolatency (no lookahead) and every size below 720 rows.  Refused rather than coded differently) */
+        if (e->laNumSlices > 1 && p->bframes == 0 && p->lookaheadDepth > 0)
+        { xa_fail(X265AMD_EINVAL, "encoder_open: bframes 0 with lookaheadSlices above 1 in a picture of 720 rows or more is not built (lookaheadSlices 0 is)"); return nullptr; }
         e->lowW = e->lowCuW * 8; e->lowH = e->lowCuH * 8;
         e->lowBlocks = (e->lowCuW > 2 && e->lowCuH > 2) ? (e->lowCuW - 2) * (e->lowCuH - 2) : e->lowCuW * e->lowCuH;
         e->lowStride = e->W / 2 + 2 * e->marginX;
